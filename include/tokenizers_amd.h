@@ -1,0 +1,137 @@
+/*
+ * tokenizers_amd.h -- C ABI of the MI355X-native encode_batch path.
+ *
+ * This is the drop-in boundary for ONE hot path of huggingface/tokenizers:
+ *   TokenizerImpl::encode_batch / encode_batch_char_offsets / encode_batch_fast
+ *   (reference: tokenizers/src/tokenizer/mod.rs:1337-1401), i.e. per document
+ *   extract_and_normalize -> PreTokenizer::pre_tokenize -> Model::tokenize ->
+ *   PreTokenizedString::into_encoding (mod.rs:762-805, pre_tokenizer.rs:198-263).
+ *
+ * The reference has no FFI for this path (its plugin API is Rust traits,
+ * tokenizer/mod.rs:56-207), so the entry points below are what a Rust
+ * `extern "C"` block / a ctypes stub would bind.  Plain
+ * pointers and sizes only; no C++ / torch types; nothing throws across the ABI.
+ *
+ * Data model (replaces Vec<EncodeInput> in, Vec<Encoding> out):
+ *   in : one contiguous UTF-8 buffer `text` + CSR `doc_offsets[n_docs+1]`
+ *        (document d = text[doc_offsets[d] .. doc_offsets[d+1]) ).
+ *   out: CSR token arrays: ids[n_tokens] (u32) + tok_offsets[n_docs+1] (i64),
+ *        and, when requested, per-token (start,end) offsets relative to the
+ *        document and per-token word ids (= pre-token index in the document,
+ *        pre_tokenizer.rs:252-256).
+ *   These are the fields of `Encoding` (tokenizer/encoding.rs:11-31) that
+ *   carry information; type_ids / attention_mask / special_tokens_mask are
+ *   constant (0 / 1 / 0) for this path and synthesised by the host shim.
+ */
+#ifndef TOKENIZERS_AMD_H
+#define TOKENIZERS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (Result<_, Box<dyn Error>> at tokenizer/mod.rs:51-52) ---- */
+#define TKAMD_OK              0
+#define TKAMD_ERR_INVALID    -1   /* bad argument / malformed tokenizer.json                    */
+#define TKAMD_ERR_UNSUPPORTED -2  /* tokenizer.json uses a component outside this hot path     */
+#define TKAMD_ERR_DEVICE     -3   /* HIP runtime error (no device, OOM, launch failure)        */
+#define TKAMD_ERR_MODEL      -4   /* model error the reference raises too (e.g. MissingUnkToken,
+                                     models/wordlevel/mod.rs:175-177, wordpiece/mod.rs:229-232) */
+
+/* ---- encode flags (OffsetType at tokenizer/pre_tokenizer.rs:10-17) ---- */
+#define TKAMD_OFFSETS_NONE   0u   /* encode_batch_fast          (mod.rs:1382-1401)             */
+#define TKAMD_OFFSETS_BYTE   1u   /* Rust encode_batch          (mod.rs:1337-1356)             */
+#define TKAMD_OFFSETS_CHAR   2u   /* encode_batch_char_offsets  (mod.rs:1360-1379; Python)     */
+#define TKAMD_OFFSETS_MASK   3u
+#define TKAMD_WANT_WORD_IDS  4u   /* also produce Encoding.words                               */
+
+/* Readable slack the caller must leave after text[n_bytes] for the device entry
+ * points (kernels read whole 16-byte words).  The host entry pads internally. */
+#define TKAMD_TEXT_PAD 64
+
+typedef struct tkamd_tokenizer tkamd_tokenizer;  /* immutable after creation; owns device tables */
+typedef struct tkamd_batch     tkamd_batch;      /* one encode_batch result (host copies)        */
+
+/* What was recognised in tokenizer.json (for the host shim / diagnostics). */
+typedef struct tkamd_info {
+    int32_t model;          /* 1 BPE, 2 WordPiece, 3 WordLevel                                  */
+    int32_t pre_tokenizer;  /* 1 ByteLevel(GPT-2 regex), 2 Llama-3 Split+ByteLevel, 3 Whitespace,
+                               4 WhitespaceSplit, 5 BertPreTokenizer, 6 ByteLevel(use_regex=false) */
+    int32_t normalizer;     /* 0 none, 1 BertNormalizer                                         */
+    int32_t vocab_size;
+    int32_t n_merges;
+    int32_t add_prefix_space;
+    int32_t ignore_merges;
+    int32_t n_added_tokens; /* special/added tokens registered in the JSON                       */
+    int32_t device;         /* HIP device ordinal, -1 = host-only handle (no kernels)           */
+    int32_t n_direct_words; /* entries of the whole-word table proven merge-stable (see DESIGN)  */
+} tkamd_info;
+
+/* Replaces Tokenizer::from_file / from_str (tokenizer/mod.rs:468-472, serialization.rs:104-171).
+ * `device` >= 0: build HBM-resident tables on that HIP device.  `device` == -1: parse and build
+ * host tables only (no GPU needed; encode calls then fail with TKAMD_ERR_DEVICE). */
+int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tkamd_tokenizer** out);
+void tkamd_tokenizer_free(tkamd_tokenizer* tok);
+int tkamd_tokenizer_info(const tkamd_tokenizer* tok, tkamd_info* info);
+
+/* Thread-local message of the last failing call on this thread (error.rs:26-31 maps
+ * the reference's error to `Exception(str(e))`; the shim does the same with this). */
+const char* tkamd_last_error(void);
+
+/* ---- host-buffer entry: H2D + kernels + D2H -------------------------------------------------
+ * Replaces TokenizerImpl::encode_batch{,_char_offsets,_fast}(inputs, add_special_tokens=false)
+ * for Single(Raw) inputs.  `text`/`doc_offsets` are borrowed for the call.  The result is owned
+ * by the library until tkamd_batch_free. */
+int tkamd_encode_batch(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* doc_offsets,
+                       int64_t n_docs, uint32_t flags, tkamd_batch** out);
+
+int64_t         tkamd_batch_n_docs(const tkamd_batch* b);
+int64_t         tkamd_batch_n_tokens(const tkamd_batch* b);
+const uint32_t* tkamd_batch_ids(const tkamd_batch* b);          /* [n_tokens]                   */
+const int64_t*  tkamd_batch_tok_offsets(const tkamd_batch* b);  /* [n_docs+1] CSR into ids      */
+const uint32_t* tkamd_batch_offsets(const tkamd_batch* b);      /* [n_tokens][2] or NULL        */
+const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b);     /* [n_tokens] or NULL           */
+void            tkamd_batch_free(tkamd_batch* b);
+
+/* ---- device-buffer entry: inputs already resident in HBM, outputs stay in HBM ---------------
+ * Enqueues the whole path on `hip_stream` (a hipStream_t, NULL = default stream) and returns
+ * without synchronising.  The output pointers refer to the handle's workspace and stay valid
+ * until the next encode call on the same handle.  d_n_tokens[0] holds the token count once the
+ * stream has drained; tkamd_device_sync() waits for it and returns it. */
+typedef struct tkamd_device_result {
+    const uint32_t* d_ids;          /* [n_tokens]                                               */
+    const int64_t*  d_tok_offsets;  /* [n_docs+1]                                               */
+    const uint32_t* d_offsets;      /* [n_tokens][2] or NULL                                    */
+    const uint32_t* d_word_ids;     /* [n_tokens] or NULL                                       */
+    const int64_t*  d_n_tokens;     /* [1]                                                      */
+    const int64_t*  d_n_pretokens;  /* [1] number of pre-tokens (splits) in the batch           */
+} tkamd_device_result;
+
+int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,
+                              int64_t n_docs, int64_t n_bytes, uint32_t flags, void* hip_stream,
+                              tkamd_device_result* out);
+int tkamd_device_sync(tkamd_tokenizer* tok, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens);
+
+/* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
+ * With profiling on, every kernel launch of the next device/host encode calls is bracketed by
+ * HIP events on the launch stream.  tkamd_profile_read returns, per kernel, the accumulated
+ * milliseconds and launch count since the last reset. */
+#define TKAMD_MAX_STAGES 24
+typedef struct tkamd_stage_time {
+    char    name[48];
+    double  ms_total;
+    int64_t launches;
+} tkamd_stage_time;
+int tkamd_profile_enable(tkamd_tokenizer* tok, int on);
+int tkamd_profile_read(tkamd_tokenizer* tok, tkamd_stage_time* stages, int max_stages, int* n_stages, int reset);
+
+/* Library version string, e.g. "tokenizers_amd 0.1.0 (gfx950)". */
+const char* tkamd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENIZERS_AMD_H */

@@ -1,0 +1,276 @@
+"""Synthetic corpora and vocabularies for the encode_batch hot path.
+
+TEST / BENCH INFRASTRUCTURE ONLY (see oracle/README.md): nothing under
+``tokenizers_amd/`` imports this module.  There is no network in the build or
+GPU environment, so BASELINE.json's configs are realised with seeded synthetic
+text and vocabularies trained on it by the reference's own trainers (the
+installed ``tokenizers`` wheel: models/bpe/trainer.rs, models/wordpiece/trainer.rs).
+
+Recipe:
+  * a "language" = a list of word types built from syllables (``type_seed``),
+    shorter words at more frequent ranks;
+  * text = Zipf-Mandelbrot rank sampling of those types (``text_seed``), 10 %
+    capitalised, 8 % trailing punctuation from ", . ! ? 's ;", 3 % integers,
+    single spaces; 1 % of the lines carry a tab, a double space and a
+    non-ASCII word (e-acute, n-tilde, CJK, emoji) to exercise UTF-8;
+  * line length target ~120 bytes (uniform 100..140).
+The tokenizer is trained on a DIFFERENT text seed of the same language than the
+one encoded (in-distribution, as in real use); ``type_seed`` can be changed to
+get out-of-distribution word types (every word needs merges: the stress case).
+"""
+from __future__ import annotations
+
+import json
+import os
+import hashlib
+import numpy as np
+
+_ONSETS = ["", "b", "c", "d", "f", "g", "h", "j", "k", "l", "m", "n", "p", "r", "s", "t", "v", "w",
+           "st", "tr", "ch", "sh", "th", "pl", "br", "cr", "gr", "pr", "qu", "wh", "y", "z", "sp", "fl"]
+_NUCLEI = ["a", "e", "i", "o", "u", "ea", "ou", "ai", "ee", "oo", "ie", "io", "au", "y"]
+_CODAS = ["", "", "", "n", "r", "s", "t", "l", "m", "d", "ng", "nd", "st", "nt", "ck", "ll", "ss",
+          "rs", "ly", "ed", "er", "es", "ing", "ion", "al", "ic", "ous", "ment", "ble", "ty"]
+_NONASCII = ["café", "niño", "中文", "\U0001F600", "naïve", "über",
+             "日本語", "déjà", "¡hola!", "—"]
+_PUNCT = [",", ".", "!", "?", "'s", ";"]
+
+
+def make_word_types(n_types: int = 60000, type_seed: int = 0) -> list[str]:
+    """Distinct pseudo-English word types, roughly shorter at frequent ranks."""
+    rng = np.random.default_rng(1000 + type_seed)
+    seen: set[str] = set()
+    out: list[str] = []
+    while len(out) < n_types:
+        r = len(out)
+        # syllable count grows with rank: the top ranks are mostly 1 syllable
+        mean_syl = 1.0 + min(1.6, 0.55 * np.log10(1 + r / 40.0))
+        nsyl = max(1, int(rng.poisson(mean_syl - 1.0)) + 1)
+        w = ""
+        for _ in range(nsyl):
+            w += _ONSETS[rng.integers(len(_ONSETS))] + _NUCLEI[rng.integers(len(_NUCLEI))]
+            if rng.random() < 0.45:
+                w += _CODAS[rng.integers(len(_CODAS))]
+        if w and w not in seen and len(w) <= 18:
+            seen.add(w)
+            out.append(w)
+    return out
+
+
+def _surface_forms(types: list[str], rng: np.random.Generator, n_numbers: int = 50000):
+    """Every type in 2 cases x (bare + 6 punctuation tails) + a pool of integers."""
+    forms: list[str] = []
+    for w in types:
+        cap = w[0].upper() + w[1:]
+        forms.append(w)
+        forms.append(cap)
+        for p in _PUNCT:
+            forms.append(w + p)
+            forms.append(cap + p)
+    base = len(forms)
+    nums = rng.integers(0, 100000, size=n_numbers)
+    forms.extend(str(int(x)) for x in nums)
+    return forms, base
+
+
+def gen_lines(n_lines: int, text_seed: int = 0, type_seed: int = 0, n_types: int = 60000,
+              target_bytes: tuple[int, int] = (104, 144), types: list[str] | None = None,
+              zipf_a: float = 1.07, special_frac: float = 0.01) -> list[str]:
+    """``n_lines`` synthetic lines (python str), deterministic in all arguments."""
+    if types is None:
+        types = make_word_types(n_types, type_seed)
+    n_types = len(types)
+    rng = np.random.default_rng(2000 + 7919 * text_seed + type_seed)
+    forms, num_base = _surface_forms(types, rng)
+    per = 2 + 2 * len(_PUNCT)           # forms per type
+    form_len = np.fromiter((len(f.encode("utf-8")) for f in forms), dtype=np.int32, count=len(forms))
+    n_numbers = len(forms) - num_base
+
+    # Zipf-Mandelbrot over ranks
+    ranks = np.arange(n_types, dtype=np.float64)
+    p = 1.0 / np.power(ranks + 2.7, zipf_a)
+    cdf = np.cumsum(p / p.sum())
+
+    W = 40  # max words per line considered
+    out: list[str] = []
+    chunk = 50000
+    for lo in range(0, n_lines, chunk):
+        n = min(chunk, n_lines - lo)
+        r = np.searchsorted(cdf, rng.random((n, W)), side="right").clip(0, n_types - 1)
+        u = rng.random((n, W))
+        cap = (rng.random((n, W)) < 0.10).astype(np.int64)
+        has_p = rng.random((n, W)) < 0.08
+        pk = rng.integers(0, len(_PUNCT), size=(n, W))
+        variant = np.where(has_p, 2 + 2 * pk + cap, cap)
+        idx = r * per + variant
+        is_num = u < 0.03
+        idx = np.where(is_num, num_base + rng.integers(0, n_numbers, size=(n, W)), idx)
+        lens = form_len[idx] + 1
+        csum = np.cumsum(lens, axis=1)
+        tgt = rng.integers(target_bytes[0], target_bytes[1] + 1, size=(n, 1))
+        k = np.maximum(1, (csum <= tgt + 1).sum(axis=1))
+        special = rng.random(n) < special_frac
+        sp_pos = rng.integers(0, 8, size=n)
+        sp_word = rng.integers(0, len(_NONASCII), size=n)
+        getf = forms.__getitem__
+        idx_l = idx.tolist()
+        k_l = k.tolist()
+        for i in range(n):
+            ws = list(map(getf, idx_l[i][: k_l[i]]))
+            if special[i]:
+                j = min(int(sp_pos[i]), len(ws) - 1)
+                ws[j] = ws[j] + "\t" + _NONASCII[int(sp_word[i])] + " "   # tab, non-ASCII, double space
+            out.append(" ".join(ws))
+    return out
+
+
+def stress_lines(seed: int = 0, n: int = 2000) -> list[str]:
+    """Parity-only adversarial set (never timed): long letter runs, digit runs, URLs, mixed
+    whitespace (SP, TAB, LF, CR, U+00A0, U+3000), contractions in both cases after every kind
+    of predecessor, emoji / CJK / combining marks, empty and whitespace-only strings."""
+    rng = np.random.default_rng(3000 + seed)
+    alpha = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ")
+    pieces = ["'s", "'t", "'re", "'ve", "'m", "'ll", "'d", "'S", "'T", "'RE", "'VE", "'M", "'LL", "'D",
+              "'", "''", " ", "  ", "   ", "\t", "\n", "\r", "\r\n", "\n\n", " ", "　", " ",
+              "a", "b", "s", "t", "I", "it", "don", "we", "they", "x", "1", "12", "123", "1234", "12345678901234567890",
+              "²", "½", "٣", "Ⅷ", "!", "?!", "...", ",", "-", "--", "_", "__", "#", "$", "@", "/", "://",
+              "é", "ñ", "中", "文", "\U0001F600", "\U0001F468‍\U0001F469", "é", "̀",
+              "ſ", "K", "K", "http", "www", ".com", "=", "==", "+", "Zm9vYmFy", "\x00", "\x01", "\x7f", "�",
+              "​", "﻿", " ", "᠎", "", "\x1c", "\x1f", "\x0b", "\x0c"]
+    out = ["", " ", "  ", "\n", "\t", " \n ", "a", "'s", "'", " '", "a's", "a 's", "　", "a　", "  b"]
+    for _ in range(n):
+        kind = rng.integers(0, 6)
+        if kind == 0:      # long letter run
+            L = int(rng.integers(60, 700))
+            s = "".join(alpha[int(x)] for x in rng.integers(0, len(alpha), size=L))
+        elif kind == 1:    # long single-letter / two-letter periodic run (deep merge chains)
+            L = int(rng.integers(17, 400))
+            unit = "".join(alpha[int(x)] for x in rng.integers(0, 6, size=int(rng.integers(1, 4))))
+            s = (unit * L)[:L]
+        elif kind == 2:    # digit runs
+            s = " ".join(str(int(x)) * int(rng.integers(1, 6)) for x in rng.integers(0, 10 ** 6, size=int(rng.integers(1, 8))))
+        else:              # random piece soup
+            m = int(rng.integers(1, 40))
+            s = "".join(pieces[int(x)] for x in rng.integers(0, len(pieces), size=m))
+        out.append(s)
+    return out
+
+
+def zipf_length_docs(total_bytes: int, text_seed: int = 0, type_seed: int = 0, lo: int = 8, hi: int = 8192) -> list[str]:
+    """Config 5: document lengths ~ 1/L over [lo, hi] bytes, same language."""
+    rng = np.random.default_rng(4000 + text_seed)
+    types = make_word_types(60000, type_seed)
+    docs: list[str] = []
+    got = 0
+    # P(L) ~ 1/L  ==> log-uniform
+    while got < total_bytes:
+        n = 4096
+        L = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n)).astype(np.int64)
+        for tl in L.tolist():
+            nl = max(1, tl // 120 + 1)
+            parts = gen_lines(nl, text_seed=int(rng.integers(1 << 30)), types=types, special_frac=0.0)
+            d = " ".join(parts)[:tl]
+            docs.append(d)
+            got += len(d)
+            if got >= total_bytes:
+                break
+    return docs
+
+
+# ---------------------------------------------------------------------------
+# vocabularies (trained by the reference's own trainers)
+# ---------------------------------------------------------------------------
+
+def _cache_dir() -> str:
+    d = os.environ.get("TKAMD_CACHE", os.path.join(os.path.dirname(os.path.abspath(__file__)), "_cache"))
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def train_bytelevel_bpe(vocab_size: int = 50257, train_lines: int = 200000, type_seed: int = 0,
+                        n_types: int = 60000, add_prefix_space: bool = False, cache: bool = True) -> str:
+    """GPT-2 style byte-level BPE tokenizer.json (string).  Config C2."""
+    key = f"bpe_{vocab_size}_{train_lines}_{type_seed}_{n_types}_{int(add_prefix_space)}"
+    path = os.path.join(_cache_dir(), key + ".json")
+    if cache and os.path.exists(path):
+        return open(path, encoding="utf-8").read()
+    from tokenizers import Tokenizer, models, pre_tokenizers, trainers, decoders
+    lines = gen_lines(train_lines, text_seed=1, type_seed=type_seed, n_types=n_types)
+    tok = Tokenizer(models.BPE())
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=add_prefix_space, use_regex=True)
+    tok.decoder = decoders.ByteLevel()
+    tr = trainers.BpeTrainer(vocab_size=vocab_size, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
+                             show_progress=False)
+    tok.train_from_iterator(lines, tr)
+    s = tok.to_str()
+    if cache:
+        open(path, "w", encoding="utf-8").write(s)
+    return s
+
+
+LLAMA3_PATTERN = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*"
+                  r"|\s*[\r\n]+|\s+(?!\S)|\s+")
+
+
+def train_llama3_bpe(vocab_size: int = 128000, train_lines: int = 400000, type_seed: int = 0,
+                     n_types: int = 250000, cache: bool = True) -> str:
+    """Llama-3 style: Sequence[Split(regex, isolated), ByteLevel(use_regex=False)] + BPE(ignore_merges)."""
+    key = f"llama3_{vocab_size}_{train_lines}_{type_seed}_{n_types}"
+    path = os.path.join(_cache_dir(), key + ".json")
+    if cache and os.path.exists(path):
+        return open(path, encoding="utf-8").read()
+    from tokenizers import Tokenizer, models, pre_tokenizers, trainers, decoders, Regex
+    lines = gen_lines(train_lines, text_seed=1, type_seed=type_seed, n_types=n_types)
+    tok = Tokenizer(models.BPE(ignore_merges=True))
+    tok.pre_tokenizer = pre_tokenizers.Sequence([
+        pre_tokenizers.Split(Regex(LLAMA3_PATTERN), behavior="isolated", invert=False),
+        pre_tokenizers.ByteLevel(add_prefix_space=False, trim_offsets=True, use_regex=False)])
+    tok.decoder = decoders.ByteLevel()
+    tr = trainers.BpeTrainer(vocab_size=vocab_size, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
+                             show_progress=False)
+    tok.train_from_iterator(lines, tr)
+    d = json.loads(tok.to_str())
+    d["model"]["ignore_merges"] = True
+    s = json.dumps(d, ensure_ascii=False)
+    if cache:
+        open(path, "w", encoding="utf-8").write(s)
+    return s
+
+
+def train_bert_wordpiece(vocab_size: int = 30522, train_lines: int = 200000, type_seed: int = 0,
+                         n_types: int = 60000, cache: bool = True) -> str:
+    """BertNormalizer + BertPreTokenizer + WordPiece.  Config C3."""
+    key = f"wp_{vocab_size}_{train_lines}_{type_seed}_{n_types}"
+    path = os.path.join(_cache_dir(), key + ".json")
+    if cache and os.path.exists(path):
+        return open(path, encoding="utf-8").read()
+    from tokenizers import Tokenizer, models, pre_tokenizers, trainers, normalizers, decoders
+    lines = gen_lines(train_lines, text_seed=1, type_seed=type_seed, n_types=n_types)
+    tok = Tokenizer(models.WordPiece(unk_token="[UNK]"))
+    tok.normalizer = normalizers.BertNormalizer()
+    tok.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    tok.decoder = decoders.WordPiece()
+    tr = trainers.WordPieceTrainer(vocab_size=vocab_size, show_progress=False,
+                                   special_tokens=["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"])
+    tok.train_from_iterator(lines, tr)
+    s = tok.to_str()
+    if cache:
+        open(path, "w", encoding="utf-8").write(s)
+    return s
+
+
+def wordlevel_whitespace(lines: list[str]) -> str:
+    """Config C1: Whitespace + WordLevel over every distinct word of ``lines`` + <unk>."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    pt = pre_tokenizers.Whitespace()
+    vocab = {"<unk>": 0}
+    for ln in lines:
+        for w, _ in pt.pre_tokenize_str(ln):
+            if w not in vocab:
+                vocab[w] = len(vocab)
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pt
+    return tok.to_str()
+
+
+def sha256(s: str) -> str:
+    return hashlib.sha256(s.encode("utf-8")).hexdigest()

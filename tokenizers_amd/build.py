@@ -1,0 +1,55 @@
+"""Build the gfx950 shared library (HIP kernels + C ABI) in-tree with hipcc.
+
+``python -m tokenizers_amd.build`` or ``tokenizers_amd.build.build_library()``.
+The result, ``tokenizers_amd/libtokenizers_amd.so``, is git-ignored but travels
+with the working tree (gpurun snapshot), so GPU boxes never need to compile.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtokenizers_amd.so")
+SOURCES = ["kernels.hip", "capi.cpp", "host_model.cpp"]
+HEADERS = ["kernels.hpp", "tables.hpp", "device_utils.hpp", "host_model.hpp", "json.hpp", "unicode_ranges.inc",
+           os.path.join("..", "..", "include", "tokenizers_amd.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X path cannot be built (there is no CPU fallback)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
+           "-Wall", "-Wno-unused-function", "-DTKAMD_BUILD"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

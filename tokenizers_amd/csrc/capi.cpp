@@ -1,0 +1,556 @@
+// C ABI of the MI355X-native encode_batch path (include/tokenizers_amd.h): tokenizer handle,
+// HBM workspace, stream-ordered kernel pipeline.  No tokenisation logic lives here -- it only
+// sequences the kernels of kernels.hip.
+#include "../../include/tokenizers_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "host_model.hpp"
+#include "kernels.hpp"
+
+using namespace tkamd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int set_error(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+#define HIP_CHECK(expr)                                                                                     \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e));                       \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_CHECK(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 4096;
+        HIP_CHECK(hipMalloc(&p, want));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+template <class T>
+void upload(DevBuf& b, const std::vector<T>& v, size_t min_bytes = 16) {
+    size_t bytes = std::max(min_bytes, v.size() * sizeof(T));
+    b.reserve(bytes);
+    if (!v.empty()) HIP_CHECK(hipMemcpy(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+}
+
+struct StageRec {
+    std::string name;
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace
+
+struct tkamd_tokenizer {
+    HostModel hm;
+    int device = -1;
+    DevTables dt{};
+    std::mutex mu;
+    // tables
+    DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
+    DevBuf t_trie_eb, t_trie_by, t_trie_ch, t_trie_id, t_trie_root;
+    // workspace (sized by the largest batch seen)
+    DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
+    DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
+    // host entry staging
+    DevBuf h_text, h_doc_off;
+    int n_cu = 256;
+    int n_direct = 0;
+    bool long_prepared = false;
+    // profiling
+    bool prof = false;
+    std::vector<StageRec> pending;
+    std::vector<tkamd_stage_time> acc;
+    // last device call (for tkamd_device_sync)
+    int64_t last_n_docs = 0;
+};
+
+struct tkamd_batch {
+    int64_t n_docs = 0, n_tokens = 0;
+    std::vector<uint32_t> ids;
+    std::vector<int64_t> tok_offsets;
+    std::vector<uint32_t> offsets;
+    std::vector<uint32_t> word_ids;
+    bool has_offsets = false, has_words = false;
+};
+
+namespace {
+
+// scalars block layout (int64 slots)
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_COUNTERS = 4 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
+
+struct Prof {
+    tkamd_tokenizer* t;
+    hipStream_t st;
+    void begin(const char* name) {
+        if (!t->prof) return;
+        StageRec r;
+        r.name = name;
+        HIP_CHECK(hipEventCreate(&r.a));
+        HIP_CHECK(hipEventCreate(&r.b));
+        HIP_CHECK(hipEventRecord(r.a, st));
+        t->pending.push_back(r);
+    }
+    void end() {
+        if (!t->prof) return;
+        HIP_CHECK(hipEventRecord(t->pending.back().b, st));
+    }
+};
+
+void drain_profile(tkamd_tokenizer* t) {
+    for (StageRec& r : t->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto it = std::find_if(t->acc.begin(), t->acc.end(), [&](const tkamd_stage_time& s) { return r.name == s.name; });
+            if (it == t->acc.end()) {
+                tkamd_stage_time s{};
+                snprintf(s.name, sizeof(s.name), "%s", r.name.c_str());
+                t->acc.push_back(s);
+                it = t->acc.end() - 1;
+            }
+            it->ms_total += ms;
+            it->launches += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    t->pending.clear();
+}
+
+void upload_tables(tkamd_tokenizer* t) {
+    HostModel& hm = t->hm;
+    upload(t->t_uc1, hm.uc_stage1);
+    upload(t->t_uc2, hm.uc_stage2);
+    std::vector<uint32_t> bid(hm.byte_id, hm.byte_id + 256);
+    upload(t->t_byte_id, bid);
+    upload(t->t_merges, hm.merge_table);
+    upload(t->t_words, hm.word_table, 64);
+    upload(t->t_long_blob, hm.long_blob);
+    upload(t->t_long_off, hm.long_off);
+    upload(t->t_long_id, hm.long_id);
+    upload(t->t_long_table, hm.long_table);
+    upload(t->t_trie_eb, hm.trie.edge_begin);
+    upload(t->t_trie_by, hm.trie.edge_byte);
+    upload(t->t_trie_ch, hm.trie.edge_child);
+    upload(t->t_trie_id, hm.trie.node_id);
+    upload(t->t_trie_root, hm.trie.root_child);
+    DevTables& d = t->dt;
+    d.uc1 = t->t_uc1.as<uint16_t>();
+    d.uc2 = t->t_uc2.as<uint8_t>();
+    d.byte_id = t->t_byte_id.as<uint32_t>();
+    d.merges = t->t_merges.as<MergeSlot>();
+    d.merge_mask = hm.merge_mask;
+    d.merge_seed = hm.merge_seed;
+    d.words = t->t_words.as<WordSlot>();
+    d.word_mask = hm.word_mask;
+    d.word_seed = hm.word_seed;
+    d.ignore_merges = hm.ignore_merges ? 1u : 0u;
+    d.unk_id = hm.unk_id;
+    d.has_unk = hm.has_unk ? 1u : 0u;
+    d.long_blob = t->t_long_blob.as<uint8_t>();
+    d.long_off = t->t_long_off.as<uint32_t>();
+    d.long_id = t->t_long_id.as<uint32_t>();
+    d.long_table = t->t_long_table.as<uint32_t>();
+    d.long_mask = hm.long_mask;
+    d.trie_edge_begin = t->t_trie_eb.as<uint32_t>();
+    d.trie_edge_byte = t->t_trie_by.as<uint8_t>();
+    d.trie_edge_child = t->t_trie_ch.as<uint32_t>();
+    d.trie_node_id = t->t_trie_id.as<uint32_t>();
+    d.trie_root_child = t->t_trie_root.as<uint32_t>();
+    d.max_input_chars = hm.max_input_chars;
+}
+
+// Load-time proof of the WORD_DIRECT flag: run the device merge kernel on every <=16-byte vocab
+// entry and keep the flag only where merge_word's result is exactly [own id].
+void verify_direct_words(tkamd_tokenizer* t) {
+    HostModel& hm = t->hm;
+    if (hm.model != MODEL_BPE || hm.n_words == 0) return;
+    std::vector<uint8_t> text;
+    std::vector<uint32_t> starts, slot_of;
+    for (uint32_t sidx = 0; sidx <= hm.word_mask; ++sidx) {
+        const WordSlot& s = hm.word_table[sidx];
+        if (s.len == 0) continue;
+        uint8_t buf[16];
+        memcpy(buf, &s.lo, 8);
+        memcpy(buf + 8, &s.hi, 8);
+        starts.push_back((uint32_t)text.size());
+        slot_of.push_back(sidx);
+        text.insert(text.end(), buf, buf + s.len);
+    }
+    uint32_t P = (uint32_t)starts.size();
+    starts.push_back((uint32_t)text.size());
+    size_t n = text.size();
+    text.resize(n + TKAMD_TEXT_PAD, 0);
+    std::vector<uint32_t> list(P);
+    for (uint32_t i = 0; i < P; ++i) list[i] = i;
+    DevBuf d_text, d_starts, d_list, d_n, d_tok0, d_ntok, d_tmp;
+    upload(d_text, text);
+    upload(d_starts, starts);
+    upload(d_list, list);
+    std::vector<uint32_t> nn{P};
+    upload(d_n, nn);
+    d_tok0.reserve(P * 4 + 16);
+    d_ntok.reserve(P * 4 + 16);
+    d_tmp.reserve(n * 4 + 64);
+    HIP_CHECK(hipMemset(d_ntok.p, 0, P * 4));
+    launch_bpe_merge(nullptr, std::max(1, (int)std::min<uint32_t>(P / 16 + 1, 4096)), 16, t->dt, d_text.as<uint8_t>(),
+                     d_starts.as<uint32_t>(), d_list.as<uint32_t>(), d_n.as<uint32_t>(), d_tok0.as<uint32_t>(),
+                     d_ntok.as<uint32_t>(), d_tmp.as<uint32_t>(), nullptr);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipDeviceSynchronize());
+    std::vector<uint32_t> tok0(P), ntok(P);
+    HIP_CHECK(hipMemcpy(tok0.data(), d_tok0.p, P * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(ntok.data(), d_ntok.p, P * 4, hipMemcpyDeviceToHost));
+    int nd = 0;
+    for (uint32_t i = 0; i < P; ++i) {
+        WordSlot& s = hm.word_table[slot_of[i]];
+        if (ntok[i] == 1 && tok0[i] == s.id) { s.flags |= WORD_DIRECT; ++nd; }
+        else s.flags &= ~WORD_DIRECT;
+    }
+    t->n_direct = nd;
+    upload(t->t_words, hm.word_table, 64);
+    t->dt.words = t->t_words.as<WordSlot>();
+    d_text.release(); d_starts.release(); d_list.release(); d_n.release(); d_tok0.release(); d_ntok.release(); d_tmp.release();
+}
+
+struct Plan {
+    int64_t n_bytes, n_docs, n_words;
+};
+
+void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint32_t flags) {
+    int64_t W = (n_bytes >> 6) + 2;
+    size_t N = (size_t)n_bytes;
+    t->w_docmask.reserve(W * 8);
+    t->w_startmask.reserve(W * 8);
+    t->w_wprefix.reserve(W * 4);
+    t->w_bsum.reserve((W / 256 + 2) * 4);
+    t->w_pt_start.reserve((N + 4) * 4);
+    t->w_tok0.reserve((N + 4) * 4);
+    t->w_ntok.reserve((N + 4) * 4);
+    t->w_pt_tokoff.reserve((N + 4) * 4);
+    t->w_tmp_ids.reserve((N + 4) * 4);
+    t->w_lists.reserve((N + N / 16 + N / 64 + 64) * 4);
+    t->w_csum.reserve((N / 1024 + 4) * 4);
+    t->w_ids.reserve((N + 4) * 4);
+    t->w_doc_pt.reserve((n_docs + 2) * 4);
+    t->w_tok_offsets.reserve((n_docs + 2) * 8);
+    t->w_scalars.reserve(SC_SLOTS * 8);
+    if (flags & TKAMD_OFFSETS_MASK) {
+        t->w_tmp_end.reserve((N + 4) * 4);
+        t->w_offsets.reserve((N + 4) * 8);
+    }
+    if (flags & TKAMD_WANT_WORD_IDS) t->w_word_ids.reserve((N + 4) * 4);
+}
+
+// Enqueue the whole path on `st`.  Inputs and outputs are device pointers.
+void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
+                  uint32_t flags, hipStream_t st, tkamd_device_result* out) {
+    HostModel& hm = t->hm;
+    if (n_bytes >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
+    if ((flags & TKAMD_OFFSETS_MASK) || (flags & TKAMD_WANT_WORD_IDS))
+        throw Unsupported("offsets / word ids are not produced by this build yet (use TKAMD_OFFSETS_NONE)");
+    if (!hm.added_tokens.empty())
+        throw Unsupported("added tokens need the AddedVocabulary split (added_vocabulary.rs:523-564), not built yet");
+    if (!(hm.model == MODEL_BPE && hm.pretok == PT_BYTELEVEL_GPT2 && !hm.add_prefix_space))
+        throw Unsupported("this build covers ByteLevel(GPT-2 regex, add_prefix_space=false) + BPE");
+
+    reserve_workspace(t, n_bytes, n_docs, flags);
+    int64_t* sc = t->w_scalars.as<int64_t>();
+    int64_t* d_npretok = sc + SC_NPRETOK;
+    int64_t* d_ntok_total = sc + SC_NTOK;
+    int* d_err = (int*)(sc + SC_ERR);
+    uint32_t* d_counters = (uint32_t*)(sc + SC_COUNTERS);
+    const int64_t W = (n_bytes >> 6) + 1;
+    Prof pf{t, st};
+
+    HIP_CHECK(hipMemsetAsync(sc, 0, SC_SLOTS * 8, st));
+    HIP_CHECK(hipMemsetAsync(t->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
+    out->d_ids = t->w_ids.as<uint32_t>();
+    out->d_tok_offsets = t->w_tok_offsets.as<int64_t>();
+    out->d_offsets = nullptr;
+    out->d_word_ids = nullptr;
+    out->d_n_tokens = d_ntok_total;
+    out->d_n_pretokens = d_npretok;
+    t->last_n_docs = n_docs;
+
+    pf.begin("mark_doc_starts");
+    launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<unsigned long long>(), d_err);
+    pf.end();
+    if (n_bytes == 0) {
+        HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
+        return;
+    }
+    pf.begin("pretok_gpt2");
+    launch_pretok_gpt2(st, d_text, n_bytes, t->w_docmask.as<unsigned long long>(), t->dt.uc1, t->dt.uc2,
+                       t->w_startmask.as<unsigned long long>());
+    pf.end();
+    pf.begin("mask_scan");
+    launch_mask_scan(st, t->w_startmask.as<unsigned long long>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
+    pf.end();
+    pf.begin("emit_pretok");
+    launch_emit_pretok(st, t->w_startmask.as<unsigned long long>(), t->w_wprefix.as<uint32_t>(), n_bytes, d_npretok,
+                       t->w_pt_start.as<uint32_t>());
+    pf.end();
+    pf.begin("doc_first_pretok");
+    launch_doc_first_pretok(st, d_doc_off, n_docs, n_bytes, t->w_startmask.as<unsigned long long>(), t->w_wprefix.as<uint32_t>(),
+                            d_npretok, t->w_doc_pt.as<uint32_t>());
+    pf.end();
+
+    const int grid = t->n_cu * 8;
+    size_t N = (size_t)n_bytes;
+    uint32_t* list16 = t->w_lists.as<uint32_t>();
+    uint32_t* list64 = list16 + N + 16;
+    uint32_t* listL = list64 + N / 16 + 16;
+    pf.begin("bpe_word_lookup");
+    launch_bpe_word_lookup(st, grid, t->dt, d_text, t->w_pt_start.as<uint32_t>(), d_npretok, t->w_tok0.as<uint32_t>(),
+                           t->w_ntok.as<uint32_t>(), list16, list64, listL, d_counters);
+    pf.end();
+    pf.begin("bpe_merge16");
+    launch_bpe_merge(st, grid, 16, t->dt, d_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16,
+                     t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
+    pf.end();
+    pf.begin("bpe_merge64");
+    launch_bpe_merge(st, grid, 64, t->dt, d_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
+                     t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
+    pf.end();
+    if (!t->long_prepared) {
+        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(long merge kernel LDS) failed");
+        t->long_prepared = true;
+    }
+    pf.begin("bpe_merge_long");
+    launch_bpe_merge_long(st, t->n_cu, t->dt, d_text, t->w_pt_start.as<uint32_t>(), listL, d_counters + CNT_LISTL,
+                          t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr, d_err);
+    pf.end();
+    pf.begin("compact");
+    launch_compact(st, grid, t->w_ntok.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(),
+                   t->w_pt_start.as<uint32_t>(), d_npretok, t->w_csum.as<uint32_t>(), d_ntok_total,
+                   t->w_pt_tokoff.as<uint32_t>(), t->w_ids.as<uint32_t>());
+    pf.end();
+    pf.begin("doc_tok_offsets");
+    launch_doc_tok_offsets(st, t->w_doc_pt.as<uint32_t>(), n_docs, t->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
+                           t->w_tok_offsets.as<int64_t>());
+    pf.end();
+    HIP_CHECK(hipGetLastError());
+}
+
+int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
+    int64_t host[SC_SLOTS];
+    HIP_CHECK(hipMemcpyAsync(host, t->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipStreamSynchronize(st));
+    int err = *(int*)&host[SC_ERR];
+    if (n_tok) *n_tok = host[SC_NTOK];
+    if (n_pretok) *n_pretok = host[SC_NPRETOK];
+    return err;
+}
+
+int error_from_bits(int bits) {
+    if (bits & ERR_BAD_OFFSETS) return set_error(TKAMD_ERR_INVALID, "doc_offsets is not a monotone CSR over [0, n_bytes]");
+    if (bits & ERR_PRETOKEN_TOO_LONG)
+        return set_error(TKAMD_ERR_UNSUPPORTED, "a pre-token is longer than 8192 bytes (workgroup merge path limit)");
+    if (bits & ERR_ADDED_TOKEN) return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text");
+    if (bits & ERR_NON_ASCII_NORM) return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer on non-ASCII text is not built yet");
+    if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
+    return TKAMD_OK;
+}
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const Unsupported& e) {
+        return set_error(TKAMD_ERR_UNSUPPORTED, e.what());
+    } catch (const Invalid& e) {
+        return set_error(TKAMD_ERR_INVALID, e.what());
+    } catch (const HipError& e) {
+        return set_error(TKAMD_ERR_DEVICE, e.what());
+    } catch (const std::bad_alloc&) {
+        return set_error(TKAMD_ERR_DEVICE, "out of host memory");
+    } catch (const std::exception& e) {
+        return set_error(TKAMD_ERR_INVALID, e.what());
+    }
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+const char* tkamd_version(void) { return "tokenizers_amd 0.1.0 (gfx950)"; }
+const char* tkamd_last_error(void) { return g_last_error.c_str(); }
+
+int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tkamd_tokenizer** out) {
+    if (!json || !out) return set_error(TKAMD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> int {
+        std::unique_ptr<tkamd_tokenizer> t(new tkamd_tokenizer());
+        t->hm = HostModel::from_json(json, json_len);
+        t->device = device;
+        if (device >= 0) {
+            int n = 0;
+            if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device available (the HIP path has no CPU fallback)");
+            if (device >= n) throw HipError("HIP device ordinal out of range");
+            HIP_CHECK(hipSetDevice(device));
+            hipDeviceProp_t prop;
+            HIP_CHECK(hipGetDeviceProperties(&prop, device));
+            t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            upload_tables(t.get());
+            verify_direct_words(t.get());
+        }
+        *out = t.release();
+        return TKAMD_OK;
+    });
+}
+
+void tkamd_tokenizer_free(tkamd_tokenizer* t) {
+    if (!t) return;
+    if (t->device >= 0) {
+        (void)hipSetDevice(t->device);
+        drain_profile(t);
+        DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
+                         &t->t_long_id, &t->t_long_table, &t->t_trie_eb, &t->t_trie_by, &t->t_trie_ch, &t->t_trie_id,
+                         &t->t_trie_root, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
+                         &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
+                         &t->h_text, &t->h_doc_off};
+        for (DevBuf* b : all) b->release();
+    }
+    delete t;
+}
+
+int tkamd_tokenizer_info(const tkamd_tokenizer* t, tkamd_info* info) {
+    if (!t || !info) return set_error(TKAMD_ERR_INVALID, "null argument");
+    const HostModel& hm = t->hm;
+    info->model = (int32_t)hm.model;
+    info->pre_tokenizer = (int32_t)hm.pretok;
+    info->normalizer = (int32_t)hm.norm;
+    info->vocab_size = (int32_t)hm.vocab_size;
+    info->n_merges = (int32_t)hm.n_merges;
+    info->add_prefix_space = hm.add_prefix_space;
+    info->ignore_merges = hm.ignore_merges;
+    info->n_added_tokens = (int32_t)hm.added_tokens.size();
+    info->device = t->device;
+    info->n_direct_words = t->n_direct;
+    return TKAMD_OK;
+}
+
+int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_offsets, int64_t n_docs,
+                              int64_t n_bytes, uint32_t flags, void* hip_stream, tkamd_device_result* out) {
+    if (!t || !out || !d_doc_offsets || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_text))
+        return set_error(TKAMD_ERR_INVALID, "bad argument");
+    if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(t->mu);
+        HIP_CHECK(hipSetDevice(t->device));
+        run_pipeline(t, d_text, d_doc_offsets, n_docs, n_bytes, flags, (hipStream_t)hip_stream, out);
+        return TKAMD_OK;
+    });
+}
+
+int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens) {
+    if (!t || t->device < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(t->mu);
+        HIP_CHECK(hipSetDevice(t->device));
+        int bits = read_scalars(t, (hipStream_t)hip_stream, n_tokens, n_pretokens);
+        return error_from_bits(bits);
+    });
+}
+
+int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
+                       tkamd_batch** out) {
+    if (!t || !out || !doc_offsets || n_docs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(t->mu);
+        HIP_CHECK(hipSetDevice(t->device));
+        int64_t n_bytes = doc_offsets[n_docs];
+        if (n_bytes < 0 || doc_offsets[0] != 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+        if (n_bytes > 0 && !text) throw Invalid("null text");
+        hipStream_t st = nullptr;
+        t->h_text.reserve((size_t)n_bytes + TKAMD_TEXT_PAD);
+        t->h_doc_off.reserve((size_t)(n_docs + 1) * 8);
+        if (n_bytes) HIP_CHECK(hipMemcpyAsync(t->h_text.p, text, (size_t)n_bytes, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemsetAsync((uint8_t*)t->h_text.p + n_bytes, 0, TKAMD_TEXT_PAD, st));
+        HIP_CHECK(hipMemcpyAsync(t->h_doc_off.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
+        tkamd_device_result r{};
+        run_pipeline(t, t->h_text.as<uint8_t>(), t->h_doc_off.as<int64_t>(), n_docs, n_bytes, flags, st, &r);
+        int64_t n_tok = 0, n_pt = 0;
+        int bits = read_scalars(t, st, &n_tok, &n_pt);
+        if (bits) return error_from_bits(bits);
+        std::unique_ptr<tkamd_batch> b(new tkamd_batch());
+        b->n_docs = n_docs;
+        b->n_tokens = n_tok;
+        b->ids.resize((size_t)n_tok);
+        b->tok_offsets.resize((size_t)n_docs + 1);
+        if (n_tok) HIP_CHECK(hipMemcpy(b->ids.data(), r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(b->tok_offsets.data(), r.d_tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        *out = b.release();
+        return TKAMD_OK;
+    });
+}
+
+int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
+int64_t tkamd_batch_n_tokens(const tkamd_batch* b) { return b ? b->n_tokens : 0; }
+const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? b->ids.data() : nullptr; }
+const int64_t* tkamd_batch_tok_offsets(const tkamd_batch* b) { return b ? b->tok_offsets.data() : nullptr; }
+const uint32_t* tkamd_batch_offsets(const tkamd_batch* b) { return (b && b->has_offsets) ? b->offsets.data() : nullptr; }
+const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b) { return (b && b->has_words) ? b->word_ids.data() : nullptr; }
+void tkamd_batch_free(tkamd_batch* b) { delete b; }
+
+int tkamd_profile_enable(tkamd_tokenizer* t, int on) {
+    if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(t->mu);
+    t->prof = on != 0;
+    return TKAMD_OK;
+}
+
+int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_stages, int* n_stages, int reset) {
+    if (!t || !n_stages) return set_error(TKAMD_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (t->device >= 0) {
+        (void)hipSetDevice(t->device);
+        drain_profile(t);
+    }
+    int n = (int)std::min<size_t>(t->acc.size(), (size_t)std::max(0, max_stages));
+    for (int i = 0; i < n && stages; ++i) stages[i] = t->acc[i];
+    *n_stages = n;
+    if (reset) t->acc.clear();
+    return TKAMD_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -1,0 +1,470 @@
+// tokenizer.json -> flat tables.  See host_model.hpp.
+#include "host_model.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <unordered_map>
+
+#include "json.hpp"
+
+namespace tkamd {
+
+namespace {
+
+struct UcRun {
+    uint32_t first, last;
+    uint8_t flags;
+};
+const UcRun kUcRuns[] = {
+#include "unicode_ranges.inc"
+};
+
+// GPT-2 bytes <-> unicode map, pre_tokenizers/byte_level.rs:15-39: printable bytes map to
+// themselves, the other 68 bytes to U+0100+n in byte order.
+void build_bytes_char(uint32_t b2c[256]) {
+    bool direct[256] = {false};
+    for (int b = '!'; b <= '~'; ++b) direct[b] = true;
+    for (int b = 0xA1; b <= 0xAC; ++b) direct[b] = true;
+    for (int b = 0xAE; b <= 0xFF; ++b) direct[b] = true;
+    uint32_t n = 0;
+    for (int b = 0; b < 256; ++b) {
+        if (direct[b]) b2c[b] = (uint32_t)b;
+        else b2c[b] = 256 + n++;
+    }
+}
+
+// decode one UTF-8 scalar; returns length or 0 if malformed
+int utf8_decode(const uint8_t* s, size_t n, uint32_t* cp) {
+    if (n == 0) return 0;
+    uint8_t b = s[0];
+    if (b < 0x80) { *cp = b; return 1; }
+    if ((b & 0xE0) == 0xC0 && n >= 2) { *cp = ((b & 0x1F) << 6) | (s[1] & 0x3F); return 2; }
+    if ((b & 0xF0) == 0xE0 && n >= 3) { *cp = ((b & 0x0F) << 12) | ((s[1] & 0x3F) << 6) | (s[2] & 0x3F); return 3; }
+    if ((b & 0xF8) == 0xF0 && n >= 4) {
+        *cp = ((b & 0x07) << 18) | ((s[1] & 0x3F) << 12) | ((s[2] & 0x3F) << 6) | (s[3] & 0x3F);
+        return 4;
+    }
+    return 0;
+}
+
+// token string in the byte-level alphabet -> raw bytes; false if a char is outside the alphabet
+bool bytelevel_to_raw(const std::string& tok, const std::unordered_map<uint32_t, uint8_t>& c2b, std::string* raw) {
+    raw->clear();
+    const uint8_t* s = (const uint8_t*)tok.data();
+    size_t n = tok.size(), i = 0;
+    while (i < n) {
+        uint32_t cp;
+        int l = utf8_decode(s + i, n - i, &cp);
+        if (!l) return false;
+        auto it = c2b.find(cp);
+        if (it == c2b.end()) return false;
+        raw->push_back((char)it->second);
+        i += l;
+    }
+    return true;
+}
+
+const char* kLlama3Pattern =
+    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+
+void build_unicode(HostModel& m) {
+    std::vector<uint8_t> flat(0x110000, 0);
+    for (const UcRun& r : kUcRuns)
+        for (uint32_t cp = r.first; cp <= r.last; ++cp) flat[cp] = r.flags;
+    m.uc_stage1.assign(UC_STAGE1_LEN, 0);
+    m.uc_stage2.clear();
+    std::unordered_map<std::string, uint16_t> seen;
+    for (uint32_t blk = 0; blk < (uint32_t)UC_STAGE1_LEN; ++blk) {
+        std::string key((const char*)&flat[blk * 256], 256);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            uint16_t idx = (uint16_t)(m.uc_stage2.size() / 256);
+            m.uc_stage2.insert(m.uc_stage2.end(), key.begin(), key.end());
+            it = seen.emplace(std::move(key), idx).first;
+        }
+        m.uc_stage1[blk] = it->second;
+    }
+}
+
+template <class Slot, class IsEmpty, class H1, class H2>
+bool cuckoo_insert(std::vector<Slot>& tab, Slot item, IsEmpty is_empty, H1 h1, H2 h2, std::mt19937& rng) {
+    for (int kick = 0; kick < 2000; ++kick) {
+        uint32_t s1 = h1(item), s2 = h2(item);
+        if (is_empty(tab[s1])) { tab[s1] = item; return true; }
+        if (is_empty(tab[s2])) { tab[s2] = item; return true; }
+        uint32_t victim = (rng() & 1) ? s1 : s2;
+        std::swap(item, tab[victim]);
+    }
+    return false;
+}
+
+void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
+    if (merges.empty()) { m.merge_table.clear(); m.merge_mask = 0; return; }
+    uint32_t cap = 16;
+    while (cap < merges.size() * 5 / 2) cap <<= 1;   // load factor <= 0.4
+    std::mt19937 rng(12345);
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        uint32_t seed = (uint32_t)rng();
+        uint32_t mask = cap - 1;
+        std::vector<MergeSlot> tab(cap, MergeSlot{MERGE_EMPTY, MERGE_EMPTY, RANK_NONE, 0});
+        bool ok = true;
+        for (const MergeSlot& e : merges) {
+            ok = cuckoo_insert(
+                tab, e, [](const MergeSlot& s) { return s.a == MERGE_EMPTY; },
+                [&](const MergeSlot& s) { return merge_hash1(s.a, s.b, seed) & mask; },
+                [&](const MergeSlot& s) { return merge_hash2(s.a, s.b, seed) & mask; }, rng);
+            if (!ok) break;
+        }
+        if (ok) { m.merge_table.swap(tab); m.merge_mask = mask; m.merge_seed = seed; return; }
+        if (attempt % 4 == 3) cap <<= 1;
+    }
+    throw Invalid("could not build the merge hash table");
+}
+
+void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {
+    uint32_t cap = 16;
+    while (cap < words.size() * 5 / 2) cap <<= 1;
+    std::mt19937 rng(54321);
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        uint32_t seed = (uint32_t)rng();
+        uint32_t mask = cap - 1;
+        std::vector<WordSlot> tab(cap, WordSlot{0, 0, 0, 0, 0, 0});
+        bool ok = true;
+        for (const WordSlot& e : words) {
+            ok = cuckoo_insert(
+                tab, e, [](const WordSlot& s) { return s.len == 0; },
+                [&](const WordSlot& s) { return word_hash1(s.lo, s.hi, s.len, seed) & mask; },
+                [&](const WordSlot& s) { return word_hash2(word_hash1(s.lo, s.hi, s.len, seed)) & mask; }, rng);
+            if (!ok) break;
+        }
+        if (ok) { m.word_table.swap(tab); m.word_mask = mask; m.word_seed = seed; return; }
+        if (attempt % 4 == 3) cap <<= 1;
+    }
+    throw Invalid("could not build the whole-word hash table");
+}
+
+void build_long_table(HostModel& m) {
+    size_t n = m.long_id.size();
+    uint32_t cap = 16;
+    while (cap < n * 2 + 1) cap <<= 1;
+    m.long_mask = cap - 1;
+    m.long_table.assign(cap, 0);
+    for (size_t e = 0; e < n; ++e) {
+        uint32_t h = fnv1a(&m.long_blob[m.long_off[e]], m.long_off[e + 1] - m.long_off[e]) & m.long_mask;
+        while (m.long_table[h]) h = (h + 1) & m.long_mask;
+        m.long_table[h] = (uint32_t)e + 1;
+    }
+}
+
+// Build the two-root byte trie for WordPiece.
+void build_trie(HostModel& m, const std::vector<std::pair<std::string, uint32_t>>& initial,
+                const std::vector<std::pair<std::string, uint32_t>>& cont) {
+    struct Node {
+        std::vector<std::pair<uint8_t, uint32_t>> kids;
+        uint32_t id = 0xFFFFFFFFu;
+    };
+    std::vector<Node> nodes(2);
+    auto insert = [&](uint32_t root, const std::string& key, uint32_t id) {
+        uint32_t cur = root;
+        for (unsigned char c : key) {
+            uint32_t nxt = 0;
+            for (auto& k : nodes[cur].kids)
+                if (k.first == c) { nxt = k.second; break; }
+            if (!nxt) {
+                nxt = (uint32_t)nodes.size();
+                nodes.emplace_back();
+                nodes[cur].kids.emplace_back(c, nxt);
+            }
+            cur = nxt;
+        }
+        nodes[cur].id = id;
+    };
+    for (auto& kv : initial) insert(0, kv.first, kv.second);
+    for (auto& kv : cont) insert(1, kv.first, kv.second);
+    ByteTrie& t = m.trie;
+    size_t nn = nodes.size();
+    t.edge_begin.assign(nn + 1, 0);
+    t.node_id.assign(nn, 0xFFFFFFFFu);
+    t.edge_byte.clear();
+    t.edge_child.clear();
+    for (size_t i = 0; i < nn; ++i) {
+        auto& k = nodes[i].kids;
+        std::sort(k.begin(), k.end());
+        t.edge_begin[i] = (uint32_t)t.edge_byte.size();
+        for (auto& e : k) { t.edge_byte.push_back(e.first); t.edge_child.push_back(e.second); }
+        t.node_id[i] = nodes[i].id;
+    }
+    t.edge_begin[nn] = (uint32_t)t.edge_byte.size();
+    t.root_child.assign(512, 0);
+    for (int r = 0; r < 2; ++r)
+        for (auto& e : nodes[r].kids) t.root_child[r * 256 + e.first] = e.second;
+}
+
+PretokKind parse_pretok(const JsonValue* pt, HostModel& m) {
+    if (!pt || pt->is_null()) throw Unsupported("pre_tokenizer: null is outside the hot path");
+    std::string type = pt->get_str("type");
+    if (type == "ByteLevel") {
+        m.byte_level = true;
+        m.add_prefix_space = pt->get_bool("add_prefix_space", true);
+        bool use_regex = pt->get_bool("use_regex", true);
+        return use_regex ? PT_BYTELEVEL_GPT2 : PT_BYTELEVEL_NOREGEX;
+    }
+    if (type == "Whitespace") return PT_WHITESPACE;
+    if (type == "WhitespaceSplit") return PT_WHITESPACE_SPLIT;
+    if (type == "BertPreTokenizer") return PT_BERT;
+    if (type == "Sequence") {
+        const JsonValue* seq = pt->get("pretokenizers");
+        if (seq && seq->is_array() && seq->arr.size() == 2) {
+            const JsonValue* a = seq->arr[0].get();
+            const JsonValue* b = seq->arr[1].get();
+            if (a->get_str("type") == "Split" && b->get_str("type") == "ByteLevel") {
+                const JsonValue* pat = a->get("pattern");
+                std::string rx = pat ? pat->get_str("Regex") : "";
+                bool invert = a->get_bool("invert", false);
+                std::string beh = a->get_str("behavior");
+                if (rx == kLlama3Pattern && !invert && beh == "Isolated" && !b->get_bool("use_regex", true)) {
+                    m.byte_level = true;
+                    m.add_prefix_space = b->get_bool("add_prefix_space", true);
+                    return PT_LLAMA3;
+                }
+                throw Unsupported("pre_tokenizer: Sequence[Split, ByteLevel] with a pattern other than the Llama-3 regex");
+            }
+        }
+        throw Unsupported("pre_tokenizer: this Sequence is outside the hot path");
+    }
+    throw Unsupported("pre_tokenizer: type '" + type + "' is outside the hot path");
+}
+
+}  // namespace
+
+uint32_t fnv1a(const uint8_t* p, size_t n) {
+    uint32_t h = 2166136261u;
+    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 16777619u; }
+    return h;
+}
+
+HostModel HostModel::from_json(const char* json, size_t len) {
+    JsonPtr root;
+    try {
+        root = json_parse(json, len);
+    } catch (const std::exception& e) {
+        throw Invalid(e.what());
+    }
+    if (!root->is_object()) throw Invalid("tokenizer.json: top level is not an object");
+    HostModel m;
+    std::fill(m.byte_id, m.byte_id + 256, 0xFFFFFFFFu);
+
+    // ---- things the hot path does not implement: say so loudly ----
+    const JsonValue* trunc = root->get("truncation");
+    if (trunc && !trunc->is_null()) throw Unsupported("truncation is applied by the caller (utils/truncation.rs), not by this path");
+    const JsonValue* pad = root->get("padding");
+    if (pad && !pad->is_null()) throw Unsupported("padding is applied by the caller (utils/padding.rs), not by this path");
+
+    // ---- normalizer ----
+    const JsonValue* norm = root->get("normalizer");
+    if (norm && !norm->is_null()) {
+        std::string t = norm->get_str("type");
+        if (t == "BertNormalizer") {
+            m.norm = NORM_BERT;
+            m.bn_clean_text = norm->get_bool("clean_text", true);
+            m.bn_handle_chinese = norm->get_bool("handle_chinese_chars", true);
+            m.bn_lowercase = norm->get_bool("lowercase", true);
+            const JsonValue* sa = norm->get("strip_accents");
+            m.bn_strip_accents = (sa && sa->is_bool()) ? sa->b : m.bn_lowercase;  // normalizers/bert.rs:124
+        } else {
+            throw Unsupported("normalizer: type '" + t + "' is outside the hot path");
+        }
+    }
+
+    // ---- pre-tokenizer ----
+    m.pretok = parse_pretok(root->get("pre_tokenizer"), m);
+
+    // ---- post-processor: only its offset trimming matters to this path ----
+    const JsonValue* pp = root->get("post_processor");
+    if (pp && !pp->is_null()) {
+        std::string t = pp->get_str("type");
+        if (t == "ByteLevel") m.trim_offsets = pp->get_bool("trim_offsets", true);
+        else if (t == "RobertaProcessing") m.trim_offsets = pp->get_bool("trim_offsets", true);
+    }
+
+    // ---- added tokens ----
+    const JsonValue* at = root->get("added_tokens");
+    if (at && at->is_array()) {
+        for (auto& e : at->arr) {
+            AddedToken a;
+            a.content = e->get_str("content");
+            a.id = (uint32_t)e->get_num("id", 0);
+            a.special = e->get_bool("special", false);
+            a.single_word = e->get_bool("single_word", false);
+            a.lstrip = e->get_bool("lstrip", false);
+            a.rstrip = e->get_bool("rstrip", false);
+            a.normalized = e->get_bool("normalized", false);
+            m.added_tokens.push_back(std::move(a));
+        }
+    }
+
+    // ---- model ----
+    const JsonValue* model = root->get("model");
+    if (!model || !model->is_object()) throw Invalid("tokenizer.json: missing model");
+    std::string mtype = model->get_str("type");
+    const JsonValue* vocab = model->get("vocab");
+    if (mtype.empty()) {
+        // legacy untagged models (models/mod.rs:71-136): BPE has merges, WordPiece has a prefix
+        if (model->get("merges")) mtype = "BPE";
+        else if (model->get("continuing_subword_prefix")) mtype = "WordPiece";
+        else mtype = "WordLevel";
+    }
+    if (!vocab || !vocab->is_object()) throw Invalid("tokenizer.json: model.vocab missing");
+
+    std::unordered_map<std::string, uint32_t> v;
+    v.reserve(vocab->obj.size() * 2);
+    for (auto& kv : vocab->obj) {
+        if (!kv.second->is_number()) throw Invalid("tokenizer.json: vocab id is not a number");
+        v[kv.first] = (uint32_t)kv.second->num;   // duplicate keys: last wins, like serde's map
+    }
+    m.vocab_size = (uint32_t)v.size();
+
+    uint32_t b2c[256];
+    build_bytes_char(b2c);
+    std::unordered_map<uint32_t, uint8_t> c2b;
+    for (int b = 0; b < 256; ++b) c2b[b2c[b]] = (uint8_t)b;
+
+    // raw-byte view of the vocab
+    m.raw_tokens.reserve(v.size());
+    m.raw_ids.reserve(v.size());
+    for (auto& kv : v) {
+        if (m.byte_level) {
+            std::string raw;
+            if (!bytelevel_to_raw(kv.first, c2b, &raw)) continue;   // not producible from bytes
+            m.raw_tokens.push_back(std::move(raw));
+        } else {
+            m.raw_tokens.push_back(kv.first);
+        }
+        m.raw_ids.push_back(kv.second);
+    }
+
+    auto opt_str = [&](const char* key, std::string* out) -> bool {
+        const JsonValue* x = model->get(key);
+        if (x && x->is_string()) { *out = x->str; return true; }
+        return false;
+    };
+
+    if (mtype == "BPE") {
+        m.model = MODEL_BPE;
+        if (!m.byte_level) throw Unsupported("BPE without a ByteLevel pre-tokenizer is outside the hot path");
+        const JsonValue* dr = model->get("dropout");
+        if (dr && dr->is_number() && dr->num != 0.0) throw Unsupported("BPE dropout needs the reference's RNG (bpe/word.rs:181)");
+        std::string s;
+        if (opt_str("continuing_subword_prefix", &s) && !s.empty()) throw Unsupported("BPE continuing_subword_prefix");
+        if (opt_str("end_of_word_suffix", &s) && !s.empty()) throw Unsupported("BPE end_of_word_suffix");
+        m.ignore_merges = model->get_bool("ignore_merges", false);
+        if (opt_str("unk_token", &m.unk_token)) {
+            auto it = v.find(m.unk_token);
+            if (it != v.end()) { m.has_unk = true; m.unk_id = it->second; }
+        }
+        // byte -> initial symbol id (bpe/model.rs:494-499 with the byte-level alphabet)
+        for (int b = 0; b < 256; ++b) {
+            std::string ch;
+            uint32_t cp = b2c[b];
+            if (cp < 0x80) ch.push_back((char)cp);
+            else { ch.push_back((char)(0xC0 | (cp >> 6))); ch.push_back((char)(0x80 | (cp & 0x3F))); }
+            auto it = v.find(ch);
+            if (it == v.end())
+                throw Unsupported("byte-level BPE vocab lacks a byte symbol (unk / byte_fallback / dropped-char paths, bpe/model.rs:501-541)");
+            m.byte_id[b] = it->second;
+        }
+        // merges (bpe/model.rs:252-275): rank = position, new_id = vocab[a+b]; duplicate pairs: last wins
+        const JsonValue* mg = model->get("merges");
+        if (!mg || !mg->is_array()) throw Invalid("tokenizer.json: BPE merges missing");
+        std::unordered_map<uint64_t, std::pair<uint32_t, uint32_t>> mm;
+        mm.reserve(mg->arr.size() * 2);
+        uint32_t rank = 0;
+        for (auto& e : mg->arr) {
+            std::string a, b;
+            if (e->is_array() && e->arr.size() == 2 && e->arr[0]->is_string() && e->arr[1]->is_string()) {
+                a = e->arr[0]->str; b = e->arr[1]->str;
+            } else if (e->is_string()) {     // legacy "a b" (bpe/serialization.rs:141-149)
+                size_t sp = e->str.find(' ');
+                if (sp == std::string::npos || e->str.find(' ', sp + 1) != std::string::npos)
+                    throw Invalid("tokenizer.json: bad legacy merge entry");
+                a = e->str.substr(0, sp); b = e->str.substr(sp + 1);
+            } else throw Invalid("tokenizer.json: bad merge entry");
+            auto ia = v.find(a), ib = v.find(b), in = v.find(a + b);
+            if (ia == v.end() || ib == v.end() || in == v.end())
+                throw Invalid("tokenizer.json: merge token out of vocabulary (MergeTokenOutOfVocabulary)");
+            mm[((uint64_t)ia->second << 32) | ib->second] = {rank, in->second};
+            ++rank;
+        }
+        if (rank >= (1u << 20)) throw Unsupported("more than 2^20 merges");
+        m.n_merges = rank;
+        std::vector<MergeSlot> merges;
+        merges.reserve(mm.size());
+        for (auto& kv : mm) merges.push_back(MergeSlot{(uint32_t)(kv.first >> 32), (uint32_t)kv.first, kv.second.first, kv.second.second});
+        std::sort(merges.begin(), merges.end(), [](const MergeSlot& x, const MergeSlot& y) { return x.rank < y.rank; });
+        build_merge_table(m, merges);
+    } else if (mtype == "WordPiece") {
+        m.model = MODEL_WORDPIECE;
+        if (m.byte_level) throw Unsupported("WordPiece behind ByteLevel");
+        m.unk_token = model->get_str("unk_token", "[UNK]");
+        m.cont_prefix = model->get_str("continuing_subword_prefix", "##");
+        m.max_input_chars = (uint32_t)model->get_num("max_input_chars_per_word", 100);
+        auto it = v.find(m.unk_token);
+        if (it != v.end()) { m.has_unk = true; m.unk_id = it->second; }
+    } else if (mtype == "WordLevel") {
+        m.model = MODEL_WORDLEVEL;
+        if (m.byte_level) throw Unsupported("WordLevel behind ByteLevel");
+        m.unk_token = model->get_str("unk_token", "<unk>");
+        auto it = v.find(m.unk_token);
+        if (it != v.end()) { m.has_unk = true; m.unk_id = it->second; }
+    } else {
+        throw Unsupported("model: type '" + mtype + "' is outside the hot path");
+    }
+
+    // ---- whole-word tables (BPE: ignore_merges + merge-stable shortcut; WordLevel: the model) ----
+    if (m.model == MODEL_BPE || m.model == MODEL_WORDLEVEL) {
+        std::vector<WordSlot> words;
+        m.long_off.push_back(0);
+        for (size_t i = 0; i < m.raw_tokens.size(); ++i) {
+            const std::string& r = m.raw_tokens[i];
+            if (r.empty()) continue;
+            if (r.size() <= (size_t)WORD_MAX_KEY) {
+                uint8_t buf[16] = {0};
+                memcpy(buf, r.data(), r.size());
+                WordSlot s{};
+                memcpy(&s.lo, buf, 8);
+                memcpy(&s.hi, buf + 8, 8);
+                s.len = (uint32_t)r.size();
+                s.id = m.raw_ids[i];
+                s.flags = 0;
+                words.push_back(s);
+            } else {
+                m.long_blob.insert(m.long_blob.end(), r.begin(), r.end());
+                m.long_off.push_back((uint32_t)m.long_blob.size());
+                m.long_id.push_back(m.raw_ids[i]);
+            }
+        }
+        m.n_words = (uint32_t)words.size();
+        build_word_table(m, words);
+        build_long_table(m);
+    }
+    if (m.model == MODEL_WORDPIECE) {
+        std::vector<std::pair<std::string, uint32_t>> ini, cont;
+        for (size_t i = 0; i < m.raw_tokens.size(); ++i) {
+            const std::string& r = m.raw_tokens[i];
+            if (r.empty()) continue;
+            ini.emplace_back(r, m.raw_ids[i]);
+            if (!m.cont_prefix.empty() && r.size() > m.cont_prefix.size() && r.compare(0, m.cont_prefix.size(), m.cont_prefix) == 0)
+                cont.emplace_back(r.substr(m.cont_prefix.size()), m.raw_ids[i]);
+            else if (m.cont_prefix.empty())
+                cont.emplace_back(r, m.raw_ids[i]);
+        }
+        build_trie(m, ini, cont);
+    }
+
+    build_unicode(m);
+    return m;
+}
+
+}  // namespace tkamd

@@ -1,0 +1,98 @@
+// Host-side model of a tokenizer.json restricted to the encode_batch hot path: parses the
+// reference's serialization (tokenizer/serialization.rs:104-171, models/bpe/serialization.rs:72-152,
+// models/wordpiece/serialization.rs, models/wordlevel/serialization.rs) and lays the model out as
+// flat lookup tables that are copied verbatim into HBM.  No tokenisation happens on the host.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tables.hpp"
+
+namespace tkamd {
+
+// thrown for components outside the hot path -> TKAMD_ERR_UNSUPPORTED
+struct Unsupported : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+// thrown for malformed input -> TKAMD_ERR_INVALID
+struct Invalid : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// Flattened byte trie for WordPiece longest-match (models/wordpiece/mod.rs:224-283).
+// Node n has children edges [edge_begin[n], edge_begin[n+1]) sorted by byte; node_id[n] is the
+// token id ending at that node or 0xFFFFFFFF.  Node 0 = root for word-initial pieces, node 1 =
+// root for continuation pieces (vocab keys starting with continuing_subword_prefix, stored
+// without the prefix).
+struct ByteTrie {
+    std::vector<uint32_t> edge_begin;  // [n_nodes+1]
+    std::vector<uint8_t> edge_byte;    // [n_edges]
+    std::vector<uint32_t> edge_child;  // [n_edges]
+    std::vector<uint32_t> node_id;     // [n_nodes]
+    // dense first-level fan-out for the two roots: child node for each first byte (0 = none)
+    std::vector<uint32_t> root_child;  // [2*256]
+};
+
+struct AddedToken {
+    std::string content;
+    uint32_t id = 0;
+    bool special = false, single_word = false, lstrip = false, rstrip = false, normalized = false;
+};
+
+struct HostModel {
+    ModelKind model = MODEL_NONE;
+    PretokKind pretok = PT_NONE;
+    NormKind norm = NORM_NONE;
+
+    // ByteLevel options (pre_tokenizers/byte_level.rs:57-70)
+    bool byte_level = false;      // model strings are in the GPT-2 byte alphabet
+    bool add_prefix_space = false;
+    bool trim_offsets = false;    // ByteLevel *post-processor* option (byte_level.rs:175-234)
+    // BertNormalizer options (normalizers/bert.rs:62-90)
+    bool bn_clean_text = true, bn_handle_chinese = true, bn_strip_accents = true, bn_lowercase = true;
+
+    // model options
+    bool ignore_merges = false;
+    bool has_unk = false;
+    uint32_t unk_id = 0;
+    std::string unk_token;
+    std::string cont_prefix;            // WordPiece continuing_subword_prefix ("##")
+    uint32_t max_input_chars = 100;     // WordPiece max_input_chars_per_word
+
+    uint32_t vocab_size = 0;            // number of vocab entries
+    uint32_t n_merges = 0;
+    std::vector<AddedToken> added_tokens;
+
+    // ---- tables copied to the device ----
+    uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level)
+    std::vector<MergeSlot> merge_table; // cuckoo, size = merge_mask+1 (power of two) or empty
+    uint32_t merge_mask = 0, merge_seed = 0;
+    std::vector<WordSlot> word_table;   // cuckoo, size = word_mask+1
+    uint32_t word_mask = 0, word_seed = 0;
+    uint32_t n_words = 0;               // keys stored in word_table (<= 16 bytes)
+    // vocab entries longer than 16 raw bytes, needed for ignore_merges / WordLevel whole-word probes:
+    // sorted blob for a device-side hash (long_table: open addressing over (hash -> entry index))
+    std::vector<uint8_t> long_blob;     // concatenated raw keys
+    std::vector<uint32_t> long_off;     // [n_long+1]
+    std::vector<uint32_t> long_id;      // [n_long]
+    std::vector<uint32_t> long_table;   // open addressing: entry index+1, 0 = empty; size long_mask+1
+    uint32_t long_mask = 0;
+    ByteTrie trie;                      // WordPiece
+
+    std::vector<uint16_t> uc_stage1;    // [UC_STAGE1_LEN]
+    std::vector<uint8_t> uc_stage2;     // [n_blocks*256]
+
+    // raw-byte form of every vocab entry that is expressible in raw bytes (byte-level: inverse of
+    // the GPT-2 alphabet; others: the UTF-8 string itself) -- used to build the tables above and by
+    // the load-time merge-stability check.
+    std::vector<std::string> raw_tokens;   // indexed by position in `ids`
+    std::vector<uint32_t> raw_ids;
+
+    static HostModel from_json(const char* json, size_t len);
+};
+
+uint32_t fnv1a(const uint8_t* p, size_t n);
+
+}  // namespace tkamd

@@ -1,0 +1,679 @@
+// HIP kernels of the encode_batch hot path for gfx950 (MI355X, CDNA4, wave64).
+//
+// Flat, structure-of-arrays pipeline over ONE concatenated UTF-8 buffer (no per-document objects):
+//
+//   text bytes ──K_docmask──► doc-start bitmask
+//        │──────K_pretok_*───► pre-token start bitmask (1 lane per byte, LDS tile + halo, ballot)
+//        │──────K_scan/emit──► pt_start[P+1]   (byte offset of every pre-token = "split")
+//        │──────K_word_lookup► whole-word table hit -> 1 token; misses queued by length class
+//        │──────K_bpe_merge──► min-rank merge loop, 16 lanes (DPP row) or 64 lanes per pre-token
+//        │──────K_compact────► ids[T] + per-document token CSR
+//
+// Every kernel cites the reference code it replaces.  All results are bit-exact integers.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_utils.hpp"
+#include "kernels.hpp"
+#include "tables.hpp"
+
+namespace tkamd {
+
+// =================================================================================================
+// K_docmask: doc_offsets CSR -> bitmask of document start bytes (+ validation of the CSR)
+// Replaces: the per-document loop of TokenizerImpl::encode_batch (tokenizer/mod.rs:1345-1348); a
+// document boundary is a hard text boundary for every pre-tokenizer rule below.
+// =================================================================================================
+__global__ void k_mark_doc_starts(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
+                                  unsigned long long* __restrict__ docmask, int* __restrict__ err) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    int64_t g = doc_off[d];
+    if (d == 0 && g != 0) atomicOr(err, ERR_BAD_OFFSETS);
+    if (d == n_docs) {
+        if (g != n_bytes) atomicOr(err, ERR_BAD_OFFSETS);
+        return;
+    }
+    int64_t g1 = doc_off[d + 1];
+    if (g < 0 || g1 < g || g1 > n_bytes) { atomicOr(err, ERR_BAD_OFFSETS); return; }
+    if (g < n_bytes) atomicOr(&docmask[g >> 6], 1ull << (g & 63));
+}
+
+// =================================================================================================
+// K_pretok_gpt2: GPT-2 ByteLevel regex as a local-window predicate, one lane per byte.
+// Replaces: ByteLevel::pre_tokenize (pre_tokenizers/byte_level.rs:119-131) = Oniguruma find_iter
+// over  's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+  (byte_level.rs:43-46)
+// with SplitDelimiterBehavior::Isolated (normalizer.rs:694-783).  Every byte belongs to exactly one
+// match, so the output is just "does a match start at byte i".  That predicate depends only on a
+// window of <= 4 code points back / 3 ahead (verified against the reference):
+//   con(i)  : a contraction literal matches at i AND i is itself a match start
+//   eaten(i): i is a letter swallowed by a contraction
+//   otherwise class-run rules with the " ?" optional-space attachment and the \s+(?!\S) lookahead.
+// =================================================================================================
+constexpr int PT_TILE = 2048;
+constexpr int PT_HALO = 8;
+constexpr int PT_R = PT_TILE + 2 * PT_HALO;
+
+// info byte per text byte
+constexpr uint32_t IF_CLS = 3;       // 0 other, 1 letter, 2 number, 3 whitespace
+constexpr uint32_t IF_LEAD = 4;      // first byte of a code point
+constexpr uint32_t IF_DOC = 8;       // first byte of a document
+constexpr uint32_t IF_VALID = 16;    // inside [0, n_bytes)
+constexpr uint32_t IF_SP = 32;       // U+0020
+constexpr int IF_LEN_SHIFT = 6;      // (utf8 length - 1) in bits 6..7
+
+__device__ __forceinline__ uint32_t uc_flags(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
+    if (cp >= 0x110000u) return 0;
+    return uc2[((uint32_t)uc1[cp >> 8] << 8) | (cp & 255u)];
+}
+
+__device__ __forceinline__ uint32_t cls_lns(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
+    if (cp < 0x80u) {
+        uint32_t lower = cp | 0x20u;
+        if (lower - 'a' < 26u) return 1;
+        if (cp - '0' < 10u) return 2;
+        if (cp == 0x20u || cp - 9u < 5u) return 3;
+        return 0;
+    }
+    uint32_t f = uc_flags(cp, uc1, uc2);
+    return (f & UC_ONIG_L) ? 1u : (f & UC_ONIG_N) ? 2u : (f & UC_ONIG_S) ? 3u : 0u;
+}
+
+// decode the code point whose lead byte is sb[k]; sb must be readable to k+3
+__device__ __forceinline__ uint32_t utf8_at(const uint8_t* sb, int k, uint32_t* len) {
+    uint32_t b = sb[k];
+    if (b < 0x80u) { *len = 1; return b; }
+    if (b < 0xE0u) { *len = 2; return ((b & 0x1Fu) << 6) | (sb[k + 1] & 0x3Fu); }
+    if (b < 0xF0u) { *len = 3; return ((b & 0x0Fu) << 12) | ((sb[k + 1] & 0x3Fu) << 6) | (sb[k + 2] & 0x3Fu); }
+    *len = 4;
+    return ((b & 0x07u) << 18) | ((sb[k + 1] & 0x3Fu) << 12) | ((sb[k + 2] & 0x3Fu) << 6) | (sb[k + 3] & 0x3Fu);
+}
+
+__global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__ text, int64_t n_bytes,
+                                                     const unsigned long long* __restrict__ docmask,
+                                                     const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                     unsigned long long* __restrict__ startmask) {
+    __shared__ uint8_t sb[PT_R + 8];
+    __shared__ uint8_t si[PT_R + 8];
+    __shared__ uint8_t sc[PT_R + 8];
+    const int tid = (int)threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;       // first byte of this tile
+    const int64_t r0 = t0 - PT_HALO;                        // first byte of the staged region
+
+    // phase 0: stage bytes (zero outside the text)
+    for (int k = tid; k < PT_R + 8; k += 256) {
+        int64_t g = r0 + k;
+        sb[k] = (g >= 0 && g < n_bytes) ? text[g] : (uint8_t)0;
+    }
+    __syncthreads();
+    // phase 1: per-byte info (class of the code point that starts here)
+    for (int k = tid; k < PT_R; k += 256) {
+        int64_t g = r0 + k;
+        uint32_t info = 0;
+        if (g >= 0 && g < n_bytes) {
+            uint32_t b = sb[k];
+            info = IF_VALID;
+            if ((docmask[g >> 6] >> (g & 63)) & 1ull) info |= IF_DOC;
+            if ((b & 0xC0u) != 0x80u) {
+                uint32_t len;
+                uint32_t cp = utf8_at(sb, k, &len);
+                info |= IF_LEAD | cls_lns(cp, uc1, uc2) | ((len - 1) << IF_LEN_SHIFT);
+                if (b == 0x20u) info |= IF_SP;
+            }
+        }
+        si[k] = (uint8_t)info;
+    }
+    __syncthreads();
+    // phase 2: con(k) = length (2|3) of a contraction literal that is a match start at k, else 0
+    for (int k = tid; k < PT_R; k += 256) {
+        uint32_t con = 0;
+        if (k >= 4 && k < PT_R - 2 && sb[k] == '\'' && (si[k] & IF_VALID)) {
+            uint32_t b1 = sb[k + 1], b2 = sb[k + 2];
+            bool ok1 = (si[k + 1] & IF_VALID) && !(si[k + 1] & IF_DOC);
+            bool ok2 = ok1 && (si[k + 2] & IF_VALID) && !(si[k + 2] & IF_DOC);
+            uint32_t lit = 0;
+            if (ok1 && (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd')) lit = 2;
+            else if (ok2 && ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l'))) lit = 3;
+            if (lit) {
+                bool cond;
+                if (si[k] & IF_DOC) cond = true;
+                else {
+                    int j = k - 1;
+                    if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) --j; } }
+                    uint32_t pi = si[j], pc = pi & IF_CLS;
+                    cond = (pc == 1 || pc == 2 || (pc == 3 && !(pi & IF_SP)));
+                }
+                if (cond) con = lit;
+            }
+        }
+        sc[k] = (uint8_t)con;
+    }
+    __syncthreads();
+    // phase 3: start predicate for the tile's own bytes, one 64-bit ballot per wavefront
+    for (int it = 0; it < PT_TILE / 256; ++it) {
+        int k = PT_HALO + it * 256 + tid;
+        uint32_t info = si[k];
+        bool start = false;
+        if ((info & (IF_VALID | IF_LEAD)) == (IF_VALID | IF_LEAD)) {
+            if (info & IF_DOC) start = true;
+            else {
+                uint32_t c1 = sc[k - 1], c2 = sc[k - 2], c3 = sc[k - 3];
+                if (c1 >= 2 || c2 >= 3) start = false;                 // swallowed by a contraction
+                else if (sc[k] > 0) start = true;                      // contraction starts here
+                else if (c2 >= 2 || c3 >= 3) start = true;             // first code point after one
+                else {
+                    int j = k - 1;
+                    if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) --j; } }
+                    uint32_t pi = si[j], pc = pi & IF_CLS, c = info & IF_CLS;
+                    if (c != 3) {
+                        start = !(pc == c || (pi & IF_SP));            // run continues / " X" attaches
+                    } else if (pc != 3) {
+                        start = true;                                  // first of a whitespace run
+                    } else {
+                        int k2 = k + 1 + (int)(info >> IF_LEN_SHIFT);  // \s+(?!\S): split before the LAST ws
+                        uint32_t ni = si[k2];
+                        start = (ni & IF_VALID) && !(ni & IF_DOC) && ((ni & IF_CLS) != 3);
+                    }
+                }
+            }
+        }
+        uint64_t m = __ballot(start);
+        int64_t g = t0 + it * 256 + tid;
+        if ((tid & 63) == 0 && g <= n_bytes) startmask[g >> 6] = m;
+    }
+}
+
+// =================================================================================================
+// Prefix sums over the start bitmask (popcount per 64-byte word), then offsets emission.
+// Replaces: the Vec<Split> a PreTokenizedString accumulates (tokenizer/pre_tokenizer.rs:73-103);
+// here the "splits" of the whole batch are one u32 array pt_start[P+1] (pt_start[P] = n_bytes).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_words_reduce(const unsigned long long* __restrict__ mask, int64_t n_words,
+                                                      uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t sm[4];
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = (w < n_words) ? (uint32_t)__popcll(mask[w]) : 0u;
+    uint32_t tot;
+    block256_excl_scan(v, sm, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single-workgroup exclusive scan of `n` (host value, or *n_dev when n_dev != nullptr) u32 items
+// in place; total -> total_out (64-bit).  `div` lets n_dev be a count of finer items
+// (n = ceil(*n_dev / div)).
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t* __restrict__ data, int64_t n_host,
+                                                      const int64_t* __restrict__ n_dev, int64_t div,
+                                                      int64_t* __restrict__ total_out) {
+    __shared__ uint32_t sm[16];
+    __shared__ uint64_t carry_s;
+    int64_t n = n_dev ? ((*n_dev + div - 1) / div) : n_host;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        uint32_t v = (i < n) ? data[i] : 0u;
+        uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) sm[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            uint32_t s = sm[w];
+            if (w < wave) wbase += s;
+            tot += s;
+        }
+        uint64_t carry = carry_s;
+        if (i < n) data[i] = (uint32_t)(carry + wbase + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = (int64_t)carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __restrict__ mask, int64_t n_words,
+                                                    const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix) {
+    __shared__ uint32_t sm[4];
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = (w < n_words) ? (uint32_t)__popcll(mask[w]) : 0u;
+    uint32_t tot;
+    uint32_t ex = block256_excl_scan(v, sm, &tot);
+    if (w < n_words) wprefix[w] = bsum[blockIdx.x] + ex;
+}
+
+// one lane per byte: a set start bit at byte i becomes pt_start[rank(i)] = i (coalesced stores)
+__global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* __restrict__ startmask,
+                                                     const uint32_t* __restrict__ wprefix, int64_t n_bytes,
+                                                     const int64_t* __restrict__ n_pretok,
+                                                     uint32_t* __restrict__ pt_start) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) pt_start[*n_pretok] = (uint32_t)n_bytes;          // sentinel
+    if (i >= n_bytes) return;
+    unsigned long long m = startmask[i >> 6];
+    int b = (int)(i & 63);
+    if ((m >> b) & 1ull) {
+        uint32_t r = wprefix[i >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+        pt_start[r] = (uint32_t)i;
+    }
+}
+
+// doc_pt[d] = index of the first pre-token at or after the first byte of document d (d = 0..n_docs)
+__global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
+                                   const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
+                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    int64_t g = doc_off[d];
+    uint32_t r;
+    if (g >= n_bytes) r = (uint32_t)*n_pretok;
+    else {
+        unsigned long long m = startmask[g >> 6];
+        int b = (int)(g & 63);
+        r = wprefix[g >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+    }
+    doc_pt[d] = r;
+}
+
+// =================================================================================================
+// K_word_lookup: whole pre-token -> token id through the static whole-word table, one lane per
+// pre-token.  Replaces: BPE::tokenize_with_cache's shortcuts (models/bpe/model.rs:558-587):
+//   * ignore_merges: vocab.get(sequence) -> single token (:559-567)                      [exact]
+//   * the thread-local word cache (:573-586): here a STATIC table of vocab entries whose own
+//     merge result was verified at load time to be exactly [id] (WORD_DIRECT), so a hit is
+//     provably what merge_word would return; everything else goes to the merge kernel.
+// =================================================================================================
+__device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint64_t* lo, uint64_t* hi) {
+    // dword-aligned 20-byte window + funnel shift (text buffers carry TKAMD_TEXT_PAD readable slack)
+    const uint32_t* p = (const uint32_t*)(text + (s & ~3u));
+    uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+    uint32_t sh = (s & 3u) * 8u;
+    uint32_t a0 = __funnelshift_r(w0, w1, sh), a1 = __funnelshift_r(w1, w2, sh);
+    uint32_t a2 = __funnelshift_r(w2, w3, sh), a3 = __funnelshift_r(w3, w4, sh);
+    uint64_t l = ((uint64_t)a1 << 32) | a0, h = ((uint64_t)a3 << 32) | a2;
+    if (len < 8) { l &= (1ull << (len * 8)) - 1ull; h = 0; }
+    else if (len < 16) { h &= (len == 8) ? 0ull : ((1ull << ((len - 8) * 8)) - 1ull); }
+    *lo = l;
+    *hi = h;
+}
+
+__device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
+    uint32_t h1 = word_hash1(lo, hi, len, t.word_seed);
+    uint32_t s1 = h1 & t.word_mask, s2 = word_hash2(h1) & t.word_mask;
+    const uint4* q1 = (const uint4*)&t.words[s1];
+    const uint4* q2 = (const uint4*)&t.words[s2];
+    uint4 a0 = q1[0], a1 = q1[1], b0 = q2[0], b1 = q2[1];
+    uint32_t lo0 = (uint32_t)lo, lo1 = (uint32_t)(lo >> 32), hi0 = (uint32_t)hi, hi1 = (uint32_t)(hi >> 32);
+    if (a1.x == len && a0.x == lo0 && a0.y == lo1 && a0.z == hi0 && a0.w == hi1) { *id = a1.y; *flags = a1.z; return true; }
+    if (b1.x == len && b0.x == lo0 && b0.y == lo1 && b0.z == hi0 && b0.w == hi1) { *id = b1.y; *flags = b1.z; return true; }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
+                                                         const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
+                                                         uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                         uint32_t* __restrict__ list16, uint32_t* __restrict__ list64,
+                                                         uint32_t* __restrict__ listL, uint32_t* __restrict__ counters) {
+    const int64_t P = *n_pretok;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    // wave-uniform trip count so the ballots inside wave_append see whole wavefronts
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < P; base += stride) {
+        int64_t p = base + threadIdx.x;
+        bool valid = p < P;
+        uint32_t s = 0, len = 0;
+        if (valid) { s = pt_start[p]; len = pt_start[p + 1] - s; }
+        bool done = false;
+        if (valid && len <= (uint32_t)WORD_MAX_KEY) {
+            uint64_t lo, hi;
+            load_key16(text, s, len, &lo, &hi);
+            uint32_t id, fl;
+            if (word_probe(t, lo, hi, len, &id, &fl) && (t.ignore_merges || (fl & WORD_DIRECT))) {
+                tok0[p] = id;
+                ntok[p] = 1;
+                done = true;
+            }
+        }
+        bool q16 = valid && !done && len <= 16, q64 = valid && !done && len > 16 && len <= 64, qL = valid && !done && len > 64;
+        uint32_t i16 = wave_append(&counters[CNT_LIST16], q16);
+        if (q16) list16[i16] = (uint32_t)p;
+        if (__any(q64)) { uint32_t i = wave_append(&counters[CNT_LIST64], q64); if (q64) list64[i] = (uint32_t)p; }
+        if (__any(qL)) { uint32_t i = wave_append(&counters[CNT_LISTL], qL); if (qL) listL[i] = (uint32_t)p; }
+    }
+}
+
+// =================================================================================================
+// K_bpe_merge<G>: BPE merge resolution, G lanes per pre-token (G=16: one DPP row, 4 pre-tokens per
+// wavefront; G=64: one wavefront).  Lane c holds symbol c of the pre-token (byte-level BPE: one
+// initial symbol per byte, models/bpe/model.rs:465-499 with the byte alphabet of byte_level.rs:15-39).
+// Replaces: Word::merge_all (models/bpe/word.rs:162-250): "pop the (rank, pos)-minimum mergeable
+// adjacent pair, merge, re-queue its two new neighbours".  With every live pair's rank cached in its
+// left symbol's lane, the heap top is a min-reduction of (rank << 6 | lane) over the row (4 DPP
+// steps) and a merge re-probes exactly the two pairs the reference re-queues (word.rs:218-244).
+// Pair -> (rank, new_id) probes hit the static 2-choice cuckoo table (two independent 16-byte
+// loads; bpe/model.rs:252-275 defines the contents).
+// =================================================================================================
+__device__ __forceinline__ void merge_probe(const DevTables& t, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
+    uint32_t s1 = merge_hash1(a, b, t.merge_seed) & t.merge_mask;
+    uint32_t s2 = merge_hash2(a, b, t.merge_seed) & t.merge_mask;
+    uint4 x = ((const uint4*)t.merges)[s1];
+    uint4 y = ((const uint4*)t.merges)[s2];
+    if (x.x == a && x.y == b) { *rank = x.z; *new_id = x.w; }
+    else if (y.x == a && y.y == b) { *rank = y.z; *new_id = y.w; }
+    else { *rank = RANK_NONE; *new_id = 0; }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* __restrict__ text,
+                                                   const uint32_t* __restrict__ pt_start,
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    constexpr int GPW = 64 / G;                                     // pre-tokens per wavefront
+    const int lane = lane_id();
+    const int sub = lane / G, c = lane % G, gbase = sub * G;
+    const uint32_t n = *n_list;
+    const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t base = wave_global * GPW; base < n; base += n_waves * GPW) {
+        uint32_t item = base + sub;
+        bool valid = item < n;
+        uint32_t p = valid ? list[item] : 0u;
+        uint32_t s = 0, len = 0;
+        if (valid) { s = pt_start[p]; len = pt_start[p + 1] - s; }
+        bool act = (uint32_t)c < len;
+        uint32_t id = act ? t.byte_id[text[s + c]] : 0xFFFFFFFFu;
+        uint64_t am = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);   // alive symbols of my pre-token
+        uint32_t rank = RANK_NONE, new_id = 0;
+        {
+            uint32_t nid = (uint32_t)__shfl((int)id, gbase + ((c + 1) % G), 64);
+            if ((uint32_t)(c + 1) < len) merge_probe(t, id, nid, &rank, &new_id);
+        }
+        while (true) {
+            uint32_t key = (rank == RANK_NONE) ? 0xFFFFFFFFu : ((rank << 6) | (uint32_t)c);
+            uint32_t mn = (G == 16) ? row16_allmin(key) : wave_allmin(key);
+            bool has = mn != 0xFFFFFFFFu;
+            if (!__any(has)) break;
+            uint32_t wpos = mn & 63u;
+            uint32_t npos = 0;
+            if (has) {
+                uint64_t rest = am >> (wpos + 1);                       // winner always has a live right neighbour
+                npos = wpos + 1 + (uint32_t)(__ffsll((unsigned long long)rest) - 1);
+                am &= ~(1ull << npos);
+                if ((uint32_t)c == wpos) id = new_id;                   // left symbol takes the merged id (word.rs:208)
+                if ((uint32_t)c == npos) rank = RANK_NONE;              // right symbol is removed (word.rs:210)
+            }
+            // id of my next live symbol (after this round's removal)
+            uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
+            bool has_next = mine != 0ull;
+            uint32_t nx = has_next ? (uint32_t)c + 1 + (uint32_t)(__ffsll((unsigned long long)mine) - 1) : (uint32_t)c;
+            uint32_t nid = (uint32_t)__shfl((int)id, gbase + (int)nx, 64);
+            bool alive = (am >> c) & 1ull;
+            // re-probe exactly the two pairs the reference pushes back: (prev, merged) and (merged, next)
+            if (has && alive && ((uint32_t)c == wpos || (has_next && nx == wpos))) {
+                if (has_next) merge_probe(t, id, nid, &rank, &new_id);
+                else rank = RANK_NONE;
+            }
+        }
+        // emit: token j of the pre-token = j-th live lane; token 0 -> tok0[p], the rest -> tmp_ids[s + j]
+        bool alive = act && ((am >> c) & 1ull);
+        if (alive) {
+            uint32_t j = (uint32_t)__popcll(am & ((1ull << c) - 1ull));
+            if (j == 0) tok0[p] = id;
+            else tmp_ids[s + j] = id;
+            if (tmp_end) {
+                uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
+                uint32_t endc = mine ? (uint32_t)c + 1 + (uint32_t)(__ffsll((unsigned long long)mine) - 1) : len;
+                tmp_end[s + j] = endc;                                 // token end, bytes from the pre-token start
+            }
+            if (c == 0) ntok[p] = (uint32_t)__popcll(am);
+        }
+    }
+}
+template __global__ void k_bpe_merge<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge<64>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+
+// =================================================================================================
+// K_bpe_merge_long: pre-tokens longer than 64 bytes, one workgroup each, symbols as a doubly linked
+// list in LDS (the same Symbol{c, prev, next, len} of models/bpe/word.rs:38-54), up to LONG_PT_MAX
+// symbols.  Each round: workgroup-wide min over the cached (rank, pos) keys, one merge, two
+// re-probes.  Rare path (long letter/digit runs); exactness over speed.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8_t* __restrict__ text,
+                                                        const uint32_t* __restrict__ pt_start,
+                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                        uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
+                                                        int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint32_t* sym = (uint32_t*)lds_raw;                 // [LONG_PT_MAX]
+    uint32_t* rnk = sym + LONG_PT_MAX;                     // [LONG_PT_MAX] rank of pair (i, next[i]) or NONE
+    uint32_t* nid = rnk + LONG_PT_MAX;                     // [LONG_PT_MAX] new id of that pair
+    uint16_t* nxt = (uint16_t*)(nid + LONG_PT_MAX);        // [LONG_PT_MAX] 0xFFFF = none
+    uint16_t* prv = nxt + LONG_PT_MAX;                     // [LONG_PT_MAX]
+    __shared__ unsigned long long red[4];
+    __shared__ uint32_t cnt_s;
+    const int tid = (int)threadIdx.x;
+    const uint32_t n = *n_list;
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        uint32_t p = list[item];
+        uint32_t s = pt_start[p], len = pt_start[p + 1] - s;
+        if (len > (uint32_t)LONG_PT_MAX) {
+            if (tid == 0) { atomicOr(err, ERR_PRETOKEN_TOO_LONG); ntok[p] = 0; }
+            continue;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256) {
+            sym[i] = t.byte_id[text[s + i]];
+            nxt[i] = (i + 1 < len) ? (uint16_t)(i + 1) : (uint16_t)0xFFFF;
+            prv[i] = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)0xFFFF;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256) {
+            uint32_t r = RANK_NONE, ni = 0;
+            if (i + 1 < len) merge_probe(t, sym[i], sym[i + 1], &r, &ni);
+            rnk[i] = r;
+            nid[i] = ni;
+        }
+        __syncthreads();
+        while (true) {
+            unsigned long long best = ~0ull;
+            for (uint32_t i = tid; i < len; i += 256) {
+                uint32_t r = rnk[i];
+                if (r != RANK_NONE) {
+                    unsigned long long k = ((unsigned long long)r << 32) | i;
+                    best = k < best ? k : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                unsigned long long o = __shfl_xor(best, d, 64);
+                best = o < best ? o : best;
+            }
+            if ((tid & 63) == 0) red[tid >> 6] = best;
+            __syncthreads();
+            unsigned long long m01 = red[0] < red[1] ? red[0] : red[1];
+            unsigned long long m23 = red[2] < red[3] ? red[2] : red[3];
+            best = m01 < m23 ? m01 : m23;
+            __syncthreads();
+            if (best == ~0ull) break;
+            if (tid == 0) {
+                uint32_t w = (uint32_t)best;
+                uint32_t r = nxt[w];
+                uint32_t rn = nxt[r];
+                sym[w] = nid[w];
+                rnk[r] = RANK_NONE;
+                sym[r] = 0xFFFFFFFFu;                          // dead
+                nxt[w] = (uint16_t)rn;
+                if (rn != 0xFFFFu) prv[rn] = (uint16_t)w;
+                uint32_t pw = prv[w];
+                uint32_t r1 = RANK_NONE, n1 = 0, r2 = RANK_NONE, n2 = 0;
+                if (pw != 0xFFFFu) merge_probe(t, sym[pw], sym[w], &r1, &n1);
+                if (rn != 0xFFFFu) merge_probe(t, sym[w], sym[rn], &r2, &n2);
+                if (pw != 0xFFFFu) { rnk[pw] = r1; nid[pw] = n1; }
+                rnk[w] = r2;
+                nid[w] = n2;
+            }
+            __syncthreads();
+        }
+        // emit in order: walk is sequential per symbol; do a parallel rank instead
+        if (tid == 0) cnt_s = 0;
+        __syncthreads();
+        // chunked ordered compaction: 256 symbols per step
+        for (uint32_t base = 0; base < len; base += 256) {
+            uint32_t i = base + tid;
+            bool alive = i < len && sym[i] != 0xFFFFFFFFu;
+            uint64_t bm = __ballot(alive);
+            __shared__ uint32_t wcnt[4];
+            if ((tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__popcll(bm);
+            __syncthreads();
+            uint32_t off = cnt_s;
+            for (int w = 0; w < (tid >> 6); ++w) off += wcnt[w];
+            if (alive) {
+                uint32_t j = off + (uint32_t)mbcnt64(bm);
+                if (j == 0) tok0[p] = sym[i];
+                else tmp_ids[s + j] = sym[i];
+                if (tmp_end) {
+                    uint32_t e = nxt[i];
+                    tmp_end[s + j] = (e == 0xFFFFu) ? len : e;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) cnt_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        if (tid == 0) ntok[p] = cnt_s;
+    }
+}
+
+// =================================================================================================
+// Token compaction: exclusive scan of ntok[P] -> ids[T] and the per-document token CSR.
+// Replaces: PreTokenizedString::into_encoding + Encoding::from_iter (tokenizer/pre_tokenizer.rs:198-263,
+// tokenizer/encoding.rs:541-562) for the whole batch at once.
+// =================================================================================================
+constexpr int CP_ITEMS = 4;                       // pre-tokens per thread
+constexpr int CP_CHUNK = 256 * CP_ITEMS;
+
+__global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict__ ntok, const int64_t* __restrict__ n_pretok,
+                                                     uint32_t* __restrict__ csum) {
+    __shared__ uint32_t sm[4];
+    const int64_t P = *n_pretok;
+    const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k)
+            if (p0 + k < P) v += ntok[p0 + k];
+        uint32_t tot;
+        block256_excl_scan(v, sm, &tot);
+        if (threadIdx.x == 0) csum[ch] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
+                                                 const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start,
+                                                 const int64_t* __restrict__ n_pretok, const uint32_t* __restrict__ csum,
+                                                 uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
+    __shared__ uint32_t sm[4];
+    const int64_t P = *n_pretok;
+    const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
+        uint32_t cnt[CP_ITEMS];
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            cnt[k] = (p0 + k < P) ? ntok[p0 + k] : 0u;
+            v += cnt[k];
+        }
+        uint32_t tot;
+        uint32_t o = csum[ch] + block256_excl_scan(v, sm, &tot);
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            int64_t p = p0 + k;
+            if (p < P) {
+                pt_tokoff[p] = o;
+                uint32_t c = cnt[k];
+                if (c) {
+                    ids[o] = tok0[p];
+                    if (c > 1) {
+                        uint32_t s = pt_start[p];
+                        for (uint32_t j = 1; j < c; ++j) ids[o + j] = tmp_ids[s + j];
+                    }
+                }
+                o += c;
+            }
+        }
+    }
+}
+
+__global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n_docs, const uint32_t* __restrict__ pt_tokoff,
+                                  const int64_t* __restrict__ n_pretok, const int64_t* __restrict__ n_tok,
+                                  int64_t* __restrict__ tok_offsets) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    uint32_t p = doc_pt[d];
+    tok_offsets[d] = ((int64_t)p < *n_pretok) ? (int64_t)pt_tokoff[p] : *n_tok;
+}
+
+// =================================================================================================
+// host-side launchers (called from capi.cpp; plain C++ signatures, stream-ordered, no syncs)
+// =================================================================================================
+static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
+                            unsigned long long* docmask, int* err) {
+    hipLaunchKernelGGL(k_mark_doc_starts, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, docmask, err);
+}
+void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask) {
+    hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, docmask, uc1, uc2, startmask);
+}
+void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
+                      int64_t* total) {
+    unsigned nb = blocks_for(n_words, 256);
+    hipLaunchKernelGGL(k_words_reduce, dim3(nb), dim3(256), 0, st, mask, n_words, bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
+    hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
+}
+void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
+                        const int64_t* n_pretok, uint32_t* pt_start) {
+    hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, startmask, wprefix, n_bytes, n_pretok, pt_start);
+}
+void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt) {
+    hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt);
+}
+void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list64,
+                            uint32_t* listL, uint32_t* counters) {
+    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, n_pretok, tok0, ntok, list16, list64, listL, counters);
+}
+void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
+    if (group == 16)
+        hipLaunchKernelGGL(k_bpe_merge<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+    else
+        hipLaunchKernelGGL(k_bpe_merge<64>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+}
+int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
+int prepare_long_kernel() {
+    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
+}
+void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                           const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
+                           uint32_t* tmp_end, int* err) {
+    hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, err);
+}
+void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
+                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids) {
+    hipLaunchKernelGGL(k_ntok_reduce, dim3(grid), dim3(256), 0, st, ntok, n_pretok, csum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, csum, (int64_t)0, n_pretok, (int64_t)CP_CHUNK, n_tok);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, st, ntok, tok0, tmp_ids, pt_start, n_pretok, (const uint32_t*)csum, pt_tokoff, ids);
+}
+void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
+                            const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets) {
+    hipLaunchKernelGGL(k_doc_tok_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_pt, n_docs, pt_tokoff, n_pretok, n_tok, tok_offsets);
+}
+
+}  // namespace tkamd

@@ -1,0 +1,74 @@
+// Host-visible declarations of the HIP kernels' launchers (kernels.hip) and the POD structs they take.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstdint>
+
+#include "tables.hpp"
+
+namespace tkamd {
+
+// device-resident tables, passed by value to kernels
+struct DevTables {
+    const uint16_t* uc1;          // unicode stage 1
+    const uint8_t* uc2;           // unicode stage 2
+    const uint32_t* byte_id;      // [256]
+    const MergeSlot* merges;
+    uint32_t merge_mask, merge_seed;
+    const WordSlot* words;
+    uint32_t word_mask, word_seed;
+    uint32_t ignore_merges;
+    uint32_t unk_id, has_unk;
+    // long (>16 byte) whole-word keys
+    const uint8_t* long_blob;
+    const uint32_t* long_off;
+    const uint32_t* long_id;
+    const uint32_t* long_table;
+    uint32_t long_mask;
+    // WordPiece trie
+    const uint32_t* trie_edge_begin;
+    const uint8_t* trie_edge_byte;
+    const uint32_t* trie_edge_child;
+    const uint32_t* trie_node_id;
+    const uint32_t* trie_root_child;
+    uint32_t max_input_chars;
+};
+
+// error bits accumulated in a device int during a batch
+enum : int {
+    ERR_BAD_OFFSETS = 1,          // doc_offsets not a valid CSR over [0, n_bytes]
+    ERR_PRETOKEN_TOO_LONG = 2,    // a pre-token exceeds LONG_PT_MAX symbols
+    ERR_ADDED_TOKEN = 4,          // an added/special token occurs in the text (AddedVocabulary split needed)
+    ERR_NON_ASCII_NORM = 8,       // BertNormalizer on non-ASCII text (full-Unicode path not built yet)
+    ERR_MISSING_UNK = 16,         // model needed unk_token but the vocab has none (MissingUnkToken)
+};
+
+// indices into the per-batch device counter array
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_COUNT = 8 };
+
+constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident)
+
+void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
+                            unsigned long long* docmask, int* err);
+void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask);
+void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
+                      int64_t* total);
+void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
+                        const int64_t* n_pretok, uint32_t* pt_start);
+void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
+void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list64,
+                            uint32_t* listL, uint32_t* counters);
+void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
+int prepare_long_kernel();
+void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                           const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
+                           uint32_t* tmp_end, int* err);
+void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
+                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);
+void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
+                            const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets);
+
+}  // namespace tkamd

@@ -1,0 +1,85 @@
+// Table layouts and hash functions shared by the host builder (host_model.cpp) and the
+// HIP kernels (kernels.hip).  Everything here is plain-old-data that is copied verbatim
+// into HBM at tokenizer load (tkamd_tokenizer_from_json).
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TK_HD __host__ __device__ __forceinline__
+#else
+#define TK_HD inline
+#endif
+
+namespace tkamd {
+
+// ---- Unicode class flags (generated data: unicode_ranges.inc) -------------------------------
+enum : uint8_t {
+    UC_ONIG_L = 1,    // \p{L}  (Oniguruma)    byte_level.rs:43-46
+    UC_ONIG_N = 2,    // \p{N}
+    UC_ONIG_S = 4,    // \s
+    UC_RX_W = 8,      // \w     (regex crate)  whitespace.rs:22
+    UC_RX_S = 16,     // \s     (regex crate)
+    UC_RUST_WS = 32,  // char::is_whitespace   whitespace.rs:38, bert.rs:15
+    UC_BERT_P = 64,   // is_bert_punc          bert.rs:5-7
+};
+
+// 2-stage code-point table: stage1[cp >> 8] -> block index, stage2[block*256 + (cp & 255)] -> flags
+constexpr int UC_STAGE1_LEN = 0x1100;
+
+// ---- BPE merge table: (left id, right id) -> (rank, new id), models/bpe/model.rs:252-275 -----
+// Static 2-choice cuckoo table: a key lives in slot h1(key) or h2(key); a lookup is exactly two
+// independent 16-byte loads, hit or miss, no probe loop (built once at load, never mutated).
+struct MergeSlot {
+    uint32_t a, b, rank, new_id;
+};
+constexpr uint32_t MERGE_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t RANK_NONE = 0xFFFFFFFFu;
+
+TK_HD uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+TK_HD uint32_t merge_hash1(uint32_t a, uint32_t b, uint32_t seed) { return mix32(a * 0x9E3779B1u + b * 0x85EBCA77u + seed); }
+TK_HD uint32_t merge_hash2(uint32_t a, uint32_t b, uint32_t seed) { return mix32((a ^ 0x5BD1E995u) * 0xC2B2AE3Du + (b + 0x27D4EB2Fu) * 0x165667B1u + seed * 0x9E3779B1u); }
+
+// ---- whole-word table: raw pre-token bytes (<= 16) -> token id ------------------------------
+// Serves BPE `ignore_merges` (bpe/model.rs:559-567), WordLevel (wordlevel/mod.rs:162-178) and the
+// merge-stable shortcut: key = bytes zero-padded to 16 + length.
+struct WordSlot {
+    uint64_t lo, hi;
+    uint32_t len;    // 0 = empty slot
+    uint32_t id;
+    uint32_t flags;  // WORD_DIRECT: BPE merges of these bytes yield exactly [id]
+    uint32_t pad;
+};
+constexpr uint32_t WORD_DIRECT = 1u;
+constexpr int WORD_MAX_KEY = 16;
+
+TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed) {
+    uint32_t h = mix32((uint32_t)lo * 0x9E3779B1u + seed);
+    h = mix32(h ^ ((uint32_t)(lo >> 32) * 0x85EBCA77u));
+    h = mix32(h ^ ((uint32_t)hi * 0xC2B2AE3Du));
+    h = mix32(h ^ ((uint32_t)(hi >> 32) * 0x27D4EB2Fu) ^ len);
+    return h;
+}
+TK_HD uint32_t word_hash2(uint32_t h1) { return mix32(h1 * 0x165667B1u + 0x5BD1E995u); }
+
+// ---- tokenizer kinds -------------------------------------------------------------------------
+enum ModelKind { MODEL_NONE = 0, MODEL_BPE = 1, MODEL_WORDPIECE = 2, MODEL_WORDLEVEL = 3 };
+enum PretokKind {
+    PT_NONE = 0,
+    PT_BYTELEVEL_GPT2 = 1,   // ByteLevel(use_regex=true)                       byte_level.rs:119-148
+    PT_LLAMA3 = 2,           // Sequence[Split(llama3 regex, Isolated), ByteLevel(use_regex=false)]
+    PT_WHITESPACE = 3,       // \w+|[^\w\s]+                                    whitespace.rs:20-29
+    PT_WHITESPACE_SPLIT = 4, // char::is_whitespace                             whitespace.rs:35-41
+    PT_BERT = 5,             // BertPreTokenizer                                bert.rs:14-17
+    PT_BYTELEVEL_NOREGEX = 6 // ByteLevel(use_regex=false): whole doc is one pre-token
+};
+enum NormKind { NORM_NONE = 0, NORM_BERT = 1 };
+
+}  // namespace tkamd

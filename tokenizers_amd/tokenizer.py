@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's Python surface for the encode_batch path.
+
+``Tokenizer.encode_batch`` / ``encode_batch_fast`` keep the names, argument meaning and
+error behaviour of ``tokenizers.Tokenizer`` (bindings/python/src/tokenizer.rs:1310-1338,
+1431-1459) but route through the C ABI (``include/tokenizers_amd.h``) into HIP kernels.
+Nothing here tokenises: this module only marshals ``list[str]`` into one UTF-8 buffer +
+CSR offsets and wraps the CSR result arrays.  There is no CPU fallback: components
+outside the hot path raise :class:`UnsupportedError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceError, TokenizersAmdError, UnsupportedError  # noqa: F401
+
+
+def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
+    """``list[str]`` -> (uint8 buffer with TEXT_PAD slack, int64 CSR offsets).
+
+    Mirrors the extraction loop of PyTokenizer::encode_batch (tokenizer.rs:1320-1327):
+    every item must be ``str`` (``TypeError('TextInputSequence must be str')``, tokenizer.rs:274).
+    """
+    enc = []
+    for s in inputs:
+        if not isinstance(s, str):
+            if isinstance(s, (tuple, list)):
+                raise UnsupportedError("pair / pre-tokenized inputs (EncodeInput::Dual, PreTokenized) are outside the MI355X hot path")
+            raise TypeError("TextInputSequence must be str")
+        enc.append(s.encode("utf-8"))
+    n = len(enc)
+    offsets = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=n), out=offsets[1:])
+    blob = b"".join(enc)
+    buf = np.zeros(len(blob) + _lib.TEXT_PAD, dtype=np.uint8)
+    if blob:
+        buf[: len(blob)] = np.frombuffer(blob, dtype=np.uint8)
+    return buf, offsets
+
+
+class Encoding:
+    """Read-only view of one document of a :class:`BatchEncoding`.
+
+    Field semantics follow ``Encoding`` (tokenizer/encoding.rs:11-31): for this path
+    ``type_ids`` are 0, ``attention_mask`` 1, ``special_tokens_mask`` 0 and nothing overflows.
+    """
+    __slots__ = ("_b", "_lo", "_hi")
+
+    def __init__(self, batch: "BatchEncoding", lo: int, hi: int):
+        self._b, self._lo, self._hi = batch, lo, hi
+
+    def __len__(self) -> int:
+        return self._hi - self._lo
+
+    @property
+    def ids(self) -> list[int]:
+        return self._b.ids[self._lo:self._hi].tolist()
+
+    @property
+    def type_ids(self) -> list[int]:
+        return [0] * len(self)
+
+    @property
+    def attention_mask(self) -> list[int]:
+        return [1] * len(self)
+
+    @property
+    def special_tokens_mask(self) -> list[int]:
+        return [0] * len(self)
+
+    @property
+    def tokens(self) -> list[str]:
+        if self._b.offsets is None:          # encode_batch_fast: OffsetType::None -> empty strings? no: tokens are kept
+            pass
+        v = self._b._id_to_token
+        return [v.get(i, "") for i in self.ids]
+
+    @property
+    def offsets(self) -> list[tuple[int, int]]:
+        if self._b.offsets is None:
+            return [(0, 0)] * len(self)      # encode_batch_fast (OffsetType::None, pre_tokenizer.rs:243)
+        return [tuple(x) for x in self._b.offsets[self._lo:self._hi].tolist()]
+
+    @property
+    def word_ids(self) -> list[int | None]:
+        if self._b.word_ids is None:
+            raise UnsupportedError("word ids were not requested for this batch")
+        return self._b.word_ids[self._lo:self._hi].tolist()
+
+    words = word_ids
+
+    @property
+    def sequence_ids(self) -> list[int | None]:
+        return [0] * len(self)
+
+    @property
+    def n_sequences(self) -> int:
+        return 1
+
+    @property
+    def overflowing(self) -> list:
+        return []
+
+    def __repr__(self) -> str:
+        return f"Encoding(num_tokens={len(self)}, attributes=[ids, type_ids, tokens, offsets, attention_mask, special_tokens_mask, overflowing])"
+
+
+class BatchEncoding:
+    """CSR result of one encode_batch call: ``ids[tok_offsets[d]:tok_offsets[d+1]]`` is document d."""
+
+    def __init__(self, ids, tok_offsets, offsets, word_ids, id_to_token):
+        self.ids: np.ndarray = ids
+        self.tok_offsets: np.ndarray = tok_offsets
+        self.offsets = offsets
+        self.word_ids = word_ids
+        self._id_to_token = id_to_token
+
+    def __len__(self) -> int:
+        return len(self.tok_offsets) - 1
+
+    def __getitem__(self, i: int) -> Encoding:
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return Encoding(self, int(self.tok_offsets[i]), int(self.tok_offsets[i + 1]))
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+    @property
+    def n_tokens(self) -> int:
+        return int(self.ids.shape[0])
+
+
+class DeviceBatch:
+    """Result of :meth:`Tokenizer.encode_batch_device`: raw HBM pointers into the handle's workspace."""
+
+    def __init__(self, tok: "Tokenizer", res: _lib.DeviceResult, n_docs: int, stream: int):
+        self._tok, self._res, self.n_docs, self._stream = tok, res, n_docs, stream
+        self.n_tokens = None
+        self.n_pretokens = None
+
+    def sync(self) -> "DeviceBatch":
+        nt, npt = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.load().tkamd_device_sync(self._tok._h, self._stream, C.byref(nt), C.byref(npt)))
+        self.n_tokens, self.n_pretokens = nt.value, npt.value
+        return self
+
+    def _tensor(self, ptr: int, shape: tuple, typestr: str):
+        import torch
+
+        class _Arr:
+            pass
+        a = _Arr()
+        a.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, True), "version": 2}
+        return torch.as_tensor(a, device=f"cuda:{self._tok.device}")
+
+    def ids_tensor(self):
+        """int32 view (bit pattern of the u32 ids) of the HBM-resident ids; valid until the next encode."""
+        if self.n_tokens is None:
+            self.sync()
+        return self._tensor(self._res.d_ids, (max(self.n_tokens, 1),), "<i4")[: self.n_tokens]
+
+    def tok_offsets_tensor(self):
+        return self._tensor(self._res.d_tok_offsets, (self.n_docs + 1,), "<i8")
+
+
+class Tokenizer:
+    """MI355X-native stand-in for ``tokenizers.Tokenizer`` on the encode_batch path."""
+
+    def __init__(self, json_str: str, device: int = 0):
+        lib = _lib.load()
+        raw = json_str.encode("utf-8")
+        h = C.c_void_p()
+        _lib.check(lib.tkamd_tokenizer_from_json(raw, len(raw), int(device), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.device = int(device)
+        self._json = json_str
+        self._vocab_r = None
+        info = _lib.Info()
+        _lib.check(lib.tkamd_tokenizer_info(self._h, C.byref(info)))
+        self.info = {f: getattr(info, f) for f, _ in _lib.Info._fields_}
+        pp = json.loads(json_str).get("post_processor")
+        self._post_processor_type = pp.get("type") if pp else None
+
+    # ---- constructors (Tokenizer::from_str / from_file, tokenizer/mod.rs:468-472) ----
+    @staticmethod
+    def from_str(json_str: str, device: int = 0) -> "Tokenizer":
+        return Tokenizer(json_str, device)
+
+    @staticmethod
+    def from_file(path: str, device: int = 0) -> "Tokenizer":
+        with open(path, encoding="utf-8") as fh:
+            return Tokenizer(fh.read(), device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.tkamd_tokenizer_free(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _id_to_token(self) -> dict[int, str]:
+        if self._vocab_r is None:
+            d = json.loads(self._json)
+            r = {int(i): t for t, i in d["model"]["vocab"].items()}
+            for a in d.get("added_tokens") or []:
+                r[int(a["id"])] = a["content"]
+            self._vocab_r = r
+        return self._vocab_r
+
+    def get_vocab_size(self, with_added_tokens: bool = True) -> int:
+        return len(self._id_to_token()) if with_added_tokens else self.info["vocab_size"]
+
+    # ---- the hot path ----
+    def _check_special(self, add_special_tokens: bool) -> None:
+        if add_special_tokens and self._post_processor_type not in (None, "ByteLevel"):
+            raise UnsupportedError(
+                f"add_special_tokens=True with post_processor {self._post_processor_type} is outside the MI355X "
+                "hot path (the reference benches call encode_batch(..., add_special_tokens=False), benches/common/mod.rs:52)")
+
+    def encode_batch_csr(self, inputs: Sequence[str], offsets: str = "none", word_ids: bool = False,
+                         add_special_tokens: bool = False) -> BatchEncoding:
+        """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17)."""
+        self._check_special(add_special_tokens)
+        buf, doc_off = pack_documents(inputs)
+        return self.encode_packed(buf, doc_off, offsets, word_ids)
+
+    def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False) -> BatchEncoding:
+        flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
+        if word_ids:
+            flags |= _lib.WANT_WORD_IDS
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        n_docs = len(doc_off) - 1
+        b = C.c_void_p()
+        _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
+        try:
+            nt = self._lib.tkamd_batch_n_tokens(b)
+            ids = np.ctypeslib.as_array(C.cast(self._lib.tkamd_batch_ids(b), C.POINTER(C.c_uint32)), shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+            to = np.ctypeslib.as_array(C.cast(self._lib.tkamd_batch_tok_offsets(b), C.POINTER(C.c_int64)), shape=(n_docs + 1,)).copy()
+            po = self._lib.tkamd_batch_offsets(b)
+            offs = None
+            if po:
+                offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(nt, 2)).copy() if nt else np.zeros((0, 2), np.uint32)
+            pw = self._lib.tkamd_batch_word_ids(b)
+            wids = None
+            if pw:
+                wids = np.ctypeslib.as_array(C.cast(pw, C.POINTER(C.c_uint32)), shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+        finally:
+            self._lib.tkamd_batch_free(b)
+        return BatchEncoding(ids, to, offs, wids, self._id_to_token())
+
+    def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
+        """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
+        if is_pretokenized:
+            raise UnsupportedError("is_pretokenized=True is outside the MI355X hot path")
+        return self.encode_batch_csr(list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens)
+
+    def encode_batch_fast(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
+        """``Tokenizer.encode_batch_fast`` (no offsets, tokenizer.rs:1433-1459)."""
+        if is_pretokenized:
+            raise UnsupportedError("is_pretokenized=True is outside the MI355X hot path")
+        return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens)
+
+    def encode_batch_device(self, d_text_ptr: int, d_doc_offsets_ptr: int, n_docs: int, n_bytes: int,
+                            offsets: str = "none", word_ids: bool = False, stream: int = 0) -> DeviceBatch:
+        """Inputs already in HBM (raw device pointers; text needs TEXT_PAD readable slack).  Enqueue only."""
+        flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
+        if word_ids:
+            flags |= _lib.WANT_WORD_IDS
+        res = _lib.DeviceResult()
+        _lib.check(self._lib.tkamd_encode_batch_device(self._h, d_text_ptr, d_doc_offsets_ptr, n_docs, n_bytes, flags,
+                                                       stream, C.byref(res)))
+        return DeviceBatch(self, res, n_docs, stream)
+
+    # ---- measurement hooks ----
+    def profile(self, on: bool) -> None:
+        _lib.check(self._lib.tkamd_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, reset: bool = True) -> dict[str, tuple[float, int]]:
+        arr = (_lib.StageTime * _lib.MAX_STAGES)()
+        n = C.c_int(0)
+        _lib.check(self._lib.tkamd_profile_read(self._h, arr, _lib.MAX_STAGES, C.byref(n), 1 if reset else 0))
+        return {arr[i].name.decode(): (arr[i].ms_total, arr[i].launches) for i in range(n.value)}
