@@ -128,6 +128,10 @@ typedef struct tkamd_stage_time {
 int tkamd_profile_enable(tkamd_tokenizer* tok, int on);
 int tkamd_profile_read(tkamd_tokenizer* tok, tkamd_stage_time* stages, int max_stages, int* n_stages, int reset);
 
+/* Work-queue sizes of the last synchronised batch: out[0] = pre-tokens sent to the 16-lane merge
+ * kernel, out[1] = to the 64-lane kernel, out[2] = to the workgroup (long) kernel. */
+int tkamd_profile_counters(tkamd_tokenizer* tok, uint32_t* out, int n);
+
 /* Library version string, e.g. "tokenizers_amd 0.1.0 (gfx950)". */
 const char* tkamd_version(void);
 

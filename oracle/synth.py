@@ -272,5 +272,19 @@ def wordlevel_whitespace(lines: list[str]) -> str:
     return tok.to_str()
 
 
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def load_or_train_gpt2() -> str:
+    """The C2 tokenizer.json: committed fixture (tests/golden/gpt2_synth_50257.json.gz, produced by
+    train_bytelevel_bpe() with the reference's BpeTrainer) if present, else train it now."""
+    import gzip
+    fx = os.path.join(GOLDEN_DIR, "gpt2_synth_50257.json.gz")
+    if os.path.exists(fx):
+        with gzip.open(fx, "rt", encoding="utf-8") as fh:
+            return fh.read()
+    return train_bytelevel_bpe()
+
+
 def sha256(s: str) -> str:
     return hashlib.sha256(s.encode("utf-8")).hexdigest()

@@ -30,7 +30,7 @@ SYMBOLS = [
     "tkamd_encode_batch", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
     "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
-    "tkamd_version",
+    "tkamd_profile_counters", "tkamd_version",
 ]
 
 
@@ -99,6 +99,8 @@ def load() -> C.CDLL:
     lib.tkamd_profile_enable.restype = i32
     lib.tkamd_profile_read.argtypes = [vp, C.POINTER(StageTime), i32, C.POINTER(i32), i32]
     lib.tkamd_profile_read.restype = i32
+    lib.tkamd_profile_counters.argtypes = [vp, C.POINTER(u32), i32]
+    lib.tkamd_profile_counters.restype = i32
     _lib = lib
     return lib
 

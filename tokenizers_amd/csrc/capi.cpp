@@ -96,6 +96,7 @@ struct tkamd_tokenizer {
     std::vector<tkamd_stage_time> acc;
     // last device call (for tkamd_device_sync)
     int64_t last_n_docs = 0;
+    uint32_t last_counters[CNT_COUNT] = {0};
 };
 
 struct tkamd_batch {
@@ -371,6 +372,7 @@ int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_
     HIP_CHECK(hipMemcpyAsync(host, t->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int err = *(int*)&host[SC_ERR];
+    memcpy(t->last_counters, &host[SC_COUNTERS], sizeof(t->last_counters));
     if (n_tok) *n_tok = host[SC_NTOK];
     if (n_pretok) *n_pretok = host[SC_NPRETOK];
     return err;
@@ -549,6 +551,13 @@ int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_sta
     for (int i = 0; i < n && stages; ++i) stages[i] = t->acc[i];
     *n_stages = n;
     if (reset) t->acc.clear();
+    return TKAMD_OK;
+}
+
+int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {
+    if (!t || !out) return set_error(TKAMD_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(t->mu);
+    for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = t->last_counters[i];
     return TKAMD_OK;
 }
 

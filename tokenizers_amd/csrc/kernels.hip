@@ -309,35 +309,70 @@ __device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint
     return false;
 }
 
+constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
+constexpr int LK_CHUNK = 256 * LK_ITEMS;
+
 __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
                                                          const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
                                                          uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
                                                          uint32_t* __restrict__ list16, uint32_t* __restrict__ list64,
                                                          uint32_t* __restrict__ listL, uint32_t* __restrict__ counters) {
+    __shared__ uint32_t sm[4];
+    __shared__ uint32_t base_s[3];
     const int64_t P = *n_pretok;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    // wave-uniform trip count so the ballots inside wave_append see whole wavefronts
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < P; base += stride) {
-        int64_t p = base + threadIdx.x;
-        bool valid = p < P;
-        uint32_t s = 0, len = 0;
-        if (valid) { s = pt_start[p]; len = pt_start[p + 1] - s; }
-        bool done = false;
-        if (valid && len <= (uint32_t)WORD_MAX_KEY) {
-            uint64_t lo, hi;
-            load_key16(text, s, len, &lo, &hi);
-            uint32_t id, fl;
-            if (word_probe(t, lo, hi, len, &id, &fl) && (t.ignore_merges || (fl & WORD_DIRECT))) {
-                tok0[p] = id;
-                ntok[p] = 1;
-                done = true;
+    const int64_t n_chunks = (P + LK_CHUNK - 1) / LK_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int64_t p0 = ch * LK_CHUNK + (int64_t)threadIdx.x * LK_ITEMS;
+        uint32_t st[LK_ITEMS + 1];
+#pragma unroll
+        for (int k = 0; k <= LK_ITEMS; ++k) st[k] = (p0 + k <= P) ? pt_start[p0 + k] : 0u;
+        uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list64, 3 -> listL
+        uint32_t n16 = 0, n64 = 0, nL = 0;
+#pragma unroll
+        for (int k = 0; k < LK_ITEMS; ++k) {
+            const int64_t p = p0 + k;
+            if (p < P) {
+                uint32_t s = st[k], len = st[k + 1] - s;
+                bool done = false;
+                if (len <= (uint32_t)WORD_MAX_KEY) {
+                    uint64_t lo, hi;
+                    load_key16(text, s, len, &lo, &hi);
+                    uint32_t id, fl;
+                    if (word_probe(t, lo, hi, len, &id, &fl) && (t.ignore_merges || (fl & WORD_DIRECT))) {
+                        tok0[p] = id;
+                        ntok[p] = 1;
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    uint32_t c = len <= 16 ? 1u : (len <= 64 ? 2u : 3u);
+                    cls |= c << (2 * k);
+                    n16 += (c == 1);
+                    n64 += (c == 2);
+                    nL += (c == 3);
+                }
             }
         }
-        bool q16 = valid && !done && len <= 16, q64 = valid && !done && len > 16 && len <= 64, qL = valid && !done && len > 64;
-        uint32_t i16 = wave_append(&counters[CNT_LIST16], q16);
-        if (q16) list16[i16] = (uint32_t)p;
-        if (__any(q64)) { uint32_t i = wave_append(&counters[CNT_LIST64], q64); if (q64) list64[i] = (uint32_t)p; }
-        if (__any(qL)) { uint32_t i = wave_append(&counters[CNT_LISTL], qL); if (qL) listL[i] = (uint32_t)p; }
+        // one atomic per workgroup per list (same-address atomics serialise at ~12 ns each on MI355X)
+        uint32_t tot, totL = 0;
+        uint32_t ex = block256_excl_scan(n16 | (n64 << 16), sm, &tot);
+        uint32_t exL = 0;
+        if (__syncthreads_or((int)nL)) exL = block256_excl_scan(nL, sm, &totL);
+        if (threadIdx.x == 0) {
+            base_s[0] = (tot & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST16], tot & 0xFFFFu) : 0u;
+            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_LIST64], tot >> 16) : 0u;
+            base_s[2] = totL ? atomicAdd(&counters[CNT_LISTL], totL) : 0u;
+        }
+        __syncthreads();
+        uint32_t o16 = base_s[0] + (ex & 0xFFFFu), o64 = base_s[1] + (ex >> 16), oL = base_s[2] + exL;
+#pragma unroll
+        for (int k = 0; k < LK_ITEMS; ++k) {
+            uint32_t c = (cls >> (2 * k)) & 3u;
+            if (c == 1) list16[o16++] = (uint32_t)(p0 + k);
+            else if (c == 2) list64[o64++] = (uint32_t)(p0 + k);
+            else if (c == 3) listL[oL++] = (uint32_t)(p0 + k);
+        }
+        __syncthreads();
     }
 }
 

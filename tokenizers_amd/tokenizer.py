@@ -289,6 +289,12 @@ class Tokenizer:
     def profile(self, on: bool) -> None:
         _lib.check(self._lib.tkamd_profile_enable(self._h, 1 if on else 0))
 
+    def queue_sizes(self) -> dict[str, int]:
+        """Merge work-queue sizes of the last synchronised batch (diagnostics)."""
+        arr = (C.c_uint32 * 8)()
+        _lib.check(self._lib.tkamd_profile_counters(self._h, arr, 8))
+        return {"merge16": arr[0], "merge64": arr[1], "merge_long": arr[2]}
+
     def profile_read(self, reset: bool = True) -> dict[str, tuple[float, int]]:
         arr = (_lib.StageTime * _lib.MAX_STAGES)()
         n = C.c_int(0)
