@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ with the REFERENCE itself.
+
+Runs only where the reference wheel is importable (this container).  For every tokenizer config of
+the hot path it writes
+    tests/golden/<name>.json.gz           the tokenizer.json (trained by the reference's trainers)
+    tests/golden/<name>_vectors.json.gz   {"docs": [...], "ids": [[...]], "offsets": [[[s,e],...]],
+                                            "words": [[...]], "reference": "tokenizers==X"}
+where ids/offsets/words are what ``tokenizers.Tokenizer.encode_batch(docs, add_special_tokens=False)``
+returns, with the offsets converted from chars to BYTES (the Rust encode_batch convention,
+tokenizer/mod.rs:1337-1356).  Tests on the GPU box (no /root/reference, maybe no wheel) compare
+the oracle and the HIP path against these files.
+"""
+import gzip
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tokenizers
+from tokenizers import Regex, Tokenizer, decoders, models, normalizers, pre_tokenizers, processors, trainers
+
+from oracle import synth
+
+GOLD = synth.GOLDEN_DIR
+
+
+def write_gz(path, text):
+    with gzip.GzipFile(path, "wb", mtime=0) as fh:
+        fh.write(text.encode("utf-8"))
+
+
+def char_to_byte(text):
+    m = [0]
+    for ch in text:
+        m.append(m[-1] + len(ch.encode("utf-8")))
+    return m
+
+
+def vectors(tok: Tokenizer, docs):
+    encs = tok.encode_batch(docs, add_special_tokens=False)
+    ids, offs, words = [], [], []
+    for d, e in zip(docs, encs):
+        m = char_to_byte(d)
+        ids.append(e.ids)
+        offs.append([[m[a], m[b]] for a, b in e.offsets])
+        words.append(e.word_ids)
+    return {"docs": docs, "ids": ids, "offsets": offs, "words": words, "reference": f"tokenizers=={tokenizers.__version__}"}
+
+
+def emit(name, tok_json, docs):
+    tok = Tokenizer.from_str(tok_json)
+    if not os.path.exists(os.path.join(GOLD, name + ".json.gz")) or name != "gpt2_synth_50257":
+        write_gz(os.path.join(GOLD, name + ".json.gz"), tok_json)
+    write_gz(os.path.join(GOLD, name + "_vectors.json.gz"), json.dumps(vectors(tok, docs), ensure_ascii=False))
+    print(name, "vocab", tok.get_vocab_size(), "docs", len(docs))
+
+
+def ascii_only(lines):
+    return [l for l in lines if all(ord(c) < 128 for c in l)]
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    base = synth.gen_lines(400, text_seed=5)
+    stress = synth.stress_lines(seed=1, n=500)
+    edge = ["", " ", "a", "it's", "'s", " 's", "Hello my friend, how is your day going?", "Hello there\nHello there",
+            "Hello there       dear", "i⭢j", "x" * 70, "ab" * 300, "  leading", "trailing  ", "a\t b", "a \tb", "12345 678"]
+
+    # C2: GPT-2 style byte-level BPE, 50,257 vocab
+    emit("gpt2_synth_50257", synth.load_or_train_gpt2(), edge + base + stress)
+
+    train = synth.gen_lines(20000, text_seed=1)
+    # small byte-level BPE with add_prefix_space + trim_offsets post-processor (roberta-style flags)
+    t = Tokenizer(models.BPE())
+    t.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=True, use_regex=True)
+    t.post_processor = processors.ByteLevel(trim_offsets=True)
+    t.decoder = decoders.ByteLevel()
+    t.train_from_iterator(train, trainers.BpeTrainer(vocab_size=3000, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), show_progress=False))
+    emit("bytelevel_prefix_trim_3000", t.to_str(), edge + base[:200] + stress[:300])
+
+    # C4 (small): Llama-3 style split + ignore_merges
+    t = Tokenizer(models.BPE(ignore_merges=True))
+    t.pre_tokenizer = pre_tokenizers.Sequence([
+        pre_tokenizers.Split(Regex(synth.LLAMA3_PATTERN), behavior="isolated", invert=False),
+        pre_tokenizers.ByteLevel(add_prefix_space=False, trim_offsets=True, use_regex=False)])
+    t.decoder = decoders.ByteLevel()
+    t.train_from_iterator(train, trainers.BpeTrainer(vocab_size=6000, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(), show_progress=False))
+    d = json.loads(t.to_str())
+    d["model"]["ignore_merges"] = True
+    emit("llama3_small_6000", json.dumps(d, ensure_ascii=False), edge + base[:300] + stress)
+
+    # C3 (small): BertNormalizer + BertPreTokenizer + WordPiece (ASCII documents: the oracle's normalizer scope)
+    t = Tokenizer(models.WordPiece(unk_token="[UNK]"))
+    t.normalizer = normalizers.BertNormalizer()
+    t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
+    t.train_from_iterator(train, trainers.WordPieceTrainer(vocab_size=4000, show_progress=False,
+                                                           special_tokens=["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"]))
+    emit("bert_wordpiece_4000", t.to_str(), ascii_only(edge + base + stress) + ["HE\x01LLO\tWorld!", "\x00hello", "hello\x01", "wor\x02ld x", "a" * 101, "b" * 100])
+
+    # C1: Whitespace + WordLevel over 1,000 ASCII lines
+    c1 = ascii_only(synth.gen_lines(1100, text_seed=0, special_frac=0.0))[:1000]
+    emit("wordlevel_whitespace_c1", synth.wordlevel_whitespace(c1), c1 + ascii_only(edge) + ["unseen words here ?!", "snake_case x_1 a.b"] + stress[:200])
+
+    # WhitespaceSplit + WordLevel (unk heavy)
+    t = Tokenizer.from_str(synth.wordlevel_whitespace(c1))
+    t.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    emit("wordlevel_wssplit", t.to_str(), c1[:200] + edge + stress[:200])
+
+
+if __name__ == "__main__":
+    main()

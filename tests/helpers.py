@@ -1,0 +1,25 @@
+"""Shared test helpers: golden fixture loading."""
+import gzip
+import json
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GOLDEN_NAMES = ["gpt2_synth_50257", "bytelevel_prefix_trim_3000", "llama3_small_6000", "bert_wordpiece_4000",
+                "wordlevel_whitespace_c1", "wordlevel_wssplit"]
+
+
+def load_tokenizer_json(name: str) -> str:
+    with gzip.open(os.path.join(GOLD, name + ".json.gz"), "rt", encoding="utf-8") as fh:
+        return fh.read()
+
+
+def load_vectors(name: str) -> dict:
+    with gzip.open(os.path.join(GOLD, name + "_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        return json.load(fh)
+
+
+def char_to_byte(text: str) -> list[int]:
+    m = [0]
+    for ch in text:
+        m.append(m[-1] + len(ch.encode("utf-8")))
+    return m

@@ -1,0 +1,113 @@
+"""CPU tests of the C-ABI boundary: the library loads, exports every declared symbol, parses
+tokenizer.json on a host-only handle, refuses what is outside the hot path, and has NO CPU fallback."""
+import ctypes as C
+import json
+import os
+import re
+
+import pytest
+
+import tokenizers_amd as ta
+from tokenizers_amd import _lib
+from tests.helpers import GOLDEN_NAMES, load_tokenizer_json
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "tokenizers_amd.h")).read()
+    declared = set(re.findall(r"\b(tkamd_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations found"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/tokenizers_amd.h but not exported"
+    assert declared == set(_lib.SYMBOLS)
+    assert b"gfx950" in lib.tkamd_version()
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_host_only_handle_parses_every_golden_tokenizer(name):
+    js = load_tokenizer_json(name)
+    t = ta.Tokenizer.from_str(js, device=-1)
+    d = json.loads(js)
+    assert t.info["vocab_size"] == len(d["model"]["vocab"])
+    assert t.info["device"] == -1
+    if d["model"]["type"] == "BPE":
+        assert t.info["n_merges"] == len(d["model"]["merges"])
+
+
+def test_no_cpu_fallback_on_host_only_handle():
+    t = ta.Tokenizer.from_str(load_tokenizer_json("gpt2_synth_50257"), device=-1)
+    with pytest.raises(ta.DeviceError, match="no CPU fallback"):
+        t.encode_batch_fast(["hello world"], add_special_tokens=False)
+
+
+def _base(model, pre=None, **kw):
+    d = {"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": None,
+         "pre_tokenizer": pre or {"type": "Whitespace"}, "post_processor": None, "decoder": None, "model": model}
+    d.update(kw)
+    return json.dumps(d)
+
+
+WL = {"type": "WordLevel", "vocab": {"<unk>": 0, "a": 1}, "unk_token": "<unk>"}
+
+
+@pytest.mark.parametrize("js,msg", [
+    (_base(WL, truncation={"max_length": 8, "strategy": "LongestFirst", "stride": 0, "direction": "Right"}), "truncation"),
+    (_base(WL, padding={"strategy": "BatchLongest", "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}), "padding"),
+    (_base(WL, normalizer={"type": "NFKC"}), "normalizer"),
+    (_base(WL, pre={"type": "Metaspace", "replacement": "_", "prepend_scheme": "always", "split": True}), "pre_tokenizer"),
+    (_base({"type": "Unigram", "unk_id": 0, "vocab": [["<unk>", 0.0]], "byte_fallback": False}), "vocab"),
+    (_base({"type": "BPE", "vocab": {"a": 0}, "merges": [], "dropout": 0.1}, pre={"type": "ByteLevel", "add_prefix_space": False, "trim_offsets": True, "use_regex": True}), "dropout"),
+])
+def test_outside_hot_path_is_refused_loudly(js, msg):
+    with pytest.raises((ta.UnsupportedError, ValueError), match=msg):
+        ta.Tokenizer.from_str(js, device=-1)
+
+
+def _byte_alphabet():
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return {chr(c): i for i, c in enumerate(cs)}
+
+
+def test_malformed_json_is_invalid():
+    with pytest.raises(ValueError):
+        ta.Tokenizer.from_str("{not json", device=-1)
+    with pytest.raises(ValueError, match="out of vocabulary"):
+        ta.Tokenizer.from_str(_base({"type": "BPE", "vocab": _byte_alphabet(), "merges": [["a", "zz"]]},
+                                    pre={"type": "ByteLevel", "add_prefix_space": False, "trim_offsets": True, "use_regex": True}), device=-1)
+
+
+def test_json_escapes_and_surrogates():
+    js = _base({"type": "WordLevel", "vocab": {"<unk>": 0, "caf\\u00e9": 1, "\\ud83d\\ude00": 2, "tab\\t": 3}, "unk_token": "<unk>"}).replace("\\\\", "\\")
+    t = ta.Tokenizer.from_str(js, device=-1)
+    assert t.info["vocab_size"] == 4
+
+
+def test_pack_documents_contract():
+    buf, off = ta.pack_documents(["ab", "", "é", "\U0001F600"])
+    assert off.tolist() == [0, 2, 2, 4, 8]
+    assert len(buf) == 8 + _lib.TEXT_PAD and buf[8:].sum() == 0
+    with pytest.raises(TypeError, match="TextInputSequence must be str"):     # bindings/python/src/tokenizer.rs:274
+        ta.pack_documents(["ok", 3])
+    with pytest.raises(ta.UnsupportedError):
+        ta.pack_documents([("a", "b")])
+    buf, off = ta.pack_documents([])
+    assert off.tolist() == [0]
+
+
+def test_product_never_imports_the_oracle_or_the_wheel():
+    pkg = os.path.join(ROOT, "tokenizers_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f), encoding="utf-8").read()
+                assert "oracle" not in src.replace("oracle/gen_unicode_tables.py", "").lower() or f == "unicode_ranges.inc", f
+                assert "import tokenizers\n" not in src and "from tokenizers " not in src, f

@@ -1,0 +1,183 @@
+"""CPU tests that PIN the oracle (oracle/oracle.c):
+  1. the reference's own inline known-answer tests, re-stated here with the
+     file:line they come from;
+  2. the committed golden vectors produced by the reference wheel (oracle/make_golden.py);
+  3. when the wheel is importable, a live differential run on fresh seeded inputs.
+"""
+import json
+
+import pytest
+
+from oracle import oracle as orc
+from oracle import synth
+from tests.helpers import GOLDEN_NAMES, char_to_byte, load_tokenizer_json, load_vectors
+
+
+def _tok_json(model: dict, pre_tokenizer=None, normalizer=None, post_processor=None) -> str:
+    return json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": normalizer,
+                       "pre_tokenizer": pre_tokenizer, "post_processor": post_processor, "decoder": None, "model": model})
+
+
+BL = {"type": "ByteLevel", "add_prefix_space": False, "trim_offsets": True, "use_regex": True}
+# byte-level alphabet so that the BPE oracle can be built for pre-tokenizer-only checks
+def _byte_vocab():
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b)
+            cs.append(256 + n)
+            n += 1
+    return {chr(c): i for i, c in enumerate(cs)}, {b: chr(c) for b, c in zip(bs, cs)}
+
+
+def _pretok_strings(o, text):
+    raw = text.encode("utf-8")
+    return [(raw[a:b].decode("utf-8", "replace"), (a, b)) for a, b in o.pre_tokenize(text)]
+
+
+@pytest.fixture(scope="module")
+def bl_oracle():
+    vocab, _ = _byte_vocab()
+    return orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": []}, BL))
+
+
+# ---- 1. reference inline known-answer tests ------------------------------------------------------
+
+def test_ref_byte_level_pre_tokenization(bl_oracle):
+    # pre_tokenizers/byte_level.rs:245-269
+    got = _pretok_strings(bl_oracle, "Hello my friend, how is your day going?")
+    assert got == [("Hello", (0, 5)), (" my", (5, 8)), (" friend", (8, 15)), (",", (15, 16)), (" how", (16, 20)),
+                   (" is", (20, 23)), (" your", (23, 28)), (" day", (28, 32)), (" going", (32, 38)), ("?", (38, 39))]
+
+
+def test_ref_byte_level_newlines_and_spaces(bl_oracle):
+    # byte_level.rs:360-380 and :382-401
+    assert [o for _, o in _pretok_strings(bl_oracle, "Hello there\nHello there")] == [(0, 5), (5, 11), (11, 12), (12, 17), (17, 23)]
+    assert [o for _, o in _pretok_strings(bl_oracle, "Hello there       dear")] == [(0, 5), (5, 11), (11, 17), (17, 22)]
+
+
+def test_ref_byte_level_char_split_up(bl_oracle):
+    # byte_level.rs:403-434: "i⭢j" -> i | ⭢ (3 bytes) | j, original offsets (0,1) (1,4) (4,5)
+    assert [o for _, o in _pretok_strings(bl_oracle, "i⭢j")] == [(0, 1), (1, 4), (4, 5)]
+    # every byte-token of the split char reports the whole char's range (tests/offsets.rs:47-57)
+    r = bl_oracle.encode_batch(["i⭢j"])
+    assert r.doc_offsets(0) == [(0, 1), (1, 4), (1, 4), (1, 4), (4, 5)]
+    assert r.doc_words(0) == [0, 1, 1, 1, 2]
+
+
+def test_ref_whitespace():
+    # pre_tokenizers/whitespace.rs:48-81
+    o = orc.Oracle(_tok_json({"type": "WordLevel", "vocab": {"<unk>": 0}, "unk_token": "<unk>"}, {"type": "Whitespace"}))
+    assert _pretok_strings(o, "Hey man!") == [("Hey", (0, 3)), ("man", (4, 7)), ("!", (7, 8))]
+    assert _pretok_strings(o, "How are you doing?") == [("How", (0, 3)), ("are", (4, 7)), ("you", (8, 11)), ("doing", (12, 17)), ("?", (17, 18))]
+    assert _pretok_strings(o, "\n") == []
+
+
+def test_ref_whitespace_split():
+    # whitespace.rs:83-105
+    o = orc.Oracle(_tok_json({"type": "WordLevel", "vocab": {"<unk>": 0}, "unk_token": "<unk>"}, {"type": "WhitespaceSplit"}))
+    assert _pretok_strings(o, "Hey man!") == [("Hey", (0, 3)), ("man!", (4, 8))]
+    assert _pretok_strings(o, "Hey, man, Good?") == [("Hey,", (0, 4)), ("man,", (5, 9)), ("Good?", (10, 15))]
+
+
+def test_ref_bert_pre_tokenizer():
+    # pre_tokenizers/bert.rs:27-50
+    o = orc.Oracle(_tok_json({"type": "WordPiece", "vocab": {"[UNK]": 0}, "unk_token": "[UNK]", "continuing_subword_prefix": "##",
+                              "max_input_chars_per_word": 100}, {"type": "BertPreTokenizer"}))
+    assert _pretok_strings(o, "Hey friend!     How are you?!?") == [
+        ("Hey", (0, 3)), ("friend", (4, 10)), ("!", (10, 11)), ("How", (16, 19)), ("are", (20, 23)), ("you", (24, 27)),
+        ("?", (27, 28)), ("!", (28, 29)), ("?", (29, 30))]
+
+
+def test_ref_bpe_unrelated():
+    # models/bpe/model.rs:831-867
+    vocab = {"u": 0, "n": 1, "r": 2, "e": 3, "l": 4, "a": 5, "t": 6, "d": 7, "re": 8, "at": 9, "ed": 10, "un": 11, "ated": 12,
+             "rel": 13, "related": 14, "unrelated": 15}
+    merges = [["r", "e"], ["a", "t"], ["e", "d"], ["u", "n"], ["at", "ed"], ["re", "l"], ["rel", "ated"], ["un", "related"]]
+    o = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": merges}, BL))
+    assert o.model_tokenize("unrelated") == [(15, (0, 9))]
+
+
+def test_ref_bpe_ignore_merges():
+    # models/bpe/model.rs:1076-1170
+    vocab = {".:.:": 0, "Ġbelirtilen": 1, ".": 2, ":": 3, "bel": 4, "irtilen": 5, "Ġ": 6, ".:": 7, "belirtilen": 8, ".:.": 9, "be": 10,
+             "l": 11, "ir": 12, "ti": 13, "en": 14, "irtil": 15, "irti": 16, "i": 17, "r": 18, "t": 19, "b": 20, "e": 21, "n": 22}
+    merges = [[".", ":"], ["b", "e"], ["be", "l"], ["i", "r"], ["t", "i"], ["ir", "ti"], ["e", "n"], ["irti", "l"]]
+    on = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": merges, "ignore_merges": True}, BL))
+    assert on.model_tokenize(".:.:") == [(0, (0, 4))]
+    assert on.model_tokenize("Ġbelirtilen") == [(1, (0, 12))]
+    off = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": merges, "ignore_merges": False}, BL))
+    assert off.model_tokenize(".:.:") == [(7, (0, 2)), (7, (2, 4))]
+    assert off.model_tokenize("Ġbelirtilen") == [(6, (0, 2)), (4, (2, 5)), (15, (5, 10)), (14, (10, 12))]
+
+
+def test_ref_wordlevel():
+    # models/wordlevel/mod.rs:223-250
+    o = orc.Oracle(_tok_json({"type": "WordLevel", "vocab": {"<unk>": 0, "a": 1, "b": 2}, "unk_token": "<unk>"}, {"type": "Whitespace"}))
+    assert o.model_tokenize("c") == [(0, (0, 1))]
+    assert o.model_tokenize("a") == [(1, (0, 1))]
+    o2 = orc.Oracle(_tok_json({"type": "WordLevel", "vocab": {"a": 0, "b": 1}, "unk_token": "<unk>"}, {"type": "Whitespace"}))
+    assert o2.model_tokenize("a") == [(0, (0, 1))]
+    with pytest.raises(orc.OracleError, match="MissingUnkToken"):
+        o2.model_tokenize("c")
+
+
+def test_ref_wordpiece_semantics():
+    # models/wordpiece/mod.rs:224-283 (the reference has no inline known-answer test for tokenize; these
+    # are the cases SURVEY 8c replayed against the wheel: jo|##hn, any-miss -> whole word unk, >100 chars)
+    vocab = {"[UNK]": 0, "jo": 1, "##hn": 2, "john": 3, "##n": 4, "a": 5}
+    o = orc.Oracle(_tok_json({"type": "WordPiece", "vocab": vocab, "unk_token": "[UNK]", "continuing_subword_prefix": "##",
+                              "max_input_chars_per_word": 100}, {"type": "BertPreTokenizer"}))
+    assert o.model_tokenize("john") == [(3, (0, 4))]
+    assert o.model_tokenize("johnn") == [(3, (0, 4)), (4, (4, 5))]
+    assert o.model_tokenize("johx") == [(0, (0, 4))]
+    assert o.model_tokenize("a" * 101) == [(0, (0, 101))]
+
+
+def test_gpt2_semantics_cheatsheet(bl_oracle):
+    # SURVEY 8c cheat-sheet, verified on the wheel
+    def pieces(t):
+        return [p for p, _ in _pretok_strings(bl_oracle, t)]
+    assert pieces("a  b") == ["a", " ", " b"]
+    assert pieces("a \tb") == ["a", " ", "\t", "b"]
+    assert pieces("a\t b") == ["a", "\t", " b"]
+    assert pieces("a \n") == ["a", " \n"]
+    assert pieces("a   ") == ["a", "   "]
+    assert pieces("it's 'sup !'s") == ["it", "'s", " '", "sup", " !'", "s"]
+    assert pieces("x123abc") == ["x", "123", "abc"]
+
+
+# ---- 2. golden vectors from the reference wheel --------------------------------------------------
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_oracle_matches_golden(name):
+    o = orc.Oracle(load_tokenizer_json(name))
+    v = load_vectors(name)
+    r = o.encode_batch(v["docs"])
+    trim = name == "bytelevel_prefix_trim_3000"       # the oracle reports untrimmed offsets
+    bad = []
+    for i, doc in enumerate(v["docs"]):
+        if r.doc_ids(i) != v["ids"][i] or r.doc_words(i) != v["words"][i]:
+            bad.append((i, doc, r.doc_ids(i)[:8], v["ids"][i][:8]))
+        elif not trim and r.doc_offsets(i) != [tuple(x) for x in v["offsets"][i]]:
+            bad.append((i, doc, r.doc_offsets(i)[:8], v["offsets"][i][:8]))
+    assert not bad, f"{len(bad)} mismatches, first {bad[0]!r}"
+
+
+# ---- 3. live differential against the wheel ------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000"])
+def test_oracle_vs_wheel_live(name, ref_tokenizers):
+    js = load_tokenizer_json(name)
+    o = orc.Oracle(js)
+    ref = ref_tokenizers.Tokenizer.from_str(js)
+    docs = synth.gen_lines(1500, text_seed=77) + synth.stress_lines(seed=5, n=1500)
+    r = o.encode_batch(docs)
+    exp = ref.encode_batch(docs, add_special_tokens=False)
+    for i, e in enumerate(exp):
+        assert r.doc_ids(i) == e.ids, docs[i]
+        m = char_to_byte(docs[i])
+        assert r.doc_offsets(i) == [(m[a], m[b]) for a, b in e.offsets], docs[i]
+        assert r.doc_words(i) == e.word_ids, docs[i]
