@@ -160,7 +160,7 @@ class DeviceBatch:
         class _Arr:
             pass
         a = _Arr()
-        a.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, True), "version": 2}
+        a.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
         return torch.as_tensor(a, device=f"cuda:{self._tok.device}")
 
     def ids_tensor(self):
