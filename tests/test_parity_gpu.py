@@ -13,7 +13,7 @@ from tests.helpers import load_tokenizer_json, load_vectors
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
-GPU_GOLDEN = ["gpt2_synth_50257"]
+GPU_GOLDEN = ["gpt2_synth_50257", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
 
 
 @pytest.fixture(scope="module")
@@ -138,3 +138,48 @@ def test_full_size_properties(gpt2, gpt2_oracle):
     exp = gpt2_oracle.encode_batch([docs[i] for i in sample])
     for k, i in enumerate(sample):
         assert got[i].ids == exp.doc_ids(k), docs[i]
+
+
+def _ascii_only(lines):
+    return [l for l in lines if all(ord(c) < 128 for c in l)]
+
+
+@pytest.mark.parametrize("name", ["wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"])
+def test_word_models_vs_oracle(name):
+    import tokenizers_amd as ta
+    js = load_tokenizer_json(name)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    docs = synth.gen_lines(20000, text_seed=13) + synth.stress_lines(seed=4, n=3000) + ["", " ", "a" * 300, "x" * 101 + " " + "y" * 100, "!!!", "a_b-c.d"]
+    if name.startswith("bert"):
+        docs = _ascii_only(docs) + ["HE\x01LLO\tWorld!", "\x00hello", "wor\x02ld x", "\x7f\x7f", "\x01"]
+    got = tok.encode_batch_fast(docs, add_special_tokens=False)
+    exp = o.encode_batch(docs)
+    _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(docs))], docs)
+
+
+def test_bert_normalizer_non_ascii_is_refused():
+    import tokenizers_amd as ta
+    tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=0)
+    with pytest.raises(ta.UnsupportedError, match="non-ASCII"):
+        tok.encode_batch_fast(["plain", "caf\u00e9"], add_special_tokens=False)
+
+
+def test_wordlevel_missing_unk_is_a_model_error():
+    import json
+    import tokenizers_amd as ta
+    js = json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": None,
+                     "pre_tokenizer": {"type": "Whitespace"}, "post_processor": None, "decoder": None,
+                     "model": {"type": "WordLevel", "vocab": {"a": 0, "b": 1}, "unk_token": "<unk>"}})
+    tok = ta.Tokenizer.from_str(js, device=0)
+    assert tok.encode_batch_fast(["a b a"], add_special_tokens=False)[0].ids == [0, 1, 0]
+    with pytest.raises(ta.TokenizersAmdError, match="MissingUnkToken"):     # models/wordlevel/mod.rs:175-177
+        tok.encode_batch_fast(["a c"], add_special_tokens=False)
+
+
+def test_added_token_in_text_is_refused():
+    import tokenizers_amd as ta
+    tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=0)
+    assert len(tok.encode_batch_fast(["no specials here [ ] UNK", "[unk]"], add_special_tokens=False)) == 2
+    with pytest.raises(ta.UnsupportedError, match="added/special token"):
+        tok.encode_batch_fast(["fine", "has [SEP] inside"], add_special_tokens=False)

@@ -81,10 +81,11 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_trie_eb, t_trie_by, t_trie_ch, t_trie_id, t_trie_root;
+    DevBuf t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -111,7 +112,7 @@ struct tkamd_batch {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_COUNTERS = 4 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
 
 struct Prof {
     tkamd_tokenizer* t;
@@ -163,11 +164,10 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_long_off, hm.long_off);
     upload(t->t_long_id, hm.long_id);
     upload(t->t_long_table, hm.long_table);
-    upload(t->t_trie_eb, hm.trie.edge_begin);
-    upload(t->t_trie_by, hm.trie.edge_byte);
-    upload(t->t_trie_ch, hm.trie.edge_child);
-    upload(t->t_trie_id, hm.trie.node_id);
-    upload(t->t_trie_root, hm.trie.root_child);
+    upload(t->t_trie, hm.trie.table);
+    upload(t->t_at_blob, hm.at_blob);
+    upload(t->t_at_off, hm.at_off);
+    upload(t->t_at_first, hm.at_first);
     DevTables& d = t->dt;
     d.uc1 = t->t_uc1.as<uint16_t>();
     d.uc2 = t->t_uc2.as<uint8_t>();
@@ -186,11 +186,9 @@ void upload_tables(tkamd_tokenizer* t) {
     d.long_id = t->t_long_id.as<uint32_t>();
     d.long_table = t->t_long_table.as<uint32_t>();
     d.long_mask = hm.long_mask;
-    d.trie_edge_begin = t->t_trie_eb.as<uint32_t>();
-    d.trie_edge_byte = t->t_trie_by.as<uint8_t>();
-    d.trie_edge_child = t->t_trie_ch.as<uint32_t>();
-    d.trie_node_id = t->t_trie_id.as<uint32_t>();
-    d.trie_root_child = t->t_trie_root.as<uint32_t>();
+    d.trie = t->t_trie.as<MergeSlot>();
+    d.trie_mask = hm.trie.mask;
+    d.trie_seed = hm.trie.seed;
     d.max_input_chars = hm.max_input_chars;
 }
 
@@ -283,19 +281,24 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     if (n_bytes >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
     if ((flags & TKAMD_OFFSETS_MASK) || (flags & TKAMD_WANT_WORD_IDS))
         throw Unsupported("offsets / word ids are not produced by this build yet (use TKAMD_OFFSETS_NONE)");
-    if (!hm.added_tokens.empty())
-        throw Unsupported("added tokens need the AddedVocabulary split (added_vocabulary.rs:523-564), not built yet");
-    if (!(hm.model == MODEL_BPE && hm.pretok == PT_BYTELEVEL_GPT2 && !hm.add_prefix_space))
-        throw Unsupported("this build covers ByteLevel(GPT-2 regex, add_prefix_space=false) + BPE");
+    if (hm.byte_level && hm.add_prefix_space)
+        throw Unsupported("ByteLevel add_prefix_space=true is not built yet");
+    const bool bpe_path = hm.model == MODEL_BPE && hm.pretok == PT_BYTELEVEL_GPT2;
+    const bool local_pretok = hm.pretok == PT_WHITESPACE || hm.pretok == PT_WHITESPACE_SPLIT || hm.pretok == PT_BERT;
+    const bool word_models = (hm.model == MODEL_WORDLEVEL || hm.model == MODEL_WORDPIECE) && local_pretok;
+    if (!bpe_path && !word_models)
+        throw Unsupported("this build covers ByteLevel(GPT-2 regex)+BPE and {Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
 
     reserve_workspace(t, n_bytes, n_docs, flags);
     int64_t* sc = t->w_scalars.as<int64_t>();
     int64_t* d_npretok = sc + SC_NPRETOK;
     int64_t* d_ntok_total = sc + SC_NTOK;
+    int64_t* d_nkept = sc + SC_NKEPT;
     int* d_err = (int*)(sc + SC_ERR);
     uint32_t* d_counters = (uint32_t*)(sc + SC_COUNTERS);
     const int64_t W = (n_bytes >> 6) + 1;
     Prof pf{t, st};
+    using ull = unsigned long long;
 
     HIP_CHECK(hipMemsetAsync(sc, 0, SC_SLOTS * 8, st));
     HIP_CHECK(hipMemsetAsync(t->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
@@ -306,55 +309,120 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
     t->last_n_docs = n_docs;
-
-    pf.begin("mark_doc_starts");
-    launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<unsigned long long>(), d_err);
-    pf.end();
     if (n_bytes == 0) {
+        pf.begin("mark_doc_starts");
+        launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<ull>(), d_err);
+        pf.end();
         HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
         return;
     }
-    pf.begin("pretok_gpt2");
-    launch_pretok_gpt2(st, d_text, n_bytes, t->w_docmask.as<unsigned long long>(), t->dt.uc1, t->dt.uc2,
-                       t->w_startmask.as<unsigned long long>());
+
+    // ---- added / special tokens: refuse the batch if one occurs in the raw text ----
+    if (hm.at_off.size() > 1) {
+        pf.begin("added_token_scan");
+        launch_added_token_scan(st, d_text, n_bytes, t->t_at_blob.as<uint8_t>(), t->t_at_off.as<uint32_t>(),
+                                t->t_at_first.as<uint32_t>(), d_err);
+        pf.end();
+    }
+
+    // ---- normalizer (BertNormalizer, ASCII): text -> normalized text + original-position map ----
+    const uint8_t* x_text = d_text;          // what the pre-tokenizer and the model read
+    const int64_t* x_doc_off = d_doc_off;
+    if (hm.norm == NORM_BERT) {
+        t->w_keepmask.reserve((size_t)(W + 1) * 8);
+        t->w_kprefix.reserve((size_t)(W + 1) * 4);
+        t->w_ntext.reserve((size_t)n_bytes + TKAMD_TEXT_PAD);
+        t->w_norig.reserve(((size_t)n_bytes + 4) * 4);
+        t->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
+        pf.begin("bert_normalize");
+        // validate the CSR first (the normalised CSR is derived from it)
+        launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<ull>(), d_err);
+        HIP_CHECK(hipMemsetAsync(t->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
+        launch_norm_keepmask(st, d_text, n_bytes, hm.bn_clean_text, t->w_keepmask.as<ull>(), d_err);
+        launch_mask_scan(st, t->w_keepmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_kprefix.as<uint32_t>(), d_nkept);
+        HIP_CHECK(hipMemsetAsync(t->w_ntext.p, 0, (size_t)n_bytes + TKAMD_TEXT_PAD, st));
+        launch_norm_scatter(st, d_text, n_bytes, hm.bn_clean_text, hm.bn_lowercase, t->w_keepmask.as<ull>(),
+                            t->w_kprefix.as<uint32_t>(), t->w_ntext.as<uint8_t>(), t->w_norig.as<uint32_t>());
+        launch_norm_doc_offsets(st, d_doc_off, n_docs, n_bytes, t->w_keepmask.as<ull>(), t->w_kprefix.as<uint32_t>(), d_nkept,
+                                t->w_ndoc_off.as<int64_t>());
+        pf.end();
+        x_text = t->w_ntext.as<uint8_t>();
+        x_doc_off = t->w_ndoc_off.as<int64_t>();
+        // The normalised length is only known on the device; kernels below take the ORIGINAL length as
+        // their launch bound and treat the zero-filled tail as text outside every document.
+    }
+    // NOTE: for the normalised path the pre-tokenizer runs over n_bytes positions of ntext; bytes past
+    // n_kept are zero (class "other"/control) but lie outside [0, ndoc_off[n_docs]) -- they must not form
+    // pre-tokens, so the effective text length for them is read from the device (x_len).
+    const int64_t* x_len_dev = (hm.norm == NORM_BERT) ? d_nkept : nullptr;
+
+    pf.begin("mark_doc_starts");
+    launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_bytes, x_len_dev, t->w_docmask.as<ull>(), d_err);
     pf.end();
+
+    uint32_t* pt_end = nullptr;
+    if (bpe_path) {
+        pf.begin("pretok_gpt2");
+        launch_pretok_gpt2(st, x_text, n_bytes, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>());
+        pf.end();
+    } else {
+        t->w_endmask.reserve((size_t)(W + 1) * 8);
+        t->w_pt_end.reserve(((size_t)n_bytes + 4) * 4);
+        pt_end = t->w_pt_end.as<uint32_t>();
+        pf.begin("pretok_local");
+        launch_pretok_local(st, (int)hm.pretok, x_text, n_bytes, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
+                            t->w_startmask.as<ull>(), t->w_endmask.as<ull>());
+        pf.end();
+    }
     pf.begin("mask_scan");
-    launch_mask_scan(st, t->w_startmask.as<unsigned long long>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
+    launch_mask_scan(st, t->w_startmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
     pf.begin("emit_pretok");
-    launch_emit_pretok(st, t->w_startmask.as<unsigned long long>(), t->w_wprefix.as<uint32_t>(), n_bytes, d_npretok,
-                       t->w_pt_start.as<uint32_t>());
+    launch_emit_pretok(st, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_bytes, d_npretok, t->w_pt_start.as<uint32_t>());
+    if (pt_end) launch_emit_pretok_end(st, t->w_startmask.as<ull>(), t->w_endmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_bytes, pt_end);
     pf.end();
     pf.begin("doc_first_pretok");
-    launch_doc_first_pretok(st, d_doc_off, n_docs, n_bytes, t->w_startmask.as<unsigned long long>(), t->w_wprefix.as<uint32_t>(),
+    launch_doc_first_pretok(st, x_doc_off, n_docs, n_bytes, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(),
                             d_npretok, t->w_doc_pt.as<uint32_t>());
     pf.end();
 
     const int grid = t->n_cu * 8;
-    size_t N = (size_t)n_bytes;
-    uint32_t* list16 = t->w_lists.as<uint32_t>();
-    uint32_t* list64 = list16 + N + 16;
-    uint32_t* listL = list64 + N / 16 + 16;
-    pf.begin("bpe_word_lookup");
-    launch_bpe_word_lookup(st, grid, t->dt, d_text, t->w_pt_start.as<uint32_t>(), d_npretok, t->w_tok0.as<uint32_t>(),
-                           t->w_ntok.as<uint32_t>(), list16, list64, listL, d_counters);
-    pf.end();
-    pf.begin("bpe_merge16");
-    launch_bpe_merge(st, grid, 16, t->dt, d_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16,
-                     t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
-    pf.end();
-    pf.begin("bpe_merge64");
-    launch_bpe_merge(st, grid, 64, t->dt, d_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
-                     t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
-    pf.end();
-    if (!t->long_prepared) {
-        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(long merge kernel LDS) failed");
-        t->long_prepared = true;
+    if (hm.model == MODEL_BPE) {
+        size_t N = (size_t)n_bytes;
+        uint32_t* list16 = t->w_lists.as<uint32_t>();
+        uint32_t* list64 = list16 + N + 16;
+        uint32_t* listL = list64 + N / 16 + 16;
+        pf.begin("bpe_word_lookup");
+        launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), d_npretok, t->w_tok0.as<uint32_t>(),
+                               t->w_ntok.as<uint32_t>(), list16, list64, listL, d_counters);
+        pf.end();
+        pf.begin("bpe_merge16");
+        launch_bpe_merge(st, grid, 16, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16,
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
+        pf.end();
+        pf.begin("bpe_merge64");
+        launch_bpe_merge(st, grid, 64, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
+        pf.end();
+        if (!t->long_prepared) {
+            if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(long merge kernel LDS) failed");
+            t->long_prepared = true;
+        }
+        pf.begin("bpe_merge_long");
+        launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), listL, d_counters + CNT_LISTL,
+                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr, d_err);
+        pf.end();
+    } else if (hm.model == MODEL_WORDLEVEL) {
+        pf.begin("wordlevel");
+        launch_wordlevel(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
+                         t->w_ntok.as<uint32_t>(), d_err);
+        pf.end();
+    } else {
+        pf.begin("wordpiece");
+        launch_wordpiece(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
+                         t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr, d_err);
+        pf.end();
     }
-    pf.begin("bpe_merge_long");
-    launch_bpe_merge_long(st, t->n_cu, t->dt, d_text, t->w_pt_start.as<uint32_t>(), listL, d_counters + CNT_LISTL,
-                          t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr, d_err);
-    pf.end();
     pf.begin("compact");
     launch_compact(st, grid, t->w_ntok.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(),
                    t->w_pt_start.as<uint32_t>(), d_npretok, t->w_csum.as<uint32_t>(), d_ntok_total,
@@ -382,7 +450,9 @@ int error_from_bits(int bits) {
     if (bits & ERR_BAD_OFFSETS) return set_error(TKAMD_ERR_INVALID, "doc_offsets is not a monotone CSR over [0, n_bytes]");
     if (bits & ERR_PRETOKEN_TOO_LONG)
         return set_error(TKAMD_ERR_UNSUPPORTED, "a pre-token is longer than 8192 bytes (workgroup merge path limit)");
-    if (bits & ERR_ADDED_TOKEN) return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text");
+    if (bits & ERR_ADDED_TOKEN)
+        return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text: the AddedVocabulary split "
+                                                "(added_vocabulary.rs:523-564) is not built on the device yet");
     if (bits & ERR_NON_ASCII_NORM) return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer on non-ASCII text is not built yet");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
@@ -442,10 +512,10 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
         DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_trie_eb, &t->t_trie_by, &t->t_trie_ch, &t->t_trie_id,
-                         &t->t_trie_root, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->t_long_id, &t->t_long_table, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }

@@ -100,27 +100,31 @@ bool cuckoo_insert(std::vector<Slot>& tab, Slot item, IsEmpty is_empty, H1 h1, H
     return false;
 }
 
-void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
-    if (merges.empty()) { m.merge_table.clear(); m.merge_mask = 0; return; }
+void build_pair_table(const std::vector<MergeSlot>& items, std::vector<MergeSlot>* out, uint32_t* out_mask, uint32_t* out_seed) {
+    if (items.empty()) { out->assign(16, MergeSlot{MERGE_EMPTY, MERGE_EMPTY, RANK_NONE, 0}); *out_mask = 15; *out_seed = 0; return; }
     uint32_t cap = 16;
-    while (cap < merges.size() * 5 / 2) cap <<= 1;   // load factor <= 0.4
+    while (cap < items.size() * 5 / 2) cap <<= 1;   // load factor <= 0.4
     std::mt19937 rng(12345);
     for (int attempt = 0; attempt < 64; ++attempt) {
         uint32_t seed = (uint32_t)rng();
         uint32_t mask = cap - 1;
         std::vector<MergeSlot> tab(cap, MergeSlot{MERGE_EMPTY, MERGE_EMPTY, RANK_NONE, 0});
         bool ok = true;
-        for (const MergeSlot& e : merges) {
+        for (const MergeSlot& e : items) {
             ok = cuckoo_insert(
                 tab, e, [](const MergeSlot& s) { return s.a == MERGE_EMPTY; },
                 [&](const MergeSlot& s) { return merge_hash1(s.a, s.b, seed) & mask; },
                 [&](const MergeSlot& s) { return merge_hash2(s.a, s.b, seed) & mask; }, rng);
             if (!ok) break;
         }
-        if (ok) { m.merge_table.swap(tab); m.merge_mask = mask; m.merge_seed = seed; return; }
+        if (ok) { out->swap(tab); *out_mask = mask; *out_seed = seed; return; }
         if (attempt % 4 == 3) cap <<= 1;
     }
-    throw Invalid("could not build the merge hash table");
+    throw Invalid("could not build a pair hash table");
+}
+
+void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
+    build_pair_table(merges, &m.merge_table, &m.merge_mask, &m.merge_seed);
 }
 
 void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {
@@ -158,48 +162,35 @@ void build_long_table(HostModel& m) {
     }
 }
 
-// Build the two-root byte trie for WordPiece.
+// Build the two-root byte trie for WordPiece and flatten it into a cuckoo table.
 void build_trie(HostModel& m, const std::vector<std::pair<std::string, uint32_t>>& initial,
                 const std::vector<std::pair<std::string, uint32_t>>& cont) {
     struct Node {
-        std::vector<std::pair<uint8_t, uint32_t>> kids;
+        std::unordered_map<uint8_t, uint32_t> kids;
         uint32_t id = 0xFFFFFFFFu;
     };
     std::vector<Node> nodes(2);
     auto insert = [&](uint32_t root, const std::string& key, uint32_t id) {
         uint32_t cur = root;
         for (unsigned char c : key) {
-            uint32_t nxt = 0;
-            for (auto& k : nodes[cur].kids)
-                if (k.first == c) { nxt = k.second; break; }
-            if (!nxt) {
+            auto it = nodes[cur].kids.find(c);
+            uint32_t nxt;
+            if (it == nodes[cur].kids.end()) {
                 nxt = (uint32_t)nodes.size();
                 nodes.emplace_back();
-                nodes[cur].kids.emplace_back(c, nxt);
-            }
+                nodes[cur].kids.emplace(c, nxt);
+            } else nxt = it->second;
             cur = nxt;
         }
         nodes[cur].id = id;
     };
     for (auto& kv : initial) insert(0, kv.first, kv.second);
     for (auto& kv : cont) insert(1, kv.first, kv.second);
-    ByteTrie& t = m.trie;
-    size_t nn = nodes.size();
-    t.edge_begin.assign(nn + 1, 0);
-    t.node_id.assign(nn, 0xFFFFFFFFu);
-    t.edge_byte.clear();
-    t.edge_child.clear();
-    for (size_t i = 0; i < nn; ++i) {
-        auto& k = nodes[i].kids;
-        std::sort(k.begin(), k.end());
-        t.edge_begin[i] = (uint32_t)t.edge_byte.size();
-        for (auto& e : k) { t.edge_byte.push_back(e.first); t.edge_child.push_back(e.second); }
-        t.node_id[i] = nodes[i].id;
-    }
-    t.edge_begin[nn] = (uint32_t)t.edge_byte.size();
-    t.root_child.assign(512, 0);
-    for (int r = 0; r < 2; ++r)
-        for (auto& e : nodes[r].kids) t.root_child[r * 256 + e.first] = e.second;
+    std::vector<MergeSlot> items;
+    for (uint32_t n = 0; n < nodes.size(); ++n)
+        for (auto& e : nodes[n].kids) items.push_back(MergeSlot{n, (uint32_t)e.first, e.second, nodes[e.second].id});
+    m.trie.n_nodes = (uint32_t)nodes.size();
+    build_pair_table(items, &m.trie.table, &m.trie.mask, &m.trie.seed);
 }
 
 PretokKind parse_pretok(const JsonValue* pt, HostModel& m) {
@@ -303,6 +294,26 @@ HostModel HostModel::from_json(const char* json, size_t len) {
             a.normalized = e->get_bool("normalized", false);
             m.added_tokens.push_back(std::move(a));
         }
+    }
+
+    {
+        std::vector<std::string> pats;
+        for (const AddedToken& a : m.added_tokens) {
+            if (a.content.empty()) continue;
+            if (a.normalized && m.norm != NORM_NONE)
+                throw Unsupported("added token '" + a.content + "' with normalized=true behind a normalizer (added_vocabulary.rs:548-553)");
+            pats.push_back(a.content);
+        }
+        std::sort(pats.begin(), pats.end());
+        pats.erase(std::unique(pats.begin(), pats.end()), pats.end());
+        m.at_first.assign(257, 0);
+        m.at_off.push_back(0);
+        for (const std::string& p : pats) {
+            m.at_first[(uint8_t)p[0] + 1]++;
+            m.at_blob.insert(m.at_blob.end(), p.begin(), p.end());
+            m.at_off.push_back((uint32_t)m.at_blob.size());
+        }
+        for (int b = 0; b < 256; ++b) m.at_first[b + 1] += m.at_first[b];
     }
 
     // ---- model ----

@@ -21,18 +21,14 @@ struct Invalid : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-// Flattened byte trie for WordPiece longest-match (models/wordpiece/mod.rs:224-283).
-// Node n has children edges [edge_begin[n], edge_begin[n+1]) sorted by byte; node_id[n] is the
-// token id ending at that node or 0xFFFFFFFF.  Node 0 = root for word-initial pieces, node 1 =
-// root for continuation pieces (vocab keys starting with continuing_subword_prefix, stored
-// without the prefix).
+// Byte trie for WordPiece longest-match (models/wordpiece/mod.rs:224-283), flattened into the same
+// 2-choice cuckoo layout as the merge table: key (parent node, byte) -> (child node, token id ending
+// at the child or 0xFFFFFFFF).  Node 0 = root for word-initial pieces, node 1 = root for continuation
+// pieces (vocab keys starting with continuing_subword_prefix, stored without the prefix).
 struct ByteTrie {
-    std::vector<uint32_t> edge_begin;  // [n_nodes+1]
-    std::vector<uint8_t> edge_byte;    // [n_edges]
-    std::vector<uint32_t> edge_child;  // [n_edges]
-    std::vector<uint32_t> node_id;     // [n_nodes]
-    // dense first-level fan-out for the two roots: child node for each first byte (0 = none)
-    std::vector<uint32_t> root_child;  // [2*256]
+    std::vector<MergeSlot> table;   // a = parent, b = byte, rank = child, new_id = token id
+    uint32_t mask = 0, seed = 0;
+    uint32_t n_nodes = 0;
 };
 
 struct AddedToken {
@@ -64,6 +60,10 @@ struct HostModel {
     uint32_t vocab_size = 0;            // number of vocab entries
     uint32_t n_merges = 0;
     std::vector<AddedToken> added_tokens;
+    // added-token contents sorted by first byte (device-side occurrence scan)
+    std::vector<uint8_t> at_blob;
+    std::vector<uint32_t> at_off;      // [n_patterns+1]
+    std::vector<uint32_t> at_first;    // [257] CSR over the first byte
 
     // ---- tables copied to the device ----
     uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level)

@@ -25,10 +25,12 @@ namespace tkamd {
 // Replaces: the per-document loop of TokenizerImpl::encode_batch (tokenizer/mod.rs:1345-1348); a
 // document boundary is a hard text boundary for every pre-tokenizer rule below.
 // =================================================================================================
-__global__ void k_mark_doc_starts(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
+__global__ void k_mark_doc_starts(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes_host,
+                                  const int64_t* __restrict__ len_dev,
                                   unsigned long long* __restrict__ docmask, int* __restrict__ err) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > n_docs) return;
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // normalised text: length lives on the device
     int64_t g = doc_off[d];
     if (d == 0 && g != 0) atomicOr(err, ERR_BAD_OFFSETS);
     if (d == n_docs) {
@@ -38,6 +40,29 @@ __global__ void k_mark_doc_starts(const int64_t* __restrict__ doc_off, int64_t n
     int64_t g1 = doc_off[d + 1];
     if (g < 0 || g1 < g || g1 > n_bytes) { atomicOr(err, ERR_BAD_OFFSETS); return; }
     if (g < n_bytes) atomicOr(&docmask[g >> 6], 1ull << (g & 63));
+}
+
+// =================================================================================================
+// K_added_token_scan: does any added/special token occur in the text?  The reference splits the
+// input on them before everything else (AddedVocabulary::extract_and_normalize,
+// tokenizer/added_vocabulary.rs:523-564; find_matches :430-490).  That split is not built on the device
+// yet, so a batch in which one occurs is REFUSED (ERR_ADDED_TOKEN) instead of being tokenised wrongly.
+// One lane per byte: first-byte CSR filter, then a bounded compare per candidate pattern.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_added_token_scan(const uint8_t* __restrict__ text, int64_t n_bytes,
+                                                          const uint8_t* __restrict__ pat_blob, const uint32_t* __restrict__ pat_off,
+                                                          const uint32_t* __restrict__ first_idx, int* __restrict__ err) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_bytes) return;
+    uint32_t b = text[i];
+    uint32_t lo = first_idx[b], hi = first_idx[b + 1];
+    for (uint32_t k = lo; k < hi; ++k) {
+        uint32_t o = pat_off[k], l = pat_off[k + 1] - o;
+        if (i + l > n_bytes) continue;
+        uint32_t j = 1;
+        while (j < l && text[i + j] == pat_blob[o + j]) ++j;
+        if (j == l) { atomicOr(err, ERR_ADDED_TOKEN); return; }
+    }
 }
 
 // =================================================================================================
@@ -185,6 +210,153 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
 }
 
 // =================================================================================================
+// K_pretok_local<KIND>: pre-tokenizers whose split rule only looks at the class of a code point and
+// of its predecessor; matches are kept, everything else is REMOVED, so a second bitmask marks ends.
+//   PT_WHITESPACE       \w+|[^\w\s]+ via Invert + Removed            (pre_tokenizers/whitespace.rs:20-29)
+//   PT_WHITESPACE_SPLIT char::is_whitespace, Removed                  (whitespace.rs:35-41)
+//   PT_BERT             whitespace Removed, then is_bert_punc Isolated (pre_tokenizers/bert.rs:5-17)
+// class: 0 = removed (whitespace), 1 / 2 = run classes, 3 = isolated (each code point its own split).
+//   start[i] = cls != 0 && (doc start || prev != cls || cls == 3)
+//   end[i]   = prev != 0 && (doc start || text end || cls != prev || prev == 3)     (exclusive end)
+// =================================================================================================
+template <int KIND>
+__device__ __forceinline__ uint32_t cls_local(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
+    uint32_t f;
+    if (cp < 0x80u) {
+        // ASCII shortcuts consistent with the generated table (checked by tests): \w = [A-Za-z0-9_],
+        // whitespace = SP \t \n \v \f \r, bert punctuation = the 32 ASCII punctuation marks
+        bool ws = (cp == 0x20u || cp - 9u < 5u);
+        if (ws) return 0;
+        if (KIND == PT_WHITESPACE_SPLIT) return 1;
+        bool alnum = ((cp | 0x20u) - 'a' < 26u) || (cp - '0' < 10u);
+        if (KIND == PT_WHITESPACE) return (alnum || cp == '_') ? 1u : 2u;
+        bool punct = (cp - 33u < 15u) || (cp - 58u < 7u) || (cp - 91u < 6u) || (cp - 123u < 4u);
+        return punct ? 3u : 1u;
+    }
+    f = uc_flags(cp, uc1, uc2);
+    if (KIND == PT_WHITESPACE) return (f & UC_RX_W) ? 1u : (f & UC_RX_S) ? 0u : 2u;
+    if (KIND == PT_WHITESPACE_SPLIT) return (f & UC_RUST_WS) ? 0u : 1u;
+    return (f & UC_RUST_WS) ? 0u : (f & UC_BERT_P) ? 3u : 1u;
+}
+
+constexpr int PL_HALO = 4;
+constexpr int PL_R = PT_TILE + 2 * PL_HALO;
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_pretok_local(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                      const int64_t* __restrict__ len_dev,
+                                                      const unsigned long long* __restrict__ docmask,
+                                                      const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                      unsigned long long* __restrict__ startmask,
+                                                      unsigned long long* __restrict__ endmask) {
+    __shared__ uint8_t sb[PL_R + 8];
+    __shared__ uint8_t si[PL_R + 8];
+    const int tid = (int)threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
+    const int64_t r0 = t0 - PL_HALO;
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // effective text length
+    for (int k = tid; k < PL_R + 8; k += 256) {
+        int64_t g = r0 + k;
+        sb[k] = (g >= 0 && g < n_bytes) ? text[g] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int k = tid; k < PL_R; k += 256) {
+        int64_t g = r0 + k;
+        uint32_t info = 0;
+        if (g >= 0 && g < n_bytes) {
+            uint32_t b = sb[k];
+            info = IF_VALID;
+            if ((docmask[g >> 6] >> (g & 63)) & 1ull) info |= IF_DOC;
+            if ((b & 0xC0u) != 0x80u) {
+                uint32_t len;
+                uint32_t cp = utf8_at(sb, k, &len);
+                info |= IF_LEAD | cls_local<KIND>(cp, uc1, uc2);
+            }
+        }
+        si[k] = (uint8_t)info;
+    }
+    __syncthreads();
+    for (int it = 0; it < PT_TILE / 256; ++it) {
+        int k = PL_HALO + it * 256 + tid;
+        int64_t g = t0 + it * 256 + tid;
+        uint32_t info = si[k];
+        bool lead = (info & (IF_VALID | IF_LEAD)) == (IF_VALID | IF_LEAD);
+        bool at_end = (g == n_bytes);
+        bool start = false, end = false;
+        if (lead || at_end) {
+            uint32_t c = lead ? (info & IF_CLS) : 0u;
+            uint32_t pc = 0;
+            if (g > 0) {
+                int j = k - 1;
+                if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) --j; } }
+                pc = si[j] & IF_CLS;
+            }
+            bool doc = lead && (info & IF_DOC);
+            start = lead && c != 0 && (doc || pc != c || c == 3);
+            end = pc != 0 && (doc || at_end || c != pc || pc == 3);
+        }
+        uint64_t ms = __ballot(start), me = __ballot(end);
+        if ((tid & 63) == 0 && g <= n_bytes_host) { startmask[g >> 6] = ms; endmask[g >> 6] = me; }
+    }
+}
+template __global__ void k_pretok_local<PT_WHITESPACE>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
+template __global__ void k_pretok_local<PT_WHITESPACE_SPLIT>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
+template __global__ void k_pretok_local<PT_BERT>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
+
+// =================================================================================================
+// BertNormalizer on ASCII text (normalizers/bert.rs:92-138): clean_text drops control characters and
+// maps \t \n \r to ' ', lowercase folds A-Z; handle_chinese_chars / strip_accents cannot fire on ASCII.
+// Pass 1 (k_norm_keepmask): keep bitmask, non-ASCII raises ERR_NON_ASCII_NORM.  Pass 2 (k_norm_scatter):
+// stream-compact into norm_text with norm_orig[k] = original byte index of normalized byte k (offsets
+// are reported through this map, never recomputed from lengths -- SURVEY 8c cheat-sheet).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_norm_keepmask(const uint8_t* __restrict__ text, int64_t n_bytes, uint32_t clean,
+                                                       unsigned long long* __restrict__ keepmask, int* __restrict__ err) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool keep = false;
+    if (i < n_bytes) {
+        uint32_t b = text[i];
+        if (b >= 0x80u) atomicOr(err, ERR_NON_ASCII_NORM);
+        keep = !clean || !((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu);
+    }
+    uint64_t m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0 && i <= n_bytes) keepmask[i >> 6] = m;
+}
+__global__ __launch_bounds__(256) void k_norm_scatter(const uint8_t* __restrict__ text, int64_t n_bytes, uint32_t clean, uint32_t lower,
+                                                      const unsigned long long* __restrict__ keepmask, const uint32_t* __restrict__ kprefix,
+                                                      uint8_t* __restrict__ ntext, uint32_t* __restrict__ norig) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_bytes) return;
+    unsigned long long m = keepmask[i >> 6];
+    int b = (int)(i & 63);
+    if ((m >> b) & 1ull) {
+        uint32_t r = kprefix[i >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+        uint32_t c = text[i];
+        if (clean && (c == '\t' || c == '\n' || c == '\r')) c = ' ';
+        if (lower && c - 'A' < 26u) c += 32u;
+        ntext[r] = (uint8_t)c;
+        norig[r] = (uint32_t)i;
+    }
+}
+// document CSR in normalized coordinates: ndoc_off[d] = #kept bytes before doc_off[d]
+__global__ void k_norm_doc_offsets(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
+                                   const unsigned long long* __restrict__ keepmask, const uint32_t* __restrict__ kprefix,
+                                   const int64_t* __restrict__ n_kept, int64_t* __restrict__ ndoc_off) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    int64_t g = doc_off[d];
+    if (g < 0) g = 0;
+    int64_t r;
+    if (g >= n_bytes) r = *n_kept;
+    else {
+        unsigned long long m = keepmask[g >> 6];
+        int b = (int)(g & 63);
+        r = (int64_t)kprefix[g >> 6] + __popcll(m & ((1ull << b) - 1ull));
+    }
+    ndoc_off[d] = r;
+}
+
+// =================================================================================================
 // Prefix sums over the start bitmask (popcount per 64-byte word), then offsets emission.
 // Replaces: the Vec<Split> a PreTokenizedString accumulates (tokenizer/pre_tokenizer.rs:73-103);
 // here the "splits" of the whole batch are one u32 array pt_start[P+1] (pt_start[P] = n_bytes).
@@ -255,6 +427,21 @@ __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* _
     if ((m >> b) & 1ull) {
         uint32_t r = wprefix[i >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
         pt_start[r] = (uint32_t)i;
+    }
+}
+
+// exclusive end of every pre-token for the "Removed" pre-tokenizers: an end bit at byte i closes the
+// pre-token that started most recently before i
+__global__ __launch_bounds__(256) void k_emit_pretok_end(const unsigned long long* __restrict__ startmask,
+                                                         const unsigned long long* __restrict__ endmask,
+                                                         const uint32_t* __restrict__ wprefix, int64_t n_bytes,
+                                                         uint32_t* __restrict__ pt_end) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > n_bytes) return;
+    int b = (int)(i & 63);
+    if ((endmask[i >> 6] >> b) & 1ull) {
+        uint32_t r = wprefix[i >> 6] + (uint32_t)__popcll(startmask[i >> 6] & ((1ull << b) - 1ull));
+        pt_end[r - 1] = (uint32_t)i;
     }
 }
 
@@ -581,6 +768,103 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
 }
 
 // =================================================================================================
+// K_wordlevel: one hash probe per pre-token.  Replaces WordLevel::tokenize (models/wordlevel/mod.rs:162-178):
+// vocab hit -> its id; miss -> unk_token id; miss without unk_token -> Error::MissingUnkToken.
+// Keys <= 16 bytes live in the whole-word cuckoo table, longer ones in an open-addressing table over
+// the vocabulary blob.
+// =================================================================================================
+__device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __restrict__ w, uint32_t len, uint32_t* id) {
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < len; ++i) { h ^= w[i]; h *= 16777619u; }
+    h &= t.long_mask;
+    for (;;) {
+        uint32_t e = t.long_table[h];
+        if (!e) return false;
+        uint32_t o = t.long_off[e - 1], l = t.long_off[e] - o;
+        if (l == len) {
+            uint32_t i = 0;
+            while (i < len && t.long_blob[o + i] == w[i]) ++i;
+            if (i == len) { *id = t.long_id[e - 1]; return true; }
+        }
+        h = (h + 1) & t.long_mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wordlevel(DevTables t, const uint8_t* __restrict__ text,
+                                                   const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
+                                                   const int64_t* __restrict__ n_pretok,
+                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok, int* __restrict__ err) {
+    const int64_t P = *n_pretok;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
+        uint32_t id = 0, fl;
+        bool hit;
+        if (len <= (uint32_t)WORD_MAX_KEY) {
+            uint64_t lo, hi;
+            load_key16(text, s, len, &lo, &hi);
+            hit = word_probe(t, lo, hi, len, &id, &fl);
+        } else hit = long_probe(t, text + s, len, &id);
+        if (!hit) {
+            if (t.has_unk) id = t.unk_id;
+            else atomicOr(err, ERR_MISSING_UNK);
+        }
+        tok0[p] = id;
+        ntok[p] = 1;
+    }
+}
+
+// =================================================================================================
+// K_wordpiece: greedy longest-match-first, one lane per pre-token walking the byte trie.
+// Replaces WordPiece::tokenize (models/wordpiece/mod.rs:224-283): words over max_input_chars_per_word
+// CHARS -> [unk]; at every position the longest vocab piece (with the continuing_subword_prefix root
+// after the first piece); if any position has no piece the WHOLE word is one [unk] (:262-279).  The
+// reference shrinks the candidate from the right one char at a time; a byte-trie walk that remembers
+// the deepest node carrying an id finds the same piece because vocab entries and text are both valid
+// UTF-8 (a full-entry byte match ends on a char boundary).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text,
+                                                   const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
+                                                   const int64_t* __restrict__ n_pretok,
+                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
+    const int64_t P = *n_pretok;
+    DevTables tt = t;
+    tt.merges = t.trie; tt.merge_mask = t.trie_mask; tt.merge_seed = t.trie_seed;     // reuse the pair probe
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
+        uint32_t chars = 0;
+        for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
+        bool bad = chars > t.max_input_chars;
+        uint32_t pos = 0, j = 0, first = 0;
+        while (!bad && pos < len) {
+            uint32_t node = pos ? 1u : 0u, q = pos, best_end = 0, best_id = 0;
+            while (q < len) {
+                uint32_t child, id;
+                merge_probe(tt, node, (uint32_t)text[s + q], &child, &id);
+                if (child == RANK_NONE) break;
+                node = child;
+                ++q;
+                if (id != 0xFFFFFFFFu) { best_end = q; best_id = id; }
+            }
+            if (!best_end) { bad = true; break; }
+            if (j == 0) first = best_id;
+            else tmp_ids[s + j] = best_id;
+            if (tmp_end) tmp_end[s + j] = best_end;
+            pos = best_end;
+            ++j;
+        }
+        if (bad) {
+            if (!t.has_unk) atomicOr(err, ERR_MISSING_UNK);
+            first = t.unk_id;
+            j = 1;
+            if (tmp_end) tmp_end[s] = len;
+        }
+        tok0[p] = first;
+        ntok[p] = j;
+    }
+}
+
+// =================================================================================================
 // Token compaction: exclusive scan of ntok[P] -> ids[T] and the per-document token CSR.
 // Replaces: PreTokenizedString::into_encoding + Encoding::from_iter (tokenizer/pre_tokenizer.rs:198-263,
 // tokenizer/encoding.rs:541-562) for the whole batch at once.
@@ -656,9 +940,13 @@ __global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n
 // =================================================================================================
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
 
+void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
+                              unsigned long long* docmask, int* err) {
+    hipLaunchKernelGGL(k_mark_doc_starts, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, len_dev, docmask, err);
+}
 void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                             unsigned long long* docmask, int* err) {
-    hipLaunchKernelGGL(k_mark_doc_starts, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, docmask, err);
+    launch_mark_doc_starts_n(st, doc_off, n_docs, n_bytes, nullptr, docmask, err);
 }
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask) {
@@ -690,6 +978,44 @@ void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, c
         hipLaunchKernelGGL(k_bpe_merge<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
     else
         hipLaunchKernelGGL(k_bpe_merge<64>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+}
+template <int KIND>
+static void launch_pretok_local_t(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                                  const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask) {
+    hipLaunchKernelGGL(k_pretok_local<KIND>, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+}
+void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask) {
+    if (kind == PT_WHITESPACE) launch_pretok_local_t<PT_WHITESPACE>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+    else if (kind == PT_WHITESPACE_SPLIT) launch_pretok_local_t<PT_WHITESPACE_SPLIT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+    else launch_pretok_local_t<PT_BERT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+}
+void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
+                            const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end) {
+    hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
+}
+void launch_norm_keepmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, unsigned long long* keepmask, int* err) {
+    hipLaunchKernelGGL(k_norm_keepmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, clean, keepmask, err);
+}
+void launch_norm_scatter(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, uint32_t lower,
+                         const unsigned long long* keepmask, const uint32_t* kprefix, uint8_t* ntext, uint32_t* norig) {
+    hipLaunchKernelGGL(k_norm_scatter, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, text, n_bytes, clean, lower, keepmask, kprefix, ntext, norig);
+}
+void launch_norm_doc_offsets(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const unsigned long long* keepmask,
+                             const uint32_t* kprefix, const int64_t* n_kept, int64_t* ndoc_off) {
+    hipLaunchKernelGGL(k_norm_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, keepmask, kprefix, n_kept, ndoc_off);
+}
+void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err) {
+    hipLaunchKernelGGL(k_wordlevel, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, err);
+}
+void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end, int* err) {
+    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, tmp_ids, tmp_end, err);
+}
+void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
+                             const uint32_t* first_idx, int* err) {
+    hipLaunchKernelGGL(k_added_token_scan, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, text, n_bytes, pat_blob, pat_off, first_idx, err);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {

@@ -24,12 +24,9 @@ struct DevTables {
     const uint32_t* long_id;
     const uint32_t* long_table;
     uint32_t long_mask;
-    // WordPiece trie
-    const uint32_t* trie_edge_begin;
-    const uint8_t* trie_edge_byte;
-    const uint32_t* trie_edge_child;
-    const uint32_t* trie_node_id;
-    const uint32_t* trie_root_child;
+    // WordPiece trie as a pair table: (parent node, byte) -> (child, token id)
+    const MergeSlot* trie;
+    uint32_t trie_mask, trie_seed;
     uint32_t max_input_chars;
 };
 
@@ -62,6 +59,23 @@ void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const 
                             uint32_t* listL, uint32_t* counters);
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
+void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
+                              unsigned long long* docmask, int* err);
+void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask);
+void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
+                            const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end);
+void launch_norm_keepmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, unsigned long long* keepmask, int* err);
+void launch_norm_scatter(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, uint32_t lower,
+                         const unsigned long long* keepmask, const uint32_t* kprefix, uint8_t* ntext, uint32_t* norig);
+void launch_norm_doc_offsets(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const unsigned long long* keepmask,
+                             const uint32_t* kprefix, const int64_t* n_kept, int64_t* ndoc_off);
+void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err);
+void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
+void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
+                             const uint32_t* first_idx, int* err);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
