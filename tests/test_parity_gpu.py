@@ -13,7 +13,7 @@ from tests.helpers import load_tokenizer_json, load_vectors
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
-GPU_GOLDEN = ["gpt2_synth_50257", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
+GPU_GOLDEN = ["gpt2_synth_50257", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
 
 
 @pytest.fixture(scope="module")
@@ -183,3 +183,35 @@ def test_added_token_in_text_is_refused():
     assert len(tok.encode_batch_fast(["no specials here [ ] UNK", "[unk]"], add_special_tokens=False)) == 2
     with pytest.raises(ta.UnsupportedError, match="added/special token"):
         tok.encode_batch_fast(["fine", "has [SEP] inside"], add_special_tokens=False)
+
+
+def test_llama3_vs_oracle():
+    import tokenizers_amd as ta
+    js = load_tokenizer_json("llama3_small_6000")
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    long_runs = ["1" * 500, " " * 400 + "x", "a" + "\n" * 300 + "b", "x" + " \t\r\n" * 90 + "y", "9" * 131 + " " + "8" * 7,
+                 "!" * 300 + "\n\n\nz", "\u3000" * 200 + "w", "1234567890" * 30 + "'s", "tail   ", "   ", "\n", "'S'T'RE'Ve'm'LL'd",
+                 "it'\u017f ok", "K\u212a'\u212a", "a\t'sb", "don't!\n\n  x", "\r\n\r\n", "a \n b", "x\n y", "p!\nq", "p !\n\nq"]
+    docs = synth.gen_lines(20000, text_seed=17) + synth.stress_lines(seed=6, n=5000) + long_runs
+    got = tok.encode_batch_fast(docs, add_special_tokens=False)
+    exp = o.encode_batch(docs)
+    _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(docs))], docs)
+    assert tok.queue_sizes()["pretok_slow_docs"] > 0      # the long runs went through the sequential path
+    # a batch of plain text must stay entirely on the tile kernel
+    tok.encode_batch_fast(synth.gen_lines(5000, text_seed=18, special_frac=0.0), add_special_tokens=False)
+    assert tok.queue_sizes()["pretok_slow_docs"] == 0
+
+
+def test_bytelevel_no_regex_vs_oracle():
+    import json
+    import tokenizers_amd as ta
+    d = json.loads(load_tokenizer_json("llama3_small_6000"))
+    d["pre_tokenizer"] = {"type": "ByteLevel", "add_prefix_space": False, "trim_offsets": True, "use_regex": False}
+    js = json.dumps(d)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    docs = [l[:40] for l in synth.gen_lines(3000, text_seed=19)] + ["", "a", "hello world", "x" * 200]
+    got = tok.encode_batch_fast(docs, add_special_tokens=False)
+    exp = o.encode_batch(docs)
+    _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(docs))], docs)

@@ -85,7 +85,7 @@ struct tkamd_tokenizer {
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -283,11 +283,12 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         throw Unsupported("offsets / word ids are not produced by this build yet (use TKAMD_OFFSETS_NONE)");
     if (hm.byte_level && hm.add_prefix_space)
         throw Unsupported("ByteLevel add_prefix_space=true is not built yet");
-    const bool bpe_path = hm.model == MODEL_BPE && hm.pretok == PT_BYTELEVEL_GPT2;
+    const bool bpe_path = hm.model == MODEL_BPE && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
     const bool local_pretok = hm.pretok == PT_WHITESPACE || hm.pretok == PT_WHITESPACE_SPLIT || hm.pretok == PT_BERT;
     const bool word_models = (hm.model == MODEL_WORDLEVEL || hm.model == MODEL_WORDPIECE) && local_pretok;
     if (!bpe_path && !word_models)
-        throw Unsupported("this build covers ByteLevel(GPT-2 regex)+BPE and {Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
+        throw Unsupported("this build covers {ByteLevel(GPT-2 regex), Llama-3 Split+ByteLevel, ByteLevel(no regex)}+BPE and "
+                          "{Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
 
     reserve_workspace(t, n_bytes, n_docs, flags);
     int64_t* sc = t->w_scalars.as<int64_t>();
@@ -361,10 +362,20 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     pf.end();
 
     uint32_t* pt_end = nullptr;
-    if (bpe_path) {
+    if (hm.pretok == PT_BYTELEVEL_GPT2) {
         pf.begin("pretok_gpt2");
         launch_pretok_gpt2(st, x_text, n_bytes, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>());
         pf.end();
+    } else if (hm.pretok == PT_LLAMA3) {
+        t->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
+        t->w_slow_docs.reserve((size_t)(n_docs + 1) * 4);
+        pf.begin("pretok_llama3");
+        launch_pretok_llama3(st, x_text, n_bytes, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(),
+                             t->w_endmask.as<ull>(), x_doc_off, n_docs, t->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
+        pf.end();
+    } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
+        // ByteLevel(use_regex=false): every document is one pre-token (byte_level.rs:128-130)
+        HIP_CHECK(hipMemcpyAsync(t->w_startmask.p, t->w_docmask.p, (size_t)W * 8, hipMemcpyDeviceToDevice, st));
     } else {
         t->w_endmask.reserve((size_t)(W + 1) * 8);
         t->w_pt_end.reserve(((size_t)n_bytes + 4) * 4);
@@ -454,6 +465,7 @@ int error_from_bits(int bits) {
         return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text: the AddedVocabulary split "
                                                 "(added_vocabulary.rs:523-564) is not built on the device yet");
     if (bits & ERR_NON_ASCII_NORM) return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer on non-ASCII text is not built yet");
+    if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal work queue overflow");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
 }
@@ -515,7 +527,7 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
                          &t->t_long_id, &t->t_long_table, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }

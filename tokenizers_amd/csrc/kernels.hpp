@@ -36,11 +36,12 @@ enum : int {
     ERR_PRETOKEN_TOO_LONG = 2,    // a pre-token exceeds LONG_PT_MAX symbols
     ERR_ADDED_TOKEN = 4,          // an added/special token occurs in the text (AddedVocabulary split needed)
     ERR_NON_ASCII_NORM = 8,       // BertNormalizer on non-ASCII text (full-Unicode path not built yet)
-    ERR_MISSING_UNK = 16,         // model needed unk_token but the vocab has none (MissingUnkToken)
+    ERR_MISSING_UNK = 16,
+    ERR_INTERNAL = 32,            // an internal work queue overflowed (bug guard)         // model needed unk_token but the vocab has none (MissingUnkToken)
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_COUNT = 8 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_SLOW_POS = 3, CNT_SLOW_DOCS = 4, CNT_COUNT = 8 };
 
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident)
 
@@ -76,6 +77,9 @@ void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_
                       const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err);
+void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+                          const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
+                          const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
