@@ -39,13 +39,17 @@ def char_to_byte(text):
 
 def vectors(tok: Tokenizer, docs):
     encs = tok.encode_batch(docs, add_special_tokens=False)
-    ids, offs, words = [], [], []
+    ids, offs, coffs, words = [], [], [], []
     for d, e in zip(docs, encs):
         m = char_to_byte(d)
         ids.append(e.ids)
+        coffs.append([[a, b] for a, b in e.offsets])
         offs.append([[m[a], m[b]] for a, b in e.offsets])
         words.append(e.word_ids)
-    return {"docs": docs, "ids": ids, "offsets": offs, "words": words, "reference": f"tokenizers=={tokenizers.__version__}"}
+    # "offsets_char" is what the wheel returns (Python encode_batch = char offsets); "offsets" is its
+    # conversion to bytes, valid whenever no offset trimming post-processor is involved
+    return {"docs": docs, "ids": ids, "offsets": offs, "offsets_char": coffs, "words": words,
+            "reference": f"tokenizers=={tokenizers.__version__}"}
 
 
 def emit(name, tok_json, docs):

@@ -169,7 +169,8 @@ enum { N_NONE = 0, N_BERT = 1 };
 
 typedef struct oracle_tok {
     int model, pretok, norm;
-    int byte_level, add_prefix_space, ignore_merges, trim_offsets;
+    int byte_level, add_prefix_space, ignore_merges, trim_offsets, pp_add_prefix_space;
+    int char_offsets;               /* OffsetType::Char (BytesToCharOffsetConverter, pre_tokenizer.rs:329-364) */
     int has_unk; uint32_t unk_id;
     uint8_t cont_prefix[16]; int cont_prefix_len;
     int max_input_chars;
@@ -200,6 +201,8 @@ oracle_tok* oracle_new(int model, int pretok, int norm, int add_prefix_space, in
     for (int b = 0; b < 256; ++b) t->b2c[b] = direct[b] ? (uint32_t)b : 256 + n++;
     return t;
 }
+void oracle_set_char_offsets(oracle_tok* t, int on) { t->char_offsets = on; }
+void oracle_set_trim(oracle_tok* t, int trim, int pp_add_prefix_space) { t->trim_offsets = trim; t->pp_add_prefix_space = pp_add_prefix_space; }
 void oracle_free(oracle_tok* t) {
     if (!t) return;
     strmap_free(&t->vocab);
@@ -615,6 +618,8 @@ static int bert_normalize_ascii(const uint8_t* s, int64_t n, uint8_t* out, int64
     return 0;
 }
 
+static int64_t count_chars(const uint8_t* s, int64_t pos) { int64_t c = 0; for (int64_t i = 0; i < pos; ++i) c += (s[i] & 0xC0) != 0x80; return c; }
+
 /* Encode one document.  Offsets are BYTE offsets into the original document (OffsetType::Byte). */
 static int encode_doc(const oracle_tok* t, const uint8_t* text, int64_t n, enc_out* out, splits* sp_out) {
     const uint8_t* s = text;
@@ -645,6 +650,7 @@ static int encode_doc(const oracle_tok* t, const uint8_t* text, int64_t n, enc_o
         default: rc = ORACLE_ERR_UNSUPPORTED;
     }
     toklist tl = {0};
+    const int64_t doc_first_tok = out->n;
     uint8_t* mapped = NULL; int64_t* mo = NULL;
     for (int64_t k = 0; k < sp.n && !rc; ++k) {
         int64_t a = sp.s[k], b = sp.e[k];
@@ -674,6 +680,21 @@ static int encode_doc(const oracle_tok* t, const uint8_t* text, int64_t n, enc_o
                     bs = bs == 0 ? 0 : bs - 1;
                     be = be <= 1 ? first_len : be - 1;
                 }
+                if (t->char_offsets) { bs = count_chars(text, bs); be = count_chars(text, be); }
+                if (t->trim_offsets) {
+                    /* ByteLevel post-processor process_offsets (byte_level.rs:202-234): strip leading / trailing
+                     * 'G-dot' (mapped space) chars of the token from its offsets */
+                    int64_t ts = mo[tl.s[q]], te = (tl.e[q] > 0 ? mo[tl.e[q] - 1] + 1 : ts);
+                    int64_t lead = 0, trail = 0;
+                    while (ts + lead < te && s[ts + lead] == ' ') lead++;
+                    while (trail < te - ts && s[te - 1 - trail] == ' ') trail++;
+                    if (lead > 0) {
+                        int is_first = (out->n == doc_first_tok) || bs == 0;
+                        if (is_first && t->pp_add_prefix_space && lead == 1) lead = 0;
+                        bs = bs + lead < be ? bs + lead : be;
+                    }
+                    if (trail > 0 && be >= trail) be = be - trail > bs ? be - trail : bs;
+                }
                 eo_push(out, tl.id[q], bs, be, (uint32_t)k);
             }
         } else {
@@ -684,6 +705,7 @@ static int encode_doc(const oracle_tok* t, const uint8_t* text, int64_t n, enc_o
             for (int64_t q = 0; q < tl.n && !rc; ++q) {
                 int64_t bs = a + tl.s[q], be = a + tl.e[q];
                 if (orig) { int64_t ob = orig[bs]; int64_t oe = orig[be - 1] + 1; bs = ob; be = oe; }
+                if (t->char_offsets) { bs = count_chars(text, bs); be = count_chars(text, be); }
                 eo_push(out, tl.id[q], bs, be, (uint32_t)k);
             }
         }

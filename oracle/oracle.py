@@ -42,6 +42,8 @@ def lib() -> C.CDLL:
         L.oracle_new.argtypes = [i32] * 6
         L.oracle_new.restype = vp
         L.oracle_free.argtypes = [vp]
+        L.oracle_set_trim.argtypes = [vp, i32, i32]
+        L.oracle_set_char_offsets.argtypes = [vp, i32]
         L.oracle_set_vocab.argtypes = [vp, vp, vp, vp, i64]
         L.oracle_set_unk.argtypes = [vp, C.c_char_p, i64]
         L.oracle_set_wordpiece.argtypes = [vp, C.c_char_p, i64, i32]
@@ -126,9 +128,10 @@ class Oracle:
             assert d["normalizer"]["type"] == "BertNormalizer"
             nk = 1
         pp = d.get("post_processor") or {}
-        trim = int(pp.get("trim_offsets", False)) if pp.get("type") in ("ByteLevel", "RobertaProcessing") else 0
+        trim = int(pp.get("trim_offsets", True)) if pp.get("type") in ("ByteLevel", "RobertaProcessing") else 0
         self._L = L
         self._h = L.oracle_new(mk, pk, nk, aps, int(bool(model.get("ignore_merges", False))), trim)
+        L.oracle_set_trim(self._h, trim, int(pp.get("add_prefix_space", True)))
         toks = list(model["vocab"].items())
         blob, off = _pack([k.encode("utf-8") for k, _ in toks])
         ids = np.array([v for _, v in toks], dtype=np.uint32)
@@ -157,7 +160,9 @@ class Oracle:
             self._L.oracle_free(self._h)
             self._h = None
 
-    def encode_batch(self, docs: list[str]) -> OracleResult:
+    def encode_batch(self, docs: list[str], char_offsets: bool = False) -> OracleResult:
+        """ids + offsets (bytes, or chars like the Python binding's encode_batch) + word ids."""
+        self._L.oracle_set_char_offsets(self._h, int(char_offsets))
         blob, off = _pack([s.encode("utf-8") for s in docs])
         b = C.c_void_p()
         rc = self._L.oracle_encode_batch(self._h, blob.ctypes.data, off.ctypes.data, len(docs), C.byref(b))

@@ -156,13 +156,16 @@ def test_oracle_matches_golden(name):
     o = orc.Oracle(load_tokenizer_json(name))
     v = load_vectors(name)
     r = o.encode_batch(v["docs"])
-    trim = name == "bytelevel_prefix_trim_3000"       # the oracle reports untrimmed offsets
+    rc = o.encode_batch(v["docs"], char_offsets=True)
+    trims = name == "bytelevel_prefix_trim_3000"      # trimming is done in the offset unit in use: pin it in chars
     bad = []
     for i, doc in enumerate(v["docs"]):
         if r.doc_ids(i) != v["ids"][i] or r.doc_words(i) != v["words"][i]:
             bad.append((i, doc, r.doc_ids(i)[:8], v["ids"][i][:8]))
-        elif not trim and r.doc_offsets(i) != [tuple(x) for x in v["offsets"][i]]:
-            bad.append((i, doc, r.doc_offsets(i)[:8], v["offsets"][i][:8]))
+        elif rc.doc_offsets(i) != [tuple(x) for x in v["offsets_char"][i]]:
+            bad.append((i, doc, "char", rc.doc_offsets(i)[:8], v["offsets_char"][i][:8]))
+        elif not trims and r.doc_offsets(i) != [tuple(x) for x in v["offsets"][i]]:
+            bad.append((i, doc, "byte", r.doc_offsets(i)[:8], v["offsets"][i][:8]))
     assert not bad, f"{len(bad)} mismatches, first {bad[0]!r}"
 
 

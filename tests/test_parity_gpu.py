@@ -215,3 +215,58 @@ def test_bytelevel_no_regex_vs_oracle():
     got = tok.encode_batch_fast(docs, add_special_tokens=False)
     exp = o.encode_batch(docs)
     _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(docs))], docs)
+
+
+def _meta_compare(tok, o, docs):
+    for mode in ("byte", "char"):
+        got = tok.encode_batch_csr(docs, offsets=mode, word_ids=True)
+        exp = o.encode_batch(docs, char_offsets=(mode == "char"))
+        assert got.tok_offsets.tolist() == exp.tok_offsets.tolist()
+        assert (got.ids == exp.ids).all()
+        if not (got.word_ids == exp.words).all():
+            i = int(np.nonzero(got.word_ids != exp.words)[0][0])
+            d = int(np.searchsorted(exp.tok_offsets, i, side="right") - 1)
+            raise AssertionError(f"word ids differ in doc {d}: {docs[d]!r} got {got[d].word_ids} exp {exp.doc_words(d)}")
+        if not (got.offsets == exp.offsets).all():
+            i = int(np.nonzero((got.offsets != exp.offsets).any(axis=1))[0][0])
+            d = int(np.searchsorted(exp.tok_offsets, i, side="right") - 1)
+            raise AssertionError(f"{mode} offsets differ in doc {d}: {docs[d]!r} got {got[d].offsets} exp {exp.doc_offsets(d)}")
+
+
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"])
+def test_offsets_and_word_ids_vs_oracle(name):
+    import tokenizers_amd as ta
+    js = load_tokenizer_json(name)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    docs = synth.gen_lines(8000, text_seed=23) + synth.stress_lines(seed=8, n=3000) + ["", "i\u2b62j", " ", "a", "", "x" * 300, "\u4e2d\u6587 caf\u00e9", ""]
+    if name.startswith("bert"):
+        docs = _ascii_only(docs) + ["HE\x01LLO\tWorld!", "\x00hello", "hello\x01", "wor\x02ld x"]
+    _meta_compare(tok, o, docs)
+
+
+def test_trim_offsets_vs_oracle(gpt2_json):
+    import json
+    import tokenizers_amd as ta
+    d = json.loads(gpt2_json)
+    for aps in (True, False):
+        d["post_processor"] = {"type": "ByteLevel", "add_prefix_space": aps, "trim_offsets": True, "use_regex": True}
+        js = json.dumps(d)
+        tok = ta.Tokenizer.from_str(js, device=0)
+        o = orc.Oracle(js)
+        docs = synth.gen_lines(4000, text_seed=29) + synth.stress_lines(seed=10, n=2000) + [" a", "  a  ", " ", "   ", "a ", "\u3000 x"]
+        _meta_compare(tok, o, docs)
+
+
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000"])
+def test_encode_batch_matches_golden_char_offsets(name):
+    """Tokenizer.encode_batch == the wheel's encode_batch (ids, char offsets, word ids) on the committed vectors."""
+    import tokenizers_amd as ta
+    tok = ta.Tokenizer.from_str(load_tokenizer_json(name), device=0)
+    v = load_vectors(name)
+    got = tok.encode_batch(v["docs"], add_special_tokens=False)
+    for i, doc in enumerate(v["docs"]):
+        e = got[i]
+        assert e.ids == v["ids"][i], doc
+        assert [list(x) for x in e.offsets] == v["offsets_char"][i], doc
+        assert e.word_ids == v["words"][i], doc

@@ -85,7 +85,7 @@ struct tkamd_tokenizer {
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -112,7 +112,7 @@ struct tkamd_batch {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* ..7 */, SC_NCHARS = 8 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
 
 struct Prof {
     tkamd_tokenizer* t;
@@ -279,8 +279,10 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
                   uint32_t flags, hipStream_t st, tkamd_device_result* out) {
     HostModel& hm = t->hm;
     if (n_bytes >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
-    if ((flags & TKAMD_OFFSETS_MASK) || (flags & TKAMD_WANT_WORD_IDS))
-        throw Unsupported("offsets / word ids are not produced by this build yet (use TKAMD_OFFSETS_NONE)");
+    const uint32_t off_mode = flags & TKAMD_OFFSETS_MASK;
+    const bool want_words = (flags & TKAMD_WANT_WORD_IDS) != 0;
+    const bool want_meta = off_mode != TKAMD_OFFSETS_NONE || want_words;
+    if (off_mode == 3u) throw Invalid("bad offsets mode");
     if (hm.byte_level && hm.add_prefix_space)
         throw Unsupported("ByteLevel add_prefix_space=true is not built yet");
     const bool bpe_path = hm.model == MODEL_BPE && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
@@ -315,6 +317,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<ull>(), d_err);
         pf.end();
         HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
+        if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = t->w_offsets.as<uint32_t>();
+        if (want_words) out->d_word_ids = t->w_word_ids.as<uint32_t>();
         return;
     }
 
@@ -398,6 +402,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     pf.end();
 
     const int grid = t->n_cu * 8;
+    uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? t->w_tmp_end.as<uint32_t>() : nullptr;
     if (hm.model == MODEL_BPE) {
         size_t N = (size_t)n_bytes;
         uint32_t* list16 = t->w_lists.as<uint32_t>();
@@ -409,11 +414,11 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         pf.end();
         pf.begin("bpe_merge16");
         launch_bpe_merge(st, grid, 16, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge64");
         launch_bpe_merge(st, grid, 64, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr);
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         if (!t->long_prepared) {
             if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(long merge kernel LDS) failed");
@@ -421,7 +426,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         }
         pf.begin("bpe_merge_long");
         launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), listL, d_counters + CNT_LISTL,
-                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr, d_err);
+                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
         pf.end();
     } else if (hm.model == MODEL_WORDLEVEL) {
         pf.begin("wordlevel");
@@ -431,7 +436,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     } else {
         pf.begin("wordpiece");
         launch_wordpiece(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
-                         t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), nullptr, d_err);
+                         t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
         pf.end();
     }
     pf.begin("compact");
@@ -443,6 +448,44 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     launch_doc_tok_offsets(st, t->w_doc_pt.as<uint32_t>(), n_docs, t->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
                            t->w_tok_offsets.as<int64_t>());
     pf.end();
+    if (want_meta) {
+        MetaArgs a{};
+        a.x_text = x_text;
+        a.pt_start = t->w_pt_start.as<uint32_t>();
+        a.pt_end = pt_end;
+        a.ntok = t->w_ntok.as<uint32_t>();
+        a.pt_tokoff = t->w_pt_tokoff.as<uint32_t>();
+        a.tmp_end = tmp_end;
+        a.n_pretok = d_npretok;
+        a.doc_pt = t->w_doc_pt.as<uint32_t>();
+        a.n_docs = n_docs;
+        a.x_doc_off = x_doc_off;
+        a.doc_off = d_doc_off;
+        a.norig = (hm.norm == NORM_BERT) ? t->w_norig.as<uint32_t>() : nullptr;
+        a.byte_level = hm.byte_level;
+        a.trim_offsets = hm.byte_level && hm.trim_offsets;
+        a.pp_add_prefix_space = hm.pp_add_prefix_space;
+        a.want_offsets = off_mode != TKAMD_OFFSETS_NONE;
+        a.char_mode = off_mode == TKAMD_OFFSETS_CHAR;
+        a.want_words = want_words;
+        a.offsets = t->w_offsets.as<uint32_t>();
+        a.word_ids = t->w_word_ids.as<uint32_t>();
+        if (a.char_mode) {
+            t->w_leadmask.reserve((size_t)(W + 1) * 8);
+            t->w_lprefix.reserve((size_t)(W + 1) * 4);
+            pf.begin("leadmask_scan");
+            launch_leadmask(st, d_text, n_bytes, t->w_leadmask.as<ull>());
+            launch_mask_scan(st, t->w_leadmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_lprefix.as<uint32_t>(), sc + SC_NCHARS);
+            pf.end();
+            a.leadmask = t->w_leadmask.as<ull>();
+            a.lprefix = t->w_lprefix.as<uint32_t>();
+        }
+        pf.begin("token_meta");
+        launch_token_meta(st, grid, a);
+        pf.end();
+        if (a.want_offsets) out->d_offsets = a.offsets;
+        if (a.want_words) out->d_word_ids = a.word_ids;
+    }
     HIP_CHECK(hipGetLastError());
 }
 
@@ -527,7 +570,7 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
                          &t->t_long_id, &t->t_long_table, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }
@@ -602,6 +645,16 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         b->tok_offsets.resize((size_t)n_docs + 1);
         if (n_tok) HIP_CHECK(hipMemcpy(b->ids.data(), r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(b->tok_offsets.data(), r.d_tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        if (r.d_offsets) {
+            b->has_offsets = true;
+            b->offsets.resize((size_t)n_tok * 2);
+            if (n_tok) HIP_CHECK(hipMemcpy(b->offsets.data(), r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost));
+        }
+        if (r.d_word_ids) {
+            b->has_words = true;
+            b->word_ids.resize((size_t)n_tok);
+            if (n_tok) HIP_CHECK(hipMemcpy(b->word_ids.data(), r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
+        }
         *out = b.release();
         return TKAMD_OK;
     });

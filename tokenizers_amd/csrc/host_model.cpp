@@ -276,8 +276,10 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     const JsonValue* pp = root->get("post_processor");
     if (pp && !pp->is_null()) {
         std::string t = pp->get_str("type");
-        if (t == "ByteLevel") m.trim_offsets = pp->get_bool("trim_offsets", true);
-        else if (t == "RobertaProcessing") m.trim_offsets = pp->get_bool("trim_offsets", true);
+        if (t == "ByteLevel" || t == "RobertaProcessing") {
+            m.trim_offsets = pp->get_bool("trim_offsets", true);
+            m.pp_add_prefix_space = pp->get_bool("add_prefix_space", true);
+        }
     }
 
     // ---- added tokens ----

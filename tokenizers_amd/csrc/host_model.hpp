@@ -46,6 +46,7 @@ struct HostModel {
     bool byte_level = false;      // model strings are in the GPT-2 byte alphabet
     bool add_prefix_space = false;
     bool trim_offsets = false;    // ByteLevel *post-processor* option (byte_level.rs:175-234)
+    bool pp_add_prefix_space = true;  // the post-processor's own add_prefix_space (process_offsets argument)
     // BertNormalizer options (normalizers/bert.rs:62-90)
     bool bn_clean_text = true, bn_handle_chinese = true, bn_strip_accents = true, bn_lowercase = true;
 

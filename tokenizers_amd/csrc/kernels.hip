@@ -1277,6 +1277,83 @@ __global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n
 }
 
 // =================================================================================================
+// K_token_meta: per-token (start, end) offsets and word ids.
+// Replaces the per-token half of PreTokenizedString::into_encoding (tokenizer/pre_tokenizer.rs:231-256):
+//   offsets = split.offsets_original().0 + convert_offsets(Normalized(token.offsets))   (:237-241)
+//   word    = index of the split inside the document                                     (:252-256)
+// plus BytesToCharOffsetConverter for OffsetType::Char (:329-364) and the ByteLevel post-processor's
+// process_offsets (pre_tokenizers/byte_level.rs:202-234) when trim_offsets is set.
+// Byte-level rule (byte_level.rs:135-143, tests/offsets.rs:47-57): a token that covers only part of a
+// multi-byte char reports the whole char, so starts snap back and ends snap forward to char boundaries.
+// One lane per pre-token; the document of a pre-token is found by binary search over doc_pt.
+// =================================================================================================
+__device__ __forceinline__ uint32_t lead_rank(const unsigned long long* __restrict__ leadmask, const uint32_t* __restrict__ lprefix, uint32_t pos) {
+    unsigned long long m = leadmask[pos >> 6];
+    uint32_t b = pos & 63u;
+    return lprefix[pos >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void k_leadmask(const uint8_t* __restrict__ text, int64_t n_bytes, unsigned long long* __restrict__ leadmask) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool lead = (i < n_bytes) && ((text[i] & 0xC0u) != 0x80u);
+    uint64_t m = __ballot(lead);
+    if ((threadIdx.x & 63) == 0 && i <= n_bytes) leadmask[i >> 6] = m;
+}
+
+__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
+    const int64_t P = *a.n_pretok;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const uint32_t c = a.ntok[p];
+        if (!c) continue;
+        const uint32_t o = a.pt_tokoff[p];
+        const uint32_t s = a.pt_start[p], e = a.pt_end ? a.pt_end[p] : a.pt_start[p + 1];
+        // document of this pre-token: last d with doc_pt[d] <= p
+        int64_t lo = 0, hi = a.n_docs;
+        while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if ((int64_t)a.doc_pt[mid] <= p) lo = mid; else hi = mid; }
+        const int64_t d = lo;
+        const uint32_t word = (uint32_t)(p - a.doc_pt[d]);
+        const uint32_t xdoc = (uint32_t)a.x_doc_off[d];
+        const uint32_t odoc = (uint32_t)a.doc_off[d];
+        uint32_t rel = 0;
+        for (uint32_t j = 0; j < c; ++j) {
+            uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s + j];
+            if (a.want_words) a.word_ids[o + j] = word;
+            if (a.want_offsets) {
+                uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
+                uint32_t bs = ts, be = te;
+                if (a.byte_level) {                                   // snap to char boundaries inside the pre-token
+                    while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
+                    while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
+                }
+                // x space -> original text
+                uint32_t os, oe;
+                if (a.norig) { os = a.norig[bs]; oe = a.norig[be - 1] + 1u; }
+                else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
+                if (a.char_mode) {
+                    uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
+                    os = lead_rank(a.leadmask, a.lprefix, os) - base;
+                    oe = lead_rank(a.leadmask, a.lprefix, oe) - base;
+                } else { os -= odoc; oe -= odoc; }
+                if (a.trim_offsets) {                                 // process_offsets, byte_level.rs:202-234
+                    uint32_t lead_sp = 0, trail_sp = 0;
+                    while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
+                    while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
+                    if (lead_sp) {
+                        bool is_first = (word == 0 && j == 0) || os == 0;
+                        if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
+                        os = min(os + lead_sp, oe);
+                    }
+                    if (trail_sp && oe >= trail_sp) oe = max(oe - trail_sp, os);
+                }
+                a.offsets[2 * (size_t)(o + j)] = os;
+                a.offsets[2 * (size_t)(o + j) + 1] = oe;
+            }
+            rel = rel_end;
+        }
+    }
+}
+
+// =================================================================================================
 // host-side launchers (called from capi.cpp; plain C++ signatures, stream-ordered, no syncs)
 // =================================================================================================
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -1364,6 +1441,12 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
     hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, docmask, uc1, uc2, startmask, slowmask);
     hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, slow_docs, n_slow_docs);
     hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, uc1, uc2, startmask);
+}
+void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask) {
+    hipLaunchKernelGGL(k_leadmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, leadmask);
+}
+void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
+    hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {

@@ -30,6 +30,27 @@ struct DevTables {
     uint32_t max_input_chars;
 };
 
+// arguments of k_token_meta (offsets / word ids), passed by value
+struct MetaArgs {
+    const uint8_t* x_text;            // text the pre-tokenizer saw (normalised if a normalizer ran)
+    const uint32_t* pt_start;
+    const uint32_t* pt_end;           // null: pt_start[p+1]
+    const uint32_t* ntok;
+    const uint32_t* pt_tokoff;
+    const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
+    const int64_t* n_pretok;
+    const uint32_t* doc_pt;
+    int64_t n_docs;
+    const int64_t* x_doc_off;         // document CSR in x space
+    const int64_t* doc_off;           // document CSR in the original text
+    const uint32_t* norig;            // x byte -> original byte, or null (identity up to the document shift)
+    const unsigned long long* leadmask;   // char mode: lead-byte bitmask of the original text + its prefix
+    const uint32_t* lprefix;
+    uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
+    uint32_t* offsets;                // [T][2]
+    uint32_t* word_ids;               // [T]
+};
+
 // error bits accumulated in a device int during a batch
 enum : int {
     ERR_BAD_OFFSETS = 1,          // doc_offsets not a valid CSR over [0, n_bytes]
@@ -80,6 +101,8 @@ void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_byte
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs);
+void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
+void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,

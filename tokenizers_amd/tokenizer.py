@@ -250,14 +250,13 @@ class Tokenizer:
             nt = self._lib.tkamd_batch_n_tokens(b)
             ids = np.ctypeslib.as_array(C.cast(self._lib.tkamd_batch_ids(b), C.POINTER(C.c_uint32)), shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
             to = np.ctypeslib.as_array(C.cast(self._lib.tkamd_batch_tok_offsets(b), C.POINTER(C.c_int64)), shape=(n_docs + 1,)).copy()
-            po = self._lib.tkamd_batch_offsets(b)
-            offs = None
-            if po:
-                offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(nt, 2)).copy() if nt else np.zeros((0, 2), np.uint32)
-            pw = self._lib.tkamd_batch_word_ids(b)
-            wids = None
-            if pw:
-                wids = np.ctypeslib.as_array(C.cast(pw, C.POINTER(C.c_uint32)), shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
+            offs = wids = None
+            if offsets != "none":
+                po = self._lib.tkamd_batch_offsets(b)
+                offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(nt, 2)).copy() if (nt and po) else np.zeros((0, 2), np.uint32)
+            if word_ids:
+                pw = self._lib.tkamd_batch_word_ids(b)
+                wids = np.ctypeslib.as_array(C.cast(pw, C.POINTER(C.c_uint32)), shape=(nt,)).copy() if (nt and pw) else np.zeros(0, np.uint32)
         finally:
             self._lib.tkamd_batch_free(b)
         return BatchEncoding(ids, to, offs, wids, self._id_to_token())
