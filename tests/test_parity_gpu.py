@@ -13,7 +13,7 @@ from tests.helpers import load_tokenizer_json, load_vectors
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
-GPU_GOLDEN = ["gpt2_synth_50257", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
+GPU_GOLDEN = ["gpt2_synth_50257", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
 
 
 @pytest.fixture(scope="module")
@@ -233,7 +233,7 @@ def _meta_compare(tok, o, docs):
             raise AssertionError(f"{mode} offsets differ in doc {d}: {docs[d]!r} got {got[d].offsets} exp {exp.doc_offsets(d)}")
 
 
-@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"])
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"])
 def test_offsets_and_word_ids_vs_oracle(name):
     import tokenizers_amd as ta
     js = load_tokenizer_json(name)
@@ -258,7 +258,7 @@ def test_trim_offsets_vs_oracle(gpt2_json):
         _meta_compare(tok, o, docs)
 
 
-@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000"])
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000"])
 def test_encode_batch_matches_golden_char_offsets(name):
     """Tokenizer.encode_batch == the wheel's encode_batch (ids, char offsets, word ids) on the committed vectors."""
     import tokenizers_amd as ta

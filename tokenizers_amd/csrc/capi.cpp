@@ -85,7 +85,7 @@ struct tkamd_tokenizer {
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -275,31 +275,40 @@ void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint
 }
 
 // Enqueue the whole path on `st`.  Inputs and outputs are device pointers.
+//
+// Coordinate spaces: the ORIGINAL text (what the caller passed, what offsets refer to) and the X text
+// (what the pre-tokenizer and the model read).  X == original unless a normalizer ran (BertNormalizer:
+// bytes deleted/replaced, w_norig maps back) or ByteLevel add_prefix_space inserted leading spaces
+// (documents shifted, mapped back per document).  When X is derived its length only exists on the
+// device (x_len_dev); kernels are launched over the host-side bound n_x and read the effective length.
 void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
                   uint32_t flags, hipStream_t st, tkamd_device_result* out) {
     HostModel& hm = t->hm;
-    if (n_bytes >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
     const uint32_t off_mode = flags & TKAMD_OFFSETS_MASK;
     const bool want_words = (flags & TKAMD_WANT_WORD_IDS) != 0;
     const bool want_meta = off_mode != TKAMD_OFFSETS_NONE || want_words;
     if (off_mode == 3u) throw Invalid("bad offsets mode");
-    if (hm.byte_level && hm.add_prefix_space)
-        throw Unsupported("ByteLevel add_prefix_space=true is not built yet");
+    const bool prefix_space = hm.byte_level && hm.add_prefix_space;
+    const int64_t n_x = n_bytes + (prefix_space ? n_docs : 0);          // host-side bound of the X text length
+    if (n_x >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
     const bool bpe_path = hm.model == MODEL_BPE && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
     const bool local_pretok = hm.pretok == PT_WHITESPACE || hm.pretok == PT_WHITESPACE_SPLIT || hm.pretok == PT_BERT;
     const bool word_models = (hm.model == MODEL_WORDLEVEL || hm.model == MODEL_WORDPIECE) && local_pretok;
     if (!bpe_path && !word_models)
         throw Unsupported("this build covers {ByteLevel(GPT-2 regex), Llama-3 Split+ByteLevel, ByteLevel(no regex)}+BPE and "
                           "{Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
+    if (prefix_space && hm.norm != NORM_NONE) throw Unsupported("ByteLevel add_prefix_space behind a normalizer");
 
-    reserve_workspace(t, n_bytes, n_docs, flags);
+    reserve_workspace(t, n_x, n_docs, flags);
     int64_t* sc = t->w_scalars.as<int64_t>();
     int64_t* d_npretok = sc + SC_NPRETOK;
     int64_t* d_ntok_total = sc + SC_NTOK;
-    int64_t* d_nkept = sc + SC_NKEPT;
+    int64_t* d_xlen = sc + SC_NKEPT;
     int* d_err = (int*)(sc + SC_ERR);
     uint32_t* d_counters = (uint32_t*)(sc + SC_COUNTERS);
-    const int64_t W = (n_bytes >> 6) + 1;
+    const int64_t W0 = (n_bytes >> 6) + 1;      // mask words over the original text
+    const int64_t W = (n_x >> 6) + 1;           // mask words over the X text
+    const int grid = t->n_cu * 8;
     Prof pf{t, st};
     using ull = unsigned long long;
 
@@ -330,51 +339,57 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         pf.end();
     }
 
-    // ---- normalizer (BertNormalizer, ASCII): text -> normalized text + original-position map ----
-    const uint8_t* x_text = d_text;          // what the pre-tokenizer and the model read
+    const uint8_t* x_text = d_text;
     const int64_t* x_doc_off = d_doc_off;
-    if (hm.norm == NORM_BERT) {
-        t->w_keepmask.reserve((size_t)(W + 1) * 8);
-        t->w_kprefix.reserve((size_t)(W + 1) * 4);
-        t->w_ntext.reserve((size_t)n_bytes + TKAMD_TEXT_PAD);
-        t->w_norig.reserve(((size_t)n_bytes + 4) * 4);
-        t->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
-        pf.begin("bert_normalize");
-        // validate the CSR first (the normalised CSR is derived from it)
+    const int64_t* x_len_dev = nullptr;
+    if (hm.norm == NORM_BERT || prefix_space) {
+        // the derived CSR is built from the caller's: validate that one first
         launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<ull>(), d_err);
         HIP_CHECK(hipMemsetAsync(t->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
-        launch_norm_keepmask(st, d_text, n_bytes, hm.bn_clean_text, t->w_keepmask.as<ull>(), d_err);
-        launch_mask_scan(st, t->w_keepmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_kprefix.as<uint32_t>(), d_nkept);
-        HIP_CHECK(hipMemsetAsync(t->w_ntext.p, 0, (size_t)n_bytes + TKAMD_TEXT_PAD, st));
-        launch_norm_scatter(st, d_text, n_bytes, hm.bn_clean_text, hm.bn_lowercase, t->w_keepmask.as<ull>(),
-                            t->w_kprefix.as<uint32_t>(), t->w_ntext.as<uint8_t>(), t->w_norig.as<uint32_t>());
-        launch_norm_doc_offsets(st, d_doc_off, n_docs, n_bytes, t->w_keepmask.as<ull>(), t->w_kprefix.as<uint32_t>(), d_nkept,
-                                t->w_ndoc_off.as<int64_t>());
-        pf.end();
+        t->w_ntext.reserve((size_t)n_x + TKAMD_TEXT_PAD);
+        t->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
+        HIP_CHECK(hipMemsetAsync(t->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
         x_text = t->w_ntext.as<uint8_t>();
         x_doc_off = t->w_ndoc_off.as<int64_t>();
-        // The normalised length is only known on the device; kernels below take the ORIGINAL length as
-        // their launch bound and treat the zero-filled tail as text outside every document.
+        x_len_dev = d_xlen;
     }
-    // NOTE: for the normalised path the pre-tokenizer runs over n_bytes positions of ntext; bytes past
-    // n_kept are zero (class "other"/control) but lie outside [0, ndoc_off[n_docs]) -- they must not form
-    // pre-tokens, so the effective text length for them is read from the device (x_len).
-    const int64_t* x_len_dev = (hm.norm == NORM_BERT) ? d_nkept : nullptr;
+    if (hm.norm == NORM_BERT) {
+        // ---- BertNormalizer (ASCII): text -> normalised text + original-position map ----
+        t->w_keepmask.reserve((size_t)(W0 + 1) * 8);
+        t->w_kprefix.reserve((size_t)(W0 + 1) * 4);
+        t->w_norig.reserve(((size_t)n_bytes + 4) * 4);
+        pf.begin("bert_normalize");
+        launch_norm_keepmask(st, d_text, n_bytes, hm.bn_clean_text, t->w_keepmask.as<ull>(), d_err);
+        launch_mask_scan(st, t->w_keepmask.as<ull>(), W0, t->w_bsum.as<uint32_t>(), t->w_kprefix.as<uint32_t>(), d_xlen);
+        launch_norm_scatter(st, d_text, n_bytes, hm.bn_clean_text, hm.bn_lowercase, t->w_keepmask.as<ull>(),
+                            t->w_kprefix.as<uint32_t>(), t->w_ntext.as<uint8_t>(), t->w_norig.as<uint32_t>());
+        launch_norm_doc_offsets(st, d_doc_off, n_docs, n_bytes, t->w_keepmask.as<ull>(), t->w_kprefix.as<uint32_t>(), d_xlen,
+                                t->w_ndoc_off.as<int64_t>());
+        pf.end();
+    } else if (prefix_space) {
+        // ---- ByteLevel add_prefix_space: documents shifted behind their virtual leading space ----
+        t->w_need.reserve((size_t)(n_docs + 2) * 4);
+        t->w_need_bsum.reserve((size_t)((n_docs + 1) / 256 + 2) * 4);
+        pf.begin("prefix_space");
+        launch_prefix_space(st, d_text, d_doc_off, n_docs, t->w_need.as<uint32_t>(), t->w_need_bsum.as<uint32_t>(),
+                            t->w_ndoc_off.as<int64_t>(), d_xlen, t->w_ntext.as<uint8_t>(), grid);
+        pf.end();
+    }
 
     pf.begin("mark_doc_starts");
-    launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_bytes, x_len_dev, t->w_docmask.as<ull>(), d_err);
+    launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_x, x_len_dev, t->w_docmask.as<ull>(), d_err);
     pf.end();
 
     uint32_t* pt_end = nullptr;
     if (hm.pretok == PT_BYTELEVEL_GPT2) {
         pf.begin("pretok_gpt2");
-        launch_pretok_gpt2(st, x_text, n_bytes, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>());
+        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>());
         pf.end();
     } else if (hm.pretok == PT_LLAMA3) {
         t->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
         t->w_slow_docs.reserve((size_t)(n_docs + 1) * 4);
         pf.begin("pretok_llama3");
-        launch_pretok_llama3(st, x_text, n_bytes, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(),
+        launch_pretok_llama3(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(),
                              t->w_endmask.as<ull>(), x_doc_off, n_docs, t->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
         pf.end();
     } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
@@ -382,10 +397,10 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         HIP_CHECK(hipMemcpyAsync(t->w_startmask.p, t->w_docmask.p, (size_t)W * 8, hipMemcpyDeviceToDevice, st));
     } else {
         t->w_endmask.reserve((size_t)(W + 1) * 8);
-        t->w_pt_end.reserve(((size_t)n_bytes + 4) * 4);
+        t->w_pt_end.reserve(((size_t)n_x + 4) * 4);
         pt_end = t->w_pt_end.as<uint32_t>();
         pf.begin("pretok_local");
-        launch_pretok_local(st, (int)hm.pretok, x_text, n_bytes, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
+        launch_pretok_local(st, (int)hm.pretok, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
                             t->w_startmask.as<ull>(), t->w_endmask.as<ull>());
         pf.end();
     }
@@ -393,18 +408,17 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     launch_mask_scan(st, t->w_startmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
     pf.begin("emit_pretok");
-    launch_emit_pretok(st, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_bytes, d_npretok, t->w_pt_start.as<uint32_t>());
-    if (pt_end) launch_emit_pretok_end(st, t->w_startmask.as<ull>(), t->w_endmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_bytes, pt_end);
+    launch_emit_pretok(st, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, t->w_pt_start.as<uint32_t>());
+    if (pt_end) launch_emit_pretok_end(st, t->w_startmask.as<ull>(), t->w_endmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, pt_end);
     pf.end();
     pf.begin("doc_first_pretok");
-    launch_doc_first_pretok(st, x_doc_off, n_docs, n_bytes, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(),
+    launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(),
                             d_npretok, t->w_doc_pt.as<uint32_t>());
     pf.end();
 
-    const int grid = t->n_cu * 8;
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? t->w_tmp_end.as<uint32_t>() : nullptr;
     if (hm.model == MODEL_BPE) {
-        size_t N = (size_t)n_bytes;
+        size_t N = (size_t)n_x;
         uint32_t* list16 = t->w_lists.as<uint32_t>();
         uint32_t* list64 = list16 + N + 16;
         uint32_t* listL = list64 + N / 16 + 16;
@@ -468,14 +482,15 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         a.want_offsets = off_mode != TKAMD_OFFSETS_NONE;
         a.char_mode = off_mode == TKAMD_OFFSETS_CHAR;
         a.want_words = want_words;
+        a.prefix_space = prefix_space;
         a.offsets = t->w_offsets.as<uint32_t>();
         a.word_ids = t->w_word_ids.as<uint32_t>();
         if (a.char_mode) {
-            t->w_leadmask.reserve((size_t)(W + 1) * 8);
-            t->w_lprefix.reserve((size_t)(W + 1) * 4);
+            t->w_leadmask.reserve((size_t)(W0 + 1) * 8);
+            t->w_lprefix.reserve((size_t)(W0 + 1) * 4);
             pf.begin("leadmask_scan");
             launch_leadmask(st, d_text, n_bytes, t->w_leadmask.as<ull>());
-            launch_mask_scan(st, t->w_leadmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_lprefix.as<uint32_t>(), sc + SC_NCHARS);
+            launch_mask_scan(st, t->w_leadmask.as<ull>(), W0, t->w_bsum.as<uint32_t>(), t->w_lprefix.as<uint32_t>(), sc + SC_NCHARS);
             pf.end();
             a.leadmask = t->w_leadmask.as<ull>();
             a.lprefix = t->w_lprefix.as<uint32_t>();
@@ -570,7 +585,7 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
                          &t->t_long_id, &t->t_long_table, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }

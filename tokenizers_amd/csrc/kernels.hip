@@ -67,6 +67,57 @@ __global__ __launch_bounds__(256) void k_added_token_scan(const uint8_t* __restr
 }
 
 // =================================================================================================
+// ByteLevel add_prefix_space (pre_tokenizers/byte_level.rs:122-125): every document that does not start
+// with ' ' is pre-tokenised as if a space were prepended.  The device materialises that text once:
+// need[d] -> exclusive scan -> shifted document CSR -> one wavefront per document copies it behind its
+// optional space.  Offsets are mapped back in k_token_meta (the inserted space shares the first
+// original char's alignment, tokenizer/normalizer.rs:503-514).
+// =================================================================================================
+__global__ void k_prefix_need(const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off, int64_t n_docs,
+                              uint32_t* __restrict__ need) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    uint32_t v = 0;
+    if (d < n_docs) {
+        int64_t a = doc_off[d], b = doc_off[d + 1];
+        v = (b > a && text[a] != ' ') ? 1u : 0u;
+    }
+    need[d] = v;
+}
+__global__ __launch_bounds__(256) void k_u32_reduce(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t sm[4];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t x = (i < n) ? v[i] : 0u, tot;
+    block256_excl_scan(x, sm, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// exclusive prefix of need[] added to the document CSR: xdoc_off[d] = doc_off[d] + #spaces inserted before doc d
+__global__ __launch_bounds__(256) void k_prefix_doc_offsets(const uint32_t* __restrict__ need, int64_t n, const uint32_t* __restrict__ bsum,
+                                                            const int64_t* __restrict__ doc_off, int64_t* __restrict__ xdoc_off,
+                                                            int64_t* __restrict__ x_len) {
+    __shared__ uint32_t sm[4];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t x = (i < n) ? need[i] : 0u, tot;
+    uint32_t ex = bsum[blockIdx.x] + block256_excl_scan(x, sm, &tot);
+    if (i < n) {
+        xdoc_off[i] = doc_off[i] + ex;
+        if (i == n - 1) *x_len = doc_off[i] + ex;         // i == n_docs: total length of the shifted text
+    }
+}
+__global__ __launch_bounds__(256) void k_prefix_copy(const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off,
+                                                     const int64_t* __restrict__ xdoc_off, int64_t n_docs, uint8_t* __restrict__ xtext) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave; d < n_docs; d += n_waves) {
+        const int64_t a = doc_off[d], len = doc_off[d + 1] - a;
+        const int64_t xa = xdoc_off[d];
+        const int64_t shift = (xdoc_off[d + 1] - xa) - len;        // 1 if a space is inserted
+        if (shift && lane == 0) xtext[xa] = ' ';
+        for (int64_t i = lane; i < len; i += 64) xtext[xa + shift + i] = text[a + i];
+    }
+}
+
+// =================================================================================================
 // K_pretok_gpt2: GPT-2 ByteLevel regex as a local-window predicate, one lane per byte.
 // Replaces: ByteLevel::pre_tokenize (pre_tokenizers/byte_level.rs:119-131) = Oniguruma find_iter
 // over  's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+  (byte_level.rs:43-46)
@@ -116,7 +167,8 @@ __device__ __forceinline__ uint32_t utf8_at(const uint8_t* sb, int k, uint32_t* 
     return ((b & 0x07u) << 18) | ((sb[k + 1] & 0x3Fu) << 12) | ((sb[k + 2] & 0x3Fu) << 6) | (sb[k + 3] & 0x3Fu);
 }
 
-__global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__ text, int64_t n_bytes,
+__global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                     const int64_t* __restrict__ len_dev,
                                                      const unsigned long long* __restrict__ docmask,
                                                      const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                      unsigned long long* __restrict__ startmask) {
@@ -126,6 +178,7 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;       // first byte of this tile
     const int64_t r0 = t0 - PT_HALO;                        // first byte of the staged region
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // effective text length (prefix-space pass: on device)
 
     // phase 0: stage bytes (zero outside the text)
     for (int k = tid; k < PT_R + 8; k += 256) {
@@ -206,7 +259,7 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
         }
         uint64_t m = __ballot(start);
         int64_t g = t0 + it * 256 + tid;
-        if ((tid & 63) == 0 && g <= n_bytes) startmask[g >> 6] = m;
+        if ((tid & 63) == 0 && g <= n_bytes_host) startmask[g >> 6] = m;
     }
 }
 
@@ -259,7 +312,8 @@ __device__ __forceinline__ uint32_t l3_letter(const L3View& v, int k, int* nx) {
     return (f - 'a' < 26u) ? f : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict__ text, int64_t n_bytes,
+__global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                       const int64_t* __restrict__ len_dev,
                                                        const unsigned long long* __restrict__ docmask,
                                                        const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                        unsigned long long* __restrict__ startmask,
@@ -270,6 +324,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
     const int64_t r0 = t0 - L3_HALO;
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     for (int k = tid; k < L3_R + 8; k += 256) {
         int64_t g = r0 + k;
         sb[k] = (g >= 0 && g < n_bytes) ? text[g] : (uint8_t)0;
@@ -421,7 +476,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
             }
         }
         uint64_t m = __ballot(start), mu = __ballot(unresolved);
-        if ((tid & 63) == 0 && g <= n_bytes) { startmask[g >> 6] = m; slowmask[g >> 6] = mu; }
+        if ((tid & 63) == 0 && g <= n_bytes_host) { startmask[g >> 6] = m; slowmask[g >> 6] = mu; }
     }
 }
 
@@ -751,10 +806,11 @@ __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __
 // one lane per byte: a set start bit at byte i becomes pt_start[rank(i)] = i (coalesced stores)
 __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* __restrict__ startmask,
                                                      const uint32_t* __restrict__ wprefix, int64_t n_bytes,
+                                                     const int64_t* __restrict__ len_dev,
                                                      const int64_t* __restrict__ n_pretok,
                                                      uint32_t* __restrict__ pt_start) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) pt_start[*n_pretok] = (uint32_t)n_bytes;          // sentinel
+    if (i == 0) pt_start[*n_pretok] = (uint32_t)(len_dev ? *len_dev : n_bytes);          // sentinel
     if (i >= n_bytes) return;
     unsigned long long m = startmask[i >> 6];
     int b = (int)(i & 63);
@@ -1328,6 +1384,14 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                 // x space -> original text
                 uint32_t os, oe;
                 if (a.norig) { os = a.norig[bs]; oe = a.norig[be - 1] + 1u; }
+                else if (a.prefix_space && ((uint32_t)(a.x_doc_off[d + 1]) - xdoc) != ((uint32_t)(a.doc_off[d + 1]) - odoc)) {
+                    // this document got a virtual leading space: x position 0 maps to [0, len(first char)), x >= 1 to x - 1
+                    uint32_t rs = bs - xdoc, re = be - xdoc;
+                    uint32_t fb = a.x_text[xdoc + 1];
+                    uint32_t first_len = fb < 0x80u ? 1u : fb < 0xE0u ? 2u : fb < 0xF0u ? 3u : 4u;
+                    os = odoc + (rs == 0 ? 0u : rs - 1u);
+                    oe = odoc + (re <= 1u ? first_len : re - 1u);
+                }
                 else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
                 if (a.char_mode) {
                     uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
@@ -1366,9 +1430,9 @@ void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_do
                             unsigned long long* docmask, int* err) {
     launch_mark_doc_starts_n(st, doc_off, n_docs, n_bytes, nullptr, docmask, err);
 }
-void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask) {
-    hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, docmask, uc1, uc2, startmask);
+    hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
 }
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total) {
@@ -1378,8 +1442,8 @@ void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_
     hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
 }
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
-                        const int64_t* n_pretok, uint32_t* pt_start) {
-    hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, startmask, wprefix, n_bytes, n_pretok, pt_start);
+                        const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
+    hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
 }
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt) {
@@ -1435,10 +1499,10 @@ void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_byte
                              const uint32_t* first_idx, int* err) {
     hipLaunchKernelGGL(k_added_token_scan, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, text, n_bytes, pat_blob, pat_off, first_idx, err);
 }
-void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs) {
-    hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, docmask, uc1, uc2, startmask, slowmask);
+    hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask);
     hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, slow_docs, n_slow_docs);
     hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, uc1, uc2, startmask);
 }
@@ -1447,6 +1511,15 @@ void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsig
 }
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc_off, int64_t n_docs, uint32_t* need, uint32_t* bsum,
+                         int64_t* xdoc_off, int64_t* x_len, uint8_t* xtext, int grid) {
+    unsigned nb = blocks_for(n_docs + 1, 256);
+    hipLaunchKernelGGL(k_prefix_need, dim3(nb), dim3(256), 0, st, text, doc_off, n_docs, need);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
+    hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, (const uint32_t*)bsum, doc_off, xdoc_off, x_len);
+    hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, doc_off, (const int64_t*)xdoc_off, n_docs, xtext);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {

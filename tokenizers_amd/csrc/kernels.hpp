@@ -47,6 +47,7 @@ struct MetaArgs {
     const unsigned long long* leadmask;   // char mode: lead-byte bitmask of the original text + its prefix
     const uint32_t* lprefix;
     uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
+    uint32_t prefix_space;            // x text carries inserted leading spaces (ByteLevel add_prefix_space)
     uint32_t* offsets;                // [T][2]
     uint32_t* word_ids;               // [T]
 };
@@ -68,12 +69,14 @@ constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup pat
 
 void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                             unsigned long long* docmask, int* err);
-void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total);
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
-                        const int64_t* n_pretok, uint32_t* pt_start);
+                        const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start);
+void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc_off, int64_t n_docs, uint32_t* need, uint32_t* bsum,
+                         int64_t* xdoc_off, int64_t* x_len, uint8_t* xtext, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
@@ -98,7 +101,7 @@ void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_
                       const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err);
-void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
