@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -261,7 +262,7 @@ void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint
     t->w_ntok.reserve((N + 4) * 4);
     t->w_pt_tokoff.reserve((N + 4) * 4);
     t->w_tmp_ids.reserve((N + 4) * 4);
-    t->w_lists.reserve((N + N / 16 + N / 64 + 64) * 4);
+    t->w_lists.reserve((N + N / 16 + N / 32 + N / 64 + 128) * 4);
     t->w_csum.reserve((N / 1024 + 4) * 4);
     t->w_ids.reserve((N + 4) * 4);
     t->w_doc_pt.reserve((n_docs + 2) * 4);
@@ -420,14 +421,22 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     if (hm.model == MODEL_BPE) {
         size_t N = (size_t)n_x;
         uint32_t* list16 = t->w_lists.as<uint32_t>();
-        uint32_t* list64 = list16 + N + 16;
-        uint32_t* listL = list64 + N / 16 + 16;
+        uint32_t* list32 = list16 + N + 16;
+        uint32_t* list64 = list32 + N / 16 + 16;
+        uint32_t* listL = list64 + N / 32 + 16;
         pf.begin("bpe_word_lookup");
         launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), d_npretok, t->w_tok0.as<uint32_t>(),
-                               t->w_ntok.as<uint32_t>(), list16, list64, listL, d_counters);
+                               t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters);
         pf.end();
-        pf.begin("bpe_merge16");
-        launch_bpe_merge(st, grid, 16, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16,
+        pf.begin("bpe_merge_lane32");
+        launch_bpe_merge(st, grid, 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        pf.end();
+        // <= 16 bytes: one lane per pre-token (register-resident Word); TKAMD_MERGE16=row selects the
+        // 16-lane DPP-row kernel instead (kept for A/B measurements)
+        static const bool row16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "row"); }();
+        pf.begin(row16 ? "bpe_merge16" : "bpe_merge_lane");
+        launch_bpe_merge(st, grid, row16 ? 16 : 1, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16,
                          t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge64");

@@ -909,10 +909,11 @@ constexpr int LK_CHUNK = 256 * LK_ITEMS;
 __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
                                                          const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
                                                          uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
-                                                         uint32_t* __restrict__ list16, uint32_t* __restrict__ list64,
+                                                         uint32_t* __restrict__ list16, uint32_t* __restrict__ list32,
+                                                         uint32_t* __restrict__ list64,
                                                          uint32_t* __restrict__ listL, uint32_t* __restrict__ counters) {
     __shared__ uint32_t sm[4];
-    __shared__ uint32_t base_s[3];
+    __shared__ uint32_t base_s[4];
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + LK_CHUNK - 1) / LK_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
 #pragma unroll
         for (int k = 0; k <= LK_ITEMS; ++k) st[k] = (p0 + k <= P) ? pt_start[p0 + k] : 0u;
         uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list64, 3 -> listL
-        uint32_t n16 = 0, n64 = 0, nL = 0;
+        uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
 #pragma unroll
         for (int k = 0; k < LK_ITEMS; ++k) {
             const int64_t p = p0 + k;
@@ -946,32 +947,40 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                     }
                 }
                 if (!done) {
-                    uint32_t c = len <= 16 ? 1u : (len <= 64 ? 2u : 3u);
+                    // 1 -> list16 (<=16 B), 2 -> list32 (<=32 B), 3 -> list64 (<=64 B) or listL (longer); the two
+                    // rare classes share code 3 and are told apart again when the queues are written
+                    uint32_t c = len <= 16 ? 1u : (len <= 32 ? 2u : 3u);
                     cls |= c << (2 * k);
                     n16 += (c == 1);
-                    n64 += (c == 2);
-                    nL += (c == 3);
+                    n32 += (c == 2);
+                    n64 += (c == 3 && len <= 64);
+                    nL += (len > 64);
                 }
             }
         }
         // one atomic per workgroup per list (same-address atomics serialise at ~12 ns each on MI355X)
-        uint32_t tot, totL = 0;
-        uint32_t ex = block256_excl_scan(n16 | (n64 << 16), sm, &tot);
-        uint32_t exL = 0;
-        if (__syncthreads_or((int)nL)) exL = block256_excl_scan(nL, sm, &totL);
+        uint32_t tot, tot2 = 0;
+        uint32_t ex = block256_excl_scan(n16 | (n32 << 16), sm, &tot);
+        uint32_t ex2 = 0;
+        if (__syncthreads_or((int)(n64 | nL))) ex2 = block256_excl_scan(n64 | (nL << 16), sm, &tot2);
         if (threadIdx.x == 0) {
             base_s[0] = (tot & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST16], tot & 0xFFFFu) : 0u;
-            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_LIST64], tot >> 16) : 0u;
-            base_s[2] = totL ? atomicAdd(&counters[CNT_LISTL], totL) : 0u;
+            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_LIST32], tot >> 16) : 0u;
+            base_s[2] = (tot2 & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST64], tot2 & 0xFFFFu) : 0u;
+            base_s[3] = (tot2 >> 16) ? atomicAdd(&counters[CNT_LISTL], tot2 >> 16) : 0u;
         }
         __syncthreads();
-        uint32_t o16 = base_s[0] + (ex & 0xFFFFu), o64 = base_s[1] + (ex >> 16), oL = base_s[2] + exL;
+        uint32_t o16 = base_s[0] + (ex & 0xFFFFu), o32 = base_s[1] + (ex >> 16);
+        uint32_t o64 = base_s[2] + (ex2 & 0xFFFFu), oL = base_s[3] + (ex2 >> 16);
 #pragma unroll
         for (int k = 0; k < LK_ITEMS; ++k) {
             uint32_t c = (cls >> (2 * k)) & 3u;
             if (c == 1) list16[o16++] = (uint32_t)(p0 + k);
-            else if (c == 2) list64[o64++] = (uint32_t)(p0 + k);
-            else if (c == 3) listL[oL++] = (uint32_t)(p0 + k);
+            else if (c == 2) list32[o32++] = (uint32_t)(p0 + k);
+            else if (c == 3) {
+                if (st[k + 1] - st[k] <= 64u) list64[o64++] = (uint32_t)(p0 + k);
+                else listL[oL++] = (uint32_t)(p0 + k);
+            }
         }
         __syncthreads();
     }
@@ -1067,6 +1076,134 @@ __global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* _
 }
 template __global__ void k_bpe_merge<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_bpe_merge<64>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+
+// =================================================================================================
+// K_bpe_merge_lane: the same merge loop for pre-tokens of <= 16 bytes, ONE LANE per pre-token with the
+// whole Word (ids, pair ranks, pair new-ids) in registers -- 64 pre-tokens per wavefront instead of 4.
+// The merge loop is a chain of dependent L2 round trips (probe -> min -> merge -> probe); giving every
+// lane its own chain multiplies the memory-level parallelism by 16 over the row-per-word kernel.
+// Arrays are indexed with compile-time indices only (selects), so nothing spills to scratch.
+// Token boundaries travel as 16 nibbles (start byte of symbol i) for the offsets output.
+// Same semantics as k_bpe_merge (models/bpe/word.rs:162-250): merge the (rank, position)-minimum pair,
+// the left symbol takes new_id, re-probe the two new neighbours.
+// =================================================================================================
+// position of the k-th (0-based) set bit of m
+__device__ __forceinline__ uint32_t select_bit32(uint32_t m, uint32_t k) {
+    uint32_t pos = 0, c;
+    c = __popc(m & 0xFFFFu); if (k >= c) { k -= c; pos += 16; m >>= 16; }
+    c = __popc(m & 0xFFu);   if (k >= c) { k -= c; pos += 8;  m >>= 8; }
+    c = __popc(m & 0xFu);    if (k >= c) { k -= c; pos += 4;  m >>= 4; }
+    c = __popc(m & 0x3u);    if (k >= c) { k -= c; pos += 2;  m >>= 2; }
+    c = m & 1u;              if (k >= c) { pos += 1; }
+    return pos;
+}
+
+template <int S>   // S = 16 or 32 symbols per lane
+__global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8_t* __restrict__ text,
+                                                        const uint32_t* __restrict__ pt_start,
+                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                        uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    constexpr uint32_t PB = (S == 16) ? 4 : 5;              // bits of the pair index inside the reduction key
+    __shared__ uint32_t s_byte_id[256];
+    s_byte_id[threadIdx.x] = t.byte_id[threadIdx.x];
+    __syncthreads();
+    const uint32_t n_items = *n_list;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t base = blockIdx.x * 256; base < n_items; base += stride) {
+        const uint32_t item = base + threadIdx.x;
+        const bool valid = item < n_items;
+        uint32_t p = 0, s = 0, len = 0;
+        if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        uint64_t key[S / 8];
+#pragma unroll
+        for (int q = 0; q < S / 8; ++q) key[q] = 0;
+        if (valid) {
+            load_key16(text, s, min(len, 16u), &key[0], &key[1]);
+            if (S == 32 && len > 16) load_key16(text, s + 16, len - 16, &key[S / 8 - 2], &key[S / 8 - 1]);
+        }
+        uint32_t ids[S], rk[S], nd[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            uint32_t b = (uint32_t)((key[i / 8] >> (8 * (i % 8))) & 0xFFu);
+            ids[i] = s_byte_id[b];
+            rk[i] = RANK_NONE;
+            nd[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < S - 1; ++i)
+            if ((uint32_t)(i + 1) < len) merge_probe(t, ids[i], ids[i + 1], &rk[i], &nd[i]);
+        uint32_t n = len;                                   // live symbols
+        uint32_t starts = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);   // bit b: a symbol starts at byte b
+        bool active = valid && len > 1;
+        while (__any(active)) {
+            if (active) {
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < S - 1; ++i) {
+                    uint32_t k = (rk[i] << PB) | (uint32_t)i;
+                    if ((uint32_t)(i + 1) < n && rk[i] != RANK_NONE) best = min(best, k);
+                }
+                if (best == 0xFFFFFFFFu) active = false;
+                else {
+                    const uint32_t w = best & (uint32_t)(S - 1);
+                    uint32_t new_id = 0;
+#pragma unroll
+                    for (int i = 0; i < S - 1; ++i) new_id = ((uint32_t)i == w) ? nd[i] : new_id;
+                    // symbol w takes new_id, symbol w+1 disappears, everything right of it shifts left
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        uint32_t nxt_id = (i + 1 < S) ? ids[i + 1] : 0u;
+                        ids[i] = ((uint32_t)i == w) ? new_id : (((uint32_t)i > w) ? nxt_id : ids[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < S - 1; ++i) {
+                        uint32_t nr = (i + 1 < S - 1) ? rk[i + 1] : RANK_NONE, nn = (i + 1 < S - 1) ? nd[i + 1] : 0u;
+                        if ((uint32_t)i >= w) { rk[i] = nr; nd[i] = nn; }
+                    }
+                    if (tmp_end) starts &= ~(1u << select_bit32(starts, w + 1));
+                    n -= 1;
+                    // re-probe (w-1, w) and (w, w+1)
+                    uint32_t left = 0, right = 0;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        left = ((uint32_t)i + 1 == w) ? ids[i] : left;
+                        right = ((uint32_t)i == w + 1) ? ids[i] : right;
+                    }
+                    uint32_t r1 = RANK_NONE, n1 = 0, r2 = RANK_NONE, n2 = 0;
+                    if (w > 0) merge_probe(t, left, new_id, &r1, &n1);
+                    if (w + 1 < n) merge_probe(t, new_id, right, &r2, &n2);
+#pragma unroll
+                    for (int i = 0; i < S - 1; ++i) {
+                        if ((uint32_t)i + 1 == w) { rk[i] = r1; nd[i] = n1; }
+                        if ((uint32_t)i == w) { rk[i] = r2; nd[i] = n2; }
+                    }
+                    if (n < 2) active = false;
+                }
+            }
+        }
+        if (valid) {
+            tok0[p] = ids[0];
+            ntok[p] = n;
+#pragma unroll
+            for (int j = 1; j < S; ++j)
+                if ((uint32_t)j < n) tmp_ids[s + j] = ids[j];
+            if (tmp_end) {
+                uint32_t m = starts & (starts - 1u);          // drop the first start: ends are the later starts, then len
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    if ((uint32_t)j < n) {
+                        uint32_t e = m ? (uint32_t)(__ffs(m) - 1) : len;
+                        tmp_end[s + j] = e;
+                        m &= m - 1u;
+                    }
+                }
+            }
+        }
+    }
+}
+template __global__ void k_bpe_merge_lane<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 
 // =================================================================================================
 // K_bpe_merge_long: pre-tokens longer than 64 bytes, one workgroup each, symbols as a doubly linked
@@ -1450,13 +1587,17 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
     hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt);
 }
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list64,
+                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32, uint32_t* list64,
                             uint32_t* listL, uint32_t* counters) {
-    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, n_pretok, tok0, ntok, list16, list64, listL, counters);
+    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, n_pretok, tok0, ntok, list16, list32, list64, listL, counters);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
-    if (group == 16)
+    if (group == 1)
+        hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+    else if (group == 2)
+        hipLaunchKernelGGL(k_bpe_merge_lane<32>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+    else if (group == 16)
         hipLaunchKernelGGL(k_bpe_merge<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
     else
         hipLaunchKernelGGL(k_bpe_merge<64>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);

@@ -63,7 +63,7 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_SLOW_POS = 3, CNT_SLOW_DOCS = 4, CNT_COUNT = 8 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_COUNT = 8 };
 
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident)
 
@@ -80,7 +80,7 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list64,
+                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32, uint32_t* list64,
                             uint32_t* listL, uint32_t* counters);
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
