@@ -44,6 +44,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lines", type=int, default=1_000_000, help="documents per GPU per step")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the final buffers")
+    ap.add_argument("--force-gather", action="store_true", help="run the gather code path even with one rank (self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
@@ -62,8 +63,11 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from oracle import synth            # test/bench infrastructure: corpus + vocab recipe
@@ -85,7 +89,7 @@ def main() -> None:
     d_text = torch.from_numpy(buf).to(dev)
     d_off = torch.from_numpy(doc_off).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 and not args.no_gather) or args.force_gather
 
     def step():
         b = tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, stream=stream)
@@ -136,8 +140,9 @@ def main() -> None:
         # algorithmic bytes of the whole path per launch: text in + doc CSR in + ids out + token CSR out
         b_alg = n_bytes + 8 * (n_docs + 1) + 4 * n_tok + 8 * (n_docs + 1)
         achieved = b_alg / (stages[dom] * 1e-3) / 1e9
+        traffic = pmc_traffic(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(stages[dom], 4),
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
@@ -162,9 +167,26 @@ def main() -> None:
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_gather:
         dist.barrier()
         dist.destroy_process_group()
+
+
+KERNEL_OF_STAGE = {"bpe_word_lookup": "k_bpe_word_lookup", "bpe_merge_lane": "k_bpe_merge_lane<16>", "bpe_merge_lane32": "k_bpe_merge_lane<32>",
+                   "bpe_merge16": "k_bpe_merge<16>", "bpe_merge64": "k_bpe_merge<64>", "pretok_gpt2": "k_pretok_gpt2",
+                   "compact": "k_compact", "emit_pretok": "k_emit_pretok"}
+
+
+def pmc_traffic(stage: str):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/):
+    (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md.  None if no PMC run covers it."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+    try:
+        with open(path) as fh:
+            k = json.load(fh)["kernels"].get(KERNEL_OF_STAGE.get(stage, ""))
+        return int(k["hbm_bytes_per_launch"]) if k else None
+    except Exception:
+        return None
 
 
 def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int) -> dict:

@@ -867,11 +867,14 @@ __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uin
     uint32_t sh = (s & 3u) * 8u;
     uint32_t a0 = __funnelshift_r(w0, w1, sh), a1 = __funnelshift_r(w1, w2, sh);
     uint32_t a2 = __funnelshift_r(w2, w3, sh), a3 = __funnelshift_r(w3, w4, sh);
-    uint64_t l = ((uint64_t)a1 << 32) | a0, h = ((uint64_t)a3 << 32) | a2;
-    if (len < 8) { l &= (1ull << (len * 8)) - 1ull; h = 0; }
-    else if (len < 16) { h &= (len == 8) ? 0ull : ((1ull << ((len - 8) * 8)) - 1ull); }
-    *lo = l;
-    *hi = h;
+    // branch-free masking of the bytes past `len` (selects only, so callers can keep many loads in flight)
+    uint32_t nl = min(len, 8u), nh = min(len, 16u) - nl;           // bytes kept in the low / high half
+    uint32_t m0 = nl >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nl)) - 1u);
+    uint32_t m1 = nl >= 8 ? 0xFFFFFFFFu : (nl > 4 ? ((1u << (8 * (nl - 4))) - 1u) : 0u);
+    uint32_t m2 = nh >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nh)) - 1u);
+    uint32_t m3 = nh >= 8 ? 0xFFFFFFFFu : (nh > 4 ? ((1u << (8 * (nh - 4))) - 1u) : 0u);
+    *lo = ((uint64_t)(a1 & m1) << 32) | (a0 & m0);
+    *hi = ((uint64_t)(a3 & m3) << 32) | (a2 & m2);
 }
 
 __device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
@@ -905,6 +908,7 @@ __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __
 
 constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
 constexpr int LK_CHUNK = 256 * LK_ITEMS;
+constexpr int LK_GROUP = 4;                      // items whose loads are kept in flight together
 
 __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
                                                          const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
@@ -917,46 +921,72 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + LK_CHUNK - 1) / LK_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        const int64_t p0 = ch * LK_CHUNK + (int64_t)threadIdx.x * LK_ITEMS;
-        uint32_t st[LK_ITEMS + 1];
+        // each lane takes LK_ITEMS consecutive pre-tokens: the work queues then stay in pre-token order, which keeps
+        // the merge kernels' text / pt_start / tmp_ids accesses local (measured: lane-strided assignment coalesces
+        // these loads better but costs the merge kernels 30 %)
+        const int64_t pbase = ch * LK_CHUNK + (int64_t)threadIdx.x * LK_ITEMS;
+        // branch-free, clamped loads so that every group's loads are in flight together
+        uint32_t st[LK_ITEMS], en[LK_ITEMS];
 #pragma unroll
-        for (int k = 0; k <= LK_ITEMS; ++k) st[k] = (p0 + k <= P) ? pt_start[p0 + k] : 0u;
-        uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list64, 3 -> listL
+        for (int k = 0; k < LK_ITEMS; ++k) st[k] = pt_start[min(pbase + k, P)];
+#pragma unroll
+        for (int k = 0; k < LK_ITEMS; ++k) en[k] = (k + 1 < LK_ITEMS) ? st[k + 1] : pt_start[min(pbase + LK_ITEMS, P)];
+        uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list32, 3 -> list64 / listL
         uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
 #pragma unroll
-        for (int k = 0; k < LK_ITEMS; ++k) {
-            const int64_t p = p0 + k;
-            if (p < P) {
-                uint32_t s = st[k], len = st[k + 1] - s;
-                bool done = false;
-                if (len <= (uint32_t)WORD_MAX_KEY) {
-                    uint64_t lo, hi;
-                    load_key16(text, s, len, &lo, &hi);
-                    uint32_t id, fl;
-                    if (word_probe(t, lo, hi, len, &id, &fl) && (t.ignore_merges || (fl & WORD_DIRECT))) {
-                        tok0[p] = id;
-                        ntok[p] = 1;
-                        done = true;
-                    }
-                } else if (t.ignore_merges) {            // whole-word vocab hit for long keys (bpe/model.rs:559-567)
-                    uint32_t id;
-                    if (long_probe(t, text + s, len, &id)) {
-                        tok0[p] = id;
-                        ntok[p] = 1;
-                        done = true;
-                    }
-                }
-                if (!done) {
-                    // 1 -> list16 (<=16 B), 2 -> list32 (<=32 B), 3 -> list64 (<=64 B) or listL (longer); the two
-                    // rare classes share code 3 and are told apart again when the queues are written
-                    uint32_t c = len <= 16 ? 1u : (len <= 32 ? 2u : 3u);
-                    cls |= c << (2 * k);
-                    n16 += (c == 1);
-                    n32 += (c == 2);
-                    n64 += (c == 3 && len <= 64);
-                    nL += (len > 64);
+        for (int g = 0; g < LK_ITEMS; g += LK_GROUP) {
+            uint64_t lo[LK_GROUP], hi[LK_GROUP];
+            uint32_t len[LK_GROUP];
+#pragma unroll
+            for (int k = 0; k < LK_GROUP; ++k) {
+                len[k] = en[g + k] - st[g + k];
+                load_key16(text, st[g + k], min(len[k], 16u), &lo[k], &hi[k]);
+            }
+            uint4 a0[LK_GROUP], a1[LK_GROUP], b0[LK_GROUP], b1[LK_GROUP];
+#pragma unroll
+            for (int k = 0; k < LK_GROUP; ++k) {
+                uint32_t h1 = word_hash1(lo[k], hi[k], len[k], t.word_seed);
+                const uint4* q1 = (const uint4*)&t.words[h1 & t.word_mask];
+                const uint4* q2 = (const uint4*)&t.words[word_hash2(h1) & t.word_mask];
+                a0[k] = q1[0]; a1[k] = q1[1]; b0[k] = q2[0]; b1[k] = q2[1];
+            }
+#pragma unroll
+            for (int k = 0; k < LK_GROUP; ++k) {
+                const int64_t p = pbase + g + k;
+                const bool valid = p < P;
+                uint32_t lo0 = (uint32_t)lo[k], lo1 = (uint32_t)(lo[k] >> 32), hi0 = (uint32_t)hi[k], hi1 = (uint32_t)(hi[k] >> 32);
+                bool ma = a1[k].x == len[k] && a0[k].x == lo0 && a0[k].y == lo1 && a0[k].z == hi0 && a0[k].w == hi1;
+                bool mb = b1[k].x == len[k] && b0[k].x == lo0 && b0[k].y == lo1 && b0[k].z == hi0 && b0[k].w == hi1;
+                uint32_t id = ma ? a1[k].y : b1[k].y, fl = ma ? a1[k].z : b1[k].z;
+                bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && (ma || mb) && (t.ignore_merges || (fl & WORD_DIRECT));
+                if (done) { tok0[p] = id; ntok[p] = 1; }
+                if (valid && !done) {
+                    uint32_t c = len[k] <= 16 ? 1u : (len[k] <= 32 ? 2u : 3u);
+                    cls |= c << (2 * (g + k));
                 }
             }
+        }
+        // ignore_merges: whole-word vocab hit for keys longer than 16 bytes (bpe/model.rs:559-567); rare, kept off
+        // the main path
+        if (t.ignore_merges) {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k) {
+                uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
+                uint32_t id;
+                if (c >= 2 && long_probe(t, text + st[k], len, &id)) {
+                    tok0[pbase + k] = id;
+                    ntok[pbase + k] = 1;
+                    cls &= ~(3u << (2 * k));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LK_ITEMS; ++k) {
+            uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
+            n16 += (c == 1);
+            n32 += (c == 2);
+            n64 += (c == 3 && len <= 64);
+            nL += (c == 3 && len > 64);
         }
         // one atomic per workgroup per list (same-address atomics serialise at ~12 ns each on MI355X)
         uint32_t tot, tot2 = 0;
@@ -975,11 +1005,11 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
 #pragma unroll
         for (int k = 0; k < LK_ITEMS; ++k) {
             uint32_t c = (cls >> (2 * k)) & 3u;
-            if (c == 1) list16[o16++] = (uint32_t)(p0 + k);
-            else if (c == 2) list32[o32++] = (uint32_t)(p0 + k);
+            if (c == 1) list16[o16++] = (uint32_t)(pbase + k);
+            else if (c == 2) list32[o32++] = (uint32_t)(pbase + k);
             else if (c == 3) {
-                if (st[k + 1] - st[k] <= 64u) list64[o64++] = (uint32_t)(p0 + k);
-                else listL[oL++] = (uint32_t)(p0 + k);
+                if (en[k] - st[k] <= 64u) list64[o64++] = (uint32_t)(pbase + k);
+                else listL[oL++] = (uint32_t)(pbase + k);
             }
         }
         __syncthreads();
