@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
                                                      const unsigned long long* __restrict__ docmask,
                                                      const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                      unsigned long long* __restrict__ startmask) {
-    __shared__ uint8_t sb[PT_R + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t sb[PT_R + 8];
     __shared__ uint8_t si[PT_R + 8];
     __shared__ uint8_t sc[PT_R + 8];
     const int tid = (int)threadIdx.x;
@@ -180,10 +180,26 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
     const int64_t r0 = t0 - PT_HALO;                        // first byte of the staged region
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // effective text length (prefix-space pass: on device)
 
-    // phase 0: stage bytes (zero outside the text)
-    for (int k = tid; k < PT_R + 8; k += 256) {
-        int64_t g = r0 + k;
-        sb[k] = (g >= 0 && g < n_bytes) ? text[g] : (uint8_t)0;
+    // phase 0: stage bytes (zero outside the text) with aligned dword loads, and this tile's doc-start words
+    __shared__ unsigned long long sdoc[PT_TILE / 64 + 2];
+    {
+        // r0 = t0 - 8 is a multiple of 4 (t0 is a multiple of 2048), so dword k covers bytes r0 + 4k .. +3
+        uint32_t* sb32 = (uint32_t*)sb;
+        for (int k = tid; k < (PT_R + 8) / 4; k += 256) {
+            int64_t g = r0 + 4 * (int64_t)k;
+            uint32_t v = 0;
+            if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
+            else if (g + 4 > 0 && g < n_bytes) {
+                for (int q = 0; q < 4; ++q)
+                    if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
+            }
+            sb32[k] = v;
+        }
+        // doc-start words covering [t0 - 64, t0 + PT_TILE + 64)
+        if (tid < PT_TILE / 64 + 2) {
+            int64_t w = (t0 >> 6) - 1 + tid;
+            sdoc[tid] = (w >= 0 && (w << 6) < n_bytes_host + 64) ? docmask[w] : 0ull;
+        }
     }
     __syncthreads();
     // phase 1: per-byte info (class of the code point that starts here)
@@ -193,7 +209,8 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
         if (g >= 0 && g < n_bytes) {
             uint32_t b = sb[k];
             info = IF_VALID;
-            if ((docmask[g >> 6] >> (g & 63)) & 1ull) info |= IF_DOC;
+            int64_t rel = g - (t0 - 64);                     // bit index inside sdoc
+            if ((sdoc[rel >> 6] >> (rel & 63)) & 1ull) info |= IF_DOC;
             if ((b & 0xC0u) != 0x80u) {
                 uint32_t len;
                 uint32_t cp = utf8_at(sb, k, &len);
