@@ -270,3 +270,24 @@ def test_encode_batch_matches_golden_char_offsets(name):
         assert e.ids == v["ids"][i], doc
         assert [list(x) for x in e.offsets] == v["offsets_char"][i], doc
         assert e.word_ids == v["words"][i], doc
+
+
+def test_alternative_kernels_agree(gpt2_json):
+    """The A/B kernel variants (bit-parallel pre-tokenizer, 16-lane DPP-row merge) must give the same ids as the
+    default ones: run them in a subprocess because the selection is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, tokenizers_amd as ta\n"
+        "from oracle import synth, oracle as orc\n"
+        "js = synth.load_or_train_gpt2()\n"
+        "docs = synth.gen_lines(6000, text_seed=41) + synth.stress_lines(seed=12, n=3000)\n"
+        "got = ta.Tokenizer.from_str(js, device=0).encode_batch_fast(docs, add_special_tokens=False)\n"
+        "exp = orc.Oracle(js).encode_batch(docs)\n"
+        "assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all()\n"
+        "print('VARIANT_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TKAMD_PRETOK="bits", TKAMD_MERGE16="row")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr

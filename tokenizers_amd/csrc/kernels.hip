@@ -281,6 +281,146 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
 }
 
 // =================================================================================================
+// K_pretok_gpt2_bits: the same GPT-2 start predicate, bit-parallel.  One lane per byte only to CLASSIFY
+// (class of the code point the byte belongs to, a handful of byte tests), every predicate becomes a
+// 64-bit ballot, and the whole window logic of k_pretok_gpt2 -- contraction literals, eaten letters,
+// " ?X+" attachment, \s+(?!\S) -- is ~80 scalar 64-bit operations per 64-byte word on masks shifted by
+// one to three bytes (carries come from the neighbouring words' masks).  A wavefront walks 16 words
+// (1 KB) of an LDS-staged 4 KB tile, carrying the previous word's masks and contraction bits.
+// Continuation bytes carry the class of their code point, so "class of the previous code point" is
+// simply "class of the previous byte".
+// =================================================================================================
+constexpr int PB_WORDS_PER_WAVE = 16;
+constexpr int PB_TILE = 4 * PB_WORDS_PER_WAVE * 64;       // 4096 bytes per workgroup
+constexpr int PB_PAD = 64;                                // one word of context on each side
+constexpr int PB_GUARD = 16;                              // readable slack before/after the staged words (UTF-8 look-around)
+
+struct PbMasks {
+    uint64_t L, N, S, LEAD, SP, AP, c_s, c_rv, c_e, c_l, VALID, DOC;
+};
+
+__device__ __forceinline__ uint64_t shl1(uint64_t cur, uint64_t prev) { return (cur << 1) | (prev >> 63); }
+__device__ __forceinline__ uint64_t shl2(uint64_t cur, uint64_t prev) { return (cur << 2) | (prev >> 62); }
+__device__ __forceinline__ uint64_t shl3(uint64_t cur, uint64_t prev) { return (cur << 3) | (prev >> 61); }
+__device__ __forceinline__ uint64_t shr1(uint64_t cur, uint64_t next) { return (cur >> 1) | (next << 63); }
+__device__ __forceinline__ uint64_t shr2(uint64_t cur, uint64_t next) { return (cur >> 2) | (next << 62); }
+
+// classify the 64 bytes of one word; `k` = byte index of the word inside the staged region
+__device__ __forceinline__ PbMasks pb_classify(const uint8_t* sb, int k, int lane, int64_t g0, int64_t n_bytes, uint64_t docword,
+                                               const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
+    const int q = k + lane;
+    const uint32_t b = sb[q];
+    const bool valid = (g0 + lane >= 0) && (g0 + lane < n_bytes);
+    uint32_t cls;
+    if (__ballot(b >= 0x80u) == 0ull) {
+        cls = cls_lns(b, uc1, uc2);                                   // ASCII: arithmetic classes
+    } else {
+        // find the lead byte of the code point this byte belongs to, decode, look the class up
+        int j = q;
+        if ((sb[j] & 0xC0u) == 0x80u) { --j; if ((sb[j] & 0xC0u) == 0x80u) { --j; if ((sb[j] & 0xC0u) == 0x80u) --j; } }
+        uint32_t len;
+        uint32_t cp = utf8_at(sb, j, &len);
+        cls = cls_lns(cp, uc1, uc2);
+    }
+    PbMasks m;
+    m.VALID = __ballot(valid);
+    m.L = __ballot(valid && cls == 1);
+    m.N = __ballot(valid && cls == 2);
+    m.S = __ballot(valid && cls == 3);
+    m.LEAD = __ballot(valid && (b & 0xC0u) != 0x80u);
+    m.SP = __ballot(valid && b == 0x20u);
+    m.AP = __ballot(valid && b == '\'');
+    m.c_s = __ballot(b == 's' || b == 't' || b == 'm' || b == 'd');
+    m.c_rv = __ballot(b == 'r' || b == 'v');
+    m.c_e = __ballot(b == 'e');
+    m.c_l = __ballot(b == 'l');
+    m.DOC = docword & m.VALID;
+    return m;
+}
+
+// contraction literals that are match starts, for the word `c` (needs the previous and next word's masks)
+__device__ __forceinline__ void pb_contractions(const PbMasks& p, const PbMasks& c, const PbMasks& n, uint64_t* con2, uint64_t* con3) {
+    uint64_t okc = c.VALID & ~c.DOC, okn = n.VALID & ~n.DOC;
+    uint64_t ok1 = shr1(okc, okn);                                   // byte i+1 exists in the same document
+    uint64_t ok2 = ok1 & shr2(okc, okn);
+    uint64_t lit2 = c.AP & ok1 & shr1(c.c_s, n.c_s);
+    uint64_t lit3 = c.AP & ok2 & ((shr1(c.c_rv, n.c_rv) & shr2(c.c_e, n.c_e)) | (shr1(c.c_l, n.c_l) & shr2(c.c_l, n.c_l)));
+    uint64_t cond = c.DOC | shl1(c.L, p.L) | shl1(c.N, p.N) | (shl1(c.S, p.S) & ~shl1(c.SP, p.SP));
+    *con2 = lit2 & cond;
+    *con3 = lit3 & cond;
+}
+
+__global__ __launch_bounds__(256) void k_pretok_gpt2_bits(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                          const int64_t* __restrict__ len_dev,
+                                                          const unsigned long long* __restrict__ docmask,
+                                                          const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                          unsigned long long* __restrict__ startmask) {
+    __shared__ __attribute__((aligned(16))) uint8_t sb[PB_TILE + 2 * PB_PAD + 2 * PB_GUARD];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * PB_TILE;
+    const int64_t r0 = t0 - PB_PAD - PB_GUARD;
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    // stage [t0 - 80, t0 + 4096 + 80) with aligned 16-byte loads (zero outside the text)
+    for (int k = tid; k < (PB_TILE + 2 * PB_PAD + 2 * PB_GUARD) / 16; k += 256) {
+        int64_t g = r0 + 16 * (int64_t)k;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g >= 0 && g + 16 <= n_bytes) v = *(const uint4*)(text + g);
+        else if (g + 16 > 0 && g < n_bytes) {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int q = 0; q < 16; ++q)
+                if (g + q >= 0 && g + q < n_bytes) w[q >> 2] |= (uint32_t)text[g + q] << (8 * (q & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        ((uint4*)sb)[k] = v;
+    }
+    __syncthreads();
+    const int64_t n_words_host = (n_bytes_host >> 6) + 1;
+    const int64_t w0 = (t0 >> 6) + (int64_t)wave * PB_WORDS_PER_WAVE;       // first word of this wavefront
+    auto docword = [&](int64_t w) -> uint64_t { return (w >= 0 && w < n_words_host) ? docmask[w] : 0ull; };
+    auto masks_of = [&](int64_t w) -> PbMasks {
+        int k = (int)((w << 6) - r0);                                         // byte index inside sb
+        return pb_classify(sb, k, lane, w << 6, n_bytes, docword(w), uc1, uc2);
+    };
+    PbMasks zero{};
+    PbMasks prev = masks_of(w0 - 1), cur = masks_of(w0);
+    uint64_t pc2, pc3;                                                        // contraction bits of the previous word
+    pb_contractions(zero, prev, cur, &pc2, &pc3);                             // bit 0 may be wrong: only bits 61..63 are used
+    for (int i = 0; i < PB_WORDS_PER_WAVE; ++i) {
+        const int64_t w = w0 + i;
+        if ((w << 6) > n_bytes_host) break;                                   // wave-uniform
+        PbMasks next = masks_of(w + 1);
+        uint64_t c2, c3;
+        pb_contractions(prev, cur, next, &c2, &c3);
+        const uint64_t con = c2 | c3, pcon = pc2 | pc3;
+        const uint64_t eaten = shl1(con, pcon) | shl2(c3, pc3);
+        const uint64_t afterc = shl2(c2, pc2) | shl3(c3, pc3);
+        const uint64_t O = cur.VALID & ~(cur.L | cur.N | cur.S), pO = prev.VALID & ~(prev.L | prev.N | prev.S);
+        const uint64_t pSP = shl1(cur.SP, prev.SP);
+        const uint64_t run = (cur.L & ~(shl1(cur.L, prev.L) | pSP)) | (cur.N & ~(shl1(cur.N, prev.N) | pSP)) | (O & ~(shl1(O, pO) | pSP));
+        const uint64_t pS = shl1(cur.S, prev.S);
+        const uint64_t wsfirst = cur.S & ~pS;
+        // G: last byte of a whitespace code point that is followed, inside the document, by a non-space
+        const uint64_t nLEAD = shr1(cur.LEAD, next.LEAD), nVALID = shr1(cur.VALID, next.VALID);
+        const uint64_t E = nLEAD | ~nVALID;
+        const uint64_t nfollow = shr1(cur.VALID & ~cur.DOC & ~cur.S, next.VALID & ~next.DOC & ~next.S);
+        const uint64_t G = cur.S & E & nfollow;
+        // next word's G is needed when a multi-byte whitespace char straddles the word edge
+        const uint64_t nG_lo = [&] {
+            // bits 0..1 of G for the next word: computed from `next` alone except nfollow at its bit 63 (irrelevant here)
+            uint64_t nE = (next.LEAD >> 1) | ~(next.VALID >> 1);
+            uint64_t nf = (next.VALID & ~next.DOC & ~next.S) >> 1;
+            return next.S & nE & nf;
+        }();
+        const uint64_t Gc = G & ~cur.LEAD, nGc = nG_lo & ~next.LEAD;
+        const uint64_t H = G | shr1(Gc, nGc) | (shr2(Gc, nGc) & ~nLEAD);
+        const uint64_t wslast = cur.S & pS & H;
+        uint64_t start = cur.VALID & cur.LEAD & (cur.DOC | (~eaten & (con | afterc | run | wsfirst | wslast)));
+        if (lane == 0) startmask[w] = start;
+        prev = cur; cur = next; pc2 = c2; pc3 = c3;
+    }
+}
+
+// =================================================================================================
 // K_pretok_llama3: the Llama-3 / tiktoken cl100k-style split
 //   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
 // Replaces Split::pre_tokenize (pre_tokenizers/split.rs:96-104, Oniguruma find_iter, Isolated) inside
@@ -1615,8 +1755,11 @@ void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_do
     launch_mark_doc_starts_n(st, doc_off, n_docs, n_bytes, nullptr, docmask, err);
 }
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask) {
-    hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant) {
+    if (variant == 0)
+        hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    else
+        hipLaunchKernelGGL(k_pretok_gpt2_bits, dim3(blocks_for(n_bytes + 1, PB_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
 }
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total) {
