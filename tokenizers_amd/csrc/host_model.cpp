@@ -123,8 +123,54 @@ void build_pair_table(const std::vector<MergeSlot>& items, std::vector<MergeSlot
     throw Invalid("could not build a pair hash table");
 }
 
+// Hash-and-displace (CHD) perfect hash over the merge pairs: buckets by hash1, largest first, each bucket
+// searches the smallest 16-bit displacement that drops all its keys into free slots.
 void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
-    build_pair_table(merges, &m.merge_table, &m.merge_mask, &m.merge_seed);
+    uint32_t cap = 16;
+    while (cap < merges.size() * 5 / 2) cap <<= 1;            // load factor <= 0.4
+    uint32_t nb = 16;
+    while (nb < merges.size() / 4) nb <<= 1;                  // 2-4 keys per bucket (50k merges -> 16384 buckets = 32 KB)
+    std::mt19937 rng(777);
+    for (int attempt = 0; attempt < 32; ++attempt) {
+        const uint32_t seed = (uint32_t)rng(), mask = cap - 1, bmask = nb - 1;
+        std::vector<std::vector<uint32_t>> buckets(nb);
+        for (uint32_t i = 0; i < merges.size(); ++i) buckets[merge_hash1(merges[i].a, merges[i].b, seed) & bmask].push_back(i);
+        std::vector<uint32_t> order(nb);
+        for (uint32_t b = 0; b < nb; ++b) order[b] = b;
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
+        std::vector<MergeSlot> tab(cap, MergeSlot{MERGE_EMPTY, MERGE_EMPTY, RANK_NONE, 0});
+        std::vector<uint16_t> disp(nb, 0);
+        bool ok = true;
+        std::vector<uint32_t> slots;
+        for (uint32_t b : order) {
+            const auto& keys = buckets[b];
+            if (keys.empty()) break;
+            bool placed = false;
+            for (uint32_t d = 0; d < 65536 && !placed; ++d) {
+                slots.clear();
+                bool clash = false;
+                for (uint32_t i : keys) {
+                    uint32_t sl = ph_slot(merge_hash2(merges[i].a, merges[i].b, seed), d, mask);
+                    if (tab[sl].a != MERGE_EMPTY || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
+                    slots.push_back(sl);
+                }
+                if (!clash) {
+                    for (size_t k = 0; k < keys.size(); ++k) tab[slots[k]] = merges[keys[k]];
+                    disp[b] = (uint16_t)d;
+                    placed = true;
+                }
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (ok) {
+            m.merge_table.swap(tab);
+            m.merge_disp.swap(disp);
+            m.merge_mask = mask; m.merge_bmask = bmask; m.merge_seed = seed;
+            return;
+        }
+        if (attempt % 2 == 1) cap <<= 1;
+    }
+    throw Invalid("could not build the merge hash table");
 }
 
 void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {

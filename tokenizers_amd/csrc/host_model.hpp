@@ -68,8 +68,9 @@ struct HostModel {
 
     // ---- tables copied to the device ----
     uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level)
-    std::vector<MergeSlot> merge_table; // cuckoo, size = merge_mask+1 (power of two) or empty
-    uint32_t merge_mask = 0, merge_seed = 0;
+    std::vector<MergeSlot> merge_table; // perfect hash (hash-and-displace), size = merge_mask+1 (power of two)
+    std::vector<uint16_t> merge_disp;   // displacement per bucket, size = merge_bmask+1
+    uint32_t merge_mask = 0, merge_seed = 0, merge_bmask = 0;
     std::vector<WordSlot> word_table;   // cuckoo, size = word_mask+1
     uint32_t word_mask = 0, word_seed = 0;
     uint32_t n_words = 0;               // keys stored in word_table (<= 16 bytes)

@@ -1063,6 +1063,7 @@ __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __
     }
 }
 
+constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
 constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
 constexpr int LK_CHUNK = 256 * LK_ITEMS;
 constexpr int LK_GROUP = 4;                      // items whose loads are kept in flight together
@@ -1184,14 +1185,25 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
 // Pair -> (rank, new_id) probes hit the static 2-choice cuckoo table (two independent 16-byte
 // loads; bpe/model.rs:252-275 defines the contents).
 // =================================================================================================
+// one-slot perfect-hash probe; `disp` may point to an LDS copy of t.merge_disp
+__device__ __forceinline__ void merge_probe_d(const DevTables& t, const uint16_t* disp, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
+    uint32_t d = disp[merge_hash1(a, b, t.merge_seed) & t.merge_bmask];
+    uint4 x = ((const uint4*)t.merges)[ph_slot(merge_hash2(a, b, t.merge_seed), d, t.merge_mask)];
+    bool hit = x.x == a && x.y == b;
+    *rank = hit ? x.z : RANK_NONE;
+    *new_id = hit ? x.w : 0u;
+}
 __device__ __forceinline__ void merge_probe(const DevTables& t, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
-    uint32_t s1 = merge_hash1(a, b, t.merge_seed) & t.merge_mask;
-    uint32_t s2 = merge_hash2(a, b, t.merge_seed) & t.merge_mask;
-    uint4 x = ((const uint4*)t.merges)[s1];
-    uint4 y = ((const uint4*)t.merges)[s2];
-    if (x.x == a && x.y == b) { *rank = x.z; *new_id = x.w; }
-    else if (y.x == a && y.y == b) { *rank = y.z; *new_id = y.w; }
-    else { *rank = RANK_NONE; *new_id = 0; }
+    merge_probe_d(t, t.merge_disp, a, b, rank, new_id);
+}
+// 2-choice cuckoo probe over a pair table (WordPiece trie edges): two independent 16-byte loads
+__device__ __forceinline__ void pair_probe2(const MergeSlot* __restrict__ tab, uint32_t mask, uint32_t seed, uint32_t a, uint32_t b,
+                                            uint32_t* v0, uint32_t* v1) {
+    uint4 x = ((const uint4*)tab)[merge_hash1(a, b, seed) & mask];
+    uint4 y = ((const uint4*)tab)[merge_hash2(a, b, seed) & mask];
+    if (x.x == a && x.y == b) { *v0 = x.z; *v1 = x.w; }
+    else if (y.x == a && y.y == b) { *v0 = y.z; *v1 = y.w; }
+    else { *v0 = RANK_NONE; *v1 = 0; }
 }
 
 template <int G>
@@ -1293,15 +1305,39 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
     constexpr uint32_t PB = (S == 16) ? 4 : 5;              // bits of the pair index inside the reduction key
     __shared__ uint32_t s_byte_id[256];
+    __shared__ uint16_t s_disp[DISP_LDS_MAX];
+    __shared__ uint32_t s_hist[S + 1];
+    __shared__ uint4 s_sort[256];
     s_byte_id[threadIdx.x] = t.byte_id[threadIdx.x];
+    const bool disp_in_lds = t.merge_bmask < (uint32_t)DISP_LDS_MAX;
+    if (disp_in_lds)
+        for (uint32_t i = threadIdx.x; i <= t.merge_bmask; i += 256) s_disp[i] = t.merge_disp[i];
     __syncthreads();
+    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;   // generic pointer: LDS or global
     const uint32_t n_items = *n_list;
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t base = blockIdx.x * 256; base < n_items; base += stride) {
         const uint32_t item = base + threadIdx.x;
-        const bool valid = item < n_items;
+        bool valid = item < n_items;
         uint32_t p = 0, s = 0, len = 0;
         if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        // The loop below runs until the slowest lane of a wavefront is done (~len - 2 rounds), so the 256 items of
+        // this workgroup are counting-sorted by length first: each wavefront then holds one quartile of the lengths.
+        {
+            __syncthreads();
+            if (threadIdx.x <= S) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t bin = valid ? len : (uint32_t)S;            // invalid lanes sort last (len <= S, so bin S is theirs + len == S)
+            const uint32_t within = atomicAdd(&s_hist[bin], 1u);
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
+            const uint32_t slot = before + within;
+            s_sort[slot] = make_uint4(p, s, len, valid ? 1u : 0u);
+            __syncthreads();
+            const uint4 it = s_sort[threadIdx.x];
+            p = it.x; s = it.y; len = it.z; valid = it.w != 0u;
+        }
         uint64_t key[S / 8];
 #pragma unroll
         for (int q = 0; q < S / 8; ++q) key[q] = 0;
@@ -1319,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
         }
 #pragma unroll
         for (int i = 0; i < S - 1; ++i)
-            if ((uint32_t)(i + 1) < len) merge_probe(t, ids[i], ids[i + 1], &rk[i], &nd[i]);
+            if ((uint32_t)(i + 1) < len) merge_probe_d(t, disp, ids[i], ids[i + 1], &rk[i], &nd[i]);
         uint32_t n = len;                                   // live symbols
         uint32_t starts = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);   // bit b: a symbol starts at byte b
         bool active = valid && len > 1;
@@ -1358,8 +1394,8 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
                         right = ((uint32_t)i == w + 1) ? ids[i] : right;
                     }
                     uint32_t r1 = RANK_NONE, n1 = 0, r2 = RANK_NONE, n2 = 0;
-                    if (w > 0) merge_probe(t, left, new_id, &r1, &n1);
-                    if (w + 1 < n) merge_probe(t, new_id, right, &r2, &n2);
+                    if (w > 0) merge_probe_d(t, disp, left, new_id, &r1, &n1);
+                    if (w + 1 < n) merge_probe_d(t, disp, new_id, right, &r2, &n2);
 #pragma unroll
                     for (int i = 0; i < S - 1; ++i) {
                         if ((uint32_t)i + 1 == w) { rk[i] = r1; nd[i] = n1; }
@@ -1549,8 +1585,6 @@ __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* _
                                                    uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
                                                    uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
     const int64_t P = *n_pretok;
-    DevTables tt = t;
-    tt.merges = t.trie; tt.merge_mask = t.trie_mask; tt.merge_seed = t.trie_seed;     // reuse the pair probe
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
         uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
         uint32_t chars = 0;
@@ -1561,7 +1595,7 @@ __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* _
             uint32_t node = pos ? 1u : 0u, q = pos, best_end = 0, best_id = 0;
             while (q < len) {
                 uint32_t child, id;
-                merge_probe(tt, node, (uint32_t)text[s + q], &child, &id);
+                pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, (uint32_t)text[s + q], &child, &id);
                 if (child == RANK_NONE) break;
                 node = child;
                 ++q;

@@ -12,8 +12,9 @@ struct DevTables {
     const uint16_t* uc1;          // unicode stage 1
     const uint8_t* uc2;           // unicode stage 2
     const uint32_t* byte_id;      // [256]
-    const MergeSlot* merges;
-    uint32_t merge_mask, merge_seed;
+    const MergeSlot* merges;          // perfect-hash table (one slot per key)
+    const uint16_t* merge_disp;       // bucket displacements
+    uint32_t merge_mask, merge_seed, merge_bmask;
     const WordSlot* words;
     uint32_t word_mask, word_seed;
     uint32_t ignore_merges;

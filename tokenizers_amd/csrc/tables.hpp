@@ -47,6 +47,12 @@ TK_HD uint32_t mix32(uint32_t x) {
 TK_HD uint32_t merge_hash1(uint32_t a, uint32_t b, uint32_t seed) { return mix32(a * 0x9E3779B1u + b * 0x85EBCA77u + seed); }
 TK_HD uint32_t merge_hash2(uint32_t a, uint32_t b, uint32_t seed) { return mix32((a ^ 0x5BD1E995u) * 0xC2B2AE3Du + (b + 0x27D4EB2Fu) * 0x165667B1u + seed * 0x9E3779B1u); }
 
+// Hash-and-displace perfect hash for the merge table: bucket = hash1 & bmask selects a 16-bit displacement d,
+// the key then lives in exactly ONE slot, (hash2 + d * PH_MULT) & mask.  A lookup -- hit or miss -- is one
+// 16-byte load; the displacement array is small enough (<= 32 KB for 50k merges) to sit in LDS.
+constexpr uint32_t PH_MULT = 0x9E3779B1u;
+TK_HD uint32_t ph_slot(uint32_t h2, uint32_t d, uint32_t mask) { return (h2 + d * PH_MULT) & mask; }
+
 // ---- whole-word table: raw pre-token bytes (<= 16) -> token id ------------------------------
 // Serves BPE `ignore_merges` (bpe/model.rs:559-567), WordLevel (wordlevel/mod.rs:162-178) and the
 // merge-stable shortcut: key = bytes zero-padded to 16 + length.
