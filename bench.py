@@ -147,6 +147,24 @@ def main() -> None:
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
 
+    # ---- host-boundary leg (rank 0, N=1): list[str] -> CSR numpy through tkamd_encode_batch (PCIe inclusive) ----
+    host = None
+    if rank == 0 and world == 1:
+        t0 = time.perf_counter()
+        hb, ho = ta.pack_documents(lines)
+        t_pack = time.perf_counter() - t0
+        tok.encode_packed(hb, ho)                                # warm-up (staging buffers)
+        best = float("inf")
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = tok.encode_packed(hb, ho)
+            best = min(best, time.perf_counter() - t0)
+        host = {"pack_list_of_str_ms": round(t_pack * 1e3, 2), "encode_packed_ms": round(best * 1e3, 2),
+                "gbps_pcie_inclusive": round(n_bytes / best / 1e9, 3),
+                "gbps_from_list_of_str": round(n_bytes / (best + t_pack) / 1e9, 3),
+                "note": "tkamd_encode_batch: pageable H2D of text + kernels + D2H of ids/CSR into host memory; never reported as value"}
+        assert res.n_tokens == n_tok
+
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's Rayon encode_batch on the host cores ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -164,7 +182,7 @@ def main() -> None:
                        "pretokens_per_gpu": int(n_pretok), "type_seed": args.type_seed,
                        "tokenizer_sha256": synth.sha256(tok_json)[:16], "gather": bool(gather),
                        "parallelism": f"dp{world} (documents sharded by rank)"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host,
         }
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_gather:

@@ -51,5 +51,31 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+MARSHAL_SRC = os.path.join(CSRC, "pymarshal.c")
+
+
+def marshal_path() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_marshal" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_marshal(force: bool = False) -> str:
+    """CPython extension for list[str] -> UTF-8 CSR marshalling (plain C, gcc)."""
+    import sysconfig
+    out = marshal_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(MARSHAL_SRC):
+        return out
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler for tokenizers_amd._marshal")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], MARSHAL_SRC, "-o", out + ".tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building _marshal failed:\n" + r.stdout + r.stderr)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
+    print(build_marshal(force="--force" in sys.argv))
     print(build_library(force="--force" in sys.argv, verbose=True))

@@ -19,17 +19,30 @@ from . import _lib
 from ._lib import DeviceError, TokenizersAmdError, UnsupportedError  # noqa: F401
 
 
+try:
+    from . import _marshal          # C extension (csrc/pymarshal.c); built by tokenizers_amd.build.build_marshal()
+except ImportError:                 # pragma: no cover - pure-Python marshalling below is equivalent, just slower
+    _marshal = None
+
+
 def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
     """``list[str]`` -> (uint8 buffer with TEXT_PAD slack, int64 CSR offsets).
 
     Mirrors the extraction loop of PyTokenizer::encode_batch (tokenizer.rs:1320-1327):
     every item must be ``str`` (``TypeError('TextInputSequence must be str')``, tokenizer.rs:274).
+    Host marshalling only -- no tokenisation happens here.
     """
+    if _marshal is not None:
+        try:
+            buf, off = _marshal.pack(inputs)
+        except NotImplementedError as e:
+            raise UnsupportedError(str(e)) from None
+        return np.frombuffer(buf, dtype=np.uint8), np.frombuffer(off, dtype=np.int64)
     enc = []
     for s in inputs:
         if not isinstance(s, str):
             if isinstance(s, (tuple, list)):
-                raise UnsupportedError("pair / pre-tokenized inputs (EncodeInput::Dual, PreTokenized) are outside the MI355X hot path")
+                raise UnsupportedError("pair / pre-tokenized inputs are outside the MI355X hot path")
             raise TypeError("TextInputSequence must be str")
         enc.append(s.encode("utf-8"))
     n = len(enc)
