@@ -273,7 +273,7 @@ def test_encode_batch_matches_golden_char_offsets(name):
 
 
 def test_alternative_kernels_agree(gpt2_json):
-    """The A/B kernel variants (bit-parallel pre-tokenizer, 16-lane DPP-row merge) must give the same ids as the
+    """The A/B kernel variants (bit-parallel pre-tokenizer, 16-lane DPP-row merge, in-batch de-duplication) must give the same ids as the
     default ones: run them in a subprocess because the selection is read once per process."""
     import os
     import subprocess
@@ -288,6 +288,6 @@ def test_alternative_kernels_agree(gpt2_json):
         "exp = orc.Oracle(js).encode_batch(docs)\n"
         "assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all()\n"
         "print('VARIANT_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TKAMD_PRETOK="bits", TKAMD_MERGE16="row")
+    env = dict(os.environ, TKAMD_PRETOK="bits", TKAMD_MERGE16="row", TKAMD_DEDUP="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr

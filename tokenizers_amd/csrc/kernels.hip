@@ -1429,6 +1429,107 @@ template __global__ void k_bpe_merge_lane<16>(DevTables, const uint8_t*, const u
 template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 
 // =================================================================================================
+// In-batch de-duplication of the merge work queue.  Natural text repeats its rare words too (Zipf), and
+// the reference exploits that with a per-thread word cache (models/bpe/model.rs:82-90, 573-586: a hit
+// returns the cached Word instead of running merge_word).  The device analogue is stateless across calls:
+//   k_dedup_insert : every queued pre-token (<= 16 bytes) claims / finds the slot of its 64-bit key hash in
+//                    an open-addressing table and lowers the slot's representative to the smallest item index
+//   k_dedup_resolve: (next launch, so all table writes are visible) an item whose representative is itself
+//                    goes to the "unique" queue; any other item is byte-compared with its representative --
+//                    equal -> (item, representative) pair in the "duplicate" queue, different (hash
+//                    collision) -> unique.  Exactness therefore never rests on the hash.
+//   merge kernels run on the unique queue only
+//   k_dedup_copy   : duplicates copy their representative's tokens.
+// A table that is too small only costs speed: items that find no slot within 16 probes are unique.
+// =================================================================================================
+__device__ __forceinline__ uint64_t key_hash64(uint64_t lo, uint64_t hi, uint32_t len) {
+    uint64_t h = (lo ^ (hi * 0x9E3779B97F4A7C15ull)) + len * 0xC2B2AE3D27D4EB4Full;
+    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+    return h | 0x8000000000000000ull;                    // never 0 (0 = empty slot)
+}
+
+__global__ __launch_bounds__(256) void k_dedup_insert(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pt_start,
+                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                      unsigned long long* __restrict__ fp_tab, uint32_t* __restrict__ rep_tab, uint32_t cmask,
+                                                      uint32_t* __restrict__ slot_of) {
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t p = list[i], s = pt_start[p], len = pt_start[p + 1] - s;
+        uint64_t lo, hi;
+        load_key16(text, s, len, &lo, &hi);
+        const unsigned long long fp = key_hash64(lo, hi, len);
+        uint32_t slot = (uint32_t)(fp >> 17) & cmask, found = 0xFFFFFFFFu;
+        for (int probe = 0; probe < 16; ++probe) {
+            unsigned long long v = fp_tab[slot];
+            if (v == 0ull) v = atomicCAS(&fp_tab[slot], 0ull, fp), v = (v == 0ull) ? fp : v;
+            if (v == fp) { found = slot; break; }
+            slot = (slot + 1) & cmask;
+        }
+        if (found != 0xFFFFFFFFu && rep_tab[found] > i) atomicMin(&rep_tab[found], i);
+        slot_of[i] = found;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dedup_resolve(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pt_start,
+                                                       const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                       const uint32_t* __restrict__ rep_tab, const uint32_t* __restrict__ slot_of,
+                                                       uint32_t* __restrict__ ulist, uint32_t* __restrict__ dlist,
+                                                       uint32_t* __restrict__ counters) {
+    __shared__ uint32_t sm[4];
+    __shared__ uint32_t base_s[2];
+    const uint32_t n = *n_list;
+    const uint32_t n_iter = (n + 255) / 256;
+    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+        const uint32_t i = it * 256 + threadIdx.x;
+        bool valid = i < n, dup = false;
+        uint32_t p = 0, pr = 0;
+        if (valid) {
+            p = list[i];
+            const uint32_t sl = slot_of[i];
+            if (sl != 0xFFFFFFFFu) {
+                const uint32_t r = rep_tab[sl];
+                if (r != i) {
+                    pr = list[r];
+                    const uint32_t s = pt_start[p], len = pt_start[p + 1] - s, sr = pt_start[pr], lenr = pt_start[pr + 1] - sr;
+                    uint64_t lo, hi, lor, hir;
+                    load_key16(text, s, len, &lo, &hi);
+                    load_key16(text, sr, lenr, &lor, &hir);
+                    dup = (len == lenr) && lo == lor && hi == hir;
+                }
+            }
+        }
+        const uint32_t nu = (valid && !dup) ? 1u : 0u, nd = dup ? 1u : 0u;
+        uint32_t tot;
+        const uint32_t ex = block256_excl_scan(nu | (nd << 16), sm, &tot);
+        if (threadIdx.x == 0) {
+            base_s[0] = (tot & 0xFFFFu) ? atomicAdd(&counters[CNT_ULIST], tot & 0xFFFFu) : 0u;
+            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_DLIST], tot >> 16) : 0u;
+        }
+        __syncthreads();
+        if (nu) ulist[base_s[0] + (ex & 0xFFFFu)] = p;
+        if (nd) { uint32_t o = base_s[1] + (ex >> 16); dlist[2 * o] = p; dlist[2 * o + 1] = pr; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dedup_copy(const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ dlist,
+                                                    const uint32_t* __restrict__ n_dup, uint32_t* __restrict__ tok0,
+                                                    uint32_t* __restrict__ ntok, uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    const uint32_t n = *n_dup;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const uint32_t p = dlist[2 * i], pr = dlist[2 * i + 1];
+        const uint32_t c = ntok[pr];
+        ntok[p] = c;
+        tok0[p] = tok0[pr];
+        if (c > 1 || tmp_end) {
+            const uint32_t s = pt_start[p], sr = pt_start[pr];
+            for (uint32_t j = 1; j < c; ++j) tmp_ids[s + j] = tmp_ids[sr + j];
+            if (tmp_end) for (uint32_t j = 0; j < c; ++j) tmp_end[s + j] = tmp_end[sr + j];
+        }
+    }
+}
+
+// =================================================================================================
 // K_bpe_merge_long: pre-tokens longer than 64 bytes, one workgroup each, symbols as a doubly linked
 // list in LDS (the same Symbol{c, prev, next, len} of models/bpe/word.rs:38-54), up to LONG_PT_MAX
 // symbols.  Each round: workgroup-wide min over the cached (rank, pos) keys, one merge, two
@@ -1885,6 +1986,17 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
     hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, (const uint32_t*)bsum, doc_off, xdoc_off, x_len);
     hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, doc_off, (const int64_t*)xdoc_off, n_docs, xtext);
+}
+void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t* pt_start, const uint32_t* list, const uint32_t* n_list,
+                  unsigned long long* fp_tab, uint32_t* rep_tab, uint32_t cmask, uint32_t* slot_of, uint32_t* ulist, uint32_t* dlist,
+                  uint32_t* counters) {
+    hipLaunchKernelGGL(k_dedup_insert, dim3(grid), dim3(256), 0, st, text, pt_start, list, n_list, fp_tab, rep_tab, cmask, slot_of);
+    hipLaunchKernelGGL(k_dedup_resolve, dim3(grid), dim3(256), 0, st, text, pt_start, list, n_list, (const uint32_t*)rep_tab, (const uint32_t*)slot_of,
+                       ulist, dlist, counters);
+}
+void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
+                       uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
+    hipLaunchKernelGGL(k_dedup_copy, dim3(grid), dim3(256), 0, st, pt_start, dlist, n_dup, tok0, ntok, tmp_ids, tmp_end);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {

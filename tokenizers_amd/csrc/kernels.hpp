@@ -64,7 +64,7 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_COUNT = 8 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_ULIST = 5, CNT_DLIST = 6, CNT_COUNT = 8 };
 
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident)
 
@@ -107,6 +107,11 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
                           const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
+void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t* pt_start, const uint32_t* list, const uint32_t* n_list,
+                  unsigned long long* fp_tab, uint32_t* rep_tab, uint32_t cmask, uint32_t* slot_of, uint32_t* ulist, uint32_t* dlist,
+                  uint32_t* counters);
+void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
+                       uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
