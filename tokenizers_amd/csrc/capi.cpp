@@ -82,7 +82,7 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_merge_disp, t_trie, t_at_blob, t_at_off, t_at_first;
+    DevBuf t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
@@ -162,6 +162,7 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_merges, hm.merge_table);
     upload(t->t_merge_disp, hm.merge_disp);
     upload(t->t_words, hm.word_table, 64);
+    upload(t->t_word_disp, hm.word_disp);
     upload(t->t_long_blob, hm.long_blob);
     upload(t->t_long_off, hm.long_off);
     upload(t->t_long_id, hm.long_id);
@@ -180,8 +181,10 @@ void upload_tables(tkamd_tokenizer* t) {
     d.merge_seed = hm.merge_seed;
     d.merge_bmask = hm.merge_bmask;
     d.words = t->t_words.as<WordSlot>();
+    d.word_disp = t->t_word_disp.as<uint16_t>();
     d.word_mask = hm.word_mask;
     d.word_seed = hm.word_seed;
+    d.word_bmask = hm.word_bmask;
     d.ignore_merges = hm.ignore_merges ? 1u : 0u;
     d.unk_id = hm.unk_id;
     d.has_unk = hm.has_unk ? 1u : 0u;
@@ -630,7 +633,7 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
         DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_merge_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->t_long_id, &t->t_long_table, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
                          &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist,

@@ -123,8 +123,44 @@ void build_pair_table(const std::vector<MergeSlot>& items, std::vector<MergeSlot
     throw Invalid("could not build a pair hash table");
 }
 
-// Hash-and-displace (CHD) perfect hash over the merge pairs: buckets by hash1, largest first, each bucket
-// searches the smallest 16-bit displacement that drops all its keys into free slots.
+// Hash-and-displace (CHD) perfect hash: keys are bucketed by h1, buckets are placed largest first, each one
+// searches the smallest 16-bit displacement d that drops all its keys into free slots (h2 + d * PH_MULT) & mask.
+// Returns false if some bucket cannot be placed (caller retries with another seed / a larger table).
+bool chd_place(const std::vector<uint32_t>& h1, const std::vector<uint32_t>& h2, uint32_t mask, uint32_t bmask,
+               std::vector<uint16_t>* disp, std::vector<uint32_t>* slot_of_key) {
+    const uint32_t nb = bmask + 1, n = (uint32_t)h1.size();
+    std::vector<std::vector<uint32_t>> buckets(nb);
+    for (uint32_t i = 0; i < n; ++i) buckets[h1[i] & bmask].push_back(i);
+    std::vector<uint32_t> order(nb);
+    for (uint32_t b = 0; b < nb; ++b) order[b] = b;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
+    std::vector<uint8_t> used(mask + 1, 0);
+    disp->assign(nb, 0);
+    slot_of_key->assign(n, 0);
+    std::vector<uint32_t> slots;
+    for (uint32_t b : order) {
+        const auto& keys = buckets[b];
+        if (keys.empty()) break;
+        bool placed = false;
+        for (uint32_t d = 0; d < 65536 && !placed; ++d) {
+            slots.clear();
+            bool clash = false;
+            for (uint32_t i : keys) {
+                uint32_t sl = ph_slot(h2[i], d, mask);
+                if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
+                slots.push_back(sl);
+            }
+            if (!clash) {
+                for (size_t k = 0; k < keys.size(); ++k) { used[slots[k]] = 1; (*slot_of_key)[keys[k]] = slots[k]; }
+                (*disp)[b] = (uint16_t)d;
+                placed = true;
+            }
+        }
+        if (!placed) return false;
+    }
+    return true;
+}
+
 void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
     uint32_t cap = 16;
     while (cap < merges.size() * 5 / 2) cap <<= 1;            // load factor <= 0.4
@@ -132,40 +168,15 @@ void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
     while (nb < merges.size() / 4) nb <<= 1;                  // 2-4 keys per bucket (50k merges -> 16384 buckets = 32 KB)
     std::mt19937 rng(777);
     for (int attempt = 0; attempt < 32; ++attempt) {
-        const uint32_t seed = (uint32_t)rng(), mask = cap - 1, bmask = nb - 1;
-        std::vector<std::vector<uint32_t>> buckets(nb);
-        for (uint32_t i = 0; i < merges.size(); ++i) buckets[merge_hash1(merges[i].a, merges[i].b, seed) & bmask].push_back(i);
-        std::vector<uint32_t> order(nb);
-        for (uint32_t b = 0; b < nb; ++b) order[b] = b;
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
-        std::vector<MergeSlot> tab(cap, MergeSlot{MERGE_EMPTY, MERGE_EMPTY, RANK_NONE, 0});
-        std::vector<uint16_t> disp(nb, 0);
-        bool ok = true;
-        std::vector<uint32_t> slots;
-        for (uint32_t b : order) {
-            const auto& keys = buckets[b];
-            if (keys.empty()) break;
-            bool placed = false;
-            for (uint32_t d = 0; d < 65536 && !placed; ++d) {
-                slots.clear();
-                bool clash = false;
-                for (uint32_t i : keys) {
-                    uint32_t sl = ph_slot(merge_hash2(merges[i].a, merges[i].b, seed), d, mask);
-                    if (tab[sl].a != MERGE_EMPTY || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
-                    slots.push_back(sl);
-                }
-                if (!clash) {
-                    for (size_t k = 0; k < keys.size(); ++k) tab[slots[k]] = merges[keys[k]];
-                    disp[b] = (uint16_t)d;
-                    placed = true;
-                }
-            }
-            if (!placed) { ok = false; break; }
-        }
-        if (ok) {
-            m.merge_table.swap(tab);
+        const uint32_t seed = (uint32_t)rng();
+        std::vector<uint32_t> h1(merges.size()), h2(merges.size()), where;
+        for (size_t i = 0; i < merges.size(); ++i) { h1[i] = merge_hash1(merges[i].a, merges[i].b, seed); h2[i] = merge_hash2(merges[i].a, merges[i].b, seed); }
+        std::vector<uint16_t> disp;
+        if (chd_place(h1, h2, cap - 1, nb - 1, &disp, &where)) {
+            m.merge_table.assign(cap, MergeSlot{MERGE_EMPTY, MERGE_EMPTY, RANK_NONE, 0});
+            for (size_t i = 0; i < merges.size(); ++i) m.merge_table[where[i]] = merges[i];
             m.merge_disp.swap(disp);
-            m.merge_mask = mask; m.merge_bmask = bmask; m.merge_seed = seed;
+            m.merge_mask = cap - 1; m.merge_bmask = nb - 1; m.merge_seed = seed;
             return;
         }
         if (attempt % 2 == 1) cap <<= 1;
@@ -176,21 +187,22 @@ void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
 void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {
     uint32_t cap = 16;
     while (cap < words.size() * 5 / 2) cap <<= 1;
+    uint32_t nb = 16;
+    while (nb < words.size() / 4) nb <<= 1;
     std::mt19937 rng(54321);
-    for (int attempt = 0; attempt < 64; ++attempt) {
-        uint32_t seed = (uint32_t)rng();
-        uint32_t mask = cap - 1;
-        std::vector<WordSlot> tab(cap, WordSlot{0, 0, 0, 0, 0, 0});
-        bool ok = true;
-        for (const WordSlot& e : words) {
-            ok = cuckoo_insert(
-                tab, e, [](const WordSlot& s) { return s.len == 0; },
-                [&](const WordSlot& s) { return word_hash1(s.lo, s.hi, s.len, seed) & mask; },
-                [&](const WordSlot& s) { return word_hash2(word_hash1(s.lo, s.hi, s.len, seed)) & mask; }, rng);
-            if (!ok) break;
+    for (int attempt = 0; attempt < 32; ++attempt) {
+        const uint32_t seed = (uint32_t)rng();
+        std::vector<uint32_t> h1(words.size()), h2(words.size()), where;
+        for (size_t i = 0; i < words.size(); ++i) { h1[i] = word_hash1(words[i].lo, words[i].hi, words[i].len, seed); h2[i] = word_hash2(h1[i]); }
+        std::vector<uint16_t> disp;
+        if (chd_place(h1, h2, cap - 1, nb - 1, &disp, &where)) {
+            m.word_table.assign(cap, WordSlot{0, 0, 0, 0, 0, 0});
+            for (size_t i = 0; i < words.size(); ++i) m.word_table[where[i]] = words[i];
+            m.word_disp.swap(disp);
+            m.word_mask = cap - 1; m.word_bmask = nb - 1; m.word_seed = seed;
+            return;
         }
-        if (ok) { m.word_table.swap(tab); m.word_mask = mask; m.word_seed = seed; return; }
-        if (attempt % 4 == 3) cap <<= 1;
+        if (attempt % 2 == 1) cap <<= 1;
     }
     throw Invalid("could not build the whole-word hash table");
 }

@@ -960,20 +960,31 @@ __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __
     if (w < n_words) wprefix[w] = bsum[blockIdx.x] + ex;
 }
 
-// one lane per byte: a set start bit at byte i becomes pt_start[rank(i)] = i (coalesced stores)
+// A wavefront takes 64 consecutive mask words (4 KB of text): one coalesced load of the words and their
+// prefixes, then word by word (broadcast with readlane) lane l tests bit l and stores pt_start[rank] = position.
+// All loads are issued up front; the per-word work is a handful of VALU ops and one masked, rank-ordered store.
 __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* __restrict__ startmask,
                                                      const uint32_t* __restrict__ wprefix, int64_t n_bytes,
                                                      const int64_t* __restrict__ len_dev,
                                                      const int64_t* __restrict__ n_pretok,
                                                      uint32_t* __restrict__ pt_start) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) pt_start[*n_pretok] = (uint32_t)(len_dev ? *len_dev : n_bytes);          // sentinel
-    if (i >= n_bytes) return;
-    unsigned long long m = startmask[i >> 6];
-    int b = (int)(i & 63);
-    if ((m >> b) & 1ull) {
-        uint32_t r = wprefix[i >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
-        pt_start[r] = (uint32_t)i;
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave == 0 && lane == 0) pt_start[*n_pretok] = (uint32_t)(len_dev ? *len_dev : n_bytes);          // sentinel
+    const int64_t n_words = (n_bytes + 63) >> 6;
+    const int64_t w0 = wave * 64;
+    if (w0 >= n_words) return;
+    const int64_t wi = w0 + lane;
+    const unsigned long long mw = (wi < n_words) ? startmask[wi] : 0ull;
+    const uint32_t pw = (wi < n_words) ? wprefix[wi] : 0u;
+    const uint32_t mlo = (uint32_t)mw, mhi = (uint32_t)(mw >> 32);
+    const int kmax = (int)min((int64_t)64, n_words - w0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0; k < kmax; ++k) {
+        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, k) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)mlo, k);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
+        if ((m >> lane) & 1ull) pt_start[base + (uint32_t)__popcll(m & below)] = (uint32_t)(((w0 + k) << 6) + lane);
     }
 }
 
@@ -1017,33 +1028,33 @@ __global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t 
 //     merge result was verified at load time to be exactly [id] (WORD_DIRECT), so a hit is
 //     provably what merge_word would return; everything else goes to the merge kernel.
 // =================================================================================================
+struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t a, b, c, d; };
+
 __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint64_t* lo, uint64_t* hi) {
-    // dword-aligned 20-byte window + funnel shift (text buffers carry TKAMD_TEXT_PAD readable slack)
-    const uint32_t* p = (const uint32_t*)(text + (s & ~3u));
-    uint32_t w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
-    uint32_t sh = (s & 3u) * 8u;
-    uint32_t a0 = __funnelshift_r(w0, w1, sh), a1 = __funnelshift_r(w1, w2, sh);
-    uint32_t a2 = __funnelshift_r(w2, w3, sh), a3 = __funnelshift_r(w3, w4, sh);
+    // ONE byte-unaligned global_load_dwordx4 (legal on gfx950; text buffers carry TKAMD_TEXT_PAD readable slack).
+    // The texture-address unit costs about a cycle per lane request for divergent addresses, so requests -- not
+    // bytes -- are what this path is priced in.
+    const Unaligned16 v = *(const Unaligned16*)(text + s);
     // branch-free masking of the bytes past `len` (selects only, so callers can keep many loads in flight)
     uint32_t nl = min(len, 8u), nh = min(len, 16u) - nl;           // bytes kept in the low / high half
     uint32_t m0 = nl >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nl)) - 1u);
     uint32_t m1 = nl >= 8 ? 0xFFFFFFFFu : (nl > 4 ? ((1u << (8 * (nl - 4))) - 1u) : 0u);
     uint32_t m2 = nh >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nh)) - 1u);
     uint32_t m3 = nh >= 8 ? 0xFFFFFFFFu : (nh > 4 ? ((1u << (8 * (nh - 4))) - 1u) : 0u);
-    *lo = ((uint64_t)(a1 & m1) << 32) | (a0 & m0);
-    *hi = ((uint64_t)(a3 & m3) << 32) | (a2 & m2);
+    *lo = ((uint64_t)(v.b & m1) << 32) | (v.a & m0);
+    *hi = ((uint64_t)(v.d & m3) << 32) | (v.c & m2);
 }
 
-__device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
+__device__ __forceinline__ bool word_probe_d(const DevTables& t, const uint16_t* disp, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
     uint32_t h1 = word_hash1(lo, hi, len, t.word_seed);
-    uint32_t s1 = h1 & t.word_mask, s2 = word_hash2(h1) & t.word_mask;
-    const uint4* q1 = (const uint4*)&t.words[s1];
-    const uint4* q2 = (const uint4*)&t.words[s2];
-    uint4 a0 = q1[0], a1 = q1[1], b0 = q2[0], b1 = q2[1];
-    uint32_t lo0 = (uint32_t)lo, lo1 = (uint32_t)(lo >> 32), hi0 = (uint32_t)hi, hi1 = (uint32_t)(hi >> 32);
-    if (a1.x == len && a0.x == lo0 && a0.y == lo1 && a0.z == hi0 && a0.w == hi1) { *id = a1.y; *flags = a1.z; return true; }
-    if (b1.x == len && b0.x == lo0 && b0.y == lo1 && b0.z == hi0 && b0.w == hi1) { *id = b1.y; *flags = b1.z; return true; }
-    return false;
+    const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
+    uint4 a0 = q[0], a1 = q[1];
+    *id = a1.y;
+    *flags = a1.z;
+    return a1.x == len && a0.x == (uint32_t)lo && a0.y == (uint32_t)(lo >> 32) && a0.z == (uint32_t)hi && a0.w == (uint32_t)(hi >> 32);
+}
+__device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
+    return word_probe_d(t, t.word_disp, lo, hi, len, id, flags);
 }
 
 __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __restrict__ w, uint32_t len, uint32_t* id) {
@@ -1076,6 +1087,12 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                                                          uint32_t* __restrict__ listL, uint32_t* __restrict__ counters) {
     __shared__ uint32_t sm[4];
     __shared__ uint32_t base_s[4];
+    __shared__ uint16_t s_disp[DISP_LDS_MAX];
+    const bool disp_in_lds = t.word_bmask < (uint32_t)DISP_LDS_MAX;
+    if (disp_in_lds)
+        for (uint32_t i = threadIdx.x; i <= t.word_bmask; i += 256) s_disp[i] = t.word_disp[i];
+    __syncthreads();
+    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.word_disp;
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + LK_CHUNK - 1) / LK_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
@@ -1083,14 +1100,19 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
         // the merge kernels' text / pt_start / tmp_ids accesses local (measured: lane-strided assignment coalesces
         // these loads better but costs the merge kernels 30 %)
         const int64_t pbase = ch * LK_CHUNK + (int64_t)threadIdx.x * LK_ITEMS;
-        // branch-free, clamped loads so that every group's loads are in flight together
         uint32_t st[LK_ITEMS], en[LK_ITEMS];
+        if (pbase + LK_ITEMS <= P) {                       // 8 offsets as two 16-byte loads (pbase is a multiple of 8)
+            const uint4 v0 = *(const uint4*)(pt_start + pbase), v1 = *(const uint4*)(pt_start + pbase + 4);
+            st[0] = v0.x; st[1] = v0.y; st[2] = v0.z; st[3] = v0.w; st[4] = v1.x; st[5] = v1.y; st[6] = v1.z; st[7] = v1.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < LK_ITEMS; ++k) st[k] = pt_start[min(pbase + k, P)];
+            for (int k = 0; k < LK_ITEMS; ++k) st[k] = pt_start[min(pbase + k, P)];
+        }
 #pragma unroll
         for (int k = 0; k < LK_ITEMS; ++k) en[k] = (k + 1 < LK_ITEMS) ? st[k + 1] : pt_start[min(pbase + LK_ITEMS, P)];
         uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list32, 3 -> list64 / listL
         uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
+        uint32_t out_id[LK_ITEMS], out_n[LK_ITEMS];
 #pragma unroll
         for (int g = 0; g < LK_ITEMS; g += LK_GROUP) {
             uint64_t lo[LK_GROUP], hi[LK_GROUP];
@@ -1100,29 +1122,38 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 len[k] = en[g + k] - st[g + k];
                 load_key16(text, st[g + k], min(len[k], 16u), &lo[k], &hi[k]);
             }
-            uint4 a0[LK_GROUP], a1[LK_GROUP], b0[LK_GROUP], b1[LK_GROUP];
+            uint4 a0[LK_GROUP], a1[LK_GROUP];
 #pragma unroll
             for (int k = 0; k < LK_GROUP; ++k) {
                 uint32_t h1 = word_hash1(lo[k], hi[k], len[k], t.word_seed);
-                const uint4* q1 = (const uint4*)&t.words[h1 & t.word_mask];
-                const uint4* q2 = (const uint4*)&t.words[word_hash2(h1) & t.word_mask];
-                a0[k] = q1[0]; a1[k] = q1[1]; b0[k] = q2[0]; b1[k] = q2[1];
+                const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
+                a0[k] = q[0]; a1[k] = q[1];
             }
 #pragma unroll
             for (int k = 0; k < LK_GROUP; ++k) {
                 const int64_t p = pbase + g + k;
                 const bool valid = p < P;
-                uint32_t lo0 = (uint32_t)lo[k], lo1 = (uint32_t)(lo[k] >> 32), hi0 = (uint32_t)hi[k], hi1 = (uint32_t)(hi[k] >> 32);
-                bool ma = a1[k].x == len[k] && a0[k].x == lo0 && a0[k].y == lo1 && a0[k].z == hi0 && a0[k].w == hi1;
-                bool mb = b1[k].x == len[k] && b0[k].x == lo0 && b0[k].y == lo1 && b0[k].z == hi0 && b0[k].w == hi1;
-                uint32_t id = ma ? a1[k].y : b1[k].y, fl = ma ? a1[k].z : b1[k].z;
-                bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && (ma || mb) && (t.ignore_merges || (fl & WORD_DIRECT));
-                if (done) { tok0[p] = id; ntok[p] = 1; }
+                bool hit = a1[k].x == len[k] && a0[k].x == (uint32_t)lo[k] && a0[k].y == (uint32_t)(lo[k] >> 32) &&
+                           a0[k].z == (uint32_t)hi[k] && a0[k].w == (uint32_t)(hi[k] >> 32);
+                bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && hit && (t.ignore_merges || (a1[k].z & WORD_DIRECT));
+                out_id[g + k] = done ? a1[k].y : 0u;
+                out_n[g + k] = done ? 1u : 0u;
                 if (valid && !done) {
                     uint32_t c = len[k] <= 16 ? 1u : (len[k] <= 32 ? 2u : 3u);
                     cls |= c << (2 * (g + k));
                 }
             }
+        }
+        // tok0 / ntok for all 8 items as 16-byte stores (queued items get 0 / 0 and are overwritten by the merge kernels)
+        if (pbase + LK_ITEMS <= P) {
+            *(uint4*)(tok0 + pbase) = make_uint4(out_id[0], out_id[1], out_id[2], out_id[3]);
+            *(uint4*)(tok0 + pbase + 4) = make_uint4(out_id[4], out_id[5], out_id[6], out_id[7]);
+            *(uint4*)(ntok + pbase) = make_uint4(out_n[0], out_n[1], out_n[2], out_n[3]);
+            *(uint4*)(ntok + pbase + 4) = make_uint4(out_n[4], out_n[5], out_n[6], out_n[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k)
+                if (pbase + k < P) { tok0[pbase + k] = out_id[k]; ntok[pbase + k] = out_n[k]; }
         }
         // ignore_merges: whole-word vocab hit for keys longer than 16 bytes (bpe/model.rs:559-567); rare, kept off
         // the main path
@@ -1736,9 +1767,12 @@ __global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict_
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
         uint32_t v = 0;
+        if (p0 + CP_ITEMS <= P) { const uint4 q = *(const uint4*)(ntok + p0); v = q.x + q.y + q.z + q.w; }
+        else {
 #pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k)
-            if (p0 + k < P) v += ntok[p0 + k];
+            for (int k = 0; k < CP_ITEMS; ++k)
+                if (p0 + k < P) v += ntok[p0 + k];
+        }
         uint32_t tot;
         block256_excl_scan(v, sm, &tot);
         if (threadIdx.x == 0) csum[ch] = tot;
@@ -1754,23 +1788,31 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ nt
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
-        uint32_t cnt[CP_ITEMS];
-        uint32_t v = 0;
+        uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
+        const bool full = p0 + CP_ITEMS <= P;
+        if (full) {                                   // 16-byte loads (p0 is a multiple of 4)
+            const uint4 q = *(const uint4*)(ntok + p0), f = *(const uint4*)(tok0 + p0);
+            cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
+            first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
+        } else {
 #pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            cnt[k] = (p0 + k < P) ? ntok[p0 + k] : 0u;
-            v += cnt[k];
+            for (int k = 0; k < CP_ITEMS; ++k) {
+                cnt[k] = (p0 + k < P) ? ntok[p0 + k] : 0u;
+                first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
+            }
         }
+        uint32_t v = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         uint32_t tot;
         uint32_t o = csum[ch] + block256_excl_scan(v, sm, &tot);
+        if (full) *(uint4*)(pt_tokoff + p0) = make_uint4(o, o + cnt[0], o + cnt[0] + cnt[1], o + cnt[0] + cnt[1] + cnt[2]);
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) {
             int64_t p = p0 + k;
             if (p < P) {
-                pt_tokoff[p] = o;
+                if (!full) pt_tokoff[p] = o;
                 uint32_t c = cnt[k];
                 if (c) {
-                    ids[o] = tok0[p];
+                    ids[o] = first[k];
                     if (c > 1) {
                         uint32_t s = pt_start[p];
                         for (uint32_t j = 1; j < c; ++j) ids[o + j] = tmp_ids[s + j];
@@ -1905,7 +1947,8 @@ void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_
 }
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
-    hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
+    // one wavefront per 64 mask words = 4096 bytes of text; 4 wavefronts per workgroup
+    hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes + 1, 4 * 4096)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
 }
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt) {

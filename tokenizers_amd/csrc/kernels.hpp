@@ -15,8 +15,9 @@ struct DevTables {
     const MergeSlot* merges;          // perfect-hash table (one slot per key)
     const uint16_t* merge_disp;       // bucket displacements
     uint32_t merge_mask, merge_seed, merge_bmask;
-    const WordSlot* words;
-    uint32_t word_mask, word_seed;
+    const WordSlot* words;            // perfect-hash table (one slot per key)
+    const uint16_t* word_disp;
+    uint32_t word_mask, word_seed, word_bmask;
     uint32_t ignore_merges;
     uint32_t unk_id, has_unk;
     // long (>16 byte) whole-word keys

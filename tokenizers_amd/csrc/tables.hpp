@@ -55,7 +55,8 @@ TK_HD uint32_t ph_slot(uint32_t h2, uint32_t d, uint32_t mask) { return (h2 + d 
 
 // ---- whole-word table: raw pre-token bytes (<= 16) -> token id ------------------------------
 // Serves BPE `ignore_merges` (bpe/model.rs:559-567), WordLevel (wordlevel/mod.rs:162-178) and the
-// merge-stable shortcut: key = bytes zero-padded to 16 + length.
+// merge-stable shortcut: key = bytes zero-padded to 16 + length.  Same hash-and-displace
+// layout as the merge table: one 32-byte slot per key, displacement = word_disp[hash1 & word_bmask].
 struct WordSlot {
     uint64_t lo, hi;
     uint32_t len;    // 0 = empty slot
