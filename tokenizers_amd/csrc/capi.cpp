@@ -101,13 +101,46 @@ struct tkamd_tokenizer {
     uint32_t last_counters[CNT_COUNT] = {0};
 };
 
+// Host results live in pinned (page-locked) memory so the D2H copies run at PCIe speed; blocks are recycled
+// through a small process-wide pool because pinning is expensive.
+struct PinnedBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+static std::mutex g_pin_mu;
+static std::vector<PinnedBlock> g_pin_free;
+
+static PinnedBlock pinned_get(size_t bytes) {
+    if (bytes < 64) bytes = 64;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_pin_free.size(); ++i)
+            if (g_pin_free[i].cap >= bytes && (best == (size_t)-1 || g_pin_free[i].cap < g_pin_free[best].cap)) best = i;
+        if (best != (size_t)-1 && g_pin_free[best].cap <= 2 * bytes + (1u << 20)) {
+            PinnedBlock b = g_pin_free[best];
+            g_pin_free.erase(g_pin_free.begin() + best);
+            return b;
+        }
+    }
+    PinnedBlock b;
+    size_t want = bytes + bytes / 8;
+    HIP_CHECK(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    b.cap = want;
+    return b;
+}
+static void pinned_put(PinnedBlock b) {
+    if (!b.p) return;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_free.size() >= 16) { (void)hipHostFree(b.p); return; }
+    g_pin_free.push_back(b);
+}
+
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    std::vector<uint32_t> ids;
-    std::vector<int64_t> tok_offsets;
-    std::vector<uint32_t> offsets;
-    std::vector<uint32_t> word_ids;
+    PinnedBlock ids, tok_offsets, offsets, word_ids;
     bool has_offsets = false, has_words = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); }
 };
 
 namespace {
@@ -707,20 +740,21 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         std::unique_ptr<tkamd_batch> b(new tkamd_batch());
         b->n_docs = n_docs;
         b->n_tokens = n_tok;
-        b->ids.resize((size_t)n_tok);
-        b->tok_offsets.resize((size_t)n_docs + 1);
-        if (n_tok) HIP_CHECK(hipMemcpy(b->ids.data(), r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(b->tok_offsets.data(), r.d_tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        b->ids = pinned_get((size_t)n_tok * 4);
+        b->tok_offsets = pinned_get((size_t)(n_docs + 1) * 8);
+        if (n_tok) HIP_CHECK(hipMemcpyAsync(b->ids.p, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(b->tok_offsets.p, r.d_tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, st));
         if (r.d_offsets) {
             b->has_offsets = true;
-            b->offsets.resize((size_t)n_tok * 2);
-            if (n_tok) HIP_CHECK(hipMemcpy(b->offsets.data(), r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost));
+            b->offsets = pinned_get((size_t)n_tok * 8);
+            if (n_tok) HIP_CHECK(hipMemcpyAsync(b->offsets.p, r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost, st));
         }
         if (r.d_word_ids) {
             b->has_words = true;
-            b->word_ids.resize((size_t)n_tok);
-            if (n_tok) HIP_CHECK(hipMemcpy(b->word_ids.data(), r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost));
+            b->word_ids = pinned_get((size_t)n_tok * 4);
+            if (n_tok) HIP_CHECK(hipMemcpyAsync(b->word_ids.p, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st));
         }
+        HIP_CHECK(hipStreamSynchronize(st));
         *out = b.release();
         return TKAMD_OK;
     });
@@ -728,10 +762,10 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
 
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_batch_n_tokens(const tkamd_batch* b) { return b ? b->n_tokens : 0; }
-const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? b->ids.data() : nullptr; }
-const int64_t* tkamd_batch_tok_offsets(const tkamd_batch* b) { return b ? b->tok_offsets.data() : nullptr; }
-const uint32_t* tkamd_batch_offsets(const tkamd_batch* b) { return (b && b->has_offsets) ? b->offsets.data() : nullptr; }
-const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b) { return (b && b->has_words) ? b->word_ids.data() : nullptr; }
+const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? (const uint32_t*)b->ids.p : nullptr; }
+const int64_t* tkamd_batch_tok_offsets(const tkamd_batch* b) { return b ? (const int64_t*)b->tok_offsets.p : nullptr; }
+const uint32_t* tkamd_batch_offsets(const tkamd_batch* b) { return (b && b->has_offsets) ? (const uint32_t*)b->offsets.p : nullptr; }
+const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b) { return (b && b->has_words) ? (const uint32_t*)b->word_ids.p : nullptr; }
 void tkamd_batch_free(tkamd_batch* b) { delete b; }
 
 int tkamd_profile_enable(tkamd_tokenizer* t, int on) {

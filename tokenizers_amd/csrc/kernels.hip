@@ -167,113 +167,107 @@ __device__ __forceinline__ uint32_t utf8_at(const uint8_t* sb, int k, uint32_t* 
     return ((b & 0x07u) << 18) | ((sb[k + 1] & 0x3Fu) << 12) | ((sb[k + 2] & 0x3Fu) << 6) | (sb[k + 3] & 0x3Fu);
 }
 
+constexpr int PT_RP = 2304;      // staged region rounded up to 9 * 256 so every phase is a fully unrolled 9-step loop
+
 __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__ text, int64_t n_bytes_host,
                                                      const int64_t* __restrict__ len_dev,
                                                      const unsigned long long* __restrict__ docmask,
                                                      const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                      unsigned long long* __restrict__ startmask) {
-    __shared__ __attribute__((aligned(16))) uint8_t sb[PT_R + 8];
-    __shared__ uint8_t si[PT_R + 8];
-    __shared__ uint8_t sc[PT_R + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t sb[PT_RP + 16];
+    __shared__ uint8_t si[PT_RP + 16];
+    __shared__ uint8_t sc[PT_RP + 16];
+    __shared__ unsigned long long sdoc[PT_RP / 64 + 2];
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;       // first byte of this tile
     const int64_t r0 = t0 - PT_HALO;                        // first byte of the staged region
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // effective text length (prefix-space pass: on device)
 
-    // phase 0: stage bytes (zero outside the text) with aligned dword loads, and this tile's doc-start words
-    __shared__ unsigned long long sdoc[PT_TILE / 64 + 2];
+    // phase 0: stage bytes (zero outside the text) with aligned dword loads, and the tile's doc-start words
     {
-        // r0 = t0 - 8 is a multiple of 4 (t0 is a multiple of 2048), so dword k covers bytes r0 + 4k .. +3
         uint32_t* sb32 = (uint32_t*)sb;
-        for (int k = tid; k < (PT_R + 8) / 4; k += 256) {
-            int64_t g = r0 + 4 * (int64_t)k;
-            uint32_t v = 0;
-            if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
-            else if (g + 4 > 0 && g < n_bytes) {
-                for (int q = 0; q < 4; ++q)
-                    if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {                    // (PT_RP + 16) / 4 = 580 dwords
+            int k = tid + it * 256;
+            if (k < (PT_RP + 16) / 4) {
+                int64_t g = r0 + 4 * (int64_t)k;            // r0 is a multiple of 4
+                uint32_t v = 0;
+                if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
+                else if (g + 4 > 0 && g < n_bytes) {
+                    for (int q = 0; q < 4; ++q)
+                        if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
+                }
+                sb32[k] = v;
             }
-            sb32[k] = v;
         }
-        // doc-start words covering [t0 - 64, t0 + PT_TILE + 64)
-        if (tid < PT_TILE / 64 + 2) {
+        if (tid < PT_RP / 64 + 2) {                         // doc-start words covering [t0 - 64, ...)
             int64_t w = (t0 >> 6) - 1 + tid;
             sdoc[tid] = (w >= 0 && (w << 6) < n_bytes_host + 64) ? docmask[w] : 0ull;
         }
     }
     __syncthreads();
+    // phases 1-3 are written branch-free (selects and boolean algebra): per-lane control flow costs scalar
+    // exec-mask instructions, and the single scalar unit per CU was the measured limiter of the branchy version.
     // phase 1: per-byte info (class of the code point that starts here)
-    for (int k = tid; k < PT_R; k += 256) {
-        int64_t g = r0 + k;
-        uint32_t info = 0;
-        if (g >= 0 && g < n_bytes) {
-            uint32_t b = sb[k];
-            info = IF_VALID;
-            int64_t rel = g - (t0 - 64);                     // bit index inside sdoc
-            if ((sdoc[rel >> 6] >> (rel & 63)) & 1ull) info |= IF_DOC;
-            if ((b & 0xC0u) != 0x80u) {
-                uint32_t len;
-                uint32_t cp = utf8_at(sb, k, &len);
-                info |= IF_LEAD | cls_lns(cp, uc1, uc2) | ((len - 1) << IF_LEN_SHIFT);
-                if (b == 0x20u) info |= IF_SP;
-            }
+#pragma unroll
+    for (int it = 0; it < PT_RP / 256; ++it) {
+        const int k = tid + it * 256;
+        const int64_t g = r0 + k;
+        const uint32_t b = sb[k];
+        const bool valid = g >= 0 && g < n_bytes;
+        const int64_t rel = g - (t0 - 64);                     // bit index inside sdoc (>= 56)
+        const bool doc = (sdoc[rel >> 6] >> (rel & 63)) & 1ull;
+        const bool lead = (b & 0xC0u) != 0x80u;
+        uint32_t cls, len = 1;
+        if (__ballot(b >= 0x80u) == 0ull) {                     // wave-uniform: all-ASCII word
+            const uint32_t lower = b | 0x20u;
+            const bool isL = lower - 'a' < 26u, isN = b - '0' < 10u, isS = (b == 0x20u) | (b - 9u < 5u);
+            cls = isL ? 1u : (isN ? 2u : (isS ? 3u : 0u));
+        } else {
+            const uint32_t cp = utf8_at(sb, k, &len);
+            cls = cls_lns(cp, uc1, uc2);
         }
-        si[k] = (uint8_t)info;
+        uint32_t info = IF_VALID | (doc ? IF_DOC : 0u) | (lead ? (IF_LEAD | cls | ((len - 1) << IF_LEN_SHIFT) | (b == 0x20u ? IF_SP : 0u)) : 0u);
+        si[k] = (uint8_t)(valid ? info : 0u);
     }
     __syncthreads();
     // phase 2: con(k) = length (2|3) of a contraction literal that is a match start at k, else 0
-    for (int k = tid; k < PT_R; k += 256) {
-        uint32_t con = 0;
-        if (k >= 4 && k < PT_R - 2 && sb[k] == '\'' && (si[k] & IF_VALID)) {
-            uint32_t b1 = sb[k + 1], b2 = sb[k + 2];
-            bool ok1 = (si[k + 1] & IF_VALID) && !(si[k + 1] & IF_DOC);
-            bool ok2 = ok1 && (si[k + 2] & IF_VALID) && !(si[k + 2] & IF_DOC);
-            uint32_t lit = 0;
-            if (ok1 && (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd')) lit = 2;
-            else if (ok2 && ((b1 == 'r' && b2 == 'e') || (b1 == 'v' && b2 == 'e') || (b1 == 'l' && b2 == 'l'))) lit = 3;
-            if (lit) {
-                bool cond;
-                if (si[k] & IF_DOC) cond = true;
-                else {
-                    int j = k - 1;
-                    if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) --j; } }
-                    uint32_t pi = si[j], pc = pi & IF_CLS;
-                    cond = (pc == 1 || pc == 2 || (pc == 3 && !(pi & IF_SP)));
-                }
-                if (cond) con = lit;
-            }
-        }
-        sc[k] = (uint8_t)con;
+#pragma unroll
+    for (int it = 0; it < PT_RP / 256; ++it) {
+        const int k = tid + it * 256;
+        const int kk = max(k, 4);                               // keeps the look-behind in range; con is only used for k >= 5
+        const uint32_t b0 = sb[kk], b1 = sb[kk + 1], b2 = sb[kk + 2];
+        const uint32_t i0 = si[kk], i1 = si[kk + 1], i2 = si[kk + 2];
+        const bool ok1 = (i1 & (IF_VALID | IF_DOC)) == IF_VALID;
+        const bool ok2 = ok1 & ((i2 & (IF_VALID | IF_DOC)) == IF_VALID);
+        const bool l2 = ok1 & ((b1 == 's') | (b1 == 't') | (b1 == 'm') | (b1 == 'd'));
+        const bool l3 = ok2 & ((((b1 == 'r') | (b1 == 'v')) & (b2 == 'e')) | ((b1 == 'l') & (b2 == 'l')));
+        // previous code point: 1..4 bytes back
+        const uint32_t p1 = si[kk - 1], p2 = si[kk - 2], p3 = si[kk - 3], p4 = si[kk - 4];
+        const uint32_t pi = (p1 & IF_LEAD) ? p1 : ((p2 & IF_LEAD) ? p2 : ((p3 & IF_LEAD) ? p3 : p4));
+        const uint32_t pc = pi & IF_CLS;
+        const bool cond = (i0 & IF_DOC) | (pc == 1) | (pc == 2) | ((pc == 3) & !(pi & IF_SP));
+        const bool ap = (b0 == '\'') & ((i0 & IF_VALID) != 0) & (k >= 4);
+        sc[k] = (uint8_t)((ap & cond) ? (l2 ? 2u : (l3 ? 3u : 0u)) : 0u);
     }
     __syncthreads();
     // phase 3: start predicate for the tile's own bytes, one 64-bit ballot per wavefront
+#pragma unroll
     for (int it = 0; it < PT_TILE / 256; ++it) {
-        int k = PT_HALO + it * 256 + tid;
-        uint32_t info = si[k];
-        bool start = false;
-        if ((info & (IF_VALID | IF_LEAD)) == (IF_VALID | IF_LEAD)) {
-            if (info & IF_DOC) start = true;
-            else {
-                uint32_t c1 = sc[k - 1], c2 = sc[k - 2], c3 = sc[k - 3];
-                if (c1 >= 2 || c2 >= 3) start = false;                 // swallowed by a contraction
-                else if (sc[k] > 0) start = true;                      // contraction starts here
-                else if (c2 >= 2 || c3 >= 3) start = true;             // first code point after one
-                else {
-                    int j = k - 1;
-                    if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) --j; } }
-                    uint32_t pi = si[j], pc = pi & IF_CLS, c = info & IF_CLS;
-                    if (c != 3) {
-                        start = !(pc == c || (pi & IF_SP));            // run continues / " X" attaches
-                    } else if (pc != 3) {
-                        start = true;                                  // first of a whitespace run
-                    } else {
-                        int k2 = k + 1 + (int)(info >> IF_LEN_SHIFT);  // \s+(?!\S): split before the LAST ws
-                        uint32_t ni = si[k2];
-                        start = (ni & IF_VALID) && !(ni & IF_DOC) && ((ni & IF_CLS) != 3);
-                    }
-                }
-            }
-        }
+        const int k = PT_HALO + it * 256 + tid;
+        const uint32_t info = si[k];
+        const uint32_t c0 = sc[k], c1 = sc[k - 1], c2 = sc[k - 2], c3 = sc[k - 3];
+        const uint32_t p1 = si[k - 1], p2 = si[k - 2], p3 = si[k - 3], p4 = si[k - 4];
+        const uint32_t pi = (p1 & IF_LEAD) ? p1 : ((p2 & IF_LEAD) ? p2 : ((p3 & IF_LEAD) ? p3 : p4));
+        const uint32_t pc = pi & IF_CLS, c = info & IF_CLS;
+        const uint32_t ni = si[k + 1 + (int)(info >> IF_LEN_SHIFT)];      // info of the next code point
+        const bool eaten = (c1 >= 2) | (c2 >= 3);
+        const bool after = (c2 == 2) | (c3 >= 3);
+        const bool run = (c != 3) & !((pc == c) | ((pi & IF_SP) != 0));      // class change, no " X" attachment
+        const bool ws_first = (c == 3) & (pc != 3);
+        const bool ws_last = (c == 3) & (pc == 3) & ((ni & (IF_VALID | IF_DOC)) == IF_VALID) & ((ni & IF_CLS) != 3);
+        const bool is_lead = (info & (IF_VALID | IF_LEAD)) == (IF_VALID | IF_LEAD);
+        const bool start = is_lead & (((info & IF_DOC) != 0) | (!eaten & ((c0 > 0) | after | run | ws_first | ws_last)));
         uint64_t m = __ballot(start);
         int64_t g = t0 + it * 256 + tid;
         if ((tid & 63) == 0 && g <= n_bytes_host) startmask[g >> 6] = m;

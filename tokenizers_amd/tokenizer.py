@@ -186,6 +186,21 @@ class DeviceBatch:
         return self._tensor(self._res.d_tok_offsets, (self.n_docs + 1,), "<i8")
 
 
+class _BatchOwner:
+    """Keeps a tkamd_batch alive while numpy views of its buffers exist."""
+
+    def __init__(self, lib, handle):
+        self._lib, self._h = lib, handle
+
+    def __del__(self):
+        if self._h:
+            try:
+                self._lib.tkamd_batch_free(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+
 class Tokenizer:
     """MI355X-native stand-in for ``tokenizers.Tokenizer`` on the encode_batch path."""
 
@@ -259,19 +274,25 @@ class Tokenizer:
         n_docs = len(doc_off) - 1
         b = C.c_void_p()
         _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
-        try:
-            nt = self._lib.tkamd_batch_n_tokens(b)
-            ids = np.ctypeslib.as_array(C.cast(self._lib.tkamd_batch_ids(b), C.POINTER(C.c_uint32)), shape=(nt,)).copy() if nt else np.zeros(0, np.uint32)
-            to = np.ctypeslib.as_array(C.cast(self._lib.tkamd_batch_tok_offsets(b), C.POINTER(C.c_int64)), shape=(n_docs + 1,)).copy()
-            offs = wids = None
-            if offsets != "none":
-                po = self._lib.tkamd_batch_offsets(b)
-                offs = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint32)), shape=(nt, 2)).copy() if (nt and po) else np.zeros((0, 2), np.uint32)
-            if word_ids:
-                pw = self._lib.tkamd_batch_word_ids(b)
-                wids = np.ctypeslib.as_array(C.cast(pw, C.POINTER(C.c_uint32)), shape=(nt,)).copy() if (nt and pw) else np.zeros(0, np.uint32)
-        finally:
-            self._lib.tkamd_batch_free(b)
+        # zero-copy views of the library's pinned result buffers; the batch is freed when the last view dies
+        owner = _BatchOwner(self._lib, b)
+        nt = self._lib.tkamd_batch_n_tokens(b)
+
+        def view(ptr, ctype, shape, dtype):
+            n = int(np.prod(shape))
+            if not n or not ptr:
+                return np.zeros(shape, dtype=dtype)
+            carr = (ctype * n).from_address(ptr)
+            carr._owner = owner
+            return np.ctypeslib.as_array(carr).reshape(shape)
+
+        ids = view(self._lib.tkamd_batch_ids(b), C.c_uint32, (nt,), np.uint32)
+        to = view(self._lib.tkamd_batch_tok_offsets(b), C.c_int64, (n_docs + 1,), np.int64)
+        offs = wids = None
+        if offsets != "none":
+            offs = view(self._lib.tkamd_batch_offsets(b), C.c_uint32, (nt, 2), np.uint32)
+        if word_ids:
+            wids = view(self._lib.tkamd_batch_word_ids(b), C.c_uint32, (nt,), np.uint32)
         return BatchEncoding(ids, to, offs, wids, self._id_to_token())
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
