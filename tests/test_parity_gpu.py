@@ -77,10 +77,17 @@ def test_gpt2_edge_documents(gpt2, gpt2_oracle):
         _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(batch))], batch)
 
 
-def test_gpt2_pretoken_longer_than_workgroup_limit_is_refused(gpt2):
-    import tokenizers_amd as ta
-    with pytest.raises(ta.UnsupportedError, match="longer than 8192"):
-        gpt2.encode_batch_fast(["q" * 9000], add_special_tokens=False)
+def test_gpt2_huge_pretokens(gpt2, gpt2_oracle):
+    """Pre-tokens beyond the 8192-byte LDS path run from the global scratch slab (k_bpe_merge_huge)."""
+    rng = np.random.default_rng(5)
+    dna = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, size=70000))
+    docs = ["q" * 9000, "start " + "ab" * 10000 + " end", dna, "x" * 8192, "y" * 8193, "short one"]
+    got = gpt2.encode_batch_csr(docs, offsets="byte", word_ids=True)
+    exp = gpt2_oracle.encode_batch(docs)
+    assert got.tok_offsets.tolist() == exp.tok_offsets.tolist()
+    assert (got.ids == exp.ids).all()
+    assert (got.offsets == exp.offsets).all() and (got.word_ids == exp.words).all()
+    assert gpt2.queue_sizes()["merge_huge"] >= 4
 
 
 def test_gpt2_vs_reference_wheel(gpt2, gpt2_json, ref_tokenizers):

@@ -86,7 +86,7 @@ struct tkamd_tokenizer {
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -146,7 +146,7 @@ struct tkamd_batch {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* ..7 */, SC_NCHARS = 8 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* ..7 */, SC_NCHARS = 8, SC_HUGE_USED = 9 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
 
 struct Prof {
     tkamd_tokenizer* t;
@@ -523,8 +523,20 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             t->long_prepared = true;
         }
         pf.begin("bpe_merge_long");
+        // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
+        // worst case this batch can contain (the whole X text being such pre-tokens), capped at 1 GiB
+        const size_t huge_words = std::min<size_t>((size_t)6 * N + 4096, (size_t)1 << 28);
+        if (N > (size_t)LONG_PT_MAX) {
+            t->w_huge.reserve(huge_words * 4);
+            t->w_list_huge.reserve((N / LONG_PT_MAX + 16) * 4);
+        } else {
+            t->w_huge.reserve(64);
+            t->w_list_huge.reserve(64);
+        }
         launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), listL, d_counters + CNT_LISTL,
-                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end,
+                              t->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, t->w_huge.as<uint32_t>(),
+                              (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
     } else if (hm.model == MODEL_WORDLEVEL) {
         pf.begin("wordlevel");
@@ -602,7 +614,7 @@ int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_
 int error_from_bits(int bits) {
     if (bits & ERR_BAD_OFFSETS) return set_error(TKAMD_ERR_INVALID, "doc_offsets is not a monotone CSR over [0, n_bytes]");
     if (bits & ERR_PRETOKEN_TOO_LONG)
-        return set_error(TKAMD_ERR_UNSUPPORTED, "a pre-token is longer than 8192 bytes (workgroup merge path limit)");
+        return set_error(TKAMD_ERR_UNSUPPORTED, "pre-tokens longer than 8192 bytes exceed the 1 GiB scratch slab of the global-memory merge path");
     if (bits & ERR_ADDED_TOKEN)
         return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text: the AddedVocabulary split "
                                                 "(added_vocabulary.rs:523-564) is not built on the device yet");
@@ -669,7 +681,7 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
                          &t->t_long_id, &t->t_long_table, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }

@@ -65,9 +65,9 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_ULIST = 5, CNT_DLIST = 6, CNT_COUNT = 8 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_ULIST = 5, CNT_DLIST = 6, CNT_LISTH = 7, CNT_COUNT = 8 };
 
-constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident)
+constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident); longer ones use the global-scratch kernel
 
 void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                             unsigned long long* docmask, int* err);
@@ -116,7 +116,8 @@ void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
-                           uint32_t* tmp_end, int* err);
+                           uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge, uint32_t* scratch, unsigned long long scratch_words,
+                           unsigned long long* scratch_used, int* err);
 void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
                     const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);
 void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
