@@ -100,7 +100,13 @@ def main():
     t.pre_tokenizer = pre_tokenizers.BertPreTokenizer()
     t.train_from_iterator(train, trainers.WordPieceTrainer(vocab_size=4000, show_progress=False,
                                                            special_tokens=["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"]))
-    emit("bert_wordpiece_4000", t.to_str(), ascii_only(edge + base + stress) + ["HE\x01LLO\tWorld!", "\x00hello", "hello\x01", "wor\x02ld x", "a" * 101, "b" * 100])
+    import random
+    random.seed(11)
+    upool = ["é", "É", "ñ", "中", "文", "日本", "ÀB", "İ", "ǅ", "ﬁ", "Å", "한국어", "ö", "ß", "Ω", "Σς", "ё", "é", "\u00a0", "\u200b", "\u3000",
+             "\u2028", "😀", "naïve", "CAFÉ", "ẞ", "ệ", "a", "B", "-", "!", "12", " ", "x̣́", "\ufeff", "\u00ad", "\x01", "\t", "丽", "豈"]
+    unicode_docs = ["".join(random.choice(upool) for _ in range(random.randint(1, 14))) for _ in range(600)]
+    bert_docs = [d for d in edge + base + stress + unicode_docs if "[" not in d and "\u302e" not in d]
+    emit("bert_wordpiece_4000", t.to_str(), bert_docs + ["HE\x01LLO\tWorld!", "\x00hello", "hello\x01", "wor\x02ld x", "a" * 101, "b" * 100])
 
     # C1: Whitespace + WordLevel over 1,000 ASCII lines
     c1 = ascii_only(synth.gen_lines(1100, text_seed=0, special_frac=0.0))[:1000]

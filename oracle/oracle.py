@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         L.oracle_free.argtypes = [vp]
         L.oracle_set_trim.argtypes = [vp, i32, i32]
         L.oracle_set_char_offsets.argtypes = [vp, i32]
+        L.oracle_set_bert_normalizer.argtypes = [vp, i32, i32, i32, i32]
         L.oracle_set_vocab.argtypes = [vp, vp, vp, vp, i64]
         L.oracle_set_unk.argtypes = [vp, C.c_char_p, i64]
         L.oracle_set_wordpiece.argtypes = [vp, C.c_char_p, i64, i32]
@@ -124,14 +125,21 @@ class Oracle:
         else:
             raise OracleError(f"pre_tokenizer {t} outside the oracle's scope")
         nk = 0
+        bn = None
         if d.get("normalizer"):
-            assert d["normalizer"]["type"] == "BertNormalizer"
+            nz = d["normalizer"]
+            assert nz["type"] == "BertNormalizer"
             nk = 1
+            lower = bool(nz.get("lowercase", True))
+            sa = nz.get("strip_accents")
+            bn = (int(nz.get("clean_text", True)), int(nz.get("handle_chinese_chars", True)), int(lower if sa is None else sa), int(lower))
         pp = d.get("post_processor") or {}
         trim = int(pp.get("trim_offsets", True)) if pp.get("type") in ("ByteLevel", "RobertaProcessing") else 0
         self._L = L
         self._h = L.oracle_new(mk, pk, nk, aps, int(bool(model.get("ignore_merges", False))), trim)
         L.oracle_set_trim(self._h, trim, int(pp.get("add_prefix_space", True)))
+        if bn:
+            L.oracle_set_bert_normalizer(self._h, *bn)
         toks = list(model["vocab"].items())
         blob, off = _pack([k.encode("utf-8") for k, _ in toks])
         ids = np.array([v for _, v in toks], dtype=np.uint32)

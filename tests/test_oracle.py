@@ -169,6 +169,24 @@ def test_oracle_matches_golden(name):
     assert not bad, f"{len(bad)} mismatches, first {bad[0]!r}"
 
 
+def test_bert_normalizer_matches_wheel_normalize_str(ref_tokenizers):
+    """The table-driven BertNormalizer restatement against the wheel's own normalize_str on random Unicode."""
+    import random
+    random.seed(5)
+    js = load_tokenizer_json("bert_wordpiece_4000")
+    o = orc.Oracle(js)
+    ref = ref_tokenizers.Tokenizer.from_str(js)
+    cps = [0x41, 0xC9, 0xE9, 0x130, 0x1C5, 0x3A3, 0x3C2, 0x410, 0x451, 0x4E2D, 0x65E5, 0xAC00, 0xD55C, 0xF900, 0x2F800, 0x1F600, 0xA0, 0x200B,
+           0x3000, 0x2028, 0xAD, 0xFEFF, 0x301, 0x323, 0x1E9E, 0xFB01, 0x212B, 0x20, 0x9, 0x1, 0x7F, 0x61, 0x2D, 0x31]
+    docs = ["".join(chr(random.choice(cps)) for _ in range(random.randint(1, 10))) for _ in range(3000)]
+    exp = ref.encode_batch(docs, add_special_tokens=False)
+    got = o.encode_batch(docs, char_offsets=True)
+    for i, e in enumerate(exp):
+        assert got.doc_ids(i) == e.ids, docs[i]
+        assert got.doc_offsets(i) == [tuple(x) for x in e.offsets], docs[i]
+        assert got.doc_words(i) == e.word_ids, docs[i]
+
+
 # ---- 3. live differential against the wheel ------------------------------------------------------
 
 @pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000"])

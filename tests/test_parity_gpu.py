@@ -165,11 +165,27 @@ def test_word_models_vs_oracle(name):
     _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(docs))], docs)
 
 
-def test_bert_normalizer_non_ascii_is_refused():
+def test_bert_normalizer_unicode_vs_oracle():
+    """Full-Unicode BertNormalizer (clean / CJK spacing / NFD + Mn strip / lowercase) incl. offsets through expansions."""
+    import random
+    import tokenizers_amd as ta
+    js = load_tokenizer_json("bert_wordpiece_4000")
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    random.seed(7)
+    pool = ["é", "É", "ñ", "中", "文", "日本", "ÀB", "İ", "ǅ", "ﬁ", "Å", "한국어", "ö", "ß", "Ω", "Σς", "ё", "é", "\u00a0", "\u200b", "\u3000",
+            "\u2028", "😀", "naïve", "CAFÉ", "ẞ", "ệ", "a", "B", "-", "!", "12", " ", "x̣́", "\ufeff", "\u00ad", "\x01", "\t", "丽", "豈"]
+    docs = ["".join(random.choice(pool) for _ in range(random.randint(1, 20))) for _ in range(6000)]
+    docs += [d for d in synth.gen_lines(4000, text_seed=37) + synth.stress_lines(seed=14, n=3000) if "[" not in d and "\u302e" not in d]
+    docs += ["", "中", "é", "\u0301", "\u0301\u0301", "İ" * 40, "中" * 120, "é" * 101]
+    _meta_compare(tok, o, docs)
+
+
+def test_bert_normalizer_reorderable_mark_is_refused():
     import tokenizers_amd as ta
     tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=0)
-    with pytest.raises(ta.UnsupportedError, match="non-ASCII"):
-        tok.encode_batch_fast(["plain", "caf\u00e9"], add_special_tokens=False)
+    with pytest.raises(ta.UnsupportedError, match="combining class"):
+        tok.encode_batch_fast(["plain", "ha\u302engul"], add_special_tokens=False)
 
 
 def test_wordlevel_missing_unk_is_a_model_error():

@@ -82,11 +82,11 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
+    DevBuf t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -201,6 +201,9 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_long_id, hm.long_id);
     upload(t->t_long_table, hm.long_table);
     upload(t->t_trie, hm.trie.table);
+    upload(t->t_bn1, hm.bn_stage1);
+    upload(t->t_bn2, hm.bn_stage2);
+    upload(t->t_bn_map, hm.bn_map);
     upload(t->t_at_blob, hm.at_blob);
     upload(t->t_at_off, hm.at_off);
     upload(t->t_at_first, hm.at_first);
@@ -329,7 +332,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const bool want_meta = off_mode != TKAMD_OFFSETS_NONE || want_words;
     if (off_mode == 3u) throw Invalid("bad offsets mode");
     const bool prefix_space = hm.byte_level && hm.add_prefix_space;
-    const int64_t n_x = n_bytes + (prefix_space ? n_docs : 0);          // host-side bound of the X text length
+    // host-side bound of the X text length: +1 per document for the virtual space; BertNormalizer can grow a
+    // character (CJK spacing: 3 -> 5 bytes, NFD/lowercase expansions <= 3x) -- 3x the input covers every case
+    const int64_t n_x = (hm.norm == NORM_BERT) ? 3 * n_bytes + 64 : n_bytes + (prefix_space ? n_docs : 0);
     if (n_x >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
     const bool bpe_path = hm.model == MODEL_BPE && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
     const bool local_pretok = hm.pretok == PT_WHITESPACE || hm.pretok == PT_WHITESPACE_SPLIT || hm.pretok == PT_BERT;
@@ -394,17 +399,18 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         x_len_dev = d_xlen;
     }
     if (hm.norm == NORM_BERT) {
-        // ---- BertNormalizer (ASCII): text -> normalised text + original-position map ----
-        t->w_keepmask.reserve((size_t)(W0 + 1) * 8);
-        t->w_kprefix.reserve((size_t)(W0 + 1) * 4);
-        t->w_norig.reserve(((size_t)n_bytes + 4) * 4);
+        // ---- BertNormalizer: text -> normalised text + original byte range of every normalised byte ----
+        t->w_keepmask.reserve((size_t)n_bytes + 64);            // olen: output bytes per source byte
+        t->w_kprefix.reserve((size_t)(W0 + 1) * 4);             // wsum
+        t->w_wbase.reserve((size_t)(W0 + 1) * 4);
+        t->w_norig.reserve(((size_t)n_x + 4) * 4);
+        t->w_norig_e.reserve(((size_t)n_x + 4) * 4);
+        BnTables bt{t->t_bn1.as<uint16_t>(), t->t_bn2.as<uint8_t>(), t->t_bn_map.as<MergeSlot>(), hm.bn_mask, hm.bn_seed,
+                    hm.bn_clean_text, hm.bn_handle_chinese, hm.bn_strip_accents, hm.bn_lowercase};
         pf.begin("bert_normalize");
-        launch_norm_keepmask(st, d_text, n_bytes, hm.bn_clean_text, t->w_keepmask.as<ull>(), d_err);
-        launch_mask_scan(st, t->w_keepmask.as<ull>(), W0, t->w_bsum.as<uint32_t>(), t->w_kprefix.as<uint32_t>(), d_xlen);
-        launch_norm_scatter(st, d_text, n_bytes, hm.bn_clean_text, hm.bn_lowercase, t->w_keepmask.as<ull>(),
-                            t->w_kprefix.as<uint32_t>(), t->w_ntext.as<uint8_t>(), t->w_norig.as<uint32_t>());
-        launch_norm_doc_offsets(st, d_doc_off, n_docs, n_bytes, t->w_keepmask.as<ull>(), t->w_kprefix.as<uint32_t>(), d_xlen,
-                                t->w_ndoc_off.as<int64_t>());
+        launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, t->w_keepmask.as<uint8_t>(), t->w_kprefix.as<uint32_t>(),
+                              t->w_bsum.as<uint32_t>(), t->w_wbase.as<uint32_t>(), d_xlen, t->w_ntext.as<uint8_t>(),
+                              t->w_norig.as<uint32_t>(), t->w_norig_e.as<uint32_t>(), t->w_ndoc_off.as<int64_t>(), d_err);
         pf.end();
     } else if (prefix_space) {
         // ---- ByteLevel add_prefix_space: documents shifted behind their virtual leading space ----
@@ -572,6 +578,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         a.x_doc_off = x_doc_off;
         a.doc_off = d_doc_off;
         a.norig = (hm.norm == NORM_BERT) ? t->w_norig.as<uint32_t>() : nullptr;
+        a.norig_e = (hm.norm == NORM_BERT) ? t->w_norig_e.as<uint32_t>() : nullptr;
         a.byte_level = hm.byte_level;
         a.trim_offsets = hm.byte_level && hm.trim_offsets;
         a.pp_add_prefix_space = hm.pp_add_prefix_space;
@@ -618,7 +625,9 @@ int error_from_bits(int bits) {
     if (bits & ERR_ADDED_TOKEN)
         return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text: the AddedVocabulary split "
                                                 "(added_vocabulary.rs:523-564) is not built on the device yet");
-    if (bits & ERR_NON_ASCII_NORM) return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer on non-ASCII text is not built yet");
+    if (bits & ERR_NON_ASCII_NORM)
+        return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: the text contains a character with a non-zero combining class that "
+                                                "survives the Mn filter; NFD may reorder it across characters (not built on the device)");
     if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal work queue overflow");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
@@ -678,10 +687,10 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
         DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->t_long_id, &t->t_long_table, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }

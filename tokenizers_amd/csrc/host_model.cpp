@@ -21,6 +21,25 @@ const UcRun kUcRuns[] = {
 #include "unicode_ranges.inc"
 };
 
+struct BnMapRow {
+    uint32_t cp, a, b, c;
+};
+#define BN_WANT_RUNS
+const UcRun kBnRuns[] = {
+#include "bert_norm_tables.inc"
+};
+#undef BN_WANT_RUNS
+#define BN_WANT_D
+const BnMapRow kBnD[] = {
+#include "bert_norm_tables.inc"
+};
+#undef BN_WANT_D
+#define BN_WANT_LC
+const BnMapRow kBnLC[] = {
+#include "bert_norm_tables.inc"
+};
+#undef BN_WANT_LC
+
 // GPT-2 bytes <-> unicode map, pre_tokenizers/byte_level.rs:15-39: printable bytes map to
 // themselves, the other 68 bytes to U+0100+n in byte order.
 void build_bytes_char(uint32_t b2c[256]) {
@@ -85,6 +104,22 @@ void build_unicode(HostModel& m) {
             it = seen.emplace(std::move(key), idx).first;
         }
         m.uc_stage1[blk] = it->second;
+    }
+}
+
+void two_stage(const std::vector<uint8_t>& flat, std::vector<uint16_t>* s1, std::vector<uint8_t>* s2) {
+    s1->assign(UC_STAGE1_LEN, 0);
+    s2->clear();
+    std::unordered_map<std::string, uint16_t> seen;
+    for (uint32_t blk = 0; blk < (uint32_t)UC_STAGE1_LEN; ++blk) {
+        std::string key((const char*)&flat[blk * 256], 256);
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            uint16_t idx = (uint16_t)(s2->size() / 256);
+            s2->insert(s2->end(), key.begin(), key.end());
+            it = seen.emplace(std::move(key), idx).first;
+        }
+        (*s1)[blk] = it->second;
     }
 }
 
@@ -249,6 +284,25 @@ void build_trie(HostModel& m, const std::vector<std::pair<std::string, uint32_t>
         for (auto& e : nodes[n].kids) items.push_back(MergeSlot{n, (uint32_t)e.first, e.second, nodes[e.second].id});
     m.trie.n_nodes = (uint32_t)nodes.size();
     build_pair_table(items, &m.trie.table, &m.trie.mask, &m.trie.seed);
+}
+
+void build_pair_table(const std::vector<MergeSlot>& items, std::vector<MergeSlot>* out, uint32_t* out_mask, uint32_t* out_seed);
+
+// BertNormalizer data: flags as a 2-stage table, the NFD+strip (kind 0) and lowercase (kind 1) maps as one
+// cuckoo table keyed (cp, kind) with the up-to-3 output code points packed 21 bits each
+void build_bert_norm(HostModel& m) {
+    std::vector<uint8_t> flat(0x110000, 0);
+    for (const UcRun& r : kBnRuns)
+        for (uint32_t cp = r.first; cp <= r.last; ++cp) flat[cp] = r.flags;
+    two_stage(flat, &m.bn_stage1, &m.bn_stage2);
+    std::vector<MergeSlot> items;
+    auto add = [&](const BnMapRow& r, uint32_t kind) {
+        uint64_t v = (uint64_t)r.a | ((uint64_t)r.b << 21) | ((uint64_t)r.c << 42);
+        items.push_back(MergeSlot{r.cp, kind, (uint32_t)v, (uint32_t)(v >> 32)});
+    };
+    for (const BnMapRow& r : kBnD) add(r, 0);
+    for (const BnMapRow& r : kBnLC) add(r, 1);
+    build_pair_table(items, &m.bn_map, &m.bn_mask, &m.bn_seed);
 }
 
 PretokKind parse_pretok(const JsonValue* pt, HostModel& m) {
@@ -535,6 +589,7 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     }
 
     build_unicode(m);
+    if (m.norm == NORM_BERT) build_bert_norm(m);
     return m;
 }
 

@@ -84,6 +84,12 @@ struct HostModel {
     uint32_t long_mask = 0;
     ByteTrie trie;                      // WordPiece
 
+    // BertNormalizer per-code-point data (bert_norm_tables.inc): 2-stage flag table + cuckoo map (cp, kind) -> 3 x 21-bit cps
+    std::vector<uint16_t> bn_stage1;
+    std::vector<uint8_t> bn_stage2;
+    std::vector<MergeSlot> bn_map;
+    uint32_t bn_mask = 0, bn_seed = 0;
+
     std::vector<uint16_t> uc_stage1;    // [UC_STAGE1_LEN]
     std::vector<uint8_t> uc_stage2;     // [n_blocks*256]
 

@@ -43,6 +43,16 @@ __global__ void k_mark_doc_starts(const int64_t* __restrict__ doc_off, int64_t n
     if (g < n_bytes) atomicOr(&docmask[g >> 6], 1ull << (g & 63));
 }
 
+// 2-choice cuckoo probe over a pair table (WordPiece trie edges): two independent 16-byte loads
+__device__ __forceinline__ void pair_probe2(const MergeSlot* __restrict__ tab, uint32_t mask, uint32_t seed, uint32_t a, uint32_t b,
+                                            uint32_t* v0, uint32_t* v1) {
+    uint4 x = ((const uint4*)tab)[merge_hash1(a, b, seed) & mask];
+    uint4 y = ((const uint4*)tab)[merge_hash2(a, b, seed) & mask];
+    if (x.x == a && x.y == b) { *v0 = x.z; *v1 = x.w; }
+    else if (y.x == a && y.y == b) { *v0 = y.z; *v1 = y.w; }
+    else { *v0 = RANK_NONE; *v1 = 0; }
+}
+
 // =================================================================================================
 // K_added_token_scan: does any added/special token occur in the text?  The reference splits the
 // input on them before everything else (AddedVocabulary::extract_and_normalize,
@@ -844,54 +854,155 @@ template __global__ void k_pretok_local<PT_WHITESPACE_SPLIT>(const uint8_t*, int
 template __global__ void k_pretok_local<PT_BERT>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
 
 // =================================================================================================
-// BertNormalizer on ASCII text (normalizers/bert.rs:92-138): clean_text drops control characters and
-// maps \t \n \r to ' ', lowercase folds A-Z; handle_chinese_chars / strip_accents cannot fire on ASCII.
-// Pass 1 (k_norm_keepmask): keep bitmask, non-ASCII raises ERR_NON_ASCII_NORM.  Pass 2 (k_norm_scatter):
-// stream-compact into norm_text with norm_orig[k] = original byte index of normalized byte k (offsets
-// are reported through this map, never recomputed from lengths -- SURVEY 8c cheat-sheet).
+// BertNormalizer (normalizers/bert.rs:92-138), one lane per source byte, full Unicode:
+//   clean_text (drop control / U+0000 / U+FFFD, whitespace -> ' ')  ->  handle_chinese_chars (' ' c ' ')
+//   ->  strip_accents (NFD, drop Mn)  ->  lowercase
+// Every step is context free per source character (data probed from the reference: flags in a 2-stage table,
+// the NFD+strip and to_lowercase maps in one cuckoo table), so each lead byte expands independently into
+// 0..11 code points.  k_bn_count sizes the output (one byte count per source byte + one sum per 64-byte word),
+// a scan places the words, k_bn_write emits the UTF-8 together with the original byte range [os, oe) of the
+// source character of every normalised byte (an inserted char keeps its source char's alignment,
+// tokenizer/normalizer.rs:317-428).  The one context-dependent case -- NFD reordering a surviving character
+// with a non-zero combining class -- raises ERR_NON_ASCII_NORM (document refused) instead of guessing.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_norm_keepmask(const uint8_t* __restrict__ text, int64_t n_bytes, uint32_t clean,
-                                                       unsigned long long* __restrict__ keepmask, int* __restrict__ err) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool keep = false;
+constexpr uint32_t BN_DROP = 1, BN_WS = 2, BN_CJK = 4, BN_REORDER = 8, BN_D = 16, BN_LC = 32;
+constexpr int BN_MAX_OUT = 12;
+
+struct __attribute__((packed, aligned(1))) Unaligned4 { uint32_t v; };
+
+__device__ __forceinline__ uint32_t bn_flags(const BnTables& b, uint32_t cp) {
+    if (cp >= 0x110000u) return 0;
+    return b.bn2[((uint32_t)b.bn1[cp >> 8] << 8) | (cp & 255u)];
+}
+__device__ __forceinline__ int bn_lookup(const BnTables& b, uint32_t cp, uint32_t kind, uint32_t* out) {
+    uint32_t lo, hi;
+    pair_probe2(b.map, b.map_mask, b.map_seed, cp, kind, &lo, &hi);
+    if (lo == RANK_NONE && hi == 0) { out[0] = cp; return 1; }                 // not in the map: identity (cannot be a real entry: a < 2^21)
+    unsigned long long v = ((unsigned long long)hi << 32) | lo;
+    int n = 0;
+    uint32_t a = (uint32_t)(v & 0x1FFFFFu), c1 = (uint32_t)((v >> 21) & 0x1FFFFFu), c2 = (uint32_t)((v >> 42) & 0x1FFFFFu);
+    if (a != 0x1FFFFFu) out[n++] = a;
+    if (c1 != 0x1FFFFFu) out[n++] = c1;
+    if (c2 != 0x1FFFFFu) out[n++] = c2;
+    return n;
+}
+// expansion of one source code point; returns the number of output code points (*reorder set for refused chars)
+__device__ __forceinline__ int bn_expand(const BnTables& b, uint32_t cp, uint32_t* out, bool* reorder) {
+    uint32_t f = bn_flags(b, cp);
+    if (b.clean) {
+        if (f & BN_DROP) return 0;
+        if (f & BN_WS) { cp = ' '; f = 0; }
+    }
+    int n = 0;
+    const bool cjk = b.cjk && (f & BN_CJK);
+    if (cjk) out[n++] = ' ';
+    uint32_t seq[3];
+    int n1 = 1;
+    seq[0] = cp;
+    if (b.strip) {
+        if (f & BN_REORDER) *reorder = true;
+        if (f & BN_D) n1 = bn_lookup(b, cp, 0, seq);
+    }
+    for (int q = 0; q < n1; ++q) {
+        uint32_t y = seq[q];
+        if (b.lower && (bn_flags(b, y) & BN_LC)) n += bn_lookup(b, y, 1, out + n);
+        else out[n++] = y;
+    }
+    if (cjk) out[n++] = ' ';
+    return n;
+}
+__device__ __forceinline__ uint32_t utf8_len_cp(uint32_t cp) { return cp < 0x80u ? 1u : cp < 0x800u ? 2u : cp < 0x10000u ? 3u : 4u; }
+// decode the code point whose lead byte is text[i] (text has TKAMD_TEXT_PAD readable slack)
+__device__ __forceinline__ uint32_t utf8_global(const uint8_t* __restrict__ text, int64_t i, uint32_t* len) {
+    uint32_t w = ((const Unaligned4*)(text + i))->v;
+    uint32_t b0 = w & 0xFFu, b1 = (w >> 8) & 0x3Fu, b2 = (w >> 16) & 0x3Fu, b3 = (w >> 24) & 0x3Fu;
+    if (b0 < 0x80u) { *len = 1; return b0; }
+    if (b0 < 0xE0u) { *len = 2; return ((b0 & 0x1Fu) << 6) | b1; }
+    if (b0 < 0xF0u) { *len = 3; return ((b0 & 0x0Fu) << 12) | (b1 << 6) | b2; }
+    *len = 4;
+    return ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
+}
+
+__global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes,
+                                                  uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t ob = 0;
     if (i < n_bytes) {
-        uint32_t b = text[i];
-        if (b >= 0x80u) atomicOr(err, ERR_NON_ASCII_NORM);
-        keep = !clean || !((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu);
+        const uint32_t b = text[i];
+        if (b < 0x80u) {
+            // ASCII: control characters except \t \n \r are dropped, everything else is one byte
+            ob = (bt.clean && ((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu)) ? 0u : 1u;
+        } else if ((b & 0xC0u) != 0x80u) {
+            uint32_t len, out[BN_MAX_OUT];
+            bool reorder = false;
+            const uint32_t cp = utf8_global(text, i, &len);
+            const int n = bn_expand(bt, cp, out, &reorder);
+            if (reorder) atomicOr(err, ERR_NON_ASCII_NORM);
+            for (int q = 0; q < n; ++q) ob += utf8_len_cp(out[q]);
+        }
+        olen[i] = (uint8_t)ob;
     }
-    uint64_t m = __ballot(keep);
-    if ((threadIdx.x & 63) == 0 && i <= n_bytes) keepmask[i >> 6] = m;
+    // per-word sum
+    uint32_t s = ob;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0 && i <= n_bytes) wsum[i >> 6] = s;
 }
-__global__ __launch_bounds__(256) void k_norm_scatter(const uint8_t* __restrict__ text, int64_t n_bytes, uint32_t clean, uint32_t lower,
-                                                      const unsigned long long* __restrict__ keepmask, const uint32_t* __restrict__ kprefix,
-                                                      uint8_t* __restrict__ ntext, uint32_t* __restrict__ norig) {
+
+__global__ __launch_bounds__(256) void k_u32_down(const uint32_t* __restrict__ v, int64_t n, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ out) {
+    __shared__ uint32_t sm[4];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_bytes) return;
-    unsigned long long m = keepmask[i >> 6];
-    int b = (int)(i & 63);
-    if ((m >> b) & 1ull) {
-        uint32_t r = kprefix[i >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
-        uint32_t c = text[i];
-        if (clean && (c == '\t' || c == '\n' || c == '\r')) c = ' ';
-        if (lower && c - 'A' < 26u) c += 32u;
-        ntext[r] = (uint8_t)c;
-        norig[r] = (uint32_t)i;
+    uint32_t x = (i < n) ? v[i] : 0u, tot;
+    uint32_t ex = bsum[blockIdx.x] + block256_excl_scan(x, sm, &tot);
+    if (i < n) out[i] = ex;
+}
+
+__global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes,
+                                                  const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
+                                                  uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t ob = (i < n_bytes) ? olen[i] : 0u;
+    const uint32_t pos = wbase[min(i, n_bytes) >> 6] + wave_incl_scan(ob) - ob;
+    if (!ob) return;
+    const uint32_t b = text[i];
+    if (b < 0x80u) {
+        uint32_t c = b;
+        if (bt.clean && (c == '\t' || c == '\n' || c == '\r')) c = ' ';
+        if (bt.lower && c - 'A' < 26u) c += 32u;
+        ntext[pos] = (uint8_t)c;
+        nos[pos] = (uint32_t)i;
+        noe[pos] = (uint32_t)i + 1u;
+        return;
+    }
+    uint32_t len, out[BN_MAX_OUT];
+    bool reorder = false;
+    const uint32_t cp = utf8_global(text, i, &len);
+    const int n = bn_expand(bt, cp, out, &reorder);
+    uint32_t k = pos;
+    for (int q = 0; q < n; ++q) {
+        const uint32_t c = out[q], l = utf8_len_cp(c);
+        if (l == 1) ntext[k] = (uint8_t)c;
+        else if (l == 2) { ntext[k] = (uint8_t)(0xC0u | (c >> 6)); ntext[k + 1] = (uint8_t)(0x80u | (c & 0x3Fu)); }
+        else if (l == 3) { ntext[k] = (uint8_t)(0xE0u | (c >> 12)); ntext[k + 1] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); ntext[k + 2] = (uint8_t)(0x80u | (c & 0x3Fu)); }
+        else { ntext[k] = (uint8_t)(0xF0u | (c >> 18)); ntext[k + 1] = (uint8_t)(0x80u | ((c >> 12) & 0x3Fu)); ntext[k + 2] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); ntext[k + 3] = (uint8_t)(0x80u | (c & 0x3Fu)); }
+        for (uint32_t z = 0; z < l; ++z) { nos[k + z] = (uint32_t)i; noe[k + z] = (uint32_t)i + len; }
+        k += l;
     }
 }
-// document CSR in normalized coordinates: ndoc_off[d] = #kept bytes before doc_off[d]
-__global__ void k_norm_doc_offsets(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
-                                   const unsigned long long* __restrict__ keepmask, const uint32_t* __restrict__ kprefix,
-                                   const int64_t* __restrict__ n_kept, int64_t* __restrict__ ndoc_off) {
+
+// document CSR in normalised coordinates: ndoc_off[d] = #normalised bytes produced before doc_off[d]
+__global__ void k_bn_doc_offsets(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
+                                 const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
+                                 const int64_t* __restrict__ x_len, int64_t* __restrict__ ndoc_off) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > n_docs) return;
     int64_t g = doc_off[d];
     if (g < 0) g = 0;
     int64_t r;
-    if (g >= n_bytes) r = *n_kept;
+    if (g >= n_bytes) r = *x_len;
     else {
-        unsigned long long m = keepmask[g >> 6];
-        int b = (int)(g & 63);
-        r = (int64_t)kprefix[g >> 6] + __popcll(m & ((1ull << b) - 1ull));
+        r = wbase[g >> 6];
+        for (int64_t q = g & ~(int64_t)63; q < g; ++q) r += olen[q];
     }
     ndoc_off[d] = r;
 }
@@ -1220,15 +1331,6 @@ __device__ __forceinline__ void merge_probe_d(const DevTables& t, const uint16_t
 }
 __device__ __forceinline__ void merge_probe(const DevTables& t, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
     merge_probe_d(t, t.merge_disp, a, b, rank, new_id);
-}
-// 2-choice cuckoo probe over a pair table (WordPiece trie edges): two independent 16-byte loads
-__device__ __forceinline__ void pair_probe2(const MergeSlot* __restrict__ tab, uint32_t mask, uint32_t seed, uint32_t a, uint32_t b,
-                                            uint32_t* v0, uint32_t* v1) {
-    uint4 x = ((const uint4*)tab)[merge_hash1(a, b, seed) & mask];
-    uint4 y = ((const uint4*)tab)[merge_hash2(a, b, seed) & mask];
-    if (x.x == a && x.y == b) { *v0 = x.z; *v1 = x.w; }
-    else if (y.x == a && y.y == b) { *v0 = y.z; *v1 = y.w; }
-    else { *v0 = RANK_NONE; *v1 = 0; }
 }
 
 template <int G>
@@ -2010,7 +2112,7 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                 }
                 // x space -> original text
                 uint32_t os, oe;
-                if (a.norig) { os = a.norig[bs]; oe = a.norig[be - 1] + 1u; }
+                if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
                 else if (a.prefix_space && ((uint32_t)(a.x_doc_off[d + 1]) - xdoc) != ((uint32_t)(a.doc_off[d + 1]) - odoc)) {
                     // this document got a virtual leading space: x position 0 maps to [0, len(first char)), x >= 1 to x - 1
                     uint32_t rs = bs - xdoc, re = be - xdoc;
@@ -2111,16 +2213,18 @@ void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask,
                             const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end) {
     hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
 }
-void launch_norm_keepmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, unsigned long long* keepmask, int* err) {
-    hipLaunchKernelGGL(k_norm_keepmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, clean, keepmask, err);
-}
-void launch_norm_scatter(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, uint32_t lower,
-                         const unsigned long long* keepmask, const uint32_t* kprefix, uint8_t* ntext, uint32_t* norig) {
-    hipLaunchKernelGGL(k_norm_scatter, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, text, n_bytes, clean, lower, keepmask, kprefix, ntext, norig);
-}
-void launch_norm_doc_offsets(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const unsigned long long* keepmask,
-                             const uint32_t* kprefix, const int64_t* n_kept, int64_t* ndoc_off) {
-    hipLaunchKernelGGL(k_norm_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, keepmask, kprefix, n_kept, ndoc_off);
+void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                           uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
+                           uint32_t* noe, int64_t* ndoc_off, int* err) {
+    const int64_t n_words = (n_bytes >> 6) + 1;
+    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, bt, text, n_bytes, olen, wsum, err);
+    unsigned nb = blocks_for(n_words, 256);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
+    hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, (const uint32_t*)bsum, wbase);
+    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, bt, text, n_bytes, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
+    hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
+                       (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
 void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
                       const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err) {

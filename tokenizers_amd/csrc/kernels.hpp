@@ -32,6 +32,15 @@ struct DevTables {
     uint32_t max_input_chars;
 };
 
+// BertNormalizer tables + options, passed by value
+struct BnTables {
+    const uint16_t* bn1;
+    const uint8_t* bn2;
+    const MergeSlot* map;             // (cp, kind) -> up to 3 code points, 21 bits each in (rank, new_id)
+    uint32_t map_mask, map_seed;
+    uint32_t clean, cjk, strip, lower;
+};
+
 // arguments of k_token_meta (offsets / word ids), passed by value
 struct MetaArgs {
     const uint8_t* x_text;            // text the pre-tokenizer saw (normalised if a normalizer ran)
@@ -45,7 +54,8 @@ struct MetaArgs {
     int64_t n_docs;
     const int64_t* x_doc_off;         // document CSR in x space
     const int64_t* doc_off;           // document CSR in the original text
-    const uint32_t* norig;            // x byte -> original byte, or null (identity up to the document shift)
+    const uint32_t* norig;            // x byte -> original byte range start of its source char, or null
+    const uint32_t* norig_e;          //           ... range end
     const unsigned long long* leadmask;   // char mode: lead-byte bitmask of the original text + its prefix
     const uint32_t* lprefix;
     uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
@@ -92,11 +102,9 @@ void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t 
                          const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask);
 void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
                             const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end);
-void launch_norm_keepmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, unsigned long long* keepmask, int* err);
-void launch_norm_scatter(hipStream_t st, const uint8_t* text, int64_t n_bytes, uint32_t clean, uint32_t lower,
-                         const unsigned long long* keepmask, const uint32_t* kprefix, uint8_t* ntext, uint32_t* norig);
-void launch_norm_doc_offsets(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const unsigned long long* keepmask,
-                             const uint32_t* kprefix, const int64_t* n_kept, int64_t* ndoc_off);
+void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                           uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
+                           uint32_t* noe, int64_t* ndoc_off, int* err);
 void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
                       const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err);
 void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
