@@ -48,6 +48,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json config: c2 GPT-2 BPE (the headline metric, default), c3 BERT WordPiece, "
+                         "c4 Llama-3 style BPE 128k, c5 GPT-2 BPE on Zipf-length documents")
     args = ap.parse_args()
 
     import torch
@@ -75,12 +78,26 @@ def main() -> None:
     from tokenizers_amd.parallel import gather_to_root
 
     t0 = time.time()
-    tok_json = synth.load_or_train_gpt2()
+    n_types = 60000
+    if args.config in ("c2", "c5"):
+        tok_json = synth.load_or_train_gpt2()
+        workload = ("BASELINE configs[1]: GPT-2 byte-level BPE 50,257 vocab / 50k merges" if args.config == "c2"
+                    else "BASELINE configs[4]: GPT-2 byte-level BPE, document lengths Zipf over 8..8192 bytes")
+    elif args.config == "c3":
+        tok_json = synth.train_bert_wordpiece()
+        workload = "BASELINE configs[2]: BertNormalizer + BertPreTokenizer + WordPiece 30,522 vocab"
+    else:
+        tok_json = synth.train_llama3_bpe()
+        n_types = 250000
+        workload = "BASELINE configs[3]: Llama-3 style Split regex + ByteLevel + BPE 128,000 vocab (ignore_merges)"
     tok = ta.Tokenizer.from_str(tok_json, device=local_rank)
     log(f"[bench] tokenizer ready in {time.time() - t0:.1f}s  sha256={synth.sha256(tok_json)[:12]} info={tok.info}")
 
     t0 = time.time()
-    lines = synth.gen_lines(args.lines, text_seed=100 + rank, type_seed=args.type_seed)
+    if args.config == "c5":
+        lines = synth.zipf_length_docs(args.lines * 120, text_seed=100 + rank, type_seed=args.type_seed)
+    else:
+        lines = synth.gen_lines(args.lines, text_seed=100 + rank, type_seed=args.type_seed, n_types=n_types)
     buf, doc_off = ta.pack_documents(lines)
     n_bytes = int(doc_off[-1])
     n_docs = len(lines)
@@ -172,12 +189,12 @@ def main() -> None:
 
     if rank == 0:
         out = {
-            "metric": "GB input text/sec (whole node), GPT-2 BPE encode_batch", "value": round(gbps, 3), "unit": "GB/s",
+            "metric": "GB input text/sec (whole node), GPT-2 BPE encode_batch" if args.config in ("c2", "c5") else f"GB input text/sec (whole node), encode_batch [{args.config}]", "value": round(gbps, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->u32", "data": "synthetic",
             "mtokens_per_s": round(mtoks, 2),
-            "config": {"workload": "BASELINE configs[1]: GPT-2 byte-level BPE 50,257 vocab / 50k merges, "
-                                   f"{n_docs} synthetic ~120-byte lines per GPU, ids-only (encode_batch_fast), inputs resident in HBM",
+            "config": {"workload": f"{workload}, {n_docs} synthetic documents ({n_bytes / 1e6:.0f} MB) per GPU, "
+                                   "ids-only (encode_batch_fast), inputs resident in HBM",
                        "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "tokens_per_gpu": int(n_tok),
                        "pretokens_per_gpu": int(n_pretok), "type_seed": args.type_seed,
                        "tokenizer_sha256": synth.sha256(tok_json)[:16], "gather": bool(gather),

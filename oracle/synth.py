@@ -156,23 +156,19 @@ def stress_lines(seed: int = 0, n: int = 2000) -> list[str]:
 
 
 def zipf_length_docs(total_bytes: int, text_seed: int = 0, type_seed: int = 0, lo: int = 8, hi: int = 8192) -> list[str]:
-    """Config 5: document lengths ~ 1/L over [lo, hi] bytes, same language."""
+    """Config 5: document lengths ~ 1/L over [lo, hi] bytes (log-uniform), same language.  Built by cutting one
+    long stream of synthetic lines at the sampled lengths (cuts land on character boundaries)."""
     rng = np.random.default_rng(4000 + text_seed)
-    types = make_word_types(60000, type_seed)
+    n_lines = total_bytes // 110 + 1000
+    stream = " ".join(gen_lines(n_lines, text_seed=500 + text_seed, type_seed=type_seed))
     docs: list[str] = []
-    got = 0
-    # P(L) ~ 1/L  ==> log-uniform
-    while got < total_bytes:
-        n = 4096
-        L = np.exp(rng.uniform(np.log(lo), np.log(hi), size=n)).astype(np.int64)
-        for tl in L.tolist():
-            nl = max(1, tl // 120 + 1)
-            parts = gen_lines(nl, text_seed=int(rng.integers(1 << 30)), types=types, special_frac=0.0)
-            d = " ".join(parts)[:tl]
-            docs.append(d)
-            got += len(d)
-            if got >= total_bytes:
-                break
+    pos = 0
+    L = np.exp(rng.uniform(np.log(lo), np.log(hi), size=max(16, total_bytes // 200))).astype(np.int64)
+    for tl in L.tolist():
+        if pos >= len(stream) or pos >= total_bytes:
+            break
+        docs.append(stream[pos:pos + tl])
+        pos += tl
     return docs
 
 
