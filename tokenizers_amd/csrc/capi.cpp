@@ -222,6 +222,7 @@ void upload_tables(tkamd_tokenizer* t) {
     d.word_seed = hm.word_seed;
     d.word_bmask = hm.word_bmask;
     d.ignore_merges = hm.ignore_merges ? 1u : 0u;
+    d.long_probe_max_len = 0xFFFFFFFFu;
     d.unk_id = hm.unk_id;
     d.has_unk = hm.has_unk ? 1u : 0u;
     d.long_blob = t->t_long_blob.as<uint8_t>();
@@ -410,7 +411,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         pf.begin("bert_normalize");
         launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, t->w_keepmask.as<uint8_t>(), t->w_kprefix.as<uint32_t>(),
                               t->w_bsum.as<uint32_t>(), t->w_wbase.as<uint32_t>(), d_xlen, t->w_ntext.as<uint8_t>(),
-                              t->w_norig.as<uint32_t>(), t->w_norig_e.as<uint32_t>(), t->w_ndoc_off.as<int64_t>(), d_err);
+                              (off_mode != TKAMD_OFFSETS_NONE) ? t->w_norig.as<uint32_t>() : nullptr,
+                              (off_mode != TKAMD_OFFSETS_NONE) ? t->w_norig_e.as<uint32_t>() : nullptr, t->w_ndoc_off.as<int64_t>(), d_err);
         pf.end();
     } else if (prefix_space) {
         // ---- ByteLevel add_prefix_space: documents shifted behind their virtual leading space ----
@@ -475,7 +477,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         uint32_t* list64 = list32 + N / 16 + 16;
         uint32_t* listL = list64 + N / 32 + 16;
         pf.begin("bpe_word_lookup");
-        launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), d_npretok, t->w_tok0.as<uint32_t>(),
+        launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), nullptr, d_npretok, t->w_tok0.as<uint32_t>(),
                                t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters);
         pf.end();
         pf.begin("bpe_merge_lane32");
@@ -550,10 +552,35 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
                          t->w_ntok.as<uint32_t>(), d_err);
         pf.end();
     } else {
-        pf.begin("wordpiece");
-        launch_wordpiece(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
-                         t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
-        pf.end();
+        // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): a whole-word
+        // table pass settles most words with one probe; only the rest walk the trie, in dense wavefronts.
+        const bool shortcut = hm.max_input_chars >= (uint32_t)WORD_MAX_KEY;
+        if (shortcut) {
+            size_t N = (size_t)n_x;
+            uint32_t* list16 = t->w_lists.as<uint32_t>();
+            uint32_t* list32 = list16 + N + 16;
+            uint32_t* list64 = list32 + N / 16 + 16;
+            uint32_t* listL = list64 + N / 32 + 16;
+            DevTables wt = t->dt;
+            wt.ignore_merges = 1;                              // any whole-word hit is final
+            wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
+            pf.begin("wordpiece_word_lookup");
+            launch_bpe_word_lookup(st, grid, wt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
+                                   t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters);
+            pf.end();
+            pf.begin("wordpiece");
+            const uint32_t* lists[4] = {list16, list32, list64, listL};
+            const int cnts[4] = {CNT_LIST16, CNT_LIST32, CNT_LIST64, CNT_LISTL};
+            for (int q = 0; q < 4; ++q)
+                launch_wordpiece(st, q == 0 ? grid : t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, lists[q],
+                                 d_counters + cnts[q], t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+            pf.end();
+        } else {
+            pf.begin("wordpiece");
+            launch_wordpiece(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, nullptr, nullptr,
+                             t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+            pf.end();
+        }
     }
     pf.begin("compact");
     launch_compact(st, grid, t->w_ntok.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(),

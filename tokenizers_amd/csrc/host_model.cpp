@@ -548,7 +548,8 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     }
 
     // ---- whole-word tables (BPE: ignore_merges + merge-stable shortcut; WordLevel: the model) ----
-    if (m.model == MODEL_BPE || m.model == MODEL_WORDLEVEL) {
+    if (m.model == MODEL_BPE || m.model == MODEL_WORDLEVEL || m.model == MODEL_WORDPIECE) {
+        // (WordPiece: the longest candidate piece is the whole word, so a whole-word hit ends the match at once)
         std::vector<WordSlot> words;
         m.long_off.push_back(0);
         for (size_t i = 0; i < m.raw_tokens.size(); ++i) {

@@ -799,15 +799,38 @@ __global__ __launch_bounds__(256) void k_pretok_local(const uint8_t* __restrict_
                                                       const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                       unsigned long long* __restrict__ startmask,
                                                       unsigned long long* __restrict__ endmask) {
-    __shared__ uint8_t sb[PL_R + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t sb[PL_R + 8];
     __shared__ uint8_t si[PL_R + 8];
+    __shared__ unsigned long long sdoc[PT_TILE / 64 + 2];
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
     const int64_t r0 = t0 - PL_HALO;
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // effective text length
-    for (int k = tid; k < PL_R + 8; k += 256) {
-        int64_t g = r0 + k;
-        sb[k] = (g >= 0 && g < n_bytes) ? text[g] : (uint8_t)0;
+    if (t0 > n_bytes + 64) {                                     // tile entirely past the text (derived X text is shorter than its bound)
+        if ((tid & 63) == 0) {
+            for (int it = 0; it < PT_TILE / 256; ++it) {
+                int64_t g = t0 + it * 256 + tid;
+                if (g <= n_bytes_host) { startmask[g >> 6] = 0ull; endmask[g >> 6] = 0ull; }
+            }
+        }
+        return;
+    }
+    {
+        uint32_t* sb32 = (uint32_t*)sb;                          // r0 is a multiple of 4
+        for (int k = tid; k < (PL_R + 8) / 4; k += 256) {
+            int64_t g = r0 + 4 * (int64_t)k;
+            uint32_t v = 0;
+            if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
+            else if (g + 4 > 0 && g < n_bytes) {
+                for (int q = 0; q < 4; ++q)
+                    if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
+            }
+            sb32[k] = v;
+        }
+        if (tid < PT_TILE / 64 + 2) {
+            int64_t w = (t0 >> 6) - 1 + tid;
+            sdoc[tid] = (w >= 0 && (w << 6) < n_bytes_host + 64) ? docmask[w] : 0ull;
+        }
     }
     __syncthreads();
     for (int k = tid; k < PL_R; k += 256) {
@@ -816,7 +839,8 @@ __global__ __launch_bounds__(256) void k_pretok_local(const uint8_t* __restrict_
         if (g >= 0 && g < n_bytes) {
             uint32_t b = sb[k];
             info = IF_VALID;
-            if ((docmask[g >> 6] >> (g & 63)) & 1ull) info |= IF_DOC;
+            int64_t rel = g - (t0 - 64);
+            if ((sdoc[rel >> 6] >> (rel & 63)) & 1ull) info |= IF_DOC;
             if ((b & 0xC0u) != 0x80u) {
                 uint32_t len;
                 uint32_t cp = utf8_at(sb, k, &len);
@@ -970,8 +994,7 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
         if (bt.clean && (c == '\t' || c == '\n' || c == '\r')) c = ' ';
         if (bt.lower && c - 'A' < 26u) c += 32u;
         ntext[pos] = (uint8_t)c;
-        nos[pos] = (uint32_t)i;
-        noe[pos] = (uint32_t)i + 1u;
+        if (nos) { nos[pos] = (uint32_t)i; noe[pos] = (uint32_t)i + 1u; }
         return;
     }
     uint32_t len, out[BN_MAX_OUT];
@@ -985,7 +1008,7 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
         else if (l == 2) { ntext[k] = (uint8_t)(0xC0u | (c >> 6)); ntext[k + 1] = (uint8_t)(0x80u | (c & 0x3Fu)); }
         else if (l == 3) { ntext[k] = (uint8_t)(0xE0u | (c >> 12)); ntext[k + 1] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); ntext[k + 2] = (uint8_t)(0x80u | (c & 0x3Fu)); }
         else { ntext[k] = (uint8_t)(0xF0u | (c >> 18)); ntext[k + 1] = (uint8_t)(0x80u | ((c >> 12) & 0x3Fu)); ntext[k + 2] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); ntext[k + 3] = (uint8_t)(0x80u | (c & 0x3Fu)); }
-        for (uint32_t z = 0; z < l; ++z) { nos[k + z] = (uint32_t)i; noe[k + z] = (uint32_t)i + len; }
+        if (nos) for (uint32_t z = 0; z < l; ++z) { nos[k + z] = (uint32_t)i; noe[k + z] = (uint32_t)i + len; }
         k += l;
     }
 }
@@ -1083,6 +1106,7 @@ __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* _
     const unsigned long long mw = (wi < n_words) ? startmask[wi] : 0ull;
     const uint32_t pw = (wi < n_words) ? wprefix[wi] : 0u;
     const uint32_t mlo = (uint32_t)mw, mhi = (uint32_t)(mw >> 32);
+    if (__ballot(mw != 0ull) == 0ull) return;                    // nothing starts in these 4 KB
     const int kmax = (int)min((int64_t)64, n_words - w0);
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int k = 0; k < kmax; ++k) {
@@ -1094,17 +1118,31 @@ __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* _
 }
 
 // exclusive end of every pre-token for the "Removed" pre-tokenizers: an end bit at byte i closes the
-// pre-token that started most recently before i
+// pre-token that started most recently before i.  Same wavefront-per-64-words structure as k_emit_pretok.
 __global__ __launch_bounds__(256) void k_emit_pretok_end(const unsigned long long* __restrict__ startmask,
                                                          const unsigned long long* __restrict__ endmask,
                                                          const uint32_t* __restrict__ wprefix, int64_t n_bytes,
                                                          uint32_t* __restrict__ pt_end) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i > n_bytes) return;
-    int b = (int)(i & 63);
-    if ((endmask[i >> 6] >> b) & 1ull) {
-        uint32_t r = wprefix[i >> 6] + (uint32_t)__popcll(startmask[i >> 6] & ((1ull << b) - 1ull));
-        pt_end[r - 1] = (uint32_t)i;
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_words = (n_bytes >> 6) + 1;               // an end bit can sit at byte n_bytes
+    const int64_t w0 = wave * 64;
+    if (w0 >= n_words) return;
+    const int64_t wi = w0 + lane;
+    const unsigned long long ms = (wi < n_words) ? startmask[wi] : 0ull, me = (wi < n_words) ? endmask[wi] : 0ull;
+    const uint32_t pw = (wi < n_words) ? wprefix[wi] : 0u;
+    const uint32_t slo = (uint32_t)ms, shi = (uint32_t)(ms >> 32), elo = (uint32_t)me, ehi = (uint32_t)(me >> 32);
+    if (__ballot(me != 0ull) == 0ull) return;
+    const int kmax = (int)min((int64_t)64, n_words - w0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0; k < kmax; ++k) {
+        const unsigned long long e = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ehi, k) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)elo, k);
+        if (e == 0ull) continue;                              // wave-uniform
+        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)shi, k) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)slo, k);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
+        if ((e >> lane) & 1ull) pt_end[base + (uint32_t)__popcll(m & below) - 1u] = (uint32_t)(((w0 + k) << 6) + lane);
     }
 }
 
@@ -1185,7 +1223,8 @@ constexpr int LK_CHUNK = 256 * LK_ITEMS;
 constexpr int LK_GROUP = 4;                      // items whose loads are kept in flight together
 
 __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
-                                                         const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
+                                                         const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
+                                                         const int64_t* __restrict__ n_pretok,
                                                          uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
                                                          uint32_t* __restrict__ list16, uint32_t* __restrict__ list32,
                                                          uint32_t* __restrict__ list64,
@@ -1213,8 +1252,13 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
 #pragma unroll
             for (int k = 0; k < LK_ITEMS; ++k) st[k] = pt_start[min(pbase + k, P)];
         }
+        if (pt_end) {                                      // "Removed" pre-tokenizers: explicit ends
 #pragma unroll
-        for (int k = 0; k < LK_ITEMS; ++k) en[k] = (k + 1 < LK_ITEMS) ? st[k + 1] : pt_start[min(pbase + LK_ITEMS, P)];
+            for (int k = 0; k < LK_ITEMS; ++k) en[k] = (pbase + k < P) ? pt_end[pbase + k] : st[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k) en[k] = (k + 1 < LK_ITEMS) ? st[k + 1] : pt_start[min(pbase + LK_ITEMS, P)];
+        }
         uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list32, 3 -> list64 / listL
         uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
         uint32_t out_id[LK_ITEMS], out_n[LK_ITEMS];
@@ -1267,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
             for (int k = 0; k < LK_ITEMS; ++k) {
                 uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
                 uint32_t id;
-                if (c >= 2 && long_probe(t, text + st[k], len, &id)) {
+                if (c >= 2 && len <= t.long_probe_max_len && long_probe(t, text + st[k], len, &id)) {
                     tok0[pbase + k] = id;
                     ntok[pbase + k] = 1;
                     cls &= ~(3u << (2 * k));
@@ -1810,10 +1854,13 @@ __global__ __launch_bounds__(256) void k_wordlevel(DevTables t, const uint8_t* _
 __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text,
                                                    const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
                                                    const int64_t* __restrict__ n_pretok,
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
                                                    uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
                                                    uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
-    const int64_t P = *n_pretok;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+    // with a work queue (`list`): only the pre-tokens the whole-word lookup could not settle; without: all of them
+    const int64_t P = list ? (int64_t)*n_list : *n_pretok;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (int64_t)gridDim.x * 256) {
+        const int64_t p = list ? (int64_t)list[q] : q;
         uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
         uint32_t chars = 0;
         for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
@@ -2183,9 +2230,9 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
     hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt);
 }
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32, uint32_t* list64,
-                            uint32_t* listL, uint32_t* counters) {
-    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, n_pretok, tok0, ntok, list16, list32, list64, listL, counters);
+                            const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters) {
+    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
@@ -2211,7 +2258,7 @@ void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t 
 }
 void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
                             const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end) {
-    hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
+    hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 64, 4 * 4096)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
 }
 void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                            uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
@@ -2231,8 +2278,9 @@ void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_
     hipLaunchKernelGGL(k_wordlevel, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, err);
 }
 void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end, int* err) {
-    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, tmp_ids, tmp_end, err);
+                      const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
+                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err) {
+    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, list, n_list, tok0, ntok, tmp_ids, tmp_end, err);
 }
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err) {

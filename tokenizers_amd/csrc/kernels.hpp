@@ -19,6 +19,7 @@ struct DevTables {
     const uint16_t* word_disp;
     uint32_t word_mask, word_seed, word_bmask;
     uint32_t ignore_merges;
+    uint32_t long_probe_max_len;      // whole-word probes of keys > 16 bytes only up to this length (WordPiece: max_input_chars)
     uint32_t unk_id, has_unk;
     // long (>16 byte) whole-word keys
     const uint8_t* long_blob;
@@ -92,8 +93,8 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                            const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32, uint32_t* list64,
-                            uint32_t* listL, uint32_t* counters);
+                            const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters);
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
@@ -108,7 +109,8 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
 void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
                       const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err);
 void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
+                      const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
+                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,

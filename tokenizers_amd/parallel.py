@@ -75,6 +75,9 @@ def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None):
         offs = torch.zeros(tot_docs + 1, dtype=torch.int64, device=device)
         torch.cumsum(counts_all, dim=0, out=offs[1:])
         return ids_all, offs
+    # send from framework-allocated memory: `ids` may be a zero-copy view of the tokenizer's own hipMalloc'd
+    # workspace, and a fresh allocator block is the buffer kind RCCL's P2P path is exercised with everywhere
+    ids = ids.clone()
     ops = []
     if n_tok:
         ops.append(dist.P2POp(dist.isend, ids, root, group))
