@@ -314,3 +314,30 @@ def test_alternative_kernels_agree(gpt2_json):
     env = dict(os.environ, TKAMD_PRETOK="bits", TKAMD_MERGE16="row", TKAMD_DEDUP="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def _adversarial_docs(n, seed):
+    """Short random strings over the alphabet SURVEY Appendix A used to verify the pre-tokenizer specs: many
+    apostrophes and contraction letters in both cases, every kind of whitespace, digits, No/Nl numbers, combining marks,
+    multi-byte letters, long-s and Kelvin (case folding), CR/LF."""
+    rng = np.random.default_rng(seed)
+    alpha = ["'", "'", "'", "s", "t", "d", "m", "l", "v", "r", "e", "S", "T", "D", "M", "L", "V", "R", "E", "a", "Z", " ", " ", " ", "\t", "\n", "\r",
+             "\u3000", "\u00a0", "\u0085", "1", "2", "9", "\u00b2", "\u00bd", "\u0663", "\u2167", "!", "-", "_", ".", "\u00e9", "\u4e2d", "\U0001F601",
+             "\u0300", "\u017f", "\u212a", "K", "\x1c", "\x00"]
+    lens = rng.integers(0, 24, size=n)
+    picks = rng.integers(0, len(alpha), size=int(lens.sum()))
+    out, k = [], 0
+    for L in lens.tolist():
+        out.append("".join(alpha[i] for i in picks[k:k + L].tolist()))
+        k += L
+    return out
+
+
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000", "bytelevel_prefix_trim_3000"])
+def test_fuzz_adversarial_alphabet(name):
+    import tokenizers_amd as ta
+    js = load_tokenizer_json(name)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    docs = _adversarial_docs(150000, seed=sum(map(ord, name)) % 1000)
+    _meta_compare(tok, o, docs)
