@@ -479,16 +479,30 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
                                                        const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                        unsigned long long* __restrict__ startmask,
                                                        unsigned long long* __restrict__ slowmask) {
-    __shared__ uint8_t sb[L3_R + 8];
+    __shared__ __attribute__((aligned(16))) uint8_t sb[L3_R + 8];
     __shared__ uint8_t si[L3_R + 8];
     __shared__ uint8_t sc[L3_R + 8];     // con: number of letters (1|2) swallowed by a contraction starting at this apostrophe
+    __shared__ unsigned long long sdoc[L3_R / 64 + 2];
     const int tid = (int)threadIdx.x;
     const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
     const int64_t r0 = t0 - L3_HALO;
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
-    for (int k = tid; k < L3_R + 8; k += 256) {
-        int64_t g = r0 + k;
-        sb[k] = (g >= 0 && g < n_bytes) ? text[g] : (uint8_t)0;
+    {
+        uint32_t* sb32 = (uint32_t*)sb;                          // r0 is a multiple of 4: aligned dword staging
+        for (int k = tid; k < (L3_R + 8) / 4; k += 256) {
+            int64_t g = r0 + 4 * (int64_t)k;
+            uint32_t v = 0;
+            if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
+            else if (g + 4 > 0 && g < n_bytes) {
+                for (int q = 0; q < 4; ++q)
+                    if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
+            }
+            sb32[k] = v;
+        }
+        if (tid < L3_R / 64 + 2) {                               // doc-start words covering [t0 - 128, ...)
+            int64_t w = (r0 >> 6) + tid;
+            sdoc[tid] = (w >= 0 && (w << 6) < n_bytes_host + 64) ? docmask[w] : 0ull;
+        }
     }
     __syncthreads();
     for (int k = tid; k < L3_R + 8; k += 256) {
@@ -497,7 +511,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
         if (k < L3_R && g >= 0 && g < n_bytes) {
             uint32_t b = sb[k];
             info = L3_VALID;
-            if ((docmask[g >> 6] >> (g & 63)) & 1ull) info |= L3_DOC;
+            if ((sdoc[k >> 6] >> (k & 63)) & 1ull) info |= L3_DOC;      // r0 is a multiple of 64: bit k of the staged words
             if ((b & 0xC0u) != 0x80u) {
                 uint32_t len;
                 uint32_t cp = utf8_at(sb, k, &len);
