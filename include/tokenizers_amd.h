@@ -47,6 +47,9 @@ extern "C" {
 #define TKAMD_OFFSETS_CHAR   2u   /* encode_batch_char_offsets  (mod.rs:1360-1379; Python)     */
 #define TKAMD_OFFSETS_MASK   3u
 #define TKAMD_WANT_WORD_IDS  4u   /* also produce Encoding.words                               */
+#define TKAMD_ADD_SPECIAL    8u   /* add_special_tokens=true: PostProcessor::process for a single sequence
+                                     (processors/bert.rs:51-120, roberta.rs, template.rs:544-590): special ids
+                                     around every document, offsets (0,0), word id 0xFFFFFFFF (None)          */
 
 /* Readable slack the caller must leave after text[n_bytes] for the device entry
  * points (kernels read whole 16-byte words).  The host entry pads internally. */
@@ -76,6 +79,11 @@ typedef struct tkamd_info {
 int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tkamd_tokenizer** out);
 void tkamd_tokenizer_free(tkamd_tokenizer* tok);
 int tkamd_tokenizer_info(const tkamd_tokenizer* tok, tkamd_info* info);
+
+/* Special-token layout of the post-processor for a single sequence: ids inserted before / after every document
+ * when TKAMD_ADD_SPECIAL is set.  Returns TKAMD_ERR_UNSUPPORTED if the post-processor is outside the path. */
+int tkamd_tokenizer_specials(const tkamd_tokenizer* tok, uint32_t* prefix_ids, int32_t* n_prefix, uint32_t* suffix_ids,
+                             int32_t* n_suffix, int32_t cap);
 
 /* Thread-local message of the last failing call on this thread (error.rs:26-31 maps
  * the reference's error to `Exception(str(e))`; the shim does the same with this). */

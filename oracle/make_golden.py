@@ -52,12 +52,29 @@ def vectors(tok: Tokenizer, docs):
             "reference": f"tokenizers=={tokenizers.__version__}"}
 
 
+def emit_specials(name, tok_json, docs):
+    """Vectors WITH add_special_tokens=True (post-processor special tokens around every document)."""
+    tok = Tokenizer.from_str(tok_json)
+    encs = tok.encode_batch(docs, add_special_tokens=True)
+    v = {"docs": docs, "ids": [e.ids for e in encs], "offsets_char": [[list(o) for o in e.offsets] for e in encs],
+         "words": [e.word_ids for e in encs], "special_tokens_mask": [e.special_tokens_mask for e in encs],
+         "type_ids": [e.type_ids for e in encs], "reference": f"tokenizers=={tokenizers.__version__}"}
+    write_gz(os.path.join(GOLD, name + ".json.gz"), tok_json)
+    write_gz(os.path.join(GOLD, name + "_vectors.json.gz"), json.dumps(v, ensure_ascii=False))
+    print(name, "vocab", tok.get_vocab_size(), "docs", len(docs), "(add_special_tokens=True)")
+
+
 def emit(name, tok_json, docs):
     tok = Tokenizer.from_str(tok_json)
     if not os.path.exists(os.path.join(GOLD, name + ".json.gz")) or name != "gpt2_synth_50257":
         write_gz(os.path.join(GOLD, name + ".json.gz"), tok_json)
     write_gz(os.path.join(GOLD, name + "_vectors.json.gz"), json.dumps(vectors(tok, docs), ensure_ascii=False))
     print(name, "vocab", tok.get_vocab_size(), "docs", len(docs))
+
+
+def load_json(name):
+    with gzip.open(os.path.join(GOLD, name + ".json.gz"), "rt", encoding="utf-8") as fh:
+        return fh.read()
 
 
 def ascii_only(lines):
@@ -107,6 +124,21 @@ def main():
     unicode_docs = ["".join(random.choice(upool) for _ in range(random.randint(1, 14))) for _ in range(600)]
     bert_docs = [d for d in edge + base + stress + unicode_docs if "[" not in d and "\u302e" not in d]
     emit("bert_wordpiece_4000", t.to_str(), bert_docs + ["HE\x01LLO\tWorld!", "\x00hello", "hello\x01", "wor\x02ld x", "a" * 101, "b" * 100])
+
+    # same BERT tokenizer with BertProcessing ([CLS] A [SEP]); and a Llama-3 style template (BOS only) behind a Sequence
+    tb = Tokenizer.from_str(t.to_str())
+    tb.post_processor = processors.BertProcessing(("[SEP]", tb.token_to_id("[SEP]")), ("[CLS]", tb.token_to_id("[CLS]")))
+    emit_specials("bert_wordpiece_4000_specials", tb.to_str(), [d for d in bert_docs[:300] + ["", " "]])
+    tl = Tokenizer.from_str(load_json("llama3_small_6000"))
+    tl.add_special_tokens(["<|begin_of_text|>", "<|end_of_text|>"])
+    bos = tl.token_to_id("<|begin_of_text|>")
+    tl.post_processor = processors.Sequence([
+        processors.ByteLevel(trim_offsets=False),
+        processors.TemplateProcessing(single="<|begin_of_text|> $A", pair="<|begin_of_text|> $A <|begin_of_text|> $B:1",
+                                      special_tokens=[("<|begin_of_text|>", bos)])])
+    dl = json.loads(tl.to_str())
+    dl["model"]["ignore_merges"] = True
+    emit_specials("llama3_small_6000_specials", json.dumps(dl, ensure_ascii=False), edge + base[:200] + stress[:200])
 
     # C1: Whitespace + WordLevel over 1,000 ASCII lines
     c1 = ascii_only(synth.gen_lines(1100, text_seed=0, special_frac=0.0))[:1000]

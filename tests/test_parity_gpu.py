@@ -341,3 +341,22 @@ def test_fuzz_adversarial_alphabet(name):
     o = orc.Oracle(js)
     docs = _adversarial_docs(150000, seed=sum(map(ord, name)) % 1000)
     _meta_compare(tok, o, docs)
+
+
+@pytest.mark.parametrize("name", ["bert_wordpiece_4000_specials", "llama3_small_6000_specials"])
+def test_add_special_tokens_matches_wheel(name):
+    """Tokenizer.encode_batch(..., add_special_tokens=True) == the wheel: ids, char offsets, word ids (None on
+    specials), special_tokens_mask, type_ids (BertProcessing / Sequence[ByteLevel, TemplateProcessing])."""
+    import tokenizers_amd as ta
+    tok = ta.Tokenizer.from_str(load_tokenizer_json(name), device=0)
+    v = load_vectors(name)
+    got = tok.encode_batch(v["docs"])            # default add_special_tokens=True, like the reference
+    for i, doc in enumerate(v["docs"]):
+        e = got[i]
+        assert e.ids == v["ids"][i], doc
+        assert [list(x) for x in e.offsets] == v["offsets_char"][i], doc
+        assert e.word_ids == v["words"][i], doc
+        assert e.special_tokens_mask == v["special_tokens_mask"][i], doc
+        assert e.type_ids == v["type_ids"][i], doc
+    plain = tok.encode_batch(v["docs"], add_special_tokens=False)
+    assert plain.n_tokens == got.n_tokens - sum(sum(m) for m in v["special_tokens_mask"])

@@ -21,6 +21,7 @@ OFFSETS_NONE = 0
 OFFSETS_BYTE = 1
 OFFSETS_CHAR = 2
 WANT_WORD_IDS = 4
+ADD_SPECIAL = 8
 TEXT_PAD = 64
 MAX_STAGES = 24
 
@@ -30,7 +31,7 @@ SYMBOLS = [
     "tkamd_encode_batch", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
     "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
-    "tkamd_profile_counters", "tkamd_version",
+    "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version",
 ]
 
 
@@ -99,6 +100,8 @@ def load() -> C.CDLL:
     lib.tkamd_profile_enable.restype = i32
     lib.tkamd_profile_read.argtypes = [vp, C.POINTER(StageTime), i32, C.POINTER(i32), i32]
     lib.tkamd_profile_read.restype = i32
+    lib.tkamd_tokenizer_specials.argtypes = [vp, C.POINTER(u32), C.POINTER(C.c_int32), C.POINTER(u32), C.POINTER(C.c_int32), C.c_int32]
+    lib.tkamd_tokenizer_specials.restype = i32
     lib.tkamd_profile_counters.argtypes = [vp, C.POINTER(u32), i32]
     lib.tkamd_profile_counters.restype = i32
     _lib = lib

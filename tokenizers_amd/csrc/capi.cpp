@@ -82,11 +82,11 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
+    DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -98,6 +98,7 @@ struct tkamd_tokenizer {
     std::vector<tkamd_stage_time> acc;
     // last device call (for tkamd_device_sync)
     int64_t last_n_docs = 0;
+    int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
 };
 
@@ -146,7 +147,7 @@ struct tkamd_batch {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* ..7 */, SC_NCHARS = 8, SC_HUGE_USED = 9 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* ..7 */, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
 
 struct Prof {
     tkamd_tokenizer* t;
@@ -201,6 +202,8 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_long_id, hm.long_id);
     upload(t->t_long_table, hm.long_table);
     upload(t->t_trie, hm.trie.table);
+    upload(t->t_pp_prefix, hm.pp_prefix);
+    upload(t->t_pp_suffix, hm.pp_suffix);
     upload(t->t_bn1, hm.bn_stage1);
     upload(t->t_bn2, hm.bn_stage2);
     upload(t->t_bn_map, hm.bn_map);
@@ -332,6 +335,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const bool want_words = (flags & TKAMD_WANT_WORD_IDS) != 0;
     const bool want_meta = off_mode != TKAMD_OFFSETS_NONE || want_words;
     if (off_mode == 3u) throw Invalid("bad offsets mode");
+    const bool add_special = (flags & TKAMD_ADD_SPECIAL) != 0 && !(hm.pp_prefix.empty() && hm.pp_suffix.empty());
+    if ((flags & TKAMD_ADD_SPECIAL) && !hm.pp_unsupported.empty()) throw Unsupported("add_special_tokens: " + hm.pp_unsupported);
     const bool prefix_space = hm.byte_level && hm.add_prefix_space;
     // host-side bound of the X text length: +1 per document for the virtual space; BertNormalizer can grow a
     // character (CJK spacing: 3 -> 5 bytes, NFD/lowercase expansions <= 3x) -- 3x the input covers every case
@@ -374,6 +379,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
         if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = t->w_offsets.as<uint32_t>();
         if (want_words) out->d_word_ids = t->w_word_ids.as<uint32_t>();
+        t->last_ntok_slot = SC_NTOK;
+        if (add_special && n_docs > 0) throw Unsupported("add_special_tokens on a batch of only empty documents");
         return;
     }
 
@@ -631,6 +638,37 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         if (a.want_offsets) out->d_offsets = a.offsets;
         if (a.want_words) out->d_word_ids = a.word_ids;
     }
+    if (add_special) {
+        const size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
+        t->w_ids2.reserve(T2 * 4);
+        t->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
+        if (out->d_offsets) t->w_offsets2.reserve(T2 * 8);
+        if (out->d_word_ids) t->w_word_ids2.reserve(T2 * 4);
+        SpecialArgs sa{};
+        sa.tok_offsets = t->w_tok_offsets.as<int64_t>();
+        sa.n_docs = n_docs;
+        sa.ids = t->w_ids.as<uint32_t>();
+        sa.offsets = out->d_offsets;
+        sa.word_ids = out->d_word_ids;
+        sa.prefix = t->t_pp_prefix.as<uint32_t>();
+        sa.suffix = t->t_pp_suffix.as<uint32_t>();
+        sa.n_prefix = (int32_t)hm.pp_prefix.size();
+        sa.n_suffix = (int32_t)hm.pp_suffix.size();
+        sa.tok_offsets2 = t->w_tok_offsets2.as<int64_t>();
+        sa.ids2 = t->w_ids2.as<uint32_t>();
+        sa.offsets2 = t->w_offsets2.as<uint32_t>();
+        sa.word_ids2 = t->w_word_ids2.as<uint32_t>();
+        sa.n_tok2 = sc + SC_NTOK2;
+        pf.begin("add_specials");
+        launch_add_specials(st, grid, sa);
+        pf.end();
+        out->d_ids = sa.ids2;
+        out->d_tok_offsets = sa.tok_offsets2;
+        if (out->d_offsets) out->d_offsets = sa.offsets2;
+        if (out->d_word_ids) out->d_word_ids = sa.word_ids2;
+        out->d_n_tokens = sa.n_tok2;
+    }
+    t->last_ntok_slot = add_special ? SC_NTOK2 : SC_NTOK;
     HIP_CHECK(hipGetLastError());
 }
 
@@ -640,7 +678,7 @@ int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_
     HIP_CHECK(hipStreamSynchronize(st));
     int err = *(int*)&host[SC_ERR];
     memcpy(t->last_counters, &host[SC_COUNTERS], sizeof(t->last_counters));
-    if (n_tok) *n_tok = host[SC_NTOK];
+    if (n_tok) *n_tok = host[t->last_ntok_slot];
     if (n_pretok) *n_pretok = host[SC_NPRETOK];
     return err;
 }
@@ -714,10 +752,10 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
         DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->t_long_id, &t->t_long_table, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }
@@ -737,6 +775,17 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* t, tkamd_info* info) {
     info->n_added_tokens = (int32_t)hm.added_tokens.size();
     info->device = t->device;
     info->n_direct_words = t->n_direct;
+    return TKAMD_OK;
+}
+
+int tkamd_tokenizer_specials(const tkamd_tokenizer* t, uint32_t* prefix_ids, int32_t* n_prefix, uint32_t* suffix_ids, int32_t* n_suffix,
+                             int32_t cap) {
+    if (!t || !n_prefix || !n_suffix) return set_error(TKAMD_ERR_INVALID, "null argument");
+    if (!t->hm.pp_unsupported.empty()) return set_error(TKAMD_ERR_UNSUPPORTED, "add_special_tokens: " + t->hm.pp_unsupported);
+    *n_prefix = (int32_t)t->hm.pp_prefix.size();
+    *n_suffix = (int32_t)t->hm.pp_suffix.size();
+    for (int32_t i = 0; i < *n_prefix && i < cap && prefix_ids; ++i) prefix_ids[i] = t->hm.pp_prefix[i];
+    for (int32_t i = 0; i < *n_suffix && i < cap && suffix_ids; ++i) suffix_ids[i] = t->hm.pp_suffix[i];
     return TKAMD_OK;
 }
 

@@ -384,14 +384,59 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     // ---- pre-tokenizer ----
     m.pretok = parse_pretok(root->get("pre_tokenizer"), m);
 
-    // ---- post-processor: only its offset trimming matters to this path ----
-    const JsonValue* pp = root->get("post_processor");
-    if (pp && !pp->is_null()) {
-        std::string t = pp->get_str("type");
-        if (t == "ByteLevel" || t == "RobertaProcessing") {
-            m.trim_offsets = pp->get_bool("trim_offsets", true);
-            m.pp_add_prefix_space = pp->get_bool("add_prefix_space", true);
-        }
+    // ---- post-processor: offset trimming + the special tokens it puts around a single sequence ----
+    {
+        std::function<void(const JsonValue*)> apply = [&](const JsonValue* pp) {
+            if (!pp || pp->is_null()) return;
+            std::string t = pp->get_str("type");
+            if (t == "ByteLevel" || t == "RobertaProcessing") {
+                m.trim_offsets = pp->get_bool("trim_offsets", true);
+                m.pp_add_prefix_space = pp->get_bool("add_prefix_space", true);
+            }
+            if (t == "ByteLevel") return;
+            if (t == "BertProcessing" || t == "RobertaProcessing") {      // [cls] A [sep]   (processors/bert.rs:51-120, roberta.rs)
+                const JsonValue* cls = pp->get("cls");
+                const JsonValue* sep = pp->get("sep");
+                if (!cls || !sep || !cls->is_array() || !sep->is_array() || cls->arr.size() != 2 || sep->arr.size() != 2)
+                    throw Invalid("tokenizer.json: bad cls/sep in post_processor");
+                m.pp_prefix.insert(m.pp_prefix.begin(), (uint32_t)cls->arr[1]->num);
+                m.pp_suffix.push_back((uint32_t)sep->arr[1]->num);
+                return;
+            }
+            if (t == "TemplateProcessing") {                               // processors/template.rs:544-590, `single` template
+                const JsonValue* single = pp->get("single");
+                const JsonValue* sp = pp->get("special_tokens");
+                if (!single || !single->is_array()) throw Invalid("tokenizer.json: TemplateProcessing without `single`");
+                std::vector<uint32_t> pre, post;
+                int n_seq = 0;
+                for (auto& piece : single->arr) {
+                    if (const JsonValue* sq = piece->get("Sequence")) {
+                        if (sq->get_str("id") != "A") { m.pp_unsupported = "TemplateProcessing single template refers to sequence B"; return; }
+                        if (sq->get_num("type_id", 0) != 0) { m.pp_unsupported = "TemplateProcessing gives sequence A a non-zero type_id"; return; }
+                        ++n_seq;
+                    } else if (const JsonValue* st = piece->get("SpecialToken")) {
+                        std::string name = st->get_str("id");
+                        const JsonValue* def = sp ? sp->get(name.c_str()) : nullptr;
+                        const JsonValue* ids = def ? def->get("ids") : nullptr;
+                        if (!ids || !ids->is_array()) throw Invalid("tokenizer.json: TemplateProcessing special token '" + name + "' is not defined");
+                        if (st->get_num("type_id", 0) != 0) { m.pp_unsupported = "TemplateProcessing special token with a non-zero type_id"; return; }
+                        for (auto& x : ids->arr) (n_seq ? post : pre).push_back((uint32_t)x->num);
+                    } else throw Invalid("tokenizer.json: bad TemplateProcessing piece");
+                }
+                if (n_seq != 1) { m.pp_unsupported = "TemplateProcessing single template must contain sequence A exactly once"; return; }
+                m.pp_prefix.insert(m.pp_prefix.begin(), pre.begin(), pre.end());
+                m.pp_suffix.insert(m.pp_suffix.end(), post.begin(), post.end());
+                return;
+            }
+            if (t == "Sequence") {                                         // processors/sequence.rs: applied in order
+                const JsonValue* ps = pp->get("processors");
+                if (ps && ps->is_array())
+                    for (auto& q : ps->arr) apply(q.get());
+                return;
+            }
+            m.pp_unsupported = "post_processor type '" + t + "' is outside the hot path";
+        };
+        apply(root->get("post_processor"));
     }
 
     // ---- added tokens ----

@@ -58,6 +58,10 @@ struct HostModel {
     std::string cont_prefix;            // WordPiece continuing_subword_prefix ("##")
     uint32_t max_input_chars = 100;     // WordPiece max_input_chars_per_word
 
+    // post-processor layout for a single sequence (processors/{bert,roberta,template,sequence}.rs)
+    std::vector<uint32_t> pp_prefix, pp_suffix;   // special ids before / after sequence A
+    std::string pp_unsupported;                    // non-empty: why add_special_tokens cannot be honoured
+
     uint32_t vocab_size = 0;            // number of vocab entries
     uint32_t n_merges = 0;
     std::vector<AddedToken> added_tokens;

@@ -2208,6 +2208,41 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
 }
 
 // =================================================================================================
+// K_add_specials: PostProcessor::process for a single sequence with add_special_tokens = true
+// (BertProcessing processors/bert.rs:51-120, RobertaProcessing, TemplateProcessing template.rs:544-590):
+// every document becomes  prefix ids | its tokens | suffix ids ; specials carry offsets (0,0) and no word id.
+// One wavefront per document copies the document's tokens to their shifted place.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_add_specials(SpecialArgs a) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int64_t add = (int64_t)a.n_prefix + a.n_suffix;
+    for (int64_t d = wave; d <= a.n_docs; d += n_waves) {
+        const int64_t lo = a.tok_offsets[d];
+        const int64_t nlo = lo + d * add;
+        if (lane == 0) a.tok_offsets2[d] = nlo;
+        if (d == a.n_docs) { if (lane == 0) *a.n_tok2 = nlo; break; }
+        const int64_t n = a.tok_offsets[d + 1] - lo;
+        for (int64_t q = lane; q < a.n_prefix; q += 64) {
+            a.ids2[nlo + q] = a.prefix[q];
+            if (a.offsets) { a.offsets2[2 * (nlo + q)] = 0; a.offsets2[2 * (nlo + q) + 1] = 0; }
+            if (a.word_ids) a.word_ids2[nlo + q] = 0xFFFFFFFFu;
+        }
+        const int64_t body = nlo + a.n_prefix;
+        for (int64_t q = lane; q < n; q += 64) {
+            a.ids2[body + q] = a.ids[lo + q];
+            if (a.offsets) { a.offsets2[2 * (body + q)] = a.offsets[2 * (lo + q)]; a.offsets2[2 * (body + q) + 1] = a.offsets[2 * (lo + q) + 1]; }
+            if (a.word_ids) a.word_ids2[body + q] = a.word_ids[lo + q];
+        }
+        for (int64_t q = lane; q < a.n_suffix; q += 64) {
+            a.ids2[body + n + q] = a.suffix[q];
+            if (a.offsets) { a.offsets2[2 * (body + n + q)] = 0; a.offsets2[2 * (body + n + q) + 1] = 0; }
+            if (a.word_ids) a.word_ids2[body + n + q] = 0xFFFFFFFFu;
+        }
+    }
+}
+
+// =================================================================================================
 // host-side launchers (called from capi.cpp; plain C++ signatures, stream-ordered, no syncs)
 // =================================================================================================
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
@@ -2332,6 +2367,9 @@ void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t*
 void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
                        uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
     hipLaunchKernelGGL(k_dedup_copy, dim3(grid), dim3(256), 0, st, pt_start, dlist, n_dup, tok0, ntok, tmp_ids, tmp_end);
+}
+void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
+    hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {

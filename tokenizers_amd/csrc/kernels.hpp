@@ -65,6 +65,23 @@ struct MetaArgs {
     uint32_t* word_ids;               // [T]
 };
 
+// arguments of k_add_specials, passed by value
+struct SpecialArgs {
+    const int64_t* tok_offsets;
+    int64_t n_docs;
+    const uint32_t* ids;
+    const uint32_t* offsets;          // null if not produced
+    const uint32_t* word_ids;         // null if not produced
+    const uint32_t* prefix;
+    const uint32_t* suffix;
+    int32_t n_prefix, n_suffix;
+    int64_t* tok_offsets2;
+    uint32_t* ids2;
+    uint32_t* offsets2;
+    uint32_t* word_ids2;
+    int64_t* n_tok2;
+};
+
 // error bits accumulated in a device int during a batch
 enum : int {
     ERR_BAD_OFFSETS = 1,          // doc_offsets not a valid CSR over [0, n_bytes]
@@ -123,6 +140,7 @@ void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t*
                   uint32_t* counters);
 void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
                        uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
+void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,

@@ -84,7 +84,10 @@ class Encoding:
 
     @property
     def special_tokens_mask(self) -> list[int]:
-        return [0] * len(self)
+        n, (nb, ne) = len(self), self._b._specials
+        if not (nb or ne):
+            return [0] * n
+        return [1] * nb + [0] * (n - nb - ne) + [1] * ne
 
     @property
     def tokens(self) -> list[str]:
@@ -103,13 +106,14 @@ class Encoding:
     def word_ids(self) -> list[int | None]:
         if self._b.word_ids is None:
             raise UnsupportedError("word ids were not requested for this batch")
-        return self._b.word_ids[self._lo:self._hi].tolist()
+        return [None if w == 0xFFFFFFFF else w for w in self._b.word_ids[self._lo:self._hi].tolist()]
 
     words = word_ids
 
     @property
     def sequence_ids(self) -> list[int | None]:
-        return [0] * len(self)
+        n, (nb, ne) = len(self), self._b._specials
+        return [None] * nb + [0] * (n - nb - ne) + [None] * ne
 
     @property
     def n_sequences(self) -> int:
@@ -126,12 +130,13 @@ class Encoding:
 class BatchEncoding:
     """CSR result of one encode_batch call: ``ids[tok_offsets[d]:tok_offsets[d+1]]`` is document d."""
 
-    def __init__(self, ids, tok_offsets, offsets, word_ids, id_to_token):
+    def __init__(self, ids, tok_offsets, offsets, word_ids, id_to_token, specials=(0, 0)):
         self.ids: np.ndarray = ids
         self.tok_offsets: np.ndarray = tok_offsets
         self.offsets = offsets
-        self.word_ids = word_ids
+        self.word_ids = word_ids            # uint32, 0xFFFFFFFF = None (special tokens)
         self._id_to_token = id_to_token
+        self._specials = specials           # (#prefix, #suffix) special tokens around every document
 
     def __len__(self) -> int:
         return len(self.tok_offsets) - 1
@@ -217,8 +222,11 @@ class Tokenizer:
         info = _lib.Info()
         _lib.check(lib.tkamd_tokenizer_info(self._h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in _lib.Info._fields_}
-        pp = json.loads(json_str).get("post_processor")
-        self._post_processor_type = pp.get("type") if pp else None
+        pre, suf = (C.c_uint32 * 16)(), (C.c_uint32 * 16)()
+        npre, nsuf = C.c_int32(0), C.c_int32(0)
+        rc = lib.tkamd_tokenizer_specials(self._h, pre, C.byref(npre), suf, C.byref(nsuf), 16)
+        self._specials_error = None if rc == _lib.OK else (lib.tkamd_last_error() or b"").decode()
+        self._specials = (npre.value, nsuf.value) if rc == _lib.OK else (0, 0)
 
     # ---- constructors (Tokenizer::from_str / from_file, tokenizer/mod.rs:468-472) ----
     @staticmethod
@@ -253,22 +261,24 @@ class Tokenizer:
 
     # ---- the hot path ----
     def _check_special(self, add_special_tokens: bool) -> None:
-        if add_special_tokens and self._post_processor_type not in (None, "ByteLevel"):
-            raise UnsupportedError(
-                f"add_special_tokens=True with post_processor {self._post_processor_type} is outside the MI355X "
-                "hot path (the reference benches call encode_batch(..., add_special_tokens=False), benches/common/mod.rs:52)")
+        if add_special_tokens and self._specials_error:
+            raise UnsupportedError(self._specials_error)
 
     def encode_batch_csr(self, inputs: Sequence[str], offsets: str = "none", word_ids: bool = False,
                          add_special_tokens: bool = False) -> BatchEncoding:
         """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17)."""
         self._check_special(add_special_tokens)
         buf, doc_off = pack_documents(inputs)
-        return self.encode_packed(buf, doc_off, offsets, word_ids)
+        return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens)
 
-    def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False) -> BatchEncoding:
+    def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
+                      add_special_tokens: bool = False) -> BatchEncoding:
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
         if word_ids:
             flags |= _lib.WANT_WORD_IDS
+        if add_special_tokens:
+            self._check_special(True)
+            flags |= _lib.ADD_SPECIAL
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n_docs = len(doc_off) - 1
@@ -293,7 +303,7 @@ class Tokenizer:
             offs = view(self._lib.tkamd_batch_offsets(b), C.c_uint32, (nt, 2), np.uint32)
         if word_ids:
             wids = view(self._lib.tkamd_batch_word_ids(b), C.c_uint32, (nt,), np.uint32)
-        return BatchEncoding(ids, to, offs, wids, self._id_to_token())
+        return BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0))
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
