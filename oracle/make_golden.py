@@ -140,6 +140,20 @@ def main():
     dl["model"]["ignore_merges"] = True
     emit_specials("llama3_small_6000_specials", json.dumps(dl, ensure_ascii=False), edge + base[:200] + stress[:200])
 
+    # AddedVocabulary: special / added tokens with every option, occurring in the text (GPT-2 style tokenizer, no normalizer)
+    import random as _r
+    _r.seed(2)
+    ta_ = Tokenizer.from_str(synth.load_or_train_gpt2())
+    ta_.add_special_tokens(["<|endoftext|>", tokenizers.AddedToken("<|pad|>", lstrip=True, rstrip=True, special=True),
+                            tokenizers.AddedToken("<sw>", single_word=True, special=True)])
+    ta_.add_tokens([tokenizers.AddedToken("ing", single_word=False, normalized=False), tokenizers.AddedToken("new_tok", single_word=True, normalized=False),
+                    tokenizers.AddedToken("<|end", normalized=False)])
+    pieces = ["<|endoftext|>", "<|pad|>", "<sw>", "ing", "new_tok", "<|end", "  ", " ", "\n", "\t", "hello", "word", "a", "_", "1", "<", "|", ">",
+              "oftext|>", "é", "中", "<|endoftext|><|endoftext|>", " <|pad|> ", "x<sw>y", " <sw> ", "walking", "new_tok1", "a new_tok b"]
+    added_docs = ["".join(_r.choice(pieces) for _ in range(_r.randint(1, 8))) for _ in range(1500)] + \
+                 ["", "<|endoftext|>", "a<|endoftext|>", "<|endoftext|>a", "  <|pad|>  ", "x <|pad|>\n\ny", "<sw>", "a<sw>", "<sw>a", " <sw>."]
+    emit("gpt2_added_tokens", ta_.to_str(), added_docs)
+
     # C1: Whitespace + WordLevel over 1,000 ASCII lines
     c1 = ascii_only(synth.gen_lines(1100, text_seed=0, special_frac=0.0))[:1000]
     emit("wordlevel_whitespace_c1", synth.wordlevel_whitespace(c1), c1 + ascii_only(edge) + ["unseen words here ?!", "snake_case x_1 a.b"] + stress[:200])

@@ -44,6 +44,7 @@ def lib() -> C.CDLL:
         L.oracle_free.argtypes = [vp]
         L.oracle_set_trim.argtypes = [vp, i32, i32]
         L.oracle_set_char_offsets.argtypes = [vp, i32]
+        L.oracle_add_token.argtypes = [vp, C.c_char_p, i64, C.c_uint32, i32, i32, i32, i32]
         L.oracle_set_bert_normalizer.argtypes = [vp, i32, i32, i32, i32]
         L.oracle_set_vocab.argtypes = [vp, vp, vp, vp, i64]
         L.oracle_set_unk.argtypes = [vp, C.c_char_p, i64]
@@ -140,6 +141,10 @@ class Oracle:
         L.oracle_set_trim(self._h, trim, int(pp.get("add_prefix_space", True)))
         if bn:
             L.oracle_set_bert_normalizer(self._h, *bn)
+        for a in d.get("added_tokens") or []:
+            c = a["content"].encode("utf-8")
+            L.oracle_add_token(self._h, c, len(c), int(a["id"]), int(a.get("single_word", False)), int(a.get("lstrip", False)),
+                               int(a.get("rstrip", False)), int(a.get("normalized", False)))
         toks = list(model["vocab"].items())
         blob, off = _pack([k.encode("utf-8") for k, _ in toks])
         ids = np.array([v for _, v in toks], dtype=np.uint32)

@@ -13,7 +13,7 @@ from tests.helpers import load_tokenizer_json, load_vectors
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
-GPU_GOLDEN = ["gpt2_synth_50257", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
+GPU_GOLDEN = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
 
 
 @pytest.fixture(scope="module")
@@ -281,7 +281,7 @@ def test_trim_offsets_vs_oracle(gpt2_json):
         _meta_compare(tok, o, docs)
 
 
-@pytest.mark.parametrize("name", ["gpt2_synth_50257", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000"])
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000"])
 def test_encode_batch_matches_golden_char_offsets(name):
     """Tokenizer.encode_batch == the wheel's encode_batch (ids, char offsets, word ids) on the committed vectors."""
     import tokenizers_amd as ta
@@ -360,3 +360,40 @@ def test_add_special_tokens_matches_wheel(name):
         assert e.type_ids == v["type_ids"][i], doc
     plain = tok.encode_batch(v["docs"], add_special_tokens=False)
     assert plain.n_tokens == got.n_tokens - sum(sum(m) for m in v["special_tokens_mask"])
+
+
+def test_added_vocabulary_on_device_vs_oracle():
+    """AddedVocabulary split on the device: single_word / lstrip / rstrip tokens, adjacent matches, matches at document
+    edges, trim_offsets on added tokens; plus the refusal of the reference's overlapping-match quirk."""
+    import json
+    import random
+    import tokenizers_amd as ta
+    js = load_tokenizer_json("gpt2_added_tokens")
+    random.seed(21)
+    pieces = ["<|endoftext|>", "<|pad|>", "<sw>", "ing", "new_tok", "<|end", " ", "\n", "\t", "hello", "word", "a", "_", "1", "<", "|", ">",
+              "oftext|>", "\u00e9", "\u4e2d", " <|pad|> ", "x<sw>y", " <sw> ", "walking", "new_tok1", "a new_tok b", "\u00a0", "\u3000"]
+    docs = ["".join(random.choice(pieces) for _ in range(random.randint(1, 10))) for _ in range(20000)] + synth.gen_lines(3000, text_seed=51)
+    for trim in (False, True):
+        d = json.loads(js)
+        d["post_processor"] = {"type": "ByteLevel", "add_prefix_space": True, "trim_offsets": trim, "use_regex": True}
+        tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
+        o = orc.Oracle(json.dumps(d))
+        _meta_compare(tok, o, docs)
+    # wordlevel + whitespace with an added token (gap pre-tokenizer: end mask patched too)
+    d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
+    d["added_tokens"] = [{"id": 9000, "content": "[ENT]", "single_word": False, "lstrip": False, "rstrip": True, "normalized": False, "special": True}]
+    tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
+    o = orc.Oracle(json.dumps(d))
+    wdocs = ["".join(random.choice(["[ENT]", " ", "hai", "jim", "!", "  ", "x", "[ENT] ", "\n"]) for _ in range(random.randint(1, 9))) for _ in range(5000)]
+    _meta_compare(tok, o, wdocs)
+
+
+def test_added_vocabulary_overlap_quirk_is_refused():
+    import json
+    import tokenizers_amd as ta
+    d = json.loads(load_tokenizer_json("gpt2_added_tokens"))
+    d["added_tokens"].append({"id": 60000, "content": "  ", "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": False})
+    tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
+    assert len(tok.encode_batch_fast(["fine <|pad|> x"], add_special_tokens=False)) == 1
+    with pytest.raises(ta.UnsupportedError, match="added/special token"):
+        tok.encode_batch_fast(["<|pad|>  x"], add_special_tokens=False)      # the "  " token starts inside the stripped whitespace

@@ -82,11 +82,12 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
+    DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2;
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
+        w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
@@ -147,7 +148,8 @@ struct tkamd_batch {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_COUNTERS = 4 /* ..7 */, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10 /* uint32[CNT_COUNT] from slot 4 */, SC_SLOTS = 16 };
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
+       SC_COUNTERS = 16 /* uint32[CNT_COUNT] */, SC_SLOTS = 32 };
 
 struct Prof {
     tkamd_tokenizer* t;
@@ -210,6 +212,8 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_at_blob, hm.at_blob);
     upload(t->t_at_off, hm.at_off);
     upload(t->t_at_first, hm.at_first);
+    upload(t->t_at_id, hm.at_id);
+    upload(t->t_at_flags, hm.at_flags);
     DevTables& d = t->dt;
     d.uc1 = t->t_uc1.as<uint16_t>();
     d.uc2 = t->t_uc2.as<uint8_t>();
@@ -384,8 +388,27 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         return;
     }
 
-    // ---- added / special tokens: refuse the batch if one occurs in the raw text ----
-    if (hm.at_off.size() > 1) {
+    // ---- added / special tokens (AddedVocabulary::extract_and_normalize runs before everything else) ----
+    const unsigned long long* matchmask = nullptr;
+    if (hm.at_match_on_device) {
+        // the split itself runs on the device: matches become single pre-tokens, their edges hard boundaries
+        const size_t mw = (size_t)(W0 + 2) * 8;
+        DevBuf* masks[5] = {&t->w_candmask, &t->w_matchmask, &t->w_spanmask, &t->w_stopmask, &t->w_hardmask};
+        for (DevBuf* b : masks) { b->reserve(mw); }
+        for (int q = 1; q < 5; ++q) HIP_CHECK(hipMemsetAsync(masks[q]->p, 0, mw, st));
+        t->w_match_docs.reserve((size_t)(n_docs + 1) * 4);
+        t->w_match_list.reserve(((size_t)n_bytes + 4) * 8);
+        AddedArgs aa{t->t_at_blob.as<uint8_t>(), t->t_at_off.as<uint32_t>(), t->t_at_first.as<uint32_t>(), t->t_at_id.as<uint32_t>(),
+                     t->t_at_flags.as<uint32_t>()};
+        pf.begin("added_token_match");
+        launch_added_match(st, grid, aa, d_text, n_bytes, d_doc_off, n_docs, t->dt.uc1, t->dt.uc2, prefix_space ? 1u : 0u,
+                           t->w_candmask.as<ull>(), t->w_matchmask.as<ull>(), t->w_spanmask.as<ull>(), t->w_stopmask.as<ull>(),
+                           t->w_hardmask.as<ull>(), t->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS,
+                           t->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, d_err);
+        pf.end();
+        matchmask = t->w_matchmask.as<ull>();
+    } else if (hm.at_off.size() > 1) {
+        // behind a normalizer / mixed token classes: detect and refuse
         pf.begin("added_token_scan");
         launch_added_token_scan(st, d_text, n_bytes, t->t_at_blob.as<uint8_t>(), t->t_at_off.as<uint32_t>(),
                                 t->t_at_first.as<uint32_t>(), d_err);
@@ -433,6 +456,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
 
     pf.begin("mark_doc_starts");
     launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_x, x_len_dev, t->w_docmask.as<ull>(), d_err);
+    if (matchmask && !prefix_space) launch_mask_or(st, t->w_docmask.as<ull>(), t->w_hardmask.as<ull>(), W0);   // match edges are hard boundaries
     pf.end();
 
     uint32_t* pt_end = nullptr;
@@ -464,6 +488,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
                             t->w_startmask.as<ull>(), t->w_endmask.as<ull>());
         pf.end();
     }
+    if (matchmask && !prefix_space)
+        launch_apply_matches(st, t->w_startmask.as<ull>(), pt_end ? t->w_endmask.as<ull>() : nullptr, matchmask, t->w_spanmask.as<ull>(),
+                             t->w_stopmask.as<ull>(), W0);
     pf.begin("mask_scan");
     launch_mask_scan(st, t->w_startmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
@@ -485,7 +512,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         uint32_t* listL = list64 + N / 32 + 16;
         pf.begin("bpe_word_lookup");
         launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), nullptr, d_npretok, t->w_tok0.as<uint32_t>(),
-                               t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters);
+                               t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask);
         pf.end();
         pf.begin("bpe_merge_lane32");
         launch_bpe_merge(st, grid, 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
@@ -556,7 +583,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     } else if (hm.model == MODEL_WORDLEVEL) {
         pf.begin("wordlevel");
         launch_wordlevel(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
-                         t->w_ntok.as<uint32_t>(), d_err);
+                         t->w_ntok.as<uint32_t>(), d_err, matchmask);
         pf.end();
     } else {
         // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): a whole-word
@@ -573,22 +600,26 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
             pf.begin("wordpiece_word_lookup");
             launch_bpe_word_lookup(st, grid, wt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
-                                   t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters);
+                                   t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask);
             pf.end();
             pf.begin("wordpiece");
             const uint32_t* lists[4] = {list16, list32, list64, listL};
             const int cnts[4] = {CNT_LIST16, CNT_LIST32, CNT_LIST64, CNT_LISTL};
             for (int q = 0; q < 4; ++q)
                 launch_wordpiece(st, q == 0 ? grid : t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, lists[q],
-                                 d_counters + cnts[q], t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+                                 d_counters + cnts[q], t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err,
+                                 matchmask);
             pf.end();
         } else {
             pf.begin("wordpiece");
             launch_wordpiece(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, nullptr, nullptr,
-                             t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+                             t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err, matchmask);
             pf.end();
         }
     }
+    if (matchmask && !prefix_space)
+        launch_apply_match_ids(st, t->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, t->w_startmask.as<ull>(),
+                               t->w_wprefix.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>());
     pf.begin("compact");
     launch_compact(st, grid, t->w_ntok.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(),
                    t->w_pt_start.as<uint32_t>(), d_npretok, t->w_csum.as<uint32_t>(), d_ntok_total,
@@ -620,6 +651,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         a.char_mode = off_mode == TKAMD_OFFSETS_CHAR;
         a.want_words = want_words;
         a.prefix_space = prefix_space;
+        a.matchmask = (matchmask && !prefix_space) ? matchmask : nullptr;
+        a.uc1 = t->dt.uc1;
+        a.uc2 = t->dt.uc2;
         a.offsets = t->w_offsets.as<uint32_t>();
         a.word_ids = t->w_word_ids.as<uint32_t>();
         if (a.char_mode) {
@@ -688,8 +722,9 @@ int error_from_bits(int bits) {
     if (bits & ERR_PRETOKEN_TOO_LONG)
         return set_error(TKAMD_ERR_UNSUPPORTED, "pre-tokens longer than 8192 bytes exceed the 1 GiB scratch slab of the global-memory merge path");
     if (bits & ERR_ADDED_TOKEN)
-        return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text: the AddedVocabulary split "
-                                                "(added_vocabulary.rs:523-564) is not built on the device yet");
+        return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text in a combination the device split does not "
+                                                "cover (behind a normalizer, mixed normalized / raw token classes, add_prefix_space, or the "
+                                                "reference's overlapping-match quirk after an rstrip token; added_vocabulary.rs:430-564)");
     if (bits & ERR_NON_ASCII_NORM)
         return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: the text contains a character with a non-zero combining class that "
                                                 "survives the Mn filter; NFD may reorder it across characters (not built on the device)");
@@ -752,10 +787,11 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
         DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->t_long_id, &t->t_long_table, &t->t_at_id, &t->t_at_flags, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2, &t->w_candmask, &t->w_matchmask, &t->w_spanmask,
+                         &t->w_stopmask, &t->w_hardmask, &t->w_match_docs, &t->w_match_list,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();
     }

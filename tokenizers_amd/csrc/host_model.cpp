@@ -456,23 +456,32 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     }
 
     {
-        std::vector<std::string> pats;
+        struct Pat { std::string s; uint32_t id, flags; };
+        std::vector<Pat> pats;
+        bool any_norm = false, any_raw = false;
         for (const AddedToken& a : m.added_tokens) {
             if (a.content.empty()) continue;
             if (a.normalized && m.norm != NORM_NONE)
                 throw Unsupported("added token '" + a.content + "' with normalized=true behind a normalizer (added_vocabulary.rs:548-553)");
-            pats.push_back(a.content);
+            (a.normalized ? any_norm : any_raw) = true;
+            pats.push_back(Pat{a.content, a.id, (a.single_word ? 1u : 0u) | (a.lstrip ? 2u : 0u) | (a.rstrip ? 4u : 0u)});
         }
-        std::sort(pats.begin(), pats.end());
-        pats.erase(std::unique(pats.begin(), pats.end()), pats.end());
+        std::sort(pats.begin(), pats.end(), [](const Pat& x, const Pat& y) { return x.s < y.s; });
+        pats.erase(std::unique(pats.begin(), pats.end(), [](const Pat& x, const Pat& y) { return x.s == y.s; }), pats.end());
         m.at_first.assign(257, 0);
         m.at_off.push_back(0);
-        for (const std::string& p : pats) {
-            m.at_first[(uint8_t)p[0] + 1]++;
-            m.at_blob.insert(m.at_blob.end(), p.begin(), p.end());
+        for (const Pat& p : pats) {
+            m.at_first[(uint8_t)p.s[0] + 1]++;
+            m.at_blob.insert(m.at_blob.end(), p.s.begin(), p.s.end());
             m.at_off.push_back((uint32_t)m.at_blob.size());
+            m.at_id.push_back(p.id);
+            m.at_flags.push_back(p.flags);
         }
         for (int b = 0; b < 256; ++b) m.at_first[b + 1] += m.at_first[b];
+        // Without a normalizer the two matching passes of extract_and_normalize (added_vocabulary.rs:531-553) see the
+        // same text; with a single token class they are one leftmost-longest pass, which the device runs.  Mixed
+        // classes (pass 1 takes priority over pass 2) and tokens behind a normalizer are detected-and-refused instead.
+        m.at_match_on_device = !pats.empty() && m.norm == NORM_NONE && !(any_norm && any_raw);
     }
 
     // ---- model ----

@@ -69,6 +69,9 @@ struct HostModel {
     std::vector<uint8_t> at_blob;
     std::vector<uint32_t> at_off;      // [n_patterns+1]
     std::vector<uint32_t> at_first;    // [257] CSR over the first byte
+    std::vector<uint32_t> at_id;       // [n_patterns] token id
+    std::vector<uint32_t> at_flags;    // [n_patterns] 1 single_word, 2 lstrip, 4 rstrip
+    bool at_match_on_device = false;   // the AddedVocabulary split runs on the device (no normalizer, one token class)
 
     // ---- tables copied to the device ----
     uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level)

@@ -21,6 +21,25 @@
 
 namespace tkamd {
 
+// ---- small helpers shared by several kernels ----
+__device__ __forceinline__ uint32_t uc_flags(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
+    if (cp >= 0x110000u) return 0;
+    return uc2[((uint32_t)uc1[cp >> 8] << 8) | (cp & 255u)];
+}
+
+struct __attribute__((packed, aligned(1))) Unaligned4 { uint32_t v; };
+// decode the code point whose lead byte is text[i] (text has TKAMD_TEXT_PAD readable slack)
+__device__ __forceinline__ uint32_t utf8_global(const uint8_t* __restrict__ text, int64_t i, uint32_t* len) {
+    uint32_t w = ((const Unaligned4*)(text + i))->v;
+    uint32_t b0 = w & 0xFFu, b1 = (w >> 8) & 0x3Fu, b2 = (w >> 16) & 0x3Fu, b3 = (w >> 24) & 0x3Fu;
+    if (b0 < 0x80u) { *len = 1; return b0; }
+    if (b0 < 0xE0u) { *len = 2; return ((b0 & 0x1Fu) << 6) | b1; }
+    if (b0 < 0xF0u) { *len = 3; return ((b0 & 0x0Fu) << 12) | (b1 << 6) | b2; }
+    *len = 4;
+    return ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
+}
+
+
 // =================================================================================================
 // K_docmask: doc_offsets CSR -> bitmask of document start bytes (+ validation of the CSR)
 // Replaces: the per-document loop of TokenizerImpl::encode_batch (tokenizer/mod.rs:1345-1348); a
@@ -73,6 +92,149 @@ __global__ __launch_bounds__(256) void k_added_token_scan(const uint8_t* __restr
         uint32_t j = 1;
         while (j < l && text[i + j] == pat_blob[o + j]) ++j;
         if (j == l) { atomicOr(err, ERR_ADDED_TOKEN); return; }
+    }
+}
+
+// =================================================================================================
+// AddedVocabulary on the device (tokenizer/added_vocabulary.rs:430-564), for tokenizers without a normalizer:
+//   k_added_candidates : lane per byte, "does some added token start here" -> candidate bitmask
+//   (k_l3_slow_docs)    : documents holding a candidate
+//   k_added_resolve    : one lane per such document replays the reference's loop over the leftmost-longest,
+//                        non-overlapping automaton matches: single_word (\w on both sides rejects), lstrip / rstrip
+//                        (\s runs swallowed), and writes four bitmasks: match start, bytes inside a match, first
+//                        byte after a match, and hard boundaries (start | stop) that the pre-tokenizers treat like
+//                        document edges -- each unmatched segment is pre-tokenised on its own, as in the reference.
+//   k_apply_matches    : start/end masks of the pre-tokenizer are patched so that a match is exactly one pre-token
+//   k_apply_match_ids  : that pre-token gets the added token's id.
+// The reference's automaton resumes after the UN-stripped end of a match, so a later match can start inside the
+// whitespace an rstrip token swallowed and overlap it; that quirk (and add_prefix_space per segment) is refused.
+// =================================================================================================
+
+// longest added token starting at text[i] inside [i, end): returns its pattern index or -1
+__device__ __forceinline__ int added_longest(const AddedArgs& a, const uint8_t* __restrict__ text, int64_t i, int64_t end, uint32_t* len) {
+    uint32_t b = text[i];
+    int best = -1;
+    uint32_t best_len = 0;
+    for (uint32_t k = a.first[b]; k < a.first[b + 1]; ++k) {
+        uint32_t o = a.off[k], l = a.off[k + 1] - o;
+        if (i + l > end || l <= best_len) continue;
+        uint32_t j = 1;
+        while (j < l && text[i + j] == a.blob[o + j]) ++j;
+        if (j == l) { best = (int)k; best_len = l; }
+    }
+    *len = best_len;
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_added_candidates(AddedArgs a, const uint8_t* __restrict__ text, int64_t n_bytes,
+                                                          unsigned long long* __restrict__ candmask) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool cand = false;
+    if (i < n_bytes) { uint32_t l; cand = added_longest(a, text, i, n_bytes, &l) >= 0; }
+    uint64_t m = __ballot(cand);
+    if ((threadIdx.x & 63) == 0 && i <= n_bytes) candmask[i >> 6] = m;
+}
+
+__device__ __forceinline__ void mask_set_range(unsigned long long* m, int64_t a, int64_t b) {      // bits [a, b)
+    for (int64_t w = a >> 6; a < b && w <= (b - 1) >> 6; ++w) {
+        int64_t lo = w << 6, hi = lo + 64;
+        unsigned long long v = ~0ull;
+        if (a > lo) v &= ~0ull << (a - lo);
+        if (b < hi) v &= ~0ull >> (hi - b);
+        atomicOr(&m[w], v);
+    }
+}
+
+__global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off,
+                                const uint32_t* __restrict__ docs, const uint32_t* __restrict__ n_docs_listed,
+                                const unsigned long long* __restrict__ candmask,
+                                const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2, uint32_t refuse_any,
+                                unsigned long long* __restrict__ matchmask, unsigned long long* __restrict__ spanmask,
+                                unsigned long long* __restrict__ stopmask, unsigned long long* __restrict__ hardmask,
+                                uint32_t* __restrict__ match_list, uint32_t* __restrict__ n_match, int* __restrict__ err) {
+    const uint32_t n = *n_docs_listed;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const int64_t da = doc_off[docs[q]], db = doc_off[docs[q] + 1];
+        int64_t cursor = da, start_offset = da;
+        for (int64_t w = da >> 6; w <= (db - 1) >> 6; ++w) {
+            unsigned long long cm = candmask[w];
+            while (cm) {
+                const int64_t pos = (w << 6) + (__ffsll((unsigned long long)cm) - 1);
+                cm &= cm - 1;
+                if (pos < cursor || pos < da || pos >= db) continue;
+                uint32_t len;
+                const int k = added_longest(a, text, pos, db, &len);
+                if (k < 0) continue;                                  // the candidate needed bytes past this document
+                int64_t start = pos, stop = pos + len;
+                cursor = stop;                                        // the automaton resumes after the un-stripped match
+                const uint32_t fl = a.flags[k];
+                if (fl & 1u) {                                        // single_word: \w on either side rejects the match
+                    bool ok = true;
+                    if (start > da) {
+                        int64_t p = start - 1;
+                        while (p > da && (text[p] & 0xC0u) == 0x80u) --p;
+                        uint32_t l2;
+                        ok = !(uc_flags(utf8_global(text, p, &l2), uc1, uc2) & UC_RX_W);
+                    }
+                    if (ok && stop < db) { uint32_t l2; ok = !(uc_flags(utf8_global(text, stop, &l2), uc1, uc2) & UC_RX_W); }
+                    if (!ok) continue;
+                }
+                if (fl & 2u) {                                        // lstrip
+                    int64_t ns = start;
+                    while (ns > da) {
+                        int64_t p = ns - 1;
+                        while (p > da && (text[p] & 0xC0u) == 0x80u) --p;
+                        uint32_t l2;
+                        if (!(uc_flags(utf8_global(text, p, &l2), uc1, uc2) & UC_RX_S)) break;
+                        ns = p;
+                    }
+                    start = ns > start_offset ? ns : start_offset;
+                }
+                if (fl & 4u) {                                        // rstrip
+                    while (stop < db) {
+                        uint32_t l2;
+                        if (!(uc_flags(utf8_global(text, stop, &l2), uc1, uc2) & UC_RX_S)) break;
+                        stop += l2;
+                    }
+                }
+                if (start < start_offset || refuse_any) { atomicOr(err, ERR_ADDED_TOKEN); continue; }   // overlap quirk / unsupported combination
+                atomicOr(&matchmask[start >> 6], 1ull << (start & 63));
+                atomicOr(&hardmask[start >> 6], 1ull << (start & 63));
+                atomicOr(&stopmask[stop >> 6], 1ull << (stop & 63));
+                if (stop < db) atomicOr(&hardmask[stop >> 6], 1ull << (stop & 63));
+                mask_set_range(spanmask, start + 1, stop);
+                const uint32_t mi = atomicAdd(n_match, 1u);
+                match_list[2 * mi] = (uint32_t)start;
+                match_list[2 * mi + 1] = a.id[k];
+                start_offset = stop;
+            }
+        }
+    }
+}
+
+// word-wise mask algebra: dst |= src
+__global__ void k_mask_or(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src, int64_t n_words) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] |= src[i];
+}
+// a match is exactly one pre-token: no starts (ends) inside it, a start at its first byte, an end at its stop
+__global__ void k_apply_matches(unsigned long long* __restrict__ startmask, unsigned long long* __restrict__ endmask,
+                                const unsigned long long* __restrict__ matchmask, const unsigned long long* __restrict__ spanmask,
+                                const unsigned long long* __restrict__ stopmask, int64_t n_words) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    startmask[i] = (startmask[i] & ~spanmask[i]) | matchmask[i];
+    if (endmask) endmask[i] = (endmask[i] & ~spanmask[i]) | stopmask[i];
+}
+__global__ void k_apply_match_ids(const uint32_t* __restrict__ match_list, const uint32_t* __restrict__ n_match,
+                                  const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
+                                  uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok) {
+    const uint32_t n = *n_match;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t pos = match_list[2 * i];
+        const uint32_t p = wprefix[pos >> 6] + (uint32_t)__popcll(startmask[pos >> 6] & ((1ull << (pos & 63)) - 1ull));
+        tok0[p] = match_list[2 * i + 1];
+        ntok[p] = 1;
     }
 }
 
@@ -150,10 +312,6 @@ constexpr uint32_t IF_VALID = 16;    // inside [0, n_bytes)
 constexpr uint32_t IF_SP = 32;       // U+0020
 constexpr int IF_LEN_SHIFT = 6;      // (utf8 length - 1) in bits 6..7
 
-__device__ __forceinline__ uint32_t uc_flags(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
-    if (cp >= 0x110000u) return 0;
-    return uc2[((uint32_t)uc1[cp >> 8] << 8) | (cp & 255u)];
-}
 
 __device__ __forceinline__ uint32_t cls_lns(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
     if (cp < 0x80u) {
@@ -906,7 +1064,6 @@ template __global__ void k_pretok_local<PT_BERT>(const uint8_t*, int64_t, const 
 constexpr uint32_t BN_DROP = 1, BN_WS = 2, BN_CJK = 4, BN_REORDER = 8, BN_D = 16, BN_LC = 32;
 constexpr int BN_MAX_OUT = 12;
 
-struct __attribute__((packed, aligned(1))) Unaligned4 { uint32_t v; };
 
 __device__ __forceinline__ uint32_t bn_flags(const BnTables& b, uint32_t cp) {
     if (cp >= 0x110000u) return 0;
@@ -950,16 +1107,6 @@ __device__ __forceinline__ int bn_expand(const BnTables& b, uint32_t cp, uint32_
     return n;
 }
 __device__ __forceinline__ uint32_t utf8_len_cp(uint32_t cp) { return cp < 0x80u ? 1u : cp < 0x800u ? 2u : cp < 0x10000u ? 3u : 4u; }
-// decode the code point whose lead byte is text[i] (text has TKAMD_TEXT_PAD readable slack)
-__device__ __forceinline__ uint32_t utf8_global(const uint8_t* __restrict__ text, int64_t i, uint32_t* len) {
-    uint32_t w = ((const Unaligned4*)(text + i))->v;
-    uint32_t b0 = w & 0xFFu, b1 = (w >> 8) & 0x3Fu, b2 = (w >> 16) & 0x3Fu, b3 = (w >> 24) & 0x3Fu;
-    if (b0 < 0x80u) { *len = 1; return b0; }
-    if (b0 < 0xE0u) { *len = 2; return ((b0 & 0x1Fu) << 6) | b1; }
-    if (b0 < 0xF0u) { *len = 3; return ((b0 & 0x0Fu) << 12) | (b1 << 6) | b2; }
-    *len = 4;
-    return ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
-}
 
 __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes,
                                                   uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
@@ -1242,7 +1389,8 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                                                          uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
                                                          uint32_t* __restrict__ list16, uint32_t* __restrict__ list32,
                                                          uint32_t* __restrict__ list64,
-                                                         uint32_t* __restrict__ listL, uint32_t* __restrict__ counters) {
+                                                         uint32_t* __restrict__ listL, uint32_t* __restrict__ counters,
+                                                         const unsigned long long* __restrict__ matchmask) {
     __shared__ uint32_t sm[4];
     __shared__ uint32_t base_s[4];
     __shared__ uint16_t s_disp[DISP_LDS_MAX];
@@ -1299,9 +1447,11 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 bool hit = a1[k].x == len[k] && a0[k].x == (uint32_t)lo[k] && a0[k].y == (uint32_t)(lo[k] >> 32) &&
                            a0[k].z == (uint32_t)hi[k] && a0[k].w == (uint32_t)(hi[k] >> 32);
                 bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && hit && (t.ignore_merges || (a1[k].z & WORD_DIRECT));
-                out_id[g + k] = done ? a1[k].y : 0u;
-                out_n[g + k] = done ? 1u : 0u;
-                if (valid && !done) {
+                // an added-token match is one pre-token whose id is patched in later (k_apply_match_ids): never queued
+                const bool is_match = matchmask && valid && ((matchmask[st[g + k] >> 6] >> (st[g + k] & 63)) & 1ull);
+                out_id[g + k] = (done && !is_match) ? a1[k].y : 0u;
+                out_n[g + k] = (done && !is_match) ? 1u : 0u;
+                if (valid && !done && !is_match) {
                     uint32_t c = len[k] <= 16 ? 1u : (len[k] <= 32 ? 2u : 3u);
                     cls |= c << (2 * (g + k));
                 }
@@ -1836,10 +1986,12 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
 __global__ __launch_bounds__(256) void k_wordlevel(DevTables t, const uint8_t* __restrict__ text,
                                                    const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
                                                    const int64_t* __restrict__ n_pretok,
-                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok, int* __restrict__ err) {
+                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok, int* __restrict__ err,
+                                                   const unsigned long long* __restrict__ matchmask) {
     const int64_t P = *n_pretok;
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
         uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
+        if (matchmask && ((matchmask[s >> 6] >> (s & 63)) & 1ull)) continue;        // added token: id patched in later
         uint32_t id = 0, fl;
         bool hit;
         if (len <= (uint32_t)WORD_MAX_KEY) {
@@ -1870,12 +2022,14 @@ __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* _
                                                    const int64_t* __restrict__ n_pretok,
                                                    const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
                                                    uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
-                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
+                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
+                                                   const unsigned long long* __restrict__ matchmask) {
     // with a work queue (`list`): only the pre-tokens the whole-word lookup could not settle; without: all of them
     const int64_t P = list ? (int64_t)*n_list : *n_pretok;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (int64_t)gridDim.x * 256) {
         const int64_t p = list ? (int64_t)list[q] : q;
         uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
+        if (matchmask && ((matchmask[s >> 6] >> (s & 63)) & 1ull)) continue;        // added token: id patched in later
         uint32_t chars = 0;
         for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
         bool bad = chars > t.max_input_chars;
@@ -2190,8 +2344,23 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                 } else { os -= odoc; oe -= odoc; }
                 if (a.trim_offsets) {                                 // process_offsets, byte_level.rs:202-234
                     uint32_t lead_sp = 0, trail_sp = 0;
+                    if (a.matchmask && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull)) {
+                        // an added token's text is the raw slice: its leading / trailing chars are tested with char::is_whitespace
+                        uint32_t q = ts;
+                        while (q < te) { uint32_t l; if (!(uc_flags(utf8_global(a.x_text, q, &l), a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
+                        q = te;
+                        while (q > ts) {
+                            uint32_t r = q - 1;
+                            while (r > ts && (a.x_text[r] & 0xC0u) == 0x80u) --r;
+                            uint32_t l;
+                            if (!(uc_flags(utf8_global(a.x_text, r, &l), a.uc1, a.uc2) & UC_RUST_WS)) break;
+                            ++trail_sp;
+                            q = r;
+                        }
+                    } else {
                     while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
                     while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
+                    }
                     if (lead_sp) {
                         bool is_first = (word == 0 && j == 0) || os == 0;
                         if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
@@ -2280,8 +2449,8 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
 }
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                             const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
-                            uint32_t* list64, uint32_t* listL, uint32_t* counters) {
-    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters);
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask) {
+    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters, matchmask);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
@@ -2323,13 +2492,13 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
 void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err) {
-    hipLaunchKernelGGL(k_wordlevel, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, err);
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err, const unsigned long long* matchmask) {
+    hipLaunchKernelGGL(k_wordlevel, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, err, matchmask);
 }
 void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
                       const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
-                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err) {
-    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, list, n_list, tok0, ntok, tmp_ids, tmp_end, err);
+                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err, const unsigned long long* matchmask) {
+    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, list, n_list, tok0, ntok, tmp_ids, tmp_end, err, matchmask);
 }
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err) {
@@ -2370,6 +2539,26 @@ void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const
 }
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
     hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                        const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
+                        unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,
+                        uint32_t* docs, uint32_t* n_docs_listed, uint32_t* match_list, uint32_t* n_match, int* err) {
+    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, a, text, n_bytes, candmask);
+    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)candmask, doc_off, n_docs, docs, n_docs_listed);
+    hipLaunchKernelGGL(k_added_resolve, dim3(1024), dim3(64), 0, st, a, text, doc_off, (const uint32_t*)docs, (const uint32_t*)n_docs_listed,
+                       (const unsigned long long*)candmask, uc1, uc2, refuse_any, matchmask, spanmask, stopmask, hardmask, match_list, n_match, err);
+}
+void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words) {
+    hipLaunchKernelGGL(k_mask_or, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, src, n_words);
+}
+void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
+                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words) {
+    hipLaunchKernelGGL(k_apply_matches, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, startmask, endmask, matchmask, spanmask, stopmask, n_words);
+}
+void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
+                            const uint32_t* wprefix, uint32_t* tok0, uint32_t* ntok) {
+    hipLaunchKernelGGL(k_apply_match_ids, dim3(64), dim3(256), 0, st, match_list, n_match, startmask, wprefix, tok0, ntok);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {

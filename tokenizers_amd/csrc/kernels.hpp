@@ -61,8 +61,20 @@ struct MetaArgs {
     const uint32_t* lprefix;
     uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
     uint32_t prefix_space;            // x text carries inserted leading spaces (ByteLevel add_prefix_space)
+    const unsigned long long* matchmask;  // added-token matches (their offsets trim real whitespace chars), or null
+    const uint16_t* uc1;
+    const uint8_t* uc2;
     uint32_t* offsets;                // [T][2]
     uint32_t* word_ids;               // [T]
+};
+
+// added-token patterns (AddedVocabulary), passed by value
+struct AddedArgs {
+    const uint8_t* blob;
+    const uint32_t* off;
+    const uint32_t* first;     // CSR over the first byte
+    const uint32_t* id;
+    const uint32_t* flags;     // 1 single_word, 2 lstrip, 4 rstrip
 };
 
 // arguments of k_add_specials, passed by value
@@ -93,7 +105,7 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_ULIST = 5, CNT_DLIST = 6, CNT_LISTH = 7, CNT_COUNT = 8 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_ULIST = 5, CNT_DLIST = 6, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_COUNT = 12 };
 
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident); longer ones use the global-scratch kernel
 
@@ -111,7 +123,7 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                             const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
-                            uint32_t* list64, uint32_t* listL, uint32_t* counters);
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask);
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
@@ -124,10 +136,10 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                            uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
                            uint32_t* noe, int64_t* ndoc_off, int* err);
 void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err);
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err, const unsigned long long* matchmask);
 void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
                       const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
-                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
+                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err, const unsigned long long* matchmask);
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
@@ -141,6 +153,15 @@ void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t*
 void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
                        uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
+void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                        const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
+                        unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,
+                        uint32_t* docs, uint32_t* n_docs_listed, uint32_t* match_list, uint32_t* n_match, int* err);
+void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words);
+void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
+                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words);
+void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
+                            const uint32_t* wprefix, uint32_t* tok0, uint32_t* ntok);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
