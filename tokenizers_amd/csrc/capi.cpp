@@ -464,10 +464,14 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         // Two implementations of the same predicate: the LDS-window kernel (default, faster: 0.33 ms @C2) and the
         // bit-parallel ballot kernel (TKAMD_PRETOK=bits; its 64-bit mask algebra lands on the scalar unit, one per
         // CU, and measures 0.54 ms) -- kept as an independent cross-check of the window logic.
-        static const bool bits_variant = [] { const char* e = getenv("TKAMD_PRETOK"); return e && !strcmp(e, "bits"); }();
-        pf.begin(bits_variant ? "pretok_gpt2_bits" : "pretok_gpt2");
-        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(),
-                           bits_variant ? 1 : 0);
+        static const int variant = [] {
+            const char* e = getenv("TKAMD_PRETOK");
+            if (e && !strcmp(e, "bits")) return 1;
+            if (e && !strcmp(e, "lds")) return 0;
+            return 2;                                        // lane-per-32-bytes sequential kernel (default)
+        }();
+        pf.begin(variant == 2 ? "pretok_gpt2_seq" : (variant == 1 ? "pretok_gpt2_bits" : "pretok_gpt2"));
+        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(), variant);
         pf.end();
     } else if (hm.pretok == PT_LLAMA3) {
         t->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask

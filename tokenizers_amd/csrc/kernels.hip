@@ -443,6 +443,137 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
 }
 
 // =================================================================================================
+// K_pretok_gpt2_seq: the GPT-2 start predicate, bit-parallel PER LANE.  A lane owns 48 bytes and looks at a 64-byte
+// window around them (8 bytes back, 8 ahead), loaded as four 16-byte loads.  Each byte indexes a small LDS table
+// whose entries are one-hot flags spaced 8 bits apart (letter, digit, space-class, U+0020 | continuation,
+// apostrophe, multi-byte lead), so ONE shift-or per byte deposits a flag into up to four masks at once and eight
+// bytes later the finished groups move into 64-bit per-lane masks.  The regex then is the same mask algebra as
+// k_pretok_gpt2_bits (shifts by one to three bytes; the halo absorbs the edge effects), but on the vector ALU,
+// one window per lane.  Non-ASCII code points and apostrophes are handled in two short loops over the set bits
+// of their masks (class lookup / literal check from memory).  ~13 instructions per byte instead of ~80 for the
+// lane-per-byte kernel.  Same predicate as k_pretok_gpt2.
+// =================================================================================================
+constexpr int SQ_MAIN = 48, SQ_HALO = 8, SQ_LUT_COPIES = 4;
+struct __attribute__((packed, aligned(8))) SqChunk { uint32_t a, b, c, d; };
+
+__global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                         const int64_t* __restrict__ len_dev,
+                                                         const unsigned long long* __restrict__ docmask,
+                                                         const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                         unsigned long long* __restrict__ startmask) {
+    __shared__ uint2 lut[SQ_LUT_COPIES * 256];
+    {
+        const uint32_t v = threadIdx.x;                      // 256 threads: one table entry each
+        const uint32_t lower = v | 0x20u;
+        const bool isL = v < 0x80u && (lower - 'a' < 26u), isN = (v - '0' < 10u), isS = (v == 0x20u) || (v - 9u < 5u);
+        uint2 e;
+        e.x = (isL ? 1u : 0u) | (isN ? 1u << 8 : 0u) | (isS ? 1u << 16 : 0u) | (v == 0x20u ? 1u << 24 : 0u);
+        e.y = ((v & 0xC0u) == 0x80u ? 1u : 0u) | (v == '\'' ? 1u << 8 : 0u) | (v >= 0xC0u ? 1u << 16 : 0u);
+#pragma unroll
+        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + v] = e;
+    }
+    __syncthreads();
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    const int64_t n_words_host = (n_bytes_host >> 6) + 1;
+    const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t a = Lg * SQ_MAIN;                          // first byte this lane decides
+    const int64_t base = a - SQ_HALO;                        // window = [base, base + 64)
+    unsigned long long out = 0;
+    if (a < n_bytes) {
+        uint32_t w[16];
+        {
+            // four 16-byte loads (8-byte aligned: gfx950 takes dwordx4 at any alignment); the text carries 64
+            // readable bytes after n_bytes, and only lane 0's window starts before the text
+            SqChunk c0{0, 0, 0, 0};
+            if (base >= 0) c0 = *(const SqChunk*)(text + base);
+            else { const uint2 t = *(const uint2*)text; c0.c = t.x; c0.d = t.y; }
+            const SqChunk c1 = *(const SqChunk*)(text + base + 16), c2 = *(const SqChunk*)(text + base + 32),
+                          c3 = *(const SqChunk*)(text + base + 48);
+            w[0] = c0.a; w[1] = c0.b; w[2] = c0.c; w[3] = c0.d; w[4] = c1.a; w[5] = c1.b; w[6] = c1.c; w[7] = c1.d;
+            w[8] = c2.a; w[9] = c2.b; w[10] = c2.c; w[11] = c2.d; w[12] = c3.a; w[13] = c3.b; w[14] = c3.c; w[15] = c3.d;
+        }
+        // valid positions of the window and their document-start bits
+        const int vlo = base < 0 ? (int)-base : 0;
+        const int64_t rem = n_bytes - base;
+        unsigned long long V = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+        V &= ~0ull << vlo;
+        unsigned long long D;
+        if (base < 0) D = docmask[0] << SQ_HALO;
+        else {
+            const int64_t wi = base >> 6;
+            const int sh = (int)(base & 63);
+            D = docmask[wi] >> sh;
+            if (sh && wi + 1 < n_words_host) D |= docmask[wi + 1] << (64 - sh);
+        }
+        D &= V;
+        // ---- per-byte flags -> 64-bit masks
+        const uint2* my_lut = lut + (threadIdx.x & (SQ_LUT_COPIES - 1)) * 256;
+        unsigned long long L = 0, N = 0, S = 0, SP = 0, C = 0, AP = 0, MU = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            uint32_t accA = 0, accB = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * g + j;
+                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint2 e = my_lut[b];
+                accA |= e.x << j;
+                accB |= e.y << j;
+            }
+            L |= (unsigned long long)(accA & 0xFFu) << (8 * g);
+            N |= (unsigned long long)((accA >> 8) & 0xFFu) << (8 * g);
+            S |= (unsigned long long)((accA >> 16) & 0xFFu) << (8 * g);
+            SP |= (unsigned long long)(accA >> 24) << (8 * g);
+            C |= (unsigned long long)(accB & 0xFFu) << (8 * g);
+            AP |= (unsigned long long)((accB >> 8) & 0xFFu) << (8 * g);
+            MU |= (unsigned long long)((accB >> 16) & 0xFFu) << (8 * g);
+        }
+        // multi-byte code points: class from the Unicode table, spread over the lead and its continuation bytes
+        for (unsigned long long m = MU & V; m; m &= m - 1) {
+            const int k = __ffsll((long long)m) - 1;
+            uint32_t len;
+            const uint32_t cls = cls_lns(utf8_global(text, base + k, &len), uc1, uc2);
+            const unsigned long long span = ((1ull << len) - 1ull) << k;
+            if (cls == 1u) L |= span; else if (cls == 2u) N |= span; else if (cls == 3u) S |= span;
+        }
+        L &= V; N &= V; S &= V; SP &= V;
+        const unsigned long long LEAD = ~C & V, nD = ~D;
+        const unsigned long long O = V & ~(L | N | S);
+        const unsigned long long pL = (L << 1) & nD, pN = (N << 1) & nD, pS = (S << 1) & nD, pO = (O << 1) & nD, pSP = (SP << 1) & nD;
+        // contraction literals 's 't 'm 'd | 're 've 'll that are match starts
+        unsigned long long CON2 = 0, CON3 = 0;
+        {
+            const unsigned long long ok = V & nD;                                   // byte exists and continues the document
+            const unsigned long long cond = D | pL | pN | (pS & ~pSP);
+            for (unsigned long long m = AP & V & cond & (ok >> 1) & (L >> 1); m; m &= m - 1) {
+                const int k = __ffsll((long long)m) - 1;
+                const uint32_t b1 = text[base + k + 1], b2 = text[base + k + 2];
+                if (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd') CON2 |= 1ull << k;
+                else if ((((b1 == 'r' || b1 == 'v') && b2 == 'e') || (b1 == 'l' && b2 == 'l')) && ((ok >> (k + 2)) & 1ull)) CON3 |= 1ull << k;
+            }
+        }
+        const unsigned long long con = CON2 | CON3;
+        const unsigned long long eaten = (con << 1) | (CON3 << 2);
+        const unsigned long long after = (CON2 << 2) | (CON3 << 3);
+        const unsigned long long run = (L & ~(pL | pSP)) | (N & ~(pN | pSP)) | (O & ~(pO | pSP));
+        const unsigned long long wsfirst = S & ~pS;
+        // whitespace after whitespace starts a match iff the NEXT code point is a non-space of the same document
+        unsigned long long Y = (LEAD & ~S & nD) >> 1;
+        Y |= (Y & C) >> 1; Y |= (Y & C) >> 1; Y |= (Y & C) >> 1;
+        const unsigned long long wslast = S & pS & Y;
+        const unsigned long long start = LEAD & (D | (~eaten & (con | after | run | wsfirst | wslast)));
+        out = (start >> SQ_HALO) & ((1ull << SQ_MAIN) - 1ull);
+    }
+    // four lanes' 48-bit results are three 64-bit mask words
+    const unsigned long long nxt = __shfl_down(out, 1, 64);
+    const int q = (int)(threadIdx.x & 3);
+    if (q < 3) {
+        const int64_t word = 3 * (Lg >> 2) + q;
+        if (word < n_words_host) startmask[word] = (out >> (16 * q)) | (nxt << (SQ_MAIN - 16 * q));
+    }
+}
+
+// =================================================================================================
 // K_pretok_gpt2_bits: the same GPT-2 start predicate, bit-parallel.  One lane per byte only to CLASSIFY
 // (class of the code point the byte belongs to, a handful of byte tests), every predicate becomes a
 // 64-bit ballot, and the whole window logic of k_pretok_gpt2 -- contraction literals, eaten letters,
@@ -2426,7 +2557,9 @@ void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_do
 }
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant) {
-    if (variant == 0)
+    if (variant == 2)
+        hipLaunchKernelGGL(k_pretok_gpt2_seq, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    else if (variant == 0)
         hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
     else
         hipLaunchKernelGGL(k_pretok_gpt2_bits, dim3(blocks_for(n_bytes + 1, PB_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
