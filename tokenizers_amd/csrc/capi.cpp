@@ -84,7 +84,7 @@ struct tkamd_tokenizer {
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
-    DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end;
+    DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
         w_match_docs, w_match_list;
@@ -222,6 +222,8 @@ void upload_tables(tkamd_tokenizer* t) {
     d.merge_disp = t->t_merge_disp.as<uint16_t>();
     d.merge_mask = hm.merge_mask;
     d.merge_seed = hm.merge_seed;
+    d.newid_affine = hm.merge_newid_affine ? 1u : 0u;
+    d.newid_base = hm.merge_newid_base;
     d.merge_bmask = hm.merge_bmask;
     d.words = t->t_words.as<WordSlot>();
     d.word_disp = t->t_word_disp.as<uint16_t>();
@@ -312,6 +314,7 @@ void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint
     t->w_ntok.reserve((N + 4) * 4);
     t->w_pt_tokoff.reserve((N + 4) * 4);
     t->w_tmp_ids.reserve((N + 4) * 4);
+    t->w_rows.reserve((N / 4 + N / 32 + 2048) * 16);   // dense result rows of the LDS merge kernels (overflow falls back to tmp_ids)
     t->w_lists.reserve((N + N / 16 + N / 32 + N / 64 + 128) * 4);
     t->w_csum.reserve((N / 1024 + 4) * 4);
     t->w_ids.reserve((N + 4) * 4);
@@ -514,17 +517,26 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         uint32_t* list32 = list16 + N + 16;
         uint32_t* list64 = list32 + N / 16 + 16;
         uint32_t* listL = list64 + N / 32 + 16;
+        if (!t->long_prepared) {
+            if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(merge kernel LDS) failed");
+            t->long_prepared = true;
+        }
         pf.begin("bpe_word_lookup");
         launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), nullptr, d_npretok, t->w_tok0.as<uint32_t>(),
                                t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask);
         pf.end();
-        pf.begin("bpe_merge_lane32");
-        launch_bpe_merge(st, grid, 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 1; }();
+        const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
+        pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
+        const uint32_t rows16_cap = (uint32_t)(N / 4 + 1024), rows32_cap = (uint32_t)(N / 32 + 1024);
+        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? (ldscfg == 2 ? 6 : 4) : 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, rows16_cap, rows32_cap);
         pf.end();
         // <= 16 bytes: (optional in-batch de-duplication, then) one lane per pre-token (register-resident Word).
         // TKAMD_MERGE16=row selects the 16-lane DPP-row kernel (A/B switch).
         static const bool row16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "row"); }();
+        static const bool lane16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "lane"); }();
+        const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // LDS-resident Word (default when new_id = rank + c)
         // De-duplication is OFF by default: measured on MI355X its two hash-table passes + the copy-back cost
         // 0.58 ms on C2 against 0.35 ms of merge work saved (the queue shrinks 10.8x, but every pass is the
         // same kind of scattered, latency-bound traffic as the merge it replaces).  TKAMD_DEDUP=1 enables it.
@@ -550,9 +562,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             mlist = t->w_ulist.as<uint32_t>();
             mcount = d_counters + CNT_ULIST;
         }
-        pf.begin(row16 ? "bpe_merge16" : "bpe_merge_lane");
-        launch_bpe_merge(st, grid, row16 ? 16 : 1, t->dt, x_text, t->w_pt_start.as<uint32_t>(), mlist, mcount,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
+        launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? (ldscfg == 2 ? 5 : 3) : 1), t->dt, x_text, t->w_pt_start.as<uint32_t>(), mlist, mcount,
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, 0u, rows16_cap);
         pf.end();
         if (dedup) {
             pf.begin("dedup_copy");
@@ -564,10 +576,6 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         launch_bpe_merge(st, grid, 64, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
                          t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
-        if (!t->long_prepared) {
-            if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(long merge kernel LDS) failed");
-            t->long_prepared = true;
-        }
         pf.begin("bpe_merge_long");
         // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
         // worst case this batch can contain (the whole X text being such pre-tokens), capped at 1 GiB
@@ -627,7 +635,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     pf.begin("compact");
     launch_compact(st, grid, t->w_ntok.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(),
                    t->w_pt_start.as<uint32_t>(), d_npretok, t->w_csum.as<uint32_t>(), d_ntok_total,
-                   t->w_pt_tokoff.as<uint32_t>(), t->w_ids.as<uint32_t>());
+                   t->w_pt_tokoff.as<uint32_t>(), t->w_ids.as<uint32_t>(), t->w_rows.p);
     pf.end();
     pf.begin("doc_tok_offsets");
     launch_doc_tok_offsets(st, t->w_doc_pt.as<uint32_t>(), n_docs, t->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,

@@ -197,6 +197,12 @@ bool chd_place(const std::vector<uint32_t>& h1, const std::vector<uint32_t>& h2,
 }
 
 void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
+    // new_id == rank + constant for every merge (true of every trainer-produced vocabulary: merged tokens are
+    // appended in merge order): the LDS-resident merge kernel then needs no per-pair new-id array
+    m.merge_newid_affine = !merges.empty();
+    m.merge_newid_base = merges.empty() ? 0u : merges[0].new_id - merges[0].rank;
+    for (const MergeSlot& e : merges)
+        if (e.new_id - e.rank != m.merge_newid_base) { m.merge_newid_affine = false; break; }
     uint32_t cap = 16;
     while (cap < merges.size() * 5 / 2) cap <<= 1;            // load factor <= 0.4
     uint32_t nb = 16;

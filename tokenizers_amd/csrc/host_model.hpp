@@ -78,6 +78,8 @@ struct HostModel {
     std::vector<MergeSlot> merge_table; // perfect hash (hash-and-displace), size = merge_mask+1 (power of two)
     std::vector<uint16_t> merge_disp;   // displacement per bucket, size = merge_bmask+1
     uint32_t merge_mask = 0, merge_seed = 0, merge_bmask = 0;
+    bool merge_newid_affine = false;    // new_id == rank + merge_newid_base for every merge
+    uint32_t merge_newid_base = 0;
     std::vector<WordSlot> word_table;   // perfect hash (hash-and-displace), size = word_mask+1
     std::vector<uint16_t> word_disp;    // size = word_bmask+1
     uint32_t word_mask = 0, word_seed = 0, word_bmask = 0;

@@ -1509,6 +1509,7 @@ __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __
     }
 }
 
+constexpr uint32_t TOK_ROW = 0x80000000u;         // tok0 flag: the low bits index a dense row of up to 4 token ids
 constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
 constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
 constexpr int LK_CHUNK = 256 * LK_ITEMS;
@@ -1893,6 +1894,173 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
 }
 template __global__ void k_bpe_merge_lane<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
 template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+
+// =================================================================================================
+// K_bpe_merge_lds: the lane-per-pre-token merge loop with the Word in LDS instead of registers.
+// The register kernel above indexes its arrays with compile-time indices only, so every dynamic access is a
+// 16- or 32-way select chain and one merge costs ~300 vector instructions; it is ALU-issue bound.  Here
+//   * symbols stay IN PLACE: sym[i] is the symbol that starts at byte i, a 32-bit `alive` mask says which
+//     positions still start a symbol (it doubles as the token-boundary mask for offsets), neighbours are
+//     found with ctz/clz -- nothing shifts;
+//   * key[i] = (rank << PB) | i for the pair (i, next alive), 0xFFFFFFFF when there is none: the
+//     (rank, position)-minimum of word.rs:177-208 is one min3 tree over S LDS words, and the winner's
+//     position and rank come out of the key itself;
+//   * new_id = rank + constant (host-verified for the loaded vocabulary), so no new-id array is kept;
+//   * sym/key live in LDS as [slot][thread] words: a lane only ever touches its own bank column, every
+//     access is conflict-free, and a dynamic index costs one multiply-add.
+// One merge is ~85 vector instructions.  LDS per lane is 8 * S bytes, which with the 32 KB displacement cache
+// allows NT = 768 (S = 16) lanes per CU.
+// Same semantics as k_bpe_merge / k_bpe_merge_lane (models/bpe/word.rs:162-250).
+// =================================================================================================
+template <int S, int NT, bool DISP_LDS>
+__global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text,
+                                                      const uint32_t* __restrict__ pt_start,
+                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                      uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                      uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
+                                                      uint4* __restrict__ rows, uint32_t row_base, uint32_t row_cap) {
+    constexpr uint32_t PB = (S == 16) ? 4 : 5;
+    extern __shared__ uint32_t lds_words[];
+    uint32_t* s_key = lds_words;                              // [S][NT]
+    uint32_t* s_sym = s_key + S * NT;                         // [S][NT]
+    uint32_t* s_byte_id = s_sym + S * NT;                     // [256]
+    uint32_t* s_hist = s_byte_id + 256;                       // [S + 1] (+ padding to 64)
+    uint16_t* s_disp = (uint16_t*)(s_hist + 64);              // [DISP_LDS_MAX]
+    uint4* s_sort = (uint4*)s_key;                            // [NT], aliases the key area between items
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 256; i += NT) s_byte_id[i] = t.byte_id[i];
+    const bool disp_in_lds = DISP_LDS && t.merge_bmask < (uint32_t)DISP_LDS_MAX;
+    if (disp_in_lds)
+        for (uint32_t i = tid; i <= t.merge_bmask; i += NT) s_disp[i] = t.merge_disp[i];
+    __syncthreads();
+    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
+    const uint32_t nid_base = t.newid_base;
+    const uint32_t n_items = *n_list;
+    const uint32_t stride = gridDim.x * NT;
+    for (uint32_t base = blockIdx.x * NT; base < n_items; base += stride) {
+        const uint32_t item = base + tid;
+        bool valid = item < n_items;
+        uint32_t p = 0, s = 0, len = 0, qidx = 0;             // qidx: position in the work queue (names the dense result row)
+        if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        // counting sort of the workgroup's items by length: a wavefront loops until its slowest lane is done
+        {
+            __syncthreads();                                  // previous item's key/sym area is dead
+            if (tid <= S) s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t bin = valid ? len : (uint32_t)S;
+            const uint32_t within = atomicAdd(&s_hist[bin], 1u);
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
+            s_sort[before + within] = make_uint4(p, s, len, valid ? item + 1u : 0u);
+            __syncthreads();
+            const uint4 it = s_sort[tid];
+            __syncthreads();                                  // everyone has read its item before keys overwrite the area
+            p = it.x; s = it.y; len = it.z; valid = it.w != 0u;
+            qidx = it.w - 1u;
+        }
+        uint32_t* my_key = s_key + tid;                       // slot i at my_key[i * NT]
+        uint32_t* my_sym = s_sym + tid;
+        {
+            uint64_t kb[S / 8];
+#pragma unroll
+            for (int q = 0; q < S / 8; ++q) kb[q] = 0;
+            if (valid) {
+                load_key16(text, s, min(len, 16u), &kb[0], &kb[1]);
+                if (S == 32 && len > 16) load_key16(text, s + 16, len - 16, &kb[S / 8 - 2], &kb[S / 8 - 1]);
+            }
+            uint32_t ids[S];
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                ids[i] = s_byte_id[(uint32_t)((kb[i / 8] >> (8 * (i % 8))) & 0xFFu)];
+                my_sym[i * NT] = ids[i];
+            }
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                uint32_t k = 0xFFFFFFFFu;
+                if (i < S - 1 && (uint32_t)(i + 1) < len) {
+                    uint32_t r, nd;
+                    merge_probe_d(t, disp, ids[i], ids[i + 1], &r, &nd);
+                    if (r != RANK_NONE) k = (r << PB) | (uint32_t)i;
+                }
+                my_key[i * NT] = k;
+            }
+        }
+        uint32_t alive = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+        bool active = valid && len > 1;
+        while (__any(active)) {
+            if (active) {
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < S - 1; ++i) best = min(best, my_key[i * NT]);
+                if (best == 0xFFFFFFFFu) active = false;
+                else {
+                    const uint32_t i = best & (uint32_t)(S - 1);
+                    const uint32_t nid = (best >> PB) + nid_base;
+                    uint32_t above = alive & ~((2u << i) - 1u);           // live positions right of i (the pair's right symbol is the first)
+                    const uint32_t j = (uint32_t)__ffs(above) - 1u;
+                    above &= above - 1u;
+                    alive &= ~(1u << j);
+                    const uint32_t below = alive & ((1u << i) - 1u);
+                    const bool has_k = above != 0u, has_h = below != 0u;
+                    const uint32_t k = has_k ? (uint32_t)__ffs(above) - 1u : i;
+                    const uint32_t h = has_h ? 31u - (uint32_t)__clz(below) : i;
+                    const uint32_t sr = my_sym[k * NT], sl = my_sym[h * NT];
+                    my_sym[i * NT] = nid;
+                    uint32_t r1, r2, nd;
+                    merge_probe_d(t, disp, sl, nid, &r1, &nd);
+                    merge_probe_d(t, disp, nid, sr, &r2, &nd);
+                    my_key[j * NT] = 0xFFFFFFFFu;
+                    my_key[i * NT] = (has_k && r2 != RANK_NONE) ? ((r2 << PB) | i) : 0xFFFFFFFFu;
+                    if (has_h) my_key[h * NT] = (r1 != RANK_NONE) ? ((r1 << PB) | h) : 0xFFFFFFFFu;
+                    if (!has_k && !has_h) active = false;                 // one symbol left
+                }
+            }
+        }
+        if (valid) {
+            const uint32_t c = (uint32_t)__popc(alive);
+            ntok[p] = c;
+            if (c >= 2u && c <= 4u && qidx < row_cap) {
+                // all ids in one dense 16-byte row named by the queue position; tok0 points at it
+                uint32_t r[4] = {my_sym[0], 0u, 0u, 0u};
+                uint32_t m = alive & ~1u;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    if (m) {
+                        const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                        r[j] = my_sym[pos * NT];
+                        if (tmp_end) tmp_end[s + j - 1] = pos;
+                        m &= m - 1u;
+                    }
+                }
+                if (tmp_end) tmp_end[s + c - 1] = len;
+                rows[row_base + qidx] = make_uint4(r[0], r[1], r[2], r[3]);
+                tok0[p] = TOK_ROW | (row_base + qidx);
+            } else {
+                tok0[p] = my_sym[0];
+                uint32_t j = 1;
+                for (uint32_t m = alive & ~1u; m; m &= m - 1u, ++j) {
+                    const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                    tmp_ids[s + j] = my_sym[pos * NT];
+                    if (tmp_end) tmp_end[s + j - 1] = pos;                // the previous token ends where this one starts
+                }
+                if (tmp_end) tmp_end[s + j - 1] = len;
+            }
+        }
+    }
+}
+constexpr int lds_merge_bytes(int S, int NT, bool disp_lds) { return (2 * S * NT + 256 + 64) * 4 + (disp_lds ? DISP_LDS_MAX * 2 : 0); }
+template <int S, int NT, bool DISP_LDS>
+static int prepare_lds_merge() {
+    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS));
+}
+template <int S, int NT, bool DISP_LDS>
+static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                             const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
+                             void* rows, uint32_t row_base, uint32_t row_cap) {
+    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
+                       (uint4*)rows, row_base, rows ? row_cap : 0u);
+}
 
 // =================================================================================================
 // In-batch de-duplication of the merge work queue.  Natural text repeats its rare words too (Zipf), and
@@ -2356,6 +2524,7 @@ __global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict_
 __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
                                                  const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start,
                                                  const int64_t* __restrict__ n_pretok, const uint32_t* __restrict__ csum,
+                                                 const uint4* __restrict__ rows,
                                                  uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
     __shared__ uint32_t sm[4];
     const int64_t P = *n_pretok;
@@ -2375,6 +2544,14 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ nt
                 first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
             }
         }
+        // 2..4-token pre-tokens resolved by the LDS merge kernels keep all their ids in one dense 16-byte row
+        // (tok0 = TOK_ROW | row index): one load here instead of scattered tmp_ids traffic
+        uint4 row[CP_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            row[k] = make_uint4(first[k], 0u, 0u, 0u);
+            if (cnt[k] > 1u && (first[k] & TOK_ROW)) row[k] = rows[first[k] & ~TOK_ROW];
+        }
         uint32_t v = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         uint32_t tot;
         uint32_t o = csum[ch] + block256_excl_scan(v, sm, &tot);
@@ -2386,10 +2563,16 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ nt
                 if (!full) pt_tokoff[p] = o;
                 uint32_t c = cnt[k];
                 if (c) {
-                    ids[o] = first[k];
+                    ids[o] = row[k].x;
                     if (c > 1) {
-                        uint32_t s = pt_start[p];
-                        for (uint32_t j = 1; j < c; ++j) ids[o + j] = tmp_ids[s + j];
+                        if (first[k] & TOK_ROW) {
+                            ids[o + 1] = row[k].y;
+                            if (c > 2) ids[o + 2] = row[k].z;
+                            if (c > 3) ids[o + 3] = row[k].w;
+                        } else {
+                            uint32_t s = pt_start[p];
+                            for (uint32_t j = 1; j < c; ++j) ids[o + j] = tmp_ids[s + j];
+                        }
                     }
                 }
                 o += c;
@@ -2586,8 +2769,14 @@ void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const 
     hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters, matchmask);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
-    if (group == 1)
+                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
+                      void* rows, uint32_t row_base, uint32_t row_cap) {
+    // LDS-resident Word (needs newid_affine; prepare_long_kernel() raised the LDS limit)
+    if (group == 3) launch_lds_merge<16, 768, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 4) launch_lds_merge<32, 384, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 5) launch_lds_merge<16, 1024, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 6) launch_lds_merge<32, 512, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 1)
         hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
     else if (group == 2)
         hipLaunchKernelGGL(k_bpe_merge_lane<32>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
@@ -2695,7 +2884,12 @@ void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const ui
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {
-    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
+    int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
+    if (rc == 0) rc = prepare_lds_merge<16, 768, true>();
+    if (rc == 0) rc = prepare_lds_merge<32, 384, true>();
+    if (rc == 0) rc = prepare_lds_merge<16, 1024, false>();
+    if (rc == 0) rc = prepare_lds_merge<32, 512, false>();
+    return rc;
 }
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
@@ -2707,10 +2901,11 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                        tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
 }
 void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
-                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids) {
+                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids,
+                    const void* rows) {
     hipLaunchKernelGGL(k_ntok_reduce, dim3(grid), dim3(256), 0, st, ntok, n_pretok, csum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, csum, (int64_t)0, n_pretok, (int64_t)CP_CHUNK, n_tok);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, st, ntok, tok0, tmp_ids, pt_start, n_pretok, (const uint32_t*)csum, pt_tokoff, ids);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, st, ntok, tok0, tmp_ids, pt_start, n_pretok, (const uint32_t*)csum, (const uint4*)rows, pt_tokoff, ids);
 }
 void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
                             const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets) {

@@ -15,6 +15,7 @@ struct DevTables {
     const MergeSlot* merges;          // perfect-hash table (one slot per key)
     const uint16_t* merge_disp;       // bucket displacements
     uint32_t merge_mask, merge_seed, merge_bmask;
+    uint32_t newid_affine, newid_base;   // new_id == rank + newid_base for every merge (host-verified)
     const WordSlot* words;            // perfect-hash table (one slot per key)
     const uint16_t* word_disp;
     uint32_t word_mask, word_seed, word_bmask;
@@ -125,7 +126,8 @@ void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const 
                             const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
                             uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask);
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
+                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
+                      void* rows = nullptr, uint32_t row_base = 0, uint32_t row_cap = 0);
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
                               unsigned long long* docmask, int* err);
 void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
@@ -168,7 +170,8 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                            uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge, uint32_t* scratch, unsigned long long scratch_words,
                            unsigned long long* scratch_used, int* err);
 void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
-                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);
+                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids,
+                    const void* rows);
 void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
                             const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets);
 

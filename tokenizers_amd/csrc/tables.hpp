@@ -44,14 +44,34 @@ TK_HD uint32_t mix32(uint32_t x) {
     x ^= x >> 16;
     return x;
 }
-TK_HD uint32_t merge_hash1(uint32_t a, uint32_t b, uint32_t seed) { return mix32(a * 0x9E3779B1u + b * 0x85EBCA77u + seed); }
-TK_HD uint32_t merge_hash2(uint32_t a, uint32_t b, uint32_t seed) { return mix32((a ^ 0x5BD1E995u) * 0xC2B2AE3Du + (b + 0x27D4EB2Fu) * 0x165667B1u + seed * 0x9E3779B1u); }
+// 24-bit multiply (v_mul_u32_u24 / v_mad_u32_u24: full rate on CDNA, where the 32-bit v_mul_lo_u32 is quarter rate).
+// Only the low 24 bits of each operand take part; token ids are far below 2^24.
+TK_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull);
+#endif
+}
+// Pair hashes: two multiply-adds and one xor-shift each.  The seed perturbs the MULTIPLIERS (an additive seed would
+// leave colliding pairs colliding); table construction retries seeds until every key has its own slot, so the
+// hash only has to spread keys, not be strong.  A merge probe is what the merge loops spend their ALU time on.
+TK_HD uint32_t merge_hash1(uint32_t a, uint32_t b, uint32_t seed) {
+    const uint32_t k1 = 0x9E3779u ^ (seed & 0xFFFFFEu), k2 = 0x85EBCBu ^ ((seed >> 7) & 0xFFFFFEu);
+    const uint32_t x = mul24(a, k1) + mul24(b, k2);
+    return x ^ (x >> 15);
+}
+TK_HD uint32_t merge_hash2(uint32_t a, uint32_t b, uint32_t seed) {
+    const uint32_t k3 = 0xC2B2AFu ^ ((seed >> 3) & 0xFFFFFEu), k4 = 0x165667u ^ ((seed >> 11) & 0xFFFFFEu);
+    const uint32_t y = mul24(a, k3) + mul24(b, k4) + 0x5BD1E995u;
+    return y ^ (y >> 13);
+}
 
 // Hash-and-displace perfect hash for the merge table: bucket = hash1 & bmask selects a 16-bit displacement d,
 // the key then lives in exactly ONE slot, (hash2 + d * PH_MULT) & mask.  A lookup -- hit or miss -- is one
 // 16-byte load; the displacement array is small enough (<= 32 KB for 50k merges) to sit in LDS.
-constexpr uint32_t PH_MULT = 0x9E3779B1u;
-TK_HD uint32_t ph_slot(uint32_t h2, uint32_t d, uint32_t mask) { return (h2 + d * PH_MULT) & mask; }
+constexpr uint32_t PH_MULT = 0x9E3779u;
+TK_HD uint32_t ph_slot(uint32_t h2, uint32_t d, uint32_t mask) { return (h2 + mul24(d, PH_MULT)) & mask; }
 
 // ---- whole-word table: raw pre-token bytes (<= 16) -> token id ------------------------------
 // Serves BPE `ignore_merges` (bpe/model.rs:559-567), WordLevel (wordlevel/mod.rs:162-178) and the
