@@ -295,9 +295,15 @@ def test_encode_batch_matches_golden_char_offsets(name):
         assert e.word_ids == v["words"][i], doc
 
 
-def test_alternative_kernels_agree(gpt2_json):
-    """The A/B kernel variants (bit-parallel pre-tokenizer, 16-lane DPP-row merge, in-batch de-duplication) must give the same ids as the
-    default ones: run them in a subprocess because the selection is read once per process."""
+@pytest.mark.parametrize("variant", [
+    {"TKAMD_PRETOK": "bits", "TKAMD_MERGE16": "row", "TKAMD_LDSCFG": "0"},     # ballot pre-tokenizer, DPP-row merge, register lane32
+    {"TKAMD_PRETOK": "lds", "TKAMD_MERGE16": "lane", "TKAMD_LDSCFG": "1"},     # lane-per-byte pre-tokenizer, register lane16, LDS lane32
+    {"TKAMD_LDSCFG": "2"},                                                      # LDS merges with the displacement table in global memory
+], ids=["bits-row16-lane32", "ldspretok-lane16", "lds-global-disp"])
+def test_alternative_kernels_agree(gpt2_json, variant):
+    """The A/B kernel variants (the fallbacks for vocabularies whose new ids are not rank + c, and the earlier generations
+    of the pre-tokenizer) must give the same ids and offsets as the oracle: run them in a subprocess because the
+    selection is read once per process."""
     import os
     import subprocess
     import sys
@@ -307,11 +313,15 @@ def test_alternative_kernels_agree(gpt2_json):
         "from oracle import synth, oracle as orc\n"
         "js = synth.load_or_train_gpt2()\n"
         "docs = synth.gen_lines(6000, text_seed=41) + synth.stress_lines(seed=12, n=3000)\n"
-        "got = ta.Tokenizer.from_str(js, device=0).encode_batch_fast(docs, add_special_tokens=False)\n"
+        "tk = ta.Tokenizer.from_str(js, device=0)\n"
+        "got = tk.encode_batch_fast(docs, add_special_tokens=False)\n"
         "exp = orc.Oracle(js).encode_batch(docs)\n"
         "assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all()\n"
+        "got = tk.encode_batch_csr(docs[:3000], offsets='byte', add_special_tokens=False)\n"
+        "exp = orc.Oracle(js).encode_batch(docs[:3000])\n"
+        "assert (got.ids == exp.ids).all() and (np.asarray(got.offsets) == np.asarray(exp.offsets)).all()\n"
         "print('VARIANT_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TKAMD_PRETOK="bits", TKAMD_MERGE16="row", TKAMD_DEDUP="1")
+    env = dict(os.environ, **variant)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr
 

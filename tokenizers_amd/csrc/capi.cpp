@@ -86,7 +86,7 @@ struct tkamd_tokenizer {
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_fp_tab, w_rep_tab, w_slot_of, w_ulist, w_dlist, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off;
@@ -521,57 +521,30 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(merge kernel LDS) failed");
             t->long_prepared = true;
         }
-        pf.begin("bpe_word_lookup");
-        launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), nullptr, d_npretok, t->w_tok0.as<uint32_t>(),
-                               t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask);
-        pf.end();
         static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 1; }();
-        const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
-        pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        const uint32_t rows16_cap = (uint32_t)(N / 4 + 1024), rows32_cap = (uint32_t)(N / 32 + 1024);
-        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? (ldscfg == 2 ? 6 : 4) : 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, rows16_cap, rows32_cap);
-        pf.end();
-        // <= 16 bytes: (optional in-batch de-duplication, then) one lane per pre-token (register-resident Word).
-        // TKAMD_MERGE16=row selects the 16-lane DPP-row kernel (A/B switch).
         static const bool row16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "row"); }();
         static const bool lane16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "lane"); }();
         const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // LDS-resident Word (default when new_id = rank + c)
-        // De-duplication is OFF by default: measured on MI355X its two hash-table passes + the copy-back cost
-        // 0.58 ms on C2 against 0.35 ms of merge work saved (the queue shrinks 10.8x, but every pass is the
-        // same kind of scattered, latency-bound traffic as the merge it replaces).  TKAMD_DEDUP=1 enables it.
-        static const bool dedup = [] { const char* e = getenv("TKAMD_DEDUP"); return e && !strcmp(e, "1"); }();
+        const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
+        // dense result rows of the LDS merge kernels, named by queue position (beyond the capacity: the tmp_ids path)
+        const uint32_t rows16_cap = lds16 ? (uint32_t)(N / 4 + 1024) : 0u, rows32_cap = lds32 ? (uint32_t)(N / 32 + 1024) : 0u;
+        const RowPlan rowplan{rows16_cap, (uint32_t)(N / 4 + 1024), rows32_cap};
+        pf.begin("bpe_word_lookup");
+        launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), nullptr, d_npretok, t->w_tok0.as<uint32_t>(),
+                               t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask, rowplan);
+        pf.end();
+        pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
+        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? (ldscfg == 2 ? 6 : 4) : 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
+                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, rowplan.base32, rows32_cap);
+        pf.end();
+        // <= 16 bytes: one lane per pre-token, Word in LDS (or in registers when new_id is not rank + c).
+        // TKAMD_MERGE16=row / lane select the 16-lane DPP-row kernel / the register-resident lane kernel (A/B switches).
         const uint32_t* mlist = list16;
         const uint32_t* mcount = d_counters + CNT_LIST16;
-        if (dedup) {
-            // table capacity: a power of two around 2x the expected queue length, bounded; too small only costs speed
-            uint32_t cap = 1u << 16;
-            while (cap < (1u << 23) && (size_t)cap < N / 8) cap <<= 1;
-            t->w_fp_tab.reserve((size_t)cap * 8);
-            t->w_rep_tab.reserve((size_t)cap * 4);
-            t->w_slot_of.reserve((N + 16) * 4);
-            t->w_ulist.reserve((N + 16) * 4);
-            t->w_dlist.reserve((N + 16) * 8);
-            pf.begin("dedup");
-            HIP_CHECK(hipMemsetAsync(t->w_fp_tab.p, 0, (size_t)cap * 8, st));
-            HIP_CHECK(hipMemsetAsync(t->w_rep_tab.p, 0xFF, (size_t)cap * 4, st));
-            launch_dedup(st, grid, x_text, t->w_pt_start.as<uint32_t>(), list16, d_counters + CNT_LIST16, t->w_fp_tab.as<ull>(),
-                         t->w_rep_tab.as<uint32_t>(), cap - 1, t->w_slot_of.as<uint32_t>(), t->w_ulist.as<uint32_t>(),
-                         t->w_dlist.as<uint32_t>(), d_counters);
-            pf.end();
-            mlist = t->w_ulist.as<uint32_t>();
-            mcount = d_counters + CNT_ULIST;
-        }
         pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
         launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? (ldscfg == 2 ? 5 : 3) : 1), t->dt, x_text, t->w_pt_start.as<uint32_t>(), mlist, mcount,
                          t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, 0u, rows16_cap);
         pf.end();
-        if (dedup) {
-            pf.begin("dedup_copy");
-            launch_dedup_copy(st, grid, t->w_pt_start.as<uint32_t>(), t->w_dlist.as<uint32_t>(), d_counters + CNT_DLIST,
-                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
-            pf.end();
-        }
         pf.begin("bpe_merge64");
         launch_bpe_merge(st, grid, 64, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
                          t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
@@ -646,7 +619,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         a.x_text = x_text;
         a.pt_start = t->w_pt_start.as<uint32_t>();
         a.pt_end = pt_end;
-        a.ntok = t->w_ntok.as<uint32_t>();
+        a.n_tok = d_ntok_total;
         a.pt_tokoff = t->w_pt_tokoff.as<uint32_t>();
         a.tmp_end = tmp_end;
         a.n_pretok = d_npretok;
@@ -802,7 +775,7 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
                          &t->t_long_id, &t->t_long_table, &t->t_at_id, &t->t_at_flags, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_fp_tab, &t->w_rep_tab, &t->w_slot_of, &t->w_ulist, &t->w_dlist, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2, &t->w_candmask, &t->w_matchmask, &t->w_spanmask,
+                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2, &t->w_candmask, &t->w_matchmask, &t->w_spanmask,
                          &t->w_stopmask, &t->w_hardmask, &t->w_match_docs, &t->w_match_list,
                          &t->h_text, &t->h_doc_off};
         for (DevBuf* b : all) b->release();

@@ -1509,7 +1509,8 @@ __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __
     }
 }
 
-constexpr uint32_t TOK_ROW = 0x80000000u;         // tok0 flag: the low bits index a dense row of up to 4 token ids
+constexpr uint32_t TOK_ROW = 0x80000000u;         // tok0 flag: the low bits index a dense result row {id0 | count << 28, id1, id2, id3}
+constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
 constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
 constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
 constexpr int LK_CHUNK = 256 * LK_ITEMS;
@@ -1522,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                                                          uint32_t* __restrict__ list16, uint32_t* __restrict__ list32,
                                                          uint32_t* __restrict__ list64,
                                                          uint32_t* __restrict__ listL, uint32_t* __restrict__ counters,
-                                                         const unsigned long long* __restrict__ matchmask) {
+                                                         const unsigned long long* __restrict__ matchmask, RowPlan rows) {
     __shared__ uint32_t sm[4];
     __shared__ uint32_t base_s[4];
     __shared__ uint16_t s_disp[DISP_LDS_MAX];
@@ -1589,17 +1590,6 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 }
             }
         }
-        // tok0 / ntok for all 8 items as 16-byte stores (queued items get 0 / 0 and are overwritten by the merge kernels)
-        if (pbase + LK_ITEMS <= P) {
-            *(uint4*)(tok0 + pbase) = make_uint4(out_id[0], out_id[1], out_id[2], out_id[3]);
-            *(uint4*)(tok0 + pbase + 4) = make_uint4(out_id[4], out_id[5], out_id[6], out_id[7]);
-            *(uint4*)(ntok + pbase) = make_uint4(out_n[0], out_n[1], out_n[2], out_n[3]);
-            *(uint4*)(ntok + pbase + 4) = make_uint4(out_n[4], out_n[5], out_n[6], out_n[7]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < LK_ITEMS; ++k)
-                if (pbase + k < P) { tok0[pbase + k] = out_id[k]; ntok[pbase + k] = out_n[k]; }
-        }
         // ignore_merges: whole-word vocab hit for keys longer than 16 bytes (bpe/model.rs:559-567); rare, kept off
         // the main path
         if (t.ignore_merges) {
@@ -1608,8 +1598,8 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
                 uint32_t id;
                 if (c >= 2 && len <= t.long_probe_max_len && long_probe(t, text + st[k], len, &id)) {
-                    tok0[pbase + k] = id;
-                    ntok[pbase + k] = 1;
+                    out_id[k] = id;
+                    out_n[k] = 1;
                     cls &= ~(3u << (2 * k));
                 }
             }
@@ -1639,12 +1629,29 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
 #pragma unroll
         for (int k = 0; k < LK_ITEMS; ++k) {
             uint32_t c = (cls >> (2 * k)) & 3u;
-            if (c == 1) list16[o16++] = (uint32_t)(pbase + k);
-            else if (c == 2) list32[o32++] = (uint32_t)(pbase + k);
-            else if (c == 3) {
+            if (c == 1) {
+                // the LDS merge kernel leaves its result in the dense row named by the queue position: point tok0 there now
+                // (coalesced with the neighbours' stores) so that it never has to touch tok0 / ntok
+                if (o16 < rows.cap16) out_id[k] = TOK_ROW | o16;
+                list16[o16++] = (uint32_t)(pbase + k);
+            } else if (c == 2) {
+                if (o32 < rows.cap32) out_id[k] = TOK_ROW | (rows.base32 + o32);
+                list32[o32++] = (uint32_t)(pbase + k);
+            } else if (c == 3) {
                 if (en[k] - st[k] <= 64u) list64[o64++] = (uint32_t)(pbase + k);
                 else listL[oL++] = (uint32_t)(pbase + k);
             }
+        }
+        // tok0 / ntok for all 8 items as 16-byte stores (queued items: a row reference or 0, and ntok 0)
+        if (pbase + LK_ITEMS <= P) {
+            *(uint4*)(tok0 + pbase) = make_uint4(out_id[0], out_id[1], out_id[2], out_id[3]);
+            *(uint4*)(tok0 + pbase + 4) = make_uint4(out_id[4], out_id[5], out_id[6], out_id[7]);
+            *(uint4*)(ntok + pbase) = make_uint4(out_n[0], out_n[1], out_n[2], out_n[3]);
+            *(uint4*)(ntok + pbase + 4) = make_uint4(out_n[4], out_n[5], out_n[6], out_n[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k)
+                if (pbase + k < P) { tok0[pbase + k] = out_id[k]; ntok[pbase + k] = out_n[k]; }
         }
         __syncthreads();
     }
@@ -2019,9 +2026,9 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
         }
         if (valid) {
             const uint32_t c = (uint32_t)__popc(alive);
-            ntok[p] = c;
-            if (c >= 2u && c <= 4u && qidx < row_cap) {
-                // all ids in one dense 16-byte row named by the queue position; tok0 points at it
+            if (qidx < row_cap) {
+                // result row named by the queue position (k_bpe_word_lookup already pointed tok0[p] at it):
+                // x = first id | count << 28 (15: more than four tokens -- count in tmp_ids[s], ids 2.. in tmp_ids[s + j])
                 uint32_t r[4] = {my_sym[0], 0u, 0u, 0u};
                 uint32_t m = alive & ~1u;
 #pragma unroll
@@ -2033,10 +2040,20 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                         m &= m - 1u;
                     }
                 }
+                uint32_t j = 4;
+                if (m) {
+                    tmp_ids[s] = c;
+                    tmp_ids[s + 1] = r[1]; tmp_ids[s + 2] = r[2]; tmp_ids[s + 3] = r[3];
+                    for (; m; m &= m - 1u, ++j) {
+                        const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                        tmp_ids[s + j] = my_sym[pos * NT];
+                        if (tmp_end) tmp_end[s + j - 1] = pos;
+                    }
+                }
                 if (tmp_end) tmp_end[s + c - 1] = len;
-                rows[row_base + qidx] = make_uint4(r[0], r[1], r[2], r[3]);
-                tok0[p] = TOK_ROW | (row_base + qidx);
+                rows[row_base + qidx] = make_uint4(r[0] | (min(c, ROW_CNT_MORE) << ROW_CNT_SHIFT), r[1], r[2], r[3]);
             } else {
+                ntok[p] = c;
                 tok0[p] = my_sym[0];
                 uint32_t j = 1;
                 for (uint32_t m = alive & ~1u; m; m &= m - 1u, ++j) {
@@ -2060,107 +2077,6 @@ static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const
                              void* rows, uint32_t row_base, uint32_t row_cap) {
     hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
                        (uint4*)rows, row_base, rows ? row_cap : 0u);
-}
-
-// =================================================================================================
-// In-batch de-duplication of the merge work queue.  Natural text repeats its rare words too (Zipf), and
-// the reference exploits that with a per-thread word cache (models/bpe/model.rs:82-90, 573-586: a hit
-// returns the cached Word instead of running merge_word).  The device analogue is stateless across calls:
-//   k_dedup_insert : every queued pre-token (<= 16 bytes) claims / finds the slot of its 64-bit key hash in
-//                    an open-addressing table and lowers the slot's representative to the smallest item index
-//   k_dedup_resolve: (next launch, so all table writes are visible) an item whose representative is itself
-//                    goes to the "unique" queue; any other item is byte-compared with its representative --
-//                    equal -> (item, representative) pair in the "duplicate" queue, different (hash
-//                    collision) -> unique.  Exactness therefore never rests on the hash.
-//   merge kernels run on the unique queue only
-//   k_dedup_copy   : duplicates copy their representative's tokens.
-// A table that is too small only costs speed: items that find no slot within 16 probes are unique.
-// =================================================================================================
-__device__ __forceinline__ uint64_t key_hash64(uint64_t lo, uint64_t hi, uint32_t len) {
-    uint64_t h = (lo ^ (hi * 0x9E3779B97F4A7C15ull)) + len * 0xC2B2AE3D27D4EB4Full;
-    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
-    return h | 0x8000000000000000ull;                    // never 0 (0 = empty slot)
-}
-
-__global__ __launch_bounds__(256) void k_dedup_insert(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pt_start,
-                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                      unsigned long long* __restrict__ fp_tab, uint32_t* __restrict__ rep_tab, uint32_t cmask,
-                                                      uint32_t* __restrict__ slot_of) {
-    const uint32_t n = *n_list;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t p = list[i], s = pt_start[p], len = pt_start[p + 1] - s;
-        uint64_t lo, hi;
-        load_key16(text, s, len, &lo, &hi);
-        const unsigned long long fp = key_hash64(lo, hi, len);
-        uint32_t slot = (uint32_t)(fp >> 17) & cmask, found = 0xFFFFFFFFu;
-        for (int probe = 0; probe < 16; ++probe) {
-            unsigned long long v = fp_tab[slot];
-            if (v == 0ull) v = atomicCAS(&fp_tab[slot], 0ull, fp), v = (v == 0ull) ? fp : v;
-            if (v == fp) { found = slot; break; }
-            slot = (slot + 1) & cmask;
-        }
-        if (found != 0xFFFFFFFFu && rep_tab[found] > i) atomicMin(&rep_tab[found], i);
-        slot_of[i] = found;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_dedup_resolve(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pt_start,
-                                                       const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                       const uint32_t* __restrict__ rep_tab, const uint32_t* __restrict__ slot_of,
-                                                       uint32_t* __restrict__ ulist, uint32_t* __restrict__ dlist,
-                                                       uint32_t* __restrict__ counters) {
-    __shared__ uint32_t sm[4];
-    __shared__ uint32_t base_s[2];
-    const uint32_t n = *n_list;
-    const uint32_t n_iter = (n + 255) / 256;
-    for (uint32_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
-        const uint32_t i = it * 256 + threadIdx.x;
-        bool valid = i < n, dup = false;
-        uint32_t p = 0, pr = 0;
-        if (valid) {
-            p = list[i];
-            const uint32_t sl = slot_of[i];
-            if (sl != 0xFFFFFFFFu) {
-                const uint32_t r = rep_tab[sl];
-                if (r != i) {
-                    pr = list[r];
-                    const uint32_t s = pt_start[p], len = pt_start[p + 1] - s, sr = pt_start[pr], lenr = pt_start[pr + 1] - sr;
-                    uint64_t lo, hi, lor, hir;
-                    load_key16(text, s, len, &lo, &hi);
-                    load_key16(text, sr, lenr, &lor, &hir);
-                    dup = (len == lenr) && lo == lor && hi == hir;
-                }
-            }
-        }
-        const uint32_t nu = (valid && !dup) ? 1u : 0u, nd = dup ? 1u : 0u;
-        uint32_t tot;
-        const uint32_t ex = block256_excl_scan(nu | (nd << 16), sm, &tot);
-        if (threadIdx.x == 0) {
-            base_s[0] = (tot & 0xFFFFu) ? atomicAdd(&counters[CNT_ULIST], tot & 0xFFFFu) : 0u;
-            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_DLIST], tot >> 16) : 0u;
-        }
-        __syncthreads();
-        if (nu) ulist[base_s[0] + (ex & 0xFFFFu)] = p;
-        if (nd) { uint32_t o = base_s[1] + (ex >> 16); dlist[2 * o] = p; dlist[2 * o + 1] = pr; }
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(256) void k_dedup_copy(const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ dlist,
-                                                    const uint32_t* __restrict__ n_dup, uint32_t* __restrict__ tok0,
-                                                    uint32_t* __restrict__ ntok, uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
-    const uint32_t n = *n_dup;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const uint32_t p = dlist[2 * i], pr = dlist[2 * i + 1];
-        const uint32_t c = ntok[pr];
-        ntok[p] = c;
-        tok0[p] = tok0[pr];
-        if (c > 1 || tmp_end) {
-            const uint32_t s = pt_start[p], sr = pt_start[pr];
-            for (uint32_t j = 1; j < c; ++j) tmp_ids[s + j] = tmp_ids[sr + j];
-            if (tmp_end) for (uint32_t j = 0; j < c; ++j) tmp_end[s + j] = tmp_end[sr + j];
-        }
-    }
 }
 
 // =================================================================================================
@@ -2501,19 +2417,39 @@ __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8
 constexpr int CP_ITEMS = 4;                       // pre-tokens per thread
 constexpr int CP_CHUNK = 256 * CP_ITEMS;
 
-__global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict__ ntok, const int64_t* __restrict__ n_pretok,
+// number of tokens of pre-token p: from its result row when tok0 references one, else ntok[p]
+__device__ __forceinline__ uint32_t row_count(const uint4& row, const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start, int64_t p) {
+    const uint32_t cf = row.x >> ROW_CNT_SHIFT;
+    return cf < ROW_CNT_MORE ? cf : tmp_ids[pt_start[p]];
+}
+
+__global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
+                                                     const uint4* __restrict__ rows, const uint32_t* __restrict__ tmp_ids,
+                                                     const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
                                                      uint32_t* __restrict__ csum) {
     __shared__ uint32_t sm[4];
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
-        uint32_t v = 0;
-        if (p0 + CP_ITEMS <= P) { const uint4 q = *(const uint4*)(ntok + p0); v = q.x + q.y + q.z + q.w; }
-        else {
+        uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
+        if (p0 + CP_ITEMS <= P) {
+            const uint4 q = *(const uint4*)(ntok + p0), f = *(const uint4*)(tok0 + p0);
+            cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
+            first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
+        } else {
 #pragma unroll
-            for (int k = 0; k < CP_ITEMS; ++k)
-                if (p0 + k < P) v += ntok[p0 + k];
+            for (int k = 0; k < CP_ITEMS; ++k) {
+                cnt[k] = (p0 + k < P) ? ntok[p0 + k] : 0u;
+                first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
+            }
+        }
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            uint32_t c = cnt[k];
+            if (first[k] & TOK_ROW) { const uint4 row = rows[first[k] & ~TOK_ROW]; c = row_count(row, tmp_ids, pt_start, p0 + k); }
+            v += c;
         }
         uint32_t tot;
         block256_excl_scan(v, sm, &tot);
@@ -2544,13 +2480,17 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ nt
                 first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
             }
         }
-        // 2..4-token pre-tokens resolved by the LDS merge kernels keep all their ids in one dense 16-byte row
-        // (tok0 = TOK_ROW | row index): one load here instead of scattered tmp_ids traffic
+        // pre-tokens resolved by the LDS merge kernels keep their count and up to four ids in one dense 16-byte row
+        // (tok0 = TOK_ROW | row index): one load here instead of scattered ntok / tmp_ids traffic
         uint4 row[CP_ITEMS];
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) {
             row[k] = make_uint4(first[k], 0u, 0u, 0u);
-            if (cnt[k] > 1u && (first[k] & TOK_ROW)) row[k] = rows[first[k] & ~TOK_ROW];
+            if (first[k] & TOK_ROW) {
+                row[k] = rows[first[k] & ~TOK_ROW];
+                cnt[k] = row_count(row[k], tmp_ids, pt_start, p0 + k);
+                row[k].x &= ROW_ID_MASK;
+            }
         }
         uint32_t v = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         uint32_t tot;
@@ -2565,7 +2505,7 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ nt
                 if (c) {
                     ids[o] = row[k].x;
                     if (c > 1) {
-                        if (first[k] & TOK_ROW) {
+                        if ((first[k] & TOK_ROW) && c <= 4u) {
                             ids[o + 1] = row[k].y;
                             if (c > 2) ids[o + 2] = row[k].z;
                             if (c > 3) ids[o + 3] = row[k].w;
@@ -2617,9 +2557,9 @@ __global__ __launch_bounds__(256) void k_leadmask(const uint8_t* __restrict__ te
 __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
     const int64_t P = *a.n_pretok;
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
-        const uint32_t c = a.ntok[p];
-        if (!c) continue;
         const uint32_t o = a.pt_tokoff[p];
+        const uint32_t c = ((p + 1 < P) ? a.pt_tokoff[p + 1] : (uint32_t)*a.n_tok) - o;
+        if (!c) continue;
         const uint32_t s = a.pt_start[p], e = a.pt_end ? a.pt_end[p] : a.pt_start[p + 1];
         // document of this pre-token: last d with doc_pt[d] <= p
         int64_t lo = 0, hi = a.n_docs;
@@ -2765,8 +2705,8 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
 }
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                             const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
-                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask) {
-    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters, matchmask);
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask, RowPlan rows) {
+    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters, matchmask, rows);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
@@ -2848,17 +2788,6 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc
     hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, (const uint32_t*)bsum, doc_off, xdoc_off, x_len);
     hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, doc_off, (const int64_t*)xdoc_off, n_docs, xtext);
 }
-void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t* pt_start, const uint32_t* list, const uint32_t* n_list,
-                  unsigned long long* fp_tab, uint32_t* rep_tab, uint32_t cmask, uint32_t* slot_of, uint32_t* ulist, uint32_t* dlist,
-                  uint32_t* counters) {
-    hipLaunchKernelGGL(k_dedup_insert, dim3(grid), dim3(256), 0, st, text, pt_start, list, n_list, fp_tab, rep_tab, cmask, slot_of);
-    hipLaunchKernelGGL(k_dedup_resolve, dim3(grid), dim3(256), 0, st, text, pt_start, list, n_list, (const uint32_t*)rep_tab, (const uint32_t*)slot_of,
-                       ulist, dlist, counters);
-}
-void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
-                       uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end) {
-    hipLaunchKernelGGL(k_dedup_copy, dim3(grid), dim3(256), 0, st, pt_start, dlist, n_dup, tok0, ntok, tmp_ids, tmp_end);
-}
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
     hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
 }
@@ -2903,7 +2832,7 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
 void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
                     const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids,
                     const void* rows) {
-    hipLaunchKernelGGL(k_ntok_reduce, dim3(grid), dim3(256), 0, st, ntok, n_pretok, csum);
+    hipLaunchKernelGGL(k_ntok_reduce, dim3(grid), dim3(256), 0, st, ntok, tok0, (const uint4*)rows, tmp_ids, pt_start, n_pretok, csum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, csum, (int64_t)0, n_pretok, (int64_t)CP_CHUNK, n_tok);
     hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, st, ntok, tok0, tmp_ids, pt_start, n_pretok, (const uint32_t*)csum, (const uint4*)rows, pt_tokoff, ids);
 }

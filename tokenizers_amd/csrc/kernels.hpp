@@ -43,12 +43,17 @@ struct BnTables {
     uint32_t clean, cjk, strip, lower;
 };
 
+// where the LDS merge kernels leave their results: queue position -> dense row (0 capacities: rows off)
+struct RowPlan {
+    uint32_t cap16, base32, cap32;
+};
+
 // arguments of k_token_meta (offsets / word ids), passed by value
 struct MetaArgs {
     const uint8_t* x_text;            // text the pre-tokenizer saw (normalised if a normalizer ran)
     const uint32_t* pt_start;
     const uint32_t* pt_end;           // null: pt_start[p+1]
-    const uint32_t* ntok;
+    const int64_t* n_tok;             // total token count (device scalar)
     const uint32_t* pt_tokoff;
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
     const int64_t* n_pretok;
@@ -106,7 +111,7 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_ULIST = 5, CNT_DLIST = 6, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_COUNT = 12 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_COUNT = 12 };
 
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident); longer ones use the global-scratch kernel
 
@@ -124,7 +129,7 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
 void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                             const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
-                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask);
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask, RowPlan rows = RowPlan{0, 0, 0});
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
                       void* rows = nullptr, uint32_t row_base = 0, uint32_t row_cap = 0);
@@ -149,11 +154,6 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
                           const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
-void launch_dedup(hipStream_t st, int grid, const uint8_t* text, const uint32_t* pt_start, const uint32_t* list, const uint32_t* n_list,
-                  unsigned long long* fp_tab, uint32_t* rep_tab, uint32_t cmask, uint32_t* slot_of, uint32_t* ulist, uint32_t* dlist,
-                  uint32_t* counters);
-void launch_dedup_copy(hipStream_t st, int grid, const uint32_t* pt_start, const uint32_t* dlist, const uint32_t* n_dup, uint32_t* tok0,
-                       uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                         const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,

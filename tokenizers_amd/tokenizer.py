@@ -336,7 +336,7 @@ class Tokenizer:
         """Merge work-queue sizes of the last synchronised batch (diagnostics)."""
         arr = (C.c_uint32 * 8)()
         _lib.check(self._lib.tkamd_profile_counters(self._h, arr, 8))
-        return {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge16_unique": arr[5], "merge16_duplicates": arr[6], "merge_huge": arr[7]}
+        return {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge_huge": arr[7]}
 
     def profile_read(self, reset: bool = True) -> dict[str, tuple[float, int]]:
         arr = (_lib.StageTime * _lib.MAX_STAGES)()
