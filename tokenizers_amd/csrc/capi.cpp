@@ -521,7 +521,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(merge kernel LDS) failed");
             t->long_prepared = true;
         }
-        static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 1; }();
+        static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 2; }();
         static const bool row16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "row"); }();
         static const bool lane16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "lane"); }();
         const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // LDS-resident Word (default when new_id = rank + c)

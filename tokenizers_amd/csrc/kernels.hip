@@ -1919,7 +1919,7 @@ template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const u
 // allows NT = 768 (S = 16) lanes per CU.
 // Same semantics as k_bpe_merge / k_bpe_merge_lane (models/bpe/word.rs:162-250).
 // =================================================================================================
-template <int S, int NT, bool DISP_LDS>
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
 __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text,
                                                       const uint32_t* __restrict__ pt_start,
                                                       const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
@@ -1929,8 +1929,8 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     constexpr uint32_t PB = (S == 16) ? 4 : 5;
     extern __shared__ uint32_t lds_words[];
     uint32_t* s_key = lds_words;                              // [S][NT]
-    uint32_t* s_sym = s_key + S * NT;                         // [S][NT]
-    uint32_t* s_byte_id = s_sym + S * NT;                     // [256]
+    uint32_t* s_sym = s_key + S * NT;                         // [S][NT], absent when the symbols stay in registers
+    uint32_t* s_byte_id = s_sym + (SYM_REGS ? 0 : S * NT);    // [256]
     uint32_t* s_hist = s_byte_id + 256;                       // [S + 1] (+ padding to 64)
     uint16_t* s_disp = (uint16_t*)(s_hist + 64);              // [DISP_LDS_MAX]
     uint4* s_sort = (uint4*)s_key;                            // [NT], aliases the key area between items
@@ -1968,6 +1968,18 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
         }
         uint32_t* my_key = s_key + tid;                       // slot i at my_key[i * NT]
         uint32_t* my_sym = s_sym + tid;
+        // SYM_REGS: symbols stay in registers (a dynamic index is a select chain -- the ALU has the headroom) and only
+        // the keys take LDS, which is what bounds the number of pre-tokens in flight per CU.  The selects are written
+        // out at every use: taking the array's address (a lambda, a helper) would send it to scratch.
+        uint32_t ids[S];
+#define TKAMD_SYM_AT(dst, pos)                                                                 \
+        do {                                                                                   \
+            if (!SYM_REGS) (dst) = my_sym[(pos) * NT];                                         \
+            else {                                                                             \
+                (dst) = ids[0];                                                                \
+                _Pragma("unroll") for (int q_ = 1; q_ < S; ++q_) (dst) = ((pos) == (uint32_t)q_) ? ids[q_] : (dst); \
+            }                                                                                  \
+        } while (0)
         {
             uint64_t kb[S / 8];
 #pragma unroll
@@ -1976,11 +1988,10 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 load_key16(text, s, min(len, 16u), &kb[0], &kb[1]);
                 if (S == 32 && len > 16) load_key16(text, s + 16, len - 16, &kb[S / 8 - 2], &kb[S / 8 - 1]);
             }
-            uint32_t ids[S];
 #pragma unroll
             for (int i = 0; i < S; ++i) {
                 ids[i] = s_byte_id[(uint32_t)((kb[i / 8] >> (8 * (i % 8))) & 0xFFu)];
-                my_sym[i * NT] = ids[i];
+                if (!SYM_REGS) my_sym[i * NT] = ids[i];
             }
 #pragma unroll
             for (int i = 0; i < S; ++i) {
@@ -2012,8 +2023,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                     const bool has_k = above != 0u, has_h = below != 0u;
                     const uint32_t k = has_k ? (uint32_t)__ffs(above) - 1u : i;
                     const uint32_t h = has_h ? 31u - (uint32_t)__clz(below) : i;
-                    const uint32_t sr = my_sym[k * NT], sl = my_sym[h * NT];
-                    my_sym[i * NT] = nid;
+                    uint32_t sr, sl;
+                    TKAMD_SYM_AT(sr, k);
+                    TKAMD_SYM_AT(sl, h);
+                    if (SYM_REGS) {
+#pragma unroll
+                        for (int q = 0; q < S; ++q) ids[q] = (i == (uint32_t)q) ? nid : ids[q];
+                    } else my_sym[i * NT] = nid;
                     uint32_t r1, r2, nd;
                     merge_probe_d(t, disp, sl, nid, &r1, &nd);
                     merge_probe_d(t, disp, nid, sr, &r2, &nd);
@@ -2029,13 +2045,14 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
             if (qidx < row_cap) {
                 // result row named by the queue position (k_bpe_word_lookup already pointed tok0[p] at it):
                 // x = first id | count << 28 (15: more than four tokens -- count in tmp_ids[s], ids 2.. in tmp_ids[s + j])
-                uint32_t r[4] = {my_sym[0], 0u, 0u, 0u};
+                uint32_t r[4] = {ids[0], 0u, 0u, 0u};
+                if (!SYM_REGS) r[0] = my_sym[0];
                 uint32_t m = alive & ~1u;
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
                     if (m) {
                         const uint32_t pos = (uint32_t)__ffs(m) - 1u;
-                        r[j] = my_sym[pos * NT];
+                        TKAMD_SYM_AT(r[j], pos);
                         if (tmp_end) tmp_end[s + j - 1] = pos;
                         m &= m - 1u;
                     }
@@ -2046,7 +2063,9 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                     tmp_ids[s + 1] = r[1]; tmp_ids[s + 2] = r[2]; tmp_ids[s + 3] = r[3];
                     for (; m; m &= m - 1u, ++j) {
                         const uint32_t pos = (uint32_t)__ffs(m) - 1u;
-                        tmp_ids[s + j] = my_sym[pos * NT];
+                        uint32_t v_;
+                        TKAMD_SYM_AT(v_, pos);
+                        tmp_ids[s + j] = v_;
                         if (tmp_end) tmp_end[s + j - 1] = pos;
                     }
                 }
@@ -2054,11 +2073,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 rows[row_base + qidx] = make_uint4(r[0] | (min(c, ROW_CNT_MORE) << ROW_CNT_SHIFT), r[1], r[2], r[3]);
             } else {
                 ntok[p] = c;
-                tok0[p] = my_sym[0];
+                tok0[p] = SYM_REGS ? ids[0] : my_sym[0];
                 uint32_t j = 1;
                 for (uint32_t m = alive & ~1u; m; m &= m - 1u, ++j) {
                     const uint32_t pos = (uint32_t)__ffs(m) - 1u;
-                    tmp_ids[s + j] = my_sym[pos * NT];
+                    uint32_t v_;
+                    TKAMD_SYM_AT(v_, pos);
+                    tmp_ids[s + j] = v_;
                     if (tmp_end) tmp_end[s + j - 1] = pos;                // the previous token ends where this one starts
                 }
                 if (tmp_end) tmp_end[s + j - 1] = len;
@@ -2066,16 +2087,17 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
         }
     }
 }
-constexpr int lds_merge_bytes(int S, int NT, bool disp_lds) { return (2 * S * NT + 256 + 64) * 4 + (disp_lds ? DISP_LDS_MAX * 2 : 0); }
-template <int S, int NT, bool DISP_LDS>
+#undef TKAMD_SYM_AT
+constexpr int lds_merge_bytes(int S, int NT, bool disp_lds, bool sym_regs) { return ((sym_regs ? 1 : 2) * S * NT + 256 + 64) * 4 + (disp_lds ? DISP_LDS_MAX * 2 : 0); }
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
 static int prepare_lds_merge() {
-    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS));
+    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
 }
-template <int S, int NT, bool DISP_LDS>
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
 static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                              const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
                              void* rows, uint32_t row_base, uint32_t row_cap) {
-    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
+    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
                        (uint4*)rows, row_base, rows ? row_cap : 0u);
 }
 
@@ -2712,10 +2734,10 @@ void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, c
                       const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
                       void* rows, uint32_t row_base, uint32_t row_cap) {
     // LDS-resident Word (needs newid_affine; prepare_long_kernel() raised the LDS limit)
-    if (group == 3) launch_lds_merge<16, 768, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
-    else if (group == 4) launch_lds_merge<32, 384, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
-    else if (group == 5) launch_lds_merge<16, 1024, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
-    else if (group == 6) launch_lds_merge<32, 512, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    if (group == 3) launch_lds_merge<16, 768, true, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 4) launch_lds_merge<32, 384, true, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);   // two 704-lane workgroups per CU
+    else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
     else if (group == 1)
         hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
     else if (group == 2)
@@ -2814,10 +2836,10 @@ void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const ui
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {
     int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
-    if (rc == 0) rc = prepare_lds_merge<16, 768, true>();
-    if (rc == 0) rc = prepare_lds_merge<32, 384, true>();
-    if (rc == 0) rc = prepare_lds_merge<16, 1024, false>();
-    if (rc == 0) rc = prepare_lds_merge<32, 512, false>();
+    if (rc == 0) rc = prepare_lds_merge<16, 768, true, false>();
+    if (rc == 0) rc = prepare_lds_merge<32, 384, true, false>();
+    if (rc == 0) rc = prepare_lds_merge<16, 704, true, true>();
+    if (rc == 0) rc = prepare_lds_merge<32, 768, true, true>();
     return rc;
 }
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
