@@ -1511,6 +1511,7 @@ __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __
 
 constexpr uint32_t TOK_ROW = 0x80000000u;         // tok0 flag: the low bits index a dense result row {id0 | count << 28, id1, id2, id3}
 constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
+constexpr uint32_t TOK_ONE = 0x40000000u;         // tok0 flag: exactly one token, its id in the low bits (ntok[p] is not written)
 constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
 constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
 constexpr int LK_CHUNK = 256 * LK_ITEMS;
@@ -1556,7 +1557,7 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
         }
         uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list32, 3 -> list64 / listL
         uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
-        uint32_t out_id[LK_ITEMS], out_n[LK_ITEMS];
+        uint32_t out_id[LK_ITEMS];
 #pragma unroll
         for (int g = 0; g < LK_ITEMS; g += LK_GROUP) {
             uint64_t lo[LK_GROUP], hi[LK_GROUP];
@@ -1582,8 +1583,7 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && hit && (t.ignore_merges || (a1[k].z & WORD_DIRECT));
                 // an added-token match is one pre-token whose id is patched in later (k_apply_match_ids): never queued
                 const bool is_match = matchmask && valid && ((matchmask[st[g + k] >> 6] >> (st[g + k] & 63)) & 1ull);
-                out_id[g + k] = (done && !is_match) ? a1[k].y : 0u;
-                out_n[g + k] = (done && !is_match) ? 1u : 0u;
+                out_id[g + k] = (done && !is_match) ? (TOK_ONE | a1[k].y) : 0u;
                 if (valid && !done && !is_match) {
                     uint32_t c = len[k] <= 16 ? 1u : (len[k] <= 32 ? 2u : 3u);
                     cls |= c << (2 * (g + k));
@@ -1598,8 +1598,7 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
                 uint32_t id;
                 if (c >= 2 && len <= t.long_probe_max_len && long_probe(t, text + st[k], len, &id)) {
-                    out_id[k] = id;
-                    out_n[k] = 1;
+                    out_id[k] = TOK_ONE | id;
                     cls &= ~(3u << (2 * k));
                 }
             }
@@ -1642,16 +1641,16 @@ __global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint
                 else listL[oL++] = (uint32_t)(pbase + k);
             }
         }
-        // tok0 / ntok for all 8 items as 16-byte stores (queued items: a row reference or 0, and ntok 0)
+        // tok0 for all 8 items as 16-byte stores: TOK_ONE | id (settled here), TOK_ROW | row (the LDS merge kernels leave the
+        // result there) or 0 (another merge kernel, or k_apply_match_ids, writes plain tok0 / ntok later).  ntok is never
+        // written here: every pre-token without a flag gets it from the kernel that resolves it.
         if (pbase + LK_ITEMS <= P) {
             *(uint4*)(tok0 + pbase) = make_uint4(out_id[0], out_id[1], out_id[2], out_id[3]);
             *(uint4*)(tok0 + pbase + 4) = make_uint4(out_id[4], out_id[5], out_id[6], out_id[7]);
-            *(uint4*)(ntok + pbase) = make_uint4(out_n[0], out_n[1], out_n[2], out_n[3]);
-            *(uint4*)(ntok + pbase + 4) = make_uint4(out_n[4], out_n[5], out_n[6], out_n[7]);
         } else {
 #pragma unroll
             for (int k = 0; k < LK_ITEMS; ++k)
-                if (pbase + k < P) { tok0[pbase + k] = out_id[k]; ntok[pbase + k] = out_n[k]; }
+                if (pbase + k < P) tok0[pbase + k] = out_id[k];
         }
         __syncthreads();
     }
@@ -2439,33 +2438,45 @@ __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8
 constexpr int CP_ITEMS = 4;                       // pre-tokens per thread
 constexpr int CP_CHUNK = 256 * CP_ITEMS;
 
-// number of tokens of pre-token p: from its result row when tok0 references one, else ntok[p]
+// tok0 / ntok decoding shared by the two compaction passes: the count of pre-token p is 1 (TOK_ONE), in its result
+// row (TOK_ROW) or in ntok[p] (everything else -- the only case that reads ntok)
 __device__ __forceinline__ uint32_t row_count(const uint4& row, const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start, int64_t p) {
     const uint32_t cf = row.x >> ROW_CNT_SHIFT;
     return cf < ROW_CNT_MORE ? cf : tmp_ids[pt_start[p]];
+}
+__device__ __forceinline__ void load_counts(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0, int64_t p0, int64_t P,
+                                            uint32_t (&cnt)[4], uint32_t (&first)[4]) {
+    if (p0 + 4 <= P) {                                // 16-byte loads (p0 is a multiple of 4)
+        const uint4 f = *(const uint4*)(tok0 + p0);
+        first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        constexpr uint32_t FL = TOK_ONE | TOK_ROW;
+        if (!((f.x & FL) && (f.y & FL) && (f.z & FL) && (f.w & FL))) q = *(const uint4*)(ntok + p0);   // some item carries neither flag
+        cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (first[k] & TOK_ONE) cnt[k] = 1u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
+            cnt[k] = (p0 + k < P) ? ((first[k] & TOK_ONE) ? 1u : ((first[k] & TOK_ROW) ? 0u : ntok[p0 + k])) : 0u;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
                                                      const uint4* __restrict__ rows, const uint32_t* __restrict__ tmp_ids,
                                                      const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
                                                      uint32_t* __restrict__ csum) {
+    static_assert(CP_ITEMS == 4, "load_counts handles four pre-tokens per thread");
     __shared__ uint32_t sm[4];
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
         int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
         uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
-        if (p0 + CP_ITEMS <= P) {
-            const uint4 q = *(const uint4*)(ntok + p0), f = *(const uint4*)(tok0 + p0);
-            cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
-            first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < CP_ITEMS; ++k) {
-                cnt[k] = (p0 + k < P) ? ntok[p0 + k] : 0u;
-                first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
-            }
-        }
+        load_counts(ntok, tok0, p0, P, cnt, first);
         uint32_t v = 0;
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) {
@@ -2491,23 +2502,13 @@ __global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ nt
         int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
         uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
         const bool full = p0 + CP_ITEMS <= P;
-        if (full) {                                   // 16-byte loads (p0 is a multiple of 4)
-            const uint4 q = *(const uint4*)(ntok + p0), f = *(const uint4*)(tok0 + p0);
-            cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
-            first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < CP_ITEMS; ++k) {
-                cnt[k] = (p0 + k < P) ? ntok[p0 + k] : 0u;
-                first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
-            }
-        }
+        load_counts(ntok, tok0, p0, P, cnt, first);
         // pre-tokens resolved by the LDS merge kernels keep their count and up to four ids in one dense 16-byte row
         // (tok0 = TOK_ROW | row index): one load here instead of scattered ntok / tmp_ids traffic
         uint4 row[CP_ITEMS];
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) {
-            row[k] = make_uint4(first[k], 0u, 0u, 0u);
+            row[k] = make_uint4(first[k] & ~TOK_ONE, 0u, 0u, 0u);
             if (first[k] & TOK_ROW) {
                 row[k] = rows[first[k] & ~TOK_ROW];
                 cnt[k] = row_count(row[k], tmp_ids, pt_start, p0 + k);
