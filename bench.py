@@ -9,8 +9,9 @@ A "step" = one pass of the whole hot path (pre-tokenize -> BPE -> ids CSR) over 
 is already resident in HBM.  Workload = BASELINE.json configs[1]: GPT-2 style byte-level BPE
 (50,257 vocab / 50k merges, trained by the reference's own trainer on synthetic pseudo-English),
 1,000,000 synthetic ~120-byte lines per GPU (weak scaling: every rank encodes its own shard,
-documents are independent, mod.rs:1345-1348).  With N > 1 each step ends with the RCCL gather of
-the final id buffers + per-document counts to rank 0 (the only exchange step of the path).
+documents are independent, mod.rs:1345-1348, so the path has no exchange step and the timed
+region contains no collective).  `--gather` adds the optional collect-to-root of the final id
+buffers + per-document counts over RCCL (tokenizers_amd.parallel.gather_to_root) to every step.
 
 Rank 0 prints ONE JSON line (see the field list in the repo instructions) with two extra
 objects: "roofline" (dominant kernel, HIP-event timed) and "cpu_baseline" (the reference wheel's
@@ -43,7 +44,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lines", type=int, default=1_000_000, help="documents per GPU per step")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the RCCL gather of the final buffers")
+    ap.add_argument("--gather", action="store_true", help="N>1: end every step with the RCCL collect-to-root of the final buffers")
+    ap.add_argument("--no-gather", action="store_true", help="(default behaviour; kept for old command lines)")
     ap.add_argument("--force-gather", action="store_true", help="run the gather code path even with one rank (self-test)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
@@ -106,7 +108,7 @@ def main() -> None:
     d_text = torch.from_numpy(buf).to(dev)
     d_off = torch.from_numpy(doc_off).to(dev)
     stream = torch.cuda.current_stream().cuda_stream
-    gather = (world > 1 and not args.no_gather) or args.force_gather
+    gather = (world > 1 and args.gather and not args.no_gather) or args.force_gather
 
     def step():
         b = tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, stream=stream)

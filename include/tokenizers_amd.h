@@ -123,6 +123,29 @@ int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const
                               tkamd_device_result* out);
 int tkamd_device_sync(tkamd_tokenizer* tok, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens);
 
+/* ---- decode_batch: token ids -> text -----------------------------------------------------------
+ * Replaces Tokenizer::decode_batch (tokenizer/mod.rs:1404-1416) = map of Tokenizer::decode (mod.rs:935-953):
+ * id -> token string (added vocabulary first, added_vocabulary.rs:239-246; ids without a token are dropped),
+ * specials dropped when TKAMD_SKIP_SPECIAL (skip_special_tokens), then the `decoder` section:
+ * ByteLevel (pre_tokenizers/byte_level.rs:155-171), WordPiece (decoders/wordpiece.rs:46-64) or none (join
+ * with " ").  Other decoders -> TKAMD_ERR_UNSUPPORTED.  The result is the raw byte string per sequence; the
+ * ByteLevel decoder's String::from_utf8_lossy (byte_level.rs:170) is left to the caller (bytes that do not
+ * form valid UTF-8 can only come from id sequences that split a character), e.g. Python's
+ * bytes.decode("utf-8", "replace"), which substitutes the same maximal invalid subparts. */
+#define TKAMD_SKIP_SPECIAL 1u
+typedef struct tkamd_text tkamd_text;
+int tkamd_decode_batch(tkamd_tokenizer* tok, const uint32_t* ids, const int64_t* tok_offsets, int64_t n_docs,
+                       uint32_t flags, tkamd_text** out);
+int64_t         tkamd_text_n_docs(const tkamd_text* b);
+int64_t         tkamd_text_n_bytes(const tkamd_text* b);
+const uint8_t*  tkamd_text_bytes(const tkamd_text* b);         /* [n_bytes]                    */
+const int64_t*  tkamd_text_doc_offsets(const tkamd_text* b);   /* [n_docs+1] CSR into bytes    */
+void            tkamd_text_free(tkamd_text* b);
+/* The byte string token `id` contributes (first_position != 0: as the first kept token of a sequence), straight from
+ * the load-time decode tables; *flags = 0 ordinary, 1 special, 2 no token has this id.  Works on host-only handles. */
+int tkamd_decode_token(const tkamd_tokenizer* tok, uint32_t id, int first_position, uint8_t* out, int32_t cap,
+                       int32_t* len, int32_t* flags);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
  * With profiling on, every kernel launch of the next device/host encode calls is bracketed by
  * HIP events on the launch stream.  tkamd_profile_read returns, per kernel, the accumulated

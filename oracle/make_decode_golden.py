@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Golden vectors for decode_batch, produced by the reference wheel (tokenizers==0.22.2) in this container.
+
+  python oracle/make_decode_golden.py      ->  tests/golden/decode_vectors.json.gz
+
+For every case: the golden tokenizer it starts from (tests/golden/<name>.json.gz), an optional `decoder` section
+that replaces the tokenizer's own, id sequences (real encodings of the committed documents, the same with special
+tokens, random ids -- which split multi-byte characters and hit ids without a token -- and empty sequences) and
+the wheel's Tokenizer.decode_batch output with skip_special_tokens = True and False.
+TEST INFRASTRUCTURE ONLY (see oracle/README.md).
+"""
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests.helpers import GOLD, load_tokenizer_json, load_vectors  # noqa: E402
+
+from tokenizers import Tokenizer  # noqa: E402
+
+CASES = [
+    ("gpt2_synth_50257", None),
+    ("gpt2_added_tokens", None),
+    ("llama3_small_6000_specials", None),
+    ("bert_wordpiece_4000_specials", None),                                                   # decoder: null -> join(" ")
+    ("bert_wordpiece_4000_specials", {"type": "WordPiece", "prefix": "##", "cleanup": True}),
+    ("bert_wordpiece_4000_specials", {"type": "WordPiece", "prefix": "##", "cleanup": False}),
+    ("wordlevel_whitespace_c1", None),
+]
+
+
+def main():
+    out = []
+    for k, (name, decoder) in enumerate(CASES):
+        d = json.loads(load_tokenizer_json(name))
+        if decoder is not None:
+            d["decoder"] = decoder
+        js = json.dumps(d)
+        tok = Tokenizer.from_str(js)
+        vec = load_vectors(name)
+        docs = vec["docs"][:120]
+        rng = np.random.default_rng(1000 + k)
+        n_ids = tok.get_vocab_size(with_added_tokens=True)
+        seqs = [e.ids for e in tok.encode_batch(docs, add_special_tokens=False)]
+        seqs += [e.ids for e in tok.encode_batch(docs[:40], add_special_tokens=True)]
+        for _ in range(60):                                   # random ids: split characters, unknown ids, specials anywhere
+            n = int(rng.integers(0, 24))
+            seqs.append([int(x) for x in rng.integers(0, n_ids + 5, size=n)])
+        seqs += [[], [0], []]
+        out.append({"tokenizer": name, "decoder": decoder, "has_decoder_override": decoder is not None, "seqs": seqs,
+                    "skip_true": tok.decode_batch(seqs, skip_special_tokens=True),
+                    "skip_false": tok.decode_batch(seqs, skip_special_tokens=False)})
+        print(name, decoder, len(seqs), "sequences")
+    with gzip.open(os.path.join(GOLD, "decode_vectors.json.gz"), "wt", encoding="utf-8") as fh:
+        json.dump({"wheel": "tokenizers==0.22.2", "cases": out}, fh)
+
+
+if __name__ == "__main__":
+    main()

@@ -111,3 +111,37 @@ def test_product_never_imports_the_oracle_or_the_wheel():
                 src = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert "oracle" not in src.replace("oracle/gen_unicode_tables.py", "").lower() or f == "unicode_ranges.inc", f
                 assert "import tokenizers\n" not in src and "from tokenizers " not in src, f
+
+
+def test_decode_tables_match_the_oracle_token_by_token():
+    """Host logic of decode_batch (no GPU): the per-id byte strings built at load time -- the device path only gathers
+    them -- equal what the decode oracle produces for that token alone / after another token."""
+    import gzip
+    import json
+    import os
+    from oracle.decode_oracle import DecodeOracle
+    from tests.helpers import GOLD, load_tokenizer_json
+    import tokenizers_amd as ta
+    with gzip.open(os.path.join(GOLD, "decode_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        cases = json.load(fh)["cases"]
+    for case in cases:
+        d = json.loads(load_tokenizer_json(case["tokenizer"]))
+        if case["has_decoder_override"]:
+            d["decoder"] = case["decoder"]
+        js = json.dumps(d)
+        tk = ta.Tokenizer.from_str(js, device=-1)
+        o = DecodeOracle(js)
+        ids = sorted(o.id2tok)
+        anchor = ids[len(ids) // 2]                      # any ordinary token to put in front
+        front = o.decode_bytes([anchor], False)
+        step = max(1, len(ids) // 1500)
+        for i in ids[::step] + ids[-8:] + [ids[-1] + 1, ids[-1] + 1000]:
+            first, fl = tk.decode_token(i, True)
+            rest, fl2 = tk.decode_token(i, False)
+            assert fl == fl2
+            if i not in o.id2tok:
+                assert fl == 2 and first == b"" and rest == b""
+                continue
+            assert fl == (1 if o.id2tok[i] in o.special else 0), (case["tokenizer"], i)
+            assert first == o.decode_bytes([i], False), (case["tokenizer"], case["decoder"], i)
+            assert front + rest == o.decode_bytes([anchor, i], False), (case["tokenizer"], case["decoder"], i)

@@ -202,3 +202,60 @@ def test_oracle_vs_wheel_live(name, ref_tokenizers):
         m = char_to_byte(docs[i])
         assert r.doc_offsets(i) == [(m[a], m[b]) for a, b in e.offsets], docs[i]
         assert r.doc_words(i) == e.word_ids, docs[i]
+
+
+# ---- decode path: the Python restatement (oracle/decode_oracle.py) pinned against the wheel ------------------------
+
+def _decode_cases():
+    import gzip
+    import os
+    from tests.helpers import GOLD
+    with gzip.open(os.path.join(GOLD, "decode_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        return json.load(fh)["cases"]
+
+
+def _decode_case_json(case) -> str:
+    d = json.loads(load_tokenizer_json(case["tokenizer"]))
+    if case["has_decoder_override"]:
+        d["decoder"] = case["decoder"]
+    return json.dumps(d)
+
+
+def test_decode_oracle_matches_golden_vectors():
+    """ids -> text of the restatement == the reference wheel's decode_batch (vectors from oracle/make_decode_golden.py):
+    real encodings with and without special tokens, random ids that split multi-byte characters or have no token."""
+    from oracle.decode_oracle import DecodeOracle
+    for case in _decode_cases():
+        o = DecodeOracle(_decode_case_json(case))
+        assert o.decode_batch(case["seqs"], True) == case["skip_true"], (case["tokenizer"], case["decoder"])
+        assert o.decode_batch(case["seqs"], False) == case["skip_false"], (case["tokenizer"], case["decoder"])
+
+
+def test_ref_decoder_known_answers():
+    from oracle.decode_oracle import DecodeOracle, bytes_char
+    # decoders/wordpiece.rs:70-86 (cleanup off): "##uelo Ara ##új ##o No ##guera" -> "##uelo Araújo Noguera"
+    toks = ["##uelo", "Ara", "##új", "##o", "No", "##guera"]
+    js = json.dumps({"added_tokens": [], "decoder": {"type": "WordPiece", "prefix": "##", "cleanup": False},
+                     "model": {"type": "WordPiece", "vocab": {t: i for i, t in enumerate(toks)}}})
+    assert DecodeOracle(js).decode(list(range(6)), False) == "##uelo Araújo Noguera"
+    # pre_tokenizers/byte_level.rs:298-322: "Hello my friend, how is your day going?" survives encode -> decode
+    b2c = bytes_char()
+    words = ["Hello", " my", " friend", ",", " how", " is", " your", " day", " going", "?"]
+    vocab = {"".join(b2c[b] for b in w.encode()): i for i, w in enumerate(words)}
+    js = json.dumps({"added_tokens": [], "decoder": {"type": "ByteLevel"}, "model": {"type": "BPE", "vocab": vocab, "merges": []}})
+    assert DecodeOracle(js).decode(list(range(10)), False) == "Hello my friend, how is your day going?"
+
+
+def test_decode_oracle_matches_reference_wheel_live():
+    tokenizers = pytest.importorskip("tokenizers")
+    import numpy as np
+    from oracle.decode_oracle import DecodeOracle
+    for name in ("gpt2_added_tokens", "llama3_small_6000_specials", "bert_wordpiece_4000_specials"):
+        js = load_tokenizer_json(name)
+        ref = tokenizers.Tokenizer.from_str(js)
+        o = DecodeOracle(js)
+        rng = np.random.default_rng(7)
+        n_ids = ref.get_vocab_size(with_added_tokens=True)
+        seqs = [[int(x) for x in rng.integers(0, n_ids + 3, size=int(rng.integers(0, 40)))] for _ in range(400)]
+        for skip in (True, False):
+            assert o.decode_batch(seqs, skip) == ref.decode_batch(seqs, skip_special_tokens=skip), (name, skip)

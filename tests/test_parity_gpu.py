@@ -407,3 +407,70 @@ def test_added_vocabulary_overlap_quirk_is_refused():
     assert len(tok.encode_batch_fast(["fine <|pad|> x"], add_special_tokens=False)) == 1
     with pytest.raises(ta.UnsupportedError, match="added/special token"):
         tok.encode_batch_fast(["<|pad|>  x"], add_special_tokens=False)      # the "  " token starts inside the stripped whitespace
+
+
+# ---- decode_batch: ids -> text on the device ---------------------------------------------
+
+def _decode_cases():
+    import gzip
+    import json
+    import os
+    from tests.helpers import GOLD
+    with gzip.open(os.path.join(GOLD, "decode_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        return json.load(fh)["cases"]
+
+
+def _decode_case_json(case) -> str:
+    import json
+    d = json.loads(load_tokenizer_json(case["tokenizer"]))
+    if case["has_decoder_override"]:
+        d["decoder"] = case["decoder"]
+    return json.dumps(d)
+
+
+@pytest.mark.parametrize("k", range(7))
+def test_decode_batch_matches_golden(k):
+    """Device decode_batch == the reference wheel's decode_batch on the committed vectors (ByteLevel, WordPiece with and
+    without cleanup, no decoder; sequences with specials, random ids that split characters or have no token, empty ones)."""
+    import tokenizers_amd as ta
+    case = _decode_cases()[k]
+    tk = ta.Tokenizer.from_str(_decode_case_json(case), device=0)
+    assert tk.decode_batch(case["seqs"], skip_special_tokens=True) == case["skip_true"]
+    assert tk.decode_batch(case["seqs"], skip_special_tokens=False) == case["skip_false"]
+    assert tk.decode(case["seqs"][0], skip_special_tokens=False) == case["skip_false"][0]
+
+
+def test_decode_batch_vs_oracle_random_ids():
+    import tokenizers_amd as ta
+    from oracle.decode_oracle import DecodeOracle
+    for name in ("gpt2_added_tokens", "bert_wordpiece_4000_specials"):
+        js = load_tokenizer_json(name)
+        tk = ta.Tokenizer.from_str(js, device=0)
+        o = DecodeOracle(js)
+        rng = np.random.default_rng(99)
+        n_ids = max(o.id2tok) + 1
+        seqs = [[int(x) for x in rng.integers(0, n_ids + 4, size=int(rng.integers(0, 300)))] for _ in range(3000)]
+        for skip in (True, False):
+            assert tk.decode_batch(seqs, skip_special_tokens=skip) == o.decode_batch(seqs, skip)
+
+
+def test_decode_round_trip_full_size(gpt2):
+    """Size-independent property at BASELINE size: byte-level BPE without a normalizer or prefix space is lossless, so
+    decode(encode(docs)) gives the documents back, byte for byte (1M lines, 120 MB)."""
+    docs = synth.gen_lines(1_000_000, text_seed=77)
+    enc = gpt2.encode_batch_fast(docs, add_special_tokens=False)
+    raw, off = gpt2.decode_batch_csr(enc.ids, enc.tok_offsets, skip_special_tokens=False)
+    import tokenizers_amd as ta
+    buf, doc_off = ta.pack_documents(docs)
+    assert off.tolist() == doc_off.tolist()
+    assert (raw == buf[:len(raw)]).all()
+
+
+def test_decode_unsupported_decoder_is_refused():
+    import json
+    import tokenizers_amd as ta
+    d = json.loads(load_tokenizer_json("gpt2_synth_50257"))
+    d["decoder"] = {"type": "Metaspace", "replacement": "▁", "prepend_scheme": "always", "split": True}
+    tk = ta.Tokenizer.from_str(json.dumps(d), device=0)
+    with pytest.raises(ta.UnsupportedError):
+        tk.decode_batch([[1, 2, 3]])

@@ -22,6 +22,7 @@ OFFSETS_BYTE = 1
 OFFSETS_CHAR = 2
 WANT_WORD_IDS = 4
 ADD_SPECIAL = 8
+SKIP_SPECIAL = 1          # tkamd_decode_batch flag
 TEXT_PAD = 64
 MAX_STAGES = 24
 
@@ -32,6 +33,8 @@ SYMBOLS = [
     "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version",
+    "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
+    "tkamd_text_free", "tkamd_decode_token",
 ]
 
 
@@ -104,6 +107,16 @@ def load() -> C.CDLL:
     lib.tkamd_tokenizer_specials.restype = i32
     lib.tkamd_profile_counters.argtypes = [vp, C.POINTER(u32), i32]
     lib.tkamd_profile_counters.restype = i32
+    lib.tkamd_decode_batch.argtypes = [vp, vp, vp, i64, u32, C.POINTER(vp)]
+    lib.tkamd_decode_batch.restype = i32
+    for name, rt in (("tkamd_text_n_docs", i64), ("tkamd_text_n_bytes", i64), ("tkamd_text_bytes", vp), ("tkamd_text_doc_offsets", vp)):
+        f = getattr(lib, name)
+        f.argtypes = [vp]
+        f.restype = rt
+    lib.tkamd_text_free.argtypes = [vp]
+    lib.tkamd_text_free.restype = None
+    lib.tkamd_decode_token.argtypes = [vp, u32, i32, vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.tkamd_decode_token.restype = i32
     _lib = lib
     return lib
 

@@ -82,10 +82,11 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_trie, t_at_blob, t_at_off, t_at_first;
+    DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
+    DevBuf dw_ids, dw_tok_off, dw_first, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
         w_match_docs, w_match_list;
     // host entry staging
@@ -145,6 +146,12 @@ struct tkamd_batch {
     ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); }
 };
 
+struct tkamd_text {
+    int64_t n_docs = 0, n_bytes = 0;
+    PinnedBlock bytes, doc_offsets;
+    ~tkamd_text() { pinned_put(bytes); pinned_put(doc_offsets); }
+};
+
 namespace {
 
 // scalars block layout (int64 slots)
@@ -199,6 +206,10 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_merge_disp, hm.merge_disp);
     upload(t->t_words, hm.word_table, 64);
     upload(t->t_word_disp, hm.word_disp);
+    if (hm.decoder != DEC_UNSUPPORTED) {
+        upload(t->t_dec_entry, hm.dec_entry, 64);
+        upload(t->t_dec_blob, hm.dec_blob, 64);
+    }
     upload(t->t_long_blob, hm.long_blob);
     upload(t->t_long_off, hm.long_off);
     upload(t->t_long_id, hm.long_id);
@@ -772,12 +783,13 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
         DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_at_id, &t->t_at_flags, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
+                         &t->t_long_id, &t->t_long_table, &t->t_at_id, &t->t_at_flags, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_dec_entry, &t->t_dec_blob, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
                          &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
                          &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
                          &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2, &t->w_candmask, &t->w_matchmask, &t->w_spanmask,
                          &t->w_stopmask, &t->w_hardmask, &t->w_match_docs, &t->w_match_list,
-                         &t->h_text, &t->h_doc_off};
+                         &t->h_text, &t->h_doc_off,
+                         &t->dw_ids, &t->dw_tok_off, &t->dw_first, &t->dw_len, &t->dw_bsum, &t->dw_pos, &t->dw_out_off, &t->dw_bytes, &t->dw_total};
         for (DevBuf* b : all) b->release();
     }
     delete t;
@@ -885,6 +897,84 @@ const int64_t* tkamd_batch_tok_offsets(const tkamd_batch* b) { return b ? (const
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b) { return (b && b->has_offsets) ? (const uint32_t*)b->offsets.p : nullptr; }
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b) { return (b && b->has_words) ? (const uint32_t*)b->word_ids.p : nullptr; }
 void tkamd_batch_free(tkamd_batch* b) { delete b; }
+
+// ---- decode_batch (tokenizer/mod.rs:1404-1416): ids CSR -> UTF-8 bytes CSR ----------------------------------------
+int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* tok_offsets, int64_t n_docs, uint32_t flags,
+                       tkamd_text** out) {
+    if (!t || !out || !tok_offsets || n_docs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(t->mu);
+        const HostModel& hm = t->hm;
+        if (hm.decoder == DEC_UNSUPPORTED) throw Unsupported("decode_batch: " + hm.dec_unsupported);
+        HIP_CHECK(hipSetDevice(t->device));
+        const int64_t n_tok = tok_offsets[n_docs];
+        if (n_tok < 0 || tok_offsets[0] != 0) throw Invalid("tok_offsets is not a monotone CSR over [0, n_tokens]");
+        for (int64_t d = 0; d < n_docs; ++d)
+            if (tok_offsets[d + 1] < tok_offsets[d]) throw Invalid("tok_offsets is not monotone");
+        if (n_tok > 0 && !ids) throw Invalid("null ids");
+        if (n_tok >= ((int64_t)1 << 31)) throw Invalid("more than 2^31 tokens in one decode_batch call");
+        hipStream_t st = nullptr;
+        const uint32_t n_ids = (uint32_t)(hm.dec_entry.size() / 4);
+        const size_t nb = (size_t)(n_tok / 256 + 2);
+        t->dw_ids.reserve((size_t)n_tok * 4 + 64);
+        t->dw_tok_off.reserve((size_t)(n_docs + 1) * 8);
+        t->dw_first.reserve((size_t)(n_tok / 32 + 2) * 4);
+        t->dw_len.reserve((size_t)n_tok * 4 + 64);
+        t->dw_bsum.reserve(nb * 4);
+        t->dw_pos.reserve((size_t)n_tok * 4 + 64);
+        t->dw_out_off.reserve((size_t)(n_docs + 1) * 8);
+        t->dw_total.reserve(64);
+        if (n_tok) HIP_CHECK(hipMemcpyAsync(t->dw_ids.p, ids, (size_t)n_tok * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(t->dw_tok_off.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
+        uint32_t* firstmask = hm.dec_position_dependent ? t->dw_first.as<uint32_t>() : nullptr;
+        const uint32_t skip = (flags & TKAMD_SKIP_SPECIAL) ? 1u : 0u;
+        launch_decode(st, t->dw_ids.as<uint32_t>(), t->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
+                      firstmask, t->dw_len.as<uint32_t>(), t->dw_bsum.as<uint32_t>(), t->dw_pos.as<uint32_t>(), t->dw_total.as<int64_t>(),
+                      t->dw_out_off.as<int64_t>(), nullptr);
+        HIP_CHECK(hipGetLastError());
+        int64_t total = 0;
+        HIP_CHECK(hipMemcpyAsync(&total, t->dw_total.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (total >= ((int64_t)1 << 32)) throw Invalid("decoded text beyond 4 GiB in one decode_batch call");
+        t->dw_bytes.reserve((size_t)total + 64);
+        launch_decode(st, t->dw_ids.as<uint32_t>(), t->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
+                      firstmask, t->dw_len.as<uint32_t>(), t->dw_bsum.as<uint32_t>(), t->dw_pos.as<uint32_t>(), t->dw_total.as<int64_t>(),
+                      t->dw_out_off.as<int64_t>(), t->dw_bytes.as<uint8_t>());
+        HIP_CHECK(hipGetLastError());
+        std::unique_ptr<tkamd_text> b(new tkamd_text());
+        b->n_docs = n_docs;
+        b->n_bytes = total;
+        b->bytes = pinned_get((size_t)total);
+        b->doc_offsets = pinned_get((size_t)(n_docs + 1) * 8);
+        if (total) HIP_CHECK(hipMemcpyAsync(b->bytes.p, t->dw_bytes.p, (size_t)total, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(b->doc_offsets.p, t->dw_out_off.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        *out = b.release();
+        return TKAMD_OK;
+    });
+}
+int tkamd_decode_token(const tkamd_tokenizer* t, uint32_t id, int first_position, uint8_t* out, int32_t cap, int32_t* len, int32_t* flags) {
+    if (!t || !len || !flags) return set_error(TKAMD_ERR_INVALID, "null argument");
+    const HostModel& hm = t->hm;
+    if (hm.decoder == DEC_UNSUPPORTED) return set_error(TKAMD_ERR_UNSUPPORTED, "decode_batch: " + hm.dec_unsupported);
+    *len = 0;
+    *flags = 2;                                              // absent
+    if ((size_t)id * 4 + 3 >= hm.dec_entry.size()) return TKAMD_OK;
+    const uint32_t* e = &hm.dec_entry[(size_t)id * 4];
+    if (e[1] & DEC_ABSENT) return TKAMD_OK;
+    *flags = (e[1] & DEC_SPECIAL) ? 1 : 0;
+    const uint32_t off = first_position ? e[0] : e[2], l = first_position ? (e[1] & DEC_LEN_MASK) : e[3];
+    *len = (int32_t)l;
+    for (uint32_t i = 0; i < l && (int32_t)i < cap && out; ++i) out[i] = hm.dec_blob[off + i];
+    return TKAMD_OK;
+}
+int64_t tkamd_text_n_docs(const tkamd_text* b) { return b ? b->n_docs : 0; }
+int64_t tkamd_text_n_bytes(const tkamd_text* b) { return b ? b->n_bytes : 0; }
+const uint8_t* tkamd_text_bytes(const tkamd_text* b) { return b ? (const uint8_t*)b->bytes.p : nullptr; }
+const int64_t* tkamd_text_doc_offsets(const tkamd_text* b) { return b ? (const int64_t*)b->doc_offsets.p : nullptr; }
+void tkamd_text_free(tkamd_text* b) { delete b; }
 
 int tkamd_profile_enable(tkamd_tokenizer* t, int on) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");

@@ -354,6 +354,110 @@ uint32_t fnv1a(const uint8_t* p, size_t n) {
     return h;
 }
 
+// WordPiece decoder cleanup (decoders/wordpiece.rs:31-44): eleven literal replacements applied in order
+static std::string wp_cleanup(std::string t) {
+    static const char* const rules[][2] = {{" .", "."}, {" ?", "?"}, {" !", "!"}, {" ,", ","}, {" ' ", "'"}, {" n't", "n't"},
+                                           {" 'm", "'m"}, {" do not", " don't"}, {" 's", "'s"}, {" 've", "'ve"}, {" 're", "'re"}};
+    for (auto& r : rules) {
+        const std::string from = r[0], to = r[1];
+        std::string out;
+        size_t pos = 0;
+        for (;;) {
+            size_t hit = t.find(from, pos);
+            if (hit == std::string::npos) { out.append(t, pos, std::string::npos); break; }
+            out.append(t, pos, hit - pos);
+            out += to;
+            pos = hit + from.size();
+        }
+        t.swap(out);
+    }
+    return t;
+}
+
+// decode_batch tables.  Tokenizer::decode (tokenizer/mod.rs:935-953) maps every id to a token string (added
+// vocabulary first, then the model; unknown ids vanish), drops specials on request and hands the strings to the
+// decoder, whose result is joined.  For the decoders on this path the contribution of a token depends only on its id
+// and on whether it is the first kept token of its sequence:
+//   ByteLevel (pre_tokenizers/byte_level.rs:155-171)  bytes of the token through the inverse byte alphabet, or the
+//                                                     token's own UTF-8 if a char is outside the alphabet
+//   WordPiece (decoders/wordpiece.rs:46-64)           first: token; later: token minus the prefix, or " " + token;
+//                                                     then cleanup()
+//   none      (mod.rs:950-952)                        tokens.join(" ")
+// so decoding is a gather of precomputed byte strings.
+static void build_decode_tables(HostModel& m, const JsonValue* root, const std::unordered_map<std::string, uint32_t>& vocab,
+                                const std::unordered_map<uint32_t, uint8_t>& c2b) {
+    const JsonValue* dec = root->get("decoder");
+    std::string prefix = "##";
+    bool cleanup = true;
+    if (!dec || dec->is_null()) m.decoder = DEC_JOIN_SPACE;
+    else {
+        const std::string t = dec->get_str("type");
+        if (t == "ByteLevel") m.decoder = DEC_BYTELEVEL;
+        else if (t == "WordPiece") {
+            m.decoder = DEC_WORDPIECE;
+            prefix = dec->get_str("prefix", "##");
+            cleanup = dec->get_bool("cleanup", true);
+        } else {
+            m.decoder = DEC_UNSUPPORTED;
+            m.dec_unsupported = "decoder type '" + t + "' is outside the decode path";
+            return;
+        }
+    }
+    // id -> token string: model vocabulary, overridden by the added vocabulary (added_vocabulary.rs:239-246)
+    uint32_t n_ids = 0;
+    for (auto& kv : vocab) n_ids = std::max(n_ids, kv.second + 1);
+    for (const AddedToken& a : m.added_tokens) n_ids = std::max(n_ids, a.id + 1);
+    if (n_ids > (1u << 26)) { m.decoder = DEC_UNSUPPORTED; m.dec_unsupported = "token ids beyond 2^26"; return; }
+    std::vector<const std::string*> tok(n_ids, nullptr);
+    std::vector<uint8_t> special(n_ids, 0);
+    for (auto& kv : vocab) tok[kv.second] = &kv.first;
+    std::unordered_map<std::string, bool> special_set;
+    for (const AddedToken& a : m.added_tokens) {
+        if (a.normalized && m.norm != NORM_NONE) {
+            m.decoder = DEC_UNSUPPORTED;
+            m.dec_unsupported = "added token '" + a.content + "' is normalized behind a normalizer (its decoded form is version dependent)";
+            return;
+        }
+        tok[a.id] = &a.content;
+        if (a.special) special_set[a.content] = true;
+    }
+    for (uint32_t id = 0; id < n_ids; ++id)
+        if (tok[id] && special_set.count(*tok[id])) special[id] = 1;     // is_special_token tests the STRING (added_vocabulary.rs:258-260)
+    m.dec_entry.assign((size_t)n_ids * 4, 0);
+    m.dec_position_dependent = false;
+    auto put = [&](const std::string& bytes) -> std::pair<uint32_t, uint32_t> {
+        uint32_t off = (uint32_t)m.dec_blob.size();
+        m.dec_blob.insert(m.dec_blob.end(), bytes.begin(), bytes.end());
+        return {off, (uint32_t)bytes.size()};
+    };
+    for (uint32_t id = 0; id < n_ids; ++id) {
+        uint32_t* e = &m.dec_entry[(size_t)id * 4];
+        if (!tok[id]) { e[1] = DEC_ABSENT; continue; }
+        const std::string& t = *tok[id];
+        std::string first, rest;
+        if (m.decoder == DEC_BYTELEVEL) {
+            if (!bytelevel_to_raw(t, c2b, &first)) first = t;
+            rest = first;
+        } else if (m.decoder == DEC_WORDPIECE) {
+            first = t;
+            if (!prefix.empty() && t.compare(0, prefix.size(), prefix) == 0) rest = t.substr(prefix.size());
+            else if (prefix.empty()) rest = t;                 // strip_prefix("") always succeeds
+            else rest = " " + t;
+            if (cleanup) { first = wp_cleanup(first); rest = wp_cleanup(rest); }
+        } else {
+            first = t;
+            rest = " " + t;
+        }
+        if (first.size() > DEC_LEN_MASK || rest.size() > DEC_LEN_MASK) { m.decoder = DEC_UNSUPPORTED; m.dec_unsupported = "token too long"; return; }
+        auto a = put(first);
+        e[0] = a.first;
+        e[1] = a.second | (special[id] ? DEC_SPECIAL : 0u);
+        if (rest == first) { e[2] = a.first; e[3] = a.second; }
+        else { auto b = put(rest); e[2] = b.first; e[3] = b.second; m.dec_position_dependent = true; }
+    }
+    m.dec_blob.resize(m.dec_blob.size() + 16, 0);                        // readable slack for vector loads
+}
+
 HostModel HostModel::from_json(const char* json, size_t len) {
     JsonPtr root;
     try {
@@ -529,6 +633,8 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         }
         m.raw_ids.push_back(kv.second);
     }
+
+    build_decode_tables(m, root.get(), v, c2b);
 
     auto opt_str = [&](const char* key, std::string* out) -> bool {
         const JsonValue* x = model->get(key);

@@ -37,6 +37,9 @@ struct AddedToken {
     bool special = false, single_word = false, lstrip = false, rstrip = false, normalized = false;
 };
 
+// decode_batch (tokenizer/mod.rs:935-953): what the `decoder` section does to the token strings
+enum DecoderKind { DEC_JOIN_SPACE = 0 /* decoder: null -> tokens.join(" ") */, DEC_BYTELEVEL = 1, DEC_WORDPIECE = 2, DEC_UNSUPPORTED = 3 };
+
 struct HostModel {
     ModelKind model = MODEL_NONE;
     PretokKind pretok = PT_NONE;
@@ -98,6 +101,15 @@ struct HostModel {
     std::vector<uint8_t> bn_stage2;
     std::vector<MergeSlot> bn_map;
     uint32_t bn_mask = 0, bn_seed = 0;
+
+    // ---- decode_batch tables: every decoder on the path is a per-token string function of (id, first kept token of the
+    // document?), so decoding is a gather.  dec_entry[id] = {offset of the FIRST-position form, its length | flags,
+    // offset of the other-position form, its length}; dec_blob holds the byte strings.
+    DecoderKind decoder = DEC_UNSUPPORTED;
+    std::string dec_unsupported;        // why decode_batch is refused (DEC_UNSUPPORTED)
+    std::vector<uint32_t> dec_entry;    // [n_ids * 4]
+    std::vector<uint8_t> dec_blob;
+    bool dec_position_dependent = false; // first-position form differs from the other one for some id
 
     std::vector<uint16_t> uc_stage1;    // [UC_STAGE1_LEN]
     std::vector<uint8_t> uc_stage2;     // [n_blocks*256]

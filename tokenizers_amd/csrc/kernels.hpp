@@ -164,6 +164,11 @@ void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigne
                           const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words);
 void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
                             const uint32_t* wprefix, uint32_t* tok0, uint32_t* ntok);
+// decode_batch: phase 1 (out_bytes_or_null == nullptr) computes lengths / positions / document offsets / *total,
+// phase 2 gathers the bytes; firstmask is null when no id has a position-dependent form
+void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, int64_t n_docs, int64_t n_tok, const void* entry, uint32_t n_ids,
+                   const uint8_t* blob, uint32_t skip_special, uint32_t* firstmask, uint32_t* len, uint32_t* bsum, uint32_t* pos, int64_t* total,
+                   int64_t* out_off, uint8_t* out_bytes_or_null);
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
                            const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,

@@ -96,6 +96,11 @@ TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed)
 }
 TK_HD uint32_t word_hash2(uint32_t h1) { return mix32(h1 * 0x165667B1u + 0x5BD1E995u); }
 
+// ---- decode_batch entry flags (in the length word of the first-position form) ----
+constexpr uint32_t DEC_SPECIAL = 0x80000000u;   // special token: dropped when skip_special_tokens
+constexpr uint32_t DEC_ABSENT = 0x40000000u;    // no token has this id: always dropped (mod.rs:938-941 filter_map)
+constexpr uint32_t DEC_LEN_MASK = 0x3FFFFFFFu;
+
 // ---- tokenizer kinds -------------------------------------------------------------------------
 enum ModelKind { MODEL_NONE = 0, MODEL_BPE = 1, MODEL_WORDPIECE = 2, MODEL_WORDLEVEL = 3 };
 enum PretokKind {

@@ -317,6 +317,51 @@ class Tokenizer:
             raise UnsupportedError("is_pretokenized=True is outside the MI355X hot path")
         return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens)
 
+    def decode_batch_csr(self, ids: np.ndarray, tok_offsets: np.ndarray, skip_special_tokens: bool = True) -> tuple[np.ndarray, np.ndarray]:
+        """ids CSR -> (bytes uint8[n_bytes], doc_offsets int64[n_docs+1]): the raw decoded byte string of every sequence."""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        tok_offsets = np.ascontiguousarray(tok_offsets, dtype=np.int64)
+        n_docs = len(tok_offsets) - 1
+        if n_docs < 0:
+            raise ValueError("tok_offsets must hold n_docs + 1 entries")
+        b = C.c_void_p()
+        flags = _lib.SKIP_SPECIAL if skip_special_tokens else 0
+        _lib.check(self._lib.tkamd_decode_batch(self._h, ids.ctypes.data, tok_offsets.ctypes.data, n_docs, flags, C.byref(b)))
+        try:
+            nb = self._lib.tkamd_text_n_bytes(b)
+            raw = np.ctypeslib.as_array(C.cast(self._lib.tkamd_text_bytes(b), C.POINTER(C.c_uint8)), shape=(max(nb, 1),))[:nb].copy()
+            off = np.ctypeslib.as_array(C.cast(self._lib.tkamd_text_doc_offsets(b), C.POINTER(C.c_int64)), shape=(n_docs + 1,)).copy()
+        finally:
+            self._lib.tkamd_text_free(b)
+        return raw, off
+
+    def decode_token(self, token_id: int, first_position: bool = False) -> tuple[bytes, int]:
+        """(bytes token ``token_id`` contributes to a decoded sequence, flags: 0 ordinary / 1 special / 2 no such id),
+        read from the load-time decode tables (host side; works on ``device=-1`` handles)."""
+        ln, fl = C.c_int32(0), C.c_int32(0)
+        buf = (C.c_uint8 * 4096)()
+        _lib.check(self._lib.tkamd_decode_token(self._h, int(token_id), int(first_position), buf, 4096, C.byref(ln), C.byref(fl)))
+        return bytes(buf[:min(ln.value, 4096)]), fl.value
+
+    def decode_batch(self, sequences: Sequence[Sequence[int]], skip_special_tokens: bool = True) -> list[str]:
+        """``Tokenizer.decode_batch`` (tokenizer/mod.rs:1404-1416; Python binding tokenizer.rs ``decode_batch``).
+
+        The gather runs on the device; the ByteLevel decoder's ``String::from_utf8_lossy`` (byte_level.rs:170) is
+        ``bytes.decode("utf-8", "replace")`` here (both replace every maximal invalid subpart by U+FFFD)."""
+        lens = np.fromiter((len(q) for q in sequences), dtype=np.int64, count=len(sequences))
+        off = np.zeros(len(sequences) + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        ids = np.empty(int(off[-1]), dtype=np.uint32)
+        for i, q in enumerate(sequences):
+            ids[off[i]:off[i + 1]] = q
+        raw, doff = self.decode_batch_csr(ids, off, skip_special_tokens)
+        buf = raw.tobytes()
+        return [buf[doff[i]:doff[i + 1]].decode("utf-8", "replace") for i in range(len(sequences))]
+
+    def decode(self, ids: Sequence[int], skip_special_tokens: bool = True) -> str:
+        """``Tokenizer.decode`` (tokenizer/mod.rs:935-953) as a batch of one."""
+        return self.decode_batch([ids], skip_special_tokens)[0]
+
     def encode_batch_device(self, d_text_ptr: int, d_doc_offsets_ptr: int, n_docs: int, n_bytes: int,
                             offsets: str = "none", word_ids: bool = False, stream: int = 0) -> DeviceBatch:
         """Inputs already in HBM (raw device pointers; text needs TEXT_PAD readable slack).  Enqueue only."""
