@@ -259,3 +259,68 @@ def test_decode_oracle_matches_reference_wheel_live():
         seqs = [[int(x) for x in rng.integers(0, n_ids + 3, size=int(rng.integers(0, 40)))] for _ in range(400)]
         for skip in (True, False):
             assert o.decode_batch(seqs, skip) == ref.decode_batch(seqs, skip_special_tokens=skip), (name, skip)
+
+
+# ---- more of the reference's inline known-answer tests (SURVEY 8c list) -------------------------------------------
+
+def test_ref_bpe_two_instances_do_not_share_state():
+    # models/bpe/model.rs:677-744 (test_cache_is_per_bpe_instance): same input, two vocabularies, interleaved
+    vocab_a = {"h": 0, "e": 1, "l": 2, "o": 3, "he": 4, "hel": 5, "hell": 6, "hello": 7}
+    merges_a = [["h", "e"], ["he", "l"], ["hel", "l"], ["hell", "o"]]
+    a = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab_a, "merges": merges_a}, BL))
+    b = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"h": 0, "e": 1, "l": 2, "o": 3}, "merges": []}, BL))
+    ids = lambda o: [t[0] for t in o.model_tokenize("hello")]
+    assert ids(a) == [7] and ids(b) == [0, 1, 2, 2, 3] and ids(a) == [7] and ids(b) == [0, 1, 2, 2, 3]
+
+
+def test_ref_byte_level_add_prefix_space():
+    # pre_tokenizers/byte_level.rs:305-334: with add_prefix_space both inputs give the same ten splits
+    # ("ĠHello", "Ġmy", ... in the byte alphabet = " Hello", " my", ... in raw bytes)
+    vocab, _ = _byte_vocab()
+    o = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": []}, dict(BL, add_prefix_space=True)))
+    want = [" Hello", " my", " friend", ",", " how", " is", " your", " day", " going", "?"]
+    # the oracle reports ORIGINAL offsets: the inserted space takes the first char's alignment (normalizer.rs:503-514),
+    # so without a leading space in the input the first split is "Hello" (0,5) in the original text
+    got = [" Hello my friend, how is your day going?".encode()[a:b].decode() for a, b in o.pre_tokenize(" Hello my friend, how is your day going?")]
+    assert got == want
+    got = ["Hello my friend, how is your day going?".encode()[a:b].decode() for a, b in o.pre_tokenize("Hello my friend, how is your day going?")]
+    assert got == ["Hello"] + want[1:]
+
+
+def _added_token_spans(text, token, **flags):
+    """(start, end) byte spans the AddedVocabulary split assigns to `token` in `text` (no normalizer, no post-processor)."""
+    vocab, _ = _byte_vocab()
+    d = json.loads(_tok_json({"type": "BPE", "vocab": vocab, "merges": []}, BL))
+    d["added_tokens"] = [dict({"id": 256, "content": token, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False,
+                               "special": False}, **flags)]
+    r = orc.Oracle(json.dumps(d)).encode_batch([text])
+    return [tuple(int(x) for x in r.offsets[i]) for i in range(len(r.ids)) if int(r.ids[i]) == 256]
+
+
+def _piece_spans(pieces):
+    out, pos = [], 0
+    for text, is_match in pieces:
+        n = len(text.encode())
+        if is_match:
+            out.append((pos, pos + n))
+        pos += n
+    return out
+
+
+def test_ref_added_token_single_word():
+    # tokenizer/added_vocabulary.rs:943-973 (test_single_word_is_correct); the Lowercase normalizer of the reference
+    # test only changes the case of the unmatched text
+    text = "<mask> My name <mask> A<mask> <mask>ony <mask>"
+    pieces = [("<mask>", 1), (" My name ", 0), ("<mask>", 1), (" A<mask> <mask>ony ", 0), ("<mask>", 1)]
+    assert _added_token_spans(text, "<mask>", single_word=True) == _piece_spans(pieces)
+    # :975-1003 (test_single_word_is_unicode_correct): punctuation and dash are not word chars, a combining mark is
+    text = "<mask>, <mask>- ◌̰<mask>"
+    pieces = [("<mask>", 1), (", ", 0), ("<mask>", 1), ("- ◌̰<mask>", 0)]
+    assert _added_token_spans(text, "<mask>", single_word=True) == _piece_spans(pieces)
+
+
+def test_ref_added_token_lstrip_rstrip_unicode_space():
+    # tokenizer/added_vocabulary.rs:1005-1037 (test_lstrip_unicode_space)
+    text = "Hi <mask> there\t<mask>\t<mask> "
+    pieces = [("Hi", 0), (" <mask> ", 1), ("there", 0), ("\t<mask>\t", 1), ("<mask> ", 1)]
+    assert _added_token_spans(text, "<mask>", single_word=True, lstrip=True, rstrip=True) == _piece_spans(pieces)
