@@ -1,0 +1,57 @@
+// CPU harness for tokenizers_amd/csrc/pretok_l3_core.hpp: runs l3_window_starts -- the exact function every lane of
+// k_pretok_llama3_lane executes -- over a whole batch, one 64-byte window per 32 bytes of text, the way the kernel
+// tiles it.  Built and driven by tests/test_pretok_core.py (g++, no GPU).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "host_model.hpp"
+#include "pretok_l3_core.hpp"
+
+using namespace tkamd;
+
+extern "C" int l3h_run(const char* json, size_t json_len, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs,
+                       uint8_t* start_out, uint8_t* unres_out) {
+    HostModel hm;
+    try {
+        hm = HostModel::from_json(json, json_len);
+    } catch (const std::exception&) {
+        return -1;
+    }
+    std::vector<uint8_t> docstart((size_t)n + 64, 0);
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) docstart[doc_off[d]] = 1;
+    // padded copy: the kernel's text carries 64 readable bytes after its end and the first window starts 16 bytes early
+    std::vector<uint8_t> buf((size_t)n + 64 + 128, 0);
+    uint8_t* t = buf.data() + 64;
+    memcpy(t, text, (size_t)n);
+    L3Flags lut[256];
+    for (uint32_t v = 0; v < 256; ++v) lut[v] = l3_byte_flags(v);
+    for (int64_t a = 0; a < n; a += L3W_MAIN) {
+        const int64_t base = a - L3W_HALO;
+        L3Window w{};
+        for (int i = 0; i < 64; ++i) {
+            const int64_t g = base + i;
+            if (g < 0 || g >= n) continue;
+            const L3Flags f = lut[t[g]];
+            const uint64_t bit = 1ull << i;
+            w.V |= bit;
+            if (f.x & 1u) w.L |= bit;
+            if (f.x & (1u << 8)) w.N |= bit;
+            if (f.x & (1u << 16)) w.W |= bit;
+            if (f.x & (1u << 24)) w.R |= bit;
+            if (f.y & 1u) w.SP |= bit;
+            if (f.y & (1u << 8)) w.C |= bit;
+            if (f.y & (1u << 16)) w.AP |= bit;
+            if (f.y & (1u << 24)) w.MU |= bit;
+            if (docstart[g]) w.D |= bit;
+        }
+        uint64_t st = 0, un = 0;
+        l3_window_starts(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data(), &st, &un);
+        for (int i = L3W_HALO; i < L3W_HALO + L3W_MAIN; ++i) {
+            const int64_t g = base + i;
+            if (g < n) { start_out[g] = (st >> i) & 1; unres_out[g] = (un >> i) & 1; }
+        }
+    }
+    return 0;
+}

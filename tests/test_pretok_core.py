@@ -1,0 +1,121 @@
+"""CPU tests of tokenizers_amd/csrc/pretok_l3_core.hpp -- the per-lane Llama-3 split logic the HIP kernel runs -- through a
+g++-built harness (tests/harness/l3_harness.cpp): every byte the core decides must agree with the oracle's sequential
+regex matcher, and on prose it must decide almost every byte itself."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import synth
+from tests.helpers import load_tokenizer_json
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "tokenizers_amd", "csrc")
+SO = os.path.join(HERE, "harness", "_l3_harness.so")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    srcs = [os.path.join(HERE, "harness", "l3_harness.cpp"), os.path.join(CSRC, "host_model.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("pretok_l3_core.hpp", "tables.hpp", "host_model.hpp")]
+    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", SO],
+                       check=True)
+    lib = C.CDLL(SO)
+    lib.l3h_run.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.l3h_run.restype = C.c_int
+    return lib
+
+
+def _run(lib, js, docs):
+    raw = [d.encode("utf-8") for d in docs]
+    off = np.zeros(len(raw) + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in raw], out=off[1:])
+    buf = np.frombuffer(b"".join(raw) + b"\0" * 64, dtype=np.uint8).copy()
+    n = int(off[-1])
+    st = np.zeros(n + 1, dtype=np.uint8)
+    un = np.zeros(n + 1, dtype=np.uint8)
+    jb = js.encode("utf-8")
+    assert lib.l3h_run(jb, len(jb), buf.ctypes.data, n, off.ctypes.data, len(raw), st.ctypes.data, un.ctypes.data) == 0
+    return st[:n], un[:n], off
+
+
+def _expected(o, docs, off):
+    exp = np.zeros(int(off[-1]), dtype=np.uint8)
+    for d, text in enumerate(docs):
+        for a, _ in o.pre_tokenize(text):
+            exp[off[d] + a] = 1
+    return exp
+
+
+def _check(lib, js, o, docs, max_unres=1.0):
+    st, un, off = _run(lib, js, docs)
+    exp = _expected(o, docs, off)
+    decided = un == 0
+    bad = np.nonzero(decided & (st != exp))[0]
+    if len(bad):
+        g = int(bad[0])
+        d = int(np.searchsorted(off, g, side="right") - 1)
+        raise AssertionError(f"{len(bad)} wrong bytes; first at doc {d} byte {g - off[d]}: {docs[d]!r} core={st[g]} oracle={exp[g]}")
+    frac = float(un.mean()) if len(un) else 0.0
+    assert frac <= max_unres, f"{frac:.4f} of the bytes left undecided"
+    return frac
+
+
+# apostrophes and contraction letters in both cases, every kind of whitespace, CR/LF, digits incl. No/Nl and multi-byte
+# ones, punctuation, multi-byte letters, a combining mark, long-s and Kelvin (case folding), control bytes
+ALPHA = ["'", "'", "s", "t", "d", "m", "l", "v", "r", "e", "S", "T", "D", "M", "L", "V", "R", "E", "a", "Z", " ", " ", " ", "\t", "\n", "\r",
+         "\n", "　", " ", "", "1", "2", "9", "²", "½", "٣", "Ⅷ", "!", "-", "_", ".", "é", "中",
+         "\U0001F601", "̀", "ſ", "K", "K", "\x1c", "\x00"]
+
+
+def _adversarial(n, seed, max_len=24):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, max_len, size=n)
+    picks = rng.integers(0, len(ALPHA), size=int(lens.sum()))
+    out, k = [], 0
+    for ln in lens.tolist():
+        out.append("".join(ALPHA[i] for i in picks[k:k + ln].tolist()))
+        k += ln
+    return out
+
+
+@pytest.fixture(scope="module")
+def l3():
+    js = load_tokenizer_json("llama3_small_6000")
+    return js, orc.Oracle(js)
+
+
+def test_core_matches_oracle_on_adversarial_strings(harness, l3):
+    js, o = l3
+    for seed in range(8):
+        _check(harness, js, o, _adversarial(40000, 100 + seed))
+
+
+def test_core_matches_oracle_on_long_mixed_documents(harness, l3):
+    """Documents longer than a window: runs that cross lane boundaries, digit runs, indentation."""
+    js, o = l3
+    for seed in range(4):
+        _check(harness, js, o, _adversarial(4000, 200 + seed, max_len=400))
+    rng = np.random.default_rng(5)
+    docs = []
+    for _ in range(3000):
+        parts = []
+        for _ in range(int(rng.integers(1, 12))):
+            kind = int(rng.integers(0, 6))
+            n = int(rng.integers(1, 40))
+            parts.append({0: "a" * n, 1: "7" * n, 2: " " * n, 3: "\n" * (n % 5 + 1) + " " * (n % 7), 4: "!" * (n % 4 + 1) + "\r\n" * (n % 3),
+                          5: "it's we'LL x're"}[kind])
+        docs.append("".join(parts))
+    _check(harness, js, o, docs)
+
+
+def test_core_decides_nearly_everything_on_prose(harness, l3):
+    js, o = l3
+    docs = synth.gen_lines(20000, text_seed=3) + synth.stress_lines(seed=4, n=3000)
+    frac = _check(harness, js, o, docs, max_unres=0.01)
+    assert frac < 0.01

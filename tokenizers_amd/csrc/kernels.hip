@@ -11,12 +11,15 @@
 //
 // Every kernel cites the reference code it replaces.  All results are bit-exact integers.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 
 #include <algorithm>
 #include <cstdint>
 
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "pretok_l3_core.hpp"
 #include "tables.hpp"
 
 namespace tkamd {
@@ -767,7 +770,15 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
                                                        const unsigned long long* __restrict__ docmask,
                                                        const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                        unsigned long long* __restrict__ startmask,
-                                                       unsigned long long* __restrict__ slowmask) {
+                                                       unsigned long long* __restrict__ slowmask, int refine) {
+    // refine: k_pretok_llama3_lane has run; only tiles in which it left bytes undecided (bits of slowmask) are redone
+    if (refine) {
+        const int64_t w0 = (int64_t)blockIdx.x * (PT_TILE / 64);
+        const int64_t n_words = (n_bytes_host >> 6) + 1;
+        int any = 0;
+        if ((int)threadIdx.x < PT_TILE / 64 && w0 + (int)threadIdx.x < n_words) any = slowmask[w0 + threadIdx.x] != 0ull;
+        if (!__syncthreads_or(any)) return;
+    }
     __shared__ __attribute__((aligned(16))) uint8_t sb[L3_R + 8];
     __shared__ uint8_t si[L3_R + 8];
     __shared__ uint8_t sc[L3_R + 8];     // con: number of letters (1|2) swallowed by a contraction starting at this apostrophe
@@ -941,6 +952,87 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
         }
         uint64_t m = __ballot(start), mu = __ballot(unresolved);
         if ((tid & 63) == 0 && g <= n_bytes_host) { startmask[g >> 6] = m; slowmask[g >> 6] = mu; }
+    }
+}
+
+// =================================================================================================
+// K_pretok_llama3_lane: the same split, bit-parallel PER LANE (the GPT-2 kernel's scheme): a lane owns 32 bytes
+// inside a 64-byte window (16 bytes of context on each side, four aligned 16-byte loads), deposits one-hot byte
+// flags from a small LDS table into 64-bit masks and runs l3_window_starts (pretok_l3_core.hpp) -- the mask algebra
+// that tests/test_pretok_core.py checks on the CPU, function for function, against a sequential matcher.  Bytes whose run
+// leaves the window are reported in slowmask; k_pretok_llama3 (refine mode) redoes only the tiles that have any.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                            const int64_t* __restrict__ len_dev,
+                                                            const unsigned long long* __restrict__ docmask,
+                                                            const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                            unsigned long long* __restrict__ startmask,
+                                                            unsigned long long* __restrict__ slowmask) {
+    __shared__ uint2 lut[SQ_LUT_COPIES * 256];
+    {
+        const L3Flags f = l3_byte_flags(threadIdx.x);
+#pragma unroll
+        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + threadIdx.x] = make_uint2(f.x, f.y);
+    }
+    __syncthreads();
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    const int64_t n_words_host = (n_bytes_host >> 6) + 1;
+    const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t a = Lg * L3W_MAIN;                         // first byte this lane decides
+    const int64_t base = a - L3W_HALO;                       // window = [base, base + 64), 16-byte aligned
+    unsigned long long st = 0, un = 0;
+    if (a < n_bytes) {
+        uint32_t w[16];
+        {
+            uint4 c0 = make_uint4(0u, 0u, 0u, 0u);
+            if (base >= 0) c0 = *(const uint4*)(text + base);
+            const uint4 c1 = *(const uint4*)(text + base + 16), c2 = *(const uint4*)(text + base + 32), c3 = *(const uint4*)(text + base + 48);
+            w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w; w[4] = c1.x; w[5] = c1.y; w[6] = c1.z; w[7] = c1.w;
+            w[8] = c2.x; w[9] = c2.y; w[10] = c2.z; w[11] = c2.w; w[12] = c3.x; w[13] = c3.y; w[14] = c3.z; w[15] = c3.w;
+        }
+        L3Window m;
+        const int vlo = base < 0 ? (int)-base : 0;
+        const int64_t rem = n_bytes - base;
+        m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
+        if (base < 0) m.D = docmask[0] << L3W_HALO;
+        else {
+            const int64_t wi = base >> 6;
+            const int sh = (int)(base & 63);
+            m.D = docmask[wi] >> sh;
+            if (sh && wi + 1 < n_words_host) m.D |= docmask[wi + 1] << (64 - sh);
+        }
+        const uint2* my_lut = lut + (threadIdx.x & (SQ_LUT_COPIES - 1)) * 256;
+        m.L = m.N = m.W = m.R = m.SP = m.C = m.AP = m.MU = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            uint32_t accA = 0, accB = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * g + j;
+                const uint2 e = my_lut[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+                accA |= e.x << j;
+                accB |= e.y << j;
+            }
+            m.L |= (unsigned long long)(accA & 0xFFu) << (8 * g);
+            m.N |= (unsigned long long)((accA >> 8) & 0xFFu) << (8 * g);
+            m.W |= (unsigned long long)((accA >> 16) & 0xFFu) << (8 * g);
+            m.R |= (unsigned long long)(accA >> 24) << (8 * g);
+            m.SP |= (unsigned long long)(accB & 0xFFu) << (8 * g);
+            m.C |= (unsigned long long)((accB >> 8) & 0xFFu) << (8 * g);
+            m.AP |= (unsigned long long)((accB >> 16) & 0xFFu) << (8 * g);
+            m.MU |= (unsigned long long)(accB >> 24) << (8 * g);
+        }
+        m.L &= m.V; m.N &= m.V; m.W &= m.V; m.R &= m.V; m.SP &= m.V; m.C &= m.V; m.AP &= m.V; m.MU &= m.V;
+        uint64_t s64, u64;
+        l3_window_starts(m, text, base, uc1, uc2, &s64, &u64);
+        st = (s64 >> L3W_HALO) & 0xFFFFFFFFull;
+        un = (u64 >> L3W_HALO) & 0xFFFFFFFFull;
+    }
+    // two lanes (32 bytes each) make one 64-bit mask word
+    const unsigned long long st_o = __shfl_xor(st, 1, 64), un_o = __shfl_xor(un, 1, 64);
+    if ((threadIdx.x & 1) == 0) {
+        const int64_t word = Lg >> 1;
+        if (word < n_words_host) { startmask[word] = st | (st_o << 32); slowmask[word] = un | (un_o << 32); }
     }
 }
 
@@ -2753,10 +2845,10 @@ void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, 
                    int64_t* out_off, uint8_t* out_bytes_or_null) {
     const uint4* e = (const uint4*)entry;
     if (!out_bytes_or_null) {                                 // phase 1: lengths, positions, document offsets, total
-        hipMemsetAsync(total, 0, 8, st);
+        (void)hipMemsetAsync(total, 0, 8, st);
         if (n_tok > 0) {
             if (firstmask && n_docs > 0) {
-                hipMemsetAsync(firstmask, 0, (size_t)((n_tok >> 5) + 1) * 4, st);
+                (void)hipMemsetAsync(firstmask, 0, (size_t)((n_tok >> 5) + 1) * 4, st);
                 hipLaunchKernelGGL(k_decode_first, dim3(blocks_for(n_docs, 256)), dim3(256), 0, st, ids, tok_off, n_docs, e, n_ids, skip_special, firstmask);
             }
             const unsigned nb = blocks_for(n_tok, 256);
@@ -2872,7 +2964,12 @@ void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_byte
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs) {
-    hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask);
+    // TKAMD_PRETOK_L3=tile: the lane-per-byte tile kernel alone; default: the per-lane bit-parallel kernel first, the tile
+    // kernel only on the tiles where it left bytes undecided
+    static const bool tile_only = [] { const char* e = getenv("TKAMD_PRETOK_L3"); return e && !strcmp(e, "tile"); }();
+    if (!tile_only)
+        hipLaunchKernelGGL(k_pretok_llama3_lane, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask);
+    hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, tile_only ? 0 : 1);
     hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, slow_docs, n_slow_docs);
     hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, uc1, uc2, startmask);
 }

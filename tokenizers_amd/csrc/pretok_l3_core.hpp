@@ -1,0 +1,204 @@
+// Llama-3 / cl100k-style split as 64-bit mask algebra over ONE 64-byte window.
+//
+//   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
+//
+// The function below is the whole per-lane logic of k_pretok_llama3_lane (kernels.hip): a lane owns the 32 bytes
+// [16, 48) of its window and decides, for each of them, whether a regex match STARTS there (Split with Isolated
+// behaviour covers every byte, pre_tokenizers/split.rs:96-104, so the starts are the whole answer).  It is written
+// as plain host+device code so that tests/test_pretok_core.py can run exactly the same function on the CPU against
+// the sequential regex matcher of the test tree on millions of adversarial strings (tests/harness/l3_harness.cpp) -- the GPU kernel only adds the loads,
+// the LDS flag table and the store.
+//
+// Unlike the GPT-2 rule this one is RUN-local: digit runs are cut every three code points from
+// the run start, a whitespace run is cut after its last CR/LF and before its last char, an O-run swallows the CR/LFs
+// that follow it.  Runs are resolved with log-step propagation inside the window; a byte whose run reaches the edge
+// of the window is reported in `unres` and redone by the tile kernel (k_pretok_llama3, 128-byte halo) and, beyond
+// that, by the sequential per-document matcher.  Bit i of every mask = window byte i.
+#pragma once
+#include <cstdint>
+
+#include "tables.hpp"
+
+namespace tkamd {
+
+constexpr int L3W_HALO = 16;      // bytes of context on each side of the 32 bytes a lane decides
+constexpr int L3W_MAIN = 32;
+constexpr uint64_t L3W_MAIN_MASK = 0x0000FFFFFFFF0000ull;
+
+// classes of one byte, deposited by the caller for ASCII (multi-byte leads are classified here through the tables)
+struct L3Window {
+    uint64_t L, N, W, R;          // letter, number, whitespace except CR/LF, CR/LF      (ASCII bytes only on entry)
+    uint64_t SP, C, AP, MU;       // U+0020, continuation byte, apostrophe, multi-byte lead
+    uint64_t V, D;                // byte exists (inside the text), byte starts a document
+};
+
+TK_HD uint32_t l3_uc_flags(uint32_t cp, const uint16_t* uc1, const uint8_t* uc2) {
+    if (cp >= 0x110000u) return 0;
+    return uc2[((uint32_t)uc1[cp >> 8] << 8) | (cp & 255u)];
+}
+TK_HD int l3_ctz(uint64_t m) { return __builtin_ctzll(m); }
+
+// backward / forward propagation of `seed` through links: link bit i = "bytes i and i+1 belong together".
+// back: result has bit i if some seed bit j >= i is reachable from i through links i..j-1.
+TK_HD uint64_t l3_spread_back(uint64_t seed, uint64_t link) {
+    uint64_t h = seed;
+    h |= (h >> 1) & link;
+    uint64_t l2 = link & (link >> 1);
+    h |= (h >> 2) & l2;
+    uint64_t l4 = l2 & (l2 >> 2);
+    h |= (h >> 4) & l4;
+    uint64_t l8 = l4 & (l4 >> 4);
+    h |= (h >> 8) & l8;
+    uint64_t l16 = l8 & (l8 >> 8);
+    h |= (h >> 16) & l16;
+    uint64_t l32 = l16 & (l16 >> 16);
+    h |= (h >> 32) & l32;
+    return h;
+}
+// fwd: link bit i = "bytes i-1 and i belong together"; result has bit i if some seed bit j <= i reaches i.
+TK_HD uint64_t l3_spread_fwd(uint64_t seed, uint64_t link) {
+    uint64_t h = seed;
+    h |= (h << 1) & link;
+    uint64_t l2 = link & (link << 1);
+    h |= (h << 2) & l2;
+    uint64_t l4 = l2 & (l2 << 2);
+    h |= (h << 4) & l4;
+    uint64_t l8 = l4 & (l4 << 4);
+    h |= (h << 8) & l8;
+    uint64_t l16 = l8 & (l8 << 8);
+    h |= (h << 16) & l16;
+    uint64_t l32 = l16 & (l16 << 16);
+    h |= (h << 32) & l32;
+    return h;
+}
+
+// `text + base` is window byte 0 (may lie before the text for the first lane: V says which bytes exist); the text
+// carries TKAMD_TEXT_PAD readable bytes after its end.  Returns the match starts of window bytes [16, 48) in bits
+// 16..47 of *start and the bytes it could not decide in *unres (same bits).
+TK_HD void l3_window_starts(L3Window m, const uint8_t* text, int64_t base, const uint16_t* uc1, const uint8_t* uc2,
+                            uint64_t* start, uint64_t* unres) {
+    const uint64_t V = m.V, D = m.D & V, nD = ~D;
+    uint64_t L = m.L, N = m.N, W = m.W, R = m.R & V;
+    const uint64_t C = m.C & V, SP = m.SP & V, AP = m.AP & V;
+    uint64_t U = 0;                                                    // unresolved
+    uint64_t NM = 0;                                                   // multi-byte digits
+    // multi-byte code points: class from the Unicode table, spread over the lead and its continuation bytes
+    for (uint64_t mm = m.MU & V; mm; mm &= mm - 1) {
+        const int k = l3_ctz(mm);
+        const uint8_t* p = text + base + k;
+        const uint32_t b0 = p[0];
+        uint32_t cp, len;
+        if (b0 < 0xE0u) { len = 2; cp = ((b0 & 0x1Fu) << 6) | (p[1] & 0x3Fu); }
+        else if (b0 < 0xF0u) { len = 3; cp = ((b0 & 0x0Fu) << 12) | ((p[1] & 0x3Fu) << 6) | (p[2] & 0x3Fu); }
+        else { len = 4; cp = ((b0 & 0x07u) << 18) | ((p[1] & 0x3Fu) << 12) | ((p[2] & 0x3Fu) << 6) | (p[3] & 0x3Fu); }
+        const uint32_t f = l3_uc_flags(cp, uc1, uc2);
+        const uint64_t span = ((len >= 64 ? 0ull : (1ull << len)) - 1ull) << k;
+        if (f & UC_ONIG_L) L |= span;
+        else if (f & UC_ONIG_N) { N |= span; NM |= span; }
+        else if (f & UC_ONIG_S) W |= span;
+    }
+    L &= V; N &= V; W &= V;
+    const uint64_t LEAD = V & ~C;
+    const uint64_t X = W | R;                                          // whitespace of any kind
+    const uint64_t O = V & ~(L | N | X);                               // everything else (continuation bytes of O chars included)
+    const uint64_t pL = (L << 1) & nD, pN = (N << 1) & nD, pW = (W << 1) & nD, pR = (R << 1) & nD, pO = (O << 1) & nD,
+                   pSP = (SP << 1) & nD, pX = (X << 1) & nD;
+
+    // ---- contraction literals (case-insensitive; a match only where the apostrophe is itself a match start)
+    uint64_t CON1 = 0, CON2 = 0;                                       // one / two letters swallowed
+    {
+        const uint64_t ok = V & nD;                                    // byte exists and continues its document
+        const uint64_t cond = D | pL | pN | pR | (pW & ~pSP);
+        for (uint64_t mm = AP & LEAD & cond & (ok >> 1); mm; mm &= mm - 1) {
+            const int k = l3_ctz(mm);
+            if (k > 60) { U |= 1ull << k; continue; }                  // literal not inside the window (never in the main region)
+            const uint8_t* p = text + base + k;
+            const uint32_t b1 = p[1], b2 = p[2];
+            if (b1 == 0xC5u && b2 == 0xBFu) {                          // U+017F folds to 's': 'ſ is a two-byte one-letter literal
+                U |= 0x1Full << k;                                     // rare enough to leave to the tile kernel
+                continue;
+            }
+            const uint32_t a = b1 | 0x20u, c = b2 | 0x20u;
+            const bool a_letter = b1 < 0x80u && (a - 'a') < 26u, c_letter = b2 < 0x80u && (c - 'a') < 26u;
+            if (!a_letter) continue;
+            if (a == 's' || a == 't' || a == 'm' || a == 'd') CON1 |= 1ull << k;
+            else if (c_letter && ((ok >> (k + 2)) & 1ull) && (((a == 'r' || a == 'v') && c == 'e') || (a == 'l' && c == 'l'))) CON2 |= 1ull << k;
+        }
+    }
+    const uint64_t CON = CON1 | CON2;
+    const uint64_t eaten = (CON << 1) | (CON2 << 2);                   // letters swallowed by a contraction
+    const uint64_t after = (CON1 << 2) | (CON2 << 3);                  // first byte after the literal: a new match
+
+    // ---- letters: [^\r\n\p{L}\p{N}]?\p{L}+   A run's first letter is NOT a start when the previous char can be its prefix:
+    //      any non-CR/LF whitespace, or a lone O char (not preceded by O or U+0020: else ` ?O+` has already taken it)
+    uint64_t Q = LEAD & (((O | SP) << 1) & nD);                        // at a lead: the previous code point is O or U+0020
+    Q |= (Q << 1) & C; Q |= (Q << 1) & C; Q |= (Q << 1) & C;           // ... on every byte of that code point
+    const uint64_t prefixO = pO & ~(Q << 1);
+    const uint64_t startL = L & ~eaten & (after | ~(pL | pW | prefixO));
+    // ---- other:  ?[^\s\p{L}\p{N}]+[\r\n]*
+    const uint64_t startO = O & (after | ~(pO | pSP));
+    // ---- digits: \p{N}{1,3} -- every third code point from the run start (byte arithmetic: ASCII digits only)
+    uint64_t startN;
+    {
+        const uint64_t Ns = N & LEAD & ~pN;                            // run starts
+        const uint64_t Cn = N & ~Ns;                                   // digits that continue a run
+        uint64_t T = Ns;
+        const uint64_t k3 = Cn & (Cn << 1) & (Cn << 2);
+        T |= (T << 3) & k3;
+        const uint64_t k6 = k3 & (k3 << 3);
+        T |= (T << 6) & k6;
+        const uint64_t k12 = k6 & (k6 << 6);
+        T |= (T << 12) & k12;
+        const uint64_t k24 = k12 & (k12 << 12);
+        T |= (T << 24) & k24;
+        const uint64_t k48 = k24 & (k24 << 24);
+        T |= (T << 48) & k48;
+        startN = N & T;
+        // a run that reaches back to the first window bytes has an unknown origin (bytes 0..2 may be the tail of a code
+        // point whose lead -- possibly a digit -- lies before the window); multi-byte digits break the byte arithmetic
+        const uint64_t link = N & pN;                                  // bit i: bytes i-1 and i are digits of one run
+        U |= l3_spread_fwd(N & 0xFull & nD, link);
+        if (NM) U |= l3_spread_fwd(l3_spread_back(NM, link >> 1), link);
+    }
+    // ---- whitespace runs: \s*[\r\n]+ | \s+(?!\S) | \s+
+    uint64_t startX;
+    {
+        const uint64_t Xs = X & LEAD & ~pX;                            // run starts
+        // leading CR/LFs of a run that follows an O char belong to that O-run's [\r\n]* tail
+        uint64_t A = Xs & R & pO;
+        for (int it = 0; it < 6; ++it) A |= (A << 1) & R & nD;
+        if ((A << 1) & R & nD & ~A) U |= X;                            // longer than that: not decided here
+        const uint64_t QE = (Xs & ~A) | ((A << 1) & X & ~A & nD);      // effective run start
+        const uint64_t Rr = R & ~A;
+        const uint64_t lk = X & (X >> 1) & ~(D >> 1);                  // bit i: bytes i and i+1 are in one run
+        const uint64_t later = l3_spread_back((Rr >> 1) & lk, lk);     // a CR/LF of the run comes after byte i
+        const uint64_t LC = Rr & ~later;                               // last CR/LF of its run
+        const uint64_t ST2 = (LC << 1) & X & nD;                       // the remainder after it
+        // a non-CR/LF whitespace char that ends its run and is followed by a non-space: \s+(?!\S) stops before it
+        uint64_t Y = (LEAD & ~X & nD) >> 1;
+        Y |= (Y & C) >> 1; Y |= (Y & C) >> 1; Y |= (Y & C) >> 1;
+        const uint64_t ST3 = W & Y;
+        startX = QE | ST2 | ST3;
+        // runs whose start (and the char before it) or end is outside the window
+        const uint64_t flk = X & pX;                                   // bit i: bytes i-1 and i are in one run
+        U |= l3_spread_fwd(X & 0xFull & ~D, flk);
+        U |= l3_spread_back(X & (1ull << 63), lk);
+    }
+    *start = LEAD & (D | startL | startO | startN | startX) & L3W_MAIN_MASK;
+    *unres = U & L3W_MAIN_MASK;
+}
+
+// ASCII flag entry of one byte value for the caller's 256-entry table: bits 0 / 8 / 16 / 24 of .x = L, N, W, R;
+// of .y = SP, continuation, apostrophe, multi-byte lead
+struct L3Flags { uint32_t x, y; };
+TK_HD L3Flags l3_byte_flags(uint32_t v) {
+    const uint32_t lower = v | 0x20u;
+    const bool isL = v < 0x80u && (lower - 'a') < 26u, isN = (v - '0') < 10u, isR = v == '\r' || v == '\n';
+    const bool isW = (v == 0x20u || (v - 9u) < 5u) && !isR;
+    L3Flags f;
+    f.x = (isL ? 1u : 0u) | (isN ? 1u << 8 : 0u) | (isW ? 1u << 16 : 0u) | (isR ? 1u << 24 : 0u);
+    f.y = (v == 0x20u ? 1u : 0u) | ((v & 0xC0u) == 0x80u ? 1u << 8 : 0u) | (v == '\'' ? 1u << 16 : 0u) | (v >= 0xC0u ? 1u << 24 : 0u);
+    return f;
+}
+
+}  // namespace tkamd
