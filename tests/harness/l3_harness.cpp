@@ -7,6 +7,7 @@
 
 #include "host_model.hpp"
 #include "pretok_l3_core.hpp"
+#include "pretok_local_core.hpp"
 
 using namespace tkamd;
 
@@ -53,5 +54,60 @@ extern "C" int l3h_run(const char* json, size_t json_len, const uint8_t* text, i
             if (g < n) { start_out[g] = (st >> i) & 1; unres_out[g] = (un >> i) & 1; }
         }
     }
+    return 0;
+}
+
+// ---- pretok_local_core.hpp: Whitespace / WhitespaceSplit / BertPreTokenizer, 48 bytes per window ----------------------
+template <int KIND>
+static void pl_run(const HostModel& hm, const uint8_t* t, int64_t n, const std::vector<uint8_t>& docstart, uint8_t* start_out, uint8_t* end_out) {
+    uint32_t lut[256];
+    for (uint32_t v = 0; v < 256; ++v) lut[v] = local_byte_flags<KIND>(v);
+    for (int64_t a = 0; a <= n; a += PLW_MAIN) {
+        const int64_t base = a - PLW_HALO;
+        LocalWindow w{};
+        for (int i = 0; i < 64; ++i) {
+            const int64_t g = base + i;
+            if (g == n) w.END = 1ull << i;
+            if (g < 0 || g >= n) continue;
+            const uint32_t f = lut[t[g]];
+            const uint64_t bit = 1ull << i;
+            w.V |= bit;
+            const bool multi = (f & 0x010101u) == 0x010101u;
+            if (multi) w.MU |= bit;
+            else {
+                if (f & 1u) w.C1 |= bit;
+                if (f & (1u << 8)) w.C2 |= bit;
+                if (f & (1u << 16)) w.C3 |= bit;
+            }
+            if (f & (1u << 24)) w.C |= bit;
+            if (docstart[g]) w.D |= bit;
+        }
+        uint64_t st = 0, en = 0;
+        local_window_masks<KIND>(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data(), &st, &en);
+        for (int i = PLW_HALO; i < PLW_HALO + PLW_MAIN; ++i) {
+            const int64_t g = base + i;
+            if (g <= n) { start_out[g] = (st >> i) & 1; end_out[g] = (en >> i) & 1; }
+        }
+    }
+}
+
+extern "C" int plh_run(const char* json, size_t json_len, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs,
+                       uint8_t* start_out, uint8_t* end_out) {
+    HostModel hm;
+    try {
+        hm = HostModel::from_json(json, json_len);
+    } catch (const std::exception&) {
+        return -1;
+    }
+    std::vector<uint8_t> docstart((size_t)n + 64, 0);
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) docstart[doc_off[d]] = 1;
+    std::vector<uint8_t> buf((size_t)n + 64 + 128, 0);
+    uint8_t* t = buf.data() + 64;
+    memcpy(t, text, (size_t)n);
+    if (hm.pretok == PT_WHITESPACE) pl_run<PT_WHITESPACE>(hm, t, n, docstart, start_out, end_out);
+    else if (hm.pretok == PT_WHITESPACE_SPLIT) pl_run<PT_WHITESPACE_SPLIT>(hm, t, n, docstart, start_out, end_out);
+    else if (hm.pretok == PT_BERT) pl_run<PT_BERT>(hm, t, n, docstart, start_out, end_out);
+    else return -2;
     return 0;
 }

@@ -21,13 +21,15 @@ SO = os.path.join(HERE, "harness", "_l3_harness.so")
 @pytest.fixture(scope="module")
 def harness():
     srcs = [os.path.join(HERE, "harness", "l3_harness.cpp"), os.path.join(CSRC, "host_model.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("pretok_l3_core.hpp", "tables.hpp", "host_model.hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("pretok_l3_core.hpp", "pretok_local_core.hpp", "tables.hpp", "host_model.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", SO],
                        check=True)
     lib = C.CDLL(SO)
     lib.l3h_run.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.l3h_run.restype = C.c_int
+    lib.plh_run.argtypes = lib.l3h_run.argtypes
+    lib.plh_run.restype = C.c_int
     return lib
 
 
@@ -119,3 +121,40 @@ def test_core_decides_nearly_everything_on_prose(harness, l3):
     docs = synth.gen_lines(20000, text_seed=3) + synth.stress_lines(seed=4, n=3000)
     frac = _check(harness, js, o, docs, max_unres=0.01)
     assert frac < 0.01
+
+
+# ---- pretok_local_core.hpp: Whitespace / WhitespaceSplit / BertPreTokenizer ------------------------------------------------
+
+def _local_case(name):
+    import json
+    d = json.loads(load_tokenizer_json(name))
+    d["normalizer"] = None                      # the pre-tokenizer alone (the BERT golden tokenizer carries a BertNormalizer)
+    js = json.dumps(d)
+    return js, orc.Oracle(js)
+
+
+@pytest.mark.parametrize("name", ["wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"])
+def test_local_core_matches_oracle(harness, name):
+    js, o = _local_case(name)
+    docs = _adversarial(60000, 7, max_len=40) + synth.gen_lines(5000, text_seed=9) + synth.stress_lines(seed=2, n=2000) + ["", " ", "a", "!", "a b", "\u3000x\u3000"]
+    raw = [d.encode("utf-8") for d in docs]
+    off = np.zeros(len(raw) + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in raw], out=off[1:])
+    n = int(off[-1])
+    buf = np.frombuffer(b"".join(raw) + b"\0" * 64, dtype=np.uint8).copy()
+    st = np.zeros(n + 2, dtype=np.uint8)
+    en = np.zeros(n + 2, dtype=np.uint8)
+    jb = js.encode("utf-8")
+    assert harness.plh_run(jb, len(jb), buf.ctypes.data, n, off.ctypes.data, len(raw), st.ctypes.data, en.ctypes.data) == 0
+    exp_s = np.zeros(n + 2, dtype=np.uint8)
+    exp_e = np.zeros(n + 2, dtype=np.uint8)
+    for d, text in enumerate(docs):
+        for a, b in o.pre_tokenize(text):
+            exp_s[off[d] + a] = 1
+            exp_e[off[d] + b] = 1
+    for got, exp, what in ((st, exp_s, "start"), (en, exp_e, "end")):
+        bad = np.nonzero(got != exp)[0]
+        if len(bad):
+            g = int(bad[0])
+            d = int(np.searchsorted(off, g, side="right") - 1)
+            raise AssertionError(f"{what}: {len(bad)} wrong bits; first at doc {d} byte {g - off[d]}: {docs[d]!r} core={got[g]} oracle={exp[g]}")
