@@ -183,6 +183,19 @@ def main() -> None:
                 "gbps_from_list_of_str": round(n_bytes / (best + t_pack) / 1e9, 3),
                 "note": "tkamd_encode_batch: pageable H2D of text + kernels + D2H of ids/CSR into host memory; never reported as value"}
         assert res.n_tokens == n_tok
+        try:        # the same from a Python list[str] through the tokenizer's reusable staging (what a caller of encode_batch_fast feels)
+            tok.encode_batch_fast(lines, add_special_tokens=False)
+            best2 = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r2 = tok.encode_batch_fast(lines, add_special_tokens=False)
+                best2 = min(best2, time.perf_counter() - t0)
+            host["encode_batch_fast_list_of_str_ms"] = round(best2 * 1e3, 2)
+            host["gbps_encode_batch_fast_list_of_str"] = round(n_bytes / best2 / 1e9, 3)
+            if r2.n_tokens != n_tok:
+                host["encode_batch_fast_list_of_str_error"] = "token count differs"
+        except Exception as ex:     # never lose the bench line to the auxiliary leg
+            host["encode_batch_fast_list_of_str_error"] = repr(ex)
 
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's Rayon encode_batch on the host cores ----
     cpu = None

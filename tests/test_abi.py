@@ -145,3 +145,27 @@ def test_decode_tables_match_the_oracle_token_by_token():
             assert fl == (1 if o.id2tok[i] in o.special else 0), (case["tokenizer"], i)
             assert first == o.decode_bytes([i], False), (case["tokenizer"], case["decoder"], i)
             assert front + rest == o.decode_bytes([anchor, i], False), (case["tokenizer"], case["decoder"], i)
+
+
+def test_staged_marshalling_matches_pack_documents():
+    """Host logic: Tokenizer._pack_staged (reusable staging, threaded copy) == pack_documents, across growth, reuse with a
+    smaller batch, empty input, non-ASCII strings and the error cases."""
+    import numpy as np
+    import pytest
+    import tokenizers_amd as ta
+    from oracle import synth
+    from tests.helpers import load_tokenizer_json
+    tk = ta.Tokenizer.from_str(load_tokenizer_json("wordlevel_wssplit"), device=-1)
+    batches = [["héllo", "中文", "", "a" * 100], [], synth.gen_lines(70000, text_seed=1) + ["\U0001F601 x"], ["tiny"], synth.gen_lines(300, text_seed=2)]
+    for docs in batches:
+        buf, off = tk._pack_staged(docs)
+        ref_buf, ref_off = ta.pack_documents(docs)
+        assert off.tolist() == ref_off.tolist()
+        assert bytes(buf) == bytes(ref_buf)                  # text + 64 zero bytes
+        assert buf.ctypes.data % 16 == 0
+    with pytest.raises(TypeError):
+        tk._pack_staged(["a", 3])
+    with pytest.raises(ta.UnsupportedError):
+        tk._pack_staged(["a", ("b", "c")])
+    with pytest.raises(ta.DeviceError):                      # the whole path on a host-only handle: marshals, then fails loudly
+        tk.encode_batch_fast(["a b"], add_special_tokens=False)

@@ -68,7 +68,7 @@ def build_marshal(force: bool = False) -> str:
     cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
     if not cc:
         raise RuntimeError("no C compiler for tokenizers_amd._marshal")
-    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"], MARSHAL_SRC, "-o", out + ".tmp"]
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-pthread", "-I" + sysconfig.get_paths()["include"], MARSHAL_SRC, "-o", out + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building _marshal failed:\n" + r.stdout + r.stderr)

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import threading
 from typing import Iterable, Sequence
 
 import numpy as np
@@ -227,6 +228,10 @@ class Tokenizer:
         rc = lib.tkamd_tokenizer_specials(self._h, pre, C.byref(npre), suf, C.byref(nsuf), 16)
         self._specials_error = None if rc == _lib.OK else (lib.tkamd_last_error() or b"").decode()
         self._specials = (npre.value, nsuf.value) if rc == _lib.OK else (0, 0)
+        # reusable host staging for list[str] inputs (grow-only; no allocation / first-touch page faults per batch)
+        self._stage_text = None
+        self._stage_off = None
+        self._stage_lock = threading.Lock()
 
     # ---- constructors (Tokenizer::from_str / from_file, tokenizer/mod.rs:468-472) ----
     @staticmethod
@@ -264,12 +269,34 @@ class Tokenizer:
         if add_special_tokens and self._specials_error:
             raise UnsupportedError(self._specials_error)
 
+    def _pack_staged(self, inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
+        """``list[str]`` -> (uint8 text + TEXT_PAD zero bytes, int64 CSR offsets) as views of this tokenizer's reusable
+        staging buffers: same contents as :func:`pack_documents`, valid until the next call (caller holds _stage_lock)."""
+        if _marshal is None or not hasattr(_marshal, "pack_into") or not isinstance(inputs, (list, tuple)):
+            return pack_documents(inputs)
+        n = len(inputs)
+        if self._stage_off is None or len(self._stage_off) < n + 1:
+            self._stage_off = np.empty(max(n + 1, 1024, 2 * (len(self._stage_off) if self._stage_off is not None else 0)), dtype=np.int64)
+        if self._stage_text is None:
+            self._stage_text = np.empty(1 << 20, dtype=np.uint8)
+        for _ in range(2):
+            text = self._stage_text
+            try:
+                total = _marshal.pack_into(inputs, text.ctypes.data, text.nbytes, self._stage_off.ctypes.data)
+            except NotImplementedError as e:
+                raise UnsupportedError(str(e)) from None
+            if total + _lib.TEXT_PAD <= text.nbytes:
+                return text[: total + _lib.TEXT_PAD], self._stage_off[: n + 1]
+            self._stage_text = np.empty(total + total // 4 + _lib.TEXT_PAD, dtype=np.uint8)     # nothing was copied: grow and redo
+        raise RuntimeError("staging buffer growth failed")          # pragma: no cover
+
     def encode_batch_csr(self, inputs: Sequence[str], offsets: str = "none", word_ids: bool = False,
                          add_special_tokens: bool = False) -> BatchEncoding:
         """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17)."""
         self._check_special(add_special_tokens)
-        buf, doc_off = pack_documents(inputs)
-        return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens)
+        with self._stage_lock:                               # the staging buffers are per tokenizer; results are copied out by the library
+            buf, doc_off = self._pack_staged(inputs)
+            return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens)
 
     def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
                       add_special_tokens: bool = False) -> BatchEncoding:
