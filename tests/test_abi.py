@@ -169,3 +169,28 @@ def test_staged_marshalling_matches_pack_documents():
         tk._pack_staged(["a", ("b", "c")])
     with pytest.raises(ta.DeviceError):                      # the whole path on a host-only handle: marshals, then fails loudly
         tk.encode_batch_fast(["a b"], add_special_tokens=False)
+
+
+def test_read_lines_keeps_terminators_like_the_reference_line_reader(tmp_path):
+    """On-disk ingest: one document per line, terminators kept (utils/iter.rs:64-100 lines_with_ending)."""
+    import numpy as np
+    import tokenizers_amd as ta
+    cases = [b"", b"\n", b"a", b"a\n", b"a\nb", b"a\r\nb\r\n", b"\n\n", "héllo wörld\n中文\n".encode("utf-8") * 1000 + b"tail"]
+    for i, data in enumerate(cases):
+        p = tmp_path / f"f{i}.txt"
+        p.write_bytes(data)
+        buf, off = ta.read_lines(str(p))
+        want = data.splitlines(keepends=True) if b"\r" not in data.replace(b"\r\n", b"") else None
+        lines = [bytes(buf[off[d]:off[d + 1]]) for d in range(len(off) - 1)]
+        # bytes.splitlines also splits on a lone \r, \v, \f...; the reference splits on \n only
+        ref, cur = [], b""
+        for b in data:
+            cur += bytes([b])
+            if b == 10:
+                ref.append(cur)
+                cur = b""
+        if cur:
+            ref.append(cur)
+        assert lines == ref, data[:40]
+        assert off[0] == 0 and off[-1] == len(data) and bytes(buf[len(data):]) == b"\0" * 64
+        assert want is None or want == ref

@@ -128,8 +128,39 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
     return total < 0 ? NULL : PyLong_FromLongLong(total);
 }
 
+/* line_offsets(addr, n) -> bytearray of int64 CSR offsets of the '\n'-terminated lines of the n bytes at addr, every line
+ * keeping its terminator -- the reference's own line reader, Lines / lines_with_ending (tokenizers/src/utils/iter.rs:64-100,
+ * used by train_from_files, tokenizer/mod.rs:1432-1444: "we want to keep the \n and potential \r").  A last line without a
+ * terminator is a line too; an empty buffer has no lines.  The file's bytes ARE the batch text: nothing is copied. */
+static PyObject* line_offsets(PyObject* self, PyObject* args) {
+    unsigned long long addr, n;
+    if (!PyArg_ParseTuple(args, "KK", &addr, &n)) return NULL;
+    const char* p = (const char*)(uintptr_t)addr;
+    Py_ssize_t lines = 0;
+    Py_BEGIN_ALLOW_THREADS
+    for (const char* q = p, *e = p + n; q < e;) {
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+        ++lines;
+        if (!nl) break;
+        q = nl + 1;
+    }
+    Py_END_ALLOW_THREADS
+    PyObject* offs = PyByteArray_FromStringAndSize(NULL, (lines + 1) * (Py_ssize_t)sizeof(int64_t));
+    if (!offs) return NULL;
+    int64_t* off = (int64_t*)PyByteArray_AS_STRING(offs);
+    Py_ssize_t k = 0;
+    off[0] = 0;
+    for (const char* q = p, *e = p + n; q < e;) {
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(e - q));
+        q = nl ? nl + 1 : e;
+        off[++k] = (int64_t)(q - p);
+    }
+    return offs;
+}
+
 static PyMethodDef methods[] = {
     {"pack", pack, METH_O, "pack(seq_of_str) -> (bytearray utf8 + 64 zero bytes, bytearray int64 offsets[n+1])"},
+    {"line_offsets", line_offsets, METH_VARARGS, "line_offsets(addr, n) -> bytearray int64 offsets of the lines (terminators kept)"},
     {"pack_into", pack_into, METH_VARARGS, "pack_into(seq_of_str, text_addr, text_capacity, off_addr) -> total bytes (copied iff it fits)"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef mod = {PyModuleDef_HEAD_INIT, "_marshal", "list[str] -> UTF-8 CSR marshalling", -1, methods};

@@ -57,6 +57,29 @@ def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
     return buf, offsets
 
 
+def read_lines(path: str) -> tuple[np.ndarray, np.ndarray]:
+    """A newline-delimited file -> (uint8 buffer with TEXT_PAD slack, int64 CSR offsets), one document per line.
+
+    Lines keep their terminator, like the reference's own line reader (``lines_with_ending``, utils/iter.rs:64-100, used by
+    ``train_from_files``, tokenizer/mod.rs:1432-1444), so the file's bytes are the batch text as they are: one read, no
+    per-line copies.  The text must be UTF-8 (the device path does not validate it).
+    """
+    import os
+    size = os.path.getsize(path)
+    buf = np.empty(size + _lib.TEXT_PAD, dtype=np.uint8)
+    with open(path, "rb") as fh:
+        got = fh.readinto(memoryview(buf)[:size]) if size else 0
+    if got != size:
+        raise OSError(f"short read on {path}: {got} of {size} bytes")
+    buf[size:] = 0
+    if _marshal is not None and hasattr(_marshal, "line_offsets"):
+        off = np.frombuffer(_marshal.line_offsets(buf.ctypes.data, size), dtype=np.int64)
+    else:                                                    # pragma: no cover - numpy equivalent of the C scan
+        nl = np.flatnonzero(buf[:size] == 10).astype(np.int64) + 1
+        off = np.concatenate([[0], nl, [size]] if size and (not len(nl) or nl[-1] != size) else [[0], nl]).astype(np.int64)
+    return buf, off
+
+
 class Encoding:
     """Read-only view of one document of a :class:`BatchEncoding`.
 
@@ -331,6 +354,11 @@ class Tokenizer:
         if word_ids:
             wids = view(self._lib.tkamd_batch_word_ids(b), C.c_uint32, (nt,), np.uint32)
         return BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0))
+
+    def encode_file(self, path: str, offsets: str = "none", word_ids: bool = False, add_special_tokens: bool = False) -> BatchEncoding:
+        """Encode a newline-delimited UTF-8 file, one document per line *including its terminator* (:func:`read_lines`)."""
+        buf, off = read_lines(path)
+        return self.encode_packed(buf, off, offsets, word_ids, add_special_tokens)
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
