@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "host_model.hpp"
+#include "pretok_gpt2_core.hpp"
 #include "pretok_l3_core.hpp"
 #include "pretok_local_core.hpp"
 
@@ -109,5 +110,49 @@ extern "C" int plh_run(const char* json, size_t json_len, const uint8_t* text, i
     else if (hm.pretok == PT_WHITESPACE_SPLIT) pl_run<PT_WHITESPACE_SPLIT>(hm, t, n, docstart, start_out, end_out);
     else if (hm.pretok == PT_BERT) pl_run<PT_BERT>(hm, t, n, docstart, start_out, end_out);
     else return -2;
+    return 0;
+}
+
+// ---- pretok_gpt2_core.hpp: GPT-2 ByteLevel split, 48 bytes per window ----------------------------------------------------
+extern "C" int g2h_run(const char* json, size_t json_len, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs,
+                       uint8_t* start_out) {
+    HostModel hm;
+    try {
+        hm = HostModel::from_json(json, json_len);
+    } catch (const std::exception&) {
+        return -1;
+    }
+    std::vector<uint8_t> docstart((size_t)n + 64, 0);
+    for (int64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) docstart[doc_off[d]] = 1;
+    std::vector<uint8_t> buf((size_t)n + 64 + 128, 0);
+    uint8_t* t = buf.data() + 64;
+    memcpy(t, text, (size_t)n);
+    Gpt2Flags lut[256];
+    for (uint32_t v = 0; v < 256; ++v) lut[v] = gpt2_byte_flags(v);
+    for (int64_t a = 0; a < n; a += G2W_MAIN) {
+        const int64_t base = a - G2W_HALO;
+        Gpt2Window w{};
+        for (int i = 0; i < 64; ++i) {
+            const int64_t g = base + i;
+            if (g < 0 || g >= n) continue;
+            const Gpt2Flags f = lut[t[g]];
+            const uint64_t bit = 1ull << i;
+            w.V |= bit;
+            if (f.x & 1u) w.L |= bit;
+            if (f.x & (1u << 8)) w.N |= bit;
+            if (f.x & (1u << 16)) w.S |= bit;
+            if (f.x & (1u << 24)) w.SP |= bit;
+            if (f.y & 1u) w.C |= bit;
+            if (f.y & (1u << 8)) w.AP |= bit;
+            if (f.y & (1u << 16)) w.MU |= bit;
+            if (docstart[g]) w.D |= bit;
+        }
+        const uint64_t st = gpt2_window_starts(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data());
+        for (int i = G2W_HALO; i < G2W_HALO + G2W_MAIN; ++i) {
+            const int64_t g = base + i;
+            if (g < n) start_out[g] = (st >> i) & 1;
+        }
+    }
     return 0;
 }

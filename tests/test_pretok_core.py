@@ -21,7 +21,7 @@ SO = os.path.join(HERE, "harness", "_l3_harness.so")
 @pytest.fixture(scope="module")
 def harness():
     srcs = [os.path.join(HERE, "harness", "l3_harness.cpp"), os.path.join(CSRC, "host_model.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("pretok_l3_core.hpp", "pretok_local_core.hpp", "tables.hpp", "host_model.hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("pretok_gpt2_core.hpp", "pretok_l3_core.hpp", "pretok_local_core.hpp", "tables.hpp", "host_model.hpp")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC, "-I" + os.path.join(ROOT, "include")] + srcs + ["-o", SO],
                        check=True)
@@ -30,6 +30,8 @@ def harness():
     lib.l3h_run.restype = C.c_int
     lib.plh_run.argtypes = lib.l3h_run.argtypes
     lib.plh_run.restype = C.c_int
+    lib.g2h_run.argtypes = lib.l3h_run.argtypes[:-1]
+    lib.g2h_run.restype = C.c_int
     return lib
 
 
@@ -158,3 +160,28 @@ def test_local_core_matches_oracle(harness, name):
             g = int(bad[0])
             d = int(np.searchsorted(off, g, side="right") - 1)
             raise AssertionError(f"{what}: {len(bad)} wrong bits; first at doc {d} byte {g - off[d]}: {docs[d]!r} core={got[g]} oracle={exp[g]}")
+
+
+# ---- pretok_gpt2_core.hpp: the GPT-2 ByteLevel split (the headline configuration's pre-tokenizer) -------------------------
+
+def test_gpt2_core_matches_oracle(harness):
+    js = load_tokenizer_json("gpt2_synth_50257")
+    o = orc.Oracle(js)
+    docs = []
+    for seed in range(6):
+        docs += _adversarial(40000, 300 + seed, max_len=40)
+    docs += _adversarial(3000, 310, max_len=400) + synth.gen_lines(10000, text_seed=11) + synth.stress_lines(seed=6, n=3000) + ["", " ", "'", "a", "it's", "  x"]
+    raw = [d.encode("utf-8") for d in docs]
+    off = np.zeros(len(raw) + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in raw], out=off[1:])
+    n = int(off[-1])
+    buf = np.frombuffer(b"".join(raw) + b"\0" * 64, dtype=np.uint8).copy()
+    st = np.zeros(n + 1, dtype=np.uint8)
+    jb = js.encode("utf-8")
+    assert harness.g2h_run(jb, len(jb), buf.ctypes.data, n, off.ctypes.data, len(raw), st.ctypes.data) == 0
+    exp = _expected(o, docs, off)
+    bad = np.nonzero(st[:n] != exp)[0]
+    if len(bad):
+        g = int(bad[0])
+        d = int(np.searchsorted(off, g, side="right") - 1)
+        raise AssertionError(f"{len(bad)} wrong bytes; first at doc {d} byte {g - off[d]}: {docs[d]!r} core={st[g]} oracle={exp[g]}")

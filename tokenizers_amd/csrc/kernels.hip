@@ -19,6 +19,7 @@
 
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include "pretok_gpt2_core.hpp"
 #include "pretok_l3_core.hpp"
 #include "pretok_local_core.hpp"
 #include "tables.hpp"
@@ -467,14 +468,9 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restri
                                                          unsigned long long* __restrict__ startmask) {
     __shared__ uint2 lut[SQ_LUT_COPIES * 256];
     {
-        const uint32_t v = threadIdx.x;                      // 256 threads: one table entry each
-        const uint32_t lower = v | 0x20u;
-        const bool isL = v < 0x80u && (lower - 'a' < 26u), isN = (v - '0' < 10u), isS = (v == 0x20u) || (v - 9u < 5u);
-        uint2 e;
-        e.x = (isL ? 1u : 0u) | (isN ? 1u << 8 : 0u) | (isS ? 1u << 16 : 0u) | (v == 0x20u ? 1u << 24 : 0u);
-        e.y = ((v & 0xC0u) == 0x80u ? 1u : 0u) | (v == '\'' ? 1u << 8 : 0u) | (v >= 0xC0u ? 1u << 16 : 0u);
+        const Gpt2Flags f = gpt2_byte_flags(threadIdx.x);    // 256 threads: one table entry each
 #pragma unroll
-        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + v] = e;
+        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + threadIdx.x] = make_uint2(f.x, f.y);
     }
     __syncthreads();
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
@@ -532,40 +528,10 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restri
             AP |= (unsigned long long)((accB >> 8) & 0xFFu) << (8 * g);
             MU |= (unsigned long long)((accB >> 16) & 0xFFu) << (8 * g);
         }
-        // multi-byte code points: class from the Unicode table, spread over the lead and its continuation bytes
-        for (unsigned long long m = MU & V; m; m &= m - 1) {
-            const int k = __ffsll((long long)m) - 1;
-            uint32_t len;
-            const uint32_t cls = cls_lns(utf8_global(text, base + k, &len), uc1, uc2);
-            const unsigned long long span = ((1ull << len) - 1ull) << k;
-            if (cls == 1u) L |= span; else if (cls == 2u) N |= span; else if (cls == 3u) S |= span;
-        }
-        L &= V; N &= V; S &= V; SP &= V;
-        const unsigned long long LEAD = ~C & V, nD = ~D;
-        const unsigned long long O = V & ~(L | N | S);
-        const unsigned long long pL = (L << 1) & nD, pN = (N << 1) & nD, pS = (S << 1) & nD, pO = (O << 1) & nD, pSP = (SP << 1) & nD;
-        // contraction literals 's 't 'm 'd | 're 've 'll that are match starts
-        unsigned long long CON2 = 0, CON3 = 0;
-        {
-            const unsigned long long ok = V & nD;                                   // byte exists and continues the document
-            const unsigned long long cond = D | pL | pN | (pS & ~pSP);
-            for (unsigned long long m = AP & V & cond & (ok >> 1) & (L >> 1); m; m &= m - 1) {
-                const int k = __ffsll((long long)m) - 1;
-                const uint32_t b1 = text[base + k + 1], b2 = text[base + k + 2];
-                if (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd') CON2 |= 1ull << k;
-                else if ((((b1 == 'r' || b1 == 'v') && b2 == 'e') || (b1 == 'l' && b2 == 'l')) && ((ok >> (k + 2)) & 1ull)) CON3 |= 1ull << k;
-            }
-        }
-        const unsigned long long con = CON2 | CON3;
-        const unsigned long long eaten = (con << 1) | (CON3 << 2);
-        const unsigned long long after = (CON2 << 2) | (CON3 << 3);
-        const unsigned long long run = (L & ~(pL | pSP)) | (N & ~(pN | pSP)) | (O & ~(pO | pSP));
-        const unsigned long long wsfirst = S & ~pS;
-        // whitespace after whitespace starts a match iff the NEXT code point is a non-space of the same document
-        unsigned long long Y = (LEAD & ~S & nD) >> 1;
-        Y |= (Y & C) >> 1; Y |= (Y & C) >> 1; Y |= (Y & C) >> 1;
-        const unsigned long long wslast = S & pS & Y;
-        const unsigned long long start = LEAD & (D | (~eaten & (con | after | run | wsfirst | wslast)));
+        // the regex as mask algebra: pretok_gpt2_core.hpp (the same function the CPU test runs against a sequential matcher)
+        Gpt2Window m;
+        m.L = L; m.N = N; m.S = S; m.SP = SP; m.C = C; m.AP = AP; m.MU = MU; m.V = V; m.D = D;
+        const unsigned long long start = gpt2_window_starts(m, text, base, uc1, uc2);
         out = (start >> SQ_HALO) & ((1ull << SQ_MAIN) - 1ull);
     }
     // four lanes' 48-bit results are three 64-bit mask words

@@ -1,0 +1,86 @@
+// GPT-2 ByteLevel split as 64-bit mask algebra over one 64-byte window.
+//
+//   's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+        pre_tokenizers/byte_level.rs:43-46
+//
+// The per-lane logic of k_pretok_gpt2_seq (kernels.hip): a lane owns the 48 bytes [8, 56) of its window and decides for
+// each of them whether a regex match starts there (the rule only looks <= 4 code points back and
+// 3 ahead, so an 8-byte halo is enough and nothing is ever left undecided).  Plain host+device code: the CPU test
+// tests/test_pretok_core.py runs this very function (tests/harness/l3_harness.cpp) against the sequential matcher of
+// the test tree.  Bit i of every mask = window byte i.
+#pragma once
+#include <cstdint>
+
+#include "tables.hpp"
+
+namespace tkamd {
+
+constexpr int G2W_HALO = 8;
+constexpr int G2W_MAIN = 48;
+constexpr uint64_t G2W_MAIN_MASK = 0x00FFFFFFFFFFFF00ull;
+
+struct Gpt2Window {
+    uint64_t L, N, S, SP;         // letter, number, whitespace (Oniguruma \s), U+0020      ASCII bytes only on entry
+    uint64_t C, AP, MU;           // continuation byte, apostrophe, multi-byte lead
+    uint64_t V, D;                // byte exists, byte starts a document
+};
+
+// flag words of one byte value for the caller's 256-entry table: bits 0 / 8 / 16 / 24 of .x = L, N, S, SP; bits 0 / 8 / 16
+// of .y = continuation, apostrophe, multi-byte lead
+struct Gpt2Flags { uint32_t x, y; };
+TK_HD Gpt2Flags gpt2_byte_flags(uint32_t v) {
+    const uint32_t lower = v | 0x20u;
+    const bool isL = v < 0x80u && (lower - 'a' < 26u), isN = (v - '0' < 10u), isS = (v == 0x20u) || (v - 9u < 5u);
+    Gpt2Flags f;
+    f.x = (isL ? 1u : 0u) | (isN ? 1u << 8 : 0u) | (isS ? 1u << 16 : 0u) | (v == 0x20u ? 1u << 24 : 0u);
+    f.y = ((v & 0xC0u) == 0x80u ? 1u : 0u) | (v == '\'' ? 1u << 8 : 0u) | (v >= 0xC0u ? 1u << 16 : 0u);
+    return f;
+}
+
+// `text + base` is window byte 0 (V says which bytes exist; the text carries TKAMD_TEXT_PAD readable bytes after its end).
+// Returns the match starts of window bytes [8, 56) in bits 8..55.
+TK_HD uint64_t gpt2_window_starts(Gpt2Window m, const uint8_t* text, int64_t base, const uint16_t* uc1, const uint8_t* uc2) {
+    const uint64_t V = m.V, D = m.D & V;
+    uint64_t L = m.L, N = m.N, S = m.S;
+    const uint64_t C = m.C, SP = m.SP & V;
+    // multi-byte code points: class from the Unicode table, spread over the lead and its continuation bytes
+    for (uint64_t mm = m.MU & V; mm; mm &= mm - 1) {
+        const int k = __builtin_ctzll(mm);
+        const uint8_t* p = text + base + k;
+        const uint32_t b0 = p[0];
+        uint32_t cp, len;
+        if (b0 < 0xE0u) { len = 2; cp = ((b0 & 0x1Fu) << 6) | (p[1] & 0x3Fu); }
+        else if (b0 < 0xF0u) { len = 3; cp = ((b0 & 0x0Fu) << 12) | ((p[1] & 0x3Fu) << 6) | (p[2] & 0x3Fu); }
+        else { len = 4; cp = ((b0 & 0x07u) << 18) | ((p[1] & 0x3Fu) << 12) | ((p[2] & 0x3Fu) << 6) | (p[3] & 0x3Fu); }
+        const uint32_t f = cp >= 0x110000u ? 0u : uc2[((uint32_t)uc1[cp >> 8] << 8) | (cp & 255u)];
+        const uint64_t span = ((1ull << len) - 1ull) << k;
+        if (f & UC_ONIG_L) L |= span; else if (f & UC_ONIG_N) N |= span; else if (f & UC_ONIG_S) S |= span;
+    }
+    L &= V; N &= V; S &= V;
+    const uint64_t LEAD = ~C & V, nD = ~D;
+    const uint64_t O = V & ~(L | N | S);
+    const uint64_t pL = (L << 1) & nD, pN = (N << 1) & nD, pS = (S << 1) & nD, pO = (O << 1) & nD, pSP = (SP << 1) & nD;
+    // contraction literals 's 't 'm 'd | 're 've 'll that are match starts
+    uint64_t CON2 = 0, CON3 = 0;
+    {
+        const uint64_t ok = V & nD;                                          // byte exists and continues the document
+        const uint64_t cond = D | pL | pN | (pS & ~pSP);
+        for (uint64_t mm = m.AP & V & cond & (ok >> 1) & (L >> 1); mm; mm &= mm - 1) {
+            const int k = __builtin_ctzll(mm);
+            const uint32_t b1 = text[base + k + 1], b2 = text[base + k + 2];
+            if (b1 == 's' || b1 == 't' || b1 == 'm' || b1 == 'd') CON2 |= 1ull << k;
+            else if ((((b1 == 'r' || b1 == 'v') && b2 == 'e') || (b1 == 'l' && b2 == 'l')) && k + 2 < 64 && ((ok >> (k + 2)) & 1ull)) CON3 |= 1ull << k;
+        }
+    }
+    const uint64_t con = CON2 | CON3;
+    const uint64_t eaten = (con << 1) | (CON3 << 2);
+    const uint64_t after = (CON2 << 2) | (CON3 << 3);
+    const uint64_t run = (L & ~(pL | pSP)) | (N & ~(pN | pSP)) | (O & ~(pO | pSP));
+    const uint64_t wsfirst = S & ~pS;
+    // whitespace after whitespace starts a match iff the NEXT code point is a non-space of the same document
+    uint64_t Y = (LEAD & ~S & nD) >> 1;
+    Y |= (Y & C) >> 1; Y |= (Y & C) >> 1; Y |= (Y & C) >> 1;
+    const uint64_t wslast = S & pS & Y;
+    return LEAD & (D | (~eaten & (con | after | run | wsfirst | wslast))) & G2W_MAIN_MASK;
+}
+
+}  // namespace tkamd
