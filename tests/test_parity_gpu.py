@@ -474,3 +474,30 @@ def test_decode_unsupported_decoder_is_refused():
     tk = ta.Tokenizer.from_str(json.dumps(d), device=0)
     with pytest.raises(ta.UnsupportedError):
         tk.decode_batch([[1, 2, 3]])
+
+
+def test_tile_pretokenizer_variants_agree():
+    """The lane-per-byte tile kernels stay behind the per-lane bit-parallel pre-tokenizers (Llama-3: as their second tier;
+    Whitespace / Bert: as the TKAMD_PRETOK_LOCAL=tile variant).  Run them alone in a subprocess (the selection is read once
+    per process) against the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, tokenizers_amd as ta\n"
+        "from oracle import synth, oracle as orc\n"
+        "from tests.helpers import load_tokenizer_json\n"
+        "from tests.test_parity_gpu import _adversarial_docs\n"
+        "base = synth.gen_lines(3000, text_seed=5) + synth.stress_lines(seed=8, n=1500)\n"
+        "for name in ('llama3_small_6000', 'bert_wordpiece_4000', 'wordlevel_whitespace_c1', 'wordlevel_wssplit'):\n"
+        "    js = load_tokenizer_json(name)\n"
+        "    # BERT: its added tokens ([UNK] ...) behind a normalizer are refused when they occur in the text\n"
+        "    docs = [d for d in base if d.isascii() and '[' not in d] if name.startswith('bert') else base + _adversarial_docs(6000, 21)\n"
+        "    got = ta.Tokenizer.from_str(js, device=0).encode_batch_fast(docs, add_special_tokens=False)\n"
+        "    exp = orc.Oracle(js).encode_batch(docs)\n"
+        "    assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all(), name\n"
+        "print('VARIANT_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TKAMD_PRETOK_L3="tile", TKAMD_PRETOK_LOCAL="tile")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr
