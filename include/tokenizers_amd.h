@@ -146,6 +146,14 @@ void            tkamd_text_free(tkamd_text* b);
 int tkamd_decode_token(const tkamd_tokenizer* tok, uint32_t id, int first_position, uint8_t* out, int32_t cap,
                        int32_t* len, int32_t* flags);
 
+/* Host-side probes of the load-time tables -- the lookups the kernels perform, on the host copy (test hooks; work on
+ * host-only handles).  Return 1 on a hit, 0 on a miss, < 0 on a bad argument.
+ *   tkamd_probe_word : raw pre-token bytes -> token id (vocab.get of bpe/model.rs:559-567, wordlevel/mod.rs:162-178);
+ *                      *flags bit 0 = WORD_DIRECT (byte-level BPE: the merges of these bytes yield exactly [id])
+ *   tkamd_probe_merge: (left id, right id) -> (rank, new id)   (the `merges` map of bpe/model.rs:252-275)          */
+int tkamd_probe_word(const tkamd_tokenizer* tok, const uint8_t* bytes, int32_t len, uint32_t* id, uint32_t* flags);
+int tkamd_probe_merge(const tkamd_tokenizer* tok, uint32_t left, uint32_t right, uint32_t* rank, uint32_t* new_id);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
  * With profiling on, every kernel launch of the next device/host encode calls is bracketed by
  * HIP events on the launch stream.  tkamd_profile_read returns, per kernel, the accumulated

@@ -194,3 +194,97 @@ def test_read_lines_keeps_terminators_like_the_reference_line_reader(tmp_path):
         assert lines == ref, data[:40]
         assert off[0] == 0 and off[-1] == len(data) and bytes(buf[len(data):]) == b"\0" * 64
         assert want is None or want == ref
+
+
+def _probe_all(js):
+    """Every vocabulary entry expressible in raw bytes and every merge of a tokenizer.json must be found by the host-side
+    probes of the load-time tables (the same perfect-hash lookups the kernels do); near-misses must miss."""
+    import ctypes as C
+    import json
+    import tokenizers_amd as ta
+    from oracle.decode_oracle import CHAR_BYTES
+    tk = ta.Tokenizer.from_str(js, device=-1)
+    lib, h = tk._lib, tk._h
+    d = json.loads(js)
+    vocab = d["model"]["vocab"]
+    byte_level = (d.get("pre_tokenizer") or {}).get("type") == "ByteLevel" or "ByteLevel" in json.dumps(d.get("pre_tokenizer"))
+    idv, fl = C.c_uint32(0), C.c_uint32(0)
+    n_found = 0
+    for tok, i in vocab.items():
+        if byte_level:
+            try:
+                raw = bytes(CHAR_BYTES[c] for c in tok)
+            except KeyError:
+                continue                         # not producible from bytes (e.g. a special token's name)
+        else:
+            raw = tok.encode("utf-8")
+        if not raw:
+            continue
+        assert lib.tkamd_probe_word(h, raw, len(raw), C.byref(idv), C.byref(fl)) == 1, tok
+        assert idv.value == i, tok
+        n_found += 1
+        miss = raw + b"\x00"
+        assert lib.tkamd_probe_word(h, miss, len(miss), C.byref(idv), C.byref(fl)) == 0
+    merges = d["model"].get("merges") or []
+    rk, nid = C.c_uint32(0), C.c_uint32(0)
+    last = {}
+    for r, m in enumerate(merges):
+        a, b = m if isinstance(m, list) else m.split(" ")
+        last[(vocab[a], vocab[b])] = (r, vocab[a + b])                   # duplicate pairs: the last rank wins
+    for (a, b), (r, n) in last.items():
+        assert lib.tkamd_probe_merge(h, a, b, C.byref(rk), C.byref(nid)) == 1
+        assert (rk.value, nid.value) == (r, n)
+    if merges:
+        assert lib.tkamd_probe_merge(h, 0xFFFFF0, 0xFFFFF1, C.byref(rk), C.byref(nid)) == 0
+    return n_found, len(last)
+
+
+def test_every_vocab_entry_and_merge_is_in_its_slot():
+    from tests.helpers import GOLDEN_NAMES, load_tokenizer_json
+    for name in GOLDEN_NAMES:
+        n_words, n_merges = _probe_all(load_tokenizer_json(name))
+        assert n_words > 0
+
+
+def test_large_synthetic_vocabulary_builds_and_probes():
+    """A 300k-entry WordLevel vocabulary of random words (lengths 1..40, many sharing prefixes): perfect-hash construction
+    must succeed and every entry must be retrievable -- including the > 16-byte keys of the open-addressing table."""
+    import json
+    import numpy as np
+    rng = np.random.default_rng(3)
+    words = set()
+    alpha = "abcdefghijklmnopqrstuvwxyzéß中"
+    while len(words) < 300_000:
+        n = int(rng.integers(1, 41))
+        words.add("".join(alpha[i] for i in rng.integers(0, len(alpha), size=n)))
+    vocab = {w: i for i, w in enumerate(sorted(words))}
+    vocab["<unk>"] = len(vocab)
+    js = json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": None,
+                     "pre_tokenizer": {"type": "WhitespaceSplit"}, "post_processor": None, "decoder": None,
+                     "model": {"type": "WordLevel", "vocab": vocab, "unk_token": "<unk>"}})
+    n_words, _ = _probe_all(js)
+    assert n_words == len(vocab)
+
+
+def test_malformed_tokenizer_json_is_rejected_not_crashed():
+    import ctypes as C
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    good = load_tokenizer_json("wordlevel_wssplit")
+    bad = ["", "{", "[]", "null", good[: len(good) // 2], good.replace(":", "", 3), '{"model": 3}', '{"model": {"type": "WordLevel", "vocab": {"a": "x"}}}',
+           good.replace('"vocab"', '"vocab\\u12"', 1), "\x00" * 10, good + "}"]
+    for js in bad:
+        with pytest.raises((ValueError, ta.UnsupportedError, ta.TokenizersAmdError)):
+            ta.Tokenizer.from_str(js, device=-1)
+    # random byte flips never crash the parser: they either load or raise one of the library's exceptions
+    import numpy as np
+    rng = np.random.default_rng(0)
+    raw = bytearray(good.encode("utf-8"))
+    for _ in range(300):
+        b = bytearray(raw)
+        for _ in range(3):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(1, 128))
+        try:
+            ta.Tokenizer.from_str(b.decode("utf-8", "replace"), device=-1)
+        except (ValueError, ta.UnsupportedError, ta.TokenizersAmdError):
+            pass

@@ -970,6 +970,51 @@ int tkamd_decode_token(const tkamd_tokenizer* t, uint32_t id, int first_position
     for (uint32_t i = 0; i < l && (int32_t)i < cap && out; ++i) out[i] = hm.dec_blob[off + i];
     return TKAMD_OK;
 }
+// ---- host-side probes of the load-time tables (the lookups the kernels perform, on the host copy; work on host-only
+// handles).  Test hooks: every vocabulary entry and every merge must be found in its one slot.
+int tkamd_probe_word(const tkamd_tokenizer* t, const uint8_t* bytes, int32_t len, uint32_t* id, uint32_t* flags) {
+    if (!t || !bytes || !id || !flags || len < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    const HostModel& hm = t->hm;
+    *id = 0;
+    *flags = 0;
+    if (len == 0 || hm.word_table.empty()) return 0;
+    if (len <= WORD_MAX_KEY) {
+        uint8_t buf[16] = {0};
+        memcpy(buf, bytes, (size_t)len);
+        uint64_t lo, hi;
+        memcpy(&lo, buf, 8);
+        memcpy(&hi, buf + 8, 8);
+        const uint32_t h1 = word_hash1(lo, hi, (uint32_t)len, hm.word_seed);
+        const WordSlot& s = hm.word_table[ph_slot(word_hash2(h1), hm.word_disp[h1 & hm.word_bmask], hm.word_mask)];
+        if (s.len != (uint32_t)len || s.lo != lo || s.hi != hi) return 0;
+        *id = s.id;
+        *flags = s.flags;
+        return 1;
+    }
+    if (hm.long_table.empty()) return 0;
+    uint32_t h = fnv1a(bytes, (size_t)len) & hm.long_mask;
+    for (;;) {
+        const uint32_t e = hm.long_table[h];
+        if (!e) return 0;
+        const uint32_t o = hm.long_off[e - 1], l = hm.long_off[e] - o;
+        if (l == (uint32_t)len && memcmp(&hm.long_blob[o], bytes, (size_t)len) == 0) { *id = hm.long_id[e - 1]; return 1; }
+        h = (h + 1) & hm.long_mask;
+    }
+}
+int tkamd_probe_merge(const tkamd_tokenizer* t, uint32_t left, uint32_t right, uint32_t* rank, uint32_t* new_id) {
+    if (!t || !rank || !new_id) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    const HostModel& hm = t->hm;
+    *rank = RANK_NONE;
+    *new_id = 0;
+    if (hm.merge_table.empty() || hm.merge_disp.empty()) return 0;
+    const uint32_t d = hm.merge_disp[merge_hash1(left, right, hm.merge_seed) & hm.merge_bmask];
+    const MergeSlot& s = hm.merge_table[ph_slot(merge_hash2(left, right, hm.merge_seed), d, hm.merge_mask)];
+    if (s.a != left || s.b != right) return 0;
+    *rank = s.rank;
+    *new_id = s.new_id;
+    return 1;
+}
+
 int64_t tkamd_text_n_docs(const tkamd_text* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_text_n_bytes(const tkamd_text* b) { return b ? b->n_bytes : 0; }
 const uint8_t* tkamd_text_bytes(const tkamd_text* b) { return b ? (const uint8_t*)b->bytes.p : nullptr; }
