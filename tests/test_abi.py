@@ -288,3 +288,82 @@ def test_malformed_tokenizer_json_is_rejected_not_crashed():
             ta.Tokenizer.from_str(b.decode("utf-8", "replace"), device=-1)
         except (ValueError, ta.UnsupportedError, ta.TokenizersAmdError):
             pass
+
+
+def test_inplace_merge_algorithm_on_the_real_tables_matches_the_oracle():
+    """The LDS merge kernels' algorithm (symbols stay in place, an `alive` mask, key = rank << 4 | position per live pair,
+    leftmost minimum, new_id = rank + c) replayed on the HOST copy of the perfect-hash merge table (tkamd_probe_merge)
+    must give merge_all's result (the oracle's heap restatement of models/bpe/word.rs:162-250) for every queued word."""
+    import ctypes as C
+    import json
+    import numpy as np
+    import tokenizers_amd as ta
+    from oracle import oracle as orc
+    from oracle import synth
+    from oracle.decode_oracle import CHAR_BYTES, bytes_char
+    from tests.helpers import load_tokenizer_json
+    js = load_tokenizer_json("gpt2_synth_50257")
+    tk = ta.Tokenizer.from_str(js, device=-1)
+    lib, h = tk._lib, tk._h
+    o = orc.Oracle(js)
+    d = json.loads(js)
+    vocab = d["model"]["vocab"]
+    b2c = bytes_char()
+    byte_id = [vocab[b2c[b]] for b in range(256)]
+    merges = d["model"]["merges"]
+    first = merges[0] if isinstance(merges[0], list) else merges[0].split(" ")
+    base = vocab[first[0] + first[1]] - 0                    # new_id = rank + base (host-verified at load; rank 0 -> base)
+    rk, nid = C.c_uint32(0), C.c_uint32(0)
+
+    def probe(a, b):
+        return (rk.value, nid.value) if lib.tkamd_probe_merge(h, a, b, C.byref(rk), C.byref(nid)) == 1 else None
+
+    def merge_inplace(raw: bytes):
+        n = len(raw)
+        sym = [byte_id[b] for b in raw]
+        alive = [True] * n
+        NONE = 0xFFFFFFFF
+        key = [NONE] * n
+        for i in range(n - 1):
+            p = probe(sym[i], sym[i + 1])
+            if p:
+                key[i] = (p[0] << 5) | i
+        while True:
+            best = min(key) if key else NONE
+            if best == NONE:
+                break
+            i, r = best & 31, best >> 5
+            new = r + base
+            j = next(x for x in range(i + 1, n) if alive[x])
+            alive[j] = False
+            k = next((x for x in range(j + 1, n) if alive[x]), None)
+            hh = next((x for x in range(i - 1, -1, -1) if alive[x]), None)
+            sym[i] = new
+            key[j] = NONE
+            p = probe(new, sym[k]) if k is not None else None
+            key[i] = ((p[0] << 5) | i) if p else NONE
+            if hh is not None:
+                p = probe(sym[hh], new)
+                key[hh] = ((p[0] << 5) | hh) if p else NONE
+        return [sym[x] for x in range(n) if alive[x]]
+
+    # the new-id rule the kernels rely on
+    for r, m in enumerate(merges[:2000] + merges[-2000:]):
+        a, b = m if isinstance(m, list) else m.split(" ")
+        rr = r if r < 2000 else len(merges) - 4000 + r
+        assert vocab[a + b] == rr + base
+    words = set()
+    for line in synth.gen_lines(3000, text_seed=12) + synth.stress_lines(seed=3, n=1500):
+        for a, b in o.pre_tokenize(line):
+            w = line.encode("utf-8")[a:b]
+            if 2 <= len(w) <= 32:
+                words.add(w)
+    rng = np.random.default_rng(1)
+    for _ in range(3000):                                    # random byte strings: unseen pairs, no merges at all, ...
+        words.add(bytes(rng.integers(32, 127, size=int(rng.integers(2, 20))).tolist()))
+    checked = 0
+    for w in sorted(words)[:12000]:
+        exp = [t[0] for t in o.model_tokenize("".join(b2c[b] for b in w))]      # the model sees the byte-level alphabet
+        assert merge_inplace(w) == exp, w
+        checked += 1
+    assert checked > 5000
