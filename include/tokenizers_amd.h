@@ -153,6 +153,13 @@ int tkamd_decode_token(const tkamd_tokenizer* tok, uint32_t id, int first_positi
  *   tkamd_probe_merge: (left id, right id) -> (rank, new id)   (the `merges` map of bpe/model.rs:252-275)          */
 int tkamd_probe_word(const tkamd_tokenizer* tok, const uint8_t* bytes, int32_t len, uint32_t* id, uint32_t* flags);
 int tkamd_probe_merge(const tkamd_tokenizer* tok, uint32_t left, uint32_t right, uint32_t* rank, uint32_t* new_id);
+/* BertNormalizer::normalize (normalizers/bert.rs:92-138) of ONE code point from the host copy of the generated tables:
+ * out[0..*n) (at most 12 code points; 0 = the char is removed), *refused = 1 where strip_accents would need a
+ * context-dependent NFD reordering (the device path refuses such text). */
+int tkamd_probe_bert_norm(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* out, int32_t* n, int32_t* refused);
+/* Class flags of one code point from the host copy of the generated Unicode table: bit 0 \p{L}, 1 \p{N}, 2 \s (as
+ * Oniguruma sees them, byte_level.rs:43-46), 3 \w, 4 \s (regex crate, whitespace.rs:22), 5 char::is_whitespace, 6 is_bert_punc. */
+int tkamd_probe_unicode_flags(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* flags);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
  * With profiling on, every kernel launch of the next device/host encode calls is bracketed by

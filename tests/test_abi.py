@@ -367,3 +367,73 @@ def test_inplace_merge_algorithm_on_the_real_tables_matches_the_oracle():
         assert merge_inplace(w) == exp, w
         checked += 1
     assert checked > 5000
+
+
+@pytest.mark.parametrize("opts", [dict(clean_text=True, handle_chinese_chars=True, strip_accents=None, lowercase=True),
+                                  dict(clean_text=True, handle_chinese_chars=False, strip_accents=False, lowercase=True),
+                                  dict(clean_text=False, handle_chinese_chars=True, strip_accents=True, lowercase=False)])
+def test_bert_normalizer_tables_cover_every_code_point(opts):
+    """The generated BertNormalizer tables (the data the device kernels read), probed on the host for ALL 1,112,064 scalar
+    values, against the reference wheel's BertNormalizer.normalize_str of the single character."""
+    tokenizers = pytest.importorskip("tokenizers")
+    import ctypes as C
+    import json
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    d = json.loads(load_tokenizer_json("bert_wordpiece_4000"))
+    d["normalizer"] = dict({"type": "BertNormalizer"}, **opts)
+    d["added_tokens"] = []
+    tk = ta.Tokenizer.from_str(json.dumps(d), device=-1)
+    ref = tokenizers.normalizers.BertNormalizer(**opts)
+    out = (C.c_uint32 * 16)()
+    n, refused = C.c_int32(0), C.c_int32(0)
+    lib, h = tk._lib, tk._h
+    n_refused = 0
+    for cp in list(range(0, 0xD800)) + list(range(0xE000, 0x110000)):
+        assert lib.tkamd_probe_bert_norm(h, cp, out, C.byref(n), C.byref(refused)) == 0
+        if refused.value:
+            n_refused += 1
+            continue
+        got = "".join(chr(out[i]) for i in range(n.value))
+        assert got == ref.normalize_str(chr(cp)), hex(cp)
+    strip = opts["strip_accents"] if opts["strip_accents"] is not None else opts["lowercase"]
+    assert (n_refused > 0) == bool(strip) and n_refused < 200
+
+
+def test_unicode_class_table_against_the_wheel():
+    """The generated Unicode class table (host copy of what the kernels read) re-probed through the reference wheel's own
+    regex engines and char predicates (the probes of oracle/gen_unicode_tables.py): every code point of the blocks where
+    the classes vary, every 16th code point elsewhere."""
+    tokenizers = pytest.importorskip("tokenizers")
+    import ctypes as C
+    import tokenizers_amd as ta
+    from tokenizers import Regex, pre_tokenizers
+    from tests.helpers import load_tokenizer_json
+    tk = ta.Tokenizer.from_str(load_tokenizer_json("wordlevel_wssplit"), device=-1)
+    onig_l = pre_tokenizers.Split(Regex(r"\p{L}"), behavior="removed")
+    onig_n = pre_tokenizers.Split(Regex(r"\p{N}"), behavior="removed")
+    onig_s = pre_tokenizers.Split(Regex(r"\s"), behavior="removed")
+    ws, wss, bert = pre_tokenizers.Whitespace(), pre_tokenizers.WhitespaceSplit(), pre_tokenizers.BertPreTokenizer()
+    fl = C.c_uint32(0)
+    cps = [cp for cp in range(0x110000) if not 0xD800 <= cp <= 0xDFFF and
+           (cp < 0x3400 or 0xA000 <= cp < 0xAC00 or 0xF900 <= cp < 0x20000 or 0xE0000 <= cp < 0xE0200 or cp % 16 == 0)]
+    for cp in cps:
+        c = chr(cp)
+        f = 0
+        if not onig_l.pre_tokenize_str(c):
+            f |= 1
+        if not onig_n.pre_tokenize_str(c):
+            f |= 2
+        if not onig_s.pre_tokenize_str(c):
+            f |= 4
+        p = ws.pre_tokenize_str("a" + c + "a")
+        if len(p) == 1:
+            f |= 8
+        elif len(p) == 2:
+            f |= 16
+        if len(wss.pre_tokenize_str("a" + c + "a")) == 2:
+            f |= 32
+        if len(bert.pre_tokenize_str("a" + c + "a")) == 3:
+            f |= 64
+        assert tk._lib.tkamd_probe_unicode_flags(tk._h, cp, C.byref(fl)) == 0
+        assert fl.value == f, hex(cp)

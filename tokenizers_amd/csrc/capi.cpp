@@ -1015,6 +1015,63 @@ int tkamd_probe_merge(const tkamd_tokenizer* t, uint32_t left, uint32_t right, u
     return 1;
 }
 
+// Unicode class flags (tables.hpp UC_*) of one code point from the host copy of the two-stage table
+int tkamd_probe_unicode_flags(const tkamd_tokenizer* t, uint32_t cp, uint32_t* flags) {
+    if (!t || !flags) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    const HostModel& hm = t->hm;
+    *flags = (cp >= 0x110000u || hm.uc_stage1.empty()) ? 0u : hm.uc_stage2[((uint32_t)hm.uc_stage1[cp >> 8] << 8) | (cp & 255u)];
+    return TKAMD_OK;
+}
+
+// BertNormalizer expansion of one code point from the HOST copy of the generated tables (the data k_bn_count / k_bn_write
+// read): out[0..*n) code points, *refused = 1 for the code points whose NFD reordering is context dependent.
+int tkamd_probe_bert_norm(const tkamd_tokenizer* t, uint32_t cp, uint32_t* out, int32_t* n, int32_t* refused) {
+    if (!t || !out || !n || !refused) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    const HostModel& hm = t->hm;
+    if (hm.norm != NORM_BERT) return set_error(TKAMD_ERR_UNSUPPORTED, "the tokenizer has no BertNormalizer");
+    constexpr uint32_t DROP = 1, WS = 2, CJK = 4, REORDER = 8, D = 16, LC = 32;     // bert_norm_tables.inc flag bits
+    auto flags = [&](uint32_t c) -> uint32_t {
+        return c >= 0x110000u ? 0u : hm.bn_stage2[((uint32_t)hm.bn_stage1[c >> 8] << 8) | (c & 255u)];
+    };
+    auto lookup = [&](uint32_t c, uint32_t kind, uint32_t* o) -> int {
+        const MergeSlot& x = hm.bn_map[merge_hash1(c, kind, hm.bn_seed) & hm.bn_mask];
+        const MergeSlot& y = hm.bn_map[merge_hash2(c, kind, hm.bn_seed) & hm.bn_mask];
+        const MergeSlot* hit = (x.a == c && x.b == kind) ? &x : (y.a == c && y.b == kind) ? &y : nullptr;
+        if (!hit) { o[0] = c; return 1; }
+        const unsigned long long v = ((unsigned long long)hit->new_id << 32) | hit->rank;
+        int k = 0;
+        const uint32_t a = (uint32_t)(v & 0x1FFFFFu), c1 = (uint32_t)((v >> 21) & 0x1FFFFFu), c2 = (uint32_t)((v >> 42) & 0x1FFFFFu);
+        if (a != 0x1FFFFFu) o[k++] = a;
+        if (c1 != 0x1FFFFFu) o[k++] = c1;
+        if (c2 != 0x1FFFFFu) o[k++] = c2;
+        return k;
+    };
+    *n = 0;
+    *refused = 0;
+    uint32_t f = flags(cp);
+    if (hm.bn_clean_text) {
+        if (f & DROP) return TKAMD_OK;
+        if (f & WS) { cp = ' '; f = 0; }
+    }
+    int k = 0;
+    const bool cjk = hm.bn_handle_chinese && (f & CJK);
+    if (cjk) out[k++] = ' ';
+    uint32_t seq[3] = {cp, 0, 0};
+    int n1 = 1;
+    if (hm.bn_strip_accents) {
+        if (f & REORDER) *refused = 1;
+        if (f & D) n1 = lookup(cp, 0, seq);
+    }
+    for (int q = 0; q < n1; ++q) {
+        const uint32_t y = seq[q];
+        if (hm.bn_lowercase && (flags(y) & LC)) k += lookup(y, 1, out + k);
+        else out[k++] = y;
+    }
+    if (cjk) out[k++] = ' ';
+    *n = k;
+    return TKAMD_OK;
+}
+
 int64_t tkamd_text_n_docs(const tkamd_text* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_text_n_bytes(const tkamd_text* b) { return b ? b->n_bytes : 0; }
 const uint8_t* tkamd_text_bytes(const tkamd_text* b) { return b ? (const uint8_t*)b->bytes.p : nullptr; }
