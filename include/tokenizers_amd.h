@@ -153,6 +153,9 @@ int tkamd_decode_token(const tkamd_tokenizer* tok, uint32_t id, int first_positi
  *   tkamd_probe_merge: (left id, right id) -> (rank, new id)   (the `merges` map of bpe/model.rs:252-275)          */
 int tkamd_probe_word(const tkamd_tokenizer* tok, const uint8_t* bytes, int32_t len, uint32_t* id, uint32_t* flags);
 int tkamd_probe_merge(const tkamd_tokenizer* tok, uint32_t left, uint32_t right, uint32_t* rank, uint32_t* new_id);
+/* One edge of the WordPiece byte trie (the longest-match walk of wordpiece/mod.rs:245-258 as a trie): (node, byte) ->
+ * (child, id of the piece ending there or 0xFFFFFFFF); node 0 = word-initial pieces, 1 = continuation pieces. */
+int tkamd_probe_trie(const tkamd_tokenizer* tok, uint32_t node, uint32_t byte, uint32_t* child, uint32_t* id);
 /* BertNormalizer::normalize (normalizers/bert.rs:92-138) of ONE code point from the host copy of the generated tables:
  * out[0..*n) (at most 12 code points; 0 = the char is removed), *refused = 1 where strip_accents would need a
  * context-dependent NFD reordering (the device path refuses such text). */

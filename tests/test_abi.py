@@ -437,3 +437,56 @@ def test_unicode_class_table_against_the_wheel():
             f |= 64
         assert tk._lib.tkamd_probe_unicode_flags(tk._h, cp, C.byref(fl)) == 0
         assert fl.value == f, hex(cp)
+
+
+def test_wordpiece_trie_walk_on_the_real_table_matches_the_oracle():
+    """k_wordpiece's walk (deepest trie node with an id from the current position; any miss -> the whole word is [UNK];
+    more than max_input_chars_per_word chars -> [UNK]) replayed on the HOST copy of the byte trie (tkamd_probe_trie) against
+    the oracle's restatement of WordPiece::tokenize (models/wordpiece/mod.rs:224-283)."""
+    import ctypes as C
+    import json
+    import tokenizers_amd as ta
+    from oracle import oracle as orc
+    from oracle import synth
+    from tests.helpers import load_tokenizer_json
+    d = json.loads(load_tokenizer_json("bert_wordpiece_4000"))
+    d["normalizer"] = None
+    d["added_tokens"] = []
+    js = json.dumps(d)
+    tk = ta.Tokenizer.from_str(js, device=-1)
+    o = orc.Oracle(js)
+    lib, h = tk._lib, tk._h
+    unk = d["model"]["vocab"][d["model"]["unk_token"]]
+    max_chars = d["model"].get("max_input_chars_per_word", 100)
+    child, tid = C.c_uint32(0), C.c_uint32(0)
+
+    def walk(raw: bytes):
+        if len(raw.decode("utf-8")) > max_chars:
+            return [unk]
+        out, pos = [], 0
+        while pos < len(raw):
+            node, q, best_end, best_id = (1 if pos else 0), pos, 0, 0
+            while q < len(raw):
+                if lib.tkamd_probe_trie(h, node, raw[q], C.byref(child), C.byref(tid)) != 1:
+                    break
+                node = child.value
+                q += 1
+                if tid.value != 0xFFFFFFFF:
+                    best_end, best_id = q, tid.value
+            if not best_end:
+                return [unk]
+            out.append(best_id)
+            pos = best_end
+        return out
+
+    words = set()
+    for line in synth.gen_lines(4000, text_seed=21) + synth.stress_lines(seed=9, n=1500):
+        for a, b in o.pre_tokenize(line):
+            words.add(line.encode("utf-8")[a:b])
+    words |= {b"a" * 101, "é".encode() * 100, "é".encode() * 101, b"x", b"zzzzqqqq", "中文".encode()}
+    n = 0
+    for w in sorted(words):
+        s = w.decode("utf-8")
+        assert walk(w) == [t[0] for t in o.model_tokenize(s)], s
+        n += 1
+    assert n > 3000

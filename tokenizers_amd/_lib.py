@@ -34,7 +34,7 @@ SYMBOLS = [
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
-    "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags",
+    "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
 ]
 
 
@@ -125,6 +125,8 @@ def load() -> C.CDLL:
     lib.tkamd_probe_bert_norm.restype = i32
     lib.tkamd_probe_unicode_flags.argtypes = [vp, u32, C.POINTER(u32)]
     lib.tkamd_probe_unicode_flags.restype = i32
+    lib.tkamd_probe_trie.argtypes = [vp, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.tkamd_probe_trie.restype = i32
     _lib = lib
     return lib
 

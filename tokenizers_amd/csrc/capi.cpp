@@ -1015,6 +1015,23 @@ int tkamd_probe_merge(const tkamd_tokenizer* t, uint32_t left, uint32_t right, u
     return 1;
 }
 
+// one edge of the WordPiece byte trie from the host copy of its 2-choice table: (node, byte) -> (child node, id of the piece that
+// ends at the child or 0xFFFFFFFF).  Node 0 = word-initial pieces, node 1 = continuation pieces.  1 = edge exists.
+int tkamd_probe_trie(const tkamd_tokenizer* t, uint32_t node, uint32_t byte, uint32_t* child, uint32_t* id) {
+    if (!t || !child || !id) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    const HostModel& hm = t->hm;
+    *child = RANK_NONE;
+    *id = 0xFFFFFFFFu;
+    if (hm.trie.table.empty()) return 0;
+    const MergeSlot& x = hm.trie.table[merge_hash1(node, byte, hm.trie.seed) & hm.trie.mask];
+    const MergeSlot& y = hm.trie.table[merge_hash2(node, byte, hm.trie.seed) & hm.trie.mask];
+    const MergeSlot* hit = (x.a == node && x.b == byte) ? &x : (y.a == node && y.b == byte) ? &y : nullptr;
+    if (!hit) return 0;
+    *child = hit->rank;
+    *id = hit->new_id;
+    return 1;
+}
+
 // Unicode class flags (tables.hpp UC_*) of one code point from the host copy of the two-stage table
 int tkamd_probe_unicode_flags(const tkamd_tokenizer* t, uint32_t cp, uint32_t* flags) {
     if (!t || !flags) return set_error(TKAMD_ERR_INVALID, "bad argument");
