@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtokenizers_amd.so")
 SOURCES = ["kernels.hip", "capi.cpp", "host_model.cpp"]
-HEADERS = ["kernels.hpp", "tables.hpp", "device_utils.hpp", "host_model.hpp", "json.hpp", "unicode_ranges.inc", "pretok_gpt2_core.hpp", "pretok_l3_core.hpp", "pretok_local_core.hpp", "bert_norm_tables.inc",
+HEADERS = [os.path.join("kernels", f + ".hip") for f in ("documents", "pretok_gpt2", "pretok_llama3", "pretok_local", "bert_norm", "scan_emit", "bpe", "word_models", "bpe_huge", "output", "decode", "launch")] + ["kernels.hpp", "tables.hpp", "device_utils.hpp", "host_model.hpp", "json.hpp", "unicode_ranges.inc", "pretok_gpt2_core.hpp", "pretok_l3_core.hpp", "pretok_local_core.hpp", "bert_norm_tables.inc",
            os.path.join("..", "..", "include", "tokenizers_amd.h")]
 ARCH = "gfx950"
 

@@ -1,0 +1,760 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  BPE: whole-word lookup and the merge kernels.
+
+// =================================================================================================
+// K_word_lookup: whole pre-token -> token id through the static whole-word table, one lane per
+// pre-token.  Replaces: BPE::tokenize_with_cache's shortcuts (models/bpe/model.rs:558-587):
+//   * ignore_merges: vocab.get(sequence) -> single token (:559-567)                      [exact]
+//   * the thread-local word cache (:573-586): here a STATIC table of vocab entries whose own
+//     merge result was verified at load time to be exactly [id] (WORD_DIRECT), so a hit is
+//     provably what merge_word would return; everything else goes to the merge kernel.
+// =================================================================================================
+struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint64_t* lo, uint64_t* hi) {
+    // ONE byte-unaligned global_load_dwordx4 (legal on gfx950; text buffers carry TKAMD_TEXT_PAD readable slack).
+    // The texture-address unit costs about a cycle per lane request for divergent addresses, so requests -- not
+    // bytes -- are what this path is priced in.
+    const Unaligned16 v = *(const Unaligned16*)(text + s);
+    // branch-free masking of the bytes past `len` (selects only, so callers can keep many loads in flight)
+    uint32_t nl = min(len, 8u), nh = min(len, 16u) - nl;           // bytes kept in the low / high half
+    uint32_t m0 = nl >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nl)) - 1u);
+    uint32_t m1 = nl >= 8 ? 0xFFFFFFFFu : (nl > 4 ? ((1u << (8 * (nl - 4))) - 1u) : 0u);
+    uint32_t m2 = nh >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nh)) - 1u);
+    uint32_t m3 = nh >= 8 ? 0xFFFFFFFFu : (nh > 4 ? ((1u << (8 * (nh - 4))) - 1u) : 0u);
+    *lo = ((uint64_t)(v.b & m1) << 32) | (v.a & m0);
+    *hi = ((uint64_t)(v.d & m3) << 32) | (v.c & m2);
+}
+
+__device__ __forceinline__ bool word_probe_d(const DevTables& t, const uint16_t* disp, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
+    uint32_t h1 = word_hash1(lo, hi, len, t.word_seed);
+    const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
+    uint4 a0 = q[0], a1 = q[1];
+    *id = a1.y;
+    *flags = a1.z;
+    return a1.x == len && a0.x == (uint32_t)lo && a0.y == (uint32_t)(lo >> 32) && a0.z == (uint32_t)hi && a0.w == (uint32_t)(hi >> 32);
+}
+__device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
+    return word_probe_d(t, t.word_disp, lo, hi, len, id, flags);
+}
+
+__device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __restrict__ w, uint32_t len, uint32_t* id) {
+    uint32_t h = 2166136261u;
+    for (uint32_t i = 0; i < len; ++i) { h ^= w[i]; h *= 16777619u; }
+    h &= t.long_mask;
+    for (;;) {
+        uint32_t e = t.long_table[h];
+        if (!e) return false;
+        uint32_t o = t.long_off[e - 1], l = t.long_off[e] - o;
+        if (l == len) {
+            uint32_t i = 0;
+            while (i < len && t.long_blob[o + i] == w[i]) ++i;
+            if (i == len) { *id = t.long_id[e - 1]; return true; }
+        }
+        h = (h + 1) & t.long_mask;
+    }
+}
+
+constexpr uint32_t TOK_ROW = 0x80000000u;         // tok0 flag: the low bits index a dense result row {id0 | count << 28, id1, id2, id3}
+constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
+constexpr uint32_t TOK_ONE = 0x40000000u;         // tok0 flag: exactly one token, its id in the low bits (ntok[p] is not written)
+constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
+constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
+constexpr int LK_CHUNK = 256 * LK_ITEMS;
+constexpr int LK_GROUP = 4;                      // items whose loads are kept in flight together
+
+__global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
+                                                         const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
+                                                         const int64_t* __restrict__ n_pretok,
+                                                         uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                         uint32_t* __restrict__ list16, uint32_t* __restrict__ list32,
+                                                         uint32_t* __restrict__ list64,
+                                                         uint32_t* __restrict__ listL, uint32_t* __restrict__ counters,
+                                                         const unsigned long long* __restrict__ matchmask, RowPlan rows) {
+    __shared__ uint32_t sm[4];
+    __shared__ uint32_t base_s[4];
+    __shared__ uint16_t s_disp[DISP_LDS_MAX];
+    const bool disp_in_lds = t.word_bmask < (uint32_t)DISP_LDS_MAX;
+    if (disp_in_lds)
+        for (uint32_t i = threadIdx.x; i <= t.word_bmask; i += 256) s_disp[i] = t.word_disp[i];
+    __syncthreads();
+    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.word_disp;
+    const int64_t P = *n_pretok;
+    const int64_t n_chunks = (P + LK_CHUNK - 1) / LK_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        // each lane takes LK_ITEMS consecutive pre-tokens: the work queues then stay in pre-token order, which keeps
+        // the merge kernels' text / pt_start / tmp_ids accesses local (measured: lane-strided assignment coalesces
+        // these loads better but costs the merge kernels 30 %)
+        const int64_t pbase = ch * LK_CHUNK + (int64_t)threadIdx.x * LK_ITEMS;
+        uint32_t st[LK_ITEMS], en[LK_ITEMS];
+        if (pbase + LK_ITEMS <= P) {                       // 8 offsets as two 16-byte loads (pbase is a multiple of 8)
+            const uint4 v0 = *(const uint4*)(pt_start + pbase), v1 = *(const uint4*)(pt_start + pbase + 4);
+            st[0] = v0.x; st[1] = v0.y; st[2] = v0.z; st[3] = v0.w; st[4] = v1.x; st[5] = v1.y; st[6] = v1.z; st[7] = v1.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k) st[k] = pt_start[min(pbase + k, P)];
+        }
+        if (pt_end) {                                      // "Removed" pre-tokenizers: explicit ends
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k) en[k] = (pbase + k < P) ? pt_end[pbase + k] : st[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k) en[k] = (k + 1 < LK_ITEMS) ? st[k + 1] : pt_start[min(pbase + LK_ITEMS, P)];
+        }
+        uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list32, 3 -> list64 / listL
+        uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
+        uint32_t out_id[LK_ITEMS];
+#pragma unroll
+        for (int g = 0; g < LK_ITEMS; g += LK_GROUP) {
+            uint64_t lo[LK_GROUP], hi[LK_GROUP];
+            uint32_t len[LK_GROUP];
+#pragma unroll
+            for (int k = 0; k < LK_GROUP; ++k) {
+                len[k] = en[g + k] - st[g + k];
+                load_key16(text, st[g + k], min(len[k], 16u), &lo[k], &hi[k]);
+            }
+            uint4 a0[LK_GROUP], a1[LK_GROUP];
+#pragma unroll
+            for (int k = 0; k < LK_GROUP; ++k) {
+                uint32_t h1 = word_hash1(lo[k], hi[k], len[k], t.word_seed);
+                const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
+                a0[k] = q[0]; a1[k] = q[1];
+            }
+#pragma unroll
+            for (int k = 0; k < LK_GROUP; ++k) {
+                const int64_t p = pbase + g + k;
+                const bool valid = p < P;
+                bool hit = a1[k].x == len[k] && a0[k].x == (uint32_t)lo[k] && a0[k].y == (uint32_t)(lo[k] >> 32) &&
+                           a0[k].z == (uint32_t)hi[k] && a0[k].w == (uint32_t)(hi[k] >> 32);
+                bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && hit && (t.ignore_merges || (a1[k].z & WORD_DIRECT));
+                // an added-token match is one pre-token whose id is patched in later (k_apply_match_ids): never queued
+                const bool is_match = matchmask && valid && ((matchmask[st[g + k] >> 6] >> (st[g + k] & 63)) & 1ull);
+                out_id[g + k] = (done && !is_match) ? (TOK_ONE | a1[k].y) : 0u;
+                if (valid && !done && !is_match) {
+                    uint32_t c = len[k] <= 16 ? 1u : (len[k] <= 32 ? 2u : 3u);
+                    cls |= c << (2 * (g + k));
+                }
+            }
+        }
+        // ignore_merges: whole-word vocab hit for keys longer than 16 bytes (bpe/model.rs:559-567); rare, kept off
+        // the main path
+        if (t.ignore_merges) {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k) {
+                uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
+                uint32_t id;
+                if (c >= 2 && len <= t.long_probe_max_len && long_probe(t, text + st[k], len, &id)) {
+                    out_id[k] = TOK_ONE | id;
+                    cls &= ~(3u << (2 * k));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < LK_ITEMS; ++k) {
+            uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
+            n16 += (c == 1);
+            n32 += (c == 2);
+            n64 += (c == 3 && len <= 64);
+            nL += (c == 3 && len > 64);
+        }
+        // one atomic per workgroup per list (same-address atomics serialise at ~12 ns each on MI355X)
+        uint32_t tot, tot2 = 0;
+        uint32_t ex = block256_excl_scan(n16 | (n32 << 16), sm, &tot);
+        uint32_t ex2 = 0;
+        if (__syncthreads_or((int)(n64 | nL))) ex2 = block256_excl_scan(n64 | (nL << 16), sm, &tot2);
+        if (threadIdx.x == 0) {
+            base_s[0] = (tot & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST16], tot & 0xFFFFu) : 0u;
+            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_LIST32], tot >> 16) : 0u;
+            base_s[2] = (tot2 & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST64], tot2 & 0xFFFFu) : 0u;
+            base_s[3] = (tot2 >> 16) ? atomicAdd(&counters[CNT_LISTL], tot2 >> 16) : 0u;
+        }
+        __syncthreads();
+        uint32_t o16 = base_s[0] + (ex & 0xFFFFu), o32 = base_s[1] + (ex >> 16);
+        uint32_t o64 = base_s[2] + (ex2 & 0xFFFFu), oL = base_s[3] + (ex2 >> 16);
+#pragma unroll
+        for (int k = 0; k < LK_ITEMS; ++k) {
+            uint32_t c = (cls >> (2 * k)) & 3u;
+            if (c == 1) {
+                // the LDS merge kernel leaves its result in the dense row named by the queue position: point tok0 there now
+                // (coalesced with the neighbours' stores) so that it never has to touch tok0 / ntok
+                if (o16 < rows.cap16) out_id[k] = TOK_ROW | o16;
+                list16[o16++] = (uint32_t)(pbase + k);
+            } else if (c == 2) {
+                if (o32 < rows.cap32) out_id[k] = TOK_ROW | (rows.base32 + o32);
+                list32[o32++] = (uint32_t)(pbase + k);
+            } else if (c == 3) {
+                if (en[k] - st[k] <= 64u) list64[o64++] = (uint32_t)(pbase + k);
+                else listL[oL++] = (uint32_t)(pbase + k);
+            }
+        }
+        // tok0 for all 8 items as 16-byte stores: TOK_ONE | id (settled here), TOK_ROW | row (the LDS merge kernels leave the
+        // result there) or 0 (another merge kernel, or k_apply_match_ids, writes plain tok0 / ntok later).  ntok is never
+        // written here: every pre-token without a flag gets it from the kernel that resolves it.
+        if (pbase + LK_ITEMS <= P) {
+            *(uint4*)(tok0 + pbase) = make_uint4(out_id[0], out_id[1], out_id[2], out_id[3]);
+            *(uint4*)(tok0 + pbase + 4) = make_uint4(out_id[4], out_id[5], out_id[6], out_id[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < LK_ITEMS; ++k)
+                if (pbase + k < P) tok0[pbase + k] = out_id[k];
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// K_bpe_merge<G>: BPE merge resolution, G lanes per pre-token (G=16: one DPP row, 4 pre-tokens per
+// wavefront; G=64: one wavefront).  Lane c holds symbol c of the pre-token (byte-level BPE: one
+// initial symbol per byte, models/bpe/model.rs:465-499 with the byte alphabet of byte_level.rs:15-39).
+// Replaces: Word::merge_all (models/bpe/word.rs:162-250): "pop the (rank, pos)-minimum mergeable
+// adjacent pair, merge, re-queue its two new neighbours".  With every live pair's rank cached in its
+// left symbol's lane, the heap top is a min-reduction of (rank << 6 | lane) over the row (4 DPP
+// steps) and a merge re-probes exactly the two pairs the reference re-queues (word.rs:218-244).
+// Pair -> (rank, new_id) probes hit the static 2-choice cuckoo table (two independent 16-byte
+// loads; bpe/model.rs:252-275 defines the contents).
+// =================================================================================================
+// one-slot perfect-hash probe; `disp` may point to an LDS copy of t.merge_disp
+__device__ __forceinline__ void merge_probe_d(const DevTables& t, const uint16_t* disp, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
+    uint32_t d = disp[merge_hash1(a, b, t.merge_seed) & t.merge_bmask];
+    uint4 x = ((const uint4*)t.merges)[ph_slot(merge_hash2(a, b, t.merge_seed), d, t.merge_mask)];
+    bool hit = x.x == a && x.y == b;
+    *rank = hit ? x.z : RANK_NONE;
+    *new_id = hit ? x.w : 0u;
+}
+__device__ __forceinline__ void merge_probe(const DevTables& t, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
+    merge_probe_d(t, t.merge_disp, a, b, rank, new_id);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* __restrict__ text,
+                                                   const uint32_t* __restrict__ pt_start,
+                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    constexpr int GPW = 64 / G;                                     // pre-tokens per wavefront
+    const int lane = lane_id();
+    const int sub = lane / G, c = lane % G, gbase = sub * G;
+    const uint32_t n = *n_list;
+    const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4;
+    for (uint32_t base = wave_global * GPW; base < n; base += n_waves * GPW) {
+        uint32_t item = base + sub;
+        bool valid = item < n;
+        uint32_t p = valid ? list[item] : 0u;
+        uint32_t s = 0, len = 0;
+        if (valid) { s = pt_start[p]; len = pt_start[p + 1] - s; }
+        bool act = (uint32_t)c < len;
+        uint32_t id = act ? t.byte_id[text[s + c]] : 0xFFFFFFFFu;
+        uint64_t am = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);   // alive symbols of my pre-token
+        uint32_t rank = RANK_NONE, new_id = 0;
+        {
+            uint32_t nid = (uint32_t)__shfl((int)id, gbase + ((c + 1) % G), 64);
+            if ((uint32_t)(c + 1) < len) merge_probe(t, id, nid, &rank, &new_id);
+        }
+        while (true) {
+            uint32_t key = (rank == RANK_NONE) ? 0xFFFFFFFFu : ((rank << 6) | (uint32_t)c);
+            uint32_t mn = (G == 16) ? row16_allmin(key) : wave_allmin(key);
+            bool has = mn != 0xFFFFFFFFu;
+            if (!__any(has)) break;
+            uint32_t wpos = mn & 63u;
+            uint32_t npos = 0;
+            if (has) {
+                uint64_t rest = am >> (wpos + 1);                       // winner always has a live right neighbour
+                npos = wpos + 1 + (uint32_t)(__ffsll((unsigned long long)rest) - 1);
+                am &= ~(1ull << npos);
+                if ((uint32_t)c == wpos) id = new_id;                   // left symbol takes the merged id (word.rs:208)
+                if ((uint32_t)c == npos) rank = RANK_NONE;              // right symbol is removed (word.rs:210)
+            }
+            // id of my next live symbol (after this round's removal)
+            uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
+            bool has_next = mine != 0ull;
+            uint32_t nx = has_next ? (uint32_t)c + 1 + (uint32_t)(__ffsll((unsigned long long)mine) - 1) : (uint32_t)c;
+            uint32_t nid = (uint32_t)__shfl((int)id, gbase + (int)nx, 64);
+            bool alive = (am >> c) & 1ull;
+            // re-probe exactly the two pairs the reference pushes back: (prev, merged) and (merged, next)
+            if (has && alive && ((uint32_t)c == wpos || (has_next && nx == wpos))) {
+                if (has_next) merge_probe(t, id, nid, &rank, &new_id);
+                else rank = RANK_NONE;
+            }
+        }
+        // emit: token j of the pre-token = j-th live lane; token 0 -> tok0[p], the rest -> tmp_ids[s + j]
+        bool alive = act && ((am >> c) & 1ull);
+        if (alive) {
+            uint32_t j = (uint32_t)__popcll(am & ((1ull << c) - 1ull));
+            if (j == 0) tok0[p] = id;
+            else tmp_ids[s + j] = id;
+            if (tmp_end) {
+                uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
+                uint32_t endc = mine ? (uint32_t)c + 1 + (uint32_t)(__ffsll((unsigned long long)mine) - 1) : len;
+                tmp_end[s + j] = endc;                                 // token end, bytes from the pre-token start
+            }
+            if (c == 0) ntok[p] = (uint32_t)__popcll(am);
+        }
+    }
+}
+template __global__ void k_bpe_merge<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge<64>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+
+// =================================================================================================
+// K_bpe_merge_lane: the same merge loop for pre-tokens of <= 16 bytes, ONE LANE per pre-token with the
+// whole Word (ids, pair ranks, pair new-ids) in registers -- 64 pre-tokens per wavefront instead of 4.
+// The merge loop is a chain of dependent L2 round trips (probe -> min -> merge -> probe); giving every
+// lane its own chain multiplies the memory-level parallelism by 16 over the row-per-word kernel.
+// Arrays are indexed with compile-time indices only (selects), so nothing spills to scratch.
+// Token boundaries travel as 16 nibbles (start byte of symbol i) for the offsets output.
+// Same semantics as k_bpe_merge (models/bpe/word.rs:162-250): merge the (rank, position)-minimum pair,
+// the left symbol takes new_id, re-probe the two new neighbours.
+// =================================================================================================
+// position of the k-th (0-based) set bit of m
+__device__ __forceinline__ uint32_t select_bit32(uint32_t m, uint32_t k) {
+    uint32_t pos = 0, c;
+    c = __popc(m & 0xFFFFu); if (k >= c) { k -= c; pos += 16; m >>= 16; }
+    c = __popc(m & 0xFFu);   if (k >= c) { k -= c; pos += 8;  m >>= 8; }
+    c = __popc(m & 0xFu);    if (k >= c) { k -= c; pos += 4;  m >>= 4; }
+    c = __popc(m & 0x3u);    if (k >= c) { k -= c; pos += 2;  m >>= 2; }
+    c = m & 1u;              if (k >= c) { pos += 1; }
+    return pos;
+}
+
+template <int S>   // S = 16 or 32 symbols per lane
+__global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8_t* __restrict__ text,
+                                                        const uint32_t* __restrict__ pt_start,
+                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                        uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    constexpr uint32_t PB = (S == 16) ? 4 : 5;              // bits of the pair index inside the reduction key
+    __shared__ uint32_t s_byte_id[256];
+    __shared__ uint16_t s_disp[DISP_LDS_MAX];
+    __shared__ uint32_t s_hist[S + 1];
+    __shared__ uint4 s_sort[256];
+    s_byte_id[threadIdx.x] = t.byte_id[threadIdx.x];
+    const bool disp_in_lds = t.merge_bmask < (uint32_t)DISP_LDS_MAX;
+    if (disp_in_lds)
+        for (uint32_t i = threadIdx.x; i <= t.merge_bmask; i += 256) s_disp[i] = t.merge_disp[i];
+    __syncthreads();
+    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;   // generic pointer: LDS or global
+    const uint32_t n_items = *n_list;
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t base = blockIdx.x * 256; base < n_items; base += stride) {
+        const uint32_t item = base + threadIdx.x;
+        bool valid = item < n_items;
+        uint32_t p = 0, s = 0, len = 0;
+        if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        // The loop below runs until the slowest lane of a wavefront is done (~len - 2 rounds), so the 256 items of
+        // this workgroup are counting-sorted by length first: each wavefront then holds one quartile of the lengths.
+        {
+            __syncthreads();
+            if (threadIdx.x <= S) s_hist[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t bin = valid ? len : (uint32_t)S;            // invalid lanes sort last (len <= S, so bin S is theirs + len == S)
+            const uint32_t within = atomicAdd(&s_hist[bin], 1u);
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
+            const uint32_t slot = before + within;
+            s_sort[slot] = make_uint4(p, s, len, valid ? 1u : 0u);
+            __syncthreads();
+            const uint4 it = s_sort[threadIdx.x];
+            p = it.x; s = it.y; len = it.z; valid = it.w != 0u;
+        }
+        uint64_t key[S / 8];
+#pragma unroll
+        for (int q = 0; q < S / 8; ++q) key[q] = 0;
+        if (valid) {
+            load_key16(text, s, min(len, 16u), &key[0], &key[1]);
+            if (S == 32 && len > 16) load_key16(text, s + 16, len - 16, &key[S / 8 - 2], &key[S / 8 - 1]);
+        }
+        uint32_t ids[S], rk[S], nd[S];
+#pragma unroll
+        for (int i = 0; i < S; ++i) {
+            uint32_t b = (uint32_t)((key[i / 8] >> (8 * (i % 8))) & 0xFFu);
+            ids[i] = s_byte_id[b];
+            rk[i] = RANK_NONE;
+            nd[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < S - 1; ++i)
+            if ((uint32_t)(i + 1) < len) merge_probe_d(t, disp, ids[i], ids[i + 1], &rk[i], &nd[i]);
+        uint32_t n = len;                                   // live symbols
+        uint32_t starts = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);   // bit b: a symbol starts at byte b
+        bool active = valid && len > 1;
+        while (__any(active)) {
+            if (active) {
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < S - 1; ++i) {
+                    uint32_t k = (rk[i] << PB) | (uint32_t)i;
+                    if ((uint32_t)(i + 1) < n && rk[i] != RANK_NONE) best = min(best, k);
+                }
+                if (best == 0xFFFFFFFFu) active = false;
+                else {
+                    const uint32_t w = best & (uint32_t)(S - 1);
+                    uint32_t new_id = 0;
+#pragma unroll
+                    for (int i = 0; i < S - 1; ++i) new_id = ((uint32_t)i == w) ? nd[i] : new_id;
+                    // symbol w takes new_id, symbol w+1 disappears, everything right of it shifts left
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        uint32_t nxt_id = (i + 1 < S) ? ids[i + 1] : 0u;
+                        ids[i] = ((uint32_t)i == w) ? new_id : (((uint32_t)i > w) ? nxt_id : ids[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < S - 1; ++i) {
+                        uint32_t nr = (i + 1 < S - 1) ? rk[i + 1] : RANK_NONE, nn = (i + 1 < S - 1) ? nd[i + 1] : 0u;
+                        if ((uint32_t)i >= w) { rk[i] = nr; nd[i] = nn; }
+                    }
+                    if (tmp_end) starts &= ~(1u << select_bit32(starts, w + 1));
+                    n -= 1;
+                    // re-probe (w-1, w) and (w, w+1)
+                    uint32_t left = 0, right = 0;
+#pragma unroll
+                    for (int i = 0; i < S; ++i) {
+                        left = ((uint32_t)i + 1 == w) ? ids[i] : left;
+                        right = ((uint32_t)i == w + 1) ? ids[i] : right;
+                    }
+                    uint32_t r1 = RANK_NONE, n1 = 0, r2 = RANK_NONE, n2 = 0;
+                    if (w > 0) merge_probe_d(t, disp, left, new_id, &r1, &n1);
+                    if (w + 1 < n) merge_probe_d(t, disp, new_id, right, &r2, &n2);
+#pragma unroll
+                    for (int i = 0; i < S - 1; ++i) {
+                        if ((uint32_t)i + 1 == w) { rk[i] = r1; nd[i] = n1; }
+                        if ((uint32_t)i == w) { rk[i] = r2; nd[i] = n2; }
+                    }
+                    if (n < 2) active = false;
+                }
+            }
+        }
+        if (valid) {
+            tok0[p] = ids[0];
+            ntok[p] = n;
+#pragma unroll
+            for (int j = 1; j < S; ++j)
+                if ((uint32_t)j < n) tmp_ids[s + j] = ids[j];
+            if (tmp_end) {
+                uint32_t m = starts & (starts - 1u);          // drop the first start: ends are the later starts, then len
+#pragma unroll
+                for (int j = 0; j < S; ++j) {
+                    if ((uint32_t)j < n) {
+                        uint32_t e = m ? (uint32_t)(__ffs(m) - 1) : len;
+                        tmp_end[s + j] = e;
+                        m &= m - 1u;
+                    }
+                }
+            }
+        }
+    }
+}
+template __global__ void k_bpe_merge_lane<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+
+// =================================================================================================
+// K_bpe_merge_lds: the lane-per-pre-token merge loop with the Word in LDS instead of registers.
+// The register kernel above indexes its arrays with compile-time indices only, so every dynamic access is a
+// 16- or 32-way select chain and one merge costs ~300 vector instructions; it is ALU-issue bound.  Here
+//   * symbols stay IN PLACE: sym[i] is the symbol that starts at byte i, a 32-bit `alive` mask says which
+//     positions still start a symbol (it doubles as the token-boundary mask for offsets), neighbours are
+//     found with ctz/clz -- nothing shifts;
+//   * key[i] = (rank << PB) | i for the pair (i, next alive), 0xFFFFFFFF when there is none: the
+//     (rank, position)-minimum of word.rs:177-208 is one min3 tree over S LDS words, and the winner's
+//     position and rank come out of the key itself;
+//   * new_id = rank + constant (host-verified for the loaded vocabulary), so no new-id array is kept;
+//   * sym/key live in LDS as [slot][thread] words: a lane only ever touches its own bank column, every
+//     access is conflict-free, and a dynamic index costs one multiply-add.
+// One merge is ~85 vector instructions.  LDS per lane is 8 * S bytes, which with the 32 KB displacement cache
+// allows NT = 768 (S = 16) lanes per CU.
+// Same semantics as k_bpe_merge / k_bpe_merge_lane (models/bpe/word.rs:162-250).
+// =================================================================================================
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
+__global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text,
+                                                      const uint32_t* __restrict__ pt_start,
+                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                      uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                      uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
+                                                      uint4* __restrict__ rows, uint32_t row_base, uint32_t row_cap) {
+    constexpr uint32_t PB = (S == 16) ? 4 : 5;
+    extern __shared__ uint32_t lds_words[];
+    uint32_t* s_key = lds_words;                              // [S][NT]
+    uint32_t* s_sym = s_key + S * NT;                         // [S][NT], absent when the symbols stay in registers
+    uint32_t* s_byte_id = s_sym + (SYM_REGS ? 0 : S * NT);    // [256]
+    uint32_t* s_hist = s_byte_id + 256;                       // [S + 1] (+ padding to 64)
+    uint16_t* s_disp = (uint16_t*)(s_hist + 64);              // [DISP_LDS_MAX]
+    uint4* s_sort = (uint4*)s_key;                            // [NT], aliases the key area between items
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 256; i += NT) s_byte_id[i] = t.byte_id[i];
+    const bool disp_in_lds = DISP_LDS && t.merge_bmask < (uint32_t)DISP_LDS_MAX;
+    if (disp_in_lds)
+        for (uint32_t i = tid; i <= t.merge_bmask; i += NT) s_disp[i] = t.merge_disp[i];
+    __syncthreads();
+    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
+    const uint32_t nid_base = t.newid_base;
+    const uint32_t n_items = *n_list;
+    const uint32_t stride = gridDim.x * NT;
+    for (uint32_t base = blockIdx.x * NT; base < n_items; base += stride) {
+        const uint32_t item = base + tid;
+        bool valid = item < n_items;
+        uint32_t p = 0, s = 0, len = 0, qidx = 0;             // qidx: position in the work queue (names the dense result row)
+        if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        // counting sort of the workgroup's items by length: a wavefront loops until its slowest lane is done
+        {
+            __syncthreads();                                  // previous item's key/sym area is dead
+            if (tid <= S) s_hist[tid] = 0;
+            __syncthreads();
+            const uint32_t bin = valid ? len : (uint32_t)S;
+            const uint32_t within = atomicAdd(&s_hist[bin], 1u);
+            __syncthreads();
+            uint32_t before = 0;
+            for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
+            s_sort[before + within] = make_uint4(p, s, len, valid ? item + 1u : 0u);
+            __syncthreads();
+            const uint4 it = s_sort[tid];
+            __syncthreads();                                  // everyone has read its item before keys overwrite the area
+            p = it.x; s = it.y; len = it.z; valid = it.w != 0u;
+            qidx = it.w - 1u;
+        }
+        uint32_t* my_key = s_key + tid;                       // slot i at my_key[i * NT]
+        uint32_t* my_sym = s_sym + tid;
+        // SYM_REGS: symbols stay in registers (a dynamic index is a select chain -- the ALU has the headroom) and only
+        // the keys take LDS, which is what bounds the number of pre-tokens in flight per CU.  The selects are written
+        // out at every use: taking the array's address (a lambda, a helper) would send it to scratch.
+        uint32_t ids[S];
+#define TKAMD_SYM_AT(dst, pos)                                                                 \
+        do {                                                                                   \
+            if (!SYM_REGS) (dst) = my_sym[(pos) * NT];                                         \
+            else {                                                                             \
+                (dst) = ids[0];                                                                \
+                _Pragma("unroll") for (int q_ = 1; q_ < S; ++q_) (dst) = ((pos) == (uint32_t)q_) ? ids[q_] : (dst); \
+            }                                                                                  \
+        } while (0)
+        {
+            uint64_t kb[S / 8];
+#pragma unroll
+            for (int q = 0; q < S / 8; ++q) kb[q] = 0;
+            if (valid) {
+                load_key16(text, s, min(len, 16u), &kb[0], &kb[1]);
+                if (S == 32 && len > 16) load_key16(text, s + 16, len - 16, &kb[S / 8 - 2], &kb[S / 8 - 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                ids[i] = s_byte_id[(uint32_t)((kb[i / 8] >> (8 * (i % 8))) & 0xFFu)];
+                if (!SYM_REGS) my_sym[i * NT] = ids[i];
+            }
+#pragma unroll
+            for (int i = 0; i < S; ++i) {
+                uint32_t k = 0xFFFFFFFFu;
+                if (i < S - 1 && (uint32_t)(i + 1) < len) {
+                    uint32_t r, nd;
+                    merge_probe_d(t, disp, ids[i], ids[i + 1], &r, &nd);
+                    if (r != RANK_NONE) k = (r << PB) | (uint32_t)i;
+                }
+                my_key[i * NT] = k;
+            }
+        }
+        uint32_t alive = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+        bool active = valid && len > 1;
+        while (__any(active)) {
+            if (active) {
+                uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < S - 1; ++i) best = min(best, my_key[i * NT]);
+                if (best == 0xFFFFFFFFu) active = false;
+                else {
+                    const uint32_t i = best & (uint32_t)(S - 1);
+                    const uint32_t nid = (best >> PB) + nid_base;
+                    uint32_t above = alive & ~((2u << i) - 1u);           // live positions right of i (the pair's right symbol is the first)
+                    const uint32_t j = (uint32_t)__ffs(above) - 1u;
+                    above &= above - 1u;
+                    alive &= ~(1u << j);
+                    const uint32_t below = alive & ((1u << i) - 1u);
+                    const bool has_k = above != 0u, has_h = below != 0u;
+                    const uint32_t k = has_k ? (uint32_t)__ffs(above) - 1u : i;
+                    const uint32_t h = has_h ? 31u - (uint32_t)__clz(below) : i;
+                    uint32_t sr, sl;
+                    TKAMD_SYM_AT(sr, k);
+                    TKAMD_SYM_AT(sl, h);
+                    if (SYM_REGS) {
+#pragma unroll
+                        for (int q = 0; q < S; ++q) ids[q] = (i == (uint32_t)q) ? nid : ids[q];
+                    } else my_sym[i * NT] = nid;
+                    uint32_t r1, r2, nd;
+                    merge_probe_d(t, disp, sl, nid, &r1, &nd);
+                    merge_probe_d(t, disp, nid, sr, &r2, &nd);
+                    my_key[j * NT] = 0xFFFFFFFFu;
+                    my_key[i * NT] = (has_k && r2 != RANK_NONE) ? ((r2 << PB) | i) : 0xFFFFFFFFu;
+                    if (has_h) my_key[h * NT] = (r1 != RANK_NONE) ? ((r1 << PB) | h) : 0xFFFFFFFFu;
+                    if (!has_k && !has_h) active = false;                 // one symbol left
+                }
+            }
+        }
+        if (valid) {
+            const uint32_t c = (uint32_t)__popc(alive);
+            if (qidx < row_cap) {
+                // result row named by the queue position (k_bpe_word_lookup already pointed tok0[p] at it):
+                // x = first id | count << 28 (15: more than four tokens -- count in tmp_ids[s], ids 2.. in tmp_ids[s + j])
+                uint32_t r[4] = {ids[0], 0u, 0u, 0u};
+                if (!SYM_REGS) r[0] = my_sym[0];
+                uint32_t m = alive & ~1u;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    if (m) {
+                        const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                        TKAMD_SYM_AT(r[j], pos);
+                        if (tmp_end) tmp_end[s + j - 1] = pos;
+                        m &= m - 1u;
+                    }
+                }
+                uint32_t j = 4;
+                if (m) {
+                    tmp_ids[s] = c;
+                    tmp_ids[s + 1] = r[1]; tmp_ids[s + 2] = r[2]; tmp_ids[s + 3] = r[3];
+                    for (; m; m &= m - 1u, ++j) {
+                        const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                        uint32_t v_;
+                        TKAMD_SYM_AT(v_, pos);
+                        tmp_ids[s + j] = v_;
+                        if (tmp_end) tmp_end[s + j - 1] = pos;
+                    }
+                }
+                if (tmp_end) tmp_end[s + c - 1] = len;
+                rows[row_base + qidx] = make_uint4(r[0] | (min(c, ROW_CNT_MORE) << ROW_CNT_SHIFT), r[1], r[2], r[3]);
+            } else {
+                ntok[p] = c;
+                tok0[p] = SYM_REGS ? ids[0] : my_sym[0];
+                uint32_t j = 1;
+                for (uint32_t m = alive & ~1u; m; m &= m - 1u, ++j) {
+                    const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                    uint32_t v_;
+                    TKAMD_SYM_AT(v_, pos);
+                    tmp_ids[s + j] = v_;
+                    if (tmp_end) tmp_end[s + j - 1] = pos;                // the previous token ends where this one starts
+                }
+                if (tmp_end) tmp_end[s + j - 1] = len;
+            }
+        }
+    }
+}
+#undef TKAMD_SYM_AT
+constexpr int lds_merge_bytes(int S, int NT, bool disp_lds, bool sym_regs) { return ((sym_regs ? 1 : 2) * S * NT + 256 + 64) * 4 + (disp_lds ? DISP_LDS_MAX * 2 : 0); }
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
+static int prepare_lds_merge() {
+    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
+}
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
+static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                             const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
+                             void* rows, uint32_t row_base, uint32_t row_cap) {
+    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
+                       (uint4*)rows, row_base, rows ? row_cap : 0u);
+}
+
+// =================================================================================================
+// K_bpe_merge_long: pre-tokens longer than 64 bytes, one workgroup each, symbols as a doubly linked
+// list in LDS (the same Symbol{c, prev, next, len} of models/bpe/word.rs:38-54), up to LONG_PT_MAX
+// symbols.  Each round: workgroup-wide min over the cached (rank, pos) keys, one merge, two
+// re-probes.  Rare path (long letter/digit runs); exactness over speed.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8_t* __restrict__ text,
+                                                        const uint32_t* __restrict__ pt_start,
+                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
+                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                        uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
+                                                        uint32_t* __restrict__ list_huge, uint32_t* __restrict__ n_huge) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    uint32_t* sym = (uint32_t*)lds_raw;                 // [LONG_PT_MAX]
+    uint32_t* rnk = sym + LONG_PT_MAX;                     // [LONG_PT_MAX] rank of pair (i, next[i]) or NONE
+    uint32_t* nid = rnk + LONG_PT_MAX;                     // [LONG_PT_MAX] new id of that pair
+    uint16_t* nxt = (uint16_t*)(nid + LONG_PT_MAX);        // [LONG_PT_MAX] 0xFFFF = none
+    uint16_t* prv = nxt + LONG_PT_MAX;                     // [LONG_PT_MAX]
+    __shared__ unsigned long long red[4];
+    __shared__ uint32_t cnt_s;
+    const int tid = (int)threadIdx.x;
+    const uint32_t n = *n_list;
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        uint32_t p = list[item];
+        uint32_t s = pt_start[p], len = pt_start[p + 1] - s;
+        if (len > (uint32_t)LONG_PT_MAX) {                 // too long for LDS: hand over to k_bpe_merge_huge
+            if (tid == 0) list_huge[atomicAdd(n_huge, 1u)] = p;
+            continue;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256) {
+            sym[i] = t.byte_id[text[s + i]];
+            nxt[i] = (i + 1 < len) ? (uint16_t)(i + 1) : (uint16_t)0xFFFF;
+            prv[i] = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)0xFFFF;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += 256) {
+            uint32_t r = RANK_NONE, ni = 0;
+            if (i + 1 < len) merge_probe(t, sym[i], sym[i + 1], &r, &ni);
+            rnk[i] = r;
+            nid[i] = ni;
+        }
+        __syncthreads();
+        while (true) {
+            unsigned long long best = ~0ull;
+            for (uint32_t i = tid; i < len; i += 256) {
+                uint32_t r = rnk[i];
+                if (r != RANK_NONE) {
+                    unsigned long long k = ((unsigned long long)r << 32) | i;
+                    best = k < best ? k : best;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                unsigned long long o = __shfl_xor(best, d, 64);
+                best = o < best ? o : best;
+            }
+            if ((tid & 63) == 0) red[tid >> 6] = best;
+            __syncthreads();
+            unsigned long long m01 = red[0] < red[1] ? red[0] : red[1];
+            unsigned long long m23 = red[2] < red[3] ? red[2] : red[3];
+            best = m01 < m23 ? m01 : m23;
+            __syncthreads();
+            if (best == ~0ull) break;
+            if (tid == 0) {
+                uint32_t w = (uint32_t)best;
+                uint32_t r = nxt[w];
+                uint32_t rn = nxt[r];
+                sym[w] = nid[w];
+                rnk[r] = RANK_NONE;
+                sym[r] = 0xFFFFFFFFu;                          // dead
+                nxt[w] = (uint16_t)rn;
+                if (rn != 0xFFFFu) prv[rn] = (uint16_t)w;
+                uint32_t pw = prv[w];
+                uint32_t r1 = RANK_NONE, n1 = 0, r2 = RANK_NONE, n2 = 0;
+                if (pw != 0xFFFFu) merge_probe(t, sym[pw], sym[w], &r1, &n1);
+                if (rn != 0xFFFFu) merge_probe(t, sym[w], sym[rn], &r2, &n2);
+                if (pw != 0xFFFFu) { rnk[pw] = r1; nid[pw] = n1; }
+                rnk[w] = r2;
+                nid[w] = n2;
+            }
+            __syncthreads();
+        }
+        // emit in order: walk is sequential per symbol; do a parallel rank instead
+        if (tid == 0) cnt_s = 0;
+        __syncthreads();
+        // chunked ordered compaction: 256 symbols per step
+        for (uint32_t base = 0; base < len; base += 256) {
+            uint32_t i = base + tid;
+            bool alive = i < len && sym[i] != 0xFFFFFFFFu;
+            uint64_t bm = __ballot(alive);
+            __shared__ uint32_t wcnt[4];
+            if ((tid & 63) == 0) wcnt[tid >> 6] = (uint32_t)__popcll(bm);
+            __syncthreads();
+            uint32_t off = cnt_s;
+            for (int w = 0; w < (tid >> 6); ++w) off += wcnt[w];
+            if (alive) {
+                uint32_t j = off + (uint32_t)mbcnt64(bm);
+                if (j == 0) tok0[p] = sym[i];
+                else tmp_ids[s + j] = sym[i];
+                if (tmp_end) {
+                    uint32_t e = nxt[i];
+                    tmp_end[s + j] = (e == 0xFFFFu) ? len : e;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) cnt_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+        }
+        if (tid == 0) ntok[p] = cnt_s;
+    }
+}

@@ -1,0 +1,82 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  Decode_batch.
+
+// =================================================================================================
+// decode_batch: ids -> text.  Replaces Tokenizer::decode_batch / decode (tokenizer/mod.rs:1404-1416, 935-953) with the
+// decoder folded into per-id byte strings at load time (host_model.cpp build_decode_tables): ByteLevel
+// (pre_tokenizers/byte_level.rs:155-171), WordPiece (decoders/wordpiece.rs:46-64) and the no-decoder join.  A token
+// contributes dec_blob[first-position form] if it is the first KEPT token of its sequence and the other form
+// otherwise; unknown ids and (on request) special tokens contribute nothing.  Three passes: mark the first kept token
+// of every sequence (only when some id has two forms), lengths + exclusive scan, gather.
+// =================================================================================================
+__device__ __forceinline__ bool dec_kept(uint32_t lenflags, uint32_t skip_special) {
+    return !(lenflags & DEC_ABSENT) && !(skip_special && (lenflags & DEC_SPECIAL));
+}
+__global__ __launch_bounds__(256) void k_decode_first(const uint32_t* __restrict__ ids, const int64_t* __restrict__ tok_off, int64_t n_docs,
+                                                      const uint4* __restrict__ entry, uint32_t n_ids, uint32_t skip_special,
+                                                      uint32_t* __restrict__ firstmask) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= n_docs) return;
+    for (int64_t t = tok_off[d], e = tok_off[d + 1]; t < e; ++t) {
+        const uint32_t id = ids[t];
+        if (id < n_ids && dec_kept(entry[id].y, skip_special)) { atomicOr(&firstmask[t >> 5], 1u << (t & 31)); break; }
+    }
+}
+__global__ __launch_bounds__(256) void k_decode_len(const uint32_t* __restrict__ ids, int64_t n_tok, const uint4* __restrict__ entry, uint32_t n_ids,
+                                                    uint32_t skip_special, const uint32_t* __restrict__ firstmask, uint32_t* __restrict__ len) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tok) return;
+    const uint32_t id = ids[t];
+    uint32_t l = 0;
+    if (id < n_ids) {
+        const uint4 e = entry[id];
+        if (dec_kept(e.y, skip_special)) l = (firstmask && ((firstmask[t >> 5] >> (t & 31)) & 1u)) ? (e.y & DEC_LEN_MASK) : e.w;
+    }
+    len[t] = l;
+}
+__global__ __launch_bounds__(256) void k_decode_doc_off(const int64_t* __restrict__ tok_off, int64_t n_docs, const uint32_t* __restrict__ pos,
+                                                        int64_t n_tok, const int64_t* __restrict__ total, int64_t* __restrict__ out_off) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d > n_docs) return;
+    const int64_t t = tok_off[d];
+    out_off[d] = t < n_tok ? (int64_t)pos[t] : *total;
+}
+__global__ __launch_bounds__(256) void k_decode_copy(const uint32_t* __restrict__ ids, int64_t n_tok, const uint4* __restrict__ entry, uint32_t n_ids,
+                                                     uint32_t skip_special, const uint32_t* __restrict__ firstmask, const uint8_t* __restrict__ blob,
+                                                     const uint32_t* __restrict__ pos, uint8_t* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tok) return;
+    const uint32_t id = ids[t];
+    if (id >= n_ids) return;
+    const uint4 e = entry[id];
+    if (!dec_kept(e.y, skip_special)) return;
+    const bool first = firstmask && ((firstmask[t >> 5] >> (t & 31)) & 1u);
+    const uint32_t off = first ? e.x : e.z, l = first ? (e.y & DEC_LEN_MASK) : e.w;
+    const uint8_t* src = blob + off;
+    uint8_t* dst = out + pos[t];
+    for (uint32_t i = 0; i < l; ++i) dst[i] = src[i];
+}
+void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, int64_t n_docs, int64_t n_tok, const void* entry, uint32_t n_ids,
+                   const uint8_t* blob, uint32_t skip_special, uint32_t* firstmask, uint32_t* len, uint32_t* bsum, uint32_t* pos, int64_t* total,
+                   int64_t* out_off, uint8_t* out_bytes_or_null) {
+    const uint4* e = (const uint4*)entry;
+    if (!out_bytes_or_null) {                                 // phase 1: lengths, positions, document offsets, total
+        (void)hipMemsetAsync(total, 0, 8, st);
+        if (n_tok > 0) {
+            if (firstmask && n_docs > 0) {
+                (void)hipMemsetAsync(firstmask, 0, (size_t)((n_tok >> 5) + 1) * 4, st);
+                hipLaunchKernelGGL(k_decode_first, dim3(blocks_for(n_docs, 256)), dim3(256), 0, st, ids, tok_off, n_docs, e, n_ids, skip_special, firstmask);
+            }
+            const unsigned nb = blocks_for(n_tok, 256);
+            hipLaunchKernelGGL(k_decode_len, dim3(nb), dim3(256), 0, st, ids, n_tok, e, n_ids, skip_special, (const uint32_t*)firstmask, len);
+            hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)len, n_tok, bsum);
+            hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
+            hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)len, n_tok, (const uint32_t*)bsum, pos);
+        }
+        hipLaunchKernelGGL(k_decode_doc_off, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, tok_off, n_docs, (const uint32_t*)pos, n_tok,
+                           (const int64_t*)total, out_off);
+    } else if (n_tok > 0) {                                   // phase 2: gather (the caller sized out_bytes from *total)
+        hipLaunchKernelGGL(k_decode_copy, dim3(blocks_for(n_tok, 256)), dim3(256), 0, st, ids, n_tok, e, n_ids, skip_special,
+                           (const uint32_t*)firstmask, blob, (const uint32_t*)pos, out_bytes_or_null);
+    }
+}

@@ -1,0 +1,186 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  Host launchers.
+
+// =================================================================================================
+// host-side launchers (called from capi.cpp; plain C++ signatures, stream-ordered, no syncs)
+// =================================================================================================
+void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
+                              unsigned long long* docmask, int* err) {
+    hipLaunchKernelGGL(k_mark_doc_starts, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, len_dev, docmask, err);
+}
+void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
+                            unsigned long long* docmask, int* err) {
+    launch_mark_doc_starts_n(st, doc_off, n_docs, n_bytes, nullptr, docmask, err);
+}
+void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant) {
+    if (variant == 2)
+        hipLaunchKernelGGL(k_pretok_gpt2_seq, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    else if (variant == 0)
+        hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    else
+        hipLaunchKernelGGL(k_pretok_gpt2_bits, dim3(blocks_for(n_bytes + 1, PB_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+}
+void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
+                      int64_t* total) {
+    unsigned nb = blocks_for(n_words, 256);
+    hipLaunchKernelGGL(k_words_reduce, dim3(nb), dim3(256), 0, st, mask, n_words, bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
+    hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
+}
+void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
+                        const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
+    // one wavefront per 64 mask words = 4096 bytes of text; 4 wavefronts per workgroup
+    hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes + 1, 4 * 4096)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
+}
+void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt) {
+    hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt);
+}
+void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                            const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
+                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask, RowPlan rows) {
+    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters, matchmask, rows);
+}
+void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
+                      void* rows, uint32_t row_base, uint32_t row_cap) {
+    // LDS-resident Word (needs newid_affine; prepare_long_kernel() raised the LDS limit)
+    if (group == 3) launch_lds_merge<16, 768, true, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 4) launch_lds_merge<32, 384, true, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);   // two 704-lane workgroups per CU
+    else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+    else if (group == 1)
+        hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+    else if (group == 2)
+        hipLaunchKernelGGL(k_bpe_merge_lane<32>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+    else if (group == 16)
+        hipLaunchKernelGGL(k_bpe_merge<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+    else
+        hipLaunchKernelGGL(k_bpe_merge<64>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+}
+template <int KIND>
+static void launch_pretok_local_t(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                                  const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask) {
+    // TKAMD_PRETOK_LOCAL=tile: the lane-per-byte tile kernel; default: the per-lane bit-parallel kernel
+    static const bool tile_variant = [] { const char* e = getenv("TKAMD_PRETOK_LOCAL"); return e && !strcmp(e, "tile"); }();
+    if (tile_variant)
+        hipLaunchKernelGGL(k_pretok_local<KIND>, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+    else
+        hipLaunchKernelGGL(k_pretok_local_lane<KIND>, dim3(blocks_for(n_bytes + 2, 256 * PLW_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+}
+void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask) {
+    if (kind == PT_WHITESPACE) launch_pretok_local_t<PT_WHITESPACE>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+    else if (kind == PT_WHITESPACE_SPLIT) launch_pretok_local_t<PT_WHITESPACE_SPLIT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+    else launch_pretok_local_t<PT_BERT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+}
+void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
+                            const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end) {
+    hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 64, 4 * 4096)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
+}
+void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                           uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
+                           uint32_t* noe, int64_t* ndoc_off, int* err) {
+    const int64_t n_words = (n_bytes >> 6) + 1;
+    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, bt, text, n_bytes, olen, wsum, err);
+    unsigned nb = blocks_for(n_words, 256);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
+    hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, (const uint32_t*)bsum, wbase);
+    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, bt, text, n_bytes, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
+    hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
+                       (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
+}
+void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
+                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err, const unsigned long long* matchmask) {
+    hipLaunchKernelGGL(k_wordlevel, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, err, matchmask);
+}
+void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
+                      const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
+                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err, const unsigned long long* matchmask) {
+    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, list, n_list, tok0, ntok, tmp_ids, tmp_end, err, matchmask);
+}
+void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
+                             const uint32_t* first_idx, int* err) {
+    hipLaunchKernelGGL(k_added_token_scan, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, text, n_bytes, pat_blob, pat_off, first_idx, err);
+}
+void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
+                          const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
+                          const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs) {
+    // TKAMD_PRETOK_L3=tile: the lane-per-byte tile kernel alone; default: the per-lane bit-parallel kernel first, the tile
+    // kernel only on the tiles where it left bytes undecided
+    static const bool tile_only = [] { const char* e = getenv("TKAMD_PRETOK_L3"); return e && !strcmp(e, "tile"); }();
+    if (!tile_only)
+        hipLaunchKernelGGL(k_pretok_llama3_lane, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask);
+    hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, tile_only ? 0 : 1);
+    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, slow_docs, n_slow_docs);
+    hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, uc1, uc2, startmask);
+}
+void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask) {
+    hipLaunchKernelGGL(k_leadmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, leadmask);
+}
+void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
+    hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc_off, int64_t n_docs, uint32_t* need, uint32_t* bsum,
+                         int64_t* xdoc_off, int64_t* x_len, uint8_t* xtext, int grid) {
+    unsigned nb = blocks_for(n_docs + 1, 256);
+    hipLaunchKernelGGL(k_prefix_need, dim3(nb), dim3(256), 0, st, text, doc_off, n_docs, need);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
+    hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, (const uint32_t*)bsum, doc_off, xdoc_off, x_len);
+    hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, doc_off, (const int64_t*)xdoc_off, n_docs, xtext);
+}
+void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
+    hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
+                        const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
+                        unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,
+                        uint32_t* docs, uint32_t* n_docs_listed, uint32_t* match_list, uint32_t* n_match, int* err) {
+    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, a, text, n_bytes, candmask);
+    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)candmask, doc_off, n_docs, docs, n_docs_listed);
+    hipLaunchKernelGGL(k_added_resolve, dim3(1024), dim3(64), 0, st, a, text, doc_off, (const uint32_t*)docs, (const uint32_t*)n_docs_listed,
+                       (const unsigned long long*)candmask, uc1, uc2, refuse_any, matchmask, spanmask, stopmask, hardmask, match_list, n_match, err);
+}
+void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words) {
+    hipLaunchKernelGGL(k_mask_or, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, src, n_words);
+}
+void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
+                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words) {
+    hipLaunchKernelGGL(k_apply_matches, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, startmask, endmask, matchmask, spanmask, stopmask, n_words);
+}
+void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
+                            const uint32_t* wprefix, uint32_t* tok0, uint32_t* ntok) {
+    hipLaunchKernelGGL(k_apply_match_ids, dim3(64), dim3(256), 0, st, match_list, n_match, startmask, wprefix, tok0, ntok);
+}
+int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
+int prepare_long_kernel() {
+    int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
+    if (rc == 0) rc = prepare_lds_merge<16, 768, true, false>();
+    if (rc == 0) rc = prepare_lds_merge<32, 384, true, false>();
+    if (rc == 0) rc = prepare_lds_merge<16, 704, true, true>();
+    if (rc == 0) rc = prepare_lds_merge<32, 768, true, true>();
+    return rc;
+}
+void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
+                           const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
+                           uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge, uint32_t* scratch, unsigned long long scratch_words,
+                           unsigned long long* scratch_used, int* err) {
+    hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
+                       list_huge, n_huge);
+    hipLaunchKernelGGL(k_bpe_merge_huge, dim3(64), dim3(256), 0, st, t, text, pt_start, (const uint32_t*)list_huge, (const uint32_t*)n_huge, tok0, ntok,
+                       tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
+}
+void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
+                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids,
+                    const void* rows) {
+    hipLaunchKernelGGL(k_ntok_reduce, dim3(grid), dim3(256), 0, st, ntok, tok0, (const uint4*)rows, tmp_ids, pt_start, n_pretok, csum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, csum, (int64_t)0, n_pretok, (int64_t)CP_CHUNK, n_tok);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, st, ntok, tok0, tmp_ids, pt_start, n_pretok, (const uint32_t*)csum, (const uint4*)rows, pt_tokoff, ids);
+}
+void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
+                            const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets) {
+    hipLaunchKernelGGL(k_doc_tok_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_pt, n_docs, pt_tokoff, n_pretok, n_tok, tok_offsets);
+}

@@ -1,0 +1,260 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  Token compaction, offsets / word ids, special tokens.
+
+// =================================================================================================
+// Token compaction: exclusive scan of ntok[P] -> ids[T] and the per-document token CSR.
+// Replaces: PreTokenizedString::into_encoding + Encoding::from_iter (tokenizer/pre_tokenizer.rs:198-263,
+// tokenizer/encoding.rs:541-562) for the whole batch at once.
+// =================================================================================================
+constexpr int CP_ITEMS = 4;                       // pre-tokens per thread
+constexpr int CP_CHUNK = 256 * CP_ITEMS;
+
+// tok0 / ntok decoding shared by the two compaction passes: the count of pre-token p is 1 (TOK_ONE), in its result
+// row (TOK_ROW) or in ntok[p] (everything else -- the only case that reads ntok)
+__device__ __forceinline__ uint32_t row_count(const uint4& row, const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start, int64_t p) {
+    const uint32_t cf = row.x >> ROW_CNT_SHIFT;
+    return cf < ROW_CNT_MORE ? cf : tmp_ids[pt_start[p]];
+}
+__device__ __forceinline__ void load_counts(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0, int64_t p0, int64_t P,
+                                            uint32_t (&cnt)[4], uint32_t (&first)[4]) {
+    if (p0 + 4 <= P) {                                // 16-byte loads (p0 is a multiple of 4)
+        const uint4 f = *(const uint4*)(tok0 + p0);
+        first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
+        uint4 q = make_uint4(0u, 0u, 0u, 0u);
+        constexpr uint32_t FL = TOK_ONE | TOK_ROW;
+        if (!((f.x & FL) && (f.y & FL) && (f.z & FL) && (f.w & FL))) q = *(const uint4*)(ntok + p0);   // some item carries neither flag
+        cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (first[k] & TOK_ONE) cnt[k] = 1u;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
+            cnt[k] = (p0 + k < P) ? ((first[k] & TOK_ONE) ? 1u : ((first[k] & TOK_ROW) ? 0u : ntok[p0 + k])) : 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
+                                                     const uint4* __restrict__ rows, const uint32_t* __restrict__ tmp_ids,
+                                                     const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
+                                                     uint32_t* __restrict__ csum) {
+    static_assert(CP_ITEMS == 4, "load_counts handles four pre-tokens per thread");
+    __shared__ uint32_t sm[4];
+    const int64_t P = *n_pretok;
+    const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
+        uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
+        load_counts(ntok, tok0, p0, P, cnt, first);
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            uint32_t c = cnt[k];
+            if (first[k] & TOK_ROW) { const uint4 row = rows[first[k] & ~TOK_ROW]; c = row_count(row, tmp_ids, pt_start, p0 + k); }
+            v += c;
+        }
+        uint32_t tot;
+        block256_excl_scan(v, sm, &tot);
+        if (threadIdx.x == 0) csum[ch] = tot;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
+                                                 const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start,
+                                                 const int64_t* __restrict__ n_pretok, const uint32_t* __restrict__ csum,
+                                                 const uint4* __restrict__ rows,
+                                                 uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
+    __shared__ uint32_t sm[4];
+    const int64_t P = *n_pretok;
+    const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
+        uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
+        const bool full = p0 + CP_ITEMS <= P;
+        load_counts(ntok, tok0, p0, P, cnt, first);
+        // pre-tokens resolved by the LDS merge kernels keep their count and up to four ids in one dense 16-byte row
+        // (tok0 = TOK_ROW | row index): one load here instead of scattered ntok / tmp_ids traffic
+        uint4 row[CP_ITEMS];
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            row[k] = make_uint4(first[k] & ~TOK_ONE, 0u, 0u, 0u);
+            if (first[k] & TOK_ROW) {
+                row[k] = rows[first[k] & ~TOK_ROW];
+                cnt[k] = row_count(row[k], tmp_ids, pt_start, p0 + k);
+                row[k].x &= ROW_ID_MASK;
+            }
+        }
+        uint32_t v = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+        uint32_t tot;
+        uint32_t o = csum[ch] + block256_excl_scan(v, sm, &tot);
+        if (full) *(uint4*)(pt_tokoff + p0) = make_uint4(o, o + cnt[0], o + cnt[0] + cnt[1], o + cnt[0] + cnt[1] + cnt[2]);
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; ++k) {
+            int64_t p = p0 + k;
+            if (p < P) {
+                if (!full) pt_tokoff[p] = o;
+                uint32_t c = cnt[k];
+                if (c) {
+                    ids[o] = row[k].x;
+                    if (c > 1) {
+                        if ((first[k] & TOK_ROW) && c <= 4u) {
+                            ids[o + 1] = row[k].y;
+                            if (c > 2) ids[o + 2] = row[k].z;
+                            if (c > 3) ids[o + 3] = row[k].w;
+                        } else {
+                            uint32_t s = pt_start[p];
+                            for (uint32_t j = 1; j < c; ++j) ids[o + j] = tmp_ids[s + j];
+                        }
+                    }
+                }
+                o += c;
+            }
+        }
+    }
+}
+
+__global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n_docs, const uint32_t* __restrict__ pt_tokoff,
+                                  const int64_t* __restrict__ n_pretok, const int64_t* __restrict__ n_tok,
+                                  int64_t* __restrict__ tok_offsets) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    uint32_t p = doc_pt[d];
+    tok_offsets[d] = ((int64_t)p < *n_pretok) ? (int64_t)pt_tokoff[p] : *n_tok;
+}
+
+// =================================================================================================
+// K_token_meta: per-token (start, end) offsets and word ids.
+// Replaces the per-token half of PreTokenizedString::into_encoding (tokenizer/pre_tokenizer.rs:231-256):
+//   offsets = split.offsets_original().0 + convert_offsets(Normalized(token.offsets))   (:237-241)
+//   word    = index of the split inside the document                                     (:252-256)
+// plus BytesToCharOffsetConverter for OffsetType::Char (:329-364) and the ByteLevel post-processor's
+// process_offsets (pre_tokenizers/byte_level.rs:202-234) when trim_offsets is set.
+// Byte-level rule (byte_level.rs:135-143, tests/offsets.rs:47-57): a token that covers only part of a
+// multi-byte char reports the whole char, so starts snap back and ends snap forward to char boundaries.
+// One lane per pre-token; the document of a pre-token is found by binary search over doc_pt.
+// =================================================================================================
+__device__ __forceinline__ uint32_t lead_rank(const unsigned long long* __restrict__ leadmask, const uint32_t* __restrict__ lprefix, uint32_t pos) {
+    unsigned long long m = leadmask[pos >> 6];
+    uint32_t b = pos & 63u;
+    return lprefix[pos >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+}
+
+__global__ __launch_bounds__(256) void k_leadmask(const uint8_t* __restrict__ text, int64_t n_bytes, unsigned long long* __restrict__ leadmask) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool lead = (i < n_bytes) && ((text[i] & 0xC0u) != 0x80u);
+    uint64_t m = __ballot(lead);
+    if ((threadIdx.x & 63) == 0 && i <= n_bytes) leadmask[i >> 6] = m;
+}
+
+__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
+    const int64_t P = *a.n_pretok;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
+        const uint32_t o = a.pt_tokoff[p];
+        const uint32_t c = ((p + 1 < P) ? a.pt_tokoff[p + 1] : (uint32_t)*a.n_tok) - o;
+        if (!c) continue;
+        const uint32_t s = a.pt_start[p], e = a.pt_end ? a.pt_end[p] : a.pt_start[p + 1];
+        // document of this pre-token: last d with doc_pt[d] <= p
+        int64_t lo = 0, hi = a.n_docs;
+        while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if ((int64_t)a.doc_pt[mid] <= p) lo = mid; else hi = mid; }
+        const int64_t d = lo;
+        const uint32_t word = (uint32_t)(p - a.doc_pt[d]);
+        const uint32_t xdoc = (uint32_t)a.x_doc_off[d];
+        const uint32_t odoc = (uint32_t)a.doc_off[d];
+        uint32_t rel = 0;
+        for (uint32_t j = 0; j < c; ++j) {
+            uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s + j];
+            if (a.want_words) a.word_ids[o + j] = word;
+            if (a.want_offsets) {
+                uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
+                uint32_t bs = ts, be = te;
+                if (a.byte_level) {                                   // snap to char boundaries inside the pre-token
+                    while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
+                    while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
+                }
+                // x space -> original text
+                uint32_t os, oe;
+                if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
+                else if (a.prefix_space && ((uint32_t)(a.x_doc_off[d + 1]) - xdoc) != ((uint32_t)(a.doc_off[d + 1]) - odoc)) {
+                    // this document got a virtual leading space: x position 0 maps to [0, len(first char)), x >= 1 to x - 1
+                    uint32_t rs = bs - xdoc, re = be - xdoc;
+                    uint32_t fb = a.x_text[xdoc + 1];
+                    uint32_t first_len = fb < 0x80u ? 1u : fb < 0xE0u ? 2u : fb < 0xF0u ? 3u : 4u;
+                    os = odoc + (rs == 0 ? 0u : rs - 1u);
+                    oe = odoc + (re <= 1u ? first_len : re - 1u);
+                }
+                else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
+                if (a.char_mode) {
+                    uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
+                    os = lead_rank(a.leadmask, a.lprefix, os) - base;
+                    oe = lead_rank(a.leadmask, a.lprefix, oe) - base;
+                } else { os -= odoc; oe -= odoc; }
+                if (a.trim_offsets) {                                 // process_offsets, byte_level.rs:202-234
+                    uint32_t lead_sp = 0, trail_sp = 0;
+                    if (a.matchmask && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull)) {
+                        // an added token's text is the raw slice: its leading / trailing chars are tested with char::is_whitespace
+                        uint32_t q = ts;
+                        while (q < te) { uint32_t l; if (!(uc_flags(utf8_global(a.x_text, q, &l), a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
+                        q = te;
+                        while (q > ts) {
+                            uint32_t r = q - 1;
+                            while (r > ts && (a.x_text[r] & 0xC0u) == 0x80u) --r;
+                            uint32_t l;
+                            if (!(uc_flags(utf8_global(a.x_text, r, &l), a.uc1, a.uc2) & UC_RUST_WS)) break;
+                            ++trail_sp;
+                            q = r;
+                        }
+                    } else {
+                    while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
+                    while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
+                    }
+                    if (lead_sp) {
+                        bool is_first = (word == 0 && j == 0) || os == 0;
+                        if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
+                        os = min(os + lead_sp, oe);
+                    }
+                    if (trail_sp && oe >= trail_sp) oe = max(oe - trail_sp, os);
+                }
+                a.offsets[2 * (size_t)(o + j)] = os;
+                a.offsets[2 * (size_t)(o + j) + 1] = oe;
+            }
+            rel = rel_end;
+        }
+    }
+}
+
+// =================================================================================================
+// K_add_specials: PostProcessor::process for a single sequence with add_special_tokens = true
+// (BertProcessing processors/bert.rs:51-120, RobertaProcessing, TemplateProcessing template.rs:544-590):
+// every document becomes  prefix ids | its tokens | suffix ids ; specials carry offsets (0,0) and no word id.
+// One wavefront per document copies the document's tokens to their shifted place.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_add_specials(SpecialArgs a) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    const int64_t add = (int64_t)a.n_prefix + a.n_suffix;
+    for (int64_t d = wave; d <= a.n_docs; d += n_waves) {
+        const int64_t lo = a.tok_offsets[d];
+        const int64_t nlo = lo + d * add;
+        if (lane == 0) a.tok_offsets2[d] = nlo;
+        if (d == a.n_docs) { if (lane == 0) *a.n_tok2 = nlo; break; }
+        const int64_t n = a.tok_offsets[d + 1] - lo;
+        for (int64_t q = lane; q < a.n_prefix; q += 64) {
+            a.ids2[nlo + q] = a.prefix[q];
+            if (a.offsets) { a.offsets2[2 * (nlo + q)] = 0; a.offsets2[2 * (nlo + q) + 1] = 0; }
+            if (a.word_ids) a.word_ids2[nlo + q] = 0xFFFFFFFFu;
+        }
+        const int64_t body = nlo + a.n_prefix;
+        for (int64_t q = lane; q < n; q += 64) {
+            a.ids2[body + q] = a.ids[lo + q];
+            if (a.offsets) { a.offsets2[2 * (body + q)] = a.offsets[2 * (lo + q)]; a.offsets2[2 * (body + q) + 1] = a.offsets[2 * (lo + q) + 1]; }
+            if (a.word_ids) a.word_ids2[body + q] = a.word_ids[lo + q];
+        }
+        for (int64_t q = lane; q < a.n_suffix; q += 64) {
+            a.ids2[body + n + q] = a.suffix[q];
+            if (a.offsets) { a.offsets2[2 * (body + n + q)] = 0; a.offsets2[2 * (body + n + q) + 1] = 0; }
+            if (a.word_ids) a.word_ids2[body + n + q] = 0xFFFFFFFFu;
+        }
+    }
+}

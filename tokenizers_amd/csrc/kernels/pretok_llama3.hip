@@ -1,0 +1,440 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  Llama-3 split: tile kernel, per-lane kernel, sequential per-document matcher.
+
+// =================================================================================================
+// K_pretok_llama3: the Llama-3 / tiktoken cl100k-style split
+//   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
+// Replaces Split::pre_tokenize (pre_tokenizers/split.rs:96-104, Oniguruma find_iter, Isolated) inside
+// Sequence[Split, ByteLevel(use_regex=false)] (sequence.rs:40-45).  Every byte is covered by a match, so
+// the output is again "a match starts at byte i".  Unlike GPT-2 the predicate is RUN-local, not
+// window-local: digit runs are cut every 3 from the run start, a whitespace run
+// is cut after its LAST CR/LF and before its last char, an O-run swallows the CR/LFs that follow it.
+// Fast path (this kernel): one lane per byte, 2 KB tile + 128 B halo in LDS, every run question answered
+// by a bounded walk over the run; a lane whose walk leaves the staged region records its byte position
+// and the whole document is redone by k_pretok_llama3_slow (sequential, exact for any run length).
+// classes: 0 other, 1 letter, 2 number, 3 whitespace (not CR/LF), 4 CR/LF
+// =================================================================================================
+constexpr int L3_HALO = 128;
+constexpr int L3_R = PT_TILE + 2 * L3_HALO;
+constexpr uint32_t L3_CLS = 7, L3_LEAD = 8, L3_DOC = 16, L3_VALID = 32, L3_SP = 64;
+
+__device__ __forceinline__ uint32_t cls_llama3(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
+    if (cp == '\r' || cp == '\n') return 4;
+    return cls_lns(cp, uc1, uc2);
+}
+
+struct L3View {
+    const uint8_t* sb;   // staged bytes
+    const uint8_t* si;   // info
+    __device__ __forceinline__ int prev(int k) const {         // lead byte of the previous code point (k > 0)
+        int j = k - 1;
+        if (!(si[j] & L3_LEAD)) { --j; if (!(si[j] & L3_LEAD)) { --j; if (!(si[j] & L3_LEAD)) --j; } }
+        return j;
+    }
+    __device__ __forceinline__ int next(int k) const {         // first byte after the code point at k
+        uint32_t b = sb[k];
+        return k + (b < 0x80u ? 1 : b < 0xE0u ? 2 : b < 0xF0u ? 3 : 4);
+    }
+    // is there a previous code point in the same document?
+    __device__ __forceinline__ bool has_prev(int k) const { return !(si[k] & L3_DOC); }
+    // is position k (a lead byte index) inside the text and the same document as its predecessor?
+    __device__ __forceinline__ bool inside(int k) const { return (si[k] & L3_VALID) && !(si[k] & L3_DOC); }
+};
+
+// case-insensitive contraction letter at lead byte k: returns 's','t','m','d','r','v','e','l' or 0; *nx = next position
+__device__ __forceinline__ uint32_t l3_letter(const L3View& v, int k, int* nx) {
+    uint32_t b = v.sb[k];
+    if (b == 0xC5u && v.sb[k + 1] == 0xBFu) { *nx = k + 2; return 's'; }       // U+017F LATIN SMALL LETTER LONG S folds to 's'
+    *nx = k + 1;
+    uint32_t f = b | 0x20u;
+    return (f - 'a' < 26u) ? f : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                       const int64_t* __restrict__ len_dev,
+                                                       const unsigned long long* __restrict__ docmask,
+                                                       const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                       unsigned long long* __restrict__ startmask,
+                                                       unsigned long long* __restrict__ slowmask, int refine) {
+    // refine: k_pretok_llama3_lane has run; only tiles in which it left bytes undecided (bits of slowmask) are redone
+    if (refine) {
+        const int64_t w0 = (int64_t)blockIdx.x * (PT_TILE / 64);
+        const int64_t n_words = (n_bytes_host >> 6) + 1;
+        int any = 0;
+        if ((int)threadIdx.x < PT_TILE / 64 && w0 + (int)threadIdx.x < n_words) any = slowmask[w0 + threadIdx.x] != 0ull;
+        if (!__syncthreads_or(any)) return;
+    }
+    __shared__ __attribute__((aligned(16))) uint8_t sb[L3_R + 8];
+    __shared__ uint8_t si[L3_R + 8];
+    __shared__ uint8_t sc[L3_R + 8];     // con: number of letters (1|2) swallowed by a contraction starting at this apostrophe
+    __shared__ unsigned long long sdoc[L3_R / 64 + 2];
+    const int tid = (int)threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
+    const int64_t r0 = t0 - L3_HALO;
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    {
+        uint32_t* sb32 = (uint32_t*)sb;                          // r0 is a multiple of 4: aligned dword staging
+        for (int k = tid; k < (L3_R + 8) / 4; k += 256) {
+            int64_t g = r0 + 4 * (int64_t)k;
+            uint32_t v = 0;
+            if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
+            else if (g + 4 > 0 && g < n_bytes) {
+                for (int q = 0; q < 4; ++q)
+                    if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
+            }
+            sb32[k] = v;
+        }
+        if (tid < L3_R / 64 + 2) {                               // doc-start words covering [t0 - 128, ...)
+            int64_t w = (r0 >> 6) + tid;
+            sdoc[tid] = (w >= 0 && (w << 6) < n_bytes_host + 64) ? docmask[w] : 0ull;
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < L3_R + 8; k += 256) {
+        int64_t g = r0 + k;
+        uint32_t info = 0;
+        if (k < L3_R && g >= 0 && g < n_bytes) {
+            uint32_t b = sb[k];
+            info = L3_VALID;
+            if ((sdoc[k >> 6] >> (k & 63)) & 1ull) info |= L3_DOC;      // r0 is a multiple of 64: bit k of the staged words
+            if ((b & 0xC0u) != 0x80u) {
+                uint32_t len;
+                uint32_t cp = utf8_at(sb, k, &len);
+                info |= L3_LEAD | cls_llama3(cp, uc1, uc2);
+                if (b == 0x20u) info |= L3_SP;
+            }
+        }
+        si[k] = (uint8_t)info;
+    }
+    __syncthreads();
+    L3View v{sb, si};
+    // contraction literals: fire only where the apostrophe is itself a match start
+    for (int k = tid; k < L3_R; k += 256) {
+        uint32_t con = 0;
+        if (k >= 4 && k < L3_R - 8 && sb[k] == '\'' && (si[k] & L3_VALID)) {
+            int k1 = k + 1, k2, k3;
+            if (v.inside(k1) && (si[k1] & L3_LEAD)) {
+                uint32_t a = l3_letter(v, k1, &k2);
+                uint32_t lit = 0;
+                if (a == 's' || a == 't' || a == 'm' || a == 'd') lit = 1;
+                else if ((a == 'r' || a == 'v' || a == 'l') && v.inside(k2) && (si[k2] & L3_LEAD) && sb[k2] < 0x80u) {
+                    uint32_t b2 = l3_letter(v, k2, &k3);
+                    if ((a == 'l') ? (b2 == 'l') : (b2 == 'e')) lit = 2;
+                }
+                if (lit) {
+                    bool cond;
+                    if (!v.has_prev(k)) cond = true;
+                    else {
+                        uint32_t pi = si[v.prev(k)], pc = pi & L3_CLS;
+                        cond = (pc == 1 || pc == 2 || pc == 4 || (pc == 3 && !(pi & L3_SP)));
+                    }
+                    if (cond) con = lit;
+                }
+            }
+        }
+        sc[k] = (uint8_t)con;
+    }
+    __syncthreads();
+    for (int it = 0; it < PT_TILE / 256; ++it) {
+        const int k = L3_HALO + it * 256 + tid;
+        const int64_t g = t0 + it * 256 + tid;
+        const uint32_t info = si[k];
+        bool start = false, unresolved = false;
+        if ((info & (L3_VALID | L3_LEAD)) == (L3_VALID | L3_LEAD)) {
+            const uint32_t c = info & L3_CLS;
+            if (info & L3_DOC) start = true;
+            else {
+                const int p1 = v.prev(k);
+                const uint32_t i1 = si[p1], c1 = i1 & L3_CLS;
+                // eaten(x): x is a letter swallowed by a contraction (the apostrophe is 1 or 2 code points back)
+                bool eaten = false, eaten_prev = false;
+                if (c == 1) {
+                    if (sb[p1] == '\'' && sc[p1] >= 1) eaten = true;
+                    else if (c1 == 1 && v.has_prev(p1)) { int p2 = v.prev(p1); if (sb[p2] == '\'' && sc[p2] == 2) eaten = true; }
+                }
+                if (c1 == 1 && v.has_prev(p1)) {
+                    int p2 = v.prev(p1);
+                    if (sb[p2] == '\'' && sc[p2] >= 1) {
+                        // p1 is the first swallowed letter; it is the LAST one iff the literal has 1 letter
+                        eaten_prev = (sc[p2] == 1);
+                    } else if ((si[p2] & L3_CLS) == 1 && v.has_prev(p2)) {
+                        int p3 = v.prev(p2);
+                        if (sb[p3] == '\'' && sc[p3] == 2) eaten_prev = true;
+                    }
+                }
+                if (c == 1) {
+                    if (eaten) start = false;
+                    else if (eaten_prev) start = true;
+                    else if (c1 == 1) start = false;
+                    else {
+                        // first letter of a run: the previous char joins as the optional prefix iff it is a match start
+                        bool prefixable = false;
+                        if (c1 == 3) prefixable = true;
+                        else if (c1 == 0 && sc[p1] == 0) {
+                            if (!v.has_prev(p1)) prefixable = true;
+                            else { uint32_t i2 = si[v.prev(p1)]; prefixable = !((i2 & L3_CLS) == 0 || (i2 & L3_SP)); }
+                        }
+                        start = !prefixable;
+                    }
+                } else if (c == 0) {
+                    start = !(c1 == 0 || (i1 & L3_SP));
+                    if (eaten_prev) start = true;
+                } else if (c == 2) {
+                    // position inside the digit run, mod 3
+                    int cnt = 0, j = k;
+                    bool ok = true;
+                    while (true) {
+                        if (!v.has_prev(j)) break;
+                        int pj = v.prev(j);
+                        if (pj < 4) { ok = false; break; }
+                        if ((si[pj] & L3_CLS) != 2) break;
+                        j = pj;
+                        ++cnt;
+                    }
+                    if (!ok) unresolved = true;
+                    start = (cnt % 3) == 0;
+                } else {
+                    // whitespace run [q, e); q' = q + leading CR/LFs swallowed by a preceding O-run match
+                    int q = k;
+                    bool ok = true;
+                    while (v.has_prev(q)) {
+                        int pq = v.prev(q);
+                        if (pq < 4) { ok = false; break; }
+                        if ((si[pq] & L3_CLS) < 3) break;
+                        q = pq;
+                    }
+                    bool absorb = ok && v.has_prev(q) && (si[v.prev(q)] & L3_CLS) == 0;
+                    int qe = q;                                   // effective run start
+                    if (absorb) while (qe < L3_R - 4 && v.inside(qe) && (si[qe] & L3_CLS) == 4) qe = v.next(qe);
+                    if (qe >= L3_R - 4) ok = false;
+                    // run end and last CR/LF at or after k
+                    int e = k, last_crlf = -1, lastcp = k;
+                    while (true) {
+                        if (e >= L3_R - 4) { ok = false; break; }
+                        if (e != k && !v.inside(e)) break;           // document / text end
+                        if ((si[e] & L3_CLS) < 3) break;
+                        if ((si[e] & L3_CLS) == 4) last_crlf = e;
+                        lastcp = e;
+                        e = v.next(e);
+                    }
+                    bool at_doc_end = ok && !v.inside(e);
+                    if (!ok) unresolved = true;
+                    else if (k < qe) start = false;                  // swallowed by the O-run's [\r\n]* tail
+                    else {
+                        // is there a CR/LF in [qe, k)?  only needed to know whether k == (last CR/LF)+1
+                        bool crlf_before = (c1 == 4) && p1 >= qe;    // previous char is a CR/LF inside the run
+                        if (k == qe) start = true;
+                        else if (last_crlf < 0 && crlf_before) start = true;          // k == lc + 1, remainder starts here
+                        else if (last_crlf < 0 && k == lastcp && !at_doc_end) {
+                            // last char of the run, followed by a non-space: split before it if the remainder has >= 2 chars
+                            // remainder start r = (last CR/LF before k) + 1 or qe; k > r  <=>  previous char is in the run,
+                            // after qe, and is not a CR/LF
+                            start = (p1 >= qe) && (c1 == 3);
+                        } else start = false;
+                    }
+                }
+            }
+        }
+        uint64_t m = __ballot(start), mu = __ballot(unresolved);
+        if ((tid & 63) == 0 && g <= n_bytes_host) { startmask[g >> 6] = m; slowmask[g >> 6] = mu; }
+    }
+}
+
+// =================================================================================================
+// K_pretok_llama3_lane: the same split, bit-parallel PER LANE (the GPT-2 kernel's scheme): a lane owns 32 bytes
+// inside a 64-byte window (16 bytes of context on each side, four aligned 16-byte loads), deposits one-hot byte
+// flags from a small LDS table into 64-bit masks and runs l3_window_starts (pretok_l3_core.hpp) -- the mask algebra
+// that tests/test_pretok_core.py checks on the CPU, function for function, against a sequential matcher.  Bytes whose run
+// leaves the window are reported in slowmask; k_pretok_llama3 (refine mode) redoes only the tiles that have any.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                            const int64_t* __restrict__ len_dev,
+                                                            const unsigned long long* __restrict__ docmask,
+                                                            const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                                            unsigned long long* __restrict__ startmask,
+                                                            unsigned long long* __restrict__ slowmask) {
+    __shared__ uint2 lut[SQ_LUT_COPIES * 256];
+    {
+        const L3Flags f = l3_byte_flags(threadIdx.x);
+#pragma unroll
+        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + threadIdx.x] = make_uint2(f.x, f.y);
+    }
+    __syncthreads();
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    const int64_t n_words_host = (n_bytes_host >> 6) + 1;
+    const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t a = Lg * L3W_MAIN;                         // first byte this lane decides
+    const int64_t base = a - L3W_HALO;                       // window = [base, base + 64), 16-byte aligned
+    unsigned long long st = 0, un = 0;
+    if (a < n_bytes) {
+        uint32_t w[16];
+        {
+            uint4 c0 = make_uint4(0u, 0u, 0u, 0u);
+            if (base >= 0) c0 = *(const uint4*)(text + base);
+            const uint4 c1 = *(const uint4*)(text + base + 16), c2 = *(const uint4*)(text + base + 32), c3 = *(const uint4*)(text + base + 48);
+            w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w; w[4] = c1.x; w[5] = c1.y; w[6] = c1.z; w[7] = c1.w;
+            w[8] = c2.x; w[9] = c2.y; w[10] = c2.z; w[11] = c2.w; w[12] = c3.x; w[13] = c3.y; w[14] = c3.z; w[15] = c3.w;
+        }
+        L3Window m;
+        const int vlo = base < 0 ? (int)-base : 0;
+        const int64_t rem = n_bytes - base;
+        m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
+        if (base < 0) m.D = docmask[0] << L3W_HALO;
+        else {
+            const int64_t wi = base >> 6;
+            const int sh = (int)(base & 63);
+            m.D = docmask[wi] >> sh;
+            if (sh && wi + 1 < n_words_host) m.D |= docmask[wi + 1] << (64 - sh);
+        }
+        const uint2* my_lut = lut + (threadIdx.x & (SQ_LUT_COPIES - 1)) * 256;
+        m.L = m.N = m.W = m.R = m.SP = m.C = m.AP = m.MU = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            uint32_t accA = 0, accB = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * g + j;
+                const uint2 e = my_lut[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+                accA |= e.x << j;
+                accB |= e.y << j;
+            }
+            m.L |= (unsigned long long)(accA & 0xFFu) << (8 * g);
+            m.N |= (unsigned long long)((accA >> 8) & 0xFFu) << (8 * g);
+            m.W |= (unsigned long long)((accA >> 16) & 0xFFu) << (8 * g);
+            m.R |= (unsigned long long)(accA >> 24) << (8 * g);
+            m.SP |= (unsigned long long)(accB & 0xFFu) << (8 * g);
+            m.C |= (unsigned long long)((accB >> 8) & 0xFFu) << (8 * g);
+            m.AP |= (unsigned long long)((accB >> 16) & 0xFFu) << (8 * g);
+            m.MU |= (unsigned long long)(accB >> 24) << (8 * g);
+        }
+        m.L &= m.V; m.N &= m.V; m.W &= m.V; m.R &= m.V; m.SP &= m.V; m.C &= m.V; m.AP &= m.V; m.MU &= m.V;
+        uint64_t s64, u64;
+        l3_window_starts(m, text, base, uc1, uc2, &s64, &u64);
+        st = (s64 >> L3W_HALO) & 0xFFFFFFFFull;
+        un = (u64 >> L3W_HALO) & 0xFFFFFFFFull;
+    }
+    // two lanes (32 bytes each) make one 64-bit mask word
+    const unsigned long long st_o = __shfl_xor(st, 1, 64), un_o = __shfl_xor(un, 1, 64);
+    if ((threadIdx.x & 1) == 0) {
+        const int64_t word = Lg >> 1;
+        if (word < n_words_host) { startmask[word] = st | (st_o << 32); slowmask[word] = un | (un_o << 32); }
+    }
+}
+
+// Slow path: documents containing a run the tile kernel could not resolve are matched sequentially,
+// alternative by alternative, one lane per document; the document's bits of the start mask are rewritten.
+__device__ __forceinline__ uint32_t l3_dec(const uint8_t* __restrict__ s, int64_t i, int64_t n, int* len) {
+    uint32_t b = s[i];
+    if (b < 0x80u) { *len = 1; return b; }
+    if (b < 0xE0u && i + 1 < n) { *len = 2; return ((b & 0x1Fu) << 6) | (s[i + 1] & 0x3Fu); }
+    if (b < 0xF0u && i + 2 < n) { *len = 3; return ((b & 0x0Fu) << 12) | ((s[i + 1] & 0x3Fu) << 6) | (s[i + 2] & 0x3Fu); }
+    if (i + 3 < n) { *len = 4; return ((b & 0x07u) << 18) | ((s[i + 1] & 0x3Fu) << 12) | ((s[i + 2] & 0x3Fu) << 6) | (s[i + 3] & 0x3Fu); }
+    *len = 1;
+    return 0xFFFDu;
+}
+__device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_t n, const uint16_t* uc1, const uint8_t* uc2) {
+    int l;
+    uint32_t c = l3_dec(s, i, n, &l);
+    uint32_t cc = cls_llama3(c, uc1, uc2);
+    if (c == '\'' && i + 1 < n) {
+        int l1, l2 = 0;
+        uint32_t a = l3_dec(s, i + 1, n, &l1);
+        uint32_t af = (a == 0x17Fu) ? 's' : ((a | 0x20u) - 'a' < 26u && a < 0x80u ? (a | 0x20u) : 0u);
+        int64_t p2 = i + 1 + l1;
+        uint32_t bf = 0;
+        if (p2 < n) { uint32_t b = l3_dec(s, p2, n, &l2); bf = (b < 0x80u && (b | 0x20u) - 'a' < 26u) ? (b | 0x20u) : 0u; }
+        if (af == 's' || af == 't') return p2;
+        if (p2 < n && ((af == 'r' && bf == 'e') || (af == 'v' && bf == 'e'))) return p2 + l2;
+        if (af == 'm') return p2;
+        if (p2 < n && af == 'l' && bf == 'l') return p2 + l2;
+        if (af == 'd') return p2;
+    }
+    {   // [^\r\n\p{L}\p{N}]?\p{L}+
+        int64_t k = (cc == 0 || cc == 3) ? i + l : i;
+        if (k < n) {
+            int lk;
+            uint32_t ck = l3_dec(s, k, n, &lk);
+            if (cls_llama3(ck, uc1, uc2) == 1) {
+                int64_t j = k + lk;
+                while (j < n) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); if (cls_llama3(cj, uc1, uc2) != 1) break; j += lj; }
+                return j;
+            }
+        }
+    }
+    if (cc == 2) {   // \p{N}{1,3}
+        int64_t j = i + l;
+        int cnt = 1;
+        while (j < n && cnt < 3) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); if (cls_llama3(cj, uc1, uc2) != 2) break; j += lj; ++cnt; }
+        return j;
+    }
+    {   // " ?[^\s\p{L}\p{N}]+[\r\n]*"
+        int64_t k = (s[i] == ' ') ? i + 1 : i;
+        if (k < n) {
+            int lk;
+            uint32_t ck = l3_dec(s, k, n, &lk);
+            if (cls_llama3(ck, uc1, uc2) == 0) {
+                int64_t j = k + lk;
+                while (j < n) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); if (cls_llama3(cj, uc1, uc2) != 0) break; j += lj; }
+                while (j < n && (s[j] == '\r' || s[j] == '\n')) ++j;
+                return j;
+            }
+        }
+    }
+    if (cc >= 3) {
+        int64_t j = i, last = -1, prev = i, cur = i;
+        while (j < n) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); uint32_t k = cls_llama3(cj, uc1, uc2); if (k < 3) break; if (k == 4) last = j; prev = cur; cur = j; j += lj; }
+        (void)prev;
+        if (last >= 0) return last + 1;          // \s*[\r\n]+
+        if (j >= n) return j;                    // \s+(?!\S) at end of text
+        if (cur > i) return cur;                 // \s+(?!\S): all but the last whitespace char
+        return j;                                // \s+
+    }
+    return i + l;
+}
+
+// documents with at least one unresolved byte -> slow_docs list (one lane per document)
+__global__ void k_l3_slow_docs(const unsigned long long* __restrict__ slowmask, const int64_t* __restrict__ doc_off, int64_t n_docs,
+                               uint32_t* __restrict__ slow_docs, uint32_t* __restrict__ n_slow_docs) {
+    for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t a = doc_off[d], b = doc_off[d + 1];
+        if (b <= a) continue;
+        bool any = false;
+        for (int64_t w = a >> 6; w <= (b - 1) >> 6 && !any; ++w) {
+            int64_t lo = w << 6, hi = lo + 64;
+            unsigned long long m = slowmask[w];
+            if (a > lo) m &= ~0ull << (a - lo);
+            if (b < hi) m &= ~0ull >> (hi - b);
+            any = m != 0ull;
+        }
+        if (any) slow_docs[atomicAdd(n_slow_docs, 1u)] = (uint32_t)d;
+    }
+}
+
+__global__ void k_pretok_llama3_slow(const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off,
+                                     const uint32_t* __restrict__ slow_docs, const uint32_t* __restrict__ n_slow_docs,
+                                     const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                     unsigned long long* __restrict__ startmask) {
+    const uint32_t n = *n_slow_docs;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t d = slow_docs[i];
+        const int64_t a = doc_off[d], b = doc_off[d + 1];
+        const uint8_t* s = text + a;
+        const int64_t len = b - a;
+        // clear the document's bits, then set one bit per sequential match start
+        for (int64_t w = a >> 6; w <= (b - 1) >> 6; ++w) {
+            int64_t lo = w << 6, hi = lo + 64;
+            unsigned long long m = ~0ull;
+            if (a > lo) m &= ~0ull << (a - lo);
+            if (b < hi) m &= ~0ull >> (hi - b);
+            atomicAnd(&startmask[w], ~m);
+        }
+        int64_t p = 0;
+        while (p < len) {
+            int64_t g = a + p;
+            atomicOr(&startmask[g >> 6], 1ull << (g & 63));
+            int64_t e = l3_match_seq(s, p, len, uc1, uc2);
+            if (e <= p) e = p + 1;
+            p = e;
+        }
+    }
+}

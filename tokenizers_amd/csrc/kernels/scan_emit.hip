@@ -1,0 +1,135 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  Start-mask scans and pre-token offset emission.
+
+// =================================================================================================
+// Prefix sums over the start bitmask (popcount per 64-byte word), then offsets emission.
+// Replaces: the Vec<Split> a PreTokenizedString accumulates (tokenizer/pre_tokenizer.rs:73-103);
+// here the "splits" of the whole batch are one u32 array pt_start[P+1] (pt_start[P] = n_bytes).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_words_reduce(const unsigned long long* __restrict__ mask, int64_t n_words,
+                                                      uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t sm[4];
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = (w < n_words) ? (uint32_t)__popcll(mask[w]) : 0u;
+    uint32_t tot;
+    block256_excl_scan(v, sm, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single-workgroup exclusive scan of `n` (host value, or *n_dev when n_dev != nullptr) u32 items
+// in place; total -> total_out (64-bit).  `div` lets n_dev be a count of finer items
+// (n = ceil(*n_dev / div)).
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t* __restrict__ data, int64_t n_host,
+                                                      const int64_t* __restrict__ n_dev, int64_t div,
+                                                      int64_t* __restrict__ total_out) {
+    __shared__ uint32_t sm[16];
+    __shared__ uint64_t carry_s;
+    int64_t n = n_dev ? ((*n_dev + div - 1) / div) : n_host;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        int64_t i = base + threadIdx.x;
+        uint32_t v = (i < n) ? data[i] : 0u;
+        uint32_t inc = wave_incl_scan(v);
+        if (lane == 63) sm[wave] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            uint32_t s = sm[w];
+            if (w < wave) wbase += s;
+            tot += s;
+        }
+        uint64_t carry = carry_s;
+        if (i < n) data[i] = (uint32_t)(carry + wbase + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = (int64_t)carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __restrict__ mask, int64_t n_words,
+                                                    const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix) {
+    __shared__ uint32_t sm[4];
+    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = (w < n_words) ? (uint32_t)__popcll(mask[w]) : 0u;
+    uint32_t tot;
+    uint32_t ex = block256_excl_scan(v, sm, &tot);
+    if (w < n_words) wprefix[w] = bsum[blockIdx.x] + ex;
+}
+
+// A wavefront takes 64 consecutive mask words (4 KB of text): one coalesced load of the words and their
+// prefixes, then word by word (broadcast with readlane) lane l tests bit l and stores pt_start[rank] = position.
+// All loads are issued up front; the per-word work is a handful of VALU ops and one masked, rank-ordered store.
+__global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* __restrict__ startmask,
+                                                     const uint32_t* __restrict__ wprefix, int64_t n_bytes,
+                                                     const int64_t* __restrict__ len_dev,
+                                                     const int64_t* __restrict__ n_pretok,
+                                                     uint32_t* __restrict__ pt_start) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave == 0 && lane == 0) pt_start[*n_pretok] = (uint32_t)(len_dev ? *len_dev : n_bytes);          // sentinel
+    const int64_t n_words = (n_bytes + 63) >> 6;
+    const int64_t w0 = wave * 64;
+    if (w0 >= n_words) return;
+    const int64_t wi = w0 + lane;
+    const unsigned long long mw = (wi < n_words) ? startmask[wi] : 0ull;
+    const uint32_t pw = (wi < n_words) ? wprefix[wi] : 0u;
+    const uint32_t mlo = (uint32_t)mw, mhi = (uint32_t)(mw >> 32);
+    if (__ballot(mw != 0ull) == 0ull) return;                    // nothing starts in these 4 KB
+    const int kmax = (int)min((int64_t)64, n_words - w0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0; k < kmax; ++k) {
+        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, k) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)mlo, k);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
+        if ((m >> lane) & 1ull) pt_start[base + (uint32_t)__popcll(m & below)] = (uint32_t)(((w0 + k) << 6) + lane);
+    }
+}
+
+// exclusive end of every pre-token for the "Removed" pre-tokenizers: an end bit at byte i closes the
+// pre-token that started most recently before i.  Same wavefront-per-64-words structure as k_emit_pretok.
+__global__ __launch_bounds__(256) void k_emit_pretok_end(const unsigned long long* __restrict__ startmask,
+                                                         const unsigned long long* __restrict__ endmask,
+                                                         const uint32_t* __restrict__ wprefix, int64_t n_bytes,
+                                                         uint32_t* __restrict__ pt_end) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_words = (n_bytes >> 6) + 1;               // an end bit can sit at byte n_bytes
+    const int64_t w0 = wave * 64;
+    if (w0 >= n_words) return;
+    const int64_t wi = w0 + lane;
+    const unsigned long long ms = (wi < n_words) ? startmask[wi] : 0ull, me = (wi < n_words) ? endmask[wi] : 0ull;
+    const uint32_t pw = (wi < n_words) ? wprefix[wi] : 0u;
+    const uint32_t slo = (uint32_t)ms, shi = (uint32_t)(ms >> 32), elo = (uint32_t)me, ehi = (uint32_t)(me >> 32);
+    if (__ballot(me != 0ull) == 0ull) return;
+    const int kmax = (int)min((int64_t)64, n_words - w0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0; k < kmax; ++k) {
+        const unsigned long long e = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ehi, k) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)elo, k);
+        if (e == 0ull) continue;                              // wave-uniform
+        const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)shi, k) << 32) |
+                                     (uint32_t)__builtin_amdgcn_readlane((int)slo, k);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)pw, k);
+        if ((e >> lane) & 1ull) pt_end[base + (uint32_t)__popcll(m & below) - 1u] = (uint32_t)(((w0 + k) << 6) + lane);
+    }
+}
+
+// doc_pt[d] = index of the first pre-token at or after the first byte of document d (d = 0..n_docs)
+__global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
+                                   const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
+                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    int64_t g = doc_off[d];
+    uint32_t r;
+    if (g >= n_bytes) r = (uint32_t)*n_pretok;
+    else {
+        unsigned long long m = startmask[g >> 6];
+        int b = (int)(g & 63);
+        r = wprefix[g >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+    }
+    doc_pt[d] = r;
+}
