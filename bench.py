@@ -227,15 +227,16 @@ KERNEL_OF_STAGE = {"bpe_word_lookup": "k_bpe_word_lookup", "bpe_merge_lds": "k_b
                    "bpe_merge_lane32": "k_bpe_merge_lane<32>", "bpe_merge16": "k_bpe_merge<16>", "bpe_merge64": "k_bpe_merge<64>",
                    "pretok_gpt2": "k_pretok_gpt2", "pretok_gpt2_seq": "k_pretok_gpt2_seq", "compact": "k_compact",
                    "emit_pretok": "k_emit_pretok"}
-PMC_SUMMARY = "r1_v3_pmc_summary.json"
-
-
 def pmc_traffic(stage: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/):
-    (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md.  None if no PMC run covers it."""
-    path = os.path.join(ROOT, "profiles", PMC_SUMMARY)
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json,
+    written by tools/round_profile.sh): (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md.
+    None if no PMC run covers the kernel."""
+    import glob
     try:
-        with open(path) as fh:
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+        if not paths:
+            return None
+        with open(paths[-1]) as fh:
             k = json.load(fh)["kernels"].get(KERNEL_OF_STAGE.get(stage, ""))
         return int(k["hbm_bytes_per_launch"]) if k else None
     except Exception:
