@@ -113,7 +113,9 @@ extern "C" int plh_run(const char* json, size_t json_len, const uint8_t* text, i
     return 0;
 }
 
-// ---- pretok_gpt2_core.hpp: GPT-2 ByteLevel split, 48 bytes per window ----------------------------------------------------
+// ---- pretok_gpt2_core.hpp: GPT-2 ByteLevel split.  gpt2_lane_starts is everything a lane of k_pretok_gpt2_seq does (loads,
+// flag deposit, masks, algebra); the loop below adds what the kernel adds: the LUT, the document-start bitmask, and the
+// "four lanes' 48 bits are three 64-bit words" assembly (__shfl_down by one lane).
 extern "C" int g2h_run(const char* json, size_t json_len, const uint8_t* text, int64_t n, const int64_t* doc_off, int64_t n_docs,
                        uint8_t* start_out) {
     HostModel hm;
@@ -122,37 +124,26 @@ extern "C" int g2h_run(const char* json, size_t json_len, const uint8_t* text, i
     } catch (const std::exception&) {
         return -1;
     }
-    std::vector<uint8_t> docstart((size_t)n + 64, 0);
+    const int64_t n_words = (n >> 6) + 1;
+    std::vector<uint64_t> docmask((size_t)n_words + 1, 0), startmask((size_t)n_words + 1, 0);
     for (int64_t d = 0; d < n_docs; ++d)
-        if (doc_off[d] < n) docstart[doc_off[d]] = 1;
-    std::vector<uint8_t> buf((size_t)n + 64 + 128, 0);
+        if (doc_off[d] < n) docmask[doc_off[d] >> 6] |= 1ull << (doc_off[d] & 63);
+    std::vector<uint8_t> buf((size_t)n + 64 + 128, 0xEE);          // garbage before the text, zero pad after it is NOT assumed either
     uint8_t* t = buf.data() + 64;
     memcpy(t, text, (size_t)n);
     Gpt2Flags lut[256];
     for (uint32_t v = 0; v < 256; ++v) lut[v] = gpt2_byte_flags(v);
-    for (int64_t a = 0; a < n; a += G2W_MAIN) {
-        const int64_t base = a - G2W_HALO;
-        Gpt2Window w{};
-        for (int i = 0; i < 64; ++i) {
-            const int64_t g = base + i;
-            if (g < 0 || g >= n) continue;
-            const Gpt2Flags f = lut[t[g]];
-            const uint64_t bit = 1ull << i;
-            w.V |= bit;
-            if (f.x & 1u) w.L |= bit;
-            if (f.x & (1u << 8)) w.N |= bit;
-            if (f.x & (1u << 16)) w.S |= bit;
-            if (f.x & (1u << 24)) w.SP |= bit;
-            if (f.y & 1u) w.C |= bit;
-            if (f.y & (1u << 8)) w.AP |= bit;
-            if (f.y & (1u << 16)) w.MU |= bit;
-            if (docstart[g]) w.D |= bit;
-        }
-        const uint64_t st = gpt2_window_starts(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data());
-        for (int i = G2W_HALO; i < G2W_HALO + G2W_MAIN; ++i) {
-            const int64_t g = base + i;
-            if (g < n) start_out[g] = (st >> i) & 1;
-        }
+    const int64_t n_lanes = ((n + 1 + 256 * G2W_MAIN - 1) / (256 * G2W_MAIN)) * 256;       // the kernel's grid
+    std::vector<uint64_t> out((size_t)n_lanes + 1, 0);
+    for (int64_t lane = 0; lane < n_lanes; ++lane)
+        out[lane] = gpt2_lane_starts(t, n, n_words, docmask.data(), lut, lane, hm.uc_stage1.data(), hm.uc_stage2.data());
+    for (int64_t lane = 0; lane < n_lanes; ++lane) {
+        const int q = (int)(lane & 3);
+        if (q == 3) continue;
+        const int64_t word = 3 * (lane >> 2) + q;
+        const uint64_t nxt = (lane & 63) == 63 ? 0 : out[lane + 1];                         // __shfl_down stays inside the wavefront
+        if (word < n_words) startmask[word] = (out[lane] >> (16 * q)) | (nxt << (G2W_MAIN - 16 * q));
     }
+    for (int64_t g = 0; g < n; ++g) start_out[g] = (startmask[g >> 6] >> (g & 63)) & 1;
     return 0;
 }

@@ -173,74 +173,19 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restri
                                                          const unsigned long long* __restrict__ docmask,
                                                          const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                          unsigned long long* __restrict__ startmask) {
-    __shared__ uint2 lut[SQ_LUT_COPIES * 256];
+    __shared__ Gpt2Flags lut[SQ_LUT_COPIES * 256];
     {
         const Gpt2Flags f = gpt2_byte_flags(threadIdx.x);    // 256 threads: one table entry each
 #pragma unroll
-        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + threadIdx.x] = make_uint2(f.x, f.y);
+        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + threadIdx.x] = f;
     }
     __syncthreads();
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     const int64_t n_words_host = (n_bytes_host >> 6) + 1;
     const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t a = Lg * SQ_MAIN;                          // first byte this lane decides
-    const int64_t base = a - SQ_HALO;                        // window = [base, base + 64)
-    unsigned long long out = 0;
-    if (a < n_bytes) {
-        uint32_t w[16];
-        {
-            // four 16-byte loads (8-byte aligned: gfx950 takes dwordx4 at any alignment); the text carries 64
-            // readable bytes after n_bytes, and only lane 0's window starts before the text
-            SqChunk c0{0, 0, 0, 0};
-            if (base >= 0) c0 = *(const SqChunk*)(text + base);
-            else { const uint2 t = *(const uint2*)text; c0.c = t.x; c0.d = t.y; }
-            const SqChunk c1 = *(const SqChunk*)(text + base + 16), c2 = *(const SqChunk*)(text + base + 32),
-                          c3 = *(const SqChunk*)(text + base + 48);
-            w[0] = c0.a; w[1] = c0.b; w[2] = c0.c; w[3] = c0.d; w[4] = c1.a; w[5] = c1.b; w[6] = c1.c; w[7] = c1.d;
-            w[8] = c2.a; w[9] = c2.b; w[10] = c2.c; w[11] = c2.d; w[12] = c3.a; w[13] = c3.b; w[14] = c3.c; w[15] = c3.d;
-        }
-        // valid positions of the window and their document-start bits
-        const int vlo = base < 0 ? (int)-base : 0;
-        const int64_t rem = n_bytes - base;
-        unsigned long long V = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
-        V &= ~0ull << vlo;
-        unsigned long long D;
-        if (base < 0) D = docmask[0] << SQ_HALO;
-        else {
-            const int64_t wi = base >> 6;
-            const int sh = (int)(base & 63);
-            D = docmask[wi] >> sh;
-            if (sh && wi + 1 < n_words_host) D |= docmask[wi + 1] << (64 - sh);
-        }
-        D &= V;
-        // ---- per-byte flags -> 64-bit masks
-        const uint2* my_lut = lut + (threadIdx.x & (SQ_LUT_COPIES - 1)) * 256;
-        unsigned long long L = 0, N = 0, S = 0, SP = 0, C = 0, AP = 0, MU = 0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            uint32_t accA = 0, accB = 0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * g + j;
-                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                const uint2 e = my_lut[b];
-                accA |= e.x << j;
-                accB |= e.y << j;
-            }
-            L |= (unsigned long long)(accA & 0xFFu) << (8 * g);
-            N |= (unsigned long long)((accA >> 8) & 0xFFu) << (8 * g);
-            S |= (unsigned long long)((accA >> 16) & 0xFFu) << (8 * g);
-            SP |= (unsigned long long)(accA >> 24) << (8 * g);
-            C |= (unsigned long long)(accB & 0xFFu) << (8 * g);
-            AP |= (unsigned long long)((accB >> 8) & 0xFFu) << (8 * g);
-            MU |= (unsigned long long)((accB >> 16) & 0xFFu) << (8 * g);
-        }
-        // the regex as mask algebra: pretok_gpt2_core.hpp (the same function the CPU test runs against a sequential matcher)
-        Gpt2Window m;
-        m.L = L; m.N = N; m.S = S; m.SP = SP; m.C = C; m.AP = AP; m.MU = MU; m.V = V; m.D = D;
-        const unsigned long long start = gpt2_window_starts(m, text, base, uc1, uc2);
-        out = (start >> SQ_HALO) & ((1ull << SQ_MAIN) - 1ull);
-    }
+    // loads, flag deposit and the regex as mask algebra: pretok_gpt2_core.hpp (the very function the CPU test runs)
+    const unsigned long long out = gpt2_lane_starts(text, n_bytes, n_words_host, (const uint64_t*)docmask,
+                                                    lut + (threadIdx.x & (SQ_LUT_COPIES - 1)) * 256, Lg, uc1, uc2);
     // four lanes' 48-bit results are three 64-bit mask words
     const unsigned long long nxt = __shfl_down(out, 1, 64);
     const int q = (int)(threadIdx.x & 3);

@@ -83,4 +83,68 @@ TK_HD uint64_t gpt2_window_starts(Gpt2Window m, const uint8_t* text, int64_t bas
     return LEAD & (D | (~eaten & (con | after | run | wsfirst | wslast))) & G2W_MAIN_MASK;
 }
 
+// ---- the whole lane: loads, flag deposit, masks of valid bytes / document starts, the algebra above ------------------
+// A lane owns bytes [48 * lane, 48 * lane + 48) of the text; its window starts 8 bytes earlier.  `text` must be readable up to
+// n_bytes + TKAMD_TEXT_PAD; `lut` is the 256-entry table of gpt2_byte_flags (an LDS copy in the kernel); `docmask` has one bit
+// per byte, (n_bytes_host >> 6) + 1 words.  Returns the 48 start bits (bit 0 = the lane's first byte), 0 past the text.
+struct __attribute__((packed, aligned(8))) LaneChunk16 { uint32_t a, b, c, d; };    // 16-byte load at 8-byte alignment
+struct __attribute__((packed, aligned(8))) LaneChunk8 { uint32_t a, b; };
+
+TK_HD uint64_t gpt2_lane_starts(const uint8_t* text, int64_t n_bytes, int64_t n_words_host, const uint64_t* docmask, const Gpt2Flags* lut,
+                                int64_t lane, const uint16_t* uc1, const uint8_t* uc2) {
+    const int64_t a = lane * G2W_MAIN;                       // first byte this lane decides
+    const int64_t base = a - G2W_HALO;                       // window = [base, base + 64)
+    if (a >= n_bytes) return 0;
+    uint32_t w[16];
+    {
+        // four 16-byte loads (8-byte aligned: gfx950 takes dwordx4 at any alignment); only lane 0's window starts before the text
+        LaneChunk16 c0{0, 0, 0, 0};
+        if (base >= 0) c0 = *(const LaneChunk16*)(text + base);
+        else { const LaneChunk8 t = *(const LaneChunk8*)text; c0.c = t.a; c0.d = t.b; }
+        const LaneChunk16 c1 = *(const LaneChunk16*)(text + base + 16), c2 = *(const LaneChunk16*)(text + base + 32),
+                          c3 = *(const LaneChunk16*)(text + base + 48);
+        w[0] = c0.a; w[1] = c0.b; w[2] = c0.c; w[3] = c0.d; w[4] = c1.a; w[5] = c1.b; w[6] = c1.c; w[7] = c1.d;
+        w[8] = c2.a; w[9] = c2.b; w[10] = c2.c; w[11] = c2.d; w[12] = c3.a; w[13] = c3.b; w[14] = c3.c; w[15] = c3.d;
+    }
+    Gpt2Window m;
+    // valid positions of the window and their document-start bits
+    const int vlo = base < 0 ? (int)-base : 0;
+    const int64_t rem = n_bytes - base;
+    m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
+    if (base < 0) m.D = docmask[0] << G2W_HALO;
+    else {
+        const int64_t wi = base >> 6;
+        const int sh = (int)(base & 63);
+        m.D = docmask[wi] >> sh;
+        if (sh && wi + 1 < n_words_host) m.D |= docmask[wi + 1] << (64 - sh);
+    }
+    m.D &= m.V;
+    // per-byte flags -> 64-bit masks: the table entries are one-hot flags 8 bits apart, so one shift-or per byte deposits a
+    // flag into four masks at once and every eight bytes the finished groups move into the 64-bit masks
+    m.L = m.N = m.S = m.SP = m.C = m.AP = m.MU = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int g = 0; g < 8; ++g) {
+        uint32_t accA = 0, accB = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;
+            const Gpt2Flags e = lut[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu];
+            accA |= e.x << j;
+            accB |= e.y << j;
+        }
+        m.L |= (uint64_t)(accA & 0xFFu) << (8 * g);
+        m.N |= (uint64_t)((accA >> 8) & 0xFFu) << (8 * g);
+        m.S |= (uint64_t)((accA >> 16) & 0xFFu) << (8 * g);
+        m.SP |= (uint64_t)(accA >> 24) << (8 * g);
+        m.C |= (uint64_t)(accB & 0xFFu) << (8 * g);
+        m.AP |= (uint64_t)((accB >> 8) & 0xFFu) << (8 * g);
+        m.MU |= (uint64_t)((accB >> 16) & 0xFFu) << (8 * g);
+    }
+    return (gpt2_window_starts(m, text, base, uc1, uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
+}
+
 }  // namespace tkamd
