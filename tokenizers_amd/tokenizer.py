@@ -57,6 +57,21 @@ def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
     return buf, offsets
 
 
+def pack_id_sequences(sequences: Sequence[Sequence[int]]) -> tuple[np.ndarray, np.ndarray]:
+    """Sequences of token ids -> (uint32 ids, int64 CSR offsets) without a Python-level loop per sequence."""
+    from itertools import chain
+    n = len(sequences)
+    off = np.zeros(n + 1, dtype=np.int64)
+    if n:
+        np.cumsum(np.fromiter(map(len, sequences), dtype=np.int64, count=n), out=off[1:])
+    total = int(off[-1])
+    if n and all(isinstance(q, np.ndarray) for q in sequences[:8]) and all(isinstance(q, np.ndarray) for q in sequences):
+        ids = np.concatenate([np.asarray(q, dtype=np.uint32) for q in sequences]) if total else np.zeros(0, dtype=np.uint32)
+    else:
+        ids = np.fromiter(chain.from_iterable(sequences), dtype=np.uint32, count=total)
+    return ids, off
+
+
 def read_lines(path: str) -> tuple[np.ndarray, np.ndarray]:
     """A newline-delimited file -> (uint8 buffer with TEXT_PAD slack, int64 CSR offsets), one document per line.
 
@@ -403,12 +418,7 @@ class Tokenizer:
 
         The gather runs on the device; the ByteLevel decoder's ``String::from_utf8_lossy`` (byte_level.rs:170) is
         ``bytes.decode("utf-8", "replace")`` here (both replace every maximal invalid subpart by U+FFFD)."""
-        lens = np.fromiter((len(q) for q in sequences), dtype=np.int64, count=len(sequences))
-        off = np.zeros(len(sequences) + 1, dtype=np.int64)
-        np.cumsum(lens, out=off[1:])
-        ids = np.empty(int(off[-1]), dtype=np.uint32)
-        for i, q in enumerate(sequences):
-            ids[off[i]:off[i + 1]] = q
+        ids, off = pack_id_sequences(sequences)
         raw, doff = self.decode_batch_csr(ids, off, skip_special_tokens)
         buf = raw.tobytes()
         return [buf[doff[i]:doff[i + 1]].decode("utf-8", "replace") for i in range(len(sequences))]
