@@ -1,27 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- GPT-2 byte-level BPE encode_batch throughput on MI355X (BASELINE.json metric).
+"""bench.py -- encode_batch throughput of the MI355X path on BASELINE.json's configs.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus 1 --steps 20 --warmup 3                      # configs[1]: GPT-2 byte-level BPE (the headline metric)
+  python bench.py --config c3|c4|c5                                    # configs[2] / [3] / [4] on one GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the whole hot path (pre-tokenize -> BPE -> ids CSR) over one batch that
-is already resident in HBM.  Workload = BASELINE.json configs[1]: GPT-2 style byte-level BPE
-(50,257 vocab / 50k merges, trained by the reference's own trainer on synthetic pseudo-English),
-1,000,000 synthetic ~120-byte lines per GPU (weak scaling: every rank encodes its own shard,
-documents are independent, mod.rs:1345-1348, so the path has no exchange step and the timed
-region contains no collective).  `--gather` adds the optional collect-to-root of the final id
-buffers + per-document counts over RCCL (tokenizers_amd.parallel.gather_to_root) to every step.
+A "step" = one pass of the whole hot path (pre-tokenize -> model -> ids CSR) over one batch that is already resident in
+HBM.  Workload (default) = BASELINE.json configs[1]: GPT-2 style byte-level BPE (50,257 vocab / 50k merges, trained by the
+reference's own trainer on synthetic pseudo-English), 1,000,000 synthetic ~120-byte lines per GPU per step (weak scaling:
+every rank encodes its own shard; documents are independent, mod.rs:1345-1348, so the path has no exchange step and the
+timed region of `value` contains no collective).  The steps ROTATE over --batches distinct batches (default 3 x 120 MB of
+text, > 256 MiB with their outputs) so that neither the text nor the intermediates of one step are still in the 256 MiB
+Infinity Cache when the next step reads them.
 
-Rank 0 prints ONE JSON line (see the field list in the repo instructions) with two extra
-objects: "roofline" (dominant kernel, HIP-event timed) and "cpu_baseline" (the reference wheel's
-Rayon encode_batch_fast on this box's host cores, or the C oracle if the wheel is missing).
+Before anything is printed, a 2 % sample of the documents of EVERY timed batch is compared with the CPU oracle
+(oracle/oracle.c): a bench line only exists for bit-exact ids.
+
+Rank 0 prints ONE JSON line.  Extra objects next to the contract's fields:
+  roofline       dominant kernel, HIP-event timed live over the same K steps; traffic from the committed PMC summary
+  cpu_baseline   the reference wheel's Rayon encode_batch_fast on this box's host cores (+ 1 thread, encode_batch with
+                 offsets, and the reference's 1,000-documents-per-call bench shape in `others`)
+  host_boundary  the C-ABI call as SURVEY 8d times it (H2D + kernels + D2H): `value_pcie_inclusive`; from list[str] too
+  out_of_distribution  the same step on text whose word types the vocabulary never saw (every word needs merges)
+  gather         N > 1 (or --force-gather): the same K steps ending with the RCCL collect-to-root of ids + CSR
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import signal
+import subprocess
 import sys
 import time
 
@@ -38,16 +48,69 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
+def load_config(config: str):
+    from oracle import synth
+    if config in ("c2", "c5"):
+        return (synth.load_or_train_gpt2(), 60000,
+                "BASELINE configs[1]: GPT-2 byte-level BPE 50,257 vocab / 50k merges" if config == "c2"
+                else "BASELINE configs[4]: GPT-2 byte-level BPE, document lengths Zipf over 8..8192 bytes")
+    if config == "c3":
+        return synth.load_or_train_bert(), 60000, "BASELINE configs[2]: BertNormalizer + BertPreTokenizer + WordPiece 30,522 vocab"
+    return synth.load_or_train_llama3(), 250000, "BASELINE configs[3]: Llama-3 style Split regex + ByteLevel + BPE 128,000 vocab (ignore_merges)"
+
+
+def make_corpus(config: str, n_lines: int, text_seed: int, type_seed: int, n_types: int) -> list[str]:
+    from oracle import synth
+    if config == "c5":
+        return synth.zipf_length_docs(n_lines * 120, text_seed=text_seed, type_seed=type_seed)
+    return synth.gen_lines(n_lines, text_seed=text_seed, type_seed=type_seed, n_types=n_types)
+
+
+class Batch:
+    """One batch resident in HBM + the 2 % oracle sample that vouches for it."""
+
+    def __init__(self, lines, dev, rank, keep_lines):
+        import torch
+        import tokenizers_amd as ta
+        buf, off = ta.pack_documents(lines)
+        self.n_docs, self.n_bytes = len(lines), int(off[-1])
+        self.d_text = torch.from_numpy(buf).to(dev)
+        self.d_off = torch.from_numpy(off).to(dev)
+        self.sample_idx = list(range(rank % 50, len(lines), 50))
+        self.sample = [lines[i] for i in self.sample_idx]
+        self.lines = lines if keep_lines else None
+        self.n_tok = self.n_pretok = None
+
+
+def check_against_oracle(tok, oracle_obj, batch: Batch, stream) -> int:
+    """ids of the batch's sample documents, HIP path vs oracle.  Returns the number of documents compared."""
+    b = tok.encode_batch_device(batch.d_text.data_ptr(), batch.d_off.data_ptr(), batch.n_docs, batch.n_bytes, stream=stream).sync()
+    ids = b.ids_tensor().cpu().numpy().view(np.uint32)
+    to = b.tok_offsets_tensor().cpu().numpy()
+    assert to[0] == 0 and to[-1] == b.n_tokens and (np.diff(to) >= 0).all(), "token CSR is not monotone"
+    exp = oracle_obj.encode_batch(batch.sample)
+    for k, i in enumerate(batch.sample_idx):
+        g = ids[to[i]:to[i + 1]]
+        e = exp.ids[exp.tok_offsets[k]:exp.tok_offsets[k + 1]]
+        if len(g) != len(e) or (g != e).any():
+            raise SystemExit(f"bench: PARITY FAILURE in document {i}: {batch.sample[k][:80]!r} hip={g[:12].tolist()} oracle={e[:12].tolist()}")
+    batch.n_tok, batch.n_pretok = b.n_tokens, b.n_pretokens
+    return len(batch.sample_idx)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=21)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--lines", type=int, default=1_000_000, help="documents per GPU per step")
-    ap.add_argument("--gather", action="store_true", help="N>1: end every step with the RCCL collect-to-root of the final buffers")
-    ap.add_argument("--no-gather", action="store_true", help="(default behaviour; kept for old command lines)")
-    ap.add_argument("--force-gather", action="store_true", help="run the gather code path even with one rank (self-test)")
+    ap.add_argument("--batches", type=int, default=3, help="distinct batches the steps rotate over (working set > Infinity Cache)")
+    ap.add_argument("--gather", action="store_true", help="(kept for old command lines: the gather leg always runs when N > 1)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the gather leg")
+    ap.add_argument("--force-gather", action="store_true", help="run the gather leg even with one rank (self-test of the RCCL path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
@@ -61,61 +124,49 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or args.force_gather:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from oracle import synth            # test/bench infrastructure: corpus + vocab recipe
+    from oracle import oracle as orc      # the checker (and the cpu_baseline fallback): never the thing measured
+    from oracle import synth
     import tokenizers_amd as ta
     from tokenizers_amd.parallel import gather_to_root
 
     t0 = time.time()
-    n_types = 60000
-    if args.config in ("c2", "c5"):
-        tok_json = synth.load_or_train_gpt2()
-        workload = ("BASELINE configs[1]: GPT-2 byte-level BPE 50,257 vocab / 50k merges" if args.config == "c2"
-                    else "BASELINE configs[4]: GPT-2 byte-level BPE, document lengths Zipf over 8..8192 bytes")
-    elif args.config == "c3":
-        tok_json = synth.train_bert_wordpiece()
-        workload = "BASELINE configs[2]: BertNormalizer + BertPreTokenizer + WordPiece 30,522 vocab"
-    else:
-        tok_json = synth.train_llama3_bpe()
-        n_types = 250000
-        workload = "BASELINE configs[3]: Llama-3 style Split regex + ByteLevel + BPE 128,000 vocab (ignore_merges)"
+    tok_json, n_types, workload = load_config(args.config)
     tok = ta.Tokenizer.from_str(tok_json, device=local_rank)
+    oracle_obj = orc.Oracle(tok_json)
     log(f"[bench] tokenizer ready in {time.time() - t0:.1f}s  sha256={synth.sha256(tok_json)[:12]} info={tok.info}")
 
     t0 = time.time()
-    if args.config == "c5":
-        lines = synth.zipf_length_docs(args.lines * 120, text_seed=100 + rank, type_seed=args.type_seed)
-    else:
-        lines = synth.gen_lines(args.lines, text_seed=100 + rank, type_seed=args.type_seed, n_types=n_types)
-    buf, doc_off = ta.pack_documents(lines)
-    n_bytes = int(doc_off[-1])
-    n_docs = len(lines)
-    log(f"[bench] corpus: {n_docs} docs, {n_bytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
-
-    d_text = torch.from_numpy(buf).to(dev)
-    d_off = torch.from_numpy(doc_off).to(dev)
+    n_batches = max(1, args.batches)
+    batches = []
+    for k in range(n_batches):
+        lines = make_corpus(args.config, args.lines, 100 + rank + 1000 * k, args.type_seed, n_types)
+        batches.append(Batch(lines, dev, rank, keep_lines=(k == 0)))
+        del lines
+    log(f"[bench] corpus: {n_batches} batches of {batches[0].n_docs} docs / {batches[0].n_bytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
     stream = torch.cuda.current_stream().cuda_stream
-    gather = (world > 1 and args.gather and not args.no_gather) or args.force_gather
 
-    def step():
-        b = tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, stream=stream)
-        if gather:
-            b.sync()
-            gather_to_root(b.ids_tensor(), b.tok_offsets_tensor(), dev)
-        return b
+    # ---- parity gate: a 2 % sample of every timed batch against the oracle, before any timing counts ----
+    t0 = time.time()
+    n_checked = sum(check_against_oracle(tok, oracle_obj, b, stream) for b in batches)
+    log(f"[bench] parity: {n_checked} sampled documents of the timed batches equal the oracle ({time.time() - t0:.1f}s)")
+
+    def encode(i):
+        b = batches[i % n_batches]
+        return tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, stream=stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -123,52 +174,102 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        b = step()
-    b.sync()
-    fence()
-    elapsed = time.perf_counter() - t_start
-    n_tok, n_pretok = b.n_tokens, b.n_pretokens
+    def timed(step_fn):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        for i in range(args.warmup):
+            step_fn(i)
+        fence()
+        t_start = time.perf_counter()
+        last = None
+        for i in range(args.steps):
+            last = step_fn(i)
+        last.sync()
+        fence()
+        el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(n_bytes), float(n_tok), float(n_docs)], dtype=torch.float64, device=dev)
+    elapsed = timed(encode)
+    # units all ranks processed in the K timed steps
+    mine = np.zeros(4, dtype=np.float64)
+    for i in range(args.steps):
+        b = batches[i % n_batches]
+        mine += [b.n_bytes, b.n_tok, b.n_docs, b.n_pretok]
+    tot = torch.tensor(mine, dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    tot_bytes, tot_tok, tot_docs = (float(x) for x in tot.tolist())
+    tot_bytes, tot_tok, tot_docs, tot_pretok = (float(x) for x in tot.tolist())
     ms_per_step = elapsed / args.steps * 1e3
-    gbps = tot_bytes / (elapsed / args.steps) / 1e9
-    mtoks = tot_tok / (elapsed / args.steps) / 1e6
+    gbps = tot_bytes / elapsed / 1e9
+    mtoks = tot_tok / elapsed / 1e6
+
+    state = {}
+
+    def finish(gather_obj):
+        if rank != 0 or state.get("done"):
+            return
+        state["done"] = True
+        out = dict(state["out"])
+        out["gather"] = gather_obj
+        print(json.dumps(out), flush=True)
 
     # ---- roofline leg: per-kernel HIP-event times over the same K steps (rank 0) ----
     roofline = None
-    stages = {}
     if rank == 0:
         tok.profile(True)
-        for _ in range(args.steps):
-            tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, stream=stream)
-        tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), n_docs, n_bytes, stream=stream).sync()
+        for i in range(args.steps):
+            encode(i)
+        encode(args.steps).sync()
         tok.profile(False)
         stages = {k: v[0] / max(1, v[1]) for k, v in tok.profile_read().items()}   # ms per launch
         dom = max(stages, key=stages.get)
         # algorithmic bytes of the whole path per launch (SURVEY 8d): text in + doc CSR in + ids out + token CSR out
-        b_alg = n_bytes + 8 * (n_docs + 1) + 4 * n_tok + 8 * (n_docs + 1)
+        b_alg = (mine[0] + 8 * (mine[2] + args.steps) + 4 * mine[1] + 8 * (mine[2] + args.steps)) / args.steps
         achieved = b_alg / (stages[dom] * 1e-3) / 1e9
-        traffic = pmc_traffic(dom)
+        traffic = pmc_traffic(dom, args.config)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(stages[dom], 4),
+                    "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
 
-    # ---- host-boundary leg (rank 0, N=1): list[str] -> CSR numpy through tkamd_encode_batch (PCIe inclusive) ----
+    # ---- out-of-distribution leg (rank 0, N=1): word types the vocabulary never saw -> every word runs the merge loop ----
+    ood = None
+    if rank == 0 and world == 1 and not args.no_ood and args.type_seed == 0:
+        t0 = time.time()
+        ob = Batch(make_corpus(args.config, args.lines, 100, 1, n_types), dev, rank, keep_lines=False)
+        check_against_oracle(tok, oracle_obj, ob, stream)
+
+        def enc_ood(i):
+            return tok.encode_batch_device(ob.d_text.data_ptr(), ob.d_off.data_ptr(), ob.n_docs, ob.n_bytes, stream=stream)
+        for i in range(2):
+            enc_ood(i)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        for i in range(10):
+            last = enc_ood(i)
+        last.sync()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t_s) / 10
+        tok.profile(True)
+        for i in range(5):
+            enc_ood(i)
+        enc_ood(0).sync()
+        tok.profile(False)
+        ost = {k: round(v[0] / max(1, v[1]), 4) for k, v in tok.profile_read().items()}
+        ood = {"type_seed": 1, "value": round(ob.n_bytes / dt / 1e9, 3), "unit": "GB/s", "ms_per_step": round(dt * 1e3, 4),
+               "tokens": int(ob.n_tok), "pretokens": int(ob.n_pretok), "merge_queue_sizes": tok.queue_sizes(),
+               "all_kernels_ms": {k: v for k, v in ost.items() if v >= 0.004},
+               "note": "one 1M-line batch (no rotation), 2 % of it checked against the oracle; same vocabulary, unseen word types"}
+        del ob
+        log(f"[bench] out-of-distribution leg in {time.time() - t0:.1f}s")
+
+    # ---- host-boundary leg (rank 0, N=1): the C-ABI call of SURVEY 8d = H2D + kernels + D2H (PCIe inclusive) ----
     host = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_host:
+        lines = batches[0].lines
         t0 = time.perf_counter()
         hb, ho = ta.pack_documents(lines)
         t_pack = time.perf_counter() - t0
@@ -179,10 +280,10 @@ def main() -> None:
             res = tok.encode_packed(hb, ho)
             best = min(best, time.perf_counter() - t0)
         host = {"pack_list_of_str_ms": round(t_pack * 1e3, 2), "encode_packed_ms": round(best * 1e3, 2),
-                "gbps_pcie_inclusive": round(n_bytes / best / 1e9, 3),
-                "gbps_from_list_of_str": round(n_bytes / (best + t_pack) / 1e9, 3),
-                "note": "tkamd_encode_batch: pageable H2D of text + kernels + D2H of ids/CSR into host memory; never reported as value"}
-        assert res.n_tokens == n_tok
+                "gbps_pcie_inclusive": round(batches[0].n_bytes / best / 1e9, 3),
+                "gbps_from_list_of_str": round(batches[0].n_bytes / (best + t_pack) / 1e9, 3),
+                "note": "tkamd_encode_batch wall clock: H2D of text + CSR, kernels, D2H of ids + CSR into pinned host memory"}
+        assert res.n_tokens == batches[0].n_tok
         try:        # the same from a Python list[str] through the tokenizer's reusable staging (what a caller of encode_batch_fast feels)
             tok.encode_batch_fast(lines, add_special_tokens=False)
             best2 = float("inf")
@@ -191,8 +292,8 @@ def main() -> None:
                 r2 = tok.encode_batch_fast(lines, add_special_tokens=False)
                 best2 = min(best2, time.perf_counter() - t0)
             host["encode_batch_fast_list_of_str_ms"] = round(best2 * 1e3, 2)
-            host["gbps_encode_batch_fast_list_of_str"] = round(n_bytes / best2 / 1e9, 3)
-            if r2.n_tokens != n_tok:
+            host["gbps_encode_batch_fast_list_of_str"] = round(batches[0].n_bytes / best2 / 1e9, 3)
+            if r2.n_tokens != batches[0].n_tok:
                 host["encode_batch_fast_list_of_str_error"] = "token count differs"
         except Exception as ex:     # never lose the bench line to the auxiliary leg
             host["encode_batch_fast_list_of_str_error"] = repr(ex)
@@ -200,24 +301,54 @@ def main() -> None:
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's Rayon encode_batch on the host cores ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(tok_json, lines, args.cpu_lines)
+        cpu = cpu_baseline(tok_json, batches[0].lines, args.cpu_lines, args.config)
 
     if rank == 0:
-        out = {
-            "metric": "GB input text/sec (whole node), GPT-2 BPE encode_batch" if args.config in ("c2", "c5") else f"GB input text/sec (whole node), encode_batch [{args.config}]", "value": round(gbps, 3), "unit": "GB/s",
+        b0 = batches[0]
+        state["out"] = {
+            "metric": ("GB input text/sec (whole node), GPT-2 BPE encode_batch" if args.config in ("c2", "c5")
+                       else f"GB input text/sec (whole node), encode_batch [{args.config}]"),
+            "value": round(gbps, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->u32", "data": "synthetic",
             "mtokens_per_s": round(mtoks, 2),
-            "config": {"workload": f"{workload}, {n_docs} synthetic documents ({n_bytes / 1e6:.0f} MB) per GPU, "
-                                   "ids-only (encode_batch_fast), inputs resident in HBM",
-                       "docs_per_gpu": n_docs, "bytes_per_gpu": n_bytes, "tokens_per_gpu": int(n_tok),
-                       "pretokens_per_gpu": int(n_pretok), "type_seed": args.type_seed,
-                       "tokenizer_sha256": synth.sha256(tok_json)[:16], "gather": bool(gather),
+            "value_definition": "input text bytes of all ranks / max-over-ranks wall time of the K steps, inputs already resident in HBM, "
+                                "outputs left in HBM (kernel pipeline only); value_pcie_inclusive is the C-ABI host call of SURVEY 8d",
+            "value_pcie_inclusive": host["gbps_pcie_inclusive"] if host else None,
+            "value_from_python_list_of_str": host.get("gbps_encode_batch_fast_list_of_str") if host else None,
+            "value_out_of_distribution": ood["value"] if ood else None,
+            "parity": {"checked_documents": int(n_checked), "against": "oracle/oracle.c", "of": "every timed batch (2 % sample), ids bit-exact"},
+            "config": {"workload": f"{workload}, {b0.n_docs} synthetic documents ({b0.n_bytes / 1e6:.0f} MB) per GPU per step, "
+                                   f"{n_batches} distinct batches rotated, ids-only (encode_batch_fast), inputs resident in HBM",
+                       "docs_per_gpu": b0.n_docs, "bytes_per_gpu": b0.n_bytes, "tokens_per_gpu": int(b0.n_tok),
+                       "pretokens_per_gpu": int(b0.n_pretok), "batches": n_batches, "type_seed": args.type_seed,
+                       "tokenizer_sha256": synth.sha256(tok_json)[:16],
                        "parallelism": f"dp{world} (documents sharded by rank)"},
-            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host,
+            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "out_of_distribution": ood,
         }
-        print(json.dumps(out), flush=True)
-    if world > 1 or args.force_gather:
+    # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
+    gather_obj = None
+    if (world > 1 or args.force_gather) and not args.no_gather:
+        def on_alarm(signum, frame):          # a collective that never completes must not cost the bench line
+            finish({"error": "the gather leg did not finish within 180 s"})
+            os._exit(0)
+
+        def step_gather(i):
+            b = encode(i)
+            gather_to_root(b.ids_tensor_unsynced(), b.tok_offsets_tensor(), dev, n_tokens_dev=b.n_tokens_tensor())
+            return b
+        signal.signal(signal.SIGALRM, on_alarm)
+        signal.alarm(180)
+        try:
+            el_g = timed(step_gather)
+            gather_obj = {"ms_per_step": round(el_g / args.steps * 1e3, 4), "value": round(tot_bytes / el_g / 1e9, 3), "unit": "GB/s",
+                          "what": "the same K steps, each followed by gather_to_root (one all_gather of sizes + one point-to-point message per "
+                                  "peer for ids and per-document counts) over RCCL; the root's copy of its own shard included"}
+        except Exception as ex:
+            gather_obj = {"error": repr(ex)}
+        signal.alarm(0)
+    finish(gather_obj)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -226,61 +357,117 @@ KERNEL_OF_STAGE = {"bpe_word_lookup": "k_bpe_word_lookup", "bpe_merge_lds": "k_b
                    "bpe_merge_lds32": "k_bpe_merge_lds<32,768,true,true>", "bpe_merge_lane": "k_bpe_merge_lane<16>",
                    "bpe_merge_lane32": "k_bpe_merge_lane<32>", "bpe_merge16": "k_bpe_merge<16>", "bpe_merge64": "k_bpe_merge<64>",
                    "pretok_gpt2": "k_pretok_gpt2", "pretok_gpt2_seq": "k_pretok_gpt2_seq", "compact": "k_compact",
-                   "emit_pretok": "k_emit_pretok"}
-def pmc_traffic(stage: str):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc_summary.json,
-    written by tools/round_profile.sh): (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md.
-    None if no PMC run covers the kernel."""
+                   "emit_pretok": "k_emit_pretok", "lookup": "k_lookup", "bert_normalize": "k_bn_write", "wordpiece": "k_wordpiece",
+                   "wordpiece_word_lookup": "k_bpe_word_lookup"}
+
+
+def pmc_traffic(stage: str, config: str = "c2"):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary of this config
+    (profiles/*_pmc_summary.json, written by tools/round_profile.sh): (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
+    MI355X_MICROARCH.md.  None if no PMC run covers the kernel."""
     import glob
     try:
-        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{config}*_pmc_summary.json"))) or \
+            (sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))) if config == "c2" else [])
         if not paths:
             return None
         with open(paths[-1]) as fh:
-            k = json.load(fh)["kernels"].get(KERNEL_OF_STAGE.get(stage, ""))
+            ks = json.load(fh)["kernels"]
+        want = KERNEL_OF_STAGE.get(stage, "k_" + stage)
+        k = ks.get(want) or next((v for n, v in ks.items() if n.startswith(want)), None)
         return int(k["hbm_bytes_per_launch"]) if k else None
     except Exception:
         return None
 
 
-def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int) -> dict:
-    """Time the reference's own encode_batch_fast (Rayon, all host cores) on a bounded sample."""
+_CPU_CHILD = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r)
+import tokenizers as ref
+from oracle import synth
+import bench
+tok_json, n_types, _ = bench.load_config(%(config)r)
+lines = bench.make_corpus(%(config)r, %(n)d, 100, 0, n_types)[:%(n)d]
+rt = ref.Tokenizer.from_str(tok_json)
+nbytes = sum(len(s.encode("utf-8")) for s in lines)
+rt.encode_batch_fast(lines[:2000], add_special_tokens=False)
+t0 = time.perf_counter(); enc = rt.encode_batch_fast(lines, add_special_tokens=False); dt = time.perf_counter() - t0
+print(json.dumps({"gbps": nbytes / dt / 1e9, "mtok": sum(len(e.ids) for e in enc) / dt / 1e6, "n": len(lines), "mb": nbytes / 1e6}))
+"""
+
+
+def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int, config: str = None) -> dict:
+    """The reference's own encode_batch (Rayon) on a bounded sample of the same corpus: all cores (the headline baseline) plus
+    the shapes SURVEY 8d / BASELINE.md section 3 ask for.  ~30 s of CPU work in total."""
     cores = os.cpu_count() or 1
     try:
         import tokenizers as ref
     except Exception:
         ref = None
-    if ref is not None:
-        rt = ref.Tokenizer.from_str(tok_json)
-        n = cpu_lines or min(len(lines), 400_000)
+    if ref is None:
+        from oracle import oracle as orc       # C restatement, single thread
+        n = cpu_lines or 50_000
         sample = lines[:n]
+        o = orc.Oracle(tok_json)
+        t0 = time.perf_counter()
+        o.encode_batch(sample)
+        dt = time.perf_counter() - t0
         nbytes = sum(len(s.encode("utf-8")) for s in sample)
-        rt.encode_batch_fast(sample[:20000], add_special_tokens=False)          # warm-up (Rayon pool, caches)
-        best = float("inf")
-        ntok = 0
-        t_all = time.time()
-        for _ in range(3):
-            t0 = time.perf_counter()
-            enc = rt.encode_batch_fast(sample, add_special_tokens=False)
-            best = min(best, time.perf_counter() - t0)
-            ntok = sum(len(e.ids) for e in enc)
-            if time.time() - t_all > 40:
-                break
-        return {"value": round(nbytes / best / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "reference",
-                "mtokens_per_s": round(ntok / best / 1e6, 3),
-                "sample": f"tokenizers=={ref.__version__} Tokenizer.encode_batch_fast(add_special_tokens=False), Rayon on all "
-                          f"{cores} host cores, first {n} lines ({nbytes / 1e6:.1f} MB) of the same corpus, best of <=3; "
-                          "includes the wheel's Python str->String marshalling and Encoding construction"}
-    from oracle import oracle as orc       # C restatement, single thread
-    n = cpu_lines or 50_000
+        return {"value": round(nbytes / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
+                "sample": f"oracle/ C restatement, 1 thread, first {n} lines ({nbytes / 1e6:.1f} MB)"}
+    rt = ref.Tokenizer.from_str(tok_json)
+    n = cpu_lines or min(len(lines), 400_000)
     sample = lines[:n]
-    o = orc.Oracle(tok_json)
-    t0 = time.perf_counter()
-    res = o.encode_batch(sample)
-    dt = time.perf_counter() - t0
     nbytes = sum(len(s.encode("utf-8")) for s in sample)
-    return {"value": round(nbytes / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/ C restatement, 1 thread, first {n} lines ({nbytes / 1e6:.1f} MB)"}
+    rt.encode_batch_fast(sample[:20000], add_special_tokens=False)          # warm-up (Rayon pool, caches)
+
+    def best_of(fn, reps, budget_s):
+        best, t_all, r = float("inf"), time.time(), None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = fn()
+            best = min(best, time.perf_counter() - t0)
+            if time.time() - t_all > budget_s:
+                break
+        return best, r
+    best, enc = best_of(lambda: rt.encode_batch_fast(sample, add_special_tokens=False), 3, 12)
+    ntok = sum(len(e.ids) for e in enc)
+    del enc
+    others = {}
+    try:
+        b2, _ = best_of(lambda: rt.encode_batch(sample[:200_000], add_special_tokens=False), 2, 8)
+        nb2 = sum(len(s.encode("utf-8")) for s in sample[:200_000])
+        others["encode_batch_with_offsets_all_cores_gbps"] = round(nb2 / b2 / 1e9, 4)
+        # the reference's own criterion shape: 1,000 documents per encode_batch call (benches/bpe_benchmark.rs:17,43; common/mod.rs:35-57)
+        sub = sample[:100_000]
+        nb3 = sum(len(s.encode("utf-8")) for s in sub)
+        t0 = time.perf_counter()
+        for k in range(0, len(sub), 1000):
+            rt.encode_batch_fast(sub[k:k + 1000], add_special_tokens=False)
+        others["encode_batch_fast_1000_docs_per_call_gbps"] = round(nb3 / (time.perf_counter() - t0) / 1e9, 4)
+        # one thread: the Rayon pool is process-global, so a fresh process with TOKENIZERS_PARALLELISM=false
+        # (bindings/python/benches/test_tiktoken.py:108-116)
+        cfg = config or _config_of(tok_json)
+        env = dict(os.environ, TOKENIZERS_PARALLELISM="false", RAYON_NUM_THREADS="1")
+        r = subprocess.run([sys.executable, "-c", _CPU_CHILD % {"root": ROOT, "config": cfg, "n": 20000}], env=env, capture_output=True, text=True, timeout=120)
+        one = json.loads(r.stdout.strip().splitlines()[-1])
+        others["encode_batch_fast_1_thread_gbps"] = round(one["gbps"], 5)
+        others["encode_batch_fast_1_thread_sample"] = f"{one['n']} lines ({one['mb']:.1f} MB), fresh process, TOKENIZERS_PARALLELISM=false"
+    except Exception as ex:
+        others["error"] = repr(ex)
+    return {"value": round(nbytes / best / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "reference",
+            "mtokens_per_s": round(ntok / best / 1e6, 3),
+            "sample": f"tokenizers=={ref.__version__} Tokenizer.encode_batch_fast(add_special_tokens=False), Rayon on all "
+                      f"{cores} host cores, first {n} lines ({nbytes / 1e6:.1f} MB) of the same corpus, best of <=3; "
+                      "includes the wheel's Python str->String marshalling and Encoding construction",
+            "others": others}
+
+
+def _config_of(tok_json: str) -> str:
+    d = json.loads(tok_json)
+    if d["model"].get("type") == "WordPiece":
+        return "c3"
+    return "c4" if d["model"].get("ignore_merges") else "c2"
 
 
 if __name__ == "__main__":

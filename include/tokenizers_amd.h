@@ -71,6 +71,9 @@ typedef struct tkamd_info {
     int32_t n_added_tokens; /* special/added tokens registered in the JSON                       */
     int32_t device;         /* HIP device ordinal, -1 = host-only handle (no kernels)           */
     int32_t n_direct_words; /* entries of the whole-word table proven merge-stable (see DESIGN)  */
+    int32_t word_disp_entries;  /* displacement entries of the whole-word perfect hash (> 16384: the kernels read them
+                                   from global memory instead of their LDS copy)                                      */
+    int32_t merge_disp_entries; /* same for the merge table                                                           */
 } tkamd_info;
 
 /* Replaces Tokenizer::from_file / from_str (tokenizer/mod.rs:468-472, serialization.rs:104-171).

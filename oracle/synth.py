@@ -282,5 +282,26 @@ def load_or_train_gpt2() -> str:
     return train_bytelevel_bpe()
 
 
+def _fixture_or(name: str, train):
+    import gzip
+    fx = os.path.join(GOLDEN_DIR, name + ".json.gz")
+    if os.path.exists(fx):
+        with gzip.open(fx, "rt", encoding="utf-8") as fh:
+            return fh.read()
+    return train()
+
+
+def load_or_train_bert() -> str:
+    """The C3 tokenizer.json (BertNormalizer + BertPreTokenizer + WordPiece 30,522): committed fixture
+    tests/golden/bert_wordpiece_30522.json.gz (oracle/make_golden_full.py) if present, else train it now."""
+    return _fixture_or("bert_wordpiece_30522", train_bert_wordpiece)
+
+
+def load_or_train_llama3() -> str:
+    """The C4 tokenizer.json (Llama-3 Split + ByteLevel + BPE 128,000, ignore_merges): committed fixture
+    tests/golden/llama3_128k.json.gz if present, else train it now."""
+    return _fixture_or("llama3_128k", train_llama3_bpe)
+
+
 def sha256(s: str) -> str:
     return hashlib.sha256(s.encode("utf-8")).hexdigest()

@@ -79,3 +79,92 @@ def test_gather_to_root_gloo(world):
     root = [g for g in got if len(g[1]) == len(exp_counts) + 1 and g[0] == exp_ids]
     assert root, got
     assert root[0][1] == [0] + np.cumsum(exp_counts).tolist()
+
+
+# ---- the whole multi-rank step: shard -> per-rank encode -> gather == the unsharded encode ----------------------------
+def _sharded_docs():
+    from oracle import synth
+    return synth.gen_lines(700, text_seed=91) + ["", "x" * 3000, ""] + synth.stress_lines(seed=31, n=200) + [""]
+
+
+def _oracle_encoder(js, device, capacity_view):
+    """CPU stand-in for the per-rank HIP encode: the oracle.  With capacity_view it hands the gather a capacity-sized ids buffer
+    and the token count as a tensor, like the device path does."""
+    from oracle import oracle as orc
+    o = orc.Oracle(js)
+
+    def encode_shard(shard, offsets):
+        raw = bytes(shard[: int(offsets[-1])])
+        docs = [raw[int(offsets[i]):int(offsets[i + 1])].decode("utf-8") for i in range(len(offsets) - 1)]
+        r = o.encode_batch(docs)
+        ids = torch.from_numpy(r.ids.astype(np.int32))
+        to = torch.from_numpy(r.tok_offsets.astype(np.int64))
+        if not capacity_view:
+            return ids, to
+        cap = torch.full((len(ids) + 37,), -1, dtype=torch.int32)
+        cap[: len(ids)] = ids
+        return cap, to, torch.tensor([len(ids)], dtype=torch.int64)
+    return encode_shard
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import synth
+        import tokenizers_amd as ta
+        from tokenizers_amd.parallel import encode_batch_sharded
+        js = synth.load_or_train_gpt2()
+        buf, off = ta.pack_documents(_sharded_docs())
+        out = encode_batch_sharded(_oracle_encoder(js, torch.device("cpu"), capacity_view=(world == 3)), buf, off, torch.device("cpu"))
+        q.put((rank, None if out is None else (out[0].tolist(), out[1].tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_encode_batch_sharded_equals_unsharded_gloo(world):
+    from oracle import oracle as orc
+    from oracle import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = orc.Oracle(synth.load_or_train_gpt2()).encode_batch(_sharded_docs())
+    assert all(got[r] is None for r in range(1, world))
+    assert got[0][0] == exp.ids.astype(np.int32).tolist()
+    assert got[0][1] == exp.tok_offsets.tolist()
+
+
+@pytest.mark.gpu
+def test_encode_batch_sharded_on_one_gpu_over_rccl():
+    """World size 1 over RCCL (the only size a 1-GPU box offers): the sharded step through the real device encoder and the real
+    collective calls equals the plain encode of the whole batch."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1')\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "import tokenizers_amd as ta\n"
+        "from tokenizers_amd.parallel import encode_batch_sharded, device_encoder\n"
+        "from oracle import synth\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "tok = ta.Tokenizer.from_str(synth.load_or_train_gpt2(), device=0)\n"
+        "docs = synth.gen_lines(20000, text_seed=92) + ['', 'x' * 3000, '']\n"
+        "buf, off = ta.pack_documents(docs)\n"
+        "ids, to = encode_batch_sharded(device_encoder(tok, dev), buf, off, dev)\n"
+        "ids, to = ids.cpu().numpy().view(np.uint32), to.cpu().numpy()\n"
+        "ref = tok.encode_packed(buf, off)\n"
+        "assert np.array_equal(ids, ref.ids) and np.array_equal(to, ref.tok_offsets)\n"
+        "dist.destroy_process_group(); print('SHARDED_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "SHARDED_OK" in r.stdout, r.stdout + r.stderr

@@ -41,7 +41,7 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "pre_tokenizer", "normalizer", "vocab_size", "n_merges", "add_prefix_space",
-        "ignore_merges", "n_added_tokens", "device", "n_direct_words")]
+        "ignore_merges", "n_added_tokens", "device", "n_direct_words", "word_disp_entries", "merge_disp_entries")]
 
 
 class DeviceResult(C.Structure):

@@ -39,10 +39,15 @@ struct HipError : std::runtime_error {
             throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e));                       \
     } while (0)
 
-// grow-only device buffer
+// grow-only device buffer; owns its allocation (freed with the struct that holds it, on whatever device is current --
+// hipFree accepts a pointer of any device)
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     void reserve(size_t bytes) {
         if (bytes <= cap) return;
         if (p) HIP_CHECK(hipFree(p));
@@ -85,6 +90,7 @@ struct tkamd_tokenizer {
     DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
+    DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
     DevBuf dw_ids, dw_tok_off, dw_first, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
@@ -306,7 +312,6 @@ void verify_direct_words(tkamd_tokenizer* t) {
     t->n_direct = nd;
     upload(t->t_words, hm.word_table, 64);
     t->dt.words = t->t_words.as<WordSlot>();
-    d_text.release(); d_starts.release(); d_list.release(); d_n.release(); d_tok0.release(); d_ntok.release(); d_tmp.release();
 }
 
 struct Plan {
@@ -390,15 +395,51 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
     t->last_n_docs = n_docs;
-    if (n_bytes == 0) {
-        pf.begin("mark_doc_starts");
-        launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<ull>(), d_err);
+    // the caller's CSR is validated once; everything below reads the validated copy
+    t->w_doc_off.reserve((size_t)(n_docs + 2) * 8);
+    pf.begin("validate_csr");
+    launch_validate_csr(st, d_doc_off, n_docs, n_bytes, d_err, t->w_doc_off.as<int64_t>());
+    pf.end();
+    d_doc_off = t->w_doc_off.as<int64_t>();
+    auto add_specials = [&]() {
+        // PostProcessor::process for a single sequence (processors/bert.rs:51-120, template.rs:544-590): specials around every document
+        const size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
+        t->w_ids2.reserve(T2 * 4);
+        t->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
+        if (out->d_offsets) t->w_offsets2.reserve(T2 * 8);
+        if (out->d_word_ids) t->w_word_ids2.reserve(T2 * 4);
+        SpecialArgs sa{};
+        sa.tok_offsets = t->w_tok_offsets.as<int64_t>();
+        sa.n_docs = n_docs;
+        sa.ids = t->w_ids.as<uint32_t>();
+        sa.offsets = out->d_offsets;
+        sa.word_ids = out->d_word_ids;
+        sa.prefix = t->t_pp_prefix.as<uint32_t>();
+        sa.suffix = t->t_pp_suffix.as<uint32_t>();
+        sa.n_prefix = (int32_t)hm.pp_prefix.size();
+        sa.n_suffix = (int32_t)hm.pp_suffix.size();
+        sa.tok_offsets2 = t->w_tok_offsets2.as<int64_t>();
+        sa.ids2 = t->w_ids2.as<uint32_t>();
+        sa.offsets2 = t->w_offsets2.as<uint32_t>();
+        sa.word_ids2 = t->w_word_ids2.as<uint32_t>();
+        sa.n_tok2 = sc + SC_NTOK2;
+        pf.begin("add_specials");
+        launch_add_specials(st, grid, sa);
         pf.end();
+        out->d_ids = sa.ids2;
+        out->d_tok_offsets = sa.tok_offsets2;
+        if (out->d_offsets) out->d_offsets = sa.offsets2;
+        if (out->d_word_ids) out->d_word_ids = sa.word_ids2;
+        out->d_n_tokens = sa.n_tok2;
+    };
+    if (n_bytes == 0) {
+        // only empty documents: no tokens, but the post-processor still puts its specials around every one of them
         HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
         if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = t->w_offsets.as<uint32_t>();
         if (want_words) out->d_word_ids = t->w_word_ids.as<uint32_t>();
-        t->last_ntok_slot = SC_NTOK;
-        if (add_special && n_docs > 0) throw Unsupported("add_special_tokens on a batch of only empty documents");
+        if (add_special) add_specials();
+        t->last_ntok_slot = add_special ? SC_NTOK2 : SC_NTOK;
+        HIP_CHECK(hipGetLastError());
         return;
     }
 
@@ -433,9 +474,6 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const int64_t* x_doc_off = d_doc_off;
     const int64_t* x_len_dev = nullptr;
     if (hm.norm == NORM_BERT || prefix_space) {
-        // the derived CSR is built from the caller's: validate that one first
-        launch_mark_doc_starts(st, d_doc_off, n_docs, n_bytes, t->w_docmask.as<ull>(), d_err);
-        HIP_CHECK(hipMemsetAsync(t->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
         t->w_ntext.reserve((size_t)n_x + TKAMD_TEXT_PAD);
         t->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
         HIP_CHECK(hipMemsetAsync(t->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
@@ -668,36 +706,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         if (a.want_offsets) out->d_offsets = a.offsets;
         if (a.want_words) out->d_word_ids = a.word_ids;
     }
-    if (add_special) {
-        const size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
-        t->w_ids2.reserve(T2 * 4);
-        t->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
-        if (out->d_offsets) t->w_offsets2.reserve(T2 * 8);
-        if (out->d_word_ids) t->w_word_ids2.reserve(T2 * 4);
-        SpecialArgs sa{};
-        sa.tok_offsets = t->w_tok_offsets.as<int64_t>();
-        sa.n_docs = n_docs;
-        sa.ids = t->w_ids.as<uint32_t>();
-        sa.offsets = out->d_offsets;
-        sa.word_ids = out->d_word_ids;
-        sa.prefix = t->t_pp_prefix.as<uint32_t>();
-        sa.suffix = t->t_pp_suffix.as<uint32_t>();
-        sa.n_prefix = (int32_t)hm.pp_prefix.size();
-        sa.n_suffix = (int32_t)hm.pp_suffix.size();
-        sa.tok_offsets2 = t->w_tok_offsets2.as<int64_t>();
-        sa.ids2 = t->w_ids2.as<uint32_t>();
-        sa.offsets2 = t->w_offsets2.as<uint32_t>();
-        sa.word_ids2 = t->w_word_ids2.as<uint32_t>();
-        sa.n_tok2 = sc + SC_NTOK2;
-        pf.begin("add_specials");
-        launch_add_specials(st, grid, sa);
-        pf.end();
-        out->d_ids = sa.ids2;
-        out->d_tok_offsets = sa.tok_offsets2;
-        if (out->d_offsets) out->d_offsets = sa.offsets2;
-        if (out->d_word_ids) out->d_word_ids = sa.word_ids2;
-        out->d_n_tokens = sa.n_tok2;
-    }
+    if (add_special) add_specials();
     t->last_ntok_slot = add_special ? SC_NTOK2 : SC_NTOK;
     HIP_CHECK(hipGetLastError());
 }
@@ -782,15 +791,6 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
     if (t->device >= 0) {
         (void)hipSetDevice(t->device);
         drain_profile(t);
-        DevBuf* all[] = {&t->t_uc1, &t->t_uc2, &t->t_byte_id, &t->t_merges, &t->t_words, &t->t_long_blob, &t->t_long_off,
-                         &t->t_long_id, &t->t_long_table, &t->t_at_id, &t->t_at_flags, &t->t_pp_prefix, &t->t_pp_suffix, &t->t_bn1, &t->t_bn2, &t->t_bn_map, &t->t_merge_disp, &t->t_word_disp, &t->t_dec_entry, &t->t_dec_blob, &t->t_trie, &t->t_at_blob, &t->t_at_off, &t->t_at_first, &t->w_docmask, &t->w_startmask, &t->w_wprefix, &t->w_bsum, &t->w_pt_start,
-                         &t->w_tok0, &t->w_ntok, &t->w_pt_tokoff, &t->w_tmp_ids, &t->w_tmp_end, &t->w_lists, &t->w_csum,
-                         &t->w_ids, &t->w_doc_pt, &t->w_tok_offsets, &t->w_scalars, &t->w_offsets, &t->w_word_ids,
-                         &t->w_endmask, &t->w_pt_end, &t->w_keepmask, &t->w_kprefix, &t->w_ntext, &t->w_norig, &t->w_ndoc_off, &t->w_slow_docs, &t->w_leadmask, &t->w_lprefix, &t->w_need, &t->w_need_bsum, &t->w_huge, &t->w_list_huge, &t->w_wbase, &t->w_norig_e, &t->w_ids2, &t->w_tok_offsets2, &t->w_offsets2, &t->w_word_ids2, &t->w_candmask, &t->w_matchmask, &t->w_spanmask,
-                         &t->w_stopmask, &t->w_hardmask, &t->w_match_docs, &t->w_match_list,
-                         &t->h_text, &t->h_doc_off,
-                         &t->dw_ids, &t->dw_tok_off, &t->dw_first, &t->dw_len, &t->dw_bsum, &t->dw_pos, &t->dw_out_off, &t->dw_bytes, &t->dw_total};
-        for (DevBuf* b : all) b->release();
     }
     delete t;
 }
@@ -808,6 +808,8 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* t, tkamd_info* info) {
     info->n_added_tokens = (int32_t)hm.added_tokens.size();
     info->device = t->device;
     info->n_direct_words = t->n_direct;
+    info->word_disp_entries = (int32_t)hm.word_disp.size();
+    info->merge_disp_entries = (int32_t)hm.merge_disp.size();
     return TKAMD_OK;
 }
 

@@ -288,6 +288,7 @@ void build_trie(HostModel& m, const std::vector<std::pair<std::string, uint32_t>
     std::vector<MergeSlot> items;
     for (uint32_t n = 0; n < nodes.size(); ++n)
         for (auto& e : nodes[n].kids) items.push_back(MergeSlot{n, (uint32_t)e.first, e.second, nodes[e.second].id});
+    if (nodes.size() >= ((size_t)1 << 24)) throw Unsupported("WordPiece trie beyond 2^24 nodes");
     m.trie.n_nodes = (uint32_t)nodes.size();
     build_pair_table(items, &m.trie.table, &m.trie.mask, &m.trie.seed);
 }
@@ -556,6 +557,7 @@ HostModel HostModel::from_json(const char* json, size_t len) {
             AddedToken a;
             a.content = e->get_str("content");
             a.id = (uint32_t)e->get_num("id", 0);
+            if (e->get_num("id", 0) < 0 || a.id >= (1u << 24)) throw Unsupported("added token id beyond 2^24");
             a.special = e->get_bool("special", false);
             a.single_word = e->get_bool("single_word", false);
             a.lstrip = e->get_bool("lstrip", false);
@@ -612,6 +614,9 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     for (auto& kv : vocab->obj) {
         if (!kv.second->is_number()) throw Invalid("tokenizer.json: vocab id is not a number");
         v[kv.first] = (uint32_t)kv.second->num;   // duplicate keys: last wins, like serde's map
+        // the pair hashes (tables.hpp) multiply 24-bit operands and the result rows keep ids in 24 bits: larger ids would
+        // collide for every seed, so they are refused here with the reason instead of failing table construction
+        if (kv.second->num < 0 || kv.second->num >= (double)(1u << 24)) throw Unsupported("token id beyond 2^24 (vocab entry '" + kv.first + "')");
     }
     m.vocab_size = (uint32_t)v.size();
 

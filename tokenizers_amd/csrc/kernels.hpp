@@ -117,6 +117,8 @@ constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup pat
 
 void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                             unsigned long long* docmask, int* err);
+// validates the caller's CSR (ERR_BAD_OFFSETS) and writes the copy every later kernel reads (a trivially valid one if it is malformed)
+void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, int* err, int64_t* san);
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,

@@ -20,7 +20,17 @@ __global__ void k_mark_doc_starts(const int64_t* __restrict__ doc_off, int64_t n
     }
     int64_t g1 = doc_off[d + 1];
     if (g < 0 || g1 < g || g1 > n_bytes) { atomicOr(err, ERR_BAD_OFFSETS); return; }
-    if (g < n_bytes) atomicOr(&docmask[g >> 6], 1ull << (g & 63));
+    if (docmask && g < n_bytes) atomicOr(&docmask[g >> 6], 1ull << (g & 63));      // docmask == nullptr: validation only
+}
+// Second half of the CSR validation: the pipeline never reads the caller's doc_offsets again, only this copy -- the
+// caller's array if k_mark_doc_starts accepted it, otherwise a trivially valid CSR (every document empty but the last),
+// so a malformed CSR handed to the device entry cannot turn into out-of-bounds accesses before the error is reported.
+__global__ void k_sanitize_csr(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes, const int* __restrict__ err,
+                               int64_t* __restrict__ san) {
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    const bool bad = (*err & ERR_BAD_OFFSETS) != 0;
+    san[d] = bad ? (d == n_docs ? n_bytes : 0) : doc_off[d];
 }
 
 // 2-choice cuckoo probe over a pair table (WordPiece trie edges): two independent 16-byte loads

@@ -12,6 +12,11 @@ void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_do
                             unsigned long long* docmask, int* err) {
     launch_mark_doc_starts_n(st, doc_off, n_docs, n_bytes, nullptr, docmask, err);
 }
+void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, int* err, int64_t* san) {
+    hipLaunchKernelGGL(k_mark_doc_starts, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const int64_t*)nullptr,
+                       (unsigned long long*)nullptr, err);
+    hipLaunchKernelGGL(k_sanitize_csr, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const int*)err, san);
+}
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant) {
     if (variant == 2)

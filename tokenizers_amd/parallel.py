@@ -6,8 +6,13 @@ Here the map is the per-GPU kernel pipeline and ``collect`` is a variable-length
 final CSR buffers to a root rank over RCCL/xGMI: one tiny all_gather of sizes, then one
 point-to-point message per (peer, buffer) -- xGMI is a full mesh, so every peer sends to the root
 over its own link; there is no ring and no reduction.
+
+``encode_batch_sharded`` is the whole step (shard -> per-rank encode -> gather); ``shard_documents`` and
+``gather_to_root`` are its two halves.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -31,11 +36,15 @@ def shard_documents(doc_offsets: np.ndarray, world: int) -> list[tuple[int, int]
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None):
+def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None, n_tokens_dev=None):
     """Gather every rank's (ids[T_r], tok_offsets[n_r+1]) to ``root`` in rank order.
 
     Tensors live on ``device`` (cuda for RCCL, cpu for gloo).  Returns on the root
     ``(ids_all[int32 sum T_r], tok_offsets_all[int64 sum n_r + 1])`` and ``None`` elsewhere.
+
+    ``n_tokens_dev``: a one-element int64 tensor on ``device`` holding T_r, for callers whose encode is still in flight on
+    the current stream (``ids`` is then a capacity-sized view): the all_gather of the sizes is the step's only host
+    synchronisation, and the messages leave straight from the tokenizer's workspace -- no copy, no earlier sync.
     """
     import torch
     import torch.distributed as dist
@@ -43,13 +52,18 @@ def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n_docs = int(tok_offsets.shape[0]) - 1
-    n_tok = int(ids.shape[0])
     counts = (tok_offsets[1:] - tok_offsets[:-1]).to(torch.int32).contiguous()
-    ids = ids.contiguous()
-    mine = torch.tensor([n_tok, n_docs], dtype=torch.int64, device=device)
+    if n_tokens_dev is None:
+        mine = torch.tensor([int(ids.shape[0]), n_docs], dtype=torch.int64, device=device)
+    else:
+        mine = torch.cat([n_tokens_dev.reshape(1).to(torch.int64), torch.tensor([n_docs], dtype=torch.int64, device=device)])
     sizes = torch.empty(2 * world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(sizes, mine, group=group)
     sizes = sizes.cpu().view(world, 2).tolist()
+    n_tok = sizes[rank][0]
+    ids = ids[:n_tok].contiguous()
+    if os.environ.get("TKAMD_GATHER_CLONE") == "1":          # escape hatch: send from a fresh allocator block instead of the workspace
+        ids = ids.clone()
     if rank == root:
         tot_tok = sum(s[0] for s in sizes)
         tot_docs = sum(s[1] for s in sizes)
@@ -75,9 +89,6 @@ def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None):
         offs = torch.zeros(tot_docs + 1, dtype=torch.int64, device=device)
         torch.cumsum(counts_all, dim=0, out=offs[1:])
         return ids_all, offs
-    # send from framework-allocated memory: `ids` may be a zero-copy view of the tokenizer's own hipMalloc'd
-    # workspace, and a fresh allocator block is the buffer kind RCCL's P2P path is exercised with everywhere
-    ids = ids.clone()
     ops = []
     if n_tok:
         ops.append(dist.P2POp(dist.isend, ids, root, group))
@@ -87,3 +98,44 @@ def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None):
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return None
+
+
+def encode_batch_sharded(encode_shard, buf: np.ndarray, doc_offsets: np.ndarray, device, root: int = 0, group=None):
+    """One encode_batch over all ranks of ``group``: the reference's map + collect (tokenizer/mod.rs:1345-1348).
+
+    Every rank calls this with the same whole batch (``buf`` = UTF-8 bytes, ``doc_offsets`` = int64 CSR).  Rank r takes its
+    byte-balanced contiguous document range (:func:`shard_documents`), rebases the CSR, and hands
+    ``(shard_bytes uint8[n + TEXT_PAD], shard_offsets int64[n_r + 1])`` to ``encode_shard``, which returns
+    ``(ids, tok_offsets)`` or ``(ids_capacity_view, tok_offsets, n_tokens_dev)`` as tensors on ``device``
+    (:func:`device_encoder` wraps a Tokenizer's HIP path that way).  The root gets ``(ids_all, tok_offsets_all)`` -- equal,
+    by construction of the document-boundary cuts, to the single-GPU result on the whole batch -- the others ``None``.
+    """
+    import torch.distributed as dist
+
+    from ._lib import TEXT_PAD
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    doc_offsets = np.ascontiguousarray(doc_offsets, dtype=np.int64)
+    lo, hi = shard_documents(doc_offsets, world)[rank]
+    b0, b1 = int(doc_offsets[lo]), int(doc_offsets[hi])
+    shard = np.zeros(b1 - b0 + TEXT_PAD, dtype=np.uint8)
+    shard[: b1 - b0] = buf[b0:b1]
+    res = encode_shard(shard, doc_offsets[lo:hi + 1] - b0)
+    ids, tok_offsets = res[0], res[1]
+    return gather_to_root(ids, tok_offsets, device, root=root, group=group, n_tokens_dev=res[2] if len(res) > 2 else None)
+
+
+def device_encoder(tok, device):
+    """``encode_shard`` for :func:`encode_batch_sharded` over a :class:`tokenizers_amd.Tokenizer`: H2D of the shard, the kernel
+    pipeline on the current stream, results left in the tokenizer's workspace (no host synchronisation)."""
+    import torch
+
+    def encode_shard(shard: np.ndarray, offsets: np.ndarray):
+        d_text = torch.from_numpy(shard).to(device)
+        d_off = torch.from_numpy(np.ascontiguousarray(offsets)).to(device)
+        b = tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), len(offsets) - 1, int(offsets[-1]),
+                                    stream=torch.cuda.current_stream(device).cuda_stream)
+        b._keep = (d_text, d_off)                      # inputs stay alive until the results have been consumed
+        encode_shard.last = b
+        return b.ids_tensor_unsynced(), b.tok_offsets_tensor(), b.n_tokens_tensor()
+    return encode_shard

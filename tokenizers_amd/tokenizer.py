@@ -200,8 +200,9 @@ class BatchEncoding:
 class DeviceBatch:
     """Result of :meth:`Tokenizer.encode_batch_device`: raw HBM pointers into the handle's workspace."""
 
-    def __init__(self, tok: "Tokenizer", res: _lib.DeviceResult, n_docs: int, stream: int):
+    def __init__(self, tok: "Tokenizer", res: _lib.DeviceResult, n_docs: int, stream: int, capacity: int = 0):
         self._tok, self._res, self.n_docs, self._stream = tok, res, n_docs, stream
+        self._capacity = capacity           # upper bound of the token count (a token covers at least one byte)
         self.n_tokens = None
         self.n_pretokens = None
 
@@ -228,6 +229,15 @@ class DeviceBatch:
 
     def tok_offsets_tensor(self):
         return self._tensor(self._res.d_tok_offsets, (self.n_docs + 1,), "<i8")
+
+    def ids_tensor_unsynced(self):
+        """Capacity-sized int32 view of the ids buffer for consumers that are stream-ordered behind the encode and learn the
+        token count from :meth:`n_tokens_tensor` (e.g. ``parallel.gather_to_root``): no host synchronisation."""
+        return self._tensor(self._res.d_ids, (max(self._capacity, 1),), "<i4")
+
+    def n_tokens_tensor(self):
+        """The token count as a one-element int64 tensor in HBM (valid once the stream has drained)."""
+        return self._tensor(self._res.d_n_tokens, (1,), "<i8")
 
 
 class _BatchOwner:
@@ -436,7 +446,7 @@ class Tokenizer:
         res = _lib.DeviceResult()
         _lib.check(self._lib.tkamd_encode_batch_device(self._h, d_text_ptr, d_doc_offsets_ptr, n_docs, n_bytes, flags,
                                                        stream, C.byref(res)))
-        return DeviceBatch(self, res, n_docs, stream)
+        return DeviceBatch(self, res, n_docs, stream, capacity=n_bytes + 4)
 
     # ---- measurement hooks ----
     def profile(self, on: bool) -> None:
