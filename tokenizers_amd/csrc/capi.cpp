@@ -19,6 +19,7 @@
 #include "kernels.hpp"
 
 using namespace tkamd;
+static_assert(TEXT_PAD == TKAMD_TEXT_PAD, "the kernels rely on the slack the ABI promises");
 
 namespace {
 
@@ -87,11 +88,13 @@ struct tkamd_tokenizer {
     std::mutex mu;
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
+    DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
     DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
-    DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_ntok, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
+    DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
+    DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
-    DevBuf w_lists, w_csum, w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
+    DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
     DevBuf dw_ids, dw_tok_off, dw_first, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
         w_match_docs, w_match_list;
@@ -99,12 +102,20 @@ struct tkamd_tokenizer {
     DevBuf h_text, h_doc_off;
     int n_cu = 256;
     int n_direct = 0;
+    int n_hot = 0;
+    int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
+    uint32_t q16_div = 4;        // capacity of the <= 16-byte queue = n_bytes / q16_div (halved and retried when a batch overflows it)
     bool long_prepared = false;
     // profiling
     bool prof = false;
     std::vector<StageRec> pending;
     std::vector<tkamd_stage_time> acc;
-    // last device call (for tkamd_device_sync)
+    // last device call (for tkamd_device_sync, which runs it again if a work queue overflowed)
+    const uint8_t* last_text = nullptr;
+    const int64_t* last_doc_off = nullptr;
+    int64_t last_n_bytes = 0;
+    uint32_t last_flags = 0;
+    tkamd_device_result last_result{};
     int64_t last_n_docs = 0;
     int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
@@ -283,30 +294,27 @@ void verify_direct_words(tkamd_tokenizer* t) {
     starts.push_back((uint32_t)text.size());
     size_t n = text.size();
     text.resize(n + TKAMD_TEXT_PAD, 0);
-    std::vector<uint32_t> list(P);
-    for (uint32_t i = 0; i < P; ++i) list[i] = i;
-    DevBuf d_text, d_starts, d_list, d_n, d_tok0, d_ntok, d_tmp;
+    std::vector<uint32_t> items(2 * (size_t)P);                 // QItem {start, length}
+    for (uint32_t i = 0; i < P; ++i) { items[2 * i] = starts[i]; items[2 * i + 1] = starts[i + 1] - starts[i]; }
+    DevBuf d_text, d_items, d_n, d_rows, d_tmp;
     upload(d_text, text);
-    upload(d_starts, starts);
-    upload(d_list, list);
-    std::vector<uint32_t> nn{P};
+    upload(d_items, items);
+    std::vector<uint32_t> nn((size_t)NSQ * QCNT_STRIDE, 0u);       // every item in sub-queue 0
+    nn[0] = P;
     upload(d_n, nn);
-    d_tok0.reserve(P * 4 + 16);
-    d_ntok.reserve(P * 4 + 16);
+    d_rows.reserve((size_t)P * 16 + 16);
     d_tmp.reserve(n * 4 + 64);
-    HIP_CHECK(hipMemset(d_ntok.p, 0, P * 4));
-    launch_bpe_merge(nullptr, std::max(1, (int)std::min<uint32_t>(P / 16 + 1, 4096)), 16, t->dt, d_text.as<uint8_t>(),
-                     d_starts.as<uint32_t>(), d_list.as<uint32_t>(), d_n.as<uint32_t>(), d_tok0.as<uint32_t>(),
-                     d_ntok.as<uint32_t>(), d_tmp.as<uint32_t>(), nullptr);
+    HIP_CHECK(hipMemset(d_rows.p, 0, (size_t)P * 16));
+    const QView v{(QItem*)d_items.p, d_n.as<uint32_t>(), P, 0u};
+    launch_bpe_merge(nullptr, std::max(1, (int)std::min<uint32_t>(P / 16 + 1, 4096)), 16, t->dt, d_text.as<uint8_t>(), v, d_rows.p, d_tmp.as<uint32_t>(), nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
-    std::vector<uint32_t> tok0(P), ntok(P);
-    HIP_CHECK(hipMemcpy(tok0.data(), d_tok0.p, P * 4, hipMemcpyDeviceToHost));
-    HIP_CHECK(hipMemcpy(ntok.data(), d_ntok.p, P * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> rows(4 * (size_t)P);
+    HIP_CHECK(hipMemcpy(rows.data(), d_rows.p, (size_t)P * 16, hipMemcpyDeviceToHost));
     int nd = 0;
     for (uint32_t i = 0; i < P; ++i) {
         WordSlot& s = hm.word_table[slot_of[i]];
-        if (ntok[i] == 1 && tok0[i] == s.id) { s.flags |= WORD_DIRECT; ++nd; }
+        if (rows[4 * (size_t)i] == (s.id | (1u << 28))) { s.flags |= WORD_DIRECT; ++nd; }      // row {id | count 1 << 28, ...}: exactly [own id]
         else s.flags &= ~WORD_DIRECT;
     }
     t->n_direct = nd;
@@ -314,29 +322,73 @@ void verify_direct_words(tkamd_tokenizer* t) {
     t->dt.words = t->t_words.as<WordSlot>();
 }
 
-struct Plan {
-    int64_t n_bytes, n_docs, n_words;
-};
+// Hot-word table of the lookup kernel: the settled words of <= 12 bytes with the lowest ids, direct mapped (tables.hpp).
+// "Settled" = a hit needs no further work: every word for WordLevel / WordPiece / ignore_merges, the WORD_DIRECT ones for
+// byte-level BPE.  Trainers hand out ids in frequency order, so low ids are the frequent words; a word that loses its slot
+// to a lower id stays reachable through the perfect-hash table.
+void build_hot_table(tkamd_tokenizer* t) {
+    HostModel& hm = t->hm;
+    const uint32_t slots = (uint32_t)hot_table_slots();
+    std::vector<HotSlot> hot(slots, HotSlot{0u, 0u, 0u, 0u});
+    std::vector<const WordSlot*> cand;
+    const bool all_final = hm.model != MODEL_BPE || hm.ignore_merges;
+    for (const WordSlot& w : hm.word_table)
+        if (w.len && w.len <= (uint32_t)HOT_MAX_KEY && (all_final || (w.flags & WORD_DIRECT))) cand.push_back(&w);
+    std::sort(cand.begin(), cand.end(), [](const WordSlot* a, const WordSlot* b) { return a->id < b->id; });
+    int n = 0;
+    for (const WordSlot* w : cand) {
+        const uint32_t k0 = (uint32_t)w->lo, k1 = (uint32_t)(w->lo >> 32), k2 = (uint32_t)w->hi;
+        HotSlot& h = hot[hot_hash(k0, k1, k2, w->len, hm.word_seed) & (slots - 1)];
+        if (h.id_len) continue;
+        h = HotSlot{k0, k1, k2, w->id | (w->len << 24)};
+        ++n;
+    }
+    t->n_hot = n;
+    upload(t->t_hot, hot);
+}
 
-void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint32_t flags) {
+
+// Queue capacities for a text of N bytes.  Every queue is NSQ sub-queues (results.hip); the workgroups feeding one sub-queue
+// see N / NSQ bytes of text (+ one tile).  A pre-token of class 1 / 2 / 3 is longer than 16 / 32 / 64 bytes, so those three
+// are sized for the worst case outright; the <= 16-byte queue (worst case: half the bytes) starts at 1 / q16_div of them and
+// the batch is run again with the worst-case size if it ever overflows (ERR_QUEUE_FULL; natural text queues 1/50 .. 1/6).
+struct QueueSizes {
+    uint32_t sq_cap[4], row_base[4];
+    size_t total;
+};
+QueueSizes queue_sizes(size_t N, uint32_t q16_div) {
+    QueueSizes z{};
+    const size_t per_sq = N / NSQ + 32768;
+    z.sq_cap[0] = (uint32_t)(per_sq / q16_div + 64);
+    z.sq_cap[1] = (uint32_t)(per_sq / 17 + 16);
+    z.sq_cap[2] = (uint32_t)(per_sq / 33 + 16);
+    z.sq_cap[3] = (uint32_t)(per_sq / 65 + 16);
+    size_t acc = 0;
+    for (int c = 0; c < 4; ++c) { z.row_base[c] = (uint32_t)acc; acc += (size_t)z.sq_cap[c] * NSQ; }
+    z.total = acc;
+    return z;
+}
+
+void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint32_t flags, bool want_meta) {
     int64_t W = (n_bytes >> 6) + 2;
     size_t N = (size_t)n_bytes;
     t->w_docmask.reserve(W * 8);
     t->w_startmask.reserve(W * 8);
     t->w_wprefix.reserve(W * 4);
     t->w_bsum.reserve((W / 256 + 2) * 4);
-    t->w_pt_start.reserve((N + 4) * 4);
     t->w_tok0.reserve((N + 4) * 4);
-    t->w_ntok.reserve((N + 4) * 4);
-    t->w_pt_tokoff.reserve((N + 4) * 4);
     t->w_tmp_ids.reserve((N + 4) * 4);
-    t->w_rows.reserve((N / 4 + N / 32 + 2048) * 16);   // dense result rows of the LDS merge kernels (overflow falls back to tmp_ids)
-    t->w_lists.reserve((N + N / 16 + N / 32 + N / 64 + 128) * 4);
-    t->w_csum.reserve((N / 1024 + 4) * 4);
+    const QueueSizes z = queue_sizes(N, t->q16_div);
+    t->w_rows.reserve(z.total * 16);
+    t->w_queues.reserve(z.total * 8);
+    t->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8);
+    t->w_qcount.reserve((size_t)QCNT_WORDS * 4);
+    t->w_pt_tokoff.reserve((N + 4) * 4);
     t->w_ids.reserve((N + 4) * 4);
     t->w_doc_pt.reserve((n_docs + 2) * 4);
     t->w_tok_offsets.reserve((n_docs + 2) * 8);
     t->w_scalars.reserve(SC_SLOTS * 8);
+    if (want_meta) t->w_pt_start.reserve((N + 4) * 4);      // pre-token offsets exist in memory only for the offsets / word-id pass
     if (flags & TKAMD_OFFSETS_MASK) {
         t->w_tmp_end.reserve((N + 4) * 4);
         t->w_offsets.reserve((N + 4) * 8);
@@ -373,7 +425,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
                           "{Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
     if (prefix_space && hm.norm != NORM_NONE) throw Unsupported("ByteLevel add_prefix_space behind a normalizer");
 
-    reserve_workspace(t, n_x, n_docs, flags);
+    reserve_workspace(t, n_x, n_docs, flags, want_meta);
     int64_t* sc = t->w_scalars.as<int64_t>();
     int64_t* d_npretok = sc + SC_NPRETOK;
     int64_t* d_ntok_total = sc + SC_NTOK;
@@ -511,7 +563,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     if (matchmask && !prefix_space) launch_mask_or(st, t->w_docmask.as<ull>(), t->w_hardmask.as<ull>(), W0);   // match edges are hard boundaries
     pf.end();
 
-    uint32_t* pt_end = nullptr;
+    uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
+    bool has_end = false;             // the pre-tokenizer produced an end bitmask
     if (hm.pretok == PT_BYTELEVEL_GPT2) {
         // Two implementations of the same predicate: the LDS-window kernel (default, faster: 0.33 ms @C2) and the
         // bit-parallel ballot kernel (TKAMD_PRETOK=bits; its 64-bit mask algebra lands on the scalar unit, one per
@@ -537,66 +590,73 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         HIP_CHECK(hipMemcpyAsync(t->w_startmask.p, t->w_docmask.p, (size_t)W * 8, hipMemcpyDeviceToDevice, st));
     } else {
         t->w_endmask.reserve((size_t)(W + 1) * 8);
-        t->w_pt_end.reserve(((size_t)n_x + 4) * 4);
-        pt_end = t->w_pt_end.as<uint32_t>();
+        has_end = true;
+        if (want_meta) {
+            t->w_pt_end.reserve(((size_t)n_x + 4) * 4);
+            pt_end = t->w_pt_end.as<uint32_t>();
+        }
         pf.begin("pretok_local");
         launch_pretok_local(st, (int)hm.pretok, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
                             t->w_startmask.as<ull>(), t->w_endmask.as<ull>());
         pf.end();
     }
     if (matchmask && !prefix_space)
-        launch_apply_matches(st, t->w_startmask.as<ull>(), pt_end ? t->w_endmask.as<ull>() : nullptr, matchmask, t->w_spanmask.as<ull>(),
+        launch_apply_matches(st, t->w_startmask.as<ull>(), has_end ? t->w_endmask.as<ull>() : nullptr, matchmask, t->w_spanmask.as<ull>(),
                              t->w_stopmask.as<ull>(), W0);
     pf.begin("mask_scan");
     launch_mask_scan(st, t->w_startmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
-    pf.begin("emit_pretok");
-    launch_emit_pretok(st, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, t->w_pt_start.as<uint32_t>());
-    if (pt_end) launch_emit_pretok_end(st, t->w_startmask.as<ull>(), t->w_endmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, pt_end);
-    pf.end();
+    if (want_meta) {
+        // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
+        // the bitmasks (k_lookup) and from (start, length) queue entries
+        pf.begin("emit_pretok");
+        launch_emit_pretok(st, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, t->w_pt_start.as<uint32_t>());
+        if (pt_end) launch_emit_pretok_end(st, t->w_startmask.as<ull>(), t->w_endmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, pt_end);
+        pf.end();
+    }
     pf.begin("doc_first_pretok");
     launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(),
                             d_npretok, t->w_doc_pt.as<uint32_t>());
     pf.end();
 
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? t->w_tmp_end.as<uint32_t>() : nullptr;
+    const size_t N = (size_t)n_x;
+    const QueueSizes qz = queue_sizes(N, t->q16_div);
+    QueuePlan plan{};
+    for (int c = 0; c < 4; ++c) {
+        plan.v[c].q = (QItem*)(t->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);
+        plan.v[c].counts = t->w_qcount.as<uint32_t>() + (size_t)c * NSQ * QCNT_STRIDE;
+        plan.v[c].sq_cap = qz.sq_cap[c];
+        plan.v[c].row_base = qz.row_base[c];
+    }
+    HIP_CHECK(hipMemsetAsync(t->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
+    if (!t->long_prepared) {
+        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
+        t->long_prepared = true;
+    }
+    const ull* endmask = has_end ? t->w_endmask.as<ull>() : nullptr;
     if (hm.model == MODEL_BPE) {
-        size_t N = (size_t)n_x;
-        uint32_t* list16 = t->w_lists.as<uint32_t>();
-        uint32_t* list32 = list16 + N + 16;
-        uint32_t* list64 = list32 + N / 16 + 16;
-        uint32_t* listL = list64 + N / 32 + 16;
-        if (!t->long_prepared) {
-            if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(merge kernel LDS) failed");
-            t->long_prepared = true;
-        }
+        pf.begin("lookup");
+        launch_lookup(st, 2 * t->n_cu, t->dt, x_text, n_x, x_len_dev, t->w_startmask.as<ull>(), endmask, t->w_wprefix.as<uint32_t>(),
+                      t->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 0u);
+        pf.end();
+        if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
+            for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], t->w_rows.p, 0u, d_err);
+        // TKAMD_MERGE16 = row / lane, TKAMD_LDSCFG = 0: the 16-lane DPP-row kernel / the register-resident lane kernels (A/B
+        // switches; the lane kernels are also what runs when new_id is not rank + c)
         static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 2; }();
         static const bool row16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "row"); }();
         static const bool lane16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "lane"); }();
-        const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // LDS-resident Word (default when new_id = rank + c)
+        const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // keys in LDS (default when new_id = rank + c)
         const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
-        // dense result rows of the LDS merge kernels, named by queue position (beyond the capacity: the tmp_ids path)
-        const uint32_t rows16_cap = lds16 ? (uint32_t)(N / 4 + 1024) : 0u, rows32_cap = lds32 ? (uint32_t)(N / 32 + 1024) : 0u;
-        const RowPlan rowplan{rows16_cap, (uint32_t)(N / 4 + 1024), rows32_cap};
-        pf.begin("bpe_word_lookup");
-        launch_bpe_word_lookup(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), nullptr, d_npretok, t->w_tok0.as<uint32_t>(),
-                               t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask, rowplan);
-        pf.end();
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? (ldscfg == 2 ? 6 : 4) : 2, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list32, d_counters + CNT_LIST32,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, rowplan.base32, rows32_cap);
+        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
-        // <= 16 bytes: one lane per pre-token, Word in LDS (or in registers when new_id is not rank + c).
-        // TKAMD_MERGE16=row / lane select the 16-lane DPP-row kernel / the register-resident lane kernel (A/B switches).
-        const uint32_t* mlist = list16;
-        const uint32_t* mcount = d_counters + CNT_LIST16;
         pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
-        launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? (ldscfg == 2 ? 5 : 3) : 1), t->dt, x_text, t->w_pt_start.as<uint32_t>(), mlist, mcount,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_rows.p, 0u, rows16_cap);
+        launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge64");
-        launch_bpe_merge(st, grid, 64, t->dt, x_text, t->w_pt_start.as<uint32_t>(), list64, d_counters + CNT_LIST64,
-                         t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(st, grid, 64, t->dt, x_text, plan.v[2], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge_long");
         // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
@@ -609,55 +669,44 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             t->w_huge.reserve(64);
             t->w_list_huge.reserve(64);
         }
-        launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), listL, d_counters + CNT_LISTL,
-                              t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end,
-                              t->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, t->w_huge.as<uint32_t>(),
+        launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, plan.v[3], t->w_rows.p,
+                              t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, t->w_huge.as<uint32_t>(),
                               (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
     } else if (hm.model == MODEL_WORDLEVEL) {
-        pf.begin("wordlevel");
-        launch_wordlevel(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
-                         t->w_ntok.as<uint32_t>(), d_err, matchmask);
+        // WordLevel::tokenize (wordlevel/mod.rs:162-178) is the lookup itself: every hit is final, a miss is the unk id
+        DevTables wt = t->dt;
+        wt.ignore_merges = 1;
+        pf.begin("wordlevel_lookup");
+        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, t->w_startmask.as<ull>(), endmask, t->w_wprefix.as<uint32_t>(),
+                      t->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 1u);
+        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], t->w_rows.p, 1u, d_err);      // words longer than 16 bytes
         pf.end();
     } else {
-        // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): a whole-word
-        // table pass settles most words with one probe; only the rest walk the trie, in dense wavefronts.
+        // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): the whole-word lookup
+        // settles most words with one probe; only the rest walk the trie.  With max_input_chars_per_word < 16 a whole-word
+        // hit could belong to a word over the limit, so every word takes the walk (which counts the chars).
         const bool shortcut = hm.max_input_chars >= (uint32_t)WORD_MAX_KEY;
-        if (shortcut) {
-            size_t N = (size_t)n_x;
-            uint32_t* list16 = t->w_lists.as<uint32_t>();
-            uint32_t* list32 = list16 + N + 16;
-            uint32_t* list64 = list32 + N / 16 + 16;
-            uint32_t* listL = list64 + N / 32 + 16;
-            DevTables wt = t->dt;
-            wt.ignore_merges = 1;                              // any whole-word hit is final
-            wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
-            pf.begin("wordpiece_word_lookup");
-            launch_bpe_word_lookup(st, grid, wt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, t->w_tok0.as<uint32_t>(),
-                                   t->w_ntok.as<uint32_t>(), list16, list32, list64, listL, d_counters, matchmask);
-            pf.end();
-            pf.begin("wordpiece");
-            const uint32_t* lists[4] = {list16, list32, list64, listL};
-            const int cnts[4] = {CNT_LIST16, CNT_LIST32, CNT_LIST64, CNT_LISTL};
-            for (int q = 0; q < 4; ++q)
-                launch_wordpiece(st, q == 0 ? grid : t->n_cu, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, lists[q],
-                                 d_counters + cnts[q], t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err,
-                                 matchmask);
-            pf.end();
-        } else {
-            pf.begin("wordpiece");
-            launch_wordpiece(st, grid, t->dt, x_text, t->w_pt_start.as<uint32_t>(), pt_end, d_npretok, nullptr, nullptr,
-                             t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err, matchmask);
-            pf.end();
-        }
+        DevTables wt = t->dt;
+        wt.ignore_merges = 1;                              // any whole-word hit is final
+        wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
+        pf.begin("wordpiece_word_lookup");
+        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, t->w_startmask.as<ull>(), endmask, t->w_wprefix.as<uint32_t>(),
+                      t->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, shortcut ? 0u : 1u, 0u);
+        pf.end();
+        pf.begin("wordpiece");
+        for (int c = 0; c < 4; ++c)
+            launch_wordpiece(st, c == 0 ? grid : t->n_cu, t->dt, x_text, plan.v[c], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+        pf.end();
     }
     if (matchmask && !prefix_space)
         launch_apply_match_ids(st, t->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, t->w_startmask.as<ull>(),
-                               t->w_wprefix.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_ntok.as<uint32_t>());
+                               t->w_wprefix.as<uint32_t>(), t->w_tok0.as<uint32_t>());
     pf.begin("compact");
-    launch_compact(st, grid, t->w_ntok.as<uint32_t>(), t->w_tok0.as<uint32_t>(), t->w_tmp_ids.as<uint32_t>(),
-                   t->w_pt_start.as<uint32_t>(), d_npretok, t->w_csum.as<uint32_t>(), d_ntok_total,
-                   t->w_pt_tokoff.as<uint32_t>(), t->w_ids.as<uint32_t>(), t->w_rows.p);
+    HIP_CHECK(hipMemsetAsync(t->w_cstate.p, 0, (N / COMPACT_CHUNK + 4) * 8, st));
+    if (!t->cp_grid) t->cp_grid = compact_grid(t->n_cu);
+    launch_compact(st, t->cp_grid, t->w_tok0.as<uint32_t>(), t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), d_npretok, t->w_cstate.as<ull>(),
+                   d_ntok_total, t->w_pt_tokoff.as<uint32_t>(), t->w_ids.as<uint32_t>());
     pf.end();
     pf.begin("doc_tok_offsets");
     launch_doc_tok_offsets(st, t->w_doc_pt.as<uint32_t>(), n_docs, t->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
@@ -711,6 +760,24 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     HIP_CHECK(hipGetLastError());
 }
 
+int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok);
+
+// Wait for the batch enqueued last; if its <= 16-byte work queue overflowed (ERR_QUEUE_FULL), grow the queue and run the
+// same call again on the same stream (the output buffers are sized for the worst case, so the result pointers stay).
+int finish_batch(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
+    int bits = read_scalars(t, st, n_tok, n_pretok);
+    while ((bits & ERR_QUEUE_FULL) && !(bits & ~ERR_QUEUE_FULL) && t->q16_div > 2) {
+        t->q16_div = 2;                                  // n_bytes / 2 + 1024 entries: a queued pre-token has at least two bytes
+        tkamd_device_result again{};
+        run_pipeline(t, t->last_text, t->last_doc_off, t->last_n_docs, t->last_n_bytes, t->last_flags, st, &again);
+        if (again.d_ids != t->last_result.d_ids || again.d_tok_offsets != t->last_result.d_tok_offsets ||
+            again.d_offsets != t->last_result.d_offsets || again.d_word_ids != t->last_result.d_word_ids)
+            throw HipError("result buffers moved while a batch was run again");
+        bits = read_scalars(t, st, n_tok, n_pretok);
+    }
+    return bits;
+}
+
 int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
     int64_t host[SC_SLOTS];
     HIP_CHECK(hipMemcpyAsync(host, t->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
@@ -733,7 +800,8 @@ int error_from_bits(int bits) {
     if (bits & ERR_NON_ASCII_NORM)
         return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: the text contains a character with a non-zero combining class that "
                                                 "survives the Mn filter; NFD may reorder it across characters (not built on the device)");
-    if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal work queue overflow");
+    if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal invariant violated");
+    if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
 }
@@ -778,8 +846,10 @@ int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tka
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, device));
             t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(2, atoi(e));     // test hook: start with a tiny queue
             upload_tables(t.get());
             verify_direct_words(t.get());
+            build_hot_table(t.get());
         }
         *out = t.release();
         return TKAMD_OK;
@@ -833,6 +903,7 @@ int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const i
         std::lock_guard<std::mutex> lk(t->mu);
         HIP_CHECK(hipSetDevice(t->device));
         run_pipeline(t, d_text, d_doc_offsets, n_docs, n_bytes, flags, (hipStream_t)hip_stream, out);
+        t->last_text = d_text; t->last_doc_off = d_doc_offsets; t->last_n_bytes = n_bytes; t->last_flags = flags; t->last_result = *out;
         return TKAMD_OK;
     });
 }
@@ -842,7 +913,7 @@ int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, i
     return guarded([&]() -> int {
         std::lock_guard<std::mutex> lk(t->mu);
         HIP_CHECK(hipSetDevice(t->device));
-        int bits = read_scalars(t, (hipStream_t)hip_stream, n_tokens, n_pretokens);
+        int bits = finish_batch(t, (hipStream_t)hip_stream, n_tokens, n_pretokens);
         return error_from_bits(bits);
     });
 }
@@ -866,8 +937,9 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         HIP_CHECK(hipMemcpyAsync(t->h_doc_off.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
         tkamd_device_result r{};
         run_pipeline(t, t->h_text.as<uint8_t>(), t->h_doc_off.as<int64_t>(), n_docs, n_bytes, flags, st, &r);
+        t->last_text = t->h_text.as<uint8_t>(); t->last_doc_off = t->h_doc_off.as<int64_t>(); t->last_n_bytes = n_bytes; t->last_flags = flags; t->last_result = r;
         int64_t n_tok = 0, n_pt = 0;
-        int bits = read_scalars(t, st, &n_tok, &n_pt);
+        int bits = finish_batch(t, st, &n_tok, &n_pt);
         if (bits) return error_from_bits(bits);
         std::unique_ptr<tkamd_batch> b(new tkamd_batch());
         b->n_docs = n_docs;
@@ -1120,9 +1192,22 @@ int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_sta
 
 int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {
     if (!t || !out) return set_error(TKAMD_ERR_INVALID, "null argument");
-    std::lock_guard<std::mutex> lk(t->mu);
-    for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = t->last_counters[i];
-    return TKAMD_OK;
+    return guarded([&]() -> int {
+        std::lock_guard<std::mutex> lk(t->mu);
+        for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = t->last_counters[i];
+        if (t->device >= 0 && t->w_qcount.p) {             // queue fills of the last batch: the sub-queue counters, summed per queue
+            HIP_CHECK(hipSetDevice(t->device));
+            std::vector<uint32_t> c(QCNT_WORDS);
+            HIP_CHECK(hipMemcpy(c.data(), t->w_qcount.p, (size_t)QCNT_WORDS * 4, hipMemcpyDeviceToHost));
+            static const int slot[4] = {CNT_LIST16, CNT_LIST32, CNT_LIST64, CNT_LISTL};
+            for (int q = 0; q < 4; ++q) {
+                uint32_t sum = 0;
+                for (int i = 0; i < NSQ; ++i) sum += c[((size_t)q * NSQ + i) * QCNT_STRIDE];
+                if (slot[q] < n) out[slot[q]] = sum;
+            }
+        }
+        return TKAMD_OK;
+    });
 }
 
 }  // extern "C"

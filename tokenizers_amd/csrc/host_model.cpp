@@ -220,7 +220,7 @@ void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
             m.merge_mask = cap - 1; m.merge_bmask = nb - 1; m.merge_seed = seed;
             return;
         }
-        if (attempt % 2 == 1) cap <<= 1;
+        if (attempt % 8 == 7) cap <<= 1;                       // a new seed almost always does it; grow (at most 8x) only as a last resort
     }
     throw Invalid("could not build the merge hash table");
 }
@@ -243,7 +243,7 @@ void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {
             m.word_mask = cap - 1; m.word_bmask = nb - 1; m.word_seed = seed;
             return;
         }
-        if (attempt % 2 == 1) cap <<= 1;
+        if (attempt % 8 == 7) cap <<= 1;
     }
     throw Invalid("could not build the whole-word hash table");
 }
@@ -349,9 +349,14 @@ PretokKind parse_pretok(const JsonValue* pt, HostModel& m) {
 
 }  // namespace
 
+// hash of a long vocabulary key (tables.hpp: long_key_hash_*); the name is historical
 uint32_t fnv1a(const uint8_t* p, size_t n) {
-    uint32_t h = 2166136261u;
-    for (size_t i = 0; i < n; ++i) { h ^= p[i]; h *= 16777619u; }
+    uint32_t h = long_key_hash_init((uint32_t)n);
+    for (size_t i = 0; i < n; i += 4) {
+        uint32_t w = 0;
+        for (size_t q = 0; q < 4 && i + q < n; ++q) w |= (uint32_t)p[i + q] << (8 * q);
+        h = long_key_hash_step(h, w);
+    }
     return h;
 }
 

@@ -6,10 +6,13 @@
 //        │──────bert_norm──────► normalised text X (BertNormalizer)                               kernels/bert_norm.hip
 //        │──────pretok_*───────► pre-token start (/ end) bitmask: per-lane 64-bit mask algebra    kernels/pretok_{gpt2,llama3,local}.hip
 //        │──────scan_emit──────► pt_start[P+1]   (byte offset of every pre-token = "split")       kernels/scan_emit.hip
-//        │──────bpe────────────► whole-word table hit -> 1 token; misses queued by length class,  kernels/bpe.hip, bpe_huge.hip
-//        │                       min-rank merge loop, one lane per pre-token (Word in LDS / registers)
-//        │──────word_models────► WordLevel probe / WordPiece trie walk                            kernels/word_models.hip
-//        │──────output─────────► ids[T] + per-document token CSR, offsets, word ids, specials     kernels/output.hip
+//        │──────lookup─────────► straight from the bitmasks: whole-word hit -> 1 token (LDS hot    kernels/lookup.hip
+//        │                       table, then the perfect hash in HBM); misses queued by length class
+//        │──────bpe────────────► min-rank merge loop, one lane per queued pre-token (Word in LDS)  kernels/bpe.hip, bpe_huge.hip
+//        │──────word_models────► WordPiece trie walk of the queued words                          kernels/word_models.hip
+//        │──────scan_emit──────► pt_start[P+1] only when offsets / word ids are requested          kernels/scan_emit.hip
+//        │──────output─────────► ids[T] (single-pass look-back compaction), per-document CSR,      kernels/output.hip, results.hip
+//        │                       offsets, word ids, specials
 //   ids ────────decode─────────► text (decode_batch)                                              kernels/decode.hip
 //
 // Every kernel cites the reference code it replaces.  All results are bit-exact integers.
@@ -49,6 +52,7 @@ __device__ __forceinline__ uint32_t utf8_global(const uint8_t* __restrict__ text
 static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }   // grid size
 
 // ---- the kernels, by pipeline stage (one translation unit; every file below is a plain slice of it) ----
+#include "kernels/results.hip"
 #include "kernels/documents.hip"
 #include "kernels/pretok_gpt2.hip"
 #include "kernels/pretok_llama3.hip"
@@ -56,6 +60,7 @@ static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)(
 #include "kernels/bert_norm.hip"
 #include "kernels/scan_emit.hip"
 #include "kernels/bpe.hip"
+#include "kernels/lookup.hip"
 #include "kernels/word_models.hip"
 #include "kernels/bpe_huge.hip"
 #include "kernels/output.hip"

@@ -43,9 +43,20 @@ struct BnTables {
     uint32_t clean, cjk, strip, lower;
 };
 
-// where the LDS merge kernels leave their results: queue position -> dense row (0 capacities: rows off)
-struct RowPlan {
-    uint32_t cap16, base32, cap32;
+// one queued pre-token (kernels/results.hip); a queue = NSQ sub-queues of sq_cap entries, each with its own fill counter
+// QCNT_STRIDE words (one 128-byte line) apart
+struct QItem;
+constexpr int NSQ = 64;
+constexpr int QCNT_STRIDE = 32;
+constexpr int QCNT_WORDS = 4 * NSQ * QCNT_STRIDE;       // fill counters of the four queues
+struct QView {
+    QItem* q;
+    uint32_t* counts;             // [NSQ] at stride QCNT_STRIDE
+    uint32_t sq_cap;              // entries per sub-queue
+    uint32_t row_base;            // rows[row_base + position]
+};
+struct QueuePlan {
+    QView v[4];                   // pre-tokens of <= 16 bytes, <= 32, <= 64, longer
 };
 
 // arguments of k_token_meta (offsets / word ids), passed by value
@@ -107,12 +118,14 @@ enum : int {
     ERR_ADDED_TOKEN = 4,          // an added/special token occurs in the text (AddedVocabulary split needed)
     ERR_NON_ASCII_NORM = 8,       // BertNormalizer on non-ASCII text (full-Unicode path not built yet)
     ERR_MISSING_UNK = 16,
-    ERR_INTERNAL = 32,            // an internal work queue overflowed (bug guard)         // model needed unk_token but the vocab has none (MissingUnkToken)
+    ERR_INTERNAL = 32,            // an internal invariant was violated (bug guard)
+    ERR_QUEUE_FULL = 64,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
 
 // indices into the per-batch device counter array
 enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_COUNT = 12 };
 
+constexpr int TEXT_PAD = 64;        // = TKAMD_TEXT_PAD (include/tokenizers_amd.h): readable bytes past the end of every text buffer
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident); longer ones use the global-scratch kernel
 
 void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
@@ -129,12 +142,16 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc
                          int64_t* xdoc_off, int64_t* x_len, uint8_t* xtext, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
-void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                            const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
-                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask, RowPlan rows = RowPlan{0, 0, 0});
-void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
-                      void* rows = nullptr, uint32_t row_base = 0, uint32_t row_cap = 0);
+// whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
+void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
+                   const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
+                   const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot,
+                   uint32_t no_hits, uint32_t miss_is_unk);
+int hot_table_slots();
+// group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
+// 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
+void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
+                      uint32_t* tmp_ids, uint32_t* tmp_end);
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
                               unsigned long long* docmask, int* err);
 void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
@@ -144,11 +161,11 @@ void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask,
 void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                            uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
                            uint32_t* noe, int64_t* ndoc_off, int* err);
-void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err, const unsigned long long* matchmask);
-void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
-                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err, const unsigned long long* matchmask);
+// whole-word vocabulary hits of QUEUED pre-tokens longer than 16 bytes (ignore_merges, WordLevel): a hit becomes the result row and
+// the queue entry is retired (length 0) so that the model kernels skip it
+void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err);
+void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
+                      uint32_t* tmp_end, int* err);
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
@@ -165,20 +182,22 @@ void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long
 void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
                           const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words);
 void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
-                            const uint32_t* wprefix, uint32_t* tok0, uint32_t* ntok);
+                            const uint32_t* wprefix, uint32_t* tok0);
 // decode_batch: phase 1 (out_bytes_or_null == nullptr) computes lengths / positions / document offsets / *total,
 // phase 2 gathers the bytes; firstmask is null when no id has a position-dependent form
 void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, int64_t n_docs, int64_t n_tok, const void* entry, uint32_t n_ids,
                    const uint8_t* blob, uint32_t skip_special, uint32_t* firstmask, uint32_t* len, uint32_t* bsum, uint32_t* pos, int64_t* total,
                    int64_t* out_off, uint8_t* out_bytes_or_null);
 int prepare_long_kernel();
-void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                           const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
-                           uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge, uint32_t* scratch, unsigned long long scratch_words,
-                           unsigned long long* scratch_used, int* err);
-void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
-                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids,
-                    const void* rows);
+void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
+                           uint32_t* tmp_ids, uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge,
+                           uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
+// single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
+// compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
+void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+                    unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);
+int compact_grid(int n_cu);
+constexpr int COMPACT_CHUNK = 2048;
 void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
                             const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets);
 

@@ -1,14 +1,6 @@
 // Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
 // helpers; it is not compiled on its own).  BPE: whole-word lookup and the merge kernels.
 
-// =================================================================================================
-// K_word_lookup: whole pre-token -> token id through the static whole-word table, one lane per
-// pre-token.  Replaces: BPE::tokenize_with_cache's shortcuts (models/bpe/model.rs:558-587):
-//   * ignore_merges: vocab.get(sequence) -> single token (:559-567)                      [exact]
-//   * the thread-local word cache (:573-586): here a STATIC table of vocab entries whose own
-//     merge result was verified at load time to be exactly [id] (WORD_DIRECT), so a hit is
-//     provably what merge_word would return; everything else goes to the merge kernel.
-// =================================================================================================
 struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t a, b, c, d; };
 
 __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint64_t* lo, uint64_t* hi) {
@@ -38,169 +30,29 @@ __device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint
     return word_probe_d(t, t.word_disp, lo, hi, len, id, flags);
 }
 
+// whole-word probe of a key longer than 16 bytes: hash and compare four bytes at a time (dword loads at any alignment; the text
+// carries TEXT_PAD readable bytes past its end, the vocabulary blob 16)
 __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __restrict__ w, uint32_t len, uint32_t* id) {
-    uint32_t h = 2166136261u;
-    for (uint32_t i = 0; i < len; ++i) { h ^= w[i]; h *= 16777619u; }
+    uint32_t h = long_key_hash_init(len);
+    const uint32_t nw = len >> 2, tail = len & 3u, tmask = (1u << (8u * tail)) - 1u;
+    for (uint32_t i = 0; i < nw; ++i) h = long_key_hash_step(h, ((const Unaligned4*)(w + 4u * i))->v);
+    if (tail) h = long_key_hash_step(h, ((const Unaligned4*)(w + 4u * nw))->v & tmask);
     h &= t.long_mask;
     for (;;) {
         uint32_t e = t.long_table[h];
         if (!e) return false;
         uint32_t o = t.long_off[e - 1], l = t.long_off[e] - o;
         if (l == len) {
+            const uint8_t* b = t.long_blob + o;
             uint32_t i = 0;
-            while (i < len && t.long_blob[o + i] == w[i]) ++i;
-            if (i == len) { *id = t.long_id[e - 1]; return true; }
+            while (i < nw && ((const Unaligned4*)(b + 4u * i))->v == ((const Unaligned4*)(w + 4u * i))->v) ++i;
+            if (i == nw && (!tail || ((((const Unaligned4*)(b + 4u * nw))->v ^ ((const Unaligned4*)(w + 4u * nw))->v) & tmask) == 0u)) { *id = t.long_id[e - 1]; return true; }
         }
         h = (h + 1) & t.long_mask;
     }
 }
 
-constexpr uint32_t TOK_ROW = 0x80000000u;         // tok0 flag: the low bits index a dense result row {id0 | count << 28, id1, id2, id3}
-constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
-constexpr uint32_t TOK_ONE = 0x40000000u;         // tok0 flag: exactly one token, its id in the low bits (ntok[p] is not written)
 constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
-constexpr int LK_ITEMS = 8;                      // consecutive pre-tokens per lane
-constexpr int LK_CHUNK = 256 * LK_ITEMS;
-constexpr int LK_GROUP = 4;                      // items whose loads are kept in flight together
-
-__global__ __launch_bounds__(256) void k_bpe_word_lookup(DevTables t, const uint8_t* __restrict__ text,
-                                                         const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
-                                                         const int64_t* __restrict__ n_pretok,
-                                                         uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
-                                                         uint32_t* __restrict__ list16, uint32_t* __restrict__ list32,
-                                                         uint32_t* __restrict__ list64,
-                                                         uint32_t* __restrict__ listL, uint32_t* __restrict__ counters,
-                                                         const unsigned long long* __restrict__ matchmask, RowPlan rows) {
-    __shared__ uint32_t sm[4];
-    __shared__ uint32_t base_s[4];
-    __shared__ uint16_t s_disp[DISP_LDS_MAX];
-    const bool disp_in_lds = t.word_bmask < (uint32_t)DISP_LDS_MAX;
-    if (disp_in_lds)
-        for (uint32_t i = threadIdx.x; i <= t.word_bmask; i += 256) s_disp[i] = t.word_disp[i];
-    __syncthreads();
-    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.word_disp;
-    const int64_t P = *n_pretok;
-    const int64_t n_chunks = (P + LK_CHUNK - 1) / LK_CHUNK;
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        // each lane takes LK_ITEMS consecutive pre-tokens: the work queues then stay in pre-token order, which keeps
-        // the merge kernels' text / pt_start / tmp_ids accesses local (measured: lane-strided assignment coalesces
-        // these loads better but costs the merge kernels 30 %)
-        const int64_t pbase = ch * LK_CHUNK + (int64_t)threadIdx.x * LK_ITEMS;
-        uint32_t st[LK_ITEMS], en[LK_ITEMS];
-        if (pbase + LK_ITEMS <= P) {                       // 8 offsets as two 16-byte loads (pbase is a multiple of 8)
-            const uint4 v0 = *(const uint4*)(pt_start + pbase), v1 = *(const uint4*)(pt_start + pbase + 4);
-            st[0] = v0.x; st[1] = v0.y; st[2] = v0.z; st[3] = v0.w; st[4] = v1.x; st[5] = v1.y; st[6] = v1.z; st[7] = v1.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < LK_ITEMS; ++k) st[k] = pt_start[min(pbase + k, P)];
-        }
-        if (pt_end) {                                      // "Removed" pre-tokenizers: explicit ends
-#pragma unroll
-            for (int k = 0; k < LK_ITEMS; ++k) en[k] = (pbase + k < P) ? pt_end[pbase + k] : st[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < LK_ITEMS; ++k) en[k] = (k + 1 < LK_ITEMS) ? st[k + 1] : pt_start[min(pbase + LK_ITEMS, P)];
-        }
-        uint32_t cls = 0;                          // 2 bits per item: 0 done/invalid, 1 -> list16, 2 -> list32, 3 -> list64 / listL
-        uint32_t n16 = 0, n32 = 0, n64 = 0, nL = 0;
-        uint32_t out_id[LK_ITEMS];
-#pragma unroll
-        for (int g = 0; g < LK_ITEMS; g += LK_GROUP) {
-            uint64_t lo[LK_GROUP], hi[LK_GROUP];
-            uint32_t len[LK_GROUP];
-#pragma unroll
-            for (int k = 0; k < LK_GROUP; ++k) {
-                len[k] = en[g + k] - st[g + k];
-                load_key16(text, st[g + k], min(len[k], 16u), &lo[k], &hi[k]);
-            }
-            uint4 a0[LK_GROUP], a1[LK_GROUP];
-#pragma unroll
-            for (int k = 0; k < LK_GROUP; ++k) {
-                uint32_t h1 = word_hash1(lo[k], hi[k], len[k], t.word_seed);
-                const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
-                a0[k] = q[0]; a1[k] = q[1];
-            }
-#pragma unroll
-            for (int k = 0; k < LK_GROUP; ++k) {
-                const int64_t p = pbase + g + k;
-                const bool valid = p < P;
-                bool hit = a1[k].x == len[k] && a0[k].x == (uint32_t)lo[k] && a0[k].y == (uint32_t)(lo[k] >> 32) &&
-                           a0[k].z == (uint32_t)hi[k] && a0[k].w == (uint32_t)(hi[k] >> 32);
-                bool done = valid && len[k] <= (uint32_t)WORD_MAX_KEY && hit && (t.ignore_merges || (a1[k].z & WORD_DIRECT));
-                // an added-token match is one pre-token whose id is patched in later (k_apply_match_ids): never queued
-                const bool is_match = matchmask && valid && ((matchmask[st[g + k] >> 6] >> (st[g + k] & 63)) & 1ull);
-                out_id[g + k] = (done && !is_match) ? (TOK_ONE | a1[k].y) : 0u;
-                if (valid && !done && !is_match) {
-                    uint32_t c = len[k] <= 16 ? 1u : (len[k] <= 32 ? 2u : 3u);
-                    cls |= c << (2 * (g + k));
-                }
-            }
-        }
-        // ignore_merges: whole-word vocab hit for keys longer than 16 bytes (bpe/model.rs:559-567); rare, kept off
-        // the main path
-        if (t.ignore_merges) {
-#pragma unroll
-            for (int k = 0; k < LK_ITEMS; ++k) {
-                uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
-                uint32_t id;
-                if (c >= 2 && len <= t.long_probe_max_len && long_probe(t, text + st[k], len, &id)) {
-                    out_id[k] = TOK_ONE | id;
-                    cls &= ~(3u << (2 * k));
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < LK_ITEMS; ++k) {
-            uint32_t c = (cls >> (2 * k)) & 3u, len = en[k] - st[k];
-            n16 += (c == 1);
-            n32 += (c == 2);
-            n64 += (c == 3 && len <= 64);
-            nL += (c == 3 && len > 64);
-        }
-        // one atomic per workgroup per list (same-address atomics serialise at ~12 ns each on MI355X)
-        uint32_t tot, tot2 = 0;
-        uint32_t ex = block256_excl_scan(n16 | (n32 << 16), sm, &tot);
-        uint32_t ex2 = 0;
-        if (__syncthreads_or((int)(n64 | nL))) ex2 = block256_excl_scan(n64 | (nL << 16), sm, &tot2);
-        if (threadIdx.x == 0) {
-            base_s[0] = (tot & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST16], tot & 0xFFFFu) : 0u;
-            base_s[1] = (tot >> 16) ? atomicAdd(&counters[CNT_LIST32], tot >> 16) : 0u;
-            base_s[2] = (tot2 & 0xFFFFu) ? atomicAdd(&counters[CNT_LIST64], tot2 & 0xFFFFu) : 0u;
-            base_s[3] = (tot2 >> 16) ? atomicAdd(&counters[CNT_LISTL], tot2 >> 16) : 0u;
-        }
-        __syncthreads();
-        uint32_t o16 = base_s[0] + (ex & 0xFFFFu), o32 = base_s[1] + (ex >> 16);
-        uint32_t o64 = base_s[2] + (ex2 & 0xFFFFu), oL = base_s[3] + (ex2 >> 16);
-#pragma unroll
-        for (int k = 0; k < LK_ITEMS; ++k) {
-            uint32_t c = (cls >> (2 * k)) & 3u;
-            if (c == 1) {
-                // the LDS merge kernel leaves its result in the dense row named by the queue position: point tok0 there now
-                // (coalesced with the neighbours' stores) so that it never has to touch tok0 / ntok
-                if (o16 < rows.cap16) out_id[k] = TOK_ROW | o16;
-                list16[o16++] = (uint32_t)(pbase + k);
-            } else if (c == 2) {
-                if (o32 < rows.cap32) out_id[k] = TOK_ROW | (rows.base32 + o32);
-                list32[o32++] = (uint32_t)(pbase + k);
-            } else if (c == 3) {
-                if (en[k] - st[k] <= 64u) list64[o64++] = (uint32_t)(pbase + k);
-                else listL[oL++] = (uint32_t)(pbase + k);
-            }
-        }
-        // tok0 for all 8 items as 16-byte stores: TOK_ONE | id (settled here), TOK_ROW | row (the LDS merge kernels leave the
-        // result there) or 0 (another merge kernel, or k_apply_match_ids, writes plain tok0 / ntok later).  ntok is never
-        // written here: every pre-token without a flag gets it from the kernel that resolves it.
-        if (pbase + LK_ITEMS <= P) {
-            *(uint4*)(tok0 + pbase) = make_uint4(out_id[0], out_id[1], out_id[2], out_id[3]);
-            *(uint4*)(tok0 + pbase + 4) = make_uint4(out_id[4], out_id[5], out_id[6], out_id[7]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < LK_ITEMS; ++k)
-                if (pbase + k < P) tok0[pbase + k] = out_id[k];
-        }
-        __syncthreads();
-    }
-}
 
 // =================================================================================================
 // K_bpe_merge<G>: BPE merge resolution, G lanes per pre-token (G=16: one DPP row, 4 pre-tokens per
@@ -226,23 +78,21 @@ __device__ __forceinline__ void merge_probe(const DevTables& t, uint32_t a, uint
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* __restrict__ text,
-                                                   const uint32_t* __restrict__ pt_start,
-                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+__global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
                                                    uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
     constexpr int GPW = 64 / G;                                     // pre-tokens per wavefront
+    __shared__ uint32_t s_qpre[NSQ + 1];
     const int lane = lane_id();
     const int sub = lane / G, c = lane % G, gbase = sub * G;
-    const uint32_t n = *n_list;
+    const uint32_t n = qview_prefix(v, s_qpre);
     const uint32_t wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t n_waves = gridDim.x * 4;
     for (uint32_t base = wave_global * GPW; base < n; base += n_waves * GPW) {
         uint32_t item = base + sub;
         bool valid = item < n;
-        uint32_t p = valid ? list[item] : 0u;
-        uint32_t s = 0, len = 0;
-        if (valid) { s = pt_start[p]; len = pt_start[p + 1] - s; }
+        uint32_t s = 0, len = 0, pos = 0;
+        if (valid) { pos = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[pos]; s = it.s; len = it.len; }
+        valid = valid && len != 0u;                                 // length 0: retired by k_long_vocab
         bool act = (uint32_t)c < len;
         uint32_t id = act ? t.byte_id[text[s + c]] : 0xFFFFFFFFu;
         uint64_t am = (len >= 64) ? ~0ull : ((1ull << len) - 1ull);   // alive symbols of my pre-token
@@ -277,23 +127,34 @@ __global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* _
                 else rank = RANK_NONE;
             }
         }
-        // emit: token j of the pre-token = j-th live lane; token 0 -> tok0[p], the rest -> tmp_ids[s + j]
+        // emit: token j of the pre-token = j-th live lane.  The first lane writes the result row (ids 1..3 come over by shuffle);
+        // with more than four tokens the live lanes also leave ids 1.. in tmp_ids[s + j]
+        const uint32_t count = (uint32_t)__popcll(am);
+        uint32_t r1 = 0, r2 = 0, r3 = 0;
+        {
+            uint64_t m = am & ~1ull;
+            const int p1 = m ? __ffsll((unsigned long long)m) - 1 : 0; m &= m - 1ull;
+            const int p2 = m ? __ffsll((unsigned long long)m) - 1 : 0; m &= m - 1ull;
+            const int p3 = m ? __ffsll((unsigned long long)m) - 1 : 0;
+            r1 = (uint32_t)__shfl((int)id, gbase + p1, 64);
+            r2 = (uint32_t)__shfl((int)id, gbase + p2, 64);
+            r3 = (uint32_t)__shfl((int)id, gbase + p3, 64);
+        }
         bool alive = act && ((am >> c) & 1ull);
-        if (alive) {
+        if (valid && alive) {
             uint32_t j = (uint32_t)__popcll(am & ((1ull << c) - 1ull));
-            if (j == 0) tok0[p] = id;
-            else tmp_ids[s + j] = id;
+            if (j == 0) rows[v.row_base + pos] = make_row(count, s, id, r1, r2, r3);
+            else if (count > 4u) tmp_ids[s + j] = id;
             if (tmp_end) {
                 uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
                 uint32_t endc = mine ? (uint32_t)c + 1 + (uint32_t)(__ffsll((unsigned long long)mine) - 1) : len;
                 tmp_end[s + j] = endc;                                 // token end, bytes from the pre-token start
             }
-            if (c == 0) ntok[p] = (uint32_t)__popcll(am);
         }
     }
 }
-template __global__ void k_bpe_merge<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_bpe_merge<64>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge<16>(DevTables, const uint8_t*, QView, uint4*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge<64>(DevTables, const uint8_t*, QView, uint4*, uint32_t*, uint32_t*);
 
 // =================================================================================================
 // K_bpe_merge_lane: the same merge loop for pre-tokens of <= 16 bytes, ONE LANE per pre-token with the
@@ -317,11 +178,9 @@ __device__ __forceinline__ uint32_t select_bit32(uint32_t m, uint32_t k) {
 }
 
 template <int S>   // S = 16 or 32 symbols per lane
-__global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8_t* __restrict__ text,
-                                                        const uint32_t* __restrict__ pt_start,
-                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+__global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
     constexpr uint32_t PB = (S == 16) ? 4 : 5;              // bits of the pair index inside the reduction key
     __shared__ uint32_t s_byte_id[256];
     __shared__ uint16_t s_disp[DISP_LDS_MAX];
@@ -333,13 +192,14 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
         for (uint32_t i = threadIdx.x; i <= t.merge_bmask; i += 256) s_disp[i] = t.merge_disp[i];
     __syncthreads();
     const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;   // generic pointer: LDS or global
-    const uint32_t n_items = *n_list;
+    const uint32_t n_items = qview_prefix(v, s_qpre);
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t base = blockIdx.x * 256; base < n_items; base += stride) {
         const uint32_t item = base + threadIdx.x;
         bool valid = item < n_items;
-        uint32_t p = 0, s = 0, len = 0;
-        if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        uint32_t p = 0, s = 0, len = 0;                      // p: queue position (names the result row)
+        if (valid) { p = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[p]; s = it.s; len = it.len; }
+        valid = valid && len != 0u;                          // length 0: retired by k_long_vocab
         // The loop below runs until the slowest lane of a wavefront is done (~len - 2 rounds), so the 256 items of
         // this workgroup are counting-sorted by length first: each wavefront then holds one quartile of the lengths.
         {
@@ -425,11 +285,12 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
             }
         }
         if (valid) {
-            tok0[p] = ids[0];
-            ntok[p] = n;
+            rows[v.row_base + p] = make_row(n, s, ids[0], ids[1], ids[2], ids[3]);
+            if (n > 4u) {
 #pragma unroll
-            for (int j = 1; j < S; ++j)
-                if ((uint32_t)j < n) tmp_ids[s + j] = ids[j];
+                for (int j = 1; j < S; ++j)
+                    if ((uint32_t)j < n) tmp_ids[s + j] = ids[j];
+            }
             if (tmp_end) {
                 uint32_t m = starts & (starts - 1u);          // drop the first start: ends are the later starts, then len
 #pragma unroll
@@ -444,8 +305,8 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
         }
     }
 }
-template __global__ void k_bpe_merge_lane<16>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
-template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge_lane<16>(DevTables, const uint8_t*, QView, uint4*, uint32_t*, uint32_t*);
+template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, QView, uint4*, uint32_t*, uint32_t*);
 
 // =================================================================================================
 // K_bpe_merge_lds: the lane-per-pre-token merge loop with the Word in LDS instead of registers.
@@ -465,12 +326,9 @@ template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, const u
 // Same semantics as k_bpe_merge / k_bpe_merge_lane (models/bpe/word.rs:162-250).
 // =================================================================================================
 template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
-__global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text,
-                                                      const uint32_t* __restrict__ pt_start,
-                                                      const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                      uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
-                                                      uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
-                                                      uint4* __restrict__ rows, uint32_t row_base, uint32_t row_cap) {
+__global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
+                                                      uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
     constexpr uint32_t PB = (S == 16) ? 4 : 5;
     extern __shared__ uint32_t lds_words[];
     uint32_t* s_key = lds_words;                              // [S][NT]
@@ -487,13 +345,14 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     __syncthreads();
     const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
     const uint32_t nid_base = t.newid_base;
-    const uint32_t n_items = *n_list;
+    const uint32_t n_items = qview_prefix(v, s_qpre);
     const uint32_t stride = gridDim.x * NT;
     for (uint32_t base = blockIdx.x * NT; base < n_items; base += stride) {
         const uint32_t item = base + tid;
         bool valid = item < n_items;
-        uint32_t p = 0, s = 0, len = 0, qidx = 0;             // qidx: position in the work queue (names the dense result row)
-        if (valid) { p = list[item]; s = pt_start[p]; len = pt_start[p + 1] - s; }
+        uint32_t s = 0, len = 0, qidx = 0;                    // qidx: position in the work queue (names the result row)
+        if (valid) { qidx = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qidx]; s = it.s; len = it.len; }
+        valid = valid && len != 0u;                           // length 0: retired by k_long_vocab
         // counting sort of the workgroup's items by length: a wavefront loops until its slowest lane is done
         {
             __syncthreads();                                  // previous item's key/sym area is dead
@@ -504,11 +363,11 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
             __syncthreads();
             uint32_t before = 0;
             for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
-            s_sort[before + within] = make_uint4(p, s, len, valid ? item + 1u : 0u);
+            s_sort[before + within] = make_uint4(0u, s, len, valid ? qidx + 1u : 0u);
             __syncthreads();
             const uint4 it = s_sort[tid];
             __syncthreads();                                  // everyone has read its item before keys overwrite the area
-            p = it.x; s = it.y; len = it.z; valid = it.w != 0u;
+            s = it.y; len = it.z; valid = it.w != 0u;
             qidx = it.w - 1u;
         }
         uint32_t* my_key = s_key + tid;                       // slot i at my_key[i * NT]
@@ -586,49 +445,33 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
             }
         }
         if (valid) {
+            // result row named by the queue position (the lookup kernel already pointed tok0 at it); beyond four tokens the
+            // ids 1.. go to tmp_ids[s + j]
             const uint32_t c = (uint32_t)__popc(alive);
-            if (qidx < row_cap) {
-                // result row named by the queue position (k_bpe_word_lookup already pointed tok0[p] at it):
-                // x = first id | count << 28 (15: more than four tokens -- count in tmp_ids[s], ids 2.. in tmp_ids[s + j])
-                uint32_t r[4] = {ids[0], 0u, 0u, 0u};
-                if (!SYM_REGS) r[0] = my_sym[0];
-                uint32_t m = alive & ~1u;
+            uint32_t r[4] = {ids[0], 0u, 0u, 0u};
+            if (!SYM_REGS) r[0] = my_sym[0];
+            uint32_t m = alive & ~1u;
 #pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    if (m) {
-                        const uint32_t pos = (uint32_t)__ffs(m) - 1u;
-                        TKAMD_SYM_AT(r[j], pos);
-                        if (tmp_end) tmp_end[s + j - 1] = pos;
-                        m &= m - 1u;
-                    }
-                }
-                uint32_t j = 4;
+            for (int j = 1; j < 4; ++j) {
                 if (m) {
-                    tmp_ids[s] = c;
-                    tmp_ids[s + 1] = r[1]; tmp_ids[s + 2] = r[2]; tmp_ids[s + 3] = r[3];
-                    for (; m; m &= m - 1u, ++j) {
-                        const uint32_t pos = (uint32_t)__ffs(m) - 1u;
-                        uint32_t v_;
-                        TKAMD_SYM_AT(v_, pos);
-                        tmp_ids[s + j] = v_;
-                        if (tmp_end) tmp_end[s + j - 1] = pos;
-                    }
+                    const uint32_t pos = (uint32_t)__ffs(m) - 1u;
+                    TKAMD_SYM_AT(r[j], pos);
+                    if (tmp_end) tmp_end[s + j - 1] = pos;
+                    m &= m - 1u;
                 }
-                if (tmp_end) tmp_end[s + c - 1] = len;
-                rows[row_base + qidx] = make_uint4(r[0] | (min(c, ROW_CNT_MORE) << ROW_CNT_SHIFT), r[1], r[2], r[3]);
-            } else {
-                ntok[p] = c;
-                tok0[p] = SYM_REGS ? ids[0] : my_sym[0];
-                uint32_t j = 1;
-                for (uint32_t m = alive & ~1u; m; m &= m - 1u, ++j) {
+            }
+            if (m) {
+                tmp_ids[s + 1] = r[1]; tmp_ids[s + 2] = r[2]; tmp_ids[s + 3] = r[3];
+                for (uint32_t j = 4; m; m &= m - 1u, ++j) {
                     const uint32_t pos = (uint32_t)__ffs(m) - 1u;
                     uint32_t v_;
                     TKAMD_SYM_AT(v_, pos);
                     tmp_ids[s + j] = v_;
-                    if (tmp_end) tmp_end[s + j - 1] = pos;                // the previous token ends where this one starts
+                    if (tmp_end) tmp_end[s + j - 1] = pos;
                 }
-                if (tmp_end) tmp_end[s + j - 1] = len;
             }
+            if (tmp_end) tmp_end[s + c - 1] = len;
+            rows[v.row_base + qidx] = make_row(c, s, r[0], r[1], r[2], r[3]);
         }
     }
 }
@@ -639,11 +482,8 @@ static int prepare_lds_merge() {
     return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
 }
 template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
-static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                             const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
-                             void* rows, uint32_t row_base, uint32_t row_cap) {
-    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
-                       (uint4*)rows, row_base, rows ? row_cap : 0u);
+static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, uint4* rows, uint32_t* tmp_ids, uint32_t* tmp_end) {
+    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, v, rows, tmp_ids, tmp_end);
 }
 
 // =================================================================================================
@@ -653,11 +493,10 @@ static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const
 // re-probes.  Rare path (long letter/digit runs); exactness over speed.
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8_t* __restrict__ text,
-                                                        const uint32_t* __restrict__ pt_start,
-                                                        const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
+                                                        QView v, uint4* __restrict__ rows,
                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
                                                         uint32_t* __restrict__ list_huge, uint32_t* __restrict__ n_huge) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     uint32_t* sym = (uint32_t*)lds_raw;                 // [LONG_PT_MAX]
     uint32_t* rnk = sym + LONG_PT_MAX;                     // [LONG_PT_MAX] rank of pair (i, next[i]) or NONE
@@ -667,12 +506,15 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
     __shared__ unsigned long long red[4];
     __shared__ uint32_t cnt_s;
     const int tid = (int)threadIdx.x;
-    const uint32_t n = *n_list;
+    __shared__ uint32_t first_s;
+    const uint32_t n = qview_prefix(v, s_qpre);
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
-        uint32_t p = list[item];
-        uint32_t s = pt_start[p], len = pt_start[p + 1] - s;
-        if (len > (uint32_t)LONG_PT_MAX) {                 // too long for LDS: hand over to k_bpe_merge_huge
-            if (tid == 0) list_huge[atomicAdd(n_huge, 1u)] = p;
+        const uint32_t pos = qview_pos(s_qpre, v.sq_cap, item);
+        const QItem it = v.q[pos];
+        const uint32_t s = it.s, len = it.len;
+        if (len == 0u) continue;                           // retired by k_long_vocab
+        if (len > (uint32_t)LONG_PT_MAX) {                 // too long for LDS: hand over to k_bpe_merge_huge (by queue position)
+            if (tid == 0) list_huge[atomicAdd(n_huge, 1u)] = pos;
             continue;
         }
         __syncthreads();
@@ -744,7 +586,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
             for (int w = 0; w < (tid >> 6); ++w) off += wcnt[w];
             if (alive) {
                 uint32_t j = off + (uint32_t)mbcnt64(bm);
-                if (j == 0) tok0[p] = sym[i];
+                if (j == 0) first_s = sym[i];
                 else tmp_ids[s + j] = sym[i];
                 if (tmp_end) {
                     uint32_t e = nxt[i];
@@ -755,6 +597,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
             if (tid == 0) cnt_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             __syncthreads();
         }
-        if (tid == 0) ntok[p] = cnt_s;
+        // long pre-tokens always use the "ids 1.. in tmp_ids" row form, whatever their count
+        if (tid == 0) rows[v.row_base + pos] = make_uint4(first_s | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, cnt_s, 0u);
     }
 }

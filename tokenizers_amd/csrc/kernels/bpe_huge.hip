@@ -21,9 +21,8 @@ __device__ __forceinline__ unsigned long long huge_chunk_min(const uint32_t* __r
 }
 
 __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8_t* __restrict__ text,
-                                                        const uint32_t* __restrict__ pt_start,
+                                                        const QItem* __restrict__ q, uint4* __restrict__ rows, uint32_t row_base,
                                                         const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                        uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
                                                         uint32_t* __restrict__ scratch, unsigned long long scratch_words,
                                                         unsigned long long* __restrict__ scratch_used, int* __restrict__ err) {
@@ -33,17 +32,19 @@ __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8
     __shared__ uint32_t cnt_s;
     __shared__ uint32_t wcnt[4];
     const int tid = (int)threadIdx.x;
+    __shared__ uint32_t first_s;
     const uint32_t n = *n_list;
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
-        const uint32_t p = list[item];
-        const uint32_t s = pt_start[p], len = pt_start[p + 1] - s;
+        const uint32_t p = list[item];                               // position in the long queue: names the result row
+        const QItem it = q[p];
+        const uint32_t s = it.s, len = it.len;
         const uint32_t n_chunks = (len + HUGE_CHUNK - 1) / HUGE_CHUNK;
         const unsigned long long need = 5ull * len + 2ull * n_chunks + 1ull;     // u32 words (+1 to 8-byte-align cmin)
         __syncthreads();
         if (tid == 0) base_s = atomicAdd(scratch_used, need);
         __syncthreads();
         if (base_s + need > scratch_words) {
-            if (tid == 0) { atomicOr(err, ERR_PRETOKEN_TOO_LONG); ntok[p] = 0; }
+            if (tid == 0) { atomicOr(err, ERR_PRETOKEN_TOO_LONG); rows[row_base + p] = make_uint4(0u, 0u, 0u, 0u); }
             continue;
         }
         uint32_t* sym = scratch + base_s;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8
             for (int w = 0; w < (tid >> 6); ++w) off += wcnt[w];
             if (alive) {
                 uint32_t j = off + (uint32_t)mbcnt64(bm);
-                if (j == 0) tok0[p] = sym[i];
+                if (j == 0) first_s = sym[i];
                 else tmp_ids[s + j] = sym[i];
                 if (tmp_end) { uint32_t e = nxt[i]; tmp_end[s + j] = (e == 0xFFFFFFFFu) ? len : e; }
             }
@@ -129,6 +130,6 @@ __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8
             if (tid == 0) cnt_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             __syncthreads();
         }
-        if (tid == 0) ntok[p] = cnt_s;
+        if (tid == 0) rows[row_base + p] = make_uint4(first_s | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, cnt_s, 0u);
     }
 }

@@ -199,13 +199,12 @@ __global__ void k_apply_matches(unsigned long long* __restrict__ startmask, unsi
 }
 __global__ void k_apply_match_ids(const uint32_t* __restrict__ match_list, const uint32_t* __restrict__ n_match,
                                   const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
-                                  uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok) {
+                                  uint32_t* __restrict__ tok0) {
     const uint32_t n = *n_match;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t pos = match_list[2 * i];
         const uint32_t p = wprefix[pos >> 6] + (uint32_t)__popcll(startmask[pos >> 6] & ((1ull << (pos & 63)) - 1ull));
-        tok0[p] = match_list[2 * i + 1];
-        ntok[p] = 1;
+        tok0[p] = TOK_ONE | match_list[2 * i + 1];
     }
 }
 

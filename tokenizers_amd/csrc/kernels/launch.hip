@@ -42,27 +42,50 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt) {
     hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt);
 }
-void launch_bpe_word_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                            const uint32_t* pt_end, const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, uint32_t* list16, uint32_t* list32,
-                            uint32_t* list64, uint32_t* listL, uint32_t* counters, const unsigned long long* matchmask, RowPlan rows) {
-    hipLaunchKernelGGL(k_bpe_word_lookup, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, list16, list32, list64, listL, counters, matchmask, rows);
+int hot_table_slots() { return HOT_SLOTS; }
+void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
+                   const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
+                   const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot,
+                   uint32_t no_hits, uint32_t miss_is_unk) {
+    LookupArgs a{};
+    a.words = t.words;
+    a.word_disp = t.word_disp;
+    a.word_mask = t.word_mask;
+    a.word_seed = t.word_seed;
+    a.word_bmask = t.word_bmask;
+    a.any_hit_final = t.ignore_merges;
+    a.unk_id = t.unk_id;
+    a.has_unk = t.has_unk;
+    a.text = text;
+    a.n_bytes_host = n_bytes;
+    a.len_dev = len_dev;
+    a.startmask = startmask;
+    a.endmask = endmask;
+    a.wprefix = wprefix;
+    a.tok0 = tok0;
+    for (int c = 0; c < 4; ++c) a.v[c] = plan.v[c];
+    a.err = err;
+    a.matchmask = matchmask;
+    a.hot = (const uint4*)hot;
+    a.no_hits = no_hits;
+    a.miss_is_unk = miss_is_unk;
+    if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
+    else hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(false), st, a);
 }
-void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                      const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids, uint32_t* tmp_end,
-                      void* rows, uint32_t row_base, uint32_t row_cap) {
-    // LDS-resident Word (needs newid_affine; prepare_long_kernel() raised the LDS limit)
-    if (group == 3) launch_lds_merge<16, 768, true, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
-    else if (group == 4) launch_lds_merge<32, 384, true, false>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
-    else if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);   // two 704-lane workgroups per CU
-    else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end, rows, row_base, row_cap);
+void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
+                      uint32_t* tmp_ids, uint32_t* tmp_end) {
+    uint4* r = (uint4*)rows;
+    // LDS-resident keys (needs newid_affine; prepare_long_kernel() raised the LDS limit)
+    if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, v, r, tmp_ids, tmp_end);   // two 704-lane workgroups per CU
+    else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, v, r, tmp_ids, tmp_end);
     else if (group == 1)
-        hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+        hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, v, r, tmp_ids, tmp_end);
     else if (group == 2)
-        hipLaunchKernelGGL(k_bpe_merge_lane<32>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+        hipLaunchKernelGGL(k_bpe_merge_lane<32>, dim3(grid), dim3(256), 0, st, t, text, v, r, tmp_ids, tmp_end);
     else if (group == 16)
-        hipLaunchKernelGGL(k_bpe_merge<16>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+        hipLaunchKernelGGL(k_bpe_merge<16>, dim3(grid), dim3(256), 0, st, t, text, v, r, tmp_ids, tmp_end);
     else
-        hipLaunchKernelGGL(k_bpe_merge<64>, dim3(grid), dim3(256), 0, st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end);
+        hipLaunchKernelGGL(k_bpe_merge<64>, dim3(grid), dim3(256), 0, st, t, text, v, r, tmp_ids, tmp_end);
 }
 template <int KIND>
 static void launch_pretok_local_t(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
@@ -97,14 +120,12 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
     hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
-void launch_wordlevel(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, uint32_t* tok0, uint32_t* ntok, int* err, const unsigned long long* matchmask) {
-    hipLaunchKernelGGL(k_wordlevel, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, tok0, ntok, err, matchmask);
+void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err) {
+    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err);
 }
-void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start, const uint32_t* pt_end,
-                      const int64_t* n_pretok, const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok,
-                      uint32_t* tmp_ids, uint32_t* tmp_end, int* err, const unsigned long long* matchmask) {
-    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, pt_start, pt_end, n_pretok, list, n_list, tok0, ntok, tmp_ids, tmp_end, err, matchmask);
+void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
+                      uint32_t* tmp_end, int* err) {
+    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
 }
 void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
                              const uint32_t* first_idx, int* err) {
@@ -157,33 +178,34 @@ void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigne
     hipLaunchKernelGGL(k_apply_matches, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, startmask, endmask, matchmask, spanmask, stopmask, n_words);
 }
 void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
-                            const uint32_t* wprefix, uint32_t* tok0, uint32_t* ntok) {
-    hipLaunchKernelGGL(k_apply_match_ids, dim3(64), dim3(256), 0, st, match_list, n_match, startmask, wprefix, tok0, ntok);
+                            const uint32_t* wprefix, uint32_t* tok0) {
+    hipLaunchKernelGGL(k_apply_match_ids, dim3(64), dim3(256), 0, st, match_list, n_match, startmask, wprefix, tok0);
 }
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {
     int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
-    if (rc == 0) rc = prepare_lds_merge<16, 768, true, false>();
-    if (rc == 0) rc = prepare_lds_merge<32, 384, true, false>();
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(true));
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(false));
     if (rc == 0) rc = prepare_lds_merge<16, 704, true, true>();
     if (rc == 0) rc = prepare_lds_merge<32, 768, true, true>();
     return rc;
 }
-void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const uint32_t* pt_start,
-                           const uint32_t* list, const uint32_t* n_list, uint32_t* tok0, uint32_t* ntok, uint32_t* tmp_ids,
-                           uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge, uint32_t* scratch, unsigned long long scratch_words,
-                           unsigned long long* scratch_used, int* err) {
-    hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, pt_start, list, n_list, tok0, ntok, tmp_ids, tmp_end,
-                       list_huge, n_huge);
-    hipLaunchKernelGGL(k_bpe_merge_huge, dim3(64), dim3(256), 0, st, t, text, pt_start, (const uint32_t*)list_huge, (const uint32_t*)n_huge, tok0, ntok,
-                       tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
+void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
+                           uint32_t* tmp_ids, uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge,
+                           uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err) {
+    hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, list_huge, n_huge);
+    hipLaunchKernelGGL(k_bpe_merge_huge, dim3(64), dim3(256), 0, st, t, text, (const QItem*)v.q, (uint4*)rows, v.row_base, (const uint32_t*)list_huge,
+                       (const uint32_t*)n_huge, tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
 }
-void launch_compact(hipStream_t st, int grid, const uint32_t* ntok, const uint32_t* tok0, const uint32_t* tmp_ids,
-                    const uint32_t* pt_start, const int64_t* n_pretok, uint32_t* csum, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids,
-                    const void* rows) {
-    hipLaunchKernelGGL(k_ntok_reduce, dim3(grid), dim3(256), 0, st, ntok, tok0, (const uint4*)rows, tmp_ids, pt_start, n_pretok, csum);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, csum, (int64_t)0, n_pretok, (int64_t)CP_CHUNK, n_tok);
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, st, ntok, tok0, tmp_ids, pt_start, n_pretok, (const uint32_t*)csum, (const uint4*)rows, pt_tokoff, ids);
+int compact_grid(int n_cu) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_compact, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    return per_cu * n_cu;
+}
+void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+                    unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids) {
+    static_assert(COMPACT_CHUNK == CP_CHUNK, "the host sizes the look-back state by COMPACT_CHUNK");
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids);
 }
 void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
                             const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets) {

@@ -2,118 +2,129 @@
 // helpers; it is not compiled on its own).  Token compaction, offsets / word ids, special tokens.
 
 // =================================================================================================
-// Token compaction: exclusive scan of ntok[P] -> ids[T] and the per-document token CSR.
+// Token compaction: tok0[P] (+ rows) -> ids[T], the running token offset of every pre-token, the total.
 // Replaces: PreTokenizedString::into_encoding + Encoding::from_iter (tokenizer/pre_tokenizer.rs:198-263,
 // tokenizer/encoding.rs:541-562) for the whole batch at once.
+// ONE pass over the data with decoupled look-back (results.hip), software-pipelined so that nobody waits for it:
+//   front(c)   load the chunk's tok0 words and result rows, count, scan, PUBLISH the chunk's total, and assemble the chunk's
+//              ids (and chunk-local token offsets) in LDS -- none of which needs the tokens in front of the chunk;
+//   back(c)    resolve the look-back (by now the predecessors have long published), then LDS -> ids[] / pt_tokoff[] as whole
+//              wavefront-wide stores.
+// A workgroup runs front(c_next) before back(c): the look-back round trips hide behind a whole chunk of work (measured: the
+// un-pipelined kernel spent 45 % of its time in them).  Two LDS buffers alternate.  A chunk whose tokens do not fit the buffer
+// (> CP_STAGE: only text made of many-token pre-tokens) is scattered straight from its rows in back().
+// Chunks go round robin over a grid of RESIDENT workgroups (launcher), so the owner of any earlier chunk is running or
+// done: front() never waits, back(c) only needs totals that earlier front() calls publish -- no deadlock.
 // =================================================================================================
-constexpr int CP_ITEMS = 4;                       // pre-tokens per thread
-constexpr int CP_CHUNK = 256 * CP_ITEMS;
+constexpr int CP_NT = 256;
+constexpr int CP_ITEMS = 8;                       // pre-tokens per thread
+constexpr int CP_CHUNK = CP_NT * CP_ITEMS;        // 2048 (the host sizes the state array by COMPACT_CHUNK)
+constexpr int CP_STAGE = 5120;                    // tokens of a chunk assembled in LDS (20 KB per buffer)
 
-// tok0 / ntok decoding shared by the two compaction passes: the count of pre-token p is 1 (TOK_ONE), in its result
-// row (TOK_ROW) or in ntok[p] (everything else -- the only case that reads ntok)
-__device__ __forceinline__ uint32_t row_count(const uint4& row, const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start, int64_t p) {
-    const uint32_t cf = row.x >> ROW_CNT_SHIFT;
-    return cf < ROW_CNT_MORE ? cf : tmp_ids[pt_start[p]];
-}
-__device__ __forceinline__ void load_counts(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0, int64_t p0, int64_t P,
-                                            uint32_t (&cnt)[4], uint32_t (&first)[4]) {
-    if (p0 + 4 <= P) {                                // 16-byte loads (p0 is a multiple of 4)
-        const uint4 f = *(const uint4*)(tok0 + p0);
-        first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
-        uint4 q = make_uint4(0u, 0u, 0u, 0u);
-        constexpr uint32_t FL = TOK_ONE | TOK_ROW;
-        if (!((f.x & FL) && (f.y & FL) && (f.z & FL) && (f.w & FL))) q = *(const uint4*)(ntok + p0);   // some item carries neither flag
-        cnt[0] = q.x; cnt[1] = q.y; cnt[2] = q.z; cnt[3] = q.w;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (first[k] & TOK_ONE) cnt[k] = 1u;
+struct CpRows {
+    uint4 row[CP_ITEMS];
+    uint32_t cnt[CP_ITEMS];
+};
+__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, int64_t p0, int64_t P, CpRows& r) {
+    uint32_t first[CP_ITEMS];
+    if (p0 + CP_ITEMS <= P) {
+        const uint4 a = *(const uint4*)(tok0 + p0), b = *(const uint4*)(tok0 + p0 + 4);
+        first[0] = a.x; first[1] = a.y; first[2] = a.z; first[3] = a.w; first[4] = b.x; first[5] = b.y; first[6] = b.z; first[7] = b.w;
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
-            cnt[k] = (p0 + k < P) ? ((first[k] & TOK_ONE) ? 1u : ((first[k] & TOK_ROW) ? 0u : ntok[p0 + k])) : 0u;
-        }
+        for (int k = 0; k < CP_ITEMS; ++k) first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k)                     // all row loads in flight together
+        r.row[k] = (first[k] & TOK_ROW) ? rows[first[k] & ~TOK_ROW] : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; ++k) { r.cnt[k] = row_count(r.row[k]); v += r.cnt[k]; }
+    return v;
 }
+#define TKAMD_CP_SCATTER(DST, R, O)                                                                           \
+    _Pragma("unroll") for (int k = 0; k < CP_ITEMS; ++k) {                                                    \
+        const uint32_t c = (R).cnt[k];                                                                        \
+        if (c) {                                                                                              \
+            const bool more = ((R).row[k].x >> ROW_CNT_SHIFT) == ROW_CNT_MORE;                                \
+            (DST)[(O)] = (R).row[k].x & ROW_ID_MASK;                                                          \
+            if (!more) {                                                                                      \
+                if (c > 1) (DST)[(O) + 1] = (R).row[k].y;                                                     \
+                if (c > 2) (DST)[(O) + 2] = (R).row[k].z;                                                     \
+                if (c > 3) (DST)[(O) + 3] = (R).row[k].w;                                                     \
+            } else {                                                                                          \
+                const uint32_t s_ = (R).row[k].y;                                                             \
+                for (uint32_t j = 1; j < c; ++j) (DST)[(O) + j] = tmp_ids[s_ + j];                            \
+            }                                                                                                 \
+        }                                                                                                     \
+        (O) += c;                                                                                             \
+    }
 
-__global__ __launch_bounds__(256) void k_ntok_reduce(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
-                                                     const uint4* __restrict__ rows, const uint32_t* __restrict__ tmp_ids,
-                                                     const uint32_t* __restrict__ pt_start, const int64_t* __restrict__ n_pretok,
-                                                     uint32_t* __restrict__ csum) {
-    static_assert(CP_ITEMS == 4, "load_counts handles four pre-tokens per thread");
+__global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows,
+                                                   const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
+                                                   unsigned long long* __restrict__ state,
+                                                   int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
     __shared__ uint32_t sm[4];
+    __shared__ uint32_t s_stage[2][CP_STAGE];
+    __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
+    __shared__ uint32_t s_tot[2];
+    __shared__ unsigned long long s_base;
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
-        uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
-        load_counts(ntok, tok0, p0, P, cnt, first);
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            uint32_t c = cnt[k];
-            if (first[k] & TOK_ROW) { const uint4 row = rows[first[k] & ~TOK_ROW]; c = row_count(row, tmp_ids, pt_start, p0 + k); }
-            v += c;
-        }
+    const int tid = (int)threadIdx.x;
+    // front half of a chunk into LDS buffer b
+    auto front = [&](int64_t ch, int b) {
+        const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
+        CpRows r;
+        const uint32_t v = cp_load(tok0, rows, p0, P, r);
         uint32_t tot;
-        block256_excl_scan(v, sm, &tot);
-        if (threadIdx.x == 0) csum[ch] = tot;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_compact(const uint32_t* __restrict__ ntok, const uint32_t* __restrict__ tok0,
-                                                 const uint32_t* __restrict__ tmp_ids, const uint32_t* __restrict__ pt_start,
-                                                 const int64_t* __restrict__ n_pretok, const uint32_t* __restrict__ csum,
-                                                 const uint4* __restrict__ rows,
-                                                 uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
-    __shared__ uint32_t sm[4];
-    const int64_t P = *n_pretok;
-    const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        int64_t p0 = ch * CP_CHUNK + (int64_t)threadIdx.x * CP_ITEMS;
-        uint32_t cnt[CP_ITEMS], first[CP_ITEMS];
-        const bool full = p0 + CP_ITEMS <= P;
-        load_counts(ntok, tok0, p0, P, cnt, first);
-        // pre-tokens resolved by the LDS merge kernels keep their count and up to four ids in one dense 16-byte row
-        // (tok0 = TOK_ROW | row index): one load here instead of scattered ntok / tmp_ids traffic
-        uint4 row[CP_ITEMS];
+        const uint32_t ex = block256_excl_scan(v, sm, &tot);
+        if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
+        uint32_t acc = ex;
 #pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            row[k] = make_uint4(first[k] & ~TOK_ONE, 0u, 0u, 0u);
-            if (first[k] & TOK_ROW) {
-                row[k] = rows[first[k] & ~TOK_ROW];
-                cnt[k] = row_count(row[k], tmp_ids, pt_start, p0 + k);
-                row[k].x &= ROW_ID_MASK;
+        for (int k = 0; k < CP_ITEMS; ++k) { s_loc[b][tid * CP_ITEMS + k] = acc; acc += r.cnt[k]; }
+        if (tot <= (uint32_t)CP_STAGE) {
+            uint32_t o = ex;
+            uint32_t* const dst = s_stage[b];
+            TKAMD_CP_SCATTER(dst, r, o)
+        }
+    };
+    int b = 0;
+    if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0);
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
+        const int64_t nxt = ch + gridDim.x;
+        if (nxt < n_chunks) front(nxt, b ^ 1);            // (its two barriers also order this chunk's LDS writes before the reads below)
+        else __syncthreads();
+        const uint32_t tot = s_tot[b];
+        if (tid < 64) {                                    // wavefront 0 resolves the chunk's place in the token stream
+            const unsigned long long base = lb_resolve(state, ch, (unsigned long long)tot);
+            if (tid == 0) s_base = base;
+        }
+        __syncthreads();
+        const unsigned long long base = s_base;
+        if (ch == n_chunks - 1 && tid == 0) *n_tok = (int64_t)(base + tot);
+        if (pt_tokoff) {
+            const int64_t pc = ch * CP_CHUNK;
+#pragma unroll
+            for (int i = 0; i < CP_ITEMS; ++i) {
+                const int q = i * CP_NT + tid;
+                if (pc + q < P) pt_tokoff[pc + q] = (uint32_t)base + s_loc[b][q];
             }
         }
-        uint32_t v = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        uint32_t tot;
-        uint32_t o = csum[ch] + block256_excl_scan(v, sm, &tot);
-        if (full) *(uint4*)(pt_tokoff + p0) = make_uint4(o, o + cnt[0], o + cnt[0] + cnt[1], o + cnt[0] + cnt[1] + cnt[2]);
-#pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            int64_t p = p0 + k;
-            if (p < P) {
-                if (!full) pt_tokoff[p] = o;
-                uint32_t c = cnt[k];
-                if (c) {
-                    ids[o] = row[k].x;
-                    if (c > 1) {
-                        if ((first[k] & TOK_ROW) && c <= 4u) {
-                            ids[o + 1] = row[k].y;
-                            if (c > 2) ids[o + 2] = row[k].z;
-                            if (c > 3) ids[o + 3] = row[k].w;
-                        } else {
-                            uint32_t s = pt_start[p];
-                            for (uint32_t j = 1; j < c; ++j) ids[o + j] = tmp_ids[s + j];
-                        }
-                    }
-                }
-                o += c;
-            }
+        if (tot <= (uint32_t)CP_STAGE) {
+            for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) ids[base + i] = s_stage[b][i];
+        } else {                                           // rare: too many tokens for the buffer -- scatter from the rows
+            const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
+            CpRows r;
+            cp_load(tok0, rows, p0, P, r);
+            uint32_t o = s_loc[b][tid * CP_ITEMS];
+            uint32_t* const dst = ids + base;
+            TKAMD_CP_SCATTER(dst, r, o)
         }
+        __syncthreads();                                   // buffer b is free for front() of the chunk after next
     }
 }
+#undef TKAMD_CP_SCATTER
 
 __global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n_docs, const uint32_t* __restrict__ pt_tokoff,
                                   const int64_t* __restrict__ n_pretok, const int64_t* __restrict__ n_tok,

@@ -1,0 +1,114 @@
+// Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
+// helpers; it is not compiled on its own).  How the model kernels hand their tokens to the compaction.
+
+// =================================================================================================
+// Result layout between Model::tokenize and into_encoding (replaces the Vec<Token> every Split carries,
+// tokenizer/pre_tokenizer.rs:22-47):
+//   tok0[p]   one word per pre-token:  TOK_ONE | id            exactly one token (settled by the lookup kernel)
+//                                      TOK_ROW | row            the tokens are in rows[row]
+//   rows[r]   16 bytes per QUEUED pre-token, named by the queue position the lookup kernel gave it (so the model kernels
+//             never touch the P-sized arrays):   { id0 | count << 28, id1, id2, id3 }                 count <= 4
+//                                                { id0 | 15 << 28, s, count, 0 }                      any count: ids 1.. in
+//             tmp_ids[s + j] -- s is the pre-token's first byte; a pre-token of L bytes has at most L tokens, so the slots
+//             s+1 .. s+L-1 of a 4-byte-per-text-byte array belong to it alone.
+//   tmp_end[s + j]  (only when offsets are requested) end of token j, in bytes from the pre-token start.
+// Token ids are < 2^24 (checked at load), so the flag / count bits never collide with an id.
+// =================================================================================================
+constexpr uint32_t TOK_ROW = 0x80000000u;
+constexpr uint32_t TOK_ONE = 0x40000000u;
+constexpr uint32_t TOK_ID_MASK = 0x00FFFFFFu;
+constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
+
+// one queued pre-token: first byte and length (the model kernels need nothing else)
+struct __attribute__((aligned(8))) QItem { uint32_t s, len; };
+
+// A work queue is NSQ sub-queues of sq_cap entries each, every one with its own fill counter in its own 128-byte line:
+// atomics on ONE address serialise at ~10 ns each on MI355X (device-scope atomics are resolved at the memory side), and the
+// lookup kernel issues one per workgroup, tile and queue -- tens of thousands per batch.  Workgroup b appends to sub-queue
+// b % NSQ; the consumers see the sub-queues laid end to end (qview_*).  Position p = sub-queue * sq_cap + index names the
+// queue entry and, with row_base, the result row.
+// (struct QView / NSQ / QCNT_STRIDE: kernels.hpp)
+// all threads of the workgroup: loads the fill counts, leaves their prefix sums in s_pre[NSQ + 1], returns the total
+__device__ __forceinline__ uint32_t qview_prefix(const QView& v, uint32_t* s_pre) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        static_assert(NSQ == 64, "one wavefront scans the sub-queue counts");
+        const uint32_t c = min(v.counts[threadIdx.x * QCNT_STRIDE], v.sq_cap);
+        const uint32_t inc = wave_incl_scan(c);
+        s_pre[threadIdx.x + 1] = inc;
+        if (threadIdx.x == 0) s_pre[0] = 0u;
+    }
+    __syncthreads();
+    return s_pre[NSQ];
+}
+// the queue position of the item-th entry of the concatenated sub-queues (item < total)
+__device__ __forceinline__ uint32_t qview_pos(const uint32_t* s_pre, uint32_t sq_cap, uint32_t item) {
+    uint32_t lo = 0, hi = NSQ;                              // invariant: s_pre[lo] <= item < s_pre[hi]
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pre[mid] <= item) lo = mid; else hi = mid;
+    }
+    return lo * sq_cap + (item - s_pre[lo]);
+}
+
+__device__ __forceinline__ uint32_t row_count(const uint4& row) {
+    const uint32_t cf = row.x >> ROW_CNT_SHIFT;
+    return cf < ROW_CNT_MORE ? cf : row.z;
+}
+// up to four tokens held in registers; beyond four the caller has written ids 1.. to tmp_ids[s + j] itself
+__device__ __forceinline__ uint4 make_row(uint32_t count, uint32_t s, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3) {
+    return count <= 4u ? make_uint4(id0 | (count << ROW_CNT_SHIFT), id1, id2, id3) : make_uint4(id0 | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, count, 0u);
+}
+
+// =================================================================================================
+// Single-pass prefix sums (decoupled look-back): chunk c publishes its own total as soon as it knows it, then adds up the
+// published totals of its predecessors until it meets one that already carries a full prefix.  One 64-bit word per chunk
+// holds the state and the value together, so a reader never sees one without the other; all accesses are device-scope
+// atomics (the L2 of one XCD is not coherent with the others').  The caller guarantees that the owner of every earlier chunk
+// is running or done (all workgroups resident, chunks in increasing order per workgroup): the waits cannot deadlock.
+// =================================================================================================
+constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_FLAGS = 3ull << 62, LB_VALUE = ~LB_FLAGS;
+
+__device__ __forceinline__ void lb_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Two halves, so that a workgroup can publish a chunk's total early and come back for its prefix after other work:
+//   lb_publish(state, ch, total)   one lane: total of chunk ch is known
+//   lb_resolve(state, ch, total)   ONE whole wavefront: returns, in every lane, the sum of all chunks before `ch`, and publishes the
+//                                  inclusive prefix of `ch`
+__device__ __forceinline__ void lb_publish(unsigned long long* __restrict__ state, int64_t ch, unsigned long long total) {
+    lb_store(&state[ch], (ch == 0 ? LB_PREFIX : LB_AGG) | total);
+}
+__device__ __forceinline__ unsigned long long lb_resolve(unsigned long long* __restrict__ state, int64_t ch, unsigned long long total) {
+    const int lane = lane_id();
+    if (ch == 0) return 0ull;
+    unsigned long long run = 0ull;
+    int64_t i = ch - 1;
+    while (true) {
+        const int64_t idx = i - lane;
+        unsigned long long st;
+        uint64_t empty, pref;
+        do {                                                        // wait until the window holds no unpublished chunk in front of the first full prefix
+            st = idx >= 0 ? lb_load(&state[idx]) : LB_PREFIX;
+            empty = __ballot((st & LB_FLAGS) == 0ull);
+            pref = __ballot((st & LB_FLAGS) == LB_PREFIX);
+            if (pref) {
+                const int first = __ffsll((unsigned long long)pref) - 1;          // nearest predecessor with a full prefix
+                empty &= (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
+            }
+        } while (empty);
+        const int first = pref ? __ffsll((unsigned long long)pref) - 1 : 63;
+        unsigned long long v = (lane <= first) ? (st & LB_VALUE) : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        run += v;
+        if (pref) break;
+        i -= 64;
+    }
+    if (lane == 0) lb_store(&state[ch], LB_PREFIX | (run + total));
+    return run;
+}

@@ -2,86 +2,84 @@
 // helpers; it is not compiled on its own).  WordLevel and WordPiece.
 
 // =================================================================================================
-// K_wordlevel: one hash probe per pre-token.  Replaces WordLevel::tokenize (models/wordlevel/mod.rs:162-178):
-// vocab hit -> its id; miss -> unk_token id; miss without unk_token -> Error::MissingUnkToken.
-// Keys <= 16 bytes live in the whole-word cuckoo table, longer ones in an open-addressing table over
-// the vocabulary blob.
+// WordLevel::tokenize (models/wordlevel/mod.rs:162-178) has no kernel of its own: vocab hit -> its id, miss -> unk_token id,
+// miss without unk_token -> Error::MissingUnkToken is exactly k_lookup with every hit final and `miss_is_unk` (lookup.hip).
+//
+// K_wordpiece: greedy longest-match-first, one lane per QUEUED pre-token (the words k_lookup could not settle as a whole)
+// walking the byte trie.  Replaces WordPiece::tokenize (models/wordpiece/mod.rs:224-283): words over
+// max_input_chars_per_word CHARS -> [unk]; at every position the longest vocab piece (with the continuing_subword_prefix
+// root after the first piece); if any position has no piece the WHOLE word is one [unk] (:262-279).  The reference shrinks
+// the candidate from the right one char at a time; a byte-trie walk that remembers the deepest node carrying an id finds
+// the same piece because vocab entries and text are both valid UTF-8 (a full-entry byte match ends on a char boundary).
+// The first four pieces stay in registers and leave as the result row; a fifth piece spills them to tmp_ids[s + j].
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_wordlevel(DevTables t, const uint8_t* __restrict__ text,
-                                                   const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
-                                                   const int64_t* __restrict__ n_pretok,
-                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok, int* __restrict__ err,
-                                                   const unsigned long long* __restrict__ matchmask) {
-    const int64_t P = *n_pretok;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
-        uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
-        if (matchmask && ((matchmask[s >> 6] >> (s & 63)) & 1ull)) continue;        // added token: id patched in later
-        uint32_t id = 0, fl;
-        bool hit;
-        if (len <= (uint32_t)WORD_MAX_KEY) {
-            uint64_t lo, hi;
-            load_key16(text, s, len, &lo, &hi);
-            hit = word_probe(t, lo, hi, len, &id, &fl);
-        } else hit = long_probe(t, text + s, len, &id);
-        if (!hit) {
-            if (t.has_unk) id = t.unk_id;
+// K_long_vocab: vocabulary entries longer than 16 bytes are not in the perfect-hash table the lookup kernel probes; they live in
+// an open-addressing table over the vocabulary blob (long_probe).  For the models where a whole pre-token found in the
+// vocabulary is final -- BPE with ignore_merges (bpe/model.rs:559-567) and WordLevel (wordlevel/mod.rs:162-178) -- this kernel
+// probes the QUEUED long pre-tokens: a hit becomes the result row and the queue entry is retired (length 0: the merge kernels
+// skip it); for WordLevel a miss is the unk id or MissingUnkToken.  Rare path: one lane per item.
+__global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
+                                                    uint32_t miss_is_unk, int* __restrict__ err) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
+    const uint32_t n = qview_prefix(v, s_qpre);
+    for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
+        const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
+        const QItem it = v.q[qpos];
+        uint32_t id = 0;
+        bool hit = it.len <= t.long_probe_max_len && long_probe(t, text + it.s, it.len, &id);
+        if (!hit && miss_is_unk) {
+            if (t.has_unk) { id = t.unk_id; hit = true; }
             else atomicOr(err, ERR_MISSING_UNK);
         }
-        tok0[p] = id;
-        ntok[p] = 1;
+        if (hit || miss_is_unk) {
+            rows[v.row_base + qpos] = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+            v.q[qpos].len = 0u;
+        }
     }
 }
 
-// =================================================================================================
-// K_wordpiece: greedy longest-match-first, one lane per pre-token walking the byte trie.
-// Replaces WordPiece::tokenize (models/wordpiece/mod.rs:224-283): words over max_input_chars_per_word
-// CHARS -> [unk]; at every position the longest vocab piece (with the continuing_subword_prefix root
-// after the first piece); if any position has no piece the WHOLE word is one [unk] (:262-279).  The
-// reference shrinks the candidate from the right one char at a time; a byte-trie walk that remembers
-// the deepest node carrying an id finds the same piece because vocab entries and text are both valid
-// UTF-8 (a full-entry byte match ends on a char boundary).
-// =================================================================================================
-__global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text,
-                                                   const uint32_t* __restrict__ pt_start, const uint32_t* __restrict__ pt_end,
-                                                   const int64_t* __restrict__ n_pretok,
-                                                   const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list,
-                                                   uint32_t* __restrict__ tok0, uint32_t* __restrict__ ntok,
-                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
-                                                   const unsigned long long* __restrict__ matchmask) {
-    // with a work queue (`list`): only the pre-tokens the whole-word lookup could not settle; without: all of them
-    const int64_t P = list ? (int64_t)*n_list : *n_pretok;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < P; q += (int64_t)gridDim.x * 256) {
-        const int64_t p = list ? (int64_t)list[q] : q;
-        uint32_t s = pt_start[p], e = pt_end ? pt_end[p] : pt_start[p + 1], len = e - s;
-        if (matchmask && ((matchmask[s >> 6] >> (s & 63)) & 1ull)) continue;        // added token: id patched in later
+__global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
+                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
+    const uint32_t n = qview_prefix(v, s_qpre);
+    for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
+        const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
+        const QItem it = v.q[qpos];
+        const uint32_t s = it.s, len = it.len;
         uint32_t chars = 0;
         for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
         bool bad = chars > t.max_input_chars;
-        uint32_t pos = 0, j = 0, first = 0;
+        uint32_t pos = 0, j = 0;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         while (!bad && pos < len) {
-            uint32_t node = pos ? 1u : 0u, q = pos, best_end = 0, best_id = 0;
-            while (q < len) {
+            uint32_t node = pos ? 1u : 0u, w = pos, best_end = 0, best_id = 0;
+            while (w < len) {
                 uint32_t child, id;
-                pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, (uint32_t)text[s + q], &child, &id);
+                pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, (uint32_t)text[s + w], &child, &id);
                 if (child == RANK_NONE) break;
                 node = child;
-                ++q;
-                if (id != 0xFFFFFFFFu) { best_end = q; best_id = id; }
+                ++w;
+                if (id != 0xFFFFFFFFu) { best_end = w; best_id = id; }
             }
             if (!best_end) { bad = true; break; }
-            if (j == 0) first = best_id;
-            else tmp_ids[s + j] = best_id;
+            if (j == 0) r0 = best_id;
+            else if (j == 1) r1 = best_id;
+            else if (j == 2) r2 = best_id;
+            else if (j == 3) r3 = best_id;
+            else {
+                if (j == 4) { tmp_ids[s + 1] = r1; tmp_ids[s + 2] = r2; tmp_ids[s + 3] = r3; }
+                tmp_ids[s + j] = best_id;
+            }
             if (tmp_end) tmp_end[s + j] = best_end;
             pos = best_end;
             ++j;
         }
         if (bad) {
             if (!t.has_unk) atomicOr(err, ERR_MISSING_UNK);
-            first = t.unk_id;
+            r0 = t.unk_id;
             j = 1;
             if (tmp_end) tmp_end[s] = len;
         }
-        tok0[p] = first;
-        ntok[p] = j;
+        rows[v.row_base + qpos] = make_row(j, s, r0, r1, r2, r3);
     }
 }

@@ -87,14 +87,40 @@ struct WordSlot {
 constexpr uint32_t WORD_DIRECT = 1u;
 constexpr int WORD_MAX_KEY = 16;
 
-TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed) {
-    uint32_t h = mix32((uint32_t)lo * 0x9E3779B1u + seed);
-    h = mix32(h ^ ((uint32_t)(lo >> 32) * 0x85EBCA77u));
-    h = mix32(h ^ ((uint32_t)hi * 0xC2B2AE3Du));
-    h = mix32(h ^ ((uint32_t)(hi >> 32) * 0x27D4EB2Fu) ^ len);
-    return h;
+// The bucket hash of the whole-word table continues the hot-table hash of the first 12 bytes + length (hot_hash below), so the
+// lookup kernel pays for the key bytes once: h1 = mix32(hot_hash ^ bytes 12..15 ^ seed); the slot hash is one more round.
+TK_HD uint32_t hot_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t seed);
+TK_HD uint32_t word_hash1_from_hot(uint32_t hot, uint32_t k3) { return mix32(hot ^ (k3 * 0x165667B1u)); }
+TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed);
+TK_HD uint32_t word_hash2(uint32_t h1) { return (h1 * 0x9E3779B1u) ^ (h1 >> 15); }
+
+// ---- hot-word table: the lowest-id settled words of <= 12 bytes, direct mapped, copied into LDS by the lookup kernel ----
+// slot = {k0, k1, k2, id | len << 24} (key bytes zero padded; len 0 = empty slot).  A word that loses its slot to a lower id
+// is simply not in the table: the perfect-hash table behind it still answers.
+constexpr int HOT_MAX_KEY = 12;
+struct HotSlot {
+    uint32_t k0, k1, k2, id_len;
+};
+// The seed (the one the perfect-hash builder settled on) goes in BEFORE the multiplies: two keys that collide under one seed
+// must not collide under every seed, or the builder could never separate them.
+TK_HD uint32_t hot_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t seed) {
+    uint32_t h = ((k0 + seed) * 0x9E3779B1u) ^ ((k1 ^ seed) * 0x85EBCA77u) ^ ((k2 + (seed >> 7)) * 0xC2B2AE3Du) ^ (len * 0x27D4EB2Fu);
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    return h ^ (h >> 12);
 }
-TK_HD uint32_t word_hash2(uint32_t h1) { return mix32(h1 * 0x165667B1u + 0x5BD1E995u); }
+
+TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed) {
+    return word_hash1_from_hot(hot_hash((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, len, seed), (uint32_t)(hi >> 32));
+}
+
+// ---- vocabulary entries longer than 16 bytes: open addressing over the vocabulary blob, keyed by this hash of the bytes, four at a
+// time (the last word zero padded; the length goes in first, so the padding is unambiguous) ----
+TK_HD uint32_t long_key_hash_step(uint32_t h, uint32_t w) {
+    h = (h ^ w) * 0x01000193u;
+    return h ^ (h >> 15);
+}
+TK_HD uint32_t long_key_hash_init(uint32_t len) { return 2166136261u ^ (len * 0x9E3779B1u); }
 
 // ---- decode_batch entry flags (in the length word of the first-position form) ----
 constexpr uint32_t DEC_SPECIAL = 0x80000000u;   // special token: dropped when skip_special_tokens
