@@ -20,8 +20,12 @@
  *        document and per-token word ids (= pre-token index in the document,
  *        pre_tokenizer.rs:252-256).
  *   These are the fields of `Encoding` (tokenizer/encoding.rs:11-31) that
- *   carry information; type_ids / attention_mask / special_tokens_mask are
- *   constant (0 / 1 / 0) for this path and synthesised by the host shim.
+ *   carry information; type_ids / attention_mask / special_tokens_mask follow
+ *   from the special-token layout (tkamd_tokenizer_specials) and the padding
+ *   counts (tkamd_batch_pad_counts) and are synthesised by the host shim.
+ *   A `truncation` / `padding` section of tokenizer.json is honoured for the
+ *   encodings themselves (utils/truncation.rs, utils/padding.rs); the
+ *   `overflowing` pieces a truncation leaves behind are not materialised.
  */
 #ifndef TOKENIZERS_AMD_H
 #define TOKENIZERS_AMD_H
@@ -71,6 +75,10 @@ typedef struct tkamd_info {
     int32_t n_added_tokens; /* special/added tokens registered in the JSON                       */
     int32_t device;         /* HIP device ordinal, -1 = host-only handle (no kernels)           */
     int32_t n_direct_words; /* entries of the whole-word table proven merge-stable (see DESIGN)  */
+    int32_t truncation;         /* max_length of the `truncation` section, -1 = none (utils/truncation.rs)          */
+    int32_t padding;            /* 0 none, 1 pad on the right, 2 on the left (utils/padding.rs)                       */
+    int32_t pad_id;
+    int32_t pad_type_id;
     int32_t word_disp_entries;  /* displacement entries of the whole-word perfect hash (> 16384: the kernels read them
                                    from global memory instead of their LDS copy)                                      */
     int32_t merge_disp_entries; /* same for the merge table                                                           */
@@ -105,6 +113,9 @@ const uint32_t* tkamd_batch_ids(const tkamd_batch* b);          /* [n_tokens]   
 const int64_t*  tkamd_batch_tok_offsets(const tkamd_batch* b);  /* [n_docs+1] CSR into ids      */
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b);      /* [n_tokens][2] or NULL        */
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b);     /* [n_tokens] or NULL           */
+const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b);   /* [n_docs] padding tokens of each encoding (at the side
+                                                                   tkamd_info.padding names), NULL without a `padding` section:
+                                                                   attention_mask = 0, special_tokens_mask = 1 on them      */
 void            tkamd_batch_free(tkamd_batch* b);
 
 /* ---- device-buffer entry: inputs already resident in HBM, outputs stay in HBM ---------------
@@ -119,6 +130,7 @@ typedef struct tkamd_device_result {
     const uint32_t* d_word_ids;     /* [n_tokens] or NULL                                       */
     const int64_t*  d_n_tokens;     /* [1]                                                      */
     const int64_t*  d_n_pretokens;  /* [1] number of pre-tokens (splits) in the batch           */
+    const uint32_t* d_pad_counts;   /* [n_docs] padding tokens per encoding, or NULL            */
 } tkamd_device_result;
 
 int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,

@@ -53,8 +53,8 @@ WL = {"type": "WordLevel", "vocab": {"<unk>": 0, "a": 1}, "unk_token": "<unk>"}
 
 
 @pytest.mark.parametrize("js,msg", [
-    (_base(WL, truncation={"max_length": 8, "strategy": "LongestFirst", "stride": 0, "direction": "Right"}), "truncation"),
-    (_base(WL, padding={"strategy": "BatchLongest", "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}), "padding"),
+    (_base(WL, truncation={"max_length": 8, "strategy": "Middle", "stride": 0, "direction": "Right"}), "truncation strategy"),
+    (_base(WL, padding={"strategy": "Shortest", "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}), "padding strategy"),
     (_base(WL, normalizer={"type": "NFKC"}), "normalizer"),
     (_base(WL, pre={"type": "Metaspace", "replacement": "_", "prepend_scheme": "always", "split": True}), "pre_tokenizer"),
     (_base({"type": "Unigram", "unk_id": 0, "vocab": [["<unk>", 0.0]], "byte_fallback": False}), "vocab"),
@@ -63,6 +63,16 @@ WL = {"type": "WordLevel", "vocab": {"<unk>": 0, "a": 1}, "unk_token": "<unk>"}
 def test_outside_hot_path_is_refused_loudly(js, msg):
     with pytest.raises((ta.UnsupportedError, ValueError), match=msg):
         ta.Tokenizer.from_str(js, device=-1)
+
+
+def test_truncation_and_padding_sections_load():
+    """tokenizer.json files saved with `truncation` / `padding` set load (utils/truncation.rs, utils/padding.rs); the parameters show in info."""
+    t = ta.Tokenizer.from_str(_base(WL, truncation={"max_length": 8, "strategy": "OnlyFirst", "stride": 2, "direction": "Left"},
+                                    padding={"strategy": {"Fixed": 16}, "direction": "Left", "pad_to_multiple_of": 8, "pad_id": 1, "pad_type_id": 2,
+                                             "pad_token": "a"}), device=-1)
+    assert t.info["truncation"] == 8 and t.info["padding"] == 2 and t.info["pad_id"] == 1 and t.info["pad_type_id"] == 2
+    t = ta.Tokenizer.from_str(_base(WL), device=-1)
+    assert t.info["truncation"] == -1 and t.info["padding"] == 0
 
 
 def _byte_alphabet():

@@ -30,7 +30,7 @@ MAX_STAGES = 24
 SYMBOLS = [
     "tkamd_tokenizer_from_json", "tkamd_tokenizer_free", "tkamd_tokenizer_info", "tkamd_last_error",
     "tkamd_encode_batch", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
-    "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_free",
+    "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_pad_counts", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
@@ -41,12 +41,13 @@ SYMBOLS = [
 class Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "pre_tokenizer", "normalizer", "vocab_size", "n_merges", "add_prefix_space",
-        "ignore_merges", "n_added_tokens", "device", "n_direct_words", "word_disp_entries", "merge_disp_entries")]
+        "ignore_merges", "n_added_tokens", "device", "n_direct_words", "truncation", "padding", "pad_id", "pad_type_id",
+        "word_disp_entries", "merge_disp_entries")]
 
 
 class DeviceResult(C.Structure):
     _fields_ = [("d_ids", C.c_void_p), ("d_tok_offsets", C.c_void_p), ("d_offsets", C.c_void_p),
-                ("d_word_ids", C.c_void_p), ("d_n_tokens", C.c_void_p), ("d_n_pretokens", C.c_void_p)]
+                ("d_word_ids", C.c_void_p), ("d_n_tokens", C.c_void_p), ("d_n_pretokens", C.c_void_p), ("d_pad_counts", C.c_void_p)]
 
 
 class StageTime(C.Structure):
@@ -89,7 +90,7 @@ def load() -> C.CDLL:
     lib.tkamd_encode_batch.argtypes = [vp, vp, vp, i64, u32, C.POINTER(vp)]
     lib.tkamd_encode_batch.restype = i32
     for name, rt in (("tkamd_batch_n_docs", i64), ("tkamd_batch_n_tokens", i64), ("tkamd_batch_ids", vp),
-                     ("tkamd_batch_tok_offsets", vp), ("tkamd_batch_offsets", vp), ("tkamd_batch_word_ids", vp)):
+                     ("tkamd_batch_tok_offsets", vp), ("tkamd_batch_offsets", vp), ("tkamd_batch_word_ids", vp), ("tkamd_batch_pad_counts", vp)):
         f = getattr(lib, name)
         f.argtypes = [vp]
         f.restype = rt

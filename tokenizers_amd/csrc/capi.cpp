@@ -92,6 +92,7 @@ struct tkamd_tokenizer {
     DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie, t_at_blob, t_at_off, t_at_first;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
+    DevBuf w_len1, w_fin, w_fbsum, w_pad_count;   // truncation / padding epilogue
     DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
@@ -158,9 +159,9 @@ static void pinned_put(PinnedBlock b) {
 
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    PinnedBlock ids, tok_offsets, offsets, word_ids;
-    bool has_offsets = false, has_words = false;
-    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); }
+    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts;
+    bool has_offsets = false, has_words = false, has_pads = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); }
 };
 
 struct tkamd_text {
@@ -172,7 +173,7 @@ struct tkamd_text {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_PADMAX = 4 /* uint32 */, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
        SC_COUNTERS = 16 /* uint32[CNT_COUNT] */, SC_SLOTS = 32 };
 
 struct Prof {
@@ -484,13 +485,86 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         if (out->d_word_ids) out->d_word_ids = sa.word_ids2;
         out->d_n_tokens = sa.n_tok2;
     };
+    out->d_pad_counts = nullptr;
+    const bool epilogue = hm.trunc_on || hm.pad_on;
+    auto finalize = [&]() {
+        // truncation -> special tokens -> padding (tokenizer/mod.rs:1265-1317) as one epilogue over the token CSR
+        const uint32_t n_add = add_special ? (uint32_t)(hm.pp_prefix.size() + hm.pp_suffix.size()) : 0u;
+        FinalArgs fa{};
+        fa.tok_offsets = t->w_tok_offsets.as<int64_t>();
+        fa.n_docs = n_docs;
+        fa.ids = t->w_ids.as<uint32_t>();
+        fa.offsets = out->d_offsets;
+        fa.word_ids = out->d_word_ids;
+        fa.prefix = t->t_pp_prefix.as<uint32_t>();
+        fa.suffix = t->t_pp_suffix.as<uint32_t>();
+        fa.n_prefix = add_special ? (int32_t)hm.pp_prefix.size() : 0;
+        fa.n_suffix = add_special ? (int32_t)hm.pp_suffix.size() : 0;
+        // max_length - n_added_tokens when specials are added (mod.rs:1273-1279; the subtraction wraps in the reference's
+        // release build when max_length is smaller: nothing is then truncated)
+        fa.trunc_len = 0xFFFFFFFFu;
+        if (hm.trunc_on) fa.trunc_len = (n_add && hm.trunc_max_length < n_add) ? 0xFFFFFFFFu : hm.trunc_max_length - n_add;
+        fa.trunc_left = hm.trunc_left ? 1u : 0u;
+        fa.trunc_needs_pair = (hm.trunc_on && hm.trunc_strategy == 2) ? 1u : 0u;
+        fa.pad_on = hm.pad_on ? 1u : 0u;
+        fa.pad_fixed = hm.pad_fixed ? 1u : 0u;
+        fa.pad_length = hm.pad_length;
+        fa.pad_multiple = hm.pad_multiple;
+        fa.pad_left = hm.pad_left ? 1u : 0u;
+        fa.pad_id = hm.pad_id;
+        t->w_len1.reserve((size_t)(n_docs + 2) * 4);
+        t->w_fin.reserve((size_t)(n_docs + 2) * 4);
+        t->w_fbsum.reserve((size_t)((n_docs + 1) / 256 + 2) * 4);
+        t->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
+        if (hm.pad_on) t->w_pad_count.reserve((size_t)(n_docs + 2) * 4);
+        fa.len1 = t->w_len1.as<uint32_t>();
+        fa.fin = t->w_fin.as<uint32_t>();
+        fa.bsum = t->w_fbsum.as<uint32_t>();
+        fa.target = (uint32_t*)(sc + SC_PADMAX);
+        fa.tok_offsets2 = t->w_tok_offsets2.as<int64_t>();
+        fa.pad_count = hm.pad_on ? t->w_pad_count.as<uint32_t>() : nullptr;
+        fa.n_tok2 = sc + SC_NTOK2;
+        fa.err = d_err;
+        pf.begin("truncate_pad");
+        launch_final_lens(st, fa);
+        // capacity of the padded arrays: known up front for Fixed; BatchLongest needs the batch maximum (one 4-byte read-back)
+        size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * n_add;
+        if (hm.pad_on) {
+            uint64_t target = hm.pad_length;
+            if (!hm.pad_fixed) {
+                uint32_t mx = 0;
+                HIP_CHECK(hipMemcpyAsync(&mx, fa.target, 4, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                target = mx;
+            }
+            if (hm.pad_multiple > 0 && target % hm.pad_multiple > 0) target += hm.pad_multiple - target % hm.pad_multiple;
+            T2 += (size_t)n_docs * (size_t)target;
+            if ((uint64_t)T2 >= ((uint64_t)1 << 32)) throw Invalid("the padded batch would hold more than 2^32 tokens: pad fewer documents per call");
+        }
+        t->w_ids2.reserve(T2 * 4);
+        if (out->d_offsets) t->w_offsets2.reserve(T2 * 8);
+        if (out->d_word_ids) t->w_word_ids2.reserve(T2 * 4);
+        fa.ids2 = t->w_ids2.as<uint32_t>();
+        fa.offsets2 = t->w_offsets2.as<uint32_t>();
+        fa.word_ids2 = t->w_word_ids2.as<uint32_t>();
+        launch_final_offsets(st, fa);
+        launch_finalize(st, grid, fa);
+        pf.end();
+        out->d_ids = fa.ids2;
+        out->d_tok_offsets = fa.tok_offsets2;
+        if (out->d_offsets) out->d_offsets = fa.offsets2;
+        if (out->d_word_ids) out->d_word_ids = fa.word_ids2;
+        out->d_n_tokens = fa.n_tok2;
+        out->d_pad_counts = fa.pad_count;
+    };
     if (n_bytes == 0) {
         // only empty documents: no tokens, but the post-processor still puts its specials around every one of them
         HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
         if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = t->w_offsets.as<uint32_t>();
         if (want_words) out->d_word_ids = t->w_word_ids.as<uint32_t>();
-        if (add_special) add_specials();
-        t->last_ntok_slot = add_special ? SC_NTOK2 : SC_NTOK;
+        if (epilogue) finalize();
+        else if (add_special) add_specials();
+        t->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -755,8 +829,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         if (a.want_offsets) out->d_offsets = a.offsets;
         if (a.want_words) out->d_word_ids = a.word_ids;
     }
-    if (add_special) add_specials();
-    t->last_ntok_slot = add_special ? SC_NTOK2 : SC_NTOK;
+    if (epilogue) finalize();
+    else if (add_special) add_specials();
+    t->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
     HIP_CHECK(hipGetLastError());
 }
 
@@ -771,7 +846,7 @@ int finish_batch(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_
         tkamd_device_result again{};
         run_pipeline(t, t->last_text, t->last_doc_off, t->last_n_docs, t->last_n_bytes, t->last_flags, st, &again);
         if (again.d_ids != t->last_result.d_ids || again.d_tok_offsets != t->last_result.d_tok_offsets ||
-            again.d_offsets != t->last_result.d_offsets || again.d_word_ids != t->last_result.d_word_ids)
+            again.d_offsets != t->last_result.d_offsets || again.d_word_ids != t->last_result.d_word_ids || again.d_pad_counts != t->last_result.d_pad_counts)
             throw HipError("result buffers moved while a batch was run again");
         bits = read_scalars(t, st, n_tok, n_pretok);
     }
@@ -802,6 +877,7 @@ int error_from_bits(int bits) {
                                                 "survives the Mn filter; NFD may reorder it across characters (not built on the device)");
     if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal invariant violated");
     if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
+    if (bits & ERR_TRUNC_SECOND) return set_error(TKAMD_ERR_INVALID, "Truncation error: Second sequence not provided");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
 }
@@ -878,6 +954,10 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* t, tkamd_info* info) {
     info->n_added_tokens = (int32_t)hm.added_tokens.size();
     info->device = t->device;
     info->n_direct_words = t->n_direct;
+    info->truncation = hm.trunc_on ? (int32_t)hm.trunc_max_length : -1;
+    info->padding = !hm.pad_on ? 0 : (hm.pad_left ? 2 : 1);
+    info->pad_id = (int32_t)hm.pad_id;
+    info->pad_type_id = (int32_t)hm.pad_type_id;
     info->word_disp_entries = (int32_t)hm.word_disp.size();
     info->merge_disp_entries = (int32_t)hm.merge_disp.size();
     return TKAMD_OK;
@@ -958,12 +1038,18 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             b->word_ids = pinned_get((size_t)n_tok * 4);
             if (n_tok) HIP_CHECK(hipMemcpyAsync(b->word_ids.p, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st));
         }
+        if (r.d_pad_counts) {
+            b->has_pads = true;
+            b->pad_counts = pinned_get((size_t)(n_docs + 1) * 4);
+            if (n_docs) HIP_CHECK(hipMemcpyAsync(b->pad_counts.p, r.d_pad_counts, (size_t)n_docs * 4, hipMemcpyDeviceToHost, st));
+        }
         HIP_CHECK(hipStreamSynchronize(st));
         *out = b.release();
         return TKAMD_OK;
     });
 }
 
+const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b) { return (b && b->has_pads) ? (const uint32_t*)b->pad_counts.p : nullptr; }
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_batch_n_tokens(const tkamd_batch* b) { return b ? b->n_tokens : 0; }
 const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? (const uint32_t*)b->ids.p : nullptr; }

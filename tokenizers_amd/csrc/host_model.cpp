@@ -475,11 +475,34 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     HostModel m;
     std::fill(m.byte_id, m.byte_id + 256, 0xFFFFFFFFu);
 
-    // ---- things the hot path does not implement: say so loudly ----
+    // ---- truncation / padding: an epilogue over the finished token CSR (tokenizer/mod.rs:1265-1317) ----
     const JsonValue* trunc = root->get("truncation");
-    if (trunc && !trunc->is_null()) throw Unsupported("truncation is applied by the caller (utils/truncation.rs), not by this path");
+    if (trunc && !trunc->is_null()) {
+        m.trunc_on = true;
+        m.trunc_max_length = (uint32_t)trunc->get_num("max_length", 512);
+        m.trunc_stride = (uint32_t)trunc->get_num("stride", 0);
+        m.trunc_left = trunc->get_str("direction", "Right") == "Left";
+        const std::string st = trunc->get_str("strategy", "LongestFirst");
+        if (st == "LongestFirst") m.trunc_strategy = 0;
+        else if (st == "OnlyFirst") m.trunc_strategy = 1;
+        else if (st == "OnlySecond") m.trunc_strategy = 2;
+        else throw Invalid("tokenizer.json: unknown truncation strategy '" + st + "'");
+    }
     const JsonValue* pad = root->get("padding");
-    if (pad && !pad->is_null()) throw Unsupported("padding is applied by the caller (utils/padding.rs), not by this path");
+    if (pad && !pad->is_null()) {
+        m.pad_on = true;
+        const JsonValue* ps = pad->get("strategy");
+        if (ps && ps->is_object() && ps->get("Fixed")) { m.pad_fixed = true; m.pad_length = (uint32_t)ps->get_num("Fixed", 0); }
+        else if (ps && ps->is_string() && ps->str == "BatchLongest") m.pad_fixed = false;
+        else throw Invalid("tokenizer.json: bad padding strategy");
+        m.pad_left = pad->get_str("direction", "Right") == "Left";
+        const JsonValue* mult = pad->get("pad_to_multiple_of");
+        m.pad_multiple = (mult && mult->is_number()) ? (uint32_t)mult->num : 0u;
+        m.pad_id = (uint32_t)pad->get_num("pad_id", 0);
+        m.pad_type_id = (uint32_t)pad->get_num("pad_type_id", 0);
+        m.pad_token = pad->get_str("pad_token", "[PAD]");
+        if (m.pad_id >= (1u << 24)) throw Unsupported("padding id beyond 2^24");
+    }
 
     // ---- normalizer ----
     const JsonValue* norm = root->get("normalizer");

@@ -65,6 +65,20 @@ struct HostModel {
     std::vector<uint32_t> pp_prefix, pp_suffix;   // special ids before / after sequence A
     std::string pp_unsupported;                    // non-empty: why add_special_tokens cannot be honoured
 
+    // truncation / padding of the finished encodings (utils/truncation.rs:70-160, utils/padding.rs:50-85; tokenizer/mod.rs:1265-1317)
+    bool trunc_on = false;
+    uint32_t trunc_max_length = 0;      // before the post-processor's special tokens are subtracted
+    bool trunc_left = false;            // TruncationDirection::Left keeps the END of the sequence
+    int trunc_strategy = 0;             // 0 LongestFirst, 1 OnlyFirst, 2 OnlySecond (a single sequence then fails when it must be cut)
+    uint32_t trunc_stride = 0;          // only shapes the overflowing pieces, which this path does not materialise
+    bool pad_on = false;
+    bool pad_fixed = false;             // PaddingStrategy::Fixed(pad_length) vs BatchLongest
+    uint32_t pad_length = 0;
+    bool pad_left = false;
+    uint32_t pad_multiple = 0;          // pad_to_multiple_of (0 = off)
+    uint32_t pad_id = 0, pad_type_id = 0;
+    std::string pad_token;
+
     uint32_t vocab_size = 0;            // number of vocab entries
     uint32_t n_merges = 0;
     std::vector<AddedToken> added_tokens;

@@ -111,6 +111,33 @@ struct SpecialArgs {
     int64_t* n_tok2;
 };
 
+// arguments of the truncation / special-token / padding epilogue (k_final_*), passed by value
+struct FinalArgs {
+    const int64_t* tok_offsets;       // token CSR of the plain encodings
+    int64_t n_docs;
+    const uint32_t* ids;
+    const uint32_t* offsets;          // null if not produced
+    const uint32_t* word_ids;         // null if not produced
+    const uint32_t* prefix;           // special ids around every sequence (n_prefix = n_suffix = 0 without add_special_tokens)
+    const uint32_t* suffix;
+    int32_t n_prefix, n_suffix;
+    uint32_t trunc_len;               // tokens of the sequence itself that survive (0xFFFFFFFF: no truncation)
+    uint32_t trunc_left;              // keep the end instead of the beginning
+    uint32_t trunc_needs_pair;        // strategy OnlySecond: a single sequence that must be cut is an error
+    uint32_t pad_on, pad_fixed, pad_length, pad_multiple, pad_left, pad_id;
+    uint32_t* len1;                   // [n_docs] tokens after truncation + specials
+    uint32_t* fin;                    // [n_docs] tokens after padding
+    uint32_t* target;                 // device scalar: longest len1 of the batch
+    uint32_t* bsum;
+    int64_t* tok_offsets2;
+    uint32_t* ids2;
+    uint32_t* offsets2;
+    uint32_t* word_ids2;
+    uint32_t* pad_count;              // [n_docs] padding tokens of each encoding (null without padding)
+    int64_t* n_tok2;
+    int* err;
+};
+
 // error bits accumulated in a device int during a batch
 enum : int {
     ERR_BAD_OFFSETS = 1,          // doc_offsets not a valid CSR over [0, n_bytes]
@@ -119,7 +146,10 @@ enum : int {
     ERR_NON_ASCII_NORM = 8,       // BertNormalizer on non-ASCII text (full-Unicode path not built yet)
     ERR_MISSING_UNK = 16,
     ERR_INTERNAL = 32,            // an internal invariant was violated (bug guard)
-    ERR_QUEUE_FULL = 64,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
+    ERR_QUEUE_FULL = 64,
+    ERR_TRUNC_SECOND = 128,       // truncation strategy OnlySecond on a single sequence that has to be cut (TruncationError::SecondSequenceNotProvided)
+    ERR_TOO_MANY_TOKENS = 256,    // the padded batch has more than 2^32 tokens
+    ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
 
 // indices into the per-batch device counter array
@@ -174,6 +204,10 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
+// truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy
+void launch_final_lens(hipStream_t st, const FinalArgs& a);
+void launch_final_offsets(hipStream_t st, const FinalArgs& a);
+void launch_finalize(hipStream_t st, int grid, const FinalArgs& a);
 void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                         const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
                         unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,

@@ -161,6 +161,19 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
     hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
 }
+void launch_final_lens(hipStream_t st, const FinalArgs& a) {
+    hipLaunchKernelGGL(k_final_lens, dim3(blocks_for(a.n_docs + 1, 256)), dim3(256), 0, st, a);
+}
+void launch_final_offsets(hipStream_t st, const FinalArgs& a) {
+    const unsigned nb = blocks_for(a.n_docs + 1, 256);
+    hipLaunchKernelGGL(k_final_fin, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)a.fin, a.n_docs + 1, a.bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, a.n_tok2);
+    hipLaunchKernelGGL(k_final_down, dim3(nb), dim3(256), 0, st, a);
+}
+void launch_finalize(hipStream_t st, int grid, const FinalArgs& a) {
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, st, a);
+}
 void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                         const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
                         unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,

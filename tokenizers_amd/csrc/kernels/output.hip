@@ -269,3 +269,86 @@ __global__ __launch_bounds__(256) void k_add_specials(SpecialArgs a) {
         }
     }
 }
+
+// =================================================================================================
+// Truncation -> special tokens -> padding of the finished encodings, for a single sequence per document:
+//   truncate_encodings (utils/truncation.rs:70-160) with n_added_tokens taken off max_length (tokenizer/mod.rs:1270-1284),
+//   Encoding::truncate (tokenizer/encoding.rs:307-400; direction Right keeps the beginning, Left the end; the overflowing
+//   pieces are not materialised), PostProcessor::process, pad_encodings (utils/padding.rs:50-85: BatchLongest / Fixed,
+//   pad_to_multiple_of, direction; an encoding already longer than the target is left alone).
+// Three small kernels over the documents: lengths (+ batch maximum), new CSR, copy (one wavefront per document).
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_final_lens(FinalArgs a) {
+    __shared__ uint32_t smax[4];
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t l = 0;
+    if (d < a.n_docs) {
+        const uint64_t n = (uint64_t)(a.tok_offsets[d + 1] - a.tok_offsets[d]);
+        if (n > a.trunc_len && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
+        l = (uint32_t)min(n, (uint64_t)a.trunc_len) + (uint32_t)(a.n_prefix + a.n_suffix);
+        a.len1[d] = l;
+    }
+    if (a.pad_on && !a.pad_fixed) {                         // BatchLongest: one atomic per workgroup
+        uint32_t m = l;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s, 64));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(a.target, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    }
+}
+__device__ __forceinline__ uint32_t final_target(const FinalArgs& a) {
+    uint32_t t = a.pad_fixed ? a.pad_length : *a.target;
+    if (a.pad_multiple > 0 && t % a.pad_multiple > 0) t += a.pad_multiple - t % a.pad_multiple;
+    return t;
+}
+__global__ __launch_bounds__(256) void k_final_fin(FinalArgs a) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d > a.n_docs) return;
+    uint32_t f = 0;
+    if (d < a.n_docs) { f = a.len1[d]; if (a.pad_on) f = max(f, final_target(a)); }
+    a.fin[d] = f;
+}
+__global__ __launch_bounds__(256) void k_final_down(FinalArgs a) {
+    __shared__ uint32_t sm[4];
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t x = (d <= a.n_docs) ? a.fin[d] : 0u;
+    uint32_t tot;
+    const uint32_t ex = a.bsum[blockIdx.x] + block256_excl_scan(x, sm, &tot);
+    if (d <= a.n_docs) a.tok_offsets2[d] = (int64_t)ex;
+}
+__global__ __launch_bounds__(256) void k_finalize(FinalArgs a) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t d = wave; d < a.n_docs; d += n_waves) {
+        const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo;
+        const int64_t n = min(n_all, (int64_t)a.trunc_len);
+        const int64_t src = lo + (a.trunc_left ? n_all - n : 0);
+        const int64_t dst0 = a.tok_offsets2[d], total = a.tok_offsets2[d + 1] - dst0;
+        const int64_t real = n + a.n_prefix + a.n_suffix, pads = total - real;
+        const int64_t body = dst0 + (a.pad_left ? pads : 0);
+        if (lane == 0 && a.pad_count) a.pad_count[d] = (uint32_t)pads;
+        for (int64_t q = lane; q < pads; q += 64) {
+            const int64_t o = a.pad_left ? dst0 + q : body + real + q;
+            a.ids2[o] = a.pad_id;
+            if (a.offsets) { a.offsets2[2 * o] = 0; a.offsets2[2 * o + 1] = 0; }
+            if (a.word_ids) a.word_ids2[o] = 0xFFFFFFFFu;
+        }
+        for (int64_t q = lane; q < a.n_prefix; q += 64) {
+            a.ids2[body + q] = a.prefix[q];
+            if (a.offsets) { a.offsets2[2 * (body + q)] = 0; a.offsets2[2 * (body + q) + 1] = 0; }
+            if (a.word_ids) a.word_ids2[body + q] = 0xFFFFFFFFu;
+        }
+        const int64_t seq = body + a.n_prefix;
+        for (int64_t q = lane; q < n; q += 64) {
+            a.ids2[seq + q] = a.ids[src + q];
+            if (a.offsets) { a.offsets2[2 * (seq + q)] = a.offsets[2 * (src + q)]; a.offsets2[2 * (seq + q) + 1] = a.offsets[2 * (src + q) + 1]; }
+            if (a.word_ids) a.word_ids2[seq + q] = a.word_ids[src + q];
+        }
+        for (int64_t q = lane; q < a.n_suffix; q += 64) {
+            a.ids2[seq + n + q] = a.suffix[q];
+            if (a.offsets) { a.offsets2[2 * (seq + n + q)] = 0; a.offsets2[2 * (seq + n + q) + 1] = 0; }
+            if (a.word_ids) a.word_ids2[seq + n + q] = 0xFFFFFFFFu;
+        }
+    }
+}

@@ -98,16 +98,28 @@ def read_lines(path: str) -> tuple[np.ndarray, np.ndarray]:
 class Encoding:
     """Read-only view of one document of a :class:`BatchEncoding`.
 
-    Field semantics follow ``Encoding`` (tokenizer/encoding.rs:11-31): for this path
-    ``type_ids`` are 0, ``attention_mask`` 1, ``special_tokens_mask`` 0 and nothing overflows.
+    Field semantics follow ``Encoding`` (tokenizer/encoding.rs:11-31).  For a single sequence ``type_ids`` are 0 and
+    ``attention_mask`` 1 on everything but padding; ``special_tokens_mask`` is 1 on the post-processor's special tokens and on
+    padding (Encoding::pad, encoding.rs:405-470).  The ``overflowing`` pieces of a truncation are not materialised.
     """
-    __slots__ = ("_b", "_lo", "_hi")
+    __slots__ = ("_b", "_lo", "_hi", "_i")
 
-    def __init__(self, batch: "BatchEncoding", lo: int, hi: int):
-        self._b, self._lo, self._hi = batch, lo, hi
+    def __init__(self, batch: "BatchEncoding", lo: int, hi: int, i: int = 0):
+        self._b, self._lo, self._hi, self._i = batch, lo, hi, i
 
     def __len__(self) -> int:
         return self._hi - self._lo
+
+    def _layout(self) -> tuple[int, int, int, int]:
+        """(#pads on the left, #prefix specials, #suffix specials, #pads on the right)"""
+        b = self._b
+        p = int(b.pad_counts[self._i]) if b.pad_counts is not None else 0
+        nb, ne = b._specials
+        return (p, nb, ne, 0) if b._pad_left else (0, nb, ne, p)
+
+    def _mask(self, pad, special, token) -> list:
+        pl, nb, ne, pr = self._layout()
+        return [pad] * pl + [special] * nb + [token] * (len(self) - pl - nb - ne - pr) + [special] * ne + [pad] * pr
 
     @property
     def ids(self) -> list[int]:
@@ -115,25 +127,26 @@ class Encoding:
 
     @property
     def type_ids(self) -> list[int]:
-        return [0] * len(self)
+        return self._mask(self._b._pad_type_id, 0, 0)
 
     @property
     def attention_mask(self) -> list[int]:
-        return [1] * len(self)
+        return self._mask(0, 1, 1)
 
     @property
     def special_tokens_mask(self) -> list[int]:
-        n, (nb, ne) = len(self), self._b._specials
-        if not (nb or ne):
-            return [0] * n
-        return [1] * nb + [0] * (n - nb - ne) + [1] * ne
+        return self._mask(1, 1, 0)
 
     @property
     def tokens(self) -> list[str]:
-        if self._b.offsets is None:          # encode_batch_fast: OffsetType::None -> empty strings? no: tokens are kept
-            pass
         v = self._b._id_to_token
-        return [v.get(i, "") for i in self.ids]
+        out = [v.get(i, "") for i in self.ids]
+        pl, _, _, pr = self._layout()
+        if pl or pr:                         # Encoding::pad writes the pad_token string, whatever the pad id maps to
+            out[:pl] = [self._b._pad_token] * pl
+            if pr:
+                out[len(out) - pr:] = [self._b._pad_token] * pr
+        return out
 
     @property
     def offsets(self) -> list[tuple[int, int]]:
@@ -151,8 +164,7 @@ class Encoding:
 
     @property
     def sequence_ids(self) -> list[int | None]:
-        n, (nb, ne) = len(self), self._b._specials
-        return [None] * nb + [0] * (n - nb - ne) + [None] * ne
+        return self._mask(None, None, 0)
 
     @property
     def n_sequences(self) -> int:
@@ -169,13 +181,16 @@ class Encoding:
 class BatchEncoding:
     """CSR result of one encode_batch call: ``ids[tok_offsets[d]:tok_offsets[d+1]]`` is document d."""
 
-    def __init__(self, ids, tok_offsets, offsets, word_ids, id_to_token, specials=(0, 0)):
+    def __init__(self, ids, tok_offsets, offsets, word_ids, id_to_token, specials=(0, 0), pad_counts=None, pad_left=False, pad_type_id=0,
+                 pad_token="[PAD]"):
         self.ids: np.ndarray = ids
         self.tok_offsets: np.ndarray = tok_offsets
         self.offsets = offsets
-        self.word_ids = word_ids            # uint32, 0xFFFFFFFF = None (special tokens)
+        self.word_ids = word_ids            # uint32, 0xFFFFFFFF = None (special tokens, padding)
+        self.pad_counts = pad_counts        # uint32 per document: padding tokens (None without a `padding` section)
         self._id_to_token = id_to_token
         self._specials = specials           # (#prefix, #suffix) special tokens around every document
+        self._pad_left, self._pad_type_id, self._pad_token = pad_left, pad_type_id, pad_token
 
     def __len__(self) -> int:
         return len(self.tok_offsets) - 1
@@ -186,7 +201,7 @@ class BatchEncoding:
             i += n
         if not 0 <= i < n:
             raise IndexError(i)
-        return Encoding(self, int(self.tok_offsets[i]), int(self.tok_offsets[i + 1]))
+        return Encoding(self, int(self.tok_offsets[i]), int(self.tok_offsets[i + 1]), i)
 
     def __iter__(self):
         for i in range(len(self)):
@@ -268,6 +283,7 @@ class Tokenizer:
         self.device = int(device)
         self._json = json_str
         self._vocab_r = None
+        self._pad_token = ((json.loads(json_str).get("padding") or {}).get("pad_token", "[PAD]")) if '"padding"' in json_str else "[PAD]"
         info = _lib.Info()
         _lib.check(lib.tkamd_tokenizer_info(self._h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in _lib.Info._fields_}
@@ -308,6 +324,37 @@ class Tokenizer:
                 r[int(a["id"])] = a["content"]
             self._vocab_r = r
         return self._vocab_r
+
+    # ---- truncation / padding (Tokenizer.enable_truncation / enable_padding, bindings/python/src/tokenizer.rs): the parameters live in
+    # the tokenizer.json sections of the same name, so changing them re-creates the handle from the edited JSON ----
+    def _reload(self, d: dict) -> None:
+        new = Tokenizer(json.dumps(d, ensure_ascii=False), self.device)
+        old_h = self._h
+        self.__dict__.update(new.__dict__)
+        new._h = old_h                      # the temporary object frees the OLD handle when it dies
+
+    def enable_truncation(self, max_length: int, stride: int = 0, strategy: str = "longest_first", direction: str = "right") -> None:
+        d = json.loads(self._json)
+        d["truncation"] = {"direction": direction.capitalize(), "max_length": int(max_length), "stride": int(stride),
+                           "strategy": {"longest_first": "LongestFirst", "only_first": "OnlyFirst", "only_second": "OnlySecond"}[strategy]}
+        self._reload(d)
+
+    def no_truncation(self) -> None:
+        d = json.loads(self._json)
+        d["truncation"] = None
+        self._reload(d)
+
+    def enable_padding(self, direction: str = "right", pad_id: int = 0, pad_type_id: int = 0, pad_token: str = "[PAD]",
+                       length: int | None = None, pad_to_multiple_of: int | None = None) -> None:
+        d = json.loads(self._json)
+        d["padding"] = {"strategy": "BatchLongest" if length is None else {"Fixed": int(length)}, "direction": direction.capitalize(),
+                        "pad_to_multiple_of": pad_to_multiple_of, "pad_id": int(pad_id), "pad_type_id": int(pad_type_id), "pad_token": pad_token}
+        self._reload(d)
+
+    def no_padding(self) -> None:
+        d = json.loads(self._json)
+        d["padding"] = None
+        self._reload(d)
 
     def get_vocab_size(self, with_added_tokens: bool = True) -> int:
         return len(self._id_to_token()) if with_added_tokens else self.info["vocab_size"]
@@ -378,7 +425,12 @@ class Tokenizer:
             offs = view(self._lib.tkamd_batch_offsets(b), C.c_uint32, (nt, 2), np.uint32)
         if word_ids:
             wids = view(self._lib.tkamd_batch_word_ids(b), C.c_uint32, (nt,), np.uint32)
-        return BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0))
+        pads = None
+        pp = self._lib.tkamd_batch_pad_counts(b)
+        if pp:
+            pads = view(pp, C.c_uint32, (n_docs,), np.uint32)
+        return BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0), pads,
+                             self.info["padding"] == 2, self.info["pad_type_id"], self._pad_token)
 
     def encode_file(self, path: str, offsets: str = "none", word_ids: bool = False, add_special_tokens: bool = False) -> BatchEncoding:
         """Encode a newline-delimited UTF-8 file, one document per line *including its terminator* (:func:`read_lines`)."""
