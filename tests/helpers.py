@@ -6,7 +6,7 @@ import os
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SPECIALS_GOLDEN = ["bert_wordpiece_4000_specials", "llama3_small_6000_specials"]
 GOLDEN_NAMES = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "bert_wordpiece_4000",
-                "wordlevel_whitespace_c1", "wordlevel_wssplit"]
+                "wordlevel_whitespace_c1", "wordlevel_wssplit", "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"]
 
 
 def load_tokenizer_json(name: str) -> str:

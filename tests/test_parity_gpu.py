@@ -13,7 +13,8 @@ from tests.helpers import load_tokenizer_json, load_vectors
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
-GPU_GOLDEN = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000"]
+GPU_GOLDEN = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000",
+              "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"]
 
 
 @pytest.fixture(scope="module")
@@ -200,12 +201,16 @@ def test_wordlevel_missing_unk_is_a_model_error():
         tok.encode_batch_fast(["a c"], add_special_tokens=False)
 
 
-def test_added_token_in_text_is_refused():
+def test_special_tokens_in_the_text_behind_bert_normalizer():
+    """[SEP] & co. occurring in the text of a BERT tokenizer: extracted by the raw pass before the normalizer sees the text
+    (added_vocabulary.rs:523-564); golden vectors from the wheel cover ids, char offsets and word ids, the oracle byte offsets."""
     import tokenizers_amd as ta
-    tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=0)
-    assert len(tok.encode_batch_fast(["no specials here [ ] UNK", "[unk]"], add_special_tokens=False)) == 2
-    with pytest.raises(ta.UnsupportedError, match="added/special token"):
-        tok.encode_batch_fast(["fine", "has [SEP] inside"], add_special_tokens=False)
+    js = load_tokenizer_json("bert_wordpiece_4000")
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    docs = ["no specials here [ ] UNK", "[unk]", "fine", "has [SEP] inside", "[CLS] two [MASK] three [SEP]", "[SEP][SEP]", "x[PAD]y", "É [UNK] é", "[SEP]"]
+    docs += [" ".join(w if k % 7 else "[MASK]" for k, w in enumerate(l.split())) for l in synth.gen_lines(4000, text_seed=43) if "[" not in l]
+    _meta_compare(tok, o, docs)
 
 
 def test_llama3_vs_oracle():
@@ -281,7 +286,8 @@ def test_trim_offsets_vs_oracle(gpt2_json):
         _meta_compare(tok, o, docs)
 
 
-@pytest.mark.parametrize("name", ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000"])
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000",
+                                  "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"])
 def test_encode_batch_matches_golden_char_offsets(name):
     """Tokenizer.encode_batch == the wheel's encode_batch (ids, char offsets, word ids) on the committed vectors."""
     import tokenizers_amd as ta
@@ -398,15 +404,37 @@ def test_added_vocabulary_on_device_vs_oracle():
     _meta_compare(tok, o, wdocs)
 
 
-def test_added_vocabulary_overlap_quirk_is_refused():
+@pytest.mark.parametrize("name", ["gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"])
+def test_full_added_vocabulary_vs_oracle(name):
+    """Both matching passes, pieces normalised / prefix-spaced one by one, the overlapping-match quirk after an rstrip token: random
+    soups of the tokens and their near misses, byte and char offsets and word ids against the oracle."""
     import json
+    import random
     import tokenizers_amd as ta
-    d = json.loads(load_tokenizer_json("gpt2_added_tokens"))
-    d["added_tokens"].append({"id": 60000, "content": "  ", "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": False})
-    tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
-    assert len(tok.encode_batch_fast(["fine <|pad|> x"], add_special_tokens=False)) == 1
-    with pytest.raises(ta.UnsupportedError, match="added/special token"):
-        tok.encode_batch_fast(["<|pad|>  x"], add_special_tokens=False)      # the "  " token starts inside the stripped whitespace
+    js = load_tokenizer_json(name)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    random.seed(sum(map(ord, name)))
+    toks = [a["content"] for a in json.loads(js)["added_tokens"]]
+    pieces = toks + [t.lower() for t in toks] + [t.upper() for t in toks] + [t[:-1] for t in toks if len(t) > 1] + \
+        [" ", "  ", "\n", "\t", "a", "ing", "x", "hello", "World", "é", "中", "!", "-", "1"]
+    docs = ["".join(random.choice(pieces) for _ in range(random.randint(1, 12))) for _ in range(30000)] + synth.gen_lines(3000, text_seed=53)
+    if name.startswith("bert"):
+        docs = [d for d in docs if "\u302e" not in d]
+    _meta_compare(tok, o, docs)
+
+
+def test_reference_bench_tokenizer_full_size():
+    """The reference's own GPT-2 bench tokenizer (benches/bpe_benchmark.rs:19-30: prefix space on every piece, "ing" + [ENT]) on a
+    full-size batch, every document against the oracle."""
+    import tokenizers_amd as ta
+    js = load_tokenizer_json("gpt2_bench_added")
+    tok = ta.Tokenizer.from_str(js, device=0)
+    docs = synth.gen_lines(300_000, text_seed=57)
+    docs[::1000] = ["[ENT] " + d for d in docs[::1000]]
+    got = tok.encode_batch_fast(docs, add_special_tokens=False)
+    exp = orc.Oracle(js).encode_batch(docs)
+    assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
 
 
 # ---- decode_batch (SURVEY section 8(f)-4): ids -> text on the device ---------------------------------------------
@@ -492,8 +520,7 @@ def test_tile_pretokenizer_variants_agree():
         "base = synth.gen_lines(3000, text_seed=5) + synth.stress_lines(seed=8, n=1500)\n"
         "for name in ('llama3_small_6000', 'bert_wordpiece_4000', 'wordlevel_whitespace_c1', 'wordlevel_wssplit'):\n"
         "    js = load_tokenizer_json(name)\n"
-        "    # BERT: its added tokens ([UNK] ...) behind a normalizer are refused when they occur in the text\n"
-        "    docs = [d for d in base if d.isascii() and '[' not in d] if name.startswith('bert') else base + _adversarial_docs(6000, 21)\n"
+        "    docs = [d for d in base if d.isascii()] if name.startswith('bert') else base + _adversarial_docs(6000, 21)\n"
         "    got = ta.Tokenizer.from_str(js, device=0).encode_batch_fast(docs, add_special_tokens=False)\n"
         "    exp = orc.Oracle(js).encode_batch(docs)\n"
         "    assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all(), name\n"

@@ -89,7 +89,8 @@ struct tkamd_tokenizer {
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
-    DevBuf t_at_id, t_at_flags, t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie, t_at_blob, t_at_off, t_at_first;
+    DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
+    DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
     // workspace (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count;   // truncation / padding epilogue
@@ -97,7 +98,7 @@ struct tkamd_tokenizer {
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
     DevBuf dw_ids, dw_tok_off, dw_first, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
-    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask,
+    DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask, w_boundmask, w_bprefix, w_seg_off, w_xseg_off,
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off;
@@ -173,7 +174,7 @@ struct tkamd_text {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_PADMAX = 4 /* uint32 */, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_PADMAX = 4 /* uint32 */, SC_NSEG = 5, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
        SC_COUNTERS = 16 /* uint32[CNT_COUNT] */, SC_SLOTS = 32 };
 
 struct Prof {
@@ -238,11 +239,13 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_bn1, hm.bn_stage1);
     upload(t->t_bn2, hm.bn_stage2);
     upload(t->t_bn_map, hm.bn_map);
-    upload(t->t_at_blob, hm.at_blob);
-    upload(t->t_at_off, hm.at_off);
-    upload(t->t_at_first, hm.at_first);
-    upload(t->t_at_id, hm.at_id);
-    upload(t->t_at_flags, hm.at_flags);
+    for (int c = 0; c < 2; ++c) {
+        upload(t->t_at_blob[c], hm.at[c].blob);
+        upload(t->t_at_off[c], hm.at[c].off);
+        upload(t->t_at_first[c], hm.at[c].first);
+        upload(t->t_at_id[c], hm.at[c].id);
+        upload(t->t_at_flags[c], hm.at[c].flags);
+    }
     DevTables& d = t->dt;
     d.uc1 = t->t_uc1.as<uint16_t>();
     d.uc2 = t->t_uc2.as<uint8_t>();
@@ -416,7 +419,14 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const bool prefix_space = hm.byte_level && hm.add_prefix_space;
     // host-side bound of the X text length: +1 per document for the virtual space; BertNormalizer can grow a
     // character (CJK spacing: 3 -> 5 bytes, NFD/lowercase expansions <= 3x) -- 3x the input covers every case
-    const int64_t n_x = (hm.norm == NORM_BERT) ? 3 * n_bytes + 64 : n_bytes + (prefix_space ? n_docs : 0);
+    // added-token matches of a batch: at most one per min_len bytes (the shortest pattern)
+    size_t at_min_len = (size_t)-1;
+    for (int c = 0; c < 2; ++c)
+        for (size_t k = 0; k + 1 < hm.at[c].off.size(); ++k) at_min_len = std::min<size_t>(at_min_len, hm.at[c].off[k + 1] - hm.at[c].off[k]);
+    const bool have_added_tokens = at_min_len != (size_t)-1;
+    const uint32_t mcap = have_added_tokens ? (uint32_t)std::min<size_t>((size_t)n_bytes / std::max<size_t>(at_min_len, 1) + 16, 0x7FFFFFF0u) : 0u;
+    // (a prefix space goes in front of every piece: every document, and what follows every match)
+    const int64_t n_x = (hm.norm == NORM_BERT) ? 3 * n_bytes + 64 : n_bytes + (prefix_space ? n_docs + (int64_t)mcap : 0);
     if (n_x >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
     const bool bpe_path = hm.model == MODEL_BPE && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
     const bool local_pretok = hm.pretok == PT_WHITESPACE || hm.pretok == PT_WHITESPACE_SPLIT || hm.pretok == PT_BERT;
@@ -569,72 +579,164 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         return;
     }
 
-    // ---- added / special tokens (AddedVocabulary::extract_and_normalize runs before everything else) ----
-    const unsigned long long* matchmask = nullptr;
-    if (hm.at_match_on_device) {
-        // the split itself runs on the device: matches become single pre-tokens, their edges hard boundaries
-        const size_t mw = (size_t)(W0 + 2) * 8;
-        DevBuf* masks[5] = {&t->w_candmask, &t->w_matchmask, &t->w_spanmask, &t->w_stopmask, &t->w_hardmask};
-        for (DevBuf* b : masks) { b->reserve(mw); }
-        for (int q = 1; q < 5; ++q) HIP_CHECK(hipMemsetAsync(masks[q]->p, 0, mw, st));
-        t->w_match_docs.reserve((size_t)(n_docs + 1) * 4);
-        t->w_match_list.reserve(((size_t)n_bytes + 4) * 8);
-        AddedArgs aa{t->t_at_blob.as<uint8_t>(), t->t_at_off.as<uint32_t>(), t->t_at_first.as<uint32_t>(), t->t_at_id.as<uint32_t>(),
-                     t->t_at_flags.as<uint32_t>()};
+    // ---- AddedVocabulary::extract_and_normalize (added_vocabulary.rs:523-564) + normalizer + ByteLevel add_prefix_space ----
+    // Three texts at most: the ORIGINAL one, the X text the pre-tokenizer reads (normalised, or shifted behind prefix spaces), and
+    // in between -- with a normalizer -- nothing else: add_prefix_space behind a normalizer is refused above.  Matches are kept as
+    // a list (start, stop, id) that is moved from text to text; the bitmasks are scattered from it in the text they are used in.
+    const HostModel::PatternSet &setA = hm.at[0], &setB = hm.at[1];
+    const bool have_raw = setA.size() > 0, have_norm = setB.size() > 0, have_added = have_raw || have_norm;
+    const ull* matchmask = nullptr;
+    uint32_t* mlist = nullptr;
+    uint32_t* n_match = d_counters + CNT_MATCHES;
+    size_t seg_cap = 0;                                        // bound of the number of pieces between document / match edges
+    int64_t* d_nseg = sc + SC_NSEG;
+    const size_t WX = (size_t)std::max(W0, W) + 2;             // mask words covering either text
+    if (have_added) {
+        seg_cap = (size_t)n_docs + 2 * (size_t)mcap + 2;
+        DevBuf* masks[6] = {&t->w_candmask, &t->w_matchmask, &t->w_spanmask, &t->w_stopmask, &t->w_hardmask, &t->w_boundmask};
+        for (DevBuf* b : masks) b->reserve(WX * 8);
+        t->w_match_docs.reserve((seg_cap + 1) * 4);
+        t->w_match_list.reserve(((size_t)mcap + 4) * 16);
+        mlist = t->w_match_list.as<uint32_t>();
+    }
+    auto args_of = [&](int c) {
+        return AddedArgs{t->t_at_blob[c].as<uint8_t>(), t->t_at_off[c].as<uint32_t>(), t->t_at_first[c].as<uint32_t>(), t->t_at_id[c].as<uint32_t>(),
+                         t->t_at_flags[c].as<uint32_t>()};
+    };
+    auto scatter_masks = [&](int64_t n_text, const int64_t* len_dev, bool with_end) {
+        ull* m4[4] = {t->w_matchmask.as<ull>(), t->w_spanmask.as<ull>(), t->w_stopmask.as<ull>(), t->w_hardmask.as<ull>()};
+        for (ull* m : m4) HIP_CHECK(hipMemsetAsync(m, 0, WX * 8, st));
+        launch_scatter_matches(st, mlist, n_match, n_text, len_dev, m4[0], m4[1], m4[2], m4[3], with_end ? t->w_tmp_end.as<uint32_t>() : nullptr);
+    };
+    // pieces of a text: what lies between document edges and match edges (boundary mask = docmask | hardmask), as an int64 CSR
+    auto build_pieces = [&](const int64_t* doc_csr, int64_t n_text, const int64_t* len_dev) -> const int64_t* {
+        const int64_t Wt = (n_text >> 6) + 1;
+        HIP_CHECK(hipMemsetAsync(t->w_boundmask.p, 0, WX * 8, st));
+        launch_mark_doc_starts_n(st, doc_csr, n_docs, n_text, len_dev, t->w_boundmask.as<ull>(), d_err);
+        launch_mask_or(st, t->w_boundmask.as<ull>(), t->w_hardmask.as<ull>(), Wt);
+        t->w_bprefix.reserve((size_t)(Wt + 2) * 4);
+        t->w_seg_off.reserve((seg_cap + 2) * 8);
+        launch_mask_scan(st, t->w_boundmask.as<ull>(), Wt, t->w_bsum.as<uint32_t>(), t->w_bprefix.as<uint32_t>(), d_nseg);
+        launch_emit_boundaries(st, t->w_boundmask.as<ull>(), t->w_bprefix.as<uint32_t>(), n_text, len_dev, d_nseg, t->w_seg_off.as<int64_t>());
+        return t->w_seg_off.as<int64_t>();
+    };
+
+    if (have_added) HIP_CHECK(hipMemsetAsync(n_match, 0, 4, st));
+    if (have_raw) {
+        // pass 1: the tokens with normalized = false, over the raw documents
         pf.begin("added_token_match");
-        launch_added_match(st, grid, aa, d_text, n_bytes, d_doc_off, n_docs, t->dt.uc1, t->dt.uc2, prefix_space ? 1u : 0u,
-                           t->w_candmask.as<ull>(), t->w_matchmask.as<ull>(), t->w_spanmask.as<ull>(), t->w_stopmask.as<ull>(),
-                           t->w_hardmask.as<ull>(), t->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS,
-                           t->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, d_err);
-        pf.end();
-        matchmask = t->w_matchmask.as<ull>();
-    } else if (hm.at_off.size() > 1) {
-        // behind a normalizer / mixed token classes: detect and refuse
-        pf.begin("added_token_scan");
-        launch_added_token_scan(st, d_text, n_bytes, t->t_at_blob.as<uint8_t>(), t->t_at_off.as<uint32_t>(),
-                                t->t_at_first.as<uint32_t>(), d_err);
+        launch_added_match(st, args_of(0), d_text, n_bytes, nullptr, d_doc_off, n_docs, nullptr, nullptr, t->dt.uc1, t->dt.uc2, t->w_candmask.as<ull>(),
+                           t->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS, mlist, n_match, mcap, MATCH_LEN_ORIG, d_err);
         pf.end();
     }
 
     const uint8_t* x_text = d_text;
     const int64_t* x_doc_off = d_doc_off;
     const int64_t* x_len_dev = nullptr;
+    const uint32_t* norig = nullptr;
+    const uint32_t* norig_e = nullptr;
     if (hm.norm == NORM_BERT || prefix_space) {
         t->w_ntext.reserve((size_t)n_x + TKAMD_TEXT_PAD);
         t->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
         HIP_CHECK(hipMemsetAsync(t->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
+        if (off_mode != TKAMD_OFFSETS_NONE) {
+            t->w_norig.reserve(((size_t)n_x + 4) * 4);
+            t->w_norig_e.reserve(((size_t)n_x + 4) * 4);
+            norig = t->w_norig.as<uint32_t>();
+            norig_e = t->w_norig_e.as<uint32_t>();
+        }
+    }
+    if (hm.norm == NORM_BERT) {
+        // ---- BertNormalizer: text -> normalised text + original byte range of every normalised byte; the matches of pass 1 are
+        // not text (their split carries the raw slice): copied verbatim ----
+        t->w_keepmask.reserve((size_t)n_bytes + 64);            // olen: output bytes per source byte
+        t->w_kprefix.reserve((size_t)(W0 + 1) * 4);             // wsum
+        t->w_wbase.reserve((size_t)(W0 + 1) * 4);
+        BnTables bt{t->t_bn1.as<uint16_t>(), t->t_bn2.as<uint8_t>(), t->t_bn_map.as<MergeSlot>(), hm.bn_mask, hm.bn_seed,
+                    hm.bn_clean_text, hm.bn_handle_chinese, hm.bn_strip_accents, hm.bn_lowercase};
+        const ull* verbatim = nullptr;
+        if (have_raw) {
+            scatter_masks(n_bytes, nullptr, false);
+            launch_mask_or2(st, t->w_boundmask.as<ull>(), t->w_matchmask.as<ull>(), t->w_spanmask.as<ull>(), W0 + 1);
+            verbatim = t->w_boundmask.as<ull>();
+        }
+        pf.begin("bert_normalize");
+        launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, verbatim, t->w_keepmask.as<uint8_t>(), t->w_kprefix.as<uint32_t>(),
+                              t->w_bsum.as<uint32_t>(), t->w_wbase.as<uint32_t>(), d_xlen, t->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e,
+                              t->w_ndoc_off.as<int64_t>(), d_err);
+        pf.end();
+        if (have_raw) launch_translate_matches_norm(st, mlist, n_match, t->w_keepmask.as<uint8_t>(), t->w_wbase.as<uint32_t>(), n_bytes, d_xlen);
         x_text = t->w_ntext.as<uint8_t>();
         x_doc_off = t->w_ndoc_off.as<int64_t>();
         x_len_dev = d_xlen;
     }
-    if (hm.norm == NORM_BERT) {
-        // ---- BertNormalizer: text -> normalised text + original byte range of every normalised byte ----
-        t->w_keepmask.reserve((size_t)n_bytes + 64);            // olen: output bytes per source byte
-        t->w_kprefix.reserve((size_t)(W0 + 1) * 4);             // wsum
-        t->w_wbase.reserve((size_t)(W0 + 1) * 4);
-        t->w_norig.reserve(((size_t)n_x + 4) * 4);
-        t->w_norig_e.reserve(((size_t)n_x + 4) * 4);
-        BnTables bt{t->t_bn1.as<uint16_t>(), t->t_bn2.as<uint8_t>(), t->t_bn_map.as<MergeSlot>(), hm.bn_mask, hm.bn_seed,
-                    hm.bn_clean_text, hm.bn_handle_chinese, hm.bn_strip_accents, hm.bn_lowercase};
-        pf.begin("bert_normalize");
-        launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, t->w_keepmask.as<uint8_t>(), t->w_kprefix.as<uint32_t>(),
-                              t->w_bsum.as<uint32_t>(), t->w_wbase.as<uint32_t>(), d_xlen, t->w_ntext.as<uint8_t>(),
-                              (off_mode != TKAMD_OFFSETS_NONE) ? t->w_norig.as<uint32_t>() : nullptr,
-                              (off_mode != TKAMD_OFFSETS_NONE) ? t->w_norig_e.as<uint32_t>() : nullptr, t->w_ndoc_off.as<int64_t>(), d_err);
+    // n_in / len_in: the text the second pass (and the prefix-space copy) reads
+    const int64_t n_in = hm.norm == NORM_BERT ? n_x : n_bytes;
+    if (have_norm) {
+        // pass 2: the tokens with normalized = true, by their normalised patterns, over every piece pass 1 left (the whole documents
+        // when it found nothing or there is no such token)
+        const int64_t* seg = x_doc_off;
+        const int64_t* nseg_dev = nullptr;
+        int64_t nseg_bound = n_docs;
+        if (have_raw) {
+            scatter_masks(n_in, x_len_dev, false);
+            seg = build_pieces(x_doc_off, n_in, x_len_dev);
+            nseg_dev = d_nseg;
+            nseg_bound = (int64_t)seg_cap;
+        }
+        pf.begin("added_token_match2");
+        launch_added_match(st, args_of(1), x_text, n_in, x_len_dev, seg, nseg_bound, nseg_dev, have_raw ? t->w_matchmask.as<ull>() : nullptr, t->dt.uc1, t->dt.uc2,
+                           t->w_candmask.as<ull>(), t->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS2, mlist, n_match, mcap,
+                           hm.norm == NORM_NONE ? MATCH_LEN_ORIG : 0u, d_err);
         pf.end();
-    } else if (prefix_space) {
-        // ---- ByteLevel add_prefix_space: documents shifted behind their virtual leading space ----
-        t->w_need.reserve((size_t)(n_docs + 2) * 4);
-        t->w_need_bsum.reserve((size_t)((n_docs + 1) / 256 + 2) * 4);
+    }
+    if (have_added && !prefix_space) {
+        scatter_masks(n_in, x_len_dev, off_mode != TKAMD_OFFSETS_NONE);
+        matchmask = t->w_matchmask.as<ull>();
+    }
+    const int64_t* piece_off = nullptr;                        // sentence CSR for the Llama-3 sequential matcher when matches cut the documents
+    const int64_t* piece_n_dev = nullptr;
+    if (prefix_space) {
+        // ---- ByteLevel add_prefix_space: every piece shifted behind its virtual leading space (byte_level.rs:120-125) ----
+        const int64_t* seg = d_doc_off;
+        const int64_t* nseg_dev = nullptr;
+        int64_t nseg_bound = n_docs;
+        if (have_added) {
+            scatter_masks(n_bytes, nullptr, false);
+            seg = build_pieces(d_doc_off, n_bytes, nullptr);
+            nseg_dev = d_nseg;
+            nseg_bound = (int64_t)seg_cap;
+            t->w_xseg_off.reserve((seg_cap + 2) * 8);
+        }
+        t->w_need.reserve((size_t)(nseg_bound + 2) * 4);
+        t->w_need_bsum.reserve((size_t)((nseg_bound + 1) / 256 + 2) * 4);
+        int64_t* xseg = have_added ? t->w_xseg_off.as<int64_t>() : t->w_ndoc_off.as<int64_t>();
         pf.begin("prefix_space");
-        launch_prefix_space(st, d_text, d_doc_off, n_docs, t->w_need.as<uint32_t>(), t->w_need_bsum.as<uint32_t>(),
-                            t->w_ndoc_off.as<int64_t>(), d_xlen, t->w_ntext.as<uint8_t>(), grid);
+        launch_prefix_space(st, d_text, seg, nseg_bound, nseg_dev, have_added ? t->w_matchmask.as<ull>() : nullptr, t->w_need.as<uint32_t>(),
+                            t->w_need_bsum.as<uint32_t>(), xseg, d_xlen, t->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e, grid);
+        if (have_added) {
+            // documents and matches in the shifted text: both start at piece boundaries
+            launch_prefix_doc_csr(st, d_doc_off, n_docs, t->w_boundmask.as<ull>(), t->w_bprefix.as<uint32_t>(), n_bytes, nullptr, d_nseg, xseg, t->w_ndoc_off.as<int64_t>());
+            launch_translate_matches_prefix(st, mlist, n_match, t->w_boundmask.as<ull>(), t->w_bprefix.as<uint32_t>(), n_bytes, nullptr, d_nseg, xseg);
+        }
         pf.end();
+        x_text = t->w_ntext.as<uint8_t>();
+        x_doc_off = t->w_ndoc_off.as<int64_t>();
+        x_len_dev = d_xlen;
+        if (have_added) {
+            scatter_masks(n_x, x_len_dev, off_mode != TKAMD_OFFSETS_NONE);
+            matchmask = t->w_matchmask.as<ull>();
+            piece_off = xseg;
+            piece_n_dev = d_nseg;
+        }
+    } else if (have_added && hm.pretok == PT_LLAMA3) {
+        piece_off = build_pieces(x_doc_off, n_in, x_len_dev);
+        piece_n_dev = d_nseg;
     }
 
     pf.begin("mark_doc_starts");
     launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_x, x_len_dev, t->w_docmask.as<ull>(), d_err);
-    if (matchmask && !prefix_space) launch_mask_or(st, t->w_docmask.as<ull>(), t->w_hardmask.as<ull>(), W0);   // match edges are hard boundaries
+    if (matchmask) launch_mask_or(st, t->w_docmask.as<ull>(), t->w_hardmask.as<ull>(), W);   // match edges are hard boundaries
     pf.end();
 
     uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
@@ -656,8 +758,10 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         t->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
         t->w_slow_docs.reserve((size_t)(n_docs + 1) * 4);
         pf.begin("pretok_llama3");
+        t->w_slow_docs.reserve((size_t)((piece_off ? seg_cap : (size_t)n_docs) + 1) * 4);
         launch_pretok_llama3(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(),
-                             t->w_endmask.as<ull>(), x_doc_off, n_docs, t->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
+                             t->w_endmask.as<ull>(), piece_off ? piece_off : x_doc_off, piece_off ? (int64_t)seg_cap : n_docs, piece_n_dev,
+                             t->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
         pf.end();
     } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
         // ByteLevel(use_regex=false): every document is one pre-token (byte_level.rs:128-130)
@@ -674,9 +778,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
                             t->w_startmask.as<ull>(), t->w_endmask.as<ull>());
         pf.end();
     }
-    if (matchmask && !prefix_space)
+    if (matchmask)
         launch_apply_matches(st, t->w_startmask.as<ull>(), has_end ? t->w_endmask.as<ull>() : nullptr, matchmask, t->w_spanmask.as<ull>(),
-                             t->w_stopmask.as<ull>(), W0);
+                             t->w_stopmask.as<ull>(), W);
     pf.begin("mask_scan");
     launch_mask_scan(st, t->w_startmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
@@ -773,7 +877,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             launch_wordpiece(st, c == 0 ? grid : t->n_cu, t->dt, x_text, plan.v[c], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
         pf.end();
     }
-    if (matchmask && !prefix_space)
+    if (matchmask)
         launch_apply_match_ids(st, t->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, t->w_startmask.as<ull>(),
                                t->w_wprefix.as<uint32_t>(), t->w_tok0.as<uint32_t>());
     pf.begin("compact");
@@ -789,6 +893,7 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     if (want_meta) {
         MetaArgs a{};
         a.x_text = x_text;
+        a.text = d_text;
         a.pt_start = t->w_pt_start.as<uint32_t>();
         a.pt_end = pt_end;
         a.n_tok = d_ntok_total;
@@ -799,16 +904,15 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         a.n_docs = n_docs;
         a.x_doc_off = x_doc_off;
         a.doc_off = d_doc_off;
-        a.norig = (hm.norm == NORM_BERT) ? t->w_norig.as<uint32_t>() : nullptr;
-        a.norig_e = (hm.norm == NORM_BERT) ? t->w_norig_e.as<uint32_t>() : nullptr;
+        a.norig = norig;                                   // normalised / shifted text: every byte's original byte range
+        a.norig_e = norig_e;
         a.byte_level = hm.byte_level;
         a.trim_offsets = hm.byte_level && hm.trim_offsets;
         a.pp_add_prefix_space = hm.pp_add_prefix_space;
         a.want_offsets = off_mode != TKAMD_OFFSETS_NONE;
         a.char_mode = off_mode == TKAMD_OFFSETS_CHAR;
         a.want_words = want_words;
-        a.prefix_space = prefix_space;
-        a.matchmask = (matchmask && !prefix_space) ? matchmask : nullptr;
+        a.matchmask = matchmask;
         a.uc1 = t->dt.uc1;
         a.uc2 = t->dt.uc2;
         a.offsets = t->w_offsets.as<uint32_t>();
@@ -868,10 +972,6 @@ int error_from_bits(int bits) {
     if (bits & ERR_BAD_OFFSETS) return set_error(TKAMD_ERR_INVALID, "doc_offsets is not a monotone CSR over [0, n_bytes]");
     if (bits & ERR_PRETOKEN_TOO_LONG)
         return set_error(TKAMD_ERR_UNSUPPORTED, "pre-tokens longer than 8192 bytes exceed the 1 GiB scratch slab of the global-memory merge path");
-    if (bits & ERR_ADDED_TOKEN)
-        return set_error(TKAMD_ERR_UNSUPPORTED, "an added/special token occurs in the input text in a combination the device split does not "
-                                                "cover (behind a normalizer, mixed normalized / raw token classes, add_prefix_space, or the "
-                                                "reference's overlapping-match quirk after an rstrip token; added_vocabulary.rs:430-564)");
     if (bits & ERR_NON_ASCII_NORM)
         return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: the text contains a character with a non-zero combining class that "
                                                 "survives the Mn filter; NFD may reorder it across characters (not built on the device)");
@@ -1206,46 +1306,9 @@ int tkamd_probe_bert_norm(const tkamd_tokenizer* t, uint32_t cp, uint32_t* out, 
     if (!t || !out || !n || !refused) return set_error(TKAMD_ERR_INVALID, "bad argument");
     const HostModel& hm = t->hm;
     if (hm.norm != NORM_BERT) return set_error(TKAMD_ERR_UNSUPPORTED, "the tokenizer has no BertNormalizer");
-    constexpr uint32_t DROP = 1, WS = 2, CJK = 4, REORDER = 8, D = 16, LC = 32;     // bert_norm_tables.inc flag bits
-    auto flags = [&](uint32_t c) -> uint32_t {
-        return c >= 0x110000u ? 0u : hm.bn_stage2[((uint32_t)hm.bn_stage1[c >> 8] << 8) | (c & 255u)];
-    };
-    auto lookup = [&](uint32_t c, uint32_t kind, uint32_t* o) -> int {
-        const MergeSlot& x = hm.bn_map[merge_hash1(c, kind, hm.bn_seed) & hm.bn_mask];
-        const MergeSlot& y = hm.bn_map[merge_hash2(c, kind, hm.bn_seed) & hm.bn_mask];
-        const MergeSlot* hit = (x.a == c && x.b == kind) ? &x : (y.a == c && y.b == kind) ? &y : nullptr;
-        if (!hit) { o[0] = c; return 1; }
-        const unsigned long long v = ((unsigned long long)hit->new_id << 32) | hit->rank;
-        int k = 0;
-        const uint32_t a = (uint32_t)(v & 0x1FFFFFu), c1 = (uint32_t)((v >> 21) & 0x1FFFFFu), c2 = (uint32_t)((v >> 42) & 0x1FFFFFu);
-        if (a != 0x1FFFFFu) o[k++] = a;
-        if (c1 != 0x1FFFFFu) o[k++] = c1;
-        if (c2 != 0x1FFFFFu) o[k++] = c2;
-        return k;
-    };
-    *n = 0;
-    *refused = 0;
-    uint32_t f = flags(cp);
-    if (hm.bn_clean_text) {
-        if (f & DROP) return TKAMD_OK;
-        if (f & WS) { cp = ' '; f = 0; }
-    }
-    int k = 0;
-    const bool cjk = hm.bn_handle_chinese && (f & CJK);
-    if (cjk) out[k++] = ' ';
-    uint32_t seq[3] = {cp, 0, 0};
-    int n1 = 1;
-    if (hm.bn_strip_accents) {
-        if (f & REORDER) *refused = 1;
-        if (f & D) n1 = lookup(cp, 0, seq);
-    }
-    for (int q = 0; q < n1; ++q) {
-        const uint32_t y = seq[q];
-        if (hm.bn_lowercase && (flags(y) & LC)) k += lookup(y, 1, out + k);
-        else out[k++] = y;
-    }
-    if (cjk) out[k++] = ' ';
-    *n = k;
+    int r = 0;
+    *n = hm.bn_expand_cp(cp, out, &r);
+    *refused = r;
     return TKAMD_OK;
 }
 

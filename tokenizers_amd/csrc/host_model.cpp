@@ -595,35 +595,6 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         }
     }
 
-    {
-        struct Pat { std::string s; uint32_t id, flags; };
-        std::vector<Pat> pats;
-        bool any_norm = false, any_raw = false;
-        for (const AddedToken& a : m.added_tokens) {
-            if (a.content.empty()) continue;
-            if (a.normalized && m.norm != NORM_NONE)
-                throw Unsupported("added token '" + a.content + "' with normalized=true behind a normalizer (added_vocabulary.rs:548-553)");
-            (a.normalized ? any_norm : any_raw) = true;
-            pats.push_back(Pat{a.content, a.id, (a.single_word ? 1u : 0u) | (a.lstrip ? 2u : 0u) | (a.rstrip ? 4u : 0u)});
-        }
-        std::sort(pats.begin(), pats.end(), [](const Pat& x, const Pat& y) { return x.s < y.s; });
-        pats.erase(std::unique(pats.begin(), pats.end(), [](const Pat& x, const Pat& y) { return x.s == y.s; }), pats.end());
-        m.at_first.assign(257, 0);
-        m.at_off.push_back(0);
-        for (const Pat& p : pats) {
-            m.at_first[(uint8_t)p.s[0] + 1]++;
-            m.at_blob.insert(m.at_blob.end(), p.s.begin(), p.s.end());
-            m.at_off.push_back((uint32_t)m.at_blob.size());
-            m.at_id.push_back(p.id);
-            m.at_flags.push_back(p.flags);
-        }
-        for (int b = 0; b < 256; ++b) m.at_first[b + 1] += m.at_first[b];
-        // Without a normalizer the two matching passes of extract_and_normalize (added_vocabulary.rs:531-553) see the
-        // same text; with a single token class they are one leftmost-longest pass, which the device runs.  Mixed
-        // classes (pass 1 takes priority over pass 2) and tokens behind a normalizer are detected-and-refused instead.
-        m.at_match_on_device = !pats.empty() && m.norm == NORM_NONE && !(any_norm && any_raw);
-    }
-
     // ---- model ----
     const JsonValue* model = root->get("model");
     if (!model || !model->is_object()) throw Invalid("tokenizer.json: missing model");
@@ -790,7 +761,109 @@ HostModel HostModel::from_json(const char* json, size_t len) {
 
     build_unicode(m);
     if (m.norm == NORM_BERT) build_bert_norm(m);
+
+    // ---- AddedVocabulary pattern sets (needs the normalizer tables: normalized tokens match by their normalized form) ----
+    {
+        struct Pat { std::string s; uint32_t id, flags; };
+        std::vector<Pat> pats[2];
+        for (const AddedToken& a : m.added_tokens) {
+            if (a.content.empty()) continue;                       // add_tokens ignores empty contents (added_vocabulary.rs:288-291)
+            std::string pat = a.content;
+            if (a.normalized && m.norm == NORM_BERT) {
+                bool refused = false;
+                pat = m.bert_normalize(a.content, &refused);
+                if (refused) throw Unsupported("added token '" + a.content + "' holds a character whose NFD reordering is context dependent");
+                if (pat.empty()) continue;                         // normalizes to nothing: the automaton has nothing to match
+            }
+            pats[a.normalized ? 1 : 0].push_back(Pat{pat, a.id, (a.single_word ? 1u : 0u) | (a.lstrip ? 2u : 0u) | (a.rstrip ? 4u : 0u)});
+        }
+        for (int c = 0; c < 2; ++c) {
+            std::vector<Pat>& ps = pats[c];
+            // equal patterns: the automaton keeps one value per pattern; the token registered last wins like a map insert
+            std::stable_sort(ps.begin(), ps.end(), [](const Pat& x, const Pat& y) { return x.s < y.s; });
+            std::vector<Pat> uniq;
+            for (const Pat& p : ps) { if (!uniq.empty() && uniq.back().s == p.s) uniq.back() = p; else uniq.push_back(p); }
+            PatternSet& S = m.at[c];
+            S.first.assign(257, 0);
+            S.off.push_back(0);
+            for (const Pat& p : uniq) {
+                S.first[(uint8_t)p.s[0] + 1]++;
+                S.blob.insert(S.blob.end(), p.s.begin(), p.s.end());
+                S.off.push_back((uint32_t)S.blob.size());
+                S.id.push_back(p.id);
+                S.flags.push_back(p.flags);
+            }
+            for (int b = 0; b < 256; ++b) S.first[b + 1] += S.first[b];
+        }
+    }
     return m;
+}
+
+int HostModel::bn_expand_cp(uint32_t cp, uint32_t* out, int* refused) const {
+    constexpr uint32_t DROP = 1, WS = 2, CJK = 4, REORDER = 8, D = 16, LC = 32;     // bert_norm_tables.inc flag bits
+    auto flags = [&](uint32_t c) -> uint32_t { return c >= 0x110000u ? 0u : bn_stage2[((uint32_t)bn_stage1[c >> 8] << 8) | (c & 255u)]; };
+    auto lookup = [&](uint32_t c, uint32_t kind, uint32_t* o) -> int {
+        const MergeSlot& x = bn_map[merge_hash1(c, kind, bn_seed) & bn_mask];
+        const MergeSlot& y = bn_map[merge_hash2(c, kind, bn_seed) & bn_mask];
+        const MergeSlot* hit = (x.a == c && x.b == kind) ? &x : (y.a == c && y.b == kind) ? &y : nullptr;
+        if (!hit) { o[0] = c; return 1; }
+        const unsigned long long v = ((unsigned long long)hit->new_id << 32) | hit->rank;
+        int k = 0;
+        const uint32_t a = (uint32_t)(v & 0x1FFFFFu), c1 = (uint32_t)((v >> 21) & 0x1FFFFFu), c2 = (uint32_t)((v >> 42) & 0x1FFFFFu);
+        if (a != 0x1FFFFFu) o[k++] = a;
+        if (c1 != 0x1FFFFFu) o[k++] = c1;
+        if (c2 != 0x1FFFFFu) o[k++] = c2;
+        return k;
+    };
+    *refused = 0;
+    uint32_t f = flags(cp);
+    if (bn_clean_text) {
+        if (f & DROP) return 0;
+        if (f & WS) { cp = ' '; f = 0; }
+    }
+    int k = 0;
+    const bool cjk = bn_handle_chinese && (f & CJK);
+    if (cjk) out[k++] = ' ';
+    uint32_t seq[3] = {cp, 0, 0};
+    int n1 = 1;
+    if (bn_strip_accents) {
+        if (f & REORDER) *refused = 1;
+        if (f & D) n1 = lookup(cp, 0, seq);
+    }
+    for (int q = 0; q < n1; ++q) {
+        const uint32_t y = seq[q];
+        if (bn_lowercase && (flags(y) & LC)) k += lookup(y, 1, out + k);
+        else out[k++] = y;
+    }
+    if (cjk) out[k++] = ' ';
+    return k;
+}
+
+std::string HostModel::bert_normalize(const std::string& s, bool* refused) const {
+    std::string out;
+    size_t i = 0;
+    while (i < s.size()) {
+        const uint8_t b0 = (uint8_t)s[i];
+        uint32_t cp, len;
+        auto cb = [&](size_t k) -> uint32_t { return i + k < s.size() ? ((uint8_t)s[i + k] & 0x3Fu) : 0u; };
+        if (b0 < 0x80u) { cp = b0; len = 1; }
+        else if (b0 < 0xE0u) { cp = ((b0 & 0x1Fu) << 6) | cb(1); len = 2; }
+        else if (b0 < 0xF0u) { cp = ((b0 & 0x0Fu) << 12) | (cb(1) << 6) | cb(2); len = 3; }
+        else { cp = ((b0 & 0x07u) << 18) | (cb(1) << 12) | (cb(2) << 6) | cb(3); len = 4; }
+        i += len;
+        uint32_t o[12];
+        int r = 0;
+        const int n = bn_expand_cp(cp, o, &r);
+        if (r && refused) *refused = true;
+        for (int q = 0; q < n; ++q) {
+            const uint32_t c = o[q];
+            if (c < 0x80u) out.push_back((char)c);
+            else if (c < 0x800u) { out.push_back((char)(0xC0u | (c >> 6))); out.push_back((char)(0x80u | (c & 0x3Fu))); }
+            else if (c < 0x10000u) { out.push_back((char)(0xE0u | (c >> 12))); out.push_back((char)(0x80u | ((c >> 6) & 0x3Fu))); out.push_back((char)(0x80u | (c & 0x3Fu))); }
+            else { out.push_back((char)(0xF0u | (c >> 18))); out.push_back((char)(0x80u | ((c >> 12) & 0x3Fu))); out.push_back((char)(0x80u | ((c >> 6) & 0x3Fu))); out.push_back((char)(0x80u | (c & 0x3Fu))); }
+        }
+    }
+    return out;
 }
 
 }  // namespace tkamd

@@ -82,13 +82,22 @@ struct HostModel {
     uint32_t vocab_size = 0;            // number of vocab entries
     uint32_t n_merges = 0;
     std::vector<AddedToken> added_tokens;
-    // added-token contents sorted by first byte (device-side occurrence scan)
-    std::vector<uint8_t> at_blob;
-    std::vector<uint32_t> at_off;      // [n_patterns+1]
-    std::vector<uint32_t> at_first;    // [257] CSR over the first byte
-    std::vector<uint32_t> at_id;       // [n_patterns] token id
-    std::vector<uint32_t> at_flags;    // [n_patterns] 1 single_word, 2 lstrip, 4 rstrip
-    bool at_match_on_device = false;   // the AddedVocabulary split runs on the device (no normalizer, one token class)
+    // AddedVocabulary patterns (added_vocabulary.rs:370-414), one set per matching pass of extract_and_normalize (:523-564):
+    // [0] normalized = false, matched by their content on the raw text; [1] normalized = true, matched by the NORMALIZED form of
+    // their content on the normalized pieces between the matches of pass 1.  Sorted, CSR over the first byte.
+    struct PatternSet {
+        std::vector<uint8_t> blob;
+        std::vector<uint32_t> off;      // [n_patterns+1]
+        std::vector<uint32_t> first;    // [257] CSR over the first byte
+        std::vector<uint32_t> id;       // [n_patterns] token id
+        std::vector<uint32_t> flags;    // [n_patterns] 1 single_word, 2 lstrip, 4 rstrip
+        size_t size() const { return id.size(); }
+    };
+    PatternSet at[2];
+    // BertNormalizer::normalize (normalizers/bert.rs:92-138) of one code point / a string from the generated tables (host side:
+    // pattern normalization at load, tkamd_probe_bert_norm); *refused = a character whose NFD reordering is context dependent
+    int bn_expand_cp(uint32_t cp, uint32_t* out, int* refused) const;
+    std::string bert_normalize(const std::string& s, bool* refused) const;
 
     // ---- tables copied to the device ----
     uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level)

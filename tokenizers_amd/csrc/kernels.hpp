@@ -62,6 +62,7 @@ struct QueuePlan {
 // arguments of k_token_meta (offsets / word ids), passed by value
 struct MetaArgs {
     const uint8_t* x_text;            // text the pre-tokenizer saw (normalised if a normalizer ran)
+    const uint8_t* text;              // the original text
     const uint32_t* pt_start;
     const uint32_t* pt_end;           // null: pt_start[p+1]
     const int64_t* n_tok;             // total token count (device scalar)
@@ -77,7 +78,6 @@ struct MetaArgs {
     const unsigned long long* leadmask;   // char mode: lead-byte bitmask of the original text + its prefix
     const uint32_t* lprefix;
     uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
-    uint32_t prefix_space;            // x text carries inserted leading spaces (ByteLevel add_prefix_space)
     const unsigned long long* matchmask;  // added-token matches (their offsets trim real whitespace chars), or null
     const uint16_t* uc1;
     const uint8_t* uc2;
@@ -153,8 +153,10 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_COUNT = 12 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_MATCH_DOCS2 = 10,
+              CNT_COUNT = 12 };
 
+constexpr uint32_t MATCH_LEN_ORIG = 0x80000000u;    // added-token match list, word 3: the length counts bytes of the ORIGINAL text
 constexpr int TEXT_PAD = 64;        // = TKAMD_TEXT_PAD (include/tokenizers_amd.h): readable bytes past the end of every text buffer
 constexpr int LONG_PT_MAX = 8192;  // symbols per pre-token on the workgroup path (LDS resident); longer ones use the global-scratch kernel
 
@@ -168,8 +170,8 @@ void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_
                       int64_t* total);
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start);
-void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc_off, int64_t n_docs, uint32_t* need, uint32_t* bsum,
-                         int64_t* xdoc_off, int64_t* x_len, uint8_t* xtext, int grid);
+void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
+                         uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
                              const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
 // whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
@@ -189,18 +191,16 @@ void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t 
 void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
                             const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end);
 void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
-                           uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
-                           uint32_t* noe, int64_t* ndoc_off, int* err);
+                           const unsigned long long* verbatim, uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext,
+                           uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err);
 // whole-word vocabulary hits of QUEUED pre-tokens longer than 16 bytes (ignore_merges, WordLevel): a hit becomes the result row and
 // the queue entry is retired (length 0) so that the model kernels skip it
 void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err);
 void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err);
-void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
-                             const uint32_t* first_idx, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
-                          const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs);
+                          const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
@@ -208,10 +208,19 @@ void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 void launch_final_lens(hipStream_t st, const FinalArgs& a);
 void launch_final_offsets(hipStream_t st, const FinalArgs& a);
 void launch_finalize(hipStream_t st, int grid, const FinalArgs& a);
-void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
-                        const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
-                        unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,
-                        uint32_t* docs, uint32_t* n_docs_listed, uint32_t* match_list, uint32_t* n_match, int* err);
+// AddedVocabulary (kernels/documents.hip): one matching pass over a sentence CSR, list -> masks, list coordinate changes
+void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
+                        const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
+                        uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err);
+void launch_scatter_matches(hipStream_t st, const uint32_t* list, const uint32_t* n_list, int64_t n_bytes, const int64_t* len_dev, unsigned long long* matchmask,
+                            unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end);
+void launch_mask_or2(hipStream_t st, unsigned long long* dst, const unsigned long long* a, const unsigned long long* b, int64_t n_words);
+void launch_emit_boundaries(hipStream_t st, const unsigned long long* mask, const uint32_t* wprefix, int64_t n_bytes, const int64_t* len_dev, const int64_t* total, int64_t* out);
+void launch_translate_matches_norm(hipStream_t st, uint32_t* list, const uint32_t* n_list, const uint8_t* olen, const uint32_t* wbase, int64_t n_bytes, const int64_t* x_len);
+void launch_translate_matches_prefix(hipStream_t st, uint32_t* list, const uint32_t* n_list, const unsigned long long* bmask, const uint32_t* wprefix, int64_t n_bytes,
+                                     const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off);
+void launch_prefix_doc_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, const unsigned long long* bmask, const uint32_t* wprefix, int64_t n_bytes,
+                           const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off, int64_t* xdoc_off);
 void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words);
 void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
                           const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words);

@@ -60,13 +60,16 @@ __device__ __forceinline__ int bn_expand(const BnTables& b, uint32_t cp, uint32_
 }
 __device__ __forceinline__ uint32_t utf8_len_cp(uint32_t cp) { return cp < 0x80u ? 1u : cp < 0x800u ? 2u : cp < 0x10000u ? 3u : 4u; }
 
-__global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes,
+// `verbatim`: bytes of added-token matches of the raw pass (null: none) -- not text for the normalizer: copied as they are
+__global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
                                                   uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t ob = 0;
     if (i < n_bytes) {
         const uint32_t b = text[i];
-        if (b < 0x80u) {
+        if (verbatim && ((verbatim[i >> 6] >> (i & 63)) & 1ull)) {
+            ob = 1u;
+        } else if (b < 0x80u) {
             // ASCII: control characters except \t \n \r are dropped, everything else is one byte
             ob = (bt.clean && ((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu)) ? 0u : 1u;
         } else if ((b & 0xC0u) != 0x80u) {
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void k_u32_down(const uint32_t* __restrict__ v
     if (i < n) out[i] = ex;
 }
 
-__global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes,
+__global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
                                                   const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
                                                   uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -102,6 +105,11 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
     const uint32_t pos = wbase[min(i, n_bytes) >> 6] + wave_incl_scan(ob) - ob;
     if (!ob) return;
     const uint32_t b = text[i];
+    if (verbatim && ((verbatim[i >> 6] >> (i & 63)) & 1ull)) {
+        ntext[pos] = (uint8_t)b;
+        if (nos) { nos[pos] = (uint32_t)i; noe[pos] = (uint32_t)i + 1u; }
+        return;
+    }
     if (b < 0x80u) {
         uint32_t c = b;
         if (bt.clean && (c == '\t' || c == '\n' || c == '\r')) c = ' ';

@@ -44,44 +44,25 @@ __device__ __forceinline__ void pair_probe2(const MergeSlot* __restrict__ tab, u
 }
 
 // =================================================================================================
-// K_added_token_scan: does any added/special token occur in the text?  The reference splits the
-// input on them before everything else (AddedVocabulary::extract_and_normalize,
-// tokenizer/added_vocabulary.rs:523-564; find_matches :430-490).  That split is not built on the device
-// yet, so a batch in which one occurs is REFUSED (ERR_ADDED_TOKEN) instead of being tokenised wrongly.
-// One lane per byte: first-byte CSR filter, then a bounded compare per candidate pattern.
-// =================================================================================================
-__global__ __launch_bounds__(256) void k_added_token_scan(const uint8_t* __restrict__ text, int64_t n_bytes,
-                                                          const uint8_t* __restrict__ pat_blob, const uint32_t* __restrict__ pat_off,
-                                                          const uint32_t* __restrict__ first_idx, int* __restrict__ err) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_bytes) return;
-    uint32_t b = text[i];
-    uint32_t lo = first_idx[b], hi = first_idx[b + 1];
-    for (uint32_t k = lo; k < hi; ++k) {
-        uint32_t o = pat_off[k], l = pat_off[k + 1] - o;
-        if (i + l > n_bytes) continue;
-        uint32_t j = 1;
-        while (j < l && text[i + j] == pat_blob[o + j]) ++j;
-        if (j == l) { atomicOr(err, ERR_ADDED_TOKEN); return; }
-    }
-}
-
-// =================================================================================================
-// AddedVocabulary on the device (tokenizer/added_vocabulary.rs:430-564), for tokenizers without a normalizer:
-//   k_added_candidates : lane per byte, "does some added token start here" -> candidate bitmask
-//   (k_l3_slow_docs)    : documents holding a candidate
-//   k_added_resolve    : one lane per such document replays the reference's loop over the leftmost-longest,
-//                        non-overlapping automaton matches: single_word (\w on both sides rejects), lstrip / rstrip
-//                        (\s runs swallowed), and writes four bitmasks: match start, bytes inside a match, first
-//                        byte after a match, and hard boundaries (start | stop) that the pre-tokenizers treat like
-//                        document edges -- each unmatched segment is pre-tokenised on its own, as in the reference.
-//   k_apply_matches    : start/end masks of the pre-tokenizer are patched so that a match is exactly one pre-token
+// AddedVocabulary on the device (tokenizer/added_vocabulary.rs:430-564).  extract_and_normalize runs two matching passes:
+// the tokens with normalized = false over the raw document, then -- on every piece left between those matches, after the
+// normalizer -- the tokens with normalized = true by their normalized patterns.  Both passes are the same three kernels over a
+// "sentence" CSR (documents for pass 1, the pieces for pass 2):
+//   k_added_candidates : lane per byte, "does some pattern of this pass start here" -> candidate bitmask
+//   (k_l3_slow_docs)    : sentences holding a candidate
+//   k_added_resolve    : one lane per such sentence replays find_matches (:430-490): leftmost-longest, non-overlapping automaton
+//                        matches; single_word (\w on either side rejects), lstrip / rstrip (\s runs swallowed, never past the
+//                        previous split).  The automaton resumes after the UN-stripped end of a match, so a later match may start
+//                        inside the whitespace an rstrip token swallowed and overlap it -- reproduced as is.  Output: a list of
+//                        (start, stop, id, length).
+// The lists are then moved into the coordinates of the text the pre-tokenizer reads (k_translate_*), and k_scatter_matches turns
+// them into four bitmasks: match start, bytes inside a match, first byte after a match, hard boundaries (start | stop) that the
+// pre-tokenizers treat like document edges -- every piece is pre-tokenised on its own, as in the reference.
+//   k_apply_matches    : start / end masks of the pre-tokenizer are patched so that a match is exactly one pre-token
 //   k_apply_match_ids  : that pre-token gets the added token's id.
-// The reference's automaton resumes after the UN-stripped end of a match, so a later match can start inside the
-// whitespace an rstrip token swallowed and overlap it; that quirk (and add_prefix_space per segment) is refused.
 // =================================================================================================
 
-// longest added token starting at text[i] inside [i, end): returns its pattern index or -1
+// longest pattern starting at text[i] inside [i, end): returns its index or -1
 __device__ __forceinline__ int added_longest(const AddedArgs& a, const uint8_t* __restrict__ text, int64_t i, int64_t end, uint32_t* len) {
     uint32_t b = text[i];
     int best = -1;
@@ -97,13 +78,14 @@ __device__ __forceinline__ int added_longest(const AddedArgs& a, const uint8_t* 
     return best;
 }
 
-__global__ __launch_bounds__(256) void k_added_candidates(AddedArgs a, const uint8_t* __restrict__ text, int64_t n_bytes,
-                                                          unsigned long long* __restrict__ candmask) {
+__global__ __launch_bounds__(256) void k_added_candidates(AddedArgs a, const uint8_t* __restrict__ text, int64_t n_bytes_host,
+                                                          const int64_t* __restrict__ len_dev, unsigned long long* __restrict__ candmask) {
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool cand = false;
     if (i < n_bytes) { uint32_t l; cand = added_longest(a, text, i, n_bytes, &l) >= 0; }
     uint64_t m = __ballot(cand);
-    if ((threadIdx.x & 63) == 0 && i <= n_bytes) candmask[i >> 6] = m;
+    if ((threadIdx.x & 63) == 0 && i <= n_bytes_host) candmask[i >> 6] = m;
 }
 
 __device__ __forceinline__ void mask_set_range(unsigned long long* m, int64_t a, int64_t b) {      // bits [a, b)
@@ -116,17 +98,20 @@ __device__ __forceinline__ void mask_set_range(unsigned long long* m, int64_t a,
     }
 }
 
-__global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off,
-                                const uint32_t* __restrict__ docs, const uint32_t* __restrict__ n_docs_listed,
-                                const unsigned long long* __restrict__ candmask,
-                                const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2, uint32_t refuse_any,
-                                unsigned long long* __restrict__ matchmask, unsigned long long* __restrict__ spanmask,
-                                unsigned long long* __restrict__ stopmask, unsigned long long* __restrict__ hardmask,
-                                uint32_t* __restrict__ match_list, uint32_t* __restrict__ n_match, int* __restrict__ err) {
-    const uint32_t n = *n_docs_listed;
+// sentences = seg_off[sents[q]] .. seg_off[sents[q] + 1]; a sentence whose first byte carries a bit of `skipmask` is a match of
+// the earlier pass (not text): skipped
+__global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, const int64_t* __restrict__ seg_off,
+                                const uint32_t* __restrict__ sents, const uint32_t* __restrict__ n_sents,
+                                const unsigned long long* __restrict__ candmask, const unsigned long long* __restrict__ skipmask,
+                                const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
+                                uint32_t* __restrict__ match_list, uint32_t* __restrict__ n_match, uint32_t cap, uint32_t len_flag, int* __restrict__ err) {
+    const uint32_t n = *n_sents;
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
-        const int64_t da = doc_off[docs[q]], db = doc_off[docs[q] + 1];
+        const int64_t da = seg_off[sents[q]], db = seg_off[sents[q] + 1];
+        if (db <= da) continue;
+        if (skipmask && ((skipmask[da >> 6] >> (da & 63)) & 1ull)) continue;
         int64_t cursor = da, start_offset = da;
+        uint32_t prev = 0xFFFFFFFFu;                                  // list index of this sentence's previous match
         for (int64_t w = da >> 6; w <= (db - 1) >> 6; ++w) {
             unsigned long long cm = candmask[w];
             while (cm) {
@@ -135,7 +120,7 @@ __global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, c
                 if (pos < cursor || pos < da || pos >= db) continue;
                 uint32_t len;
                 const int k = added_longest(a, text, pos, db, &len);
-                if (k < 0) continue;                                  // the candidate needed bytes past this document
+                if (k < 0) continue;                                  // the candidate needed bytes past this sentence
                 int64_t start = pos, stop = pos + len;
                 cursor = stop;                                        // the automaton resumes after the un-stripped match
                 const uint32_t fl = a.flags[k];
@@ -168,19 +153,96 @@ __global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, c
                         stop += l2;
                     }
                 }
-                if (start < start_offset || refuse_any) { atomicOr(err, ERR_ADDED_TOKEN); continue; }   // overlap quirk / unsupported combination
-                atomicOr(&matchmask[start >> 6], 1ull << (start & 63));
-                atomicOr(&hardmask[start >> 6], 1ull << (start & 63));
-                atomicOr(&stopmask[stop >> 6], 1ull << (stop & 63));
-                if (stop < db) atomicOr(&hardmask[stop >> 6], 1ull << (stop & 63));
-                mask_set_range(spanmask, start + 1, stop);
+                // this match starts inside the whitespace the previous (rstrip) one swallowed: the two splits overlap in the reference;
+                // in the flat text the earlier one ends, for the masks, where this one starts (its full length stays on record)
+                if (prev != 0xFFFFFFFFu && start < start_offset) match_list[4 * prev + 1] = (uint32_t)start;
                 const uint32_t mi = atomicAdd(n_match, 1u);
-                match_list[2 * mi] = (uint32_t)start;
-                match_list[2 * mi + 1] = a.id[k];
+                if (mi < cap) {
+                    match_list[4 * mi] = (uint32_t)start;
+                    match_list[4 * mi + 1] = (uint32_t)stop;          // end in the masks
+                    match_list[4 * mi + 2] = a.id[k];
+                    match_list[4 * mi + 3] = (uint32_t)(stop - start) | len_flag;   // the split's own length (in this text's bytes)
+                    prev = mi;
+                } else atomicOr(err, ERR_INTERNAL);
                 start_offset = stop;
             }
         }
     }
+}
+
+// (start, stop, id, length) list -> bitmasks over the same text.  tmp_end (offsets requested): the split's own length (MATCH_LEN_ORIG:
+// counted in bytes of the original text), for the offsets of a match -- a later, overlapping match may have cut it short in the masks.
+__global__ void k_scatter_matches(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, int64_t n_bytes_host, const int64_t* __restrict__ len_dev,
+                                  unsigned long long* __restrict__ matchmask, unsigned long long* __restrict__ spanmask,
+                                  unsigned long long* __restrict__ stopmask, unsigned long long* __restrict__ hardmask, uint32_t* __restrict__ tmp_end) {
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int64_t start = list[4 * i], stop = list[4 * i + 1];
+        atomicOr(&matchmask[start >> 6], 1ull << (start & 63));
+        if (hardmask) atomicOr(&hardmask[start >> 6], 1ull << (start & 63));
+        if (stopmask) atomicOr(&stopmask[stop >> 6], 1ull << (stop & 63));
+        if (hardmask && stop < n_bytes) atomicOr(&hardmask[stop >> 6], 1ull << (stop & 63));
+        mask_set_range(spanmask, start + 1, stop);
+        if (tmp_end) tmp_end[start] = list[4 * i + 3];
+    }
+}
+// every byte of a match (start and inside), for the normalizer to copy verbatim
+__global__ void k_mask_or2(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ b, int64_t n_words) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] = a[i] | b[i];
+}
+// positions of the set bits of a boundary mask, in order, as an int64 CSR (one lane per mask word; out[total] = the text length)
+__global__ void k_emit_boundaries(const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ wprefix, int64_t n_bytes_host,
+                                  const int64_t* __restrict__ len_dev, const int64_t* __restrict__ total, int64_t* __restrict__ out) {
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    const int64_t n_words = (n_bytes + 63) >> 6;
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) out[*total] = n_bytes;
+    if (w >= n_words) return;
+    uint32_t r = wprefix[w];
+    for (unsigned long long m = mask[w]; m; m &= m - 1ull, ++r) out[r] = (w << 6) + (__ffsll(m) - 1);
+}
+// list entries from the raw text into the normalised text: position of a source byte = bytes the normalizer emitted before it
+// (matches are copied verbatim, so their length is unchanged)
+__device__ __forceinline__ uint32_t bn_position(const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase, int64_t n_bytes, const int64_t* __restrict__ x_len, int64_t g) {
+    if (g >= n_bytes) return (uint32_t)*x_len;
+    uint32_t r = wbase[g >> 6];
+    for (int64_t q = g & ~(int64_t)63; q < g; ++q) r += olen[q];
+    return r;
+}
+__global__ void k_translate_matches_norm(uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, const uint8_t* __restrict__ olen,
+                                         const uint32_t* __restrict__ wbase, int64_t n_bytes, const int64_t* __restrict__ x_len) {
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        list[4 * i] = bn_position(olen, wbase, n_bytes, x_len, list[4 * i]);
+        list[4 * i + 1] = bn_position(olen, wbase, n_bytes, x_len, list[4 * i + 1]);
+    }
+}
+// list entries into the prefix-space text: a match edge is a piece boundary, and piece k starts at xseg_off[k]
+__device__ __forceinline__ uint32_t boundary_rank(const unsigned long long* __restrict__ mask, const uint32_t* __restrict__ wprefix, int64_t pos, int64_t n_bytes,
+                                                  const int64_t* __restrict__ total) {
+    if (pos >= n_bytes) return (uint32_t)*total;
+    return wprefix[pos >> 6] + (uint32_t)__popcll(mask[pos >> 6] & ((1ull << (pos & 63)) - 1ull));
+}
+__global__ void k_translate_matches_prefix(uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, const unsigned long long* __restrict__ bmask,
+                                           const uint32_t* __restrict__ wprefix, int64_t n_bytes_host, const int64_t* __restrict__ len_dev,
+                                           const int64_t* __restrict__ total, const int64_t* __restrict__ xseg_off) {
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        list[4 * i] = (uint32_t)xseg_off[boundary_rank(bmask, wprefix, list[4 * i], n_bytes, total)];
+        list[4 * i + 1] = (uint32_t)xseg_off[boundary_rank(bmask, wprefix, list[4 * i + 1], n_bytes, total)];
+    }
+}
+// document CSR in the prefix-space text: a document start is a piece boundary
+__global__ void k_prefix_doc_csr(const int64_t* __restrict__ doc_off, int64_t n_docs, const unsigned long long* __restrict__ bmask, const uint32_t* __restrict__ wprefix,
+                                 int64_t n_bytes_host, const int64_t* __restrict__ len_dev, const int64_t* __restrict__ total, const int64_t* __restrict__ xseg_off,
+                                 int64_t* __restrict__ xdoc_off) {
+    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
+    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > n_docs) return;
+    xdoc_off[d] = xseg_off[boundary_rank(bmask, wprefix, doc_off[d], n_bytes, total)];
 }
 
 // word-wise mask algebra: dst |= src
@@ -202,27 +264,31 @@ __global__ void k_apply_match_ids(const uint32_t* __restrict__ match_list, const
                                   uint32_t* __restrict__ tok0) {
     const uint32_t n = *n_match;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t pos = match_list[2 * i];
+        const uint32_t pos = match_list[4 * i];
         const uint32_t p = wprefix[pos >> 6] + (uint32_t)__popcll(startmask[pos >> 6] & ((1ull << (pos & 63)) - 1ull));
-        tok0[p] = TOK_ONE | match_list[2 * i + 1];
+        tok0[p] = TOK_ONE | match_list[4 * i + 2];
     }
 }
 
 // =================================================================================================
-// ByteLevel add_prefix_space (pre_tokenizers/byte_level.rs:122-125): every document that does not start
-// with ' ' is pre-tokenised as if a space were prepended.  The device materialises that text once:
-// need[d] -> exclusive scan -> shifted document CSR -> one wavefront per document copies it behind its
-// optional space.  Offsets are mapped back in k_token_meta (the inserted space shares the first
-// original char's alignment, tokenizer/normalizer.rs:503-514).
+// ByteLevel add_prefix_space (pre_tokenizers/byte_level.rs:120-125): every piece the pre-tokenizer is handed -- a whole document,
+// or what lies between added-token matches -- that does not start with ' ' is pre-tokenised as if a space were prepended.  The
+// device materialises that text once: need[piece] -> exclusive scan -> shifted piece CSR -> one wavefront per piece copies it
+// behind its optional space.  The inserted space shares the first original char's alignment (tokenizer/normalizer.rs:503-514):
+// with offsets requested the copy also writes, per byte of the new text, the original byte range it stands for.
+// A piece that is itself an added-token match (matchmask bit at its first byte) is copied as it is.
 // =================================================================================================
-__global__ void k_prefix_need(const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off, int64_t n_docs,
-                              uint32_t* __restrict__ need) {
+// (n_dev: the number of pieces when it only exists on the device; the launch covers its host-side bound n_bound, need[] is 0 past it)
+__global__ void k_prefix_need(const uint8_t* __restrict__ text, const int64_t* __restrict__ seg_off, int64_t n_bound, const int64_t* __restrict__ n_dev,
+                              const unsigned long long* __restrict__ matchmask, uint32_t* __restrict__ need) {
+    const int64_t n_segs = n_dev ? *n_dev : n_bound;
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d > n_docs) return;
+    if (d > n_bound) return;
     uint32_t v = 0;
-    if (d < n_docs) {
-        int64_t a = doc_off[d], b = doc_off[d + 1];
-        v = (b > a && text[a] != ' ') ? 1u : 0u;
+    if (d < n_segs) {
+        int64_t a = seg_off[d], b = seg_off[d + 1];
+        const bool is_match = matchmask && b > a && ((matchmask[a >> 6] >> (a & 63)) & 1ull);
+        v = (b > a && text[a] != ' ' && !is_match) ? 1u : 0u;
     }
     need[d] = v;
 }
@@ -233,28 +299,41 @@ __global__ __launch_bounds__(256) void k_u32_reduce(const uint32_t* __restrict__
     block256_excl_scan(x, sm, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
-// exclusive prefix of need[] added to the document CSR: xdoc_off[d] = doc_off[d] + #spaces inserted before doc d
-__global__ __launch_bounds__(256) void k_prefix_doc_offsets(const uint32_t* __restrict__ need, int64_t n, const uint32_t* __restrict__ bsum,
+// exclusive prefix of need[] added to the piece CSR: xseg_off[d] = seg_off[d] + #spaces inserted before piece d
+__global__ __launch_bounds__(256) void k_prefix_doc_offsets(const uint32_t* __restrict__ need, int64_t n_bound, const int64_t* __restrict__ n_dev, const uint32_t* __restrict__ bsum,
                                                             const int64_t* __restrict__ doc_off, int64_t* __restrict__ xdoc_off,
                                                             int64_t* __restrict__ x_len) {
     __shared__ uint32_t sm[4];
+    const int64_t n = (n_dev ? *n_dev : n_bound) + 1;     // CSR entries
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t x = (i < n) ? need[i] : 0u, tot;
+    uint32_t x = (i <= n_bound) ? need[i] : 0u, tot;
     uint32_t ex = bsum[blockIdx.x] + block256_excl_scan(x, sm, &tot);
     if (i < n) {
         xdoc_off[i] = doc_off[i] + ex;
-        if (i == n - 1) *x_len = doc_off[i] + ex;         // i == n_docs: total length of the shifted text
+        if (i == n - 1) *x_len = doc_off[i] + ex;         // i == n_segs: total length of the shifted text
     }
 }
-__global__ __launch_bounds__(256) void k_prefix_copy(const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off,
-                                                     const int64_t* __restrict__ xdoc_off, int64_t n_docs, uint8_t* __restrict__ xtext) {
+__global__ __launch_bounds__(256) void k_prefix_copy(const uint8_t* __restrict__ text, const int64_t* __restrict__ seg_off,
+                                                     const int64_t* __restrict__ xseg_off, int64_t n_segs, const int64_t* __restrict__ n_dev, uint8_t* __restrict__ xtext,
+                                                     uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
+    if (n_dev) n_segs = *n_dev;
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t d = wave; d < n_docs; d += n_waves) {
-        const int64_t a = doc_off[d], len = doc_off[d + 1] - a;
-        const int64_t xa = xdoc_off[d];
-        const int64_t shift = (xdoc_off[d + 1] - xa) - len;        // 1 if a space is inserted
-        if (shift && lane == 0) xtext[xa] = ' ';
-        for (int64_t i = lane; i < len; i += 64) xtext[xa + shift + i] = text[a + i];
+    for (int64_t d = wave; d < n_segs; d += n_waves) {
+        const int64_t a = seg_off[d], len = seg_off[d + 1] - a;
+        const int64_t xa = xseg_off[d];
+        const int64_t shift = (xseg_off[d + 1] - xa) - len;        // 1 if a space is inserted
+        if (shift && lane == 0) {
+            xtext[xa] = ' ';
+            if (nos) {
+                const uint32_t fb = text[a];
+                nos[xa] = (uint32_t)a;
+                noe[xa] = (uint32_t)a + (fb < 0x80u ? 1u : fb < 0xE0u ? 2u : fb < 0xF0u ? 3u : 4u);
+            }
+        }
+        for (int64_t i = lane; i < len; i += 64) {
+            xtext[xa + shift + i] = text[a + i];
+            if (nos) { nos[xa + shift + i] = (uint32_t)(a + i); noe[xa + shift + i] = (uint32_t)(a + i + 1); }
+        }
     }
 }

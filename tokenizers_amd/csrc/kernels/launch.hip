@@ -108,15 +108,15 @@ void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask,
     hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 64, 4 * 4096)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
 }
 void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
-                           uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext, uint32_t* nos,
-                           uint32_t* noe, int64_t* ndoc_off, int* err) {
+                           const unsigned long long* verbatim, uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext,
+                           uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err) {
     const int64_t n_words = (n_bytes >> 6) + 1;
-    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, bt, text, n_bytes, olen, wsum, err);
+    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, bt, text, n_bytes, verbatim, olen, wsum, err);
     unsigned nb = blocks_for(n_words, 256);
     hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, bsum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
     hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, (const uint32_t*)bsum, wbase);
-    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, bt, text, n_bytes, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
+    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, bt, text, n_bytes, verbatim, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
     hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
@@ -127,20 +127,17 @@ void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_
                       uint32_t* tmp_end, int* err) {
     hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
 }
-void launch_added_token_scan(hipStream_t st, const uint8_t* text, int64_t n_bytes, const uint8_t* pat_blob, const uint32_t* pat_off,
-                             const uint32_t* first_idx, int* err) {
-    hipLaunchKernelGGL(k_added_token_scan, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, text, n_bytes, pat_blob, pat_off, first_idx, err);
-}
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
-                          const int64_t* doc_off, int64_t n_docs, uint32_t* slow_docs, uint32_t* n_slow_docs) {
+                          const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs) {
     // TKAMD_PRETOK_L3=tile: the lane-per-byte tile kernel alone; default: the per-lane bit-parallel kernel first, the tile
-    // kernel only on the tiles where it left bytes undecided
+    // kernel only on the tiles where it left bytes undecided.  doc_off: the sentences the sequential matcher may be handed
+    // (documents, or the pieces between added-token matches).
     static const bool tile_only = [] { const char* e = getenv("TKAMD_PRETOK_L3"); return e && !strcmp(e, "tile"); }();
     if (!tile_only)
         hipLaunchKernelGGL(k_pretok_llama3_lane, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask);
     hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, tile_only ? 0 : 1);
-    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, slow_docs, n_slow_docs);
+    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
     hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, uc1, uc2, startmask);
 }
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask) {
@@ -149,14 +146,14 @@ void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsig
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
 }
-void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* doc_off, int64_t n_docs, uint32_t* need, uint32_t* bsum,
-                         int64_t* xdoc_off, int64_t* x_len, uint8_t* xtext, int grid) {
-    unsigned nb = blocks_for(n_docs + 1, 256);
-    hipLaunchKernelGGL(k_prefix_need, dim3(nb), dim3(256), 0, st, text, doc_off, n_docs, need);
-    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, bsum);
+void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
+                         uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid) {
+    unsigned nb = blocks_for(n_bound + 1, 256);
+    hipLaunchKernelGGL(k_prefix_need, dim3(nb), dim3(256), 0, st, text, seg_off, n_bound, n_dev, matchmask, need);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_bound + 1, bsum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
-    hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_docs + 1, (const uint32_t*)bsum, doc_off, xdoc_off, x_len);
-    hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, doc_off, (const int64_t*)xdoc_off, n_docs, xtext);
+    hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_bound, n_dev, (const uint32_t*)bsum, seg_off, xseg_off, x_len);
+    hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, seg_off, (const int64_t*)xseg_off, n_bound, n_dev, xtext, nos, noe);
 }
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
     hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
@@ -174,14 +171,35 @@ void launch_final_offsets(hipStream_t st, const FinalArgs& a) {
 void launch_finalize(hipStream_t st, int grid, const FinalArgs& a) {
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, st, a);
 }
-void launch_added_match(hipStream_t st, int grid, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
-                        const uint16_t* uc1, const uint8_t* uc2, uint32_t refuse_any, unsigned long long* candmask,
-                        unsigned long long* matchmask, unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask,
-                        uint32_t* docs, uint32_t* n_docs_listed, uint32_t* match_list, uint32_t* n_match, int* err) {
-    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, a, text, n_bytes, candmask);
-    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)candmask, doc_off, n_docs, docs, n_docs_listed);
-    hipLaunchKernelGGL(k_added_resolve, dim3(1024), dim3(64), 0, st, a, text, doc_off, (const uint32_t*)docs, (const uint32_t*)n_docs_listed,
-                       (const unsigned long long*)candmask, uc1, uc2, refuse_any, matchmask, spanmask, stopmask, hardmask, match_list, n_match, err);
+// one matching pass of the AddedVocabulary over the sentences seg_off[0 .. n_segs]: appends (start, stop, id) to match_list
+void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
+                        const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
+                        uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err) {
+    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, a, text, n_bytes, len_dev, candmask);
+    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_segs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)candmask, seg_off, n_segs, n_segs_dev, sents, n_sents);
+    hipLaunchKernelGGL(k_added_resolve, dim3(1024), dim3(64), 0, st, a, text, seg_off, (const uint32_t*)sents, (const uint32_t*)n_sents,
+                       (const unsigned long long*)candmask, skipmask, uc1, uc2, match_list, n_match, cap, len_flag, err);
+}
+void launch_scatter_matches(hipStream_t st, const uint32_t* list, const uint32_t* n_list, int64_t n_bytes, const int64_t* len_dev, unsigned long long* matchmask,
+                            unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end) {
+    hipLaunchKernelGGL(k_scatter_matches, dim3(256), dim3(256), 0, st, list, n_list, n_bytes, len_dev, matchmask, spanmask, stopmask, hardmask, tmp_end);
+}
+void launch_mask_or2(hipStream_t st, unsigned long long* dst, const unsigned long long* a, const unsigned long long* b, int64_t n_words) {
+    hipLaunchKernelGGL(k_mask_or2, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, a, b, n_words);
+}
+void launch_emit_boundaries(hipStream_t st, const unsigned long long* mask, const uint32_t* wprefix, int64_t n_bytes, const int64_t* len_dev, const int64_t* total, int64_t* out) {
+    hipLaunchKernelGGL(k_emit_boundaries, dim3(blocks_for((n_bytes >> 6) + 2, 256)), dim3(256), 0, st, mask, wprefix, n_bytes, len_dev, total, out);
+}
+void launch_translate_matches_norm(hipStream_t st, uint32_t* list, const uint32_t* n_list, const uint8_t* olen, const uint32_t* wbase, int64_t n_bytes, const int64_t* x_len) {
+    hipLaunchKernelGGL(k_translate_matches_norm, dim3(256), dim3(256), 0, st, list, n_list, olen, wbase, n_bytes, x_len);
+}
+void launch_translate_matches_prefix(hipStream_t st, uint32_t* list, const uint32_t* n_list, const unsigned long long* bmask, const uint32_t* wprefix, int64_t n_bytes,
+                                     const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off) {
+    hipLaunchKernelGGL(k_translate_matches_prefix, dim3(256), dim3(256), 0, st, list, n_list, bmask, wprefix, n_bytes, len_dev, total, xseg_off);
+}
+void launch_prefix_doc_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, const unsigned long long* bmask, const uint32_t* wprefix, int64_t n_bytes,
+                           const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off, int64_t* xdoc_off) {
+    hipLaunchKernelGGL(k_prefix_doc_csr, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, bmask, wprefix, n_bytes, len_dev, total, xseg_off, xdoc_off);
 }
 void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words) {
     hipLaunchKernelGGL(k_mask_or, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, src, n_words);

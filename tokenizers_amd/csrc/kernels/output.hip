@@ -174,27 +174,30 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         const uint32_t xdoc = (uint32_t)a.x_doc_off[d];
         const uint32_t odoc = (uint32_t)a.doc_off[d];
         uint32_t rel = 0;
+        // an added-token match is one token whose own length is on record (k_scatter_matches): a later, overlapping match may have
+        // cut it short in the start mask, and its text is the raw slice (trimmed by real whitespace chars)
+        const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
         for (uint32_t j = 0; j < c; ++j) {
             uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s + j];
             if (a.want_words) a.word_ids[o + j] = word;
             if (a.want_offsets) {
                 uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
                 uint32_t bs = ts, be = te;
-                if (a.byte_level) {                                   // snap to char boundaries inside the pre-token
+                if (a.byte_level && !is_match) {                      // snap to char boundaries inside the pre-token
                     while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
                     while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
                 }
                 // x space -> original text
                 uint32_t os, oe;
-                if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
-                else if (a.prefix_space && ((uint32_t)(a.x_doc_off[d + 1]) - xdoc) != ((uint32_t)(a.doc_off[d + 1]) - odoc)) {
-                    // this document got a virtual leading space: x position 0 maps to [0, len(first char)), x >= 1 to x - 1
-                    uint32_t rs = bs - xdoc, re = be - xdoc;
-                    uint32_t fb = a.x_text[xdoc + 1];
-                    uint32_t first_len = fb < 0x80u ? 1u : fb < 0xE0u ? 2u : fb < 0xF0u ? 3u : 4u;
-                    os = odoc + (rs == 0 ? 0u : rs - 1u);
-                    oe = odoc + (re <= 1u ? first_len : re - 1u);
+                const uint8_t* ttext = a.x_text;                      // text the trimming below reads, and the token's span in it
+                uint32_t tts = ts, tte = te;
+                if (is_match) {
+                    const uint32_t ml = a.tmp_end[s];
+                    os = a.norig ? a.norig[s] : s - xdoc + odoc;
+                    if (ml & MATCH_LEN_ORIG) { oe = os + (ml & ~MATCH_LEN_ORIG); ttext = a.text; tts = os; tte = oe; }
+                    else { tte = s + ml; oe = a.norig ? a.norig_e[tte - 1] : tte - xdoc + odoc; }
                 }
+                else if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
                 else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
                 if (a.char_mode) {
                     uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
@@ -203,22 +206,22 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                 } else { os -= odoc; oe -= odoc; }
                 if (a.trim_offsets) {                                 // process_offsets, byte_level.rs:202-234
                     uint32_t lead_sp = 0, trail_sp = 0;
-                    if (a.matchmask && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull)) {
+                    if (is_match) {
                         // an added token's text is the raw slice: its leading / trailing chars are tested with char::is_whitespace
-                        uint32_t q = ts;
-                        while (q < te) { uint32_t l; if (!(uc_flags(utf8_global(a.x_text, q, &l), a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
-                        q = te;
-                        while (q > ts) {
+                        uint32_t q = tts;
+                        while (q < tte) { uint32_t l; if (!(uc_flags(utf8_global(ttext, q, &l), a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
+                        q = tte;
+                        while (q > tts) {
                             uint32_t r = q - 1;
-                            while (r > ts && (a.x_text[r] & 0xC0u) == 0x80u) --r;
+                            while (r > tts && (ttext[r] & 0xC0u) == 0x80u) --r;
                             uint32_t l;
-                            if (!(uc_flags(utf8_global(a.x_text, r, &l), a.uc1, a.uc2) & UC_RUST_WS)) break;
+                            if (!(uc_flags(utf8_global(ttext, r, &l), a.uc1, a.uc2) & UC_RUST_WS)) break;
                             ++trail_sp;
                             q = r;
                         }
                     } else {
-                    while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
-                    while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
+                        while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
+                        while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
                     }
                     if (lead_sp) {
                         bool is_first = (word == 0 && j == 0) || os == 0;

@@ -393,8 +393,10 @@ __device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_
 }
 
 // documents with at least one unresolved byte -> slow_docs list (one lane per document)
-__global__ void k_l3_slow_docs(const unsigned long long* __restrict__ slowmask, const int64_t* __restrict__ doc_off, int64_t n_docs,
+// (n_dev: the number of sentences when it only exists on the device -- pieces between added-token matches; n_docs is then its bound)
+__global__ void k_l3_slow_docs(const unsigned long long* __restrict__ slowmask, const int64_t* __restrict__ doc_off, int64_t n_docs, const int64_t* __restrict__ n_dev,
                                uint32_t* __restrict__ slow_docs, uint32_t* __restrict__ n_slow_docs) {
+    if (n_dev) n_docs = *n_dev;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
         const int64_t a = doc_off[d], b = doc_off[d + 1];
         if (b <= a) continue;
