@@ -528,3 +528,65 @@ def test_tile_pretokenizer_variants_agree():
     env = dict(os.environ, TKAMD_PRETOK_L3="tile", TKAMD_PRETOK_LOCAL="tile")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_concurrent_host_callers(gpt2, gpt2_oracle):
+    """TokenizerImpl::encode_batch is &self + Send + Sync (tokenizer/mod.rs:1328-1335): four host threads encode different batches through
+    the same handle at once (each call takes its own workspace and streams); every result equals the oracle's."""
+    import threading
+    import tokenizers_amd as ta
+    batches = [synth.gen_lines(40000, text_seed=200 + k) + synth.stress_lines(seed=40 + k, n=500) for k in range(4)]
+    packed = [ta.pack_documents(b) for b in batches]
+    out = [None] * 4
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(3):
+                out[k] = gpt2.encode_packed(*packed[k], offsets="byte", word_ids=True)
+        except Exception as ex:                 # pragma: no cover
+            errs.append(ex)
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    for k in range(4):
+        exp = gpt2_oracle.encode_batch(batches[k])
+        assert np.array_equal(out[k].tok_offsets, exp.tok_offsets) and np.array_equal(out[k].ids, exp.ids)
+        assert np.array_equal(out[k].offsets, exp.offsets) and np.array_equal(out[k].word_ids, exp.words)
+
+
+def test_sliced_host_entry_equals_one_slice(gpt2_json):
+    """The host entry cuts a batch into document-aligned slices that pipeline H2D / kernels / D2H; forced down to 1 MB slices the
+    result (ids, CSR, offsets, word ids, specials, padding) must be the one-slice result."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, tokenizers_amd as ta\n"
+        "from oracle import synth, oracle as orc\n"
+        "from tests.helpers import load_tokenizer_json\n"
+        "docs = synth.gen_lines(60000, text_seed=61) + ['', 'x' * 70000, ''] + synth.stress_lines(seed=44, n=800)\n"
+        "js = synth.load_or_train_gpt2()\n"
+        "tk = ta.Tokenizer.from_str(js, device=0)\n"
+        "got = tk.encode_batch_csr(docs, offsets='char', word_ids=True)\n"
+        "exp = orc.Oracle(js).encode_batch(docs, char_offsets=True)\n"
+        "assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)\n"
+        "assert np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)\n"
+        "d = json.loads(load_tokenizer_json('bert_wordpiece_4000_specials'))\n"
+        "d['padding'] = {'strategy': {'Fixed': 24}, 'direction': 'Right', 'pad_to_multiple_of': None, 'pad_id': 0, 'pad_type_id': 0, 'pad_token': '[PAD]'}\n"
+        "d['truncation'] = {'direction': 'Right', 'max_length': 24, 'strategy': 'LongestFirst', 'stride': 0}\n"
+        "tb = ta.Tokenizer.from_str(json.dumps(d), device=0)\n"
+        "bd = [x for x in docs if '[' not in x and len(x) < 3000 and x.isascii()]\n"
+        "g = tb.encode_batch_csr(bd, add_special_tokens=True)\n"
+        "assert len(g.ids) == 24 * len(bd) and g.tok_offsets[-1] == len(g.ids) and (np.diff(g.tok_offsets) == 24).all()\n"
+        "print('SLICED_OK', g.pad_counts[:3])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mb in ("1", "4096"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_HOST_SLICE_MB=mb), capture_output=True, text=True, timeout=600)
+        assert "SLICED_OK" in r.stdout, r.stdout + r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -81,17 +83,16 @@ struct StageRec {
 
 }  // namespace
 
-struct tkamd_tokenizer {
-    HostModel hm;
-    int device = -1;
-    DevTables dt{};
-    std::mutex mu;
-    // tables
-    DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
-    DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
-    DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
-    DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
-    // workspace (sized by the largest batch seen)
+// Everything one encode / decode call writes: intermediate and result buffers in HBM (grow-only), the stream of the host entry, the
+// call's bookkeeping.  A tokenizer handle owns a small pool of them, so calls from different host threads run concurrently
+// (TokenizerImpl::encode_batch is &self + Send + Sync, tokenizer/mod.rs:1328-1335); the tables stay shared and read-only.
+struct Workspace {
+    std::mutex mu;               // a workspace serves one call at a time
+    bool busy = false;           // taken by a host-entry call
+    bool device_bound = false;   // belongs to the device entry: keyed by the caller's stream, results stay valid in it
+    hipStream_t bound_stream = nullptr;
+    hipStream_t own_stream = nullptr;   // host entry: its own non-blocking stream
+    // (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count;   // truncation / padding epilogue
     DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
@@ -102,17 +103,9 @@ struct tkamd_tokenizer {
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off;
-    int n_cu = 256;
-    int n_direct = 0;
-    int n_hot = 0;
-    int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
-    uint32_t q16_div = 4;        // capacity of the <= 16-byte queue = n_bytes / q16_div (halved and retried when a batch overflows it)
-    bool long_prepared = false;
-    // profiling
-    bool prof = false;
+    // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
     std::vector<StageRec> pending;
-    std::vector<tkamd_stage_time> acc;
-    // last device call (for tkamd_device_sync, which runs it again if a work queue overflowed)
+    // last call (for tkamd_device_sync, which runs it again if a work queue overflowed)
     const uint8_t* last_text = nullptr;
     const int64_t* last_doc_off = nullptr;
     int64_t last_n_bytes = 0;
@@ -121,7 +114,33 @@ struct tkamd_tokenizer {
     int64_t last_n_docs = 0;
     int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
+    ~Workspace() { if (own_stream) (void)hipStreamDestroy(own_stream); }
 };
+
+struct tkamd_tokenizer {
+    HostModel hm;
+    int device = -1;
+    DevTables dt{};
+    std::mutex mu;                       // pool, profile totals
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<Workspace>> pool;
+    Workspace* last_used = nullptr;      // workspace of the most recent call (diagnostics: tkamd_profile_counters)
+    // tables
+    DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
+    DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
+    DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
+    DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
+    int n_cu = 256;
+    int n_direct = 0;
+    int n_hot = 0;
+    int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
+    std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
+    // profiling
+    std::atomic<bool> prof{false};
+    std::vector<tkamd_stage_time> acc;
+};
+
+constexpr size_t MAX_HOST_WORKSPACES = 4;       // concurrent host-entry calls per handle; further callers wait for a free one
 
 // Host results live in pinned (page-locked) memory so the D2H copies run at PCIe speed; blocks are recycled
 // through a small process-wide pool because pinning is expensive.
@@ -179,6 +198,7 @@ enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_PADMA
 
 struct Prof {
     tkamd_tokenizer* t;
+    Workspace* w;
     hipStream_t st;
     void begin(const char* name) {
         if (!t->prof) return;
@@ -187,16 +207,17 @@ struct Prof {
         HIP_CHECK(hipEventCreate(&r.a));
         HIP_CHECK(hipEventCreate(&r.b));
         HIP_CHECK(hipEventRecord(r.a, st));
-        t->pending.push_back(r);
+        w->pending.push_back(r);
     }
     void end() {
         if (!t->prof) return;
-        HIP_CHECK(hipEventRecord(t->pending.back().b, st));
+        HIP_CHECK(hipEventRecord(w->pending.back().b, st));
     }
 };
 
-void drain_profile(tkamd_tokenizer* t) {
-    for (StageRec& r : t->pending) {
+// (caller holds t->mu)
+void drain_profile(tkamd_tokenizer* t, Workspace* w) {
+    for (StageRec& r : w->pending) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto it = std::find_if(t->acc.begin(), t->acc.end(), [&](const tkamd_stage_time& s) { return r.name == s.name; });
@@ -212,7 +233,7 @@ void drain_profile(tkamd_tokenizer* t) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
-    t->pending.clear();
+    w->pending.clear();
 }
 
 void upload_tables(tkamd_tokenizer* t) {
@@ -373,31 +394,31 @@ QueueSizes queue_sizes(size_t N, uint32_t q16_div) {
     return z;
 }
 
-void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint32_t flags, bool want_meta) {
+void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_t n_docs, uint32_t flags, bool want_meta) {
     int64_t W = (n_bytes >> 6) + 2;
     size_t N = (size_t)n_bytes;
-    t->w_docmask.reserve(W * 8);
-    t->w_startmask.reserve(W * 8);
-    t->w_wprefix.reserve(W * 4);
-    t->w_bsum.reserve((W / 256 + 2) * 4);
-    t->w_tok0.reserve((N + 4) * 4);
-    t->w_tmp_ids.reserve((N + 4) * 4);
+    w->w_docmask.reserve(W * 8);
+    w->w_startmask.reserve(W * 8);
+    w->w_wprefix.reserve(W * 4);
+    w->w_bsum.reserve((W / 256 + 2) * 4);
+    w->w_tok0.reserve((N + 4) * 4);
+    w->w_tmp_ids.reserve((N + 4) * 4);
     const QueueSizes z = queue_sizes(N, t->q16_div);
-    t->w_rows.reserve(z.total * 16);
-    t->w_queues.reserve(z.total * 8);
-    t->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8);
-    t->w_qcount.reserve((size_t)QCNT_WORDS * 4);
-    t->w_pt_tokoff.reserve((N + 4) * 4);
-    t->w_ids.reserve((N + 4) * 4);
-    t->w_doc_pt.reserve((n_docs + 2) * 4);
-    t->w_tok_offsets.reserve((n_docs + 2) * 8);
-    t->w_scalars.reserve(SC_SLOTS * 8);
-    if (want_meta) t->w_pt_start.reserve((N + 4) * 4);      // pre-token offsets exist in memory only for the offsets / word-id pass
+    w->w_rows.reserve(z.total * 16);
+    w->w_queues.reserve(z.total * 8);
+    w->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8);
+    w->w_qcount.reserve((size_t)QCNT_WORDS * 4);
+    w->w_pt_tokoff.reserve((N + 4) * 4);
+    w->w_ids.reserve((N + 4) * 4);
+    w->w_doc_pt.reserve((n_docs + 2) * 4);
+    w->w_tok_offsets.reserve((n_docs + 2) * 8);
+    w->w_scalars.reserve(SC_SLOTS * 8);
+    if (want_meta) w->w_pt_start.reserve((N + 4) * 4);      // pre-token offsets exist in memory only for the offsets / word-id pass
     if (flags & TKAMD_OFFSETS_MASK) {
-        t->w_tmp_end.reserve((N + 4) * 4);
-        t->w_offsets.reserve((N + 4) * 8);
+        w->w_tmp_end.reserve((N + 4) * 4);
+        w->w_offsets.reserve((N + 4) * 8);
     }
-    if (flags & TKAMD_WANT_WORD_IDS) t->w_word_ids.reserve((N + 4) * 4);
+    if (flags & TKAMD_WANT_WORD_IDS) w->w_word_ids.reserve((N + 4) * 4);
 }
 
 // Enqueue the whole path on `st`.  Inputs and outputs are device pointers.
@@ -407,7 +428,7 @@ void reserve_workspace(tkamd_tokenizer* t, int64_t n_bytes, int64_t n_docs, uint
 // bytes deleted/replaced, w_norig maps back) or ByteLevel add_prefix_space inserted leading spaces
 // (documents shifted, mapped back per document).  When X is derived its length only exists on the
 // device (x_len_dev); kernels are launched over the host-side bound n_x and read the effective length.
-void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
+void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
                   uint32_t flags, hipStream_t st, tkamd_device_result* out) {
     HostModel& hm = t->hm;
     const uint32_t off_mode = flags & TKAMD_OFFSETS_MASK;
@@ -436,8 +457,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
                           "{Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
     if (prefix_space && hm.norm != NORM_NONE) throw Unsupported("ByteLevel add_prefix_space behind a normalizer");
 
-    reserve_workspace(t, n_x, n_docs, flags, want_meta);
-    int64_t* sc = t->w_scalars.as<int64_t>();
+    reserve_workspace(t, w, n_x, n_docs, flags, want_meta);
+    int64_t* sc = w->w_scalars.as<int64_t>();
     int64_t* d_npretok = sc + SC_NPRETOK;
     int64_t* d_ntok_total = sc + SC_NTOK;
     int64_t* d_xlen = sc + SC_NKEPT;
@@ -446,45 +467,45 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const int64_t W0 = (n_bytes >> 6) + 1;      // mask words over the original text
     const int64_t W = (n_x >> 6) + 1;           // mask words over the X text
     const int grid = t->n_cu * 8;
-    Prof pf{t, st};
+    Prof pf{t, w, st};
     using ull = unsigned long long;
 
     HIP_CHECK(hipMemsetAsync(sc, 0, SC_SLOTS * 8, st));
-    HIP_CHECK(hipMemsetAsync(t->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
-    out->d_ids = t->w_ids.as<uint32_t>();
-    out->d_tok_offsets = t->w_tok_offsets.as<int64_t>();
+    HIP_CHECK(hipMemsetAsync(w->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
+    out->d_ids = w->w_ids.as<uint32_t>();
+    out->d_tok_offsets = w->w_tok_offsets.as<int64_t>();
     out->d_offsets = nullptr;
     out->d_word_ids = nullptr;
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
-    t->last_n_docs = n_docs;
+    w->last_n_docs = n_docs;
     // the caller's CSR is validated once; everything below reads the validated copy
-    t->w_doc_off.reserve((size_t)(n_docs + 2) * 8);
+    w->w_doc_off.reserve((size_t)(n_docs + 2) * 8);
     pf.begin("validate_csr");
-    launch_validate_csr(st, d_doc_off, n_docs, n_bytes, d_err, t->w_doc_off.as<int64_t>());
+    launch_validate_csr(st, d_doc_off, n_docs, n_bytes, d_err, w->w_doc_off.as<int64_t>());
     pf.end();
-    d_doc_off = t->w_doc_off.as<int64_t>();
+    d_doc_off = w->w_doc_off.as<int64_t>();
     auto add_specials = [&]() {
         // PostProcessor::process for a single sequence (processors/bert.rs:51-120, template.rs:544-590): specials around every document
         const size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
-        t->w_ids2.reserve(T2 * 4);
-        t->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
-        if (out->d_offsets) t->w_offsets2.reserve(T2 * 8);
-        if (out->d_word_ids) t->w_word_ids2.reserve(T2 * 4);
+        w->w_ids2.reserve(T2 * 4);
+        w->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
+        if (out->d_offsets) w->w_offsets2.reserve(T2 * 8);
+        if (out->d_word_ids) w->w_word_ids2.reserve(T2 * 4);
         SpecialArgs sa{};
-        sa.tok_offsets = t->w_tok_offsets.as<int64_t>();
+        sa.tok_offsets = w->w_tok_offsets.as<int64_t>();
         sa.n_docs = n_docs;
-        sa.ids = t->w_ids.as<uint32_t>();
+        sa.ids = w->w_ids.as<uint32_t>();
         sa.offsets = out->d_offsets;
         sa.word_ids = out->d_word_ids;
         sa.prefix = t->t_pp_prefix.as<uint32_t>();
         sa.suffix = t->t_pp_suffix.as<uint32_t>();
         sa.n_prefix = (int32_t)hm.pp_prefix.size();
         sa.n_suffix = (int32_t)hm.pp_suffix.size();
-        sa.tok_offsets2 = t->w_tok_offsets2.as<int64_t>();
-        sa.ids2 = t->w_ids2.as<uint32_t>();
-        sa.offsets2 = t->w_offsets2.as<uint32_t>();
-        sa.word_ids2 = t->w_word_ids2.as<uint32_t>();
+        sa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
+        sa.ids2 = w->w_ids2.as<uint32_t>();
+        sa.offsets2 = w->w_offsets2.as<uint32_t>();
+        sa.word_ids2 = w->w_word_ids2.as<uint32_t>();
         sa.n_tok2 = sc + SC_NTOK2;
         pf.begin("add_specials");
         launch_add_specials(st, grid, sa);
@@ -501,9 +522,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         // truncation -> special tokens -> padding (tokenizer/mod.rs:1265-1317) as one epilogue over the token CSR
         const uint32_t n_add = add_special ? (uint32_t)(hm.pp_prefix.size() + hm.pp_suffix.size()) : 0u;
         FinalArgs fa{};
-        fa.tok_offsets = t->w_tok_offsets.as<int64_t>();
+        fa.tok_offsets = w->w_tok_offsets.as<int64_t>();
         fa.n_docs = n_docs;
-        fa.ids = t->w_ids.as<uint32_t>();
+        fa.ids = w->w_ids.as<uint32_t>();
         fa.offsets = out->d_offsets;
         fa.word_ids = out->d_word_ids;
         fa.prefix = t->t_pp_prefix.as<uint32_t>();
@@ -522,17 +543,17 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         fa.pad_multiple = hm.pad_multiple;
         fa.pad_left = hm.pad_left ? 1u : 0u;
         fa.pad_id = hm.pad_id;
-        t->w_len1.reserve((size_t)(n_docs + 2) * 4);
-        t->w_fin.reserve((size_t)(n_docs + 2) * 4);
-        t->w_fbsum.reserve((size_t)((n_docs + 1) / 256 + 2) * 4);
-        t->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
-        if (hm.pad_on) t->w_pad_count.reserve((size_t)(n_docs + 2) * 4);
-        fa.len1 = t->w_len1.as<uint32_t>();
-        fa.fin = t->w_fin.as<uint32_t>();
-        fa.bsum = t->w_fbsum.as<uint32_t>();
+        w->w_len1.reserve((size_t)(n_docs + 2) * 4);
+        w->w_fin.reserve((size_t)(n_docs + 2) * 4);
+        w->w_fbsum.reserve((size_t)((n_docs + 1) / 256 + 2) * 4);
+        w->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
+        if (hm.pad_on) w->w_pad_count.reserve((size_t)(n_docs + 2) * 4);
+        fa.len1 = w->w_len1.as<uint32_t>();
+        fa.fin = w->w_fin.as<uint32_t>();
+        fa.bsum = w->w_fbsum.as<uint32_t>();
         fa.target = (uint32_t*)(sc + SC_PADMAX);
-        fa.tok_offsets2 = t->w_tok_offsets2.as<int64_t>();
-        fa.pad_count = hm.pad_on ? t->w_pad_count.as<uint32_t>() : nullptr;
+        fa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
+        fa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
         fa.n_tok2 = sc + SC_NTOK2;
         fa.err = d_err;
         pf.begin("truncate_pad");
@@ -551,12 +572,12 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             T2 += (size_t)n_docs * (size_t)target;
             if ((uint64_t)T2 >= ((uint64_t)1 << 32)) throw Invalid("the padded batch would hold more than 2^32 tokens: pad fewer documents per call");
         }
-        t->w_ids2.reserve(T2 * 4);
-        if (out->d_offsets) t->w_offsets2.reserve(T2 * 8);
-        if (out->d_word_ids) t->w_word_ids2.reserve(T2 * 4);
-        fa.ids2 = t->w_ids2.as<uint32_t>();
-        fa.offsets2 = t->w_offsets2.as<uint32_t>();
-        fa.word_ids2 = t->w_word_ids2.as<uint32_t>();
+        w->w_ids2.reserve(T2 * 4);
+        if (out->d_offsets) w->w_offsets2.reserve(T2 * 8);
+        if (out->d_word_ids) w->w_word_ids2.reserve(T2 * 4);
+        fa.ids2 = w->w_ids2.as<uint32_t>();
+        fa.offsets2 = w->w_offsets2.as<uint32_t>();
+        fa.word_ids2 = w->w_word_ids2.as<uint32_t>();
         launch_final_offsets(st, fa);
         launch_finalize(st, grid, fa);
         pf.end();
@@ -569,12 +590,12 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     };
     if (n_bytes == 0) {
         // only empty documents: no tokens, but the post-processor still puts its specials around every one of them
-        HIP_CHECK(hipMemsetAsync(t->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
-        if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = t->w_offsets.as<uint32_t>();
-        if (want_words) out->d_word_ids = t->w_word_ids.as<uint32_t>();
+        HIP_CHECK(hipMemsetAsync(w->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
+        if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = w->w_offsets.as<uint32_t>();
+        if (want_words) out->d_word_ids = w->w_word_ids.as<uint32_t>();
         if (epilogue) finalize();
         else if (add_special) add_specials();
-        t->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
+        w->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -593,40 +614,40 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const size_t WX = (size_t)std::max(W0, W) + 2;             // mask words covering either text
     if (have_added) {
         seg_cap = (size_t)n_docs + 2 * (size_t)mcap + 2;
-        DevBuf* masks[6] = {&t->w_candmask, &t->w_matchmask, &t->w_spanmask, &t->w_stopmask, &t->w_hardmask, &t->w_boundmask};
+        DevBuf* masks[6] = {&w->w_candmask, &w->w_matchmask, &w->w_spanmask, &w->w_stopmask, &w->w_hardmask, &w->w_boundmask};
         for (DevBuf* b : masks) b->reserve(WX * 8);
-        t->w_match_docs.reserve((seg_cap + 1) * 4);
-        t->w_match_list.reserve(((size_t)mcap + 4) * 16);
-        mlist = t->w_match_list.as<uint32_t>();
+        w->w_match_docs.reserve((seg_cap + 1) * 4);
+        w->w_match_list.reserve(((size_t)mcap + 4) * 16);
+        mlist = w->w_match_list.as<uint32_t>();
     }
     auto args_of = [&](int c) {
         return AddedArgs{t->t_at_blob[c].as<uint8_t>(), t->t_at_off[c].as<uint32_t>(), t->t_at_first[c].as<uint32_t>(), t->t_at_id[c].as<uint32_t>(),
                          t->t_at_flags[c].as<uint32_t>()};
     };
     auto scatter_masks = [&](int64_t n_text, const int64_t* len_dev, bool with_end) {
-        ull* m4[4] = {t->w_matchmask.as<ull>(), t->w_spanmask.as<ull>(), t->w_stopmask.as<ull>(), t->w_hardmask.as<ull>()};
+        ull* m4[4] = {w->w_matchmask.as<ull>(), w->w_spanmask.as<ull>(), w->w_stopmask.as<ull>(), w->w_hardmask.as<ull>()};
         for (ull* m : m4) HIP_CHECK(hipMemsetAsync(m, 0, WX * 8, st));
-        launch_scatter_matches(st, mlist, n_match, n_text, len_dev, m4[0], m4[1], m4[2], m4[3], with_end ? t->w_tmp_end.as<uint32_t>() : nullptr);
+        launch_scatter_matches(st, mlist, n_match, n_text, len_dev, m4[0], m4[1], m4[2], m4[3], with_end ? w->w_tmp_end.as<uint32_t>() : nullptr);
     };
     // pieces of a text: what lies between document edges and match edges (boundary mask = docmask | hardmask), as an int64 CSR
     auto build_pieces = [&](const int64_t* doc_csr, int64_t n_text, const int64_t* len_dev) -> const int64_t* {
         const int64_t Wt = (n_text >> 6) + 1;
-        HIP_CHECK(hipMemsetAsync(t->w_boundmask.p, 0, WX * 8, st));
-        launch_mark_doc_starts_n(st, doc_csr, n_docs, n_text, len_dev, t->w_boundmask.as<ull>(), d_err);
-        launch_mask_or(st, t->w_boundmask.as<ull>(), t->w_hardmask.as<ull>(), Wt);
-        t->w_bprefix.reserve((size_t)(Wt + 2) * 4);
-        t->w_seg_off.reserve((seg_cap + 2) * 8);
-        launch_mask_scan(st, t->w_boundmask.as<ull>(), Wt, t->w_bsum.as<uint32_t>(), t->w_bprefix.as<uint32_t>(), d_nseg);
-        launch_emit_boundaries(st, t->w_boundmask.as<ull>(), t->w_bprefix.as<uint32_t>(), n_text, len_dev, d_nseg, t->w_seg_off.as<int64_t>());
-        return t->w_seg_off.as<int64_t>();
+        HIP_CHECK(hipMemsetAsync(w->w_boundmask.p, 0, WX * 8, st));
+        launch_mark_doc_starts_n(st, doc_csr, n_docs, n_text, len_dev, w->w_boundmask.as<ull>(), d_err);
+        launch_mask_or(st, w->w_boundmask.as<ull>(), w->w_hardmask.as<ull>(), Wt);
+        w->w_bprefix.reserve((size_t)(Wt + 2) * 4);
+        w->w_seg_off.reserve((seg_cap + 2) * 8);
+        launch_mask_scan(st, w->w_boundmask.as<ull>(), Wt, w->w_bsum.as<uint32_t>(), w->w_bprefix.as<uint32_t>(), d_nseg);
+        launch_emit_boundaries(st, w->w_boundmask.as<ull>(), w->w_bprefix.as<uint32_t>(), n_text, len_dev, d_nseg, w->w_seg_off.as<int64_t>());
+        return w->w_seg_off.as<int64_t>();
     };
 
     if (have_added) HIP_CHECK(hipMemsetAsync(n_match, 0, 4, st));
     if (have_raw) {
         // pass 1: the tokens with normalized = false, over the raw documents
         pf.begin("added_token_match");
-        launch_added_match(st, args_of(0), d_text, n_bytes, nullptr, d_doc_off, n_docs, nullptr, nullptr, t->dt.uc1, t->dt.uc2, t->w_candmask.as<ull>(),
-                           t->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS, mlist, n_match, mcap, MATCH_LEN_ORIG, d_err);
+        launch_added_match(st, args_of(0), d_text, n_bytes, nullptr, d_doc_off, n_docs, nullptr, nullptr, t->dt.uc1, t->dt.uc2, w->w_candmask.as<ull>(),
+                           w->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS, mlist, n_match, mcap, MATCH_LEN_ORIG, d_err);
         pf.end();
     }
 
@@ -636,38 +657,38 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     const uint32_t* norig = nullptr;
     const uint32_t* norig_e = nullptr;
     if (hm.norm == NORM_BERT || prefix_space) {
-        t->w_ntext.reserve((size_t)n_x + TKAMD_TEXT_PAD);
-        t->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
-        HIP_CHECK(hipMemsetAsync(t->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
+        w->w_ntext.reserve((size_t)n_x + TKAMD_TEXT_PAD);
+        w->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
+        HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
         if (off_mode != TKAMD_OFFSETS_NONE) {
-            t->w_norig.reserve(((size_t)n_x + 4) * 4);
-            t->w_norig_e.reserve(((size_t)n_x + 4) * 4);
-            norig = t->w_norig.as<uint32_t>();
-            norig_e = t->w_norig_e.as<uint32_t>();
+            w->w_norig.reserve(((size_t)n_x + 4) * 4);
+            w->w_norig_e.reserve(((size_t)n_x + 4) * 4);
+            norig = w->w_norig.as<uint32_t>();
+            norig_e = w->w_norig_e.as<uint32_t>();
         }
     }
     if (hm.norm == NORM_BERT) {
         // ---- BertNormalizer: text -> normalised text + original byte range of every normalised byte; the matches of pass 1 are
         // not text (their split carries the raw slice): copied verbatim ----
-        t->w_keepmask.reserve((size_t)n_bytes + 64);            // olen: output bytes per source byte
-        t->w_kprefix.reserve((size_t)(W0 + 1) * 4);             // wsum
-        t->w_wbase.reserve((size_t)(W0 + 1) * 4);
+        w->w_keepmask.reserve((size_t)n_bytes + 64);            // olen: output bytes per source byte
+        w->w_kprefix.reserve((size_t)(W0 + 1) * 4);             // wsum
+        w->w_wbase.reserve((size_t)(W0 + 1) * 4);
         BnTables bt{t->t_bn1.as<uint16_t>(), t->t_bn2.as<uint8_t>(), t->t_bn_map.as<MergeSlot>(), hm.bn_mask, hm.bn_seed,
                     hm.bn_clean_text, hm.bn_handle_chinese, hm.bn_strip_accents, hm.bn_lowercase};
         const ull* verbatim = nullptr;
         if (have_raw) {
             scatter_masks(n_bytes, nullptr, false);
-            launch_mask_or2(st, t->w_boundmask.as<ull>(), t->w_matchmask.as<ull>(), t->w_spanmask.as<ull>(), W0 + 1);
-            verbatim = t->w_boundmask.as<ull>();
+            launch_mask_or2(st, w->w_boundmask.as<ull>(), w->w_matchmask.as<ull>(), w->w_spanmask.as<ull>(), W0 + 1);
+            verbatim = w->w_boundmask.as<ull>();
         }
         pf.begin("bert_normalize");
-        launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, verbatim, t->w_keepmask.as<uint8_t>(), t->w_kprefix.as<uint32_t>(),
-                              t->w_bsum.as<uint32_t>(), t->w_wbase.as<uint32_t>(), d_xlen, t->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e,
-                              t->w_ndoc_off.as<int64_t>(), d_err);
+        launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, verbatim, w->w_keepmask.as<uint8_t>(), w->w_kprefix.as<uint32_t>(),
+                              w->w_bsum.as<uint32_t>(), w->w_wbase.as<uint32_t>(), d_xlen, w->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e,
+                              w->w_ndoc_off.as<int64_t>(), d_err);
         pf.end();
-        if (have_raw) launch_translate_matches_norm(st, mlist, n_match, t->w_keepmask.as<uint8_t>(), t->w_wbase.as<uint32_t>(), n_bytes, d_xlen);
-        x_text = t->w_ntext.as<uint8_t>();
-        x_doc_off = t->w_ndoc_off.as<int64_t>();
+        if (have_raw) launch_translate_matches_norm(st, mlist, n_match, w->w_keepmask.as<uint8_t>(), w->w_wbase.as<uint32_t>(), n_bytes, d_xlen);
+        x_text = w->w_ntext.as<uint8_t>();
+        x_doc_off = w->w_ndoc_off.as<int64_t>();
         x_len_dev = d_xlen;
     }
     // n_in / len_in: the text the second pass (and the prefix-space copy) reads
@@ -685,14 +706,14 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             nseg_bound = (int64_t)seg_cap;
         }
         pf.begin("added_token_match2");
-        launch_added_match(st, args_of(1), x_text, n_in, x_len_dev, seg, nseg_bound, nseg_dev, have_raw ? t->w_matchmask.as<ull>() : nullptr, t->dt.uc1, t->dt.uc2,
-                           t->w_candmask.as<ull>(), t->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS2, mlist, n_match, mcap,
+        launch_added_match(st, args_of(1), x_text, n_in, x_len_dev, seg, nseg_bound, nseg_dev, have_raw ? w->w_matchmask.as<ull>() : nullptr, t->dt.uc1, t->dt.uc2,
+                           w->w_candmask.as<ull>(), w->w_match_docs.as<uint32_t>(), d_counters + CNT_MATCH_DOCS2, mlist, n_match, mcap,
                            hm.norm == NORM_NONE ? MATCH_LEN_ORIG : 0u, d_err);
         pf.end();
     }
     if (have_added && !prefix_space) {
         scatter_masks(n_in, x_len_dev, off_mode != TKAMD_OFFSETS_NONE);
-        matchmask = t->w_matchmask.as<ull>();
+        matchmask = w->w_matchmask.as<ull>();
     }
     const int64_t* piece_off = nullptr;                        // sentence CSR for the Llama-3 sequential matcher when matches cut the documents
     const int64_t* piece_n_dev = nullptr;
@@ -706,26 +727,26 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             seg = build_pieces(d_doc_off, n_bytes, nullptr);
             nseg_dev = d_nseg;
             nseg_bound = (int64_t)seg_cap;
-            t->w_xseg_off.reserve((seg_cap + 2) * 8);
+            w->w_xseg_off.reserve((seg_cap + 2) * 8);
         }
-        t->w_need.reserve((size_t)(nseg_bound + 2) * 4);
-        t->w_need_bsum.reserve((size_t)((nseg_bound + 1) / 256 + 2) * 4);
-        int64_t* xseg = have_added ? t->w_xseg_off.as<int64_t>() : t->w_ndoc_off.as<int64_t>();
+        w->w_need.reserve((size_t)(nseg_bound + 2) * 4);
+        w->w_need_bsum.reserve((size_t)((nseg_bound + 1) / 256 + 2) * 4);
+        int64_t* xseg = have_added ? w->w_xseg_off.as<int64_t>() : w->w_ndoc_off.as<int64_t>();
         pf.begin("prefix_space");
-        launch_prefix_space(st, d_text, seg, nseg_bound, nseg_dev, have_added ? t->w_matchmask.as<ull>() : nullptr, t->w_need.as<uint32_t>(),
-                            t->w_need_bsum.as<uint32_t>(), xseg, d_xlen, t->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e, grid);
+        launch_prefix_space(st, d_text, seg, nseg_bound, nseg_dev, have_added ? w->w_matchmask.as<ull>() : nullptr, w->w_need.as<uint32_t>(),
+                            w->w_need_bsum.as<uint32_t>(), xseg, d_xlen, w->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e, grid);
         if (have_added) {
             // documents and matches in the shifted text: both start at piece boundaries
-            launch_prefix_doc_csr(st, d_doc_off, n_docs, t->w_boundmask.as<ull>(), t->w_bprefix.as<uint32_t>(), n_bytes, nullptr, d_nseg, xseg, t->w_ndoc_off.as<int64_t>());
-            launch_translate_matches_prefix(st, mlist, n_match, t->w_boundmask.as<ull>(), t->w_bprefix.as<uint32_t>(), n_bytes, nullptr, d_nseg, xseg);
+            launch_prefix_doc_csr(st, d_doc_off, n_docs, w->w_boundmask.as<ull>(), w->w_bprefix.as<uint32_t>(), n_bytes, nullptr, d_nseg, xseg, w->w_ndoc_off.as<int64_t>());
+            launch_translate_matches_prefix(st, mlist, n_match, w->w_boundmask.as<ull>(), w->w_bprefix.as<uint32_t>(), n_bytes, nullptr, d_nseg, xseg);
         }
         pf.end();
-        x_text = t->w_ntext.as<uint8_t>();
-        x_doc_off = t->w_ndoc_off.as<int64_t>();
+        x_text = w->w_ntext.as<uint8_t>();
+        x_doc_off = w->w_ndoc_off.as<int64_t>();
         x_len_dev = d_xlen;
         if (have_added) {
             scatter_masks(n_x, x_len_dev, off_mode != TKAMD_OFFSETS_NONE);
-            matchmask = t->w_matchmask.as<ull>();
+            matchmask = w->w_matchmask.as<ull>();
             piece_off = xseg;
             piece_n_dev = d_nseg;
         }
@@ -735,8 +756,8 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     }
 
     pf.begin("mark_doc_starts");
-    launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_x, x_len_dev, t->w_docmask.as<ull>(), d_err);
-    if (matchmask) launch_mask_or(st, t->w_docmask.as<ull>(), t->w_hardmask.as<ull>(), W);   // match edges are hard boundaries
+    launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_x, x_len_dev, w->w_docmask.as<ull>(), d_err);
+    if (matchmask) launch_mask_or(st, w->w_docmask.as<ull>(), w->w_hardmask.as<ull>(), W);   // match edges are hard boundaries
     pf.end();
 
     uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
@@ -752,74 +773,70 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
             return 2;                                        // lane-per-32-bytes sequential kernel (default)
         }();
         pf.begin(variant == 2 ? "pretok_gpt2_seq" : (variant == 1 ? "pretok_gpt2_bits" : "pretok_gpt2"));
-        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(), variant);
+        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(), variant);
         pf.end();
     } else if (hm.pretok == PT_LLAMA3) {
-        t->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
-        t->w_slow_docs.reserve((size_t)(n_docs + 1) * 4);
+        w->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
+        w->w_slow_docs.reserve((size_t)(n_docs + 1) * 4);
         pf.begin("pretok_llama3");
-        t->w_slow_docs.reserve((size_t)((piece_off ? seg_cap : (size_t)n_docs) + 1) * 4);
-        launch_pretok_llama3(st, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, t->w_startmask.as<ull>(),
-                             t->w_endmask.as<ull>(), piece_off ? piece_off : x_doc_off, piece_off ? (int64_t)seg_cap : n_docs, piece_n_dev,
-                             t->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
+        w->w_slow_docs.reserve((size_t)((piece_off ? seg_cap : (size_t)n_docs) + 1) * 4);
+        launch_pretok_llama3(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(),
+                             w->w_endmask.as<ull>(), piece_off ? piece_off : x_doc_off, piece_off ? (int64_t)seg_cap : n_docs, piece_n_dev,
+                             w->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
         pf.end();
     } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
         // ByteLevel(use_regex=false): every document is one pre-token (byte_level.rs:128-130)
-        HIP_CHECK(hipMemcpyAsync(t->w_startmask.p, t->w_docmask.p, (size_t)W * 8, hipMemcpyDeviceToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(w->w_startmask.p, w->w_docmask.p, (size_t)W * 8, hipMemcpyDeviceToDevice, st));
     } else {
-        t->w_endmask.reserve((size_t)(W + 1) * 8);
+        w->w_endmask.reserve((size_t)(W + 1) * 8);
         has_end = true;
         if (want_meta) {
-            t->w_pt_end.reserve(((size_t)n_x + 4) * 4);
-            pt_end = t->w_pt_end.as<uint32_t>();
+            w->w_pt_end.reserve(((size_t)n_x + 4) * 4);
+            pt_end = w->w_pt_end.as<uint32_t>();
         }
         pf.begin("pretok_local");
-        launch_pretok_local(st, (int)hm.pretok, x_text, n_x, x_len_dev, t->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
-                            t->w_startmask.as<ull>(), t->w_endmask.as<ull>());
+        launch_pretok_local(st, (int)hm.pretok, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
+                            w->w_startmask.as<ull>(), w->w_endmask.as<ull>());
         pf.end();
     }
     if (matchmask)
-        launch_apply_matches(st, t->w_startmask.as<ull>(), has_end ? t->w_endmask.as<ull>() : nullptr, matchmask, t->w_spanmask.as<ull>(),
-                             t->w_stopmask.as<ull>(), W);
+        launch_apply_matches(st, w->w_startmask.as<ull>(), has_end ? w->w_endmask.as<ull>() : nullptr, matchmask, w->w_spanmask.as<ull>(),
+                             w->w_stopmask.as<ull>(), W);
     pf.begin("mask_scan");
-    launch_mask_scan(st, t->w_startmask.as<ull>(), W, t->w_bsum.as<uint32_t>(), t->w_wprefix.as<uint32_t>(), d_npretok);
+    launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
     if (want_meta) {
         // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
         // the bitmasks (k_lookup) and from (start, length) queue entries
         pf.begin("emit_pretok");
-        launch_emit_pretok(st, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, t->w_pt_start.as<uint32_t>());
-        if (pt_end) launch_emit_pretok_end(st, t->w_startmask.as<ull>(), t->w_endmask.as<ull>(), t->w_wprefix.as<uint32_t>(), n_x, pt_end);
+        launch_emit_pretok(st, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, w->w_pt_start.as<uint32_t>());
+        if (pt_end) launch_emit_pretok_end(st, w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, pt_end);
         pf.end();
     }
     pf.begin("doc_first_pretok");
-    launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, t->w_startmask.as<ull>(), t->w_wprefix.as<uint32_t>(),
-                            d_npretok, t->w_doc_pt.as<uint32_t>());
+    launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
+                            d_npretok, w->w_doc_pt.as<uint32_t>());
     pf.end();
 
-    uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? t->w_tmp_end.as<uint32_t>() : nullptr;
+    uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
     const size_t N = (size_t)n_x;
     const QueueSizes qz = queue_sizes(N, t->q16_div);
     QueuePlan plan{};
     for (int c = 0; c < 4; ++c) {
-        plan.v[c].q = (QItem*)(t->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);
-        plan.v[c].counts = t->w_qcount.as<uint32_t>() + (size_t)c * NSQ * QCNT_STRIDE;
+        plan.v[c].q = (QItem*)(w->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);
+        plan.v[c].counts = w->w_qcount.as<uint32_t>() + (size_t)c * NSQ * QCNT_STRIDE;
         plan.v[c].sq_cap = qz.sq_cap[c];
         plan.v[c].row_base = qz.row_base[c];
     }
-    HIP_CHECK(hipMemsetAsync(t->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
-    if (!t->long_prepared) {
-        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
-        t->long_prepared = true;
-    }
-    const ull* endmask = has_end ? t->w_endmask.as<ull>() : nullptr;
+    HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
+    const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
-        launch_lookup(st, 2 * t->n_cu, t->dt, x_text, n_x, x_len_dev, t->w_startmask.as<ull>(), endmask, t->w_wprefix.as<uint32_t>(),
-                      t->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 0u);
+        launch_lookup(st, 2 * t->n_cu, t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 0u);
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
-            for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], t->w_rows.p, 0u, d_err);
+            for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err);
         // TKAMD_MERGE16 = row / lane, TKAMD_LDSCFG = 0: the 16-lane DPP-row kernel / the register-resident lane kernels (A/B
         // switches; the lane kernels are also what runs when new_id is not rank + c)
         static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 2; }();
@@ -828,27 +845,27 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // keys in LDS (default when new_id = rank + c)
         const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
-        launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge64");
-        launch_bpe_merge(st, grid, 64, t->dt, x_text, plan.v[2], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(st, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge_long");
         // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
         // worst case this batch can contain (the whole X text being such pre-tokens), capped at 1 GiB
         const size_t huge_words = std::min<size_t>((size_t)6 * N + 4096, (size_t)1 << 28);
         if (N > (size_t)LONG_PT_MAX) {
-            t->w_huge.reserve(huge_words * 4);
-            t->w_list_huge.reserve((N / LONG_PT_MAX + 16) * 4);
+            w->w_huge.reserve(huge_words * 4);
+            w->w_list_huge.reserve((N / LONG_PT_MAX + 16) * 4);
         } else {
-            t->w_huge.reserve(64);
-            t->w_list_huge.reserve(64);
+            w->w_huge.reserve(64);
+            w->w_list_huge.reserve(64);
         }
-        launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, plan.v[3], t->w_rows.p,
-                              t->w_tmp_ids.as<uint32_t>(), tmp_end, t->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, t->w_huge.as<uint32_t>(),
+        launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, plan.v[3], w->w_rows.p,
+                              w->w_tmp_ids.as<uint32_t>(), tmp_end, w->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, w->w_huge.as<uint32_t>(),
                               (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
     } else if (hm.model == MODEL_WORDLEVEL) {
@@ -856,9 +873,9 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         DevTables wt = t->dt;
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
-        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, t->w_startmask.as<ull>(), endmask, t->w_wprefix.as<uint32_t>(),
-                      t->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 1u);
-        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], t->w_rows.p, 1u, d_err);      // words longer than 16 bytes
+        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 1u);
+        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err);      // words longer than 16 bytes
         pf.end();
     } else {
         // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): the whole-word lookup
@@ -869,38 +886,37 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         wt.ignore_merges = 1;                              // any whole-word hit is final
         wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
         pf.begin("wordpiece_word_lookup");
-        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, t->w_startmask.as<ull>(), endmask, t->w_wprefix.as<uint32_t>(),
-                      t->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, shortcut ? 0u : 1u, 0u);
+        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, shortcut ? 0u : 1u, 0u);
         pf.end();
         pf.begin("wordpiece");
         for (int c = 0; c < 4; ++c)
-            launch_wordpiece(st, c == 0 ? grid : t->n_cu, t->dt, x_text, plan.v[c], t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+            launch_wordpiece(st, c == 0 ? grid : t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
         pf.end();
     }
     if (matchmask)
-        launch_apply_match_ids(st, t->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, t->w_startmask.as<ull>(),
-                               t->w_wprefix.as<uint32_t>(), t->w_tok0.as<uint32_t>());
+        launch_apply_match_ids(st, w->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, w->w_startmask.as<ull>(),
+                               w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
     pf.begin("compact");
-    HIP_CHECK(hipMemsetAsync(t->w_cstate.p, 0, (N / COMPACT_CHUNK + 4) * 8, st));
-    if (!t->cp_grid) t->cp_grid = compact_grid(t->n_cu);
-    launch_compact(st, t->cp_grid, t->w_tok0.as<uint32_t>(), t->w_rows.p, t->w_tmp_ids.as<uint32_t>(), d_npretok, t->w_cstate.as<ull>(),
-                   d_ntok_total, t->w_pt_tokoff.as<uint32_t>(), t->w_ids.as<uint32_t>());
+    HIP_CHECK(hipMemsetAsync(w->w_cstate.p, 0, (N / COMPACT_CHUNK + 4) * 8, st));
+    launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
+                   d_ntok_total, w->w_pt_tokoff.as<uint32_t>(), w->w_ids.as<uint32_t>());
     pf.end();
     pf.begin("doc_tok_offsets");
-    launch_doc_tok_offsets(st, t->w_doc_pt.as<uint32_t>(), n_docs, t->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
-                           t->w_tok_offsets.as<int64_t>());
+    launch_doc_tok_offsets(st, w->w_doc_pt.as<uint32_t>(), n_docs, w->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
+                           w->w_tok_offsets.as<int64_t>());
     pf.end();
     if (want_meta) {
         MetaArgs a{};
         a.x_text = x_text;
         a.text = d_text;
-        a.pt_start = t->w_pt_start.as<uint32_t>();
+        a.pt_start = w->w_pt_start.as<uint32_t>();
         a.pt_end = pt_end;
         a.n_tok = d_ntok_total;
-        a.pt_tokoff = t->w_pt_tokoff.as<uint32_t>();
+        a.pt_tokoff = w->w_pt_tokoff.as<uint32_t>();
         a.tmp_end = tmp_end;
         a.n_pretok = d_npretok;
-        a.doc_pt = t->w_doc_pt.as<uint32_t>();
+        a.doc_pt = w->w_doc_pt.as<uint32_t>();
         a.n_docs = n_docs;
         a.x_doc_off = x_doc_off;
         a.doc_off = d_doc_off;
@@ -915,17 +931,17 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
         a.matchmask = matchmask;
         a.uc1 = t->dt.uc1;
         a.uc2 = t->dt.uc2;
-        a.offsets = t->w_offsets.as<uint32_t>();
-        a.word_ids = t->w_word_ids.as<uint32_t>();
+        a.offsets = w->w_offsets.as<uint32_t>();
+        a.word_ids = w->w_word_ids.as<uint32_t>();
         if (a.char_mode) {
-            t->w_leadmask.reserve((size_t)(W0 + 1) * 8);
-            t->w_lprefix.reserve((size_t)(W0 + 1) * 4);
+            w->w_leadmask.reserve((size_t)(W0 + 1) * 8);
+            w->w_lprefix.reserve((size_t)(W0 + 1) * 4);
             pf.begin("leadmask_scan");
-            launch_leadmask(st, d_text, n_bytes, t->w_leadmask.as<ull>());
-            launch_mask_scan(st, t->w_leadmask.as<ull>(), W0, t->w_bsum.as<uint32_t>(), t->w_lprefix.as<uint32_t>(), sc + SC_NCHARS);
+            launch_leadmask(st, d_text, n_bytes, w->w_leadmask.as<ull>());
+            launch_mask_scan(st, w->w_leadmask.as<ull>(), W0, w->w_bsum.as<uint32_t>(), w->w_lprefix.as<uint32_t>(), sc + SC_NCHARS);
             pf.end();
-            a.leadmask = t->w_leadmask.as<ull>();
-            a.lprefix = t->w_lprefix.as<uint32_t>();
+            a.leadmask = w->w_leadmask.as<ull>();
+            a.lprefix = w->w_lprefix.as<uint32_t>();
         }
         pf.begin("token_meta");
         launch_token_meta(st, grid, a);
@@ -935,35 +951,35 @@ void run_pipeline(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_do
     }
     if (epilogue) finalize();
     else if (add_special) add_specials();
-    t->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
+    w->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
     HIP_CHECK(hipGetLastError());
 }
 
-int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok);
+int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok);
 
 // Wait for the batch enqueued last; if its <= 16-byte work queue overflowed (ERR_QUEUE_FULL), grow the queue and run the
 // same call again on the same stream (the output buffers are sized for the worst case, so the result pointers stay).
-int finish_batch(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
-    int bits = read_scalars(t, st, n_tok, n_pretok);
+int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
+    int bits = read_scalars(t, w, st, n_tok, n_pretok);
     while ((bits & ERR_QUEUE_FULL) && !(bits & ~ERR_QUEUE_FULL) && t->q16_div > 2) {
         t->q16_div = 2;                                  // n_bytes / 2 + 1024 entries: a queued pre-token has at least two bytes
         tkamd_device_result again{};
-        run_pipeline(t, t->last_text, t->last_doc_off, t->last_n_docs, t->last_n_bytes, t->last_flags, st, &again);
-        if (again.d_ids != t->last_result.d_ids || again.d_tok_offsets != t->last_result.d_tok_offsets ||
-            again.d_offsets != t->last_result.d_offsets || again.d_word_ids != t->last_result.d_word_ids || again.d_pad_counts != t->last_result.d_pad_counts)
+        run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_flags, st, &again);
+        if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
+            again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts)
             throw HipError("result buffers moved while a batch was run again");
-        bits = read_scalars(t, st, n_tok, n_pretok);
+        bits = read_scalars(t, w, st, n_tok, n_pretok);
     }
     return bits;
 }
 
-int read_scalars(tkamd_tokenizer* t, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
+int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
     int64_t host[SC_SLOTS];
-    HIP_CHECK(hipMemcpyAsync(host, t->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
+    HIP_CHECK(hipMemcpyAsync(host, w->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
     int err = *(int*)&host[SC_ERR];
-    memcpy(t->last_counters, &host[SC_COUNTERS], sizeof(t->last_counters));
-    if (n_tok) *n_tok = host[t->last_ntok_slot];
+    memcpy(w->last_counters, &host[SC_COUNTERS], sizeof(w->last_counters));
+    if (n_tok) *n_tok = host[w->last_ntok_slot];
     if (n_pretok) *n_pretok = host[SC_NPRETOK];
     return err;
 }
@@ -999,6 +1015,56 @@ int guarded(F&& f) {
     }
 }
 
+// ---- workspace pool ----
+Workspace* acquire_host(tkamd_tokenizer* t) {
+    std::unique_lock<std::mutex> lk(t->mu);
+    for (;;) {
+        size_t n_host = 0;
+        for (auto& w : t->pool) {
+            if (w->device_bound) continue;
+            ++n_host;
+            if (!w->busy) { w->busy = true; t->last_used = w.get(); return w.get(); }
+        }
+        if (n_host < MAX_HOST_WORKSPACES) {
+            t->pool.emplace_back(new Workspace());
+            Workspace* w = t->pool.back().get();
+            w->busy = true;
+            t->last_used = w;
+            return w;
+        }
+        t->cv.wait(lk);
+    }
+}
+void release_host(tkamd_tokenizer* t, Workspace* w) {
+    { std::lock_guard<std::mutex> lk(t->mu); w->busy = false; }
+    t->cv.notify_one();
+}
+struct HostLease {
+    tkamd_tokenizer* t;
+    Workspace* w;
+    HostLease(tkamd_tokenizer* t_) : t(t_), w(acquire_host(t_)) {}
+    ~HostLease() { release_host(t, w); }
+    HostLease(const HostLease&) = delete;
+    HostLease& operator=(const HostLease&) = delete;
+};
+hipStream_t own_stream(Workspace* w) {
+    if (!w->own_stream) HIP_CHECK(hipStreamCreateWithFlags(&w->own_stream, hipStreamNonBlocking));
+    return w->own_stream;
+}
+// the device entry keeps one workspace per caller stream: the results of a call stay valid in it until the next call on that stream
+Workspace* workspace_of_stream(tkamd_tokenizer* t, hipStream_t st, bool create) {
+    std::lock_guard<std::mutex> lk(t->mu);
+    for (auto& w : t->pool)
+        if (w->device_bound && w->bound_stream == st) { t->last_used = w.get(); return w.get(); }
+    if (!create) return nullptr;
+    t->pool.emplace_back(new Workspace());
+    Workspace* w = t->pool.back().get();
+    w->device_bound = true;
+    w->bound_stream = st;
+    t->last_used = w;
+    return w;
+}
+
 }  // namespace
 
 #pragma GCC visibility push(default)
@@ -1026,6 +1092,8 @@ int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tka
             upload_tables(t.get());
             verify_direct_words(t.get());
             build_hot_table(t.get());
+            if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
+            t->cp_grid = compact_grid(t->n_cu);
         }
         *out = t.release();
         return TKAMD_OK;
@@ -1036,7 +1104,9 @@ void tkamd_tokenizer_free(tkamd_tokenizer* t) {
     if (!t) return;
     if (t->device >= 0) {
         (void)hipSetDevice(t->device);
-        drain_profile(t);
+        (void)hipDeviceSynchronize();
+        std::lock_guard<std::mutex> lk(t->mu);
+        for (auto& w : t->pool) drain_profile(t, w.get());
     }
     delete t;
 }
@@ -1080,10 +1150,11 @@ int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const i
         return set_error(TKAMD_ERR_INVALID, "bad argument");
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
     return guarded([&]() -> int {
-        std::lock_guard<std::mutex> lk(t->mu);
+        Workspace* w = workspace_of_stream(t, (hipStream_t)hip_stream, true);
+        std::lock_guard<std::mutex> lk(w->mu);
         HIP_CHECK(hipSetDevice(t->device));
-        run_pipeline(t, d_text, d_doc_offsets, n_docs, n_bytes, flags, (hipStream_t)hip_stream, out);
-        t->last_text = d_text; t->last_doc_off = d_doc_offsets; t->last_n_bytes = n_bytes; t->last_flags = flags; t->last_result = *out;
+        run_pipeline(t, w, d_text, d_doc_offsets, n_docs, n_bytes, flags, (hipStream_t)hip_stream, out);
+        w->last_text = d_text; w->last_doc_off = d_doc_offsets; w->last_n_bytes = n_bytes; w->last_flags = flags; w->last_result = *out;
         return TKAMD_OK;
     });
 }
@@ -1091,59 +1162,133 @@ int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const i
 int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens) {
     if (!t || t->device < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
     return guarded([&]() -> int {
-        std::lock_guard<std::mutex> lk(t->mu);
+        Workspace* w = workspace_of_stream(t, (hipStream_t)hip_stream, false);
+        if (!w) throw Invalid("tkamd_device_sync: no encode call was made on this stream");
+        std::lock_guard<std::mutex> lk(w->mu);
         HIP_CHECK(hipSetDevice(t->device));
-        int bits = finish_batch(t, (hipStream_t)hip_stream, n_tokens, n_pretokens);
+        int bits = finish_batch(t, w, (hipStream_t)hip_stream, n_tokens, n_pretokens);
         return error_from_bits(bits);
     });
 }
 
+// Host entry.  The batch is cut into document-aligned slices that alternate between two workspaces, each on its own stream:
+// while slice k's kernels run, slice k+1's text crosses the bus and slice k-1's ids go back (H2D, kernels and D2H use different
+// engines).  Small batches, and BatchLongest padding (its target is a property of the whole batch), go as one slice.
 int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
                        tkamd_batch** out) {
     if (!t || !out || !doc_offsets || n_docs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
     *out = nullptr;
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
     return guarded([&]() -> int {
-        std::lock_guard<std::mutex> lk(t->mu);
         HIP_CHECK(hipSetDevice(t->device));
-        int64_t n_bytes = doc_offsets[n_docs];
+        const int64_t n_bytes = doc_offsets[n_docs];
         if (n_bytes < 0 || doc_offsets[0] != 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
         if (n_bytes > 0 && !text) throw Invalid("null text");
-        hipStream_t st = nullptr;
-        t->h_text.reserve((size_t)n_bytes + TKAMD_TEXT_PAD);
-        t->h_doc_off.reserve((size_t)(n_docs + 1) * 8);
-        if (n_bytes) HIP_CHECK(hipMemcpyAsync(t->h_text.p, text, (size_t)n_bytes, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemsetAsync((uint8_t*)t->h_text.p + n_bytes, 0, TKAMD_TEXT_PAD, st));
-        HIP_CHECK(hipMemcpyAsync(t->h_doc_off.p, doc_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
-        tkamd_device_result r{};
-        run_pipeline(t, t->h_text.as<uint8_t>(), t->h_doc_off.as<int64_t>(), n_docs, n_bytes, flags, st, &r);
-        t->last_text = t->h_text.as<uint8_t>(); t->last_doc_off = t->h_doc_off.as<int64_t>(); t->last_n_bytes = n_bytes; t->last_flags = flags; t->last_result = r;
-        int64_t n_tok = 0, n_pt = 0;
-        int bits = finish_batch(t, st, &n_tok, &n_pt);
-        if (bits) return error_from_bits(bits);
+        static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
+        int n_slices = (int)std::min<int64_t>(8, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
+        if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed)) n_slices = 1;
+        // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
+        // device validation of each slice reports it)
+        std::vector<int64_t> cut(n_slices + 1, 0);
+        cut[n_slices] = n_docs;
+        for (int k = 1; k < n_slices; ++k) {
+            const int64_t target = n_bytes / n_slices * k;
+            cut[k] = std::max<int64_t>(cut[k - 1], std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets);
+        }
+        HostLease l0(t);
+        std::unique_ptr<HostLease> l1(n_slices > 1 ? new HostLease(t) : nullptr);
+        Workspace* ws[2] = {l0.w, l1 ? l1->w : l0.w};
+        std::lock_guard<std::mutex> g0(ws[0]->mu);
+        std::unique_ptr<std::lock_guard<std::mutex>> g1(l1 ? new std::lock_guard<std::mutex>(ws[1]->mu) : nullptr);
+        hipStream_t st[2] = {own_stream(ws[0]), own_stream(ws[1])};
+
         std::unique_ptr<tkamd_batch> b(new tkamd_batch());
         b->n_docs = n_docs;
-        b->n_tokens = n_tok;
-        b->ids = pinned_get((size_t)n_tok * 4);
         b->tok_offsets = pinned_get((size_t)(n_docs + 1) * 8);
-        if (n_tok) HIP_CHECK(hipMemcpyAsync(b->ids.p, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(b->tok_offsets.p, r.d_tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, st));
-        if (r.d_offsets) {
-            b->has_offsets = true;
-            b->offsets = pinned_get((size_t)n_tok * 8);
-            if (n_tok) HIP_CHECK(hipMemcpyAsync(b->offsets.p, r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost, st));
+        tkamd_device_result res[8]{};
+        int64_t slice_tok[8] = {0};
+        size_t tok_cap = 0;
+        int64_t tok_base = 0;
+        auto grow = [&](PinnedBlock& blk, size_t unit, size_t need_tokens, size_t have_tokens) {
+            // (rare after the first estimate: move what has arrived into a bigger pinned block)
+            PinnedBlock nb = pinned_get(need_tokens * unit);
+            if (blk.p && have_tokens) memcpy(nb.p, blk.p, have_tokens * unit);
+            pinned_put(blk);
+            blk = nb;
+        };
+        auto issue = [&](int k) {
+            Workspace* w = ws[k & 1];
+            hipStream_t s = st[k & 1];
+            const int64_t d0 = cut[k], d1 = cut[k + 1], b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
+            if (nb < 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+            w->h_text.reserve((size_t)nb + TKAMD_TEXT_PAD);
+            w->h_doc_off.reserve((size_t)(d1 - d0 + 1) * 8);
+            if (nb) HIP_CHECK(hipMemcpyAsync(w->h_text.p, text + b0, (size_t)nb, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + nb, 0, TKAMD_TEXT_PAD, s));
+            HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, s));
+            if (b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), d1 - d0 + 1, -b0);           // the slice's own CSR starts at 0
+            run_pipeline(t, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), d1 - d0, nb, flags, s, &res[k]);
+            w->last_text = w->h_text.as<uint8_t>(); w->last_doc_off = w->h_doc_off.as<int64_t>(); w->last_n_bytes = nb; w->last_flags = flags; w->last_result = res[k];
+        };
+        auto finish = [&](int k) -> int {
+            Workspace* w = ws[k & 1];
+            hipStream_t s = st[k & 1];
+            int64_t n_tok = 0, n_pt = 0;
+            const int bits = finish_batch(t, w, s, &n_tok, &n_pt);
+            if (bits) return bits;
+            const tkamd_device_result& r = res[k];
+            const int64_t d0 = cut[k], d1 = cut[k + 1];
+            slice_tok[k] = n_tok;
+            const size_t need = (size_t)(tok_base + n_tok);
+            if (need > tok_cap) {
+                // estimate the whole batch from what has been seen: tokens per byte so far, 12 % headroom
+                const int64_t seen = doc_offsets[d1];
+                size_t est = (k + 1 == n_slices || seen <= 0) ? need : (size_t)((double)need * (double)n_bytes / (double)seen * 1.12) + 4096;
+                est = std::max(est, need);
+                if (k) {                                        // earlier slices' copies are still landing in the old blocks
+                    HIP_CHECK(hipStreamSynchronize(st[0]));
+                    HIP_CHECK(hipStreamSynchronize(st[1]));
+                }
+                grow(b->ids, 4, est, (size_t)tok_base);
+                if (r.d_offsets) grow(b->offsets, 8, est, (size_t)tok_base);
+                if (r.d_word_ids) grow(b->word_ids, 4, est, (size_t)tok_base);
+                tok_cap = est;
+            }
+            if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
+            if (tok_base) launch_add_i64(s, (int64_t*)r.d_tok_offsets, d1 - d0 + 1, tok_base);   // the slice's CSR continues the batch's
+            HIP_CHECK(hipMemcpyAsync((int64_t*)b->tok_offsets.p + d0, r.d_tok_offsets, (size_t)(d1 - d0 + 1) * 8, hipMemcpyDeviceToHost, s));
+            if (r.d_offsets) {
+                b->has_offsets = true;
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->offsets.p + 2 * tok_base, r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost, s));
+            }
+            if (r.d_word_ids) {
+                b->has_words = true;
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->word_ids.p + tok_base, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
+            }
+            if (r.d_pad_counts) {
+                if (!b->has_pads) { b->has_pads = true; b->pad_counts = pinned_get((size_t)(n_docs + 1) * 4); }
+                if (d1 > d0) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->pad_counts.p + d0, r.d_pad_counts, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, s));
+            }
+            tok_base += n_tok;
+            return 0;
+        };
+        int bits = 0;
+        try {
+            issue(0);
+            for (int k = 0; k < n_slices && !bits; ++k) {
+                if (k + 1 < n_slices) issue(k + 1);             // slice k+1 is on the other stream: enqueued before we wait for slice k
+                bits = finish(k);
+            }
+        } catch (...) {
+            (void)hipStreamSynchronize(st[0]);
+            (void)hipStreamSynchronize(st[1]);
+            throw;
         }
-        if (r.d_word_ids) {
-            b->has_words = true;
-            b->word_ids = pinned_get((size_t)n_tok * 4);
-            if (n_tok) HIP_CHECK(hipMemcpyAsync(b->word_ids.p, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, st));
-        }
-        if (r.d_pad_counts) {
-            b->has_pads = true;
-            b->pad_counts = pinned_get((size_t)(n_docs + 1) * 4);
-            if (n_docs) HIP_CHECK(hipMemcpyAsync(b->pad_counts.p, r.d_pad_counts, (size_t)n_docs * 4, hipMemcpyDeviceToHost, st));
-        }
-        HIP_CHECK(hipStreamSynchronize(st));
+        HIP_CHECK(hipStreamSynchronize(st[0]));
+        HIP_CHECK(hipStreamSynchronize(st[1]));
+        if (bits) return error_from_bits(bits);
+        b->n_tokens = tok_base;
+        if (!b->ids.p) b->ids = pinned_get(64);
         *out = b.release();
         return TKAMD_OK;
     });
@@ -1165,51 +1310,53 @@ int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* t
     *out = nullptr;
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
     return guarded([&]() -> int {
-        std::lock_guard<std::mutex> lk(t->mu);
         const HostModel& hm = t->hm;
         if (hm.decoder == DEC_UNSUPPORTED) throw Unsupported("decode_batch: " + hm.dec_unsupported);
         HIP_CHECK(hipSetDevice(t->device));
+        HostLease lease(t);
+        Workspace* w = lease.w;
+        std::lock_guard<std::mutex> lk(w->mu);
         const int64_t n_tok = tok_offsets[n_docs];
         if (n_tok < 0 || tok_offsets[0] != 0) throw Invalid("tok_offsets is not a monotone CSR over [0, n_tokens]");
         for (int64_t d = 0; d < n_docs; ++d)
             if (tok_offsets[d + 1] < tok_offsets[d]) throw Invalid("tok_offsets is not monotone");
         if (n_tok > 0 && !ids) throw Invalid("null ids");
         if (n_tok >= ((int64_t)1 << 31)) throw Invalid("more than 2^31 tokens in one decode_batch call");
-        hipStream_t st = nullptr;
+        hipStream_t st = own_stream(w);
         const uint32_t n_ids = (uint32_t)(hm.dec_entry.size() / 4);
         const size_t nb = (size_t)(n_tok / 256 + 2);
-        t->dw_ids.reserve((size_t)n_tok * 4 + 64);
-        t->dw_tok_off.reserve((size_t)(n_docs + 1) * 8);
-        t->dw_first.reserve((size_t)(n_tok / 32 + 2) * 4);
-        t->dw_len.reserve((size_t)n_tok * 4 + 64);
-        t->dw_bsum.reserve(nb * 4);
-        t->dw_pos.reserve((size_t)n_tok * 4 + 64);
-        t->dw_out_off.reserve((size_t)(n_docs + 1) * 8);
-        t->dw_total.reserve(64);
-        if (n_tok) HIP_CHECK(hipMemcpyAsync(t->dw_ids.p, ids, (size_t)n_tok * 4, hipMemcpyHostToDevice, st));
-        HIP_CHECK(hipMemcpyAsync(t->dw_tok_off.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
-        uint32_t* firstmask = hm.dec_position_dependent ? t->dw_first.as<uint32_t>() : nullptr;
+        w->dw_ids.reserve((size_t)n_tok * 4 + 64);
+        w->dw_tok_off.reserve((size_t)(n_docs + 1) * 8);
+        w->dw_first.reserve((size_t)(n_tok / 32 + 2) * 4);
+        w->dw_len.reserve((size_t)n_tok * 4 + 64);
+        w->dw_bsum.reserve(nb * 4);
+        w->dw_pos.reserve((size_t)n_tok * 4 + 64);
+        w->dw_out_off.reserve((size_t)(n_docs + 1) * 8);
+        w->dw_total.reserve(64);
+        if (n_tok) HIP_CHECK(hipMemcpyAsync(w->dw_ids.p, ids, (size_t)n_tok * 4, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipMemcpyAsync(w->dw_tok_off.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
+        uint32_t* firstmask = hm.dec_position_dependent ? w->dw_first.as<uint32_t>() : nullptr;
         const uint32_t skip = (flags & TKAMD_SKIP_SPECIAL) ? 1u : 0u;
-        launch_decode(st, t->dw_ids.as<uint32_t>(), t->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
-                      firstmask, t->dw_len.as<uint32_t>(), t->dw_bsum.as<uint32_t>(), t->dw_pos.as<uint32_t>(), t->dw_total.as<int64_t>(),
-                      t->dw_out_off.as<int64_t>(), nullptr);
+        launch_decode(st, w->dw_ids.as<uint32_t>(), w->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
+                      firstmask, w->dw_len.as<uint32_t>(), w->dw_bsum.as<uint32_t>(), w->dw_pos.as<uint32_t>(), w->dw_total.as<int64_t>(),
+                      w->dw_out_off.as<int64_t>(), nullptr);
         HIP_CHECK(hipGetLastError());
         int64_t total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, t->dw_total.p, 8, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(&total, w->dw_total.p, 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (total >= ((int64_t)1 << 32)) throw Invalid("decoded text beyond 4 GiB in one decode_batch call");
-        t->dw_bytes.reserve((size_t)total + 64);
-        launch_decode(st, t->dw_ids.as<uint32_t>(), t->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
-                      firstmask, t->dw_len.as<uint32_t>(), t->dw_bsum.as<uint32_t>(), t->dw_pos.as<uint32_t>(), t->dw_total.as<int64_t>(),
-                      t->dw_out_off.as<int64_t>(), t->dw_bytes.as<uint8_t>());
+        w->dw_bytes.reserve((size_t)total + 64);
+        launch_decode(st, w->dw_ids.as<uint32_t>(), w->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
+                      firstmask, w->dw_len.as<uint32_t>(), w->dw_bsum.as<uint32_t>(), w->dw_pos.as<uint32_t>(), w->dw_total.as<int64_t>(),
+                      w->dw_out_off.as<int64_t>(), w->dw_bytes.as<uint8_t>());
         HIP_CHECK(hipGetLastError());
         std::unique_ptr<tkamd_text> b(new tkamd_text());
         b->n_docs = n_docs;
         b->n_bytes = total;
         b->bytes = pinned_get((size_t)total);
         b->doc_offsets = pinned_get((size_t)(n_docs + 1) * 8);
-        if (total) HIP_CHECK(hipMemcpyAsync(b->bytes.p, t->dw_bytes.p, (size_t)total, hipMemcpyDeviceToHost, st));
-        HIP_CHECK(hipMemcpyAsync(b->doc_offsets.p, t->dw_out_off.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (total) HIP_CHECK(hipMemcpyAsync(b->bytes.p, w->dw_bytes.p, (size_t)total, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipMemcpyAsync(b->doc_offsets.p, w->dw_out_off.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
         *out = b.release();
         return TKAMD_OK;
@@ -1320,7 +1467,6 @@ void tkamd_text_free(tkamd_text* b) { delete b; }
 
 int tkamd_profile_enable(tkamd_tokenizer* t, int on) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
-    std::lock_guard<std::mutex> lk(t->mu);
     t->prof = on != 0;
     return TKAMD_OK;
 }
@@ -1330,7 +1476,7 @@ int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_sta
     std::lock_guard<std::mutex> lk(t->mu);
     if (t->device >= 0) {
         (void)hipSetDevice(t->device);
-        drain_profile(t);
+        for (auto& w : t->pool) drain_profile(t, w.get());
     }
     int n = (int)std::min<size_t>(t->acc.size(), (size_t)std::max(0, max_stages));
     for (int i = 0; i < n && stages; ++i) stages[i] = t->acc[i];
@@ -1343,11 +1489,15 @@ int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {
     if (!t || !out) return set_error(TKAMD_ERR_INVALID, "null argument");
     return guarded([&]() -> int {
         std::lock_guard<std::mutex> lk(t->mu);
-        for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = t->last_counters[i];
-        if (t->device >= 0 && t->w_qcount.p) {             // queue fills of the last batch: the sub-queue counters, summed per queue
+        Workspace* w = t->last_used;
+        for (int i = 0; i < n; ++i) out[i] = 0;
+        if (!w) return TKAMD_OK;
+        for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = w->last_counters[i];
+        if (t->device >= 0 && w->w_qcount.p) {             // queue fills of the last batch: the sub-queue counters, summed per queue
             HIP_CHECK(hipSetDevice(t->device));
+            HIP_CHECK(hipDeviceSynchronize());
             std::vector<uint32_t> c(QCNT_WORDS);
-            HIP_CHECK(hipMemcpy(c.data(), t->w_qcount.p, (size_t)QCNT_WORDS * 4, hipMemcpyDeviceToHost));
+            HIP_CHECK(hipMemcpy(c.data(), w->w_qcount.p, (size_t)QCNT_WORDS * 4, hipMemcpyDeviceToHost));
             static const int slot[4] = {CNT_LIST16, CNT_LIST32, CNT_LIST64, CNT_LISTL};
             for (int q = 0; q < 4; ++q) {
                 uint32_t sum = 0;

@@ -205,6 +205,7 @@ void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsig
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 // truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy
+void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta);
 void launch_final_lens(hipStream_t st, const FinalArgs& a);
 void launch_final_offsets(hipStream_t st, const FinalArgs& a);
 void launch_finalize(hipStream_t st, int grid, const FinalArgs& a);

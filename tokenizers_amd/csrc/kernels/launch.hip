@@ -158,6 +158,9 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
     hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
 }
+void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta) {
+    hipLaunchKernelGGL(k_add_i64, dim3(blocks_for(n, 256)), dim3(256), 0, st, data, n, delta);
+}
 void launch_final_lens(hipStream_t st, const FinalArgs& a) {
     hipLaunchKernelGGL(k_final_lens, dim3(blocks_for(a.n_docs + 1, 256)), dim3(256), 0, st, a);
 }
