@@ -55,6 +55,10 @@ extern "C" {
                                      (processors/bert.rs:51-120, roberta.rs, template.rs:544-590): special ids
                                      around every document, offsets (0,0), word id 0xFFFFFFFF (None)          */
 
+#define TKAMD_PAIRS          16u   /* EncodeInput::Dual (tokenizer/mod.rs:871-889): documents 2i and 2i+1 are sequence A and B of
+                                     encoding i (n_docs must be even); the result holds n_docs / 2 encodings: the pair is
+                                     truncated together, laid out by the post-processor's pair template (type ids), padded  */
+
 /* Readable slack the caller must leave after text[n_bytes] for the device entry
  * points (kernels read whole 16-byte words).  The host entry pads internally. */
 #define TKAMD_TEXT_PAD 64
@@ -113,6 +117,9 @@ const uint32_t* tkamd_batch_ids(const tkamd_batch* b);          /* [n_tokens]   
 const int64_t*  tkamd_batch_tok_offsets(const tkamd_batch* b);  /* [n_docs+1] CSR into ids      */
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b);      /* [n_tokens][2] or NULL        */
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b);     /* [n_tokens] or NULL           */
+const uint8_t*  tkamd_batch_type_ids(const tkamd_batch* b);     /* [n_tokens] Encoding.type_ids, or NULL (single sequences: 0, pad_type_id on padding) */
+const uint8_t*  tkamd_batch_sequence_ids(const tkamd_batch* b); /* [n_tokens] 0 / 1 = token of sequence A / B, 2 = special token, 3 = padding, or NULL
+                                                                   (single sequences: derived from tkamd_tokenizer_specials and the pad counts)      */
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b);   /* [n_docs] padding tokens of each encoding (at the side
                                                                    tkamd_info.padding names), NULL without a `padding` section:
                                                                    attention_mask = 0, special_tokens_mask = 1 on them      */
@@ -131,6 +138,8 @@ typedef struct tkamd_device_result {
     const int64_t*  d_n_tokens;     /* [1]                                                      */
     const int64_t*  d_n_pretokens;  /* [1] number of pre-tokens (splits) in the batch           */
     const uint32_t* d_pad_counts;   /* [n_docs] padding tokens per encoding, or NULL            */
+    const uint8_t*  d_type_ids;     /* TKAMD_PAIRS: [n_tokens] type ids, else NULL              */
+    const uint8_t*  d_seq_ids;      /* TKAMD_PAIRS: [n_tokens] 0 / 1 / 2 special / 3 padding    */
 } tkamd_device_result;
 
 int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,

@@ -22,6 +22,7 @@ OFFSETS_BYTE = 1
 OFFSETS_CHAR = 2
 WANT_WORD_IDS = 4
 ADD_SPECIAL = 8
+PAIRS = 16
 SKIP_SPECIAL = 1          # tkamd_decode_batch flag
 TEXT_PAD = 64
 MAX_STAGES = 24
@@ -30,7 +31,7 @@ MAX_STAGES = 24
 SYMBOLS = [
     "tkamd_tokenizer_from_json", "tkamd_tokenizer_free", "tkamd_tokenizer_info", "tkamd_last_error",
     "tkamd_encode_batch", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
-    "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_pad_counts", "tkamd_batch_free",
+    "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_pad_counts", "tkamd_batch_type_ids", "tkamd_batch_sequence_ids", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
@@ -47,7 +48,8 @@ class Info(C.Structure):
 
 class DeviceResult(C.Structure):
     _fields_ = [("d_ids", C.c_void_p), ("d_tok_offsets", C.c_void_p), ("d_offsets", C.c_void_p),
-                ("d_word_ids", C.c_void_p), ("d_n_tokens", C.c_void_p), ("d_n_pretokens", C.c_void_p), ("d_pad_counts", C.c_void_p)]
+                ("d_word_ids", C.c_void_p), ("d_n_tokens", C.c_void_p), ("d_n_pretokens", C.c_void_p), ("d_pad_counts", C.c_void_p),
+                ("d_type_ids", C.c_void_p), ("d_seq_ids", C.c_void_p)]
 
 
 class StageTime(C.Structure):
@@ -90,7 +92,8 @@ def load() -> C.CDLL:
     lib.tkamd_encode_batch.argtypes = [vp, vp, vp, i64, u32, C.POINTER(vp)]
     lib.tkamd_encode_batch.restype = i32
     for name, rt in (("tkamd_batch_n_docs", i64), ("tkamd_batch_n_tokens", i64), ("tkamd_batch_ids", vp),
-                     ("tkamd_batch_tok_offsets", vp), ("tkamd_batch_offsets", vp), ("tkamd_batch_word_ids", vp), ("tkamd_batch_pad_counts", vp)):
+                     ("tkamd_batch_tok_offsets", vp), ("tkamd_batch_offsets", vp), ("tkamd_batch_word_ids", vp), ("tkamd_batch_pad_counts", vp),
+                     ("tkamd_batch_type_ids", vp), ("tkamd_batch_sequence_ids", vp)):
         f = getattr(lib, name)
         f.argtypes = [vp]
         f.restype = rt

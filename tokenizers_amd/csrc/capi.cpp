@@ -94,7 +94,7 @@ struct Workspace {
     hipStream_t own_stream = nullptr;   // host entry: its own non-blocking stream
     // (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
-    DevBuf w_len1, w_fin, w_fbsum, w_pad_count;   // truncation / padding epilogue
+    DevBuf w_len1, w_fin, w_fbsum, w_pad_count, w_keep, w_type_ids2, w_seq_ids2;   // truncation / padding / pair epilogue
     DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
@@ -129,6 +129,7 @@ struct tkamd_tokenizer {
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
+    DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
     DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
     int n_cu = 256;
     int n_direct = 0;
@@ -179,9 +180,9 @@ static void pinned_put(PinnedBlock b) {
 
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts;
-    bool has_offsets = false, has_words = false, has_pads = false;
-    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); }
+    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids;
+    bool has_offsets = false, has_words = false, has_pads = false, has_types = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); }
 };
 
 struct tkamd_text {
@@ -255,6 +256,14 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_long_id, hm.long_id);
     upload(t->t_long_table, hm.long_table);
     upload(t->t_trie, hm.trie.table);
+    {
+        std::vector<uint32_t> tpl;
+        for (const HostModel::TplPiece& q : hm.pp_pair) { tpl.push_back(q.kind); tpl.push_back(q.id); tpl.push_back(q.type_id); }
+        upload(t->t_pp_pair, tpl);
+        tpl.clear();
+        for (const HostModel::TplPiece& q : hm.pp_pair_plain) { tpl.push_back(q.kind); tpl.push_back(q.id); tpl.push_back(q.type_id); }
+        upload(t->t_pp_pair_plain, tpl);
+    }
     upload(t->t_pp_prefix, hm.pp_prefix);
     upload(t->t_pp_suffix, hm.pp_suffix);
     upload(t->t_bn1, hm.bn_stage1);
@@ -517,7 +526,94 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         out->d_n_tokens = sa.n_tok2;
     };
     out->d_pad_counts = nullptr;
-    const bool epilogue = hm.trunc_on || hm.pad_on;
+    out->d_type_ids = nullptr;
+    out->d_seq_ids = nullptr;
+    const bool pairs = (flags & TKAMD_PAIRS) != 0;
+    if (pairs && (n_docs & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
+    if (pairs && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
+    const bool epilogue = hm.trunc_on || hm.pad_on || pairs;
+    auto finalize_pairs = [&]() {
+        // EncodeInput::Dual: the two sequences of a pair were encoded as two documents; cut, lay out and pad them together
+        const int64_t n_pairs = n_docs / 2;
+        const bool tpl_on = (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair.empty();
+        uint32_t n_special = 0;
+        if (tpl_on) for (const HostModel::TplPiece& q : hm.pp_pair) n_special += q.kind == 2u;
+        PairArgs pa{};
+        pa.tok_offsets = w->w_tok_offsets.as<int64_t>();
+        pa.n_pairs = n_pairs;
+        pa.ids = w->w_ids.as<uint32_t>();
+        pa.offsets = out->d_offsets;
+        pa.word_ids = out->d_word_ids;
+        w->w_keep.reserve((size_t)(n_docs + 2) * 4);
+        pa.tpl = tpl_on ? t->t_pp_pair.as<uint32_t>() : t->t_pp_pair_plain.as<uint32_t>();
+        pa.n_tpl = tpl_on ? (int32_t)hm.pp_pair.size() : (int32_t)hm.pp_pair_plain.size();
+        pa.n_special = n_special;
+        pa.trunc_on = hm.trunc_on ? 1u : 0u;
+        pa.trunc_max = hm.trunc_max_length;
+        pa.trunc_left = hm.trunc_left ? 1u : 0u;
+        pa.trunc_strategy = (uint32_t)hm.trunc_strategy;
+        pa.pad_on = hm.pad_on ? 1u : 0u;
+        pa.pad_fixed = hm.pad_fixed ? 1u : 0u;
+        pa.pad_length = hm.pad_length;
+        pa.pad_multiple = hm.pad_multiple;
+        pa.pad_left = hm.pad_left ? 1u : 0u;
+        pa.pad_id = hm.pad_id;
+        pa.pad_type_id = hm.pad_type_id;
+        w->w_len1.reserve((size_t)(n_pairs + 2) * 4);
+        w->w_fin.reserve((size_t)(n_pairs + 2) * 4);
+        w->w_fbsum.reserve((size_t)((n_pairs + 1) / 256 + 2) * 4);
+        w->w_tok_offsets2.reserve((size_t)(n_pairs + 2) * 8);
+        if (hm.pad_on) w->w_pad_count.reserve((size_t)(n_pairs + 2) * 4);
+        pa.keep = w->w_keep.as<uint32_t>();
+        pa.len1 = w->w_len1.as<uint32_t>();
+        pa.fin = w->w_fin.as<uint32_t>();
+        pa.bsum = w->w_fbsum.as<uint32_t>();
+        pa.target = (uint32_t*)(sc + SC_PADMAX);
+        pa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
+        pa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
+        pa.n_tok2 = sc + SC_NTOK2;
+        pa.err = d_err;
+        pf.begin("pair_epilogue");
+        launch_pair_lens(st, pa);
+        size_t T2 = (size_t)n_x + 4 + (size_t)(n_pairs + 1) * n_special;
+        if (hm.pad_on) {
+            uint64_t target = hm.pad_length;
+            if (!hm.pad_fixed) {
+                uint32_t mx = 0;
+                HIP_CHECK(hipMemcpyAsync(&mx, pa.target, 4, hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+                target = mx;
+            }
+            if (hm.pad_multiple > 0 && target % hm.pad_multiple > 0) target += hm.pad_multiple - target % hm.pad_multiple;
+            T2 += (size_t)n_pairs * (size_t)target;
+            if ((uint64_t)T2 >= ((uint64_t)1 << 32)) throw Invalid("the padded batch would hold more than 2^32 tokens: pad fewer documents per call");
+        }
+        w->w_ids2.reserve(T2 * 4);
+        w->w_type_ids2.reserve(T2 + 64);
+        w->w_seq_ids2.reserve(T2 + 64);
+        if (out->d_offsets) w->w_offsets2.reserve(T2 * 8);
+        if (out->d_word_ids) w->w_word_ids2.reserve(T2 * 4);
+        pa.ids2 = w->w_ids2.as<uint32_t>();
+        pa.offsets2 = w->w_offsets2.as<uint32_t>();
+        pa.word_ids2 = w->w_word_ids2.as<uint32_t>();
+        pa.type_ids2 = w->w_type_ids2.as<uint8_t>();
+        pa.seq_ids2 = w->w_seq_ids2.as<uint8_t>();
+        FinalArgs fa{};                                    // the CSR of the padded lengths: same three kernels as for single sequences
+        fa.n_docs = n_pairs;
+        fa.len1 = pa.len1; fa.fin = pa.fin; fa.bsum = pa.bsum; fa.target = pa.target; fa.tok_offsets2 = pa.tok_offsets2; fa.n_tok2 = pa.n_tok2;
+        fa.pad_on = pa.pad_on; fa.pad_fixed = pa.pad_fixed; fa.pad_length = pa.pad_length; fa.pad_multiple = pa.pad_multiple;
+        launch_final_offsets(st, fa);
+        launch_pair_finalize(st, grid, pa);
+        pf.end();
+        out->d_ids = pa.ids2;
+        out->d_tok_offsets = pa.tok_offsets2;
+        if (out->d_offsets) out->d_offsets = pa.offsets2;
+        if (out->d_word_ids) out->d_word_ids = pa.word_ids2;
+        out->d_n_tokens = pa.n_tok2;
+        out->d_pad_counts = pa.pad_count;
+        out->d_type_ids = pa.type_ids2;
+        out->d_seq_ids = pa.seq_ids2;
+    };
     auto finalize = [&]() {
         // truncation -> special tokens -> padding (tokenizer/mod.rs:1265-1317) as one epilogue over the token CSR
         const uint32_t n_add = add_special ? (uint32_t)(hm.pp_prefix.size() + hm.pp_suffix.size()) : 0u;
@@ -949,7 +1045,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         if (a.want_offsets) out->d_offsets = a.offsets;
         if (a.want_words) out->d_word_ids = a.word_ids;
     }
-    if (epilogue) finalize();
+    if (pairs) finalize_pairs();
+    else if (epilogue) finalize();
     else if (add_special) add_specials();
     w->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
     HIP_CHECK(hipGetLastError());
@@ -966,7 +1063,7 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
         tkamd_device_result again{};
         run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_flags, st, &again);
         if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
-            again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts)
+            again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts || again.d_type_ids != w->last_result.d_type_ids)
             throw HipError("result buffers moved while a batch was run again");
         bits = read_scalars(t, w, st, n_tok, n_pretok);
     }
@@ -994,6 +1091,7 @@ int error_from_bits(int bits) {
     if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal invariant violated");
     if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
     if (bits & ERR_TRUNC_SECOND) return set_error(TKAMD_ERR_INVALID, "Truncation error: Second sequence not provided");
+    if (bits & ERR_TRUNC_SHORT) return set_error(TKAMD_ERR_INVALID, "Truncation error: Sequence to truncate too short to respect the provided max_length");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
 }
@@ -1184,6 +1282,8 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         const int64_t n_bytes = doc_offsets[n_docs];
         if (n_bytes < 0 || doc_offsets[0] != 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
         if (n_bytes > 0 && !text) throw Invalid("null text");
+        const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;            // documents per encoding
+        if (n_docs % unit) throw Invalid("TKAMD_PAIRS: an odd number of documents");
         static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
         int n_slices = (int)std::min<int64_t>(8, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed)) n_slices = 1;
@@ -1193,8 +1293,9 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         cut[n_slices] = n_docs;
         for (int k = 1; k < n_slices; ++k) {
             const int64_t target = n_bytes / n_slices * k;
-            cut[k] = std::max<int64_t>(cut[k - 1], std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets);
+            cut[k] = std::max<int64_t>(cut[k - 1], (std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets) / unit * unit);
         }
+        const int64_t n_enc = n_docs / unit;
         HostLease l0(t);
         std::unique_ptr<HostLease> l1(n_slices > 1 ? new HostLease(t) : nullptr);
         Workspace* ws[2] = {l0.w, l1 ? l1->w : l0.w};
@@ -1203,8 +1304,8 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         hipStream_t st[2] = {own_stream(ws[0]), own_stream(ws[1])};
 
         std::unique_ptr<tkamd_batch> b(new tkamd_batch());
-        b->n_docs = n_docs;
-        b->tok_offsets = pinned_get((size_t)(n_docs + 1) * 8);
+        b->n_docs = n_enc;
+        b->tok_offsets = pinned_get((size_t)(n_enc + 1) * 8);
         tkamd_device_result res[8]{};
         int64_t slice_tok[8] = {0};
         size_t tok_cap = 0;
@@ -1237,12 +1338,13 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             const int bits = finish_batch(t, w, s, &n_tok, &n_pt);
             if (bits) return bits;
             const tkamd_device_result& r = res[k];
-            const int64_t d0 = cut[k], d1 = cut[k + 1];
+            const int64_t seen_docs = cut[k + 1];
+            const int64_t d0 = cut[k] / unit, d1 = cut[k + 1] / unit;      // encodings of this slice
             slice_tok[k] = n_tok;
             const size_t need = (size_t)(tok_base + n_tok);
             if (need > tok_cap) {
                 // estimate the whole batch from what has been seen: tokens per byte so far, 12 % headroom
-                const int64_t seen = doc_offsets[d1];
+                const int64_t seen = doc_offsets[seen_docs];
                 size_t est = (k + 1 == n_slices || seen <= 0) ? need : (size_t)((double)need * (double)n_bytes / (double)seen * 1.12) + 4096;
                 est = std::max(est, need);
                 if (k) {                                        // earlier slices' copies are still landing in the old blocks
@@ -1252,6 +1354,7 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 grow(b->ids, 4, est, (size_t)tok_base);
                 if (r.d_offsets) grow(b->offsets, 8, est, (size_t)tok_base);
                 if (r.d_word_ids) grow(b->word_ids, 4, est, (size_t)tok_base);
+                if (r.d_type_ids) { grow(b->type_ids, 1, est, (size_t)tok_base); grow(b->seq_ids, 1, est, (size_t)tok_base); }
                 tok_cap = est;
             }
             if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
@@ -1265,8 +1368,13 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 b->has_words = true;
                 if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->word_ids.p + tok_base, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
             }
+            if (r.d_type_ids) {
+                b->has_types = true;
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->type_ids.p + tok_base, r.d_type_ids, (size_t)n_tok, hipMemcpyDeviceToHost, s));
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->seq_ids.p + tok_base, r.d_seq_ids, (size_t)n_tok, hipMemcpyDeviceToHost, s));
+            }
             if (r.d_pad_counts) {
-                if (!b->has_pads) { b->has_pads = true; b->pad_counts = pinned_get((size_t)(n_docs + 1) * 4); }
+                if (!b->has_pads) { b->has_pads = true; b->pad_counts = pinned_get((size_t)(n_enc + 1) * 4); }
                 if (d1 > d0) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->pad_counts.p + d0, r.d_pad_counts, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, s));
             }
             tok_base += n_tok;
@@ -1295,6 +1403,8 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
 }
 
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b) { return (b && b->has_pads) ? (const uint32_t*)b->pad_counts.p : nullptr; }
+const uint8_t* tkamd_batch_type_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->type_ids.p : nullptr; }
+const uint8_t* tkamd_batch_sequence_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->seq_ids.p : nullptr; }
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_batch_n_tokens(const tkamd_batch* b) { return b ? b->n_tokens : 0; }
 const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? (const uint32_t*)b->ids.p : nullptr; }

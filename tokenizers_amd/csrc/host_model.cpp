@@ -540,6 +540,12 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                     throw Invalid("tokenizer.json: bad cls/sep in post_processor");
                 m.pp_prefix.insert(m.pp_prefix.begin(), (uint32_t)cls->arr[1]->num);
                 m.pp_suffix.push_back((uint32_t)sep->arr[1]->num);
+                if (!m.pp_pair.empty()) m.pp_pair_unsupported = "two post-processors that add special tokens";
+                const uint32_t c = (uint32_t)cls->arr[1]->num, e = (uint32_t)sep->arr[1]->num;
+                if (t == "BertProcessing")         // [CLS] A [SEP] : 0   B [SEP] : 1          (processors/bert.rs:121-150)
+                    m.pp_pair = {{2, c, 0}, {0, 0, 0}, {2, e, 0}, {1, 0, 1}, {2, e, 1}};
+                else                               // <s> A </s> </s> B </s>, all type 0        (processors/roberta.rs)
+                    m.pp_pair_plain = {{0, 0, 0}, {1, 0, 0}}, m.pp_pair = {{2, c, 0}, {0, 0, 0}, {2, e, 0}, {2, e, 0}, {1, 0, 0}, {2, e, 0}};
                 return;
             }
             if (t == "TemplateProcessing") {                               // processors/template.rs:544-590, `single` template
@@ -565,6 +571,29 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                 if (n_seq != 1) { m.pp_unsupported = "TemplateProcessing single template must contain sequence A exactly once"; return; }
                 m.pp_prefix.insert(m.pp_prefix.begin(), pre.begin(), pre.end());
                 m.pp_suffix.insert(m.pp_suffix.end(), post.begin(), post.end());
+                // the `pair` template (processors/template.rs:544-590): any order of A, B and special tokens, each with its type id
+                if (!m.pp_pair.empty()) m.pp_pair_unsupported = "two post-processors that add special tokens";
+                const JsonValue* pair = pp->get("pair");
+                if (!pair || !pair->is_array()) { m.pp_pair_unsupported = "TemplateProcessing without a `pair` template"; return; }
+                int na = 0, nb = 0;
+                for (auto& piece : pair->arr) {
+                    if (const JsonValue* sq = piece->get("Sequence")) {
+                        const bool is_a = sq->get_str("id") == "A";
+                        (is_a ? na : nb)++;
+                        m.pp_pair.push_back({is_a ? 0u : 1u, 0u, (uint32_t)sq->get_num("type_id", 0)});
+                    } else if (const JsonValue* st = piece->get("SpecialToken")) {
+                        std::string name = st->get_str("id");
+                        const JsonValue* def = sp ? sp->get(name.c_str()) : nullptr;
+                        const JsonValue* ids = def ? def->get("ids") : nullptr;
+                        if (!ids || !ids->is_array()) throw Invalid("tokenizer.json: TemplateProcessing special token '" + name + "' is not defined");
+                        for (auto& x : ids->arr) m.pp_pair.push_back({2u, (uint32_t)x->num, (uint32_t)st->get_num("type_id", 0)});
+                    } else throw Invalid("tokenizer.json: bad TemplateProcessing piece");
+                }
+                if (na != 1 || nb != 1) m.pp_pair_unsupported = "TemplateProcessing pair template must contain A and B exactly once each";
+                m.pp_pair_plain.clear();
+                for (const HostModel::TplPiece& q : m.pp_pair)
+                    if (q.kind != 2u) m.pp_pair_plain.push_back(q);
+                if (m.pp_pair.size() > 64) m.pp_pair_unsupported = "TemplateProcessing pair template with more than 64 pieces";
                 return;
             }
             if (t == "Sequence") {                                         // processors/sequence.rs: applied in order

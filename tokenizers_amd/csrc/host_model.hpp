@@ -64,6 +64,14 @@ struct HostModel {
     // post-processor layout for a single sequence (processors/{bert,roberta,template,sequence}.rs)
     std::vector<uint32_t> pp_prefix, pp_suffix;   // special ids before / after sequence A
     std::string pp_unsupported;                    // non-empty: why add_special_tokens cannot be honoured
+    // the same post-processor for a PAIR of sequences (processors/bert.rs:51-150, roberta.rs, template.rs `pair`): the pieces in
+    // order -- kind 0 = sequence A, 1 = sequence B, 2 = one special token id -- each with the type id its tokens get
+    struct TplPiece { uint32_t kind, id, type_id; };
+    std::vector<TplPiece> pp_pair;                 // empty: no adding post-processor (a pair is then A followed by B, type ids 0 / 1)
+    std::string pp_pair_unsupported;
+    // the layout of a pair when NO special tokens are added: A : 0, B : 1 by default (bert.rs:56-58 returns the encodings as they are);
+    // RobertaProcessing zeroes every type id first (roberta.rs); TemplateProcessing still applies its order and type ids
+    std::vector<TplPiece> pp_pair_plain = {{0, 0, 0}, {1, 0, 1}};
 
     // truncation / padding of the finished encodings (utils/truncation.rs:70-160, utils/padding.rs:50-85; tokenizer/mod.rs:1265-1317)
     bool trunc_on = false;

@@ -138,6 +138,34 @@ struct FinalArgs {
     int* err;
 };
 
+// arguments of the PAIR epilogue (k_pair_*): documents 2i / 2i+1 are sequence A / B of encoding i (tokenizer/mod.rs:871-889)
+struct PairArgs {
+    const int64_t* tok_offsets;       // token CSR over the 2 * n_pairs documents
+    int64_t n_pairs;
+    const uint32_t* ids;
+    const uint32_t* offsets;          // null if not produced
+    const uint32_t* word_ids;         // null if not produced
+    const uint32_t* tpl;              // [n_tpl][3] kind (0 A, 1 B, 2 special), id, type id
+    int32_t n_tpl;
+    uint32_t n_special;               // special tokens of the template (taken off max_length)
+    uint32_t trunc_on, trunc_max, trunc_left, trunc_strategy;
+    uint32_t pad_on, pad_fixed, pad_length, pad_multiple, pad_left, pad_id, pad_type_id;
+    uint32_t* keep;                   // [2 * n_pairs] tokens of A / B that survive the truncation
+    uint32_t* len1;                   // [n_pairs] tokens of the pair encoding before padding
+    uint32_t* fin;
+    uint32_t* target;
+    uint32_t* bsum;
+    int64_t* tok_offsets2;            // [n_pairs + 1]
+    uint32_t* ids2;
+    uint32_t* offsets2;
+    uint32_t* word_ids2;
+    uint8_t* type_ids2;               // per token
+    uint8_t* seq_ids2;                // per token: 0 sequence A, 1 sequence B, 2 special token, 3 padding
+    uint32_t* pad_count;
+    int64_t* n_tok2;
+    int* err;
+};
+
 // error bits accumulated in a device int during a batch
 enum : int {
     ERR_BAD_OFFSETS = 1,          // doc_offsets not a valid CSR over [0, n_bytes]
@@ -148,7 +176,8 @@ enum : int {
     ERR_INTERNAL = 32,            // an internal invariant was violated (bug guard)
     ERR_QUEUE_FULL = 64,
     ERR_TRUNC_SECOND = 128,       // truncation strategy OnlySecond on a single sequence that has to be cut (TruncationError::SecondSequenceNotProvided)
-    ERR_TOO_MANY_TOKENS = 256,    // the padded batch has more than 2^32 tokens
+    ERR_TOO_MANY_TOKENS = 256,
+    ERR_TRUNC_SHORT = 512,        // OnlyFirst / OnlySecond: the sequence to cut is not longer than what must go (TruncationError::SequenceTooShort)    // the padded batch has more than 2^32 tokens
     ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
 
@@ -209,6 +238,8 @@ void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta);
 void launch_final_lens(hipStream_t st, const FinalArgs& a);
 void launch_final_offsets(hipStream_t st, const FinalArgs& a);
 void launch_finalize(hipStream_t st, int grid, const FinalArgs& a);
+void launch_pair_lens(hipStream_t st, const PairArgs& a);
+void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a);
 // AddedVocabulary (kernels/documents.hip): one matching pass over a sentence CSR, list -> masks, list coordinate changes
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,

@@ -175,6 +175,12 @@ void launch_finalize(hipStream_t st, int grid, const FinalArgs& a) {
     hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, st, a);
 }
 // one matching pass of the AddedVocabulary over the sentences seg_off[0 .. n_segs]: appends (start, stop, id) to match_list
+void launch_pair_lens(hipStream_t st, const PairArgs& a) {
+    hipLaunchKernelGGL(k_pair_lens, dim3(blocks_for(a.n_pairs + 1, 256)), dim3(256), 0, st, a);
+}
+void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a) {
+    hipLaunchKernelGGL(k_pair_finalize, dim3(grid), dim3(256), 0, st, a);
+}
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
                         uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err) {

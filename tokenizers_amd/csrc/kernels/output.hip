@@ -355,3 +355,96 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs a) {
         }
     }
 }
+
+// =================================================================================================
+// The same epilogue for PAIRS (EncodeInput::Dual, tokenizer/mod.rs:871-889): documents 2i and 2i+1 went through the pipeline as
+// sequence A and B of encoding i; here they are cut together (truncate_encodings, utils/truncation.rs:70-160: LongestFirst /
+// OnlyFirst / OnlySecond), laid out by the post-processor's pair template with its type ids (processors/bert.rs:121-150,
+// roberta.rs, template.rs:544-590; without one: A then B, type ids 0 / 1, PostProcessor::default_process), and padded.
+// Every output token also gets its sequence id (0 / 1; 2 special; 3 padding) -- Encoding::token_to_sequence, the masks.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_pair_lens(PairArgs a) {
+    __shared__ uint32_t smax[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t l = 0;
+    if (i < a.n_pairs) {
+        uint64_t n1 = (uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), n2 = (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1]);
+        if (a.trunc_on) {
+            // max_length - n_added_tokens (mod.rs:1273-1279; the subtraction wraps in the reference's release build when max_length is smaller)
+            const uint64_t maxl = (a.n_special && a.trunc_max < a.n_special) ? ~0ull : (uint64_t)(a.trunc_max - a.n_special);
+            const uint64_t total = n1 + n2;
+            if (maxl == 0) { n1 = 0; n2 = 0; }
+            else if (total > maxl) {
+                const uint64_t to_remove = total - maxl;
+                if (a.trunc_strategy == 0) {                          // LongestFirst (truncation.rs:101-141)
+                    uint64_t s1 = n1, s2 = n2;
+                    const bool swap = s1 > s2;
+                    if (swap) { const uint64_t x = s1; s1 = s2; s2 = x; }
+                    if (s1 > maxl) s2 = s1; else s2 = max(s1, maxl - s1);
+                    if (s1 + s2 > maxl) { s1 = maxl / 2; s2 = s1 + maxl % 2; }
+                    if (swap) { const uint64_t x = s1; s1 = s2; s2 = x; }
+                    n1 = min(n1, s1); n2 = min(n2, s2);
+                } else {                                              // OnlyFirst / OnlySecond (:143-159)
+                    uint64_t& tgt = a.trunc_strategy == 1 ? n1 : n2;
+                    if (tgt > to_remove) tgt -= to_remove;
+                    else atomicOr(a.err, ERR_TRUNC_SHORT);
+                }
+            }
+        }
+        a.keep[2 * i] = (uint32_t)n1;
+        a.keep[2 * i + 1] = (uint32_t)n2;
+        l = (uint32_t)(n1 + n2) + a.n_special;
+        a.len1[i] = l;
+    }
+    if (a.pad_on && !a.pad_fixed) {
+        uint32_t m = l;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s, 64));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(a.target, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    }
+}
+__global__ __launch_bounds__(256) void k_pair_finalize(PairArgs a) {
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave; i < a.n_pairs; i += n_waves) {
+        const int64_t dst0 = a.tok_offsets2[i], total = a.tok_offsets2[i + 1] - dst0;
+        const int64_t real = a.len1[i], pads = total - real;
+        int64_t cur = dst0 + (a.pad_left ? pads : 0);
+        if (lane == 0 && a.pad_count) a.pad_count[i] = (uint32_t)pads;
+        for (int64_t q = lane; q < pads; q += 64) {
+            const int64_t o = a.pad_left ? dst0 + q : cur + real + q;
+            a.ids2[o] = a.pad_id;
+            a.type_ids2[o] = (uint8_t)a.pad_type_id;
+            a.seq_ids2[o] = 3;
+            if (a.offsets) { a.offsets2[2 * o] = 0; a.offsets2[2 * o + 1] = 0; }
+            if (a.word_ids) a.word_ids2[o] = 0xFFFFFFFFu;
+        }
+        for (int k = 0; k < a.n_tpl; ++k) {
+            const uint32_t kind = a.tpl[3 * k], id = a.tpl[3 * k + 1], ty = a.tpl[3 * k + 2];
+            if (kind == 2u) {
+                if (lane == 0) {
+                    a.ids2[cur] = id;
+                    a.type_ids2[cur] = (uint8_t)ty;
+                    a.seq_ids2[cur] = 2;
+                    if (a.offsets) { a.offsets2[2 * cur] = 0; a.offsets2[2 * cur + 1] = 0; }
+                    if (a.word_ids) a.word_ids2[cur] = 0xFFFFFFFFu;
+                }
+                cur += 1;
+            } else {
+                const int64_t d = 2 * i + kind;
+                const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo, n = a.keep[d];
+                const int64_t src = lo + (a.trunc_left ? n_all - n : 0);
+                for (int64_t q = lane; q < n; q += 64) {
+                    a.ids2[cur + q] = a.ids[src + q];
+                    a.type_ids2[cur + q] = (uint8_t)ty;
+                    a.seq_ids2[cur + q] = (uint8_t)kind;
+                    if (a.offsets) { a.offsets2[2 * (cur + q)] = a.offsets[2 * (src + q)]; a.offsets2[2 * (cur + q) + 1] = a.offsets[2 * (src + q) + 1]; }
+                    if (a.word_ids) a.word_ids2[cur + q] = a.word_ids[src + q];
+                }
+                cur += n;
+            }
+        }
+    }
+}

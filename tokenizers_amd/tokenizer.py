@@ -118,6 +118,9 @@ class Encoding:
         return (p, nb, ne, 0) if b._pad_left else (0, nb, ne, p)
 
     def _mask(self, pad, special, token) -> list:
+        b = self._b
+        if b.seq_ids is not None:            # pairs: the device wrote every token's sequence id (0 / 1, 2 special, 3 padding)
+            return [token if q < 2 else (special if q == 2 else pad) for q in b.seq_ids[self._lo:self._hi].tolist()]
         pl, nb, ne, pr = self._layout()
         return [pad] * pl + [special] * nb + [token] * (len(self) - pl - nb - ne - pr) + [special] * ne + [pad] * pr
 
@@ -127,6 +130,8 @@ class Encoding:
 
     @property
     def type_ids(self) -> list[int]:
+        if self._b.type_ids is not None:
+            return self._b.type_ids[self._lo:self._hi].tolist()
         return self._mask(self._b._pad_type_id, 0, 0)
 
     @property
@@ -141,6 +146,8 @@ class Encoding:
     def tokens(self) -> list[str]:
         v = self._b._id_to_token
         out = [v.get(i, "") for i in self.ids]
+        if self._b.seq_ids is not None:
+            return [self._b._pad_token if q == 3 else tkn for tkn, q in zip(out, self._b.seq_ids[self._lo:self._hi].tolist())]
         pl, _, _, pr = self._layout()
         if pl or pr:                         # Encoding::pad writes the pad_token string, whatever the pad id maps to
             out[:pl] = [self._b._pad_token] * pl
@@ -164,11 +171,13 @@ class Encoding:
 
     @property
     def sequence_ids(self) -> list[int | None]:
+        if self._b.seq_ids is not None:
+            return [q if q < 2 else None for q in self._b.seq_ids[self._lo:self._hi].tolist()]
         return self._mask(None, None, 0)
 
     @property
     def n_sequences(self) -> int:
-        return 1
+        return 2 if self._b.seq_ids is not None else 1
 
     @property
     def overflowing(self) -> list:
@@ -188,6 +197,8 @@ class BatchEncoding:
         self.offsets = offsets
         self.word_ids = word_ids            # uint32, 0xFFFFFFFF = None (special tokens, padding)
         self.pad_counts = pad_counts        # uint32 per document: padding tokens (None without a `padding` section)
+        self.type_ids = None                # pairs only: uint8 per token
+        self.seq_ids = None                 # pairs only: uint8 per token, 0 / 1 sequence A / B, 2 special token, 3 padding
         self._id_to_token = id_to_token
         self._specials = specials           # (#prefix, #suffix) special tokens around every document
         self._pad_left, self._pad_type_id, self._pad_token = pad_left, pad_type_id, pad_token
@@ -389,13 +400,27 @@ class Tokenizer:
                          add_special_tokens: bool = False) -> BatchEncoding:
         """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17)."""
         self._check_special(add_special_tokens)
+        pairs = len(inputs) > 0 and isinstance(inputs[0], (tuple, list))
+        if pairs:
+            # EncodeInput::Dual for every item (a batch mixing single sequences and pairs is outside this path): A and B as
+            # neighbouring documents
+            flat = []
+            for it in inputs:
+                if not isinstance(it, (tuple, list)) or len(it) != 2 or not isinstance(it[0], str) or not isinstance(it[1], str):
+                    raise UnsupportedError("a batch must hold either single sequences (str) or pairs (str, str); pre-tokenized inputs are outside the MI355X hot path")
+                flat.append(it[0])
+                flat.append(it[1])
+            inputs = flat
         with self._stage_lock:                               # the staging buffers are per tokenizer; results are copied out by the library
             buf, doc_off = self._pack_staged(inputs)
-            return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens)
+            return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens, pairs)
 
     def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
-                      add_special_tokens: bool = False) -> BatchEncoding:
+                      add_special_tokens: bool = False, pairs: bool = False) -> BatchEncoding:
+        """``pairs``: documents 2i and 2i+1 are sequence A and B of encoding i (EncodeInput::Dual, tokenizer/mod.rs:871-889)."""
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
+        if pairs:
+            flags |= _lib.PAIRS
         if word_ids:
             flags |= _lib.WANT_WORD_IDS
         if add_special_tokens:
@@ -406,6 +431,7 @@ class Tokenizer:
         n_docs = len(doc_off) - 1
         b = C.c_void_p()
         _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
+        n_docs = self._lib.tkamd_batch_n_docs(b)             # encodings (half the documents for pairs)
         # zero-copy views of the library's pinned result buffers; the batch is freed when the last view dies
         owner = _BatchOwner(self._lib, b)
         nt = self._lib.tkamd_batch_n_tokens(b)
@@ -429,8 +455,13 @@ class Tokenizer:
         pp = self._lib.tkamd_batch_pad_counts(b)
         if pp:
             pads = view(pp, C.c_uint32, (n_docs,), np.uint32)
-        return BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0), pads,
-                             self.info["padding"] == 2, self.info["pad_type_id"], self._pad_token)
+        be = BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0), pads,
+                           self.info["padding"] == 2, self.info["pad_type_id"], self._pad_token)
+        tp = self._lib.tkamd_batch_type_ids(b)
+        if tp:
+            be.type_ids = view(tp, C.c_uint8, (nt,), np.uint8)
+            be.seq_ids = view(self._lib.tkamd_batch_sequence_ids(b), C.c_uint8, (nt,), np.uint8)
+        return be
 
     def encode_file(self, path: str, offsets: str = "none", word_ids: bool = False, add_special_tokens: bool = False) -> BatchEncoding:
         """Encode a newline-delimited UTF-8 file, one document per line *including its terminator* (:func:`read_lines`)."""
