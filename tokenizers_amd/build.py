@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtokenizers_amd.so")
 SOURCES = ["kernels.hip", "capi.cpp", "host_model.cpp"]
-HEADERS = [os.path.join("kernels", f + ".hip") for f in ("documents", "pretok_gpt2", "pretok_llama3", "pretok_local", "bert_norm", "scan_emit", "bpe", "word_models", "bpe_huge", "output", "decode", "launch")] + ["kernels.hpp", "tables.hpp", "device_utils.hpp", "host_model.hpp", "json.hpp", "unicode_ranges.inc", "pretok_gpt2_core.hpp", "pretok_l3_core.hpp", "pretok_local_core.hpp", "bert_norm_tables.inc",
-           os.path.join("..", "..", "include", "tokenizers_amd.h")]
+# everything the three translation units include (kernels.hip is ONE unit made of the kernels/*.hip slices)
+HEADERS = sorted(os.path.join("kernels", f) for f in os.listdir(os.path.join(CSRC, "kernels")) if f.endswith(".hip")) + \
+    sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join("..", "..", "include", "tokenizers_amd.h")]
 ARCH = "gfx950"
 
 

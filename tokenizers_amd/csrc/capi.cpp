@@ -201,7 +201,10 @@ struct Prof {
     tkamd_tokenizer* t;
     Workspace* w;
     hipStream_t st;
+    // TKAMD_TRACE=1: every stage is announced on stderr and waited for -- a faulting kernel is the last name printed
+    static bool trace() { static const bool on = getenv("TKAMD_TRACE") != nullptr; return on; }
     void begin(const char* name) {
+        if (trace()) fprintf(stderr, "[tkamd] %s ...\n", name);
         if (!t->prof) return;
         StageRec r;
         r.name = name;
@@ -211,6 +214,7 @@ struct Prof {
         w->pending.push_back(r);
     }
     void end() {
+        if (trace()) { HIP_CHECK(hipStreamSynchronize(st)); fprintf(stderr, "[tkamd]   done\n"); }
         if (!t->prof) return;
         HIP_CHECK(hipEventRecord(w->pending.back().b, st));
     }
@@ -382,17 +386,19 @@ void build_hot_table(tkamd_tokenizer* t) {
 }
 
 
-// Queue capacities for a text of N bytes.  Every queue is NSQ sub-queues (results.hip); the workgroups feeding one sub-queue
-// see N / NSQ bytes of text (+ one tile).  A pre-token of class 1 / 2 / 3 is longer than 16 / 32 / 64 bytes, so those three
+// Queue capacities for a text of N bytes.  Every queue is NSQ sub-queues (results.hip), one per lookup workgroup; a workgroup
+// takes every grid-th tile of LOOKUP_TILE_BYTES.  A pre-token of class 1 / 2 / 3 is longer than 16 / 32 / 64 bytes, so those three
 // are sized for the worst case outright; the <= 16-byte queue (worst case: half the bytes) starts at 1 / q16_div of them and
 // the batch is run again with the worst-case size if it ever overflows (ERR_QUEUE_FULL; natural text queues 1/50 .. 1/6).
+int lookup_grid(const tkamd_tokenizer* t) { return std::min(2 * t->n_cu, (int)NSQ); }
 struct QueueSizes {
     uint32_t sq_cap[4], row_base[4];
     size_t total;
 };
-QueueSizes queue_sizes(size_t N, uint32_t q16_div) {
+QueueSizes queue_sizes(size_t N, uint32_t q16_div, int grid) {
     QueueSizes z{};
-    const size_t per_sq = N / NSQ + 32768;
+    const size_t n_tiles = N / LOOKUP_TILE_BYTES + 1;
+    const size_t per_sq = ((n_tiles + grid - 1) / grid) * LOOKUP_TILE_BYTES;
     z.sq_cap[0] = (uint32_t)(per_sq / q16_div + 64);
     z.sq_cap[1] = (uint32_t)(per_sq / 17 + 16);
     z.sq_cap[2] = (uint32_t)(per_sq / 33 + 16);
@@ -412,7 +418,7 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
     w->w_bsum.reserve((W / 256 + 2) * 4);
     w->w_tok0.reserve((N + 4) * 4);
     w->w_tmp_ids.reserve((N + 4) * 4);
-    const QueueSizes z = queue_sizes(N, t->q16_div);
+    const QueueSizes z = queue_sizes(N, t->q16_div, lookup_grid(t));
     w->w_rows.reserve(z.total * 16);
     w->w_queues.reserve(z.total * 8);
     w->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8);
@@ -916,7 +922,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
 
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
     const size_t N = (size_t)n_x;
-    const QueueSizes qz = queue_sizes(N, t->q16_div);
+    const QueueSizes qz = queue_sizes(N, t->q16_div, lookup_grid(t));
     QueuePlan plan{};
     for (int c = 0; c < 4; ++c) {
         plan.v[c].q = (QItem*)(w->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);
@@ -928,7 +934,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
-        launch_lookup(st, 2 * t->n_cu, t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+        launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 0u);
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
@@ -969,7 +975,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         DevTables wt = t->dt;
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
-        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+        launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 1u);
         for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err);      // words longer than 16 bytes
         pf.end();
@@ -982,7 +988,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;                              // any whole-word hit is final
         wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
         pf.begin("wordpiece_word_lookup");
-        launch_lookup(st, 2 * t->n_cu, wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+        launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, shortcut ? 0u : 1u, 0u);
         pf.end();
         pf.begin("wordpiece");

@@ -43,11 +43,12 @@ struct BnTables {
     uint32_t clean, cjk, strip, lower;
 };
 
-// one queued pre-token (kernels/results.hip); a queue = NSQ sub-queues of sq_cap entries, each with its own fill counter
-// QCNT_STRIDE words (one 128-byte line) apart
+// one queued pre-token (kernels/results.hip); a queue = NSQ sub-queues of sq_cap entries, one per lookup workgroup, each with its
+// own fill counter
 struct QItem;
-constexpr int NSQ = 64;
-constexpr int QCNT_STRIDE = 32;
+constexpr int NSQ = 512;
+constexpr int QCNT_STRIDE = 1;
+constexpr int LOOKUP_TILE_BYTES = 16384;                  // text one lookup workgroup takes at a time (kernels/lookup.hip)
 constexpr int QCNT_WORDS = 4 * NSQ * QCNT_STRIDE;       // fill counters of the four queues
 struct QView {
     QItem* q;

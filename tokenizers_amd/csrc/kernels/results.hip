@@ -22,20 +22,24 @@ constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFF
 // one queued pre-token: first byte and length (the model kernels need nothing else)
 struct __attribute__((aligned(8))) QItem { uint32_t s, len; };
 
-// A work queue is NSQ sub-queues of sq_cap entries each, every one with its own fill counter in its own 128-byte line:
-// atomics on ONE address serialise at ~10 ns each on MI355X (device-scope atomics are resolved at the memory side), and the
-// lookup kernel issues one per workgroup, tile and queue -- tens of thousands per batch.  Workgroup b appends to sub-queue
-// b % NSQ; the consumers see the sub-queues laid end to end (qview_*).  Position p = sub-queue * sq_cap + index names the
-// queue entry and, with row_base, the result row.
+// A work queue is NSQ sub-queues of sq_cap entries each.  Atomics on ONE address serialise at ~10 ns each on MI355X (device-scope
+// atomics are resolved at the memory side), and a shared fill counter would take one per workgroup, tile and queue -- tens of
+// thousands per batch.  Instead lookup workgroup b owns sub-queue b outright and writes its fill once, at the end; the
+// consumers see the sub-queues laid end to end (qview_*).  Position p = sub-queue * sq_cap + index names the queue entry and,
+// with row_base, the result row.
 // (struct QView / NSQ / QCNT_STRIDE: kernels.hpp)
 // all threads of the workgroup: loads the fill counts, leaves their prefix sums in s_pre[NSQ + 1], returns the total
 __device__ __forceinline__ uint32_t qview_prefix(const QView& v, uint32_t* s_pre) {
+    constexpr int PER = NSQ / 64;                           // one wavefront scans the counts, PER consecutive ones per lane
+    static_assert(NSQ % 64 == 0, "sub-queues per lane");
     __syncthreads();
     if (threadIdx.x < 64) {
-        static_assert(NSQ == 64, "one wavefront scans the sub-queue counts");
-        const uint32_t c = min(v.counts[threadIdx.x * QCNT_STRIDE], v.sq_cap);
-        const uint32_t inc = wave_incl_scan(c);
-        s_pre[threadIdx.x + 1] = inc;
+        uint32_t c[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { c[k] = min(v.counts[(threadIdx.x * PER + k) * QCNT_STRIDE], v.sq_cap); sum += c[k]; }
+        uint32_t run = wave_incl_scan(sum) - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { run += c[k]; s_pre[threadIdx.x * PER + k + 1] = run; }
         if (threadIdx.x == 0) s_pre[0] = 0u;
     }
     __syncthreads();
@@ -45,9 +49,10 @@ __device__ __forceinline__ uint32_t qview_prefix(const QView& v, uint32_t* s_pre
 __device__ __forceinline__ uint32_t qview_pos(const uint32_t* s_pre, uint32_t sq_cap, uint32_t item) {
     uint32_t lo = 0, hi = NSQ;                              // invariant: s_pre[lo] <= item < s_pre[hi]
 #pragma unroll
-    for (int it = 0; it < 6; ++it) {
+    for (int it = 0; it < 9; ++it) {
+        static_assert(NSQ <= 512, "binary search depth");
         const uint32_t mid = (lo + hi) >> 1;
-        if (s_pre[mid] <= item) lo = mid; else hi = mid;
+        if (hi - lo > 1) { if (s_pre[mid] <= item) lo = mid; else hi = mid; }
     }
     return lo * sq_cap + (item - s_pre[lo]);
 }
