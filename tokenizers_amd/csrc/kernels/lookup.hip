@@ -25,7 +25,7 @@
 //      wavefronts, so the tok0 stores are one 256-byte line per wavefront); the first <= 12 bytes of the key are probed in an LDS
 //      copy of the HOT table -- the lowest-id (= most frequent, the trainers append tokens in frequency order) settled words of
 //      <= 12 bytes, direct mapped, 16-byte slots.  A hit stores its id; a miss costs one more LDS store: its rank goes to the
-//      wavefront's own miss list;
+//      workgroup's miss list;
 //   4. PASS 2, the misses only, densely packed 64 to a step (a tenth to a fifth of the pre-tokens on natural text): the full
 //      16-byte key in the perfect-hash table in HBM (one displacement load + one 32-byte slot); what still misses is queued by
 //      length class: every workgroup appends to its OWN sub-queue of each queue (results.hip) -- the position comes from an
@@ -40,7 +40,6 @@ static_assert(LU_TILE == LOOKUP_TILE_BYTES, "the host sizes the sub-queues per t
 constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile: a key may start at its last byte
 constexpr int LU_POS_CAP = 4096;                         // pre-tokens expanded per round (more in a tile: another round)
 constexpr int LU_STEPS = LU_POS_CAP / LU_NT;             // steps per lane and round (8)
-constexpr int LU_MISS_CAP = LU_STEPS * 64;               // a wavefront's share of one round
 constexpr int HOT_SLOTS = 2048;                          // 32 KB of LDS: two workgroups per CU overlap each other's load / probe / queue phases
 
 struct LookupArgs {
@@ -70,10 +69,10 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT_SLOTS]
     uint32_t* s_text32 = (uint32_t*)(s_hot + HOT_SLOTS);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
     uint16_t* s_pos = (uint16_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [LU_POS_CAP + 2] start of rank r, relative to the tile
-    uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_WAVES][LU_MISS_CAP] ranks the hot table did not settle
-    uint16_t* s_end = s_miss + LU_WAVES * LU_MISS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
+    uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
+    uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
-    __shared__ uint32_t s_n, s_pbase, s_last_end;
+    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss;
     __shared__ uint32_t s_fill[4];                                               // fill of this workgroup's sub-queues so far
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sq = blockIdx.x;                                // this workgroup's PRIVATE sub-queue (the launcher keeps the grid <= NSQ)
@@ -91,7 +90,6 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     constexpr bool has_end = HAS_END;
     const bool hits_on = a.no_hits == 0u;
     const int64_t readable = a.n_bytes_host + TEXT_PAD;
-    uint16_t* const my_miss = s_miss + wave * LU_MISS_CAP;
     const int half = tid & 1, hword = tid >> 1;                      // lane pair (2 w, 2 w + 1) shares mask word w: low / high 32 bits
     // What a tile needs from memory -- its text, its mask words with their prefix counts, and the 64 mask words behind it (where its
     // last pre-token ends) -- is loaded into registers one tile AHEAD: the loads of tile k+1 are issued before the lookup phase of
@@ -172,6 +170,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 __syncthreads();
             }
             // ---- 2b. positions of the set bits, by rank (ranks rb .. rb + cnt, the extra one is the next start) ----
+            if (tid == 0) s_nmiss = 0u;
             if (rbase != 0xFFFFFFFFu) {
                 const uint32_t lo32 = (uint32_t)ms, bit0 = (uint32_t)hword * 64u + (uint32_t)half * 32u;
                 uint32_t r = rbase - rb + (half ? (uint32_t)__popc(lo32) : 0u);
@@ -206,7 +205,6 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
             };
             // ---- 3. pass 1: the hot table, every pre-token ----
             const uint32_t n_chunks = (cnt + 63u) >> 6;
-            uint32_t n_miss = 0u;                                                   // (wavefront-uniform)
             for (uint32_t chunk = (uint32_t)wave; chunk < n_chunks; chunk += LU_WAVES) {
                 const uint32_t rel = chunk * 64u + lane;
                 const bool v = rel < cnt;
@@ -227,13 +225,19 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 }
                 if (hit) a.tok0[pbase + rb + rel] = TOK_ONE | (h.w & TOK_ID_MASK);
                 const uint64_t mb = __ballot(miss);
-                if (miss) my_miss[n_miss + (uint32_t)mbcnt64(mb)] = (uint16_t)rel;
-                n_miss += (uint32_t)__popcll(mb);
+                if (mb) {                                                           // (wavefront-uniform) the workgroup's miss list
+                    uint32_t base = 0u;
+                    if (lane == 0) base = atomicAdd(&s_nmiss, (uint32_t)__popcll(mb));
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    if (miss) s_miss[base + (uint32_t)mbcnt64(mb)] = (uint16_t)rel;
+                }
             }
-            // ---- 4. pass 2: the misses, packed ----
-            for (uint32_t m0 = 0; m0 < n_miss; m0 += 64u) {
+            __syncthreads();
+            // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
+            const uint32_t n_miss = s_nmiss;
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
                 const bool v = m0 + lane < n_miss;
-                const uint32_t rel = my_miss[v ? m0 + lane : m0];
+                const uint32_t rel = s_miss[v ? m0 + lane : m0];
                 uint32_t s_rel, len, k0, k1, k2, k3;
                 load_key(rel, s_rel, len, k0, k1, k2, k3, true);
                 uint32_t out = 0u;
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                     const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
                     const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
                     const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
-                    const uint4 a0 = q[0], a1 = q[1];
+                    uint4 a0 = q[0], a1 = q[1];
+                    asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
                     const uint32_t diff = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | (a0.w ^ k3) | (a1.x ^ len);
                     if (diff == 0u && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
                 }
@@ -290,4 +295,4 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     }
 }
 
-constexpr int lookup_lds_bytes(bool has_end) { return HOT_SLOTS * 16 + (LU_TILE + LU_TEXT_SLACK) + 16 + (has_end ? 2 : 1) * (LU_POS_CAP + 2) * 2 + LU_WAVES * LU_MISS_CAP * 2; }
+constexpr int lookup_lds_bytes(bool has_end) { return HOT_SLOTS * 16 + (LU_TILE + LU_TEXT_SLACK) + 16 + (has_end ? 2 : 1) * (LU_POS_CAP + 2) * 2 + LU_POS_CAP * 2; }
