@@ -723,8 +723,16 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         mlist = w->w_match_list.as<uint32_t>();
     }
     auto args_of = [&](int c) {
-        return AddedArgs{t->t_at_blob[c].as<uint8_t>(), t->t_at_off[c].as<uint32_t>(), t->t_at_first[c].as<uint32_t>(), t->t_at_id[c].as<uint32_t>(),
-                         t->t_at_flags[c].as<uint32_t>()};
+        AddedArgs a{t->t_at_blob[c].as<uint8_t>(), t->t_at_off[c].as<uint32_t>(), t->t_at_first[c].as<uint32_t>(), t->t_at_id[c].as<uint32_t>(),
+                    t->t_at_flags[c].as<uint32_t>(), {0ull, 0ull, 0ull, 0ull}, 0u, {0u, 0u, 0u, 0u}};
+        const std::vector<uint32_t>& first = hm.at[c].first;
+        for (uint32_t b = 0; b < 256u && first.size() == 257; ++b)
+            if (first[b + 1] > first[b]) {
+                a.first_set[b >> 6] |= 1ull << (b & 63);
+                if (a.n_first < 4u) a.first_byte[a.n_first] = b;
+                ++a.n_first;
+            }
+        return a;
     };
     auto scatter_masks = [&](int64_t n_text, const int64_t* len_dev, bool with_end) {
         ull* m4[4] = {w->w_matchmask.as<ull>(), w->w_spanmask.as<ull>(), w->w_stopmask.as<ull>(), w->w_hardmask.as<ull>()};

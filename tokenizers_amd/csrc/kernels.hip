@@ -39,6 +39,7 @@ __device__ __forceinline__ uint32_t uc_flags(uint32_t cp, const uint16_t* __rest
 }
 
 struct __attribute__((packed, aligned(1))) Unaligned4 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t a, b, c, d; };      // 16-byte global access at any alignment
 // decode the code point whose lead byte is text[i] (text has TKAMD_TEXT_PAD readable slack)
 __device__ __forceinline__ uint32_t utf8_global(const uint8_t* __restrict__ text, int64_t i, uint32_t* len) {
     uint32_t w = ((const Unaligned4*)(text + i))->v;

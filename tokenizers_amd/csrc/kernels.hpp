@@ -93,6 +93,9 @@ struct AddedArgs {
     const uint32_t* first;     // CSR over the first byte
     const uint32_t* id;
     const uint32_t* flags;     // 1 single_word, 2 lstrip, 4 rstrip
+    unsigned long long first_set[4];   // bit b: some pattern starts with byte b
+    uint32_t n_first;          // distinct first bytes; the first four of them:
+    uint32_t first_byte[4];
 };
 
 // arguments of k_add_specials, passed by value

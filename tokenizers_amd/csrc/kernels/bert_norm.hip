@@ -2,7 +2,7 @@
 // helpers; it is not compiled on its own).  BertNormalizer.
 
 // =================================================================================================
-// BertNormalizer (normalizers/bert.rs:92-138), one lane per source byte, full Unicode:
+// BertNormalizer (normalizers/bert.rs:92-138), full Unicode:
 //   clean_text (drop control / U+0000 / U+FFFD, whitespace -> ' ')  ->  handle_chinese_chars (' ' c ' ')
 //   ->  strip_accents (NFD, drop Mn)  ->  lowercase
 // Every step is context free per source character (data probed from the reference: flags in a 2-stage table,
@@ -60,33 +60,60 @@ __device__ __forceinline__ int bn_expand(const BnTables& b, uint32_t cp, uint32_
 }
 __device__ __forceinline__ uint32_t utf8_len_cp(uint32_t cp) { return cp < 0x80u ? 1u : cp < 0x800u ? 2u : cp < 0x10000u ? 3u : 4u; }
 
+// ---- 16 source bytes per lane ----
+// BERT corpora are almost all ASCII, where every step of the normalizer is a byte-wise map: a lane takes 16 bytes with one load,
+// classifies them four at a time with SWAR arithmetic (all bytes < 0x80, so the per-byte high bit is free to carry the
+// comparison results), and only a lane that holds a non-ASCII byte, a byte of a verbatim added-token match or the end of the
+// text walks its bytes one by one through the table-driven path.
+constexpr int BN_LANE = 16;
+constexpr uint32_t SW_H = 0x80808080u, SW_1 = 0x01010101u;
+// 0x80 in every byte of x (all bytes < 0x80) that is < c / == c
+__device__ __forceinline__ uint32_t sw_lt(uint32_t x, uint32_t c) { return ~((x | SW_H) - c * SW_1) & SW_H; }
+__device__ __forceinline__ uint32_t sw_eq(uint32_t x, uint32_t c) { return sw_lt(x ^ (c * SW_1), 1u); }
+// ASCII control characters clean_text drops: < 0x20 except \t \n \r, and 0x7F
+__device__ __forceinline__ uint32_t sw_ascii_ws(uint32_t x) { return sw_eq(x, 9u) | sw_eq(x, 10u) | sw_eq(x, 13u); }
+__device__ __forceinline__ uint32_t sw_ascii_dropped(uint32_t x) { return (sw_lt(x, 0x20u) & ~sw_ascii_ws(x)) | sw_eq(x, 0x7Fu); }
+// bits [i0, i0 + 16) of a bit mask (i0 a multiple of 16)
+__device__ __forceinline__ uint32_t mask16(const unsigned long long* __restrict__ m, int64_t i0) { return (uint32_t)(m[i0 >> 6] >> (i0 & 63)) & 0xFFFFu; }
+
+// output bytes of source byte i, the table-driven way (any byte)
+__device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint8_t* __restrict__ text, int64_t i, uint32_t b, bool verbatim, int* __restrict__ err) {
+    if (verbatim) return 1u;
+    if (b < 0x80u)      // ASCII: control characters except \t \n \r are dropped, everything else is one byte
+        return (bt.clean && ((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu)) ? 0u : 1u;
+    if ((b & 0xC0u) == 0x80u) return 0u;
+    uint32_t len, out[BN_MAX_OUT], ob = 0;
+    bool reorder = false;
+    const uint32_t cp = utf8_global(text, i, &len);
+    const int n = bn_expand(bt, cp, out, &reorder);
+    if (reorder) atomicOr(err, ERR_NON_ASCII_NORM);
+    for (int q = 0; q < n; ++q) ob += utf8_len_cp(out[q]);
+    return ob;
+}
+
 // `verbatim`: bytes of added-token matches of the raw pass (null: none) -- not text for the normalizer: copied as they are
 __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
                                                   uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t ob = 0;
-    if (i < n_bytes) {
-        const uint32_t b = text[i];
-        if (verbatim && ((verbatim[i >> 6] >> (i & 63)) & 1ull)) {
-            ob = 1u;
-        } else if (b < 0x80u) {
-            // ASCII: control characters except \t \n \r are dropped, everything else is one byte
-            ob = (bt.clean && ((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu)) ? 0u : 1u;
-        } else if ((b & 0xC0u) != 0x80u) {
-            uint32_t len, out[BN_MAX_OUT];
-            bool reorder = false;
-            const uint32_t cp = utf8_global(text, i, &len);
-            const int n = bn_expand(bt, cp, out, &reorder);
-            if (reorder) atomicOr(err, ERR_NON_ASCII_NORM);
-            for (int q = 0; q < n; ++q) ob += utf8_len_cp(out[q]);
-        }
-        olen[i] = (uint8_t)ob;
-    }
-    // per-word sum
-    uint32_t s = ob;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BN_LANE;
+    uint32_t o[4] = {0u, 0u, 0u, 0u};                               // output bytes of my 16 source bytes, one per byte
+    if (i0 < n_bytes) {
+        const Unaligned16 t = *(const Unaligned16*)(text + i0);                 // (any alignment: the caller's pointer; readable TEXT_PAD bytes past the end)
+        const uint32_t x[4] = {t.a, t.b, t.c, t.d};
+        const uint32_t vb = verbatim ? mask16(verbatim, i0) : 0u;
+        if (((t.a | t.b | t.c | t.d) & SW_H) == 0u && vb == 0u && i0 + BN_LANE <= n_bytes) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if ((threadIdx.x & 63) == 0 && i <= n_bytes) wsum[i >> 6] = s;
+            for (int k = 0; k < 4; ++k) o[k] = SW_1 - (bt.clean ? (sw_ascii_dropped(x[k]) >> 7) : 0u);
+        } else {
+            const int nv = (int)min((int64_t)BN_LANE, n_bytes - i0);
+            for (int j = 0; j < nv; ++j) o[j >> 2] |= bn_count_byte(bt, text, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, err) << (8 * (j & 3));
+        }
+        *(uint4*)(olen + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    // per-word sum: the four lanes of a 64-byte word
+    uint32_t s = ((o[0] * SW_1) >> 24) + ((o[1] * SW_1) >> 24) + ((o[2] * SW_1) >> 24) + ((o[3] * SW_1) >> 24);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if ((threadIdx.x & 3) == 0 && i0 <= n_bytes) wsum[i0 >> 6] = s;
 }
 
 __global__ __launch_bounds__(256) void k_u32_down(const uint32_t* __restrict__ v, int64_t n, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ out) {
@@ -97,15 +124,10 @@ __global__ __launch_bounds__(256) void k_u32_down(const uint32_t* __restrict__ v
     if (i < n) out[i] = ex;
 }
 
-__global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
-                                                  const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
-                                                  uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint32_t ob = (i < n_bytes) ? olen[i] : 0u;
-    const uint32_t pos = wbase[min(i, n_bytes) >> 6] + wave_incl_scan(ob) - ob;
-    if (!ob) return;
-    const uint32_t b = text[i];
-    if (verbatim && ((verbatim[i >> 6] >> (i & 63)) & 1ull)) {
+// writes the normalised bytes of source byte i (it has some) at `pos`, the table-driven way
+__device__ __forceinline__ void bn_write_byte(const BnTables& bt, const uint8_t* __restrict__ text, int64_t i, uint32_t b, bool verbatim, uint32_t pos,
+                                              uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
+    if (verbatim) {
         ntext[pos] = (uint8_t)b;
         if (nos) { nos[pos] = (uint32_t)i; noe[pos] = (uint32_t)i + 1u; }
         return;
@@ -134,6 +156,45 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
     }
 }
 
+__global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
+                                                  const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
+                                                  uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BN_LANE;
+    uint4 ol = make_uint4(0u, 0u, 0u, 0u);
+    if (i0 < n_bytes) ol = *(const uint4*)(olen + i0);
+    const uint32_t tot = ((ol.x * SW_1) >> 24) + ((ol.y * SW_1) >> 24) + ((ol.z * SW_1) >> 24) + ((ol.w * SW_1) >> 24);
+    // my place: the word's base + the output of the lanes before me in the word (four lanes a word)
+    const int lane = lane_id();
+    const uint32_t t1 = (uint32_t)__shfl_up((int)tot, 1, 64), t2 = (uint32_t)__shfl_up((int)tot, 2, 64), t3 = (uint32_t)__shfl_up((int)tot, 3, 64);
+    const int sub = lane & 3;
+    if (!tot) return;
+    uint32_t pos = wbase[i0 >> 6] + (sub >= 1 ? t1 : 0u) + (sub >= 2 ? t2 : 0u) + (sub >= 3 ? t3 : 0u);
+    const Unaligned16 t = *(const Unaligned16*)(text + i0);
+    uint32_t x[4] = {t.a, t.b, t.c, t.d};
+    const uint32_t vb = verbatim ? mask16(verbatim, i0) : 0u;
+    if (tot == (uint32_t)BN_LANE && ((t.a | t.b | t.c | t.d) & SW_H) == 0u && vb == 0u && i0 + BN_LANE <= n_bytes) {
+        // 16 ASCII bytes, none dropped: \t \n \r -> ' ', A-Z -> a-z, one 16-byte store (at any alignment)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (bt.clean) { const uint32_t m = (sw_ascii_ws(x[k]) >> 7) * 0xFFu; x[k] = (x[k] & ~m) | (0x20202020u & m); }
+            if (bt.lower) x[k] += (~sw_lt(x[k], 0x41u) & sw_lt(x[k], 0x5Bu) & SW_H) >> 2;
+        }
+        *(Unaligned16*)(ntext + pos) = Unaligned16{x[0], x[1], x[2], x[3]};
+        if (nos) {
+#pragma unroll
+            for (int j = 0; j < BN_LANE; ++j) { nos[pos + j] = (uint32_t)i0 + j; noe[pos + j] = (uint32_t)i0 + j + 1u; }
+        }
+        return;
+    }
+    const uint32_t o[4] = {ol.x, ol.y, ol.z, ol.w};
+    const int nv = (int)min((int64_t)BN_LANE, n_bytes - i0);
+    for (int j = 0; j < nv; ++j) {
+        const uint32_t ob = (o[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (ob) bn_write_byte(bt, text, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, pos, ntext, nos, noe);
+        pos += ob;
+    }
+}
+
 // document CSR in normalised coordinates: ndoc_off[d] = #normalised bytes produced before doc_off[d]
 __global__ void k_bn_doc_offsets(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
                                  const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
@@ -146,7 +207,17 @@ __global__ void k_bn_doc_offsets(const int64_t* __restrict__ doc_off, int64_t n_
     if (g >= n_bytes) r = *x_len;
     else {
         r = wbase[g >> 6];
-        for (int64_t q = g & ~(int64_t)63; q < g; ++q) r += olen[q];
+        const int64_t base = g & ~(int64_t)63;
+        for (int q = 0, nb = (int)(g - base); q < nb; q += 16) {       // the bytes of the word before g, 16 at a time
+            const uint4 v = *(const uint4*)(olen + base + q);
+            const uint32_t o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int keep = nb - q - 4 * k;                       // bytes of this 4-byte group that lie before g
+                const uint32_t m = keep >= 4 ? 0xFFFFFFFFu : (keep > 0 ? (1u << (8 * keep)) - 1u : 0u);
+                r += ((o[k] & m) * SW_1) >> 24;
+            }
+        }
     }
     ndoc_off[d] = r;
 }

@@ -1,7 +1,6 @@
 // Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
 // helpers; it is not compiled on its own).  BPE: whole-word lookup and the merge kernels.
 
-struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t a, b, c, d; };
 
 __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint64_t* lo, uint64_t* hi) {
     // ONE byte-unaligned global_load_dwordx4 (legal on gfx950; text buffers carry TKAMD_TEXT_PAD readable slack).

@@ -78,14 +78,41 @@ __device__ __forceinline__ int added_longest(const AddedArgs& a, const uint8_t* 
     return best;
 }
 
+// 16 bytes per lane.  Almost no byte starts a pattern: the lane first asks "is any of my bytes the first byte of a pattern" --
+// four SWAR operations per first byte and 4-byte word when the patterns start with at most four distinct bytes (special tokens:
+// '[' or '<'), a 256-bit set in scalar registers otherwise -- and runs the exact comparison only from the bytes that are.
 __global__ __launch_bounds__(256) void k_added_candidates(AddedArgs a, const uint8_t* __restrict__ text, int64_t n_bytes_host,
                                                           const int64_t* __restrict__ len_dev, unsigned long long* __restrict__ candmask) {
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool cand = false;
-    if (i < n_bytes) { uint32_t l; cand = added_longest(a, text, i, n_bytes, &l) >= 0; }
-    uint64_t m = __ballot(cand);
-    if ((threadIdx.x & 63) == 0 && i <= n_bytes_host) candmask[i >> 6] = m;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    uint32_t cand = 0u;                                             // bit j: a pattern starts at byte i0 + j
+    if (i0 < n_bytes) {
+        const Unaligned16 t = *(const Unaligned16*)(text + i0);                 // (any alignment: the caller's pointer; readable TEXT_PAD bytes past the end)
+        const uint32_t x[4] = {t.a, t.b, t.c, t.d};
+        bool any = a.n_first > 4u;
+        if (!any) {
+            uint32_t f = 0u;
+            for (uint32_t q = 0; q < a.n_first; ++q) {              // (uniform, <= 4 rounds) zero-byte test of x ^ first byte; may overshoot, never misses
+                const uint32_t c = a.first_byte[q] * 0x01010101u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { const uint32_t z = x[k] ^ c; f |= (z - 0x01010101u) & ~z; }
+            }
+            any = (f & 0x80808080u) != 0u;
+        }
+        if (any) {
+            const int nv = (int)min((int64_t)16, n_bytes - i0);
+            for (int j = 0; j < nv; ++j) {
+                const uint32_t b = (x[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                const unsigned long long set = b < 128u ? (b < 64u ? a.first_set[0] : a.first_set[1]) : (b < 192u ? a.first_set[2] : a.first_set[3]);
+                if ((set >> (b & 63u)) & 1ull) { uint32_t l; if (added_longest(a, text, i0 + j, n_bytes, &l) >= 0) cand |= 1u << j; }
+            }
+        }
+    }
+    // the four lanes of a 64-byte word
+    unsigned long long m = (unsigned long long)cand << (16 * (threadIdx.x & 3));
+    m |= ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), 1, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)m, 1, 64);
+    m |= ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(m >> 32), 2, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)m, 2, 64);
+    if ((threadIdx.x & 3) == 0 && i0 <= n_bytes_host) candmask[i0 >> 6] = m;
 }
 
 __device__ __forceinline__ void mask_set_range(unsigned long long* m, int64_t a, int64_t b) {      // bits [a, b)

@@ -111,12 +111,12 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                            const unsigned long long* verbatim, uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext,
                            uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err) {
     const int64_t n_words = (n_bytes >> 6) + 1;
-    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, bt, text, n_bytes, verbatim, olen, wsum, err);
+    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, olen, wsum, err);
     unsigned nb = blocks_for(n_words, 256);
     hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, bsum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
     hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, (const uint32_t*)bsum, wbase);
-    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256)), dim3(256), 0, st, bt, text, n_bytes, verbatim, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
+    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
     hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
@@ -184,7 +184,7 @@ void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a) {
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
                         uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err) {
-    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, a, text, n_bytes, len_dev, candmask);
+    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256 * 16)), dim3(256), 0, st, a, text, n_bytes, len_dev, candmask);
     hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_segs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)candmask, seg_off, n_segs, n_segs_dev, sents, n_sents);
     hipLaunchKernelGGL(k_added_resolve, dim3(1024), dim3(64), 0, st, a, text, seg_off, (const uint32_t*)sents, (const uint32_t*)n_sents,
                        (const unsigned long long*)candmask, skipmask, uc1, uc2, match_list, n_match, cap, len_flag, err);

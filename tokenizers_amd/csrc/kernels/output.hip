@@ -53,8 +53,16 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
                 if (c > 2) (DST)[(O) + 2] = (R).row[k].z;                                                     \
                 if (c > 3) (DST)[(O) + 3] = (R).row[k].w;                                                     \
             } else {                                                                                          \
-                const uint32_t s_ = (R).row[k].y;                                                             \
-                for (uint32_t j = 1; j < c; ++j) (DST)[(O) + j] = tmp_ids[s_ + j];                            \
+                /* ids 1.. of a longer run: tmp_ids[s + 1 ..], four to a load (16 bytes at any alignment; the  */ \
+                /* buffer extends four words past the text, so the last load may overshoot the run)           */ \
+                const uint32_t* const src_ = tmp_ids + (R).row[k].y;                                          \
+                for (uint32_t j = 1; j < c; j += 4) {                                                         \
+                    const Unaligned16 v_ = *(const Unaligned16*)(src_ + j);                                   \
+                    (DST)[(O) + j] = v_.a;                                                                    \
+                    if (j + 1 < c) (DST)[(O) + j + 1] = v_.b;                                                 \
+                    if (j + 2 < c) (DST)[(O) + j + 2] = v_.c;                                                 \
+                    if (j + 3 < c) (DST)[(O) + j + 3] = v_.d;                                                 \
+                }                                                                                             \
             }                                                                                                 \
         }                                                                                                     \
         (O) += c;                                                                                             \
