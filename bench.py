@@ -353,12 +353,13 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-KERNEL_OF_STAGE = {"bpe_word_lookup": "k_bpe_word_lookup", "bpe_merge_lds": "k_bpe_merge_lds<16,704,true,true>",
-                   "bpe_merge_lds32": "k_bpe_merge_lds<32,768,true,true>", "bpe_merge_lane": "k_bpe_merge_lane<16>",
+# profile stage (capi.cpp Prof) -> the kernel that dominates it, as rocprofv3 names it (prefix match)
+KERNEL_OF_STAGE = {"bpe_merge_lds": "k_bpe_merge_lds<16,", "bpe_merge_lds32": "k_bpe_merge_lds<32,", "bpe_merge_lane": "k_bpe_merge_lane<16>",
                    "bpe_merge_lane32": "k_bpe_merge_lane<32>", "bpe_merge16": "k_bpe_merge<16>", "bpe_merge64": "k_bpe_merge<64>",
-                   "pretok_gpt2": "k_pretok_gpt2", "pretok_gpt2_seq": "k_pretok_gpt2_seq", "compact": "k_compact",
-                   "emit_pretok": "k_emit_pretok", "lookup": "k_lookup", "bert_normalize": "k_bn_write", "wordpiece": "k_wordpiece",
-                   "wordpiece_word_lookup": "k_bpe_word_lookup"}
+                   "pretok_gpt2": "k_pretok_gpt2", "pretok_gpt2_seq": "k_pretok_gpt2_seq", "pretok_llama3": "k_pretok_llama3_lane",
+                   "pretok_local": "k_pretok_local", "compact": "k_compact", "emit_pretok": "k_emit_pretok", "lookup": "k_lookup",
+                   "wordpiece_word_lookup": "k_lookup", "wordlevel_lookup": "k_lookup", "bert_normalize": "k_bn_write",
+                   "wordpiece": "k_wordpiece", "added_token_match": "k_added_candidates"}
 
 
 def pmc_traffic(stage: str, config: str = "c2"):

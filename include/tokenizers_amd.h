@@ -111,6 +111,16 @@ const char* tkamd_last_error(void);
 int tkamd_encode_batch(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* doc_offsets,
                        int64_t n_docs, uint32_t flags, tkamd_batch** out);
 
+/* is_pretokenized = true (InputSequence::PreTokenized, tokenizer/mod.rs:225-290; encode_single_sequence :782-795): every input
+ * sequence is a list of words.  The reference encodes each word on its own -- AddedVocabulary, normalizer, pre-tokenizer, model:
+ * a ByteLevel add_prefix_space therefore applies to every word, and offsets are relative to the WORD -- and merges the
+ * encodings with word_ids = the word's index in its sequence; truncation, special tokens and padding then see one encoding per
+ * sequence.  `text` is the concatenation of all words, word_offsets[n_words + 1] their byte CSR, seq_offsets[n_seqs + 1] the CSR of
+ * the sequences over the words.  With TKAMD_PAIRS sequences 2i and 2i + 1 are sequence A and B of encoding i.  The result holds one
+ * encoding per sequence (or pair). */
+int tkamd_encode_batch_words(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* word_offsets, int64_t n_words,
+                             const int64_t* seq_offsets, int64_t n_seqs, uint32_t flags, tkamd_batch** out);
+
 int64_t         tkamd_batch_n_docs(const tkamd_batch* b);
 int64_t         tkamd_batch_n_tokens(const tkamd_batch* b);
 const uint32_t* tkamd_batch_ids(const tkamd_batch* b);          /* [n_tokens]                   */
@@ -145,6 +155,10 @@ typedef struct tkamd_device_result {
 int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,
                               int64_t n_docs, int64_t n_bytes, uint32_t flags, void* hip_stream,
                               tkamd_device_result* out);
+/* tkamd_encode_batch_words on device-resident buffers (d_seq_offsets: [n_seqs + 1] int64 in HBM as well). */
+int tkamd_encode_batch_words_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_word_offsets, int64_t n_words,
+                                    int64_t n_bytes, const int64_t* d_seq_offsets, int64_t n_seqs, uint32_t flags, void* hip_stream,
+                                    tkamd_device_result* out);
 int tkamd_device_sync(tkamd_tokenizer* tok, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens);
 
 /* ---- decode_batch: token ids -> text -----------------------------------------------------------

@@ -40,6 +40,10 @@ def test_no_cpu_fallback_on_host_only_handle():
     t = ta.Tokenizer.from_str(load_tokenizer_json("gpt2_synth_50257"), device=-1)
     with pytest.raises(ta.DeviceError, match="no CPU fallback"):
         t.encode_batch_fast(["hello world"], add_special_tokens=False)
+    with pytest.raises(ta.DeviceError, match="no CPU fallback"):      # is_pretokenized: marshals the words, then fails as loudly
+        t.encode_batch_fast([["hello", "world"], []], is_pretokenized=True, add_special_tokens=False)
+    with pytest.raises(TypeError, match="list of str"):
+        t.encode_batch_fast(["hello world"], is_pretokenized=True)
 
 
 def _base(model, pre=None, **kw):

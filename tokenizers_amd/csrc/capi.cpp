@@ -102,12 +102,15 @@ struct Workspace {
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask, w_boundmask, w_bprefix, w_seg_off, w_xseg_off,
         w_match_docs, w_match_list;
     // host entry staging
-    DevBuf h_text, h_doc_off;
+    DevBuf h_text, h_doc_off, h_seq_off;
+    DevBuf w_seq_off, w_seq_tok_off, w_word_idx;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
     // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
     std::vector<StageRec> pending;
     // last call (for tkamd_device_sync, which runs it again if a work queue overflowed)
     const uint8_t* last_text = nullptr;
     const int64_t* last_doc_off = nullptr;
+    const int64_t* last_seq_off = nullptr;      // is_pretokenized call: the sequence CSR (else null)
+    int64_t last_n_seqs = -1;
     int64_t last_n_bytes = 0;
     uint32_t last_flags = 0;
     tkamd_device_result last_result{};
@@ -443,8 +446,10 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
 // bytes deleted/replaced, w_norig maps back) or ByteLevel add_prefix_space inserted leading spaces
 // (documents shifted, mapped back per document).  When X is derived its length only exists on the
 // device (x_len_dev); kernels are launched over the host-side bound n_x and read the effective length.
+// d_seq_off / n_seqs: is_pretokenized inputs (InputSequence::PreTokenized, tokenizer/mod.rs:782-795) -- the documents are the WORDS and
+// sequence s is the words [d_seq_off[s], d_seq_off[s + 1]); n_seqs < 0: plain documents.
 void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
-                  uint32_t flags, hipStream_t st, tkamd_device_result* out) {
+                  const int64_t* d_seq_off, int64_t n_seqs, uint32_t flags, hipStream_t st, tkamd_device_result* out) {
     HostModel& hm = t->hm;
     const uint32_t off_mode = flags & TKAMD_OFFSETS_MASK;
     const bool want_words = (flags & TKAMD_WANT_WORD_IDS) != 0;
@@ -494,22 +499,36 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
     w->last_n_docs = n_docs;
+    w->last_seq_off = d_seq_off;
+    w->last_n_seqs = n_seqs;
     // the caller's CSR is validated once; everything below reads the validated copy
     w->w_doc_off.reserve((size_t)(n_docs + 2) * 8);
     pf.begin("validate_csr");
     launch_validate_csr(st, d_doc_off, n_docs, n_bytes, d_err, w->w_doc_off.as<int64_t>());
     pf.end();
     d_doc_off = w->w_doc_off.as<int64_t>();
+    // what the epilogues below see: one encoding per document, or per sequence of words
+    const bool words_in = n_seqs >= 0;
+    if (words_in) {
+        if (!d_seq_off) throw Invalid("null sequence offsets");
+        w->w_seq_off.reserve((size_t)(n_seqs + 2) * 8);
+        w->w_seq_tok_off.reserve((size_t)(n_seqs + 2) * 8);
+        launch_validate_csr(st, d_seq_off, n_seqs, n_docs, d_err, w->w_seq_off.as<int64_t>());     // a CSR over [0, n_words]
+        d_seq_off = w->w_seq_off.as<int64_t>();
+        out->d_tok_offsets = w->w_seq_tok_off.as<int64_t>();
+    }
+    const int64_t* const e_tok_off = words_in ? w->w_seq_tok_off.as<int64_t>() : w->w_tok_offsets.as<int64_t>();
+    const int64_t e_n = words_in ? n_seqs : n_docs;
     auto add_specials = [&]() {
         // PostProcessor::process for a single sequence (processors/bert.rs:51-120, template.rs:544-590): specials around every document
-        const size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
+        const size_t T2 = (size_t)n_x + 4 + (size_t)(e_n + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
         w->w_ids2.reserve(T2 * 4);
-        w->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
+        w->w_tok_offsets2.reserve((size_t)(e_n + 2) * 8);
         if (out->d_offsets) w->w_offsets2.reserve(T2 * 8);
         if (out->d_word_ids) w->w_word_ids2.reserve(T2 * 4);
         SpecialArgs sa{};
-        sa.tok_offsets = w->w_tok_offsets.as<int64_t>();
-        sa.n_docs = n_docs;
+        sa.tok_offsets = e_tok_off;
+        sa.n_docs = e_n;
         sa.ids = w->w_ids.as<uint32_t>();
         sa.offsets = out->d_offsets;
         sa.word_ids = out->d_word_ids;
@@ -535,22 +554,22 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_type_ids = nullptr;
     out->d_seq_ids = nullptr;
     const bool pairs = (flags & TKAMD_PAIRS) != 0;
-    if (pairs && (n_docs & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
+    if (pairs && (e_n & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
     if (pairs && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
     const bool epilogue = hm.trunc_on || hm.pad_on || pairs;
     auto finalize_pairs = [&]() {
         // EncodeInput::Dual: the two sequences of a pair were encoded as two documents; cut, lay out and pad them together
-        const int64_t n_pairs = n_docs / 2;
+        const int64_t n_pairs = e_n / 2;
         const bool tpl_on = (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair.empty();
         uint32_t n_special = 0;
         if (tpl_on) for (const HostModel::TplPiece& q : hm.pp_pair) n_special += q.kind == 2u;
         PairArgs pa{};
-        pa.tok_offsets = w->w_tok_offsets.as<int64_t>();
+        pa.tok_offsets = e_tok_off;
         pa.n_pairs = n_pairs;
         pa.ids = w->w_ids.as<uint32_t>();
         pa.offsets = out->d_offsets;
         pa.word_ids = out->d_word_ids;
-        w->w_keep.reserve((size_t)(n_docs + 2) * 4);
+        w->w_keep.reserve((size_t)(e_n + 2) * 4);
         pa.tpl = tpl_on ? t->t_pp_pair.as<uint32_t>() : t->t_pp_pair_plain.as<uint32_t>();
         pa.n_tpl = tpl_on ? (int32_t)hm.pp_pair.size() : (int32_t)hm.pp_pair_plain.size();
         pa.n_special = n_special;
@@ -624,8 +643,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         // truncation -> special tokens -> padding (tokenizer/mod.rs:1265-1317) as one epilogue over the token CSR
         const uint32_t n_add = add_special ? (uint32_t)(hm.pp_prefix.size() + hm.pp_suffix.size()) : 0u;
         FinalArgs fa{};
-        fa.tok_offsets = w->w_tok_offsets.as<int64_t>();
-        fa.n_docs = n_docs;
+        fa.tok_offsets = e_tok_off;
+        fa.n_docs = e_n;
         fa.ids = w->w_ids.as<uint32_t>();
         fa.offsets = out->d_offsets;
         fa.word_ids = out->d_word_ids;
@@ -645,11 +664,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.pad_multiple = hm.pad_multiple;
         fa.pad_left = hm.pad_left ? 1u : 0u;
         fa.pad_id = hm.pad_id;
-        w->w_len1.reserve((size_t)(n_docs + 2) * 4);
-        w->w_fin.reserve((size_t)(n_docs + 2) * 4);
-        w->w_fbsum.reserve((size_t)((n_docs + 1) / 256 + 2) * 4);
-        w->w_tok_offsets2.reserve((size_t)(n_docs + 2) * 8);
-        if (hm.pad_on) w->w_pad_count.reserve((size_t)(n_docs + 2) * 4);
+        w->w_len1.reserve((size_t)(e_n + 2) * 4);
+        w->w_fin.reserve((size_t)(e_n + 2) * 4);
+        w->w_fbsum.reserve((size_t)((e_n + 1) / 256 + 2) * 4);
+        w->w_tok_offsets2.reserve((size_t)(e_n + 2) * 8);
+        if (hm.pad_on) w->w_pad_count.reserve((size_t)(e_n + 2) * 4);
         fa.len1 = w->w_len1.as<uint32_t>();
         fa.fin = w->w_fin.as<uint32_t>();
         fa.bsum = w->w_fbsum.as<uint32_t>();
@@ -661,7 +680,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.begin("truncate_pad");
         launch_final_lens(st, fa);
         // capacity of the padded arrays: known up front for Fixed; BatchLongest needs the batch maximum (one 4-byte read-back)
-        size_t T2 = (size_t)n_x + 4 + (size_t)(n_docs + 1) * n_add;
+        size_t T2 = (size_t)n_x + 4 + (size_t)(e_n + 1) * n_add;
         if (hm.pad_on) {
             uint64_t target = hm.pad_length;
             if (!hm.pad_fixed) {
@@ -671,7 +690,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                 target = mx;
             }
             if (hm.pad_multiple > 0 && target % hm.pad_multiple > 0) target += hm.pad_multiple - target % hm.pad_multiple;
-            T2 += (size_t)n_docs * (size_t)target;
+            T2 += (size_t)e_n * (size_t)target;
             if ((uint64_t)T2 >= ((uint64_t)1 << 32)) throw Invalid("the padded batch would hold more than 2^32 tokens: pad fewer documents per call");
         }
         w->w_ids2.reserve(T2 * 4);
@@ -693,9 +712,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (n_bytes == 0) {
         // only empty documents: no tokens, but the post-processor still puts its specials around every one of them
         HIP_CHECK(hipMemsetAsync(w->w_tok_offsets.p, 0, (size_t)(n_docs + 1) * 8, st));
+        if (words_in) HIP_CHECK(hipMemsetAsync(w->w_seq_tok_off.p, 0, (size_t)(n_seqs + 1) * 8, st));
         if (off_mode != TKAMD_OFFSETS_NONE) out->d_offsets = w->w_offsets.as<uint32_t>();
         if (want_words) out->d_word_ids = w->w_word_ids.as<uint32_t>();
-        if (epilogue) finalize();
+        if (pairs) finalize_pairs();
+        else if (epilogue) finalize();
         else if (add_special) add_specials();
         w->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
         HIP_CHECK(hipGetLastError());
@@ -1001,7 +1022,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.end();
         pf.begin("wordpiece");
         for (int c = 0; c < 4; ++c)
-            launch_wordpiece(st, c == 0 ? grid : t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+            launch_wordpiece(st, c == 0 ? grid : t->n_cu, c == 0, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
         pf.end();
     }
     if (matchmask)
@@ -1016,8 +1037,15 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     launch_doc_tok_offsets(st, w->w_doc_pt.as<uint32_t>(), n_docs, w->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
                            w->w_tok_offsets.as<int64_t>());
     pf.end();
+    const uint32_t* word_of_doc = nullptr;
+    if (words_in) {
+        // the words' token CSR -> the sequences'; the word id of a token is its word's index in the sequence
+        if (want_words) { w->w_word_idx.reserve((size_t)(n_docs + 2) * 4); word_of_doc = w->w_word_idx.as<uint32_t>(); }
+        launch_seq_regroup(st, d_seq_off, n_seqs, n_docs, w->w_tok_offsets.as<int64_t>(), w->w_seq_tok_off.as<int64_t>(), (uint32_t*)word_of_doc);
+    }
     if (want_meta) {
         MetaArgs a{};
+        a.word_of_doc = word_of_doc;
         a.x_text = x_text;
         a.text = d_text;
         a.pt_start = w->w_pt_start.as<uint32_t>();
@@ -1075,7 +1103,7 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
     while ((bits & ERR_QUEUE_FULL) && !(bits & ~ERR_QUEUE_FULL) && t->q16_div > 2) {
         t->q16_div = 2;                                  // n_bytes / 2 + 1024 entries: a queued pre-token has at least two bytes
         tkamd_device_result again{};
-        run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_flags, st, &again);
+        run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again);
         if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
             again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts || again.d_type_ids != w->last_result.d_type_ids)
             throw HipError("result buffers moved while a batch was run again");
@@ -1256,8 +1284,8 @@ int tkamd_tokenizer_specials(const tkamd_tokenizer* t, uint32_t* prefix_ids, int
     return TKAMD_OK;
 }
 
-int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_offsets, int64_t n_docs,
-                              int64_t n_bytes, uint32_t flags, void* hip_stream, tkamd_device_result* out) {
+static int encode_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_offsets, int64_t n_docs, int64_t n_bytes,
+                         const int64_t* d_seq_offsets, int64_t n_seqs, uint32_t flags, void* hip_stream, tkamd_device_result* out) {
     if (!t || !out || !d_doc_offsets || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_text))
         return set_error(TKAMD_ERR_INVALID, "bad argument");
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
@@ -1265,10 +1293,19 @@ int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const i
         Workspace* w = workspace_of_stream(t, (hipStream_t)hip_stream, true);
         std::lock_guard<std::mutex> lk(w->mu);
         HIP_CHECK(hipSetDevice(t->device));
-        run_pipeline(t, w, d_text, d_doc_offsets, n_docs, n_bytes, flags, (hipStream_t)hip_stream, out);
+        run_pipeline(t, w, d_text, d_doc_offsets, n_docs, n_bytes, d_seq_offsets, n_seqs, flags, (hipStream_t)hip_stream, out);
         w->last_text = d_text; w->last_doc_off = d_doc_offsets; w->last_n_bytes = n_bytes; w->last_flags = flags; w->last_result = *out;
         return TKAMD_OK;
     });
+}
+int tkamd_encode_batch_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_offsets, int64_t n_docs,
+                              int64_t n_bytes, uint32_t flags, void* hip_stream, tkamd_device_result* out) {
+    return encode_device(t, d_text, d_doc_offsets, n_docs, n_bytes, nullptr, -1, flags, hip_stream, out);
+}
+int tkamd_encode_batch_words_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_word_offsets, int64_t n_words, int64_t n_bytes,
+                                    const int64_t* d_seq_offsets, int64_t n_seqs, uint32_t flags, void* hip_stream, tkamd_device_result* out) {
+    if (!d_seq_offsets || n_seqs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    return encode_device(t, d_text, d_word_offsets, n_words, n_bytes, d_seq_offsets, n_seqs, flags, hip_stream, out);
 }
 
 int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens) {
@@ -1286,8 +1323,10 @@ int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, i
 // Host entry.  The batch is cut into document-aligned slices that alternate between two workspaces, each on its own stream:
 // while slice k's kernels run, slice k+1's text crosses the bus and slice k-1's ids go back (H2D, kernels and D2H use different
 // engines).  Small batches, and BatchLongest padding (its target is a property of the whole batch), go as one slice.
-int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
-                       tkamd_batch** out) {
+// seq_offsets / n_seqs: is_pretokenized inputs -- the documents are words, sequence s = words [seq_offsets[s], seq_offsets[s + 1]); the
+// slices are then cut between sequences.  n_seqs < 0: plain documents.
+static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
+                       int64_t n_seqs, uint32_t flags, tkamd_batch** out) {
     if (!t || !out || !doc_offsets || n_docs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
     *out = nullptr;
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
@@ -1296,20 +1335,30 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         const int64_t n_bytes = doc_offsets[n_docs];
         if (n_bytes < 0 || doc_offsets[0] != 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
         if (n_bytes > 0 && !text) throw Invalid("null text");
-        const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;            // documents per encoding
-        if (n_docs % unit) throw Invalid("TKAMD_PAIRS: an odd number of documents");
+        const bool words_in = n_seqs >= 0;
+        if (words_in) {
+            if (seq_offsets[0] != 0 || seq_offsets[n_seqs] != n_docs) throw Invalid("seq_offsets is not a monotone CSR over [0, n_words]");
+            for (int64_t q = 0; q < n_seqs; ++q)
+                if (seq_offsets[q + 1] < seq_offsets[q]) throw Invalid("seq_offsets is not a monotone CSR over [0, n_words]");
+        }
+        const int64_t n_grp = words_in ? n_seqs : n_docs;              // sequences: what slices and encodings are counted in
+        auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
+        const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;            // sequences per encoding
+        if (n_grp % unit) throw Invalid("TKAMD_PAIRS: an odd number of sequences");
         static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
         int n_slices = (int)std::min<int64_t>(8, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed)) n_slices = 1;
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)
-        std::vector<int64_t> cut(n_slices + 1, 0);
-        cut[n_slices] = n_docs;
+        std::vector<int64_t> cut(n_slices + 1, 0);                     // in sequences
+        cut[n_slices] = n_grp;
         for (int k = 1; k < n_slices; ++k) {
             const int64_t target = n_bytes / n_slices * k;
-            cut[k] = std::max<int64_t>(cut[k - 1], (std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets) / unit * unit);
+            int64_t g = std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets;
+            if (words_in) g = std::lower_bound(seq_offsets, seq_offsets + n_seqs, g) - seq_offsets;      // the first sequence starting at or after that word
+            cut[k] = std::max<int64_t>(cut[k - 1], g / unit * unit);
         }
-        const int64_t n_enc = n_docs / unit;
+        const int64_t n_enc = n_grp / unit;
         HostLease l0(t);
         std::unique_ptr<HostLease> l1(n_slices > 1 ? new HostLease(t) : nullptr);
         Workspace* ws[2] = {l0.w, l1 ? l1->w : l0.w};
@@ -1334,15 +1383,22 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         auto issue = [&](int k) {
             Workspace* w = ws[k & 1];
             hipStream_t s = st[k & 1];
-            const int64_t d0 = cut[k], d1 = cut[k + 1], b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
+            const int64_t d0 = doc_of(cut[k]), d1 = doc_of(cut[k + 1]), b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
             if (nb < 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+            const int64_t g0 = cut[k], g1 = cut[k + 1];
+            if (words_in) {
+                w->h_seq_off.reserve((size_t)(g1 - g0 + 1) * 8);
+                HIP_CHECK(hipMemcpyAsync(w->h_seq_off.p, seq_offsets + g0, (size_t)(g1 - g0 + 1) * 8, hipMemcpyHostToDevice, s));
+                if (d0) launch_add_i64(s, w->h_seq_off.as<int64_t>(), g1 - g0 + 1, -d0);             // the slice's words count from 0
+            }
             w->h_text.reserve((size_t)nb + TKAMD_TEXT_PAD);
             w->h_doc_off.reserve((size_t)(d1 - d0 + 1) * 8);
             if (nb) HIP_CHECK(hipMemcpyAsync(w->h_text.p, text + b0, (size_t)nb, hipMemcpyHostToDevice, s));
             HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + nb, 0, TKAMD_TEXT_PAD, s));
             HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, s));
             if (b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), d1 - d0 + 1, -b0);           // the slice's own CSR starts at 0
-            run_pipeline(t, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), d1 - d0, nb, flags, s, &res[k]);
+            run_pipeline(t, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), d1 - d0, nb, words_in ? w->h_seq_off.as<int64_t>() : nullptr,
+                         words_in ? g1 - g0 : -1, flags, s, &res[k]);
             w->last_text = w->h_text.as<uint8_t>(); w->last_doc_off = w->h_doc_off.as<int64_t>(); w->last_n_bytes = nb; w->last_flags = flags; w->last_result = res[k];
         };
         auto finish = [&](int k) -> int {
@@ -1352,7 +1408,7 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             const int bits = finish_batch(t, w, s, &n_tok, &n_pt);
             if (bits) return bits;
             const tkamd_device_result& r = res[k];
-            const int64_t seen_docs = cut[k + 1];
+            const int64_t seen_docs = doc_of(cut[k + 1]);
             const int64_t d0 = cut[k] / unit, d1 = cut[k + 1] / unit;      // encodings of this slice
             slice_tok[k] = n_tok;
             const size_t need = (size_t)(tok_base + n_tok);
@@ -1414,6 +1470,16 @@ int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         *out = b.release();
         return TKAMD_OK;
     });
+}
+
+int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
+                       tkamd_batch** out) {
+    return encode_host(t, text, doc_offsets, n_docs, nullptr, -1, flags, out);
+}
+int tkamd_encode_batch_words(tkamd_tokenizer* t, const uint8_t* text, const int64_t* word_offsets, int64_t n_words, const int64_t* seq_offsets,
+                             int64_t n_seqs, uint32_t flags, tkamd_batch** out) {
+    if (!seq_offsets || n_seqs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    return encode_host(t, text, word_offsets, n_words, seq_offsets, n_seqs, flags, out);
 }
 
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b) { return (b && b->has_pads) ? (const uint32_t*)b->pad_counts.p : nullptr; }

@@ -71,6 +71,7 @@ struct MetaArgs {
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
     const int64_t* n_pretok;
     const uint32_t* doc_pt;
+    const uint32_t* word_of_doc;      // is_pretokenized: word id of every token of document d (its index in the sequence); else null
     int64_t n_docs;
     const int64_t* x_doc_off;         // document CSR in x space
     const int64_t* doc_off;           // document CSR in the original text
@@ -229,12 +230,13 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
 // whole-word vocabulary hits of QUEUED pre-tokens longer than 16 bytes (ignore_merges, WordLevel): a hit becomes the result row and
 // the queue entry is retired (length 0) so that the model kernels skip it
 void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err);
-void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
+void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
+void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx);
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 // truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy

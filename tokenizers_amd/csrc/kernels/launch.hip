@@ -123,9 +123,10 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
 void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err) {
     hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err);
 }
-void launch_wordpiece(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
+void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err) {
-    hipLaunchKernelGGL(k_wordpiece, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
+    if (short_words) hipLaunchKernelGGL(k_wordpiece<true>, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
+    else hipLaunchKernelGGL(k_wordpiece<false>, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
 }
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
@@ -142,6 +143,10 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
 }
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask) {
     hipLaunchKernelGGL(k_leadmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, leadmask);
+}
+void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx) {
+    hipLaunchKernelGGL(k_seq_tok_offsets, dim3(blocks_for(n_seqs + 1, 256)), dim3(256), 0, st, seq_off, n_seqs, word_tok_off, seq_tok_off);
+    if (widx && n_words) hipLaunchKernelGGL(k_word_index, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, seq_off, n_seqs, n_words, widx);
 }
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);

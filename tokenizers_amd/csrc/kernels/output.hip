@@ -143,6 +143,23 @@ __global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n
     tok_offsets[d] = ((int64_t)p < *n_pretok) ? (int64_t)pt_tokoff[p] : *n_tok;
 }
 
+// is_pretokenized inputs (InputSequence::PreTokenized, tokenizer/mod.rs:782-795): every word of a sequence went through the pipeline
+// as a document of its own -- the reference encodes each word separately and merges the encodings -- and sequence s owns the tokens
+// of the words [seq_off[s], seq_off[s + 1]).  (seq_off is the validated copy: launch_validate_csr.)
+__global__ void k_seq_tok_offsets(const int64_t* __restrict__ seq_off, int64_t n_seqs, const int64_t* __restrict__ word_tok_off,
+                                  int64_t* __restrict__ seq_tok_off) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= n_seqs) seq_tok_off[s] = word_tok_off[seq_off[s]];
+}
+// Encoding.word_ids of a pre-tokenized sequence: the index of the word in its sequence (do_tokenize's word_idx, mod.rs:1178-1200)
+__global__ void k_word_index(const int64_t* __restrict__ seq_off, int64_t n_seqs, int64_t n_words, uint32_t* __restrict__ widx) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    int64_t lo = 0, hi = n_seqs;                          // last s with seq_off[s] <= w
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (seq_off[mid] <= w) lo = mid; else hi = mid; }
+    widx[w] = (uint32_t)(w - seq_off[lo]);
+}
+
 // =================================================================================================
 // K_token_meta: per-token (start, end) offsets and word ids.
 // Replaces the per-token half of PreTokenizedString::into_encoding (tokenizer/pre_tokenizer.rs:231-256):
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         int64_t lo = 0, hi = a.n_docs;
         while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if ((int64_t)a.doc_pt[mid] <= p) lo = mid; else hi = mid; }
         const int64_t d = lo;
-        const uint32_t word = (uint32_t)(p - a.doc_pt[d]);
+        const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - a.doc_pt[d]);
         const uint32_t xdoc = (uint32_t)a.x_doc_off[d];
         const uint32_t odoc = (uint32_t)a.doc_off[d];
         uint32_t rel = 0;

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
     }
 }
 
+// SHORT: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again
+template <bool SHORT>
 __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
                                                    uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
     __shared__ uint32_t s_qpre[NSQ + 1];
@@ -46,8 +48,16 @@ __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* _
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
         const uint32_t s = it.s, len = it.len;
+        uint64_t lo = 0, hi = 0;
         uint32_t chars = 0;
-        for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
+        if (SHORT) {
+            load_key16(text, s, len, &lo, &hi);
+            // chars = bytes that are not 10xxxxxx continuation bytes (bit 7 set, bit 6 clear)
+            const uint64_t cl = lo & 0x8080808080808080ull & ~((lo << 1) & 0x8080808080808080ull), ch = hi & 0x8080808080808080ull & ~((hi << 1) & 0x8080808080808080ull);
+            chars = len - (uint32_t)(__popcll(cl) + __popcll(ch));
+        } else {
+            for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
+        }
         bool bad = chars > t.max_input_chars;
         uint32_t pos = 0, j = 0;
         uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -55,7 +65,8 @@ __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* _
             uint32_t node = pos ? 1u : 0u, w = pos, best_end = 0, best_id = 0;
             while (w < len) {
                 uint32_t child, id;
-                pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, (uint32_t)text[s + w], &child, &id);
+                const uint32_t byte = SHORT ? (uint32_t)((w < 8u ? lo >> (8u * w) : hi >> (8u * (w - 8u))) & 0xFFu) : (uint32_t)text[s + w];
+                pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, byte, &child, &id);
                 if (child == RANK_NONE) break;
                 node = child;
                 ++w;

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import re
 import threading
 from typing import Iterable, Sequence
 
@@ -173,7 +174,7 @@ class Encoding:
     def sequence_ids(self) -> list[int | None]:
         if self._b.seq_ids is not None:
             return [q if q < 2 else None for q in self._b.seq_ids[self._lo:self._hi].tolist()]
-        return self._mask(None, None, 0)
+        return [0] * len(self) if getattr(self._b, "_no_seq_ranges", False) else self._mask(None, None, 0)
 
     @property
     def n_sequences(self) -> int:
@@ -295,6 +296,9 @@ class Tokenizer:
         self._json = json_str
         self._vocab_r = None
         self._pad_token = ((json.loads(json_str).get("padding") or {}).get("pad_token", "[PAD]")) if '"padding"' in json_str else "[PAD]"
+        # no post-processor at all: the reference never sets Encoding.sequence_ranges for a single sequence, and token_to_sequence
+        # (encoding.rs) then answers 0 for every token -- padding included
+        self._no_post_processor = re.search(r'"post_processor"\s*:\s*null', json_str) is not None or '"post_processor"' not in json_str
         info = _lib.Info()
         _lib.check(lib.tkamd_tokenizer_info(self._h, C.byref(info)))
         self.info = {f: getattr(info, f) for f, _ in _lib.Info._fields_}
@@ -397,9 +401,13 @@ class Tokenizer:
         raise RuntimeError("staging buffer growth failed")          # pragma: no cover
 
     def encode_batch_csr(self, inputs: Sequence[str], offsets: str = "none", word_ids: bool = False,
-                         add_special_tokens: bool = False) -> BatchEncoding:
-        """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17)."""
+                         add_special_tokens: bool = False, is_pretokenized: bool = False) -> BatchEncoding:
+        """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17).
+
+        ``is_pretokenized``: every item is a list of words (or a pair of lists) -- InputSequence::PreTokenized, tokenizer/mod.rs:225-290."""
         self._check_special(add_special_tokens)
+        if is_pretokenized:
+            return self._encode_words(inputs, offsets, word_ids, add_special_tokens)
         pairs = len(inputs) > 0 and isinstance(inputs[0], (tuple, list))
         if pairs:
             # EncodeInput::Dual for every item (a batch mixing single sequences and pairs is outside this path): A and B as
@@ -407,7 +415,7 @@ class Tokenizer:
             flat = []
             for it in inputs:
                 if not isinstance(it, (tuple, list)) or len(it) != 2 or not isinstance(it[0], str) or not isinstance(it[1], str):
-                    raise UnsupportedError("a batch must hold either single sequences (str) or pairs (str, str); pre-tokenized inputs are outside the MI355X hot path")
+                    raise UnsupportedError("a batch must hold either single sequences (str) or pairs (str, str); lists of words need is_pretokenized=True")
                 flat.append(it[0])
                 flat.append(it[1])
             inputs = flat
@@ -415,9 +423,31 @@ class Tokenizer:
             buf, doc_off = self._pack_staged(inputs)
             return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens, pairs)
 
+    def _encode_words(self, inputs, offsets, word_ids, add_special_tokens) -> BatchEncoding:
+        """is_pretokenized inputs: all words of all sequences as one packed buffer + the CSR of the sequences over the words."""
+        def is_words(x):
+            return isinstance(x, (list, tuple)) and all(isinstance(w, str) for w in x)
+        pairs = len(inputs) > 0 and isinstance(inputs[0], (tuple, list)) and len(inputs[0]) == 2 and \
+            all(isinstance(x, (list, tuple)) for x in inputs[0])
+        words: list[str] = []
+        seq_off = [0]
+        for it in inputs:
+            seqs = it if pairs else (it,)
+            if pairs and not (isinstance(it, (tuple, list)) and len(it) == 2):
+                raise UnsupportedError("a batch must hold either single sequences or pairs")
+            for sq in seqs:
+                if not is_words(sq):
+                    raise TypeError("is_pretokenized=True: every sequence must be a list of str (TextInputSequence / PreTokenizedInputSequence)")
+                words.extend(sq)
+                seq_off.append(len(words))
+        with self._stage_lock:
+            buf, word_off = self._pack_staged(words)
+            return self.encode_packed(buf, word_off, offsets, word_ids, add_special_tokens, pairs, np.asarray(seq_off, dtype=np.int64))
+
     def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
-                      add_special_tokens: bool = False, pairs: bool = False) -> BatchEncoding:
-        """``pairs``: documents 2i and 2i+1 are sequence A and B of encoding i (EncodeInput::Dual, tokenizer/mod.rs:871-889)."""
+                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None) -> BatchEncoding:
+        """``pairs``: documents 2i and 2i+1 are sequence A and B of encoding i (EncodeInput::Dual, tokenizer/mod.rs:871-889).
+        ``seq_off``: the documents are the words of pre-tokenized sequences, sequence s = words [seq_off[s], seq_off[s+1])."""
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
         if pairs:
             flags |= _lib.PAIRS
@@ -430,8 +460,13 @@ class Tokenizer:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n_docs = len(doc_off) - 1
         b = C.c_void_p()
-        _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
-        n_docs = self._lib.tkamd_batch_n_docs(b)             # encodings (half the documents for pairs)
+        if seq_off is None:
+            _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
+        else:
+            seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+            _lib.check(self._lib.tkamd_encode_batch_words(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, seq_off.ctypes.data,
+                                                          len(seq_off) - 1, flags, C.byref(b)))
+        n_docs = self._lib.tkamd_batch_n_docs(b)             # encodings (sequences; half of them for pairs)
         # zero-copy views of the library's pinned result buffers; the batch is freed when the last view dies
         owner = _BatchOwner(self._lib, b)
         nt = self._lib.tkamd_batch_n_tokens(b)
@@ -457,6 +492,7 @@ class Tokenizer:
             pads = view(pp, C.c_uint32, (n_docs,), np.uint32)
         be = BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0), pads,
                            self.info["padding"] == 2, self.info["pad_type_id"], self._pad_token)
+        be._no_seq_ranges = self._no_post_processor
         tp = self._lib.tkamd_batch_type_ids(b)
         if tp:
             be.type_ids = view(tp, C.c_uint8, (nt,), np.uint8)
@@ -470,15 +506,11 @@ class Tokenizer:
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
-        if is_pretokenized:
-            raise UnsupportedError("is_pretokenized=True is outside the MI355X hot path")
-        return self.encode_batch_csr(list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens)
+        return self.encode_batch_csr(list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized)
 
     def encode_batch_fast(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch_fast`` (no offsets, tokenizer.rs:1433-1459)."""
-        if is_pretokenized:
-            raise UnsupportedError("is_pretokenized=True is outside the MI355X hot path")
-        return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens)
+        return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized)
 
     def decode_batch_csr(self, ids: np.ndarray, tok_offsets: np.ndarray, skip_special_tokens: bool = True) -> tuple[np.ndarray, np.ndarray]:
         """ids CSR -> (bytes uint8[n_bytes], doc_offsets int64[n_docs+1]): the raw decoded byte string of every sequence."""
