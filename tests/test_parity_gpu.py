@@ -590,3 +590,23 @@ def test_sliced_host_entry_equals_one_slice(gpt2_json):
         assert "SLICED_OK" in r.stdout, r.stdout + r.stderr
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+def test_runs_of_unknown_one_byte_words_grow_the_queue_twice():
+    """WordPiece over punctuation the vocabulary does not know: every byte is a pre-token of its own and every one of them is queued
+    for the trie walk -- more entries than half the bytes, the size the <= 16-byte queue is grown to first.  The batch is run again
+    with one entry per byte and must come out right: [UNK] per character."""
+    import json
+    import tokenizers_amd as ta
+    d = {"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": None,
+         "pre_tokenizer": {"type": "BertPreTokenizer"}, "post_processor": None, "decoder": None,
+         "model": {"type": "WordPiece", "unk_token": "[UNK]", "continuing_subword_prefix": "##", "max_input_chars_per_word": 100,
+                   "vocab": {"[UNK]": 0, "a": 1, "##a": 2, "b": 3}}}
+    js = json.dumps(d)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    docs = ["!" * 50000, "a!" * 30000, "~?~" * 7000 + " aa b", ""]
+    got = tok.encode_batch_csr(docs, offsets="byte", word_ids=True)
+    exp = orc.Oracle(js).encode_batch(docs)
+    assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
+    assert np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)
+    assert got.ids[:50000].tolist() == [0] * 50000

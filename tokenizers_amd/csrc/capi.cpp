@@ -952,6 +952,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
     const size_t N = (size_t)n_x;
     const QueueSizes qz = queue_sizes(N, t->q16_div, lookup_grid(t));
+    if (qz.total >= ((size_t)1 << 30)) throw Invalid("batch too large for the work queues (row indices are 30-bit): split it");
     QueuePlan plan{};
     for (int c = 0; c < 4; ++c) {
         plan.v[c].q = (QItem*)(w->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);
@@ -1100,8 +1101,10 @@ int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
 // same call again on the same stream (the output buffers are sized for the worst case, so the result pointers stay).
 int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
     int bits = read_scalars(t, w, st, n_tok, n_pretok);
-    while ((bits & ERR_QUEUE_FULL) && !(bits & ~ERR_QUEUE_FULL) && t->q16_div > 2) {
-        t->q16_div = 2;                                  // n_bytes / 2 + 1024 entries: a queued pre-token has at least two bytes
+    while ((bits & ERR_QUEUE_FULL) && !(bits & ~ERR_QUEUE_FULL) && t->q16_div > 1) {
+        // half the bytes covers every text whose queued pre-tokens have two bytes or more (a word and its separator); one entry per
+        // byte covers the rest (runs of one-byte pre-tokens the vocabulary does not know, e.g. punctuation under WordPiece)
+        t->q16_div = t->q16_div > 2 ? 2 : 1;
         tkamd_device_result again{};
         run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again);
         if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
@@ -1228,7 +1231,7 @@ int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tka
             hipDeviceProp_t prop;
             HIP_CHECK(hipGetDeviceProperties(&prop, device));
             t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(2, atoi(e));     // test hook: start with a tiny queue
+            if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
             upload_tables(t.get());
             verify_direct_words(t.get());
             build_hot_table(t.get());

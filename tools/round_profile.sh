@@ -28,6 +28,6 @@ for c in c2 c3; do
 done
 timeout 400 python bench.py > "$O/c2_bench.json" 2> "$O/c2_bench.log"; echo "bench c2 rc=$?"; head -c 300 "$O/c2_bench.json"; echo
 for c in c3 c4 c5; do
-  timeout 300 python bench.py --config $c --no-host > "$O/${c}_bench.json" 2> "$O/${c}_bench.log"; echo "bench $c rc=$?"; head -c 200 "$O/${c}_bench.json"; echo
+  timeout 300 python bench.py --config $c --no-host --no-ood > "$O/${c}_bench.json" 2> "$O/${c}_bench.log"; echo "bench $c rc=$?"; head -c 200 "$O/${c}_bench.json"; echo
 done
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1
