@@ -111,6 +111,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
+    ap.add_argument("--no-word-cache", action="store_true", help="skip the word-cache leg")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
@@ -235,6 +236,49 @@ def main() -> None:
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
 
+    # ---- word-cache leg (rank 0, N=1, BPE configs): the device-side counterpart of the reference's per-thread word cache
+    # (models/bpe/model.rs:573-586).  NOT `value`: the steps revisit the same three batches, so a warm cache has seen every word of
+    # them -- the upper end of what a long-running service sees; the cold figure (cache cleared before every step: every queued word
+    # is merged AND inserted) is the lower end. ----
+    wcache = None
+    if rank == 0 and world == 1 and args.config != "c3" and not args.no_word_cache:
+        tok.word_cache(True, clear=True)
+        for i in range(n_batches):
+            encode(i)
+        encode(0).sync()
+        sizes_warm = tok.queue_sizes()
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        for i in range(args.steps):
+            last = encode(i)
+        last.sync()
+        torch.cuda.synchronize()
+        dt_warm = (time.perf_counter() - t_s) / args.steps
+        tok.profile(True)
+        for i in range(6):
+            encode(i)
+        encode(0).sync()
+        tok.profile(False)
+        wst = {k: round(v[0] / max(1, v[1]), 4) for k, v in tok.profile_read().items()}
+        n_cold = min(args.steps, 6)
+        torch.cuda.synchronize()
+        t_s = time.perf_counter()
+        for i in range(n_cold):
+            tok.word_cache(True, clear=True)
+            last = encode(i)
+        last.sync()
+        torch.cuda.synchronize()
+        dt_cold = (time.perf_counter() - t_s) / n_cold
+        for b in batches:                                    # parity with a warm cache: the same oracle sample as the gate above
+            check_against_oracle(tok, oracle_obj, b, stream)
+        tok.word_cache(False, clear=True)
+        bytes_per_step = tot_bytes / args.steps
+        wcache = {"value_warm": round(bytes_per_step / dt_warm / 1e9, 3), "ms_per_step_warm": round(dt_warm * 1e3, 4),
+                  "value_cold": round(bytes_per_step / dt_cold / 1e9, 3), "ms_per_step_cold": round(dt_cold * 1e3, 4), "unit": "GB/s",
+                  "merge_queue_sizes_warm": sizes_warm, "all_kernels_ms_warm": {k: v for k, v in wst.items() if v >= 0.004},
+                  "note": "tkamd_word_cache on (off by default and in `value`): warm = the rotating batches after one pass over them "
+                          "(every word of them cached), cold = cache cleared before every step; oracle sample re-checked with the cache warm"}
+
     # ---- out-of-distribution leg (rank 0, N=1): word types the vocabulary never saw -> every word runs the merge loop ----
     ood = None
     if rank == 0 and world == 1 and not args.no_ood and args.type_seed == 0:
@@ -317,6 +361,7 @@ def main() -> None:
             "value_pcie_inclusive": host["gbps_pcie_inclusive"] if host else None,
             "value_from_python_list_of_str": host.get("gbps_encode_batch_fast_list_of_str") if host else None,
             "value_out_of_distribution": ood["value"] if ood else None,
+            "value_with_word_cache": wcache["value_warm"] if wcache else None,
             "parity": {"checked_documents": int(n_checked), "against": "oracle/oracle.c", "of": "every timed batch (2 % sample), ids bit-exact"},
             "config": {"workload": f"{workload}, {b0.n_docs} synthetic documents ({b0.n_bytes / 1e6:.0f} MB) per GPU per step, "
                                    f"{n_batches} distinct batches rotated, ids-only (encode_batch_fast), inputs resident in HBM",
@@ -324,7 +369,7 @@ def main() -> None:
                        "pretokens_per_gpu": int(b0.n_pretok), "batches": n_batches, "type_seed": args.type_seed,
                        "tokenizer_sha256": synth.sha256(tok_json)[:16],
                        "parallelism": f"dp{world} (documents sharded by rank)"},
-            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "out_of_distribution": ood,
+            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "out_of_distribution": ood, "word_cache": wcache,
         }
     # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
     gather_obj = None

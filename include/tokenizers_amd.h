@@ -202,6 +202,14 @@ int tkamd_probe_bert_norm(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* out
  * Oniguruma sees them, byte_level.rs:43-46), 3 \w, 4 \s (regex crate, whitespace.rs:22), 5 char::is_whitespace, 6 is_bert_punc. */
 int tkamd_probe_unicode_flags(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* flags);
 
+/* ---- word cache --------------------------------------------------------------------------------
+ * What BPE::tokenize_with_cache keeps per thread (models/bpe/model.rs:573-586, utils/cache.rs): pre-token bytes -> its tokens.
+ * `enable` != 0: every workspace of the handle keeps a table (1 M entries, in HBM) of the <= 16-byte words its batches have merged
+ * (results of <= 4 tokens); later ids-only batches (TKAMD_OFFSETS_NONE) look such a word up instead of merging it again.  Like the
+ * reference's cache it only fills, never evicts, and never changes a result.  `clear` != 0: forget everything (every workspace
+ * zeroes its table before its next batch).  Off by default. */
+int tkamd_word_cache(tkamd_tokenizer* tok, int enable, int clear);
+
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
  * With profiling on, every kernel launch of the next device/host encode calls is bracketed by
  * HIP events on the launch stream.  tkamd_profile_read returns, per kernel, the accumulated

@@ -610,3 +610,35 @@ def test_runs_of_unknown_one_byte_words_grow_the_queue_twice():
     assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
     assert np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)
     assert got.ids[:50000].tolist() == [0] * 50000
+
+
+@pytest.mark.parametrize("name", ["gpt2", "llama3_small_6000_specials", "gpt2_bench_added"])
+def test_word_cache_never_changes_a_result(name, gpt2_json):
+    """tkamd_word_cache: later batches look up the words earlier batches merged (the reference's tokenize_with_cache,
+    models/bpe/model.rs:573-586).  Cold, warm, after a clear, with offsets (the cache is bypassed) and on text it has never seen:
+    always the oracle's ids; and the merge queue of a repeated batch is (nearly) empty once the cache is warm."""
+    import tokenizers_amd as ta
+    js = gpt2_json if name == "gpt2" else load_tokenizer_json(name)
+    tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+    a = synth.gen_lines(30000, text_seed=201) + synth.stress_lines(seed=31, n=1500)
+    b = synth.gen_lines(30000, text_seed=202, type_seed=1) + ["", "x" * 5000, "a" * 17 + " " + "b" * 16]
+    exp_a, exp_b = o.encode_batch(a), o.encode_batch(b)
+
+    def check(docs, exp):
+        got = tok.encode_batch_fast(docs, add_special_tokens=False)
+        assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
+        return tok.queue_sizes()["merge16"]
+    cold = check(a, exp_a)                                  # cache off
+    tok.word_cache(True)
+    first = check(a, exp_a)                                 # fills the cache
+    warm = check(a, exp_a)                                  # served from it
+    assert first == cold and warm * 5 < cold, (cold, first, warm)
+    first_b = check(b, exp_b)                               # unseen word types (longer results: more of them stay with the merge kernels)
+    assert check(b, exp_b) * 2 < first_b
+    assert check(a, exp_a) == warm                          # a slot never changes hands
+    got = tok.encode_batch_csr(a, offsets="byte", word_ids=True)          # offsets: merged again, not looked up
+    assert np.array_equal(got.ids, exp_a.ids) and np.array_equal(got.offsets, exp_a.offsets) and np.array_equal(got.word_ids, exp_a.words)
+    tok.word_cache(True, clear=True)
+    assert check(a, exp_a) == cold
+    tok.word_cache(False)
+    assert check(a, exp_a) == cold

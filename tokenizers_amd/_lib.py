@@ -33,7 +33,7 @@ SYMBOLS = [
     "tkamd_encode_batch", "tkamd_encode_batch_words", "tkamd_encode_batch_words_device", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
     "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_pad_counts", "tkamd_batch_type_ids", "tkamd_batch_sequence_ids", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
-    "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version",
+    "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version", "tkamd_word_cache",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
 ]
@@ -105,6 +105,8 @@ def load() -> C.CDLL:
     lib.tkamd_batch_free.restype = None
     lib.tkamd_encode_batch_device.argtypes = [vp, vp, vp, i64, i64, u32, vp, C.POINTER(DeviceResult)]
     lib.tkamd_encode_batch_device.restype = i32
+    lib.tkamd_word_cache.argtypes = [vp, i32, i32]
+    lib.tkamd_word_cache.restype = i32
     lib.tkamd_device_sync.argtypes = [vp, vp, C.POINTER(i64), C.POINTER(i64)]
     lib.tkamd_device_sync.restype = i32
     lib.tkamd_profile_enable.argtypes = [vp, i32]

@@ -103,6 +103,8 @@ struct Workspace {
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off, h_seq_off;
+    DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
+    uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
     DevBuf w_seq_off, w_seq_tok_off, w_word_idx;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
     // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
     std::vector<StageRec> pending;
@@ -141,6 +143,8 @@ struct tkamd_tokenizer {
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling
     std::atomic<bool> prof{false};
+    std::atomic<bool> word_cache{false};        // tkamd_word_cache: BPE words merged by earlier batches are looked up instead of merged again
+    std::atomic<uint64_t> cache_epoch{1};       // bumped by a clear: every workspace zeroes its cache before its next batch
     std::vector<tkamd_stage_time> acc;
 };
 
@@ -962,10 +966,24 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
+    WordCache wc{nullptr, nullptr};
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
+        // the word cache serves the ids-only path (a cached row carries no token ends)
+        if (t->word_cache && off_mode == TKAMD_OFFSETS_NONE) {
+            const size_t slots = (size_t)1 << WORD_CACHE_BITS;
+            w->w_cache_keys.reserve(slots * sizeof(CacheKey));
+            w->w_cache_rows.reserve(slots * 16);
+            const uint64_t epoch = t->cache_epoch;
+            if (w->cache_epoch != epoch) {
+                HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
+                w->cache_epoch = epoch;
+            }
+            wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p};
+            if (qz.total >= (size_t)CACHE_ROW_BIT) throw Invalid("batch too large for the work queues with the word cache on (row indices are 29-bit): split it");
+        }
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 0u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err);
@@ -982,6 +1000,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
         launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
+        if (wc.keys) {
+            pf.begin("word_cache_insert");
+            launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            pf.end();
+        }
         pf.begin("bpe_merge64");
         launch_bpe_merge(st, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
@@ -1006,7 +1029,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, 0u, 1u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr}, 0u, 1u);
         for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err);      // words longer than 16 bytes
         pf.end();
     } else {
@@ -1019,7 +1042,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, shortcut ? 0u : 1u, 0u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr}, shortcut ? 0u : 1u, 0u);
         pf.end();
         pf.begin("wordpiece");
         for (int c = 0; c < 4; ++c)
@@ -1031,7 +1054,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                                w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
     pf.begin("compact");
     HIP_CHECK(hipMemsetAsync(w->w_cstate.p, 0, (N / COMPACT_CHUNK + 4) * 8, st));
-    launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
+    launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, w->w_pt_tokoff.as<uint32_t>(), w->w_ids.as<uint32_t>());
     pf.end();
     pf.begin("doc_tok_offsets");
@@ -1657,6 +1680,13 @@ int64_t tkamd_text_n_bytes(const tkamd_text* b) { return b ? b->n_bytes : 0; }
 const uint8_t* tkamd_text_bytes(const tkamd_text* b) { return b ? (const uint8_t*)b->bytes.p : nullptr; }
 const int64_t* tkamd_text_doc_offsets(const tkamd_text* b) { return b ? (const int64_t*)b->doc_offsets.p : nullptr; }
 void tkamd_text_free(tkamd_text* b) { delete b; }
+
+int tkamd_word_cache(tkamd_tokenizer* t, int enable, int clear) {
+    if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
+    if (clear) ++t->cache_epoch;
+    t->word_cache = enable != 0;
+    return TKAMD_OK;
+}
 
 int tkamd_profile_enable(tkamd_tokenizer* t, int on) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");

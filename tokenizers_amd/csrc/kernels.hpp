@@ -56,6 +56,23 @@ struct QView {
     uint32_t sq_cap;              // entries per sub-queue
     uint32_t row_base;            // rows[row_base + position]
 };
+// ---- word cache (kernels/lookup.hip, output.hip): what BPE::tokenize_with_cache keeps per thread (models/bpe/model.rs:573-586,
+// utils/cache.rs) -- pre-token bytes -> its tokens -- kept per workspace in HBM.  A direct-mapped table that only ever fills (the
+// reference's cache does not evict either); an entry is a key slot + a result row in the same 16-byte format the merge kernels
+// write, so a hit costs the lookup one probe and the compaction nothing extra.
+constexpr int WORD_CACHE_BITS = 20;                       // 1 M entries: 32 MB of keys + 16 MB of rows per workspace
+constexpr uint32_t CACHE_ROW_BIT = 1u << 29;              // tok0 = TOK_ROW | CACHE_ROW_BIT | slot: the row lives in the cache
+constexpr uint32_t CACHE_CLAIMED = 0x80000000u;
+struct __attribute__((aligned(32))) CacheKey {
+    uint32_t k[4];               // the pre-token's bytes, zero padded to 16
+    uint32_t state;              // 0 empty, CACHE_CLAIMED while its writer fills it in, else the length (1..16)
+    uint32_t pad[3];
+};
+struct WordCache {
+    CacheKey* keys;              // null: no cache
+    void* rows;                  // [1 << WORD_CACHE_BITS] 16-byte rows
+};
+
 struct QueuePlan {
     QView v[4];                   // pre-tokens of <= 16 bytes, <= 32, <= 64, longer
 };
@@ -211,7 +228,7 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
 // whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
-                   const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot,
+                   const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
                    uint32_t no_hits, uint32_t miss_is_unk);
 int hot_table_slots();
 // group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
@@ -275,7 +292,8 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
 // single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
 // compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
-void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
+void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);
 int compact_grid(int n_cu);
 constexpr int COMPACT_CHUNK = 2048;

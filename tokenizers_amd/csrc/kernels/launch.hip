@@ -45,7 +45,7 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
 int hot_table_slots() { return HOT_SLOTS; }
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
-                   const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot,
+                   const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
                    uint32_t no_hits, uint32_t miss_is_unk) {
     LookupArgs a{};
     a.words = t.words;
@@ -67,6 +67,7 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.err = err;
     a.matchmask = matchmask;
     a.hot = (const uint4*)hot;
+    a.cache_keys = wc.keys;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
     if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
@@ -247,10 +248,13 @@ int compact_grid(int n_cu) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_compact, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
 }
-void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
+    hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);
+}
+void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids) {
     static_assert(COMPACT_CHUNK == CP_CHUNK, "the host sizes the look-back state by COMPACT_CHUNK");
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids);
 }
 void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
                             const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets) {

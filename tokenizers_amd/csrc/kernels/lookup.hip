@@ -61,7 +61,11 @@ struct LookupArgs {
     uint32_t no_hits;                // WordPiece with max_input_chars_per_word < 16: every word takes the trie walk
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
     uint32_t unk_id, has_unk;
+    const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
 };
+
+// slot of a word in the word cache, from the bucket hash of the whole-word table
+__device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
 
 template <bool HAS_END>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
@@ -250,6 +254,15 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                     asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
                     const uint32_t diff = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | (a0.w ^ k3) | (a1.x ^ len);
                     if (diff == 0u && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
+                    if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
+                        // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
+                        // measured 20 % slower (the extra 32-byte reads cost more than the round trip they save)
+                        const uint32_t slot = cache_slot(h1);
+                        const CacheKey* const ck = a.cache_keys + slot;
+                        const uint4 ckey = *(const uint4*)ck->k;
+                        const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
+                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
+                    }
                 }
                 if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
                     if (pend && len <= (uint32_t)WORD_MAX_KEY) {
@@ -296,3 +309,30 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 }
 
 constexpr int lookup_lds_bytes(bool has_end) { return HOT_SLOTS * 16 + (LU_TILE + LU_TEXT_SLACK) + 16 + (has_end ? 2 : 1) * (LU_POS_CAP + 2) * 2 + LU_POS_CAP * 2; }
+
+// =================================================================================================
+// K_word_cache_insert: after the merge kernels, every queued pre-token of <= 16 bytes whose result fits a row (<= 4 tokens) is
+// offered to the word cache: the lane claims the slot of its word if it is still empty (a slot never changes hands: like the
+// reference's cache, utils/cache.rs, the table only fills) and writes key, row and length.  The lookup kernel of the NEXT batch is the
+// only reader, so readers never see a half-written entry.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_word_cache_insert(DevTables t, const uint8_t* __restrict__ text, QView v, const uint4* __restrict__ rows,
+                                                           WordCache wc) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
+    const uint32_t n = qview_prefix(v, s_qpre);
+    for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
+        const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
+        const QItem it = v.q[qpos];
+        if (it.len == 0u || it.len > 16u) continue;
+        const uint4 row = rows[v.row_base + qpos];
+        if ((row.x >> ROW_CNT_SHIFT) > 4u) continue;                                // longer results stay with the merge kernels
+        uint64_t lo, hi;
+        load_key16(text, it.s, it.len, &lo, &hi);
+        const uint32_t slot = cache_slot(word_hash1(lo, hi, it.len, t.word_seed));
+        CacheKey* const ck = wc.keys + slot;
+        if (atomicCAS(&ck->state, 0u, CACHE_CLAIMED) != 0u) continue;               // taken (by this word or another)
+        *(uint4*)ck->k = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        ((uint4*)wc.rows)[slot] = row;
+        ck->state = it.len;                                                         // (read by later kernels only: no fence needed)
+    }
+}

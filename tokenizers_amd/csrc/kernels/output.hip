@@ -25,7 +25,7 @@ struct CpRows {
     uint4 row[CP_ITEMS];
     uint32_t cnt[CP_ITEMS];
 };
-__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, int64_t p0, int64_t P, CpRows& r) {
+__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows& r) {
     uint32_t first[CP_ITEMS];
     if (p0 + CP_ITEMS <= P) {
         const uint4 a = *(const uint4*)(tok0 + p0), b = *(const uint4*)(tok0 + p0 + 4);
@@ -36,7 +36,7 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
     }
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k)                     // all row loads in flight together
-        r.row[k] = (first[k] & TOK_ROW) ? rows[first[k] & ~TOK_ROW] : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
+        r.row[k] = (first[k] & TOK_ROW) ? ((first[k] & CACHE_ROW_BIT) ? crows[first[k] & (CACHE_ROW_BIT - 1u)] : rows[first[k] & ~TOK_ROW]) : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) { r.cnt[k] = row_count(r.row[k]); v += r.cnt[k]; }
@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
         (O) += c;                                                                                             \
     }
 
-__global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows,
+__global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
     auto front = [&](int64_t ch, int b) {
         const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
         CpRows r;
-        const uint32_t v = cp_load(tok0, rows, p0, P, r);
+        const uint32_t v = cp_load(tok0, rows, crows, p0, P, r);
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
         if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         } else {                                           // rare: too many tokens for the buffer -- scatter from the rows
             const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
             CpRows r;
-            cp_load(tok0, rows, p0, P, r);
+            cp_load(tok0, rows, crows, p0, P, r);
             uint32_t o = s_loc[b][tid * CP_ITEMS];
             uint32_t* const dst = ids + base;
             TKAMD_CP_SCATTER(dst, r, o)

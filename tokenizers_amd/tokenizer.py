@@ -563,6 +563,12 @@ class Tokenizer:
                                                        stream, C.byref(res)))
         return DeviceBatch(self, res, n_docs, stream, capacity=n_bytes + 4)
 
+    def word_cache(self, enable: bool = True, clear: bool = False) -> None:
+        """The device-side counterpart of the reference's per-thread BPE word cache (models/bpe/model.rs:573-586): words of <= 16
+        bytes merged by earlier batches are looked up instead of merged again by later ids-only batches.  Off by default;
+        ``clear`` forgets everything.  Results never change."""
+        _lib.check(self._lib.tkamd_word_cache(self._h, 1 if enable else 0, 1 if clear else 0))
+
     # ---- measurement hooks ----
     def profile(self, on: bool) -> None:
         _lib.check(self._lib.tkamd_profile_enable(self._h, 1 if on else 0))

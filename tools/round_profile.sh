@@ -12,7 +12,7 @@ mkdir -p "$O"
 if [ "$2" != "skip-pytest" ]; then
   timeout 900 python -m pytest tests -m gpu -q > "$O/pytest_gpu.txt" 2>&1; tail -2 "$O/pytest_gpu.txt"
 fi
-B="python bench.py --no-cpu-baseline --no-ood --no-host --steps 3 --warmup 1"
+B="python bench.py --no-cpu-baseline --no-ood --no-host --no-word-cache --steps 3 --warmup 1"
 timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch" -- $B > "$O/pmc_fetch.log" 2>&1; echo "pmc fetch rc=$?"
 timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write" -- $B > "$O/pmc_write.log" 2>&1; echo "pmc write rc=$?"
 F=$(ls $O/pmc_fetch/*/*counter_collection.csv 2>/dev/null | head -1); W=$(ls $O/pmc_write/*/*counter_collection.csv 2>/dev/null | head -1)
@@ -22,7 +22,7 @@ if [ -n "$F" ] && [ -n "$W" ]; then
 fi
 rm -rf "$O/pmc_fetch" "$O/pmc_write"
 for c in c2 c3; do
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$c" -- python bench.py --config $c --no-cpu-baseline --no-ood --no-host --steps 10 --warmup 2 > "$O/stats_$c.log" 2>&1; echo "stats $c rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$c" -- python bench.py --config $c --no-cpu-baseline --no-ood --no-host --no-word-cache --steps 10 --warmup 2 > "$O/stats_$c.log" 2>&1; echo "stats $c rc=$?"
   S=$(ls $O/stats_$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp "$S" "$O/${c}_kernel_stats.csv"
   rm -rf "$O/stats_$c"
 done
