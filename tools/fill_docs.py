@@ -35,6 +35,8 @@ def main():
     if b:
         r, cpu, host, ood = b["roofline"], b.get("cpu_baseline") or {}, b.get("host_boundary") or {}, b.get("out_of_distribution") or {}
         o = cpu.get("others", {})
+        wc = b.get("word_cache") or {}
+        sub.update({"WC_WARM": f"{wc.get('value_warm', float('nan')):.1f}", "WC_COLD": f"{wc.get('value_cold', float('nan')):.1f}"})
         sub.update({"C2_GBPS": f"{b['value']:.1f}", "C2_MTOK": f"{b['mtokens_per_s']:,.0f}", "C2_MS": f"{b['ms_per_step']:.3f}",
                     "C2_SUM": f"{r['sum_kernels_ms']:.2f}", "C2_DOM": r["kernel"], "C2_DOM_MS": f"{r['kernel_ms']:.3f}",
                     "C2_ACH": f"{r['achieved']:.0f}", "C2_FRAC": f"{100 * r['frac']:.1f} %",
