@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line.  Extra objects next to the contract's fields:
                  offsets, and the reference's 1,000-documents-per-call bench shape in `others`)
   host_boundary  the C-ABI call as SURVEY 8d times it (H2D + kernels + D2H): `value_pcie_inclusive`; from list[str] too
   out_of_distribution  the same step on text whose word types the vocabulary never saw (every word needs merges)
+  word_cache     the same K steps with tkamd_word_cache on (off in `value`): warm and cold (cleared every step) figures
   gather         N > 1 (or --force-gather): the same K steps ending with the RCCL collect-to-root of ids + CSR
 """
 from __future__ import annotations

@@ -50,7 +50,7 @@ struct LookupArgs {
     const unsigned long long* endmask;   // "Removed" pre-tokenizers: explicit ends; null: a pre-token ends where the next starts
     const uint32_t* wprefix;         // #starts before each mask word
     uint32_t* tok0;
-    QView v[4];                      // queues: <= 16 bytes, <= 32, <= 64, longer (sub-queue blockIdx % NSQ of each)
+    QView v[4];                      // queues: <= 16 bytes, <= 32, <= 64, longer (this workgroup fills sub-queue blockIdx of each)
     int* err;
     const unsigned long long* matchmask;   // added-token matches: one pre-token, id patched in later
     const uint4* hot;                // [HOT_SLOTS] {k0, k1, k2, id | len << 24}, len 0 = empty
