@@ -237,12 +237,12 @@ def main() -> None:
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
 
-    # ---- word-cache leg (rank 0, N=1, BPE configs): the device-side counterpart of the reference's per-thread word cache
+    # ---- word-cache leg (rank 0, N=1): the device-side counterpart of the reference's per-thread word cache
     # (models/bpe/model.rs:573-586).  NOT `value`: the steps revisit the same three batches, so a warm cache has seen every word of
     # them -- the upper end of what a long-running service sees; the cold figure (cache cleared before every step: every queued word
     # is merged AND inserted) is the lower end. ----
     wcache = None
-    if rank == 0 and world == 1 and args.config != "c3" and not args.no_word_cache:
+    if rank == 0 and world == 1 and not args.no_word_cache:
         tok.word_cache(True, clear=True)
         for i in range(n_batches):
             encode(i)

@@ -612,7 +612,7 @@ def test_runs_of_unknown_one_byte_words_grow_the_queue_twice():
     assert got.ids[:50000].tolist() == [0] * 50000
 
 
-@pytest.mark.parametrize("name", ["gpt2", "llama3_small_6000_specials", "gpt2_bench_added"])
+@pytest.mark.parametrize("name", ["gpt2", "llama3_small_6000_specials", "gpt2_bench_added", "bert_wordpiece_4000_specials"])
 def test_word_cache_never_changes_a_result(name, gpt2_json):
     """tkamd_word_cache: later batches look up the words earlier batches merged (the reference's tokenize_with_cache,
     models/bpe/model.rs:573-586).  Cold, warm, after a clear, with offsets (the cache is bypassed) and on text it has never seen:
@@ -622,6 +622,8 @@ def test_word_cache_never_changes_a_result(name, gpt2_json):
     tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
     a = synth.gen_lines(30000, text_seed=201) + synth.stress_lines(seed=31, n=1500)
     b = synth.gen_lines(30000, text_seed=202, type_seed=1) + ["", "x" * 5000, "a" * 17 + " " + "b" * 16]
+    if name.startswith("bert"):            # (the 96 reorderable marks are refused: another test)
+        a, b = [d for d in a if "\u302e" not in d], [d for d in b if "\u302e" not in d]
     exp_a, exp_b = o.encode_batch(a), o.encode_batch(b)
 
     def check(docs, exp):

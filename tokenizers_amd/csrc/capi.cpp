@@ -967,21 +967,23 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
     WordCache wc{nullptr, nullptr};
+    // the word cache (kernels.hpp WordCache) serves the ids-only path: a cached row carries no token ends
+    auto open_word_cache = [&]() {
+        if (!(t->word_cache && off_mode == TKAMD_OFFSETS_NONE)) return;
+        const size_t slots = (size_t)1 << WORD_CACHE_BITS;
+        w->w_cache_keys.reserve(slots * sizeof(CacheKey));
+        w->w_cache_rows.reserve(slots * 16);
+        const uint64_t epoch = t->cache_epoch;
+        if (w->cache_epoch != epoch) {
+            HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
+            w->cache_epoch = epoch;
+        }
+        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p};
+        if (qz.total >= (size_t)CACHE_ROW_BIT) throw Invalid("batch too large for the work queues with the word cache on (row indices are 29-bit): split it");
+    };
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
-        // the word cache serves the ids-only path (a cached row carries no token ends)
-        if (t->word_cache && off_mode == TKAMD_OFFSETS_NONE) {
-            const size_t slots = (size_t)1 << WORD_CACHE_BITS;
-            w->w_cache_keys.reserve(slots * sizeof(CacheKey));
-            w->w_cache_rows.reserve(slots * 16);
-            const uint64_t epoch = t->cache_epoch;
-            if (w->cache_epoch != epoch) {
-                HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
-                w->cache_epoch = epoch;
-            }
-            wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p};
-            if (qz.total >= (size_t)CACHE_ROW_BIT) throw Invalid("batch too large for the work queues with the word cache on (row indices are 29-bit): split it");
-        }
+        open_word_cache();
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
         pf.end();
@@ -1040,14 +1042,22 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         DevTables wt = t->dt;
         wt.ignore_merges = 1;                              // any whole-word hit is final
         wt.long_probe_max_len = hm.max_input_chars;        // len <= limit  =>  chars <= limit
+        // (the reference keeps no cache for WordPiece; a word's pieces depend on nothing but the word, so the same table serves. With
+        // every word taking the walk -- max_input_chars_per_word < 16 -- the lookup probes nothing, the cache included.)
+        if (shortcut) open_word_cache();
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr}, shortcut ? 0u : 1u, 0u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u);
         pf.end();
         pf.begin("wordpiece");
         for (int c = 0; c < 4; ++c)
             launch_wordpiece(st, c == 0 ? grid : t->n_cu, c == 0, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
         pf.end();
+        if (wc.keys) {
+            pf.begin("word_cache_insert");
+            launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            pf.end();
+        }
     }
     if (matchmask)
         launch_apply_match_ids(st, w->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, w->w_startmask.as<ull>(),
