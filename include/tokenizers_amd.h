@@ -23,9 +23,10 @@
  *   carry information; type_ids / attention_mask / special_tokens_mask follow
  *   from the special-token layout (tkamd_tokenizer_specials) and the padding
  *   counts (tkamd_batch_pad_counts) and are synthesised by the host shim.
- *   A `truncation` / `padding` section of tokenizer.json is honoured for the
- *   encodings themselves (utils/truncation.rs, utils/padding.rs); the
- *   `overflowing` pieces a truncation leaves behind are not materialised.
+ *   A `truncation` / `padding` section of tokenizer.json is honoured
+ *   (utils/truncation.rs, utils/padding.rs); with TKAMD_WANT_OVERFLOW the
+ *   `overflowing` encodings a truncation leaves behind (Encoding::truncate,
+ *   tokenizer/encoding.rs:307-395) are further encodings of the result.
  */
 #ifndef TOKENIZERS_AMD_H
 #define TOKENIZERS_AMD_H
@@ -58,6 +59,15 @@ extern "C" {
 #define TKAMD_PAIRS          16u   /* EncodeInput::Dual (tokenizer/mod.rs:871-889): documents 2i and 2i+1 are sequence A and B of
                                      encoding i (n_docs must be even); the result holds n_docs / 2 encodings: the pair is
                                      truncated together, laid out by the post-processor's pair template (type ids), padded  */
+
+#define TKAMD_WANT_OVERFLOW   32u   /* Encoding.overflowing: with a `truncation` section, what a single sequence loses to the cut comes back as
+                                     further encodings -- windows of max_length tokens (less the special tokens) that share `stride` tokens
+                                     with their neighbour (tokenizer/encoding.rs:307-395), each with the same special tokens and padding as
+                                     the truncated encoding (processors/bert.rs:88-125, encoding.rs:466-469).  The result then holds
+                                     n_encodings >= n_docs encodings: every document's own followed by its overflowing ones in the
+                                     reference's order; tkamd_batch_encoding_docs / d_enc_docs name the document of each.  Ignored
+                                     without a `truncation` section and for TKAMD_PAIRS (a pair's overflowing encodings, the cross
+                                     product of both sides', are not materialised).                                                  */
 
 /* Readable slack the caller must leave after text[n_bytes] for the device entry
  * points (kernels read whole 16-byte words).  The host entry pads internally. */
@@ -121,7 +131,8 @@ int tkamd_encode_batch(tkamd_tokenizer* tok, const uint8_t* text, const int64_t*
 int tkamd_encode_batch_words(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* word_offsets, int64_t n_words,
                              const int64_t* seq_offsets, int64_t n_seqs, uint32_t flags, tkamd_batch** out);
 
-int64_t         tkamd_batch_n_docs(const tkamd_batch* b);
+int64_t         tkamd_batch_n_docs(const tkamd_batch* b);       /* encodings in the result (= documents / sequences / pairs, plus the
+                                                                   overflowing encodings with TKAMD_WANT_OVERFLOW)              */
 int64_t         tkamd_batch_n_tokens(const tkamd_batch* b);
 const uint32_t* tkamd_batch_ids(const tkamd_batch* b);          /* [n_tokens]                   */
 const int64_t*  tkamd_batch_tok_offsets(const tkamd_batch* b);  /* [n_docs+1] CSR into ids      */
@@ -133,6 +144,10 @@ const uint8_t*  tkamd_batch_sequence_ids(const tkamd_batch* b); /* [n_tokens] 0 
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b);   /* [n_docs] padding tokens of each encoding (at the side
                                                                    tkamd_info.padding names), NULL without a `padding` section:
                                                                    attention_mask = 0, special_tokens_mask = 1 on them      */
+const uint32_t* tkamd_batch_encoding_docs(const tkamd_batch* b);/* [n_docs] TKAMD_WANT_OVERFLOW with a `truncation` section: the document
+                                                                   (sequence) every encoding belongs to, ascending -- a document's
+                                                                   first encoding is the truncated one, the rest are its
+                                                                   Encoding.overflowing in order; NULL otherwise                */
 void            tkamd_batch_free(tkamd_batch* b);
 
 /* ---- device-buffer entry: inputs already resident in HBM, outputs stay in HBM ---------------
@@ -150,6 +165,9 @@ typedef struct tkamd_device_result {
     const uint32_t* d_pad_counts;   /* [n_docs] padding tokens per encoding, or NULL            */
     const uint8_t*  d_type_ids;     /* TKAMD_PAIRS: [n_tokens] type ids, else NULL              */
     const uint8_t*  d_seq_ids;      /* TKAMD_PAIRS: [n_tokens] 0 / 1 / 2 special / 3 padding    */
+    const uint32_t* d_enc_docs;     /* TKAMD_WANT_OVERFLOW (with a `truncation` section): [n_encodings] document of every encoding, else NULL;
+                                       d_tok_offsets / d_pad_counts then have n_encodings (+ 1) entries                                        */
+    const int64_t*  d_n_encodings;  /* [1] with d_enc_docs, else NULL (the call itself waits for this count: it sizes the result)              */
 } tkamd_device_result;
 
 int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,
@@ -194,6 +212,11 @@ int tkamd_probe_merge(const tkamd_tokenizer* tok, uint32_t left, uint32_t right,
 /* One edge of the WordPiece byte trie (the longest-match walk of wordpiece/mod.rs:245-258 as a trie): (node, byte) ->
  * (child, id of the piece ending there or 0xFFFFFFFF); node 0 = word-initial pieces, 1 = continuation pieces. */
 int tkamd_probe_trie(const tkamd_tokenizer* tok, uint32_t node, uint32_t byte, uint32_t* child, uint32_t* id);
+/* Encoding::truncate (tokenizer/encoding.rs:307-395) of a sequence of n_tokens to max_len with `stride`, direction Right (left = 0) or
+ * Left, straight from the function the epilogue kernels call (csrc/overflow_core.hpp): returns the number of encodings it leaves
+ * (1 = nothing is cut; 0 = the reference's assert stride < max_len) and, for part < that number, its token range (part 0 = the
+ * truncated encoding, 1.. = Encoding.overflowing in order). */
+int tkamd_probe_truncation(uint64_t n_tokens, uint32_t max_len, uint32_t stride, int left, uint32_t part, uint64_t* start, uint64_t* count);
 /* BertNormalizer::normalize (normalizers/bert.rs:92-138) of ONE code point from the host copy of the generated tables:
  * out[0..*n) (at most 12 code points; 0 = the char is removed), *refused = 1 where strip_accents would need a
  * context-dependent NFD reordering (the device path refuses such text). */

@@ -504,3 +504,64 @@ def test_wordpiece_trie_walk_on_the_real_table_matches_the_oracle():
         assert walk(w) == [t[0] for t in o.model_tokenize(s)], s
         n += 1
     assert n > 3000
+
+
+def _rust_truncate_parts(n, max_len, stride, left):
+    """Encoding::truncate's window list, statement by statement (tokenizer/encoding.rs:307-356)."""
+    if max_len >= n:
+        return [(0, n)]
+    if max_len == 0:
+        return [(0, 0), (0, n)]
+    assert stride < max_len
+    offset = max_len - stride
+    parts, end = [], False
+    if not left:
+        for start in range(0, n, offset):
+            if not end:
+                stop = min(start + max_len, n)
+                end = stop == n
+                parts.append((start, stop))
+    else:
+        for stop in range(n - 1, -1, -offset):
+            stop += 1
+            start = max(stop - max_len, 0)
+            if start < stop and not end:
+                end = start == 0
+                parts.append((start, stop))
+    return parts
+
+
+def _probe_parts(lib, n, max_len, stride, left):
+    s, c = C.c_uint64(0), C.c_uint64(0)
+    k = lib.tkamd_probe_truncation(n, max_len, stride, int(left), 0, C.byref(s), C.byref(c))
+    out = []
+    for p in range(k):
+        assert lib.tkamd_probe_truncation(n, max_len, stride, int(left), p, C.byref(s), C.byref(c)) == k
+        out.append((s.value, s.value + c.value))
+    return out
+
+
+def test_truncation_windows_closed_form_equals_the_reference_loop():
+    """csrc/overflow_core.hpp (what k_ovf_parts / k_ovf_ranges call) against a statement-by-statement replay of
+    Encoding::truncate, exhaustively for small sizes, and against the wheel's Encoding.truncate itself."""
+    lib = _lib.load()
+    for n in range(0, 41):
+        for max_len in range(0, 45):
+            for stride in range(0, max(max_len, 1)):
+                for left in (False, True):
+                    want = _rust_truncate_parts(n, max_len, stride, left)
+                    assert _probe_parts(lib, n, max_len, stride, left) == want, (n, max_len, stride, left)
+    s, c = C.c_uint64(0), C.c_uint64(0)
+    assert lib.tkamd_probe_truncation(10, 4, 4, 0, 0, C.byref(s), C.byref(c)) == 0       # the reference asserts stride < max_len
+    assert lib.tkamd_probe_truncation(10, 4, 9, 1, 0, C.byref(s), C.byref(c)) == 0
+    assert lib.tkamd_probe_truncation(3, 4, 9, 1, 0, C.byref(s), C.byref(c)) == 1        # ... only when something is cut
+    assert lib.tkamd_probe_truncation(1 << 36, 512, 128, 0, 5, C.byref(s), C.byref(c)) == ((1 << 36) - 512 + 383) // 384 + 1
+    assert (s.value, c.value) == (5 * 384, 512)
+    tokenizers = pytest.importorskip("tokenizers")
+    tok = tokenizers.Tokenizer.from_str(_base({"type": "WordLevel", "vocab": {"<unk>": 0, **{f"w{i}": i + 1 for i in range(64)}}, "unk_token": "<unk>"}))
+    for n, max_len, stride in ((37, 8, 3), (37, 8, 0), (16, 4, 3), (9, 9, 2), (30, 1, 0), (12, 5, 4)):
+        for direction in ("right", "left"):
+            e = tok.encode(" ".join(f"w{i}" for i in range(n)))
+            e.truncate(max_len, stride=stride, direction=direction)
+            got = _probe_parts(lib, n, max_len, stride, direction == "left")
+            assert [list(range(a + 1, b + 1)) for a, b in got] == [e.ids] + [o.ids for o in e.overflowing], (n, max_len, stride, direction)

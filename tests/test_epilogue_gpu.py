@@ -106,3 +106,78 @@ def test_pair_inputs_match_wheel(k):
         assert [list(x) for x in e.offsets] == c["offsets_char"][i], ctx
         assert e.word_ids == c["words"][i], ctx
         assert e.sequence_ids == c["sequence_ids"][i], ctx
+
+
+def _overflow_cases():
+    with gzip.open(os.path.join(GOLD, "overflow_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        return json.load(fh)["cases"]
+
+
+OVERFLOW_CASES = _overflow_cases()
+_ENC_FIELDS = (("ids", "ids"), ("type_ids", "type_ids"), ("attention_mask", "attention_mask"), ("special_tokens_mask", "special_tokens_mask"),
+               ("word_ids", "words"), ("tokens", "tokens"))
+
+
+@pytest.mark.parametrize("k", range(len(OVERFLOW_CASES)))
+def test_overflowing_encodings_match_wheel(k):
+    """Encoding.overflowing (Encoding::truncate tokenizer/encoding.rs:307-395: windows of max_length sharing `stride` tokens, both
+    directions, max_length 0 / 1, the stride assert), with the post-processor's specials and the padding on every piece -- every
+    field of every encoding against the wheel (oracle/make_golden_overflow.py)."""
+    import tokenizers_amd as ta
+    c = OVERFLOW_CASES[k]
+    d = json.loads(load_tokenizer_json(c["tokenizer"]))
+    d["truncation"], d["padding"] = c["truncation"], c["padding"]
+    tok = ta.Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=0)
+    kw = dict(add_special_tokens=c["add_special_tokens"], is_pretokenized=c["is_pretokenized"])
+    if c.get("error"):
+        with pytest.raises(ValueError, match="`stride` must be strictly less than `max_len`"):
+            tok.encode_batch(c["docs"], **kw)
+        return
+    got = tok.encode_batch(c["docs"], **kw)
+    assert len(got) == len(c["docs"])
+    assert got.n_encodings == sum(len(x) for x in c["encodings"])
+    for i, want in enumerate(c["encodings"]):
+        encs = [got[i]] + got[i].overflowing
+        ctx = (c["tokenizer"], c["truncation"], c["padding"], c["add_special_tokens"], c["is_pretokenized"], c["docs"][i])
+        assert len(encs) == len(want), ctx
+        for e, w in zip(encs, want):
+            for mine, theirs in _ENC_FIELDS:
+                assert getattr(e, mine) == w[theirs], (mine,) + ctx
+            assert [list(x) for x in e.offsets] == w["offsets_char"], ctx
+            assert e is encs[0] or e.overflowing == []
+    fast = tok.encode_batch_fast(c["docs"], **kw)
+    assert [[e.ids for e in [fast[i]] + fast[i].overflowing] for i in range(len(c["docs"]))] == [[w["ids"] for w in x] for x in c["encodings"]]
+    # without the flag the result is the truncated encodings alone, exactly as before
+    plain = tok.encode_batch_csr(c["docs"], offsets="none", **kw)
+    assert plain.enc_docs is None and len(plain) == plain.n_encodings == len(c["docs"])
+    assert [plain[i].ids for i in range(len(plain))] == [x[0]["ids"] for x in c["encodings"]]
+
+
+def test_overflowing_encodings_through_the_c_abi_arrays():
+    """The raw result arrays of TKAMD_WANT_OVERFLOW on 60 k documents: encoding_docs ascending, a document's own encoding first, the
+    number of windows per document in closed form, and the windows tiling the document's own tokens (one of them 400 lines long)."""
+    import numpy as np
+    import tokenizers_amd as ta
+    from oracle import synth
+    d = json.loads(load_tokenizer_json("gpt2_synth_50257"))
+    d["truncation"] = {"direction": "Right", "max_length": 32, "strategy": "LongestFirst", "stride": 8}
+    tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
+    docs = synth.gen_lines(60000, text_seed=5)
+    docs[7] = " ".join(docs[:400])                               # one long document: many windows
+    full = ta.Tokenizer.from_str(load_tokenizer_json("gpt2_synth_50257"), device=0).encode_batch_csr(docs)
+    got = tok.encode_batch_csr(docs, overflowing=True)
+    assert len(got) == len(docs) and got.n_encodings > len(docs)
+    ed = got.enc_docs.astype(np.int64)
+    assert (np.diff(ed) >= 0).all() and ed[0] == 0 and ed[-1] == len(docs) - 1
+    lens = np.diff(got.tok_offsets)
+    n_full = np.diff(full.tok_offsets)
+    first = np.searchsorted(ed, np.arange(len(docs)))
+    parts = np.diff(np.append(first, len(ed)))
+    want_parts = np.where(n_full <= 32, 1, -(-(n_full - 32) // 24) + 1)
+    assert (parts == want_parts).all()
+    assert (lens[first] == np.minimum(n_full, 32)).all()
+    for i in (0, 7, 11, len(docs) - 1):                          # windows advance by max_length - stride over the document's own tokens
+        ids = full.ids[full.tok_offsets[i]:full.tok_offsets[i + 1]]
+        for p in range(parts[i]):
+            e = first[i] + p
+            assert (got.ids[got.tok_offsets[e]:got.tok_offsets[e + 1]] == ids[24 * p: 24 * p + 32]).all()

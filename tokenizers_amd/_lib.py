@@ -23,6 +23,7 @@ OFFSETS_CHAR = 2
 WANT_WORD_IDS = 4
 ADD_SPECIAL = 8
 PAIRS = 16
+WANT_OVERFLOW = 32
 SKIP_SPECIAL = 1          # tkamd_decode_batch flag
 TEXT_PAD = 64
 MAX_STAGES = 24
@@ -36,6 +37,7 @@ SYMBOLS = [
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version", "tkamd_word_cache",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
+    "tkamd_batch_encoding_docs", "tkamd_probe_truncation",
 ]
 
 
@@ -49,7 +51,7 @@ class Info(C.Structure):
 class DeviceResult(C.Structure):
     _fields_ = [("d_ids", C.c_void_p), ("d_tok_offsets", C.c_void_p), ("d_offsets", C.c_void_p),
                 ("d_word_ids", C.c_void_p), ("d_n_tokens", C.c_void_p), ("d_n_pretokens", C.c_void_p), ("d_pad_counts", C.c_void_p),
-                ("d_type_ids", C.c_void_p), ("d_seq_ids", C.c_void_p)]
+                ("d_type_ids", C.c_void_p), ("d_seq_ids", C.c_void_p), ("d_enc_docs", C.c_void_p), ("d_n_encodings", C.c_void_p)]
 
 
 class StageTime(C.Structure):
@@ -97,7 +99,7 @@ def load() -> C.CDLL:
     lib.tkamd_encode_batch_words_device.restype = i32
     for name, rt in (("tkamd_batch_n_docs", i64), ("tkamd_batch_n_tokens", i64), ("tkamd_batch_ids", vp),
                      ("tkamd_batch_tok_offsets", vp), ("tkamd_batch_offsets", vp), ("tkamd_batch_word_ids", vp), ("tkamd_batch_pad_counts", vp),
-                     ("tkamd_batch_type_ids", vp), ("tkamd_batch_sequence_ids", vp)):
+                     ("tkamd_batch_type_ids", vp), ("tkamd_batch_sequence_ids", vp), ("tkamd_batch_encoding_docs", vp)):
         f = getattr(lib, name)
         f.argtypes = [vp]
         f.restype = rt
@@ -137,6 +139,8 @@ def load() -> C.CDLL:
     lib.tkamd_probe_unicode_flags.restype = i32
     lib.tkamd_probe_trie.argtypes = [vp, u32, u32, C.POINTER(u32), C.POINTER(u32)]
     lib.tkamd_probe_trie.restype = i32
+    lib.tkamd_probe_truncation.argtypes = [C.c_uint64, u32, u32, i32, u32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.tkamd_probe_truncation.restype = i32
     _lib = lib
     return lib
 

@@ -19,6 +19,7 @@
 
 #include "host_model.hpp"
 #include "kernels.hpp"
+#include "overflow_core.hpp"
 
 using namespace tkamd;
 static_assert(TEXT_PAD == TKAMD_TEXT_PAD, "the kernels rely on the slack the ABI promises");
@@ -95,6 +96,7 @@ struct Workspace {
     // (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count, w_keep, w_type_ids2, w_seq_ids2;   // truncation / padding / pair epilogue
+    DevBuf w_ovf_parts, w_enc_base, w_enc_doc, w_enc_start, w_enc_cnt;             // overflowing encodings (TKAMD_WANT_OVERFLOW)
     DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
@@ -117,6 +119,7 @@ struct Workspace {
     uint32_t last_flags = 0;
     tkamd_device_result last_result{};
     int64_t last_n_docs = 0;
+    int64_t last_n_enc = -1;                    // encodings of the last call when it materialised overflowing ones, else -1
     int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
     ~Workspace() { if (own_stream) (void)hipStreamDestroy(own_stream); }
@@ -187,9 +190,9 @@ static void pinned_put(PinnedBlock b) {
 
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids;
-    bool has_offsets = false, has_words = false, has_pads = false, has_types = false;
-    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); }
+    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs;
+    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); }
 };
 
 struct tkamd_text {
@@ -201,7 +204,7 @@ struct tkamd_text {
 namespace {
 
 // scalars block layout (int64 slots)
-enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_PADMAX = 4 /* uint32 */, SC_NSEG = 5, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
+enum { SC_NPRETOK = 0, SC_NTOK = 1, SC_ERR = 2 /* int */, SC_NKEPT = 3, SC_PADMAX = 4 /* uint32 */, SC_NSEG = 5, SC_NENC = 6, SC_NCHARS = 8, SC_HUGE_USED = 9, SC_NTOK2 = 10,
        SC_COUNTERS = 16 /* uint32[CNT_COUNT] */, SC_SLOTS = 32 };
 
 struct Prof {
@@ -503,6 +506,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
     w->last_n_docs = n_docs;
+    w->last_n_enc = -1;
+    out->d_enc_docs = nullptr;
+    out->d_n_encodings = nullptr;
     w->last_seq_off = d_seq_off;
     w->last_n_seqs = n_seqs;
     // the caller's CSR is validated once; everything below reads the validated copy
@@ -561,6 +567,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (pairs && (e_n & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
     if (pairs && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
     const bool epilogue = hm.trunc_on || hm.pad_on || pairs;
+    // Encoding.overflowing: what a truncation cuts off, as further encodings of the result (single sequences; a pair's overflowing
+    // encodings are the cross product of both sides', Encoding::merge_with encoding.rs:408-432 -- not materialised)
+    const bool want_overflow = (flags & TKAMD_WANT_OVERFLOW) != 0 && hm.trunc_on && !pairs;
     auto finalize_pairs = [&]() {
         // EncodeInput::Dual: the two sequences of a pair were encoded as two documents; cut, lay out and pad them together
         const int64_t n_pairs = e_n / 2;
@@ -581,6 +590,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pa.trunc_max = hm.trunc_max_length;
         pa.trunc_left = hm.trunc_left ? 1u : 0u;
         pa.trunc_strategy = (uint32_t)hm.trunc_strategy;
+        pa.trunc_stride = hm.trunc_stride;
         pa.pad_on = hm.pad_on ? 1u : 0u;
         pa.pad_fixed = hm.pad_fixed ? 1u : 0u;
         pa.pad_length = hm.pad_length;
@@ -662,30 +672,65 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         if (hm.trunc_on) fa.trunc_len = (n_add && hm.trunc_max_length < n_add) ? 0xFFFFFFFFu : hm.trunc_max_length - n_add;
         fa.trunc_left = hm.trunc_left ? 1u : 0u;
         fa.trunc_needs_pair = (hm.trunc_on && hm.trunc_strategy == 2) ? 1u : 0u;
+        fa.trunc_stride = hm.trunc_stride;
         fa.pad_on = hm.pad_on ? 1u : 0u;
         fa.pad_fixed = hm.pad_fixed ? 1u : 0u;
         fa.pad_length = hm.pad_length;
         fa.pad_multiple = hm.pad_multiple;
         fa.pad_left = hm.pad_left ? 1u : 0u;
         fa.pad_id = hm.pad_id;
-        w->w_len1.reserve((size_t)(e_n + 2) * 4);
-        w->w_fin.reserve((size_t)(e_n + 2) * 4);
         w->w_fbsum.reserve((size_t)((e_n + 1) / 256 + 2) * 4);
-        w->w_tok_offsets2.reserve((size_t)(e_n + 2) * 8);
-        if (hm.pad_on) w->w_pad_count.reserve((size_t)(e_n + 2) * 4);
-        fa.len1 = w->w_len1.as<uint32_t>();
-        fa.fin = w->w_fin.as<uint32_t>();
         fa.bsum = w->w_fbsum.as<uint32_t>();
         fa.target = (uint32_t*)(sc + SC_PADMAX);
-        fa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
-        fa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
         fa.n_tok2 = sc + SC_NTOK2;
         fa.err = d_err;
         pf.begin("truncate_pad");
-        launch_final_lens(st, fa);
+        int64_t n_enc = e_n;                                   // encodings of the result
+        if (want_overflow) {
+            // how many encodings every document leaves -> their numbering; the total is read back (8 bytes) because everything
+            // below is sized and launched per encoding
+            w->w_ovf_parts.reserve((size_t)(e_n + 2) * 4);
+            w->w_enc_base.reserve((size_t)(e_n + 2) * 8);
+            fa.ovf_parts = w->w_ovf_parts.as<uint32_t>();
+            fa.enc_base = w->w_enc_base.as<int64_t>();
+            launch_overflow_count(st, fa, sc + SC_NENC);
+            HIP_CHECK(hipMemcpyAsync(&n_enc, sc + SC_NENC, 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (n_enc < e_n || n_enc >= ((int64_t)1 << 31)) throw Invalid("the truncation leaves more than 2^31 overflowing encodings: raise max_length - stride or split the batch");
+            w->w_enc_doc.reserve((size_t)(n_enc + 2) * 4);
+            w->w_enc_start.reserve((size_t)(n_enc + 2) * 4);
+            w->w_enc_cnt.reserve((size_t)(n_enc + 2) * 4);
+            fa.enc_doc = w->w_enc_doc.as<uint32_t>();
+            fa.enc_start = w->w_enc_start.as<uint32_t>();
+            fa.enc_cnt = w->w_enc_cnt.as<uint32_t>();
+            w->w_fbsum.reserve((size_t)((n_enc + 1) / 256 + 2) * 4);
+            fa.bsum = w->w_fbsum.as<uint32_t>();
+        }
+        w->w_len1.reserve((size_t)(n_enc + 2) * 4);
+        w->w_fin.reserve((size_t)(n_enc + 2) * 4);
+        w->w_tok_offsets2.reserve((size_t)(n_enc + 2) * 8);
+        if (hm.pad_on) w->w_pad_count.reserve((size_t)(n_enc + 2) * 4);
+        fa.len1 = w->w_len1.as<uint32_t>();
+        fa.fin = w->w_fin.as<uint32_t>();
+        fa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
+        fa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
+        if (want_overflow) {
+            launch_overflow_ranges(st, fa);                    // (fa.n_docs still counts documents)
+            fa.n_docs = n_enc;
+        } else {
+            launch_final_lens(st, fa);
+        }
         // capacity of the padded arrays: known up front for Fixed; BatchLongest needs the batch maximum (one 4-byte read-back)
         size_t T2 = (size_t)n_x + 4 + (size_t)(e_n + 1) * n_add;
-        if (hm.pad_on) {
+        if (want_overflow) {
+            // overlapping windows: the token total is whatever the new CSR says (read back once it is built)
+            launch_final_offsets(st, fa);
+            int64_t total = 0;
+            HIP_CHECK(hipMemcpyAsync(&total, fa.n_tok2, 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (total < 0 || (uint64_t)total >= ((uint64_t)1 << 32)) throw Invalid("the batch with its overflowing encodings would hold more than 2^32 tokens: encode fewer documents per call");
+            T2 = (size_t)total + 4;
+        } else if (hm.pad_on) {
             uint64_t target = hm.pad_length;
             if (!hm.pad_fixed) {
                 uint32_t mx = 0;
@@ -703,9 +748,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.ids2 = w->w_ids2.as<uint32_t>();
         fa.offsets2 = w->w_offsets2.as<uint32_t>();
         fa.word_ids2 = w->w_word_ids2.as<uint32_t>();
-        launch_final_offsets(st, fa);
+        if (!want_overflow) launch_final_offsets(st, fa);
         launch_finalize(st, grid, fa);
         pf.end();
+        if (want_overflow) {
+            w->last_n_enc = n_enc;
+            out->d_enc_docs = fa.enc_doc;
+            out->d_n_encodings = sc + SC_NENC;
+        }
         out->d_ids = fa.ids2;
         out->d_tok_offsets = fa.tok_offsets2;
         if (out->d_offsets) out->d_offsets = fa.offsets2;
@@ -1141,7 +1191,8 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
         tkamd_device_result again{};
         run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again);
         if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
-            again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts || again.d_type_ids != w->last_result.d_type_ids)
+            again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts || again.d_type_ids != w->last_result.d_type_ids ||
+            again.d_enc_docs != w->last_result.d_enc_docs)
             throw HipError("result buffers moved while a batch was run again");
         bits = read_scalars(t, w, st, n_tok, n_pretok);
     }
@@ -1170,6 +1221,10 @@ int error_from_bits(int bits) {
     if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
     if (bits & ERR_TRUNC_SECOND) return set_error(TKAMD_ERR_INVALID, "Truncation error: Second sequence not provided");
     if (bits & ERR_TRUNC_SHORT) return set_error(TKAMD_ERR_INVALID, "Truncation error: Sequence to truncate too short to respect the provided max_length");
+    if (bits & ERR_TRUNC_STRIDE)
+        return set_error(TKAMD_ERR_INVALID, "`stride` must be strictly less than `max_len` (note that `max_len` may be shorter than the max length of the "
+                                            "original model, as it subtracts the number of special characters");
+    if (bits & ERR_TOO_MANY_TOKENS) return set_error(TKAMD_ERR_INVALID, "a truncation leaves more than 2^32 overflowing encodings of one sequence");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     return TKAMD_OK;
 }
@@ -1383,7 +1438,9 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         if (n_grp % unit) throw Invalid("TKAMD_PAIRS: an odd number of sequences");
         static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
         int n_slices = (int)std::min<int64_t>(8, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
-        if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed)) n_slices = 1;
+        // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
+        const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on && !(flags & TKAMD_PAIRS);
+        if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)
         std::vector<int64_t> cut(n_slices + 1, 0);                     // in sequences
@@ -1445,7 +1502,18 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             if (bits) return bits;
             const tkamd_device_result& r = res[k];
             const int64_t seen_docs = doc_of(cut[k + 1]);
-            const int64_t d0 = cut[k] / unit, d1 = cut[k + 1] / unit;      // encodings of this slice
+            int64_t d0 = cut[k] / unit, d1 = cut[k + 1] / unit;            // encodings of this slice
+            if (r.d_enc_docs) {                                            // (one slice) the documents' own encodings + their overflowing ones
+                d0 = 0;
+                d1 = w->last_n_enc;
+                b->n_docs = d1;
+                pinned_put(b->tok_offsets);
+                b->tok_offsets = PinnedBlock{};
+                b->tok_offsets = pinned_get((size_t)(d1 + 1) * 8);
+                b->enc_docs = pinned_get((size_t)(d1 + 1) * 4);
+                b->has_enc_docs = true;
+                if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_docs.p, r.d_enc_docs, (size_t)d1 * 4, hipMemcpyDeviceToHost, s));
+            }
             slice_tok[k] = n_tok;
             const size_t need = (size_t)(tok_base + n_tok);
             if (need > tok_cap) {
@@ -1480,7 +1548,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->seq_ids.p + tok_base, r.d_seq_ids, (size_t)n_tok, hipMemcpyDeviceToHost, s));
             }
             if (r.d_pad_counts) {
-                if (!b->has_pads) { b->has_pads = true; b->pad_counts = pinned_get((size_t)(n_enc + 1) * 4); }
+                if (!b->has_pads) { b->has_pads = true; b->pad_counts = pinned_get((size_t)(std::max(n_enc, d1) + 1) * 4); }
                 if (d1 > d0) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->pad_counts.p + d0, r.d_pad_counts, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, s));
             }
             tok_base += n_tok;
@@ -1519,6 +1587,7 @@ int tkamd_encode_batch_words(tkamd_tokenizer* t, const uint8_t* text, const int6
 }
 
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b) { return (b && b->has_pads) ? (const uint32_t*)b->pad_counts.p : nullptr; }
+const uint32_t* tkamd_batch_encoding_docs(const tkamd_batch* b) { return (b && b->has_enc_docs) ? (const uint32_t*)b->enc_docs.p : nullptr; }
 const uint8_t* tkamd_batch_type_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->type_ids.p : nullptr; }
 const uint8_t* tkamd_batch_sequence_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->seq_ids.p : nullptr; }
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
@@ -1646,6 +1715,15 @@ int tkamd_probe_merge(const tkamd_tokenizer* t, uint32_t left, uint32_t right, u
     *rank = s.rank;
     *new_id = s.new_id;
     return 1;
+}
+
+int tkamd_probe_truncation(uint64_t n_tokens, uint32_t max_len, uint32_t stride, int left, uint32_t part, uint64_t* start, uint64_t* count) {
+    if (!start || !count) return set_error(TKAMD_ERR_INVALID, "null argument");
+    const uint32_t parts = ovf_parts(n_tokens, max_len, stride);
+    *start = 0;
+    *count = 0;
+    if (part < parts) ovf_part_range(n_tokens, max_len, stride, left != 0, part, start, count);
+    return (int)std::min<uint32_t>(parts, 0x7FFFFFFFu);
 }
 
 // one edge of the WordPiece byte trie from the host copy of its 2-choice table: (node, byte) -> (child node, id of the piece that

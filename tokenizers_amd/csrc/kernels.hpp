@@ -146,7 +146,16 @@ struct FinalArgs {
     uint32_t trunc_len;               // tokens of the sequence itself that survive (0xFFFFFFFF: no truncation)
     uint32_t trunc_left;              // keep the end instead of the beginning
     uint32_t trunc_needs_pair;        // strategy OnlySecond: a single sequence that must be cut is an error
+    uint32_t trunc_stride;            // tokens two neighbouring windows of a truncation share (shapes the overflowing encodings; must be < trunc_len)
     uint32_t pad_on, pad_fixed, pad_length, pad_multiple, pad_left, pad_id;
+    // overflowing encodings (TKAMD_WANT_OVERFLOW; overflow_core.hpp): document d leaves ovf_parts[d] encodings, numbered from
+    // enc_base[d]; encoding e is tokens [enc_start[e], enc_start[e] + enc_cnt[e]) of document enc_doc[e].  With these set, n_docs of
+    // k_final_fin / k_final_down / k_finalize counts ENCODINGS and len1 .. pad_count are per encoding.  All null: one encoding per document.
+    uint32_t* ovf_parts;              // [n_docs + 1]
+    int64_t* enc_base;                // [n_docs + 1]
+    uint32_t* enc_doc;
+    uint32_t* enc_start;
+    uint32_t* enc_cnt;
     uint32_t* len1;                   // [n_docs] tokens after truncation + specials
     uint32_t* fin;                    // [n_docs] tokens after padding
     uint32_t* target;                 // device scalar: longest len1 of the batch
@@ -170,7 +179,7 @@ struct PairArgs {
     const uint32_t* tpl;              // [n_tpl][3] kind (0 A, 1 B, 2 special), id, type id
     int32_t n_tpl;
     uint32_t n_special;               // special tokens of the template (taken off max_length)
-    uint32_t trunc_on, trunc_max, trunc_left, trunc_strategy;
+    uint32_t trunc_on, trunc_max, trunc_left, trunc_strategy, trunc_stride;
     uint32_t pad_on, pad_fixed, pad_length, pad_multiple, pad_left, pad_id, pad_type_id;
     uint32_t* keep;                   // [2 * n_pairs] tokens of A / B that survive the truncation
     uint32_t* len1;                   // [n_pairs] tokens of the pair encoding before padding
@@ -200,6 +209,7 @@ enum : int {
     ERR_TRUNC_SECOND = 128,       // truncation strategy OnlySecond on a single sequence that has to be cut (TruncationError::SecondSequenceNotProvided)
     ERR_TOO_MANY_TOKENS = 256,
     ERR_TRUNC_SHORT = 512,        // OnlyFirst / OnlySecond: the sequence to cut is not longer than what must go (TruncationError::SequenceTooShort)    // the padded batch has more than 2^32 tokens
+    ERR_TRUNC_STRIDE = 1024,      // a sequence has to be cut to max_len tokens and stride >= max_len (the assert of Encoding::truncate, encoding.rs:319)
     ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
 
@@ -259,6 +269,11 @@ void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 // truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy
 void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta);
 void launch_final_lens(hipStream_t st, const FinalArgs& a);
+// overflowing encodings: encodings per document + their numbering (*n_enc = how many there are), then -- with a.n_docs still the
+// number of DOCUMENTS -- every encoding's token range, its length with the specials, and the batch maximum over the truncated
+// encodings themselves (what launch_final_lens computes when nothing overflows)
+void launch_overflow_count(hipStream_t st, const FinalArgs& a, int64_t* n_enc);
+void launch_overflow_ranges(hipStream_t st, const FinalArgs& a);
 void launch_final_offsets(hipStream_t st, const FinalArgs& a);
 void launch_finalize(hipStream_t st, int grid, const FinalArgs& a);
 void launch_pair_lens(hipStream_t st, const PairArgs& a);

@@ -170,6 +170,19 @@ void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta) {
 void launch_final_lens(hipStream_t st, const FinalArgs& a) {
     hipLaunchKernelGGL(k_final_lens, dim3(blocks_for(a.n_docs + 1, 256)), dim3(256), 0, st, a);
 }
+void launch_overflow_count(hipStream_t st, const FinalArgs& a, int64_t* n_enc) {
+    const unsigned nb = blocks_for(a.n_docs + 1, 256);
+    hipLaunchKernelGGL(k_ovf_parts, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)a.ovf_parts, a.n_docs + 1, a.bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, n_enc);
+    FinalArgs s = a;                                        // exclusive scan of the parts = k_final_down over them
+    s.fin = a.ovf_parts;
+    s.tok_offsets2 = a.enc_base;
+    hipLaunchKernelGGL(k_final_down, dim3(nb), dim3(256), 0, st, s);
+}
+void launch_overflow_ranges(hipStream_t st, const FinalArgs& a) {
+    hipLaunchKernelGGL(k_ovf_ranges, dim3(blocks_for(a.n_docs + 1, 256)), dim3(256), 0, st, a);
+}
 void launch_final_offsets(hipStream_t st, const FinalArgs& a) {
     const unsigned nb = blocks_for(a.n_docs + 1, 256);
     hipLaunchKernelGGL(k_final_fin, dim3(nb), dim3(256), 0, st, a);

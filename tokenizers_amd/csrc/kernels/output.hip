@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void k_final_lens(FinalArgs a) {
     if (d < a.n_docs) {
         const uint64_t n = (uint64_t)(a.tok_offsets[d + 1] - a.tok_offsets[d]);
         if (n > a.trunc_len && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
+        if (n > a.trunc_len && a.trunc_len > 0u && a.trunc_stride >= a.trunc_len) atomicOr(a.err, ERR_TRUNC_STRIDE);      // encoding.rs:319
         l = (uint32_t)min(n, (uint64_t)a.trunc_len) + (uint32_t)(a.n_prefix + a.n_suffix);
         a.len1[d] = l;
     }
@@ -345,13 +346,66 @@ __global__ __launch_bounds__(256) void k_final_down(FinalArgs a) {
     const uint32_t ex = a.bsum[blockIdx.x] + block256_excl_scan(x, sm, &tot);
     if (d <= a.n_docs) a.tok_offsets2[d] = (int64_t)ex;
 }
+// ---- overflowing encodings (TKAMD_WANT_OVERFLOW) ----
+// Encoding::truncate keeps what it cuts off: further windows of max_len tokens, each sharing `stride` tokens with its neighbour
+// (tokenizer/encoding.rs:307-395), pushed to Encoding.overflowing; the post-processor then puts the same special tokens around
+// every one of them (processors/bert.rs:88-125, Encoding::merge_with encoding.rs:408-432) and Encoding::pad pads them like the
+// encoding itself (:466-469).  Here they are simply further encodings of the result, numbered right behind their document's own:
+// parts per document -> scan -> (document, first token, count) per encoding; from there on the epilogue runs per encoding.
+__global__ __launch_bounds__(256) void k_ovf_parts(FinalArgs a) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d > a.n_docs) return;
+    uint32_t p = 0;
+    if (d < a.n_docs) {
+        const uint64_t n = (uint64_t)(a.tok_offsets[d + 1] - a.tok_offsets[d]);
+        if (n > a.trunc_len && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
+        p = ovf_parts(n, a.trunc_len, a.trunc_stride);
+        if (p == 0u) { atomicOr(a.err, ERR_TRUNC_STRIDE); p = 1u; }
+        if (p == 0xFFFFFFFFu) { atomicOr(a.err, ERR_TOO_MANY_TOKENS); p = 1u; }
+    }
+    a.ovf_parts[d] = p;
+}
+__global__ __launch_bounds__(256) void k_ovf_ranges(FinalArgs a) {
+    __shared__ uint32_t smax[4];
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t l = 0;                                         // length of the truncated encoding itself (part 0)
+    if (d < a.n_docs) {
+        const uint64_t n = (uint64_t)(a.tok_offsets[d + 1] - a.tok_offsets[d]);
+        const int64_t e0 = a.enc_base[d];
+        const uint32_t parts = (uint32_t)(a.enc_base[d + 1] - e0);
+        const uint32_t add = (uint32_t)(a.n_prefix + a.n_suffix);
+        for (uint32_t p = 0; p < parts; ++p) {
+            uint64_t s, c;
+            ovf_part_range(n, a.trunc_len, a.trunc_stride, a.trunc_left != 0u, p, &s, &c);
+            a.enc_doc[e0 + p] = (uint32_t)d;
+            a.enc_start[e0 + p] = (uint32_t)s;
+            a.enc_cnt[e0 + p] = (uint32_t)c;
+            a.len1[e0 + p] = (uint32_t)c + add;
+            if (p == 0u) l = (uint32_t)c + add;
+        }
+    }
+    if (a.pad_on && !a.pad_fixed) {                         // BatchLongest looks at the encodings themselves, not at their overflowing pieces (utils/padding.rs:55-63)
+        uint32_t m = l;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s, 64));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(a.target, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    }
+}
 __global__ __launch_bounds__(256) void k_finalize(FinalArgs a) {
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     for (int64_t d = wave; d < a.n_docs; d += n_waves) {
-        const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo;
-        const int64_t n = min(n_all, (int64_t)a.trunc_len);
-        const int64_t src = lo + (a.trunc_left ? n_all - n : 0);
+        int64_t n, src;
+        if (a.enc_doc) {                                    // d numbers the encodings: a document's own, then its overflowing ones
+            n = a.enc_cnt[d];
+            src = a.tok_offsets[a.enc_doc[d]] + a.enc_start[d];
+        } else {
+            const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo;
+            n = min(n_all, (int64_t)a.trunc_len);
+            src = lo + (a.trunc_left ? n_all - n : 0);
+        }
         const int64_t dst0 = a.tok_offsets2[d], total = a.tok_offsets2[d + 1] - dst0;
         const int64_t real = n + a.n_prefix + a.n_suffix, pads = total - real;
         const int64_t body = dst0 + (a.pad_left ? pads : 0);
@@ -415,6 +469,11 @@ __global__ __launch_bounds__(256) void k_pair_lens(PairArgs a) {
                     else atomicOr(a.err, ERR_TRUNC_SHORT);
                 }
             }
+        }
+        // Encoding::truncate(kept, stride): a sequence that is cut to kept > 0 tokens asserts stride < kept (encoding.rs:319)
+        {
+            const uint64_t a1 = (uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), a2 = (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1]);
+            if ((n1 < a1 && n1 > 0 && a.trunc_stride >= n1) || (n2 < a2 && n2 > 0 && a.trunc_stride >= n2)) atomicOr(a.err, ERR_TRUNC_STRIDE);
         }
         a.keep[2 * i] = (uint32_t)n1;
         a.keep[2 * i + 1] = (uint32_t)n2;

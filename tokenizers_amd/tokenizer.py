@@ -101,7 +101,8 @@ class Encoding:
 
     Field semantics follow ``Encoding`` (tokenizer/encoding.rs:11-31).  For a single sequence ``type_ids`` are 0 and
     ``attention_mask`` 1 on everything but padding; ``special_tokens_mask`` is 1 on the post-processor's special tokens and on
-    padding (Encoding::pad, encoding.rs:405-470).  The ``overflowing`` pieces of a truncation are not materialised.
+    padding (Encoding::pad, encoding.rs:405-470).  ``overflowing``: what a truncation cut off a single sequence, as further
+    encodings (Encoding::truncate, encoding.rs:307-395); a pair's are not materialised.
     """
     __slots__ = ("_b", "_lo", "_hi", "_i")
 
@@ -182,7 +183,19 @@ class Encoding:
 
     @property
     def overflowing(self) -> list:
-        return []
+        b = self._b
+        if b.enc_docs is None:
+            return []
+        # the encodings right behind this one that belong to the same document (only a document's own encoding has any)
+        i, n, doc = self._i, len(b.enc_docs), b.enc_docs[self._i]
+        if i > 0 and b.enc_docs[i - 1] == doc:
+            return []
+        j = i + 1
+        out = []
+        while j < n and b.enc_docs[j] == doc:
+            out.append(Encoding(b, int(b.tok_offsets[j]), int(b.tok_offsets[j + 1]), j))
+            j += 1
+        return out
 
     def __repr__(self) -> str:
         return f"Encoding(num_tokens={len(self)}, attributes=[ids, type_ids, tokens, offsets, attention_mask, special_tokens_mask, overflowing])"
@@ -200,11 +213,20 @@ class BatchEncoding:
         self.pad_counts = pad_counts        # uint32 per document: padding tokens (None without a `padding` section)
         self.type_ids = None                # pairs only: uint8 per token
         self.seq_ids = None                 # pairs only: uint8 per token, 0 / 1 sequence A / B, 2 special token, 3 padding
+        # overflowing encodings materialised: tok_offsets / pad_counts run over ENCODINGS, enc_docs[e] = the input encoding e belongs to
+        # (an input's own encoding first, then its Encoding.overflowing), _first[i] = the own encoding of input i
+        self.enc_docs = None
+        self._first = None
         self._id_to_token = id_to_token
         self._specials = specials           # (#prefix, #suffix) special tokens around every document
         self._pad_left, self._pad_type_id, self._pad_token = pad_left, pad_type_id, pad_token
 
     def __len__(self) -> int:
+        return len(self.tok_offsets) - 1 if self._first is None else len(self._first)
+
+    @property
+    def n_encodings(self) -> int:
+        """Encodings held, the overflowing ones included (== len(self) unless a truncation left overflowing encodings)."""
         return len(self.tok_offsets) - 1
 
     def __getitem__(self, i: int) -> Encoding:
@@ -213,6 +235,8 @@ class BatchEncoding:
             i += n
         if not 0 <= i < n:
             raise IndexError(i)
+        if self._first is not None:
+            i = int(self._first[i])
         return Encoding(self, int(self.tok_offsets[i]), int(self.tok_offsets[i + 1]), i)
 
     def __iter__(self):
@@ -401,13 +425,14 @@ class Tokenizer:
         raise RuntimeError("staging buffer growth failed")          # pragma: no cover
 
     def encode_batch_csr(self, inputs: Sequence[str], offsets: str = "none", word_ids: bool = False,
-                         add_special_tokens: bool = False, is_pretokenized: bool = False) -> BatchEncoding:
+                         add_special_tokens: bool = False, is_pretokenized: bool = False, overflowing: bool = False) -> BatchEncoding:
         """CSR arrays for a batch; ``offsets`` in {'none','byte','char'} (OffsetType, pre_tokenizer.rs:10-17).
 
-        ``is_pretokenized``: every item is a list of words (or a pair of lists) -- InputSequence::PreTokenized, tokenizer/mod.rs:225-290."""
+        ``is_pretokenized``: every item is a list of words (or a pair of lists) -- InputSequence::PreTokenized, tokenizer/mod.rs:225-290.
+        ``overflowing``: with a truncation section, keep what single sequences lose to the cut as ``Encoding.overflowing``."""
         self._check_special(add_special_tokens)
         if is_pretokenized:
-            return self._encode_words(inputs, offsets, word_ids, add_special_tokens)
+            return self._encode_words(inputs, offsets, word_ids, add_special_tokens, overflowing)
         pairs = len(inputs) > 0 and isinstance(inputs[0], (tuple, list))
         if pairs:
             # EncodeInput::Dual for every item (a batch mixing single sequences and pairs is outside this path): A and B as
@@ -421,9 +446,9 @@ class Tokenizer:
             inputs = flat
         with self._stage_lock:                               # the staging buffers are per tokenizer; results are copied out by the library
             buf, doc_off = self._pack_staged(inputs)
-            return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens, pairs)
+            return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens, pairs, overflowing=overflowing)
 
-    def _encode_words(self, inputs, offsets, word_ids, add_special_tokens) -> BatchEncoding:
+    def _encode_words(self, inputs, offsets, word_ids, add_special_tokens, overflowing=False) -> BatchEncoding:
         """is_pretokenized inputs: all words of all sequences as one packed buffer + the CSR of the sequences over the words."""
         def is_words(x):
             return isinstance(x, (list, tuple)) and all(isinstance(w, str) for w in x)
@@ -442,13 +467,16 @@ class Tokenizer:
                 seq_off.append(len(words))
         with self._stage_lock:
             buf, word_off = self._pack_staged(words)
-            return self.encode_packed(buf, word_off, offsets, word_ids, add_special_tokens, pairs, np.asarray(seq_off, dtype=np.int64))
+            return self.encode_packed(buf, word_off, offsets, word_ids, add_special_tokens, pairs, np.asarray(seq_off, dtype=np.int64), overflowing)
 
     def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
-                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None) -> BatchEncoding:
+                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None, overflowing: bool = False) -> BatchEncoding:
         """``pairs``: documents 2i and 2i+1 are sequence A and B of encoding i (EncodeInput::Dual, tokenizer/mod.rs:871-889).
-        ``seq_off``: the documents are the words of pre-tokenized sequences, sequence s = words [seq_off[s], seq_off[s+1])."""
+        ``seq_off``: the documents are the words of pre-tokenized sequences, sequence s = words [seq_off[s], seq_off[s+1]).
+        ``overflowing``: TKAMD_WANT_OVERFLOW -- the result then also holds every input's overflowing encodings."""
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
+        if overflowing:
+            flags |= _lib.WANT_OVERFLOW
         if pairs:
             flags |= _lib.PAIRS
         if word_ids:
@@ -459,6 +487,7 @@ class Tokenizer:
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n_docs = len(doc_off) - 1
+        n_inputs = (n_docs if seq_off is None else len(seq_off) - 1) // (2 if pairs else 1)
         b = C.c_void_p()
         if seq_off is None:
             _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
@@ -497,6 +526,10 @@ class Tokenizer:
         if tp:
             be.type_ids = view(tp, C.c_uint8, (nt,), np.uint8)
             be.seq_ids = view(self._lib.tkamd_batch_sequence_ids(b), C.c_uint8, (nt,), np.uint8)
+        ed = self._lib.tkamd_batch_encoding_docs(b)
+        if ed:
+            be.enc_docs = view(ed, C.c_uint32, (n_docs,), np.uint32)
+            be._first = np.searchsorted(be.enc_docs, np.arange(n_inputs, dtype=np.uint32), side="left")
         return be
 
     def encode_file(self, path: str, offsets: str = "none", word_ids: bool = False, add_special_tokens: bool = False) -> BatchEncoding:
@@ -506,11 +539,13 @@ class Tokenizer:
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
-        return self.encode_batch_csr(list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized)
+        return self.encode_batch_csr(list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized,
+                                     overflowing=self.info["truncation"] >= 0)
 
     def encode_batch_fast(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch_fast`` (no offsets, tokenizer.rs:1433-1459)."""
-        return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized)
+        return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized,
+                                     overflowing=self.info["truncation"] >= 0)
 
     def decode_batch_csr(self, ids: np.ndarray, tok_offsets: np.ndarray, skip_special_tokens: bool = True) -> tuple[np.ndarray, np.ndarray]:
         """ids CSR -> (bytes uint8[n_bytes], doc_offsets int64[n_docs+1]): the raw decoded byte string of every sequence."""
