@@ -181,3 +181,43 @@ def test_overflowing_encodings_through_the_c_abi_arrays():
         for p in range(parts[i]):
             e = first[i] + p
             assert (got.ids[got.tok_offsets[e]:got.tok_offsets[e + 1]] == ids[24 * p: 24 * p + 32]).all()
+
+
+def test_overflowing_encodings_survive_a_queue_overflow_rerun():
+    """A work queue far too small (TKAMD_Q16_DIV test hook): the overflow epilogue, which waits for the number of encodings anyway,
+    sees ERR_QUEUE_FULL, grows the queue and runs the batch again inside the same call -- same result as with the default queue,
+    through the host entry and through the device entry."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, ctypes as C; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, tokenizers_amd as ta\n"
+        "from tokenizers_amd import _lib\n"
+        "from oracle import synth\n"
+        "from tests.helpers import load_tokenizer_json\n"
+        "d = json.loads(load_tokenizer_json('gpt2_synth_50257'))\n"
+        "d['truncation'] = {'direction': 'Left', 'max_length': 20, 'strategy': 'LongestFirst', 'stride': 3}\n"
+        "tok = ta.Tokenizer.from_str(json.dumps(d), device=0)\n"
+        "docs = synth.gen_lines(20000, text_seed=77, type_seed=1)\n"
+        "g = tok.encode_batch_csr(docs, overflowing=True)\n"
+        "buf, off = ta.pack_documents(docs)\n"
+        "tb, to = torch.from_numpy(buf.copy()).cuda(), torch.from_numpy(off.copy()).cuda()\n"
+        "res = _lib.DeviceResult()\n"
+        "_lib.check(tok._lib.tkamd_encode_batch_device(tok._h, tb.data_ptr(), to.data_ptr(), len(docs), int(off[-1]), _lib.WANT_OVERFLOW, 0, C.byref(res)))\n"
+        "nt, npt = C.c_int64(0), C.c_int64(0)\n"
+        "_lib.check(tok._lib.tkamd_device_sync(tok._h, 0, C.byref(nt), C.byref(npt)))\n"
+        "assert nt.value == g.n_tokens and res.d_enc_docs\n"
+        "torch.cuda.synchronize()\n"
+        "ids = np.empty(nt.value, dtype=np.uint32)\n"
+        "import ctypes\n"
+        "hip = ctypes.CDLL('libamdhip64.so')\n"
+        "assert hip.hipMemcpy(ctypes.c_void_p(ids.ctypes.data), ctypes.c_void_p(res.d_ids), ctypes.c_size_t(ids.nbytes), 2) == 0\n"
+        "assert np.array_equal(ids, g.ids)\n"
+        "print('OVF', g.n_encodings, g.n_tokens, int(g.ids.astype(np.uint64).sum()), int(g.tok_offsets.sum()), int(g.enc_docs.astype(np.int64).sum()))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"TKAMD_Q16_DIV": "100000"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert "OVF" in r.stdout, r.stdout + r.stderr
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]

@@ -458,6 +458,9 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
 void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
                   const int64_t* d_seq_off, int64_t n_seqs, uint32_t flags, hipStream_t st, tkamd_device_result* out) {
     HostModel& hm = t->hm;
+    const int64_t* const d_doc_off_in = d_doc_off;         // as the caller passed them (the pipeline below works on validated copies)
+    const int64_t* const d_seq_off_in = d_seq_off;
+    bool rerun = false;                                    // set by the overflow epilogue: a work queue was too small, run the batch again
     const uint32_t off_mode = flags & TKAMD_OFFSETS_MASK;
     const bool want_words = (flags & TKAMD_WANT_WORD_IDS) != 0;
     const bool want_meta = off_mode != TKAMD_OFFSETS_NONE || want_words;
@@ -686,16 +689,32 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.err = d_err;
         pf.begin("truncate_pad");
         int64_t n_enc = e_n;                                   // encodings of the result
-        if (want_overflow) {
-            // how many encodings every document leaves -> their numbering; the total is read back (8 bytes) because everything
-            // below is sized and launched per encoding
+        bool overflow = want_overflow;
+        if (overflow) {
+            // how many encodings every document leaves -> their numbering; the total is read back because everything below is
+            // sized and launched per encoding
             w->w_ovf_parts.reserve((size_t)(e_n + 2) * 4);
             w->w_enc_base.reserve((size_t)(e_n + 2) * 8);
             fa.ovf_parts = w->w_ovf_parts.as<uint32_t>();
             fa.enc_base = w->w_enc_base.as<int64_t>();
             launch_overflow_count(st, fa, sc + SC_NENC);
-            HIP_CHECK(hipMemcpyAsync(&n_enc, sc + SC_NENC, 8, hipMemcpyDeviceToHost, st));
+            int64_t head[SC_NENC + 1];
+            HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
+            const int err_now = *(const int*)&head[SC_ERR];
+            if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {
+                // the token CSR is incomplete: this call is synchronous here anyway, so the batch is run again right away with the
+                // larger queue (what finish_batch does for the calls that never wait)
+                t->q16_div = t->q16_div > 2 ? 2 : 1;
+                rerun = true;
+                pf.end();
+                return;
+            }
+            // any other error: the batch fails when it is synchronised; finish it without the overflowing encodings
+            if (err_now) overflow = false;
+            else n_enc = head[SC_NENC];
+        }
+        if (overflow) {
             if (n_enc < e_n || n_enc >= ((int64_t)1 << 31)) throw Invalid("the truncation leaves more than 2^31 overflowing encodings: raise max_length - stride or split the batch");
             w->w_enc_doc.reserve((size_t)(n_enc + 2) * 4);
             w->w_enc_start.reserve((size_t)(n_enc + 2) * 4);
@@ -714,7 +733,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.fin = w->w_fin.as<uint32_t>();
         fa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
         fa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
-        if (want_overflow) {
+        if (overflow) {
             launch_overflow_ranges(st, fa);                    // (fa.n_docs still counts documents)
             fa.n_docs = n_enc;
         } else {
@@ -722,7 +741,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         // capacity of the padded arrays: known up front for Fixed; BatchLongest needs the batch maximum (one 4-byte read-back)
         size_t T2 = (size_t)n_x + 4 + (size_t)(e_n + 1) * n_add;
-        if (want_overflow) {
+        if (overflow) {
             // overlapping windows: the token total is whatever the new CSR says (read back once it is built)
             launch_final_offsets(st, fa);
             int64_t total = 0;
@@ -748,10 +767,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.ids2 = w->w_ids2.as<uint32_t>();
         fa.offsets2 = w->w_offsets2.as<uint32_t>();
         fa.word_ids2 = w->w_word_ids2.as<uint32_t>();
-        if (!want_overflow) launch_final_offsets(st, fa);
+        if (!overflow) launch_final_offsets(st, fa);
         launch_finalize(st, grid, fa);
         pf.end();
-        if (want_overflow) {
+        if (overflow) {
             w->last_n_enc = n_enc;
             out->d_enc_docs = fa.enc_doc;
             out->d_n_encodings = sc + SC_NENC;
@@ -1174,6 +1193,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (pairs) finalize_pairs();
     else if (epilogue) finalize();
     else if (add_special) add_specials();
+    if (rerun) {
+        run_pipeline(t, w, d_text, d_doc_off_in, n_docs, n_bytes, d_seq_off_in, n_seqs, flags, st, out);
+        return;
+    }
     w->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
     HIP_CHECK(hipGetLastError());
 }
@@ -1192,8 +1215,12 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
         run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again);
         if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
             again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts || again.d_type_ids != w->last_result.d_type_ids ||
-            again.d_enc_docs != w->last_result.d_enc_docs)
-            throw HipError("result buffers moved while a batch was run again");
+            again.d_enc_docs != w->last_result.d_enc_docs) {
+            // (buffers sized from the data -- the padded / overflowing encodings -- may have grown; a device-entry caller already
+            // holds the old pointers, the host entry reads w->last_result after this)
+            if (w->device_bound) throw HipError("result buffers moved while a batch was run again");
+            w->last_result = again;
+        }
         bits = read_scalars(t, w, st, n_tok, n_pretok);
     }
     return bits;
@@ -1500,6 +1527,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             int64_t n_tok = 0, n_pt = 0;
             const int bits = finish_batch(t, w, s, &n_tok, &n_pt);
             if (bits) return bits;
+            res[k] = w->last_result;
             const tkamd_device_result& r = res[k];
             const int64_t seen_docs = doc_of(cut[k + 1]);
             int64_t d0 = cut[k] / unit, d1 = cut[k + 1] / unit;            // encodings of this slice
