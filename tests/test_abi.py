@@ -565,3 +565,32 @@ def test_truncation_windows_closed_form_equals_the_reference_loop():
             e.truncate(max_len, stride=stride, direction=direction)
             got = _probe_parts(lib, n, max_len, stride, direction == "left")
             assert [list(range(a + 1, b + 1)) for a, b in got] == [e.ids] + [o.ids for o in e.overflowing], (n, max_len, stride, direction)
+
+
+def test_threaded_marshalling_of_every_str_kind_and_the_first_bad_item():
+    """csrc/pymarshal.c on a batch big enough for its helper threads: ASCII, Latin-1, UCS2 and UCS4 strs (encoded straight from their
+    code units), a str that already carries a cached UTF-8 form; a non-str and a lone surrogate raise what the reference's extraction
+    loop raises (tokenizer.rs:274, the str -> String conversion), and it is the FIRST bad item that speaks."""
+    import random
+    import numpy as np
+    random.seed(3)
+    pool = ["abc", "é", "ÿ\x80", "中文", "😀", "á", "", "x" * 300, "Ω", "\U0010ffff", "\x00", "\x7f"]
+    docs = ["".join(random.choice(pool) for _ in range(random.randint(0, 6))) for _ in range(70000)]
+    cached = "héllo wörld"
+    C.pythonapi.PyUnicode_AsUTF8.restype = C.c_char_p
+    C.pythonapi.PyUnicode_AsUTF8.argtypes = [C.py_object]
+    C.pythonapi.PyUnicode_AsUTF8(cached)                          # materialises the cached UTF-8 inside the str
+    docs[123] = cached
+    for dd in (docs, docs[:100], [], [""]):
+        buf, off = ta.pack_documents(dd)
+        exp = b"".join(d.encode() for d in dd)
+        assert bytes(buf[:off[-1]]) == exp and len(buf) == len(exp) + _lib.TEXT_PAD and not buf[off[-1]:].any()
+        assert np.array_equal(np.diff(off), np.array([len(d.encode()) for d in dd], dtype=np.int64))
+    with pytest.raises(TypeError, match="TextInputSequence must be str"):
+        ta.pack_documents(docs[:30000] + [3] + docs[:30000])
+    with pytest.raises(UnicodeEncodeError):
+        ta.pack_documents(docs[:20000] + ["a\ud800b"] + docs)
+    with pytest.raises(UnicodeEncodeError):                      # the surrogate comes first
+        ta.pack_documents(docs[:40000] + ["a\ud800"] + docs[:20000] + [5] + docs[:30000])
+    with pytest.raises(TypeError):                                # the non-str comes first
+        ta.pack_documents(docs[:40000] + [5] + docs[:20000] + ["a\ud800"] + docs[:30000])

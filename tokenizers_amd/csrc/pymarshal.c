@@ -16,91 +16,218 @@
 
 #define TEXT_PAD 64
 
-/* The list's str objects are scattered over the heap, so both passes are bound by cache misses on the object headers
- * and on the character data, not by the copy: pass 1 prefetches the headers a few items ahead and records (pointer,
- * length) of every item's UTF-8; pass 2 copies from those pointers on several threads.  The GIL is held throughout --
- * the helper threads touch no Python state, they only read the (immutable) character data of objects the sequence
- * keeps alive, and nothing can mutate the sequence while this thread holds the GIL. */
+/* The list's str objects are scattered over the heap, so marshalling is bound by cache misses on the object headers and on the
+ * character data, not by the copy.  Both passes therefore run on several threads: pass A reads every item's header (type, kind,
+ * length) and sizes its UTF-8; the main thread turns the per-thread totals into base offsets and provides the destination; pass C
+ * writes the CSR offsets and the bytes.  The GIL is held by the calling thread throughout -- the helper threads touch no Python
+ * state, they only READ the (immutable) headers and character data of objects the sequence keeps alive, and nothing can mutate the
+ * sequence or its strs while this thread holds the GIL.  A str that is not ASCII is encoded straight from its UCS1 / UCS2 / UCS4
+ * code units into the batch buffer (PyUnicode_AsUTF8AndSize would first materialise a second, cached copy inside every such str);
+ * the rare items that need the interpreter (a non-str: the exception; a str with lone surrogates: the UnicodeEncodeError; a
+ * legacy non-compact str) are left to the main thread, in index order, so the first bad item raises what the sequential loop would. */
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <unistd.h>
 
-typedef struct { const char* p; int64_t len; } span_t;
-typedef struct { const span_t* sp; const int64_t* off; char* dst; Py_ssize_t lo, hi; } copy_job_t;
+typedef struct { const void* p; int64_t len; } span_t;     /* len >= 0: UTF-8 bytes at p; len | SPAN_ENCODE: p is the str, encoded from its code units */
+#define SPAN_ENCODE ((int64_t)1 << 62)
+#define SPAN_LEN(sp) ((sp)->len & ~SPAN_ENCODE)
 
-static void* copy_worker(void* arg) {
-    const copy_job_t* j = (const copy_job_t*)arg;
-    for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
-        if (i + 8 < j->hi) __builtin_prefetch(j->sp[i + 8].p);
-        memcpy(j->dst + j->off[i], j->sp[i].p, (size_t)j->sp[i].len);
+#define PACK_PREFETCH 12
+#define PACK_MAX_THREADS 32
+#define SPAN_SLOW (-1)         /* needs the interpreter (main thread) */
+
+static inline int64_t utf8_size_ucs1(const Py_UCS1* s, int64_t n) { int64_t b = n; for (int64_t i = 0; i < n; ++i) b += s[i] >> 7; return b; }
+static inline int64_t utf8_size_ucs2(const Py_UCS2* s, int64_t n) {
+    int64_t b = 0;
+    for (int64_t i = 0; i < n; ++i) { const unsigned c = s[i]; if (c - 0xD800u < 0x800u) return -1; b += c < 0x80u ? 1 : c < 0x800u ? 2 : 3; }
+    return b;
+}
+static inline int64_t utf8_size_ucs4(const Py_UCS4* s, int64_t n) {
+    int64_t b = 0;
+    for (int64_t i = 0; i < n; ++i) { const unsigned c = s[i]; if (c - 0xD800u < 0x800u || c > 0x10FFFFu) return -1; b += c < 0x80u ? 1 : c < 0x800u ? 2 : c < 0x10000u ? 3 : 4; }
+    return b;
+}
+static inline char* utf8_put(char* d, unsigned c) {
+    if (c < 0x80u) { *d++ = (char)c; }
+    else if (c < 0x800u) { *d++ = (char)(0xC0u | (c >> 6)); *d++ = (char)(0x80u | (c & 0x3Fu)); }
+    else if (c < 0x10000u) { *d++ = (char)(0xE0u | (c >> 12)); *d++ = (char)(0x80u | ((c >> 6) & 0x3Fu)); *d++ = (char)(0x80u | (c & 0x3Fu)); }
+    else { *d++ = (char)(0xF0u | (c >> 18)); *d++ = (char)(0x80u | ((c >> 12) & 0x3Fu)); *d++ = (char)(0x80u | ((c >> 6) & 0x3Fu)); *d++ = (char)(0x80u | (c & 0x3Fu)); }
+    return d;
+}
+static void span_write(const span_t* sp, char* d) {
+    if (!(sp->len & SPAN_ENCODE)) { memcpy(d, sp->p, (size_t)sp->len); return; }
+    PyObject* it = (PyObject*)sp->p;                              /* a compact, non-ASCII str without a cached UTF-8 form */
+    const int64_t n = (int64_t)PyUnicode_GET_LENGTH(it);
+    const void* data = (const void*)(((const PyCompactUnicodeObject*)it) + 1);
+    const int kind = (int)PyUnicode_KIND(it);
+    if (kind == PyUnicode_1BYTE_KIND) { const Py_UCS1* s = (const Py_UCS1*)data; for (int64_t i = 0; i < n; ++i) d = utf8_put(d, s[i]); }
+    else if (kind == PyUnicode_2BYTE_KIND) { const Py_UCS2* s = (const Py_UCS2*)data; for (int64_t i = 0; i < n; ++i) d = utf8_put(d, s[i]); }
+    else { const Py_UCS4* s = (const Py_UCS4*)data; for (int64_t i = 0; i < n; ++i) d = utf8_put(d, s[i]); }
+}
+
+/* pass A for one item, without touching interpreter state: the item's UTF-8 source and size, or SPAN_SLOW */
+static inline void span_of(PyObject* it, span_t* sp) {
+    if (!PyUnicode_Check(it)) { sp->p = NULL; sp->len = SPAN_SLOW; return; }
+    const int64_t n = (int64_t)PyUnicode_GET_LENGTH(it);
+    if (PyUnicode_IS_COMPACT_ASCII(it)) { sp->p = (const void*)(((PyASCIIObject*)it) + 1); sp->len = n; return; }      /* (ready by construction) */
+    sp->p = NULL; sp->len = SPAN_SLOW;
+    if (!PyUnicode_IS_READY(it) || !PyUnicode_IS_COMPACT(it)) return;
+    const PyCompactUnicodeObject* cu = (const PyCompactUnicodeObject*)it;
+    if (cu->utf8) { sp->p = cu->utf8; sp->len = (int64_t)cu->utf8_length; return; }              /* already cached: plain bytes */
+    const void* data = (const void*)(cu + 1);
+    const int kind = (int)PyUnicode_KIND(it);
+    int64_t b = kind == PyUnicode_1BYTE_KIND ? utf8_size_ucs1((const Py_UCS1*)data, n)
+              : kind == PyUnicode_2BYTE_KIND ? utf8_size_ucs2((const Py_UCS2*)data, n) : utf8_size_ucs4((const Py_UCS4*)data, n);
+    if (b < 0) return;                                                                           /* lone surrogate: the interpreter raises */
+    sp->p = it; sp->len = b | SPAN_ENCODE;
+}
+
+typedef struct pack_ctx {
+    PyObject** items; Py_ssize_t n; span_t* sp; int64_t* off;
+    int nt; pthread_barrier_t bar;
+    int64_t total[PACK_MAX_THREADS], base[PACK_MAX_THREADS];
+    Py_ssize_t first_slow[PACK_MAX_THREADS];          /* first item of the thread's range that needs the interpreter, or -1 */
+    char* dst;                                        /* set by the main thread between the passes; NULL: do not copy */
+    int go;                                           /* start gate of the helpers: 0 wait, 1 go (nt is final), -1 leave */
+} pack_ctx;
+typedef struct { pack_ctx* c; int t; } pack_arg;
+
+static void pass_a(pack_ctx* c, int t) {
+    const Py_ssize_t lo = c->n * t / c->nt, hi = c->n * (t + 1) / c->nt;
+    int64_t total = 0;
+    Py_ssize_t slow = -1;
+    for (Py_ssize_t i = lo; i < hi; ++i) {
+        if (i + PACK_PREFETCH < hi) __builtin_prefetch(c->items[i + PACK_PREFETCH]);
+        span_of(c->items[i], &c->sp[i]);
+        if (c->sp[i].len == SPAN_SLOW) { if (slow < 0) slow = i; }
+        else total += SPAN_LEN(&c->sp[i]);
     }
+    c->total[t] = total;
+    c->first_slow[t] = slow;
+}
+static void pass_c(pack_ctx* c, int t) {
+    const Py_ssize_t lo = c->n * t / c->nt, hi = c->n * (t + 1) / c->nt;
+    int64_t at = c->base[t];
+    for (Py_ssize_t i = lo; i < hi; ++i) {
+        if (c->dst && i + 8 < hi) __builtin_prefetch(c->sp[i + 8].p);
+        c->off[i] = at;
+        if (c->dst) span_write(&c->sp[i], c->dst + at);
+        at += SPAN_LEN(&c->sp[i]);
+    }
+}
+static void* pack_worker(void* arg) {
+    pack_ctx* c = ((pack_arg*)arg)->c;
+    const int t = ((pack_arg*)arg)->t;
+    int go;
+    while ((go = __atomic_load_n(&c->go, __ATOMIC_ACQUIRE)) == 0) sched_yield();
+    if (go < 0) return NULL;
+    pass_a(c, t);
+    pthread_barrier_wait(&c->bar);                    /* main: slow items, base offsets, destination */
+    pthread_barrier_wait(&c->bar);
+    if (c->base[0] >= 0) pass_c(c, t);                /* (base[0] < 0: an exception is pending, nothing to write) */
     return NULL;
 }
 
-#define PACK_PREFETCH 12
-#define PACK_MAX_THREADS 16
-
-/* pass 1: type checks, (pointer, length) of every item's UTF-8, CSR offsets.  Returns the total or -1 with an exception set. */
-static int64_t measure(PyObject** items, Py_ssize_t n, span_t* sp, int64_t* off) {
-    int64_t total = 0;
-    off[0] = 0;
-    for (Py_ssize_t i = 0; i < n; ++i) {
-        if (i + PACK_PREFETCH < n) __builtin_prefetch(items[i + PACK_PREFETCH]);
-        PyObject* it = items[i];
-        if (!PyUnicode_Check(it)) {
-            if (PyTuple_Check(it) || PyList_Check(it))
-                PyErr_SetString(PyExc_NotImplementedError, "pair / pre-tokenized inputs are outside the MI355X hot path");
-            else
-                PyErr_SetString(PyExc_TypeError, "TextInputSequence must be str");
-            return -1;
+/* the items the helper threads could not size: the interpreter's own conversion, in index order (the first failing item raises) */
+static int resolve_slow(pack_ctx* c) {
+    for (int t = 0; t < c->nt; ++t) {
+        if (c->first_slow[t] < 0) continue;
+        const Py_ssize_t hi = c->n * (t + 1) / c->nt;
+        for (Py_ssize_t i = c->first_slow[t]; i < hi; ++i) {
+            if (c->sp[i].len != SPAN_SLOW) continue;
+            PyObject* it = c->items[i];
+            if (!PyUnicode_Check(it)) {
+                if (PyTuple_Check(it) || PyList_Check(it))
+                    PyErr_SetString(PyExc_NotImplementedError, "pair / pre-tokenized inputs are outside the MI355X hot path");
+                else
+                    PyErr_SetString(PyExc_TypeError, "TextInputSequence must be str");
+                return -1;
+            }
+            Py_ssize_t len;
+            const char* s = PyUnicode_AsUTF8AndSize(it, &len);      /* e.g. lone surrogates: UnicodeEncodeError */
+            if (!s) return -1;
+            c->sp[i].p = s; c->sp[i].len = len;
+            c->total[t] += len;
         }
-        Py_ssize_t len;
-        const char* s = PyUnicode_AsUTF8AndSize(it, &len);      /* materialises the cached UTF-8 of a non-ASCII str */
-        if (!s) return -1;                                      /* e.g. lone surrogates */
-        sp[i].p = s;
-        sp[i].len = len;
-        total += len;
-        off[i + 1] = total;
     }
+    return 0;
+}
+
+/* list[str] -> CSR offsets in off[0..n] + (if `provide` hands out a destination for the total) the UTF-8 bytes and TEXT_PAD zero
+ * bytes.  Returns the total or -1 with an exception set. */
+typedef char* (*dst_fn)(void* user, int64_t total);
+static int64_t pack_core(PyObject** items, Py_ssize_t n, int64_t* off, dst_fn provide, void* user) {
+    pack_ctx* c = (pack_ctx*)calloc(1, sizeof(pack_ctx));
+    span_t* sp = (span_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(span_t));
+    if (!c || !sp) { free(c); free(sp); PyErr_NoMemory(); return -1; }
+    static int max_threads = 0;
+    if (!max_threads) {
+        const char* e = getenv("TKAMD_PACK_THREADS");
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        long want = e ? atol(e) : ncpu;
+        max_threads = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
+    }
+    int nt = n < 16384 ? 1 : max_threads;
+    c->items = items; c->n = n; c->sp = sp; c->off = off;
+    pthread_t th[PACK_MAX_THREADS];
+    pack_arg args[PACK_MAX_THREADS];
+    int started = 0;
+    /* the helpers wait at a gate until it is known how many of them could be created: the ranges and the barrier are sized for that */
+    for (int t = 1; t < nt; ++t) {
+        args[t].c = c; args[t].t = t;
+        if (pthread_create(&th[t], NULL, pack_worker, &args[t]) != 0) break;
+        started = t;
+    }
+    nt = started + 1;
+    c->nt = nt;
+    if (nt > 1 && pthread_barrier_init(&c->bar, NULL, (unsigned)nt) != 0) {
+        __atomic_store_n(&c->go, -1, __ATOMIC_RELEASE);                      /* helpers leave at once */
+        for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+        nt = 1; c->nt = 1; started = 0;
+    }
+    __atomic_store_n(&c->go, 1, __ATOMIC_RELEASE);
+    int64_t total = -1;
+    pass_a(c, 0);
+    if (nt > 1) pthread_barrier_wait(&c->bar);
+    int rc = resolve_slow(c);
+    if (rc == 0) {
+        int64_t acc = 0;
+        for (int t = 0; t < nt; ++t) { c->base[t] = acc; acc += c->total[t]; }
+        total = acc;
+        c->dst = provide(user, total);                /* NULL: offsets only (the caller's buffer is too small, or allocation failed) */
+        if (!c->dst && PyErr_Occurred()) { rc = -1; total = -1; }
+    }
+    if (rc != 0) c->base[0] = -1;
+    if (nt > 1) pthread_barrier_wait(&c->bar);
+    if (rc == 0) pass_c(c, 0);
+    for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+    if (nt > 1) pthread_barrier_destroy(&c->bar);
+    if (rc == 0) {
+        off[n] = total;
+        if (c->dst) memset(c->dst + total, 0, TEXT_PAD);
+    }
+    free(sp);
+    free(c);
     return total;
 }
 
-/* pass 2: copy, on several threads for big batches; zero the TEXT_PAD bytes after the text */
-static void copy_all(const span_t* sp, const int64_t* off, Py_ssize_t n, int64_t total, char* dst) {
-    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-    int nt = (int)(ncpu < 1 ? 1 : (ncpu > PACK_MAX_THREADS ? PACK_MAX_THREADS : ncpu));
-    if (n < 65536 || total < (4 << 20)) nt = 1;
-    copy_job_t jobs[PACK_MAX_THREADS];
-    pthread_t th[PACK_MAX_THREADS];
-    int started = 0;
-    for (int t = 0; t < nt; ++t) {
-        jobs[t].sp = sp; jobs[t].off = off; jobs[t].dst = dst;
-        jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt;
-    }
-    for (int t = 1; t < nt; ++t) {
-        if (pthread_create(&th[t], NULL, copy_worker, &jobs[t]) != 0) break;
-        started = t;
-    }
-    copy_worker(&jobs[0]);
-    for (int t = started + 1; t < nt; ++t) copy_worker(&jobs[t]);          /* threads that could not be created: do their share here */
-    for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
-    memset(dst + total, 0, TEXT_PAD);
+static char* provide_bytearray(void* user, int64_t total) {
+    PyObject* buf = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)total + TEXT_PAD);
+    *(PyObject**)user = buf;
+    return buf ? PyByteArray_AS_STRING(buf) : NULL;
 }
-
 static PyObject* pack(PyObject* self, PyObject* arg) {
     PyObject* seq = PySequence_Fast(arg, "encode_batch expects a sequence of str");
     if (!seq) return NULL;
     Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
     PyObject* offs = PyByteArray_FromStringAndSize(NULL, (n + 1) * (Py_ssize_t)sizeof(int64_t));
-    span_t* sp = (span_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(span_t));
-    if (!offs || !sp) { Py_XDECREF(offs); free(sp); Py_DECREF(seq); return sp ? NULL : PyErr_NoMemory(); }
-    int64_t* off = (int64_t*)PyByteArray_AS_STRING(offs);
-    int64_t total = measure(PySequence_Fast_ITEMS(seq), n, sp, off);
-    PyObject* buf = total < 0 ? NULL : PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)total + TEXT_PAD);
-    if (!buf) { Py_DECREF(offs); free(sp); Py_DECREF(seq); return NULL; }
-    copy_all(sp, off, n, total, PyByteArray_AS_STRING(buf));
-    free(sp);
+    if (!offs) { Py_DECREF(seq); return NULL; }
+    PyObject* buf = NULL;
+    int64_t total = pack_core(PySequence_Fast_ITEMS(seq), n, (int64_t*)PyByteArray_AS_STRING(offs), provide_bytearray, &buf);
     Py_DECREF(seq);
+    if (total < 0 || !buf) { Py_XDECREF(buf); Py_DECREF(offs); return NULL; }
     PyObject* r = PyTuple_Pack(2, buf, offs);
     Py_DECREF(buf);
     Py_DECREF(offs);
@@ -111,19 +238,19 @@ static PyObject* pack(PyObject* self, PyObject* arg) {
  * off_addr and, if total + 64 <= text_capacity, the UTF-8 bytes + 64 zero bytes to text_addr; otherwise nothing is
  * copied and the caller retries with a buffer of at least the returned size + 64.  The destination is the tokenizer
  * handle's reusable host staging (tkamd_host_staging): no allocation and no first-touch page faults per batch. */
+typedef struct { char* addr; unsigned long long cap; } fixed_dst;
+static char* provide_fixed(void* user, int64_t total) {
+    fixed_dst* f = (fixed_dst*)user;
+    return ((unsigned long long)total + TEXT_PAD <= f->cap) ? f->addr : NULL;
+}
 static PyObject* pack_into(PyObject* self, PyObject* args) {
     PyObject* arg;
     unsigned long long text_addr, text_cap, off_addr;
     if (!PyArg_ParseTuple(args, "OKKK", &arg, &text_addr, &text_cap, &off_addr)) return NULL;
     PyObject* seq = PySequence_Fast(arg, "encode_batch expects a sequence of str");
     if (!seq) return NULL;
-    Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
-    span_t* sp = (span_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(span_t));
-    if (!sp) { Py_DECREF(seq); return PyErr_NoMemory(); }
-    int64_t* off = (int64_t*)(uintptr_t)off_addr;
-    int64_t total = measure(PySequence_Fast_ITEMS(seq), n, sp, off);
-    if (total >= 0 && (unsigned long long)total + TEXT_PAD <= text_cap) copy_all(sp, off, n, total, (char*)(uintptr_t)text_addr);
-    free(sp);
+    fixed_dst f = {(char*)(uintptr_t)text_addr, text_cap};
+    int64_t total = pack_core(PySequence_Fast_ITEMS(seq), PySequence_Fast_GET_SIZE(seq), (int64_t*)(uintptr_t)off_addr, provide_fixed, &f);
     Py_DECREF(seq);
     return total < 0 ? NULL : PyLong_FromLongLong(total);
 }
