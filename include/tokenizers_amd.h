@@ -218,9 +218,16 @@ int tkamd_probe_trie(const tkamd_tokenizer* tok, uint32_t node, uint32_t byte, u
  * truncated encoding, 1.. = Encoding.overflowing in order). */
 int tkamd_probe_truncation(uint64_t n_tokens, uint32_t max_len, uint32_t stride, int left, uint32_t part, uint64_t* start, uint64_t* count);
 /* BertNormalizer::normalize (normalizers/bert.rs:92-138) of ONE code point from the host copy of the generated tables:
- * out[0..*n) (at most 12 code points; 0 = the char is removed), *refused = 1 where strip_accents would need a
- * context-dependent NFD reordering (the device path refuses such text). */
+ * out[0..*n) (at most 12 code points; 0 = the char is removed), *refused = 1 for the characters NFD's canonical ordering could
+ * move (they survive the Mn filter with a non-zero combining class): whether it does depends on their neighbours, see
+ * tkamd_probe_bert_alone. */
 int tkamd_probe_bert_norm(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* out, int32_t* n, int32_t* refused);
+/* BertNormalizer strip_accents on the character whose lead byte is text[pos] (text[0 .. n) = one piece handed to the normalizer: a
+ * document, or what lies between two added-token matches): *reorder = 1 if it survives the Mn filter with a non-zero combining
+ * class (NFD's canonical ordering could move it), *alone = 1 if it is alone in its run of non-starters -- nothing moves, the device
+ * encodes it; 0: the device refuses the document.  The very function the kernels call (csrc/bert_norm_core.hpp), on the host copy
+ * of the tables. */
+int tkamd_probe_bert_alone(const tkamd_tokenizer* tok, const uint8_t* text, int64_t n, int64_t pos, int32_t* reorder, int32_t* alone);
 /* Class flags of one code point from the host copy of the generated Unicode table: bit 0 \p{L}, 1 \p{N}, 2 \s (as
  * Oniguruma sees them, byte_level.rs:43-46), 3 \w, 4 \s (regex crate, whitespace.rs:22), 5 char::is_whitespace, 6 is_bert_punc. */
 int tkamd_probe_unicode_flags(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* flags);

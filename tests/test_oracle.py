@@ -324,3 +324,76 @@ def test_ref_added_token_lstrip_rstrip_unicode_space():
     text = "Hi <mask> there\t<mask>\t<mask> "
     pieces = [("Hi", 0), (" <mask> ", 1), ("there", 0), ("\t<mask>\t", 1), ("<mask> ", 1)]
     assert _added_token_spans(text, "<mask>", single_word=True, lstrip=True, rstrip=True) == _piece_spans(pieces)
+
+
+# ---- BertNormalizer: NFD's canonical ordering around the characters that survive the Mn filter as non-starters ------------------
+
+def _reorder_tokenizer_json(ref_tokenizers, pool):
+    """BertNormalizer + BertPreTokenizer + a WordPiece vocabulary in which every (normalised) pool character is a token of its own,
+    word-initial and ##-continued: the ids then show the ORDER of the characters and the offsets their alignments."""
+    bn = ref_tokenizers.normalizers.BertNormalizer()
+    vocab = {"[UNK]": 0}
+    for c in pool:
+        for y in bn.normalize_str(c):
+            if not y.isspace():
+                vocab.setdefault(y, len(vocab))
+                vocab.setdefault("##" + y, len(vocab))
+    return json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [],
+                       "normalizer": {"type": "BertNormalizer", "clean_text": True, "handle_chinese_chars": True, "strip_accents": None, "lowercase": True},
+                       "pre_tokenizer": {"type": "BertPreTokenizer"}, "post_processor": None, "decoder": None,
+                       "model": {"type": "WordPiece", "unk_token": "[UNK]", "continuing_subword_prefix": "##", "max_input_chars_per_word": 100, "vocab": vocab}},
+                      ensure_ascii=False)
+
+
+REORDER_SURVIVORS = [0x1B44, 0x302E, 0x302F, 0x8D4, 0x1E944, 0x1E94A, 0x11446, 0x1D165, 0x1D16D, 0x1D15E, 0x1D160, 0xA9C0, 0x1DFB]
+REORDER_MARKS = [0x301, 0x323, 0x334, 0x5B0, 0x941, 0xFE0F, 0x344, 0x1B34]          # dropped by the filter: classes 230 220 1 10 0 0 (230 230) 7
+REORDER_OTHERS = [0x61, 0x65, 0xE9, 0x1B13, 0xD55C, 0x4E2D, 0x20, 0x1, 0x200D, 0x41, 0x1D157]
+
+
+def reorder_docs(n, seed):
+    import random
+    rnd = random.Random(seed)
+    docs = []
+    for _ in range(n):
+        k = rnd.randint(1, 8)
+        docs.append("".join(chr(rnd.choice(REORDER_SURVIVORS if rnd.random() < 0.35 else REORDER_MARKS if rnd.random() < 0.4 else REORDER_OTHERS)) for _ in range(k)))
+    return docs
+
+
+def test_bert_normalizer_survivors_alone_in_their_run_match_the_wheel(ref_tokenizers):
+    """NFD's canonical ordering (normalizer.rs:449-470) can only move -- or re-align -- a character that survives the Mn filter with a
+    non-zero combining class, and only if it shares its run of non-starters with another one.  The oracle encodes the documents in
+    which every such character is alone in its run and refuses the others; on the former it must equal the wheel in ids, offsets and
+    word ids (a vocabulary with one token per character makes order and alignment visible), and the product's own decision function
+    (tkamd_probe_bert_alone, what the kernels call) must draw the same line."""
+    import ctypes as C
+    import tokenizers_amd as ta
+    js = _reorder_tokenizer_json(ref_tokenizers, [chr(c) for c in REORDER_SURVIVORS + REORDER_MARKS + REORDER_OTHERS])
+    o = orc.Oracle(js)
+    ref = ref_tokenizers.Tokenizer.from_str(js)
+    host = ta.Tokenizer.from_str(js, device=-1)
+    docs = reorder_docs(6000, 11) + ["ᬓ᭄", "ᬓ᭄ᬓ", "a〮", "〮", "᭄〮", "é᭄", "é᭄", "᭄́",
+                                      "᭄\x01́", "᭄\x01a", "\U0001d15é", "\U0001d15e", "a\U0001d165\U0001d16d", "᭄ु〮", "ु᭄"]
+    exp = ref.encode_batch(docs, add_special_tokens=False)
+    accepted_with_survivor = refused = 0
+    for doc, e in zip(docs, exp):
+        raw = doc.encode("utf-8")
+        pos, all_alone, any_reorder = 0, True, False
+        for ch in doc:
+            r, a = C.c_int32(0), C.c_int32(0)
+            assert host._lib.tkamd_probe_bert_alone(host._h, raw, len(raw), pos, C.byref(r), C.byref(a)) == 0
+            any_reorder |= bool(r.value)
+            all_alone &= bool(a.value)
+            pos += len(ch.encode("utf-8"))
+        try:
+            got = o.encode_batch([doc], char_offsets=True)
+        except orc.OracleError:
+            assert not all_alone, ascii(doc)                   # the product refuses the same documents
+            refused += 1
+            continue
+        assert all_alone, ascii(doc)
+        assert got.doc_ids(0) == e.ids, ascii(doc)
+        assert got.doc_offsets(0) == [tuple(x) for x in e.offsets], ascii(doc)
+        assert got.doc_words(0) == e.word_ids, ascii(doc)
+        accepted_with_survivor += any_reorder
+    assert accepted_with_survivor > 800 and refused > 300, (accepted_with_survivor, refused)

@@ -20,6 +20,7 @@
 #include "host_model.hpp"
 #include "kernels.hpp"
 #include "overflow_core.hpp"
+#include "bert_norm_core.hpp"
 
 using namespace tkamd;
 static_assert(TEXT_PAD == TKAMD_TEXT_PAD, "the kernels rely on the slack the ABI promises");
@@ -1242,8 +1243,9 @@ int error_from_bits(int bits) {
     if (bits & ERR_PRETOKEN_TOO_LONG)
         return set_error(TKAMD_ERR_UNSUPPORTED, "pre-tokens longer than 8192 bytes exceed the 1 GiB scratch slab of the global-memory merge path");
     if (bits & ERR_NON_ASCII_NORM)
-        return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: the text contains a character with a non-zero combining class that "
-                                                "survives the Mn filter; NFD may reorder it across characters (not built on the device)");
+        return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: a character with a non-zero combining class that survives the Mn filter "
+                                                "stands next to another combining character; NFD's canonical ordering would move it (or its offsets) "
+                                                "across characters (not built on the device)");
     if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal invariant violated");
     if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
     if (bits & ERR_TRUNC_SECOND) return set_error(TKAMD_ERR_INVALID, "Truncation error: Second sequence not provided");
@@ -1788,6 +1790,18 @@ int tkamd_probe_bert_norm(const tkamd_tokenizer* t, uint32_t cp, uint32_t* out, 
     int r = 0;
     *n = hm.bn_expand_cp(cp, out, &r);
     *refused = r;
+    return TKAMD_OK;
+}
+
+int tkamd_probe_bert_alone(const tkamd_tokenizer* t, const uint8_t* text, int64_t n, int64_t pos, int32_t* reorder, int32_t* alone) {
+    if (!t || !text || !reorder || !alone || n < 0 || pos < 0 || pos >= n) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    const HostModel& hm = t->hm;
+    if (hm.norm != NORM_BERT) return set_error(TKAMD_ERR_UNSUPPORTED, "the tokenizer has no BertNormalizer");
+    uint32_t len;
+    const uint32_t cp = bn_core_decode(text, pos, n, &len);
+    const uint32_t f = bn_core_flags(hm.bn_stage1.data(), hm.bn_stage2.data(), cp);
+    *reorder = (hm.bn_strip_accents && (f & BN_F_REORDER)) ? 1 : 0;
+    *alone = (!*reorder || bn_alone_in_run(hm.bn_stage1.data(), hm.bn_stage2.data(), hm.bn_clean_text, text, 0, n, pos, len, f, nullptr)) ? 1 : 0;
     return TKAMD_OK;
 }
 

@@ -26,6 +26,7 @@
 #include "device_utils.hpp"
 #include "kernels.hpp"
 #include "overflow_core.hpp"
+#include "bert_norm_core.hpp"
 #include "pretok_gpt2_core.hpp"
 #include "pretok_l3_core.hpp"
 #include "pretok_local_core.hpp"

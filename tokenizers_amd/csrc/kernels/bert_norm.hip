@@ -10,8 +10,10 @@
 // 0..11 code points.  k_bn_count sizes the output (one byte count per source byte + one sum per 64-byte word),
 // a scan places the words, k_bn_write emits the UTF-8 together with the original byte range [os, oe) of the
 // source character of every normalised byte (an inserted char keeps its source char's alignment,
-// tokenizer/normalizer.rs:317-428).  The one context-dependent case -- NFD reordering a surviving character
-// with a non-zero combining class -- raises ERR_NON_ASCII_NORM (document refused) instead of guessing.
+// tokenizer/normalizer.rs:317-428).  The one context-dependent step -- NFD's canonical ordering -- shows only on a character
+// that survives the Mn filter with a non-zero combining class, and only if it shares its run of non-starters with another one
+// (bert_norm_core.hpp): alone in its run it stays where the per-character expansion puts it; otherwise ERR_NON_ASCII_NORM
+// (document refused) instead of guessing.
 // =================================================================================================
 constexpr uint32_t BN_DROP = 1, BN_WS = 2, BN_CJK = 4, BN_REORDER = 8, BN_D = 16, BN_LC = 32;
 constexpr int BN_MAX_OUT = 12;
@@ -76,8 +78,22 @@ __device__ __forceinline__ uint32_t sw_ascii_dropped(uint32_t x) { return (sw_lt
 // bits [i0, i0 + 16) of a bit mask (i0 a multiple of 16)
 __device__ __forceinline__ uint32_t mask16(const unsigned long long* __restrict__ m, int64_t i0) { return (uint32_t)(m[i0 >> 6] >> (i0 & 63)) & 0xFFFFu; }
 
+// a REORDER character at byte i: refuse the batch unless it is alone in its run of non-starters (rare: off the fast paths)
+__device__ __noinline__ void bn_check_reorder(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t cp, uint32_t len,
+                                              const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
+    // the document holding byte i: the last d with doc_off[d] <= i
+    int64_t lo = 0, hi = n_docs;
+    while (lo < hi) {
+        const int64_t m = (lo + hi + 1) >> 1;
+        if (doc_off[m] <= i) lo = m; else hi = m - 1;
+    }
+    const int64_t da = max(doc_off[lo], (int64_t)0), db = min(lo < n_docs ? doc_off[lo + 1] : n_bytes, n_bytes);
+    if (!bn_alone_in_run(bt.bn1, bt.bn2, bt.clean != 0u, text, da, db, i, len, bn_flags(bt, cp), vmask)) atomicOr(err, ERR_NON_ASCII_NORM);
+}
+
 // output bytes of source byte i, the table-driven way (any byte)
-__device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint8_t* __restrict__ text, int64_t i, uint32_t b, bool verbatim, int* __restrict__ err) {
+__device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t b, bool verbatim,
+                                                  const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
     if (verbatim) return 1u;
     if (b < 0x80u)      // ASCII: control characters except \t \n \r are dropped, everything else is one byte
         return (bt.clean && ((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu)) ? 0u : 1u;
@@ -86,13 +102,14 @@ __device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint
     bool reorder = false;
     const uint32_t cp = utf8_global(text, i, &len);
     const int n = bn_expand(bt, cp, out, &reorder);
-    if (reorder) atomicOr(err, ERR_NON_ASCII_NORM);
+    if (reorder) bn_check_reorder(bt, text, n_bytes, i, cp, len, vmask, doc_off, n_docs, err);
     for (int q = 0; q < n; ++q) ob += utf8_len_cp(out[q]);
     return ob;
 }
 
 // `verbatim`: bytes of added-token matches of the raw pass (null: none) -- not text for the normalizer: copied as they are
 __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
+                                                  const int64_t* __restrict__ doc_off, int64_t n_docs,
                                                   uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BN_LANE;
     uint32_t o[4] = {0u, 0u, 0u, 0u};                               // output bytes of my 16 source bytes, one per byte
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __
             for (int k = 0; k < 4; ++k) o[k] = SW_1 - (bt.clean ? (sw_ascii_dropped(x[k]) >> 7) : 0u);
         } else {
             const int nv = (int)min((int64_t)BN_LANE, n_bytes - i0);
-            for (int j = 0; j < nv; ++j) o[j >> 2] |= bn_count_byte(bt, text, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, err) << (8 * (j & 3));
+            for (int j = 0; j < nv; ++j) o[j >> 2] |= bn_count_byte(bt, text, n_bytes, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, verbatim, doc_off, n_docs, err) << (8 * (j & 3));
         }
         *(uint4*)(olen + i0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
