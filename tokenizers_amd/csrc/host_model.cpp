@@ -1,5 +1,6 @@
 // tokenizer.json -> flat tables.  See host_model.hpp.
 #include "host_model.hpp"
+#include "bert_norm_core.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -879,11 +880,16 @@ std::string HostModel::bert_normalize(const std::string& s, bool* refused) const
         else if (b0 < 0xE0u) { cp = ((b0 & 0x1Fu) << 6) | cb(1); len = 2; }
         else if (b0 < 0xF0u) { cp = ((b0 & 0x0Fu) << 12) | (cb(1) << 6) | cb(2); len = 3; }
         else { cp = ((b0 & 0x07u) << 18) | (cb(1) << 12) | (cb(2) << 6) | cb(3); len = 4; }
+        const size_t at = i;
         i += len;
         uint32_t o[12];
         int r = 0;
         const int n = bn_expand_cp(cp, o, &r);
-        if (r && refused) *refused = true;
+        // (a character NFD's canonical ordering could move: fine as long as it is alone in its run, bert_norm_core.hpp)
+        if (r && refused &&
+            !bn_alone_in_run(bn_stage1.data(), bn_stage2.data(), bn_clean_text, (const uint8_t*)s.data(), 0, (int64_t)s.size(), (int64_t)at, len,
+                             bn_core_flags(bn_stage1.data(), bn_stage2.data(), cp), nullptr))
+            *refused = true;
         for (int q = 0; q < n; ++q) {
             const uint32_t c = o[q];
             if (c < 0x80u) out.push_back((char)c);
