@@ -594,3 +594,69 @@ def test_threaded_marshalling_of_every_str_kind_and_the_first_bad_item():
         ta.pack_documents(docs[:40000] + ["a\ud800"] + docs[:20000] + [5] + docs[:30000])
     with pytest.raises(TypeError):                                # the non-str comes first
         ta.pack_documents(docs[:40000] + [5] + docs[:20000] + ["a\ud800"] + docs[:30000])
+
+
+def _view_of(e, specials, pad_left, pair, no_pp):
+    """A tokenizers_amd Encoding view over the arrays the device would have written for the wheel's encoding `e`."""
+    import numpy as np
+    from tokenizers_amd.tokenizer import BatchEncoding
+    n = len(e.ids)
+    words = np.array([0xFFFFFFFF if w is None else w for w in e.word_ids], dtype=np.uint32)
+    pads = sum(1 for a in e.attention_mask if a == 0)
+    be = BatchEncoding(np.array(e.ids, dtype=np.uint32), np.array([0, n], dtype=np.int64), np.array(e.offsets, dtype=np.uint32).reshape(n, 2), words,
+                       {}, specials, np.array([pads], dtype=np.uint32), pad_left, 0, "[PAD]")
+    be._no_seq_ranges = no_pp
+    if pair:
+        be.type_ids = np.array(e.type_ids, dtype=np.uint8)
+        be.seq_ids = np.array([3 if a == 0 else (2 if q is None else q) for q, a in zip(e.sequence_ids, e.attention_mask)], dtype=np.uint8)
+    return be[0]
+
+
+def test_encoding_mapping_helpers_match_the_wheel(ref_tokenizers):
+    """Encoding.token_to_sequence / word_to_tokens / word_to_chars / token_to_chars / token_to_word / char_to_token / char_to_word
+    (tokenizer/encoding.rs:204-300) of the host mirror, over arrays shaped like the device's result, against the wheel's own
+    methods: single sequences and pairs, with and without a post-processor, truncated, padded left and right."""
+    import json
+    base = json.loads(load_tokenizer_json("bert_wordpiece_4000_specials"))
+    pad = lambda side: {"strategy": {"Fixed": 14}, "direction": side, "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}
+    trunc = {"direction": "Right", "max_length": 12, "strategy": "LongestFirst", "stride": 0}
+    singles = ["hello world again", "", "one two three four five six seven eight nine ten eleven twelve", "a"]
+    pairs = [("hello world", "second one here"), ("", "x"), ("one two three four five six seven", "eight nine ten eleven twelve thirteen")]
+    for pp in (True, False):
+        for padding, truncation in ((None, None), (pad("Right"), None), (pad("Left"), trunc)):
+            d = dict(base)
+            d["padding"], d["truncation"] = padding, truncation
+            if not pp:
+                d["post_processor"] = None
+            ref = ref_tokenizers.Tokenizer.from_str(json.dumps(d))
+            for items, pair in ((singles, False), (pairs, True)):
+                for e in ref.encode_batch(items, add_special_tokens=True):
+                    v = _view_of(e, (1, 1) if pp else (0, 0), padding is not None and padding["direction"] == "Left", pair, not pp)
+                    ctx = (pp, padding and padding["direction"], truncation is not None, pair, e.tokens)
+                    assert v.sequence_ids == e.sequence_ids, ctx
+                    for t in range(len(e.ids) + 3):
+                        assert v.token_to_sequence(t) == e.token_to_sequence(t), (t,) + ctx
+                        assert v.token_to_chars(t) == e.token_to_chars(t), (t,) + ctx
+                        assert v.token_to_word(t) == e.token_to_word(t), (t,) + ctx
+                    for sq in (0, 1):
+                        for w in range(9):
+                            assert v.word_to_tokens(w, sq) == e.word_to_tokens(w, sq), (w, sq) + ctx
+                            assert v.word_to_chars(w, sq) == e.word_to_chars(w, sq), (w, sq) + ctx
+                        for c in range(70):
+                            assert v.char_to_token(c, sq) == e.char_to_token(c, sq), (c, sq) + ctx
+                            assert v.char_to_word(c, sq) == e.char_to_word(c, sq), (c, sq) + ctx
+
+
+def test_vocabulary_lookups_match_the_wheel(ref_tokenizers):
+    """get_vocab / token_to_id / id_to_token / num_special_tokens_to_add of the host mirror (TokenizerImpl, tokenizer/mod.rs:683-735)."""
+    for name in ("bert_wordpiece_4000_specials", "llama3_small_6000_specials", "gpt2_synth_50257", "gpt2_bench_added"):
+        js = load_tokenizer_json(name)
+        t, r = ta.Tokenizer.from_str(js, device=-1), ref_tokenizers.Tokenizer.from_str(js)
+        assert t.get_vocab() == r.get_vocab() and t.get_vocab(False) == r.get_vocab(False)
+        assert t.get_vocab_size() == r.get_vocab_size() and t.get_vocab_size(False) == r.get_vocab_size(False)
+        for tok in ("hello", "[SEP]", "<|begin_of_text|>", "zzzzqq", "the", "ing", "[ENT]"):
+            assert t.token_to_id(tok) == r.token_to_id(tok), (name, tok)
+        for i in (0, 5, 3999, 50256, 50257, 10 ** 6):
+            assert t.id_to_token(i) == r.id_to_token(i), (name, i)
+        for is_pair in (False, True):
+            assert t.num_special_tokens_to_add(is_pair) == r.num_special_tokens_to_add(is_pair), (name, is_pair)

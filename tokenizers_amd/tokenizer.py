@@ -181,6 +181,78 @@ class Encoding:
     def n_sequences(self) -> int:
         return 2 if self._b.seq_ids is not None else 1
 
+    # ---- token / word / char mappings (tokenizer/encoding.rs:204-300; Python signatures of bindings/python/src/encoding.rs:283-390).
+    # Host-side views over the arrays the device wrote; `sequence_ranges` of the reference = the spans of sequence_ids 0 / 1.
+    def _ranges(self) -> dict:
+        r: dict = {}
+        if self._b.seq_ids is None and getattr(self._b, "_no_seq_ranges", False):
+            return r                            # no post-processor, single sequence: the reference never sets sequence_ranges
+        for i, q in enumerate(self.sequence_ids):
+            if q is not None:
+                lo, _ = r.get(q, (i, i))
+                r[q] = (lo, i + 1)
+        return r
+
+    def _sequence_range(self, sequence_index: int) -> tuple[int, int]:
+        r = self._ranges()
+        if sequence_index in r:
+            return r[sequence_index]
+        has_ranges = not (self._b.seq_ids is None and getattr(self._b, "_no_seq_ranges", False))
+        if has_ranges and sequence_index < self.n_sequences:
+            return (0, 0)                       # a sequence without tokens: its range exists and is empty (where it sits changes no answer)
+        return (0, len(self))                   # encoding.rs:204-209: no such range -> the whole encoding
+
+    def token_to_sequence(self, token_index: int) -> int | None:
+        if token_index > len(self):             # (`>`: encoding.rs:213)
+            return None
+        if self._b.seq_ids is None and getattr(self._b, "_no_seq_ranges", False):
+            return 0                            # sequence_ranges is empty (an empty RANGE, e.g. of an empty document, is not)
+        for q, (lo, hi) in self._ranges().items():
+            if lo <= token_index < hi:
+                return q
+        return None
+
+    def word_to_tokens(self, word_index: int, sequence_index: int = 0) -> tuple[int, int] | None:
+        lo, hi = self._sequence_range(sequence_index)
+        words = self.word_ids[lo:hi]
+        start = end = None
+        for i, w in enumerate(words):
+            if w is not None and w > word_index:                       # take_while(w <= Some(word)); None sorts first
+                break
+            if w == word_index:
+                if start is None:
+                    start = i
+                end = i + 1
+        return None if start is None else (lo + start, lo + end)
+
+    def word_to_chars(self, word_index: int, sequence_index: int = 0) -> tuple[int, int] | None:
+        t = self.word_to_tokens(word_index, sequence_index)
+        if t is None or t[1] == 0:
+            return None
+        offs = self.offsets
+        return (offs[t[0]][0], offs[t[1] - 1][1])
+
+    def token_to_chars(self, token_index: int) -> tuple[int, int] | None:
+        if self.token_to_sequence(token_index) is None or not 0 <= token_index < len(self):
+            return None
+        return self.offsets[token_index]
+
+    def token_to_word(self, token_index: int) -> int | None:
+        if self.token_to_sequence(token_index) is None or not 0 <= token_index < len(self):
+            return None
+        return self.word_ids[token_index]
+
+    def char_to_token(self, char_pos: int, sequence_index: int = 0) -> int | None:
+        lo, hi = self._sequence_range(sequence_index)
+        for i, (a, b) in enumerate(self.offsets[lo:hi]):
+            if a <= char_pos < b:
+                return lo + i
+        return None
+
+    def char_to_word(self, char_pos: int, sequence_index: int = 0) -> int | None:
+        t = self.char_to_token(char_pos, sequence_index)
+        return None if t is None else self.token_to_word(t)
+
     @property
     def overflowing(self) -> list:
         b = self._b
@@ -398,6 +470,46 @@ class Tokenizer:
     def get_vocab_size(self, with_added_tokens: bool = True) -> int:
         return len(self._id_to_token()) if with_added_tokens else self.info["vocab_size"]
 
+    # ---- vocabulary lookups (TokenizerImpl::get_vocab / token_to_id / id_to_token, tokenizer/mod.rs:683-735: the added vocabulary
+    # answers first); host-side, from the tokenizer.json the handle was built from ----
+    def get_vocab(self, with_added_tokens: bool = True) -> dict[str, int]:
+        d = json.loads(self._json)
+        v = dict(d["model"]["vocab"])
+        if with_added_tokens:
+            for a in d.get("added_tokens") or []:
+                v[a["content"]] = int(a["id"])
+        return v
+
+    def token_to_id(self, token: str) -> int | None:
+        if getattr(self, "_vocab_f", None) is None:
+            self._vocab_f = self.get_vocab(True)
+        return self._vocab_f.get(token)
+
+    def id_to_token(self, id: int) -> str | None:
+        return self._id_to_token().get(int(id))
+
+    def num_special_tokens_to_add(self, is_pair: bool) -> int:
+        """PostProcessor::added_tokens (processors/bert.rs:43-49, template.rs:520-530): special tokens a single sequence / a pair gets."""
+        if not is_pair:
+            self._check_special(True)
+            return sum(self._specials)
+        pp = json.loads(self._json).get("post_processor")
+        if not pp:
+            return 0
+
+        def count(p):
+            t = p.get("type")
+            if t == "BertProcessing":
+                return 3
+            if t == "RobertaProcessing":
+                return 4
+            if t == "TemplateProcessing":
+                return sum(len(p["special_tokens"][x["SpecialToken"]["id"]]["ids"]) for x in p.get("pair", []) if "SpecialToken" in x)
+            if t == "Sequence":
+                return sum(count(q) for q in p.get("processors", []))
+            return 0
+        return count(pp)
+
     # ---- the hot path ----
     def _check_special(self, add_special_tokens: bool) -> None:
         if add_special_tokens and self._specials_error:
@@ -536,6 +648,12 @@ class Tokenizer:
         """Encode a newline-delimited UTF-8 file, one document per line *including its terminator* (:func:`read_lines`)."""
         buf, off = read_lines(path)
         return self.encode_packed(buf, off, offsets, word_ids, add_special_tokens)
+
+    def encode(self, sequence, pair=None, is_pretokenized: bool = False, add_special_tokens: bool = True) -> Encoding:
+        """``Tokenizer.encode`` (TokenizerImpl::encode_char_offsets, tokenizer/mod.rs:871-930; Python tokenizer.rs:1178-1230): a batch
+        of one through the same kernels."""
+        item = sequence if pair is None else (sequence, pair)
+        return self.encode_batch([item], is_pretokenized=is_pretokenized, add_special_tokens=add_special_tokens)[0]
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
