@@ -110,6 +110,11 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* tok, tkamd_info* info);
 int tkamd_tokenizer_specials(const tkamd_tokenizer* tok, uint32_t* prefix_ids, int32_t* n_prefix, uint32_t* suffix_ids,
                              int32_t* n_suffix, int32_t cap);
 
+/* The same for a pair (TKAMD_PAIRS): the post-processor's pair template as pieces of three values each -- kind (0 sequence A,
+ * 1 sequence B, 2 special token), token id (kind 2), type id -- in output order; with_specials = 0: the layout without
+ * add_special_tokens (A then B, PostProcessor::default_process).  *n_pieces = number of pieces (written even beyond cap). */
+int tkamd_tokenizer_pair_template(const tkamd_tokenizer* tok, int with_specials, uint32_t* pieces, int32_t cap, int32_t* n_pieces);
+
 /* Thread-local message of the last failing call on this thread (error.rs:26-31 maps
  * the reference's error to `Exception(str(e))`; the shim does the same with this). */
 const char* tkamd_last_error(void);

@@ -1404,6 +1404,15 @@ int tkamd_tokenizer_specials(const tkamd_tokenizer* t, uint32_t* prefix_ids, int
     return TKAMD_OK;
 }
 
+int tkamd_tokenizer_pair_template(const tkamd_tokenizer* t, int with_specials, uint32_t* pieces, int32_t cap, int32_t* n_pieces) {
+    if (!t || !n_pieces) return set_error(TKAMD_ERR_INVALID, "null argument");
+    if (with_specials && !t->hm.pp_pair_unsupported.empty()) return set_error(TKAMD_ERR_UNSUPPORTED, "add_special_tokens on a pair: " + t->hm.pp_pair_unsupported);
+    const std::vector<HostModel::TplPiece>& tpl = (with_specials && !t->hm.pp_pair.empty()) ? t->hm.pp_pair : t->hm.pp_pair_plain;
+    *n_pieces = (int32_t)tpl.size();
+    for (int32_t i = 0; i < *n_pieces && i < cap && pieces; ++i) { pieces[3 * i] = tpl[i].kind; pieces[3 * i + 1] = tpl[i].id; pieces[3 * i + 2] = tpl[i].type_id; }
+    return TKAMD_OK;
+}
+
 static int encode_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_t* d_doc_offsets, int64_t n_docs, int64_t n_bytes,
                          const int64_t* d_seq_offsets, int64_t n_seqs, uint32_t flags, void* hip_stream, tkamd_device_result* out) {
     if (!t || !out || !d_doc_offsets || n_docs < 0 || n_bytes < 0 || (n_bytes > 0 && !d_text))

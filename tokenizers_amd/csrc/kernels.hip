@@ -56,6 +56,7 @@ static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)(
 
 // ---- the kernels, by pipeline stage (one translation unit; every file below is a plain slice of it) ----
 #include "kernels/results.hip"
+#include "kernels/scan_util.hip"
 #include "kernels/documents.hip"
 #include "kernels/pretok_gpt2.hip"
 #include "kernels/pretok_llama3.hip"
@@ -67,6 +68,7 @@ static inline unsigned blocks_for(int64_t n, int per_block) { return (unsigned)(
 #include "kernels/word_models.hip"
 #include "kernels/bpe_huge.hip"
 #include "kernels/output.hip"
+#include "kernels/epilogue.hip"
 #include "kernels/decode.hip"
 #include "kernels/launch.hip"
 

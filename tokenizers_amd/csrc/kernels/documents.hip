@@ -319,13 +319,6 @@ __global__ void k_prefix_need(const uint8_t* __restrict__ text, const int64_t* _
     }
     need[d] = v;
 }
-__global__ __launch_bounds__(256) void k_u32_reduce(const uint32_t* __restrict__ v, int64_t n, uint32_t* __restrict__ bsum) {
-    __shared__ uint32_t sm[4];
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t x = (i < n) ? v[i] : 0u, tot;
-    block256_excl_scan(x, sm, &tot);
-    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
 // exclusive prefix of need[] added to the piece CSR: xseg_off[d] = seg_off[d] + #spaces inserted before piece d
 __global__ __launch_bounds__(256) void k_prefix_doc_offsets(const uint32_t* __restrict__ need, int64_t n_bound, const int64_t* __restrict__ n_dev, const uint32_t* __restrict__ bsum,
                                                             const int64_t* __restrict__ doc_off, int64_t* __restrict__ xdoc_off,

@@ -161,45 +161,10 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg
     hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_bound, n_dev, (const uint32_t*)bsum, seg_off, xseg_off, x_len);
     hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, seg_off, (const int64_t*)xseg_off, n_bound, n_dev, xtext, nos, noe);
 }
-void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a) {
-    hipLaunchKernelGGL(k_add_specials, dim3(grid), dim3(256), 0, st, a);
-}
 void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta) {
     hipLaunchKernelGGL(k_add_i64, dim3(blocks_for(n, 256)), dim3(256), 0, st, data, n, delta);
 }
-void launch_final_lens(hipStream_t st, const FinalArgs& a) {
-    hipLaunchKernelGGL(k_final_lens, dim3(blocks_for(a.n_docs + 1, 256)), dim3(256), 0, st, a);
-}
-void launch_overflow_count(hipStream_t st, const FinalArgs& a, int64_t* n_enc) {
-    const unsigned nb = blocks_for(a.n_docs + 1, 256);
-    hipLaunchKernelGGL(k_ovf_parts, dim3(nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)a.ovf_parts, a.n_docs + 1, a.bsum);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, n_enc);
-    FinalArgs s = a;                                        // exclusive scan of the parts = k_final_down over them
-    s.fin = a.ovf_parts;
-    s.tok_offsets2 = a.enc_base;
-    hipLaunchKernelGGL(k_final_down, dim3(nb), dim3(256), 0, st, s);
-}
-void launch_overflow_ranges(hipStream_t st, const FinalArgs& a) {
-    hipLaunchKernelGGL(k_ovf_ranges, dim3(blocks_for(a.n_docs + 1, 256)), dim3(256), 0, st, a);
-}
-void launch_final_offsets(hipStream_t st, const FinalArgs& a) {
-    const unsigned nb = blocks_for(a.n_docs + 1, 256);
-    hipLaunchKernelGGL(k_final_fin, dim3(nb), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)a.fin, a.n_docs + 1, a.bsum);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, a.n_tok2);
-    hipLaunchKernelGGL(k_final_down, dim3(nb), dim3(256), 0, st, a);
-}
-void launch_finalize(hipStream_t st, int grid, const FinalArgs& a) {
-    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, st, a);
-}
 // one matching pass of the AddedVocabulary over the sentences seg_off[0 .. n_segs]: appends (start, stop, id) to match_list
-void launch_pair_lens(hipStream_t st, const PairArgs& a) {
-    hipLaunchKernelGGL(k_pair_lens, dim3(blocks_for(a.n_pairs + 1, 256)), dim3(256), 0, st, a);
-}
-void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a) {
-    hipLaunchKernelGGL(k_pair_finalize, dim3(grid), dim3(256), 0, st, a);
-}
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
                         uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err) {
