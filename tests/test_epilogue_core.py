@@ -98,17 +98,32 @@ def _view(L, host, add_special, pad, pair, n_inputs):
     return be
 
 
+_CACHE: dict = {}
+
+
+def _plain(ref_tokenizers, name, post_processor, docs, pretok):
+    """(the wheel's plain encodings of `docs` as flat arrays, a host-only handle of the product for that tokenizer) -- both depend on
+    the tokenizer alone, not on the truncation / padding of a case"""
+    key = (name, json.dumps(post_processor, sort_keys=True), pretok, json.dumps(docs, ensure_ascii=False))
+    if key not in _CACHE:
+        d = json.loads(load_tokenizer_json(name))
+        if post_processor is not None:
+            d["post_processor"] = post_processor
+        d["truncation"] = d["padding"] = None
+        js = json.dumps(d, ensure_ascii=False)
+        encs = ref_tokenizers.Tokenizer.from_str(js).encode_batch(docs, add_special_tokens=False, is_pretokenized=pretok)
+        if len(_CACHE) > 6:
+            _CACHE.clear()
+        _CACHE[key] = (_flatten(encs), ta.Tokenizer.from_str(js, device=-1))
+    return _CACHE[key]
+
+
 def _single(L, ref_tokenizers, c, overflow):
-    d = json.loads(load_tokenizer_json(c["tokenizer"]))
-    plain = dict(d)
-    plain["truncation"] = plain["padding"] = None
-    encs = ref_tokenizers.Tokenizer.from_str(json.dumps(plain, ensure_ascii=False)).encode_batch(c["docs"], add_special_tokens=False, is_pretokenized=c.get("is_pretokenized", False))
-    d["truncation"], d["padding"] = c["truncation"], c["padding"]
-    host = ta.Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=-1)
+    (to, ids, offs, words), host = _plain(ref_tokenizers, c["tokenizer"], None, c["docs"], c.get("is_pretokenized", False))
+    encs = range(len(to) - 1)
     pre, suf = (C.c_uint32 * 16)(), (C.c_uint32 * 16)()
     npre, nsuf = C.c_int32(0), C.c_int32(0)
     _lib.check(host._lib.tkamd_tokenizer_specials(host._h, pre, C.byref(npre), suf, C.byref(nsuf), 16))
-    to, ids, offs, words = _flatten(encs)
     p = _params(c["truncation"], c["padding"], c["add_special_tokens"], overflow)
     err = L.epi_single(to.ctypes.data, len(encs), ids.ctypes.data, offs.ctypes.data, words.ctypes.data, pre, npre.value, suf, nsuf.value, p.ctypes.data)
     return err, _view(L, host, c["add_special_tokens"], c["padding"], False, len(encs))
@@ -160,18 +175,10 @@ def test_pair_kernels_match_wheel(harness, ref_tokenizers):
     cases = _load("pair_vectors.json.gz")["cases"]
     n_err = 0
     for c in cases:
-        d = json.loads(load_tokenizer_json(c["tokenizer"]))
-        if c["post_processor"] is not None:
-            d["post_processor"] = c["post_processor"]
-        plain = dict(d)
-        plain["truncation"] = plain["padding"] = None
         flat = [s for pr in c["pairs"] for s in pr]
-        encs = ref_tokenizers.Tokenizer.from_str(json.dumps(plain, ensure_ascii=False)).encode_batch(flat, add_special_tokens=False)
-        d["truncation"], d["padding"] = c["truncation"], c["padding"]
-        host = ta.Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=-1)
+        (to, ids, offs, words), host = _plain(ref_tokenizers, c["tokenizer"], c["post_processor"], flat, False)
         tpl, n_tpl = (C.c_uint32 * 96)(), C.c_int32(0)
         _lib.check(host._lib.tkamd_tokenizer_pair_template(host._h, int(c["add_special_tokens"]), tpl, 32, C.byref(n_tpl)))
-        to, ids, offs, words = _flatten(encs)
         p = _params(c["truncation"], c["padding"], c["add_special_tokens"], 0)
         err = harness.epi_pair(to.ctypes.data, len(c["pairs"]), ids.ctypes.data, offs.ctypes.data, words.ctypes.data, tpl, n_tpl.value, p.ctypes.data)
         ctx0 = (c["tokenizer"], c["post_processor"] and c["post_processor"]["type"], c["truncation"], c["padding"], c["add_special_tokens"])

@@ -1,0 +1,127 @@
+"""The WHOLE device path on the CPU: tokenizers_amd/csrc (kernels.hip, capi.cpp, host_model.cpp) compiled for the host, unchanged,
+under the SIMT shim of tests/harness/simt/ (threads of a workgroup as fibers; barriers, wavefront shuffles / ballots / DPP as
+rendezvous with the active set of the call site; HIP runtime calls on host memory), loaded in place of libtokenizers_amd.so, and
+driven through the same Python mirror and C ABI by the very functions of the -m gpu test modules.
+
+This is test infrastructure: the product library is only ever built by hipcc for gfx950 and nothing in tokenizers_amd/ knows about
+the shim (the tests swap the path the ctypes loader opens).  It cannot say anything about speed, and it cannot see bugs that need
+real concurrency between workgroups -- the -m gpu run on the MI355X stays the parity gate.  What it does show without a GPU: the
+kernels' logic, their launch sequences and the host plumbing around them produce the reference's results.
+
+By default a slice of the GPU suite runs (about two minutes); TKAMD_SIMT_FULL=1 runs every case that fits the emulation (ten)."""
+import os
+import subprocess
+
+import pytest
+
+from tokenizers_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(ROOT, "tokenizers_amd", "csrc")
+SO = os.path.join(HERE, "harness", "_libtokenizers_amd_simt.so")
+FULL = os.environ.get("TKAMD_SIMT_FULL") == "1"
+
+
+def _build():
+    deps = [os.path.join(HERE, "harness", "simt", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "tokenizers_amd.h")]
+    for d, _, files in os.walk(CSRC):
+        deps += [os.path.join(d, f) for f in files if f.endswith((".hip", ".hpp", ".cpp", ".inc"))]
+    if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(d) for d in deps):
+        return
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-Wno-unknown-pragmas", "-Wno-attributes",
+           "-I", os.path.join(HERE, "harness", "simt"), "-DTKAMD_BUILD", "-x", "c++",
+           os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "capi.cpp"), os.path.join(CSRC, "host_model.cpp"), "-o", SO + ".tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    os.replace(SO + ".tmp", SO)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def simt_library():
+    """ctypes opens the host build for the tests of this module (handles made before and after keep their own library)"""
+    _build()
+    saved = (_lib.LIB_PATH, _lib._lib)
+    _lib.LIB_PATH, _lib._lib = SO, None
+    try:
+        yield
+    finally:
+        _lib.LIB_PATH, _lib._lib = saved
+
+
+def _every(cases, step, keep=lambda c: True):
+    ks = [k for k, c in enumerate(cases) if keep(c)]
+    return ks if FULL else ks[::step]
+
+
+# the 50 k-vocabulary GPT-2 fixtures take ~40 s to LOAD here (the load-time proof of the whole-word table runs the merge kernel over
+# the vocabulary): one of them in the full run, the 3 k / 4 k / 6 k vocabularies otherwise
+_small = lambda c: not c["tokenizer"].startswith("gpt2")
+
+
+@pytest.mark.parametrize("name", ["bert_wordpiece_4000", "llama3_small_6000", "bytelevel_prefix_trim_3000", "wordlevel_whitespace_c1", "wordlevel_wssplit",
+                                  "bert_wordpiece_4000_added"] + (["gpt2_synth_50257", "gpt2_bench_added"] if FULL else []))
+def test_golden_vectors_from_the_wheel(name):
+    """ids, char offsets and word ids of every committed golden document: normalizer, both AddedVocabulary passes, the three
+    pre-tokenizer families (the Llama-3 one with its three tiers), lookup, BPE merges / WordPiece walk / WordLevel, compaction, meta."""
+    from tests import test_parity_gpu as P
+    P.test_encode_batch_matches_golden_char_offsets(name)
+    P.test_golden_vectors(name) if name in P.GPU_GOLDEN else None
+
+
+def test_epilogues_match_wheel():
+    """truncation / padding, overflowing encodings, pairs, pre-tokenized inputs through the C ABI and the host mirror"""
+    from tests import test_epilogue_gpu as E
+    from tests import test_pretokenized_gpu as W
+    for k in _every(E.OVERFLOW_CASES, 4, _small):
+        E.test_overflowing_encodings_match_wheel(k)
+    for k in _every(E.CASES, 5, _small):
+        E.test_truncation_padding_matches_wheel(k)
+    for k in _every(E.PAIR_CASES, 6, _small):
+        E.test_pair_inputs_match_wheel(k)
+    for k in _every(W.CASES, 6, _small):
+        W.test_pretokenized_inputs_match_wheel(k)
+    E.test_enable_truncation_and_padding_at_run_time()
+
+
+def test_normalizer_added_vocabulary_and_models(ref_tokenizers):
+    from tests import test_parity_gpu as P
+    P.test_bert_normalizer_reorderable_marks(ref_tokenizers)
+    P.test_special_tokens_in_the_text_behind_bert_normalizer()
+    P.test_wordlevel_missing_unk_is_a_model_error()
+    P.test_runs_of_unknown_one_byte_words_grow_the_queue_twice()
+    P.test_add_special_tokens_matches_wheel("bert_wordpiece_4000_specials")
+    if FULL:
+        P.test_add_special_tokens_matches_wheel("llama3_small_6000_specials")
+        P.test_full_added_vocabulary_vs_oracle("bert_wordpiece_4000_added")
+        P.test_bert_normalizer_unicode_vs_oracle()
+        P.test_bytelevel_no_regex_vs_oracle()
+
+
+def test_decode_batch_matches_golden():
+    from tests import test_parity_gpu as P
+    for k in (range(7) if FULL else (2, 3, 4, 5, 6)):
+        P.test_decode_batch_matches_golden(k)
+    P.test_decode_unsupported_decoder_is_refused()
+
+
+def test_overflow_epilogue_reruns_after_a_queue_overflow(monkeypatch):
+    """TKAMD_Q16_DIV (read when the handle is made) starts with a work queue far too small: the overflow epilogue sees ERR_QUEUE_FULL at
+    its read-back and runs the batch again inside the call; the plain path re-runs it from tkamd's synchronisation."""
+    import json
+    import numpy as np
+    import tokenizers_amd as ta
+    from oracle import synth
+    from tests.helpers import load_tokenizer_json
+    d = json.loads(load_tokenizer_json("bytelevel_prefix_trim_3000"))
+    d["truncation"] = {"direction": "Left", "max_length": 20, "strategy": "LongestFirst", "stride": 3}
+    docs = synth.gen_lines(300, text_seed=77, type_seed=1)
+    want = ta.Tokenizer.from_str(json.dumps(d), device=0).encode_batch_csr(docs, overflowing=True)
+    monkeypatch.setenv("TKAMD_Q16_DIV", "100000")
+    tiny = ta.Tokenizer.from_str(json.dumps(d), device=0)
+    for overflowing in (True, False):
+        got = tiny.encode_batch_csr(docs, overflowing=overflowing)
+        ref = want if overflowing else ta.Tokenizer.from_str(json.dumps(d), device=0).encode_batch_csr(docs)
+        assert np.array_equal(got.ids, ref.ids) and np.array_equal(got.tok_offsets, ref.tok_offsets)
+        assert (got.enc_docs is None) == (not overflowing) and (not overflowing or np.array_equal(got.enc_docs, ref.enc_docs))
+    assert want.n_encodings > len(docs)

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                                                       uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     constexpr uint32_t PB = (S == 16) ? 4 : 5;
-    extern __shared__ uint32_t lds_words[];
+    HIP_DYNAMIC_SHARED(uint32_t, lds_words)
     uint32_t* s_key = lds_words;                              // [S][NT]
     uint32_t* s_sym = s_key + S * NT;                         // [S][NT], absent when the symbols stay in registers
     uint32_t* s_byte_id = s_sym + (SYM_REGS ? 0 : S * NT);    // [256]
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end,
                                                         uint32_t* __restrict__ list_huge, uint32_t* __restrict__ n_huge) {
     __shared__ uint32_t s_qpre[NSQ + 1];
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lds_raw)
     uint32_t* sym = (uint32_t*)lds_raw;                 // [LONG_PT_MAX]
     uint32_t* rnk = sym + LONG_PT_MAX;                     // [LONG_PT_MAX] rank of pair (i, next[i]) or NONE
     uint32_t* nid = rnk + LONG_PT_MAX;                     // [LONG_PT_MAX] new id of that pair

@@ -69,7 +69,7 @@ __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2
 
 template <bool HAS_END>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
-    extern __shared__ __attribute__((aligned(16))) uint8_t lu_lds[];
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lu_lds)
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT_SLOTS]
     uint32_t* s_text32 = (uint32_t*)(s_hot + HOT_SLOTS);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
     uint16_t* s_pos = (uint16_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [LU_POS_CAP + 2] start of rank r, relative to the tile
