@@ -152,10 +152,19 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> fn) {
             for (int r = 3; r <= 8; ++r) top[-r] = nullptr;
             f.sp = (void*)(top - 8);
         }
-        // only runnable fibers are resumed: a parked one is made runnable by whoever completes its rendezvous
+        // only runnable fibers are resumed: a parked one is made runnable by whoever completes its rendezvous.  The order in which
+        // the runnable ones get their turn is free between rendezvous points on the hardware too -- SIMT_SCHEDULE=reverse or
+        // shuffle:<seed> changes it, which makes a missing barrier show up as a changed result.
+        static const int mode = [] { const char* e = getenv("SIMT_SCHEDULE"); return !e ? 0 : !strcmp(e, "reverse") ? 1 : !strncmp(e, "shuffle:", 8) ? 2 : 0; }();
+        static uint64_t rng = [] { const char* e = getenv("SIMT_SCHEDULE"); return (e && !strncmp(e, "shuffle:", 8)) ? strtoull(e + 8, nullptr, 10) * 2654435761ull + 1 : 1ull; }();
+        static unsigned order[MAX_THREADS];
+        for (unsigned t = 0; t < block.x; ++t) order[t] = mode == 1 ? block.x - 1 - t : t;
         for (;;) {
             unsigned ran = 0, live = 0;
-            for (unsigned t = 0; t < block.x; ++t) {
+            if (mode == 2)
+                for (unsigned t = block.x; t > 1; --t) { rng = rng * 6364136223846793005ull + 1442695040888963407ull; std::swap(order[t - 1], order[(rng >> 33) % t]); }
+            for (unsigned q = 0; q < block.x; ++q) {
+                const unsigned t = order[q];
                 const int st = waves()[t >> 6].state[t & 63];
                 live += st != DONE;
                 if (st != RUN) continue;

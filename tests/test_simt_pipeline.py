@@ -125,3 +125,15 @@ def test_overflow_epilogue_reruns_after_a_queue_overflow(monkeypatch):
         assert np.array_equal(got.ids, ref.ids) and np.array_equal(got.tok_offsets, ref.tok_offsets)
         assert (got.enc_docs is None) == (not overflowing) and (not overflowing or np.array_equal(got.enc_docs, ref.enc_docs))
     assert want.n_encodings > len(docs)
+
+
+def test_results_do_not_depend_on_the_order_the_threads_run_in():
+    """Between two rendezvous points the hardware may run the threads of a workgroup in any order; the shim's scheduler can too
+    (SIMT_SCHEDULE=reverse / shuffle:<seed>, read once per process).  A kernel that is missing a barrier -- one thread reading LDS or
+    global memory another thread of its workgroup has not written yet -- changes its result under a different order: the golden
+    vectors must come out the same with the threads shuffled."""
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "golden_vectors and (bert_wordpiece_4000 or llama3 or bytelevel or whitespace_c1)"],
+                       env=dict(os.environ, SIMT_SCHEDULE="shuffle:3", TKAMD_SIMT_FULL="0"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
