@@ -65,9 +65,13 @@ extern "C" {
                                      with their neighbour (tokenizer/encoding.rs:307-395), each with the same special tokens and padding as
                                      the truncated encoding (processors/bert.rs:88-125, encoding.rs:466-469).  The result then holds
                                      n_encodings >= n_docs encodings: every document's own followed by its overflowing ones in the
-                                     reference's order; tkamd_batch_encoding_docs / d_enc_docs name the document of each.  Ignored
-                                     without a `truncation` section and for TKAMD_PAIRS (a pair's overflowing encodings, the cross
-                                     product of both sides', are not materialised).                                                  */
+                                     reference's order; tkamd_batch_encoding_docs / d_enc_docs name the document of each.  A PAIR
+                                     leaves every combination of its two sequences' windows (Encoding::merge_with, encoding.rs:408-432):
+                                     with F the sequence the template names first, S the other, f_1.. / s_1.. their overflowing
+                                     windows, the pair's encodings are F+S; then for every f_x: f_x+S, f_x+s_1, f_x+s_2 ..; then
+                                     F+s_1, F+s_2 .. -- the reference's flat `overflowing` list (it also hangs f_x+s_* below f_x+S and
+                                     f_*+s_y below F+s_y as nested lists: the same encodings; tkamd_batch_encoding_parts names the
+                                     windows so a binding can rebuild them).  Ignored without a `truncation` section.                */
 
 /* Readable slack the caller must leave after text[n_bytes] for the device entry
  * points (kernels read whole 16-byte words).  The host entry pads internally. */
@@ -153,6 +157,9 @@ const uint32_t* tkamd_batch_encoding_docs(const tkamd_batch* b);/* [n_docs] TKAM
                                                                    (sequence) every encoding belongs to, ascending -- a document's
                                                                    first encoding is the truncated one, the rest are its
                                                                    Encoding.overflowing in order; NULL otherwise                */
+const uint32_t* tkamd_batch_encoding_parts(const tkamd_batch* b);/* [n_docs][2] TKAMD_WANT_OVERFLOW | TKAMD_PAIRS: which window of sequence A
+                                                                   and of sequence B every encoding combines (0 = the truncated
+                                                                   sequence itself, 1.. = its overflowing windows); NULL otherwise */
 void            tkamd_batch_free(tkamd_batch* b);
 
 /* ---- device-buffer entry: inputs already resident in HBM, outputs stay in HBM ---------------
@@ -173,6 +180,7 @@ typedef struct tkamd_device_result {
     const uint32_t* d_enc_docs;     /* TKAMD_WANT_OVERFLOW (with a `truncation` section): [n_encodings] document of every encoding, else NULL;
                                        d_tok_offsets / d_pad_counts then have n_encodings (+ 1) entries                                        */
     const int64_t*  d_n_encodings;  /* [1] with d_enc_docs, else NULL (the call itself waits for this count: it sizes the result)              */
+    const uint32_t* d_enc_parts;    /* TKAMD_WANT_OVERFLOW | TKAMD_PAIRS: [n_encodings][2] window of A / of B, else NULL                       */
 } tkamd_device_result;
 
 int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,

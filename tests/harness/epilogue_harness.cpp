@@ -24,7 +24,7 @@ using namespace tkamd;
 namespace {
 struct Result {
     std::vector<int64_t> tok_offsets2;
-    std::vector<uint32_t> ids2, offsets2, word_ids2, pad_count, enc_doc;
+    std::vector<uint32_t> ids2, offsets2, word_ids2, pad_count, enc_doc, enc_parts;
     std::vector<uint8_t> type_ids2, seq_ids2;
     int64_t n_enc = 0, n_tok = 0;
     int err = 0;
@@ -103,21 +103,39 @@ int epi_pair(const int64_t* tok_offsets, int64_t n_pairs, const uint32_t* ids, c
     pa.trunc_on = params[1]; pa.trunc_max = params[2]; pa.trunc_left = params[4]; pa.trunc_strategy = params[5]; pa.trunc_stride = params[3];
     pa.pad_on = params[6]; pa.pad_fixed = params[7]; pa.pad_length = params[8]; pa.pad_multiple = params[9]; pa.pad_left = params[10]; pa.pad_id = params[11];
     pa.pad_type_id = params[12];
-    std::vector<uint32_t> keep((size_t)2 * n_pairs + 2), len1((size_t)n_pairs + 2), fin((size_t)n_pairs + 2), bsum((size_t)(n_pairs + 1) / 256 + 2);
-    R.tok_offsets2.assign((size_t)n_pairs + 2, 0);
-    if (pa.pad_on) R.pad_count.assign((size_t)n_pairs + 2, 0);
-    pa.keep = keep.data(); pa.len1 = len1.data(); pa.fin = fin.data(); pa.bsum = bsum.data(); pa.target = &target; pa.tok_offsets2 = R.tok_offsets2.data();
-    pa.pad_count = pa.pad_on ? R.pad_count.data() : nullptr; pa.n_tok2 = &R.n_tok; pa.err = &R.err;
+    std::vector<uint32_t> keep((size_t)2 * n_pairs + 2), len1((size_t)n_pairs + 2), fin, bsum((size_t)(n_pairs + 1) / 256 + 2), parts, enc_win;
+    std::vector<int64_t> enc_base;
+    pa.keep = keep.data(); pa.bsum = bsum.data(); pa.target = &target; pa.n_tok2 = &R.n_tok; pa.err = &R.err;
+    for (int k = 0; k < n_tpl; ++k) if (tpl[3 * k] < 2u) { pa.first_is_b = tpl[3 * k] == 1u; break; }
+    const bool overflow = params[13] && pa.trunc_on;
+    int64_t n_enc = n_pairs;
+    if (overflow) {
+        parts.assign((size_t)n_pairs + 2, 0); enc_base.assign((size_t)n_pairs + 2, 0);
+        pa.ovf_parts = parts.data(); pa.enc_base = enc_base.data();
+    } else pa.len1 = len1.data();
     launch_pair_lens(nullptr, pa);
+    if (overflow) {
+        launch_pair_overflow_scan(nullptr, pa, &n_enc);
+        R.enc_doc.assign((size_t)n_enc + 2, 0xDEADBEEFu); R.enc_parts.assign(2 * ((size_t)n_enc + 2), 0xDEADBEEFu); enc_win.assign(4 * ((size_t)n_enc + 2), 0);
+        len1.assign((size_t)n_enc + 2, 0); bsum.assign((size_t)(n_enc + 1) / 256 + 2, 0);
+        pa.enc_doc = R.enc_doc.data(); pa.enc_idx = R.enc_parts.data(); pa.enc_win = enc_win.data(); pa.len1 = len1.data(); pa.bsum = bsum.data();
+    }
+    fin.assign((size_t)n_enc + 2, 0);
+    R.tok_offsets2.assign((size_t)n_enc + 2, 0);
+    if (pa.pad_on) R.pad_count.assign((size_t)n_enc + 2, 0);
+    pa.fin = fin.data(); pa.tok_offsets2 = R.tok_offsets2.data(); pa.pad_count = pa.pad_on ? R.pad_count.data() : nullptr;
+    if (overflow) launch_pair_ranges(nullptr, pa);
     FinalArgs fa{};
-    fa.n_docs = n_pairs; fa.len1 = pa.len1; fa.fin = pa.fin; fa.bsum = pa.bsum; fa.target = pa.target; fa.tok_offsets2 = pa.tok_offsets2; fa.n_tok2 = pa.n_tok2;
+    fa.n_docs = n_enc; fa.len1 = pa.len1; fa.fin = pa.fin; fa.bsum = pa.bsum; fa.target = pa.target; fa.tok_offsets2 = pa.tok_offsets2; fa.n_tok2 = pa.n_tok2;
     fa.pad_on = pa.pad_on; fa.pad_fixed = pa.pad_fixed; fa.pad_length = pa.pad_length; fa.pad_multiple = pa.pad_multiple;
     launch_final_offsets(nullptr, fa);
     const size_t T2 = (size_t)R.n_tok + 4;
     R.ids2.assign(T2, 0xDEADBEEFu); R.offsets2.assign(2 * T2, 0xDEADBEEFu); R.word_ids2.assign(T2, 0xDEADBEEFu); R.type_ids2.assign(T2, 0xEE); R.seq_ids2.assign(T2, 0xEE);
     pa.ids2 = R.ids2.data(); pa.offsets2 = R.offsets2.data(); pa.word_ids2 = R.word_ids2.data(); pa.type_ids2 = R.type_ids2.data(); pa.seq_ids2 = R.seq_ids2.data();
+    if (overflow) pa.n_pairs = n_enc;
     launch_pair_finalize(nullptr, GRID, pa);
-    R.n_enc = n_pairs;
+    R.n_enc = n_enc;
+    if (!overflow) { R.enc_doc.clear(); R.enc_parts.clear(); }
     return R.err;
 }
 
@@ -129,6 +147,7 @@ const uint32_t* epi_offsets(void) { return R.offsets2.data(); }
 const uint32_t* epi_word_ids(void) { return R.word_ids2.data(); }
 const uint32_t* epi_pad_count(void) { return R.pad_count.empty() ? nullptr : R.pad_count.data(); }
 const uint32_t* epi_enc_doc(void) { return R.enc_doc.empty() ? nullptr : R.enc_doc.data(); }
+const uint32_t* epi_enc_parts(void) { return R.enc_parts.empty() ? nullptr : R.enc_parts.data(); }
 const uint8_t* epi_type_ids(void) { return R.type_ids2.empty() ? nullptr : R.type_ids2.data(); }
 const uint8_t* epi_seq_ids(void) { return R.seq_ids2.empty() ? nullptr : R.seq_ids2.data(); }
 

@@ -43,7 +43,7 @@ def harness():
     L.epi_pair.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp]
     for f in ("epi_n_enc", "epi_n_tok"):
         getattr(L, f).restype = C.c_int64
-    for f in ("epi_tok_offsets", "epi_ids", "epi_offsets", "epi_word_ids", "epi_pad_count", "epi_enc_doc", "epi_type_ids", "epi_seq_ids"):
+    for f in ("epi_tok_offsets", "epi_ids", "epi_offsets", "epi_word_ids", "epi_pad_count", "epi_enc_doc", "epi_enc_parts", "epi_type_ids", "epi_seq_ids"):
         getattr(L, f).restype = vp
     return L
 
@@ -94,6 +94,8 @@ def _view(L, host, add_special, pad, pair, n_inputs):
     if L.epi_enc_doc():
         be.enc_docs = arr(L.epi_enc_doc(), C.c_uint32, n_enc)
         be._first = np.searchsorted(be.enc_docs, np.arange(n_inputs, dtype=np.uint32), side="left")
+        if L.epi_enc_parts():
+            be.enc_parts = arr(L.epi_enc_parts(), C.c_uint32, 2 * n_enc, (n_enc, 2))
     assert int(be.tok_offsets[-1]) == n_tok and (np.diff(be.tok_offsets) >= 0).all()
     return be
 
@@ -198,3 +200,61 @@ def test_pair_kernels_match_wheel(harness, ref_tokenizers):
             assert e.word_ids == c["words"][i], ctx
             assert e.sequence_ids == c["sequence_ids"][i], ctx
     assert n_err > 0
+
+
+def assert_pair_overflow(be, c, ctx0):
+    """the flat overflowing list of every pair, every field, and the nested lists the reference hangs below its entries"""
+    assert len(be) == len(c["pairs"]) and be.n_encodings == sum(len(x) for x in c["encodings"]), ctx0
+    for i, want in enumerate(c["encodings"]):
+        got = [be[i]] + be[i].overflowing
+        ctx = ctx0 + (c["pairs"][i],)
+        assert len(got) == len(want), ctx
+        for q, (e, w) in enumerate(zip(got, want)):
+            assert e.ids == w["ids"], ctx
+            assert e.type_ids == w["type_ids"], ctx
+            assert e.attention_mask == w["attention_mask"], ctx
+            assert e.special_tokens_mask == w["special_tokens_mask"], ctx
+            assert [list(x) for x in e.offsets] == w["offsets_char"], ctx
+            assert e.word_ids == w["words"], ctx
+            assert e.sequence_ids == w["sequence_ids"], ctx
+            if q:
+                assert [o.ids for o in e.overflowing] == w["nested"], ctx
+
+
+def test_pair_overflowing_encoding_kernels_match_wheel(harness, ref_tokenizers):
+    cases = _load("pair_overflow_vectors.json.gz")["cases"]
+    n_err = n_over = 0
+    for c in cases:
+        flat = [s for pr in c["pairs"] for s in pr]
+        pp = None if c["post_processor"] in (None, "none") else c["post_processor"]
+        name = c["tokenizer"]
+        if c["post_processor"] == "none":
+            (to, ids, offs, words), host = _plain_nopp(ref_tokenizers, name, flat)
+        else:
+            (to, ids, offs, words), host = _plain(ref_tokenizers, name, pp, flat, False)
+        tpl, n_tpl = (C.c_uint32 * 96)(), C.c_int32(0)
+        _lib.check(host._lib.tkamd_tokenizer_pair_template(host._h, int(c["add_special_tokens"]), tpl, 32, C.byref(n_tpl)))
+        p = _params(c["truncation"], c["padding"], c["add_special_tokens"], 1)
+        err = harness.epi_pair(to.ctypes.data, len(c["pairs"]), ids.ctypes.data, offs.ctypes.data, words.ctypes.data, tpl, n_tpl.value, p.ctypes.data)
+        ctx0 = (name, c["post_processor"] if isinstance(c["post_processor"], str) or c["post_processor"] is None else c["post_processor"]["type"], c["truncation"], c["padding"], c["add_special_tokens"])
+        if c["error"]:
+            assert err & (1024 if c["error"] == "stride" else 512), ctx0
+            n_err += 1
+            continue
+        assert err == 0, ctx0
+        be = _view(harness, host, c["add_special_tokens"], c["padding"], True, len(c["pairs"]))
+        assert_pair_overflow(be, c, ctx0)
+        n_over += be.n_encodings - len(be)
+    assert n_err > 0 and n_over > 3000
+
+
+def _plain_nopp(ref_tokenizers, name, docs):
+    key = (name, "none", json.dumps(docs, ensure_ascii=False))
+    if key not in _CACHE:
+        d = json.loads(load_tokenizer_json(name))
+        d["post_processor"] = None
+        d["truncation"] = d["padding"] = None
+        js = json.dumps(d, ensure_ascii=False)
+        encs = ref_tokenizers.Tokenizer.from_str(js).encode_batch(docs, add_special_tokens=False)
+        _CACHE[key] = (_flatten(encs), ta.Tokenizer.from_str(js, device=-1))
+    return _CACHE[key]

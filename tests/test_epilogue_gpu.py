@@ -221,3 +221,39 @@ def test_overflowing_encodings_survive_a_queue_overflow_rerun():
         assert "OVF" in r.stdout, r.stdout + r.stderr
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+def _pair_overflow_cases():
+    with gzip.open(os.path.join(GOLD, "pair_overflow_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        return json.load(fh)["cases"]
+
+
+PAIR_OVERFLOW_CASES = _pair_overflow_cases()
+
+
+@pytest.mark.parametrize("k", range(len(PAIR_OVERFLOW_CASES)))
+def test_pair_overflowing_encodings_match_wheel(k):
+    """Encoding.overflowing of PAIRS: every combination of the two sequences' windows in the reference's order (Encoding::merge_with,
+    tokenizer/encoding.rs:408-432), BertProcessing / TemplateProcessing (sequence B first, its type ids only on the pair's own encoding) /
+    no post-processor, three strategies, both directions, padded; every field of every encoding and the nested lists the reference
+    hangs below its entries -- against the wheel (oracle/make_golden_pair_overflow.py)."""
+    import tokenizers_amd as ta
+    from tests.test_epilogue_core import assert_pair_overflow
+    c = PAIR_OVERFLOW_CASES[k]
+    d = json.loads(load_tokenizer_json(c["tokenizer"]))
+    if c["post_processor"] == "none":
+        d["post_processor"] = None
+    elif c["post_processor"] is not None:
+        d["post_processor"] = c["post_processor"]
+    d["truncation"], d["padding"] = c["truncation"], c["padding"]
+    tok = ta.Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=0)
+    inputs = [tuple(p) for p in c["pairs"]]
+    if c["error"]:
+        with pytest.raises(ValueError, match="stride. must be strictly less" if c["error"] == "stride" else c["error"][:40]):
+            tok.encode_batch(inputs, add_special_tokens=c["add_special_tokens"])
+        return
+    got = tok.encode_batch(inputs, add_special_tokens=c["add_special_tokens"])
+    pp = c["post_processor"]
+    assert_pair_overflow(got, c, (c["tokenizer"], pp if isinstance(pp, str) or pp is None else pp["type"], c["truncation"], c["padding"], c["add_special_tokens"]))
+    plain = tok.encode_batch_csr(inputs, offsets="none", add_special_tokens=c["add_special_tokens"])
+    assert plain.enc_docs is None and [plain[i].ids for i in range(len(plain))] == [x[0]["ids"] for x in c["encodings"]]

@@ -81,6 +81,8 @@ def test_epilogues_match_wheel():
         E.test_pair_inputs_match_wheel(k)
     for k in _every(W.CASES, 6, _small):
         W.test_pretokenized_inputs_match_wheel(k)
+    for k in _every(E.PAIR_OVERFLOW_CASES, 5, _small):
+        E.test_pair_overflowing_encodings_match_wheel(k)
     E.test_enable_truncation_and_padding_at_run_time()
 
 

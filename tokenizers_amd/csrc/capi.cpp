@@ -98,6 +98,7 @@ struct Workspace {
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count, w_keep, w_type_ids2, w_seq_ids2;   // truncation / padding / pair epilogue
     DevBuf w_ovf_parts, w_enc_base, w_enc_doc, w_enc_start, w_enc_cnt;             // overflowing encodings (TKAMD_WANT_OVERFLOW)
+    DevBuf w_enc_idx, w_enc_win;                                                   // ... of pairs: window indices / token windows of A and B
     DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
@@ -191,9 +192,9 @@ static void pinned_put(PinnedBlock b) {
 
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs;
-    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false;
-    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); }
+    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs, enc_parts;
+    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false, has_enc_parts = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); pinned_put(enc_parts); }
 };
 
 struct tkamd_text {
@@ -571,9 +572,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (pairs && (e_n & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
     if (pairs && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
     const bool epilogue = hm.trunc_on || hm.pad_on || pairs;
-    // Encoding.overflowing: what a truncation cuts off, as further encodings of the result (single sequences; a pair's overflowing
-    // encodings are the cross product of both sides', Encoding::merge_with encoding.rs:408-432 -- not materialised)
-    const bool want_overflow = (flags & TKAMD_WANT_OVERFLOW) != 0 && hm.trunc_on && !pairs;
+    // Encoding.overflowing: what a truncation cuts off, as further encodings of the result (a pair leaves every combination of its two
+    // sequences' windows, Encoding::merge_with encoding.rs:408-432)
+    const bool want_overflow = (flags & TKAMD_WANT_OVERFLOW) != 0 && hm.trunc_on;
+    out->d_enc_parts = nullptr;
     auto finalize_pairs = [&]() {
         // EncodeInput::Dual: the two sequences of a pair were encoded as two documents; cut, lay out and pad them together
         const int64_t n_pairs = e_n / 2;
@@ -602,24 +604,83 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pa.pad_left = hm.pad_left ? 1u : 0u;
         pa.pad_id = hm.pad_id;
         pa.pad_type_id = hm.pad_type_id;
-        w->w_len1.reserve((size_t)(n_pairs + 2) * 4);
-        w->w_fin.reserve((size_t)(n_pairs + 2) * 4);
         w->w_fbsum.reserve((size_t)((n_pairs + 1) / 256 + 2) * 4);
-        w->w_tok_offsets2.reserve((size_t)(n_pairs + 2) * 8);
-        if (hm.pad_on) w->w_pad_count.reserve((size_t)(n_pairs + 2) * 4);
         pa.keep = w->w_keep.as<uint32_t>();
-        pa.len1 = w->w_len1.as<uint32_t>();
-        pa.fin = w->w_fin.as<uint32_t>();
         pa.bsum = w->w_fbsum.as<uint32_t>();
         pa.target = (uint32_t*)(sc + SC_PADMAX);
-        pa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
-        pa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
         pa.n_tok2 = sc + SC_NTOK2;
         pa.err = d_err;
+        for (int32_t k = 0; k < pa.n_tpl; ++k) {            // which sequence the template names first (it is "self" in the merge of the overflowing windows)
+            const uint32_t kind = (tpl_on ? hm.pp_pair : hm.pp_pair_plain)[(size_t)k].kind;
+            if (kind < 2u) { pa.first_is_b = kind == 1u ? 1u : 0u; break; }
+        }
         pf.begin("pair_epilogue");
+        int64_t n_enc = n_pairs;
+        bool overflow = want_overflow;
+        if (overflow) {
+            w->w_ovf_parts.reserve((size_t)(n_pairs + 2) * 4);
+            w->w_enc_base.reserve((size_t)(n_pairs + 2) * 8);
+            pa.ovf_parts = w->w_ovf_parts.as<uint32_t>();
+            pa.enc_base = w->w_enc_base.as<int64_t>();
+        } else {
+            w->w_len1.reserve((size_t)(n_pairs + 2) * 4);
+            pa.len1 = w->w_len1.as<uint32_t>();
+        }
         launch_pair_lens(st, pa);
+        if (overflow) {
+            launch_pair_overflow_scan(st, pa, sc + SC_NENC);
+            int64_t head[SC_NENC + 1];
+            HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            const int err_now = *(const int*)&head[SC_ERR];
+            if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {     // (see finalize(): the batch is run again right away)
+                t->q16_div = t->q16_div > 2 ? 2 : 1;
+                rerun = true;
+                pf.end();
+                return;
+            }
+            if (err_now) {                                  // the batch fails when it is synchronised: finish it without the overflowing encodings
+                overflow = false;
+                pa.ovf_parts = nullptr;
+                pa.enc_base = nullptr;
+                w->w_len1.reserve((size_t)(n_pairs + 2) * 4);
+                pa.len1 = w->w_len1.as<uint32_t>();
+                launch_pair_lens(st, pa);
+            } else {
+                n_enc = head[SC_NENC];
+                if (n_enc < n_pairs || n_enc >= ((int64_t)1 << 31)) throw Invalid("the truncation leaves more than 2^31 overflowing encodings: raise max_length - stride or split the batch");
+                w->w_enc_doc.reserve((size_t)(n_enc + 2) * 4);
+                w->w_enc_idx.reserve((size_t)(n_enc + 2) * 8);
+                w->w_enc_win.reserve((size_t)(n_enc + 2) * 16);
+                w->w_len1.reserve((size_t)(n_enc + 2) * 4);
+                w->w_fbsum.reserve((size_t)((n_enc + 1) / 256 + 2) * 4);
+                pa.enc_doc = w->w_enc_doc.as<uint32_t>();
+                pa.enc_idx = w->w_enc_idx.as<uint32_t>();
+                pa.enc_win = w->w_enc_win.as<uint32_t>();
+                pa.len1 = w->w_len1.as<uint32_t>();
+                pa.bsum = w->w_fbsum.as<uint32_t>();
+            }
+        }
+        w->w_fin.reserve((size_t)(n_enc + 2) * 4);
+        w->w_tok_offsets2.reserve((size_t)(n_enc + 2) * 8);
+        if (hm.pad_on) w->w_pad_count.reserve((size_t)(n_enc + 2) * 4);
+        pa.fin = w->w_fin.as<uint32_t>();
+        pa.tok_offsets2 = w->w_tok_offsets2.as<int64_t>();
+        pa.pad_count = hm.pad_on ? w->w_pad_count.as<uint32_t>() : nullptr;
+        if (overflow) launch_pair_ranges(st, pa);           // (pa.n_pairs still counts pairs)
+        FinalArgs fa{};                                    // the CSR of the padded lengths: same three kernels as for single sequences
+        fa.n_docs = n_enc;
+        fa.len1 = pa.len1; fa.fin = pa.fin; fa.bsum = pa.bsum; fa.target = pa.target; fa.tok_offsets2 = pa.tok_offsets2; fa.n_tok2 = pa.n_tok2;
+        fa.pad_on = pa.pad_on; fa.pad_fixed = pa.pad_fixed; fa.pad_length = pa.pad_length; fa.pad_multiple = pa.pad_multiple;
         size_t T2 = (size_t)n_x + 4 + (size_t)(n_pairs + 1) * n_special;
-        if (hm.pad_on) {
+        if (overflow) {
+            launch_final_offsets(st, fa);
+            int64_t total = 0;
+            HIP_CHECK(hipMemcpyAsync(&total, fa.n_tok2, 8, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            if (total < 0 || (uint64_t)total >= ((uint64_t)1 << 32)) throw Invalid("the batch with its overflowing encodings would hold more than 2^32 tokens: encode fewer pairs per call");
+            T2 = (size_t)total + 4;
+        } else if (hm.pad_on) {
             uint64_t target = hm.pad_length;
             if (!hm.pad_fixed) {
                 uint32_t mx = 0;
@@ -641,13 +702,16 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pa.word_ids2 = w->w_word_ids2.as<uint32_t>();
         pa.type_ids2 = w->w_type_ids2.as<uint8_t>();
         pa.seq_ids2 = w->w_seq_ids2.as<uint8_t>();
-        FinalArgs fa{};                                    // the CSR of the padded lengths: same three kernels as for single sequences
-        fa.n_docs = n_pairs;
-        fa.len1 = pa.len1; fa.fin = pa.fin; fa.bsum = pa.bsum; fa.target = pa.target; fa.tok_offsets2 = pa.tok_offsets2; fa.n_tok2 = pa.n_tok2;
-        fa.pad_on = pa.pad_on; fa.pad_fixed = pa.pad_fixed; fa.pad_length = pa.pad_length; fa.pad_multiple = pa.pad_multiple;
-        launch_final_offsets(st, fa);
+        if (!overflow) launch_final_offsets(st, fa);
+        else pa.n_pairs = n_enc;                            // the copy runs per encoding
         launch_pair_finalize(st, grid, pa);
         pf.end();
+        if (overflow) {
+            w->last_n_enc = n_enc;
+            out->d_enc_docs = pa.enc_doc;
+            out->d_enc_parts = pa.enc_idx;
+            out->d_n_encodings = sc + SC_NENC;
+        }
         out->d_ids = pa.ids2;
         out->d_tok_offsets = pa.tok_offsets2;
         if (out->d_offsets) out->d_offsets = pa.offsets2;
@@ -1477,7 +1541,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
         int n_slices = (int)std::min<int64_t>(8, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
-        const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on && !(flags & TKAMD_PAIRS);
+        const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)
@@ -1552,6 +1616,11 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 b->enc_docs = pinned_get((size_t)(d1 + 1) * 4);
                 b->has_enc_docs = true;
                 if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_docs.p, r.d_enc_docs, (size_t)d1 * 4, hipMemcpyDeviceToHost, s));
+                if (r.d_enc_parts) {
+                    b->enc_parts = pinned_get((size_t)(d1 + 1) * 8);
+                    b->has_enc_parts = true;
+                    if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_parts.p, r.d_enc_parts, (size_t)d1 * 8, hipMemcpyDeviceToHost, s));
+                }
             }
             slice_tok[k] = n_tok;
             const size_t need = (size_t)(tok_base + n_tok);
@@ -1627,6 +1696,7 @@ int tkamd_encode_batch_words(tkamd_tokenizer* t, const uint8_t* text, const int6
 
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b) { return (b && b->has_pads) ? (const uint32_t*)b->pad_counts.p : nullptr; }
 const uint32_t* tkamd_batch_encoding_docs(const tkamd_batch* b) { return (b && b->has_enc_docs) ? (const uint32_t*)b->enc_docs.p : nullptr; }
+const uint32_t* tkamd_batch_encoding_parts(const tkamd_batch* b) { return (b && b->has_enc_parts) ? (const uint32_t*)b->enc_parts.p : nullptr; }
 const uint8_t* tkamd_batch_type_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->type_ids.p : nullptr; }
 const uint8_t* tkamd_batch_sequence_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->seq_ids.p : nullptr; }
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }

@@ -182,6 +182,18 @@ struct PairArgs {
     uint32_t trunc_on, trunc_max, trunc_left, trunc_strategy, trunc_stride;
     uint32_t pad_on, pad_fixed, pad_length, pad_multiple, pad_left, pad_id, pad_type_id;
     uint32_t* keep;                   // [2 * n_pairs] tokens of A / B that survive the truncation
+    // overflowing encodings of pairs (TKAMD_WANT_OVERFLOW): sequence A leaves pa windows (its truncated self + its overflowing pieces),
+    // B leaves pb; Encoding::merge_with (tokenizer/encoding.rs:408-432) combines every window of the sequence that comes FIRST in the
+    // template with every window of the other one.  Pair i leaves ovf_parts[i] = pa * pb encodings numbered from enc_base[i], in the
+    // reference's order (k_pair_ranges); encoding e is windows enc_idx[2e] / [2e + 1] of A / B of pair enc_doc[e], token ranges
+    // enc_win[4e ..] = {first token of A's window, count, first token of B's window, count}.  With these set, n_pairs of
+    // k_pair_finalize counts ENCODINGS and len1 .. pad_count are per encoding.  All null: one encoding per pair.
+    uint32_t first_is_b;              // the template names sequence B before sequence A
+    uint32_t* ovf_parts;              // [n_pairs + 1]
+    int64_t* enc_base;                // [n_pairs + 1]
+    uint32_t* enc_doc;
+    uint32_t* enc_idx;
+    uint32_t* enc_win;
     uint32_t* len1;                   // [n_pairs] tokens of the pair encoding before padding
     uint32_t* fin;
     uint32_t* target;
@@ -277,6 +289,10 @@ void launch_overflow_ranges(hipStream_t st, const FinalArgs& a);
 void launch_final_offsets(hipStream_t st, const FinalArgs& a);
 void launch_finalize(hipStream_t st, int grid, const FinalArgs& a);
 void launch_pair_lens(hipStream_t st, const PairArgs& a);
+// overflowing encodings of pairs: launch_pair_lens (with ovf_parts set) counts them; this numbers them (*n_enc = how many), then
+// launch_pair_ranges -- a.n_pairs still the number of PAIRS -- writes every encoding's windows, its length and the batch maximum
+void launch_pair_overflow_scan(hipStream_t st, const PairArgs& a, int64_t* n_enc);
+void launch_pair_ranges(hipStream_t st, const PairArgs& a);
 void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a);
 // AddedVocabulary (kernels/documents.hip): one matching pass over a sentence CSR, list -> masks, list coordinate changes
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,

@@ -219,9 +219,75 @@ __global__ __launch_bounds__(256) void k_pair_lens(PairArgs a) {
         a.keep[2 * i] = (uint32_t)n1;
         a.keep[2 * i + 1] = (uint32_t)n2;
         l = (uint32_t)(n1 + n2) + a.n_special;
-        a.len1[i] = l;
+        if (a.ovf_parts) {
+            // Encoding::truncate keeps what it cuts off either sequence; the pair then leaves every combination of their windows
+            const uint64_t a1 = (uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), a2 = (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1]);
+            uint64_t pa = ovf_parts(a1, (uint32_t)n1, a.trunc_stride), pb = ovf_parts(a2, (uint32_t)n2, a.trunc_stride);
+            if (pa == 0u) pa = 1u;                          // (the stride assert: reported above)
+            if (pb == 0u) pb = 1u;
+            uint64_t p = pa * pb;
+            if (p >= 0x7FFFFFFFull) { atomicOr(a.err, ERR_TOO_MANY_TOKENS); p = 1u; }
+            a.ovf_parts[i] = (uint32_t)p;
+        } else {
+            a.len1[i] = l;
+        }
+    } else if (i == a.n_pairs && a.ovf_parts) {
+        a.ovf_parts[i] = 0u;
     }
+    if (a.ovf_parts) return;                                // lengths and the batch maximum: k_pair_ranges, per encoding
     if (a.pad_on && !a.pad_fixed) {
+        uint32_t m = l;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s, 64));
+        if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(a.target, max(max(smax[0], smax[1]), max(smax[2], smax[3])));
+    }
+}
+// Encodings of pair i in the reference's order (Encoding::merge_with, tokenizer/encoding.rs:408-432, F = the sequence the template names
+// first, S the other, f_1.. / s_1.. their overflowing windows):  F+S ;  for every f_x:  f_x+S , f_x+s_1 , f_x+s_2 .. ;  then F+s_1 , F+s_2 ..
+// (the reference also hangs f_x+s_* below f_x+S, and f_*+s_y below F+s_y, as nested `overflowing` lists: the same encodings again --
+// the host rebuilds those lists from the window indices written here).
+__global__ __launch_bounds__(256) void k_pair_ranges(PairArgs a) {
+    __shared__ uint32_t smax[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t l = 0;
+    if (i < a.n_pairs) {
+        const uint64_t n_all[2] = {(uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1])};
+        const uint32_t keep[2] = {a.keep[2 * i], a.keep[2 * i + 1]};
+        uint32_t parts[2] = {ovf_parts(n_all[0], keep[0], a.trunc_stride), ovf_parts(n_all[1], keep[1], a.trunc_stride)};
+        if (parts[0] == 0u) parts[0] = 1u;
+        if (parts[1] == 0u) parts[1] = 1u;
+        const int64_t e0 = a.enc_base[i];
+        const uint32_t total = (uint32_t)(a.enc_base[i + 1] - e0);
+        if (total != parts[0] * parts[1]) { parts[0] = 1u; parts[1] = 1u; }      // (the count was clamped: an error is pending)
+        const int F = a.first_is_b ? 1 : 0, S = 1 - F;
+        for (uint32_t q = 0; q < total; ++q) {
+            // q -> (window of F, window of S) in the order above
+            uint32_t wf, ws;
+            const uint32_t rows = (parts[F] - 1u) * parts[S];          // the f_x rows
+            if (q == 0u) { wf = 0u; ws = 0u; }
+            else if (q <= rows) { wf = 1u + (q - 1u) / parts[S]; ws = (q - 1u) % parts[S]; }
+            else { wf = 0u; ws = q - rows; }
+            uint32_t w[2];
+            w[F] = wf;
+            w[S] = ws;
+            uint64_t s0, c0, s1, c1;
+            ovf_part_range(n_all[0], keep[0], a.trunc_stride, a.trunc_left != 0u, w[0], &s0, &c0);
+            ovf_part_range(n_all[1], keep[1], a.trunc_stride, a.trunc_left != 0u, w[1], &s1, &c1);
+            const int64_t e = e0 + q;
+            a.enc_doc[e] = (uint32_t)i;
+            a.enc_idx[2 * e] = w[0];
+            a.enc_idx[2 * e + 1] = w[1];
+            a.enc_win[4 * e] = (uint32_t)s0;
+            a.enc_win[4 * e + 1] = (uint32_t)c0;
+            a.enc_win[4 * e + 2] = (uint32_t)s1;
+            a.enc_win[4 * e + 3] = (uint32_t)c1;
+            a.len1[e] = (uint32_t)(c0 + c1) + a.n_special;
+            if (q == 0u) l = (uint32_t)(c0 + c1) + a.n_special;
+        }
+    }
+    if (a.pad_on && !a.pad_fixed) {                         // BatchLongest: the pairs' own encodings (utils/padding.rs:55-63)
         uint32_t m = l;
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, s, 64));
@@ -258,12 +324,23 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PairArgs a) {
                 }
                 cur += 1;
             } else {
-                const int64_t d = 2 * i + kind;
-                const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo, n = a.keep[d];
-                const int64_t src = lo + (a.trunc_left ? n_all - n : 0);
+                int64_t n, src;
+                uint32_t ty_here = ty;
+                if (a.enc_doc) {                            // i numbers the encodings: this one's window of sequence `kind`
+                    n = a.enc_win[4 * i + 2 * kind + 1];
+                    src = a.tok_offsets[2 * (int64_t)a.enc_doc[i] + kind] + a.enc_win[4 * i + 2 * kind];
+                    // the template's type id is put on the sequence's own encoding only (template.rs:554-559); an overflowing window
+                    // keeps what encode gave its tokens: 0 for the first sequence, 1 for the second (mod.rs:879-884)
+                    if (a.enc_idx[2 * i + kind] != 0u) ty_here = kind;
+                } else {
+                    const int64_t d = 2 * i + kind;
+                    const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo;
+                    n = a.keep[d];
+                    src = lo + (a.trunc_left ? n_all - n : 0);
+                }
                 for (int64_t q = lane; q < n; q += 64) {
                     a.ids2[cur + q] = a.ids[src + q];
-                    a.type_ids2[cur + q] = (uint8_t)ty;
+                    a.type_ids2[cur + q] = (uint8_t)ty_here;
                     a.seq_ids2[cur + q] = (uint8_t)kind;
                     if (a.offsets) { a.offsets2[2 * (cur + q)] = a.offsets[2 * (src + q)]; a.offsets2[2 * (cur + q) + 1] = a.offsets[2 * (src + q) + 1]; }
                     if (a.word_ids) a.word_ids2[cur + q] = a.word_ids[src + q];
@@ -306,6 +383,20 @@ void launch_finalize(hipStream_t st, int grid, const FinalArgs& a) {
 }
 void launch_pair_lens(hipStream_t st, const PairArgs& a) {
     hipLaunchKernelGGL(k_pair_lens, dim3(blocks_for(a.n_pairs + 1, 256)), dim3(256), 0, st, a);
+}
+void launch_pair_overflow_scan(hipStream_t st, const PairArgs& a, int64_t* n_enc) {
+    const unsigned nb = blocks_for(a.n_pairs + 1, 256);
+    hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)a.ovf_parts, a.n_pairs + 1, a.bsum);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, a.bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, n_enc);
+    FinalArgs s{};                                          // exclusive scan of the counts = k_final_down over them
+    s.n_docs = a.n_pairs;
+    s.fin = a.ovf_parts;
+    s.bsum = a.bsum;
+    s.tok_offsets2 = a.enc_base;
+    hipLaunchKernelGGL(k_final_down, dim3(nb), dim3(256), 0, st, s);
+}
+void launch_pair_ranges(hipStream_t st, const PairArgs& a) {
+    hipLaunchKernelGGL(k_pair_ranges, dim3(blocks_for(a.n_pairs + 1, 256)), dim3(256), 0, st, a);
 }
 void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a) {
     hipLaunchKernelGGL(k_pair_finalize, dim3(grid), dim3(256), 0, st, a);

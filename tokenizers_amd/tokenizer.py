@@ -102,7 +102,7 @@ class Encoding:
     Field semantics follow ``Encoding`` (tokenizer/encoding.rs:11-31).  For a single sequence ``type_ids`` are 0 and
     ``attention_mask`` 1 on everything but padding; ``special_tokens_mask`` is 1 on the post-processor's special tokens and on
     padding (Encoding::pad, encoding.rs:405-470).  ``overflowing``: what a truncation cut off a single sequence, as further
-    encodings (Encoding::truncate, encoding.rs:307-395); a pair's are not materialised.
+    encodings (Encoding::truncate, encoding.rs:307-395); a pair leaves every combination of its two sequences' windows.
     """
     __slots__ = ("_b", "_lo", "_hi", "_i")
 
@@ -174,7 +174,17 @@ class Encoding:
     @property
     def sequence_ids(self) -> list[int | None]:
         if self._b.seq_ids is not None:
-            return [q if q < 2 else None for q in self._b.seq_ids[self._lo:self._hi].tolist()]
+            nat = [q if q < 2 else None for q in self._b.seq_ids[self._lo:self._hi].tolist()]
+            b = self._b
+            if b.enc_parts is not None and getattr(b, "_no_seq_ranges", False) and (self._i > 0 and b.enc_docs[self._i - 1] == b.enc_docs[self._i]):
+                # an overflowing encoding of a pair WITHOUT a post-processor: default_process gives sequence ranges to the pair's own
+                # encoding only (tokenizer/mod.rs:158-173).  A combination that holds an overflowing window of the first sequence has no
+                # range at all -- token_to_sequence then answers 0 for every token (encoding.rs:213-216) --; the first sequence itself
+                # with an overflowing window of the second keeps its own range and nothing else
+                if int(b.enc_parts[self._i][0]):
+                    return [0] * len(nat)
+                return [q if q == 0 else None for q in nat]
+            return nat
         return [0] * len(self) if getattr(self._b, "_no_seq_ranges", False) else self._mask(None, None, 0)
 
     @property
@@ -258,16 +268,28 @@ class Encoding:
         b = self._b
         if b.enc_docs is None:
             return []
-        # the encodings right behind this one that belong to the same document (only a document's own encoding has any)
         i, n, doc = self._i, len(b.enc_docs), b.enc_docs[self._i]
-        if i > 0 and b.enc_docs[i - 1] == doc:
+        view = lambda j: Encoding(b, int(b.tok_offsets[j]), int(b.tok_offsets[j + 1]), j)
+        first = i
+        while first > 0 and b.enc_docs[first - 1] == doc:
+            first -= 1
+        last = i + 1
+        while last < n and b.enc_docs[last] == doc:
+            last += 1
+        if b.enc_parts is None:
+            # single sequence: the encodings right behind the document's own one (only that one has any)
+            return [view(j) for j in range(i + 1, last)] if i == first else []
+        # pair: Encoding::merge_with (encoding.rs:408-432).  The input's own encoding lists every other combination of windows; below
+        # a combination of an overflowing window with the other sequence's own one hang its combinations with that sequence's overflowing
+        # windows (the same encodings again)
+        wa, wb = int(b.enc_parts[i][0]), int(b.enc_parts[i][1])
+        if i == first:
+            return [view(j) for j in range(first + 1, last)]
+        if wa and wb:
             return []
-        j = i + 1
-        out = []
-        while j < n and b.enc_docs[j] == doc:
-            out.append(Encoding(b, int(b.tok_offsets[j]), int(b.tok_offsets[j + 1]), j))
-            j += 1
-        return out
+        col = 0 if wa else 1                       # the window index that stays fixed
+        fixed = wa or wb
+        return [view(j) for j in range(first + 1, last) if int(b.enc_parts[j][col]) == fixed and int(b.enc_parts[j][1 - col]) != 0]
 
     def __repr__(self) -> str:
         return f"Encoding(num_tokens={len(self)}, attributes=[ids, type_ids, tokens, offsets, attention_mask, special_tokens_mask, overflowing])"
@@ -288,6 +310,7 @@ class BatchEncoding:
         # overflowing encodings materialised: tok_offsets / pad_counts run over ENCODINGS, enc_docs[e] = the input encoding e belongs to
         # (an input's own encoding first, then its Encoding.overflowing), _first[i] = the own encoding of input i
         self.enc_docs = None
+        self.enc_parts = None               # pairs: [n_encodings, 2] window of sequence A / B each encoding combines
         self._first = None
         self._id_to_token = id_to_token
         self._specials = specials           # (#prefix, #suffix) special tokens around every document
@@ -642,6 +665,9 @@ class Tokenizer:
         if ed:
             be.enc_docs = view(ed, C.c_uint32, (n_docs,), np.uint32)
             be._first = np.searchsorted(be.enc_docs, np.arange(n_inputs, dtype=np.uint32), side="left")
+            ep = self._lib.tkamd_batch_encoding_parts(b)
+            if ep:
+                be.enc_parts = view(ep, C.c_uint32, (n_docs, 2), np.uint32)
         return be
 
     def encode_file(self, path: str, offsets: str = "none", word_ids: bool = False, add_special_tokens: bool = False) -> BatchEncoding:
