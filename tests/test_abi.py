@@ -660,3 +660,20 @@ def test_vocabulary_lookups_match_the_wheel(ref_tokenizers):
             assert t.id_to_token(i) == r.id_to_token(i), (name, i)
         for is_pair in (False, True):
             assert t.num_special_tokens_to_add(is_pair) == r.num_special_tokens_to_add(is_pair), (name, is_pair)
+
+
+def test_add_tokens_matches_the_wheel(ref_tokenizers):
+    """Tokenizer.add_tokens / add_special_tokens of the host mirror (AddedVocabulary::add_tokens, added_vocabulary.rs:272-360): the ids
+    handed out, what is ignored, what replaces what -- the resulting `added_tokens` section equals the wheel's serialisation."""
+    import json
+    AddedToken = ref_tokenizers.AddedToken
+    for name in ("bert_wordpiece_4000_specials", "gpt2_synth_50257", "llama3_small_6000_specials"):
+        js = load_tokenizer_json(name)
+        t, r = ta.Tokenizer.from_str(js, device=-1), ref_tokenizers.Tokenizer.from_str(js)
+        for toks, special in ((["<new1>", "hello", "", "<new1>"], False), (["[SEP]", "<pad2>"], True),
+                              ([AddedToken("<w>", single_word=True, lstrip=True), AddedToken("the", normalized=False)], False), (["<new1>"], True)):
+            got = (t.add_special_tokens if special else t.add_tokens)(toks)
+            assert got == (r.add_special_tokens if special else r.add_tokens)(toks), (name, toks)
+            assert t.get_vocab() == r.get_vocab(), (name, toks)
+        assert json.loads(t._json)["added_tokens"] == json.loads(r.to_str())["added_tokens"], name
+        assert t.token_to_id("<new1>") == r.token_to_id("<new1>") and t.id_to_token(t.token_to_id("<pad2>")) == "<pad2>"

@@ -155,3 +155,25 @@ def test_a_batch_whose_queue_rows_reach_bit_29_is_refused():
     with pytest.raises(ValueError, match="29-bit"):
         tok.encode_batch_fast(docs, add_special_tokens=False)
     assert tok.encode_batch_fast(docs[:2000], add_special_tokens=False).n_tokens > 0
+
+
+def test_tokens_added_at_run_time_are_matched_like_the_wheel_matches_them(ref_tokenizers):
+    """Tokenizer.add_tokens / add_special_tokens re-create the handle from the edited tokenizer.json; the new tokens then go through the
+    device's AddedVocabulary passes (raw and normalized patterns, single_word / lstrip) like the wheel's."""
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    for name in ("bert_wordpiece_4000_specials", "llama3_small_6000_specials"):
+        js = load_tokenizer_json(name)
+        t, r = ta.Tokenizer.from_str(js, device=0), ref_tokenizers.Tokenizer.from_str(js)
+        for tk in (t, r):
+            tk.add_tokens(["<new1>", "Hello"])
+            tk.add_special_tokens(["<pad2>"])
+            tk.add_tokens([ref_tokenizers.AddedToken("<w>", single_word=True, lstrip=True)])
+        docs = ["say <new1> twice<new1>", "hello Hello HELLO", "a <w> b<w>c  <w>", "x<pad2>y <pad2>", "plain text only", ""]
+        got = t.encode_batch(docs, add_special_tokens=True)
+        exp = r.encode_batch(docs, add_special_tokens=True)
+        for i, e in enumerate(exp):
+            assert got[i].ids == e.ids and [tuple(x) for x in got[i].offsets] == e.offsets and got[i].word_ids == e.word_ids, (name, docs[i])
+            assert got[i].special_tokens_mask == e.special_tokens_mask, (name, docs[i])
+            # (token STRINGS: the wheel shows the matched slice, i.e. with the whitespace an lstrip / rstrip token swallowed; the mirror the token)
+            assert got[i].tokens == [x.strip() if x.strip() == "<w>" else x for x in e.tokens], (name, docs[i])

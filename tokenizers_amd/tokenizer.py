@@ -146,6 +146,8 @@ class Encoding:
 
     @property
     def tokens(self) -> list[str]:
+        # (an added-token match shows the token's -- normalized -- content; the reference shows the matched slice, which also holds the
+        # whitespace an lstrip / rstrip token swallowed)
         v = self._b._id_to_token
         out = [v.get(i, "") for i in self.ids]
         if self._b.seq_ids is not None:
@@ -450,12 +452,22 @@ class Tokenizer:
                 pass
             self._h = None
 
+    def _normalized(self, text: str) -> str:
+        """BertNormalizer::normalize of a short string from the host copy of the load-time tables (character by character)"""
+        out, cps, n, refused = [], (C.c_uint32 * 16)(), C.c_int32(0), C.c_int32(0)
+        for ch in text:
+            _lib.check(self._lib.tkamd_probe_bert_norm(self._h, ord(ch), cps, C.byref(n), C.byref(refused)))
+            out.extend(chr(cps[i]) for i in range(n.value))
+        return "".join(out)
+
     def _id_to_token(self) -> dict[int, str]:
         if self._vocab_r is None:
             d = json.loads(self._json)
             r = {int(i): t for t, i in d["model"]["vocab"].items()}
             for a in d.get("added_tokens") or []:
-                r[int(a["id"])] = a["content"]
+                # the token string of an added-token match is the matched slice of the NORMALIZED text (added_vocabulary.rs:497-516), i.e.
+                # the token's normalized pattern when it is matched through the normalizer
+                r[int(a["id"])] = self._normalized(a["content"]) if a.get("normalized") and self.info["normalizer"] == 1 else a["content"]
             self._vocab_r = r
         return self._vocab_r
 
@@ -490,6 +502,50 @@ class Tokenizer:
         d["padding"] = None
         self._reload(d)
 
+    # ---- Tokenizer.add_tokens / add_special_tokens (AddedVocabulary::add_tokens, tokenizer/added_vocabulary.rs:272-360; Python
+    # tokenizer.rs:1262-1308): the added vocabulary lives in the tokenizer.json's `added_tokens`, so the handle is re-created ----
+    def _add(self, tokens, special: bool) -> int:
+        d = json.loads(self._json)
+        added = d.get("added_tokens") or []
+        model_vocab = d["model"]["vocab"]
+        by_content = {a["content"]: a for a in added}
+        n_model = len(model_vocab)
+        max_added = max((int(a["id"]) for a in added), default=None)
+        next_id = n_model if max_added is None else (max_added + 1 if (max_added >= n_model or n_model == 0) else n_model)
+        n_new = 0
+        for t in tokens:
+            if isinstance(t, str):
+                e = {"content": t, "single_word": False, "lstrip": False, "rstrip": False, "normalized": not special, "special": special}
+            else:                               # an AddedToken-like object (content / single_word / lstrip / rstrip / normalized attributes)
+                e = {"content": t.content, "single_word": bool(t.single_word), "lstrip": bool(t.lstrip), "rstrip": bool(t.rstrip),
+                     "normalized": bool(t.normalized) if not special else bool(getattr(t, "normalized", False)), "special": special or bool(getattr(t, "special", False))}
+            if not e["content"]:
+                continue
+            old = by_content.get(e["content"])
+            if old is not None and all(old.get(k) == e[k] for k in e):
+                continue
+            if old is not None:
+                e["id"] = int(old["id"])
+                added.remove(old)
+            elif e["content"] in model_vocab:
+                e["id"] = int(model_vocab[e["content"]])
+            else:
+                e["id"] = next_id
+                next_id += 1
+            added.append(e)
+            by_content[e["content"]] = e
+            n_new += 1
+        if n_new:
+            d["added_tokens"] = sorted(added, key=lambda a: int(a["id"]))
+            self._reload(d)
+        return n_new
+
+    def add_tokens(self, tokens) -> int:
+        return self._add(list(tokens), special=False)
+
+    def add_special_tokens(self, tokens) -> int:
+        return self._add(list(tokens), special=True)
+
     def get_vocab_size(self, with_added_tokens: bool = True) -> int:
         return len(self._id_to_token()) if with_added_tokens else self.info["vocab_size"]
 
@@ -509,7 +565,9 @@ class Tokenizer:
         return self._vocab_f.get(token)
 
     def id_to_token(self, id: int) -> str | None:
-        return self._id_to_token().get(int(id))
+        if getattr(self, "_vocab_c", None) is None:
+            self._vocab_c = {i: t for t, i in self.get_vocab(True).items()}       # (contents as registered; Encoding.tokens shows matched text)
+        return self._vocab_c.get(int(id))
 
     def num_special_tokens_to_add(self, is_pair: bool) -> int:
         """PostProcessor::added_tokens (processors/bert.rs:43-49, template.rs:520-530): special tokens a single sequence / a pair gets."""
