@@ -632,7 +632,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             int64_t head[SC_NENC + 1];
             HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            const int err_now = *(const int*)&head[SC_ERR];
+            const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_REORDER_SEEN;
             if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {     // (see finalize(): the batch is run again right away)
                 t->q16_div = t->q16_div > 2 ? 2 : 1;
                 rerun = true;
@@ -766,7 +766,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             int64_t head[SC_NENC + 1];
             HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            const int err_now = *(const int*)&head[SC_ERR];
+            const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_REORDER_SEEN;
             if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {
                 // the token CSR is incomplete: this call is synchronous here anyway, so the batch is run again right away with the
                 // larger queue (what finish_batch does for the calls that never wait)
@@ -1295,7 +1295,7 @@ int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
     int64_t host[SC_SLOTS];
     HIP_CHECK(hipMemcpyAsync(host, w->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    int err = *(int*)&host[SC_ERR];
+    int err = *(int*)&host[SC_ERR] & ~NOTE_REORDER_SEEN;     // (a note of the normalizer, not an error)
     memcpy(w->last_counters, &host[SC_COUNTERS], sizeof(w->last_counters));
     if (n_tok) *n_tok = host[w->last_ntok_slot];
     if (n_pretok) *n_pretok = host[SC_NPRETOK];

@@ -78,9 +78,9 @@ __device__ __forceinline__ uint32_t sw_ascii_dropped(uint32_t x) { return (sw_lt
 // bits [i0, i0 + 16) of a bit mask (i0 a multiple of 16)
 __device__ __forceinline__ uint32_t mask16(const unsigned long long* __restrict__ m, int64_t i0) { return (uint32_t)(m[i0 >> 6] >> (i0 & 63)) & 0xFFFFu; }
 
-// a REORDER character at byte i: refuse the batch unless it is alone in its run of non-starters (rare: off the fast paths)
-__device__ __noinline__ void bn_check_reorder(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t cp, uint32_t len,
-                                              const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
+// a REORDER character at byte i: refuse the batch unless it is alone in its run of non-starters
+__device__ __forceinline__ void bn_check_reorder(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t cp, uint32_t len,
+                                                 const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
     // the document holding byte i: the last d with doc_off[d] <= i
     int64_t lo = 0, hi = n_docs;
     while (lo < hi) {
@@ -92,8 +92,7 @@ __device__ __noinline__ void bn_check_reorder(const BnTables& bt, const uint8_t*
 }
 
 // output bytes of source byte i, the table-driven way (any byte)
-__device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t b, bool verbatim,
-                                                  const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
+__device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint8_t* __restrict__ text, int64_t i, uint32_t b, bool verbatim, int* __restrict__ err) {
     if (verbatim) return 1u;
     if (b < 0x80u)      // ASCII: control characters except \t \n \r are dropped, everything else is one byte
         return (bt.clean && ((b < 0x20u && b != '\t' && b != '\n' && b != '\r') || b == 0x7Fu)) ? 0u : 1u;
@@ -102,14 +101,13 @@ __device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint
     bool reorder = false;
     const uint32_t cp = utf8_global(text, i, &len);
     const int n = bn_expand(bt, cp, out, &reorder);
-    if (reorder) bn_check_reorder(bt, text, n_bytes, i, cp, len, vmask, doc_off, n_docs, err);
+    if (reorder) atomicOr(err, NOTE_REORDER_SEEN);              // (k_bn_reorder_check decides; the hot kernel only takes note)
     for (int q = 0; q < n; ++q) ob += utf8_len_cp(out[q]);
     return ob;
 }
 
 // `verbatim`: bytes of added-token matches of the raw pass (null: none) -- not text for the normalizer: copied as they are
 __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
-                                                  const int64_t* __restrict__ doc_off, int64_t n_docs,
                                                   uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BN_LANE;
     uint32_t o[4] = {0u, 0u, 0u, 0u};                               // output bytes of my 16 source bytes, one per byte
@@ -122,7 +120,7 @@ __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __
             for (int k = 0; k < 4; ++k) o[k] = SW_1 - (bt.clean ? (sw_ascii_dropped(x[k]) >> 7) : 0u);
         } else {
             const int nv = (int)min((int64_t)BN_LANE, n_bytes - i0);
-            for (int j = 0; j < nv; ++j) o[j >> 2] |= bn_count_byte(bt, text, n_bytes, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, verbatim, doc_off, n_docs, err) << (8 * (j & 3));
+            for (int j = 0; j < nv; ++j) o[j >> 2] |= bn_count_byte(bt, text, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, err) << (8 * (j & 3));
         }
         *(uint4*)(olen + i0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -131,6 +129,22 @@ __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if ((threadIdx.x & 3) == 0 && i0 <= n_bytes) wsum[i0 >> 6] = s;
+}
+
+// Runs behind k_bn_count and does nothing unless that kernel met a REORDER character (NOTE_REORDER_SEEN): then every such character of
+// the text -- a lead byte of a 2..4-byte sequence whose table flags say so, outside the verbatim added-token matches -- is looked at
+// with its neighbours, and the batch is refused if one of them is not alone in its run of non-starters (bert_norm_core.hpp).
+__global__ __launch_bounds__(256) void k_bn_reorder_check(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
+                                                          const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
+    if (!(*err & NOTE_REORDER_SEEN) || !bt.strip) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_bytes; i += (int64_t)gridDim.x * 256) {
+        const uint32_t b = text[i];
+        if (b < 0xC0u) continue;                                 // ASCII or a continuation byte
+        if (verbatim && ((verbatim[i >> 6] >> (i & 63)) & 1ull)) continue;
+        uint32_t len;
+        const uint32_t cp = utf8_global(text, i, &len);
+        if (bn_flags(bt, cp) & BN_REORDER) bn_check_reorder(bt, text, n_bytes, i, cp, len, verbatim, doc_off, n_docs, err);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_u32_down(const uint32_t* __restrict__ v, int64_t n, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ out) {
