@@ -741,13 +741,14 @@ class Tokenizer:
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
-        return self.encode_batch_csr(list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized,
-                                     overflowing=self.info["truncation"] >= 0)
+        # (no list(input) for a list: copying a million references touches -- and later releases -- every str object once more)
+        return self.encode_batch_csr(input if isinstance(input, (list, tuple)) else list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens,
+                                     is_pretokenized=is_pretokenized, overflowing=self.info["truncation"] >= 0)
 
     def encode_batch_fast(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch_fast`` (no offsets, tokenizer.rs:1433-1459)."""
-        return self.encode_batch_csr(list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens, is_pretokenized=is_pretokenized,
-                                     overflowing=self.info["truncation"] >= 0)
+        return self.encode_batch_csr(input if isinstance(input, (list, tuple)) else list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens,
+                                     is_pretokenized=is_pretokenized, overflowing=self.info["truncation"] >= 0)
 
     def decode_batch_csr(self, ids: np.ndarray, tok_offsets: np.ndarray, skip_special_tokens: bool = True) -> tuple[np.ndarray, np.ndarray]:
         """ids CSR -> (bytes uint8[n_bytes], doc_offsets int64[n_docs+1]): the raw decoded byte string of every sequence."""
