@@ -237,9 +237,9 @@ int tkamd_probe_truncation(uint64_t n_tokens, uint32_t max_len, uint32_t stride,
 int tkamd_probe_bert_norm(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* out, int32_t* n, int32_t* refused);
 /* BertNormalizer strip_accents on the character whose lead byte is text[pos] (text[0 .. n) = one piece handed to the normalizer: a
  * document, or what lies between two added-token matches): *reorder = 1 if it survives the Mn filter with a non-zero combining
- * class (NFD's canonical ordering could move it), *alone = 1 if it is alone in its run of non-starters -- nothing moves, the device
- * encodes it; 0: the device refuses the document.  The very function the kernels call (csrc/bert_norm_core.hpp), on the host copy
- * of the tables. */
+ * class (NFD's canonical ordering could move it), *alone = 1 if it is alone in its run of non-starters -- nothing moves; 0: the
+ * device puts that run into canonical order (csrc/bert_norm_core.hpp bn_fix_run).  The very function the kernels call, on the host
+ * copy of the tables. */
 int tkamd_probe_bert_alone(const tkamd_tokenizer* tok, const uint8_t* text, int64_t n, int64_t pos, int32_t* reorder, int32_t* alone);
 /* Class flags of one code point from the host copy of the generated Unicode table: bit 0 \p{L}, 1 \p{N}, 2 \s (as
  * Oniguruma sees them, byte_level.rs:43-46), 3 \w, 4 \s (regex crate, whitespace.rs:22), 5 char::is_whitespace, 6 is_bert_punc. */

@@ -39,6 +39,7 @@ def main():
     flags = bytearray(0x110000)
     dmap, lcmap = {}, {}
     ccc_cache = {}
+    nfd_pieces = {}            # cp -> (NFD form, non-starter?, survives the Mn filter?) per piece, for characters with a non-starter piece
     for cp in range(0x110000):
         if 0xD800 <= cp <= 0xDFFF:
             continue
@@ -86,7 +87,41 @@ def main():
             assert all(ns), f"U+{cp:04X}: a starter after a non-starter inside one decomposition"
         if ns and ns[-1]:
             f |= F_NS_LAST
+        if any(ns):
+            # which pieces survive the filter: d is a subsequence of full
+            surv, k = [], 0
+            for y in full:
+                hit = k < len(d) and d[k] == y
+                surv.append(hit)
+                k += hit
+            assert k == len(d) and len(full) <= 4, hex(cp)
+            for q in range(1, len(ns)):
+                assert ns[q] or not ns[q - 1], hex(cp)     # starters first, then non-starters
+            nfd_pieces[cp] = (full, ns, surv)
         flags[cp] = f
+    # relative combining classes of every non-starter: Python's table is the hint, the wheel's NFD the judge (x sorts after y iff
+    # NFD swaps "x y"); characters the hint gets wrong, or does not know, are placed by probing
+    import unicodedata
+    marks = sorted({y for full, ns, _ in nfd_pieces.values() for y, f in zip(full, ns) if f})
+    swaps = lambda x, y: x != y and nfd.normalize_str("a" + x + y) == "a" + y + x
+    reps = {}
+    for y in marks:
+        reps.setdefault(unicodedata.combining(y), y)
+    order = sorted(k for k in reps if k)
+    for a, b in zip(order, order[1:]):
+        assert swaps(reps[b], reps[a]) and not swaps(reps[a], reps[b]), (a, b)
+    cls_of = {}
+    for y in marks:
+        k = unicodedata.combining(y)
+        ok = k in order and not swaps(y, reps[k]) and not swaps(reps[k], y)
+        if ok:
+            i = order.index(k)
+            ok = (i == 0 or swaps(y, reps[order[i - 1]])) and (i + 1 == len(order) or swaps(reps[order[i + 1]], y))
+        if not ok:                                   # place it among the representatives by probing
+            k = next((c for c in order if not swaps(y, reps[c]) and not swaps(reps[c], y)), None)
+            assert k is not None, f"U+{ord(y):04X}: a combining class of its own"
+        cls_of[y] = order.index(k) + 1
+    assert len(order) < 64
     runs = []
     start, cur = 0, flags[0]
     for cp in range(1, 0x110000):
@@ -101,7 +136,9 @@ def main():
         fh.write("// flags: 1 DROP (clean_text removes), 2 WS (clean_text maps to ' '), 4 CJK, 8 REORDER (ccc>0, survives the Mn filter),\n")
         fh.write("//        16 D (NFD + Mn-strip is not the identity), 32 LC (to_lowercase is not the identity),\n")
         fh.write("//        64 NS_FIRST / 128 NS_LAST (the first / last piece of the character's NFD form has a non-zero combining class)\n")
-        fh.write(f"#define BN_N_RUNS {len(runs)}\n#define BN_N_D {len(dmap)}\n#define BN_N_LC {len(lcmap)}\n")
+        fh.write("// NFD: for every character whose NFD form holds a non-starter: cp, then n | piece q at bit 3 + 7q: class rank (6 bits, 0 = starter,\n")
+        fh.write("//      otherwise the rank of its canonical combining class among the classes in use) | survives the Mn filter << 6\n")
+        fh.write(f"#define BN_N_RUNS {len(runs)}\n#define BN_N_D {len(dmap)}\n#define BN_N_LC {len(lcmap)}\n#define BN_N_NFD {len(nfd_pieces)}\n")
         fh.write("#ifdef BN_WANT_RUNS\n")
         for a, b, f in runs:
             fh.write(f"{{0x{a:X},0x{b:X},{f}}},\n")
@@ -113,9 +150,16 @@ def main():
         for cp in sorted(lcmap):
             v = lcmap[cp] + [0x1FFFFF] * (3 - len(lcmap[cp]))
             fh.write(f"{{0x{cp:X},0x{v[0]:X},0x{v[1]:X},0x{v[2]:X}}},\n")
+        fh.write("#endif\n#ifdef BN_WANT_NFD\n")
+        for cp in sorted(nfd_pieces):
+            full, ns, surv = nfd_pieces[cp]
+            v = len(full)
+            for q, (y, f, sv) in enumerate(zip(full, ns, surv)):
+                v |= ((cls_of[y] if f else 0) | (int(sv) << 6)) << (3 + 7 * q)
+            fh.write(f"{{0x{cp:X},0x{v:X}}},\n")
         fh.write("#endif\n")
     cnt = lambda bit: sum(1 for cp in range(0x110000) if flags[cp] & bit)
-    print(f"runs={len(runs)} drop={cnt(1)} ws={cnt(2)} cjk={cnt(4)} reorder={cnt(8)} ns_first={cnt(64)} ns_last={cnt(128)} D={len(dmap)} LC={len(lcmap)}")
+    print(f"runs={len(runs)} drop={cnt(1)} ws={cnt(2)} cjk={cnt(4)} reorder={cnt(8)} ns_first={cnt(64)} ns_last={cnt(128)} D={len(dmap)} LC={len(lcmap)} NFD={len(nfd_pieces)} classes={len(order)}")
 
 
 if __name__ == "__main__":

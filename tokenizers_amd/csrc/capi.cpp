@@ -1308,8 +1308,8 @@ int error_from_bits(int bits) {
         return set_error(TKAMD_ERR_UNSUPPORTED, "pre-tokens longer than 8192 bytes exceed the 1 GiB scratch slab of the global-memory merge path");
     if (bits & ERR_NON_ASCII_NORM)
         return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: a character with a non-zero combining class that survives the Mn filter "
-                                                "stands next to another combining character; NFD's canonical ordering would move it (or its offsets) "
-                                                "across characters (not built on the device)");
+                                                "stands in a run of more than 48 combining characters; NFD's canonical ordering of such a run is not built "
+                                                "on the device");
     if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal invariant violated");
     if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
     if (bits & ERR_TRUNC_SECOND) return set_error(TKAMD_ERR_INVALID, "Truncation error: Second sequence not provided");

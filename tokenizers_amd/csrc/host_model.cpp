@@ -40,6 +40,14 @@ const BnMapRow kBnLC[] = {
 #include "bert_norm_tables.inc"
 };
 #undef BN_WANT_LC
+struct BnNfdRow {
+    uint32_t cp, packed;
+};
+#define BN_WANT_NFD
+const BnNfdRow kBnNFD[] = {
+#include "bert_norm_tables.inc"
+};
+#undef BN_WANT_NFD
 
 // GPT-2 bytes <-> unicode map, pre_tokenizers/byte_level.rs:15-39: printable bytes map to
 // themselves, the other 68 bytes to U+0100+n in byte order.
@@ -310,6 +318,7 @@ void build_bert_norm(HostModel& m) {
     };
     for (const BnMapRow& r : kBnD) add(r, 0);
     for (const BnMapRow& r : kBnLC) add(r, 1);
+    for (const BnNfdRow& r : kBnNFD) items.push_back(MergeSlot{r.cp, 2u, r.packed, 0u});      // kind 2: classes of the NFD pieces (bert_norm_core.hpp)
     build_pair_table(items, &m.bn_map, &m.bn_mask, &m.bn_seed);
 }
 

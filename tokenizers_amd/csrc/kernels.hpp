@@ -222,7 +222,7 @@ enum : int {
     ERR_TOO_MANY_TOKENS = 256,
     ERR_TRUNC_SHORT = 512,        // OnlyFirst / OnlySecond: the sequence to cut is not longer than what must go (TruncationError::SequenceTooShort)    // the padded batch has more than 2^32 tokens
     ERR_TRUNC_STRIDE = 1024,      // a sequence has to be cut to max_len tokens and stride >= max_len (the assert of Encoding::truncate, encoding.rs:319)
-    NOTE_REORDER_SEEN = 2048,     // not an error: the normalizer met a character NFD's canonical ordering could move (k_bn_reorder_check then looks at its neighbours)
+    NOTE_REORDER_SEEN = 2048,     // not an error: the normalizer met a character NFD's canonical ordering could move (k_bn_reorder_fix then looks at its neighbours)
     ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
 

@@ -12,8 +12,8 @@
 // source character of every normalised byte (an inserted char keeps its source char's alignment,
 // tokenizer/normalizer.rs:317-428).  The one context-dependent step -- NFD's canonical ordering -- shows only on a character
 // that survives the Mn filter with a non-zero combining class, and only if it shares its run of non-starters with another one
-// (bert_norm_core.hpp): alone in its run it stays where the per-character expansion puts it; otherwise ERR_NON_ASCII_NORM
-// (document refused) instead of guessing.
+// (bert_norm_core.hpp): alone in its run it stays where the per-character expansion puts it; otherwise k_bn_reorder_fix sorts that
+// run and re-aligns it the way the reference's transform does.
 // =================================================================================================
 constexpr uint32_t BN_DROP = 1, BN_WS = 2, BN_CJK = 4, BN_REORDER = 8, BN_D = 16, BN_LC = 32;
 constexpr int BN_MAX_OUT = 12;
@@ -78,9 +78,12 @@ __device__ __forceinline__ uint32_t sw_ascii_dropped(uint32_t x) { return (sw_lt
 // bits [i0, i0 + 16) of a bit mask (i0 a multiple of 16)
 __device__ __forceinline__ uint32_t mask16(const unsigned long long* __restrict__ m, int64_t i0) { return (uint32_t)(m[i0 >> 6] >> (i0 & 63)) & 0xFFFFu; }
 
-// a REORDER character at byte i: refuse the batch unless it is alone in its run of non-starters
-__device__ __forceinline__ void bn_check_reorder(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t cp, uint32_t len,
-                                                 const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
+// a REORDER character at byte i: nothing to do if it is alone in its run of non-starters; otherwise the run is put into NFD's canonical
+// order (survivors rewritten in the normalised text, with the alignments transform() would give them)
+__device__ __forceinline__ void bn_fix_reorder(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t cp, uint32_t len,
+                                               const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs,
+                                               const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase, uint8_t* __restrict__ ntext,
+                                               uint32_t* __restrict__ nos, uint32_t* __restrict__ noe, int* __restrict__ err) {
     // the document holding byte i: the last d with doc_off[d] <= i
     int64_t lo = 0, hi = n_docs;
     while (lo < hi) {
@@ -88,7 +91,10 @@ __device__ __forceinline__ void bn_check_reorder(const BnTables& bt, const uint8
         if (doc_off[m] <= i) lo = m; else hi = m - 1;
     }
     const int64_t da = max(doc_off[lo], (int64_t)0), db = min(lo < n_docs ? doc_off[lo + 1] : n_bytes, n_bytes);
-    if (!bn_alone_in_run(bt.bn1, bt.bn2, bt.clean != 0u, text, da, db, i, len, bn_flags(bt, cp), vmask)) atomicOr(err, ERR_NON_ASCII_NORM);
+    const uint32_t f = bn_flags(bt, cp);
+    if (bn_alone_in_run(bt.bn1, bt.bn2, bt.clean != 0u, text, da, db, i, len, f, vmask)) return;
+    const BnCoreTables ct{bt.bn1, bt.bn2, bt.map, bt.map_mask, bt.map_seed, bt.clean != 0u};
+    if (!bn_fix_run(ct, text, da, db, i, len, f, vmask, olen, wbase, ntext, nos, noe)) atomicOr(err, ERR_NON_ASCII_NORM);
 }
 
 // output bytes of source byte i, the table-driven way (any byte)
@@ -101,7 +107,7 @@ __device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint
     bool reorder = false;
     const uint32_t cp = utf8_global(text, i, &len);
     const int n = bn_expand(bt, cp, out, &reorder);
-    if (reorder) atomicOr(err, NOTE_REORDER_SEEN);              // (k_bn_reorder_check decides; the hot kernel only takes note)
+    if (reorder) atomicOr(err, NOTE_REORDER_SEEN);              // (k_bn_reorder_fix looks at it; the hot kernel only takes note)
     for (int q = 0; q < n; ++q) ob += utf8_len_cp(out[q]);
     return ob;
 }
@@ -131,11 +137,14 @@ __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __
     if ((threadIdx.x & 3) == 0 && i0 <= n_bytes) wsum[i0 >> 6] = s;
 }
 
-// Runs behind k_bn_count and does nothing unless that kernel met a REORDER character (NOTE_REORDER_SEEN): then every such character of
+// Runs behind k_bn_write and does nothing unless k_bn_count met a REORDER character (NOTE_REORDER_SEEN): then every such character of
 // the text -- a lead byte of a 2..4-byte sequence whose table flags say so, outside the verbatim added-token matches -- is looked at
-// with its neighbours, and the batch is refused if one of them is not alone in its run of non-starters (bert_norm_core.hpp).
-__global__ __launch_bounds__(256) void k_bn_reorder_check(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
-                                                          const int64_t* __restrict__ doc_off, int64_t n_docs, int* __restrict__ err) {
+// with its neighbours; one that is not alone in its run of non-starters has that run put into NFD's canonical order
+// (bert_norm_core.hpp).  A run longer than BN_RUN_MAX pieces refuses the batch.
+__global__ __launch_bounds__(256) void k_bn_reorder_fix(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
+                                                        const int64_t* __restrict__ doc_off, int64_t n_docs, const uint8_t* __restrict__ olen,
+                                                        const uint32_t* __restrict__ wbase, uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos,
+                                                        uint32_t* __restrict__ noe, int* __restrict__ err) {
     if (!(*err & NOTE_REORDER_SEEN) || !bt.strip) return;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_bytes; i += (int64_t)gridDim.x * 256) {
         const uint32_t b = text[i];
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bn_reorder_check(BnTables bt, const uin
         if (verbatim && ((verbatim[i >> 6] >> (i & 63)) & 1ull)) continue;
         uint32_t len;
         const uint32_t cp = utf8_global(text, i, &len);
-        if (bn_flags(bt, cp) & BN_REORDER) bn_check_reorder(bt, text, n_bytes, i, cp, len, verbatim, doc_off, n_docs, err);
+        if (bn_flags(bt, cp) & BN_REORDER) bn_fix_reorder(bt, text, n_bytes, i, cp, len, verbatim, doc_off, n_docs, olen, wbase, ntext, nos, noe, err);
     }
 }
 

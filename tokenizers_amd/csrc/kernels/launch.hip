@@ -113,12 +113,14 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                            uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err) {
     const int64_t n_words = (n_bytes >> 6) + 1;
     hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, olen, wsum, err);
-    hipLaunchKernelGGL(k_bn_reorder_check, dim3(std::min<unsigned>(blocks_for(n_bytes + 1, 256), 2048u)), dim3(256), 0, st, bt, text, n_bytes, verbatim, doc_off, n_docs, err);
+
     unsigned nb = blocks_for(n_words, 256);
     hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, bsum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
     hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, (const uint32_t*)bsum, wbase);
     hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
+    hipLaunchKernelGGL(k_bn_reorder_fix, dim3(std::min<unsigned>(blocks_for(n_bytes + 1, 256), 2048u)), dim3(256), 0, st, bt, text, n_bytes, verbatim, doc_off, n_docs,
+                       (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe, err);
     hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
