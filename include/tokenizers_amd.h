@@ -241,6 +241,11 @@ int tkamd_probe_bert_norm(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* out
  * device puts that run into canonical order (csrc/bert_norm_core.hpp bn_fix_run).  The very function the kernels call, on the host
  * copy of the tables. */
 int tkamd_probe_bert_alone(const tkamd_tokenizer* tok, const uint8_t* text, int64_t n, int64_t pos, int32_t* reorder, int32_t* alone);
+/* The NFD form of one code point as bn_fix_run sees it, from the host copy of the tables: *packed = n | per piece q, at bit 3 + 7q,
+ * (rank of its canonical combining class among the classes in use, 0 = starter) | (survives the Mn filter) << 6; 0: no piece of
+ * the form is a non-starter.  *flags = the per-character table flags (1 dropped by clean_text, 2 whitespace, 4 CJK, 8 reorderable,
+ * 16 / 32 has an NFD / lowercase expansion, 64 / 128 first / last piece is a non-starter). */
+int tkamd_probe_bert_nfd(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* packed, uint32_t* flags);
 /* Class flags of one code point from the host copy of the generated Unicode table: bit 0 \p{L}, 1 \p{N}, 2 \s (as
  * Oniguruma sees them, byte_level.rs:43-46), 3 \w, 4 \s (regex crate, whitespace.rs:22), 5 char::is_whitespace, 6 is_bert_punc. */
 int tkamd_probe_unicode_flags(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* flags);

@@ -677,3 +677,64 @@ def test_add_tokens_matches_the_wheel(ref_tokenizers):
             assert t.get_vocab() == r.get_vocab(), (name, toks)
         assert json.loads(t._json)["added_tokens"] == json.loads(r.to_str())["added_tokens"], name
         assert t.token_to_id("<new1>") == r.token_to_id("<new1>") and t.id_to_token(t.token_to_id("<pad2>")) == "<pad2>"
+
+
+def test_nfd_piece_table_matches_the_wheel_for_every_code_point(ref_tokenizers):
+    """The data bn_fix_run works from (host copy of the load-time tables, tkamd_probe_bert_nfd), against the wheel over all 1,112,064
+    scalar values: the number of pieces of every NFD form, which of them are non-starters (NFD moves them past a class-1 mark or before
+    a class-230 one), which survive the Mn filter, the first / last-piece flags; and the class ranks order any two non-starters the
+    way NFD does (every character against one representative of its own, the next lower and the next higher class)."""
+    import unicodedata
+    nfd = ref_tokenizers.normalizers.NFD()
+    strip = ref_tokenizers.normalizers.BertNormalizer(clean_text=False, handle_chinese_chars=False, strip_accents=True, lowercase=False)
+    t = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=-1)
+    lib, h = t._lib, t._h
+    pk, fl = C.c_uint32(0), C.c_uint32(0)
+    ns_cache = {}
+
+    def non_starter(y):
+        if y not in ns_cache:
+            ns_cache[y] = nfd.normalize_str("a" + y + "\u0334") != "a" + y + "\u0334" or nfd.normalize_str("a\u0301" + y) != "a\u0301" + y
+        return ns_cache[y]
+    rank_of, n_rows = {}, 0
+    for cp in range(0x110000):
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        assert lib.tkamd_probe_bert_nfd(h, cp, C.byref(pk), C.byref(fl)) == 0
+        c = chr(cp)
+        full = nfd.normalize_str(c)
+        if full == c and pk.value == 0 and not (fl.value & (64 | 128)):
+            # no decomposition and no table entry: right unless the character is a non-starter itself.  Probed for everything up to
+            # U+323F, for what Python's own tables call a mark or give a combining class, and for every 16th of the rest.
+            if cp > 0x323F and cp % 16 and not unicodedata.category(c).startswith("M") and not unicodedata.combining(c):
+                continue
+
+        ns = [non_starter(y) for y in full]
+        assert bool(fl.value & 64) == bool(ns and ns[0]) and bool(fl.value & 128) == bool(ns and ns[-1]), hex(cp)
+        if not any(ns):
+            assert pk.value == 0, hex(cp)
+            continue
+        n_rows += 1
+        d = strip.normalize_str(c)
+        assert (pk.value & 7) == len(full), hex(cp)
+        k = 0
+        for q, y in enumerate(full):
+            cls, surv = (pk.value >> (3 + 7 * q)) & 63, (pk.value >> (9 + 7 * q)) & 1
+            assert bool(cls) == ns[q], hex(cp)
+            hit = k < len(d) and d[k] == y
+            assert surv == int(hit), hex(cp)
+            k += hit
+            if cls:
+                assert rank_of.setdefault(y, cls) == cls, hex(cp)
+        assert k == len(d)
+    assert n_rows == 1804 or n_rows > 1700
+    reps = {}
+    for y, r in rank_of.items():
+        reps.setdefault(r, y)
+    swaps = lambda x, y: x != y and nfd.normalize_str("a" + x + y) == "a" + y + x
+    for y, r in rank_of.items():
+        assert not swaps(y, reps[r]) and not swaps(reps[r], y), hex(ord(y))
+        if r - 1 in reps:
+            assert swaps(y, reps[r - 1]), hex(ord(y))
+        if r + 1 in reps:
+            assert swaps(reps[r + 1], y), hex(ord(y))

@@ -37,7 +37,7 @@ SYMBOLS = [
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version", "tkamd_word_cache",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
-    "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts",
+    "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd",
 ]
 
 
@@ -145,6 +145,8 @@ def load() -> C.CDLL:
     lib.tkamd_probe_truncation.restype = i32
     lib.tkamd_probe_bert_alone.argtypes = [vp, C.c_char_p, i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.tkamd_probe_bert_alone.restype = i32
+    lib.tkamd_probe_bert_nfd.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32)]
+    lib.tkamd_probe_bert_nfd.restype = i32
     _lib = lib
     return lib
 

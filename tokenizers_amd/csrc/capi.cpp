@@ -1884,6 +1884,17 @@ int tkamd_probe_bert_alone(const tkamd_tokenizer* t, const uint8_t* text, int64_
     return TKAMD_OK;
 }
 
+int tkamd_probe_bert_nfd(const tkamd_tokenizer* t, uint32_t cp, uint32_t* packed, uint32_t* flags) {
+    if (!t || !packed || !flags) return set_error(TKAMD_ERR_INVALID, "null argument");
+    const HostModel& hm = t->hm;
+    if (hm.norm != NORM_BERT) return set_error(TKAMD_ERR_UNSUPPORTED, "the tokenizer has no BertNormalizer");
+    const BnCoreTables ct{hm.bn_stage1.data(), hm.bn_stage2.data(), hm.bn_map.data(), hm.bn_mask, hm.bn_seed, hm.bn_clean_text};
+    uint32_t lo = 0, hi = 0;
+    *packed = bn_core_map(ct, cp, 2u, &lo, &hi) ? lo : 0u;
+    *flags = bn_core_flags(ct.bn1, ct.bn2, cp);
+    return TKAMD_OK;
+}
+
 int64_t tkamd_text_n_docs(const tkamd_text* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_text_n_bytes(const tkamd_text* b) { return b ? b->n_bytes : 0; }
 const uint8_t* tkamd_text_bytes(const tkamd_text* b) { return b ? (const uint8_t*)b->bytes.p : nullptr; }
