@@ -329,6 +329,20 @@ def main() -> None:
                 "gbps_from_list_of_str": round(batches[0].n_bytes / (best + t_pack) / 1e9, 3),
                 "note": "tkamd_encode_batch wall clock: H2D of text + CSR, kernels, D2H of ids + CSR into pinned host memory"}
         assert res.n_tokens == batches[0].n_tok
+        try:        # the same call handing the ids back as 16-bit values (TKAMD_IDS_U16: GPT-2-sized vocabularies; half the D2H bytes)
+            r16 = tok.encode_packed(hb, ho, ids_dtype="uint16")
+            best16 = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r16 = tok.encode_packed(hb, ho, ids_dtype="uint16")
+                best16 = min(best16, time.perf_counter() - t0)
+            if r16.n_tokens == batches[0].n_tok and bool((r16.ids[:100000] == res.ids[:100000]).all()):
+                host["encode_packed_ids_u16_ms"] = round(best16 * 1e3, 2)
+                host["gbps_pcie_inclusive_ids_u16"] = round(batches[0].n_bytes / best16 / 1e9, 3)
+            else:
+                host["encode_packed_ids_u16_error"] = "result differs"
+        except Exception as ex:     # (vocabularies beyond 65,535 ids: refused -- not an error of the bench)
+            host["encode_packed_ids_u16_error"] = repr(ex)[:200]
         try:        # the same from a Python list[str] through the tokenizer's reusable staging (what a caller of encode_batch_fast feels)
             tok.encode_batch_fast(lines, add_special_tokens=False)
             best2 = float("inf")

@@ -257,3 +257,27 @@ def test_pair_overflowing_encodings_match_wheel(k):
     assert_pair_overflow(got, c, (c["tokenizer"], pp if isinstance(pp, str) or pp is None else pp["type"], c["truncation"], c["padding"], c["add_special_tokens"]))
     plain = tok.encode_batch_csr(inputs, offsets="none", add_special_tokens=c["add_special_tokens"])
     assert plain.enc_docs is None and [plain[i].ids for i in range(len(plain))] == [x[0]["ids"] for x in c["encodings"]]
+
+
+def test_ids_as_16_bit_values():
+    """TKAMD_IDS_U16: the host entry narrows the ids on the device and copies two bytes a token; same ids, same CSR; a vocabulary
+    with ids beyond 65,535 is refused; works behind the special-token epilogue."""
+    import numpy as np
+    import tokenizers_amd as ta
+    from oracle import synth
+    docs = synth.gen_lines(3000, text_seed=9) + ["", "x", "it's"]
+    for name in ("bytelevel_prefix_trim_3000", "bert_wordpiece_4000_specials"):
+        tok = ta.Tokenizer.from_str(load_tokenizer_json(name), device=0)
+        buf, off = ta.pack_documents(docs)
+        for special in (False, True):
+            a = tok.encode_packed(buf, off, add_special_tokens=special)
+            b = tok.encode_packed(buf, off, add_special_tokens=special, ids_dtype="uint16")
+            assert b.ids.dtype == np.uint16 and np.array_equal(a.ids, b.ids.astype(np.uint32)) and np.array_equal(a.tok_offsets, b.tok_offsets)
+    d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
+    big = max(d["model"]["vocab"].values()) + 1
+    d["added_tokens"].append({"id": 70000, "content": "<far>", "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": True})
+    tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
+    assert big < 65536
+    assert tok.encode_packed(*ta.pack_documents(["no such token here"]), ids_dtype="uint16").ids.dtype == np.uint16
+    with pytest.raises(ValueError, match="65,535"):
+        tok.encode_packed(*ta.pack_documents(["a <far> b"]), ids_dtype="uint16")

@@ -86,6 +86,7 @@ def test_epilogues_match_wheel():
     for k in _every(E.PAIR_OVERFLOW_CASES, 5, _small):
         E.test_pair_overflowing_encodings_match_wheel(k)
     E.test_enable_truncation_and_padding_at_run_time()
+    E.test_ids_as_16_bit_values()
 
 
 def test_normalizer_added_vocabulary_and_models(ref_tokenizers):

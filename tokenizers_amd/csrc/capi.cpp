@@ -107,6 +107,7 @@ struct Workspace {
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off, h_seq_off;
+    DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
     DevBuf w_seq_off, w_seq_tok_off, w_word_idx;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
@@ -192,9 +193,9 @@ static void pinned_put(PinnedBlock b) {
 
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs, enc_parts;
-    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false, has_enc_parts = false;
-    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); pinned_put(enc_parts); }
+    PinnedBlock ids, ids16, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs, enc_parts;
+    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false, has_enc_parts = false, has_ids16 = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(ids16); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); pinned_put(enc_parts); }
 };
 
 struct tkamd_text {
@@ -1561,7 +1562,14 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         std::unique_ptr<std::lock_guard<std::mutex>> g1(l1 ? new std::lock_guard<std::mutex>(ws[1]->mu) : nullptr);
         hipStream_t st[2] = {own_stream(ws[0]), own_stream(ws[1])};
 
+        const bool ids16 = (flags & TKAMD_IDS_U16) != 0;
+        if (ids16)
+            for (int q = 0; q < (l1 ? 2 : 1); ++q) {
+                ws[q]->w_wide.reserve(64);
+                HIP_CHECK(hipMemsetAsync(ws[q]->w_wide.p, 0, 4, st[q]));
+            }
         std::unique_ptr<tkamd_batch> b(new tkamd_batch());
+        b->has_ids16 = ids16;
         b->n_docs = n_enc;
         b->tok_offsets = pinned_get((size_t)(n_enc + 1) * 8);
         tkamd_device_result res[8]{};
@@ -1633,13 +1641,19 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                     HIP_CHECK(hipStreamSynchronize(st[0]));
                     HIP_CHECK(hipStreamSynchronize(st[1]));
                 }
-                grow(b->ids, 4, est, (size_t)tok_base);
+                if (ids16) grow(b->ids16, 2, est, (size_t)tok_base);
+                else grow(b->ids, 4, est, (size_t)tok_base);
                 if (r.d_offsets) grow(b->offsets, 8, est, (size_t)tok_base);
                 if (r.d_word_ids) grow(b->word_ids, 4, est, (size_t)tok_base);
                 if (r.d_type_ids) { grow(b->type_ids, 1, est, (size_t)tok_base); grow(b->seq_ids, 1, est, (size_t)tok_base); }
                 tok_cap = est;
             }
-            if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
+            if (ids16) {
+                // half the bytes on the way back: narrow on the device, copy 2 bytes a token
+                w->w_ids16.reserve((size_t)n_tok * 2 + 64);
+                launch_narrow_ids(s, r.d_ids, n_tok, w->w_ids16.as<uint16_t>(), w->w_wide.as<int>());
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint16_t*)b->ids16.p + tok_base, w->w_ids16.p, (size_t)n_tok * 2, hipMemcpyDeviceToHost, s));
+            } else if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
             if (tok_base) launch_add_i64(s, (int64_t*)r.d_tok_offsets, d1 - d0 + 1, tok_base);   // the slice's CSR continues the batch's
             HIP_CHECK(hipMemcpyAsync((int64_t*)b->tok_offsets.p + d0, r.d_tok_offsets, (size_t)(d1 - d0 + 1) * 8, hipMemcpyDeviceToHost, s));
             if (r.d_offsets) {
@@ -1677,8 +1691,16 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         HIP_CHECK(hipStreamSynchronize(st[0]));
         HIP_CHECK(hipStreamSynchronize(st[1]));
         if (bits) return error_from_bits(bits);
+        if (ids16) {
+            for (int q = 0; q < (l1 ? 2 : 1); ++q) {
+                int wide = 0;
+                HIP_CHECK(hipMemcpy(&wide, ws[q]->w_wide.p, 4, hipMemcpyDeviceToHost));
+                if (wide) throw Invalid("TKAMD_IDS_U16: the batch holds a token id beyond 65,535");
+            }
+            if (!b->ids16.p) b->ids16 = pinned_get(64);
+        }
         b->n_tokens = tok_base;
-        if (!b->ids.p) b->ids = pinned_get(64);
+        if (!b->ids.p && !ids16) b->ids = pinned_get(64);
         *out = b.release();
         return TKAMD_OK;
     });
@@ -1701,7 +1723,8 @@ const uint8_t* tkamd_batch_type_ids(const tkamd_batch* b) { return (b && b->has_
 const uint8_t* tkamd_batch_sequence_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->seq_ids.p : nullptr; }
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_batch_n_tokens(const tkamd_batch* b) { return b ? b->n_tokens : 0; }
-const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? (const uint32_t*)b->ids.p : nullptr; }
+const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return (b && !b->has_ids16) ? (const uint32_t*)b->ids.p : nullptr; }
+const uint16_t* tkamd_batch_ids16(const tkamd_batch* b) { return (b && b->has_ids16) ? (const uint16_t*)b->ids16.p : nullptr; }
 const int64_t* tkamd_batch_tok_offsets(const tkamd_batch* b) { return b ? (const int64_t*)b->tok_offsets.p : nullptr; }
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b) { return (b && b->has_offsets) ? (const uint32_t*)b->offsets.p : nullptr; }
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b) { return (b && b->has_words) ? (const uint32_t*)b->word_ids.p : nullptr; }

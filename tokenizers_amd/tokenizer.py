@@ -663,13 +663,19 @@ class Tokenizer:
             return self.encode_packed(buf, word_off, offsets, word_ids, add_special_tokens, pairs, np.asarray(seq_off, dtype=np.int64), overflowing)
 
     def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
-                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None, overflowing: bool = False) -> BatchEncoding:
+                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None, overflowing: bool = False,
+                      ids_dtype: str = "uint32") -> BatchEncoding:
         """``pairs``: documents 2i and 2i+1 are sequence A and B of encoding i (EncodeInput::Dual, tokenizer/mod.rs:871-889).
         ``seq_off``: the documents are the words of pre-tokenized sequences, sequence s = words [seq_off[s], seq_off[s+1]).
-        ``overflowing``: TKAMD_WANT_OVERFLOW -- the result then also holds every input's overflowing encodings."""
+        ``overflowing``: TKAMD_WANT_OVERFLOW -- the result then also holds every input's overflowing encodings.
+        ``ids_dtype`` "uint16": TKAMD_IDS_U16 -- the ids come back as 16-bit values (half the PCIe bytes; vocabularies below 65,536)."""
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
         if overflowing:
             flags |= _lib.WANT_OVERFLOW
+        if ids_dtype not in ("uint32", "uint16"):
+            raise ValueError("ids_dtype must be 'uint32' or 'uint16'")
+        if ids_dtype == "uint16":
+            flags |= _lib.IDS_U16
         if pairs:
             flags |= _lib.PAIRS
         if word_ids:
@@ -701,7 +707,8 @@ class Tokenizer:
             carr._owner = owner
             return np.ctypeslib.as_array(carr).reshape(shape)
 
-        ids = view(self._lib.tkamd_batch_ids(b), C.c_uint32, (nt,), np.uint32)
+        ids = view(self._lib.tkamd_batch_ids16(b), C.c_uint16, (nt,), np.uint16) if ids_dtype == "uint16" else \
+            view(self._lib.tkamd_batch_ids(b), C.c_uint32, (nt,), np.uint32)
         to = view(self._lib.tkamd_batch_tok_offsets(b), C.c_int64, (n_docs + 1,), np.int64)
         offs = wids = None
         if offsets != "none":
