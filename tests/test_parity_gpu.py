@@ -177,7 +177,7 @@ def test_bert_normalizer_unicode_vs_oracle():
     pool = ["é", "É", "ñ", "中", "文", "日本", "ÀB", "İ", "ǅ", "ﬁ", "Å", "한국어", "ö", "ß", "Ω", "Σς", "ё", "é", "\u00a0", "\u200b", "\u3000",
             "\u2028", "😀", "naïve", "CAFÉ", "ẞ", "ệ", "a", "B", "-", "!", "12", " ", "x̣́", "\ufeff", "\u00ad", "\x01", "\t", "丽", "豈"]
     docs = ["".join(random.choice(pool) for _ in range(random.randint(1, 20))) for _ in range(6000)]
-    docs += [d for d in synth.gen_lines(4000, text_seed=37) + synth.stress_lines(seed=14, n=3000) if "[" not in d and "\u302e" not in d]
+    docs += [d for d in synth.gen_lines(4000, text_seed=37) + synth.stress_lines(seed=14, n=3000) if "[" not in d]
     docs += ["", "中", "é", "\u0301", "\u0301\u0301", "İ" * 40, "中" * 120, "é" * 101]
     _meta_compare(tok, o, docs)
 
@@ -440,8 +440,6 @@ def test_full_added_vocabulary_vs_oracle(name):
     pieces = toks + [t.lower() for t in toks] + [t.upper() for t in toks] + [t[:-1] for t in toks if len(t) > 1] + \
         [" ", "  ", "\n", "\t", "a", "ing", "x", "hello", "World", "é", "中", "!", "-", "1"]
     docs = ["".join(random.choice(pieces) for _ in range(random.randint(1, 12))) for _ in range(30000)] + synth.gen_lines(3000, text_seed=53)
-    if name.startswith("bert"):
-        docs = [d for d in docs if "\u302e" not in d]
     _meta_compare(tok, o, docs)
 
 
@@ -643,7 +641,7 @@ def test_word_cache_never_changes_a_result(name, gpt2_json):
     tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
     a = synth.gen_lines(30000, text_seed=201) + synth.stress_lines(seed=31, n=1500)
     b = synth.gen_lines(30000, text_seed=202, type_seed=1) + ["", "x" * 5000, "a" * 17 + " " + "b" * 16]
-    if name.startswith("bert"):            # (the 96 reorderable marks are refused: another test)
+    if name.startswith("bert"):            # (the normalizer's reorderable marks have a test of their own)
         a, b = [d for d in a if "\u302e" not in d], [d for d in b if "\u302e" not in d]
     exp_a, exp_b = o.encode_batch(a), o.encode_batch(b)
 
