@@ -281,3 +281,48 @@ def test_ids_as_16_bit_values():
     assert tok.encode_packed(*ta.pack_documents(["no such token here"]), ids_dtype="uint16").ids.dtype == np.uint16
     with pytest.raises(ValueError, match="65,535"):
         tok.encode_packed(*ta.pack_documents(["a <far> b"]), ids_dtype="uint16")
+
+
+def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers):
+    """A seeded walk over truncation x padding x post-processor x single / pair settings the golden grids do not hold, against the
+    wheel run here: every field of every encoding, its overflowing ones and their nested lists.  It is how two corners were found --
+    process_offsets (byte_level.rs:202-234) runs on the CUT encoding, so a token that becomes the first of a window keeps the one
+    leading space that stands for the prefix space (and a lone-space token then loses its END to the trailing trim); and max_length 0
+    cuts everything before the strategy is looked at, so OnlySecond on a single sequence is no error there
+    (utils/truncation.rs:75-81)."""
+    import random
+    import tokenizers_amd as ta
+    from oracle import synth
+    rnd = random.Random(20240611)
+    lines = [d[:rnd.randint(0, 140)] for d in synth.gen_lines(300, text_seed=5)] + ["", "a", "x y", "two  spaces\tand a tab  here", "  lead", "trail  "]
+    fields = lambda e: (e.ids, e.type_ids, e.attention_mask, e.special_tokens_mask, [tuple(o) for o in e.offsets], e.word_ids, e.sequence_ids)
+    n_over = 0
+    for case in range(36):
+        name = ("bytelevel_prefix_trim_3000", "bert_wordpiece_4000_specials", "llama3_small_6000_specials")[case % 3]
+        d = json.loads(load_tokenizer_json(name))
+        trunc = {"direction": rnd.choice(["Right", "Left"]), "max_length": rnd.choice([0, 1, 2, 3, 5, 8, 13, 21, 40]),
+                 "strategy": rnd.choice(["LongestFirst", "OnlyFirst", "OnlySecond"]), "stride": rnd.choice([0, 0, 1, 2, 3, 7])}
+        pad = rnd.choice([None, None, {"strategy": rnd.choice(["BatchLongest", {"Fixed": rnd.choice([4, 16, 33])}]), "direction": rnd.choice(["Right", "Left"]),
+                                       "pad_to_multiple_of": rnd.choice([None, None, 4, 7]), "pad_id": rnd.choice([0, 3]), "pad_type_id": rnd.choice([0, 1]), "pad_token": "[PAD]"}])
+        d["truncation"], d["padding"] = (None if rnd.random() < 0.1 else trunc), pad
+        if rnd.random() < 0.2:
+            d["post_processor"] = None
+        js = json.dumps(d, ensure_ascii=False)
+        pairs, special = rnd.random() < 0.4, rnd.random() < 0.6
+        docs = [x for x in rnd.sample(lines, 24) if not (name.startswith("bert") and "[" in x)]
+        inputs = [(docs[2 * i], docs[2 * i + 1]) for i in range(len(docs) // 2)] if pairs else docs
+        ctx = (name, d["truncation"], pad, d.get("post_processor") is not None, pairs, special)
+        tok = ta.Tokenizer.from_str(js, device=0)
+        try:
+            exp = ref_tokenizers.Tokenizer.from_str(js).encode_batch(inputs, add_special_tokens=special)
+        except BaseException:                                # (a TruncationError, or the stride assert's panic)
+            with pytest.raises(ValueError):
+                tok.encode_batch(inputs, add_special_tokens=special)
+            continue
+        got = tok.encode_batch(inputs, add_special_tokens=special)
+        for i, e in enumerate(exp):
+            assert [fields(e)] + [fields(o) for o in e.overflowing] == [fields(got[i])] + [fields(o) for o in got[i].overflowing], ctx + (inputs[i],)
+            for o, go in zip(e.overflowing, got[i].overflowing):
+                assert [x.ids for x in o.overflowing] == [x.ids for x in go.overflowing], ctx + (inputs[i],)
+            n_over += len(e.overflowing)
+    assert n_over > 500

@@ -89,6 +89,11 @@ def test_epilogues_match_wheel():
     E.test_ids_as_16_bit_values()
 
 
+def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers):
+    from tests import test_epilogue_gpu as E
+    E.test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers)
+
+
 def test_normalizer_added_vocabulary_and_models(ref_tokenizers):
     from tests import test_parity_gpu as P
     P.test_bert_normalizer_reorderable_marks(ref_tokenizers)

@@ -107,6 +107,8 @@ struct Workspace {
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off, h_seq_off;
+    DevBuf w_trim1;                              // per token: process_offsets took one leading space off it (MetaArgs::trim1)
+    const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
@@ -512,6 +514,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
     w->last_n_docs = n_docs;
+    w->cur_trim1 = nullptr;
     w->last_n_enc = -1;
     out->d_enc_docs = nullptr;
     out->d_n_encodings = nullptr;
@@ -589,6 +592,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pa.ids = w->w_ids.as<uint32_t>();
         pa.offsets = out->d_offsets;
         pa.word_ids = out->d_word_ids;
+        pa.trim1 = pa.offsets ? w->cur_trim1 : nullptr;
         w->w_keep.reserve((size_t)(e_n + 2) * 4);
         pa.tpl = tpl_on ? t->t_pp_pair.as<uint32_t>() : t->t_pp_pair_plain.as<uint32_t>();
         pa.n_tpl = tpl_on ? (int32_t)hm.pp_pair.size() : (int32_t)hm.pp_pair_plain.size();
@@ -731,6 +735,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.ids = w->w_ids.as<uint32_t>();
         fa.offsets = out->d_offsets;
         fa.word_ids = out->d_word_ids;
+        fa.trim1 = fa.offsets ? w->cur_trim1 : nullptr;
         fa.prefix = t->t_pp_prefix.as<uint32_t>();
         fa.suffix = t->t_pp_suffix.as<uint32_t>();
         fa.n_prefix = add_special ? (int32_t)hm.pp_prefix.size() : 0;
@@ -1240,6 +1245,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.uc2 = t->dt.uc2;
         a.offsets = w->w_offsets.as<uint32_t>();
         a.word_ids = w->w_word_ids.as<uint32_t>();
+        if (a.want_offsets && a.trim_offsets && a.pp_add_prefix_space && hm.trunc_on) {      // (see MetaArgs::trim1)
+            w->w_trim1.reserve((size_t)n_x + 8);
+            a.trim1 = w->w_trim1.as<uint8_t>();
+            w->cur_trim1 = a.trim1;
+        }
         if (a.char_mode) {
             w->w_leadmask.reserve((size_t)(W0 + 1) * 8);
             w->w_lprefix.reserve((size_t)(W0 + 1) * 4);

@@ -102,6 +102,9 @@ struct MetaArgs {
     const uint8_t* uc2;
     uint32_t* offsets;                // [T][2]
     uint32_t* word_ids;               // [T]
+    uint8_t* trim1;                   // [T] or null: 1 where process_offsets took exactly one leading space off a token that is not the first of its
+                                      // document -- the truncation epilogue gives it back to a token that BECOMES the first of an encoding
+                                      // (byte_level.rs:213-222 keeps the one space add_prefix_space stands for on token 0 of whatever it processes)
 };
 
 // added-token patterns (AddedVocabulary), passed by value
@@ -140,6 +143,7 @@ struct FinalArgs {
     const uint32_t* ids;
     const uint32_t* offsets;          // null if not produced
     const uint32_t* word_ids;         // null if not produced
+    const uint8_t* trim1;             // MetaArgs::trim1 or null
     const uint32_t* prefix;           // special ids around every sequence (n_prefix = n_suffix = 0 without add_special_tokens)
     const uint32_t* suffix;
     int32_t n_prefix, n_suffix;
@@ -176,6 +180,7 @@ struct PairArgs {
     const uint32_t* ids;
     const uint32_t* offsets;          // null if not produced
     const uint32_t* word_ids;         // null if not produced
+    const uint8_t* trim1;             // MetaArgs::trim1 or null
     const uint32_t* tpl;              // [n_tpl][3] kind (0 A, 1 B, 2 special), id, type id
     int32_t n_tpl;
     uint32_t n_special;               // special tokens of the template (taken off max_length)

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void k_final_lens(FinalArgs a) {
     uint32_t l = 0;
     if (d < a.n_docs) {
         const uint64_t n = (uint64_t)(a.tok_offsets[d + 1] - a.tok_offsets[d]);
-        if (n > a.trunc_len && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
+        // (max_length 0 cuts everything before the strategy is looked at, utils/truncation.rs:75-81)
+        if (n > a.trunc_len && a.trunc_len > 0u && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
         if (n > a.trunc_len && a.trunc_len > 0u && a.trunc_stride >= a.trunc_len) atomicOr(a.err, ERR_TRUNC_STRIDE);      // encoding.rs:319
         l = (uint32_t)min(n, (uint64_t)a.trunc_len) + (uint32_t)(a.n_prefix + a.n_suffix);
         a.len1[d] = l;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void k_ovf_parts(FinalArgs a) {
     uint32_t p = 0;
     if (d < a.n_docs) {
         const uint64_t n = (uint64_t)(a.tok_offsets[d + 1] - a.tok_offsets[d]);
-        if (n > a.trunc_len && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
+        if (n > a.trunc_len && a.trunc_len > 0u && a.trunc_needs_pair) atomicOr(a.err, ERR_TRUNC_SECOND);
         p = ovf_parts(n, a.trunc_len, a.trunc_stride);
         if (p == 0u) { atomicOr(a.err, ERR_TRUNC_STRIDE); p = 1u; }
         if (p == 0xFFFFFFFFu) { atomicOr(a.err, ERR_TOO_MANY_TOKENS); p = 1u; }
@@ -165,7 +166,12 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs a) {
         const int64_t seq = body + a.n_prefix;
         for (int64_t q = lane; q < n; q += 64) {
             a.ids2[seq + q] = a.ids[src + q];
-            if (a.offsets) { a.offsets2[2 * (seq + q)] = a.offsets[2 * (src + q)]; a.offsets2[2 * (seq + q) + 1] = a.offsets[2 * (src + q) + 1]; }
+            // (process_offsets runs on the cut encoding: its token 0 keeps the one leading space that stands for the prefix space)
+            if (a.offsets) {
+                const uint32_t back = (q == 0 && a.trim1) ? a.trim1[src] : 0u;
+                a.offsets2[2 * (seq + q)] = a.offsets[2 * (src + q)] - (back ? 1u : 0u);
+                a.offsets2[2 * (seq + q) + 1] = a.offsets[2 * (src + q) + 1] - (back == 2u ? 1u : 0u);
+            }
             if (a.word_ids) a.word_ids2[seq + q] = a.word_ids[src + q];
         }
         for (int64_t q = lane; q < a.n_suffix; q += 64) {
@@ -342,7 +348,11 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PairArgs a) {
                     a.ids2[cur + q] = a.ids[src + q];
                     a.type_ids2[cur + q] = (uint8_t)ty_here;
                     a.seq_ids2[cur + q] = (uint8_t)kind;
-                    if (a.offsets) { a.offsets2[2 * (cur + q)] = a.offsets[2 * (src + q)]; a.offsets2[2 * (cur + q) + 1] = a.offsets[2 * (src + q) + 1]; }
+                    if (a.offsets) {
+                        const uint32_t back = (q == 0 && a.trim1) ? a.trim1[src] : 0u;
+                        a.offsets2[2 * (cur + q)] = a.offsets[2 * (src + q)] - (back ? 1u : 0u);
+                        a.offsets2[2 * (cur + q) + 1] = a.offsets[2 * (src + q) + 1] - (back == 2u ? 1u : 0u);
+                    }
                     if (a.word_ids) a.word_ids2[cur + q] = a.word_ids[src + q];
                 }
                 cur += n;

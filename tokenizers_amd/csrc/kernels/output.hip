@@ -248,11 +248,15 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                         while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
                         while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
                     }
+                    bool took_one = false;
                     if (lead_sp) {
                         bool is_first = (word == 0 && j == 0) || os == 0;
                         if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
+                        took_one = lead_sp == 1 && a.pp_add_prefix_space && os < oe;
                         os = min(os + lead_sp, oe);
                     }
+                    // (2: the token IS that one space -- kept as the first token of an encoding, its END is what the trailing trim moves)
+                    if (a.trim1) a.trim1[o + j] = took_one ? ((!is_match && te - ts == 1u) ? 2 : 1) : 0;
                     if (trail_sp && oe >= trail_sp) oe = max(oe - trail_sp, os);
                 }
                 a.offsets[2 * (size_t)(o + j)] = os;
