@@ -738,3 +738,23 @@ def test_nfd_piece_table_matches_the_wheel_for_every_code_point(ref_tokenizers):
             assert swaps(y, reps[r - 1]), hex(ord(y))
         if r + 1 in reps:
             assert swaps(reps[r + 1], y), hex(ord(y))
+
+
+def test_added_token_ids_are_assigned_like_the_reference_assigns_them(ref_tokenizers):
+    """A tokenizer.json whose added_tokens carry ids the library would not have written (a content the model already knows under
+    another id, a gap, a duplicate): the reference ignores the `id` fields -- add_tokens over the list in order
+    (serialization.rs:153-167) -- and so does the host model and the mirror."""
+    import json
+    d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
+    n = len(d["model"]["vocab"])
+    known = next(k for k in d["model"]["vocab"] if k.isalpha() and len(k) > 2)
+    tok = lambda c, i, **kw: dict({"id": i, "content": c, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": False}, **kw)
+    d["added_tokens"] = [tok(known, n + 50), tok("<gap>", n + 7), tok("<two>", n + 8), tok("<gap>", n + 9, special=True), tok("", n + 10), tok("<last>", n + 3)]
+    js = json.dumps(d)
+    r = ref_tokenizers.Tokenizer.from_str(js)
+    t = ta.Tokenizer.from_str(js, device=-1)
+    assert t.get_vocab() == r.get_vocab()
+    for c in (known, "<gap>", "<two>", "<last>"):
+        assert t.token_to_id(c) == r.token_to_id(c), c
+    assert t.token_to_id("<gap>") == n and t.token_to_id("<two>") == n + 1 and t.token_to_id("<last>") == n + 2
+    assert t.info["n_added_tokens"] == 4

@@ -658,6 +658,33 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     }
     m.vocab_size = (uint32_t)v.size();
 
+    // The ids the reference gives the added tokens are not the ones in the file: deserialisation hands them, in file order, to
+    // AddedVocabulary::add_tokens (serialization.rs:153-167 -- it only WARNS when the outcome differs from the file), which gives a
+    // token whose content the model knows the model's id and every other one the next free id from the model's vocabulary size on; a
+    // content seen twice keeps its first id and its last properties (added_vocabulary.rs:272-360).  Files the library wrote agree with
+    // that already.
+    {
+        std::unordered_map<std::string, size_t> seen;
+        std::vector<AddedToken> kept;
+        uint32_t next_id = m.vocab_size;
+        for (AddedToken& a : m.added_tokens) {
+            if (a.content.empty()) continue;
+            auto it = seen.find(a.content);
+            if (it != seen.end()) {
+                AddedToken& old = kept[it->second];
+                a.id = old.id;
+                old = a;
+                continue;
+            }
+            auto vit = v.find(a.content);
+            a.id = vit != v.end() ? vit->second : next_id++;
+            if (a.id >= (1u << 24)) throw Unsupported("added token id beyond 2^24");
+            seen[a.content] = kept.size();
+            kept.push_back(a);
+        }
+        m.added_tokens = std::move(kept);
+    }
+
     uint32_t b2c[256];
     build_bytes_char(b2c);
     std::unordered_map<uint32_t, uint8_t> c2b;

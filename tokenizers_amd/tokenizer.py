@@ -460,11 +460,35 @@ class Tokenizer:
             out.extend(chr(cps[i]) for i in range(n.value))
         return "".join(out)
 
+    @staticmethod
+    def _effective_added(d: dict) -> list[dict]:
+        """The added tokens with the ids the reference gives them at load: AddedVocabulary::add_tokens over the file's list in order
+        (serialization.rs:153-167, added_vocabulary.rs:272-360) -- a content the model knows gets the model's id, any other the next
+        free id from the model's vocabulary size on, a content listed twice keeps its first id and its last properties.  (The `id`
+        fields of a file the library wrote say the same; the reference only warns when they do not.)"""
+        vocab = d["model"]["vocab"]
+        out, seen, next_id = [], {}, len(vocab)
+        for a in d.get("added_tokens") or []:
+            if not a.get("content"):
+                continue
+            e = dict(a)
+            if e["content"] in seen:
+                e["id"] = out[seen[e["content"]]]["id"]
+                out[seen[e["content"]]] = e
+                continue
+            if e["content"] in vocab:
+                e["id"] = int(vocab[e["content"]])
+            else:
+                e["id"], next_id = next_id, next_id + 1
+            seen[e["content"]] = len(out)
+            out.append(e)
+        return out
+
     def _id_to_token(self) -> dict[int, str]:
         if self._vocab_r is None:
             d = json.loads(self._json)
             r = {int(i): t for t, i in d["model"]["vocab"].items()}
-            for a in d.get("added_tokens") or []:
+            for a in self._effective_added(d):
                 # the token string of an added-token match is the matched slice of the NORMALIZED text (added_vocabulary.rs:497-516), i.e.
                 # the token's normalized pattern when it is matched through the normalizer
                 r[int(a["id"])] = self._normalized(a["content"]) if a.get("normalized") and self.info["normalizer"] == 1 else a["content"]
@@ -506,7 +530,7 @@ class Tokenizer:
     # tokenizer.rs:1262-1308): the added vocabulary lives in the tokenizer.json's `added_tokens`, so the handle is re-created ----
     def _add(self, tokens, special: bool) -> int:
         d = json.loads(self._json)
-        added = d.get("added_tokens") or []
+        added = self._effective_added(d)
         model_vocab = d["model"]["vocab"]
         by_content = {a["content"]: a for a in added}
         n_model = len(model_vocab)
@@ -555,7 +579,7 @@ class Tokenizer:
         d = json.loads(self._json)
         v = dict(d["model"]["vocab"])
         if with_added_tokens:
-            for a in d.get("added_tokens") or []:
+            for a in self._effective_added(d):
                 v[a["content"]] = int(a["id"])
         return v
 
