@@ -663,3 +663,34 @@ def test_word_cache_never_changes_a_result(name, gpt2_json):
     assert check(a, exp_a) == cold
     tok.word_cache(False)
     assert check(a, exp_a) == cold
+
+
+def test_added_vocabulary_of_random_shape_matches_the_wheel_live(ref_tokenizers):
+    """A seeded walk over added vocabularies the fixtures do not hold -- one to six tokens with random single_word / lstrip / rstrip /
+    normalized / special flags, some of them words the model already knows, ids as a careless hand would write them -- on text that is
+    mostly made of those tokens and their fragments, behind BertNormalizer, ByteLevel with its prefix space, the Llama-3 split and
+    Whitespace: ids, offsets and word ids against the wheel run here."""
+    import json
+    import random
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    rnd = random.Random(7)
+    pool = ["<x>", "ab", "ing", "[T]", "<x><y>", "Hello", "\u00e9", "<|eot|>", "the", " <sp>", "a b", "</s>", "##ing", "\u0130", "<x", "x>"]
+    filler = ["the", "cat", "ing", "sing", "Hello", "hello", "HELLO", " ", "  ", "\t", "\n", ".", ",", "!", "a", "b", "ab", "abc", "\u00e9", "e\u0301", "\u4e2d", "x", "<", ">", "|",
+              "[", "]", "T", "s", "y", "\u0130", "i\u0307"]
+    for case in range(24):
+        name = ("bert_wordpiece_4000", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1")[case % 4]
+        d = json.loads(load_tokenizer_json(name))
+        toks = rnd.sample(pool, rnd.randint(1, 6))
+        d["added_tokens"] = [a for a in d.get("added_tokens", []) if a["content"] not in toks]
+        nid = max([max(d["model"]["vocab"].values()) + 1] + [a["id"] + 1 for a in d["added_tokens"]])
+        for k, t in enumerate(toks):
+            d["added_tokens"].append({"id": nid + k, "content": t, "single_word": rnd.random() < 0.3, "lstrip": rnd.random() < 0.3, "rstrip": rnd.random() < 0.3,
+                                      "normalized": rnd.random() < 0.5, "special": rnd.random() < 0.5})
+        js = json.dumps(d, ensure_ascii=False)
+        docs = ["".join(rnd.choice(toks if rnd.random() < 0.3 else filler) for _ in range(rnd.randint(0, 14))) for _ in range(40)]
+        exp = ref_tokenizers.Tokenizer.from_str(js).encode_batch(docs, add_special_tokens=False)
+        got = ta.Tokenizer.from_str(js, device=0).encode_batch(docs, add_special_tokens=False)
+        for i, e in enumerate(exp):
+            ctx = (name, [(a["content"], a["single_word"], a["lstrip"], a["rstrip"], a["normalized"]) for a in d["added_tokens"][-len(toks):]], ascii(docs[i]))
+            assert got[i].ids == e.ids and [tuple(o) for o in got[i].offsets] == [tuple(o) for o in e.offsets] and got[i].word_ids == e.word_ids, ctx
