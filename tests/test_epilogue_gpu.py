@@ -274,13 +274,13 @@ def test_ids_as_16_bit_values():
             b = tok.encode_packed(buf, off, add_special_tokens=special, ids_dtype="uint16")
             assert b.ids.dtype == np.uint16 and np.array_equal(a.ids, b.ids.astype(np.uint32)) and np.array_equal(a.tok_offsets, b.tok_offsets)
     d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
-    big = max(d["model"]["vocab"].values()) + 1
-    d["added_tokens"].append({"id": 70000, "content": "<far>", "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": True})
+    d["model"]["vocab"] = {"<unk>": 0, **{f"w{i}": i for i in range(1, 66000)}}
+    d["model"]["unk_token"] = "<unk>"
+    d["added_tokens"] = []
     tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
-    assert big < 65536
-    assert tok.encode_packed(*ta.pack_documents(["no such token here"]), ids_dtype="uint16").ids.dtype == np.uint16
+    assert tok.encode_packed(*ta.pack_documents(["w1 w65535 nothing"]), ids_dtype="uint16").ids.tolist() == [1, 65535, 0]
     with pytest.raises(ValueError, match="65,535"):
-        tok.encode_packed(*ta.pack_documents(["a <far> b"]), ids_dtype="uint16")
+        tok.encode_packed(*ta.pack_documents(["w1 w65536 w2"]), ids_dtype="uint16")
 
 
 def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers):
@@ -326,3 +326,40 @@ def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers)
                 assert [x.ids for x in o.overflowing] == [x.ids for x in go.overflowing], ctx + (inputs[i],)
             n_over += len(e.overflowing)
     assert n_over > 500
+
+
+def test_template_shapes_match_the_wheel_live(ref_tokenizers):
+    """TemplateProcessing outside the BERT shape (processors/template.rs:544-590): the sequence first and the special tokens after it
+    (XLNet), special tokens of several ids, type ids on the pair's pieces, B before A -- pairs follow the pair template whatever the
+    single one looks like; a single template this path does not hold (a typed sequence A) is refused for single sequences only, with or
+    without special tokens, because the template's type ids are applied either way."""
+    import tokenizers_amd as ta
+    from oracle import synth
+    base = json.loads(load_tokenizer_json("bert_wordpiece_4000_specials"))
+    docs = [d[:60] for d in synth.gen_lines(24, text_seed=9) if "[" not in d] + ["", "a"]
+    pairs = [(docs[i], docs[-1 - i]) for i in range(len(docs) // 2)]
+    fields = lambda e: (e.ids, e.type_ids, e.attention_mask, e.special_tokens_mask, [tuple(o) for o in e.offsets], e.word_ids, e.sequence_ids)
+    sp = {"[CLS]": {"id": "[CLS]", "ids": [2], "tokens": ["[CLS]"]}, "[SEP]": {"id": "[SEP]", "ids": [3], "tokens": ["[SEP]"]},
+          "<two>": {"id": "<two>", "ids": [2, 3], "tokens": ["[CLS]", "[SEP]"]}}
+    S = lambda i, t=0: {"SpecialToken": {"id": i, "type_id": t}}
+    Q = lambda i, t=0: {"Sequence": {"id": i, "type_id": t}}
+    shapes = {
+        "xlnet": ([Q("A"), S("[SEP]"), S("[CLS]", 2)], [Q("A"), S("[SEP]"), Q("B", 1), S("[SEP]", 1), S("[CLS]", 2)]),
+        "multi": ([S("<two>"), Q("A")], [S("<two>"), Q("A"), S("<two>", 1), Q("B", 1)]),
+        "b_first": ([S("[CLS]"), Q("A"), S("[SEP]")], [S("[CLS]"), Q("B", 1), S("[SEP]"), Q("A"), S("[SEP]")]),
+        "typed_single": ([S("[CLS]", 1), Q("A", 1)], [S("[CLS]"), Q("A"), S("[SEP]"), Q("B", 1)]),
+    }
+    for name, (single, pair) in shapes.items():
+        d = dict(base, post_processor={"type": "TemplateProcessing", "single": single, "pair": pair, "special_tokens": sp})
+        js = json.dumps(d, ensure_ascii=False)
+        ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
+        for special in (True, False):
+            exp, got = ref.encode_batch(pairs, add_special_tokens=special), tok.encode_batch(pairs, add_special_tokens=special)
+            assert [fields(e) for e in exp] == [fields(g) for g in got], (name, special)
+            single_ok = name in ("multi", "b_first") or (name == "xlnet" and not special)
+            if single_ok:
+                exp, got = ref.encode_batch(docs, add_special_tokens=special), tok.encode_batch(docs, add_special_tokens=special)
+                assert [fields(e) for e in exp] == [fields(g) for g in got], (name, special)
+            else:
+                with pytest.raises(ta.UnsupportedError):
+                    tok.encode_batch(docs, add_special_tokens=special)

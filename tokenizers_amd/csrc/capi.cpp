@@ -471,7 +471,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     const bool want_meta = off_mode != TKAMD_OFFSETS_NONE || want_words;
     if (off_mode == 3u) throw Invalid("bad offsets mode");
     const bool add_special = (flags & TKAMD_ADD_SPECIAL) != 0 && !(hm.pp_prefix.empty() && hm.pp_suffix.empty());
-    if ((flags & TKAMD_ADD_SPECIAL) && !hm.pp_unsupported.empty()) throw Unsupported("add_special_tokens: " + hm.pp_unsupported);
+    if ((flags & TKAMD_ADD_SPECIAL) && !(flags & TKAMD_PAIRS) && !hm.pp_unsupported.empty()) throw Unsupported("add_special_tokens: " + hm.pp_unsupported);
+    if (!(flags & TKAMD_PAIRS) && hm.pp_single_typed) throw Unsupported("post_processor: " + hm.pp_unsupported + " (type ids of single sequences are 0 on this path)");
     const bool prefix_space = hm.byte_level && hm.add_prefix_space;
     // host-side bound of the X text length: +1 per document for the virtual space; BertNormalizer can grow a
     // character (CJK spacing: 3 -> 5 bytes, NFD/lowercase expansions <= 3x) -- 3x the input covers every case

@@ -564,23 +564,28 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                 if (!single || !single->is_array()) throw Invalid("tokenizer.json: TemplateProcessing without `single`");
                 std::vector<uint32_t> pre, post;
                 int n_seq = 0;
+                // (what the single template asks for beyond "ids around the sequence, everything type 0" is refused when a single sequence
+                // is encoded -- the pair template below is parsed regardless)
                 for (auto& piece : single->arr) {
                     if (const JsonValue* sq = piece->get("Sequence")) {
-                        if (sq->get_str("id") != "A") { m.pp_unsupported = "TemplateProcessing single template refers to sequence B"; return; }
-                        if (sq->get_num("type_id", 0) != 0) { m.pp_unsupported = "TemplateProcessing gives sequence A a non-zero type_id"; return; }
+                        if (sq->get_str("id") != "A") m.pp_unsupported = "TemplateProcessing single template refers to sequence B";
+                        // the template's type id goes on the sequence's tokens whether or not special tokens are added (template.rs:554-559)
+                        if (sq->get_num("type_id", 0) != 0) { m.pp_unsupported = "TemplateProcessing gives sequence A a non-zero type_id"; m.pp_single_typed = true; }
                         ++n_seq;
                     } else if (const JsonValue* st = piece->get("SpecialToken")) {
                         std::string name = st->get_str("id");
                         const JsonValue* def = sp ? sp->get(name.c_str()) : nullptr;
                         const JsonValue* ids = def ? def->get("ids") : nullptr;
                         if (!ids || !ids->is_array()) throw Invalid("tokenizer.json: TemplateProcessing special token '" + name + "' is not defined");
-                        if (st->get_num("type_id", 0) != 0) { m.pp_unsupported = "TemplateProcessing special token with a non-zero type_id"; return; }
+                        if (st->get_num("type_id", 0) != 0 && m.pp_unsupported.empty()) m.pp_unsupported = "TemplateProcessing special token with a non-zero type_id";
                         for (auto& x : ids->arr) (n_seq ? post : pre).push_back((uint32_t)x->num);
                     } else throw Invalid("tokenizer.json: bad TemplateProcessing piece");
                 }
-                if (n_seq != 1) { m.pp_unsupported = "TemplateProcessing single template must contain sequence A exactly once"; return; }
-                m.pp_prefix.insert(m.pp_prefix.begin(), pre.begin(), pre.end());
-                m.pp_suffix.insert(m.pp_suffix.end(), post.begin(), post.end());
+                if (n_seq != 1 && m.pp_unsupported.empty()) m.pp_unsupported = "TemplateProcessing single template must contain sequence A exactly once";
+                if (m.pp_unsupported.empty()) {
+                    m.pp_prefix.insert(m.pp_prefix.begin(), pre.begin(), pre.end());
+                    m.pp_suffix.insert(m.pp_suffix.end(), post.begin(), post.end());
+                }
                 // the `pair` template (processors/template.rs:544-590): any order of A, B and special tokens, each with its type id
                 if (!m.pp_pair.empty()) m.pp_pair_unsupported = "two post-processors that add special tokens";
                 const JsonValue* pair = pp->get("pair");

@@ -69,6 +69,7 @@ struct HostModel {
     struct TplPiece { uint32_t kind, id, type_id; };
     std::vector<TplPiece> pp_pair;                 // empty: no adding post-processor (a pair is then A followed by B, type ids 0 / 1)
     std::string pp_pair_unsupported;
+    bool pp_single_typed = false;      // the single template puts a non-zero type id on sequence A: with or without special tokens (refused for single sequences)
     // the layout of a pair when NO special tokens are added: A : 0, B : 1 by default (bert.rs:56-58 returns the encodings as they are);
     // RobertaProcessing zeroes every type id first (roberta.rs); TemplateProcessing still applies its order and type ids
     std::vector<TplPiece> pp_pair_plain = {{0, 0, 0}, {1, 0, 1}};

@@ -647,7 +647,6 @@ class Tokenizer:
 
         ``is_pretokenized``: every item is a list of words (or a pair of lists) -- InputSequence::PreTokenized, tokenizer/mod.rs:225-290.
         ``overflowing``: with a truncation section, keep what single sequences lose to the cut as ``Encoding.overflowing``."""
-        self._check_special(add_special_tokens)
         if is_pretokenized:
             return self._encode_words(inputs, offsets, word_ids, add_special_tokens, overflowing)
         pairs = len(inputs) > 0 and isinstance(inputs[0], (tuple, list))
@@ -705,7 +704,8 @@ class Tokenizer:
         if word_ids:
             flags |= _lib.WANT_WORD_IDS
         if add_special_tokens:
-            self._check_special(True)
+            if not pairs:                        # (a pair only needs the pair template: the library checks that one)
+                self._check_special(True)
             flags |= _lib.ADD_SPECIAL
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
