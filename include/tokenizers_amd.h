@@ -153,7 +153,7 @@ const uint16_t* tkamd_batch_ids16(const tkamd_batch* b);        /* [n_tokens] wi
 const int64_t*  tkamd_batch_tok_offsets(const tkamd_batch* b);  /* [n_docs+1] CSR into ids      */
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b);      /* [n_tokens][2] or NULL        */
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b);     /* [n_tokens] or NULL           */
-const uint8_t*  tkamd_batch_type_ids(const tkamd_batch* b);     /* [n_tokens] Encoding.type_ids, or NULL (single sequences: 0, pad_type_id on padding) */
+const uint8_t*  tkamd_batch_type_ids(const tkamd_batch* b);     /* [n_tokens] Encoding.type_ids (pairs; single sequences under a TemplateProcessing with type ids), or NULL: 0, pad_type_id on padding */
 const uint8_t*  tkamd_batch_sequence_ids(const tkamd_batch* b); /* [n_tokens] 0 / 1 = token of sequence A / B, 2 = special token, 3 = padding, or NULL
                                                                    (single sequences: derived from tkamd_tokenizer_specials and the pad counts)      */
 const uint32_t* tkamd_batch_pad_counts(const tkamd_batch* b);   /* [n_docs] padding tokens of each encoding (at the side
@@ -181,7 +181,7 @@ typedef struct tkamd_device_result {
     const int64_t*  d_n_tokens;     /* [1]                                                      */
     const int64_t*  d_n_pretokens;  /* [1] number of pre-tokens (splits) in the batch           */
     const uint32_t* d_pad_counts;   /* [n_docs] padding tokens per encoding, or NULL            */
-    const uint8_t*  d_type_ids;     /* TKAMD_PAIRS: [n_tokens] type ids, else NULL              */
+    const uint8_t*  d_type_ids;     /* TKAMD_PAIRS, or a single template with type ids: [n_tokens], else NULL */
     const uint8_t*  d_seq_ids;      /* TKAMD_PAIRS: [n_tokens] 0 / 1 / 2 special / 3 padding    */
     const uint32_t* d_enc_docs;     /* TKAMD_WANT_OVERFLOW (with a `truncation` section): [n_encodings] document of every encoding, else NULL;
                                        d_tok_offsets / d_pad_counts then have n_encodings (+ 1) entries                                        */

@@ -38,8 +38,10 @@ def main():
            "special_tokens": {"[CLS]": {"id": "[CLS]", "ids": [bert["model"]["vocab"]["[CLS]"]], "tokens": ["[CLS]"]},
                               "[SEP]": {"id": "[SEP]", "ids": [bert["model"]["vocab"]["[SEP]"], bert["model"]["vocab"]["[MASK]"]], "tokens": ["[SEP]", "[MASK]"]}}}
     nopp = "none"
+    # (RobertaProcessing writes zeros over every type id -- with special tokens over the overflowing windows' too, roberta.rs:121-126)
+    roberta = {"type": "RobertaProcessing", "sep": ["[SEP]", bert["model"]["vocab"]["[SEP]"]], "cls": ["[CLS]", bert["model"]["vocab"]["[CLS]"]], "trim_offsets": True, "add_prefix_space": False}
     toks = [("bert_wordpiece_4000_specials", None, bert), ("llama3_small_6000_specials", None, llama), ("bert_wordpiece_4000_specials", tpl, bert),
-            ("bert_wordpiece_4000_specials", nopp, bert)]
+            ("bert_wordpiece_4000_specials", nopp, bert), ("bert_wordpiece_4000_specials", roberta, bert)]
     cases = []
     for name, pp, base in toks:
         for trunc, pad in combos:

@@ -103,6 +103,7 @@ int epi_pair(const int64_t* tok_offsets, int64_t n_pairs, const uint32_t* ids, c
     pa.trunc_on = params[1]; pa.trunc_max = params[2]; pa.trunc_left = params[4]; pa.trunc_strategy = params[5]; pa.trunc_stride = params[3];
     pa.pad_on = params[6]; pa.pad_fixed = params[7]; pa.pad_length = params[8]; pa.pad_multiple = params[9]; pa.pad_left = params[10]; pa.pad_id = params[11];
     pa.pad_type_id = params[12];
+    pa.ovf_ty_tpl = params[14];
     std::vector<uint32_t> keep((size_t)2 * n_pairs + 2), len1((size_t)n_pairs + 2), fin, bsum((size_t)(n_pairs + 1) / 256 + 2), parts, enc_win;
     std::vector<int64_t> enc_base;
     pa.keep = keep.data(); pa.bsum = bsum.data(); pa.target = &target; pa.n_tok2 = &R.n_tok; pa.err = &R.err;

@@ -18,7 +18,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
+#include <mutex>
 #include <vector>
+#include <sys/mman.h>
 
 #define __global__
 #define __device__
@@ -130,7 +133,10 @@ inline void trampoline() {
     try_fire(w);
     for (;;) yield();                                         // never scheduled again
 }
+inline void device_open();
+inline void device_close();
 inline void launch(dim3 grid, dim3 block, std::function<void()> fn) {
+    device_open();
     if (block.x > (unsigned)MAX_THREADS || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) { fprintf(stderr, "simt: unsupported launch shape\n"); abort(); }
     std::function<void()>* outer = body();
     body() = &fn;
@@ -178,6 +184,7 @@ inline void launch(dim3 grid, dim3 block, std::function<void()> fn) {
     }
     cur() = nullptr;
     body() = outer;
+    device_close();
 }
 inline uint64_t snap(int lane) { return waves()[cur()->tid.x >> 6].snap[lane]; }
 template <class T> inline uint64_t bits(T v) { uint64_t b = 0; memcpy(&b, &v, sizeof(T)); return b; }
@@ -284,14 +291,75 @@ inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->multiProcessorCount = 1; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+#ifdef __SANITIZE_ADDRESS__
+// AddressSanitizer build: plain heap blocks, so that an out-of-bounds access of a kernel lands in a redzone
+namespace simt { inline void device_open() {} inline void device_close() {} inline int where(const void*) { return -1; } }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+#else
+// Guarded build: device allocations come out of one reserved range that is PROT_NONE while host code runs and readable / writable
+// only inside a kernel launch or a hipMemcpy / hipMemset -- host code that dereferences a device pointer (harmless on host memory, a
+// crash on the GPU) is a segmentation fault here too.  Fresh blocks are filled with 0xA5: hipMalloc does not zero memory either.
+namespace simt {
+struct Arena {
+    char* base = nullptr; size_t cap = 0, used = 0; int open = 0; std::mutex mu;
+    std::multimap<size_t, char*> spare;             // freed blocks by size (reused for an equal size only)
+    std::map<char*, size_t> live;
+};
+inline Arena& arena() { static Arena a; return a; }
+inline int where(const void* p) { Arena& a = arena(); return a.base && (const char*)p >= a.base && (const char*)p < a.base + a.cap; }
+inline void device_open() { Arena& a = arena(); std::lock_guard<std::mutex> g(a.mu); if (a.open++ == 0 && a.used) mprotect(a.base, a.used, PROT_READ | PROT_WRITE); }
+inline void device_close() { Arena& a = arena(); std::lock_guard<std::mutex> g(a.mu); if (--a.open == 0 && a.used) mprotect(a.base, a.used, PROT_NONE); }
+inline void check_kind(const void* d, const void* s, hipMemcpyKind k) {
+    const int wd = where(d), ws = where(s);
+    const bool ok = k == hipMemcpyHostToDevice ? (wd && !ws) : k == hipMemcpyDeviceToHost ? (!wd && ws) : k == hipMemcpyDeviceToDevice ? (wd && ws) : (!wd && !ws);
+    if (!ok && !getenv("SIMT_FOREIGN_DEVICE_MEMORY")) { fprintf(stderr, "simt: hipMemcpy kind %d with dst %s / src %s memory\n", (int)k, wd ? "device" : "host", ws ? "device" : "host"); abort(); }
+}
+}  // namespace simt
+inline hipError_t hipMalloc(void** p, size_t n) {
+    simt::Arena& a = simt::arena();
+    const size_t len = (n + 256 + 4095) / 4096 * 4096;
+    char* q = nullptr;
+    {
+        std::lock_guard<std::mutex> g(a.mu);
+        if (!a.base) {
+            a.cap = (size_t)1 << 40;
+            a.base = (char*)mmap(nullptr, a.cap, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (a.base == (char*)MAP_FAILED) { fprintf(stderr, "simt: cannot reserve the device range\n"); abort(); }
+        }
+        auto it = a.spare.find(len);
+        if (it != a.spare.end()) { q = it->second; a.spare.erase(it); }
+        else { if (a.used + len > a.cap) return hipErrorInvalidValue; q = a.base + a.used; a.used += len; }
+        a.live[q] = len;
+        mprotect(q, len, PROT_READ | PROT_WRITE);
+        if (len <= ((size_t)8 << 20)) memset(q, 0xA5, len);          // (large blocks: the two ends only -- the fill is what the big-batch tests would spend their time on)
+        else { memset(q, 0xA5, (size_t)1 << 20); memset(q + len - ((size_t)1 << 16), 0xA5, (size_t)1 << 16); }
+        if (!a.open) mprotect(q, len, PROT_NONE);
+    }
+    *p = q;
+    return hipSuccess;
+}
+inline hipError_t hipFree(void* p) {
+    if (!p) return hipSuccess;
+    simt::Arena& a = simt::arena();
+    std::lock_guard<std::mutex> g(a.mu);
+    auto it = a.live.find((char*)p);
+    if (it == a.live.end()) { fprintf(stderr, "simt: hipFree of a pointer hipMalloc did not return\n"); abort(); }
+    madvise(p, it->second, MADV_DONTNEED);
+    a.spare.emplace(it->second, (char*)p);
+    a.live.erase(it);
+    return hipSuccess;
+}
+#endif
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+#ifdef __SANITIZE_ADDRESS__
+namespace simt { inline void check_kind(const void*, const void*, hipMemcpyKind) {} }
+#endif
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) { simt::check_kind(d, s, k); simt::device_open(); memmove(d, s, n); simt::device_close(); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemset(void* d, int v, size_t n) { simt::device_open(); memset(d, v, n); simt::device_close(); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = malloc(1); return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

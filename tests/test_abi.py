@@ -758,3 +758,34 @@ def test_added_token_ids_are_assigned_like_the_reference_assigns_them(ref_tokeni
         assert t.token_to_id(c) == r.token_to_id(c), c
     assert t.token_to_id("<gap>") == n and t.token_to_id("<two>") == n + 1 and t.token_to_id("<last>") == n + 2
     assert t.info["n_added_tokens"] == 4
+
+
+def test_special_token_counts_and_the_untagged_post_processor_match_the_wheel(ref_tokenizers):
+    """PostProcessor::added_tokens for single sequences and pairs, over the post-processor shapes of the path -- including the serde
+    corner of processors/mod.rs:19-23: PostProcessorWrapper is untagged, Roberta is tried before Bert and tags are not validated, so a
+    `BertProcessing` that carries both of Roberta's flags IS a RobertaProcessing (<s> A </s></s> B </s>), and a `RobertaProcessing`
+    without them is a BertProcessing."""
+    base = json.loads(load_tokenizer_json("bert_wordpiece_4000_specials"))
+    S = lambda i, t=0: {"SpecialToken": {"id": i, "type_id": t}}
+    Q = lambda i, t=0: {"Sequence": {"id": i, "type_id": t}}
+    sp = {"<a>": {"id": "<a>", "ids": [1], "tokens": ["<a>"]}, "<b>": {"id": "<b>", "ids": [2, 1], "tokens": ["<b>", "<a>"]}}
+    shapes = [None,
+              {"type": "BertProcessing", "sep": ["[SEP]", 3], "cls": ["[CLS]", 2]},
+              {"type": "BertProcessing", "sep": ["[SEP]", 3], "cls": ["[CLS]", 2], "trim_offsets": False, "add_prefix_space": True},
+              {"type": "BertProcessing", "sep": ["[SEP]", 3], "cls": ["[CLS]", 2], "trim_offsets": False},
+              {"type": "RobertaProcessing", "sep": ["[SEP]", 3], "cls": ["[CLS]", 2], "trim_offsets": True, "add_prefix_space": False},
+              {"type": "RobertaProcessing", "sep": ["[SEP]", 3], "cls": ["[CLS]", 2]},
+              {"type": "TemplateProcessing", "special_tokens": sp, "single": [S("<b>", 1), Q("A", 2), S("<a>")], "pair": [Q("B", 1), S("<b>"), Q("A"), S("<b>", 3)]},
+              {"type": "Sequence", "processors": [{"type": "ByteLevel", "add_prefix_space": True, "trim_offsets": False, "use_regex": True},
+                                                  {"type": "TemplateProcessing", "special_tokens": sp, "single": [S("<a>"), Q("A")], "pair": [S("<a>"), Q("A"), Q("B", 1)]}]}]
+    for pp in shapes:
+        js = json.dumps(dict(base, post_processor=pp))
+        t, r = ta.Tokenizer.from_str(js, device=-1), ref_tokenizers.Tokenizer.from_str(js)
+        assert (t.num_special_tokens_to_add(False), t.num_special_tokens_to_add(True)) == (r.num_special_tokens_to_add(False), r.num_special_tokens_to_add(True)), pp
+        if pp and pp["type"].endswith("tProcessing") or pp and pp["type"] == "RobertaProcessing":
+            exp = r.encode("a", "b").ids                           # (two one-token words: the ids around them are the template's)
+            pieces, n = (C.c_uint32 * 240)(), C.c_int32(0)
+            assert t._lib.tkamd_tokenizer_pair_template(t._h, 1, pieces, 80, C.byref(n)) == 0
+            got = [pieces[3 * i + 1] if pieces[3 * i] == 2 else ("A", "B")[pieces[3 * i]] for i in range(n.value)]
+            a, b = r.encode("a", add_special_tokens=False).ids[0], r.encode("b", add_special_tokens=False).ids[0]
+            assert got == [("A" if x == a else "B" if x == b else x) for x in exp], pp

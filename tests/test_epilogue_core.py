@@ -53,8 +53,8 @@ def _load(name):
         return json.load(fh)
 
 
-def _params(trunc, pad, add_special, overflow):
-    p = np.zeros(14, dtype=np.uint32)
+def _params(trunc, pad, add_special, overflow, roberta=False):
+    p = np.zeros(15, dtype=np.uint32)
     p[0] = add_special
     if trunc:
         p[1], p[2], p[3], p[4] = 1, trunc["max_length"], trunc["stride"], trunc["direction"] == "Left"
@@ -65,6 +65,7 @@ def _params(trunc, pad, add_special, overflow):
         p[7], p[8] = fixed, pad["strategy"]["Fixed"] if fixed else 0
         p[9], p[10], p[11], p[12] = pad["pad_to_multiple_of"] or 0, pad["direction"] == "Left", pad["pad_id"], pad["pad_type_id"]
     p[13] = overflow
+    p[14] = bool(roberta and add_special)        # (RobertaProcessing with special tokens: zeros on the overflowing windows too)
     return p
 
 
@@ -234,7 +235,7 @@ def test_pair_overflowing_encoding_kernels_match_wheel(harness, ref_tokenizers):
             (to, ids, offs, words), host = _plain(ref_tokenizers, name, pp, flat, False)
         tpl, n_tpl = (C.c_uint32 * 96)(), C.c_int32(0)
         _lib.check(host._lib.tkamd_tokenizer_pair_template(host._h, int(c["add_special_tokens"]), tpl, 32, C.byref(n_tpl)))
-        p = _params(c["truncation"], c["padding"], c["add_special_tokens"], 1)
+        p = _params(c["truncation"], c["padding"], c["add_special_tokens"], 1, roberta=bool(pp) and pp["type"] == "RobertaProcessing")
         err = harness.epi_pair(to.ctypes.data, len(c["pairs"]), ids.ctypes.data, offs.ctypes.data, words.ctypes.data, tpl, n_tpl.value, p.ctypes.data)
         ctx0 = (name, c["post_processor"] if isinstance(c["post_processor"], str) or c["post_processor"] is None else c["post_processor"]["type"], c["truncation"], c["padding"], c["add_special_tokens"])
         if c["error"]:

@@ -330,15 +330,17 @@ def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers)
 
 def test_template_shapes_match_the_wheel_live(ref_tokenizers):
     """TemplateProcessing outside the BERT shape (processors/template.rs:544-590): the sequence first and the special tokens after it
-    (XLNet), special tokens of several ids, type ids on the pair's pieces, B before A -- pairs follow the pair template whatever the
-    single one looks like; a single template this path does not hold (a typed sequence A) is refused for single sequences only, with or
-    without special tokens, because the template's type ids are applied either way."""
+    (XLNet), special tokens of several ids, type ids on the pieces of the single and of the pair template (a single sequence's own
+    type id is applied with or without special tokens, and not to its overflowing windows), B before A -- with truncation, overflowing
+    encodings and padding on top.  Pairs follow the pair template whatever the single one looks like; a single template this path
+    does not hold (sequence A twice) is refused for single sequences only."""
     import tokenizers_amd as ta
     from oracle import synth
     base = json.loads(load_tokenizer_json("bert_wordpiece_4000_specials"))
     docs = [d[:60] for d in synth.gen_lines(24, text_seed=9) if "[" not in d] + ["", "a"]
     pairs = [(docs[i], docs[-1 - i]) for i in range(len(docs) // 2)]
-    fields = lambda e: (e.ids, e.type_ids, e.attention_mask, e.special_tokens_mask, [tuple(o) for o in e.offsets], e.word_ids, e.sequence_ids)
+    fields = lambda e: (e.ids, e.type_ids, e.attention_mask, e.special_tokens_mask, [tuple(o) for o in e.offsets], e.word_ids, e.sequence_ids, e.tokens)
+    deep = lambda e: [fields(e)] + [fields(o) for o in e.overflowing]
     sp = {"[CLS]": {"id": "[CLS]", "ids": [2], "tokens": ["[CLS]"]}, "[SEP]": {"id": "[SEP]", "ids": [3], "tokens": ["[SEP]"]},
           "<two>": {"id": "<two>", "ids": [2, 3], "tokens": ["[CLS]", "[SEP]"]}}
     S = lambda i, t=0: {"SpecialToken": {"id": i, "type_id": t}}
@@ -347,19 +349,29 @@ def test_template_shapes_match_the_wheel_live(ref_tokenizers):
         "xlnet": ([Q("A"), S("[SEP]"), S("[CLS]", 2)], [Q("A"), S("[SEP]"), Q("B", 1), S("[SEP]", 1), S("[CLS]", 2)]),
         "multi": ([S("<two>"), Q("A")], [S("<two>"), Q("A"), S("<two>", 1), Q("B", 1)]),
         "b_first": ([S("[CLS]"), Q("A"), S("[SEP]")], [S("[CLS]"), Q("B", 1), S("[SEP]"), Q("A"), S("[SEP]")]),
-        "typed_single": ([S("[CLS]", 1), Q("A", 1)], [S("[CLS]"), Q("A"), S("[SEP]"), Q("B", 1)]),
+        "typed_single": ([S("[CLS]", 1), Q("A", 3), S("<two>", 2)], [S("[CLS]"), Q("A"), S("[SEP]"), Q("B", 1)]),
+        "typed_sequence_only": ([Q("A", 7)], [Q("A", 7), Q("B", 1)]),
+        "a_twice": ([S("[CLS]"), Q("A"), S("[SEP]"), Q("A")], [S("[CLS]"), Q("A"), S("[SEP]"), Q("B", 1)]),
     }
+    pad = {"strategy": "BatchLongest", "direction": "Left", "pad_to_multiple_of": 4, "pad_id": 0, "pad_type_id": 5, "pad_token": "[PAD]"}
+    trunc = {"direction": "Right", "max_length": 12, "strategy": "LongestFirst", "stride": 1}
     for name, (single, pair) in shapes.items():
-        d = dict(base, post_processor={"type": "TemplateProcessing", "single": single, "pair": pair, "special_tokens": sp})
-        js = json.dumps(d, ensure_ascii=False)
-        ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
-        for special in (True, False):
-            exp, got = ref.encode_batch(pairs, add_special_tokens=special), tok.encode_batch(pairs, add_special_tokens=special)
-            assert [fields(e) for e in exp] == [fields(g) for g in got], (name, special)
-            single_ok = name in ("multi", "b_first") or (name == "xlnet" and not special)
-            if single_ok:
-                exp, got = ref.encode_batch(docs, add_special_tokens=special), tok.encode_batch(docs, add_special_tokens=special)
-                assert [fields(e) for e in exp] == [fields(g) for g in got], (name, special)
-            else:
-                with pytest.raises(ta.UnsupportedError):
-                    tok.encode_batch(docs, add_special_tokens=special)
+        for tr, pd in ((None, None), (trunc, pad), (dict(trunc, direction="Left", max_length=9), dict(pad, direction="Right"))):
+            d = dict(base, post_processor={"type": "TemplateProcessing", "single": single, "pair": pair, "special_tokens": sp}, truncation=tr, padding=pd)
+            js = json.dumps(d, ensure_ascii=False)
+            ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
+            for special in (True, False):
+                exp, got = ref.encode_batch(pairs, add_special_tokens=special), tok.encode_batch(pairs, add_special_tokens=special)
+                assert [deep(e) for e in exp] == [deep(g) for g in got], (name, special, tr, pd)
+                if name != "a_twice":
+                    exp, got = ref.encode_batch(docs, add_special_tokens=special), tok.encode_batch(docs, add_special_tokens=special)
+                    assert [deep(e) for e in exp] == [deep(g) for g in got], (name, special, tr, pd)
+                    exp, got = ref.encode_batch(["", ""], add_special_tokens=special), tok.encode_batch(["", ""], add_special_tokens=special)      # (a batch without a byte)
+                    assert [deep(e) for e in exp] == [deep(g) for g in got], (name, special, tr, pd)
+                    words = [d.split() for d in docs[:6]]
+                    exp = ref.encode_batch(words, add_special_tokens=special, is_pretokenized=True)
+                    got = tok.encode_batch(words, add_special_tokens=special, is_pretokenized=True)
+                    assert [deep(e) for e in exp] == [deep(g) for g in got], (name, special, tr, pd)
+                else:
+                    with pytest.raises(ta.UnsupportedError):
+                        tok.encode_batch(docs, add_special_tokens=special)

@@ -11,6 +11,7 @@ kernels' logic, their launch sequences and the host plumbing around them produce
 By default a slice of the GPU suite runs (about two minutes); TKAMD_SIMT_FULL=1 runs every case that fits the emulation (ten)."""
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -189,3 +190,29 @@ def test_tokens_added_at_run_time_are_matched_like_the_wheel_matches_them(ref_to
 def test_added_vocabulary_of_random_shape_matches_the_wheel_live(ref_tokenizers):
     from tests import test_parity_gpu as P
     P.test_added_vocabulary_of_random_shape_matches_the_wheel_live(ref_tokenizers)
+
+
+def test_host_code_cannot_read_device_memory_here_either():
+    """The shim hands out device memory that only kernels and hipMemcpy / hipMemset can touch (PROT_NONE otherwise), so a host-side
+    dereference of a device pointer -- invisible on plain host memory, a crash on the MI355X -- ends these tests too.  Shown on a
+    device pointer the C ABI returns: reading it from the host is a segmentation fault, reading the host-side result is fine."""
+    if ASAN:
+        pytest.skip("the AddressSanitizer build keeps plain heap blocks (redzones instead of the guard)")
+    code = r'''
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r)
+from tokenizers_amd import _lib
+_lib.LIB_PATH = %r
+import tokenizers_amd as ta
+from tests.helpers import load_tokenizer_json
+tok = ta.Tokenizer.from_str(load_tokenizer_json("wordlevel_whitespace_c1"), device=0)
+assert len(tok.encode_batch(["the cat"])[0].ids) > 0
+text = np.frombuffer(b"the cat sat" + bytes(64), dtype=np.uint8).copy()
+offs = np.array([0, 11], dtype=np.int64)
+b = tok.encode_batch_device(text.ctypes.data, offs.ctypes.data, 1, 11).sync()
+assert b.n_tokens == 3
+print("synced", flush=True)
+print(C.cast(b._res.d_ids, C.POINTER(C.c_uint32))[0])
+''' % (ROOT, SO)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SIMT_FOREIGN_DEVICE_MEMORY="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert "synced" in r.stdout and r.returncode == -11, (r.returncode, r.stdout, r.stderr[-2000:])

@@ -143,7 +143,7 @@ struct tkamd_tokenizer {
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
-    DevBuf t_pp_prefix, t_pp_suffix, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
+    DevBuf t_pp_prefix, t_pp_suffix, t_pp_prefix_ty, t_pp_suffix_ty, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
@@ -285,6 +285,8 @@ void upload_tables(tkamd_tokenizer* t) {
     }
     upload(t->t_pp_prefix, hm.pp_prefix);
     upload(t->t_pp_suffix, hm.pp_suffix);
+    upload(t->t_pp_prefix_ty, hm.pp_prefix_ty);
+    upload(t->t_pp_suffix_ty, hm.pp_suffix_ty);
     upload(t->t_bn1, hm.bn_stage1);
     upload(t->t_bn2, hm.bn_stage2);
     upload(t->t_bn_map, hm.bn_map);
@@ -472,7 +474,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (off_mode == 3u) throw Invalid("bad offsets mode");
     const bool add_special = (flags & TKAMD_ADD_SPECIAL) != 0 && !(hm.pp_prefix.empty() && hm.pp_suffix.empty());
     if ((flags & TKAMD_ADD_SPECIAL) && !(flags & TKAMD_PAIRS) && !hm.pp_unsupported.empty()) throw Unsupported("add_special_tokens: " + hm.pp_unsupported);
-    if (!(flags & TKAMD_PAIRS) && hm.pp_single_typed) throw Unsupported("post_processor: " + hm.pp_unsupported + " (type ids of single sequences are 0 on this path)");
+    if (!(flags & TKAMD_PAIRS) && hm.pp_single_refused) throw Unsupported("post_processor: " + hm.pp_unsupported);
     const bool prefix_space = hm.byte_level && hm.add_prefix_space;
     // host-side bound of the X text length: +1 per document for the virtual space; BertNormalizer can grow a
     // character (CJK spacing: 3 -> 5 bytes, NFD/lowercase expansions <= 3x) -- 3x the input covers every case
@@ -576,7 +578,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     const bool pairs = (flags & TKAMD_PAIRS) != 0;
     if (pairs && (e_n & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
     if (pairs && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
-    const bool epilogue = hm.trunc_on || hm.pad_on || pairs;
+    const bool typed_single = !pairs && hm.pp_single_typed;          // the single template's type ids: written by the epilogue, with or without special tokens
+    const bool epilogue = hm.trunc_on || hm.pad_on || pairs || typed_single;
     // Encoding.overflowing: what a truncation cuts off, as further encodings of the result (a pair leaves every combination of its two
     // sequences' windows, Encoding::merge_with encoding.rs:408-432)
     const bool want_overflow = (flags & TKAMD_WANT_OVERFLOW) != 0 && hm.trunc_on;
@@ -598,6 +601,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pa.tpl = tpl_on ? t->t_pp_pair.as<uint32_t>() : t->t_pp_pair_plain.as<uint32_t>();
         pa.n_tpl = tpl_on ? (int32_t)hm.pp_pair.size() : (int32_t)hm.pp_pair_plain.size();
         pa.n_special = n_special;
+        pa.ovf_ty_tpl = (tpl_on && hm.pp_roberta) ? 1u : 0u;
         pa.trunc_on = hm.trunc_on ? 1u : 0u;
         pa.trunc_max = hm.trunc_max_length;
         pa.trunc_left = hm.trunc_left ? 1u : 0u;
@@ -839,6 +843,18 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.ids2 = w->w_ids2.as<uint32_t>();
         fa.offsets2 = w->w_offsets2.as<uint32_t>();
         fa.word_ids2 = w->w_word_ids2.as<uint32_t>();
+        if (typed_single) {
+            w->w_type_ids2.reserve(T2 + 64);
+            w->w_seq_ids2.reserve(T2 + 64);
+            fa.type_ids2 = w->w_type_ids2.as<uint8_t>();
+            fa.seq_ids2 = w->w_seq_ids2.as<uint8_t>();
+            fa.prefix_ty = t->t_pp_prefix_ty.as<uint8_t>();
+            fa.suffix_ty = t->t_pp_suffix_ty.as<uint8_t>();
+            fa.seq_ty = hm.pp_seq_ty;
+            fa.pad_type_id = hm.pad_type_id;
+            out->d_type_ids = fa.type_ids2;
+            out->d_seq_ids = fa.seq_ids2;
+        }
         if (!overflow) launch_final_offsets(st, fa);
         launch_finalize(st, grid, fa);
         pf.end();

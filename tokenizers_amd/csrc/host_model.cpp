@@ -538,6 +538,13 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         std::function<void(const JsonValue*)> apply = [&](const JsonValue* pp) {
             if (!pp || pp->is_null()) return;
             std::string t = pp->get_str("type");
+            if (t == "BertProcessing" || t == "RobertaProcessing") {
+                // PostProcessorWrapper is an untagged enum that tries Roberta before Bert and "serde does not validate tags"
+                // (processors/mod.rs:19-23): with both of Roberta's flags present it is a RobertaProcessing whatever `type` says, else Bert
+                const JsonValue* a = pp->get("trim_offsets");
+                const JsonValue* b = pp->get("add_prefix_space");
+                t = (a && a->is_bool() && b && b->is_bool()) ? "RobertaProcessing" : "BertProcessing";
+            }
             if (t == "ByteLevel" || t == "RobertaProcessing") {
                 m.trim_offsets = pp->get_bool("trim_offsets", true);
                 m.pp_add_prefix_space = pp->get_bool("add_prefix_space", true);
@@ -550,12 +557,15 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                     throw Invalid("tokenizer.json: bad cls/sep in post_processor");
                 m.pp_prefix.insert(m.pp_prefix.begin(), (uint32_t)cls->arr[1]->num);
                 m.pp_suffix.push_back((uint32_t)sep->arr[1]->num);
+                m.pp_prefix_ty.insert(m.pp_prefix_ty.begin(), (uint8_t)0);
+                m.pp_suffix_ty.push_back((uint8_t)0);
+                if (m.pp_single_typed) m.pp_unsupported = "a TemplateProcessing with type ids combined with another post-processor";
                 if (!m.pp_pair.empty()) m.pp_pair_unsupported = "two post-processors that add special tokens";
                 const uint32_t c = (uint32_t)cls->arr[1]->num, e = (uint32_t)sep->arr[1]->num;
                 if (t == "BertProcessing")         // [CLS] A [SEP] : 0   B [SEP] : 1          (processors/bert.rs:121-150)
                     m.pp_pair = {{2, c, 0}, {0, 0, 0}, {2, e, 0}, {1, 0, 1}, {2, e, 1}};
                 else                               // <s> A </s> </s> B </s>, all type 0        (processors/roberta.rs)
-                    m.pp_pair_plain = {{0, 0, 0}, {1, 0, 0}}, m.pp_pair = {{2, c, 0}, {0, 0, 0}, {2, e, 0}, {2, e, 0}, {1, 0, 0}, {2, e, 0}};
+                    m.pp_roberta = true, m.pp_pair_plain = {{0, 0, 0}, {1, 0, 0}}, m.pp_pair = {{2, c, 0}, {0, 0, 0}, {2, e, 0}, {2, e, 0}, {1, 0, 0}, {2, e, 0}};
                 return;
             }
             if (t == "TemplateProcessing") {                               // processors/template.rs:544-590, `single` template
@@ -563,28 +573,44 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                 const JsonValue* sp = pp->get("special_tokens");
                 if (!single || !single->is_array()) throw Invalid("tokenizer.json: TemplateProcessing without `single`");
                 std::vector<uint32_t> pre, post;
+                std::vector<uint8_t> pre_ty, post_ty;
+                double seq_ty = 0, max_ty = 0;
                 int n_seq = 0;
-                // (what the single template asks for beyond "ids around the sequence, everything type 0" is refused when a single sequence
-                // is encoded -- the pair template below is parsed regardless)
+                // (a single template that is not "ids around sequence A" is refused when a single sequence is encoded with special tokens --
+                // the pair template below is parsed regardless)
                 for (auto& piece : single->arr) {
                     if (const JsonValue* sq = piece->get("Sequence")) {
                         if (sq->get_str("id") != "A") m.pp_unsupported = "TemplateProcessing single template refers to sequence B";
-                        // the template's type id goes on the sequence's tokens whether or not special tokens are added (template.rs:554-559)
-                        if (sq->get_num("type_id", 0) != 0) { m.pp_unsupported = "TemplateProcessing gives sequence A a non-zero type_id"; m.pp_single_typed = true; }
+                        seq_ty = sq->get_num("type_id", 0);
+                        max_ty = std::max(max_ty, seq_ty);
                         ++n_seq;
                     } else if (const JsonValue* st = piece->get("SpecialToken")) {
                         std::string name = st->get_str("id");
                         const JsonValue* def = sp ? sp->get(name.c_str()) : nullptr;
                         const JsonValue* ids = def ? def->get("ids") : nullptr;
                         if (!ids || !ids->is_array()) throw Invalid("tokenizer.json: TemplateProcessing special token '" + name + "' is not defined");
-                        if (st->get_num("type_id", 0) != 0 && m.pp_unsupported.empty()) m.pp_unsupported = "TemplateProcessing special token with a non-zero type_id";
-                        for (auto& x : ids->arr) (n_seq ? post : pre).push_back((uint32_t)x->num);
+                        const double ty = st->get_num("type_id", 0);
+                        max_ty = std::max(max_ty, ty);
+                        for (auto& x : ids->arr) { (n_seq ? post : pre).push_back((uint32_t)x->num); (n_seq ? post_ty : pre_ty).push_back((uint8_t)ty); }
                     } else throw Invalid("tokenizer.json: bad TemplateProcessing piece");
                 }
                 if (n_seq != 1 && m.pp_unsupported.empty()) m.pp_unsupported = "TemplateProcessing single template must contain sequence A exactly once";
+                if (max_ty > 255 && m.pp_unsupported.empty()) m.pp_unsupported = "TemplateProcessing type id above 255";
+                if (max_ty > 0 && m.pp_unsupported.empty()) {
+                    // (a second post-processor would see -- and a second template overwrite -- these type ids)
+                    if (!m.pp_prefix.empty() || !m.pp_suffix.empty() || m.pp_single_typed) m.pp_unsupported = "a TemplateProcessing with type ids combined with another post-processor";
+                    else m.pp_single_typed = true, m.pp_seq_ty = (uint32_t)seq_ty;
+                } else if (m.pp_single_typed && m.pp_unsupported.empty()) {
+                    m.pp_unsupported = "a TemplateProcessing with type ids combined with another post-processor";
+                }
                 if (m.pp_unsupported.empty()) {
                     m.pp_prefix.insert(m.pp_prefix.begin(), pre.begin(), pre.end());
                     m.pp_suffix.insert(m.pp_suffix.end(), post.begin(), post.end());
+                    m.pp_prefix_ty.insert(m.pp_prefix_ty.begin(), pre_ty.begin(), pre_ty.end());
+                    m.pp_suffix_ty.insert(m.pp_suffix_ty.end(), post_ty.begin(), post_ty.end());
+                } else {
+                    m.pp_single_typed = false;
+                    m.pp_single_refused = true;           // (sequence A twice, or typed, comes out that way without special tokens too)
                 }
                 // the `pair` template (processors/template.rs:544-590): any order of A, B and special tokens, each with its type id
                 if (!m.pp_pair.empty()) m.pp_pair_unsupported = "two post-processors that add special tokens";

@@ -69,7 +69,13 @@ struct HostModel {
     struct TplPiece { uint32_t kind, id, type_id; };
     std::vector<TplPiece> pp_pair;                 // empty: no adding post-processor (a pair is then A followed by B, type ids 0 / 1)
     std::string pp_pair_unsupported;
-    bool pp_single_typed = false;      // the single template puts a non-zero type id on sequence A: with or without special tokens (refused for single sequences)
+    bool pp_roberta = false;           // RobertaProcessing: with special tokens every type id is 0, overflowing windows included
+    // TemplateProcessing's single template may give its pieces type ids (template.rs:554-575; the sequence's applies with or without
+    // special tokens): single sequences then carry a type id array like pairs do
+    std::vector<uint8_t> pp_prefix_ty, pp_suffix_ty;   // aligned with pp_prefix / pp_suffix
+    uint32_t pp_seq_ty = 0;
+    bool pp_single_typed = false;      // any of the three is non-zero
+    bool pp_single_refused = false;    // a single template outside the path (pp_unsupported says why): it shapes a single sequence with or without special tokens
     // the layout of a pair when NO special tokens are added: A : 0, B : 1 by default (bert.rs:56-58 returns the encodings as they are);
     // RobertaProcessing zeroes every type id first (roberta.rs); TemplateProcessing still applies its order and type ids
     std::vector<TplPiece> pp_pair_plain = {{0, 0, 0}, {1, 0, 1}};

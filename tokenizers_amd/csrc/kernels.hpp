@@ -171,6 +171,14 @@ struct FinalArgs {
     uint32_t* pad_count;              // [n_docs] padding tokens of each encoding (null without padding)
     int64_t* n_tok2;
     int* err;
+    // a single template with type ids (TemplateProcessing, template.rs:554-575): every output token's type id and sequence id
+    // (0; 2 special; 3 padding) are written like the pair epilogue writes them.  Null otherwise: single sequences are all type 0.
+    uint8_t* type_ids2;
+    uint8_t* seq_ids2;
+    const uint8_t* prefix_ty;         // [n_prefix] / [n_suffix] type ids of the special tokens
+    const uint8_t* suffix_ty;
+    uint32_t seq_ty;                  // type id of the sequence's own tokens (an overflowing window keeps 0)
+    uint32_t pad_type_id;
 };
 
 // arguments of the PAIR epilogue (k_pair_*): documents 2i / 2i+1 are sequence A / B of encoding i (tokenizer/mod.rs:871-889)
@@ -194,6 +202,7 @@ struct PairArgs {
     // enc_win[4e ..] = {first token of A's window, count, first token of B's window, count}.  With these set, n_pairs of
     // k_pair_finalize counts ENCODINGS and len1 .. pad_count are per encoding.  All null: one encoding per pair.
     uint32_t first_is_b;              // the template names sequence B before sequence A
+    uint32_t ovf_ty_tpl;              // overflowing windows take the template's type id too (RobertaProcessing with special tokens: everything 0)
     uint32_t* ovf_parts;              // [n_pairs + 1]
     int64_t* enc_base;                // [n_pairs + 1]
     uint32_t* enc_doc;

@@ -152,6 +152,23 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs a) {
         const int64_t real = n + a.n_prefix + a.n_suffix, pads = total - real;
         const int64_t body = dst0 + (a.pad_left ? pads : 0);
         if (lane == 0 && a.pad_count) a.pad_count[d] = (uint32_t)pads;
+        if (a.type_ids2) {
+            // the template's type id is put on the sequence's own encoding only (set_type_ids on encodings[0], template.rs:554-559);
+            // the special tokens are fresh encodings in every window
+            const bool own = !a.enc_doc || d == a.enc_base[a.enc_doc[d]];
+            for (int64_t q = lane; q < total; q += 64) {
+                const int64_t r = a.pad_left ? q - pads : q;       // position inside prefix + sequence + suffix
+                uint32_t ty = a.pad_type_id, sq = 3u;
+                if (r >= 0 && r < real) {
+                    sq = 2u;
+                    if (r < a.n_prefix) ty = a.prefix_ty[r];
+                    else if (r < a.n_prefix + n) { ty = own ? a.seq_ty : 0u; sq = 0u; }
+                    else ty = a.suffix_ty[r - a.n_prefix - n];
+                }
+                a.type_ids2[dst0 + q] = (uint8_t)ty;
+                a.seq_ids2[dst0 + q] = (uint8_t)sq;
+            }
+        }
         for (int64_t q = lane; q < pads; q += 64) {
             const int64_t o = a.pad_left ? dst0 + q : body + real + q;
             a.ids2[o] = a.pad_id;
@@ -336,8 +353,9 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PairArgs a) {
                     n = a.enc_win[4 * i + 2 * kind + 1];
                     src = a.tok_offsets[2 * (int64_t)a.enc_doc[i] + kind] + a.enc_win[4 * i + 2 * kind];
                     // the template's type id is put on the sequence's own encoding only (template.rs:554-559); an overflowing window
-                    // keeps what encode gave its tokens: 0 for the first sequence, 1 for the second (mod.rs:879-884)
-                    if (a.enc_idx[2 * i + kind] != 0u) ty_here = kind;
+                    // keeps what encode gave its tokens: 0 for the first sequence, 1 for the second (mod.rs:879-884) -- RobertaProcessing
+                    // writes zeros over its overflowing windows as well when it adds the special tokens (roberta.rs:121-126, 187-192)
+                    if (a.enc_idx[2 * i + kind] != 0u && !a.ovf_ty_tpl) ty_here = kind;
                 } else {
                     const int64_t d = 2 * i + kind;
                     const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo;

@@ -307,7 +307,7 @@ class BatchEncoding:
         self.offsets = offsets
         self.word_ids = word_ids            # uint32, 0xFFFFFFFF = None (special tokens, padding)
         self.pad_counts = pad_counts        # uint32 per document: padding tokens (None without a `padding` section)
-        self.type_ids = None                # pairs only: uint8 per token
+        self.type_ids = None                # pairs, and single sequences under a template with type ids: uint8 per token
         self.seq_ids = None                 # pairs only: uint8 per token, 0 / 1 sequence A / B, 2 special token, 3 padding
         # overflowing encodings materialised: tok_offsets / pad_counts run over ENCODINGS, enc_docs[e] = the input encoding e belongs to
         # (an input's own encoding first, then its Encoding.overflowing), _first[i] = the own encoding of input i
@@ -598,22 +598,9 @@ class Tokenizer:
         if not is_pair:
             self._check_special(True)
             return sum(self._specials)
-        pp = json.loads(self._json).get("post_processor")
-        if not pp:
-            return 0
-
-        def count(p):
-            t = p.get("type")
-            if t == "BertProcessing":
-                return 3
-            if t == "RobertaProcessing":
-                return 4
-            if t == "TemplateProcessing":
-                return sum(len(p["special_tokens"][x["SpecialToken"]["id"]]["ids"]) for x in p.get("pair", []) if "SpecialToken" in x)
-            if t == "Sequence":
-                return sum(count(q) for q in p.get("processors", []))
-            return 0
-        return count(pp)
+        pieces, n = (C.c_uint32 * (3 * 80))(), C.c_int32(0)          # the pair template as the library parsed it: (kind, id, type id) a piece
+        _lib.check(self._lib.tkamd_tokenizer_pair_template(self._h, 1, pieces, 80, C.byref(n)))
+        return sum(1 for i in range(min(n.value, 80)) if pieces[3 * i] == 2)
 
     # ---- the hot path ----
     def _check_special(self, add_special_tokens: bool) -> None:
@@ -747,9 +734,10 @@ class Tokenizer:
                            self.info["padding"] == 2, self.info["pad_type_id"], self._pad_token)
         be._no_seq_ranges = self._no_post_processor
         tp = self._lib.tkamd_batch_type_ids(b)
-        if tp:
+        if tp or pairs:                          # (a pair batch without a single token has no arrays: empty views)
             be.type_ids = view(tp, C.c_uint8, (nt,), np.uint8)
-            be.seq_ids = view(self._lib.tkamd_batch_sequence_ids(b), C.c_uint8, (nt,), np.uint8)
+            if pairs:                            # (single sequences under a template with type ids: the layout says the rest)
+                be.seq_ids = view(self._lib.tkamd_batch_sequence_ids(b), C.c_uint8, (nt,), np.uint8)
         ed = self._lib.tkamd_batch_encoding_docs(b)
         if ed:
             be.enc_docs = view(ed, C.c_uint32, (n_docs,), np.uint32)
