@@ -789,3 +789,27 @@ def test_special_token_counts_and_the_untagged_post_processor_match_the_wheel(re
             got = [pieces[3 * i + 1] if pieces[3 * i] == 2 else ("A", "B")[pieces[3 * i]] for i in range(n.value)]
             a, b = r.encode("a", add_special_tokens=False).ids[0], r.encode("b", add_special_tokens=False).ids[0]
             assert got == [("A" if x == a else "B" if x == b else x) for x in exp], pp
+
+
+def test_truncation_padding_getters_and_to_str_match_the_wheel(ref_tokenizers, tmp_path):
+    """Tokenizer.truncation / .padding (the dicts the reference's getters show) after enable_* / no_*, and to_str / save: the wheel
+    loads what the mirror writes into the tokenizer the wheel itself holds after the same calls."""
+    js = load_tokenizer_json("bert_wordpiece_4000_specials")
+    t, r = ta.Tokenizer.from_str(js, device=-1), ref_tokenizers.Tokenizer.from_str(js)
+    assert (t.truncation, t.padding) == (r.truncation, r.padding) == (None, None)
+    for kw in (dict(max_length=7), dict(max_length=9, stride=2, strategy="only_second", direction="left"), dict(max_length=5, strategy="only_first")):
+        t.enable_truncation(**kw)
+        r.enable_truncation(**kw)
+        assert t.truncation == r.truncation, kw
+    for kw in (dict(), dict(direction="left", pad_id=3, pad_type_id=2, pad_token="x", length=12, pad_to_multiple_of=4)):
+        t.enable_padding(**kw)
+        r.enable_padding(**kw)
+        assert t.padding == r.padding, kw
+    t.add_tokens(["zzzq"])
+    r.add_tokens(["zzzq"])
+    assert ref_tokenizers.Tokenizer.from_str(t.to_str()).to_str() == r.to_str()
+    t.save(str(tmp_path / "tok.json"))
+    assert ref_tokenizers.Tokenizer.from_file(str(tmp_path / "tok.json")).to_str() == r.to_str()
+    assert ta.Tokenizer.from_file(str(tmp_path / "tok.json"), device=-1).truncation == r.truncation
+    t.no_truncation(), t.no_padding(), r.no_truncation(), r.no_padding()
+    assert (t.truncation, t.padding) == (r.truncation, r.padding) == (None, None)

@@ -526,6 +526,36 @@ class Tokenizer:
         d["padding"] = None
         self._reload(d)
 
+    @property
+    def truncation(self) -> dict | None:
+        """The truncation section as the reference's getter shows it (bindings/python/src/tokenizer.rs:820-840)."""
+        t = json.loads(self._json).get("truncation")
+        if not t:
+            return None
+        snake = {"LongestFirst": "longest_first", "OnlyFirst": "only_first", "OnlySecond": "only_second"}
+        return {"max_length": int(t["max_length"]), "stride": int(t.get("stride", 0)), "strategy": snake[t.get("strategy", "LongestFirst")],
+                "direction": t.get("direction", "Right").lower()}
+
+    @property
+    def padding(self) -> dict | None:
+        """The padding section as the reference's getter shows it (bindings/python/src/tokenizer.rs:930-960): `length` of a Fixed
+        strategy, None for BatchLongest."""
+        p = json.loads(self._json).get("padding")
+        if not p:
+            return None
+        st = p.get("strategy", "BatchLongest")
+        return {"length": int(st["Fixed"]) if isinstance(st, dict) else None, "pad_to_multiple_of": p.get("pad_to_multiple_of"), "pad_id": int(p.get("pad_id", 0)),
+                "pad_token": p.get("pad_token", "[PAD]"), "pad_type_id": int(p.get("pad_type_id", 0)), "direction": p.get("direction", "Right").lower()}
+
+    def to_str(self, pretty: bool = False) -> str:
+        """The tokenizer.json this handle was made from, with what enable_* / add_tokens changed since (Tokenizer.to_str)."""
+        d = json.loads(self._json)
+        return json.dumps(d, ensure_ascii=False, indent=2) if pretty else json.dumps(d, ensure_ascii=False, separators=(",", ":"))
+
+    def save(self, path: str, pretty: bool = True) -> None:
+        with open(path, "w", encoding="utf-8") as f:
+            f.write(self.to_str(pretty))
+
     # ---- Tokenizer.add_tokens / add_special_tokens (AddedVocabulary::add_tokens, tokenizer/added_vocabulary.rs:272-360; Python
     # tokenizer.rs:1262-1308): the added vocabulary lives in the tokenizer.json's `added_tokens`, so the handle is re-created ----
     def _add(self, tokens, special: bool) -> int:
