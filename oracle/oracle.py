@@ -141,7 +141,9 @@ class Oracle:
         L.oracle_set_trim(self._h, trim, int(pp.get("add_prefix_space", True)))
         if bn:
             L.oracle_set_bert_normalizer(self._h, *bn)
-        for a in d.get("added_tokens") or []:
+        # (the automaton is built over the special tokens first, then the others, each in the order they were added -- of two tokens
+        # with one normalized pattern the first in that order is reported, refresh_added_tokens added_vocabulary.rs:379-399)
+        for a in sorted(d.get("added_tokens") or [], key=lambda a: not a.get("special", False)):
             c = a["content"].encode("utf-8")
             L.oracle_add_token(self._h, c, len(c), int(a["id"]), int(a.get("single_word", False)), int(a.get("lstrip", False)),
                                int(a.get("rstrip", False)), int(a.get("normalized", False)))
@@ -180,7 +182,7 @@ class Oracle:
         b = C.c_void_p()
         rc = self._L.oracle_encode_batch(self._h, blob.ctypes.data, off.ctypes.data, len(docs), C.byref(b))
         if rc:
-            raise OracleError({-4: "MissingUnkToken", -2: "unsupported input (e.g. non-ASCII through BertNormalizer)"}.get(rc, str(rc)))
+            raise OracleError({-4: "MissingUnkToken", -2: "unsupported input (e.g. non-ASCII through BertNormalizer)", -5: "AddedVocabulary bad split"}.get(rc, str(rc)))
         try:
             n = self._L.oracle_batch_n_tokens(b)
             def arr(ptr, ct, shape):

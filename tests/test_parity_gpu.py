@@ -694,3 +694,58 @@ def test_added_vocabulary_of_random_shape_matches_the_wheel_live(ref_tokenizers)
         for i, e in enumerate(exp):
             ctx = (name, [(a["content"], a["single_word"], a["lstrip"], a["rstrip"], a["normalized"]) for a in d["added_tokens"][-len(toks):]], ascii(docs[i]))
             assert got[i].ids == e.ids and [tuple(o) for o in got[i].offsets] == [tuple(o) for o in e.offsets] and got[i].word_ids == e.word_ids, ctx
+
+
+def test_added_token_corners_the_random_differential_found(ref_tokenizers):
+    """Corners tools/fuzz_live.py found, pinned on the wheel run here (every field, overflowing encodings included):
+    (1) an lstrip + rstrip token that lies wholly inside the whitespace the previous match swallowed becomes an EMPTY split at that
+        match's stop and is dropped like every empty split (added_vocabulary.rs:466-477, pre_tokenizer.rs:90-96); without rstrip the
+        range is inverted and the reference panics ("AddedVocabulary bad split") -- an error here;
+    (2) process_offsets' "first token" is token 0 of the ENCODING (byte_level.rs:213-216): in a pre-tokenized sequence a later
+        pre-token of word 0 is not it;
+    (3) a trimming post-processor (RobertaProcessing) on a model that is not byte-level still trims an added token's whitespace;
+    (4) a token that is nothing but one whitespace character, as token 0 of an overflowing window: its END moves, not its start."""
+    import json
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    fields = lambda e: (e.ids, e.type_ids, e.attention_mask, e.special_tokens_mask, [tuple(o) for o in e.offsets], e.word_ids, e.sequence_ids)
+    deep = lambda e: [fields(e)] + [fields(o) for o in e.overflowing]
+    A = lambda c, **k: dict({"id": 0, "content": c, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": True}, **k)
+    roberta = {"type": "RobertaProcessing", "sep": ["<s>", 1], "cls": ["<c>", 2], "trim_offsets": True, "add_prefix_space": True}
+    cases = [
+        ("wordlevel_whitespace_c1", dict(pre_tokenizer={"type": "WhitespaceSplit"}, added_tokens=[A("\n", lstrip=True, rstrip=True)]), False,
+         ["558349t''\n\r \r CPKKwg   \r\n  \n\r6987", "\n\n", " \n \n ", "a\n\nb"]),
+        ("bytelevel_prefix_trim_3000", dict(added_tokens=[A("\n", lstrip=True, special=False)]), True,
+         [["カが\t\t\n\r"], ["a", "b\n\rc", ""], ["", "x\ny z"]]),
+        ("wordlevel_wssplit", dict(post_processor=roberta, added_tokens=[A("\n", single_word=True)], truncation={"direction": "Left", "max_length": 40, "strategy": "OnlyFirst", "stride": 1}), True,
+         [["αЯ`", "\t\r\n\r7x'se'", "", "\t\r"], ["\n", " \n"]]),
+        ("wordlevel_wssplit", dict(post_processor=roberta, added_tokens=[A("\n", single_word=True), A(" x ", special=False)]), False,
+         ["ab \n cd x ef", "\n", " \n", "a x \n"]),
+        ("bytelevel_prefix_trim_3000", dict(added_tokens=[A("\n", special=False)], truncation={"direction": "Right", "max_length": 4, "strategy": "OnlyFirst", "stride": 1},
+                                            padding={"strategy": {"Fixed": 12}, "direction": "Left", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 1, "pad_token": "[PAD]"}), False,
+         ["EUhpjZ abc de\r\n 30 x   yz\n\nq", "\n", "a\nb\nc\nd\ne\nf"]),
+        # (5) two tokens with ONE normalized pattern ("ab" behind the lowercasing normalizer): the automaton is built over the special tokens
+        #     first, then the others, in the order they were added -- the first in that order is reported (added_vocabulary.rs:379-399)
+        ("bert_wordpiece_4000_specials", dict(added_tokens=[A("Ab", normalized=True, special=False), A("AB", normalized=True), A("aB", normalized=True)]), False, ["x ab y AB Ab aB"]),
+        ("bert_wordpiece_4000_specials", dict(added_tokens=[A("Ab", normalized=True, special=False), A("AB", normalized=True, special=False)]), False, ["x ab y AB Ab aB"]),
+    ]
+    for name, patch, pre, inputs in cases:
+        d = json.loads(load_tokenizer_json(name))
+        d.update(patch)
+        if name == "bytelevel_prefix_trim_3000" and "truncation" in patch:
+            d["pre_tokenizer"]["add_prefix_space"] = False
+        js = json.dumps(d, ensure_ascii=False)
+        ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
+        for special in (False, True):
+            exp = ref.encode_batch(inputs, add_special_tokens=special, is_pretokenized=pre)
+            got = tok.encode_batch(inputs, add_special_tokens=special, is_pretokenized=pre)
+            for i, e in enumerate(exp):
+                assert deep(e) == deep(got[i]), (name, patch.keys(), special, inputs[i])
+    # the inverted range: <r> swallows " \n " to its right, the automaton then finds "\n" inside it; lstrip pushes its start past its end
+    d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
+    d["added_tokens"] = [A("<r>", rstrip=True), A("\n", lstrip=True)]
+    js = json.dumps(d)
+    with pytest.raises(BaseException):
+        ref_tokenizers.Tokenizer.from_str(js).encode_batch(["a <r> \n x"])
+    with pytest.raises(ValueError, match="bad split"):
+        ta.Tokenizer.from_str(js, device=0).encode_batch(["a <r> \n x"])

@@ -112,7 +112,7 @@ struct Workspace {
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
-    DevBuf w_seq_off, w_seq_tok_off, w_word_idx;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
+    DevBuf w_seq_off, w_seq_tok_off, w_word_idx, w_first_tok;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
     // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
     std::vector<StageRec> pending;
     // last call (for tkamd_device_sync, which runs it again if a work queue overflowed)
@@ -1229,14 +1229,17 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                            w->w_tok_offsets.as<int64_t>());
     pf.end();
     const uint32_t* word_of_doc = nullptr;
+    const int64_t* first_tok = nullptr;
     if (words_in) {
         // the words' token CSR -> the sequences'; the word id of a token is its word's index in the sequence
         if (want_words) { w->w_word_idx.reserve((size_t)(n_docs + 2) * 4); word_of_doc = w->w_word_idx.as<uint32_t>(); }
-        launch_seq_regroup(st, d_seq_off, n_seqs, n_docs, w->w_tok_offsets.as<int64_t>(), w->w_seq_tok_off.as<int64_t>(), (uint32_t*)word_of_doc);
+        if (off_mode != TKAMD_OFFSETS_NONE && hm.trim_offsets) { w->w_first_tok.reserve((size_t)(n_docs + 2) * 8); first_tok = w->w_first_tok.as<int64_t>(); }
+        launch_seq_regroup(st, d_seq_off, n_seqs, n_docs, w->w_tok_offsets.as<int64_t>(), w->w_seq_tok_off.as<int64_t>(), (uint32_t*)word_of_doc, (int64_t*)first_tok);
     }
     if (want_meta) {
         MetaArgs a{};
         a.word_of_doc = word_of_doc;
+        a.first_tok = first_tok;
         a.x_text = x_text;
         a.text = d_text;
         a.pt_start = w->w_pt_start.as<uint32_t>();
@@ -1252,7 +1255,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.norig = norig;                                   // normalised / shifted text: every byte's original byte range
         a.norig_e = norig_e;
         a.byte_level = hm.byte_level;
-        a.trim_offsets = hm.byte_level && hm.trim_offsets;
+        a.trim_offsets = hm.trim_offsets;
+        a.trim_matches_only = !hm.byte_level;            // (a model that is not byte-level: only an added token's slice can hold what is trimmed; the loader checked the vocabulary)
         a.pp_add_prefix_space = hm.pp_add_prefix_space;
         a.want_offsets = off_mode != TKAMD_OFFSETS_NONE;
         a.char_mode = off_mode == TKAMD_OFFSETS_CHAR;
@@ -1338,6 +1342,7 @@ int error_from_bits(int bits) {
         return set_error(TKAMD_ERR_UNSUPPORTED, "BertNormalizer strip_accents: a character with a non-zero combining class that survives the Mn filter "
                                                 "stands in a run of more than 48 combining characters; NFD's canonical ordering of such a run is not built "
                                                 "on the device");
+    if (bits & ERR_ADDED_SPLIT) return set_error(TKAMD_ERR_INVALID, "AddedVocabulary bad split");
     if (bits & ERR_INTERNAL) return set_error(TKAMD_ERR_DEVICE, "internal invariant violated");
     if (bits & ERR_QUEUE_FULL) return set_error(TKAMD_ERR_DEVICE, "work queues still too small after growing them");
     if (bits & ERR_TRUNC_SECOND) return set_error(TKAMD_ERR_INVALID, "Truncation error: Second sequence not provided");

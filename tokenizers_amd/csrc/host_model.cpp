@@ -688,6 +688,24 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         if (kv.second->num < 0 || kv.second->num >= (double)(1u << 24)) throw Unsupported("token id beyond 2^24 (vocab entry '" + kv.first + "')");
     }
     m.vocab_size = (uint32_t)v.size();
+    if (m.trim_offsets && !m.byte_level) {
+        // a trimming post-processor (ByteLevel / RobertaProcessing) on a model that is not byte-level: process_offsets moves the offsets
+        // of every token whose STRING starts or ends with whitespace or 'Ġ' (byte_level.rs:202-234).  The added tokens' raw slices
+        // can (k_token_meta trims those); a vocabulary entry that could is outside the path
+        if (m.uc_stage1.empty()) build_unicode(m);
+        for (auto& kv : v) {
+            const uint8_t* b = (const uint8_t*)kv.first.data();
+            const size_t n = kv.first.size();
+            if (!n) continue;
+            uint32_t c0 = 0, c1 = 0;
+            utf8_decode(b, n, &c0);
+            size_t q = n - 1;
+            while (q > 0 && (b[q] & 0xC0u) == 0x80u) --q;
+            utf8_decode(b + q, n - q, &c1);
+            auto trimmed = [&](uint32_t c) { return c == 0x120u || (c < 0x110000u && (m.uc_stage2[((size_t)m.uc_stage1[c >> 8] << 8) | (c & 255u)] & UC_RUST_WS)); };
+            if (trimmed(c0) || trimmed(c1)) throw Unsupported("post_processor with trim_offsets on a vocabulary that is not byte-level and holds an entry with leading / trailing whitespace or 'Ġ' ('" + kv.first + "')");
+        }
+    }
 
     // The ids the reference gives the added tokens are not the ones in the file: deserialisation hands them, in file order, to
     // AddedVocabulary::add_tokens (serialization.rs:153-167 -- it only WARNS when the outcome differs from the file), which gives a
@@ -863,7 +881,15 @@ HostModel HostModel::from_json(const char* json, size_t len) {
     {
         struct Pat { std::string s; uint32_t id, flags; };
         std::vector<Pat> pats[2];
-        for (const AddedToken& a : m.added_tokens) {
+        // the automaton is built over the special tokens first, then the others, each in the order they were added
+        // (refresh_added_tokens, added_vocabulary.rs:379-399): of two tokens with one pattern -- "Ab" and "AB" behind a lowercasing
+        // normalizer -- the first in THAT order is the one a match reports
+        std::vector<const AddedToken*> order;
+        for (int pass = 0; pass < 2; ++pass)
+            for (const AddedToken& a : m.added_tokens)
+                if ((pass == 0) == a.special) order.push_back(&a);
+        for (const AddedToken* ap : order) {
+            const AddedToken& a = *ap;
             if (a.content.empty()) continue;                       // add_tokens ignores empty contents (added_vocabulary.rs:288-291)
             std::string pat = a.content;
             if (a.normalized && m.norm == NORM_BERT) {
@@ -876,10 +902,10 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         }
         for (int c = 0; c < 2; ++c) {
             std::vector<Pat>& ps = pats[c];
-            // equal patterns: the automaton keeps one value per pattern; the token registered last wins like a map insert
+            // equal patterns: the first one in the automaton's order is reported
             std::stable_sort(ps.begin(), ps.end(), [](const Pat& x, const Pat& y) { return x.s < y.s; });
             std::vector<Pat> uniq;
-            for (const Pat& p : ps) { if (!uniq.empty() && uniq.back().s == p.s) uniq.back() = p; else uniq.push_back(p); }
+            for (const Pat& p : ps) { if (uniq.empty() || uniq.back().s != p.s) uniq.push_back(p); }
             PatternSet& S = m.at[c];
             S.first.assign(257, 0);
             S.off.push_back(0);

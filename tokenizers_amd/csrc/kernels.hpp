@@ -89,6 +89,7 @@ struct MetaArgs {
     const int64_t* n_pretok;
     const uint32_t* doc_pt;
     const uint32_t* word_of_doc;      // is_pretokenized: word id of every token of document d (its index in the sequence); else null
+    const int64_t* first_tok;         // is_pretokenized with trim_offsets: index of the first token of document d's sequence; else null
     int64_t n_docs;
     const int64_t* x_doc_off;         // document CSR in x space
     const int64_t* doc_off;           // document CSR in the original text
@@ -97,6 +98,7 @@ struct MetaArgs {
     const unsigned long long* leadmask;   // char mode: lead-byte bitmask of the original text + its prefix
     const uint32_t* lprefix;
     uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
+    uint32_t trim_matches_only;       // trim_offsets on a model that is not byte-level: only added-token matches are looked at
     const unsigned long long* matchmask;  // added-token matches (their offsets trim real whitespace chars), or null
     const uint16_t* uc1;
     const uint8_t* uc2;
@@ -227,7 +229,7 @@ struct PairArgs {
 enum : int {
     ERR_BAD_OFFSETS = 1,          // doc_offsets not a valid CSR over [0, n_bytes]
     ERR_PRETOKEN_TOO_LONG = 2,    // a pre-token exceeds LONG_PT_MAX symbols
-    ERR_ADDED_TOKEN = 4,          // an added/special token occurs in the text (AddedVocabulary split needed)
+    ERR_ADDED_SPLIT = 4,          // an lstrip added token whose start was pushed past its own end by the previous match (the reference panics: "AddedVocabulary bad split")
     ERR_NON_ASCII_NORM = 8,       // BertNormalizer on non-ASCII text (full-Unicode path not built yet)
     ERR_MISSING_UNK = 16,
     ERR_INTERNAL = 32,            // an internal invariant was violated (bug guard)
@@ -290,7 +292,8 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
-void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx);
+void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx,
+                        int64_t* first_tok);
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 // truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy

@@ -183,6 +183,14 @@ __global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, c
                 // this match starts inside the whitespace the previous (rstrip) one swallowed: the two splits overlap in the reference;
                 // in the flat text the earlier one ends, for the masks, where this one starts (its full length stays on record)
                 if (prev != 0xFFFFFFFFu && start < start_offset) match_list[4 * prev + 1] = (uint32_t)start;
+                // an lstrip match that lay wholly inside that whitespace has its start pushed up to the previous stop: with rstrip it is
+                // an EMPTY split there (dropped with the other empty splits, pre_tokenizer.rs:90-96; the sentence goes on behind it),
+                // without, an inverted range the reference cannot slice ("AddedVocabulary bad split")
+                if (stop <= start) {
+                    if (stop < start) atomicOr(err, ERR_ADDED_SPLIT);
+                    start_offset = stop > start_offset ? stop : start_offset;
+                    continue;
+                }
                 const uint32_t mi = atomicAdd(n_match, 1u);
                 if (mi < cap) {
                     match_list[4 * mi] = (uint32_t)start;

@@ -148,9 +148,11 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask) {
     hipLaunchKernelGGL(k_leadmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, leadmask);
 }
-void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx) {
+void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx,
+                        int64_t* first_tok) {
     hipLaunchKernelGGL(k_seq_tok_offsets, dim3(blocks_for(n_seqs + 1, 256)), dim3(256), 0, st, seq_off, n_seqs, word_tok_off, seq_tok_off);
-    if (widx && n_words) hipLaunchKernelGGL(k_word_index, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, seq_off, n_seqs, n_words, widx);
+    if ((widx || first_tok) && n_words)
+        hipLaunchKernelGGL(k_word_index, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, seq_off, n_seqs, n_words, widx, (const int64_t*)seq_tok_off, first_tok);
 }
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);

@@ -152,12 +152,15 @@ __global__ void k_seq_tok_offsets(const int64_t* __restrict__ seq_off, int64_t n
     if (s <= n_seqs) seq_tok_off[s] = word_tok_off[seq_off[s]];
 }
 // Encoding.word_ids of a pre-tokenized sequence: the index of the word in its sequence (do_tokenize's word_idx, mod.rs:1178-1200)
-__global__ void k_word_index(const int64_t* __restrict__ seq_off, int64_t n_seqs, int64_t n_words, uint32_t* __restrict__ widx) {
+// first_tok (process_offsets needs "token 0 of the encoding", byte_level.rs:213-216): the index of the first token of the word's sequence
+__global__ void k_word_index(const int64_t* __restrict__ seq_off, int64_t n_seqs, int64_t n_words, uint32_t* __restrict__ widx,
+                             const int64_t* __restrict__ seq_tok_off, int64_t* __restrict__ first_tok) {
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     int64_t lo = 0, hi = n_seqs;                          // last s with seq_off[s] <= w
     while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (seq_off[mid] <= w) lo = mid; else hi = mid; }
-    widx[w] = (uint32_t)(w - seq_off[lo]);
+    if (widx) widx[w] = (uint32_t)(w - seq_off[lo]);
+    if (first_tok) first_tok[w] = seq_tok_off[lo];
 }
 
 // =================================================================================================
@@ -234,30 +237,35 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                     if (is_match) {
                         // an added token's text is the raw slice: its leading / trailing chars are tested with char::is_whitespace
                         uint32_t q = tts;
-                        while (q < tte) { uint32_t l; if (!(uc_flags(utf8_global(ttext, q, &l), a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
+                        while (q < tte) { uint32_t l; const uint32_t cp = utf8_global(ttext, q, &l); if (cp != 0x120u && !(uc_flags(cp, a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
                         q = tte;
                         while (q > tts) {
                             uint32_t r = q - 1;
                             while (r > tts && (ttext[r] & 0xC0u) == 0x80u) --r;
                             uint32_t l;
-                            if (!(uc_flags(utf8_global(ttext, r, &l), a.uc1, a.uc2) & UC_RUST_WS)) break;
+                            const uint32_t cp = utf8_global(ttext, r, &l);
+                            if (cp != 0x120u && !(uc_flags(cp, a.uc1, a.uc2) & UC_RUST_WS)) break;   // (*c == 'Ġ' || c.is_whitespace())
                             ++trail_sp;
                             q = r;
                         }
-                    } else {
+                    } else if (!a.trim_matches_only) {
                         while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
                         while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
                     }
                     bool took_one = false;
+                    const uint32_t os0 = os, oe0 = oe;
                     if (lead_sp) {
-                        bool is_first = (word == 0 && j == 0) || os == 0;
+                        // (token 0 of the encoding, or offsets that start at 0 -- every word of a pre-tokenized sequence, byte_level.rs:213-216;
+                        // `word` is no test for it: all pre-tokens of a sequence's word 0 carry word id 0; first_tok: pre-tokenized input)
+                        bool is_first = (a.first_tok ? (int64_t)(o + j) == a.first_tok[d] : (p == (int64_t)a.doc_pt[d] && j == 0)) || os == 0;
                         if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
                         took_one = lead_sp == 1 && a.pp_add_prefix_space && os < oe;
                         os = min(os + lead_sp, oe);
                     }
-                    // (2: the token IS that one space -- kept as the first token of an encoding, its END is what the trailing trim moves)
-                    if (a.trim1) a.trim1[o + j] = took_one ? ((!is_match && te - ts == 1u) ? 2 : 1) : 0;
                     if (trail_sp && oe >= trail_sp) oe = max(oe - trail_sp, os);
+                    // (2: as token 0 of an encoding its END would differ too -- the token is nothing but that one space, so the trailing
+                    // trim stops at a start that lies one further left)
+                    if (a.trim1) a.trim1[o + j] = !took_one ? 0 : (((trail_sp && oe0 >= trail_sp) ? max(oe0 - trail_sp, os0) : oe0) != oe) ? 2 : 1;
                 }
                 a.offsets[2 * (size_t)(o + j)] = os;
                 a.offsets[2 * (size_t)(o + j) + 1] = oe;

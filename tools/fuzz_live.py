@@ -144,6 +144,7 @@ while time.time() - t0 < budget:
     for i, e in enumerate(exp):
         if deep(e) != deep(got[i]):
             print("MISMATCH", ctx, repr(inputs[i]))
+            json.dump({"json": js, "inputs": [inputs[i]], "special": special, "pre": pre}, open(f"/tmp/fuzz_fail_{seed}.json", "w"), ensure_ascii=False)
             a, b = deep(e), deep(got[i])
             print(" encodings", len(a), len(b))
             for k, (x, y) in enumerate(zip(a, b)):
