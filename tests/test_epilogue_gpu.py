@@ -375,3 +375,31 @@ def test_template_shapes_match_the_wheel_live(ref_tokenizers):
                 else:
                     with pytest.raises(ta.UnsupportedError):
                         tok.encode_batch(docs, add_special_tokens=special)
+
+
+def test_batches_mixing_single_sequences_and_pairs_match_the_wheel_live(ref_tokenizers):
+    """Vec<EncodeInput> may mix Single and Dual items (tokenizer/mod.rs:1337-1356).  The mirror sends the two kinds down as two calls
+    and puts the encodings back in order; BatchLongest padding -- the one thing that couples them, pad_encodings takes the longest
+    encoding of the whole batch (utils/padding.rs:50-81) -- is resolved from an unpadded run.  Raw and pre-tokenized."""
+    import tokenizers_amd as ta
+    from oracle import synth
+    docs = [d[:50] for d in synth.gen_lines(16, text_seed=21) if "[" not in d]
+    mixed = [docs[0], (docs[1], docs[2]), docs[3], "", (docs[4], ""), (docs[5], docs[6] + " " + docs[7]), docs[8]]
+    words = [x.split() if isinstance(x, str) else (x[0].split(), x[1].split()) for x in mixed]
+    fields = lambda e: (e.ids, e.type_ids, e.attention_mask, e.special_tokens_mask, [tuple(o) for o in e.offsets], e.word_ids, e.sequence_ids, e.tokens)
+    deep = lambda e: [fields(e)] + [fields(o) for o in e.overflowing]
+    P = lambda **k: dict({"strategy": "BatchLongest", "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}, **k)
+    T = {"direction": "Right", "max_length": 12, "strategy": "LongestFirst", "stride": 1}
+    for name in ("bert_wordpiece_4000_specials", "llama3_small_6000_specials"):
+        for trunc, pad in ((None, None), (None, P()), (T, P(pad_to_multiple_of=8, direction="Left")), (T, P(strategy={"Fixed": 20})), (T, None)):
+            d = dict(json.loads(load_tokenizer_json(name)), truncation=trunc, padding=pad)
+            js = json.dumps(d, ensure_ascii=False)
+            ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
+            for special in (True, False):
+                for inputs, pre in ((mixed, False), (words, True)):
+                    exp = ref.encode_batch(inputs, add_special_tokens=special, is_pretokenized=pre)
+                    got = tok.encode_batch(inputs, add_special_tokens=special, is_pretokenized=pre)
+                    assert len(exp) == len(got)
+                    for i, e in enumerate(exp):
+                        assert deep(e) == deep(got[i]), (name, trunc, pad, special, pre, inputs[i])
+                assert [e.ids for e in ref.encode_batch_fast(mixed, add_special_tokens=special)] == [e.ids for e in tok.encode_batch_fast(mixed, add_special_tokens=special)]

@@ -94,6 +94,7 @@ def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers)
     from tests import test_epilogue_gpu as E
     E.test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers)
     E.test_template_shapes_match_the_wheel_live(ref_tokenizers)
+    E.test_batches_mixing_single_sequences_and_pairs_match_the_wheel_live(ref_tokenizers)
 
 
 def test_normalizer_added_vocabulary_and_models(ref_tokenizers):

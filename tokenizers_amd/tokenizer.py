@@ -668,8 +668,8 @@ class Tokenizer:
             return self._encode_words(inputs, offsets, word_ids, add_special_tokens, overflowing)
         pairs = len(inputs) > 0 and isinstance(inputs[0], (tuple, list))
         if pairs:
-            # EncodeInput::Dual for every item (a batch mixing single sequences and pairs is outside this path): A and B as
-            # neighbouring documents
+            # EncodeInput::Dual for every item: A and B as neighbouring documents (encode_batch / encode_batch_fast split a small batch
+            # that mixes single sequences and pairs into two calls; a CSR holds one kind)
             flat = []
             for it in inputs:
                 if not isinstance(it, (tuple, list)) or len(it) != 2 or not isinstance(it[0], str) or not isinstance(it[1], str):
@@ -788,16 +788,50 @@ class Tokenizer:
         item = sequence if pair is None else (sequence, pair)
         return self.encode_batch([item], is_pretokenized=is_pretokenized, add_special_tokens=add_special_tokens)[0]
 
-    def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
-        """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338)."""
+    def _encode_any(self, input, offsets: str, word_ids: bool, add_special_tokens: bool, is_pretokenized: bool):
         # (no list(input) for a list: copying a million references touches -- and later releases -- every str object once more)
-        return self.encode_batch_csr(input if isinstance(input, (list, tuple)) else list(input), offsets="char", word_ids=True, add_special_tokens=add_special_tokens,
-                                     is_pretokenized=is_pretokenized, overflowing=self.info["truncation"] >= 0)
+        inputs = input if isinstance(input, (list, tuple)) else list(input)
+        if is_pretokenized:
+            is_pair = lambda it: isinstance(it, (tuple, list)) and len(it) == 2 and all(isinstance(x, (list, tuple)) for x in it)
+        else:
+            is_pair = lambda it: isinstance(it, (tuple, list))
+        overflowing = self.info["truncation"] >= 0
+        first = is_pair(inputs[0]) if len(inputs) else False
+        # a batch of one kind (every batch worth the device) goes down as it is; its items are checked on the way
+        if len(inputs) < 2 or len(inputs) > 4096 or all(is_pair(it) == first for it in inputs):
+            return self.encode_batch_csr(inputs, offsets=offsets, word_ids=word_ids, add_special_tokens=add_special_tokens,
+                                         is_pretokenized=is_pretokenized, overflowing=overflowing)
+        # Vec<EncodeInput> may mix Single and Dual items (tokenizer/mod.rs:1337-1356): the two kinds are two calls, put back in order.
+        # What couples them is BatchLongest padding -- pad_encodings takes the longest encoding of the WHOLE batch
+        # (utils/padding.rs:50-81) --: the lengths are taken from an unpadded run and the batch is then padded to that, Fixed.
+        groups = [[i for i, it in enumerate(inputs) if not is_pair(it)], [i for i, it in enumerate(inputs) if is_pair(it)]]
+        run = lambda t: [t.encode_batch_csr([inputs[i] for i in g], offsets=offsets, word_ids=word_ids, add_special_tokens=add_special_tokens,
+                                            is_pretokenized=is_pretokenized, overflowing=overflowing) for g in groups]
+        tok, pad = self, self.padding
+        if pad is not None and pad["length"] is None:
+            d = json.loads(self._json)
+            d["padding"] = None
+            plain = run(Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=self.device))
+            target = max(len(e) for b in plain for e in b)
+            m = pad["pad_to_multiple_of"]
+            if m and target % m:
+                target += m - target % m
+            d["padding"] = dict(json.loads(self._json)["padding"], strategy={"Fixed": int(target)})
+            tok = Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=self.device)
+        out: list = [None] * len(inputs)
+        for g, b in zip(groups, run(tok)):
+            for i, e in zip(g, b):
+                out[i] = e
+        return out
+
+    def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
+        """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338).  A batch that mixes single sequences and pairs
+        comes back as a list of :class:`Encoding` (two calls underneath); every other batch as one :class:`BatchEncoding`."""
+        return self._encode_any(input, "char", True, add_special_tokens, is_pretokenized)
 
     def encode_batch_fast(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch_fast`` (no offsets, tokenizer.rs:1433-1459)."""
-        return self.encode_batch_csr(input if isinstance(input, (list, tuple)) else list(input), offsets="none", word_ids=False, add_special_tokens=add_special_tokens,
-                                     is_pretokenized=is_pretokenized, overflowing=self.info["truncation"] >= 0)
+        return self._encode_any(input, "none", False, add_special_tokens, is_pretokenized)
 
     def decode_batch_csr(self, ids: np.ndarray, tok_offsets: np.ndarray, skip_special_tokens: bool = True) -> tuple[np.ndarray, np.ndarray]:
         """ids CSR -> (bytes uint8[n_bytes], doc_offsets int64[n_docs+1]): the raw decoded byte string of every sequence."""
