@@ -256,6 +256,12 @@ int tkamd_probe_bert_nfd(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* pack
  * Oniguruma sees them, byte_level.rs:43-46), 3 \w, 4 \s (regex crate, whitespace.rs:22), 5 char::is_whitespace, 6 is_bert_punc. */
 int tkamd_probe_unicode_flags(const tkamd_tokenizer* tok, uint32_t cp, uint32_t* flags);
 
+/* Tokenizer.encode_special_tokens (tokenizer/mod.rs:752-759, AddedVocabulary::set_encode_special_tokens added_vocabulary.rs:249-255):
+ * value != 0 -> the special tokens of the added vocabulary are no longer extracted from the text (find_matches skips them,
+ * added_vocabulary.rs:450-453): their characters go through the normalizer, pre-tokenizer and model like any text.  Applies to the
+ * batches enqueued after the call.  Off by default. */
+int tkamd_encode_special_tokens(tkamd_tokenizer* tok, int value);
+
 /* ---- word cache --------------------------------------------------------------------------------
  * What BPE::tokenize_with_cache keeps per thread (models/bpe/model.rs:573-586, utils/cache.rs): pre-token bytes -> its tokens.
  * `enable` != 0: every workspace of the handle keeps a table (1 M entries, in HBM) of the <= 16-byte words its batches have merged

@@ -45,6 +45,8 @@ def lib() -> C.CDLL:
         L.oracle_set_trim.argtypes = [vp, i32, i32]
         L.oracle_set_char_offsets.argtypes = [vp, i32]
         L.oracle_add_token.argtypes = [vp, C.c_char_p, i64, C.c_uint32, i32, i32, i32, i32]
+        L.oracle_mark_last_special.argtypes = [vp]
+        L.oracle_set_encode_special.argtypes = [vp, i32]
         L.oracle_set_bert_normalizer.argtypes = [vp, i32, i32, i32, i32]
         L.oracle_set_vocab.argtypes = [vp, vp, vp, vp, i64]
         L.oracle_set_unk.argtypes = [vp, C.c_char_p, i64]
@@ -147,6 +149,8 @@ class Oracle:
             c = a["content"].encode("utf-8")
             L.oracle_add_token(self._h, c, len(c), int(a["id"]), int(a.get("single_word", False)), int(a.get("lstrip", False)),
                                int(a.get("rstrip", False)), int(a.get("normalized", False)))
+            if a.get("special", False):
+                L.oracle_mark_last_special(self._h)
         toks = list(model["vocab"].items())
         blob, off = _pack([k.encode("utf-8") for k, _ in toks])
         ids = np.array([v for _, v in toks], dtype=np.uint32)
@@ -174,6 +178,10 @@ class Oracle:
         if getattr(self, "_h", None):
             self._L.oracle_free(self._h)
             self._h = None
+
+    def set_encode_special_tokens(self, value: bool) -> None:
+        """Tokenizer.encode_special_tokens (tokenizer/mod.rs:752-759): special tokens stay in the text."""
+        self._L.oracle_set_encode_special(self._h, int(bool(value)))
 
     def encode_batch(self, docs: list[str], char_offsets: bool = False) -> OracleResult:
         """ids + offsets (bytes, or chars like the Python binding's encode_batch) + word ids."""

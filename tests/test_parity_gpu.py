@@ -749,3 +749,39 @@ def test_added_token_corners_the_random_differential_found(ref_tokenizers):
         ref_tokenizers.Tokenizer.from_str(js).encode_batch(["a <r> \n x"])
     with pytest.raises(ValueError, match="bad split"):
         ta.Tokenizer.from_str(js, device=0).encode_batch(["a <r> \n x"])
+
+
+def test_encode_special_tokens_leaves_special_tokens_in_the_text(ref_tokenizers):
+    """Tokenizer.encode_special_tokens (tokenizer/mod.rs:752-759; find_matches skips the special tokens, added_vocabulary.rs:450-453):
+    the reference's own known-answer text (added_vocabulary.rs:1039-1090: "<mask>" stays text, the plain token "ask>" is then found
+    inside it), and the fixtures' special tokens in running text -- against the wheel run here and against the oracle, on and off again."""
+    import json
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    fields = lambda e: (e.ids, [tuple(o) for o in e.offsets], e.word_ids, e.special_tokens_mask)
+    A = lambda c, **k: dict({"id": 0, "content": c, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": True}, **k)
+    known = "Hi <mask> there\t<mask>\t<mask>  <pad> <mask><pad><pad>"
+    cases = [("bert_wordpiece_4000", [A("<mask>", lstrip=True, rstrip=True, single_word=True), A("ask>", normalized=True, special=False), A("<pad>")], [known, "<mask>", "x<pad>y ask> <mask>"]),
+             ("bert_wordpiece_4000_specials", None, ["a [SEP] b [CLS][MASK] c", "[PAD]", "no specials here"]),
+             ("llama3_small_6000_specials", None, ["a<|begin_of_text|>b <|end_of_text|>", "<|end_of_text|>"]),
+             ("bytelevel_prefix_trim_3000", [A("<s>", rstrip=True), A("the", special=False)], ["the <s> cat<s>the", "<s>"])]
+    for name, added, docs in cases:
+        d = json.loads(load_tokenizer_json(name))
+        if added is not None:
+            d["added_tokens"] = added
+        js = json.dumps(d, ensure_ascii=False)
+        ref, tok, orac = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0), orc.Oracle(ref_tokenizers.Tokenizer.from_str(js).to_str())
+        assert tok.encode_special_tokens is False
+        for value in (True, False, True):
+            ref.encode_special_tokens = value
+            tok.encode_special_tokens = value
+            orac.set_encode_special_tokens(value)
+            assert tok.encode_special_tokens is value
+            exp, got = ref.encode_batch(docs, add_special_tokens=False), tok.encode_batch(docs, add_special_tokens=False)
+            assert [fields(e) for e in exp] == [fields(g) for g in got], (name, value)
+            o = orac.encode_batch(docs, char_offsets=True)
+            assert [list(o.doc_ids(i)) for i in range(len(docs))] == [e.ids for e in exp], (name, value)
+        tok.enable_truncation(64)                          # (the handle is re-created: the switch stays on)
+        ref.enable_truncation(64)
+        assert tok.encode_special_tokens is True
+        assert [e.ids for e in ref.encode_batch(docs, add_special_tokens=False)] == [e.ids for e in tok.encode_batch(docs, add_special_tokens=False)]

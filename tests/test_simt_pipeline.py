@@ -101,6 +101,7 @@ def test_normalizer_added_vocabulary_and_models(ref_tokenizers):
     from tests import test_parity_gpu as P
     P.test_bert_normalizer_reorderable_marks(ref_tokenizers)
     P.test_added_token_corners_the_random_differential_found(ref_tokenizers)
+    P.test_encode_special_tokens_leaves_special_tokens_in_the_text(ref_tokenizers)
     P.test_special_tokens_in_the_text_behind_bert_normalizer()
     P.test_wordlevel_missing_unk_is_a_model_error()
     P.test_runs_of_unknown_one_byte_words_grow_the_queue_twice()

@@ -38,7 +38,7 @@ SYMBOLS = [
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version", "tkamd_word_cache",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
-    "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16",
+    "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16", "tkamd_encode_special_tokens",
 ]
 
 
@@ -120,6 +120,8 @@ def load() -> C.CDLL:
     lib.tkamd_tokenizer_specials.restype = i32
     lib.tkamd_tokenizer_pair_template.argtypes = [vp, i32, C.POINTER(u32), C.c_int32, C.POINTER(C.c_int32)]
     lib.tkamd_tokenizer_pair_template.restype = i32
+    lib.tkamd_encode_special_tokens.argtypes = [vp, i32]
+    lib.tkamd_encode_special_tokens.restype = i32
     lib.tkamd_profile_counters.argtypes = [vp, C.POINTER(u32), i32]
     lib.tkamd_profile_counters.restype = i32
     lib.tkamd_decode_batch.argtypes = [vp, vp, vp, i64, u32, C.POINTER(vp)]

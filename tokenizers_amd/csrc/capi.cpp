@@ -151,6 +151,7 @@ struct tkamd_tokenizer {
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling
     std::atomic<bool> prof{false};
+    std::atomic<bool> encode_special{false};    // tkamd_encode_special_tokens (Tokenizer.encode_special_tokens): special tokens in the text are not extracted
     std::atomic<bool> word_cache{false};        // tkamd_word_cache: BPE words merged by earlier batches are looked up instead of merged again
     std::atomic<uint64_t> cache_epoch{1};       // bumped by a clear: every workspace zeroes its cache before its next batch
     std::vector<tkamd_stage_time> acc;
@@ -906,7 +907,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     auto args_of = [&](int c) {
         AddedArgs a{t->t_at_blob[c].as<uint8_t>(), t->t_at_off[c].as<uint32_t>(), t->t_at_first[c].as<uint32_t>(), t->t_at_id[c].as<uint32_t>(),
-                    t->t_at_flags[c].as<uint32_t>(), {0ull, 0ull, 0ull, 0ull}, 0u, {0u, 0u, 0u, 0u}};
+                    t->t_at_flags[c].as<uint32_t>(), {0ull, 0ull, 0ull, 0ull}, 0u, {0u, 0u, 0u, 0u}, t->encode_special ? 1u : 0u};
         const std::vector<uint32_t>& first = hm.at[c].first;
         for (uint32_t b = 0; b < 256u && first.size() == 257; ++b)
             if (first[b + 1] > first[b]) {
@@ -1955,6 +1956,12 @@ int64_t tkamd_text_n_bytes(const tkamd_text* b) { return b ? b->n_bytes : 0; }
 const uint8_t* tkamd_text_bytes(const tkamd_text* b) { return b ? (const uint8_t*)b->bytes.p : nullptr; }
 const int64_t* tkamd_text_doc_offsets(const tkamd_text* b) { return b ? (const int64_t*)b->doc_offsets.p : nullptr; }
 void tkamd_text_free(tkamd_text* b) { delete b; }
+
+int tkamd_encode_special_tokens(tkamd_tokenizer* t, int value) {
+    if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
+    t->encode_special = value != 0;
+    return TKAMD_OK;
+}
 
 int tkamd_word_cache(tkamd_tokenizer* t, int enable, int clear) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");

@@ -898,7 +898,7 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                 if (refused) throw Unsupported("added token '" + a.content + "' holds a character whose NFD reordering is context dependent");
                 if (pat.empty()) continue;                         // normalizes to nothing: the automaton has nothing to match
             }
-            pats[a.normalized ? 1 : 0].push_back(Pat{pat, a.id, (a.single_word ? 1u : 0u) | (a.lstrip ? 2u : 0u) | (a.rstrip ? 4u : 0u)});
+            pats[a.normalized ? 1 : 0].push_back(Pat{pat, a.id, (a.single_word ? 1u : 0u) | (a.lstrip ? 2u : 0u) | (a.rstrip ? 4u : 0u) | (a.special ? 8u : 0u)});
         }
         for (int c = 0; c < 2; ++c) {
             std::vector<Pat>& ps = pats[c];

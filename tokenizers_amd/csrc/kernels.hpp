@@ -115,10 +115,11 @@ struct AddedArgs {
     const uint32_t* off;
     const uint32_t* first;     // CSR over the first byte
     const uint32_t* id;
-    const uint32_t* flags;     // 1 single_word, 2 lstrip, 4 rstrip
+    const uint32_t* flags;     // 1 single_word, 2 lstrip, 4 rstrip, 8 special
     unsigned long long first_set[4];   // bit b: some pattern starts with byte b
     uint32_t n_first;          // distinct first bytes; the first four of them:
     uint32_t first_byte[4];
+    uint32_t skip_special;     // Tokenizer.encode_special_tokens: a special token found in the text is left there as text (added_vocabulary.rs:450-453)
 };
 
 // arguments of k_add_specials, passed by value

@@ -151,6 +151,7 @@ __global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, c
                 int64_t start = pos, stop = pos + len;
                 cursor = stop;                                        // the automaton resumes after the un-stripped match
                 const uint32_t fl = a.flags[k];
+                if ((fl & 8u) && a.skip_special) continue;            // encode_special_tokens: its text stays text (for this pass and the next)
                 if (fl & 1u) {                                        // single_word: \w on either side rejects the match
                     bool ok = true;
                     if (start > da) {

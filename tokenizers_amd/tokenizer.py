@@ -499,9 +499,22 @@ class Tokenizer:
     # the tokenizer.json sections of the same name, so changing them re-creates the handle from the edited JSON ----
     def _reload(self, d: dict) -> None:
         new = Tokenizer(json.dumps(d, ensure_ascii=False), self.device)
-        old_h = self._h
+        old_h, esp = self._h, getattr(self, "_encode_special", False)
         self.__dict__.update(new.__dict__)
         new._h = old_h                      # the temporary object frees the OLD handle when it dies
+        if esp:
+            self.encode_special_tokens = True
+
+    @property
+    def encode_special_tokens(self) -> bool:
+        """``Tokenizer.encode_special_tokens`` (bindings/python/src/tokenizer.rs:1640-1665): True -> the special tokens of the added
+        vocabulary are not extracted from the text any more, their characters are tokenized like any text."""
+        return getattr(self, "_encode_special", False)
+
+    @encode_special_tokens.setter
+    def encode_special_tokens(self, value: bool) -> None:
+        _lib.check(self._lib.tkamd_encode_special_tokens(self._h, 1 if value else 0))
+        self._encode_special = bool(value)
 
     def enable_truncation(self, max_length: int, stride: int = 0, strategy: str = "longest_first", direction: str = "right") -> None:
         d = json.loads(self._json)
