@@ -403,3 +403,7 @@ def test_batches_mixing_single_sequences_and_pairs_match_the_wheel_live(ref_toke
                     for i, e in enumerate(exp):
                         assert deep(e) == deep(got[i]), (name, trunc, pad, special, pre, inputs[i])
                 assert [e.ids for e in ref.encode_batch_fast(mixed, add_special_tokens=special)] == [e.ids for e in tok.encode_batch_fast(mixed, add_special_tokens=special)]
+            # (the handles the BatchLongest resolution makes on the side carry this one's switches)
+            ref.encode_special_tokens = tok.encode_special_tokens = True
+            sp = [mixed[0] + " [SEP] x", (mixed[1][0], "[CLS] " + mixed[1][1]), "<|end_of_text|>"]
+            assert [deep(e) for e in ref.encode_batch(sp)] == [deep(g) for g in tok.encode_batch(sp)], (name, trunc, pad)

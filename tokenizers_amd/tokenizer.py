@@ -821,16 +821,21 @@ class Tokenizer:
         run = lambda t: [t.encode_batch_csr([inputs[i] for i in g], offsets=offsets, word_ids=word_ids, add_special_tokens=add_special_tokens,
                                             is_pretokenized=is_pretokenized, overflowing=overflowing) for g in groups]
         tok, pad = self, self.padding
+
+        def variant(d):                          # (a second handle with another padding section and this one's switches)
+            t = Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=self.device)
+            t.encode_special_tokens = self.encode_special_tokens
+            return t
         if pad is not None and pad["length"] is None:
             d = json.loads(self._json)
             d["padding"] = None
-            plain = run(Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=self.device))
+            plain = run(variant(d))
             target = max(len(e) for b in plain for e in b)
             m = pad["pad_to_multiple_of"]
             if m and target % m:
                 target += m - target % m
             d["padding"] = dict(json.loads(self._json)["padding"], strategy={"Fixed": int(target)})
-            tok = Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=self.device)
+            tok = variant(d)
         out: list = [None] * len(inputs)
         for g, b in zip(groups, run(tok)):
             for i, e in zip(g, b):

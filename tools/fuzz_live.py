@@ -104,7 +104,7 @@ while time.time() - t0 < budget:
                                "single": rnd.choice([[S("<a>", t[0]), Q("A", t[1])], [Q("A", t[1]), S("<b>", t[2])], [S("<b>", t[0]), Q("A", t[1]), S("<a>", t[2])], [Q("A", t[1])]]),
                                "pair": rnd.choice([[S("<a>", t[3]), Q("A", t[4]), S("<b>", t[5]), Q("B", t[6]), S("<a>", t[7])], [Q("B", t[6]), Q("A", t[4])], [Q("A", t[4]), S("<b>", t[5]), Q("B", t[6])]])}
     js = json.dumps(d, ensure_ascii=False)
-    mode = rnd.choice(["single", "single", "pair", "words", "wordpairs"])
+    mode = rnd.choice(["single", "single", "pair", "words", "wordpairs", "mixed", "mixedwords"])
     special = rnd.random() < 0.5
     docs = [text(120) for _ in range(rnd.randint(1, 24))]
     if mode == "single":
@@ -113,15 +113,22 @@ while time.time() - t0 < budget:
         inputs = [(docs[i], docs[-1 - i]) for i in range((len(docs) + 1) // 2)]
     elif mode == "words":
         inputs = [x.split(" ") if rnd.random() < 0.8 else [] for x in docs]
+    elif mode == "mixed":
+        inputs = [docs[i] if rnd.random() < 0.5 else (docs[i], docs[-1 - i]) for i in range(len(docs))]
+    elif mode == "mixedwords":
+        inputs = [docs[i].split(" ") if rnd.random() < 0.5 else (docs[i].split(" "), docs[-1 - i].split(" ")) for i in range(len(docs))]
     else:
         inputs = [(docs[i].split(" "), docs[-1 - i].split(" ")) for i in range((len(docs) + 1) // 2)]
-    pre = mode in ("words", "wordpairs")
+    pre = mode in ("words", "wordpairs", "mixedwords")
     try:
         tok = ta.Tokenizer.from_str(js, device=0)
     except ta.UnsupportedError:
         continue
     rt = ref.Tokenizer.from_str(js)
-    ctx = (name, d.get("truncation"), d.get("padding"), mode, special, d.get("post_processor"), d.get("normalizer"), d.get("pre_tokenizer"), {k: v for k, v in d["model"].items() if k not in ("vocab", "merges")}, d["added_tokens"][-4:])
+    if rnd.random() < 0.15:
+        rt.encode_special_tokens = True
+        tok.encode_special_tokens = True
+    ctx = (name, rt.encode_special_tokens, d.get("truncation"), d.get("padding"), mode, special, d.get("post_processor"), d.get("normalizer"), d.get("pre_tokenizer"), {k: v for k, v in d["model"].items() if k not in ("vocab", "merges")}, d["added_tokens"][-4:])
     try:
         exp = rt.encode_batch(inputs, add_special_tokens=special, is_pretokenized=pre)
     except BaseException as e:          # (a TruncationError, or the stride assert's panic)
@@ -144,7 +151,7 @@ while time.time() - t0 < budget:
     for i, e in enumerate(exp):
         if deep(e) != deep(got[i]):
             print("MISMATCH", ctx, repr(inputs[i]))
-            json.dump({"json": js, "inputs": [inputs[i]], "special": special, "pre": pre}, open(f"/tmp/fuzz_fail_{seed}.json", "w"), ensure_ascii=False)
+            json.dump({"json": js, "inputs": inputs, "index": i, "special": special, "pre": pre, "esp": rt.encode_special_tokens}, open(f"/tmp/fuzz_fail_{seed}.json", "w"), ensure_ascii=False)
             a, b = deep(e), deep(got[i])
             print(" encodings", len(a), len(b))
             for k, (x, y) in enumerate(zip(a, b)):
