@@ -398,3 +398,32 @@ def test_bert_normalizer_canonical_ordering_matches_the_wheel(ref_tokenizers):
             assert per_char == bn.normalize_str(doc), ascii(doc)
         moved += per_char != bn.normalize_str(doc)
     assert moved > 100
+
+
+def test_added_vocabulary_corners_match_the_wheel(ref_tokenizers):
+    """The oracle's find_matches on the corners the live differential found (tools/fuzz_live.py), against the wheel run here: an
+    lstrip + rstrip token swallowed by the previous match (an empty split: dropped), two tokens with one normalized pattern (the
+    first in the automaton's order -- special tokens, then the others -- is reported), encode_special_tokens, and the reference's
+    own known-answer text for the latter (added_vocabulary.rs:1039-1090)."""
+    A = lambda c, **k: dict({"id": 0, "content": c, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": True}, **k)
+    known = "Hi <mask> there\t<mask>\t<mask>  <pad> <mask><pad><pad>"
+    cases = [("wordlevel_whitespace_c1", [A("\n", lstrip=True, rstrip=True)], ["558349t''\n\r \r CPKKwg   \r\n  \n\r6987", "\n\n", " \n \n ", "a\n\nb"], False),
+             ("bert_wordpiece_4000", [A("Ab", normalized=True, special=False), A("AB", normalized=True), A("aB", normalized=True)], ["x ab y AB Ab aB"], False),
+             ("bert_wordpiece_4000", [A("Ab", normalized=True, special=False), A("AB", normalized=True, special=False)], ["x ab y AB Ab aB"], False),
+             ("bert_wordpiece_4000", [A("<mask>", lstrip=True, rstrip=True, single_word=True), A("ask>", normalized=True, special=False), A("<pad>")], [known, "<mask>"], True),
+             ("bert_wordpiece_4000", [A("<mask>", lstrip=True, rstrip=True, single_word=True), A("ask>", normalized=True, special=False), A("<pad>")], [known, "<mask>"], False)]
+    for name, added, docs, esp in cases:
+        d = json.loads(load_tokenizer_json(name))
+        d["added_tokens"] = added
+        ref = ref_tokenizers.Tokenizer.from_str(json.dumps(d, ensure_ascii=False))
+        o = orc.Oracle(ref.to_str())                       # (the ids the wheel assigned)
+        ref.encode_special_tokens = esp
+        o.set_encode_special_tokens(esp)
+        exp, got = ref.encode_batch(docs, add_special_tokens=False), o.encode_batch(docs, char_offsets=True)
+        for i, e in enumerate(exp):
+            assert list(got.doc_ids(i)) == e.ids and [tuple(x) for x in got.doc_offsets(i)] == [tuple(x) for x in e.offsets] and list(got.doc_words(i)) == e.word_ids, (name, esp, docs[i])
+    # the inverted range is the reference's panic
+    d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
+    d["added_tokens"] = [A("<r>", rstrip=True), A("\n", lstrip=True)]
+    with pytest.raises(orc.OracleError, match="bad split"):
+        orc.Oracle(ref_tokenizers.Tokenizer.from_str(json.dumps(d)).to_str()).encode_batch(["a <r> \n x"])
