@@ -219,3 +219,15 @@ print(C.cast(b._res.d_ids, C.POINTER(C.c_uint32))[0])
 ''' % (ROOT, SO)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SIMT_FOREIGN_DEVICE_MEMORY="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert "synced" in r.stdout and r.returncode == -11, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_a_short_run_of_the_live_differential(ref_tokenizers):
+    """tools/fuzz_live.py for twenty seconds on a fixed seed: random Unicode x single / pair / pre-tokenized / mixed inputs x random
+    component options, truncation, padding and post-processor sections, every field of every encoding (and decode_batch of the
+    result) against the wheel -- the open-ended version is how the corners pinned in tests/test_parity_gpu.py were found."""
+    if ASAN:
+        pytest.skip("the tool opens the plain SIMT build")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_live.py"), "7", "20"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1:] or [""]
+    assert r.returncode == 0 and last[0].startswith("ok seed 7"), (r.returncode, r.stdout[-3000:], r.stderr[-1500:])
+    assert int(last[0].split("cases")[1].split()[0]) >= 5

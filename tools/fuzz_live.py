@@ -107,6 +107,10 @@ while time.time() - t0 < budget:
     mode = rnd.choice(["single", "single", "pair", "words", "wordpairs", "mixed", "mixedwords"])
     special = rnd.random() < 0.5
     docs = [text(120) for _ in range(rnd.randint(1, 24))]
+    if rnd.random() < 0.3:                       # text made of the added tokens, their fragments and whitespace
+        frag = [a["content"] for a in d["added_tokens"]] + [a["content"][:-1] for a in d["added_tokens"] if len(a["content"]) > 1] + \
+               [a["content"].upper() for a in d["added_tokens"]] + [" ", "  ", "\t", "\n", "a", "b", "x", ".", "'", "é", "İ"]
+        docs = ["".join(rnd.choice(frag) for _ in range(rnd.randint(0, 16))) for _ in range(rnd.randint(1, 24))]
     if mode == "single":
         inputs = docs
     elif mode == "pair":
