@@ -86,8 +86,9 @@ while time.time() - t0 < budget:
     if mdl["type"] == "BPE" and rnd.random() < 0.3:
         mdl["ignore_merges"] = not mdl.get("ignore_merges", False)
     if rnd.random() < 0.35:                      # a few added tokens of random shape (their ids follow the reference's rule whatever is written here)
-        pool = ["ing", "the", " a", "<x>", "[Y]", "é", "İ", "中", "##s", "ab ", " '", "１", "Ab", "AB", "\n", "a b"]
-        for c in rnd.sample(pool, rnd.randint(1, 4)):
+        pool = ["ing", "the", " a", "<x>", "[Y]", "é", "İ", "中", "##s", "ab ", " '", "１", "Ab", "AB", "\n", "a b",
+                "<x", "x>", "<x><y>", "ab", "abc", "b", "bc", "e\u0301", "\u00c9", "  ", "\t", "a", "A", "<X>", "i\u0307", "ı", "ﬁ", "fi", "ǆ"]
+        for c in rnd.sample(pool, rnd.randint(1, 6)):
             d["added_tokens"].append({"id": 0, "content": c, "single_word": rnd.random() < 0.3, "lstrip": rnd.random() < 0.3, "rstrip": rnd.random() < 0.3,
                                       "normalized": rnd.random() < 0.5, "special": rnd.random() < 0.4})
     r = rnd.random()
