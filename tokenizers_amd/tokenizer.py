@@ -44,7 +44,7 @@ def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
     for s in inputs:
         if not isinstance(s, str):
             if isinstance(s, (tuple, list)):
-                raise UnsupportedError("pair / pre-tokenized inputs are outside the MI355X hot path")
+                raise UnsupportedError("a pair or a list of words among single sequences: a batch holds one kind of input (encode_batch splits batches of up to 4,096 items that mix them; lists of words need is_pretokenized=True)")
             raise TypeError("TextInputSequence must be str")
         enc.append(s.encode("utf-8"))
     n = len(enc)
