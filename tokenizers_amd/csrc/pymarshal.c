@@ -140,7 +140,7 @@ static int resolve_slow(pack_ctx* c) {
             PyObject* it = c->items[i];
             if (!PyUnicode_Check(it)) {
                 if (PyTuple_Check(it) || PyList_Check(it))
-                    PyErr_SetString(PyExc_NotImplementedError, "a pair or a list of words among single sequences: a batch holds one kind of input (encode_batch splits batches of up to 4,096 items that mix them; lists of words need is_pretokenized=True)");
+                    PyErr_SetString(PyExc_NotImplementedError, "a pair or a list of words among single sequences: a batch holds one kind of input (encode_batch splits a batch that mixes them; lists of words need is_pretokenized=True)");
                 else
                     PyErr_SetString(PyExc_TypeError, "TextInputSequence must be str");
                 return -1;

@@ -44,7 +44,7 @@ def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
     for s in inputs:
         if not isinstance(s, str):
             if isinstance(s, (tuple, list)):
-                raise UnsupportedError("a pair or a list of words among single sequences: a batch holds one kind of input (encode_batch splits batches of up to 4,096 items that mix them; lists of words need is_pretokenized=True)")
+                raise UnsupportedError("a pair or a list of words among single sequences: a batch holds one kind of input (encode_batch splits a batch that mixes them; lists of words need is_pretokenized=True)")
             raise TypeError("TextInputSequence must be str")
         enc.append(s.encode("utf-8"))
     n = len(enc)
@@ -810,10 +810,15 @@ class Tokenizer:
             is_pair = lambda it: isinstance(it, (tuple, list))
         overflowing = self.info["truncation"] >= 0
         first = is_pair(inputs[0]) if len(inputs) else False
-        # a batch of one kind (every batch worth the device) goes down as it is; its items are checked on the way
+        # a batch of one kind (every batch worth the device) goes down as it is; its items are checked on the way, so a large batch
+        # is not walked here first -- the marshalling stops at an item of the other kind and the batch is then looked at again
         if len(inputs) < 2 or len(inputs) > 4096 or all(is_pair(it) == first for it in inputs):
-            return self.encode_batch_csr(inputs, offsets=offsets, word_ids=word_ids, add_special_tokens=add_special_tokens,
-                                         is_pretokenized=is_pretokenized, overflowing=overflowing)
+            try:
+                return self.encode_batch_csr(inputs, offsets=offsets, word_ids=word_ids, add_special_tokens=add_special_tokens,
+                                             is_pretokenized=is_pretokenized, overflowing=overflowing)
+            except (UnsupportedError, TypeError):
+                if len(inputs) <= 4096 or all(is_pair(it) == first for it in inputs):
+                    raise
         # Vec<EncodeInput> may mix Single and Dual items (tokenizer/mod.rs:1337-1356): the two kinds are two calls, put back in order.
         # What couples them is BatchLongest padding -- pad_encodings takes the longest encoding of the WHOLE batch
         # (utils/padding.rs:50-81) --: the lengths are taken from an unpadded run and the batch is then padded to that, Fixed.
