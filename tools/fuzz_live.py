@@ -65,9 +65,10 @@ n_cases = n_docs = n_ref = n_refused = n_dec = 0
 while time.time() - t0 < budget:
     name = rnd.choice(names)
     d = json.loads(load_tokenizer_json(name))
-    if rnd.random() < 0.3:
-        d["truncation"] = {"direction": rnd.choice(["Right", "Left"]), "max_length": rnd.choice([4, 7, 16, 40]),
-                           "strategy": rnd.choice(["LongestFirst", "OnlyFirst", "OnlySecond"]), "stride": rnd.choice([0, 1])}
+    heavy = os.environ.get("FUZZ_TRUNCATION") == "1"       # (mostly truncated batches, short windows, wider strides)
+    if rnd.random() < (0.9 if heavy else 0.3):
+        d["truncation"] = {"direction": rnd.choice(["Right", "Left"]), "max_length": rnd.choice([2, 3, 4, 5, 7, 9, 12] if heavy else [4, 7, 16, 40]),
+                           "strategy": rnd.choice(["LongestFirst", "OnlyFirst", "OnlySecond"]), "stride": rnd.choice([0, 1, 2, 3] if heavy else [0, 1])}
     if rnd.random() < 0.3:
         d["padding"] = {"strategy": rnd.choice(["BatchLongest", {"Fixed": 24}]), "direction": rnd.choice(["Right", "Left"]),
                         "pad_to_multiple_of": rnd.choice([None, 8]), "pad_id": 0, "pad_type_id": 1, "pad_token": "[PAD]"}
