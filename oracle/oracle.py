@@ -98,6 +98,40 @@ class OracleError(Exception):
     pass
 
 
+def assign_added_token_ids(added_tokens: list, vocab: dict) -> list:
+    """The ids the reference gives the file's `added_tokens` -- NOT the file's `id` fields.
+
+    Deserialisation hands the tokens, in file order, to AddedVocabulary::add_tokens and only warns when the outcome differs from the
+    file (tokenizer/serialization.rs:153-167).  add_tokens (tokenizer/added_vocabulary.rs:273-343): an empty content is ignored; a
+    content that the added vocabulary or the model already knows keeps that id (`token_to_id`, :314); every other content takes
+    `next_id`, which starts at the model's vocabulary size (the added map is empty at load, :282-292) and counts up.  A content that
+    appears twice keeps its first id and its LAST properties (`added_tokens_map_r.insert(new_id, token)`, :338).
+    Returns copies of the entries with `id` rewritten, first-appearance order.
+    """
+    next_id = len(vocab)
+    by_content: dict = {}
+    out: list = []
+    for a in added_tokens:
+        c = a["content"]
+        if not c:
+            continue
+        if c in by_content:
+            k = by_content[c]
+            b = dict(a)
+            b["id"] = out[k]["id"]
+            out[k] = b
+            continue
+        b = dict(a)
+        if c in vocab:
+            b["id"] = int(vocab[c])
+        else:
+            b["id"] = next_id
+            next_id += 1
+        by_content[c] = len(out)
+        out.append(b)
+    return out
+
+
 class Oracle:
     """CPU oracle for a tokenizer.json inside the hot-path scope."""
 
@@ -145,7 +179,9 @@ class Oracle:
             L.oracle_set_bert_normalizer(self._h, *bn)
         # (the automaton is built over the special tokens first, then the others, each in the order they were added -- of two tokens
         # with one normalized pattern the first in that order is reported, refresh_added_tokens added_vocabulary.rs:379-399)
-        for a in sorted(d.get("added_tokens") or [], key=lambda a: not a.get("special", False)):
+        added = assign_added_token_ids(d.get("added_tokens") or [], model["vocab"])
+        self.added_tokens = added
+        for a in sorted(added, key=lambda a: not a.get("special", False)):
             c = a["content"].encode("utf-8")
             L.oracle_add_token(self._h, c, len(c), int(a["id"]), int(a.get("single_word", False)), int(a.get("lstrip", False)),
                                int(a.get("rstrip", False)), int(a.get("normalized", False)))

@@ -24,3 +24,19 @@ def char_to_byte(text: str) -> list[int]:
     for ch in text:
         m.append(m[-1] + len(ch.encode("utf-8")))
     return m
+
+
+
+def N(n: int, floor: int = 300) -> int:
+    """A size a -m gpu test asserts on: n on the MI355X; under the SIMT emulation (TKAMD_SIMT=1, tests/harness/simt_env.py) the corpora
+    are n / 200 of themselves (at least `floor`)."""
+    if os.environ.get("TKAMD_SIMT") != "1":
+        return n
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return n
+    except Exception:
+        pass
+    from tests.harness import simt_env
+    return simt_env.scale(n, floor=floor)

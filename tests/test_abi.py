@@ -813,3 +813,26 @@ def test_truncation_padding_getters_and_to_str_match_the_wheel(ref_tokenizers, t
     assert ta.Tokenizer.from_file(str(tmp_path / "tok.json"), device=-1).truncation == r.truncation
     t.no_truncation(), t.no_padding(), r.no_truncation(), r.no_padding()
     assert (t.truncation, t.padding) == (r.truncation, r.padding) == (None, None)
+
+
+def test_lookups_follow_a_reload_and_the_stride_is_checked_when_it_is_set(ref_tokenizers):
+    """(round-2 advisor findings) token_to_id / id_to_token after add_tokens answer from the NEW vocabulary -- the caches do not survive
+    the handle swap; enable_truncation refuses a stride that does not fit at set time with the reference's message
+    (TokenizerImpl::with_truncation, tokenizer/mod.rs:660-672), including its usize wrap for a max_length below the special tokens."""
+    import tokenizers_amd as ta
+    js = load_tokenizer_json("bert_wordpiece_4000_specials")
+    t, r = ta.Tokenizer.from_str(js, device=-1), ref_tokenizers.Tokenizer.from_str(js)
+    assert t.token_to_id("<x>") is None and t.id_to_token(t.info["vocab_size"] + 50) is None          # fills both caches
+    for tk in (t, r):
+        assert tk.add_tokens(["<x>"]) == 1
+    assert t.token_to_id("<x>") == r.token_to_id("<x>") is not None
+    assert t.id_to_token(r.token_to_id("<x>")) == "<x>"
+    for ml, st in ((4, 2), (4, 3), (2, 5), (1, 0), (1, 7)):
+        outcome = []
+        for tk in (t, r):
+            try:
+                tk.enable_truncation(max_length=ml, stride=st)
+                outcome.append("ok")
+            except Exception as e:           # noqa: BLE001 (ValueError here, the binding's Exception there)
+                outcome.append(str(e))
+        assert outcome[0] == outcome[1], (ml, st, outcome)

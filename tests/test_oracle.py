@@ -427,3 +427,61 @@ def test_added_vocabulary_corners_match_the_wheel(ref_tokenizers):
     d["added_tokens"] = [A("<r>", rstrip=True), A("\n", lstrip=True)]
     with pytest.raises(orc.OracleError, match="bad split"):
         orc.Oracle(ref_tokenizers.Tokenizer.from_str(json.dumps(d)).to_str()).encode_batch(["a <r> \n x"])
+
+
+def _added_id_cases():
+    """(golden name, the file's added_tokens with ids the reference will NOT keep, documents)."""
+    A = lambda i, c, **k: dict({"id": i, "content": c, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": True}, **k)
+    return [
+        # a file id far beyond the vocabulary: the reference hands out vocab_size, vocab_size + 1, ... in file order
+        ("wordlevel_whitespace_c1", [A(9000, "[ENT]", rstrip=True), A(17, "[X]"), A(9000, "<y>", special=False)], ["a [ENT] b [X] c <y> d", "[X][X]<y>"]),
+        # a content the model knows keeps the MODEL's id whatever the file says; the next unknown one still takes vocab_size
+        ("bert_wordpiece_4000", [A(3999, "[CLS]"), A(5, "the", special=False, single_word=True), A(123456, "[NEW]"), A(0, "[NEW2]")], ["[CLS] the [NEW] other [NEW2] the", "[NEW2][NEW]"]),
+        # the same content twice: first id, last properties (rstrip from the second entry)
+        ("gpt2_synth_50257", [A(70000, "<|a|>"), A(70001, "<|b|>"), A(70002, "<|a|>", rstrip=True)], ["x <|a|>   y<|b|> z", "<|a|> <|a|>"]),
+    ]
+
+
+
+
+def test_added_token_id_assignment_restated():
+    """assign_added_token_ids follows AddedVocabulary::add_tokens (added_vocabulary.rs:273-343) as deserialisation calls it
+    (serialization.rs:153-167): model's id when the content is known, else the next free id from the vocabulary size, file order."""
+    for name, added, _docs in _added_id_cases():
+        d = json.loads(load_tokenizer_json(name))
+        vocab = d["model"]["vocab"]
+        out = orc.assign_added_token_ids(added, vocab)
+        nxt = len(vocab)
+        seen = {}
+        for a in added:
+            c = a["content"]
+            if c in seen:
+                continue
+            if c in vocab:
+                seen[c] = vocab[c]
+            else:
+                seen[c] = nxt
+                nxt += 1
+        assert {a["content"]: a["id"] for a in out} == seen
+        assert len(out) == len(seen)
+    out = orc.assign_added_token_ids(_added_id_cases()[2][1], {"x": 0})
+    assert [(a["content"], a["id"], a["rstrip"]) for a in out] == [("<|a|>", 1, True), ("<|b|>", 2, False)]
+    assert orc.assign_added_token_ids([{"content": "", "id": 5}], {"x": 0}) == []
+
+
+def test_added_token_ids_match_the_wheel_when_the_file_ids_do_not(ref_tokenizers):
+    """The oracle is given the RAW file (ids 9000 / 17 / 123456 ...), the wheel loads the same text: ids, offsets and word ids must
+    agree, and so must the assignment itself (`get_added_tokens_decoder`)."""
+    for name, added, docs in _added_id_cases():
+        d = json.loads(load_tokenizer_json(name))
+        d["added_tokens"] = added
+        js = json.dumps(d, ensure_ascii=False)
+        ref = ref_tokenizers.Tokenizer.from_str(js)
+        o = orc.Oracle(js)
+        assert {a["content"]: a["id"] for a in o.added_tokens} == {t.content: i for i, t in ref.get_added_tokens_decoder().items()}, name
+        assert any(a["id"] != f["id"] for a, f in zip(o.added_tokens, added)), "the case must move an id"
+        exp, got = ref.encode_batch(docs, add_special_tokens=False), o.encode_batch(docs, char_offsets=True)
+        for i, e in enumerate(exp):
+            assert list(got.doc_ids(i)) == e.ids, (name, docs[i])
+            assert [tuple(x) for x in got.doc_offsets(i)] == [tuple(x) for x in e.offsets], (name, docs[i])
+            assert list(got.doc_words(i)) == e.word_ids, (name, docs[i])

@@ -17,27 +17,13 @@ import pytest
 
 from tokenizers_amd import _lib
 
+from tests.harness import simt_build
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-CSRC = os.path.join(ROOT, "tokenizers_amd", "csrc")
-ASAN = os.environ.get("TKAMD_SIMT_ASAN") == "1"      # AddressSanitizer build: "device" memory is host memory, so an out-of-bounds access of a
-                                                      # kernel is a heap-buffer-overflow report (run python with LD_PRELOAD=libasan, tools/simt_check.sh)
-SO = os.path.join(HERE, "harness", "_libtokenizers_amd_simt_asan.so" if ASAN else "_libtokenizers_amd_simt.so")
+SO = simt_build.SO
 FULL = os.environ.get("TKAMD_SIMT_FULL") == "1"
-
-
-def _build():
-    deps = [os.path.join(HERE, "harness", "simt", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "tokenizers_amd.h")]
-    for d, _, files in os.walk(CSRC):
-        deps += [os.path.join(d, f) for f in files if f.endswith((".hip", ".hpp", ".cpp", ".inc"))]
-    if os.path.exists(SO) and os.path.getmtime(SO) >= max(os.path.getmtime(d) for d in deps):
-        return
-    cmd = ["g++"] + (["-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"] if ASAN else ["-O2"]) + ["-std=c++17", "-fPIC", "-shared", "-fno-gnu-unique", "-Wl,-Bsymbolic", "-Wno-unknown-pragmas", "-Wno-attributes",
-           "-I", os.path.join(HERE, "harness", "simt"), "-DTKAMD_BUILD", "-x", "c++",
-           os.path.join(CSRC, "kernels.hip"), os.path.join(CSRC, "capi.cpp"), os.path.join(CSRC, "host_model.cpp"), "-o", SO + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    os.replace(SO + ".tmp", SO)
+_build = simt_build.build
 
 
 @pytest.fixture(scope="module", autouse=True)

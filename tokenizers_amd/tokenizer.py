@@ -415,7 +415,7 @@ class Tokenizer:
         self._lib = lib
         self.device = int(device)
         self._json = json_str
-        self._vocab_r = None
+        self._vocab_r = self._vocab_f = self._vocab_c = None      # (reset by _reload through __dict__.update: no stale lookups after add_tokens)
         self._pad_token = ((json.loads(json_str).get("padding") or {}).get("pad_token", "[PAD]")) if '"padding"' in json_str else "[PAD]"
         # no post-processor at all: the reference never sets Encoding.sequence_ranges for a single sequence, and token_to_sequence
         # (encoding.rs) then answers 0 for every token -- padding included
@@ -498,12 +498,23 @@ class Tokenizer:
     # ---- truncation / padding (Tokenizer.enable_truncation / enable_padding, bindings/python/src/tokenizer.rs): the parameters live in
     # the tokenizer.json sections of the same name, so changing them re-creates the handle from the edited JSON ----
     def _reload(self, d: dict) -> None:
+        """Re-create the native handle from an edited tokenizer.json.  Switches that live on the handle (encode_special_tokens, the word
+        cache, the profile hooks) are re-applied; the swap happens under the staging lock so a concurrent encode sees the old or the new
+        handle, never half of each.  A DeviceBatch of the old handle points into freed workspace afterwards -- like the reference,
+        whose setters need `&mut self`, do not reconfigure a tokenizer while results of it are in flight."""
         new = Tokenizer(json.dumps(d, ensure_ascii=False), self.device)
-        old_h, esp = self._h, getattr(self, "_encode_special", False)
-        self.__dict__.update(new.__dict__)
-        new._h = old_h                      # the temporary object frees the OLD handle when it dies
+        esp, wc, prof = getattr(self, "_encode_special", False), getattr(self, "_word_cache_on", False), getattr(self, "_profile_on", False)
+        with self._stage_lock:
+            old_h, lock = self._h, self._stage_lock
+            self.__dict__.update(new.__dict__)
+            self._stage_lock = lock
+            new._h = old_h                      # the temporary object frees the OLD handle when it dies
         if esp:
             self.encode_special_tokens = True
+        if wc:
+            self.word_cache(True)
+        if prof:
+            self.profile(True)
 
     @property
     def encode_special_tokens(self) -> bool:
@@ -517,6 +528,13 @@ class Tokenizer:
         self._encode_special = bool(value)
 
     def enable_truncation(self, max_length: int, stride: int = 0, strategy: str = "longest_first", direction: str = "right") -> None:
+        # TokenizerImpl::with_truncation (tokenizer/mod.rs:660-672): refused at SET time when the stride does not fit what is left of
+        # max_length after the special tokens (usize arithmetic: a max_length below the specials wraps and passes)
+        n_added = self.num_special_tokens_to_add(False)
+        effective = (int(max_length) - n_added) % (1 << 64)
+        if effective < int(stride):
+            raise ValueError(f"tokenizer stride set to {int(stride)}, which is greater than or equal to its effective max length of {effective} "
+                             f"(= {int(max_length)} original max length - {n_added} added special tokens), ")
         d = json.loads(self._json)
         d["truncation"] = {"direction": direction.capitalize(), "max_length": int(max_length), "stride": int(stride),
                            "strategy": {"longest_first": "LongestFirst", "only_first": "OnlyFirst", "only_second": "OnlySecond"}[strategy]}
@@ -912,10 +930,12 @@ class Tokenizer:
         bytes merged by earlier batches are looked up instead of merged again by later ids-only batches.  Off by default;
         ``clear`` forgets everything.  Results never change."""
         _lib.check(self._lib.tkamd_word_cache(self._h, 1 if enable else 0, 1 if clear else 0))
+        self._word_cache_on = bool(enable)
 
     # ---- measurement hooks ----
     def profile(self, on: bool) -> None:
         _lib.check(self._lib.tkamd_profile_enable(self._h, 1 if on else 0))
+        self._profile_on = bool(on)
 
     def queue_sizes(self) -> dict[str, int]:
         """Merge work-queue sizes of the last synchronised batch (diagnostics)."""
