@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line.  Extra objects next to the contract's fields:
   host_boundary  the C-ABI call as SURVEY 8d times it (H2D + kernels + D2H): `value_pcie_inclusive`; from list[str] too
   out_of_distribution  the same step on text whose word types the vocabulary never saw (every word needs merges)
   word_cache     the same K steps with tkamd_word_cache on (off in `value`): warm and cold (cleared every step) figures
+  single_call_multi_gpu  ONE tkamd_encode_batch on a handle over every visible GPU (sharded inside the library), per collect mode
   gather         N > 1 (or --force-gather): the same K steps ending with the RCCL collect-to-root of ids + CSR
 """
 from __future__ import annotations
@@ -113,6 +114,8 @@ def main() -> None:
     ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
     ap.add_argument("--no-word-cache", action="store_true", help="skip the word-cache leg")
+    ap.add_argument("--no-single-call", action="store_true", help="skip the single-call multi-GPU leg")
+    ap.add_argument("--single-call-gpus", type=int, default=0, help="devices of the single-call leg (0 = every visible GPU)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
@@ -357,6 +360,18 @@ def main() -> None:
         except Exception as ex:     # never lose the bench line to the auxiliary leg
             host["encode_batch_fast_list_of_str_error"] = repr(ex)
 
+    # ---- single-call multi-GPU leg (rank 0, one process): ONE tkamd_encode_batch on a handle made over a device list; the library
+    # shards the documents by bytes, one host thread + stream per device, and the shards' results meet per collect mode
+    # (include/tokenizers_amd.h "one call, every GPU"; the reference: one encode_batch call uses the whole Rayon pool,
+    # tokenizer/mod.rs:1345-1348).  PCIe inclusive by construction (host buffers in, host buffers out).  With one visible GPU the list
+    # names it twice: the code path runs, the figure says nothing about scaling. ----
+    single_call = None
+    if rank == 0 and world == 1 and not args.no_host and not args.no_single_call:
+        try:
+            single_call = single_call_leg(ta, tok_json, batches[0], torch.cuda.device_count(), args.single_call_gpus)
+        except Exception as ex:     # never lose the bench line to an auxiliary leg
+            single_call = {"error": repr(ex)[:300]}
+
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's Rayon encode_batch on the host cores ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -384,7 +399,8 @@ def main() -> None:
                        "pretokens_per_gpu": int(b0.n_pretok), "batches": n_batches, "type_seed": args.type_seed,
                        "tokenizer_sha256": synth.sha256(tok_json)[:16],
                        "parallelism": f"dp{world} (documents sharded by rank)"},
-            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "out_of_distribution": ood, "word_cache": wcache,
+            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "single_call_multi_gpu": single_call,
+            "out_of_distribution": ood, "word_cache": wcache,
         }
     # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
     gather_obj = None
@@ -411,6 +427,49 @@ def main() -> None:
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def single_call_leg(ta, tok_json: str, batch0, n_visible: int, want: int) -> dict:
+    """One host-entry call over a device list, per collect mode: best of 3 wall clocks of `encode_packed` on n_dev x batch 0."""
+    n_dev = want or n_visible
+    emulated = n_visible < 2
+    devices = [0, 0] if emulated else list(range(min(n_dev, n_visible)))
+    hb0, ho0 = ta.pack_documents(batch0.lines)
+    k = len(devices)
+    nb0 = int(ho0[-1])
+    hb = np.empty(nb0 * k + 64, dtype=np.uint8)
+    ho = np.empty(batch0.n_docs * k + 1, dtype=np.int64)
+    for r in range(k):                                       # the batch n_dev times over: every device gets batch 0's work
+        hb[r * nb0:(r + 1) * nb0] = hb0[:nb0]
+        ho[r * batch0.n_docs:(r + 1) * batch0.n_docs + 1] = ho0 + r * nb0
+    out = {"devices": devices, "emulated_on_one_gpu": emulated, "bytes": nb0 * k, "docs": batch0.n_docs * k, "unit": "GB/s",
+           "what": "wall clock of ONE tkamd_encode_batch (pageable host text in, pinned ids + CSR out) on a multi-device handle, best of 3"}
+    one = ta.Tokenizer.from_str(tok_json, device=devices[0])
+    one.encode_packed(hb, ho)
+    best, ref = float("inf"), None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ref = one.encode_packed(hb, ho)
+        best = min(best, time.perf_counter() - t0)
+    out["one_device"] = {"ms": round(best * 1e3, 2), "value": round(nb0 * k / best / 1e9, 3)}
+    for mode in ("host", "p2p") + (() if emulated else ("rccl",)):
+        try:
+            many = ta.Tokenizer.from_str(tok_json, device=devices, collect=mode)
+            many.encode_packed(hb, ho)                       # warm-up: workspaces, pinned blocks, (rccl) the communicators
+            best, res = float("inf"), None
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res = many.encode_packed(hb, ho)
+                best = min(best, time.perf_counter() - t0)
+            same = res.n_tokens == ref.n_tokens and bool((res.ids == ref.ids).all()) and bool((res.tok_offsets == ref.tok_offsets).all())
+            st = many.shard_stats()
+            busy = [ms for _, _, ms in st]
+            out[mode] = {"ms": round(best * 1e3, 2), "value": round(nb0 * k / best / 1e9, 3), "equals_one_device": same,
+                         "busy_ms_max_over_mean": round(max(busy) / (sum(busy) / len(busy)), 3) if busy else None}
+            del many
+        except Exception as ex:
+            out[mode] = {"error": repr(ex)[:300]}
+    return out
 
 
 # profile stage (capi.cpp Prof) -> the kernel that dominates it, as rocprofv3 names it (prefix match)

@@ -114,6 +114,33 @@ int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tka
 void tkamd_tokenizer_free(tkamd_tokenizer* tok);
 int tkamd_tokenizer_info(const tkamd_tokenizer* tok, tkamd_info* info);
 
+/* ---- one call, every GPU ------------------------------------------------------------------------
+ * TokenizerImpl::encode_batch is ONE call that uses every parallel resource of the machine: it maps `encode` over the inputs on the
+ * Rayon pool (tokenizer/mod.rs:1345-1348, utils/parallelism.rs:85-106).  The counterpart here: a handle made over a LIST of devices
+ * replicates the tables on each (<= 5 MB) and the host entries (tkamd_encode_batch, tkamd_encode_batch_words) then cut every batch
+ * into one contiguous, byte-balanced run of documents per device -- one host thread and one stream per device, each shard's text
+ * going up its own PCIe link -- and return ONE result in document order.  How the shards' results meet is the handle's collect mode:
+ *   TKAMD_COLLECT_HOST       every device copies its ids straight into its slice of the one pinned result (no collective): the
+ *                            default; N links carry the result.
+ *   TKAMD_COLLECT_ROOT_P2P   the peers push their shards into one buffer on devices[0] over xGMI (hipMemcpyPeerAsync), one D2H.
+ *   TKAMD_COLLECT_ROOT_RCCL  the same gather with RCCL: ncclSend on every peer, ncclRecv at the displacement on devices[0]
+ *                            (RCCL has no gatherv; librccl.so is opened at first use) -- the reference's `collect()` of the
+ *                            Vec<Encoding> as a collective, for consumers that want the result on one GPU.
+ * A device may be named more than once (two shards then share a GPU: how the sharded path is tested on a one-GPU box; RCCL needs
+ * distinct devices).  n_devices == 0: the list comes from the environment, TOKENIZERS_GPU_DEVICES = "all" | "0,2,3" (unset: device
+ * 0).  BatchLongest padding and TKAMD_WANT_OVERFLOW couple the documents of a batch and run on devices[0] alone; so does a batch of
+ * less than 1 MB per device (TKAMD_SHARD_MIN_KB, read when the handle is made).  The device-buffer entries and decode_batch run on devices[0]. */
+#define TKAMD_COLLECT_HOST      0
+#define TKAMD_COLLECT_ROOT_P2P  1
+#define TKAMD_COLLECT_ROOT_RCCL 2
+int tkamd_tokenizer_from_json_devices(const char* json, size_t json_len, const int* devices, int n_devices, tkamd_tokenizer** out);
+int tkamd_tokenizer_set_collect(tkamd_tokenizer* tok, int mode);
+/* devices[0 .. *n) of the handle (1 entry for a single-device handle, 0 for a host-only one). */
+int tkamd_tokenizer_devices(const tkamd_tokenizer* tok, int* devices, int cap, int* n);
+/* The last sharded host-entry call: per device of the handle, the bytes of its shard and the wall milliseconds its host thread was
+ * busy (H2D + kernels + its part of the collect) -- BASELINE configs[4]'s "per-GPU busy time imbalance (max / mean)". */
+int tkamd_shard_stats(const tkamd_tokenizer* tok, int64_t* shard_bytes, double* busy_ms, int cap, int* n);
+
 /* Special-token layout of the post-processor for a single sequence: ids inserted before / after every document
  * when TKAMD_ADD_SPECIAL is set.  Returns TKAMD_ERR_UNSUPPORTED if the post-processor is outside the path. */
 int tkamd_tokenizer_specials(const tkamd_tokenizer* tok, uint32_t* prefix_ids, int32_t* n_prefix, uint32_t* suffix_ids,

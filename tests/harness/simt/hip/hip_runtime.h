@@ -135,7 +135,11 @@ inline void trampoline() {
 }
 inline void device_open();
 inline void device_close();
+// launches of different host threads (concurrent callers, the per-device threads of a sharded call) take turns: the fibers, the wave
+// state and the kernels' __shared__ statics are one set -- one "device" that runs one kernel at a time
+inline std::recursive_mutex& launch_mu() { static std::recursive_mutex m; return m; }
 inline void launch(dim3 grid, dim3 block, std::function<void()> fn) {
+    std::lock_guard<std::recursive_mutex> one_kernel_at_a_time(launch_mu());
     device_open();
     if (block.x > (unsigned)MAX_THREADS || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) { fprintf(stderr, "simt: unsupported launch shape\n"); abort(); }
     std::function<void()>* outer = body();
@@ -283,7 +287,7 @@ typedef void* hipStream_t;
 typedef void* hipEvent_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
-enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum { hipStreamNonBlocking = 1, hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipEventDisableTiming = 2, hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 struct hipDeviceProp_t { int multiProcessorCount; };
 inline const char* hipGetErrorString(hipError_t) { return "simt shim error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
@@ -363,6 +367,10 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { return
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = malloc(1); return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t) { return hipMemcpy(d, s, n, hipMemcpyDeviceToDevice); }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

@@ -183,6 +183,7 @@ def test_overflowing_encodings_through_the_c_abi_arrays():
             assert (got.ids[got.tok_offsets[e]:got.tok_offsets[e + 1]] == ids[24 * p: 24 * p + 32]).all()
 
 
+@pytest.mark.needs_hw
 def test_overflowing_encodings_survive_a_queue_overflow_rerun():
     """A work queue far too small (TKAMD_Q16_DIV test hook): the overflow epilogue, which waits for the number of encodings anyway,
     sees ERR_QUEUE_FULL, grows the queue and runs the batch again inside the same call -- same result as with the default queue,

@@ -144,6 +144,7 @@ def test_encode_batch_sharded_equals_unsharded_gloo(world):
 
 
 @pytest.mark.gpu
+@pytest.mark.needs_hw
 def test_encode_batch_sharded_on_one_gpu_over_rccl():
     """World size 1 over RCCL (the only size a 1-GPU box offers): the sharded step through the real device encoder and the real
     collective calls equals the plain encode of the whole batch."""

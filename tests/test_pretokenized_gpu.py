@@ -82,6 +82,7 @@ def test_pretokenized_vs_oracle_word_by_word(name):
     assert np.array_equal(got.word_ids, np.repeat(word_idx, per_word).astype(np.uint32))
 
 
+@pytest.mark.needs_hw
 def test_pretokenized_device_entry_and_slices():
     """tkamd_encode_batch_words_device on resident buffers, and the host entry forced down to 1 MB slices (cut between sequences,
     between pairs), equal the one-slice host result."""

@@ -22,6 +22,7 @@ from tests.harness import simt_build
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SO = simt_build.SO
+ASAN = simt_build.ASAN
 FULL = os.environ.get("TKAMD_SIMT_FULL") == "1"
 _build = simt_build.build
 

@@ -39,7 +39,9 @@ SYMBOLS = [
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
     "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16", "tkamd_encode_special_tokens",
+    "tkamd_tokenizer_from_json_devices", "tkamd_tokenizer_set_collect", "tkamd_tokenizer_devices", "tkamd_shard_stats",
 ]
+COLLECT_HOST, COLLECT_ROOT_P2P, COLLECT_ROOT_RCCL = 0, 1, 2
 
 
 class Info(C.Structure):
@@ -88,6 +90,14 @@ def load() -> C.CDLL:
     lib.tkamd_last_error.restype = C.c_char_p
     lib.tkamd_tokenizer_from_json.argtypes = [C.c_char_p, C.c_size_t, i32, C.POINTER(vp)]
     lib.tkamd_tokenizer_from_json.restype = i32
+    lib.tkamd_tokenizer_from_json_devices.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), i32, C.POINTER(vp)]
+    lib.tkamd_tokenizer_from_json_devices.restype = i32
+    lib.tkamd_tokenizer_set_collect.argtypes = [vp, i32]
+    lib.tkamd_tokenizer_set_collect.restype = i32
+    lib.tkamd_tokenizer_devices.argtypes = [vp, C.POINTER(C.c_int), i32, C.POINTER(C.c_int)]
+    lib.tkamd_tokenizer_devices.restype = i32
+    lib.tkamd_shard_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), i32, C.POINTER(C.c_int)]
+    lib.tkamd_shard_stats.restype = i32
     lib.tkamd_tokenizer_free.argtypes = [vp]
     lib.tkamd_tokenizer_free.restype = None
     lib.tkamd_tokenizer_info.argtypes = [vp, C.POINTER(Info)]

@@ -14,6 +14,10 @@
 #include <condition_variable>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
+#include <chrono>
+#include <dlfcn.h>
+#include <pthread.h>
 #include <string>
 #include <vector>
 
@@ -43,6 +47,76 @@ struct HipError : std::runtime_error {
         if (_e != hipSuccess)                                                                               \
             throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(_e));                       \
     } while (0)
+
+// ---- fork() ----
+// The reference's Python binding registers a pthread_atfork child handler so that a forked child does not hang on the parent's Rayon
+// pool (bindings/python/src/lib.rs:41-47: it switches parallelism off in the child).  The counterpart here: the HIP runtime of a
+// process that has initialised it does not survive fork() -- a child that touches the inherited device state hangs or faults.  The
+// child handler marks the process; from then on every entry that needs the device fails at once with TKAMD_ERR_DEVICE and says why,
+// inherited handles are dropped without a HIP call, and the pinned-block pool is forgotten.  HIP is initialised lazily (the first
+// handle with device >= 0), so a parent that only ever made host-only handles leaves its children free to use the GPU.
+std::atomic<bool> g_hip_used{false};     // this process made a device handle
+std::atomic<bool> g_forked{false};       // ... and we are a child forked after that
+void check_not_forked() {
+    if (g_forked) throw HipError("this process was fork()ed after its parent initialised the HIP runtime: the inherited device state is unusable "
+                                 "(create tokenizers in the child before the parent touches the GPU, or start workers with spawn / exec)");
+}
+
+// ---- RCCL, opened at first use (TKAMD_COLLECT_ROOT_RCCL) ----
+// The library does not link librccl: only a multi-device handle in that collect mode needs it.  Types as rccl.h declares them
+// (ncclComm_t is an opaque pointer, ncclResult_t / ncclDataType_t are enums: ncclSuccess = 0, ncclUint8 = 1).
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (a.lib) break;
+        }
+        if (!a.lib) { a.why = std::string("librccl.so could not be opened: ") + (dlerror() ? dlerror() : "?"); return a; }
+        auto sym = [&](const char* n) { void* p = dlsym(a.lib, n); if (!p && a.why.empty()) a.why = std::string("librccl.so lacks ") + n; return p; };
+        a.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
+        a.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        a.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+        a.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+        a.GroupStart = (int (*)())sym("ncclGroupStart");
+        a.GroupEnd = (int (*)())sym("ncclGroupEnd");
+        a.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        return a;
+    }();
+    return api;
+}
+#define RCCL_CHECK(expr)                                                                                                         \
+    do {                                                                                                                         \
+        int _r = (expr);                                                                                                         \
+        if (_r != 0) throw HipError(std::string(#expr) + " failed: " + (rccl_api().GetErrorString ? rccl_api().GetErrorString(_r) : "?")); \
+    } while (0)
+
+// every thread of a sharded call meets here between its phases
+struct Rendezvous {
+    std::mutex mu;
+    std::condition_variable cv;
+    const int n;
+    int waiting = 0;
+    uint64_t gen = 0;
+    explicit Rendezvous(int n_) : n(n_) {}
+    void arrive() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
 
 // grow-only device buffer; owns its allocation (freed with the struct that holds it, on whatever device is current --
 // hipFree accepts a pointer of any device)
@@ -111,6 +185,7 @@ struct Workspace {
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
+    DevBuf w_claims;                             // in-batch word claims (kernels.hpp WordCache::claims); their rows live in w_cache_rows
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
     DevBuf w_seq_off, w_seq_tok_off, w_word_idx, w_first_tok;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
     // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
@@ -155,6 +230,17 @@ struct tkamd_tokenizer {
     std::atomic<bool> word_cache{false};        // tkamd_word_cache: BPE words merged by earlier batches are looked up instead of merged again
     std::atomic<uint64_t> cache_epoch{1};       // bumped by a clear: every workspace zeroes its cache before its next batch
     std::vector<tkamd_stage_time> acc;
+    // ---- multi-device handle (tkamd_tokenizer_from_json_devices): this object is the replica on devices[0]; replicas[r - 1] holds the
+    // tables on devices[r].  One host-entry call then shards its documents over all of them (encode_host_sharded).
+    std::vector<int> devices;
+    std::vector<std::unique_ptr<tkamd_tokenizer>> replicas;
+    std::mutex group_mu;                 // one sharded call at a time (it already uses every device)
+    std::atomic<int> collect{0};         // TKAMD_COLLECT_*
+    DevBuf g_root[8];                    // COLLECT_ROOT_*: the whole result on devices[0] before its one D2H (indexed like the descriptors of the call)
+    std::vector<void*> rccl_comms;       // ncclComm_t per device of the handle (COLLECT_ROOT_RCCL, made at first use)
+    int64_t shard_min_bytes = 1 << 20;   // a batch of less than this per device is not worth the threads: it runs on devices[0] (TKAMD_SHARD_MIN_KB, read at load)
+    std::vector<double> shard_ms;        // last sharded call: wall milliseconds every device's thread was busy (H2D + kernels + collect)
+    std::vector<int64_t> shard_bytes;
 };
 
 constexpr size_t MAX_HOST_WORKSPACES = 4;       // concurrent host-entry calls per handle; further callers wait for a free one
@@ -183,12 +269,12 @@ static PinnedBlock pinned_get(size_t bytes) {
     }
     PinnedBlock b;
     size_t want = bytes + bytes / 8;
-    HIP_CHECK(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&b.p, want, hipHostMallocPortable));      // (one result buffer is written by every device of a multi-device handle)
     b.cap = want;
     return b;
 }
 static void pinned_put(PinnedBlock b) {
-    if (!b.p) return;
+    if (!b.p || g_forked) return;
     std::lock_guard<std::mutex> lk(g_pin_mu);
     if (g_pin_free.size() >= 16) { (void)hipHostFree(b.p); return; }
     g_pin_free.push_back(b);
@@ -1125,11 +1211,22 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
-    WordCache wc{nullptr, nullptr};
-    // the word cache (kernels.hpp WordCache) serves the ids-only path: a cached row carries no token ends
+    WordCache wc{nullptr, nullptr, nullptr};
+    // In-batch word claims (default; TKAMD_CLAIMS=0 switches them off for A/B runs): repeated words reach the model kernels once
+    // per batch (kernels/lookup.hip).  The word cache (kernels.hpp WordCache, tkamd_word_cache: across batches) takes their place when
+    // it is switched on.  Both serve the ids-only path: a shared row carries no token ends.
+    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
     auto open_word_cache = [&]() {
-        if (!(t->word_cache && off_mode == TKAMD_OFFSETS_NONE)) return;
+        if (off_mode != TKAMD_OFFSETS_NONE) return;
         const size_t slots = (size_t)1 << WORD_CACHE_BITS;
+        if (!t->word_cache) {
+            if (!claims_on) return;
+            w->w_claims.reserve(slots * 8);
+            w->w_cache_rows.reserve(slots * 16);
+            HIP_CHECK(hipMemsetAsync(w->w_claims.p, 0, slots * 8, st));
+            wc = WordCache{nullptr, w->w_cache_rows.p, (unsigned long long*)w->w_claims.p};
+            return;
+        }
         w->w_cache_keys.reserve(slots * sizeof(CacheKey));
         w->w_cache_rows.reserve(slots * 16);
         const uint64_t epoch = t->cache_epoch;
@@ -1137,7 +1234,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
             w->cache_epoch = epoch;
         }
-        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p};
+        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr};
     };
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
@@ -1165,6 +1262,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
             pf.end();
         }
+        if (wc.claims) {
+            pf.begin("claims_publish");
+            launch_claims_publish(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            pf.end();
+        }
         pf.begin("bpe_merge64");
         launch_bpe_merge(st, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
@@ -1189,7 +1291,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr}, 0u, 1u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr}, 0u, 1u);
         for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err);      // words longer than 16 bytes
         pf.end();
     } else {
@@ -1214,6 +1316,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         if (wc.keys) {
             pf.begin("word_cache_insert");
             launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            pf.end();
+        }
+        if (wc.claims) {
+            pf.begin("claims_publish");
+            launch_claims_publish(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
             pf.end();
         }
     }
@@ -1431,35 +1538,132 @@ extern "C" {
 const char* tkamd_version(void) { return "tokenizers_amd 0.1.0 (gfx950)"; }
 const char* tkamd_last_error(void) { return g_last_error.c_str(); }
 
+// One replica of the tables.  `primary`: parse, hash and the load-time proof of the whole-word table happened there; the replica
+// uploads the same host tables to its own device.
+static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t json_len, int device, const tkamd_tokenizer* primary) {
+    std::unique_ptr<tkamd_tokenizer> t(new tkamd_tokenizer());
+    if (primary) { t->hm = primary->hm; t->n_direct = primary->n_direct; }
+    else t->hm = HostModel::from_json(json, json_len);
+    t->device = device;
+    if (device >= 0) {
+        check_not_forked();
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device available (the HIP path has no CPU fallback)");
+        if (device >= n) throw HipError("HIP device ordinal out of range");
+        HIP_CHECK(hipSetDevice(device));
+        if (!g_hip_used.exchange(true)) pthread_atfork(nullptr, nullptr, [] { g_forked = true; });
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
+        upload_tables(t.get());
+        if (!primary) verify_direct_words(t.get());
+        build_hot_table(t.get());
+        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
+        t->cp_grid = compact_grid(t->n_cu);
+        t->devices.push_back(device);
+    }
+    return t;
+}
+
+// TOKENIZERS_GPU_DEVICES = "all" | "0,2,3" (unset or empty: device 0)
+static std::vector<int> devices_from_env() {
+    std::vector<int> d;
+    const char* e = getenv("TOKENIZERS_GPU_DEVICES");
+    if (!e || !*e) return {0};
+    if (!strcmp(e, "all")) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device available (the HIP path has no CPU fallback)");
+        for (int i = 0; i < n; ++i) d.push_back(i);
+        return d;
+    }
+    for (const char* q = e; *q;) {
+        char* end = nullptr;
+        const long v = strtol(q, &end, 10);
+        if (end == q || v < 0 || v > 1023) throw Invalid("TOKENIZERS_GPU_DEVICES: expected \"all\" or a comma-separated list of device ordinals");
+        d.push_back((int)v);
+        q = end;
+        if (*q == ',') ++q;
+        else if (*q) throw Invalid("TOKENIZERS_GPU_DEVICES: expected \"all\" or a comma-separated list of device ordinals");
+    }
+    if (d.empty()) d.push_back(0);
+    return d;
+}
+
 int tkamd_tokenizer_from_json(const char* json, size_t json_len, int device, tkamd_tokenizer** out) {
     if (!json || !out) return set_error(TKAMD_ERR_INVALID, "null argument");
     *out = nullptr;
     return guarded([&]() -> int {
-        std::unique_ptr<tkamd_tokenizer> t(new tkamd_tokenizer());
-        t->hm = HostModel::from_json(json, json_len);
-        t->device = device;
-        if (device >= 0) {
-            int n = 0;
-            if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device available (the HIP path has no CPU fallback)");
-            if (device >= n) throw HipError("HIP device ordinal out of range");
-            HIP_CHECK(hipSetDevice(device));
-            hipDeviceProp_t prop;
-            HIP_CHECK(hipGetDeviceProperties(&prop, device));
-            t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
-            upload_tables(t.get());
-            verify_direct_words(t.get());
-            build_hot_table(t.get());
-            if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
-            t->cp_grid = compact_grid(t->n_cu);
+        *out = make_tokenizer(json, json_len, device, nullptr).release();
+        return TKAMD_OK;
+    });
+}
+
+int tkamd_tokenizer_from_json_devices(const char* json, size_t json_len, const int* devices, int n_devices, tkamd_tokenizer** out) {
+    if (!json || !out || n_devices < 0 || (n_devices > 0 && !devices)) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    *out = nullptr;
+    return guarded([&]() -> int {
+        std::vector<int> devs = n_devices ? std::vector<int>(devices, devices + n_devices) : devices_from_env();
+        if (devs.size() > 64) throw Invalid("more than 64 devices");
+        for (int d : devs) if (d < 0) throw Invalid("a multi-device handle needs device ordinals >= 0");
+        std::unique_ptr<tkamd_tokenizer> t = make_tokenizer(json, json_len, devs[0], nullptr);
+        for (size_t r = 1; r < devs.size(); ++r) {
+            t->replicas.push_back(make_tokenizer(nullptr, 0, devs[r], t.get()));
+            // the peers push their shards to devices[0] over xGMI (COLLECT_ROOT_P2P): let them map its memory
+            if (devs[r] != devs[0]) {
+                const hipError_t e = hipDeviceEnablePeerAccess(devs[0], 0);
+                if (e != hipSuccess) (void)hipGetLastError();        // (already enabled, or no direct link: the copy is then staged by the runtime)
+            }
         }
+        t->devices = devs;
+        if (const char* e = getenv("TKAMD_SHARD_MIN_KB")) t->shard_min_bytes = (int64_t)std::max(1, atoi(e)) << 10;
+        HIP_CHECK(hipSetDevice(devs[0]));
         *out = t.release();
         return TKAMD_OK;
     });
 }
 
+int tkamd_tokenizer_set_collect(tkamd_tokenizer* t, int mode) {
+    if (!t || mode < TKAMD_COLLECT_HOST || mode > TKAMD_COLLECT_ROOT_RCCL) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    if (mode == TKAMD_COLLECT_ROOT_RCCL) {
+        std::vector<int> seen;
+        for (int d : t->devices) {
+            if (std::find(seen.begin(), seen.end(), d) != seen.end()) return set_error(TKAMD_ERR_INVALID, "TKAMD_COLLECT_ROOT_RCCL: a device is named twice (RCCL wants one rank per GPU)");
+            seen.push_back(d);
+        }
+    }
+    t->collect = mode;
+    return TKAMD_OK;
+}
+
+int tkamd_tokenizer_devices(const tkamd_tokenizer* t, int* devices, int cap, int* n) {
+    if (!t || !n) return set_error(TKAMD_ERR_INVALID, "null argument");
+    *n = (int)t->devices.size();
+    for (int i = 0; i < *n && i < cap && devices; ++i) devices[i] = t->devices[(size_t)i];
+    return TKAMD_OK;
+}
+
+int tkamd_shard_stats(const tkamd_tokenizer* t, int64_t* shard_bytes, double* busy_ms, int cap, int* n) {
+    if (!t || !n) return set_error(TKAMD_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(const_cast<tkamd_tokenizer*>(t)->group_mu);
+    *n = (int)t->shard_ms.size();
+    for (int i = 0; i < *n && i < cap; ++i) {
+        if (shard_bytes) shard_bytes[i] = t->shard_bytes[(size_t)i];
+        if (busy_ms) busy_ms[i] = t->shard_ms[(size_t)i];
+    }
+    return TKAMD_OK;
+}
+
 void tkamd_tokenizer_free(tkamd_tokenizer* t) {
     if (!t) return;
+    if (g_forked) {                      // a handle inherited over fork(): the parent's device state is not ours to touch or free
+        for (auto& r : t->replicas) (void)r.release();
+        return;
+    }
+    for (void* c : t->rccl_comms) if (c) rccl_api().CommDestroy(c);
+    t->rccl_comms.clear();
+    for (auto& r : t->replicas) tkamd_tokenizer_free(r.release());
+    t->replicas.clear();
     if (t->device >= 0) {
         (void)hipSetDevice(t->device);
         (void)hipDeviceSynchronize();
@@ -1517,6 +1721,7 @@ static int encode_device(tkamd_tokenizer* t, const uint8_t* d_text, const int64_
         return set_error(TKAMD_ERR_INVALID, "bad argument");
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
     return guarded([&]() -> int {
+        check_not_forked();
         Workspace* w = workspace_of_stream(t, (hipStream_t)hip_stream, true);
         std::lock_guard<std::mutex> lk(w->mu);
         HIP_CHECK(hipSetDevice(t->device));
@@ -1538,6 +1743,7 @@ int tkamd_encode_batch_words_device(tkamd_tokenizer* t, const uint8_t* d_text, c
 int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, int64_t* n_pretokens) {
     if (!t || t->device < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
     return guarded([&]() -> int {
+        check_not_forked();
         Workspace* w = workspace_of_stream(t, (hipStream_t)hip_stream, false);
         if (!w) throw Invalid("tkamd_device_sync: no encode call was made on this stream");
         std::lock_guard<std::mutex> lk(w->mu);
@@ -1545,6 +1751,258 @@ int tkamd_device_sync(tkamd_tokenizer* t, void* hip_stream, int64_t* n_tokens, i
         int bits = finish_batch(t, w, (hipStream_t)hip_stream, n_tokens, n_pretokens);
         return error_from_bits(bits);
     });
+}
+
+// ---- one call, several devices (multi-device handle) ----
+// The documents are cut into one contiguous run per device with about equal BYTES (the prefix sums of doc_offsets, cut at document /
+// sequence / pair boundaries: rank order is document order).  One host thread per device: H2D of its shard from the caller's
+// buffer, the whole path on its own stream, the token count back.  The threads then meet: the displacement of a shard in the result
+// is the sum of the counts before it.  What follows is the collect mode (include/tokenizers_amd.h): every device writes its slice of
+// the one pinned result itself, or pushes it to devices[0] (peer copy, or RCCL send / recv) which makes the one D2H.
+// No data-path collective exists before that point: the documents are independent (tokenizer/mod.rs:1345-1348).
+struct ShardDesc {                       // one result array
+    const void* src = nullptr;           // on the shard's device
+    size_t esz = 0;                      // bytes per element
+    bool per_token = true;               // else per encoding
+    int64_t extra = 0;                   // elements past the shard's own count (tok_offsets: the closing entry)
+    PinnedBlock* dst = nullptr;          // the batch's host array
+};
+struct Shard {
+    tkamd_tokenizer* tr = nullptr;
+    std::unique_ptr<HostLease> lease;
+    Workspace* w = nullptr;
+    hipStream_t s = nullptr;
+    int64_t d0 = 0, d1 = 0, g0 = 0, g1 = 0, b0 = 0, nb = 0;
+    int64_t n_tok = 0, n_enc = 0, tok_base = 0, enc_base = 0;
+    tkamd_device_result res{};
+    int rc = TKAMD_OK;
+    std::string err;
+    hipEvent_t ev = nullptr;
+    double ms = 0;
+};
+
+static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
+                               int64_t n_seqs, uint32_t flags, tkamd_batch** out) {
+    std::lock_guard<std::mutex> group_lock(t->group_mu);
+    const int n_dev = (int)t->replicas.size() + 1;
+    const int collect = t->collect;
+    const int64_t n_bytes = doc_offsets[n_docs];
+    const bool words_in = n_seqs >= 0;
+    const int64_t n_grp = words_in ? n_seqs : n_docs;
+    auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
+    const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;
+    const bool ids16 = (flags & TKAMD_IDS_U16) != 0;
+    std::vector<Shard> sh((size_t)n_dev);
+    {
+        int64_t prev = 0;
+        for (int r = 0; r < n_dev; ++r) {
+            int64_t g = n_grp;
+            if (r + 1 < n_dev) {
+                const int64_t target = n_bytes / n_dev * (r + 1);
+                g = std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets;
+                if (words_in) g = std::lower_bound(seq_offsets, seq_offsets + n_seqs, g) - seq_offsets;
+                g = std::min(n_grp, std::max<int64_t>(prev, g / unit * unit));
+                // the boundary nearer to the target of the two around it (a long document straddling the target goes to the lighter side)
+                if (g - unit >= prev && g <= n_grp && target - doc_offsets[doc_of(g - unit)] < doc_offsets[doc_of(g)] - target) g -= unit;
+            }
+            Shard& x = sh[(size_t)r];
+            x.tr = r ? t->replicas[(size_t)r - 1].get() : t;
+            x.g0 = prev; x.g1 = g;
+            x.d0 = doc_of(prev); x.d1 = doc_of(g);
+            x.b0 = doc_offsets[x.d0]; x.nb = doc_offsets[x.d1] - x.b0;
+            if (x.nb < 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+            x.n_enc = (g - prev) / unit;
+            prev = g;
+        }
+    }
+    if (collect == TKAMD_COLLECT_ROOT_RCCL && t->rccl_comms.empty()) {
+        RcclApi& api = rccl_api();
+        if (!api.why.empty()) throw HipError("TKAMD_COLLECT_ROOT_RCCL: " + api.why);
+        t->rccl_comms.assign((size_t)n_dev, nullptr);
+        RCCL_CHECK(api.CommInitAll(t->rccl_comms.data(), n_dev, t->devices.data()));
+    }
+    std::unique_ptr<tkamd_batch> b(new tkamd_batch());
+    b->has_ids16 = ids16;
+    b->n_docs = n_grp / unit;
+    std::vector<std::vector<ShardDesc>> desc((size_t)n_dev);
+    Rendezvous rv(n_dev);
+    std::atomic<bool> go{false};
+    int64_t total_tok = 0;
+
+    auto describe = [&](Shard& x) {      // the result arrays of a shard, the same list on every shard (the tokenizer decides which exist)
+        std::vector<ShardDesc> d;
+        const tkamd_device_result& r = x.res;
+        if (ids16) d.push_back({x.w->w_ids16.p, 2, true, 0, &b->ids16});
+        else d.push_back({r.d_ids, 4, true, 0, &b->ids});
+        d.push_back({r.d_tok_offsets, 8, false, 1, &b->tok_offsets});
+        if (r.d_offsets) d.push_back({r.d_offsets, 8, true, 0, &b->offsets});
+        if (r.d_word_ids) d.push_back({r.d_word_ids, 4, true, 0, &b->word_ids});
+        if (r.d_type_ids) { d.push_back({r.d_type_ids, 1, true, 0, &b->type_ids}); d.push_back({r.d_seq_ids, 1, true, 0, &b->seq_ids}); }
+        if (r.d_pad_counts) d.push_back({r.d_pad_counts, 4, false, 0, &b->pad_counts});
+        return d;
+    };
+    auto count_of = [&](const Shard& x, const ShardDesc& d) { return (d.per_token ? x.n_tok : x.n_enc) + d.extra; };
+    auto base_of = [&](const Shard& x, const ShardDesc& d) { return d.per_token ? x.tok_base : x.enc_base; };
+
+    auto worker = [&](int r) {
+        Shard& x = sh[(size_t)r];
+        const auto t_start = std::chrono::steady_clock::now();
+        // phase 1: the shard through the whole path on its own device
+        x.rc = guarded([&]() -> int {
+            tkamd_tokenizer* tr = x.tr;
+            HIP_CHECK(hipSetDevice(tr->device));
+            x.lease.reset(new HostLease(tr));
+            Workspace* w = x.w = x.lease->w;
+            std::lock_guard<std::mutex> wl(w->mu);
+            hipStream_t s = x.s = own_stream(w);
+            const int64_t nd = x.d1 - x.d0, ng = x.g1 - x.g0;
+            if (words_in) {
+                w->h_seq_off.reserve((size_t)(ng + 1) * 8);
+                HIP_CHECK(hipMemcpyAsync(w->h_seq_off.p, seq_offsets + x.g0, (size_t)(ng + 1) * 8, hipMemcpyHostToDevice, s));
+                if (x.d0) launch_add_i64(s, w->h_seq_off.as<int64_t>(), ng + 1, -x.d0);
+            }
+            w->h_text.reserve((size_t)x.nb + TKAMD_TEXT_PAD);
+            w->h_doc_off.reserve((size_t)(nd + 1) * 8);
+            if (x.nb) HIP_CHECK(hipMemcpyAsync(w->h_text.p, text + x.b0, (size_t)x.nb, hipMemcpyHostToDevice, s));
+            HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + x.nb, 0, TKAMD_TEXT_PAD, s));
+            HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + x.d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, s));
+            if (x.b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), nd + 1, -x.b0);
+            run_pipeline(tr, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), nd, x.nb, words_in ? w->h_seq_off.as<int64_t>() : nullptr,
+                         words_in ? ng : -1, flags, s, &x.res);
+            w->last_text = w->h_text.as<uint8_t>(); w->last_doc_off = w->h_doc_off.as<int64_t>(); w->last_n_bytes = x.nb; w->last_flags = flags; w->last_result = x.res;
+            int64_t n_pt = 0;
+            const int bits = finish_batch(tr, w, s, &x.n_tok, &n_pt);
+            if (bits) return error_from_bits(bits);
+            x.res = w->last_result;
+            if (ids16) {
+                w->w_wide.reserve(64);
+                HIP_CHECK(hipMemsetAsync(w->w_wide.p, 0, 4, s));
+                w->w_ids16.reserve((size_t)x.n_tok * 2 + 64);
+                launch_narrow_ids(s, x.res.d_ids, x.n_tok, w->w_ids16.as<uint16_t>(), w->w_wide.as<int>());
+                int wide = 0;
+                HIP_CHECK(hipMemcpyAsync(&wide, w->w_wide.p, 4, hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (wide) throw Invalid("TKAMD_IDS_U16: the batch holds a token id beyond 65,535");
+            }
+            if (collect == TKAMD_COLLECT_ROOT_P2P) HIP_CHECK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming));
+            desc[(size_t)r] = describe(x);
+            return TKAMD_OK;
+        });
+        if (x.rc != TKAMD_OK) x.err = g_last_error;
+        rv.arrive();
+        // the coordinator: displacements, the result arrays
+        if (r == 0) {
+            bool ok = true;
+            for (const Shard& y : sh) ok = ok && y.rc == TKAMD_OK;
+            if (ok) {
+                x.rc = guarded([&]() -> int {
+                    int64_t tb = 0, eb = 0;
+                    for (Shard& y : sh) { y.tok_base = tb; y.enc_base = eb; tb += y.n_tok; eb += y.n_enc; }
+                    total_tok = tb;
+                    if ((uint64_t)tb >= ((uint64_t)1 << 40)) throw Invalid("more than 2^40 tokens in one batch");
+                    for (size_t q = 0; q < desc[0].size(); ++q) {
+                        const ShardDesc& d = desc[0][q];
+                        const size_t elems = (size_t)(d.per_token ? tb : eb) + (size_t)d.extra;
+                        *d.dst = pinned_get(elems * d.esz + 64);
+                        if (collect != TKAMD_COLLECT_HOST) t->g_root[q].reserve(elems * d.esz + 64);
+                    }
+                    return TKAMD_OK;
+                });
+                if (x.rc != TKAMD_OK) x.err = g_last_error;
+                else go = true;
+            }
+        }
+        rv.arrive();
+        // phase 2: the shard's arrays go to their place in the result
+        if (go) {
+            x.rc = guarded([&]() -> int {
+                tkamd_tokenizer* tr = x.tr;
+                HIP_CHECK(hipSetDevice(tr->device));
+                std::lock_guard<std::mutex> wl(x.w->mu);
+                if (x.tok_base) launch_add_i64(x.s, (int64_t*)x.res.d_tok_offsets, x.n_enc + 1, x.tok_base);      // the shard's CSR continues the batch's
+                const std::vector<ShardDesc>& dl = desc[(size_t)r];
+                if (collect == TKAMD_COLLECT_HOST) {
+                    for (const ShardDesc& d : dl) {
+                        const int64_t n = count_of(x, d);
+                        if (n > 0) HIP_CHECK(hipMemcpyAsync((uint8_t*)d.dst->p + (size_t)base_of(x, d) * d.esz, d.src, (size_t)n * d.esz, hipMemcpyDeviceToHost, x.s));
+                    }
+                } else if (collect == TKAMD_COLLECT_ROOT_P2P) {
+                    for (size_t q = 0; q < dl.size(); ++q) {
+                        const ShardDesc& d = dl[q];
+                        const int64_t n = count_of(x, d);
+                        if (n > 0) HIP_CHECK(hipMemcpyPeerAsync((uint8_t*)t->g_root[q].p + (size_t)base_of(x, d) * d.esz, t->device, d.src, tr->device, (size_t)n * d.esz, x.s));
+                    }
+                    HIP_CHECK(hipEventRecord(x.ev, x.s));
+                } else {
+                    RcclApi& api = rccl_api();
+                    RCCL_CHECK(api.GroupStart());
+                    for (size_t q = 0; q < dl.size(); ++q) {
+                        const int64_t n = count_of(x, dl[q]);
+                        if (n > 0) RCCL_CHECK(api.Send(dl[q].src, (size_t)n * dl[q].esz, 1 /* ncclUint8 */, 0, t->rccl_comms[(size_t)r], x.s));
+                    }
+                    if (r == 0)
+                        for (int p = 0; p < n_dev; ++p)
+                            for (size_t q = 0; q < dl.size(); ++q) {
+                                const ShardDesc& d = desc[(size_t)p][q];
+                                const int64_t n = count_of(sh[(size_t)p], d);
+                                if (n > 0) RCCL_CHECK(api.Recv((uint8_t*)t->g_root[q].p + (size_t)base_of(sh[(size_t)p], d) * d.esz, (size_t)n * d.esz, 1, p, t->rccl_comms[0], x.s));
+                            }
+                    RCCL_CHECK(api.GroupEnd());
+                }
+                return TKAMD_OK;
+            });
+            if (x.rc != TKAMD_OK) x.err = g_last_error;
+        }
+        if (collect != TKAMD_COLLECT_HOST) {
+            rv.arrive();
+            bool ok = go;
+            for (const Shard& y : sh) ok = ok && y.rc == TKAMD_OK;
+            if (r == 0 && ok) {
+                x.rc = guarded([&]() -> int {
+                    HIP_CHECK(hipSetDevice(t->device));
+                    if (collect == TKAMD_COLLECT_ROOT_P2P)
+                        for (const Shard& y : sh) HIP_CHECK(hipStreamWaitEvent(x.s, y.ev, 0));
+                    int64_t eb = 0;
+                    for (const Shard& y : sh) eb += y.n_enc;
+                    for (size_t q = 0; q < desc[0].size(); ++q) {
+                        const ShardDesc& d = desc[0][q];
+                        const size_t elems = (size_t)(d.per_token ? total_tok : eb) + (size_t)d.extra;
+                        if (elems) HIP_CHECK(hipMemcpyAsync(d.dst->p, t->g_root[q].p, elems * d.esz, hipMemcpyDeviceToHost, x.s));
+                    }
+                    return TKAMD_OK;
+                });
+                if (x.rc != TKAMD_OK) x.err = g_last_error;
+            }
+        }
+        if (x.s) {
+            (void)hipSetDevice(x.tr->device);
+            if (hipStreamSynchronize(x.s) != hipSuccess && x.rc == TKAMD_OK) { x.rc = TKAMD_ERR_DEVICE; x.err = "hipStreamSynchronize failed on a shard's stream"; }
+        }
+        x.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < n_dev; ++r) th.emplace_back(worker, r);
+    worker(0);
+    for (std::thread& q : th) q.join();
+    // (a peer's push must have landed before root's buffers are reused: every stream was drained above, root's last)
+    for (Shard& x : sh) {
+        if (x.ev) { (void)hipSetDevice(x.tr->device); (void)hipEventDestroy(x.ev); }
+        x.lease.reset();
+    }
+    (void)hipSetDevice(t->device);
+    t->shard_ms.assign((size_t)n_dev, 0.0);
+    t->shard_bytes.assign((size_t)n_dev, 0);
+    for (int r = 0; r < n_dev; ++r) { t->shard_ms[(size_t)r] = sh[(size_t)r].ms; t->shard_bytes[(size_t)r] = sh[(size_t)r].nb; }
+    for (const Shard& x : sh)
+        if (x.rc != TKAMD_OK) return set_error(x.rc, x.err);
+    const tkamd_device_result& r0 = sh[0].res;
+    b->has_offsets = r0.d_offsets != nullptr;
+    b->has_words = r0.d_word_ids != nullptr;
+    b->has_types = r0.d_type_ids != nullptr;
+    b->has_pads = r0.d_pad_counts != nullptr;
+    b->n_tokens = total_tok;
+    *out = b.release();
+    return TKAMD_OK;
 }
 
 // Host entry.  The batch is cut into document-aligned slices that alternate between two workspaces, each on its own stream:
@@ -1558,6 +2016,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
     *out = nullptr;
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
     return guarded([&]() -> int {
+        check_not_forked();
         HIP_CHECK(hipSetDevice(t->device));
         const int64_t n_bytes = doc_offsets[n_docs];
         if (n_bytes < 0 || doc_offsets[0] != 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
@@ -1577,6 +2036,9 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
+        // a multi-device handle: one shard per device (what couples the documents of a batch stays on devices[0], like it stays in one slice)
+        if (!t->replicas.empty() && !(t->hm.pad_on && !t->hm.pad_fixed) && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes)
+            return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)
         std::vector<int64_t> cut(n_slices + 1, 0);                     // in sequences
@@ -1772,6 +2234,7 @@ int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* t
     return guarded([&]() -> int {
         const HostModel& hm = t->hm;
         if (hm.decoder == DEC_UNSUPPORTED) throw Unsupported("decode_batch: " + hm.dec_unsupported);
+        check_not_forked();
         HIP_CHECK(hipSetDevice(t->device));
         HostLease lease(t);
         Workspace* w = lease.w;
@@ -1960,6 +2423,7 @@ void tkamd_text_free(tkamd_text* b) { delete b; }
 int tkamd_encode_special_tokens(tkamd_tokenizer* t, int value) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
     t->encode_special = value != 0;
+    for (auto& r : t->replicas) r->encode_special = value != 0;
     return TKAMD_OK;
 }
 
@@ -1967,19 +2431,21 @@ int tkamd_word_cache(tkamd_tokenizer* t, int enable, int clear) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
     if (clear) ++t->cache_epoch;
     t->word_cache = enable != 0;
+    for (auto& r : t->replicas) { if (clear) ++r->cache_epoch; r->word_cache = enable != 0; }
     return TKAMD_OK;
 }
 
 int tkamd_profile_enable(tkamd_tokenizer* t, int on) {
     if (!t) return set_error(TKAMD_ERR_INVALID, "null argument");
     t->prof = on != 0;
+    for (auto& r : t->replicas) r->prof = on != 0;
     return TKAMD_OK;
 }
 
 int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_stages, int* n_stages, int reset) {
     if (!t || !n_stages) return set_error(TKAMD_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(t->mu);
-    if (t->device >= 0) {
+    if (t->device >= 0 && !g_forked) {
         (void)hipSetDevice(t->device);
         for (auto& w : t->pool) drain_profile(t, w.get());
     }
@@ -1998,7 +2464,7 @@ int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {
         for (int i = 0; i < n; ++i) out[i] = 0;
         if (!w) return TKAMD_OK;
         for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = w->last_counters[i];
-        if (t->device >= 0 && w->w_qcount.p) {             // queue fills of the last batch: the sub-queue counters, summed per queue
+        if (t->device >= 0 && w->w_qcount.p && !g_forked) {             // queue fills of the last batch: the sub-queue counters, summed per queue
             HIP_CHECK(hipSetDevice(t->device));
             HIP_CHECK(hipDeviceSynchronize());
             std::vector<uint32_t> c(QCNT_WORDS);

@@ -71,6 +71,9 @@ struct __attribute__((aligned(32))) CacheKey {
 struct WordCache {
     CacheKey* keys;              // null: no cache
     void* rows;                  // [1 << WORD_CACHE_BITS] 16-byte rows
+    // In-batch word claims (kernels/lookup.hip "claims"): one 64-bit word per slot, 0 = free, else (length << 32 | first byte) of the
+    // pre-token that claimed the slot in THIS batch.  Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
+    unsigned long long* claims;
 };
 
 struct QueuePlan {
@@ -344,6 +347,7 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
 // single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
 // compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
+void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);

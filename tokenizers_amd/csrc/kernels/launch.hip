@@ -68,6 +68,7 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.matchmask = matchmask;
     a.hot = (const uint4*)hot;
     a.cache_keys = wc.keys;
+    a.claims = wc.claims;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
     if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
@@ -233,6 +234,9 @@ int compact_grid(int n_cu) {
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_compact, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
+}
+void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
+    hipLaunchKernelGGL(k_claims_publish, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc.claims, (uint4*)wc.rows);
 }
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);

@@ -62,6 +62,7 @@ struct LookupArgs {
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
     uint32_t unk_id, has_unk;
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
+    unsigned long long* claims;      // in-batch word claims (kernels.hpp WordCache::claims), or null
 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
@@ -263,6 +264,25 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                         const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
                         if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
                     }
+                    if (a.claims && pend) {                                         // (the outer test is wavefront-uniform)
+                        // In-batch claims: the FIRST occurrence of a word the tables do not settle claims the slot of its hash and is queued
+                        // for the model kernel; every later occurrence finds the claim, checks it against the claimant's bytes in the text
+                        // (immutable: nothing here waits for another lane's writes) and points tok0 at the slot's row, which
+                        // k_claims_publish fills from the claimant's result after the model kernels.  A slot taken by another word: queued
+                        // like before.  The reference does the same per thread with its cache (bpe/model.rs:573-586); here natural text's
+                        // repeats leave the model kernels a few percent of the queued words.
+                        const uint32_t slot = cache_slot(h1);
+                        unsigned long long* const cp = a.claims + slot;
+                        const unsigned long long mine = ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel);
+                        // (a plain device-scope load first: a frequent word would otherwise serialise thousands of read-modify-writes on one address)
+                        unsigned long long old = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old == 0ull) old = atomicCAS(cp, 0ull, mine);
+                        if (old != 0ull && (uint32_t)(old >> 32) == len) {
+                            const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)old);      // (readable: the text carries TEXT_PAD bytes of slack)
+                            const uint4 km = s_kmask[len];
+                            if ((((o.a & km.x) ^ k0) | ((o.b & km.y) ^ k1) | ((o.c & km.z) ^ k2) | ((o.d & km.w) ^ k3)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
+                        }
+                    }
                 }
                 if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
                     if (pend && len <= (uint32_t)WORD_MAX_KEY) {
@@ -305,6 +325,26 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         uint32_t* const cnt_p = tid == 0 ? a.v[0].counts : tid == 1 ? a.v[1].counts : tid == 2 ? a.v[2].counts : a.v[3].counts;
         const uint32_t cap = tid == 0 ? a.v[0].sq_cap : tid == 1 ? a.v[1].sq_cap : tid == 2 ? a.v[2].sq_cap : a.v[3].sq_cap;
         cnt_p[sq * QCNT_STRIDE] = min(s_fill[tid], cap);
+    }
+}
+
+// =================================================================================================
+// K_claims_publish: after the model kernels, the result row of every queued pre-token that holds the claim of its slot is copied to
+// the slot's row, where the compaction finds it for the word's other occurrences (tok0 = TOK_ROW | CACHE_ROW_BIT | slot).  A row of
+// more than four tokens names its ids by the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v, const uint4* __restrict__ rows,
+                                                        const unsigned long long* __restrict__ claims, uint4* __restrict__ crows) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
+    const uint32_t n = qview_prefix(v, s_qpre);
+    for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
+        const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
+        const QItem it = v.q[qpos];
+        if (it.len == 0u || it.len > 16u) continue;
+        uint64_t lo, hi;
+        load_key16(text, it.s, it.len, &lo, &hi);
+        const uint32_t slot = cache_slot(word_hash1(lo, hi, it.len, t.word_seed));
+        if (claims[slot] == (((unsigned long long)it.len << 32) | (unsigned long long)it.s)) crows[slot] = rows[v.row_base + qpos];
     }
 }
 

@@ -406,11 +406,34 @@ class _BatchOwner:
 class Tokenizer:
     """MI355X-native stand-in for ``tokenizers.Tokenizer`` on the encode_batch path."""
 
-    def __init__(self, json_str: str, device: int = 0):
+    def __init__(self, json_str: str, device=0, collect: str = "host"):
+        """``device``: a HIP ordinal (-1: host-only handle), or a LIST of ordinals / ``"env"`` (TOKENIZERS_GPU_DEVICES = ``all`` |
+        ``0,2,3``) for a multi-device handle: the tables are replicated and every ``encode_batch`` call is sharded by document over all
+        of them inside the library (``tkamd_tokenizer_from_json_devices``); ``collect`` = how the shards' results meet: ``"host"``
+        (every device writes its slice of the one pinned result), ``"p2p"`` / ``"rccl"`` (gathered on the first device, one D2H)."""
         lib = _lib.load()
         raw = json_str.encode("utf-8")
         h = C.c_void_p()
-        _lib.check(lib.tkamd_tokenizer_from_json(raw, len(raw), int(device), C.byref(h)))
+        if isinstance(device, (list, tuple)) or device == "env":
+            devs = [] if device == "env" else [int(x) for x in device]
+            arr = (C.c_int * max(len(devs), 1))(*devs)
+            _lib.check(lib.tkamd_tokenizer_from_json_devices(raw, len(raw), arr, len(devs), C.byref(h)))
+            got, n = (C.c_int * 64)(), C.c_int(0)
+            _lib.check(lib.tkamd_tokenizer_devices(h, got, 64, C.byref(n)))
+            self.devices = [got[i] for i in range(n.value)]
+            device = self.devices[0]
+            self._device_arg = list(self.devices)
+            mode = {"host": _lib.COLLECT_HOST, "p2p": _lib.COLLECT_ROOT_P2P, "rccl": _lib.COLLECT_ROOT_RCCL}[collect]
+            if mode:
+                rc = lib.tkamd_tokenizer_set_collect(h, mode)
+                if rc != _lib.OK:
+                    lib.tkamd_tokenizer_free(h)
+                    _lib.check(rc)
+        else:
+            _lib.check(lib.tkamd_tokenizer_from_json(raw, len(raw), int(device), C.byref(h)))
+            self.devices = [int(device)] if int(device) >= 0 else []
+            self._device_arg = int(device)
+        self._collect = collect
         self._h = h
         self._lib = lib
         self.device = int(device)
@@ -435,8 +458,8 @@ class Tokenizer:
 
     # ---- constructors (Tokenizer::from_str / from_file, tokenizer/mod.rs:468-472) ----
     @staticmethod
-    def from_str(json_str: str, device: int = 0) -> "Tokenizer":
-        return Tokenizer(json_str, device)
+    def from_str(json_str: str, device=0, collect: str = "host") -> "Tokenizer":
+        return Tokenizer(json_str, device, collect)
 
     @staticmethod
     def from_file(path: str, device: int = 0) -> "Tokenizer":
@@ -502,7 +525,7 @@ class Tokenizer:
         cache, the profile hooks) are re-applied; the swap happens under the staging lock so a concurrent encode sees the old or the new
         handle, never half of each.  A DeviceBatch of the old handle points into freed workspace afterwards -- like the reference,
         whose setters need `&mut self`, do not reconfigure a tokenizer while results of it are in flight."""
-        new = Tokenizer(json.dumps(d, ensure_ascii=False), self.device)
+        new = Tokenizer(json.dumps(d, ensure_ascii=False), self._device_arg, self._collect)
         esp, wc, prof = getattr(self, "_encode_special", False), getattr(self, "_word_cache_on", False), getattr(self, "_profile_on", False)
         with self._stage_lock:
             old_h, lock = self._h, self._stage_lock
@@ -931,6 +954,13 @@ class Tokenizer:
         ``clear`` forgets everything.  Results never change."""
         _lib.check(self._lib.tkamd_word_cache(self._h, 1 if enable else 0, 1 if clear else 0))
         self._word_cache_on = bool(enable)
+
+    def shard_stats(self) -> list[tuple[int, int, float]]:
+        """The last sharded call of a multi-device handle: (device, bytes of its shard, milliseconds its host thread was busy)."""
+        n = max(len(self.devices), 1)
+        nb, ms, k = (C.c_int64 * n)(), (C.c_double * n)(), C.c_int(0)
+        _lib.check(self._lib.tkamd_shard_stats(self._h, nb, ms, n, C.byref(k)))
+        return [(self.devices[i], nb[i], ms[i]) for i in range(min(k.value, n))]
 
     # ---- measurement hooks ----
     def profile(self, on: bool) -> None:
