@@ -653,6 +653,8 @@ def test_in_batch_claims_vs_oracle(name, gpt2_json):
     def word():
         return "".join(alpha[i] for i in rng.integers(0, len(alpha), size=int(rng.integers(2, 22))))
     few = [word() for _ in range(80)]
+    letters = "qzxjkvwQZXJ"
+    few += ["".join(letters[i] for i in rng.integers(0, len(letters), size=n)) for n in (15, 16, 17, 18, 24, 30, 31, 32, 33, 40)]     # 17..32-byte words claim too
     docs = [" ".join(few[i] for i in rng.integers(0, len(few), size=int(rng.integers(1, 30)))) for _ in range(N(40000))]
     docs += ["", few[0], few[0] + few[0], " " + few[1] + " "]
     exp = o.encode_batch(docs)
@@ -707,7 +709,8 @@ def test_word_cache_never_changes_a_result(name, gpt2_json):
     tok.word_cache(True, clear=True)
     assert check(a, exp_a) == first
     tok.word_cache(False)
-    assert check(a, exp_a) == claimed
+    again = check(a, exp_a)                                 # (which of two words that share both slots gets one is a race between workgroups:
+    assert abs(again - claimed) <= max(8, claimed // 50)    # the queue length may differ by a few entries from run to run, never the ids)
 
 
 def test_added_vocabulary_of_random_shape_matches_the_wheel_live(ref_tokenizers):

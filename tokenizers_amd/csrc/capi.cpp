@@ -185,7 +185,7 @@ struct Workspace {
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
-    DevBuf w_claims;                             // in-batch word claims (kernels.hpp WordCache::claims); their rows live in w_cache_rows
+    DevBuf w_claims, w_claim_rows;               // in-batch word claims (kernels.hpp WordCache::claims) and the rows of the claimed slots
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
     DevBuf w_seq_off, w_seq_tok_off, w_word_idx, w_first_tok;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
     // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
@@ -1211,22 +1211,27 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
-    WordCache wc{nullptr, nullptr, nullptr};
+    WordCache wc{nullptr, nullptr, nullptr, 0u, 0u};
     // In-batch word claims (default; TKAMD_CLAIMS=0 switches them off for A/B runs): repeated words reach the model kernels once
     // per batch (kernels/lookup.hip).  The word cache (kernels.hpp WordCache, tkamd_word_cache: across batches) takes their place when
-    // it is switched on.  Both serve the ids-only path: a shared row carries no token ends.
-    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
+    // it is switched on.  With offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.
+    static const int claims_mode = [] { const char* e = getenv("TKAMD_CLAIMS"); return e ? atoi(e) : 3; }();      // 0 off; 1 / 2 / 3: WordCache::claim_mode
     auto open_word_cache = [&]() {
-        if (off_mode != TKAMD_OFFSETS_NONE) return;
         const size_t slots = (size_t)1 << WORD_CACHE_BITS;
         if (!t->word_cache) {
-            if (!claims_on) return;
-            w->w_claims.reserve(slots * 8);
-            w->w_cache_rows.reserve(slots * 16);
-            HIP_CHECK(hipMemsetAsync(w->w_claims.p, 0, slots * 8, st));
-            wc = WordCache{nullptr, w->w_cache_rows.p, (unsigned long long*)w->w_claims.p};
+            if (claims_mode < 1 || claims_mode > 3) return;
+            // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
+            // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch, zeroed per batch
+            int bits = 18;
+            while (bits < 24 && ((size_t)1 << bits) < N / 64) ++bits;
+            const size_t cslots = (size_t)1 << bits;
+            w->w_claims.reserve(cslots * 8);
+            w->w_claim_rows.reserve(cslots * 16);
+            HIP_CHECK(hipMemsetAsync(w->w_claims.p, 0, cslots * 8, st));
+            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(cslots - 1), (uint32_t)claims_mode};
             return;
         }
+        if (off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends; the claims' rows would overwrite the cache's)
         w->w_cache_keys.reserve(slots * sizeof(CacheKey));
         w->w_cache_rows.reserve(slots * 16);
         const uint64_t epoch = t->cache_epoch;
@@ -1234,7 +1239,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
             w->cache_epoch = epoch;
         }
-        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr};
+        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u, 0u};
     };
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
@@ -1243,7 +1248,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
-            for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err);
+            for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
         // TKAMD_MERGE16 = row / lane, TKAMD_LDSCFG = 0: the 16-lane DPP-row kernel / the register-resident lane kernels (A/B
         // switches; the lane kernels are also what runs when new_id is not rank + c)
         static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 2; }();
@@ -1264,7 +1269,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         if (wc.claims) {
             pf.begin("claims_publish");
-            launch_claims_publish(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[1], w->w_rows.p, wc);
             pf.end();
         }
         pf.begin("bpe_merge64");
@@ -1291,8 +1297,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr}, 0u, 1u);
-        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err);      // words longer than 16 bytes
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u, 0u}, 0u, 1u);
+        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u, 0u});      // words longer than 16 bytes
         pf.end();
     } else {
         // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): the whole-word lookup
@@ -1320,7 +1326,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         if (wc.claims) {
             pf.begin("claims_publish");
-            launch_claims_publish(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[1], w->w_rows.p, wc);
             pf.end();
         }
     }
@@ -1355,6 +1362,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.n_tok = d_ntok_total;
         a.pt_tokoff = w->w_pt_tokoff.as<uint32_t>();
         a.tmp_end = tmp_end;
+        a.tok0 = wc.claims ? w->w_tok0.as<uint32_t>() : nullptr;
+        a.claims = wc.claims;
         a.n_pretok = d_npretok;
         a.doc_pt = w->w_doc_pt.as<uint32_t>();
         a.n_docs = n_docs;

@@ -74,6 +74,9 @@ struct WordCache {
     // In-batch word claims (kernels/lookup.hip "claims"): one 64-bit word per slot, 0 = free, else (length << 32 | first byte) of the
     // pre-token that claimed the slot in THIS batch.  Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
     unsigned long long* claims;
+    uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host: claim_table_bits)
+    uint32_t claim_mode;         // how the lookup reads a slot (A/B switch TKAMD_CLAIMS): 1 device-scope loads only, 2 a cached load first,
+                                 // 3 (default) the cached load rides along with the whole-word table probe
 };
 
 struct QueuePlan {
@@ -89,6 +92,8 @@ struct MetaArgs {
     const int64_t* n_tok;             // total token count (device scalar)
     const uint32_t* pt_tokoff;
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
+    const uint32_t* tok0;             // in-batch claims: a pre-token whose tok0 names a claimed slot shares the claimant's tokens, and its token
+    const unsigned long long* claims; // ends are the claimant's: tmp_end[claimant's first byte + j] (both null when the claims are off)
     const int64_t* n_pretok;
     const uint32_t* doc_pt;
     const uint32_t* word_of_doc;      // is_pretokenized: word id of every token of document d (its index in the sequence); else null
@@ -289,7 +294,8 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                            uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err);
 // whole-word vocabulary hits of QUEUED pre-tokens longer than 16 bytes (ignore_merges, WordLevel): a hit becomes the result row and
 // the queue entry is retired (length 0) so that the model kernels skip it
-void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err);
+void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
+                       const WordCache& wc);
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,

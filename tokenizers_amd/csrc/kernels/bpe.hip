@@ -345,10 +345,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
     const uint32_t nid_base = t.newid_base;
     const uint32_t n_items = qview_prefix(v, s_qpre);
-    const uint32_t stride = gridDim.x * NT;
-    for (uint32_t base = blockIdx.x * NT; base < n_items; base += stride) {
+    // a short queue (the in-batch claims leave the distinct words only) is spread over the whole grid, a few wavefronts of every
+    // workgroup busy, instead of filling the first workgroups and leaving most CUs idle
+    const uint32_t take = min((uint32_t)NT, ((n_items + gridDim.x - 1u) / gridDim.x + 63u) & ~63u);
+    const uint32_t stride = gridDim.x * take;
+    for (uint32_t base = blockIdx.x * take; base < n_items; base += stride) {
         const uint32_t item = base + tid;
-        bool valid = item < n_items;
+        bool valid = tid < take && item < n_items;
         uint32_t s = 0, len = 0, qidx = 0;                    // qidx: position in the work queue (names the result row)
         if (valid) { qidx = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qidx]; s = it.s; len = it.len; }
         valid = valid && len != 0u;                           // length 0: retired by k_long_vocab

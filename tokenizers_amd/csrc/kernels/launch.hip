@@ -69,6 +69,8 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.hot = (const uint4*)hot;
     a.cache_keys = wc.keys;
     a.claims = wc.claims;
+    a.claim_mask = wc.claim_mask;
+    a.claim_mode = wc.claim_mode;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
     if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
@@ -125,8 +127,9 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
     hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
-void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err) {
-    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err);
+void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
+                       const WordCache& wc) {
+    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err, (const unsigned long long*)wc.claims, wc.claim_mask, (uint4*)wc.rows);
 }
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err) {
@@ -236,7 +239,7 @@ int compact_grid(int n_cu) {
     return per_cu * n_cu;
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
-    hipLaunchKernelGGL(k_claims_publish, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc.claims, (uint4*)wc.rows);
+    hipLaunchKernelGGL(k_claims_publish, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc.claims, wc.claim_mask, (uint4*)wc.rows);
 }
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);

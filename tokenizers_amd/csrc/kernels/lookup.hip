@@ -63,10 +63,22 @@ struct LookupArgs {
     uint32_t unk_id, has_unk;
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
     unsigned long long* claims;      // in-batch word claims (kernels.hpp WordCache::claims), or null
+    uint32_t claim_mask, claim_mode;
 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
+// claims of words of 17..32 bytes: the hash of the first 16 bytes (+ the whole length) continued over bytes 16..31, zero padded
+constexpr uint32_t CLAIM_MAX_LEN = 32u;
+__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
+    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
+}
+// A word has two slots in the claims table: the second is tried when another word holds the first (a frequent word that lost its
+// only slot to a rare one would send every occurrence to the model kernels).
+__device__ __forceinline__ uint32_t claim_slot_a(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
+__device__ __forceinline__ uint32_t claim_slot_b(uint32_t h, uint32_t mask) { return (mix32(h ^ 0x5BD1E995u) >> 5) & mask; }
+// the hash a queued pre-token of <= 32 bytes claims with (recomputed from the text by the kernels behind the lookup)
+__device__ __forceinline__ uint32_t claim_hash_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed);
 
 template <bool HAS_END>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
@@ -238,6 +250,29 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 }
             }
             __syncthreads();
+            // In-batch claims: the FIRST occurrence of a word the tables do not settle claims a slot of its hash and is queued for the model
+            // kernel; every later occurrence finds the claim, checks it against the claimant's bytes in the text (immutable: nothing here
+            // waits for another lane's writes) and points tok0 at the slot's row, which k_claims_publish fills from the claimant's result
+            // after the model kernels.  Both slots of the word taken by other words: queued like before.  The reference does the same per
+            // thread with its cache (bpe/model.rs:573-586); natural text's repeats leave the model kernels a few percent of the queued words.
+            // A slot only ever goes from 0 to its claim, so a cached (possibly stale) read that shows a claim is as good as a fresh one;
+            // only a read of 0 has to be confirmed at device scope, and only a confirmed 0 is worth the read-modify-write (a frequent word
+            // would otherwise serialise thousands of them on one address).
+            // claim_at: the claim found in `slot` (0: the slot was free and is now this pre-token's); `seen` = what a cached read showed.
+            auto claim_at = [&](uint32_t slot, unsigned long long seen, uint32_t start, uint32_t len) -> unsigned long long {
+                unsigned long long* const cp = a.claims + slot;
+                unsigned long long old = seen;
+                if (old == 0ull) old = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == 0ull) old = atomicCAS(cp, 0ull, ((unsigned long long)len << 32) | (unsigned long long)start);
+                return old;
+            };
+            // is the claim `c` this word (<= 16 bytes: k0..k3 masked; longer: k4..k7 as well)?
+            auto same_short = [&](unsigned long long c, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) -> bool {
+                if ((uint32_t)(c >> 32) != len) return false;
+                const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c);                // (readable: the text carries TEXT_PAD bytes of slack)
+                const uint4 km = s_kmask[len];
+                return (((o.a & km.x) ^ k0) | ((o.b & km.y) ^ k1) | ((o.c & km.z) ^ k2) | ((o.d & km.w) ^ k3)) == 0u;
+            };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
             const uint32_t n_miss = s_nmiss;
             for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
@@ -250,6 +285,16 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 if (v && hits_on && len <= (uint32_t)WORD_MAX_KEY) {
                     const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
                     const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
+                    // claim_mode 3: the (cached) read of the word's first slot and, if it shows a claim of this length, of the claimant's
+                    // bytes fly together with the displacement -> slot chain of the table probe: no round trip is added for a repeated word
+                    const uint32_t slot_a = claim_slot_a(h1, a.claim_mask);
+                    unsigned long long seen = 0ull;
+                    Unaligned16 so{0u, 0u, 0u, 0u};
+                    const bool spec = a.claims && a.claim_mode == 3u && len != 0u;
+                    if (spec) {
+                        seen = a.claims[slot_a];
+                        if ((uint32_t)(seen >> 32) == len) so = *(const Unaligned16*)(a.text + (uint32_t)seen);
+                    }
                     const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
                     uint4 a0 = q[0], a1 = q[1];
                     asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
@@ -264,25 +309,48 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                         const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
                         if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
                     }
-                    if (a.claims && pend) {                                         // (the outer test is wavefront-uniform)
-                        // In-batch claims: the FIRST occurrence of a word the tables do not settle claims the slot of its hash and is queued
-                        // for the model kernel; every later occurrence finds the claim, checks it against the claimant's bytes in the text
-                        // (immutable: nothing here waits for another lane's writes) and points tok0 at the slot's row, which
-                        // k_claims_publish fills from the claimant's result after the model kernels.  A slot taken by another word: queued
-                        // like before.  The reference does the same per thread with its cache (bpe/model.rs:573-586); here natural text's
-                        // repeats leave the model kernels a few percent of the queued words.
-                        const uint32_t slot = cache_slot(h1);
-                        unsigned long long* const cp = a.claims + slot;
-                        const unsigned long long mine = ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel);
-                        // (a plain device-scope load first: a frequent word would otherwise serialise thousands of read-modify-writes on one address)
-                        unsigned long long old = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (old == 0ull) old = atomicCAS(cp, 0ull, mine);
-                        if (old != 0ull && (uint32_t)(old >> 32) == len) {
-                            const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)old);      // (readable: the text carries TEXT_PAD bytes of slack)
+                    if (a.claims && pend && len != 0u) {                            // (a.claims is wavefront-uniform)
+                        bool dup = false;
+                        uint32_t slot = slot_a;
+                        if (spec && (uint32_t)(seen >> 32) == len) {
                             const uint4 km = s_kmask[len];
-                            if ((((o.a & km.x) ^ k0) | ((o.b & km.y) ^ k1) | ((o.c & km.z) ^ k2) | ((o.d & km.w) ^ k3)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
+                            dup = (((so.a & km.x) ^ k0) | ((so.b & km.y) ^ k1) | ((so.c & km.z) ^ k2) | ((so.d & km.w) ^ k3)) == 0u;
                         }
+                        if (!dup) {
+                            unsigned long long c = seen;                            // (a claim seen is final: another word's, or not yet compared)
+                            if (!spec && a.claim_mode == 2u) c = a.claims[slot_a];
+                            if (c == 0ull) c = claim_at(slot_a, 0ull, (uint32_t)t0 + s_rel, len);
+                            if (c != 0ull && !(spec && c == seen)) dup = same_short(c, len, k0, k1, k2, k3);
+                            if (c != 0ull && !dup) {                                // another word holds the first slot: the second
+                                slot = claim_slot_b(h1, a.claim_mask);
+                                c = claim_at(slot, a.claim_mode == 1u ? 0ull : a.claims[slot], (uint32_t)t0 + s_rel, len);
+                                dup = c != 0ull && same_short(c, len, k0, k1, k2, k3);
+                            }
+                        }
+                        if (dup) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
                     }
+                }
+                if (a.claims && v && len > (uint32_t)WORD_MAX_KEY && len <= CLAIM_MAX_LEN) {      // claims of the 17..32-byte words (few lanes)
+                    const uint32_t wi = (s_rel >> 2) + 4u, sh = s_rel & 3u;
+                    const uint32_t d4 = s_text32[wi], d5 = s_text32[wi + 1], d6 = s_text32[wi + 2], d7 = s_text32[wi + 3], d8 = s_text32[wi + 4];
+                    const uint4 km = s_kmask[len - 16u];
+                    const uint32_t k4 = __builtin_amdgcn_alignbyte(d5, d4, sh) & km.x, k5 = __builtin_amdgcn_alignbyte(d6, d5, sh) & km.y;
+                    const uint32_t k6 = __builtin_amdgcn_alignbyte(d7, d6, sh) & km.z, k7 = __builtin_amdgcn_alignbyte(d8, d7, sh) & km.w;
+                    const uint32_t h = claim_hash_long(word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), k4, k5, k6, k7);
+                    auto same_long = [&](unsigned long long c) -> bool {
+                        if ((uint32_t)(c >> 32) != len) return false;
+                        const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c), o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
+                        return ((o.a ^ k0) | (o.b ^ k1) | (o.c ^ k2) | (o.d ^ k3) | ((o2.a & km.x) ^ k4) | ((o2.b & km.y) ^ k5) | ((o2.c & km.z) ^ k6) | ((o2.d & km.w) ^ k7)) == 0u;
+                    };
+                    uint32_t slot = claim_slot_a(h, a.claim_mask);
+                    unsigned long long c = claim_at(slot, a.claim_mode == 1u ? 0ull : a.claims[slot], (uint32_t)t0 + s_rel, len);
+                    bool dup = c != 0ull && same_long(c);
+                    if (c != 0ull && !dup) {
+                        slot = claim_slot_b(h, a.claim_mask);
+                        c = claim_at(slot, a.claim_mode == 1u ? 0ull : a.claims[slot], (uint32_t)t0 + s_rel, len);
+                        dup = c != 0ull && same_long(c);
+                    }
+                    if (dup) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
                 }
                 if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
                     if (pend && len <= (uint32_t)WORD_MAX_KEY) {
@@ -333,18 +401,34 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 // the slot's row, where the compaction finds it for the word's other occurrences (tok0 = TOK_ROW | CACHE_ROW_BIT | slot).  A row of
 // more than four tokens names its ids by the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.
 // =================================================================================================
+__device__ __forceinline__ uint32_t claim_hash_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed) {
+    uint64_t lo, hi;
+    load_key16(text, s, min(len, 16u), &lo, &hi);
+    const uint32_t h16 = word_hash1(lo, hi, len, seed);
+    if (len <= 16u) return h16;
+    uint64_t lo2, hi2;
+    load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
+    return claim_hash_long(h16, (uint32_t)lo2, (uint32_t)(lo2 >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32));
+}
+// one queued pre-token with its finished row: if it holds the claim of one of its two slots the row becomes that slot's
+__device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len, const uint4& row,
+                                                   const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
+    if (len == 0u || len > CLAIM_MAX_LEN) return;
+    const uint32_t h = claim_hash_of(text, s, len, seed);
+    const unsigned long long mine = ((unsigned long long)len << 32) | (unsigned long long)s;
+    const uint32_t sa = claim_slot_a(h, claim_mask);
+    if (claims[sa] == mine) { crows[sa] = row; return; }
+    const uint32_t sb = claim_slot_b(h, claim_mask);
+    if (claims[sb] == mine) crows[sb] = row;
+}
 __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v, const uint4* __restrict__ rows,
-                                                        const unsigned long long* __restrict__ claims, uint4* __restrict__ crows) {
+                                                        const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t n = qview_prefix(v, s_qpre);
     for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
-        if (it.len == 0u || it.len > 16u) continue;
-        uint64_t lo, hi;
-        load_key16(text, it.s, it.len, &lo, &hi);
-        const uint32_t slot = cache_slot(word_hash1(lo, hi, it.len, t.word_seed));
-        if (claims[slot] == (((unsigned long long)it.len << 32) | (unsigned long long)it.s)) crows[slot] = rows[v.row_base + qpos];
+        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claims, claim_mask, crows);
     }
 }
 

@@ -205,8 +205,13 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         // an added-token match is one token whose own length is on record (k_scatter_matches): a later, overlapping match may have
         // cut it short in the start mask, and its text is the raw slice (trimmed by real whitespace chars)
         const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+        uint32_t s_ends = s;                                          // whose token ends: the pre-token's own, or the claimant's of its word
+        if (a.claims && c > 1) {
+            const uint32_t t0 = a.tok0[p];
+            if ((t0 & (TOK_ROW | CACHE_ROW_BIT)) == (TOK_ROW | CACHE_ROW_BIT)) s_ends = (uint32_t)a.claims[t0 & (CACHE_ROW_BIT - 1u)];
+        }
         for (uint32_t j = 0; j < c; ++j) {
-            uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s + j];
+            uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s_ends + j];
             if (a.want_words) a.word_ids[o + j] = word;
             if (a.want_offsets) {
                 uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space

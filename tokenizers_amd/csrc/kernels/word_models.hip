@@ -18,8 +18,10 @@
 // vocabulary is final -- BPE with ignore_merges (bpe/model.rs:559-567) and WordLevel (wordlevel/mod.rs:162-178) -- this kernel
 // probes the QUEUED long pre-tokens: a hit becomes the result row and the queue entry is retired (length 0: the merge kernels
 // skip it); for WordLevel a miss is the unk id or MissingUnkToken.  Rare path: one lane per item.
+// A retired entry that holds the in-batch claim of its word (lookup.hip) publishes its row here: k_claims_publish no longer sees it.
 __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
-                                                    uint32_t miss_is_unk, int* __restrict__ err) {
+                                                    uint32_t miss_is_unk, int* __restrict__ err, const unsigned long long* __restrict__ claims,
+                                                    uint32_t claim_mask, uint4* __restrict__ crows) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t n = qview_prefix(v, s_qpre);
     for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
@@ -32,7 +34,9 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
             else atomicOr(err, ERR_MISSING_UNK);
         }
         if (hit || miss_is_unk) {
-            rows[v.row_base + qpos] = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 row = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+            rows[v.row_base + qpos] = row;
+            if (claims) claim_publish_item(text, t.word_seed, it.s, it.len, row, claims, claim_mask, crows);
             v.q[qpos].len = 0u;
         }
     }
