@@ -638,6 +638,31 @@ def test_runs_of_unknown_one_byte_words_grow_the_queue_twice():
     assert got.ids[:50000].tolist() == [0] * 50000
 
 
+@pytest.mark.parametrize("name", ["wordlevel_whitespace_c1", "bytelevel_prefix_trim_3000"])
+def test_document_token_csr_corners(name):
+    """The documents' token CSR is written by the compaction, chunk of 2048 pre-tokens by chunk (kernels/output.hip): no pre-token
+    at all, a pre-token count that is a multiple of the chunk, runs of more than 256 empty documents inside / at the head / at the
+    tail of a chunk, documents spanning several chunks, thousands of one-pre-token documents in one chunk."""
+    import tokenizers_amd as ta
+    js = load_tokenizer_json(name)
+    tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+    long_doc = " ".join(["the", "cat", "xq"] * 2500)
+    cases = [
+        [""] * 700,
+        [""],
+        ["the"] * 4096,
+        ["the"] * 2048 + [""] * 300,
+        [""] * 300 + ["the"] * 2047 + [""] * 600 + ["cat"] + [""] * 5,
+        [long_doc, "", "", long_doc, "the", ""] + [""] * 400 + [long_doc],
+        ["the cat"] * 1024 + [""] * 1000 + ["the cat"] * 1024 + [""] * 1000,
+    ]
+    for docs in cases:
+        exp = o.encode_batch(docs)
+        for kw in ({}, {"offsets": "byte", "word_ids": True}):
+            got = tok.encode_batch_csr(docs, **kw)
+            assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids), (len(docs), kw)
+
+
 @pytest.mark.parametrize("name", ["gpt2", "llama3_small_6000_specials", "bert_wordpiece_4000_specials", "bytelevel_prefix_trim_3000"])
 def test_in_batch_claims_vs_oracle(name, gpt2_json):
     """The in-batch word claims of the lookup kernel (kernels/lookup.hip: the first occurrence of a word the tables do not settle is

@@ -168,6 +168,10 @@ struct Workspace {
     bool device_bound = false;   // belongs to the device entry: keyed by the caller's stream, results stay valid in it
     hipStream_t bound_stream = nullptr;
     hipStream_t own_stream = nullptr;   // host entry: its own non-blocking stream
+    // the model kernels of the queue classes are independent of each other and, once the claims have thinned the queues, each too small
+    // to fill the chip: they run side by side on two more streams, forked from and joined into the call's stream with events
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count, w_keep, w_type_ids2, w_seq_ids2;   // truncation / padding / pair epilogue
@@ -175,6 +179,7 @@ struct Workspace {
     DevBuf w_enc_idx, w_enc_win;                                                   // ... of pairs: window indices / token windows of A and B
     DevBuf w_queues, w_qcount, w_cstate;   // work queues (start, length) of the model kernels + their fill counters; look-back state of the compaction
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
+    DevBuf w_chunk_lo;                           // first document of every compaction chunk (k_doc_first_pretok -> k_compact)
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
     DevBuf dw_ids, dw_tok_off, dw_first, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask, w_boundmask, w_bprefix, w_seg_off, w_xseg_off,
@@ -202,7 +207,14 @@ struct Workspace {
     int64_t last_n_enc = -1;                    // encodings of the last call when it materialised overflowing ones, else -1
     int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
-    ~Workspace() { if (own_stream) (void)hipStreamDestroy(own_stream); }
+    ~Workspace() {
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        for (int i = 0; i < 2; ++i) {
+            if (side[i]) (void)hipStreamDestroy(side[i]);
+            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+    }
 };
 
 struct tkamd_tokenizer {
@@ -526,6 +538,7 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
     w->w_rows.reserve(z.total * 16);
     w->w_queues.reserve(z.total * 8);
     w->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8);
+    w->w_chunk_lo.reserve((N / COMPACT_CHUNK + 4) * 4);
     w->w_qcount.reserve((size_t)QCNT_WORDS * 4);
     w->w_pt_tokoff.reserve((N + 4) * 4);
     w->w_ids.reserve((N + 4) * 4);
@@ -1194,7 +1207,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     pf.begin("doc_first_pretok");
     launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
-                            d_npretok, w->w_doc_pt.as<uint32_t>());
+                            d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>());
     pf.end();
 
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
@@ -1211,15 +1224,15 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
-    WordCache wc{nullptr, nullptr, nullptr, 0u, 0u};
+    WordCache wc{nullptr, nullptr, nullptr, 0u};
     // In-batch word claims (default; TKAMD_CLAIMS=0 switches them off for A/B runs): repeated words reach the model kernels once
     // per batch (kernels/lookup.hip).  The word cache (kernels.hpp WordCache, tkamd_word_cache: across batches) takes their place when
     // it is switched on.  With offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.
-    static const int claims_mode = [] { const char* e = getenv("TKAMD_CLAIMS"); return e ? atoi(e) : 3; }();      // 0 off; 1 / 2 / 3: WordCache::claim_mode
+    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
     auto open_word_cache = [&]() {
         const size_t slots = (size_t)1 << WORD_CACHE_BITS;
         if (!t->word_cache) {
-            if (claims_mode < 1 || claims_mode > 3) return;
+            if (!claims_on) return;
             // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
             // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch, zeroed per batch
             int bits = 18;
@@ -1228,7 +1241,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             w->w_claims.reserve(cslots * 8);
             w->w_claim_rows.reserve(cslots * 16);
             HIP_CHECK(hipMemsetAsync(w->w_claims.p, 0, cslots * 8, st));
-            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(cslots - 1), (uint32_t)claims_mode};
+            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(cslots - 1)};
             return;
         }
         if (off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends; the claims' rows would overwrite the cache's)
@@ -1239,7 +1252,33 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
             w->cache_epoch = epoch;
         }
-        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u, 0u};
+        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u};
+    };
+    // Fork / join of the side streams: the model kernels of the queue classes are independent of each other.  (Serial with
+    // TKAMD_SIDE_STREAMS=0 and while stage times are taken: the profile's events sit on the call's stream.)
+    static const bool side_on = [] { const char* e = getenv("TKAMD_SIDE_STREAMS"); return !(e && !strcmp(e, "0")); }();
+    const bool fork = side_on && !t->prof && !Prof::trace();
+    hipStream_t s_b = st, s_c = st;                      // streams of the <= 32-byte class and of the longer ones
+    auto fork_side = [&]() {
+        if (!fork) return;
+        if (!w->ev_fork) {
+            HIP_CHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; ++i) {
+                HIP_CHECK(hipStreamCreateWithFlags(&w->side[i], hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&w->ev_join[i], hipEventDisableTiming));
+            }
+        }
+        HIP_CHECK(hipEventRecord(w->ev_fork, st));
+        for (int i = 0; i < 2; ++i) HIP_CHECK(hipStreamWaitEvent(w->side[i], w->ev_fork, 0));
+        s_b = w->side[0];
+        s_c = w->side[1];
+    };
+    auto join_side = [&]() {
+        if (!fork) return;
+        for (int i = 0; i < 2; ++i) {
+            HIP_CHECK(hipEventRecord(w->ev_join[i], w->side[i]));
+            HIP_CHECK(hipStreamWaitEvent(st, w->ev_join[i], 0));
+        }
     };
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
@@ -1247,6 +1286,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
         pf.end();
+        if (wc.claims) {
+            pf.begin("claims_dedup");
+            launch_claims_dedup(st, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
+            pf.end();
+        }
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
         // TKAMD_MERGE16 = row / lane, TKAMD_LDSCFG = 0: the 16-lane DPP-row kernel / the register-resident lane kernels (A/B
@@ -1256,25 +1300,15 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         static const bool lane16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "lane"); }();
         const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // keys in LDS (default when new_id = rank + c)
         const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
+        fork_side();                                       // the <= 32-byte class on one side stream, the 64-byte / long classes on the other, the <= 16-byte class here
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
         launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
-        if (wc.keys) {
-            pf.begin("word_cache_insert");
-            launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
-            pf.end();
-        }
-        if (wc.claims) {
-            pf.begin("claims_publish");
-            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
-            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[1], w->w_rows.p, wc);
-            pf.end();
-        }
         pf.begin("bpe_merge64");
-        launch_bpe_merge(st, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(s_c, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge_long");
         // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
@@ -1287,18 +1321,29 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             w->w_huge.reserve(64);
             w->w_list_huge.reserve(64);
         }
-        launch_bpe_merge_long(st, t->n_cu, t->dt, x_text, plan.v[3], w->w_rows.p,
+        launch_bpe_merge_long(s_c, t->n_cu, t->dt, x_text, plan.v[3], w->w_rows.p,
                               w->w_tmp_ids.as<uint32_t>(), tmp_end, w->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, w->w_huge.as<uint32_t>(),
                               (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
+        join_side();
+        if (wc.keys) {
+            pf.begin("word_cache_insert");
+            launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            pf.end();
+        }
+        if (wc.claims) {
+            pf.begin("claims_publish");
+            launch_claims_publish(st, t->n_cu * 2, t->dt, x_text, plan, w->w_rows.p, wc);
+            pf.end();
+        }
     } else if (hm.model == MODEL_WORDLEVEL) {
         // WordLevel::tokenize (wordlevel/mod.rs:162-178) is the lookup itself: every hit is final, a miss is the unk id
         DevTables wt = t->dt;
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u, 0u}, 0u, 1u);
-        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u, 0u});      // words longer than 16 bytes
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u}, 0u, 1u);
+        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u});      // words longer than 16 bytes
         pf.end();
     } else {
         // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): the whole-word lookup
@@ -1315,9 +1360,16 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u);
         pf.end();
+        if (wc.claims) {
+            pf.begin("claims_dedup");
+            launch_claims_dedup(st, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
+            pf.end();
+        }
         pf.begin("wordpiece");
+        fork_side();
         for (int c = 0; c < 4; ++c)
-            launch_wordpiece(st, c == 0 ? grid : t->n_cu, c == 0, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+            launch_wordpiece(c == 0 ? st : (c == 1 ? s_b : s_c), c == 0 ? grid : t->n_cu, c == 0, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+        join_side();
         pf.end();
         if (wc.keys) {
             pf.begin("word_cache_insert");
@@ -1326,8 +1378,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         if (wc.claims) {
             pf.begin("claims_publish");
-            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
-            launch_claims_publish(st, t->n_cu, t->dt, x_text, plan.v[1], w->w_rows.p, wc);
+            launch_claims_publish(st, t->n_cu * 2, t->dt, x_text, plan, w->w_rows.p, wc);
             pf.end();
         }
     }
@@ -1336,12 +1387,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                                w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
     pf.begin("compact");
     HIP_CHECK(hipMemsetAsync(w->w_cstate.p, 0, (N / COMPACT_CHUNK + 4) * 8, st));
+    // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
     launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
-                   d_ntok_total, w->w_pt_tokoff.as<uint32_t>(), w->w_ids.as<uint32_t>());
-    pf.end();
-    pf.begin("doc_tok_offsets");
-    launch_doc_tok_offsets(st, w->w_doc_pt.as<uint32_t>(), n_docs, w->w_pt_tokoff.as<uint32_t>(), d_npretok, d_ntok_total,
-                           w->w_tok_offsets.as<int64_t>());
+                   d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
+                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>());
     pf.end();
     const uint32_t* word_of_doc = nullptr;
     const int64_t* first_tok = nullptr;

@@ -74,9 +74,7 @@ struct WordCache {
     // In-batch word claims (kernels/lookup.hip "claims"): one 64-bit word per slot, 0 = free, else (length << 32 | first byte) of the
     // pre-token that claimed the slot in THIS batch.  Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
     unsigned long long* claims;
-    uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host: claim_table_bits)
-    uint32_t claim_mode;         // how the lookup reads a slot (A/B switch TKAMD_CLAIMS): 1 device-scope loads only, 2 a cached load first,
-                                 // 3 (default) the cached load rides along with the whole-word table probe
+    uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host)
 };
 
 struct QueuePlan {
@@ -272,7 +270,7 @@ void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, con
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt);
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo);
 // whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
@@ -353,13 +351,14 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
 // single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
 // compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
-void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
+void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
+                         const QueuePlan& plan, const WordCache& wc);
+void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
-                    unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids);
+                    unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
+                    int64_t n_docs, int64_t* tok_offsets);
 int compact_grid(int n_cu);
 constexpr int COMPACT_CHUNK = 2048;
-void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
-                            const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets);
 
 }  // namespace tkamd

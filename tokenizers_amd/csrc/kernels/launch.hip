@@ -28,7 +28,7 @@ void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, co
 }
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total) {
-    unsigned nb = blocks_for(n_words, 256);
+    unsigned nb = blocks_for(n_words, 256 * WS_PER);
     hipLaunchKernelGGL(k_words_reduce, dim3(nb), dim3(256), 0, st, mask, n_words, bsum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
     hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
@@ -39,8 +39,8 @@ void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, con
     hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes + 1, 4 * 4096)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
 }
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt) {
-    hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt);
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo) {
+    hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt, chunk_lo);
 }
 int hot_table_slots() { return HOT_SLOTS; }
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
@@ -68,9 +68,6 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.matchmask = matchmask;
     a.hot = (const uint4*)hot;
     a.cache_keys = wc.keys;
-    a.claims = wc.claims;
-    a.claim_mask = wc.claim_mask;
-    a.claim_mode = wc.claim_mode;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
     if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
@@ -238,18 +235,30 @@ int compact_grid(int n_cu) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_compact, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
 }
-void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
-    hipLaunchKernelGGL(k_claims_publish, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc.claims, wc.claim_mask, (uint4*)wc.rows);
+void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
+                         const QueuePlan& plan, const WordCache& wc) {
+    ClaimArgs a{};
+    a.text = text;
+    a.startmask = startmask;
+    a.wprefix = wprefix;
+    a.tok0 = tok0;
+    a.v[0] = plan.v[0];
+    a.v[1] = plan.v[1];
+    a.claims = wc.claims;
+    a.claim_mask = wc.claim_mask;
+    a.seed = t.word_seed;
+    hipLaunchKernelGGL(k_claims_dedup, dim3(2 * NSQ), dim3(CD_NT), 0, st, a);
+}
+void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
+    hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claims, wc.claim_mask, (uint4*)wc.rows);
 }
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);
 }
 void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
-                    unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids) {
+                    unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
+                    int64_t n_docs, int64_t* tok_offsets) {
     static_assert(COMPACT_CHUNK == CP_CHUNK, "the host sizes the look-back state by COMPACT_CHUNK");
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids);
-}
-void launch_doc_tok_offsets(hipStream_t st, const uint32_t* doc_pt, int64_t n_docs, const uint32_t* pt_tokoff,
-                            const int64_t* n_pretok, const int64_t* n_tok, int64_t* tok_offsets) {
-    hipLaunchKernelGGL(k_doc_tok_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_pt, n_docs, pt_tokoff, n_pretok, n_tok, tok_offsets);
+    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
+                       chunk_lo, doc_pt, n_docs, tok_offsets);
 }

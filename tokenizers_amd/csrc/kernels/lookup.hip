@@ -62,23 +62,10 @@ struct LookupArgs {
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
     uint32_t unk_id, has_unk;
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
-    unsigned long long* claims;      // in-batch word claims (kernels.hpp WordCache::claims), or null
-    uint32_t claim_mask, claim_mode;
 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
-// claims of words of 17..32 bytes: the hash of the first 16 bytes (+ the whole length) continued over bytes 16..31, zero padded
-constexpr uint32_t CLAIM_MAX_LEN = 32u;
-__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
-    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
-}
-// A word has two slots in the claims table: the second is tried when another word holds the first (a frequent word that lost its
-// only slot to a rare one would send every occurrence to the model kernels).
-__device__ __forceinline__ uint32_t claim_slot_a(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
-__device__ __forceinline__ uint32_t claim_slot_b(uint32_t h, uint32_t mask) { return (mix32(h ^ 0x5BD1E995u) >> 5) & mask; }
-// the hash a queued pre-token of <= 32 bytes claims with (recomputed from the text by the kernels behind the lookup)
-__device__ __forceinline__ uint32_t claim_hash_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed);
 
 template <bool HAS_END>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
@@ -250,29 +237,6 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 }
             }
             __syncthreads();
-            // In-batch claims: the FIRST occurrence of a word the tables do not settle claims a slot of its hash and is queued for the model
-            // kernel; every later occurrence finds the claim, checks it against the claimant's bytes in the text (immutable: nothing here
-            // waits for another lane's writes) and points tok0 at the slot's row, which k_claims_publish fills from the claimant's result
-            // after the model kernels.  Both slots of the word taken by other words: queued like before.  The reference does the same per
-            // thread with its cache (bpe/model.rs:573-586); natural text's repeats leave the model kernels a few percent of the queued words.
-            // A slot only ever goes from 0 to its claim, so a cached (possibly stale) read that shows a claim is as good as a fresh one;
-            // only a read of 0 has to be confirmed at device scope, and only a confirmed 0 is worth the read-modify-write (a frequent word
-            // would otherwise serialise thousands of them on one address).
-            // claim_at: the claim found in `slot` (0: the slot was free and is now this pre-token's); `seen` = what a cached read showed.
-            auto claim_at = [&](uint32_t slot, unsigned long long seen, uint32_t start, uint32_t len) -> unsigned long long {
-                unsigned long long* const cp = a.claims + slot;
-                unsigned long long old = seen;
-                if (old == 0ull) old = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == 0ull) old = atomicCAS(cp, 0ull, ((unsigned long long)len << 32) | (unsigned long long)start);
-                return old;
-            };
-            // is the claim `c` this word (<= 16 bytes: k0..k3 masked; longer: k4..k7 as well)?
-            auto same_short = [&](unsigned long long c, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) -> bool {
-                if ((uint32_t)(c >> 32) != len) return false;
-                const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c);                // (readable: the text carries TEXT_PAD bytes of slack)
-                const uint4 km = s_kmask[len];
-                return (((o.a & km.x) ^ k0) | ((o.b & km.y) ^ k1) | ((o.c & km.z) ^ k2) | ((o.d & km.w) ^ k3)) == 0u;
-            };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
             const uint32_t n_miss = s_nmiss;
             for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
@@ -285,16 +249,6 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 if (v && hits_on && len <= (uint32_t)WORD_MAX_KEY) {
                     const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
                     const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
-                    // claim_mode 3: the (cached) read of the word's first slot and, if it shows a claim of this length, of the claimant's
-                    // bytes fly together with the displacement -> slot chain of the table probe: no round trip is added for a repeated word
-                    const uint32_t slot_a = claim_slot_a(h1, a.claim_mask);
-                    unsigned long long seen = 0ull;
-                    Unaligned16 so{0u, 0u, 0u, 0u};
-                    const bool spec = a.claims && a.claim_mode == 3u && len != 0u;
-                    if (spec) {
-                        seen = a.claims[slot_a];
-                        if ((uint32_t)(seen >> 32) == len) so = *(const Unaligned16*)(a.text + (uint32_t)seen);
-                    }
                     const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
                     uint4 a0 = q[0], a1 = q[1];
                     asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
@@ -309,48 +263,6 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                         const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
                         if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
                     }
-                    if (a.claims && pend && len != 0u) {                            // (a.claims is wavefront-uniform)
-                        bool dup = false;
-                        uint32_t slot = slot_a;
-                        if (spec && (uint32_t)(seen >> 32) == len) {
-                            const uint4 km = s_kmask[len];
-                            dup = (((so.a & km.x) ^ k0) | ((so.b & km.y) ^ k1) | ((so.c & km.z) ^ k2) | ((so.d & km.w) ^ k3)) == 0u;
-                        }
-                        if (!dup) {
-                            unsigned long long c = seen;                            // (a claim seen is final: another word's, or not yet compared)
-                            if (!spec && a.claim_mode == 2u) c = a.claims[slot_a];
-                            if (c == 0ull) c = claim_at(slot_a, 0ull, (uint32_t)t0 + s_rel, len);
-                            if (c != 0ull && !(spec && c == seen)) dup = same_short(c, len, k0, k1, k2, k3);
-                            if (c != 0ull && !dup) {                                // another word holds the first slot: the second
-                                slot = claim_slot_b(h1, a.claim_mask);
-                                c = claim_at(slot, a.claim_mode == 1u ? 0ull : a.claims[slot], (uint32_t)t0 + s_rel, len);
-                                dup = c != 0ull && same_short(c, len, k0, k1, k2, k3);
-                            }
-                        }
-                        if (dup) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
-                    }
-                }
-                if (a.claims && v && len > (uint32_t)WORD_MAX_KEY && len <= CLAIM_MAX_LEN) {      // claims of the 17..32-byte words (few lanes)
-                    const uint32_t wi = (s_rel >> 2) + 4u, sh = s_rel & 3u;
-                    const uint32_t d4 = s_text32[wi], d5 = s_text32[wi + 1], d6 = s_text32[wi + 2], d7 = s_text32[wi + 3], d8 = s_text32[wi + 4];
-                    const uint4 km = s_kmask[len - 16u];
-                    const uint32_t k4 = __builtin_amdgcn_alignbyte(d5, d4, sh) & km.x, k5 = __builtin_amdgcn_alignbyte(d6, d5, sh) & km.y;
-                    const uint32_t k6 = __builtin_amdgcn_alignbyte(d7, d6, sh) & km.z, k7 = __builtin_amdgcn_alignbyte(d8, d7, sh) & km.w;
-                    const uint32_t h = claim_hash_long(word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), k4, k5, k6, k7);
-                    auto same_long = [&](unsigned long long c) -> bool {
-                        if ((uint32_t)(c >> 32) != len) return false;
-                        const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c), o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
-                        return ((o.a ^ k0) | (o.b ^ k1) | (o.c ^ k2) | (o.d ^ k3) | ((o2.a & km.x) ^ k4) | ((o2.b & km.y) ^ k5) | ((o2.c & km.z) ^ k6) | ((o2.d & km.w) ^ k7)) == 0u;
-                    };
-                    uint32_t slot = claim_slot_a(h, a.claim_mask);
-                    unsigned long long c = claim_at(slot, a.claim_mode == 1u ? 0ull : a.claims[slot], (uint32_t)t0 + s_rel, len);
-                    bool dup = c != 0ull && same_long(c);
-                    if (c != 0ull && !dup) {
-                        slot = claim_slot_b(h, a.claim_mask);
-                        c = claim_at(slot, a.claim_mode == 1u ? 0ull : a.claims[slot], (uint32_t)t0 + s_rel, len);
-                        dup = c != 0ull && same_long(c);
-                    }
-                    if (dup) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
                 }
                 if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
                     if (pend && len <= (uint32_t)WORD_MAX_KEY) {
@@ -397,35 +309,146 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 }
 
 // =================================================================================================
-// K_claims_publish: after the model kernels, the result row of every queued pre-token that holds the claim of its slot is copied to
-// the slot's row, where the compaction finds it for the word's other occurrences (tok0 = TOK_ROW | CACHE_ROW_BIT | slot).  A row of
-// more than four tokens names its ids by the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.
+// In-batch word claims.  Natural text repeats its words: of the pre-tokens the static tables do not settle (13 % on C2) a few
+// percent are distinct.  The reference's per-thread cache exploits that (BPE::tokenize_with_cache, bpe/model.rs:573-586); here, between
+// the lookup and the model kernels, K_claims_dedup lets the FIRST occurrence of a word claim a slot of a hash table (two slots to choose
+// from; 64-bit entries, 0 = free, else length << 32 | first byte of the claimant) and stay queued; every other occurrence finds the
+// claim, checks it against the claimant's BYTES in the text (immutable: nothing here waits for another lane's writes, and no result
+// depends on which occurrence wins), leaves the queue and points its tok0 at the slot's row.  K_claims_publish copies the claimants'
+// finished rows there after the model kernels; the compaction reads them like cached rows (TOK_ROW | CACHE_ROW_BIT | slot), and
+// k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.  A word that finds both of its slots taken by
+// other words is simply merged every time.  The table is zeroed per batch: no state crosses batches.
+// A slot only ever goes from 0 to its claim, so a read that shows a claim is final; a read of 0 is confirmed with a device-scope load
+// before the read-modify-write (a frequent word would otherwise serialise thousands of them on one address).
+// One 1024-lane workgroup per sub-queue (the lookup workgroup that filled it saw a contiguous share of the text, so the reads of the
+// keys and of the masks are nearly sequential) and queue class; it compacts its sub-queue IN PLACE -- survivors move to the front, their
+// tok0 is pointed at the new row -- so the model kernels see dense queues of distinct words.
 // =================================================================================================
-__device__ __forceinline__ uint32_t claim_hash_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed) {
-    uint64_t lo, hi;
-    load_key16(text, s, min(len, 16u), &lo, &hi);
-    const uint32_t h16 = word_hash1(lo, hi, len, seed);
-    if (len <= 16u) return h16;
-    uint64_t lo2, hi2;
-    load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
-    return claim_hash_long(h16, (uint32_t)lo2, (uint32_t)(lo2 >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32));
+constexpr uint32_t CLAIM_MAX_LEN = 32u;
+constexpr int CD_NT = 1024;
+__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
+    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
 }
-// one queued pre-token with its finished row: if it holds the claim of one of its two slots the row becomes that slot's
+__device__ __forceinline__ uint32_t claim_slot_a(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
+__device__ __forceinline__ uint32_t claim_slot_b(uint32_t h, uint32_t mask) { return (mix32(h ^ 0x5BD1E995u) >> 5) & mask; }
+// key of a pre-token of <= 32 bytes, zero padded, and its hash: the whole-word table's hash of the first 16 bytes and the whole
+// length, continued over bytes 16..31
+struct ClaimKey { uint64_t k[4]; uint32_t h; };
+__device__ __forceinline__ ClaimKey claim_key_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed) {
+    ClaimKey c;
+    load_key16(text, s, min(len, 16u), &c.k[0], &c.k[1]);
+    c.k[2] = c.k[3] = 0ull;
+    c.h = word_hash1(c.k[0], c.k[1], len, seed);
+    if (len > 16u) {
+        load_key16(text, s + 16u, len - 16u, &c.k[2], &c.k[3]);
+        c.h = claim_hash_long(c.h, (uint32_t)c.k[2], (uint32_t)(c.k[2] >> 32), (uint32_t)c.k[3], (uint32_t)(c.k[3] >> 32));
+    }
+    return c;
+}
+
+struct ClaimArgs {
+    const uint8_t* text;
+    const unsigned long long* startmask;
+    const uint32_t* wprefix;
+    uint32_t* tok0;
+    QView v[2];                      // the <= 16-byte and the <= 32-byte queue
+    unsigned long long* claims;
+    uint32_t claim_mask, seed;
+};
+
+__global__ __launch_bounds__(CD_NT) void k_claims_dedup(ClaimArgs a) {
+    __shared__ uint32_t s_wave[CD_NT / 64];
+    __shared__ uint32_t s_w;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t sq = blockIdx.x % (uint32_t)NSQ;
+    const bool cls = blockIdx.x >= (uint32_t)NSQ;        // grid = 2 NSQ: the <= 16-byte queue's sub-queues, then the <= 32-byte queue's
+    // (selects, not indexed loads: the argument arrays stay in scalar registers)
+    QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
+    uint32_t* const cnt_p = (cls ? a.v[1].counts : a.v[0].counts) + sq * QCNT_STRIDE;
+    const uint32_t cap = cls ? a.v[1].sq_cap : a.v[0].sq_cap;
+    const uint32_t row0 = (cls ? a.v[1].row_base : a.v[0].row_base) + sq * cap;
+    const uint32_t n = min(*cnt_p, cap);
+    if (tid == 0) s_w = 0u;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += CD_NT) {
+        const uint32_t i = base + tid;
+        const bool valid = i < n;
+        QItem it{0u, 0u};
+        if (valid) it = q[i];
+        bool keep = valid;
+        uint32_t dup_tok = 0u, p = 0u;
+        if (valid) {
+            // rank of the pre-token among the batch's: its tok0 word (survivors get a new row, the others the slot)
+            const unsigned long long m = a.startmask[it.s >> 6];
+            p = a.wprefix[it.s >> 6] + (uint32_t)__popcll(m & ((1ull << (it.s & 63u)) - 1ull));
+        }
+        if (valid && it.len != 0u && it.len <= CLAIM_MAX_LEN) {
+            const ClaimKey key = claim_key_of(a.text, it.s, it.len, a.seed);
+            const unsigned long long mine = ((unsigned long long)it.len << 32) | (unsigned long long)it.s;
+            uint32_t slot = claim_slot_a(key.h, a.claim_mask);
+#pragma unroll 1
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                unsigned long long* const cp = a.claims + slot;
+                unsigned long long c = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 0ull) c = atomicCAS(cp, 0ull, mine);
+                if (c == 0ull || c == mine) break;                                   // the slot is this pre-token's: it stays queued
+                if ((uint32_t)(c >> 32) == it.len) {                                 // the same word?
+                    uint64_t o[4] = {0ull, 0ull, 0ull, 0ull};
+                    load_key16(a.text, (uint32_t)c, min(it.len, 16u), &o[0], &o[1]);
+                    if (it.len > 16u) load_key16(a.text, (uint32_t)c + 16u, it.len - 16u, &o[2], &o[3]);
+                    if (((o[0] ^ key.k[0]) | (o[1] ^ key.k[1]) | (o[2] ^ key.k[2]) | (o[3] ^ key.k[3])) == 0ull) {
+                        keep = false;
+                        dup_tok = TOK_ROW | CACHE_ROW_BIT | slot;
+                        break;
+                    }
+                }
+                slot = claim_slot_b(key.h, a.claim_mask);                            // another word holds the slot: the second one
+            }
+        }
+        __syncthreads();                                     // every entry of this round has been read: survivors may overwrite them
+        const uint64_t kb = __ballot(keep);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(kb);
+        __syncthreads();
+        uint32_t before = 0u, total = 0u;
+#pragma unroll
+        for (int w = 0; w < CD_NT / 64; ++w) { const uint32_t c = s_wave[w]; before += (uint32_t)w < wave ? c : 0u; total += c; }
+        const uint32_t w0 = s_w;
+        if (keep) {
+            const uint32_t pos = w0 + before + (uint32_t)mbcnt64(kb);      // <= i: never an entry of a later round
+            q[pos] = it;
+            a.tok0[p] = TOK_ROW | (row0 + pos);
+        } else if (valid) {
+            a.tok0[p] = dup_tok;
+        }
+        __syncthreads();
+        if (tid == 0) s_w = w0 + total;
+    }
+    __syncthreads();
+    if (tid == 0) *cnt_p = s_w;
+}
+
+// =================================================================================================
+// K_claims_publish: after the model kernels, the result row of every queued pre-token that holds the claim of one of its slots is
+// copied to the slot's row, where the compaction finds it for the word's other occurrences.  A row of more than four tokens names its
+// ids by the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.  The two halves of the grid take the two queue classes.
+// =================================================================================================
 __device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len, const uint4& row,
                                                    const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
     if (len == 0u || len > CLAIM_MAX_LEN) return;
-    const uint32_t h = claim_hash_of(text, s, len, seed);
+    const uint32_t h = claim_key_of(text, s, len, seed).h;
     const unsigned long long mine = ((unsigned long long)len << 32) | (unsigned long long)s;
     const uint32_t sa = claim_slot_a(h, claim_mask);
     if (claims[sa] == mine) { crows[sa] = row; return; }
     const uint32_t sb = claim_slot_b(h, claim_mask);
     if (claims[sb] == mine) crows[sb] = row;
 }
-__global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v, const uint4* __restrict__ rows,
+__global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
                                                         const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
     __shared__ uint32_t s_qpre[NSQ + 1];
+    const uint32_t half = gridDim.x >> 1;
+    const QView v = blockIdx.x >= half ? v1 : v0;
     const uint32_t n = qview_prefix(v, s_qpre);
-    for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
+    for (uint32_t item = (blockIdx.x % half) * 256 + threadIdx.x; item < n; item += half * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
         claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claims, claim_mask, crows);

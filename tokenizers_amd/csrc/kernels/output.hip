@@ -68,11 +68,18 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
         (O) += c;                                                                                             \
     }
 
+// The token CSR of the documents (Encoding per document, tokenizer/mod.rs:1345-1348) leaves this kernel too: the documents whose first
+// pre-token lies in a chunk (chunk_lo / doc_pt of k_doc_first_pretok; an empty document starts at its successor's) get
+// tok_offsets[d] = the token offset of that pre-token -- so the ids-only path never writes the P-sized pt_tokoff (null then).
 __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
-                                                   int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids) {
+                                                   int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
+                                                   const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
+                                                   int64_t* __restrict__ tok_offsets) {
     __shared__ uint32_t sm[4];
+    __shared__ uint32_t s_dlo[2], s_dhi[2];              // documents [dlo, dhi) start in the chunk
+    __shared__ uint32_t s_docpt[2][CP_NT];               // doc_pt of the first CP_NT of them, loaded with the chunk
     __shared__ uint32_t s_stage[2][CP_STAGE];
     __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
     __shared__ uint32_t s_tot[2];
@@ -80,11 +87,20 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     const int tid = (int)threadIdx.x;
+    if (n_chunks == 0) {                                  // no pre-token at all: every document is empty
+        if (blockIdx.x == 0)
+            for (int64_t d = tid; d <= n_docs; d += CP_NT) tok_offsets[d] = 0;
+        return;
+    }
     // front half of a chunk into LDS buffer b
     auto front = [&](int64_t ch, int b) {
         const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
+        // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
+        const uint32_t dlo = chunk_lo[ch], dhi = ch == n_chunks - 1 ? (uint32_t)n_docs + 1u : chunk_lo[ch + 1];
         CpRows r;
         const uint32_t v = cp_load(tok0, rows, crows, p0, P, r);
+        if (dlo + (uint32_t)tid < dhi) s_docpt[b][tid] = doc_pt[dlo + (uint32_t)tid];
+        if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
         if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
@@ -111,12 +127,19 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         __syncthreads();
         const unsigned long long base = s_base;
         if (ch == n_chunks - 1 && tid == 0) *n_tok = (int64_t)(base + tot);
+        const int64_t pc = ch * CP_CHUNK;
         if (pt_tokoff) {
-            const int64_t pc = ch * CP_CHUNK;
 #pragma unroll
             for (int i = 0; i < CP_ITEMS; ++i) {
                 const int q = i * CP_NT + tid;
                 if (pc + q < P) pt_tokoff[pc + q] = (uint32_t)base + s_loc[b][q];
+            }
+        }
+        {
+            const uint32_t dlo = s_dlo[b], dhi = s_dhi[b];
+            for (uint32_t d = dlo + (uint32_t)tid; d < dhi; d += CP_NT) {
+                const uint32_t local = (d - dlo < (uint32_t)CP_NT ? s_docpt[b][d - dlo] : doc_pt[d]) - (uint32_t)pc;
+                tok_offsets[d] = (int64_t)(base + (local < (uint32_t)CP_CHUNK ? s_loc[b][local] : tot));
             }
         }
         if (tot <= (uint32_t)CP_STAGE) {
@@ -133,15 +156,6 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
     }
 }
 #undef TKAMD_CP_SCATTER
-
-__global__ void k_doc_tok_offsets(const uint32_t* __restrict__ doc_pt, int64_t n_docs, const uint32_t* __restrict__ pt_tokoff,
-                                  const int64_t* __restrict__ n_pretok, const int64_t* __restrict__ n_tok,
-                                  int64_t* __restrict__ tok_offsets) {
-    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d > n_docs) return;
-    uint32_t p = doc_pt[d];
-    tok_offsets[d] = ((int64_t)p < *n_pretok) ? (int64_t)pt_tokoff[p] : *n_tok;
-}
 
 // is_pretokenized inputs (InputSequence::PreTokenized, tokenizer/mod.rs:782-795): every word of a sequence went through the pipeline
 // as a document of its own -- the reference encodes each word separately and merges the encodings -- and sequence s owns the tokens

@@ -6,25 +6,54 @@
 // Replaces: the Vec<Split> a PreTokenizedString accumulates (tokenizer/pre_tokenizer.rs:73-103);
 // here the "splits" of the whole batch are one u32 array pt_start[P+1] (pt_start[P] = n_bytes).
 // =================================================================================================
+// (eight words per lane: the single-workgroup scan over the workgroup totals then has a few hundred entries for a 120 MB batch and
+// is one round instead of eight)
+constexpr int WS_PER = 8;
 __global__ __launch_bounds__(256) void k_words_reduce(const unsigned long long* __restrict__ mask, int64_t n_words,
                                                       uint32_t* __restrict__ bsum) {
     __shared__ uint32_t sm[4];
-    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t v = (w < n_words) ? (uint32_t)__popcll(mask[w]) : 0u;
+    const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * WS_PER;
+    uint32_t v = 0;
+    if (w0 + WS_PER <= n_words) {
+        const ulonglong2* const q = (const ulonglong2*)(mask + w0);                 // (w0 is a multiple of 8: 64-byte aligned)
+#pragma unroll
+        for (int k = 0; k < WS_PER / 2; ++k) { const ulonglong2 m = q[k]; v += (uint32_t)(__popcll(m.x) + __popcll(m.y)); }
+    } else {
+        for (int k = 0; k < WS_PER; ++k) v += (w0 + k < n_words) ? (uint32_t)__popcll(mask[w0 + k]) : 0u;
+    }
     uint32_t tot;
     block256_excl_scan(v, sm, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-
 __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __restrict__ mask, int64_t n_words,
                                                     const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix) {
     __shared__ uint32_t sm[4];
-    int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t v = (w < n_words) ? (uint32_t)__popcll(mask[w]) : 0u;
+    const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * WS_PER;
+    uint32_t c[WS_PER], v = 0;
+    const bool whole = w0 + WS_PER <= n_words;
+    if (whole) {
+        const ulonglong2* const q = (const ulonglong2*)(mask + w0);
+#pragma unroll
+        for (int k = 0; k < WS_PER / 2; ++k) { const ulonglong2 m = q[k]; c[2 * k] = (uint32_t)__popcll(m.x); c[2 * k + 1] = (uint32_t)__popcll(m.y); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < WS_PER; ++k) c[k] = (w0 + k < n_words) ? (uint32_t)__popcll(mask[w0 + k]) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < WS_PER; ++k) v += c[k];
     uint32_t tot;
-    uint32_t ex = block256_excl_scan(v, sm, &tot);
-    if (w < n_words) wprefix[w] = bsum[blockIdx.x] + ex;
+    uint32_t run = bsum[blockIdx.x] + block256_excl_scan(v, sm, &tot);
+    if (whole) {
+        uint4 o0, o1;
+        o0.x = run; run += c[0]; o0.y = run; run += c[1]; o0.z = run; run += c[2]; o0.w = run; run += c[3];
+        o1.x = run; run += c[4]; o1.y = run; run += c[5]; o1.z = run; run += c[6]; o1.w = run;
+        ((uint4*)(wprefix + w0))[0] = o0;
+        ((uint4*)(wprefix + w0))[1] = o1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < WS_PER; ++k) { if (w0 + k < n_words) wprefix[w0 + k] = run; run += c[k]; }
+    }
 }
 
 // A wavefront takes 64 consecutive mask words (4 KB of text): one coalesced load of the words and their
@@ -86,20 +115,27 @@ __global__ __launch_bounds__(256) void k_emit_pretok_end(const unsigned long lon
 }
 
 // doc_pt[d] = index of the first pre-token at or after the first byte of document d (d = 0..n_docs)
+// chunk_lo[c] = the first document d with doc_pt[d] >= c * COMPACT_CHUNK (c = 0 .. P / COMPACT_CHUNK + 1; n_docs + 1: none): the
+// compaction (output.hip) finds the documents that start in a chunk of pre-tokens there and writes their token offsets itself.
+// Document d fills the entries of the chunks between its predecessor's first pre-token and its own.
+__device__ __forceinline__ uint32_t doc_first_rank(int64_t g, int64_t n_bytes, const unsigned long long* __restrict__ startmask,
+                                                   const uint32_t* __restrict__ wprefix, const int64_t* __restrict__ n_pretok) {
+    if (g >= n_bytes) return (uint32_t)*n_pretok;
+    const unsigned long long m = startmask[g >> 6];
+    const int b = (int)(g & 63);
+    return wprefix[g >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
+}
 __global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
                                    const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
-                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt) {
+                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt, uint32_t* __restrict__ chunk_lo) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > n_docs) return;
-    int64_t g = doc_off[d];
-    uint32_t r;
-    if (g >= n_bytes) r = (uint32_t)*n_pretok;
-    else {
-        unsigned long long m = startmask[g >> 6];
-        int b = (int)(g & 63);
-        r = wprefix[g >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
-    }
+    const uint32_t r = doc_first_rank(doc_off[d], n_bytes, startmask, wprefix, n_pretok);
     doc_pt[d] = r;
+    const uint32_t c_hi = r / (uint32_t)COMPACT_CHUNK;
+    uint32_t c = d ? doc_first_rank(doc_off[d - 1], n_bytes, startmask, wprefix, n_pretok) / (uint32_t)COMPACT_CHUNK + 1u : 0u;
+    for (; c <= c_hi; ++c) chunk_lo[c] = (uint32_t)d;
+    if (d == n_docs) chunk_lo[c_hi + 1u] = (uint32_t)n_docs + 1u;
 }
 
 // data[i] += delta (rebasing a CSR slice)
