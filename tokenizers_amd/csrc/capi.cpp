@@ -235,6 +235,7 @@ struct tkamd_tokenizer {
     int n_direct = 0;
     int n_hot = 0;
     int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
+    int cp_items = 8;            // pre-tokens per lane of k_compact: 8 or 4 (TKAMD_CP_ITEMS)
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling
     std::atomic<bool> prof{false};
@@ -537,8 +538,8 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
     const QueueSizes z = queue_sizes(N, t->q16_div, lookup_grid(t));
     w->w_rows.reserve(z.total * 16);
     w->w_queues.reserve(z.total * 8);
-    w->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8);
-    w->w_chunk_lo.reserve((N / COMPACT_CHUNK + 4) * 4);
+    w->w_cstate.reserve((N / COMPACT_CHUNK_MIN + 4) * 8);
+    w->w_chunk_lo.reserve((N / COMPACT_CHUNK_MIN + 4) * 4);
     w->w_qcount.reserve((size_t)QCNT_WORDS * 4);
     w->w_pt_tokoff.reserve((N + 4) * 4);
     w->w_ids.reserve((N + 4) * 4);
@@ -1207,7 +1208,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     pf.begin("doc_first_pretok");
     launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
-                            d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>());
+                            d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(), t->cp_items);
     pf.end();
 
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
@@ -1254,9 +1255,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u};
     };
-    // Fork / join of the side streams: the model kernels of the queue classes are independent of each other.  (Serial with
-    // TKAMD_SIDE_STREAMS=0 and while stage times are taken: the profile's events sit on the call's stream.)
-    static const bool side_on = [] { const char* e = getenv("TKAMD_SIDE_STREAMS"); return !(e && !strcmp(e, "0")); }();
+    // Fork / join of the side streams: the model kernels of the queue classes are independent of each other.  OFF by default: measured on
+    // C2 the two event hand-overs cost more (0.78 ms a step) than running the thinned-out queues one after the other (0.72);
+    // TKAMD_SIDE_STREAMS=1 switches it on (never while stage times are taken: the profile's events sit on the call's stream).
+    static const bool side_on = [] { const char* e = getenv("TKAMD_SIDE_STREAMS"); return e && !strcmp(e, "1"); }();
     const bool fork = side_on && !t->prof && !Prof::trace();
     hipStream_t s_b = st, s_c = st;                      // streams of the <= 32-byte class and of the longer ones
     auto fork_side = [&]() {
@@ -1386,9 +1388,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_apply_match_ids(st, w->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, w->w_startmask.as<ull>(),
                                w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
     pf.begin("compact");
-    HIP_CHECK(hipMemsetAsync(w->w_cstate.p, 0, (N / COMPACT_CHUNK + 4) * 8, st));
+    HIP_CHECK(hipMemsetAsync(w->w_cstate.p, 0, (N / ((size_t)256 * (size_t)t->cp_items) + 4) * 8, st));
     // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
-    launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
+    launch_compact(st, t->cp_grid, t->cp_items, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
                    w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>());
     pf.end();
@@ -1618,7 +1620,8 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (!primary) verify_direct_words(t.get());
         build_hot_table(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
-        t->cp_grid = compact_grid(t->n_cu);
+        if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 4 ? 4 : 8;
+        t->cp_grid = compact_grid(t->n_cu, t->cp_items);
         t->devices.push_back(device);
     }
     return t;

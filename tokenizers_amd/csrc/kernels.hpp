@@ -270,7 +270,7 @@ void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, con
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo);
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items);
 // whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
@@ -355,10 +355,10 @@ void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text
                          const QueuePlan& plan, const WordCache& wc);
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
-void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
                     int64_t n_docs, int64_t* tok_offsets);
-int compact_grid(int n_cu);
-constexpr int COMPACT_CHUNK = 2048;
+int compact_grid(int n_cu, int cp_items);
+constexpr int COMPACT_CHUNK_MIN = 1024;             // pre-tokens per compaction chunk: 256 lanes x cp_items (4 or 8)
 
 }  // namespace tkamd

@@ -39,8 +39,9 @@ void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, con
     hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes + 1, 4 * 4096)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
 }
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo) {
-    hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt, chunk_lo);
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items) {
+    hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt, chunk_lo,
+                       (uint32_t)(CP_NT * cp_items));
 }
 int hot_table_slots() { return HOT_SLOTS; }
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
@@ -230,9 +231,10 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
     hipLaunchKernelGGL(k_bpe_merge_huge, dim3(64), dim3(256), 0, st, t, text, (const QItem*)v.q, (uint4*)rows, v.row_base, (const uint32_t*)list_huge,
                        (const uint32_t*)n_huge, tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
 }
-int compact_grid(int n_cu) {
+int compact_grid(int n_cu, int cp_items) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_compact, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    const void* k = cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
 }
 void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
@@ -255,10 +257,14 @@ void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const u
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);
 }
-void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
                     int64_t n_docs, int64_t* tok_offsets) {
-    static_assert(COMPACT_CHUNK == CP_CHUNK, "the host sizes the look-back state by COMPACT_CHUNK");
-    hipLaunchKernelGGL(k_compact, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                       chunk_lo, doc_pt, n_docs, tok_offsets);
+    static_assert(COMPACT_CHUNK_MIN == CpShape<4>::CHUNK, "the host sizes the look-back state and chunk_lo by the smaller chunk");
+    if (cp_items == 4)
+        hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
+                           chunk_lo, doc_pt, n_docs, tok_offsets);
+    else
+        hipLaunchKernelGGL(k_compact<8>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
+                           chunk_lo, doc_pt, n_docs, tok_offsets);
 }

@@ -16,20 +16,30 @@
 // Chunks go round robin over a grid of RESIDENT workgroups (launcher), so the owner of any earlier chunk is running or
 // done: front() never waits, back(c) only needs totals that earlier front() calls publish -- no deadlock.
 // =================================================================================================
+// Two shapes: 8 pre-tokens per lane (chunks of 2048, 56 KB of LDS: two workgroups per CU) and 4 (chunks of 1024, 28 KB and half the
+// registers: five workgroups per CU -- more chunks in flight to hide the load -> rows -> look-back chain of each); the host picks one
+// (TKAMD_CP_ITEMS) and k_doc_first_pretok is told the chunk size.
 constexpr int CP_NT = 256;
-constexpr int CP_ITEMS = 8;                       // pre-tokens per thread
-constexpr int CP_CHUNK = CP_NT * CP_ITEMS;        // 2048 (the host sizes the state array by COMPACT_CHUNK)
-constexpr int CP_STAGE = 5120;                    // tokens of a chunk assembled in LDS (20 KB per buffer)
+template <int CP_ITEMS> struct CpShape {
+    static constexpr int CHUNK = CP_NT * CP_ITEMS;     // pre-tokens per chunk (the host sizes the state array by COMPACT_CHUNK_MIN)
+    static constexpr int STAGE = CP_ITEMS * 640;       // tokens of a chunk assembled in LDS (2.5 per pre-token; more: scattered from the rows)
+};
 
-struct CpRows {
+template <int CP_ITEMS> struct CpRows {
     uint4 row[CP_ITEMS];
     uint32_t cnt[CP_ITEMS];
 };
-__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows& r) {
+template <int CP_ITEMS>
+__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
+    static_assert(CP_ITEMS == 4 || CP_ITEMS == 8, "one or two 16-byte loads of tok0 per lane");
     uint32_t first[CP_ITEMS];
     if (p0 + CP_ITEMS <= P) {
-        const uint4 a = *(const uint4*)(tok0 + p0), b = *(const uint4*)(tok0 + p0 + 4);
-        first[0] = a.x; first[1] = a.y; first[2] = a.z; first[3] = a.w; first[4] = b.x; first[5] = b.y; first[6] = b.z; first[7] = b.w;
+        const uint4 a = *(const uint4*)(tok0 + p0);
+        first[0] = a.x; first[1] = a.y; first[2] = a.z; first[3] = a.w;
+        if (CP_ITEMS == 8) {
+            const uint4 b = *(const uint4*)(tok0 + p0 + 4);
+            first[CP_ITEMS - 4] = b.x; first[CP_ITEMS - 3] = b.y; first[CP_ITEMS - 2] = b.z; first[CP_ITEMS - 1] = b.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
@@ -71,12 +81,14 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 // The token CSR of the documents (Encoding per document, tokenizer/mod.rs:1345-1348) leaves this kernel too: the documents whose first
 // pre-token lies in a chunk (chunk_lo / doc_pt of k_doc_first_pretok; an empty document starts at its successor's) get
 // tok_offsets[d] = the token offset of that pre-token -- so the ids-only path never writes the P-sized pt_tokoff (null then).
+template <int CP_ITEMS>
 __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
                                                    int64_t* __restrict__ tok_offsets) {
+    constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
     __shared__ uint32_t sm[4];
     __shared__ uint32_t s_dlo[2], s_dhi[2];              // documents [dlo, dhi) start in the chunk
     __shared__ uint32_t s_docpt[2][CP_NT];               // doc_pt of the first CP_NT of them, loaded with the chunk
@@ -97,8 +109,8 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
         const uint32_t dlo = chunk_lo[ch], dhi = ch == n_chunks - 1 ? (uint32_t)n_docs + 1u : chunk_lo[ch + 1];
-        CpRows r;
-        const uint32_t v = cp_load(tok0, rows, crows, p0, P, r);
+        CpRows<CP_ITEMS> r;
+        const uint32_t v = cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
         if (dlo + (uint32_t)tid < dhi) s_docpt[b][tid] = doc_pt[dlo + (uint32_t)tid];
         if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         uint32_t tot;
@@ -146,8 +158,8 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
             for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) ids[base + i] = s_stage[b][i];
         } else {                                           // rare: too many tokens for the buffer -- scatter from the rows
             const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
-            CpRows r;
-            cp_load(tok0, rows, crows, p0, P, r);
+            CpRows<CP_ITEMS> r;
+            cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
             uint32_t o = s_loc[b][tid * CP_ITEMS];
             uint32_t* const dst = ids + base;
             TKAMD_CP_SCATTER(dst, r, o)

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void k_emit_pretok_end(const unsigned long lon
 }
 
 // doc_pt[d] = index of the first pre-token at or after the first byte of document d (d = 0..n_docs)
-// chunk_lo[c] = the first document d with doc_pt[d] >= c * COMPACT_CHUNK (c = 0 .. P / COMPACT_CHUNK + 1; n_docs + 1: none): the
+// chunk_lo[c] = the first document d with doc_pt[d] >= c * chunk (c = 0 .. P / chunk + 1; n_docs + 1: none; chunk = the compaction's): the
 // compaction (output.hip) finds the documents that start in a chunk of pre-tokens there and writes their token offsets itself.
 // Document d fills the entries of the chunks between its predecessor's first pre-token and its own.
 __device__ __forceinline__ uint32_t doc_first_rank(int64_t g, int64_t n_bytes, const unsigned long long* __restrict__ startmask,
@@ -127,13 +127,13 @@ __device__ __forceinline__ uint32_t doc_first_rank(int64_t g, int64_t n_bytes, c
 }
 __global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
                                    const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
-                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt, uint32_t* __restrict__ chunk_lo) {
+                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt, uint32_t* __restrict__ chunk_lo, uint32_t chunk) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > n_docs) return;
     const uint32_t r = doc_first_rank(doc_off[d], n_bytes, startmask, wprefix, n_pretok);
     doc_pt[d] = r;
-    const uint32_t c_hi = r / (uint32_t)COMPACT_CHUNK;
-    uint32_t c = d ? doc_first_rank(doc_off[d - 1], n_bytes, startmask, wprefix, n_pretok) / (uint32_t)COMPACT_CHUNK + 1u : 0u;
+    const uint32_t c_hi = r / chunk;
+    uint32_t c = d ? doc_first_rank(doc_off[d - 1], n_bytes, startmask, wprefix, n_pretok) / chunk + 1u : 0u;
     for (; c <= c_hi; ++c) chunk_lo[c] = (uint32_t)d;
     if (d == n_docs) chunk_lo[c_hi + 1u] = (uint32_t)n_docs + 1u;
 }
