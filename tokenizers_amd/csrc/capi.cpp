@@ -235,7 +235,7 @@ struct tkamd_tokenizer {
     int n_direct = 0;
     int n_hot = 0;
     int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
-    int cp_items = 8;            // pre-tokens per lane of k_compact: 8 or 4 (TKAMD_CP_ITEMS)
+    int cp_items = 4;            // pre-tokens per lane of k_compact: 4 (default: 0.145 ms on C2 against 0.187) or 8 (TKAMD_CP_ITEMS)
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling
     std::atomic<bool> prof{false};
@@ -1620,7 +1620,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (!primary) verify_direct_words(t.get());
         build_hot_table(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
-        if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 4 ? 4 : 8;
+        if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
         t->cp_grid = compact_grid(t->n_cu, t->cp_items);
         t->devices.push_back(device);
     }

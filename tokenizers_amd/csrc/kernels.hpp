@@ -359,6 +359,6 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
                     int64_t n_docs, int64_t* tok_offsets);
 int compact_grid(int n_cu, int cp_items);
-constexpr int COMPACT_CHUNK_MIN = 1024;             // pre-tokens per compaction chunk: 256 lanes x cp_items (4 or 8)
+constexpr int COMPACT_CHUNK_MIN = 512;              // pre-tokens per compaction chunk: 256 lanes x cp_items (2, 4 or 8)
 
 }  // namespace tkamd

@@ -233,7 +233,7 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
 }
 int compact_grid(int n_cu, int cp_items) {
     int per_cu = 0;
-    const void* k = cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
+    const void* k = cp_items == 2 ? (const void*)k_compact<2> : cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
 }
@@ -249,6 +249,11 @@ void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text
     a.claims = wc.claims;
     a.claim_mask = wc.claim_mask;
     a.seed = t.word_seed;
+    static const int n_seed = [] { const char* e = getenv("TKAMD_CLAIM_SEEDS"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > NSQ ? NSQ : v); }();
+    static_assert((NSQ & (NSQ - 1)) == 0, "the seed workgroups take every (NSQ / n)-th sub-queue");
+    int ns = 1;
+    while (ns * 2 <= n_seed) ns *= 2;                    // a power of two: divides NSQ
+    if (n_seed > 0) hipLaunchKernelGGL(k_claims_seed, dim3(2 * ns), dim3(CD_NT), 0, st, a);
     hipLaunchKernelGGL(k_claims_dedup, dim3(2 * NSQ), dim3(CD_NT), 0, st, a);
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
@@ -260,8 +265,11 @@ void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, cons
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
                     int64_t n_docs, int64_t* tok_offsets) {
-    static_assert(COMPACT_CHUNK_MIN == CpShape<4>::CHUNK, "the host sizes the look-back state and chunk_lo by the smaller chunk");
-    if (cp_items == 4)
+    static_assert(COMPACT_CHUNK_MIN == CpShape<2>::CHUNK, "the host sizes the look-back state and chunk_lo by the smallest chunk");
+    if (cp_items == 2)
+        hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
+                           chunk_lo, doc_pt, n_docs, tok_offsets);
+    else if (cp_items == 4)
         hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
                            chunk_lo, doc_pt, n_docs, tok_offsets);
     else

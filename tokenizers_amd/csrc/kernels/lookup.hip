@@ -356,6 +356,27 @@ struct ClaimArgs {
     uint32_t claim_mask, seed;
 };
 
+// K_claims_seed: a read-modify-write on ONE address takes ~10 ns at the memory side, and at the start of k_claims_dedup every resident lane
+// holding a frequent word would see its slot free and issue one (measured: 2.5 M Zipf-distributed load-then-CAS probes on a zeroed table
+// 0.33 ms, the loads alone 0.02 ms -- tools/microbench/claims_probe.hip).  So a few workgroups first claim the first slot for the first
+// 1024 entries of every (NSQ / n)-th sub-queue: a sample that holds every frequent word; the main pass then finds those slots claimed
+// with plain device-scope loads and only the rare words, a few lanes at a time, take the CAS.  (A seeded entry finds its own claim again
+// in the main pass and stays queued.)
+__global__ __launch_bounds__(CD_NT) void k_claims_seed(ClaimArgs a) {
+    const uint32_t half = gridDim.x >> 1;
+    const bool cls = blockIdx.x >= half;
+    const uint32_t sq = (blockIdx.x % half) * ((uint32_t)NSQ / half);
+    const QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
+    const uint32_t n = min((cls ? a.v[1].counts : a.v[0].counts)[sq * QCNT_STRIDE], cls ? a.v[1].sq_cap : a.v[0].sq_cap);
+    if (threadIdx.x >= n) return;
+    const QItem it = q[threadIdx.x];
+    if (it.len == 0u || it.len > CLAIM_MAX_LEN) return;
+    const ClaimKey key = claim_key_of(a.text, it.s, it.len, a.seed);
+    unsigned long long* const cp = a.claims + claim_slot_a(key.h, a.claim_mask);
+    if (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull)
+        (void)atomicCAS(cp, 0ull, ((unsigned long long)it.len << 32) | (unsigned long long)it.s);
+}
+
 __global__ __launch_bounds__(CD_NT) void k_claims_dedup(ClaimArgs a) {
     __shared__ uint32_t s_wave[CD_NT / 64];
     __shared__ uint32_t s_w;

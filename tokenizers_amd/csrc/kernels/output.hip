@@ -23,6 +23,7 @@ constexpr int CP_NT = 256;
 template <int CP_ITEMS> struct CpShape {
     static constexpr int CHUNK = CP_NT * CP_ITEMS;     // pre-tokens per chunk (the host sizes the state array by COMPACT_CHUNK_MIN)
     static constexpr int STAGE = CP_ITEMS * 640;       // tokens of a chunk assembled in LDS (2.5 per pre-token; more: scattered from the rows)
+    static_assert(CP_ITEMS == 2 || CP_ITEMS == 4 || CP_ITEMS == 8, "shapes the launcher knows");
 };
 
 template <int CP_ITEMS> struct CpRows {
@@ -31,11 +32,16 @@ template <int CP_ITEMS> struct CpRows {
 };
 template <int CP_ITEMS>
 __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
-    static_assert(CP_ITEMS == 4 || CP_ITEMS == 8, "one or two 16-byte loads of tok0 per lane");
+    static_assert(CP_ITEMS == 2 || CP_ITEMS == 4 || CP_ITEMS == 8, "one 8-byte, one or two 16-byte loads of tok0 per lane");
     uint32_t first[CP_ITEMS];
     if (p0 + CP_ITEMS <= P) {
-        const uint4 a = *(const uint4*)(tok0 + p0);
-        first[0] = a.x; first[1] = a.y; first[2] = a.z; first[3] = a.w;
+        if (CP_ITEMS == 2) {
+            const uint2 a = *(const uint2*)(tok0 + p0);
+            first[0] = a.x; first[CP_ITEMS - 1] = a.y;
+        } else {
+            const uint4 a = *(const uint4*)(tok0 + p0);
+            first[0] = a.x; first[1] = a.y; first[CP_ITEMS > 2 ? 2 : 0] = a.z; first[CP_ITEMS > 3 ? 3 : 0] = a.w;
+        }
         if (CP_ITEMS == 8) {
             const uint4 b = *(const uint4*)(tok0 + p0 + 4);
             first[CP_ITEMS - 4] = b.x; first[CP_ITEMS - 3] = b.y; first[CP_ITEMS - 2] = b.z; first[CP_ITEMS - 1] = b.w;
