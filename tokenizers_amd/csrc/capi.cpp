@@ -609,8 +609,31 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     Prof pf{t, w, st};
     using ull = unsigned long long;
 
-    HIP_CHECK(hipMemsetAsync(sc, 0, SC_SLOTS * 8, st));
-    HIP_CHECK(hipMemsetAsync(w->w_docmask.p, 0, (size_t)(W + 1) * 8, st));
+    // Everything the batch needs zeroed, in one launch: the scalars, the document mask, the queues' fill counters, the look-back state
+    // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default, TKAMD_CLAIMS=0 switches them off
+    // for A/B runs; the word cache -- tkamd_word_cache, across batches -- takes their place when it is switched on).
+    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
+    const bool use_claims = claims_on && !t->word_cache &&
+                            (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
+    size_t claim_slots = 0;
+    {
+        ZeroRegions z{};
+        z.add(sc, SC_SLOTS * 8);
+        z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
+        z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
+        z.add(w->w_cstate.p, ((size_t)n_x / ((size_t)256 * (size_t)t->cp_items) + 4) * 8);
+        if (use_claims) {
+            // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
+            // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch
+            int bits = 18;
+            while (bits < 24 && ((size_t)1 << bits) < (size_t)n_x / 64) ++bits;
+            claim_slots = (size_t)1 << bits;
+            w->w_claims.reserve(claim_slots * 8);
+            w->w_claim_rows.reserve(claim_slots * 16);
+            z.add(w->w_claims.p, claim_slots * 8);
+        }
+        launch_zero_regions(st, t->n_cu * 4, z);
+    }
     out->d_ids = w->w_ids.as<uint32_t>();
     out->d_tok_offsets = w->w_tok_offsets.as<int64_t>();
     out->d_offsets = nullptr;
@@ -1223,29 +1246,16 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         plan.v[c].sq_cap = qz.sq_cap[c];
         plan.v[c].row_base = qz.row_base[c];
     }
-    HIP_CHECK(hipMemsetAsync(w->w_qcount.p, 0, (size_t)QCNT_WORDS * 4, st));
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
     WordCache wc{nullptr, nullptr, nullptr, 0u};
-    // In-batch word claims (default; TKAMD_CLAIMS=0 switches them off for A/B runs): repeated words reach the model kernels once
-    // per batch (kernels/lookup.hip).  The word cache (kernels.hpp WordCache, tkamd_word_cache: across batches) takes their place when
-    // it is switched on.  With offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.
-    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
+    // (claims: see the top of this function; with offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end)
     auto open_word_cache = [&]() {
         const size_t slots = (size_t)1 << WORD_CACHE_BITS;
-        if (!t->word_cache) {
-            if (!claims_on) return;
-            // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
-            // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch, zeroed per batch
-            int bits = 18;
-            while (bits < 24 && ((size_t)1 << bits) < N / 64) ++bits;
-            const size_t cslots = (size_t)1 << bits;
-            w->w_claims.reserve(cslots * 8);
-            w->w_claim_rows.reserve(cslots * 16);
-            HIP_CHECK(hipMemsetAsync(w->w_claims.p, 0, cslots * 8, st));
-            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(cslots - 1)};
+        if (use_claims) {
+            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(claim_slots - 1)};
             return;
         }
-        if (off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends; the claims' rows would overwrite the cache's)
+        if (!t->word_cache || off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends)
         w->w_cache_keys.reserve(slots * sizeof(CacheKey));
         w->w_cache_rows.reserve(slots * 16);
         const uint64_t epoch = t->cache_epoch;
@@ -1289,8 +1299,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
         pf.end();
         if (wc.claims) {
-            pf.begin("claims_dedup");
-            launch_claims_dedup(st, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
+            pf.begin("claims_mark");
+            launch_claims_dedup(st, 0, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
+            pf.end();
+            pf.begin("claims_compact");
+            launch_claims_dedup(st, 1, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
             pf.end();
         }
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
@@ -1363,8 +1376,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u);
         pf.end();
         if (wc.claims) {
-            pf.begin("claims_dedup");
-            launch_claims_dedup(st, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
+            pf.begin("claims_mark");
+            launch_claims_dedup(st, 0, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
+            pf.end();
+            pf.begin("claims_compact");
+            launch_claims_dedup(st, 1, t->dt, x_text, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>(), plan, wc);
             pf.end();
         }
         pf.begin("wordpiece");
@@ -1388,7 +1404,6 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_apply_match_ids(st, w->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, w->w_startmask.as<ull>(),
                                w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
     pf.begin("compact");
-    HIP_CHECK(hipMemsetAsync(w->w_cstate.p, 0, (N / ((size_t)256 * (size_t)t->cp_items) + 4) * 8, st));
     // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
     launch_compact(st, t->cp_grid, t->cp_items, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),

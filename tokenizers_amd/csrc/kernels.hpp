@@ -77,6 +77,13 @@ struct WordCache {
     uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host)
 };
 
+// buffers zeroed by one launch (launch_zero_regions)
+struct ZeroRegions {
+    void* p[6];
+    unsigned long long n16[6];       // 16-byte words
+    int n;
+    void add(void* ptr, size_t bytes) { if (n < 6 && ptr && bytes) { p[n] = ptr; n16[n] = (bytes + 15) / 16; ++n; } }
+};
 struct QueuePlan {
     QView v[4];                   // pre-tokens of <= 16 bytes, <= 32, <= 64, longer
 };
@@ -351,7 +358,8 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
 // single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
 // compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
-void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
+// phase 0: k_claims_mark, 1: k_claims_compact
+void launch_claims_dedup(hipStream_t st, int phase, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
                          const QueuePlan& plan, const WordCache& wc);
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
@@ -359,6 +367,7 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
                     int64_t n_docs, int64_t* tok_offsets);
 int compact_grid(int n_cu, int cp_items);
+void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
 constexpr int COMPACT_CHUNK_MIN = 512;              // pre-tokens per compaction chunk: 256 lanes x cp_items (2, 4 or 8)
 
 }  // namespace tkamd

@@ -231,13 +231,16 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
     hipLaunchKernelGGL(k_bpe_merge_huge, dim3(64), dim3(256), 0, st, t, text, (const QItem*)v.q, (uint4*)rows, v.row_base, (const uint32_t*)list_huge,
                        (const uint32_t*)n_huge, tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
 }
+void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z) {
+    if (z.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(grid), dim3(256), 0, st, z);
+}
 int compact_grid(int n_cu, int cp_items) {
     int per_cu = 0;
     const void* k = cp_items == 2 ? (const void*)k_compact<2> : cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
 }
-void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
+void launch_claims_dedup(hipStream_t st, int phase, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
                          const QueuePlan& plan, const WordCache& wc) {
     ClaimArgs a{};
     a.text = text;
@@ -249,12 +252,8 @@ void launch_claims_dedup(hipStream_t st, const DevTables& t, const uint8_t* text
     a.claims = wc.claims;
     a.claim_mask = wc.claim_mask;
     a.seed = t.word_seed;
-    static const int n_seed = [] { const char* e = getenv("TKAMD_CLAIM_SEEDS"); const int v = e ? atoi(e) : 16; return v < 0 ? 0 : (v > NSQ ? NSQ : v); }();
-    static_assert((NSQ & (NSQ - 1)) == 0, "the seed workgroups take every (NSQ / n)-th sub-queue");
-    int ns = 1;
-    while (ns * 2 <= n_seed) ns *= 2;                    // a power of two: divides NSQ
-    if (n_seed > 0) hipLaunchKernelGGL(k_claims_seed, dim3(2 * ns), dim3(CD_NT), 0, st, a);
-    hipLaunchKernelGGL(k_claims_dedup, dim3(2 * NSQ), dim3(CD_NT), 0, st, a);
+    if (phase == 0) hipLaunchKernelGGL(k_claims_mark, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
+    else hipLaunchKernelGGL(k_claims_compact, dim3(2 * NSQ), dim3(CD_NT), 0, st, a);
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claims, wc.claim_mask, (uint4*)wc.rows);

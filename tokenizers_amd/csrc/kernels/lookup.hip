@@ -311,18 +311,17 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 // =================================================================================================
 // In-batch word claims.  Natural text repeats its words: of the pre-tokens the static tables do not settle (13 % on C2) a few
 // percent are distinct.  The reference's per-thread cache exploits that (BPE::tokenize_with_cache, bpe/model.rs:573-586); here, between
-// the lookup and the model kernels, K_claims_dedup lets the FIRST occurrence of a word claim a slot of a hash table (two slots to choose
+// the lookup and the model kernels, the FIRST occurrence of a word claims a slot of a hash table (K_claims_mark; two slots to choose
 // from; 64-bit entries, 0 = free, else length << 32 | first byte of the claimant) and stay queued; every other occurrence finds the
 // claim, checks it against the claimant's BYTES in the text (immutable: nothing here waits for another lane's writes, and no result
 // depends on which occurrence wins), leaves the queue and points its tok0 at the slot's row.  K_claims_publish copies the claimants'
 // finished rows there after the model kernels; the compaction reads them like cached rows (TOK_ROW | CACHE_ROW_BIT | slot), and
 // k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.  A word that finds both of its slots taken by
 // other words is simply merged every time.  The table is zeroed per batch: no state crosses batches.
-// A slot only ever goes from 0 to its claim, so a read that shows a claim is final; a read of 0 is confirmed with a device-scope load
-// before the read-modify-write (a frequent word would otherwise serialise thousands of them on one address).
-// One 1024-lane workgroup per sub-queue (the lookup workgroup that filled it saw a contiguous share of the text, so the reads of the
-// keys and of the masks are nearly sequential) and queue class; it compacts its sub-queue IN PLACE -- survivors move to the front, their
-// tok0 is pointed at the new row -- so the model kernels see dense queues of distinct words.
+// A slot only ever goes from 0 to its claim, so a read that shows a claim is final.  All reads of the table are device-scope loads (the
+// L2 of an XCD keeps a line it read as 0 whatever another XCD's CAS did since -- tools/microbench/claims_probe.hip: a plain load after a
+// remote store was stale in 63 of 63 workgroups, a device-scope load fresh in all, at the same 140 G probes/s under a Zipf law), and a
+// read of 0 comes before the read-modify-write (a frequent word would otherwise serialise thousands of them on one address).
 // =================================================================================================
 constexpr uint32_t CLAIM_MAX_LEN = 32u;
 constexpr int CD_NT = 1024;
@@ -356,34 +355,59 @@ struct ClaimArgs {
     uint32_t claim_mask, seed;
 };
 
-// K_claims_seed: a read-modify-write on ONE address takes ~10 ns at the memory side, and at the start of k_claims_dedup every resident lane
-// holding a frequent word would see its slot free and issue one (measured: 2.5 M Zipf-distributed load-then-CAS probes on a zeroed table
-// 0.33 ms, the loads alone 0.02 ms -- tools/microbench/claims_probe.hip).  So a few workgroups first claim the first slot for the first
-// 1024 entries of every (NSQ / n)-th sub-queue: a sample that holds every frequent word; the main pass then finds those slots claimed
-// with plain device-scope loads and only the rare words, a few lanes at a time, take the CAS.  (A seeded entry finds its own claim again
-// in the main pass and stays queued.)
-__global__ __launch_bounds__(CD_NT) void k_claims_seed(ClaimArgs a) {
-    const uint32_t half = gridDim.x >> 1;
-    const bool cls = blockIdx.x >= half;
-    const uint32_t sq = (blockIdx.x % half) * ((uint32_t)NSQ / half);
-    const QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
+// Two kernels (measured on C2, 2.56 M queued pre-tokens: one kernel that did both, a 1024-lane workgroup per sub-queue with its claim
+// round trips between the barriers of the compaction, took 0.15 ms -- every round waited for the slowest of 1024 four-deep load chains):
+//   K_claims_mark     no barrier anywhere: a lane takes an entry, runs the claim protocol, and if the word is another entry's it points
+//                     tok0 at the slot and marks the entry dead;
+//   K_claims_compact  one workgroup per sub-queue moves the survivors to the front (the lookup workgroup that filled the sub-queue saw
+//                     a contiguous share of the text, so the reads of the masks for the survivors' tok0 words are nearly sequential) and
+//                     points their tok0 at the new rows: the model kernels see dense queues of distinct words.
+constexpr uint32_t CLAIM_DEAD = 0xFFFFFFFFu;             // length of an entry k_claims_mark retired (never leaves the two kernels)
+constexpr int CM_NT = 256, CM_SPLIT = 8;                 // k_claims_mark: workgroups per sub-queue
+__device__ __forceinline__ uint32_t pretok_rank(const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix, uint32_t s) {
+    const unsigned long long m = startmask[s >> 6];
+    return wprefix[s >> 6] + (uint32_t)__popcll(m & ((1ull << (s & 63u)) - 1ull));
+}
+__global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
+    const uint32_t part = blockIdx.x % (uint32_t)CM_SPLIT, sqc = blockIdx.x / (uint32_t)CM_SPLIT;
+    const uint32_t sq = sqc % (uint32_t)NSQ;
+    const bool cls = sqc >= (uint32_t)NSQ;               // grid = 2 NSQ CM_SPLIT: the <= 16-byte queue's sub-queues, then the <= 32-byte queue's
+    // (selects, not indexed loads: the argument arrays stay in scalar registers)
+    QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
     const uint32_t n = min((cls ? a.v[1].counts : a.v[0].counts)[sq * QCNT_STRIDE], cls ? a.v[1].sq_cap : a.v[0].sq_cap);
-    if (threadIdx.x >= n) return;
-    const QItem it = q[threadIdx.x];
-    if (it.len == 0u || it.len > CLAIM_MAX_LEN) return;
-    const ClaimKey key = claim_key_of(a.text, it.s, it.len, a.seed);
-    unsigned long long* const cp = a.claims + claim_slot_a(key.h, a.claim_mask);
-    if (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull)
-        (void)atomicCAS(cp, 0ull, ((unsigned long long)it.len << 32) | (unsigned long long)it.s);
+    for (uint32_t i = part * CM_NT + threadIdx.x; i < n; i += CM_SPLIT * CM_NT) {
+        const QItem it = q[i];
+        if (it.len == 0u || it.len > CLAIM_MAX_LEN) continue;
+        const ClaimKey key = claim_key_of(a.text, it.s, it.len, a.seed);
+        const unsigned long long mine = ((unsigned long long)it.len << 32) | (unsigned long long)it.s;
+        uint32_t slot = claim_slot_a(key.h, a.claim_mask);
+#pragma unroll 1
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            unsigned long long* const cp = a.claims + slot;
+            unsigned long long c = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == 0ull) c = atomicCAS(cp, 0ull, mine);
+            if (c == 0ull || c == mine) break;                                   // the slot is this pre-token's: it stays queued
+            if ((uint32_t)(c >> 32) == it.len) {                                 // the same word?
+                uint64_t o[4] = {0ull, 0ull, 0ull, 0ull};
+                load_key16(a.text, (uint32_t)c, min(it.len, 16u), &o[0], &o[1]);
+                if (it.len > 16u) load_key16(a.text, (uint32_t)c + 16u, it.len - 16u, &o[2], &o[3]);
+                if (((o[0] ^ key.k[0]) | (o[1] ^ key.k[1]) | (o[2] ^ key.k[2]) | (o[3] ^ key.k[3])) == 0ull) {
+                    a.tok0[pretok_rank(a.startmask, a.wprefix, it.s)] = TOK_ROW | CACHE_ROW_BIT | slot;
+                    q[i].len = CLAIM_DEAD;
+                    break;
+                }
+            }
+            slot = claim_slot_b(key.h, a.claim_mask);                            // another word holds the slot: the second one
+        }
+    }
 }
 
-__global__ __launch_bounds__(CD_NT) void k_claims_dedup(ClaimArgs a) {
+__global__ __launch_bounds__(CD_NT) void k_claims_compact(ClaimArgs a) {
     __shared__ uint32_t s_wave[CD_NT / 64];
     __shared__ uint32_t s_w;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t sq = blockIdx.x % (uint32_t)NSQ;
-    const bool cls = blockIdx.x >= (uint32_t)NSQ;        // grid = 2 NSQ: the <= 16-byte queue's sub-queues, then the <= 32-byte queue's
-    // (selects, not indexed loads: the argument arrays stay in scalar registers)
+    const bool cls = blockIdx.x >= (uint32_t)NSQ;        // grid = 2 NSQ
     QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
     uint32_t* const cnt_p = (cls ? a.v[1].counts : a.v[0].counts) + sq * QCNT_STRIDE;
     const uint32_t cap = cls ? a.v[1].sq_cap : a.v[0].sq_cap;
@@ -393,39 +417,10 @@ __global__ __launch_bounds__(CD_NT) void k_claims_dedup(ClaimArgs a) {
     __syncthreads();
     for (uint32_t base = 0; base < n; base += CD_NT) {
         const uint32_t i = base + tid;
-        const bool valid = i < n;
-        QItem it{0u, 0u};
-        if (valid) it = q[i];
-        bool keep = valid;
-        uint32_t dup_tok = 0u, p = 0u;
-        if (valid) {
-            // rank of the pre-token among the batch's: its tok0 word (survivors get a new row, the others the slot)
-            const unsigned long long m = a.startmask[it.s >> 6];
-            p = a.wprefix[it.s >> 6] + (uint32_t)__popcll(m & ((1ull << (it.s & 63u)) - 1ull));
-        }
-        if (valid && it.len != 0u && it.len <= CLAIM_MAX_LEN) {
-            const ClaimKey key = claim_key_of(a.text, it.s, it.len, a.seed);
-            const unsigned long long mine = ((unsigned long long)it.len << 32) | (unsigned long long)it.s;
-            uint32_t slot = claim_slot_a(key.h, a.claim_mask);
-#pragma unroll 1
-            for (int attempt = 0; attempt < 2; ++attempt) {
-                unsigned long long* const cp = a.claims + slot;
-                unsigned long long c = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c == 0ull) c = atomicCAS(cp, 0ull, mine);
-                if (c == 0ull || c == mine) break;                                   // the slot is this pre-token's: it stays queued
-                if ((uint32_t)(c >> 32) == it.len) {                                 // the same word?
-                    uint64_t o[4] = {0ull, 0ull, 0ull, 0ull};
-                    load_key16(a.text, (uint32_t)c, min(it.len, 16u), &o[0], &o[1]);
-                    if (it.len > 16u) load_key16(a.text, (uint32_t)c + 16u, it.len - 16u, &o[2], &o[3]);
-                    if (((o[0] ^ key.k[0]) | (o[1] ^ key.k[1]) | (o[2] ^ key.k[2]) | (o[3] ^ key.k[3])) == 0ull) {
-                        keep = false;
-                        dup_tok = TOK_ROW | CACHE_ROW_BIT | slot;
-                        break;
-                    }
-                }
-                slot = claim_slot_b(key.h, a.claim_mask);                            // another word holds the slot: the second one
-            }
-        }
+        QItem it{0u, CLAIM_DEAD};
+        if (i < n) it = q[i];
+        const bool keep = it.len != CLAIM_DEAD;
+        const uint32_t p = keep ? pretok_rank(a.startmask, a.wprefix, it.s) : 0u;      // (its tok0 word: loaded before the barrier, with the entry)
         __syncthreads();                                     // every entry of this round has been read: survivors may overwrite them
         const uint64_t kb = __ballot(keep);
         if (lane == 0) s_wave[wave] = (uint32_t)__popcll(kb);
@@ -436,10 +431,10 @@ __global__ __launch_bounds__(CD_NT) void k_claims_dedup(ClaimArgs a) {
         const uint32_t w0 = s_w;
         if (keep) {
             const uint32_t pos = w0 + before + (uint32_t)mbcnt64(kb);      // <= i: never an entry of a later round
-            q[pos] = it;
-            a.tok0[p] = TOK_ROW | (row0 + pos);
-        } else if (valid) {
-            a.tok0[p] = dup_tok;
+            if (pos != i) {
+                q[pos] = it;
+                a.tok0[p] = TOK_ROW | (row0 + pos);
+            }
         }
         __syncthreads();
         if (tid == 0) s_w = w0 + total;
