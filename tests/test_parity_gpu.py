@@ -638,6 +638,30 @@ def test_runs_of_unknown_one_byte_words_grow_the_queue_twice():
     assert got.ids[:50000].tolist() == [0] * 50000
 
 
+@pytest.mark.parametrize("name", ["gpt2", "bert_wordpiece_4000_specials"])
+def test_encode_file_on_device_vs_oracle(name, gpt2_json, tmp_path):
+    """On-disk ingest: Tokenizer.encode_file reads a newline-delimited file in one piece, every line WITH its terminator is a
+    document (the reference's own line reader, lines_with_ending, utils/iter.rs:64-100, used by train_from_files,
+    tokenizer/mod.rs:1432-1444) and the batch goes through the device path: ids, offsets and word ids equal the oracle's on the same
+    lines; a last line without a terminator, CRLF and empty lines, an empty file."""
+    import tokenizers_amd as ta
+    js = gpt2_json if name == "gpt2" else load_tokenizer_json(name)
+    tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+    lines = synth.gen_lines(20000, text_seed=71) + synth.stress_lines(seed=19, n=400)
+    lines = [l.replace("\n", " ").replace("\r", " ").replace("\u302e", "") for l in lines]
+    docs = [l + ("\r\n" if i % 7 == 3 else "\n") for i, l in enumerate(lines)] + ["\n", "\n", "the last line has no terminator"]
+    path = tmp_path / "corpus.txt"
+    path.write_bytes("".join(docs).encode("utf-8"))
+    exp = o.encode_batch(docs)
+    got = tok.encode_file(str(path))
+    assert len(got.tok_offsets) == len(docs) + 1 and np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
+    got = tok.encode_file(str(path), offsets="byte", word_ids=True)
+    assert np.array_equal(got.ids, exp.ids) and np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)
+    empty = tmp_path / "empty.txt"
+    empty.write_bytes(b"")
+    assert tok.encode_file(str(empty)).n_tokens == 0
+
+
 @pytest.mark.parametrize("name", ["wordlevel_whitespace_c1", "bytelevel_prefix_trim_3000"])
 def test_document_token_csr_corners(name):
     """The documents' token CSR is written by the compaction, chunk of 2048 pre-tokens by chunk (kernels/output.hip): no pre-token

@@ -1316,12 +1316,18 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // keys in LDS (default when new_id = rank + c)
         const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
         fork_side();                                       // the <= 32-byte class on one side stream, the 64-byte / long classes on the other, the <= 16-byte class here
+        // With the claims on both queues hold the distinct words only, and a launch of the LDS kernels lasts as long as its longest word's
+        // chain of dependent merge probes whatever it holds: the 32-symbol kernel takes both queues in one launch (TKAMD_MERGE_ONE=0: two).
+        static const bool merge_one = [] { const char* e = getenv("TKAMD_MERGE_ONE"); return !(e && !strcmp(e, "0")); }();
+        const bool one = merge_one && wc.claims && lds16 && lds32;
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, one ? &plan.v[0] : nullptr);
         pf.end();
-        pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
-        launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
-        pf.end();
+        if (!one) {
+            pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
+            launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+            pf.end();
+        }
         pf.begin("bpe_merge64");
         launch_bpe_merge(s_c, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();

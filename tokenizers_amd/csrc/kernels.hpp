@@ -286,8 +286,9 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
 int hot_table_slots();
 // group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
 // 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
+// also (group 6 only): a second queue for the same launch
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
-                      uint32_t* tmp_ids, uint32_t* tmp_end);
+                      uint32_t* tmp_ids, uint32_t* tmp_end, const QView* also = nullptr);
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
                               unsigned long long* docmask, int* err);
 void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,

@@ -324,10 +324,14 @@ template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, QView, 
 // allows NT = 768 (S = 16) lanes per CU.
 // Same semantics as k_bpe_merge / k_bpe_merge_lane (models/bpe/word.rs:162-250).
 // =================================================================================================
+// v2 (v2.q != nullptr): a second queue, taken after the first -- the 32-symbol kernel also serves the <= 16-byte class when the
+// in-batch claims have thinned both queues to the distinct words: each launch then lasts as long as its longest word's chain of
+// dependent merge probes whatever the queue holds, and one launch is cheaper than two.
 template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
-__global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
+__global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text, QView v, QView v2, uint4* __restrict__ rows,
                                                       uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
     __shared__ uint32_t s_qpre[NSQ + 1];
+    __shared__ uint32_t s_qpre2[S == 32 ? NSQ + 1 : 1];    // (only the 32-symbol kernel takes a second queue: two 704-lane workgroups of the 16-symbol one fill a CU's LDS to the last KB)
     constexpr uint32_t PB = (S == 16) ? 4 : 5;
     HIP_DYNAMIC_SHARED(uint32_t, lds_words)
     uint32_t* s_key = lds_words;                              // [S][NT]
@@ -344,7 +348,8 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     __syncthreads();
     const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
     const uint32_t nid_base = t.newid_base;
-    const uint32_t n_items = qview_prefix(v, s_qpre);
+    const uint32_t n_first = qview_prefix(v, s_qpre);
+    const uint32_t n_items = n_first + ((S == 32 && v2.q) ? qview_prefix(v2, s_qpre2) : 0u);
     // a short queue (the in-batch claims leave the distinct words only) is spread over the whole grid, a few wavefronts of every
     // workgroup busy, instead of filling the first workgroups and leaving most CUs idle
     const uint32_t take = min((uint32_t)NT, ((n_items + gridDim.x - 1u) / gridDim.x + 63u) & ~63u);
@@ -352,8 +357,11 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     for (uint32_t base = blockIdx.x * take; base < n_items; base += stride) {
         const uint32_t item = base + tid;
         bool valid = tid < take && item < n_items;
-        uint32_t s = 0, len = 0, qidx = 0;                    // qidx: position in the work queue (names the result row)
-        if (valid) { qidx = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qidx]; s = it.s; len = it.len; }
+        uint32_t s = 0, len = 0, qidx = 0;                    // qidx: the result row (named by the position in the work queue)
+        if (valid) {
+            if (item < n_first) { const uint32_t qp = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qp]; s = it.s; len = it.len; qidx = v.row_base + qp; }
+            else { const uint32_t qp = qview_pos(s_qpre2, v2.sq_cap, item - n_first); const QItem it = v2.q[qp]; s = it.s; len = it.len; qidx = v2.row_base + qp; }
+        }
         valid = valid && len != 0u;                           // length 0: retired by k_long_vocab
         // counting sort of the workgroup's items by length: a wavefront loops until its slowest lane is done
         {
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 }
             }
             if (tmp_end) tmp_end[s + c - 1] = len;
-            rows[v.row_base + qidx] = make_row(c, s, r[0], r[1], r[2], r[3]);
+            rows[qidx] = make_row(c, s, r[0], r[1], r[2], r[3]);
         }
     }
 }
@@ -484,8 +492,8 @@ static int prepare_lds_merge() {
     return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
 }
 template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
-static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, uint4* rows, uint32_t* tmp_ids, uint32_t* tmp_end) {
-    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, v, rows, tmp_ids, tmp_end);
+static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const QView& v2, uint4* rows, uint32_t* tmp_ids, uint32_t* tmp_end) {
+    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, v, v2, rows, tmp_ids, tmp_end);
 }
 
 // =================================================================================================

@@ -75,11 +75,12 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     else hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(false), st, a);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
-                      uint32_t* tmp_ids, uint32_t* tmp_end) {
+                      uint32_t* tmp_ids, uint32_t* tmp_end, const QView* also) {
     uint4* r = (uint4*)rows;
+    const QView none{};
     // LDS-resident keys (needs newid_affine; prepare_long_kernel() raised the LDS limit)
-    if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, v, r, tmp_ids, tmp_end);   // two 704-lane workgroups per CU
-    else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, v, r, tmp_ids, tmp_end);
+    if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, v, none, r, tmp_ids, tmp_end);   // two 704-lane workgroups per CU
+    else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, v, also ? *also : none, r, tmp_ids, tmp_end);
     else if (group == 1)
         hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, v, r, tmp_ids, tmp_end);
     else if (group == 2)

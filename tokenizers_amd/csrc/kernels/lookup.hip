@@ -368,6 +368,10 @@ __device__ __forceinline__ uint32_t pretok_rank(const unsigned long long* __rest
     const unsigned long long m = startmask[s >> 6];
     return wprefix[s >> 6] + (uint32_t)__popcll(m & ((1ull << (s & 63u)) - 1ull));
 }
+// A lane runs the protocol for CM_K entries AT ONCE, stage by stage (entries, keys, slots, claimants' bytes, ranks): the first version
+// took one entry through its five dependent round trips before it looked at the next and was bound by exactly that latency
+// (0.18 ms for C2's 2.56 M entries); the loads of a stage are independent of each other and fly together.
+constexpr int CM_K = 4;
 __global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
     const uint32_t part = blockIdx.x % (uint32_t)CM_SPLIT, sqc = blockIdx.x / (uint32_t)CM_SPLIT;
     const uint32_t sq = sqc % (uint32_t)NSQ;
@@ -375,29 +379,86 @@ __global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
     // (selects, not indexed loads: the argument arrays stay in scalar registers)
     QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
     const uint32_t n = min((cls ? a.v[1].counts : a.v[0].counts)[sq * QCNT_STRIDE], cls ? a.v[1].sq_cap : a.v[0].sq_cap);
-    for (uint32_t i = part * CM_NT + threadIdx.x; i < n; i += CM_SPLIT * CM_NT) {
-        const QItem it = q[i];
-        if (it.len == 0u || it.len > CLAIM_MAX_LEN) continue;
-        const ClaimKey key = claim_key_of(a.text, it.s, it.len, a.seed);
-        const unsigned long long mine = ((unsigned long long)it.len << 32) | (unsigned long long)it.s;
-        uint32_t slot = claim_slot_a(key.h, a.claim_mask);
-#pragma unroll 1
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            unsigned long long* const cp = a.claims + slot;
-            unsigned long long c = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (c == 0ull) c = atomicCAS(cp, 0ull, mine);
-            if (c == 0ull || c == mine) break;                                   // the slot is this pre-token's: it stays queued
-            if ((uint32_t)(c >> 32) == it.len) {                                 // the same word?
-                uint64_t o[4] = {0ull, 0ull, 0ull, 0ull};
-                load_key16(a.text, (uint32_t)c, min(it.len, 16u), &o[0], &o[1]);
-                if (it.len > 16u) load_key16(a.text, (uint32_t)c + 16u, it.len - 16u, &o[2], &o[3]);
-                if (((o[0] ^ key.k[0]) | (o[1] ^ key.k[1]) | (o[2] ^ key.k[2]) | (o[3] ^ key.k[3])) == 0ull) {
-                    a.tok0[pretok_rank(a.startmask, a.wprefix, it.s)] = TOK_ROW | CACHE_ROW_BIT | slot;
-                    q[i].len = CLAIM_DEAD;
-                    break;
+    for (uint32_t base = part * (uint32_t)(CM_NT * CM_K); base < n; base += (uint32_t)(CM_SPLIT * CM_NT * CM_K)) {
+        QItem it[CM_K];
+        bool live[CM_K];
+        // stage 1: the entries
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) {
+            const uint32_t i = base + (uint32_t)k * CM_NT + threadIdx.x;
+            it[k] = q[i < n ? i : 0u];                                           // (n > 0 here: entry 0 exists)
+            live[k] = i < n && it[k].len != 0u && it[k].len <= CLAIM_MAX_LEN;
+        }
+        // stage 2: the keys (a dead lane reads the key of a one-byte word: no branch around the loads)
+        ClaimKey key[CM_K];
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) {
+            const uint32_t len = live[k] ? it[k].len : 1u;
+            load_key16(a.text, it[k].s, min(len, 16u), &key[k].k[0], &key[k].k[1]);
+            key[k].k[2] = key[k].k[3] = 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k)
+            if (live[k] && it[k].len > 16u) load_key16(a.text, it[k].s + 16u, it[k].len - 16u, &key[k].k[2], &key[k].k[3]);       // (few lanes)
+        // stage 3: the first slot of every word
+        uint32_t slot[CM_K];
+        unsigned long long c[CM_K];
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) {
+            key[k].h = word_hash1(key[k].k[0], key[k].k[1], it[k].len, a.seed);
+            if (it[k].len > 16u) key[k].h = claim_hash_long(key[k].h, (uint32_t)key[k].k[2], (uint32_t)(key[k].k[2] >> 32), (uint32_t)key[k].k[3], (uint32_t)(key[k].k[3] >> 32));
+            slot[k] = claim_slot_a(key[k].h, a.claim_mask);
+            c[k] = __hip_atomic_load(a.claims + slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k)
+            if (live[k] && c[k] == 0ull) c[k] = atomicCAS(a.claims + slot[k], 0ull, ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s);
+        // stage 4: a claim that is not this entry's: the same word?  (the claimant's bytes; a lane without such a claim reads its own)
+        uint64_t o[CM_K][4];
+        bool foreign[CM_K], dup[CM_K];
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) {
+            const unsigned long long mine = ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s;
+            foreign[k] = live[k] && c[k] != 0ull && c[k] != mine;                // else: the slot is this entry's, it stays queued
+            const bool cmp = foreign[k] && (uint32_t)(c[k] >> 32) == it[k].len;
+            const uint32_t at = cmp ? (uint32_t)c[k] : it[k].s, len = cmp ? it[k].len : 1u;
+            load_key16(a.text, at, min(len, 16u), &o[k][0], &o[k][1]);
+            o[k][2] = o[k][3] = 0ull;
+            dup[k] = cmp;
+        }
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k)
+            if (dup[k] && it[k].len > 16u) load_key16(a.text, (uint32_t)c[k] + 16u, it[k].len - 16u, &o[k][2], &o[k][3]);
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k)
+            dup[k] = dup[k] && ((o[k][0] ^ key[k].k[0]) | (o[k][1] ^ key[k].k[1]) | (o[k][2] ^ key[k].k[2]) | (o[k][3] ^ key[k].k[3])) == 0ull;
+        // stage 5 (few lanes): another word holds the first slot -- the second one, entry by entry
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) {
+            if (foreign[k] && !dup[k]) {
+                const unsigned long long mine = ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s;
+                slot[k] = claim_slot_b(key[k].h, a.claim_mask);
+                unsigned long long* const cp = a.claims + slot[k];
+                unsigned long long c2 = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c2 == 0ull) c2 = atomicCAS(cp, 0ull, mine);
+                if (c2 != 0ull && c2 != mine && (uint32_t)(c2 >> 32) == it[k].len) {
+                    uint64_t o2[4] = {0ull, 0ull, 0ull, 0ull};
+                    load_key16(a.text, (uint32_t)c2, min(it[k].len, 16u), &o2[0], &o2[1]);
+                    if (it[k].len > 16u) load_key16(a.text, (uint32_t)c2 + 16u, it[k].len - 16u, &o2[2], &o2[3]);
+                    dup[k] = ((o2[0] ^ key[k].k[0]) | (o2[1] ^ key[k].k[1]) | (o2[2] ^ key[k].k[2]) | (o2[3] ^ key[k].k[3])) == 0ull;
                 }
             }
-            slot = claim_slot_b(key.h, a.claim_mask);                            // another word holds the slot: the second one
+        }
+        // stage 6: the other occurrences leave the queue and point their tok0 at the slot
+        uint32_t p[CM_K];
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) p[k] = pretok_rank(a.startmask, a.wprefix, it[k].s);      // (every lane: no branch around the loads)
+#pragma unroll
+        for (int k = 0; k < CM_K; ++k) {
+            if (dup[k]) {
+                a.tok0[p[k]] = TOK_ROW | CACHE_ROW_BIT | slot[k];
+                q[base + (uint32_t)k * CM_NT + threadIdx.x].len = CLAIM_DEAD;
+            }
         }
     }
 }
