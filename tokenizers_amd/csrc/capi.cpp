@@ -1237,8 +1237,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
     const size_t N = (size_t)n_x;
     const QueueSizes qz = queue_sizes(N, t->q16_div, lookup_grid(t));
-    // (bit 29 of a row index is the compaction's "row lives in the word cache" flag, whether or not a cache is open)
-    if (qz.total >= (size_t)CACHE_ROW_BIT) throw Invalid("batch too large for the work queues (row indices are 29-bit): split it");
+    if (qz.total >= (size_t)ROW_INDEX_LIMIT) throw Invalid("batch too large for the work queues (row indices are 30-bit: about 3 GB of text): split it");
     QueuePlan plan{};
     for (int c = 0; c < 4; ++c) {
         plan.v[c].q = (QItem*)(w->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);

@@ -61,7 +61,7 @@ struct QView {
 // reference's cache does not evict either); an entry is a key slot + a result row in the same 16-byte format the merge kernels
 // write, so a hit costs the lookup one probe and the compaction nothing extra.
 constexpr int WORD_CACHE_BITS = 20;                       // 1 M entries: 32 MB of keys + 16 MB of rows per workspace
-constexpr uint32_t CACHE_ROW_BIT = 1u << 29;              // tok0 = TOK_ROW | CACHE_ROW_BIT | slot: the row lives in the cache
+constexpr uint32_t ROW_INDEX_LIMIT = 1u << 30;            // tok0 carries 30 bits of row index (results.hip)
 constexpr uint32_t CACHE_CLAIMED = 0x80000000u;
 struct __attribute__((aligned(32))) CacheKey {
     uint32_t k[4];               // the pre-token's bytes, zero padded to 16

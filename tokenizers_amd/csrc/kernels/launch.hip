@@ -253,7 +253,17 @@ void launch_claims_dedup(hipStream_t st, int phase, const DevTables& t, const ui
     a.claims = wc.claims;
     a.claim_mask = wc.claim_mask;
     a.seed = t.word_seed;
-    if (phase == 0) hipLaunchKernelGGL(k_claims_mark, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
+    // (read at every call: tools/cm_probe.py walks through the settings inside one process)
+    const char* const e_k = getenv("TKAMD_CM_K");
+    const char* const e_d = getenv("TKAMD_CM_DEBUG");
+    const int cm_k = e_k ? atoi(e_k) : 1;
+    const uint32_t cm_debug = e_d ? (uint32_t)atoi(e_d) : 0u;
+    a.debug = cm_debug;
+    if (phase == 0) {
+        if (cm_k == 4) hipLaunchKernelGGL(k_claims_mark<4>, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
+        else if (cm_k == 2) hipLaunchKernelGGL(k_claims_mark<2>, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
+        else hipLaunchKernelGGL(k_claims_mark<1>, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
+    }
     else hipLaunchKernelGGL(k_claims_compact, dim3(2 * NSQ), dim3(CD_NT), 0, st, a);
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                         const CacheKey* const ck = a.cache_keys + slot;
                         const uint4 ckey = *(const uint4*)ck->k;
                         const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
-                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_ROW | CACHE_ROW_BIT | slot; pend = false; }
+                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_SLOT | slot; pend = false; }
                     }
                 }
                 if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 // from; 64-bit entries, 0 = free, else length << 32 | first byte of the claimant) and stay queued; every other occurrence finds the
 // claim, checks it against the claimant's BYTES in the text (immutable: nothing here waits for another lane's writes, and no result
 // depends on which occurrence wins), leaves the queue and points its tok0 at the slot's row.  K_claims_publish copies the claimants'
-// finished rows there after the model kernels; the compaction reads them like cached rows (TOK_ROW | CACHE_ROW_BIT | slot), and
+// finished rows there after the model kernels; the compaction reads them like cached rows (TOK_SLOT | slot), and
 // k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.  A word that finds both of its slots taken by
 // other words is simply merged every time.  The table is zeroed per batch: no state crosses batches.
 // A slot only ever goes from 0 to its claim, so a read that shows a claim is final.  All reads of the table are device-scope loads (the
@@ -353,6 +353,7 @@ struct ClaimArgs {
     QView v[2];                      // the <= 16-byte and the <= 32-byte queue
     unsigned long long* claims;
     uint32_t claim_mask, seed;
+    uint32_t debug;                  // timing experiments only (TKAMD_CM_DEBUG): skips parts of k_claims_mark -- results are then WRONG
 };
 
 // Two kernels (measured on C2, 2.56 M queued pre-tokens: one kernel that did both, a 1024-lane workgroup per sub-queue with its claim
@@ -371,7 +372,7 @@ __device__ __forceinline__ uint32_t pretok_rank(const unsigned long long* __rest
 // A lane runs the protocol for CM_K entries AT ONCE, stage by stage (entries, keys, slots, claimants' bytes, ranks): the first version
 // took one entry through its five dependent round trips before it looked at the next and was bound by exactly that latency
 // (0.18 ms for C2's 2.56 M entries); the loads of a stage are independent of each other and fly together.
-constexpr int CM_K = 4;
+template <int CM_K>
 __global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
     const uint32_t part = blockIdx.x % (uint32_t)CM_SPLIT, sqc = blockIdx.x / (uint32_t)CM_SPLIT;
     const uint32_t sq = sqc % (uint32_t)NSQ;
@@ -408,11 +409,11 @@ __global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
             key[k].h = word_hash1(key[k].k[0], key[k].k[1], it[k].len, a.seed);
             if (it[k].len > 16u) key[k].h = claim_hash_long(key[k].h, (uint32_t)key[k].k[2], (uint32_t)(key[k].k[2] >> 32), (uint32_t)key[k].k[3], (uint32_t)(key[k].k[3] >> 32));
             slot[k] = claim_slot_a(key[k].h, a.claim_mask);
-            c[k] = __hip_atomic_load(a.claims + slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            c[k] = (a.debug & 1u) ? 0ull : __hip_atomic_load(a.claims + slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int k = 0; k < CM_K; ++k)
-            if (live[k] && c[k] == 0ull) c[k] = atomicCAS(a.claims + slot[k], 0ull, ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s);
+            if (live[k] && c[k] == 0ull && !(a.debug & 3u)) c[k] = atomicCAS(a.claims + slot[k], 0ull, ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s);
         // stage 4: a claim that is not this entry's: the same word?  (the claimant's bytes; a lane without such a claim reads its own)
         uint64_t o[CM_K][4];
         bool foreign[CM_K], dup[CM_K];
@@ -422,20 +423,22 @@ __global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
             foreign[k] = live[k] && c[k] != 0ull && c[k] != mine;                // else: the slot is this entry's, it stays queued
             const bool cmp = foreign[k] && (uint32_t)(c[k] >> 32) == it[k].len;
             const uint32_t at = cmp ? (uint32_t)c[k] : it[k].s, len = cmp ? it[k].len : 1u;
-            load_key16(a.text, at, min(len, 16u), &o[k][0], &o[k][1]);
+            if (!(a.debug & 4u)) load_key16(a.text, at, min(len, 16u), &o[k][0], &o[k][1]);
+            else { o[k][0] = key[k].k[0]; o[k][1] = key[k].k[1]; }
             o[k][2] = o[k][3] = 0ull;
             dup[k] = cmp;
         }
 #pragma unroll
         for (int k = 0; k < CM_K; ++k)
-            if (dup[k] && it[k].len > 16u) load_key16(a.text, (uint32_t)c[k] + 16u, it[k].len - 16u, &o[k][2], &o[k][3]);
+            if (dup[k] && it[k].len > 16u && !(a.debug & 4u)) load_key16(a.text, (uint32_t)c[k] + 16u, it[k].len - 16u, &o[k][2], &o[k][3]);
+            else if (dup[k]) { o[k][2] = key[k].k[2]; o[k][3] = key[k].k[3]; }
 #pragma unroll
         for (int k = 0; k < CM_K; ++k)
             dup[k] = dup[k] && ((o[k][0] ^ key[k].k[0]) | (o[k][1] ^ key[k].k[1]) | (o[k][2] ^ key[k].k[2]) | (o[k][3] ^ key[k].k[3])) == 0ull;
         // stage 5 (few lanes): another word holds the first slot -- the second one, entry by entry
 #pragma unroll
         for (int k = 0; k < CM_K; ++k) {
-            if (foreign[k] && !dup[k]) {
+            if (foreign[k] && !dup[k] && !(a.debug & 32u)) {
                 const unsigned long long mine = ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s;
                 slot[k] = claim_slot_b(key[k].h, a.claim_mask);
                 unsigned long long* const cp = a.claims + slot[k];
@@ -452,12 +455,12 @@ __global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
         // stage 6: the other occurrences leave the queue and point their tok0 at the slot
         uint32_t p[CM_K];
 #pragma unroll
-        for (int k = 0; k < CM_K; ++k) p[k] = pretok_rank(a.startmask, a.wprefix, it[k].s);      // (every lane: no branch around the loads)
+        for (int k = 0; k < CM_K; ++k) p[k] = (a.debug & 8u) ? 0u : pretok_rank(a.startmask, a.wprefix, it[k].s);      // (every lane: no branch around the loads)
 #pragma unroll
         for (int k = 0; k < CM_K; ++k) {
             if (dup[k]) {
-                a.tok0[p[k]] = TOK_ROW | CACHE_ROW_BIT | slot[k];
-                q[base + (uint32_t)k * CM_NT + threadIdx.x].len = CLAIM_DEAD;
+                if (!(a.debug & 8u)) a.tok0[p[k]] = TOK_SLOT | slot[k];
+                if (!(a.debug & 16u)) q[base + (uint32_t)k * CM_NT + threadIdx.x].len = CLAIM_DEAD;
             }
         }
     }

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
     }
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k)                     // all row loads in flight together
-        r.row[k] = (first[k] & TOK_ROW) ? ((first[k] & CACHE_ROW_BIT) ? crows[first[k] & (CACHE_ROW_BIT - 1u)] : rows[first[k] & ~TOK_ROW]) : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
+        r.row[k] = (first[k] & TOK_ROW) ? ((first[k] & TOK_ONE) ? crows[first[k] & TOK_REF_MASK] : rows[first[k] & TOK_REF_MASK]) : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) { r.cnt[k] = row_count(r.row[k]); v += r.cnt[k]; }
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         uint32_t s_ends = s;                                          // whose token ends: the pre-token's own, or the claimant's of its word
         if (a.claims && c > 1) {
             const uint32_t t0 = a.tok0[p];
-            if ((t0 & (TOK_ROW | CACHE_ROW_BIT)) == (TOK_ROW | CACHE_ROW_BIT)) s_ends = (uint32_t)a.claims[t0 & (CACHE_ROW_BIT - 1u)];
+            if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = (uint32_t)a.claims[t0 & TOK_REF_MASK];
         }
         for (uint32_t j = 0; j < c; ++j) {
             uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s_ends + j];

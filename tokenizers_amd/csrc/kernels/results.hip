@@ -5,7 +5,8 @@
 // Result layout between Model::tokenize and into_encoding (replaces the Vec<Token> every Split carries,
 // tokenizer/pre_tokenizer.rs:22-47):
 //   tok0[p]   one word per pre-token:  TOK_ONE | id            exactly one token (settled by the lookup kernel)
-//                                      TOK_ROW | row            the tokens are in rows[row]
+//                                      TOK_ROW | row            the tokens are in rows[row]        (30 bits of row)
+//                                      TOK_SLOT | slot          the tokens are in the row of a claimed / cached slot (both flag bits; kernels/lookup.hip)
 //   rows[r]   16 bytes per QUEUED pre-token, named by the queue position the lookup kernel gave it (so the model kernels
 //             never touch the P-sized arrays):   { id0 | count << 28, id1, id2, id3 }                 count <= 4
 //                                                { id0 | 15 << 28, s, count, 0 }                      any count: ids 1.. in
@@ -17,6 +18,7 @@
 constexpr uint32_t TOK_ROW = 0x80000000u;
 constexpr uint32_t TOK_ONE = 0x40000000u;
 constexpr uint32_t TOK_ID_MASK = 0x00FFFFFFu;
+constexpr uint32_t TOK_SLOT = TOK_ROW | TOK_ONE, TOK_REF_MASK = 0x3FFFFFFFu;
 constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
 
 // one queued pre-token: first byte and length (the model kernels need nothing else)
