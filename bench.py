@@ -478,7 +478,7 @@ KERNEL_OF_STAGE = {"bpe_merge_lds": "k_bpe_merge_lds<16,", "bpe_merge_lds32": "k
                    "pretok_gpt2": "k_pretok_gpt2", "pretok_gpt2_seq": "k_pretok_gpt2_seq", "pretok_llama3": "k_pretok_llama3_lane",
                    "pretok_local": "k_pretok_local", "compact": "k_compact", "emit_pretok": "k_emit_pretok", "lookup": "k_lookup",
                    "wordpiece_word_lookup": "k_lookup", "wordlevel_lookup": "k_lookup", "bert_normalize": "k_bn_write",
-                   "wordpiece": "k_wordpiece", "added_token_match": "k_added_candidates", "claims_mark": "k_claims_mark", "claims_compact": "k_claims_compact",
+                   "wordpiece": "k_wordpiece", "added_token_match": "k_added_candidates",
                    "claims_publish": "k_claims_publish"}
 
 

@@ -75,6 +75,7 @@ struct WordCache {
     // pre-token that claimed the slot in THIS batch.  Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
     unsigned long long* claims;
     uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host)
+    uint32_t claim_mode;         // LookupArgs::claim_mode (TKAMD_CLAIMS = 1 / 3)
 };
 
 // buffers zeroed by one launch (launch_zero_regions)
@@ -359,9 +360,6 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
 // single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
 // compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
-// phase 0: k_claims_mark, 1: k_claims_compact
-void launch_claims_dedup(hipStream_t st, int phase, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
-                         const QueuePlan& plan, const WordCache& wc);
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,

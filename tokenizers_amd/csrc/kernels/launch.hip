@@ -69,6 +69,9 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.matchmask = matchmask;
     a.hot = (const uint4*)hot;
     a.cache_keys = wc.keys;
+    a.claims = wc.claims;
+    a.claim_mask = wc.claim_mask;
+    a.claim_mode = wc.claim_mode;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
     if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
@@ -240,31 +243,6 @@ int compact_grid(int n_cu, int cp_items) {
     const void* k = cp_items == 2 ? (const void*)k_compact<2> : cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
-}
-void launch_claims_dedup(hipStream_t st, int phase, const DevTables& t, const uint8_t* text, const unsigned long long* startmask, const uint32_t* wprefix, uint32_t* tok0,
-                         const QueuePlan& plan, const WordCache& wc) {
-    ClaimArgs a{};
-    a.text = text;
-    a.startmask = startmask;
-    a.wprefix = wprefix;
-    a.tok0 = tok0;
-    a.v[0] = plan.v[0];
-    a.v[1] = plan.v[1];
-    a.claims = wc.claims;
-    a.claim_mask = wc.claim_mask;
-    a.seed = t.word_seed;
-    // (read at every call: tools/cm_probe.py walks through the settings inside one process)
-    const char* const e_k = getenv("TKAMD_CM_K");
-    const char* const e_d = getenv("TKAMD_CM_DEBUG");
-    const int cm_k = e_k ? atoi(e_k) : 1;
-    const uint32_t cm_debug = e_d ? (uint32_t)atoi(e_d) : 0u;
-    a.debug = cm_debug;
-    if (phase == 0) {
-        if (cm_k == 4) hipLaunchKernelGGL(k_claims_mark<4>, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
-        else if (cm_k == 2) hipLaunchKernelGGL(k_claims_mark<2>, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
-        else hipLaunchKernelGGL(k_claims_mark<1>, dim3(2 * NSQ * CM_SPLIT), dim3(CM_NT), 0, st, a);
-    }
-    else hipLaunchKernelGGL(k_claims_compact, dim3(2 * NSQ), dim3(CD_NT), 0, st, a);
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claims, wc.claim_mask, (uint4*)wc.rows);

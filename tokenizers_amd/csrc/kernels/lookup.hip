@@ -62,10 +62,21 @@ struct LookupArgs {
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
     uint32_t unk_id, has_unk;
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
+    unsigned long long* claims;      // in-batch word claims (below), or null
+    uint32_t claim_mask;             // slots - 1
+    uint32_t claim_mode;             // 1: the slot is read after the table probe has missed; 3: its read rides along with the table probe
 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
+
+// ---- in-batch word claims: hash and slot of a word of <= 32 bytes (the section behind k_lookup says what they are for) ----
+constexpr uint32_t CLAIM_MAX_LEN = 32u;
+// the whole-word table's hash of the first 16 bytes and the whole length, continued over bytes 16..31 (zero padded)
+__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
+    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
+}
+__device__ __forceinline__ uint32_t claim_slot(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
 
 template <bool HAS_END>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
@@ -246,9 +257,42 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 load_key(rel, s_rel, len, k0, k1, k2, k3, true);
                 uint32_t out = 0u;
                 bool pend = v;
-                if (v && hits_on && len <= (uint32_t)WORD_MAX_KEY) {
-                    const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
+                // In-batch claims (the section behind this kernel): ONE chain for the words of <= 16 and of 17..32 bytes, so that the
+                // lanes of a step wait together.  claim_mode 3: the device-scope read of the word's slot, and then of the claimant's
+                // bytes, fly alongside the displacement -> slot chain of the table probe -- a repeated word costs no further round trip.
+                const bool is16 = v && hits_on && len <= (uint32_t)WORD_MAX_KEY;
+                const bool is32 = a.claims != nullptr && v && len > (uint32_t)WORD_MAX_KEY && len <= CLAIM_MAX_LEN;
+                uint32_t h1 = 0u, k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u;
+                uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
+                if (is16 || is32) h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
+                uint32_t hc = h1;
+                if (is32) {                                                         // (few lanes) bytes 16..31 of the key
+                    const uint32_t wi = (s_rel >> 2) + 4u, sh = s_rel & 3u;
+                    const uint32_t d4 = s_text32[wi], d5 = s_text32[wi + 1], d6 = s_text32[wi + 2], d7 = s_text32[wi + 3], d8 = s_text32[wi + 4];
+                    kmh = s_kmask[len - 16u];
+                    k4 = __builtin_amdgcn_alignbyte(d5, d4, sh) & kmh.x; k5 = __builtin_amdgcn_alignbyte(d6, d5, sh) & kmh.y;
+                    k6 = __builtin_amdgcn_alignbyte(d7, d6, sh) & kmh.z; k7 = __builtin_amdgcn_alignbyte(d8, d7, sh) & kmh.w;
+                    hc = claim_hash_long(h1, k4, k5, k6, k7);
+                }
+                const bool cand = a.claims != nullptr && (is16 || is32) && len != 0u;
+                const uint32_t slot = claim_slot(hc, a.claim_mask);
+                const uint4 kml = s_kmask[min(len, 16u)];
+                unsigned long long seen = 0ull;
+                Unaligned16 so{0u, 0u, 0u, 0u}, so2{0u, 0u, 0u, 0u};
+                // is the claim `c` this word?  o / o2: the claimant's bytes
+                auto load_claimant = [&](unsigned long long c, Unaligned16& o, Unaligned16& o2) {
+                    o = *(const Unaligned16*)(a.text + (uint32_t)c);                // (readable: the text carries TEXT_PAD bytes of slack)
+                    if (len > 16u) o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
+                };
+                auto same_word = [&](const Unaligned16& o, const Unaligned16& o2) -> bool {
+                    return (((o.a & kml.x) ^ k0) | ((o.b & kml.y) ^ k1) | ((o.c & kml.z) ^ k2) | ((o.d & kml.w) ^ k3) |
+                            ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
+                };
+                const bool spec = cand && a.claim_mode == 3u;
+                if (spec) seen = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (is16) {
                     const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
+                    if (spec && (uint32_t)(seen >> 32) == len) load_claimant(seen, so, so2);
                     const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
                     uint4 a0 = q[0], a1 = q[1];
                     asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
@@ -257,11 +301,25 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                     if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
                         // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
                         // measured 20 % slower (the extra 32-byte reads cost more than the round trip they save)
-                        const uint32_t slot = cache_slot(h1);
-                        const CacheKey* const ck = a.cache_keys + slot;
+                        const uint32_t cslot = cache_slot(h1);
+                        const CacheKey* const ck = a.cache_keys + cslot;
                         const uint4 ckey = *(const uint4*)ck->k;
                         const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
-                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_SLOT | slot; pend = false; }
+                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_SLOT | cslot; pend = false; }
+                    }
+                } else if (spec && (uint32_t)(seen >> 32) == len) {
+                    load_claimant(seen, so, so2);
+                }
+                if (cand && pend) {
+                    // the first occurrence of a word claims the slot and is queued; every other one finds the claim, checks it against the
+                    // claimant's bytes and shares its row.  A slot only ever goes from 0 to its claim: a claim read is final, a 0 is
+                    // followed by the compare-and-swap.  The slot holds another word: queued like before.
+                    unsigned long long c = spec ? seen : __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool have = spec && c != 0ull && (uint32_t)(c >> 32) == len;    // the claimant's bytes are already here
+                    if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
+                    if (c != 0ull && (uint32_t)(c >> 32) == len) {
+                        if (!have) load_claimant(c, so, so2);
+                        if (same_word(so, so2)) { out = TOK_SLOT | slot; pend = false; }
                     }
                 }
                 if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
@@ -310,217 +368,46 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 
 // =================================================================================================
 // In-batch word claims.  Natural text repeats its words: of the pre-tokens the static tables do not settle (13 % on C2) a few
-// percent are distinct.  The reference's per-thread cache exploits that (BPE::tokenize_with_cache, bpe/model.rs:573-586); here, between
-// the lookup and the model kernels, the FIRST occurrence of a word claims a slot of a hash table (K_claims_mark; two slots to choose
-// from; 64-bit entries, 0 = free, else length << 32 | first byte of the claimant) and stay queued; every other occurrence finds the
-// claim, checks it against the claimant's BYTES in the text (immutable: nothing here waits for another lane's writes, and no result
-// depends on which occurrence wins), leaves the queue and points its tok0 at the slot's row.  K_claims_publish copies the claimants'
-// finished rows there after the model kernels; the compaction reads them like cached rows (TOK_SLOT | slot), and
-// k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.  A word that finds both of its slots taken by
-// other words is simply merged every time.  The table is zeroed per batch: no state crosses batches.
-// A slot only ever goes from 0 to its claim, so a read that shows a claim is final.  All reads of the table are device-scope loads (the
-// L2 of an XCD keeps a line it read as 0 whatever another XCD's CAS did since -- tools/microbench/claims_probe.hip: a plain load after a
-// remote store was stale in 63 of 63 workgroups, a device-scope load fresh in all, at the same 140 G probes/s under a Zipf law), and a
-// read of 0 comes before the read-modify-write (a frequent word would otherwise serialise thousands of them on one address).
+// percent are distinct.  The reference's per-thread cache exploits that (BPE::tokenize_with_cache, bpe/model.rs:573-586); here the
+// FIRST occurrence of such a word claims the slot of its hash in a table of 64-bit entries (0 = free, else length << 32 | first byte of
+// the claimant) in pass 2 of k_lookup and is queued for the model kernel; every other occurrence finds the claim, checks it against the
+// claimant's BYTES in the text (immutable: nothing waits for another lane's writes, and no result depends on which occurrence wins),
+// is not queued and points its tok0 at the slot's row (TOK_SLOT | slot).  K_claims_publish copies the claimants' finished rows there
+// after the model kernels; the compaction reads them like the rows of the word cache, and k_token_meta takes the token ends of a
+// shared row from the claimant's slots of tmp_end.  A word whose slot another word holds is simply merged every time.  The table is
+// zeroed per batch: no state crosses batches.
+// Measured on the way here (C2, 2.56 M candidates; tools/microbench/claims_probe.hip, tools/cm_probe.py):
+//   * all reads of the table are device-scope loads: the L2 of an XCD keeps a line it read as 0 whatever another XCD's CAS did since
+//     (a plain load after a remote store was stale in 63 of 63 workgroups, a device-scope load fresh in all);
+//   * the claims as kernels of their own between the lookup and the model kernels (mark the repeats, compact the sub-queues in place)
+//     cost 0.19 ms against 0.06 ms inside the lookup: re-reading the queue entries and keys (0.04), the claim reads (0.05), the
+//     claimants' bytes (0.04), the rank of every repeat for its tok0 word (0.03) -- all of which pass 2 has in registers or in LDS;
+//     four entries per lane made it slower (0.30), a seeding pass for the frequent words changed nothing;
+//   * two slots per word, and a separate chain for the 17..32-byte words, each added a serialised round trip to nearly every step
+//     of pass 2 (a step waits for its slowest lane): one slot, one chain.
 // =================================================================================================
-constexpr uint32_t CLAIM_MAX_LEN = 32u;
-constexpr int CD_NT = 1024;
-__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
-    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
-}
-__device__ __forceinline__ uint32_t claim_slot_a(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
-__device__ __forceinline__ uint32_t claim_slot_b(uint32_t h, uint32_t mask) { return (mix32(h ^ 0x5BD1E995u) >> 5) & mask; }
-// key of a pre-token of <= 32 bytes, zero padded, and its hash: the whole-word table's hash of the first 16 bytes and the whole
-// length, continued over bytes 16..31
-struct ClaimKey { uint64_t k[4]; uint32_t h; };
-__device__ __forceinline__ ClaimKey claim_key_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed) {
-    ClaimKey c;
-    load_key16(text, s, min(len, 16u), &c.k[0], &c.k[1]);
-    c.k[2] = c.k[3] = 0ull;
-    c.h = word_hash1(c.k[0], c.k[1], len, seed);
+// the slot of a queued pre-token of <= 32 bytes, recomputed from the text by the kernels behind the lookup
+__device__ __forceinline__ uint32_t claim_slot_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed, uint32_t mask) {
+    uint64_t lo, hi;
+    load_key16(text, s, min(len, 16u), &lo, &hi);
+    uint32_t h = word_hash1(lo, hi, len, seed);
     if (len > 16u) {
-        load_key16(text, s + 16u, len - 16u, &c.k[2], &c.k[3]);
-        c.h = claim_hash_long(c.h, (uint32_t)c.k[2], (uint32_t)(c.k[2] >> 32), (uint32_t)c.k[3], (uint32_t)(c.k[3] >> 32));
+        uint64_t lo2, hi2;
+        load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
+        h = claim_hash_long(h, (uint32_t)lo2, (uint32_t)(lo2 >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32));
     }
-    return c;
+    return claim_slot(h, mask);
 }
-
-struct ClaimArgs {
-    const uint8_t* text;
-    const unsigned long long* startmask;
-    const uint32_t* wprefix;
-    uint32_t* tok0;
-    QView v[2];                      // the <= 16-byte and the <= 32-byte queue
-    unsigned long long* claims;
-    uint32_t claim_mask, seed;
-    uint32_t debug;                  // timing experiments only (TKAMD_CM_DEBUG): skips parts of k_claims_mark -- results are then WRONG
-};
-
-// Two kernels (measured on C2, 2.56 M queued pre-tokens: one kernel that did both, a 1024-lane workgroup per sub-queue with its claim
-// round trips between the barriers of the compaction, took 0.15 ms -- every round waited for the slowest of 1024 four-deep load chains):
-//   K_claims_mark     no barrier anywhere: a lane takes an entry, runs the claim protocol, and if the word is another entry's it points
-//                     tok0 at the slot and marks the entry dead;
-//   K_claims_compact  one workgroup per sub-queue moves the survivors to the front (the lookup workgroup that filled the sub-queue saw
-//                     a contiguous share of the text, so the reads of the masks for the survivors' tok0 words are nearly sequential) and
-//                     points their tok0 at the new rows: the model kernels see dense queues of distinct words.
-constexpr uint32_t CLAIM_DEAD = 0xFFFFFFFFu;             // length of an entry k_claims_mark retired (never leaves the two kernels)
-constexpr int CM_NT = 256, CM_SPLIT = 8;                 // k_claims_mark: workgroups per sub-queue
-__device__ __forceinline__ uint32_t pretok_rank(const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix, uint32_t s) {
-    const unsigned long long m = startmask[s >> 6];
-    return wprefix[s >> 6] + (uint32_t)__popcll(m & ((1ull << (s & 63u)) - 1ull));
-}
-// A lane runs the protocol for CM_K entries AT ONCE, stage by stage (entries, keys, slots, claimants' bytes, ranks): the first version
-// took one entry through its five dependent round trips before it looked at the next and was bound by exactly that latency
-// (0.18 ms for C2's 2.56 M entries); the loads of a stage are independent of each other and fly together.
-template <int CM_K>
-__global__ __launch_bounds__(CM_NT) void k_claims_mark(ClaimArgs a) {
-    const uint32_t part = blockIdx.x % (uint32_t)CM_SPLIT, sqc = blockIdx.x / (uint32_t)CM_SPLIT;
-    const uint32_t sq = sqc % (uint32_t)NSQ;
-    const bool cls = sqc >= (uint32_t)NSQ;               // grid = 2 NSQ CM_SPLIT: the <= 16-byte queue's sub-queues, then the <= 32-byte queue's
-    // (selects, not indexed loads: the argument arrays stay in scalar registers)
-    QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
-    const uint32_t n = min((cls ? a.v[1].counts : a.v[0].counts)[sq * QCNT_STRIDE], cls ? a.v[1].sq_cap : a.v[0].sq_cap);
-    for (uint32_t base = part * (uint32_t)(CM_NT * CM_K); base < n; base += (uint32_t)(CM_SPLIT * CM_NT * CM_K)) {
-        QItem it[CM_K];
-        bool live[CM_K];
-        // stage 1: the entries
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) {
-            const uint32_t i = base + (uint32_t)k * CM_NT + threadIdx.x;
-            it[k] = q[i < n ? i : 0u];                                           // (n > 0 here: entry 0 exists)
-            live[k] = i < n && it[k].len != 0u && it[k].len <= CLAIM_MAX_LEN;
-        }
-        // stage 2: the keys (a dead lane reads the key of a one-byte word: no branch around the loads)
-        ClaimKey key[CM_K];
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) {
-            const uint32_t len = live[k] ? it[k].len : 1u;
-            load_key16(a.text, it[k].s, min(len, 16u), &key[k].k[0], &key[k].k[1]);
-            key[k].k[2] = key[k].k[3] = 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k)
-            if (live[k] && it[k].len > 16u) load_key16(a.text, it[k].s + 16u, it[k].len - 16u, &key[k].k[2], &key[k].k[3]);       // (few lanes)
-        // stage 3: the first slot of every word
-        uint32_t slot[CM_K];
-        unsigned long long c[CM_K];
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) {
-            key[k].h = word_hash1(key[k].k[0], key[k].k[1], it[k].len, a.seed);
-            if (it[k].len > 16u) key[k].h = claim_hash_long(key[k].h, (uint32_t)key[k].k[2], (uint32_t)(key[k].k[2] >> 32), (uint32_t)key[k].k[3], (uint32_t)(key[k].k[3] >> 32));
-            slot[k] = claim_slot_a(key[k].h, a.claim_mask);
-            c[k] = (a.debug & 1u) ? 0ull : __hip_atomic_load(a.claims + slot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k)
-            if (live[k] && c[k] == 0ull && !(a.debug & 3u)) c[k] = atomicCAS(a.claims + slot[k], 0ull, ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s);
-        // stage 4: a claim that is not this entry's: the same word?  (the claimant's bytes; a lane without such a claim reads its own)
-        uint64_t o[CM_K][4];
-        bool foreign[CM_K], dup[CM_K];
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) {
-            const unsigned long long mine = ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s;
-            foreign[k] = live[k] && c[k] != 0ull && c[k] != mine;                // else: the slot is this entry's, it stays queued
-            const bool cmp = foreign[k] && (uint32_t)(c[k] >> 32) == it[k].len;
-            const uint32_t at = cmp ? (uint32_t)c[k] : it[k].s, len = cmp ? it[k].len : 1u;
-            if (!(a.debug & 4u)) load_key16(a.text, at, min(len, 16u), &o[k][0], &o[k][1]);
-            else { o[k][0] = key[k].k[0]; o[k][1] = key[k].k[1]; }
-            o[k][2] = o[k][3] = 0ull;
-            dup[k] = cmp;
-        }
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k)
-            if (dup[k] && it[k].len > 16u && !(a.debug & 4u)) load_key16(a.text, (uint32_t)c[k] + 16u, it[k].len - 16u, &o[k][2], &o[k][3]);
-            else if (dup[k]) { o[k][2] = key[k].k[2]; o[k][3] = key[k].k[3]; }
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k)
-            dup[k] = dup[k] && ((o[k][0] ^ key[k].k[0]) | (o[k][1] ^ key[k].k[1]) | (o[k][2] ^ key[k].k[2]) | (o[k][3] ^ key[k].k[3])) == 0ull;
-        // stage 5 (few lanes): another word holds the first slot -- the second one, entry by entry
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) {
-            if (foreign[k] && !dup[k] && !(a.debug & 32u)) {
-                const unsigned long long mine = ((unsigned long long)it[k].len << 32) | (unsigned long long)it[k].s;
-                slot[k] = claim_slot_b(key[k].h, a.claim_mask);
-                unsigned long long* const cp = a.claims + slot[k];
-                unsigned long long c2 = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c2 == 0ull) c2 = atomicCAS(cp, 0ull, mine);
-                if (c2 != 0ull && c2 != mine && (uint32_t)(c2 >> 32) == it[k].len) {
-                    uint64_t o2[4] = {0ull, 0ull, 0ull, 0ull};
-                    load_key16(a.text, (uint32_t)c2, min(it[k].len, 16u), &o2[0], &o2[1]);
-                    if (it[k].len > 16u) load_key16(a.text, (uint32_t)c2 + 16u, it[k].len - 16u, &o2[2], &o2[3]);
-                    dup[k] = ((o2[0] ^ key[k].k[0]) | (o2[1] ^ key[k].k[1]) | (o2[2] ^ key[k].k[2]) | (o2[3] ^ key[k].k[3])) == 0ull;
-                }
-            }
-        }
-        // stage 6: the other occurrences leave the queue and point their tok0 at the slot
-        uint32_t p[CM_K];
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) p[k] = (a.debug & 8u) ? 0u : pretok_rank(a.startmask, a.wprefix, it[k].s);      // (every lane: no branch around the loads)
-#pragma unroll
-        for (int k = 0; k < CM_K; ++k) {
-            if (dup[k]) {
-                if (!(a.debug & 8u)) a.tok0[p[k]] = TOK_SLOT | slot[k];
-                if (!(a.debug & 16u)) q[base + (uint32_t)k * CM_NT + threadIdx.x].len = CLAIM_DEAD;
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(CD_NT) void k_claims_compact(ClaimArgs a) {
-    __shared__ uint32_t s_wave[CD_NT / 64];
-    __shared__ uint32_t s_w;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t sq = blockIdx.x % (uint32_t)NSQ;
-    const bool cls = blockIdx.x >= (uint32_t)NSQ;        // grid = 2 NSQ
-    QItem* const q = (cls ? a.v[1].q : a.v[0].q) + (size_t)sq * (cls ? a.v[1].sq_cap : a.v[0].sq_cap);
-    uint32_t* const cnt_p = (cls ? a.v[1].counts : a.v[0].counts) + sq * QCNT_STRIDE;
-    const uint32_t cap = cls ? a.v[1].sq_cap : a.v[0].sq_cap;
-    const uint32_t row0 = (cls ? a.v[1].row_base : a.v[0].row_base) + sq * cap;
-    const uint32_t n = min(*cnt_p, cap);
-    if (tid == 0) s_w = 0u;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += CD_NT) {
-        const uint32_t i = base + tid;
-        QItem it{0u, CLAIM_DEAD};
-        if (i < n) it = q[i];
-        const bool keep = it.len != CLAIM_DEAD;
-        const uint32_t p = keep ? pretok_rank(a.startmask, a.wprefix, it.s) : 0u;      // (its tok0 word: loaded before the barrier, with the entry)
-        __syncthreads();                                     // every entry of this round has been read: survivors may overwrite them
-        const uint64_t kb = __ballot(keep);
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(kb);
-        __syncthreads();
-        uint32_t before = 0u, total = 0u;
-#pragma unroll
-        for (int w = 0; w < CD_NT / 64; ++w) { const uint32_t c = s_wave[w]; before += (uint32_t)w < wave ? c : 0u; total += c; }
-        const uint32_t w0 = s_w;
-        if (keep) {
-            const uint32_t pos = w0 + before + (uint32_t)mbcnt64(kb);      // <= i: never an entry of a later round
-            if (pos != i) {
-                q[pos] = it;
-                a.tok0[p] = TOK_ROW | (row0 + pos);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) s_w = w0 + total;
-    }
-    __syncthreads();
-    if (tid == 0) *cnt_p = s_w;
-}
-
 // =================================================================================================
-// K_claims_publish: after the model kernels, the result row of every queued pre-token that holds the claim of one of its slots is
-// copied to the slot's row, where the compaction finds it for the word's other occurrences.  A row of more than four tokens names its
-// ids by the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.  The two halves of the grid take the two queue classes.
+// K_claims_publish: after the model kernels, the result row of every queued pre-token that holds the claim of its slot is copied to
+// the slot's row, where the compaction finds it for the word's other occurrences.  A row of more than four tokens names its ids by
+// the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.  The two halves of the grid take the two queue classes.
 // =================================================================================================
 __device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len, const uint4& row,
                                                    const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
     if (len == 0u || len > CLAIM_MAX_LEN) return;
-    const uint32_t h = claim_key_of(text, s, len, seed).h;
-    const unsigned long long mine = ((unsigned long long)len << 32) | (unsigned long long)s;
-    const uint32_t sa = claim_slot_a(h, claim_mask);
-    if (claims[sa] == mine) { crows[sa] = row; return; }
-    const uint32_t sb = claim_slot_b(h, claim_mask);
-    if (claims[sb] == mine) crows[sb] = row;
+    const uint32_t slot = claim_slot_of(text, s, len, seed, claim_mask);
+    if (claims[slot] == (((unsigned long long)len << 32) | (unsigned long long)s)) crows[slot] = row;
 }
 __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
                                                         const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
