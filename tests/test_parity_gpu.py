@@ -638,6 +638,39 @@ def test_runs_of_unknown_one_byte_words_grow_the_queue_twice():
     assert got.ids[:50000].tolist() == [0] * 50000
 
 
+@pytest.mark.needs_hw
+def test_two_gigabyte_batch_in_one_pipeline_run(gpt2_json):
+    """Capacity: ONE run of the pipeline over 2.1 GB of text (row indices are 30-bit, byte positions 32-bit: the limit is about 3 GB;
+    it was 1.5 GB while bit 29 of a row index flagged cached rows): 21 copies of a 100 MB corpus, resident, through the device
+    entry.  A size-independent property carries the check -- every copy's ids and token CSR equal the first copy's -- and the first
+    copy's first documents are compared with the oracle."""
+    import torch
+    import tokenizers_amd as ta
+    tok, o = ta.Tokenizer.from_str(gpt2_json, device=0), orc.Oracle(gpt2_json)
+    docs = synth.gen_lines(830_000, text_seed=91)
+    buf, off = ta.pack_documents(docs)
+    n, d, copies = int(off[-1]), len(docs), 21
+    big = np.empty(n * copies + 64, dtype=np.uint8)
+    big_off = np.empty(d * copies + 1, dtype=np.int64)
+    for k in range(copies):
+        big[k * n:(k + 1) * n] = buf[:n]
+        big_off[k * d:(k + 1) * d] = off[:-1] + k * n
+    big[n * copies:] = 0
+    big_off[-1] = n * copies
+    assert n * copies > 2_000_000_000
+    d_text, d_off = torch.from_numpy(big).cuda(), torch.from_numpy(big_off).cuda()
+    b = tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), d * copies, n * copies, stream=torch.cuda.current_stream().cuda_stream).sync()
+    ids = b.ids_tensor().cpu().numpy().view(np.uint32)
+    tok_off = b.tok_offsets_tensor().cpu().numpy()
+    t = int(tok_off[d])
+    assert b.n_tokens == t * copies and len(ids) == t * copies
+    for k in range(1, copies):
+        assert np.array_equal(ids[k * t:(k + 1) * t], ids[:t]), k
+        assert np.array_equal(tok_off[k * d:(k + 1) * d + 1] - k * t, tok_off[:d + 1]), k
+    exp = o.encode_batch(docs[:20000])
+    assert np.array_equal(tok_off[:20001], exp.tok_offsets) and np.array_equal(ids[:int(exp.tok_offsets[-1])], exp.ids)
+
+
 @pytest.mark.parametrize("name", ["gpt2", "bert_wordpiece_4000_specials"])
 def test_encode_file_on_device_vs_oracle(name, gpt2_json, tmp_path):
     """On-disk ingest: Tokenizer.encode_file reads a newline-delimited file in one piece, every line WITH its terminator is a

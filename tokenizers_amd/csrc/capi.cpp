@@ -612,7 +612,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // Everything the batch needs zeroed, in one launch: the scalars, the document mask, the queues' fill counters, the look-back state
     // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default, TKAMD_CLAIMS=0 switches them off
     // for A/B runs; the word cache -- tkamd_word_cache, across batches -- takes their place when it is switched on).
-    static const int claims_mode = [] { const char* e = getenv("TKAMD_CLAIMS"); const int v = e ? atoi(e) : 3; return v == 1 || v == 3 ? v : 0; }();
+    static const int claims_mode = [] { const char* e = getenv("TKAMD_CLAIMS"); const int v = e ? atoi(e) : 1; return v == 1 || v == 3 ? v : 0; }();
     const bool use_claims = claims_mode != 0 && !t->word_cache &&
                             (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
     size_t claim_slots = 0;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     __shared__ uint32_t s_qpre[NSQ + 1];
     __shared__ uint32_t s_qpre2[S == 32 ? NSQ + 1 : 1];    // (only the 32-symbol kernel takes a second queue: two 704-lane workgroups of the 16-symbol one fill a CU's LDS to the last KB)
     constexpr uint32_t PB = (S == 16) ? 4 : 5;
-    HIP_DYNAMIC_SHARED(uint32_t, lds_words)
+    HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint32_t, lds_words)
     uint32_t* s_key = lds_words;                              // [S][NT]
     uint32_t* s_sym = s_key + S * NT;                         // [S][NT], absent when the symbols stay in registers
     uint32_t* s_byte_id = s_sym + (SYM_REGS ? 0 : S * NT);    // [256]
@@ -343,8 +343,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i < 256; i += NT) s_byte_id[i] = t.byte_id[i];
     const bool disp_in_lds = DISP_LDS && t.merge_bmask < (uint32_t)DISP_LDS_MAX;
-    if (disp_in_lds)
-        for (uint32_t i = tid; i <= t.merge_bmask; i += NT) s_disp[i] = t.merge_disp[i];
+    if (disp_in_lds) {
+        // sixteen bytes a load (eight displacements): with thin queues the kernel is as long as its prologue plus one word's chain of
+        // merges, and 2-byte loads made the prologue twenty dependent round trips per lane
+        static_assert((DISP_LDS_MAX * 2) % 16 == 0, "whole 16-byte words");
+        const uint32_t n16 = (t.merge_bmask + 8u) >> 3;                             // (the table is a power of two of entries; the upload is padded)
+        for (uint32_t i = tid; i < n16; i += NT) ((uint4*)s_disp)[i] = ((const uint4*)t.merge_disp)[i];
+    }
     __syncthreads();
     const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
     const uint32_t nid_base = t.newid_base;

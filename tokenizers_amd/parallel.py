@@ -61,8 +61,12 @@ def gather_to_root(ids, tok_offsets, device, root: int = 0, group=None, n_tokens
     dist.all_gather_into_tensor(sizes, mine, group=group)
     sizes = sizes.cpu().view(world, 2).tolist()
     n_tok = sizes[rank][0]
+    if n_tok > int(ids.shape[0]):
+        raise RuntimeError(f"gather_to_root: rank {rank} holds {n_tok} tokens but its ids view has {int(ids.shape[0])} elements")
     ids = ids[:n_tok].contiguous()
-    if os.environ.get("TKAMD_GATHER_CLONE") == "1":          # escape hatch: send from a fresh allocator block instead of the workspace
+    # The message leaves from a fresh allocator block by default: sending straight from the hipMalloc'd workspace (no copy) has run on
+    # one GPU only (TKAMD_GATHER_CLONE=0 selects it; to be made the default once it has run over RCCL on several).
+    if os.environ.get("TKAMD_GATHER_CLONE") != "0":
         ids = ids.clone()
     if rank == root:
         tot_tok = sum(s[0] for s in sizes)

@@ -381,7 +381,9 @@ class DeviceBatch:
     def ids_tensor_unsynced(self):
         """Capacity-sized int32 view of the ids buffer for consumers that are stream-ordered behind the encode and learn the
         token count from :meth:`n_tokens_tensor` (e.g. ``parallel.gather_to_root``): no host synchronisation."""
-        return self._tensor(self._res.d_ids, (max(self._capacity, 1),), "<i4")
+        if not self._capacity:
+            raise TokenizersAmdError("ids_tensor_unsynced: a tokenizer with a truncation / padding section has no static bound of its token count -- sync() and take ids_tensor()")
+        return self._tensor(self._res.d_ids, (self._capacity,), "<i4")
 
     def n_tokens_tensor(self):
         """The token count as a one-element int64 tensor in HBM (valid once the stream has drained)."""
@@ -946,7 +948,11 @@ class Tokenizer:
         res = _lib.DeviceResult()
         _lib.check(self._lib.tkamd_encode_batch_device(self._h, d_text_ptr, d_doc_offsets_ptr, n_docs, n_bytes, flags,
                                                        stream, C.byref(res)))
-        return DeviceBatch(self, res, n_docs, stream, capacity=n_bytes + 4)
+        # upper bound of the token count for the capacity-sized view: a token covers at least one byte of the text the model reads (one
+        # more per document with a ByteLevel prefix space).  A `truncation` / `padding` section runs the epilogue, whose output the
+        # text does not bound (padding writes n_docs x target tokens): no unsynchronised view then.
+        bounded = self.info["truncation"] < 0 and self.info["padding"] == 0
+        return DeviceBatch(self, res, n_docs, stream, capacity=(n_bytes + n_docs + 4) if bounded else 0)
 
     def word_cache(self, enable: bool = True, clear: bool = False) -> None:
         """The device-side counterpart of the reference's per-thread BPE word cache (models/bpe/model.rs:573-586): words of <= 16
