@@ -1291,9 +1291,19 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             HIP_CHECK(hipStreamWaitEvent(st, w->ev_join[i], 0));
         }
     };
+    // the model kernels end an entry by publishing its row if it holds a claim (bpe.hip claim_publish_item); TKAMD_PUBLISH=kernel: a
+    // kernel of its own does it after them (k_claims_publish)
+    static const bool pub_kernel = [] { const char* e = getenv("TKAMD_PUBLISH"); return e && !strcmp(e, "kernel"); }();
+    DevTables mdt = t->dt;
+    bool pub_inline = false;
+    auto set_publish = [&]() {
+        pub_inline = wc.claims && !pub_kernel;
+        if (pub_inline) { mdt.pub_claims = wc.claims; mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; }
+    };
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
         open_word_cache();
+        set_publish();
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
         pf.end();
@@ -1312,15 +1322,15 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         static const bool merge_one = [] { const char* e = getenv("TKAMD_MERGE_ONE"); return !(e && !strcmp(e, "0")); }();
         const bool one = merge_one && wc.claims && lds16 && lds32;
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, t->dt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, one ? &plan.v[0] : nullptr);
+        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, one ? &plan.v[0] : nullptr);
         pf.end();
         if (!one) {
             pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
-            launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), t->dt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+            launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
             pf.end();
         }
         pf.begin("bpe_merge64");
-        launch_bpe_merge(s_c, grid, 64, t->dt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(s_c, grid, 64, mdt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge_long");
         // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
@@ -1333,17 +1343,17 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             w->w_huge.reserve(64);
             w->w_list_huge.reserve(64);
         }
-        launch_bpe_merge_long(s_c, t->n_cu, t->dt, x_text, plan.v[3], w->w_rows.p,
+        launch_bpe_merge_long(s_c, t->n_cu, mdt, x_text, plan.v[3], w->w_rows.p,
                               w->w_tmp_ids.as<uint32_t>(), tmp_end, w->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, w->w_huge.as<uint32_t>(),
                               (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
         join_side();
         if (wc.keys) {
             pf.begin("word_cache_insert");
-            launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
+            launch_word_cache_insert(st, grid, mdt, x_text, plan.v[0], w->w_rows.p, wc);
             pf.end();
         }
-        if (wc.claims) {
+        if (wc.claims && !pub_inline) {
             pf.begin("claims_publish");
             launch_claims_publish(st, t->n_cu * 2, t->dt, x_text, plan, w->w_rows.p, wc);
             pf.end();
@@ -1368,22 +1378,21 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         // (the reference keeps no cache for WordPiece; a word's pieces depend on nothing but the word, so the same table serves. With
         // every word taking the walk -- max_input_chars_per_word < 16 -- the lookup probes nothing, the cache included.)
         if (shortcut) open_word_cache();
+        set_publish();
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u);
         pf.end();
         pf.begin("wordpiece");
-        fork_side();
-        for (int c = 0; c < 4; ++c)
-            launch_wordpiece(c == 0 ? st : (c == 1 ? s_b : s_c), c == 0 ? grid : t->n_cu, c == 0, t->dt, x_text, plan.v[c], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
-        join_side();
+        launch_wordpiece(st, grid, true, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
+        launch_wordpiece_long3(st, t->n_cu, mdt, x_text, plan, w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);      // the words longer than 16 bytes
         pf.end();
         if (wc.keys) {
             pf.begin("word_cache_insert");
             launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
             pf.end();
         }
-        if (wc.claims) {
+        if (wc.claims && !pub_inline) {
             pf.begin("claims_publish");
             launch_claims_publish(st, t->n_cu * 2, t->dt, x_text, plan, w->w_rows.p, wc);
             pf.end();

@@ -16,6 +16,10 @@ struct DevTables {
     const uint16_t* merge_disp;       // bucket displacements
     uint32_t merge_mask, merge_seed, merge_bmask;
     uint32_t newid_affine, newid_base;   // new_id == rank + newid_base for every merge (host-verified)
+    // in-batch claims: set (per call, in the host's copy) when the model kernels publish the claimants' rows themselves (bpe.hip)
+    const unsigned long long* pub_claims;
+    void* pub_rows;
+    uint32_t pub_mask;
     const WordSlot* words;            // perfect-hash table (one slot per key)
     const uint16_t* word_disp;
     uint32_t word_mask, word_seed, word_bmask;
@@ -305,6 +309,7 @@ void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8
                        const WordCache& wc);
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err);
+void launch_wordpiece_long3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs);

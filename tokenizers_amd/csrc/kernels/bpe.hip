@@ -17,6 +17,36 @@ __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uin
     *hi = ((uint64_t)(v.d & m3) << 32) | (v.c & m2);
 }
 
+// ---- in-batch word claims (kernels/lookup.hip has the whole story): hash and slot of a word of <= 32 bytes, and the step every model
+// kernel ends an entry with: a queued pre-token that holds the claim of its slot copies its finished row to the slot's row, where
+// the compaction finds it for the word's other occurrences (a row of more than four tokens names its ids by the claimant's first byte,
+// tmp_ids[s + j]: valid for the whole batch).  The slot is recomputed from the entry's bytes (an L2 hit: the kernel has just read them).
+constexpr uint32_t CLAIM_MAX_LEN = 32u;
+// the whole-word table's hash of the first 16 bytes and the whole length, continued over bytes 16..31 (zero padded)
+__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
+    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
+}
+__device__ __forceinline__ uint32_t claim_slot(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
+__device__ __forceinline__ uint32_t claim_slot_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed, uint32_t mask) {
+    uint64_t lo, hi;
+    load_key16(text, s, min(len, 16u), &lo, &hi);
+    uint32_t h = word_hash1(lo, hi, len, seed);
+    if (len > 16u) {
+        uint64_t lo2, hi2;
+        load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
+        h = claim_hash_long(h, (uint32_t)lo2, (uint32_t)(lo2 >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32));
+    }
+    return claim_slot(h, mask);
+}
+__device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len, const uint4& row,
+                                                   const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
+    if (len == 0u || len > CLAIM_MAX_LEN) return;
+    const uint32_t slot = claim_slot_of(text, s, len, seed, claim_mask);
+    if (claims[slot] == (((unsigned long long)len << 32) | (unsigned long long)s)) crows[slot] = row;
+}
+// (t.pub_claims: set by the host when the model kernels are to publish -- DevTables is what every one of them is handed)
+#define TKAMD_PUBLISH_ROW(t_, text_, s_, len_, row_) do { if ((t_).pub_claims) claim_publish_item((text_), (t_).word_seed, (s_), (len_), (row_), (t_).pub_claims, (t_).pub_mask, (uint4*)(t_).pub_rows); } while (0)
+
 __device__ __forceinline__ bool word_probe_d(const DevTables& t, const uint16_t* disp, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
     uint32_t h1 = word_hash1(lo, hi, len, t.word_seed);
     const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
@@ -142,7 +172,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* _
         bool alive = act && ((am >> c) & 1ull);
         if (valid && alive) {
             uint32_t j = (uint32_t)__popcll(am & ((1ull << c) - 1ull));
-            if (j == 0) rows[v.row_base + pos] = make_row(count, s, id, r1, r2, r3);
+            if (j == 0) { const uint4 row_ = make_row(count, s, id, r1, r2, r3); rows[v.row_base + pos] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
             else if (count > 4u) tmp_ids[s + j] = id;
             if (tmp_end) {
                 uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
             }
         }
         if (valid) {
-            rows[v.row_base + p] = make_row(n, s, ids[0], ids[1], ids[2], ids[3]);
+            { const uint4 row_ = make_row(n, s, ids[0], ids[1], ids[2], ids[3]); rows[v.row_base + p] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
             if (n > 4u) {
 #pragma unroll
                 for (int j = 1; j < S; ++j)
@@ -486,7 +516,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 }
             }
             if (tmp_end) tmp_end[s + c - 1] = len;
-            rows[qidx] = make_row(c, s, r[0], r[1], r[2], r[3]);
+            { const uint4 row_ = make_row(c, s, r[0], r[1], r[2], r[3]); rows[qidx] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
         }
     }
 }

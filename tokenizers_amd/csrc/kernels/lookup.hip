@@ -70,14 +70,7 @@ struct LookupArgs {
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
 
-// ---- in-batch word claims: hash and slot of a word of <= 32 bytes (the section behind k_lookup says what they are for) ----
-constexpr uint32_t CLAIM_MAX_LEN = 32u;
-// the whole-word table's hash of the first 16 bytes and the whole length, continued over bytes 16..31 (zero padded)
-__device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
-    return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
-}
-__device__ __forceinline__ uint32_t claim_slot(uint32_t h, uint32_t mask) { return (word_hash2(h) >> 7) & mask; }
-
+// (claim_hash_long / claim_slot / CLAIM_MAX_LEN: bpe.hip, next to the publish helper the model kernels call)
 template <bool HAS_END>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lu_lds)
@@ -386,29 +379,11 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 //   * two slots per word, and a separate chain for the 17..32-byte words, each added a serialised round trip to nearly every step
 //     of pass 2 (a step waits for its slowest lane): one slot, one chain.
 // =================================================================================================
-// the slot of a queued pre-token of <= 32 bytes, recomputed from the text by the kernels behind the lookup
-__device__ __forceinline__ uint32_t claim_slot_of(const uint8_t* __restrict__ text, uint32_t s, uint32_t len, uint32_t seed, uint32_t mask) {
-    uint64_t lo, hi;
-    load_key16(text, s, min(len, 16u), &lo, &hi);
-    uint32_t h = word_hash1(lo, hi, len, seed);
-    if (len > 16u) {
-        uint64_t lo2, hi2;
-        load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
-        h = claim_hash_long(h, (uint32_t)lo2, (uint32_t)(lo2 >> 32), (uint32_t)hi2, (uint32_t)(hi2 >> 32));
-    }
-    return claim_slot(h, mask);
-}
 // =================================================================================================
-// K_claims_publish: after the model kernels, the result row of every queued pre-token that holds the claim of its slot is copied to
-// the slot's row, where the compaction finds it for the word's other occurrences.  A row of more than four tokens names its ids by
-// the claimant's first byte (tmp_ids[s + j]): valid for the whole batch.  The two halves of the grid take the two queue classes.
+// K_claims_publish (TKAMD_PUBLISH=kernel; by default the model kernels publish their rows themselves, claim_publish_item in bpe.hip):
+// after the model kernels, the result row of every queued pre-token that holds the claim of its slot is copied to the slot's row, where
+// the compaction finds it for the word's other occurrences.  The two halves of the grid take the two queue classes.
 // =================================================================================================
-__device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len, const uint4& row,
-                                                   const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
-    if (len == 0u || len > CLAIM_MAX_LEN) return;
-    const uint32_t slot = claim_slot_of(text, s, len, seed, claim_mask);
-    if (claims[slot] == (((unsigned long long)len << 32) | (unsigned long long)s)) crows[slot] = row;
-}
 __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
                                                         const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
     __shared__ uint32_t s_qpre[NSQ + 1];

@@ -44,11 +44,11 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
 
 // SHORT: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again
 template <bool SHORT>
-__global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
-                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
-    __shared__ uint32_t s_qpre[NSQ + 1];
+__device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t* __restrict__ text, const QView& v, uint4* __restrict__ rows,
+                                               uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
+                                               uint32_t block, uint32_t n_blocks, uint32_t* s_qpre) {
     const uint32_t n = qview_prefix(v, s_qpre);
-    for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
+    for (uint32_t item = block * 256 + threadIdx.x; item < n; item += n_blocks * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
         const uint32_t s = it.s, len = it.len;
@@ -95,6 +95,21 @@ __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* _
             j = 1;
             if (tmp_end) tmp_end[s] = len;
         }
-        rows[v.row_base + qpos] = make_row(j, s, r0, r1, r2, r3);
+        { const uint4 row_ = make_row(j, s, r0, r1, r2, r3); rows[v.row_base + qpos] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
     }
+}
+template <bool SHORT>
+__global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
+                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
+    wordpiece_body<SHORT>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
+}
+// the three queues of words longer than 16 bytes in one launch (a third of the grid each): on natural text they hold a few thousand
+// words between them, and a launch costs more than the walk
+__global__ __launch_bounds__(256) void k_wordpiece_long3(DevTables t, const uint8_t* __restrict__ text, QView v1, QView v2, QView v3, uint4* __restrict__ rows,
+                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
+    __shared__ uint32_t s_qpre[NSQ + 1];
+    const uint32_t third = gridDim.x / 3u, which = min(blockIdx.x / third, 2u);
+    const QView v = which == 0u ? v1 : (which == 1u ? v2 : v3);
+    wordpiece_body<false>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - which * third, which == 2u ? gridDim.x - 2u * third : third, s_qpre);
 }
