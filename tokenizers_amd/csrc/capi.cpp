@@ -612,8 +612,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // Everything the batch needs zeroed, in one launch: the scalars, the document mask, the queues' fill counters, the look-back state
     // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default, TKAMD_CLAIMS=0 switches them off
     // for A/B runs; the word cache -- tkamd_word_cache, across batches -- takes their place when it is switched on).
-    static const int claims_mode = [] { const char* e = getenv("TKAMD_CLAIMS"); const int v = e ? atoi(e) : 1; return v == 1 || v == 3 ? v : 0; }();
-    const bool use_claims = claims_mode != 0 && !t->word_cache &&
+    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
+    const bool use_claims = claims_on && !t->word_cache &&
                             (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
     size_t claim_slots = 0;
     {
@@ -1246,12 +1246,12 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         plan.v[c].row_base = qz.row_base[c];
     }
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
-    WordCache wc{nullptr, nullptr, nullptr, 0u, 0u};
+    WordCache wc{nullptr, nullptr, nullptr, 0u};
     // (claims: see the top of this function; with offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end)
     auto open_word_cache = [&]() {
         const size_t slots = (size_t)1 << WORD_CACHE_BITS;
         if (use_claims) {
-            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(claim_slots - 1), (uint32_t)claims_mode};
+            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(claim_slots - 1)};
             return;
         }
         if (!t->word_cache || off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends)
@@ -1262,7 +1262,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
             w->cache_epoch = epoch;
         }
-        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u, 0u};
+        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u};
     };
     // Fork / join of the side streams: the model kernels of the queue classes are independent of each other.  OFF by default: measured on
     // C2 the two event hand-overs cost more (0.78 ms a step) than running the thinned-out queues one after the other (0.72);
@@ -1364,8 +1364,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u, 0u}, 0u, 1u);
-        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u, 0u});      // words longer than 16 bytes
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u}, 0u, 1u);
+        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u});      // words longer than 16 bytes
         pf.end();
     } else {
         // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): the whole-word lookup

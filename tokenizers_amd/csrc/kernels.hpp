@@ -79,7 +79,6 @@ struct WordCache {
     // pre-token that claimed the slot in THIS batch.  Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
     unsigned long long* claims;
     uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host)
-    uint32_t claim_mode;         // LookupArgs::claim_mode (TKAMD_CLAIMS = 1 / 3)
 };
 
 // buffers zeroed by one launch (launch_zero_regions)

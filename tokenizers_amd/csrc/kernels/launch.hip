@@ -71,7 +71,6 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.cache_keys = wc.keys;
     a.claims = wc.claims;
     a.claim_mask = wc.claim_mask;
-    a.claim_mode = wc.claim_mode;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
     if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);

@@ -64,7 +64,6 @@ struct LookupArgs {
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
-    uint32_t claim_mode;             // 1: the slot is read after the table probe has missed; 3: its read rides along with the table probe
 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
@@ -80,7 +79,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
-    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss;
+    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand;
     __shared__ uint32_t s_fill[4];                                               // fill of this workgroup's sub-queues so far
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t sq = blockIdx.x;                                // this workgroup's PRIVATE sub-queue (the launcher keeps the grid <= NSQ)
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 __syncthreads();
             }
             // ---- 2b. positions of the set bits, by rank (ranks rb .. rb + cnt, the extra one is the next start) ----
-            if (tid == 0) s_nmiss = 0u;
+            if (tid == 0) { s_nmiss = 0u; s_ncand = 0u; }
             if (rbase != 0xFFFFFFFFu) {
                 const uint32_t lo32 = (uint32_t)ms, bit0 = (uint32_t)hword * 64u + (uint32_t)half * 32u;
                 uint32_t r = rbase - rb + (half ? (uint32_t)__popc(lo32) : 0u);
@@ -241,88 +240,9 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 }
             }
             __syncthreads();
-            // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
-            const uint32_t n_miss = s_nmiss;
-            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
-                const bool v = m0 + lane < n_miss;
-                const uint32_t rel = s_miss[v ? m0 + lane : m0];
-                uint32_t s_rel, len, k0, k1, k2, k3;
-                load_key(rel, s_rel, len, k0, k1, k2, k3, true);
-                uint32_t out = 0u;
-                bool pend = v;
-                // In-batch claims (the section behind this kernel): ONE chain for the words of <= 16 and of 17..32 bytes, so that the
-                // lanes of a step wait together.  claim_mode 3: the device-scope read of the word's slot, and then of the claimant's
-                // bytes, fly alongside the displacement -> slot chain of the table probe -- a repeated word costs no further round trip.
-                const bool is16 = v && hits_on && len <= (uint32_t)WORD_MAX_KEY;
-                const bool is32 = a.claims != nullptr && v && len > (uint32_t)WORD_MAX_KEY && len <= CLAIM_MAX_LEN;
-                uint32_t h1 = 0u, k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u;
-                uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
-                if (is16 || is32) h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
-                uint32_t hc = h1;
-                if (is32) {                                                         // (few lanes) bytes 16..31 of the key
-                    const uint32_t wi = (s_rel >> 2) + 4u, sh = s_rel & 3u;
-                    const uint32_t d4 = s_text32[wi], d5 = s_text32[wi + 1], d6 = s_text32[wi + 2], d7 = s_text32[wi + 3], d8 = s_text32[wi + 4];
-                    kmh = s_kmask[len - 16u];
-                    k4 = __builtin_amdgcn_alignbyte(d5, d4, sh) & kmh.x; k5 = __builtin_amdgcn_alignbyte(d6, d5, sh) & kmh.y;
-                    k6 = __builtin_amdgcn_alignbyte(d7, d6, sh) & kmh.z; k7 = __builtin_amdgcn_alignbyte(d8, d7, sh) & kmh.w;
-                    hc = claim_hash_long(h1, k4, k5, k6, k7);
-                }
-                const bool cand = a.claims != nullptr && (is16 || is32) && len != 0u;
-                const uint32_t slot = claim_slot(hc, a.claim_mask);
-                const uint4 kml = s_kmask[min(len, 16u)];
-                unsigned long long seen = 0ull;
-                Unaligned16 so{0u, 0u, 0u, 0u}, so2{0u, 0u, 0u, 0u};
-                // is the claim `c` this word?  o / o2: the claimant's bytes
-                auto load_claimant = [&](unsigned long long c, Unaligned16& o, Unaligned16& o2) {
-                    o = *(const Unaligned16*)(a.text + (uint32_t)c);                // (readable: the text carries TEXT_PAD bytes of slack)
-                    if (len > 16u) o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
-                };
-                auto same_word = [&](const Unaligned16& o, const Unaligned16& o2) -> bool {
-                    return (((o.a & kml.x) ^ k0) | ((o.b & kml.y) ^ k1) | ((o.c & kml.z) ^ k2) | ((o.d & kml.w) ^ k3) |
-                            ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
-                };
-                const bool spec = cand && a.claim_mode == 3u;
-                if (spec) seen = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (is16) {
-                    const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
-                    if (spec && (uint32_t)(seen >> 32) == len) load_claimant(seen, so, so2);
-                    const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
-                    uint4 a0 = q[0], a1 = q[1];
-                    asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
-                    const uint32_t diff = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | (a0.w ^ k3) | (a1.x ^ len);
-                    if (diff == 0u && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
-                    if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
-                        // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
-                        // measured 20 % slower (the extra 32-byte reads cost more than the round trip they save)
-                        const uint32_t cslot = cache_slot(h1);
-                        const CacheKey* const ck = a.cache_keys + cslot;
-                        const uint4 ckey = *(const uint4*)ck->k;
-                        const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
-                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_SLOT | cslot; pend = false; }
-                    }
-                } else if (spec && (uint32_t)(seen >> 32) == len) {
-                    load_claimant(seen, so, so2);
-                }
-                if (cand && pend) {
-                    // the first occurrence of a word claims the slot and is queued; every other one finds the claim, checks it against the
-                    // claimant's bytes and shares its row.  A slot only ever goes from 0 to its claim: a claim read is final, a 0 is
-                    // followed by the compare-and-swap.  The slot holds another word: queued like before.
-                    unsigned long long c = spec ? seen : __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bool have = spec && c != 0ull && (uint32_t)(c >> 32) == len;    // the claimant's bytes are already here
-                    if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
-                    if (c != 0ull && (uint32_t)(c >> 32) == len) {
-                        if (!have) load_claimant(c, so, so2);
-                        if (same_word(so, so2)) { out = TOK_SLOT | slot; pend = false; }
-                    }
-                }
-                if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
-                    if (pend && len <= (uint32_t)WORD_MAX_KEY) {
-                        if (a.has_unk) out = TOK_ONE | a.unk_id;
-                        else atomicOr(a.err, ERR_MISSING_UNK);
-                        pend = false;
-                    }
-                }
-                // still pending: a model kernel's work, queued by length class (<= 16 bytes, <= 32, <= 64, longer)
+            // what pass 2 and pass 3 end a lane with: a pre-token still pending is a model kernel's work, queued by length class
+            // (<= 16 bytes, <= 32, <= 64, longer); its tok0 word names the row, any other lane's its result.  (wavefront-wide: ballots)
+            auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out) {
                 const uint32_t c = len <= 16u ? 0u : (len <= 32u ? 1u : (len <= 64u ? 2u : 3u));
                 const uint64_t b0 = __ballot(pend && c == 0u), b1 = __ballot(pend && c == 1u), b2 = __ballot(pend && c == 2u), b3 = __ballot(pend && c == 3u);
                 if (b0 | b1 | b2 | b3) {                                            // wavefront-uniform
@@ -347,6 +267,114 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                     }
                 }
                 if (v) a.tok0[pbase + rb + rel] = out;
+            };
+            // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
+            // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
+            // slowest lane: inline they doubled the chain of EVERY step for the third of its lanes that are candidates.  Without end
+            // masks there is LDS left for a list of the candidates: pass 2 only notes them, PASS 3 takes them packed 64 to a step --
+            // a third as many steps pay the two round trips.  (With end masks the list does not fit: the claims stay inline.)
+            constexpr bool CAND_PASS = !HAS_END;
+            uint16_t* const s_cand = s_end;                                         // (the end array's place: unused without end masks)
+            // bytes 16..31 of a key of 17..32 bytes, masked; and the hash the word claims with
+            auto long_key = [&](uint32_t s_rel, uint32_t len, uint32_t h16, uint32_t& k4, uint32_t& k5, uint32_t& k6, uint32_t& k7, uint4& kmh) -> uint32_t {
+                const uint32_t wi = (s_rel >> 2) + 4u, sh = s_rel & 3u;
+                const uint32_t d4 = s_text32[wi], d5 = s_text32[wi + 1], d6 = s_text32[wi + 2], d7 = s_text32[wi + 3], d8 = s_text32[wi + 4];
+                kmh = s_kmask[len - 16u];
+                k4 = __builtin_amdgcn_alignbyte(d5, d4, sh) & kmh.x; k5 = __builtin_amdgcn_alignbyte(d6, d5, sh) & kmh.y;
+                k6 = __builtin_amdgcn_alignbyte(d7, d6, sh) & kmh.z; k7 = __builtin_amdgcn_alignbyte(d8, d7, sh) & kmh.w;
+                return claim_hash_long(h16, k4, k5, k6, k7);
+            };
+            // the claim protocol of one candidate: true if the word is another pre-token's (tok0 -> TOK_SLOT | slot), false if this
+            // pre-token now holds the claim or the slot is another word's (queued either way).  The first occurrence of a word claims
+            // the slot; a slot only ever goes from 0 to its claim, so a claim read is final and a 0 is followed by the compare-and-swap.
+            auto claim_word = [&](uint32_t slot, uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3,
+                                  uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7, const uint4& kmh) -> bool {
+                unsigned long long c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
+                if (c == 0ull || (uint32_t)(c >> 32) != len) return false;
+                const uint4 kml = s_kmask[min(len, 16u)];
+                const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c);  // (readable: the text carries TEXT_PAD bytes of slack)
+                Unaligned16 o2{0u, 0u, 0u, 0u};
+                if (len > 16u) o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
+                return (((o.a & kml.x) ^ k0) | ((o.b & kml.y) ^ k1) | ((o.c & kml.z) ^ k2) | ((o.d & kml.w) ^ k3) |
+                        ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
+            };
+            // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
+            const uint32_t n_miss = s_nmiss;
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
+                const bool v = m0 + lane < n_miss;
+                const uint32_t rel = s_miss[v ? m0 + lane : m0];
+                uint32_t s_rel, len, k0, k1, k2, k3;
+                load_key(rel, s_rel, len, k0, k1, k2, k3, true);
+                uint32_t out = 0u;
+                bool pend = v;
+                uint32_t h1 = 0u;
+                if (v && hits_on && len <= (uint32_t)WORD_MAX_KEY) {
+                    h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
+                    const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
+                    const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
+                    uint4 a0 = q[0], a1 = q[1];
+                    asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
+                    const uint32_t diff = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | (a0.w ^ k3) | (a1.x ^ len);
+                    if (diff == 0u && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
+                    if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
+                        // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
+                        // measured 20 % slower (the extra 32-byte reads cost more than the round trip they save)
+                        const uint32_t cslot = cache_slot(h1);
+                        const CacheKey* const ck = a.cache_keys + cslot;
+                        const uint4 ckey = *(const uint4*)ck->k;
+                        const uint32_t cstate = ck->state;                          // (an empty slot has state 0, never a length)
+                        if (((ckey.x ^ k0) | (ckey.y ^ k1) | (ckey.z ^ k2) | (ckey.w ^ k3) | (cstate ^ len)) == 0u) { out = TOK_SLOT | cslot; pend = false; }
+                    }
+                }
+                if (a.miss_is_unk) {                                                // wavefront-uniform: WordLevel (wordlevel/mod.rs:170-177)
+                    if (pend && len <= (uint32_t)WORD_MAX_KEY) {
+                        if (a.has_unk) out = TOK_ONE | a.unk_id;
+                        else atomicOr(a.err, ERR_MISSING_UNK);
+                        pend = false;
+                    }
+                }
+                bool cand = false;
+                if (a.claims) {                                                     // wavefront-uniform
+                    cand = pend && hits_on && len != 0u && len <= CLAIM_MAX_LEN;
+                    if (CAND_PASS) {
+                        const uint64_t cb = __ballot(cand);
+                        if (cb) {                                                   // (wavefront-uniform) the workgroup's candidate list
+                            uint32_t base = 0u;
+                            if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(cb));
+                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                            if (cand) s_cand[base + (uint32_t)mbcnt64(cb)] = (uint16_t)rel;
+                        }
+                    } else if (cand) {
+                        uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u, hc = h1;
+                        uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
+                        if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), k4, k5, k6, k7, kmh);
+                        const uint32_t slot = claim_slot(hc, a.claim_mask);
+                        if (claim_word(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh)) { out = TOK_SLOT | slot; pend = false; }
+                        cand = false;
+                    }
+                }
+                finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
+            }
+            // ---- 5. pass 3: the candidates, packed 64 to a step ----
+            if (CAND_PASS && a.claims) {                                            // wavefront-uniform
+                __syncthreads();
+                const uint32_t n_cand = s_ncand;
+                for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_cand; c0 += (uint32_t)LU_NT) {
+                    const bool v = c0 + lane < n_cand;
+                    const uint32_t rel = s_cand[v ? c0 + lane : c0];
+                    uint32_t s_rel, len, k0, k1, k2, k3;
+                    load_key(rel, s_rel, len, k0, k1, k2, k3, true);
+                    uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u;
+                    uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
+                    uint32_t hc = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
+                    if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, hc, k4, k5, k6, k7, kmh);
+                    const uint32_t slot = claim_slot(hc, a.claim_mask);
+                    uint32_t out = 0u;
+                    bool pend = v;
+                    if (v && claim_word(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh)) { out = TOK_SLOT | slot; pend = false; }
+                    finish(v, pend, rel, s_rel, len, out);
+                }
             }
         }
     }
@@ -363,11 +391,11 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 // In-batch word claims.  Natural text repeats its words: of the pre-tokens the static tables do not settle (13 % on C2) a few
 // percent are distinct.  The reference's per-thread cache exploits that (BPE::tokenize_with_cache, bpe/model.rs:573-586); here the
 // FIRST occurrence of such a word claims the slot of its hash in a table of 64-bit entries (0 = free, else length << 32 | first byte of
-// the claimant) in pass 2 of k_lookup and is queued for the model kernel; every other occurrence finds the claim, checks it against the
-// claimant's BYTES in the text (immutable: nothing waits for another lane's writes, and no result depends on which occurrence wins),
-// is not queued and points its tok0 at the slot's row (TOK_SLOT | slot).  K_claims_publish copies the claimants' finished rows there
-// after the model kernels; the compaction reads them like the rows of the word cache, and k_token_meta takes the token ends of a
-// shared row from the claimant's slots of tmp_end.  A word whose slot another word holds is simply merged every time.  The table is
+// the claimant) in k_lookup (pass 3; inline in pass 2 with end masks) and is queued for the model kernel; every other occurrence finds
+// the claim, checks it against the claimant's BYTES in the text (immutable: nothing waits for another lane's writes, and no result
+// depends on which occurrence wins), is not queued and points its tok0 at the slot's row (TOK_SLOT | slot).  The model kernels copy the
+// claimants' finished rows there (claim_publish_item, bpe.hip); the compaction reads them like the rows of the word cache, and
+// k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.  A word whose slot another word holds is simply merged every time.  The table is
 // zeroed per batch: no state crosses batches.
 // Measured on the way here (C2, 2.56 M candidates; tools/microbench/claims_probe.hip, tools/cm_probe.py):
 //   * all reads of the table are device-scope loads: the L2 of an XCD keeps a line it read as 0 whatever another XCD's CAS did since
@@ -377,7 +405,9 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
 //     claimants' bytes (0.04), the rank of every repeat for its tok0 word (0.03) -- all of which pass 2 has in registers or in LDS;
 //     four entries per lane made it slower (0.30), a seeding pass for the frequent words changed nothing;
 //   * two slots per word, and a separate chain for the 17..32-byte words, each added a serialised round trip to nearly every step
-//     of pass 2 (a step waits for its slowest lane): one slot, one chain.
+//     of pass 2 (a step waits for its slowest lane): one slot, one chain;
+//   * reading the slot alongside the table probe (more device-scope loads, no shorter chain in practice) was slower than reading it
+//     after the probe has missed (0.286 against 0.251 ms).
 // =================================================================================================
 // =================================================================================================
 // K_claims_publish (TKAMD_PUBLISH=kernel; by default the model kernels publish their rows themselves, claim_publish_item in bpe.hip):
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
     }
 }
 
-constexpr int lookup_lds_bytes(bool has_end) { return HOT_SLOTS * 16 + (LU_TILE + LU_TEXT_SLACK) + 16 + (has_end ? 2 : 1) * (LU_POS_CAP + 2) * 2 + LU_POS_CAP * 2; }
+constexpr int lookup_lds_bytes(bool) { return HOT_SLOTS * 16 + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * (LU_POS_CAP + 2) * 2 + LU_POS_CAP * 2; }      // (the end array's place holds the candidate list when there are no end masks)
 
 // =================================================================================================
 // K_word_cache_insert: after the merge kernels, every queued pre-token of <= 16 bytes whose result fits a row (<= 4 tokens) is
