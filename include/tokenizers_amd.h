@@ -294,7 +294,9 @@ int tkamd_encode_special_tokens(tkamd_tokenizer* tok, int value);
  * `enable` != 0: every workspace of the handle keeps a table (1 M entries, in HBM) of the <= 16-byte words its batches have merged
  * (results of <= 4 tokens); later ids-only batches (TKAMD_OFFSETS_NONE) look such a word up instead of merging it again.  Like the
  * reference's cache it only fills, never evicts, and never changes a result.  `clear` != 0: forget everything (every workspace
- * zeroes its table before its next batch).  Off by default. */
+ * zeroes its table before its next batch).  Off by default -- the default is the cache's counterpart WITHIN a batch, which keeps no
+ * state: the first occurrence of a word the static tables do not settle goes to the model kernel, its other occurrences in the same
+ * batch share the result (in-batch claims, csrc/kernels/lookup.hip; with or without offsets).  Switching this cache on replaces them. */
 int tkamd_word_cache(tkamd_tokenizer* tok, int enable, int clear);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
