@@ -141,16 +141,17 @@ def test_results_do_not_depend_on_the_order_the_threads_run_in():
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_a_batch_whose_queue_rows_reach_bit_29_is_refused():
-    """A row index with bit 29 set would be read by the compaction as "this row lives in the word cache": the host refuses the batch
-    before it gets that far (found by this emulation: with its one-CU device the 512 sub-queues of a queue are sized for two lookup
-    workgroups, so a 2.5 MB batch already needs 2^29 rows; on the MI355X that takes about 1.5 GB of text)."""
+def test_a_batch_whose_queue_rows_reach_bit_30_is_refused():
+    """tok0 carries 30 bits of row index (its two top bits say what the word is: an id, a row, a slot): the host refuses a batch whose
+    work queues would need more rows before it gets that far (found by this emulation while bit 29 still flagged cached rows: with
+    its one-CU device the 512 sub-queues of a queue are sized for two lookup workgroups, so a 5 MB batch already needs 2^30 rows; on
+    the MI355X that takes about 3 GB of text)."""
     import tokenizers_amd as ta
     from oracle import synth
     from tests.helpers import load_tokenizer_json
     tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=0)      # (behind BertNormalizer the queues are sized for 3x the text)
-    docs = [d for d in synth.gen_lines(24000, text_seed=13) if d.isascii()]
-    with pytest.raises(ValueError, match="29-bit"):
+    docs = [d for d in synth.gen_lines(48000, text_seed=13) if d.isascii()]
+    with pytest.raises(ValueError, match="30-bit"):
         tok.encode_batch_fast(docs, add_special_tokens=False)
     assert tok.encode_batch_fast(docs[:2000], add_special_tokens=False).n_tokens > 0
 

@@ -289,7 +289,11 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
             // the slot; a slot only ever goes from 0 to its claim, so a claim read is final and a 0 is followed by the compare-and-swap.
             auto claim_word = [&](uint32_t slot, uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3,
                                   uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7, const uint4& kmh) -> bool {
-                unsigned long long c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // A plain (cached) read first: a claim it shows is final, and the repeats of a frequent word then hit the L2 instead of
+                // crossing the fabric each time.  A 0 may be stale (the L2 of an XCD keeps what it read whatever another XCD's CAS did since):
+                // the device-scope read confirms it -- and refreshes the line for the next plain read (tools/microbench/claims_probe.hip).
+                unsigned long long c = a.claims[slot];
+                if (c == 0ull) c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
                 if (c == 0ull || (uint32_t)(c >> 32) != len) return false;
                 const uint4 kml = s_kmask[min(len, 16u)];
