@@ -100,6 +100,39 @@ def test_normalizer_added_vocabulary_and_models(ref_tokenizers):
         P.test_bytelevel_no_regex_vs_oracle()
 
 
+def _emulation_sizes(monkeypatch):
+    """the sizes the -m gpu tests take under TKAMD_SIMT=1 (tests/harness/simt_env.py): the emulation runs one workgroup at a time"""
+    from oracle import synth
+    from tests.harness import simt_env
+    monkeypatch.setenv("TKAMD_SIMT", "1")                  # tests.helpers.N()
+    gen = synth.gen_lines
+    monkeypatch.setattr(synth, "gen_lines", lambda n_lines, *a, **k: gen(simt_env.scale(n_lines), *a, **k))
+
+
+def test_in_batch_claims_token_csr_and_file_ingest(tmp_path, monkeypatch):
+    """round 3: repeated words share one result row (claims in the lookup kernel, rows published by the model kernels, the compaction
+    and the offsets pass following the slot), the compaction writes the documents' token CSR chunk by chunk, encode_file"""
+    from tests import test_parity_gpu as P
+    _emulation_sizes(monkeypatch)
+    for name in ("bytelevel_prefix_trim_3000", "bert_wordpiece_4000_specials") + (("llama3_small_6000_specials",) if FULL else ()):
+        P.test_in_batch_claims_vs_oracle(name, None)
+    for name in ("wordlevel_whitespace_c1", "bytelevel_prefix_trim_3000"):
+        P.test_document_token_csr_corners(name)
+    P.test_encode_file_on_device_vs_oracle("bert_wordpiece_4000_specials", None, tmp_path)
+
+
+def test_one_call_over_a_device_list(monkeypatch):
+    """round 3: the multi-device handle -- shard cuts, host threads, displacements, the host and the peer-copy collect -- with the one
+    emulated device named three times"""
+    from tests import test_multi_device_gpu as M
+    _emulation_sizes(monkeypatch)
+    monkeypatch.setenv("TKAMD_SHARD_MIN_KB", "8")
+    M.test_sharded_call_equals_the_unsharded_call("host", 3)
+    M.test_sharded_call_equals_the_unsharded_call("p2p", 2)
+    M.test_sharded_pairs_truncation_fixed_padding_and_words("bert_wordpiece_4000_specials")
+    M.test_an_error_in_one_shard_fails_the_call_and_the_handle_survives()
+
+
 def test_decode_batch_matches_golden():
     from tests import test_parity_gpu as P
     for k in (range(7) if FULL else (2, 3, 4, 5, 6)):
