@@ -296,7 +296,9 @@ int tkamd_encode_special_tokens(tkamd_tokenizer* tok, int value);
  * reference's cache it only fills, never evicts, and never changes a result.  `clear` != 0: forget everything (every workspace
  * zeroes its table before its next batch).  Off by default -- the default is the cache's counterpart WITHIN a batch, which keeps no
  * state: the first occurrence of a word the static tables do not settle goes to the model kernel, its other occurrences in the same
- * batch share the result (in-batch claims, csrc/kernels/lookup.hip; with or without offsets).  Switching this cache on replaces them. */
+ * batch share the result (in-batch claims, csrc/kernels/lookup.hip; with or without offsets).  Switching this cache on replaces them.
+ * A batch that shared nothing (more than 35 % of its pre-tokens still queued) pauses the claims for the handle's next 32 batches
+ * (TKAMD_CLAIMS_PAUSE, read when the handle is made): on text that never repeats a word they only cost. */
 int tkamd_word_cache(tkamd_tokenizer* tok, int enable, int clear);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------

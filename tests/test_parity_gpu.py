@@ -760,6 +760,37 @@ def test_in_batch_claims_vs_oracle(name, gpt2_json):
     assert np.array_equal(got.ids, exp.ids)
 
 
+def test_claims_pause_while_nothing_is_shared(monkeypatch):
+    """Text that never repeats a word is the claims' worst case (every candidate claims, nothing is shared: DESIGN section 4).  A batch
+    that ran with the claims and left more than 35 % of its pre-tokens in the work queues pauses them for the handle's next batches
+    (TKAMD_CLAIMS_PAUSE of them, 32 by default), after which they are tried again.  Seen from outside: the queue of a repetitive
+    batch holds its distinct words while the claims run and every occurrence while they pause -- and the ids never change."""
+    import tokenizers_amd as ta
+    monkeypatch.setenv("TKAMD_CLAIMS_PAUSE", "3")             # (read when the handle is made)
+    js = load_tokenizer_json("bytelevel_prefix_trim_3000")
+    tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+    rng = np.random.default_rng(78)
+    letters = "qzxjkvwQZXJ"
+    word = lambda: "".join(letters[i] for i in rng.integers(0, len(letters), size=int(rng.integers(5, 12))))
+    few = [word() for _ in range(50)]
+    repetitive = [" ".join(few[i] for i in rng.integers(0, len(few), size=12)) for _ in range(2000)]
+    never = [" ".join(word() for _ in range(12)) for _ in range(3000)]            # 36 k pre-tokens, (almost) all distinct
+    exp_r, exp_n = o.encode_batch(repetitive), o.encode_batch(never)
+
+    def run(docs, exp):
+        got = tok.encode_batch_fast(docs, add_special_tokens=False)
+        assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
+        q = tok.queue_sizes()
+        return q["merge16"] + q["merge32"]
+    n_occ = sum(len(d.split()) for d in repetitive)
+    shared = run(repetitive, exp_r)
+    assert shared * 8 < n_occ                                 # the claims run: the distinct words
+    assert run(never, exp_n) > 30000                          # nothing to share: this batch pauses them ...
+    for _ in range(3):
+        assert run(repetitive, exp_r) >= n_occ                # ... for three batches: every occurrence is queued
+    assert run(repetitive, exp_r) * 8 < n_occ                 # and they are back
+
+
 @pytest.mark.parametrize("name", ["gpt2", "llama3_small_6000_specials", "gpt2_bench_added", "bert_wordpiece_4000_specials"])
 def test_word_cache_never_changes_a_result(name, gpt2_json):
     """tkamd_word_cache: later batches look up the words earlier batches merged (the reference's tokenize_with_cache,

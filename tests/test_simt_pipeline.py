@@ -119,6 +119,7 @@ def test_in_batch_claims_token_csr_and_file_ingest(tmp_path, monkeypatch):
     for name in ("wordlevel_whitespace_c1", "bytelevel_prefix_trim_3000"):
         P.test_document_token_csr_corners(name)
     P.test_encode_file_on_device_vs_oracle("bert_wordpiece_4000_specials", None, tmp_path)
+    P.test_claims_pause_while_nothing_is_shared(monkeypatch)
 
 
 def test_one_call_over_a_device_list(monkeypatch):

@@ -207,6 +207,7 @@ struct Workspace {
     int64_t last_n_enc = -1;                    // encodings of the last call when it materialised overflowing ones, else -1
     int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
+    bool last_used_claims = false;               // the batch enqueued last ran with the in-batch claims
     ~Workspace() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
         for (int i = 0; i < 2; ++i) {
@@ -235,6 +236,11 @@ struct tkamd_tokenizer {
     int n_direct = 0;
     int n_hot = 0;
     int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
+    // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
+    // of the step (the claims' worst case).  A batch that ran with the claims and whose work queues still hold more
+    // than 35 % of its pre-tokens pauses them for the next claims_pause_len batches of the handle; then they are tried again.
+    std::atomic<int> claims_pause{0};
+    int claims_pause_len = 32;   // TKAMD_CLAIMS_PAUSE (0: never pause)
     int cp_items = 4;            // pre-tokens per lane of k_compact: 4 (default: 0.145 ms on C2 against 0.187) or 8 (TKAMD_CP_ITEMS)
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling
@@ -613,8 +619,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default, TKAMD_CLAIMS=0 switches them off
     // for A/B runs; the word cache -- tkamd_word_cache, across batches -- takes their place when it is switched on).
     static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
-    const bool use_claims = claims_on && !t->word_cache &&
-                            (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
+    bool use_claims = claims_on && !t->word_cache &&
+                      (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
+    if (use_claims) {                                      // paused by an earlier batch that shared nothing (read_scalars)? one batch less to go
+        int p = t->claims_pause.load();
+        while (p > 0 && !t->claims_pause.compare_exchange_weak(p, p - 1)) {}
+        if (p > 0) use_claims = false;
+    }
+    w->last_used_claims = use_claims;
     size_t claim_slots = 0;
     {
         ZeroRegions z{};
@@ -1506,8 +1518,16 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
 
 int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
     int64_t host[SC_SLOTS];
+    uint32_t qfill[2 * NSQ * QCNT_STRIDE];                   // fill of the sub-queues of the <= 16- and <= 32-byte classes (the claims' survivors)
+    const bool watch = w->last_used_claims && t->claims_pause_len > 0;
     HIP_CHECK(hipMemcpyAsync(host, w->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
+    if (watch) HIP_CHECK(hipMemcpyAsync(qfill, w->w_qcount.p, sizeof(qfill), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
+    if (watch && host[SC_NPRETOK] >= 32768) {
+        uint64_t survivors = 0;
+        for (int i = 0; i < 2 * NSQ; ++i) survivors += qfill[i * QCNT_STRIDE];
+        if (survivors * 20 > (uint64_t)host[SC_NPRETOK] * 7) t->claims_pause = t->claims_pause_len;     // nothing shared: see tkamd_tokenizer::claims_pause
+    }
     int err = *(int*)&host[SC_ERR] & ~NOTE_REORDER_SEEN;     // (a note of the normalizer, not an error)
     memcpy(w->last_counters, &host[SC_COUNTERS], sizeof(w->last_counters));
     if (n_tok) *n_tok = host[w->last_ntok_slot];
@@ -1633,6 +1653,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (!primary) verify_direct_words(t.get());
         build_hot_table(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
+        if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
         t->cp_grid = compact_grid(t->n_cu, t->cp_items);
         t->devices.push_back(device);
