@@ -368,7 +368,12 @@ def main() -> None:
     single_call = None
     if rank == 0 and world == 1 and not args.no_host and not args.no_single_call:
         try:
-            single_call = single_call_leg(ta, tok_json, batches[0], torch.cuda.device_count(), args.single_call_gpus)
+            if torch.cuda.device_count() < 2:
+                single_call = single_call_leg(ta, tok_json, batches[0].lines, 1, args.single_call_gpus)
+            else:
+                # several GPUs visible: this is the first time the sharded path meets real peers -- in a child process under a
+                # timeout, one JSON line per collect mode, so that a hang costs the leg (what it printed so far is kept), not the line
+                single_call = single_call_child(args.config, batches[0].n_docs, args.type_seed, args.single_call_gpus)
         except Exception as ex:     # never lose the bench line to an auxiliary leg
             single_call = {"error": repr(ex)[:300]}
 
@@ -429,21 +434,27 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def single_call_leg(ta, tok_json: str, batch0, n_visible: int, want: int) -> dict:
-    """One host-entry call over a device list, per collect mode: best of 3 wall clocks of `encode_packed` on n_dev x batch 0."""
+def single_call_items(ta, tok_json: str, lines: list, n_visible: int, want: int):
+    """One host-entry call over a device list, per collect mode: best of 3 wall clocks of `encode_packed` on n_dev x the batch.
+    Yields (key, value) pairs as they are measured."""
     n_dev = want or n_visible
     emulated = n_visible < 2
     devices = [0, 0] if emulated else list(range(min(n_dev, n_visible)))
-    hb0, ho0 = ta.pack_documents(batch0.lines)
+    hb0, ho0 = ta.pack_documents(lines)
+    n_docs = len(lines)
     k = len(devices)
     nb0 = int(ho0[-1])
     hb = np.empty(nb0 * k + 64, dtype=np.uint8)
-    ho = np.empty(batch0.n_docs * k + 1, dtype=np.int64)
-    for r in range(k):                                       # the batch n_dev times over: every device gets batch 0's work
+    ho = np.empty(n_docs * k + 1, dtype=np.int64)
+    for r in range(k):                                       # the batch n_dev times over: every device gets the batch's work
         hb[r * nb0:(r + 1) * nb0] = hb0[:nb0]
-        ho[r * batch0.n_docs:(r + 1) * batch0.n_docs + 1] = ho0 + r * nb0
-    out = {"devices": devices, "emulated_on_one_gpu": emulated, "bytes": nb0 * k, "docs": batch0.n_docs * k, "unit": "GB/s",
-           "what": "wall clock of ONE tkamd_encode_batch (pageable host text in, pinned ids + CSR out) on a multi-device handle, best of 3"}
+        ho[r * n_docs:(r + 1) * n_docs + 1] = ho0 + r * nb0
+    yield "devices", devices
+    yield "emulated_on_one_gpu", emulated
+    yield "bytes", nb0 * k
+    yield "docs", n_docs * k
+    yield "unit", "GB/s"
+    yield "what", "wall clock of ONE tkamd_encode_batch (pageable host text in, pinned ids + CSR out) on a multi-device handle, best of 3"
     one = ta.Tokenizer.from_str(tok_json, device=devices[0])
     one.encode_packed(hb, ho)
     best, ref = float("inf"), None
@@ -451,7 +462,7 @@ def single_call_leg(ta, tok_json: str, batch0, n_visible: int, want: int) -> dic
         t0 = time.perf_counter()
         ref = one.encode_packed(hb, ho)
         best = min(best, time.perf_counter() - t0)
-    out["one_device"] = {"ms": round(best * 1e3, 2), "value": round(nb0 * k / best / 1e9, 3)}
+    yield "one_device", {"ms": round(best * 1e3, 2), "value": round(nb0 * k / best / 1e9, 3)}
     for mode in ("host", "p2p") + (() if emulated else ("rccl",)):
         try:
             many = ta.Tokenizer.from_str(tok_json, device=devices, collect=mode)
@@ -464,12 +475,54 @@ def single_call_leg(ta, tok_json: str, batch0, n_visible: int, want: int) -> dic
             same = res.n_tokens == ref.n_tokens and bool((res.ids == ref.ids).all()) and bool((res.tok_offsets == ref.tok_offsets).all())
             st = many.shard_stats()
             busy = [ms for _, _, ms in st]
-            out[mode] = {"ms": round(best * 1e3, 2), "value": round(nb0 * k / best / 1e9, 3), "equals_one_device": same,
+            yield mode, {"ms": round(best * 1e3, 2), "value": round(nb0 * k / best / 1e9, 3), "equals_one_device": same,
                          "busy_ms_max_over_mean": round(max(busy) / (sum(busy) / len(busy)), 3) if busy else None}
             del many
         except Exception as ex:
-            out[mode] = {"error": repr(ex)[:300]}
-    return out
+            yield mode, {"error": repr(ex)[:300]}
+
+
+def single_call_leg(ta, tok_json: str, lines: list, n_visible: int, want: int) -> dict:
+    return dict(single_call_items(ta, tok_json, lines, n_visible, want))
+
+
+_SINGLE_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import torch
+import bench
+import tokenizers_amd as ta
+tok_json, n_types, _ = bench.load_config(%(config)r)
+lines = bench.make_corpus(%(config)r, %(n)d, 100, %(type_seed)d, n_types)
+for k, v in bench.single_call_items(ta, tok_json, lines, torch.cuda.device_count(), %(want)d):
+    print(json.dumps({k: v}), flush=True)
+"""
+
+
+def single_call_child(config: str, n_lines: int, type_seed: int, want: int, timeout_s: int = 300) -> dict:
+    import subprocess
+    code = _SINGLE_CHILD % {"root": ROOT, "config": config, "n": n_lines, "type_seed": type_seed, "want": want}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out, note = "", None
+    try:
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout_s)
+        out = r.stdout
+        if r.returncode != 0:
+            note = f"child exited with {r.returncode}: {r.stderr[-300:]}"
+    except subprocess.TimeoutExpired as ex:
+        out = ex.stdout.decode() if isinstance(ex.stdout, bytes) else (ex.stdout or "")
+        note = f"child killed after {timeout_s} s (what it had measured by then is kept)"
+    res = {}
+    for line in out.splitlines():
+        line = line.strip()
+        if line.startswith("{"):
+            try:
+                res.update(json.loads(line))
+            except Exception:
+                pass
+    if note:
+        res["note"] = note
+    return res
 
 
 # profile stage (capi.cpp Prof) -> the kernel that dominates it, as rocprofv3 names it (prefix match)
