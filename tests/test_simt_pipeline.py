@@ -122,6 +122,32 @@ def test_in_batch_claims_token_csr_and_file_ingest(tmp_path, monkeypatch):
     P.test_claims_pause_while_nothing_is_shared(monkeypatch)
 
 
+def test_repeated_words_against_the_wheel(ref_tokenizers):
+    """The in-batch claims pinned on the reference itself (not only on the oracle): text made of a few dozen words the vocabulary has
+    never seen, ASCII and not, 2 to 40 bytes, in random order -- ids, char offsets and word ids of every encoding equal the wheel's
+    (the offsets of a repeated word come from the claimant's token ends), with and without special tokens."""
+    import numpy as np
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    rng = np.random.default_rng(79)
+    alpha = list("qzxjkvwQZXJ") + ["\u00e9", "\u4e2d", "\u0416", "\u00df"]
+    word = lambda lo, hi: "".join(alpha[i] for i in rng.integers(0, len(alpha), size=int(rng.integers(lo, hi))))
+    words = [word(2, 12) for _ in range(40)] + [word(12, 30) for _ in range(12)] + ["the", "of", "a"]
+    docs = [" ".join(words[i] for i in rng.integers(0, len(words), size=int(rng.integers(1, 40)))) for _ in range(600)] + ["", words[0]]
+    for name in ("bytelevel_prefix_trim_3000", "bert_wordpiece_4000_specials", "llama3_small_6000_specials", "wordlevel_whitespace_c1"):
+        js = load_tokenizer_json(name)
+        ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
+        for special in (False, True):
+            exp = ref.encode_batch(docs, add_special_tokens=special)
+            got = tok.encode_batch(docs, add_special_tokens=special)
+            for d, (e, g) in enumerate(zip(exp, got)):
+                assert g.ids == e.ids and [tuple(o) for o in g.offsets] == [tuple(o) for o in e.offsets] and g.word_ids == e.word_ids, (name, special, docs[d])
+        if name != "wordlevel_whitespace_c1":                # (WordLevel queues nothing: a miss is the unk id)
+            tok.encode_batch_fast(docs, add_special_tokens=False)
+            q = tok.queue_sizes()
+            assert (q["merge16"] + q["merge32"]) * 6 < sum(len(x.split()) for x in docs), (name, q)      # the distinct words, not their occurrences
+
+
 def test_one_call_over_a_device_list(monkeypatch):
     """round 3: the multi-device handle -- shard cuts, host threads, displacements, the host and the peer-copy collect -- with the one
     emulated device named three times"""
