@@ -32,7 +32,6 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import signal
 import subprocess
 import sys
 import time
@@ -410,7 +409,12 @@ def main() -> None:
     # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
     gather_obj = None
     if (world > 1 or args.force_gather) and not args.no_gather:
-        def on_alarm(signum, frame):          # a collective that never completes must not cost the bench line
+        # A collective that never completes must not cost the bench line.  A watchdog THREAD, not SIGALRM: a rank stuck inside a RCCL
+        # wait sits in C++ with the GIL released, where a Python signal handler never gets to run; a thread does.  Every rank has
+        # one (rank 0 prints the line first), so a hang ends the whole job instead of leaving torchrun waiting on the others.
+        import threading
+
+        def on_timeout():
             finish({"error": "the gather leg did not finish within 180 s"})
             os._exit(0)
 
@@ -418,8 +422,9 @@ def main() -> None:
             b = encode(i)
             gather_to_root(b.ids_tensor_unsynced(), b.tok_offsets_tensor(), dev, n_tokens_dev=b.n_tokens_tensor())
             return b
-        signal.signal(signal.SIGALRM, on_alarm)
-        signal.alarm(180)
+        watchdog = threading.Timer(180.0, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             el_g = timed(step_gather)
             gather_obj = {"ms_per_step": round(el_g / args.steps * 1e3, 4), "value": round(tot_bytes / el_g / 1e9, 3), "unit": "GB/s",
@@ -427,7 +432,7 @@ def main() -> None:
                                   "peer for ids and per-document counts) over RCCL; the root's copy of its own shard included"}
         except Exception as ex:
             gather_obj = {"error": repr(ex)}
-        signal.alarm(0)
+        watchdog.cancel()
     finish(gather_obj)
     if use_dist:
         dist.barrier()
