@@ -214,6 +214,10 @@ typedef struct tkamd_device_result {
                                        d_tok_offsets / d_pad_counts then have n_encodings (+ 1) entries                                        */
     const int64_t*  d_n_encodings;  /* [1] with d_enc_docs, else NULL (the call itself waits for this count: it sizes the result)              */
     const uint32_t* d_enc_parts;    /* TKAMD_WANT_OVERFLOW | TKAMD_PAIRS: [n_encodings][2] window of A / of B, else NULL                       */
+    int64_t         ids_capacity;   /* an upper bound of n_tokens known when the call returns (before the stream has drained): a consumer on
+                                       the same stream may treat d_ids (and the other per-token arrays) as arrays of this many elements and
+                                       read the count from d_n_tokens on the device.  0: no such bound (the padded / overflowing encodings of
+                                       a `truncation` / `padding` section are sized from the data)                                            */
 } tkamd_device_result;
 
 int tkamd_encode_batch_device(tkamd_tokenizer* tok, const uint8_t* d_text, const int64_t* d_doc_offsets,

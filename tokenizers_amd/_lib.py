@@ -54,7 +54,8 @@ class Info(C.Structure):
 class DeviceResult(C.Structure):
     _fields_ = [("d_ids", C.c_void_p), ("d_tok_offsets", C.c_void_p), ("d_offsets", C.c_void_p),
                 ("d_word_ids", C.c_void_p), ("d_n_tokens", C.c_void_p), ("d_n_pretokens", C.c_void_p), ("d_pad_counts", C.c_void_p),
-                ("d_type_ids", C.c_void_p), ("d_seq_ids", C.c_void_p), ("d_enc_docs", C.c_void_p), ("d_n_encodings", C.c_void_p), ("d_enc_parts", C.c_void_p)]
+                ("d_type_ids", C.c_void_p), ("d_seq_ids", C.c_void_p), ("d_enc_docs", C.c_void_p), ("d_n_encodings", C.c_void_p), ("d_enc_parts", C.c_void_p),
+                ("ids_capacity", C.c_int64)]
 
 
 class StageTime(C.Structure):

@@ -79,11 +79,16 @@ struct RcclApi {
 RcclApi& rccl_api() {
     static RcclApi api = [] {
         RcclApi a;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        // TKAMD_RCCL_LIB: another library name to open (tests name one that does not exist: the error path without uninstalling RCCL)
+        const char* const over = getenv("TKAMD_RCCL_LIB");
+        std::string last = "?";
+        for (const char* name : {over ? over : "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
+            if (const char* e = dlerror()) last = e;       // (dlerror() clears the message it returns: read once)
+            if (over) break;
         }
-        if (!a.lib) { a.why = std::string("librccl.so could not be opened: ") + (dlerror() ? dlerror() : "?"); return a; }
+        if (!a.lib) { a.why = std::string("librccl.so could not be opened: ") + last; return a; }
         auto sym = [&](const char* n) { void* p = dlsym(a.lib, n); if (!p && a.why.empty()) a.why = std::string("librccl.so lacks ") + n; return p; };
         a.CommInitAll = (int (*)(void**, int, const int*))sym("ncclCommInitAll");
         a.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
@@ -235,7 +240,7 @@ struct tkamd_tokenizer {
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
-    int cp_grid = 0;             // resident workgroups of k_compact (its look-back needs every workgroup running)
+    int cp_grid = 0;             // grid of k_compact: what is resident at once (chunks go by ticket: any grid makes progress, TKAMD_CP_GRID)
     // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
     // of the step (the claims' worst case).  A batch that ran with the claims and whose work queues still hold more
     // than 35 % of its pre-tokens pauses them for the next claims_pause_len batches of the handle; then they are tried again.
@@ -255,6 +260,7 @@ struct tkamd_tokenizer {
     std::vector<std::unique_ptr<tkamd_tokenizer>> replicas;
     std::mutex group_mu;                 // one sharded call at a time (it already uses every device)
     std::atomic<int> collect{0};         // TKAMD_COLLECT_*
+    std::string collect_note;            // why the handle left TKAMD_COLLECT_ROOT_RCCL for the peer copies (written under group_mu)
     DevBuf g_root[8];                    // COLLECT_ROOT_*: the whole result on devices[0] before its one D2H (indexed like the descriptors of the call)
     std::vector<void*> rccl_comms;       // ncclComm_t per device of the handle (COLLECT_ROOT_RCCL, made at first use)
     int64_t shard_min_bytes = 1 << 20;   // a batch of less than this per device is not worth the threads: it runs on devices[0] (TKAMD_SHARD_MIN_KB, read at load)
@@ -652,6 +658,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_word_ids = nullptr;
     out->d_n_tokens = d_ntok_total;
     out->d_n_pretokens = d_npretok;
+    out->ids_capacity = n_x + 4;          // what w_ids holds (a token covers a byte of the X text); the epilogues below size theirs from the data
     w->last_n_docs = n_docs;
     w->cur_trim1 = nullptr;
     w->last_n_enc = -1;
@@ -703,6 +710,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_add_specials(st, grid, sa);
         pf.end();
         out->d_ids = sa.ids2;
+        out->ids_capacity = (int64_t)T2;
         out->d_tok_offsets = sa.tok_offsets2;
         if (out->d_offsets) out->d_offsets = sa.offsets2;
         if (out->d_word_ids) out->d_word_ids = sa.word_ids2;
@@ -859,6 +867,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             out->d_n_encodings = sc + SC_NENC;
         }
         out->d_ids = pa.ids2;
+        out->ids_capacity = 0;
         out->d_tok_offsets = pa.tok_offsets2;
         if (out->d_offsets) out->d_offsets = pa.offsets2;
         if (out->d_word_ids) out->d_word_ids = pa.word_ids2;
@@ -1000,6 +1009,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             out->d_n_encodings = sc + SC_NENC;
         }
         out->d_ids = fa.ids2;
+        out->ids_capacity = 0;
         out->d_tok_offsets = fa.tok_offsets2;
         if (out->d_offsets) out->d_offsets = fa.offsets2;
         if (out->d_word_ids) out->d_word_ids = fa.word_ids2;
@@ -1656,6 +1666,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
         t->cp_grid = compact_grid(t->n_cu, t->cp_items);
+        if (const char* e = getenv("TKAMD_CP_GRID")) t->cp_grid = std::max(1, atoi(e));      // test hook: an over- / under-subscribed compaction
         t->devices.push_back(device);
     }
     return t;
@@ -1880,7 +1891,7 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
                                int64_t n_seqs, uint32_t flags, tkamd_batch** out) {
     std::lock_guard<std::mutex> group_lock(t->group_mu);
     const int n_dev = (int)t->replicas.size() + 1;
-    const int collect = t->collect;
+    int collect = t->collect;
     const int64_t n_bytes = doc_offsets[n_docs];
     const bool words_in = n_seqs >= 0;
     const int64_t n_grp = words_in ? n_seqs : n_docs;
@@ -1905,16 +1916,31 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
             x.g0 = prev; x.g1 = g;
             x.d0 = doc_of(prev); x.d1 = doc_of(g);
             x.b0 = doc_offsets[x.d0]; x.nb = doc_offsets[x.d1] - x.b0;
-            if (x.nb < 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+            // (the cut points are read from the caller's CSR before the device has validated it: a shard must lie inside the text,
+            // whatever the offsets between the cuts look like -- those are the device validation's business)
+            if (x.nb < 0 || x.b0 < 0 || x.b0 + x.nb > n_bytes) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
             x.n_enc = (g - prev) / unit;
             prev = g;
         }
     }
     if (collect == TKAMD_COLLECT_ROOT_RCCL && t->rccl_comms.empty()) {
+        // RCCL that cannot be opened or initialised is no reason to fail the call: the peer-copy collect moves the same bytes over the
+        // same links.  The handle switches to it for good and says why (once, on stderr, and in tkamd_last_error of no failing call).
         RcclApi& api = rccl_api();
-        if (!api.why.empty()) throw HipError("TKAMD_COLLECT_ROOT_RCCL: " + api.why);
-        t->rccl_comms.assign((size_t)n_dev, nullptr);
-        RCCL_CHECK(api.CommInitAll(t->rccl_comms.data(), n_dev, t->devices.data()));
+        std::string why = api.why;
+        if (why.empty()) {
+            t->rccl_comms.assign((size_t)n_dev, nullptr);
+            const int rc = api.CommInitAll(t->rccl_comms.data(), n_dev, t->devices.data());
+            if (rc != 0) {
+                why = std::string("ncclCommInitAll failed: ") + (api.GetErrorString ? api.GetErrorString(rc) : "?");
+                t->rccl_comms.clear();
+            }
+        }
+        if (!why.empty()) {
+            fprintf(stderr, "[tokenizers_amd] TKAMD_COLLECT_ROOT_RCCL falls back to TKAMD_COLLECT_ROOT_P2P: %s\n", why.c_str());
+            t->collect_note = why;
+            t->collect = collect = TKAMD_COLLECT_ROOT_P2P;
+        }
     }
     std::unique_ptr<tkamd_batch> b(new tkamd_batch());
     b->has_ids16 = ids16;
@@ -2029,20 +2055,27 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
                     }
                     HIP_CHECK(hipEventRecord(x.ev, x.s));
                 } else {
+                    // (every rank got here through `go`: all shards are fine and the displacements are known, so all of them open the
+                    // group.  A group that was opened is closed whatever a send / recv inside it returned -- a rank that left its group
+                    // open would leave the others' receives waiting for ever -- and the first error is reported after that.)
                     RcclApi& api = rccl_api();
+                    int first_bad = 0;
+                    const char* what = "";
+                    auto note = [&](int rc_, const char* w_) { if (rc_ != 0 && first_bad == 0) { first_bad = rc_; what = w_; } };
                     RCCL_CHECK(api.GroupStart());
                     for (size_t q = 0; q < dl.size(); ++q) {
                         const int64_t n = count_of(x, dl[q]);
-                        if (n > 0) RCCL_CHECK(api.Send(dl[q].src, (size_t)n * dl[q].esz, 1 /* ncclUint8 */, 0, t->rccl_comms[(size_t)r], x.s));
+                        if (n > 0) note(api.Send(dl[q].src, (size_t)n * dl[q].esz, 1 /* ncclUint8 */, 0, t->rccl_comms[(size_t)r], x.s), "ncclSend");
                     }
                     if (r == 0)
                         for (int p = 0; p < n_dev; ++p)
                             for (size_t q = 0; q < dl.size(); ++q) {
                                 const ShardDesc& d = desc[(size_t)p][q];
                                 const int64_t n = count_of(sh[(size_t)p], d);
-                                if (n > 0) RCCL_CHECK(api.Recv((uint8_t*)t->g_root[q].p + (size_t)base_of(sh[(size_t)p], d) * d.esz, (size_t)n * d.esz, 1, p, t->rccl_comms[0], x.s));
+                                if (n > 0) note(api.Recv((uint8_t*)t->g_root[q].p + (size_t)base_of(sh[(size_t)p], d) * d.esz, (size_t)n * d.esz, 1, p, t->rccl_comms[0], x.s), "ncclRecv");
                             }
-                    RCCL_CHECK(api.GroupEnd());
+                    note(api.GroupEnd(), "ncclGroupEnd");
+                    if (first_bad) throw HipError(std::string(what) + " failed: " + (api.GetErrorString ? api.GetErrorString(first_bad) : "?"));
                 }
                 return TKAMD_OK;
             });
@@ -2051,7 +2084,8 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
         if (collect != TKAMD_COLLECT_HOST) {
             rv.arrive();
             bool ok = go;
-            for (const Shard& y : sh) ok = ok && y.rc == TKAMD_OK;
+            if (r == 0)                                   // (only the root looks: it is also the one thread that writes an rc from here on)
+                for (const Shard& y : sh) ok = ok && y.rc == TKAMD_OK;
             if (r == 0 && ok) {
                 x.rc = guarded([&]() -> int {
                     HIP_CHECK(hipSetDevice(t->device));
@@ -2543,6 +2577,14 @@ int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_sta
     if (t->device >= 0 && !g_forked) {
         (void)hipSetDevice(t->device);
         for (auto& w : t->pool) drain_profile(t, w.get());
+        // a multi-device handle: the shards' stages ran on the replicas' workspaces; their events are read (and destroyed) on their own
+        // device and folded into the one table of the handle -- a stage's time is then the sum over the devices
+        for (auto& r : t->replicas) {
+            std::lock_guard<std::mutex> rl(r->mu);
+            (void)hipSetDevice(r->device);
+            for (auto& w : r->pool) drain_profile(t, w.get());
+        }
+        if (!t->replicas.empty()) (void)hipSetDevice(t->device);
     }
     int n = (int)std::min<size_t>(t->acc.size(), (size_t)std::max(0, max_stages));
     for (int i = 0; i < n && stages; ++i) stages[i] = t->acc[i];

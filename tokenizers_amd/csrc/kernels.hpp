@@ -362,8 +362,9 @@ int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                            uint32_t* tmp_ids, uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge,
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
-// single-pass compaction; `state` (8 bytes per 2048 pre-tokens) must be zero on entry; pt_tokoff may be null.  The grid is
-// compact_grid(n_cu): every workgroup must be resident (a chunk waits for its predecessors' totals).
+// single-pass compaction; `state` (8 bytes: the chunk ticket, then 8 bytes per chunk of 256 x cp_items pre-tokens) must be zero on
+// entry; pt_tokoff may be null.  Any grid works (chunks are handed out by ticket: kernels/output.hip); compact_grid(n_cu) -- what is
+// resident at once -- is the one that wastes no launches.
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,

@@ -13,8 +13,16 @@
 // A workgroup runs front(c_next) before back(c): the look-back round trips hide behind a whole chunk of work (measured: the
 // un-pipelined kernel spent 45 % of its time in them).  Two LDS buffers alternate.  A chunk whose tokens do not fit the buffer
 // (> CP_STAGE: only text made of many-token pre-tokens) is scattered straight from its rows in back().
-// Chunks go round robin over a grid of RESIDENT workgroups (launcher), so the owner of any earlier chunk is running or
-// done: front() never waits, back(c) only needs totals that earlier front() calls publish -- no deadlock.
+// Chunks are handed out by TICKET (one counter per launch, state[0]; the chunks' look-back words follow it): a workgroup draws the
+// number of its next chunk when it needs one.  Forward progress then needs NO assumption about which workgroups are resident --
+// the reference's encode_batch is &self + Send + Sync (tokenizer/mod.rs:1328-1348): any number of callers, two compactions on two
+// streams each holding half the chip included.  Why: a ticket is only ever held, unpublished, by a workgroup that has STARTED;
+// front() waits for nothing; and a workgroup holds at most one drawn ticket it has not yet run front() on (the one drawn an
+// iteration early, so that the atomic's round trip hides behind a whole chunk of work) while it sits in back(c) of an OLDER
+// ticket.  Take the smallest ticket m whose total is not published: its holder is at most waiting in back(c) for some c < m,
+// i.e. for totals of tickets < c < m, which are all published -- it gets out, and front(m) comes next.  So every wait ends.
+// (The static round-robin hand-out this replaces, chunk = blockIdx + k * gridDim, needed every workgroup of the grid resident:
+// a predecessor could belong to a workgroup the hardware had not scheduled yet.)
 // =================================================================================================
 // Two shapes: 8 pre-tokens per lane (chunks of 2048, 56 KB of LDS: two workgroups per CU) and 4 (chunks of 1024, 28 KB and half the
 // registers: five workgroups per CU -- more chunks in flight to hide the load -> rows -> look-back chain of each); the host picks one
@@ -101,7 +109,9 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
     __shared__ uint32_t s_stage[2][CP_STAGE];
     __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
     __shared__ uint32_t s_tot[2];
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_tk[2];
+    unsigned long long* const ticket = state;             // the next chunk to hand out (zeroed with the look-back words, which follow)
+    unsigned long long* const lb = state + 1;
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     const int tid = (int)threadIdx.x;
@@ -121,7 +131,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
-        if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
+        if (tid == 0) { lb_publish(lb, ch, (unsigned long long)tot); s_tot[b] = tot; }
         uint32_t acc = ex;
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) { s_loc[b][tid * CP_ITEMS + k] = acc; acc += r.cnt[k]; }
@@ -131,15 +141,25 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
             TKAMD_CP_SCATTER(dst, r, o)
         }
     };
+    // lane 0 draws; the value reaches the others through s_tk.  (A workgroup stops drawing once it has seen the end: the counter
+    // overshoots n_chunks by at most two per workgroup.)
+    auto draw = [&]() -> unsigned long long { return tid == 0 ? atomicAdd(ticket, 1ull) : 0ull; };
+    {
+        const unsigned long long d0 = draw(), d1 = draw();
+        if (tid == 0) { s_tk[0] = d0; s_tk[1] = d1; }
+    }
+    __syncthreads();
+    int64_t ch = (int64_t)s_tk[0], nxt = (int64_t)s_tk[1];
     int b = 0;
-    if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0);
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
-        const int64_t nxt = ch + gridDim.x;
+    if (ch < n_chunks) front(ch, 0);
+    for (; ch < n_chunks; b ^= 1) {
+        // the ticket of the iteration AFTER next: issued here, read at the bottom of the loop
+        const unsigned long long after = nxt < n_chunks ? draw() : (unsigned long long)n_chunks;
         if (nxt < n_chunks) front(nxt, b ^ 1);            // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
         const uint32_t tot = s_tot[b];
         if (tid < 64) {                                    // wavefront 0 resolves the chunk's place in the token stream
-            const unsigned long long base = lb_resolve(state, ch, (unsigned long long)tot);
+            const unsigned long long base = lb_resolve(lb, ch, (unsigned long long)tot);
             if (tid == 0) s_base = base;
         }
         __syncthreads();
@@ -170,7 +190,10 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
             uint32_t* const dst = ids + base;
             TKAMD_CP_SCATTER(dst, r, o)
         }
+        if (tid == 0) s_tk[0] = after;
         __syncthreads();                                   // buffer b is free for front() of the chunk after next
+        ch = nxt;
+        nxt = (int64_t)s_tk[0];                            // (rewritten only behind the barriers of the next front())
     }
 }
 #undef TKAMD_CP_SCATTER

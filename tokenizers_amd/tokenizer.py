@@ -948,11 +948,11 @@ class Tokenizer:
         res = _lib.DeviceResult()
         _lib.check(self._lib.tkamd_encode_batch_device(self._h, d_text_ptr, d_doc_offsets_ptr, n_docs, n_bytes, flags,
                                                        stream, C.byref(res)))
-        # upper bound of the token count for the capacity-sized view: a token covers at least one byte of the text the model reads (one
-        # more per document with a ByteLevel prefix space).  A `truncation` / `padding` section runs the epilogue, whose output the
-        # text does not bound (padding writes n_docs x target tokens): no unsynchronised view then.
-        bounded = self.info["truncation"] < 0 and self.info["padding"] == 0
-        return DeviceBatch(self, res, n_docs, stream, capacity=(n_bytes + n_docs + 4) if bounded else 0)
+        # upper bound of the token count for the capacity-sized view: the library's own (a token covers at least one byte of the text
+        # the model reads -- the input plus a ByteLevel prefix space per piece, i.e. per document and per added-token match).  A
+        # `truncation` / `padding` section runs the epilogue, whose output the text does not bound: the library reports 0, no
+        # unsynchronised view then.
+        return DeviceBatch(self, res, n_docs, stream, capacity=int(res.ids_capacity))
 
     def word_cache(self, enable: bool = True, clear: bool = False) -> None:
         """The device-side counterpart of the reference's per-thread BPE word cache (models/bpe/model.rs:573-586): words of <= 16

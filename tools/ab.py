@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""A/B of kernel variants on one config (developer loop; bench.py is the measurement of record).
+
+  python tools/ab.py c2 [--ood] [--steps 20] [--lines 1000000] -- "" "TKAMD_X=1" "TKAMD_X=1 TKAMD_Y=2" ...
+
+The corpus (three rotating batches, like bench.py) is generated and packed ONCE into /tmp; every variant is a child process
+with its environment variables that loads the packed batches (seconds instead of half a minute of corpus generation), checks
+a 1 % sample of every batch against the oracle AND the whole result against the first variant's checksums, times K rotating
+steps and prints the per-kernel HIP-event times.  One line per variant on stdout, JSON lines into --out."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def cache_paths(cfg, ts, n, k):
+    d = os.environ.get("TKAMD_AB_CACHE", "/tmp/tkamd_ab")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, f"{cfg}_ts{ts}_n{n}_b{k}")
+
+
+def ensure_corpus(cfg, ts, n, n_batches):
+    import numpy as np
+    import bench
+    import tokenizers_amd as ta
+    js, n_types, _ = bench.load_config(cfg)
+    for k in range(n_batches):
+        p = cache_paths(cfg, ts, n, k)
+        if os.path.exists(p + ".sample.json"):
+            continue
+        lines = bench.make_corpus(cfg, n, 100 + 1000 * k, ts, n_types)
+        buf, off = ta.pack_documents(lines)
+        np.save(p + ".buf.npy", buf)
+        np.save(p + ".off.npy", off)
+        idx = list(range(0, len(lines), 100))
+        with open(p + ".sample.json", "w") as fh:
+            json.dump({"idx": idx, "docs": [lines[i] for i in idx]}, fh)
+
+
+def child(cfg, ts, n, n_batches, steps, ref_path):
+    import numpy as np
+    import torch
+    import bench
+    import tokenizers_amd as ta
+    from oracle import oracle as orc
+    js, _, _ = bench.load_config(cfg)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    class B:
+        pass
+    bs = []
+    for k in range(n_batches):
+        p = cache_paths(cfg, ts, n, k)
+        b = B()
+        buf, off = np.load(p + ".buf.npy"), np.load(p + ".off.npy")
+        b.n_docs, b.n_bytes = len(off) - 1, int(off[-1])
+        b.d_text, b.d_off = torch.from_numpy(buf).to(dev), torch.from_numpy(off).to(dev)
+        with open(p + ".sample.json") as fh:
+            s = json.load(fh)
+        b.sample_idx, b.sample = s["idx"], s["docs"]
+        bs.append(b)
+    for b in bs:
+        bench.check_against_oracle(tok, o, b, stream)
+    sums = [list(b.checksum) for b in bs]
+    if ref_path and os.path.exists(ref_path):
+        with open(ref_path) as fh:
+            assert json.load(fh) == sums, "the result differs from the first variant's"
+    elif ref_path:
+        with open(ref_path, "w") as fh:
+            json.dump(sums, fh)
+    enc = lambda i: tok.encode_batch_device(bs[i % n_batches].d_text.data_ptr(), bs[i % n_batches].d_off.data_ptr(), bs[i % n_batches].n_docs,
+                                            bs[i % n_batches].n_bytes, stream=stream)
+    best = float("inf")
+    for rep in range(3):
+        for i in range(3):
+            enc(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            r = enc(i)
+        r.sync()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / steps)
+    assert list(bench.result_checksum(r)) == sums[(steps - 1) % n_batches], "a timed step's result differs from the gated one"
+    tok.profile(True)
+    for i in range(steps):
+        enc(i)
+    enc(0).sync()
+    tok.profile(False)
+    st = {k: round(v[0] / max(1, v[1]), 4) for k, v in tok.profile_read().items()}
+    nb = sum(b.n_bytes for b in bs) / n_batches
+    print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("TKAMD_") and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
+                                     "gbps": round(nb / best / 1e9, 2), "ms": round(best * 1e3, 4), "sum_kernels_ms": round(sum(st.values()), 4),
+                                     "kernels_ms": {k: v for k, v in sorted(st.items(), key=lambda kv: -kv[1]) if v >= 0.003}, "queues": tok.queue_sizes()}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cfg", nargs="?", default="c2")
+    ap.add_argument("--ood", action="store_true", help="type seed 1: word types the vocabulary never saw")
+    ap.add_argument("--steps", type=int, default=21)
+    ap.add_argument("--lines", type=int, default=1_000_000)
+    ap.add_argument("--batches", type=int, default=3)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--child", action="store_true")
+    ap.add_argument("--ref", default="")
+    ap.add_argument("variants", nargs="*", help='each one a string of VAR=value pairs ("" = the defaults)')
+    a = ap.parse_args()
+    ts = 1 if a.ood else 0
+    if a.child:
+        child(a.cfg, ts, a.lines, a.batches, a.steps, a.ref)
+        return
+    t0 = time.time()
+    ensure_corpus(a.cfg, ts, a.lines, a.batches)
+    print(f"[ab] corpus ready in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
+    ref = cache_paths(a.cfg, ts, a.lines, 0) + f".ref{os.getpid()}.json"
+    for v in (a.variants or [""]):
+        env = dict(os.environ)
+        for kv in v.split():
+            k, _, val = kv.partition("=")
+            env[k] = val
+        cmd = [sys.executable, os.path.abspath(__file__), a.cfg, "--child", "--steps", str(a.steps), "--lines", str(a.lines), "--batches", str(a.batches), "--ref", ref] + (["--ood"] if a.ood else [])
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+            line = next((ln for ln in r.stdout.splitlines() if ln.startswith("AB_RESULT ")), None)
+        except subprocess.TimeoutExpired:
+            r, line = None, None
+        if line is None:
+            print(f"[{v}] FAILED: {(r.stdout[-600:] + r.stderr[-1200:]) if r else 'timeout'}", flush=True)
+            continue
+        j = json.loads(line[len("AB_RESULT "):])
+        print(f"[{v or 'default'}] {j['gbps']} GB/s {j['ms']} ms  sum {j['sum_kernels_ms']}  {j['kernels_ms']}  q={j['queues']}", flush=True)
+        if a.out:
+            with open(a.out, "a") as fh:
+                fh.write(json.dumps(j) + "\n")
+    if os.path.exists(ref):
+        os.remove(ref)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,7 @@ if [ "$2" != "skip-pytest" ]; then
 fi
 pmc() {   # FETCH_SIZE and WRITE_SIZE in separate passes (the guide's rule)
   local c=$1
-  local B="python bench.py --config $c --no-cpu-baseline --no-ood --no-host --no-word-cache --no-single-call --steps 3 --warmup 1"
+  local B="python bench.py --config $c --no-cpu-baseline --no-ood --no-host --no-word-cache --no-single-call --also none --steps 3 --warmup 1"
   timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/pmc_fetch_$c" -- $B > "$O/pmc_fetch_$c.log" 2>&1; echo "pmc fetch $c rc=$?"
   timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/pmc_write_$c" -- $B > "$O/pmc_write_$c.log" 2>&1; echo "pmc write $c rc=$?"
   local F=$(ls $O/pmc_fetch_$c/*/*counter_collection.csv 2>/dev/null | head -1); local W=$(ls $O/pmc_write_$c/*/*counter_collection.csv 2>/dev/null | head -1)
@@ -26,7 +26,7 @@ pmc() {   # FETCH_SIZE and WRITE_SIZE in separate passes (the guide's rule)
 }
 stats() {
   local c=$1
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$c" -- python bench.py --config $c --no-cpu-baseline --no-ood --no-host --no-word-cache --no-single-call --steps 10 --warmup 2 > "$O/stats_$c.log" 2>&1; echo "stats $c rc=$?"
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$c" -- python bench.py --config $c --no-cpu-baseline --no-ood --no-host --no-word-cache --no-single-call --also none --steps 10 --warmup 2 > "$O/stats_$c.log" 2>&1; echo "stats $c rc=$?"
   local S=$(ls $O/stats_$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp "$S" "$O/${c}_kernel_stats.csv"
   rm -rf "$O/stats_$c"
 }
