@@ -322,6 +322,14 @@ int tkamd_profile_read(tkamd_tokenizer* tok, tkamd_stage_time* stages, int max_s
  * kernel, out[1] = to the 64-lane kernel, out[2] = to the workgroup (long) kernel. */
 int tkamd_profile_counters(tkamd_tokenizer* tok, uint32_t* out, int n);
 
+/* Where the two longest kernels spend their time.  With TKAMD_PHASES=1 in the environment (read once per process) the whole-word
+ * lookup (which = 0) and the token compaction (which = 1) run as diagnostic instantiations that stamp the shader clock behind the
+ * barriers that end their phases; out[0..7] = ticks summed over all workgroups and batches since the last reset
+ * (lookup: 0 staging a tile, 1 expanding the mask bits, 2 pass 1 (LDS hot table), 3 pass 2 (perfect hash), 4 pass 3 (claims) +
+ * waiting for the slowest wavefront; compaction: 0 loads + scan + publish, 1 LDS scatter, 2 look-back wait, 3 copy-out; 7 = the
+ * whole kernel, both).  All zero without the variable.  A development aid: never set it in a measured run. */
+int tkamd_debug_phases(tkamd_tokenizer* tok, int which, uint64_t* out, int reset);
+
 /* Library version string, e.g. "tokenizers_amd 0.1.0 (gfx950)". */
 const char* tkamd_version(void);
 

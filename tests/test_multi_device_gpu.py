@@ -130,6 +130,32 @@ def test_devices_from_the_environment(monkeypatch):
         ta.Tokenizer.from_str(js, device=[0, 0], collect="rccl")
 
 
+def test_rccl_that_cannot_be_opened_falls_back_to_peer_copies():
+    """collect="rccl" on a box whose librccl.so cannot be opened (here: TKAMD_RCCL_LIB names a file that is not there) must not fail
+    the call, let alone the process (dlerror() returns its message ONCE): the handle says why on stderr, switches to the peer-copy
+    collect -- the same bytes over the same links -- and the result is the unsharded call's."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, tokenizers_amd as ta\n"
+        "from oracle import synth\n"
+        "from tests.helpers import load_tokenizer_json\n"
+        "js = load_tokenizer_json('bytelevel_prefix_trim_3000')\n"
+        "docs = synth.gen_lines(20000, text_seed=305) + ['', 'x' * 30000]\n"
+        "one = ta.Tokenizer.from_str(js, device=0).encode_batch_csr(docs, offsets='byte')\n"
+        "many = ta.Tokenizer.from_str(js, device=[0, 0, 0], collect='rccl')\n"
+        "for _ in range(2):\n"
+        "    got = many.encode_batch_csr(docs, offsets='byte')\n"
+        "    assert np.array_equal(got.ids, one.ids) and np.array_equal(got.tok_offsets, one.tok_offsets) and np.array_equal(got.offsets, one.offsets)\n"
+        "assert len(many.shard_stats()) == 3\n"
+        "print('FALLBACK_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_RCCL_LIB="/nonexistent/librccl.so", TKAMD_SHARD_MIN_KB="8"),
+                       capture_output=True, text=True, timeout=600)
+    assert "FALLBACK_OK" in r.stdout, r.stdout + r.stderr
+    assert r.stderr.count("falls back to TKAMD_COLLECT_ROOT_P2P") == 1 and "could not be opened" in r.stderr, r.stderr
+
+
 @pytest.mark.needs_hw
 def test_rccl_collect_on_one_rank():
     """TKAMD_COLLECT_ROOT_RCCL with a one-device list: ncclCommInitAll over [0], rank 0's shard travels through ncclSend / ncclRecv to

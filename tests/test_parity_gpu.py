@@ -333,7 +333,8 @@ def test_encode_batch_matches_golden_char_offsets(name):
     {"TKAMD_PRETOK": "lds", "TKAMD_MERGE16": "lane", "TKAMD_LDSCFG": "1"},     # lane-per-byte pre-tokenizer, register lane16, LDS lane32
     {"TKAMD_Q16_DIV": "100000"},                                                # a work queue far too small: the batch overflows it and is run again
     {"TKAMD_CLAIMS": "0"},                                                      # every occurrence of a word goes to the model kernels
-], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims"])
+    {"TKAMD_LEAN_PROLOGUE": "0", "TKAMD_SCAN1": "0", "TKAMD_LU_FILL": "1"},     # validate / sanitize / mark as kernels of their own, the three-launch mask scan, whole rows of tok0 from pass 1
+], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue-scan3"])
 def test_alternative_kernels_agree(gpt2_json, variant):
     """The A/B kernel variants (the fallbacks for vocabularies whose new ids are not rank + c, and the earlier generations
     of the pre-tokenizer) must give the same ids and offsets as the oracle: run them in a subprocess because the
@@ -946,3 +947,28 @@ def test_encode_special_tokens_leaves_special_tokens_in_the_text(ref_tokenizers)
         ref.enable_truncation(64)
         assert tok.encode_special_tokens is True
         assert [e.ids for e in ref.encode_batch(docs, add_special_tokens=False)] == [e.ids for e in tok.encode_batch(docs, add_special_tokens=False)]
+
+
+@pytest.mark.parametrize("name", ["gpt2", "bert_wordpiece_4000_specials"])
+def test_a_malformed_document_csr_is_reported_not_dereferenced(name, gpt2_json):
+    """doc_offsets is validated ON THE DEVICE before any stage trusts it (k_mark_doc_starts; the later stages read a validated copy --
+    written by k_sanitize_csr, or on the plain GPT-2 path by k_doc_first_pretok): interior offsets that run backwards, leave the text
+    or are negative fail the batch with the CSR message, nothing is read out of bounds (the SIMT build's poisoned device range and
+    its AddressSanitizer variant would say so), and the handle encodes the next batch as if nothing had happened."""
+    import tokenizers_amd as ta
+    js = gpt2_json if name == "gpt2" else load_tokenizer_json(name)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    docs = synth.gen_lines(3000, text_seed=17)
+    buf, off = ta.pack_documents(docs)
+    want = tok.encode_packed(buf, off)
+    want = (np.array(want.ids, copy=True), np.array(want.tok_offsets, copy=True))
+    n, d = int(off[-1]), len(docs)
+    for where, value in ((d // 2, int(off[d // 2 - 1]) - 7), (10, n + 4096), (d - 1, -5), (1, int(off[2]) + 1), (2 * d // 3, 1 << 40)):
+        bad = off.copy()
+        bad[where] = value
+        with pytest.raises(ValueError, match="monotone CSR"):
+            tok.encode_packed(buf, bad)
+        with pytest.raises(ValueError, match="monotone CSR"):
+            tok.encode_packed(buf, bad, offsets="byte", word_ids=True)
+    got = tok.encode_packed(buf, off)
+    assert np.array_equal(got.ids, want[0]) and np.array_equal(got.tok_offsets, want[1])

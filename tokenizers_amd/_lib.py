@@ -39,7 +39,7 @@ SYMBOLS = [
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
     "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16", "tkamd_encode_special_tokens",
-    "tkamd_tokenizer_from_json_devices", "tkamd_tokenizer_set_collect", "tkamd_tokenizer_devices", "tkamd_shard_stats",
+    "tkamd_tokenizer_from_json_devices", "tkamd_tokenizer_set_collect", "tkamd_tokenizer_devices", "tkamd_shard_stats", "tkamd_debug_phases",
 ]
 COLLECT_HOST, COLLECT_ROOT_P2P, COLLECT_ROOT_RCCL = 0, 1, 2
 
@@ -99,6 +99,8 @@ def load() -> C.CDLL:
     lib.tkamd_tokenizer_devices.restype = i32
     lib.tkamd_shard_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), i32, C.POINTER(C.c_int)]
     lib.tkamd_shard_stats.restype = i32
+    lib.tkamd_debug_phases.argtypes = [vp, i32, C.POINTER(C.c_uint64), i32]
+    lib.tkamd_debug_phases.restype = i32
     lib.tkamd_tokenizer_free.argtypes = [vp]
     lib.tkamd_tokenizer_free.restype = None
     lib.tkamd_tokenizer_info.argtypes = [vp, C.POINTER(Info)]

@@ -196,6 +196,7 @@ struct Workspace {
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
     DevBuf w_claims, w_claim_rows;               // in-batch word claims (kernels.hpp WordCache::claims) and the rows of the claimed slots
+    DevBuf w_phases;                             // TKAMD_PHASES: shader-clock ticks per phase of the lookup / compaction, [2][PHASE_WGS][8] u64 (tkamd_debug_phases)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
     DevBuf w_seq_off, w_seq_tok_off, w_word_idx, w_first_tok;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
     // profiling records of this workspace's launches, folded into the tokenizer's totals when drained
@@ -268,6 +269,7 @@ struct tkamd_tokenizer {
     std::vector<int64_t> shard_bytes;
 };
 
+constexpr size_t PHASE_WGS = 1 << 17;           // workgroups the phase table has rows for (per kernel)
 constexpr size_t MAX_HOST_WORKSPACES = 4;       // concurrent host-entry calls per handle; further callers wait for a free one
 
 // Host results live in pinned (page-locked) memory so the D2H copies run at PCIe speed; blocks are recycled
@@ -550,7 +552,7 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
     const QueueSizes z = queue_sizes(N, t->q16_div, lookup_grid(t));
     w->w_rows.reserve(z.total * 16);
     w->w_queues.reserve(z.total * 8);
-    w->w_cstate.reserve((N / COMPACT_CHUNK_MIN + 4) * 8);
+    w->w_cstate.reserve((N / COMPACT_CHUNK_MIN + 4) * 8 + 16 + mask_scan1_state_words(W) * 8);   // the compaction's look-back words, then the mask scan's
     w->w_chunk_lo.reserve((N / COMPACT_CHUNK_MIN + 4) * 4);
     w->w_qcount.reserve((size_t)QCNT_WORDS * 4);
     w->w_pt_tokoff.reserve((N + 4) * 4);
@@ -634,12 +636,13 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     w->last_used_claims = use_claims;
     size_t claim_slots = 0;
+    const size_t cstate_bytes = (((size_t)n_x / ((size_t)256 * (size_t)t->cp_items) + 4) * 8 + 15) & ~(size_t)15;
     {
         ZeroRegions z{};
         z.add(sc, SC_SLOTS * 8);
         z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
-        z.add(w->w_cstate.p, ((size_t)n_x / ((size_t)256 * (size_t)t->cp_items) + 4) * 8);
+        z.add(w->w_cstate.p, cstate_bytes + mask_scan1_state_words(W) * 8);      // (the mask scan's look-back words follow the compaction's)
         if (use_claims) {
             // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
             // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch
@@ -668,9 +671,21 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     w->last_n_seqs = n_seqs;
     // the caller's CSR is validated once; everything below reads the validated copy
     w->w_doc_off.reserve((size_t)(n_docs + 2) * 8);
-    pf.begin("validate_csr");
-    launch_validate_csr(st, d_doc_off, n_docs, n_bytes, d_err, w->w_doc_off.as<int64_t>());
-    pf.end();
+    // The plain GPT-2 path (no added tokens, no normalizer, no prefix space: BASELINE configs[1] / [4]) reads the document CSR in two
+    // places only: the document bitmask, and the documents' first pre-tokens.  The first is built by the validating kernel itself
+    // (a bit only from a document that is consistent on its own: always inside the text), the second kernel writes the validated
+    // copy on its way (it runs behind the whole validation, so it knows the verdict) -- two launches instead of four
+    // (TKAMD_LEAN_PROLOGUE=0: the general order).  A malformed CSR still never turns into an access outside the buffers; the batch
+    // fails with TKAMD_ERR_INVALID as before.
+    static const bool lean_on = [] { const char* e = getenv("TKAMD_LEAN_PROLOGUE"); return !(e && !strcmp(e, "0")); }();
+    const bool lean = lean_on && n_bytes > 0 && hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !prefix_space &&
+                      (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_BYTELEVEL_NOREGEX);
+    const int64_t* const raw_doc_off = d_doc_off;
+    if (!lean) {
+        pf.begin("validate_csr");
+        launch_validate_csr(st, d_doc_off, n_docs, n_bytes, d_err, w->w_doc_off.as<int64_t>());
+        pf.end();
+    }
     d_doc_off = w->w_doc_off.as<int64_t>();
     // what the epilogues below see: one encoding per document, or per sequence of words
     const bool words_in = n_seqs >= 0;
@@ -1194,7 +1209,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
 
     pf.begin("mark_doc_starts");
-    launch_mark_doc_starts_n(st, x_doc_off, n_docs, n_x, x_len_dev, w->w_docmask.as<ull>(), d_err);
+    launch_mark_doc_starts_n(st, lean ? raw_doc_off : x_doc_off, n_docs, n_x, x_len_dev, w->w_docmask.as<ull>(), d_err);
     if (matchmask) launch_mask_or(st, w->w_docmask.as<ull>(), w->w_hardmask.as<ull>(), W);   // match edges are hard boundaries
     pf.end();
 
@@ -1241,7 +1256,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_apply_matches(st, w->w_startmask.as<ull>(), has_end ? w->w_endmask.as<ull>() : nullptr, matchmask, w->w_spanmask.as<ull>(),
                              w->w_stopmask.as<ull>(), W);
     pf.begin("mask_scan");
-    launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
+    // one launch (ticket + look-back) instead of reduce / scan / down (TKAMD_SCAN1=0: the three)
+    static const bool scan1 = [] { const char* e = getenv("TKAMD_SCAN1"); return !(e && !strcmp(e, "0")); }();
+    if (scan1) launch_mask_scan1(st, t->n_cu * 8, w->w_startmask.as<ull>(), W, (ull*)((uint8_t*)w->w_cstate.p + cstate_bytes), w->w_wprefix.as<uint32_t>(), d_npretok);
+    else launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
     if (want_meta) {
         // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
@@ -1252,8 +1270,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.end();
     }
     pf.begin("doc_first_pretok");
-    launch_doc_first_pretok(st, x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
-                            d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(), t->cp_items);
+    launch_doc_first_pretok(st, lean ? raw_doc_off : x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
+                            d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(), t->cp_items,
+                            lean ? d_err : nullptr, lean ? w->w_doc_off.as<int64_t>() : nullptr);
     pf.end();
 
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
@@ -1268,6 +1287,17 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         plan.v[c].row_base = qz.row_base[c];
     }
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
+    // TKAMD_PHASES=1 (read once): the lookup and the compaction run as their diagnostic instantiations, which add the shader-clock
+    // ticks of their phases to a table of this workspace (tkamd_debug_phases reads and clears it); never in a measured run
+    static const bool phases_on = getenv("TKAMD_PHASES") != nullptr;
+    auto phases_of = [&](int which) -> void* {
+        if (!phases_on) return nullptr;
+        if (!w->w_phases.p) {
+            w->w_phases.reserve(2 * PHASE_WGS * 64);
+            HIP_CHECK(hipMemsetAsync(w->w_phases.p, 0, 2 * PHASE_WGS * 64, st));
+        }
+        return (uint8_t*)w->w_phases.p + (size_t)which * PHASE_WGS * 64;
+    };
     WordCache wc{nullptr, nullptr, nullptr, 0u};
     // (claims: see the top of this function; with offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end)
     auto open_word_cache = [&]() {
@@ -1327,7 +1357,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         open_word_cache();
         set_publish();
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0));
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
@@ -1403,7 +1433,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         set_publish();
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0));
         pf.end();
         pf.begin("wordpiece");
         launch_wordpiece(st, grid, true, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
@@ -1427,7 +1457,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
     launch_compact(st, t->cp_grid, t->cp_items, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
-                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>());
+                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>(), (size_t)t->cp_grid <= PHASE_WGS ? phases_of(1) : nullptr);
     pf.end();
     const uint32_t* word_of_doc = nullptr;
     const int64_t* first_tok = nullptr;
@@ -1731,7 +1761,7 @@ int tkamd_tokenizer_from_json_devices(const char* json, size_t json_len, const i
 
 int tkamd_tokenizer_set_collect(tkamd_tokenizer* t, int mode) {
     if (!t || mode < TKAMD_COLLECT_HOST || mode > TKAMD_COLLECT_ROOT_RCCL) return set_error(TKAMD_ERR_INVALID, "bad argument");
-    if (mode == TKAMD_COLLECT_ROOT_RCCL) {
+    if (mode == TKAMD_COLLECT_ROOT_RCCL && !getenv("TKAMD_RCCL_LIB")) {     // (TKAMD_RCCL_LIB: a test naming a library that is not there -- the call never reaches RCCL)
         std::vector<int> seen;
         for (int d : t->devices) {
             if (std::find(seen.begin(), seen.end(), d) != seen.end()) return set_error(TKAMD_ERR_INVALID, "TKAMD_COLLECT_ROOT_RCCL: a device is named twice (RCCL wants one rank per GPU)");
@@ -2591,6 +2621,27 @@ int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_sta
     *n_stages = n;
     if (reset) t->acc.clear();
     return TKAMD_OK;
+}
+
+int tkamd_debug_phases(tkamd_tokenizer* t, int which, uint64_t* out, int reset) {
+    if (!t || !out || which < 0 || which > 1) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    return guarded([&]() -> int {
+        for (int k = 0; k < 8; ++k) out[k] = 0;
+        if (t->device < 0 || g_forked) return TKAMD_OK;
+        HIP_CHECK(hipSetDevice(t->device));
+        HIP_CHECK(hipDeviceSynchronize());
+        std::lock_guard<std::mutex> lk(t->mu);
+        std::vector<uint64_t> h(PHASE_WGS * 8);
+        for (auto& w : t->pool) {
+            if (!w->w_phases.p) continue;
+            uint8_t* const p = (uint8_t*)w->w_phases.p + (size_t)which * PHASE_WGS * 64;
+            HIP_CHECK(hipMemcpy(h.data(), p, PHASE_WGS * 64, hipMemcpyDeviceToHost));
+            for (size_t g = 0; g < PHASE_WGS; ++g)
+                for (int k = 0; k < 8; ++k) out[k] += h[g * 8 + k];
+            if (reset) HIP_CHECK(hipMemset(p, 0, PHASE_WGS * 64));
+        }
+        return TKAMD_OK;
+    });
 }
 
 int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {

@@ -276,17 +276,21 @@ void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, co
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total);
+// the same in one launch (single pass, chunks by ticket + look-back); `state` = mask_scan1_state_words(n_words) zeroed 64-bit words
+void launch_mask_scan1(hipStream_t st, int grid, const unsigned long long* mask, int64_t n_words, unsigned long long* state, uint32_t* wprefix, int64_t* total);
+inline size_t mask_scan1_state_words(int64_t n_words) { return (size_t)(n_words / 2048 + 4); }
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start);
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items);
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items,
+                             const int* err = nullptr, int64_t* san = nullptr);      // san: doc_off is the caller's array, the kernel also writes its validated copy
 // whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk);
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
 int hot_table_slots();
 // group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
 // 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
@@ -369,7 +373,7 @@ void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const u
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
-                    int64_t n_docs, int64_t* tok_offsets);
+                    int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr);
 int compact_grid(int n_cu, int cp_items);
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
 constexpr int COMPACT_CHUNK_MIN = 512;              // pre-tokens per compaction chunk: 256 lanes x cp_items (2, 4 or 8)

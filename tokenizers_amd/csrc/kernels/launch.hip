@@ -33,21 +33,26 @@ void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
     hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
 }
+void launch_mask_scan1(hipStream_t st, int grid, const unsigned long long* mask, int64_t n_words, unsigned long long* state, uint32_t* wprefix, int64_t* total) {
+    const unsigned nb = std::max(1u, std::min<unsigned>((unsigned)grid, blocks_for(n_words, 256 * WS_PER)));
+    hipLaunchKernelGGL(k_words_scan1, dim3(nb), dim3(256), 0, st, mask, n_words, state, wprefix, total);
+}
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
     // one wavefront per 64 mask words = 4096 bytes of text; 4 wavefronts per workgroup
     hipLaunchKernelGGL(k_emit_pretok, dim3(blocks_for(n_bytes + 1, 4 * 4096)), dim3(256), 0, st, startmask, wprefix, n_bytes, len_dev, n_pretok, pt_start);
 }
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items) {
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items,
+                             const int* err, int64_t* san) {
     hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt, chunk_lo,
-                       (uint32_t)(CP_NT * cp_items));
+                       (uint32_t)(CP_NT * cp_items), err, san);
 }
 int hot_table_slots() { return HOT_SLOTS; }
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk) {
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases) {
     LookupArgs a{};
     a.words = t.words;
     a.word_disp = t.word_disp;
@@ -73,7 +78,14 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.claim_mask = wc.claim_mask;
     a.no_hits = no_hits;
     a.miss_is_unk = miss_is_unk;
-    if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
+    a.phases = (unsigned long long*)phases;
+    static const uint32_t fill = [] { const char* e = getenv("TKAMD_LU_FILL"); return (e && !strcmp(e, "1")) ? 1u : 0u; }();
+    a.fill = fill;
+    if (phases) {                                            // the diagnostic instantiations (TKAMD_PHASES)
+        if (endmask) hipLaunchKernelGGL((k_lookup<true, true>), dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
+        else hipLaunchKernelGGL((k_lookup<false, true>), dim3(grid), dim3(LU_NT), lookup_lds_bytes(false), st, a);
+    }
+    else if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
     else hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(false), st, a);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
@@ -226,6 +238,8 @@ int prepare_long_kernel() {
     int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
     if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(true));
     if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(false));
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(true));
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(false));
     if (rc == 0) rc = prepare_lds_merge<16, 704, true, true>();
     if (rc == 0) rc = prepare_lds_merge<32, 768, true, true>();
     return rc;
@@ -254,15 +268,19 @@ void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, cons
 }
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
-                    int64_t n_docs, int64_t* tok_offsets) {
+                    int64_t n_docs, int64_t* tok_offsets, void* phases) {
     static_assert(COMPACT_CHUNK_MIN == CpShape<2>::CHUNK, "the host sizes the look-back state and chunk_lo by the smallest chunk");
-    if (cp_items == 2)
+    unsigned long long* const ph = (unsigned long long*)phases;
+    if (ph && cp_items == 4)                                 // the diagnostic instantiation (TKAMD_PHASES)
+        hipLaunchKernelGGL((k_compact<4, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
+    else if (cp_items == 2)
         hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
     else if (cp_items == 4)
         hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
     else
         hipLaunchKernelGGL(k_compact<8>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
 }

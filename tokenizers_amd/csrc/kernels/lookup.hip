@@ -64,13 +64,19 @@ struct LookupArgs {
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
+    uint32_t fill;                   // TKAMD_LU_FILL (A/B): pass 1 stores whole rows of tok0
+    unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
 };
+// phases of k_lookup<.., true>, as wavefront 0 sees the workgroup's barriers: staging the tile (LDS stores, the last pre-token's end,
+// next tile's prefetch issued), expanding the mask bits into positions, pass 1, pass 2, pass 3 (+ waiting for the slowest wavefront);
+// slot 7: the whole kernel
+enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_PH_PASS3 = 4, LU_PH_TOTAL = 7 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
 
 // (claim_hash_long / claim_slot / CLAIM_MAX_LEN: bpe.hip, next to the publish helper the model kernels call)
-template <bool HAS_END>
+template <bool HAS_END, bool PROF = false>
 __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lu_lds)
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT_SLOTS]
@@ -82,6 +88,12 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand;
     __shared__ uint32_t s_fill[4];                                               // fill of this workgroup's sub-queues so far
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (PROF: thread 0 stamps the shader clock behind every barrier that ends a phase; compiled out of the product instantiation)
+    unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+    auto tick = [&](int k) {
+        if (PROF && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph_acc[k] += now - ph_t; ph_t = now; }
+    };
+    if (PROF && tid == 0) ph_t = ph_t0 = __builtin_amdgcn_s_memtime();
     const uint32_t sq = blockIdx.x;                                // this workgroup's PRIVATE sub-queue (the launcher keeps the grid <= NSQ)
     if (tid < 4) s_fill[tid] = 0u;
     for (int i = tid; i < HOT_SLOTS; i += LU_NT) s_hot[i] = a.hot[i];
@@ -130,6 +142,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         const int64_t w0 = tile * LU_TILE_WORDS;
         const int64_t t0 = w0 << 6;                                  // first byte of the tile
         __syncthreads();                                             // previous tile's LDS use is over
+        tick(LU_PH_PASS3);
         // ---- 1. text tile -> LDS (prefetched registers) ----
         ((uint4*)s_text32)[tid] = make_uint4(pf_t0.a, pf_t0.b, pf_t0.c, pf_t0.d);
         ((uint4*)s_text32)[tid + LU_NT] = make_uint4(pf_t1.a, pf_t1.b, pf_t1.c, pf_t1.d);
@@ -166,6 +179,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         }
         prefetch(tile + gridDim.x);                                   // the next tile's loads fly while this one is looked up
         __syncthreads();
+        tick(LU_PH_STAGE);
         const uint32_t n = s_n;                                      // pre-tokens starting in this tile
         const uint32_t pbase = s_pbase;                              // global rank of the first one
         const uint32_t last_rel = s_last_end - (uint32_t)t0;         // (positions below are relative to the tile)
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 }
             }
             __syncthreads();
+            tick(LU_PH_EXPAND);
             // start, end (tile relative) and the first 16 key bytes of the pre-token of local rank rel (< cnt)
             auto load_key = [&](uint32_t rel, uint32_t& s_rel, uint32_t& len, uint32_t& k0, uint32_t& k1, uint32_t& k2, uint32_t& k3, bool want_k3) {
                 s_rel = s_pos[rel];
@@ -230,7 +245,8 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                         miss = false;
                     }
                 }
-                if (hit) a.tok0[pbase + rb + rel] = TOK_ONE | (h.w & TOK_ID_MASK);
+                // (a.fill: the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them)
+                if (hit || (a.fill && miss)) a.tok0[pbase + rb + rel] = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
                 const uint64_t mb = __ballot(miss);
                 if (mb) {                                                           // (wavefront-uniform) the workgroup's miss list
                     uint32_t base = 0u;
@@ -240,6 +256,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 }
             }
             __syncthreads();
+            tick(LU_PH_PASS1);
             // what pass 2 and pass 3 end a lane with: a pre-token still pending is a model kernel's work, queued by length class
             // (<= 16 bytes, <= 32, <= 64, longer); its tok0 word names the row, any other lane's its result.  (wavefront-wide: ballots)
             auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out) {
@@ -363,6 +380,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
             if (CAND_PASS && a.claims) {                                            // wavefront-uniform
                 __syncthreads();
+                tick(LU_PH_PASS2);
                 const uint32_t n_cand = s_ncand;
                 for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_cand; c0 += (uint32_t)LU_NT) {
                     const bool v = c0 + lane < n_cand;
@@ -384,6 +402,12 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     }
     // the fill of this workgroup's sub-queues (the counters were zeroed by the host; a workgroup without tiles leaves them 0)
     __syncthreads();
+    tick(LU_PH_PASS3);
+    if (PROF && tid == 0 && a.phases) {
+        unsigned long long* const o = a.phases + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 5; ++k) o[k] += ph_acc[k];
+        o[LU_PH_TOTAL] += ph_t - ph_t0;
+    }
     if (tid < 4) {
         uint32_t* const cnt_p = tid == 0 ? a.v[0].counts : tid == 1 ? a.v[1].counts : tid == 2 ? a.v[2].counts : a.v[3].counts;
         const uint32_t cap = tid == 0 ? a.v[0].sq_cap : tid == 1 ? a.v[1].sq_cap : tid == 2 ? a.v[2].sq_cap : a.v[3].sq_cap;

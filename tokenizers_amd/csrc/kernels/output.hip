@@ -95,14 +95,21 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 // The token CSR of the documents (Encoding per document, tokenizer/mod.rs:1345-1348) leaves this kernel too: the documents whose first
 // pre-token lies in a chunk (chunk_lo / doc_pt of k_doc_first_pretok; an empty document starts at its successor's) get
 // tok_offsets[d] = the token offset of that pre-token -- so the ids-only path never writes the P-sized pt_tokoff (null then).
-template <int CP_ITEMS>
+// (PROF: the diagnostic instantiation -- TKAMD_PHASES, tkamd_debug_phases -- stamps the shader clock per phase into phases[workgroup][8]:
+// 0 loads + scan + publish of front(), 1 its LDS scatter, 2 the look-back wait, 3 the copy-out, 7 the whole kernel)
+template <int CP_ITEMS, bool PROF = false>
 __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
-                                                   int64_t* __restrict__ tok_offsets) {
+                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases) {
     constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
+    unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[4] = {0ull, 0ull, 0ull, 0ull};
+    auto tick = [&](int k) {
+        if (PROF && threadIdx.x == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph_acc[k] += now - ph_t; ph_t = now; }
+    };
+    if (PROF && threadIdx.x == 0) ph_t = ph_t0 = __builtin_amdgcn_s_memtime();
     __shared__ uint32_t sm[4];
     __shared__ uint32_t s_dlo[2], s_dhi[2];              // documents [dlo, dhi) start in the chunk
     __shared__ uint32_t s_docpt[2][CP_NT];               // doc_pt of the first CP_NT of them, loaded with the chunk
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
         if (tid == 0) { lb_publish(lb, ch, (unsigned long long)tot); s_tot[b] = tot; }
+        tick(0);
         uint32_t acc = ex;
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) { s_loc[b][tid * CP_ITEMS + k] = acc; acc += r.cnt[k]; }
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
             uint32_t* const dst = s_stage[b];
             TKAMD_CP_SCATTER(dst, r, o)
         }
+        tick(1);
     };
     // lane 0 draws; the value reaches the others through s_tk.  (A workgroup stops drawing once it has seen the end: the counter
     // overshoots n_chunks by at most two per workgroup.)
@@ -163,6 +172,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
             if (tid == 0) s_base = base;
         }
         __syncthreads();
+        tick(2);
         const unsigned long long base = s_base;
         if (ch == n_chunks - 1 && tid == 0) *n_tok = (int64_t)(base + tot);
         const int64_t pc = ch * CP_CHUNK;
@@ -192,8 +202,14 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         }
         if (tid == 0) s_tk[0] = after;
         __syncthreads();                                   // buffer b is free for front() of the chunk after next
+        tick(3);
         ch = nxt;
         nxt = (int64_t)s_tk[0];                            // (rewritten only behind the barriers of the next front())
+    }
+    if (PROF && tid == 0 && phases) {
+        unsigned long long* const o = phases + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 4; ++k) o[k] += ph_acc[k];
+        o[7] += ph_t - ph_t0;
     }
 }
 #undef TKAMD_CP_SCATTER

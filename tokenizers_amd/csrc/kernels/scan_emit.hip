@@ -56,6 +56,63 @@ __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __
     }
 }
 
+// The same prefix sums in ONE launch (k_words_reduce + k_scan_single + k_words_down are three, and the middle one is a single
+// workgroup): a workgroup draws a chunk of 256 x 8 mask words by ticket, publishes the chunk's popcount and looks back over its
+// predecessors' (results.hip; the ticket makes every predecessor a workgroup that has started, so the wait ends at any residency).
+// state[0] = the ticket, state[1 + chunk] = the look-back words, all zero on entry.  Used for the start mask of every batch.
+__global__ __launch_bounds__(256) void k_words_scan1(const unsigned long long* __restrict__ mask, int64_t n_words, unsigned long long* __restrict__ state,
+                                                     uint32_t* __restrict__ wprefix, int64_t* __restrict__ total) {
+    __shared__ uint32_t sm[4];
+    __shared__ unsigned long long s_tk, s_base;
+    constexpr int64_t CHUNK = 256 * WS_PER;
+    const int64_t n_chunks = (n_words + CHUNK - 1) / CHUNK;
+    unsigned long long* const lb = state + 1;
+    if (n_chunks == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *total = 0;
+        return;
+    }
+    for (;;) {
+        if (threadIdx.x == 0) s_tk = atomicAdd(state, 1ull);
+        __syncthreads();
+        const int64_t ch = (int64_t)s_tk;
+        if (ch >= n_chunks) break;                                  // (uniform)
+        const int64_t w0 = ch * CHUNK + (int64_t)threadIdx.x * WS_PER;
+        uint32_t c[WS_PER], v = 0;
+        const bool whole = w0 + WS_PER <= n_words;
+        if (whole) {
+            const ulonglong2* const q = (const ulonglong2*)(mask + w0);
+#pragma unroll
+            for (int k = 0; k < WS_PER / 2; ++k) { const ulonglong2 m = q[k]; c[2 * k] = (uint32_t)__popcll(m.x); c[2 * k + 1] = (uint32_t)__popcll(m.y); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < WS_PER; ++k) c[k] = (w0 + k < n_words) ? (uint32_t)__popcll(mask[w0 + k]) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < WS_PER; ++k) v += c[k];
+        uint32_t tot;
+        const uint32_t ex = block256_excl_scan(v, sm, &tot);
+        if (threadIdx.x == 0) lb_publish(lb, ch, (unsigned long long)tot);
+        if (threadIdx.x < 64) {
+            const unsigned long long base = lb_resolve(lb, ch, (unsigned long long)tot);
+            if (threadIdx.x == 0) s_base = base;
+        }
+        __syncthreads();
+        uint32_t run = (uint32_t)s_base + ex;
+        if (ch == n_chunks - 1 && threadIdx.x == 0) *total = (int64_t)(s_base + tot);
+        if (whole) {
+            uint4 o0, o1;
+            o0.x = run; run += c[0]; o0.y = run; run += c[1]; o0.z = run; run += c[2]; o0.w = run; run += c[3];
+            o1.x = run; run += c[4]; o1.y = run; run += c[5]; o1.z = run; run += c[6]; o1.w = run;
+            ((uint4*)(wprefix + w0))[0] = o0;
+            ((uint4*)(wprefix + w0))[1] = o1;
+        } else {
+#pragma unroll
+            for (int k = 0; k < WS_PER; ++k) { if (w0 + k < n_words) wprefix[w0 + k] = run; run += c[k]; }
+        }
+        __syncthreads();                                            // s_tk / s_base are rewritten by the next round
+    }
+}
+
 // A wavefront takes 64 consecutive mask words (4 KB of text): one coalesced load of the words and their
 // prefixes, then word by word (broadcast with readlane) lane l tests bit l and stores pt_start[rank] = position.
 // All loads are issued up front; the per-word work is a handful of VALU ops and one masked, rank-ordered store.
@@ -125,15 +182,22 @@ __device__ __forceinline__ uint32_t doc_first_rank(int64_t g, int64_t n_bytes, c
     const int b = (int)(g & 63);
     return wprefix[g >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
 }
+// san != nullptr (the lean prologue, capi.cpp): doc_off is the CALLER's array, err holds the verdict of its validation
+// (k_mark_doc_starts, finished: an earlier launch), and this kernel doubles as k_sanitize_csr -- it reads the array through the same
+// rule and writes the validated copy the later stages (offsets, epilogues) read.
 __global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
                                    const unsigned long long* __restrict__ startmask, const uint32_t* __restrict__ wprefix,
-                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt, uint32_t* __restrict__ chunk_lo, uint32_t chunk) {
+                                   const int64_t* __restrict__ n_pretok, uint32_t* __restrict__ doc_pt, uint32_t* __restrict__ chunk_lo, uint32_t chunk,
+                                   const int* __restrict__ err, int64_t* __restrict__ san) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > n_docs) return;
-    const uint32_t r = doc_first_rank(doc_off[d], n_bytes, startmask, wprefix, n_pretok);
+    const bool bad = san && (*err & ERR_BAD_OFFSETS) != 0;
+    const int64_t g = bad ? (d == n_docs ? n_bytes : 0) : doc_off[d];
+    if (san) san[d] = g;
+    const uint32_t r = doc_first_rank(g, n_bytes, startmask, wprefix, n_pretok);
     doc_pt[d] = r;
     const uint32_t c_hi = r / chunk;
-    uint32_t c = d ? doc_first_rank(doc_off[d - 1], n_bytes, startmask, wprefix, n_pretok) / chunk + 1u : 0u;
+    uint32_t c = d ? doc_first_rank(bad ? 0 : doc_off[d - 1], n_bytes, startmask, wprefix, n_pretok) / chunk + 1u : 0u;
     for (; c <= c_hi; ++c) chunk_lo[c] = (uint32_t)d;
     if (d == n_docs) chunk_lo[c_hi + 1u] = (uint32_t)n_docs + 1u;
 }

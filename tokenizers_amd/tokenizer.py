@@ -979,6 +979,15 @@ class Tokenizer:
         _lib.check(self._lib.tkamd_profile_counters(self._h, arr, 8))
         return {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge_huge": arr[7]}
 
+    def debug_phases(self, reset: bool = True) -> dict[str, list[int]]:
+        """TKAMD_PHASES=1 runs only: shader-clock ticks per phase of the lookup and the compaction (``tkamd_debug_phases``)."""
+        out = {}
+        for which, name in ((0, "lookup"), (1, "compact")):
+            arr = (C.c_uint64 * 8)()
+            _lib.check(self._lib.tkamd_debug_phases(self._h, which, arr, 1 if reset else 0))
+            out[name] = list(arr)
+        return out
+
     def profile_read(self, reset: bool = True) -> dict[str, tuple[float, int]]:
         arr = (_lib.StageTime * _lib.MAX_STAGES)()
         n = C.c_int(0)

@@ -97,9 +97,16 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
     tok.profile(False)
     st = {k: round(v[0] / max(1, v[1]), 4) for k, v in tok.profile_read().items()}
     nb = sum(b.n_bytes for b in bs) / n_batches
+    phases = None
+    if os.environ.get("TKAMD_PHASES"):                       # shares of the kernel's own clock, per phase (include/tokenizers_amd.h tkamd_debug_phases)
+        phases = {}
+        for name, v in tok.debug_phases().items():
+            if v[7]:
+                phases[name] = [round(x / v[7], 3) for x in v[:5]]
     print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("TKAMD_") and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
                                      "gbps": round(nb / best / 1e9, 2), "ms": round(best * 1e3, 4), "sum_kernels_ms": round(sum(st.values()), 4),
-                                     "kernels_ms": {k: v for k, v in sorted(st.items(), key=lambda kv: -kv[1]) if v >= 0.003}, "queues": tok.queue_sizes()}), flush=True)
+                                     "kernels_ms": {k: v for k, v in sorted(st.items(), key=lambda kv: -kv[1]) if v >= 0.003}, "queues": tok.queue_sizes(),
+                                     "phases": phases}), flush=True)
 
 
 def main():
@@ -137,7 +144,8 @@ def main():
             print(f"[{v}] FAILED: {(r.stdout[-600:] + r.stderr[-1200:]) if r else 'timeout'}", flush=True)
             continue
         j = json.loads(line[len("AB_RESULT "):])
-        print(f"[{v or 'default'}] {j['gbps']} GB/s {j['ms']} ms  sum {j['sum_kernels_ms']}  {j['kernels_ms']}  q={j['queues']}", flush=True)
+        print(f"[{v or 'default'}] {j['gbps']} GB/s {j['ms']} ms  sum {j['sum_kernels_ms']}  {j['kernels_ms']}  q={j['queues']}" +
+              (f"  phases={j['phases']}" if j.get("phases") else ""), flush=True)
         if a.out:
             with open(a.out, "a") as fh:
                 fh.write(json.dumps(j) + "\n")
