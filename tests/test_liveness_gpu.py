@@ -3,9 +3,11 @@
 TokenizerImpl::encode_batch is `&self` + Send + Sync over `into_maybe_par_iter` (tokenizer/mod.rs:1328-1348,
 utils/parallelism.rs:85-106): any number of concurrent callers, and every call returns.  The one kernel of the path with a wait
 in it is k_compact (kernels/output.hip): a chunk's place in the token stream comes from a look-back over its predecessors'
-published totals.  Its chunks are handed out by ticket, so a predecessor always belongs to a workgroup that has started -- these
-tests put that claim under load: grids far beyond (and below) what is resident, two multi-round compactions at once on two
-streams, and the sliced host entry (two workspaces, two streams per call) from two host threads.  Every run sits in a child
+published totals.  A look-back that runs out of patience computes the missing totals itself, so no wait depends on another
+workgroup being scheduled -- these tests put that claim under load: grids far beyond (and below) what is resident (a grid of
+3,000 workgroups on a chip that holds 1,280 was a certain deadlock for round 3's kernel: the second-round chunks of the resident
+workgroups wait for workgroups that cannot start), look-backs with no patience at all, two multi-round compactions at once on
+two streams, and the sliced host entry (two workspaces, two streams per call) from two host threads.  Every run sits in a child
 process under a timeout: a compaction that waited for ever would show as a failed test, not as a hung session."""
 from __future__ import annotations
 
@@ -41,11 +43,13 @@ _GRID_CODE = (
     "print('GRID_OK')\n")
 
 
-@pytest.mark.parametrize("grid", ["1", "7", "100000"])
-def test_compaction_makes_progress_at_any_grid(grid):
-    """One workgroup for every chunk, a handful, and forty times more workgroups than the chip holds at once (the static
-    round-robin hand-out of round 3 waited for ever on a grid it could not keep resident): same result as the oracle."""
-    _run(_GRID_CODE, {"TKAMD_CP_GRID": grid}, 900, "GRID_OK")
+@pytest.mark.parametrize("grid,patience", [("1", None), ("7", None), ("7", "0"), ("3000", "64"), ("100000", None)])
+def test_compaction_makes_progress_at_any_grid(grid, patience):
+    """One workgroup, a handful (also with look-backs that help at their first poll: every total is then computed by whoever asks
+    for it first), more than twice what the chip holds at once, and a workgroup per chunk forty times over: same result as the
+    oracle.  (Under the SIMT emulation the workgroups of a launch run one after the other -- every predecessor that belongs to a
+    later workgroup is unpublished for good, and the helper is the only way out.)"""
+    _run(_GRID_CODE, {"TKAMD_CP_GRID": grid, **({"TKAMD_LB_PATIENCE": patience} if patience is not None else {})}, 900, "GRID_OK")
 
 
 _TWO_STREAMS_CODE = (
@@ -99,12 +103,13 @@ _TWO_STREAMS_CODE = (
 
 
 @pytest.mark.needs_hw
-@pytest.mark.parametrize("grid", [None, "100000"], ids=["resident-grid", "oversubscribed"])
+@pytest.mark.parametrize("grid", [None, "3000"], ids=["resident-grid", "oversubscribed"])
 def test_two_compactions_on_two_streams_always_finish(grid):
     """Two host threads, two streams, two resident batches of more than 200 MB (33 M pre-tokens: ~25 rounds of chunks per
     compaction at the default grid), 50 iterations each, through the device entry -- the two compactions share the chip however the
     hardware deals it out.  Every iteration's ids and token CSR equal the first one's, the four copies of the corpus inside a batch agree, and the
-    first 20,000 documents equal the oracle's.  Once more with a grid forty times the chip."""
+    first 20,000 documents equal the oracle's.  Once more with grids of 3,000 workgroups: more than twice what fits, so second-round
+    chunks wait on workgroups that cannot start until the waiting ones have helped themselves out."""
     _run(_TWO_STREAMS_CODE % 50, {} if grid is None else {"TKAMD_CP_GRID": grid}, 1500, "TWO_STREAMS_OK")
 
 

@@ -241,10 +241,12 @@ struct tkamd_tokenizer {
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
-    int cp_grid = 0;             // grid of k_compact: what is resident at once (chunks go by ticket: any grid makes progress, TKAMD_CP_GRID)
+    int cp_grid = 0;             // grid of k_compact: what is resident at once (any grid makes progress -- its look-back helps itself --, TKAMD_CP_GRID)
     // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
-    // of the step (the claims' worst case).  A batch that ran with the claims and whose work queues still hold more
-    // than 35 % of its pre-tokens pauses them for the next claims_pause_len batches of the handle; then they are tried again.
+    // of the step (the claims' worst case).  Inside a batch every lookup workgroup gives the claims up by itself once
+    // it has seen that (kernels/lookup.hip CLAIM_ADAPT_MIN); across batches, a batch that ran with the claims and found fewer than a
+    // quarter of its candidates shared pauses them for the next claims_pause_len batches of the handle; then they are tried again.
+    std::atomic<int> q16_fat_hint{1};    // the last batch that ran with the claims left a fat <= 16-byte queue (or none has run yet): see run_pipeline's merge launches
     std::atomic<int> claims_pause{0};
     int claims_pause_len = 32;   // TKAMD_CLAIMS_PAUSE (0: never pause)
     int cp_items = 4;            // pre-tokens per lane of k_compact: 4 (default: 0.145 ms on C2 against 0.187) or 8 (TKAMD_CP_ITEMS)
@@ -269,6 +271,7 @@ struct tkamd_tokenizer {
     std::vector<int64_t> shard_bytes;
 };
 
+constexpr uint32_t MERGE_THIN_LIMIT = 393216;   // <= 16-byte queue entries up to which the 32-symbol merge launch takes them along (two rounds of its 768 lanes x 256 CUs)
 constexpr size_t PHASE_WGS = 1 << 17;           // workgroups the phase table has rows for (per kernel)
 constexpr size_t MAX_HOST_WORKSPACES = 4;       // concurrent host-entry calls per handle; further callers wait for a free one
 
@@ -552,7 +555,7 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
     const QueueSizes z = queue_sizes(N, t->q16_div, lookup_grid(t));
     w->w_rows.reserve(z.total * 16);
     w->w_queues.reserve(z.total * 8);
-    w->w_cstate.reserve((N / COMPACT_CHUNK_MIN + 4) * 8 + 16 + mask_scan1_state_words(W) * 8);   // the compaction's look-back words, then the mask scan's
+    w->w_cstate.reserve((N / COMPACT_CHUNK_MIN + 4) * 8 + 16);
     w->w_chunk_lo.reserve((N / COMPACT_CHUNK_MIN + 4) * 4);
     w->w_qcount.reserve((size_t)QCNT_WORDS * 4);
     w->w_pt_tokoff.reserve((N + 4) * 4);
@@ -642,7 +645,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         z.add(sc, SC_SLOTS * 8);
         z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
-        z.add(w->w_cstate.p, cstate_bytes + mask_scan1_state_words(W) * 8);      // (the mask scan's look-back words follow the compaction's)
+        z.add(w->w_cstate.p, cstate_bytes);
         if (use_claims) {
             // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
             // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch
@@ -1256,10 +1259,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_apply_matches(st, w->w_startmask.as<ull>(), has_end ? w->w_endmask.as<ull>() : nullptr, matchmask, w->w_spanmask.as<ull>(),
                              w->w_stopmask.as<ull>(), W);
     pf.begin("mask_scan");
-    // one launch (ticket + look-back) instead of reduce / scan / down (TKAMD_SCAN1=0: the three)
-    static const bool scan1 = [] { const char* e = getenv("TKAMD_SCAN1"); return !(e && !strcmp(e, "0")); }();
-    if (scan1) launch_mask_scan1(st, t->n_cu * 8, w->w_startmask.as<ull>(), W, (ull*)((uint8_t*)w->w_cstate.p + cstate_bytes), w->w_wprefix.as<uint32_t>(), d_npretok);
-    else launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
+    // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
+    // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
+    launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
     pf.end();
     if (want_meta) {
         // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
@@ -1357,7 +1359,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         open_word_cache();
         set_publish();
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0));
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters);
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
@@ -1371,10 +1373,17 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fork_side();                                       // the <= 32-byte class on one side stream, the 64-byte / long classes on the other, the <= 16-byte class here
         // With the claims on both queues hold the distinct words only, and a launch of the LDS kernels lasts as long as its longest word's
         // chain of dependent merge probes whatever it holds: the 32-symbol kernel takes both queues in one launch (TKAMD_MERGE_ONE=0: two).
-        static const bool merge_one = [] { const char* e = getenv("TKAMD_MERGE_ONE"); return !(e && !strcmp(e, "0")); }();
-        const bool one = merge_one && wc.claims && lds16 && lds32;
+        // Thin or not is only known on the device.  TKAMD_MERGE_ONE unset: while the handle has not seen a thin <= 16-byte queue (its first
+        // batch, or text that repeats nothing) BOTH kernels are launched and pick the queue's owner from its fill themselves
+        // (thin_limit; an extra ~4 us launch); once a batch came back thin the next ones launch the 32-symbol kernel alone, until a fat
+        // one is seen again.  = 1: always the one launch; = 0: always two, each with its own queue.
+        static const int merge_mode = [] { const char* e = getenv("TKAMD_MERGE_ONE"); return !e ? 2 : (!strcmp(e, "0") ? 0 : 1); }();
+        const bool can_one = wc.claims && lds16 && lds32;
+        const bool both = can_one && merge_mode == 2 && t->q16_fat_hint.load() != 0;
+        const bool one = can_one && merge_mode != 0 && !both;
+        if (both) mdt.thin_limit = MERGE_THIN_LIMIT;
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, one ? &plan.v[0] : nullptr);
+        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, (one || both) ? &plan.v[0] : nullptr);
         pf.end();
         if (!one) {
             pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
@@ -1433,7 +1442,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         set_publish();
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0));
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0), d_counters);
         pf.end();
         pf.begin("wordpiece");
         launch_wordpiece(st, grid, true, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
@@ -1558,18 +1567,17 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
 
 int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
     int64_t host[SC_SLOTS];
-    uint32_t qfill[2 * NSQ * QCNT_STRIDE];                   // fill of the sub-queues of the <= 16- and <= 32-byte classes (the claims' survivors)
-    const bool watch = w->last_used_claims && t->claims_pause_len > 0;
     HIP_CHECK(hipMemcpyAsync(host, w->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
-    if (watch) HIP_CHECK(hipMemcpyAsync(qfill, w->w_qcount.p, sizeof(qfill), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    if (watch && host[SC_NPRETOK] >= 32768) {
-        uint64_t survivors = 0;
-        for (int i = 0; i < 2 * NSQ; ++i) survivors += qfill[i * QCNT_STRIDE];
-        if (survivors * 20 > (uint64_t)host[SC_NPRETOK] * 7) t->claims_pause = t->claims_pause_len;     // nothing shared: see tkamd_tokenizer::claims_pause
-    }
     int err = *(int*)&host[SC_ERR] & ~NOTE_REORDER_SEEN;     // (a note of the normalizer, not an error)
     memcpy(w->last_counters, &host[SC_COUNTERS], sizeof(w->last_counters));
+    if (w->last_used_claims && t->claims_pause_len > 0) {
+        // the claims' yield, counted by the lookup itself: candidates it looked at and how many of them were another pre-token's word.
+        // Fewer than one in four shared: the round trips cost more than the merges they save (tkamd_tokenizer::claims_pause)
+        const uint64_t cands = w->last_counters[CNT_CLAIM_CANDS], shared = w->last_counters[CNT_CLAIM_SHARED];
+        if (cands >= 32768 && shared * 4 < cands) t->claims_pause = t->claims_pause_len;
+        t->q16_fat_hint = w->last_counters[CNT_CLAIM_CANDS] - w->last_counters[CNT_CLAIM_SHARED] >= MERGE_THIN_LIMIT ? 1 : 0;   // (survivors: an upper bound of the queue's fill)
+    }
     if (n_tok) *n_tok = host[w->last_ntok_slot];
     if (n_pretok) *n_pretok = host[SC_NPRETOK];
     return err;

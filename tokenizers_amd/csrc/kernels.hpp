@@ -16,6 +16,7 @@ struct DevTables {
     const uint16_t* merge_disp;       // bucket displacements
     uint32_t merge_mask, merge_seed, merge_bmask;
     uint32_t newid_affine, newid_base;   // new_id == rank + newid_base for every merge (host-verified)
+    uint32_t thin_limit;              // != 0 (per call, in the host's copy): the LDS merge kernels pick the owner of the <= 16-byte queue by its fill (bpe.hip)
     // in-batch claims: set (per call, in the host's copy) when the model kernels publish the claimants' rows themselves (bpe.hip)
     const unsigned long long* pub_claims;
     void* pub_rows;
@@ -261,8 +262,9 @@ enum : int {
 };
 
 // indices into the per-batch device counter array
-enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_LISTH = 7, CNT_MATCH_DOCS = 8, CNT_MATCHES = 9, CNT_MATCH_DOCS2 = 10,
-              CNT_COUNT = 12 };
+enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_CLAIM_CANDS = 5, CNT_CLAIM_SHARED = 6, CNT_LISTH = 7, CNT_MATCH_DOCS = 8,
+              CNT_MATCHES = 9, CNT_MATCH_DOCS2 = 10, CNT_CLAIM_GAVE_UP = 11, CNT_COUNT = 12 };
+// (CNT_CLAIM_*: in-batch claims -- candidates the lookup looked at, how many were another pre-token's word, workgroups that stopped claiming)
 
 constexpr uint32_t MATCH_LEN_ORIG = 0x80000000u;    // added-token match list, word 3: the length counts bytes of the ORIGINAL text
 constexpr int TEXT_PAD = 64;        // = TKAMD_TEXT_PAD (include/tokenizers_amd.h): readable bytes past the end of every text buffer
@@ -276,9 +278,6 @@ void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, co
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total);
-// the same in one launch (single pass, chunks by ticket + look-back); `state` = mask_scan1_state_words(n_words) zeroed 64-bit words
-void launch_mask_scan1(hipStream_t st, int grid, const unsigned long long* mask, int64_t n_words, unsigned long long* state, uint32_t* wprefix, int64_t* total);
-inline size_t mask_scan1_state_words(int64_t n_words) { return (size_t)(n_words / 2048 + 4); }
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start);
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
@@ -290,7 +289,7 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr, uint32_t* counters = nullptr);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
 int hot_table_slots();
 // group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
 // 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
@@ -366,9 +365,9 @@ int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                            uint32_t* tmp_ids, uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge,
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
-// single-pass compaction; `state` (8 bytes: the chunk ticket, then 8 bytes per chunk of 256 x cp_items pre-tokens) must be zero on
-// entry; pt_tokoff may be null.  Any grid works (chunks are handed out by ticket: kernels/output.hip); compact_grid(n_cu) -- what is
-// resident at once -- is the one that wastes no launches.
+// single-pass compaction; `state` (8 bytes per chunk of 256 x cp_items pre-tokens) must be zero on entry; pt_tokoff may be null.
+// Any grid makes progress (a look-back that runs out of patience computes the missing totals itself: kernels/output.hip);
+// compact_grid(n_cu) -- what is resident at once -- is the one that never has to.
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,

@@ -371,6 +371,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     uint16_t* s_disp = (uint16_t*)(s_hist + 64);              // [DISP_LDS_MAX]
     uint4* s_sort = (uint4*)s_key;                            // [NT], aliases the key area between items
     const uint32_t tid = threadIdx.x;
+    // Which kernel takes the <= 16-byte class is decided HERE, from the queue's fill, when the host asks for it (t.thin_limit != 0: both
+    // kernels are launched).  Thin -- the in-batch claims left the distinct words only -- it rides along in the 32-symbol launch (one
+    // launch lasts as long as its longest word's chain of merges whatever it holds, and this kernel returns at once); fat -- text that
+    // repeats nothing -- it stays with this kernel's twice as many lanes per CU (13 M short words: 0.85 ms against 1.51).  Both kernels
+    // read the same counters, so exactly one of them takes the queue.
+    const uint32_t n_first = qview_prefix(v, s_qpre);
+    if (S == 16 && t.thin_limit && n_first < t.thin_limit) return;
     for (uint32_t i = tid; i < 256; i += NT) s_byte_id[i] = t.byte_id[i];
     const bool disp_in_lds = DISP_LDS && t.merge_bmask < (uint32_t)DISP_LDS_MAX;
     if (disp_in_lds) {
@@ -383,8 +390,9 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     __syncthreads();
     const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
     const uint32_t nid_base = t.newid_base;
-    const uint32_t n_first = qview_prefix(v, s_qpre);
-    const uint32_t n_items = n_first + ((S == 32 && v2.q) ? qview_prefix(v2, s_qpre2) : 0u);
+    uint32_t n_second = (S == 32 && v2.q) ? qview_prefix(v2, s_qpre2) : 0u;
+    if (t.thin_limit && n_second >= t.thin_limit) n_second = 0u;   // (fat: the 16-symbol kernel's)
+    const uint32_t n_items = n_first + n_second;
     // a short queue (the in-batch claims leave the distinct words only) is spread over the whole grid, a few wavefronts of every
     // workgroup busy, instead of filling the first workgroups and leaving most CUs idle
     const uint32_t take = min((uint32_t)NT, ((n_items + gridDim.x - 1u) / gridDim.x + 63u) & ~63u);

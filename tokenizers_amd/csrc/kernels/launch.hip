@@ -33,10 +33,6 @@ void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
     hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
 }
-void launch_mask_scan1(hipStream_t st, int grid, const unsigned long long* mask, int64_t n_words, unsigned long long* state, uint32_t* wprefix, int64_t* total) {
-    const unsigned nb = std::max(1u, std::min<unsigned>((unsigned)grid, blocks_for(n_words, 256 * WS_PER)));
-    hipLaunchKernelGGL(k_words_scan1, dim3(nb), dim3(256), 0, st, mask, n_words, state, wprefix, total);
-}
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
     // one wavefront per 64 mask words = 4096 bytes of text; 4 wavefronts per workgroup
@@ -52,8 +48,11 @@ int hot_table_slots() { return HOT_SLOTS; }
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk, void* phases) {
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases, uint32_t* counters) {
     LookupArgs a{};
+    static const uint32_t adapt = [] { const char* e = getenv("TKAMD_CLAIM_ADAPT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
+    a.claim_adapt = adapt;
+    a.counters = counters;
     a.words = t.words;
     a.word_disp = t.word_disp;
     a.word_mask = t.word_mask;
@@ -271,16 +270,19 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                     int64_t n_docs, int64_t* tok_offsets, void* phases) {
     static_assert(COMPACT_CHUNK_MIN == CpShape<2>::CHUNK, "the host sizes the look-back state and chunk_lo by the smallest chunk");
     unsigned long long* const ph = (unsigned long long*)phases;
+    // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); TKAMD_LB_PATIENCE: tests set it to a
+    // handful so that the helping path runs on every wait
+    static const uint32_t patience = [] { const char* e = getenv("TKAMD_LB_PATIENCE"); return e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE; }();
     if (ph && cp_items == 4)                                 // the diagnostic instantiation (TKAMD_PHASES)
         hipLaunchKernelGGL((k_compact<4, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 2)
         hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 4)
         hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else
         hipLaunchKernelGGL(k_compact<8>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
 }

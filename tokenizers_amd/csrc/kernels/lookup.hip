@@ -40,6 +40,7 @@ static_assert(LU_TILE == LOOKUP_TILE_BYTES, "the host sizes the sub-queues per t
 constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile: a key may start at its last byte
 constexpr int LU_POS_CAP = 4096;                         // pre-tokens expanded per round (more in a tile: another round)
 constexpr int LU_STEPS = LU_POS_CAP / LU_NT;             // steps per lane and round (8)
+constexpr uint32_t CLAIM_ADAPT_MIN = 768u;               // candidates a workgroup looks at before it judges the claims' yield (about two tiles of prose)
 constexpr int HOT_SLOTS = 2048;                          // 32 KB of LDS: two workgroups per CU overlap each other's load / probe / queue phases
 
 struct LookupArgs {
@@ -65,6 +66,8 @@ struct LookupArgs {
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
     uint32_t fill;                   // TKAMD_LU_FILL (A/B): pass 1 stores whole rows of tok0
+    uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
+    uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
 };
 // phases of k_lookup<.., true>, as wavefront 0 sees the workgroup's barriers: staging the tile (LDS stores, the last pre-token's end,
@@ -86,6 +89,11 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
     __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand;
+    // the claims' yield as this workgroup sees it: candidates it looked at, how many of them were another pre-token's word.  Text that
+    // never repeats a word pays two dependent round trips per candidate for nothing: a workgroup that has seen CLAIM_ADAPT_MIN
+    // candidates and shared fewer than one in eight stops claiming for the rest of its tiles (its candidates are queued like any
+    // other miss -- the claims are an optimisation, a word nobody claims is simply merged every time).
+    __shared__ uint32_t s_seen, s_shared, s_claims_on;
     __shared__ uint32_t s_fill[4];                                               // fill of this workgroup's sub-queues so far
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (PROF: thread 0 stamps the shader clock behind every barrier that ends a phase; compiled out of the product instantiation)
@@ -96,6 +104,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     if (PROF && tid == 0) ph_t = ph_t0 = __builtin_amdgcn_s_memtime();
     const uint32_t sq = blockIdx.x;                                // this workgroup's PRIVATE sub-queue (the launcher keeps the grid <= NSQ)
     if (tid < 4) s_fill[tid] = 0u;
+    if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
     for (int i = tid; i < HOT_SLOTS; i += LU_NT) s_hot[i] = a.hot[i];
     if (tid < 17) {
         const uint32_t l = (uint32_t)tid;
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         const int64_t t0 = w0 << 6;                                  // first byte of the tile
         __syncthreads();                                             // previous tile's LDS use is over
         tick(LU_PH_PASS3);
+        if (tid == 0 && s_claims_on && a.claim_adapt && s_seen >= CLAIM_ADAPT_MIN && s_shared * 8u < s_seen) s_claims_on = 0u;   // (read behind the next barrier)
         // ---- 1. text tile -> LDS (prefetched registers) ----
         ((uint4*)s_text32)[tid] = make_uint4(pf_t0.a, pf_t0.b, pf_t0.c, pf_t0.d);
         ((uint4*)s_text32)[tid + LU_NT] = make_uint4(pf_t1.a, pf_t1.b, pf_t1.c, pf_t1.d);
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         prefetch(tile + gridDim.x);                                   // the next tile's loads fly while this one is looked up
         __syncthreads();
         tick(LU_PH_STAGE);
+        const bool claims_now = s_claims_on != 0u;                   // (workgroup-uniform for the whole tile)
         const uint32_t n = s_n;                                      // pre-tokens starting in this tile
         const uint32_t pbase = s_pbase;                              // global rank of the first one
         const uint32_t last_rel = s_last_end - (uint32_t)t0;         // (positions below are relative to the tile)
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                     }
                 }
                 bool cand = false;
-                if (a.claims) {                                                     // wavefront-uniform
+                if (claims_now) {                                                   // wavefront-uniform
                     cand = pend && hits_on && len != 0u && len <= CLAIM_MAX_LEN;
                     if (CAND_PASS) {
                         const uint64_t cb = __ballot(cand);
@@ -372,16 +383,24 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                         if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), k4, k5, k6, k7, kmh);
                         const uint32_t slot = claim_slot(hc, a.claim_mask);
                         if (claim_word(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh)) { out = TOK_SLOT | slot; pend = false; }
+                    }
+                    if (!CAND_PASS) {                                               // (the inline variant keeps the yield per step)
+                        const uint64_t cb = __ballot(cand), sb = __ballot(cand && !pend);
+                        if (cb && lane == 0) { atomicAdd(&s_seen, (uint32_t)__popcll(cb)); if (sb) atomicAdd(&s_shared, (uint32_t)__popcll(sb)); }
                         cand = false;
                     }
+                } else if (a.claims) {                                              // (wavefront-uniform) given up: the candidates still count -- the host's pause rule wants the batch's yield
+                    const uint64_t cb = __ballot(pend && hits_on && len != 0u && len <= CLAIM_MAX_LEN);
+                    if (cb && lane == 0) atomicAdd(&s_seen, (uint32_t)__popcll(cb));
                 }
                 finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
-            if (CAND_PASS && a.claims) {                                            // wavefront-uniform
+            if (CAND_PASS && claims_now) {                                          // wavefront-uniform
                 __syncthreads();
                 tick(LU_PH_PASS2);
                 const uint32_t n_cand = s_ncand;
+                if (tid == 0) s_seen += n_cand;                                     // (thread 0 alone writes it)
                 for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_cand; c0 += (uint32_t)LU_NT) {
                     const bool v = c0 + lane < n_cand;
                     const uint32_t rel = s_cand[v ? c0 + lane : c0];
@@ -395,6 +414,8 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                     uint32_t out = 0u;
                     bool pend = v;
                     if (v && claim_word(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh)) { out = TOK_SLOT | slot; pend = false; }
+                    const uint64_t sb = __ballot(v && !pend);
+                    if (sb && lane == 0) atomicAdd(&s_shared, (uint32_t)__popcll(sb));
                     finish(v, pend, rel, s_rel, len, out);
                 }
             }
@@ -407,6 +428,11 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         unsigned long long* const o = a.phases + (size_t)blockIdx.x * 8;
         for (int k = 0; k < 5; ++k) o[k] += ph_acc[k];
         o[LU_PH_TOTAL] += ph_t - ph_t0;
+    }
+    if (tid == 0 && a.claims && a.counters) {                      // the batch's totals: what the host's pause rule reads (capi.cpp read_scalars)
+        if (s_seen) atomicAdd(a.counters + CNT_CLAIM_CANDS, s_seen);
+        if (s_shared) atomicAdd(a.counters + CNT_CLAIM_SHARED, s_shared);
+        if (!s_claims_on) atomicAdd(a.counters + CNT_CLAIM_GAVE_UP, 1u);
     }
     if (tid < 4) {
         uint32_t* const cnt_p = tid == 0 ? a.v[0].counts : tid == 1 ? a.v[1].counts : tid == 2 ? a.v[2].counts : a.v[3].counts;

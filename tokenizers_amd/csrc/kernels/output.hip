@@ -13,16 +13,17 @@
 // A workgroup runs front(c_next) before back(c): the look-back round trips hide behind a whole chunk of work (measured: the
 // un-pipelined kernel spent 45 % of its time in them).  Two LDS buffers alternate.  A chunk whose tokens do not fit the buffer
 // (> CP_STAGE: only text made of many-token pre-tokens) is scattered straight from its rows in back().
-// Chunks are handed out by TICKET (one counter per launch, state[0]; the chunks' look-back words follow it): a workgroup draws the
-// number of its next chunk when it needs one.  Forward progress then needs NO assumption about which workgroups are resident --
-// the reference's encode_batch is &self + Send + Sync (tokenizer/mod.rs:1328-1348): any number of callers, two compactions on two
-// streams each holding half the chip included.  Why: a ticket is only ever held, unpublished, by a workgroup that has STARTED;
-// front() waits for nothing; and a workgroup holds at most one drawn ticket it has not yet run front() on (the one drawn an
-// iteration early, so that the atomic's round trip hides behind a whole chunk of work) while it sits in back(c) of an OLDER
-// ticket.  Take the smallest ticket m whose total is not published: its holder is at most waiting in back(c) for some c < m,
-// i.e. for totals of tickets < c < m, which are all published -- it gets out, and front(m) comes next.  So every wait ends.
-// (The static round-robin hand-out this replaces, chunk = blockIdx + k * gridDim, needed every workgroup of the grid resident:
-// a predecessor could belong to a workgroup the hardware had not scheduled yet.)
+// Chunks go round robin over the grid (chunk = blockIdx + k * gridDim): neighbouring chunks belong to neighbouring workgroups, which
+// run in step, so a look-back rarely finds anything unpublished.  Forward progress does NOT depend on that, nor on which workgroups
+// the hardware keeps resident -- the reference's encode_batch is &self + Send + Sync (tokenizer/mod.rs:1328-1348): any number of
+// callers, two compactions on two streams each holding half the chip included.  front() waits for nothing; back(c) needs the TOTALS
+// of the chunks in front of c, and a total is a pure function of tok0 and the rows, which are final before this kernel starts: a
+// wavefront that has polled an unpublished predecessor lb `patience` times (its owner may not have been scheduled yet, and may
+// not be until this workgroup gets out of the way) computes that chunk's total itself and publishes it on the owner's behalf
+// (results.hip lb_resolve; the owner later stores the same value and does its own copy-out, which nobody waits for).  Every missing
+// total is therefore finite work for whoever waits for it: every wait ends, at any grid and any residency.
+// (Round 4 first handed the chunks out by a global ticket, which gives the same guarantee by construction: an atomic on one address
+// resolves at ~12 ns apiece at the memory side, 19 k tickets a C2 batch, and the kernel went from 0.14 to 0.26 ms -- profiles/r4a_*.)
 // =================================================================================================
 // Two shapes: 8 pre-tokens per lane (chunks of 2048, 56 KB of LDS: two workgroups per CU) and 4 (chunks of 1024, 28 KB and half the
 // registers: five workgroups per CU -- more chunks in flight to hide the load -> rows -> look-back chain of each); the host picks one
@@ -97,13 +98,15 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 // tok_offsets[d] = the token offset of that pre-token -- so the ids-only path never writes the P-sized pt_tokoff (null then).
 // (PROF: the diagnostic instantiation -- TKAMD_PHASES, tkamd_debug_phases -- stamps the shader clock per phase into phases[workgroup][8]:
 // 0 loads + scan + publish of front(), 1 its LDS scatter, 2 the look-back wait, 3 the copy-out, 7 the whole kernel)
+// (min. wavefronts per SIMD: 5 -- five workgroups per CU, <= 96 VGPRs -- for the shapes of 2 and 4 pre-tokens per lane, whose 28 KB of LDS
+// allow it; the helper of the look-back must not cost the main path its occupancy)
 template <int CP_ITEMS, bool PROF = false>
-__global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
+__global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
-                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases) {
+                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience) {
     constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
     unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto tick = [&](int k) {
@@ -116,9 +119,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
     __shared__ uint32_t s_stage[2][CP_STAGE];
     __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
     __shared__ uint32_t s_tot[2];
-    __shared__ unsigned long long s_base, s_tk[2];
-    unsigned long long* const ticket = state;             // the next chunk to hand out (zeroed with the look-back words, which follow)
-    unsigned long long* const lb = state + 1;
+    __shared__ unsigned long long s_base;
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     const int tid = (int)threadIdx.x;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
-        if (tid == 0) { lb_publish(lb, ch, (unsigned long long)tot); s_tot[b] = tot; }
+        if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
         tick(0);
         uint32_t acc = ex;
 #pragma unroll
@@ -150,25 +151,27 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
         }
         tick(1);
     };
-    // lane 0 draws; the value reaches the others through s_tk.  (A workgroup stops drawing once it has seen the end: the counter
-    // overshoots n_chunks by at most two per workgroup.)
-    auto draw = [&]() -> unsigned long long { return tid == 0 ? atomicAdd(ticket, 1ull) : 0ull; };
-    {
-        const unsigned long long d0 = draw(), d1 = draw();
-        if (tid == 0) { s_tk[0] = d0; s_tk[1] = d1; }
-    }
-    __syncthreads();
-    int64_t ch = (int64_t)s_tk[0], nxt = (int64_t)s_tk[1];
+    // the total of a chunk some other workgroup owns, by ONE wavefront (the look-back's way out of waiting: see the top of this section)
+    auto chunk_total = [&](int64_t hc) -> unsigned long long {
+        uint32_t v = 0;
+#pragma unroll 1
+        for (int j = 0; j < CP_NT / 64; ++j) {
+            CpRows<CP_ITEMS> r;
+            v += cp_load<CP_ITEMS>(tok0, rows, crows, hc * CP_CHUNK + (int64_t)(j * 64 + (tid & 63)) * CP_ITEMS, P, r);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        return (unsigned long long)v;
+    };
     int b = 0;
-    if (ch < n_chunks) front(ch, 0);
-    for (; ch < n_chunks; b ^= 1) {
-        // the ticket of the iteration AFTER next: issued here, read at the bottom of the loop
-        const unsigned long long after = nxt < n_chunks ? draw() : (unsigned long long)n_chunks;
+    if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0);
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
+        const int64_t nxt = ch + gridDim.x;
         if (nxt < n_chunks) front(nxt, b ^ 1);            // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
         const uint32_t tot = s_tot[b];
         if (tid < 64) {                                    // wavefront 0 resolves the chunk's place in the token stream
-            const unsigned long long base = lb_resolve(lb, ch, (unsigned long long)tot);
+            const unsigned long long base = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total);
             if (tid == 0) s_base = base;
         }
         __syncthreads();
@@ -200,11 +203,8 @@ __global__ __launch_bounds__(CP_NT) void k_compact(const uint32_t* __restrict__ 
             uint32_t* const dst = ids + base;
             TKAMD_CP_SCATTER(dst, r, o)
         }
-        if (tid == 0) s_tk[0] = after;
         __syncthreads();                                   // buffer b is free for front() of the chunk after next
         tick(3);
-        ch = nxt;
-        nxt = (int64_t)s_tk[0];                            // (rewritten only behind the barriers of the next front())
     }
     if (PROF && tid == 0 && phases) {
         unsigned long long* const o = phases + (size_t)blockIdx.x * 8;

@@ -72,8 +72,10 @@ __device__ __forceinline__ uint4 make_row(uint32_t count, uint32_t s, uint32_t i
 // Single-pass prefix sums (decoupled look-back): chunk c publishes its own total as soon as it knows it, then adds up the
 // published totals of its predecessors until it meets one that already carries a full prefix.  One 64-bit word per chunk
 // holds the state and the value together, so a reader never sees one without the other; all accesses are device-scope
-// atomics (the L2 of one XCD is not coherent with the others').  The caller guarantees that the owner of every earlier chunk
-// is running or done (all workgroups resident, chunks in increasing order per workgroup): the waits cannot deadlock.
+// atomics (the L2 of one XCD is not coherent with the others').  A wait never depends on another workgroup being scheduled: a
+// chunk's total is a pure function of data that is final before the kernel starts, so a wavefront that has polled an unpublished
+// predecessor `patience` times computes that total itself (`help`) and publishes it on the owner's behalf -- compare-and-swap from
+// "nothing", so an owner that got there first wins, and either way the word holds the same value.
 // =================================================================================================
 constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_FLAGS = 3ull << 62, LB_VALUE = ~LB_FLAGS;
 
@@ -85,16 +87,20 @@ __device__ __forceinline__ unsigned long long lb_load(const unsigned long long* 
 }
 // Two halves, so that a workgroup can publish a chunk's total early and come back for its prefix after other work:
 //   lb_publish(state, ch, total)   one lane: total of chunk ch is known
-//   lb_resolve(state, ch, total)   ONE whole wavefront: returns, in every lane, the sum of all chunks before `ch`, and publishes the
-//                                  inclusive prefix of `ch`
+//   lb_resolve(state, ch, total, patience, help)
+//                                  ONE whole wavefront: returns, in every lane, the sum of all chunks before `ch`, and publishes the
+//                                  inclusive prefix of `ch`.  help(c): called by the whole wavefront, returns chunk c's total in every lane.
 __device__ __forceinline__ void lb_publish(unsigned long long* __restrict__ state, int64_t ch, unsigned long long total) {
     lb_store(&state[ch], (ch == 0 ? LB_PREFIX : LB_AGG) | total);
 }
-__device__ __forceinline__ unsigned long long lb_resolve(unsigned long long* __restrict__ state, int64_t ch, unsigned long long total) {
+constexpr uint32_t LB_PATIENCE = 1024;              // polls of an unpublished predecessor before its total is computed here (about half a millisecond; TKAMD_LB_PATIENCE)
+template <class Help>
+__device__ __forceinline__ unsigned long long lb_resolve(unsigned long long* __restrict__ state, int64_t ch, unsigned long long total, uint32_t patience, Help&& help) {
     const int lane = lane_id();
     if (ch == 0) return 0ull;
     unsigned long long run = 0ull;
     int64_t i = ch - 1;
+    uint32_t polls = 0u;
     while (true) {
         const int64_t idx = i - lane;
         unsigned long long st;
@@ -106,6 +112,17 @@ __device__ __forceinline__ unsigned long long lb_resolve(unsigned long long* __r
             if (pref) {
                 const int first = __ffsll((unsigned long long)pref) - 1;          // nearest predecessor with a full prefix
                 empty &= (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
+            }
+            if (empty && ++polls > patience) {                      // (wavefront-uniform) out of patience: one of the missing totals is computed here
+                // (different workgroups pick different ones; having helped once, this wait goes on helping without the long pause)
+                int k = (int)((blockIdx.x + polls) % (uint32_t)__popcll((unsigned long long)empty));
+                uint64_t e = empty;
+                for (; k > 0; --k) e &= e - 1ull;
+                const int64_t hc = i - (int64_t)(__ffsll((unsigned long long)e) - 1);
+                const unsigned long long t = help(hc);
+                if (lane == 0) atomicCAS(&state[hc], 0ull, (hc == 0 ? LB_PREFIX : LB_AGG) | t);
+                patience = 8u;
+                polls = 0u;
             }
         } while (empty);
         const int first = pref ? __ffsll((unsigned long long)pref) - 1 : 63;

@@ -56,63 +56,6 @@ __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __
     }
 }
 
-// The same prefix sums in ONE launch (k_words_reduce + k_scan_single + k_words_down are three, and the middle one is a single
-// workgroup): a workgroup draws a chunk of 256 x 8 mask words by ticket, publishes the chunk's popcount and looks back over its
-// predecessors' (results.hip; the ticket makes every predecessor a workgroup that has started, so the wait ends at any residency).
-// state[0] = the ticket, state[1 + chunk] = the look-back words, all zero on entry.  Used for the start mask of every batch.
-__global__ __launch_bounds__(256) void k_words_scan1(const unsigned long long* __restrict__ mask, int64_t n_words, unsigned long long* __restrict__ state,
-                                                     uint32_t* __restrict__ wprefix, int64_t* __restrict__ total) {
-    __shared__ uint32_t sm[4];
-    __shared__ unsigned long long s_tk, s_base;
-    constexpr int64_t CHUNK = 256 * WS_PER;
-    const int64_t n_chunks = (n_words + CHUNK - 1) / CHUNK;
-    unsigned long long* const lb = state + 1;
-    if (n_chunks == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) *total = 0;
-        return;
-    }
-    for (;;) {
-        if (threadIdx.x == 0) s_tk = atomicAdd(state, 1ull);
-        __syncthreads();
-        const int64_t ch = (int64_t)s_tk;
-        if (ch >= n_chunks) break;                                  // (uniform)
-        const int64_t w0 = ch * CHUNK + (int64_t)threadIdx.x * WS_PER;
-        uint32_t c[WS_PER], v = 0;
-        const bool whole = w0 + WS_PER <= n_words;
-        if (whole) {
-            const ulonglong2* const q = (const ulonglong2*)(mask + w0);
-#pragma unroll
-            for (int k = 0; k < WS_PER / 2; ++k) { const ulonglong2 m = q[k]; c[2 * k] = (uint32_t)__popcll(m.x); c[2 * k + 1] = (uint32_t)__popcll(m.y); }
-        } else {
-#pragma unroll
-            for (int k = 0; k < WS_PER; ++k) c[k] = (w0 + k < n_words) ? (uint32_t)__popcll(mask[w0 + k]) : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < WS_PER; ++k) v += c[k];
-        uint32_t tot;
-        const uint32_t ex = block256_excl_scan(v, sm, &tot);
-        if (threadIdx.x == 0) lb_publish(lb, ch, (unsigned long long)tot);
-        if (threadIdx.x < 64) {
-            const unsigned long long base = lb_resolve(lb, ch, (unsigned long long)tot);
-            if (threadIdx.x == 0) s_base = base;
-        }
-        __syncthreads();
-        uint32_t run = (uint32_t)s_base + ex;
-        if (ch == n_chunks - 1 && threadIdx.x == 0) *total = (int64_t)(s_base + tot);
-        if (whole) {
-            uint4 o0, o1;
-            o0.x = run; run += c[0]; o0.y = run; run += c[1]; o0.z = run; run += c[2]; o0.w = run; run += c[3];
-            o1.x = run; run += c[4]; o1.y = run; run += c[5]; o1.z = run; run += c[6]; o1.w = run;
-            ((uint4*)(wprefix + w0))[0] = o0;
-            ((uint4*)(wprefix + w0))[1] = o1;
-        } else {
-#pragma unroll
-            for (int k = 0; k < WS_PER; ++k) { if (w0 + k < n_words) wprefix[w0 + k] = run; run += c[k]; }
-        }
-        __syncthreads();                                            // s_tk / s_base are rewritten by the next round
-    }
-}
-
 // A wavefront takes 64 consecutive mask words (4 KB of text): one coalesced load of the words and their
 // prefixes, then word by word (broadcast with readlane) lane l tests bit l and stores pt_start[rank] = position.
 // All loads are issued up front; the per-word work is a handful of VALU ops and one masked, rank-ordered store.

@@ -119,8 +119,14 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--ref", default="")
-    ap.add_argument("variants", nargs="*", help='each one a string of VAR=value pairs ("" = the defaults)')
-    a = ap.parse_args()
+    # everything behind a bare `--` is a variant: a string of VAR=value pairs ("" = the defaults)
+    argv = sys.argv[1:]
+    variants = []
+    if "--" in argv:
+        k = argv.index("--")
+        argv, variants = argv[:k], argv[k + 1:]
+    a = ap.parse_args(argv)
+    a.variants = variants
     ts = 1 if a.ood else 0
     if a.child:
         child(a.cfg, ts, a.lines, a.batches, a.steps, a.ref)
