@@ -195,6 +195,15 @@ const uint32_t* tkamd_batch_encoding_parts(const tkamd_batch* b);/* [n_docs][2] 
                                                                    sequence itself, 1.. = its overflowing windows); NULL otherwise */
 void            tkamd_batch_free(tkamd_batch* b);
 
+/* ---- page-locked memory for the caller's side of the host entry ---------------------------------
+ * tkamd_encode_batch takes `text` / `doc_offsets` from any host memory; from pageable memory the runtime stages the copy through
+ * its own bounce buffers (about half the link's rate, and the calling thread does the copying).  The binding has to pack the
+ * documents into one buffer anyway: packing them into a block from here costs nothing extra and lets the H2D
+ * copies run as plain DMA.  Blocks are portable across the devices of a multi-device handle; free them with tkamd_pinned_free
+ * (never free()).  Fails with TKAMD_ERR_DEVICE where no HIP device exists. */
+int  tkamd_pinned_alloc(size_t bytes, void** out);
+void tkamd_pinned_free(void* p);
+
 /* ---- device-buffer entry: inputs already resident in HBM, outputs stay in HBM ---------------
  * Enqueues the whole path on `hip_stream` (a hipStream_t, NULL = default stream) and returns
  * without synchronising.  The output pointers refer to the handle's workspace and stay valid

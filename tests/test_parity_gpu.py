@@ -335,7 +335,8 @@ def test_encode_batch_matches_golden_char_offsets(name):
     {"TKAMD_CLAIMS": "0"},                                                      # every occurrence of a word goes to the model kernels
     {"TKAMD_LEAN_PROLOGUE": "0", "TKAMD_LU_FILL": "1", "TKAMD_CLAIM_ADAPT": "0", "TKAMD_MERGE_ONE": "1"},   # validate / sanitize / mark as kernels of their own, whole rows of tok0 from pass 1, claims that never give up, one merge launch
     {"TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_ONE": "0", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
-], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges"])
+    {"TKAMD_HOT_SLOTS": "1024"},                                                # the three-workgroups-per-CU shape of the lookup (1,024 hot slots, 3,072 positions per round, text loaded per tile)
+], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-3-per-cu"])
 def test_alternative_kernels_agree(gpt2_json, variant):
     """The A/B kernel variants (the fallbacks for vocabularies whose new ids are not rank + c, and the earlier generations
     of the pre-tokenizer) must give the same ids and offsets as the oracle: run them in a subprocess because the
@@ -973,3 +974,24 @@ def test_a_malformed_document_csr_is_reported_not_dereferenced(name, gpt2_json):
             tok.encode_packed(buf, bad, offsets="byte", word_ids=True)
     got = tok.encode_packed(buf, off)
     assert np.array_equal(got.ids, want[0]) and np.array_equal(got.tok_offsets, want[1])
+
+
+def test_pinned_caller_buffers_give_the_same_result(gpt2, gpt2_oracle):
+    """tkamd_pinned_alloc: the caller's side of the host entry in page-locked memory (the H2D copies then run as plain DMA).  The
+    same documents from a pinned block, from ordinary memory and from a list[str] (whose staging is pinned since round 4) must
+    give one result, and the blocks can be made, viewed as other dtypes and dropped freely."""
+    import tokenizers_amd as ta
+    docs = synth.gen_lines(20000, text_seed=88) + ["", "é" * 300, ""]
+    buf, off = ta.pack_documents(docs)
+    pb, po = ta.pinned_copy(buf), ta.pinned_copy(off)
+    assert pb.dtype == np.uint8 and po.dtype == np.int64 and np.array_equal(pb, buf) and np.array_equal(po, off)
+    exp = gpt2_oracle.encode_batch(docs)
+    for got in (gpt2.encode_packed(pb, po), gpt2.encode_packed(buf, off), gpt2.encode_batch_fast(docs, add_special_tokens=False)):
+        assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
+    got = gpt2.encode_packed(pb, po, offsets="byte", word_ids=True)
+    assert np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)
+    for n in (0, 1, 4097):
+        a = ta.pinned_empty(n, np.int64)
+        a[:] = 7
+        assert a.shape == (n,) and a.dtype == np.int64
+    del pb, po, a

@@ -203,17 +203,32 @@ def test_results_do_not_depend_on_the_order_the_threads_run_in():
 
 def test_a_batch_whose_queue_rows_reach_bit_30_is_refused():
     """tok0 carries 30 bits of row index (its two top bits say what the word is: an id, a row, a slot): the host refuses a batch whose
-    work queues would need more rows before it gets that far (found by this emulation while bit 29 still flagged cached rows: with
-    its one-CU device the 512 sub-queues of a queue are sized for two lookup workgroups, so a 5 MB batch already needs 2^30 rows; on
-    the MI355X that takes about 3 GB of text)."""
-    import tokenizers_amd as ta
-    from oracle import synth
-    from tests.helpers import load_tokenizer_json
-    tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000"), device=0)      # (behind BertNormalizer the queues are sized for 3x the text)
-    docs = [d for d in synth.gen_lines(48000, text_seed=13) if d.isascii()]
-    with pytest.raises(ValueError, match="30-bit"):
-        tok.encode_batch_fast(docs, add_special_tokens=False)
-    assert tok.encode_batch_fast(docs[:2000], add_special_tokens=False).n_tokens > 0
+    work queues would need more rows before it gets that far -- about 3 GB of text on the MI355X (found by this emulation while bit 29
+    still flagged cached rows).  Rows are counted for the sub-queues in use only (one per lookup workgroup), so the emulation's one-CU
+    device takes a 5 MB batch through (round 3 sized every queue for all 512 sub-queues and refused it); the refusal itself is seen
+    with the threshold lowered (TKAMD_ROW_LIMIT_BITS, a test hook: the real width never changes)."""
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import pytest, tokenizers_amd as ta\n"
+        "from oracle import synth\n"
+        "from tests.helpers import load_tokenizer_json\n"
+        "tok = ta.Tokenizer.from_str(load_tokenizer_json('bert_wordpiece_4000'), device=0)\n"
+        "docs = ['the quick brown fox jumps over the lazy dog and runs off into the woods again ' * 2] * 32000\n"
+        "try:\n"
+        "    tok.encode_batch_fast(docs, add_special_tokens=False)\n"
+        "    print('TOOK_IT')\n"
+        "except ValueError as e:\n"
+        "    print('REFUSED' if '30-bit' in str(e) else 'OTHER ' + str(e))\n"
+        "print('SMALL_OK' if tok.encode_batch_fast(docs[:100], add_special_tokens=False).n_tokens > 0 else 'SMALL_BAD')\n") % ROOT
+    for bits, want in ((None, "TOOK_IT"), ("18", "REFUSED")):
+        env = dict(os.environ, TKAMD_SIMT="1")
+        if bits:
+            env["TKAMD_ROW_LIMIT_BITS"] = bits
+        site = os.path.join(ROOT, "tests", "harness", "simt_site")
+        env["PYTHONPATH"] = site + os.pathsep + env.get("PYTHONPATH", "")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert want in r.stdout and "SMALL_OK" in r.stdout, (bits, r.stdout[-1500:] + r.stderr[-1500:])
 
 
 def test_tokens_added_at_run_time_are_matched_like_the_wheel_matches_them(ref_tokenizers):

@@ -40,6 +40,7 @@ SYMBOLS = [
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
     "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16", "tkamd_encode_special_tokens",
     "tkamd_tokenizer_from_json_devices", "tkamd_tokenizer_set_collect", "tkamd_tokenizer_devices", "tkamd_shard_stats", "tkamd_debug_phases",
+    "tkamd_pinned_alloc", "tkamd_pinned_free",
 ]
 COLLECT_HOST, COLLECT_ROOT_P2P, COLLECT_ROOT_RCCL = 0, 1, 2
 
@@ -99,6 +100,10 @@ def load() -> C.CDLL:
     lib.tkamd_tokenizer_devices.restype = i32
     lib.tkamd_shard_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), i32, C.POINTER(C.c_int)]
     lib.tkamd_shard_stats.restype = i32
+    lib.tkamd_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.tkamd_pinned_alloc.restype = i32
+    lib.tkamd_pinned_free.argtypes = [vp]
+    lib.tkamd_pinned_free.restype = None
     lib.tkamd_debug_phases.argtypes = [vp, i32, C.POINTER(C.c_uint64), i32]
     lib.tkamd_debug_phases.restype = i32
     lib.tkamd_tokenizer_free.argtypes = [vp]

@@ -57,6 +57,10 @@ struct HipError : std::runtime_error {
 // handle with device >= 0), so a parent that only ever made host-only handles leaves its children free to use the GPU.
 std::atomic<bool> g_hip_used{false};     // this process made a device handle
 std::atomic<bool> g_forked{false};       // ... and we are a child forked after that
+// (first touch of the HIP runtime by this process: from here on a fork()ed child must not use what it inherits)
+void note_hip_used() {
+    if (!g_hip_used.exchange(true)) pthread_atfork(nullptr, nullptr, [] { g_forked = true; });
+}
 void check_not_forked() {
     if (g_forked) throw HipError("this process was fork()ed after its parent initialised the HIP runtime: the inherited device state is unusable "
                                  "(create tokenizers in the child before the parent touches the GPU, or start workers with spawn / exec)");
@@ -241,6 +245,7 @@ struct tkamd_tokenizer {
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
+    int hot_slots = 2048;        // slots of the hot-word table (kernels/lookup.hip: 2048 = two lookup workgroups per CU, 1024 = three; TKAMD_HOT_SLOTS)
     int cp_grid = 0;             // grid of k_compact: what is resident at once (any grid makes progress -- its look-back helps itself --, TKAMD_CP_GRID)
     // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
     // of the step (the claims' worst case).  Inside a batch every lookup workgroup gives the claims up by itself once
@@ -500,31 +505,61 @@ void verify_direct_words(tkamd_tokenizer* t) {
 // to a lower id stays reachable through the perfect-hash table.
 void build_hot_table(tkamd_tokenizer* t) {
     HostModel& hm = t->hm;
-    const uint32_t slots = (uint32_t)hot_table_slots();
+    const uint32_t slots = (uint32_t)t->hot_slots, n_buckets = slots / 4u;
     std::vector<HotSlot> hot(slots, HotSlot{0u, 0u, 0u, 0u});
+    std::vector<uint16_t> disp(n_buckets, 0);
     std::vector<const WordSlot*> cand;
     const bool all_final = hm.model != MODEL_BPE || hm.ignore_merges;
     for (const WordSlot& w : hm.word_table)
         if (w.len && w.len <= (uint32_t)HOT_MAX_KEY && (all_final || (w.flags & WORD_DIRECT))) cand.push_back(&w);
+    // the lowest ids (= the most frequent words: the trainers append tokens in frequency order), as many as fit at 15/16 full
     std::sort(cand.begin(), cand.end(), [](const WordSlot* a, const WordSlot* b) { return a->id < b->id; });
+    if (cand.size() > (size_t)slots * 15 / 16) cand.resize((size_t)slots * 15 / 16);
+    auto hash_of = [&](const WordSlot* w) { return hot_hash((uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->len, hm.word_seed); };
+    // hash-and-displace: the fullest buckets first, each takes the first displacement that drops all of its words on free slots; a
+    // bucket nothing fits loses its highest id and tries again (that word is then answered by the table in HBM, like every other)
+    std::vector<std::vector<const WordSlot*>> buckets(n_buckets);
+    for (const WordSlot* w : cand) buckets[hot_bucket(hash_of(w), slots)].push_back(w);      // (ascending ids inside a bucket)
+    std::vector<uint32_t> order(n_buckets);
+    for (uint32_t i = 0; i < n_buckets; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return buckets[a].size() > buckets[b].size(); });
     int n = 0;
-    for (const WordSlot* w : cand) {
-        const uint32_t k0 = (uint32_t)w->lo, k1 = (uint32_t)(w->lo >> 32), k2 = (uint32_t)w->hi;
-        HotSlot& h = hot[hot_hash(k0, k1, k2, w->len, hm.word_seed) & (slots - 1)];
-        if (h.id_len) continue;
-        h = HotSlot{k0, k1, k2, w->id | (w->len << 24)};
-        ++n;
+    for (uint32_t bi : order) {
+        std::vector<const WordSlot*>& bk = buckets[bi];
+        while (!bk.empty()) {
+            uint32_t d = 0;
+            for (; d < slots; ++d) {
+                bool ok = true;
+                for (size_t i = 0; i < bk.size() && ok; ++i) {
+                    const uint32_t s = hot_slot(hash_of(bk[i]), d, slots);
+                    ok = hot[s].id_len == 0u;
+                    for (size_t j = 0; j < i && ok; ++j) ok = hot_slot(hash_of(bk[j]), d, slots) != s;
+                }
+                if (ok) break;
+            }
+            if (d < slots) {
+                disp[bi] = (uint16_t)d;
+                for (const WordSlot* w : bk) hot[hot_slot(hash_of(w), d, slots)] = HotSlot{(uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->id | (w->len << 24)};
+                n += (int)bk.size();
+                break;
+            }
+            bk.pop_back();
+        }
     }
     t->n_hot = n;
-    upload(t->t_hot, hot);
+    std::vector<uint8_t> blob((size_t)hot_table_bytes((int)slots));
+    memcpy(blob.data(), hot.data(), (size_t)slots * 16);
+    memcpy(blob.data() + (size_t)slots * 16, disp.data(), (size_t)n_buckets * 2);
+    upload(t->t_hot, blob);
 }
-
 
 // Queue capacities for a text of N bytes.  Every queue is NSQ sub-queues (results.hip), one per lookup workgroup; a workgroup
 // takes every grid-th tile of LOOKUP_TILE_BYTES.  A pre-token of class 1 / 2 / 3 is longer than 16 / 32 / 64 bytes, so those three
 // are sized for the worst case outright; the <= 16-byte queue (worst case: half the bytes) starts at 1 / q16_div of them and
 // the batch is run again with the worst-case size if it ever overflows (ERR_QUEUE_FULL; natural text queues 1/50 .. 1/6).
-int lookup_grid(const tkamd_tokenizer* t) { return std::min(2 * t->n_cu, (int)NSQ); }
+// the lookup's grid: what is resident at once (kernels/lookup.hip LuShape), one private sub-queue per workgroup
+int lookup_grid(const tkamd_tokenizer* t) { return std::min((t->hot_slots == 1024 ? 3 : 2) * t->n_cu, (int)NSQ); }
+
 struct QueueSizes {
     uint32_t sq_cap[4], row_base[4];
     size_t total;
@@ -538,7 +573,7 @@ QueueSizes queue_sizes(size_t N, uint32_t q16_div, int grid) {
     z.sq_cap[2] = (uint32_t)(per_sq / 33 + 16);
     z.sq_cap[3] = (uint32_t)(per_sq / 65 + 16);
     size_t acc = 0;
-    for (int c = 0; c < 4; ++c) { z.row_base[c] = (uint32_t)acc; acc += (size_t)z.sq_cap[c] * NSQ; }
+    for (int c = 0; c < 4; ++c) { z.row_base[c] = (uint32_t)acc; acc += (size_t)z.sq_cap[c] * (size_t)grid; }      // (sub-queues grid .. NSQ - 1 stay empty)
     z.total = acc;
     return z;
 }
@@ -1280,7 +1315,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
     const size_t N = (size_t)n_x;
     const QueueSizes qz = queue_sizes(N, t->q16_div, lookup_grid(t));
-    if (qz.total >= (size_t)ROW_INDEX_LIMIT) throw Invalid("batch too large for the work queues (row indices are 30-bit: about 3 GB of text): split it");
+    // (TKAMD_ROW_LIMIT_BITS: a test lowers the threshold -- never the 30 bits tok0 really has -- to see the refusal without a 3 GB batch)
+    static const size_t row_limit = [] { const char* e = getenv("TKAMD_ROW_LIMIT_BITS"); return e ? std::min<size_t>((size_t)1 << std::max(8, atoi(e)), ROW_INDEX_LIMIT) : (size_t)ROW_INDEX_LIMIT; }();
+    if (qz.total >= row_limit) throw Invalid("batch too large for the work queues (row indices are 30-bit: about 3 GB of text): split it");
     QueuePlan plan{};
     for (int c = 0; c < 4; ++c) {
         plan.v[c].q = (QItem*)(w->w_queues.as<uint8_t>() + (size_t)qz.row_base[c] * 8);
@@ -1359,7 +1396,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         open_word_cache();
         set_publish();
         launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters, t->hot_slots);
         pf.end();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
@@ -1425,7 +1462,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u}, 0u, 1u);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u}, 0u, 1u, nullptr, nullptr, t->hot_slots);
         for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u});      // words longer than 16 bytes
         pf.end();
     } else {
@@ -1442,7 +1479,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         set_publish();
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0), d_counters);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0), d_counters, t->hot_slots);
         pf.end();
         pf.begin("wordpiece");
         launch_wordpiece(st, grid, true, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
@@ -1692,13 +1729,14 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (hipGetDeviceCount(&n) != hipSuccess || n == 0) throw HipError("no HIP device available (the HIP path has no CPU fallback)");
         if (device >= n) throw HipError("HIP device ordinal out of range");
         HIP_CHECK(hipSetDevice(device));
-        if (!g_hip_used.exchange(true)) pthread_atfork(nullptr, nullptr, [] { g_forked = true; });
+        note_hip_used();
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
         upload_tables(t.get());
         if (!primary) verify_direct_words(t.get());
+        if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 1024 ? 1024 : 2048;
         build_hot_table(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
@@ -2629,6 +2667,22 @@ int tkamd_profile_read(tkamd_tokenizer* t, tkamd_stage_time* stages, int max_sta
     *n_stages = n;
     if (reset) t->acc.clear();
     return TKAMD_OK;
+}
+
+int tkamd_pinned_alloc(size_t bytes, void** out) {
+    if (!out) return set_error(TKAMD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    return guarded([&]() -> int {
+        check_not_forked();
+        void* p = nullptr;
+        note_hip_used();
+        HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocPortable));
+        *out = p;
+        return TKAMD_OK;
+    });
+}
+void tkamd_pinned_free(void* p) {
+    if (p && !g_forked) (void)hipHostFree(p);
 }
 
 int tkamd_debug_phases(tkamd_tokenizer* t, int which, uint64_t* out, int reset) {

@@ -51,7 +51,7 @@ struct BnTables {
 // one queued pre-token (kernels/results.hip); a queue = NSQ sub-queues of sq_cap entries, one per lookup workgroup, each with its
 // own fill counter
 struct QItem;
-constexpr int NSQ = 512;
+constexpr int NSQ = 768;                                  // (three lookup workgroups per CU x 256 CUs)
 constexpr int QCNT_STRIDE = 1;
 constexpr int LOOKUP_TILE_BYTES = 16384;                  // text one lookup workgroup takes at a time (kernels/lookup.hip)
 constexpr int QCNT_WORDS = 4 * NSQ * QCNT_STRIDE;       // fill counters of the four queues
@@ -289,8 +289,7 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr, uint32_t* counters = nullptr);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
-int hot_table_slots();
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr, uint32_t* counters = nullptr, int hot_slots = 2048);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
 // group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
 // 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
 // also (group 6 only): a second queue for the same launch

@@ -44,11 +44,11 @@ void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_d
     hipLaunchKernelGGL(k_doc_first_pretok, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, startmask, wprefix, n_pretok, doc_pt, chunk_lo,
                        (uint32_t)(CP_NT * cp_items), err, san);
 }
-int hot_table_slots() { return HOT_SLOTS; }
+
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk, void* phases, uint32_t* counters) {
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases, uint32_t* counters, int hot_slots) {
     LookupArgs a{};
     static const uint32_t adapt = [] { const char* e = getenv("TKAMD_CLAIM_ADAPT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
     a.claim_adapt = adapt;
@@ -80,19 +80,25 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.phases = (unsigned long long*)phases;
     static const uint32_t fill = [] { const char* e = getenv("TKAMD_LU_FILL"); return (e && !strcmp(e, "1")) ? 1u : 0u; }();
     a.fill = fill;
-    if (phases) {                                            // the diagnostic instantiations (TKAMD_PHASES)
-        if (endmask) hipLaunchKernelGGL((k_lookup<true, true>), dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
-        else hipLaunchKernelGGL((k_lookup<false, true>), dim3(grid), dim3(LU_NT), lookup_lds_bytes(false), st, a);
+    const int lds = lookup_lds_bytes(hot_slots);
+#define TKAMD_LU(E, P, H) hipLaunchKernelGGL((k_lookup<E, P, H>), dim3(grid), dim3(LU_NT), lds, st, a)
+    if (hot_slots == 1024) {
+        if (phases) { if (endmask) TKAMD_LU(true, true, 1024); else TKAMD_LU(false, true, 1024); }     // (the diagnostic instantiations: TKAMD_PHASES)
+        else if (endmask) TKAMD_LU(true, false, 1024);
+        else TKAMD_LU(false, false, 1024);
+    } else {
+        if (phases) { if (endmask) TKAMD_LU(true, true, 2048); else TKAMD_LU(false, true, 2048); }
+        else if (endmask) TKAMD_LU(true, false, 2048);
+        else TKAMD_LU(false, false, 2048);
     }
-    else if (endmask) hipLaunchKernelGGL(k_lookup<true>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(true), st, a);
-    else hipLaunchKernelGGL(k_lookup<false>, dim3(grid), dim3(LU_NT), lookup_lds_bytes(false), st, a);
+#undef TKAMD_LU
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                       uint32_t* tmp_ids, uint32_t* tmp_end, const QView* also) {
     uint4* r = (uint4*)rows;
     const QView none{};
     // LDS-resident keys (needs newid_affine; prepare_long_kernel() raised the LDS limit)
-    if (group == 5) launch_lds_merge<16, 704, true, true>(st, grid * 2, t, text, v, none, r, tmp_ids, tmp_end);   // two 704-lane workgroups per CU
+    if (group == 5) launch_lds_merge<16, 640, true, true>(st, grid * 2, t, text, v, none, r, tmp_ids, tmp_end);   // two 640-lane workgroups per CU (704 with 512 sub-queues: the prefix array is static LDS)
     else if (group == 6) launch_lds_merge<32, 768, true, true>(st, grid, t, text, v, also ? *also : none, r, tmp_ids, tmp_end);
     else if (group == 1)
         hipLaunchKernelGGL(k_bpe_merge_lane<16>, dim3(grid), dim3(256), 0, st, t, text, v, r, tmp_ids, tmp_end);
@@ -235,11 +241,11 @@ void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const ui
 int long_kernel_lds_bytes() { return LONG_PT_MAX * (4 + 4 + 4 + 2 + 2); }
 int prepare_long_kernel() {
     int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_long, hipFuncAttributeMaxDynamicSharedMemorySize, long_kernel_lds_bytes());
-    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(true));
-    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(false));
-    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(true));
-    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(false));
-    if (rc == 0) rc = prepare_lds_merge<16, 704, true, true>();
+#define TKAMD_LU_ATTR(E, P, H) if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<E, P, H>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_lds_bytes(H))
+    TKAMD_LU_ATTR(true, false, 2048); TKAMD_LU_ATTR(false, false, 2048); TKAMD_LU_ATTR(true, true, 2048); TKAMD_LU_ATTR(false, true, 2048);
+    TKAMD_LU_ATTR(true, false, 1024); TKAMD_LU_ATTR(false, false, 1024); TKAMD_LU_ATTR(true, true, 1024); TKAMD_LU_ATTR(false, true, 1024);
+#undef TKAMD_LU_ATTR
+    if (rc == 0) rc = prepare_lds_merge<16, 640, true, true>();
     if (rc == 0) rc = prepare_lds_merge<32, 768, true, true>();
     return rc;
 }

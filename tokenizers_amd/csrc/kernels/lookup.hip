@@ -38,10 +38,16 @@ constexpr int LU_TILE_WORDS = 256;                       // mask words per tile
 constexpr int LU_TILE = LU_TILE_WORDS * 64;              // bytes of text per tile (16 KB)
 static_assert(LU_TILE == LOOKUP_TILE_BYTES, "the host sizes the sub-queues per tile (capi.cpp queue_sizes)");
 constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile: a key may start at its last byte
-constexpr int LU_POS_CAP = 4096;                         // pre-tokens expanded per round (more in a tile: another round)
-constexpr int LU_STEPS = LU_POS_CAP / LU_NT;             // steps per lane and round (8)
+// Two shapes, picked per handle (TKAMD_HOT_SLOTS):
+//   HOT = 2048  hot-word table of 2,048 slots (33 KB), 4,096 pre-tokens expanded per round: 75 KB of LDS, two workgroups per CU
+//   HOT = 1024  1,024 slots (16.5 KB), 3,072 per round (a tile of prose holds ~2,700): 52 KB and <= 80 VGPRs, THREE workgroups per CU --
+//               passes 2 and 3 wait for memory (70 % of the kernel's time, profiles/r4b_*), and more wavefronts hide more of it
+template <int HOT> struct LuShape {
+    static_assert(HOT == 2048 || HOT == 1024, "shapes the launcher knows");
+    static constexpr int POS_CAP = HOT == 2048 ? 4096 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
+    static constexpr int WAVES_PER_SIMD = HOT == 2048 ? 4 : 6;     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU
+};
 constexpr uint32_t CLAIM_ADAPT_MIN = 768u;               // candidates a workgroup looks at before it judges the claims' yield (about two tiles of prose)
-constexpr int HOT_SLOTS = 2048;                          // 32 KB of LDS: two workgroups per CU overlap each other's load / probe / queue phases
 
 struct LookupArgs {
     const uint8_t* text;
@@ -54,7 +60,7 @@ struct LookupArgs {
     QView v[4];                      // queues: <= 16 bytes, <= 32, <= 64, longer (this workgroup fills sub-queue blockIdx of each)
     int* err;
     const unsigned long long* matchmask;   // added-token matches: one pre-token, id patched in later
-    const uint4* hot;                // [HOT_SLOTS] {k0, k1, k2, id | len << 24}, len 0 = empty
+    const uint4* hot;                // [HOT] {k0, k1, k2, id | len << 24}, len 0 = empty; then [HOT / 4] 16-bit displacements (tables.hpp)
     const WordSlot* words;           // perfect-hash table behind the hot table
     const uint16_t* word_disp;
     uint32_t word_mask, word_seed, word_bmask;
@@ -79,11 +85,13 @@ enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_P
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
 
 // (claim_hash_long / claim_slot / CLAIM_MAX_LEN: bpe.hip, next to the publish helper the model kernels call)
-template <bool HAS_END, bool PROF = false>
-__global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 wavefronts / SIMD = two workgroups per CU: <= 128 VGPRs
+template <bool HAS_END, bool PROF = false, int HOT = 2048>
+__global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(LookupArgs a) {      // (4 wavefronts / SIMD: <= 128 VGPRs; 6: <= 80)
+    constexpr int LU_POS_CAP = LuShape<HOT>::POS_CAP;
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lu_lds)
-    uint4* s_hot = (uint4*)lu_lds;                                              // [HOT_SLOTS]
-    uint32_t* s_text32 = (uint32_t*)(s_hot + HOT_SLOTS);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
+    uint4* s_hot = (uint4*)lu_lds;                                              // [HOT]
+    uint16_t* s_hdisp = (uint16_t*)(s_hot + HOT);                               // [HOT / 4]
+    uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
     uint16_t* s_pos = (uint16_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [LU_POS_CAP + 2] start of rank r, relative to the tile
     uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     const uint32_t sq = blockIdx.x;                                // this workgroup's PRIVATE sub-queue (the launcher keeps the grid <= NSQ)
     if (tid < 4) s_fill[tid] = 0u;
     if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
-    for (int i = tid; i < HOT_SLOTS; i += LU_NT) s_hot[i] = a.hot[i];
+    static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
+    for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
     if (tid < 17) {
         const uint32_t l = (uint32_t)tid;
         auto m = [&](uint32_t lo) -> uint32_t { return l >= lo + 4u ? 0xFFFFFFFFu : (l > lo ? ((1u << (8u * (l - lo))) - 1u) : 0u); };
@@ -127,16 +136,24 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
     Unaligned16 pf_t0{0u, 0u, 0u, 0u}, pf_t1{0u, 0u, 0u, 0u}, pf_ts{0u, 0u, 0u, 0u};
     unsigned long long pf_ms = 0ull, pf_me = 0ull, pf_scan = 0ull;
     uint32_t pf_wp = 0u, pf_first = 0u;
+    // (the three-workgroups-per-CU shape has 80 VGPRs: it keeps the masks a tile ahead but loads the text when the tile starts -- the
+    // other two workgroups of the CU cover that round trip)
+    constexpr bool PF_TEXT = HOT == 2048;
+    auto load_text = [&](int64_t tile, Unaligned16& x0, Unaligned16& x1, Unaligned16& xs) {
+        x0 = x1 = xs = Unaligned16{0u, 0u, 0u, 0u};
+        if (tile >= n_tiles) return;
+        const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
+        const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT, gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
+        if (g0 + 16 <= readable) x0 = *(const Unaligned16*)(a.text + g0);
+        if (g1 + 16 <= readable) x1 = *(const Unaligned16*)(a.text + g1);
+        if (tid < 4 && gs + 16 <= readable) xs = *(const Unaligned16*)(a.text + gs);
+    };
     auto prefetch = [&](int64_t tile) {
-        pf_t0 = pf_t1 = pf_ts = Unaligned16{0u, 0u, 0u, 0u};
+        if (PF_TEXT) load_text(tile, pf_t0, pf_t1, pf_ts);
         pf_ms = pf_me = pf_scan = 0ull;
         pf_wp = pf_first = 0u;
         if (tile >= n_tiles) return;
-        const int64_t w0 = tile * LU_TILE_WORDS, t0 = w0 << 6;
-        const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT, gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
-        if (g0 + 16 <= readable) pf_t0 = *(const Unaligned16*)(a.text + g0);
-        if (g1 + 16 <= readable) pf_t1 = *(const Unaligned16*)(a.text + g1);
-        if (tid < 4 && gs + 16 <= readable) pf_ts = *(const Unaligned16*)(a.text + gs);
+        const int64_t w0 = tile * LU_TILE_WORDS;
         const int64_t w = w0 + hword;
         if (w < total_words) { pf_ms = a.startmask[w]; pf_wp = a.wprefix[w]; }
         if (has_end && w < end_words) pf_me = a.endmask[w];
@@ -153,10 +170,15 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
         __syncthreads();                                             // previous tile's LDS use is over
         tick(LU_PH_PASS3);
         if (tid == 0 && s_claims_on && a.claim_adapt && s_seen >= CLAIM_ADAPT_MIN && s_shared * 8u < s_seen) s_claims_on = 0u;   // (read behind the next barrier)
-        // ---- 1. text tile -> LDS (prefetched registers) ----
-        ((uint4*)s_text32)[tid] = make_uint4(pf_t0.a, pf_t0.b, pf_t0.c, pf_t0.d);
-        ((uint4*)s_text32)[tid + LU_NT] = make_uint4(pf_t1.a, pf_t1.b, pf_t1.c, pf_t1.d);
-        if (tid < 4) ((uint4*)s_text32)[2 * LU_NT + tid] = make_uint4(pf_ts.a, pf_ts.b, pf_ts.c, pf_ts.d);
+        // ---- 1. text tile -> LDS (prefetched registers; or loaded now and dropped into LDS behind the mask work below) ----
+        Unaligned16 tx0 = pf_t0, tx1 = pf_t1, txs = pf_ts;
+        if (!PF_TEXT) load_text(tile, tx0, tx1, txs);
+        auto stage_text = [&]() {
+            ((uint4*)s_text32)[tid] = make_uint4(tx0.a, tx0.b, tx0.c, tx0.d);
+            ((uint4*)s_text32)[tid + LU_NT] = make_uint4(tx1.a, tx1.b, tx1.c, tx1.d);
+            if (tid < 4) ((uint4*)s_text32)[2 * LU_NT + tid] = make_uint4(txs.a, txs.b, txs.c, txs.d);
+        };
+        if (PF_TEXT) stage_text();
         // ---- 2. the tile's mask words: local rank of each word's first start ----
         const unsigned long long ms = pf_ms, me = pf_me;
         uint32_t rbase = 0xFFFFFFFFu;
@@ -187,6 +209,7 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
             }
             if (lane == 0) s_last_end = found;
         }
+        if (!PF_TEXT) stage_text();
         prefetch(tile + gridDim.x);                                   // the next tile's loads fly while this one is looked up
         __syncthreads();
         tick(LU_PH_STAGE);
@@ -244,7 +267,8 @@ __global__ __launch_bounds__(LU_NT, 4) void k_lookup(LookupArgs a) {      // 4 w
                 uint32_t s_rel, len, k0, k1, k2, k3;
                 load_key(v ? rel : cnt - 1u, s_rel, len, k0, k1, k2, k3, false);
                 // settled words of <= 12 bytes (a slot's length is <= 12 and 0 when empty, so a hit proves bytes 12.. are not part of the key)
-                const uint4 h = s_hot[hot_hash(k0, k1, k2, len, a.word_seed) & (uint32_t)(HOT_SLOTS - 1)];
+                const uint32_t hh = hot_hash(k0, k1, k2, len, a.word_seed);
+                const uint4 h = s_hot[hot_slot(hh, (uint32_t)s_hdisp[hot_bucket(hh, (uint32_t)HOT)], (uint32_t)HOT)];
                 const uint32_t diff = (h.x ^ k0) | (h.y ^ k1) | (h.z ^ k2) | ((h.w >> 24) ^ len);
                 bool hit = v && diff == 0u && len != 0u && hits_on;
                 bool miss = v && !hit;
@@ -481,7 +505,9 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
     }
 }
 
-constexpr int lookup_lds_bytes(bool) { return HOT_SLOTS * 16 + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * (LU_POS_CAP + 2) * 2 + LU_POS_CAP * 2; }      // (the end array's place holds the candidate list when there are no end masks)
+constexpr int lookup_lds_bytes(int hot) {      // (the end array's place holds the candidate list when there are no end masks)
+    return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 4096 : 3072) + 2) * 2 + (hot == 2048 ? 4096 : 3072) * 2;
+}
 
 // =================================================================================================
 // K_word_cache_insert: after the merge kernels, every queued pre-token of <= 16 bytes whose result fits a row (<= 4 tokens) is

@@ -51,8 +51,8 @@ __device__ __forceinline__ uint32_t qview_prefix(const QView& v, uint32_t* s_pre
 __device__ __forceinline__ uint32_t qview_pos(const uint32_t* s_pre, uint32_t sq_cap, uint32_t item) {
     uint32_t lo = 0, hi = NSQ;                              // invariant: s_pre[lo] <= item < s_pre[hi]
 #pragma unroll
-    for (int it = 0; it < 9; ++it) {
-        static_assert(NSQ <= 512, "binary search depth");
+    for (int it = 0; it < 10; ++it) {
+        static_assert(NSQ <= 1024, "binary search depth");
         const uint32_t mid = (lo + hi) >> 1;
         if (hi - lo > 1) { if (s_pre[mid] <= item) lo = mid; else hi = mid; }
     }

@@ -27,6 +27,39 @@ except ImportError:                 # pragma: no cover - pure-Python marshalling
     _marshal = None
 
 
+class _PinnedBlock:
+    """Page-locked host memory from ``tkamd_pinned_alloc``; numpy views keep it alive (``__array_interface__``), the last one frees it."""
+
+    def __init__(self, nbytes: int):
+        lib = _lib.load()
+        p = C.c_void_p()
+        _lib.check(lib.tkamd_pinned_alloc(max(int(nbytes), 64), C.byref(p)))
+        self._lib, self._p, self.nbytes = lib, p.value, max(int(nbytes), 64)
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self._p, False), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "_p", None):
+            try:
+                self._lib.tkamd_pinned_free(self._p)
+            except Exception:
+                pass
+            self._p = None
+
+
+def pinned_empty(n: int, dtype=np.uint8) -> np.ndarray:
+    """An uninitialised array in page-locked host memory (``tkamd_pinned_alloc``): what ``encode_packed`` copies to the device at
+    the link's full rate, as plain DMA, instead of through the runtime's bounce buffers.  Needs a HIP device."""
+    dt = np.dtype(dtype)
+    return np.asarray(_PinnedBlock(int(n) * dt.itemsize)).view(dt)[: int(n)]
+
+
+def pinned_copy(a: np.ndarray) -> np.ndarray:
+    """``a`` in page-locked host memory."""
+    out = pinned_empty(a.size, a.dtype)
+    out[:] = a.reshape(-1)
+    return out
+
+
 def pack_documents(inputs: Sequence[str]) -> tuple[np.ndarray, np.ndarray]:
     """``list[str]`` -> (uint8 buffer with TEXT_PAD slack, int64 CSR offsets).
 
@@ -699,10 +732,13 @@ class Tokenizer:
         if _marshal is None or not hasattr(_marshal, "pack_into") or not isinstance(inputs, (list, tuple)):
             return pack_documents(inputs)
         n = len(inputs)
+        # (page-locked where a device is bound: the H2D copies of the host entry then run as plain DMA; grow-only, so the cost of
+        # pinning is paid a few times per tokenizer, not per batch)
+        empty = pinned_empty if self.device >= 0 else np.empty
         if self._stage_off is None or len(self._stage_off) < n + 1:
-            self._stage_off = np.empty(max(n + 1, 1024, 2 * (len(self._stage_off) if self._stage_off is not None else 0)), dtype=np.int64)
+            self._stage_off = empty(max(n + 1, 1024, 2 * (len(self._stage_off) if self._stage_off is not None else 0)), dtype=np.int64)
         if self._stage_text is None:
-            self._stage_text = np.empty(1 << 20, dtype=np.uint8)
+            self._stage_text = empty(1 << 20, dtype=np.uint8)
         for _ in range(2):
             text = self._stage_text
             try:
@@ -711,7 +747,7 @@ class Tokenizer:
                 raise UnsupportedError(str(e)) from None
             if total + _lib.TEXT_PAD <= text.nbytes:
                 return text[: total + _lib.TEXT_PAD], self._stage_off[: n + 1]
-            self._stage_text = np.empty(total + total // 4 + _lib.TEXT_PAD, dtype=np.uint8)     # nothing was copied: grow and redo
+            self._stage_text = empty(total + total // 4 + _lib.TEXT_PAD, dtype=np.uint8)     # nothing was copied: grow and redo
         raise RuntimeError("staging buffer growth failed")          # pragma: no cover
 
     def encode_batch_csr(self, inputs: Sequence[str], offsets: str = "none", word_ids: bool = False,
