@@ -71,7 +71,8 @@ struct LookupArgs {
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
-    uint32_t fill;                   // TKAMD_LU_FILL (A/B): pass 1 stores whole rows of tok0
+    uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
+    uint32_t p2_deep;                // pass 2 runs two steps side by side (TKAMD_LU_P2=1: one at a time)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -356,21 +357,41 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
             };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
+            // A step is three stages with a memory round trip between them -- key + hash + the bucket's displacement, the slot, the
+            // verdict -- and with the hot table hitting three pre-tokens in five a wavefront has one to three steps a tile: too few to
+            // hide anything behind each other in program order.  TWO steps are therefore run stage by stage side by side (P2_DEEP:
+            // the two-workgroups-per-CU shape has the registers; a.p2_deep switches it for A/B runs): both displacement loads fly
+            // together, then both slot loads.
+            struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1, dsp; uint4 a0, a1; };
             const uint32_t n_miss = s_nmiss;
-            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
-                const bool v = m0 + lane < n_miss;
-                const uint32_t rel = s_miss[v ? m0 + lane : m0];
-                uint32_t s_rel, len, k0, k1, k2, k3;
-                load_key(rel, s_rel, len, k0, k1, k2, k3, true);
+            auto p2_key = [&](uint32_t m0, P2& x) {
+                x.v = m0 + lane < n_miss;
+                x.rel = s_miss[x.v ? m0 + lane : m0];
+                load_key(x.rel, x.s_rel, x.len, x.k0, x.k1, x.k2, x.k3, true);
+                x.h1 = 0u;
+                x.dsp = 0u;
+                x.probe = x.v && hits_on && x.len <= (uint32_t)WORD_MAX_KEY;
+                if (x.probe) {
+                    x.h1 = word_hash1_from_hot(hot_hash(x.k0, x.k1, x.k2, x.len, a.word_seed), x.k3);
+                    x.dsp = (uint32_t)a.word_disp[x.h1 & a.word_bmask];
+                }
+            };
+            auto p2_slot = [&](P2& x) {
+                x.a0 = x.a1 = make_uint4(0u, 0u, 0u, 0u);
+                if (x.probe) {
+                    const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(x.h1), x.dsp, a.word_mask)];
+                    x.a0 = q[0];
+                    x.a1 = q[1];
+                    asm volatile("" : "+v"(x.a0.x), "+v"(x.a1.x), "+v"(x.a1.y), "+v"(x.a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
+                }
+            };
+            auto p2_done = [&](P2& x) {
+                const bool v = x.v;
+                const uint32_t rel = x.rel, s_rel = x.s_rel, len = x.len, k0 = x.k0, k1 = x.k1, k2 = x.k2, k3 = x.k3, h1 = x.h1;
                 uint32_t out = 0u;
                 bool pend = v;
-                uint32_t h1 = 0u;
-                if (v && hits_on && len <= (uint32_t)WORD_MAX_KEY) {
-                    h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
-                    const uint32_t dsp = (uint32_t)a.word_disp[h1 & a.word_bmask];
-                    const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(h1), dsp, a.word_mask)];
-                    uint4 a0 = q[0], a1 = q[1];
-                    asm volatile("" : "+v"(a0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
+                if (x.probe) {
+                    const uint4 a0 = x.a0, a1 = x.a1;
                     const uint32_t diff = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | (a0.w ^ k3) | (a1.x ^ len);
                     if (diff == 0u && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
                     if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
@@ -418,6 +439,26 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                     if (cb && lane == 0) atomicAdd(&s_seen, (uint32_t)__popcll(cb));
                 }
                 finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
+            };
+            constexpr bool P2_DEEP = HOT == 2048 && !HAS_END;             // (with end masks the claims run inline in this pass: no registers left)
+            if (P2_DEEP && a.p2_deep) {                                             // wavefront-uniform
+                for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += 2u * (uint32_t)LU_NT) {
+                    const bool two = m0 + (uint32_t)LU_NT < n_miss;                 // (uniform) this wavefront has a second step in the round
+                    P2 x, y;
+                    p2_key(m0, x);
+                    if (two) p2_key(m0 + (uint32_t)LU_NT, y);
+                    p2_slot(x);
+                    if (two) p2_slot(y);
+                    p2_done(x);
+                    if (two) p2_done(y);
+                }
+            } else {
+                for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
+                    P2 x;
+                    p2_key(m0, x);
+                    p2_slot(x);
+                    p2_done(x);
+                }
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
             if (CAND_PASS && claims_now) {                                          // wavefront-uniform

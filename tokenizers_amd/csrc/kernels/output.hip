@@ -39,10 +39,12 @@ template <int CP_ITEMS> struct CpRows {
     uint4 row[CP_ITEMS];
     uint32_t cnt[CP_ITEMS];
 };
+// the two halves of a chunk's loads: a lane's CP_ITEMS consecutive tok0 words, then -- once those are here -- the rows they name
+template <int CP_ITEMS> struct CpTok0 { uint32_t w[CP_ITEMS]; };
 template <int CP_ITEMS>
-__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
+__device__ __forceinline__ void cp_load_tok0(const uint32_t* __restrict__ tok0, int64_t p0, int64_t P, CpTok0<CP_ITEMS>& f) {
     static_assert(CP_ITEMS == 2 || CP_ITEMS == 4 || CP_ITEMS == 8, "one 8-byte, one or two 16-byte loads of tok0 per lane");
-    uint32_t first[CP_ITEMS];
+    uint32_t* const first = f.w;
     if (p0 + CP_ITEMS <= P) {
         if (CP_ITEMS == 2) {
             const uint2 a = *(const uint2*)(tok0 + p0);
@@ -59,6 +61,10 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
     }
+}
+template <int CP_ITEMS>
+__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
+    const uint32_t* const first = f.w;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k)                     // all row loads in flight together
         r.row[k] = (first[k] & TOK_ROW) ? ((first[k] & TOK_ONE) ? crows[first[k] & TOK_REF_MASK] : rows[first[k] & TOK_REF_MASK]) : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
@@ -66,6 +72,12 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) { r.cnt[k] = row_count(r.row[k]); v += r.cnt[k]; }
     return v;
+}
+template <int CP_ITEMS>
+__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
+    CpTok0<CP_ITEMS> f;
+    cp_load_tok0<CP_ITEMS>(tok0, p0, P, f);
+    return cp_load_rows<CP_ITEMS>(f, rows, crows, r);
 }
 #define TKAMD_CP_SCATTER(DST, R, O)                                                                           \
     _Pragma("unroll") for (int k = 0; k < CP_ITEMS; ++k) {                                                    \
@@ -128,13 +140,14 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
             for (int64_t d = tid; d <= n_docs; d += CP_NT) tok_offsets[d] = 0;
         return;
     }
-    // front half of a chunk into LDS buffer b
-    auto front = [&](int64_t ch, int b) {
-        const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
+    // front half of a chunk into LDS buffer b; f: the chunk's tok0 words, loaded a chunk AHEAD (tok0 -> rows is a dependent pair of round
+    // trips: with the first one taken out of front() -- issued an iteration earlier, behind the previous chunk's work -- front() waits
+    // for one; 49 % of the kernel's time sat in this wait, profiles/r4b_*)
+    auto front = [&](int64_t ch, int b, const CpTok0<CP_ITEMS>& f) {
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
         const uint32_t dlo = chunk_lo[ch], dhi = ch == n_chunks - 1 ? (uint32_t)n_docs + 1u : chunk_lo[ch + 1];
         CpRows<CP_ITEMS> r;
-        const uint32_t v = cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
+        const uint32_t v = cp_load_rows<CP_ITEMS>(f, rows, crows, r);
         if (dlo + (uint32_t)tid < dhi) s_docpt[b][tid] = doc_pt[dlo + (uint32_t)tid];
         if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         uint32_t tot;
@@ -163,12 +176,25 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
         return (unsigned long long)v;
     };
+    auto tok0_of = [&](int64_t c, CpTok0<CP_ITEMS>& f) {    // (a chunk beyond the end: zeros, never used)
+        if (c < n_chunks) cp_load_tok0<CP_ITEMS>(tok0, c * CP_CHUNK + (int64_t)tid * CP_ITEMS, P, f);
+        else for (int k = 0; k < CP_ITEMS; ++k) f.w[k] = 0u;
+    };
     int b = 0;
-    if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0);
+    CpTok0<CP_ITEMS> fa;                                   // tok0 of the NEXT chunk
+    {
+        CpTok0<CP_ITEMS> f0;
+        tok0_of(blockIdx.x, f0);
+        tok0_of((int64_t)blockIdx.x + gridDim.x, fa);
+        if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0, f0);
+    }
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
         const int64_t nxt = ch + gridDim.x;
-        if (nxt < n_chunks) front(nxt, b ^ 1);            // (its two barriers also order this chunk's LDS writes before the reads below)
+        CpTok0<CP_ITEMS> fb;                               // ... and of the one after it: in flight while front(nxt) works
+        tok0_of(nxt + gridDim.x, fb);
+        if (nxt < n_chunks) front(nxt, b ^ 1, fa);        // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
+        fa = fb;
         const uint32_t tot = s_tot[b];
         if (tid < 64) {                                    // wavefront 0 resolves the chunk's place in the token stream
             const unsigned long long base = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total);
