@@ -177,6 +177,10 @@ struct Workspace {
     bool device_bound = false;   // belongs to the device entry: keyed by the caller's stream, results stay valid in it
     hipStream_t bound_stream = nullptr;
     hipStream_t own_stream = nullptr;   // host entry: its own non-blocking stream
+    // host entry, sliced: every H2D of a call goes down one stream in slice order and every D2H down another, so that the two
+    // directions of the link run side by side and neither waits behind the other in a compute stream's order (encode_host)
+    hipStream_t io_in = nullptr, io_out = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // the model kernels of the queue classes are independent of each other and, once the claims have thinned the queues, each too small
     // to fill the chip: they run side by side on two more streams, forked from and joined into the call's stream with events
     hipStream_t side[2] = {nullptr, nullptr};
@@ -220,6 +224,12 @@ struct Workspace {
     bool last_used_claims = false;               // the batch enqueued last ran with the in-batch claims
     ~Workspace() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (io_in) (void)hipStreamDestroy(io_in);
+        if (io_out) (void)hipStreamDestroy(io_out);
+        for (int i = 0; i < 2; ++i) {
+            if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
+            if (ev_out[i]) (void)hipEventDestroy(ev_out[i]);
+        }
         for (int i = 0; i < 2; ++i) {
             if (side[i]) (void)hipStreamDestroy(side[i]);
             if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
@@ -2210,9 +2220,12 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
     return TKAMD_OK;
 }
 
-// Host entry.  The batch is cut into document-aligned slices that alternate between two workspaces, each on its own stream:
-// while slice k's kernels run, slice k+1's text crosses the bus and slice k-1's ids go back (H2D, kernels and D2H use different
-// engines).  Small batches, and BatchLongest padding (its target is a property of the whole batch), go as one slice.
+// Host entry.  The batch is cut into document-aligned slices that alternate between two workspaces: while slice k's kernels run,
+// slice k+1's text crosses the bus and slice k-1's ids go back -- all H2D copies on one stream, all D2H copies on another, the
+// kernels on the workspaces' own (see the streams below).  Small batches, and BatchLongest padding (its target is a property of
+// the whole batch), go as one slice.  The caller's buffers may be any host memory; from tkamd_pinned_alloc the two directions
+// really overlap (pageable copies are staged by the runtime and block the other direction: 51 against 90 GB/s in both
+// directions together, profiles/r4d_link_probe.txt).
 // seq_offsets / n_seqs: is_pretokenized inputs -- the documents are words, sequence s = words [seq_offsets[s], seq_offsets[s + 1]); the
 // slices are then cut between sequences.  n_seqs < 0: plain documents.
 static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
@@ -2236,8 +2249,9 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
         const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;            // sequences per encoding
         if (n_grp % unit) throw Invalid("TKAMD_PAIRS: an odd number of sequences");
-        static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 32) << 20; }();
-        int n_slices = (int)std::min<int64_t>(8, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
+        static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 16) << 20; }();
+        constexpr int MAX_SLICES = 16;
+        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
@@ -2261,6 +2275,23 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         std::lock_guard<std::mutex> g0(ws[0]->mu);
         std::unique_ptr<std::lock_guard<std::mutex>> g1(l1 ? new std::lock_guard<std::mutex>(ws[1]->mu) : nullptr);
         hipStream_t st[2] = {own_stream(ws[0]), own_stream(ws[1])};
+        // Three roles, three kinds of streams (the link is full duplex -- 53 GB/s each way at once from page-locked memory,
+        // tools/link_probe.py -- but only for copies that do not queue behind each other): `cin` carries every H2D of the call in slice
+        // order, the slices' kernels alternate between the two workspaces' streams, `cout` carries every D2H.  Events tie them: a
+        // slice's kernels wait for its H2D; they also wait for the D2H of the slice that used the workspace before (its result
+        // buffers are about to be overwritten).  The H2D of slice k + 2 needs no event: the host has already waited for slice k's
+        // kernels (it needed their token count).
+        Workspace* const w0 = ws[0];
+        if (!w0->io_in) {
+            HIP_CHECK(hipStreamCreateWithFlags(&w0->io_in, hipStreamNonBlocking));
+            HIP_CHECK(hipStreamCreateWithFlags(&w0->io_out, hipStreamNonBlocking));
+            for (int q = 0; q < 2; ++q) {
+                HIP_CHECK(hipEventCreateWithFlags(&w0->ev_in[q], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&w0->ev_out[q], hipEventDisableTiming));
+            }
+        }
+        const hipStream_t cin = w0->io_in, cout = w0->io_out;
+        bool out_pending[2] = {false, false};                        // a D2H of this workspace's results is (or may still be) in flight
 
         const bool ids16 = (flags & TKAMD_IDS_U16) != 0;
         if (ids16)
@@ -2272,8 +2303,8 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         b->has_ids16 = ids16;
         b->n_docs = n_enc;
         b->tok_offsets = pinned_get((size_t)(n_enc + 1) * 8);
-        tkamd_device_result res[8]{};
-        int64_t slice_tok[8] = {0};
+        tkamd_device_result res[MAX_SLICES]{};
+        int64_t slice_tok[MAX_SLICES] = {0};
         size_t tok_cap = 0;
         int64_t tok_base = 0;
         auto grow = [&](PinnedBlock& blk, size_t unit, size_t need_tokens, size_t have_tokens) {
@@ -2289,16 +2320,17 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             const int64_t d0 = doc_of(cut[k]), d1 = doc_of(cut[k + 1]), b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
             if (nb < 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
             const int64_t g0 = cut[k], g1 = cut[k + 1];
-            if (words_in) {
-                w->h_seq_off.reserve((size_t)(g1 - g0 + 1) * 8);
-                HIP_CHECK(hipMemcpyAsync(w->h_seq_off.p, seq_offsets + g0, (size_t)(g1 - g0 + 1) * 8, hipMemcpyHostToDevice, s));
-                if (d0) launch_add_i64(s, w->h_seq_off.as<int64_t>(), g1 - g0 + 1, -d0);             // the slice's words count from 0
-            }
+            if (words_in) w->h_seq_off.reserve((size_t)(g1 - g0 + 1) * 8);
             w->h_text.reserve((size_t)nb + TKAMD_TEXT_PAD);
             w->h_doc_off.reserve((size_t)(d1 - d0 + 1) * 8);
-            if (nb) HIP_CHECK(hipMemcpyAsync(w->h_text.p, text + b0, (size_t)nb, hipMemcpyHostToDevice, s));
+            if (words_in) HIP_CHECK(hipMemcpyAsync(w->h_seq_off.p, seq_offsets + g0, (size_t)(g1 - g0 + 1) * 8, hipMemcpyHostToDevice, cin));
+            if (nb) HIP_CHECK(hipMemcpyAsync(w->h_text.p, text + b0, (size_t)nb, hipMemcpyHostToDevice, cin));
+            HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, cin));
+            HIP_CHECK(hipEventRecord(w0->ev_in[k & 1], cin));
+            HIP_CHECK(hipStreamWaitEvent(s, w0->ev_in[k & 1], 0));
+            if (out_pending[k & 1]) HIP_CHECK(hipStreamWaitEvent(s, w0->ev_out[k & 1], 0));      // (the previous tenant's results are still going home)
+            if (words_in && d0) launch_add_i64(s, w->h_seq_off.as<int64_t>(), g1 - g0 + 1, -d0);            // the slice's words count from 0
             HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + nb, 0, TKAMD_TEXT_PAD, s));
-            HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, s));
             if (b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), d1 - d0 + 1, -b0);           // the slice's own CSR starts at 0
             run_pipeline(t, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), d1 - d0, nb, words_in ? w->h_seq_off.as<int64_t>() : nullptr,
                          words_in ? g1 - g0 : -1, flags, s, &res[k]);
@@ -2323,11 +2355,11 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 b->tok_offsets = pinned_get((size_t)(d1 + 1) * 8);
                 b->enc_docs = pinned_get((size_t)(d1 + 1) * 4);
                 b->has_enc_docs = true;
-                if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_docs.p, r.d_enc_docs, (size_t)d1 * 4, hipMemcpyDeviceToHost, s));
+                if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_docs.p, r.d_enc_docs, (size_t)d1 * 4, hipMemcpyDeviceToHost, cout));
                 if (r.d_enc_parts) {
                     b->enc_parts = pinned_get((size_t)(d1 + 1) * 8);
                     b->has_enc_parts = true;
-                    if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_parts.p, r.d_enc_parts, (size_t)d1 * 8, hipMemcpyDeviceToHost, s));
+                    if (d1) HIP_CHECK(hipMemcpyAsync(b->enc_parts.p, r.d_enc_parts, (size_t)d1 * 8, hipMemcpyDeviceToHost, cout));
                 }
             }
             slice_tok[k] = n_tok;
@@ -2337,10 +2369,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 const int64_t seen = doc_offsets[seen_docs];
                 size_t est = (k + 1 == n_slices || seen <= 0) ? need : (size_t)((double)need * (double)n_bytes / (double)seen * 1.12) + 4096;
                 est = std::max(est, need);
-                if (k) {                                        // earlier slices' copies are still landing in the old blocks
-                    HIP_CHECK(hipStreamSynchronize(st[0]));
-                    HIP_CHECK(hipStreamSynchronize(st[1]));
-                }
+                if (k) HIP_CHECK(hipStreamSynchronize(cout));   // earlier slices' copies are still landing in the old blocks
                 if (ids16) grow(b->ids16, 2, est, (size_t)tok_base);
                 else grow(b->ids, 4, est, (size_t)tok_base);
                 if (r.d_offsets) grow(b->offsets, 8, est, (size_t)tok_base);
@@ -2351,29 +2380,31 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             if (ids16) {
                 // half the bytes on the way back: narrow on the device, copy 2 bytes a token
                 w->w_ids16.reserve((size_t)n_tok * 2 + 64);
-                launch_narrow_ids(s, r.d_ids, n_tok, w->w_ids16.as<uint16_t>(), w->w_wide.as<int>());
-                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint16_t*)b->ids16.p + tok_base, w->w_ids16.p, (size_t)n_tok * 2, hipMemcpyDeviceToHost, s));
-            } else if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
-            if (tok_base) launch_add_i64(s, (int64_t*)r.d_tok_offsets, d1 - d0 + 1, tok_base);   // the slice's CSR continues the batch's
-            HIP_CHECK(hipMemcpyAsync((int64_t*)b->tok_offsets.p + d0, r.d_tok_offsets, (size_t)(d1 - d0 + 1) * 8, hipMemcpyDeviceToHost, s));
+                launch_narrow_ids(cout, r.d_ids, n_tok, w->w_ids16.as<uint16_t>(), w->w_wide.as<int>());
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint16_t*)b->ids16.p + tok_base, w->w_ids16.p, (size_t)n_tok * 2, hipMemcpyDeviceToHost, cout));
+            } else if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, cout));
+            if (tok_base) launch_add_i64(cout, (int64_t*)r.d_tok_offsets, d1 - d0 + 1, tok_base);   // the slice's CSR continues the batch's
+            HIP_CHECK(hipMemcpyAsync((int64_t*)b->tok_offsets.p + d0, r.d_tok_offsets, (size_t)(d1 - d0 + 1) * 8, hipMemcpyDeviceToHost, cout));
             if (r.d_offsets) {
                 b->has_offsets = true;
-                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->offsets.p + 2 * tok_base, r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost, s));
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->offsets.p + 2 * tok_base, r.d_offsets, (size_t)n_tok * 8, hipMemcpyDeviceToHost, cout));
             }
             if (r.d_word_ids) {
                 b->has_words = true;
-                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->word_ids.p + tok_base, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, s));
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->word_ids.p + tok_base, r.d_word_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, cout));
             }
             if (r.d_type_ids) {
                 b->has_types = true;
-                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->type_ids.p + tok_base, r.d_type_ids, (size_t)n_tok, hipMemcpyDeviceToHost, s));
-                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->seq_ids.p + tok_base, r.d_seq_ids, (size_t)n_tok, hipMemcpyDeviceToHost, s));
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->type_ids.p + tok_base, r.d_type_ids, (size_t)n_tok, hipMemcpyDeviceToHost, cout));
+                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint8_t*)b->seq_ids.p + tok_base, r.d_seq_ids, (size_t)n_tok, hipMemcpyDeviceToHost, cout));
             }
             if (r.d_pad_counts) {
                 if (!b->has_pads) { b->has_pads = true; b->pad_counts = pinned_get((size_t)(std::max(n_enc, d1) + 1) * 4); }
-                if (d1 > d0) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->pad_counts.p + d0, r.d_pad_counts, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, s));
+                if (d1 > d0) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->pad_counts.p + d0, r.d_pad_counts, (size_t)(d1 - d0) * 4, hipMemcpyDeviceToHost, cout));
             }
             tok_base += n_tok;
+            HIP_CHECK(hipEventRecord(w0->ev_out[k & 1], cout));
+            out_pending[k & 1] = true;
             return 0;
         };
         int bits = 0;
@@ -2384,12 +2415,16 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 bits = finish(k);
             }
         } catch (...) {
+            (void)hipStreamSynchronize(cin);
             (void)hipStreamSynchronize(st[0]);
             (void)hipStreamSynchronize(st[1]);
+            (void)hipStreamSynchronize(cout);
             throw;
         }
+        HIP_CHECK(hipStreamSynchronize(cin));
         HIP_CHECK(hipStreamSynchronize(st[0]));
         HIP_CHECK(hipStreamSynchronize(st[1]));
+        HIP_CHECK(hipStreamSynchronize(cout));
         if (bits) return error_from_bits(bits);
         if (ids16) {
             for (int q = 0; q < (l1 ? 2 : 1); ++q) {

@@ -80,8 +80,6 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.phases = (unsigned long long*)phases;
     static const uint32_t fill = [] { const char* e = getenv("TKAMD_LU_FILL"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
     a.fill = fill;
-    static const uint32_t p2_deep = [] { const char* e = getenv("TKAMD_LU_P2"); return (e && !strcmp(e, "1")) ? 0u : 1u; }();
-    a.p2_deep = p2_deep;
     const int lds = lookup_lds_bytes(hot_slots);
 #define TKAMD_LU(E, P, H) hipLaunchKernelGGL((k_lookup<E, P, H>), dim3(grid), dim3(LU_NT), lds, st, a)
     if (hot_slots == 1024) {

@@ -72,7 +72,6 @@ struct LookupArgs {
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
     uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
-    uint32_t p2_deep;                // pass 2 runs two steps side by side (TKAMD_LU_P2=1: one at a time)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -357,11 +356,9 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
             };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
-            // A step is three stages with a memory round trip between them -- key + hash + the bucket's displacement, the slot, the
-            // verdict -- and with the hot table hitting three pre-tokens in five a wavefront has one to three steps a tile: too few to
-            // hide anything behind each other in program order.  TWO steps are therefore run stage by stage side by side (P2_DEEP:
-            // the two-workgroups-per-CU shape has the registers; a.p2_deep switches it for A/B runs): both displacement loads fly
-            // together, then both slot loads.
+            // A step is three stages with a memory round trip between them: key + hash + the bucket's displacement, the slot, the verdict.
+            // (Two steps run stage by stage side by side -- both displacement loads in flight together, then both slot loads -- measured
+            // SLOWER, 0.2475 against 0.2337 ms, as batching the probes had in round 2: profiles/r4d_ab_c2.txt.)
             struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1, dsp; uint4 a0, a1; };
             const uint32_t n_miss = s_nmiss;
             auto p2_key = [&](uint32_t m0, P2& x) {
@@ -440,25 +437,11 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 }
                 finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
             };
-            constexpr bool P2_DEEP = HOT == 2048 && !HAS_END;             // (with end masks the claims run inline in this pass: no registers left)
-            if (P2_DEEP && a.p2_deep) {                                             // wavefront-uniform
-                for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += 2u * (uint32_t)LU_NT) {
-                    const bool two = m0 + (uint32_t)LU_NT < n_miss;                 // (uniform) this wavefront has a second step in the round
-                    P2 x, y;
-                    p2_key(m0, x);
-                    if (two) p2_key(m0 + (uint32_t)LU_NT, y);
-                    p2_slot(x);
-                    if (two) p2_slot(y);
-                    p2_done(x);
-                    if (two) p2_done(y);
-                }
-            } else {
-                for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
-                    P2 x;
-                    p2_key(m0, x);
-                    p2_slot(x);
-                    p2_done(x);
-                }
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
+                P2 x;
+                p2_key(m0, x);
+                p2_slot(x);
+                p2_done(x);
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
             if (CAND_PASS && claims_now) {                                          // wavefront-uniform

@@ -140,14 +140,15 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
             for (int64_t d = tid; d <= n_docs; d += CP_NT) tok_offsets[d] = 0;
         return;
     }
-    // front half of a chunk into LDS buffer b; f: the chunk's tok0 words, loaded a chunk AHEAD (tok0 -> rows is a dependent pair of round
-    // trips: with the first one taken out of front() -- issued an iteration earlier, behind the previous chunk's work -- front() waits
-    // for one; 49 % of the kernel's time sat in this wait, profiles/r4b_*)
-    auto front = [&](int64_t ch, int b, const CpTok0<CP_ITEMS>& f) {
+    // front half of a chunk into LDS buffer b.  (49 % of the kernel's time is the wait in here -- tok0, then the rows it names, then the
+    // scan: profiles/r4b_ab_c2.txt.  Loading tok0 a chunk ahead, so that front() starts with the row loads, changed nothing: 0.1417
+    // against 0.1403 ms, r4d.)
+    auto front = [&](int64_t ch, int b) {
+        const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
         const uint32_t dlo = chunk_lo[ch], dhi = ch == n_chunks - 1 ? (uint32_t)n_docs + 1u : chunk_lo[ch + 1];
         CpRows<CP_ITEMS> r;
-        const uint32_t v = cp_load_rows<CP_ITEMS>(f, rows, crows, r);
+        const uint32_t v = cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
         if (dlo + (uint32_t)tid < dhi) s_docpt[b][tid] = doc_pt[dlo + (uint32_t)tid];
         if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         uint32_t tot;
@@ -176,25 +177,12 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
         return (unsigned long long)v;
     };
-    auto tok0_of = [&](int64_t c, CpTok0<CP_ITEMS>& f) {    // (a chunk beyond the end: zeros, never used)
-        if (c < n_chunks) cp_load_tok0<CP_ITEMS>(tok0, c * CP_CHUNK + (int64_t)tid * CP_ITEMS, P, f);
-        else for (int k = 0; k < CP_ITEMS; ++k) f.w[k] = 0u;
-    };
     int b = 0;
-    CpTok0<CP_ITEMS> fa;                                   // tok0 of the NEXT chunk
-    {
-        CpTok0<CP_ITEMS> f0;
-        tok0_of(blockIdx.x, f0);
-        tok0_of((int64_t)blockIdx.x + gridDim.x, fa);
-        if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0, f0);
-    }
+    if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0);
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
         const int64_t nxt = ch + gridDim.x;
-        CpTok0<CP_ITEMS> fb;                               // ... and of the one after it: in flight while front(nxt) works
-        tok0_of(nxt + gridDim.x, fb);
-        if (nxt < n_chunks) front(nxt, b ^ 1, fa);        // (its two barriers also order this chunk's LDS writes before the reads below)
+        if (nxt < n_chunks) front(nxt, b ^ 1);            // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
-        fa = fb;
         const uint32_t tot = s_tot[b];
         if (tid < 64) {                                    // wavefront 0 resolves the chunk's place in the token stream
             const unsigned long long base = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total);
