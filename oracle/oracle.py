@@ -51,6 +51,7 @@ def lib() -> C.CDLL:
         L.oracle_set_vocab.argtypes = [vp, vp, vp, vp, i64]
         L.oracle_set_unk.argtypes = [vp, C.c_char_p, i64]
         L.oracle_set_wordpiece.argtypes = [vp, C.c_char_p, i64, i32]
+        L.oracle_set_bpe_options.argtypes = [vp, C.c_char_p, i64, C.c_char_p, i64, i32, i32]
         L.oracle_set_merges.argtypes = [vp, vp, vp, vp, vp, i64]
         L.oracle_set_merges.restype = i32
         L.oracle_encode_batch.argtypes = [vp, vp, vp, i64, C.POINTER(vp)]
@@ -199,6 +200,9 @@ class Oracle:
             p = model.get("continuing_subword_prefix", "##").encode("utf-8")
             L.oracle_set_wordpiece(self._h, p, len(p), int(model.get("max_input_chars_per_word", 100)))
         if mk == M_BPE:
+            pre = (model.get("continuing_subword_prefix") or "").encode("utf-8")
+            suf = (model.get("end_of_word_suffix") or "").encode("utf-8")
+            L.oracle_set_bpe_options(self._h, pre, len(pre), suf, len(suf), int(bool(model.get("fuse_unk", False))), int(bool(model.get("byte_fallback", False))))
             ma, mb = [], []
             for m in model["merges"]:
                 a, b = m.split(" ") if isinstance(m, str) else m
@@ -226,7 +230,8 @@ class Oracle:
         b = C.c_void_p()
         rc = self._L.oracle_encode_batch(self._h, blob.ctypes.data, off.ctypes.data, len(docs), C.byref(b))
         if rc:
-            raise OracleError({-4: "MissingUnkToken", -2: "unsupported input (e.g. non-ASCII through BertNormalizer)", -5: "AddedVocabulary bad split"}.get(rc, str(rc)))
+            raise OracleError({-4: "MissingUnkToken", -2: "unsupported input (e.g. non-ASCII through BertNormalizer)", -5: "AddedVocabulary bad split",
+                               -6: "UnkTokenOutOfVocabulary"}.get(rc, str(rc)))
         try:
             n = self._L.oracle_batch_n_tokens(b)
             def arr(ptr, ct, shape):
@@ -259,5 +264,5 @@ class Oracle:
         offs = np.zeros(2 * (n + 2), dtype=np.int64)
         m = self._L.oracle_model_tokenize(self._h, raw.ctypes.data, n, ids.ctypes.data, offs.ctypes.data, n + 2)
         if m < 0:
-            raise OracleError({-4: "MissingUnkToken"}.get(m, str(m)))
+            raise OracleError({-4: "MissingUnkToken", -6: "UnkTokenOutOfVocabulary"}.get(m, str(m)))
         return [(int(ids[k]), (int(offs[2 * k]), int(offs[2 * k + 1]))) for k in range(m)]

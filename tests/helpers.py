@@ -9,6 +9,11 @@ GOLDEN_NAMES = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_
                 "wordlevel_whitespace_c1", "wordlevel_wssplit", "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"]
 
 
+# BPE over characters (no ByteLevel pre-tokenizer): unk_token / fuse_unk / dropped chars / affixes / byte_fallback / ignore_merges
+# (oracle/make_golden_bpe.py)
+BPE_CHAR_GOLDEN = ["bpe_ws_unk", "bpe_ws_fuse_unk", "bpe_ws_no_unk", "bpe_bert_affixes", "bpe_wssplit_suffix_fuse", "bpe_ws_byte_fallback", "bpe_ws_ignore_merges"]
+
+
 def load_tokenizer_json(name: str) -> str:
     with gzip.open(os.path.join(GOLD, name + ".json.gz"), "rt", encoding="utf-8") as fh:
         return fh.read()

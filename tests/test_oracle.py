@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle as orc
 from oracle import synth
-from tests.helpers import GOLDEN_NAMES, char_to_byte, load_tokenizer_json, load_vectors
+from tests.helpers import BPE_CHAR_GOLDEN, GOLDEN_NAMES, char_to_byte, load_tokenizer_json, load_vectors
 
 
 def _tok_json(model: dict, pre_tokenizer=None, normalizer=None, post_processor=None) -> str:
@@ -124,6 +124,53 @@ def test_ref_wordlevel():
         o2.model_tokenize("c")
 
 
+def test_ref_bpe_unk_fused_or_not():
+    # models/bpe/model.rs:763-824 (test_unk_not_fused / test_unk_get_fused)
+    WS = {"type": "Whitespace"}
+    vocab = {"<unk>": 0, "a": 1, "b": 2}
+    o = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": [], "unk_token": "<unk>"}, WS))
+    assert o.model_tokenize("c") == [(0, (0, 1))]
+    assert o.model_tokenize("cc") == [(0, (0, 1)), (0, (1, 2))]
+    assert o.model_tokenize("accb") == [(1, (0, 1)), (0, (1, 2)), (0, (2, 3)), (2, (3, 4))]
+    f = orc.Oracle(_tok_json({"type": "BPE", "vocab": vocab, "merges": [], "unk_token": "<unk>", "fuse_unk": True}, WS))
+    assert f.model_tokenize("c") == [(0, (0, 1))]
+    assert f.model_tokenize("cc") == [(0, (0, 2))]
+    assert f.model_tokenize("accb") == [(1, (0, 1)), (0, (1, 3)), (2, (3, 4))]
+    # an unk_token the vocabulary lacks: Error::UnkTokenOutOfVocabulary the moment it is needed (model.rs:528-533), not before
+    m = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"a": 0}, "merges": [], "unk_token": "<unk>"}, WS))
+    assert m.model_tokenize("aa") == [(0, (0, 1)), (0, (1, 2))]
+    with pytest.raises(orc.OracleError, match="UnkTokenOutOfVocabulary"):
+        m.model_tokenize("ab")
+    # no unk_token at all: the char is dropped and the offsets are running sums of what is left (model.rs:518, word.rs:260-268)
+    n = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"a": 0, "b": 1}, "merges": []}, WS))
+    assert n.model_tokenize("acb") == [(0, (0, 1)), (1, (1, 2))]
+    assert n.model_tokenize("ccc") == []
+
+
+def test_ref_bpe_continuing_subword_prefix_and_suffix():
+    # models/bpe/model.rs:937-978 (test_bpe_with_continuing_subword_prefix): the merge map cuts the prefix off the right-hand token
+    o = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"a": 0, "##b": 1, "##c": 2, "ab": 3, "abc": 4}, "merges": [["a", "##b"], ["ab", "##c"]],
+                              "unk_token": "[UNK]", "continuing_subword_prefix": "##"}, {"type": "Whitespace"}))
+    assert o.model_tokenize("ab") == [(3, (0, 2))]
+    assert o.model_tokenize("abc") == [(4, (0, 3))]
+    # end_of_word_suffix (model.rs:486-491): glued to the LAST char before the lookup
+    s = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"a": 0, "b": 1, "b</w>": 2, "a</w>": 3, "ab</w>": 4}, "merges": [["a", "b</w>"]],
+                              "end_of_word_suffix": "</w>"}, {"type": "Whitespace"}))
+    assert s.model_tokenize("ab") == [(4, (0, 2))]
+    assert s.model_tokenize("ba") == [(1, (0, 1)), (3, (1, 2))]
+    assert s.model_tokenize("a") == [(3, (0, 1))]
+
+
+def test_ref_bpe_byte_fallback():
+    # models/bpe/model.rs:1040-1074 (test_bpe_byte_fallback, ..._newline)
+    WS = {"type": "Whitespace"}
+    o = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"<unk>": 0, "<0x61>": 1}, "merges": [], "unk_token": "<unk>", "byte_fallback": True}, WS))
+    assert o.model_tokenize("c") == [(0, (0, 1))]
+    assert o.model_tokenize("a") == [(1, (0, 1))]
+    nl = orc.Oracle(_tok_json({"type": "BPE", "vocab": {"<unk>": 0, "<0x0A>": 1}, "merges": [], "unk_token": "<unk>", "byte_fallback": True}, WS))
+    assert nl.model_tokenize("\n") == [(1, (0, 1))]
+
+
 def test_ref_wordpiece_semantics():
     # models/wordpiece/mod.rs:224-283 (the reference has no inline known-answer test for tokenize; these
     # are the cases SURVEY 8c replayed against the wheel: jo|##hn, any-miss -> whole word unk, >100 chars)
@@ -151,7 +198,7 @@ def test_gpt2_semantics_cheatsheet(bl_oracle):
 
 # ---- 2. golden vectors from the reference wheel --------------------------------------------------
 
-@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("name", GOLDEN_NAMES + BPE_CHAR_GOLDEN)
 def test_oracle_matches_golden(name):
     o = orc.Oracle(load_tokenizer_json(name))
     v = load_vectors(name)
