@@ -10,13 +10,13 @@ import pytest
 
 from oracle import oracle as orc
 from oracle import synth
-from tests.helpers import N, load_tokenizer_json, load_vectors
+from tests.helpers import BPE_CHAR_GOLDEN, N, load_tokenizer_json, load_vectors
 
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
 GPU_GOLDEN = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000",
-              "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"]
+              "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"] + BPE_CHAR_GOLDEN
 
 
 @pytest.fixture(scope="module")
@@ -314,7 +314,7 @@ def test_trim_offsets_vs_oracle(gpt2_json):
 
 
 @pytest.mark.parametrize("name", ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000",
-                                  "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"])
+                                  "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"] + BPE_CHAR_GOLDEN)
 def test_encode_batch_matches_golden_char_offsets(name):
     """Tokenizer.encode_batch == the wheel's encode_batch (ids, char offsets, word ids) on the committed vectors."""
     import tokenizers_amd as ta
@@ -995,3 +995,80 @@ def test_pinned_caller_buffers_give_the_same_result(gpt2, gpt2_oracle):
         a[:] = 7
         assert a.shape == (n,) and a.dtype == np.int64
     del pb, po, a
+
+
+# ---- BPE over characters (no ByteLevel pre-tokenizer): BPE::merge_word with all its options (bpe/model.rs:465-550) ----
+
+def _char_bpe_docs(n_lines):
+    import random
+    random.seed(77)
+    pool = ["é", "ñ", "中", "文", "😀", "ß", "Ω", "ё", "naïve", "CAFÉ", "a", "B", "-", "!", "12", " ", "x̣́", "hello", "word", "ing", "the", "é中", "中中中", "😀😀", "aé", "xé中y", "ﬁ", "_"]
+    mixed = ["".join(random.choice(pool) for _ in range(random.randint(1, 16))) for _ in range(n_lines // 10)]
+    # words past the 16- / 32- / 64-byte classes (the workgroup-per-pre-token kernel), with and without chars the vocabulary lacks
+    long_words = ["internationalization" * k for k in (1, 2, 4, 9)] + ["é" * 40, "ab" * 300, "x" * 17 + "中" + "y" * 20, "😀".join(["word"] * 12), "a" * 33, "b" * 65,
+                                                                     "supercalifragilisticexpialidocious", "1234567890" * 7]
+    return synth.gen_lines(n_lines, text_seed=23) + synth.stress_lines(seed=6, n=n_lines // 10) + mixed + long_words + ["", " ", "é", "é é", "a é b"]
+
+
+@pytest.mark.parametrize("name", BPE_CHAR_GOLDEN)
+def test_bpe_over_characters_vs_oracle(name):
+    """Fresh documents (prose, the stress set, chars outside every fixture's alphabet, words of every length class) through every
+    option set: ids, byte offsets and word ids against the oracle's literal merge_word (pinned on the same fixtures' wheel vectors
+    in tests/test_oracle.py); then char offsets, whose edges snap to whole chars the way convert_offsets reports them."""
+    import tokenizers_amd as ta
+    js = load_tokenizer_json(name)
+    tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+    docs = _char_bpe_docs(N(12000))
+    if name == "bpe_bert_affixes":
+        docs = [d for d in docs if "[" not in d and "\u302e" not in d]
+    exp = o.encode_batch(docs)
+    got = tok.encode_batch_csr(docs, offsets="byte", word_ids=True)
+    _assert_ids_equal(got, [exp.doc_ids(i) for i in range(len(docs))], docs)
+    assert np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)
+    fast = tok.encode_batch_fast(docs, add_special_tokens=False)
+    assert np.array_equal(fast.ids, exp.ids) and np.array_equal(fast.tok_offsets, exp.tok_offsets)
+    expc = o.encode_batch(docs, char_offsets=True)
+    gotc = tok.encode_batch_csr(docs, offsets="char")
+    assert np.array_equal(gotc.offsets, expc.offsets)
+
+
+def test_bpe_over_characters_corners(ref_tokenizers):
+    """Vocabularies the trainer would not write, against the wheel run on the spot: new ids that are NOT in merge order (the LDS
+    kernels cannot run: every word takes the workgroup-per-pre-token kernel), the reference's own tiny known-answer vocabularies
+    (model.rs:763-824, 937-978), an unk_token the vocabulary lacks (UnkTokenOutOfVocabulary only when a char needs it), and the
+    corners that are refused at load."""
+    import json
+    import tokenizers_amd as ta
+    WS = {"type": "Whitespace"}
+
+    def tj(model, pre=WS):
+        return json.dumps({"version": "1.0", "truncation": None, "padding": None, "added_tokens": [], "normalizer": None, "pre_tokenizer": pre,
+                           "post_processor": None, "decoder": None, "model": dict({"type": "BPE", "dropout": None, "unk_token": None, "continuing_subword_prefix": None,
+                                                                                    "end_of_word_suffix": None, "fuse_unk": False, "byte_fallback": False, "ignore_merges": False}, **model)})
+    docs = ["ab abc a b c cab abcabc", "accb cc c", "", "abc " * 40, "c" * 50 + "ab", "ab" * 30]
+    cases = [
+        tj({"vocab": {"<unk>": 0, "a": 1, "b": 2}, "merges": [], "unk_token": "<unk>"}),
+        tj({"vocab": {"<unk>": 0, "a": 1, "b": 2}, "merges": [], "unk_token": "<unk>", "fuse_unk": True}),
+        tj({"vocab": {"a": 0, "##b": 1, "##c": 2, "ab": 3, "abc": 4}, "merges": [["a", "##b"], ["ab", "##c"]], "unk_token": "[UNK]", "continuing_subword_prefix": "##"}),
+        # new ids out of merge order: rank 0 -> id 9, rank 1 -> id 5
+        tj({"vocab": {"a": 0, "b": 1, "c": 2, "<unk>": 3, "abc": 5, "ab": 9}, "merges": [["a", "b"], ["ab", "c"]], "unk_token": "<unk>"}),
+        tj({"vocab": {"a": 0, "b": 1, "b</w>": 2, "a</w>": 3, "ab</w>": 4, "c</w>": 5, "c": 6}, "merges": [["a", "b</w>"]], "end_of_word_suffix": "</w>"}),
+        tj({"vocab": {"a": 0, "b": 1, "ab": 2}, "merges": [["a", "b"]]}),                      # no unk_token: 'c' is dropped, offsets move up
+    ]
+    for js in cases:
+        ref = ref_tokenizers.Tokenizer.from_str(js)
+        tok = ta.Tokenizer.from_str(js, device=0)
+        if json.loads(js)["model"]["unk_token"] == "[UNK]":     # (not in the vocabulary: only documents that never need it)
+            use = ["ab abc a", "abc " * 40, "a ab", ""]
+            with pytest.raises(ta.TokenizersAmdError, match="UnkTokenOutOfVocabulary"):
+                tok.encode_batch(["ab x"], add_special_tokens=False)
+        else:
+            use = docs
+        want = ref.encode_batch(use, add_special_tokens=False)
+        got = tok.encode_batch(use, add_special_tokens=False)
+        for d, e, g in zip(use, want, got):
+            assert g.ids == e.ids and [tuple(x) for x in g.offsets] == [tuple(x) for x in e.offsets] and g.word_ids == e.word_ids, (js[:200], d)
+    for model, why in (({"vocab": {"a": 0, "<0x61>": 1}, "merges": [], "byte_fallback": True}, "byte token"),
+                       ({"vocab": dict({"a": 0, "##a": 300}, **{"<0x%02X>" % b: 1 + b for b in range(256)}), "merges": [], "byte_fallback": True, "continuing_subword_prefix": "##"}, "byte_fallback together")):
+        with pytest.raises(ta.UnsupportedError, match=why):
+            ta.Tokenizer.from_str(tj(model), device=0)

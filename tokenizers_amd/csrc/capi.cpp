@@ -249,6 +249,7 @@ struct tkamd_tokenizer {
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
+    DevBuf t_char_id;            // BPE over characters: HostModel::char_id
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
     DevBuf t_pp_prefix, t_pp_suffix, t_pp_prefix_ty, t_pp_suffix_ty, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
@@ -458,6 +459,15 @@ void upload_tables(tkamd_tokenizer* t) {
     d.trie_mask = hm.trie.mask;
     d.trie_seed = hm.trie.seed;
     d.max_input_chars = hm.max_input_chars;
+    // BPE over characters (host_model.cpp: char_id; tables.hpp CB_*)
+    d.char_id = nullptr;
+    d.cb = 0u;
+    if (hm.char_bpe) {
+        upload(t->t_char_id, hm.char_id);
+        d.char_id = t->t_char_id.as<uint32_t>();
+        d.cb = CB_ON | (hm.bpe_prefix.empty() ? 0u : CB_PREFIX) | (hm.bpe_suffix.empty() ? 0u : CB_SUFFIX) | (hm.has_unk ? CB_UNK : 0u) |
+               ((hm.unk_configured && !hm.has_unk) ? CB_UNK_MISSING : 0u) | (hm.fuse_unk ? CB_FUSE : 0u) | (hm.byte_fallback ? CB_BYTES : 0u);
+    }
 }
 
 // Load-time proof of the WORD_DIRECT flag: run the device merge kernel on every <=16-byte vocab
@@ -493,6 +503,20 @@ void verify_direct_words(tkamd_tokenizer* t) {
     d_tmp.reserve(n * 4 + 64);
     HIP_CHECK(hipMemset(d_rows.p, 0, (size_t)P * 16));
     const QView v{(QItem*)d_items.p, d_n.as<uint32_t>(), P, 0u};
+    if (hm.char_bpe) {
+        // BPE over characters: the kernels that know its start; nothing is published, errors of the vocabulary's own entries do not count
+        DevBuf d_errs, d_hl;
+        d_errs.reserve(64);
+        d_hl.reserve(64);
+        HIP_CHECK(hipMemset(d_errs.p, 0, 64));
+        HIP_CHECK(hipMemset(d_hl.p, 0, 64));
+        DevTables vt = t->dt;
+        vt.err = d_errs.as<int>();
+        if (vt.newid_affine) launch_bpe_merge(nullptr, t->n_cu, 5, vt, d_text.as<uint8_t>(), v, d_rows.p, d_tmp.as<uint32_t>(), nullptr);
+        else launch_bpe_merge_long_only(nullptr, t->n_cu * 2, vt, d_text.as<uint8_t>(), v, d_rows.p, d_tmp.as<uint32_t>(), nullptr, d_hl.as<uint32_t>(), d_hl.as<uint32_t>() + 4);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+    } else
     launch_bpe_merge(nullptr, std::max(1, (int)std::min<uint32_t>(P / 16 + 1, 4096)), 16, t->dt, d_text.as<uint8_t>(), v, d_rows.p, d_tmp.as<uint32_t>(), nullptr);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipDeviceSynchronize());
@@ -501,7 +525,10 @@ void verify_direct_words(tkamd_tokenizer* t) {
     int nd = 0;
     for (uint32_t i = 0; i < P; ++i) {
         WordSlot& s = hm.word_table[slot_of[i]];
-        if (rows[4 * (size_t)i] == (s.id | (1u << 28))) { s.flags |= WORD_DIRECT; ++nd; }      // row {id | count 1 << 28, ...}: exactly [own id]
+        const uint32_t r0 = rows[4 * (size_t)i];
+        const bool one_own = r0 == (s.id | (1u << 28)) ||                                       // row {id | count 1 << 28, ...}: exactly [own id]
+                             (r0 == (s.id | (15u << 28)) && rows[4 * (size_t)i + 2] == 1u);   // ... in the long kernel's row form {id | ROW_CNT_MORE << 28, s, count, 0} (results.hip)
+        if (one_own) { s.flags |= WORD_DIRECT; ++nd; }
         else s.flags &= ~WORD_DIRECT;
     }
     t->n_direct = nd;
@@ -650,12 +677,13 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // (a prefix space goes in front of every piece: every document, and what follows every match)
     const int64_t n_x = (hm.norm == NORM_BERT) ? 3 * n_bytes + 64 : n_bytes + (prefix_space ? n_docs + (int64_t)mcap : 0);
     if (n_x >= (int64_t)0xFFFFFF00ll) throw Invalid("batch larger than 4 GiB: split it (byte offsets are 32-bit on the device)");
-    const bool bpe_path = hm.model == MODEL_BPE && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
+    const bool bpe_path = hm.model == MODEL_BPE && !hm.char_bpe && (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_LLAMA3 || hm.pretok == PT_BYTELEVEL_NOREGEX);
     const bool local_pretok = hm.pretok == PT_WHITESPACE || hm.pretok == PT_WHITESPACE_SPLIT || hm.pretok == PT_BERT;
     const bool word_models = (hm.model == MODEL_WORDLEVEL || hm.model == MODEL_WORDPIECE) && local_pretok;
-    if (!bpe_path && !word_models)
+    const bool char_bpe = hm.model == MODEL_BPE && hm.char_bpe && local_pretok;      // BPE over characters rides the word models' pre-tokenizers
+    if (!bpe_path && !word_models && !char_bpe)
         throw Unsupported("this build covers {ByteLevel(GPT-2 regex), Llama-3 Split+ByteLevel, ByteLevel(no regex)}+BPE and "
-                          "{Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece}");
+                          "{Whitespace,WhitespaceSplit,BertPreTokenizer}+{WordLevel,WordPiece,BPE over characters}");
     if (prefix_space && hm.norm != NORM_NONE) throw Unsupported("ByteLevel add_prefix_space behind a normalizer");
 
     reserve_workspace(t, w, n_x, n_docs, flags, want_meta);
@@ -1396,6 +1424,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // kernel of its own does it after them (k_claims_publish)
     static const bool pub_kernel = [] { const char* e = getenv("TKAMD_PUBLISH"); return e && !strcmp(e, "kernel"); }();
     DevTables mdt = t->dt;
+    mdt.err = d_err;
     bool pub_inline = false;
     auto set_publish = [&]() {
         pub_inline = wc.claims && !pub_kernel;
@@ -1429,6 +1458,29 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         const bool both = can_one && merge_mode == 2 && t->q16_fat_hint.load() != 0;
         const bool one = can_one && merge_mode != 0 && !both;
         if (both) mdt.thin_limit = MERGE_THIN_LIMIT;
+        // BPE over characters: only the kernels that know its start (kernels/bpe.hip CHARS) -- the two LDS kernels, each on its own queue,
+        // and the workgroup-per-pre-token kernel for everything beyond 32 bytes (or for everything, when the vocabulary's new ids are not
+        // in merge order and the LDS kernels cannot run)
+        if (hm.char_bpe) {
+            mdt.thin_limit = 0u;                           // (each queue has its one kernel here)
+            w->w_huge.reserve(64);
+            w->w_list_huge.reserve(64);
+            auto long_only = [&](const QView& q) {
+                launch_bpe_merge_long_only(st, t->n_cu * 2, mdt, x_text, q, w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, w->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH);
+            };
+            pf.begin("bpe_merge_lds32");
+            if (t->dt.newid_affine) launch_bpe_merge(st, t->n_cu, 6, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, nullptr);
+            else long_only(plan.v[1]);
+            pf.end();
+            pf.begin("bpe_merge_lds");
+            if (t->dt.newid_affine) launch_bpe_merge(st, t->n_cu, 5, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+            else long_only(plan.v[0]);
+            pf.end();
+            pf.begin("bpe_merge_long");
+            long_only(plan.v[2]);
+            long_only(plan.v[3]);
+            pf.end();
+        } else {
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
         launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, (one || both) ? &plan.v[0] : nullptr);
         pf.end();
@@ -1455,6 +1507,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                               w->w_tmp_ids.as<uint32_t>(), tmp_end, w->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, w->w_huge.as<uint32_t>(),
                               (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
+        }
         join_side();
         if (wc.keys) {
             pf.begin("word_cache_insert");
@@ -1544,6 +1597,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.norig = norig;                                   // normalised / shifted text: every byte's original byte range
         a.norig_e = norig_e;
         a.byte_level = hm.byte_level;
+        a.snap_chars = hm.byte_level || hm.char_bpe;
+        if (hm.char_bpe && !hm.unk_configured && !hm.byte_fallback) { a.char_id = t->dt.char_id; a.cb = t->dt.cb; }      // (chars can be dropped: offsets are running sums)
         a.trim_offsets = hm.trim_offsets;
         a.trim_matches_only = !hm.byte_level;            // (a model that is not byte-level: only an added token's slice can hold what is trimmed; the loader checked the vocabulary)
         a.pp_add_prefix_space = hm.pp_add_prefix_space;
@@ -1648,6 +1703,7 @@ int error_from_bits(int bits) {
                                             "original model, as it subtracts the number of special characters");
     if (bits & ERR_TOO_MANY_TOKENS) return set_error(TKAMD_ERR_INVALID, "a truncation leaves more than 2^32 overflowing encodings of one sequence");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
+    if (bits & ERR_UNK_OOV) return set_error(TKAMD_ERR_MODEL, "UnkTokenOutOfVocabulary: Unk token not found in the vocabulary");
     return TKAMD_OK;
 }
 
@@ -1745,10 +1801,10 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
         upload_tables(t.get());
+        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
         if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 1024 ? 1024 : 2048;
         build_hot_table(t.get());
-        if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
         t->cp_grid = compact_grid(t->n_cu, t->cp_items);

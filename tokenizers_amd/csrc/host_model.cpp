@@ -752,6 +752,7 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         }
         m.raw_ids.push_back(kv.second);
     }
+    const size_t n_raw_plain = m.raw_tokens.size();
 
     build_decode_tables(m, root.get(), v, c2b);
 
@@ -763,19 +764,59 @@ HostModel HostModel::from_json(const char* json, size_t len) {
 
     if (mtype == "BPE") {
         m.model = MODEL_BPE;
-        if (!m.byte_level) throw Unsupported("BPE without a ByteLevel pre-tokenizer is outside the hot path");
         const JsonValue* dr = model->get("dropout");
         if (dr && dr->is_number() && dr->num != 0.0) throw Unsupported("BPE dropout needs the reference's RNG (bpe/word.rs:181)");
-        std::string s;
-        if (opt_str("continuing_subword_prefix", &s) && !s.empty()) throw Unsupported("BPE continuing_subword_prefix");
-        if (opt_str("end_of_word_suffix", &s) && !s.empty()) throw Unsupported("BPE end_of_word_suffix");
+        opt_str("continuing_subword_prefix", &m.bpe_prefix);
+        opt_str("end_of_word_suffix", &m.bpe_suffix);
+        m.fuse_unk = model->get_bool("fuse_unk", false);
+        m.byte_fallback = model->get_bool("byte_fallback", false);
         m.ignore_merges = model->get_bool("ignore_merges", false);
         if (opt_str("unk_token", &m.unk_token)) {
+            m.unk_configured = true;
             auto it = v.find(m.unk_token);
             if (it != v.end()) { m.has_unk = true; m.unk_id = it->second; }
         }
+        m.char_bpe = !m.byte_level;
+        if (m.byte_level && (!m.bpe_prefix.empty() || !m.bpe_suffix.empty())) throw Unsupported("byte-level BPE with continuing_subword_prefix / end_of_word_suffix");
+        if (m.byte_level && m.byte_fallback) throw Unsupported("byte-level BPE with byte_fallback");
+        if (m.char_bpe) {
+            // BPE over characters (BPE::merge_word, bpe/model.rs:465-550): a char's initial symbol is the vocabulary entry of the char with
+            // the affixes its place in the word glues on.  Every (char, affix combination) the vocabulary knows goes into one direct
+            // indexed table
+            if (m.bpe_prefix.size() > 31 || m.bpe_suffix.size() > 31) throw Unsupported("BPE continuing_subword_prefix / end_of_word_suffix longer than 31 bytes");
+            m.char_id.assign(CHAR_TABLE_WORDS, CHAR_NONE);
+            for (auto& kv : v) {
+                const std::string& e = kv.first;
+                for (uint32_t var = 0; var < 4; ++var) {
+                    if ((var & 1u) && m.bpe_prefix.empty()) continue;
+                    if ((var & 2u) && m.bpe_suffix.empty()) continue;
+                    size_t a = 0, b = e.size();
+                    if (var & 1u) { if (e.compare(0, m.bpe_prefix.size(), m.bpe_prefix) != 0 || e.size() < m.bpe_prefix.size()) continue; a = m.bpe_prefix.size(); }
+                    if (var & 2u) { if (b - a < m.bpe_suffix.size() || e.compare(b - m.bpe_suffix.size(), m.bpe_suffix.size(), m.bpe_suffix) != 0) continue; b -= m.bpe_suffix.size(); }
+                    if (b <= a || b - a > 4) continue;
+                    uint32_t cp = 0;
+                    const size_t l = utf8_decode((const uint8_t*)e.data() + a, b - a, &cp);
+                    if (l != b - a || cp >= 0x110000u) continue;                  // exactly one char between the affixes
+                    m.char_id[((size_t)cp << 2) | var] = kv.second;
+                }
+            }
+            for (int b = 0; b < 256; ++b) m.byte_id[b] = CHAR_NONE;
+            if (m.byte_fallback) {
+                // (merge_word glues the affixes on BEFORE it falls back to bytes, so they would be spelt out as <0xXX> tokens too --
+                // symbols the word has no bytes for; and a byte without its token sends the char on to the unk path behind symbols
+                // already added: both corners are refused)
+                if (!m.bpe_prefix.empty() || !m.bpe_suffix.empty()) throw Unsupported("BPE byte_fallback together with continuing_subword_prefix / end_of_word_suffix");
+                for (int b = 0; b < 256; ++b) {
+                    char code[8];
+                    snprintf(code, sizeof(code), "<0x%02X>", b);
+                    auto it = v.find(code);
+                    if (it == v.end()) throw Unsupported(std::string("BPE byte_fallback without the byte token ") + code);
+                    m.byte_id[b] = it->second;
+                }
+            }
+        }
         // byte -> initial symbol id (bpe/model.rs:494-499 with the byte-level alphabet)
-        for (int b = 0; b < 256; ++b) {
+        for (int b = 0; b < 256 && m.byte_level; ++b) {
             std::string ch;
             uint32_t cp = b2c[b];
             if (cp < 0x80) ch.push_back((char)cp);
@@ -801,7 +842,9 @@ HostModel HostModel::from_json(const char* json, size_t len) {
                     throw Invalid("tokenizer.json: bad legacy merge entry");
                 a = e->str.substr(0, sp); b = e->str.substr(sp + 1);
             } else throw Invalid("tokenizer.json: bad merge entry");
-            auto ia = v.find(a), ib = v.find(b), in = v.find(a + b);
+            // (new token = a + b minus the continuing_subword_prefix's LENGTH in bytes, whatever b starts with: BpeBuilder::build :246-271)
+            if (b.size() < m.bpe_prefix.size()) throw Invalid("tokenizer.json: a merge's right-hand token is shorter than continuing_subword_prefix");
+            auto ia = v.find(a), ib = v.find(b), in = v.find(a + b.substr(m.bpe_prefix.size()));
             if (ia == v.end() || ib == v.end() || in == v.end())
                 throw Invalid("tokenizer.json: merge token out of vocabulary (MergeTokenOutOfVocabulary)");
             mm[((uint64_t)ia->second << 32) | ib->second] = {rank, in->second};
@@ -830,6 +873,23 @@ HostModel HostModel::from_json(const char* json, size_t len) {
         if (it != v.end()) { m.has_unk = true; m.unk_id = it->second; }
     } else {
         throw Unsupported("model: type '" + mtype + "' is outside the hot path");
+    }
+
+    // BPE over characters with an end_of_word_suffix: the vocabulary entry of a WHOLE word carries the suffix its text does not.  The
+    // whole-word table (below) is keyed by text: the merge-stable shortcut's candidates are the entries minus their suffix (an entry
+    // without it cannot be a word's last symbol, let alone the whole word) -- each is then run through the device's merge kernel and
+    // only kept if the result is exactly its own id (capi.cpp verify_direct_words).  ignore_merges looks the TEXT up as it stands
+    // (vocab.get(sequence), bpe/model.rs:559-567): no stripping there.
+    if (m.char_bpe && !m.ignore_merges && !m.bpe_suffix.empty()) {
+        (void)n_raw_plain;
+        for (std::string& r : m.raw_tokens) {
+            if (r.size() > m.bpe_suffix.size() && r.compare(r.size() - m.bpe_suffix.size(), m.bpe_suffix.size(), m.bpe_suffix) == 0) r.resize(r.size() - m.bpe_suffix.size());
+            else r.clear();
+        }
+        // (two entries may now share a text -- "ab</w>" and a stray "ab</w></w>" -- : the table wants distinct keys, the first one stays)
+        std::unordered_map<std::string, size_t> seen;
+        for (size_t i = 0; i < m.raw_tokens.size(); ++i)
+            if (!m.raw_tokens[i].empty() && !seen.emplace(m.raw_tokens[i], i).second) m.raw_tokens[i].clear();
     }
 
     // ---- whole-word tables (BPE: ignore_merges + merge-stable shortcut; WordLevel: the model) ----

@@ -115,7 +115,15 @@ struct HostModel {
     std::string bert_normalize(const std::string& s, bool* refused) const;
 
     // ---- tables copied to the device ----
-    uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level)
+    uint32_t byte_id[256];              // byte -> id of its one-symbol token (BPE byte-level); BPE over chars with byte_fallback: id of "<0xXX>"
+    // BPE over CHARACTERS (no ByteLevel pre-tokenizer): the options of BPE::merge_word (bpe/model.rs:465-550)
+    bool char_bpe = false;
+    bool unk_configured = false;        // an unk_token is set (has_unk: ... and the vocabulary holds it; else UnkTokenOutOfVocabulary when first needed)
+    bool fuse_unk = false, byte_fallback = false;
+    std::string bpe_prefix, bpe_suffix; // continuing_subword_prefix / end_of_word_suffix ("" = none)
+    // char -> id of its one-symbol token, indexed by (code point << 2 | variant), variant bit 0: the prefix is glued on (not the word's first
+    // char), bit 1: the suffix (its last char); CHAR_NONE: the vocabulary has no such entry.  Direct indexed: 0x110000 x 4 words (17 MB)
+    std::vector<uint32_t> char_id;
     std::vector<MergeSlot> merge_table; // perfect hash (hash-and-displace), size = merge_mask+1 (power of two)
     std::vector<uint16_t> merge_disp;   // displacement per bucket, size = merge_bmask+1
     uint32_t merge_mask = 0, merge_seed = 0, merge_bmask = 0;

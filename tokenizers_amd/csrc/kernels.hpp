@@ -16,6 +16,9 @@ struct DevTables {
     const uint16_t* merge_disp;       // bucket displacements
     uint32_t merge_mask, merge_seed, merge_bmask;
     uint32_t newid_affine, newid_base;   // new_id == rank + newid_base for every merge (host-verified)
+    const uint32_t* char_id;          // BPE over characters: (code point << 2 | affix variant) -> id of the char's one-symbol token or CHAR_NONE (tables.hpp), else null
+    uint32_t cb;                      // CB_* flags of that model (0: byte-level BPE, or another model)
+    int* err;                         // (per call, in the host's copy) the batch's error bits: the char start reports ERR_UNK_OOV
     uint32_t thin_limit;              // != 0 (per call, in the host's copy): the LDS merge kernels pick the owner of the <= 16-byte queue by its fill (bpe.hip)
     // in-batch claims: set (per call, in the host's copy) when the model kernels publish the claimants' rows themselves (bpe.hip)
     const unsigned long long* pub_claims;
@@ -117,6 +120,10 @@ struct MetaArgs {
     const uint32_t* lprefix;
     uint32_t byte_level, trim_offsets, pp_add_prefix_space, want_offsets, char_mode, want_words;
     uint32_t trim_matches_only;       // trim_offsets on a model that is not byte-level: only added-token matches are looked at
+    uint32_t snap_chars;              // token edges snap outwards to char boundaries: byte-level tokens, and BPE over characters (its offsets are running
+                                      // sums of symbol lengths, which cut chars behind a dropped char or inside byte_fallback's one-byte symbols)
+    const uint32_t* char_id;          // BPE over characters WITHOUT an unk_token: chars the vocabulary lacks are dropped and every offset behind them
+    uint32_t cb;                      // moves up -- k_token_meta subtracts the dropped bytes in front of every token edge (null / 0: nothing is ever dropped)
     const unsigned long long* matchmask;  // added-token matches (their offsets trim real whitespace chars), or null
     const uint16_t* uc1;
     const uint8_t* uc2;
@@ -257,6 +264,7 @@ enum : int {
     ERR_TOO_MANY_TOKENS = 256,
     ERR_TRUNC_SHORT = 512,        // OnlyFirst / OnlySecond: the sequence to cut is not longer than what must go (TruncationError::SequenceTooShort)    // the padded batch has more than 2^32 tokens
     ERR_TRUNC_STRIDE = 1024,      // a sequence has to be cut to max_len tokens and stride >= max_len (the assert of Encoding::truncate, encoding.rs:319)
+    ERR_UNK_OOV = 4096,           // BPE: a char the vocabulary lacks, and the unk_token that should stand for it is not in the vocabulary either (Error::UnkTokenOutOfVocabulary, bpe/model.rs:528-533)
     NOTE_REORDER_SEEN = 2048,     // not an error: the normalizer met a character NFD's canonical ordering could move (k_bn_reorder_fix then looks at its neighbours)
     ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
@@ -364,6 +372,10 @@ int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                            uint32_t* tmp_ids, uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge,
                            uint32_t* scratch, unsigned long long scratch_words, unsigned long long* scratch_used, int* err);
+// the workgroup-per-pre-token kernel alone, on any queue (BPE over characters: the 33..64-byte class, and every class when the LDS
+// kernels cannot run)
+void launch_bpe_merge_long_only(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end,
+                                uint32_t* list_huge, uint32_t* n_huge);
 // single-pass compaction; `state` (8 bytes per chunk of 256 x cp_items pre-tokens) must be zero on entry; pt_tokoff may be null.
 // Any grid makes progress (a look-back that runs out of patience computes the missing totals itself: kernels/output.hip);
 // compact_grid(n_cu) -- what is resident at once -- is the one that never has to.

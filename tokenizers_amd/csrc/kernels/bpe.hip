@@ -357,7 +357,12 @@ template __global__ void k_bpe_merge_lane<32>(DevTables, const uint8_t*, QView, 
 // v2 (v2.q != nullptr): a second queue, taken after the first -- the 32-symbol kernel also serves the <= 16-byte class when the
 // in-batch claims have thinned both queues to the distinct words: each launch then lasts as long as its longest word's chain of
 // dependent merge probes whatever the queue holds, and one launch is cheaper than two.
-template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
+// CHARS: BPE over CHARACTERS (no ByteLevel pre-tokenizer; the instantiation a tokenizer with t.cb & CB_ON runs).  Only the start differs:
+// a symbol per char -- the vocabulary entry of the char with the affixes its place in the word glues on (t.char_id), an unk symbol
+// (one per unknown char, or one per run of them: fuse_unk), the <0xXX> tokens of its bytes (byte_fallback), or nothing at all (no
+// unk_token: the char is dropped) -- BPE::merge_word, bpe/model.rs:465-550.  Symbols still sit at the byte position they start at, so
+// the merge loop, the token-boundary mask and the row format are the byte-level ones.
+template <int S, int NT, bool DISP_LDS, bool SYM_REGS, bool CHARS = false>
 __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t* __restrict__ text, QView v, QView v2, uint4* __restrict__ rows,
                                                       uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
     __shared__ uint32_t s_qpre[NSQ + 1];
@@ -437,6 +442,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 _Pragma("unroll") for (int q_ = 1; q_ < S; ++q_) (dst) = ((pos) == (uint32_t)q_) ? ids[q_] : (dst); \
             }                                                                                  \
         } while (0)
+        uint32_t alive0 = 0u;                                  // the positions a symbol starts at
         {
             uint64_t kb[S / 8];
 #pragma unroll
@@ -445,24 +451,78 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 load_key16(text, s, min(len, 16u), &kb[0], &kb[1]);
                 if (S == 32 && len > 16) load_key16(text, s + 16, len - 16, &kb[S / 8 - 2], &kb[S / 8 - 1]);
             }
+#define TKAMD_BYTE_AT(i_) ((i_) < S ? (uint32_t)((kb[((i_) < S ? (i_) : 0) / 8] >> (8 * (((i_) < S ? (i_) : 0) % 8))) & 0xFFu) : 0u)
+            if (!CHARS) {
 #pragma unroll
-            for (int i = 0; i < S; ++i) {
-                ids[i] = s_byte_id[(uint32_t)((kb[i / 8] >> (8 * (i % 8))) & 0xFFu)];
-                if (!SYM_REGS) my_sym[i * NT] = ids[i];
-            }
-#pragma unroll
-            for (int i = 0; i < S; ++i) {
-                uint32_t k = 0xFFFFFFFFu;
-                if (i < S - 1 && (uint32_t)(i + 1) < len) {
-                    uint32_t r, nd;
-                    merge_probe_d(t, disp, ids[i], ids[i + 1], &r, &nd);
-                    if (r != RANK_NONE) k = (r << PB) | (uint32_t)i;
+                for (int i = 0; i < S; ++i) {
+                    ids[i] = s_byte_id[TKAMD_BYTE_AT(i)];
+                    if (!SYM_REGS) my_sym[i * NT] = ids[i];
                 }
-                my_key[i * NT] = k;
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    uint32_t k = 0xFFFFFFFFu;
+                    if (i < S - 1 && (uint32_t)(i + 1) < len) {
+                        uint32_t r, nd;
+                        merge_probe_d(t, disp, ids[i], ids[i + 1], &r, &nd);
+                        if (r != RANK_NONE) k = (r << PB) | (uint32_t)i;
+                    }
+                    my_key[i * NT] = k;
+                }
+                alive0 = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);
+            } else {
+                static_assert(!CHARS || SYM_REGS, "the char start keeps its symbols in registers");
+                // 1. every char's own entry: S independent loads (a continuation byte asks for nothing)
+                uint32_t own[S];
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    const uint32_t b0 = TKAMD_BYTE_AT(i), b1 = TKAMD_BYTE_AT(i + 1) & 0x3Fu, b2 = TKAMD_BYTE_AT(i + 2) & 0x3Fu, b3 = TKAMD_BYTE_AT(i + 3) & 0x3Fu;
+                    const bool lead = (uint32_t)i < len && (b0 & 0xC0u) != 0x80u;
+                    const uint32_t cl = b0 < 0x80u ? 1u : b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : 4u;
+                    const uint32_t cp = b0 < 0x80u ? b0 : b0 < 0xE0u ? ((b0 & 0x1Fu) << 6) | b1 : b0 < 0xF0u ? ((b0 & 0x0Fu) << 12) | (b1 << 6) | b2
+                                                                                                              : ((b0 & 0x07u) << 18) | (b1 << 12) | (b2 << 6) | b3;
+                    const uint32_t var = ((i != 0 && (t.cb & CB_PREFIX)) ? 1u : 0u) | (((uint32_t)i + cl >= len && (t.cb & CB_SUFFIX)) ? 2u : 0u);
+                    own[i] = (lead && cp < 0x110000u) ? t.char_id[(cp << 2) | var] : CHAR_NONE;
+                }
+                // 2. what stands where (in order: an unknown char's fate depends on the one before it)
+                bool unknown = false, prev_unk = false;
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    ids[i] = 0u;
+                    if ((uint32_t)i < len) {
+                        const uint32_t b0 = TKAMD_BYTE_AT(i);
+                        const bool lead = (b0 & 0xC0u) != 0x80u;
+                        if (lead) unknown = own[i] == CHAR_NONE;
+                        if (!unknown) { if (lead) { ids[i] = own[i]; alive0 |= 1u << i; prev_unk = false; } }
+                        else if (t.cb & CB_BYTES) { ids[i] = s_byte_id[b0]; alive0 |= 1u << i; prev_unk = false; }
+                        else if (lead) {
+                            if (t.cb & CB_UNK) {
+                                if (!(prev_unk && (t.cb & CB_FUSE))) { ids[i] = t.unk_id; alive0 |= 1u << i; }
+                                prev_unk = true;
+                            } else if (t.cb & CB_UNK_MISSING) atomicOr(t.err, ERR_UNK_OOV);
+                        }                                      // (no unk_token at all: dropped without trace)
+                    }
+                }
+                // 3. the rank of every symbol's pair with the next one standing
+#pragma unroll
+                for (int i = 0; i < S; ++i) {
+                    uint32_t k = 0xFFFFFFFFu;
+                    const uint32_t above = (i < S - 1) ? (alive0 & ~((2u << i) - 1u)) : 0u;
+                    if (((alive0 >> i) & 1u) && above) {
+                        const uint32_t j = (uint32_t)__ffs(above) - 1u;
+                        uint32_t right = ids[0];
+#pragma unroll
+                        for (int q_ = 1; q_ < S; ++q_) right = (j == (uint32_t)q_) ? ids[q_] : right;
+                        uint32_t r, nd;
+                        merge_probe_d(t, disp, ids[i], right, &r, &nd);
+                        if (r != RANK_NONE) k = (r << PB) | (uint32_t)i;
+                    }
+                    my_key[i * NT] = k;
+                }
             }
+#undef TKAMD_BYTE_AT
         }
-        uint32_t alive = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);
-        bool active = valid && len > 1;
+        uint32_t alive = alive0;
+        bool active = valid && __popc(alive) > 1;
         while (__any(active)) {
             if (active) {
                 uint32_t best = 0xFFFFFFFFu;
@@ -504,6 +564,11 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
             uint32_t r[4] = {ids[0], 0u, 0u, 0u};
             if (!SYM_REGS) r[0] = my_sym[0];
             uint32_t m = alive & ~1u;
+            if (CHARS) {                                       // (a dropped char may leave position 0 empty -- or the whole word)
+                m = alive;
+                r[0] = 0u;
+                if (m) { const uint32_t p0 = (uint32_t)__ffs(m) - 1u; TKAMD_SYM_AT(r[0], p0); m &= m - 1u; }
+            }
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
                 if (m) {
@@ -523,7 +588,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                     if (tmp_end) tmp_end[s + j - 1] = pos;
                 }
             }
-            if (tmp_end) tmp_end[s + c - 1] = len;
+            if (tmp_end && c) tmp_end[s + c - 1] = len;
             { const uint4 row_ = make_row(c, s, r[0], r[1], r[2], r[3]); rows[qidx] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
         }
     }
@@ -532,11 +597,16 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
 constexpr int lds_merge_bytes(int S, int NT, bool disp_lds, bool sym_regs) { return ((sym_regs ? 1 : 2) * S * NT + 256 + 64) * 4 + (disp_lds ? DISP_LDS_MAX * 2 : 0); }
 template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
 static int prepare_lds_merge() {
-    return (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
+    int rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS));
+    return rc;
 }
 template <int S, int NT, bool DISP_LDS, bool SYM_REGS>
 static void launch_lds_merge(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const QView& v2, uint4* rows, uint32_t* tmp_ids, uint32_t* tmp_end) {
-    hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, v, v2, rows, tmp_ids, tmp_end);
+    if (t.cb & CB_ON)
+        hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS, true>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, v, v2, rows, tmp_ids, tmp_end);
+    else
+        hipLaunchKernelGGL((k_bpe_merge_lds<S, NT, DISP_LDS, SYM_REGS, false>), dim3(grid), dim3(NT), lds_merge_bytes(S, NT, DISP_LDS, SYM_REGS), st, t, text, v, v2, rows, tmp_ids, tmp_end);
 }
 
 // =================================================================================================
@@ -567,19 +637,72 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
         const uint32_t s = it.s, len = it.len;
         if (len == 0u) continue;                           // retired by k_long_vocab
         if (len > (uint32_t)LONG_PT_MAX) {                 // too long for LDS: hand over to k_bpe_merge_huge (by queue position)
-            if (tid == 0) list_huge[atomicAdd(n_huge, 1u)] = pos;
+            if (tid == 0) {
+                if (t.cb & CB_ON) atomicOr(t.err, ERR_PRETOKEN_TOO_LONG);      // (BPE over characters: no global-scratch variant -- a "word" of more than 8 KB)
+                else list_huge[atomicAdd(n_huge, 1u)] = pos;
+            }
+            if (t.cb & CB_ON) {                            // (uniform) an empty row keeps the compaction well defined until the error is reported
+                if (tid == 0) rows[v.row_base + pos] = make_uint4(ROW_CNT_MORE << ROW_CNT_SHIFT, s, 0u, 0u);
+            }
             continue;
         }
         __syncthreads();
-        for (uint32_t i = tid; i < len; i += 256) {
-            sym[i] = t.byte_id[text[s + i]];
-            nxt[i] = (i + 1 < len) ? (uint16_t)(i + 1) : (uint16_t)0xFFFF;
-            prv[i] = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)0xFFFF;
+        if (!(t.cb & CB_ON)) {                             // (uniform) byte-level: a symbol per byte
+            for (uint32_t i = tid; i < len; i += 256) {
+                sym[i] = t.byte_id[text[s + i]];
+                nxt[i] = (i + 1 < len) ? (uint16_t)(i + 1) : (uint16_t)0xFFFF;
+                prv[i] = (i > 0) ? (uint16_t)(i - 1) : (uint16_t)0xFFFF;
+            }
+        } else {
+            // BPE over characters (merge_word, bpe/model.rs:465-550; the same start as k_bpe_merge_lds<.., CHARS>): every lead byte asks
+            // for its char's entry -- in parallel, parked in nid[] --, then ONE thread links up what stands where: an unknown char's fate
+            // (its own unk symbol, part of the previous one, its bytes' tokens, nothing) depends on the char before it
+            for (uint32_t i = tid; i < len; i += 256) {
+                const uint32_t b0 = text[s + i];
+                uint32_t own = CHAR_NONE;
+                if ((b0 & 0xC0u) != 0x80u) {
+                    const uint32_t cl = b0 < 0x80u ? 1u : b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : 4u;
+                    uint32_t cp = b0 < 0x80u ? b0 : b0 < 0xE0u ? (b0 & 0x1Fu) : b0 < 0xF0u ? (b0 & 0x0Fu) : (b0 & 0x07u);
+                    for (uint32_t q = 1; q < cl; ++q) cp = (cp << 6) | (i + q < len ? (text[s + i + q] & 0x3Fu) : 0u);
+                    const uint32_t var = ((i != 0 && (t.cb & CB_PREFIX)) ? 1u : 0u) | ((i + cl >= len && (t.cb & CB_SUFFIX)) ? 2u : 0u);
+                    if (cp < 0x110000u) own = t.char_id[(cp << 2) | var];
+                }
+                nid[i] = own;
+                sym[i] = 0xFFFFFFFFu;                      // nothing stands here (yet)
+                nxt[i] = prv[i] = (uint16_t)0xFFFF;
+                rnk[i] = RANK_NONE;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                bool unknown = false, prev_unk = false;
+                uint32_t last = 0xFFFFu;
+                for (uint32_t i = 0; i < len; ++i) {
+                    const uint32_t b0 = text[s + i];
+                    const bool lead = (b0 & 0xC0u) != 0x80u;
+                    if (lead) unknown = nid[i] == CHAR_NONE;
+                    uint32_t id = 0xFFFFFFFFu;
+                    if (!unknown) { if (lead) { id = nid[i]; prev_unk = false; } }
+                    else if (t.cb & CB_BYTES) { id = t.byte_id[b0]; prev_unk = false; }
+                    else if (lead) {
+                        if (t.cb & CB_UNK) {
+                            if (!(prev_unk && (t.cb & CB_FUSE))) id = t.unk_id;
+                            prev_unk = true;
+                        } else if (t.cb & CB_UNK_MISSING) atomicOr(t.err, ERR_UNK_OOV);
+                    }
+                    if (id != 0xFFFFFFFFu) {
+                        sym[i] = id;
+                        prv[i] = (uint16_t)last;
+                        if (last != 0xFFFFu) nxt[last] = (uint16_t)i;
+                        last = i;
+                    }
+                }
+            }
         }
         __syncthreads();
         for (uint32_t i = tid; i < len; i += 256) {
             uint32_t r = RANK_NONE, ni = 0;
-            if (i + 1 < len) merge_probe(t, sym[i], sym[i + 1], &r, &ni);
+            const uint32_t j = nxt[i];
+            if (sym[i] != 0xFFFFFFFFu && j != 0xFFFFu) merge_probe(t, sym[i], sym[j], &r, &ni);
             rnk[i] = r;
             nid[i] = ni;
         }
@@ -641,7 +764,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
                 uint32_t j = off + (uint32_t)mbcnt64(bm);
                 if (j == 0) first_s = sym[i];
                 else tmp_ids[s + j] = sym[i];
-                if (tmp_end) {
+                if (tmp_end) {                                 // (the end of a token = where the next one starts: k_token_meta's convention)
                     uint32_t e = nxt[i];
                     tmp_end[s + j] = (e == 0xFFFFu) ? len : e;
                 }
@@ -651,6 +774,10 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
             __syncthreads();
         }
         // long pre-tokens always use the "ids 1.. in tmp_ids" row form, whatever their count
-        if (tid == 0) rows[v.row_base + pos] = make_uint4(first_s | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, cnt_s, 0u);
+        if (tid == 0) {
+            const uint4 row_ = make_uint4((cnt_s ? first_s : 0u) | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, cnt_s, 0u);
+            rows[v.row_base + pos] = row_;
+            TKAMD_PUBLISH_ROW(t, text, s, len, row_);      // (short words come here when the LDS kernels cannot take them: BPE over characters whose new ids are not in merge order)
+        }
     }
 }

@@ -256,6 +256,10 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
     hipLaunchKernelGGL(k_bpe_merge_huge, dim3(64), dim3(256), 0, st, t, text, (const QItem*)v.q, (uint4*)rows, v.row_base, (const uint32_t*)list_huge,
                        (const uint32_t*)n_huge, tmp_ids, tmp_end, scratch, scratch_words, scratch_used, err);
 }
+void launch_bpe_merge_long_only(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end,
+                                uint32_t* list_huge, uint32_t* n_huge) {
+    hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, list_huge, n_huge);
+}
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z) {
     if (z.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(grid), dim3(256), 0, st, z);
 }

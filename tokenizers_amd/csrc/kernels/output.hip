@@ -295,13 +295,30 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             const uint32_t t0 = a.tok0[p];
             if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = (uint32_t)a.claims[t0 & TOK_REF_MASK];
         }
+        // BPE over characters without an unk_token: a char the vocabulary lacks leaves no symbol, and the reference's token offsets are
+        // running sums of the symbols' lengths (word.rs:260-268) -- every edge behind a dropped char moves up by its bytes.  The model
+        // kernels report edges as positions; the dropped bytes in front of each edge are counted here, walking the word once.
+        uint32_t dq = s, dropped = 0u;
+        auto running = [&](uint32_t rel_pos) -> uint32_t {
+            if (!a.char_id) return rel_pos;
+            const uint32_t target = s + rel_pos;
+            while (dq < target) {
+                uint32_t l;
+                const uint32_t cp = utf8_global(a.x_text, dq, &l);
+                l = min(l, e - dq);
+                const uint32_t var = ((dq != s && (a.cb & CB_PREFIX)) ? 1u : 0u) | ((dq + l >= e && (a.cb & CB_SUFFIX)) ? 2u : 0u);
+                if (cp >= 0x110000u || a.char_id[(cp << 2) | var] == CHAR_NONE) dropped += l;
+                dq += l;
+            }
+            return rel_pos - dropped;
+        };
         for (uint32_t j = 0; j < c; ++j) {
-            uint32_t rel_end = (c == 1) ? (e - s) : a.tmp_end[s_ends + j];
+            uint32_t rel_end = running((c == 1) ? (e - s) : a.tmp_end[s_ends + j]);
             if (a.want_words) a.word_ids[o + j] = word;
             if (a.want_offsets) {
                 uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
                 uint32_t bs = ts, be = te;
-                if (a.byte_level && !is_match) {                      // snap to char boundaries inside the pre-token
+                if (a.snap_chars && !is_match) {                      // snap to char boundaries inside the pre-token
                     while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
                     while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
                 }

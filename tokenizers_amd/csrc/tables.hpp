@@ -120,6 +120,19 @@ TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed)
     return word_hash1_from_hot(hot_hash((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, len, seed), (uint32_t)(hi >> 32));
 }
 
+// ---- BPE over characters: initial symbols (bpe/model.rs:465-550), see HostModel::char_id and kernels/bpe.hip ----
+constexpr uint32_t CHAR_NONE = 0xFFFFFFFFu;
+constexpr uint32_t CHAR_TABLE_WORDS = 0x110000u * 4u;
+enum : uint32_t {
+    CB_ON = 1,            // the model is a BPE over characters
+    CB_PREFIX = 2,        // continuing_subword_prefix glued to every char but the first
+    CB_SUFFIX = 4,        // end_of_word_suffix glued to the last char
+    CB_UNK = 8,           // an unk_token stands for chars the vocabulary lacks ...
+    CB_UNK_MISSING = 16,  // ... or was configured but is not in the vocabulary: an error the moment it is needed
+    CB_FUSE = 32,         // consecutive unknown chars become ONE unk symbol
+    CB_BYTES = 64,        // byte_fallback: such a char becomes the <0xXX> tokens of its bytes (all 256 exist: checked at load)
+};
+
 // ---- vocabulary entries longer than 16 bytes: open addressing over the vocabulary blob, keyed by this hash of the bytes, four at a
 // time (the last word zero padded; the length goes in first, so the padding is unambiguous) ----
 TK_HD uint32_t long_key_hash_step(uint32_t h, uint32_t w) {
