@@ -118,6 +118,38 @@ def check_against_oracle(tok, oracle_obj, batch: Batch, stream) -> int:
     return len(batch.sample_idx)
 
 
+def timed_steps(step_fn, steps: int, warmup: int, fence, reduce_max, finish_last=None) -> float:
+    """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps between two fences (barrier + device
+    synchronisation on both sides), and the MAX over ranks of the wall time.  `fence()` / `reduce_max(seconds) -> seconds` carry
+    the process group (no-ops for one rank); `finish_last(x)` waits for what the last step returned.  Kept free of CUDA so that
+    tests/test_parallel.py runs this very function over gloo with a stand-in step."""
+    for i in range(warmup):
+        step_fn(i)
+    fence()
+    t_start = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = step_fn(i)
+    if finish_last is not None and last is not None:
+        finish_last(last)
+    fence()
+    return reduce_max(time.perf_counter() - t_start), last
+
+
+def run_guarded(fn, seconds: float, on_timeout):
+    """fn() under a watchdog THREAD (not SIGALRM: a rank stuck inside a collective sits in C++ with the GIL released, where a Python
+    signal handler never gets to run; a thread does).  on_timeout() runs on the watchdog thread and is expected not to return
+    (bench.py prints what it has and os._exit()s, on every rank, so that a hang ends the whole job)."""
+    import threading
+    wd = threading.Timer(seconds, on_timeout)
+    wd.daemon = True
+    wd.start()
+    try:
+        return fn()
+    finally:
+        wd.cancel()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,22 +231,17 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(step_fn):
-        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
-        for i in range(args.warmup):
-            step_fn(i)
-        fence()
-        t_start = time.perf_counter()
-        last = None
-        for i in range(args.steps):
-            last = step_fn(i)
-        last.sync()
-        fence()
-        el = torch.tensor([time.perf_counter() - t_start], dtype=torch.float64, device=dev)
+    def reduce_max(seconds):
+        el = torch.tensor([seconds], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        state["last"] = last
         return float(el.item())
+
+    def timed(step_fn):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        el, last = timed_steps(step_fn, args.steps, args.warmup, fence, reduce_max, finish_last=lambda b: b.sync())
+        state["last"] = last
+        return el
 
     state = {}
     elapsed = timed(encode)
@@ -493,8 +520,6 @@ def main() -> None:
         # A collective that never completes must not cost the bench line.  A watchdog THREAD, not SIGALRM: a rank stuck inside a RCCL
         # wait sits in C++ with the GIL released, where a Python signal handler never gets to run; a thread does.  Every rank has
         # one (rank 0 prints the line first), so a hang ends the whole job instead of leaving torchrun waiting on the others.
-        import threading
-
         def on_timeout():
             finish({"error": "the gather leg did not finish within 180 s"})
             os._exit(0)
@@ -503,17 +528,13 @@ def main() -> None:
             b = encode(i)
             gather_to_root(b.ids_tensor_unsynced(), b.tok_offsets_tensor(), dev, n_tokens_dev=b.n_tokens_tensor())
             return b
-        watchdog = threading.Timer(180.0, on_timeout)
-        watchdog.daemon = True
-        watchdog.start()
         try:
-            el_g = timed(step_gather)
+            el_g = run_guarded(lambda: timed(step_gather), 180.0, on_timeout)
             gather_obj = {"ms_per_step": round(el_g / args.steps * 1e3, 4), "value": round(tot_bytes / el_g / 1e9, 3), "unit": "GB/s",
                           "what": "the same K steps, each followed by gather_to_root (one all_gather of sizes + one point-to-point message per "
                                   "peer for ids and per-document counts) over RCCL; the root's copy of its own shard included"}
         except Exception as ex:
             gather_obj = {"error": repr(ex)}
-        watchdog.cancel()
     finish(gather_obj)
     if use_dist:
         dist.barrier()

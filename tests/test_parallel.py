@@ -169,3 +169,65 @@ def test_encode_batch_sharded_on_one_gpu_over_rccl():
         "dist.destroy_process_group(); print('SHARDED_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "SHARDED_OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- bench.py's multi-rank control flow (the timed region's contract, the gather leg's watchdog) over gloo ------------------------
+def _bench_worker(rank, world, port, q):
+    import time
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        calls = []
+
+        def step(i):                                    # a stand-in encode: rank r takes (r + 1) x 20 ms a step, and gathers like bench.py's gather leg
+            time.sleep(0.02 * (rank + 1))
+            calls.append(i)
+            ids = torch.arange(5 + rank, dtype=torch.int32)
+            offs = torch.tensor([0, 2, 5 + rank], dtype=torch.int64)
+            gather_to_root(ids, offs, torch.device("cpu"))
+            return i
+
+        def fence():
+            dist.barrier()
+
+        def reduce_max(seconds):
+            el = torch.tensor([seconds], dtype=torch.float64)
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            return float(el.item())
+        finished = []
+        el, last = bench.run_guarded(lambda: bench.timed_steps(step, 5, 2, fence, reduce_max, finish_last=finished.append), 60.0, lambda: os._exit(3))
+        q.put((rank, el, last, calls, finished))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_timed_region_and_watchdog_over_gloo():
+    """bench.timed_steps / bench.run_guarded are the functions bench.py itself runs: W untimed + exactly K timed steps between two
+    barriers, the MAX over ranks of the wall time (every rank reports the slowest rank's figure), the last step's result handed to
+    finish_last; and a step that never returns ends the process from the watchdog thread instead of hanging the job."""
+    import subprocess
+    import sys
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, el, last, calls, finished in got:
+        assert calls == [0, 1, 0, 1, 2, 3, 4] and last == 4 and finished == [4]
+        assert 5 * 0.04 <= el < 5 * 0.04 + 1.0              # the slow rank's five 40 ms steps, on both ranks
+    assert got[0][1] == got[1][1]
+    # the watchdog: a "collective" that never completes (a sleep in C, GIL released) -- the thread still fires
+    code = ("import os, sys, time; sys.path.insert(0, %r); import bench\n"
+            "bench.run_guarded(lambda: time.sleep(60), 0.5, lambda: (print('WATCHDOG', flush=True), os._exit(7)))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 7 and "WATCHDOG" in r.stdout
+    import bench
+    assert bench.run_guarded(lambda: 41 + 1, 5.0, lambda: os._exit(9)) == 42
