@@ -299,6 +299,16 @@ def main() -> None:
                     "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
+        # SURVEY 8d's secondary model for the merge kernels: (k - 1) + 2 m merge-table probes for a word of k symbols and m merges,
+        # counted by the kernels themselves during this (profiling) pass for the batch that ran last
+        qs = roofline["merge_queue_sizes"]
+        mk = [k for k in stages if k.startswith("bpe_merge_lds")]
+        if qs.get("merge_probes") and mk:
+            t_merge = sum(stages[k] for k in mk) * 1e-3
+            roofline["merge_probes"] = {"per_batch": int(qs["merge_probes"]), "words": int(qs["merge16"] + qs["merge32"]),
+                                        "probes_per_s": round(qs["merge_probes"] / t_merge / 1e9, 3), "unit": "G probes/s",
+                                        "kernels_ms": round(t_merge * 1e3, 4), "bytes_per_probe": 16,
+                                        "model": "(k - 1) + 2 m per queued word of k symbols and m merges; the in-batch claims leave the distinct words only"}
 
     # ---- word-cache leg (rank 0, N=1): the device-side counterpart of the reference's per-thread word cache
     # (models/bpe/model.rs:573-586).  NOT `value`: the steps revisit the same three batches, so a warm cache has seen every word of

@@ -1425,6 +1425,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     static const bool pub_kernel = [] { const char* e = getenv("TKAMD_PUBLISH"); return e && !strcmp(e, "kernel"); }();
     DevTables mdt = t->dt;
     mdt.err = d_err;
+    mdt.probes = t->prof ? d_counters + CNT_MERGE_PROBES : nullptr;
     bool pub_inline = false;
     auto set_publish = [&]() {
         pub_inline = wc.claims && !pub_kernel;

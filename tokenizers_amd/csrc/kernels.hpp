@@ -19,6 +19,7 @@ struct DevTables {
     const uint32_t* char_id;          // BPE over characters: (code point << 2 | affix variant) -> id of the char's one-symbol token or CHAR_NONE (tables.hpp), else null
     uint32_t cb;                      // CB_* flags of that model (0: byte-level BPE, or another model)
     int* err;                         // (per call, in the host's copy) the batch's error bits: the char start reports ERR_UNK_OOV
+    uint32_t* probes;                 // (per call, profiling runs only, else null) counter of merge-table probes, (k - 1) + 2 m per word
     uint32_t thin_limit;              // != 0 (per call, in the host's copy): the LDS merge kernels pick the owner of the <= 16-byte queue by its fill (bpe.hip)
     // in-batch claims: set (per call, in the host's copy) when the model kernels publish the claimants' rows themselves (bpe.hip)
     const unsigned long long* pub_claims;
@@ -271,7 +272,7 @@ enum : int {
 
 // indices into the per-batch device counter array
 enum : int { CNT_LIST16 = 0, CNT_LIST64 = 1, CNT_LISTL = 2, CNT_LIST32 = 3, CNT_SLOW_DOCS = 4, CNT_CLAIM_CANDS = 5, CNT_CLAIM_SHARED = 6, CNT_LISTH = 7, CNT_MATCH_DOCS = 8,
-              CNT_MATCHES = 9, CNT_MATCH_DOCS2 = 10, CNT_CLAIM_GAVE_UP = 11, CNT_COUNT = 12 };
+              CNT_MATCHES = 9, CNT_MATCH_DOCS2 = 10, CNT_CLAIM_GAVE_UP = 11, CNT_MERGE_PROBES = 12, CNT_COUNT = 13 };
 // (CNT_CLAIM_*: in-batch claims -- candidates the lookup looked at, how many were another pre-token's word, workgroups that stopped claiming)
 
 constexpr uint32_t MATCH_LEN_ORIG = 0x80000000u;    // added-token match list, word 3: the length counts bytes of the ORIGINAL text

@@ -367,6 +367,8 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                                                       uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     __shared__ uint32_t s_qpre2[S == 32 ? NSQ + 1 : 1];    // (only the 32-symbol kernel takes a second queue: two 704-lane workgroups of the 16-symbol one fill a CU's LDS to the last KB)
+    __shared__ uint32_t s_probes;                          // t.probes (profiling runs): merge-table probes of this workgroup's words, SURVEY 8d's model
+    if (threadIdx.x == 0) s_probes = 0u;
     constexpr uint32_t PB = (S == 16) ? 4 : 5;
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint32_t, lds_words)
     uint32_t* s_key = lds_words;                              // [S][NT]
@@ -590,7 +592,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
             }
             if (tmp_end && c) tmp_end[s + c - 1] = len;
             { const uint4 row_ = make_row(c, s, r[0], r[1], r[2], r[3]); rows[qidx] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
+            // (k - 1) + 2 m probes for a word of k symbols and m merges: every initial pair once, two new pairs per merge
+            if (t.probes) { const uint32_t k0 = (uint32_t)__popc(alive0); if (k0) atomicAdd(&s_probes, (k0 - 1u) + 2u * (k0 - c)); }
         }
+    }
+    if (t.probes) {                                        // (uniform)
+        __syncthreads();
+        if (threadIdx.x == 0 && s_probes) atomicAdd(t.probes, s_probes);
     }
 }
 #undef TKAMD_SYM_AT

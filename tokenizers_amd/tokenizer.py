@@ -1011,9 +1011,14 @@ class Tokenizer:
 
     def queue_sizes(self) -> dict[str, int]:
         """Merge work-queue sizes of the last synchronised batch (diagnostics)."""
-        arr = (C.c_uint32 * 8)()
-        _lib.check(self._lib.tkamd_profile_counters(self._h, arr, 8))
-        return {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge_huge": arr[7]}
+        arr = (C.c_uint32 * 16)()
+        _lib.check(self._lib.tkamd_profile_counters(self._h, arr, 16))
+        out = {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge_huge": arr[7]}
+        if arr[5]:                                       # in-batch claims: candidates the lookup looked at / how many were another pre-token's word
+            out["claim_candidates"], out["claim_shared"] = arr[5], arr[6]
+        if arr[12]:                                      # (profiling runs) merge-table probes of the LDS merge kernels, (k - 1) + 2 m per word
+            out["merge_probes"] = arr[12]
+        return out
 
     def debug_phases(self, reset: bool = True) -> dict[str, list[int]]:
         """TKAMD_PHASES=1 runs only: shader-clock ticks per phase of the lookup and the compaction (``tkamd_debug_phases``)."""
