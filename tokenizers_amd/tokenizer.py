@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 import re
 import threading
 from typing import Iterable, Sequence
@@ -25,6 +26,11 @@ try:
     from . import _marshal          # C extension (csrc/pymarshal.c); built by tokenizers_amd.build.build_marshal()
 except ImportError:                 # pragma: no cover - pure-Python marshalling below is equivalent, just slower
     _marshal = None
+
+
+# set in a fork()ed child (the library has its own pthread_atfork handler: capi.cpp): page-locked memory is the parent's
+_FORKED = [False]
+os.register_at_fork(after_in_child=lambda: _FORKED.__setitem__(0, True))
 
 
 class _PinnedBlock:
@@ -733,8 +739,11 @@ class Tokenizer:
             return pack_documents(inputs)
         n = len(inputs)
         # (page-locked where a device is bound: the H2D copies of the host entry then run as plain DMA; grow-only, so the cost of
-        # pinning is paid a few times per tokenizer, not per batch)
-        empty = pinned_empty if self.device >= 0 else np.empty
+        # pinning is paid a few times per tokenizer, not per batch.  Page-locked blocks are not mapped in a fork()ed child: a child
+        # drops the parent's -- its calls fail in the library anyway, with the message, not with a fault on the way there)
+        if getattr(self, "_stage_pid", None) != os.getpid():
+            self._stage_pid, self._stage_off, self._stage_text = os.getpid(), None, None
+        empty = pinned_empty if (self.device >= 0 and not _FORKED[0]) else np.empty
         if self._stage_off is None or len(self._stage_off) < n + 1:
             self._stage_off = empty(max(n + 1, 1024, 2 * (len(self._stage_off) if self._stage_off is not None else 0)), dtype=np.int64)
         if self._stage_text is None:
