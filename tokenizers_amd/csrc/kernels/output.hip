@@ -62,6 +62,7 @@ __device__ __forceinline__ void cp_load_tok0(const uint32_t* __restrict__ tok0, 
         for (int k = 0; k < CP_ITEMS; ++k) first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
     }
 }
+template <int CP_ITEMS> struct CpAhead { CpTok0<CP_ITEMS> f; uint32_t dlo, dhi; };     // what k_compact loads a chunk ahead
 template <int CP_ITEMS>
 __device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
     const uint32_t* const first = f.w;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
-                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience) {
+                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience, uint32_t ab) {      // ab: A/B switches (launch.hip), bit 0 single-wavefront look-back, bit 1 nothing loaded ahead
     constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
     unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto tick = [&](int k) {
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
     __shared__ uint32_t s_stage[2][CP_STAGE];
     __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
     __shared__ uint32_t s_tot[2];
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_lbw[4];
+    __shared__ uint32_t s_lbf[4];
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     const int tid = (int)threadIdx.x;
@@ -140,20 +142,23 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
             for (int64_t d = tid; d <= n_docs; d += CP_NT) tok_offsets[d] = 0;
         return;
     }
-    // front half of a chunk into LDS buffer b.  (49 % of the kernel's time is the wait in here -- tok0, then the rows it names, then the
-    // scan: profiles/r4b_ab_c2.txt.  Loading tok0 a chunk ahead, so that front() starts with the row loads, changed nothing: 0.1417
-    // against 0.1403 ms, r4d.)
-    auto front = [&](int64_t ch, int b) {
-        const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
+    // front half of a chunk into LDS buffer b.  49 % of the kernel's time was the wait in here (profiles/r4b_ab_c2.txt): TWO chains of
+    // two dependent round trips each -- tok0, then the rows it names; chunk_lo, then the doc_pt entries it names.  The heads of both
+    // are loaded a chunk AHEAD (`a`, behind the previous chunk's work), so front() starts with the second halves, and the doc_pt
+    // values are only parked in LDS behind the scan: the chunk's total is published as soon as the ROWS are in.
+    auto front = [&](int64_t ch, int b, const CpAhead<CP_ITEMS>& a) {
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
-        const uint32_t dlo = chunk_lo[ch], dhi = ch == n_chunks - 1 ? (uint32_t)n_docs + 1u : chunk_lo[ch + 1];
+        const uint32_t dlo = a.dlo, dhi = a.dhi;
         CpRows<CP_ITEMS> r;
-        const uint32_t v = cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
-        if (dlo + (uint32_t)tid < dhi) s_docpt[b][tid] = doc_pt[dlo + (uint32_t)tid];
-        if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
+        const uint32_t v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, r);
+        const bool has_doc = dlo + (uint32_t)tid < dhi;
+        uint32_t my_docpt = 0u;
+        if (has_doc) my_docpt = doc_pt[dlo + (uint32_t)tid];
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
         if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
+        if (has_doc) s_docpt[b][tid] = my_docpt;
+        if (tid == 0) { s_dlo[b] = dlo; s_dhi[b] = dhi; }
         tick(0);
         uint32_t acc = ex;
 #pragma unroll
@@ -177,20 +182,43 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
         return (unsigned long long)v;
     };
+    auto ahead_of = [&](int64_t c, CpAhead<CP_ITEMS>& a) {     // (a chunk beyond the end: zeros, never used)
+        a.dlo = a.dhi = 0u;
+        if (c < n_chunks) {
+            cp_load_tok0<CP_ITEMS>(tok0, c * CP_CHUNK + (int64_t)tid * CP_ITEMS, P, a.f);
+            a.dlo = chunk_lo[c];
+            a.dhi = c == n_chunks - 1 ? (uint32_t)n_docs + 1u : chunk_lo[c + 1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < CP_ITEMS; ++k) a.f.w[k] = 0u;
+        }
+    };
     int b = 0;
-    if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0);
+    CpAhead<CP_ITEMS> aa;                                  // the NEXT chunk's tok0 words and document range
+    {
+        CpAhead<CP_ITEMS> a0;
+        ahead_of(blockIdx.x, a0);
+        ahead_of((int64_t)blockIdx.x + gridDim.x, aa);
+        if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0, a0);
+    }
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
         const int64_t nxt = ch + gridDim.x;
-        if (nxt < n_chunks) front(nxt, b ^ 1);            // (its two barriers also order this chunk's LDS writes before the reads below)
+        CpAhead<CP_ITEMS> an;                              // ... and those of the one after it: in flight while front(nxt) works
+        if (ab & 2u) ahead_of(nxt, aa);                    // (uniform; TKAMD_CP_AHEAD=0) just in time instead
+        else ahead_of(nxt + gridDim.x, an);
+        if (nxt < n_chunks) front(nxt, b ^ 1, aa);        // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
+        if (!(ab & 2u)) aa = an;
         const uint32_t tot = s_tot[b];
-        if (tid < 64) {                                    // wavefront 0 resolves the chunk's place in the token stream
-            const unsigned long long base = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total);
-            if (tid == 0) s_base = base;
-        }
-        __syncthreads();
+        // the chunk's place in the token stream (the whole workgroup looks back: four windows a round, results.hip)
+        unsigned long long base;
+        if (ab & 1u) {                                     // (uniform; TKAMD_CP_LB=wave) wavefront 0 alone, as before round 4
+            if (tid < 64) { const unsigned long long r = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total); if (tid == 0) s_lbw[0] = r; }
+            __syncthreads();
+            base = s_lbw[0];
+            __syncthreads();
+        } else base = lb_resolve_wg(state, ch, (unsigned long long)tot, patience, chunk_total, s_lbw, s_lbf);
         tick(2);
-        const unsigned long long base = s_base;
         if (ch == n_chunks - 1 && tid == 0) *n_tok = (int64_t)(base + tot);
         const int64_t pc = ch * CP_CHUNK;
         if (pt_tokoff) {
