@@ -283,21 +283,16 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
     // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); TKAMD_LB_PATIENCE: tests set it to a
     // handful so that the helping path runs on every wait
     static const uint32_t patience = [] { const char* e = getenv("TKAMD_LB_PATIENCE"); return e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE; }();
-    static const uint32_t ab = [] {
-        const char* l = getenv("TKAMD_CP_LB");
-        const char* a = getenv("TKAMD_CP_AHEAD");
-        return ((l && !strcmp(l, "wave")) ? 1u : 0u) | ((a && !strcmp(a, "0")) ? 2u : 0u);
-    }();
     if (ph && cp_items == 4)                                 // the diagnostic instantiation (TKAMD_PHASES)
         hipLaunchKernelGGL((k_compact<4, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, ab);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 2)
         hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, ab);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 4)
         hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, ab);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else
         hipLaunchKernelGGL(k_compact<8>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, ab);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
 }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
-                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience, uint32_t ab) {      // ab: A/B switches (launch.hip), bit 0 single-wavefront look-back, bit 1 nothing loaded ahead
+                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience) {
     constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
     unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto tick = [&](int k) {
@@ -132,8 +132,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
     __shared__ uint32_t s_stage[2][CP_STAGE];
     __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
     __shared__ uint32_t s_tot[2];
-    __shared__ unsigned long long s_lbw[4];
-    __shared__ uint32_t s_lbf[4];
+    __shared__ unsigned long long s_lbw;
     const int64_t P = *n_pretok;
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     const int tid = (int)threadIdx.x;
@@ -204,20 +203,15 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
         const int64_t nxt = ch + gridDim.x;
         CpAhead<CP_ITEMS> an;                              // ... and those of the one after it: in flight while front(nxt) works
-        if (ab & 2u) ahead_of(nxt, aa);                    // (uniform; TKAMD_CP_AHEAD=0) just in time instead
-        else ahead_of(nxt + gridDim.x, an);
+        ahead_of(nxt + gridDim.x, an);
         if (nxt < n_chunks) front(nxt, b ^ 1, aa);        // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
-        if (!(ab & 2u)) aa = an;
+        aa = an;
         const uint32_t tot = s_tot[b];
-        // the chunk's place in the token stream (the whole workgroup looks back: four windows a round, results.hip)
-        unsigned long long base;
-        if (ab & 1u) {                                     // (uniform; TKAMD_CP_LB=wave) wavefront 0 alone, as before round 4
-            if (tid < 64) { const unsigned long long r = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total); if (tid == 0) s_lbw[0] = r; }
-            __syncthreads();
-            base = s_lbw[0];
-            __syncthreads();
-        } else base = lb_resolve_wg(state, ch, (unsigned long long)tot, patience, chunk_total, s_lbw, s_lbf);
+        // the chunk's place in the token stream: wavefront 0 looks back (results.hip), the others wait at the barrier
+        if (tid < 64) { const unsigned long long r = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total); if (tid == 0) s_lbw = r; }
+        __syncthreads();
+        const unsigned long long base = s_lbw;
         tick(2);
         if (ch == n_chunks - 1 && tid == 0) *n_tok = (int64_t)(base + tot);
         const int64_t pc = ch * CP_CHUNK;

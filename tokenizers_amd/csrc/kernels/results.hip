@@ -137,54 +137,5 @@ __device__ __forceinline__ unsigned long long lb_resolve(unsigned long long* __r
     return run;
 }
 
-// The same by a whole 256-lane workgroup: FOUR windows of 64 predecessors a round instead of one.  Chunks go round robin over ~1,300
-// workgroups that run in step, so a chunk's nearest full prefix is typically hundreds of chunks back (the previous round's) and the
-// single-wavefront walk above is a dozen dependent device-scope loads -- a quarter of k_compact's time (profiles/r4b_ab_c2.txt) while
-// three of the workgroup's four wavefronts sat at the barrier.  Out of patience it hands over to lb_resolve (which helps itself).
-// s_w: 4 x 64-bit, s_f: 4 x 32-bit of LDS.  Contains barriers: every thread of the workgroup calls it; returns the sum in every thread.
-template <class Help>
-__device__ __forceinline__ unsigned long long lb_resolve_wg(unsigned long long* __restrict__ state, int64_t ch, unsigned long long total, uint32_t patience,
-                                                            Help&& help, unsigned long long* s_w, uint32_t* s_f) {
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    if (ch == 0) return 0ull;
-    unsigned long long run = 0ull;
-    int64_t i = ch - 1;
-    uint32_t polls = 0u;
-    while (true) {
-        const int64_t idx = i - (int64_t)(wave * 64 + lane);
-        const unsigned long long st = idx >= 0 ? lb_load(&state[idx]) : LB_PREFIX;
-        uint64_t empty = __ballot((st & LB_FLAGS) == 0ull);
-        const uint64_t pref = __ballot((st & LB_FLAGS) == LB_PREFIX);
-        const int first = pref ? __ffsll((unsigned long long)pref) - 1 : 63;
-        if (pref) empty &= (first >= 63) ? ~0ull : ((2ull << first) - 1ull);
-        unsigned long long v = (lane <= first) ? (st & LB_VALUE) : 0ull;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        if (lane == 0) { s_w[wave] = v; s_f[wave] = (empty ? 1u : 0u) | (pref ? 2u : 0u); }
-        __syncthreads();
-        unsigned long long add = 0ull;
-        bool retry = false, done = false;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            if (!retry && !done) {
-                const uint32_t f = s_f[w];
-                if (f & 1u) retry = true;                           // something in front of the nearest full prefix is not published yet
-                else { add += s_w[w]; done = (f & 2u) != 0u; }
-            }
-        }
-        __syncthreads();                                            // (s_w / s_f are rewritten by the next round)
-        if (retry) {
-            if (++polls > patience) {                               // (uniform) hand over: one wavefront, helping itself from its first poll
-                if (wave == 0) { const unsigned long long r = lb_resolve(state, ch, total, 0u, help); if (lane == 0) s_w[0] = r; }
-                __syncthreads();
-                return s_w[0];
-            }
-            continue;
-        }
-        run += add;
-        if (done) break;
-        i -= 256;
-    }
-    if (threadIdx.x == 0) lb_store(&state[ch], LB_PREFIX | (run + total));
-    return run;
-}
+// (Round 4 also tried the look-back by the whole 256-lane workgroup, four windows of 64 predecessors a round: two barriers a round
+// cost more than the shorter walk saved -- k_compact 0.152 ms against 0.143 ms on C2, profiles/r4g_ab_c2.txt.)

@@ -42,8 +42,10 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
     }
 }
 
-// SHORT: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again
-template <bool SHORT>
+// REGS = 16: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again;
+// REGS = 32: the 17..32-byte queue, four registers (a word of that queue took two dependent loads per trie step and a byte-by-byte
+// char count: 0.062 ms for 3,400 words on C3, profiles/r3_c3_kernel_stats.csv); REGS = 0: any length, from the text
+template <int REGS>
 __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t* __restrict__ text, const QView& v, uint4* __restrict__ rows,
                                                uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
                                                uint32_t block, uint32_t n_blocks, uint32_t* s_qpre) {
@@ -52,13 +54,15 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
         const uint32_t s = it.s, len = it.len;
-        uint64_t lo = 0, hi = 0;
+        constexpr bool SHORT = REGS != 0;
+        uint64_t lo = 0, hi = 0, lo2 = 0, hi2 = 0;
         uint32_t chars = 0;
         if (SHORT) {
-            load_key16(text, s, len, &lo, &hi);
+            load_key16(text, s, min(len, 16u), &lo, &hi);
+            if (REGS == 32 && len > 16u) load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
             // chars = bytes that are not 10xxxxxx continuation bytes (bit 7 set, bit 6 clear)
-            const uint64_t cl = lo & 0x8080808080808080ull & ~((lo << 1) & 0x8080808080808080ull), ch = hi & 0x8080808080808080ull & ~((hi << 1) & 0x8080808080808080ull);
-            chars = len - (uint32_t)(__popcll(cl) + __popcll(ch));
+            auto cont = [](uint64_t x) { return (uint32_t)__popcll(x & 0x8080808080808080ull & ~((x << 1) & 0x8080808080808080ull)); };
+            chars = len - (cont(lo) + cont(hi) + cont(lo2) + cont(hi2));
         } else {
             for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
         }
@@ -69,7 +73,8 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
             uint32_t node = pos ? 1u : 0u, w = pos, best_end = 0, best_id = 0;
             while (w < len) {
                 uint32_t child, id;
-                const uint32_t byte = SHORT ? (uint32_t)((w < 8u ? lo >> (8u * w) : hi >> (8u * (w - 8u))) & 0xFFu) : (uint32_t)text[s + w];
+                const uint64_t word8 = w < 8u ? lo : (w < 16u ? hi : (w < 24u ? lo2 : hi2));
+                const uint32_t byte = SHORT ? (uint32_t)((word8 >> (8u * (w & 7u))) & 0xFFu) : (uint32_t)text[s + w];
                 pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, byte, &child, &id);
                 if (child == RANK_NONE) break;
                 node = child;
@@ -102,7 +107,8 @@ template <bool SHORT>
 __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
                                                    uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
     __shared__ uint32_t s_qpre[NSQ + 1];
-    wordpiece_body<SHORT>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
+    if (SHORT) wordpiece_body<16>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
+    else wordpiece_body<0>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
 }
 // the three queues of words longer than 16 bytes in one launch (a third of the grid each): on natural text they hold a few thousand
 // words between them, and a launch costs more than the walk
@@ -111,5 +117,7 @@ __global__ __launch_bounds__(256) void k_wordpiece_long3(DevTables t, const uint
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t third = gridDim.x / 3u, which = min(blockIdx.x / third, 2u);
     const QView v = which == 0u ? v1 : (which == 1u ? v2 : v3);
-    wordpiece_body<false>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - which * third, which == 2u ? gridDim.x - 2u * third : third, s_qpre);
+    // (uniform per workgroup) the 17..32-byte words -- nearly all of them -- walk from registers
+    if (which == 0u) wordpiece_body<32>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, third, s_qpre);
+    else wordpiece_body<0>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - which * third, which == 2u ? gridDim.x - 2u * third : third, s_qpre);
 }
