@@ -52,8 +52,6 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     LookupArgs a{};
     static const uint32_t adapt = [] { const char* e = getenv("TKAMD_CLAIM_ADAPT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
     a.claim_adapt = adapt;
-    static const uint32_t defer = [] { const char* e = getenv("TKAMD_LU_DEFER"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
-    a.defer = defer;
     a.counters = counters;
     a.words = t.words;
     a.word_disp = t.word_disp;
@@ -268,7 +266,6 @@ void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z) {
 int compact_grid(int n_cu, int cp_items) {
     int per_cu = 0;
     const void* k = cp_items == 2 ? (const void*)k_compact<2> : cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
-    if (cp_items == 4 && getenv("TKAMD_CP_DEEP")) k = (const void*)k_compact<4, false, true>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     return per_cu * n_cu;
 }
@@ -286,12 +283,8 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
     // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); TKAMD_LB_PATIENCE: tests set it to a
     // handful so that the helping path runs on every wait
     static const uint32_t patience = [] { const char* e = getenv("TKAMD_LB_PATIENCE"); return e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE; }();
-    static const bool deep = getenv("TKAMD_CP_DEEP") != nullptr;
     if (ph && cp_items == 4)                                 // the diagnostic instantiation (TKAMD_PHASES)
         hipLaunchKernelGGL((k_compact<4, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
-    else if (cp_items == 4 && deep)
-        hipLaunchKernelGGL((k_compact<4, false, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
                            chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 2)
         hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,

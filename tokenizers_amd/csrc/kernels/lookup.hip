@@ -72,7 +72,6 @@ struct LookupArgs {
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
     uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
-    uint32_t defer;                  // the claims of a tile's candidates resolve behind the next tile's work (TKAMD_LU_DEFER=0: on the spot, in pass 3)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -164,84 +163,6 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             if (ws < (has_end ? end_words : total_words)) pf_scan = (has_end ? a.endmask : a.startmask)[ws];
         }
     };
-    // what pass 2 and pass 3 end a lane with: a pre-token still pending is a model kernel's work, queued by length class
-    // (<= 16 bytes, <= 32, <= 64, longer); its tok0 word names the row, any other lane's its result.  (wavefront-wide: ballots)
-    // gidx: the pre-token's rank in the batch, s_abs: its first byte.
-    auto finish_abs = [&](bool v, bool pend, uint32_t gidx, uint32_t s_abs, uint32_t len, uint32_t out) {
-        const uint32_t c = len <= 16u ? 0u : (len <= 32u ? 1u : (len <= 64u ? 2u : 3u));
-        const uint64_t b0 = __ballot(pend && c == 0u), b1 = __ballot(pend && c == 1u), b2 = __ballot(pend && c == 2u), b3 = __ballot(pend && c == 3u);
-        if (b0 | b1 | b2 | b3) {                                            // wavefront-uniform
-            uint32_t base = 0u;
-            if (lane < 4) {
-                const uint32_t take = (uint32_t)__popcll(lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3);
-                if (take) base = atomicAdd(&s_fill[lane], take);             // LDS: the sub-queue is this workgroup's alone
-            }
-            base = (uint32_t)__shfl((int)base, (int)c, 64);
-            if (pend) {
-                const uint32_t pos = base + (uint32_t)mbcnt64(c == 0u ? b0 : c == 1u ? b1 : c == 2u ? b2 : b3);
-                // (selects, not indexed loads: the argument arrays must stay in scalar registers)
-                QItem* const qp = c == 0u ? a.v[0].q : c == 1u ? a.v[1].q : c == 2u ? a.v[2].q : a.v[3].q;
-                const uint32_t qcap = c == 0u ? a.v[0].sq_cap : c == 1u ? a.v[1].sq_cap : c == 2u ? a.v[2].sq_cap : a.v[3].sq_cap;
-                const uint32_t rowb = c == 0u ? a.v[0].row_base : c == 1u ? a.v[1].row_base : c == 2u ? a.v[2].row_base : a.v[3].row_base;
-                if (pos < qcap) {
-                    qp[sq * qcap + pos] = QItem{s_abs, len};
-                    out = TOK_ROW | (rowb + sq * qcap + pos);
-                } else {
-                    atomicOr(a.err, ERR_QUEUE_FULL);                         // the host grows the queues and runs the batch again
-                }
-            }
-        }
-        if (v) a.tok0[gidx] = out;
-    };
-    // DEFERRED CLAIMS.  The claim of a candidate is a chain of dependent round trips -- the slot, a compare-and-swap where it is
-    // free, the claimant's bytes -- and pass 3 took 32 % of the kernel waiting for them, one step of 64 candidates per wavefront and
-    // tile (profiles/r4g_ab_c2.txt).  Nothing in the NEXT tile needs their outcome: a wavefront parks its step in registers (D: the key,
-    // the slot, where the verdict goes), issues the slot read and goes on; the chain advances one link behind each barrier of the next
-    // tile -- by then the previous link's answer has long arrived -- and the verdict (tok0 word, queue entry) is written a tile late.
-    // The table read is a device-scope load straight away: its latency is no longer waited for, and it can never be stale.
-    // (Candidates beyond 64 per wavefront -- more than 512 in a tile -- and the three-workgroup shape, which has no registers to
-    // spare, take the synchronous protocol below.)
-    constexpr bool DEFER = !HAS_END && HOT == 2048;
-    struct Defer {
-        uint32_t stage;                                              // 0 nothing parked | 1 slot read in flight | 2 CAS in flight | 3 claimant's bytes in flight
-        bool v;
-        uint32_t gidx, s_abs, len, slot;                             // (the key is not kept: seven registers live through the next tile's pass 2 ...
-        unsigned long long c;
-        Unaligned16 o, m;                                            //  ... these eight only through its pass 1: the claimant's first 16 bytes and this pre-token's, read again)
-    } D;
-    D.stage = 0u; D.v = false; D.gidx = D.s_abs = D.len = D.slot = 0u; D.c = 0ull;
-    D.o = D.m = Unaligned16{0u, 0u, 0u, 0u};
-    auto d_advance = [&]() {
-        if (!DEFER) return;
-        const uint32_t stage = (uint32_t)__builtin_amdgcn_readfirstlane((int)D.stage);      // (wavefront-uniform)
-        if (stage == 0u) return;
-        const bool theirs = D.v && D.c != 0ull && (uint32_t)(D.c >> 32) == D.len;          // (meaningful from stage 2 on)
-        if (stage == 1u) {                                           // the slot: free -> this pre-token claims it (the CAS returns what it found)
-            if (D.v && D.c == 0ull) D.c = atomicCAS(a.claims + D.slot, 0ull, ((unsigned long long)D.len << 32) | (unsigned long long)D.s_abs);
-            D.stage = 2u;
-        } else if (stage == 2u) {                                    // a claim of the same length: is it this word?  the claimant's bytes and ours
-            if (theirs) {
-                D.o = *(const Unaligned16*)(a.text + (uint32_t)D.c);        // (readable: the text carries TEXT_PAD bytes of slack)
-                D.m = *(const Unaligned16*)(a.text + D.s_abs);
-            }
-            D.stage = 3u;
-        } else {
-            const uint4 kml = s_kmask[min(D.len, 16u)];
-            bool shared = theirs && ((((D.o.a ^ D.m.a) & kml.x) | ((D.o.b ^ D.m.b) & kml.y) | ((D.o.c ^ D.m.c) & kml.z) | ((D.o.d ^ D.m.d) & kml.w)) == 0u);
-            if (__ballot(shared && D.len > 16u)) {                    // (wavefront-uniform) words of 17..32 bytes, 6 % of the candidates: bytes 16.. now -- the lines are the ones just read
-                if (shared && D.len > 16u) {
-                    const uint4 kmh = s_kmask[min(D.len, 32u) - 16u];
-                    const Unaligned16 o2 = *(const Unaligned16*)(a.text + (uint32_t)D.c + 16u), m2 = *(const Unaligned16*)(a.text + D.s_abs + 16u);
-                    shared = (((o2.a ^ m2.a) & kmh.x) | ((o2.b ^ m2.b) & kmh.y) | ((o2.c ^ m2.c) & kmh.z) | ((o2.d ^ m2.d) & kmh.w)) == 0u;
-                }
-            }
-            const uint64_t vb = __ballot(D.v), sb = __ballot(shared);
-            if (lane == 0) { atomicAdd(&s_seen, (uint32_t)__popcll(vb)); if (sb) atomicAdd(&s_shared, (uint32_t)__popcll(sb)); }
-            finish_abs(D.v, D.v && !shared, D.gidx, D.s_abs, D.len, shared ? (TOK_SLOT | D.slot) : 0u);
-            D.stage = 0u;
-            D.v = false;
-        }
-    };
     prefetch(blockIdx.x);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t w0 = tile * LU_TILE_WORDS;
@@ -292,7 +213,6 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         prefetch(tile + gridDim.x);                                   // the next tile's loads fly while this one is looked up
         __syncthreads();
         tick(LU_PH_STAGE);
-        d_advance();                                                 // (the previous tile's parked candidates: the slot read has arrived)
         const bool claims_now = s_claims_on != 0u;                   // (workgroup-uniform for the whole tile)
         const uint32_t n = s_n;                                      // pre-tokens starting in this tile
         const uint32_t pbase = s_pbase;                              // global rank of the first one
@@ -324,7 +244,6 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             }
             __syncthreads();
             tick(LU_PH_EXPAND);
-            d_advance();
             // start, end (tile relative) and the first 16 key bytes of the pre-token of local rank rel (< cnt)
             auto load_key = [&](uint32_t rel, uint32_t& s_rel, uint32_t& len, uint32_t& k0, uint32_t& k1, uint32_t& k2, uint32_t& k3, bool want_k3) {
                 s_rel = s_pos[rel];
@@ -373,9 +292,33 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             }
             __syncthreads();
             tick(LU_PH_PASS1);
-            d_advance();                                             // (normally the verdict of the previous tile's parked candidates)
+            // what pass 2 and pass 3 end a lane with: a pre-token still pending is a model kernel's work, queued by length class
+            // (<= 16 bytes, <= 32, <= 64, longer); its tok0 word names the row, any other lane's its result.  (wavefront-wide: ballots)
             auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out) {
-                finish_abs(v, pend, pbase + rb + rel, (uint32_t)t0 + s_rel, len, out);
+                const uint32_t c = len <= 16u ? 0u : (len <= 32u ? 1u : (len <= 64u ? 2u : 3u));
+                const uint64_t b0 = __ballot(pend && c == 0u), b1 = __ballot(pend && c == 1u), b2 = __ballot(pend && c == 2u), b3 = __ballot(pend && c == 3u);
+                if (b0 | b1 | b2 | b3) {                                            // wavefront-uniform
+                    uint32_t base = 0u;
+                    if (lane < 4) {
+                        const uint32_t take = (uint32_t)__popcll(lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3);
+                        if (take) base = atomicAdd(&s_fill[lane], take);             // LDS: the sub-queue is this workgroup's alone
+                    }
+                    base = (uint32_t)__shfl((int)base, (int)c, 64);
+                    if (pend) {
+                        const uint32_t pos = base + (uint32_t)mbcnt64(c == 0u ? b0 : c == 1u ? b1 : c == 2u ? b2 : b3);
+                        // (selects, not indexed loads: the argument arrays must stay in scalar registers)
+                        QItem* const qp = c == 0u ? a.v[0].q : c == 1u ? a.v[1].q : c == 2u ? a.v[2].q : a.v[3].q;
+                        const uint32_t qcap = c == 0u ? a.v[0].sq_cap : c == 1u ? a.v[1].sq_cap : c == 2u ? a.v[2].sq_cap : a.v[3].sq_cap;
+                        const uint32_t rowb = c == 0u ? a.v[0].row_base : c == 1u ? a.v[1].row_base : c == 2u ? a.v[2].row_base : a.v[3].row_base;
+                        if (pos < qcap) {
+                            qp[sq * qcap + pos] = QItem{(uint32_t)t0 + s_rel, len};
+                            out = TOK_ROW | (rowb + sq * qcap + pos);
+                        } else {
+                            atomicOr(a.err, ERR_QUEUE_FULL);                         // the host grows the queues and runs the batch again
+                        }
+                    }
+                }
+                if (v) a.tok0[pbase + rb + rel] = out;
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
@@ -501,31 +444,17 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 p2_done(x);
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
+            // (Round 4 parked a wavefront's step of candidates in registers and advanced its chain -- slot, compare-and-swap, the
+            // claimant's bytes -- one link behind each barrier of the NEXT tile: slower, 0.255 against 0.243 ms and 0.64 against 0.46 ms on
+            // out-of-distribution text, profiles/r4h_ab_c2*.txt.  A wait for one load is a wait for every memory operation issued
+            // before it -- s_waitcnt counts in order -- so each link also waited for the next tile's prefetch and the tok0 stores just
+            // issued; and the 17 extra live registers cost the other passes.)
             if (CAND_PASS && claims_now) {                                          // wavefront-uniform
                 __syncthreads();
                 tick(LU_PH_PASS2);
                 const uint32_t n_cand = s_ncand;
-                uint32_t c0 = (uint32_t)wave * 64u;
-                if (DEFER && a.defer) {
-                    while (__builtin_amdgcn_readfirstlane((int)D.stage)) d_advance();   // (a second round of the same tile: finish what is parked)
-                    if (c0 < n_cand) {                                              // wavefront-uniform: park this wavefront's first step
-                        const bool v = c0 + lane < n_cand;
-                        const uint32_t rel = s_cand[v ? c0 + lane : c0];
-                        uint32_t s_rel, len, k0, k1, k2, k3;
-                        load_key(rel, s_rel, len, k0, k1, k2, k3, true);
-                        uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u;
-                        uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
-                        uint32_t hc = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
-                        if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, hc, k4, k5, k6, k7, kmh);
-                        D.v = v; D.gidx = pbase + rb + rel; D.s_abs = (uint32_t)t0 + s_rel; D.len = len; D.slot = claim_slot(hc, a.claim_mask);
-                        D.c = 0ull;
-                        if (v) D.c = __hip_atomic_load(a.claims + D.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        D.stage = 1u;
-                        c0 += (uint32_t)LU_NT;
-                    }
-                    if (tid == 0 && n_cand > (uint32_t)LU_NT) atomicAdd(&s_seen, n_cand - (uint32_t)LU_NT);     // (the parked ones count with their verdict)
-                } else if (tid == 0) atomicAdd(&s_seen, n_cand);
-                for (; c0 < n_cand; c0 += (uint32_t)LU_NT) {
+                if (tid == 0) s_seen += n_cand;                                     // (thread 0 alone writes it)
+                for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_cand; c0 += (uint32_t)LU_NT) {
                     const bool v = c0 + lane < n_cand;
                     const uint32_t rel = s_cand[v ? c0 + lane : c0];
                     uint32_t s_rel, len, k0, k1, k2, k3;
@@ -545,7 +474,6 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             }
         }
     }
-    while (DEFER && __builtin_amdgcn_readfirstlane((int)D.stage)) d_advance();       // the last tile's parked candidates
     // the fill of this workgroup's sub-queues (the counters were zeroed by the host; a workgroup without tiles leaves them 0)
     __syncthreads();
     tick(LU_PH_PASS3);

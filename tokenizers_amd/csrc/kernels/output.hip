@@ -64,23 +64,15 @@ __device__ __forceinline__ void cp_load_tok0(const uint32_t* __restrict__ tok0, 
 }
 template <int CP_ITEMS> struct CpAhead { CpTok0<CP_ITEMS> f; uint32_t dlo, dhi; };     // what k_compact loads a chunk ahead
 template <int CP_ITEMS>
-__device__ __forceinline__ void cp_issue_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
+__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
     const uint32_t* const first = f.w;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k)                     // all row loads in flight together
         r.row[k] = (first[k] & TOK_ROW) ? ((first[k] & TOK_ONE) ? crows[first[k] & TOK_REF_MASK] : rows[first[k] & TOK_REF_MASK]) : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
-}
-template <int CP_ITEMS>
-__device__ __forceinline__ uint32_t cp_count_rows(CpRows<CP_ITEMS>& r) {
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) { r.cnt[k] = row_count(r.row[k]); v += r.cnt[k]; }
     return v;
-}
-template <int CP_ITEMS>
-__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
-    cp_issue_rows<CP_ITEMS>(f, rows, crows, r);
-    return cp_count_rows<CP_ITEMS>(r);
 }
 template <int CP_ITEMS>
 __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
@@ -121,9 +113,7 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 // 0 loads + scan + publish of front(), 1 its LDS scatter, 2 the look-back wait, 3 the copy-out, 7 the whole kernel)
 // (min. wavefronts per SIMD: 5 -- five workgroups per CU, <= 96 VGPRs -- for the shapes of 2 and 4 pre-tokens per lane, whose 28 KB of LDS
 // allow it; the helper of the look-back must not cost the main path its occupancy)
-// DEEP (TKAMD_CP_DEEP=1, an experiment): the ROWS too are loaded a chunk ahead (and tok0 two ahead) -- front() starts with everything in
-// registers (91 of them: still five workgroups per CU)
-template <int CP_ITEMS, bool PROF = false, bool DEEP = false>
+template <int CP_ITEMS, bool PROF = false>
 __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
@@ -155,22 +145,16 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
     // two dependent round trips each -- tok0, then the rows it names; chunk_lo, then the doc_pt entries it names.  The heads of both
     // are loaded a chunk AHEAD (`a`, behind the previous chunk's work), so front() starts with the second halves, and the doc_pt
     // values are only parked in LDS behind the scan: the chunk's total is published as soon as the ROWS are in.
-    // (rd / docpt_ahead: DEEP only -- the chunk's rows and this lane's doc_pt value, already loaded)
-    auto front = [&](int64_t ch, int b, const CpAhead<CP_ITEMS>& a, CpRows<CP_ITEMS>* rd, uint32_t docpt_ahead) {
+    // (The rows and the doc_pt value a chunk ahead as well, tok0 two ahead -- 91 VGPRs, still five workgroups per CU -- measured level:
+    // 0.1408 against 0.1414 ms, profiles/r4h_ab_c2.txt.  The wait is not these loads' latency alone.)
+    auto front = [&](int64_t ch, int b, const CpAhead<CP_ITEMS>& a) {
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
         const uint32_t dlo = a.dlo, dhi = a.dhi;
         CpRows<CP_ITEMS> r;
-        uint32_t v;
+        const uint32_t v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, r);
         const bool has_doc = dlo + (uint32_t)tid < dhi;
         uint32_t my_docpt = 0u;
-        if (DEEP) {
-            r = *rd;
-            v = cp_count_rows<CP_ITEMS>(r);
-            my_docpt = docpt_ahead;
-        } else {
-            v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, r);
-            if (has_doc) my_docpt = doc_pt[dlo + (uint32_t)tid];
-        }
+        if (has_doc) my_docpt = doc_pt[dlo + (uint32_t)tid];
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
         if (tid == 0) { lb_publish(state, ch, (unsigned long long)tot); s_tot[b] = tot; }
@@ -211,45 +195,19 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         }
     };
     int b = 0;
-    CpAhead<CP_ITEMS> aa;                                  // the NEXT chunk's tok0 words and document range (DEEP: the one after it)
-    CpAhead<CP_ITEMS> ad;                                  // DEEP: the next chunk's, whose rows ra and doc_pt value dpa are in flight
-    CpRows<CP_ITEMS> ra;
-    uint32_t dpa = 0u;
-    auto rows_of = [&](const CpAhead<CP_ITEMS>& a, CpRows<CP_ITEMS>& r, uint32_t& dp) {
-        cp_issue_rows<CP_ITEMS>(a.f, rows, crows, r);
-        dp = 0u;
-        if (a.dlo + (uint32_t)tid < a.dhi) dp = doc_pt[a.dlo + (uint32_t)tid];
-    };
+    CpAhead<CP_ITEMS> aa;                                  // the NEXT chunk's tok0 words and document range
     {
         CpAhead<CP_ITEMS> a0;
         ahead_of(blockIdx.x, a0);
         ahead_of((int64_t)blockIdx.x + gridDim.x, aa);
-        if (DEEP) {
-            CpRows<CP_ITEMS> r0;
-            uint32_t dp0;
-            rows_of(a0, r0, dp0);
-            ad = aa;
-            rows_of(ad, ra, dpa);
-            ahead_of((int64_t)blockIdx.x + 2 * (int64_t)gridDim.x, aa);
-            if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0, a0, &r0, dp0);
-        } else if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0, a0, nullptr, 0u);
+        if ((int64_t)blockIdx.x < n_chunks) front(blockIdx.x, 0, a0);
     }
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
         const int64_t nxt = ch + gridDim.x;
         CpAhead<CP_ITEMS> an;                              // ... and those of the one after it: in flight while front(nxt) works
-        if (DEEP) {
-            CpRows<CP_ITEMS> rn;
-            uint32_t dpn;
-            ahead_of(nxt + 2 * (int64_t)gridDim.x, an);
-            rows_of(aa, rn, dpn);                          // (aa: chunk nxt + grid, its tok0 words arrived during the last iteration)
-            if (nxt < n_chunks) front(nxt, b ^ 1, ad, &ra, dpa);
-            else __syncthreads();
-            ad = aa; ra = rn; dpa = dpn;
-        } else {
-            ahead_of(nxt + gridDim.x, an);
-            if (nxt < n_chunks) front(nxt, b ^ 1, aa, nullptr, 0u);        // (its two barriers also order this chunk's LDS writes before the reads below)
-            else __syncthreads();
-        }
+        ahead_of(nxt + gridDim.x, an);
+        if (nxt < n_chunks) front(nxt, b ^ 1, aa);        // (its two barriers also order this chunk's LDS writes before the reads below)
+        else __syncthreads();
         aa = an;
         const uint32_t tot = s_tot[b];
         // the chunk's place in the token stream: wavefront 0 looks back (results.hip), the others wait at the barrier
