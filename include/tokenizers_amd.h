@@ -102,9 +102,10 @@ typedef struct tkamd_info {
     int32_t padding;            /* 0 none, 1 pad on the right, 2 on the left (utils/padding.rs)                       */
     int32_t pad_id;
     int32_t pad_type_id;
-    int32_t word_disp_entries;  /* displacement entries of the whole-word perfect hash (> 16384: the kernels read them
+    int32_t word_disp_entries;  /* always 0 since round 4 (the whole-word table is a two-choice table without displacements);
+                                   the field keeps the struct's layout                                                */
+    int32_t merge_disp_entries; /* displacement entries of the merge table's perfect hash (> 16384: the kernels read them
                                    from global memory instead of their LDS copy)                                      */
-    int32_t merge_disp_entries; /* same for the merge table                                                           */
 } tkamd_info;
 
 /* Replaces Tokenizer::from_file / from_str (tokenizer/mod.rs:468-472, serialization.rs:104-171).

@@ -10,6 +10,8 @@ Every config: the wheel's golden vectors (ids, char offsets, word ids), the C or
 byte + char offsets and word ids on a slice), the wheel live when importable, and the full 1M-document batch bench.py
 times, compared document by document with the oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -68,11 +70,32 @@ def test_c4_llama3_128k_vs_oracle():
     tok, o = _tok(js), orc.Oracle(js)
     info = tok.info
     assert info["vocab_size"] == 128000 and info["ignore_merges"] == 1 and info["pre_tokenizer"] == 2
-    assert info["word_disp_entries"] > 16384 and info["merge_disp_entries"] > 16384      # the global-displacement branches run
+    assert info["merge_disp_entries"] == 16384     # 128 k merges in the 16,384 buckets the merge kernels keep in LDS (eight keys a bucket)
     docs = synth.gen_lines(120000, text_seed=83, n_types=250000) + synth.gen_lines(20000, text_seed=84, type_seed=3) + synth.stress_lines(seed=22, n=4000)
     docs += ["", " ", "1" * 500, "a" + "\n" * 300 + "b", "x" * 9000, "supercalifragilisticexpialidocious " * 3, "don't!\n\n  x"]
     _same_csr(tok.encode_batch_fast(docs, add_special_tokens=False), o.encode_batch(docs), docs)
     _meta_compare(tok, o, docs[:15000] + docs[-4100:])
+
+
+def test_c4_with_the_merge_displacements_in_global_memory():
+    """TKAMD_MERGE_BUCKETS=wide: the sizing of rounds 1-3 (four keys a bucket: 32,768 buckets at 128 k merges, more than the LDS
+    copy holds) -- the branch of the merge kernels that reads the displacements from global memory, which a vocabulary of more
+    than ~250 k merges still takes.  The selection is read at load: a subprocess."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import tokenizers_amd as ta\n"
+        "from oracle import synth, oracle as orc\n"
+        "js = synth.load_or_train_llama3()\n"
+        "tk = ta.Tokenizer.from_str(js, device=0)\n"
+        "assert tk.info['merge_disp_entries'] > 16384, tk.info\n"
+        "docs = synth.gen_lines(20000, text_seed=85, n_types=250000) + synth.gen_lines(5000, text_seed=86, type_seed=3) + synth.stress_lines(seed=23, n=2000)\n"
+        "got, exp = tk.encode_batch_fast(docs, add_special_tokens=False), orc.Oracle(js).encode_batch(docs)\n"
+        "assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all()\n"
+        "print('WIDE_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_MERGE_BUCKETS="wide"), capture_output=True, text=True, timeout=900)
+    assert "WIDE_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_c5_zipf_length_documents_vs_oracle():

@@ -252,7 +252,7 @@ struct tkamd_tokenizer {
     DevBuf t_char_id;            // BPE over characters: HostModel::char_id
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
-    DevBuf t_pp_prefix, t_pp_suffix, t_pp_prefix_ty, t_pp_suffix_ty, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_word_disp, t_dec_entry, t_dec_blob, t_trie;
+    DevBuf t_pp_prefix, t_pp_suffix, t_pp_prefix_ty, t_pp_suffix_ty, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_dec_entry, t_dec_blob, t_trie;
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
@@ -398,7 +398,6 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_merges, hm.merge_table);
     upload(t->t_merge_disp, hm.merge_disp);
     upload(t->t_words, hm.word_table, 64);
-    upload(t->t_word_disp, hm.word_disp);
     if (hm.decoder != DEC_UNSUPPORTED) {
         upload(t->t_dec_entry, hm.dec_entry, 64);
         upload(t->t_dec_blob, hm.dec_blob, 64);
@@ -442,10 +441,8 @@ void upload_tables(tkamd_tokenizer* t) {
     d.newid_base = hm.merge_newid_base;
     d.merge_bmask = hm.merge_bmask;
     d.words = t->t_words.as<WordSlot>();
-    d.word_disp = t->t_word_disp.as<uint16_t>();
     d.word_mask = hm.word_mask;
     d.word_seed = hm.word_seed;
-    d.word_bmask = hm.word_bmask;
     d.ignore_merges = hm.ignore_merges ? 1u : 0u;
     d.long_probe_max_len = 0xFFFFFFFFu;
     d.unk_id = hm.unk_id;
@@ -1939,7 +1936,7 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* t, tkamd_info* info) {
     info->padding = !hm.pad_on ? 0 : (hm.pad_left ? 2 : 1);
     info->pad_id = (int32_t)hm.pad_id;
     info->pad_type_id = (int32_t)hm.pad_type_id;
-    info->word_disp_entries = (int32_t)hm.word_disp.size();
+    info->word_disp_entries = 0;                            // (round 4: the whole-word table is two-choice, it has no displacements)
     info->merge_disp_entries = (int32_t)hm.merge_disp.size();
     return TKAMD_OK;
 }
@@ -2612,7 +2609,8 @@ int tkamd_probe_word(const tkamd_tokenizer* t, const uint8_t* bytes, int32_t len
         memcpy(&lo, buf, 8);
         memcpy(&hi, buf + 8, 8);
         const uint32_t h1 = word_hash1(lo, hi, (uint32_t)len, hm.word_seed);
-        const WordSlot& s = hm.word_table[ph_slot(word_hash2(h1), hm.word_disp[h1 & hm.word_bmask], hm.word_mask)];
+        const WordSlot& sa = hm.word_table[word_slot_a(h1, hm.word_mask)];
+        const WordSlot& s = (sa.len == (uint32_t)len && sa.lo == lo && sa.hi == hi) ? sa : hm.word_table[word_slot_b(h1, hm.word_mask)];
         if (s.len != (uint32_t)len || s.lo != lo || s.hi != hi) return 0;
         *id = s.id;
         *flags = s.flags;

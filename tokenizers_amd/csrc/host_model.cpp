@@ -214,10 +214,18 @@ void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
         if (e.new_id - e.rank != m.merge_newid_base) { m.merge_newid_affine = false; break; }
     uint32_t cap = 16;
     while (cap < merges.size() * 5 / 2) cap <<= 1;            // load factor <= 0.4
-    uint32_t nb = 16;
-    while (nb < merges.size() / 4) nb <<= 1;                  // 2-4 keys per bucket (50k merges -> 16384 buckets = 32 KB)
+    uint32_t nb_wide = 16;
+    while (nb_wide < merges.size() / 4) nb_wide <<= 1;        // 2-4 keys per bucket (50k merges -> 16384 buckets = 32 KB)
+    // The merge kernels keep up to DISP_LDS_MAX displacements in LDS; beyond that every probe of the merge chain reads its
+    // displacement from global memory first -- two dependent round trips instead of one (C4's 128 k merges: 32,768 buckets,
+    // the merge kernels 0.17 ms against C2's 0.10).  More keys per bucket (8 at 128 k) only cost the builder trials: at load
+    // factor <= 0.4 a bucket of k keys fits a given displacement with probability >= 0.6^k, and 16 bits of displacement are 65,536 tries.
+    // (TKAMD_MERGE_BUCKETS=wide: the old sizing -- the tests' way to the global-displacement branch.)
+    const char* wide_env = getenv("TKAMD_MERGE_BUCKETS");
+    const bool want_wide = wide_env && !strcmp(wide_env, "wide");
     std::mt19937 rng(777);
     for (int attempt = 0; attempt < 32; ++attempt) {
+        const uint32_t nb = (want_wide || attempt >= 8) ? nb_wide : std::min(nb_wide, (uint32_t)DISP_LDS_MAX);
         const uint32_t seed = (uint32_t)rng();
         std::vector<uint32_t> h1(merges.size()), h2(merges.size()), where;
         for (size_t i = 0; i < merges.size(); ++i) { h1[i] = merge_hash1(merges[i].a, merges[i].b, seed); h2[i] = merge_hash2(merges[i].a, merges[i].b, seed); }
@@ -235,24 +243,36 @@ void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
 }
 
 void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {
+    // two-choice (cuckoo) placement: a key goes to its slot a, else b, else it evicts the tenant of a, who moves to ITS other slot,
+    // and so on; a walk that does not end within the bound means an unlucky seed (at load factor <= 0.4 that is rare)
     uint32_t cap = 16;
     while (cap < words.size() * 5 / 2) cap <<= 1;
-    uint32_t nb = 16;
-    while (nb < words.size() / 4) nb <<= 1;
     std::mt19937 rng(54321);
     for (int attempt = 0; attempt < 32; ++attempt) {
         const uint32_t seed = (uint32_t)rng();
-        std::vector<uint32_t> h1(words.size()), h2(words.size()), where;
-        for (size_t i = 0; i < words.size(); ++i) { h1[i] = word_hash1(words[i].lo, words[i].hi, words[i].len, seed); h2[i] = word_hash2(h1[i]); }
-        std::vector<uint16_t> disp;
-        if (chd_place(h1, h2, cap - 1, nb - 1, &disp, &where)) {
+        const uint32_t mask = cap - 1;
+        std::vector<uint32_t> h1(words.size());
+        for (size_t i = 0; i < words.size(); ++i) h1[i] = word_hash1(words[i].lo, words[i].hi, words[i].len, seed);
+        std::vector<uint32_t> tenant(cap, 0xFFFFFFFFu);           // index into words
+        bool ok = true;
+        for (size_t i = 0; i < words.size() && ok; ++i) {
+            uint32_t cur = (uint32_t)i, pos = word_slot_a(h1[cur], mask);
+            if (tenant[pos] != 0xFFFFFFFFu && tenant[word_slot_b(h1[cur], mask)] == 0xFFFFFFFFu) pos = word_slot_b(h1[cur], mask);
+            for (int kicks = 0;; ++kicks) {
+                if (tenant[pos] == 0xFFFFFFFFu) { tenant[pos] = cur; break; }
+                if (kicks == 512) { ok = false; break; }
+                std::swap(cur, tenant[pos]);                      // cur takes the slot; its tenant moves to ITS other slot
+                pos = pos == word_slot_a(h1[cur], mask) ? word_slot_b(h1[cur], mask) : word_slot_a(h1[cur], mask);
+            }
+        }
+        if (ok) {
             m.word_table.assign(cap, WordSlot{0, 0, 0, 0, 0, 0});
-            for (size_t i = 0; i < words.size(); ++i) m.word_table[where[i]] = words[i];
-            m.word_disp.swap(disp);
-            m.word_mask = cap - 1; m.word_bmask = nb - 1; m.word_seed = seed;
+            for (uint32_t sidx = 0; sidx < cap; ++sidx)
+                if (tenant[sidx] != 0xFFFFFFFFu) m.word_table[sidx] = words[tenant[sidx]];
+            m.word_mask = mask; m.word_seed = seed;
             return;
         }
-        if (attempt % 8 == 7) cap <<= 1;
+        if (attempt % 8 == 7) cap <<= 1;                          // a new seed almost always does it; grow only as a last resort
     }
     throw Invalid("could not build the whole-word hash table");
 }

@@ -129,9 +129,8 @@ struct HostModel {
     uint32_t merge_mask = 0, merge_seed = 0, merge_bmask = 0;
     bool merge_newid_affine = false;    // new_id == rank + merge_newid_base for every merge
     uint32_t merge_newid_base = 0;
-    std::vector<WordSlot> word_table;   // perfect hash (hash-and-displace), size = word_mask+1
-    std::vector<uint16_t> word_disp;    // size = word_bmask+1
-    uint32_t word_mask = 0, word_seed = 0, word_bmask = 0;
+    std::vector<WordSlot> word_table;   // two-choice table (tables.hpp word_slot_a / word_slot_b), size = word_mask+1
+    uint32_t word_mask = 0, word_seed = 0;
     uint32_t n_words = 0;               // keys stored in word_table (<= 16 bytes)
     // vocab entries longer than 16 raw bytes, needed for ignore_merges / WordLevel whole-word probes:
     // sorted blob for a device-side hash (long_table: open addressing over (hash -> entry index))

@@ -25,9 +25,8 @@ struct DevTables {
     const unsigned long long* pub_claims;
     void* pub_rows;
     uint32_t pub_mask;
-    const WordSlot* words;            // perfect-hash table (one slot per key)
-    const uint16_t* word_disp;
-    uint32_t word_mask, word_seed, word_bmask;
+    const WordSlot* words;            // two-choice table (tables.hpp): a key sits in word_slot_a or word_slot_b of its hash
+    uint32_t word_mask, word_seed;
     uint32_t ignore_merges;
     uint32_t long_probe_max_len;      // whole-word probes of keys > 16 bytes only up to this length (WordPiece: max_input_chars)
     uint32_t unk_id, has_unk;

@@ -47,18 +47,6 @@ __device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ t
 // (t.pub_claims: set by the host when the model kernels are to publish -- DevTables is what every one of them is handed)
 #define TKAMD_PUBLISH_ROW(t_, text_, s_, len_, row_) do { if ((t_).pub_claims) claim_publish_item((text_), (t_).word_seed, (s_), (len_), (row_), (t_).pub_claims, (t_).pub_mask, (uint4*)(t_).pub_rows); } while (0)
 
-__device__ __forceinline__ bool word_probe_d(const DevTables& t, const uint16_t* disp, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
-    uint32_t h1 = word_hash1(lo, hi, len, t.word_seed);
-    const uint4* q = (const uint4*)&t.words[ph_slot(word_hash2(h1), disp[h1 & t.word_bmask], t.word_mask)];
-    uint4 a0 = q[0], a1 = q[1];
-    *id = a1.y;
-    *flags = a1.z;
-    return a1.x == len && a0.x == (uint32_t)lo && a0.y == (uint32_t)(lo >> 32) && a0.z == (uint32_t)hi && a0.w == (uint32_t)(hi >> 32);
-}
-__device__ __forceinline__ bool word_probe(const DevTables& t, uint64_t lo, uint64_t hi, uint32_t len, uint32_t* id, uint32_t* flags) {
-    return word_probe_d(t, t.word_disp, lo, hi, len, id, flags);
-}
-
 // whole-word probe of a key longer than 16 bytes: hash and compare four bytes at a time (dword loads at any alignment; the text
 // carries TEXT_PAD readable bytes past its end, the vocabulary blob 16)
 __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __restrict__ w, uint32_t len, uint32_t* id) {
@@ -81,7 +69,6 @@ __device__ __forceinline__ bool long_probe(const DevTables& t, const uint8_t* __
     }
 }
 
-constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries cached in LDS (32 KB)
 
 // =================================================================================================
 // K_bpe_merge<G>: BPE merge resolution, G lanes per pre-token (G=16: one DPP row, 4 pre-tokens per

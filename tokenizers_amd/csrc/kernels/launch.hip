@@ -52,12 +52,12 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     LookupArgs a{};
     static const uint32_t adapt = [] { const char* e = getenv("TKAMD_CLAIM_ADAPT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
     a.claim_adapt = adapt;
+    static const uint32_t direct = [] { const char* e = getenv("TKAMD_CLAIM_CHAIN"); return (e && !strcmp(e, "cas")) ? 1u : 0u; }();
+    a.claim_direct = direct;
     a.counters = counters;
     a.words = t.words;
-    a.word_disp = t.word_disp;
     a.word_mask = t.word_mask;
     a.word_seed = t.word_seed;
-    a.word_bmask = t.word_bmask;
     a.any_hit_final = t.ignore_merges;
     a.unk_id = t.unk_id;
     a.has_unk = t.has_unk;

@@ -61,9 +61,8 @@ struct LookupArgs {
     int* err;
     const unsigned long long* matchmask;   // added-token matches: one pre-token, id patched in later
     const uint4* hot;                // [HOT] {k0, k1, k2, id | len << 24}, len 0 = empty; then [HOT / 4] 16-bit displacements (tables.hpp)
-    const WordSlot* words;           // perfect-hash table behind the hot table
-    const uint16_t* word_disp;
-    uint32_t word_mask, word_seed, word_bmask;
+    const WordSlot* words;           // two-choice table behind the hot table
+    uint32_t word_mask, word_seed;
     uint32_t any_hit_final;          // ignore_merges / WordLevel / WordPiece: every hit is final (else only WORD_DIRECT ones)
     uint32_t no_hits;                // WordPiece with max_input_chars_per_word < 16: every word takes the trie walk
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
@@ -72,6 +71,7 @@ struct LookupArgs {
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
     uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
+    uint32_t claim_direct;           // TKAMD_CLAIM_CHAIN=cas (claim_word)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -345,9 +345,18 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 // crossing the fabric each time.  A 0 may be stale (the L2 of an XCD keeps what it read whatever another XCD's CAS did since):
                 // the device-scope read confirms it -- and refreshes the line for the next plain read (tools/microbench/claims_probe.hip).
                 unsigned long long c = a.claims[slot];
-                if (c == 0ull) c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
-                if (c == 0ull || (uint32_t)(c >> 32) != len) return false;
+                unsigned long long fresh = 1ull;
+                if (a.claim_direct) {                                               // (uniform; TKAMD_CLAIM_CHAIN=cas, an experiment) a 0 goes straight to the compare-and-swap, which returns what it found:
+                    // one round trip less for a step with a first occurrence in it; where the 0 was stale the line is read afresh NEXT to the claimant's bytes
+                    if (c == 0ull) {
+                        c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
+                        if (c != 0ull) fresh = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else {
+                    if (c == 0ull) c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
+                }
+                if (c == 0ull || (uint32_t)(c >> 32) != len || fresh == 0ull) return false;     // (fresh is never 0: a claimed slot stays claimed -- the test only keeps the load)
                 const uint4 kml = s_kmask[min(len, 16u)];
                 const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c);  // (readable: the text carries TEXT_PAD bytes of slack)
                 Unaligned16 o2{0u, 0u, 0u, 0u};
@@ -356,30 +365,25 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
             };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
-            // A step is three stages with a memory round trip between them: key + hash + the bucket's displacement, the slot, the verdict.
-            // (Two steps run stage by stage side by side -- both displacement loads in flight together, then both slot loads -- measured
-            // SLOWER, 0.2475 against 0.2337 ms, as batching the probes had in round 2: profiles/r4d_ab_c2.txt.)
-            struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1, dsp; uint4 a0, a1; };
+            // A step is the key + hash, ONE memory round trip -- the two slots of the two-choice table the word may live in, 64 bytes a
+            // lane -- and the verdict.  (Until round 4 the table was hash-and-displace: the bucket's displacement, then the slot, two
+            // dependent round trips.  Two such steps side by side, stage by stage, had measured SLOWER, 0.2475 against 0.2337 ms, as
+            // batching the probes had in round 2: profiles/r4d_ab_c2.txt.)
+            struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1; uint4 a0, a1, b0, b1; };
             const uint32_t n_miss = s_nmiss;
             auto p2_key = [&](uint32_t m0, P2& x) {
                 x.v = m0 + lane < n_miss;
                 x.rel = s_miss[x.v ? m0 + lane : m0];
                 load_key(x.rel, x.s_rel, x.len, x.k0, x.k1, x.k2, x.k3, true);
                 x.h1 = 0u;
-                x.dsp = 0u;
                 x.probe = x.v && hits_on && x.len <= (uint32_t)WORD_MAX_KEY;
-                if (x.probe) {
+                x.a0 = x.a1 = x.b0 = x.b1 = make_uint4(0u, 0u, 0u, 0u);
+                if (x.probe) {                                                      // both slots the word may live in, in ONE round trip
                     x.h1 = word_hash1_from_hot(hot_hash(x.k0, x.k1, x.k2, x.len, a.word_seed), x.k3);
-                    x.dsp = (uint32_t)a.word_disp[x.h1 & a.word_bmask];
-                }
-            };
-            auto p2_slot = [&](P2& x) {
-                x.a0 = x.a1 = make_uint4(0u, 0u, 0u, 0u);
-                if (x.probe) {
-                    const uint4* q = (const uint4*)&a.words[ph_slot(word_hash2(x.h1), x.dsp, a.word_mask)];
-                    x.a0 = q[0];
-                    x.a1 = q[1];
-                    asm volatile("" : "+v"(x.a0.x), "+v"(x.a1.x), "+v"(x.a1.y), "+v"(x.a1.z));      // the whole slot in ONE round trip (keeps the id load out of the hit branch)
+                    const uint4* qa = (const uint4*)&a.words[word_slot_a(x.h1, a.word_mask)];
+                    const uint4* qb = (const uint4*)&a.words[word_slot_b(x.h1, a.word_mask)];
+                    x.a0 = qa[0]; x.a1 = qa[1]; x.b0 = qb[0]; x.b1 = qb[1];
+                    asm volatile("" : "+v"(x.a0.x), "+v"(x.a1.x), "+v"(x.b0.x), "+v"(x.b1.x));      // (all four loads issued before anything is compared)
                 }
             };
             auto p2_done = [&](P2& x) {
@@ -388,9 +392,10 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 uint32_t out = 0u;
                 bool pend = v;
                 if (x.probe) {
-                    const uint4 a0 = x.a0, a1 = x.a1;
-                    const uint32_t diff = (a0.x ^ k0) | (a0.y ^ k1) | (a0.z ^ k2) | (a0.w ^ k3) | (a1.x ^ len);
-                    if (diff == 0u && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
+                    const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (x.a0.w ^ k3) | (x.a1.x ^ len);
+                    const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (x.b0.w ^ k3) | (x.b1.x ^ len);
+                    const uint4 a1 = da == 0u ? x.a1 : x.b1;                         // (len, id, flags, -) of the slot that holds the word, if one does
+                    if ((da == 0u || db == 0u) && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
                     if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
                         // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
                         // measured 20 % slower (the extra 32-byte reads cost more than the round trip they save)
@@ -440,7 +445,6 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
                 P2 x;
                 p2_key(m0, x);
-                p2_slot(x);
                 p2_done(x);
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----

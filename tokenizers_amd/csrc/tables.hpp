@@ -71,12 +71,16 @@ TK_HD uint32_t merge_hash2(uint32_t a, uint32_t b, uint32_t seed) {
 // the key then lives in exactly ONE slot, (hash2 + d * PH_MULT) & mask.  A lookup -- hit or miss -- is one
 // 16-byte load; the displacement array is small enough (<= 32 KB for 50k merges) to sit in LDS.
 constexpr uint32_t PH_MULT = 0x9E3779u;
+constexpr int DISP_LDS_MAX = 16384;              // merge displacement entries the merge kernels cache in LDS (32 KB); the builder stays within it if it can
 TK_HD uint32_t ph_slot(uint32_t h2, uint32_t d, uint32_t mask) { return (h2 + mul24(d, PH_MULT)) & mask; }
 
 // ---- whole-word table: raw pre-token bytes (<= 16) -> token id ------------------------------
 // Serves BPE `ignore_merges` (bpe/model.rs:559-567), WordLevel (wordlevel/mod.rs:162-178) and the
-// merge-stable shortcut: key = bytes zero-padded to 16 + length.  Same hash-and-displace
-// layout as the merge table: one 32-byte slot per key, displacement = word_disp[hash1 & word_bmask].
+// merge-stable shortcut: key = bytes zero-padded to 16 + length, 32-byte slots.
+// Static TWO-CHOICE table (round 4; it was hash-and-displace like the merge table): a key lives in slot word_slot_a or word_slot_b of
+// its hash, the lookup kernel loads BOTH at once -- one round trip, hit or miss, where the displacement of the bucket and then
+// the slot were two dependent ones (pass 2 of k_lookup is a third of the path's longest kernel and waits for exactly that
+// chain).  Twice the bytes per probe, from a table that sits in the L2; built once at load (cuckoo insertion, load factor <= 0.4).
 struct WordSlot {
     uint64_t lo, hi;
     uint32_t len;    // 0 = empty slot
@@ -93,6 +97,11 @@ TK_HD uint32_t hot_hash(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uin
 TK_HD uint32_t word_hash1_from_hot(uint32_t hot, uint32_t k3) { return mix32(hot ^ (k3 * 0x165667B1u)); }
 TK_HD uint32_t word_hash1(uint64_t lo, uint64_t hi, uint32_t len, uint32_t seed);
 TK_HD uint32_t word_hash2(uint32_t h1) { return (h1 * 0x9E3779B1u) ^ (h1 >> 15); }
+TK_HD uint32_t word_slot_a(uint32_t h1, uint32_t mask) { return h1 & mask; }
+TK_HD uint32_t word_slot_b(uint32_t h1, uint32_t mask) {       // (never slot a: two real choices for every key)
+    const uint32_t b = (word_hash2(h1) >> 9) & mask;
+    return b == (h1 & mask) ? (b ^ 1u) : b;
+}
 
 // ---- hot-word table: the lowest-id settled words of <= 12 bytes, copied into LDS by the lookup kernel ----
 // slot = {k0, k1, k2, id | len << 24} (key bytes zero padded; len 0 = empty slot).  Hash-and-displace like the tables in HBM, so the
