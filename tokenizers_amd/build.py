@@ -40,7 +40,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wall", "-Wno-unused-function", "-DTKAMD_BUILD"]
+           "-Wall", "-Wno-unused-function", "-DTKAMD_BUILD", "-Wl,-z,defs"]     # (-z defs: an undefined symbol fails the build, not the first dlopen)
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB + ".tmp"]
     if verbose:

@@ -249,6 +249,7 @@ struct tkamd_tokenizer {
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
+    DevBuf t_word12;             // the words of <= 12 bytes in 16-byte slots (tables.hpp WORD12_*)
     DevBuf t_char_id;            // BPE over characters: HostModel::char_id
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
@@ -531,6 +532,34 @@ void verify_direct_words(tkamd_tokenizer* t) {
     t->n_direct = nd;
     upload(t->t_words, hm.word_table, 64);
     t->dt.words = t->t_words.as<WordSlot>();
+}
+
+// The words of <= 12 bytes in 16-byte slots (tables.hpp): what pass 2 of the lookup probes for all but the longest keys.  Built from the
+// 32-byte table once its WORD_DIRECT flags are final; same seed, same two slot functions, its own size.
+void build_word12_table(tkamd_tokenizer* t) {
+    HostModel& hm = t->hm;
+    std::vector<const WordSlot*> ws;
+    for (const WordSlot& w : hm.word_table)
+        if (w.len && w.len <= (uint32_t)HOT_MAX_KEY) ws.push_back(&w);
+    uint32_t cap = 16;
+    while (cap < ws.size() * 5 / 2) cap <<= 1;
+    std::vector<uint32_t> h1(ws.size()), tenant;
+    for (size_t i = 0; i < ws.size(); ++i) h1[i] = word_hash1(ws[i]->lo, ws[i]->hi, ws[i]->len, hm.word_seed);
+    // (the seed is the 32-byte table's: the kernel hashes a key once.  A walk that fails under it gets a larger table, not a new seed.)
+    while (!cuckoo_place(h1, cap - 1, &tenant)) {
+        if (cap >= (1u << 26)) throw Invalid("could not build the short-word hash table");
+        cap <<= 1;
+    }
+    std::vector<HotSlot> tab(cap, HotSlot{0u, 0u, 0u, 0u});
+    for (uint32_t sidx = 0; sidx < cap; ++sidx) {
+        if (tenant[sidx] == 0xFFFFFFFFu) continue;
+        const WordSlot* w = ws[tenant[sidx]];
+        if (w->id > WORD12_ID_MASK) throw Invalid("token id beyond 24 bits");           // (checked at load already: ids < 2^24)
+        tab[sidx] = HotSlot{(uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->id | (w->len << WORD12_LEN_SHIFT) | ((w->flags & WORD_DIRECT) ? WORD12_DIRECT : 0u)};
+    }
+    upload(t->t_word12, tab, 64);
+    t->dt.word12 = t->t_word12.p;
+    t->dt.word12_mask = cap - 1;
 }
 
 // Hot-word table of the lookup kernel: the settled words of <= 12 bytes with the lowest ids, direct mapped (tables.hpp).
@@ -1802,6 +1831,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
         if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 1024 ? 1024 : 2048;
+        build_word12_table(t.get());
         build_hot_table(t.get());
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);

@@ -12,6 +12,25 @@
 
 namespace tkamd {
 
+// Two-choice (cuckoo) placement of keys with hashes h1 into a table of mask + 1 slots (word_slot_a / word_slot_b, tables.hpp): a key
+// goes to its slot a, else b, else it evicts the tenant of a, who moves to ITS other slot, and so on; a walk that does not end within
+// the bound means an unlucky seed (at load factor <= 0.4 that is rare).  tenant[slot] = index of the key, or 0xFFFFFFFF.
+bool cuckoo_place(const std::vector<uint32_t>& h1, uint32_t mask, std::vector<uint32_t>* tenant) {
+    tenant->assign((size_t)mask + 1, 0xFFFFFFFFu);
+    std::vector<uint32_t>& tn = *tenant;
+    for (size_t i = 0; i < h1.size(); ++i) {
+        uint32_t cur = (uint32_t)i, pos = word_slot_a(h1[cur], mask);
+        if (tn[pos] != 0xFFFFFFFFu && tn[word_slot_b(h1[cur], mask)] == 0xFFFFFFFFu) pos = word_slot_b(h1[cur], mask);
+        for (int kicks = 0;; ++kicks) {
+            if (tn[pos] == 0xFFFFFFFFu) { tn[pos] = cur; break; }
+            if (kicks == 512) return false;
+            std::swap(cur, tn[pos]);                              // cur takes the slot; its tenant moves to ITS other slot
+            pos = pos == word_slot_a(h1[cur], mask) ? word_slot_b(h1[cur], mask) : word_slot_a(h1[cur], mask);
+        }
+    }
+    return true;
+}
+
 namespace {
 
 struct UcRun {
@@ -243,33 +262,18 @@ void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {
 }
 
 void build_word_table(HostModel& m, const std::vector<WordSlot>& words) {
-    // two-choice (cuckoo) placement: a key goes to its slot a, else b, else it evicts the tenant of a, who moves to ITS other slot,
-    // and so on; a walk that does not end within the bound means an unlucky seed (at load factor <= 0.4 that is rare)
     uint32_t cap = 16;
     while (cap < words.size() * 5 / 2) cap <<= 1;
     std::mt19937 rng(54321);
     for (int attempt = 0; attempt < 32; ++attempt) {
         const uint32_t seed = (uint32_t)rng();
-        const uint32_t mask = cap - 1;
-        std::vector<uint32_t> h1(words.size());
+        std::vector<uint32_t> h1(words.size()), tenant;
         for (size_t i = 0; i < words.size(); ++i) h1[i] = word_hash1(words[i].lo, words[i].hi, words[i].len, seed);
-        std::vector<uint32_t> tenant(cap, 0xFFFFFFFFu);           // index into words
-        bool ok = true;
-        for (size_t i = 0; i < words.size() && ok; ++i) {
-            uint32_t cur = (uint32_t)i, pos = word_slot_a(h1[cur], mask);
-            if (tenant[pos] != 0xFFFFFFFFu && tenant[word_slot_b(h1[cur], mask)] == 0xFFFFFFFFu) pos = word_slot_b(h1[cur], mask);
-            for (int kicks = 0;; ++kicks) {
-                if (tenant[pos] == 0xFFFFFFFFu) { tenant[pos] = cur; break; }
-                if (kicks == 512) { ok = false; break; }
-                std::swap(cur, tenant[pos]);                      // cur takes the slot; its tenant moves to ITS other slot
-                pos = pos == word_slot_a(h1[cur], mask) ? word_slot_b(h1[cur], mask) : word_slot_a(h1[cur], mask);
-            }
-        }
-        if (ok) {
+        if (cuckoo_place(h1, cap - 1, &tenant)) {
             m.word_table.assign(cap, WordSlot{0, 0, 0, 0, 0, 0});
             for (uint32_t sidx = 0; sidx < cap; ++sidx)
                 if (tenant[sidx] != 0xFFFFFFFFu) m.word_table[sidx] = words[tenant[sidx]];
-            m.word_mask = mask; m.word_seed = seed;
+            m.word_mask = cap - 1; m.word_seed = seed;
             return;
         }
         if (attempt % 8 == 7) cap <<= 1;                          // a new seed almost always does it; grow only as a last resort

@@ -169,5 +169,7 @@ struct HostModel {
 };
 
 uint32_t fnv1a(const uint8_t* p, size_t n);
+// two-choice placement of keys with hashes h1 (tables.hpp word_slot_a / word_slot_b): tenant[slot] = key index or 0xFFFFFFFF; false: unlucky seed
+bool cuckoo_place(const std::vector<uint32_t>& h1, uint32_t mask, std::vector<uint32_t>* tenant);
 
 }  // namespace tkamd

@@ -27,6 +27,8 @@ struct DevTables {
     uint32_t pub_mask;
     const WordSlot* words;            // two-choice table (tables.hpp): a key sits in word_slot_a or word_slot_b of its hash
     uint32_t word_mask, word_seed;
+    const void* word12;               // the words of <= 12 bytes in 16-byte slots (tables.hpp), same seed and slot functions
+    uint32_t word12_mask;
     uint32_t ignore_merges;
     uint32_t long_probe_max_len;      // whole-word probes of keys > 16 bytes only up to this length (WordPiece: max_input_chars)
     uint32_t unk_id, has_unk;

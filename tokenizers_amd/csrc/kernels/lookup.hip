@@ -63,6 +63,8 @@ struct LookupArgs {
     const uint4* hot;                // [HOT] {k0, k1, k2, id | len << 24}, len 0 = empty; then [HOT / 4] 16-bit displacements (tables.hpp)
     const WordSlot* words;           // two-choice table behind the hot table
     uint32_t word_mask, word_seed;
+    const uint4* word12;             // the words of <= 12 bytes in 16-byte slots {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, two-choice too
+    uint32_t word12_mask;
     uint32_t any_hit_final;          // ignore_merges / WordLevel / WordPiece: every hit is final (else only WORD_DIRECT ones)
     uint32_t no_hits;                // WordPiece with max_input_chars_per_word < 16: every word takes the trie walk
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
@@ -376,14 +378,19 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 x.rel = s_miss[x.v ? m0 + lane : m0];
                 load_key(x.rel, x.s_rel, x.len, x.k0, x.k1, x.k2, x.k3, true);
                 x.h1 = 0u;
-                x.probe = x.v && hits_on && x.len <= (uint32_t)WORD_MAX_KEY;
+                x.probe = x.v && hits_on && x.len != 0u && x.len <= (uint32_t)WORD_MAX_KEY;
                 x.a0 = x.a1 = x.b0 = x.b1 = make_uint4(0u, 0u, 0u, 0u);
                 if (x.probe) {                                                      // both slots the word may live in, in ONE round trip
                     x.h1 = word_hash1_from_hot(hot_hash(x.k0, x.k1, x.k2, x.len, a.word_seed), x.k3);
-                    const uint4* qa = (const uint4*)&a.words[word_slot_a(x.h1, a.word_mask)];
-                    const uint4* qb = (const uint4*)&a.words[word_slot_b(x.h1, a.word_mask)];
-                    x.a0 = qa[0]; x.a1 = qa[1]; x.b0 = qb[0]; x.b1 = qb[1];
-                    asm volatile("" : "+v"(x.a0.x), "+v"(x.a1.x), "+v"(x.b0.x), "+v"(x.b1.x));      // (all four loads issued before anything is compared)
+                    if (x.len <= (uint32_t)HOT_MAX_KEY) {                            // ... of the 16-byte table: two requests (nearly every lane)
+                        x.a0 = a.word12[word_slot_a(x.h1, a.word12_mask)];
+                        x.b0 = a.word12[word_slot_b(x.h1, a.word12_mask)];
+                    } else {                                                        // a key of 13..16 bytes: the 32-byte slots, four requests
+                        const uint4* qa = (const uint4*)&a.words[word_slot_a(x.h1, a.word_mask)];
+                        const uint4* qb = (const uint4*)&a.words[word_slot_b(x.h1, a.word_mask)];
+                        x.a0 = qa[0]; x.a1 = qa[1]; x.b0 = qb[0]; x.b1 = qb[1];
+                    }
+                    asm volatile("" : "+v"(x.a0.x), "+v"(x.a1.x), "+v"(x.b0.x), "+v"(x.b1.x));      // (all loads issued before anything is compared)
                 }
             };
             auto p2_done = [&](P2& x) {
@@ -392,10 +399,20 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 uint32_t out = 0u;
                 bool pend = v;
                 if (x.probe) {
-                    const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (x.a0.w ^ k3) | (x.a1.x ^ len);
-                    const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (x.b0.w ^ k3) | (x.b1.x ^ len);
-                    const uint4 a1 = da == 0u ? x.a1 : x.b1;                         // (len, id, flags, -) of the slot that holds the word, if one does
-                    if ((da == 0u || db == 0u) && (a.any_hit_final | (a1.z & WORD_DIRECT))) { out = TOK_ONE | a1.y; pend = false; }
+                    bool found, direct;
+                    uint32_t id;
+                    if (len <= (uint32_t)HOT_MAX_KEY) {
+                        const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (((x.a0.w >> WORD12_LEN_SHIFT) & WORD12_LEN_MASK) ^ len);
+                        const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (((x.b0.w >> WORD12_LEN_SHIFT) & WORD12_LEN_MASK) ^ len);
+                        const uint32_t w = da == 0u ? x.a0.w : x.b0.w;
+                        found = da == 0u || db == 0u; id = w & WORD12_ID_MASK; direct = (w & WORD12_DIRECT) != 0u;
+                    } else {
+                        const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (x.a0.w ^ k3) | (x.a1.x ^ len);
+                        const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (x.b0.w ^ k3) | (x.b1.x ^ len);
+                        const uint4 a1 = da == 0u ? x.a1 : x.b1;                     // (len, id, flags, -) of the slot that holds the word, if one does
+                        found = da == 0u || db == 0u; id = a1.y; direct = (a1.z & WORD_DIRECT) != 0u;
+                    }
+                    if (found && (a.any_hit_final || direct)) { out = TOK_ONE | id; pend = false; }
                     if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
                         // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
                         // measured 20 % slower (the extra 32-byte reads cost more than the round trip they save)

@@ -103,6 +103,15 @@ TK_HD uint32_t word_slot_b(uint32_t h1, uint32_t mask) {       // (never slot a:
     return b == (h1 & mask) ? (b ^ 1u) : b;
 }
 
+// ---- the words of <= 12 bytes once more, in 16-byte slots (device only, built from the table above when its flags are final):
+// {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, two-choice like the table above and with the same two slot functions.  A probe of the
+// lookup's pass 2 is then TWO 16-byte requests in one round trip (97 % of the pre-tokens are <= 12 bytes); the 32-byte slots
+// above serve the keys of 13..16 bytes.  What pass 2 is bound by, as measured in round 4 (profiles/r4i_ab_*.txt): loading both
+// 32-byte slots of the two-choice table -- four requests, one round trip -- was SLOWER than displacement + slot (three requests, two
+// dependent round trips), 0.265 against 0.243 ms: the requests count, not only the chain.
+constexpr uint32_t WORD12_DIRECT = 0x80000000u;
+constexpr uint32_t WORD12_LEN_SHIFT = 24, WORD12_LEN_MASK = 0xFu, WORD12_ID_MASK = 0xFFFFFFu;
+
 // ---- hot-word table: the lowest-id settled words of <= 12 bytes, copied into LDS by the lookup kernel ----
 // slot = {k0, k1, k2, id | len << 24} (key bytes zero padded; len 0 = empty slot).  Hash-and-displace like the tables in HBM, so the
 // table holds exactly the words it is meant to hold: bucket = hot_hash & (slots / 4 - 1) selects a 16-bit displacement (the array
