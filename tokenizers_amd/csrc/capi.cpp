@@ -249,7 +249,7 @@ struct tkamd_tokenizer {
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
-    DevBuf t_word12;             // the words of <= 12 bytes in 16-byte slots (tables.hpp WORD12_*)
+    DevBuf t_word12, t_word12_disp;   // the words of <= 12 bytes in 16-byte slots + their eight-bit displacements (tables.hpp WORD12_*)
     DevBuf t_char_id;            // BPE over characters: HostModel::char_id
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
@@ -535,7 +535,9 @@ void verify_direct_words(tkamd_tokenizer* t) {
 }
 
 // The words of <= 12 bytes in 16-byte slots (tables.hpp): what pass 2 of the lookup probes for all but the longest keys.  Built from the
-// 32-byte table once its WORD_DIRECT flags are final; same seed, same two slot functions, its own size.
+// 32-byte table once its WORD_DIRECT flags are final; same seed (the kernel hashes a key once), its own size.  The displacements must
+// fit eight bits: a placement that needs a larger one gets a table twice the size (a bucket of k keys fits a given displacement with
+// probability (1 - fill)^k, and there are 256 tries).
 void build_word12_table(tkamd_tokenizer* t) {
     HostModel& hm = t->hm;
     std::vector<const WordSlot*> ws;
@@ -543,23 +545,58 @@ void build_word12_table(tkamd_tokenizer* t) {
         if (w.len && w.len <= (uint32_t)HOT_MAX_KEY) ws.push_back(&w);
     uint32_t cap = 16;
     while (cap < ws.size() * 5 / 2) cap <<= 1;
-    std::vector<uint32_t> h1(ws.size()), tenant;
-    for (size_t i = 0; i < ws.size(); ++i) h1[i] = word_hash1(ws[i]->lo, ws[i]->hi, ws[i]->len, hm.word_seed);
-    // (the seed is the 32-byte table's: the kernel hashes a key once.  A walk that fails under it gets a larger table, not a new seed.)
-    while (!cuckoo_place(h1, cap - 1, &tenant)) {
+    std::vector<uint32_t> h1(ws.size()), km(ws.size()), where(ws.size());
+    for (size_t i = 0; i < ws.size(); ++i) {
+        h1[i] = word_hash1(ws[i]->lo, ws[i]->hi, ws[i]->len, hm.word_seed);
+        km[i] = word12_kmix((uint32_t)ws[i]->lo, (uint32_t)(ws[i]->lo >> 32), (uint32_t)ws[i]->hi);
+    }
+    // hash-and-displace, the fullest buckets first, each takes the smallest displacement < 256 that drops all its words on free slots
+    std::vector<std::vector<uint32_t>> buckets((size_t)WORD12_BUCKETS);
+    for (size_t i = 0; i < ws.size(); ++i) buckets[h1[i] & (uint32_t)(WORD12_BUCKETS - 1)].push_back((uint32_t)i);
+    std::vector<uint32_t> order((size_t)WORD12_BUCKETS);
+    for (uint32_t b = 0; b < (uint32_t)WORD12_BUCKETS; ++b) order[b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
+    std::vector<uint8_t> disp;
+    for (;;) {
+        std::vector<uint8_t> used((size_t)cap, 0);
+        disp.assign((size_t)WORD12_BUCKETS, 0);
+        bool ok = true;
+        std::vector<uint32_t> slots;
+        for (uint32_t b : order) {
+            const std::vector<uint32_t>& keys = buckets[b];
+            if (keys.empty()) break;
+            bool placed = false;
+            for (uint32_t d = 0; d < 256u && !placed; ++d) {
+                slots.clear();
+                bool clash = false;
+                for (uint32_t i : keys) {
+                    const uint32_t sl = word12_slot(h1[i], km[i], d, cap - 1);
+                    if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
+                    slots.push_back(sl);
+                }
+                if (clash) continue;
+                for (size_t k = 0; k < keys.size(); ++k) { used[slots[k]] = 1; where[keys[k]] = slots[k]; }
+                disp[b] = (uint8_t)d;
+                placed = true;
+            }
+            if (!placed) { ok = false; break; }
+        }
+        if (ok) break;
         if (cap >= (1u << 26)) throw Invalid("could not build the short-word hash table");
         cap <<= 1;
     }
     std::vector<HotSlot> tab(cap, HotSlot{0u, 0u, 0u, 0u});
-    for (uint32_t sidx = 0; sidx < cap; ++sidx) {
-        if (tenant[sidx] == 0xFFFFFFFFu) continue;
-        const WordSlot* w = ws[tenant[sidx]];
+    for (size_t i = 0; i < ws.size(); ++i) {
+        const WordSlot* w = ws[i];
         if (w->id > WORD12_ID_MASK) throw Invalid("token id beyond 24 bits");           // (checked at load already: ids < 2^24)
-        tab[sidx] = HotSlot{(uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->id | (w->len << WORD12_LEN_SHIFT) | ((w->flags & WORD_DIRECT) ? WORD12_DIRECT : 0u)};
+        tab[where[i]] = HotSlot{(uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->id | (w->len << WORD12_LEN_SHIFT) | ((w->flags & WORD_DIRECT) ? WORD12_DIRECT : 0u)};
     }
     upload(t->t_word12, tab, 64);
+    upload(t->t_word12_disp, disp, 64);
     t->dt.word12 = t->t_word12.p;
+    t->dt.word12_disp = t->t_word12_disp.as<uint8_t>();
     t->dt.word12_mask = cap - 1;
+    if (getenv("TKAMD_DEBUG_TABLES")) fprintf(stderr, "[tkamd] short-word table: %zu words in %u slots of 16 bytes, %d buckets\n", ws.size(), cap, WORD12_BUCKETS);
 }
 
 // Hot-word table of the lookup kernel: the settled words of <= 12 bytes with the lowest ids, direct mapped (tables.hpp).

@@ -31,6 +31,44 @@ bool cuckoo_place(const std::vector<uint32_t>& h1, uint32_t mask, std::vector<ui
     return true;
 }
 
+// Hash-and-displace (CHD) perfect hash: keys are bucketed by h1, buckets are placed largest first, each one
+// searches the smallest 16-bit displacement d that drops all its keys into free slots (h2 + d * PH_MULT) & mask.
+// Returns false if some bucket cannot be placed (caller retries with another seed / a larger table).
+bool chd_place(const std::vector<uint32_t>& h1, const std::vector<uint32_t>& h2, uint32_t mask, uint32_t bmask,
+               std::vector<uint16_t>* disp, std::vector<uint32_t>* slot_of_key) {
+    const uint32_t nb = bmask + 1, n = (uint32_t)h1.size();
+    std::vector<std::vector<uint32_t>> buckets(nb);
+    for (uint32_t i = 0; i < n; ++i) buckets[h1[i] & bmask].push_back(i);
+    std::vector<uint32_t> order(nb);
+    for (uint32_t b = 0; b < nb; ++b) order[b] = b;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
+    std::vector<uint8_t> used(mask + 1, 0);
+    disp->assign(nb, 0);
+    slot_of_key->assign(n, 0);
+    std::vector<uint32_t> slots;
+    for (uint32_t b : order) {
+        const auto& keys = buckets[b];
+        if (keys.empty()) break;
+        bool placed = false;
+        for (uint32_t d = 0; d < 65536 && !placed; ++d) {
+            slots.clear();
+            bool clash = false;
+            for (uint32_t i : keys) {
+                uint32_t sl = ph_slot(h2[i], d, mask);
+                if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
+                slots.push_back(sl);
+            }
+            if (!clash) {
+                for (size_t k = 0; k < keys.size(); ++k) { used[slots[k]] = 1; (*slot_of_key)[keys[k]] = slots[k]; }
+                (*disp)[b] = (uint16_t)d;
+                placed = true;
+            }
+        }
+        if (!placed) return false;
+    }
+    return true;
+}
+
 namespace {
 
 struct UcRun {
@@ -184,44 +222,6 @@ void build_pair_table(const std::vector<MergeSlot>& items, std::vector<MergeSlot
         if (attempt % 4 == 3) cap <<= 1;
     }
     throw Invalid("could not build a pair hash table");
-}
-
-// Hash-and-displace (CHD) perfect hash: keys are bucketed by h1, buckets are placed largest first, each one
-// searches the smallest 16-bit displacement d that drops all its keys into free slots (h2 + d * PH_MULT) & mask.
-// Returns false if some bucket cannot be placed (caller retries with another seed / a larger table).
-bool chd_place(const std::vector<uint32_t>& h1, const std::vector<uint32_t>& h2, uint32_t mask, uint32_t bmask,
-               std::vector<uint16_t>* disp, std::vector<uint32_t>* slot_of_key) {
-    const uint32_t nb = bmask + 1, n = (uint32_t)h1.size();
-    std::vector<std::vector<uint32_t>> buckets(nb);
-    for (uint32_t i = 0; i < n; ++i) buckets[h1[i] & bmask].push_back(i);
-    std::vector<uint32_t> order(nb);
-    for (uint32_t b = 0; b < nb; ++b) order[b] = b;
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
-    std::vector<uint8_t> used(mask + 1, 0);
-    disp->assign(nb, 0);
-    slot_of_key->assign(n, 0);
-    std::vector<uint32_t> slots;
-    for (uint32_t b : order) {
-        const auto& keys = buckets[b];
-        if (keys.empty()) break;
-        bool placed = false;
-        for (uint32_t d = 0; d < 65536 && !placed; ++d) {
-            slots.clear();
-            bool clash = false;
-            for (uint32_t i : keys) {
-                uint32_t sl = ph_slot(h2[i], d, mask);
-                if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
-                slots.push_back(sl);
-            }
-            if (!clash) {
-                for (size_t k = 0; k < keys.size(); ++k) { used[slots[k]] = 1; (*slot_of_key)[keys[k]] = slots[k]; }
-                (*disp)[b] = (uint16_t)d;
-                placed = true;
-            }
-        }
-        if (!placed) return false;
-    }
-    return true;
 }
 
 void build_merge_table(HostModel& m, const std::vector<MergeSlot>& merges) {

@@ -59,6 +59,7 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.word_mask = t.word_mask;
     a.word12 = (const uint4*)t.word12;
     a.word12_mask = t.word12_mask;
+    a.word12_disp = t.word12_disp;
     a.word_seed = t.word_seed;
     a.any_hit_final = t.ignore_merges;
     a.unk_id = t.unk_id;

@@ -44,7 +44,8 @@ constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile
 //               passes 2 and 3 wait for memory (70 % of the kernel's time, profiles/r4b_*), and more wavefronts hide more of it
 template <int HOT> struct LuShape {
     static_assert(HOT == 2048 || HOT == 1024, "shapes the launcher knows");
-    static constexpr int POS_CAP = HOT == 2048 ? 4096 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
+    static constexpr int POS_CAP = HOT == 2048 ? 3584 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
+    static constexpr bool DISP_LDS = HOT == 2048;                  // the 8 KB of WORD12 displacements in LDS (the other shape has no room: it reads them from memory)
     static constexpr int WAVES_PER_SIMD = HOT == 2048 ? 4 : 6;     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU
 };
 constexpr uint32_t CLAIM_ADAPT_MIN = 768u;               // candidates a workgroup looks at before it judges the claims' yield (about two tiles of prose)
@@ -63,7 +64,8 @@ struct LookupArgs {
     const uint4* hot;                // [HOT] {k0, k1, k2, id | len << 24}, len 0 = empty; then [HOT / 4] 16-bit displacements (tables.hpp)
     const WordSlot* words;           // two-choice table behind the hot table
     uint32_t word_mask, word_seed;
-    const uint4* word12;             // the words of <= 12 bytes in 16-byte slots {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, two-choice too
+    const uint4* word12;             // the words of <= 12 bytes in 16-byte slots {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, hash-and-displace
+    const uint8_t* word12_disp;      // [WORD12_BUCKETS] their displacements: copied into LDS (shape HOT = 2048)
     uint32_t word12_mask;
     uint32_t any_hit_final;          // ignore_merges / WordLevel / WordPiece: every hit is final (else only WORD_DIRECT ones)
     uint32_t no_hits;                // WordPiece with max_input_chars_per_word < 16: every word takes the trie walk
@@ -94,9 +96,11 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT]
     uint16_t* s_hdisp = (uint16_t*)(s_hot + HOT);                               // [HOT / 4]
     uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
-    uint16_t* s_pos = (uint16_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [LU_POS_CAP + 2] start of rank r, relative to the tile
+    uint8_t* s_wdisp = (uint8_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [WORD12_BUCKETS] if DISP_LDS, else nothing (16-byte aligned: copied sixteen bytes a lane)
+    uint16_t* s_pos = (uint16_t*)(s_wdisp + (LuShape<HOT>::DISP_LDS ? WORD12_BUCKETS : 0));    // [LU_POS_CAP + 2] start of rank r, relative to the tile
     uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
+    static_assert(((LU_TILE + LU_TEXT_SLACK) + 16) % 16 == 0 && hot_table_bytes(HOT) % 16 == 0, "s_wdisp is copied sixteen bytes a lane");
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
     __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand;
     // the claims' yield as this workgroup sees it: candidates it looked at, how many of them were another pre-token's word.  Text that
@@ -117,6 +121,9 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
     static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
     for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
+    if (LuShape<HOT>::DISP_LDS)
+        for (int i = tid; i < WORD12_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.word12_disp)[i];
+    const uint8_t* const wdisp = LuShape<HOT>::DISP_LDS ? (const uint8_t*)s_wdisp : a.word12_disp;
     if (tid < 17) {
         const uint32_t l = (uint32_t)tid;
         auto m = [&](uint32_t lo) -> uint32_t { return l >= lo + 4u ? 0xFFFFFFFFu : (l > lo ? ((1u << (8u * (l - lo))) - 1u) : 0u); };
@@ -382,9 +389,8 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 x.a0 = x.a1 = x.b0 = x.b1 = make_uint4(0u, 0u, 0u, 0u);
                 if (x.probe) {                                                      // both slots the word may live in, in ONE round trip
                     x.h1 = word_hash1_from_hot(hot_hash(x.k0, x.k1, x.k2, x.len, a.word_seed), x.k3);
-                    if (x.len <= (uint32_t)HOT_MAX_KEY) {                            // ... of the 16-byte table: two requests (nearly every lane)
-                        x.a0 = a.word12[word_slot_a(x.h1, a.word12_mask)];
-                        x.b0 = a.word12[word_slot_b(x.h1, a.word12_mask)];
+                    if (x.len <= (uint32_t)HOT_MAX_KEY) {                            // the 16-byte table: displacement from LDS, ONE request (nearly every lane)
+                        x.a0 = a.word12[word12_slot(x.h1, word12_kmix(x.k0, x.k1, x.k2), (uint32_t)wdisp[x.h1 & (uint32_t)(WORD12_BUCKETS - 1)], a.word12_mask)];
                     } else {                                                        // a key of 13..16 bytes: the 32-byte slots, four requests
                         const uint4* qa = (const uint4*)&a.words[word_slot_a(x.h1, a.word_mask)];
                         const uint4* qb = (const uint4*)&a.words[word_slot_b(x.h1, a.word_mask)];
@@ -402,10 +408,8 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                     bool found, direct;
                     uint32_t id;
                     if (len <= (uint32_t)HOT_MAX_KEY) {
-                        const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (((x.a0.w >> WORD12_LEN_SHIFT) & WORD12_LEN_MASK) ^ len);
-                        const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (((x.b0.w >> WORD12_LEN_SHIFT) & WORD12_LEN_MASK) ^ len);
-                        const uint32_t w = da == 0u ? x.a0.w : x.b0.w;
-                        found = da == 0u || db == 0u; id = w & WORD12_ID_MASK; direct = (w & WORD12_DIRECT) != 0u;
+                        found = ((x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (((x.a0.w >> WORD12_LEN_SHIFT) & WORD12_LEN_MASK) ^ len)) == 0u;
+                        id = x.a0.w & WORD12_ID_MASK; direct = (x.a0.w & WORD12_DIRECT) != 0u;
                     } else {
                         const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (x.a0.w ^ k3) | (x.a1.x ^ len);
                         const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (x.b0.w ^ k3) | (x.b1.x ^ len);
@@ -556,8 +560,9 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
 }
 
 constexpr int lookup_lds_bytes(int hot) {      // (the end array's place holds the candidate list when there are no end masks)
-    return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 4096 : 3072) + 2) * 2 + (hot == 2048 ? 4096 : 3072) * 2;
+    return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 3584 : 3072) + 2) * 2 + (hot == 2048 ? 3584 : 3072) * 2 + (hot == 2048 ? WORD12_BUCKETS : 0);
 }
+static_assert(lookup_lds_bytes(2048) + 1024 <= 81920, "two workgroups of the 2,048-slot shape share a CU's 160 KB (1 KB: the kernel's static LDS)");
 
 // =================================================================================================
 // K_word_cache_insert: after the merge kernels, every queued pre-token of <= 16 bytes whose result fits a row (<= 4 tokens) is

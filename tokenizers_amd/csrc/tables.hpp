@@ -104,13 +104,27 @@ TK_HD uint32_t word_slot_b(uint32_t h1, uint32_t mask) {       // (never slot a:
 }
 
 // ---- the words of <= 12 bytes once more, in 16-byte slots (device only, built from the table above when its flags are final):
-// {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, two-choice like the table above and with the same two slot functions.  A probe of the
-// lookup's pass 2 is then TWO 16-byte requests in one round trip (97 % of the pre-tokens are <= 12 bytes); the 32-byte slots
-// above serve the keys of 13..16 bytes.  What pass 2 is bound by, as measured in round 4 (profiles/r4i_ab_*.txt): loading both
-// 32-byte slots of the two-choice table -- four requests, one round trip -- was SLOWER than displacement + slot (three requests, two
-// dependent round trips), 0.265 against 0.243 ms: the requests count, not only the chain.
+// {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, hash-and-displace with EIGHT-bit displacements over WORD12_BUCKETS buckets: the 8 KB of
+// displacements sit in the LDS of the lookup kernel, so a probe of its pass 2 is ONE 16-byte request at ONE random line (97 % of the
+// pre-tokens are <= 12 bytes; the 32-byte two-choice table above serves the keys of 13..16 bytes).  bucket = h1 & (WORD12_BUCKETS - 1),
+// slot = word12_slot(h1, key mix, d, mask), below.
+// What pass 2 is bound by, as measured in round 4 (profiles/r4i_*, r4j_*; the table was displacement-in-HBM + one 32-byte slot before,
+// 0.233..0.243 ms for the kernel): both 32-byte slots of a two-choice table at once -- four requests, ONE round trip -- 0.265 ms; both
+// 16-byte slots of a two-choice table -- two requests, one round trip -- 0.257 ms.  Fewer dependent round trips and fewer requests,
+// and slower: what a probe costs is the random LINES it touches beyond the L2 (two per probe there, one here; the displacements are
+// a small hot array), not the length of its chain.
 constexpr uint32_t WORD12_DIRECT = 0x80000000u;
 constexpr uint32_t WORD12_LEN_SHIFT = 24, WORD12_LEN_MASK = 0xFu, WORD12_ID_MASK = 0xFFFFFFu;
+constexpr int WORD12_BUCKETS = 8192;
+// The slot: double hashing on the displacement -- (base + d * step) & mask, base and step from the key bytes once more.  The table
+// shares the 32-byte table's seed (the kernel hashes a key once), so it cannot answer an unlucky placement with another seed: a
+// displacement that moves every key of a bucket by the SAME amount (the merge table's ph_slot) can never part two keys of a bucket
+// whose bases agree under the mask -- a key-dependent step does, at the next d.
+TK_HD uint32_t word12_kmix(uint32_t k0, uint32_t k1, uint32_t k2) { return (k0 * 0x85EBCA77u) ^ (k1 * 0xC2B2AE3Du) ^ (k2 * 0x27D4EB2Fu); }
+TK_HD uint32_t word12_slot(uint32_t h1, uint32_t kmix, uint32_t d, uint32_t mask) {
+    const uint32_t base = ((h1 * 0x9E3779B1u) ^ (h1 >> 15)) ^ kmix, step = ((kmix * 0x9E3779B1u) >> 9) | 1u;
+    return (base + d * step) & mask;
+}
 
 // ---- hot-word table: the lowest-id settled words of <= 12 bytes, copied into LDS by the lookup kernel ----
 // slot = {k0, k1, k2, id | len << 24} (key bytes zero padded; len 0 = empty slot).  Hash-and-displace like the tables in HBM, so the
