@@ -249,7 +249,7 @@ struct tkamd_tokenizer {
     // tables
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
-    DevBuf t_word12, t_word12_disp;   // the words of <= 12 bytes in 16-byte slots + their eight-bit displacements (tables.hpp WORD12_*)
+    DevBuf t_shortw, t_shortw_k3, t_shortw_disp;   // the short-word table: 16-byte slots, key bytes 12..15, eight-bit displacements (tables.hpp SHORTW_*)
     DevBuf t_char_id;            // BPE over characters: HostModel::char_id
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
@@ -534,32 +534,32 @@ void verify_direct_words(tkamd_tokenizer* t) {
     t->dt.words = t->t_words.as<WordSlot>();
 }
 
-// The words of <= 12 bytes in 16-byte slots (tables.hpp): what pass 2 of the lookup probes for all but the longest keys.  Built from the
-// 32-byte table once its WORD_DIRECT flags are final; same seed (the kernel hashes a key once), its own size.  The displacements must
-// fit eight bits: a placement that needs a larger one gets a table twice the size (a bucket of k keys fits a given displacement with
-// probability (1 - fill)^k, and there are 256 tries).
-void build_word12_table(tkamd_tokenizer* t) {
+// The short-word table (tables.hpp): what pass 2 of the lookup probes.  Built from the 32-byte table (the host's copy of record) once
+// its WORD_DIRECT flags are final; same seed (the kernel hashes a key once), its own size.  The displacements must fit eight bits: a
+// placement that needs a larger one gets a table twice the size (a bucket of k keys fits a given displacement with probability
+// (1 - fill)^k, and there are 256 tries).
+void build_shortw_table(tkamd_tokenizer* t) {
     HostModel& hm = t->hm;
     std::vector<const WordSlot*> ws;
     for (const WordSlot& w : hm.word_table)
-        if (w.len && w.len <= (uint32_t)HOT_MAX_KEY) ws.push_back(&w);
+        if (w.len) ws.push_back(&w);
     uint32_t cap = 16;
     while (cap < ws.size() * 5 / 2) cap <<= 1;
     std::vector<uint32_t> h1(ws.size()), km(ws.size()), where(ws.size());
     for (size_t i = 0; i < ws.size(); ++i) {
         h1[i] = word_hash1(ws[i]->lo, ws[i]->hi, ws[i]->len, hm.word_seed);
-        km[i] = word12_kmix((uint32_t)ws[i]->lo, (uint32_t)(ws[i]->lo >> 32), (uint32_t)ws[i]->hi);
+        km[i] = shortw_kmix((uint32_t)ws[i]->lo, (uint32_t)(ws[i]->lo >> 32), (uint32_t)ws[i]->hi, (uint32_t)(ws[i]->hi >> 32));
     }
     // hash-and-displace, the fullest buckets first, each takes the smallest displacement < 256 that drops all its words on free slots
-    std::vector<std::vector<uint32_t>> buckets((size_t)WORD12_BUCKETS);
-    for (size_t i = 0; i < ws.size(); ++i) buckets[h1[i] & (uint32_t)(WORD12_BUCKETS - 1)].push_back((uint32_t)i);
-    std::vector<uint32_t> order((size_t)WORD12_BUCKETS);
-    for (uint32_t b = 0; b < (uint32_t)WORD12_BUCKETS; ++b) order[b] = b;
+    std::vector<std::vector<uint32_t>> buckets((size_t)SHORTW_BUCKETS);
+    for (size_t i = 0; i < ws.size(); ++i) buckets[h1[i] & (uint32_t)(SHORTW_BUCKETS - 1)].push_back((uint32_t)i);
+    std::vector<uint32_t> order((size_t)SHORTW_BUCKETS);
+    for (uint32_t b = 0; b < (uint32_t)SHORTW_BUCKETS; ++b) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
     std::vector<uint8_t> disp;
     for (;;) {
         std::vector<uint8_t> used((size_t)cap, 0);
-        disp.assign((size_t)WORD12_BUCKETS, 0);
+        disp.assign((size_t)SHORTW_BUCKETS, 0);
         bool ok = true;
         std::vector<uint32_t> slots;
         for (uint32_t b : order) {
@@ -570,7 +570,7 @@ void build_word12_table(tkamd_tokenizer* t) {
                 slots.clear();
                 bool clash = false;
                 for (uint32_t i : keys) {
-                    const uint32_t sl = word12_slot(h1[i], km[i], d, cap - 1);
+                    const uint32_t sl = shortw_slot(h1[i], km[i], d, cap - 1);
                     if (used[sl] || std::find(slots.begin(), slots.end(), sl) != slots.end()) { clash = true; break; }
                     slots.push_back(sl);
                 }
@@ -586,17 +586,21 @@ void build_word12_table(tkamd_tokenizer* t) {
         cap <<= 1;
     }
     std::vector<HotSlot> tab(cap, HotSlot{0u, 0u, 0u, 0u});
+    std::vector<uint32_t> k3(cap, 0u);
     for (size_t i = 0; i < ws.size(); ++i) {
         const WordSlot* w = ws[i];
-        if (w->id > WORD12_ID_MASK) throw Invalid("token id beyond 24 bits");           // (checked at load already: ids < 2^24)
-        tab[where[i]] = HotSlot{(uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->id | (w->len << WORD12_LEN_SHIFT) | ((w->flags & WORD_DIRECT) ? WORD12_DIRECT : 0u)};
+        if (w->id > SHORTW_ID_MASK) throw Invalid("token id beyond 24 bits");           // (checked at load already: ids < 2^24)
+        tab[where[i]] = HotSlot{(uint32_t)w->lo, (uint32_t)(w->lo >> 32), (uint32_t)w->hi, w->id | (w->len << SHORTW_LEN_SHIFT) | ((w->flags & WORD_DIRECT) ? SHORTW_DIRECT : 0u)};
     }
-    upload(t->t_word12, tab, 64);
-    upload(t->t_word12_disp, disp, 64);
-    t->dt.word12 = t->t_word12.p;
-    t->dt.word12_disp = t->t_word12_disp.as<uint8_t>();
-    t->dt.word12_mask = cap - 1;
-    if (getenv("TKAMD_DEBUG_TABLES")) fprintf(stderr, "[tkamd] short-word table: %zu words in %u slots of 16 bytes, %d buckets\n", ws.size(), cap, WORD12_BUCKETS);
+    for (size_t i = 0; i < ws.size(); ++i) k3[where[i]] = (uint32_t)(ws[i]->hi >> 32);
+    upload(t->t_shortw, tab, 64);
+    upload(t->t_shortw_k3, k3, 64);
+    t->dt.shortw_k3 = t->t_shortw_k3.as<uint32_t>();
+    upload(t->t_shortw_disp, disp, 64);
+    t->dt.shortw = t->t_shortw.p;
+    t->dt.shortw_disp = t->t_shortw_disp.as<uint8_t>();
+    t->dt.shortw_mask = cap - 1;
+    if (getenv("TKAMD_DEBUG_TABLES")) fprintf(stderr, "[tkamd] short-word table: %zu words in %u slots of 16 + 4 bytes, %d buckets\n", ws.size(), cap, SHORTW_BUCKETS);
 }
 
 // Hot-word table of the lookup kernel: the settled words of <= 12 bytes with the lowest ids, direct mapped (tables.hpp).
@@ -1868,7 +1872,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
         if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 1024 ? 1024 : 2048;
-        build_word12_table(t.get());
+        build_shortw_table(t.get());
         build_hot_table(t.get());
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);

@@ -27,9 +27,10 @@ struct DevTables {
     uint32_t pub_mask;
     const WordSlot* words;            // two-choice table (tables.hpp): a key sits in word_slot_a or word_slot_b of its hash
     uint32_t word_mask, word_seed;
-    const void* word12;               // the words of <= 12 bytes in 16-byte slots (tables.hpp), same seed
-    const uint8_t* word12_disp;       // [WORD12_BUCKETS] eight-bit displacements (the lookup kernel keeps them in LDS)
-    uint32_t word12_mask;
+    const void* shortw;               // the short-word table (tables.hpp): every word of `words` in 16-byte slots, same seed
+    const uint32_t* shortw_k3;        // bytes 12..15 of the key in slot i
+    const uint8_t* shortw_disp;       // [SHORTW_BUCKETS] eight-bit displacements (the lookup kernel keeps them in LDS)
+    uint32_t shortw_mask;
     uint32_t ignore_merges;
     uint32_t long_probe_max_len;      // whole-word probes of keys > 16 bytes only up to this length (WordPiece: max_input_chars)
     uint32_t unk_id, has_unk;

@@ -54,12 +54,13 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.claim_adapt = adapt;
     static const uint32_t direct = [] { const char* e = getenv("TKAMD_CLAIM_CHAIN"); return (e && !strcmp(e, "cas")) ? 1u : 0u; }();
     a.claim_direct = direct;
+    static const uint32_t p2_single = [] { const char* e = getenv("TKAMD_LU_P2"); return (e && !strcmp(e, "1")) ? 1u : 0u; }();
+    a.p2_single = p2_single;
     a.counters = counters;
-    a.words = t.words;
-    a.word_mask = t.word_mask;
-    a.word12 = (const uint4*)t.word12;
-    a.word12_mask = t.word12_mask;
-    a.word12_disp = t.word12_disp;
+    a.shortw = (const uint4*)t.shortw;
+    a.shortw_mask = t.shortw_mask;
+    a.shortw_disp = t.shortw_disp;
+    a.shortw_k3 = t.shortw_k3;
     a.word_seed = t.word_seed;
     a.any_hit_final = t.ignore_merges;
     a.unk_id = t.unk_id;

@@ -62,11 +62,11 @@ struct LookupArgs {
     int* err;
     const unsigned long long* matchmask;   // added-token matches: one pre-token, id patched in later
     const uint4* hot;                // [HOT] {k0, k1, k2, id | len << 24}, len 0 = empty; then [HOT / 4] 16-bit displacements (tables.hpp)
-    const WordSlot* words;           // two-choice table behind the hot table
-    uint32_t word_mask, word_seed;
-    const uint4* word12;             // the words of <= 12 bytes in 16-byte slots {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, hash-and-displace
-    const uint8_t* word12_disp;      // [WORD12_BUCKETS] their displacements: copied into LDS (shape HOT = 2048)
-    uint32_t word12_mask;
+    uint32_t word_seed;
+    const uint4* shortw;             // the short-word table behind the hot table (tables.hpp): 16-byte slots {k0, k1, k2, id | len << 24 | SHORTW_DIRECT}
+    const uint32_t* shortw_k3;       // bytes 12..15 of the key in slot i (read by the pre-tokens longer than 12 bytes only)
+    const uint8_t* shortw_disp;      // [SHORTW_BUCKETS] the displacements: copied into LDS (shape HOT = 2048)
+    uint32_t shortw_mask;
     uint32_t any_hit_final;          // ignore_merges / WordLevel / WordPiece: every hit is final (else only WORD_DIRECT ones)
     uint32_t no_hits;                // WordPiece with max_input_chars_per_word < 16: every word takes the trie walk
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
@@ -76,6 +76,7 @@ struct LookupArgs {
     uint32_t claim_mask;             // slots - 1
     uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
     uint32_t claim_direct;           // TKAMD_CLAIM_CHAIN=cas (claim_word)
+    uint32_t p2_single;              // TKAMD_LU_P2=1 (pass 2)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -96,8 +97,8 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT]
     uint16_t* s_hdisp = (uint16_t*)(s_hot + HOT);                               // [HOT / 4]
     uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
-    uint8_t* s_wdisp = (uint8_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [WORD12_BUCKETS] if DISP_LDS, else nothing (16-byte aligned: copied sixteen bytes a lane)
-    uint16_t* s_pos = (uint16_t*)(s_wdisp + (LuShape<HOT>::DISP_LDS ? WORD12_BUCKETS : 0));    // [LU_POS_CAP + 2] start of rank r, relative to the tile
+    uint8_t* s_wdisp = (uint8_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [SHORTW_BUCKETS] if DISP_LDS, else nothing (16-byte aligned: copied sixteen bytes a lane)
+    uint16_t* s_pos = (uint16_t*)(s_wdisp + (LuShape<HOT>::DISP_LDS ? SHORTW_BUCKETS : 0));    // [LU_POS_CAP + 2] start of rank r, relative to the tile
     uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
     static_assert(((LU_TILE + LU_TEXT_SLACK) + 16) % 16 == 0 && hot_table_bytes(HOT) % 16 == 0, "s_wdisp is copied sixteen bytes a lane");
@@ -122,8 +123,8 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
     for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
     if (LuShape<HOT>::DISP_LDS)
-        for (int i = tid; i < WORD12_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.word12_disp)[i];
-    const uint8_t* const wdisp = LuShape<HOT>::DISP_LDS ? (const uint8_t*)s_wdisp : a.word12_disp;
+        for (int i = tid; i < SHORTW_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.shortw_disp)[i];
+    const uint8_t* const wdisp = LuShape<HOT>::DISP_LDS ? (const uint8_t*)s_wdisp : a.shortw_disp;
     if (tid < 17) {
         const uint32_t l = (uint32_t)tid;
         auto m = [&](uint32_t lo) -> uint32_t { return l >= lo + 4u ? 0xFFFFFFFFu : (l > lo ? ((1u << (8u * (l - lo))) - 1u) : 0u); };
@@ -374,29 +375,25 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
             };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
-            // A step is the key + hash, ONE memory round trip -- the two slots of the two-choice table the word may live in, 64 bytes a
-            // lane -- and the verdict.  (Until round 4 the table was hash-and-displace: the bucket's displacement, then the slot, two
-            // dependent round trips.  Two such steps side by side, stage by stage, had measured SLOWER, 0.2475 against 0.2337 ms, as
-            // batching the probes had in round 2: profiles/r4d_ab_c2.txt.)
-            struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1; uint4 a0, a1, b0, b1; };
+            // A step is the key + hash + the bucket's displacement (LDS), ONE memory round trip -- the word's one slot of the short-word
+            // table (tables.hpp), 16 bytes a lane -- and the verdict.  (Until round 4 the table had 32-byte slots and its displacements in
+            // HBM: two dependent round trips, three requests.  Two of THOSE steps side by side, stage by stage, had measured slower, 0.2475
+            // against 0.2337 ms, as batching the probes had in round 2: profiles/r4d_ab_c2.txt.)
+            struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1, k3t; uint4 a0; };
             const uint32_t n_miss = s_nmiss;
             auto p2_key = [&](uint32_t m0, P2& x) {
                 x.v = m0 + lane < n_miss;
                 x.rel = s_miss[x.v ? m0 + lane : m0];
                 load_key(x.rel, x.s_rel, x.len, x.k0, x.k1, x.k2, x.k3, true);
                 x.h1 = 0u;
+                x.k3t = 0u;
                 x.probe = x.v && hits_on && x.len != 0u && x.len <= (uint32_t)WORD_MAX_KEY;
-                x.a0 = x.a1 = x.b0 = x.b1 = make_uint4(0u, 0u, 0u, 0u);
-                if (x.probe) {                                                      // both slots the word may live in, in ONE round trip
+                x.a0 = make_uint4(0u, 0u, 0u, 0u);
+                if (x.probe) {                                                      // displacement from LDS, then ONE 16-byte request (+ 4 bytes for the few keys longer than 12)
                     x.h1 = word_hash1_from_hot(hot_hash(x.k0, x.k1, x.k2, x.len, a.word_seed), x.k3);
-                    if (x.len <= (uint32_t)HOT_MAX_KEY) {                            // the 16-byte table: displacement from LDS, ONE request (nearly every lane)
-                        x.a0 = a.word12[word12_slot(x.h1, word12_kmix(x.k0, x.k1, x.k2), (uint32_t)wdisp[x.h1 & (uint32_t)(WORD12_BUCKETS - 1)], a.word12_mask)];
-                    } else {                                                        // a key of 13..16 bytes: the 32-byte slots, four requests
-                        const uint4* qa = (const uint4*)&a.words[word_slot_a(x.h1, a.word_mask)];
-                        const uint4* qb = (const uint4*)&a.words[word_slot_b(x.h1, a.word_mask)];
-                        x.a0 = qa[0]; x.a1 = qa[1]; x.b0 = qb[0]; x.b1 = qb[1];
-                    }
-                    asm volatile("" : "+v"(x.a0.x), "+v"(x.a1.x), "+v"(x.b0.x), "+v"(x.b1.x));      // (all loads issued before anything is compared)
+                    const uint32_t slot = shortw_slot(x.h1, shortw_kmix(x.k0, x.k1, x.k2, x.k3), (uint32_t)wdisp[x.h1 & (uint32_t)(SHORTW_BUCKETS - 1)], a.shortw_mask);
+                    x.a0 = a.shortw[slot];
+                    if (x.len > (uint32_t)HOT_MAX_KEY) x.k3t = a.shortw_k3[slot];
                 }
             };
             auto p2_done = [&](P2& x) {
@@ -405,17 +402,9 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 uint32_t out = 0u;
                 bool pend = v;
                 if (x.probe) {
-                    bool found, direct;
-                    uint32_t id;
-                    if (len <= (uint32_t)HOT_MAX_KEY) {
-                        found = ((x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (((x.a0.w >> WORD12_LEN_SHIFT) & WORD12_LEN_MASK) ^ len)) == 0u;
-                        id = x.a0.w & WORD12_ID_MASK; direct = (x.a0.w & WORD12_DIRECT) != 0u;
-                    } else {
-                        const uint32_t da = (x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (x.a0.w ^ k3) | (x.a1.x ^ len);
-                        const uint32_t db = (x.b0.x ^ k0) | (x.b0.y ^ k1) | (x.b0.z ^ k2) | (x.b0.w ^ k3) | (x.b1.x ^ len);
-                        const uint4 a1 = da == 0u ? x.a1 : x.b1;                     // (len, id, flags, -) of the slot that holds the word, if one does
-                        found = da == 0u || db == 0u; id = a1.y; direct = (a1.z & WORD_DIRECT) != 0u;
-                    }
+                    const bool found = ((x.a0.x ^ k0) | (x.a0.y ^ k1) | (x.a0.z ^ k2) | (x.k3t ^ k3) | (((x.a0.w >> SHORTW_LEN_SHIFT) & SHORTW_LEN_MASK) ^ len)) == 0u;
+                    const uint32_t id = x.a0.w & SHORTW_ID_MASK;
+                    const bool direct = (x.a0.w & SHORTW_DIRECT) != 0u;
                     if (found && (a.any_hit_final || direct)) { out = TOK_ONE | id; pend = false; }
                     if (a.cache_keys && pend) {                                     // (the outer test is wavefront-uniform) the word cache: merged by an earlier batch?
                         // probed only by the lanes the table did not settle: riding along with the table probe for every lane was
@@ -463,10 +452,16 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 }
                 finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
             };
-            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
-                P2 x;
+            // two steps side by side: both probes in flight together (a tile of prose is two steps a wavefront; the 80-register shape
+            // has no room for the second step's state)
+            constexpr bool TWO = HOT == 2048;
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (TWO ? 2u : 1u) * (uint32_t)LU_NT) {
+                P2 x, y;
+                const bool two = TWO && a.p2_single == 0u && m0 + (uint32_t)LU_NT < n_miss;      // wavefront-uniform (TKAMD_LU_P2=1: one step at a time)
                 p2_key(m0, x);
+                if (two) p2_key(m0 + (uint32_t)LU_NT, y);
                 p2_done(x);
+                if (two) p2_done(y);
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
             // (Round 4 parked a wavefront's step of candidates in registers and advanced its chain -- slot, compare-and-swap, the
@@ -560,7 +555,7 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
 }
 
 constexpr int lookup_lds_bytes(int hot) {      // (the end array's place holds the candidate list when there are no end masks)
-    return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 3584 : 3072) + 2) * 2 + (hot == 2048 ? 3584 : 3072) * 2 + (hot == 2048 ? WORD12_BUCKETS : 0);
+    return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 3584 : 3072) + 2) * 2 + (hot == 2048 ? 3584 : 3072) * 2 + (hot == 2048 ? SHORTW_BUCKETS : 0);
 }
 static_assert(lookup_lds_bytes(2048) + 1024 <= 81920, "two workgroups of the 2,048-slot shape share a CU's 160 KB (1 KB: the kernel's static LDS)");
 

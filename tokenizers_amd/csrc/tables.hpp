@@ -103,25 +103,25 @@ TK_HD uint32_t word_slot_b(uint32_t h1, uint32_t mask) {       // (never slot a:
     return b == (h1 & mask) ? (b ^ 1u) : b;
 }
 
-// ---- the words of <= 12 bytes once more, in 16-byte slots (device only, built from the table above when its flags are final):
-// {k0, k1, k2, id | len << 24 | WORD12_DIRECT}, hash-and-displace with EIGHT-bit displacements over WORD12_BUCKETS buckets: the 8 KB of
-// displacements sit in the LDS of the lookup kernel, so a probe of its pass 2 is ONE 16-byte request at ONE random line (97 % of the
-// pre-tokens are <= 12 bytes; the 32-byte two-choice table above serves the keys of 13..16 bytes).  bucket = h1 & (WORD12_BUCKETS - 1),
-// slot = word12_slot(h1, key mix, d, mask), below.
-// What pass 2 is bound by, as measured in round 4 (profiles/r4i_*, r4j_*; the table was displacement-in-HBM + one 32-byte slot before,
-// 0.233..0.243 ms for the kernel): both 32-byte slots of a two-choice table at once -- four requests, ONE round trip -- 0.265 ms; both
-// 16-byte slots of a two-choice table -- two requests, one round trip -- 0.257 ms.  Fewer dependent round trips and fewer requests,
-// and slower: what a probe costs is the random LINES it touches beyond the L2 (two per probe there, one here; the displacements are
-// a small hot array), not the length of its chain.
-constexpr uint32_t WORD12_DIRECT = 0x80000000u;
-constexpr uint32_t WORD12_LEN_SHIFT = 24, WORD12_LEN_MASK = 0xFu, WORD12_ID_MASK = 0xFFFFFFu;
-constexpr int WORD12_BUCKETS = 8192;
+// ---- the short-word table: every word of the table above once more, in 16-byte slots (device only, built when the flags above are
+// final) -- what pass 2 of the lookup kernel probes:  slot = {k0, k1, k2, id | len << 24 | SHORTW_DIRECT}, bytes 12..15 of the key
+// in a parallel array k3[slot] that only the 3 % of pre-tokens longer than 12 bytes read (same index: no dependent load).
+// Hash-and-displace with EIGHT-bit displacements over SHORTW_BUCKETS buckets: the 8 KB of displacements sit in the kernel's LDS, so
+// a probe is ONE 16-byte request at ONE random line.  bucket = h1 & (SHORTW_BUCKETS - 1), slot = shortw_slot(h1, key mix, d, mask).
+// How it got there, as measured in round 4 (the table was displacement-in-HBM + one 32-byte slot before: 0.233..0.243 ms for the
+// kernel on C2, 0.44..0.455 on out-of-distribution text): both 32-byte slots of a two-choice table at once -- four requests, ONE
+// round trip -- 0.265 ms; both 16-byte slots of a two-choice table -- two requests, one round trip -- 0.257 ms (profiles/r4i_*,
+// r4j_*): fewer dependent round trips, fewer requests, and slower -- a probe costs the random LINES it touches beyond the L2 (two
+// there, one here), not the length of its chain.  One 16-byte slot behind an LDS displacement: 0.235 / 0.40 ms (r4k_*).
+constexpr uint32_t SHORTW_DIRECT = 0x80000000u;
+constexpr uint32_t SHORTW_LEN_SHIFT = 24, SHORTW_LEN_MASK = 0x1Fu, SHORTW_ID_MASK = 0xFFFFFFu;
+constexpr int SHORTW_BUCKETS = 8192;
 // The slot: double hashing on the displacement -- (base + d * step) & mask, base and step from the key bytes once more.  The table
 // shares the 32-byte table's seed (the kernel hashes a key once), so it cannot answer an unlucky placement with another seed: a
 // displacement that moves every key of a bucket by the SAME amount (the merge table's ph_slot) can never part two keys of a bucket
 // whose bases agree under the mask -- a key-dependent step does, at the next d.
-TK_HD uint32_t word12_kmix(uint32_t k0, uint32_t k1, uint32_t k2) { return (k0 * 0x85EBCA77u) ^ (k1 * 0xC2B2AE3Du) ^ (k2 * 0x27D4EB2Fu); }
-TK_HD uint32_t word12_slot(uint32_t h1, uint32_t kmix, uint32_t d, uint32_t mask) {
+TK_HD uint32_t shortw_kmix(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) { return (k0 * 0x85EBCA77u) ^ (k1 * 0xC2B2AE3Du) ^ (k2 * 0x27D4EB2Fu) ^ (k3 * 0x165667B1u); }
+TK_HD uint32_t shortw_slot(uint32_t h1, uint32_t kmix, uint32_t d, uint32_t mask) {
     const uint32_t base = ((h1 * 0x9E3779B1u) ^ (h1 >> 15)) ^ kmix, step = ((kmix * 0x9E3779B1u) >> 9) | 1u;
     return (base + d * step) & mask;
 }
