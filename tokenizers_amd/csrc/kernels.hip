@@ -42,6 +42,22 @@ __device__ __forceinline__ uint32_t uc_flags(uint32_t cp, const uint16_t* __rest
 
 struct __attribute__((packed, aligned(1))) Unaligned4 { uint32_t v; };
 struct __attribute__((packed, aligned(1))) Unaligned16 { uint32_t a, b, c, d; };      // 16-byte global access at any alignment
+// Streaming accesses (`nt` on the instruction): what a kernel reads or writes ONCE should not push what it keeps probing -- the word
+// table, the claims -- out of the L2.  (The host build of the tests has no such thing: plain accesses.)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t nt_u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ Unaligned16 load_nt16(const uint8_t* p) { const nt_u32x4 v = __builtin_nontemporal_load((const nt_u32x4*)p); return Unaligned16{v.x, v.y, v.z, v.w}; }
+template <class T> __device__ __forceinline__ T load_nt(const T* p) { return __builtin_nontemporal_load(p); }
+template <class T> __device__ __forceinline__ void store_nt(T* p, T v) { __builtin_nontemporal_store(v, p); }
+typedef uint32_t nt_a_u32x4 __attribute__((ext_vector_type(4)));          // (HIP's uint4 / uint2 are structs: the builtin wants vectors)
+typedef uint32_t nt_a_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 load_nt(const uint4* p) { const nt_a_u32x4 v = __builtin_nontemporal_load((const nt_a_u32x4*)p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 load_nt(const uint2* p) { const nt_a_u32x2 v = __builtin_nontemporal_load((const nt_a_u32x2*)p); return make_uint2(v.x, v.y); }
+#else
+__device__ __forceinline__ Unaligned16 load_nt16(const uint8_t* p) { return *(const Unaligned16*)p; }
+template <class T> __device__ __forceinline__ T load_nt(const T* p) { return *p; }
+template <class T> __device__ __forceinline__ void store_nt(T* p, T v) { *p = v; }
+#endif
 // decode the code point whose lead byte is text[i] (text has TKAMD_TEXT_PAD readable slack)
 __device__ __forceinline__ uint32_t utf8_global(const uint8_t* __restrict__ text, int64_t i, uint32_t* len) {
     uint32_t w = ((const Unaligned4*)(text + i))->v;

@@ -77,6 +77,7 @@ struct LookupArgs {
     uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
     uint32_t claim_direct;           // TKAMD_CLAIM_CHAIN=cas (claim_word)
     uint32_t p2_single;              // TKAMD_LU_P2=1 (pass 2)
+    uint32_t stream;                 // the tile's text, masks and tok0 words as non-temporal accesses (TKAMD_LU_NT=0: plain)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -154,9 +155,15 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         if (tile >= n_tiles) return;
         const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
         const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT, gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
-        if (g0 + 16 <= readable) x0 = *(const Unaligned16*)(a.text + g0);
-        if (g1 + 16 <= readable) x1 = *(const Unaligned16*)(a.text + g1);
-        if (tid < 4 && gs + 16 <= readable) xs = *(const Unaligned16*)(a.text + gs);
+        if (a.stream) {                                             // (uniform; TKAMD_LU_NT=0: plain accesses) the tile's text is read once
+            if (g0 + 16 <= readable) x0 = load_nt16(a.text + g0);
+            if (g1 + 16 <= readable) x1 = load_nt16(a.text + g1);
+            if (tid < 4 && gs + 16 <= readable) xs = load_nt16(a.text + gs);
+        } else {
+            if (g0 + 16 <= readable) x0 = *(const Unaligned16*)(a.text + g0);
+            if (g1 + 16 <= readable) x1 = *(const Unaligned16*)(a.text + g1);
+            if (tid < 4 && gs + 16 <= readable) xs = *(const Unaligned16*)(a.text + gs);
+        }
     };
     auto prefetch = [&](int64_t tile) {
         if (PF_TEXT) load_text(tile, pf_t0, pf_t1, pf_ts);
@@ -165,8 +172,13 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         if (tile >= n_tiles) return;
         const int64_t w0 = tile * LU_TILE_WORDS;
         const int64_t w = w0 + hword;
-        if (w < total_words) { pf_ms = a.startmask[w]; pf_wp = a.wprefix[w]; }
-        if (has_end && w < end_words) pf_me = a.endmask[w];
+        if (a.stream) {
+            if (w < total_words) { pf_ms = load_nt(a.startmask + w); pf_wp = load_nt(a.wprefix + w); }
+            if (has_end && w < end_words) pf_me = load_nt(a.endmask + w);
+        } else {
+            if (w < total_words) { pf_ms = a.startmask[w]; pf_wp = a.wprefix[w]; }
+            if (has_end && w < end_words) pf_me = a.endmask[w];
+        }
         pf_first = a.wprefix[w0];
         if (wave == 0) {
             const int64_t ws = w0 + LU_TILE_WORDS + lane;
@@ -291,7 +303,11 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                     }
                 }
                 // (a.fill: the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them)
-                if (hit || (a.fill && miss)) a.tok0[pbase + rb + rel] = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
+                if (hit || (a.fill && miss)) {
+                    const uint32_t w0 = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
+                    if (a.stream) store_nt(a.tok0 + pbase + rb + rel, w0);
+                    else a.tok0[pbase + rb + rel] = w0;
+                }
                 const uint64_t mb = __ballot(miss);
                 if (mb) {                                                           // (wavefront-uniform) the workgroup's miss list
                     uint32_t base = 0u;
@@ -328,7 +344,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         }
                     }
                 }
-                if (v) a.tok0[pbase + rb + rel] = out;
+                if (v) { if (a.stream) store_nt(a.tok0 + pbase + rb + rel, out); else a.tok0[pbase + rb + rel] = out; }
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
@@ -455,9 +471,10 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             // two steps side by side: both probes in flight together (a tile of prose is two steps a wavefront; the 80-register shape
             // has no room for the second step's state)
             constexpr bool TWO = HOT == 2048;
-            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (TWO ? 2u : 1u) * (uint32_t)LU_NT) {
+            const bool pairs = TWO && a.p2_single == 0u;                            // (uniform; TKAMD_LU_P2=1: one step at a time)
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (pairs ? 2u : 1u) * (uint32_t)LU_NT) {
                 P2 x, y;
-                const bool two = TWO && a.p2_single == 0u && m0 + (uint32_t)LU_NT < n_miss;      // wavefront-uniform (TKAMD_LU_P2=1: one step at a time)
+                const bool two = pairs && m0 + (uint32_t)LU_NT < n_miss;            // wavefront-uniform
                 p2_key(m0, x);
                 if (two) p2_key(m0 + (uint32_t)LU_NT, y);
                 p2_done(x);

@@ -45,16 +45,17 @@ template <int CP_ITEMS>
 __device__ __forceinline__ void cp_load_tok0(const uint32_t* __restrict__ tok0, int64_t p0, int64_t P, CpTok0<CP_ITEMS>& f) {
     static_assert(CP_ITEMS == 2 || CP_ITEMS == 4 || CP_ITEMS == 8, "one 8-byte, one or two 16-byte loads of tok0 per lane");
     uint32_t* const first = f.w;
+    // (tok0 is read once: non-temporal, so that the rows the kernel gathers stay in the L2)
     if (p0 + CP_ITEMS <= P) {
         if (CP_ITEMS == 2) {
-            const uint2 a = *(const uint2*)(tok0 + p0);
+            const uint2 a = load_nt((const uint2*)(tok0 + p0));
             first[0] = a.x; first[CP_ITEMS - 1] = a.y;
         } else {
-            const uint4 a = *(const uint4*)(tok0 + p0);
+            const uint4 a = load_nt((const uint4*)(tok0 + p0));
             first[0] = a.x; first[1] = a.y; first[CP_ITEMS > 2 ? 2 : 0] = a.z; first[CP_ITEMS > 3 ? 3 : 0] = a.w;
         }
         if (CP_ITEMS == 8) {
-            const uint4 b = *(const uint4*)(tok0 + p0 + 4);
+            const uint4 b = load_nt((const uint4*)(tok0 + p0 + 4));
             first[CP_ITEMS - 4] = b.x; first[CP_ITEMS - 3] = b.y; first[CP_ITEMS - 2] = b.z; first[CP_ITEMS - 1] = b.w;
         }
     } else {
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
             }
         }
         if (tot <= (uint32_t)CP_STAGE) {
-            for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) ids[base + i] = s_stage[b][i];
+            for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) store_nt(ids + base + i, s_stage[b][i]);
         } else {                                           // rare: too many tokens for the buffer -- scatter from the rows
             const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
             CpRows<CP_ITEMS> r;
