@@ -335,9 +335,8 @@ def test_encode_batch_matches_golden_char_offsets(name):
     {"TKAMD_CLAIMS": "0"},                                                      # every occurrence of a word goes to the model kernels
     {"TKAMD_LEAN_PROLOGUE": "0", "TKAMD_LU_FILL": "0", "TKAMD_CLAIM_ADAPT": "0", "TKAMD_MERGE_ONE": "1"},   # validate / sanitize / mark as kernels of their own, pass 1 stores its hits only, claims that never give up, one merge launch
     {"TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_ONE": "0", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
-    {"TKAMD_HOT_SLOTS": "1024"},                                                # the three-workgroups-per-CU shape of the lookup (1,024 hot slots, 3,072 positions per round, text loaded per tile)
-    {"TKAMD_LU_P2": "1", "TKAMD_LU_NT": "0", "TKAMD_CLAIM_CHAIN": "cas"},       # pass 2 one step at a time, plain (temporal) accesses, claims by plain read -> compare-and-swap
-], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-3-per-cu", "lookup-single-step-plain"])
+    {"TKAMD_HOT_SLOTS": "2048"},                                                # the two-workgroups-per-CU shape of the lookup (2,048 hot slots, the short-word displacements in LDS, pass 2 two steps side by side)
+], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-2-per-cu"])
 def test_alternative_kernels_agree(gpt2_json, variant):
     """The A/B kernel variants (the fallbacks for vocabularies whose new ids are not rank + c, and the earlier generations
     of the pre-tokenizer) must give the same ids and offsets as the oracle: run them in a subprocess because the

@@ -257,7 +257,8 @@ struct tkamd_tokenizer {
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
-    int hot_slots = 2048;        // slots of the hot-word table (kernels/lookup.hip: 2048 = two lookup workgroups per CU, 1024 = three; TKAMD_HOT_SLOTS)
+    int hot_slots = 1024;        // slots of the hot-word table (kernels/lookup.hip: 1024 = three lookup workgroups per CU -- the default since the short-word
+                                 // table made a miss of the hot table cheap: 0.2237 against 0.2279 ms on C2, 0.246 against 0.265 on C3, profiles/r4m_* --, 2048 = two; TKAMD_HOT_SLOTS)
     int cp_grid = 0;             // grid of k_compact: what is resident at once (any grid makes progress -- its look-back helps itself --, TKAMD_CP_GRID)
     // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
     // of the step (the claims' worst case).  Inside a batch every lookup workgroup gives the claims up by itself once
@@ -1871,7 +1872,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         upload_tables(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
-        if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 1024 ? 1024 : 2048;
+        if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 2048 ? 2048 : 1024;
         build_shortw_table(t.get());
         build_hot_table(t.get());
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));

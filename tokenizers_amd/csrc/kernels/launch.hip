@@ -52,12 +52,6 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     LookupArgs a{};
     static const uint32_t adapt = [] { const char* e = getenv("TKAMD_CLAIM_ADAPT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
     a.claim_adapt = adapt;
-    static const uint32_t direct = [] { const char* e = getenv("TKAMD_CLAIM_CHAIN"); return (e && !strcmp(e, "cas")) ? 1u : 0u; }();
-    a.claim_direct = direct;
-    static const uint32_t p2_single = [] { const char* e = getenv("TKAMD_LU_P2"); return (e && !strcmp(e, "1")) ? 1u : 0u; }();
-    a.p2_single = p2_single;
-    static const uint32_t stream = [] { const char* e = getenv("TKAMD_LU_NT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
-    a.stream = stream;
     a.counters = counters;
     a.shortw = (const uint4*)t.shortw;
     a.shortw_mask = t.shortw_mask;

@@ -14,9 +14,10 @@
 // and the Vec<Split> bookkeeping of pre_tokenizer.rs:73-103: the kernel reads the start (/ end) BITMASKS and never needs
 // the pre-token offsets in global memory.
 //
-// One 512-lane workgroup per 16 KB tile of text (256 mask words), two workgroups per CU.  The kernel is bound by vector-ALU issue
-// (a wave64 instruction occupies its SIMD16 for four cycles; all operands sit in LDS), so it is built to spend few instructions
-// per pre-token:
+// One 512-lane workgroup per 16 KB tile of text (256 mask words), three (or two) workgroups per CU.  Passes 1 and the staging are bound
+// by vector-ALU issue (a wave64 instruction occupies its SIMD16 for four cycles; all operands sit in LDS), so they are built to spend
+// few instructions per pre-token; passes 2 and 3 -- two thirds of the kernel's time -- by the random lines they fetch from beyond the
+// L2 (round 4's sessions i-m, tables.hpp): one per probe of the short-word table, two or three per claim.
 //   1. the tile's text (+ 64 bytes), its mask words and their prefix counts are loaded into registers one tile AHEAD and
 //      dropped into LDS when the tile starts;
 //   2. one lane per HALF mask word walks its set bits and drops the positions into an LDS array, indexed by the pre-token's
@@ -24,10 +25,10 @@
 //   3. PASS 1, every pre-token: lane l of a wavefront takes rank 64 c + l of chunk c (chunks dealt round robin to the eight
 //      wavefronts, so the tok0 stores are one 256-byte line per wavefront); the first <= 12 bytes of the key are probed in an LDS
 //      copy of the HOT table -- the lowest-id (= most frequent, the trainers append tokens in frequency order) settled words of
-//      <= 12 bytes, direct mapped, 16-byte slots.  A hit stores its id; a miss costs one more LDS store: its rank goes to the
+//      <= 12 bytes, hash-and-displace, 16-byte slots.  A hit stores its id; a miss costs one more LDS store: its rank goes to the
 //      workgroup's miss list;
-//   4. PASS 2, the misses only, densely packed 64 to a step (a tenth to a fifth of the pre-tokens on natural text): the full
-//      16-byte key in the perfect-hash table in HBM (one displacement load + one 32-byte slot); what still misses is queued by
+//   4. PASS 2, the misses only, densely packed 64 to a step (four to five tenths of the pre-tokens on natural text): the full
+//      16-byte key in the short-word table in HBM (tables.hpp: one 16-byte slot behind an 8-bit displacement); what still misses is queued by
 //      length class: every workgroup appends to its OWN sub-queue of each queue (results.hip) -- the position comes from an
 //      LDS counter, no global atomic -- the queue entry is (start, length), and
 //      the tok0 word of a queued pre-token names the row its result will be written to (results.hip).
@@ -39,13 +40,17 @@ constexpr int LU_TILE = LU_TILE_WORDS * 64;              // bytes of text per ti
 static_assert(LU_TILE == LOOKUP_TILE_BYTES, "the host sizes the sub-queues per tile (capi.cpp queue_sizes)");
 constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile: a key may start at its last byte
 // Two shapes, picked per handle (TKAMD_HOT_SLOTS):
-//   HOT = 2048  hot-word table of 2,048 slots (33 KB), 4,096 pre-tokens expanded per round: 75 KB of LDS, two workgroups per CU
-//   HOT = 1024  1,024 slots (16.5 KB), 3,072 per round (a tile of prose holds ~2,700): 52 KB and <= 80 VGPRs, THREE workgroups per CU --
-//               passes 2 and 3 wait for memory (70 % of the kernel's time, profiles/r4b_*), and more wavefronts hide more of it
+//   HOT = 1024  (default) hot-word table of 1,024 slots (16.5 KB), 3,072 pre-tokens expanded per round (a tile of prose holds ~2,700):
+//               52 KB of LDS and <= 80 VGPRs, THREE workgroups per CU -- passes 2 and 3 wait for memory, and more wavefronts hide more
+//               of it; the short-word displacements are read from memory (a hot 8 KB array), pass 2 takes one step at a time
+//   HOT = 2048  2,048 slots (33 KB; 61 % of C2's pre-tokens hit instead of 50 %), 3,584 per round, the short-word displacements in LDS
+//               (8 KB), pass 2 two steps side by side: 80 KB of LDS, two workgroups per CU.  The default until the short-word table
+//               made a miss of the hot table cheap (profiles/r4m_*: 0.2279 against 0.2237 ms on C2, 0.265 against 0.246 on C3, level on C4
+//               and on out-of-distribution text)
 template <int HOT> struct LuShape {
     static_assert(HOT == 2048 || HOT == 1024, "shapes the launcher knows");
     static constexpr int POS_CAP = HOT == 2048 ? 3584 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
-    static constexpr bool DISP_LDS = HOT == 2048;                  // the 8 KB of WORD12 displacements in LDS (the other shape has no room: it reads them from memory)
+    static constexpr bool DISP_LDS = HOT == 2048;                  // the 8 KB of short-word displacements in LDS (the other shape has no room: it reads them from memory)
     static constexpr int WAVES_PER_SIMD = HOT == 2048 ? 4 : 6;     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU
 };
 constexpr uint32_t CLAIM_ADAPT_MIN = 768u;               // candidates a workgroup looks at before it judges the claims' yield (about two tiles of prose)
@@ -75,9 +80,6 @@ struct LookupArgs {
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
     uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
-    uint32_t claim_direct;           // TKAMD_CLAIM_CHAIN=cas (claim_word)
-    uint32_t p2_single;              // TKAMD_LU_P2=1 (pass 2)
-    uint32_t stream;                 // the tile's text, masks and tok0 words as non-temporal accesses (TKAMD_LU_NT=0: plain)
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
@@ -155,15 +157,11 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         if (tile >= n_tiles) return;
         const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
         const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT, gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
-        if (a.stream) {                                             // (uniform; TKAMD_LU_NT=0: plain accesses) the tile's text is read once
-            if (g0 + 16 <= readable) x0 = load_nt16(a.text + g0);
-            if (g1 + 16 <= readable) x1 = load_nt16(a.text + g1);
-            if (tid < 4 && gs + 16 <= readable) xs = load_nt16(a.text + gs);
-        } else {
-            if (g0 + 16 <= readable) x0 = *(const Unaligned16*)(a.text + g0);
-            if (g1 + 16 <= readable) x1 = *(const Unaligned16*)(a.text + g1);
-            if (tid < 4 && gs + 16 <= readable) xs = *(const Unaligned16*)(a.text + gs);
-        }
+        // (the tile's text, its masks and the tok0 words are read / written once: non-temporal accesses, kernels.hip -- level here, 0.2279
+        // against 0.229 ms, 3 % in the compaction; profiles/r4m_ab_c2.txt)
+        if (g0 + 16 <= readable) x0 = load_nt16(a.text + g0);
+        if (g1 + 16 <= readable) x1 = load_nt16(a.text + g1);
+        if (tid < 4 && gs + 16 <= readable) xs = load_nt16(a.text + gs);
     };
     auto prefetch = [&](int64_t tile) {
         if (PF_TEXT) load_text(tile, pf_t0, pf_t1, pf_ts);
@@ -172,13 +170,8 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         if (tile >= n_tiles) return;
         const int64_t w0 = tile * LU_TILE_WORDS;
         const int64_t w = w0 + hword;
-        if (a.stream) {
-            if (w < total_words) { pf_ms = load_nt(a.startmask + w); pf_wp = load_nt(a.wprefix + w); }
-            if (has_end && w < end_words) pf_me = load_nt(a.endmask + w);
-        } else {
-            if (w < total_words) { pf_ms = a.startmask[w]; pf_wp = a.wprefix[w]; }
-            if (has_end && w < end_words) pf_me = a.endmask[w];
-        }
+        if (w < total_words) { pf_ms = load_nt(a.startmask + w); pf_wp = load_nt(a.wprefix + w); }
+        if (has_end && w < end_words) pf_me = load_nt(a.endmask + w);
         pf_first = a.wprefix[w0];
         if (wave == 0) {
             const int64_t ws = w0 + LU_TILE_WORDS + lane;
@@ -305,8 +298,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 // (a.fill: the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them)
                 if (hit || (a.fill && miss)) {
                     const uint32_t w0 = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
-                    if (a.stream) store_nt(a.tok0 + pbase + rb + rel, w0);
-                    else a.tok0[pbase + rb + rel] = w0;
+                    store_nt(a.tok0 + pbase + rb + rel, w0);
                 }
                 const uint64_t mb = __ballot(miss);
                 if (mb) {                                                           // (wavefront-uniform) the workgroup's miss list
@@ -344,7 +336,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         }
                     }
                 }
-                if (v) { if (a.stream) store_nt(a.tok0 + pbase + rb + rel, out); else a.tok0[pbase + rb + rel] = out; }
+                if (v) store_nt(a.tok0 + pbase + rb + rel, out);
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
@@ -371,18 +363,11 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 // crossing the fabric each time.  A 0 may be stale (the L2 of an XCD keeps what it read whatever another XCD's CAS did since):
                 // the device-scope read confirms it -- and refreshes the line for the next plain read (tools/microbench/claims_probe.hip).
                 unsigned long long c = a.claims[slot];
-                unsigned long long fresh = 1ull;
-                if (a.claim_direct) {                                               // (uniform; TKAMD_CLAIM_CHAIN=cas, an experiment) a 0 goes straight to the compare-and-swap, which returns what it found:
-                    // one round trip less for a step with a first occurrence in it; where the 0 was stale the line is read afresh NEXT to the claimant's bytes
-                    if (c == 0ull) {
-                        c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
-                        if (c != 0ull) fresh = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else {
-                    if (c == 0ull) c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
-                }
-                if (c == 0ull || (uint32_t)(c >> 32) != len || fresh == 0ull) return false;     // (fresh is never 0: a claimed slot stays claimed -- the test only keeps the load)
+                if (c == 0ull) c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
+                // (a 0 straight into the compare-and-swap, the stale line read afresh next to the claimant's bytes: level in distribution,
+                // 0.476 against 0.44 ms on out-of-distribution text -- profiles/r4i_ab_c2*.txt)
+                if (c == 0ull || (uint32_t)(c >> 32) != len) return false;
                 const uint4 kml = s_kmask[min(len, 16u)];
                 const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c);  // (readable: the text carries TEXT_PAD bytes of slack)
                 Unaligned16 o2{0u, 0u, 0u, 0u};
@@ -469,12 +454,12 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
             };
             // two steps side by side: both probes in flight together (a tile of prose is two steps a wavefront; the 80-register shape
-            // has no room for the second step's state)
+            // has no room for the second step's state).  Against one step at a time, same session (profiles/r4m_ab_*.txt): level on C2,
+            // 0.367 against 0.390 ms on out-of-distribution text, 0.246 against 0.253 ms on C4.
             constexpr bool TWO = HOT == 2048;
-            const bool pairs = TWO && a.p2_single == 0u;                            // (uniform; TKAMD_LU_P2=1: one step at a time)
-            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (pairs ? 2u : 1u) * (uint32_t)LU_NT) {
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (TWO ? 2u : 1u) * (uint32_t)LU_NT) {
                 P2 x, y;
-                const bool two = pairs && m0 + (uint32_t)LU_NT < n_miss;            // wavefront-uniform
+                const bool two = TWO && m0 + (uint32_t)LU_NT < n_miss;              // wavefront-uniform
                 p2_key(m0, x);
                 if (two) p2_key(m0 + (uint32_t)LU_NT, y);
                 p2_done(x);
