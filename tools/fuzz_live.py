@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tokenizers_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "tests", "harness", "_libtokenizers_amd_simt.so")
+if os.environ.get("TKAMD_FUZZ_GPU") != "1":             # (TKAMD_FUZZ_GPU=1 on a GPU box: the product library on cuda:0 instead of the emulation)
+    _lib.LIB_PATH = os.path.join(ROOT, "tests", "harness", "_libtokenizers_amd_simt.so")
 import tokenizers as ref  # noqa: E402
 
 import tokenizers_amd as ta  # noqa: E402
