@@ -1231,7 +1231,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         const int64_t Wt = (n_text >> 6) + 1;
         HIP_CHECK(hipMemsetAsync(w->w_boundmask.p, 0, WX * 8, st));
         launch_mark_doc_starts_n(st, doc_csr, n_docs, n_text, len_dev, w->w_boundmask.as<ull>(), d_err);
-        launch_mask_or(st, w->w_boundmask.as<ull>(), w->w_hardmask.as<ull>(), Wt);
+        launch_mask_or(st, w->w_boundmask.as<ull>(), w->w_hardmask.as<ull>(), Wt, n_match);
         w->w_bprefix.reserve((size_t)(Wt + 2) * 4);
         w->w_seg_off.reserve((seg_cap + 2) * 8);
         launch_mask_scan(st, w->w_boundmask.as<ull>(), Wt, w->w_bsum.as<uint32_t>(), w->w_bprefix.as<uint32_t>(), d_nseg);
@@ -1354,7 +1354,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
 
     pf.begin("mark_doc_starts");
     launch_mark_doc_starts_n(st, lean ? raw_doc_off : x_doc_off, n_docs, n_x, x_len_dev, w->w_docmask.as<ull>(), d_err);
-    if (matchmask) launch_mask_or(st, w->w_docmask.as<ull>(), w->w_hardmask.as<ull>(), W);   // match edges are hard boundaries
+    if (matchmask) launch_mask_or(st, w->w_docmask.as<ull>(), w->w_hardmask.as<ull>(), W, n_match);   // match edges are hard boundaries
     pf.end();
 
     uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
@@ -1398,7 +1398,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     if (matchmask)
         launch_apply_matches(st, w->w_startmask.as<ull>(), has_end ? w->w_endmask.as<ull>() : nullptr, matchmask, w->w_spanmask.as<ull>(),
-                             w->w_stopmask.as<ull>(), W);
+                             w->w_stopmask.as<ull>(), W, n_match);
     pf.begin("mask_scan");
     // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
     // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)

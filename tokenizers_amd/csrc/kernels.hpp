@@ -362,9 +362,9 @@ void launch_translate_matches_prefix(hipStream_t st, uint32_t* list, const uint3
                                      const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off);
 void launch_prefix_doc_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, const unsigned long long* bmask, const uint32_t* wprefix, int64_t n_bytes,
                            const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off, int64_t* xdoc_off);
-void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words);
+void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words, const uint32_t* n_list);
 void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
-                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words);
+                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words, const uint32_t* n_list);
 void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
                             const uint32_t* wprefix, uint32_t* tok0);
 // decode_batch: phase 1 (out_bytes_or_null == nullptr) computes lengths / positions / document offsets / *total,

@@ -227,12 +227,12 @@ void launch_prefix_doc_csr(hipStream_t st, const int64_t* doc_off, int64_t n_doc
                            const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off, int64_t* xdoc_off) {
     hipLaunchKernelGGL(k_prefix_doc_csr, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, bmask, wprefix, n_bytes, len_dev, total, xseg_off, xdoc_off);
 }
-void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words) {
-    hipLaunchKernelGGL(k_mask_or, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, src, n_words);
+void launch_mask_or(hipStream_t st, unsigned long long* dst, const unsigned long long* src, int64_t n_words, const uint32_t* n_list) {
+    hipLaunchKernelGGL(k_mask_or, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, src, n_words, n_list);
 }
 void launch_apply_matches(hipStream_t st, unsigned long long* startmask, unsigned long long* endmask, const unsigned long long* matchmask,
-                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words) {
-    hipLaunchKernelGGL(k_apply_matches, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, startmask, endmask, matchmask, spanmask, stopmask, n_words);
+                          const unsigned long long* spanmask, const unsigned long long* stopmask, int64_t n_words, const uint32_t* n_list) {
+    hipLaunchKernelGGL(k_apply_matches, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, startmask, endmask, matchmask, spanmask, stopmask, n_words, n_list);
 }
 void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const uint32_t* n_match, const unsigned long long* startmask,
                             const uint32_t* wprefix, uint32_t* tok0) {

@@ -43,8 +43,9 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
 }
 
 // REGS = 16: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again;
-// REGS = 32: the 17..32-byte queue, four registers (a word of that queue took two dependent loads per trie step and a byte-by-byte
-// char count: 0.062 ms for 3,400 words on C3, profiles/r3_c3_kernel_stats.csv); REGS = 0: any length, from the text
+// REGS = 32 / 64: the 17..32-byte and 33..64-byte queues, four / eight registers (a word of those queues took two dependent loads per
+// trie step and a byte-by-byte char count: 0.062 ms for 3,400 words on C3, profiles/r3_c3_kernel_stats.csv; 0.054 with the first of
+// them in registers, r4_c3_kernel_stats.csv: the launch lasts as long as its longest word); REGS = 0: any length, from the text
 template <int REGS>
 __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t* __restrict__ text, const QView& v, uint4* __restrict__ rows,
                                                uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
@@ -55,14 +56,16 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
         const QItem it = v.q[qpos];
         const uint32_t s = it.s, len = it.len;
         constexpr bool SHORT = REGS != 0;
-        uint64_t lo = 0, hi = 0, lo2 = 0, hi2 = 0;
+        uint64_t lo = 0, hi = 0, lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0, lo4 = 0, hi4 = 0;
         uint32_t chars = 0;
         if (SHORT) {
             load_key16(text, s, min(len, 16u), &lo, &hi);
-            if (REGS == 32 && len > 16u) load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
+            if (REGS >= 32 && len > 16u) load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
+            if (REGS >= 64 && len > 32u) load_key16(text, s + 32u, len - 32u, &lo3, &hi3);
+            if (REGS >= 64 && len > 48u) load_key16(text, s + 48u, len - 48u, &lo4, &hi4);
             // chars = bytes that are not 10xxxxxx continuation bytes (bit 7 set, bit 6 clear)
             auto cont = [](uint64_t x) { return (uint32_t)__popcll(x & 0x8080808080808080ull & ~((x << 1) & 0x8080808080808080ull)); };
-            chars = len - (cont(lo) + cont(hi) + cont(lo2) + cont(hi2));
+            chars = len - (cont(lo) + cont(hi) + cont(lo2) + cont(hi2) + cont(lo3) + cont(hi3) + cont(lo4) + cont(hi4));
         } else {
             for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
         }
@@ -73,7 +76,7 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
             uint32_t node = pos ? 1u : 0u, w = pos, best_end = 0, best_id = 0;
             while (w < len) {
                 uint32_t child, id;
-                const uint64_t word8 = w < 8u ? lo : (w < 16u ? hi : (w < 24u ? lo2 : hi2));
+                const uint64_t word8 = w < 32u ? (w < 8u ? lo : (w < 16u ? hi : (w < 24u ? lo2 : hi2))) : (w < 40u ? lo3 : (w < 48u ? hi3 : (w < 56u ? lo4 : hi4)));
                 const uint32_t byte = SHORT ? (uint32_t)((word8 >> (8u * (w & 7u))) & 0xFFu) : (uint32_t)text[s + w];
                 pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, byte, &child, &id);
                 if (child == RANK_NONE) break;
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256) void k_wordpiece_long3(DevTables t, const uint
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t third = gridDim.x / 3u, which = min(blockIdx.x / third, 2u);
     const QView v = which == 0u ? v1 : (which == 1u ? v2 : v3);
-    // (uniform per workgroup) the 17..32-byte words -- nearly all of them -- walk from registers
+    // (uniform per workgroup) the words of up to 64 bytes -- nearly all of them -- walk from registers
     if (which == 0u) wordpiece_body<32>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, third, s_qpre);
+    else if (which == 1u) wordpiece_body<64>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - third, third, s_qpre);
     else wordpiece_body<0>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - which * third, which == 2u ? gridDim.x - 2u * third : third, s_qpre);
 }
