@@ -1223,7 +1223,12 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     };
     auto scatter_masks = [&](int64_t n_text, const int64_t* len_dev, bool with_end) {
         ull* m4[4] = {w->w_matchmask.as<ull>(), w->w_spanmask.as<ull>(), w->w_stopmask.as<ull>(), w->w_hardmask.as<ull>()};
-        for (ull* m : m4) HIP_CHECK(hipMemsetAsync(m, 0, WX * 8, st));
+        // (one launch for the four; over the RAW text -- no device-side length -- only the words that text has: the masks are sized for the
+        // normalised text's bound, three times that.  Over a text with a device-side length the kernels downstream run over the bound.)
+        const size_t zero_bytes = len_dev ? WX * 8 : std::min(WX, (size_t)(n_text >> 6) + 2) * 8;
+        ZeroRegions z{};
+        for (ull* m : m4) z.add(m, zero_bytes);
+        launch_zero_regions(st, t->n_cu * 4, z);
         launch_scatter_matches(st, mlist, n_match, n_text, len_dev, m4[0], m4[1], m4[2], m4[3], with_end ? w->w_tmp_end.as<uint32_t>() : nullptr);
     };
     // pieces of a text: what lies between document edges and match edges (boundary mask = docmask | hardmask), as an int64 CSR
@@ -1256,7 +1261,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (hm.norm == NORM_BERT || prefix_space) {
         w->w_ntext.reserve((size_t)n_x + TKAMD_TEXT_PAD);
         w->w_ndoc_off.reserve((size_t)(n_docs + 2) * 8);
-        HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
+        // (the prefix-space copy leaves nothing unwritten either, but only the normaliser's path has been taken through the tests without
+        // this memset: k_zero_tail behind launch_bert_normalize zeroes the slack behind the text it wrote)
+        if (hm.norm != NORM_BERT) HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
         if (off_mode != TKAMD_OFFSETS_NONE) {
             w->w_norig.reserve(((size_t)n_x + 4) * 4);
             w->w_norig_e.reserve(((size_t)n_x + 4) * 4);
@@ -1282,6 +1289,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, verbatim, w->w_keepmask.as<uint8_t>(), w->w_kprefix.as<uint32_t>(),
                               w->w_bsum.as<uint32_t>(), w->w_wbase.as<uint32_t>(), d_xlen, w->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e,
                               w->w_ndoc_off.as<int64_t>(), d_err);
+        launch_zero_tail(st, w->w_ntext.as<uint8_t>(), d_xlen, TKAMD_TEXT_PAD);
         pf.end();
         if (have_raw) launch_translate_matches_norm(st, mlist, n_match, w->w_keepmask.as<uint8_t>(), w->w_wbase.as<uint32_t>(), n_bytes, d_xlen);
         x_text = w->w_ntext.as<uint8_t>();

@@ -390,6 +390,7 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                     int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr);
 int compact_grid(int n_cu, int cp_items);
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
+void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n);      // n <= 256 zero bytes at p[*len_dev ..]
 constexpr int COMPACT_CHUNK_MIN = 512;              // pre-tokens per compaction chunk: 256 lanes x cp_items (2, 4 or 8)
 
 }  // namespace tkamd

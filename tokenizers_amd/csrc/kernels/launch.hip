@@ -260,6 +260,9 @@ void launch_bpe_merge_long_only(hipStream_t st, int grid, const DevTables& t, co
                                 uint32_t* list_huge, uint32_t* n_huge) {
     hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, list_huge, n_huge);
 }
+void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n) {
+    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(256), 0, st, p, len_dev, n);
+}
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z) {
     if (z.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(grid), dim3(256), 0, st, z);
 }
