@@ -42,11 +42,8 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
     }
 }
 
-// REGS = 16: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again;
-// REGS = 32 / 64: the 17..32-byte and 33..64-byte queues, four / eight registers (a word of those queues took two dependent loads per
-// trie step and a byte-by-byte char count: 0.062 ms for 3,400 words on C3, profiles/r3_c3_kernel_stats.csv; 0.054 with the first of
-// them in registers, r4_c3_kernel_stats.csv: the launch lasts as long as its longest word); REGS = 0: any length, from the text
-template <int REGS>
+// SHORT: the queue of words of <= 16 bytes -- the word sits in two registers (one 16-byte load), the walk never touches the text again
+template <bool SHORT>
 __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t* __restrict__ text, const QView& v, uint4* __restrict__ rows,
                                                uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
                                                uint32_t block, uint32_t n_blocks, uint32_t* s_qpre) {
@@ -55,17 +52,13 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
         const uint32_t s = it.s, len = it.len;
-        constexpr bool SHORT = REGS != 0;
-        uint64_t lo = 0, hi = 0, lo2 = 0, hi2 = 0, lo3 = 0, hi3 = 0, lo4 = 0, hi4 = 0;
+        uint64_t lo = 0, hi = 0;
         uint32_t chars = 0;
         if (SHORT) {
-            load_key16(text, s, min(len, 16u), &lo, &hi);
-            if (REGS >= 32 && len > 16u) load_key16(text, s + 16u, len - 16u, &lo2, &hi2);
-            if (REGS >= 64 && len > 32u) load_key16(text, s + 32u, len - 32u, &lo3, &hi3);
-            if (REGS >= 64 && len > 48u) load_key16(text, s + 48u, len - 48u, &lo4, &hi4);
+            load_key16(text, s, len, &lo, &hi);
             // chars = bytes that are not 10xxxxxx continuation bytes (bit 7 set, bit 6 clear)
-            auto cont = [](uint64_t x) { return (uint32_t)__popcll(x & 0x8080808080808080ull & ~((x << 1) & 0x8080808080808080ull)); };
-            chars = len - (cont(lo) + cont(hi) + cont(lo2) + cont(hi2) + cont(lo3) + cont(hi3) + cont(lo4) + cont(hi4));
+            const uint64_t cl = lo & 0x8080808080808080ull & ~((lo << 1) & 0x8080808080808080ull), ch = hi & 0x8080808080808080ull & ~((hi << 1) & 0x8080808080808080ull);
+            chars = len - (uint32_t)(__popcll(cl) + __popcll(ch));
         } else {
             for (uint32_t i = 0; i < len; ++i) chars += ((text[s + i] & 0xC0u) != 0x80u);
         }
@@ -76,8 +69,7 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
             uint32_t node = pos ? 1u : 0u, w = pos, best_end = 0, best_id = 0;
             while (w < len) {
                 uint32_t child, id;
-                const uint64_t word8 = w < 32u ? (w < 8u ? lo : (w < 16u ? hi : (w < 24u ? lo2 : hi2))) : (w < 40u ? lo3 : (w < 48u ? hi3 : (w < 56u ? lo4 : hi4)));
-                const uint32_t byte = SHORT ? (uint32_t)((word8 >> (8u * (w & 7u))) & 0xFFu) : (uint32_t)text[s + w];
+                const uint32_t byte = SHORT ? (uint32_t)((w < 8u ? lo >> (8u * w) : hi >> (8u * (w - 8u))) & 0xFFu) : (uint32_t)text[s + w];
                 pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, byte, &child, &id);
                 if (child == RANK_NONE) break;
                 node = child;
@@ -106,12 +98,94 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
         { const uint4 row_ = make_row(j, s, r0, r1, r2, r3); rows[v.row_base + qpos] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
     }
 }
+// The queues of 17..32-byte (G = 32) and 33..64-byte words (G = 64): a few thousand words a batch, and a launch over them lasts as long
+// as its longest word's walk -- one lane per word took 0.054 ms for 3,400 words on C3 (profiles/r4o_c3_kernel_stats.csv), a chain of
+// pieces x steps dependent probes.  Here G lanes share a word and lane p walks the trie FROM BYTE p (the word-initial root for p = 0,
+// the continuation root behind it): every longest match the greedy loop can ask for is found at once, the chain is one walk long, and
+// the loop of wordpiece/mod.rs:245-279 is then a walk over those answers with shuffles -- no memory in it.  (More probes in total,
+// which is why the <= 16-byte queue, 92 k words, keeps one lane per word.)
+template <int G>
+__device__ __forceinline__ void wordpiece_wide(const DevTables& t, const uint8_t* __restrict__ text, const QView& v, uint4* __restrict__ rows,
+                                               uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err,
+                                               uint32_t block, uint32_t n_blocks, uint32_t* s_qpre) {
+    static_assert(G == 32 || G == 64, "half a wavefront or a whole one per word");
+    constexpr uint32_t WPW = 64 / G;                                     // words per wavefront
+    const uint32_t n = qview_prefix(v, s_qpre);
+    const int lane = lane_id();
+    const uint32_t sub = (uint32_t)lane / G, p = (uint32_t)lane % G, gbase = sub * G;
+    const uint32_t wave_global = block * 4u + (threadIdx.x >> 6), n_waves = n_blocks * 4u;
+    for (uint32_t base = wave_global * WPW; base < n; base += n_waves * WPW) {
+        const uint32_t item = base + sub;
+        const bool valid = item < n;
+        uint32_t qpos = 0, s = 0, len = 0;
+        if (valid) { qpos = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qpos]; s = it.s; len = min(it.len, (uint32_t)G); }      // (the queue class bounds the length)
+        // the word in registers (every lane of the group loads the same bytes: one line, broadcast)
+        uint64_t k[G / 8];
+#pragma unroll
+        for (int q = 0; q < G / 16; ++q) {
+            k[2 * q] = k[2 * q + 1] = 0ull;
+            if (valid && len > 16u * q) load_key16(text, s + 16u * q, len - 16u * q, &k[2 * q], &k[2 * q + 1]);
+        }
+        auto cont = [](uint64_t x) { return (uint32_t)__popcll(x & 0x8080808080808080ull & ~((x << 1) & 0x8080808080808080ull)); };
+        uint32_t chars = len;
+#pragma unroll
+        for (int q = 0; q < G / 8; ++q) chars -= cont(k[q]);
+        auto byte_at = [&](uint32_t w) -> uint32_t {                      // (select chain: the array stays in registers)
+            uint64_t x = k[0];
+#pragma unroll
+            for (int q = 1; q < G / 8; ++q) x = (w >> 3) == (uint32_t)q ? k[q] : x;
+            return (uint32_t)(x >> (8u * (w & 7u))) & 0xFFu;
+        };
+        // the longest piece that starts at byte p (a lead byte of the word)
+        uint32_t best_end = 0, best_id = 0;
+        if (valid && p < len && (byte_at(p) & 0xC0u) != 0x80u) {
+            uint32_t node = p ? 1u : 0u, w = p;
+            while (w < len) {
+                uint32_t child, id;
+                pair_probe2(t.trie, t.trie_mask, t.trie_seed, node, byte_at(w), &child, &id);
+                if (child == RANK_NONE) break;
+                node = child;
+                ++w;
+                if (id != 0xFFFFFFFFu) { best_end = w; best_id = id; }
+            }
+        }
+        // the greedy loop over the answers (every lane of the group follows it; lane 0 of the group writes)
+        bool bad = chars > t.max_input_chars;
+        uint32_t pos = 0, j = 0;
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        while (valid && !bad && pos < len) {                              // (uniform within the group: pos, len and the shuffled answers are)
+            const uint32_t e = (uint32_t)__shfl((int)best_end, (int)(gbase + pos), 64), id = (uint32_t)__shfl((int)best_id, (int)(gbase + pos), 64);
+            if (!e) { bad = true; break; }
+            if (j == 0) r0 = id;
+            else if (j == 1) r1 = id;
+            else if (j == 2) r2 = id;
+            else if (j == 3) r3 = id;
+            else if (p == 0u) {
+                if (j == 4) { tmp_ids[s + 1] = r1; tmp_ids[s + 2] = r2; tmp_ids[s + 3] = r3; }
+                tmp_ids[s + j] = id;
+            }
+            if (tmp_end && p == 0u) tmp_end[s + j] = e;
+            pos = e;
+            ++j;
+        }
+        if (valid && p == 0u) {
+            if (bad) {
+                if (!t.has_unk) atomicOr(err, ERR_MISSING_UNK);
+                r0 = t.unk_id;
+                j = 1;
+                if (tmp_end) tmp_end[s] = len;
+            }
+            const uint4 row_ = make_row(j, s, r0, r1, r2, r3);
+            rows[v.row_base + qpos] = row_;
+            TKAMD_PUBLISH_ROW(t, text, s, len, row_);
+        }
+    }
+}
 template <bool SHORT>
 __global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
                                                    uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
     __shared__ uint32_t s_qpre[NSQ + 1];
-    if (SHORT) wordpiece_body<16>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
-    else wordpiece_body<0>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
+    wordpiece_body<SHORT>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
 }
 // the three queues of words longer than 16 bytes in one launch (a third of the grid each): on natural text they hold a few thousand
 // words between them, and a launch costs more than the walk
@@ -119,9 +193,8 @@ __global__ __launch_bounds__(256) void k_wordpiece_long3(DevTables t, const uint
                                                          uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t third = gridDim.x / 3u, which = min(blockIdx.x / third, 2u);
-    const QView v = which == 0u ? v1 : (which == 1u ? v2 : v3);
-    // (uniform per workgroup) the words of up to 64 bytes -- nearly all of them -- walk from registers
-    if (which == 0u) wordpiece_body<32>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, third, s_qpre);
-    else if (which == 1u) wordpiece_body<64>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - third, third, s_qpre);
-    else wordpiece_body<0>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x - which * third, which == 2u ? gridDim.x - 2u * third : third, s_qpre);
+    // (uniform per workgroup)
+    if (which == 0u) wordpiece_wide<32>(t, text, v1, rows, tmp_ids, tmp_end, err, blockIdx.x, third, s_qpre);
+    else if (which == 1u) wordpiece_wide<64>(t, text, v2, rows, tmp_ids, tmp_end, err, blockIdx.x - third, third, s_qpre);
+    else wordpiece_body<false>(t, text, v3, rows, tmp_ids, tmp_end, err, blockIdx.x - 2u * third, gridDim.x - 2u * third, s_qpre);
 }
