@@ -788,10 +788,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
         z.add(w->w_cstate.p, cstate_bytes);
         if (use_claims) {
-            // one slot per 64 bytes of text (a word is a few bytes, most are repeats; two slots to choose from keep the table useful
-            // well past half full), 2^18 .. 2^24 slots: 16 MB of claims + 32 MB of rows for a 120 MB batch
+            // one slot per 64 bytes of the INPUT text (a word is a few bytes, most are repeats), 2^18 .. 2^24 slots: 16 MB of claims +
+            // 32 MB of rows for a 120 MB batch.  (Not of the normalised text's bound, three times that behind BertNormalizer: the
+            // words are the input's, and a table four times the size is four times the zeroing and a quarter of the cache hits.)
             int bits = 18;
-            while (bits < 24 && ((size_t)1 << bits) < (size_t)n_x / 64) ++bits;
+            while (bits < 24 && ((size_t)1 << bits) < (size_t)n_bytes / 64) ++bits;
             claim_slots = (size_t)1 << bits;
             w->w_claims.reserve(claim_slots * 8);
             w->w_claim_rows.reserve(claim_slots * 16);
