@@ -328,6 +328,30 @@ def test_encode_batch_matches_golden_char_offsets(name):
         assert e.word_ids == v["words"][i], doc
 
 
+@pytest.mark.parametrize("name", ["wordlevel_whitespace_c1", "bert_wordpiece_4000"])
+def test_every_whole_word_of_the_vocabulary_is_settled_by_the_tables(name):
+    """The whole-word tables of the lookup kernel (hot table in LDS, the short-word table behind it -- 16-byte slots, bytes 12..15 of a key
+    in a parallel array --, the open-addressing table of the longer entries) must hold EVERY vocabulary entry: a word they lose is not
+    a wrong result for WordPiece (the trie walk finds it again) but a silent loss of the shortcut, and IS a wrong result for WordLevel
+    (wordlevel/mod.rs:162-178: a miss is the unk token).  Every entry made of word characters alone, one per document and all of
+    them in one document: each comes back as exactly its own id, and no word of <= 16 bytes reaches the work queues."""
+    import json
+    import re
+    import tokenizers_amd as ta
+    js = load_tokenizer_json(name)
+    vocab = json.loads(js)["model"]["vocab"]
+    words = [w for w in vocab if re.fullmatch(r"[A-Za-z0-9_]+", w) and (name.startswith("wordlevel") or w == w.lower())]
+    assert len(words) > 500 and any(len(w) > 12 for w in words) and any(len(w) <= 4 for w in words), len(words)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    got = tok.encode_batch_fast(words + [" ".join(words)], add_special_tokens=False)
+    ids, off = np.asarray(got.ids), np.asarray(got.tok_offsets)
+    want = np.array([vocab[w] for w in words], dtype=ids.dtype)
+    assert np.array_equal(off[:len(words) + 1], np.arange(len(words) + 1)), "a vocabulary word came back as more than one token"
+    assert np.array_equal(ids[:len(words)], want) and np.array_equal(ids[len(words):], want)
+    q = tok.queue_sizes()
+    assert q["merge16"] == 0, q       # (no word of <= 16 bytes fell through to a model kernel; the longer ones are queued by design: k_long_vocab probes them there)
+
+
 @pytest.mark.parametrize("variant", [
     {"TKAMD_PRETOK": "bits", "TKAMD_MERGE16": "row", "TKAMD_LDSCFG": "0"},     # ballot pre-tokenizer, DPP-row merge, register lane32
     {"TKAMD_PRETOK": "lds", "TKAMD_MERGE16": "lane", "TKAMD_LDSCFG": "1"},     # lane-per-byte pre-tokenizer, register lane16, LDS lane32

@@ -122,6 +122,12 @@ def test_in_batch_claims_token_csr_and_file_ingest(tmp_path, monkeypatch):
     P.test_claims_pause_while_nothing_is_shared(monkeypatch)
 
 
+def test_the_tables_hold_every_whole_word():
+    from tests import test_parity_gpu as P
+    for name in ("wordlevel_whitespace_c1", "bert_wordpiece_4000"):
+        P.test_every_whole_word_of_the_vocabulary_is_settled_by_the_tables(name)
+
+
 def test_repeated_words_against_the_wheel(ref_tokenizers):
     """The in-batch claims pinned on the reference itself (not only on the oracle): text made of a few dozen words the vocabulary has
     never seen, ASCII and not, 2 to 40 bytes, in random order -- ids, char offsets and word ids of every encoding equal the wheel's
