@@ -299,6 +299,12 @@ def main() -> None:
                     "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
                     "sum_kernels_ms": round(sum(stages.values()), 4), "merge_queue_sizes": tok.queue_sizes()}
+        if traffic:
+            # what the fabric actually carried while the kernel ran (the committed PMC summary's bytes per launch over THIS run's kernel
+            # time): the kernel's distance from the bandwidth roofline on the bytes it fetches, next to `frac` on the bytes it needs
+            roofline["traffic_gbps"] = round(traffic / (stages[dom] * 1e-3) / 1e9, 1)
+            roofline["traffic_frac"] = round(traffic / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+            roofline["traffic_over_algorithmic"] = round(traffic / b_alg, 2)
         # SURVEY 8d's secondary model for the merge kernels: (k - 1) + 2 m merge-table probes for a word of k symbols and m merges,
         # counted by the kernels themselves during this (profiling) pass for the batch that ran last
         qs = roofline["merge_queue_sizes"]
