@@ -90,7 +90,13 @@ while time.time() - t0 < budget:
     if rnd.random() < 0.35:                      # a few added tokens of random shape (their ids follow the reference's rule whatever is written here)
         pool = ["ing", "the", " a", "<x>", "[Y]", "é", "İ", "中", "##s", "ab ", " '", "１", "Ab", "AB", "\n", "a b",
                 "<x", "x>", "<x><y>", "ab", "abc", "b", "bc", "e\u0301", "\u00c9", "  ", "\t", "a", "A", "<X>", "i\u0307", "ı", "ﬁ", "fi", "ǆ"]
+        have = {a["content"] for a in d["added_tokens"]}
         for c in rnd.sample(pool, rnd.randint(1, 6)):
+            # (a content the file already holds, with OTHER properties, is where the 0.22.2 wheel and the reference tree part: the wheel
+            # keeps the stale entry in its pattern lists -- both the old and the new token match --, the tree builds its tries from the
+            # id -> token map, added_vocabulary.rs:379-399: last properties only, which is what the library does.  Found by seed 60602.)
+            if c in have:
+                continue
             d["added_tokens"].append({"id": 0, "content": c, "single_word": rnd.random() < 0.3, "lstrip": rnd.random() < 0.3, "rstrip": rnd.random() < 0.3,
                                       "normalized": rnd.random() < 0.5, "special": rnd.random() < 0.4})
     r = rnd.random()
