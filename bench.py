@@ -160,6 +160,7 @@ def main() -> None:
     ap.add_argument("--gather", action="store_true", help="(kept for old command lines: the gather leg always runs when N > 1)")
     ap.add_argument("--no-gather", action="store_true", help="skip the gather leg")
     ap.add_argument("--force-gather", action="store_true", help="run the gather leg even with one rank (self-test of the RCCL path)")
+    ap.add_argument("--repeat-blocks", type=int, default=5, help="further blocks of K steps timed like the contract's one (min / median / max in `repeat`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
@@ -168,7 +169,7 @@ def main() -> None:
     ap.add_argument("--single-call-gpus", type=int, default=0, help="devices of the single-call leg (0 = every visible GPU)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
-    ap.add_argument("--also", default="c3,c4", help="(N = 1, --config c2 only) further BASELINE configs timed by child runs of this script after the "
+    ap.add_argument("--also", default="c3,c4,c5", help="(N = 1, --config c2 only) further BASELINE configs timed by child runs of this script after the "
                                                      "headline measurement and attached as `other_configs`; 'none' = skip")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json config: c2 GPT-2 BPE (the headline metric, default), c3 BERT WordPiece, "
@@ -245,6 +246,13 @@ def main() -> None:
 
     state = {}
     elapsed = timed(encode)
+    # ---- the same measurement again, `repeat_blocks` times: K steps between the same fences, max over ranks.  The contract's block is
+    # 20 steps of about half a millisecond -- eleven milliseconds; min / median / max over five more say how much of a 2-3 % difference
+    # between two builds is the box (every rank takes part: reduce_max is a collective). ----
+    rep_ms = []
+    for _ in range(max(0, args.repeat_blocks)):
+        el, _ = timed_steps(encode, args.steps, 0, fence, reduce_max, finish_last=lambda b: b.sync())
+        rep_ms.append(el / args.steps * 1e3)
     # ---- the outputs of the timed region: the LAST timed step's ids + token CSR (still in the workspace) must be the result the
     # parity gate vouched for, and so must every step of one more pass over the same K-step sequence (un-timed: the checksum runs
     # on the stream behind each encode) -- with in-batch claims a repeat's result depends on a row another workgroup publishes, so
@@ -269,6 +277,14 @@ def main() -> None:
     tot_bytes, tot_tok, tot_docs, tot_pretok = (float(x) for x in tot.tolist())
     ms_per_step = elapsed / args.steps * 1e3
     gbps = tot_bytes / elapsed / 1e9
+    repeat = None
+    if rep_ms:
+        srt = sorted(rep_ms)
+        med = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        repeat = {"blocks": len(rep_ms), "steps_per_block": args.steps, "ms_per_step": [round(x, 4) for x in rep_ms],
+                  "ms_per_step_min": round(srt[0], 4), "ms_per_step_median": round(med, 4), "ms_per_step_max": round(srt[-1], 4),
+                  "value_median": round(tot_bytes / args.steps / (med * 1e-3) / 1e9, 3), "unit": "GB/s",
+                  "note": "further blocks of K steps, each timed exactly like the contract's block (`ms_per_step` / `value` above are that first block alone)"}
     mtoks = tot_tok / elapsed / 1e6
 
     def finish(gather_obj):
@@ -292,9 +308,12 @@ def main() -> None:
         # algorithmic bytes of the whole path per launch: text in + doc CSR in + ids out + token CSR out
         b_alg = (mine[0] + 8 * (mine[2] + args.steps) + 4 * mine[1] + 8 * (mine[2] + args.steps)) / args.steps
         achieved = b_alg / (stages[dom] * 1e-3) / 1e9
-        traffic = pmc_traffic(dom, args.config)
+        traffic, traffic_source = pmc_traffic(dom, args.config)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    # (traffic is NOT re-measured in this run -- PMC passes need rocprofv3 around the process: it is the committed summary's
+                    # figure for this kernel, per launch; the file and the commit it was taken on)
+                    "traffic_source": traffic_source,
                     "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms": round(stages[dom], 4),
                     "whole_path_frac": round(b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                     "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()},
@@ -508,7 +527,7 @@ def main() -> None:
             "value": round(gbps, 3), "unit": "GB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8->u32", "data": "synthetic",
-            "mtokens_per_s": round(mtoks, 2),
+            "mtokens_per_s": round(mtoks, 2), "repeat": repeat,
             "value_definition": "input text bytes of all ranks / max-over-ranks wall time of the K steps with inputs already resident in HBM "
                                 "when the timed region starts and outputs left in HBM -- the task statement pins `value` to exactly that ("
                                 "'whole-job throughput with inputs already resident in HBM ...; the PCIe-inclusive rate ... is never value'). "
@@ -572,7 +591,8 @@ def other_config_leg(cfg: str, steps: int, warmup: int, n_lines: int, n_batches:
         rf = j.get("roofline") or {}
         return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "mtokens_per_s": j.get("mtokens_per_s"),
                 "steps": j["steps"], "workload": j["config"]["workload"], "parity": j.get("parity"),
-                "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "whole_path_frac", "traffic", "all_kernels_ms")}}
+                "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "whole_path_frac", "traffic", "traffic_source", "all_kernels_ms")},
+                "repeat": j.get("repeat")}
     except subprocess.TimeoutExpired:
         return {"error": f"child killed after {timeout_s} s"}
     except Exception as ex:
@@ -682,21 +702,27 @@ KERNEL_OF_STAGE = {"bpe_merge_lds": "k_bpe_merge_lds<16,", "bpe_merge_lds32": "k
 
 def pmc_traffic(stage: str, config: str = "c2"):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary of this config
-    (profiles/*_pmc_summary.json, written by tools/round_profile.sh): (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
-    MI355X_MICROARCH.md.  None if no PMC run covers the kernel."""
+    (profiles/rN_<config>_pmc_summary.json, written by tools/round_profile.sh): (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
+    MI355X_MICROARCH.md -- and where the figure comes from (file, kernel, commit).  (None, None) if no PMC run covers the kernel."""
     import glob
     try:
-        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{config}*_pmc_summary.json"))) or \
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9]_{config}_pmc_summary.json"))) or \
+            sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{config}*_pmc_summary.json"))) or \
             (sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))) if config == "c2" else [])
         if not paths:
-            return None
+            return None, None
         with open(paths[-1]) as fh:
-            ks = json.load(fh)["kernels"]
+            summary = json.load(fh)
+        ks = summary["kernels"]
         want = KERNEL_OF_STAGE.get(stage, "k_" + stage)
-        k = ks.get(want) or next((v for n, v in ks.items() if n.startswith(want)), None)
-        return int(k["hbm_bytes_per_launch"]) if k else None
+        name, k = (want, ks[want]) if want in ks else next(((n, v) for n, v in ks.items() if n.startswith(want)), (None, None))
+        if not k:
+            return None, None
+        src = {"file": os.path.relpath(paths[-1], ROOT), "kernel": name, "commit": summary.get("commit"),
+               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; (2 * FETCH_SIZE + WRITE_SIZE) per launch (gfx950 correction)"}
+        return int(k["hbm_bytes_per_launch"]), src
     except Exception:
-        return None
+        return None, None
 
 
 _CPU_CHILD = r"""

@@ -16,7 +16,8 @@ from tokenizers import Tokenizer, models, normalizers, pre_tokenizers, trainers
 from oracle import synth
 from oracle.make_golden import emit
 
-NAMES = ["bpe_ws_unk", "bpe_ws_fuse_unk", "bpe_ws_no_unk", "bpe_bert_affixes", "bpe_wssplit_suffix_fuse", "bpe_ws_byte_fallback", "bpe_ws_ignore_merges"]
+NAMES = ["bpe_ws_unk", "bpe_ws_fuse_unk", "bpe_ws_no_unk", "bpe_bert_affixes", "bpe_wssplit_suffix_fuse", "bpe_ws_byte_fallback", "bpe_ws_ignore_merges",
+         "bpe_ws_ignore_merges_no_unk"]
 
 
 def train(pretok, vocab_size=2500, normalizer=None, specials=("[UNK]",), **kw):
@@ -44,9 +45,31 @@ def docs():
     return edge + base + stress + mixed
 
 
+def ignore_merges_no_unk(ws, dd):
+    """ignore_merges WITHOUT an unk_token, and whole words in the vocabulary that hold chars the alphabet lacks: a whole-word hit
+    reports (0, len) (bpe/model.rs:559-567) while a merged word's offsets are running sums that skip the dropped chars."""
+    d = train(ws, specials=())
+    d["model"]["ignore_merges"] = True
+    vocab = d["model"]["vocab"]
+    alphabet = {k for k in vocab if len(k) == 1}
+    whole = ["straße", "Ωmega", "ёж", "aßb", "ß", "weiß", "Ωmegastraßenbahnhof"]          # ("ß" itself: a one-char word is a whole-word hit too)
+    assert all(any(c not in alphabet for c in w) for w in whole if len(w) > 1)
+    nxt = max(vocab.values()) + 1
+    for w in whole:
+        if w != "ß":
+            vocab[w] = nxt
+            nxt += 1
+    extra = ["straße", "die straße ist weiß", "Ωmega ёж aßb", "straßen", "xstraße straßex", "aßb aßbc ßa aß", "ёж ёжик жё", "weiß, weiß! Ωmega?",
+             "ß", "ßß", "a ß b", "Ω", "Ωmegastraßenbahnhof", "der Ωmegastraßenbahnhof ist Ωmegastraßenbahnhofx", "Ωmegastraßenbahnhof Ωmegastraßenbahnhof", "Ωmega" * 3, "straße" * 12, "naïve straße café"]
+    emit("bpe_ws_ignore_merges_no_unk", json.dumps(d, ensure_ascii=False), extra + dd)
+
+
 def main():
     dd = docs()
     ws = pre_tokenizers.Whitespace()
+    if len(sys.argv) > 1 and sys.argv[1] == "ignore_merges_no_unk":      # (the fixture added last: the others stay byte for byte)
+        ignore_merges_no_unk(ws, dd)
+        return
     emit("bpe_ws_unk", json.dumps(train(ws, unk_token="[UNK]"), ensure_ascii=False), dd)
     emit("bpe_ws_fuse_unk", json.dumps(train(ws, unk_token="[UNK]", fuse_unk=True), ensure_ascii=False), dd)
     emit("bpe_ws_no_unk", json.dumps(train(ws, specials=()), ensure_ascii=False), dd)
@@ -64,6 +87,7 @@ def main():
     d = train(ws, unk_token="[UNK]")
     d["model"]["ignore_merges"] = True
     emit("bpe_ws_ignore_merges", json.dumps(d, ensure_ascii=False), dd)
+    ignore_merges_no_unk(ws, dd)
 
 
 if __name__ == "__main__":

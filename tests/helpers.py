@@ -11,7 +11,8 @@ GOLDEN_NAMES = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_
 
 # BPE over characters (no ByteLevel pre-tokenizer): unk_token / fuse_unk / dropped chars / affixes / byte_fallback / ignore_merges
 # (oracle/make_golden_bpe.py)
-BPE_CHAR_GOLDEN = ["bpe_ws_unk", "bpe_ws_fuse_unk", "bpe_ws_no_unk", "bpe_bert_affixes", "bpe_wssplit_suffix_fuse", "bpe_ws_byte_fallback", "bpe_ws_ignore_merges"]
+BPE_CHAR_GOLDEN = ["bpe_ws_unk", "bpe_ws_fuse_unk", "bpe_ws_no_unk", "bpe_bert_affixes", "bpe_wssplit_suffix_fuse", "bpe_ws_byte_fallback", "bpe_ws_ignore_merges",
+                   "bpe_ws_ignore_merges_no_unk"]
 
 
 def load_tokenizer_json(name: str) -> str:

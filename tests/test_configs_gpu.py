@@ -110,10 +110,13 @@ def test_c5_zipf_length_documents_vs_oracle():
     _meta_compare(tok, o, docs[:20000])
 
 
-@pytest.mark.parametrize("config", ["c3", "c4"])
+@pytest.mark.parametrize("config", ["c2", "c3", "c4"])
 def test_full_size_batch_equals_oracle(config):
-    """The batch bench.py --config cN times (1M documents / 120 MB, rank 0's seed), every document against the oracle."""
-    if config == "c3":
+    """The batch bench.py --config cN times (1M documents / 120 MB, rank 0's seed), every document against the oracle.  c2 is the headline
+    config: the very batch the driver's line is quoted on (bench.py gates 2 % of it before it prints; here it is every document)."""
+    if config == "c2":
+        js, docs = synth.load_or_train_gpt2(), synth.gen_lines(1_000_000, text_seed=100)
+    elif config == "c3":
         js, docs = synth.load_or_train_bert(), synth.gen_lines(1_000_000, text_seed=100)
     else:
         js, docs = synth.load_or_train_llama3(), synth.gen_lines(1_000_000, text_seed=100, n_types=250000)

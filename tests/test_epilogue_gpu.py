@@ -217,7 +217,7 @@ def test_overflowing_encodings_survive_a_queue_overflow_rerun():
         "print('OVF', g.n_encodings, g.n_tokens, int(g.ids.astype(np.uint64).sum()), int(g.tok_offsets.sum()), int(g.enc_docs.astype(np.int64).sum()))\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({}, {"TKAMD_Q16_DIV": "100000"}):
+    for env in ({}, {"TKAMD_TEST_HOOKS": "1", "TKAMD_Q16_DIV": "100000"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert "OVF" in r.stdout, r.stdout + r.stderr
         outs.append(r.stdout.strip().splitlines()[-1])

@@ -49,7 +49,7 @@ def test_compaction_makes_progress_at_any_grid(grid, patience):
     for it first), more than twice what the chip holds at once, and a workgroup per chunk forty times over: same result as the
     oracle.  (Under the SIMT emulation the workgroups of a launch run one after the other -- every predecessor that belongs to a
     later workgroup is unpublished for good, and the helper is the only way out.)"""
-    _run(_GRID_CODE, {"TKAMD_CP_GRID": grid, **({"TKAMD_LB_PATIENCE": patience} if patience is not None else {})}, 900, "GRID_OK")
+    _run(_GRID_CODE, {"TKAMD_TEST_HOOKS": "1", "TKAMD_CP_GRID": grid, **({"TKAMD_LB_PATIENCE": patience} if patience is not None else {})}, 900, "GRID_OK")
 
 
 _TWO_STREAMS_CODE = (
@@ -110,7 +110,7 @@ def test_two_compactions_on_two_streams_always_finish(grid):
     hardware deals it out.  Every iteration's ids and token CSR equal the first one's, the four copies of the corpus inside a batch agree, and the
     first 20,000 documents equal the oracle's.  Once more with grids of 3,000 workgroups: more than twice what fits, so second-round
     chunks wait on workgroups that cannot start until the waiting ones have helped themselves out."""
-    _run(_TWO_STREAMS_CODE % 50, {} if grid is None else {"TKAMD_CP_GRID": grid}, 1500, "TWO_STREAMS_OK")
+    _run(_TWO_STREAMS_CODE % 50, {} if grid is None else {"TKAMD_TEST_HOOKS": "1", "TKAMD_CP_GRID": grid}, 1500, "TWO_STREAMS_OK")
 
 
 _HOST_CODE = (

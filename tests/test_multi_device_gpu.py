@@ -150,7 +150,7 @@ def test_rccl_that_cannot_be_opened_falls_back_to_peer_copies():
         "    assert np.array_equal(got.ids, one.ids) and np.array_equal(got.tok_offsets, one.tok_offsets) and np.array_equal(got.offsets, one.offsets)\n"
         "assert len(many.shard_stats()) == 3\n"
         "print('FALLBACK_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_RCCL_LIB="/nonexistent/librccl.so", TKAMD_SHARD_MIN_KB="8"),
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_TEST_HOOKS="1", TKAMD_RCCL_LIB="/nonexistent/librccl.so", TKAMD_SHARD_MIN_KB="8"),
                        capture_output=True, text=True, timeout=600)
     assert "FALLBACK_OK" in r.stdout, r.stdout + r.stderr
     assert r.stderr.count("falls back to TKAMD_COLLECT_ROOT_P2P") == 1 and "could not be opened" in r.stderr, r.stderr

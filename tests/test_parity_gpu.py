@@ -355,10 +355,10 @@ def test_every_whole_word_of_the_vocabulary_is_settled_by_the_tables(name):
 @pytest.mark.parametrize("variant", [
     {"TKAMD_PRETOK": "bits", "TKAMD_MERGE16": "row", "TKAMD_LDSCFG": "0"},     # ballot pre-tokenizer, DPP-row merge, register lane32
     {"TKAMD_PRETOK": "lds", "TKAMD_MERGE16": "lane", "TKAMD_LDSCFG": "1"},     # lane-per-byte pre-tokenizer, register lane16, LDS lane32
-    {"TKAMD_Q16_DIV": "100000"},                                                # a work queue far too small: the batch overflows it and is run again
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_Q16_DIV": "100000"},                                                # a work queue far too small: the batch overflows it and is run again
     {"TKAMD_CLAIMS": "0"},                                                      # every occurrence of a word goes to the model kernels
     {"TKAMD_LEAN_PROLOGUE": "0", "TKAMD_LU_FILL": "0", "TKAMD_CLAIM_ADAPT": "0", "TKAMD_MERGE_ONE": "1"},   # validate / sanitize / mark as kernels of their own, pass 1 stores its hits only, claims that never give up, one merge launch
-    {"TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_ONE": "0", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_ONE": "0", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
     {"TKAMD_HOT_SLOTS": "2048"},                                                # the two-workgroups-per-CU shape of the lookup (2,048 hot slots, the short-word displacements in LDS, pass 2 two steps side by side)
 ], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-2-per-cu"])
 def test_alternative_kernels_agree(gpt2_json, variant):
@@ -1096,3 +1096,105 @@ def test_bpe_over_characters_corners(ref_tokenizers):
                        ({"vocab": dict({"a": 0, "##a": 300}, **{"<0x%02X>" % b: 1 + b for b in range(256)}), "merges": [], "byte_fallback": True, "continuing_subword_prefix": "##"}, "byte_fallback together")):
         with pytest.raises(ta.UnsupportedError, match=why):
             ta.Tokenizer.from_str(tj(model), device=0)
+
+
+def test_a_malformed_csr_through_the_sliced_host_entry_is_refused_on_the_host():
+    """The host entry cuts slices from the CALLER's doc_offsets (a binary search) and copies text + doc_offsets[d0] .. from HOST memory before
+    the device sees the slice: a CSR that is not monotone must be refused there -- nothing outside the caller's buffer is read (the
+    ASan variant of the SIMT build would say so) -- exactly as encode_host_sharded refuses it.  1 MB slices so that a 6 MB batch is cut
+    (8 KB slices for the few hundred lines the SIMT emulation runs)."""
+    import os
+    import subprocess
+    import sys
+    slice_kb = 1024 if N(50000) == 50000 else 8
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, tokenizers_amd as ta\n"
+        "from oracle import synth\n"
+        "docs = synth.gen_lines(50000, text_seed=63)\n"
+        "tk = ta.Tokenizer.from_str(synth.load_or_train_gpt2(), device=0)\n"
+        "buf, off = ta.pack_documents(docs)\n"
+        "want = tk.encode_packed(buf, off)\n"
+        "want = (np.array(want.ids, copy=True), np.array(want.tok_offsets, copy=True))\n"
+        "n, d = int(off[-1]), len(docs)\n"
+        "assert n > 4 * (%d << 10)\n"
+        "bad_cases = []\n"
+        "for lo, hi, value in ((d // 4, d // 2, n + (1 << 30)), (d // 4, 3 * d // 4, -(1 << 33)), (d // 2 - 3, d // 2 + 3, 1 << 41), (d // 3, d // 3 + 1, n)):\n"
+        "    bad = off.copy(); bad[lo:hi] = value; bad_cases.append(bad)\n"
+        "rng = np.random.default_rng(5)\n"
+        "for _ in range(6):\n"
+        "    bad = off.copy(); k = rng.integers(1, d - 1, size=40); bad[k] = rng.integers(-(1 << 40), 1 << 40, size=40); bad_cases.append(bad)\n"
+        "for bad in bad_cases:\n"
+        "    try:\n"
+        "        tk.encode_packed(buf, bad)\n"
+        "    except ValueError as e:\n"
+        "        assert 'monotone CSR' in str(e), e\n"
+        "    else:\n"
+        "        raise AssertionError('a malformed CSR went through')\n"
+        "got = tk.encode_packed(buf, off)\n"
+        "assert np.array_equal(got.ids, want[0]) and np.array_equal(got.tok_offsets, want[1])\n"
+        "print('SLICED_CSR_OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), slice_kb)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_TEST_HOOKS="1", TKAMD_HOST_SLICE_KB=str(slice_kb)), capture_output=True, text=True, timeout=900)
+    assert "SLICED_CSR_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["bert_wordpiece_4000", "bert_wordpiece_4000_added", "bpe_bert_affixes"])
+def test_nothing_reads_the_normalised_text_beyond_its_device_length(name):
+    """BertNormalizer's output buffer is sized by the host's bound (3 x the input) and only the TEXT_PAD bytes behind the text the kernel
+    wrote are zeroed: every later stage must bound its reads by the DEVICE length.  With the buffer poisoned (0xFF) before every batch
+    (test hook TKAMD_POISON_NTEXT) the golden vectors still come out -- a long batch first, so that a short one finds stale text too."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import tokenizers_amd as ta\n"
+        "from tests.helpers import load_tokenizer_json, load_vectors\n"
+        "name = %r\n"
+        "tok = ta.Tokenizer.from_str(load_tokenizer_json(name), device=0)\n"
+        "v = load_vectors(name)\n"
+        "for sl in (slice(None), slice(0, 40), slice(40, 43), slice(None, None, 7)):\n"
+        "    docs = v['docs'][sl]\n"
+        "    got = tok.encode_batch(docs, add_special_tokens=False)\n"
+        "    for i, e in enumerate(got):\n"
+        "        assert e.ids == v['ids'][sl][i], docs[i]\n"
+        "        assert [list(x) for x in e.offsets] == v['offsets_char'][sl][i], docs[i]\n"
+        "        assert e.word_ids == v['words'][sl][i], docs[i]\n"
+        "print('POISON_OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), name)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_TEST_HOOKS="1", TKAMD_POISON_NTEXT="1"), capture_output=True, text=True, timeout=900)
+    assert "POISON_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_one_added_content_listed_twice_follows_the_tree():
+    """An `added_tokens` list that names ONE content twice with different properties: the tree rebuilds its matching tries from the
+    id -> token map (added_vocabulary.rs:379-399), so the content keeps its FIRST id and its LAST properties and sits in exactly one of
+    the two pattern lists.  The 0.22.2 wheel also keeps the stale first entry in its lists (version skew), so the
+    checker here is the oracle, which restates the tree (tests/test_oracle.py::test_added_token_id_assignment_restated pins the
+    assignment): ids, offsets and word ids, with the duplicate differing in rstrip, in lstrip + single_word, and in `normalized`
+    (the case tools/fuzz_live.py found) -- behind no normalizer and behind BertNormalizer."""
+    import json
+    import tokenizers_amd as ta
+    A = lambda i, c, **k: dict({"id": i, "content": c, "single_word": False, "lstrip": False, "rstrip": False, "normalized": False, "special": False}, **k)
+    cases = [
+        ("gpt2_synth_50257", [A(70000, "<|a|>", special=True), A(70001, "<|b|>", special=True), A(70002, "<|a|>", rstrip=True, special=True)],
+         ["x <|a|>   y<|b|> z", "<|a|> <|a|>", "<|a|>\t\n<|b|>  <|a|>"]),
+        ("gpt2_synth_50257", [A(70000, "  ", normalized=False), A(70001, "zz"), A(70002, "  ", normalized=True)],
+         ["a  b   c    d", "  ", "zz  zz", "x   y  "]),
+        ("gpt2_synth_50257", [A(70000, "  ", normalized=True), A(70001, "zz", normalized=True), A(70002, "  ", normalized=False, lstrip=True)],
+         ["a  b   c    d", "  ", "zz  zz", "x   y  "]),
+        ("bert_wordpiece_4000", [A(5000, "New York", normalized=True), A(5001, "[ENT]", special=True), A(5002, "New York", normalized=False, single_word=True)],
+         ["new york New York NEW YORK", "in New York, and New Yorker", "[ENT]New York[ENT] new york"]),
+        ("bert_wordpiece_4000", [A(5000, "New York", normalized=False, single_word=True), A(5002, "New York", normalized=True)],
+         ["new york New York NEW YORK", "in New York, and New Yorker", "xNew York new yorkx"]),
+    ]
+    for name, added, docs in cases:
+        d = json.loads(load_tokenizer_json(name))
+        d["added_tokens"] = added
+        js = json.dumps(d, ensure_ascii=False)
+        tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+        got = tok.encode_batch(docs, add_special_tokens=False)
+        exp = o.encode_batch(docs, char_offsets=True)
+        for i, e in enumerate(got):
+            assert e.ids == list(exp.doc_ids(i)), (name, added, docs[i])
+            assert [tuple(x) for x in e.offsets] == [tuple(x) for x in exp.doc_offsets(i)], (name, added, docs[i])
+            assert [w for w in e.word_ids] == list(exp.doc_words(i)), (name, added, docs[i])

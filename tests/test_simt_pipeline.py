@@ -185,6 +185,7 @@ def test_overflow_epilogue_reruns_after_a_queue_overflow(monkeypatch):
     d["truncation"] = {"direction": "Left", "max_length": 20, "strategy": "LongestFirst", "stride": 3}
     docs = synth.gen_lines(300, text_seed=77, type_seed=1)
     want = ta.Tokenizer.from_str(json.dumps(d), device=0).encode_batch_csr(docs, overflowing=True)
+    monkeypatch.setenv("TKAMD_TEST_HOOKS", "1")
     monkeypatch.setenv("TKAMD_Q16_DIV", "100000")
     tiny = ta.Tokenizer.from_str(json.dumps(d), device=0)
     for overflowing in (True, False):
@@ -230,6 +231,7 @@ def test_a_batch_whose_queue_rows_reach_bit_30_is_refused():
     for bits, want in ((None, "TOOK_IT"), ("18", "REFUSED")):
         env = dict(os.environ, TKAMD_SIMT="1")
         if bits:
+            env["TKAMD_TEST_HOOKS"] = "1"
             env["TKAMD_ROW_LIMIT_BITS"] = bits
         site = os.path.join(ROOT, "tests", "harness", "simt_site")
         env["PYTHONPATH"] = site + os.pathsep + env.get("PYTHONPATH", "")

@@ -38,6 +38,14 @@ int set_error(int code, const std::string& msg) {
     return code;
 }
 
+// Environment switches that exist for the TESTS alone (a compaction grid no launch would pick, a look-back without patience, a work queue
+// far too small, a lowered row limit, a RCCL library that is not there, poisoned scratch text) change launch shapes or skip a check: they
+// are read only when TKAMD_TEST_HOOKS=1 is set as well, so that a stray variable in a production environment changes nothing.
+const char* test_hook(const char* name) {
+    static const bool on = [] { const char* e = getenv("TKAMD_TEST_HOOKS"); return e && !strcmp(e, "1"); }();
+    return on ? getenv(name) : nullptr;
+}
+
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
@@ -84,7 +92,7 @@ RcclApi& rccl_api() {
     static RcclApi api = [] {
         RcclApi a;
         // TKAMD_RCCL_LIB: another library name to open (tests name one that does not exist: the error path without uninstalling RCCL)
-        const char* const over = getenv("TKAMD_RCCL_LIB");
+        const char* const over = test_hook("TKAMD_RCCL_LIB");
         std::string last = "?";
         for (const char* name : {over ? over : "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             a.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
@@ -247,7 +255,7 @@ struct tkamd_tokenizer {
     std::vector<std::unique_ptr<Workspace>> pool;
     Workspace* last_used = nullptr;      // workspace of the most recent call (diagnostics: tkamd_profile_counters)
     // tables
-    DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_words, t_long_blob, t_long_off, t_long_id, t_long_table;
+    DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
     DevBuf t_shortw, t_shortw_k3, t_shortw_disp;   // the short-word table: 16-byte slots, key bytes 12..15, eight-bit displacements (tables.hpp SHORTW_*)
     DevBuf t_char_id;            // BPE over characters: HostModel::char_id
@@ -399,7 +407,8 @@ void upload_tables(tkamd_tokenizer* t) {
     upload(t->t_byte_id, bid);
     upload(t->t_merges, hm.merge_table);
     upload(t->t_merge_disp, hm.merge_disp);
-    upload(t->t_words, hm.word_table, 64);
+    // (the two-choice whole-word table stays on the HOST: it is the copy of record build_shortw_table and tkamd_probe_word read; the
+    // device probes the short-word table made from it)
     if (hm.decoder != DEC_UNSUPPORTED) {
         upload(t->t_dec_entry, hm.dec_entry, 64);
         upload(t->t_dec_blob, hm.dec_blob, 64);
@@ -442,8 +451,6 @@ void upload_tables(tkamd_tokenizer* t) {
     d.newid_affine = hm.merge_newid_affine ? 1u : 0u;
     d.newid_base = hm.merge_newid_base;
     d.merge_bmask = hm.merge_bmask;
-    d.words = t->t_words.as<WordSlot>();
-    d.word_mask = hm.word_mask;
     d.word_seed = hm.word_seed;
     d.ignore_merges = hm.ignore_merges ? 1u : 0u;
     d.long_probe_max_len = 0xFFFFFFFFu;
@@ -531,8 +538,6 @@ void verify_direct_words(tkamd_tokenizer* t) {
         else s.flags &= ~WORD_DIRECT;
     }
     t->n_direct = nd;
-    upload(t->t_words, hm.word_table, 64);
-    t->dt.words = t->t_words.as<WordSlot>();
 }
 
 // The short-word table (tables.hpp): what pass 2 of the lookup probes.  Built from the 32-byte table (the host's copy of record) once
@@ -1265,6 +1270,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         // (the prefix-space copy leaves nothing unwritten either, but only the normaliser's path has been taken through the tests without
         // this memset: k_zero_tail behind launch_bert_normalize zeroes the slack behind the text it wrote)
         if (hm.norm != NORM_BERT) HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0, (size_t)n_x + TKAMD_TEXT_PAD, st));
+        // test hook TKAMD_POISON_NTEXT (with TKAMD_TEST_HOOKS=1): the normaliser's output buffer starts every batch as 0xFF, so a kernel that
+        // reads it beyond *x_len + TEXT_PAD -- bounded by the host's n_x instead of the device length -- changes a result instead of
+        // meeting zeros an earlier batch or the allocator happened to leave (tests/test_parity_gpu.py runs the BertNormalizer fixtures so)
+        else if (test_hook("TKAMD_POISON_NTEXT")) HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0xFF, (size_t)n_x + TKAMD_TEXT_PAD, st));
         if (off_mode != TKAMD_OFFSETS_NONE) {
             w->w_norig.reserve(((size_t)n_x + 4) * 4);
             w->w_norig_e.reserve(((size_t)n_x + 4) * 4);
@@ -1431,7 +1440,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     const size_t N = (size_t)n_x;
     const QueueSizes qz = queue_sizes(N, t->q16_div, lookup_grid(t));
     // (TKAMD_ROW_LIMIT_BITS: a test lowers the threshold -- never the 30 bits tok0 really has -- to see the refusal without a 3 GB batch)
-    static const size_t row_limit = [] { const char* e = getenv("TKAMD_ROW_LIMIT_BITS"); return e ? std::min<size_t>((size_t)1 << std::max(8, atoi(e)), ROW_INDEX_LIMIT) : (size_t)ROW_INDEX_LIMIT; }();
+    static const size_t row_limit = [] { const char* e = test_hook("TKAMD_ROW_LIMIT_BITS"); return e ? std::min<size_t>((size_t)1 << std::max(8, atoi(e)), ROW_INDEX_LIMIT) : (size_t)ROW_INDEX_LIMIT; }();
     if (qz.total >= row_limit) throw Invalid("batch too large for the work queues (row indices are 30-bit: about 3 GB of text): split it");
     QueuePlan plan{};
     for (int c = 0; c < 4; ++c) {
@@ -1676,7 +1685,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.norig_e = norig_e;
         a.byte_level = hm.byte_level;
         a.snap_chars = hm.byte_level || hm.char_bpe;
-        if (hm.char_bpe && !hm.unk_configured && !hm.byte_fallback) { a.char_id = t->dt.char_id; a.cb = t->dt.cb; }      // (chars can be dropped: offsets are running sums)
+        if (hm.char_bpe && !hm.unk_configured && !hm.byte_fallback) {      // (chars can be dropped: offsets are running sums)
+            a.char_id = t->dt.char_id;
+            a.cb = t->dt.cb;
+            if (hm.ignore_merges) { a.ww_tok0 = w->w_tok0.as<uint32_t>(); a.ww_rows = w->w_rows.p; a.ww_crows = wc.rows; }      // (... but not on a whole-word hit)
+        }
         a.trim_offsets = hm.trim_offsets;
         a.trim_matches_only = !hm.byte_level;            // (a model that is not byte-level: only an added token's slice can hold what is trimmed; the loader checked the vocabulary)
         a.pp_add_prefix_space = hm.pp_add_prefix_space;
@@ -1877,7 +1890,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         hipDeviceProp_t prop;
         HIP_CHECK(hipGetDeviceProperties(&prop, device));
         t->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (const char* e = getenv("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
+        if (const char* e = test_hook("TKAMD_Q16_DIV")) t->q16_div = (uint32_t)std::max(1, atoi(e));     // test hook: start with a tiny queue
         upload_tables(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
@@ -1887,7 +1900,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
         t->cp_grid = compact_grid(t->n_cu, t->cp_items);
-        if (const char* e = getenv("TKAMD_CP_GRID")) t->cp_grid = std::max(1, atoi(e));      // test hook: an over- / under-subscribed compaction
+        if (const char* e = test_hook("TKAMD_CP_GRID")) t->cp_grid = std::max(1, atoi(e));      // test hook: an over- / under-subscribed compaction
         t->devices.push_back(device);
     }
     return t;
@@ -1952,7 +1965,7 @@ int tkamd_tokenizer_from_json_devices(const char* json, size_t json_len, const i
 
 int tkamd_tokenizer_set_collect(tkamd_tokenizer* t, int mode) {
     if (!t || mode < TKAMD_COLLECT_HOST || mode > TKAMD_COLLECT_ROOT_RCCL) return set_error(TKAMD_ERR_INVALID, "bad argument");
-    if (mode == TKAMD_COLLECT_ROOT_RCCL && !getenv("TKAMD_RCCL_LIB")) {     // (TKAMD_RCCL_LIB: a test naming a library that is not there -- the call never reaches RCCL)
+    if (mode == TKAMD_COLLECT_ROOT_RCCL && !test_hook("TKAMD_RCCL_LIB")) {     // (the test hook TKAMD_RCCL_LIB names a library that is not there: the call never reaches RCCL)
         std::vector<int> seen;
         for (int d : t->devices) {
             if (std::find(seen.begin(), seen.end(), d) != seen.end()) return set_error(TKAMD_ERR_INVALID, "TKAMD_COLLECT_ROOT_RCCL: a device is named twice (RCCL wants one rank per GPU)");
@@ -2384,9 +2397,14 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
         const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;            // sequences per encoding
         if (n_grp % unit) throw Invalid("TKAMD_PAIRS: an odd number of sequences");
-        static const int64_t slice_bytes = [] { const char* e = getenv("TKAMD_HOST_SLICE_MB"); return (int64_t)(e ? atoi(e) : 16) << 20; }();
+        // (test hook TKAMD_HOST_SLICE_KB: slices small enough for the batches the SIMT emulation can run)
+        static const int64_t slice_bytes = [] {
+            if (const char* k = test_hook("TKAMD_HOST_SLICE_KB")) return (int64_t)std::max(4, atoi(k)) << 10;
+            const char* e = getenv("TKAMD_HOST_SLICE_MB");
+            return (int64_t)std::max(1, e ? atoi(e) : 16) << 20;
+        }();
         constexpr int MAX_SLICES = 16;
-        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / std::max<int64_t>(slice_bytes, 1 << 20));
+        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / slice_bytes);
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
@@ -2452,8 +2470,12 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         auto issue = [&](int k) {
             Workspace* w = ws[k & 1];
             hipStream_t s = st[k & 1];
-            const int64_t d0 = doc_of(cut[k]), d1 = doc_of(cut[k + 1]), b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
-            if (nb < 0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+            const int64_t d0 = doc_of(cut[k]), d1 = doc_of(cut[k + 1]);
+            if (d0 < 0 || d1 < d0 || d1 > n_docs) throw Invalid(words_in ? "seq_offsets is not a monotone CSR over [0, n_words]" : "doc_offsets is not a monotone CSR over [0, n_bytes]");
+            const int64_t b0 = doc_offsets[d0], nb = doc_offsets[d1] - b0;
+            // (the cuts came from a binary search over the caller's array: a CSR that is not monotone gives any cut at all, and the copy
+            // below reads text + b0 .. + nb on the HOST, before the device validation sees the slice -- like encode_host_sharded)
+            if (nb < 0 || b0 < 0 || b0 > n_bytes || nb > n_bytes - b0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
             const int64_t g0 = cut[k], g1 = cut[k + 1];
             if (words_in) w->h_seq_off.reserve((size_t)(g1 - g0 + 1) * 8);
             w->h_text.reserve((size_t)nb + TKAMD_TEXT_PAD);

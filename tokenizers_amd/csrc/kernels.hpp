@@ -25,9 +25,8 @@ struct DevTables {
     const unsigned long long* pub_claims;
     void* pub_rows;
     uint32_t pub_mask;
-    const WordSlot* words;            // two-choice table (tables.hpp): a key sits in word_slot_a or word_slot_b of its hash
-    uint32_t word_mask, word_seed;
-    const void* shortw;               // the short-word table (tables.hpp): every word of `words` in 16-byte slots, same seed
+    uint32_t word_seed;               // seed of the whole-word hashes (the two-choice table of record lives on the host, tables.hpp)
+    const void* shortw;               // the short-word table (tables.hpp): every whole word of <= 16 bytes in 16-byte slots
     const uint32_t* shortw_k3;        // bytes 12..15 of the key in slot i
     const uint8_t* shortw_disp;       // [SHORTW_BUCKETS] eight-bit displacements (the lookup kernel keeps them in LDS)
     uint32_t shortw_mask;
@@ -128,6 +127,11 @@ struct MetaArgs {
                                       // sums of symbol lengths, which cut chars behind a dropped char or inside byte_fallback's one-byte symbols)
     const uint32_t* char_id;          // BPE over characters WITHOUT an unk_token: chars the vocabulary lacks are dropped and every offset behind them
     uint32_t cb;                      // moves up -- k_token_meta subtracts the dropped bytes in front of every token edge (null / 0: nothing is ever dropped)
+    // ... except on a WHOLE-WORD hit of ignore_merges, which reports (0, len) whatever the word holds (bpe/model.rs:559-567).  Set only when
+    // both are on: the tok0 words (TOK_ONE: the lookup's hit) and the rows / claimed rows (a long word's hit carries ROW_WHOLE_WORD)
+    const uint32_t* ww_tok0;
+    const void* ww_rows;
+    const void* ww_crows;
     const unsigned long long* matchmask;  // added-token matches (their offsets trim real whitespace chars), or null
     const uint16_t* uc1;
     const uint8_t* uc2;

@@ -285,7 +285,12 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
     unsigned long long* const ph = (unsigned long long*)phases;
     // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); TKAMD_LB_PATIENCE: tests set it to a
     // handful so that the helping path runs on every wait
-    static const uint32_t patience = [] { const char* e = getenv("TKAMD_LB_PATIENCE"); return e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE; }();
+    // (a test hook: read only next to TKAMD_TEST_HOOKS=1, like the ones of capi.cpp)
+    static const uint32_t patience = [] {
+        const char* const on = getenv("TKAMD_TEST_HOOKS");
+        const char* e = (on && !strcmp(on, "1")) ? getenv("TKAMD_LB_PATIENCE") : nullptr;
+        return e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE;
+    }();
     if (ph && cp_items == 4)                                 // the diagnostic instantiation (TKAMD_PHASES)
         hipLaunchKernelGGL((k_compact<4, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
                            chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);

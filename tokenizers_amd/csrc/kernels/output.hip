@@ -323,9 +323,16 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         // BPE over characters without an unk_token: a char the vocabulary lacks leaves no symbol, and the reference's token offsets are
         // running sums of the symbols' lengths (word.rs:260-268) -- every edge behind a dropped char moves up by its bytes.  The model
         // kernels report edges as positions; the dropped bytes in front of each edge are counted here, walking the word once.
+        // (not on a whole-word hit of ignore_merges: vocab.get(sequence) reports (0, sequence.len()), bpe/model.rs:559-567)
+        bool whole_word = false;
+        if (a.ww_tok0 && c == 1) {
+            const uint32_t t0 = a.ww_tok0[p];
+            if ((t0 & TOK_SLOT) == TOK_ONE) whole_word = true;
+            else if (t0 & TOK_ROW) whole_word = (((t0 & TOK_ONE) ? (const uint4*)a.ww_crows : (const uint4*)a.ww_rows)[t0 & TOK_REF_MASK]).y == ROW_WHOLE_WORD;
+        }
         uint32_t dq = s, dropped = 0u;
         auto running = [&](uint32_t rel_pos) -> uint32_t {
-            if (!a.char_id) return rel_pos;
+            if (!a.char_id || whole_word) return rel_pos;
             const uint32_t target = s + rel_pos;
             while (dq < target) {
                 uint32_t l;

@@ -20,6 +20,7 @@ constexpr uint32_t TOK_ONE = 0x40000000u;
 constexpr uint32_t TOK_ID_MASK = 0x00FFFFFFu;
 constexpr uint32_t TOK_SLOT = TOK_ROW | TOK_ONE, TOK_REF_MASK = 0x3FFFFFFFu;
 constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
+constexpr uint32_t ROW_WHOLE_WORD = 0xFFFFFFFFu;      // word 1 of a ONE-token row (unused otherwise): a whole-word vocabulary hit of k_long_vocab, not a merge result (k_token_meta)
 
 // one queued pre-token: first byte and length (the model kernels need nothing else)
 struct __attribute__((aligned(8))) QItem { uint32_t s, len; };

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
             else atomicOr(err, ERR_MISSING_UNK);
         }
         if (hit || miss_is_unk) {
-            const uint4 row = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), 0u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 row = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), ROW_WHOLE_WORD, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
             rows[v.row_base + qpos] = row;
             if (claims) claim_publish_item(text, t.word_seed, it.s, it.len, row, claims, claim_mask, crows);
             v.q[qpos].len = 0u;

@@ -77,10 +77,10 @@ TK_HD uint32_t ph_slot(uint32_t h2, uint32_t d, uint32_t mask) { return (h2 + mu
 // ---- whole-word table: raw pre-token bytes (<= 16) -> token id ------------------------------
 // Serves BPE `ignore_merges` (bpe/model.rs:559-567), WordLevel (wordlevel/mod.rs:162-178) and the
 // merge-stable shortcut: key = bytes zero-padded to 16 + length, 32-byte slots.
-// Static TWO-CHOICE table (round 4; it was hash-and-displace like the merge table): a key lives in slot word_slot_a or word_slot_b of
-// its hash, the lookup kernel loads BOTH at once -- one round trip, hit or miss, where the displacement of the bucket and then
-// the slot were two dependent ones (pass 2 of k_lookup is a third of the path's longest kernel and waits for exactly that
-// chain).  Twice the bytes per probe, from a table that sits in the L2; built once at load (cuckoo insertion, load factor <= 0.4).
+// Static TWO-CHOICE table, HOST ONLY since round 5: a key lives in slot word_slot_a or word_slot_b of its hash (cuckoo insertion at
+// load, load factor <= 0.4).  It is the copy of record -- the WORD_DIRECT flags are proved on it (verify_direct_words), tkamd_probe_word
+// reads it, and the table the lookup kernel PROBES, the short-word table below, is built from it.  (Round 4 probed it on the device,
+// both 32-byte slots in one round trip: slower than one 16-byte slot behind an 8-bit displacement, profiles/r4i-k.)
 struct WordSlot {
     uint64_t lo, hi;
     uint32_t len;    // 0 = empty slot

@@ -39,8 +39,15 @@ def main():
         wk = statistics.median(w[k]) if w.get(k) else 0.0
         kernels[k] = {"launches": len(f.get(k) or w.get(k)), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    commit = None                       # (tools/stamp_commit.sh writes it before the snapshot goes to the GPU box: there is no .git there)
+    try:
+        import os
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")) as fh:
+            commit = fh.read().strip()
+    except OSError:
+        pass
     with open(out, "w") as fh:
-        json.dump({"_doc": note, "kernels": kernels}, fh, indent=1)
+        json.dump({"_doc": note, "commit": commit, "kernels": kernels}, fh, indent=1)
     print(f"{out}: {len(kernels)} kernels")
 
 
