@@ -211,7 +211,7 @@ struct Workspace {
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
-    DevBuf w_claims, w_claim_rows;               // in-batch word claims (kernels.hpp WordCache::claims) and the rows of the claimed slots
+    DevBuf w_claims, w_claim_rows, w_claim_pos;  // in-batch word claims (kernels.hpp WordCache::claims), the rows of the claimed slots, the claimants' first bytes
     DevBuf w_phases;                             // TKAMD_PHASES: shader-clock ticks per phase of the lookup / compaction, [2][PHASE_WGS][8] u64 (tkamd_debug_phases)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
     DevBuf w_seq_off, w_seq_tok_off, w_word_idx, w_first_tok;      // is_pretokenized: validated sequence CSR over the words, the sequences' token CSR, word index of every word
@@ -793,15 +793,18 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
         z.add(w->w_cstate.p, cstate_bytes);
         if (use_claims) {
-            // one slot per 64 bytes of the INPUT text (a word is a few bytes, most are repeats), 2^18 .. 2^24 slots: 16 MB of claims +
-            // 32 MB of rows for a 120 MB batch.  (Not of the normalised text's bound, three times that behind BertNormalizer: the
+            // one slot per 64 bytes of the INPUT text (a word is a few bytes, most are repeats), 2^18 .. 2^24 slots: 32 MB of claims (two
+            // 64-bit words a slot) + 32 MB of rows for a 120 MB batch.  (Not of the normalised text's bound, three times that behind BertNormalizer: the
             // words are the input's, and a table four times the size is four times the zeroing and a quarter of the cache hits.)
+            // (TKAMD_CLAIM_DIV: bytes of text per slot, an A/B knob -- a smaller table is less to zero and more of it in the caches, and
+            // more words whose slot another word holds)
+            static const size_t per_slot = [] { const char* e = getenv("TKAMD_CLAIM_DIV"); return (size_t)std::max(8, e ? atoi(e) : 64); }();
             int bits = 18;
-            while (bits < 24 && ((size_t)1 << bits) < (size_t)n_bytes / 64) ++bits;
+            while (bits < 24 && ((size_t)1 << bits) < (size_t)n_bytes / per_slot) ++bits;
             claim_slots = (size_t)1 << bits;
-            w->w_claims.reserve(claim_slots * 8);
+            w->w_claims.reserve(claim_slots * 16);
             w->w_claim_rows.reserve(claim_slots * 16);
-            z.add(w->w_claims.p, claim_slots * 8);
+            z.add(w->w_claims.p, claim_slots * 16);
         }
         launch_zero_regions(st, t->n_cu * 4, z);
     }
@@ -1461,12 +1464,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         return (uint8_t*)w->w_phases.p + (size_t)which * PHASE_WGS * 64;
     };
-    WordCache wc{nullptr, nullptr, nullptr, 0u};
+    WordCache wc{nullptr, nullptr, nullptr, 0u, nullptr};
     // (claims: see the top of this function; with offsets k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end)
     auto open_word_cache = [&]() {
         const size_t slots = (size_t)1 << WORD_CACHE_BITS;
         if (use_claims) {
-            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(claim_slots - 1)};
+            uint32_t* cpos = nullptr;                        // (the claimants' first bytes: only k_token_meta wants them)
+            if (off_mode != TKAMD_OFFSETS_NONE) { w->w_claim_pos.reserve(claim_slots * 4); cpos = w->w_claim_pos.as<uint32_t>(); }
+            wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(claim_slots - 1), cpos};
             return;
         }
         if (!t->word_cache || off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends)
@@ -1477,7 +1482,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             HIP_CHECK(hipMemsetAsync(w->w_cache_keys.p, 0, slots * sizeof(CacheKey), st));
             w->cache_epoch = epoch;
         }
-        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u};
+        wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u, nullptr};
     };
     // Fork / join of the side streams: the model kernels of the queue classes are independent of each other.  OFF by default: measured on
     // C2 the two event hand-overs cost more (0.78 ms a step) than running the thinned-out queues one after the other (0.72);
@@ -1515,7 +1520,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     bool pub_inline = false;
     auto set_publish = [&]() {
         pub_inline = wc.claims && !pub_kernel;
-        if (pub_inline) { mdt.pub_claims = wc.claims; mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; }
+        if (pub_inline) { mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; mdt.pub_pos = wc.claim_pos; }
     };
     if (hm.model == MODEL_BPE) {
         pf.begin("lookup");
@@ -1612,8 +1617,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u}, 0u, 1u, nullptr, nullptr, t->hot_slots);
-        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u});      // words longer than 16 bytes
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u, nullptr}, 0u, 1u, nullptr, nullptr, t->hot_slots);
+        for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u, nullptr});      // words longer than 16 bytes
         pf.end();
     } else {
         // WordPiece's first candidate is the whole word (wordpiece/mod.rs:245-258 starts at end = len): the whole-word lookup
@@ -1675,7 +1680,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.pt_tokoff = w->w_pt_tokoff.as<uint32_t>();
         a.tmp_end = tmp_end;
         a.tok0 = wc.claims ? w->w_tok0.as<uint32_t>() : nullptr;
-        a.claims = wc.claims;
+        a.claim_pos = wc.claims ? wc.claim_pos : nullptr;
         a.n_pretok = d_npretok;
         a.doc_pt = w->w_doc_pt.as<uint32_t>();
         a.n_docs = n_docs;

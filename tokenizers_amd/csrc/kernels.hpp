@@ -21,9 +21,10 @@ struct DevTables {
     int* err;                         // (per call, in the host's copy) the batch's error bits: the char start reports ERR_UNK_OOV
     uint32_t* probes;                 // (per call, profiling runs only, else null) counter of merge-table probes, (k - 1) + 2 m per word
     uint32_t thin_limit;              // != 0 (per call, in the host's copy): the LDS merge kernels pick the owner of the <= 16-byte queue by its fill (bpe.hip)
-    // in-batch claims: set (per call, in the host's copy) when the model kernels publish the claimants' rows themselves (bpe.hip)
-    const unsigned long long* pub_claims;
+    // in-batch claims: set (per call, in the host's copy) when the model kernels publish the claimants' rows themselves (bpe.hip):
+    // the rows of the claimed slots, the slot mask, and -- only when offsets are requested -- where the claimant's first byte goes
     void* pub_rows;
+    uint32_t* pub_pos;
     uint32_t pub_mask;
     uint32_t word_seed;               // seed of the whole-word hashes (the two-choice table of record lives on the host, tables.hpp)
     const void* shortw;               // the short-word table (tables.hpp): every whole word of <= 16 bytes in 16-byte slots
@@ -82,10 +83,13 @@ struct __attribute__((aligned(32))) CacheKey {
 struct WordCache {
     CacheKey* keys;              // null: no cache
     void* rows;                  // [1 << WORD_CACHE_BITS] 16-byte rows
-    // In-batch word claims (kernels/lookup.hip "claims"): one 64-bit word per slot, 0 = free, else (length << 32 | first byte) of the
-    // pre-token that claimed the slot in THIS batch.  Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
+    // In-batch word claims (kernels/lookup.hip "claims"): TWO 64-bit words per slot.  Word 0: 0 = free; a word of <= 15 bytes claims with
+    // its own bytes 0..6 | length << 56 and leaves bytes 7..14 in word 1 -- the entry IS the key, a later occurrence settles on this one
+    // line; a word of 16..32 bytes claims with 0xFF << 56 | length << 32 | first byte of the claimant, whose bytes in the text are the key.
+    // Zeroed before every batch.  null: off.  (keys and claims are alternatives.)
     unsigned long long* claims;
     uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host)
+    uint32_t* claim_pos;         // [slots] first byte of the claimant (written with its row; k_token_meta reads it): only when offsets are requested, else null
 };
 
 // buffers zeroed by one launch (launch_zero_regions)
@@ -109,7 +113,7 @@ struct MetaArgs {
     const uint32_t* pt_tokoff;
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
     const uint32_t* tok0;             // in-batch claims: a pre-token whose tok0 names a claimed slot shares the claimant's tokens, and its token
-    const unsigned long long* claims; // ends are the claimant's: tmp_end[claimant's first byte + j] (both null when the claims are off)
+    const uint32_t* claim_pos;        // ends are the claimant's: tmp_end[claim_pos[slot] + j] (both null when the claims are off)
     const int64_t* n_pretok;
     const uint32_t* doc_pt;
     const uint32_t* word_of_doc;      // is_pretokenized: word id of every token of document d (its index in the sequence); else null

@@ -18,10 +18,13 @@ __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uin
 }
 
 // ---- in-batch word claims (kernels/lookup.hip has the whole story): hash and slot of a word of <= 32 bytes, and the step every model
-// kernel ends an entry with: a queued pre-token that holds the claim of its slot copies its finished row to the slot's row, where
-// the compaction finds it for the word's other occurrences (a row of more than four tokens names its ids by the claimant's first byte,
-// tmp_ids[s + j]: valid for the whole batch).  The slot is recomputed from the entry's bytes (an L2 hit: the kernel has just read them).
+// kernel ends an entry with: a queued pre-token that HOLDS the claim of its word (QLEN_CLAIM in its queue entry, set by the lookup when its
+// compare-and-swap won the slot) copies its finished row to the slot's row, where the compaction finds it for the word's other
+// occurrences (a row of more than four tokens names its ids by the claimant's first byte, tmp_ids[s + j]: valid for the whole batch), and
+// -- when offsets are requested -- leaves its first byte in claim_pos[slot]: k_token_meta takes a sharer's token ends from the claimant's
+// slots of tmp_end.  The slot is recomputed from the entry's bytes (the kernel has just read them); the claims table itself is not read again.
 constexpr uint32_t CLAIM_MAX_LEN = 32u;
+constexpr uint32_t CLAIM_KEY_MAX = 15u;           // words of <= 15 bytes: the claim entry IS the key (lookup.hip); longer ones name their claimant's bytes
 // the whole-word table's hash of the first 16 bytes and the whole length, continued over bytes 16..31 (zero padded)
 __device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
     return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));
@@ -38,14 +41,16 @@ __device__ __forceinline__ uint32_t claim_slot_of(const uint8_t* __restrict__ te
     }
     return claim_slot(h, mask);
 }
-__device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len, const uint4& row,
-                                                   const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
-    if (len == 0u || len > CLAIM_MAX_LEN) return;
-    const uint32_t slot = claim_slot_of(text, s, len, seed, claim_mask);
-    if (claims[slot] == (((unsigned long long)len << 32) | (unsigned long long)s)) crows[slot] = row;
+// len_word: the queue entry's length word (QLEN_CLAIM and all)
+__device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len_word, const uint4& row,
+                                                   uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
+    if (!(len_word & QLEN_CLAIM)) return;
+    const uint32_t slot = claim_slot_of(text, s, qitem_len(len_word), seed, claim_mask);
+    crows[slot] = row;
+    if (cpos) cpos[slot] = s;
 }
-// (t.pub_claims: set by the host when the model kernels are to publish -- DevTables is what every one of them is handed)
-#define TKAMD_PUBLISH_ROW(t_, text_, s_, len_, row_) do { if ((t_).pub_claims) claim_publish_item((text_), (t_).word_seed, (s_), (len_), (row_), (t_).pub_claims, (t_).pub_mask, (uint4*)(t_).pub_rows); } while (0)
+// (t.pub_rows: set by the host when the model kernels are to publish -- DevTables is what every one of them is handed)
+#define TKAMD_PUBLISH_ROW(t_, text_, s_, lenw_, row_) do { if ((t_).pub_rows) claim_publish_item((text_), (t_).word_seed, (s_), (lenw_), (row_), (t_).pub_mask, (uint4*)(t_).pub_rows, (t_).pub_pos); } while (0)
 
 // whole-word probe of a key longer than 16 bytes: hash and compare four bytes at a time (dword loads at any alignment; the text
 // carries TEXT_PAD readable bytes past its end, the vocabulary blob 16)
@@ -106,8 +111,8 @@ __global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* _
     for (uint32_t base = wave_global * GPW; base < n; base += n_waves * GPW) {
         uint32_t item = base + sub;
         bool valid = item < n;
-        uint32_t s = 0, len = 0, pos = 0;
-        if (valid) { pos = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[pos]; s = it.s; len = it.len; }
+        uint32_t s = 0, len = 0, pos = 0, lenw = 0;            // lenw: the entry's length word (QLEN_CLAIM: it publishes its row)
+        if (valid) { pos = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[pos]; s = it.s; lenw = it.len; len = qitem_len(lenw); }
         valid = valid && len != 0u;                                 // length 0: retired by k_long_vocab
         bool act = (uint32_t)c < len;
         uint32_t id = act ? t.byte_id[text[s + c]] : 0xFFFFFFFFu;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* _
         bool alive = act && ((am >> c) & 1ull);
         if (valid && alive) {
             uint32_t j = (uint32_t)__popcll(am & ((1ull << c) - 1ull));
-            if (j == 0) { const uint4 row_ = make_row(count, s, id, r1, r2, r3); rows[v.row_base + pos] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
+            if (j == 0) { const uint4 row_ = make_row(count, s, id, r1, r2, r3); rows[v.row_base + pos] = row_; TKAMD_PUBLISH_ROW(t, text, s, lenw, row_); }
             else if (count > 4u) tmp_ids[s + j] = id;
             if (tmp_end) {
                 uint64_t mine = ((uint32_t)c + 1 < 64u) ? (am >> (c + 1)) : 0ull;
@@ -213,8 +218,8 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
     for (uint32_t base = blockIdx.x * 256; base < n_items; base += stride) {
         const uint32_t item = base + threadIdx.x;
         bool valid = item < n_items;
-        uint32_t p = 0, s = 0, len = 0;                      // p: queue position (names the result row)
-        if (valid) { p = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[p]; s = it.s; len = it.len; }
+        uint32_t p = 0, s = 0, len = 0, claim = 0;           // p: queue position (names the result row); claim: QLEN_CLAIM of the entry
+        if (valid) { p = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[p]; s = it.s; len = qitem_len(it.len); claim = it.len & QLEN_CLAIM; }
         valid = valid && len != 0u;                          // length 0: retired by k_long_vocab
         // The loop below runs until the slowest lane of a wavefront is done (~len - 2 rounds), so the 256 items of
         // this workgroup are counting-sorted by length first: each wavefront then holds one quartile of the lengths.
@@ -228,10 +233,10 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
             uint32_t before = 0;
             for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
             const uint32_t slot = before + within;
-            s_sort[slot] = make_uint4(p, s, len, valid ? 1u : 0u);
+            s_sort[slot] = make_uint4(p, s, len | claim, valid ? 1u : 0u);
             __syncthreads();
             const uint4 it = s_sort[threadIdx.x];
-            p = it.x; s = it.y; len = it.z; valid = it.w != 0u;
+            p = it.x; s = it.y; len = qitem_len(it.z); claim = it.z & QLEN_CLAIM; valid = it.w != 0u;
         }
         uint64_t key[S / 8];
 #pragma unroll
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
             }
         }
         if (valid) {
-            { const uint4 row_ = make_row(n, s, ids[0], ids[1], ids[2], ids[3]); rows[v.row_base + p] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
+            { const uint4 row_ = make_row(n, s, ids[0], ids[1], ids[2], ids[3]); rows[v.row_base + p] = row_; TKAMD_PUBLISH_ROW(t, text, s, len | claim, row_); }
             if (n > 4u) {
 #pragma unroll
                 for (int j = 1; j < S; ++j)
@@ -394,10 +399,10 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     for (uint32_t base = blockIdx.x * take; base < n_items; base += stride) {
         const uint32_t item = base + tid;
         bool valid = tid < take && item < n_items;
-        uint32_t s = 0, len = 0, qidx = 0;                    // qidx: the result row (named by the position in the work queue)
+        uint32_t s = 0, len = 0, qidx = 0, claim = 0;         // qidx: the result row (named by the position in the work queue); claim: QLEN_CLAIM of the entry
         if (valid) {
-            if (item < n_first) { const uint32_t qp = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qp]; s = it.s; len = it.len; qidx = v.row_base + qp; }
-            else { const uint32_t qp = qview_pos(s_qpre2, v2.sq_cap, item - n_first); const QItem it = v2.q[qp]; s = it.s; len = it.len; qidx = v2.row_base + qp; }
+            if (item < n_first) { const uint32_t qp = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qp]; s = it.s; len = qitem_len(it.len); claim = it.len & QLEN_CLAIM; qidx = v.row_base + qp; }
+            else { const uint32_t qp = qview_pos(s_qpre2, v2.sq_cap, item - n_first); const QItem it = v2.q[qp]; s = it.s; len = qitem_len(it.len); claim = it.len & QLEN_CLAIM; qidx = v2.row_base + qp; }
         }
         valid = valid && len != 0u;                           // length 0: retired by k_long_vocab
         // counting sort of the workgroup's items by length: a wavefront loops until its slowest lane is done
@@ -410,11 +415,11 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
             __syncthreads();
             uint32_t before = 0;
             for (uint32_t b = 0; b < bin; ++b) before += s_hist[b];
-            s_sort[before + within] = make_uint4(0u, s, len, valid ? qidx + 1u : 0u);
+            s_sort[before + within] = make_uint4(claim, s, len, valid ? qidx + 1u : 0u);
             __syncthreads();
             const uint4 it = s_sort[tid];
             __syncthreads();                                  // everyone has read its item before keys overwrite the area
-            s = it.y; len = it.z; valid = it.w != 0u;
+            claim = it.x; s = it.y; len = it.z; valid = it.w != 0u;
             qidx = it.w - 1u;
         }
         uint32_t* my_key = s_key + tid;                       // slot i at my_key[i * NT]
@@ -578,7 +583,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 }
             }
             if (tmp_end && c) tmp_end[s + c - 1] = len;
-            { const uint4 row_ = make_row(c, s, r[0], r[1], r[2], r[3]); rows[qidx] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
+            { const uint4 row_ = make_row(c, s, r[0], r[1], r[2], r[3]); rows[qidx] = row_; TKAMD_PUBLISH_ROW(t, text, s, len | claim, row_); }
             // (k - 1) + 2 m probes for a word of k symbols and m merges: every initial pair once, two new pairs per merge
             if (t.probes) { const uint32_t k0 = (uint32_t)__popc(alive0); if (k0) atomicAdd(&s_probes, (k0 - 1u) + 2u * (k0 - c)); }
         }
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const uint32_t pos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[pos];
-        const uint32_t s = it.s, len = it.len;
+        const uint32_t s = it.s, len = qitem_len(it.len);
         if (len == 0u) continue;                           // retired by k_long_vocab
         if (len > (uint32_t)LONG_PT_MAX) {                 // too long for LDS: hand over to k_bpe_merge_huge (by queue position)
             if (tid == 0) {
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_long(DevTables t, const uint8
         if (tid == 0) {
             const uint4 row_ = make_uint4((cnt_s ? first_s : 0u) | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, cnt_s, 0u);
             rows[v.row_base + pos] = row_;
-            TKAMD_PUBLISH_ROW(t, text, s, len, row_);      // (short words come here when the LDS kernels cannot take them: BPE over characters whose new ids are not in merge order)
+            TKAMD_PUBLISH_ROW(t, text, s, it.len, row_);   // (short words come here when the LDS kernels cannot take them: BPE over characters whose new ids are not in merge order)
         }
     }
 }

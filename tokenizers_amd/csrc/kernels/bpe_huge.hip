@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_bpe_merge_huge(DevTables t, const uint8
     for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
         const uint32_t p = list[item];                               // position in the long queue: names the result row
         const QItem it = q[p];
-        const uint32_t s = it.s, len = it.len;
+        const uint32_t s = it.s, len = qitem_len(it.len);      // (far beyond the claims' 32 bytes: the flag is never set here)
         const uint32_t n_chunks = (len + HUGE_CHUNK - 1) / HUGE_CHUNK;
         const unsigned long long need = 5ull * len + 2ull * n_chunks + 1ull;     // u32 words (+1 to 8-byte-align cmin)
         __syncthreads();

@@ -19,8 +19,13 @@ void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs,
 }
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant) {
-    if (variant == 2)
-        hipLaunchKernelGGL(k_pretok_gpt2_seq, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    static const int lut_copies = [] { const char* e = getenv("TKAMD_SQ_LUT"); return e ? atoi(e) : SQ_LUT_COPIES; }();
+    if (variant == 2 && lut_copies == 1)
+        hipLaunchKernelGGL(k_pretok_gpt2_seq<1>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    else if (variant == 2 && lut_copies == 2)
+        hipLaunchKernelGGL(k_pretok_gpt2_seq<2>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    else if (variant == 2)
+        hipLaunchKernelGGL(k_pretok_gpt2_seq<SQ_LUT_COPIES>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
     else if (variant == 0)
         hipLaunchKernelGGL(k_pretok_gpt2, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
     else
@@ -147,7 +152,7 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
 }
 void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
                        const WordCache& wc) {
-    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err, (const unsigned long long*)wc.claims, wc.claim_mask, (uint4*)wc.rows);
+    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err, wc.claim_mask, wc.claims ? (uint4*)wc.rows : (uint4*)nullptr, wc.claim_pos);
 }
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err) {
@@ -273,7 +278,7 @@ int compact_grid(int n_cu, int cp_items) {
     return per_cu * n_cu;
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
-    hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claims, wc.claim_mask, (uint4*)wc.rows);
+    hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claim_mask, (uint4*)wc.rows, wc.claim_pos);
 }
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
     static_assert(((LU_TILE + LU_TEXT_SLACK) + 16) % 16 == 0 && hot_table_bytes(HOT) % 16 == 0, "s_wdisp is copied sixteen bytes a lane");
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
-    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand;
+    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand, s_ncandl;
     // the claims' yield as this workgroup sees it: candidates it looked at, how many of them were another pre-token's word.  Text that
     // never repeats a word pays two dependent round trips per candidate for nothing: a workgroup that has seen CLAIM_ADAPT_MIN
     // candidates and shared fewer than one in eight stops claiming for the rest of its tiles (its candidates are queued like any
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 __syncthreads();
             }
             // ---- 2b. positions of the set bits, by rank (ranks rb .. rb + cnt, the extra one is the next start) ----
-            if (tid == 0) { s_nmiss = 0u; s_ncand = 0u; }
+            if (tid == 0) { s_nmiss = 0u; s_ncand = 0u; s_ncandl = 0u; }
             if (rbase != 0xFFFFFFFFu) {
                 const uint32_t lo32 = (uint32_t)ms, bit0 = (uint32_t)hword * 64u + (uint32_t)half * 32u;
                 uint32_t r = rbase - rb + (half ? (uint32_t)__popc(lo32) : 0u);
@@ -312,7 +312,8 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             tick(LU_PH_PASS1);
             // what pass 2 and pass 3 end a lane with: a pre-token still pending is a model kernel's work, queued by length class
             // (<= 16 bytes, <= 32, <= 64, longer); its tok0 word names the row, any other lane's its result.  (wavefront-wide: ballots)
-            auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out) {
+            // (holds: this pre-token won the claim of its word -- QLEN_CLAIM in its queue entry makes the model kernel publish its row)
+            auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out, bool holds) {
                 const uint32_t c = len <= 16u ? 0u : (len <= 32u ? 1u : (len <= 64u ? 2u : 3u));
                 const uint64_t b0 = __ballot(pend && c == 0u), b1 = __ballot(pend && c == 1u), b2 = __ballot(pend && c == 2u), b3 = __ballot(pend && c == 3u);
                 if (b0 | b1 | b2 | b3) {                                            // wavefront-uniform
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         const uint32_t qcap = c == 0u ? a.v[0].sq_cap : c == 1u ? a.v[1].sq_cap : c == 2u ? a.v[2].sq_cap : a.v[3].sq_cap;
                         const uint32_t rowb = c == 0u ? a.v[0].row_base : c == 1u ? a.v[1].row_base : c == 2u ? a.v[2].row_base : a.v[3].row_base;
                         if (pos < qcap) {
-                            qp[sq * qcap + pos] = QItem{(uint32_t)t0 + s_rel, len};
+                            qp[sq * qcap + pos] = QItem{(uint32_t)t0 + s_rel, len | (holds ? QLEN_CLAIM : 0u)};
                             out = TOK_ROW | (rowb + sq * qcap + pos);
                         } else {
                             atomicOr(a.err, ERR_QUEUE_FULL);                         // the host grows the queues and runs the batch again
@@ -354,26 +355,72 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 k6 = __builtin_amdgcn_alignbyte(d7, d6, sh) & kmh.z; k7 = __builtin_amdgcn_alignbyte(d8, d7, sh) & kmh.w;
                 return claim_hash_long(h16, k4, k5, k6, k7);
             };
-            // the claim protocol of one candidate: true if the word is another pre-token's (tok0 -> TOK_SLOT | slot), false if this
-            // pre-token now holds the claim or the slot is another word's (queued either way).  The first occurrence of a word claims
-            // the slot; a slot only ever goes from 0 to its claim, so a claim read is final and a 0 is followed by the compare-and-swap.
-            auto claim_word = [&](uint32_t slot, uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3,
-                                  uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7, const uint4& kmh) -> bool {
-                // A plain (cached) read first: a claim it shows is final, and the repeats of a frequent word then hit the L2 instead of
-                // crossing the fabric each time.  A 0 may be stale (the L2 of an XCD keeps what it read whatever another XCD's CAS did since):
-                // the device-scope read confirms it -- and refreshes the line for the next plain read (tools/microbench/claims_probe.hip).
-                unsigned long long c = a.claims[slot];
-                if (c == 0ull) c = __hip_atomic_load(a.claims + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (c == 0ull) c = atomicCAS(a.claims + slot, 0ull, ((unsigned long long)len << 32) | (unsigned long long)((uint32_t)t0 + s_rel));
-                // (a 0 straight into the compare-and-swap, the stale line read afresh next to the claimant's bytes: level in distribution,
-                // 0.476 against 0.44 ms on out-of-distribution text -- profiles/r4i_ab_c2*.txt)
-                if (c == 0ull || (uint32_t)(c >> 32) != len) return false;
-                const uint4 kml = s_kmask[min(len, 16u)];
+            // The claim protocol of one candidate.  Returns CLAIM_SHARED if the word is another pre-token's (tok0 -> TOK_SLOT | slot, not queued),
+            // CLAIM_HOLDS if this pre-token now holds the claim (queued, its entry flagged: the model kernel publishes its row to the slot),
+            // CLAIM_NONE if the slot is another word's or the claim could not be read whole (queued like any other miss).  A slot only ever
+            // goes from 0 to its claim, so a claim read is final; a 0 is followed by the compare-and-swap.
+            // A word of <= CLAIM_KEY_MAX (15) bytes claims with ITSELF: word 0 of the entry = bytes 0..6 | length << 56 (never 0, never the long
+            // form's 0xFF), word 1 = bytes 7..14, stored by the winner right behind its compare-and-swap.  A later occurrence compares the
+            // entry with its own key -- ONE line, where round 4's entry named the claimant's first byte and every candidate fetched a second
+            // line somewhere in the text (2.4 M random HBM lines a batch on C2: tools/claims_sim.py).  An entry whose word 0
+            // matches while word 1 does not (another word with the same first seven bytes and length, or the winner's second store still
+            // on its way) is NOT waited for: the pre-token is queued and merged on its own, which is always right.
+            // A plain (cached) read first: a claim it shows is final, and the repeats of a frequent word then hit the L2 instead of crossing
+            // the fabric each time.  A 0 may be stale (the L2 of an XCD keeps what it read whatever another XCD's CAS did since): the
+            // device-scope read confirms it (tools/microbench/claims_probe.hip).
+            enum : uint32_t { CLAIM_NONE = 0u, CLAIM_SHARED = 1u, CLAIM_HOLDS = 2u };
+            auto claim_short = [&](uint32_t slot, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) -> uint32_t {
+                unsigned long long* const e = a.claims + 2u * (size_t)slot;
+                const unsigned long long w0 = (unsigned long long)k0 | ((unsigned long long)(k1 & 0x00FFFFFFu) << 32) | ((unsigned long long)len << 56);
+                const unsigned long long w1 = (unsigned long long)(k1 >> 24) | ((unsigned long long)k2 << 8) | ((unsigned long long)(k3 & 0x00FFFFFFu) << 40);
+                const ulonglong2 c = *(const ulonglong2*)e;
+                unsigned long long c0 = c.x, c1 = c.y;
+                bool fresh1 = false;
+                if (c0 == 0ull) {
+                    c0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (c0 == 0ull) {
+                        c0 = atomicCAS(e, 0ull, w0);
+                        if (c0 == 0ull) {
+                            if (w1) __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            return CLAIM_HOLDS;
+                        }
+                    }
+                    if (c0 == w0 && w1) { c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh1 = true; }      // (claimed since the stale read)
+                }
+                if (c0 != w0) return CLAIM_NONE;
+                if (c1 == w1) return CLAIM_SHARED;
+                if (!fresh1) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return c1 == w1 ? CLAIM_SHARED : CLAIM_NONE;
+            };
+            // 16..32 bytes (9 % of C2's candidates): the entry names the claimant -- 0xFF << 56 | length << 32 | first byte -- and its BYTES in
+            // the text are the key (immutable: nothing waits for another lane's writes, no result depends on which occurrence wins)
+            auto claim_long = [&](uint32_t slot, uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3,
+                                  uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7, const uint4& kmh) -> uint32_t {
+                unsigned long long* const e = a.claims + 2u * (size_t)slot;
+                const unsigned long long tag = (0xFFull << 56) | ((unsigned long long)len << 32);
+                unsigned long long c = *e;
+                if (c == 0ull) c = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 0ull) {
+                    c = atomicCAS(e, 0ull, tag | (unsigned long long)((uint32_t)t0 + s_rel));
+                    if (c == 0ull) return CLAIM_HOLDS;
+                }
+                if ((c >> 32) != (tag >> 32)) return CLAIM_NONE;
                 const Unaligned16 o = *(const Unaligned16*)(a.text + (uint32_t)c);  // (readable: the text carries TEXT_PAD bytes of slack)
-                Unaligned16 o2{0u, 0u, 0u, 0u};
-                if (len > 16u) o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
-                return (((o.a & kml.x) ^ k0) | ((o.b & kml.y) ^ k1) | ((o.c & kml.z) ^ k2) | ((o.d & kml.w) ^ k3) |
-                        ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u;
+                const Unaligned16 o2 = *(const Unaligned16*)(a.text + (uint32_t)c + 16u);
+                return ((((o.a) ^ k0) | ((o.b) ^ k1) | ((o.c) ^ k2) | ((o.d) ^ k3) |
+                         ((o2.a & kmh.x) ^ k4) | ((o2.b & kmh.y) ^ k5) | ((o2.c & kmh.z) ^ k6) | ((o2.d & kmh.w) ^ k7)) == 0u) ? CLAIM_SHARED : CLAIM_NONE;
+            };
+            // the claim of one candidate of any length (<= CLAIM_MAX_LEN); h1: the whole-word table's hash of its first 16 bytes
+            auto claim_any = [&](uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t h1, uint32_t& slot) -> uint32_t {
+                if (len <= CLAIM_KEY_MAX) {
+                    slot = claim_slot(h1, a.claim_mask);
+                    return claim_short(slot, len, k0, k1, k2, k3);
+                }
+                uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u, hc = h1;
+                uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
+                if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, h1, k4, k5, k6, k7, kmh);
+                slot = claim_slot(hc, a.claim_mask);
+                return claim_long(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh);
             };
             // ---- 4. pass 2: the misses, packed 64 to a step, steps dealt round robin ----
             // A step is the key + hash + the bucket's displacement (LDS), ONE memory round trip -- the word's one slot of the short-word
@@ -424,23 +471,27 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         pend = false;
                     }
                 }
-                bool cand = false;
+                bool cand = false, holds = false;
                 if (claims_now) {                                                   // wavefront-uniform
                     cand = pend && hits_on && len != 0u && len <= CLAIM_MAX_LEN;
                     if (CAND_PASS) {
-                        const uint64_t cb = __ballot(cand);
-                        if (cb) {                                                   // (wavefront-uniform) the workgroup's candidate list
+                        // two lists in the one array: the words whose claim entry is their key from the front, the 16..32-byte ones -- a second
+                        // dependent round trip, and a step waits for its slowest lane -- from the back: their steps are few and their own
+                        const bool lng = cand && len > CLAIM_KEY_MAX;
+                        const uint64_t cb = __ballot(cand && !lng), lb = __ballot(lng);
+                        if (cb | lb) {                                              // (wavefront-uniform) the workgroup's candidate lists
                             uint32_t base = 0u;
-                            if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(cb));
-                            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                            if (cand) s_cand[base + (uint32_t)mbcnt64(cb)] = (uint16_t)rel;
+                            if (lane == 0 && cb) base = atomicAdd(&s_ncand, (uint32_t)__popcll(cb));
+                            if (lane == 1 && lb) base = atomicAdd(&s_ncandl, (uint32_t)__popcll(lb));
+                            const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)base, 0), bl = (uint32_t)__builtin_amdgcn_readlane((int)base, 1);
+                            if (cand && !lng) s_cand[bs + (uint32_t)mbcnt64(cb)] = (uint16_t)rel;
+                            if (lng) s_cand[(uint32_t)LU_POS_CAP - 1u - (bl + (uint32_t)mbcnt64(lb))] = (uint16_t)rel;
                         }
                     } else if (cand) {
-                        uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u, hc = h1;
-                        uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
-                        if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), k4, k5, k6, k7, kmh);
-                        const uint32_t slot = claim_slot(hc, a.claim_mask);
-                        if (claim_word(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh)) { out = TOK_SLOT | slot; pend = false; }
+                        uint32_t slot = 0u;                                         // (h1 is the probe's: a word beyond the table's 16-byte keys was not probed)
+                        const uint32_t r = claim_any(s_rel, len, k0, k1, k2, k3, x.probe ? h1 : word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), slot);
+                        if (r == CLAIM_SHARED) { out = TOK_SLOT | slot; pend = false; }
+                        holds = r == CLAIM_HOLDS;
                     }
                     if (!CAND_PASS) {                                               // (the inline variant keeps the yield per step)
                         const uint64_t cb = __ballot(cand), sb = __ballot(cand && !pend);
@@ -451,7 +502,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                     const uint64_t cb = __ballot(pend && hits_on && len != 0u && len <= CLAIM_MAX_LEN);
                     if (cb && lane == 0) atomicAdd(&s_seen, (uint32_t)__popcll(cb));
                 }
-                finish(v && !cand, pend && !cand, rel, s_rel, len, out);            // (a listed candidate is finished by pass 3)
+                finish(v && !cand, pend && !cand, rel, s_rel, len, out, holds);     // (a listed candidate is finished by pass 3)
             };
             // two steps side by side: both probes in flight together (a tile of prose is two steps a wavefront; the 80-register shape
             // has no room for the second step's state).  Against one step at a time, same session (profiles/r4m_ab_*.txt): level on C2,
@@ -474,24 +525,29 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
             if (CAND_PASS && claims_now) {                                          // wavefront-uniform
                 __syncthreads();
                 tick(LU_PH_PASS2);
-                const uint32_t n_cand = s_ncand;
-                if (tid == 0) s_seen += n_cand;                                     // (thread 0 alone writes it)
-                for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_cand; c0 += (uint32_t)LU_NT) {
-                    const bool v = c0 + lane < n_cand;
-                    const uint32_t rel = s_cand[v ? c0 + lane : c0];
+                const uint32_t n_cand = s_ncand, n_candl = s_ncandl;
+                if (tid == 0) s_seen += n_cand + n_candl;                           // (thread 0 alone writes it)
+                // the short words' steps, then the long ones' (from the back of the list); steps dealt round robin over both
+                const uint32_t steps_s = (n_cand + 63u) >> 6, steps_l = (n_candl + 63u) >> 6;
+                for (uint32_t st = (uint32_t)wave; st < steps_s + steps_l; st += (uint32_t)LU_WAVES) {
+                    const bool lng = st >= steps_s;                                 // wavefront-uniform
+                    const uint32_t c0 = (lng ? st - steps_s : st) * 64u, nc = lng ? n_candl : n_cand;
+                    const bool v = c0 + lane < nc;
+                    const uint32_t ci = v ? c0 + lane : c0;
+                    const uint32_t rel = s_cand[lng ? (uint32_t)LU_POS_CAP - 1u - ci : ci];
                     uint32_t s_rel, len, k0, k1, k2, k3;
                     load_key(rel, s_rel, len, k0, k1, k2, k3, true);
-                    uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u;
-                    uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
-                    uint32_t hc = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
-                    if (len > (uint32_t)WORD_MAX_KEY) hc = long_key(s_rel, len, hc, k4, k5, k6, k7, kmh);
-                    const uint32_t slot = claim_slot(hc, a.claim_mask);
-                    uint32_t out = 0u;
+                    const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
+                    uint32_t out = 0u, slot = 0u, r = CLAIM_NONE;
                     bool pend = v;
-                    if (v && claim_word(slot, s_rel, len, k0, k1, k2, k3, k4, k5, k6, k7, kmh)) { out = TOK_SLOT | slot; pend = false; }
+                    if (v) {
+                        if (lng) r = claim_any(s_rel, len, k0, k1, k2, k3, h1, slot);
+                        else { slot = claim_slot(h1, a.claim_mask); r = claim_short(slot, len, k0, k1, k2, k3); }
+                    }
+                    if (r == CLAIM_SHARED) { out = TOK_SLOT | slot; pend = false; }
                     const uint64_t sb = __ballot(v && !pend);
                     if (sb && lane == 0) atomicAdd(&s_shared, (uint32_t)__popcll(sb));
-                    finish(v, pend, rel, s_rel, len, out);
+                    finish(v, pend, rel, s_rel, len, out, r == CLAIM_HOLDS);
                 }
             }
         }
@@ -519,13 +575,19 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
 // =================================================================================================
 // In-batch word claims.  Natural text repeats its words: of the pre-tokens the static tables do not settle (13 % on C2) a few
 // percent are distinct.  The reference's per-thread cache exploits that (BPE::tokenize_with_cache, bpe/model.rs:573-586); here the
-// FIRST occurrence of such a word claims the slot of its hash in a table of 64-bit entries (0 = free, else length << 32 | first byte of
-// the claimant) in k_lookup (pass 3; inline in pass 2 with end masks) and is queued for the model kernel; every other occurrence finds
-// the claim, checks it against the claimant's BYTES in the text (immutable: nothing waits for another lane's writes, and no result
-// depends on which occurrence wins), is not queued and points its tok0 at the slot's row (TOK_SLOT | slot).  The model kernels copy the
-// claimants' finished rows there (claim_publish_item, bpe.hip); the compaction reads them like the rows of the word cache, and
-// k_token_meta takes the token ends of a shared row from the claimant's slots of tmp_end.  A word whose slot another word holds is simply merged every time.  The table is
-// zeroed per batch: no state crosses batches.
+// FIRST occurrence of such a word claims the slot of its hash in a table of 16-byte entries (claim_short / claim_long in k_lookup:
+// pass 3; inline in pass 2 with end masks), is queued for the model kernel with QLEN_CLAIM in its queue entry, and every other
+// occurrence finds the claim, checks it -- against the KEY in the entry for a word of <= 15 bytes (round 5: one line per candidate),
+// against the claimant's BYTES in the text for a longer one (immutable: nothing waits for another lane's writes, and no result depends
+// on which occurrence wins) -- is not queued and points its tok0 at the slot's row (TOK_SLOT | slot).  The model kernels copy the
+// claimants' finished rows there (claim_publish_item, bpe.hip: the flag in the queue entry says who, the table is not read again); the
+// compaction reads them like the rows of the word cache, and k_token_meta takes the token ends of a shared row from the claimant's slots
+// of tmp_end (claim_pos[slot]).  A word whose slot another word holds is simply merged every time.  The table is zeroed per batch: no
+// state crosses batches.
+// Round 5 measured what the candidates ARE before changing the entry (tools/claims_sim.py over the bench's own first batch: 2.37 M
+// candidates, 219 k distinct words, a flat tail -- the 4,096 most frequent of them cover 10 %): 0.2 % repeat inside their 16 KB tile and
+// 1.6 % inside everything their workgroup ever sees, so a workgroup-local table in front of the claims would answer next to nothing;
+// 39 % are <= 7 bytes, 47 % <= 8, 91 % <= 15 (profiles/r5_claims_sim.txt).
 // Measured on the way here (C2, 2.56 M candidates; tools/microbench/claims_probe.hip, tools/cm_probe.py):
 //   * all reads of the table are device-scope loads: the L2 of an XCD keeps a line it read as 0 whatever another XCD's CAS did since
 //     (a plain load after a remote store was stale in 63 of 63 workgroups, a device-scope load fresh in all);
@@ -544,7 +606,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
 // the compaction finds it for the word's other occurrences.  The two halves of the grid take the two queue classes.
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
-                                                        const unsigned long long* __restrict__ claims, uint32_t claim_mask, uint4* __restrict__ crows) {
+                                                        uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t half = gridDim.x >> 1;
     const QView v = blockIdx.x >= half ? v1 : v0;
@@ -552,7 +614,7 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
     for (uint32_t item = (blockIdx.x % half) * 256 + threadIdx.x; item < n; item += half * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
-        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claims, claim_mask, crows);
+        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claim_mask, crows, cpos);
     }
 }
 
@@ -573,7 +635,8 @@ __global__ __launch_bounds__(256) void k_word_cache_insert(DevTables t, const ui
     const uint32_t n = qview_prefix(v, s_qpre);
     for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
-        const QItem it = v.q[qpos];
+        QItem it = v.q[qpos];
+        it.len = qitem_len(it.len);
         if (it.len == 0u || it.len > 16u) continue;
         const uint4 row = rows[v.row_base + qpos];
         if ((row.x >> ROW_CNT_SHIFT) > 4u) continue;                                // longer results stay with the merge kernels

@@ -316,9 +316,9 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         // cut it short in the start mask, and its text is the raw slice (trimmed by real whitespace chars)
         const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
         uint32_t s_ends = s;                                          // whose token ends: the pre-token's own, or the claimant's of its word
-        if (a.claims && c > 1) {
+        if (a.claim_pos && c > 1) {
             const uint32_t t0 = a.tok0[p];
-            if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = (uint32_t)a.claims[t0 & TOK_REF_MASK];
+            if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = a.claim_pos[t0 & TOK_REF_MASK];
         }
         // BPE over characters without an unk_token: a char the vocabulary lacks leaves no symbol, and the reference's token offsets are
         // running sums of the symbols' lengths (word.rs:260-268) -- every edge behind a dropped char moves up by its bytes.  The model
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             return rel_pos - dropped;
         };
         for (uint32_t j = 0; j < c; ++j) {
-            uint32_t rel_end = running((c == 1) ? (e - s) : a.tmp_end[s_ends + j]);
+            uint32_t rel_end = running((c == 1 || !a.tmp_end) ? (e - s) : a.tmp_end[s_ends + j]);      // (no token ends without offsets: word ids only)
             if (a.want_words) a.word_ids[o + j] = word;
             if (a.want_offsets) {
                 uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space

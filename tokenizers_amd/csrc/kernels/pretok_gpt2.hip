@@ -168,16 +168,19 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
 constexpr int SQ_MAIN = 48, SQ_HALO = 8, SQ_LUT_COPIES = 4;
 struct __attribute__((packed, aligned(8))) SqChunk { uint32_t a, b, c, d; };
 
+// COPIES: replicas of the 2 KB flag table, lane l reads replica l % COPIES.  (Lanes that read the SAME entry of one replica are a
+// broadcast; the same entry of two replicas is a bank conflict: TKAMD_SQ_LUT=1 / 2 A/B the replication.)
+template <int COPIES = SQ_LUT_COPIES>
 __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restrict__ text, int64_t n_bytes_host,
                                                          const int64_t* __restrict__ len_dev,
                                                          const unsigned long long* __restrict__ docmask,
                                                          const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                          unsigned long long* __restrict__ startmask) {
-    __shared__ Gpt2Flags lut[SQ_LUT_COPIES * 256];
+    __shared__ Gpt2Flags lut[COPIES * 256];
     {
         const Gpt2Flags f = gpt2_byte_flags(threadIdx.x);    // 256 threads: one table entry each
 #pragma unroll
-        for (int c = 0; c < SQ_LUT_COPIES; ++c) lut[c * 256 + threadIdx.x] = f;
+        for (int c = 0; c < COPIES; ++c) lut[c * 256 + threadIdx.x] = f;
     }
     __syncthreads();
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restri
     const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
     // loads, flag deposit and the regex as mask algebra: pretok_gpt2_core.hpp (the very function the CPU test runs)
     const unsigned long long out = gpt2_lane_starts(text, n_bytes, n_words_host, (const uint64_t*)docmask,
-                                                    lut + (threadIdx.x & (SQ_LUT_COPIES - 1)) * 256, Lg, uc1, uc2);
+                                                    lut + (threadIdx.x & (COPIES - 1)) * 256, Lg, uc1, uc2);
     // four lanes' 48-bit results are three 64-bit mask words
     const unsigned long long nxt = __shfl_down(out, 1, 64);
     const int q = (int)(threadIdx.x & 3);

@@ -22,8 +22,12 @@ constexpr uint32_t TOK_SLOT = TOK_ROW | TOK_ONE, TOK_REF_MASK = 0x3FFFFFFFu;
 constexpr uint32_t ROW_CNT_SHIFT = 28, ROW_CNT_MORE = 15u, ROW_ID_MASK = 0x0FFFFFFFu;
 constexpr uint32_t ROW_WHOLE_WORD = 0xFFFFFFFFu;      // word 1 of a ONE-token row (unused otherwise): a whole-word vocabulary hit of k_long_vocab, not a merge result (k_token_meta)
 
-// one queued pre-token: first byte and length (the model kernels need nothing else)
+// one queued pre-token: first byte and length (the model kernels need nothing else).  Bit 31 of the length: this entry HOLDS the in-batch
+// claim of its word (kernels/lookup.hip) -- the model kernel that finishes it also copies its row to the claimed slot's row, where
+// the compaction finds it for the word's other occurrences.  Every reader takes the length through qitem_len().
 struct __attribute__((aligned(8))) QItem { uint32_t s, len; };
+constexpr uint32_t QLEN_CLAIM = 0x80000000u;
+__device__ __forceinline__ uint32_t qitem_len(uint32_t len_word) { return len_word & ~QLEN_CLAIM; }
 
 // A work queue is NSQ sub-queues of sq_cap entries each.  Atomics on ONE address serialise at ~10 ns each on MI355X (device-scope
 // atomics are resolved at the memory side), and a shared fill counter would take one per workgroup, tile and queue -- tens of

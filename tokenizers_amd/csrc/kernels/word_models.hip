@@ -20,15 +20,16 @@
 // skip it); for WordLevel a miss is the unk id or MissingUnkToken.  Rare path: one lane per item.
 // A retired entry that holds the in-batch claim of its word (lookup.hip) publishes its row here: k_claims_publish no longer sees it.
 __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
-                                                    uint32_t miss_is_unk, int* __restrict__ err, const unsigned long long* __restrict__ claims,
-                                                    uint32_t claim_mask, uint4* __restrict__ crows) {
+                                                    uint32_t miss_is_unk, int* __restrict__ err, uint32_t claim_mask, uint4* __restrict__ crows,
+                                                    uint32_t* __restrict__ cpos) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t n = qview_prefix(v, s_qpre);
     for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
         uint32_t id = 0;
-        bool hit = it.len <= t.long_probe_max_len && long_probe(t, text + it.s, it.len, &id);
+        const uint32_t len = qitem_len(it.len);
+        bool hit = len <= t.long_probe_max_len && long_probe(t, text + it.s, len, &id);
         if (!hit && miss_is_unk) {
             if (t.has_unk) { id = t.unk_id; hit = true; }
             else atomicOr(err, ERR_MISSING_UNK);
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
         if (hit || miss_is_unk) {
             const uint4 row = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), ROW_WHOLE_WORD, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
             rows[v.row_base + qpos] = row;
-            if (claims) claim_publish_item(text, t.word_seed, it.s, it.len, row, claims, claim_mask, crows);
+            if (crows) claim_publish_item(text, t.word_seed, it.s, it.len, row, claim_mask, crows, cpos);
             v.q[qpos].len = 0u;
         }
     }
@@ -51,7 +52,7 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
     for (uint32_t item = block * 256 + threadIdx.x; item < n; item += n_blocks * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
-        const uint32_t s = it.s, len = it.len;
+        const uint32_t s = it.s, len = qitem_len(it.len);
         uint64_t lo = 0, hi = 0;
         uint32_t chars = 0;
         if (SHORT) {
@@ -95,7 +96,7 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
             j = 1;
             if (tmp_end) tmp_end[s] = len;
         }
-        { const uint4 row_ = make_row(j, s, r0, r1, r2, r3); rows[v.row_base + qpos] = row_; TKAMD_PUBLISH_ROW(t, text, s, len, row_); }
+        { const uint4 row_ = make_row(j, s, r0, r1, r2, r3); rows[v.row_base + qpos] = row_; TKAMD_PUBLISH_ROW(t, text, s, it.len, row_); }
     }
 }
 // The queues of 17..32-byte (G = 32) and 33..64-byte words (G = 64): a few thousand words a batch, and a launch over them lasts as long
@@ -117,8 +118,8 @@ __device__ __forceinline__ void wordpiece_wide(const DevTables& t, const uint8_t
     for (uint32_t base = wave_global * WPW; base < n; base += n_waves * WPW) {
         const uint32_t item = base + sub;
         const bool valid = item < n;
-        uint32_t qpos = 0, s = 0, len = 0;
-        if (valid) { qpos = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qpos]; s = it.s; len = min(it.len, (uint32_t)G); }      // (the queue class bounds the length)
+        uint32_t qpos = 0, s = 0, len = 0, claim = 0;
+        if (valid) { qpos = qview_pos(s_qpre, v.sq_cap, item); const QItem it = v.q[qpos]; s = it.s; len = min(qitem_len(it.len), (uint32_t)G); claim = it.len & QLEN_CLAIM; }      // (the queue class bounds the length)
         // the word in registers (every lane of the group loads the same bytes: one line, broadcast)
         uint64_t k[G / 8];
 #pragma unroll
@@ -177,7 +178,7 @@ __device__ __forceinline__ void wordpiece_wide(const DevTables& t, const uint8_t
             }
             const uint4 row_ = make_row(j, s, r0, r1, r2, r3);
             rows[v.row_base + qpos] = row_;
-            TKAMD_PUBLISH_ROW(t, text, s, len, row_);
+            TKAMD_PUBLISH_ROW(t, text, s, len | claim, row_);
         }
     }
 }

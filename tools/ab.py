@@ -3,6 +3,8 @@
 
   python tools/ab.py c2 [--ood] [--steps 20] [--lines 1000000] -- "" "TKAMD_X=1" "TKAMD_X=1 TKAMD_Y=2" ...
 
+A variant may also name another BUILD of the library: "AB_LIB=tools/ab_libs/r5_base.so" (a copy of an earlier commit's .so; they are
+git-ignored and travel to the GPU box like the product's).
 The corpus (three rotating batches, like bench.py) is generated and packed ONCE into /tmp; every variant is a child process
 with its environment variables that loads the packed batches (seconds instead of half a minute of corpus generation), checks
 a 1 % sample of every batch against the oracle AND the whole result against the first variant's checksums, times K rotating
@@ -48,6 +50,9 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
     import bench
     import tokenizers_amd as ta
     from oracle import oracle as orc
+    if os.environ.get("AB_LIB"):                             # a variant that is another BUILD of the library (tools/ab_libs/*.so: an earlier commit's)
+        from tokenizers_amd import _lib
+        _lib.LIB_PATH, _lib._lib = os.path.join(ROOT, os.environ["AB_LIB"]), None
     js, _, _ = bench.load_config(cfg)
     tok = ta.Tokenizer.from_str(js, device=0)
     o = orc.Oracle(js)
@@ -103,7 +108,7 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
         for name, v in tok.debug_phases().items():
             if v[7]:
                 phases[name] = [round(x / v[7], 3) for x in v[:5]]
-    print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if k.startswith("TKAMD_") and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
+    print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if (k.startswith("TKAMD_") or k == "AB_LIB") and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
                                      "gbps": round(nb / best / 1e9, 2), "ms": round(best * 1e3, 4), "sum_kernels_ms": round(sum(st.values()), 4),
                                      "kernels_ms": {k: v for k, v in sorted(st.items(), key=lambda kv: -kv[1]) if v >= 0.003}, "queues": tok.queue_sizes(),
                                      "phases": phases}), flush=True)
