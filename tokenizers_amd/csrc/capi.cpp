@@ -211,6 +211,7 @@ struct Workspace {
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
+    DevBuf w_lstate;                             // look-back state of the fused pre-tokenizer + lookup pass (kernels/lookup.hip FUSED)
     DevBuf w_claims, w_claim_rows, w_claim_pos;  // in-batch word claims (kernels.hpp WordCache::claims), the rows of the claimed slots, the claimants' first bytes
     DevBuf w_phases;                             // TKAMD_PHASES: shader-clock ticks per phase of the lookup / compaction, [2][PHASE_WGS][8] u64 (tkamd_debug_phases)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
@@ -267,6 +268,7 @@ struct tkamd_tokenizer {
     int n_hot = 0;
     int hot_slots = 1024;        // slots of the hot-word table (kernels/lookup.hip: 1024 = three lookup workgroups per CU -- the default since the short-word
                                  // table made a miss of the hot table cheap: 0.2237 against 0.2279 ms on C2, 0.246 against 0.265 on C3, profiles/r4m_* --, 2048 = two; TKAMD_HOT_SLOTS)
+    bool lu_fused = false;       // the plain GPT-2 byte-level path runs pre-tokenizer + mask scan + lookup as ONE kernel (kernels/lookup.hip FUSED; TKAMD_FUSED=0: three)
     int cp_grid = 0;             // grid of k_compact: what is resident at once (any grid makes progress -- its look-back helps itself --, TKAMD_CP_GRID)
     // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
     // of the step (the claims' worst case).  Inside a batch every lookup workgroup gives the claims up by itself once
@@ -668,7 +670,11 @@ void build_hot_table(tkamd_tokenizer* t) {
 // are sized for the worst case outright; the <= 16-byte queue (worst case: half the bytes) starts at 1 / q16_div of them and
 // the batch is run again with the worst-case size if it ever overflows (ERR_QUEUE_FULL; natural text queues 1/50 .. 1/6).
 // the lookup's grid: what is resident at once (kernels/lookup.hip LuShape), one private sub-queue per workgroup
-int lookup_grid(const tkamd_tokenizer* t) { return std::min((t->hot_slots == 1024 ? 3 : 2) * t->n_cu, (int)NSQ); }
+// (test hook TKAMD_LU_GRID: a grid no launch would pick -- the fused pass's look-back must make progress at any grid and residency)
+int lookup_grid(const tkamd_tokenizer* t) {
+    static const int forced = [] { const char* e = test_hook("TKAMD_LU_GRID"); return e ? std::max(1, std::min(atoi(e), (int)NSQ)) : 0; }();
+    return forced ? forced : std::min((t->hot_slots == 1024 && !t->lu_fused ? 3 : 2) * t->n_cu, (int)NSQ);
+}
 
 struct QueueSizes {
     uint32_t sq_cap[4], row_base[4];
@@ -792,6 +798,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
         z.add(w->w_cstate.p, cstate_bytes);
+        if (t->lu_fused) {                                 // the fused pass's look-back state: 8 bytes per 16 KB tile of text
+            const size_t lb = (((size_t)n_x / LOOKUP_TILE_BYTES + 2) * 8 + 15) & ~(size_t)15;
+            w->w_lstate.reserve(lb);
+            z.add(w->w_lstate.p, lb);
+        }
         if (use_claims) {
             // one slot per 64 bytes of the INPUT text (a word is a few bytes, most are repeats), 2^18 .. 2^24 slots: 32 MB of claims (two
             // 64-bit words a slot) + 32 MB of rows for a 120 MB batch.  (Not of the normalised text's bound, three times that behind BertNormalizer: the
@@ -1380,7 +1391,31 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
 
     uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
     bool has_end = false;             // the pre-tokenizer produced an end bitmask
-    if (hm.pretok == PT_BYTELEVEL_GPT2) {
+    // The fused pass (round 5, kernels/lookup.hip FUSED): for the plain GPT-2 byte-level BPE -- the text as the caller gave it, no added
+    // tokens -- the pre-tokenizer, the mask scan and the lookup are ONE kernel over the text; the start mask and its prefix counts leave
+    // it for the stages behind (k_doc_first_pretok, the offsets pass), which therefore run after it.  TKAMD_FUSED=0: the three kernels.
+    static const bool fused_on = [] { const char* e = getenv("TKAMD_FUSED"); return !(e && !strcmp(e, "0")); }();
+    static const bool pretok_default = [] { const char* e = getenv("TKAMD_PRETOK"); return !e || (strcmp(e, "bits") && strcmp(e, "lds")); }();
+    const bool fused = fused_on && pretok_default && t->lu_fused && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe && !matchmask &&
+                       !x_len_dev && x_text == d_text && n_bytes > 0;
+    auto after_masks = [&]() {        // what reads the start mask and its prefix counts: behind the pre-tokenizer + scan, or behind the fused pass
+        if (want_meta) {
+            // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
+            // the bitmasks (k_lookup) and from (start, length) queue entries
+            pf.begin("emit_pretok");
+            launch_emit_pretok(st, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, w->w_pt_start.as<uint32_t>());
+            if (pt_end) launch_emit_pretok_end(st, w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, pt_end);
+            pf.end();
+        }
+        pf.begin("doc_first_pretok");
+        launch_doc_first_pretok(st, lean ? raw_doc_off : x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
+                                d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(), t->cp_items,
+                                lean ? d_err : nullptr, lean ? w->w_doc_off.as<int64_t>() : nullptr);
+        pf.end();
+    };
+    if (fused) {
+        // (nothing here: launch_lookup_fused below)
+    } else if (hm.pretok == PT_BYTELEVEL_GPT2) {
         // Two implementations of the same predicate: the LDS-window kernel (default, faster: 0.33 ms @C2) and the
         // bit-parallel ballot kernel (TKAMD_PRETOK=bits; its 64-bit mask algebra lands on the scalar unit, one per
         // CU, and measures 0.54 ms) -- kept as an independent cross-check of the window logic.
@@ -1420,24 +1455,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (matchmask)
         launch_apply_matches(st, w->w_startmask.as<ull>(), has_end ? w->w_endmask.as<ull>() : nullptr, matchmask, w->w_spanmask.as<ull>(),
                              w->w_stopmask.as<ull>(), W, n_match);
-    pf.begin("mask_scan");
-    // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
-    // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
-    launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
-    pf.end();
-    if (want_meta) {
-        // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
-        // the bitmasks (k_lookup) and from (start, length) queue entries
-        pf.begin("emit_pretok");
-        launch_emit_pretok(st, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, w->w_pt_start.as<uint32_t>());
-        if (pt_end) launch_emit_pretok_end(st, w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, pt_end);
+    if (!fused) {
+        pf.begin("mask_scan");
+        // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
+        // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
+        launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
         pf.end();
+        after_masks();
     }
-    pf.begin("doc_first_pretok");
-    launch_doc_first_pretok(st, lean ? raw_doc_off : x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
-                            d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(), t->cp_items,
-                            lean ? d_err : nullptr, lean ? w->w_doc_off.as<int64_t>() : nullptr);
-    pf.end();
 
     uint32_t* tmp_end = (off_mode != TKAMD_OFFSETS_NONE) ? w->w_tmp_end.as<uint32_t>() : nullptr;
     const size_t N = (size_t)n_x;
@@ -1523,12 +1548,17 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         if (pub_inline) { mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; mdt.pub_pos = wc.claim_pos; }
     };
     if (hm.model == MODEL_BPE) {
-        pf.begin("lookup");
+        pf.begin(fused ? "pretok_scan_lookup" : "lookup");
         open_word_cache();
         set_publish();
-        launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters, t->hot_slots);
+        if (fused)
+            launch_lookup_fused(st, lookup_grid(t), t->dt, x_text, n_x, w->w_docmask.as<ull>(), w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
+                                w->w_tok0.as<uint32_t>(), plan, d_err, t->t_hot.p, wc, phases_of(0), d_counters, w->w_lstate.as<ull>(), d_npretok);
+        else
+            launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+                          w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters, t->hot_slots);
         pf.end();
+        if (fused) after_masks();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
         // TKAMD_MERGE16 = row / lane, TKAMD_LDSCFG = 0: the 16-lane DPP-row kernel / the register-resident lane kernels (A/B
@@ -1900,6 +1930,12 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
         if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 2048 ? 2048 : 1024;
+        {
+            const char* e = getenv("TKAMD_FUSED");
+            const HostModel& hm = t->hm;
+            t->lu_fused = !(e && !strcmp(e, "0")) && t->hot_slots == 1024 && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe &&
+                          hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !hm.add_prefix_space;
+        }
         build_shortw_table(t.get());
         build_hot_table(t.get());
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));

@@ -310,6 +310,11 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
                    uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr, uint32_t* counters = nullptr, int hot_slots = 2048);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
+// the plain GPT-2 byte-level path: pre-tokenizer (from docmask), mask scan and lookup in ONE pass over the text; leaves startmask_out /
+// wprefix_out / *n_pretok_out for the stages behind it.  lb_state: 8 bytes per LOOKUP_TILE_BYTES of text, zero on entry.  grid <= 2 x CUs.
+void launch_lookup_fused(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+                         unsigned long long* startmask_out, uint32_t* wprefix_out, uint32_t* tok0, const QueuePlan& plan, int* err, const void* hot,
+                         const WordCache& wc, void* phases, uint32_t* counters, unsigned long long* lb_state, int64_t* n_pretok_out);
 // group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
 // 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
 // also (group 6 only): a second queue for the same launch

@@ -20,8 +20,8 @@ void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs,
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant) {
     static const int lut_copies = [] { const char* e = getenv("TKAMD_SQ_LUT"); return e ? atoi(e) : SQ_LUT_COPIES; }();
-    if (variant == 2 && lut_copies == 1)
-        hipLaunchKernelGGL(k_pretok_gpt2_seq<1>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+    if (variant == 2 && lut_copies == 4)
+        hipLaunchKernelGGL(k_pretok_gpt2_seq<4>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
     else if (variant == 2 && lut_copies == 2)
         hipLaunchKernelGGL(k_pretok_gpt2_seq<2>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
     else if (variant == 2)
@@ -97,6 +97,48 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
         else TKAMD_LU(false, false, 2048);
     }
 #undef TKAMD_LU
+}
+// pre-tokenizer + mask scan + lookup in one pass (kernels/lookup.hip FUSED): the plain GPT-2 byte-level path
+void launch_lookup_fused(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
+                         unsigned long long* startmask_out, uint32_t* wprefix_out, uint32_t* tok0, const QueuePlan& plan, int* err, const void* hot,
+                         const WordCache& wc, void* phases, uint32_t* counters, unsigned long long* lb_state, int64_t* n_pretok_out) {
+    LookupArgs a{};
+    static const uint32_t adapt = [] { const char* e = getenv("TKAMD_CLAIM_ADAPT"); return (e && !strcmp(e, "0")) ? 0u : 1u; }();
+    static const uint32_t patience = [] {       // (a test hook, like the compaction's: read only next to TKAMD_TEST_HOOKS=1)
+        const char* const on = getenv("TKAMD_TEST_HOOKS");
+        const char* e = (on && !strcmp(on, "1")) ? getenv("TKAMD_LB_PATIENCE") : nullptr;
+        return e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE;
+    }();
+    a.claim_adapt = adapt;
+    a.counters = counters;
+    a.shortw = (const uint4*)t.shortw;
+    a.shortw_mask = t.shortw_mask;
+    a.shortw_disp = t.shortw_disp;
+    a.shortw_k3 = t.shortw_k3;
+    a.word_seed = t.word_seed;
+    a.any_hit_final = t.ignore_merges;
+    a.unk_id = t.unk_id;
+    a.has_unk = t.has_unk;
+    a.text = text;
+    a.n_bytes_host = n_bytes;
+    a.tok0 = tok0;
+    for (int c = 0; c < 4; ++c) a.v[c] = plan.v[c];
+    a.err = err;
+    a.hot = (const uint4*)hot;
+    a.cache_keys = wc.keys;
+    a.claims = wc.claims;
+    a.claim_mask = wc.claim_mask;
+    a.phases = (unsigned long long*)phases;
+    a.docmask = docmask;
+    a.uc1 = t.uc1;
+    a.uc2 = t.uc2;
+    a.startmask_out = startmask_out;
+    a.wprefix_out = wprefix_out;
+    a.lb_state = lb_state;
+    a.n_pretok_out = n_pretok_out;
+    a.lb_patience = patience;
+    if (phases) hipLaunchKernelGGL((k_lookup<false, true, 1024, true>), dim3(grid), dim3(LU_NT), lookup_fused_lds_bytes(), st, a);
+    else hipLaunchKernelGGL((k_lookup<false, false, 1024, true>), dim3(grid), dim3(LU_NT), lookup_fused_lds_bytes(), st, a);
 }
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                       uint32_t* tmp_ids, uint32_t* tmp_end, const QView* also) {
@@ -250,6 +292,8 @@ int prepare_long_kernel() {
     TKAMD_LU_ATTR(true, false, 2048); TKAMD_LU_ATTR(false, false, 2048); TKAMD_LU_ATTR(true, true, 2048); TKAMD_LU_ATTR(false, true, 2048);
     TKAMD_LU_ATTR(true, false, 1024); TKAMD_LU_ATTR(false, false, 1024); TKAMD_LU_ATTR(true, true, 1024); TKAMD_LU_ATTR(false, true, 1024);
 #undef TKAMD_LU_ATTR
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false, false, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_fused_lds_bytes());
+    if (rc == 0) rc = (int)hipFuncSetAttribute((const void*)k_lookup<false, true, 1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lookup_fused_lds_bytes());
     if (rc == 0) rc = prepare_lds_merge<16, 640, true, true>();
     if (rc == 0) rc = prepare_lds_merge<32, 768, true, true>();
     return rc;

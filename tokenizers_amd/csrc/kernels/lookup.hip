@@ -47,12 +47,24 @@ constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile
 //               (8 KB), pass 2 two steps side by side: 80 KB of LDS, two workgroups per CU.  The default until the short-word table
 //               made a miss of the hot table cheap (profiles/r4m_*: 0.2279 against 0.2237 ms on C2, 0.265 against 0.246 on C3, level on C4
 //               and on out-of-distribution text)
-template <int HOT> struct LuShape {
+//   FUSED (round 5, HOT = 1024 only)  the pre-tokenizer, the mask scan and the lookup in ONE pass over the text: the tile's start mask is
+//               computed from the staged text (pretok_gpt2_core.hpp, the same host+device function k_pretok_gpt2_seq runs), its rank in the
+//               batch comes from a decoupled look-back over the tiles' counts (results.hip), and the tile's tok0 words are staged in LDS
+//               and written once, coalesced, when the look-back has resolved -- behind the tile's own work, so nobody waits for it.
+//               1,024 hot slots, 3,584 pre-tokens per round, 78 KB of LDS, <= 128 VGPRs: two workgroups per CU.  Only the lean GPT-2 path
+//               (no end masks, no added tokens, the text as the caller gave it).
+template <int HOT, bool FUSED = false> struct LuShape {
     static_assert(HOT == 2048 || HOT == 1024, "shapes the launcher knows");
-    static constexpr int POS_CAP = HOT == 2048 ? 3584 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
-    static constexpr bool DISP_LDS = HOT == 2048;                  // the 8 KB of short-word displacements in LDS (the other shape has no room: it reads them from memory)
-    static constexpr int WAVES_PER_SIMD = HOT == 2048 ? 4 : 6;     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU
+    static_assert(!FUSED || HOT == 1024, "the fused shape has 1,024 hot slots");
+    static constexpr int POS_CAP = (HOT == 2048 || FUSED) ? 3584 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
+    static constexpr bool DISP_LDS = HOT == 2048;                  // the 8 KB of short-word displacements in LDS (the other shapes have no room: they read them from memory)
+    static constexpr int WAVES_PER_SIMD = (HOT == 2048 || FUSED) ? 4 : 6;     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU
+    static constexpr int TEXT_SLACK = FUSED ? 128 : 64;            // staged past the tile: a key may start at its last byte (fused: and the pre-tokenizer decides 80 bytes beyond the tile)
 };
+constexpr int LU_LUT_COPIES = 1;                         // fused: replicas of the pre-tokenizer's 2 KB flag table (pretok_gpt2.hip)
+constexpr int LU_WINDOWS = 343;                          // fused: 48-byte windows of the pre-tokenizer per tile (343 x 48 = the tile + 80 bytes: where its last pre-token ends)
+constexpr int LU_MASK_WORDS = LU_TILE_WORDS + 2;         // fused: the tile's mask words + the two the windows spill into
+static_assert(LU_WINDOWS * G2W_MAIN >= LU_TILE + 64 && (LU_WINDOWS * G2W_MAIN + 63) / 64 <= LU_MASK_WORDS, "the windows cover the tile and one more pre-token start");
 constexpr uint32_t CLAIM_ADAPT_MIN = 768u;               // candidates a workgroup looks at before it judges the claims' yield (about two tiles of prose)
 
 struct LookupArgs {
@@ -83,6 +95,17 @@ struct LookupArgs {
     uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
+    // FUSED only: the document-start mask the pre-tokenizer reads, the Unicode class table, what the tile leaves for the later stages
+    // (start mask and its per-word prefix counts: k_doc_first_pretok, offsets), the look-back state (8 bytes per tile, zeroed), the
+    // batch's pre-token count
+    const unsigned long long* docmask;
+    const uint16_t* uc1;
+    const uint8_t* uc2;
+    unsigned long long* startmask_out;
+    uint32_t* wprefix_out;
+    unsigned long long* lb_state;
+    int64_t* n_pretok_out;
+    uint32_t lb_patience;
 };
 // phases of k_lookup<.., true>, as wavefront 0 sees the workgroup's barriers: staging the tile (LDS stores, the last pre-token's end,
 // next tile's prefetch issued), expanding the mask bits into positions, pass 1, pass 2, pass 3 (+ waiting for the slowest wavefront);
@@ -93,18 +116,31 @@ enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_P
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
 
 // (claim_hash_long / claim_slot / CLAIM_MAX_LEN: bpe.hip, next to the publish helper the model kernels call)
-template <bool HAS_END, bool PROF = false, int HOT = 2048>
-__global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(LookupArgs a) {      // (4 wavefronts / SIMD: <= 128 VGPRs; 6: <= 80)
-    constexpr int LU_POS_CAP = LuShape<HOT>::POS_CAP;
+template <bool HAS_END, bool PROF = false, int HOT = 2048, bool FUSED = false>
+__global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void k_lookup(LookupArgs a) {      // (4 wavefronts / SIMD: <= 128 VGPRs; 6: <= 80)
+    static_assert(!FUSED || !HAS_END, "the fused pass is the GPT-2 pre-tokenizer's: no end masks");
+    using Shape = LuShape<HOT, FUSED>;
+    constexpr int LU_POS_CAP = Shape::POS_CAP;
+    constexpr int LU_TEXT_SLACK = Shape::TEXT_SLACK;
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lu_lds)
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT]
     uint16_t* s_hdisp = (uint16_t*)(s_hot + HOT);                               // [HOT / 4]
-    uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
+    // (fused: sixteen bytes in FRONT of the tile are staged too -- the pre-tokenizer's first window starts eight bytes before it)
+    uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4) + (FUSED ? 4 : 0);      // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
     uint8_t* s_wdisp = (uint8_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [SHORTW_BUCKETS] if DISP_LDS, else nothing (16-byte aligned: copied sixteen bytes a lane)
-    uint16_t* s_pos = (uint16_t*)(s_wdisp + (LuShape<HOT>::DISP_LDS ? SHORTW_BUCKETS : 0));    // [LU_POS_CAP + 2] start of rank r, relative to the tile
+    uint16_t* s_pos = (uint16_t*)(s_wdisp + (Shape::DISP_LDS ? SHORTW_BUCKETS : 0));    // [LU_POS_CAP + 2] start of rank r, relative to the tile
     uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
+    // fused only: the tile's tok0 words (written once, when the tile's place in the batch is known), its start-mask words (+ the two the
+    // windows spill into), the pre-tokenizer's flag table; the document-mask words the windows read share the tok0 words' place (they
+    // are dead before pass 1 stores its first word)
+    uint32_t* s_tok = (uint32_t*)(s_end + LU_POS_CAP + 2);                      // [LU_POS_CAP]
+    unsigned long long* s_mask = (unsigned long long*)(s_tok + LU_POS_CAP);    // [LU_MASK_WORDS]
+    Gpt2Flags* s_lut = (Gpt2Flags*)(s_mask + LU_MASK_WORDS);                   // [LU_LUT_COPIES * 256]
+    unsigned long long* s_doc = (unsigned long long*)s_tok;                    // [LU_MASK_WORDS + 2] mask words w0 - 1 ..
     static_assert(((LU_TILE + LU_TEXT_SLACK) + 16) % 16 == 0 && hot_table_bytes(HOT) % 16 == 0, "s_wdisp is copied sixteen bytes a lane");
+    static_assert((2 * (LU_POS_CAP + 2) + LU_POS_CAP) % 4 == 0, "s_tok is 8-byte aligned: s_doc shares its place");
+    __shared__ uint32_t s_wsum[LU_WAVES];                                       // fused: the wavefronts' start counts
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
     __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand, s_ncandl;
     // the claims' yield as this workgroup sees it: candidates it looked at, how many of them were another pre-token's word.  Text that
@@ -125,9 +161,14 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
     static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
     for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
-    if (LuShape<HOT>::DISP_LDS)
+    if (Shape::DISP_LDS)
         for (int i = tid; i < SHORTW_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.shortw_disp)[i];
-    const uint8_t* const wdisp = LuShape<HOT>::DISP_LDS ? (const uint8_t*)s_wdisp : a.shortw_disp;
+    const uint8_t* const wdisp = Shape::DISP_LDS ? (const uint8_t*)s_wdisp : a.shortw_disp;
+    if (FUSED && tid < 256) {
+        const Gpt2Flags f = gpt2_byte_flags((uint32_t)tid);
+#pragma unroll
+        for (int c = 0; c < LU_LUT_COPIES; ++c) s_lut[c * 256 + tid] = f;
+    }
     if (tid < 17) {
         const uint32_t l = (uint32_t)tid;
         auto m = [&](uint32_t lo) -> uint32_t { return l >= lo + 4u ? 0xFFFFFFFFu : (l > lo ? ((1u << (8u * (l - lo))) - 1u) : 0u); };
@@ -144,30 +185,33 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
     // What a tile needs from memory -- its text, its mask words with their prefix counts, and the 64 mask words behind it (where its
     // last pre-token ends) -- is loaded into registers one tile AHEAD: the loads of tile k+1 are issued before the lookup phase of
     // tile k and have long arrived when tile k+1 starts, so no phase of a tile begins with a memory round trip.
-    static_assert((LU_TILE + LU_TEXT_SLACK) / 16 == 2 * LU_NT + 4, "two 16-byte text chunks per lane (+ the slack chunks of lanes 0..3)");
+    constexpr int LU_SLACK_CHUNKS = LU_TEXT_SLACK / 16;              // (fused: lanes 0..7 load the slack, lane 8 the sixteen bytes in front of the tile)
+    static_assert((LU_TILE + LU_TEXT_SLACK) / 16 == 2 * LU_NT + LU_SLACK_CHUNKS, "two 16-byte text chunks per lane (+ the slack chunks of the first lanes)");
+    const int64_t n_words_host = (a.n_bytes_host >> 6) + 1;          // words of the document / start masks
     static_assert(LU_NT == 2 * LU_TILE_WORDS, "two lanes per mask word");
     Unaligned16 pf_t0{0u, 0u, 0u, 0u}, pf_t1{0u, 0u, 0u, 0u}, pf_ts{0u, 0u, 0u, 0u};
     unsigned long long pf_ms = 0ull, pf_me = 0ull, pf_scan = 0ull;
     uint32_t pf_wp = 0u, pf_first = 0u;
     // (the three-workgroups-per-CU shape has 80 VGPRs: it keeps the masks a tile ahead but loads the text when the tile starts -- the
     // other two workgroups of the CU cover that round trip)
-    constexpr bool PF_TEXT = HOT == 2048;
+    constexpr bool PF_TEXT = HOT == 2048;      // (fused: A/B, tools/ab_libs/r5_fused_pf.so has it on)
     auto load_text = [&](int64_t tile, Unaligned16& x0, Unaligned16& x1, Unaligned16& xs) {
         x0 = x1 = xs = Unaligned16{0u, 0u, 0u, 0u};
         if (tile >= n_tiles) return;
         const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
-        const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT, gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
+        const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT;
+        const int64_t gs = (FUSED && tid == LU_SLACK_CHUNKS) ? t0 - 16 : t0 + 16 * (int64_t)(2 * LU_NT + tid);
         // (the tile's text, its masks and the tok0 words are read / written once: non-temporal accesses, kernels.hip -- level here, 0.2279
         // against 0.229 ms, 3 % in the compaction; profiles/r4m_ab_c2.txt)
         if (g0 + 16 <= readable) x0 = load_nt16(a.text + g0);
         if (g1 + 16 <= readable) x1 = load_nt16(a.text + g1);
-        if (tid < 4 && gs + 16 <= readable) xs = load_nt16(a.text + gs);
+        if (tid < LU_SLACK_CHUNKS + (FUSED ? 1 : 0) && gs >= 0 && gs + 16 <= readable) xs = load_nt16(a.text + gs);
     };
     auto prefetch = [&](int64_t tile) {
         if (PF_TEXT) load_text(tile, pf_t0, pf_t1, pf_ts);
         pf_ms = pf_me = pf_scan = 0ull;
         pf_wp = pf_first = 0u;
-        if (tile >= n_tiles) return;
+        if (FUSED || tile >= n_tiles) return;                        // (fused: the masks are this kernel's own work)
         const int64_t w0 = tile * LU_TILE_WORDS;
         const int64_t w = w0 + hword;
         if (w < total_words) { pf_ms = load_nt(a.startmask + w); pf_wp = load_nt(a.wprefix + w); }
@@ -191,13 +235,84 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         auto stage_text = [&]() {
             ((uint4*)s_text32)[tid] = make_uint4(tx0.a, tx0.b, tx0.c, tx0.d);
             ((uint4*)s_text32)[tid + LU_NT] = make_uint4(tx1.a, tx1.b, tx1.c, tx1.d);
-            if (tid < 4) ((uint4*)s_text32)[2 * LU_NT + tid] = make_uint4(txs.a, txs.b, txs.c, txs.d);
+            if (tid < LU_SLACK_CHUNKS) ((uint4*)s_text32)[2 * LU_NT + tid] = make_uint4(txs.a, txs.b, txs.c, txs.d);
+            if (FUSED && tid == LU_SLACK_CHUNKS) ((uint4*)s_text32)[-1] = make_uint4(txs.a, txs.b, txs.c, txs.d);
         };
         if (PF_TEXT) stage_text();
         // ---- 2. the tile's mask words: local rank of each word's first start ----
-        const unsigned long long ms = pf_ms, me = pf_me;
+        unsigned long long ms = pf_ms;
+        const unsigned long long me = pf_me;
         uint32_t rbase = 0xFFFFFFFFu;
-        {
+        if (FUSED) {
+            // ---- 2f. the pre-tokenizer on the staged tile.  Window v (lane v < LU_WINDOWS) decides the 48 bytes [48 v, 48 v + 48) of the
+            // tile from the 64 staged bytes around them (pretok_gpt2_core.hpp: the function k_pretok_gpt2_seq runs, fed from LDS); four
+            // lanes' 48-bit results are three mask words.  The windows reach 80 bytes beyond the tile: where its last pre-token ends.
+            if (tid < LU_MASK_WORDS + 2) {
+                const int64_t wi = w0 - 1 + tid;
+                s_doc[tid] = (wi >= 0 && wi < n_words_host) ? a.docmask[wi] : 0ull;
+            }
+            __syncthreads();                                         // the staged text and the document words are in LDS
+            unsigned long long out = 0ull;
+            if (tid < LU_WINDOWS && t0 + (int64_t)G2W_MAIN * tid < n_bytes) {
+                const int64_t base = t0 + (int64_t)G2W_MAIN * tid - G2W_HALO;      // the text's byte under window byte 0
+                uint32_t w[16];
+                const uint2* const src = (const uint2*)(s_text32 + 12 * tid - 2);  // (eight bytes in front of the window's own: 8-byte aligned)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const uint2 v = src[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
+                Gpt2Window m;
+                const int vlo = base < 0 ? (int)-base : 0;
+                const int64_t rem = n_bytes - base;
+                m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
+                const uint32_t rel = (uint32_t)(G2W_MAIN * tid) + 64u - (uint32_t)G2W_HALO, sh = rel & 63u;      // the window's first bit in s_doc (which starts one word before the tile)
+                m.D = s_doc[rel >> 6] >> sh;
+                if (sh) m.D |= s_doc[(rel >> 6) + 1u] << (64u - sh);
+                m.D &= m.V;
+                gpt2_window_flags(w, s_lut + (tid & (LU_LUT_COPIES - 1)) * 256, m);
+                out = (gpt2_window_starts(m, a.text, base, a.uc1, a.uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
+            }
+            {
+                const unsigned long long nxt = __shfl_down(out, 1, 64);
+                const int q = tid & 3, word = 3 * (tid >> 2) + q;
+                if (q < 3 && word < LU_MASK_WORDS) s_mask[word] = (out >> (16 * q)) | (nxt << (G2W_MAIN - 16 * q));
+            }
+            __syncthreads();                                         // (s_doc is dead: its place is s_tok's from here on)
+            // ranks inside the tile: the lane pair of word w needs the starts in the words before it
+            ms = s_mask[hword];
+            const uint32_t pc = half ? 0u : (uint32_t)__popcll(ms);
+            const uint32_t incl = wave_incl_scan(pc);
+            if (lane == 63) s_wsum[wave] = incl;
+            // end of the tile's LAST pre-token: the first start behind the tile -- in the two spill words, or (a pre-token of more than 80
+            // bytes across the tile's edge) wherever wavefront 0 finds it, pre-tokenizing on from global memory, 64 windows a step
+            if (wave == 0) {
+                const unsigned long long m0 = s_mask[LU_TILE_WORDS], m1 = s_mask[LU_TILE_WORDS + 1];
+                const int64_t edge = t0 + LU_TILE;
+                int64_t found = n_bytes;
+                if (m0) found = edge + (__ffsll(m0) - 1);
+                else if (m1) found = edge + 64 + (__ffsll(m1) - 1);
+                else {
+                    for (int64_t p0 = t0 + (int64_t)LU_WINDOWS * G2W_MAIN; p0 < n_bytes; p0 += 64 * G2W_MAIN) {
+                        const unsigned long long o = gpt2_starts_at(a.text, p0 + (int64_t)G2W_MAIN * lane, n_bytes, n_words_host, (const uint64_t*)a.docmask, s_lut, a.uc1, a.uc2);
+                        const uint64_t any = __ballot(o != 0ull);
+                        if (any) {
+                            const int l = __ffsll((unsigned long long)any) - 1;
+                            const unsigned long long oo = ((unsigned long long)(uint32_t)__shfl((int)(o >> 32), l, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)o, l, 64);
+                            found = p0 + (int64_t)G2W_MAIN * l + (__ffsll(oo) - 1);
+                            break;
+                        }
+                    }
+                }
+                if (lane == 0) s_last_end = (uint32_t)min(found, n_bytes);
+            }
+            __syncthreads();
+            uint32_t before = 0u, total = 0u;
+#pragma unroll
+            for (int q = 0; q < LU_WAVES; ++q) { const uint32_t c = s_wsum[q]; before += q < wave ? c : 0u; total += c; }
+            rbase = before + incl - (uint32_t)__popcll(ms);
+            if (tid == 0) {
+                s_n = total;
+                lb_publish(a.lb_state, tile, (unsigned long long)total);      // (early: the tiles behind this one look back over it)
+            }
+        } else {
             const int64_t w = w0 + hword;
             if (w < total_words) rbase = pf_wp - pf_first;
             if (tid == 0) s_pbase = pf_first;
@@ -205,7 +320,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         }
         // end of the tile's LAST pre-token when it lies beyond the tile: the next start (or end bit) after the tile -- almost always in
         // the 64 prefetched words behind it; otherwise wavefront 0 walks the mask on
-        if (wave == 0) {
+        if (!FUSED && wave == 0) {
             const unsigned long long* mk = has_end ? a.endmask : a.startmask;
             const int64_t lim = has_end ? end_words : total_words;
             int64_t w = w0 + LU_TILE_WORDS;
@@ -230,8 +345,44 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
         tick(LU_PH_STAGE);
         const bool claims_now = s_claims_on != 0u;                   // (workgroup-uniform for the whole tile)
         const uint32_t n = s_n;                                      // pre-tokens starting in this tile
-        const uint32_t pbase = s_pbase;                              // global rank of the first one
+        uint32_t pbase = FUSED ? 0u : s_pbase;                       // global rank of the first one (fused: known when the look-back has resolved, behind round 0)
         const uint32_t last_rel = s_last_end - (uint32_t)t0;         // (positions below are relative to the tile)
+        // (fused) The tile's place in the batch -- the pre-tokens in front of it -- is the sum of the counts the tiles before it have
+        // published since the top of THEIR work (results.hip: a count that is still missing after `patience` polls is computed here, by
+        // pre-tokenizing that tile from global memory: finite work, whoever waits).  Called by the whole workgroup behind round 0 of the
+        // tile -- by then the look-back finds everything published -- and leaves what the later stages read: the start mask and the
+        // number of starts in front of every word of it, and (the last tile) the batch's pre-token count.
+        auto place_tile = [&]() {
+            if (wave == 0) {
+                auto tile_count = [&](int64_t hc) -> unsigned long long {
+                    const int64_t tb = hc * LU_TILE;
+                    uint32_t c = 0u;
+#pragma unroll 1
+                    for (int v0 = 0; v0 < LU_TILE / G2W_MAIN + 1; v0 += 64) {
+                        const int vv = v0 + lane;                                // window vv decides bytes [48 vv, 48 vv + 48) of tile hc
+                        if (vv * G2W_MAIN < LU_TILE) {
+                            unsigned long long o = gpt2_starts_at(a.text, tb + (int64_t)G2W_MAIN * vv, n_bytes, n_words_host, (const uint64_t*)a.docmask, s_lut, a.uc1, a.uc2);
+                            const int keep = LU_TILE - vv * G2W_MAIN;            // (the last window straddles the tile's edge)
+                            if (keep < G2W_MAIN) o &= (1ull << keep) - 1ull;
+                            c += (uint32_t)__popcll(o);
+                        }
+                    }
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+                    return (unsigned long long)c;
+                };
+                const unsigned long long r = lb_resolve(a.lb_state, tile, (unsigned long long)n, a.lb_patience, tile_count);
+                if (lane == 0) s_pbase = (uint32_t)r;
+            }
+            __syncthreads();
+            pbase = s_pbase;
+            if (!half && w0 + hword < n_words_host) {
+                a.startmask_out[w0 + hword] = ms;
+                a.wprefix_out[w0 + hword] = pbase + rbase;
+            }
+            if (tid == 0 && tile == n_tiles - 1) *a.n_pretok_out = (int64_t)pbase + (int64_t)n;
+        };
+        if (FUSED && n == 0u) place_tile();                          // (a tile inside one long pre-token: no round runs)
         for (uint32_t rb = 0; rb < n; rb += LU_POS_CAP) {
             if (rb) __syncthreads();                                 // previous round has read s_pos / s_end
             const uint32_t cnt = min((uint32_t)LU_POS_CAP, n - rb);
@@ -287,7 +438,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 const uint32_t diff = (h.x ^ k0) | (h.y ^ k1) | (h.z ^ k2) | ((h.w >> 24) ^ len);
                 bool hit = v && diff == 0u && len != 0u && hits_on;
                 bool miss = v && !hit;
-                if (a.matchmask) {                                                  // wavefront-uniform: tokenizers with added tokens only
+                if (!FUSED && a.matchmask) {                                        // wavefront-uniform: tokenizers with added tokens only
                     const uint32_t s_abs = (uint32_t)t0 + s_rel;
                     if (v && len && ((a.matchmask[s_abs >> 6] >> (s_abs & 63u)) & 1ull)) {       // an added-token match: its id is patched in later
                         a.tok0[pbase + rb + rel] = 0u;
@@ -296,7 +447,9 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                     }
                 }
                 // (a.fill: the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them)
-                if (hit || (a.fill && miss)) {
+                if (FUSED) {
+                    if (hit) s_tok[rel] = TOK_ONE | (h.w & TOK_ID_MASK);             // (a miss leaves its word to pass 2 / 3; the tile's words go out together)
+                } else if (hit || (a.fill && miss)) {
                     const uint32_t w0 = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
                     store_nt(a.tok0 + pbase + rb + rel, w0);
                 }
@@ -337,7 +490,7 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                         }
                     }
                 }
-                if (v) store_nt(a.tok0 + pbase + rb + rel, out);
+                if (v) { if (FUSED) s_tok[rel] = out; else store_nt(a.tok0 + pbase + rb + rel, out); }
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
@@ -389,7 +542,11 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                 }
                 if (c0 != w0) return CLAIM_NONE;
                 if (c1 == w1) return CLAIM_SHARED;
-                if (!fresh1) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // word 1 is written once, so a value read is final; a 0 may be a stale line or the winner's store still on its way (it follows
+                // the compare-and-swap by a round trip: on a small batch of few distinct words -- every tile in flight at once -- a fifth of
+                // the occurrences arrived inside that window, profiles/r5a_pytest.txt).  A few fresh reads, never a wait without end.
+#pragma unroll 1
+                for (int tries = fresh1 ? 1 : 0; c1 == 0ull && tries < 4; ++tries) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return c1 == w1 ? CLAIM_SHARED : CLAIM_NONE;
             };
             // 16..32 bytes (9 % of C2's candidates): the entry names the claimant -- 0xFF << 56 | length << 32 | first byte -- and its BYTES in
@@ -550,6 +707,12 @@ __global__ __launch_bounds__(LU_NT, LuShape<HOT>::WAVES_PER_SIMD) void k_lookup(
                     finish(v, pend, rel, s_rel, len, out, r == CLAIM_HOLDS);
                 }
             }
+            if (FUSED) {
+                // ---- 6. the round's tok0 words, once and whole (the tile's place in the batch: place_tile above, behind round 0) ----
+                __syncthreads();
+                if (rb == 0u) place_tile();
+                for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)LU_NT) store_nt(a.tok0 + pbase + rb + i, s_tok[i]);
+            }
         }
     }
     // the fill of this workgroup's sub-queues (the counters were zeroed by the host; a workgroup without tiles leaves them 0)
@@ -622,6 +785,12 @@ constexpr int lookup_lds_bytes(int hot) {      // (the end array's place holds t
     return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 3584 : 3072) + 2) * 2 + (hot == 2048 ? 3584 : 3072) * 2 + (hot == 2048 ? SHORTW_BUCKETS : 0);
 }
 static_assert(lookup_lds_bytes(2048) + 1024 <= 81920, "two workgroups of the 2,048-slot shape share a CU's 160 KB (1 KB: the kernel's static LDS)");
+// the fused shape: 16 bytes in front of the tile, 128 behind it, the staged tok0 words, the tile's mask words, the pre-tokenizer's flag table
+constexpr int lookup_fused_lds_bytes() {
+    return hot_table_bytes(1024) + 16 + (LU_TILE + 128) + 16 + 2 * (3584 + 2) * 2 + 3584 * 2 + 3584 * 4 + LU_MASK_WORDS * 8 + LU_LUT_COPIES * 256 * 8;
+}
+static_assert(lookup_fused_lds_bytes() + 1024 <= 81920, "two workgroups of the fused shape share a CU's 160 KB");
+static_assert((LU_MASK_WORDS + 2) * 8 <= 3584 * 4, "the document-mask words fit the tok0 words' place"); 
 
 // =================================================================================================
 // K_word_cache_insert: after the merge kernels, every queued pre-token of <= 16 bytes whose result fits a row (<= 4 tokens) is

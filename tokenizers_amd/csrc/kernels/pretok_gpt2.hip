@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2(const uint8_t* __restrict__
 // of their masks (class lookup / literal check from memory).  ~13 instructions per byte instead of ~80 for the
 // lane-per-byte kernel.  Same predicate as k_pretok_gpt2.
 // =================================================================================================
-constexpr int SQ_MAIN = 48, SQ_HALO = 8, SQ_LUT_COPIES = 4;
+// SQ_LUT_COPIES: replicas of the per-lane kernels' 2 KB flag tables.  ONE since round 5: lanes that read the same entry are a broadcast,
+// the same entry of two replicas is a bank conflict (four replicas: k_pretok_gpt2_seq 0.0521 -> 0.0495 ms, profiles/r5a_ab_c2.txt)
+constexpr int SQ_MAIN = 48, SQ_HALO = 8, SQ_LUT_COPIES = 1;
 struct __attribute__((packed, aligned(8))) SqChunk { uint32_t a, b, c, d; };
 
 // COPIES: replicas of the 2 KB flag table, lane l reads replica l % COPIES.  (Lanes that read the SAME entry of one replica are a

@@ -90,37 +90,10 @@ TK_HD uint64_t gpt2_window_starts(Gpt2Window m, const uint8_t* text, int64_t bas
 struct __attribute__((packed, aligned(8))) LaneChunk16 { uint32_t a, b, c, d; };    // 16-byte load at 8-byte alignment
 struct __attribute__((packed, aligned(8))) LaneChunk8 { uint32_t a, b; };
 
-TK_HD uint64_t gpt2_lane_starts(const uint8_t* text, int64_t n_bytes, int64_t n_words_host, const uint64_t* docmask, const Gpt2Flags* lut,
-                                int64_t lane, const uint16_t* uc1, const uint8_t* uc2) {
-    const int64_t a = lane * G2W_MAIN;                       // first byte this lane decides
-    const int64_t base = a - G2W_HALO;                       // window = [base, base + 64)
-    if (a >= n_bytes) return 0;
-    uint32_t w[16];
-    {
-        // four 16-byte loads (8-byte aligned: gfx950 takes dwordx4 at any alignment); only lane 0's window starts before the text
-        LaneChunk16 c0{0, 0, 0, 0};
-        if (base >= 0) c0 = *(const LaneChunk16*)(text + base);
-        else { const LaneChunk8 t = *(const LaneChunk8*)text; c0.c = t.a; c0.d = t.b; }
-        const LaneChunk16 c1 = *(const LaneChunk16*)(text + base + 16), c2 = *(const LaneChunk16*)(text + base + 32),
-                          c3 = *(const LaneChunk16*)(text + base + 48);
-        w[0] = c0.a; w[1] = c0.b; w[2] = c0.c; w[3] = c0.d; w[4] = c1.a; w[5] = c1.b; w[6] = c1.c; w[7] = c1.d;
-        w[8] = c2.a; w[9] = c2.b; w[10] = c2.c; w[11] = c2.d; w[12] = c3.a; w[13] = c3.b; w[14] = c3.c; w[15] = c3.d;
-    }
-    Gpt2Window m;
-    // valid positions of the window and their document-start bits
-    const int vlo = base < 0 ? (int)-base : 0;
-    const int64_t rem = n_bytes - base;
-    m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
-    if (base < 0) m.D = docmask[0] << G2W_HALO;
-    else {
-        const int64_t wi = base >> 6;
-        const int sh = (int)(base & 63);
-        m.D = docmask[wi] >> sh;
-        if (sh && wi + 1 < n_words_host) m.D |= docmask[wi + 1] << (64 - sh);
-    }
-    m.D &= m.V;
-    // per-byte flags -> 64-bit masks: the table entries are one-hot flags 8 bits apart, so one shift-or per byte deposits a
-    // flag into four masks at once and every eight bytes the finished groups move into the 64-bit masks
+// flag deposit: the window's 64 bytes (16 dwords, little endian) -> the seven byte-class masks of Gpt2Window.  The table entries are
+// one-hot flags 8 bits apart, so one shift-or per byte deposits a flag into four masks at once and every eight bytes the finished
+// groups move into the 64-bit masks.  (V and D are the caller's.)
+TK_HD void gpt2_window_flags(const uint32_t* w, const Gpt2Flags* lut, Gpt2Window& m) {
     m.L = m.N = m.S = m.SP = m.C = m.AP = m.MU = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -144,6 +117,65 @@ TK_HD uint64_t gpt2_lane_starts(const uint8_t* text, int64_t n_bytes, int64_t n_
         m.AP |= (uint64_t)((accB >> 8) & 0xFFu) << (8 * g);
         m.MU |= (uint64_t)((accB >> 16) & 0xFFu) << (8 * g);
     }
+}
+// which bytes of the window [base, base + 64) exist, and which of them start a document (docmask: one bit per byte of the text,
+// n_words_host words)
+TK_HD void gpt2_window_valid(int64_t base, int64_t n_bytes, int64_t n_words_host, const uint64_t* docmask, Gpt2Window& m) {
+    const int vlo = base < 0 ? (int)-base : 0;
+    const int64_t rem = n_bytes - base;
+    m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
+    if (base < 0) m.D = docmask[0] << (int)-base;
+    else {
+        const int64_t wi = base >> 6;
+        const int sh = (int)(base & 63);
+        m.D = docmask[wi] >> sh;
+        if (sh && wi + 1 < n_words_host) m.D |= docmask[wi + 1] << (64 - sh);
+    }
+    m.D &= m.V;
+}
+
+TK_HD uint64_t gpt2_lane_starts(const uint8_t* text, int64_t n_bytes, int64_t n_words_host, const uint64_t* docmask, const Gpt2Flags* lut,
+                                int64_t lane, const uint16_t* uc1, const uint8_t* uc2) {
+    const int64_t a = lane * G2W_MAIN;                       // first byte this lane decides
+    const int64_t base = a - G2W_HALO;                       // window = [base, base + 64)
+    if (a >= n_bytes) return 0;
+    uint32_t w[16];
+    {
+        // four 16-byte loads (8-byte aligned: gfx950 takes dwordx4 at any alignment); only lane 0's window starts before the text
+        LaneChunk16 c0{0, 0, 0, 0};
+        if (base >= 0) c0 = *(const LaneChunk16*)(text + base);
+        else { const LaneChunk8 t = *(const LaneChunk8*)text; c0.c = t.a; c0.d = t.b; }
+        const LaneChunk16 c1 = *(const LaneChunk16*)(text + base + 16), c2 = *(const LaneChunk16*)(text + base + 32),
+                          c3 = *(const LaneChunk16*)(text + base + 48);
+        w[0] = c0.a; w[1] = c0.b; w[2] = c0.c; w[3] = c0.d; w[4] = c1.a; w[5] = c1.b; w[6] = c1.c; w[7] = c1.d;
+        w[8] = c2.a; w[9] = c2.b; w[10] = c2.c; w[11] = c2.d; w[12] = c3.a; w[13] = c3.b; w[14] = c3.c; w[15] = c3.d;
+    }
+    Gpt2Window m;
+    gpt2_window_valid(base, n_bytes, n_words_host, docmask, m);      // valid positions of the window and their document-start bits
+    gpt2_window_flags(w, lut, m);
+    return (gpt2_window_starts(m, text, base, uc1, uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
+}
+
+// The same for 48 bytes that start ANYWHERE in the text (first byte a >= 0): byte-unaligned loads.  The fused lookup (kernels/lookup.hip)
+// uses it off its main path -- a pre-token that runs on beyond the staged tile, a look-back that computes a missing tile's count.
+struct __attribute__((packed, aligned(1))) LaneChunk16u { uint32_t a, b, c, d; };
+TK_HD uint64_t gpt2_starts_at(const uint8_t* text, int64_t a, int64_t n_bytes, int64_t n_words_host, const uint64_t* docmask, const Gpt2Flags* lut,
+                              const uint16_t* uc1, const uint8_t* uc2) {
+    if (a >= n_bytes) return 0;
+    const int64_t base = a - G2W_HALO;
+    uint32_t w[16];
+    if (base >= 0) {
+        for (int k = 0; k < 4; ++k) {
+            const LaneChunk16u c = *(const LaneChunk16u*)(text + base + 16 * k);
+            w[4 * k] = c.a; w[4 * k + 1] = c.b; w[4 * k + 2] = c.c; w[4 * k + 3] = c.d;
+        }
+    } else {                                                 // (the text's first bytes: the window starts in front of it)
+        for (int k = 0; k < 16; ++k) w[k] = 0;
+        for (int k = (int)-base; k < 64; ++k) w[k >> 2] |= (uint32_t)text[base + k] << (8 * (k & 3));
+    }
+    Gpt2Window m;
+    gpt2_window_valid(base, n_bytes, n_words_host, docmask, m);
+    gpt2_window_flags(w, lut, m);
     return (gpt2_window_starts(m, text, base, uc1, uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
 }
 
