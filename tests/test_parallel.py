@@ -143,6 +143,63 @@ def test_encode_batch_sharded_equals_unsharded_gloo(world):
     assert got[0][1] == exp.tok_offsets.tolist()
 
 
+# ---- the same step with the PRODUCT's kernels on every rank: the SIMT build of csrc/ (tests/harness/simt_build.py) is the encoder, the
+# oracle only the checker -- shard cuts, the real pipeline per rank (host entry -> every kernel the device would run), the gather and
+# its displacements, compared with the unsharded oracle result.  What a second GPU adds to this is speed and RCCL's own transport.
+def _simt_kernel_worker(rank, world, port, q, docs, js, fixed_capacity):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.harness import simt_env
+        simt_env.install()                       # this process opens the SIMT build where the product opens libtokenizers_amd.so
+        import tokenizers_amd as ta
+        from tokenizers_amd.parallel import encode_batch_sharded
+        tok = ta.Tokenizer.from_str(js, device=0)
+
+        def encode_shard(shard, offsets):
+            r = tok.encode_packed(np.ascontiguousarray(shard[: int(offsets[-1])]), np.ascontiguousarray(offsets))
+            ids = torch.from_numpy(np.array(r.ids, copy=True).astype(np.int32))
+            to = torch.from_numpy(np.array(r.tok_offsets, copy=True).astype(np.int64))
+            if not fixed_capacity:
+                return ids, to
+            cap = torch.full((len(ids) + 129,), -7, dtype=torch.int32)      # a capacity-sized buffer + the count as a tensor: the device path's shape
+            cap[: len(ids)] = ids
+            return cap, to, torch.tensor([len(ids)], dtype=torch.int64)
+        buf, off = ta.pack_documents(docs)
+        out = encode_batch_sharded(encode_shard, buf, off, torch.device("cpu"))
+        q.put((rank, None if out is None else (out[0].tolist(), out[1].tolist())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "gpt2"), (3, "gpt2"), (2, "bert_wordpiece_4000"), (3, "llama3_small_6000")])
+def test_sharded_encode_with_the_real_kernels_gloo(world, name):
+    from oracle import oracle as orc
+    from oracle import synth
+    from tests.helpers import load_tokenizer_json
+    from tests.harness import simt_build
+    simt_build.build()                           # (once, here: the ranks would race for the build otherwise)
+    js = synth.load_or_train_gpt2() if name == "gpt2" else load_tokenizer_json(name)
+    docs = synth.gen_lines(260, text_seed=93) + ["", "x" * 3000, ""] + synth.stress_lines(seed=32, n=120) + ["", ""]
+    if name.startswith("bert"):
+        docs = [d for d in docs if "[" not in d]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_simt_kernel_worker, args=(r, world, port, q, docs, js, world == 3)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exp = orc.Oracle(js).encode_batch(docs)
+    assert all(got[r] is None for r in range(1, world))
+    assert got[0][0] == exp.ids.astype(np.int32).tolist()
+    assert got[0][1] == exp.tok_offsets.tolist()
+
+
 @pytest.mark.gpu
 @pytest.mark.needs_hw
 def test_encode_batch_sharded_on_one_gpu_over_rccl():

@@ -360,7 +360,10 @@ def test_every_whole_word_of_the_vocabulary_is_settled_by_the_tables(name):
     {"TKAMD_LEAN_PROLOGUE": "0", "TKAMD_LU_FILL": "0", "TKAMD_CLAIM_ADAPT": "0", "TKAMD_MERGE_ONE": "1"},   # validate / sanitize / mark as kernels of their own, pass 1 stores its hits only, claims that never give up, one merge launch
     {"TKAMD_TEST_HOOKS": "1", "TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_ONE": "0", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
     {"TKAMD_HOT_SLOTS": "2048"},                                                # the two-workgroups-per-CU shape of the lookup (2,048 hot slots, the short-word displacements in LDS, pass 2 two steps side by side)
-], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-2-per-cu"])
+    {"TKAMD_FUSED": "1"},                                                       # pre-tokenizer + mask scan + lookup as ONE kernel (round 5; measured slower than the three: opt-in)
+    {"TKAMD_FUSED": "1", "TKAMD_TEST_HOOKS": "1", "TKAMD_LU_GRID": "5", "TKAMD_LB_PATIENCE": "0", "TKAMD_CLAIMS": "0", "TKAMD_SQ_LUT": "4"},   # ... on five workgroups whose look-backs compute every count they find missing themselves
+], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-2-per-cu",
+        "fused-pretok-scan-lookup", "fused-helping-lookback"])
 def test_alternative_kernels_agree(gpt2_json, variant):
     """The A/B kernel variants (the fallbacks for vocabularies whose new ids are not rank + c, and the earlier generations
     of the pre-tokenizer) must give the same ids and offsets as the oracle: run them in a subprocess because the

@@ -1393,8 +1393,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     bool has_end = false;             // the pre-tokenizer produced an end bitmask
     // The fused pass (round 5, kernels/lookup.hip FUSED): for the plain GPT-2 byte-level BPE -- the text as the caller gave it, no added
     // tokens -- the pre-tokenizer, the mask scan and the lookup are ONE kernel over the text; the start mask and its prefix counts leave
-    // it for the stages behind (k_doc_first_pretok, the offsets pass), which therefore run after it.  TKAMD_FUSED=0: the three kernels.
-    static const bool fused_on = [] { const char* e = getenv("TKAMD_FUSED"); return !(e && !strcmp(e, "0")); }();
+    // it for the stages behind (k_doc_first_pretok, the offsets pass), which therefore run after it.  TKAMD_FUSED=1 selects it (a handle
+    // made with it: lu_fused); the default is the three kernels, which measure faster.
+    static const bool fused_on = true;
     static const bool pretok_default = [] { const char* e = getenv("TKAMD_PRETOK"); return !e || (strcmp(e, "bits") && strcmp(e, "lds")); }();
     const bool fused = fused_on && pretok_default && t->lu_fused && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe && !matchmask &&
                        !x_len_dev && x_text == d_text && n_bytes > 0;
@@ -1931,9 +1932,10 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         if (!primary) verify_direct_words(t.get());
         if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 2048 ? 2048 : 1024;
         {
+            // (OFF by default: measured 0.49 ms against 0.285 for the three kernels on C2, profiles/r5b_ab_c2.txt, r5c -- DESIGN section 4)
             const char* e = getenv("TKAMD_FUSED");
             const HostModel& hm = t->hm;
-            t->lu_fused = !(e && !strcmp(e, "0")) && t->hot_slots == 1024 && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe &&
+            t->lu_fused = (e && !strcmp(e, "1")) && t->hot_slots == 1024 && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe &&
                           hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !hm.add_prefix_space;
         }
         build_shortw_table(t.get());

@@ -110,7 +110,7 @@ struct LookupArgs {
 // phases of k_lookup<.., true>, as wavefront 0 sees the workgroup's barriers: staging the tile (LDS stores, the last pre-token's end,
 // next tile's prefetch issued), expanding the mask bits into positions, pass 1, pass 2, pass 3 (+ waiting for the slowest wavefront);
 // slot 7: the whole kernel
-enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_PH_PASS3 = 4, LU_PH_TOTAL = 7 };
+enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_PH_PASS3 = 4, LU_PH_PRETOK = 5, LU_PH_PLACE = 6, LU_PH_TOTAL = 7 };      // (5, 6: the fused shape's pre-tokenizer; its look-back + write-out)
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     __shared__ uint32_t s_fill[4];                                               // fill of this workgroup's sub-queues so far
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (PROF: thread 0 stamps the shader clock behind every barrier that ends a phase; compiled out of the product instantiation)
-    unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[7] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     auto tick = [&](int k) {
         if (PROF && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph_acc[k] += now - ph_t; ph_t = now; }
     };
@@ -194,7 +194,8 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     uint32_t pf_wp = 0u, pf_first = 0u;
     // (the three-workgroups-per-CU shape has 80 VGPRs: it keeps the masks a tile ahead but loads the text when the tile starts -- the
     // other two workgroups of the CU cover that round trip)
-    constexpr bool PF_TEXT = HOT == 2048;      // (fused: A/B, tools/ab_libs/r5_fused_pf.so has it on)
+    constexpr bool PF_TEXT = HOT == 2048 || FUSED;
+    static_assert(!FUSED || PF_TEXT, "the fused pre-tokenizer reads the staged tile: the text is in LDS before step 2");
     auto load_text = [&](int64_t tile, Unaligned16& x0, Unaligned16& x1, Unaligned16& xs) {
         x0 = x1 = xs = Unaligned16{0u, 0u, 0u, 0u};
         if (tile >= n_tiles) return;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 s_doc[tid] = (wi >= 0 && wi < n_words_host) ? a.docmask[wi] : 0ull;
             }
             __syncthreads();                                         // the staged text and the document words are in LDS
+            tick(LU_PH_STAGE);
             unsigned long long out = 0ull;
             if (tid < LU_WINDOWS && t0 + (int64_t)G2W_MAIN * tid < n_bytes) {
                 const int64_t base = t0 + (int64_t)G2W_MAIN * tid - G2W_HALO;      // the text's byte under window byte 0
@@ -268,7 +270,9 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 if (sh) m.D |= s_doc[(rel >> 6) + 1u] << (64u - sh);
                 m.D &= m.V;
                 gpt2_window_flags(w, s_lut + (tid & (LU_LUT_COPIES - 1)) * 256, m);
-                out = (gpt2_window_starts(m, a.text, base, a.uc1, a.uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
+                // (the bytes the algebra looks at again -- behind an apostrophe, a multi-byte char -- come from the STAGED tile: a global load
+                // there was a round trip per wavefront and loop turn, with two workgroups a CU to hide it: 0.15 ms of the first version's 0.49)
+                out = (gpt2_window_starts(m, (const uint8_t*)s_text32, (int64_t)G2W_MAIN * tid - G2W_HALO, a.uc1, a.uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
             }
             {
                 const unsigned long long nxt = __shfl_down(out, 1, 64);
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
 #pragma unroll
             for (int q = 0; q < LU_WAVES; ++q) { const uint32_t c = s_wsum[q]; before += q < wave ? c : 0u; total += c; }
             rbase = before + incl - (uint32_t)__popcll(ms);
+            tick(LU_PH_PRETOK);
             if (tid == 0) {
                 s_n = total;
                 lb_publish(a.lb_state, tile, (unsigned long long)total);      // (early: the tiles behind this one look back over it)
@@ -528,23 +533,23 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 const unsigned long long w1 = (unsigned long long)(k1 >> 24) | ((unsigned long long)k2 << 8) | ((unsigned long long)(k3 & 0x00FFFFFFu) << 40);
                 const ulonglong2 c = *(const ulonglong2*)e;
                 unsigned long long c0 = c.x, c1 = c.y;
-                bool fresh1 = false;
+                bool fresh1 = false, won = false;
                 if (c0 == 0ull) {
                     c0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (c0 == 0ull) {
-                        c0 = atomicCAS(e, 0ull, w0);
-                        if (c0 == 0ull) {
-                            if (w1) __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            return CLAIM_HOLDS;
-                        }
-                    }
-                    if (c0 == w0 && w1) { c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh1 = true; }      // (claimed since the stale read)
+                    if (c0 == 0ull) { c0 = atomicCAS(e, 0ull, w0); won = c0 == 0ull; }
+                }
+                // The winner's second store comes BEFORE any loser reads word 1, in program order: lanes of one wavefront step often hold
+                // the same word (text of few distinct words), and a loser polling in its own branch would spin on a store its wavefront
+                // has not issued yet.
+                if (won) {
+                    if (w1) __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return CLAIM_HOLDS;
                 }
                 if (c0 != w0) return CLAIM_NONE;
+                if (c.x == 0ull && w1) { c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh1 = true; }      // (claimed since the stale read)
                 if (c1 == w1) return CLAIM_SHARED;
                 // word 1 is written once, so a value read is final; a 0 may be a stale line or the winner's store still on its way (it follows
-                // the compare-and-swap by a round trip: on a small batch of few distinct words -- every tile in flight at once -- a fifth of
-                // the occurrences arrived inside that window, profiles/r5a_pytest.txt).  A few fresh reads, never a wait without end.
+                // the compare-and-swap by a round trip).  A few fresh reads, never a wait without end.
 #pragma unroll 1
                 for (int tries = fresh1 ? 1 : 0; c1 == 0ull && tries < 4; ++tries) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return c1 == w1 ? CLAIM_SHARED : CLAIM_NONE;
@@ -710,8 +715,10 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
             if (FUSED) {
                 // ---- 6. the round's tok0 words, once and whole (the tile's place in the batch: place_tile above, behind round 0) ----
                 __syncthreads();
+                tick(claims_now ? LU_PH_PASS3 : LU_PH_PASS2);
                 if (rb == 0u) place_tile();
                 for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)LU_NT) store_nt(a.tok0 + pbase + rb + i, s_tok[i]);
+                tick(LU_PH_PLACE);
             }
         }
     }
@@ -720,7 +727,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     tick(LU_PH_PASS3);
     if (PROF && tid == 0 && a.phases) {
         unsigned long long* const o = a.phases + (size_t)blockIdx.x * 8;
-        for (int k = 0; k < 5; ++k) o[k] += ph_acc[k];
+        for (int k = 0; k < 7; ++k) o[k] += ph_acc[k];
         o[LU_PH_TOTAL] += ph_t - ph_t0;
     }
     if (tid == 0 && a.claims && a.counters) {                      // the batch's totals: what the host's pause rule reads (capi.cpp read_scalars)

@@ -107,7 +107,7 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
         phases = {}
         for name, v in tok.debug_phases().items():
             if v[7]:
-                phases[name] = [round(x / v[7], 3) for x in v[:5]]
+                phases[name] = [round(x / v[7], 3) for x in v[:7]]
     print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if (k.startswith("TKAMD_") or k == "AB_LIB") and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
                                      "gbps": round(nb / best / 1e9, 2), "ms": round(best * 1e3, 4), "sum_kernels_ms": round(sum(st.values()), 4),
                                      "kernels_ms": {k: v for k, v in sorted(st.items(), key=lambda kv: -kv[1]) if v >= 0.003}, "queues": tok.queue_sizes(),
