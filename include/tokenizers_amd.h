@@ -173,6 +173,23 @@ int tkamd_encode_batch(tkamd_tokenizer* tok, const uint8_t* text, const int64_t*
 int tkamd_encode_batch_words(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* word_offsets, int64_t n_words,
                              const int64_t* seq_offsets, int64_t n_seqs, uint32_t flags, tkamd_batch** out);
 
+/* tkamd_encode_batch for a caller that is still FILLING `text` while the call runs.  The reference's Python binding turns every
+ * input into an owned Rust String first and encodes afterwards (bindings/python/src/tokenizer.rs:1312-1338: the extraction loop,
+ * then py.allow_threads around encode_batch); a binding of this library packs its strings into one buffer anyway -- with this entry
+ * the packing of the batch's tail overlaps the H2D copy and the kernels of its head.  doc_offsets[0 .. n_docs] is complete on entry;
+ * bytes [0, *ready_bytes) of `text` are valid, *ready_bytes only grows (written with release semantics by the caller's packing
+ * threads, read with acquire semantics here) and reaches doc_offsets[n_docs].  The call never reads a byte it has not seen announced.
+ * `consumed(user)`, if not NULL, is called once from the calling thread as soon as the call has seen *ready_bytes at its final value
+ * (the caller's source objects are no longer needed: a Python binding releases the GIL there) -- also on every error path that
+ * waited that long; a call that fails before has not called it.  pace == NULL: tkamd_encode_batch. */
+typedef struct tkamd_pace {
+    const int64_t* ready_bytes;
+    void (*consumed)(void* user);
+    void* user;
+} tkamd_pace;
+int tkamd_encode_batch_paced(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
+                             const tkamd_pace* pace, tkamd_batch** out);
+
 int64_t         tkamd_batch_n_docs(const tkamd_batch* b);       /* encodings in the result (= documents / sequences / pairs, plus the
                                                                    overflowing encodings with TKAMD_WANT_OVERFLOW)              */
 int64_t         tkamd_batch_n_tokens(const tkamd_batch* b);

@@ -302,3 +302,44 @@ def test_a_short_run_of_the_live_differential(ref_tokenizers):
     last = [l for l in r.stdout.splitlines() if l.strip()][-1:] or [""]
     assert r.returncode == 0 and last[0].startswith("ok seed 7"), (r.returncode, r.stdout[-3000:], r.stderr[-1500:])
     assert int(last[0].split("cases")[1].split()[0]) >= 5
+
+
+def test_paced_list_of_str_entry_packs_behind_the_encode():
+    """tkamd_encode_batch_paced through _marshal.pack_encode: the strs are packed stripe by stripe by helper threads while the host entry
+    (sliced, waiting for every slice's bytes to be announced) already encodes the head of the batch.  Small stripes and slices so that a
+    batch the emulation can run is cut many times; every str kind (ASCII, UCS1 / UCS2 / UCS4 code units); the result equals the
+    packed call's; the errors of the sequential loop (a non-str item, a lone surrogate, a tuple among strs) surface before anything runs."""
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "from tests.harness import simt_env; simt_env.install()\n"
+        "import numpy as np, tokenizers_amd as ta\n"
+        "from tests.helpers import load_tokenizer_json\n"
+        "from oracle import synth\n"
+        "tok = ta.Tokenizer.from_str(load_tokenizer_json('bytelevel_prefix_trim_3000'), device=0)\n"
+        "docs = (synth.gen_lines(300, text_seed=5) + ['', 'caf\\u00e9 na\\u00efve', '\\u4e2d\\u6587 \\u65e5\\u672c', '\\U0001F600 ok', 'x' * 3000, '']) * 60\n"
+        "assert len(docs) >= 16384\n"
+        "got = tok.encode_batch_csr(docs, offsets='char', word_ids=True)\n"
+        "got = (np.array(got.ids), np.array(got.tok_offsets), np.array(got.offsets), np.array(got.word_ids))\n"
+        "os.environ['TKAMD_PACED'] = '0'\n"
+        "ref = tok.encode_batch_csr(docs, offsets='char', word_ids=True)\n"
+        "os.environ['TKAMD_PACED'] = '1'\n"
+        "assert np.array_equal(got[0], ref.ids) and np.array_equal(got[1], ref.tok_offsets) and np.array_equal(got[2], ref.offsets) and np.array_equal(got[3], ref.word_ids)\n"
+        "pairs = [(a, b) for a, b in zip(docs[:9000], docs[1:9001])]\n"
+        "gp = tok.encode_batch_csr(pairs)\n"
+        "os.environ['TKAMD_PACED'] = '0'\n"
+        "rp = tok.encode_batch_csr(pairs)\n"
+        "os.environ['TKAMD_PACED'] = '1'\n"
+        "assert np.array_equal(gp.ids, rp.ids) and np.array_equal(gp.tok_offsets, rp.tok_offsets)\n"
+        "for bad, exc in ((docs[:20000] + [7], TypeError), (docs[:20000] + ['\\ud800'], UnicodeEncodeError), (docs[:20000] + [('a', 'b')], ta.UnsupportedError)):\n"
+        "    try:\n"
+        "        tok.encode_batch_csr(bad)\n"
+        "    except exc:\n"
+        "        pass\n"
+        "    else:\n"
+        "        raise AssertionError(exc)\n"
+        "again = tok.encode_batch_csr(docs)\n"
+        "assert np.array_equal(again.ids, got[0])\n"
+        "print('PACED_OK')\n") % ROOT
+    env = dict(os.environ, TKAMD_TEST_HOOKS="1", TKAMD_HOST_SLICE_KB="64", TKAMD_PACK_STRIPE_KB="16", TKAMD_PACK_THREADS="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert "PACED_OK" in r.stdout, r.stdout + r.stderr

@@ -40,7 +40,7 @@ SYMBOLS = [
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
     "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16", "tkamd_encode_special_tokens",
     "tkamd_tokenizer_from_json_devices", "tkamd_tokenizer_set_collect", "tkamd_tokenizer_devices", "tkamd_shard_stats", "tkamd_debug_phases",
-    "tkamd_pinned_alloc", "tkamd_pinned_free",
+    "tkamd_pinned_alloc", "tkamd_pinned_free", "tkamd_encode_batch_paced",
 ]
 COLLECT_HOST, COLLECT_ROOT_P2P, COLLECT_ROOT_RCCL = 0, 1, 2
 
@@ -111,6 +111,8 @@ def load() -> C.CDLL:
     lib.tkamd_tokenizer_info.argtypes = [vp, C.POINTER(Info)]
     lib.tkamd_tokenizer_info.restype = i32
     lib.tkamd_encode_batch.argtypes = [vp, vp, vp, i64, u32, C.POINTER(vp)]
+    lib.tkamd_encode_batch_paced.restype = i32
+    lib.tkamd_encode_batch_paced.argtypes = [vp, vp, vp, i64, u32, vp, C.POINTER(vp)]
     lib.tkamd_encode_batch.restype = i32
     lib.tkamd_encode_batch_words.argtypes = [vp, vp, vp, i64, vp, i64, u32, C.POINTER(vp)]
     lib.tkamd_encode_batch_words.restype = i32

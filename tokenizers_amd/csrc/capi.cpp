@@ -2420,10 +2420,18 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
 // seq_offsets / n_seqs: is_pretokenized inputs -- the documents are words, sequence s = words [seq_offsets[s], seq_offsets[s + 1]); the
 // slices are then cut between sequences.  n_seqs < 0: plain documents.
 static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
-                       int64_t n_seqs, uint32_t flags, tkamd_batch** out) {
+                       int64_t n_seqs, uint32_t flags, tkamd_batch** out, const tkamd_pace* pace = nullptr) {
     if (!t || !out || !doc_offsets || n_docs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
     *out = nullptr;
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
+    // tkamd_encode_batch_paced: the caller is still packing `text` -- wait until the bytes below `need` are announced, and tell the
+    // caller once the whole text has been (a slice is read by its H2D copy, enqueued right after its wait)
+    bool pace_done = false;
+    auto wait_ready = [&](int64_t need, int64_t all) {
+        if (!pace || !pace->ready_bytes) return;
+        while (__atomic_load_n(pace->ready_bytes, __ATOMIC_ACQUIRE) < need) std::this_thread::yield();
+        if (need >= all && !pace_done) { pace_done = true; if (pace->consumed) pace->consumed(pace->user); }
+    };
     return guarded([&]() -> int {
         check_not_forked();
         HIP_CHECK(hipSetDevice(t->device));
@@ -2452,8 +2460,10 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
         // a multi-device handle: one shard per device (what couples the documents of a batch stays on devices[0], like it stays in one slice)
-        if (!t->replicas.empty() && !(t->hm.pad_on && !t->hm.pad_fixed) && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes)
+        if (!t->replicas.empty() && !(t->hm.pad_on && !t->hm.pad_fixed) && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
+            wait_ready(n_bytes, n_bytes);                        // (the shards' workers read the whole text: no pacing across devices yet)
             return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
+        }
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)
         std::vector<int64_t> cut(n_slices + 1, 0);                     // in sequences
@@ -2519,6 +2529,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             // (the cuts came from a binary search over the caller's array: a CSR that is not monotone gives any cut at all, and the copy
             // below reads text + b0 .. + nb on the HOST, before the device validation sees the slice -- like encode_host_sharded)
             if (nb < 0 || b0 < 0 || b0 > n_bytes || nb > n_bytes - b0) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
+            wait_ready(b0 + nb, n_bytes);                        // (paced call: the slice's bytes have been packed)
             const int64_t g0 = cut[k], g1 = cut[k + 1];
             if (words_in) w->h_seq_off.reserve((size_t)(g1 - g0 + 1) * 8);
             w->h_text.reserve((size_t)nb + TKAMD_TEXT_PAD);
@@ -2644,6 +2655,11 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
 int tkamd_encode_batch(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
                        tkamd_batch** out) {
     return encode_host(t, text, doc_offsets, n_docs, nullptr, -1, flags, out);
+}
+int tkamd_encode_batch_paced(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags,
+                             const tkamd_pace* pace, tkamd_batch** out) {
+    if (pace && !pace->ready_bytes) return set_error(TKAMD_ERR_INVALID, "tkamd_pace without ready_bytes");
+    return encode_host(t, text, doc_offsets, n_docs, nullptr, -1, flags, out, pace);
 }
 int tkamd_encode_batch_words(tkamd_tokenizer* t, const uint8_t* text, const int64_t* word_offsets, int64_t n_words, const int64_t* seq_offsets,
                              int64_t n_seqs, uint32_t flags, tkamd_batch** out) {

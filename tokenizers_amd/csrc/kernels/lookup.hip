@@ -142,7 +142,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     static_assert((2 * (LU_POS_CAP + 2) + LU_POS_CAP) % 4 == 0, "s_tok is 8-byte aligned: s_doc shares its place");
     __shared__ uint32_t s_wsum[LU_WAVES];                                       // fused: the wavefronts' start counts
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
-    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand, s_ncandl;
+    __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand, s_ncandl, s_nretry;
     // the claims' yield as this workgroup sees it: candidates it looked at, how many of them were another pre-token's word.  Text that
     // never repeats a word pays two dependent round trips per candidate for nothing: a workgroup that has seen CLAIM_ADAPT_MIN
     // candidates and shared fewer than one in eight stops claiming for the rest of its tiles (its candidates are queued like any
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 __syncthreads();
             }
             // ---- 2b. positions of the set bits, by rank (ranks rb .. rb + cnt, the extra one is the next start) ----
-            if (tid == 0) { s_nmiss = 0u; s_ncand = 0u; s_ncandl = 0u; }
+            if (tid == 0) { s_nmiss = 0u; s_ncand = 0u; s_ncandl = 0u; s_nretry = 0u; }
             if (rbase != 0xFFFFFFFFu) {
                 const uint32_t lo32 = (uint32_t)ms, bit0 = (uint32_t)hword * 64u + (uint32_t)half * 32u;
                 uint32_t r = rbase - rb + (half ? (uint32_t)__popc(lo32) : 0u);
@@ -526,8 +526,9 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
             // A plain (cached) read first: a claim it shows is final, and the repeats of a frequent word then hit the L2 instead of crossing
             // the fabric each time.  A 0 may be stale (the L2 of an XCD keeps what it read whatever another XCD's CAS did since): the
             // device-scope read confirms it (tools/microbench/claims_probe.hip).
-            enum : uint32_t { CLAIM_NONE = 0u, CLAIM_SHARED = 1u, CLAIM_HOLDS = 2u };
-            auto claim_short = [&](uint32_t slot, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) -> uint32_t {
+            // (CLAIM_RETRY, only when the caller can come back -- `last` false: word 0 is this word's, word 1 not there yet)
+            enum : uint32_t { CLAIM_NONE = 0u, CLAIM_SHARED = 1u, CLAIM_HOLDS = 2u, CLAIM_RETRY = 3u };
+            auto claim_short = [&](uint32_t slot, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, bool last) -> uint32_t {
                 unsigned long long* const e = a.claims + 2u * (size_t)slot;
                 const unsigned long long w0 = (unsigned long long)k0 | ((unsigned long long)(k1 & 0x00FFFFFFu) << 32) | ((unsigned long long)len << 56);
                 const unsigned long long w1 = (unsigned long long)(k1 >> 24) | ((unsigned long long)k2 << 8) | ((unsigned long long)(k3 & 0x00FFFFFFu) << 40);
@@ -549,9 +550,14 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 if (c.x == 0ull && w1) { c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); fresh1 = true; }      // (claimed since the stale read)
                 if (c1 == w1) return CLAIM_SHARED;
                 // word 1 is written once, so a value read is final; a 0 may be a stale line or the winner's store still on its way (it follows
-                // the compare-and-swap by a round trip).  A few fresh reads, never a wait without end.
+                // the compare-and-swap by a round trip, and on a small batch of few distinct words -- every tile's first steps at once --
+                // a quarter of the occurrences arrive inside that window: profiles/r5d_pytest.txt).  One fresh read; then the candidate
+                // goes to the tile's retry list (pass 3 comes back to it behind its other steps), or, where there is no coming back, a
+                // few more reads -- never a wait without end: a word that cannot be settled is queued, which is always right.
+                if (c1 == 0ull && !fresh1) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c1 == 0ull && !last) return CLAIM_RETRY;
 #pragma unroll 1
-                for (int tries = fresh1 ? 1 : 0; c1 == 0ull && tries < 4; ++tries) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int tries = 0; c1 == 0ull && tries < 3; ++tries) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return c1 == w1 ? CLAIM_SHARED : CLAIM_NONE;
             };
             // 16..32 bytes (9 % of C2's candidates): the entry names the claimant -- 0xFF << 56 | length << 32 | first byte -- and its BYTES in
@@ -576,7 +582,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
             auto claim_any = [&](uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t h1, uint32_t& slot) -> uint32_t {
                 if (len <= CLAIM_KEY_MAX) {
                     slot = claim_slot(h1, a.claim_mask);
-                    return claim_short(slot, len, k0, k1, k2, k3);
+                    return claim_short(slot, len, k0, k1, k2, k3, true);
                 }
                 uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u, hc = h1;
                 uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
@@ -689,14 +695,12 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 tick(LU_PH_PASS2);
                 const uint32_t n_cand = s_ncand, n_candl = s_ncandl;
                 if (tid == 0) s_seen += n_cand + n_candl;                           // (thread 0 alone writes it)
-                // the short words' steps, then the long ones' (from the back of the list); steps dealt round robin over both
+                // the short words' steps, then the long ones' (from the back of the list); steps dealt round robin over both.  A short word
+                // whose claim is half written (CLAIM_RETRY) goes to the retry list -- the miss list's place, pass 2 is done with it -- and
+                // is looked at once more behind a barrier, when the winner's second store has long landed.
+                uint16_t* const s_retry = s_miss;
                 const uint32_t steps_s = (n_cand + 63u) >> 6, steps_l = (n_candl + 63u) >> 6;
-                for (uint32_t st = (uint32_t)wave; st < steps_s + steps_l; st += (uint32_t)LU_WAVES) {
-                    const bool lng = st >= steps_s;                                 // wavefront-uniform
-                    const uint32_t c0 = (lng ? st - steps_s : st) * 64u, nc = lng ? n_candl : n_cand;
-                    const bool v = c0 + lane < nc;
-                    const uint32_t ci = v ? c0 + lane : c0;
-                    const uint32_t rel = s_cand[lng ? (uint32_t)LU_POS_CAP - 1u - ci : ci];
+                auto claim_step = [&](bool v, uint32_t rel, bool lng, bool last) {
                     uint32_t s_rel, len, k0, k1, k2, k3;
                     load_key(rel, s_rel, len, k0, k1, k2, k3, true);
                     const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
@@ -704,12 +708,33 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                     bool pend = v;
                     if (v) {
                         if (lng) r = claim_any(s_rel, len, k0, k1, k2, k3, h1, slot);
-                        else { slot = claim_slot(h1, a.claim_mask); r = claim_short(slot, len, k0, k1, k2, k3); }
+                        else { slot = claim_slot(h1, a.claim_mask); r = claim_short(slot, len, k0, k1, k2, k3, last); }
                     }
                     if (r == CLAIM_SHARED) { out = TOK_SLOT | slot; pend = false; }
-                    const uint64_t sb = __ballot(v && !pend);
+                    const bool again = r == CLAIM_RETRY;
+                    const uint64_t rbm = __ballot(again);
+                    if (rbm) {                                                      // (wavefront-uniform; never in the last round)
+                        uint32_t base = 0u;
+                        if (lane == 0) base = atomicAdd(&s_nretry, (uint32_t)__popcll(rbm));
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                        if (again) s_retry[base + (uint32_t)mbcnt64(rbm)] = (uint16_t)rel;
+                    }
+                    const uint64_t sb = __ballot(v && !pend && !again);
                     if (sb && lane == 0) atomicAdd(&s_shared, (uint32_t)__popcll(sb));
-                    finish(v, pend, rel, s_rel, len, out, r == CLAIM_HOLDS);
+                    finish(v && !again, pend && !again, rel, s_rel, len, out, r == CLAIM_HOLDS);
+                };
+                for (uint32_t st = (uint32_t)wave; st < steps_s + steps_l; st += (uint32_t)LU_WAVES) {
+                    const bool lng = st >= steps_s;                                 // wavefront-uniform
+                    const uint32_t c0 = (lng ? st - steps_s : st) * 64u, nc = lng ? n_candl : n_cand;
+                    const bool v = c0 + lane < nc;
+                    const uint32_t ci = v ? c0 + lane : c0;
+                    claim_step(v, s_cand[lng ? (uint32_t)LU_POS_CAP - 1u - ci : ci], lng, false);
+                }
+                __syncthreads();
+                const uint32_t n_retry = s_nretry;                                  // (workgroup-uniform; 0 on all but a batch's first steps)
+                for (uint32_t c0 = (uint32_t)wave * 64u; c0 < n_retry; c0 += (uint32_t)LU_NT) {
+                    const bool v = c0 + lane < n_retry;
+                    claim_step(v, s_retry[v ? c0 + lane : c0], false, true);
                 }
             }
             if (FUSED) {

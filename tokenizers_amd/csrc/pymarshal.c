@@ -285,7 +285,169 @@ static PyObject* line_offsets(PyObject* self, PyObject* args) {
     return offs;
 }
 
+/* ---- pack_encode: list[str] -> tkamd_encode_batch_paced, the packing of the batch's tail behind the H2D copy and the kernels of its head ----
+ * pack_encode(seq, text_addr, text_capacity, off_addr, fn_addr, tok_addr, flags) -> (total, status, batch_addr)
+ *   fn_addr: the address of tkamd_encode_batch_paced (include/tokenizers_amd.h), tok_addr: the tokenizer handle.
+ * Pass A (sizes) and the CSR offsets are finished first, as in pack_into; if total + 64 > text_capacity nothing else happens and
+ * (total, None, None) tells the caller to grow its buffer.  Otherwise the helper threads copy the bytes STRIPE by stripe (4 MB of
+ * text, every helper its share of the stripe's items) and announce every finished stripe in `ready`, while this thread is inside
+ * the library call, which waits for `ready` before it reads a slice.  The GIL is held until the library reports that it has seen the
+ * whole text announced (tkamd_pace.consumed): until then the helpers read the strs' character data, and nothing may mutate the list
+ * or drop a str; from there on the call only waits for the GPU, and other Python threads run. */
+typedef struct tkamd_pace_c { const int64_t* ready_bytes; void (*consumed)(void*); void* user; } tkamd_pace_c;
+typedef int (*paced_fn)(void* tok, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, uint32_t flags, const tkamd_pace_c* pace, void** out);
+static int64_t stripe_bytes(void) {      /* 4 MB of text a stripe (TKAMD_PACK_STRIPE_KB: tests run the striped copy on small batches) */
+    static int64_t v = 0;
+    if (!v) { const char* e = getenv("TKAMD_PACK_STRIPE_KB"); long kb = e ? atol(e) : 4096; v = (int64_t)(kb < 4 ? 4 : kb) << 10; }
+    return v;
+}
+#define STRIPE_BYTES (stripe_bytes())
+typedef struct stripe_ctx {
+    const span_t* sp; const int64_t* off; char* dst; Py_ssize_t n;
+    int nh;                              /* helper threads */
+    Py_ssize_t* bound; int n_stripes;    /* stripe s = items [bound[s], bound[s + 1]) */
+    int* done;                           /* helpers that finished stripe s */
+    int64_t ready;                       /* bytes announced */
+} stripe_ctx;
+typedef struct { stripe_ctx* c; int h; } stripe_arg;
+static void* stripe_worker(void* arg) {
+    stripe_ctx* c = ((stripe_arg*)arg)->c;
+    const int h = ((stripe_arg*)arg)->h;
+    for (int s = 0; s < c->n_stripes; ++s) {
+        const Py_ssize_t a = c->bound[s], b = c->bound[s + 1];
+        const Py_ssize_t lo = a + (b - a) * h / c->nh, hi = a + (b - a) * (h + 1) / c->nh;
+        for (Py_ssize_t i = lo; i < hi; ++i) {
+            if (i + 8 < hi) __builtin_prefetch(c->sp[i + 8].p);
+            span_write(&c->sp[i], c->dst + c->off[i]);
+        }
+        if (__atomic_add_fetch(&c->done[s], 1, __ATOMIC_ACQ_REL) == c->nh)         /* the last helper of the stripe: everything below its end is packed */
+            __atomic_store_n(&c->ready, c->off[b], __ATOMIC_RELEASE);
+    }
+    return NULL;
+}
+static void pace_consumed(void* user) { *(PyThreadState**)user = PyEval_SaveThread(); }
+
+static PyObject* pack_encode(PyObject* self, PyObject* args) {
+    PyObject* arg;
+    unsigned long long text_addr, text_cap, off_addr, fn_addr, tok_addr, flags;
+    if (!PyArg_ParseTuple(args, "OKKKKKK", &arg, &text_addr, &text_cap, &off_addr, &fn_addr, &tok_addr, &flags)) return NULL;
+    PyObject* seq = PySequence_Fast(arg, "encode_batch expects a sequence of str");
+    if (!seq) return NULL;
+    PyObject** items = PySequence_Fast_ITEMS(seq);
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    int64_t* off = (int64_t*)(uintptr_t)off_addr;
+    char* dst = (char*)(uintptr_t)text_addr;
+    /* sizes + offsets: pack_core without a destination (pass C then writes the offsets only) */
+    span_t* sp = NULL;
+    int64_t total;
+    {
+        /* pack_core frees its spans: the stripes need them, so the sizing runs here with the same helpers */
+        pack_ctx* c = (pack_ctx*)calloc(1, sizeof(pack_ctx));
+        sp = (span_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(span_t));
+        if (!c || !sp) { free(c); free(sp); Py_DECREF(seq); return PyErr_NoMemory(); }
+        c->items = items; c->n = n; c->sp = sp; c->off = off; c->nt = 1; c->dst = NULL;
+        /* (one thread for the sizes of a small batch; a large one: the same gate / barrier protocol as pack_core) */
+        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+        const char* e = getenv("TKAMD_PACK_THREADS");
+        long want = e ? atol(e) : ncpu;
+        int max_threads = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
+        int nt = n < 16384 ? 1 : max_threads;
+        pthread_t th[PACK_MAX_THREADS];
+        pack_arg pargs[PACK_MAX_THREADS];
+        int started = 0;
+        for (int t = 1; t < nt; ++t) {
+            pargs[t].c = c; pargs[t].t = t;
+            if (pthread_create(&th[t], NULL, pack_worker, &pargs[t]) != 0) break;
+            started = t;
+        }
+        nt = started + 1;
+        c->nt = nt;
+        if (nt > 1 && pthread_barrier_init(&c->bar, NULL, (unsigned)nt) != 0) {
+            __atomic_store_n(&c->go, -1, __ATOMIC_RELEASE);
+            for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+            nt = 1; c->nt = 1; started = 0;
+        }
+        __atomic_store_n(&c->go, 1, __ATOMIC_RELEASE);
+        pass_a(c, 0);
+        if (nt > 1) pthread_barrier_wait(&c->bar);
+        int rc = resolve_slow(c);
+        total = -1;
+        if (rc == 0) {
+            int64_t acc = 0;
+            for (int t = 0; t < nt; ++t) { c->base[t] = acc; acc += c->total[t]; }
+            total = acc;
+        } else c->base[0] = -1;
+        if (nt > 1) pthread_barrier_wait(&c->bar);
+        if (rc == 0) pass_c(c, 0);                      /* (dst NULL: the offsets) */
+        for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+        if (nt > 1) pthread_barrier_destroy(&c->bar);
+        free(c);
+        if (rc != 0) { free(sp); Py_DECREF(seq); return NULL; }
+        off[n] = total;
+    }
+    if ((unsigned long long)total + TEXT_PAD > text_cap) {          /* the caller grows its buffer and comes back */
+        free(sp);
+        Py_DECREF(seq);
+        return Py_BuildValue("LOO", (long long)total, Py_None, Py_None);
+    }
+    /* stripes of ~4 MB of text; helpers (none for a small batch: the copy is done here, before the call) */
+    stripe_ctx sc;
+    memset(&sc, 0, sizeof sc);
+    sc.sp = sp; sc.off = off; sc.dst = dst; sc.n = n;
+    long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
+    const char* e = getenv("TKAMD_PACK_THREADS");
+    long want = e ? atol(e) : ncpu;
+    int nh = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
+    if (n < 16384 || total < 2 * STRIPE_BYTES) nh = 0;
+    int n_stripes = nh ? (int)(total / STRIPE_BYTES) + 1 : 1;
+    Py_ssize_t* bound = (Py_ssize_t*)malloc((size_t)(n_stripes + 1) * sizeof(Py_ssize_t));
+    int* done = (int*)calloc((size_t)n_stripes, sizeof(int));
+    if (!bound || !done) { free(bound); free(done); free(sp); Py_DECREF(seq); return PyErr_NoMemory(); }
+    bound[0] = 0;
+    for (int s = 1; s < n_stripes; ++s) {                       /* first item at or behind s x 4 MB (binary search over the offsets) */
+        const int64_t target = (int64_t)s * STRIPE_BYTES;
+        Py_ssize_t lo = bound[s - 1], hi = n;
+        while (lo < hi) { const Py_ssize_t mid = lo + (hi - lo) / 2; if (off[mid] < target) lo = mid + 1; else hi = mid; }
+        bound[s] = lo;
+    }
+    bound[n_stripes] = n;
+    sc.bound = bound; sc.n_stripes = n_stripes; sc.done = done; sc.nh = nh;
+    pthread_t hth[PACK_MAX_THREADS];
+    stripe_arg hargs[PACK_MAX_THREADS];
+    int hstarted = 0;
+    if (nh) {
+        for (int h = 0; h < nh; ++h) {
+            hargs[h].c = &sc; hargs[h].h = h;
+        }
+        /* (a stripe is finished when all nh shares of it are: a helper that could not be created leaves its shares to this thread) */
+        sc.nh = nh;
+        for (int h = 0; h < nh; ++h) {
+            if (pthread_create(&hth[h], NULL, stripe_worker, &hargs[h]) != 0) break;
+            hstarted = h + 1;
+        }
+        if (hstarted < nh) {                                     /* rare: do the missing helpers' shares here, synchronously */
+            for (int h = hstarted; h < nh; ++h) stripe_worker(&hargs[h]);
+        }
+    } else {
+        for (Py_ssize_t i = 0; i < n; ++i) span_write(&sp[i], dst + off[i]);
+        sc.ready = total;
+    }
+    memset(dst + total, 0, TEXT_PAD);
+    PyThreadState* ts = NULL;
+    tkamd_pace_c pace = {&sc.ready, pace_consumed, &ts};
+    void* batch = NULL;
+    const int status = ((paced_fn)(uintptr_t)fn_addr)((void*)(uintptr_t)tok_addr, (const uint8_t*)dst, off, (int64_t)n, (uint32_t)flags, &pace, &batch);
+    for (int h = 0; h < hstarted; ++h) pthread_join(hth[h], NULL);
+    if (ts) PyEval_RestoreThread(ts);
+    free(bound);
+    free(done);
+    free(sp);
+    Py_DECREF(seq);
+    return Py_BuildValue("LiK", (long long)total, status, (unsigned long long)(uintptr_t)batch);
+}
+
 static PyMethodDef methods[] = {
+    {"pack_encode", pack_encode, METH_VARARGS, "pack_encode(seq_of_str, text_addr, text_capacity, off_addr, fn_addr, tok_addr, flags) -> (total, status | None, batch_addr | None)"},
     {"pack", pack, METH_O, "pack(seq_of_str) -> (bytearray utf8 + 64 zero bytes, bytearray int64 offsets[n+1])"},
     {"line_offsets", line_offsets, METH_VARARGS, "line_offsets(addr, n) -> bytearray int64 offsets of the lines (terminators kept)"},
     {"pack_into", pack_into, METH_VARARGS, "pack_into(seq_of_str, text_addr, text_capacity, off_addr) -> total bytes (copied iff it fits)"},

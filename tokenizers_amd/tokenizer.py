@@ -779,8 +779,40 @@ class Tokenizer:
                 flat.append(it[1])
             inputs = flat
         with self._stage_lock:                               # the staging buffers are per tokenizer; results are copied out by the library
+            be = self._encode_list_paced(inputs, offsets, word_ids, add_special_tokens, pairs, overflowing)
+            if be is not None:
+                return be
             buf, doc_off = self._pack_staged(inputs)
             return self.encode_packed(buf, doc_off, offsets, word_ids, add_special_tokens, pairs, overflowing=overflowing)
+
+    def _encode_list_paced(self, inputs, offsets, word_ids, add_special_tokens, pairs, overflowing):
+        """``list[str]`` -> ``tkamd_encode_batch_paced`` in ONE call of the marshalling extension: the strs of the batch's tail are
+        packed (helper threads, into the page-locked staging) while the H2D copy and the kernels of its head run -- the reference's
+        binding extracts every str first and encodes afterwards (bindings/python/src/tokenizer.rs:1312-1338).  None: not available
+        (no extension, a host-only or forked handle, not a list) -- the caller packs, then calls."""
+        if _marshal is None or not hasattr(_marshal, "pack_encode") or not isinstance(inputs, (list, tuple)) or self.device < 0 or _FORKED[0] or \
+                os.environ.get("TKAMD_PACED") == "0":
+            return None
+        flags = self._flags(offsets, word_ids, add_special_tokens, pairs, overflowing, "uint32")
+        n = len(inputs)
+        if getattr(self, "_stage_pid", None) != os.getpid():
+            self._stage_pid, self._stage_off, self._stage_text = os.getpid(), None, None
+        if self._stage_off is None or len(self._stage_off) < n + 1:
+            self._stage_off = pinned_empty(max(n + 1, 1024, 2 * (len(self._stage_off) if self._stage_off is not None else 0)), dtype=np.int64)
+        if self._stage_text is None:
+            self._stage_text = pinned_empty(1 << 20, dtype=np.uint8)
+        fn = C.cast(self._lib.tkamd_encode_batch_paced, C.c_void_p).value
+        for _ in range(2):
+            text = self._stage_text
+            try:
+                total, status, b = _marshal.pack_encode(inputs, text.ctypes.data, text.nbytes, self._stage_off.ctypes.data, fn, self._h.value, flags)
+            except NotImplementedError as e:
+                raise UnsupportedError(str(e)) from None
+            if status is not None:
+                _lib.check(status)
+                return self._wrap_batch(C.c_void_p(b), n // (2 if pairs else 1), offsets, word_ids, add_special_tokens, pairs, "uint32")
+            self._stage_text = pinned_empty(total + total // 4 + _lib.TEXT_PAD, dtype=np.uint8)     # nothing was copied: grow and redo
+        raise RuntimeError("staging buffer growth failed")          # pragma: no cover
 
     def _encode_words(self, inputs, offsets, word_ids, add_special_tokens, overflowing=False) -> BatchEncoding:
         """is_pretokenized inputs: all words of all sequences as one packed buffer + the CSR of the sequences over the words."""
@@ -810,6 +842,21 @@ class Tokenizer:
         ``seq_off``: the documents are the words of pre-tokenized sequences, sequence s = words [seq_off[s], seq_off[s+1]).
         ``overflowing``: TKAMD_WANT_OVERFLOW -- the result then also holds every input's overflowing encodings.
         ``ids_dtype`` "uint16": TKAMD_IDS_U16 -- the ids come back as 16-bit values (half the PCIe bytes; vocabularies below 65,536)."""
+        flags = self._flags(offsets, word_ids, add_special_tokens, pairs, overflowing, ids_dtype)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        n_docs = len(doc_off) - 1
+        n_inputs = (n_docs if seq_off is None else len(seq_off) - 1) // (2 if pairs else 1)
+        b = C.c_void_p()
+        if seq_off is None:
+            _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
+        else:
+            seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
+            _lib.check(self._lib.tkamd_encode_batch_words(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, seq_off.ctypes.data,
+                                                          len(seq_off) - 1, flags, C.byref(b)))
+        return self._wrap_batch(b, n_inputs, offsets, word_ids, add_special_tokens, pairs, ids_dtype)
+
+    def _flags(self, offsets, word_ids, add_special_tokens, pairs, overflowing, ids_dtype) -> int:
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
         if overflowing:
             flags |= _lib.WANT_OVERFLOW
@@ -825,17 +872,10 @@ class Tokenizer:
             if not pairs:                        # (a pair only needs the pair template: the library checks that one)
                 self._check_special(True)
             flags |= _lib.ADD_SPECIAL
-        doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
-        buf = np.ascontiguousarray(buf, dtype=np.uint8)
-        n_docs = len(doc_off) - 1
-        n_inputs = (n_docs if seq_off is None else len(seq_off) - 1) // (2 if pairs else 1)
-        b = C.c_void_p()
-        if seq_off is None:
-            _lib.check(self._lib.tkamd_encode_batch(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, flags, C.byref(b)))
-        else:
-            seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
-            _lib.check(self._lib.tkamd_encode_batch_words(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, seq_off.ctypes.data,
-                                                          len(seq_off) - 1, flags, C.byref(b)))
+        return flags
+
+    def _wrap_batch(self, b, n_inputs, offsets, word_ids, add_special_tokens, pairs, ids_dtype) -> BatchEncoding:
+        """Zero-copy views of a finished ``tkamd_batch`` (the library's pinned result buffers)."""
         n_docs = self._lib.tkamd_batch_n_docs(b)             # encodings (sequences; half of them for pairs)
         # zero-copy views of the library's pinned result buffers; the batch is freed when the last view dies
         owner = _BatchOwner(self._lib, b)
