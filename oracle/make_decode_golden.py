@@ -30,6 +30,12 @@ CASES = [
     ("bert_wordpiece_4000_specials", {"type": "WordPiece", "prefix": "##", "cleanup": True}),
     ("bert_wordpiece_4000_specials", {"type": "WordPiece", "prefix": "##", "cleanup": False}),
     ("wordlevel_whitespace_c1", None),
+    # round 5: the decoders of the BPE over characters round 4 added
+    ("bpe_wssplit_suffix_fuse", {"type": "BPEDecoder", "suffix": "</w>"}),
+    ("bpe_bert_affixes", {"type": "BPEDecoder", "suffix": "</w>"}),
+    ("bpe_ws_byte_fallback", {"type": "ByteFallback"}),
+    ("bpe_ws_byte_fallback", {"type": "Sequence", "decoders": [{"type": "ByteFallback"}, {"type": "Fuse"}]}),
+    ("bpe_ws_unk", {"type": "Fuse"}),
 ]
 
 
@@ -50,6 +56,23 @@ def main():
         for _ in range(60):                                   # random ids: split characters, unknown ids, specials anywhere
             n = int(rng.integers(0, 24))
             seqs.append([int(x) for x in rng.integers(0, n_ids + 5, size=n)])
+        if decoder is not None and "ByteFallback" in json.dumps(decoder):      # runs of <0xXX> tokens: valid, truncated, overlong, surrogates
+            byte_id = {b: tok.token_to_id("<0x%02X>" % b) for b in range(256)}
+            word = [i for i in range(20, 200) if i not in byte_id.values()]
+            raw = ["é".encode(), "中文".encode(), "😀".encode(), b"\xe4\xb8", b"\xc0\x80", b"\xed\xa0\x80", b"\xf4\x90\x80\x80", b"\xff", b"a\xc3", b"\x80\x80",
+                   "aé".encode(), b"\xf0\x9f\x98", b"\xe2\x82\xac\xe2\x82"]
+            for r in raw:
+                seqs.append([byte_id[b] for b in r])
+                seqs.append([word[0]] + [byte_id[b] for b in r] + [word[1]] + [byte_id[b] for b in r[:1]])
+            for _ in range(80):
+                q = []
+                for _ in range(int(rng.integers(1, 6))):
+                    if rng.random() < 0.6:
+                        r = raw[int(rng.integers(0, len(raw)))]
+                        q += [byte_id[b] for b in r[: int(rng.integers(1, len(r) + 1))]]
+                    else:
+                        q.append(int(word[int(rng.integers(0, len(word)))]))
+                seqs.append(q)
         seqs += [[], [0], []]
         out.append({"tokenizer": name, "decoder": decoder, "has_decoder_override": decoder is not None, "seqs": seqs,
                     "skip_true": tok.decode_batch(seqs, skip_special_tokens=True),

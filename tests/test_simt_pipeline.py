@@ -168,7 +168,7 @@ def test_one_call_over_a_device_list(monkeypatch):
 
 def test_decode_batch_matches_golden():
     from tests import test_parity_gpu as P
-    for k in (range(7) if FULL else (2, 3, 4, 5, 6)):
+    for k in (range(12) if FULL else (2, 3, 4, 5, 6, 7, 8, 9, 10, 11)):
         P.test_decode_batch_matches_golden(k)
     P.test_decode_unsupported_decoder_is_refused()
 

@@ -202,7 +202,7 @@ struct Workspace {
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_chunk_lo;                           // first document of every compaction chunk (k_doc_first_pretok -> k_compact)
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf dw_ids, dw_tok_off, dw_first, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
+    DevBuf dw_ids, dw_tok_off, dw_first, dw_bad, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask, w_boundmask, w_bprefix, w_seg_off, w_xseg_off,
         w_match_docs, w_match_list;
     // host entry staging
@@ -2715,10 +2715,13 @@ int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* t
         if (n_tok) HIP_CHECK(hipMemcpyAsync(w->dw_ids.p, ids, (size_t)n_tok * 4, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipMemcpyAsync(w->dw_tok_off.p, tok_offsets, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, st));
         uint32_t* firstmask = hm.dec_position_dependent ? w->dw_first.as<uint32_t>() : nullptr;
+        uint32_t* badmask = nullptr;                          // ByteFallback: tokens of byte runs that are not UTF-8
+        if (hm.dec_has_bytes) { w->dw_bad.reserve((size_t)(n_tok / 32 + 2) * 4); badmask = w->dw_bad.as<uint32_t>(); }
+        const uint32_t from_end = hm.dec_special_is_last ? 1u : 0u;
         const uint32_t skip = (flags & TKAMD_SKIP_SPECIAL) ? 1u : 0u;
         launch_decode(st, w->dw_ids.as<uint32_t>(), w->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
                       firstmask, w->dw_len.as<uint32_t>(), w->dw_bsum.as<uint32_t>(), w->dw_pos.as<uint32_t>(), w->dw_total.as<int64_t>(),
-                      w->dw_out_off.as<int64_t>(), nullptr);
+                      w->dw_out_off.as<int64_t>(), nullptr, from_end, badmask);
         HIP_CHECK(hipGetLastError());
         int64_t total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, w->dw_total.p, 8, hipMemcpyDeviceToHost, st));
@@ -2727,7 +2730,7 @@ int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* t
         w->dw_bytes.reserve((size_t)total + 64);
         launch_decode(st, w->dw_ids.as<uint32_t>(), w->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
                       firstmask, w->dw_len.as<uint32_t>(), w->dw_bsum.as<uint32_t>(), w->dw_pos.as<uint32_t>(), w->dw_total.as<int64_t>(),
-                      w->dw_out_off.as<int64_t>(), w->dw_bytes.as<uint8_t>());
+                      w->dw_out_off.as<int64_t>(), w->dw_bytes.as<uint8_t>(), from_end, badmask);
         HIP_CHECK(hipGetLastError());
         std::unique_ptr<tkamd_text> b(new tkamd_text());
         b->n_docs = n_docs;
@@ -2751,6 +2754,11 @@ int tkamd_decode_token(const tkamd_tokenizer* t, uint32_t id, int first_position
     const uint32_t* e = &hm.dec_entry[(size_t)id * 4];
     if (e[1] & DEC_ABSENT) return TKAMD_OK;
     *flags = (e[1] & DEC_SPECIAL) ? 1 : 0;
+    if (e[1] & DEC_BYTE) {                                   // ByteFallback: the token's byte (what a run of them becomes is decided per run)
+        *len = 1;
+        if (cap > 0 && out) out[0] = (uint8_t)e[0];
+        return TKAMD_OK;
+    }
     const uint32_t off = first_position ? e[0] : e[2], l = first_position ? (e[1] & DEC_LEN_MASK) : e[3];
     *len = (int32_t)l;
     for (uint32_t i = 0; i < l && (int32_t)i < cap && out; ++i) out[i] = hm.dec_blob[off + i];

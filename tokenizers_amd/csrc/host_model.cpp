@@ -427,7 +427,7 @@ static std::string wp_cleanup(std::string t) {
 static void build_decode_tables(HostModel& m, const JsonValue* root, const std::unordered_map<std::string, uint32_t>& vocab,
                                 const std::unordered_map<uint32_t, uint8_t>& c2b) {
     const JsonValue* dec = root->get("decoder");
-    std::string prefix = "##";
+    std::string prefix = "##", suffix = "</w>";
     bool cleanup = true;
     if (!dec || dec->is_null()) m.decoder = DEC_JOIN_SPACE;
     else {
@@ -437,6 +437,29 @@ static void build_decode_tables(HostModel& m, const JsonValue* root, const std::
             m.decoder = DEC_WORDPIECE;
             prefix = dec->get_str("prefix", "##");
             cleanup = dec->get_bool("cleanup", true);
+        } else if (t == "BPEDecoder") {
+            m.decoder = DEC_BPE;
+            suffix = dec->get_str("suffix", "</w>");
+            if (suffix.empty()) {        // (str::replace("", " ") puts a space between all chars: not a shape worth tables)
+                m.decoder = DEC_UNSUPPORTED;
+                m.dec_unsupported = "BPEDecoder with an empty suffix is outside the decode path";
+                return;
+            }
+        } else if (t == "ByteFallback") m.decoder = DEC_BYTE_FALLBACK;
+        else if (t == "Fuse") m.decoder = DEC_FUSE;
+        else if (t == "Sequence") {
+            // Sequence[ByteFallback, Fuse] / [ByteFallback] / [Fuse]: Fuse behind ByteFallback changes nothing of the final string
+            // (Decoder::decode joins the chain's output with "", tokenizer/mod.rs:184-187)
+            const JsonValue* ds = dec->get("decoders");
+            std::vector<std::string> kinds;
+            if (ds && ds->is_array()) for (const auto& d : ds->arr) kinds.push_back(d->get_str("type"));
+            if (kinds == std::vector<std::string>{"ByteFallback", "Fuse"} || kinds == std::vector<std::string>{"ByteFallback"}) m.decoder = DEC_BYTE_FALLBACK;
+            else if (kinds == std::vector<std::string>{"Fuse"}) m.decoder = DEC_FUSE;
+            else {
+                m.decoder = DEC_UNSUPPORTED;
+                m.dec_unsupported = "a decoder Sequence other than [ByteFallback, Fuse] is outside the decode path";
+                return;
+            }
         } else {
             m.decoder = DEC_UNSUPPORTED;
             m.dec_unsupported = "decoder type '" + t + "' is outside the decode path";
@@ -484,6 +507,40 @@ static void build_decode_tables(HostModel& m, const JsonValue* root, const std::
             else if (prefix.empty()) rest = t;                 // strip_prefix("") always succeeds
             else rest = " " + t;
             if (cleanup) { first = wp_cleanup(first); rest = wp_cleanup(rest); }
+        } else if (m.decoder == DEC_BPE) {
+            // token.replace(suffix, " "), and token.replace(suffix, "") on the LAST token (decoders/bpe.rs:30-37): `first` is the form of
+            // the position that has one of its own -- here the last kept token (dec_special_is_last)
+            auto replace_all = [&](const std::string& with) {
+                std::string out;
+                size_t pos = 0;
+                for (;;) {
+                    const size_t hit = t.find(suffix, pos);
+                    if (hit == std::string::npos) { out.append(t, pos, std::string::npos); break; }
+                    out.append(t, pos, hit - pos);
+                    out += with;
+                    pos = hit + suffix.size();
+                }
+                return out;
+            };
+            first = replace_all("");
+            rest = replace_all(" ");
+        } else if (m.decoder == DEC_FUSE || m.decoder == DEC_BYTE_FALLBACK) {
+            first = rest = t;
+            // <0xXX>: six bytes, "<0x", two hex digits as u8::from_str_radix reads them (a leading '+' counts as a digit's place), ">"
+            if (m.decoder == DEC_BYTE_FALLBACK && t.size() == 6 && t.compare(0, 3, "<0x") == 0 && t[5] == '>') {
+                auto hex = [](char c) -> int { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
+                int v = -1;
+                if (t[3] == '+') { const int lo = hex(t[4]); if (lo >= 0) v = lo; }
+                else { const int hi = hex(t[3]), lo = hex(t[4]); if (hi >= 0 && lo >= 0) v = hi * 16 + lo; }
+                if (v >= 0) {
+                    e[0] = (uint32_t)v;
+                    e[1] = 1u | DEC_BYTE | (special[id] ? DEC_SPECIAL : 0u);
+                    e[2] = (uint32_t)v;
+                    e[3] = 1u;
+                    m.dec_has_bytes = true;
+                    continue;
+                }
+            }
         } else {
             first = t;
             rest = " " + t;
@@ -495,6 +552,7 @@ static void build_decode_tables(HostModel& m, const JsonValue* root, const std::
         if (rest == first) { e[2] = a.first; e[3] = a.second; }
         else { auto b = put(rest); e[2] = b.first; e[3] = b.second; m.dec_position_dependent = true; }
     }
+    m.dec_special_is_last = m.decoder == DEC_BPE;
     m.dec_blob.resize(m.dec_blob.size() + 16, 0);                        // readable slack for vector loads
 }
 

@@ -38,7 +38,10 @@ struct AddedToken {
 };
 
 // decode_batch (tokenizer/mod.rs:935-953): what the `decoder` section does to the token strings
-enum DecoderKind { DEC_JOIN_SPACE = 0 /* decoder: null -> tokens.join(" ") */, DEC_BYTELEVEL = 1, DEC_WORDPIECE = 2, DEC_UNSUPPORTED = 3 };
+enum DecoderKind { DEC_JOIN_SPACE = 0 /* decoder: null -> tokens.join(" ") */, DEC_BYTELEVEL = 1, DEC_WORDPIECE = 2, DEC_UNSUPPORTED = 3,
+                   DEC_BPE = 4 /* BPEDecoder: the end-of-word suffix becomes a space, nothing on the last token (decoders/bpe.rs:26-39) */,
+                   DEC_BYTE_FALLBACK = 5 /* ByteFallback, alone or Sequence[ByteFallback, Fuse] (decoders/byte_fallback.rs:27-67, fuse.rs:24-29) */,
+                   DEC_FUSE = 6 /* Fuse: tokens.join("") */ };
 
 struct HostModel {
     ModelKind model = MODEL_NONE;
@@ -155,6 +158,8 @@ struct HostModel {
     std::vector<uint32_t> dec_entry;    // [n_ids * 4]
     std::vector<uint8_t> dec_blob;
     bool dec_position_dependent = false; // first-position form differs from the other one for some id
+    bool dec_special_is_last = false;    // BPEDecoder: the position with a form of its own is the LAST kept token of a sequence, not the first
+    bool dec_has_bytes = false;          // ByteFallback: some id is a <0xXX> token (runs of them are validated as UTF-8 on the device)
 
     std::vector<uint16_t> uc_stage1;    // [UC_STAGE1_LEN]
     std::vector<uint8_t> uc_stage2;     // [n_blocks*256]

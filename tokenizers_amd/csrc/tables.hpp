@@ -176,7 +176,8 @@ TK_HD uint32_t long_key_hash_init(uint32_t len) { return 2166136261u ^ (len * 0x
 // ---- decode_batch entry flags (in the length word of the first-position form) ----
 constexpr uint32_t DEC_SPECIAL = 0x80000000u;   // special token: dropped when skip_special_tokens
 constexpr uint32_t DEC_ABSENT = 0x40000000u;    // no token has this id: always dropped (mod.rs:938-941 filter_map)
-constexpr uint32_t DEC_LEN_MASK = 0x3FFFFFFFu;
+constexpr uint32_t DEC_BYTE = 0x20000000u;      // a <0xXX> token under the ByteFallback decoder: word 0 of the entry is the byte (decoders/byte_fallback.rs:31-35)
+constexpr uint32_t DEC_LEN_MASK = 0x1FFFFFFFu;
 
 // ---- tokenizer kinds -------------------------------------------------------------------------
 enum ModelKind { MODEL_NONE = 0, MODEL_BPE = 1, MODEL_WORDPIECE = 2, MODEL_WORDLEVEL = 3 };
