@@ -396,7 +396,13 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     // workgroup busy, instead of filling the first workgroups and leaving most CUs idle
     const uint32_t take = min((uint32_t)NT, ((n_items + gridDim.x - 1u) / gridDim.x + 63u) & ~63u);
     const uint32_t stride = gridDim.x * take;
-    for (uint32_t base = blockIdx.x * take; base < n_items; base += stride) {
+    // Rounds alternate their direction over the workgroups: the queue of the LONGER class comes first in the item order, so it is the
+    // first workgroups whose round 0 is as long as a 32-symbol word's chain of merges -- a second round on top of that made them the
+    // launch's critical path (two rounds at C2: 296 k words on 196 k lanes); reversed, round 1 goes to the workgroups whose round 0 was short.
+    uint32_t round = 0u;
+    for (uint32_t base0 = 0u; base0 < n_items; base0 += stride, ++round) {
+        const uint32_t base = base0 + ((round & 1u) ? (gridDim.x - 1u - blockIdx.x) : blockIdx.x) * take;
+        if (base >= n_items) { if (base0 + stride >= n_items) break; continue; }         // (workgroup-uniform)
         const uint32_t item = base + tid;
         bool valid = tid < take && item < n_items;
         uint32_t s = 0, len = 0, qidx = 0, claim = 0;         // qidx: the result row (named by the position in the work queue); claim: QLEN_CLAIM of the entry

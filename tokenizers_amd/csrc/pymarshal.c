@@ -36,6 +36,7 @@ typedef struct { const void* p; int64_t len; } span_t;     /* len >= 0: UTF-8 by
 
 #define PACK_PREFETCH 12
 #define PACK_MAX_THREADS 32
+#define PACK_DEFAULT_THREADS 24   /* measured on the MI355X box's 256 cores (profiles/r5f_list_leg.txt): 24 threads pack fastest, 32 lose to them */
 #define SPAN_SLOW (-1)         /* needs the interpreter (main thread) */
 
 static inline int64_t utf8_size_ucs1(const Py_UCS1* s, int64_t n) { int64_t b = n; for (int64_t i = 0; i < n; ++i) b += s[i] >> 7; return b; }
@@ -166,7 +167,7 @@ static int64_t pack_core(PyObject** items, Py_ssize_t n, int64_t* off, dst_fn pr
     if (!max_threads) {
         const char* e = getenv("TKAMD_PACK_THREADS");
         long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-        long want = e ? atol(e) : ncpu;
+        long want = e ? atol(e) : (ncpu > PACK_DEFAULT_THREADS ? PACK_DEFAULT_THREADS : ncpu);
         max_threads = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
     }
     int nt = n < 16384 ? 1 : max_threads;
@@ -309,10 +310,7 @@ typedef struct stripe_ctx {
     int* done;                           /* helpers that finished stripe s */
     int64_t ready;                       /* bytes announced */
 } stripe_ctx;
-typedef struct { stripe_ctx* c; int h; } stripe_arg;
-static void* stripe_worker(void* arg) {
-    stripe_ctx* c = ((stripe_arg*)arg)->c;
-    const int h = ((stripe_arg*)arg)->h;
+static void stripe_copy(stripe_ctx* c, int h) {
     for (int s = 0; s < c->n_stripes; ++s) {
         const Py_ssize_t a = c->bound[s], b = c->bound[s + 1];
         const Py_ssize_t lo = a + (b - a) * h / c->nh, hi = a + (b - a) * (h + 1) / c->nh;
@@ -323,6 +321,24 @@ static void* stripe_worker(void* arg) {
         if (__atomic_add_fetch(&c->done[s], 1, __ATOMIC_ACQ_REL) == c->nh)         /* the last helper of the stripe: everything below its end is packed */
             __atomic_store_n(&c->ready, c->off[b], __ATOMIC_RELEASE);
     }
+}
+/* one set of helper threads for the whole of pack_encode: sizes (pass A), offsets (pass C without a destination), then -- if the main
+ * thread says so -- the striped copy, which the main thread does not take part in (it is inside the library call by then) */
+typedef struct pe_ctx { pack_ctx pc; stripe_ctx sc; int stripe_go; } pe_ctx;
+typedef struct { pe_ctx* c; int t; } pe_arg;
+static void* pe_worker(void* arg) {
+    pe_ctx* c = ((pe_arg*)arg)->c;
+    const int t = ((pe_arg*)arg)->t;
+    int go;
+    while ((go = __atomic_load_n(&c->pc.go, __ATOMIC_ACQUIRE)) == 0) sched_yield();
+    if (go < 0) return NULL;
+    pass_a(&c->pc, t);
+    pthread_barrier_wait(&c->pc.bar);                 /* main: slow items, base offsets */
+    pthread_barrier_wait(&c->pc.bar);
+    if (c->pc.base[0] >= 0) pass_c(&c->pc, t);        /* (dst NULL: the offsets) */
+    pthread_barrier_wait(&c->pc.bar);                 /* main: capacity, stripes */
+    pthread_barrier_wait(&c->pc.bar);
+    if (c->stripe_go) stripe_copy(&c->sc, t - 1);     /* helpers 1 .. nt - 1 are stripe workers 0 .. nt - 2 */
     return NULL;
 }
 static void pace_consumed(void* user) { *(PyThreadState**)user = PyEval_SaveThread(); }
@@ -337,113 +353,100 @@ static PyObject* pack_encode(PyObject* self, PyObject* args) {
     const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
     int64_t* off = (int64_t*)(uintptr_t)off_addr;
     char* dst = (char*)(uintptr_t)text_addr;
-    /* sizes + offsets: pack_core without a destination (pass C then writes the offsets only) */
-    span_t* sp = NULL;
-    int64_t total;
-    {
-        /* pack_core frees its spans: the stripes need them, so the sizing runs here with the same helpers */
-        pack_ctx* c = (pack_ctx*)calloc(1, sizeof(pack_ctx));
-        sp = (span_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(span_t));
-        if (!c || !sp) { free(c); free(sp); Py_DECREF(seq); return PyErr_NoMemory(); }
-        c->items = items; c->n = n; c->sp = sp; c->off = off; c->nt = 1; c->dst = NULL;
-        /* (one thread for the sizes of a small batch; a large one: the same gate / barrier protocol as pack_core) */
-        long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
-        const char* e = getenv("TKAMD_PACK_THREADS");
-        long want = e ? atol(e) : ncpu;
-        int max_threads = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
-        int nt = n < 16384 ? 1 : max_threads;
-        pthread_t th[PACK_MAX_THREADS];
-        pack_arg pargs[PACK_MAX_THREADS];
-        int started = 0;
-        for (int t = 1; t < nt; ++t) {
-            pargs[t].c = c; pargs[t].t = t;
-            if (pthread_create(&th[t], NULL, pack_worker, &pargs[t]) != 0) break;
-            started = t;
-        }
-        nt = started + 1;
-        c->nt = nt;
-        if (nt > 1 && pthread_barrier_init(&c->bar, NULL, (unsigned)nt) != 0) {
-            __atomic_store_n(&c->go, -1, __ATOMIC_RELEASE);
-            for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
-            nt = 1; c->nt = 1; started = 0;
-        }
-        __atomic_store_n(&c->go, 1, __ATOMIC_RELEASE);
-        pass_a(c, 0);
-        if (nt > 1) pthread_barrier_wait(&c->bar);
-        int rc = resolve_slow(c);
-        total = -1;
-        if (rc == 0) {
-            int64_t acc = 0;
-            for (int t = 0; t < nt; ++t) { c->base[t] = acc; acc += c->total[t]; }
-            total = acc;
-        } else c->base[0] = -1;
-        if (nt > 1) pthread_barrier_wait(&c->bar);
-        if (rc == 0) pass_c(c, 0);                      /* (dst NULL: the offsets) */
-        for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
-        if (nt > 1) pthread_barrier_destroy(&c->bar);
-        free(c);
-        if (rc != 0) { free(sp); Py_DECREF(seq); return NULL; }
-        off[n] = total;
-    }
-    if ((unsigned long long)total + TEXT_PAD > text_cap) {          /* the caller grows its buffer and comes back */
-        free(sp);
-        Py_DECREF(seq);
-        return Py_BuildValue("LOO", (long long)total, Py_None, Py_None);
-    }
-    /* stripes of ~4 MB of text; helpers (none for a small batch: the copy is done here, before the call) */
-    stripe_ctx sc;
-    memset(&sc, 0, sizeof sc);
-    sc.sp = sp; sc.off = off; sc.dst = dst; sc.n = n;
+    pe_ctx* c = (pe_ctx*)calloc(1, sizeof(pe_ctx));
+    span_t* sp = (span_t*)malloc((size_t)(n > 0 ? n : 1) * sizeof(span_t));
+    if (!c || !sp) { free(c); free(sp); Py_DECREF(seq); return PyErr_NoMemory(); }
+    c->pc.items = items; c->pc.n = n; c->pc.sp = sp; c->pc.off = off; c->pc.dst = NULL;
     long ncpu = sysconf(_SC_NPROCESSORS_ONLN);
     const char* e = getenv("TKAMD_PACK_THREADS");
-    long want = e ? atol(e) : ncpu;
-    int nh = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
-    if (n < 16384 || total < 2 * STRIPE_BYTES) nh = 0;
-    int n_stripes = nh ? (int)(total / STRIPE_BYTES) + 1 : 1;
-    Py_ssize_t* bound = (Py_ssize_t*)malloc((size_t)(n_stripes + 1) * sizeof(Py_ssize_t));
-    int* done = (int*)calloc((size_t)n_stripes, sizeof(int));
-    if (!bound || !done) { free(bound); free(done); free(sp); Py_DECREF(seq); return PyErr_NoMemory(); }
-    bound[0] = 0;
-    for (int s = 1; s < n_stripes; ++s) {                       /* first item at or behind s x 4 MB (binary search over the offsets) */
-        const int64_t target = (int64_t)s * STRIPE_BYTES;
-        Py_ssize_t lo = bound[s - 1], hi = n;
-        while (lo < hi) { const Py_ssize_t mid = lo + (hi - lo) / 2; if (off[mid] < target) lo = mid + 1; else hi = mid; }
-        bound[s] = lo;
+    long want = e ? atol(e) : (ncpu > PACK_DEFAULT_THREADS ? PACK_DEFAULT_THREADS : ncpu);
+    int max_threads = (int)(want < 1 ? 1 : (want > PACK_MAX_THREADS ? PACK_MAX_THREADS : want));
+    int nt = n < 16384 ? 1 : max_threads;
+    pthread_t th[PACK_MAX_THREADS];
+    pe_arg pargs[PACK_MAX_THREADS];
+    int started = 0;
+    for (int t = 1; t < nt; ++t) {
+        pargs[t].c = c; pargs[t].t = t;
+        if (pthread_create(&th[t], NULL, pe_worker, &pargs[t]) != 0) break;
+        started = t;
     }
-    bound[n_stripes] = n;
-    sc.bound = bound; sc.n_stripes = n_stripes; sc.done = done; sc.nh = nh;
-    pthread_t hth[PACK_MAX_THREADS];
-    stripe_arg hargs[PACK_MAX_THREADS];
-    int hstarted = 0;
-    if (nh) {
-        for (int h = 0; h < nh; ++h) {
-            hargs[h].c = &sc; hargs[h].h = h;
+    nt = started + 1;
+    c->pc.nt = nt;
+    if (nt > 1 && pthread_barrier_init(&c->pc.bar, NULL, (unsigned)nt) != 0) {
+        __atomic_store_n(&c->pc.go, -1, __ATOMIC_RELEASE);
+        for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+        nt = 1; c->pc.nt = 1; started = 0;
+    }
+    __atomic_store_n(&c->pc.go, 1, __ATOMIC_RELEASE);
+    pass_a(&c->pc, 0);
+    if (nt > 1) pthread_barrier_wait(&c->pc.bar);
+    int rc = resolve_slow(&c->pc);
+    int64_t total = -1;
+    if (rc == 0) {
+        int64_t acc = 0;
+        for (int t = 0; t < nt; ++t) { c->pc.base[t] = acc; acc += c->pc.total[t]; }
+        total = acc;
+    } else c->pc.base[0] = -1;
+    if (nt > 1) pthread_barrier_wait(&c->pc.bar);
+    if (rc == 0) pass_c(&c->pc, 0);
+    if (nt > 1) pthread_barrier_wait(&c->pc.bar);     /* the offsets are complete */
+    /* the stripes (the helpers wait at the next barrier for the decision) */
+    const int fits = rc == 0 && (unsigned long long)total + TEXT_PAD <= text_cap;
+    const int nh = nt - 1;
+    Py_ssize_t* bound = NULL;
+    int* done = NULL;
+    int striped = 0;
+    if (fits) {
+        off[n] = total;
+        if (nh > 0 && total >= 2 * STRIPE_BYTES) {
+            const int n_stripes = (int)(total / STRIPE_BYTES) + 1;
+            bound = (Py_ssize_t*)malloc((size_t)(n_stripes + 1) * sizeof(Py_ssize_t));
+            done = (int*)calloc((size_t)n_stripes, sizeof(int));
+            if (bound && done) {
+                bound[0] = 0;
+                for (int s = 1; s < n_stripes; ++s) {               /* first item at or behind s stripes of text (binary search over the offsets) */
+                    const int64_t target = (int64_t)s * STRIPE_BYTES;
+                    Py_ssize_t lo = bound[s - 1], hi = n;
+                    while (lo < hi) { const Py_ssize_t mid = lo + (hi - lo) / 2; if (off[mid] < target) lo = mid + 1; else hi = mid; }
+                    bound[s] = lo;
+                }
+                bound[n_stripes] = n;
+                c->sc.sp = sp; c->sc.off = off; c->sc.dst = dst; c->sc.n = n; c->sc.nh = nh;
+                c->sc.bound = bound; c->sc.n_stripes = n_stripes; c->sc.done = done;
+                striped = 1;
+            }
         }
-        /* (a stripe is finished when all nh shares of it are: a helper that could not be created leaves its shares to this thread) */
-        sc.nh = nh;
-        for (int h = 0; h < nh; ++h) {
-            if (pthread_create(&hth[h], NULL, stripe_worker, &hargs[h]) != 0) break;
-            hstarted = h + 1;
-        }
-        if (hstarted < nh) {                                     /* rare: do the missing helpers' shares here, synchronously */
-            for (int h = hstarted; h < nh; ++h) stripe_worker(&hargs[h]);
-        }
+    }
+    c->stripe_go = striped;
+    if (nt > 1) pthread_barrier_wait(&c->pc.bar);     /* helpers: copy the stripes, or leave */
+    PyObject* result = NULL;
+    if (rc != 0) {
+        /* (the exception is set) */
+    } else if (!fits) {
+        result = Py_BuildValue("LOO", (long long)total, Py_None, Py_None);          /* the caller grows its buffer and comes back */
     } else {
-        for (Py_ssize_t i = 0; i < n; ++i) span_write(&sp[i], dst + off[i]);
-        sc.ready = total;
+        if (!striped) {                                                            /* a small batch: the copy is done here, before the call */
+            for (Py_ssize_t i = 0; i < n; ++i) span_write(&sp[i], dst + off[i]);
+            c->sc.ready = total;
+        }
+        memset(dst + total, 0, TEXT_PAD);
+        PyThreadState* ts = NULL;
+        tkamd_pace_c pace = {&c->sc.ready, pace_consumed, &ts};
+        void* batch = NULL;
+        const int status = ((paced_fn)(uintptr_t)fn_addr)((void*)(uintptr_t)tok_addr, (const uint8_t*)dst, off, (int64_t)n, (uint32_t)flags, &pace, &batch);
+        for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+        started = 0;
+        if (ts) PyEval_RestoreThread(ts);
+        result = Py_BuildValue("LiK", (long long)total, status, (unsigned long long)(uintptr_t)batch);
     }
-    memset(dst + total, 0, TEXT_PAD);
-    PyThreadState* ts = NULL;
-    tkamd_pace_c pace = {&sc.ready, pace_consumed, &ts};
-    void* batch = NULL;
-    const int status = ((paced_fn)(uintptr_t)fn_addr)((void*)(uintptr_t)tok_addr, (const uint8_t*)dst, off, (int64_t)n, (uint32_t)flags, &pace, &batch);
-    for (int h = 0; h < hstarted; ++h) pthread_join(hth[h], NULL);
-    if (ts) PyEval_RestoreThread(ts);
+    for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+    if (nt > 1) pthread_barrier_destroy(&c->pc.bar);
     free(bound);
     free(done);
     free(sp);
+    free(c);
     Py_DECREF(seq);
-    return Py_BuildValue("LiK", (long long)total, status, (unsigned long long)(uintptr_t)batch);
+    return result;
 }
 
 static PyMethodDef methods[] = {
