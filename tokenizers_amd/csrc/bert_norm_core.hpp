@@ -99,11 +99,27 @@ TK_HD bool bn_core_map(const BnCoreTables& t, uint32_t cp, uint32_t kind, uint32
 }
 TK_HD uint32_t bn_core_utf8_len(uint32_t cp) { return cp < 0x80u ? 1u : cp < 0x800u ? 2u : cp < 0x10000u ? 3u : 4u; }
 
+// Output bytes per source byte, as the count pass leaves them (round 5): one byte per 16-byte LANE of the source -- its output bytes,
+// < 128, with BN_LTOT_PLAIN when the lane is sixteen ASCII bytes none of which is dropped or verbatim (every byte one output byte) --
+// and the per-byte array only where a lane is NOT plain (99.8 % of a BERT corpus' lanes are: 120 MB less to write, and to read twice).
+constexpr uint32_t BN_LTOT_PLAIN = 0x80u;
+struct BnOlen { const uint8_t* olen; const uint8_t* ltot; };
+TK_HD uint32_t bn_olen_at(const BnOlen& o, int64_t q) { return (o.ltot[q >> 4] & BN_LTOT_PLAIN) ? 1u : (uint32_t)o.olen[q]; }
+// output bytes of the source bytes [word start of g, g): what a position inside a 64-byte word adds to the word's base
+TK_HD uint32_t bn_olen_before(const BnOlen& o, int64_t g) {
+    uint32_t r = 0;
+    const int64_t w0 = g & ~(int64_t)63, l0 = g & ~(int64_t)15;
+    for (int64_t q = w0; q < l0; q += 16) r += o.ltot[q >> 4] & 0x7Fu;
+    if (o.ltot[l0 >> 4] & BN_LTOT_PLAIN) r += (uint32_t)(g - l0);
+    else for (int64_t q = l0; q < g; ++q) r += o.olen[q];
+    return r;
+}
+
 // text[lo, hi): the piece; i / len / f: the REORDER character that is not alone.  olen / wbase: output bytes per source byte and the
 // normalised position of every 64-byte source word (what k_bn_write used); ntext / nos / noe: the normalised text and, if kept, the
 // source byte range of every normalised byte.  Returns false if the run does not fit BN_RUN_MAX pieces.
 TK_HD bool bn_fix_run(const BnCoreTables& t, const uint8_t* text, int64_t lo, int64_t hi, int64_t i, uint32_t len, uint32_t f, const unsigned long long* verbatim,
-                      const uint8_t* olen, const uint32_t* wbase, uint8_t* ntext, uint32_t* nos, uint32_t* noe) {
+                      const BnOlen& olen, const uint32_t* wbase, uint8_t* ntext, uint32_t* nos, uint32_t* noe) {
     // ---- where the run starts: back over the characters that are non-starters throughout, up to (and including) one that merely ends in some
     int64_t start = i;
     bool head_partial = !(f & BN_F_NS_FIRST);            // the survivor's own character begins with a starter: the run begins inside it
@@ -152,8 +168,7 @@ TK_HD bool bn_fix_run(const BnCoreTables& t, const uint8_t* text, int64_t lo, in
             }
         }
         // normalised position of the character: the word's base + the output of the bytes before it in the word
-        int64_t xc = wbase[p >> 6];
-        for (int64_t q = p & ~(int64_t)63; q < p; ++q) xc += olen[q];
+        const int64_t xc = (int64_t)wbase[p >> 6] + (int64_t)bn_olen_before(olen, p);
         const int np = (int)(pk & 7u);
         int taken = 0;
         uint32_t run_bytes_here = 0;
@@ -171,7 +186,7 @@ TK_HD bool bn_fix_run(const BnCoreTables& t, const uint8_t* text, int64_t lo, in
             ++n;
         }
         if (head) { last_a = (uint32_t)p; last_len = l; }
-        if (x < 0 && run_bytes_here) x = xc + (int64_t)olen[p] - (int64_t)run_bytes_here;      // its starters' bytes come first
+        if (x < 0 && run_bytes_here) x = xc + (int64_t)bn_olen_at(olen, p) - (int64_t)run_bytes_here;      // its starters' bytes come first
         first = false;
         p += l;
     }

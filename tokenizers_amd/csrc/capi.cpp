@@ -1298,7 +1298,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (hm.norm == NORM_BERT) {
         // ---- BertNormalizer: text -> normalised text + original byte range of every normalised byte; the matches of pass 1 are
         // not text (their split carries the raw slice): copied verbatim ----
-        w->w_keepmask.reserve((size_t)n_bytes + 64);            // olen: output bytes per source byte
+        w->w_keepmask.reserve(bn_olen_bytes(n_bytes));          // olen + the per-lane totals: output bytes per source byte (kernels.hpp bn_olen_bytes)
         w->w_kprefix.reserve((size_t)(W0 + 1) * 4);             // wsum
         w->w_wbase.reserve((size_t)(W0 + 1) * 4);
         BnTables bt{t->t_bn1.as<uint16_t>(), t->t_bn2.as<uint8_t>(), t->t_bn_map.as<MergeSlot>(), hm.bn_mask, hm.bn_seed,

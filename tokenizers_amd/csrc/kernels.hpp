@@ -320,6 +320,10 @@ void launch_lookup_fused(hipStream_t st, int grid, const DevTables& t, const uin
 // also (group 6 only): a second queue for the same launch
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                       uint32_t* tmp_ids, uint32_t* tmp_end, const QView* also = nullptr);
+// the normaliser's count arrays share one buffer: n_bytes + 64 per-byte counts (written for the lanes that are not plain only), then
+// one byte per 16-byte lane (bert_norm_core.hpp BnOlen); bn_olen_bytes(n) is what the buffer must hold
+inline size_t bn_olen_bytes(int64_t n_bytes) { return (((size_t)n_bytes + 64 + 15) & ~(size_t)15) + ((size_t)n_bytes >> 4) + 64; }
+inline uint8_t* bn_ltot_of(uint8_t* olen, int64_t n_bytes) { return olen + (((size_t)n_bytes + 64 + 15) & ~(size_t)15); }
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
                               unsigned long long* docmask, int* err);
 void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,

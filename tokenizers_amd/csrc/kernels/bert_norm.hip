@@ -82,7 +82,7 @@ __device__ __forceinline__ uint32_t mask16(const unsigned long long* __restrict_
 // order (survivors rewritten in the normalised text, with the alignments transform() would give them)
 __device__ __forceinline__ void bn_fix_reorder(const BnTables& bt, const uint8_t* __restrict__ text, int64_t n_bytes, int64_t i, uint32_t cp, uint32_t len,
                                                const unsigned long long* __restrict__ vmask, const int64_t* __restrict__ doc_off, int64_t n_docs,
-                                               const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase, uint8_t* __restrict__ ntext,
+                                               const BnOlen& olen, const uint32_t* __restrict__ wbase, uint8_t* __restrict__ ntext,
                                                uint32_t* __restrict__ nos, uint32_t* __restrict__ noe, int* __restrict__ err) {
     // the document holding byte i: the last d with doc_off[d] <= i
     int64_t lo = 0, hi = n_docs;
@@ -114,24 +114,29 @@ __device__ __forceinline__ uint32_t bn_count_byte(const BnTables& bt, const uint
 
 // `verbatim`: bytes of added-token matches of the raw pass (null: none) -- not text for the normalizer: copied as they are
 __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
-                                                  uint8_t* __restrict__ olen, uint32_t* __restrict__ wsum, int* __restrict__ err) {
+                                                  uint8_t* __restrict__ olen, uint8_t* __restrict__ ltot, uint32_t* __restrict__ wsum, int* __restrict__ err) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BN_LANE;
     uint32_t o[4] = {0u, 0u, 0u, 0u};                               // output bytes of my 16 source bytes, one per byte
+    bool plain = false;                                             // sixteen ASCII bytes, none dropped, none verbatim: one output byte each
     if (i0 < n_bytes) {
         const Unaligned16 t = *(const Unaligned16*)(text + i0);                 // (any alignment: the caller's pointer; readable TEXT_PAD bytes past the end)
         const uint32_t x[4] = {t.a, t.b, t.c, t.d};
         const uint32_t vb = verbatim ? mask16(verbatim, i0) : 0u;
         if (((t.a | t.b | t.c | t.d) & SW_H) == 0u && vb == 0u && i0 + BN_LANE <= n_bytes) {
+            uint32_t dropped = 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = SW_1 - (bt.clean ? (sw_ascii_dropped(x[k]) >> 7) : 0u);
+            for (int k = 0; k < 4; ++k) { const uint32_t d = bt.clean ? (sw_ascii_dropped(x[k]) >> 7) : 0u; o[k] = SW_1 - d; dropped |= d; }
+            plain = dropped == 0u;
         } else {
             const int nv = (int)min((int64_t)BN_LANE, n_bytes - i0);
             for (int j = 0; j < nv; ++j) o[j >> 2] |= bn_count_byte(bt, text, i0 + j, (x[j >> 2] >> (8 * (j & 3))) & 0xFFu, (vb >> j) & 1u, err) << (8 * (j & 3));
         }
-        *(uint4*)(olen + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+        // (the per-byte counts only where the lane is not plain: BnOlen, bert_norm_core.hpp)
+        if (!plain) *(uint4*)(olen + i0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
     // per-word sum: the four lanes of a 64-byte word
     uint32_t s = ((o[0] * SW_1) >> 24) + ((o[1] * SW_1) >> 24) + ((o[2] * SW_1) >> 24) + ((o[3] * SW_1) >> 24);
+    if (i0 < n_bytes) ltot[i0 >> 4] = (uint8_t)(s | (plain ? BN_LTOT_PLAIN : 0u));      // (a lane's output is < 128 bytes: sixteen source bytes are at most eight chars of at most twelve bytes)
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     if ((threadIdx.x & 3) == 0 && i0 <= n_bytes) wsum[i0 >> 6] = s;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void k_bn_count(BnTables bt, const uint8_t* __
 // with its neighbours; one that is not alone in its run of non-starters has that run put into NFD's canonical order
 // (bert_norm_core.hpp).  A run longer than BN_RUN_MAX pieces refuses the batch.
 __global__ __launch_bounds__(256) void k_bn_reorder_fix(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
-                                                        const int64_t* __restrict__ doc_off, int64_t n_docs, const uint8_t* __restrict__ olen,
+                                                        const int64_t* __restrict__ doc_off, int64_t n_docs, BnOlen olen,
                                                         const uint32_t* __restrict__ wbase, uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos,
                                                         uint32_t* __restrict__ noe, int* __restrict__ err) {
     if (!(*err & NOTE_REORDER_SEEN) || !bt.strip) return;
@@ -197,12 +202,11 @@ __device__ __forceinline__ void bn_write_byte(const BnTables& bt, const uint8_t*
 }
 
 __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __restrict__ text, int64_t n_bytes, const unsigned long long* __restrict__ verbatim,
-                                                  const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
+                                                  BnOlen olen, const uint32_t* __restrict__ wbase,
                                                   uint8_t* __restrict__ ntext, uint32_t* __restrict__ nos, uint32_t* __restrict__ noe) {
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * BN_LANE;
-    uint4 ol = make_uint4(0u, 0u, 0u, 0u);
-    if (i0 < n_bytes) ol = *(const uint4*)(olen + i0);
-    const uint32_t tot = ((ol.x * SW_1) >> 24) + ((ol.y * SW_1) >> 24) + ((ol.z * SW_1) >> 24) + ((ol.w * SW_1) >> 24);
+    const uint32_t lt = i0 < n_bytes ? (uint32_t)olen.ltot[i0 >> 4] : 0u;      // my lane's output bytes (| BN_LTOT_PLAIN)
+    const uint32_t tot = lt & 0x7Fu;
     // my place: the word's base + the output of the lanes before me in the word (four lanes a word)
     const int lane = lane_id();
     const uint32_t t1 = (uint32_t)__shfl_up((int)tot, 1, 64), t2 = (uint32_t)__shfl_up((int)tot, 2, 64), t3 = (uint32_t)__shfl_up((int)tot, 3, 64);
@@ -212,8 +216,8 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
     const Unaligned16 t = *(const Unaligned16*)(text + i0);
     uint32_t x[4] = {t.a, t.b, t.c, t.d};
     const uint32_t vb = verbatim ? mask16(verbatim, i0) : 0u;
-    if (tot == (uint32_t)BN_LANE && ((t.a | t.b | t.c | t.d) & SW_H) == 0u && vb == 0u && i0 + BN_LANE <= n_bytes) {
-        // 16 ASCII bytes, none dropped: \t \n \r -> ' ', A-Z -> a-z, one 16-byte store (at any alignment)
+    if (lt & BN_LTOT_PLAIN) {
+        // 16 ASCII bytes, none dropped (what the count pass called plain): \t \n \r -> ' ', A-Z -> a-z, one 16-byte store (at any alignment)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (bt.clean) { const uint32_t m = (sw_ascii_ws(x[k]) >> 7) * 0xFFu; x[k] = (x[k] & ~m) | (0x20202020u & m); }
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
         }
         return;
     }
+    const uint4 ol = *(const uint4*)(olen.olen + i0);                    // (not plain: the count pass left the per-byte counts)
     const uint32_t o[4] = {ol.x, ol.y, ol.z, ol.w};
     const int nv = (int)min((int64_t)BN_LANE, n_bytes - i0);
     for (int j = 0; j < nv; ++j) {
@@ -237,27 +242,12 @@ __global__ __launch_bounds__(256) void k_bn_write(BnTables bt, const uint8_t* __
 
 // document CSR in normalised coordinates: ndoc_off[d] = #normalised bytes produced before doc_off[d]
 __global__ void k_bn_doc_offsets(const int64_t* __restrict__ doc_off, int64_t n_docs, int64_t n_bytes,
-                                 const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase,
+                                 BnOlen olen, const uint32_t* __restrict__ wbase,
                                  const int64_t* __restrict__ x_len, int64_t* __restrict__ ndoc_off) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d > n_docs) return;
     int64_t g = doc_off[d];
     if (g < 0) g = 0;
-    int64_t r;
-    if (g >= n_bytes) r = *x_len;
-    else {
-        r = wbase[g >> 6];
-        const int64_t base = g & ~(int64_t)63;
-        for (int q = 0, nb = (int)(g - base); q < nb; q += 16) {       // the bytes of the word before g, 16 at a time
-            const uint4 v = *(const uint4*)(olen + base + q);
-            const uint32_t o[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int keep = nb - q - 4 * k;                       // bytes of this 4-byte group that lie before g
-                const uint32_t m = keep >= 4 ? 0xFFFFFFFFu : (keep > 0 ? (1u << (8 * keep)) - 1u : 0u);
-                r += ((o[k] & m) * SW_1) >> 24;
-            }
-        }
-    }
-    ndoc_off[d] = r;
+    // (the word's base + the lanes before g's in the word + g's place in its own lane: a plain lane's bytes are one output byte each)
+    ndoc_off[d] = g >= n_bytes ? *x_len : (int64_t)wbase[g >> 6] + (int64_t)bn_olen_before(olen, g);
 }

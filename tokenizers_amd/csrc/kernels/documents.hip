@@ -241,13 +241,11 @@ __global__ void k_emit_boundaries(const unsigned long long* __restrict__ mask, c
 }
 // list entries from the raw text into the normalised text: position of a source byte = bytes the normalizer emitted before it
 // (matches are copied verbatim, so their length is unchanged)
-__device__ __forceinline__ uint32_t bn_position(const uint8_t* __restrict__ olen, const uint32_t* __restrict__ wbase, int64_t n_bytes, const int64_t* __restrict__ x_len, int64_t g) {
+__device__ __forceinline__ uint32_t bn_position(const BnOlen& olen, const uint32_t* __restrict__ wbase, int64_t n_bytes, const int64_t* __restrict__ x_len, int64_t g) {
     if (g >= n_bytes) return (uint32_t)*x_len;
-    uint32_t r = wbase[g >> 6];
-    for (int64_t q = g & ~(int64_t)63; q < g; ++q) r += olen[q];
-    return r;
+    return wbase[g >> 6] + bn_olen_before(olen, g);
 }
-__global__ void k_translate_matches_norm(uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, const uint8_t* __restrict__ olen,
+__global__ void k_translate_matches_norm(uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, BnOlen olen,
                                          const uint32_t* __restrict__ wbase, int64_t n_bytes, const int64_t* __restrict__ x_len) {
     const uint32_t n = *n_list;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {

@@ -180,16 +180,18 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                            const unsigned long long* verbatim, uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext,
                            uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err) {
     const int64_t n_words = (n_bytes >> 6) + 1;
-    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, olen, wsum, err);
+    uint8_t* const ltot = bn_ltot_of(olen, n_bytes);           // (one byte per 16-byte lane, behind the per-byte array: BnOlen, bert_norm_core.hpp)
+    const BnOlen ol{olen, ltot};
+    hipLaunchKernelGGL(k_bn_count, dim3(blocks_for(n_bytes + 1, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, olen, ltot, wsum, err);
 
     unsigned nb = blocks_for(n_words, 256);
     hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, bsum);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, x_len);
     hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)wsum, n_words, (const uint32_t*)bsum, wbase);
-    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe);
+    hipLaunchKernelGGL(k_bn_write, dim3(blocks_for(n_bytes, 256 * BN_LANE)), dim3(256), 0, st, bt, text, n_bytes, verbatim, ol, (const uint32_t*)wbase, ntext, nos, noe);
     hipLaunchKernelGGL(k_bn_reorder_fix, dim3(std::min<unsigned>(blocks_for(n_bytes + 1, 256), 2048u)), dim3(256), 0, st, bt, text, n_bytes, verbatim, doc_off, n_docs,
-                       (const uint8_t*)olen, (const uint32_t*)wbase, ntext, nos, noe, err);
-    hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const uint8_t*)olen,
+                       ol, (const uint32_t*)wbase, ntext, nos, noe, err);
+    hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, ol,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
 void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
@@ -264,7 +266,7 @@ void launch_emit_boundaries(hipStream_t st, const unsigned long long* mask, cons
     hipLaunchKernelGGL(k_emit_boundaries, dim3(blocks_for((n_bytes >> 6) + 2, 256)), dim3(256), 0, st, mask, wprefix, n_bytes, len_dev, total, out);
 }
 void launch_translate_matches_norm(hipStream_t st, uint32_t* list, const uint32_t* n_list, const uint8_t* olen, const uint32_t* wbase, int64_t n_bytes, const int64_t* x_len) {
-    hipLaunchKernelGGL(k_translate_matches_norm, dim3(256), dim3(256), 0, st, list, n_list, olen, wbase, n_bytes, x_len);
+    hipLaunchKernelGGL(k_translate_matches_norm, dim3(256), dim3(256), 0, st, list, n_list, BnOlen{olen, bn_ltot_of((uint8_t*)olen, n_bytes)}, wbase, n_bytes, x_len);
 }
 void launch_translate_matches_prefix(hipStream_t st, uint32_t* list, const uint32_t* n_list, const unsigned long long* bmask, const uint32_t* wprefix, int64_t n_bytes,
                                      const int64_t* len_dev, const int64_t* total, const int64_t* xseg_off) {
