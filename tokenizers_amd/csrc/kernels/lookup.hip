@@ -597,9 +597,6 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
             // against 0.2337 ms, as batching the probes had in round 2: profiles/r4d_ab_c2.txt.)
             struct P2 { bool v, probe; uint32_t rel, s_rel, len, k0, k1, k2, k3, h1, k3t; uint4 a0; };
             const uint32_t n_miss = s_nmiss;
-            // (end-mask shapes) the wavefront's own candidate list: entry k sits in the k-th slot of the miss list this wavefront reads
-            uint32_t wl_n = 0u;
-            auto wave_list_slot = [&](uint32_t k) -> uint32_t { return (k >> 6) * (uint32_t)LU_NT + (uint32_t)wave * 64u + (k & 63u); };
             auto p2_key = [&](uint32_t m0, P2& x) {
                 x.v = m0 + lane < n_miss;
                 x.rel = s_miss[x.v ? m0 + lane : m0];
@@ -658,16 +655,20 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                             if (cand && !lng) s_cand[bs + (uint32_t)mbcnt64(cb)] = (uint16_t)rel;
                             if (lng) s_cand[(uint32_t)LU_POS_CAP - 1u - (bl + (uint32_t)mbcnt64(lb))] = (uint16_t)rel;
                         }
-                    } else {
-                        // With end masks there is no LDS for a candidate list of the workgroup's -- the WAVEFRONT keeps its own, in the
-                        // slots of the miss list it has already read (a step's candidates are at most its misses, so the write cursor
-                        // never passes the read cursor): wave_list_slot.  Its steps of candidates follow its steps of misses, no barrier
-                        // in between (round 4 ran the claim inline here: two more dependent round trips in EVERY step of pass 2).
-                        const uint64_t cb = __ballot(cand);
-                        if (cb) {                                                   // (wavefront-uniform)
-                            if (cand) s_miss[wave_list_slot(wl_n + (uint32_t)mbcnt64(cb))] = (uint16_t)rel;
-                            wl_n += (uint32_t)__popcll(cb);
-                        }
+                    } else if (cand) {
+                        // (Round 5 tried a candidate list of the WAVEFRONT's own here -- in the miss-list slots it has already read, its steps of
+                        // candidates behind its steps of misses, no barrier: C3's lookup 0.2545 -> 0.2685 ms, profiles/r5h_ab_c3.txt.  A
+                        // wavefront has ~40 candidates a tile: two more sparsely filled steps cost more than the claim chain inside the steps
+                        // it runs anyway.)
+                        uint32_t slot = 0u;                                         // (h1 is the probe's: a word beyond the table's 16-byte keys was not probed)
+                        const uint32_t r = claim_any(s_rel, len, k0, k1, k2, k3, x.probe ? h1 : word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3), slot);
+                        if (r == CLAIM_SHARED) { out = TOK_SLOT | slot; pend = false; }
+                        holds = r == CLAIM_HOLDS;
+                    }
+                    if (!CAND_PASS) {                                               // (the inline variant keeps the yield per step)
+                        const uint64_t cb = __ballot(cand), sb = __ballot(cand && !pend);
+                        if (cb && lane == 0) { atomicAdd(&s_seen, (uint32_t)__popcll(cb)); if (sb) atomicAdd(&s_shared, (uint32_t)__popcll(sb)); }
+                        cand = false;
                     }
                 } else if (a.claims) {                                              // (wavefront-uniform) given up: the candidates still count -- the host's pause rule wants the batch's yield
                     const uint64_t cb = __ballot(pend && hits_on && len != 0u && len <= CLAIM_MAX_LEN);
@@ -693,40 +694,6 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
             // out-of-distribution text, profiles/r4h_ab_c2*.txt.  A wait for one load is a wait for every memory operation issued
             // before it -- s_waitcnt counts in order -- so each link also waited for the next tile's prefetch and the tok0 stores just
             // issued; and the 17 extra live registers cost the other passes.)
-            if (!CAND_PASS && claims_now) {                                         // wavefront-uniform: the wavefront's own candidates, two sweeps
-                // sweep 1: the words whose claim entry is their key; a 16..32-byte word (a second dependent round trip, and a step waits for
-                // its slowest lane) and a half-written claim are put back on the list -- again into slots this sweep has already read --
-                // for sweep 2, which settles whatever is left for good
-                uint32_t n1 = wl_n, n2 = 0u, seen = 0u, shared = 0u;
-#pragma unroll 1
-                for (int sweep = 0; sweep < 2; ++sweep) {
-                    const uint32_t nk = sweep ? n2 : n1;
-#pragma unroll 1
-                    for (uint32_t k0 = 0u; k0 < nk; k0 += 64u) {
-                        const bool v = k0 + lane < nk;
-                        const uint32_t rel = s_miss[wave_list_slot(v ? k0 + lane : k0)];
-                        uint32_t s_rel, len, k0_, k1, k2, k3;
-                        load_key(rel, s_rel, len, k0_, k1, k2, k3, true);
-                        const uint32_t h1 = word_hash1_from_hot(hot_hash(k0_, k1, k2, len, a.word_seed), k3);
-                        uint32_t out = 0u, slot = 0u, r = CLAIM_NONE;
-                        bool pend = v, again = false;
-                        if (v) {
-                            if (len > CLAIM_KEY_MAX) { if (sweep) r = claim_any(s_rel, len, k0_, k1, k2, k3, h1, slot); else again = true; }
-                            else { slot = claim_slot(h1, a.claim_mask); r = claim_short(slot, len, k0_, k1, k2, k3, sweep != 0); again = r == CLAIM_RETRY; }
-                        }
-                        if (r == CLAIM_SHARED) { out = TOK_SLOT | slot; pend = false; }
-                        const uint64_t ab = __ballot(again);
-                        if (ab) {                                                   // (wavefront-uniform; sweep 1 only)
-                            if (again) s_miss[wave_list_slot(n2 + (uint32_t)mbcnt64(ab))] = (uint16_t)rel;
-                            n2 += (uint32_t)__popcll(ab);
-                        }
-                        seen += (uint32_t)__popcll(__ballot(v && !again));
-                        shared += (uint32_t)__popcll(__ballot(v && !pend && !again));
-                        finish(v && !again, pend && !again, rel, s_rel, len, out, r == CLAIM_HOLDS);
-                    }
-                }
-                if (lane == 0 && seen) { atomicAdd(&s_seen, seen); if (shared) atomicAdd(&s_shared, shared); }
-            }
             if (CAND_PASS && claims_now) {                                          // wavefront-uniform
                 __syncthreads();
                 tick(LU_PH_PASS2);
