@@ -5,12 +5,12 @@
 #   legs), rocprofv3 --kernel-trace --stats; for C2 also the SQ / TCC counters of the dominant kernels; smoke().
 # usage (on the GPU box, from the repo root): tools/round_profile.sh <tag> [skip-pytest]        e.g. r3
 # Every profiler run sits under `timeout`: a rocprofv3 that aborts can otherwise hang in its finaliser for minutes.
-tag=${1:-r3}
+tag=${1:-r5}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/$tag
 mkdir -p "$O"
 if [ "$2" != "skip-pytest" ]; then
-  timeout 1200 python -m pytest tests -m gpu -q > "$O/pytest_gpu.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$O/pytest_gpu.txt"
+  timeout 1500 python -m pytest tests -m gpu -q -n 4 > "$O/pytest_gpu.txt" 2>&1; echo "pytest rc=$?"; tail -3 "$O/pytest_gpu.txt"
 fi
 pmc() {   # FETCH_SIZE and WRITE_SIZE in separate passes (the guide's rule)
   local c=$1
