@@ -30,14 +30,16 @@ stats() {
   local S=$(ls $O/stats_$c/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$S" ] && cp "$S" "$O/${c}_kernel_stats.csv"
   rm -rf "$O/stats_$c"
 }
-pmc c2
+# Order matters (round 5): a bench line taken right BEHIND a rocprofv3 --pmc pass came out 12 % slow (the lookup 0.274 ms instead of 0.212:
+# profiles/r5_first_order_c2_bench.json against r5i_bench*.txt, same commit) -- the counters' collection leaves the device in another
+# clock state for a while.  So: every bench line and every --kernel-trace --stats run first, all PMC passes last.  bench.py reads the
+# traffic figure from the committed summary of the previous run of this script (same kernels: the summaries carry their commit).
 timeout 500 python bench.py > "$O/c2_bench.json" 2> "$O/c2_bench.log"; echo "bench c2 rc=$?"; head -c 400 "$O/c2_bench.json"; echo
-stats c2
+for c in c3 c4 c5; do
+  timeout 300 python bench.py --config $c --no-host --no-ood --no-word-cache --no-single-call > "$O/${c}_bench.json" 2> "$O/${c}_bench.log"; echo "bench $c rc=$?"; head -c 200 "$O/${c}_bench.json"; echo
+done
+for c in c2 c3 c4 c5; do stats $c; done
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1
+for c in c2 c3 c4 c5; do pmc $c; done
 # SQ / TCC counters of the dominant kernels (C2)
 tools/sq.sh $tag/sq c2 k_lookup,k_compact,k_bpe_merge_lds,k_pretok_gpt2_seq > "$O/sq.log" 2>&1; cp gpurun_out/$tag/sq/sq_c2.json "$O/c2_sq_summary.json" 2>/dev/null; echo "sq rc=$?"
-for c in c3 c4 c5; do
-  pmc $c
-  timeout 300 python bench.py --config $c --no-host --no-ood --no-word-cache --no-single-call > "$O/${c}_bench.json" 2> "$O/${c}_bench.log"; echo "bench $c rc=$?"; head -c 200 "$O/${c}_bench.json"; echo
-  stats $c
-done
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1
