@@ -165,6 +165,7 @@ def main() -> None:
     ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
     ap.add_argument("--no-word-cache", action="store_true", help="skip the word-cache leg")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the two-batches-in-flight leg")
     ap.add_argument("--no-single-call", action="store_true", help="skip the single-call multi-GPU leg")
     ap.add_argument("--single-call-gpus", type=int, default=0, help="devices of the single-call leg (0 = every visible GPU)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
@@ -334,6 +335,41 @@ def main() -> None:
                                         "probes_per_s": round(qs["merge_probes"] / t_merge / 1e9, 3), "unit": "G probes/s",
                                         "kernels_ms": round(t_merge * 1e3, 4), "bytes_per_probe": 16,
                                         "model": "(k - 1) + 2 m per queued word of k symbols and m merges; the in-batch claims leave the distinct words only"}
+
+    # ---- two batches in flight (rank 0, N=1): the same K steps, alternating over TWO streams (the device entry keys its workspace by the
+    # caller's stream: two streams, two workspaces).  NOT `value` -- a step of `value` is one batch after the other on one stream --
+    # but what a loader that keeps two batches in flight gets: the chain-bound tail of one batch (thin merge queues, the compaction's
+    # look-back) overlaps the bandwidth-bound head of the next.  Every step's result is checked like the timed ones'. ----
+    two = None
+    if rank == 0 and world == 1 and not args.no_two_streams:
+        try:
+            side = torch.cuda.Stream()
+            streams = [stream, side.cuda_stream]
+
+            def enc2(i):
+                b = batches[i % n_batches]
+                return tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, stream=streams[i & 1])
+            for i in range(4):
+                enc2(i)
+            torch.cuda.synchronize()
+            best = float("inf")
+            for _ in range(3):
+                t_s = time.perf_counter()
+                for i in range(args.steps):
+                    enc2(i)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t_s) / args.steps)
+            ok = True
+            for i in range(2 * n_batches):                   # (both workspaces' results against the gate's checksums)
+                ok = ok and result_checksum(enc2(i).sync()) == batches[i % n_batches].checksum
+                torch.cuda.synchronize()
+            two = {"value": round(tot_bytes / args.steps / best / 1e9, 3), "unit": "GB/s", "ms_per_step": round(best * 1e3, 4), "streams": 2,
+                   "results_equal_the_gate": bool(ok),
+                   "note": "K steps alternating over two streams (two workspaces of the handle), best of 3 passes; not `value`"}
+            if not ok:
+                two["error"] = "a result differs from the gated one"
+        except Exception as ex:     # never lose the bench line to an auxiliary leg
+            two = {"error": repr(ex)[:300]}
 
     # ---- word-cache leg (rank 0, N=1): the device-side counterpart of the reference's per-thread word cache
     # (models/bpe/model.rs:573-586).  NOT `value`: the steps revisit the same three batches, so a warm cache has seen every word of
@@ -538,6 +574,7 @@ def main() -> None:
             "value_from_python_list_of_str": host.get("gbps_encode_batch_fast_list_of_str") if host else None,
             "value_out_of_distribution": ood["value"] if ood else None,
             "value_with_word_cache": wcache["value_warm"] if wcache else None,
+            "value_two_batches_in_flight": two.get("value") if two else None,
             "parity": {"checked_documents": int(n_checked), "against": "oracle/oracle.c", "of": "every timed batch (2 % sample), ids bit-exact",
                        "timed_outputs": f"checksums of ids + token CSR of the last timed step and of {n_verified} re-run steps equal the gated results'"},
             "config": {"workload": f"{workload}, {b0.n_docs} synthetic documents ({b0.n_bytes / 1e6:.0f} MB) per GPU per step, "
@@ -547,7 +584,7 @@ def main() -> None:
                        "tokenizer_sha256": synth.sha256(tok_json)[:16],
                        "parallelism": f"dp{world} (documents sharded by rank)"},
             "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "single_call_multi_gpu": single_call,
-            "out_of_distribution": ood, "word_cache": wcache, "other_configs": others_cfg,
+            "out_of_distribution": ood, "word_cache": wcache, "two_batches_in_flight": two, "other_configs": others_cfg,
         }
     # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
     gather_obj = None
@@ -580,7 +617,7 @@ def other_config_leg(cfg: str, steps: int, warmup: int, n_lines: int, n_batches:
     """`python bench.py --config cfg` (kernel pipeline + parity gate + roofline leg only) as a child process; the fields of its line
     that matter, or an error -- never an exception (the headline line must not be lost to an auxiliary leg)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup), "--lines", str(n_lines),
-           "--batches", str(n_batches), "--no-cpu-baseline", "--no-ood", "--no-host", "--no-word-cache", "--no-single-call", "--also", "none"]
+           "--batches", str(n_batches), "--no-cpu-baseline", "--no-ood", "--no-host", "--no-word-cache", "--no-single-call", "--no-two-streams", "--also", "none"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
