@@ -165,7 +165,8 @@ def main() -> None:
     ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
     ap.add_argument("--no-word-cache", action="store_true", help="skip the word-cache leg")
-    ap.add_argument("--no-two-streams", action="store_true", help="skip the two-batches-in-flight leg")
+    ap.add_argument("--two-streams", action="store_true", help="also time the K steps alternating over two streams (two batches in flight); measured "
+                                                               "SLOWER than one stream -- 0.998 against 0.535 ms a step, profiles/r5j_c2_bench.json -- so not part of the default line")
     ap.add_argument("--no-single-call", action="store_true", help="skip the single-call multi-GPU leg")
     ap.add_argument("--single-call-gpus", type=int, default=0, help="devices of the single-call leg (0 = every visible GPU)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
@@ -339,9 +340,11 @@ def main() -> None:
     # ---- two batches in flight (rank 0, N=1): the same K steps, alternating over TWO streams (the device entry keys its workspace by the
     # caller's stream: two streams, two workspaces).  NOT `value` -- a step of `value` is one batch after the other on one stream --
     # but what a loader that keeps two batches in flight gets: the chain-bound tail of one batch (thin merge queues, the compaction's
-    # look-back) overlaps the bandwidth-bound head of the next.  Every step's result is checked like the timed ones'. ----
+    # look-back) could overlap the bandwidth-bound head of the next.  Measured (round 5): it does not -- 0.998 ms a step against 0.535,
+    # two lookups and two compactions each on half the chip cost more than they hide -- so the leg is opt-in (--two-streams).  Every
+    # step's result is checked like the timed ones'. ----
     two = None
-    if rank == 0 and world == 1 and not args.no_two_streams:
+    if rank == 0 and world == 1 and args.two_streams:
         try:
             side = torch.cuda.Stream()
             streams = [stream, side.cuda_stream]
@@ -617,7 +620,7 @@ def other_config_leg(cfg: str, steps: int, warmup: int, n_lines: int, n_batches:
     """`python bench.py --config cfg` (kernel pipeline + parity gate + roofline leg only) as a child process; the fields of its line
     that matter, or an error -- never an exception (the headline line must not be lost to an auxiliary leg)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup), "--lines", str(n_lines),
-           "--batches", str(n_batches), "--no-cpu-baseline", "--no-ood", "--no-host", "--no-word-cache", "--no-single-call", "--no-two-streams", "--also", "none"]
+           "--batches", str(n_batches), "--no-cpu-baseline", "--no-ood", "--no-host", "--no-word-cache", "--no-single-call", "--also", "none"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
