@@ -359,10 +359,6 @@ inline hipError_t hipFree(void* p) {
 #endif
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-// (every host pointer is "ordinary" memory to the emulation: the host entry's staging of pageable caller buffers runs in the CPU tests)
-enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
-struct hipPointerAttribute_t { hipMemoryType type; };
-inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeUnregistered; return hipSuccess; }
 #ifdef __SANITIZE_ADDRESS__
 namespace simt { inline void check_kind(const void*, const void*, hipMemcpyKind) {} }
 #endif

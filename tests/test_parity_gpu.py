@@ -643,8 +643,8 @@ def test_sliced_host_entry_equals_one_slice(gpt2_json):
         "assert len(g.ids) == 24 * len(bd) and g.tok_offsets[-1] == len(g.ids) and (np.diff(g.tok_offsets) == 24).all()\n"
         "print('SLICED_OK', g.pad_counts[:3])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for mb in ("1", "4096"):          # (STAGE_MIN 0: sliced, the ordinary numpy memory of the caller goes through the entry's staging threads)
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_HOST_SLICE_MB=mb, TKAMD_STAGE_MIN_MB="0"), capture_output=True, text=True, timeout=600)
+    for mb in ("1", "4096"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_HOST_SLICE_MB=mb), capture_output=True, text=True, timeout=600)
         assert "SLICED_OK" in r.stdout, r.stdout + r.stderr
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
@@ -1139,7 +1139,7 @@ def test_a_malformed_csr_through_the_sliced_host_entry_is_refused_on_the_host():
         "got = tk.encode_packed(buf, off)\n"
         "assert np.array_equal(got.ids, want[0]) and np.array_equal(got.tok_offsets, want[1])\n"
         "print('SLICED_CSR_OK')\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), slice_kb)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_TEST_HOOKS="1", TKAMD_HOST_SLICE_KB=str(slice_kb), TKAMD_STAGE_MIN_MB="0"), capture_output=True, text=True, timeout=900)      # (STAGE_MIN 0: the pageable caller text is staged by the entry's helper threads, at any size)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, TKAMD_TEST_HOOKS="1", TKAMD_HOST_SLICE_KB=str(slice_kb)), capture_output=True, text=True, timeout=900)
     assert "SLICED_CSR_OK" in r.stdout, r.stdout + r.stderr
 
 

@@ -338,62 +338,6 @@ static void pinned_put(PinnedBlock b) {
     g_pin_free.push_back(b);
 }
 
-// Page-locked blocks the library has handed out (tkamd_pinned_alloc): a caller buffer inside one of them goes to the device as it is.
-static std::vector<std::pair<const uint8_t*, size_t>> g_pin_user;       // (under g_pin_mu)
-static bool is_page_locked(const void* p) {
-    {
-        std::lock_guard<std::mutex> lk(g_pin_mu);
-        for (const auto& b : g_pin_user)
-            if ((const uint8_t*)p >= b.first && (const uint8_t*)p < b.first + b.second) return true;
-    }
-    hipPointerAttribute_t a{};
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // (older runtimes: an error for ordinary memory)
-    return a.type == hipMemoryTypeHost;
-}
-
-// Ordinary (pageable) caller text: the runtime would stage it through its own bounce buffers on the CALLING thread, one copy engine's
-// worth of memcpy (5.9 ms per 120 MB batch against 3.1 from page-locked memory).  The host entry stages it itself --
-// helper threads copy it stripe by stripe into a page-locked block of the pool and announce every finished stripe, and the entry's
-// slices wait for their bytes exactly as they wait for a caller that is still packing (tkamd_encode_batch_paced) -- so the staging
-// copy runs on several cores and behind the H2D copies and kernels of the slices before it.
-struct PageableStager {
-    PinnedBlock blk;
-    int64_t ready = 0;
-    std::vector<std::thread> th;
-    std::vector<int> done;
-    const uint8_t* src = nullptr;
-    int64_t n = 0, stripe = 0;
-    int nh = 0, n_stripes = 0;
-    tkamd_pace pace{};
-    PageableStager(const uint8_t* text, int64_t n_bytes) : src(text), n(n_bytes) {
-        blk = pinned_get((size_t)n_bytes + TKAMD_TEXT_PAD);
-        static const int threads = [] {
-            const char* e = getenv("TKAMD_STAGE_THREADS");
-            const int hw = (int)std::thread::hardware_concurrency();
-            return std::max(1, std::min(e ? atoi(e) : 8, hw > 1 ? hw - 1 : 1));
-        }();
-        nh = threads;
-        stripe = (int64_t)4 << 20;
-        n_stripes = (int)((n + stripe - 1) / stripe);
-        done.assign((size_t)n_stripes, 0);
-        memset((uint8_t*)blk.p + n, 0, TKAMD_TEXT_PAD);
-        pace.ready_bytes = &ready;
-        for (int h = 0; h < nh; ++h) th.emplace_back([this, h] { run(h); });
-    }
-    void run(int h) {
-        for (int s = 0; s < n_stripes; ++s) {
-            const int64_t a = (int64_t)s * stripe, b = std::min(n, a + stripe);
-            const int64_t lo = a + (b - a) * h / nh, hi = a + (b - a) * (h + 1) / nh;
-            if (hi > lo) memcpy((uint8_t*)blk.p + lo, src + lo, (size_t)(hi - lo));
-            if (__atomic_add_fetch(&done[(size_t)s], 1, __ATOMIC_ACQ_REL) == nh) __atomic_store_n(&ready, b, __ATOMIC_RELEASE);
-        }
-    }
-    ~PageableStager() {
-        for (std::thread& t : th) t.join();               // (the helpers never wait for anything: they always finish)
-        pinned_put(blk);
-    }
-};
-
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
     PinnedBlock ids, ids16, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs, enc_parts;
@@ -2520,14 +2464,6 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             wait_ready(n_bytes, n_bytes);                        // (the shards' workers read the whole text: no pacing across devices yet)
             return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
         }
-        // ordinary caller memory, a batch worth slicing: staged by helper threads behind the slices in front (PageableStager)
-        std::unique_ptr<PageableStager> stager;
-        static const int64_t stage_min = [] { const char* e = getenv("TKAMD_STAGE_MIN_MB"); return (int64_t)std::max(0, e ? atoi(e) : 8) << 20; }();
-        if (!pace && n_slices > 1 && n_bytes >= stage_min && !is_page_locked(text)) {
-            stager.reset(new PageableStager(text, n_bytes));
-            text = (const uint8_t*)stager->blk.p;
-            pace = &stager->pace;
-        }
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)
         std::vector<int64_t> cut(n_slices + 1, 0);                     // in sequences
@@ -3001,22 +2937,12 @@ int tkamd_pinned_alloc(size_t bytes, void** out) {
         void* p = nullptr;
         note_hip_used();
         HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 64, hipHostMallocPortable));
-        {
-            std::lock_guard<std::mutex> lk(g_pin_mu);
-            g_pin_user.emplace_back((const uint8_t*)p, bytes ? bytes : 64);
-        }
         *out = p;
         return TKAMD_OK;
     });
 }
 void tkamd_pinned_free(void* p) {
-    if (!p) return;
-    {
-        std::lock_guard<std::mutex> lk(g_pin_mu);
-        for (size_t i = 0; i < g_pin_user.size(); ++i)
-            if (g_pin_user[i].first == (const uint8_t*)p) { g_pin_user.erase(g_pin_user.begin() + (long)i); break; }
-    }
-    if (!g_forked) (void)hipHostFree(p);
+    if (p && !g_forked) (void)hipHostFree(p);
 }
 
 int tkamd_debug_phases(tkamd_tokenizer* t, int which, uint64_t* out, int reset) {
