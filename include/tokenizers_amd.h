@@ -173,6 +173,20 @@ int tkamd_encode_batch(tkamd_tokenizer* tok, const uint8_t* text, const int64_t*
 int tkamd_encode_batch_words(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* word_offsets, int64_t n_words,
                              const int64_t* seq_offsets, int64_t n_seqs, uint32_t flags, tkamd_batch** out);
 
+/* One call for a Vec<EncodeInput> that mixes EncodeInput::Single and EncodeInput::Dual items (tokenizer/mod.rs:225-290; encode_batch
+ * maps `encode` over them, :1337-1356, and pads the lot together, utils/padding.rs:50-81).  The sequences of the batch are laid out as
+ * for tkamd_encode_batch (seq_offsets == NULL: `text` + doc_offsets[n_docs + 1], a sequence is a document) or as for
+ * tkamd_encode_batch_words (seq_offsets[n_seqs + 1] over the words word_offsets = doc_offsets[n_docs + 1]); input i is the sequences
+ * [input_offsets[i], input_offsets[i + 1]): one -- a single sequence -- or two -- sequence A and B of a pair.  Every input is cut,
+ * laid out by the post-processor's template of ITS kind (n_added_tokens(is_pair) taken off max_length, mod.rs:1270-1284) and the batch
+ * is padded as one (BatchLongest over every input).  TKAMD_PAIRS must not be set.  The result holds one encoding per input (plus the
+ * overflowing ones with TKAMD_WANT_OVERFLOW; tkamd_batch_encoding_parts then gives (window, 0) for a single sequence); type ids and
+ * sequence ids are written for every token.  A batch that turns out to hold one kind only is handed to the entry of that kind; a
+ * mixed one runs as one slice on devices[0].  TKAMD_ERR_INVALID for an input of no or more than two sequences. */
+int tkamd_encode_batch_mixed(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
+                             const int64_t* seq_offsets, int64_t n_seqs, const int64_t* input_offsets, int64_t n_inputs,
+                             uint32_t flags, tkamd_batch** out);
+
 /* tkamd_encode_batch for a caller that is still FILLING `text` while the call runs.  The reference's Python binding turns every
  * input into an owned Rust String first and encodes afterwards (bindings/python/src/tokenizer.rs:1312-1338: the extraction loop,
  * then py.allow_threads around encode_batch); a binding of this library packs its strings into one buffer anyway -- with this entry

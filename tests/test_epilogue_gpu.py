@@ -411,3 +411,103 @@ def test_batches_mixing_single_sequences_and_pairs_match_the_wheel_live(ref_toke
             ref.encode_special_tokens = tok.encode_special_tokens = True
             sp = [mixed[0] + " [SEP] x", (mixed[1][0], "[CLS] " + mixed[1][1]), "<|end_of_text|>"]
             assert [deep(e) for e in ref.encode_batch(sp)] == [deep(g) for g in tok.encode_batch(sp)], (name, trunc, pad)
+
+
+def _mixed_cases():
+    with gzip.open(os.path.join(GOLD, "mixed_vectors.json.gz"), "rt", encoding="utf-8") as fh:
+        return json.load(fh)["cases"]
+
+
+MIXED_CASES = _mixed_cases()
+
+
+def _mixed_tokenizer(c):
+    import tokenizers_amd as ta
+    d = json.loads(load_tokenizer_json(c["tokenizer"]))
+    if c["post_processor"] == "none":
+        d["post_processor"] = None
+    elif c["post_processor"] is not None:
+        d["post_processor"] = c["post_processor"]
+    d["truncation"], d["padding"] = c["truncation"], c["padding"]
+    return ta.Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=0)
+
+
+@pytest.mark.parametrize("k", range(len(MIXED_CASES)))
+def test_mixed_batches_match_wheel(k):
+    """A Vec<EncodeInput> that mixes EncodeInput::Single and ::Dual items (tokenizer/mod.rs:225-290, 1337-1356) through ONE C-ABI call
+    (tkamd_encode_batch_mixed): every input cut with the special tokens of its own kind taken off max_length (mod.rs:1270-1284), laid
+    out by the template of its kind (Bert / Roberta / TemplateProcessing with typed pieces and B first / none), padded as one batch
+    (utils/padding.rs:50-81) -- every field of every encoding, the overflowing ones and their nested lists, raw and pre-tokenized,
+    against the wheel (oracle/make_golden_mixed.py)."""
+    c = MIXED_CASES[k]
+    tok = _mixed_tokenizer(c)
+    inputs = [tuple(x) if kind else x for x, kind in zip(c["inputs"], c["kinds"])]
+    pp = c["post_processor"]
+    ctx0 = (c["tokenizer"], pp if isinstance(pp, str) or pp is None else pp["type"], c["truncation"], c["padding"], c["add_special_tokens"], c["is_pretokenized"])
+    if c["error"]:
+        # (a batch may hold an input that trips the stride assert -- a panic in the reference -- AND one whose truncation is an Err: the
+        # wheel then reports the panic, this library the error; either names a real failure of the batch)
+        with pytest.raises(ValueError, match="stride. must be strictly less|Truncation error" if c["error"] == "stride" else c["error"][:40]):
+            tok.encode_batch(inputs, add_special_tokens=c["add_special_tokens"], is_pretokenized=c["is_pretokenized"])
+        return
+    be = tok.encode_batch(inputs, add_special_tokens=c["add_special_tokens"], is_pretokenized=c["is_pretokenized"])
+    assert be.kinds is not None and be.kinds.tolist() == c["kinds"]            # (one call: the batch came back as one result)
+    assert len(be) == len(inputs) and be.n_encodings == sum(len(x) for x in c["encodings"]), ctx0
+    for i, want in enumerate(c["encodings"]):
+        got = [be[i]] + be[i].overflowing
+        ctx = ctx0 + (inputs[i],)
+        assert len(got) == len(want), ctx
+        assert be[i].n_sequences == 1 + c["kinds"][i], ctx
+        for q, (e, w) in enumerate(zip(got, want)):
+            assert e.ids == w["ids"], ctx
+            assert e.type_ids == w["type_ids"], ctx
+            assert e.attention_mask == w["attention_mask"], ctx
+            assert e.special_tokens_mask == w["special_tokens_mask"], ctx
+            assert [list(x) for x in e.offsets] == w["offsets_char"], ctx
+            assert e.word_ids == w["words"], ctx
+            assert e.sequence_ids == w["sequence_ids"], ctx
+            assert e.tokens == w["tokens"], ctx
+            if q:
+                assert [o.ids for o in e.overflowing] == w["nested"], ctx
+    fast = tok.encode_batch_fast(inputs, add_special_tokens=c["add_special_tokens"], is_pretokenized=c["is_pretokenized"])
+    assert [fast[i].ids for i in range(len(fast))] == [x[0]["ids"] for x in c["encodings"]]
+
+
+def test_mixed_entry_through_the_c_abi():
+    """tkamd_encode_batch_mixed itself: an input of no or three sequences, a CSR that does not cover the sequences and TKAMD_PAIRS next to it
+    are TKAMD_ERR_INVALID; a batch that holds one kind after all equals the entry of that kind."""
+    import ctypes as C
+    import numpy as np
+    import tokenizers_amd as ta
+    from tokenizers_amd import _lib
+    tok = ta.Tokenizer.from_str(load_tokenizer_json("bert_wordpiece_4000_specials"), device=0)
+    docs = ["hello world", "a b c", "the quick brown fox", "", "x", "jumps over"]
+    buf, off = ta.pack_documents(docs)
+    L = tok._lib
+
+    def call(inp, flags=_lib.ADD_SPECIAL):
+        inp = np.asarray(inp, dtype=np.int64)
+        b = C.c_void_p()
+        rc = L.tkamd_encode_batch_mixed(tok._h, buf.ctypes.data, off.ctypes.data, len(docs), None, -1, inp.ctypes.data, len(inp) - 1, flags, C.byref(b))
+        if rc != 0:
+            return rc, None
+        n, nt = L.tkamd_batch_n_docs(b), L.tkamd_batch_n_tokens(b)
+        ids = np.ctypeslib.as_array((C.c_uint32 * max(nt, 1)).from_address(L.tkamd_batch_ids(b)))[:nt].copy()
+        to = np.ctypeslib.as_array((C.c_int64 * (n + 1)).from_address(L.tkamd_batch_tok_offsets(b))).copy()
+        L.tkamd_batch_free(b)
+        return rc, (ids.tolist(), to.tolist())
+
+    assert call([0, 1, 4, 6])[0] == _lib.ERR_INVALID                      # three sequences in one input
+    assert call([0, 1, 1, 6])[0] == _lib.ERR_INVALID                      # none
+    assert call([0, 2, 4])[0] == _lib.ERR_INVALID                         # does not cover the six sequences
+    assert call([0, 1, 3, 4, 6], _lib.ADD_SPECIAL | _lib.PAIRS)[0] == _lib.ERR_INVALID
+    singles = tok.encode_batch_csr(docs, add_special_tokens=True)
+    rc, got = call(list(range(7)))
+    assert rc == 0 and got == (singles.ids.tolist(), singles.tok_offsets.tolist())
+    pairs = tok.encode_batch_csr([(docs[0], docs[1]), (docs[2], docs[3]), (docs[4], docs[5])], add_special_tokens=True)
+    rc, got = call([0, 2, 4, 6])
+    assert rc == 0 and got == (pairs.ids.tolist(), pairs.tok_offsets.tolist())
+    rc, got = call([0, 1, 3, 4, 6])                                       # single, pair, single, pair
+    assert rc == 0
+    want = [singles[0].ids, tok.encode_batch([(docs[1], docs[2])])[0].ids, singles[3].ids, pairs[2].ids]
+    assert got[0] == [t for e in want for t in e] and got[1] == np.cumsum([0] + [len(e) for e in want]).tolist()

@@ -3,6 +3,7 @@
    (b) the CPU oracle (oracle/oracle.c) on fresh seeded inputs,
    (c) the reference wheel itself when it is importable on the box,
    (d) size-independent properties at BASELINE.json's full size (1M lines)."""
+import json
 import os
 
 import numpy as np
@@ -1203,3 +1204,27 @@ def test_one_added_content_listed_twice_follows_the_tree():
             assert e.ids == list(exp.doc_ids(i)), (name, added, docs[i])
             assert [tuple(x) for x in e.offsets] == [tuple(x) for x in exp.doc_offsets(i)], (name, added, docs[i])
             assert [w for w in e.word_ids] == list(exp.doc_words(i)), (name, added, docs[i])
+
+
+@pytest.mark.parametrize("name,special", [("bert_wordpiece_4000_specials", "[SEP]"), ("llama3_small_6000_specials", "<|end_of_text|>"),
+                                          ("gpt2_added_tokens", None)])
+def test_match_masks_stay_clean_between_batches(name, special, ref_tokenizers):
+    """The four added-token match masks are zeroed only when the scatter before them set a bit (capi.cpp scatter_masks, w_mask_dirty):
+    ONE handle sees a long batch full of special tokens, a short one without any, a short one with them at other places, an empty one and
+    the long one again -- every batch equals the wheel's (ids, offsets, word ids), so no bit of an earlier batch survives into a later
+    one and none is missing.  (AddedVocabulary::extract_and_normalize, added_vocabulary.rs:430-564.)"""
+    import tokenizers_amd as ta
+    from oracle import synth
+    js = load_tokenizer_json(name)
+    ref, tok = ref_tokenizers.Tokenizer.from_str(js), ta.Tokenizer.from_str(js, device=0)
+    if special is None:                                      # (a fixture with added tokens of its own: take one of its contents)
+        special = json.loads(js)["added_tokens"][-1]["content"]
+    plain = [d for d in synth.gen_lines(N(400), text_seed=61) if "[" not in d and "<" not in d]
+    long_with = [d[:len(d) // 2] + special + d[len(d) // 2:] + (" " + special if i % 3 == 0 else "") for i, d in enumerate(plain)]
+    short_plain = plain[:7]
+    short_with = [special + plain[0], plain[1], plain[2] + special + special, special]
+    fields = lambda e: (e.ids, [tuple(o) for o in e.offsets], e.word_ids)
+    for batch in (long_with, short_plain, short_with, ["", ""], short_plain[:2], long_with, plain):
+        exp = ref.encode_batch(batch, add_special_tokens=False)
+        got = tok.encode_batch(batch, add_special_tokens=False)
+        assert [fields(e) for e in exp] == [fields(got[i]) for i in range(len(got))], (name, batch[:2])

@@ -32,7 +32,7 @@ MAX_STAGES = 24
 # every symbol include/tokenizers_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "tkamd_tokenizer_from_json", "tkamd_tokenizer_free", "tkamd_tokenizer_info", "tkamd_last_error",
-    "tkamd_encode_batch", "tkamd_encode_batch_words", "tkamd_encode_batch_words_device", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
+    "tkamd_encode_batch", "tkamd_encode_batch_mixed", "tkamd_encode_batch_words", "tkamd_encode_batch_words_device", "tkamd_batch_n_docs", "tkamd_batch_n_tokens", "tkamd_batch_ids",
     "tkamd_batch_tok_offsets", "tkamd_batch_offsets", "tkamd_batch_word_ids", "tkamd_batch_pad_counts", "tkamd_batch_type_ids", "tkamd_batch_sequence_ids", "tkamd_batch_free",
     "tkamd_encode_batch_device", "tkamd_device_sync", "tkamd_profile_enable", "tkamd_profile_read",
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version", "tkamd_word_cache",
@@ -116,6 +116,8 @@ def load() -> C.CDLL:
     lib.tkamd_encode_batch.restype = i32
     lib.tkamd_encode_batch_words.argtypes = [vp, vp, vp, i64, vp, i64, u32, C.POINTER(vp)]
     lib.tkamd_encode_batch_words.restype = i32
+    lib.tkamd_encode_batch_mixed.argtypes = [vp, vp, vp, i64, vp, i64, vp, i64, u32, C.POINTER(vp)]
+    lib.tkamd_encode_batch_mixed.restype = i32
     lib.tkamd_encode_batch_words_device.argtypes = [vp, vp, vp, i64, i64, vp, i64, u32, vp, C.POINTER(DeviceResult)]
     lib.tkamd_encode_batch_words_device.restype = i32
     for name, rt in (("tkamd_batch_n_docs", i64), ("tkamd_batch_n_tokens", i64), ("tkamd_batch_ids", vp),

@@ -206,7 +206,7 @@ struct Workspace {
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask, w_boundmask, w_bprefix, w_seg_off, w_xseg_off,
         w_match_docs, w_match_list;
     // host entry staging
-    DevBuf h_text, h_doc_off, h_seq_off;
+    DevBuf h_text, h_doc_off, h_seq_off, h_inp_off;
     DevBuf w_trim1;                              // per token: process_offsets took one leading space off it (MetaArgs::trim1)
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
@@ -223,6 +223,10 @@ struct Workspace {
     const int64_t* last_doc_off = nullptr;
     const int64_t* last_seq_off = nullptr;      // is_pretokenized call: the sequence CSR (else null)
     int64_t last_n_seqs = -1;
+    const int64_t* last_inp_off = nullptr;      // mixed call: the inputs' CSR over the sequences (else null)
+    int64_t last_n_inputs = -1;
+    DevBuf w_inp_off;                           // ... its validated copy
+    DevBuf w_mask_dirty;                        // one word: the four added-token match masks may hold bits (run_pipeline scatter_masks)
     int64_t last_n_bytes = 0;
     uint32_t last_flags = 0;
     tkamd_device_result last_result{};
@@ -261,6 +265,7 @@ struct tkamd_tokenizer {
     DevBuf t_shortw, t_shortw_k3, t_shortw_disp;   // the short-word table: 16-byte slots, key bytes 12..15, eight-bit displacements (tables.hpp SHORTW_*)
     DevBuf t_char_id;            // BPE over characters: HostModel::char_id
     DevBuf t_at_id[2], t_at_flags[2], t_at_blob[2], t_at_off[2], t_at_first[2];   // AddedVocabulary patterns of the two matching passes
+    DevBuf t_pp_single, t_pp_single_plain;      // the single layout as pieces (the single inputs of a mixed batch)
     DevBuf t_pp_pair, t_pp_pair_plain;   // pair template of the post-processor with / without its special tokens: [pieces][3]
     DevBuf t_pp_prefix, t_pp_suffix, t_pp_prefix_ty, t_pp_suffix_ty, t_bn1, t_bn2, t_bn_map, t_merge_disp, t_dec_entry, t_dec_blob, t_trie;
     int n_cu = 256;
@@ -427,6 +432,12 @@ void upload_tables(tkamd_tokenizer* t) {
         tpl.clear();
         for (const HostModel::TplPiece& q : hm.pp_pair_plain) { tpl.push_back(q.kind); tpl.push_back(q.id); tpl.push_back(q.type_id); }
         upload(t->t_pp_pair_plain, tpl);
+        tpl.clear();
+        for (const HostModel::TplPiece& q : hm.pp_single) { tpl.push_back(q.kind); tpl.push_back(q.id); tpl.push_back(q.type_id); }
+        upload(t->t_pp_single, tpl);
+        tpl.clear();
+        for (const HostModel::TplPiece& q : hm.pp_single_plain) { tpl.push_back(q.kind); tpl.push_back(q.id); tpl.push_back(q.type_id); }
+        upload(t->t_pp_single_plain, tpl);
     }
     upload(t->t_pp_prefix, hm.pp_prefix);
     upload(t->t_pp_suffix, hm.pp_suffix);
@@ -551,8 +562,11 @@ void build_shortw_table(tkamd_tokenizer* t) {
     std::vector<const WordSlot*> ws;
     for (const WordSlot& w : hm.word_table)
         if (w.len) ws.push_back(&w);
+    // the first size tried: the power of two at or above `x10 / 10` slots a word (TKAMD_SHORTW_X10, an A/B knob; 25 = two and a half --
+    // a fuller table is fewer lines for the caches to hold and more displacements to try; a size that cannot be placed doubles below)
+    static const size_t x10 = [] { const char* e = getenv("TKAMD_SHORTW_X10"); return (size_t)std::max(11, e ? atoi(e) : 25); }();
     uint32_t cap = 16;
-    while (cap < ws.size() * 5 / 2) cap <<= 1;
+    while (cap < ws.size() * x10 / 10) cap <<= 1;
     std::vector<uint32_t> h1(ws.size()), km(ws.size()), where(ws.size());
     for (size_t i = 0; i < ws.size(); ++i) {
         h1[i] = word_hash1(ws[i]->lo, ws[i]->hi, ws[i]->len, hm.word_seed);
@@ -731,11 +745,18 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
 // device (x_len_dev); kernels are launched over the host-side bound n_x and read the effective length.
 // d_seq_off / n_seqs: is_pretokenized inputs (InputSequence::PreTokenized, tokenizer/mod.rs:782-795) -- the documents are the WORDS and
 // sequence s is the words [d_seq_off[s], d_seq_off[s + 1]); n_seqs < 0: plain documents.
+// d_inp_off / n_inputs: a Vec<EncodeInput> that mixes Single and Dual items (tokenizer/mod.rs:225-290, 1337-1356) -- input i is the
+// sequences (documents, or sequences of words) [d_inp_off[i], d_inp_off[i + 1]), one or two of them; n_inputs < 0: one kind, per flags.
 void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const int64_t* d_doc_off, int64_t n_docs, int64_t n_bytes,
-                  const int64_t* d_seq_off, int64_t n_seqs, uint32_t flags, hipStream_t st, tkamd_device_result* out) {
+                  const int64_t* d_seq_off, int64_t n_seqs, uint32_t flags, hipStream_t st, tkamd_device_result* out,
+                  const int64_t* d_inp_off = nullptr, int64_t n_inputs = -1) {
     HostModel& hm = t->hm;
     const int64_t* const d_doc_off_in = d_doc_off;         // as the caller passed them (the pipeline below works on validated copies)
     const int64_t* const d_seq_off_in = d_seq_off;
+    const int64_t* const d_inp_off_in = d_inp_off;
+    const bool mixed = n_inputs >= 0;
+    if (mixed && (flags & TKAMD_PAIRS)) throw Invalid("a mixed batch names the kind of every input itself: TKAMD_PAIRS must not be set");
+    if (mixed && !d_inp_off) throw Invalid("null input offsets");
     bool rerun = false;                                    // set by the overflow epilogue: a work queue was too small, run the batch again
     const uint32_t off_mode = flags & TKAMD_OFFSETS_MASK;
     const bool want_words = (flags & TKAMD_WANT_WORD_IDS) != 0;
@@ -744,6 +765,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     const bool add_special = (flags & TKAMD_ADD_SPECIAL) != 0 && !(hm.pp_prefix.empty() && hm.pp_suffix.empty());
     if ((flags & TKAMD_ADD_SPECIAL) && !(flags & TKAMD_PAIRS) && !hm.pp_unsupported.empty()) throw Unsupported("add_special_tokens: " + hm.pp_unsupported);
     if (!(flags & TKAMD_PAIRS) && hm.pp_single_refused) throw Unsupported("post_processor: " + hm.pp_unsupported);
+    if (mixed && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
     const bool prefix_space = hm.byte_level && hm.add_prefix_space;
     // host-side bound of the X text length: +1 per document for the virtual space; BertNormalizer can grow a
     // character (CJK spacing: 3 -> 5 bytes, NFD/lowercase expansions <= 3x) -- 3x the input covers every case
@@ -782,6 +804,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default, TKAMD_CLAIMS=0 switches them off
     // for A/B runs; the word cache -- tkamd_word_cache, across batches -- takes their place when it is switched on).
     static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
+    // A text made on the device (the normaliser's) has its length there; its masks and prefix counts are launched over the host's bound.
+    // TKAMD_LEN_BOUND=0 (A/B): every word of the bound is zeroed / written / scanned, as up to round 4.
+    static const bool len_bound = [] { const char* e = getenv("TKAMD_LEN_BOUND"); return !(e && !strcmp(e, "0")); }();
     bool use_claims = claims_on && !t->word_cache &&
                       (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
     if (use_claims) {                                      // paused by an earlier batch that shared nothing (read_scalars)? one batch less to go
@@ -795,7 +820,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     {
         ZeroRegions z{};
         z.add(sc, SC_SLOTS * 8);
-        z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
+        // (behind BertNormalizer the mask covers the bound of the normalised text, three times the input: the words that text really has
+        // are zeroed behind the normaliser, next to the slack of the text -- launch_zero_tail below)
+        if (!(len_bound && hm.norm == NORM_BERT)) z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
         z.add(w->w_cstate.p, cstate_bytes);
         if (t->lu_fused) {                                 // the fused pass's look-back state: 8 bytes per 16 KB tile of text
@@ -833,6 +860,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_n_encodings = nullptr;
     w->last_seq_off = d_seq_off;
     w->last_n_seqs = n_seqs;
+    w->last_inp_off = d_inp_off;
+    w->last_n_inputs = n_inputs;
     // the caller's CSR is validated once; everything below reads the validated copy
     w->w_doc_off.reserve((size_t)(n_docs + 2) * 8);
     // The plain GPT-2 path (no added tokens, no normalizer, no prefix space: BASELINE configs[1] / [4]) reads the document CSR in two
@@ -863,6 +892,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     const int64_t* const e_tok_off = words_in ? w->w_seq_tok_off.as<int64_t>() : w->w_tok_offsets.as<int64_t>();
     const int64_t e_n = words_in ? n_seqs : n_docs;
+    if (mixed) {
+        w->w_inp_off.reserve((size_t)(n_inputs + 2) * 8);
+        launch_validate_csr(st, d_inp_off, n_inputs, e_n, d_err, w->w_inp_off.as<int64_t>());      // a CSR over [0, sequences]
+        d_inp_off = w->w_inp_off.as<int64_t>();
+    }
     auto add_specials = [&]() {
         // PostProcessor::process for a single sequence (processors/bert.rs:51-120, template.rs:544-590): specials around every document
         const size_t T2 = (size_t)n_x + 4 + (size_t)(e_n + 1) * (hm.pp_prefix.size() + hm.pp_suffix.size());
@@ -898,8 +932,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_pad_counts = nullptr;
     out->d_type_ids = nullptr;
     out->d_seq_ids = nullptr;
-    const bool pairs = (flags & TKAMD_PAIRS) != 0;
-    if (pairs && (e_n & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
+    const bool pairs = (flags & TKAMD_PAIRS) != 0 || mixed;       // (a mixed batch: the pair epilogue lays out both kinds of input)
+    if (pairs && !mixed && (e_n & 1)) throw Invalid("TKAMD_PAIRS: an odd number of documents");
     if (pairs && (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair_unsupported.empty()) throw Unsupported("add_special_tokens on a pair: " + hm.pp_pair_unsupported);
     const bool typed_single = !pairs && hm.pp_single_typed;          // the single template's type ids: written by the epilogue, with or without special tokens
     const bool epilogue = hm.trunc_on || hm.pad_on || pairs || typed_single;
@@ -909,18 +943,25 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     out->d_enc_parts = nullptr;
     auto finalize_pairs = [&]() {
         // EncodeInput::Dual: the two sequences of a pair were encoded as two documents; cut, lay out and pad them together
-        const int64_t n_pairs = e_n / 2;
+        const int64_t n_pairs = mixed ? n_inputs : e_n / 2;
         const bool tpl_on = (flags & TKAMD_ADD_SPECIAL) && !hm.pp_pair.empty();
         uint32_t n_special = 0;
         if (tpl_on) for (const HostModel::TplPiece& q : hm.pp_pair) n_special += q.kind == 2u;
         PairArgs pa{};
         pa.tok_offsets = e_tok_off;
         pa.n_pairs = n_pairs;
+        if (mixed) {
+            pa.inp_off = d_inp_off;
+            pa.tpl1 = add_special ? t->t_pp_single.as<uint32_t>() : t->t_pp_single_plain.as<uint32_t>();
+            pa.n_tpl1 = add_special ? (int32_t)hm.pp_single.size() : (int32_t)hm.pp_single_plain.size();
+            pa.n_special1 = add_special ? (uint32_t)(hm.pp_prefix.size() + hm.pp_suffix.size()) : 0u;
+        }
+        const uint32_t n_special_max = std::max(n_special, pa.n_special1);      // (the bound of the output's size)
         pa.ids = w->w_ids.as<uint32_t>();
         pa.offsets = out->d_offsets;
         pa.word_ids = out->d_word_ids;
         pa.trim1 = pa.offsets ? w->cur_trim1 : nullptr;
-        w->w_keep.reserve((size_t)(e_n + 2) * 4);
+        w->w_keep.reserve((size_t)(std::max(e_n, 2 * n_pairs) + 2) * 4);
         pa.tpl = tpl_on ? t->t_pp_pair.as<uint32_t>() : t->t_pp_pair_plain.as<uint32_t>();
         pa.n_tpl = tpl_on ? (int32_t)hm.pp_pair.size() : (int32_t)hm.pp_pair_plain.size();
         pa.n_special = n_special;
@@ -1005,7 +1046,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         fa.n_docs = n_enc;
         fa.len1 = pa.len1; fa.fin = pa.fin; fa.bsum = pa.bsum; fa.target = pa.target; fa.tok_offsets2 = pa.tok_offsets2; fa.n_tok2 = pa.n_tok2;
         fa.pad_on = pa.pad_on; fa.pad_fixed = pa.pad_fixed; fa.pad_length = pa.pad_length; fa.pad_multiple = pa.pad_multiple;
-        size_t T2 = (size_t)n_x + 4 + (size_t)(n_pairs + 1) * n_special;
+        size_t T2 = (size_t)n_x + 4 + (size_t)(n_pairs + 1) * n_special_max;
         if (overflow) {
             launch_final_offsets(st, fa);
             int64_t total = 0;
@@ -1224,7 +1265,13 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (have_added) {
         seg_cap = (size_t)n_docs + 2 * (size_t)mcap + 2;
         DevBuf* masks[6] = {&w->w_candmask, &w->w_matchmask, &w->w_spanmask, &w->w_stopmask, &w->w_hardmask, &w->w_boundmask};
-        for (DevBuf* b : masks) b->reserve(WX * 8);
+        bool grew = !w->w_mask_dirty.p;
+        for (DevBuf* b : masks) { const size_t before = b->cap; b->reserve(WX * 8); grew = grew || b->cap != before; }
+        // The four match masks are kept CLEAN between their uses: k_scatter_matches leaves "bits were set" in w_mask_dirty, and the zeroing
+        // in front of the next scatter runs only then (natural text holds no special token: 240 MB of zeroing per C3 step went this way).
+        // Fresh allocations hold anything: flagged dirty.
+        w->w_mask_dirty.reserve(16);
+        if (grew) HIP_CHECK(hipMemsetAsync(w->w_mask_dirty.p, 1, 4, st));
         w->w_match_docs.reserve((seg_cap + 1) * 4);
         w->w_match_list.reserve(((size_t)mcap + 4) * 16);
         mlist = w->w_match_list.as<uint32_t>();
@@ -1245,11 +1292,16 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         ull* m4[4] = {w->w_matchmask.as<ull>(), w->w_spanmask.as<ull>(), w->w_stopmask.as<ull>(), w->w_hardmask.as<ull>()};
         // (one launch for the four; over the RAW text -- no device-side length -- only the words that text has: the masks are sized for the
         // normalised text's bound, three times that.  Over a text with a device-side length the kernels downstream run over the bound.)
+        static const bool lazy = [] { const char* e = getenv("TKAMD_MASK_LAZY_ZERO"); return !(e && !strcmp(e, "0")); }();      // (A/B: 0 = zero them every time)
         const size_t zero_bytes = len_dev ? WX * 8 : std::min(WX, (size_t)(n_text >> 6) + 2) * 8;
         ZeroRegions z{};
-        for (ull* m : m4) z.add(m, zero_bytes);
+        // (lazily: the WHOLE buffers -- the bits may be an earlier, larger batch's)
+        const size_t cap4[4] = {w->w_matchmask.cap, w->w_spanmask.cap, w->w_stopmask.cap, w->w_hardmask.cap};
+        for (int q = 0; q < 4; ++q) z.add(m4[q], lazy ? (cap4[q] & ~(size_t)15) : zero_bytes);
+        if (lazy) z.only_if = w->w_mask_dirty.as<uint32_t>();
         launch_zero_regions(st, t->n_cu * 4, z);
-        launch_scatter_matches(st, mlist, n_match, n_text, len_dev, m4[0], m4[1], m4[2], m4[3], with_end ? w->w_tmp_end.as<uint32_t>() : nullptr);
+        launch_scatter_matches(st, mlist, n_match, n_text, len_dev, m4[0], m4[1], m4[2], m4[3], with_end ? w->w_tmp_end.as<uint32_t>() : nullptr,
+                               lazy ? w->w_mask_dirty.as<uint32_t>() : nullptr);
     };
     // pieces of a text: what lies between document edges and match edges (boundary mask = docmask | hardmask), as an int64 CSR
     auto build_pieces = [&](const int64_t* doc_csr, int64_t n_text, const int64_t* len_dev) -> const int64_t* {
@@ -1287,7 +1339,15 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         // test hook TKAMD_POISON_NTEXT (with TKAMD_TEST_HOOKS=1): the normaliser's output buffer starts every batch as 0xFF, so a kernel that
         // reads it beyond *x_len + TEXT_PAD -- bounded by the host's n_x instead of the device length -- changes a result instead of
         // meeting zeros an earlier batch or the allocator happened to leave (tests/test_parity_gpu.py runs the BertNormalizer fixtures so)
-        else if (test_hook("TKAMD_POISON_NTEXT")) HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0xFF, (size_t)n_x + TKAMD_TEXT_PAD, st));
+        else if (test_hook("TKAMD_POISON_NTEXT")) {
+            HIP_CHECK(hipMemsetAsync(w->w_ntext.p, 0xFF, (size_t)n_x + TKAMD_TEXT_PAD, st));
+            // ... and so do the masks and prefix counts over that text: with TKAMD_LEN_BOUND only the words of its own length are written
+            // (the document mask's are zeroed behind the normaliser), every reader must stop there too
+            if (len_bound) HIP_CHECK(hipMemsetAsync(w->w_docmask.p, 0xFF, w->w_docmask.cap, st));
+            HIP_CHECK(hipMemsetAsync(w->w_startmask.p, 0xFF, w->w_startmask.cap, st));
+            HIP_CHECK(hipMemsetAsync(w->w_wprefix.p, 0xFF, w->w_wprefix.cap, st));
+            if (w->w_endmask.p) HIP_CHECK(hipMemsetAsync(w->w_endmask.p, 0xFF, w->w_endmask.cap, st));
+        }
         if (off_mode != TKAMD_OFFSETS_NONE) {
             w->w_norig.reserve(((size_t)n_x + 4) * 4);
             w->w_norig_e.reserve(((size_t)n_x + 4) * 4);
@@ -1313,7 +1373,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_bert_normalize(st, bt, d_text, n_bytes, d_doc_off, n_docs, verbatim, w->w_keepmask.as<uint8_t>(), w->w_kprefix.as<uint32_t>(),
                               w->w_bsum.as<uint32_t>(), w->w_wbase.as<uint32_t>(), d_xlen, w->w_ntext.as<uint8_t>(), (uint32_t*)norig, (uint32_t*)norig_e,
                               w->w_ndoc_off.as<int64_t>(), d_err);
-        launch_zero_tail(st, w->w_ntext.as<uint8_t>(), d_xlen, TKAMD_TEXT_PAD);
+        launch_zero_tail(st, w->w_ntext.as<uint8_t>(), d_xlen, TKAMD_TEXT_PAD, len_bound ? w->w_docmask.as<ull>() : nullptr, W + 1, t->n_cu * 4);
         pf.end();
         if (have_raw) launch_translate_matches_norm(st, mlist, n_match, w->w_keepmask.as<uint8_t>(), w->w_wbase.as<uint32_t>(), n_bytes, d_xlen);
         x_text = w->w_ntext.as<uint8_t>();
@@ -1405,7 +1465,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             // the bitmasks (k_lookup) and from (start, length) queue entries
             pf.begin("emit_pretok");
             launch_emit_pretok(st, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, w->w_pt_start.as<uint32_t>());
-            if (pt_end) launch_emit_pretok_end(st, w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, pt_end);
+            if (pt_end) launch_emit_pretok_end(st, w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, pt_end);
             pf.end();
         }
         pf.begin("doc_first_pretok");
@@ -1450,7 +1510,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         pf.begin("pretok_local");
         launch_pretok_local(st, (int)hm.pretok, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2,
-                            w->w_startmask.as<ull>(), w->w_endmask.as<ull>());
+                            w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), len_bound);
         pf.end();
     }
     if (matchmask)
@@ -1460,7 +1520,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.begin("mask_scan");
         // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
         // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
-        launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok);
+        launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok, len_bound ? x_len_dev : nullptr);
         pf.end();
         after_masks();
     }
@@ -1762,7 +1822,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     else if (epilogue) finalize();
     else if (add_special) add_specials();
     if (rerun) {
-        run_pipeline(t, w, d_text, d_doc_off_in, n_docs, n_bytes, d_seq_off_in, n_seqs, flags, st, out);
+        run_pipeline(t, w, d_text, d_doc_off_in, n_docs, n_bytes, d_seq_off_in, n_seqs, flags, st, out, d_inp_off_in, n_inputs);
         return;
     }
     w->last_ntok_slot = (add_special || epilogue) ? SC_NTOK2 : SC_NTOK;
@@ -1780,7 +1840,8 @@ int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
         // byte covers the rest (runs of one-byte pre-tokens the vocabulary does not know, e.g. punctuation under WordPiece)
         t->q16_div = t->q16_div > 2 ? 2 : 1;
         tkamd_device_result again{};
-        run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again);
+        run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again,
+                     w->last_inp_off, w->last_n_inputs);
         if (again.d_ids != w->last_result.d_ids || again.d_tok_offsets != w->last_result.d_tok_offsets ||
             again.d_offsets != w->last_result.d_offsets || again.d_word_ids != w->last_result.d_word_ids || again.d_pad_counts != w->last_result.d_pad_counts || again.d_type_ids != w->last_result.d_type_ids ||
             again.d_enc_docs != w->last_result.d_enc_docs) {
@@ -1831,6 +1892,7 @@ int error_from_bits(int bits) {
     if (bits & ERR_TOO_MANY_TOKENS) return set_error(TKAMD_ERR_INVALID, "a truncation leaves more than 2^32 overflowing encodings of one sequence");
     if (bits & ERR_MISSING_UNK) return set_error(TKAMD_ERR_MODEL, "MissingUnkToken: the model needed an unknown token but the vocabulary has none");
     if (bits & ERR_UNK_OOV) return set_error(TKAMD_ERR_MODEL, "UnkTokenOutOfVocabulary: Unk token not found in the vocabulary");
+    if (bits & ERR_INPUT_KIND) return set_error(TKAMD_ERR_INVALID, "input_offsets: every input of a mixed batch is one sequence or two");
     return TKAMD_OK;
 }
 
@@ -2419,8 +2481,11 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
 // directions together, profiles/r4d_link_probe.txt).
 // seq_offsets / n_seqs: is_pretokenized inputs -- the documents are words, sequence s = words [seq_offsets[s], seq_offsets[s + 1]); the
 // slices are then cut between sequences.  n_seqs < 0: plain documents.
+// input_offsets / n_inputs: a batch that mixes single sequences and pairs (tkamd_encode_batch_mixed) -- input i is the sequences
+// [input_offsets[i], input_offsets[i + 1]), one or two; such a batch goes as one slice on one device.  n_inputs < 0: one kind (flags).
 static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
-                       int64_t n_seqs, uint32_t flags, tkamd_batch** out, const tkamd_pace* pace = nullptr) {
+                       int64_t n_seqs, uint32_t flags, tkamd_batch** out, const tkamd_pace* pace = nullptr,
+                       const int64_t* input_offsets = nullptr, int64_t n_inputs = -1) {
     if (!t || !out || !doc_offsets || n_docs < 0) return set_error(TKAMD_ERR_INVALID, "bad argument");
     *out = nullptr;
     if (t->device < 0) return set_error(TKAMD_ERR_DEVICE, "host-only tokenizer handle: no HIP device bound (there is no CPU fallback)");
@@ -2446,6 +2511,15 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         }
         const int64_t n_grp = words_in ? n_seqs : n_docs;              // sequences: what slices and encodings are counted in
         auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
+        const bool mixed = n_inputs >= 0;
+        if (mixed) {
+            if (flags & TKAMD_PAIRS) throw Invalid("a mixed batch names the kind of every input itself: TKAMD_PAIRS must not be set");
+            if (!input_offsets || input_offsets[0] != 0 || input_offsets[n_inputs] != n_grp) throw Invalid("input_offsets is not a CSR over the sequences");
+            for (int64_t i = 0; i < n_inputs; ++i) {
+                const int64_t c = input_offsets[i + 1] - input_offsets[i];
+                if (c < 1 || c > 2) throw Invalid("input_offsets: every input of a mixed batch is one sequence or two");
+            }
+        }
         const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;            // sequences per encoding
         if (n_grp % unit) throw Invalid("TKAMD_PAIRS: an odd number of sequences");
         // (test hook TKAMD_HOST_SLICE_KB: slices small enough for the batches the SIMT emulation can run)
@@ -2458,9 +2532,9 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / slice_bytes);
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
-        if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow) n_slices = 1;
+        if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow || mixed) n_slices = 1;
         // a multi-device handle: one shard per device (what couples the documents of a batch stays on devices[0], like it stays in one slice)
-        if (!t->replicas.empty() && !(t->hm.pad_on && !t->hm.pad_fixed) && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
+        if (!t->replicas.empty() && !mixed && !(t->hm.pad_on && !t->hm.pad_fixed) && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
             wait_ready(n_bytes, n_bytes);                        // (the shards' workers read the whole text: no pacing across devices yet)
             return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
         }
@@ -2474,7 +2548,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             if (words_in) g = std::lower_bound(seq_offsets, seq_offsets + n_seqs, g) - seq_offsets;      // the first sequence starting at or after that word
             cut[k] = std::max<int64_t>(cut[k - 1], g / unit * unit);
         }
-        const int64_t n_enc = n_grp / unit;
+        const int64_t n_enc = mixed ? n_inputs : n_grp / unit;
         HostLease l0(t);
         std::unique_ptr<HostLease> l1(n_slices > 1 ? new HostLease(t) : nullptr);
         Workspace* ws[2] = {l0.w, l1 ? l1->w : l0.w};
@@ -2535,6 +2609,10 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             w->h_text.reserve((size_t)nb + TKAMD_TEXT_PAD);
             w->h_doc_off.reserve((size_t)(d1 - d0 + 1) * 8);
             if (words_in) HIP_CHECK(hipMemcpyAsync(w->h_seq_off.p, seq_offsets + g0, (size_t)(g1 - g0 + 1) * 8, hipMemcpyHostToDevice, cin));
+            if (mixed) {                                         // (one slice: the inputs' CSR as the caller gave it)
+                w->h_inp_off.reserve((size_t)(n_inputs + 1) * 8);
+                HIP_CHECK(hipMemcpyAsync(w->h_inp_off.p, input_offsets, (size_t)(n_inputs + 1) * 8, hipMemcpyHostToDevice, cin));
+            }
             if (nb) HIP_CHECK(hipMemcpyAsync(w->h_text.p, text + b0, (size_t)nb, hipMemcpyHostToDevice, cin));
             HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + d0, (size_t)(d1 - d0 + 1) * 8, hipMemcpyHostToDevice, cin));
             HIP_CHECK(hipEventRecord(w0->ev_in[k & 1], cin));
@@ -2544,7 +2622,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + nb, 0, TKAMD_TEXT_PAD, s));
             if (b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), d1 - d0 + 1, -b0);           // the slice's own CSR starts at 0
             run_pipeline(t, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), d1 - d0, nb, words_in ? w->h_seq_off.as<int64_t>() : nullptr,
-                         words_in ? g1 - g0 : -1, flags, s, &res[k]);
+                         words_in ? g1 - g0 : -1, flags, s, &res[k], mixed ? w->h_inp_off.as<int64_t>() : nullptr, mixed ? n_inputs : -1);
             w->last_text = w->h_text.as<uint8_t>(); w->last_doc_off = w->h_doc_off.as<int64_t>(); w->last_n_bytes = nb; w->last_flags = flags; w->last_result = res[k];
         };
         auto finish = [&](int k) -> int {
@@ -2557,6 +2635,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             const tkamd_device_result& r = res[k];
             const int64_t seen_docs = doc_of(cut[k + 1]);
             int64_t d0 = cut[k] / unit, d1 = cut[k + 1] / unit;            // encodings of this slice
+            if (mixed) d1 = n_inputs;
             if (r.d_enc_docs) {                                            // (one slice) the documents' own encodings + their overflowing ones
                 d0 = 0;
                 d1 = w->last_n_enc;
@@ -2660,6 +2739,25 @@ int tkamd_encode_batch_paced(tkamd_tokenizer* t, const uint8_t* text, const int6
                              const tkamd_pace* pace, tkamd_batch** out) {
     if (pace && !pace->ready_bytes) return set_error(TKAMD_ERR_INVALID, "tkamd_pace without ready_bytes");
     return encode_host(t, text, doc_offsets, n_docs, nullptr, -1, flags, out, pace);
+}
+int tkamd_encode_batch_mixed(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
+                             int64_t n_seqs, const int64_t* input_offsets, int64_t n_inputs, uint32_t flags, tkamd_batch** out) {
+    if (!input_offsets || n_inputs < 0 || (seq_offsets && n_seqs < 0)) return set_error(TKAMD_ERR_INVALID, "bad argument");
+    if (!seq_offsets) n_seqs = -1;
+    // a batch of one kind after all: the entry of that kind (sliced, sharded); the CSR itself is checked by encode_host either way
+    const int64_t n_grp = seq_offsets ? n_seqs : n_docs;
+    if (n_inputs > 0 && input_offsets[0] == 0 && input_offsets[n_inputs] == n_grp && !(flags & TKAMD_PAIRS)) {
+        if (n_grp == n_inputs) {
+            bool ones = true;
+            for (int64_t i = 0; i < n_inputs && ones; ++i) ones = input_offsets[i + 1] - input_offsets[i] == 1;
+            if (ones) return encode_host(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
+        } else if (n_grp == 2 * n_inputs) {
+            bool twos = true;
+            for (int64_t i = 0; i < n_inputs && twos; ++i) twos = input_offsets[i + 1] - input_offsets[i] == 2;
+            if (twos) return encode_host(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags | TKAMD_PAIRS, out);
+        }
+    }
+    return encode_host(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out, nullptr, input_offsets, n_inputs);
 }
 int tkamd_encode_batch_words(tkamd_tokenizer* t, const uint8_t* text, const int64_t* word_offsets, int64_t n_words, const int64_t* seq_offsets,
                              int64_t n_seqs, uint32_t flags, tkamd_batch** out) {

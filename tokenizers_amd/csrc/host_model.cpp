@@ -728,6 +728,10 @@ HostModel HostModel::from_json(const char* json, size_t len) {
             m.pp_unsupported = "post_processor type '" + t + "' is outside the hot path";
         };
         apply(root->get("post_processor"));
+        for (size_t k = 0; k < m.pp_prefix.size(); ++k) m.pp_single.push_back({2u, m.pp_prefix[k], k < m.pp_prefix_ty.size() ? (uint32_t)m.pp_prefix_ty[k] : 0u});
+        m.pp_single.push_back({0u, 0u, m.pp_single_typed ? m.pp_seq_ty : 0u});
+        for (size_t k = 0; k < m.pp_suffix.size(); ++k) m.pp_single.push_back({2u, m.pp_suffix[k], k < m.pp_suffix_ty.size() ? (uint32_t)m.pp_suffix_ty[k] : 0u});
+        m.pp_single_plain = {{0u, 0u, m.pp_single_typed ? m.pp_seq_ty : 0u}};
     }
 
     // ---- added tokens ----

@@ -82,6 +82,9 @@ struct HostModel {
     // the layout of a pair when NO special tokens are added: A : 0, B : 1 by default (bert.rs:56-58 returns the encodings as they are);
     // RobertaProcessing zeroes every type id first (roberta.rs); TemplateProcessing still applies its order and type ids
     std::vector<TplPiece> pp_pair_plain = {{0, 0, 0}, {1, 0, 1}};
+    // the single layout as pieces, for the inputs of a mixed batch that are single sequences (tkamd_encode_batch_mixed: the pair kernels
+    // lay out both kinds): pp_prefix | A | pp_suffix with their type ids, and A alone when no special tokens are added
+    std::vector<TplPiece> pp_single, pp_single_plain;
 
     // truncation / padding of the finished encodings (utils/truncation.rs:70-160, utils/padding.rs:50-85; tokenizer/mod.rs:1265-1317)
     bool trunc_on = false;

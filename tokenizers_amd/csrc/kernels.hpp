@@ -97,6 +97,7 @@ struct ZeroRegions {
     void* p[6];
     unsigned long long n16[6];       // 16-byte words
     int n;
+    const uint32_t* only_if;         // not null: the launch returns at once when this word is zero (the match masks' "may hold bits" flag, capi.cpp scatter_masks)
     void add(void* ptr, size_t bytes) { if (n < 6 && ptr && bytes) { p[n] = ptr; n16[n] = (bytes + 15) / 16; ++n; } }
 };
 struct QueuePlan {
@@ -232,6 +233,14 @@ struct PairArgs {
     const uint32_t* tpl;              // [n_tpl][3] kind (0 A, 1 B, 2 special), id, type id
     int32_t n_tpl;
     uint32_t n_special;               // special tokens of the template (taken off max_length)
+    // A Vec<EncodeInput> that mixes EncodeInput::Single and ::Dual (tokenizer/mod.rs:225-290, 1337-1356): input i is the sequences
+    // [inp_off[i], inp_off[i + 1]) -- one (Single) or two (Dual, A then B) -- instead of 2i / 2i + 1; a Single is laid out by the single
+    // template tpl1 (n_special1 special tokens), cut like truncate_encodings cuts an encoding without a pair (utils/truncation.rs:70-160)
+    // and leaves the windows Encoding::truncate leaves a single sequence.  Null: every input is a pair.
+    const int64_t* inp_off;           // [n_pairs + 1] or null
+    const uint32_t* tpl1;             // [n_tpl1][3] the single template (kind 0 and 2 only)
+    int32_t n_tpl1;
+    uint32_t n_special1;
     uint32_t trunc_on, trunc_max, trunc_left, trunc_strategy, trunc_stride;
     uint32_t pad_on, pad_fixed, pad_length, pad_multiple, pad_left, pad_id, pad_type_id;
     uint32_t* keep;                   // [2 * n_pairs] tokens of A / B that survive the truncation
@@ -276,6 +285,7 @@ enum : int {
     ERR_TOO_MANY_TOKENS = 256,
     ERR_TRUNC_SHORT = 512,        // OnlyFirst / OnlySecond: the sequence to cut is not longer than what must go (TruncationError::SequenceTooShort)    // the padded batch has more than 2^32 tokens
     ERR_TRUNC_STRIDE = 1024,      // a sequence has to be cut to max_len tokens and stride >= max_len (the assert of Encoding::truncate, encoding.rs:319)
+    ERR_INPUT_KIND = 8192,        // an input of a mixed batch that is neither one sequence nor two (tkamd_encode_batch_mixed)
     ERR_UNK_OOV = 4096,           // BPE: a char the vocabulary lacks, and the unk_token that should stand for it is not in the vocabulary either (Error::UnkTokenOutOfVocabulary, bpe/model.rs:528-533)
     NOTE_REORDER_SEEN = 2048,     // not an error: the normalizer met a character NFD's canonical ordering could move (k_bn_reorder_fix then looks at its neighbours)
     ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
@@ -297,7 +307,7 @@ void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs,
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
-                      int64_t* total);
+                      int64_t* total, const int64_t* len_dev = nullptr);      // len_dev: only the words of a text of that (device-side) length
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start);
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
@@ -327,9 +337,9 @@ inline uint8_t* bn_ltot_of(uint8_t* olen, int64_t n_bytes) { return olen + (((si
 void launch_mark_doc_starts_n(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, const int64_t* len_dev,
                               unsigned long long* docmask, int* err);
 void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask);
+                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask, bool len_bound = false);
 void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
-                            const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end);
+                            const uint32_t* wprefix, int64_t n_bytes, const int64_t* len_dev, uint32_t* pt_end);
 void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                            const unsigned long long* verbatim, uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext,
                            uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err);
@@ -371,7 +381,7 @@ void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
                         uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err);
 void launch_scatter_matches(hipStream_t st, const uint32_t* list, const uint32_t* n_list, int64_t n_bytes, const int64_t* len_dev, unsigned long long* matchmask,
-                            unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end);
+                            unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end, uint32_t* dirty);
 void launch_mask_or2(hipStream_t st, unsigned long long* dst, const unsigned long long* a, const unsigned long long* b, int64_t n_words);
 void launch_emit_boundaries(hipStream_t st, const unsigned long long* mask, const uint32_t* wprefix, int64_t n_bytes, const int64_t* len_dev, const int64_t* total, int64_t* out);
 void launch_translate_matches_norm(hipStream_t st, uint32_t* list, const uint32_t* n_list, const uint8_t* olen, const uint32_t* wbase, int64_t n_bytes, const int64_t* x_len);
@@ -407,7 +417,7 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                     int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr);
 int compact_grid(int n_cu, int cp_items);
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
-void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n);      // n <= 256 zero bytes at p[*len_dev ..]
+void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n, unsigned long long* mask = nullptr, int64_t mask_words = 0, int grid = 1);      // n <= 256 zero bytes at p[*len_dev ..]; mask: its words below (*len_dev >> 6) + 3 zeroed too
 constexpr int COMPACT_CHUNK_MIN = 512;              // pre-tokens per compaction chunk: 256 lanes x cp_items (2, 4 or 8)
 
 }  // namespace tkamd

@@ -210,9 +210,12 @@ __global__ void k_added_resolve(AddedArgs a, const uint8_t* __restrict__ text, c
 // counted in bytes of the original text), for the offsets of a match -- a later, overlapping match may have cut it short in the masks.
 __global__ void k_scatter_matches(const uint32_t* __restrict__ list, const uint32_t* __restrict__ n_list, int64_t n_bytes_host, const int64_t* __restrict__ len_dev,
                                   unsigned long long* __restrict__ matchmask, unsigned long long* __restrict__ spanmask,
-                                  unsigned long long* __restrict__ stopmask, unsigned long long* __restrict__ hardmask, uint32_t* __restrict__ tmp_end) {
+                                  unsigned long long* __restrict__ stopmask, unsigned long long* __restrict__ hardmask, uint32_t* __restrict__ tmp_end,
+                                  uint32_t* __restrict__ dirty) {
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     const uint32_t n = *n_list;
+    // the masks hold bits from here on exactly if this launch sets any: the next zeroing of them (ZeroRegions::only_if) is skipped otherwise
+    if (dirty && blockIdx.x == 0 && threadIdx.x == 0) *dirty = n ? 1u : 0u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int64_t start = list[4 * i], stop = list[4 * i + 1];
         atomicOr(&matchmask[start >> 6], 1ull << (start & 63));

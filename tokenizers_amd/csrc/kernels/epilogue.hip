@@ -206,20 +206,42 @@ __global__ __launch_bounds__(256) void k_finalize(FinalArgs a) {
 // roberta.rs, template.rs:544-590; without one: A then B, type ids 0 / 1, PostProcessor::default_process), and padded.
 // Every output token also gets its sequence id (0 / 1; 2 special; 3 padding) -- Encoding::token_to_sequence, the masks.
 // =================================================================================================
+// A mixed batch (PairArgs::inp_off): input i is one sequence (EncodeInput::Single) or two (::Dual).  What the three kernels below need
+// of an input: its first sequence, whether it has a second one, its token counts -- and, per kind, the template and its special tokens.
+struct PairInput { int64_t d0; bool has_b; uint64_t n1, n2; };
+__device__ __forceinline__ PairInput pair_input(const PairArgs& a, int64_t i) {
+    PairInput p;
+    p.d0 = 2 * i;
+    p.has_b = true;
+    int64_t c = 2;
+    if (a.inp_off) {
+        p.d0 = a.inp_off[i];
+        c = a.inp_off[i + 1] - p.d0;
+        if (c < 1 || c > 2) atomicOr(a.err, ERR_INPUT_KIND);      // (the batch fails; the sequences read below all exist: the CSR was validated)
+        p.has_b = c >= 2;
+    }
+    p.n1 = c >= 1 ? (uint64_t)(a.tok_offsets[p.d0 + 1] - a.tok_offsets[p.d0]) : 0ull;
+    p.n2 = p.has_b ? (uint64_t)(a.tok_offsets[p.d0 + 2] - a.tok_offsets[p.d0 + 1]) : 0ull;
+    return p;
+}
 __global__ __launch_bounds__(256) void k_pair_lens(PairArgs a) {
     __shared__ uint32_t smax[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t l = 0;
     if (i < a.n_pairs) {
-        uint64_t n1 = (uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), n2 = (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1]);
+        const PairInput in = pair_input(a, i);
+        const uint32_t n_special = in.has_b ? a.n_special : a.n_special1;      // get_n_added_tokens(is_pair), mod.rs:1270-1272
+        uint64_t n1 = in.n1, n2 = in.n2;
         if (a.trunc_on) {
             // max_length - n_added_tokens (mod.rs:1273-1279; the subtraction wraps in the reference's release build when max_length is smaller)
-            const uint64_t maxl = (a.n_special && a.trunc_max < a.n_special) ? ~0ull : (uint64_t)(a.trunc_max - a.n_special);
+            const uint64_t maxl = (n_special && a.trunc_max < n_special) ? ~0ull : (uint64_t)(a.trunc_max - n_special);
             const uint64_t total = n1 + n2;
             if (maxl == 0) { n1 = 0; n2 = 0; }
-            else if (total > maxl) {
+            else if (total > maxl && !in.has_b && a.trunc_strategy == 2) {
+                atomicOr(a.err, ERR_TRUNC_SECOND);                    // OnlySecond without a second sequence (truncation.rs:147-151)
+            } else if (total > maxl) {
                 const uint64_t to_remove = total - maxl;
-                if (a.trunc_strategy == 0) {                          // LongestFirst (truncation.rs:101-141)
+                if (a.trunc_strategy == 0) {                          // LongestFirst (truncation.rs:101-141; without a pair: total - to_remove, the same numbers)
                     uint64_t s1 = n1, s2 = n2;
                     const bool swap = s1 > s2;
                     if (swap) { const uint64_t x = s1; s1 = s2; s2 = x; }
@@ -236,15 +258,15 @@ __global__ __launch_bounds__(256) void k_pair_lens(PairArgs a) {
         }
         // Encoding::truncate(kept, stride): a sequence that is cut to kept > 0 tokens asserts stride < kept (encoding.rs:319)
         {
-            const uint64_t a1 = (uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), a2 = (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1]);
+            const uint64_t a1 = in.n1, a2 = in.n2;
             if ((n1 < a1 && n1 > 0 && a.trunc_stride >= n1) || (n2 < a2 && n2 > 0 && a.trunc_stride >= n2)) atomicOr(a.err, ERR_TRUNC_STRIDE);
         }
         a.keep[2 * i] = (uint32_t)n1;
         a.keep[2 * i + 1] = (uint32_t)n2;
-        l = (uint32_t)(n1 + n2) + a.n_special;
+        l = (uint32_t)(n1 + n2) + n_special;
         if (a.ovf_parts) {
             // Encoding::truncate keeps what it cuts off either sequence; the pair then leaves every combination of their windows
-            const uint64_t a1 = (uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), a2 = (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1]);
+            const uint64_t a1 = in.n1, a2 = in.n2;
             uint64_t pa = ovf_parts(a1, (uint32_t)n1, a.trunc_stride), pb = ovf_parts(a2, (uint32_t)n2, a.trunc_stride);
             if (pa == 0u) pa = 1u;                          // (the stride assert: reported above)
             if (pb == 0u) pb = 1u;
@@ -276,7 +298,9 @@ __global__ __launch_bounds__(256) void k_pair_ranges(PairArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t l = 0;
     if (i < a.n_pairs) {
-        const uint64_t n_all[2] = {(uint64_t)(a.tok_offsets[2 * i + 1] - a.tok_offsets[2 * i]), (uint64_t)(a.tok_offsets[2 * i + 2] - a.tok_offsets[2 * i + 1])};
+        const PairInput in = pair_input(a, i);
+        const uint32_t n_special = in.has_b ? a.n_special : a.n_special1;
+        const uint64_t n_all[2] = {in.n1, in.n2};
         const uint32_t keep[2] = {a.keep[2 * i], a.keep[2 * i + 1]};
         uint32_t parts[2] = {ovf_parts(n_all[0], keep[0], a.trunc_stride), ovf_parts(n_all[1], keep[1], a.trunc_stride)};
         if (parts[0] == 0u) parts[0] = 1u;
@@ -284,7 +308,7 @@ __global__ __launch_bounds__(256) void k_pair_ranges(PairArgs a) {
         const int64_t e0 = a.enc_base[i];
         const uint32_t total = (uint32_t)(a.enc_base[i + 1] - e0);
         if (total != parts[0] * parts[1]) { parts[0] = 1u; parts[1] = 1u; }      // (the count was clamped: an error is pending)
-        const int F = a.first_is_b ? 1 : 0, S = 1 - F;
+        const int F = (a.first_is_b && in.has_b) ? 1 : 0, S = 1 - F;      // (a single sequence: its own windows, in order -- the S side has one part)
         for (uint32_t q = 0; q < total; ++q) {
             // q -> (window of F, window of S) in the order above
             uint32_t wf, ws;
@@ -306,8 +330,8 @@ __global__ __launch_bounds__(256) void k_pair_ranges(PairArgs a) {
             a.enc_win[4 * e + 1] = (uint32_t)c0;
             a.enc_win[4 * e + 2] = (uint32_t)s1;
             a.enc_win[4 * e + 3] = (uint32_t)c1;
-            a.len1[e] = (uint32_t)(c0 + c1) + a.n_special;
-            if (q == 0u) l = (uint32_t)(c0 + c1) + a.n_special;
+            a.len1[e] = (uint32_t)(c0 + c1) + n_special;
+            if (q == 0u) l = (uint32_t)(c0 + c1) + n_special;
         }
     }
     if (a.pad_on && !a.pad_fixed) {                         // BatchLongest: the pairs' own encodings (utils/padding.rs:55-63)
@@ -335,8 +359,17 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PairArgs a) {
             if (a.offsets) { a.offsets2[2 * o] = 0; a.offsets2[2 * o + 1] = 0; }
             if (a.word_ids) a.word_ids2[o] = 0xFFFFFFFFu;
         }
-        for (int k = 0; k < a.n_tpl; ++k) {
-            const uint32_t kind = a.tpl[3 * k], id = a.tpl[3 * k + 1], ty = a.tpl[3 * k + 2];
+        // (a mixed batch: the input behind encoding i, its first sequence, and the template of its kind)
+        const int64_t inp = a.enc_doc ? (int64_t)a.enc_doc[i] : i;
+        int64_t d0 = 2 * inp;
+        const uint32_t* tpl = a.tpl;
+        int n_tpl = a.n_tpl;
+        if (a.inp_off) {
+            d0 = a.inp_off[inp];
+            if (a.inp_off[inp + 1] - d0 < 2) { tpl = a.tpl1; n_tpl = a.n_tpl1; }
+        }
+        for (int k = 0; k < n_tpl; ++k) {
+            const uint32_t kind = tpl[3 * k], id = tpl[3 * k + 1], ty = tpl[3 * k + 2];
             if (kind == 2u) {
                 if (lane == 0) {
                     a.ids2[cur] = id;
@@ -351,15 +384,15 @@ __global__ __launch_bounds__(256) void k_pair_finalize(PairArgs a) {
                 uint32_t ty_here = ty;
                 if (a.enc_doc) {                            // i numbers the encodings: this one's window of sequence `kind`
                     n = a.enc_win[4 * i + 2 * kind + 1];
-                    src = a.tok_offsets[2 * (int64_t)a.enc_doc[i] + kind] + a.enc_win[4 * i + 2 * kind];
+                    src = a.tok_offsets[d0 + kind] + a.enc_win[4 * i + 2 * kind];
                     // the template's type id is put on the sequence's own encoding only (template.rs:554-559); an overflowing window
                     // keeps what encode gave its tokens: 0 for the first sequence, 1 for the second (mod.rs:879-884) -- RobertaProcessing
                     // writes zeros over its overflowing windows as well when it adds the special tokens (roberta.rs:121-126, 187-192)
                     if (a.enc_idx[2 * i + kind] != 0u && !a.ovf_ty_tpl) ty_here = kind;
                 } else {
-                    const int64_t d = 2 * i + kind;
+                    const int64_t d = d0 + kind;
                     const int64_t lo = a.tok_offsets[d], n_all = a.tok_offsets[d + 1] - lo;
-                    n = a.keep[d];
+                    n = a.keep[2 * i + kind];
                     src = lo + (a.trunc_left ? n_all - n : 0);
                 }
                 for (int64_t q = lane; q < n; q += 64) {

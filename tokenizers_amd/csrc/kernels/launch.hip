@@ -32,11 +32,11 @@ void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, co
         hipLaunchKernelGGL(k_pretok_gpt2_bits, dim3(blocks_for(n_bytes + 1, PB_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
 }
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
-                      int64_t* total) {
+                      int64_t* total, const int64_t* len_dev) {
     unsigned nb = blocks_for(n_words, 256 * WS_PER);
-    hipLaunchKernelGGL(k_words_reduce, dim3(nb), dim3(256), 0, st, mask, n_words, bsum);
+    hipLaunchKernelGGL(k_words_reduce, dim3(nb), dim3(256), 0, st, mask, n_words, bsum, len_dev);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
-    hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix);
+    hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix, len_dev);
 }
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
@@ -158,23 +158,24 @@ void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, c
 }
 template <int KIND>
 static void launch_pretok_local_t(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                                  const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask) {
+                                  const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask, bool len_bound) {
     // TKAMD_PRETOK_LOCAL=tile: the lane-per-byte tile kernel; default: the per-lane bit-parallel kernel
     static const bool tile_variant = [] { const char* e = getenv("TKAMD_PRETOK_LOCAL"); return e && !strcmp(e, "tile"); }();
     if (tile_variant)
         hipLaunchKernelGGL(k_pretok_local<KIND>, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
     else
-        hipLaunchKernelGGL(k_pretok_local_lane<KIND>, dim3(blocks_for(n_bytes + 2, 256 * PLW_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+        hipLaunchKernelGGL(k_pretok_local_lane<KIND>, dim3(blocks_for(n_bytes + 2, 256 * PLW_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask,
+                           (len_bound && len_dev) ? 1 : 0);
 }
 void launch_pretok_local(hipStream_t st, int kind, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask) {
-    if (kind == PT_WHITESPACE) launch_pretok_local_t<PT_WHITESPACE>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
-    else if (kind == PT_WHITESPACE_SPLIT) launch_pretok_local_t<PT_WHITESPACE_SPLIT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
-    else launch_pretok_local_t<PT_BERT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask);
+                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* endmask, bool len_bound) {
+    if (kind == PT_WHITESPACE) launch_pretok_local_t<PT_WHITESPACE>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask, len_bound);
+    else if (kind == PT_WHITESPACE_SPLIT) launch_pretok_local_t<PT_WHITESPACE_SPLIT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask, len_bound);
+    else launch_pretok_local_t<PT_BERT>(st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, endmask, len_bound);
 }
 void launch_emit_pretok_end(hipStream_t st, const unsigned long long* startmask, const unsigned long long* endmask,
-                            const uint32_t* wprefix, int64_t n_bytes, uint32_t* pt_end) {
-    hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 64, 4 * 4096)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, pt_end);
+                            const uint32_t* wprefix, int64_t n_bytes, const int64_t* len_dev, uint32_t* pt_end) {
+    hipLaunchKernelGGL(k_emit_pretok_end, dim3(blocks_for(n_bytes + 64, 4 * 4096)), dim3(256), 0, st, startmask, endmask, wprefix, n_bytes, len_dev, pt_end);
 }
 void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* text, int64_t n_bytes, const int64_t* doc_off, int64_t n_docs,
                            const unsigned long long* verbatim, uint8_t* olen, uint32_t* wsum, uint32_t* bsum, uint32_t* wbase, int64_t* x_len, uint8_t* ntext,
@@ -256,8 +257,8 @@ void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text,
                        (const unsigned long long*)candmask, skipmask, uc1, uc2, match_list, n_match, cap, len_flag, err);
 }
 void launch_scatter_matches(hipStream_t st, const uint32_t* list, const uint32_t* n_list, int64_t n_bytes, const int64_t* len_dev, unsigned long long* matchmask,
-                            unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end) {
-    hipLaunchKernelGGL(k_scatter_matches, dim3(256), dim3(256), 0, st, list, n_list, n_bytes, len_dev, matchmask, spanmask, stopmask, hardmask, tmp_end);
+                            unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end, uint32_t* dirty) {
+    hipLaunchKernelGGL(k_scatter_matches, dim3(256), dim3(256), 0, st, list, n_list, n_bytes, len_dev, matchmask, spanmask, stopmask, hardmask, tmp_end, dirty);
 }
 void launch_mask_or2(hipStream_t st, unsigned long long* dst, const unsigned long long* a, const unsigned long long* b, int64_t n_words) {
     hipLaunchKernelGGL(k_mask_or2, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, dst, a, b, n_words);
@@ -311,8 +312,8 @@ void launch_bpe_merge_long_only(hipStream_t st, int grid, const DevTables& t, co
                                 uint32_t* list_huge, uint32_t* n_huge) {
     hipLaunchKernelGGL(k_bpe_merge_long, dim3(grid), dim3(256), long_kernel_lds_bytes(), st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, list_huge, n_huge);
 }
-void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n) {
-    hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(256), 0, st, p, len_dev, n);
+void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n, unsigned long long* mask, int64_t mask_words, int grid) {
+    hipLaunchKernelGGL(k_zero_tail, dim3(mask ? std::max(1, grid) : 1), dim3(256), 0, st, p, len_dev, n, mask, mask_words);
 }
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z) {
     if (z.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(grid), dim3(256), 0, st, z);

@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256) void k_pretok_local_lane(const uint8_t* __rest
                                                            const unsigned long long* __restrict__ docmask,
                                                            const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                            unsigned long long* __restrict__ startmask,
-                                                           unsigned long long* __restrict__ endmask) {
+                                                           unsigned long long* __restrict__ endmask, int len_bound) {
     __shared__ uint32_t lut[SQ_LUT_COPIES * 256];
+    // len_bound (with len_dev): the launch covers the host's bound of the text -- three times the input behind BertNormalizer -- but only
+    // the mask words of the text's own length are written ((len >> 6) + 2 of them: what the scan, the lookup and the emit kernels read);
+    // a workgroup wholly behind them is gone before it fills its table
+    if (len_bound && (int64_t)blockIdx.x * 256 * PLW_MAIN > *len_dev + 192) return;
     {
         const uint32_t f = local_byte_flags<KIND>(threadIdx.x);
 #pragma unroll
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void k_pretok_local_lane(const uint8_t* __rest
     const int q = (int)(threadIdx.x & 3);
     if (q < 3) {
         const int64_t word = 3 * (Lg >> 2) + q;
-        if (word < n_words_host) {
+        if (word < (len_bound ? min(n_words_host, (n_bytes >> 6) + 2) : n_words_host)) {
             startmask[word] = (st >> (16 * q)) | (st_n << (PLW_MAIN - 16 * q));
             endmask[word] = (en >> (16 * q)) | (en_n << (PLW_MAIN - 16 * q));
         }

@@ -9,9 +9,12 @@
 // (eight words per lane: the single-workgroup scan over the workgroup totals then has a few hundred entries for a 120 MB batch and
 // is one round instead of eight)
 constexpr int WS_PER = 8;
+// (len_dev: the mask covers a text whose length only exists on the device -- the normaliser's output, launched over the host's bound of
+// three times the input: only the words that text has are read, summed and given a prefix; the others' block sums are zero)
 __global__ __launch_bounds__(256) void k_words_reduce(const unsigned long long* __restrict__ mask, int64_t n_words,
-                                                      uint32_t* __restrict__ bsum) {
+                                                      uint32_t* __restrict__ bsum, const int64_t* __restrict__ len_dev) {
     __shared__ uint32_t sm[4];
+    if (len_dev) n_words = min(n_words, (*len_dev >> 6) + 2);
     const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * WS_PER;
     uint32_t v = 0;
     if (w0 + WS_PER <= n_words) {
@@ -27,8 +30,10 @@ __global__ __launch_bounds__(256) void k_words_reduce(const unsigned long long* 
 }
 
 __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __restrict__ mask, int64_t n_words,
-                                                    const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix) {
+                                                    const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix, const int64_t* __restrict__ len_dev) {
     __shared__ uint32_t sm[4];
+    if (len_dev) n_words = min(n_words, (*len_dev >> 6) + 2);
+    if ((int64_t)blockIdx.x * 256 * WS_PER >= n_words) return;      // (the whole workgroup)
     const int64_t w0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * WS_PER;
     uint32_t c[WS_PER], v = 0;
     const bool whole = w0 + WS_PER <= n_words;
@@ -67,6 +72,7 @@ __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* _
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wave == 0 && lane == 0) pt_start[*n_pretok] = (uint32_t)(len_dev ? *len_dev : n_bytes);          // sentinel
+    if (len_dev) n_bytes = min(n_bytes, *len_dev);                // (start bits exist only below the text's own length)
     const int64_t n_words = (n_bytes + 63) >> 6;
     const int64_t w0 = wave * 64;
     if (w0 >= n_words) return;
@@ -89,10 +95,11 @@ __global__ __launch_bounds__(256) void k_emit_pretok(const unsigned long long* _
 // pre-token that started most recently before i.  Same wavefront-per-64-words structure as k_emit_pretok.
 __global__ __launch_bounds__(256) void k_emit_pretok_end(const unsigned long long* __restrict__ startmask,
                                                          const unsigned long long* __restrict__ endmask,
-                                                         const uint32_t* __restrict__ wprefix, int64_t n_bytes,
+                                                         const uint32_t* __restrict__ wprefix, int64_t n_bytes, const int64_t* __restrict__ len_dev,
                                                          uint32_t* __restrict__ pt_end) {
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (len_dev) n_bytes = min(n_bytes, *len_dev);
     const int64_t n_words = (n_bytes >> 6) + 1;               // an end bit can sit at byte n_bytes
     const int64_t w0 = wave * 64;
     if (w0 >= n_words) return;

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(1024) void k_scan_single(uint32_t* __restrict__ dat
 // Several buffers zeroed by ONE launch (a hipMemsetAsync is a kernel launch of its own: five of them per batch were 27 us of a 700 us
 // step).  Regions are 16-byte aligned device allocations with slack: whole 16-byte words are written.
 __global__ __launch_bounds__(256) void k_zero_regions(ZeroRegions z) {
+    if (z.only_if && *z.only_if == 0u) return;
     const size_t stride = (size_t)gridDim.x * 256;
     for (int r = 0; r < z.n; ++r) {
         uint4* const p = (uint4*)(r == 0 ? z.p[0] : r == 1 ? z.p[1] : r == 2 ? z.p[2] : r == 3 ? z.p[3] : r == 4 ? z.p[4] : z.p[5]);
@@ -56,8 +57,14 @@ __global__ __launch_bounds__(256) void k_zero_regions(ZeroRegions z) {
 }
 // The readable slack behind a text that a kernel produced (the normaliser): `n` zero bytes from its device-side length on.  (The
 // buffer is sized for the host's bound of that length, 3 x the input; zeroing all of it was a 360 MB memset per C3 step.)
-__global__ void k_zero_tail(uint8_t* __restrict__ p, const int64_t* __restrict__ len, int n) {
+// mask (optional): a bitmask over that text (the document mask) -- its words up to the text's own length are zeroed here as well, instead of
+// all the words of the host's bound at the head of the batch.
+__global__ void k_zero_tail(uint8_t* __restrict__ p, const int64_t* __restrict__ len, int n, unsigned long long* __restrict__ mask, int64_t mask_words) {
     const int i = (int)threadIdx.x;
-    if (i < n) p[*len + i] = 0;
+    if (blockIdx.x == 0 && i < n) p[*len + i] = 0;
+    if (mask) {
+        const int64_t nw = min(mask_words, (*len >> 6) + 3);
+        for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) mask[w] = 0ull;
+    }
 }
 

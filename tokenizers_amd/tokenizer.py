@@ -158,6 +158,15 @@ class Encoding:
         nb, ne = b._specials
         return (p, nb, ne, 0) if b._pad_left else (0, nb, ne, p)
 
+    def _single(self) -> bool:
+        """This encoding holds ONE sequence (every encoding of a batch of single sequences; the Single items of a mixed batch)."""
+        b = self._b
+        if b.seq_ids is None:
+            return True
+        if b.kinds is None:
+            return False
+        return not b.kinds[int(b.enc_docs[self._i]) if b.enc_docs is not None else self._i]
+
     def _mask(self, pad, special, token) -> list:
         b = self._b
         if b.seq_ids is not None:            # pairs: the device wrote every token's sequence id (0 / 1, 2 special, 3 padding)
@@ -217,6 +226,8 @@ class Encoding:
         if self._b.seq_ids is not None:
             nat = [q if q < 2 else None for q in self._b.seq_ids[self._lo:self._hi].tolist()]
             b = self._b
+            if self._single():                  # (a Single item of a mixed batch: what a batch of single sequences answers below)
+                return [0] * len(nat) if getattr(b, "_no_seq_ranges", False) else nat
             if b.enc_parts is not None and getattr(b, "_no_seq_ranges", False) and (self._i > 0 and b.enc_docs[self._i - 1] == b.enc_docs[self._i]):
                 # an overflowing encoding of a pair WITHOUT a post-processor: default_process gives sequence ranges to the pair's own
                 # encoding only (tokenizer/mod.rs:158-173).  A combination that holds an overflowing window of the first sequence has no
@@ -230,13 +241,13 @@ class Encoding:
 
     @property
     def n_sequences(self) -> int:
-        return 2 if self._b.seq_ids is not None else 1
+        return 1 if self._single() else 2
 
     # ---- token / word / char mappings (tokenizer/encoding.rs:204-300; Python signatures of bindings/python/src/encoding.rs:283-390).
     # Host-side views over the arrays the device wrote; `sequence_ranges` of the reference = the spans of sequence_ids 0 / 1.
     def _ranges(self) -> dict:
         r: dict = {}
-        if self._b.seq_ids is None and getattr(self._b, "_no_seq_ranges", False):
+        if self._single() and getattr(self._b, "_no_seq_ranges", False):
             return r                            # no post-processor, single sequence: the reference never sets sequence_ranges
         for i, q in enumerate(self.sequence_ids):
             if q is not None:
@@ -248,7 +259,7 @@ class Encoding:
         r = self._ranges()
         if sequence_index in r:
             return r[sequence_index]
-        has_ranges = not (self._b.seq_ids is None and getattr(self._b, "_no_seq_ranges", False))
+        has_ranges = not (self._single() and getattr(self._b, "_no_seq_ranges", False))
         if has_ranges and sequence_index < self.n_sequences:
             return (0, 0)                       # a sequence without tokens: its range exists and is empty (where it sits changes no answer)
         return (0, len(self))                   # encoding.rs:204-209: no such range -> the whole encoding
@@ -256,7 +267,7 @@ class Encoding:
     def token_to_sequence(self, token_index: int) -> int | None:
         if token_index > len(self):             # (`>`: encoding.rs:213)
             return None
-        if self._b.seq_ids is None and getattr(self._b, "_no_seq_ranges", False):
+        if self._single() and getattr(self._b, "_no_seq_ranges", False):
             return 0                            # sequence_ranges is empty (an empty RANGE, e.g. of an empty document, is not)
         for q, (lo, hi) in self._ranges().items():
             if lo <= token_index < hi:
@@ -352,6 +363,7 @@ class BatchEncoding:
         # (an input's own encoding first, then its Encoding.overflowing), _first[i] = the own encoding of input i
         self.enc_docs = None
         self.enc_parts = None               # pairs: [n_encodings, 2] window of sequence A / B each encoding combines
+        self.kinds = None                   # a mixed batch: uint8 per INPUT, 0 a single sequence, 1 a pair (None: one kind)
         self._first = None
         self._id_to_token = id_to_token
         self._specials = specials           # (#prefix, #suffix) special tokens around every document
@@ -874,7 +886,7 @@ class Tokenizer:
             flags |= _lib.ADD_SPECIAL
         return flags
 
-    def _wrap_batch(self, b, n_inputs, offsets, word_ids, add_special_tokens, pairs, ids_dtype) -> BatchEncoding:
+    def _wrap_batch(self, b, n_inputs, offsets, word_ids, add_special_tokens, pairs, ids_dtype, kinds=None) -> BatchEncoding:
         """Zero-copy views of a finished ``tkamd_batch`` (the library's pinned result buffers)."""
         n_docs = self._lib.tkamd_batch_n_docs(b)             # encodings (sequences; half of them for pairs)
         # zero-copy views of the library's pinned result buffers; the batch is freed when the last view dies
@@ -904,6 +916,7 @@ class Tokenizer:
         be = BatchEncoding(ids, to, offs, wids, self._id_to_token(), self._specials if add_special_tokens else (0, 0), pads,
                            self.info["padding"] == 2, self.info["pad_type_id"], self._pad_token)
         be._no_seq_ranges = self._no_post_processor
+        be.kinds = kinds
         tp = self._lib.tkamd_batch_type_ids(b)
         if tp or pairs:                          # (a pair batch without a single token has no arrays: empty views)
             be.type_ids = view(tp, C.c_uint8, (nt,), np.uint8)
@@ -947,37 +960,50 @@ class Tokenizer:
             except (UnsupportedError, TypeError):
                 if len(inputs) <= 4096 or all(is_pair(it) == first for it in inputs):
                     raise
-        # Vec<EncodeInput> may mix Single and Dual items (tokenizer/mod.rs:1337-1356): the two kinds are two calls, put back in order.
-        # What couples them is BatchLongest padding -- pad_encodings takes the longest encoding of the WHOLE batch
-        # (utils/padding.rs:50-81) --: the lengths are taken from an unpadded run and the batch is then padded to that, Fixed.
-        groups = [[i for i, it in enumerate(inputs) if not is_pair(it)], [i for i, it in enumerate(inputs) if is_pair(it)]]
-        run = lambda t: [t.encode_batch_csr([inputs[i] for i in g], offsets=offsets, word_ids=word_ids, add_special_tokens=add_special_tokens,
-                                            is_pretokenized=is_pretokenized, overflowing=overflowing) for g in groups]
-        tok, pad = self, self.padding
+        # Vec<EncodeInput> may mix Single and Dual items (tokenizer/mod.rs:1337-1356): ONE call (tkamd_encode_batch_mixed) -- every
+        # sequence a document (or a list of words), the inputs a CSR over them; the device cuts and lays out every input by its kind
+        # and pads the whole batch together (BatchLongest takes the longest encoding of the WHOLE batch, utils/padding.rs:50-81).
+        return self._encode_mixed(inputs, offsets, word_ids, add_special_tokens, is_pretokenized, overflowing, is_pair)
 
-        def variant(d):                          # (a second handle with another padding section and this one's switches)
-            t = Tokenizer.from_str(json.dumps(d, ensure_ascii=False), device=self.device)
-            t.encode_special_tokens = self.encode_special_tokens
-            return t
-        if pad is not None and pad["length"] is None:
-            d = json.loads(self._json)
-            d["padding"] = None
-            plain = run(variant(d))
-            target = max(len(e) for b in plain for e in b)
-            m = pad["pad_to_multiple_of"]
-            if m and target % m:
-                target += m - target % m
-            d["padding"] = dict(json.loads(self._json)["padding"], strategy={"Fixed": int(target)})
-            tok = variant(d)
-        out: list = [None] * len(inputs)
-        for g, b in zip(groups, run(tok)):
-            for i, e in zip(g, b):
-                out[i] = e
-        return out
+    def _encode_mixed(self, inputs, offsets, word_ids, add_special_tokens, is_pretokenized, overflowing, is_pair) -> BatchEncoding:
+        seqs: list = []
+        inp_off = [0]
+        kinds = np.zeros(len(inputs), dtype=np.uint8)
+        for i, it in enumerate(inputs):
+            if is_pair(it):
+                if len(it) != 2:
+                    raise UnsupportedError("an input is a sequence or a pair of sequences")
+                seqs.extend(it)
+                kinds[i] = 1
+            else:
+                seqs.append(it)
+            inp_off.append(len(seqs))
+        seq_off = None
+        if is_pretokenized:
+            words: list[str] = []
+            seq_off = [0]
+            for sq in seqs:
+                if not (isinstance(sq, (list, tuple)) and all(isinstance(x, str) for x in sq)):
+                    raise TypeError("is_pretokenized=True: every sequence must be a list of str (TextInputSequence / PreTokenizedInputSequence)")
+                words.extend(sq)
+                seq_off.append(len(words))
+            seqs = words
+        elif not all(isinstance(x, str) for x in seqs):
+            raise UnsupportedError("a batch holds single sequences (str) and pairs (str, str); lists of words need is_pretokenized=True")
+        flags = self._flags(offsets, word_ids, add_special_tokens, False, overflowing, "uint32")
+        inp = np.asarray(inp_off, dtype=np.int64)
+        b = C.c_void_p()
+        with self._stage_lock:
+            buf, doc_off = self._pack_staged(seqs)
+            so = np.asarray(seq_off, dtype=np.int64) if seq_off is not None else None
+            _lib.check(self._lib.tkamd_encode_batch_mixed(self._h, buf.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
+                                                          so.ctypes.data if so is not None else None, len(so) - 1 if so is not None else -1,
+                                                          inp.ctypes.data, len(inputs), flags, C.byref(b)))
+        return self._wrap_batch(b, len(inputs), offsets, word_ids, add_special_tokens, True, "uint32", kinds)
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
-        """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338).  A batch that mixes single sequences and pairs
-        comes back as a list of :class:`Encoding` (two calls underneath); every other batch as one :class:`BatchEncoding`."""
+        """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338).  A batch may mix single sequences and pairs
+        (``EncodeInput::Single`` / ``::Dual``): one call either way."""
         return self._encode_any(input, "char", True, add_special_tokens, is_pretokenized)
 
     def encode_batch_fast(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
