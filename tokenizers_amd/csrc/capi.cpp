@@ -564,7 +564,12 @@ void build_shortw_table(tkamd_tokenizer* t) {
         if (w.len) ws.push_back(&w);
     // the first size tried: the power of two at or above `x10 / 10` slots a word (TKAMD_SHORTW_X10, an A/B knob; 25 = two and a half --
     // a fuller table is fewer lines for the caches to hold and more displacements to try; a size that cannot be placed doubles below)
-    static const size_t x10 = [] { const char* e = getenv("TKAMD_SHORTW_X10"); return (size_t)std::max(11, e ? atoi(e) : 25); }();
+    static const size_t x10 = [] { const char* e = getenv("TKAMD_SHORTW_X10"); return (size_t)std::max(11, e ? atoi(e) : 13); }();
+    // displacement buckets: SHORTW_BUCKETS, four times that for a vocabulary beyond 65,536 words (Llama-3's 128 k: fifteen words a bucket
+    // find no eight-bit displacement in a table less than a quarter full -- 8 MB for 124 k words; four a bucket settle at 47 %, 4 MB)
+    // (TKAMD_SHORTW_BUCKETS: an A/B knob, a power of two)
+    static const uint32_t forced_buckets = [] { const char* e = getenv("TKAMD_SHORTW_BUCKETS"); const int v = e ? atoi(e) : 0; return (v >= 1024 && !(v & (v - 1))) ? (uint32_t)v : 0u; }();
+    const uint32_t n_buckets = forced_buckets ? forced_buckets : (ws.size() > 65536 ? 4u * (uint32_t)SHORTW_BUCKETS : (uint32_t)SHORTW_BUCKETS);
     uint32_t cap = 16;
     while (cap < ws.size() * x10 / 10) cap <<= 1;
     std::vector<uint32_t> h1(ws.size()), km(ws.size()), where(ws.size());
@@ -573,15 +578,15 @@ void build_shortw_table(tkamd_tokenizer* t) {
         km[i] = shortw_kmix((uint32_t)ws[i]->lo, (uint32_t)(ws[i]->lo >> 32), (uint32_t)ws[i]->hi, (uint32_t)(ws[i]->hi >> 32));
     }
     // hash-and-displace, the fullest buckets first, each takes the smallest displacement < 256 that drops all its words on free slots
-    std::vector<std::vector<uint32_t>> buckets((size_t)SHORTW_BUCKETS);
-    for (size_t i = 0; i < ws.size(); ++i) buckets[h1[i] & (uint32_t)(SHORTW_BUCKETS - 1)].push_back((uint32_t)i);
-    std::vector<uint32_t> order((size_t)SHORTW_BUCKETS);
-    for (uint32_t b = 0; b < (uint32_t)SHORTW_BUCKETS; ++b) order[b] = b;
+    std::vector<std::vector<uint32_t>> buckets((size_t)n_buckets);
+    for (size_t i = 0; i < ws.size(); ++i) buckets[h1[i] & (n_buckets - 1u)].push_back((uint32_t)i);
+    std::vector<uint32_t> order((size_t)n_buckets);
+    for (uint32_t b = 0; b < n_buckets; ++b) order[b] = b;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return buckets[x].size() > buckets[y].size(); });
     std::vector<uint8_t> disp;
     for (;;) {
         std::vector<uint8_t> used((size_t)cap, 0);
-        disp.assign((size_t)SHORTW_BUCKETS, 0);
+        disp.assign((size_t)n_buckets, 0);
         bool ok = true;
         std::vector<uint32_t> slots;
         for (uint32_t b : order) {
@@ -622,7 +627,8 @@ void build_shortw_table(tkamd_tokenizer* t) {
     t->dt.shortw = t->t_shortw.p;
     t->dt.shortw_disp = t->t_shortw_disp.as<uint8_t>();
     t->dt.shortw_mask = cap - 1;
-    if (getenv("TKAMD_DEBUG_TABLES")) fprintf(stderr, "[tkamd] short-word table: %zu words in %u slots of 16 + 4 bytes, %d buckets\n", ws.size(), cap, SHORTW_BUCKETS);
+    t->dt.shortw_bmask = n_buckets - 1u;
+    if (getenv("TKAMD_DEBUG_TABLES")) fprintf(stderr, "[tkamd] short-word table: %zu words in %u slots of 16 + 4 bytes, %u buckets\n", ws.size(), cap, n_buckets);
 }
 
 // Hot-word table of the lookup kernel: the settled words of <= 12 bytes with the lowest ids, direct mapped (tables.hpp).

@@ -31,6 +31,7 @@ struct DevTables {
     const uint32_t* shortw_k3;        // bytes 12..15 of the key in slot i
     const uint8_t* shortw_disp;       // [SHORTW_BUCKETS] eight-bit displacements (the lookup kernel keeps them in LDS)
     uint32_t shortw_mask;
+    uint32_t shortw_bmask;            // buckets - 1 of the displacement array (SHORTW_BUCKETS of them; four times that for vocabularies beyond 65,536 words)
     uint32_t ignore_merges;
     uint32_t long_probe_max_len;      // whole-word probes of keys > 16 bytes only up to this length (WordPiece: max_input_chars)
     uint32_t unk_id, has_unk;

@@ -60,6 +60,7 @@ void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* 
     a.counters = counters;
     a.shortw = (const uint4*)t.shortw;
     a.shortw_mask = t.shortw_mask;
+    a.shortw_bmask = t.shortw_bmask;
     a.shortw_disp = t.shortw_disp;
     a.shortw_k3 = t.shortw_k3;
     a.word_seed = t.word_seed;
@@ -113,6 +114,7 @@ void launch_lookup_fused(hipStream_t st, int grid, const DevTables& t, const uin
     a.counters = counters;
     a.shortw = (const uint4*)t.shortw;
     a.shortw_mask = t.shortw_mask;
+    a.shortw_bmask = t.shortw_bmask;
     a.shortw_disp = t.shortw_disp;
     a.shortw_k3 = t.shortw_k3;
     a.word_seed = t.word_seed;

@@ -84,6 +84,7 @@ struct LookupArgs {
     const uint32_t* shortw_k3;       // bytes 12..15 of the key in slot i (read by the pre-tokens longer than 12 bytes only)
     const uint8_t* shortw_disp;      // [SHORTW_BUCKETS] the displacements: copied into LDS (shape HOT = 2048)
     uint32_t shortw_mask;
+    uint32_t shortw_bmask;           // displacement buckets - 1
     uint32_t any_hit_final;          // ignore_merges / WordLevel / WordPiece: every hit is final (else only WORD_DIRECT ones)
     uint32_t no_hits;                // WordPiece with max_input_chars_per_word < 16: every word takes the trie walk
     uint32_t miss_is_unk;            // WordLevel: a miss of <= 16 bytes is the unk id (or MissingUnkToken), never queued
@@ -161,9 +162,11 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
     static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
     for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
-    if (Shape::DISP_LDS)
+    // (the displacements of a large vocabulary's table -- four times the buckets -- stay in memory in either shape)
+    const bool disp_lds = Shape::DISP_LDS && a.shortw_bmask == (uint32_t)(SHORTW_BUCKETS - 1);
+    if (disp_lds)
         for (int i = tid; i < SHORTW_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.shortw_disp)[i];
-    const uint8_t* const wdisp = Shape::DISP_LDS ? (const uint8_t*)s_wdisp : a.shortw_disp;
+    const uint8_t* const wdisp = disp_lds ? (const uint8_t*)s_wdisp : a.shortw_disp;
     if (FUSED && tid < 256) {
         const Gpt2Flags f = gpt2_byte_flags((uint32_t)tid);
 #pragma unroll
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 x.a0 = make_uint4(0u, 0u, 0u, 0u);
                 if (x.probe) {                                                      // displacement from LDS, then ONE 16-byte request (+ 4 bytes for the few keys longer than 12)
                     x.h1 = word_hash1_from_hot(hot_hash(x.k0, x.k1, x.k2, x.len, a.word_seed), x.k3);
-                    const uint32_t slot = shortw_slot(x.h1, shortw_kmix(x.k0, x.k1, x.k2, x.k3), (uint32_t)wdisp[x.h1 & (uint32_t)(SHORTW_BUCKETS - 1)], a.shortw_mask);
+                    const uint32_t slot = shortw_slot(x.h1, shortw_kmix(x.k0, x.k1, x.k2, x.k3), (uint32_t)wdisp[x.h1 & a.shortw_bmask], a.shortw_mask);
                     x.a0 = a.shortw[slot];
                     if (x.len > (uint32_t)HOT_MAX_KEY) x.k3t = a.shortw_k3[slot];
                 }
