@@ -260,6 +260,7 @@ inline unsigned simt_mbcnt(unsigned mask, unsigned acc, int lo_half) {
 #define __builtin_amdgcn_mbcnt_lo(m, a) simt_mbcnt((m), (a), 1)
 #define __builtin_amdgcn_mbcnt_hi(m, a) simt_mbcnt((m), (a), 0)
 inline unsigned long long __builtin_amdgcn_s_memtime() { return 0ull; }      // (phase timers of the diagnostic kernel instantiations: no clock here)
+inline void __builtin_amdgcn_sched_barrier(int) {}                                 // (an instruction-scheduling fence: nothing to order here)
 inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) { return (unsigned)(((((uint64_t)hi) << 32) | lo) >> (8 * (sh & 3))); }
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }

@@ -43,14 +43,15 @@ __device__ __forceinline__ uint32_t claim_slot_of(const uint8_t* __restrict__ te
 }
 // len_word: the queue entry's length word (QLEN_CLAIM and all)
 __device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len_word, const uint4& row,
-                                                   uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
+                                                   uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos, uint8_t* __restrict__ ccnt) {
     if (!(len_word & QLEN_CLAIM)) return;
     const uint32_t slot = claim_slot_of(text, s, qitem_len(len_word), seed, claim_mask);
     crows[slot] = row;
+    if (ccnt) ccnt[slot] = (uint8_t)row_count(row);           // (a claimed word has at most CLAIM_MAX_LEN bytes, so as many tokens)
     if (cpos) cpos[slot] = s;
 }
 // (t.pub_rows: set by the host when the model kernels are to publish -- DevTables is what every one of them is handed)
-#define TKAMD_PUBLISH_ROW(t_, text_, s_, lenw_, row_) do { if ((t_).pub_rows) claim_publish_item((text_), (t_).word_seed, (s_), (lenw_), (row_), (t_).pub_mask, (uint4*)(t_).pub_rows, (t_).pub_pos); } while (0)
+#define TKAMD_PUBLISH_ROW(t_, text_, s_, lenw_, row_) do { if ((t_).pub_rows) claim_publish_item((text_), (t_).word_seed, (s_), (lenw_), (row_), (t_).pub_mask, (uint4*)(t_).pub_rows, (t_).pub_pos, (t_).pub_cnt); } while (0)
 
 // whole-word probe of a key longer than 16 bytes: hash and compare four bytes at a time (dword loads at any alignment; the text
 // carries TEXT_PAD readable bytes past its end, the vocabulary blob 16)
@@ -93,6 +94,18 @@ __device__ __forceinline__ void merge_probe_d(const DevTables& t, const uint16_t
     bool hit = x.x == a && x.y == b;
     *rank = hit ? x.z : RANK_NONE;
     *new_id = hit ? x.w : 0u;
+}
+// two independent probes (the two new pairs a merge leaves): both displacements, then both slots -- the two loads are in flight together
+__device__ __forceinline__ void merge_probe2_d(const DevTables& t, const uint16_t* disp, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t* rank1, uint32_t* rank2) {
+    const uint32_t d1 = disp[merge_hash1(a1, b1, t.merge_seed) & t.merge_bmask], d2 = disp[merge_hash1(a2, b2, t.merge_seed) & t.merge_bmask];
+    const uint4* const m = (const uint4*)t.merges;
+    const uint32_t s1 = ph_slot(merge_hash2(a1, b1, t.merge_seed), d1, t.merge_mask), s2 = ph_slot(merge_hash2(a2, b2, t.merge_seed), d2, t.merge_mask);
+    // (left alone the compiler sinks the second symbol's select chain -- and with it the second probe -- below the first probe's wait)
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4 x1 = m[s1], x2 = m[s2];
+    __builtin_amdgcn_sched_barrier(0);
+    *rank1 = (x1.x == a1 && x1.y == b1) ? x1.z : RANK_NONE;
+    *rank2 = (x2.x == a2 && x2.y == b2) ? x2.z : RANK_NONE;
 }
 __device__ __forceinline__ void merge_probe(const DevTables& t, uint32_t a, uint32_t b, uint32_t* rank, uint32_t* new_id) {
     merge_probe_d(t, t.merge_disp, a, b, rank, new_id);
@@ -378,7 +391,11 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
     const uint32_t n_first = qview_prefix(v, s_qpre);
     if (S == 16 && t.thin_limit && n_first < t.thin_limit) return;
     for (uint32_t i = tid; i < 256; i += NT) s_byte_id[i] = t.byte_id[i];
-    const bool disp_in_lds = DISP_LDS && t.merge_bmask < (uint32_t)DISP_LDS_MAX;
+    // (DISP_LDS is the launcher's choice: only for a displacement table that fits.  A pointer that is the LDS copy or the table in memory
+    // by a RUN-TIME test is a flat pointer: its loads count on both memory counters and return in no order, so the compiler waits for
+    // everything in flight behind every one of them -- up to round 5 each of a word's up to 31 first probes, and both probes of every
+    // merge, was a round trip of its own: s_waitcnt vmcnt(0) lgkmcnt(0) around each in the ISA)
+    constexpr bool disp_in_lds = DISP_LDS;
     if (disp_in_lds) {
         // sixteen bytes a load (eight displacements): with thin queues the kernel is as long as its prologue plus one word's chain of
         // merges, and 2-byte loads made the prologue twenty dependent round trips per lane
@@ -387,7 +404,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
         for (uint32_t i = tid; i < n16; i += NT) ((uint4*)s_disp)[i] = ((const uint4*)t.merge_disp)[i];
     }
     __syncthreads();
-    const uint16_t* disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
+    const uint16_t* const disp = disp_in_lds ? (const uint16_t*)s_disp : t.merge_disp;
     const uint32_t nid_base = t.newid_base;
     uint32_t n_second = (S == 32 && v2.q) ? qview_prefix(v2, s_qpre2) : 0u;
     if (t.thin_limit && n_second >= t.thin_limit) n_second = 0u;   // (fat: the 16-symbol kernel's)
@@ -458,15 +475,34 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                     ids[i] = s_byte_id[TKAMD_BYTE_AT(i)];
                     if (!SYM_REGS) my_sym[i * NT] = ids[i];
                 }
+                // The first probes, one per pair of neighbours: EIGHT at a time, unconditionally (a lane whose word ends earlier probes the
+                // pair of whatever its padding bytes map to and drops the answer) -- the eight loads are in flight together, where a probe
+                // under `if (i + 1 < len)` that is also consumed there is a round trip of its own.  A group no word of the wavefront reaches
+                // (the workgroup's words are sorted by length) is skipped as a whole: a scalar branch.
+                uint32_t wmax = valid ? len : 0u;
 #pragma unroll
-                for (int i = 0; i < S; ++i) {
-                    uint32_t k = 0xFFFFFFFFu;
-                    if (i < S - 1 && (uint32_t)(i + 1) < len) {
-                        uint32_t r, nd;
-                        merge_probe_d(t, disp, ids[i], ids[i + 1], &r, &nd);
-                        if (r != RANK_NONE) k = (r << PB) | (uint32_t)i;
+                for (int d_ = 32; d_ >= 1; d_ >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d_, 64));
+                wmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wmax);
+                constexpr int PG = 8;
+#pragma unroll
+                for (int g = 0; g < S; g += PG) {
+                    if ((uint32_t)(g + 1) < wmax) {
+                        uint32_t rk[PG];
+#pragma unroll
+                        for (int q = 0; q < PG; ++q) {
+                            const int i = g + q;
+                            rk[q] = RANK_NONE;
+                            if (i < S - 1) { uint32_t nd; merge_probe_d(t, disp, ids[i], ids[i + 1], &rk[q], &nd); }
+                        }
+#pragma unroll
+                        for (int q = 0; q < PG; ++q) {
+                            const int i = g + q;
+                            my_key[i * NT] = ((uint32_t)(i + 1) < len && rk[q] != RANK_NONE) ? ((rk[q] << PB) | (uint32_t)i) : 0xFFFFFFFFu;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < PG; ++q) my_key[(g + q) * NT] = 0xFFFFFFFFu;
                     }
-                    my_key[i * NT] = k;
                 }
                 alive0 = (len >= 32) ? 0xFFFFFFFFu : ((1u << len) - 1u);
             } else {
@@ -547,9 +583,8 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
 #pragma unroll
                         for (int q = 0; q < S; ++q) ids[q] = (i == (uint32_t)q) ? nid : ids[q];
                     } else my_sym[i * NT] = nid;
-                    uint32_t r1, r2, nd;
-                    merge_probe_d(t, disp, sl, nid, &r1, &nd);
-                    merge_probe_d(t, disp, nid, sr, &r2, &nd);
+                    uint32_t r1, r2;
+                    merge_probe2_d(t, disp, sl, nid, nid, sr, &r1, &r2);
                     my_key[j * NT] = 0xFFFFFFFFu;
                     my_key[i * NT] = (has_k && r2 != RANK_NONE) ? ((r2 << PB) | i) : 0xFFFFFFFFu;
                     if (has_h) my_key[h * NT] = (r1 != RANK_NONE) ? ((r1 << PB) | h) : 0xFFFFFFFFu;

@@ -808,7 +808,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
 // the compaction finds it for the word's other occurrences.  The two halves of the grid take the two queue classes.
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
-                                                        uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
+                                                        uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos, uint8_t* __restrict__ ccnt) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t half = gridDim.x >> 1;
     const QView v = blockIdx.x >= half ? v1 : v0;
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
     for (uint32_t item = (blockIdx.x % half) * 256 + threadIdx.x; item < n; item += half * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
-        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claim_mask, crows, cpos);
+        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claim_mask, crows, cpos, ccnt);
     }
 }
 
