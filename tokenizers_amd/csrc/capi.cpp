@@ -212,7 +212,6 @@ struct Workspace {
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
     DevBuf w_lstate;                             // look-back state of the fused pre-tokenizer + lookup pass (kernels/lookup.hip FUSED)
-    DevBuf w_claim_cnt;                          // ... and the rows' token counts, one byte a slot (WordCache::claim_cnt)
     DevBuf w_claims, w_claim_rows, w_claim_pos;  // in-batch word claims (kernels.hpp WordCache::claims), the rows of the claimed slots, the claimants' first bytes
     DevBuf w_phases;                             // TKAMD_PHASES: shader-clock ticks per phase of the lookup / compaction, [2][PHASE_WGS][8] u64 (tkamd_debug_phases)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
@@ -1565,9 +1564,6 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             uint32_t* cpos = nullptr;                        // (the claimants' first bytes: only k_token_meta wants them)
             if (off_mode != TKAMD_OFFSETS_NONE) { w->w_claim_pos.reserve(claim_slots * 4); cpos = w->w_claim_pos.as<uint32_t>(); }
             wc = WordCache{nullptr, w->w_claim_rows.p, (unsigned long long*)w->w_claims.p, (uint32_t)(claim_slots - 1), cpos};
-            // one byte per slot: the row's token count, what the compaction asks for ahead of the row (output.hip cp_load_rows; TKAMD_CP_CNT=1 selects it)
-            static const bool cnt_on = [] { const char* e = getenv("TKAMD_CP_CNT"); return e && !strcmp(e, "1"); }();
-            if (cnt_on) { w->w_claim_cnt.reserve(claim_slots + 16); wc.claim_cnt = w->w_claim_cnt.as<uint8_t>(); }
             return;
         }
         if (!t->word_cache || off_mode != TKAMD_OFFSETS_NONE) return;        // (a cached row carries no token ends)
@@ -1616,7 +1612,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     bool pub_inline = false;
     auto set_publish = [&]() {
         pub_inline = wc.claims && !pub_kernel;
-        if (pub_inline) { mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; mdt.pub_pos = wc.claim_pos; mdt.pub_cnt = wc.claim_cnt; }
+        if (pub_inline) { mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; mdt.pub_pos = wc.claim_pos; }
     };
     if (hm.model == MODEL_BPE) {
         pf.begin(fused ? "pretok_scan_lookup" : "lookup");
@@ -1759,8 +1755,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
     launch_compact(st, t->cp_grid, t->cp_items, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
-                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>(), (size_t)t->cp_grid <= PHASE_WGS ? phases_of(1) : nullptr,
-                   wc.claims ? wc.claim_cnt : nullptr);
+                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>(), (size_t)t->cp_grid <= PHASE_WGS ? phases_of(1) : nullptr);
     pf.end();
     const uint32_t* word_of_doc = nullptr;
     const int64_t* first_tok = nullptr;
@@ -2012,6 +2007,9 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
                           hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !hm.add_prefix_space;
         }
         build_shortw_table(t.get());
+        // (the 2,048-slot shape keeps the short-word table's displacements in LDS -- SHORTW_BUCKETS of them, known at compile time; a
+        // vocabulary whose table has more buckets runs the default shape)
+        if (t->dt.shortw_bmask != (uint32_t)(SHORTW_BUCKETS - 1)) t->hot_slots = 1024;
         build_hot_table(t.get());
         if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
         if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);

@@ -25,7 +25,6 @@ struct DevTables {
     // the rows of the claimed slots, the slot mask, and -- only when offsets are requested -- where the claimant's first byte goes
     void* pub_rows;
     uint32_t* pub_pos;
-    uint8_t* pub_cnt;                 // ... and one BYTE per slot: the row's token count, what the compaction needs of a slot before it needs the row (output.hip) -- or null
     uint32_t pub_mask;
     uint32_t word_seed;               // seed of the whole-word hashes (the two-choice table of record lives on the host, tables.hpp)
     const void* shortw;               // the short-word table (tables.hpp): every whole word of <= 16 bytes in 16-byte slots
@@ -92,7 +91,6 @@ struct WordCache {
     unsigned long long* claims;
     uint32_t claim_mask;         // slots - 1 (a power of two, sized from the batch by the host)
     uint32_t* claim_pos;         // [slots] first byte of the claimant (written with its row; k_token_meta reads it): only when offsets are requested, else null
-    uint8_t* claim_cnt = nullptr;    // [slots] token count of the slot's row, one byte (written with the row; the compaction reads it ahead of the row), or null
 };
 
 // buffers zeroed by one launch (launch_zero_regions)
@@ -417,7 +415,7 @@ void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const u
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
-                    int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr, const uint8_t* slot_cnt = nullptr);
+                    int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr);
 int compact_grid(int n_cu, int cp_items);
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
 void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n, unsigned long long* mask = nullptr, int64_t mask_words = 0, int grid = 1);      // n <= 256 zero bytes at p[*len_dev ..]; mask: its words below (*len_dev >> 6) + 3 zeroed too

@@ -43,15 +43,14 @@ __device__ __forceinline__ uint32_t claim_slot_of(const uint8_t* __restrict__ te
 }
 // len_word: the queue entry's length word (QLEN_CLAIM and all)
 __device__ __forceinline__ void claim_publish_item(const uint8_t* __restrict__ text, uint32_t seed, uint32_t s, uint32_t len_word, const uint4& row,
-                                                   uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos, uint8_t* __restrict__ ccnt) {
+                                                   uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
     if (!(len_word & QLEN_CLAIM)) return;
     const uint32_t slot = claim_slot_of(text, s, qitem_len(len_word), seed, claim_mask);
     crows[slot] = row;
-    if (ccnt) ccnt[slot] = (uint8_t)row_count(row);           // (a claimed word has at most CLAIM_MAX_LEN bytes, so as many tokens)
     if (cpos) cpos[slot] = s;
 }
 // (t.pub_rows: set by the host when the model kernels are to publish -- DevTables is what every one of them is handed)
-#define TKAMD_PUBLISH_ROW(t_, text_, s_, lenw_, row_) do { if ((t_).pub_rows) claim_publish_item((text_), (t_).word_seed, (s_), (lenw_), (row_), (t_).pub_mask, (uint4*)(t_).pub_rows, (t_).pub_pos, (t_).pub_cnt); } while (0)
+#define TKAMD_PUBLISH_ROW(t_, text_, s_, lenw_, row_) do { if ((t_).pub_rows) claim_publish_item((text_), (t_).word_seed, (s_), (lenw_), (row_), (t_).pub_mask, (uint4*)(t_).pub_rows, (t_).pub_pos); } while (0)
 
 // whole-word probe of a key longer than 16 bytes: hash and compare four bytes at a time (dword loads at any alignment; the text
 // carries TEXT_PAD readable bytes past its end, the vocabulary blob 16)

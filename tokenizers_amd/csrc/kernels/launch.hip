@@ -203,7 +203,7 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
 }
 void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
                        const WordCache& wc) {
-    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err, wc.claim_mask, wc.claims ? (uint4*)wc.rows : (uint4*)nullptr, wc.claim_pos, wc.claims ? wc.claim_cnt : (uint8_t*)nullptr);
+    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err, wc.claim_mask, wc.claims ? (uint4*)wc.rows : (uint4*)nullptr, wc.claim_pos);
 }
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err) {
@@ -333,14 +333,14 @@ int compact_grid(int n_cu, int cp_items) {
     return per_cu * n_cu;
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
-    hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claim_mask, (uint4*)wc.rows, wc.claim_pos, wc.claim_cnt);
+    hipLaunchKernelGGL(k_claims_publish, dim3(2 * grid), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], (const uint4*)rows, wc.claim_mask, (uint4*)wc.rows, wc.claim_pos);
 }
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc) {
     hipLaunchKernelGGL(k_word_cache_insert, dim3(grid), dim3(256), 0, st, t, text, v, (const uint4*)rows, wc);
 }
 void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
-                    int64_t n_docs, int64_t* tok_offsets, void* phases, const uint8_t* slot_cnt) {
+                    int64_t n_docs, int64_t* tok_offsets, void* phases) {
     static_assert(COMPACT_CHUNK_MIN == CpShape<2>::CHUNK, "the host sizes the look-back state and chunk_lo by the smallest chunk");
     unsigned long long* const ph = (unsigned long long*)phases;
     // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); TKAMD_LB_PATIENCE: tests set it to a
@@ -353,17 +353,14 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
     }();
     if (ph && cp_items == 4)                                 // the diagnostic instantiation (TKAMD_PHASES)
         hipLaunchKernelGGL((k_compact<4, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, slot_cnt);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 2)
         hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, slot_cnt);
-    else if (cp_items == 4 && slot_cnt)
-        hipLaunchKernelGGL((k_compact<4, false, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, slot_cnt);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 4)
         hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, slot_cnt);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else
         hipLaunchKernelGGL(k_compact<8>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, slot_cnt);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
 }

@@ -162,8 +162,9 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
     static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
     for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
-    // (the displacements of a large vocabulary's table -- four times the buckets -- stay in memory in either shape)
-    const bool disp_lds = Shape::DISP_LDS && a.shortw_bmask == (uint32_t)(SHORTW_BUCKETS - 1);
+    // (a large vocabulary's table has four times the buckets: the host runs it in the shape that leaves the displacements in memory --
+    // which of the two a shape reads is a compile-time fact, a pointer chosen at run time would be a flat one)
+    constexpr bool disp_lds = Shape::DISP_LDS;
     if (disp_lds)
         for (int i = tid; i < SHORTW_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.shortw_disp)[i];
     const uint8_t* const wdisp = disp_lds ? (const uint8_t*)s_wdisp : a.shortw_disp;
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
 // the compaction finds it for the word's other occurrences.  The two halves of the grid take the two queue classes.
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
-                                                        uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos, uint8_t* __restrict__ ccnt) {
+                                                        uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t half = gridDim.x >> 1;
     const QView v = blockIdx.x >= half ? v1 : v0;
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8
     for (uint32_t item = (blockIdx.x % half) * 256 + threadIdx.x; item < n; item += half * 256) {
         const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
         const QItem it = v.q[qpos];
-        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claim_mask, crows, cpos, ccnt);
+        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claim_mask, crows, cpos);
     }
 }
 

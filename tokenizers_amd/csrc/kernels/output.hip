@@ -64,54 +64,19 @@ __device__ __forceinline__ void cp_load_tok0(const uint32_t* __restrict__ tok0, 
     }
 }
 template <int CP_ITEMS> struct CpAhead { CpTok0<CP_ITEMS> f; uint32_t dlo, dhi; };     // what k_compact loads a chunk ahead
-// ccnt (round 5, the claims' path): one BYTE per claimed slot, the token count of its row, written with the row (bpe.hip
-// claim_publish_item).  A chunk's total -- what its successors' look-backs wait for -- needs the COUNTS of its rows only; the rows of the
-// claimed slots are 16 bytes at random places of a table of 32 MB (2 M slots for C2's 0.28 M words: 42 % of these loads hit the L2), their
-// counts a table of 2 MB.  The counts and the queued words' own rows (a dense 4 MB) are requested first, the slots' rows behind them:
-// loads return in order, so the total is there -- and published -- while the slots' rows are still on their way to the copy-out.
-// (the rows of the claimed slots while they are still in flight: registers of their own, so that nothing written before the chunk's
-// total is published has to wait for them -- cp_settle moves them into place)
-template <int CP_ITEMS> struct CpLate { uint4 x[CP_ITEMS]; };
 template <int CP_ITEMS>
-__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, const uint8_t* __restrict__ ccnt,
-                                                 CpRows<CP_ITEMS>& r, CpLate<CP_ITEMS>& late) {
+__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
     const uint32_t* const first = f.w;
     // EVERY word loads a row -- one that names none (seven of eight at C2) loads row 0 and drops it.  A load under `if (names a row)`
     // whose other branch fills the same registers with the inline token makes the compiler wait for the load before that branch may
     // write them (a write-after-write on the registers, whatever the lanes): up to round 5 the CP_ITEMS gathers of a lane went out one
     // after the other, a memory round trip each (s_waitcnt vmcnt(0) behind every one of them in the ISA), although a wavefront all of
-    // whose 64 lanes skip a given load is one in thousands.  Unconditional, they are all in flight together.
+    // whose 64 lanes skip a given load is one in thousands.  Unconditional, they are all in flight together (0.140 -> 0.126 ms at C2,
+    // profiles/r5l_ab_c2.txt).
+    // (Also tried there: one BYTE per claimed slot with the row's token count, read ahead of the row so that the chunk's total is
+    // published while the slots' rows are still in flight -- the rows then need registers of their own until the copy-out, the kernel
+    // spills at five workgroups per CU, and it measured 0.151 ms.)
     uint4 ld[CP_ITEMS];
-    uint32_t c8[CP_ITEMS];
-    if (ccnt) {
-        // the counts of the claimed slots (one byte each) and the queued words' own rows first, the slots' rows behind them: loads return
-        // in order, so the chunk's total is known -- and published -- while the slots' rows are still on their way to the copy-out
-#pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            const bool slot = (first[k] & TOK_SLOT) == TOK_SLOT;
-            c8[k] = ccnt[slot ? (first[k] & TOK_REF_MASK) : 0u];
-        }
-#pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            const bool own = (first[k] & TOK_SLOT) == TOK_ROW;
-            ld[k] = rows[own ? (first[k] & TOK_REF_MASK) : 0u];
-        }
-        uint32_t v = 0;
-#pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {
-            const bool slot = (first[k] & TOK_SLOT) == TOK_SLOT, own = (first[k] & TOK_SLOT) == TOK_ROW;
-            const uint4 in = make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
-            r.row[k] = own ? ld[k] : in;
-            r.cnt[k] = slot ? c8[k] : row_count(r.row[k]);
-            v += r.cnt[k];
-        }
-#pragma unroll
-        for (int k = 0; k < CP_ITEMS; ++k) {                // (the slots' rows: needed by the copy-out only -- cp_settle)
-            const bool slot = (first[k] & TOK_SLOT) == TOK_SLOT;
-            late.x[k] = crows[slot ? (first[k] & TOK_REF_MASK) : 0u];
-        }
-        return v;
-    }
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) {
         const uint4* const src = ((first[k] & TOK_SLOT) == TOK_SLOT) ? crows : rows;
@@ -127,21 +92,10 @@ __device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, cons
     return v;
 }
 template <int CP_ITEMS>
-__device__ __forceinline__ void cp_settle(const CpTok0<CP_ITEMS>& f, const uint8_t* __restrict__ ccnt, CpRows<CP_ITEMS>& r, const CpLate<CP_ITEMS>& late) {
-    if (!ccnt) return;
-#pragma unroll
-    for (int k = 0; k < CP_ITEMS; ++k)
-        if ((f.w[k] & TOK_SLOT) == TOK_SLOT) r.row[k] = late.x[k];
-}
-template <int CP_ITEMS>
-__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, const uint8_t* __restrict__ ccnt,
-                                            int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
+__device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
     CpTok0<CP_ITEMS> f;
-    CpLate<CP_ITEMS> late;
     cp_load_tok0<CP_ITEMS>(tok0, p0, P, f);
-    const uint32_t v = cp_load_rows<CP_ITEMS>(f, rows, crows, ccnt, r, late);
-    cp_settle<CP_ITEMS>(f, ccnt, r, late);
-    return v;
+    return cp_load_rows<CP_ITEMS>(f, rows, crows, r);
 }
 #define TKAMD_CP_SCATTER(DST, R, O)                                                                           \
     _Pragma("unroll") for (int k = 0; k < CP_ITEMS; ++k) {                                                    \
@@ -176,16 +130,13 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 // 0 loads + scan + publish of front(), 1 its LDS scatter, 2 the look-back wait, 3 the copy-out, 7 the whole kernel)
 // (min. wavefronts per SIMD: 5 -- five workgroups per CU, <= 96 VGPRs -- for the shapes of 2 and 4 pre-tokens per lane, whose 28 KB of LDS
 // allow it; the helper of the look-back must not cost the main path its occupancy)
-// (CNT: the instantiation that reads the claimed slots' token counts ahead of their rows -- cp_load_rows; its extra registers are its own)
-template <int CP_ITEMS, bool PROF = false, bool CNT = false>
+template <int CP_ITEMS, bool PROF = false>
 __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
-                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience,
-                                                   const uint8_t* __restrict__ ccnt_arg) {
-    const uint8_t* const ccnt = CNT ? ccnt_arg : nullptr;
+                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience) {
     constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
     unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto tick = [&](int k) {
@@ -217,8 +168,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
         const uint32_t dlo = a.dlo, dhi = a.dhi;
         CpRows<CP_ITEMS> r;
-        CpLate<CP_ITEMS> late;
-        const uint32_t v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, ccnt, r, late);
+        const uint32_t v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, r);
         const bool has_doc = dlo + (uint32_t)tid < dhi;
         uint32_t my_docpt = 0u;
         if (has_doc) my_docpt = doc_pt[dlo + (uint32_t)tid];
@@ -231,8 +181,6 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         uint32_t acc = ex;
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) { s_loc[b][tid * CP_ITEMS + k] = acc; acc += r.cnt[k]; }
-        if (CNT) __builtin_amdgcn_sched_barrier(0);       // (nothing of the copy-out's side moves in front of the publication)
-        cp_settle<CP_ITEMS>(a.f, ccnt, r, late);          // (the claimed slots' rows: this is where they are first needed)
         if (tot <= (uint32_t)CP_STAGE) {
             uint32_t o = ex;
             uint32_t* const dst = s_stage[b];
@@ -246,7 +194,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
 #pragma unroll 1
         for (int j = 0; j < CP_NT / 64; ++j) {
             CpRows<CP_ITEMS> r;
-            v += cp_load<CP_ITEMS>(tok0, rows, crows, ccnt, hc * CP_CHUNK + (int64_t)(j * 64 + (tid & 63)) * CP_ITEMS, P, r);
+            v += cp_load<CP_ITEMS>(tok0, rows, crows, hc * CP_CHUNK + (int64_t)(j * 64 + (tid & 63)) * CP_ITEMS, P, r);
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
@@ -308,7 +256,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         } else {                                           // rare: too many tokens for the buffer -- scatter from the rows
             const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
             CpRows<CP_ITEMS> r;
-            cp_load<CP_ITEMS>(tok0, rows, crows, ccnt, p0, P, r);
+            cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
             uint32_t o = s_loc[b][tid * CP_ITEMS];
             uint32_t* const dst = ids + base;
             TKAMD_CP_SCATTER(dst, r, o)

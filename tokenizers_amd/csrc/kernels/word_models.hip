@@ -21,7 +21,7 @@
 // A retired entry that holds the in-batch claim of its word (lookup.hip) publishes its row here: k_claims_publish no longer sees it.
 __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
                                                     uint32_t miss_is_unk, int* __restrict__ err, uint32_t claim_mask, uint4* __restrict__ crows,
-                                                    uint32_t* __restrict__ cpos, uint8_t* __restrict__ ccnt) {
+                                                    uint32_t* __restrict__ cpos) {
     __shared__ uint32_t s_qpre[NSQ + 1];
     const uint32_t n = qview_prefix(v, s_qpre);
     for (uint32_t item = blockIdx.x * 256 + threadIdx.x; item < n; item += gridDim.x * 256) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_long_vocab(DevTables t, const uint8_t* 
         if (hit || miss_is_unk) {
             const uint4 row = hit ? make_uint4(id | (1u << ROW_CNT_SHIFT), ROW_WHOLE_WORD, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
             rows[v.row_base + qpos] = row;
-            if (crows) claim_publish_item(text, t.word_seed, it.s, it.len, row, claim_mask, crows, cpos, ccnt);
+            if (crows) claim_publish_item(text, t.word_seed, it.s, it.len, row, claim_mask, crows, cpos);
             v.q[qpos].len = 0u;
         }
     }
