@@ -244,9 +244,11 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         {
             const uint32_t dlo = s_dlo[b], dhi = s_dhi[b];
             for (uint32_t d = dlo + (uint32_t)tid; d < dhi; d += CP_NT) {
-                uint32_t dp;                              // (two loads in two branches: one expression would be a load through a flat pointer, which waits for every load in flight)
-                if (d - dlo < (uint32_t)CP_NT) dp = s_docpt[b][d - dlo];
-                else dp = doc_pt[d];
+                // (the LDS copy read by every lane, the array in memory only by the lanes beyond it -- through a volatile access: `in LDS ?
+                // s_docpt[..] : doc_pt[..]`, and two plain loads in two branches, which the compiler folds back into it, is ONE load
+                // through a flat pointer, which waits for everything in flight)
+                uint32_t dp = s_docpt[b][(d - dlo) & (uint32_t)(CP_NT - 1)];
+                if (d - dlo >= (uint32_t)CP_NT) dp = *(const volatile uint32_t*)(doc_pt + d);
                 const uint32_t local = dp - (uint32_t)pc;
                 tok_offsets[d] = (int64_t)(base + (local < (uint32_t)CP_CHUNK ? s_loc[b][local] : tot));
             }
