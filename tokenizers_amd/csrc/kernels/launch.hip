@@ -343,6 +343,7 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                     int64_t n_docs, int64_t* tok_offsets, void* phases) {
     static_assert(COMPACT_CHUNK_MIN == CpShape<2>::CHUNK, "the host sizes the look-back state and chunk_lo by the smallest chunk");
     unsigned long long* const ph = (unsigned long long*)phases;
+    static const bool early = [] { const char* e = getenv("TKAMD_CP_EARLY"); return !(e && !strcmp(e, "0")); }();      // (k_compact EARLY: the look-back's first read at the top of the iteration; 0 = A/B)
     // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); TKAMD_LB_PATIENCE: tests set it to a
     // handful so that the helping path runs on every wait
     // (a test hook: read only next to TKAMD_TEST_HOOKS=1, like the ones of capi.cpp)
@@ -356,6 +357,9 @@ void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0
                            chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 2)
         hipLaunchKernelGGL(k_compact<2>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
+    else if (cp_items == 4 && !early)
+        hipLaunchKernelGGL((k_compact<4, false, false>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
                            chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
     else if (cp_items == 4)
         hipLaunchKernelGGL(k_compact<4>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,

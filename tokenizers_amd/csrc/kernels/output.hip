@@ -46,26 +46,35 @@ __device__ __forceinline__ void cp_load_tok0(const uint32_t* __restrict__ tok0, 
     static_assert(CP_ITEMS == 2 || CP_ITEMS == 4 || CP_ITEMS == 8, "one 8-byte, one or two 16-byte loads of tok0 per lane");
     uint32_t* const first = f.w;
     // (tok0 is read once: non-temporal, so that the rows the kernel gathers stay in the L2)
-    if (p0 + CP_ITEMS <= P) {
-        if (CP_ITEMS == 2) {
-            const uint2 a = load_nt((const uint2*)(tok0 + p0));
-            first[0] = a.x; first[CP_ITEMS - 1] = a.y;
-        } else {
-            const uint4 a = load_nt((const uint4*)(tok0 + p0));
-            first[0] = a.x; first[1] = a.y; first[CP_ITEMS > 2 ? 2 : 0] = a.z; first[CP_ITEMS > 3 ? 3 : 0] = a.w;
-        }
-        if (CP_ITEMS == 8) {
-            const uint4 b = load_nt((const uint4*)(tok0 + p0 + 4));
-            first[CP_ITEMS - 4] = b.x; first[CP_ITEMS - 3] = b.y; first[CP_ITEMS - 2] = b.z; first[CP_ITEMS - 1] = b.w;
-        }
+    // The wide load is UNCONDITIONAL -- a lane whose words reach beyond P (the batch's last chunk only) loads the array's first words
+    // instead and then fetches its words one by one.  Written as `if (whole) wide load else word loads`, the two branches fill the same
+    // registers and the compiler waits for the wide load right behind it (a write-after-write on the registers): the load a chunk
+    // AHEAD -- the whole point of CpAhead -- was a round trip at the top of every iteration (s_waitcnt vmcnt(0) seven instructions
+    // behind the load in the ISA of rounds 3 to 5).
+    const bool whole = p0 + CP_ITEMS <= P;
+    const int64_t pl = whole ? p0 : 0;
+    if (CP_ITEMS == 2) {
+        const uint2 a = load_nt((const uint2*)(tok0 + pl));
+        first[0] = a.x; first[CP_ITEMS - 1] = a.y;
     } else {
+        const uint4 a = load_nt((const uint4*)(tok0 + pl));
+        first[0] = a.x; first[1] = a.y; first[CP_ITEMS > 2 ? 2 : 0] = a.z; first[CP_ITEMS > 3 ? 3 : 0] = a.w;
+    }
+    if (CP_ITEMS == 8) {
+        const uint4 b = load_nt((const uint4*)(tok0 + pl + 4));
+        first[CP_ITEMS - 4] = b.x; first[CP_ITEMS - 3] = b.y; first[CP_ITEMS - 2] = b.z; first[CP_ITEMS - 1] = b.w;
+    }
+    if (!whole) {
 #pragma unroll
         for (int k = 0; k < CP_ITEMS; ++k) first[k] = (p0 + k < P) ? tok0[p0 + k] : 0u;
     }
 }
 template <int CP_ITEMS> struct CpAhead { CpTok0<CP_ITEMS> f; uint32_t dlo, dhi; };     // what k_compact loads a chunk ahead
+// the gathers of a lane's rows, issued (cp_issue_rows) and turned into rows and counts (cp_settle_rows) -- two steps, so that the DEEP
+// shape of the kernel can put a whole chunk of work between them
+template <int CP_ITEMS> struct CpGather { uint4 ld[CP_ITEMS]; };
 template <int CP_ITEMS>
-__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
+__device__ __forceinline__ void cp_issue_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpGather<CP_ITEMS>& g) {
     const uint32_t* const first = f.w;
     // EVERY word loads a row -- one that names none (seven of eight at C2) loads row 0 and drops it.  A load under `if (names a row)`
     // whose other branch fills the same registers with the inline token makes the compiler wait for the load before that branch may
@@ -76,20 +85,29 @@ __device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, cons
     // (Also tried there: one BYTE per claimed slot with the row's token count, read ahead of the row so that the chunk's total is
     // published while the slots' rows are still in flight -- the rows then need registers of their own until the copy-out, the kernel
     // spills at five workgroups per CU, and it measured 0.151 ms.)
-    uint4 ld[CP_ITEMS];
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) {
         const uint4* const src = ((first[k] & TOK_SLOT) == TOK_SLOT) ? crows : rows;
-        ld[k] = src[(first[k] & TOK_ROW) ? (first[k] & TOK_REF_MASK) : 0u];
+        g.ld[k] = src[(first[k] & TOK_ROW) ? (first[k] & TOK_REF_MASK) : 0u];
     }
+}
+template <int CP_ITEMS>
+__device__ __forceinline__ uint32_t cp_settle_rows(const CpTok0<CP_ITEMS>& f, const CpGather<CP_ITEMS>& g, CpRows<CP_ITEMS>& r) {
+    const uint32_t* const first = f.w;
     uint32_t v = 0;
 #pragma unroll
     for (int k = 0; k < CP_ITEMS; ++k) {
-        r.row[k] = (first[k] & TOK_ROW) ? ld[k] : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
+        r.row[k] = (first[k] & TOK_ROW) ? g.ld[k] : make_uint4((first[k] & TOK_ID_MASK) | (((first[k] & TOK_ONE) ? 1u : 0u) << ROW_CNT_SHIFT), 0u, 0u, 0u);
         r.cnt[k] = row_count(r.row[k]);
         v += r.cnt[k];
     }
     return v;
+}
+template <int CP_ITEMS>
+__device__ __forceinline__ uint32_t cp_load_rows(const CpTok0<CP_ITEMS>& f, const uint4* __restrict__ rows, const uint4* __restrict__ crows, CpRows<CP_ITEMS>& r) {
+    CpGather<CP_ITEMS> g;
+    cp_issue_rows<CP_ITEMS>(f, rows, crows, g);
+    return cp_settle_rows<CP_ITEMS>(f, g, r);
 }
 template <int CP_ITEMS>
 __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows, int64_t p0, int64_t P, CpRows<CP_ITEMS>& r) {
@@ -130,7 +148,11 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
 // 0 loads + scan + publish of front(), 1 its LDS scatter, 2 the look-back wait, 3 the copy-out, 7 the whole kernel)
 // (min. wavefronts per SIMD: 5 -- five workgroups per CU, <= 96 VGPRs -- for the shapes of 2 and 4 pre-tokens per lane, whose 28 KB of LDS
 // allow it; the helper of the look-back must not cost the main path its occupancy)
-template <int CP_ITEMS, bool PROF = false>
+// (Session Q also ran a shape with the rows of a chunk gathered a chunk ahead -- issued at the top of an iteration for the chunk after
+// next, settled at the top of the next one, 94 VGPRs: level, 0.1266 against 0.1250 ms -- the front's round trip is not what a chunk waits for.)
+// EARLY: the look-back's first read -- the 128 chunks in front -- goes out at the TOP of the iteration and is looked at behind front()
+// of the next chunk (results.hip lb_prefetch / lb_resolve_pre).
+template <int CP_ITEMS, bool PROF = false, bool EARLY = true>
 __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const uint32_t* __restrict__ tok0, const uint4* __restrict__ rows, const uint4* __restrict__ crows,
                                                    const uint32_t* __restrict__ tmp_ids, const int64_t* __restrict__ n_pretok,
                                                    unsigned long long* __restrict__ state,
@@ -168,9 +190,9 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         // (the last chunk also takes the documents that start behind the last pre-token: trailing empty ones and the closing entry)
         const uint32_t dlo = a.dlo, dhi = a.dhi;
         CpRows<CP_ITEMS> r;
-        const uint32_t v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, r);
         const bool has_doc = dlo + (uint32_t)tid < dhi;
         uint32_t my_docpt = 0u;
+        const uint32_t v = cp_load_rows<CP_ITEMS>(a.f, rows, crows, r);
         if (has_doc) my_docpt = doc_pt[dlo + (uint32_t)tid];
         uint32_t tot;
         const uint32_t ex = block256_excl_scan(v, sm, &tot);
@@ -221,14 +243,28 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
     }
     for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x, b ^= 1) {
         const int64_t nxt = ch + gridDim.x;
+        // EARLY: wavefront 0 asks for the states of the 128 chunks in front of `ch` NOW and looks at them behind front(nxt).  Every
+        // workgroup's look-back finds its predecessors' prefixes just in time -- the workgroups fell into step at the kernel's start, 64
+        // of them a round trip behind the 64 before -- so the read that starts when back() starts always costs its whole round trip
+        // (31..36 % of the kernel, three wavefronts at a barrier meanwhile); the prefixes some 64 to 128 chunks back are older:
+        // a read two windows wide often finds one of them, every total in between has long been published, and the answer is there when
+        // front(nxt) is done (compact 0.1245 -> 0.115 ms at C2, profiles/r5r_*, r5t_*).  What it does not settle, lb_resolve_pre goes on polling for like lb_resolve.
+        // (behind ahead_of: the compiler drains every memory operation of the last iteration in there -- the registers of `an` are the
+        // loop's own -- and a read issued in front of that would be waited for at once; from here it returns with front(nxt)'s gathers)
+        LbPre pre;
         CpAhead<CP_ITEMS> an;                              // ... and those of the one after it: in flight while front(nxt) works
         ahead_of(nxt + gridDim.x, an);
+        if (EARLY && tid < 64) lb_prefetch(state, ch, pre);
         if (nxt < n_chunks) front(nxt, b ^ 1, aa);        // (its two barriers also order this chunk's LDS writes before the reads below)
         else __syncthreads();
         aa = an;
         const uint32_t tot = s_tot[b];
         // the chunk's place in the token stream: wavefront 0 looks back (results.hip), the others wait at the barrier
-        if (tid < 64) { const unsigned long long r = lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total); if (tid == 0) s_lbw = r; }
+        if (tid < 64) {
+            const unsigned long long r = EARLY ? lb_resolve_pre(state, ch, (unsigned long long)tot, patience, chunk_total, pre)
+                                               : lb_resolve(state, ch, (unsigned long long)tot, patience, chunk_total);
+            if (tid == 0) s_lbw = r;
+        }
         __syncthreads();
         const unsigned long long base = s_lbw;
         tick(2);
