@@ -330,6 +330,10 @@ int compact_grid(int n_cu, int cp_items) {
     int per_cu = 0;
     const void* k = cp_items == 2 ? (const void*)k_compact<2> : cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    // (a CU holds 32 wavefronts: eight of these workgroups, whatever LDS and registers would allow -- the two-per-lane shape was handed
+    // a grid a quarter of which was not resident, and its look-backs waited out their patience on the chunks of workgroups that had not
+    // started: 6.7 ms instead of 0.13, session M; results equal either way, the look-back computes what it waits for)
+    per_cu = std::min(per_cu, 32 / (CP_NT / 64));
     return per_cu * n_cu;
 }
 void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc) {
