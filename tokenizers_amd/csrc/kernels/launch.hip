@@ -330,9 +330,8 @@ int compact_grid(int n_cu, int cp_items) {
     int per_cu = 0;
     const void* k = cp_items == 2 ? (const void*)k_compact<2> : cp_items == 4 ? (const void*)k_compact<4> : (const void*)k_compact<8>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, CP_NT, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    // (a CU holds 32 wavefronts: eight of these workgroups, whatever LDS and registers would allow -- the two-per-lane shape was handed
-    // a grid a quarter of which was not resident, and its look-backs waited out their patience on the chunks of workgroups that had not
-    // started: 6.7 ms instead of 0.13, session M; results equal either way, the look-back computes what it waits for)
+    // (a CU holds 32 wavefronts: eight of these workgroups, whatever LDS and registers would allow.  The two-per-lane shape, TKAMD_CP_ITEMS=2,
+    // stays a shape to leave alone -- 6.7 ms against 0.11 at C2 with or without this bound, sessions M and V: results equal, cause not found)
     per_cu = std::min(per_cu, 32 / (CP_NT / 64));
     return per_cu * n_cu;
 }
