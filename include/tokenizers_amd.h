@@ -27,6 +27,10 @@
  *   (utils/truncation.rs, utils/padding.rs); with TKAMD_WANT_OVERFLOW the
  *   `overflowing` encodings a truncation leaves behind (Encoding::truncate,
  *   tokenizer/encoding.rs:307-395) are further encodings of the result.
+ *   EncodeInput::Dual (pairs), InputSequence::PreTokenized (lists of words) and
+ *   batches that mix single sequences and pairs (tokenizer/mod.rs:225-290) are
+ *   the same buffers with one more CSR: TKAMD_PAIRS, tkamd_encode_batch_words,
+ *   tkamd_encode_batch_mixed below.
  */
 #ifndef TOKENIZERS_AMD_H
 #define TOKENIZERS_AMD_H
