@@ -118,6 +118,114 @@ def check_against_oracle(tok, oracle_obj, batch: Batch, stream) -> int:
     return len(batch.sample_idx)
 
 
+def meta_checksum(b) -> tuple:
+    """result_checksum's counterpart for the per-token (start, end) offsets and word ids of a with-offsets result."""
+    import torch
+    off = b.offsets_tensor().to(torch.int64)
+    wid = b.word_ids_tensor().to(torch.int64)
+    n = off.shape[0]
+    w = _WEIGHTS.get(off.device)
+    if w is None or w.numel() < n:
+        w = _WEIGHTS[off.device] = (torch.arange(n + (n >> 2), dtype=torch.int64, device=off.device) % 1000003) + 1
+    return result_checksum(b) + (int(off[:, 0].sum()), int((off[:, 1] * w[:n]).sum()), int((wid * w[:n]).sum()))
+
+
+def check_meta_against_oracle(enc_fn, oracle_obj, batch: Batch, char: bool):
+    """ids, (start, end) offsets and word ids of the batch's sample documents, HIP path vs oracle.  Returns the synced result."""
+    b = enc_fn(batch).sync()
+    ids = b.ids_tensor().cpu().numpy().view(np.uint32)
+    offs = b.offsets_tensor().cpu().numpy().view(np.uint32)
+    wid = b.word_ids_tensor().cpu().numpy().view(np.uint32)
+    to = b.tok_offsets_tensor().cpu().numpy()
+    exp = oracle_obj.encode_batch(batch.sample, char_offsets=char)
+    for k, i in enumerate(batch.sample_idx):
+        lo, hi = to[i], to[i + 1]
+        elo, ehi = exp.tok_offsets[k], exp.tok_offsets[k + 1]
+        if hi - lo != ehi - elo or (ids[lo:hi] != exp.ids[elo:ehi]).any():
+            raise SystemExit(f"bench: PARITY FAILURE (ids, with offsets) in document {i}: {batch.sample[k][:80]!r}")
+        if (offs[lo:hi] != exp.offsets[elo:ehi]).any():
+            raise SystemExit(f"bench: PARITY FAILURE ({'char' if char else 'byte'} offsets) in document {i}: {batch.sample[k][:80]!r} "
+                             f"hip={offs[lo:hi][:8].tolist()} oracle={exp.offsets[elo:ehi][:8].tolist()}")
+        if (wid[lo:hi] != exp.words[elo:ehi]).any():
+            raise SystemExit(f"bench: PARITY FAILURE (word ids) in document {i}: {batch.sample[k][:80]!r}")
+    return b
+
+
+OFFSET_KERNELS = ("emit_pretok", "leadmask_scan", "token_meta")
+
+
+def offsets_leg(tok, oracle_obj, batches, stream, steps: int, mode: str, b_alg_ids: float, config: str) -> dict:
+    """The function BASELINE's metric NAMES: Rust `encode_batch` returns byte offsets + word ids (tokenizer/mod.rs:1337-1356), Python's
+    `encode_batch` char offsets + word ids (mod.rs:1360-1379); `value` above is `encode_batch_fast` (ids only, mod.rs:1382-1401).  The same K
+    steps over the same rotating HBM-resident batches with TKAMD_OFFSETS_BYTE|CHAR + TKAMD_WANT_WORD_IDS: a 2 % oracle gate on ids, offsets
+    and word ids of every batch, wall clock between device synchronisations, checksums of the timed outputs, per-kernel HIP-event times,
+    and a roofline on SURVEY 8d's bytes (B_alg + 8 T offsets + 4 T word ids)."""
+    import torch
+    n_batches = len(batches)
+    char = mode == "char"
+
+    def enc_b(b):
+        return tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, offsets=mode, word_ids=True, stream=stream)
+
+    def enc(i):
+        return enc_b(batches[i % n_batches])
+    sums = [meta_checksum(check_meta_against_oracle(enc_b, oracle_obj, b, char)) for b in batches]
+    n_checked = sum(len(b.sample_idx) for b in batches)
+    for i in range(3 * n_batches):
+        enc(i)
+    torch.cuda.synchronize()
+    blocks = []
+    last = None
+    for _ in range(4):
+        t_s = time.perf_counter()
+        for i in range(steps):
+            last = enc(i)
+        last.sync()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t_s) / steps)
+    if meta_checksum(last) != sums[(steps - 1) % n_batches]:
+        raise SystemExit(f"bench: the last timed with-offsets step ({mode}) differs from the gated result of its batch")
+    for i in range(n_batches):
+        if meta_checksum(enc(i).sync()) != sums[i]:
+            raise SystemExit(f"bench: a re-run with-offsets step ({mode}) differs from the gated result of its batch")
+    tok.profile(True)
+    for i in range(steps):
+        enc(i)
+    enc(steps).sync()
+    tok.profile(False)
+    stages = {k: v[0] / max(1, v[1]) for k, v in tok.profile_read().items()}
+    n_bytes = sum(batches[i % n_batches].n_bytes for i in range(steps)) / steps
+    n_tok = sum(batches[i % n_batches].n_tok for i in range(steps)) / steps
+    b_alg = b_alg_ids + 12.0 * n_tok
+    first, srt = blocks[0], sorted(blocks[1:])
+    med = srt[len(srt) // 2]
+    dom = max(stages, key=stages.get)
+    ach = b_alg / (stages[dom] * 1e-3) / 1e9
+    okern = {}
+    for k in OFFSET_KERNELS:
+        if k in stages:
+            tr, src = pmc_traffic(k, config)
+            # what the offsets kernels must move between them: 8 T offsets + 4 T word ids out (SURVEY 8d); their inputs (masks, rows,
+            # pre-token starts) are intermediates of the path
+            okern[k] = {"ms": round(stages[k], 4), "traffic": tr, "traffic_source": src}
+    t_off = sum(stages.get(k, 0.0) for k in OFFSET_KERNELS)
+    return {"offsets": mode, "word_ids": True,
+            "reference_function": "TokenizerImpl::encode_batch_char_offsets (tokenizer/mod.rs:1360-1379; Python's encode_batch)" if char
+                                  else "TokenizerImpl::encode_batch (tokenizer/mod.rs:1337-1356)",
+            "value": round(n_bytes / first / 1e9, 3), "unit": "GB/s", "ms_per_step": round(first * 1e3, 4),
+            "value_median": round(n_bytes / med / 1e9, 3), "ms_per_step_blocks": [round(x * 1e3, 4) for x in blocks],
+            "mtokens_per_s": round(n_tok / first / 1e6, 2), "steps": steps,
+            "parity": {"checked_documents": n_checked, "against": "oracle/oracle.c", "of": "every timed batch (2 % sample): ids, offsets and word ids bit-exact",
+                       "timed_outputs": "checksums of ids, token CSR, offsets and word ids of the last timed step and of one re-run per batch equal the gated results'"},
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": round(stages[dom], 4), "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBPS, 5), "algorithmic_bytes_per_launch": int(b_alg),
+                         "whole_path_frac": round(b_alg / first / 1e9 / HBM_PEAK_GBPS, 5),
+                         "offsets_kernels": okern, "offsets_kernels_ms": round(t_off, 4),
+                         "offsets_kernels_algorithmic_bytes": int(12.0 * n_tok),
+                         "offsets_kernels_achieved": round(12.0 * n_tok / (t_off * 1e-3) / 1e9, 2) if t_off else None,
+                         "all_kernels_ms": {k: round(v, 4) for k, v in stages.items()}, "sum_kernels_ms": round(sum(stages.values()), 4)}}
+
+
 def timed_steps(step_fn, steps: int, warmup: int, fence, reduce_max, finish_last=None) -> float:
     """The contract's timed region: W untimed warm-up steps, then EXACTLY K steps between two fences (barrier + device
     synchronisation on both sides), and the MAX over ranks of the wall time.  `fence()` / `reduce_max(seconds) -> seconds` carry
@@ -165,11 +273,13 @@ def main() -> None:
     ap.add_argument("--no-ood", action="store_true", help="skip the out-of-distribution leg")
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
     ap.add_argument("--no-word-cache", action="store_true", help="skip the word-cache leg")
+    ap.add_argument("--no-offsets", action="store_true", help="skip the with-offsets legs (encode_batch with byte / char offsets + word ids)")
     ap.add_argument("--two-streams", action="store_true", help="also time the K steps alternating over two streams (two batches in flight); measured "
                                                                "SLOWER than one stream -- 0.998 against 0.535 ms a step, profiles/r5j_c2_bench.json -- so not part of the default line")
     ap.add_argument("--no-single-call", action="store_true", help="skip the single-call multi-GPU leg")
     ap.add_argument("--single-call-gpus", type=int, default=0, help="devices of the single-call leg (0 = every visible GPU)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
+    ap.add_argument("--cpu-brief", action="store_true", help="CPU baseline: the all-cores encode_batch_fast and encode_batch figures only")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
     ap.add_argument("--also", default="c3,c4,c5", help="(N = 1, --config c2 only) further BASELINE configs timed by child runs of this script after the "
                                                      "headline measurement and attached as `other_configs`; 'none' = skip")
@@ -247,6 +357,11 @@ def main() -> None:
         return el
 
     state = {}
+    # (un-timed, in front of the contract's W warm-up steps: three full rotations over the batches, so that clocks, the workspaces and
+    # the handle's claims statistics are where the repeat blocks find them -- round 5's first block ran 2.5 % behind the later ones)
+    for i in range(3 * n_batches):
+        encode(i)
+    torch.cuda.synchronize()
     elapsed = timed(encode)
     # ---- the same measurement again, `repeat_blocks` times: K steps between the same fences, max over ranks.  The contract's block is
     # 20 steps of about half a millisecond -- eleven milliseconds; min / median / max over five more say how much of a 2-3 % difference
@@ -311,8 +426,9 @@ def main() -> None:
         b_alg = (mine[0] + 8 * (mine[2] + args.steps) + 4 * mine[1] + 8 * (mine[2] + args.steps)) / args.steps
         achieved = b_alg / (stages[dom] * 1e-3) / 1e9
         traffic, traffic_source = pmc_traffic(dom, args.config)
+        traffic_stale = bool(traffic_source and traffic_source.get("traffic_stale"))
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_stale": traffic_stale,
                     # (traffic is NOT re-measured in this run -- PMC passes need rocprofv3 around the process: it is the committed summary's
                     # figure for this kernel, per launch; the file and the commit it was taken on)
                     "traffic_source": traffic_source,
@@ -336,6 +452,22 @@ def main() -> None:
                                         "probes_per_s": round(qs["merge_probes"] / t_merge / 1e9, 3), "unit": "G probes/s",
                                         "kernels_ms": round(t_merge * 1e3, 4), "bytes_per_probe": 16,
                                         "model": "(k - 1) + 2 m per queued word of k symbols and m merges; the in-batch claims leave the distinct words only"}
+
+    # ---- with-offsets legs (rank 0, N=1): the functions the metric names -- Rust encode_batch (byte offsets + word ids) and Python's
+    # encode_batch (char offsets + word ids); `value` above is encode_batch_fast ----
+    with_off = None
+    if rank == 0 and world == 1 and not args.no_offsets:
+        with_off = {}
+        for mode in ("byte", "char"):
+            t0 = time.time()
+            try:
+                with_off[mode] = offsets_leg(tok, oracle_obj, batches, stream, args.steps, mode, b_alg, args.config)
+                with_off[mode]["ratio_to_value"] = round(with_off[mode]["value"] / gbps, 3)
+            except SystemExit:
+                raise
+            except Exception as ex:     # never lose the bench line to an auxiliary leg
+                with_off[mode] = {"error": repr(ex)[:300]}
+            log(f"[bench] with-offsets leg ({mode}) in {time.time() - t0:.1f}s: {with_off[mode].get('value', with_off[mode].get('error'))}")
 
     # ---- two batches in flight (rank 0, N=1): the same K steps, alternating over TWO streams (the device entry keys its workspace by the
     # caller's stream: two streams, two workspaces).  NOT `value` -- a step of `value` is one batch after the other on one stream --
@@ -545,7 +677,7 @@ def main() -> None:
     # ---- CPU baseline leg (rank 0, N=1 only): the reference's Rayon encode_batch on the host cores ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(tok_json, batches[0].lines, args.cpu_lines, args.config)
+        cpu = cpu_baseline(tok_json, batches[0].lines, args.cpu_lines, args.config, brief=args.cpu_brief)
 
     # ---- the other BASELINE configs on this GPU (rank 0, N=1, headline config only): the same script, same flags, as child processes
     # one after the other -- so that C3 / C4 are driver-timed numbers too, not only builder-run ones ----
@@ -575,6 +707,8 @@ def main() -> None:
                                 "including the RCCL collect is gather.value",
             "value_pcie_inclusive": host["gbps_pcie_inclusive"] if host else None,
             "value_from_python_list_of_str": host.get("gbps_encode_batch_fast_list_of_str") if host else None,
+            "value_with_offsets": (with_off or {}).get("byte", {}).get("value"),
+            "value_with_char_offsets": (with_off or {}).get("char", {}).get("value"),
             "value_out_of_distribution": ood["value"] if ood else None,
             "value_with_word_cache": wcache["value_warm"] if wcache else None,
             "value_two_batches_in_flight": two.get("value") if two else None,
@@ -586,7 +720,7 @@ def main() -> None:
                        "pretokens_per_gpu": int(b0.n_pretok), "batches": n_batches, "type_seed": args.type_seed,
                        "tokenizer_sha256": synth.sha256(tok_json)[:16],
                        "parallelism": f"dp{world} (documents sharded by rank)"},
-            "roofline": roofline, "cpu_baseline": cpu, "host_boundary": host, "single_call_multi_gpu": single_call,
+            "roofline": roofline, "with_offsets": with_off, "cpu_baseline": cpu, "host_boundary": host, "single_call_multi_gpu": single_call,
             "out_of_distribution": ood, "word_cache": wcache, "two_batches_in_flight": two, "other_configs": others_cfg,
         }
     # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
@@ -616,11 +750,12 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-def other_config_leg(cfg: str, steps: int, warmup: int, n_lines: int, n_batches: int, timeout_s: int = 300) -> dict:
+def other_config_leg(cfg: str, steps: int, warmup: int, n_lines: int, n_batches: int, timeout_s: int = 420) -> dict:
     """`python bench.py --config cfg` (kernel pipeline + parity gate + roofline leg only) as a child process; the fields of its line
     that matter, or an error -- never an exception (the headline line must not be lost to an auxiliary leg)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", str(steps), "--warmup", str(warmup), "--lines", str(n_lines),
-           "--batches", str(n_batches), "--no-cpu-baseline", "--no-ood", "--no-host", "--no-word-cache", "--no-single-call", "--also", "none"]
+           "--batches", str(n_batches), "--cpu-lines", str(min(n_lines, 250_000)), "--cpu-brief", "--no-ood", "--no-host", "--no-word-cache",
+           "--no-single-call", "--also", "none"] + (["--no-offsets"] if cfg == "c5" else [])
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
@@ -632,7 +767,8 @@ def other_config_leg(cfg: str, steps: int, warmup: int, n_lines: int, n_batches:
         return {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "mtokens_per_s": j.get("mtokens_per_s"),
                 "steps": j["steps"], "workload": j["config"]["workload"], "parity": j.get("parity"),
                 "roofline": {k: rf.get(k) for k in ("kernel", "kernel_ms", "achieved", "frac", "whole_path_frac", "traffic", "traffic_source", "all_kernels_ms")},
-                "repeat": j.get("repeat")}
+                "repeat": j.get("repeat"), "value_with_offsets": j.get("value_with_offsets"), "value_with_char_offsets": j.get("value_with_char_offsets"),
+                "with_offsets": j.get("with_offsets"), "cpu_baseline": j.get("cpu_baseline")}
     except subprocess.TimeoutExpired:
         return {"error": f"child killed after {timeout_s} s"}
     except Exception as ex:
@@ -737,18 +873,34 @@ KERNEL_OF_STAGE = {"bpe_merge_lds": "k_bpe_merge_lds<16,", "bpe_merge_lds32": "k
                    "pretok_local": "k_pretok_local", "compact": "k_compact", "emit_pretok": "k_emit_pretok", "lookup": "k_lookup",
                    "wordpiece_word_lookup": "k_lookup", "wordlevel_lookup": "k_lookup", "bert_normalize": "k_bn_write",
                    "wordpiece": "k_wordpiece", "added_token_match": "k_added_candidates",
-                   "claims_publish": "k_claims_publish"}
+                   "claims_publish": "k_claims_publish", "leadmask_scan": "k_leadmask", "token_meta": "k_token_meta"}
 
 
-def pmc_traffic(stage: str, config: str = "c2"):
+def csrc_sha16() -> str:
+    """sha256 over the kernel / host sources the library is built from (tokenizers_amd/csrc, sorted paths): what a committed PMC summary
+    is stamped with (tools/pmc_summary.py) -- its traffic figures describe THIS build iff the hashes agree."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "tokenizers_amd", "csrc")
+    for d, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".hpp", ".cpp", ".c", ".h", ".inc")):
+                h.update(os.path.relpath(os.path.join(d, f), base).encode())
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(stage: str, config: str = "c2", suffix: str = ""):
     """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary of this config
     (profiles/rN_<config>_pmc_summary.json, written by tools/round_profile.sh): (2*FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of
     MI355X_MICROARCH.md -- and where the figure comes from (file, kernel, commit).  (None, None) if no PMC run covers the kernel."""
     import glob
     try:
-        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9]_{config}_pmc_summary.json"))) or \
-            sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{config}*_pmc_summary.json"))) or \
-            (sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))) if config == "c2" else [])
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9]_{config}{suffix}_pmc_summary.json")))
+        if not paths and not suffix:
+            paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*{config}*_pmc_summary.json"))) or \
+                (sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))) if config == "c2" else [])
         if not paths:
             return None, None
         with open(paths[-1]) as fh:
@@ -758,7 +910,17 @@ def pmc_traffic(stage: str, config: str = "c2"):
         name, k = (want, ks[want]) if want in ks else next(((n, v) for n, v in ks.items() if n.startswith(want)), (None, None))
         if not k:
             return None, None
-        src = {"file": os.path.relpath(paths[-1], ROOT), "kernel": name, "commit": summary.get("commit"),
+        # stale = the summary was taken on other kernel sources than the ones this run was built from (hash of tokenizers_amd/csrc; a summary
+        # without the hash -- rounds 1-5 -- falls back to comparing its commit with .build_commit)
+        if summary.get("csrc_sha16"):
+            stale = summary["csrc_sha16"] != csrc_sha16()
+        else:
+            try:
+                with open(os.path.join(ROOT, ".build_commit")) as fh:
+                    stale = fh.read().strip().split("+")[0] != str(summary.get("commit")).split("+")[0]
+            except OSError:
+                stale = True
+        src = {"file": os.path.relpath(paths[-1], ROOT), "kernel": name, "commit": summary.get("commit"), "traffic_stale": bool(stale),
                "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; (2 * FETCH_SIZE + WRITE_SIZE) per launch (gfx950 correction)"}
         return int(k["hbm_bytes_per_launch"]), src
     except Exception:
@@ -781,7 +943,7 @@ print(json.dumps({"gbps": nbytes / dt / 1e9, "mtok": sum(len(e.ids) for e in enc
 """
 
 
-def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int, config: str = None) -> dict:
+def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int, config: str = None, brief: bool = False) -> dict:
     """The reference's own encode_batch (Rayon) on a bounded sample of the same corpus: all cores (the headline baseline) plus
     the shapes SURVEY 8d / BASELINE.md section 3 ask for.  ~30 s of CPU work in total."""
     cores = os.cpu_count() or 1
@@ -823,6 +985,8 @@ def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int, config: str = 
         b2, _ = best_of(lambda: rt.encode_batch(sample[:200_000], add_special_tokens=False), 2, 8)
         nb2 = sum(len(s.encode("utf-8")) for s in sample[:200_000])
         others["encode_batch_with_offsets_all_cores_gbps"] = round(nb2 / b2 / 1e9, 4)
+        if brief:
+            raise StopIteration
         # the reference's own criterion shape: 1,000 documents per encode_batch call (benches/bpe_benchmark.rs:17,43; common/mod.rs:35-57)
         sub = sample[:100_000]
         nb3 = sum(len(s.encode("utf-8")) for s in sub)
@@ -838,6 +1002,8 @@ def cpu_baseline(tok_json: str, lines: list[str], cpu_lines: int, config: str = 
         one = json.loads(r.stdout.strip().splitlines()[-1])
         others["encode_batch_fast_1_thread_gbps"] = round(one["gbps"], 5)
         others["encode_batch_fast_1_thread_sample"] = f"{one['n']} lines ({one['mb']:.1f} MB), fresh process, TOKENIZERS_PARALLELISM=false"
+    except StopIteration:
+        pass
     except Exception as ex:
         others["error"] = repr(ex)
     return {"value": round(nbytes / best / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "reference",

@@ -199,7 +199,9 @@ int tkamd_encode_batch_mixed(tkamd_tokenizer* tok, const uint8_t* text, const in
  * threads, read with acquire semantics here) and reaches doc_offsets[n_docs].  The call never reads a byte it has not seen announced.
  * `consumed(user)`, if not NULL, is called once from the calling thread as soon as the call has seen *ready_bytes at its final value
  * (the caller's source objects are no longer needed: a Python binding releases the GIL there) -- also on every error path that
- * waited that long; a call that fails before has not called it.  pace == NULL: tkamd_encode_batch. */
+ * waited that long; a call that fails before has not called it.  A producer that cannot finish stores a NEGATIVE value in
+ * *ready_bytes: the call stops waiting, calls `consumed` and fails with TKAMD_ERR_INVALID (without that signal a producer that
+ * dies leaves the call waiting for ever).  pace == NULL: tkamd_encode_batch. */
 typedef struct tkamd_pace {
     const int64_t* ready_bytes;
     void (*consumed)(void* user);

@@ -187,9 +187,12 @@ def test_overflow_epilogue_reruns_after_a_queue_overflow(monkeypatch):
     want = ta.Tokenizer.from_str(json.dumps(d), device=0).encode_batch_csr(docs, overflowing=True)
     monkeypatch.setenv("TKAMD_TEST_HOOKS", "1")
     monkeypatch.setenv("TKAMD_Q16_DIV", "100000")
-    tiny = ta.Tokenizer.from_str(json.dumps(d), device=0)
     for overflowing in (True, False):
+        tiny = ta.Tokenizer.from_str(json.dumps(d), device=0)       # (a fresh handle each time: the queue stays grown once a batch was re-run)
+        tiny.encode_batch_csr(docs[:1])
+        assert tiny.queue_sizes()["q16_div"] == 100000, "the test hook was not read: the queue is not tiny"
         got = tiny.encode_batch_csr(docs, overflowing=overflowing)
+        assert tiny.queue_sizes()["q16_div"] <= 2, "the batch was not run again"
         ref = want if overflowing else ta.Tokenizer.from_str(json.dumps(d), device=0).encode_batch_csr(docs)
         assert np.array_equal(got.ids, ref.ids) and np.array_equal(got.tok_offsets, ref.tok_offsets)
         assert (got.enc_docs is None) == (not overflowing) and (not overflowing or np.array_equal(got.enc_docs, ref.enc_docs))

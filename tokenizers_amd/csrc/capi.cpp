@@ -41,9 +41,10 @@ int set_error(int code, const std::string& msg) {
 // Environment switches that exist for the TESTS alone (a compaction grid no launch would pick, a look-back without patience, a work queue
 // far too small, a lowered row limit, a RCCL library that is not there, poisoned scratch text) change launch shapes or skip a check: they
 // are read only when TKAMD_TEST_HOOKS=1 is set as well, so that a stray variable in a production environment changes nothing.
+// (read on every call: a test that sets the variables after the process made its first handle must still get its hook)
 const char* test_hook(const char* name) {
-    static const bool on = [] { const char* e = getenv("TKAMD_TEST_HOOKS"); return e && !strcmp(e, "1"); }();
-    return on ? getenv(name) : nullptr;
+    const char* const e = getenv("TKAMD_TEST_HOOKS");
+    return (e && !strcmp(e, "1")) ? getenv(name) : nullptr;
 }
 
 struct HipError : std::runtime_error {
@@ -1277,7 +1278,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         // in front of the next scatter runs only then (natural text holds no special token: 240 MB of zeroing per C3 step went this way).
         // Fresh allocations hold anything: flagged dirty.
         w->w_mask_dirty.reserve(16);
-        if (grew) HIP_CHECK(hipMemsetAsync(w->w_mask_dirty.p, 1, 4, st));
+        if (grew) HIP_CHECK(hipMemsetAsync(w->w_mask_dirty.p, 0xFF, 8, st));      // (dirty, as far as the buffers go)
         w->w_match_docs.reserve((seg_cap + 1) * 4);
         w->w_match_list.reserve(((size_t)mcap + 4) * 16);
         mlist = w->w_match_list.as<uint32_t>();
@@ -2503,7 +2504,15 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
     bool pace_done = false;
     auto wait_ready = [&](int64_t need, int64_t all) {
         if (!pace || !pace->ready_bytes) return;
-        while (__atomic_load_n(pace->ready_bytes, __ATOMIC_ACQUIRE) < need) std::this_thread::yield();
+        for (;;) {
+            const int64_t r = __atomic_load_n(pace->ready_bytes, __ATOMIC_ACQUIRE);
+            if (r < 0) {        // the producer gave up (tkamd_pace: a negative value): the call fails instead of waiting for bytes that never come
+                if (!pace_done) { pace_done = true; if (pace->consumed) pace->consumed(pace->user); }
+                throw Invalid("tkamd_encode_batch_paced: the caller's producer reported a failure (ready_bytes < 0)");
+            }
+            if (r >= need) break;
+            std::this_thread::yield();
+        }
         if (need >= all && !pace_done) { pace_done = true; if (pace->consumed) pace->consumed(pace->user); }
     };
     return guarded([&]() -> int {
@@ -2538,7 +2547,10 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             return (int64_t)std::max(1, e ? atoi(e) : 16) << 20;
         }();
         constexpr int MAX_SLICES = 16;
-        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / slice_bytes);
+        // (a paced call is cut finer -- 4 MB, the stripe its producer announces: its first slice's copy and kernels then start behind the
+        // first stripes instead of behind the whole text, also for a batch below two ordinary slices)
+        const int64_t slice_min = (pace && pace->ready_bytes) ? std::min<int64_t>(slice_bytes, (int64_t)4 << 20) : slice_bytes;
+        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / slice_min);
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow || mixed) n_slices = 1;
@@ -3081,6 +3093,7 @@ int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {
         for (int i = 0; i < n; ++i) out[i] = 0;
         if (!w) return TKAMD_OK;
         for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = w->last_counters[i];
+        if (n > 15) out[15] = t->q16_div;                                  // (the <= 16-byte queue's divisor: shrinks when a batch had to be run again)
         if (t->device >= 0 && w->w_qcount.p && !g_forked) {             // queue fills of the last batch: the sub-queue counters, summed per queue
             HIP_CHECK(hipSetDevice(t->device));
             HIP_CHECK(hipDeviceSynchronize());

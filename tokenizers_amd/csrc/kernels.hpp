@@ -98,7 +98,8 @@ struct ZeroRegions {
     void* p[6];
     unsigned long long n16[6];       // 16-byte words
     int n;
-    const uint32_t* only_if;         // not null: the launch returns at once when this word is zero (the match masks' "may hold bits" flag, capi.cpp scatter_masks)
+    const uint32_t* only_if;         // not null: the launch returns at once when word 0 is zero (the match masks' "may hold bits" flag, capi.cpp scatter_masks);
+                                     // word 1 bounds every region: the 16-byte words the last writer could have reached
     void add(void* ptr, size_t bytes) { if (n < 6 && ptr && bytes) { p[n] = ptr; n16[n] = (bytes + 15) / 16; ++n; } }
 };
 struct QueuePlan {

@@ -215,7 +215,8 @@ __global__ void k_scatter_matches(const uint32_t* __restrict__ list, const uint3
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     const uint32_t n = *n_list;
     // the masks hold bits from here on exactly if this launch sets any: the next zeroing of them (ZeroRegions::only_if) is skipped otherwise
-    if (dirty && blockIdx.x == 0 && threadIdx.x == 0) *dirty = n ? 1u : 0u;
+    // (and only as far as this text reaches: dirty[1] = the 16-byte words of a mask a bit of this launch can lie in)
+    if (dirty && blockIdx.x == 0 && threadIdx.x == 0) { dirty[0] = n ? 1u : 0u; dirty[1] = n ? (uint32_t)(((n_bytes >> 6) + 3) >> 1) + 1u : 0u; }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int64_t start = list[4 * i], stop = list[4 * i + 1];
         atomicOr(&matchmask[start >> 6], 1ull << (start & 63));

@@ -536,6 +536,9 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 unsigned long long* const e = a.claims + 2u * (size_t)slot;
                 const unsigned long long w0 = (unsigned long long)k0 | ((unsigned long long)(k1 & 0x00FFFFFFu) << 32) | ((unsigned long long)len << 56);
                 const unsigned long long w1 = (unsigned long long)(k1 >> 24) | ((unsigned long long)k2 << 8) | ((unsigned long long)(k3 & 0x00FFFFFFu) << 40);
+                // A word of 8..15 bytes whose bytes 7.. are all NUL has w1 == 0 -- indistinguishable from "word 1 not written yet" of another
+                // word with the same first seven bytes and length.  Such a word neither claims nor shares: it is queued and merged on its own.
+                if (len > 7u && w1 == 0ull) return CLAIM_NONE;
                 const ulonglong2 c = *(const ulonglong2*)e;
                 unsigned long long c0 = c.x, c1 = c.y;
                 bool fresh1 = false, won = false;

@@ -47,11 +47,13 @@ __global__ __launch_bounds__(1024) void k_scan_single(uint32_t* __restrict__ dat
 // Several buffers zeroed by ONE launch (a hipMemsetAsync is a kernel launch of its own: five of them per batch were 27 us of a 700 us
 // step).  Regions are 16-byte aligned device allocations with slack: whole 16-byte words are written.
 __global__ __launch_bounds__(256) void k_zero_regions(ZeroRegions z) {
-    if (z.only_if && *z.only_if == 0u) return;
+    if (z.only_if && z.only_if[0] == 0u) return;
+    // (only_if[1]: how far the last writer of these regions could have reached, in 16-byte words -- the rest is still clean)
+    const size_t extent = z.only_if ? (size_t)z.only_if[1] : ~(size_t)0;
     const size_t stride = (size_t)gridDim.x * 256;
     for (int r = 0; r < z.n; ++r) {
         uint4* const p = (uint4*)(r == 0 ? z.p[0] : r == 1 ? z.p[1] : r == 2 ? z.p[2] : r == 3 ? z.p[3] : r == 4 ? z.p[4] : z.p[5]);
-        const size_t n = (size_t)(r == 0 ? z.n16[0] : r == 1 ? z.n16[1] : r == 2 ? z.n16[2] : r == 3 ? z.n16[3] : r == 4 ? z.n16[4] : z.n16[5]);
+        const size_t n = min(extent, (size_t)(r == 0 ? z.n16[0] : r == 1 ? z.n16[1] : r == 2 ? z.n16[2] : r == 3 ? z.n16[3] : r == 4 ? z.n16[4] : z.n16[5]));
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
     }
 }

@@ -429,6 +429,22 @@ class DeviceBatch:
     def tok_offsets_tensor(self):
         return self._tensor(self._res.d_tok_offsets, (self.n_docs + 1,), "<i8")
 
+    def offsets_tensor(self):
+        """[n_tokens, 2] int32 view (bit pattern of the u32 (start, end) pairs), or None when the call asked for no offsets."""
+        if self.n_tokens is None:
+            self.sync()
+        if not self._res.d_offsets:
+            return None
+        return self._tensor(self._res.d_offsets, (max(self.n_tokens, 1), 2), "<i4")[: self.n_tokens]
+
+    def word_ids_tensor(self):
+        """[n_tokens] int32 view of the word ids (-1 = None), or None when the call asked for none."""
+        if self.n_tokens is None:
+            self.sync()
+        if not self._res.d_word_ids:
+            return None
+        return self._tensor(self._res.d_word_ids, (max(self.n_tokens, 1),), "<i4")[: self.n_tokens]
+
     def ids_tensor_unsynced(self):
         """Capacity-sized int32 view of the ids buffer for consumers that are stream-ordered behind the encode and learn the
         token count from :meth:`n_tokens_tensor` (e.g. ``parallel.gather_to_root``): no host synchronisation."""
@@ -1091,6 +1107,7 @@ class Tokenizer:
         out = {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge_huge": arr[7]}
         if arr[5]:                                       # in-batch claims: candidates the lookup looked at / how many were another pre-token's word
             out["claim_candidates"], out["claim_shared"] = arr[5], arr[6]
+        out["q16_div"] = arr[15]                         # the <= 16-byte queue holds n_bytes / q16_div entries (a queue overflow re-runs the batch with 2, then 1)
         if arr[12]:                                      # (profiling runs) merge-table probes of the LDS merge kernels, (k - 1) + 2 m per word
             out["merge_probes"] = arr[12]
         return out

@@ -39,6 +39,7 @@ def main():
         wk = statistics.median(w[k]) if w.get(k) else 0.0
         kernels[k] = {"launches": len(f.get(k) or w.get(k)), "FETCH_SIZE_KB": round(fk, 1), "WRITE_SIZE_KB": round(wk, 1),
                       "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+    import os
     commit = None                       # (tools/stamp_commit.sh writes it before the snapshot goes to the GPU box: there is no .git there)
     try:
         import os
@@ -46,8 +47,10 @@ def main():
             commit = fh.read().strip()
     except OSError:
         pass
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench                        # (the hash of the kernel sources this run was built from: bench.py flags a summary of other sources)
     with open(out, "w") as fh:
-        json.dump({"_doc": note, "commit": commit, "kernels": kernels}, fh, indent=1)
+        json.dump({"_doc": note, "commit": commit, "csrc_sha16": bench.csrc_sha16(), "kernels": kernels}, fh, indent=1)
     print(f"{out}: {len(kernels)} kernels")
 
 
