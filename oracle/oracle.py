@@ -19,14 +19,54 @@ LIB = os.path.join(HERE, "liboracle.so")
 LLAMA3_PATTERN = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*"
                   r"|\s*[\r\n]+|\s+(?!\S)|\s+")
 
+GPT2_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+_CI = r"(?i:'s|'t|'re|'ve|'m|'ll|'d)"
+_PRE, _UP, _LO = r"[^\r\n\p{L}\p{N}]?", r"[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]", r"[\p{Ll}\p{Lm}\p{Lo}\p{M}]"
+
+
+def split_rule(pattern: str):
+    """(contr, letters, digits, tail) of a Split pattern of the tiktoken family (oracle.c oracle_tok.sp_*), None for the GPT-2 regex
+    itself; OracleError for anything else.  The family's spellings are spelled out: the pattern is compared piece by piece, in order."""
+    if pattern == GPT2_PATTERN:
+        return None
+    rest = pattern
+    contr = 0
+    for head, mode in ((_CI + "|", 1), (r"'(?i:[sdmt]|ll|ve|re)|", 1), (r"'s|'t|'re|'ve|'m|'ll|'d|", 2)):
+        if rest.startswith(head):
+            contr, rest = mode, rest[len(head):]
+            break
+    letters = None
+    for spelled, lm, suffix in ((_PRE + r"\p{L}+|", 0, 0),
+                                (_PRE + _UP + "*" + _LO + "+" + _CI + "?|" + _PRE + _UP + "+" + _LO + "*" + _CI + "?|", 2, 1),
+                                (_PRE + _UP + "*" + _LO + "+|" + _PRE + _UP + "+" + _LO + "*|", 2, 0)):
+        if rest.startswith(spelled):
+            letters, rest = lm, rest[len(spelled):]
+            if suffix:
+                if contr:
+                    raise OracleError("contractions twice")
+                contr = 3
+            break
+    if letters is None:
+        raise OracleError(f"Split pattern outside the oracle's scope: {pattern!r}")
+    digits = None
+    for spelled, k in ((r"\p{N}{1,3}|", 3), (r"\p{N}{1,2}|", 2), (r"\p{N}{1}|", 1), (r"\p{N}{1,1}|", 1), (r"\p{N}+|", 0), (r"\p{N}|", 1)):
+        if rest.startswith(spelled):
+            digits, rest = k, rest[len(spelled):]
+            break
+    tail = {r" ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+": 1, r" ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+": 2}.get(rest)
+    if digits is None or tail is None:
+        raise OracleError(f"Split pattern outside the oracle's scope: {pattern!r}")
+    return contr, letters, digits, tail
+
+
 M_BPE, M_WORDPIECE, M_WORDLEVEL = 1, 2, 3
 PT_GPT2, PT_LLAMA3, PT_WS, PT_WSSPLIT, PT_BERT, PT_BL_NOREGEX = 1, 2, 3, 4, 5, 6
 
 
 def build(force: bool = False) -> str:
     src = os.path.join(HERE, "oracle.c")
-    inc = os.path.join(HERE, "..", "tokenizers_amd", "csrc", "unicode_ranges.inc")
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(src), os.path.getmtime(inc)):
+    incs = [os.path.join(HERE, "..", "tokenizers_amd", "csrc", f) for f in ("unicode_ranges.inc", "unicode_case_ranges.inc")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in [src] + incs):
         subprocess.run(["make", "-C", HERE, "-B", "liboracle.so"], check=True, capture_output=True)
     return LIB
 
@@ -44,6 +84,7 @@ def lib() -> C.CDLL:
         L.oracle_free.argtypes = [vp]
         L.oracle_set_trim.argtypes = [vp, i32, i32]
         L.oracle_set_char_offsets.argtypes = [vp, i32]
+        L.oracle_set_split_rule.argtypes = [vp, i32, i32, i32, i32]
         L.oracle_add_token.argtypes = [vp, C.c_char_p, i64, C.c_uint32, i32, i32, i32, i32]
         L.oracle_mark_last_special.argtypes = [vp]
         L.oracle_set_encode_special.argtypes = [vp, i32]
@@ -143,7 +184,7 @@ class Oracle:
         mtype = model.get("type") or ("BPE" if "merges" in model else "WordPiece" if "continuing_subword_prefix" in model else "WordLevel")
         mk = {"BPE": M_BPE, "WordPiece": M_WORDPIECE, "WordLevel": M_WORDLEVEL}[mtype]
         pt = d.get("pre_tokenizer") or {}
-        aps, pk = 0, 0
+        aps, pk, rule = 0, 0, None
         t = pt.get("type")
         if t == "ByteLevel":
             pk = PT_GPT2 if pt.get("use_regex", True) else PT_BL_NOREGEX
@@ -156,10 +197,15 @@ class Oracle:
             pk = PT_BERT
         elif t == "Sequence":
             a, b = pt["pretokenizers"]
-            assert a["type"] == "Split" and a["pattern"].get("Regex") == LLAMA3_PATTERN and a["behavior"] == "Isolated"
+            assert a["type"] == "Split" and a["behavior"] == "Isolated" and not a.get("invert", False)
             assert b["type"] == "ByteLevel" and not b.get("use_regex", True)
-            pk = PT_LLAMA3
-            aps = int(b.get("add_prefix_space", True))
+            # (ByteLevel puts its prefix space in front of every split it is handed, byte_level.rs:122-125: behind a Split that is every
+            # pre-token.  Not restated -- no tokenizer in use is configured that way; the product refuses it at load too)
+            if b.get("add_prefix_space", True):
+                raise OracleError("Sequence[Split, ByteLevel(add_prefix_space=true)] is outside the oracle's scope")
+            rule = split_rule(a["pattern"].get("Regex"))
+            pk = PT_GPT2 if rule is None else PT_LLAMA3
+            aps = 0
         else:
             raise OracleError(f"pre_tokenizer {t} outside the oracle's scope")
         nk = 0
@@ -176,6 +222,8 @@ class Oracle:
         self._L = L
         self._h = L.oracle_new(mk, pk, nk, aps, int(bool(model.get("ignore_merges", False))), trim)
         L.oracle_set_trim(self._h, trim, int(pp.get("add_prefix_space", True)))
+        if pk == PT_LLAMA3:
+            L.oracle_set_split_rule(self._h, *rule)
         if bn:
             L.oracle_set_bert_normalizer(self._h, *bn)
         # (the automaton is built over the special tokens first, then the others, each in the order they were added -- of two tokens

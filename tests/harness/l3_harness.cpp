@@ -49,7 +49,7 @@ extern "C" int l3h_run(const char* json, size_t json_len, const uint8_t* text, i
             if (docstart[g]) w.D |= bit;
         }
         uint64_t st = 0, un = 0;
-        l3_window_starts(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data(), &st, &un);
+        l3_window_starts(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data(), &st, &un, hm.split_rule);      // (the member of the family the JSON names)
         for (int i = L3W_HALO; i < L3W_HALO + L3W_MAIN; ++i) {
             const int64_t g = base + i;
             if (g < n) { start_out[g] = (st >> i) & 1; unres_out[g] = (un >> i) & 1; }

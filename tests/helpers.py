@@ -15,6 +15,12 @@ BPE_CHAR_GOLDEN = ["bpe_ws_unk", "bpe_ws_fuse_unk", "bpe_ws_no_unk", "bpe_bert_a
                    "bpe_ws_ignore_merges_no_unk"]
 
 
+# the tiktoken family of Split patterns (oracle/make_golden_split.py): Qwen2 (single digits), o200k (case-split letters, contraction suffix,
+# `/` in the O-run's tail), tekken (case split, no contractions), digit runs whole + case-sensitive contractions, no contractions + digit
+# pairs, and the GPT-2 regex spelled as a Split
+SPLIT_GOLDEN = ["split_qwen2", "split_o200k", "split_tekken", "split_cs_digits", "split_nocontr_d2", "split_gpt2"]
+
+
 def load_tokenizer_json(name: str) -> str:
     with gzip.open(os.path.join(GOLD, name + ".json.gz"), "rt", encoding="utf-8") as fh:
         return fh.read()

@@ -9,7 +9,7 @@ import pytest
 
 import tokenizers_amd as ta
 from tokenizers_amd import _lib
-from tests.helpers import GOLDEN_NAMES, load_tokenizer_json
+from tests.helpers import GOLDEN_NAMES, SPLIT_GOLDEN, load_tokenizer_json
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.tkamd_version()
 
 
-@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("name", GOLDEN_NAMES + SPLIT_GOLDEN)
 def test_host_only_handle_parses_every_golden_tokenizer(name):
     js = load_tokenizer_json(name)
     t = ta.Tokenizer.from_str(js, device=-1)

@@ -10,7 +10,7 @@ import pytest
 
 from oracle import oracle as orc
 from oracle import synth
-from tests.helpers import BPE_CHAR_GOLDEN, GOLDEN_NAMES, char_to_byte, load_tokenizer_json, load_vectors
+from tests.helpers import BPE_CHAR_GOLDEN, GOLDEN_NAMES, SPLIT_GOLDEN, char_to_byte, load_tokenizer_json, load_vectors
 
 
 def _tok_json(model: dict, pre_tokenizer=None, normalizer=None, post_processor=None) -> str:
@@ -198,7 +198,7 @@ def test_gpt2_semantics_cheatsheet(bl_oracle):
 
 # ---- 2. golden vectors from the reference wheel --------------------------------------------------
 
-@pytest.mark.parametrize("name", GOLDEN_NAMES + BPE_CHAR_GOLDEN)
+@pytest.mark.parametrize("name", GOLDEN_NAMES + BPE_CHAR_GOLDEN + SPLIT_GOLDEN)
 def test_oracle_matches_golden(name):
     o = orc.Oracle(load_tokenizer_json(name))
     v = load_vectors(name)
@@ -236,7 +236,7 @@ def test_bert_normalizer_matches_wheel_normalize_str(ref_tokenizers):
 
 # ---- 3. live differential against the wheel ------------------------------------------------------
 
-@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000"])
+@pytest.mark.parametrize("name", ["gpt2_synth_50257", "llama3_small_6000"] + SPLIT_GOLDEN)
 def test_oracle_vs_wheel_live(name, ref_tokenizers):
     js = load_tokenizer_json(name)
     o = orc.Oracle(js)

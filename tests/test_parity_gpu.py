@@ -11,13 +11,13 @@ import pytest
 
 from oracle import oracle as orc
 from oracle import synth
-from tests.helpers import BPE_CHAR_GOLDEN, N, load_tokenizer_json, load_vectors
+from tests.helpers import BPE_CHAR_GOLDEN, N, SPLIT_GOLDEN, load_tokenizer_json, load_vectors
 
 pytestmark = pytest.mark.gpu
 
 # tokenizer configs the HIP path covers so far (grows with SURVEY section 8's rows)
 GPU_GOLDEN = ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "wordlevel_wssplit", "bert_wordpiece_4000",
-              "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"] + BPE_CHAR_GOLDEN
+              "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"] + BPE_CHAR_GOLDEN + SPLIT_GOLDEN
 
 
 @pytest.fixture(scope="module")
@@ -259,6 +259,44 @@ def test_llama3_vs_oracle():
     assert tok.queue_sizes()["pretok_slow_docs"] == 0
 
 
+@pytest.mark.parametrize("name", SPLIT_GOLDEN)
+def test_split_family_vs_oracle(name):
+    """Every member of the tiktoken family the loader parses (tables.hpp SplitRule) against the oracle: ids, byte and char offsets, word ids --
+    prose, the stress set, long digit / whitespace / letter runs (the three tiers of the fast members, the sequential matcher of the
+    case-split ones) and the documents the case-split alternatives care about."""
+    import tokenizers_amd as ta
+    from oracle.make_golden_split import case_docs
+    js = load_tokenizer_json(name)
+    tok = ta.Tokenizer.from_str(js, device=0)
+    o = orc.Oracle(js)
+    long_runs = ["1" * 500, " " * 400 + "x", "a" + "\n" * 300 + "b", "x" + " \t\r\n" * 90 + "y", "9" * 131 + " " + "8" * 7, "12" * 200 + "a" + "3" * 77,
+                 "!" * 300 + "\n\n\nz", "/" * 200 + "\n/\n" * 50, "\u3000" * 200 + "w", "1234567890" * 30 + "'s", "tail   ", "   ", "\n", "'S'T'RE'Ve'm'LL'd",
+                 "it'\u017f ok", "K\u212a'\u212a", "a\t'sb", "don't!\n\n  x", "\r\n\r\n", "a \n b", "x\n y", "p!\nq", "p !\n\nq",
+                 "aB" * 300, "Ab" * 300, "A" * 400 + "b" * 400 + "C" * 300, "\u4e2d" * 300 + "A" + "\u0301" * 100 + "B", "\u0661\u0662\u0663\u0664\u0665" * 40]
+    docs = synth.gen_lines(N(20000), text_seed=17) + synth.stress_lines(seed=6, n=N(5000)) + case_docs(31, N(6000)) + long_runs
+    _meta_compare(tok, o, docs)
+
+
+def test_split_patterns_outside_the_family_are_refused():
+    """What does not reduce to the family's parameters is refused at load with the part that did not parse -- never guessed at."""
+    import json
+    import tokenizers_amd as ta
+    d = json.loads(load_tokenizer_json("split_qwen2"))
+    good = d["pre_tokenizer"]["pretokenizers"][0]["pattern"]["Regex"]
+    for bad in (good.replace("\\p{N}|", "\\p{N}{1,4}|"), good.replace("\\s+(?!\\S)|", ""), good + "|x", good.replace("[\\r\\n]*", "[\\r\\n]+"), "\\w+"):
+        d["pre_tokenizer"]["pretokenizers"][0]["pattern"]["Regex"] = bad
+        with pytest.raises(ta.UnsupportedError, match="tiktoken family"):
+            ta.Tokenizer.from_str(json.dumps(d), device=-1)
+    d["pre_tokenizer"]["pretokenizers"][0]["pattern"]["Regex"] = good
+    d["pre_tokenizer"]["pretokenizers"][0]["behavior"] = "Removed"
+    with pytest.raises(ta.UnsupportedError, match="Isolated"):
+        ta.Tokenizer.from_str(json.dumps(d), device=-1)
+    d["pre_tokenizer"]["pretokenizers"][0]["behavior"] = "Isolated"
+    d["pre_tokenizer"]["pretokenizers"][1]["add_prefix_space"] = True           # a prefix space in front of every pre-token (byte_level.rs:122-125)
+    with pytest.raises(ta.UnsupportedError, match="prefix space"):
+        ta.Tokenizer.from_str(json.dumps(d), device=-1)
+
+
 def test_bytelevel_no_regex_vs_oracle():
     import json
     import tokenizers_amd as ta
@@ -315,7 +353,7 @@ def test_trim_offsets_vs_oracle(gpt2_json):
 
 
 @pytest.mark.parametrize("name", ["gpt2_synth_50257", "gpt2_added_tokens", "bytelevel_prefix_trim_3000", "llama3_small_6000", "wordlevel_whitespace_c1", "bert_wordpiece_4000",
-                                  "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"] + BPE_CHAR_GOLDEN)
+                                  "gpt2_bench_added", "gpt2_added_quirk", "bert_wordpiece_4000_added"] + BPE_CHAR_GOLDEN + SPLIT_GOLDEN)
 def test_encode_batch_matches_golden_char_offsets(name):
     """Tokenizer.encode_batch == the wheel's encode_batch (ids, char offsets, word ids) on the committed vectors."""
     import tokenizers_amd as ta

@@ -118,6 +118,18 @@ def test_core_matches_oracle_on_long_mixed_documents(harness, l3):
     _check(harness, js, o, docs)
 
 
+@pytest.mark.parametrize("name", ["split_qwen2", "split_cs_digits", "split_nocontr_d2"])
+def test_core_matches_oracle_on_the_fast_members_of_the_family(harness, name):
+    """the members of the tiktoken family the bit-parallel core implements besides the Llama-3 pattern (tables.hpp split_rule_fast): single
+    digits, digit runs kept whole, digit pairs; contractions case-sensitive or absent"""
+    js = load_tokenizer_json(name)
+    o = orc.Oracle(js)
+    for seed in range(3):
+        _check(harness, js, o, _adversarial(40000, 300 + seed))
+    _check(harness, js, o, _adversarial(4000, 400, max_len=400))
+    _check(harness, js, o, ["1" * 200 + "a" + "22" * 70, "12345 1234 123 12 1", "x" + "9" * 63, "9" * 64 + "x", "1" * 31 + "\u0663" * 40 + "7" * 9])
+
+
 def test_core_decides_nearly_everything_on_prose(harness, l3):
     js, o = l3
     docs = synth.gen_lines(20000, text_seed=3) + synth.stress_lines(seed=4, n=3000)

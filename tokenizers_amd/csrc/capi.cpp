@@ -261,6 +261,7 @@ struct tkamd_tokenizer {
     std::vector<std::unique_ptr<Workspace>> pool;
     Workspace* last_used = nullptr;      // workspace of the most recent call (diagnostics: tkamd_profile_counters)
     // tables
+    DevBuf t_ucc1, t_ucc2;               // case classes of a case-split Split pattern (HostModel::ucc_stage1 / 2), else empty
     DevBuf t_uc1, t_uc2, t_byte_id, t_merges, t_long_blob, t_long_off, t_long_id, t_long_table;
     DevBuf t_hot;                // hot-word table of the lookup kernel (copied into LDS)
     DevBuf t_shortw, t_shortw_k3, t_shortw_disp;   // the short-word table: 16-byte slots, key bytes 12..15, eight-bit displacements (tables.hpp SHORTW_*)
@@ -411,6 +412,7 @@ void upload_tables(tkamd_tokenizer* t) {
     HostModel& hm = t->hm;
     upload(t->t_uc1, hm.uc_stage1);
     upload(t->t_uc2, hm.uc_stage2);
+    if (!hm.ucc_stage1.empty()) { upload(t->t_ucc1, hm.ucc_stage1); upload(t->t_ucc2, hm.ucc_stage2); }
     std::vector<uint32_t> bid(hm.byte_id, hm.byte_id + 256);
     upload(t->t_byte_id, bid);
     upload(t->t_merges, hm.merge_table);
@@ -1503,7 +1505,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         w->w_slow_docs.reserve((size_t)((piece_off ? seg_cap : (size_t)n_docs) + 1) * 4);
         launch_pretok_llama3(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(),
                              w->w_endmask.as<ull>(), piece_off ? piece_off : x_doc_off, piece_off ? (int64_t)seg_cap : n_docs, piece_n_dev,
-                             w->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS);
+                             w->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS, hm.split_rule,
+                             t->t_ucc1.p ? t->t_ucc1.as<uint16_t>() : nullptr, t->t_ucc2.p ? t->t_ucc2.as<uint8_t>() : nullptr);
         pf.end();
     } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
         // ByteLevel(use_regex=false): every document is one pre-token (byte_level.rs:128-130)
@@ -2547,10 +2550,11 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
             return (int64_t)std::max(1, e ? atoi(e) : 16) << 20;
         }();
         constexpr int MAX_SLICES = 16;
-        // (a paced call is cut finer -- 4 MB, the stripe its producer announces: its first slice's copy and kernels then start behind the
-        // first stripes instead of behind the whole text, also for a batch below two ordinary slices)
-        const int64_t slice_min = (pace && pace->ready_bytes) ? std::min<int64_t>(slice_bytes, (int64_t)4 << 20) : slice_bytes;
-        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / slice_min);
+        int n_slices = (int)std::min<int64_t>(MAX_SLICES, n_bytes / slice_bytes);
+        // (a paced call of 8 MB or more goes as two slices at least: the first one's copy and kernels start behind the first half of the
+        // text instead of behind all of it.  Cutting every paced call at 4 MB was measured and lost: 16 slices of 7.5 MB made the 120 MB
+        // list-of-str call 7.5 ms instead of 6.2, profiles/r6a_c2_bench.json)
+        if (pace && pace->ready_bytes && n_slices < 2 && n_bytes >= ((int64_t)8 << 20)) n_slices = 2;
         // (overflowing encodings: how many encodings a slice yields is only known on the device -- one slice)
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow || mixed) n_slices = 1;

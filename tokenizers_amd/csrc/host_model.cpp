@@ -78,6 +78,9 @@ struct UcRun {
 const UcRun kUcRuns[] = {
 #include "unicode_ranges.inc"
 };
+const UcRun kUcCaseRuns[] = {      // (flags: UCC_UPPER / UCC_LOWER, tables.hpp)
+#include "unicode_case_ranges.inc"
+};
 
 struct BnMapRow {
     uint32_t cp, a, b, c;
@@ -150,9 +153,6 @@ bool bytelevel_to_raw(const std::string& tok, const std::unordered_map<uint32_t,
     }
     return true;
 }
-
-const char* kLlama3Pattern =
-    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 
 void build_unicode(HostModel& m) {
     std::vector<uint8_t> flat(0x110000, 0);
@@ -346,6 +346,71 @@ void build_bert_norm(HostModel& m) {
     build_pair_table(items, &m.bn_map, &m.bn_mask, &m.bn_seed);
 }
 
+// The top-level alternatives of a regex source: cut at every '|' outside (...) and [...]; a backslash escapes the next character.
+std::vector<std::string> regex_alternatives(const std::string& rx) {
+    std::vector<std::string> out(1);
+    int depth = 0;
+    bool cls = false;
+    for (size_t i = 0; i < rx.size(); ++i) {
+        const char c = rx[i];
+        if (c == '\\' && i + 1 < rx.size()) { out.back() += c; out.back() += rx[++i]; continue; }
+        if (cls) { if (c == ']') cls = false; }
+        else if (c == '[') cls = true;
+        else if (c == '(') ++depth;
+        else if (c == ')') --depth;
+        else if (c == '|' && depth == 0) { out.emplace_back(); continue; }
+        out.back() += c;
+    }
+    return out;
+}
+
+// Split(Regex(pattern), Isolated) of the tiktoken family -> the parameters of tables.hpp SplitRule (pre_tokenizers/split.rs:76-105 hands
+// the pattern to Oniguruma, tokenizer/pattern.rs:63-83; here the pattern is READ, alternative by alternative, and everything that is not
+// one of the family's spellings is refused).  *gpt2: the pattern is the GPT-2 regex itself (byte_level.rs:43-46), served by that kernel.
+bool parse_split_pattern(const std::string& rx, SplitRule* rule, bool* gpt2, std::string* why) {
+    *gpt2 = rx == "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+    if (*gpt2) return true;
+    const std::vector<std::string> alt = regex_alternatives(rx);
+    size_t k = 0;
+    SplitRule r{0, 0, 3, 1};
+    static const char* const lits[7] = {"'s", "'t", "'re", "'ve", "'m", "'ll", "'d"};
+    const std::string ci = "(?i:'s|'t|'re|'ve|'m|'ll|'d)";
+    auto at = [&](size_t i) -> const std::string& { static const std::string none; return i < alt.size() ? alt[i] : none; };
+    if (at(k) == ci || at(k) == "'(?i:[sdmt]|ll|ve|re)") { r.contr = 1; ++k; }
+    else {
+        bool all = alt.size() >= 7;
+        for (size_t q = 0; q < 7 && all; ++q) all = alt[q] == lits[q];
+        if (all) { r.contr = 2; k = 7; }
+    }
+    const std::string pre = "[^\\r\\n\\p{L}\\p{N}]?", up = "[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]", lo = "[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]";
+    if (at(k) == pre + "\\p{L}+") { r.letters = 0; ++k; }
+    else if ((at(k) == pre + up + "*" + lo + "+" && at(k + 1) == pre + up + "+" + lo + "*") ||
+             (at(k) == pre + up + "*" + lo + "+" + ci + "?" && at(k + 1) == pre + up + "+" + lo + "*" + ci + "?")) {
+        if (at(k).size() > (pre + up + "*" + lo + "+").size()) {
+            if (r.contr) { *why = "contractions both as an alternative and as a suffix of the letter alternatives"; return false; }
+            r.contr = 3;
+        }
+        r.letters = 2;
+        k += 2;
+    } else { *why = "letter alternative '" + at(k) + "'"; return false; }
+    if (at(k) == "\\p{N}{1,3}") r.digit_max = 3;
+    else if (at(k) == "\\p{N}{1,2}") r.digit_max = 2;
+    else if (at(k) == "\\p{N}" || at(k) == "\\p{N}{1}" || at(k) == "\\p{N}{1,1}") r.digit_max = 1;
+    else if (at(k) == "\\p{N}+") r.digit_max = 0;
+    else { *why = "digit alternative '" + at(k) + "'"; return false; }
+    ++k;
+    if (at(k) == " ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*") r.other_tail = 1;
+    else if (at(k) == " ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*") r.other_tail = 2;
+    else { *why = "alternative '" + at(k) + "'"; return false; }
+    ++k;
+    if (at(k) != "\\s*[\\r\\n]+" || at(k + 1) != "\\s+(?!\\S)" || at(k + 2) != "\\s+" || alt.size() != k + 3) {
+        *why = "the whitespace alternatives are not \\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+        return false;
+    }
+    *rule = r;
+    return true;
+}
+
 PretokKind parse_pretok(const JsonValue* pt, HostModel& m) {
     if (!pt || pt->is_null()) throw Unsupported("pre_tokenizer: null is outside the hot path");
     std::string type = pt->get_str("type");
@@ -368,12 +433,23 @@ PretokKind parse_pretok(const JsonValue* pt, HostModel& m) {
                 std::string rx = pat ? pat->get_str("Regex") : "";
                 bool invert = a->get_bool("invert", false);
                 std::string beh = a->get_str("behavior");
-                if (rx == kLlama3Pattern && !invert && beh == "Isolated" && !b->get_bool("use_regex", true)) {
-                    m.byte_level = true;
-                    m.add_prefix_space = b->get_bool("add_prefix_space", true);
-                    return PT_LLAMA3;
-                }
-                throw Unsupported("pre_tokenizer: Sequence[Split, ByteLevel] with a pattern other than the Llama-3 regex");
+                if (rx.empty()) throw Unsupported("pre_tokenizer: Split with a String pattern (only Regex patterns of the tiktoken family are on the path)");
+                if (invert || beh != "Isolated") throw Unsupported("pre_tokenizer: Split with behavior '" + beh + "'" + (invert ? " inverted" : "") + " (only Isolated is on the path)");
+                if (b->get_bool("use_regex", true)) throw Unsupported("pre_tokenizer: Sequence[Split, ByteLevel(use_regex=true)] applies two regexes");
+                // ByteLevel::pre_tokenize puts its prefix space in front of every SPLIT it is handed (byte_level.rs:122-125) -- behind a Split
+                // that is every pre-token, not every document: no tokenizer in use is configured that way, and the path does not build it
+                if (b->get_bool("add_prefix_space", true))
+                    throw Unsupported("pre_tokenizer: Sequence[Split, ByteLevel(add_prefix_space=true)] (a prefix space in front of every pre-token)");
+                SplitRule rule{};
+                bool gpt2 = false;
+                std::string why;
+                if (!parse_split_pattern(rx, &rule, &gpt2, &why))
+                    throw Unsupported("pre_tokenizer: Split pattern outside the tiktoken family (" + why + ")");
+                m.byte_level = true;
+                m.add_prefix_space = false;
+                if (gpt2) return PT_BYTELEVEL_GPT2;
+                m.split_rule = rule;
+                return PT_LLAMA3;
             }
         }
         throw Unsupported("pre_tokenizer: this Sequence is outside the hot path");
@@ -614,6 +690,12 @@ HostModel HostModel::from_json(const char* json, size_t len) {
 
     // ---- pre-tokenizer ----
     m.pretok = parse_pretok(root->get("pre_tokenizer"), m);
+    if (m.pretok == PT_LLAMA3 && m.split_rule.letters == 2) {         // the case classes of the case-split letter alternatives
+        std::vector<uint8_t> flat(0x110000, 0);
+        for (const UcRun& r : kUcCaseRuns)
+            for (uint32_t cp = r.first; cp <= r.last; ++cp) flat[cp] = r.flags;
+        two_stage(flat, &m.ucc_stage1, &m.ucc_stage2);
+    }
 
     // ---- post-processor: offset trimming + the special tokens it puts around a single sequence ----
     {

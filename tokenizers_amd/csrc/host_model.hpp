@@ -166,6 +166,9 @@ struct HostModel {
 
     std::vector<uint16_t> uc_stage1;    // [UC_STAGE1_LEN]
     std::vector<uint8_t> uc_stage2;     // [n_blocks*256]
+    SplitRule split_rule = SPLIT_RULE_LLAMA3;   // PT_LLAMA3: which member of the tiktoken family the Split pattern is (tables.hpp)
+    std::vector<uint16_t> ucc_stage1;   // case classes of the case-split letter alternatives (split_rule.letters == 2), same two stages; else empty
+    std::vector<uint8_t> ucc_stage2;
 
     // raw-byte form of every vocab entry that is expressible in raw bytes (byte-level: inverse of
     // the GPT-2 alphabet; others: the UTF-8 string itself) -- used to build the tables above and by

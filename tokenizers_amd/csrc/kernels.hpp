@@ -352,9 +352,11 @@ void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err);
 void launch_wordpiece_long3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
+// (rule: the member of the tiktoken family, tables.hpp SplitRule; ucc1 / ucc2: the case classes its case-split letter alternatives read, else null)
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
-                          const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs);
+                          const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs,
+                          SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2);
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);
 void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx,
                         int64_t* first_tok);

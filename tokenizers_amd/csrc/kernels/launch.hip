@@ -215,19 +215,27 @@ void launch_wordpiece_long3(hipStream_t st, int grid, const DevTables& t, const 
 }
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
-                          const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs) {
-    // TKAMD_PRETOK_L3=tile: the lane-per-byte tile kernel alone; default: the per-lane bit-parallel kernel first, the tile
-    // kernel only on the tiles where it left bytes undecided.  doc_off: the sentences the sequential matcher may be handed
-    // (documents, or the pieces between added-token matches).
-    static const bool tile_only = [] { const char* e = getenv("TKAMD_PRETOK_L3"); return e && !strcmp(e, "tile"); }();
-    if (!tile_only)
-        hipLaunchKernelGGL(k_pretok_llama3_lane, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask);
-    hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, tile_only ? 0 : 1);
-    hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_docs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
-    hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, uc1, uc2, startmask);
+                          const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs,
+                          SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2) {
+    // Three tiers: the per-lane bit-parallel kernel, the tile kernel on the tiles where that left bytes undecided, the sequential matcher
+    // on the sentences (doc_off: documents, or the pieces between added-token matches) the tile kernel could not finish.  A member of the
+    // family the first two do not implement (tables.hpp split_rule_fast: the case-split letters of o200k / tekken, the `/` in the tail of
+    // an O-run) goes to the sequential matcher whole: every sentence, one lane each.
+    const L3Seq q{uc1, uc2, ucc1, ucc2, rule};
+    const unsigned doc_blocks = std::min<unsigned>(blocks_for(n_docs, 256), 4096u);
+    if (split_rule_fast(rule)) {
+        hipLaunchKernelGGL(k_pretok_llama3_lane, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule);
+        hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, 1, rule);
+        hipLaunchKernelGGL(k_l3_slow_docs, dim3(doc_blocks), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
+        hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, q, startmask);
+    } else {
+        (void)hipMemsetAsync(startmask, 0, (size_t)((n_bytes >> 6) + 1) * 8, st);
+        hipLaunchKernelGGL(k_l3_slow_docs, dim3(doc_blocks), dim3(256), 0, st, (const unsigned long long*)nullptr, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
+        hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(8192), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, q, startmask);
+    }
 }
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask) {
-    hipLaunchKernelGGL(k_leadmask, dim3(blocks_for(n_bytes + 1, 256)), dim3(256), 0, st, text, n_bytes, leadmask);
+    hipLaunchKernelGGL(k_leadmask, dim3(blocks_for(n_bytes + 64, 256 * 16)), dim3(256), 0, st, text, n_bytes, leadmask);
 }
 void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, int64_t n_words, const int64_t* word_tok_off, int64_t* seq_tok_off, uint32_t* widx,
                         int64_t* first_tok) {
@@ -236,7 +244,9 @@ void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, 
         hipLaunchKernelGGL(k_word_index, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, seq_off, n_seqs, n_words, widx, (const int64_t*)seq_tok_off, first_tok);
 }
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
-    hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
+    // (char_id: BPE over characters without an unk_token -- token edges depend on the tokens in front of them: the sequential shape)
+    if (a.char_id) hipLaunchKernelGGL(k_token_meta_seq, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
 }
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid) {

@@ -347,14 +347,99 @@ __device__ __forceinline__ uint32_t lead_rank(const unsigned long long* __restri
     return lprefix[pos >> 6] + (uint32_t)__popcll(m & ((1ull << b) - 1ull));
 }
 
+// lead-byte bitmask of the text (char offsets: BytesToCharOffsetConverter, pre_tokenizer.rs:329-364, as ranks of lead bytes).  A lane takes
+// sixteen bytes -- one load -- and folds "not a continuation byte" of each into four bits per word with a multiply (bits 0 / 8 / 16 / 24 of
+// a word land on bits 24..27, no carries); four lanes make one mask word.  (Rounds 1-5: a lane per byte and a ballot, 0.215 ms on 120 MB.)
 __global__ __launch_bounds__(256) void k_leadmask(const uint8_t* __restrict__ text, int64_t n_bytes, unsigned long long* __restrict__ leadmask) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool lead = (i < n_bytes) && ((text[i] & 0xC0u) != 0x80u);
-    uint64_t m = __ballot(lead);
-    if ((threadIdx.x & 63) == 0 && i <= n_bytes) leadmask[i >> 6] = m;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;          // 16-byte group
+    const int64_t i = q * 16;
+    uint32_t bits = 0u;
+    if (i < n_bytes) {                                                   // (the text is readable TEXT_PAD bytes beyond its end)
+        const uint4 v = *(const uint4*)(text + i);
+        auto four = [](uint32_t w) -> uint32_t {
+            const uint32_t cont = (w >> 7) & (~w >> 6) & 0x01010101u;    // byte is 10xxxxxx
+            return (((cont ^ 0x01010101u) * 0x01020408u) >> 24) & 0xFu;
+        };
+        bits = four(v.x) | (four(v.y) << 4) | (four(v.z) << 8) | (four(v.w) << 12);
+        const int64_t left = n_bytes - i;
+        if (left < 16) bits &= (1u << left) - 1u;
+    }
+    unsigned long long m = (unsigned long long)bits << (16 * (threadIdx.x & 3));
+    m |= __shfl_xor(m, 1, 64);
+    m |= __shfl_xor(m, 2, 64);
+    if ((threadIdx.x & 3) == 0 && i <= n_bytes) leadmask[i >> 6] = m;
 }
 
-__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
+// offsets / word id of ONE token: token j of pre-token p (document d; [s, e) in x space; its tokens are o .. o + c), covering
+// [s + rel, s + rel_end) of the x text.  Everything of into_encoding / process_offsets that is per token.
+__device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int64_t d, uint32_t s, uint32_t e, bool is_match, uint32_t o, uint32_t j,
+                                               uint32_t rel, uint32_t rel_end, uint32_t xdoc, uint32_t odoc, uint32_t word) {
+    if (a.want_words) a.word_ids[o + j] = word;
+    if (!a.want_offsets) return;
+    uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
+    uint32_t bs = ts, be = te;
+    if (a.snap_chars && !is_match) {                      // snap to char boundaries inside the pre-token (its own edges are char boundaries)
+        while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
+        while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
+    }
+    // x space -> original text
+    uint32_t os, oe;
+    const uint8_t* ttext = a.x_text;                      // text the trimming below reads, and the token's span in it
+    uint32_t tts = ts, tte = te;
+    if (is_match) {
+        const uint32_t ml = a.tmp_end[s];
+        os = a.norig ? a.norig[s] : s - xdoc + odoc;
+        if (ml & MATCH_LEN_ORIG) { oe = os + (ml & ~MATCH_LEN_ORIG); ttext = a.text; tts = os; tte = oe; }
+        else { tte = s + ml; oe = a.norig ? a.norig_e[tte - 1] : tte - xdoc + odoc; }
+    }
+    else if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
+    else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
+    if (a.char_mode) {
+        uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
+        os = lead_rank(a.leadmask, a.lprefix, os) - base;
+        oe = lead_rank(a.leadmask, a.lprefix, oe) - base;
+    } else { os -= odoc; oe -= odoc; }
+    if (a.trim_offsets) {                                 // process_offsets, byte_level.rs:202-234
+        uint32_t lead_sp = 0, trail_sp = 0;
+        if (is_match) {
+            // an added token's text is the raw slice: its leading / trailing chars are tested with char::is_whitespace
+            uint32_t q = tts;
+            while (q < tte) { uint32_t l; const uint32_t cp = utf8_global(ttext, q, &l); if (cp != 0x120u && !(uc_flags(cp, a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
+            q = tte;
+            while (q > tts) {
+                uint32_t r = q - 1;
+                while (r > tts && (ttext[r] & 0xC0u) == 0x80u) --r;
+                uint32_t l;
+                const uint32_t cp = utf8_global(ttext, r, &l);
+                if (cp != 0x120u && !(uc_flags(cp, a.uc1, a.uc2) & UC_RUST_WS)) break;   // (*c == 'Ġ' || c.is_whitespace())
+                ++trail_sp;
+                q = r;
+            }
+        } else if (!a.trim_matches_only) {
+            while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
+            while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
+        }
+        bool took_one = false;
+        const uint32_t os0 = os, oe0 = oe;
+        if (lead_sp) {
+            // (token 0 of the encoding, or offsets that start at 0 -- every word of a pre-tokenized sequence, byte_level.rs:213-216;
+            // `word` is no test for it: all pre-tokens of a sequence's word 0 carry word id 0; first_tok: pre-tokenized input)
+            bool is_first = (a.first_tok ? (int64_t)(o + j) == a.first_tok[d] : (p == (int64_t)a.doc_pt[d] && j == 0)) || os == 0;
+            if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
+            took_one = lead_sp == 1 && a.pp_add_prefix_space && os < oe;
+            os = min(os + lead_sp, oe);
+        }
+        if (trail_sp && oe >= trail_sp) oe = max(oe - trail_sp, os);
+        // (2: as token 0 of an encoding its END would differ too -- the token is nothing but that one space, so the trailing
+        // trim stops at a start that lies one further left)
+        if (a.trim1) a.trim1[o + j] = !took_one ? 0 : (((trail_sp && oe0 >= trail_sp) ? max(oe0 - trail_sp, os0) : oe0) != oe) ? 2 : 1;
+    }
+    *(uint2*)(a.offsets + 2 * (size_t)(o + j)) = make_uint2(os, oe);
+}
+
+// One lane per PRE-TOKEN, its tokens in a loop: the shape of rounds 1-5, kept for the one configuration whose token edges depend on the
+// tokens in front of them -- BPE over characters without an unk_token, where dropped chars move every later edge (`running` below).
+__global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
     const int64_t P = *a.n_pretok;
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (int64_t)gridDim.x * 256) {
         const uint32_t o = a.pt_tokoff[p];
@@ -403,70 +488,98 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         };
         for (uint32_t j = 0; j < c; ++j) {
             uint32_t rel_end = running((c == 1 || !a.tmp_end) ? (e - s) : a.tmp_end[s_ends + j]);      // (no token ends without offsets: word ids only)
-            if (a.want_words) a.word_ids[o + j] = word;
-            if (a.want_offsets) {
-                uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
-                uint32_t bs = ts, be = te;
-                if (a.snap_chars && !is_match) {                      // snap to char boundaries inside the pre-token
-                    while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
-                    while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
-                }
-                // x space -> original text
-                uint32_t os, oe;
-                const uint8_t* ttext = a.x_text;                      // text the trimming below reads, and the token's span in it
-                uint32_t tts = ts, tte = te;
-                if (is_match) {
-                    const uint32_t ml = a.tmp_end[s];
-                    os = a.norig ? a.norig[s] : s - xdoc + odoc;
-                    if (ml & MATCH_LEN_ORIG) { oe = os + (ml & ~MATCH_LEN_ORIG); ttext = a.text; tts = os; tte = oe; }
-                    else { tte = s + ml; oe = a.norig ? a.norig_e[tte - 1] : tte - xdoc + odoc; }
-                }
-                else if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
-                else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
-                if (a.char_mode) {
-                    uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
-                    os = lead_rank(a.leadmask, a.lprefix, os) - base;
-                    oe = lead_rank(a.leadmask, a.lprefix, oe) - base;
-                } else { os -= odoc; oe -= odoc; }
-                if (a.trim_offsets) {                                 // process_offsets, byte_level.rs:202-234
-                    uint32_t lead_sp = 0, trail_sp = 0;
-                    if (is_match) {
-                        // an added token's text is the raw slice: its leading / trailing chars are tested with char::is_whitespace
-                        uint32_t q = tts;
-                        while (q < tte) { uint32_t l; const uint32_t cp = utf8_global(ttext, q, &l); if (cp != 0x120u && !(uc_flags(cp, a.uc1, a.uc2) & UC_RUST_WS)) break; ++lead_sp; q += l; }
-                        q = tte;
-                        while (q > tts) {
-                            uint32_t r = q - 1;
-                            while (r > tts && (ttext[r] & 0xC0u) == 0x80u) --r;
-                            uint32_t l;
-                            const uint32_t cp = utf8_global(ttext, r, &l);
-                            if (cp != 0x120u && !(uc_flags(cp, a.uc1, a.uc2) & UC_RUST_WS)) break;   // (*c == 'Ġ' || c.is_whitespace())
-                            ++trail_sp;
-                            q = r;
-                        }
-                    } else if (!a.trim_matches_only) {
-                        while (ts + lead_sp < te && a.x_text[ts + lead_sp] == 0x20u) ++lead_sp;
-                        while (trail_sp < te - ts && a.x_text[te - 1 - trail_sp] == 0x20u) ++trail_sp;
-                    }
-                    bool took_one = false;
-                    const uint32_t os0 = os, oe0 = oe;
-                    if (lead_sp) {
-                        // (token 0 of the encoding, or offsets that start at 0 -- every word of a pre-tokenized sequence, byte_level.rs:213-216;
-                        // `word` is no test for it: all pre-tokens of a sequence's word 0 carry word id 0; first_tok: pre-tokenized input)
-                        bool is_first = (a.first_tok ? (int64_t)(o + j) == a.first_tok[d] : (p == (int64_t)a.doc_pt[d] && j == 0)) || os == 0;
-                        if (is_first && a.pp_add_prefix_space && lead_sp == 1) lead_sp = 0;
-                        took_one = lead_sp == 1 && a.pp_add_prefix_space && os < oe;
-                        os = min(os + lead_sp, oe);
-                    }
-                    if (trail_sp && oe >= trail_sp) oe = max(oe - trail_sp, os);
-                    // (2: as token 0 of an encoding its END would differ too -- the token is nothing but that one space, so the trailing
-                    // trim stops at a start that lies one further left)
-                    if (a.trim1) a.trim1[o + j] = !took_one ? 0 : (((trail_sp && oe0 >= trail_sp) ? max(oe0 - trail_sp, os0) : oe0) != oe) ? 2 : 1;
-                }
-                a.offsets[2 * (size_t)(o + j)] = os;
-                a.offsets[2 * (size_t)(o + j) + 1] = oe;
-            }
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word);
             rel = rel_end;
+        }
+    }
+}
+
+// One lane per TOKEN (round 6).  A workgroup takes tiles of TM_TILE consecutive pre-tokens: their token offsets, starts and ends go to LDS
+// with coalesced loads; the document of the tile's first pre-token is found ONCE (a 64-ary search of wavefront 0 over doc_pt: four
+// dependent loads, where every lane of the old shape ran twenty), the documents that start inside the tile are counted into the tile's
+// pre-tokens and a scan turns the counts into every pre-token's document; then the tile's tokens -- consecutive in the output arrays --
+// are dealt to the lanes round robin: a lane finds its token's pre-token by a binary search over the LDS copy of the token offsets and
+// writes 12 bytes next to its neighbour's.  The per-pre-token shape spent 1.14 ms on C2's 22.7 M tokens (profiles/r6a_c2_bench.json: the
+// binary search and its scattered stores); this one is bound by the 12 T bytes it writes and the token ends it gathers.
+constexpr int TM_TILE = 1024;
+__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
+    __shared__ uint32_t s_tokoff[TM_TILE + 1];
+    __shared__ uint32_t s_start[TM_TILE + 1];
+    __shared__ uint32_t s_end[TM_TILE];
+    __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
+    __shared__ uint32_t s_scan[8];
+    const int64_t P = *a.n_pretok;
+    const uint32_t n_tok = (uint32_t)*a.n_tok;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n_tiles = (P + TM_TILE - 1) / TM_TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TM_TILE;
+        const int np = (int)min((int64_t)TM_TILE, P - base);
+        __syncthreads();                                  // (the previous tile's readers are done)
+        for (int i = tid; i <= np; i += 256) {
+            const int64_t p = base + i;
+            s_tokoff[i] = p < P ? a.pt_tokoff[p] : n_tok;
+            s_start[i] = a.pt_start[p];                   // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
+            if (i < np) { s_doc[i] = 0u; if (a.pt_end) s_end[i] = a.pt_end[p]; }
+        }
+        // the document of the tile's first pre-token: the last d with doc_pt[d] <= base (doc_pt[0] = 0, doc_pt[n_docs] = P > base)
+        if (wave == 0) {
+            int64_t lo = 0, hi = a.n_docs;
+            while (hi - lo > 1) {
+                const int64_t step = (hi - lo + 63) / 64;
+                const int64_t idx = lo + (int64_t)(lane + 1) * step;
+                const bool le = idx < hi && (int64_t)a.doc_pt[idx] <= base;
+                const int k = __popcll(__ballot(le));     // doc_pt is monotone: the lanes that hold are the first k
+                const int64_t nlo = lo + (int64_t)k * step;
+                hi = min(hi, lo + (int64_t)(k + 1) * step);
+                lo = nlo;
+            }
+            if (lane == 0) s_scan[4] = (uint32_t)lo;
+        }
+        __syncthreads();
+        const uint32_t d_first = s_scan[4];
+        // documents d > d_first that start inside the tile: one count at their first pre-token (an empty document adds to the next one's)
+        for (int64_t d = (int64_t)d_first + 1 + tid; d < a.n_docs; d += 256) {
+            const int64_t r = (int64_t)a.doc_pt[d] - base;
+            if (r >= np) break;
+            atomicAdd(&s_doc[r], 1u);
+        }
+        __syncthreads();
+        {   // inclusive scan over the tile, four pre-tokens a lane
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = (4 * tid + q < np) ? s_doc[4 * tid + q] : 0u; sum += v[q]; }
+            uint32_t tot;
+            uint32_t run = block256_excl_scan(sum, s_scan, &tot) + d_first;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
+        }
+        __syncthreads();
+        const uint32_t T0 = s_tokoff[0], T1 = s_tokoff[np];
+        for (uint32_t t = T0 + (uint32_t)tid; t < T1; t += 256u) {
+            // the pre-token of token t: the last i with tokoff[i] <= t (pre-tokens without tokens are skipped by construction)
+            int lo = 0, hi = np;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_tokoff[mid] <= t) lo = mid; else hi = mid; }
+            const int i = lo;
+            const int64_t p = base + i;
+            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o, j = t - o;
+            const uint32_t s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const int64_t d = (int64_t)s_doc[i];
+            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
+            const uint32_t xdoc = (uint32_t)a.x_doc_off[d];
+            const uint32_t odoc = (uint32_t)a.doc_off[d];
+            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+            uint32_t rel = 0u, rel_end = e - s;
+            if (c > 1u && a.tmp_end) {
+                uint32_t s_ends = s;                      // whose token ends: the pre-token's own, or the claimant's of its word
+                if (a.claim_pos) {
+                    const uint32_t t0 = a.tok0[p];
+                    if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = a.claim_pos[t0 & TOK_REF_MASK];
+                }
+                if (j) rel = a.tmp_end[s_ends + j - 1u];
+                rel_end = a.tmp_end[s_ends + j];
+            }
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word);
         }
     }
 }

@@ -41,12 +41,13 @@ struct L3View {
     __device__ __forceinline__ bool inside(int k) const { return (si[k] & L3_VALID) && !(si[k] & L3_DOC); }
 };
 
-// case-insensitive contraction letter at lead byte k: returns 's','t','m','d','r','v','e','l' or 0; *nx = next position
-__device__ __forceinline__ uint32_t l3_letter(const L3View& v, int k, int* nx) {
+// contraction letter at lead byte k: returns 's','t','m','d','r','v','e','l' (any ASCII letter, lower case) or 0; *nx = next position.
+// fold: the literals are case-insensitive ((?i:...): upper case matches, and U+017F folds to 's'); else only lower case does
+__device__ __forceinline__ uint32_t l3_letter(const L3View& v, int k, int* nx, bool fold) {
     uint32_t b = v.sb[k];
-    if (b == 0xC5u && v.sb[k + 1] == 0xBFu) { *nx = k + 2; return 's'; }       // U+017F LATIN SMALL LETTER LONG S folds to 's'
+    if (fold && b == 0xC5u && v.sb[k + 1] == 0xBFu) { *nx = k + 2; return 's'; }       // U+017F LATIN SMALL LETTER LONG S folds to 's'
     *nx = k + 1;
-    uint32_t f = b | 0x20u;
+    uint32_t f = fold ? (b | 0x20u) : b;
     return (f - 'a' < 26u) ? f : 0u;
 }
 
@@ -55,7 +56,9 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
                                                        const unsigned long long* __restrict__ docmask,
                                                        const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                        unsigned long long* __restrict__ startmask,
-                                                       unsigned long long* __restrict__ slowmask, int refine) {
+                                                       unsigned long long* __restrict__ slowmask, int refine, SplitRule rule) {
+    // rule: which member of the family (tables.hpp SplitRule; this kernel: split_rule_fast ones -- the contraction alternative absent /
+    // case-insensitive / case-sensitive, digit runs cut every 1, 2, 3 code points or not at all)
     // refine: k_pretok_llama3_lane has run; only tiles in which it left bytes undecided (bits of slowmask) are redone
     if (refine) {
         const int64_t w0 = (int64_t)blockIdx.x * (PT_TILE / 64);
@@ -111,14 +114,15 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
     // contraction literals: fire only where the apostrophe is itself a match start
     for (int k = tid; k < L3_R; k += 256) {
         uint32_t con = 0;
-        if (k >= 4 && k < L3_R - 8 && sb[k] == '\'' && (si[k] & L3_VALID)) {
+        if (rule.contr && k >= 4 && k < L3_R - 8 && sb[k] == '\'' && (si[k] & L3_VALID)) {
+            const bool fold = rule.contr == 1;
             int k1 = k + 1, k2, k3;
             if (v.inside(k1) && (si[k1] & L3_LEAD)) {
-                uint32_t a = l3_letter(v, k1, &k2);
+                uint32_t a = l3_letter(v, k1, &k2, fold);
                 uint32_t lit = 0;
                 if (a == 's' || a == 't' || a == 'm' || a == 'd') lit = 1;
                 else if ((a == 'r' || a == 'v' || a == 'l') && v.inside(k2) && (si[k2] & L3_LEAD) && sb[k2] < 0x80u) {
-                    uint32_t b2 = l3_letter(v, k2, &k3);
+                    uint32_t b2 = l3_letter(v, k2, &k3, fold);
                     if ((a == 'l') ? (b2 == 'l') : (b2 == 'e')) lit = 2;
                 }
                 if (lit) {
@@ -180,19 +184,23 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
                     start = !(c1 == 0 || (i1 & L3_SP));
                     if (eaten_prev) start = true;
                 } else if (c == 2) {
-                    // position inside the digit run, mod 3
-                    int cnt = 0, j = k;
-                    bool ok = true;
-                    while (true) {
-                        if (!v.has_prev(j)) break;
-                        int pj = v.prev(j);
-                        if (pj < 4) { ok = false; break; }
-                        if ((si[pj] & L3_CLS) != 2) break;
-                        j = pj;
-                        ++cnt;
+                    // position inside the digit run, mod digit_max (1: every digit starts a match; 0: \p{N}+, the run's first one does)
+                    if (rule.digit_max == 1) start = true;
+                    else if (rule.digit_max == 0) start = c1 != 2;
+                    else {
+                        int cnt = 0, j = k;
+                        bool ok = true;
+                        while (true) {
+                            if (!v.has_prev(j)) break;
+                            int pj = v.prev(j);
+                            if (pj < 4) { ok = false; break; }
+                            if ((si[pj] & L3_CLS) != 2) break;
+                            j = pj;
+                            ++cnt;
+                        }
+                        if (!ok) unresolved = true;
+                        start = (cnt % (int)rule.digit_max) == 0;
                     }
-                    if (!ok) unresolved = true;
-                    start = (cnt % 3) == 0;
                 } else {
                     // whitespace run [q, e); q' = q + leading CR/LFs swallowed by a preceding O-run match
                     int q = k;
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
                                                             const unsigned long long* __restrict__ docmask,
                                                             const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                             unsigned long long* __restrict__ startmask,
-                                                            unsigned long long* __restrict__ slowmask) {
+                                                            unsigned long long* __restrict__ slowmask, SplitRule rule) {
     __shared__ uint2 lut[SQ_LUT_COPIES * 256];
     {
         const L3Flags f = l3_byte_flags(threadIdx.x);
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
         }
         m.L &= m.V; m.N &= m.V; m.W &= m.V; m.R &= m.V; m.SP &= m.V; m.C &= m.V; m.AP &= m.V; m.MU &= m.V;
         uint64_t s64, u64;
-        l3_window_starts(m, text, base, uc1, uc2, &s64, &u64);
+        l3_window_starts(m, text, base, uc1, uc2, &s64, &u64, rule);
         st = (s64 >> L3W_HALO) & 0xFFFFFFFFull;
         un = (u64 >> L3W_HALO) & 0xFFFFFFFFull;
     }
@@ -332,24 +340,70 @@ __device__ __forceinline__ uint32_t l3_dec(const uint8_t* __restrict__ s, int64_
     *len = 1;
     return 0xFFFDu;
 }
-__device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_t n, const uint16_t* uc1, const uint8_t* uc2) {
+// What the sequential matcher needs besides the text: the class tables and the member of the family (tables.hpp SplitRule)
+struct L3Seq {
+    const uint16_t* uc1;
+    const uint8_t* uc2;
+    const uint16_t* ucc1;        // case classes (rule.letters == 2), else null
+    const uint8_t* ucc2;
+    SplitRule rule;
+};
+__device__ __forceinline__ uint32_t l3_case(const L3Seq& q, uint32_t cp) {
+    return cp < 0x110000u ? (uint32_t)q.ucc2[((uint32_t)q.ucc1[cp >> 8] << 8) | (cp & 255u)] : 0u;
+}
+// 'S|'T|'RE|'VE|'M|'LL|'D at the apostrophe s[i] (fold: (?i:...) -- Unicode simple case folding: upper case, and U+017F for 's'):
+// the end of the literal, or i when none starts there
+__device__ int64_t l3_contraction(const uint8_t* __restrict__ s, int64_t i, int64_t n, bool fold) {
+    if (i + 1 >= n || s[i] != '\'') return i;
+    int l1, l2 = 0;
+    const uint32_t a = l3_dec(s, i + 1, n, &l1);
+    const uint32_t af = (fold && a == 0x17Fu) ? 's' : ((a < 0x80u && ((fold ? (a | 0x20u) : a) - 'a') < 26u) ? (fold ? (a | 0x20u) : a) : 0u);
+    const int64_t p2 = i + 1 + l1;
+    uint32_t bf = 0;
+    if (p2 < n) { const uint32_t b = l3_dec(s, p2, n, &l2); bf = (b < 0x80u && ((fold ? (b | 0x20u) : b) - 'a') < 26u) ? (fold ? (b | 0x20u) : b) : 0u; }
+    if (af == 's' || af == 't' || af == 'm' || af == 'd') return p2;
+    if (p2 < n && (((af == 'r' || af == 'v') && bf == 'e') || (af == 'l' && bf == 'l'))) return p2 + l2;
+    return i;
+}
+// The case-split letter alternatives of o200k / tekken from p on, without their optional prefix char:
+//   A  [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+        B  [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*
+// With u = upper only (Lu, Lt), l = lower only (Ll), b = both (Lm, Lo, M): the greedy U* takes the longest [ub]* run; if an l follows, A is
+// that run + the longest [lb]+ behind it; else A backtracks to the LAST b of the run (its L+ is that one char: only u's follow it) --
+// the trailing u's are left for the next match; a run of u's alone fails A and is B's.  *kind: 1 A matched, 2 only B, 0 neither.
+__device__ int64_t l3_case_run(const L3Seq& q, const uint8_t* __restrict__ s, int64_t p, int64_t n, int* kind) {
+    int64_t j = p, last_b_end = -1;
+    int l = 1;
+    uint32_t cc = 0;
+    while (j < n) {
+        cc = l3_case(q, l3_dec(s, j, n, &l));
+        if (!(cc & UCC_UPPER)) break;
+        if (cc & UCC_LOWER) last_b_end = j + l;
+        j += l;
+    }
+    if (j < n && (cc & UCC_LOWER)) {                      // (not UPPER, so lower only) U* then L+
+        j += l;
+        while (j < n) { int lj; if (!(l3_case(q, l3_dec(s, j, n, &lj)) & UCC_LOWER)) break; j += lj; }
+        *kind = 1;
+        return j;
+    }
+    if (last_b_end >= 0) { *kind = 1; return last_b_end; }
+    *kind = j > p ? 2 : 0;
+    return j;
+}
+// One leftmost-first match of the family's pattern at s[i] (the alternatives in the pattern's order, each with the backtracking the
+// regex engine would do); returns its end
+__device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_t n, const L3Seq& q) {
+    const uint16_t* const uc1 = q.uc1;
+    const uint8_t* const uc2 = q.uc2;
+    const SplitRule rule = q.rule;
     int l;
     uint32_t c = l3_dec(s, i, n, &l);
     uint32_t cc = cls_llama3(c, uc1, uc2);
-    if (c == '\'' && i + 1 < n) {
-        int l1, l2 = 0;
-        uint32_t a = l3_dec(s, i + 1, n, &l1);
-        uint32_t af = (a == 0x17Fu) ? 's' : ((a | 0x20u) - 'a' < 26u && a < 0x80u ? (a | 0x20u) : 0u);
-        int64_t p2 = i + 1 + l1;
-        uint32_t bf = 0;
-        if (p2 < n) { uint32_t b = l3_dec(s, p2, n, &l2); bf = (b < 0x80u && (b | 0x20u) - 'a' < 26u) ? (b | 0x20u) : 0u; }
-        if (af == 's' || af == 't') return p2;
-        if (p2 < n && ((af == 'r' && bf == 'e') || (af == 'v' && bf == 'e'))) return p2 + l2;
-        if (af == 'm') return p2;
-        if (p2 < n && af == 'l' && bf == 'l') return p2 + l2;
-        if (af == 'd') return p2;
+    if (rule.contr == 1 || rule.contr == 2) {
+        const int64_t e = l3_contraction(s, i, n, rule.contr == 1);
+        if (e > i) return e;
     }
-    {   // [^\r\n\p{L}\p{N}]?\p{L}+
+    if (rule.letters == 0) {   // [^\r\n\p{L}\p{N}]?\p{L}+
         int64_t k = (cc == 0 || cc == 3) ? i + l : i;
         if (k < n) {
             int lk;
@@ -360,14 +414,27 @@ __device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_
                 return j;
             }
         }
+    } else {                   // prefix? A | prefix? B, each with the contraction suffix: A with the prefix char, A without, B with, B without
+        int64_t e = -1;
+        int k0 = 0, k1 = 0;
+        int64_t e1 = -1;
+        if ((cc == 0 || cc == 3) && i + l < n) e1 = l3_case_run(q, s, i + l, n, &k1);
+        if (k1 == 1) e = e1;
+        else {
+            const int64_t e0 = l3_case_run(q, s, i, n, &k0);
+            if (k0 == 1) e = e0;
+            else if (k1 == 2) e = e1;
+            else if (k0 == 2) e = e0;
+        }
+        if (e >= 0) return rule.contr == 3 ? l3_contraction(s, e, n, true) : e;
     }
-    if (cc == 2) {   // \p{N}{1,3}
+    if (cc == 2) {   // \p{N}{1,k} / \p{N}+
         int64_t j = i + l;
         int cnt = 1;
-        while (j < n && cnt < 3) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); if (cls_llama3(cj, uc1, uc2) != 2) break; j += lj; ++cnt; }
+        while (j < n && (rule.digit_max == 0 || cnt < (int)rule.digit_max)) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); if (cls_llama3(cj, uc1, uc2) != 2) break; j += lj; ++cnt; }
         return j;
     }
-    {   // " ?[^\s\p{L}\p{N}]+[\r\n]*"
+    {   // " ?[^\s\p{L}\p{N}]+[\r\n]*"   (o200k: [\r\n/]*)
         int64_t k = (s[i] == ' ') ? i + 1 : i;
         if (k < n) {
             int lk;
@@ -375,15 +442,14 @@ __device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_
             if (cls_llama3(ck, uc1, uc2) == 0) {
                 int64_t j = k + lk;
                 while (j < n) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); if (cls_llama3(cj, uc1, uc2) != 0) break; j += lj; }
-                while (j < n && (s[j] == '\r' || s[j] == '\n')) ++j;
+                while (j < n && (s[j] == '\r' || s[j] == '\n' || (rule.other_tail == 2 && s[j] == '/'))) ++j;
                 return j;
             }
         }
     }
     if (cc >= 3) {
-        int64_t j = i, last = -1, prev = i, cur = i;
-        while (j < n) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); uint32_t k = cls_llama3(cj, uc1, uc2); if (k < 3) break; if (k == 4) last = j; prev = cur; cur = j; j += lj; }
-        (void)prev;
+        int64_t j = i, last = -1, cur = i;
+        while (j < n) { int lj; uint32_t cj = l3_dec(s, j, n, &lj); uint32_t k = cls_llama3(cj, uc1, uc2); if (k < 3) break; if (k == 4) last = j; cur = j; j += lj; }
         if (last >= 0) return last + 1;          // \s*[\r\n]+
         if (j >= n) return j;                    // \s+(?!\S) at end of text
         if (cur > i) return cur;                 // \s+(?!\S): all but the last whitespace char
@@ -394,13 +460,14 @@ __device__ int64_t l3_match_seq(const uint8_t* __restrict__ s, int64_t i, int64_
 
 // documents with at least one unresolved byte -> slow_docs list (one lane per document)
 // (n_dev: the number of sentences when it only exists on the device -- pieces between added-token matches; n_docs is then its bound)
+// (slowmask null: every document that is not empty -- the members of the family only the sequential matcher serves)
 __global__ void k_l3_slow_docs(const unsigned long long* __restrict__ slowmask, const int64_t* __restrict__ doc_off, int64_t n_docs, const int64_t* __restrict__ n_dev,
                                uint32_t* __restrict__ slow_docs, uint32_t* __restrict__ n_slow_docs) {
     if (n_dev) n_docs = *n_dev;
     for (int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; d < n_docs; d += (int64_t)gridDim.x * blockDim.x) {
         const int64_t a = doc_off[d], b = doc_off[d + 1];
         if (b <= a) continue;
-        bool any = false;
+        bool any = slowmask == nullptr;
         for (int64_t w = a >> 6; w <= (b - 1) >> 6 && !any; ++w) {
             int64_t lo = w << 6, hi = lo + 64;
             unsigned long long m = slowmask[w];
@@ -414,8 +481,7 @@ __global__ void k_l3_slow_docs(const unsigned long long* __restrict__ slowmask, 
 
 __global__ void k_pretok_llama3_slow(const uint8_t* __restrict__ text, const int64_t* __restrict__ doc_off,
                                      const uint32_t* __restrict__ slow_docs, const uint32_t* __restrict__ n_slow_docs,
-                                     const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
-                                     unsigned long long* __restrict__ startmask) {
+                                     L3Seq q, unsigned long long* __restrict__ startmask) {
     const uint32_t n = *n_slow_docs;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t d = slow_docs[i];
@@ -434,7 +500,7 @@ __global__ void k_pretok_llama3_slow(const uint8_t* __restrict__ text, const int
         while (p < len) {
             int64_t g = a + p;
             atomicOr(&startmask[g >> 6], 1ull << (g & 63));
-            int64_t e = l3_match_seq(s, p, len, uc1, uc2);
+            int64_t e = l3_match_seq(s, p, len, q);
             if (e <= p) e = p + 1;
             p = e;
         }

@@ -2,6 +2,9 @@
 //
 //   (?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+
 //
+// and the members of its family that differ in the contraction alternative (absent / case-sensitive) and in the digit alternative
+// (\p{N}{1,k} with k = 1, 2, 3, or \p{N}+): tables.hpp SplitRule, split_rule_fast().
+//
 // The function below is the whole per-lane logic of k_pretok_llama3_lane (kernels.hip): a lane owns the 32 bytes
 // [16, 48) of its window and decides, for each of them, whether a regex match STARTS there (Split with Isolated
 // behaviour covers every byte, pre_tokenizers/split.rs:96-104, so the starts are the whole answer).  It is written
@@ -76,7 +79,7 @@ TK_HD uint64_t l3_spread_fwd(uint64_t seed, uint64_t link) {
 // carries TKAMD_TEXT_PAD readable bytes after its end.  Returns the match starts of window bytes [16, 48) in bits
 // 16..47 of *start and the bytes it could not decide in *unres (same bits).
 TK_HD void l3_window_starts(L3Window m, const uint8_t* text, int64_t base, const uint16_t* uc1, const uint8_t* uc2,
-                            uint64_t* start, uint64_t* unres) {
+                            uint64_t* start, uint64_t* unres, const SplitRule rule = SPLIT_RULE_LLAMA3) {
     const uint64_t V = m.V, D = m.D & V, nD = ~D;
     uint64_t L = m.L, N = m.N, W = m.W, R = m.R & V;
     const uint64_t C = m.C & V, SP = m.SP & V, AP = m.AP & V;
@@ -109,16 +112,18 @@ TK_HD void l3_window_starts(L3Window m, const uint8_t* text, int64_t base, const
     {
         const uint64_t ok = V & nD;                                    // byte exists and continues its document
         const uint64_t cond = D | pL | pN | pR | (pW & ~pSP);
-        for (uint64_t mm = AP & LEAD & cond & (ok >> 1); mm; mm &= mm - 1) {
+        // (rule.contr: 0 no contraction alternative; 1 case-insensitive -- U+017F folds to 's'; 2 case-sensitive)
+        const uint32_t fold = rule.contr == 1 ? 0x20u : 0u;
+        for (uint64_t mm = rule.contr ? (AP & LEAD & cond & (ok >> 1)) : 0ull; mm; mm &= mm - 1) {
             const int k = l3_ctz(mm);
             if (k > 60) { U |= 1ull << k; continue; }                  // literal not inside the window (never in the main region)
             const uint8_t* p = text + base + k;
             const uint32_t b1 = p[1], b2 = p[2];
-            if (b1 == 0xC5u && b2 == 0xBFu) {                          // U+017F folds to 's': 'ſ is a two-byte one-letter literal
+            if (fold && b1 == 0xC5u && b2 == 0xBFu) {                  // U+017F folds to 's': 'ſ is a two-byte one-letter literal
                 U |= 0x1Full << k;                                     // rare enough to leave to the tile kernel
                 continue;
             }
-            const uint32_t a = b1 | 0x20u, c = b2 | 0x20u;
+            const uint32_t a = b1 | fold, c = b2 | fold;
             const bool a_letter = b1 < 0x80u && (a - 'a') < 26u, c_letter = b2 < 0x80u && (c - 'a') < 26u;
             if (!a_letter) continue;
             if (a == 's' || a == 't' || a == 'm' || a == 'd') CON1 |= 1ull << k;
@@ -137,22 +142,20 @@ TK_HD void l3_window_starts(L3Window m, const uint8_t* text, int64_t base, const
     const uint64_t startL = L & ~eaten & (after | ~(pL | pW | prefixO));
     // ---- other:  ?[^\s\p{L}\p{N}]+[\r\n]*
     const uint64_t startO = O & (after | ~(pO | pSP));
-    // ---- digits: \p{N}{1,3} -- every third code point from the run start (byte arithmetic: ASCII digits only)
+    // ---- digits: \p{N}{1,k} -- every k-th code point from the run start (byte arithmetic: ASCII digits only); \p{N}+: the run start
     uint64_t startN;
-    {
+    if (rule.digit_max == 1) startN = N & LEAD;                        // every digit is its own match, whatever its width
+    else if (rule.digit_max == 0) startN = N & LEAD & ~pN;
+    else {
         const uint64_t Ns = N & LEAD & ~pN;                            // run starts
         const uint64_t Cn = N & ~Ns;                                   // digits that continue a run
         uint64_t T = Ns;
-        const uint64_t k3 = Cn & (Cn << 1) & (Cn << 2);
-        T |= (T << 3) & k3;
-        const uint64_t k6 = k3 & (k3 << 3);
-        T |= (T << 6) & k6;
-        const uint64_t k12 = k6 & (k6 << 6);
-        T |= (T << 12) & k12;
-        const uint64_t k24 = k12 & (k12 << 12);
-        T |= (T << 24) & k24;
-        const uint64_t k48 = k24 & (k24 << 24);
-        T |= (T << 48) & k48;
+        uint64_t kk = Cn & (Cn << 1);                                  // bit i: bytes i-k+1 .. i continue a run (k = digit_max)
+        if (rule.digit_max == 3) kk &= Cn << 2;
+        for (int step = rule.digit_max; step < 64; step *= 2) {
+            T |= (T << step) & kk;
+            kk &= kk << step;
+        }
         startN = N & T;
         // a run that reaches back to the first window bytes has an unknown origin (bytes 0..2 may be the tail of a code
         // point whose lead -- possibly a digit -- lies before the window); multi-byte digits break the byte arithmetic

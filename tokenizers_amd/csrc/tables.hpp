@@ -184,12 +184,31 @@ enum ModelKind { MODEL_NONE = 0, MODEL_BPE = 1, MODEL_WORDPIECE = 2, MODEL_WORDL
 enum PretokKind {
     PT_NONE = 0,
     PT_BYTELEVEL_GPT2 = 1,   // ByteLevel(use_regex=true)                       byte_level.rs:119-148
-    PT_LLAMA3 = 2,           // Sequence[Split(llama3 regex, Isolated), ByteLevel(use_regex=false)]
+    PT_LLAMA3 = 2,           // Sequence[Split(a pattern of the tiktoken family: SplitRule below, Isolated), ByteLevel(use_regex=false)]
     PT_WHITESPACE = 3,       // \w+|[^\w\s]+                                    whitespace.rs:20-29
     PT_WHITESPACE_SPLIT = 4, // char::is_whitespace                             whitespace.rs:35-41
     PT_BERT = 5,             // BertPreTokenizer                                bert.rs:14-17
     PT_BYTELEVEL_NOREGEX = 6 // ByteLevel(use_regex=false): whole doc is one pre-token
 };
 enum NormKind { NORM_NONE = 0, NORM_BERT = 1 };
+
+// ---- the tiktoken family of Split patterns (pre_tokenizers/split.rs:76-105 with a SysRegex, tokenizer/pattern.rs:63-83) -------
+// Every member is the alternation
+//   [contractions |] letters | digits |  ?[^\s\p{L}\p{N}]+ tail | \s*[\r\n]+ | \s+(?!\S) | \s+
+// and differs from the Llama-3 / cl100k pattern in a handful of parameters (host_model.cpp parse_split_pattern is the reader; a pattern
+// that does not reduce to them is refused):
+struct SplitRule {
+    uint8_t contr;       // 'S|'T|'RE|'VE|'M|'LL|'D: 0 absent; 1 first alternative, case-insensitive (?i:...) (Llama-3, Qwen2); 2 first alternative,
+                         // case-sensitive; 3 optional SUFFIX of the letter alternatives, case-insensitive (o200k)
+    uint8_t letters;     // 0: [^\r\n\p{L}\p{N}]?\p{L}+      2: the two case-split alternatives of o200k / tekken,
+                         //    [^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+ | ...[\p{Lu}..]+[\p{Ll}..]*
+    uint8_t digit_max;   // \p{N}{1,k}: k = 1 (\p{N}: Qwen2), 2, 3 (Llama-3); 0: \p{N}+
+    uint8_t other_tail;  // what follows  ?[^\s\p{L}\p{N}]+ : 1 [\r\n]*, 2 [\r\n/]* (o200k)
+};
+constexpr SplitRule SPLIT_RULE_LLAMA3 = {1, 0, 3, 1};
+// the rules the bit-parallel and the tile kernel implement (kernels/pretok_llama3.hip); the others run on the sequential matcher
+TK_HD bool split_rule_fast(const SplitRule& r) { return r.letters == 0 && r.other_tail == 1 && r.contr <= 2; }
+// case classes of the case-split letters (generated data: unicode_case_ranges.inc)
+enum : uint8_t { UCC_UPPER = 1 /* [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}] */, UCC_LOWER = 2 /* [\p{Ll}\p{Lm}\p{Lo}\p{M}] */ };
 
 }  // namespace tkamd
