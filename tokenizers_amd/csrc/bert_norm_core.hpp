@@ -212,7 +212,7 @@ TK_HD bool bn_fix_run(const BnCoreTables& t, const uint8_t* text, int64_t lo, in
         else if (l == 2u) { ntext[x] = (uint8_t)(0xC0u | (c >> 6)); ntext[x + 1] = (uint8_t)(0x80u | (c & 0x3Fu)); }
         else if (l == 3u) { ntext[x] = (uint8_t)(0xE0u | (c >> 12)); ntext[x + 1] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); ntext[x + 2] = (uint8_t)(0x80u | (c & 0x3Fu)); }
         else { ntext[x] = (uint8_t)(0xF0u | (c >> 18)); ntext[x + 1] = (uint8_t)(0x80u | ((c >> 12) & 0x3Fu)); ntext[x + 2] = (uint8_t)(0x80u | ((c >> 6) & 0x3Fu)); ntext[x + 3] = (uint8_t)(0x80u | (c & 0x3Fu)); }
-        if (nos) for (uint32_t z = 0; z < l; ++z) { nos[x + z] = last_a; noe[x + z] = last_a + last_len; }
+        if (nos) for (uint32_t z = 0; z < l; ++z) { nos[x + z] = last_a; if (noe) noe[x + z] = last_a + last_len; }
         x += l;
     }
     return true;

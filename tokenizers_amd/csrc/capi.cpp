@@ -1359,9 +1359,13 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         if (off_mode != TKAMD_OFFSETS_NONE) {
             w->w_norig.reserve(((size_t)n_x + 4) * 4);
-            w->w_norig_e.reserve(((size_t)n_x + 4) * 4);
             norig = w->w_norig.as<uint32_t>();
-            norig_e = w->w_norig_e.as<uint32_t>();
+            // (behind BertNormalizer the END of a byte's original range follows from its start and the original text -- kernels/output.hip
+            // norig_end: 4 bytes per normalised byte less to write and to read; the prefix-space copy keeps per-byte ends)
+            if (hm.norm != NORM_BERT) {
+                w->w_norig_e.reserve(((size_t)n_x + 4) * 4);
+                norig_e = w->w_norig_e.as<uint32_t>();
+            }
         }
     }
     if (hm.norm == NORM_BERT) {
@@ -1784,6 +1788,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.claim_pos = wc.claims ? wc.claim_pos : nullptr;
         a.n_pretok = d_npretok;
         a.doc_pt = w->w_doc_pt.as<uint32_t>();
+        a.chunk_lo = w->w_chunk_lo.as<uint32_t>();
+        a.chunk = (uint32_t)(256 * t->cp_items);
         a.n_docs = n_docs;
         a.x_doc_off = x_doc_off;
         a.doc_off = d_doc_off;

@@ -119,6 +119,8 @@ struct MetaArgs {
     const uint32_t* claim_pos;        // ends are the claimant's: tmp_end[claim_pos[slot] + j] (both null when the claims are off)
     const int64_t* n_pretok;
     const uint32_t* doc_pt;
+    const uint32_t* chunk_lo;         // the compaction's: chunk_lo[c] = the first document d with doc_pt[d] >= c * chunk (k_doc_first_pretok)
+    uint32_t chunk;
     const uint32_t* word_of_doc;      // is_pretokenized: word id of every token of document d (its index in the sequence); else null
     const int64_t* first_tok;         // is_pretokenized with trim_offsets: index of the first token of document d's sequence; else null
     int64_t n_docs;

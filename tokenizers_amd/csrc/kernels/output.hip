@@ -370,6 +370,16 @@ __global__ __launch_bounds__(256) void k_leadmask(const uint8_t* __restrict__ te
     if ((threadIdx.x & 3) == 0 && i <= n_bytes) leadmask[i >> 6] = m;
 }
 
+// end of the original byte range of x byte k.  Behind BertNormalizer (norig_e null) every byte of a normalised char carries the range of
+// its SOURCE char -- (i, i + that char's UTF-8 length), a verbatim byte (i, i + 1) -- so the end follows from the start and one byte
+// of the original text (a continuation byte, as the last byte of a verbatim char is, counts 1); the prefix-space copy keeps its
+// per-byte ends in memory.
+__device__ __forceinline__ uint32_t norig_end(const MetaArgs& a, uint32_t k) {
+    if (a.norig_e) return a.norig_e[k];
+    const uint32_t i = a.norig[k], b = a.text[i];
+    return i + (b < 0xC0u ? 1u : b < 0xE0u ? 2u : b < 0xF0u ? 3u : 4u);
+}
+
 // offsets / word id of ONE token: token j of pre-token p (document d; [s, e) in x space; its tokens are o .. o + c), covering
 // [s + rel, s + rel_end) of the x text.  Everything of into_encoding / process_offsets that is per token.
 __device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int64_t d, uint32_t s, uint32_t e, bool is_match, uint32_t o, uint32_t j,
@@ -390,9 +400,9 @@ __device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int
         const uint32_t ml = a.tmp_end[s];
         os = a.norig ? a.norig[s] : s - xdoc + odoc;
         if (ml & MATCH_LEN_ORIG) { oe = os + (ml & ~MATCH_LEN_ORIG); ttext = a.text; tts = os; tte = oe; }
-        else { tte = s + ml; oe = a.norig ? a.norig_e[tte - 1] : tte - xdoc + odoc; }
+        else { tte = s + ml; oe = a.norig ? norig_end(a, tte - 1u) : tte - xdoc + odoc; }
     }
-    else if (a.norig) { os = a.norig[bs]; oe = a.norig_e[be - 1]; }
+    else if (a.norig) { os = a.norig[bs]; oe = norig_end(a, be - 1u); }
     else { os = bs - xdoc + odoc; oe = be - xdoc + odoc; }
     if (a.char_mode) {
         uint32_t base = lead_rank(a.leadmask, a.lprefix, odoc);
@@ -494,23 +504,27 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
     }
 }
 
-// One lane per TOKEN (round 6).  A workgroup takes tiles of TM_TILE consecutive pre-tokens: their token offsets, starts and ends go to LDS
-// with coalesced loads; the document of the tile's first pre-token is found ONCE (a 64-ary search of wavefront 0 over doc_pt: four
-// dependent loads, where every lane of the old shape ran twenty), the documents that start inside the tile are counted into the tile's
-// pre-tokens and a scan turns the counts into every pre-token's document; then the tile's tokens -- consecutive in the output arrays --
-// are dealt to the lanes round robin: a lane finds its token's pre-token by a binary search over the LDS copy of the token offsets and
-// writes 12 bytes next to its neighbour's.  The per-pre-token shape spent 1.14 ms on C2's 22.7 M tokens (profiles/r6a_c2_bench.json: the
-// binary search and its scattered stores); this one is bound by the 12 T bytes it writes and the token ends it gathers.
+// Round 6's shape.  A workgroup takes tiles of TM_TILE consecutive pre-tokens: their token offsets, starts and ends go to LDS with coalesced
+// loads; the documents that start inside the tile are counted into its pre-tokens (the compaction's chunk_lo names the first of them: no
+// search) and a scan turns the counts into every pre-token's document.  Then a lane takes FOUR pre-tokens, 256 apart -- neighbouring
+// lanes hold neighbouring pre-tokens, whose tokens are neighbours in the output arrays -- loads what all four need first (document,
+// claimant, token ends: the round trips overlap) and writes their tokens: one for seven pre-tokens in eight, up to TM_INLINE in a
+// lane's own loop, and a pre-token of more than that is handed to the whole workgroup, a token a lane.
+// (Rounds 1-5: a lane per pre-token, a twenty-step binary search over doc_pt each, 1.14 ms on C2's 22.7 M tokens; a lane per TOKEN with
+// a binary search over the tile's token offsets in LDS: 0.52 ms, profiles/r6b_c2_bench.json.)
 constexpr int TM_TILE = 1024;
-__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
+constexpr uint32_t TM_INLINE = 8u;
+__global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (six wavefronts a SIMD: <= 80 VGPRs)
     __shared__ uint32_t s_tokoff[TM_TILE + 1];
     __shared__ uint32_t s_start[TM_TILE + 1];
     __shared__ uint32_t s_end[TM_TILE];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
-    __shared__ uint32_t s_scan[8];
+    __shared__ uint32_t s_scan[4];
+    __shared__ uint32_t s_before, s_nbig;
+    __shared__ uint16_t s_big[TM_TILE];
     const int64_t P = *a.n_pretok;
     const uint32_t n_tok = (uint32_t)*a.n_tok;
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x;
     const int64_t n_tiles = (P + TM_TILE - 1) / TM_TILE;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * TM_TILE;
@@ -522,64 +536,92 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             s_start[i] = a.pt_start[p];                   // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
             if (i < np) { s_doc[i] = 0u; if (a.pt_end) s_end[i] = a.pt_end[p]; }
         }
-        // the document of the tile's first pre-token: the last d with doc_pt[d] <= base (doc_pt[0] = 0, doc_pt[n_docs] = P > base)
-        if (wave == 0) {
-            int64_t lo = 0, hi = a.n_docs;
-            while (hi - lo > 1) {
-                const int64_t step = (hi - lo + 63) / 64;
-                const int64_t idx = lo + (int64_t)(lane + 1) * step;
-                const bool le = idx < hi && (int64_t)a.doc_pt[idx] <= base;
-                const int k = __popcll(__ballot(le));     // doc_pt is monotone: the lanes that hold are the first k
-                const int64_t nlo = lo + (int64_t)k * step;
-                hi = min(hi, lo + (int64_t)(k + 1) * step);
-                lo = nlo;
-            }
-            if (lane == 0) s_scan[4] = (uint32_t)lo;
-        }
+        if (tid == 0) { s_before = 0u; s_nbig = 0u; }
         __syncthreads();
-        const uint32_t d_first = s_scan[4];
-        // documents d > d_first that start inside the tile: one count at their first pre-token (an empty document adds to the next one's)
-        for (int64_t d = (int64_t)d_first + 1 + tid; d < a.n_docs; d += 256) {
+        // documents from the first one of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with doc_pt[d] >= c * chunk):
+        // the ones in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
+        const int64_t d0 = (int64_t)a.chunk_lo[base / a.chunk];
+        for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
             const int64_t r = (int64_t)a.doc_pt[d] - base;
             if (r >= np) break;
-            atomicAdd(&s_doc[r], 1u);
+            atomicAdd(r < 0 ? &s_before : &s_doc[r], 1u);
         }
         __syncthreads();
-        {   // inclusive scan over the tile, four pre-tokens a lane
+        {   // inclusive scan over the tile, four pre-tokens a lane: the document of pre-token i = the last d with doc_pt[d] <= base + i
             uint32_t v[4], sum = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v[q] = (4 * tid + q < np) ? s_doc[4 * tid + q] : 0u; sum += v[q]; }
             uint32_t tot;
-            uint32_t run = block256_excl_scan(sum, s_scan, &tot) + d_first;
+            uint32_t run = block256_excl_scan(sum, s_scan, &tot) + (uint32_t)d0 + s_before - 1u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
         __syncthreads();
-        const uint32_t T0 = s_tokoff[0], T1 = s_tokoff[np];
-        for (uint32_t t = T0 + (uint32_t)tid; t < T1; t += 256u) {
-            // the pre-token of token t: the last i with tokoff[i] <= t (pre-tokens without tokens are skipped by construction)
-            int lo = 0, hi = np;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_tokoff[mid] <= t) lo = mid; else hi = mid; }
-            const int i = lo;
+        // ---- a lane's four pre-tokens, one behind the other, the NEXT one's loads (document, claimant) issued before this one's tokens
+        // are written: the round trips overlap without four copies of the token code (which took 126 VGPRs: half the occupancy)
+        struct Pt { uint32_t o, c, s, e, se, word, xdoc, odoc; int64_t d; bool match; };
+        auto fetch = [&](int q) -> Pt {
+            Pt x;
+            x.c = 0u;
+            const int i = tid + 256 * q;
+            if (q >= 4 || i >= np) return x;
+            x.o = s_tokoff[i];
+            x.c = s_tokoff[i + 1] - x.o;
+            if (!x.c) return x;
+            x.s = s_start[i];
+            x.e = a.pt_end ? s_end[i] : s_start[i + 1];
+            x.d = (int64_t)s_doc[i];
             const int64_t p = base + i;
-            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o, j = t - o;
-            const uint32_t s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
-            const int64_t d = (int64_t)s_doc[i];
-            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
-            const uint32_t xdoc = (uint32_t)a.x_doc_off[d];
-            const uint32_t odoc = (uint32_t)a.doc_off[d];
-            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            uint32_t rel = 0u, rel_end = e - s;
-            if (c > 1u && a.tmp_end) {
-                uint32_t s_ends = s;                      // whose token ends: the pre-token's own, or the claimant's of its word
-                if (a.claim_pos) {
-                    const uint32_t t0 = a.tok0[p];
-                    if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = a.claim_pos[t0 & TOK_REF_MASK];
-                }
-                if (j) rel = a.tmp_end[s_ends + j - 1u];
-                rel_end = a.tmp_end[s_ends + j];
+            x.word = a.word_of_doc ? a.word_of_doc[x.d] : (uint32_t)(p - (int64_t)a.doc_pt[x.d]);
+            x.xdoc = (uint32_t)a.x_doc_off[x.d];
+            x.odoc = (uint32_t)a.doc_off[x.d];
+            x.match = a.matchmask && a.tmp_end && ((a.matchmask[x.s >> 6] >> (x.s & 63)) & 1ull);
+            x.se = x.s;                                   // whose token ends: the pre-token's own, or the claimant's of its word
+            if (x.c > 1u && a.claim_pos) {
+                const uint32_t t0 = a.tok0[p];
+                if ((t0 & TOK_SLOT) == TOK_SLOT) x.se = a.claim_pos[t0 & TOK_REF_MASK];
             }
-            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word);
+            return x;
+        };
+        Pt cur = fetch(0);
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            const Pt nxt = fetch(q + 1);
+            const uint32_t c = cur.c;
+            if (c) {
+                const int64_t p = base + tid + 256 * q;
+                const bool ends = c > 1u && a.tmp_end;    // (no token ends without offsets: word ids only)
+                uint32_t rel = 0u;
+                const uint32_t n_in = min(c, TM_INLINE);
+                for (uint32_t j = 0; j < n_in; ++j) {
+                    const uint32_t rel_end = ends ? a.tmp_end[cur.se + j] : cur.e - cur.s;
+                    meta_one_token(a, p, cur.d, cur.s, cur.e, cur.match, cur.o, j, rel, rel_end, cur.xdoc, cur.odoc, cur.word);
+                    rel = rel_end;
+                }
+                if (c > TM_INLINE) s_big[atomicAdd(&s_nbig, 1u)] = (uint16_t)(tid + 256 * q);
+            }
+            cur = nxt;
+        }
+        __syncthreads();
+        // ---- the long pre-tokens of the tile (a run of letters the vocabulary cuts into many tokens): a token a lane
+        const uint32_t nbig = s_nbig;
+        for (uint32_t b = 0; b < nbig; ++b) {
+            const int i = (int)s_big[b];
+            const int64_t p = base + i, d = (int64_t)s_doc[i];
+            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o, s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
+            const uint32_t xdoc = (uint32_t)a.x_doc_off[d], odoc = (uint32_t)a.doc_off[d];
+            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+            uint32_t s_ends = s;
+            if (a.claim_pos) {
+                const uint32_t t0 = a.tok0[p];
+                if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = a.claim_pos[t0 & TOK_REF_MASK];
+            }
+            for (uint32_t j = TM_INLINE + (uint32_t)tid; j < c; j += 256u) {
+                const uint32_t rel = a.tmp_end ? a.tmp_end[s_ends + j - 1u] : 0u;
+                const uint32_t rel_end = a.tmp_end ? a.tmp_end[s_ends + j] : e - s;
+                meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word);
+            }
         }
     }
 }

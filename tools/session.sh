@@ -7,7 +7,7 @@
 #   stats:<cfg>                     rocprofv3 --kernel-trace --stats over a short bench run (the with-offsets legs included)
 #   pmc:<cfg>                       FETCH_SIZE / WRITE_SIZE in separate passes -> <cfg>_pmc_summary.json (tools/pmc_summary.py, stamped with the
 #                                   kernel sources' hash: bench.py flags a summary of other sources as stale)
-#   sq:<cfg>[:<kernel prefixes>]    SQ / TCC counters of the named kernels (tools/sq.sh)
+#   sq:<cfg>[:<kernel prefixes>[:<none|byte|char>]]   SQ / TCC counters of the named kernels (tools/sq.sh); the last field: with offsets
 #   smoke                           __graft_entry__.smoke()
 #   ab:<cfg>:<args of tools/ab.py>  same-session A/B of environment switches / library builds
 #   py:<script and args>            any python script of tools/ (output to <tag>/<script>.txt)
@@ -43,7 +43,8 @@ for step in "$@"; do
       rm -rf "$O/pmc_fetch_$c" "$O/pmc_write_$c" ;;
     sq)
       c=${rest%%:*}; only=${rest#*:}; [ "$only" = "$rest" ] && only="k_lookup,k_compact,k_bpe_merge_lds,k_pretok_gpt2_seq"
-      tools/sq.sh $tag/sq $c $only > "$O/sq_$c.log" 2>&1; cp gpurun_out/$tag/sq/sq_$c.json "$O/${c}_sq_summary.json" 2>/dev/null; echo "sq $c rc=$?" ;;
+      mode=${only#*:}; [ "$mode" = "$only" ] && mode=none; only=${only%%:*}
+      tools/sq.sh $tag/sq $c $only $mode > "$O/sq_$c.log" 2>&1; cp gpurun_out/$tag/sq/sq_$c.json "$O/${c}_sq_summary.json" 2>/dev/null; echo "sq $c rc=$?" ;;
     smoke) timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1 ;;
     ab)
       c=${rest%%:*}; args=${rest#*:}

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event times of one config on one batch (developer loop; bench.py is the measurement of record).
-usage: python tools/stages.py [c2|c3|c4|c5] [type_seed] [n_lines]   -- checks a 1 % sample against the oracle first."""
+usage: python tools/stages.py [c2|c3|c4|c5] [type_seed] [n_lines] [none|byte|char]   -- checks a 1 % sample against the oracle first;
+the last argument: offsets + word ids as well (encode_batch / encode_batch_char_offsets instead of encode_batch_fast)."""
 import os
 import sys
 import time
@@ -16,6 +17,7 @@ from oracle import oracle as orc
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 ts = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+mode = sys.argv[4] if len(sys.argv) > 4 else "none"
 js, n_types, _ = bench.load_config(cfg)
 tok = ta.Tokenizer.from_str(js, device=0)
 dev = torch.device("cuda", 0)
@@ -23,7 +25,7 @@ b = bench.Batch(bench.make_corpus(cfg, n, 100, ts, n_types), dev, 0, False)
 stream = torch.cuda.current_stream().cuda_stream
 if not os.environ.get("TKAMD_NOCHECK"):
     bench.check_against_oracle(tok, orc.Oracle(js), b, stream)
-enc = lambda: tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, stream=stream)
+enc = lambda: tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, offsets=mode, word_ids=mode != "none", stream=stream)
 for _ in range(3):
     enc()
 torch.cuda.synchronize()
