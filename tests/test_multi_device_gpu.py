@@ -89,7 +89,7 @@ def test_sharded_pairs_truncation_fixed_padding_and_words(name):
         _same(many.encode_batch_csr(pairs, add_special_tokens=True, **kw), one.encode_batch_csr(pairs, add_special_tokens=True, **kw))
     words = [l.split(" ") for l in lines]
     _same(many.encode_batch_csr(words, is_pretokenized=True, add_special_tokens=True), one.encode_batch_csr(words, is_pretokenized=True, add_special_tokens=True))
-    # BatchLongest / overflowing: the whole batch on devices[0], same results
+    # BatchLongest: sharded since round 6 (the shards exchange their longest encoding); overflowing: the whole batch on devices[0]
     d["padding"]["strategy"] = "BatchLongest"
     js = json.dumps(d)
     one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=[0, 0, 0])
@@ -97,6 +97,41 @@ def test_sharded_pairs_truncation_fixed_padding_and_words(name):
     a, b = many.encode_batch_csr(lines, add_special_tokens=True, overflowing=True), one.encode_batch_csr(lines, add_special_tokens=True, overflowing=True)
     _same(a, b)
     assert np.array_equal(a.enc_docs, b.enc_docs)
+
+
+@pytest.mark.parametrize("n_dev", [2, 3, 5])
+def test_batch_longest_padding_is_sharded(n_dev):
+    """BatchLongest (utils/padding.rs:55-63) couples the documents of a batch through ONE number, the longest encoding: the shards hand
+    theirs to the call's exchange and pad to the batch's -- singles, pairs, pad_to_multiple_of, either side; the longest document sits in
+    the LAST shard, so every other shard pads to a length it has not seen.  And a shard that fails must not leave the others waiting."""
+    import tokenizers_amd as ta
+    d = json.loads(load_tokenizer_json("bert_wordpiece_4000_specials"))
+    lines = [l for l in synth.gen_lines(9000, text_seed=305) if "[" not in l]
+    lines[-3] = " ".join(lines[:40])                       # the batch's longest, in the last shard
+    pairs = [(a, b) for a, b in zip(lines[0::2], lines[1::2])]
+    for direction, multiple, trunc in (("Right", None, None), ("Left", 8, None), ("Right", 16, 40)):
+        d["padding"] = {"strategy": "BatchLongest", "direction": direction, "pad_to_multiple_of": multiple, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}
+        d["truncation"] = None if trunc is None else {"direction": "Right", "max_length": trunc, "strategy": "LongestFirst", "stride": 0}
+        js = json.dumps(d)
+        one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=[0] * n_dev)
+        for batch in (lines, pairs):
+            got, want = many.encode_batch_csr(batch, add_special_tokens=True, offsets="char", word_ids=True), one.encode_batch_csr(batch, add_special_tokens=True, offsets="char", word_ids=True)
+            _same(got, want)
+            lens = np.diff(got.tok_offsets)
+            assert lens.min() == lens.max(), "every encoding of the batch has the batch's length"
+            st = many.shard_stats()
+            if sum(len(x.encode()) for x in lines) >= (n_dev + 1) * 8192:      # (under the CPU emulation the corpus is too small for five shards)
+                assert len(st) == n_dev and all(b > 0 for _, b, _ in st), "the call ran on every device of the list"
+    # an error in one shard: the call fails, nobody waits for the shard that left, the handle works afterwards
+    dw = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
+    dw["model"]["unk_token"] = "<nope>"           # not in the vocabulary: MissingUnkToken the moment a word misses (wordlevel/mod.rs:175-177)
+    dw["padding"] = {"strategy": "BatchLongest", "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}
+    bad = ta.Tokenizer.from_str(json.dumps(dw), device=[0] * n_dev)
+    vocab = [w for w in dw["model"]["vocab"] if w.isascii() and w.isalnum()]
+    good = [" ".join(vocab[(7 * i + k) % len(vocab)] for k in range(12)) for i in range(20000)]
+    with pytest.raises(Exception, match="MissingUnkToken"):
+        bad.encode_batch_csr(good[:-100] + ["zzzzqqqq"] * 100)
+    assert bad.encode_batch_csr(good).n_tokens == 12 * len(good)
 
 
 def test_an_error_in_one_shard_fails_the_call_and_the_handle_survives():

@@ -12,6 +12,7 @@
 #include <memory>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -136,6 +137,31 @@ struct Rendezvous {
     }
 };
 
+// BatchLongest padding across the shards of one call (utils/padding.rs:55-63: the target is the longest encoding of the BATCH): every
+// shard hands in the maximum over its own encodings and gets the batch's.  A shard that fails before it gets here leaves, so that
+// the others never wait for it.
+struct MaxExchange {
+    std::mutex mu;
+    std::condition_variable cv;
+    int expected;
+    int arrived = 0;
+    uint32_t mx = 0;
+    explicit MaxExchange(int n) : expected(n) {}
+    uint32_t exchange(uint32_t v) {
+        std::unique_lock<std::mutex> lk(mu);
+        mx = std::max(mx, v);
+        ++arrived;
+        cv.notify_all();
+        cv.wait(lk, [&] { return arrived >= expected; });
+        return mx;
+    }
+    void leave() {
+        std::lock_guard<std::mutex> lk(mu);
+        --expected;
+        cv.notify_all();
+    }
+};
+
 // grow-only device buffer; owns its allocation (freed with the struct that holds it, on whatever device is current --
 // hipFree accepts a pointer of any device)
 struct DevBuf {
@@ -182,6 +208,10 @@ struct StageRec {
 // (TokenizerImpl::encode_batch is &self + Send + Sync, tokenizer/mod.rs:1328-1335); the tables stay shared and read-only.
 struct Workspace {
     std::mutex mu;               // a workspace serves one call at a time
+    // a sharded call with BatchLongest padding: the epilogue hands its shard's maximum to the call's MaxExchange here and pads to what
+    // comes back (null: the batch is this workspace's alone)
+    std::function<uint32_t(uint32_t)> pad_exchange;
+    uint32_t h_padmax = 0;       // (the exchanged maximum on its way back to the device)
     bool busy = false;           // taken by a host-entry call
     bool device_bound = false;   // belongs to the device entry: keyed by the caller's stream, results stay valid in it
     hipStream_t bound_stream = nullptr;
@@ -950,6 +980,31 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // sequences' windows, Encoding::merge_with encoding.rs:408-432)
     const bool want_overflow = (flags & TKAMD_WANT_OVERFLOW) != 0 && hm.trunc_on;
     out->d_enc_parts = nullptr;
+    // BatchLongest (utils/padding.rs:55-63): the batch's longest encoding, read back from the device -- and, in a call that is sharded
+    // over several devices, exchanged with the other shards' (Workspace::pad_exchange), the batch's written back for the kernels behind.
+    // *again: a sharded call found its work queue too small -- the batch is run again BEFORE the exchange (every shard takes part in
+    // it exactly once; finish_batch's later re-run would hand in a second value the others no longer wait for).
+    auto batch_longest = [&](uint32_t* d_target, bool* again) -> uint64_t {
+        int64_t head[SC_PADMAX + 1];
+        HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
+        uint32_t mx = 0;
+        if (d_target != (uint32_t*)(sc + SC_PADMAX)) HIP_CHECK(hipMemcpyAsync(&mx, d_target, 4, hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (d_target == (uint32_t*)(sc + SC_PADMAX)) mx = *(const uint32_t*)&head[SC_PADMAX];
+        if (!w->pad_exchange) return mx;
+        const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_REORDER_SEEN;
+        if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {
+            t->q16_div = t->q16_div > 2 ? 2 : 1;
+            *again = true;
+            return 0;
+        }
+        const uint32_t all = w->pad_exchange(mx);
+        if (all != mx) {
+            w->h_padmax = all;
+            HIP_CHECK(hipMemcpyAsync(d_target, &w->h_padmax, 4, hipMemcpyHostToDevice, st));
+        }
+        return all;
+    };
     auto finalize_pairs = [&]() {
         // EncodeInput::Dual: the two sequences of a pair were encoded as two documents; cut, lay out and pad them together
         const int64_t n_pairs = mixed ? n_inputs : e_n / 2;
@@ -1066,10 +1121,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         } else if (hm.pad_on) {
             uint64_t target = hm.pad_length;
             if (!hm.pad_fixed) {
-                uint32_t mx = 0;
-                HIP_CHECK(hipMemcpyAsync(&mx, pa.target, 4, hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-                target = mx;
+                target = batch_longest(pa.target, &rerun);
+                if (rerun) { pf.end(); return; }
             }
             if (hm.pad_multiple > 0 && target % hm.pad_multiple > 0) target += hm.pad_multiple - target % hm.pad_multiple;
             T2 += (size_t)n_pairs * (size_t)target;
@@ -1202,10 +1255,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         } else if (hm.pad_on) {
             uint64_t target = hm.pad_length;
             if (!hm.pad_fixed) {
-                uint32_t mx = 0;
-                HIP_CHECK(hipMemcpyAsync(&mx, fa.target, 4, hipMemcpyDeviceToHost, st));
-                HIP_CHECK(hipStreamSynchronize(st));
-                target = mx;
+                target = batch_longest(fa.target, &rerun);
+                if (rerun) { pf.end(); return; }
             }
             if (hm.pad_multiple > 0 && target % hm.pad_multiple > 0) target += hm.pad_multiple - target % hm.pad_multiple;
             T2 += (size_t)e_n * (size_t)target;
@@ -2243,6 +2294,7 @@ struct Shard {
     std::string err;
     hipEvent_t ev = nullptr;
     double ms = 0;
+    bool exchanged = false;      // BatchLongest: this shard took part in the call's MaxExchange
 };
 
 static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
@@ -2307,6 +2359,10 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
     Rendezvous rv(n_dev);
     std::atomic<bool> go{false};
     int64_t total_tok = 0;
+    // BatchLongest padding: the one thing that couples the shards' documents -- one integer through the call's MaxExchange (round 6;
+    // rounds 3-5 ran such a batch on devices[0] alone)
+    const bool batch_longest = t->hm.pad_on && !t->hm.pad_fixed;
+    MaxExchange pad_max(n_dev);
 
     auto describe = [&](Shard& x) {      // the result arrays of a shard, the same list on every shard (the tokenizer decides which exist)
         std::vector<ShardDesc> d;
@@ -2346,10 +2402,13 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
             HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + x.nb, 0, TKAMD_TEXT_PAD, s));
             HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + x.d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, s));
             if (x.b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), nd + 1, -x.b0);
+            if (batch_longest) w->pad_exchange = [&x, &pad_max](uint32_t v) { x.exchanged = true; return pad_max.exchange(v); };
+            struct Unhook { Workspace* w; ~Unhook() { w->pad_exchange = nullptr; } } unhook{w};
             run_pipeline(tr, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), nd, x.nb, words_in ? w->h_seq_off.as<int64_t>() : nullptr,
                          words_in ? ng : -1, flags, s, &x.res);
             w->last_text = w->h_text.as<uint8_t>(); w->last_doc_off = w->h_doc_off.as<int64_t>(); w->last_n_bytes = x.nb; w->last_flags = flags; w->last_result = x.res;
             int64_t n_pt = 0;
+            w->pad_exchange = nullptr;                       // (the exchange is over: batch_longest saw a queue overflow before it, so finish_batch has nothing to run again)
             const int bits = finish_batch(tr, w, s, &x.n_tok, &n_pt);
             if (bits) return error_from_bits(bits);
             x.res = w->last_result;
@@ -2368,6 +2427,7 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
             return TKAMD_OK;
         });
         if (x.rc != TKAMD_OK) x.err = g_last_error;
+        if (batch_longest && !x.exchanged) pad_max.leave();          // (failed, or had nothing to pad: the others do not wait for this shard)
         rv.arrive();
         // the coordinator: displacements, the result arrays
         if (r == 0) {
@@ -2565,7 +2625,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow || mixed) n_slices = 1;
         // a multi-device handle: one shard per device (what couples the documents of a batch stays on devices[0], like it stays in one slice)
-        if (!t->replicas.empty() && !mixed && !(t->hm.pad_on && !t->hm.pad_fixed) && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
+        if (!t->replicas.empty() && !mixed && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
             wait_ready(n_bytes, n_bytes);                        // (the shards' workers read the whole text: no pacing across devices yet)
             return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
         }

@@ -506,22 +506,28 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
 
 // Round 6's shape.  A workgroup takes tiles of TM_TILE consecutive pre-tokens: their token offsets, starts and ends go to LDS with coalesced
 // loads; the documents that start inside the tile are counted into its pre-tokens (the compaction's chunk_lo names the first of them: no
-// search) and a scan turns the counts into every pre-token's document.  Then a lane takes FOUR pre-tokens, 256 apart -- neighbouring
-// lanes hold neighbouring pre-tokens, whose tokens are neighbours in the output arrays -- loads what all four need first (document,
-// claimant, token ends: the round trips overlap) and writes their tokens: one for seven pre-tokens in eight, up to TM_INLINE in a
-// lane's own loop, and a pre-token of more than that is handed to the whole workgroup, a token a lane.
-// (Rounds 1-5: a lane per pre-token, a twenty-step binary search over doc_pt each, 1.14 ms on C2's 22.7 M tokens; a lane per TOKEN with
-// a binary search over the tile's token offsets in LDS: 0.52 ms, profiles/r6b_c2_bench.json.)
+// search) and a scan turns the counts into every pre-token's document.  Then
+//   * a lane takes four pre-tokens, 256 apart (neighbouring lanes hold neighbouring pre-tokens, whose tokens are neighbours in the output
+//     arrays).  Seven pre-tokens in eight are ONE token: its offsets are the pre-token's own edges -- no token ends to fetch, no char to
+//     snap to -- and leave at once.  A pre-token of several tokens only resolves whose token ends it reads (its own, or the claimant's
+//     of its word: tok0 -> claim_pos) and goes on the tile's list;
+//   * the tokens of the listed pre-tokens are dealt to the lanes one each (a scan over the list's counts, a binary search over at most a
+//     few hundred bases in LDS): the two dependent round trips a token of theirs costs -- its ends, then the bytes at a cut inside a
+//     char -- are paid once per 256 tokens, not once per token of the longest word a wavefront holds.
+// (Rounds 1-5: a lane per pre-token with its tokens in a loop and a twenty-step binary search over doc_pt each: 1.14 ms on C2's
+// 22.7 M tokens.  A lane per token, every token through the whole chain: 0.52 ms.  Four pre-tokens a lane with their tokens in a loop
+// again: 0.73 ms -- a wavefront ran the loop as often as its longest word has tokens.  profiles/r6[abc]_c2_bench.json.)
 constexpr int TM_TILE = 1024;
-constexpr uint32_t TM_INLINE = 8u;
-__global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (six wavefronts a SIMD: <= 80 VGPRs)
+__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
     __shared__ uint32_t s_tokoff[TM_TILE + 1];
     __shared__ uint32_t s_start[TM_TILE + 1];
     __shared__ uint32_t s_end[TM_TILE];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
+    __shared__ uint32_t s_mse[TM_TILE];                   // listed pre-token k: where its token ends are (tmp_end + this)
+    __shared__ uint32_t s_mbase[TM_TILE + 1];             // ... its token count, then (scanned) its first token among the list's
+    __shared__ uint16_t s_mlist[TM_TILE];                 // ... its index in the tile
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_before, s_nbig;
-    __shared__ uint16_t s_big[TM_TILE];
+    __shared__ uint32_t s_before, s_nm;
     const int64_t P = *a.n_pretok;
     const uint32_t n_tok = (uint32_t)*a.n_tok;
     const int tid = (int)threadIdx.x;
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (si
             s_start[i] = a.pt_start[p];                   // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
             if (i < np) { s_doc[i] = 0u; if (a.pt_end) s_end[i] = a.pt_end[p]; }
         }
-        if (tid == 0) { s_before = 0u; s_nbig = 0u; }
+        if (tid == 0) { s_before = 0u; s_nm = 0u; }
         __syncthreads();
         // documents from the first one of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with doc_pt[d] >= c * chunk):
         // the ones in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
@@ -557,71 +563,62 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (si
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
         __syncthreads();
-        // ---- a lane's four pre-tokens, one behind the other, the NEXT one's loads (document, claimant) issued before this one's tokens
-        // are written: the round trips overlap without four copies of the token code (which took 126 VGPRs: half the occupancy)
-        struct Pt { uint32_t o, c, s, e, se, word, xdoc, odoc; int64_t d; bool match; };
-        auto fetch = [&](int q) -> Pt {
-            Pt x;
-            x.c = 0u;
-            const int i = tid + 256 * q;
-            if (q >= 4 || i >= np) return x;
-            x.o = s_tokoff[i];
-            x.c = s_tokoff[i + 1] - x.o;
-            if (!x.c) return x;
-            x.s = s_start[i];
-            x.e = a.pt_end ? s_end[i] : s_start[i + 1];
-            x.d = (int64_t)s_doc[i];
-            const int64_t p = base + i;
-            x.word = a.word_of_doc ? a.word_of_doc[x.d] : (uint32_t)(p - (int64_t)a.doc_pt[x.d]);
-            x.xdoc = (uint32_t)a.x_doc_off[x.d];
-            x.odoc = (uint32_t)a.doc_off[x.d];
-            x.match = a.matchmask && a.tmp_end && ((a.matchmask[x.s >> 6] >> (x.s & 63)) & 1ull);
-            x.se = x.s;                                   // whose token ends: the pre-token's own, or the claimant's of its word
-            if (x.c > 1u && a.claim_pos) {
-                const uint32_t t0 = a.tok0[p];
-                if ((t0 & TOK_SLOT) == TOK_SLOT) x.se = a.claim_pos[t0 & TOK_REF_MASK];
-            }
-            return x;
-        };
-        Pt cur = fetch(0);
+        // ---- a lane's four pre-tokens: one token -> written here; several -> listed
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
-            const Pt nxt = fetch(q + 1);
-            const uint32_t c = cur.c;
-            if (c) {
-                const int64_t p = base + tid + 256 * q;
-                const bool ends = c > 1u && a.tmp_end;    // (no token ends without offsets: word ids only)
-                uint32_t rel = 0u;
-                const uint32_t n_in = min(c, TM_INLINE);
-                for (uint32_t j = 0; j < n_in; ++j) {
-                    const uint32_t rel_end = ends ? a.tmp_end[cur.se + j] : cur.e - cur.s;
-                    meta_one_token(a, p, cur.d, cur.s, cur.e, cur.match, cur.o, j, rel, rel_end, cur.xdoc, cur.odoc, cur.word);
-                    rel = rel_end;
+            const int i = tid + 256 * q;
+            if (i >= np) break;
+            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o;
+            if (!c) continue;
+            const int64_t p = base + i;
+            const uint32_t s = s_start[i];
+            if (c > 1u) {
+                uint32_t se = s;                          // whose token ends: the pre-token's own, or the claimant's of its word
+                if (a.claim_pos && a.tmp_end) {
+                    const uint32_t t0 = a.tok0[p];
+                    if ((t0 & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[t0 & TOK_REF_MASK];
                 }
-                if (c > TM_INLINE) s_big[atomicAdd(&s_nbig, 1u)] = (uint16_t)(tid + 256 * q);
+                const uint32_t k = atomicAdd(&s_nm, 1u);
+                s_mlist[k] = (uint16_t)i;
+                s_mse[k] = se;
+                s_mbase[k] = c;
+                continue;
             }
-            cur = nxt;
+            const uint32_t e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const int64_t d = (int64_t)s_doc[i];
+            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
+            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+            meta_one_token(a, p, d, s, e, is_match, o, 0u, 0u, e - s, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word);
         }
         __syncthreads();
-        // ---- the long pre-tokens of the tile (a run of letters the vocabulary cuts into many tokens): a token a lane
-        const uint32_t nbig = s_nbig;
-        for (uint32_t b = 0; b < nbig; ++b) {
-            const int i = (int)s_big[b];
+        // ---- the listed pre-tokens' tokens, one a lane
+        const uint32_t nm = s_nm;
+        uint32_t mt;
+        {
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = (4u * (uint32_t)tid + q < nm) ? s_mbase[4 * tid + q] : 0u; sum += v[q]; }
+            uint32_t run = block256_excl_scan(sum, s_scan, &mt);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { if (4u * (uint32_t)tid + q < nm) s_mbase[4 * tid + q] = run; run += v[q]; }
+            if (tid == 0) s_mbase[nm] = mt;
+        }
+        __syncthreads();
+        for (uint32_t t = (uint32_t)tid; t < mt; t += 256u) {
+            int lo = 0, hi = (int)nm;                     // the last k with mbase[k] <= t
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_mbase[mid] <= t) lo = mid; else hi = mid; }
+            const int k = lo, i = (int)s_mlist[k];
+            const uint32_t j = t - s_mbase[k], se = s_mse[k];
             const int64_t p = base + i, d = (int64_t)s_doc[i];
-            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o, s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const uint32_t o = s_tokoff[i], s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
+            uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
+            if (a.tmp_end) {
+                if (j) rel = a.tmp_end[se + j - 1u];
+                rel_end = a.tmp_end[se + j];
+            }
             const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
-            const uint32_t xdoc = (uint32_t)a.x_doc_off[d], odoc = (uint32_t)a.doc_off[d];
             const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            uint32_t s_ends = s;
-            if (a.claim_pos) {
-                const uint32_t t0 = a.tok0[p];
-                if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = a.claim_pos[t0 & TOK_REF_MASK];
-            }
-            for (uint32_t j = TM_INLINE + (uint32_t)tid; j < c; j += 256u) {
-                const uint32_t rel = a.tmp_end ? a.tmp_end[s_ends + j - 1u] : 0u;
-                const uint32_t rel_end = a.tmp_end ? a.tmp_end[s_ends + j] : e - s;
-                meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word);
-            }
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word);
         }
     }
 }
