@@ -24,6 +24,16 @@ def _small_shards(monkeypatch):
     monkeypatch.setenv("TKAMD_SHARD_MIN_KB", "8")        # (read when a handle is made) the test batches are a few hundred kB
 
 
+def _devs(n: int) -> list:
+    """the device list of an n-shard handle: device 0 named n times (one-GPU boxes; what the driver's gate runs), or -- with
+    TKAMD_TEST_DISTINCT_DEVICES=1 on a node that has them, tools/first_contact_multi_gpu.sh -- n distinct GPUs"""
+    if os.environ.get("TKAMD_TEST_DISTINCT_DEVICES") == "1":
+        import torch
+        if torch.cuda.device_count() >= n:
+            return list(range(n))
+    return [0] * n
+
+
 def _same(a, b):
     assert a.n_tokens == b.n_tokens and np.array_equal(a.tok_offsets, b.tok_offsets) and np.array_equal(a.ids, b.ids)
     for f in ("offsets", "word_ids", "pad_counts", "type_ids"):
@@ -44,8 +54,8 @@ def test_sharded_call_equals_the_unsharded_call(collect, n_dev):
     import tokenizers_amd as ta
     js = load_tokenizer_json("bytelevel_prefix_trim_3000")
     one = ta.Tokenizer.from_str(js, device=0)
-    many = ta.Tokenizer.from_str(js, device=[0] * n_dev, collect=collect)
-    assert many.devices == [0] * n_dev
+    many = ta.Tokenizer.from_str(js, device=_devs(n_dev), collect=collect)
+    assert many.devices == _devs(n_dev)
     docs = _docs()
     _same(many.encode_batch_csr(docs), one.encode_batch_csr(docs))
     st = many.shard_stats()
@@ -62,7 +72,7 @@ def test_sharded_call_equals_the_unsharded_call(collect, n_dev):
 def test_sharded_call_vs_oracle_gpt2_and_ids16():
     import tokenizers_amd as ta
     js = synth.load_or_train_gpt2()
-    many = ta.Tokenizer.from_str(js, device=[0, 0, 0, 0])
+    many = ta.Tokenizer.from_str(js, device=_devs(4))
     docs = synth.gen_lines(60000, text_seed=302) + synth.stress_lines(seed=46, n=800)
     exp = orc.Oracle(js).encode_batch(docs)
     got = many.encode_batch_csr(docs)
@@ -81,7 +91,7 @@ def test_sharded_pairs_truncation_fixed_padding_and_words(name):
     d["truncation"] = {"direction": "Right", "max_length": 24, "strategy": "LongestFirst", "stride": 2}
     d["padding"] = {"strategy": {"Fixed": 28}, "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}
     js = json.dumps(d)
-    one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=[0, 0, 0])
+    one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=_devs(3))
     lines = [l for l in synth.gen_lines(9000, text_seed=303) if "[" not in l]
     pairs = [(a, b) for a, b in zip(lines[0::2], lines[1::2])]
     for kw in ({}, {"offsets": "char", "word_ids": True}):
@@ -92,7 +102,7 @@ def test_sharded_pairs_truncation_fixed_padding_and_words(name):
     # BatchLongest: sharded since round 6 (the shards exchange their longest encoding); overflowing: the whole batch on devices[0]
     d["padding"]["strategy"] = "BatchLongest"
     js = json.dumps(d)
-    one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=[0, 0, 0])
+    one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=_devs(3))
     _same(many.encode_batch_csr(lines, add_special_tokens=True), one.encode_batch_csr(lines, add_special_tokens=True))
     a, b = many.encode_batch_csr(lines, add_special_tokens=True, overflowing=True), one.encode_batch_csr(lines, add_special_tokens=True, overflowing=True)
     _same(a, b)
@@ -113,7 +123,7 @@ def test_batch_longest_padding_is_sharded(n_dev):
         d["padding"] = {"strategy": "BatchLongest", "direction": direction, "pad_to_multiple_of": multiple, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}
         d["truncation"] = None if trunc is None else {"direction": "Right", "max_length": trunc, "strategy": "LongestFirst", "stride": 0}
         js = json.dumps(d)
-        one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=[0] * n_dev)
+        one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=_devs(n_dev))
         for batch in (lines, pairs):
             got, want = many.encode_batch_csr(batch, add_special_tokens=True, offsets="char", word_ids=True), one.encode_batch_csr(batch, add_special_tokens=True, offsets="char", word_ids=True)
             _same(got, want)
@@ -126,7 +136,7 @@ def test_batch_longest_padding_is_sharded(n_dev):
     dw = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
     dw["model"]["unk_token"] = "<nope>"           # not in the vocabulary: MissingUnkToken the moment a word misses (wordlevel/mod.rs:175-177)
     dw["padding"] = {"strategy": "BatchLongest", "direction": "Right", "pad_to_multiple_of": None, "pad_id": 0, "pad_type_id": 0, "pad_token": "[PAD]"}
-    bad = ta.Tokenizer.from_str(json.dumps(dw), device=[0] * n_dev)
+    bad = ta.Tokenizer.from_str(json.dumps(dw), device=_devs(n_dev))
     vocab = [w for w in dw["model"]["vocab"] if w.isascii() and w.isalnum()]
     good = [" ".join(vocab[(7 * i + k) % len(vocab)] for k in range(12)) for i in range(20000)]
     with pytest.raises(Exception, match="MissingUnkToken"):
@@ -138,7 +148,7 @@ def test_an_error_in_one_shard_fails_the_call_and_the_handle_survives():
     import tokenizers_amd as ta
     d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
     d["model"]["unk_token"] = "<nope>"            # not in the vocabulary: MissingUnkToken the moment a word misses (wordlevel/mod.rs:175-177)
-    many = ta.Tokenizer.from_str(json.dumps(d), device=[0, 0, 0])
+    many = ta.Tokenizer.from_str(json.dumps(d), device=_devs(3))
     vocab = [w for w in d["model"]["vocab"] if w.isascii() and w.isalnum()]
     good = [" ".join(vocab[(7 * i + k) % len(vocab)] for k in range(12)) for i in range(20000)]
     assert many.encode_batch_csr(good).n_tokens == 12 * len(good)
