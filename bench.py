@@ -274,8 +274,6 @@ def main() -> None:
     ap.add_argument("--no-host", action="store_true", help="skip the host-boundary leg")
     ap.add_argument("--no-word-cache", action="store_true", help="skip the word-cache leg")
     ap.add_argument("--no-offsets", action="store_true", help="skip the with-offsets legs (encode_batch with byte / char offsets + word ids)")
-    ap.add_argument("--two-streams", action="store_true", help="also time the K steps alternating over two streams (two batches in flight); measured "
-                                                               "SLOWER than one stream -- 0.998 against 0.535 ms a step, profiles/r5j_c2_bench.json -- so not part of the default line")
     ap.add_argument("--no-single-call", action="store_true", help="skip the single-call multi-GPU leg")
     ap.add_argument("--single-call-gpus", type=int, default=0, help="devices of the single-call leg (0 = every visible GPU)")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
@@ -468,43 +466,6 @@ def main() -> None:
             except Exception as ex:     # never lose the bench line to an auxiliary leg
                 with_off[mode] = {"error": repr(ex)[:300]}
             log(f"[bench] with-offsets leg ({mode}) in {time.time() - t0:.1f}s: {with_off[mode].get('value', with_off[mode].get('error'))}")
-
-    # ---- two batches in flight (rank 0, N=1): the same K steps, alternating over TWO streams (the device entry keys its workspace by the
-    # caller's stream: two streams, two workspaces).  NOT `value` -- a step of `value` is one batch after the other on one stream --
-    # but what a loader that keeps two batches in flight gets: the chain-bound tail of one batch (thin merge queues, the compaction's
-    # look-back) could overlap the bandwidth-bound head of the next.  Measured (round 5): it does not -- 0.998 ms a step against 0.535,
-    # two lookups and two compactions each on half the chip cost more than they hide -- so the leg is opt-in (--two-streams).  Every
-    # step's result is checked like the timed ones'. ----
-    two = None
-    if rank == 0 and world == 1 and args.two_streams:
-        try:
-            side = torch.cuda.Stream()
-            streams = [stream, side.cuda_stream]
-
-            def enc2(i):
-                b = batches[i % n_batches]
-                return tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, stream=streams[i & 1])
-            for i in range(4):
-                enc2(i)
-            torch.cuda.synchronize()
-            best = float("inf")
-            for _ in range(3):
-                t_s = time.perf_counter()
-                for i in range(args.steps):
-                    enc2(i)
-                torch.cuda.synchronize()
-                best = min(best, (time.perf_counter() - t_s) / args.steps)
-            ok = True
-            for i in range(2 * n_batches):                   # (both workspaces' results against the gate's checksums)
-                ok = ok and result_checksum(enc2(i).sync()) == batches[i % n_batches].checksum
-                torch.cuda.synchronize()
-            two = {"value": round(tot_bytes / args.steps / best / 1e9, 3), "unit": "GB/s", "ms_per_step": round(best * 1e3, 4), "streams": 2,
-                   "results_equal_the_gate": bool(ok),
-                   "note": "K steps alternating over two streams (two workspaces of the handle), best of 3 passes; not `value`"}
-            if not ok:
-                two["error"] = "a result differs from the gated one"
-        except Exception as ex:     # never lose the bench line to an auxiliary leg
-            two = {"error": repr(ex)[:300]}
 
     # ---- word-cache leg (rank 0, N=1): the device-side counterpart of the reference's per-thread word cache
     # (models/bpe/model.rs:573-586).  NOT `value`: the steps revisit the same three batches, so a warm cache has seen every word of
@@ -711,7 +672,6 @@ def main() -> None:
             "value_with_char_offsets": (with_off or {}).get("char", {}).get("value"),
             "value_out_of_distribution": ood["value"] if ood else None,
             "value_with_word_cache": wcache["value_warm"] if wcache else None,
-            "value_two_batches_in_flight": two.get("value") if two else None,
             "parity": {"checked_documents": int(n_checked), "against": "oracle/oracle.c", "of": "every timed batch (2 % sample), ids bit-exact",
                        "timed_outputs": f"checksums of ids + token CSR of the last timed step and of {n_verified} re-run steps equal the gated results'"},
             "config": {"workload": f"{workload}, {b0.n_docs} synthetic documents ({b0.n_bytes / 1e6:.0f} MB) per GPU per step, "
@@ -721,7 +681,7 @@ def main() -> None:
                        "tokenizer_sha256": synth.sha256(tok_json)[:16],
                        "parallelism": f"dp{world} (documents sharded by rank)"},
             "roofline": roofline, "with_offsets": with_off, "cpu_baseline": cpu, "host_boundary": host, "single_call_multi_gpu": single_call,
-            "out_of_distribution": ood, "word_cache": wcache, "two_batches_in_flight": two, "other_configs": others_cfg,
+            "out_of_distribution": ood, "word_cache": wcache, "other_configs": others_cfg,
         }
     # ---- gather leg: the same K steps, each ending with the collect-to-root of the final buffers over RCCL ----
     gather_obj = None

@@ -349,7 +349,7 @@ int tkamd_encode_special_tokens(tkamd_tokenizer* tok, int value);
  * state: the first occurrence of a word the static tables do not settle goes to the model kernel, its other occurrences in the same
  * batch share the result (in-batch claims, csrc/kernels/lookup.hip; with or without offsets).  Switching this cache on replaces them.
  * A batch that shared nothing (more than 35 % of its pre-tokens still queued) pauses the claims for the handle's next 32 batches
- * (TKAMD_CLAIMS_PAUSE, read when the handle is made): on text that never repeats a word they only cost. */
+ * : on text that never repeats a word they only cost. */
 int tkamd_word_cache(tkamd_tokenizer* tok, int enable, int clear);
 
 /* ---- measurement hooks (bench.py roofline leg; not part of the reference surface) -----------
@@ -369,7 +369,7 @@ int tkamd_profile_read(tkamd_tokenizer* tok, tkamd_stage_time* stages, int max_s
  * kernel, out[1] = to the 64-lane kernel, out[2] = to the workgroup (long) kernel. */
 int tkamd_profile_counters(tkamd_tokenizer* tok, uint32_t* out, int n);
 
-/* Where the two longest kernels spend their time.  With TKAMD_PHASES=1 in the environment (read once per process) the whole-word
+/* Where the two longest kernels spend their time.  With the test hook TKAMD_PHASES (TKAMD_TEST_HOOKS=1 TKAMD_PHASES=1) the whole-word
  * lookup (which = 0) and the token compaction (which = 1) run as diagnostic instantiations that stamp the shader clock behind the
  * barriers that end their phases; out[0..7] = ticks summed over all workgroups and batches since the last reset
  * (lookup: 0 staging a tile, 1 expanding the mask bits, 2 pass 1 (LDS hot table), 3 pass 2 (perfect hash), 4 pass 3 (claims) +

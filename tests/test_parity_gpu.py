@@ -392,21 +392,16 @@ def test_every_whole_word_of_the_vocabulary_is_settled_by_the_tables(name):
 
 
 @pytest.mark.parametrize("variant", [
-    {"TKAMD_PRETOK": "bits", "TKAMD_MERGE16": "row", "TKAMD_LDSCFG": "0"},     # ballot pre-tokenizer, DPP-row merge, register lane32
-    {"TKAMD_PRETOK": "lds", "TKAMD_MERGE16": "lane", "TKAMD_LDSCFG": "1"},     # lane-per-byte pre-tokenizer, register lane16, LDS lane32
-    {"TKAMD_TEST_HOOKS": "1", "TKAMD_Q16_DIV": "100000"},                                                # a work queue far too small: the batch overflows it and is run again
-    {"TKAMD_CLAIMS": "0"},                                                      # every occurrence of a word goes to the model kernels
-    {"TKAMD_LEAN_PROLOGUE": "0", "TKAMD_LU_FILL": "0", "TKAMD_CLAIM_ADAPT": "0", "TKAMD_MERGE_ONE": "1"},   # validate / sanitize / mark as kernels of their own, pass 1 stores its hits only, claims that never give up, one merge launch
-    {"TKAMD_TEST_HOOKS": "1", "TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_ONE": "0", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
-    {"TKAMD_HOT_SLOTS": "2048"},                                                # the two-workgroups-per-CU shape of the lookup (2,048 hot slots, the short-word displacements in LDS, pass 2 two steps side by side)
-    {"TKAMD_FUSED": "1"},                                                       # pre-tokenizer + mask scan + lookup as ONE kernel (round 5; measured slower than the three: opt-in)
-    {"TKAMD_FUSED": "1", "TKAMD_TEST_HOOKS": "1", "TKAMD_LU_GRID": "5", "TKAMD_LB_PATIENCE": "0", "TKAMD_CLAIMS": "0", "TKAMD_SQ_LUT": "4"},   # ... on five workgroups whose look-backs compute every count they find missing themselves
-], ids=["bits-row16-lane32", "ldspretok-lane16", "queue-overflow-retry", "no-claims", "general-prologue", "helping-lookback-two-merges", "lookup-2-per-cu",
-        "fused-pretok-scan-lookup", "fused-helping-lookback"])
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_FORCE_LANE_MERGE": "1"},                   # the register-resident lane kernels: what runs for a vocabulary whose new ids are not rank + c
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_Q16_DIV": "100000"},                      # a work queue far too small: the batch overflows it and is run again
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_CLAIMS": "0"},                             # every occurrence of a word goes to the model kernels
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_LB_PATIENCE": "0", "TKAMD_MERGE_TWO": "1", "TKAMD_CP_GRID": "5"},   # a compaction whose look-backs compute every total they find missing themselves, two merge launches
+    {"TKAMD_TEST_HOOKS": "1", "TKAMD_PHASES": "1"},                             # the diagnostic instantiations of the lookup and the compaction (tkamd_debug_phases)
+], ids=["lane-merge-kernels", "queue-overflow-retry", "no-claims", "helping-lookback-two-merges", "phase-timers"])
 def test_alternative_kernels_agree(gpt2_json, variant):
-    """The A/B kernel variants (the fallbacks for vocabularies whose new ids are not rank + c, and the earlier generations
-    of the pre-tokenizer) must give the same ids and offsets as the oracle: run them in a subprocess because the
-    selection is read once per process."""
+    """The paths a plain run does not take -- the fallback kernels for vocabularies whose new ids are not rank + c, a queue overflow, no
+    in-batch claims, a look-back that helps itself, the diagnostic instantiations -- must give the same ids and offsets as the oracle.
+    Test hooks (TKAMD_TEST_HOOKS=1) select them; a subprocess, because a handle reads some of them when it is made."""
     import os
     import subprocess
     import sys
@@ -599,32 +594,6 @@ def test_decode_unsupported_decoder_is_refused():
     tk = ta.Tokenizer.from_str(json.dumps(d), device=0)
     with pytest.raises(ta.UnsupportedError):
         tk.decode_batch([[1, 2, 3]])
-
-
-def test_tile_pretokenizer_variants_agree():
-    """The lane-per-byte tile kernels stay behind the per-lane bit-parallel pre-tokenizers (Llama-3: as their second tier;
-    Whitespace / Bert: as the TKAMD_PRETOK_LOCAL=tile variant).  Run them alone in a subprocess (the selection is read once
-    per process) against the oracle."""
-    import os
-    import subprocess
-    import sys
-    code = (
-        "import sys; sys.path.insert(0, %r)\n"
-        "import numpy as np, tokenizers_amd as ta\n"
-        "from oracle import synth, oracle as orc\n"
-        "from tests.helpers import load_tokenizer_json\n"
-        "from tests.test_parity_gpu import _adversarial_docs\n"
-        "base = synth.gen_lines(3000, text_seed=5) + synth.stress_lines(seed=8, n=1500)\n"
-        "for name in ('llama3_small_6000', 'bert_wordpiece_4000', 'wordlevel_whitespace_c1', 'wordlevel_wssplit'):\n"
-        "    js = load_tokenizer_json(name)\n"
-        "    docs = [d for d in base if d.isascii()] if name.startswith('bert') else base + _adversarial_docs(6000, 21)\n"
-        "    got = ta.Tokenizer.from_str(js, device=0).encode_batch_fast(docs, add_special_tokens=False)\n"
-        "    exp = orc.Oracle(js).encode_batch(docs)\n"
-        "    assert got.tok_offsets.tolist() == exp.tok_offsets.tolist() and (got.ids == exp.ids).all(), name\n"
-        "print('VARIANT_OK')\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TKAMD_PRETOK_L3="tile", TKAMD_PRETOK_LOCAL="tile")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert "VARIANT_OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_concurrent_host_callers(gpt2, gpt2_oracle):
@@ -837,7 +806,8 @@ def test_claims_pause_while_nothing_is_shared(monkeypatch):
     (TKAMD_CLAIMS_PAUSE of them, 32 by default), after which they are tried again.  Seen from outside: the queue of a repetitive
     batch holds its distinct words while the claims run and every occurrence while they pause -- and the ids never change."""
     import tokenizers_amd as ta
-    monkeypatch.setenv("TKAMD_CLAIMS_PAUSE", "3")             # (read when the handle is made)
+    monkeypatch.setenv("TKAMD_TEST_HOOKS", "1")
+    monkeypatch.setenv("TKAMD_CLAIMS_PAUSE", "3")             # (a test hook, read when the handle is made)
     js = load_tokenizer_json("bytelevel_prefix_trim_3000")
     tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
     rng = np.random.default_rng(78)

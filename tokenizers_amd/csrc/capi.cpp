@@ -43,10 +43,14 @@ int set_error(int code, const std::string& msg) {
 // far too small, a lowered row limit, a RCCL library that is not there, poisoned scratch text) change launch shapes or skip a check: they
 // are read only when TKAMD_TEST_HOOKS=1 is set as well, so that a stray variable in a production environment changes nothing.
 // (read on every call: a test that sets the variables after the process made its first handle must still get its hook)
+}  // namespace
+namespace tkamd {
 const char* test_hook(const char* name) {
     const char* const e = getenv("TKAMD_TEST_HOOKS");
     return (e && !strcmp(e, "1")) ? getenv(name) : nullptr;
 }
+}  // namespace tkamd
+namespace {
 
 struct HipError : std::runtime_error {
     using std::runtime_error::runtime_error;
@@ -220,10 +224,6 @@ struct Workspace {
     // directions of the link run side by side and neither waits behind the other in a compute stream's order (encode_host)
     hipStream_t io_in = nullptr, io_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
-    // the model kernels of the queue classes are independent of each other and, once the claims have thinned the queues, each too small
-    // to fill the chip: they run side by side on two more streams, forked from and joined into the call's stream with events
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     // (sized by the largest batch seen)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count, w_keep, w_type_ids2, w_seq_ids2;   // truncation / padding / pair epilogue
@@ -242,7 +242,6 @@ struct Workspace {
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
-    DevBuf w_lstate;                             // look-back state of the fused pre-tokenizer + lookup pass (kernels/lookup.hip FUSED)
     DevBuf w_claims, w_claim_rows, w_claim_pos;  // in-batch word claims (kernels.hpp WordCache::claims), the rows of the claimed slots, the claimants' first bytes
     DevBuf w_phases;                             // TKAMD_PHASES: shader-clock ticks per phase of the lookup / compaction, [2][PHASE_WGS][8] u64 (tkamd_debug_phases)
     uint64_t cache_epoch = 0;                    // the tokenizer's cache_epoch these were last cleared at (0: never)
@@ -274,11 +273,6 @@ struct Workspace {
             if (ev_in[i]) (void)hipEventDestroy(ev_in[i]);
             if (ev_out[i]) (void)hipEventDestroy(ev_out[i]);
         }
-        for (int i = 0; i < 2; ++i) {
-            if (side[i]) (void)hipStreamDestroy(side[i]);
-            if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
-        }
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
     }
 };
 
@@ -303,9 +297,6 @@ struct tkamd_tokenizer {
     int n_cu = 256;
     int n_direct = 0;
     int n_hot = 0;
-    int hot_slots = 1024;        // slots of the hot-word table (kernels/lookup.hip: 1024 = three lookup workgroups per CU -- the default since the short-word
-                                 // table made a miss of the hot table cheap: 0.2237 against 0.2279 ms on C2, 0.246 against 0.265 on C3, profiles/r4m_* --, 2048 = two; TKAMD_HOT_SLOTS)
-    bool lu_fused = false;       // the plain GPT-2 byte-level path runs pre-tokenizer + mask scan + lookup as ONE kernel (kernels/lookup.hip FUSED; TKAMD_FUSED=0: three)
     int cp_grid = 0;             // grid of k_compact: what is resident at once (any grid makes progress -- its look-back helps itself --, TKAMD_CP_GRID)
     // In-batch claims on text that shares nothing (every candidate word distinct): the claim traffic then buys nothing and costs a third
     // of the step (the claims' worst case).  Inside a batch every lookup workgroup gives the claims up by itself once
@@ -313,8 +304,7 @@ struct tkamd_tokenizer {
     // quarter of its candidates shared pauses them for the next claims_pause_len batches of the handle; then they are tried again.
     std::atomic<int> q16_fat_hint{1};    // the last batch that ran with the claims left a fat <= 16-byte queue (or none has run yet): see run_pipeline's merge launches
     std::atomic<int> claims_pause{0};
-    int claims_pause_len = 32;   // TKAMD_CLAIMS_PAUSE (0: never pause)
-    int cp_items = 4;            // pre-tokens per lane of k_compact: 4 (default: 0.145 ms on C2 against 0.187) or 8 (TKAMD_CP_ITEMS)
+    int claims_pause_len = 32;   // (test hook TKAMD_CLAIMS_PAUSE; 0: never pause)
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling
     std::atomic<bool> prof{false};
@@ -595,14 +585,12 @@ void build_shortw_table(tkamd_tokenizer* t) {
     std::vector<const WordSlot*> ws;
     for (const WordSlot& w : hm.word_table)
         if (w.len) ws.push_back(&w);
-    // the first size tried: the power of two at or above `x10 / 10` slots a word (TKAMD_SHORTW_X10, an A/B knob; 25 = two and a half --
-    // a fuller table is fewer lines for the caches to hold and more displacements to try; a size that cannot be placed doubles below)
-    static const size_t x10 = [] { const char* e = getenv("TKAMD_SHORTW_X10"); return (size_t)std::max(11, e ? atoi(e) : 13); }();
+    // the first size tried: the power of two at or above 1.3 slots a word (a fuller table is fewer lines for the caches to hold and more
+    // displacements to try; a size that cannot be placed doubles below)
+    const size_t x10 = 13;
     // displacement buckets: SHORTW_BUCKETS, four times that for a vocabulary beyond 65,536 words (Llama-3's 128 k: fifteen words a bucket
     // find no eight-bit displacement in a table less than a quarter full -- 8 MB for 124 k words; four a bucket settle at 47 %, 4 MB)
-    // (TKAMD_SHORTW_BUCKETS: an A/B knob, a power of two)
-    static const uint32_t forced_buckets = [] { const char* e = getenv("TKAMD_SHORTW_BUCKETS"); const int v = e ? atoi(e) : 0; return (v >= 1024 && !(v & (v - 1))) ? (uint32_t)v : 0u; }();
-    const uint32_t n_buckets = forced_buckets ? forced_buckets : (ws.size() > 65536 ? 4u * (uint32_t)SHORTW_BUCKETS : (uint32_t)SHORTW_BUCKETS);
+    const uint32_t n_buckets = ws.size() > 65536 ? 4u * (uint32_t)SHORTW_BUCKETS : (uint32_t)SHORTW_BUCKETS;
     uint32_t cap = 16;
     while (cap < ws.size() * x10 / 10) cap <<= 1;
     std::vector<uint32_t> h1(ws.size()), km(ws.size()), where(ws.size());
@@ -661,7 +649,6 @@ void build_shortw_table(tkamd_tokenizer* t) {
     t->dt.shortw_disp = t->t_shortw_disp.as<uint8_t>();
     t->dt.shortw_mask = cap - 1;
     t->dt.shortw_bmask = n_buckets - 1u;
-    if (getenv("TKAMD_DEBUG_TABLES")) fprintf(stderr, "[tkamd] short-word table: %zu words in %u slots of 16 + 4 bytes, %u buckets\n", ws.size(), cap, n_buckets);
 }
 
 // Hot-word table of the lookup kernel: the settled words of <= 12 bytes with the lowest ids, direct mapped (tables.hpp).
@@ -670,7 +657,7 @@ void build_shortw_table(tkamd_tokenizer* t) {
 // to a lower id stays reachable through the perfect-hash table.
 void build_hot_table(tkamd_tokenizer* t) {
     HostModel& hm = t->hm;
-    const uint32_t slots = (uint32_t)t->hot_slots, n_buckets = slots / 4u;
+    const uint32_t slots = (uint32_t)HOT_SLOTS, n_buckets = slots / 4u;
     std::vector<HotSlot> hot(slots, HotSlot{0u, 0u, 0u, 0u});
     std::vector<uint16_t> disp(n_buckets, 0);
     std::vector<const WordSlot*> cand;
@@ -722,12 +709,8 @@ void build_hot_table(tkamd_tokenizer* t) {
 // takes every grid-th tile of LOOKUP_TILE_BYTES.  A pre-token of class 1 / 2 / 3 is longer than 16 / 32 / 64 bytes, so those three
 // are sized for the worst case outright; the <= 16-byte queue (worst case: half the bytes) starts at 1 / q16_div of them and
 // the batch is run again with the worst-case size if it ever overflows (ERR_QUEUE_FULL; natural text queues 1/50 .. 1/6).
-// the lookup's grid: what is resident at once (kernels/lookup.hip LuShape), one private sub-queue per workgroup
-// (test hook TKAMD_LU_GRID: a grid no launch would pick -- the fused pass's look-back must make progress at any grid and residency)
-int lookup_grid(const tkamd_tokenizer* t) {
-    static const int forced = [] { const char* e = test_hook("TKAMD_LU_GRID"); return e ? std::max(1, std::min(atoi(e), (int)NSQ)) : 0; }();
-    return forced ? forced : std::min((t->hot_slots == 1024 && !t->lu_fused ? 3 : 2) * t->n_cu, (int)NSQ);
-}
+// the lookup's grid: what is resident at once (kernels/lookup.hip: three workgroups a CU), one private sub-queue per workgroup
+int lookup_grid(const tkamd_tokenizer* t) { return std::min(3 * t->n_cu, (int)NSQ); }
 
 struct QueueSizes {
     uint32_t sq_cap[4], row_base[4];
@@ -759,8 +742,8 @@ void reserve_workspace(tkamd_tokenizer* t, Workspace* w, int64_t n_bytes, int64_
     const QueueSizes z = queue_sizes(N, t->q16_div, lookup_grid(t));
     w->w_rows.reserve(z.total * 16);
     w->w_queues.reserve(z.total * 8);
-    w->w_cstate.reserve((N / COMPACT_CHUNK_MIN + 4) * 8 + 16);
-    w->w_chunk_lo.reserve((N / COMPACT_CHUNK_MIN + 4) * 4);
+    w->w_cstate.reserve((N / COMPACT_CHUNK + 4) * 8 + 16);
+    w->w_chunk_lo.reserve((N / COMPACT_CHUNK + 4) * 4);
     w->w_qcount.reserve((size_t)QCNT_WORDS * 4);
     w->w_pt_tokoff.reserve((N + 4) * 4);
     w->w_ids.reserve((N + 4) * 4);
@@ -840,12 +823,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     using ull = unsigned long long;
 
     // Everything the batch needs zeroed, in one launch: the scalars, the document mask, the queues' fill counters, the look-back state
-    // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default, TKAMD_CLAIMS=0 switches them off
-    // for A/B runs; the word cache -- tkamd_word_cache, across batches -- takes their place when it is switched on).
-    static const bool claims_on = [] { const char* e = getenv("TKAMD_CLAIMS"); return !(e && !strcmp(e, "0")); }();
-    // A text made on the device (the normaliser's) has its length there; its masks and prefix counts are launched over the host's bound.
-    // TKAMD_LEN_BOUND=0 (A/B): every word of the bound is zeroed / written / scanned, as up to round 4.
-    static const bool len_bound = [] { const char* e = getenv("TKAMD_LEN_BOUND"); return !(e && !strcmp(e, "0")); }();
+    // of the compaction and the claims table (in-batch word claims, kernels/lookup.hip: on by default -- the test hook TKAMD_CLAIMS=0
+    // switches them off, every occurrence of a word then goes to the model kernels; the word cache -- tkamd_word_cache, across batches --
+    // takes their place when it is switched on).
+    const char* const claims_hook = test_hook("TKAMD_CLAIMS");
+    const bool claims_on = !(claims_hook && !strcmp(claims_hook, "0"));
+    // A text made on the device (the normaliser's) has its length there; its masks and prefix counts are launched over the host's bound
+    // and stop at the text's own length.
+    constexpr bool len_bound = true;
     bool use_claims = claims_on && !t->word_cache &&
                       (hm.model == MODEL_BPE || (hm.model == MODEL_WORDPIECE && hm.max_input_chars >= (uint32_t)WORD_MAX_KEY));
     if (use_claims) {                                      // paused by an earlier batch that shared nothing (read_scalars)? one batch less to go
@@ -855,7 +840,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     w->last_used_claims = use_claims;
     size_t claim_slots = 0;
-    const size_t cstate_bytes = (((size_t)n_x / ((size_t)256 * (size_t)t->cp_items) + 4) * 8 + 15) & ~(size_t)15;
+    const size_t cstate_bytes = (((size_t)n_x / (size_t)COMPACT_CHUNK + 4) * 8 + 15) & ~(size_t)15;
     {
         ZeroRegions z{};
         z.add(sc, SC_SLOTS * 8);
@@ -864,18 +849,12 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         if (!(len_bound && hm.norm == NORM_BERT)) z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
         z.add(w->w_cstate.p, cstate_bytes);
-        if (t->lu_fused) {                                 // the fused pass's look-back state: 8 bytes per 16 KB tile of text
-            const size_t lb = (((size_t)n_x / LOOKUP_TILE_BYTES + 2) * 8 + 15) & ~(size_t)15;
-            w->w_lstate.reserve(lb);
-            z.add(w->w_lstate.p, lb);
-        }
         if (use_claims) {
             // one slot per 64 bytes of the INPUT text (a word is a few bytes, most are repeats), 2^18 .. 2^24 slots: 32 MB of claims (two
             // 64-bit words a slot) + 32 MB of rows for a 120 MB batch.  (Not of the normalised text's bound, three times that behind BertNormalizer: the
             // words are the input's, and a table four times the size is four times the zeroing and a quarter of the cache hits.)
-            // (TKAMD_CLAIM_DIV: bytes of text per slot, an A/B knob -- a smaller table is less to zero and more of it in the caches, and
-            // more words whose slot another word holds)
-            static const size_t per_slot = [] { const char* e = getenv("TKAMD_CLAIM_DIV"); return (size_t)std::max(8, e ? atoi(e) : 64); }();
+            // (a smaller table is less to zero and more of it in the caches, and more words whose slot another word holds)
+            constexpr size_t per_slot = 64;
             int bits = 18;
             while (bits < 24 && ((size_t)1 << bits) < (size_t)n_bytes / per_slot) ++bits;
             claim_slots = (size_t)1 << bits;
@@ -907,10 +886,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // places only: the document bitmask, and the documents' first pre-tokens.  The first is built by the validating kernel itself
     // (a bit only from a document that is consistent on its own: always inside the text), the second kernel writes the validated
     // copy on its way (it runs behind the whole validation, so it knows the verdict) -- two launches instead of four
-    // (TKAMD_LEAN_PROLOGUE=0: the general order).  A malformed CSR still never turns into an access outside the buffers; the batch
+    // (every other tokenizer takes the general order).  A malformed CSR still never turns into an access outside the buffers; the batch
     // fails with TKAMD_ERR_INVALID as before.
-    static const bool lean_on = [] { const char* e = getenv("TKAMD_LEAN_PROLOGUE"); return !(e && !strcmp(e, "0")); }();
-    const bool lean = lean_on && n_bytes > 0 && hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !prefix_space &&
+    const bool lean = n_bytes > 0 && hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !prefix_space &&
                       (hm.pretok == PT_BYTELEVEL_GPT2 || hm.pretok == PT_BYTELEVEL_NOREGEX);
     const int64_t* const raw_doc_off = d_doc_off;
     if (!lean) {
@@ -1352,7 +1330,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         ull* m4[4] = {w->w_matchmask.as<ull>(), w->w_spanmask.as<ull>(), w->w_stopmask.as<ull>(), w->w_hardmask.as<ull>()};
         // (one launch for the four; over the RAW text -- no device-side length -- only the words that text has: the masks are sized for the
         // normalised text's bound, three times that.  Over a text with a device-side length the kernels downstream run over the bound.)
-        static const bool lazy = [] { const char* e = getenv("TKAMD_MASK_LAZY_ZERO"); return !(e && !strcmp(e, "0")); }();      // (A/B: 0 = zero them every time)
+        constexpr bool lazy = true;
         const size_t zero_bytes = len_dev ? WX * 8 : std::min(WX, (size_t)(n_text >> 6) + 2) * 8;
         ZeroRegions z{};
         // (lazily: the WHOLE buffers -- the bits may be an earlier, larger batch's)
@@ -1515,15 +1493,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
 
     uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
     bool has_end = false;             // the pre-tokenizer produced an end bitmask
-    // The fused pass (round 5, kernels/lookup.hip FUSED): for the plain GPT-2 byte-level BPE -- the text as the caller gave it, no added
-    // tokens -- the pre-tokenizer, the mask scan and the lookup are ONE kernel over the text; the start mask and its prefix counts leave
-    // it for the stages behind (k_doc_first_pretok, the offsets pass), which therefore run after it.  TKAMD_FUSED=1 selects it (a handle
-    // made with it: lu_fused); the default is the three kernels, which measure faster.
-    static const bool fused_on = true;
-    static const bool pretok_default = [] { const char* e = getenv("TKAMD_PRETOK"); return !e || (strcmp(e, "bits") && strcmp(e, "lds")); }();
-    const bool fused = fused_on && pretok_default && t->lu_fused && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe && !matchmask &&
-                       !x_len_dev && x_text == d_text && n_bytes > 0;
-    auto after_masks = [&]() {        // what reads the start mask and its prefix counts: behind the pre-tokenizer + scan, or behind the fused pass
+    auto after_masks = [&]() {        // what reads the start mask and its prefix counts: behind the pre-tokenizer + scan
         if (want_meta) {
             // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
             // the bitmasks (k_lookup) and from (start, length) queue entries
@@ -1534,24 +1504,13 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         pf.begin("doc_first_pretok");
         launch_doc_first_pretok(st, lean ? raw_doc_off : x_doc_off, n_docs, n_x, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
-                                d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(), t->cp_items,
+                                d_npretok, w->w_doc_pt.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
                                 lean ? d_err : nullptr, lean ? w->w_doc_off.as<int64_t>() : nullptr);
         pf.end();
     };
-    if (fused) {
-        // (nothing here: launch_lookup_fused below)
-    } else if (hm.pretok == PT_BYTELEVEL_GPT2) {
-        // Two implementations of the same predicate: the LDS-window kernel (default, faster: 0.33 ms @C2) and the
-        // bit-parallel ballot kernel (TKAMD_PRETOK=bits; its 64-bit mask algebra lands on the scalar unit, one per
-        // CU, and measures 0.54 ms) -- kept as an independent cross-check of the window logic.
-        static const int variant = [] {
-            const char* e = getenv("TKAMD_PRETOK");
-            if (e && !strcmp(e, "bits")) return 1;
-            if (e && !strcmp(e, "lds")) return 0;
-            return 2;                                        // lane-per-32-bytes sequential kernel (default)
-        }();
-        pf.begin(variant == 2 ? "pretok_gpt2_seq" : (variant == 1 ? "pretok_gpt2_bits" : "pretok_gpt2"));
-        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(), variant);
+    if (hm.pretok == PT_BYTELEVEL_GPT2) {
+        pf.begin("pretok_gpt2_seq");
+        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>());
         pf.end();
     } else if (hm.pretok == PT_LLAMA3) {
         w->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
@@ -1581,7 +1540,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (matchmask)
         launch_apply_matches(st, w->w_startmask.as<ull>(), has_end ? w->w_endmask.as<ull>() : nullptr, matchmask, w->w_spanmask.as<ull>(),
                              w->w_stopmask.as<ull>(), W, n_match);
-    if (!fused) {
+    {
         pf.begin("mask_scan");
         // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
         // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
@@ -1604,9 +1563,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         plan.v[c].row_base = qz.row_base[c];
     }
     const ull* endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
-    // TKAMD_PHASES=1 (read once): the lookup and the compaction run as their diagnostic instantiations, which add the shader-clock
+    // test hook TKAMD_PHASES: the lookup and the compaction run as their diagnostic instantiations, which add the shader-clock
     // ticks of their phases to a table of this workspace (tkamd_debug_phases reads and clears it); never in a measured run
-    static const bool phases_on = getenv("TKAMD_PHASES") != nullptr;
+    const bool phases_on = test_hook("TKAMD_PHASES") != nullptr;
     auto phases_of = [&](int which) -> void* {
         if (!phases_on) return nullptr;
         if (!w->w_phases.p) {
@@ -1635,76 +1594,35 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         }
         wc = WordCache{(CacheKey*)w->w_cache_keys.p, w->w_cache_rows.p, nullptr, 0u, nullptr};
     };
-    // Fork / join of the side streams: the model kernels of the queue classes are independent of each other.  OFF by default: measured on
-    // C2 the two event hand-overs cost more (0.78 ms a step) than running the thinned-out queues one after the other (0.72);
-    // TKAMD_SIDE_STREAMS=1 switches it on (never while stage times are taken: the profile's events sit on the call's stream).
-    static const bool side_on = [] { const char* e = getenv("TKAMD_SIDE_STREAMS"); return e && !strcmp(e, "1"); }();
-    const bool fork = side_on && !t->prof && !Prof::trace();
-    hipStream_t s_b = st, s_c = st;                      // streams of the <= 32-byte class and of the longer ones
-    auto fork_side = [&]() {
-        if (!fork) return;
-        if (!w->ev_fork) {
-            HIP_CHECK(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i < 2; ++i) {
-                HIP_CHECK(hipStreamCreateWithFlags(&w->side[i], hipStreamNonBlocking));
-                HIP_CHECK(hipEventCreateWithFlags(&w->ev_join[i], hipEventDisableTiming));
-            }
-        }
-        HIP_CHECK(hipEventRecord(w->ev_fork, st));
-        for (int i = 0; i < 2; ++i) HIP_CHECK(hipStreamWaitEvent(w->side[i], w->ev_fork, 0));
-        s_b = w->side[0];
-        s_c = w->side[1];
-    };
-    auto join_side = [&]() {
-        if (!fork) return;
-        for (int i = 0; i < 2; ++i) {
-            HIP_CHECK(hipEventRecord(w->ev_join[i], w->side[i]));
-            HIP_CHECK(hipStreamWaitEvent(st, w->ev_join[i], 0));
-        }
-    };
-    // the model kernels end an entry by publishing its row if it holds a claim (bpe.hip claim_publish_item); TKAMD_PUBLISH=kernel: a
-    // kernel of its own does it after them (k_claims_publish)
-    static const bool pub_kernel = [] { const char* e = getenv("TKAMD_PUBLISH"); return e && !strcmp(e, "kernel"); }();
+    // the model kernels end an entry by publishing its row if it holds a claim (bpe.hip claim_publish_item)
     DevTables mdt = t->dt;
     mdt.err = d_err;
     mdt.probes = t->prof ? d_counters + CNT_MERGE_PROBES : nullptr;
-    bool pub_inline = false;
     auto set_publish = [&]() {
-        pub_inline = wc.claims && !pub_kernel;
-        if (pub_inline) { mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; mdt.pub_pos = wc.claim_pos; }
+        if (wc.claims) { mdt.pub_rows = wc.rows; mdt.pub_mask = wc.claim_mask; mdt.pub_pos = wc.claim_pos; }
     };
     if (hm.model == MODEL_BPE) {
-        pf.begin(fused ? "pretok_scan_lookup" : "lookup");
+        pf.begin("lookup");
         open_word_cache();
         set_publish();
-        if (fused)
-            launch_lookup_fused(st, lookup_grid(t), t->dt, x_text, n_x, w->w_docmask.as<ull>(), w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(),
-                                w->w_tok0.as<uint32_t>(), plan, d_err, t->t_hot.p, wc, phases_of(0), d_counters, w->w_lstate.as<ull>(), d_npretok);
-        else
-            launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                          w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters, t->hot_slots);
+        launch_lookup(st, lookup_grid(t), t->dt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, 0u, 0u, phases_of(0), d_counters);
         pf.end();
-        if (fused) after_masks();
         if (hm.ignore_merges)                              // vocab.get(sequence) for pre-tokens beyond the 16-byte keys (bpe/model.rs:559-567)
             for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, t->dt, x_text, plan.v[c], w->w_rows.p, 0u, d_err, wc);
-        // TKAMD_MERGE16 = row / lane, TKAMD_LDSCFG = 0: the 16-lane DPP-row kernel / the register-resident lane kernels (A/B
-        // switches; the lane kernels are also what runs when new_id is not rank + c)
-        static const int ldscfg = [] { const char* e = getenv("TKAMD_LDSCFG"); return e ? atoi(e) : 2; }();
-        static const bool row16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "row"); }();
-        static const bool lane16 = [] { const char* e = getenv("TKAMD_MERGE16"); return e && !strcmp(e, "lane"); }();
-        const bool lds16 = !row16 && !lane16 && t->dt.newid_affine;     // keys in LDS (default when new_id = rank + c)
-        const bool lds32 = t->dt.newid_affine && ldscfg >= 1;
-        fork_side();                                       // the <= 32-byte class on one side stream, the 64-byte / long classes on the other, the <= 16-byte class here
+        // the LDS kernels need new_id = rank + c (true of every trainer-made vocabulary); otherwise -- and under the test hook
+        // TKAMD_FORCE_LANE_MERGE -- the register-resident lane kernels run
+        const bool lds16 = t->dt.newid_affine && !test_hook("TKAMD_FORCE_LANE_MERGE");      // keys in LDS
+        const bool lds32 = lds16;
         // With the claims on both queues hold the distinct words only, and a launch of the LDS kernels lasts as long as its longest word's
-        // chain of dependent merge probes whatever it holds: the 32-symbol kernel takes both queues in one launch (TKAMD_MERGE_ONE=0: two).
-        // Thin or not is only known on the device.  TKAMD_MERGE_ONE unset: while the handle has not seen a thin <= 16-byte queue (its first
-        // batch, or text that repeats nothing) BOTH kernels are launched and pick the queue's owner from its fill themselves
-        // (thin_limit; an extra ~4 us launch); once a batch came back thin the next ones launch the 32-symbol kernel alone, until a fat
-        // one is seen again.  = 1: always the one launch; = 0: always two, each with its own queue.
-        static const int merge_mode = [] { const char* e = getenv("TKAMD_MERGE_ONE"); return !e ? 2 : (!strcmp(e, "0") ? 0 : 1); }();
-        const bool can_one = wc.claims && lds16 && lds32;
-        const bool both = can_one && merge_mode == 2 && t->q16_fat_hint.load() != 0;
-        const bool one = can_one && merge_mode != 0 && !both;
+        // chain of dependent merge probes whatever it holds: the 32-symbol kernel takes both queues in one launch.  Thin or not is only
+        // known on the device: while the handle has not seen a thin <= 16-byte queue (its first batch, or text that repeats nothing) BOTH
+        // kernels are launched and pick the queue's owner from its fill themselves (thin_limit; an extra ~4 us launch); once a batch came
+        // back thin the next ones launch the 32-symbol kernel alone, until a fat one is seen again.  (Test hook TKAMD_MERGE_TWO: always two
+        // launches, each with its own queue.)
+        const bool can_one = wc.claims && lds16 && lds32 && !test_hook("TKAMD_MERGE_TWO");
+        const bool both = can_one && t->q16_fat_hint.load() != 0;
+        const bool one = can_one && !both;
         if (both) mdt.thin_limit = MERGE_THIN_LIMIT;
         // BPE over characters: only the kernels that know its start (kernels/bpe.hip CHARS) -- the two LDS kernels, each on its own queue,
         // and the workgroup-per-pre-token kernel for everything beyond 32 bytes (or for everything, when the vocabulary's new ids are not
@@ -1730,15 +1648,15 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             pf.end();
         } else {
         pf.begin(lds32 ? "bpe_merge_lds32" : "bpe_merge_lane32");
-        launch_bpe_merge(s_b, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, (one || both) ? &plan.v[0] : nullptr);
+        launch_bpe_merge(st, lds32 ? t->n_cu : grid, lds32 ? 6 : 2, mdt, x_text, plan.v[1], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, (one || both) ? &plan.v[0] : nullptr);
         pf.end();
         if (!one) {
-            pf.begin(row16 ? "bpe_merge16" : (lds16 ? "bpe_merge_lds" : "bpe_merge_lane"));
-            launch_bpe_merge(st, lds16 ? t->n_cu : grid, row16 ? 16 : (lds16 ? 5 : 1), mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+            pf.begin(lds16 ? "bpe_merge_lds" : "bpe_merge_lane");
+            launch_bpe_merge(st, lds16 ? t->n_cu : grid, lds16 ? 5 : 1, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
             pf.end();
         }
         pf.begin("bpe_merge64");
-        launch_bpe_merge(s_c, grid, 64, mdt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
+        launch_bpe_merge(st, grid, 64, mdt, x_text, plan.v[2], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end);
         pf.end();
         pf.begin("bpe_merge_long");
         // pre-tokens beyond the LDS path (> 8192 B) run from a global scratch slab: 5 words per symbol, sized for the
@@ -1751,20 +1669,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             w->w_huge.reserve(64);
             w->w_list_huge.reserve(64);
         }
-        launch_bpe_merge_long(s_c, t->n_cu, mdt, x_text, plan.v[3], w->w_rows.p,
+        launch_bpe_merge_long(st, t->n_cu, mdt, x_text, plan.v[3], w->w_rows.p,
                               w->w_tmp_ids.as<uint32_t>(), tmp_end, w->w_list_huge.as<uint32_t>(), d_counters + CNT_LISTH, w->w_huge.as<uint32_t>(),
                               (unsigned long long)(N > (size_t)LONG_PT_MAX ? huge_words : 0), (unsigned long long*)(sc + SC_HUGE_USED), d_err);
         pf.end();
         }
-        join_side();
         if (wc.keys) {
             pf.begin("word_cache_insert");
             launch_word_cache_insert(st, grid, mdt, x_text, plan.v[0], w->w_rows.p, wc);
-            pf.end();
-        }
-        if (wc.claims && !pub_inline) {
-            pf.begin("claims_publish");
-            launch_claims_publish(st, t->n_cu * 2, t->dt, x_text, plan, w->w_rows.p, wc);
             pf.end();
         }
     } else if (hm.model == MODEL_WORDLEVEL) {
@@ -1773,7 +1685,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         wt.ignore_merges = 1;
         pf.begin("wordlevel_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u, nullptr}, 0u, 1u, nullptr, nullptr, t->hot_slots);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, WordCache{nullptr, nullptr, nullptr, 0u, nullptr}, 0u, 1u, nullptr, nullptr);
         for (int c = 1; c < 4; ++c) launch_long_vocab(st, t->n_cu, wt, x_text, plan.v[c], w->w_rows.p, 1u, d_err, WordCache{nullptr, nullptr, nullptr, 0u, nullptr});      // words longer than 16 bytes
         pf.end();
     } else {
@@ -1790,7 +1702,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         set_publish();
         pf.begin("wordpiece_word_lookup");
         launch_lookup(st, lookup_grid(t), wt, x_text, n_x, x_len_dev, w->w_startmask.as<ull>(), endmask, w->w_wprefix.as<uint32_t>(),
-                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0), d_counters, t->hot_slots);
+                      w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0), d_counters);
         pf.end();
         pf.begin("wordpiece");
         launch_wordpiece(st, grid, true, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
@@ -1801,18 +1713,13 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             launch_word_cache_insert(st, grid, t->dt, x_text, plan.v[0], w->w_rows.p, wc);
             pf.end();
         }
-        if (wc.claims && !pub_inline) {
-            pf.begin("claims_publish");
-            launch_claims_publish(st, t->n_cu * 2, t->dt, x_text, plan, w->w_rows.p, wc);
-            pf.end();
-        }
     }
     if (matchmask)
         launch_apply_match_ids(st, w->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, w->w_startmask.as<ull>(),
                                w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
     pf.begin("compact");
     // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
-    launch_compact(st, t->cp_grid, t->cp_items, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
+    launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
                    w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>(), (size_t)t->cp_grid <= PHASE_WGS ? phases_of(1) : nullptr);
     pf.end();
@@ -1840,7 +1747,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.n_pretok = d_npretok;
         a.doc_pt = w->w_doc_pt.as<uint32_t>();
         a.chunk_lo = w->w_chunk_lo.as<uint32_t>();
-        a.chunk = (uint32_t)(256 * t->cp_items);
+        a.chunk = (uint32_t)COMPACT_CHUNK;
         a.n_docs = n_docs;
         a.x_doc_off = x_doc_off;
         a.doc_off = d_doc_off;
@@ -2059,22 +1966,10 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         upload_tables(t.get());
         if (prepare_long_kernel() != 0) throw HipError("hipFuncSetAttribute(dynamic LDS) failed");
         if (!primary) verify_direct_words(t.get());
-        if (const char* e = getenv("TKAMD_HOT_SLOTS")) t->hot_slots = atoi(e) == 2048 ? 2048 : 1024;
-        {
-            // (OFF by default: measured 0.49 ms against 0.285 for the three kernels on C2, profiles/r5b_ab_c2.txt, r5c -- DESIGN section 4)
-            const char* e = getenv("TKAMD_FUSED");
-            const HostModel& hm = t->hm;
-            t->lu_fused = (e && !strcmp(e, "1")) && t->hot_slots == 1024 && hm.pretok == PT_BYTELEVEL_GPT2 && hm.model == MODEL_BPE && !hm.char_bpe &&
-                          hm.at[0].size() == 0 && hm.at[1].size() == 0 && hm.norm == NORM_NONE && !hm.add_prefix_space;
-        }
         build_shortw_table(t.get());
-        // (the 2,048-slot shape keeps the short-word table's displacements in LDS -- SHORTW_BUCKETS of them, known at compile time; a
-        // vocabulary whose table has more buckets runs the default shape)
-        if (t->dt.shortw_bmask != (uint32_t)(SHORTW_BUCKETS - 1)) t->hot_slots = 1024;
         build_hot_table(t.get());
-        if (const char* e = getenv("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
-        if (const char* e = getenv("TKAMD_CP_ITEMS")) t->cp_items = atoi(e) == 8 ? 8 : (atoi(e) == 2 ? 2 : 4);
-        t->cp_grid = compact_grid(t->n_cu, t->cp_items);
+        if (const char* e = test_hook("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
+        t->cp_grid = compact_grid(t->n_cu);
         if (const char* e = test_hook("TKAMD_CP_GRID")) t->cp_grid = std::max(1, atoi(e));      // test hook: an over- / under-subscribed compaction
         t->devices.push_back(device);
     }

@@ -309,7 +309,7 @@ void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_do
 // validates the caller's CSR (ERR_BAD_OFFSETS) and writes the copy every later kernel reads (a trivially valid one if it is malformed)
 void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, int* err, int64_t* san);
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, int variant);
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total, const int64_t* len_dev = nullptr);      // len_dev: only the words of a text of that (device-side) length
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
@@ -317,19 +317,14 @@ void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, con
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid);
 void launch_doc_first_pretok(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes,
-                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo, int cp_items,
+                             const unsigned long long* startmask, const uint32_t* wprefix, const int64_t* n_pretok, uint32_t* doc_pt, uint32_t* chunk_lo,
                              const int* err = nullptr, int64_t* san = nullptr);      // san: doc_off is the caller's array, the kernel also writes its validated copy
 // whole-word lookup straight from the start (/ end) bitmasks: settles or queues every pre-token (kernels/lookup.hip)
 void launch_lookup(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev,
                    const unsigned long long* startmask, const unsigned long long* endmask, const uint32_t* wprefix, uint32_t* tok0,
                    const QueuePlan& plan, int* err, const unsigned long long* matchmask, const void* hot, const WordCache& wc,
-                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr, uint32_t* counters = nullptr, int hot_slots = 2048);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
-// the plain GPT-2 byte-level path: pre-tokenizer (from docmask), mask scan and lookup in ONE pass over the text; leaves startmask_out /
-// wprefix_out / *n_pretok_out for the stages behind it.  lb_state: 8 bytes per LOOKUP_TILE_BYTES of text, zero on entry.  grid <= 2 x CUs.
-void launch_lookup_fused(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, int64_t n_bytes, const unsigned long long* docmask,
-                         unsigned long long* startmask_out, uint32_t* wprefix_out, uint32_t* tok0, const QueuePlan& plan, int* err, const void* hot,
-                         const WordCache& wc, void* phases, uint32_t* counters, unsigned long long* lb_state, int64_t* n_pretok_out);
-// group: 16 / 64 = lanes per pre-token (DPP row / wavefront); 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols);
+                   uint32_t no_hits, uint32_t miss_is_unk, void* phases = nullptr, uint32_t* counters = nullptr);      // phases: [grid][8] u64, diagnostic instantiation (lookup.hip)
+// group: 64 = a wavefront per pre-token; 1 / 2 = one lane per pre-token, Word in registers (16 / 32 symbols: vocabularies whose new ids are not rank + c);
 // 5 / 6 = one lane per pre-token, keys in LDS (16 / 32 symbols; needs new_id = rank + c)
 // also (group 6 only): a second queue for the same launch
 void launch_bpe_merge(hipStream_t st, int grid, int group, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
@@ -413,17 +408,20 @@ void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const u
 // kernels cannot run)
 void launch_bpe_merge_long_only(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end,
                                 uint32_t* list_huge, uint32_t* n_huge);
-// single-pass compaction; `state` (8 bytes per chunk of 256 x cp_items pre-tokens) must be zero on entry; pt_tokoff may be null.
+// single-pass compaction; `state` (8 bytes per chunk of COMPACT_CHUNK pre-tokens) must be zero on entry; pt_tokoff may be null.
 // Any grid makes progress (a look-back that runs out of patience computes the missing totals itself: kernels/output.hip);
 // compact_grid(n_cu) -- what is resident at once -- is the one that never has to.
-void launch_claims_publish(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, const void* rows, const WordCache& wc);
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
-void launch_compact(hipStream_t st, int grid, int cp_items, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
+void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
                     int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr);
-int compact_grid(int n_cu, int cp_items);
+int compact_grid(int n_cu);
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
 void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n, unsigned long long* mask = nullptr, int64_t mask_words = 0, int grid = 1);      // n <= 256 zero bytes at p[*len_dev ..]; mask: its words below (*len_dev >> 6) + 3 zeroed too
-constexpr int COMPACT_CHUNK_MIN = 512;              // pre-tokens per compaction chunk: 256 lanes x cp_items (2, 4 or 8)
+constexpr int CP_ITEMS_PER_LANE = 4;                // pre-tokens per lane of k_compact (0.145 ms on C2 against 0.187 with eight; two: deleted in round 6, HISTORY.md)
+constexpr int COMPACT_CHUNK = 256 * CP_ITEMS_PER_LANE;   // pre-tokens per compaction chunk (and per tile of k_token_meta)
+// test hooks: environment switches the TESTS alone use (a compaction grid no launch would pick, a look-back without patience, ...), read
+// only when TKAMD_TEST_HOOKS=1 is set as well (capi.cpp)
+const char* test_hook(const char* name);
 
 }  // namespace tkamd

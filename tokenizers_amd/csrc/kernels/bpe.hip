@@ -186,7 +186,6 @@ __global__ __launch_bounds__(256) void k_bpe_merge(DevTables t, const uint8_t* _
         }
     }
 }
-template __global__ void k_bpe_merge<16>(DevTables, const uint8_t*, QView, uint4*, uint32_t*, uint32_t*);
 template __global__ void k_bpe_merge<64>(DevTables, const uint8_t*, QView, uint4*, uint32_t*, uint32_t*);
 
 // =================================================================================================

@@ -39,32 +39,15 @@ constexpr int LU_TILE_WORDS = 256;                       // mask words per tile
 constexpr int LU_TILE = LU_TILE_WORDS * 64;              // bytes of text per tile (16 KB)
 static_assert(LU_TILE == LOOKUP_TILE_BYTES, "the host sizes the sub-queues per tile (capi.cpp queue_sizes)");
 constexpr int LU_TEXT_SLACK = 64;                        // staged past the tile: a key may start at its last byte
-// Two shapes, picked per handle (TKAMD_HOT_SLOTS):
-//   HOT = 1024  (default) hot-word table of 1,024 slots (16.5 KB), 3,072 pre-tokens expanded per round (a tile of prose holds ~2,700):
-//               52 KB of LDS and <= 80 VGPRs, THREE workgroups per CU -- passes 2 and 3 wait for memory, and more wavefronts hide more
-//               of it; the short-word displacements are read from memory (a hot 8 KB array), pass 2 takes one step at a time
-//   HOT = 2048  2,048 slots (33 KB; 61 % of C2's pre-tokens hit instead of 50 %), 3,584 per round, the short-word displacements in LDS
-//               (8 KB), pass 2 two steps side by side: 80 KB of LDS, two workgroups per CU.  The default until the short-word table
-//               made a miss of the hot table cheap (profiles/r4m_*: 0.2279 against 0.2237 ms on C2, 0.265 against 0.246 on C3, level on C4
-//               and on out-of-distribution text)
-//   FUSED (round 5, HOT = 1024 only)  the pre-tokenizer, the mask scan and the lookup in ONE pass over the text: the tile's start mask is
-//               computed from the staged text (pretok_gpt2_core.hpp, the same host+device function k_pretok_gpt2_seq runs), its rank in the
-//               batch comes from a decoupled look-back over the tiles' counts (results.hip), and the tile's tok0 words are staged in LDS
-//               and written once, coalesced, when the look-back has resolved -- behind the tile's own work, so nobody waits for it.
-//               1,024 hot slots, 3,584 pre-tokens per round, 78 KB of LDS, <= 128 VGPRs: two workgroups per CU.  Only the lean GPT-2 path
-//               (no end masks, no added tokens, the text as the caller gave it).
-template <int HOT, bool FUSED = false> struct LuShape {
-    static_assert(HOT == 2048 || HOT == 1024, "shapes the launcher knows");
-    static_assert(!FUSED || HOT == 1024, "the fused shape has 1,024 hot slots");
-    static constexpr int POS_CAP = (HOT == 2048 || FUSED) ? 3584 : 3072;      // pre-tokens expanded per round (more in a tile: another round)
-    static constexpr bool DISP_LDS = HOT == 2048;                  // the 8 KB of short-word displacements in LDS (the other shapes have no room: they read them from memory)
-    static constexpr int WAVES_PER_SIMD = (HOT == 2048 || FUSED) ? 4 : 6;     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU
-    static constexpr int TEXT_SLACK = FUSED ? 128 : 64;            // staged past the tile: a key may start at its last byte (fused: and the pre-tokenizer decides 80 bytes beyond the tile)
-};
-constexpr int LU_LUT_COPIES = 1;                         // fused: replicas of the pre-tokenizer's 2 KB flag table (pretok_gpt2.hip)
-constexpr int LU_WINDOWS = 343;                          // fused: 48-byte windows of the pre-tokenizer per tile (343 x 48 = the tile + 80 bytes: where its last pre-token ends)
-constexpr int LU_MASK_WORDS = LU_TILE_WORDS + 2;         // fused: the tile's mask words + the two the windows spill into
-static_assert(LU_WINDOWS * G2W_MAIN >= LU_TILE + 64 && (LU_WINDOWS * G2W_MAIN + 63) / 64 <= LU_MASK_WORDS, "the windows cover the tile and one more pre-token start");
+// The shape: a hot-word table of 1,024 slots (16.5 KB), 3,072 pre-tokens expanded per round (a tile of prose holds ~2,700): 52 KB of LDS and
+// <= 80 VGPRs, THREE workgroups per CU -- passes 2 and 3 wait for memory, and more wavefronts hide more of it; the short-word
+// displacements are read from memory (a hot 8 KB array), pass 2 takes one step at a time.  (Rounds 3-5 also shipped a two-workgroup shape
+// with 2,048 hot slots and the displacements in LDS -- 0.2279 against 0.2237 ms on C2, slower on C3 -- and a FUSED shape with the
+// pre-tokenizer and the mask scan inside this kernel -- parity-green, 0.474 ms against 0.285 for the three kernels; both were deleted in
+// round 6, HISTORY.md has their measurements.)
+constexpr int HOT = HOT_SLOTS;                           // hot-word slots (tables.hpp)
+constexpr int LU_POS_CAP = 3072;                         // pre-tokens expanded per round (more in a tile: another round)
+constexpr int LU_WAVES_PER_SIMD = 6;                     // LU_NT / 64 wavefronts a workgroup, four SIMDs a CU: three workgroups (<= 80 VGPRs)
 constexpr uint32_t CLAIM_ADAPT_MIN = 768u;               // candidates a workgroup looks at before it judges the claims' yield (about two tiles of prose)
 
 struct LookupArgs {
@@ -92,56 +75,28 @@ struct LookupArgs {
     const CacheKey* cache_keys;      // word cache (kernels.hpp): words an earlier batch merged, or null
     unsigned long long* claims;      // in-batch word claims (below), or null
     uint32_t claim_mask;             // slots - 1
-    uint32_t fill;                   // pass 1 stores whole rows of tok0, a placeholder where it missed (lookup 0.2337 -> 0.2296 ms on C2; TKAMD_LU_FILL=0: hits only)
-    uint32_t claim_adapt;            // a workgroup that shares next to nothing stops claiming (TKAMD_CLAIM_ADAPT=0: never)
     uint32_t* counters;              // the batch's device counters (kernels.hpp CNT_*), or null
     unsigned long long* phases;      // PROF instantiation only (TKAMD_PHASES, tkamd_debug_phases): [workgroup][8] shader-clock ticks per phase
-    // FUSED only: the document-start mask the pre-tokenizer reads, the Unicode class table, what the tile leaves for the later stages
-    // (start mask and its per-word prefix counts: k_doc_first_pretok, offsets), the look-back state (8 bytes per tile, zeroed), the
-    // batch's pre-token count
-    const unsigned long long* docmask;
-    const uint16_t* uc1;
-    const uint8_t* uc2;
-    unsigned long long* startmask_out;
-    uint32_t* wprefix_out;
-    unsigned long long* lb_state;
-    int64_t* n_pretok_out;
-    uint32_t lb_patience;
 };
 // phases of k_lookup<.., true>, as wavefront 0 sees the workgroup's barriers: staging the tile (LDS stores, the last pre-token's end,
 // next tile's prefetch issued), expanding the mask bits into positions, pass 1, pass 2, pass 3 (+ waiting for the slowest wavefront);
 // slot 7: the whole kernel
-enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_PH_PASS3 = 4, LU_PH_PRETOK = 5, LU_PH_PLACE = 6, LU_PH_TOTAL = 7 };      // (5, 6: the fused shape's pre-tokenizer; its look-back + write-out)
+enum { LU_PH_STAGE = 0, LU_PH_EXPAND = 1, LU_PH_PASS1 = 2, LU_PH_PASS2 = 3, LU_PH_PASS3 = 4, LU_PH_TOTAL = 7 };
 
 // slot of a word in the word cache, from the bucket hash of the whole-word table
 __device__ __forceinline__ uint32_t cache_slot(uint32_t h1) { return (word_hash2(h1) >> 7) & ((1u << WORD_CACHE_BITS) - 1u); }
 
 // (claim_hash_long / claim_slot / CLAIM_MAX_LEN: bpe.hip, next to the publish helper the model kernels call)
-template <bool HAS_END, bool PROF = false, int HOT = 2048, bool FUSED = false>
-__global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void k_lookup(LookupArgs a) {      // (4 wavefronts / SIMD: <= 128 VGPRs; 6: <= 80)
-    static_assert(!FUSED || !HAS_END, "the fused pass is the GPT-2 pre-tokenizer's: no end masks");
-    using Shape = LuShape<HOT, FUSED>;
-    constexpr int LU_POS_CAP = Shape::POS_CAP;
-    constexpr int LU_TEXT_SLACK = Shape::TEXT_SLACK;
+template <bool HAS_END, bool PROF = false>
+__global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs a) {
     HIP_DYNAMIC_SHARED(__attribute__((aligned(16))) uint8_t, lu_lds)
     uint4* s_hot = (uint4*)lu_lds;                                              // [HOT]
     uint16_t* s_hdisp = (uint16_t*)(s_hot + HOT);                               // [HOT / 4]
-    // (fused: sixteen bytes in FRONT of the tile are staged too -- the pre-tokenizer's first window starts eight bytes before it)
-    uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4) + (FUSED ? 4 : 0);      // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
-    uint8_t* s_wdisp = (uint8_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [SHORTW_BUCKETS] if DISP_LDS, else nothing (16-byte aligned: copied sixteen bytes a lane)
-    uint16_t* s_pos = (uint16_t*)(s_wdisp + (Shape::DISP_LDS ? SHORTW_BUCKETS : 0));    // [LU_POS_CAP + 2] start of rank r, relative to the tile
+    uint32_t* s_text32 = (uint32_t*)(s_hdisp + HOT / 4);                        // [(LU_TILE + LU_TEXT_SLACK) / 4 + 4]
+    uint16_t* s_pos = (uint16_t*)(s_text32 + (LU_TILE + LU_TEXT_SLACK) / 4 + 4);    // [LU_POS_CAP + 2] start of rank r, relative to the tile
     uint16_t* s_miss = s_pos + LU_POS_CAP + 2;                                  // [LU_POS_CAP] ranks the hot table did not settle
     uint16_t* s_end = s_miss + LU_POS_CAP;                          // [LU_POS_CAP + 2] explicit ends (0xFFFF: beyond the tile)
-    // fused only: the tile's tok0 words (written once, when the tile's place in the batch is known), its start-mask words (+ the two the
-    // windows spill into), the pre-tokenizer's flag table; the document-mask words the windows read share the tok0 words' place (they
-    // are dead before pass 1 stores its first word)
-    uint32_t* s_tok = (uint32_t*)(s_end + LU_POS_CAP + 2);                      // [LU_POS_CAP]
-    unsigned long long* s_mask = (unsigned long long*)(s_tok + LU_POS_CAP);    // [LU_MASK_WORDS]
-    Gpt2Flags* s_lut = (Gpt2Flags*)(s_mask + LU_MASK_WORDS);                   // [LU_LUT_COPIES * 256]
-    unsigned long long* s_doc = (unsigned long long*)s_tok;                    // [LU_MASK_WORDS + 2] mask words w0 - 1 ..
-    static_assert(((LU_TILE + LU_TEXT_SLACK) + 16) % 16 == 0 && hot_table_bytes(HOT) % 16 == 0, "s_wdisp is copied sixteen bytes a lane");
-    static_assert((2 * (LU_POS_CAP + 2) + LU_POS_CAP) % 4 == 0, "s_tok is 8-byte aligned: s_doc shares its place");
-    __shared__ uint32_t s_wsum[LU_WAVES];                                       // fused: the wavefronts' start counts
+    static_assert(hot_table_bytes(HOT) % 16 == 0, "the text behind the hot table is 16-byte aligned");
     __shared__ uint4 s_kmask[17];                                                // byte masks of a key of 0..16 bytes
     __shared__ uint32_t s_n, s_pbase, s_last_end, s_nmiss, s_ncand, s_ncandl, s_nretry;
     // the claims' yield as this workgroup sees it: candidates it looked at, how many of them were another pre-token's word.  Text that
@@ -162,17 +117,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     if (tid == 0) { s_seen = 0u; s_shared = 0u; s_claims_on = a.claims ? 1u : 0u; }
     static_assert(hot_table_bytes(HOT) % 16 == 0, "whole 16-byte words");
     for (int i = tid; i < hot_table_bytes(HOT) / 16; i += LU_NT) s_hot[i] = a.hot[i];      // (slots and displacements: one buffer)
-    // (a large vocabulary's table has four times the buckets: the host runs it in the shape that leaves the displacements in memory --
-    // which of the two a shape reads is a compile-time fact, a pointer chosen at run time would be a flat one)
-    constexpr bool disp_lds = Shape::DISP_LDS;
-    if (disp_lds)
-        for (int i = tid; i < SHORTW_BUCKETS / 16; i += LU_NT) ((uint4*)s_wdisp)[i] = ((const uint4*)a.shortw_disp)[i];
-    const uint8_t* const wdisp = disp_lds ? (const uint8_t*)s_wdisp : a.shortw_disp;
-    if (FUSED && tid < 256) {
-        const Gpt2Flags f = gpt2_byte_flags((uint32_t)tid);
-#pragma unroll
-        for (int c = 0; c < LU_LUT_COPIES; ++c) s_lut[c * 256 + tid] = f;
-    }
+    const uint8_t* const wdisp = a.shortw_disp;                    // the short-word displacements: a hot 8 KB array in memory
     if (tid < 17) {
         const uint32_t l = (uint32_t)tid;
         auto m = [&](uint32_t lo) -> uint32_t { return l >= lo + 4u ? 0xFFFFFFFFu : (l > lo ? ((1u << (8u * (l - lo))) - 1u) : 0u); };
@@ -189,34 +134,30 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     // What a tile needs from memory -- its text, its mask words with their prefix counts, and the 64 mask words behind it (where its
     // last pre-token ends) -- is loaded into registers one tile AHEAD: the loads of tile k+1 are issued before the lookup phase of
     // tile k and have long arrived when tile k+1 starts, so no phase of a tile begins with a memory round trip.
-    constexpr int LU_SLACK_CHUNKS = LU_TEXT_SLACK / 16;              // (fused: lanes 0..7 load the slack, lane 8 the sixteen bytes in front of the tile)
+    constexpr int LU_SLACK_CHUNKS = LU_TEXT_SLACK / 16;
     static_assert((LU_TILE + LU_TEXT_SLACK) / 16 == 2 * LU_NT + LU_SLACK_CHUNKS, "two 16-byte text chunks per lane (+ the slack chunks of the first lanes)");
     const int64_t n_words_host = (a.n_bytes_host >> 6) + 1;          // words of the document / start masks
     static_assert(LU_NT == 2 * LU_TILE_WORDS, "two lanes per mask word");
-    Unaligned16 pf_t0{0u, 0u, 0u, 0u}, pf_t1{0u, 0u, 0u, 0u}, pf_ts{0u, 0u, 0u, 0u};
     unsigned long long pf_ms = 0ull, pf_me = 0ull, pf_scan = 0ull;
     uint32_t pf_wp = 0u, pf_first = 0u;
-    // (the three-workgroups-per-CU shape has 80 VGPRs: it keeps the masks a tile ahead but loads the text when the tile starts -- the
-    // other two workgroups of the CU cover that round trip)
-    constexpr bool PF_TEXT = HOT == 2048 || FUSED;
-    static_assert(!FUSED || PF_TEXT, "the fused pre-tokenizer reads the staged tile: the text is in LDS before step 2");
+    // (80 VGPRs: the masks are kept a tile ahead, the text is loaded when the tile starts -- the other two workgroups of the CU cover that
+    // round trip)
     auto load_text = [&](int64_t tile, Unaligned16& x0, Unaligned16& x1, Unaligned16& xs) {
         x0 = x1 = xs = Unaligned16{0u, 0u, 0u, 0u};
         if (tile >= n_tiles) return;
         const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
         const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT;
-        const int64_t gs = (FUSED && tid == LU_SLACK_CHUNKS) ? t0 - 16 : t0 + 16 * (int64_t)(2 * LU_NT + tid);
+        const int64_t gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
         // (the tile's text, its masks and the tok0 words are read / written once: non-temporal accesses, kernels.hip -- level here, 0.2279
         // against 0.229 ms, 3 % in the compaction; profiles/r4m_ab_c2.txt)
         if (g0 + 16 <= readable) x0 = load_nt16(a.text + g0);
         if (g1 + 16 <= readable) x1 = load_nt16(a.text + g1);
-        if (tid < LU_SLACK_CHUNKS + (FUSED ? 1 : 0) && gs >= 0 && gs + 16 <= readable) xs = load_nt16(a.text + gs);
+        if (tid < LU_SLACK_CHUNKS && gs + 16 <= readable) xs = load_nt16(a.text + gs);
     };
     auto prefetch = [&](int64_t tile) {
-        if (PF_TEXT) load_text(tile, pf_t0, pf_t1, pf_ts);
         pf_ms = pf_me = pf_scan = 0ull;
         pf_wp = pf_first = 0u;
-        if (FUSED || tile >= n_tiles) return;                        // (fused: the masks are this kernel's own work)
+        if (tile >= n_tiles) return;
         const int64_t w0 = tile * LU_TILE_WORDS;
         const int64_t w = w0 + hword;
         if (w < total_words) { pf_ms = load_nt(a.startmask + w); pf_wp = load_nt(a.wprefix + w); }
@@ -233,95 +174,19 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
         const int64_t t0 = w0 << 6;                                  // first byte of the tile
         __syncthreads();                                             // previous tile's LDS use is over
         tick(LU_PH_PASS3);
-        if (tid == 0 && s_claims_on && a.claim_adapt && s_seen >= CLAIM_ADAPT_MIN && s_shared * 8u < s_seen) s_claims_on = 0u;   // (read behind the next barrier)
-        // ---- 1. text tile -> LDS (prefetched registers; or loaded now and dropped into LDS behind the mask work below) ----
-        Unaligned16 tx0 = pf_t0, tx1 = pf_t1, txs = pf_ts;
-        if (!PF_TEXT) load_text(tile, tx0, tx1, txs);
+        if (tid == 0 && s_claims_on && s_seen >= CLAIM_ADAPT_MIN && s_shared * 8u < s_seen) s_claims_on = 0u;   // (read behind the next barrier)
+        // ---- 1. text tile -> LDS (loaded now, dropped into LDS behind the mask work below) ----
+        Unaligned16 tx0, tx1, txs;
+        load_text(tile, tx0, tx1, txs);
         auto stage_text = [&]() {
             ((uint4*)s_text32)[tid] = make_uint4(tx0.a, tx0.b, tx0.c, tx0.d);
             ((uint4*)s_text32)[tid + LU_NT] = make_uint4(tx1.a, tx1.b, tx1.c, tx1.d);
             if (tid < LU_SLACK_CHUNKS) ((uint4*)s_text32)[2 * LU_NT + tid] = make_uint4(txs.a, txs.b, txs.c, txs.d);
-            if (FUSED && tid == LU_SLACK_CHUNKS) ((uint4*)s_text32)[-1] = make_uint4(txs.a, txs.b, txs.c, txs.d);
         };
-        if (PF_TEXT) stage_text();
         // ---- 2. the tile's mask words: local rank of each word's first start ----
-        unsigned long long ms = pf_ms;
-        const unsigned long long me = pf_me;
+        const unsigned long long ms = pf_ms, me = pf_me;
         uint32_t rbase = 0xFFFFFFFFu;
-        if (FUSED) {
-            // ---- 2f. the pre-tokenizer on the staged tile.  Window v (lane v < LU_WINDOWS) decides the 48 bytes [48 v, 48 v + 48) of the
-            // tile from the 64 staged bytes around them (pretok_gpt2_core.hpp: the function k_pretok_gpt2_seq runs, fed from LDS); four
-            // lanes' 48-bit results are three mask words.  The windows reach 80 bytes beyond the tile: where its last pre-token ends.
-            if (tid < LU_MASK_WORDS + 2) {
-                const int64_t wi = w0 - 1 + tid;
-                s_doc[tid] = (wi >= 0 && wi < n_words_host) ? a.docmask[wi] : 0ull;
-            }
-            __syncthreads();                                         // the staged text and the document words are in LDS
-            tick(LU_PH_STAGE);
-            unsigned long long out = 0ull;
-            if (tid < LU_WINDOWS && t0 + (int64_t)G2W_MAIN * tid < n_bytes) {
-                const int64_t base = t0 + (int64_t)G2W_MAIN * tid - G2W_HALO;      // the text's byte under window byte 0
-                uint32_t w[16];
-                const uint2* const src = (const uint2*)(s_text32 + 12 * tid - 2);  // (eight bytes in front of the window's own: 8-byte aligned)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) { const uint2 v = src[k]; w[2 * k] = v.x; w[2 * k + 1] = v.y; }
-                Gpt2Window m;
-                const int vlo = base < 0 ? (int)-base : 0;
-                const int64_t rem = n_bytes - base;
-                m.V = (rem >= 64 ? ~0ull : ((1ull << rem) - 1ull)) & (~0ull << vlo);
-                const uint32_t rel = (uint32_t)(G2W_MAIN * tid) + 64u - (uint32_t)G2W_HALO, sh = rel & 63u;      // the window's first bit in s_doc (which starts one word before the tile)
-                m.D = s_doc[rel >> 6] >> sh;
-                if (sh) m.D |= s_doc[(rel >> 6) + 1u] << (64u - sh);
-                m.D &= m.V;
-                gpt2_window_flags(w, s_lut + (tid & (LU_LUT_COPIES - 1)) * 256, m);
-                // (the bytes the algebra looks at again -- behind an apostrophe, a multi-byte char -- come from the STAGED tile: a global load
-                // there was a round trip per wavefront and loop turn, with two workgroups a CU to hide it: 0.15 ms of the first version's 0.49)
-                out = (gpt2_window_starts(m, (const uint8_t*)s_text32, (int64_t)G2W_MAIN * tid - G2W_HALO, a.uc1, a.uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
-            }
-            {
-                const unsigned long long nxt = __shfl_down(out, 1, 64);
-                const int q = tid & 3, word = 3 * (tid >> 2) + q;
-                if (q < 3 && word < LU_MASK_WORDS) s_mask[word] = (out >> (16 * q)) | (nxt << (G2W_MAIN - 16 * q));
-            }
-            __syncthreads();                                         // (s_doc is dead: its place is s_tok's from here on)
-            // ranks inside the tile: the lane pair of word w needs the starts in the words before it
-            ms = s_mask[hword];
-            const uint32_t pc = half ? 0u : (uint32_t)__popcll(ms);
-            const uint32_t incl = wave_incl_scan(pc);
-            if (lane == 63) s_wsum[wave] = incl;
-            // end of the tile's LAST pre-token: the first start behind the tile -- in the two spill words, or (a pre-token of more than 80
-            // bytes across the tile's edge) wherever wavefront 0 finds it, pre-tokenizing on from global memory, 64 windows a step
-            if (wave == 0) {
-                const unsigned long long m0 = s_mask[LU_TILE_WORDS], m1 = s_mask[LU_TILE_WORDS + 1];
-                const int64_t edge = t0 + LU_TILE;
-                int64_t found = n_bytes;
-                if (m0) found = edge + (__ffsll(m0) - 1);
-                else if (m1) found = edge + 64 + (__ffsll(m1) - 1);
-                else {
-                    for (int64_t p0 = t0 + (int64_t)LU_WINDOWS * G2W_MAIN; p0 < n_bytes; p0 += 64 * G2W_MAIN) {
-                        const unsigned long long o = gpt2_starts_at(a.text, p0 + (int64_t)G2W_MAIN * lane, n_bytes, n_words_host, (const uint64_t*)a.docmask, s_lut, a.uc1, a.uc2);
-                        const uint64_t any = __ballot(o != 0ull);
-                        if (any) {
-                            const int l = __ffsll((unsigned long long)any) - 1;
-                            const unsigned long long oo = ((unsigned long long)(uint32_t)__shfl((int)(o >> 32), l, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)o, l, 64);
-                            found = p0 + (int64_t)G2W_MAIN * l + (__ffsll(oo) - 1);
-                            break;
-                        }
-                    }
-                }
-                if (lane == 0) s_last_end = (uint32_t)min(found, n_bytes);
-            }
-            __syncthreads();
-            uint32_t before = 0u, total = 0u;
-#pragma unroll
-            for (int q = 0; q < LU_WAVES; ++q) { const uint32_t c = s_wsum[q]; before += q < wave ? c : 0u; total += c; }
-            rbase = before + incl - (uint32_t)__popcll(ms);
-            tick(LU_PH_PRETOK);
-            if (tid == 0) {
-                s_n = total;
-                lb_publish(a.lb_state, tile, (unsigned long long)total);      // (early: the tiles behind this one look back over it)
-            }
-        } else {
+        {
             const int64_t w = w0 + hword;
             if (w < total_words) rbase = pf_wp - pf_first;
             if (tid == 0) s_pbase = pf_first;
@@ -329,7 +194,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
         }
         // end of the tile's LAST pre-token when it lies beyond the tile: the next start (or end bit) after the tile -- almost always in
         // the 64 prefetched words behind it; otherwise wavefront 0 walks the mask on
-        if (!FUSED && wave == 0) {
+        if (wave == 0) {
             const unsigned long long* mk = has_end ? a.endmask : a.startmask;
             const int64_t lim = has_end ? end_words : total_words;
             int64_t w = w0 + LU_TILE_WORDS;
@@ -348,50 +213,14 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
             }
             if (lane == 0) s_last_end = found;
         }
-        if (!PF_TEXT) stage_text();
+        stage_text();
         prefetch(tile + gridDim.x);                                   // the next tile's loads fly while this one is looked up
         __syncthreads();
         tick(LU_PH_STAGE);
         const bool claims_now = s_claims_on != 0u;                   // (workgroup-uniform for the whole tile)
         const uint32_t n = s_n;                                      // pre-tokens starting in this tile
-        uint32_t pbase = FUSED ? 0u : s_pbase;                       // global rank of the first one (fused: known when the look-back has resolved, behind round 0)
+        const uint32_t pbase = s_pbase;                              // global rank of the first one
         const uint32_t last_rel = s_last_end - (uint32_t)t0;         // (positions below are relative to the tile)
-        // (fused) The tile's place in the batch -- the pre-tokens in front of it -- is the sum of the counts the tiles before it have
-        // published since the top of THEIR work (results.hip: a count that is still missing after `patience` polls is computed here, by
-        // pre-tokenizing that tile from global memory: finite work, whoever waits).  Called by the whole workgroup behind round 0 of the
-        // tile -- by then the look-back finds everything published -- and leaves what the later stages read: the start mask and the
-        // number of starts in front of every word of it, and (the last tile) the batch's pre-token count.
-        auto place_tile = [&]() {
-            if (wave == 0) {
-                auto tile_count = [&](int64_t hc) -> unsigned long long {
-                    const int64_t tb = hc * LU_TILE;
-                    uint32_t c = 0u;
-#pragma unroll 1
-                    for (int v0 = 0; v0 < LU_TILE / G2W_MAIN + 1; v0 += 64) {
-                        const int vv = v0 + lane;                                // window vv decides bytes [48 vv, 48 vv + 48) of tile hc
-                        if (vv * G2W_MAIN < LU_TILE) {
-                            unsigned long long o = gpt2_starts_at(a.text, tb + (int64_t)G2W_MAIN * vv, n_bytes, n_words_host, (const uint64_t*)a.docmask, s_lut, a.uc1, a.uc2);
-                            const int keep = LU_TILE - vv * G2W_MAIN;            // (the last window straddles the tile's edge)
-                            if (keep < G2W_MAIN) o &= (1ull << keep) - 1ull;
-                            c += (uint32_t)__popcll(o);
-                        }
-                    }
-#pragma unroll
-                    for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
-                    return (unsigned long long)c;
-                };
-                const unsigned long long r = lb_resolve(a.lb_state, tile, (unsigned long long)n, a.lb_patience, tile_count);
-                if (lane == 0) s_pbase = (uint32_t)r;
-            }
-            __syncthreads();
-            pbase = s_pbase;
-            if (!half && w0 + hword < n_words_host) {
-                a.startmask_out[w0 + hword] = ms;
-                a.wprefix_out[w0 + hword] = pbase + rbase;
-            }
-            if (tid == 0 && tile == n_tiles - 1) *a.n_pretok_out = (int64_t)pbase + (int64_t)n;
-        };
-        if (FUSED && n == 0u) place_tile();                          // (a tile inside one long pre-token: no round runs)
         for (uint32_t rb = 0; rb < n; rb += LU_POS_CAP) {
             if (rb) __syncthreads();                                 // previous round has read s_pos / s_end
             const uint32_t cnt = min((uint32_t)LU_POS_CAP, n - rb);
@@ -447,7 +276,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 const uint32_t diff = (h.x ^ k0) | (h.y ^ k1) | (h.z ^ k2) | ((h.w >> 24) ^ len);
                 bool hit = v && diff == 0u && len != 0u && hits_on;
                 bool miss = v && !hit;
-                if (!FUSED && a.matchmask) {                                        // wavefront-uniform: tokenizers with added tokens only
+                if (a.matchmask) {                                                  // wavefront-uniform: tokenizers with added tokens only
                     const uint32_t s_abs = (uint32_t)t0 + s_rel;
                     if (v && len && ((a.matchmask[s_abs >> 6] >> (s_abs & 63u)) & 1ull)) {       // an added-token match: its id is patched in later
                         a.tok0[pbase + rb + rel] = 0u;
@@ -455,10 +284,9 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                         miss = false;
                     }
                 }
-                // (a.fill: the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them)
-                if (FUSED) {
-                    if (hit) s_tok[rel] = TOK_ONE | (h.w & TOK_ID_MASK);             // (a miss leaves its word to pass 2 / 3; the tile's words go out together)
-                } else if (hit || (a.fill && miss)) {
+                // (the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them:
+                // 0.2337 -> 0.2296 ms on C2 against storing the hits alone)
+                if (hit || miss) {
                     const uint32_t w0 = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
                     store_nt(a.tok0 + pbase + rb + rel, w0);
                 }
@@ -499,7 +327,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                         }
                     }
                 }
-                if (v) { if (FUSED) s_tok[rel] = out; else store_nt(a.tok0 + pbase + rb + rel, out); }
+                if (v) store_nt(a.tok0 + pbase + rb + rel, out);
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
@@ -683,17 +511,11 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                 }
                 finish(v && !cand, pend && !cand, rel, s_rel, len, out, holds);     // (a listed candidate is finished by pass 3)
             };
-            // two steps side by side: both probes in flight together (a tile of prose is two steps a wavefront; the 80-register shape
-            // has no room for the second step's state).  Against one step at a time, same session (profiles/r4m_ab_*.txt): level on C2,
-            // 0.367 against 0.390 ms on out-of-distribution text, 0.246 against 0.253 ms on C4.
-            constexpr bool TWO = HOT == 2048;
-            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (TWO ? 2u : 1u) * (uint32_t)LU_NT) {
-                P2 x, y;
-                const bool two = TWO && m0 + (uint32_t)LU_NT < n_miss;              // wavefront-uniform
+            // (one step at a time: the 80-register shape has no room for a second step's state side by side)
+            for (uint32_t m0 = (uint32_t)wave * 64u; m0 < n_miss; m0 += (uint32_t)LU_NT) {
+                P2 x;
                 p2_key(m0, x);
-                if (two) p2_key(m0 + (uint32_t)LU_NT, y);
                 p2_done(x);
-                if (two) p2_done(y);
             }
             // ---- 5. pass 3: the candidates, packed 64 to a step ----
             // (Round 4 parked a wavefront's step of candidates in registers and advanced its chain -- slot, compare-and-swap, the
@@ -748,14 +570,6 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
                     claim_step(v, s_retry[v ? c0 + lane : c0], false, true);
                 }
             }
-            if (FUSED) {
-                // ---- 6. the round's tok0 words, once and whole (the tile's place in the batch: place_tile above, behind round 0) ----
-                __syncthreads();
-                tick(claims_now ? LU_PH_PASS3 : LU_PH_PASS2);
-                if (rb == 0u) place_tile();
-                for (uint32_t i = (uint32_t)tid; i < cnt; i += (uint32_t)LU_NT) store_nt(a.tok0 + pbase + rb + i, s_tok[i]);
-                tick(LU_PH_PLACE);
-            }
         }
     }
     // the fill of this workgroup's sub-queues (the counters were zeroed by the host; a workgroup without tiles leaves them 0)
@@ -763,7 +577,7 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
     tick(LU_PH_PASS3);
     if (PROF && tid == 0 && a.phases) {
         unsigned long long* const o = a.phases + (size_t)blockIdx.x * 8;
-        for (int k = 0; k < 7; ++k) o[k] += ph_acc[k];
+        for (int k = 0; k < 5; ++k) o[k] += ph_acc[k];
         o[LU_PH_TOTAL] += ph_t - ph_t0;
     }
     if (tid == 0 && a.claims && a.counters) {                      // the batch's totals: what the host's pause rule reads (capi.cpp read_scalars)
@@ -806,34 +620,10 @@ __global__ __launch_bounds__(LU_NT, (LuShape<HOT, FUSED>::WAVES_PER_SIMD)) void 
 //   * reading the slot alongside the table probe (more device-scope loads, no shorter chain in practice) was slower than reading it
 //     after the probe has missed (0.286 against 0.251 ms).
 // =================================================================================================
-// =================================================================================================
-// K_claims_publish (TKAMD_PUBLISH=kernel; by default the model kernels publish their rows themselves, claim_publish_item in bpe.hip):
-// after the model kernels, the result row of every queued pre-token that holds the claim of its slot is copied to the slot's row, where
-// the compaction finds it for the word's other occurrences.  The two halves of the grid take the two queue classes.
-// =================================================================================================
-__global__ __launch_bounds__(256) void k_claims_publish(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, const uint4* __restrict__ rows,
-                                                        uint32_t claim_mask, uint4* __restrict__ crows, uint32_t* __restrict__ cpos) {
-    __shared__ uint32_t s_qpre[NSQ + 1];
-    const uint32_t half = gridDim.x >> 1;
-    const QView v = blockIdx.x >= half ? v1 : v0;
-    const uint32_t n = qview_prefix(v, s_qpre);
-    for (uint32_t item = (blockIdx.x % half) * 256 + threadIdx.x; item < n; item += half * 256) {
-        const uint32_t qpos = qview_pos(s_qpre, v.sq_cap, item);
-        const QItem it = v.q[qpos];
-        claim_publish_item(text, t.word_seed, it.s, it.len, rows[v.row_base + qpos], claim_mask, crows, cpos);
-    }
+constexpr int lookup_lds_bytes() {      // (the end array's place holds the candidate list when there are no end masks)
+    return hot_table_bytes(HOT) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * (LU_POS_CAP + 2) * 2 + LU_POS_CAP * 2;
 }
-
-constexpr int lookup_lds_bytes(int hot) {      // (the end array's place holds the candidate list when there are no end masks)
-    return hot_table_bytes(hot) + (LU_TILE + LU_TEXT_SLACK) + 16 + 2 * ((hot == 2048 ? 3584 : 3072) + 2) * 2 + (hot == 2048 ? 3584 : 3072) * 2 + (hot == 2048 ? SHORTW_BUCKETS : 0);
-}
-static_assert(lookup_lds_bytes(2048) + 1024 <= 81920, "two workgroups of the 2,048-slot shape share a CU's 160 KB (1 KB: the kernel's static LDS)");
-// the fused shape: 16 bytes in front of the tile, 128 behind it, the staged tok0 words, the tile's mask words, the pre-tokenizer's flag table
-constexpr int lookup_fused_lds_bytes() {
-    return hot_table_bytes(1024) + 16 + (LU_TILE + 128) + 16 + 2 * (3584 + 2) * 2 + 3584 * 2 + 3584 * 4 + LU_MASK_WORDS * 8 + LU_LUT_COPIES * 256 * 8;
-}
-static_assert(lookup_fused_lds_bytes() + 1024 <= 81920, "two workgroups of the fused shape share a CU's 160 KB");
-static_assert((LU_MASK_WORDS + 2) * 8 <= 3584 * 4, "the document-mask words fit the tok0 words' place"); 
+static_assert(3 * (lookup_lds_bytes() + 1024) <= 163840, "three workgroups share a CU's 160 KB (1 KB: the kernel's static LDS)");
 
 // =================================================================================================
 // K_word_cache_insert: after the merge kernels, every queued pre-token of <= 16 bytes whose result fits a row (<= 4 tokens) is

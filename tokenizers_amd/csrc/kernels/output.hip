@@ -382,23 +382,15 @@ __device__ __forceinline__ uint32_t norig_end(const MetaArgs& a, uint32_t k) {
 
 // offsets / word id of ONE token: token j of pre-token p (document d; [s, e) in x space; its tokens are o .. o + c), covering
 // [s + rel, s + rel_end) of the x text.  Everything of into_encoding / process_offsets that is per token.
-// cont: bit b = byte s + b of the x text is a continuation byte, for the bytes the caller already holds (have_cont: the whole pre-token,
-// at most sixteen bytes) -- the snapping then reads no text.
 __device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int64_t d, uint32_t s, uint32_t e, bool is_match, uint32_t o, uint32_t j,
-                                               uint32_t rel, uint32_t rel_end, uint32_t xdoc, uint32_t odoc, uint32_t word,
-                                               uint32_t cont = 0u, bool have_cont = false) {
+                                               uint32_t rel, uint32_t rel_end, uint32_t xdoc, uint32_t odoc, uint32_t word) {
     if (a.want_words) a.word_ids[o + j] = word;
     if (!a.want_offsets) return;
     uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
     uint32_t bs = ts, be = te;
     if (a.snap_chars && !is_match) {                      // snap to char boundaries inside the pre-token (its own edges are char boundaries)
-        if (have_cont) {
-            while (bs > s && ((cont >> (bs - s)) & 1u)) --bs;
-            while (be < e && ((cont >> (be - s)) & 1u)) ++be;
-        } else {
-            while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
-            while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
-        }
+        while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
+        while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
     }
     // x space -> original text
     uint32_t os, oe;
@@ -514,23 +506,22 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
 
 // Round 6's shape.  A workgroup takes tiles of TM_TILE consecutive pre-tokens: their token offsets, starts and ends go to LDS with coalesced
 // loads; the documents that start inside the tile are counted into its pre-tokens (the compaction's chunk_lo names the first of them: no
-// search) and a scan turns the counts into every pre-token's document.  Then a lane takes four pre-tokens, 256 apart (neighbouring lanes
-// hold neighbouring pre-tokens, whose tokens are neighbours in the output arrays):
-//   * a pre-token of SEVERAL tokens (one in eight on prose) goes on the tile's list, and what its tokens need from memory is fetched for all
-//     four of the lane's pre-tokens stage by stage -- whose token ends it reads (its own, or the claimant's of its word: tok0, then
-//     claim_pos), then its first four token ends and its first sixteen bytes (as a mask of continuation bytes: what the snapping asks) --
-//     into LDS: three round trips a TILE, where a token of such a word had cost four of its own;
-//   * a pre-token of ONE token has the pre-token's own edges as its offsets -- no token ends, no char to snap to -- and is written from a
-//     loop that has the next pre-token's document loads in flight;
+// search) and a scan turns the counts into every pre-token's document.  Then
+//   * a lane takes four pre-tokens, 256 apart (neighbouring lanes hold neighbouring pre-tokens, whose tokens are neighbours in the output
+//     arrays).  Seven pre-tokens in eight are ONE token: its offsets are the pre-token's own edges -- no token ends to fetch, no char to
+//     snap to -- and leave at once.  A pre-token of several tokens only resolves whose token ends it reads (its own, or the claimant's
+//     of its word: tok0 -> claim_pos) and goes on the tile's list;
 //   * the tokens of the listed pre-tokens are dealt to the lanes one each (a scan over the list's counts, a binary search over at most a
-//     few hundred bases in LDS) and, the usual case, written from LDS alone; a longer word or a longer list reads memory as before.
+//     few hundred bases in LDS): the two dependent round trips a token of theirs costs -- its ends, then the bytes at a cut inside a
+//     char -- are paid once per 256 tokens, not once per token of the longest word a wavefront holds.
 // (Rounds 1-5: a lane per pre-token with its tokens in a loop and a twenty-step binary search over doc_pt each: 1.14 ms on C2's
 // 22.7 M tokens.  A lane per token, every token through the whole chain: 0.52 ms.  Four pre-tokens a lane with their tokens in a loop
-// again: 0.73 ms -- a wavefront ran the loop as often as its longest word has tokens.  The list without the staged fetches: 0.40 ms,
-// fourteen dependent round trips a tile at ~2 us each under this kernel's 10 M random lines.  profiles/r6[a-d]_c2_bench.json.)
+// again: 0.73 ms -- a wavefront ran the loop as often as its longest word has tokens.  This shape: 0.40 ms; the listed pre-tokens' ends and
+// bytes fetched stage by stage into LDS first: 0.48 ms.  profiles/r6[a-e]_c2_bench.json.  What bounds it: 9.5 M L2 misses a launch
+// (profiles/r6d_c2_sq_token_meta.json), seven million of them random 128-byte lines -- the token ends of the multi-token pre-tokens live
+// in a sparse array indexed by byte position (tmp_end), their claimants behind tok0 -> claim_pos, the bytes at a cut in the text.)
 constexpr int TM_TILE = 1024;
-constexpr uint32_t TM_FAST = 256u;                        // listed pre-tokens whose ends and bytes are staged in LDS (a tile of prose lists ~130)
-__global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {      // (five wavefronts a SIMD: what 31 KB of LDS a workgroup allow)
+__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
     __shared__ uint32_t s_tokoff[TM_TILE + 1];
     __shared__ uint32_t s_start[TM_TILE + 1];
     __shared__ uint32_t s_end[TM_TILE];
@@ -538,19 +529,15 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {      // (fi
     __shared__ uint32_t s_mse[TM_TILE];                   // listed pre-token k: where its token ends are (tmp_end + this)
     __shared__ uint32_t s_mbase[TM_TILE + 1];             // ... its token count, then (scanned) its first token among the list's
     __shared__ uint16_t s_mlist[TM_TILE];                 // ... its index in the tile
-    __shared__ uint4 s_mends[TM_FAST];                    // ... its first four token ends
-    __shared__ uint16_t s_mcont[TM_FAST];                 // ... which of its first sixteen bytes are continuation bytes
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_before, s_nm;
     const int64_t P = *a.n_pretok;
     const uint32_t n_tok = (uint32_t)*a.n_tok;
     const int tid = (int)threadIdx.x;
     const int64_t n_tiles = (P + TM_TILE - 1) / TM_TILE;
-    const bool claims = a.claim_pos && a.tmp_end;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * TM_TILE;
         const int np = (int)min((int64_t)TM_TILE, P - base);
-        const int64_t d0 = (int64_t)a.chunk_lo[base / a.chunk];      // (asked for first: the documents below wait for it, not for the tile's loads as well)
         __syncthreads();                                  // (the previous tile's readers are done)
         for (int i = tid; i <= np; i += 256) {
             const int64_t p = base + i;
@@ -562,43 +549,11 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {      // (fi
         __syncthreads();
         // documents from the first one of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with doc_pt[d] >= c * chunk):
         // the ones in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
+        const int64_t d0 = (int64_t)a.chunk_lo[base / a.chunk];
         for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
             const int64_t r = (int64_t)a.doc_pt[d] - base;
             if (r >= np) break;
             atomicAdd(r < 0 ? &s_before : &s_doc[r], 1u);
-        }
-        // ---- the lane's pre-tokens of several tokens: listed; stage 1 of their fetches (independent of the documents)
-        uint32_t kq[4], xq[4];                            // list position (~0u: not listed), then tok0 / the place of the token ends
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 256 * q;
-            kq[q] = ~0u;
-            xq[q] = 0u;
-            if (i >= np) continue;
-            const uint32_t c = s_tokoff[i + 1] - s_tokoff[i];
-            if (c <= 1u) continue;
-            const uint32_t k = atomicAdd(&s_nm, 1u);
-            kq[q] = k;
-            s_mlist[k] = (uint16_t)i;
-            s_mbase[k] = c;
-            if (claims) xq[q] = a.tok0[base + i];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                     // stage 2: whose token ends -- the pre-token's own, or the claimant's of its word
-            if (kq[q] == ~0u) continue;
-            uint32_t se = s_start[tid + 256 * q];
-            if (claims && (xq[q] & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[xq[q] & TOK_REF_MASK];
-            xq[q] = se;
-            s_mse[kq[q]] = se;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                     // stage 3: four token ends and sixteen bytes each, into LDS
-            if (kq[q] >= TM_FAST || !a.tmp_end) continue;
-            const Unaligned16 en = *(const Unaligned16*)(a.tmp_end + xq[q]);
-            const Unaligned16 tx = *(const Unaligned16*)(a.x_text + s_start[tid + 256 * q]);
-            auto four = [](uint32_t w) -> uint32_t { return ((((w >> 7) & (~w >> 6) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; };
-            s_mends[kq[q]] = make_uint4(en.a, en.b, en.c, en.d);
-            s_mcont[kq[q]] = (uint16_t)(four(tx.a) | (four(tx.b) << 4) | (four(tx.c) << 8) | (four(tx.d) << 12));
         }
         __syncthreads();
         {   // inclusive scan over the tile, four pre-tokens a lane: the document of pre-token i = the last d with doc_pt[d] <= base + i
@@ -611,32 +566,34 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {      // (fi
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
         __syncthreads();
-        // ---- the lane's pre-tokens of ONE token, the next one's document loads in flight while this one is written
-        struct Doc { uint32_t word, xdoc, odoc; int64_t d; bool one; };
-        auto fetch = [&](int q) -> Doc {
-            Doc x;
-            x.one = false;
-            const int i = tid + 256 * q;
-            if (q >= 4 || i >= np || s_tokoff[i + 1] - s_tokoff[i] != 1u) return x;
-            x.one = true;
-            x.d = (int64_t)s_doc[i];
-            x.word = a.word_of_doc ? a.word_of_doc[x.d] : (uint32_t)(base + i - (int64_t)a.doc_pt[x.d]);
-            x.xdoc = (uint32_t)a.x_doc_off[x.d];
-            x.odoc = (uint32_t)a.doc_off[x.d];
-            return x;
-        };
-        Doc cur = fetch(0);
+        // ---- a lane's four pre-tokens: one token -> written here; several -> listed
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
-            const Doc nxt = fetch(q + 1);
-            if (cur.one) {
-                const int i = tid + 256 * q;
-                const uint32_t s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
-                const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-                meta_one_token(a, base + i, cur.d, s, e, is_match, s_tokoff[i], 0u, 0u, e - s, cur.xdoc, cur.odoc, cur.word);
+            const int i = tid + 256 * q;
+            if (i >= np) break;
+            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o;
+            if (!c) continue;
+            const int64_t p = base + i;
+            const uint32_t s = s_start[i];
+            if (c > 1u) {
+                uint32_t se = s;                          // whose token ends: the pre-token's own, or the claimant's of its word
+                if (a.claim_pos && a.tmp_end) {
+                    const uint32_t t0 = a.tok0[p];
+                    if ((t0 & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[t0 & TOK_REF_MASK];
+                }
+                const uint32_t k = atomicAdd(&s_nm, 1u);
+                s_mlist[k] = (uint16_t)i;
+                s_mse[k] = se;
+                s_mbase[k] = c;
+                continue;
             }
-            cur = nxt;
+            const uint32_t e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const int64_t d = (int64_t)s_doc[i];
+            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
+            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+            meta_one_token(a, p, d, s, e, is_match, o, 0u, 0u, e - s, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word);
         }
+        __syncthreads();
         // ---- the listed pre-tokens' tokens, one a lane
         const uint32_t nm = s_nm;
         uint32_t mt;
@@ -653,25 +610,18 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {      // (fi
         for (uint32_t t = (uint32_t)tid; t < mt; t += 256u) {
             int lo = 0, hi = (int)nm;                     // the last k with mbase[k] <= t
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_mbase[mid] <= t) lo = mid; else hi = mid; }
-            const uint32_t k = (uint32_t)lo;
-            const int i = (int)s_mlist[k];
-            const uint32_t j = t - s_mbase[k], c = s_mbase[k + 1] - s_mbase[k], se = s_mse[k];
+            const int k = lo, i = (int)s_mlist[k];
+            const uint32_t j = t - s_mbase[k], se = s_mse[k];
             const int64_t p = base + i, d = (int64_t)s_doc[i];
             const uint32_t o = s_tokoff[i], s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
-            uint32_t rel = 0u, rel_end = e - s, cont = 0u;           // (no token ends without offsets: word ids only)
-            const bool fast = k < TM_FAST && c <= 4u && a.tmp_end != nullptr;
-            if (fast) {
-                const uint4 en = s_mends[k];
-                rel = j == 0u ? 0u : j == 1u ? en.x : j == 2u ? en.y : en.z;
-                rel_end = j == 0u ? en.x : j == 1u ? en.y : j == 2u ? en.z : en.w;
-                cont = s_mcont[k];
-            } else if (a.tmp_end) {
+            uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
+            if (a.tmp_end) {
                 if (j) rel = a.tmp_end[se + j - 1u];
                 rel_end = a.tmp_end[se + j];
             }
             const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
             const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word, cont, fast && e - s <= 16u);
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word);
         }
     }
 }

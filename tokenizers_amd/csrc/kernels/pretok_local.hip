@@ -1,8 +1,8 @@
 // Part of kernels.hip (ONE translation unit: this file is #included there, inside namespace tkamd, after the shared
-// helpers; it is not compiled on its own).  Whitespace / WhitespaceSplit / BertPreTokenizer (tile kernel + per-lane kernel).
+// helpers; it is not compiled on its own).  Whitespace / WhitespaceSplit / BertPreTokenizer (the per-lane bit-parallel kernel; round 1's lane-per-byte tile kernel is gone).
 
 // =================================================================================================
-// K_pretok_local<KIND>: pre-tokenizers whose split rule only looks at the class of a code point and
+// The pre-tokenizers whose split rule only looks at the class of a code point and
 // of its predecessor; matches are kept, everything else is REMOVED, so a second bitmask marks ends.
 //   PT_WHITESPACE       \w+|[^\w\s]+ via Invert + Removed            (pre_tokenizers/whitespace.rs:20-29)
 //   PT_WHITESPACE_SPLIT char::is_whitespace, Removed                  (whitespace.rs:35-41)
@@ -11,116 +11,8 @@
 //   start[i] = cls != 0 && (doc start || prev != cls || cls == 3)
 //   end[i]   = prev != 0 && (doc start || text end || cls != prev || prev == 3)     (exclusive end)
 // =================================================================================================
-template <int KIND>
-__device__ __forceinline__ uint32_t cls_local(uint32_t cp, const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2) {
-    uint32_t f;
-    if (cp < 0x80u) {
-        // ASCII shortcuts consistent with the generated table (checked by tests): \w = [A-Za-z0-9_],
-        // whitespace = SP \t \n \v \f \r, bert punctuation = the 32 ASCII punctuation marks
-        bool ws = (cp == 0x20u || cp - 9u < 5u);
-        if (ws) return 0;
-        if (KIND == PT_WHITESPACE_SPLIT) return 1;
-        bool alnum = ((cp | 0x20u) - 'a' < 26u) || (cp - '0' < 10u);
-        if (KIND == PT_WHITESPACE) return (alnum || cp == '_') ? 1u : 2u;
-        bool punct = (cp - 33u < 15u) || (cp - 58u < 7u) || (cp - 91u < 6u) || (cp - 123u < 4u);
-        return punct ? 3u : 1u;
-    }
-    f = uc_flags(cp, uc1, uc2);
-    if (KIND == PT_WHITESPACE) return (f & UC_RX_W) ? 1u : (f & UC_RX_S) ? 0u : 2u;
-    if (KIND == PT_WHITESPACE_SPLIT) return (f & UC_RUST_WS) ? 0u : 1u;
-    return (f & UC_RUST_WS) ? 0u : (f & UC_BERT_P) ? 3u : 1u;
-}
-
-constexpr int PL_HALO = 4;
-constexpr int PL_R = PT_TILE + 2 * PL_HALO;
-
-template <int KIND>
-__global__ __launch_bounds__(256) void k_pretok_local(const uint8_t* __restrict__ text, int64_t n_bytes_host,
-                                                      const int64_t* __restrict__ len_dev,
-                                                      const unsigned long long* __restrict__ docmask,
-                                                      const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
-                                                      unsigned long long* __restrict__ startmask,
-                                                      unsigned long long* __restrict__ endmask) {
-    __shared__ __attribute__((aligned(16))) uint8_t sb[PL_R + 8];
-    __shared__ uint8_t si[PL_R + 8];
-    __shared__ unsigned long long sdoc[PT_TILE / 64 + 2];
-    const int tid = (int)threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
-    const int64_t r0 = t0 - PL_HALO;
-    const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;   // effective text length
-    if (t0 > n_bytes + 64) {                                     // tile entirely past the text (derived X text is shorter than its bound)
-        if ((tid & 63) == 0) {
-            for (int it = 0; it < PT_TILE / 256; ++it) {
-                int64_t g = t0 + it * 256 + tid;
-                if (g <= n_bytes_host) { startmask[g >> 6] = 0ull; endmask[g >> 6] = 0ull; }
-            }
-        }
-        return;
-    }
-    {
-        uint32_t* sb32 = (uint32_t*)sb;                          // r0 is a multiple of 4
-        for (int k = tid; k < (PL_R + 8) / 4; k += 256) {
-            int64_t g = r0 + 4 * (int64_t)k;
-            uint32_t v = 0;
-            if (g >= 0 && g + 4 <= n_bytes) v = *(const uint32_t*)(text + g);
-            else if (g + 4 > 0 && g < n_bytes) {
-                for (int q = 0; q < 4; ++q)
-                    if (g + q >= 0 && g + q < n_bytes) v |= (uint32_t)text[g + q] << (8 * q);
-            }
-            sb32[k] = v;
-        }
-        if (tid < PT_TILE / 64 + 2) {
-            int64_t w = (t0 >> 6) - 1 + tid;
-            sdoc[tid] = (w >= 0 && (w << 6) < n_bytes_host + 64) ? docmask[w] : 0ull;
-        }
-    }
-    __syncthreads();
-    for (int k = tid; k < PL_R; k += 256) {
-        int64_t g = r0 + k;
-        uint32_t info = 0;
-        if (g >= 0 && g < n_bytes) {
-            uint32_t b = sb[k];
-            info = IF_VALID;
-            int64_t rel = g - (t0 - 64);
-            if ((sdoc[rel >> 6] >> (rel & 63)) & 1ull) info |= IF_DOC;
-            if ((b & 0xC0u) != 0x80u) {
-                uint32_t len;
-                uint32_t cp = utf8_at(sb, k, &len);
-                info |= IF_LEAD | cls_local<KIND>(cp, uc1, uc2);
-            }
-        }
-        si[k] = (uint8_t)info;
-    }
-    __syncthreads();
-    for (int it = 0; it < PT_TILE / 256; ++it) {
-        int k = PL_HALO + it * 256 + tid;
-        int64_t g = t0 + it * 256 + tid;
-        uint32_t info = si[k];
-        bool lead = (info & (IF_VALID | IF_LEAD)) == (IF_VALID | IF_LEAD);
-        bool at_end = (g == n_bytes);
-        bool start = false, end = false;
-        if (lead || at_end) {
-            uint32_t c = lead ? (info & IF_CLS) : 0u;
-            uint32_t pc = 0;
-            if (g > 0) {
-                int j = k - 1;
-                if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) { --j; if (!(si[j] & IF_LEAD)) --j; } }
-                pc = si[j] & IF_CLS;
-            }
-            bool doc = lead && (info & IF_DOC);
-            start = lead && c != 0 && (doc || pc != c || c == 3);
-            end = pc != 0 && (doc || at_end || c != pc || pc == 3);
-        }
-        uint64_t ms = __ballot(start), me = __ballot(end);
-        if ((tid & 63) == 0 && g <= n_bytes_host) { startmask[g >> 6] = ms; endmask[g >> 6] = me; }
-    }
-}
-template __global__ void k_pretok_local<PT_WHITESPACE>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
-template __global__ void k_pretok_local<PT_WHITESPACE_SPLIT>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
-template __global__ void k_pretok_local<PT_BERT>(const uint8_t*, int64_t, const int64_t*, const unsigned long long*, const uint16_t*, const uint8_t*, unsigned long long*, unsigned long long*);
-
 // =================================================================================================
-// K_pretok_local_lane: the same three pre-tokenizers, bit-parallel per lane (the scheme of k_pretok_gpt2_seq): a lane
+// K_pretok_local_lane: the three pre-tokenizers, bit-parallel per lane (the scheme of k_pretok_gpt2_seq): a lane
 // owns 48 bytes inside a 64-byte window, deposits one-hot class flags from a 1 KB LDS table into 64-bit masks and
 // runs local_window_masks (pretok_local_core.hpp; checked on the CPU by tests/test_pretok_core.py) to get the start
 // and end bits of its bytes.  Four lanes' 48-bit results are three mask words.

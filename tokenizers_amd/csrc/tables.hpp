@@ -133,6 +133,7 @@ TK_HD uint32_t shortw_slot(uint32_t h1, uint32_t kmix, uint32_t d, uint32_t mask
 // 2,048 lowest ids 1,295 kept their slot, and 46 % of C2's pre-tokens hit; placed like this the same LDS hits 61 %, and 1,024
 // slots hit 50 %.)  A word that could not be placed is simply not in the table: the perfect-hash table behind it still answers.
 constexpr int HOT_MAX_KEY = 12;
+constexpr int HOT_SLOTS = 1024;      // (what leaves three lookup workgroups on a CU, kernels/lookup.hip)
 struct HotSlot {
     uint32_t k0, k1, k2, id_len;
 };

@@ -1113,7 +1113,7 @@ class Tokenizer:
         return out
 
     def debug_phases(self, reset: bool = True) -> dict[str, list[int]]:
-        """TKAMD_PHASES=1 runs only: shader-clock ticks per phase of the lookup and the compaction (``tkamd_debug_phases``)."""
+        """TKAMD_TEST_HOOKS=1 TKAMD_PHASES=1 runs only: shader-clock ticks per phase of the lookup and the compaction (``tkamd_debug_phases``)."""
         out = {}
         for which, name in ((0, "lookup"), (1, "compact")):
             arr = (C.c_uint64 * 8)()

@@ -44,7 +44,8 @@ for step in "$@"; do
     sq)
       c=${rest%%:*}; only=${rest#*:}; [ "$only" = "$rest" ] && only="k_lookup,k_compact,k_bpe_merge_lds,k_pretok_gpt2_seq"
       mode=${only#*:}; [ "$mode" = "$only" ] && mode=none; only=${only%%:*}
-      tools/sq.sh $tag/sq $c $only $mode > "$O/sq_$c.log" 2>&1; cp gpurun_out/$tag/sq/sq_$c.json "$O/${c}_sq_summary.json" 2>/dev/null; echo "sq $c rc=$?" ;;
+      sfx=""; [ "$mode" != none ] && sfx="_$mode"
+      tools/sq.sh $tag/sq$sfx $c $only $mode > "$O/sq_$c$sfx.log" 2>&1; cp gpurun_out/$tag/sq$sfx/sq_$c.json "$O/${c}_sq_summary$sfx.json" 2>/dev/null; echo "sq $c$sfx rc=$?" ;;
     smoke) timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" 2>&1 | tail -1 ;;
     ab)
       c=${rest%%:*}; args=${rest#*:}
