@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtokenizers_amd.so")
 SOURCES = ["kernels.hip", "capi.cpp", "host_model.cpp"]
-# everything the three translation units include (kernels.hip is ONE unit made of the kernels/*.hip slices)
+# everything the three translation units include (kernels.hip is ONE unit made of the kernels/*.hip slices, capi.cpp of capi/*.cpp)
 HEADERS = sorted(os.path.join("kernels", f) for f in os.listdir(os.path.join(CSRC, "kernels")) if f.endswith(".hip")) + \
+    sorted(os.path.join("capi", f) for f in os.listdir(os.path.join(CSRC, "capi")) if f.endswith(".cpp")) + \
     sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))) + [os.path.join("..", "..", "include", "tokenizers_amd.h")]
 ARCH = "gfx950"
 
