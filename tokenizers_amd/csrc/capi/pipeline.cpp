@@ -1039,7 +1039,6 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.tmp_end = tmp_end;
         a.tok0 = wc.claims ? w->w_tok0.as<uint32_t>() : nullptr;
         a.claim_pos = wc.claims ? wc.claim_pos : nullptr;
-        for (int c = 0; c < 4; ++c) { a.q[c] = plan.v[c].q; a.q_row_base[c] = plan.v[c].row_base; }
         a.n_pretok = d_npretok;
         a.doc_pt = w->w_doc_pt.as<uint32_t>();
         a.chunk_lo = w->w_chunk_lo.as<uint32_t>();

@@ -117,10 +117,6 @@ struct MetaArgs {
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
     const uint32_t* tok0;             // in-batch claims: a pre-token whose tok0 names a claimed slot shares the claimant's tokens, and its token
     const uint32_t* claim_pos;        // ends are the claimant's: tmp_end[claim_pos[slot] + j] (both null when the claims are off)
-    // ... or (round 6: a word of <= 11 bytes) names the claimant's ROW: the queue entry of that row holds the claimant's first byte
-    // (row = row_base + position in its queue: the four work queues, kernels/results.hip)
-    const QItem* q[4];
-    uint32_t q_row_base[4];
     const int64_t* n_pretok;
     const uint32_t* doc_pt;
     const uint32_t* chunk_lo;         // the compaction's: chunk_lo[c] = the first document d with doc_pt[d] >= c * chunk (k_doc_first_pretok)

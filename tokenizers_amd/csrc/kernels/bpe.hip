@@ -25,7 +25,6 @@ __device__ __forceinline__ void load_key16(const uint8_t* __restrict__ text, uin
 // slots of tmp_end.  The slot is recomputed from the entry's bytes (the kernel has just read them); the claims table itself is not read again.
 constexpr uint32_t CLAIM_MAX_LEN = 32u;
 constexpr uint32_t CLAIM_KEY_MAX = 15u;           // words of <= 15 bytes: the claim entry IS the key (lookup.hip); longer ones name their claimant's bytes
-constexpr uint32_t CLAIM_ROW_MAX = 11u;           // ... and of <= 11 bytes: the entry also names the claimant's ROW (lookup.hip claim_short, pass 3)
 // the whole-word table's hash of the first 16 bytes and the whole length, continued over bytes 16..31 (zero padded)
 __device__ __forceinline__ uint32_t claim_hash_long(uint32_t h16, uint32_t k4, uint32_t k5, uint32_t k6, uint32_t k7) {
     return mix32(h16 ^ (k4 * 0x9E3779B1u) ^ (k5 * 0x85EBCA77u) ^ (k6 * 0xC2B2AE3Du) ^ (k7 * 0x27D4EB2Fu));

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
             // what pass 2 and pass 3 end a lane with: a pre-token still pending is a model kernel's work, queued by length class
             // (<= 16 bytes, <= 32, <= 64, longer); its tok0 word names the row, any other lane's its result.  (wavefront-wide: ballots)
             // (holds: this pre-token won the claim of its word -- QLEN_CLAIM in its queue entry makes the model kernel publish its row)
-            auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out, bool holds) -> uint32_t {
+            auto finish = [&](bool v, bool pend, uint32_t rel, uint32_t s_rel, uint32_t len, uint32_t out, bool holds) {
                 const uint32_t c = len <= 16u ? 0u : (len <= 32u ? 1u : (len <= 64u ? 2u : 3u));
                 const uint64_t b0 = __ballot(pend && c == 0u), b1 = __ballot(pend && c == 1u), b2 = __ballot(pend && c == 2u), b3 = __ballot(pend && c == 3u);
                 if (b0 | b1 | b2 | b3) {                                            // wavefront-uniform
@@ -328,7 +328,6 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                     }
                 }
                 if (v) store_nt(a.tok0 + pbase + rb + rel, out);
-                return out;
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its
@@ -361,32 +360,8 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
             // device-scope read confirms it (tools/microbench/claims_probe.hip).
             // (CLAIM_RETRY, only when the caller can come back -- `last` false: word 0 is this word's, word 1 not there yet)
             enum : uint32_t { CLAIM_NONE = 0u, CLAIM_SHARED = 1u, CLAIM_HOLDS = 2u, CLAIM_RETRY = 3u };
-            // ROWED (round 6, pass 3 only): a word of <= CLAIM_ROW_MAX (11) bytes has four bytes to spare in word 1 -- they carry the CLAIMANT'S ROW
-            // (+ 1: never 0), stored by the winner once its queue position is known (claim_step, behind finish()).  A sharer points its
-            // tok0 at that row -- TOK_ROW | row, in the dense array the model kernels write -- where round 5's TOK_SLOT | slot sent the
-            // compaction to a 32 MB array of slot rows, one random line a sharer; and such a claimant has nothing to publish.
-            auto claim_short = [&](uint32_t slot, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, bool last, bool rows, uint32_t& row) -> uint32_t {
+            auto claim_short = [&](uint32_t slot, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, bool last) -> uint32_t {
                 unsigned long long* const e = a.claims + 2u * (size_t)slot;
-                if (rows && len <= CLAIM_ROW_MAX) {
-                    const unsigned long long w0 = (unsigned long long)k0 | ((unsigned long long)(k1 & 0x00FFFFFFu) << 32) | ((unsigned long long)len << 56);
-                    const uint32_t w1lo = (k1 >> 24) | (k2 << 8);                   // bytes 7..10 (byte 11 is beyond the word)
-                    const ulonglong2 c = *(const ulonglong2*)e;
-                    unsigned long long c0 = c.x, c1 = c.y;
-                    if (c0 == 0ull) {
-                        c0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (c0 == 0ull) { c0 = atomicCAS(e, 0ull, w0); if (c0 == 0ull) return CLAIM_HOLDS; }      // (word 1 follows when the row is known)
-                        c1 = 0ull;
-                    }
-                    if (c0 != w0) return CLAIM_NONE;
-                    // word 1 is written once: a value read is final, a 0 is a stale line or the winner's store still on its way
-                    if ((c1 >> 32) == 0ull) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((c1 >> 32) == 0ull && !last) return CLAIM_RETRY;
-#pragma unroll 1
-                    for (int tries = 0; (c1 >> 32) == 0ull && tries < 3; ++tries) c1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((c1 >> 32) == 0ull || (uint32_t)c1 != w1lo) return CLAIM_NONE;
-                    row = (uint32_t)(c1 >> 32) - 1u;
-                    return CLAIM_SHARED;
-                }
                 const unsigned long long w0 = (unsigned long long)k0 | ((unsigned long long)(k1 & 0x00FFFFFFu) << 32) | ((unsigned long long)len << 56);
                 const unsigned long long w1 = (unsigned long long)(k1 >> 24) | ((unsigned long long)k2 << 8) | ((unsigned long long)(k3 & 0x00FFFFFFu) << 40);
                 // A word of 8..15 bytes whose bytes 7.. are all NUL has w1 == 0 -- indistinguishable from "word 1 not written yet" of another
@@ -442,8 +417,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
             auto claim_any = [&](uint32_t s_rel, uint32_t len, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3, uint32_t h1, uint32_t& slot) -> uint32_t {
                 if (len <= CLAIM_KEY_MAX) {
                     slot = claim_slot(h1, a.claim_mask);
-                    uint32_t row_unused = 0u;
-                    return claim_short(slot, len, k0, k1, k2, k3, true, false, row_unused);
+                    return claim_short(slot, len, k0, k1, k2, k3, true);
                 }
                 uint32_t k4 = 0u, k5 = 0u, k6 = 0u, k7 = 0u, hc = h1;
                 uint4 kmh = make_uint4(0u, 0u, 0u, 0u);
@@ -563,14 +537,13 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                     uint32_t s_rel, len, k0, k1, k2, k3;
                     load_key(rel, s_rel, len, k0, k1, k2, k3, true);
                     const uint32_t h1 = word_hash1_from_hot(hot_hash(k0, k1, k2, len, a.word_seed), k3);
-                    uint32_t out = 0u, slot = 0u, r = CLAIM_NONE, row = 0u;
+                    uint32_t out = 0u, slot = 0u, r = CLAIM_NONE;
                     bool pend = v;
-                    const bool rowed = !lng && len <= CLAIM_ROW_MAX;                 // (the entry carries the claimant's row: claim_short)
                     if (v) {
                         if (lng) r = claim_any(s_rel, len, k0, k1, k2, k3, h1, slot);
-                        else { slot = claim_slot(h1, a.claim_mask); r = claim_short(slot, len, k0, k1, k2, k3, last, true, row); }
+                        else { slot = claim_slot(h1, a.claim_mask); r = claim_short(slot, len, k0, k1, k2, k3, last); }
                     }
-                    if (r == CLAIM_SHARED) { out = rowed ? (TOK_ROW | row) : (TOK_SLOT | slot); pend = false; }
+                    if (r == CLAIM_SHARED) { out = TOK_SLOT | slot; pend = false; }
                     const bool again = r == CLAIM_RETRY;
                     const uint64_t rbm = __ballot(again);
                     if (rbm) {                                                      // (wavefront-uniform; never in the last round)
@@ -581,12 +554,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                     }
                     const uint64_t sb = __ballot(v && !pend && !again);
                     if (sb && lane == 0) atomicAdd(&s_shared, (uint32_t)__popcll(sb));
-                    const uint32_t fo = finish(v && !again, pend && !again, rel, s_rel, len, out, r == CLAIM_HOLDS && !rowed);
-                    // the winner of a rowed entry: its row is known now -- word 1 = bytes 7..10 | (row + 1) << 32.  (A queue that overflowed left
-                    // no row: the entry stays half written, its sharers are queued on their own, and the batch is run again anyway.)
-                    if (r == CLAIM_HOLDS && rowed && (fo & TOK_SLOT) == TOK_ROW)
-                        __hip_atomic_store(a.claims + 2u * (size_t)slot + 1u,
-                                           (unsigned long long)((k1 >> 24) | (k2 << 8)) | ((unsigned long long)((fo & TOK_REF_MASK) + 1u) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    finish(v && !again, pend && !again, rel, s_rel, len, out, r == CLAIM_HOLDS);
                 };
                 for (uint32_t st = (uint32_t)wave; st < steps_s + steps_l; st += (uint32_t)LU_WAVES) {
                     const bool lng = st >= steps_s;                                 // wavefront-uniform

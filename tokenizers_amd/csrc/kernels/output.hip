@@ -380,22 +380,6 @@ __device__ __forceinline__ uint32_t norig_end(const MetaArgs& a, uint32_t k) {
     return i + (b < 0xC0u ? 1u : b < 0xE0u ? 2u : b < 0xF0u ? 3u : 4u);
 }
 
-// Whose token ends a pre-token of several tokens reads: its own (tmp_end + its first byte), or -- a word another pre-token of the batch
-// claimed first -- the claimant's: behind the slot (TOK_SLOT: claim_pos), or behind the claimant's row (TOK_ROW: the queue entry of the
-// row holds its first byte; a pre-token's own row gives its own first byte back).
-__device__ __forceinline__ uint32_t meta_ends_of(const MetaArgs& a, int64_t p, uint32_t s) {
-    if (!a.claim_pos || !a.tmp_end) return s;
-    const uint32_t t0 = a.tok0[p], kind = t0 & TOK_SLOT, ref = t0 & TOK_REF_MASK;
-    if (kind == TOK_SLOT) return a.claim_pos[ref];
-    if (kind == TOK_ROW) {
-        const int c = ref >= a.q_row_base[3] ? 3 : ref >= a.q_row_base[2] ? 2 : ref >= a.q_row_base[1] ? 1 : 0;
-        const QItem* const q = c == 3 ? a.q[3] : c == 2 ? a.q[2] : c == 1 ? a.q[1] : a.q[0];
-        const uint32_t rb = c == 3 ? a.q_row_base[3] : c == 2 ? a.q_row_base[2] : c == 1 ? a.q_row_base[1] : a.q_row_base[0];
-        return q[ref - rb].s;
-    }
-    return s;
-}
-
 // offsets / word id of ONE token: token j of pre-token p (document d; [s, e) in x space; its tokens are o .. o + c), covering
 // [s + rel, s + rel_end) of the x text.  Everything of into_encoding / process_offsets that is per token.
 __device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int64_t d, uint32_t s, uint32_t e, bool is_match, uint32_t o, uint32_t j,
@@ -483,7 +467,11 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
         // an added-token match is one token whose own length is on record (k_scatter_matches): a later, overlapping match may have
         // cut it short in the start mask, and its text is the raw slice (trimmed by real whitespace chars)
         const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-        const uint32_t s_ends = c > 1 ? meta_ends_of(a, p, s) : s;    // whose token ends: the pre-token's own, or the claimant's of its word
+        uint32_t s_ends = s;                                          // whose token ends: the pre-token's own, or the claimant's of its word
+        if (a.claim_pos && c > 1) {
+            const uint32_t t0 = a.tok0[p];
+            if ((t0 & TOK_SLOT) == TOK_SLOT) s_ends = a.claim_pos[t0 & TOK_REF_MASK];
+        }
         // BPE over characters without an unk_token: a char the vocabulary lacks leaves no symbol, and the reference's token offsets are
         // running sums of the symbols' lengths (word.rs:260-268) -- every edge behind a dropped char moves up by its bytes.  The model
         // kernels report edges as positions; the dropped bytes in front of each edge are counted here, walking the word once.
@@ -588,7 +576,11 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             const int64_t p = base + i;
             const uint32_t s = s_start[i];
             if (c > 1u) {
-                const uint32_t se = meta_ends_of(a, p, s);   // whose token ends: the pre-token's own, or the claimant's of its word
+                uint32_t se = s;                          // whose token ends: the pre-token's own, or the claimant's of its word
+                if (a.claim_pos && a.tmp_end) {
+                    const uint32_t t0 = a.tok0[p];
+                    if ((t0 & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[t0 & TOK_REF_MASK];
+                }
                 const uint32_t k = atomicAdd(&s_nm, 1u);
                 s_mlist[k] = (uint16_t)i;
                 s_mse[k] = se;
