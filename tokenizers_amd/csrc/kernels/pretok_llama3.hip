@@ -249,8 +249,8 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
 }
 
 // =================================================================================================
-// K_pretok_llama3_lane: the same split, bit-parallel PER LANE (the GPT-2 kernel's scheme): a lane owns 32 bytes
-// inside a 64-byte window (16 bytes of context on each side, four aligned 16-byte loads), deposits one-hot byte
+// K_pretok_llama3_lane: the same split, bit-parallel PER LANE (the GPT-2 kernel's scheme): a lane owns 48 bytes
+// inside a 64-byte window (8 bytes of context on each side, four 16-byte loads), deposits one-hot byte
 // flags from a small LDS table into 64-bit masks and runs l3_window_starts (pretok_l3_core.hpp) -- the mask algebra
 // that tests/test_pretok_core.py checks on the CPU, function for function, against a sequential matcher.  Bytes whose run
 // leaves the window are reported in slowmask; k_pretok_llama3 (refine mode) redoes only the tiles that have any.
@@ -272,16 +272,18 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
     const int64_t n_words_host = (n_bytes_host >> 6) + 1;
     const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t a = Lg * L3W_MAIN;                         // first byte this lane decides
-    const int64_t base = a - L3W_HALO;                       // window = [base, base + 64), 16-byte aligned
+    const int64_t base = a - L3W_HALO;                       // window = [base, base + 64), 8-byte aligned
     unsigned long long st = 0, un = 0;
     if (a < n_bytes) {
         uint32_t w[16];
         {
-            uint4 c0 = make_uint4(0u, 0u, 0u, 0u);
-            if (base >= 0) c0 = *(const uint4*)(text + base);
-            const uint4 c1 = *(const uint4*)(text + base + 16), c2 = *(const uint4*)(text + base + 32), c3 = *(const uint4*)(text + base + 48);
-            w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w; w[4] = c1.x; w[5] = c1.y; w[6] = c1.z; w[7] = c1.w;
-            w[8] = c2.x; w[9] = c2.y; w[10] = c2.z; w[11] = c2.w; w[12] = c3.x; w[13] = c3.y; w[14] = c3.z; w[15] = c3.w;
+            // four 16-byte loads (8-byte aligned: gfx950 takes dwordx4 at any alignment); only lane 0's window starts before the text
+            SqChunk c0{0u, 0u, 0u, 0u};
+            if (base >= 0) c0 = *(const SqChunk*)(text + base);
+            else { const uint2 t = *(const uint2*)text; c0.c = t.x; c0.d = t.y; }
+            const SqChunk c1 = *(const SqChunk*)(text + base + 16), c2 = *(const SqChunk*)(text + base + 32), c3 = *(const SqChunk*)(text + base + 48);
+            w[0] = c0.a; w[1] = c0.b; w[2] = c0.c; w[3] = c0.d; w[4] = c1.a; w[5] = c1.b; w[6] = c1.c; w[7] = c1.d;
+            w[8] = c2.a; w[9] = c2.b; w[10] = c2.c; w[11] = c2.d; w[12] = c3.a; w[13] = c3.b; w[14] = c3.c; w[15] = c3.d;
         }
         L3Window m;
         const int vlo = base < 0 ? (int)-base : 0;
@@ -318,14 +320,18 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
         m.L &= m.V; m.N &= m.V; m.W &= m.V; m.R &= m.V; m.SP &= m.V; m.C &= m.V; m.AP &= m.V; m.MU &= m.V;
         uint64_t s64, u64;
         l3_window_starts(m, text, base, uc1, uc2, &s64, &u64, rule);
-        st = (s64 >> L3W_HALO) & 0xFFFFFFFFull;
-        un = (u64 >> L3W_HALO) & 0xFFFFFFFFull;
+        st = (s64 >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);
+        un = (u64 >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);
     }
-    // two lanes (32 bytes each) make one 64-bit mask word
-    const unsigned long long st_o = __shfl_xor(st, 1, 64), un_o = __shfl_xor(un, 1, 64);
-    if ((threadIdx.x & 1) == 0) {
-        const int64_t word = Lg >> 1;
-        if (word < n_words_host) { startmask[word] = st | (st_o << 32); slowmask[word] = un | (un_o << 32); }
+    // four lanes' 48-bit results are three 64-bit mask words
+    const unsigned long long st_n = __shfl_down(st, 1, 64), un_n = __shfl_down(un, 1, 64);
+    const int q = (int)(threadIdx.x & 3);
+    if (q < 3) {
+        const int64_t word = 3 * (Lg >> 2) + q;
+        if (word < n_words_host) {
+            startmask[word] = (st >> (16 * q)) | (st_n << (L3W_MAIN - 16 * q));
+            slowmask[word] = (un >> (16 * q)) | (un_n << (L3W_MAIN - 16 * q));
+        }
     }
 }
 

@@ -5,8 +5,8 @@
 // and the members of its family that differ in the contraction alternative (absent / case-sensitive) and in the digit alternative
 // (\p{N}{1,k} with k = 1, 2, 3, or \p{N}+): tables.hpp SplitRule, split_rule_fast().
 //
-// The function below is the whole per-lane logic of k_pretok_llama3_lane (kernels.hip): a lane owns the 32 bytes
-// [16, 48) of its window and decides, for each of them, whether a regex match STARTS there (Split with Isolated
+// The function below is the whole per-lane logic of k_pretok_llama3_lane (kernels.hip): a lane owns the 48 bytes
+// [8, 56) of its window and decides, for each of them, whether a regex match STARTS there (Split with Isolated
 // behaviour covers every byte, pre_tokenizers/split.rs:96-104, so the starts are the whole answer).  It is written
 // as plain host+device code so that tests/test_pretok_core.py can run exactly the same function on the CPU against
 // the sequential regex matcher of the test tree on millions of adversarial strings (tests/harness/l3_harness.cpp) -- the GPU kernel only adds the loads,
@@ -24,9 +24,12 @@
 
 namespace tkamd {
 
-constexpr int L3W_HALO = 16;      // bytes of context on each side of the 32 bytes a lane decides
-constexpr int L3W_MAIN = 32;
-constexpr uint64_t L3W_MAIN_MASK = 0x0000FFFFFFFF0000ull;
+// (round 6: 48 bytes a lane behind 8 bytes of context, the GPT-2 kernel's window -- the mask algebra costs the same per WINDOW, so a third
+// fewer windows; rounds 3-5 decided 32 bytes behind 16.  A run that reaches the window's first four bytes or its last one is left to the
+// tile kernel: with the narrower halo that is a whitespace or digit run of eight bytes and more at a window's edge.)
+constexpr int L3W_HALO = 8;       // bytes of context on each side of the 48 bytes a lane decides
+constexpr int L3W_MAIN = 48;
+constexpr uint64_t L3W_MAIN_MASK = ((1ull << L3W_MAIN) - 1ull) << L3W_HALO;
 
 // classes of one byte, deposited by the caller for ASCII (multi-byte leads are classified here through the tables)
 struct L3Window {
@@ -76,8 +79,8 @@ TK_HD uint64_t l3_spread_fwd(uint64_t seed, uint64_t link) {
 }
 
 // `text + base` is window byte 0 (may lie before the text for the first lane: V says which bytes exist); the text
-// carries TKAMD_TEXT_PAD readable bytes after its end.  Returns the match starts of window bytes [16, 48) in bits
-// 16..47 of *start and the bytes it could not decide in *unres (same bits).
+// carries TKAMD_TEXT_PAD readable bytes after its end.  Returns the match starts of window bytes [8, 56) in bits
+// 8..55 of *start and the bytes it could not decide in *unres (same bits).
 TK_HD void l3_window_starts(L3Window m, const uint8_t* text, int64_t base, const uint16_t* uc1, const uint8_t* uc2,
                             uint64_t* start, uint64_t* unres, const SplitRule rule = SPLIT_RULE_LLAMA3) {
     const uint64_t V = m.V, D = m.D & V, nD = ~D;
