@@ -53,6 +53,7 @@ typedef uint32_t nt_a_u32x4 __attribute__((ext_vector_type(4)));          // (HI
 typedef uint32_t nt_a_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint4 load_nt(const uint4* p) { const nt_a_u32x4 v = __builtin_nontemporal_load((const nt_a_u32x4*)p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint2 load_nt(const uint2* p) { const nt_a_u32x2 v = __builtin_nontemporal_load((const nt_a_u32x2*)p); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ void store_nt(uint2* p, uint2 v) { nt_a_u32x2 x; x.x = v.x; x.y = v.y; __builtin_nontemporal_store(x, (nt_a_u32x2*)p); }
 #else
 __device__ __forceinline__ Unaligned16 load_nt16(const uint8_t* p) { return *(const Unaligned16*)p; }
 template <class T> __device__ __forceinline__ T load_nt(const T* p) { return *p; }

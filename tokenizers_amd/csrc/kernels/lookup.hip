@@ -285,10 +285,13 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                     }
                 }
                 // (the misses store a placeholder too, so that a wavefront's 64 words leave as whole lines; pass 2 / 3 overwrite them:
-                // 0.2337 -> 0.2296 ms on C2 against storing the hits alone)
+                // 0.2337 -> 0.2296 ms on C2 against storing the hits alone.  PLAIN stores since round 6: the L2 then merges the placeholder
+                // with the word pass 2 / 3 write microseconds later, and the compaction finds tok0 there -- non-temporal stores sent
+                // every partial line out on its own, WRITE_SIZE 272 MB for 79 MB of tok0.  Same-session A/B, twice: lookup 0.209 ->
+                // 0.202 ms, compact 0.115 -> 0.111, the step 0.489 -> 0.478 ms, profiles/r6h_ab_c2_plain_tok0.txt)
                 if (hit || miss) {
                     const uint32_t w0 = hit ? (TOK_ONE | (h.w & TOK_ID_MASK)) : 0u;
-                    store_nt(a.tok0 + pbase + rb + rel, w0);
+                    a.tok0[pbase + rb + rel] = w0;
                 }
                 const uint64_t mb = __ballot(miss);
                 if (mb) {                                                           // (wavefront-uniform) the workgroup's miss list
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                         }
                     }
                 }
-                if (v) store_nt(a.tok0 + pbase + rb + rel, out);
+                if (v) a.tok0[pbase + rb + rel] = out;
             };
             // In-batch claims (the section behind this kernel).  The claim of a candidate -- a pre-token of <= 32 bytes the tables did
             // not settle -- is two more dependent round trips (the slot, then the claimant's bytes), and a step of pass 2 waits for its

@@ -11,6 +11,7 @@
 #   smoke                           __graft_entry__.smoke()
 #   ab:<cfg>:<args of tools/ab.py>  same-session A/B of environment switches / library builds
 #   py:<script and args>            any python script of tools/ (output to <tag>/<script>.txt)
+#   sh:<name>:<command>             any command (output to <tag>/<name>.txt)
 # Order matters: a bench line right BEHIND a --pmc pass came out 12 % slow (round 5), so put pmc / sq steps last.
 # Every profiler run sits under `timeout`: a rocprofv3 that aborts can otherwise hang in its finaliser for minutes.
 tag=$1; shift
@@ -53,6 +54,9 @@ for step in "$@"; do
     py)
       name=$(echo "$rest" | awk '{print $1}' | xargs basename | sed 's/\.py$//')
       eval "timeout 900 python $rest" > "$O/$name.txt" 2>&1; echo "py $name rc=$?"; tail -15 "$O/$name.txt" ;;
+    sh)
+      name=${rest%%:*}; cmd=${rest#*:}
+      eval "timeout 900 $cmd" > "$O/$name.txt" 2>&1; echo "sh $name rc=$?"; tail -6 "$O/$name.txt" ;;
     *) echo "unknown step $step" ;;
   esac
 done

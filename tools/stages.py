@@ -14,6 +14,9 @@ import bench
 import tokenizers_amd as ta
 from oracle import oracle as orc
 
+if os.environ.get("AB_LIB"):                                 # another BUILD of the library (tools/ab_libs/*.so), like tools/ab.py
+    from tokenizers_amd import _lib
+    _lib.LIB_PATH, _lib._lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["AB_LIB"]), None
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c2"
 ts = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
