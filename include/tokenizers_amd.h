@@ -92,7 +92,8 @@ typedef struct tkamd_batch     tkamd_batch;      /* one encode_batch result (hos
 /* What was recognised in tokenizer.json (for the host shim / diagnostics). */
 typedef struct tkamd_info {
     int32_t model;          /* 1 BPE, 2 WordPiece, 3 WordLevel                                  */
-    int32_t pre_tokenizer;  /* 1 ByteLevel(GPT-2 regex), 2 Llama-3 Split+ByteLevel, 3 Whitespace,
+    int32_t pre_tokenizer;  /* 1 ByteLevel(GPT-2 regex; also that regex spelled as a Split), 2 Split(a pattern of the tiktoken family:
+                               Llama-3 / cl100k, Qwen2, o200k, tekken ...; pre_tokenizers/split.rs:76-105) + ByteLevel, 3 Whitespace,
                                4 WhitespaceSplit, 5 BertPreTokenizer, 6 ByteLevel(use_regex=false) */
     int32_t normalizer;     /* 0 none, 1 BertNormalizer                                         */
     int32_t vocab_size;
@@ -133,7 +134,8 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* tok, tkamd_info* info);
  *                            Vec<Encoding> as a collective, for consumers that want the result on one GPU.
  * A device may be named more than once (two shards then share a GPU: how the sharded path is tested on a one-GPU box; RCCL needs
  * distinct devices).  n_devices == 0: the list comes from the environment, TOKENIZERS_GPU_DEVICES = "all" | "0,2,3" (unset: device
- * 0).  BatchLongest padding and TKAMD_WANT_OVERFLOW couple the documents of a batch and run on devices[0] alone; so does a batch of
+ * 0).  BatchLongest padding couples the documents of a batch through one number -- the longest encoding: the shards exchange theirs and
+ * pad to the batch's (utils/padding.rs:55-63).  TKAMD_WANT_OVERFLOW and mixed batches run on devices[0] alone; so does a batch of
  * less than 1 MB per device (TKAMD_SHARD_MIN_KB, read when the handle is made).  The device-buffer entries and decode_batch run on devices[0]. */
 #define TKAMD_COLLECT_HOST      0
 #define TKAMD_COLLECT_ROOT_P2P  1

@@ -31,6 +31,7 @@ struct Workspace {
         w_match_docs, w_match_list;
     // host entry staging
     DevBuf h_text, h_doc_off, h_seq_off, h_inp_off;
+    DevBuf w_tok_b8;                             // with offsets: per token, the boundary byte its row carried (kernels/results.hip row_boundary)
     DevBuf w_trim1;                              // per token: process_offsets took one leading space off it (MetaArgs::trim1)
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
     DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag

@@ -1012,11 +1012,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     if (matchmask)
         launch_apply_match_ids(st, w->w_match_list.as<uint32_t>(), d_counters + CNT_MATCHES, w->w_startmask.as<ull>(),
                                w->w_wprefix.as<uint32_t>(), w->w_tok0.as<uint32_t>());
+    // with offsets: one byte per token next to the ids -- the boundary in front of the token, where its row carried it (results.hip)
+    uint8_t* tok_b8 = nullptr;
+    if (tmp_end) { w->w_tok_b8.reserve((size_t)n_x + 64); tok_b8 = w->w_tok_b8.as<uint8_t>(); }
     pf.begin("compact");
     // (the token offsets of the pre-tokens are only materialised for the offsets / word-id pass; the documents' token CSR comes out of the compaction itself)
     launch_compact(st, t->cp_grid, w->w_tok0.as<uint32_t>(), w->w_rows.p, wc.rows, w->w_tmp_ids.as<uint32_t>(), d_npretok, w->w_cstate.as<ull>(),
                    d_ntok_total, want_meta ? w->w_pt_tokoff.as<uint32_t>() : nullptr, w->w_ids.as<uint32_t>(), w->w_chunk_lo.as<uint32_t>(),
-                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>(), (size_t)t->cp_grid <= PHASE_WGS ? phases_of(1) : nullptr);
+                   w->w_doc_pt.as<uint32_t>(), n_docs, w->w_tok_offsets.as<int64_t>(), (size_t)t->cp_grid <= PHASE_WGS ? phases_of(1) : nullptr, tok_b8);
     pf.end();
     const uint32_t* word_of_doc = nullptr;
     const int64_t* first_tok = nullptr;
@@ -1037,6 +1040,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.n_tok = d_ntok_total;
         a.pt_tokoff = w->w_pt_tokoff.as<uint32_t>();
         a.tmp_end = tmp_end;
+        a.tok_b8 = tok_b8;
         a.tok0 = wc.claims ? w->w_tok0.as<uint32_t>() : nullptr;
         a.claim_pos = wc.claims ? wc.claim_pos : nullptr;
         a.n_pretok = d_npretok;

@@ -115,6 +115,8 @@ struct MetaArgs {
     const int64_t* n_tok;             // total token count (device scalar)
     const uint32_t* pt_tokoff;
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
+    const uint8_t* tok_b8;            // per token: the boundary byte in front of it, if its row carried one (kernels/results.hip row_boundary; the
+                                      // compaction wrote it next to the ids), else 0 -- token_meta then takes the ends from tmp_end; null without offsets
     const uint32_t* tok0;             // in-batch claims: a pre-token whose tok0 names a claimed slot shares the claimant's tokens, and its token
     const uint32_t* claim_pos;        // ends are the claimant's: tmp_end[claim_pos[slot] + j] (both null when the claims are off)
     const int64_t* n_pretok;
@@ -414,7 +416,7 @@ void launch_bpe_merge_long_only(hipStream_t st, int grid, const DevTables& t, co
 void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, const void* rows, const WordCache& wc);
 void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
-                    int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr);
+                    int64_t n_docs, int64_t* tok_offsets, void* phases = nullptr, uint8_t* tok_b8 = nullptr);
 int compact_grid(int n_cu);
 void launch_zero_regions(hipStream_t st, int grid, const ZeroRegions& z);
 void launch_zero_tail(hipStream_t st, uint8_t* p, const int64_t* len_dev, int n, unsigned long long* mask = nullptr, int64_t mask_words = 0, int grid = 1);      // n <= 256 zero bytes at p[*len_dev ..]; mask: its words below (*len_dev >> 6) + 3 zeroed too

@@ -317,6 +317,12 @@ __global__ __launch_bounds__(256) void k_bpe_merge_lane(DevTables t, const uint8
             }
         }
         if (valid) {
+            if (tmp_end && n >= 2u && n <= 4u) {               // (the token ends ride in the row: results.hip row_boundary; tmp_end is written as well here)
+                uint32_t m = starts & (starts - 1u);
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+                    if (m) { ids[j] |= row_boundary(text, s, (uint32_t)(__ffs(m) - 1), true); m &= m - 1u; }
+            }
             { const uint4 row_ = make_row(n, s, ids[0], ids[1], ids[2], ids[3]); rows[v.row_base + p] = row_; TKAMD_PUBLISH_ROW(t, text, s, len | claim, row_); }
             if (n > 4u) {
 #pragma unroll
@@ -602,12 +608,15 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                 r[0] = 0u;
                 if (m) { const uint32_t p0 = (uint32_t)__ffs(m) - 1u; TKAMD_SYM_AT(r[0], p0); m &= m - 1u; }
             }
+            // (byte-level words of <= 4 tokens: the token ends ride in the row, results.hip row_boundary -- nothing goes to tmp_end)
+            const bool carry = !CHARS && tmp_end != nullptr && c <= 4u;
 #pragma unroll
             for (int j = 1; j < 4; ++j) {
                 if (m) {
                     const uint32_t pos = (uint32_t)__ffs(m) - 1u;
                     TKAMD_SYM_AT(r[j], pos);
-                    if (tmp_end) tmp_end[s + j - 1] = pos;
+                    if (carry) r[j] |= row_boundary(text, s, pos, true);
+                    else if (tmp_end) tmp_end[s + j - 1] = pos;
                     m &= m - 1u;
                 }
             }
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(NT) void k_bpe_merge_lds(DevTables t, const uint8_t
                     if (tmp_end) tmp_end[s + j - 1] = pos;
                 }
             }
-            if (tmp_end && c) tmp_end[s + c - 1] = len;
+            if (tmp_end && c && !carry) tmp_end[s + c - 1] = len;
             { const uint4 row_ = make_row(c, s, r[0], r[1], r[2], r[3]); rows[qidx] = row_; TKAMD_PUBLISH_ROW(t, text, s, len | claim, row_); }
             // (k - 1) + 2 m probes for a word of k symbols and m merges: every initial pair once, two new pairs per merge
             if (t.probes) { const uint32_t k0 = (uint32_t)__popc(alive0); if (k0) atomicAdd(&s_probes, (k0 - 1u) + 2u * (k0 - c)); }

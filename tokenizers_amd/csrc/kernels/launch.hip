@@ -273,7 +273,7 @@ void launch_word_cache_insert(hipStream_t st, int grid, const DevTables& t, cons
 }
 void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* rows, const void* cache_rows, const uint32_t* tmp_ids, const int64_t* n_pretok,
                     unsigned long long* state, int64_t* n_tok, uint32_t* pt_tokoff, uint32_t* ids, const uint32_t* chunk_lo, const uint32_t* doc_pt,
-                    int64_t n_docs, int64_t* tok_offsets, void* phases) {
+                    int64_t n_docs, int64_t* tok_offsets, void* phases, uint8_t* tok_b8) {
     static_assert(COMPACT_CHUNK == CpShape<CP_ITEMS_PER_LANE>::CHUNK, "the host sizes the look-back state and chunk_lo by the chunk");
     unsigned long long* const ph = (unsigned long long*)phases;
     // polls before a look-back computes a missing total itself (kernels/output.hip, results.hip); the test hook TKAMD_LB_PATIENCE sets it
@@ -282,8 +282,8 @@ void launch_compact(hipStream_t st, int grid, const uint32_t* tok0, const void* 
     const uint32_t patience = e ? (uint32_t)std::max(0, atoi(e)) : LB_PATIENCE;
     if (ph)                                                  // the diagnostic instantiation (tkamd_debug_phases)
         hipLaunchKernelGGL((k_compact<CP_ITEMS_PER_LANE, true>), dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, tok_b8);
     else
         hipLaunchKernelGGL(k_compact<CP_ITEMS_PER_LANE>, dim3(grid), dim3(CP_NT), 0, st, tok0, (const uint4*)rows, (const uint4*)cache_rows, tmp_ids, n_pretok, state, n_tok, pt_tokoff, ids,
-                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience);
+                           chunk_lo, doc_pt, n_docs, tok_offsets, ph, patience, tok_b8);
 }

@@ -115,17 +115,22 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
     cp_load_tok0<CP_ITEMS>(tok0, p0, P, f);
     return cp_load_rows<CP_ITEMS>(f, rows, crows, r);
 }
-#define TKAMD_CP_SCATTER(DST, R, O)                                                                           \
+// (words 1..3 of a row go out WITH their top byte -- the boundary in front of the token, results.hip row_boundary -- when DST is the
+// LDS stage: the copy-out splits them into ids and tok_b8; the direct scatter of an oversized chunk splits them here, B8 null: ids only)
+#define TKAMD_CP_SCATTER(DST, R, O, RAW, B8)                                                                  \
     _Pragma("unroll") for (int k = 0; k < CP_ITEMS; ++k) {                                                    \
         const uint32_t c = (R).cnt[k];                                                                        \
         if (c) {                                                                                              \
             const bool more = ((R).row[k].x >> ROW_CNT_SHIFT) == ROW_CNT_MORE;                                \
+            const uint32_t keep_ = (RAW) ? 0xFFFFFFFFu : TOK_ID_MASK;                                         \
             (DST)[(O)] = (R).row[k].x & ROW_ID_MASK;                                                          \
+            if (!(RAW) && (B8)) (B8)[(O)] = 0;                                                                \
             if (!more) {                                                                                      \
-                if (c > 1) (DST)[(O) + 1] = (R).row[k].y;                                                     \
-                if (c > 2) (DST)[(O) + 2] = (R).row[k].z;                                                     \
-                if (c > 3) (DST)[(O) + 3] = (R).row[k].w;                                                     \
+                if (c > 1) { (DST)[(O) + 1] = (R).row[k].y & keep_; if (!(RAW) && (B8)) (B8)[(O) + 1] = (uint8_t)((R).row[k].y >> ROW_B8_SHIFT); } \
+                if (c > 2) { (DST)[(O) + 2] = (R).row[k].z & keep_; if (!(RAW) && (B8)) (B8)[(O) + 2] = (uint8_t)((R).row[k].z >> ROW_B8_SHIFT); } \
+                if (c > 3) { (DST)[(O) + 3] = (R).row[k].w & keep_; if (!(RAW) && (B8)) (B8)[(O) + 3] = (uint8_t)((R).row[k].w >> ROW_B8_SHIFT); } \
             } else {                                                                                          \
+                if (!(RAW) && (B8)) for (uint32_t j = 1; j < c; ++j) (B8)[(O) + j] = 0;                       \
                 /* ids 1.. of a longer run: tmp_ids[s + 1 ..], four to a load (16 bytes at any alignment; the  */ \
                 /* buffer extends four words past the text, so the last load may overshoot the run)           */ \
                 const uint32_t* const src_ = tmp_ids + (R).row[k].y;                                          \
@@ -158,7 +163,9 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
                                                    unsigned long long* __restrict__ state,
                                                    int64_t* __restrict__ n_tok, uint32_t* __restrict__ pt_tokoff, uint32_t* __restrict__ ids,
                                                    const uint32_t* __restrict__ chunk_lo, const uint32_t* __restrict__ doc_pt, int64_t n_docs,
-                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience) {
+                                                   int64_t* __restrict__ tok_offsets, unsigned long long* __restrict__ phases, uint32_t patience,
+                                                   uint8_t* __restrict__ tok_b8) {
+    // tok_b8 (with offsets only, else null): per token, the boundary byte in front of it that its row carried (results.hip row_boundary)
     constexpr int CP_CHUNK = CpShape<CP_ITEMS>::CHUNK, CP_STAGE = CpShape<CP_ITEMS>::STAGE;
     unsigned long long ph_t = 0ull, ph_t0 = 0ull, ph_acc[4] = {0ull, 0ull, 0ull, 0ull};
     auto tick = [&](int k) {
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         if (tot <= (uint32_t)CP_STAGE) {
             uint32_t o = ex;
             uint32_t* const dst = s_stage[b];
-            TKAMD_CP_SCATTER(dst, r, o)
+            TKAMD_CP_SCATTER(dst, r, o, true, (uint8_t*)nullptr)
         }
         tick(1);
     };
@@ -290,14 +297,23 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
             }
         }
         if (tot <= (uint32_t)CP_STAGE) {
-            for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) store_nt(ids + base + i, s_stage[b][i]);
+            if (tok_b8) {                                  // (wavefront-uniform) the staged words carry the boundary bytes: split them
+                for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) {
+                    const uint32_t w = s_stage[b][i];
+                    store_nt(ids + base + i, w & TOK_ID_MASK);
+                    tok_b8[base + i] = (uint8_t)(w >> ROW_B8_SHIFT);
+                }
+            } else {
+                for (uint32_t i = (uint32_t)tid; i < tot; i += CP_NT) store_nt(ids + base + i, s_stage[b][i]);
+            }
         } else {                                           // rare: too many tokens for the buffer -- scatter from the rows
             const int64_t p0 = ch * CP_CHUNK + (int64_t)tid * CP_ITEMS;
             CpRows<CP_ITEMS> r;
             cp_load<CP_ITEMS>(tok0, rows, crows, p0, P, r);
             uint32_t o = s_loc[b][tid * CP_ITEMS];
             uint32_t* const dst = ids + base;
-            TKAMD_CP_SCATTER(dst, r, o)
+            uint8_t* const b8 = tok_b8 ? tok_b8 + base : nullptr;
+            TKAMD_CP_SCATTER(dst, r, o, false, b8)
         }
         __syncthreads();                                   // buffer b is free for front() of the chunk after next
         tick(3);
@@ -382,13 +398,17 @@ __device__ __forceinline__ uint32_t norig_end(const MetaArgs& a, uint32_t k) {
 
 // offsets / word id of ONE token: token j of pre-token p (document d; [s, e) in x space; its tokens are o .. o + c), covering
 // [s + rel, s + rel_end) of the x text.  Everything of into_encoding / process_offsets that is per token.
+// snapped: the caller knows the edges already snapped to char boundaries (the boundary bytes the rows carried, results.hip): bs / be.
+// (the outputs are written once and read by nobody here: non-temporal stores -- token_meta 0.4005 -> 0.391 ms, profiles/r6i_*)
 __device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int64_t d, uint32_t s, uint32_t e, bool is_match, uint32_t o, uint32_t j,
-                                               uint32_t rel, uint32_t rel_end, uint32_t xdoc, uint32_t odoc, uint32_t word) {
-    if (a.want_words) a.word_ids[o + j] = word;
+                                               uint32_t rel, uint32_t rel_end, uint32_t xdoc, uint32_t odoc, uint32_t word,
+                                               bool snapped = false, uint32_t snap_bs = 0u, uint32_t snap_be = 0u) {
+    if (a.want_words) store_nt(a.word_ids + o + j, word);
     if (!a.want_offsets) return;
     uint32_t ts = s + rel, te = s + rel_end;              // token bytes in x space
     uint32_t bs = ts, be = te;
-    if (a.snap_chars && !is_match) {                      // snap to char boundaries inside the pre-token (its own edges are char boundaries)
+    if (snapped) { bs = snap_bs; be = snap_be; }
+    else if (a.snap_chars && !is_match) {                 // snap to char boundaries inside the pre-token (its own edges are char boundaries)
         while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
         while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
     }
@@ -444,7 +464,7 @@ __device__ __forceinline__ void meta_one_token(const MetaArgs& a, int64_t p, int
         // trim stops at a start that lies one further left)
         if (a.trim1) a.trim1[o + j] = !took_one ? 0 : (((trail_sp && oe0 >= trail_sp) ? max(oe0 - trail_sp, os0) : oe0) != oe) ? 2 : 1;
     }
-    *(uint2*)(a.offsets + 2 * (size_t)(o + j)) = make_uint2(os, oe);
+    store_nt((uint2*)(a.offsets + 2 * (size_t)(o + j)), make_uint2(os, oe));
 }
 
 // One lane per PRE-TOKEN, its tokens in a loop: the shape of rounds 1-5, kept for the one configuration whose token edges depend on the
@@ -521,6 +541,7 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
 // (profiles/r6d_c2_sq_token_meta.json), seven million of them random 128-byte lines -- the token ends of the multi-token pre-tokens live
 // in a sparse array indexed by byte position (tmp_end), their claimants behind tok0 -> claim_pos, the bytes at a cut in the text.)
 constexpr int TM_TILE = 1024;
+constexpr uint32_t TM_CARRIED = 0xFFFFFFFFu;              // (in the tile's list: this pre-token's token ends ride in tok_b8)
 __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
     __shared__ uint32_t s_tokoff[TM_TILE + 1];
     __shared__ uint32_t s_start[TM_TILE + 1];
@@ -576,10 +597,15 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             const int64_t p = base + i;
             const uint32_t s = s_start[i];
             if (c > 1u) {
-                uint32_t se = s;                          // whose token ends: the pre-token's own, or the claimant's of its word
-                if (a.claim_pos && a.tmp_end) {
-                    const uint32_t t0 = a.tok0[p];
-                    if ((t0 & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[t0 & TOK_REF_MASK];
+                // its token ends: carried by its row -- a dense byte per token, next to the ids (tok_b8; a row of <= 4 tokens of a pre-token
+                // of <= 32 bytes: nearly all of them) -- or, the old way, in tmp_end: its own, or behind tok0 -> claim_pos its claimant's
+                uint32_t se = TM_CARRIED;
+                if (!a.tok_b8 || a.tok_b8[o + 1u] == 0u) {
+                    se = s;
+                    if (a.claim_pos && a.tmp_end) {
+                        const uint32_t t0 = a.tok0[p];
+                        if ((t0 & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[t0 & TOK_REF_MASK];
+                    }
                 }
                 const uint32_t k = atomicAdd(&s_nm, 1u);
                 s_mlist[k] = (uint16_t)i;
@@ -615,13 +641,21 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             const int64_t p = base + i, d = (int64_t)s_doc[i];
             const uint32_t o = s_tokoff[i], s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
             uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
-            if (a.tmp_end) {
+            bool snapped = false;
+            uint32_t bs = s, be = e;
+            if (se == TM_CARRIED) {                       // the boundary bytes in front of this token and of the next one
+                const uint32_t c = s_mbase[k + 1] - s_mbase[k];
+                const uint32_t v0 = j ? (uint32_t)a.tok_b8[o + j] : 0u, v1 = j + 1u < c ? (uint32_t)a.tok_b8[o + j + 1u] : 0u;
+                snapped = true;
+                if (j) { rel = v0 & 31u; bs = s + rel - b8_back(v0); }
+                if (j + 1u < c) { rel_end = v1 & 31u; be = s + rel_end + b8_fwd(v1); }
+            } else if (a.tmp_end) {
                 if (j) rel = a.tmp_end[se + j - 1u];
                 rel_end = a.tmp_end[se + j];
             }
             const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
             const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word);
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word, snapped, bs, be);
         }
     }
 }

@@ -69,6 +69,27 @@ __device__ __forceinline__ uint32_t row_count(const uint4& row) {
     return cf < ROW_CNT_MORE ? cf : row.z;
 }
 // up to four tokens held in registers; beyond four the caller has written ids 1.. to tmp_ids[s + j] itself
+// (round 6) Token ENDS in the row.  With offsets requested, a row of two to four tokens of a pre-token of <= 32 bytes carries the boundary
+// in front of token j (1..3) in the top byte of its word j (ids are < 2^24): position in the pre-token (1..31, five bits) and -- byte-level
+// tokens may cut a multi-byte char, whose whole range both neighbours then report (byte_level.rs:135-143) -- how far the token that
+// starts there snaps back and the one that ends there snaps forward (three bits: 0 = a char boundary; 1..6 = (back, fwd) of a cut at
+// byte k of a char of L bytes: (1,1) (1,2) (2,1) (1,3) (2,2) (3,1)).  The compaction hands the byte on, one per token, next to the ids
+// (tok_b8: a dense array), and k_token_meta reads its neighbours' instead of a sparse array indexed by byte position, a claimant's
+// place behind tok0 -> claim_pos and the text at every cut (kernels/output.hip).  0 = not carried: token_meta takes the old way.
+constexpr uint32_t ROW_B8_SHIFT = 24;
+__device__ __forceinline__ uint32_t row_boundary(const uint8_t* __restrict__ text, uint32_t s, uint32_t pos, bool snap) {
+    uint32_t code = 0u;
+    if (snap && (text[s + pos] & 0xC0u) == 0x80u) {       // (the pre-token starts and ends on char boundaries: the walks stay inside it)
+        uint32_t back = 1u, fwd = 1u;
+        while (back < 3u && (text[s + pos - back] & 0xC0u) == 0x80u) ++back;
+        while (fwd < 3u && (text[s + pos + fwd] & 0xC0u) == 0x80u) ++fwd;
+        code = back == 1u ? (fwd == 1u ? 1u : fwd == 2u ? 2u : 4u) : back == 2u ? (fwd == 1u ? 3u : 5u) : 6u;
+    }
+    return (pos | (code << 5)) << ROW_B8_SHIFT;
+}
+__device__ __forceinline__ uint32_t b8_back(uint32_t v) { const uint32_t c = v >> 5; return c == 0u ? 0u : (c == 3u || c == 5u) ? 2u : c == 6u ? 3u : 1u; }
+__device__ __forceinline__ uint32_t b8_fwd(uint32_t v) { const uint32_t c = v >> 5; return c == 0u ? 0u : (c == 2u || c == 5u) ? 2u : c == 4u ? 3u : 1u; }
+
 __device__ __forceinline__ uint4 make_row(uint32_t count, uint32_t s, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3) {
     return count <= 4u ? make_uint4(id0 | (count << ROW_CNT_SHIFT), id1, id2, id3) : make_uint4(id0 | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, count, 0u);
 }

@@ -78,12 +78,15 @@ __device__ __forceinline__ void wordpiece_body(const DevTables& t, const uint8_t
                 if (id != 0xFFFFFFFFu) { best_end = w; best_id = id; }
             }
             if (!best_end) { bad = true; break; }
+            // (with offsets, a word of <= 32 bytes: the boundary in front of piece j rides in the row's word j, results.hip row_boundary --
+            // pieces are whole chars, nothing snaps; a row of more than four pieces drops the bytes with its ids' move to tmp_ids)
+            const uint32_t bnd = (tmp_end && len <= 32u) ? (pos << ROW_B8_SHIFT) : 0u;
             if (j == 0) r0 = best_id;
-            else if (j == 1) r1 = best_id;
-            else if (j == 2) r2 = best_id;
-            else if (j == 3) r3 = best_id;
+            else if (j == 1) r1 = best_id | bnd;
+            else if (j == 2) r2 = best_id | bnd;
+            else if (j == 3) r3 = best_id | bnd;
             else {
-                if (j == 4) { tmp_ids[s + 1] = r1; tmp_ids[s + 2] = r2; tmp_ids[s + 3] = r3; }
+                if (j == 4) { tmp_ids[s + 1] = r1 & TOK_ID_MASK; tmp_ids[s + 2] = r2 & TOK_ID_MASK; tmp_ids[s + 3] = r3 & TOK_ID_MASK; }
                 tmp_ids[s + j] = best_id;
             }
             if (tmp_end) tmp_end[s + j] = best_end;
@@ -157,12 +160,13 @@ __device__ __forceinline__ void wordpiece_wide(const DevTables& t, const uint8_t
         while (valid && !bad && pos < len) {                              // (uniform within the group: pos, len and the shuffled answers are)
             const uint32_t e = (uint32_t)__shfl((int)best_end, (int)(gbase + pos), 64), id = (uint32_t)__shfl((int)best_id, (int)(gbase + pos), 64);
             if (!e) { bad = true; break; }
+            const uint32_t bnd = (tmp_end && len <= 32u) ? (pos << ROW_B8_SHIFT) : 0u;      // (as in the short-word kernel above)
             if (j == 0) r0 = id;
-            else if (j == 1) r1 = id;
-            else if (j == 2) r2 = id;
-            else if (j == 3) r3 = id;
+            else if (j == 1) r1 = id | bnd;
+            else if (j == 2) r2 = id | bnd;
+            else if (j == 3) r3 = id | bnd;
             else if (p == 0u) {
-                if (j == 4) { tmp_ids[s + 1] = r1; tmp_ids[s + 2] = r2; tmp_ids[s + 3] = r3; }
+                if (j == 4) { tmp_ids[s + 1] = r1 & TOK_ID_MASK; tmp_ids[s + 2] = r2 & TOK_ID_MASK; tmp_ids[s + 3] = r3 & TOK_ID_MASK; }
                 tmp_ids[s + j] = id;
             }
             if (tmp_end && p == 0u) tmp_end[s + j] = e;
