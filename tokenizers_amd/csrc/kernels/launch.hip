@@ -173,8 +173,16 @@ void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, 
 }
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     // (char_id: BPE over characters without an unk_token -- token edges depend on the tokens in front of them: the sequential shape)
-    if (a.char_id) hipLaunchKernelGGL(k_token_meta_seq, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_token_meta, dim3(grid), dim3(256), 0, st, a);
+    if (a.char_id) { hipLaunchKernelGGL(k_token_meta_seq, dim3(grid), dim3(256), 0, st, a); return; }
+    // the grid: what is RESIDENT at once -- a workgroup walks its tiles in a loop whose every step is a chain of dependent round trips, so
+    // the kernel lasts as long as the workgroup with the most tiles: 2,048 workgroups on a chip that holds 1,536 of them ran a second,
+    // half-empty round (profiles/r6j_c2_sq_summary_byte.json)
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta, 256, 0) != hipSuccess || n < 1) n = 4;
+        return std::min(n, 8);
+    }();
+    hipLaunchKernelGGL(k_token_meta, dim3(std::max(1, grid / 8) * per_cu), dim3(256), 0, st, a);
 }
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid) {

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
 // in a sparse array indexed by byte position (tmp_end), their claimants behind tok0 -> claim_pos, the bytes at a cut in the text.)
 constexpr int TM_TILE = 1024;
 constexpr uint32_t TM_CARRIED = 0xFFFFFFFFu;              // (in the tile's list: this pre-token's token ends ride in tok_b8)
-__global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
+__global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (six wavefronts a SIMD -- six workgroups a CU, what 26 KB of LDS each allow: <= 80 VGPRs)
     __shared__ uint32_t s_tokoff[TM_TILE + 1];
     __shared__ uint32_t s_start[TM_TILE + 1];
     __shared__ uint32_t s_end[TM_TILE];
@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * TM_TILE;
         const int np = (int)min((int64_t)TM_TILE, P - base);
+        const int64_t d0 = (int64_t)a.chunk_lo[base / a.chunk];      // (asked for first: the documents below wait for it alone, not for the tile's loads as well)
         __syncthreads();                                  // (the previous tile's readers are done)
         for (int i = tid; i <= np; i += 256) {
             const int64_t p = base + i;
@@ -570,7 +571,6 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
         __syncthreads();
         // documents from the first one of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with doc_pt[d] >= c * chunk):
         // the ones in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
-        const int64_t d0 = (int64_t)a.chunk_lo[base / a.chunk];
         for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
             const int64_t r = (int64_t)a.doc_pt[d] - base;
             if (r >= np) break;
@@ -587,7 +587,23 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
         __syncthreads();
-        // ---- a lane's four pre-tokens: one token -> written here; several -> listed
+        // ---- a lane's four pre-tokens: one token -> written here; several -> listed.  What they need from memory -- the document's
+        // entries, or the first boundary byte -- is asked for first, for all four (the loop behind it is not unrolled: four copies of the
+        // token code took 126 VGPRs; a round trip per pre-token was four round trips a tile)
+        uint32_t ld0[4], ld1[4], ld2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ld0[q] = ld1[q] = ld2[q] = 0u;
+            const int i = tid + 256 * q;
+            if (i >= np) continue;
+            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o;
+            if (c == 1u) {
+                const int64_t d = (int64_t)s_doc[i];
+                ld0[q] = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(base + i - (int64_t)a.doc_pt[d]);
+                ld1[q] = (uint32_t)a.x_doc_off[d];
+                ld2[q] = (uint32_t)a.doc_off[d];
+            } else if (c > 1u && a.tok_b8) ld0[q] = a.tok_b8[o + 1u];
+        }
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             const int i = tid + 256 * q;
@@ -596,11 +612,12 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
             if (!c) continue;
             const int64_t p = base + i;
             const uint32_t s = s_start[i];
+            const uint32_t v0 = q == 0 ? ld0[0] : q == 1 ? ld0[1] : q == 2 ? ld0[2] : ld0[3];
             if (c > 1u) {
                 // its token ends: carried by its row -- a dense byte per token, next to the ids (tok_b8; a row of <= 4 tokens of a pre-token
                 // of <= 32 bytes: nearly all of them) -- or, the old way, in tmp_end: its own, or behind tok0 -> claim_pos its claimant's
                 uint32_t se = TM_CARRIED;
-                if (!a.tok_b8 || a.tok_b8[o + 1u] == 0u) {
+                if (v0 == 0u) {
                     se = s;
                     if (a.claim_pos && a.tmp_end) {
                         const uint32_t t0 = a.tok0[p];
@@ -614,10 +631,10 @@ __global__ __launch_bounds__(256) void k_token_meta(MetaArgs a) {
                 continue;
             }
             const uint32_t e = a.pt_end ? s_end[i] : s_start[i + 1];
-            const int64_t d = (int64_t)s_doc[i];
-            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
+            const uint32_t v1 = q == 0 ? ld1[0] : q == 1 ? ld1[1] : q == 2 ? ld1[2] : ld1[3];
+            const uint32_t v2 = q == 0 ? ld2[0] : q == 1 ? ld2[1] : q == 2 ? ld2[2] : ld2[3];
             const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            meta_one_token(a, p, d, s, e, is_match, o, 0u, 0u, e - s, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word);
+            meta_one_token(a, p, (int64_t)s_doc[i], s, e, is_match, o, 0u, 0u, e - s, v1, v2, v0);
         }
         __syncthreads();
         // ---- the listed pre-tokens' tokens, one a lane
