@@ -123,8 +123,8 @@ __device__ __forceinline__ uint32_t cp_load(const uint32_t* __restrict__ tok0, c
         if (c) {                                                                                              \
             const bool more = ((R).row[k].x >> ROW_CNT_SHIFT) == ROW_CNT_MORE;                                \
             const uint32_t keep_ = (RAW) ? 0xFFFFFFFFu : TOK_ID_MASK;                                         \
-            (DST)[(O)] = (R).row[k].x & ROW_ID_MASK;                                                          \
-            if (!(RAW) && (B8)) (B8)[(O)] = 0;                                                                \
+            (DST)[(O)] = ((R).row[k].x & ROW_ID_MASK) | ((RAW) && (B8) ? B8_FIRST << ROW_B8_SHIFT : 0u);      \
+            if (!(RAW) && (B8)) (B8)[(O)] = (uint8_t)B8_FIRST;                                                \
             if (!more) {                                                                                      \
                 if (c > 1) { (DST)[(O) + 1] = (R).row[k].y & keep_; if (!(RAW) && (B8)) (B8)[(O) + 1] = (uint8_t)((R).row[k].y >> ROW_B8_SHIFT); } \
                 if (c > 2) { (DST)[(O) + 2] = (R).row[k].z & keep_; if (!(RAW) && (B8)) (B8)[(O) + 2] = (uint8_t)((R).row[k].z >> ROW_B8_SHIFT); } \
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
         if (tot <= (uint32_t)CP_STAGE) {
             uint32_t o = ex;
             uint32_t* const dst = s_stage[b];
-            TKAMD_CP_SCATTER(dst, r, o, true, (uint8_t*)nullptr)
+            TKAMD_CP_SCATTER(dst, r, o, true, tok_b8)
         }
         tick(1);
     };
@@ -524,34 +524,40 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
     }
 }
 
-// Round 6's shape.  A workgroup takes tiles of TM_TILE consecutive pre-tokens: their token offsets, starts and ends go to LDS with coalesced
-// loads; the documents that start inside the tile are counted into its pre-tokens (the compaction's chunk_lo names the first of them: no
-// search) and a scan turns the counts into every pre-token's document.  Then
-//   * a lane takes four pre-tokens, 256 apart (neighbouring lanes hold neighbouring pre-tokens, whose tokens are neighbours in the output
-//     arrays).  Seven pre-tokens in eight are ONE token: its offsets are the pre-token's own edges -- no token ends to fetch, no char to
-//     snap to -- and leave at once.  A pre-token of several tokens only resolves whose token ends it reads (its own, or the claimant's
-//     of its word: tok0 -> claim_pos) and goes on the tile's list;
-//   * the tokens of the listed pre-tokens are dealt to the lanes one each (a scan over the list's counts, a binary search over at most a
-//     few hundred bases in LDS): the two dependent round trips a token of theirs costs -- its ends, then the bytes at a cut inside a
-//     char -- are paid once per 256 tokens, not once per token of the longest word a wavefront holds.
+// Round 6's shape.  A workgroup takes tiles of TM_TILE consecutive pre-tokens.  Into LDS, with coalesced loads: their token offsets, starts
+// and ends; the entries of the documents around them (first pre-token, start in both texts: a table of TM_DOCS documents from the one
+// the compaction's chunk_lo names -- no search); the tile's tokens' boundary bytes (tok_b8, dense per token next to the ids:
+// results.hip row_boundary; the byte of a pre-token's FIRST token is a marker the compaction puts there).  The documents that start
+// inside the tile are counted into its pre-tokens and a scan turns the counts into every pre-token's document.  Then A LANE PER TOKEN,
+// in output order: the tile's tokens are one dense range [T0, T1) of the output arrays, so every store of the kernel is a coalesced one,
+// and the loop reads nothing but LDS.  Which pre-token a token belongs to is a RANK: the markers make a bit mask over the tile's tokens
+// (a compare of sixteen bytes a lane, four lanes a mask word -- LDS atomics on one mask word from the 50 lanes whose pre-tokens share it
+// serialised: 0.09 ms of a 0.43 ms kernel, profiles/r6n_*), a scan over the mask's words gives the set bits in front of each, and token
+// t's pre-token is prefix[t / 64] + popcount(mask word below bit t).  (A tile with more tokens than the mask holds, or with a pre-token
+// of no token at all -- BPE over characters dropping every char of a word -- takes a binary search over the tile's token offsets and
+// reads its bytes from memory.)  Rows that carry no boundary bytes (pre-tokens of > 32 bytes or > 4 tokens) take the old way: tmp_end at
+// the pre-token's byte position, or behind tok0 -> claim_pos.
 // (Rounds 1-5: a lane per pre-token with its tokens in a loop and a twenty-step binary search over doc_pt each: 1.14 ms on C2's
-// 22.7 M tokens.  A lane per token, every token through the whole chain: 0.52 ms.  Four pre-tokens a lane with their tokens in a loop
-// again: 0.73 ms -- a wavefront ran the loop as often as its longest word has tokens.  This shape: 0.40 ms; the listed pre-tokens' ends and
-// bytes fetched stage by stage into LDS first: 0.48 ms.  profiles/r6[a-e]_c2_bench.json.  What bounds it: 9.5 M L2 misses a launch
-// (profiles/r6d_c2_sq_token_meta.json), seven million of them random 128-byte lines -- the token ends of the multi-token pre-tokens live
-// in a sparse array indexed by byte position (tmp_end), their claimants behind tok0 -> claim_pos, the bytes at a cut in the text.)
+// 22.7 M tokens.  A lane per token with a binary search over the tile's token offsets and every token through tmp_end: 0.52 ms.  Four
+// pre-tokens a lane with their tokens in a loop: 0.73 ms -- a wavefront ran the loop as often as its longest word has tokens.  Single-token
+// pre-tokens written by their lane, the others listed and dealt a token a lane: 0.40 ms, 0.39 with the boundary bytes dense, 0.29 with a
+// grid of what is resident (profiles/r6[a-k]_*): four dependent round trips a tile, and stores that left holes for the second phase to
+// fill -- 400 MB written for 272.)
 constexpr int TM_TILE = 1024;
-constexpr uint32_t TM_CARRIED = 0xFFFFFFFFu;              // (in the tile's list: this pre-token's token ends ride in tok_b8)
-__global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (six wavefronts a SIMD -- six workgroups a CU, what 26 KB of LDS each allow: <= 80 VGPRs)
+constexpr int TM_TOKCAP = 4096;                           // tokens of a tile the rank mask and the LDS copy of their bytes hold (four per pre-token)
+constexpr int TM_DOCS = 256;                              // documents of a tile whose entries sit in LDS
+__global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {
     __shared__ uint32_t s_tokoff[TM_TILE + 1];
     __shared__ uint32_t s_start[TM_TILE + 1];
     __shared__ uint32_t s_end[TM_TILE];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
-    __shared__ uint32_t s_mse[TM_TILE];                   // listed pre-token k: where its token ends are (tmp_end + this)
-    __shared__ uint32_t s_mbase[TM_TILE + 1];             // ... its token count, then (scanned) its first token among the list's
-    __shared__ uint16_t s_mlist[TM_TILE];                 // ... its index in the tile
+    __shared__ unsigned long long s_tmask[TM_TOKCAP / 64];    // bit t: token T0 + t is the first token of a pre-token
+    __shared__ uint32_t s_tpre[TM_TOKCAP / 64];           // set bits in front of word w
+    __shared__ __attribute__((aligned(16))) uint8_t s_b8[TM_TOKCAP + 16];
+    __shared__ uint32_t s_dpt[TM_DOCS], s_dxo[TM_DOCS], s_dod[TM_DOCS];   // document dbase + k: first pre-token, start in the x text, in the original
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_before, s_nm;
+    __shared__ uint32_t s_before, s_slow;
+    static_assert(TM_TOKCAP == 256 * 16, "sixteen boundary bytes a lane");
     const int64_t P = *a.n_pretok;
     const uint32_t n_tok = (uint32_t)*a.n_tok;
     const int tid = (int)threadIdx.x;
@@ -567,14 +573,45 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (si
             s_start[i] = a.pt_start[p];                   // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
             if (i < np) { s_doc[i] = 0u; if (a.pt_end) s_end[i] = a.pt_end[p]; }
         }
-        if (tid == 0) { s_before = 0u; s_nm = 0u; }
+        if (tid == 0) { s_before = 0u; s_slow = 0u; }
+        // documents from the one in front of the first of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with
+        // doc_pt[d] >= c * chunk -- the tile's first pre-tokens may belong to its predecessor): their entries go to the table; the ones
+        // in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
+        const int64_t dbase = d0 > 0 ? d0 - 1 : 0;
+        {
+            const int64_t d = dbase + tid;
+            if (d < a.n_docs) { s_dpt[tid] = a.doc_pt[d]; s_dxo[tid] = (uint32_t)a.x_doc_off[d]; s_dod[tid] = (uint32_t)a.doc_off[d]; }
+        }
         __syncthreads();
-        // documents from the first one of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with doc_pt[d] >= c * chunk):
-        // the ones in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
         for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
-            const int64_t r = (int64_t)a.doc_pt[d] - base;
+            const int64_t k = d - dbase;
+            const int64_t r = (int64_t)(k < TM_DOCS ? s_dpt[k] : a.doc_pt[d]) - base;
             if (r >= np) break;
             atomicAdd(r < 0 ? &s_before : &s_doc[r], 1u);
+        }
+        const uint32_t T0 = s_tokoff[0], nt = s_tokoff[np] - T0;
+        bool slow = nt > (uint32_t)TM_TOKCAP || !a.tok_b8;
+        if (!slow) {
+            // the tile's boundary bytes, sixteen a lane, and the mask of the FIRST markers among them (four lanes a word)
+            uint32_t bits = 0u;
+            if (16u * (uint32_t)tid < nt + 1u) {          // (+ 1: the byte behind the last token is looked at, not used)
+                const Unaligned16 v = *(const Unaligned16*)(a.tok_b8 + T0 + 16u * (uint32_t)tid);
+                *(uint4*)(s_b8 + 16 * tid) = make_uint4(v.a, v.b, v.c, v.d);
+                auto four = [](uint32_t w) -> uint32_t {  // bit k: byte k of w is B8_FIRST
+                    const uint32_t x = w ^ (B8_FIRST * 0x01010101u);
+                    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+                };
+                bits = four(v.a) | (four(v.b) << 4) | (four(v.c) << 8) | (four(v.d) << 12);
+                const uint32_t left = nt - min(nt, 16u * (uint32_t)tid);
+                if (left < 16u) bits &= (1u << left) - 1u;
+            }
+            unsigned long long m = (unsigned long long)bits << (16 * (tid & 3));
+            m |= __shfl_xor(m, 1, 64);
+            m |= __shfl_xor(m, 2, 64);
+            if ((tid & 3) == 0) s_tmask[tid >> 2] = m;
+            for (int i = tid; i < np; i += 256)
+                if (s_tokoff[i + 1] == s_tokoff[i]) s_slow = 1u;      // (a pre-token of no token: ranks do not count it)
         }
         __syncthreads();
         {   // inclusive scan over the tile, four pre-tokens a lane: the document of pre-token i = the last d with doc_pt[d] <= base + i
@@ -586,93 +623,59 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {      // (si
 #pragma unroll
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
-        __syncthreads();
-        // ---- a lane's four pre-tokens: one token -> written here; several -> listed.  What they need from memory -- the document's
-        // entries, or the first boundary byte -- is asked for first, for all four (the loop behind it is not unrolled: four copies of the
-        // token code took 126 VGPRs; a round trip per pre-token was four round trips a tile)
-        uint32_t ld0[4], ld1[4], ld2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ld0[q] = ld1[q] = ld2[q] = 0u;
-            const int i = tid + 256 * q;
-            if (i >= np) continue;
-            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o;
-            if (c == 1u) {
-                const int64_t d = (int64_t)s_doc[i];
-                ld0[q] = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(base + i - (int64_t)a.doc_pt[d]);
-                ld1[q] = (uint32_t)a.x_doc_off[d];
-                ld2[q] = (uint32_t)a.doc_off[d];
-            } else if (c > 1u && a.tok_b8) ld0[q] = a.tok_b8[o + 1u];
+        slow = slow || s_slow != 0u;
+        if (!slow) {                                      // (workgroup-uniform) set bits in front of every mask word
+            uint32_t tot;
+            const uint32_t ex = block256_excl_scan(tid < TM_TOKCAP / 64 ? (uint32_t)__popcll(s_tmask[tid]) : 0u, s_scan, &tot);
+            if (tid < TM_TOKCAP / 64) s_tpre[tid] = ex;
         }
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            const int i = tid + 256 * q;
-            if (i >= np) break;
-            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o;
-            if (!c) continue;
-            const int64_t p = base + i;
-            const uint32_t s = s_start[i];
-            const uint32_t v0 = q == 0 ? ld0[0] : q == 1 ? ld0[1] : q == 2 ? ld0[2] : ld0[3];
-            if (c > 1u) {
-                // its token ends: carried by its row -- a dense byte per token, next to the ids (tok_b8; a row of <= 4 tokens of a pre-token
-                // of <= 32 bytes: nearly all of them) -- or, the old way, in tmp_end: its own, or behind tok0 -> claim_pos its claimant's
-                uint32_t se = TM_CARRIED;
-                if (v0 == 0u) {
-                    se = s;
-                    if (a.claim_pos && a.tmp_end) {
+        __syncthreads();
+        // ---- a lane per token, in output order
+        for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+            const uint32_t tt = T0 + t;
+            uint32_t v0 = 0u, v1 = 0u;                    // the boundary bytes in front of the token and behind it
+            int i;
+            if (!slow) {
+                const uint32_t w = t >> 6;
+                i = (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1;
+                v0 = s_b8[t]; v1 = s_b8[t + 1u];
+            } else {
+                if (a.tok_b8) { v0 = a.tok_b8[tt]; v1 = a.tok_b8[tt + 1u]; }
+                int lo = 0, hi = np;                      // the last i with tokoff[i] <= tt (its successor's lies beyond: it has tokens)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_tokoff[mid] <= tt) lo = mid; else hi = mid; }
+                i = lo;
+            }
+            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o, j = tt - o;
+            const uint32_t s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const int64_t p = base + i, d = (int64_t)s_doc[i];
+            const int64_t dk = d - dbase;
+            uint32_t word, xdoc, odoc;
+            if (dk < TM_DOCS) { word = (uint32_t)p - s_dpt[dk]; xdoc = s_dxo[dk]; odoc = s_dod[dk]; }
+            else { word = (uint32_t)(p - (int64_t)a.doc_pt[d]); xdoc = (uint32_t)a.x_doc_off[d]; odoc = (uint32_t)a.doc_off[d]; }
+            if (a.word_of_doc) word = a.word_of_doc[d];
+            uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
+            bool snapped = c == 1u;                       // (one token: the pre-token's own edges, char boundaries both)
+            uint32_t bs = s, be = e;
+            if (c > 1u && a.tok_b8) {
+                // its token ends: carried by its row -- a row of <= 4 tokens of a pre-token of <= 32 bytes: nearly all of them; the byte in
+                // front of token 1 says so -- or, the old way, in tmp_end: its own, or behind tok0 -> claim_pos its claimant's
+                const uint32_t carried = j == 1u ? v0 : j == 0u ? v1 : !slow ? (uint32_t)s_b8[o + 1u - T0] : (uint32_t)a.tok_b8[o + 1u];
+                if (carried) {
+                    snapped = true;
+                    if (j) { rel = v0 & 31u; bs = s + rel - b8_back(v0); }
+                    if (j + 1u < c) { rel_end = v1 & 31u; be = s + rel_end + b8_fwd(v1); }
+                } else if (a.tmp_end) {
+                    uint32_t se = s;
+                    if (a.claim_pos) {
                         const uint32_t t0 = a.tok0[p];
                         if ((t0 & TOK_SLOT) == TOK_SLOT) se = a.claim_pos[t0 & TOK_REF_MASK];
                     }
+                    if (j) rel = a.tmp_end[se + j - 1u];
+                    rel_end = a.tmp_end[se + j];
                 }
-                const uint32_t k = atomicAdd(&s_nm, 1u);
-                s_mlist[k] = (uint16_t)i;
-                s_mse[k] = se;
-                s_mbase[k] = c;
-                continue;
             }
-            const uint32_t e = a.pt_end ? s_end[i] : s_start[i + 1];
-            const uint32_t v1 = q == 0 ? ld1[0] : q == 1 ? ld1[1] : q == 2 ? ld1[2] : ld1[3];
-            const uint32_t v2 = q == 0 ? ld2[0] : q == 1 ? ld2[1] : q == 2 ? ld2[2] : ld2[3];
             const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            meta_one_token(a, p, (int64_t)s_doc[i], s, e, is_match, o, 0u, 0u, e - s, v1, v2, v0);
-        }
-        __syncthreads();
-        // ---- the listed pre-tokens' tokens, one a lane
-        const uint32_t nm = s_nm;
-        uint32_t mt;
-        {
-            uint32_t v[4], sum = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] = (4u * (uint32_t)tid + q < nm) ? s_mbase[4 * tid + q] : 0u; sum += v[q]; }
-            uint32_t run = block256_excl_scan(sum, s_scan, &mt);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { if (4u * (uint32_t)tid + q < nm) s_mbase[4 * tid + q] = run; run += v[q]; }
-            if (tid == 0) s_mbase[nm] = mt;
-        }
-        __syncthreads();
-        for (uint32_t t = (uint32_t)tid; t < mt; t += 256u) {
-            int lo = 0, hi = (int)nm;                     // the last k with mbase[k] <= t
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_mbase[mid] <= t) lo = mid; else hi = mid; }
-            const int k = lo, i = (int)s_mlist[k];
-            const uint32_t j = t - s_mbase[k], se = s_mse[k];
-            const int64_t p = base + i, d = (int64_t)s_doc[i];
-            const uint32_t o = s_tokoff[i], s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
-            uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
-            bool snapped = false;
-            uint32_t bs = s, be = e;
-            if (se == TM_CARRIED) {                       // the boundary bytes in front of this token and of the next one
-                const uint32_t c = s_mbase[k + 1] - s_mbase[k];
-                const uint32_t v0 = j ? (uint32_t)a.tok_b8[o + j] : 0u, v1 = j + 1u < c ? (uint32_t)a.tok_b8[o + j + 1u] : 0u;
-                snapped = true;
-                if (j) { rel = v0 & 31u; bs = s + rel - b8_back(v0); }
-                if (j + 1u < c) { rel_end = v1 & 31u; be = s + rel_end + b8_fwd(v1); }
-            } else if (a.tmp_end) {
-                if (j) rel = a.tmp_end[se + j - 1u];
-                rel_end = a.tmp_end[se + j];
-            }
-            const uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
-            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, (uint32_t)a.x_doc_off[d], (uint32_t)a.doc_off[d], word, snapped, bs, be);
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word, snapped && !is_match, bs, be);
         }
     }
 }

@@ -76,7 +76,9 @@ __device__ __forceinline__ uint32_t row_count(const uint4& row) {
 // byte k of a char of L bytes: (1,1) (1,2) (2,1) (1,3) (2,2) (3,1)).  The compaction hands the byte on, one per token, next to the ids
 // (tok_b8: a dense array), and k_token_meta reads its neighbours' instead of a sparse array indexed by byte position, a claimant's
 // place behind tok0 -> claim_pos and the text at every cut (kernels/output.hip).  0 = not carried: token_meta takes the old way.
+// The byte of token 0 is B8_FIRST, put there by the compaction: the set of them is token_meta's map from tokens to pre-tokens.
 constexpr uint32_t ROW_B8_SHIFT = 24;
+constexpr uint32_t B8_FIRST = 0xE0u;                  // the byte of a pre-token's FIRST token in tok_b8 (no boundary looks like it: position 0, code 7) -- the compaction's marker
 __device__ __forceinline__ uint32_t row_boundary(const uint8_t* __restrict__ text, uint32_t s, uint32_t pos, bool snap) {
     uint32_t code = 0u;
     if (snap && (text[s + pos] & 0xC0u) == 0x80u) {       // (the pre-token starts and ends on char boundaries: the walks stay inside it)

@@ -72,17 +72,27 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
             s = json.load(fh)
         b.sample_idx, b.sample = s["idx"], s["docs"]
         bs.append(b)
+    mode = os.environ.get("AB_OFFSETS", "none")             # byte | char: the with-offsets legs (offsets + word ids), gated like bench.py's
+    kw = {} if mode == "none" else {"offsets": mode, "word_ids": True}
+    nocheck = bool(os.environ.get("AB_NOCHECK"))           # an experimental build with a piece knocked out: times only, nothing is compared
     for b in bs:
         bench.check_against_oracle(tok, o, b, stream)
+        if kw and nocheck:
+            b.checksum = ()
+        elif kw:
+            fn = lambda bb: tok.encode_batch_device(bb.d_text.data_ptr(), bb.d_off.data_ptr(), bb.n_docs, bb.n_bytes, stream=stream, **kw)
+            b.checksum = bench.meta_checksum(bench.check_meta_against_oracle(fn, o, b, mode == "char"))
     sums = [list(b.checksum) for b in bs]
-    if ref_path and os.path.exists(ref_path):
+    if nocheck:
+        pass
+    elif ref_path and os.path.exists(ref_path):
         with open(ref_path) as fh:
             assert json.load(fh) == sums, "the result differs from the first variant's"
     elif ref_path:
         with open(ref_path, "w") as fh:
             json.dump(sums, fh)
     enc = lambda i: tok.encode_batch_device(bs[i % n_batches].d_text.data_ptr(), bs[i % n_batches].d_off.data_ptr(), bs[i % n_batches].n_docs,
-                                            bs[i % n_batches].n_bytes, stream=stream)
+                                            bs[i % n_batches].n_bytes, stream=stream, **kw)
     best = float("inf")
     for rep in range(3):
         for i in range(3):
@@ -94,7 +104,7 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
         r.sync()
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / steps)
-    assert list(bench.result_checksum(r)) == sums[(steps - 1) % n_batches], "a timed step's result differs from the gated one"
+    assert nocheck or list(bench.meta_checksum(r) if kw else bench.result_checksum(r)) == sums[(steps - 1) % n_batches], "a timed step's result differs from the gated one"
     tok.profile(True)
     for i in range(steps):
         enc(i)
@@ -108,7 +118,7 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
         for name, v in tok.debug_phases().items():
             if v[7]:
                 phases[name] = [round(x / v[7], 3) for x in v[:7]]
-    print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if (k.startswith("TKAMD_") or k == "AB_LIB") and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
+    print("AB_RESULT " + json.dumps({"env": {k: v for k, v in os.environ.items() if (k.startswith("TKAMD_") or k in ("AB_LIB", "AB_OFFSETS")) and k != "TKAMD_AB_CACHE"}, "cfg": cfg, "type_seed": ts,
                                      "gbps": round(nb / best / 1e9, 2), "ms": round(best * 1e3, 4), "sum_kernels_ms": round(sum(st.values()), 4),
                                      "kernels_ms": {k: v for k, v in sorted(st.items(), key=lambda kv: -kv[1]) if v >= 0.003}, "queues": tok.queue_sizes(),
                                      "phases": phases}), flush=True)
