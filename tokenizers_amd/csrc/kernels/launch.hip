@@ -179,10 +179,13 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     // half-empty round (profiles/r6j_c2_sq_summary_byte.json)
     static const int per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta, 256, 0) != hipSuccess || n < 1) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<false, true>, 256, 0) != hipSuccess || n < 1) n = 4;
         return std::min(n, 8);
     }();
-    hipLaunchKernelGGL(k_token_meta, dim3(std::max(1, grid / 8) * per_cu), dim3(256), 0, st, a);
+    const dim3 g(std::max(1, grid / 8) * per_cu);
+    const bool simple = !a.norig && !a.matchmask && !a.trim_offsets && !a.word_of_doc && !a.first_tok;
+    if (a.pt_end) { if (simple) hipLaunchKernelGGL((k_token_meta<true, true>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_token_meta<true, false>), g, dim3(256), 0, st, a); }
+    else { if (simple) hipLaunchKernelGGL((k_token_meta<false, true>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_token_meta<false, false>), g, dim3(256), 0, st, a); }
 }
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid) {

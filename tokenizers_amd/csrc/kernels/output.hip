@@ -546,15 +546,25 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
 constexpr int TM_TILE = 1024;
 constexpr int TM_TOKCAP = 4096;                           // tokens of a tile the rank mask and the LDS copy of their bytes hold (four per pre-token)
 constexpr int TM_DOCS = 256;                              // documents of a tile whose entries sit in LDS
-__global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {
-    __shared__ uint32_t s_tokoff[TM_TILE + 1];
-    __shared__ uint32_t s_start[TM_TILE + 1];
-    __shared__ uint32_t s_end[TM_TILE];
+// (software-pipelined: a tile's loads -- everything above -- are issued a tile AHEAD into registers, behind the parking of the current
+// tile's into LDS, and the three scalars they depend on -- the tile's first and last token, its first document -- two tiles ahead: the
+// two dependent round trips a tile cost, 0.09 ms of the kernel's 0.29 with nothing else to do, fly during the previous tile's work.
+// Loads are unconditional with clamped addresses: a load under a condition whose other branch fills the same registers is waited for
+// at once -- kernels/output.hip cp_load_tok0.)
+struct TmScal { uint32_t T0, T1, s_end; int64_t d0; };
+template <bool HAS_END> struct TmAhead { uint32_t tokoff[4], start[4], end[HAS_END ? 4 : 1], dpt, dxo, dod; Unaligned16 b8; };
+// SIMPLE: what most tokenizers are -- no normalizer's alignment map, no added-token matches, no trim_offsets, documents that are not the
+// words of pre-tokenized sequences: a token's offsets are its (snapped) edges minus its document's start, and the general path's flag
+// tests (a thousand scalar instructions in meta_one_token, taken or not) are not compiled in.
+template <bool HAS_END, bool SIMPLE>
+__global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {
+    __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
+    __shared__ uint32_t s_end[HAS_END ? TM_TILE : 1];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
     __shared__ unsigned long long s_tmask[TM_TOKCAP / 64];    // bit t: token T0 + t is the first token of a pre-token
     __shared__ uint32_t s_tpre[TM_TOKCAP / 64];           // set bits in front of word w
     __shared__ __attribute__((aligned(16))) uint8_t s_b8[TM_TOKCAP + 16];
-    __shared__ uint32_t s_dpt[TM_DOCS], s_dxo[TM_DOCS], s_dod[TM_DOCS];   // document dbase + k: first pre-token, start in the x text, in the original
+    __shared__ uint4 s_dtab[TM_DOCS];                     // document dbase + k: first pre-token, start in the x text, in the original, (char mode) lead bytes in front of it
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_before, s_slow;
     static_assert(TM_TOKCAP == 256 * 16, "sixteen boundary bytes a lane");
@@ -562,56 +572,94 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {
     const uint32_t n_tok = (uint32_t)*a.n_tok;
     const int tid = (int)threadIdx.x;
     const int64_t n_tiles = (P + TM_TILE - 1) / TM_TILE;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (n_tiles == 0) return;
+    const int64_t G = gridDim.x;
+    auto scal_of = [&](int64_t tile, TmScal& sc) {        // (a tile beyond the end: the last one's, never used)
+        const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
+        const int64_t pe = min(base + TM_TILE, P);
+        sc.T0 = a.pt_tokoff[base];
+        sc.T1 = pe < P ? a.pt_tokoff[pe] : n_tok;
+        sc.s_end = a.pt_start[pe];                        // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
+        sc.d0 = (int64_t)a.chunk_lo[base / a.chunk];      // chunk_lo[c]: the first d with doc_pt[d] >= c * chunk
+    };
+    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END>& h) {
+        const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t p = min(base + tid + 256 * q, P - 1);
+            h.tokoff[q] = a.pt_tokoff[p];
+            h.start[q] = a.pt_start[p];
+            if (HAS_END) h.end[q] = a.pt_end[p];
+        }
+        const int64_t d = min((sc.d0 > 0 ? sc.d0 - 1 : 0) + tid, a.n_docs - 1);
+        h.dpt = a.doc_pt[d];
+        h.dxo = ((const uint32_t*)a.x_doc_off)[2 * d];    // (the low words: a batch is < 4 GiB)
+        h.dod = ((const uint32_t*)a.doc_off)[2 * d];
+        if (a.tok_b8) h.b8 = *(const Unaligned16*)(a.tok_b8 + min(sc.T0 + 16u * (uint32_t)tid, n_tok));     // (readable 64 bytes beyond the tokens)
+        else h.b8 = Unaligned16{0u, 0u, 0u, 0u};
+    };
+    TmScal sc0, sc1;
+    TmAhead<HAS_END> h;
+    scal_of(blockIdx.x, sc0);
+    scal_of((int64_t)blockIdx.x + G, sc1);
+    ahead_of(blockIdx.x, sc0, h);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += G) {
         const int64_t base = tile * TM_TILE;
         const int np = (int)min((int64_t)TM_TILE, P - base);
-        const int64_t d0 = (int64_t)a.chunk_lo[base / a.chunk];      // (asked for first: the documents below wait for it alone, not for the tile's loads as well)
-        __syncthreads();                                  // (the previous tile's readers are done)
-        for (int i = tid; i <= np; i += 256) {
-            const int64_t p = base + i;
-            s_tokoff[i] = p < P ? a.pt_tokoff[p] : n_tok;
-            s_start[i] = a.pt_start[p];                   // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
-            if (i < np) { s_doc[i] = 0u; if (a.pt_end) s_end[i] = a.pt_end[p]; }
-        }
-        if (tid == 0) { s_before = 0u; s_slow = 0u; }
-        // documents from the one in front of the first of the compaction chunk that holds `base` on (chunk_lo[c]: the first d with
-        // doc_pt[d] >= c * chunk -- the tile's first pre-tokens may belong to its predecessor): their entries go to the table; the ones
-        // in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
+        TmScal sc2;
+        scal_of(tile + 2 * G, sc2);
+        const int64_t d0 = sc0.d0;
         const int64_t dbase = d0 > 0 ? d0 - 1 : 0;
-        {
-            const int64_t d = dbase + tid;
-            if (d < a.n_docs) { s_dpt[tid] = a.doc_pt[d]; s_dxo[tid] = (uint32_t)a.x_doc_off[d]; s_dod[tid] = (uint32_t)a.doc_off[d]; }
-        }
-        __syncthreads();
-        for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
-            const int64_t k = d - dbase;
-            const int64_t r = (int64_t)(k < TM_DOCS ? s_dpt[k] : a.doc_pt[d]) - base;
-            if (r >= np) break;
-            atomicAdd(r < 0 ? &s_before : &s_doc[r], 1u);
-        }
-        const uint32_t T0 = s_tokoff[0], nt = s_tokoff[np] - T0;
+        const uint32_t T0 = sc0.T0, nt = sc0.T1 - T0;
         bool slow = nt > (uint32_t)TM_TOKCAP || !a.tok_b8;
+        __syncthreads();                                  // (the previous tile's readers are done)
+        // ---- this tile's loads, asked for a tile ago: into LDS
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q;
+            s_ts[i] = make_uint2(h.tokoff[q], h.start[q]);    // (beyond np: the clamped loads' values, read by nobody)
+            if (HAS_END) s_end[i] = h.end[q];
+            s_doc[i] = 0u;
+        }
+        // documents from the one in front of the first of the compaction chunk that holds `base` on (the tile's first pre-tokens may belong
+        // to that one): their entries go to the table
+        s_dtab[tid] = make_uint4(h.dpt, h.dxo, h.dod, 0u);
+        // (char mode: the lead bytes in front of every listed document -- asked for in FRONT of the next tile's loads: loads return in order)
+        uint32_t dlead_now = 0u;
+        if (SIMPLE && a.char_mode && a.want_offsets && dbase + tid < a.n_docs) dlead_now = lead_rank(a.leadmask, a.lprefix, h.dod);
+        if (tid == 0) { s_before = 0u; s_slow = 0u; }
         if (!slow) {
             // the tile's boundary bytes, sixteen a lane, and the mask of the FIRST markers among them (four lanes a word)
-            uint32_t bits = 0u;
-            if (16u * (uint32_t)tid < nt + 1u) {          // (+ 1: the byte behind the last token is looked at, not used)
-                const Unaligned16 v = *(const Unaligned16*)(a.tok_b8 + T0 + 16u * (uint32_t)tid);
-                *(uint4*)(s_b8 + 16 * tid) = make_uint4(v.a, v.b, v.c, v.d);
-                auto four = [](uint32_t w) -> uint32_t {  // bit k: byte k of w is B8_FIRST
-                    const uint32_t x = w ^ (B8_FIRST * 0x01010101u);
-                    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
-                    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
-                };
-                bits = four(v.a) | (four(v.b) << 4) | (four(v.c) << 8) | (four(v.d) << 12);
-                const uint32_t left = nt - min(nt, 16u * (uint32_t)tid);
-                if (left < 16u) bits &= (1u << left) - 1u;
-            }
+            const Unaligned16 v = h.b8;
+            *(uint4*)(s_b8 + 16 * tid) = make_uint4(v.a, v.b, v.c, v.d);
+            auto four = [](uint32_t w) -> uint32_t {      // bit k: byte k of w is B8_FIRST
+                const uint32_t x = w ^ (B8_FIRST * 0x01010101u);
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+                return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+            };
+            uint32_t bits = four(v.a) | (four(v.b) << 4) | (four(v.c) << 8) | (four(v.d) << 12);
+            const uint32_t left = nt - min(nt, 16u * (uint32_t)tid);
+            if (left < 16u) bits &= (1u << left) - 1u;
             unsigned long long m = (unsigned long long)bits << (16 * (tid & 3));
             m |= __shfl_xor(m, 1, 64);
             m |= __shfl_xor(m, 2, 64);
             if ((tid & 3) == 0) s_tmask[tid >> 2] = m;
+        }
+        ahead_of(tile + G, sc1, h);                       // the next tile's loads: in flight from here to the top of the next iteration
+        __syncthreads();
+        if (tid == 0) s_ts[np] = make_uint2(sc0.T1, sc0.s_end);               // (behind the barrier: lane np & 255 wrote a clamped value there)
+        if (SIMPLE && a.char_mode && a.want_offsets) s_dtab[tid].w = dlead_now;
+        // the documents in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
+        for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
+            const int64_t k = d - dbase;
+            const int64_t r = (int64_t)(k < TM_DOCS ? s_dtab[k].x : a.doc_pt[d]) - base;
+            if (r >= np) break;
+            atomicAdd(r < 0 ? &s_before : &s_doc[r], 1u);
+        }
+        if (!slow) {
+            // (a pre-token of no token: ranks do not count it.  Lane np's pair uses the sentinel: by value, tid 0's store may not be there yet)
             for (int i = tid; i < np; i += 256)
-                if (s_tokoff[i + 1] == s_tokoff[i]) s_slow = 1u;      // (a pre-token of no token: ranks do not count it)
+                if ((i + 1 == np ? sc0.T1 : s_ts[i + 1].x) == s_ts[i].x) s_slow = 1u;
         }
         __syncthreads();
         {   // inclusive scan over the tile, four pre-tokens a lane: the document of pre-token i = the last d with doc_pt[d] <= base + i
@@ -642,17 +690,21 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {
             } else {
                 if (a.tok_b8) { v0 = a.tok_b8[tt]; v1 = a.tok_b8[tt + 1u]; }
                 int lo = 0, hi = np;                      // the last i with tokoff[i] <= tt (its successor's lies beyond: it has tokens)
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_tokoff[mid] <= tt) lo = mid; else hi = mid; }
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ts[mid].x <= tt) lo = mid; else hi = mid; }
                 i = lo;
             }
-            const uint32_t o = s_tokoff[i], c = s_tokoff[i + 1] - o, j = tt - o;
-            const uint32_t s = s_start[i], e = a.pt_end ? s_end[i] : s_start[i + 1];
+            const uint2 ts0 = s_ts[i], ts1 = s_ts[i + 1];
+            const uint32_t o = ts0.x, c = ts1.x - o, j = tt - o;
+            const uint32_t s = ts0.y, e = HAS_END ? s_end[i] : ts1.y;
             const int64_t p = base + i, d = (int64_t)s_doc[i];
             const int64_t dk = d - dbase;
-            uint32_t word, xdoc, odoc;
-            if (dk < TM_DOCS) { word = (uint32_t)p - s_dpt[dk]; xdoc = s_dxo[dk]; odoc = s_dod[dk]; }
-            else { word = (uint32_t)(p - (int64_t)a.doc_pt[d]); xdoc = (uint32_t)a.x_doc_off[d]; odoc = (uint32_t)a.doc_off[d]; }
-            if (a.word_of_doc) word = a.word_of_doc[d];
+            uint32_t word, xdoc, odoc, dlead = 0u;
+            if (dk < TM_DOCS) { const uint4 de = s_dtab[dk]; word = (uint32_t)p - de.x; xdoc = de.y; odoc = de.z; dlead = de.w; }
+            else {
+                word = (uint32_t)(p - (int64_t)a.doc_pt[d]); xdoc = (uint32_t)a.x_doc_off[d]; odoc = (uint32_t)a.doc_off[d];
+                if (SIMPLE && a.char_mode && a.want_offsets) dlead = lead_rank(a.leadmask, a.lprefix, odoc);
+            }
+            if (!SIMPLE && a.word_of_doc) word = a.word_of_doc[d];
             uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
             bool snapped = c == 1u;                       // (one token: the pre-token's own edges, char boundaries both)
             uint32_t bs = s, be = e;
@@ -674,8 +726,26 @@ __global__ __launch_bounds__(256, 6) void k_token_meta(MetaArgs a) {
                     rel_end = a.tmp_end[se + j];
                 }
             }
-            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word, snapped && !is_match, bs, be);
+            if (SIMPLE) {
+                if (a.want_words) store_nt(a.word_ids + tt, word);
+                if (a.want_offsets) {
+                    if (!snapped && a.snap_chars) {       // (a row without boundary bytes: the edges snap to char boundaries at the text)
+                        bs = s + rel; be = s + rel_end;
+                        while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
+                        while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
+                    } else if (!snapped) { bs = s + rel; be = s + rel_end; }
+                    uint32_t os = bs - xdoc, oe = be - xdoc;
+                    if (a.char_mode) {
+                        os = lead_rank(a.leadmask, a.lprefix, os + odoc) - dlead;
+                        oe = lead_rank(a.leadmask, a.lprefix, oe + odoc) - dlead;
+                    }
+                    store_nt((uint2*)(a.offsets + 2 * (size_t)tt), make_uint2(os, oe));
+                }
+            } else {
+                const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+                meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word, snapped && !is_match, bs, be);
+            }
         }
+        sc0 = sc1; sc1 = sc2;
     }
 }
