@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void k_token_meta_seq(MetaArgs a) {
 constexpr int TM_TILE = 1024;
 constexpr int TM_TOKCAP = 4096;                           // tokens of a tile the rank mask and the LDS copy of their bytes hold (four per pre-token)
 constexpr int TM_DOCS = 256;                              // documents of a tile whose entries sit in LDS
+constexpr int TM_EXC = 512;                               // tokens of a tile on the list of those that need memory
 // (software-pipelined: a tile's loads -- everything above -- are issued a tile AHEAD into registers, behind the parking of the current
 // tile's into LDS, and the three scalars they depend on -- the tile's first and last token, its first document -- two tiles ahead: the
 // two dependent round trips a tile cost, 0.09 ms of the kernel's 0.29 with nothing else to do, fly during the previous tile's work.
@@ -557,7 +558,7 @@ template <bool HAS_END> struct TmAhead { uint32_t tokoff[4], start[4], end[HAS_E
 // words of pre-tokenized sequences: a token's offsets are its (snapped) edges minus its document's start, and the general path's flag
 // tests (a thousand scalar instructions in meta_one_token, taken or not) are not compiled in.
 template <bool HAS_END, bool SIMPLE>
-__global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {
+__global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
     __shared__ uint32_t s_end[HAS_END ? TM_TILE : 1];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_b8[TM_TOKCAP + 16];
     __shared__ uint4 s_dtab[TM_DOCS];                     // document dbase + k: first pre-token, start in the x text, in the original, (char mode) lead bytes in front of it
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_before, s_slow;
+    __shared__ uint32_t s_before, s_slow, s_nexc;
+    __shared__ uint16_t s_exc[TM_EXC];                    // tokens of the tile that need memory (see the token loop)
     static_assert(TM_TOKCAP == 256 * 16, "sixteen boundary bytes a lane");
     const int64_t P = *a.n_pretok;
     const uint32_t n_tok = (uint32_t)*a.n_tok;
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {
         // (char mode: the lead bytes in front of every listed document -- asked for in FRONT of the next tile's loads: loads return in order)
         uint32_t dlead_now = 0u;
         if (SIMPLE && a.char_mode && a.want_offsets && dbase + tid < a.n_docs) dlead_now = lead_rank(a.leadmask, a.lprefix, h.dod);
-        if (tid == 0) { s_before = 0u; s_slow = 0u; }
+        if (tid == 0) { s_before = 0u; s_slow = 0u; s_nexc = 0u; }
         if (!slow) {
             // the tile's boundary bytes, sixteen a lane, and the mask of the FIRST markers among them (four lanes a word)
             const Unaligned16 v = h.b8;
@@ -678,40 +680,28 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {
             if (tid < TM_TOKCAP / 64) s_tpre[tid] = ex;
         }
         __syncthreads();
-        // ---- a lane per token, in output order
-        for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+        // ---- a lane per token, in output order.  The loop of the tokens whose every need is in LDS holds NO load from memory, on any
+        // branch: a load that fills the registers an LDS read fills elsewhere makes the compiler wait for everything in flight in front of
+        // that read (s_waitcnt vmcnt(0): the next tile's loads, and the last iteration's STORES -- a round trip an iteration, 0.26 ms for
+        // this kernel against 0.2x).  The tokens that need memory -- a row without boundary bytes, a document beyond the table -- go on
+        // a list and through `general` behind the loop; so does every token of a tile without a rank mask.
+        auto general = [&](uint32_t t, int i) {
             const uint32_t tt = T0 + t;
             uint32_t v0 = 0u, v1 = 0u;                    // the boundary bytes in front of the token and behind it
-            int i;
-            if (!slow) {
-                const uint32_t w = t >> 6;
-                i = (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1;
-                v0 = s_b8[t]; v1 = s_b8[t + 1u];
-            } else {
-                if (a.tok_b8) { v0 = a.tok_b8[tt]; v1 = a.tok_b8[tt + 1u]; }
-                int lo = 0, hi = np;                      // the last i with tokoff[i] <= tt (its successor's lies beyond: it has tokens)
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ts[mid].x <= tt) lo = mid; else hi = mid; }
-                i = lo;
-            }
+            if (a.tok_b8) { v0 = a.tok_b8[tt]; v1 = a.tok_b8[tt + 1u]; }
             const uint2 ts0 = s_ts[i], ts1 = s_ts[i + 1];
             const uint32_t o = ts0.x, c = ts1.x - o, j = tt - o;
             const uint32_t s = ts0.y, e = HAS_END ? s_end[i] : ts1.y;
             const int64_t p = base + i, d = (int64_t)s_doc[i];
-            const int64_t dk = d - dbase;
-            uint32_t word, xdoc, odoc, dlead = 0u;
-            if (dk < TM_DOCS) { const uint4 de = s_dtab[dk]; word = (uint32_t)p - de.x; xdoc = de.y; odoc = de.z; dlead = de.w; }
-            else {
-                word = (uint32_t)(p - (int64_t)a.doc_pt[d]); xdoc = (uint32_t)a.x_doc_off[d]; odoc = (uint32_t)a.doc_off[d];
-                if (SIMPLE && a.char_mode && a.want_offsets) dlead = lead_rank(a.leadmask, a.lprefix, odoc);
-            }
-            if (!SIMPLE && a.word_of_doc) word = a.word_of_doc[d];
+            uint32_t word = a.word_of_doc ? a.word_of_doc[d] : (uint32_t)(p - (int64_t)a.doc_pt[d]);
+            const uint32_t xdoc = (uint32_t)a.x_doc_off[d], odoc = (uint32_t)a.doc_off[d];
             uint32_t rel = 0u, rel_end = e - s;           // (no token ends without offsets: word ids only)
             bool snapped = c == 1u;                       // (one token: the pre-token's own edges, char boundaries both)
             uint32_t bs = s, be = e;
             if (c > 1u && a.tok_b8) {
-                // its token ends: carried by its row -- a row of <= 4 tokens of a pre-token of <= 32 bytes: nearly all of them; the byte in
-                // front of token 1 says so -- or, the old way, in tmp_end: its own, or behind tok0 -> claim_pos its claimant's
-                const uint32_t carried = j == 1u ? v0 : j == 0u ? v1 : !slow ? (uint32_t)s_b8[o + 1u - T0] : (uint32_t)a.tok_b8[o + 1u];
+                // its token ends: carried by its row -- the byte in front of token 1 says so -- or, the old way, in tmp_end: its own, or
+                // behind tok0 -> claim_pos its claimant's
+                const uint32_t carried = j == 1u ? v0 : j == 0u ? v1 : (uint32_t)a.tok_b8[o + 1u];
                 if (carried) {
                     snapped = true;
                     if (j) { rel = v0 & 31u; bs = s + rel - b8_back(v0); }
@@ -726,24 +716,67 @@ __global__ __launch_bounds__(256, 5) void k_token_meta(MetaArgs a) {
                     rel_end = a.tmp_end[se + j];
                 }
             }
-            if (SIMPLE) {
-                if (a.want_words) store_nt(a.word_ids + tt, word);
-                if (a.want_offsets) {
-                    if (!snapped && a.snap_chars) {       // (a row without boundary bytes: the edges snap to char boundaries at the text)
-                        bs = s + rel; be = s + rel_end;
-                        while (bs > s && (a.x_text[bs] & 0xC0u) == 0x80u) --bs;
-                        while (be < e && (a.x_text[be] & 0xC0u) == 0x80u) ++be;
-                    } else if (!snapped) { bs = s + rel; be = s + rel_end; }
-                    uint32_t os = bs - xdoc, oe = be - xdoc;
-                    if (a.char_mode) {
-                        os = lead_rank(a.leadmask, a.lprefix, os + odoc) - dlead;
-                        oe = lead_rank(a.leadmask, a.lprefix, oe + odoc) - dlead;
+            const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+            meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word, snapped && !is_match, bs, be);
+        };
+        if (slow) {                                       // (workgroup-uniform)
+            for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+                int lo = 0, hi = np;                      // the last i with tokoff[i] <= T0 + t (its successor's lies beyond: it has tokens)
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_ts[mid].x <= T0 + t) lo = mid; else hi = mid; }
+                general(t, lo);
+            }
+        } else {
+            for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+                const uint32_t tt = T0 + t, w = t >> 6;
+                const int i = (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1;
+                const uint32_t v0 = s_b8[t], v1 = s_b8[t + 1u];
+                const uint2 ts0 = s_ts[i], ts1 = s_ts[i + 1];
+                const uint32_t o = ts0.x, c = ts1.x - o, j = tt - o;
+                const uint32_t s = ts0.y, e = HAS_END ? s_end[i] : ts1.y;
+                const int64_t p = base + i, d = (int64_t)s_doc[i];
+                const int64_t dk = d - dbase;
+                const uint32_t carried = c == 1u ? 1u : j == 1u ? v0 : j == 0u ? v1 : (uint32_t)s_b8[o + 1u - T0];
+                if (dk >= TM_DOCS || !carried) {
+                    const uint32_t k = atomicAdd(&s_nexc, 1u);
+                    if (k < (uint32_t)TM_EXC) s_exc[k] = (uint16_t)t;
+                    continue;
+                }
+                const uint4 de = s_dtab[dk];
+                const uint32_t word = (uint32_t)p - de.x, xdoc = de.y, odoc = de.z;
+                uint32_t rel = 0u, rel_end = e - s, bs = s, be = e;
+                if (c > 1u) {
+                    if (j) { rel = v0 & 31u; bs = s + rel - b8_back(v0); }
+                    if (j + 1u < c) { rel_end = v1 & 31u; be = s + rel_end + b8_fwd(v1); }
+                }
+                if (SIMPLE) {
+                    if (a.want_words) store_nt(a.word_ids + tt, word);
+                    if (a.want_offsets) {
+                        uint32_t os = bs - xdoc, oe = be - xdoc;
+                        if (a.char_mode) {
+                            os = lead_rank(a.leadmask, a.lprefix, os + odoc) - de.w;
+                            oe = lead_rank(a.leadmask, a.lprefix, oe + odoc) - de.w;
+                        }
+                        store_nt((uint2*)(a.offsets + 2 * (size_t)tt), make_uint2(os, oe));
                     }
-                    store_nt((uint2*)(a.offsets + 2 * (size_t)tt), make_uint2(os, oe));
+                } else {
+                    const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
+                    meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, a.word_of_doc ? a.word_of_doc[d] : word, !is_match, bs, be);
+                }
+            }
+            __syncthreads();
+            const uint32_t nexc = s_nexc;
+            if (nexc > (uint32_t)TM_EXC) {                // (more than the list holds: every token asked again)
+                for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+                    const uint32_t w = t >> 6;
+                    const int i = (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1;
+                    const uint32_t o = s_ts[i].x, c = s_ts[i + 1].x - o;
+                    if ((int64_t)s_doc[i] - dbase >= TM_DOCS || (c > 1u && !s_b8[o + 1u - T0])) general(t, i);
                 }
             } else {
-                const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
-                meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, word, snapped && !is_match, bs, be);
+                for (uint32_t k = (uint32_t)tid; k < nexc; k += 256u) {
+                    const uint32_t t = s_exc[k], w = t >> 6;
+                    general(t, (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1);
+                }
             }
         }
         sc0 = sc1; sc1 = sc2;
