@@ -726,28 +726,28 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                 general(t, lo);
             }
         } else {
+            const uint32_t dbase32 = (uint32_t)dbase;
             for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+                // (branch-free up to the stores: every branch of a wavefront is a dozen scalar instructions whether taken or not)
                 const uint32_t tt = T0 + t, w = t >> 6;
                 const int i = (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1;
-                const uint32_t v0 = s_b8[t], v1 = s_b8[t + 1u];
+                const uint32_t b0 = s_b8[t], b1 = s_b8[t + 1u];
                 const uint2 ts0 = s_ts[i], ts1 = s_ts[i + 1];
                 const uint32_t o = ts0.x, c = ts1.x - o, j = tt - o;
                 const uint32_t s = ts0.y, e = HAS_END ? s_end[i] : ts1.y;
-                const int64_t p = base + i, d = (int64_t)s_doc[i];
-                const int64_t dk = d - dbase;
-                const uint32_t carried = c == 1u ? 1u : j == 1u ? v0 : j == 0u ? v1 : (uint32_t)s_b8[o + 1u - T0];
-                if (dk >= TM_DOCS || !carried) {
+                const uint32_t dk = s_doc[i] - dbase32;
+                const uint32_t carried = (uint32_t)s_b8[o + 1u - T0] | (c == 1u ? 1u : 0u);      // (the byte in front of token 1: 0 = a row without boundary bytes)
+                if (dk >= (uint32_t)TM_DOCS || !carried) {
                     const uint32_t k = atomicAdd(&s_nexc, 1u);
                     if (k < (uint32_t)TM_EXC) s_exc[k] = (uint16_t)t;
                     continue;
                 }
                 const uint4 de = s_dtab[dk];
-                const uint32_t word = (uint32_t)p - de.x, xdoc = de.y, odoc = de.z;
-                uint32_t rel = 0u, rel_end = e - s, bs = s, be = e;
-                if (c > 1u) {
-                    if (j) { rel = v0 & 31u; bs = s + rel - b8_back(v0); }
-                    if (j + 1u < c) { rel_end = v1 & 31u; be = s + rel_end + b8_fwd(v1); }
-                }
+                const uint32_t word = (uint32_t)(base + i) - de.x, xdoc = de.y, odoc = de.z;
+                // the boundary in front of the token (none in front of token 0) and behind it (none behind the last one: the pre-token's end)
+                const uint32_t v0 = j ? b0 : 0u, v1 = j + 1u < c ? b1 : 0u;
+                const uint32_t rel = v0 & 31u, rel_end = v1 ? (v1 & 31u) : e - s;
+                const uint32_t bs = s + rel - b8_back(v0), be = s + rel_end + b8_fwd(v1);
                 if (SIMPLE) {
                     if (a.want_words) store_nt(a.word_ids + tt, word);
                     if (a.want_offsets) {
@@ -759,6 +759,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                         store_nt((uint2*)(a.offsets + 2 * (size_t)tt), make_uint2(os, oe));
                     }
                 } else {
+                    const int64_t p = base + i, d = (int64_t)dk + dbase;
                     const bool is_match = a.matchmask && a.tmp_end && ((a.matchmask[s >> 6] >> (s & 63)) & 1ull);
                     meta_one_token(a, p, d, s, e, is_match, o, j, rel, rel_end, xdoc, odoc, a.word_of_doc ? a.word_of_doc[d] : word, !is_match, bs, be);
                 }

@@ -89,8 +89,9 @@ __device__ __forceinline__ uint32_t row_boundary(const uint8_t* __restrict__ tex
     }
     return (pos | (code << 5)) << ROW_B8_SHIFT;
 }
-__device__ __forceinline__ uint32_t b8_back(uint32_t v) { const uint32_t c = v >> 5; return c == 0u ? 0u : (c == 3u || c == 5u) ? 2u : c == 6u ? 3u : 1u; }
-__device__ __forceinline__ uint32_t b8_fwd(uint32_t v) { const uint32_t c = v >> 5; return c == 0u ? 0u : (c == 2u || c == 5u) ? 2u : c == 4u ? 3u : 1u; }
+// (two bits a code, looked up in a constant: code 0 -> 0; (back, fwd) of codes 1..6 as listed above)
+__device__ __forceinline__ uint32_t b8_back(uint32_t v) { return (0x3994u >> ((v >> 5) * 2u)) & 3u; }
+__device__ __forceinline__ uint32_t b8_fwd(uint32_t v) { return (0x1B64u >> ((v >> 5) * 2u)) & 3u; }
 
 __device__ __forceinline__ uint4 make_row(uint32_t count, uint32_t s, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3) {
     return count <= 4u ? make_uint4(id0 | (count << ROW_CNT_SHIFT), id1, id2, id3) : make_uint4(id0 | (ROW_CNT_MORE << ROW_CNT_SHIFT), s, count, 0u);
