@@ -76,7 +76,11 @@ def child(cfg, ts, n, n_batches, steps, ref_path):
     kw = {} if mode == "none" else {"offsets": mode, "word_ids": True}
     nocheck = bool(os.environ.get("AB_NOCHECK"))           # an experimental build with a piece knocked out: times only, nothing is compared
     for b in bs:
-        bench.check_against_oracle(tok, o, b, stream)
+        if nocheck:
+            r0 = tok.encode_batch_device(b.d_text.data_ptr(), b.d_off.data_ptr(), b.n_docs, b.n_bytes, stream=stream).sync()
+            b.n_tok, b.n_pretok, b.checksum = r0.n_tokens, r0.n_pretokens, ()
+        else:
+            bench.check_against_oracle(tok, o, b, stream)
         if kw and nocheck:
             b.checksum = ()
         elif kw:
