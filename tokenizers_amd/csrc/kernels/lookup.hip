@@ -136,36 +136,43 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
     // tile k and have long arrived when tile k+1 starts, so no phase of a tile begins with a memory round trip.
     constexpr int LU_SLACK_CHUNKS = LU_TEXT_SLACK / 16;
     static_assert((LU_TILE + LU_TEXT_SLACK) / 16 == 2 * LU_NT + LU_SLACK_CHUNKS, "two 16-byte text chunks per lane (+ the slack chunks of the first lanes)");
-    const int64_t n_words_host = (a.n_bytes_host >> 6) + 1;          // words of the document / start masks
     static_assert(LU_NT == 2 * LU_TILE_WORDS, "two lanes per mask word");
     unsigned long long pf_ms = 0ull, pf_me = 0ull, pf_scan = 0ull;
     uint32_t pf_wp = 0u, pf_first = 0u;
     // (80 VGPRs: the masks are kept a tile ahead, the text is loaded when the tile starts -- the other two workgroups of the CU cover that
     // round trip)
+    // (lane offsets in 32 bits against uniform 64-bit bases: the 64-bit per-lane addresses and bounds of rounds 3-5 were loop invariants the
+    // compiler kept in registers it did not have -- 80 VGPRs, three spilled pairs -- and a reload from scratch is a vector-memory operation:
+    // the s_waitcnt vmcnt(0) behind it also waited for the text load just issued, so a tile's two text loads went out one round trip
+    // after the other)
     auto load_text = [&](int64_t tile, Unaligned16& x0, Unaligned16& x1, Unaligned16& xs) {
         x0 = x1 = xs = Unaligned16{0u, 0u, 0u, 0u};
         if (tile >= n_tiles) return;
         const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
-        const int64_t g0 = t0 + 16 * (int64_t)tid, g1 = g0 + 16 * (int64_t)LU_NT;
-        const int64_t gs = t0 + 16 * (int64_t)(2 * LU_NT + tid);
+        const uint8_t* const tb = a.text + t0;                       // (uniform)
+        const uint32_t room = (uint32_t)min(readable - t0, (int64_t)(LU_TILE + LU_TEXT_SLACK + 64));      // readable bytes from t0 on, as far as this tile cares
+        const uint32_t g0 = 16u * (uint32_t)tid, g1 = g0 + 16u * (uint32_t)LU_NT, gs = 16u * (uint32_t)(2 * LU_NT + tid);
         // (the tile's text, its masks and the tok0 words are read / written once: non-temporal accesses, kernels.hip -- level here, 0.2279
         // against 0.229 ms, 3 % in the compaction; profiles/r4m_ab_c2.txt)
-        if (g0 + 16 <= readable) x0 = load_nt16(a.text + g0);
-        if (g1 + 16 <= readable) x1 = load_nt16(a.text + g1);
-        if (tid < LU_SLACK_CHUNKS && gs + 16 <= readable) xs = load_nt16(a.text + gs);
+        if (g0 + 16u <= room) x0 = load_nt16(tb + g0);
+        if (g1 + 16u <= room) x1 = load_nt16(tb + g1);
+        if (tid < LU_SLACK_CHUNKS && gs + 16u <= room) xs = load_nt16(tb + gs);
     };
     auto prefetch = [&](int64_t tile) {
         pf_ms = pf_me = pf_scan = 0ull;
         pf_wp = pf_first = 0u;
         if (tile >= n_tiles) return;
         const int64_t w0 = tile * LU_TILE_WORDS;
-        const int64_t w = w0 + hword;
-        if (w < total_words) { pf_ms = load_nt(a.startmask + w); pf_wp = load_nt(a.wprefix + w); }
-        if (has_end && w < end_words) pf_me = load_nt(a.endmask + w);
-        pf_first = a.wprefix[w0];
+        // (uniform bases, 32-bit lane indices and bounds: see load_text)
+        const int words_left = (int)min(total_words - w0, (int64_t)(LU_TILE_WORDS + 64)), ends_left = (int)min(end_words - w0, (int64_t)(LU_TILE_WORDS + 64));
+        const unsigned long long* const sm0 = a.startmask + w0;
+        const uint32_t* const wp0 = a.wprefix + w0;
+        if (hword < words_left) { pf_ms = load_nt(sm0 + hword); pf_wp = load_nt(wp0 + hword); }
+        if (has_end && hword < ends_left) pf_me = load_nt(a.endmask + w0 + hword);
+        pf_first = wp0[0];
         if (wave == 0) {
-            const int64_t ws = w0 + LU_TILE_WORDS + lane;
-            if (ws < (has_end ? end_words : total_words)) pf_scan = (has_end ? a.endmask : a.startmask)[ws];
+            const int ws = LU_TILE_WORDS + lane;
+            if (ws < (has_end ? ends_left : words_left)) pf_scan = (has_end ? a.endmask + w0 : sm0)[ws];
         }
     };
     prefetch(blockIdx.x);
@@ -175,7 +182,17 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
         __syncthreads();                                             // previous tile's LDS use is over
         tick(LU_PH_PASS3);
         if (tid == 0 && s_claims_on && s_seen >= CLAIM_ADAPT_MIN && s_shared * 8u < s_seen) s_claims_on = 0u;   // (read behind the next barrier)
-        // ---- 1. text tile -> LDS (loaded now, dropped into LDS behind the mask work below) ----
+        // ---- 1. the tile's mask words (loaded a tile ago): local rank of each word's first start ----
+        // (in front of the text loads: what reads a register a load of the LAST tile filled waits for every load issued since)
+        const unsigned long long ms = pf_ms, me = pf_me;
+        uint32_t rbase = 0xFFFFFFFFu;
+        {
+            const int wl = (int)min(total_words - w0, (int64_t)(LU_TILE_WORDS + 64));       // words of the text from w0 on (uniform; 32-bit lane compares)
+            if (hword < wl) rbase = pf_wp - pf_first;
+            if (tid == 0) s_pbase = pf_first;
+            if (half && hword < wl && (hword == wl - 1 || hword == LU_TILE_WORDS - 1)) s_n = rbase + (uint32_t)__popcll(ms);
+        }
+        // ---- 2. text tile -> LDS (loaded now, dropped into LDS behind the work below) ----
         Unaligned16 tx0, tx1, txs;
         load_text(tile, tx0, tx1, txs);
         auto stage_text = [&]() {
@@ -183,15 +200,6 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
             ((uint4*)s_text32)[tid + LU_NT] = make_uint4(tx1.a, tx1.b, tx1.c, tx1.d);
             if (tid < LU_SLACK_CHUNKS) ((uint4*)s_text32)[2 * LU_NT + tid] = make_uint4(txs.a, txs.b, txs.c, txs.d);
         };
-        // ---- 2. the tile's mask words: local rank of each word's first start ----
-        const unsigned long long ms = pf_ms, me = pf_me;
-        uint32_t rbase = 0xFFFFFFFFu;
-        {
-            const int64_t w = w0 + hword;
-            if (w < total_words) rbase = pf_wp - pf_first;
-            if (tid == 0) s_pbase = pf_first;
-            if (half && (w == total_words - 1 || (hword == LU_TILE_WORDS - 1 && w < total_words))) s_n = rbase + (uint32_t)__popcll(ms);
-        }
         // end of the tile's LAST pre-token when it lies beyond the tile: the next start (or end bit) after the tile -- almost always in
         // the 64 prefetched words behind it; otherwise wavefront 0 walks the mask on
         if (wave == 0) {
