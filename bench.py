@@ -590,23 +590,6 @@ def main() -> None:
                         "`calls` back-to-back calls rotating over the timed batches (best single call next to it).  Caller buffers from "
                         "tkamd_pinned_alloc; `_pageable`: ordinary (numpy) memory"}
         assert res.n_tokens == batches[0].n_tok
-        try:        # the same calls handing the ids back as 16-bit values (TKAMD_IDS_U16: GPT-2-sized vocabularies; half the D2H bytes) -- like for
-            # like: the same page-locked caller buffers, the same rotation, the same number of calls as `encode_packed_ms` above
-            pinned = [(ta.pinned_copy(bk.h_buf), ta.pinned_copy(bk.h_off)) for bk in batches]
-            r16 = tok.encode_packed(*pinned[0], ids_dtype="uint16")
-            t16 = time.perf_counter()
-            for i in range(n_host):
-                r16 = tok.encode_packed(*pinned[i % n_batches], ids_dtype="uint16")
-            t16 = (time.perf_counter() - t16) / n_host
-            ref16 = tok.encode_packed(*pinned[(n_host - 1) % n_batches])
-            del pinned
-            if r16.n_tokens == ref16.n_tokens and bool((r16.ids == ref16.ids.astype(np.uint16)).all()):
-                host["encode_packed_ids_u16_ms"] = round(t16 * 1e3, 2)
-                host["gbps_pcie_inclusive_ids_u16"] = round(host_bytes / n_host / t16 / 1e9, 3)
-            else:
-                host["encode_packed_ids_u16_error"] = "result differs"
-        except Exception as ex:     # (vocabularies beyond 65,535 ids: refused -- not an error of the bench)
-            host["encode_packed_ids_u16_error"] = repr(ex)[:200]
         try:        # the same from a Python list[str] through the tokenizer's reusable staging (what a caller of encode_batch_fast feels)
             tok.encode_batch_fast(lines, add_special_tokens=False)
             best2 = float("inf")

@@ -77,11 +77,6 @@ extern "C" {
                                      f_*+s_y below F+s_y as nested lists: the same encodings; tkamd_batch_encoding_parts names the
                                      windows so a binding can rebuild them).  Ignored without a `truncation` section.                */
 
-#define TKAMD_IDS_U16        64u   /* host entries only: hand the token ids back as 16-bit values (tkamd_batch_ids16; tkamd_batch_ids is then
-                                     NULL) -- half the bytes of the largest array that crosses PCIe on the way back, for vocabularies
-                                     below 65,536 entries (GPT-2's 50,257: what such pipelines store anyway).  TKAMD_ERR_INVALID if an id of
-                                     the batch does not fit.                                                                          */
-
 /* Readable slack the caller must leave after text[n_bytes] for the device entry
  * points (kernels read whole 16-byte words).  The host entry pads internally. */
 #define TKAMD_TEXT_PAD 64
@@ -216,7 +211,6 @@ int64_t         tkamd_batch_n_docs(const tkamd_batch* b);       /* encodings in 
                                                                    overflowing encodings with TKAMD_WANT_OVERFLOW)              */
 int64_t         tkamd_batch_n_tokens(const tkamd_batch* b);
 const uint32_t* tkamd_batch_ids(const tkamd_batch* b);          /* [n_tokens]                   */
-const uint16_t* tkamd_batch_ids16(const tkamd_batch* b);        /* [n_tokens] with TKAMD_IDS_U16 (tkamd_batch_ids is NULL then), else NULL */
 const int64_t*  tkamd_batch_tok_offsets(const tkamd_batch* b);  /* [n_docs+1] CSR into ids      */
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b);      /* [n_tokens][2] or NULL        */
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b);     /* [n_tokens] or NULL           */

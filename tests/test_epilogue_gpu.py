@@ -260,30 +260,6 @@ def test_pair_overflowing_encodings_match_wheel(k):
     assert plain.enc_docs is None and [plain[i].ids for i in range(len(plain))] == [x[0]["ids"] for x in c["encodings"]]
 
 
-def test_ids_as_16_bit_values():
-    """TKAMD_IDS_U16: the host entry narrows the ids on the device and copies two bytes a token; same ids, same CSR; a vocabulary
-    with ids beyond 65,535 is refused; works behind the special-token epilogue."""
-    import numpy as np
-    import tokenizers_amd as ta
-    from oracle import synth
-    docs = synth.gen_lines(3000, text_seed=9) + ["", "x", "it's"]
-    for name in ("bytelevel_prefix_trim_3000", "bert_wordpiece_4000_specials"):
-        tok = ta.Tokenizer.from_str(load_tokenizer_json(name), device=0)
-        buf, off = ta.pack_documents(docs)
-        for special in (False, True):
-            a = tok.encode_packed(buf, off, add_special_tokens=special)
-            b = tok.encode_packed(buf, off, add_special_tokens=special, ids_dtype="uint16")
-            assert b.ids.dtype == np.uint16 and np.array_equal(a.ids, b.ids.astype(np.uint32)) and np.array_equal(a.tok_offsets, b.tok_offsets)
-    d = json.loads(load_tokenizer_json("wordlevel_whitespace_c1"))
-    d["model"]["vocab"] = {"<unk>": 0, **{f"w{i}": i for i in range(1, 66000)}}
-    d["model"]["unk_token"] = "<unk>"
-    d["added_tokens"] = []
-    tok = ta.Tokenizer.from_str(json.dumps(d), device=0)
-    assert tok.encode_packed(*ta.pack_documents(["w1 w65535 nothing"]), ids_dtype="uint16").ids.tolist() == [1, 65535, 0]
-    with pytest.raises(ValueError, match="65,535"):
-        tok.encode_packed(*ta.pack_documents(["w1 w65536 w2"]), ids_dtype="uint16")
-
-
 def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers):
     """A seeded walk over truncation x padding x post-processor x single / pair settings the golden grids do not hold, against the
     wheel run here: every field of every encoding, its overflowing ones and their nested lists.  It is how two corners were found --

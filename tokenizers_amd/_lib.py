@@ -24,7 +24,6 @@ WANT_WORD_IDS = 4
 ADD_SPECIAL = 8
 PAIRS = 16
 WANT_OVERFLOW = 32
-IDS_U16 = 64
 SKIP_SPECIAL = 1          # tkamd_decode_batch flag
 TEXT_PAD = 64
 MAX_STAGES = 24
@@ -38,7 +37,7 @@ SYMBOLS = [
     "tkamd_profile_counters", "tkamd_tokenizer_specials", "tkamd_version", "tkamd_word_cache",
     "tkamd_decode_batch", "tkamd_text_n_docs", "tkamd_text_n_bytes", "tkamd_text_bytes", "tkamd_text_doc_offsets",
     "tkamd_text_free", "tkamd_decode_token", "tkamd_probe_word", "tkamd_probe_merge", "tkamd_probe_bert_norm", "tkamd_probe_unicode_flags", "tkamd_probe_trie",
-    "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_batch_ids16", "tkamd_encode_special_tokens",
+    "tkamd_batch_encoding_docs", "tkamd_probe_truncation", "tkamd_probe_bert_alone", "tkamd_tokenizer_pair_template", "tkamd_batch_encoding_parts", "tkamd_probe_bert_nfd", "tkamd_encode_special_tokens",
     "tkamd_tokenizer_from_json_devices", "tkamd_tokenizer_set_collect", "tkamd_tokenizer_devices", "tkamd_shard_stats", "tkamd_debug_phases",
     "tkamd_pinned_alloc", "tkamd_pinned_free", "tkamd_encode_batch_paced",
 ]
@@ -122,7 +121,7 @@ def load() -> C.CDLL:
     lib.tkamd_encode_batch_words_device.restype = i32
     for name, rt in (("tkamd_batch_n_docs", i64), ("tkamd_batch_n_tokens", i64), ("tkamd_batch_ids", vp),
                      ("tkamd_batch_tok_offsets", vp), ("tkamd_batch_offsets", vp), ("tkamd_batch_word_ids", vp), ("tkamd_batch_pad_counts", vp),
-                     ("tkamd_batch_type_ids", vp), ("tkamd_batch_sequence_ids", vp), ("tkamd_batch_encoding_docs", vp), ("tkamd_batch_encoding_parts", vp), ("tkamd_batch_ids16", vp)):
+                     ("tkamd_batch_type_ids", vp), ("tkamd_batch_sequence_ids", vp), ("tkamd_batch_encoding_docs", vp), ("tkamd_batch_encoding_parts", vp)):
         f = getattr(lib, name)
         f.argtypes = [vp]
         f.restype = rt

@@ -34,7 +34,6 @@ struct Workspace {
     DevBuf w_tok_b8;                             // with offsets: per token, the boundary byte its row carried (kernels/results.hip row_boundary)
     DevBuf w_trim1;                              // per token: process_offsets took one leading space off it (MetaArgs::trim1)
     const uint8_t* cur_trim1 = nullptr;          // ... of the batch being enqueued, or null
-    DevBuf w_ids16, w_wide;                      // TKAMD_IDS_U16: the narrowed ids of a slice, the "an id did not fit" flag
     DevBuf w_cache_keys, w_cache_rows;           // word cache of this workspace (kernels.hpp WordCache)
     DevBuf w_claims, w_claim_rows, w_claim_pos;  // in-batch word claims (kernels.hpp WordCache::claims), the rows of the claimed slots, the claimants' first bytes
     DevBuf w_phases;                             // TKAMD_PHASES: shader-clock ticks per phase of the lookup / compaction, [2][PHASE_WGS][8] u64 (tkamd_debug_phases)
@@ -161,9 +160,9 @@ static void pinned_put(PinnedBlock b) {
 
 struct tkamd_batch {
     int64_t n_docs = 0, n_tokens = 0;
-    PinnedBlock ids, ids16, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs, enc_parts;
-    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false, has_enc_parts = false, has_ids16 = false;
-    ~tkamd_batch() { pinned_put(ids); pinned_put(ids16); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); pinned_put(enc_parts); }
+    PinnedBlock ids, tok_offsets, offsets, word_ids, pad_counts, type_ids, seq_ids, enc_docs, enc_parts;
+    bool has_offsets = false, has_words = false, has_pads = false, has_types = false, has_enc_docs = false, has_enc_parts = false;
+    ~tkamd_batch() { pinned_put(ids); pinned_put(tok_offsets); pinned_put(offsets); pinned_put(word_ids); pinned_put(pad_counts); pinned_put(type_ids); pinned_put(seq_ids); pinned_put(enc_docs); pinned_put(enc_parts); }
 };
 
 struct tkamd_text {

@@ -112,14 +112,7 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         const hipStream_t cin = w0->io_in, cout = w0->io_out;
         bool out_pending[2] = {false, false};                        // a D2H of this workspace's results is (or may still be) in flight
 
-        const bool ids16 = (flags & TKAMD_IDS_U16) != 0;
-        if (ids16)
-            for (int q = 0; q < (l1 ? 2 : 1); ++q) {
-                ws[q]->w_wide.reserve(64);
-                HIP_CHECK(hipMemsetAsync(ws[q]->w_wide.p, 0, 4, st[q]));
-            }
         std::unique_ptr<tkamd_batch> b(new tkamd_batch());
-        b->has_ids16 = ids16;
         b->n_docs = n_enc;
         b->tok_offsets = pinned_get((size_t)(n_enc + 1) * 8);
         tkamd_device_result res[MAX_SLICES]{};
@@ -199,19 +192,13 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
                 size_t est = (k + 1 == n_slices || seen <= 0) ? need : (size_t)((double)need * (double)n_bytes / (double)seen * 1.12) + 4096;
                 est = std::max(est, need);
                 if (k) HIP_CHECK(hipStreamSynchronize(cout));   // earlier slices' copies are still landing in the old blocks
-                if (ids16) grow(b->ids16, 2, est, (size_t)tok_base);
-                else grow(b->ids, 4, est, (size_t)tok_base);
+                grow(b->ids, 4, est, (size_t)tok_base);
                 if (r.d_offsets) grow(b->offsets, 8, est, (size_t)tok_base);
                 if (r.d_word_ids) grow(b->word_ids, 4, est, (size_t)tok_base);
                 if (r.d_type_ids) { grow(b->type_ids, 1, est, (size_t)tok_base); grow(b->seq_ids, 1, est, (size_t)tok_base); }
                 tok_cap = est;
             }
-            if (ids16) {
-                // half the bytes on the way back: narrow on the device, copy 2 bytes a token
-                w->w_ids16.reserve((size_t)n_tok * 2 + 64);
-                launch_narrow_ids(cout, r.d_ids, n_tok, w->w_ids16.as<uint16_t>(), w->w_wide.as<int>());
-                if (n_tok) HIP_CHECK(hipMemcpyAsync((uint16_t*)b->ids16.p + tok_base, w->w_ids16.p, (size_t)n_tok * 2, hipMemcpyDeviceToHost, cout));
-            } else if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, cout));
+            if (n_tok) HIP_CHECK(hipMemcpyAsync((uint32_t*)b->ids.p + tok_base, r.d_ids, (size_t)n_tok * 4, hipMemcpyDeviceToHost, cout));
             if (tok_base) launch_add_i64(cout, (int64_t*)r.d_tok_offsets, d1 - d0 + 1, tok_base);   // the slice's CSR continues the batch's
             HIP_CHECK(hipMemcpyAsync((int64_t*)b->tok_offsets.p + d0, r.d_tok_offsets, (size_t)(d1 - d0 + 1) * 8, hipMemcpyDeviceToHost, cout));
             if (r.d_offsets) {
@@ -255,16 +242,8 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         HIP_CHECK(hipStreamSynchronize(st[1]));
         HIP_CHECK(hipStreamSynchronize(cout));
         if (bits) return error_from_bits(bits);
-        if (ids16) {
-            for (int q = 0; q < (l1 ? 2 : 1); ++q) {
-                int wide = 0;
-                HIP_CHECK(hipMemcpy(&wide, ws[q]->w_wide.p, 4, hipMemcpyDeviceToHost));
-                if (wide) throw Invalid("TKAMD_IDS_U16: the batch holds a token id beyond 65,535");
-            }
-            if (!b->ids16.p) b->ids16 = pinned_get(64);
-        }
         b->n_tokens = tok_base;
-        if (!b->ids.p && !ids16) b->ids = pinned_get(64);
+        if (!b->ids.p) b->ids = pinned_get(64);
         *out = b.release();
         return TKAMD_OK;
     });
@@ -311,8 +290,7 @@ const uint8_t* tkamd_batch_type_ids(const tkamd_batch* b) { return (b && b->has_
 const uint8_t* tkamd_batch_sequence_ids(const tkamd_batch* b) { return (b && b->has_types) ? (const uint8_t*)b->seq_ids.p : nullptr; }
 int64_t tkamd_batch_n_docs(const tkamd_batch* b) { return b ? b->n_docs : 0; }
 int64_t tkamd_batch_n_tokens(const tkamd_batch* b) { return b ? b->n_tokens : 0; }
-const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return (b && !b->has_ids16) ? (const uint32_t*)b->ids.p : nullptr; }
-const uint16_t* tkamd_batch_ids16(const tkamd_batch* b) { return (b && b->has_ids16) ? (const uint16_t*)b->ids16.p : nullptr; }
+const uint32_t* tkamd_batch_ids(const tkamd_batch* b) { return b ? (const uint32_t*)b->ids.p : nullptr; }
 const int64_t* tkamd_batch_tok_offsets(const tkamd_batch* b) { return b ? (const int64_t*)b->tok_offsets.p : nullptr; }
 const uint32_t* tkamd_batch_offsets(const tkamd_batch* b) { return (b && b->has_offsets) ? (const uint32_t*)b->offsets.p : nullptr; }
 const uint32_t* tkamd_batch_word_ids(const tkamd_batch* b) { return (b && b->has_words) ? (const uint32_t*)b->word_ids.p : nullptr; }

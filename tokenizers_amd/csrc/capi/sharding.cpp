@@ -39,7 +39,6 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
     const int64_t n_grp = words_in ? n_seqs : n_docs;
     auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
     const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;
-    const bool ids16 = (flags & TKAMD_IDS_U16) != 0;
     std::vector<Shard> sh((size_t)n_dev);
     {
         int64_t prev = 0;
@@ -85,7 +84,6 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
         }
     }
     std::unique_ptr<tkamd_batch> b(new tkamd_batch());
-    b->has_ids16 = ids16;
     b->n_docs = n_grp / unit;
     std::vector<std::vector<ShardDesc>> desc((size_t)n_dev);
     Rendezvous rv(n_dev);
@@ -99,8 +97,7 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
     auto describe = [&](Shard& x) {      // the result arrays of a shard, the same list on every shard (the tokenizer decides which exist)
         std::vector<ShardDesc> d;
         const tkamd_device_result& r = x.res;
-        if (ids16) d.push_back({x.w->w_ids16.p, 2, true, 0, &b->ids16});
-        else d.push_back({r.d_ids, 4, true, 0, &b->ids});
+        d.push_back({r.d_ids, 4, true, 0, &b->ids});
         d.push_back({r.d_tok_offsets, 8, false, 1, &b->tok_offsets});
         if (r.d_offsets) d.push_back({r.d_offsets, 8, true, 0, &b->offsets});
         if (r.d_word_ids) d.push_back({r.d_word_ids, 4, true, 0, &b->word_ids});
@@ -144,16 +141,6 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
             const int bits = finish_batch(tr, w, s, &x.n_tok, &n_pt);
             if (bits) return error_from_bits(bits);
             x.res = w->last_result;
-            if (ids16) {
-                w->w_wide.reserve(64);
-                HIP_CHECK(hipMemsetAsync(w->w_wide.p, 0, 4, s));
-                w->w_ids16.reserve((size_t)x.n_tok * 2 + 64);
-                launch_narrow_ids(s, x.res.d_ids, x.n_tok, w->w_ids16.as<uint16_t>(), w->w_wide.as<int>());
-                int wide = 0;
-                HIP_CHECK(hipMemcpyAsync(&wide, w->w_wide.p, 4, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                if (wide) throw Invalid("TKAMD_IDS_U16: the batch holds a token id beyond 65,535");
-            }
             if (collect == TKAMD_COLLECT_ROOT_P2P) HIP_CHECK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming));
             desc[(size_t)r] = describe(x);
             return TKAMD_OK;

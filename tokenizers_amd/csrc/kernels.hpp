@@ -363,8 +363,6 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 // truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy
 void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta);
-// ids -> 16-bit ids (TKAMD_IDS_U16); *wide is set if one of them does not fit
-void launch_narrow_ids(hipStream_t st, const uint32_t* ids, int64_t n, uint16_t* out, int* wide);
 void launch_final_lens(hipStream_t st, const FinalArgs& a);
 // overflowing encodings: encodings per document + their numbering (*n_enc = how many there are), then -- with a.n_docs still the
 // number of DOCUMENTS -- every encoding's token range, its length with the specials, and the batch maximum over the truncated

@@ -153,20 +153,6 @@ __global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t 
 }
 
 // data[i] += delta (rebasing a CSR slice)
-// TKAMD_IDS_U16: the ids of a finished batch as 16-bit values for the trip back over PCIe (four ids per lane and step)
-__global__ __launch_bounds__(256) void k_narrow_ids(const uint32_t* __restrict__ ids, int64_t n, uint16_t* __restrict__ out, int* __restrict__ wide) {
-    uint32_t seen = 0;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
-        if (i + 4 <= n) {
-            const uint4 v = *(const uint4*)(ids + i);           // (ids is 16-byte aligned: a workspace buffer)
-            seen |= v.x | v.y | v.z | v.w;
-            *(uint2*)(out + i) = make_uint2((v.x & 0xFFFFu) | (v.y << 16), (v.z & 0xFFFFu) | (v.w << 16));
-        } else {
-            for (int64_t j = i; j < n; ++j) { seen |= ids[j]; out[j] = (uint16_t)ids[j]; }
-        }
-    }
-    if (seen > 0xFFFFu) atomicOr(wide, 1);
-}
 __global__ void k_add_i64(int64_t* __restrict__ data, int64_t n, int64_t delta) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) data[i] += delta;

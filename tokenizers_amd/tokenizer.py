@@ -821,7 +821,7 @@ class Tokenizer:
         if _marshal is None or not hasattr(_marshal, "pack_encode") or not isinstance(inputs, (list, tuple)) or self.device < 0 or _FORKED[0] or \
                 os.environ.get("TKAMD_PACED") == "0":
             return None
-        flags = self._flags(offsets, word_ids, add_special_tokens, pairs, overflowing, "uint32")
+        flags = self._flags(offsets, word_ids, add_special_tokens, pairs, overflowing)
         n = len(inputs)
         if getattr(self, "_stage_pid", None) != os.getpid():
             self._stage_pid, self._stage_off, self._stage_text = os.getpid(), None, None
@@ -838,7 +838,7 @@ class Tokenizer:
                 raise UnsupportedError(str(e)) from None
             if status is not None:
                 _lib.check(status)
-                return self._wrap_batch(C.c_void_p(b), n // (2 if pairs else 1), offsets, word_ids, add_special_tokens, pairs, "uint32")
+                return self._wrap_batch(C.c_void_p(b), n // (2 if pairs else 1), offsets, word_ids, add_special_tokens, pairs)
             self._stage_text = pinned_empty(total + total // 4 + _lib.TEXT_PAD, dtype=np.uint8)     # nothing was copied: grow and redo
         raise RuntimeError("staging buffer growth failed")          # pragma: no cover
 
@@ -864,13 +864,11 @@ class Tokenizer:
             return self.encode_packed(buf, word_off, offsets, word_ids, add_special_tokens, pairs, np.asarray(seq_off, dtype=np.int64), overflowing)
 
     def encode_packed(self, buf: np.ndarray, doc_off: np.ndarray, offsets: str = "none", word_ids: bool = False,
-                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None, overflowing: bool = False,
-                      ids_dtype: str = "uint32") -> BatchEncoding:
+                      add_special_tokens: bool = False, pairs: bool = False, seq_off: np.ndarray = None, overflowing: bool = False) -> BatchEncoding:
         """``pairs``: documents 2i and 2i+1 are sequence A and B of encoding i (EncodeInput::Dual, tokenizer/mod.rs:871-889).
         ``seq_off``: the documents are the words of pre-tokenized sequences, sequence s = words [seq_off[s], seq_off[s+1]).
-        ``overflowing``: TKAMD_WANT_OVERFLOW -- the result then also holds every input's overflowing encodings.
-        ``ids_dtype`` "uint16": TKAMD_IDS_U16 -- the ids come back as 16-bit values (half the PCIe bytes; vocabularies below 65,536)."""
-        flags = self._flags(offsets, word_ids, add_special_tokens, pairs, overflowing, ids_dtype)
+        ``overflowing``: TKAMD_WANT_OVERFLOW -- the result then also holds every input's overflowing encodings."""
+        flags = self._flags(offsets, word_ids, add_special_tokens, pairs, overflowing)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.int64)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         n_docs = len(doc_off) - 1
@@ -882,16 +880,12 @@ class Tokenizer:
             seq_off = np.ascontiguousarray(seq_off, dtype=np.int64)
             _lib.check(self._lib.tkamd_encode_batch_words(self._h, buf.ctypes.data, doc_off.ctypes.data, n_docs, seq_off.ctypes.data,
                                                           len(seq_off) - 1, flags, C.byref(b)))
-        return self._wrap_batch(b, n_inputs, offsets, word_ids, add_special_tokens, pairs, ids_dtype)
+        return self._wrap_batch(b, n_inputs, offsets, word_ids, add_special_tokens, pairs)
 
-    def _flags(self, offsets, word_ids, add_special_tokens, pairs, overflowing, ids_dtype) -> int:
+    def _flags(self, offsets, word_ids, add_special_tokens, pairs, overflowing) -> int:
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
         if overflowing:
             flags |= _lib.WANT_OVERFLOW
-        if ids_dtype not in ("uint32", "uint16"):
-            raise ValueError("ids_dtype must be 'uint32' or 'uint16'")
-        if ids_dtype == "uint16":
-            flags |= _lib.IDS_U16
         if pairs:
             flags |= _lib.PAIRS
         if word_ids:
@@ -902,7 +896,7 @@ class Tokenizer:
             flags |= _lib.ADD_SPECIAL
         return flags
 
-    def _wrap_batch(self, b, n_inputs, offsets, word_ids, add_special_tokens, pairs, ids_dtype, kinds=None) -> BatchEncoding:
+    def _wrap_batch(self, b, n_inputs, offsets, word_ids, add_special_tokens, pairs, kinds=None) -> BatchEncoding:
         """Zero-copy views of a finished ``tkamd_batch`` (the library's pinned result buffers)."""
         n_docs = self._lib.tkamd_batch_n_docs(b)             # encodings (sequences; half of them for pairs)
         # zero-copy views of the library's pinned result buffers; the batch is freed when the last view dies
@@ -917,8 +911,7 @@ class Tokenizer:
             carr._owner = owner
             return np.ctypeslib.as_array(carr).reshape(shape)
 
-        ids = view(self._lib.tkamd_batch_ids16(b), C.c_uint16, (nt,), np.uint16) if ids_dtype == "uint16" else \
-            view(self._lib.tkamd_batch_ids(b), C.c_uint32, (nt,), np.uint32)
+        ids = view(self._lib.tkamd_batch_ids(b), C.c_uint32, (nt,), np.uint32)
         to = view(self._lib.tkamd_batch_tok_offsets(b), C.c_int64, (n_docs + 1,), np.int64)
         offs = wids = None
         if offsets != "none":
@@ -1006,7 +999,7 @@ class Tokenizer:
             seqs = words
         elif not all(isinstance(x, str) for x in seqs):
             raise UnsupportedError("a batch holds single sequences (str) and pairs (str, str); lists of words need is_pretokenized=True")
-        flags = self._flags(offsets, word_ids, add_special_tokens, False, overflowing, "uint32")
+        flags = self._flags(offsets, word_ids, add_special_tokens, False, overflowing)
         inp = np.asarray(inp_off, dtype=np.int64)
         b = C.c_void_p()
         with self._stage_lock:
@@ -1015,7 +1008,7 @@ class Tokenizer:
             _lib.check(self._lib.tkamd_encode_batch_mixed(self._h, buf.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1,
                                                           so.ctypes.data if so is not None else None, len(so) - 1 if so is not None else -1,
                                                           inp.ctypes.data, len(inputs), flags, C.byref(b)))
-        return self._wrap_batch(b, len(inputs), offsets, word_ids, add_special_tokens, True, "uint32", kinds)
+        return self._wrap_batch(b, len(inputs), offsets, word_ids, add_special_tokens, True, kinds)
 
     def encode_batch(self, input: Iterable[str], is_pretokenized: bool = False, add_special_tokens: bool = True) -> BatchEncoding:
         """``Tokenizer.encode_batch`` (char offsets + word ids, tokenizer.rs:1312-1338).  A batch may mix single sequences and pairs

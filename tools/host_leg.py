@@ -33,7 +33,7 @@ def run(sets, **kw):
     ts.sort()
     nb = sum(int(o[-1]) for _, o in sets) / 3
     return "best %%.2f median %%.2f ms = %%.1f GB/s" %% (ts[0] * 1e3, ts[6] * 1e3, nb / ts[6] / 1e9)
-print("HOST slices of", sys.argv[1], "MB | pinned:", run(pin), "| pageable:", run(bs), "| pinned, u16 ids:", run(pin, ids_dtype="uint16"))
+print("HOST slices of", sys.argv[1], "MB | pinned:", run(pin), "| pageable:", run(bs))
 """ % (ROOT, os.path.join(ROOT, "tools"))
 
 for mb in sys.argv[1:] or ["16"]:
