@@ -276,8 +276,10 @@ int tkamd_device_sync(tkamd_tokenizer* tok, void* hip_stream, int64_t* n_tokens,
  * Replaces Tokenizer::decode_batch (tokenizer/mod.rs:1404-1416) = map of Tokenizer::decode (mod.rs:935-953):
  * id -> token string (added vocabulary first, added_vocabulary.rs:239-246; ids without a token are dropped),
  * specials dropped when TKAMD_SKIP_SPECIAL (skip_special_tokens), then the `decoder` section:
- * ByteLevel (pre_tokenizers/byte_level.rs:155-171), WordPiece (decoders/wordpiece.rs:46-64) or none (join
- * with " ").  Other decoders -> TKAMD_ERR_UNSUPPORTED.  The result is the raw byte string per sequence; the
+ * ByteLevel (pre_tokenizers/byte_level.rs:155-171), WordPiece (decoders/wordpiece.rs:46-64), BPEDecoder (decoders/bpe.rs:26-39),
+ * ByteFallback (byte_fallback.rs:27-67), Fuse (fuse.rs:24-29), Replace with a literal pattern (normalizers/replace.rs:88-106), Strip
+ * (strip.rs:27-60), a Sequence (sequence.rs:26-33) of the shape [Replace*, Strip*, ByteFallback?, Fuse?, Strip(c, <= 1, 0)?], CTC
+ * (ctc.rs:45-63) or none (join with " ").  Other decoders / shapes -> TKAMD_ERR_UNSUPPORTED.  The result is the raw byte string per sequence; the
  * ByteLevel decoder's String::from_utf8_lossy (byte_level.rs:170) is left to the caller (bytes that do not
  * form valid UTF-8 can only come from id sequences that split a character), e.g. Python's
  * bytes.decode("utf-8", "replace"), which substitutes the same maximal invalid subparts. */

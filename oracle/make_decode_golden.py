@@ -36,6 +36,17 @@ CASES = [
     ("bpe_ws_byte_fallback", {"type": "ByteFallback"}),
     ("bpe_ws_byte_fallback", {"type": "Sequence", "decoders": [{"type": "ByteFallback"}, {"type": "Fuse"}]}),
     ("bpe_ws_unk", {"type": "Fuse"}),
+    # round 6: chains of the per-token decoders (Replace with a literal pattern, Strip), the SentencePiece-style chain
+    # [Replace, ByteFallback, Fuse, Strip(c, 1, 0)] (here "a" plays U+2581), CTC
+    ("bpe_ws_byte_fallback", {"type": "Sequence", "decoders": [{"type": "Replace", "pattern": {"String": "a"}, "content": " "}, {"type": "ByteFallback"},
+                                                               {"type": "Fuse"}, {"type": "Strip", "content": " ", "start": 1, "stop": 0}]}),
+    ("bpe_ws_byte_fallback", {"type": "Sequence", "decoders": [{"type": "ByteFallback"}, {"type": "Fuse"}, {"type": "Strip", "content": "t", "start": 1, "stop": 0}]}),
+    ("bpe_ws_unk", {"type": "Strip", "content": "t", "start": 2, "stop": 0}),
+    ("bpe_ws_unk", {"type": "Strip", "content": "s", "start": 0, "stop": 1}),
+    ("bpe_ws_unk", {"type": "Replace", "pattern": {"String": "th"}, "content": "TH-"}),
+    ("bpe_ws_unk", {"type": "Sequence", "decoders": [{"type": "Replace", "pattern": {"String": "e"}, "content": "3"}, {"type": "Strip", "content": "3", "start": 1, "stop": 0}]}),
+    ("wordlevel_whitespace_c1", "CTC:True"),
+    ("wordlevel_whitespace_c1", "CTC:False"),
 ]
 
 
@@ -43,6 +54,9 @@ def main():
     out = []
     for k, (name, decoder) in enumerate(CASES):
         d = json.loads(load_tokenizer_json(name))
+        if isinstance(decoder, str) and decoder.startswith("CTC:"):     # pad / delimiter: two frequent words of the vocabulary
+            by_id = sorted(d["model"]["vocab"].items(), key=lambda kv: kv[1])
+            decoder = {"type": "CTC", "pad_token": by_id[5][0], "word_delimiter_token": by_id[6][0], "cleanup": decoder.endswith("True")}
         if decoder is not None:
             d["decoder"] = decoder
         js = json.dumps(d)
@@ -72,6 +86,25 @@ def main():
                         q += [byte_id[b] for b in r[: int(rng.integers(1, len(r) + 1))]]
                     else:
                         q.append(int(word[int(rng.integers(0, len(word)))]))
+                seqs.append(q)
+        if decoder is not None and "Strip" in json.dumps(decoder) and "ByteFallback" in json.dumps(decoder):
+            # the leading Strip behind Fuse against byte tokens: the stripped char as a byte token in front -- alone, twice, in a run that is
+            # UTF-8 and in one that is not (one U+FFFD per byte then: nothing to strip)
+            c = json.loads(json.dumps(decoder))["decoders"][-1]["content"].encode()[0]
+            for r in ([c], [c, c], [c, 0xC3, 0xA9], [c, 0xC3], [0xC3, c], [c, 0xE4, 0xB8]):
+                seqs.append([byte_id[b] for b in r])
+                seqs.append([byte_id[b] for b in r] + [word[2]])
+                seqs.append([word[3]] + [byte_id[b] for b in r])
+        if decoder is not None and decoder.get("type") == "CTC":      # runs of equal ids, also across ids that are dropped (no token, specials)
+            for _ in range(120):
+                n = int(rng.integers(1, 30))
+                q, cur = [], int(rng.integers(0, 12))
+                for _ in range(n):
+                    if rng.random() < 0.45:
+                        cur = int(rng.integers(0, 12))
+                    q.append(cur)
+                    if rng.random() < 0.15:
+                        q.append(n_ids + 3)                   # an id without a token between two equal ones
                 seqs.append(q)
         seqs += [[], [0], []]
         out.append({"tokenizer": name, "decoder": decoder, "has_decoder_override": decoder is not None, "seqs": seqs,

@@ -164,11 +164,36 @@ def test_decode_tables_match_the_oracle_token_by_token():
                 assert a_rest + first == o.decode_bytes([anchor, i], False) and rest + a_first == o.decode_bytes([i, anchor], False), (case["tokenizer"], i)
                 continue
             t = o.id2tok[i]
-            if o.kind == "ByteFallback" and len(t) == 6 and t.startswith("<0x") and t.endswith(">"):      # the byte itself; what a RUN of them becomes is the device's business
-                assert first == rest == bytes([int(t[3:5], 16)]), (case["tokenizer"], i)
+            has_bf = o.kind == "ByteFallback" or (o.kind == "Sequence" and any(m["type"] == "ByteFallback" for m in o.dec["decoders"]))
+            if has_bf and len(t) == 6 and t.startswith("<0x") and t.endswith(">"):      # the byte itself; what a RUN of them becomes is the device's business
+                byte = bytes([int(t[3:5], 16)])
+                strip = o.dec["decoders"][-1] if o.kind == "Sequence" and o.dec["decoders"][-1]["type"] == "Strip" else None
+                gone = strip is not None and strip["start"] >= 1 and strip["content"].encode() == byte      # (the leading Strip behind Fuse takes this very byte)
+                assert rest == byte and first == (b"" if gone else byte), (case["tokenizer"], i)
                 continue
             assert first == o.decode_bytes([i], False), (case["tokenizer"], case["decoder"], i)
             assert front + rest == o.decode_bytes([anchor, i], False), (case["tokenizer"], case["decoder"], i)
+
+
+def test_decoder_chains_outside_the_path_are_refused():
+    """decode_batch names what it does not fold into its per-id tables (the handle still loads: encode is unaffected)."""
+    import json
+    import pytest
+    import tokenizers_amd as ta
+    from tests.helpers import load_tokenizer_json
+    base = json.loads(load_tokenizer_json("bpe_ws_byte_fallback"))
+    strip = lambda a, b: {"type": "Strip", "content": " ", "start": a, "stop": b}
+    for dec, msg in (({"type": "Replace", "pattern": {"Regex": "a+"}, "content": "b"}, "Regex"),
+                     ({"type": "Sequence", "decoders": [{"type": "Fuse"}, strip(2, 0)]}, "behind Fuse"),
+                     ({"type": "Sequence", "decoders": [{"type": "Fuse"}, strip(1, 1)]}, "behind Fuse"),
+                     ({"type": "Sequence", "decoders": [{"type": "ByteFallback"}, strip(1, 0)]}, "at this place"),
+                     ({"type": "Sequence", "decoders": [{"type": "Fuse"}, {"type": "Replace", "pattern": {"String": "a"}, "content": "b"}]}, "at this place"),
+                     ({"type": "Sequence", "decoders": [{"type": "ByteFallback"}, {"type": "Fuse"}, {"type": "Strip", "content": "é", "start": 1, "stop": 0}]}, "non-ASCII"),
+                     ({"type": "Metaspace", "replacement": "▁", "prepend_scheme": "always", "split": True}, "Metaspace")):
+        d = dict(base, decoder=dec)
+        tk = ta.Tokenizer.from_str(json.dumps(d), device=-1)
+        with pytest.raises(ta.UnsupportedError, match=msg):
+            tk.decode_token(5, True)
 
 
 def test_staged_marshalling_matches_pack_documents():

@@ -546,12 +546,14 @@ def _decode_case_json(case) -> str:
     return json.dumps(d)
 
 
-@pytest.mark.parametrize("k", range(12))
+@pytest.mark.parametrize("k", range(20))
 def test_decode_batch_matches_golden(k):
     """Device decode_batch == the reference wheel's decode_batch on the committed vectors (ByteLevel, WordPiece with and
     without cleanup, no decoder; sequences with specials, random ids that split characters or have no token, empty ones).
     Cases 7..11 (round 5): BPEDecoder, ByteFallback alone and as Sequence[ByteFallback, Fuse] -- runs of <0xXX> tokens that are valid,
-    truncated, overlong or surrogate UTF-8 --, Fuse."""
+    truncated, overlong or surrogate UTF-8 --, Fuse.  Cases 12..19 (round 6): the SentencePiece-style chain [Replace, ByteFallback, Fuse,
+    Strip(c, 1, 0)] -- with the stripped char as a byte token in front, in runs that are UTF-8 and runs that are not --, Strip and Replace
+    alone and as a Sequence, CTC with and without cleanup (runs of equal ids, also across ids that are dropped)."""
     import tokenizers_amd as ta
     case = _decode_cases()[k]
     tk = ta.Tokenizer.from_str(_decode_case_json(case), device=0)

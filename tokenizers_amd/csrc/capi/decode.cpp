@@ -36,11 +36,13 @@ int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* t
         uint32_t* firstmask = hm.dec_position_dependent ? w->dw_first.as<uint32_t>() : nullptr;
         uint32_t* badmask = nullptr;                          // ByteFallback: tokens of byte runs that are not UTF-8
         if (hm.dec_has_bytes) { w->dw_bad.reserve((size_t)(n_tok / 32 + 2) * 4); badmask = w->dw_bad.as<uint32_t>(); }
+        uint32_t* dupmask = nullptr;                          // CTC: kept tokens equal to the kept token in front of them
+        if (hm.dec_dedup) { w->dw_dup.reserve((size_t)(n_tok / 32 + 2) * 4); dupmask = w->dw_dup.as<uint32_t>(); }
         const uint32_t from_end = hm.dec_special_is_last ? 1u : 0u;
         const uint32_t skip = (flags & TKAMD_SKIP_SPECIAL) ? 1u : 0u;
         launch_decode(st, w->dw_ids.as<uint32_t>(), w->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
                       firstmask, w->dw_len.as<uint32_t>(), w->dw_bsum.as<uint32_t>(), w->dw_pos.as<uint32_t>(), w->dw_total.as<int64_t>(),
-                      w->dw_out_off.as<int64_t>(), nullptr, from_end, badmask);
+                      w->dw_out_off.as<int64_t>(), nullptr, from_end, badmask, dupmask);
         HIP_CHECK(hipGetLastError());
         int64_t total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, w->dw_total.p, 8, hipMemcpyDeviceToHost, st));
@@ -49,7 +51,7 @@ int tkamd_decode_batch(tkamd_tokenizer* t, const uint32_t* ids, const int64_t* t
         w->dw_bytes.reserve((size_t)total + 64);
         launch_decode(st, w->dw_ids.as<uint32_t>(), w->dw_tok_off.as<int64_t>(), n_docs, n_tok, t->t_dec_entry.p, n_ids, t->t_dec_blob.as<uint8_t>(), skip,
                       firstmask, w->dw_len.as<uint32_t>(), w->dw_bsum.as<uint32_t>(), w->dw_pos.as<uint32_t>(), w->dw_total.as<int64_t>(),
-                      w->dw_out_off.as<int64_t>(), w->dw_bytes.as<uint8_t>(), from_end, badmask);
+                      w->dw_out_off.as<int64_t>(), w->dw_bytes.as<uint8_t>(), from_end, badmask, dupmask);
         HIP_CHECK(hipGetLastError());
         std::unique_ptr<tkamd_text> b(new tkamd_text());
         b->n_docs = n_docs;
@@ -73,9 +75,9 @@ int tkamd_decode_token(const tkamd_tokenizer* t, uint32_t id, int first_position
     const uint32_t* e = &hm.dec_entry[(size_t)id * 4];
     if (e[1] & DEC_ABSENT) return TKAMD_OK;
     *flags = (e[1] & DEC_SPECIAL) ? 1 : 0;
-    if (e[1] & DEC_BYTE) {                                   // ByteFallback: the token's byte (what a run of them becomes is decided per run)
-        *len = 1;
-        if (cap > 0 && out) out[0] = (uint8_t)e[0];
+    if (e[1] & DEC_BYTE) {                                   // ByteFallback: the token's byte (what a run of them becomes is decided per run);
+        *len = (int32_t)(first_position ? (e[1] & DEC_LEN_MASK) : e[3]);      // nothing as the first token under a leading Strip of this very byte
+        if (*len && cap > 0 && out) out[0] = (uint8_t)e[0];
         return TKAMD_OK;
     }
     const uint32_t off = first_position ? e[0] : e[2], l = first_position ? (e[1] & DEC_LEN_MASK) : e[3];

@@ -26,7 +26,7 @@ struct Workspace {
     DevBuf w_doc_off;            // validated copy of the caller's document CSR
     DevBuf w_chunk_lo;                           // first document of every compaction chunk (k_doc_first_pretok -> k_compact)
     DevBuf w_ids, w_doc_pt, w_tok_offsets, w_scalars, w_offsets, w_word_ids;
-    DevBuf dw_ids, dw_tok_off, dw_first, dw_bad, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
+    DevBuf dw_ids, dw_tok_off, dw_first, dw_bad, dw_dup, dw_len, dw_bsum, dw_pos, dw_out_off, dw_bytes, dw_total;   // decode_batch workspace
     DevBuf w_endmask, w_pt_end, w_keepmask, w_kprefix, w_ntext, w_norig, w_ndoc_off, w_slow_docs, w_leadmask, w_lprefix, w_need, w_need_bsum, w_huge, w_list_huge, w_wbase, w_norig_e, w_ids2, w_tok_offsets2, w_offsets2, w_word_ids2, w_candmask, w_matchmask, w_spanmask, w_stopmask, w_hardmask, w_boundmask, w_bprefix, w_seg_off, w_xseg_off,
         w_match_docs, w_match_list;
     // host entry staging

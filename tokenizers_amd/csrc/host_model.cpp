@@ -503,8 +503,38 @@ static std::string wp_cleanup(std::string t) {
 static void build_decode_tables(HostModel& m, const JsonValue* root, const std::unordered_map<std::string, uint32_t>& vocab,
                                 const std::unordered_map<uint32_t, uint8_t>& c2b) {
     const JsonValue* dec = root->get("decoder");
-    std::string prefix = "##", suffix = "</w>";
-    bool cleanup = true;
+    std::string prefix = "##", suffix = "</w>", ctc_pad, ctc_delim, post_strip;
+    bool cleanup = true, chain_bytes = false;
+    struct DecEl { int kind; std::string a, b; int64_t start, stop; };      // 0: Replace a -> b; 1: Strip a (one char), start / stop
+    std::vector<DecEl> chain;
+    auto replace_lit = [](const std::string& t, const std::string& from, const std::string& to) {
+        std::string out;
+        size_t pos = 0;
+        for (;;) {
+            const size_t hit = t.find(from, pos);
+            if (hit == std::string::npos) { out.append(t, pos, std::string::npos); break; }
+            out.append(t, pos, hit - pos);
+            out += to;
+            pos = hit + from.size();
+        }
+        return out;
+    };
+    // chars of a UTF-8 string as byte ranges (Strip counts chars)
+    auto char_starts = [](const std::string& t) {
+        std::vector<size_t> st;
+        for (size_t i = 0; i < t.size(); ++i) if (((uint8_t)t[i] & 0xC0u) != 0x80u) st.push_back(i);
+        st.push_back(t.size());
+        return st;
+    };
+    auto strip = [&](const std::string& t, const std::string& c, int64_t start, int64_t stop) {
+        const std::vector<size_t> cs = char_starts(t);
+        const size_t n = cs.size() - 1;
+        auto is_c = [&](size_t k) { return t.compare(cs[k], cs[k + 1] - cs[k], c) == 0; };
+        size_t a = 0, b = n;
+        for (size_t k = 0; k < n && (int64_t)k < start; ++k) { if (!is_c(k)) break; a = k + 1; }
+        for (int64_t k = 0; k < stop && (size_t)k < n; ++k) { const size_t j = n - (size_t)k - 1; if (!is_c(j)) break; b = j; }
+        return b >= a ? t.substr(cs[a], cs[b] - cs[a]) : std::string();
+    };
     if (!dec || dec->is_null()) m.decoder = DEC_JOIN_SPACE;
     else {
         const std::string t = dec->get_str("type");
@@ -523,19 +553,48 @@ static void build_decode_tables(HostModel& m, const JsonValue* root, const std::
             }
         } else if (t == "ByteFallback") m.decoder = DEC_BYTE_FALLBACK;
         else if (t == "Fuse") m.decoder = DEC_FUSE;
-        else if (t == "Sequence") {
-            // Sequence[ByteFallback, Fuse] / [ByteFallback] / [Fuse]: Fuse behind ByteFallback changes nothing of the final string
-            // (Decoder::decode joins the chain's output with "", tokenizer/mod.rs:184-187)
-            const JsonValue* ds = dec->get("decoders");
-            std::vector<std::string> kinds;
-            if (ds && ds->is_array()) for (const auto& d : ds->arr) kinds.push_back(d->get_str("type"));
-            if (kinds == std::vector<std::string>{"ByteFallback", "Fuse"} || kinds == std::vector<std::string>{"ByteFallback"}) m.decoder = DEC_BYTE_FALLBACK;
-            else if (kinds == std::vector<std::string>{"Fuse"}) m.decoder = DEC_FUSE;
-            else {
-                m.decoder = DEC_UNSUPPORTED;
-                m.dec_unsupported = "a decoder Sequence other than [ByteFallback, Fuse] is outside the decode path";
-                return;
+        else if (t == "CTC") {
+            // decoders/ctc.rs:45-63: consecutive equal tokens collapse (on the device: an id equal to the kept id in front of it), then per
+            // token: pad_token -> "", cleanup() and word_delimiter_token -> " "; a token that ends up empty contributes nothing
+            m.decoder = DEC_CTC;
+            m.dec_dedup = true;
+            ctc_pad = dec->get_str("pad_token", "<pad>");
+            ctc_delim = dec->get_str("word_delimiter_token", "|");
+            cleanup = dec->get_bool("cleanup", true);
+        } else if (t == "Sequence" || t == "Replace" || t == "Strip") {
+            // A chain (decoders/sequence.rs:26-33: every member's decode_chain in turn; Decoder::decode joins the result with "",
+            // tokenizer/mod.rs:184-187) of the per-token members -- Replace with a literal pattern (normalizers/replace.rs:88-106), Strip
+            // (decoders/strip.rs:27-60) --, then ByteFallback, then Fuse, then Strip { start <= 1, stop 0 }: what the SentencePiece-style
+            // tokenizers carry ([Replace("\u2581", " "), ByteFallback, Fuse, Strip(" ", 1, 0)]).  Behind Fuse there is ONE string, so that Strip
+            // only ever looks at the first kept token -- its first-position form.  Anything else is refused.
+            std::vector<const JsonValue*> members;
+            if (t == "Sequence") {
+                const JsonValue* ds = dec->get("decoders");
+                if (ds && ds->is_array()) for (const auto& d : ds->arr) members.push_back(d.get());
+            } else members.push_back(dec);
+            int stage = 0;                      // 0: per-token members, 1: behind ByteFallback, 2: behind Fuse, 3: behind the leading Strip
+            auto refuse = [&](const std::string& why) { m.decoder = DEC_UNSUPPORTED; m.dec_unsupported = why; };
+            m.decoder = DEC_CHAIN;
+            for (const JsonValue* d : members) {
+                const std::string k = d->get_str("type");
+                if (k == "Replace" && stage == 0) {
+                    const JsonValue* pat = d->get("pattern");
+                    const std::string lit = pat ? pat->get_str("String") : "";
+                    if (lit.empty()) { refuse("a Replace decoder with a Regex (or empty) pattern is outside the decode path"); return; }
+                    chain.push_back(DecEl{0, lit, d->get_str("content"), 0, 0});
+                } else if (k == "Strip" && (stage == 0 || stage == 2)) {
+                    const std::string c = d->get_str("content");
+                    const int64_t a = (int64_t)d->get_num("start", 0), b = (int64_t)d->get_num("stop", 0);
+                    if (c.empty() || a < 0 || b < 0) { refuse("a Strip decoder without a content char"); return; }
+                    if (stage == 2) {
+                        if (a > 1 || b != 0) { refuse("a Strip decoder behind Fuse with start > 1 or stop > 0 is outside the decode path"); return; }
+                        if (a == 1) { post_strip = c; stage = 3; }
+                    } else chain.push_back(DecEl{1, c, "", a, b});
+                } else if (k == "ByteFallback" && stage == 0) { chain_bytes = true; stage = 1; }
+                else if (k == "Fuse" && stage <= 1) stage = 2;
+                else { refuse("decoder '" + k + "' at this place of a decoder Sequence is outside the decode path"); return; }
             }
+            if (chain_bytes && !post_strip.empty() && (uint8_t)post_strip[0] >= 0x80u) { refuse("a non-ASCII Strip behind ByteFallback is outside the decode path"); return; }
         } else {
             m.decoder = DEC_UNSUPPORTED;
             m.dec_unsupported = "decoder type '" + t + "' is outside the decode path";
@@ -600,17 +659,36 @@ static void build_decode_tables(HostModel& m, const JsonValue* root, const std::
             };
             first = replace_all("");
             rest = replace_all(" ");
-        } else if (m.decoder == DEC_FUSE || m.decoder == DEC_BYTE_FALLBACK) {
+        } else if (m.decoder == DEC_CTC) {
+            first = replace_lit(t, ctc_pad, "");
+            if (ctc_pad.empty()) first = t;
+            if (cleanup) { first = wp_cleanup(first); if (!ctc_delim.empty()) first = replace_lit(first, ctc_delim, " "); }
+            rest = first;
+        } else if (m.decoder == DEC_FUSE || m.decoder == DEC_BYTE_FALLBACK || m.decoder == DEC_CHAIN) {
+            std::string u = t;
+            for (const DecEl& el : chain) u = el.kind == 0 ? replace_lit(u, el.a, el.b) : strip(u, el.a, el.start, el.stop);
+            const std::string& t = u;                       // (what ByteFallback / Fuse see)
             first = rest = t;
+            if (!post_strip.empty()) {
+                // Strip(c, 1, 0) behind Fuse: one leading c off the FUSED string -- off the first kept token.  (An empty token would hand the
+                // strip on to its successor: no table says that.)
+                if (t.empty() && !special[id]) { m.decoder = DEC_UNSUPPORTED; m.dec_unsupported = "a token that decodes to nothing in front of a Strip behind Fuse"; return; }
+                first = strip(t, post_strip, 1, 0);
+            }
+            const bool bytes_on = m.decoder == DEC_BYTE_FALLBACK || chain_bytes;
             // <0xXX>: six bytes, "<0x", two hex digits as u8::from_str_radix reads them (a leading '+' counts as a digit's place), ">"
-            if (m.decoder == DEC_BYTE_FALLBACK && t.size() == 6 && t.compare(0, 3, "<0x") == 0 && t[5] == '>') {
+            if (bytes_on && t.size() == 6 && t.compare(0, 3, "<0x") == 0 && t[5] == '>') {
                 auto hex = [](char c) -> int { return c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1; };
                 int v = -1;
                 if (t[3] == '+') { const int lo = hex(t[4]); if (lo >= 0) v = lo; }
                 else { const int hi = hex(t[3]), lo = hex(t[4]); if (hi >= 0 && lo >= 0) v = hi * 16 + lo; }
                 if (v >= 0) {
+                    // (as the first kept token under a leading Strip of this very byte: nothing -- unless its run is not UTF-8, which the
+                    // device decides: the length of the first-position form is 0 then)
+                    const bool gone_first = !post_strip.empty() && post_strip.size() == 1 && (uint8_t)post_strip[0] == (uint8_t)v;
+                    if (gone_first) m.dec_position_dependent = true;
                     e[0] = (uint32_t)v;
-                    e[1] = 1u | DEC_BYTE | (special[id] ? DEC_SPECIAL : 0u);
+                    e[1] = (gone_first ? 0u : 1u) | DEC_BYTE | (special[id] ? DEC_SPECIAL : 0u);
                     e[2] = (uint32_t)v;
                     e[3] = 1u;
                     m.dec_has_bytes = true;

@@ -41,7 +41,9 @@ struct AddedToken {
 enum DecoderKind { DEC_JOIN_SPACE = 0 /* decoder: null -> tokens.join(" ") */, DEC_BYTELEVEL = 1, DEC_WORDPIECE = 2, DEC_UNSUPPORTED = 3,
                    DEC_BPE = 4 /* BPEDecoder: the end-of-word suffix becomes a space, nothing on the last token (decoders/bpe.rs:26-39) */,
                    DEC_BYTE_FALLBACK = 5 /* ByteFallback, alone or Sequence[ByteFallback, Fuse] (decoders/byte_fallback.rs:27-67, fuse.rs:24-29) */,
-                   DEC_FUSE = 6 /* Fuse: tokens.join("") */ };
+                   DEC_FUSE = 6 /* Fuse: tokens.join("") */,
+                   DEC_CHAIN = 7 /* Replace / Strip, alone or as Sequence[Replace*, Strip*, ByteFallback?, Fuse?, Strip(c, <= 1, 0)?] (replace.rs:88-106, strip.rs:27-60, sequence.rs:26-33) */,
+                   DEC_CTC = 8 /* decoders/ctc.rs:45-63 */ };
 
 struct HostModel {
     ModelKind model = MODEL_NONE;
@@ -162,6 +164,7 @@ struct HostModel {
     std::vector<uint8_t> dec_blob;
     bool dec_position_dependent = false; // first-position form differs from the other one for some id
     bool dec_special_is_last = false;    // BPEDecoder: the position with a form of its own is the LAST kept token of a sequence, not the first
+    bool dec_dedup = false;              // CTC: a kept token equal to the kept token in front of it is dropped first
     bool dec_has_bytes = false;          // ByteFallback: some id is a <0xXX> token (runs of them are validated as UTF-8 on the device)
 
     std::vector<uint16_t> uc_stage1;    // [UC_STAGE1_LEN]

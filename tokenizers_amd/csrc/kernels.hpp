@@ -399,7 +399,7 @@ void launch_apply_match_ids(hipStream_t st, const uint32_t* match_list, const ui
 // phase 2 gathers the bytes; firstmask is null when no id has a position-dependent form
 void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, int64_t n_docs, int64_t n_tok, const void* entry, uint32_t n_ids,
                    const uint8_t* blob, uint32_t skip_special, uint32_t* firstmask, uint32_t* len, uint32_t* bsum, uint32_t* pos, int64_t* total,
-                   int64_t* out_off, uint8_t* out_bytes_or_null, uint32_t from_end = 0, uint32_t* badmask = nullptr);      // from_end: the position mask marks the LAST kept token (BPEDecoder); badmask: ByteFallback
+                   int64_t* out_off, uint8_t* out_bytes_or_null, uint32_t from_end = 0, uint32_t* badmask = nullptr, uint32_t* dupmask = nullptr);      // from_end: the position mask marks the LAST kept token (BPEDecoder); badmask: ByteFallback
 int prepare_long_kernel();
 void launch_bpe_merge_long(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows,
                            uint32_t* tmp_ids, uint32_t* tmp_end, uint32_t* list_huge, uint32_t* n_huge,

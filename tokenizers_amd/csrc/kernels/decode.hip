@@ -84,17 +84,33 @@ __global__ __launch_bounds__(256) void k_decode_byte_runs(const uint32_t* __rest
     }
     close_run(end);
 }
+// CTC (decoders/ctc.rs:47-48: `.dedup()` over the kept tokens): a kept token whose id equals the kept id in front of it is marked and
+// contributes nothing.  One lane per sequence.
+__global__ __launch_bounds__(256) void k_decode_dups(const uint32_t* __restrict__ ids, const int64_t* __restrict__ tok_off, int64_t n_docs,
+                                                     const uint4* __restrict__ entry, uint32_t n_ids, uint32_t skip_special, uint32_t* __restrict__ dupmask) {
+    const int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (d >= n_docs) return;
+    uint32_t prev = 0xFFFFFFFFu;
+    for (int64_t t = tok_off[d], e = tok_off[d + 1]; t < e; ++t) {
+        const uint32_t id = ids[t];
+        if (id >= n_ids || !dec_kept(entry[id].y, skip_special)) continue;
+        if (id == prev) atomicOr(&dupmask[t >> 5], 1u << (t & 31));
+        prev = id;
+    }
+}
 __global__ __launch_bounds__(256) void k_decode_len(const uint32_t* __restrict__ ids, int64_t n_tok, const uint4* __restrict__ entry, uint32_t n_ids,
                                                     uint32_t skip_special, const uint32_t* __restrict__ firstmask, const uint32_t* __restrict__ badmask,
-                                                    uint32_t* __restrict__ len) {
+                                                    const uint32_t* __restrict__ dupmask, uint32_t* __restrict__ len) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_tok) return;
     const uint32_t id = ids[t];
     uint32_t l = 0;
-    if (id < n_ids) {
+    if (id < n_ids && !(dupmask && ((dupmask[t >> 5] >> (t & 31)) & 1u))) {
         const uint4 e = entry[id];
         if (dec_kept(e.y, skip_special)) {
-            if (e.y & DEC_BYTE) l = (badmask && ((badmask[t >> 5] >> (t & 31)) & 1u)) ? 3u : 1u;      // (U+FFFD is three bytes)
+            // (a byte token: U+FFFD -- three bytes -- if its run is not UTF-8, else its byte; as the first kept token under a leading
+            // Strip of that very byte the first-position form has length 0)
+            if ((e.y & DEC_BYTE) && badmask && ((badmask[t >> 5] >> (t & 31)) & 1u)) l = 3u;
             else l = (firstmask && ((firstmask[t >> 5] >> (t & 31)) & 1u)) ? (e.y & DEC_LEN_MASK) : e.w;
         }
     }
@@ -109,20 +125,21 @@ __global__ __launch_bounds__(256) void k_decode_doc_off(const int64_t* __restric
 }
 __global__ __launch_bounds__(256) void k_decode_copy(const uint32_t* __restrict__ ids, int64_t n_tok, const uint4* __restrict__ entry, uint32_t n_ids,
                                                      uint32_t skip_special, const uint32_t* __restrict__ firstmask, const uint32_t* __restrict__ badmask,
-                                                     const uint8_t* __restrict__ blob, const uint32_t* __restrict__ pos, uint8_t* __restrict__ out) {
+                                                     const uint32_t* __restrict__ dupmask, const uint8_t* __restrict__ blob, const uint32_t* __restrict__ pos,
+                                                     uint8_t* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_tok) return;
     const uint32_t id = ids[t];
-    if (id >= n_ids) return;
+    if (id >= n_ids || (dupmask && ((dupmask[t >> 5] >> (t & 31)) & 1u))) return;
     const uint4 e = entry[id];
     if (!dec_kept(e.y, skip_special)) return;
+    const bool first = firstmask && ((firstmask[t >> 5] >> (t & 31)) & 1u);
     if (e.y & DEC_BYTE) {
         uint8_t* const dst = out + pos[t];
         if (badmask && ((badmask[t >> 5] >> (t & 31)) & 1u)) { dst[0] = 0xEFu; dst[1] = 0xBFu; dst[2] = 0xBDu; }
-        else dst[0] = (uint8_t)e.x;
+        else if ((first ? (e.y & DEC_LEN_MASK) : e.w) != 0u) dst[0] = (uint8_t)e.x;
         return;
     }
-    const bool first = firstmask && ((firstmask[t >> 5] >> (t & 31)) & 1u);
     const uint32_t off = first ? e.x : e.z, l = first ? (e.y & DEC_LEN_MASK) : e.w;
     const uint8_t* src = blob + off;
     uint8_t* dst = out + pos[t];
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(256) void k_decode_copy(const uint32_t* __restrict_
 }
 void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, int64_t n_docs, int64_t n_tok, const void* entry, uint32_t n_ids,
                    const uint8_t* blob, uint32_t skip_special, uint32_t* firstmask, uint32_t* len, uint32_t* bsum, uint32_t* pos, int64_t* total,
-                   int64_t* out_off, uint8_t* out_bytes_or_null, uint32_t from_end, uint32_t* badmask) {
+                   int64_t* out_off, uint8_t* out_bytes_or_null, uint32_t from_end, uint32_t* badmask, uint32_t* dupmask) {
     const uint4* e = (const uint4*)entry;
     if (!out_bytes_or_null) {                                 // phase 1: lengths, positions, document offsets, total
         (void)hipMemsetAsync(total, 0, 8, st);
@@ -143,8 +160,13 @@ void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, 
                 (void)hipMemsetAsync(badmask, 0, (size_t)((n_tok >> 5) + 1) * 4, st);
                 hipLaunchKernelGGL(k_decode_byte_runs, dim3(blocks_for(n_docs, 256)), dim3(256), 0, st, ids, tok_off, n_docs, e, n_ids, skip_special, badmask);
             }
+            if (dupmask && n_docs > 0) {
+                (void)hipMemsetAsync(dupmask, 0, (size_t)((n_tok >> 5) + 1) * 4, st);
+                hipLaunchKernelGGL(k_decode_dups, dim3(blocks_for(n_docs, 256)), dim3(256), 0, st, ids, tok_off, n_docs, e, n_ids, skip_special, dupmask);
+            }
             const unsigned nb = blocks_for(n_tok, 256);
-            hipLaunchKernelGGL(k_decode_len, dim3(nb), dim3(256), 0, st, ids, n_tok, e, n_ids, skip_special, (const uint32_t*)firstmask, (const uint32_t*)badmask, len);
+            hipLaunchKernelGGL(k_decode_len, dim3(nb), dim3(256), 0, st, ids, n_tok, e, n_ids, skip_special, (const uint32_t*)firstmask, (const uint32_t*)badmask,
+                               (const uint32_t*)dupmask, len);
             hipLaunchKernelGGL(k_u32_reduce, dim3(nb), dim3(256), 0, st, (const uint32_t*)len, n_tok, bsum);
             hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
             hipLaunchKernelGGL(k_u32_down, dim3(nb), dim3(256), 0, st, (const uint32_t*)len, n_tok, (const uint32_t*)bsum, pos);
@@ -153,6 +175,6 @@ void launch_decode(hipStream_t st, const uint32_t* ids, const int64_t* tok_off, 
                            (const int64_t*)total, out_off);
     } else if (n_tok > 0) {                                   // phase 2: gather (the caller sized out_bytes from *total)
         hipLaunchKernelGGL(k_decode_copy, dim3(blocks_for(n_tok, 256)), dim3(256), 0, st, ids, n_tok, e, n_ids, skip_special,
-                           (const uint32_t*)firstmask, (const uint32_t*)badmask, blob, (const uint32_t*)pos, out_bytes_or_null);
+                           (const uint32_t*)firstmask, (const uint32_t*)badmask, (const uint32_t*)dupmask, blob, (const uint32_t*)pos, out_bytes_or_null);
     }
 }
