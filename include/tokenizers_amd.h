@@ -130,8 +130,9 @@ int tkamd_tokenizer_info(const tkamd_tokenizer* tok, tkamd_info* info);
  * A device may be named more than once (two shards then share a GPU: how the sharded path is tested on a one-GPU box; RCCL needs
  * distinct devices).  n_devices == 0: the list comes from the environment, TOKENIZERS_GPU_DEVICES = "all" | "0,2,3" (unset: device
  * 0).  BatchLongest padding couples the documents of a batch through one number -- the longest encoding: the shards exchange theirs and
- * pad to the batch's (utils/padding.rs:55-63).  TKAMD_WANT_OVERFLOW and mixed batches run on devices[0] alone; so does a batch of
- * less than 1 MB per device (TKAMD_SHARD_MIN_KB, read when the handle is made).  The device-buffer entries and decode_batch run on devices[0]. */
+ * pad to the batch's (utils/padding.rs:55-63).  TKAMD_WANT_OVERFLOW (a shard's encodings are counted when its kernels are done, its
+ * document indices rebased) and mixed batches (cut between inputs) are sharded like the rest; a batch of
+ * less than 1 MB per device runs on devices[0] alone (TKAMD_SHARD_MIN_KB, read when the handle is made).  The device-buffer entries and decode_batch run on devices[0]. */
 #define TKAMD_COLLECT_HOST      0
 #define TKAMD_COLLECT_ROOT_P2P  1
 #define TKAMD_COLLECT_ROOT_RCCL 2
@@ -183,7 +184,7 @@ int tkamd_encode_batch_words(tkamd_tokenizer* tok, const uint8_t* text, const in
  * is padded as one (BatchLongest over every input).  TKAMD_PAIRS must not be set.  The result holds one encoding per input (plus the
  * overflowing ones with TKAMD_WANT_OVERFLOW; tkamd_batch_encoding_parts then gives (window, 0) for a single sequence); type ids and
  * sequence ids are written for every token.  A batch that turns out to hold one kind only is handed to the entry of that kind; a
- * mixed one runs as one slice on devices[0].  TKAMD_ERR_INVALID for an input of no or more than two sequences. */
+ * mixed one runs as one slice (a multi-device handle: one shard per device, cut between inputs).  TKAMD_ERR_INVALID for an input of no or more than two sequences. */
 int tkamd_encode_batch_mixed(tkamd_tokenizer* tok, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs,
                              const int64_t* seq_offsets, int64_t n_seqs, const int64_t* input_offsets, int64_t n_inputs,
                              uint32_t flags, tkamd_batch** out);

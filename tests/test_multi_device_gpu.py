@@ -82,7 +82,7 @@ def test_sharded_call_vs_oracle_gpt2():
 @pytest.mark.parametrize("name", ["bert_wordpiece_4000_specials", "llama3_small_6000_specials"])
 def test_sharded_pairs_truncation_fixed_padding_and_words(name):
     """what rides on the epilogues: pairs (shards are cut between pairs), truncation, Fixed padding, special tokens, pre-tokenized
-    sequences (cut between sequences); BatchLongest padding and the overflowing encodings couple the batch and stay on devices[0]"""
+    sequences (cut between sequences); BatchLongest padding and the overflowing encodings (both sharded since round 6)"""
     import tokenizers_amd as ta
     d = json.loads(load_tokenizer_json(name))
     d["truncation"] = {"direction": "Right", "max_length": 24, "strategy": "LongestFirst", "stride": 2}
@@ -96,14 +96,27 @@ def test_sharded_pairs_truncation_fixed_padding_and_words(name):
         _same(many.encode_batch_csr(pairs, add_special_tokens=True, **kw), one.encode_batch_csr(pairs, add_special_tokens=True, **kw))
     words = [l.split(" ") for l in lines]
     _same(many.encode_batch_csr(words, is_pretokenized=True, add_special_tokens=True), one.encode_batch_csr(words, is_pretokenized=True, add_special_tokens=True))
+    # a batch that mixes single sequences and pairs: cut between inputs, every shard with its slice of the inputs' CSR (round 6)
+    mixed = [lines[i] if i % 3 else (lines[i], lines[i + 1]) for i in range(0, len(lines) - 1)]
+    is_pair = lambda it: isinstance(it, (tuple, list))
+    _same(many._encode_mixed(mixed, "char", True, True, False, False, is_pair), one._encode_mixed(mixed, "char", True, True, False, False, is_pair))
+    st = many.shard_stats()
+    assert len(st) == 3 and all(nb > 0 for _, nb, _ in st), "the mixed batch went over every device"
     # BatchLongest: sharded since round 6 (the shards exchange their longest encoding); overflowing: the whole batch on devices[0]
     d["padding"]["strategy"] = "BatchLongest"
     js = json.dumps(d)
     one, many = ta.Tokenizer.from_str(js, device=0), ta.Tokenizer.from_str(js, device=_devs(3))
     _same(many.encode_batch_csr(lines, add_special_tokens=True), one.encode_batch_csr(lines, add_special_tokens=True))
-    a, b = many.encode_batch_csr(lines, add_special_tokens=True, overflowing=True), one.encode_batch_csr(lines, add_special_tokens=True, overflowing=True)
-    _same(a, b)
-    assert np.array_equal(a.enc_docs, b.enc_docs)
+    # overflowing: sharded too since round 6 (a shard knows how many encodings it yields when its kernels are done: the displacements are
+    # summed then, its document indices rebased) -- singles and pairs, with the shards' own BatchLongest exchange
+    for inp in (lines, pairs):
+        a, b = many.encode_batch_csr(inp, add_special_tokens=True, overflowing=True), one.encode_batch_csr(inp, add_special_tokens=True, overflowing=True)
+        _same(a, b)
+        assert np.array_equal(a.enc_docs, b.enc_docs) and len(a.enc_docs) > len(inp)
+        if a.enc_parts is not None or b.enc_parts is not None:
+            assert np.array_equal(a.enc_parts, b.enc_parts)
+        st = many.shard_stats()
+        assert len(st) == 3 and all(nb > 0 for _, nb, _ in st), "the overflowing batch went over every device"
 
 
 @pytest.mark.parametrize("n_dev", [2, 3, 5])

@@ -73,9 +73,9 @@ static int encode_host(tkamd_tokenizer* t, const uint8_t* text, const int64_t* d
         const bool overflow = (flags & TKAMD_WANT_OVERFLOW) && t->hm.trunc_on;
         if (n_slices < 2 || (t->hm.pad_on && !t->hm.pad_fixed) || overflow || mixed) n_slices = 1;
         // a multi-device handle: one shard per device (what couples the documents of a batch stays on devices[0], like it stays in one slice)
-        if (!t->replicas.empty() && !mixed && !overflow && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
+        if (!t->replicas.empty() && n_bytes >= (int64_t)(t->replicas.size() + 1) * t->shard_min_bytes) {
             wait_ready(n_bytes, n_bytes);                        // (the shards' workers read the whole text: no pacing across devices yet)
-            return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out);
+            return encode_host_sharded(t, text, doc_offsets, n_docs, seq_offsets, n_seqs, flags, out, mixed ? input_offsets : nullptr, mixed ? n_inputs : -1);
         }
         // slice boundaries: the first document at or after k / n_slices of the bytes (a malformed CSR just gives odd slices: the
         // device validation of each slice reports it)

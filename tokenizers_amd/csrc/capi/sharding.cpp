@@ -21,6 +21,7 @@ struct Shard {
     hipStream_t s = nullptr;
     int64_t d0 = 0, d1 = 0, g0 = 0, g1 = 0, b0 = 0, nb = 0;
     int64_t n_tok = 0, n_enc = 0, tok_base = 0, enc_base = 0;
+    int64_t i0 = 0, i1 = 0;                  // a mixed batch: the shard's inputs
     tkamd_device_result res{};
     int rc = TKAMD_OK;
     std::string err;
@@ -30,7 +31,7 @@ struct Shard {
 };
 
 static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const int64_t* doc_offsets, int64_t n_docs, const int64_t* seq_offsets,
-                               int64_t n_seqs, uint32_t flags, tkamd_batch** out) {
+                               int64_t n_seqs, uint32_t flags, tkamd_batch** out, const int64_t* input_offsets = nullptr, int64_t n_inputs = -1) {
     std::lock_guard<std::mutex> group_lock(t->group_mu);
     const int n_dev = (int)t->replicas.size() + 1;
     int collect = t->collect;
@@ -39,6 +40,9 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
     const int64_t n_grp = words_in ? n_seqs : n_docs;
     auto doc_of = [&](int64_t g) { return words_in ? seq_offsets[g] : g; };
     const int64_t unit = (flags & TKAMD_PAIRS) ? 2 : 1;
+    // a batch that mixes single sequences and pairs (round 6: sharded like the rest -- cut between INPUTS, every shard gets its slice of
+    // the inputs' CSR, counted from its own first sequence)
+    const bool mixed = n_inputs >= 0;
     std::vector<Shard> sh((size_t)n_dev);
     {
         int64_t prev = 0;
@@ -48,9 +52,10 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
                 const int64_t target = n_bytes / n_dev * (r + 1);
                 g = std::lower_bound(doc_offsets, doc_offsets + n_docs, target) - doc_offsets;
                 if (words_in) g = std::lower_bound(seq_offsets, seq_offsets + n_seqs, g) - seq_offsets;
+                if (mixed) g = *std::lower_bound(input_offsets, input_offsets + n_inputs, g);       // the first input starting at or after that sequence
                 g = std::min(n_grp, std::max<int64_t>(prev, g / unit * unit));
                 // the boundary nearer to the target of the two around it (a long document straddling the target goes to the lighter side)
-                if (g - unit >= prev && g <= n_grp && target - doc_offsets[doc_of(g - unit)] < doc_offsets[doc_of(g)] - target) g -= unit;
+                if (!mixed && g - unit >= prev && g <= n_grp && target - doc_offsets[doc_of(g - unit)] < doc_offsets[doc_of(g)] - target) g -= unit;
             }
             Shard& x = sh[(size_t)r];
             x.tr = r ? t->replicas[(size_t)r - 1].get() : t;
@@ -61,6 +66,11 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
             // whatever the offsets between the cuts look like -- those are the device validation's business)
             if (x.nb < 0 || x.b0 < 0 || x.b0 + x.nb > n_bytes) throw Invalid("doc_offsets is not a monotone CSR over [0, n_bytes]");
             x.n_enc = (g - prev) / unit;
+            if (mixed) {                                     // inputs [i0, i1): input_offsets was checked by the caller (a CSR of ones and twos over the sequences)
+                x.i0 = std::lower_bound(input_offsets, input_offsets + n_inputs + 1, prev) - input_offsets;
+                x.i1 = std::lower_bound(input_offsets, input_offsets + n_inputs + 1, g) - input_offsets;
+                x.n_enc = x.i1 - x.i0;
+            }
             prev = g;
         }
     }
@@ -84,7 +94,7 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
         }
     }
     std::unique_ptr<tkamd_batch> b(new tkamd_batch());
-    b->n_docs = n_grp / unit;
+    b->n_docs = mixed ? n_inputs : n_grp / unit;
     std::vector<std::vector<ShardDesc>> desc((size_t)n_dev);
     Rendezvous rv(n_dev);
     std::atomic<bool> go{false};
@@ -103,6 +113,9 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
         if (r.d_word_ids) d.push_back({r.d_word_ids, 4, true, 0, &b->word_ids});
         if (r.d_type_ids) { d.push_back({r.d_type_ids, 1, true, 0, &b->type_ids}); d.push_back({r.d_seq_ids, 1, true, 0, &b->seq_ids}); }
         if (r.d_pad_counts) d.push_back({r.d_pad_counts, 4, false, 0, &b->pad_counts});
+        // TKAMD_WANT_OVERFLOW: the document of every encoding (rebased to the batch's documents in phase 2), a pair's windows
+        if (r.d_enc_docs) d.push_back({r.d_enc_docs, 4, false, 0, &b->enc_docs});
+        if (r.d_enc_parts) d.push_back({r.d_enc_parts, 8, false, 0, &b->enc_parts});
         return d;
     };
     auto count_of = [&](const Shard& x, const ShardDesc& d) { return (d.per_token ? x.n_tok : x.n_enc) + d.extra; };
@@ -131,16 +144,24 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
             HIP_CHECK(hipMemsetAsync((uint8_t*)w->h_text.p + x.nb, 0, TKAMD_TEXT_PAD, s));
             HIP_CHECK(hipMemcpyAsync(w->h_doc_off.p, doc_offsets + x.d0, (size_t)(nd + 1) * 8, hipMemcpyHostToDevice, s));
             if (x.b0) launch_add_i64(s, w->h_doc_off.as<int64_t>(), nd + 1, -x.b0);
+            if (mixed) {
+                w->h_inp_off.reserve((size_t)(x.n_enc + 1) * 8);
+                HIP_CHECK(hipMemcpyAsync(w->h_inp_off.p, input_offsets + x.i0, (size_t)(x.n_enc + 1) * 8, hipMemcpyHostToDevice, s));
+                if (x.g0) launch_add_i64(s, w->h_inp_off.as<int64_t>(), x.n_enc + 1, -x.g0);
+            }
             if (batch_longest) w->pad_exchange = [&x, &pad_max](uint32_t v) { x.exchanged = true; return pad_max.exchange(v); };
             struct Unhook { Workspace* w; ~Unhook() { w->pad_exchange = nullptr; } } unhook{w};
             run_pipeline(tr, w, w->h_text.as<uint8_t>(), w->h_doc_off.as<int64_t>(), nd, x.nb, words_in ? w->h_seq_off.as<int64_t>() : nullptr,
-                         words_in ? ng : -1, flags, s, &x.res);
+                         words_in ? ng : -1, flags, s, &x.res, mixed ? w->h_inp_off.as<int64_t>() : nullptr, mixed ? x.n_enc : -1);
             w->last_text = w->h_text.as<uint8_t>(); w->last_doc_off = w->h_doc_off.as<int64_t>(); w->last_n_bytes = x.nb; w->last_flags = flags; w->last_result = x.res;
             int64_t n_pt = 0;
             w->pad_exchange = nullptr;                       // (the exchange is over: batch_longest saw a queue overflow before it, so finish_batch has nothing to run again)
             const int bits = finish_batch(tr, w, s, &x.n_tok, &n_pt);
             if (bits) return error_from_bits(bits);
             x.res = w->last_result;
+            // (the overflowing encodings: how many this shard yields is known now -- finish_batch waited for the count; round 6: rounds
+            // 3-5 ran such a batch on devices[0] alone because the displacements were not known up front.  They never were needed up front.)
+            if (x.res.d_enc_docs && w->last_n_enc >= 0) x.n_enc = w->last_n_enc;
             if (collect == TKAMD_COLLECT_ROOT_P2P) HIP_CHECK(hipEventCreateWithFlags(&x.ev, hipEventDisableTiming));
             desc[(size_t)r] = describe(x);
             return TKAMD_OK;
@@ -178,6 +199,7 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
                 HIP_CHECK(hipSetDevice(tr->device));
                 std::lock_guard<std::mutex> wl(x.w->mu);
                 if (x.tok_base) launch_add_i64(x.s, (int64_t*)x.res.d_tok_offsets, x.n_enc + 1, x.tok_base);      // the shard's CSR continues the batch's
+                if (x.res.d_enc_docs && x.g0) launch_add_u32(x.s, (uint32_t*)x.res.d_enc_docs, x.n_enc, (uint32_t)(mixed ? x.i0 : x.g0 / unit));   // ... and its documents the batch's
                 const std::vector<ShardDesc>& dl = desc[(size_t)r];
                 if (collect == TKAMD_COLLECT_HOST) {
                     for (const ShardDesc& d : dl) {
@@ -266,6 +288,9 @@ static int encode_host_sharded(tkamd_tokenizer* t, const uint8_t* text, const in
     b->has_words = r0.d_word_ids != nullptr;
     b->has_types = r0.d_type_ids != nullptr;
     b->has_pads = r0.d_pad_counts != nullptr;
+    b->has_enc_docs = r0.d_enc_docs != nullptr;
+    b->has_enc_parts = r0.d_enc_parts != nullptr;
+    if (b->has_enc_docs) { b->n_docs = 0; for (const Shard& x : sh) b->n_docs += x.n_enc; }
     b->n_tokens = total_tok;
     *out = b.release();
     return TKAMD_OK;

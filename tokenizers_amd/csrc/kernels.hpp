@@ -363,6 +363,7 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a);
 void launch_add_specials(hipStream_t st, int grid, const SpecialArgs& a);
 // truncation + specials + padding: lengths (and the batch maximum), then the new CSR (*n_tok2 = its total), then the copy
 void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta);
+void launch_add_u32(hipStream_t st, uint32_t* data, int64_t n, uint32_t delta);
 void launch_final_lens(hipStream_t st, const FinalArgs& a);
 // overflowing encodings: encodings per document + their numbering (*n_enc = how many there are), then -- with a.n_docs still the
 // number of DOCUMENTS -- every encoding's token range, its length with the specials, and the batch maximum over the truncated

@@ -196,6 +196,9 @@ void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg
     hipLaunchKernelGGL(k_prefix_doc_offsets, dim3(nb), dim3(256), 0, st, (const uint32_t*)need, n_bound, n_dev, (const uint32_t*)bsum, seg_off, xseg_off, x_len);
     hipLaunchKernelGGL(k_prefix_copy, dim3(grid), dim3(256), 0, st, text, seg_off, (const int64_t*)xseg_off, n_bound, n_dev, xtext, nos, noe);
 }
+void launch_add_u32(hipStream_t st, uint32_t* data, int64_t n, uint32_t delta) {
+    if (n > 0) hipLaunchKernelGGL(k_add_u32, dim3(blocks_for(n, 256)), dim3(256), 0, st, data, n, delta);
+}
 void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta) {
     hipLaunchKernelGGL(k_add_i64, dim3(blocks_for(n, 256)), dim3(256), 0, st, data, n, delta);
 }

@@ -153,6 +153,10 @@ __global__ void k_doc_first_pretok(const int64_t* __restrict__ doc_off, int64_t 
 }
 
 // data[i] += delta (rebasing a CSR slice)
+__global__ void k_add_u32(uint32_t* __restrict__ data, int64_t n, uint32_t delta) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) data[i] += delta;
+}
 __global__ void k_add_i64(int64_t* __restrict__ data, int64_t n, int64_t delta) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) data[i] += delta;
