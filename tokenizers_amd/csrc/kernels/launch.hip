@@ -179,13 +179,17 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     // half-empty round (profiles/r6j_c2_sq_summary_byte.json)
     static const int per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<false, true>, 256, 0) != hipSuccess || n < 1) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<false, true, false>, 256, 0) != hipSuccess || n < 1) n = 4;
         return std::min(n, 8);
     }();
     const dim3 g(std::max(1, grid / 8) * per_cu);
-    const bool simple = !a.norig && !a.matchmask && !a.trim_offsets && !a.word_of_doc && !a.first_tok;
-    if (a.pt_end) { if (simple) hipLaunchKernelGGL((k_token_meta<true, true>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_token_meta<true, false>), g, dim3(256), 0, st, a); }
-    else { if (simple) hipLaunchKernelGGL((k_token_meta<false, true>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_token_meta<false, false>), g, dim3(256), 0, st, a); }
+    // (SIMPLE also reads char offsets off the ORIGINAL text's lead-byte mask at x positions: the two texts must be one)
+    const bool simple = !a.norig && !a.matchmask && !a.trim_offsets && !a.word_of_doc && !a.first_tok && a.x_doc_off == a.doc_off && a.x_text == a.text;
+    const bool chars = simple && a.char_mode && a.want_offsets;
+#define TKAMD_TM(E, S, C) hipLaunchKernelGGL((k_token_meta<E, S, C>), g, dim3(256), 0, st, a)
+    if (a.pt_end) { if (chars) TKAMD_TM(true, true, true); else if (simple) TKAMD_TM(true, true, false); else TKAMD_TM(true, false, false); }
+    else { if (chars) TKAMD_TM(false, true, true); else if (simple) TKAMD_TM(false, true, false); else TKAMD_TM(false, false, false); }
+#undef TKAMD_TM
 }
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,
                          uint32_t* need, uint32_t* bsum, int64_t* xseg_off, int64_t* x_len, uint8_t* xtext, uint32_t* nos, uint32_t* noe, int grid) {

@@ -552,13 +552,17 @@ constexpr int TM_EXC = 512;                               // tokens of a tile on
 // two dependent round trips a tile cost, 0.09 ms of the kernel's 0.29 with nothing else to do, fly during the previous tile's work.
 // Loads are unconditional with clamped addresses: a load under a condition whose other branch fills the same registers is waited for
 // at once -- kernels/output.hip cp_load_tok0.)
-struct TmScal { uint32_t T0, T1, s_end; int64_t d0; };
-template <bool HAS_END> struct TmAhead { uint32_t tokoff[4], start[4], end[HAS_END ? 4 : 1], dpt, dxo, dod; Unaligned16 b8; };
+struct TmScal { uint32_t T0, T1, s0, s_end; int64_t d0; };
+template <bool HAS_END, bool CHARS> struct TmAhead { uint32_t tokoff[4], start[4], end[HAS_END ? 4 : 1], dpt, dxo, dod; Unaligned16 b8; unsigned long long lm[CHARS ? 1 : 0]; uint32_t lp[CHARS ? 1 : 0]; };
+constexpr int TM_LEADW = 256;                             // char mode: 64-byte words of the text, from the tile's first pre-token on, whose lead-byte mask and prefix sit in LDS
 // SIMPLE: what most tokenizers are -- no normalizer's alignment map, no added-token matches, no trim_offsets, documents that are not the
 // words of pre-tokenized sequences: a token's offsets are its (snapped) edges minus its document's start, and the general path's flag
 // tests (a thousand scalar instructions in meta_one_token, taken or not) are not compiled in.
-template <bool HAS_END, bool SIMPLE>
+// CHARS (with SIMPLE): char offsets, ranks from the LDS window of the lead-byte mask (an instantiation of its own: the byte-offset kernel
+// measured 6 % slower carrying the window's registers and LDS, profiles/r7d_*)
+template <bool HAS_END, bool SIMPLE, bool CHARS>
 __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
+    static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
     __shared__ uint32_t s_end[HAS_END ? TM_TILE : 1];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
@@ -569,6 +573,11 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     __shared__ uint32_t s_scan[4];
     __shared__ uint32_t s_before, s_slow, s_nexc;
     __shared__ uint16_t s_exc[TM_EXC];                    // tokens of the tile that need memory (see the token loop)
+    // char mode (SIMPLE: the x text IS the original text): lead-byte mask and lead bytes in front of the TM_LEADW words from the tile's
+    // first pre-token on -- a tile of prose spans about a hundred; a token that ends beyond them takes the general path
+    __shared__ unsigned long long s_lm[CHARS ? TM_LEADW : 1];
+    __shared__ uint32_t s_lp[CHARS ? TM_LEADW : 1];
+    static_assert(TM_LEADW == 256, "a word a lane");
     static_assert(TM_TOKCAP == 256 * 16, "sixteen boundary bytes a lane");
     const int64_t P = *a.n_pretok;
     const uint32_t n_tok = (uint32_t)*a.n_tok;
@@ -576,15 +585,18 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     const int64_t n_tiles = (P + TM_TILE - 1) / TM_TILE;
     if (n_tiles == 0) return;
     const int64_t G = gridDim.x;
+    constexpr bool chars = CHARS;
+    const uint32_t lw_max = chars ? (uint32_t)(a.doc_off[a.n_docs] >> 6) : 0u;      // the last word of the lead-byte mask
     auto scal_of = [&](int64_t tile, TmScal& sc) {        // (a tile beyond the end: the last one's, never used)
         const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
         const int64_t pe = min(base + TM_TILE, P);
         sc.T0 = a.pt_tokoff[base];
+        sc.s0 = CHARS ? a.pt_start[base] : 0u;
         sc.T1 = pe < P ? a.pt_tokoff[pe] : n_tok;
         sc.s_end = a.pt_start[pe];                        // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
         sc.d0 = (int64_t)a.chunk_lo[base / a.chunk];      // chunk_lo[c]: the first d with doc_pt[d] >= c * chunk
     };
-    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END>& h) {
+    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END, CHARS>& h) {
         const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -599,9 +611,10 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         h.dod = ((const uint32_t*)a.doc_off)[2 * d];
         if (a.tok_b8) h.b8 = *(const Unaligned16*)(a.tok_b8 + min(sc.T0 + 16u * (uint32_t)tid, n_tok));     // (readable 64 bytes beyond the tokens)
         else h.b8 = Unaligned16{0u, 0u, 0u, 0u};
+        if constexpr (CHARS) { const uint32_t w = min((sc.s0 >> 6) + (uint32_t)tid, lw_max); h.lm[0] = a.leadmask[w]; h.lp[0] = a.lprefix[w]; }
     };
     TmScal sc0, sc1;
-    TmAhead<HAS_END> h;
+    TmAhead<HAS_END, CHARS> h;
     scal_of(blockIdx.x, sc0);
     scal_of((int64_t)blockIdx.x + G, sc1);
     ahead_of(blockIdx.x, sc0, h);
@@ -626,9 +639,10 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         // documents from the one in front of the first of the compaction chunk that holds `base` on (the tile's first pre-tokens may belong
         // to that one): their entries go to the table
         s_dtab[tid] = make_uint4(h.dpt, h.dxo, h.dod, 0u);
+        if constexpr (CHARS) { s_lm[tid] = h.lm[0]; s_lp[tid] = h.lp[0]; }
         // (char mode: the lead bytes in front of every listed document -- asked for in FRONT of the next tile's loads: loads return in order)
         uint32_t dlead_now = 0u;
-        if (SIMPLE && a.char_mode && a.want_offsets && dbase + tid < a.n_docs) dlead_now = lead_rank(a.leadmask, a.lprefix, h.dod);
+        if (CHARS && dbase + tid < a.n_docs) dlead_now = lead_rank(a.leadmask, a.lprefix, h.dod);
         if (tid == 0) { s_before = 0u; s_slow = 0u; s_nexc = 0u; }
         if (!slow) {
             // the tile's boundary bytes, sixteen a lane, and the mask of the FIRST markers among them (four lanes a word)
@@ -650,7 +664,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         ahead_of(tile + G, sc1, h);                       // the next tile's loads: in flight from here to the top of the next iteration
         __syncthreads();
         if (tid == 0) s_ts[np] = make_uint2(sc0.T1, sc0.s_end);               // (behind the barrier: lane np & 255 wrote a clamped value there)
-        if (SIMPLE && a.char_mode && a.want_offsets) s_dtab[tid].w = dlead_now;
+        if (CHARS) s_dtab[tid].w = dlead_now;
         // the documents in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
         for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
             const int64_t k = d - dbase;
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                 general(t, lo);
             }
         } else {
-            const uint32_t dbase32 = (uint32_t)dbase;
+            const uint32_t dbase32 = (uint32_t)dbase, lw0 = sc0.s0 >> 6;
             for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
                 // (branch-free up to the stores: every branch of a wavefront is a dozen scalar instructions whether taken or not)
                 const uint32_t tt = T0 + t, w = t >> 6;
@@ -737,24 +751,25 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                 const uint32_t s = ts0.y, e = HAS_END ? s_end[i] : ts1.y;
                 const uint32_t dk = s_doc[i] - dbase32;
                 const uint32_t carried = (uint32_t)s_b8[o + 1u - T0] | (c == 1u ? 1u : 0u);      // (the byte in front of token 1: 0 = a row without boundary bytes)
-                if (dk >= (uint32_t)TM_DOCS || !carried) {
+                // the boundary in front of the token (none in front of token 0) and behind it (none behind the last one: the pre-token's end)
+                const uint32_t v0 = j ? b0 : 0u, v1 = j + 1u < c ? b1 : 0u;
+                const uint32_t rel = v0 & 31u, rel_end = v1 ? (v1 & 31u) : e - s;
+                const uint32_t bs = s + rel - b8_back(v0), be = s + rel_end + b8_fwd(v1);
+                if (dk >= (uint32_t)TM_DOCS || !carried || (chars && (be >> 6) - lw0 >= (uint32_t)TM_LEADW)) {
                     const uint32_t k = atomicAdd(&s_nexc, 1u);
                     if (k < (uint32_t)TM_EXC) s_exc[k] = (uint16_t)t;
                     continue;
                 }
                 const uint4 de = s_dtab[dk];
                 const uint32_t word = (uint32_t)(base + i) - de.x, xdoc = de.y, odoc = de.z;
-                // the boundary in front of the token (none in front of token 0) and behind it (none behind the last one: the pre-token's end)
-                const uint32_t v0 = j ? b0 : 0u, v1 = j + 1u < c ? b1 : 0u;
-                const uint32_t rel = v0 & 31u, rel_end = v1 ? (v1 & 31u) : e - s;
-                const uint32_t bs = s + rel - b8_back(v0), be = s + rel_end + b8_fwd(v1);
                 if (SIMPLE) {
                     if (a.want_words) store_nt(a.word_ids + tt, word);
                     if (a.want_offsets) {
                         uint32_t os = bs - xdoc, oe = be - xdoc;
-                        if (a.char_mode) {
-                            os = lead_rank(a.leadmask, a.lprefix, os + odoc) - de.w;
-                            oe = lead_rank(a.leadmask, a.lprefix, oe + odoc) - de.w;
+                        if (chars) {                      // (x text == original text here: launch_token_meta)
+                            const uint32_t ws = (bs >> 6) - lw0, we = (be >> 6) - lw0;
+                            os = s_lp[ws] + (uint32_t)__popcll(s_lm[ws] & ((1ull << (bs & 63u)) - 1ull)) - de.w;
+                            oe = s_lp[we] + (uint32_t)__popcll(s_lm[we] & ((1ull << (be & 63u)) - 1ull)) - de.w;
                         }
                         store_nt((uint2*)(a.offsets + 2 * (size_t)tt), make_uint2(os, oe));
                     }
@@ -771,7 +786,14 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                     const uint32_t w = t >> 6;
                     const int i = (int)(s_tpre[w] + (uint32_t)__popcll(s_tmask[w] & ((2ull << (t & 63u)) - 1ull))) - 1;
                     const uint32_t o = s_ts[i].x, c = s_ts[i + 1].x - o;
-                    if ((int64_t)s_doc[i] - dbase >= TM_DOCS || (c > 1u && !s_b8[o + 1u - T0])) general(t, i);
+                    bool exc = (int64_t)s_doc[i] - dbase >= TM_DOCS || (c > 1u && !s_b8[o + 1u - T0]);
+                    if (!exc && chars) {                  // (the token's end, as the loop above computed it)
+                        const uint32_t j = T0 + t - o, b1 = s_b8[t + 1u], v1 = j + 1u < c ? b1 : 0u;
+                        const uint32_t s = s_ts[i].y, e = HAS_END ? s_end[i] : s_ts[i + 1].y;
+                        const uint32_t be = s + (v1 ? (v1 & 31u) : e - s) + b8_fwd(v1);
+                        exc = (be >> 6) - lw0 >= (uint32_t)TM_LEADW;
+                    }
+                    if (exc) general(t, i);
                 }
             } else {
                 for (uint32_t k = (uint32_t)tid; k < nexc; k += 256u) {
