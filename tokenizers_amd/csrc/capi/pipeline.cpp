@@ -788,10 +788,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
 
     uint32_t* pt_end = nullptr;       // explicit pre-token ends in memory (offsets pass of the "Removed" pre-tokenizers)
     bool has_end = false;             // the pre-tokenizer produced an end bitmask
+    bool meta_masks = false;          // offsets / word ids: k_token_meta reads the pre-tokens' starts off the start mask (no pt_start array)
     auto after_masks = [&]() {        // what reads the start mask and its prefix counts: behind the pre-tokenizer + scan
-        if (want_meta) {
-            // the pre-token offsets themselves are only materialised for the offsets / word-id pass; the model kernels work from
-            // the bitmasks (k_lookup) and from (start, length) queue entries
+        if (want_meta && !meta_masks) {
+            // the pre-token offsets themselves are only materialised for the offsets / word-id pass of the pre-tokenizers WITH an end mask
+            // (and of BPE over characters without an unk_token: k_token_meta_seq); the others' k_token_meta reads the start mask itself
             pf.begin("emit_pretok");
             launch_emit_pretok(st, w->w_startmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, d_npretok, w->w_pt_start.as<uint32_t>());
             if (pt_end) launch_emit_pretok_end(st, w->w_startmask.as<ull>(), w->w_endmask.as<ull>(), w->w_wprefix.as<uint32_t>(), n_x, x_len_dev, pt_end);
@@ -839,7 +840,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.begin("mask_scan");
         // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
         // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
-        launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok, len_bound ? x_len_dev : nullptr);
+        meta_masks = want_meta && !has_end && !(hm.char_bpe && !hm.unk_configured && !hm.byte_fallback);
+        if (meta_masks) w->w_tile_w.reserve(((size_t)n_x / META_TILE + 4) * 4);
+        launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok, len_bound ? x_len_dev : nullptr,
+                         meta_masks ? w->w_tile_w.as<uint32_t>() : nullptr);
         pf.end();
         after_masks();
     }
@@ -1035,8 +1039,14 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.first_tok = first_tok;
         a.x_text = x_text;
         a.text = d_text;
-        a.pt_start = w->w_pt_start.as<uint32_t>();
+        a.pt_start = meta_masks ? nullptr : w->w_pt_start.as<uint32_t>();
         a.pt_end = pt_end;
+        a.startmask = w->w_startmask.as<ull>();
+        a.wprefix = w->w_wprefix.as<uint32_t>();
+        a.tile_w = meta_masks ? w->w_tile_w.as<uint32_t>() : nullptr;
+        a.n_mask_words = W;
+        a.x_len_dev = x_len_dev;
+        a.x_len_host = n_x;
         a.n_tok = d_ntok_total;
         a.pt_tokoff = w->w_pt_tokoff.as<uint32_t>();
         a.tmp_end = tmp_end;

@@ -106,12 +106,20 @@ struct QueuePlan {
     QView v[4];                   // pre-tokens of <= 16 bytes, <= 32, <= 64, longer
 };
 
+constexpr int META_TILE = 1024;      // pre-tokens a tile of k_token_meta (kernels/output.hip TM_TILE)
 // arguments of k_token_meta (offsets / word ids), passed by value
 struct MetaArgs {
     const uint8_t* x_text;            // text the pre-tokenizer saw (normalised if a normalizer ran)
     const uint8_t* text;              // the original text
     const uint32_t* pt_start;
     const uint32_t* pt_end;           // null: pt_start[p+1]
+    // pt_start null (pre-tokenizers without an end mask, round 6): k_token_meta reads the starts off the start mask itself
+    const unsigned long long* startmask;
+    const uint32_t* wprefix;          // starts in front of every 64-byte word
+    const uint32_t* tile_w;           // [ceil(P / META_TILE)] the word that holds the start of pre-token k * META_TILE (launch_mask_scan)
+    int64_t n_mask_words;
+    const int64_t* x_len_dev;         // length of the x text: on the device if it was derived there, else x_len_host
+    int64_t x_len_host;
     const int64_t* n_tok;             // total token count (device scalar)
     const uint32_t* pt_tokoff;
     const uint32_t* tmp_end;          // token ends relative to the pre-token start (multi-token pre-tokens)
@@ -313,7 +321,7 @@ void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs,
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                         const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask);
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
-                      int64_t* total, const int64_t* len_dev = nullptr);      // len_dev: only the words of a text of that (device-side) length
+                      int64_t* total, const int64_t* len_dev = nullptr, uint32_t* tile_w = nullptr);      // len_dev: only the words of a text of that (device-side) length
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start);
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,

@@ -22,11 +22,11 @@ void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, co
     hipLaunchKernelGGL(k_pretok_gpt2_seq<SQ_LUT_COPIES>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
 }
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
-                      int64_t* total, const int64_t* len_dev) {
+                      int64_t* total, const int64_t* len_dev, uint32_t* tile_w) {
     unsigned nb = blocks_for(n_words, 256 * WS_PER);
     hipLaunchKernelGGL(k_words_reduce, dim3(nb), dim3(256), 0, st, mask, n_words, bsum, len_dev);
     hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, bsum, (int64_t)nb, (const int64_t*)nullptr, (int64_t)1, total);
-    hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix, len_dev);
+    hipLaunchKernelGGL(k_words_down, dim3(nb), dim3(256), 0, st, mask, n_words, (const uint32_t*)bsum, wprefix, len_dev, tile_w);
 }
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,
                         const int64_t* len_dev, const int64_t* n_pretok, uint32_t* pt_start) {
@@ -179,16 +179,18 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     // half-empty round (profiles/r6j_c2_sq_summary_byte.json)
     static const int per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<false, true, false>, 256, 0) != hipSuccess || n < 1) n = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<false, true, false, true>, 256, 0) != hipSuccess || n < 1) n = 4;
         return std::min(n, 8);
     }();
     const dim3 g(std::max(1, grid / 8) * per_cu);
     // (SIMPLE also reads char offsets off the ORIGINAL text's lead-byte mask at x positions: the two texts must be one)
     const bool simple = !a.norig && !a.matchmask && !a.trim_offsets && !a.word_of_doc && !a.first_tok && a.x_doc_off == a.doc_off && a.x_text == a.text;
     const bool chars = simple && a.char_mode && a.want_offsets;
-#define TKAMD_TM(E, S, C) hipLaunchKernelGGL((k_token_meta<E, S, C>), g, dim3(256), 0, st, a)
-    if (a.pt_end) { if (chars) TKAMD_TM(true, true, true); else if (simple) TKAMD_TM(true, true, false); else TKAMD_TM(true, false, false); }
-    else { if (chars) TKAMD_TM(false, true, true); else if (simple) TKAMD_TM(false, true, false); else TKAMD_TM(false, false, false); }
+    const bool masks = !a.pt_start;                      // (the starts off the start mask: pipeline.cpp, pre-tokenizers without an end mask)
+#define TKAMD_TM(E, S, C, M) hipLaunchKernelGGL((k_token_meta<E, S, C, M>), g, dim3(256), 0, st, a)
+    if (a.pt_end) { if (chars) TKAMD_TM(true, true, true, false); else if (simple) TKAMD_TM(true, true, false, false); else TKAMD_TM(true, false, false, false); }
+    else if (masks) { if (chars) TKAMD_TM(false, true, true, true); else if (simple) TKAMD_TM(false, true, false, true); else TKAMD_TM(false, false, false, true); }
+    else { if (chars) TKAMD_TM(false, true, true, false); else if (simple) TKAMD_TM(false, true, false, false); else TKAMD_TM(false, false, false, false); }
 #undef TKAMD_TM
 }
 void launch_prefix_space(hipStream_t st, const uint8_t* text, const int64_t* seg_off, int64_t n_bound, const int64_t* n_dev, const unsigned long long* matchmask,

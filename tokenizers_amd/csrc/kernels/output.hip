@@ -552,17 +552,27 @@ constexpr int TM_EXC = 512;                               // tokens of a tile on
 // two dependent round trips a tile cost, 0.09 ms of the kernel's 0.29 with nothing else to do, fly during the previous tile's work.
 // Loads are unconditional with clamped addresses: a load under a condition whose other branch fills the same registers is waited for
 // at once -- kernels/output.hip cp_load_tok0.)
-struct TmScal { uint32_t T0, T1, s0, s_end; int64_t d0; };
-template <bool HAS_END, bool CHARS> struct TmAhead { uint32_t tokoff[4], start[4], end[HAS_END ? 4 : 1], dpt, dxo, dod; Unaligned16 b8; unsigned long long lm[CHARS ? 1 : 0]; uint32_t lp[CHARS ? 1 : 0]; };
+struct TmScal { uint32_t T0, T1, lw, s_end; int64_t d0; };      // lw: the 64-byte word of the text that holds the tile's first pre-token's start (CHARS / MASKS)
+template <bool HAS_END, bool CHARS, bool MASKS> struct TmAhead {
+    uint32_t tokoff[4], start[MASKS ? 1 : 4], end[HAS_END ? 4 : 1], dpt, dxo, dod;
+    Unaligned16 b8;
+    unsigned long long lm[CHARS ? 1 : 0]; uint32_t lp[CHARS ? 1 : 0];
+    unsigned long long sm[MASKS ? 1 : 0]; uint32_t wp[MASKS ? 1 : 0];      // MASKS: word lw + lane of the start mask, the starts in front of it
+};
 constexpr int TM_LEADW = 256;                             // char mode: 64-byte words of the text, from the tile's first pre-token on, whose lead-byte mask and prefix sit in LDS
 // SIMPLE: what most tokenizers are -- no normalizer's alignment map, no added-token matches, no trim_offsets, documents that are not the
 // words of pre-tokenized sequences: a token's offsets are its (snapped) edges minus its document's start, and the general path's flag
 // tests (a thousand scalar instructions in meta_one_token, taken or not) are not compiled in.
 // CHARS (with SIMPLE): char offsets, ranks from the LDS window of the lead-byte mask (an instantiation of its own: the byte-offset kernel
 // measured 6 % slower carrying the window's registers and LDS, profiles/r7d_*)
-template <bool HAS_END, bool SIMPLE, bool CHARS>
+// MASKS (pre-tokenizers without an end mask): the pre-tokens' starts are read off the START MASK -- the 256 words from the one that holds
+// the tile's first pre-token on (tile_w, a by-product of the mask scan), every lane walking its word's bits into the tile's LDS array by
+// rank; more windows if the tile's text is longer (pre-tokens of hundreds of bytes).  pt_start -- 4 bytes a pre-token written by
+// k_emit_pretok and read back here, 0.06 ms of launch on C2 -- does not exist then.
+template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS>
 __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
+    static_assert(!(MASKS && HAS_END), "an end mask: the ends come from pt_end, the starts from pt_start");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
     __shared__ uint32_t s_end[HAS_END ? TM_TILE : 1];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_b8[TM_TOKCAP + 16];
     __shared__ uint4 s_dtab[TM_DOCS];                     // document dbase + k: first pre-token, start in the x text, in the original, (char mode) lead bytes in front of it
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_before, s_slow, s_nexc;
+    __shared__ uint32_t s_before, s_slow, s_nexc, s_cov;
     __shared__ uint16_t s_exc[TM_EXC];                    // tokens of the tile that need memory (see the token loop)
     // char mode (SIMPLE: the x text IS the original text): lead-byte mask and lead bytes in front of the TM_LEADW words from the tile's
     // first pre-token on -- a tile of prose spans about a hundred; a token that ends beyond them takes the general path
@@ -587,22 +597,24 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     const int64_t G = gridDim.x;
     constexpr bool chars = CHARS;
     const uint32_t lw_max = chars ? (uint32_t)(a.doc_off[a.n_docs] >> 6) : 0u;      // the last word of the lead-byte mask
+    const uint32_t x_len = MASKS ? (uint32_t)(a.x_len_dev ? *a.x_len_dev : a.x_len_host) : 0u;
+    const uint32_t n_mw = MASKS ? (uint32_t)min(a.n_mask_words, (int64_t)(x_len >> 6) + 1) : 0u;     // words of the start mask that hold bits
     auto scal_of = [&](int64_t tile, TmScal& sc) {        // (a tile beyond the end: the last one's, never used)
         const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
         const int64_t pe = min(base + TM_TILE, P);
         sc.T0 = a.pt_tokoff[base];
-        sc.s0 = CHARS ? a.pt_start[base] : 0u;
+        sc.lw = MASKS ? a.tile_w[base / TM_TILE] : CHARS ? a.pt_start[base] >> 6 : 0u;
         sc.T1 = pe < P ? a.pt_tokoff[pe] : n_tok;
-        sc.s_end = a.pt_start[pe];                        // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
+        sc.s_end = MASKS ? 0u : a.pt_start[pe];           // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
         sc.d0 = (int64_t)a.chunk_lo[base / a.chunk];      // chunk_lo[c]: the first d with doc_pt[d] >= c * chunk
     };
-    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END, CHARS>& h) {
+    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END, CHARS, MASKS>& h) {
         const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int64_t p = min(base + tid + 256 * q, P - 1);
             h.tokoff[q] = a.pt_tokoff[p];
-            h.start[q] = a.pt_start[p];
+            if constexpr (!MASKS) h.start[q] = a.pt_start[p];
             if (HAS_END) h.end[q] = a.pt_end[p];
         }
         const int64_t d = min((sc.d0 > 0 ? sc.d0 - 1 : 0) + tid, a.n_docs - 1);
@@ -611,10 +623,11 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         h.dod = ((const uint32_t*)a.doc_off)[2 * d];
         if (a.tok_b8) h.b8 = *(const Unaligned16*)(a.tok_b8 + min(sc.T0 + 16u * (uint32_t)tid, n_tok));     // (readable 64 bytes beyond the tokens)
         else h.b8 = Unaligned16{0u, 0u, 0u, 0u};
-        if constexpr (CHARS) { const uint32_t w = min((sc.s0 >> 6) + (uint32_t)tid, lw_max); h.lm[0] = a.leadmask[w]; h.lp[0] = a.lprefix[w]; }
+        if constexpr (CHARS) { const uint32_t w = min(sc.lw + (uint32_t)tid, lw_max); h.lm[0] = a.leadmask[w]; h.lp[0] = a.lprefix[w]; }
+        if constexpr (MASKS) { const uint32_t w = min(sc.lw + (uint32_t)tid, n_mw - 1u); h.sm[0] = a.startmask[w]; h.wp[0] = a.wprefix[w]; }
     };
     TmScal sc0, sc1;
-    TmAhead<HAS_END, CHARS> h;
+    TmAhead<HAS_END, CHARS, MASKS> h;
     scal_of(blockIdx.x, sc0);
     scal_of((int64_t)blockIdx.x + G, sc1);
     ahead_of(blockIdx.x, sc0, h);
@@ -632,7 +645,8 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = tid + 256 * q;
-            s_ts[i] = make_uint2(h.tokoff[q], h.start[q]);    // (beyond np: the clamped loads' values, read by nobody)
+            if constexpr (MASKS) s_ts[i].x = h.tokoff[q];     // (the starts: the walk over the mask words below)
+            else s_ts[i] = make_uint2(h.tokoff[q], h.start[q]);    // (beyond np: the clamped loads' values, read by nobody)
             if (HAS_END) s_end[i] = h.end[q];
             s_doc[i] = 0u;
         }
@@ -644,6 +658,18 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         uint32_t dlead_now = 0u;
         if (CHARS && dbase + tid < a.n_docs) dlead_now = lead_rank(a.leadmask, a.lprefix, h.dod);
         if (tid == 0) { s_before = 0u; s_slow = 0u; s_nexc = 0u; }
+        // MASKS: the starts of the pre-tokens base .. base + np (the last one: the end of pre-token np - 1), by rank, from a window of 256
+        // mask words; `wp` counts the starts in front of the word -- ranks in front of the tile wrap around and fail the test
+        auto walk_starts = [&](unsigned long long m, uint32_t wp, uint32_t word) {
+            uint32_t r = wp - (uint32_t)base;
+            for (; m; m &= m - 1ull, ++r)
+                if (r <= (uint32_t)np) s_ts[r].y = (word << 6) + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+        };
+        if constexpr (MASKS) {
+            const uint32_t word = sc0.lw + (uint32_t)tid;
+            walk_starts(word < n_mw ? h.sm[0] : 0ull, h.wp[0], word);
+            if (tid == 255) s_cov = h.wp[0] + (uint32_t)__popcll(h.sm[0]) - (uint32_t)base;      // ranks below this are placed (a clamped word: every rank there is)
+        }
         if (!slow) {
             // the tile's boundary bytes, sixteen a lane, and the mask of the FIRST markers among them (four lanes a word)
             const Unaligned16 v = h.b8;
@@ -663,7 +689,22 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         }
         ahead_of(tile + G, sc1, h);                       // the next tile's loads: in flight from here to the top of the next iteration
         __syncthreads();
-        if (tid == 0) s_ts[np] = make_uint2(sc0.T1, sc0.s_end);               // (behind the barrier: lane np & 255 wrote a clamped value there)
+        if constexpr (MASKS) {
+            // (rare: the tile's text is longer than a window -- more windows, loaded here and waited for)
+            uint32_t cov = s_cov, wnext = sc0.lw + 256u;
+            while (cov <= (uint32_t)np && wnext < n_mw) {
+                __syncthreads();                          // (everyone has read s_cov)
+                const uint32_t word = wnext + (uint32_t)tid, wc = min(word, n_mw - 1u);
+                const unsigned long long m = a.startmask[wc];
+                const uint32_t wp = a.wprefix[wc];
+                walk_starts(word < n_mw ? m : 0ull, wp, word);
+                if (tid == 255) s_cov = wp + (uint32_t)__popcll(m) - (uint32_t)base;
+                __syncthreads();
+                cov = s_cov;
+                wnext += 256u;
+            }
+            if (tid == 0) { s_ts[np].x = sc0.T1; if (base + np == P) s_ts[np].y = x_len; }     // (the sentinel: the text's length)
+        } else if (tid == 0) s_ts[np] = make_uint2(sc0.T1, sc0.s_end);        // (behind the barrier: lane np & 255 wrote a clamped value there)
         if (CHARS) s_dtab[tid].w = dlead_now;
         // the documents in front of the tile are counted, the ones inside it add to their first pre-token (an empty document to the next one's)
         for (int64_t d = d0 + tid; d < a.n_docs; d += 256) {
@@ -740,7 +781,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                 general(t, lo);
             }
         } else {
-            const uint32_t dbase32 = (uint32_t)dbase, lw0 = sc0.s0 >> 6;
+            const uint32_t dbase32 = (uint32_t)dbase, lw0 = sc0.lw;
             for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
                 // (branch-free up to the stores: every branch of a wavefront is a dozen scalar instructions whether taken or not)
                 const uint32_t tt = T0 + t, w = t >> 6;

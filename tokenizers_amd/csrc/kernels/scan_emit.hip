@@ -29,8 +29,11 @@ __global__ __launch_bounds__(256) void k_words_reduce(const unsigned long long* 
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
+// tile_w (not null: the start mask, with offsets requested): tile_w[k] = the word that holds set bit number k * META_TILE -- where tile k
+// of k_token_meta starts reading the mask (kernels/output.hip MASKS)
 __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __restrict__ mask, int64_t n_words,
-                                                    const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix, const int64_t* __restrict__ len_dev) {
+                                                    const uint32_t* __restrict__ bsum, uint32_t* __restrict__ wprefix, const int64_t* __restrict__ len_dev,
+                                                    uint32_t* __restrict__ tile_w) {
     __shared__ uint32_t sm[4];
     if (len_dev) n_words = min(n_words, (*len_dev >> 6) + 2);
     if ((int64_t)blockIdx.x * 256 * WS_PER >= n_words) return;      // (the whole workgroup)
@@ -49,6 +52,15 @@ __global__ __launch_bounds__(256) void k_words_down(const unsigned long long* __
     for (int k = 0; k < WS_PER; ++k) v += c[k];
     uint32_t tot;
     uint32_t run = bsum[blockIdx.x] + block256_excl_scan(v, sm, &tot);
+    if (tile_w) {
+        uint32_t ex = run;
+#pragma unroll
+        for (int k = 0; k < WS_PER; ++k) {                 // (a word holds at most 64 bits: at most one multiple of the tile lies in it)
+            const uint32_t kk = (ex + (uint32_t)META_TILE - 1u) / (uint32_t)META_TILE;
+            if (c[k] && kk * (uint32_t)META_TILE < ex + c[k]) tile_w[kk] = (uint32_t)(w0 + k);
+            ex += c[k];
+        }
+    }
     if (whole) {
         uint4 o0, o1;
         o0.x = run; run += c[0]; o0.y = run; run += c[1]; o0.z = run; run += c[2]; o0.w = run; run += c[3];
