@@ -840,7 +840,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         pf.begin("mask_scan");
         // (three launches: reduce, a one-workgroup scan of the totals, down.  A single-pass ticket + look-back kernel in their place measured
         // 0.031 ms against 0.015: 917 tickets on one address and a look-back chain cost more than two launch gaps, profiles/r4a_*)
-        meta_masks = want_meta && !has_end && !(hm.char_bpe && !hm.unk_configured && !hm.byte_fallback);
+        meta_masks = want_meta && !(hm.char_bpe && !hm.unk_configured && !hm.byte_fallback);       // (that one: k_token_meta_seq, from pt_start / pt_end)
         if (meta_masks) w->w_tile_w.reserve(((size_t)n_x / META_TILE + 4) * 4);
         launch_mask_scan(st, w->w_startmask.as<ull>(), W, w->w_bsum.as<uint32_t>(), w->w_wprefix.as<uint32_t>(), d_npretok, len_bound ? x_len_dev : nullptr,
                          meta_masks ? w->w_tile_w.as<uint32_t>() : nullptr);
@@ -1040,8 +1040,9 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         a.x_text = x_text;
         a.text = d_text;
         a.pt_start = meta_masks ? nullptr : w->w_pt_start.as<uint32_t>();
-        a.pt_end = pt_end;
+        a.pt_end = meta_masks ? nullptr : pt_end;
         a.startmask = w->w_startmask.as<ull>();
+        a.endmask = has_end ? w->w_endmask.as<ull>() : nullptr;
         a.wprefix = w->w_wprefix.as<uint32_t>();
         a.tile_w = meta_masks ? w->w_tile_w.as<uint32_t>() : nullptr;
         a.n_mask_words = W;

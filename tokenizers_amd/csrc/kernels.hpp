@@ -115,6 +115,7 @@ struct MetaArgs {
     const uint32_t* pt_end;           // null: pt_start[p+1]
     // pt_start null (pre-tokenizers without an end mask, round 6): k_token_meta reads the starts off the start mask itself
     const unsigned long long* startmask;
+    const unsigned long long* endmask;    // "Removed" pre-tokenizers: explicit ends (pt_end null then too), else null
     const uint32_t* wprefix;          // starts in front of every 64-byte word
     const uint32_t* tile_w;           // [ceil(P / META_TILE)] the word that holds the start of pre-token k * META_TILE (launch_mask_scan)
     int64_t n_mask_words;

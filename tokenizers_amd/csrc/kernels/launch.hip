@@ -188,7 +188,9 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     const bool chars = simple && a.char_mode && a.want_offsets;
     const bool masks = !a.pt_start;                      // (the starts off the start mask: pipeline.cpp, pre-tokenizers without an end mask)
 #define TKAMD_TM(E, S, C, M) hipLaunchKernelGGL((k_token_meta<E, S, C, M>), g, dim3(256), 0, st, a)
-    if (a.pt_end) { if (chars) TKAMD_TM(true, true, true, false); else if (simple) TKAMD_TM(true, true, false, false); else TKAMD_TM(true, false, false, false); }
+    const bool ends = a.pt_end || (masks && a.endmask);
+    if (ends && masks) { if (chars) TKAMD_TM(true, true, true, true); else if (simple) TKAMD_TM(true, true, false, true); else TKAMD_TM(true, false, false, true); }
+    else if (ends) { if (chars) TKAMD_TM(true, true, true, false); else if (simple) TKAMD_TM(true, true, false, false); else TKAMD_TM(true, false, false, false); }
     else if (masks) { if (chars) TKAMD_TM(false, true, true, true); else if (simple) TKAMD_TM(false, true, false, true); else TKAMD_TM(false, false, false, true); }
     else { if (chars) TKAMD_TM(false, true, true, false); else if (simple) TKAMD_TM(false, true, false, false); else TKAMD_TM(false, false, false, false); }
 #undef TKAMD_TM

@@ -554,10 +554,11 @@ constexpr int TM_EXC = 512;                               // tokens of a tile on
 // at once -- kernels/output.hip cp_load_tok0.)
 struct TmScal { uint32_t T0, T1, lw, s_end; int64_t d0; };      // lw: the 64-byte word of the text that holds the tile's first pre-token's start (CHARS / MASKS)
 template <bool HAS_END, bool CHARS, bool MASKS> struct TmAhead {
-    uint32_t tokoff[4], start[MASKS ? 1 : 4], end[HAS_END ? 4 : 1], dpt, dxo, dod;
+    uint32_t tokoff[4], start[MASKS ? 1 : 4], end[HAS_END && !MASKS ? 4 : 1], dpt, dxo, dod;
     Unaligned16 b8;
     unsigned long long lm[CHARS ? 1 : 0]; uint32_t lp[CHARS ? 1 : 0];
     unsigned long long sm[MASKS ? 1 : 0]; uint32_t wp[MASKS ? 1 : 0];      // MASKS: word lw + lane of the start mask, the starts in front of it
+    unsigned long long em[MASKS && HAS_END ? 1 : 0];                       // ... of the end mask ("Removed" pre-tokenizers)
 };
 constexpr int TM_LEADW = 256;                             // char mode: 64-byte words of the text, from the tile's first pre-token on, whose lead-byte mask and prefix sit in LDS
 // SIMPLE: what most tokenizers are -- no normalizer's alignment map, no added-token matches, no trim_offsets, documents that are not the
@@ -572,7 +573,6 @@ constexpr int TM_LEADW = 256;                             // char mode: 64-byte 
 template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS>
 __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
-    static_assert(!(MASKS && HAS_END), "an end mask: the ends come from pt_end, the starts from pt_start");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
     __shared__ uint32_t s_end[HAS_END ? TM_TILE : 1];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
             const int64_t p = min(base + tid + 256 * q, P - 1);
             h.tokoff[q] = a.pt_tokoff[p];
             if constexpr (!MASKS) h.start[q] = a.pt_start[p];
-            if (HAS_END) h.end[q] = a.pt_end[p];
+            if constexpr (HAS_END && !MASKS) h.end[q] = a.pt_end[p];
         }
         const int64_t d = min((sc.d0 > 0 ? sc.d0 - 1 : 0) + tid, a.n_docs - 1);
         h.dpt = a.doc_pt[d];
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         if (a.tok_b8) h.b8 = *(const Unaligned16*)(a.tok_b8 + min(sc.T0 + 16u * (uint32_t)tid, n_tok));     // (readable 64 bytes beyond the tokens)
         else h.b8 = Unaligned16{0u, 0u, 0u, 0u};
         if constexpr (CHARS) { const uint32_t w = min(sc.lw + (uint32_t)tid, lw_max); h.lm[0] = a.leadmask[w]; h.lp[0] = a.lprefix[w]; }
-        if constexpr (MASKS) { const uint32_t w = min(sc.lw + (uint32_t)tid, n_mw - 1u); h.sm[0] = a.startmask[w]; h.wp[0] = a.wprefix[w]; }
+        if constexpr (MASKS) { const uint32_t w = min(sc.lw + (uint32_t)tid, n_mw - 1u); h.sm[0] = a.startmask[w]; h.wp[0] = a.wprefix[w]; if constexpr (HAS_END) h.em[0] = a.endmask[w]; }
     };
     TmScal sc0, sc1;
     TmAhead<HAS_END, CHARS, MASKS> h;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
             const int i = tid + 256 * q;
             if constexpr (MASKS) s_ts[i].x = h.tokoff[q];     // (the starts: the walk over the mask words below)
             else s_ts[i] = make_uint2(h.tokoff[q], h.start[q]);    // (beyond np: the clamped loads' values, read by nobody)
-            if (HAS_END) s_end[i] = h.end[q];
+            if constexpr (HAS_END && !MASKS) s_end[i] = h.end[q];
             s_doc[i] = 0u;
         }
         // documents from the one in front of the first of the compaction chunk that holds `base` on (the tile's first pre-tokens may belong
@@ -665,9 +665,19 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
             for (; m; m &= m - 1ull, ++r)
                 if (r <= (uint32_t)np) s_ts[r].y = (word << 6) + (uint32_t)(__ffsll((unsigned long long)m) - 1);
         };
+        // (an end bit closes the last start in front of it: the end of pre-token [starts in front of the word + starts below the bit] - 1.
+        // Every pre-token of such a pre-tokenizer has one, in front of the next start: the windows that hold the starts hold the ends)
+        auto walk_ends = [&](unsigned long long sm, unsigned long long em, uint32_t wp, uint32_t word) {
+            for (; em; em &= em - 1ull) {
+                const uint32_t b = (uint32_t)(__ffsll((unsigned long long)em) - 1);
+                const uint32_t r = wp + (uint32_t)__popcll(sm & ((1ull << b) - 1ull)) - 1u - (uint32_t)base;
+                if (r < (uint32_t)np) s_end[r] = (word << 6) + b;
+            }
+        };
         if constexpr (MASKS) {
             const uint32_t word = sc0.lw + (uint32_t)tid;
             walk_starts(word < n_mw ? h.sm[0] : 0ull, h.wp[0], word);
+            if constexpr (HAS_END) walk_ends(word < n_mw ? h.sm[0] : 0ull, word < n_mw ? h.em[0] : 0ull, h.wp[0], word);
             if (tid == 255) s_cov = h.wp[0] + (uint32_t)__popcll(h.sm[0]) - (uint32_t)base;      // ranks below this are placed (a clamped word: every rank there is)
         }
         if (!slow) {
@@ -698,6 +708,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                 const unsigned long long m = a.startmask[wc];
                 const uint32_t wp = a.wprefix[wc];
                 walk_starts(word < n_mw ? m : 0ull, wp, word);
+                if constexpr (HAS_END) walk_ends(word < n_mw ? m : 0ull, word < n_mw ? a.endmask[wc] : 0ull, wp, word);
                 if (tid == 255) s_cov = wp + (uint32_t)__popcll(m) - (uint32_t)base;
                 __syncthreads();
                 cov = s_cov;
