@@ -189,7 +189,10 @@ void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     const bool masks = !a.pt_start;                      // (the starts off the start mask: pipeline.cpp, pre-tokenizers without an end mask)
 #define TKAMD_TM(E, S, C, M) hipLaunchKernelGGL((k_token_meta<E, S, C, M>), g, dim3(256), 0, st, a)
     const bool ends = a.pt_end || (masks && a.endmask);
-    if (ends && masks) { if (chars) TKAMD_TM(true, true, true, true); else if (simple) TKAMD_TM(true, true, false, true); else TKAMD_TM(true, false, false, true); }
+    // (behind BertNormalizer: the alignment map without per-byte ends; matches by tile -- kernels/output.hip NORIG)
+    const bool norig_simple = masks && a.norig && !a.norig_e && !a.trim_offsets && !a.word_of_doc && !a.first_tok;
+    if (norig_simple) { if (ends) hipLaunchKernelGGL((k_token_meta<true, true, false, true, true>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_token_meta<false, true, false, true, true>), g, dim3(256), 0, st, a); }
+    else if (ends && masks) { if (chars) TKAMD_TM(true, true, true, true); else if (simple) TKAMD_TM(true, true, false, true); else TKAMD_TM(true, false, false, true); }
     else if (ends) { if (chars) TKAMD_TM(true, true, true, false); else if (simple) TKAMD_TM(true, true, false, false); else TKAMD_TM(true, false, false, false); }
     else if (masks) { if (chars) TKAMD_TM(false, true, true, true); else if (simple) TKAMD_TM(false, true, false, true); else TKAMD_TM(false, false, false, true); }
     else { if (chars) TKAMD_TM(false, true, true, false); else if (simple) TKAMD_TM(false, true, false, false); else TKAMD_TM(false, false, false, false); }

@@ -553,12 +553,13 @@ constexpr int TM_EXC = 512;                               // tokens of a tile on
 // Loads are unconditional with clamped addresses: a load under a condition whose other branch fills the same registers is waited for
 // at once -- kernels/output.hip cp_load_tok0.)
 struct TmScal { uint32_t T0, T1, lw, s_end; int64_t d0; };      // lw: the 64-byte word of the text that holds the tile's first pre-token's start (CHARS / MASKS)
-template <bool HAS_END, bool CHARS, bool MASKS> struct TmAhead {
+template <bool HAS_END, bool CHARS, bool MASKS, bool NORIG> struct TmAhead {
     uint32_t tokoff[4], start[MASKS ? 1 : 4], end[HAS_END && !MASKS ? 4 : 1], dpt, dxo, dod;
     Unaligned16 b8;
     unsigned long long lm[CHARS ? 1 : 0]; uint32_t lp[CHARS ? 1 : 0];
     unsigned long long sm[MASKS ? 1 : 0]; uint32_t wp[MASKS ? 1 : 0];      // MASKS: word lw + lane of the start mask, the starts in front of it
     unsigned long long em[MASKS && HAS_END ? 1 : 0];                       // ... of the end mask ("Removed" pre-tokenizers)
+    unsigned long long mm[NORIG ? 1 : 0];                                  // ... of the added-token matches (NORIG)
 };
 constexpr int TM_LEADW = 256;                             // char mode: 64-byte words of the text, from the tile's first pre-token on, whose lead-byte mask and prefix sit in LDS
 // SIMPLE: what most tokenizers are -- no normalizer's alignment map, no added-token matches, no trim_offsets, documents that are not the
@@ -570,9 +571,14 @@ constexpr int TM_LEADW = 256;                             // char mode: 64-byte 
 // the tile's first pre-token on (tile_w, a by-product of the mask scan), every lane walking its word's bits into the tile's LDS array by
 // rank; more windows if the tile's text is longer (pre-tokens of hundreds of bytes).  pt_start -- 4 bytes a pre-token written by
 // k_emit_pretok and read back here, 0.06 ms of launch on C2 -- does not exist then.
-template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS>
+// NORIG (with SIMPLE and MASKS, round 6's last step): behind BertNormalizer -- the x text is the normalised text, a token's offsets
+// are its edges through the alignment map (norig; the end of a byte's range from its start and one byte of the original text) -- with
+// the general path's flag tests compiled out like SIMPLE's.  Added-token matches are a property of the TILE there: the match mask
+// rides in the mask window, a tile that holds a match bit takes the general path whole.
+template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS, bool NORIG = false>
 __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
+    static_assert(!NORIG || (SIMPLE && MASKS && !CHARS), "the alignment-map path reads the match mask with the mask window; char ranks from memory");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
     __shared__ uint32_t s_end[HAS_END ? TM_TILE : 1];
     __shared__ uint32_t s_doc[TM_TILE];                   // documents starting AT pre-token i, then (scanned) the document of pre-token i
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_b8[TM_TOKCAP + 16];
     __shared__ uint4 s_dtab[TM_DOCS];                     // document dbase + k: first pre-token, start in the x text, in the original, (char mode) lead bytes in front of it
     __shared__ uint32_t s_scan[4];
-    __shared__ uint32_t s_before, s_slow, s_nexc, s_cov;
+    __shared__ uint32_t s_before, s_slow, s_nexc, s_cov, s_match;
     __shared__ uint16_t s_exc[TM_EXC];                    // tokens of the tile that need memory (see the token loop)
     // char mode (SIMPLE: the x text IS the original text): lead-byte mask and lead bytes in front of the TM_LEADW words from the tile's
     // first pre-token on -- a tile of prose spans about a hundred; a token that ends beyond them takes the general path
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         sc.s_end = MASKS ? 0u : a.pt_start[pe];           // (pt_start[P] is the sentinel k_emit_pretok writes: the text's length)
         sc.d0 = (int64_t)a.chunk_lo[base / a.chunk];      // chunk_lo[c]: the first d with doc_pt[d] >= c * chunk
     };
-    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END, CHARS, MASKS>& h) {
+    auto ahead_of = [&](int64_t tile, const TmScal& sc, TmAhead<HAS_END, CHARS, MASKS, NORIG>& h) {
         const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -624,10 +630,10 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         if (a.tok_b8) h.b8 = *(const Unaligned16*)(a.tok_b8 + min(sc.T0 + 16u * (uint32_t)tid, n_tok));     // (readable 64 bytes beyond the tokens)
         else h.b8 = Unaligned16{0u, 0u, 0u, 0u};
         if constexpr (CHARS) { const uint32_t w = min(sc.lw + (uint32_t)tid, lw_max); h.lm[0] = a.leadmask[w]; h.lp[0] = a.lprefix[w]; }
-        if constexpr (MASKS) { const uint32_t w = min(sc.lw + (uint32_t)tid, n_mw - 1u); h.sm[0] = a.startmask[w]; h.wp[0] = a.wprefix[w]; if constexpr (HAS_END) h.em[0] = a.endmask[w]; }
+        if constexpr (MASKS) { const uint32_t w = min(sc.lw + (uint32_t)tid, n_mw - 1u); h.sm[0] = a.startmask[w]; h.wp[0] = a.wprefix[w]; if constexpr (HAS_END) h.em[0] = a.endmask[w]; if constexpr (NORIG) h.mm[0] = a.matchmask ? a.matchmask[w] : 0ull; }
     };
     TmScal sc0, sc1;
-    TmAhead<HAS_END, CHARS, MASKS> h;
+    TmAhead<HAS_END, CHARS, MASKS, NORIG> h;
     scal_of(blockIdx.x, sc0);
     scal_of((int64_t)blockIdx.x + G, sc1);
     ahead_of(blockIdx.x, sc0, h);
@@ -640,6 +646,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
         const int64_t dbase = d0 > 0 ? d0 - 1 : 0;
         const uint32_t T0 = sc0.T0, nt = sc0.T1 - T0;
         bool slow = nt > (uint32_t)TM_TOKCAP || !a.tok_b8;
+        if (NORIG && tid == 0) s_match = 0u;              // (its last reader was the previous tile's second barrier)
         __syncthreads();                                  // (the previous tile's readers are done)
         // ---- this tile's loads, asked for a tile ago: into LDS
 #pragma unroll
@@ -679,6 +686,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
             walk_starts(word < n_mw ? h.sm[0] : 0ull, h.wp[0], word);
             if constexpr (HAS_END) walk_ends(word < n_mw ? h.sm[0] : 0ull, word < n_mw ? h.em[0] : 0ull, h.wp[0], word);
             if (tid == 255) s_cov = h.wp[0] + (uint32_t)__popcll(h.sm[0]) - (uint32_t)base;      // ranks below this are placed (a clamped word: every rank there is)
+            if constexpr (NORIG) { if (h.mm[0]) s_match = 1u; }
         }
         if (!slow) {
             // the tile's boundary bytes, sixteen a lane, and the mask of the FIRST markers among them (four lanes a word)
@@ -709,6 +717,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                 const uint32_t wp = a.wprefix[wc];
                 walk_starts(word < n_mw ? m : 0ull, wp, word);
                 if constexpr (HAS_END) walk_ends(word < n_mw ? m : 0ull, word < n_mw ? a.endmask[wc] : 0ull, wp, word);
+                if constexpr (NORIG) { if (a.matchmask && a.matchmask[wc]) s_match = 1u; }
                 if (tid == 255) s_cov = wp + (uint32_t)__popcll(m) - (uint32_t)base;
                 __syncthreads();
                 cov = s_cov;
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
-        slow = slow || s_slow != 0u;
+        slow = slow || s_slow != 0u || (NORIG && s_match != 0u);
         if (!slow) {                                      // (workgroup-uniform) set bits in front of every mask word
             uint32_t tot;
             const uint32_t ex = block256_excl_scan(tid < TM_TOKCAP / 64 ? (uint32_t)__popcll(s_tmask[tid]) : 0u, s_scan, &tot);
@@ -818,6 +827,17 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
                     if (a.want_words) store_nt(a.word_ids + tt, word);
                     if (a.want_offsets) {
                         uint32_t os = bs - xdoc, oe = be - xdoc;
+                        if constexpr (NORIG) {            // x space -> original text through the alignment map (meta_one_token's way, no match in this tile)
+                            const uint32_t i1 = a.norig[be - 1u];
+                            os = a.norig[bs];
+                            const uint32_t b = a.text[i1];
+                            oe = i1 + (b < 0xC0u ? 1u : b < 0xE0u ? 2u : b < 0xF0u ? 3u : 4u);
+                            if (a.char_mode) {
+                                const uint32_t lead0 = lead_rank(a.leadmask, a.lprefix, odoc);
+                                os = lead_rank(a.leadmask, a.lprefix, os) - lead0;
+                                oe = lead_rank(a.leadmask, a.lprefix, oe) - lead0;
+                            } else { os -= odoc; oe -= odoc; }
+                        }
                         if (chars) {                      // (x text == original text here: launch_token_meta)
                             const uint32_t ws = (bs >> 6) - lw0, we = (be >> 6) - lw0;
                             os = s_lp[ws] + (uint32_t)__popcll(s_lm[ws] & ((1ull << (bs & 63u)) - 1ull)) - de.w;
