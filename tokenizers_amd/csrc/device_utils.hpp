@@ -44,6 +44,24 @@ __device__ __forceinline__ uint32_t wave_allmin(uint32_t x) {
     return min(min(a, b), min(c, d));
 }
 
+// a pointer every lane holds the same value of, handed to the compiler as what it is: two scalar registers.  A load through it with a
+// 32-bit lane offset is `global_load v, v_off, s[base:base+1]`; without this the compiler may hoist "pointer's lane-invariant part +
+// lane offset" out of a loop as a 64-bit per-lane value -- two registers a pointer, and in a kernel at its register limit a spill
+// whose reload from scratch is itself a vector-memory operation in front of the load it feeds (kernels/lookup.hip prefetch)
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const T*)(((unsigned long long)hi << 32) | lo);
+}
+
+// (the same for a 64-bit value every lane holds alike -- one loaded through a pointer, which the compiler keeps in vector registers)
+__device__ __forceinline__ int64_t uniform_i64(int64_t x) {
+    const unsigned long long v = (unsigned long long)x;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
 // inclusive wavefront prefix sum (6 shuffle steps; used off the hot loops only)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const int lane = lane_id();

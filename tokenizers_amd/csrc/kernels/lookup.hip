@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
         auto m = [&](uint32_t lo) -> uint32_t { return l >= lo + 4u ? 0xFFFFFFFFu : (l > lo ? ((1u << (8u * (l - lo))) - 1u) : 0u); };
         s_kmask[tid] = make_uint4(m(0u), m(4u), m(8u), m(12u));
     }
-    const int64_t n_bytes = a.len_dev ? *a.len_dev : a.n_bytes_host;
+    const int64_t n_bytes = uniform_i64(a.len_dev ? *a.len_dev : a.n_bytes_host);      // (scalar registers: the tile count and the bounds derived from it were two spilled pairs)
     const int64_t total_words = (n_bytes + 63) >> 6;                 // start bits exist only below n_bytes
     const int64_t end_words = (n_bytes >> 6) + 1;                    // an end bit can sit at byte n_bytes
     const int64_t n_tiles = (total_words + LU_TILE_WORDS - 1) / LU_TILE_WORDS;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
         x0 = x1 = xs = Unaligned16{0u, 0u, 0u, 0u};
         if (tile >= n_tiles) return;
         const int64_t t0 = (tile * LU_TILE_WORDS) << 6;
-        const uint8_t* const tb = a.text + t0;                       // (uniform)
+        const uint8_t* const tb = uniform_ptr(a.text + t0);
         const uint32_t room = (uint32_t)min(readable - t0, (int64_t)(LU_TILE + LU_TEXT_SLACK + 64));      // readable bytes from t0 on, as far as this tile cares
         const uint32_t g0 = 16u * (uint32_t)tid, g1 = g0 + 16u * (uint32_t)LU_NT, gs = 16u * (uint32_t)(2 * LU_NT + tid);
         // (the tile's text, its masks and the tok0 words are read / written once: non-temporal accesses, kernels.hip -- level here, 0.2279
@@ -165,14 +165,15 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
         const int64_t w0 = tile * LU_TILE_WORDS;
         // (uniform bases, 32-bit lane indices and bounds: see load_text)
         const int words_left = (int)min(total_words - w0, (int64_t)(LU_TILE_WORDS + 64)), ends_left = (int)min(end_words - w0, (int64_t)(LU_TILE_WORDS + 64));
-        const unsigned long long* const sm0 = a.startmask + w0;
-        const uint32_t* const wp0 = a.wprefix + w0;
-        if (hword < words_left) { pf_ms = load_nt(sm0 + hword); pf_wp = load_nt(wp0 + hword); }
-        if (has_end && hword < ends_left) pf_me = load_nt(a.endmask + w0 + hword);
+        const unsigned long long* const sm0 = uniform_ptr(a.startmask + w0);
+        const unsigned long long* const em0 = has_end ? uniform_ptr(a.endmask + w0) : sm0;
+        const uint32_t* const wp0 = uniform_ptr(a.wprefix + w0);
+        if (hword < words_left) { pf_ms = load_nt(sm0 + (uint32_t)hword); pf_wp = load_nt(wp0 + (uint32_t)hword); }
+        if (has_end && hword < ends_left) pf_me = load_nt(em0 + (uint32_t)hword);
         pf_first = wp0[0];
         if (wave == 0) {
-            const int ws = LU_TILE_WORDS + lane;
-            if (ws < (has_end ? ends_left : words_left)) pf_scan = (has_end ? a.endmask + w0 : sm0)[ws];
+            const uint32_t ws = (uint32_t)(LU_TILE_WORDS + lane);
+            if ((int)ws < (has_end ? ends_left : words_left)) pf_scan = em0[ws];
         }
     };
     prefetch(blockIdx.x);

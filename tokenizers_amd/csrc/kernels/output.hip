@@ -749,10 +749,10 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
             for (int q = 0; q < 4; ++q) { run += v[q]; if (4 * tid + q < np) s_doc[4 * tid + q] = run; }
         }
         slow = slow || s_slow != 0u || (NORIG && s_match != 0u);
-        if (!slow) {                                      // (workgroup-uniform) set bits in front of every mask word
-            uint32_t tot;
-            const uint32_t ex = block256_excl_scan(tid < TM_TOKCAP / 64 ? (uint32_t)__popcll(s_tmask[tid]) : 0u, s_scan, &tot);
-            if (tid < TM_TOKCAP / 64) s_tpre[tid] = ex;
+        if (!slow && tid < 64) {                          // set bits in front of every mask word: sixty-four words, one wavefront, no barrier of its own
+            static_assert(TM_TOKCAP / 64 == 64, "a word a lane of wavefront 0");
+            const uint32_t v = (uint32_t)__popcll(s_tmask[tid]);
+            s_tpre[tid] = wave_incl_scan(v) - v;
         }
         __syncthreads();
         // ---- a lane per token, in output order.  The loop of the tokens whose every need is in LDS holds NO load from memory, on any
