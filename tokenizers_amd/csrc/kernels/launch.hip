@@ -171,27 +171,31 @@ void launch_seq_regroup(hipStream_t st, const int64_t* seq_off, int64_t n_seqs, 
     if ((widx || first_tok) && n_words)
         hipLaunchKernelGGL(k_word_index, dim3(blocks_for(n_words, 256)), dim3(256), 0, st, seq_off, n_seqs, n_words, widx, (const int64_t*)seq_tok_off, first_tok);
 }
+// one instantiation of k_token_meta on a grid of what is RESIDENT at once -- a workgroup walks its tiles in a loop whose every step is a
+// chain of dependent phases, so the kernel lasts as long as the workgroup with the most tiles: 2,048 workgroups on a chip that holds
+// 1,536 of them ran a second, half-empty round (profiles/r6j_c2_sq_summary_byte.json).  The occupancy is the instantiation's own (five
+// workgroups a CU for some, four for the others: kernels/output.hip)
+template <bool E, bool S, bool C, bool M, bool N>
+static void launch_tm(hipStream_t st, int grid, const MetaArgs& a) {
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<E, S, C, M, N>, 256, 0) != hipSuccess || n < 1) n = 4;
+        return std::min(n, 8);
+    }();
+    hipLaunchKernelGGL((k_token_meta<E, S, C, M, N>), dim3(std::max(1, grid / 8) * per_cu), dim3(256), 0, st, a);
+}
 void launch_token_meta(hipStream_t st, int grid, const MetaArgs& a) {
     // (char_id: BPE over characters without an unk_token -- token edges depend on the tokens in front of them: the sequential shape)
     if (a.char_id) { hipLaunchKernelGGL(k_token_meta_seq, dim3(grid), dim3(256), 0, st, a); return; }
-    // the grid: what is RESIDENT at once -- a workgroup walks its tiles in a loop whose every step is a chain of dependent round trips, so
-    // the kernel lasts as long as the workgroup with the most tiles: 2,048 workgroups on a chip that holds 1,536 of them ran a second,
-    // half-empty round (profiles/r6j_c2_sq_summary_byte.json)
-    static const int per_cu = [] {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k_token_meta<false, true, false, true>, 256, 0) != hipSuccess || n < 1) n = 4;
-        return std::min(n, 8);
-    }();
-    const dim3 g(std::max(1, grid / 8) * per_cu);
     // (SIMPLE also reads char offsets off the ORIGINAL text's lead-byte mask at x positions: the two texts must be one)
     const bool simple = !a.norig && !a.matchmask && !a.trim_offsets && !a.word_of_doc && !a.first_tok && a.x_doc_off == a.doc_off && a.x_text == a.text;
     const bool chars = simple && a.char_mode && a.want_offsets;
-    const bool masks = !a.pt_start;                      // (the starts off the start mask: pipeline.cpp, pre-tokenizers without an end mask)
-#define TKAMD_TM(E, S, C, M) hipLaunchKernelGGL((k_token_meta<E, S, C, M>), g, dim3(256), 0, st, a)
+    const bool masks = !a.pt_start;                      // (the starts off the start mask: pipeline.cpp)
     const bool ends = a.pt_end || (masks && a.endmask);
     // (behind BertNormalizer: the alignment map without per-byte ends; matches by tile -- kernels/output.hip NORIG)
     const bool norig_simple = masks && a.norig && !a.norig_e && !a.trim_offsets && !a.word_of_doc && !a.first_tok;
-    if (norig_simple) { if (ends) hipLaunchKernelGGL((k_token_meta<true, true, false, true, true>), g, dim3(256), 0, st, a); else hipLaunchKernelGGL((k_token_meta<false, true, false, true, true>), g, dim3(256), 0, st, a); }
+#define TKAMD_TM(E, S, C, M) launch_tm<E, S, C, M, false>(st, grid, a)
+    if (norig_simple) { if (ends) launch_tm<true, true, false, true, true>(st, grid, a); else launch_tm<false, true, false, true, true>(st, grid, a); }
     else if (ends && masks) { if (chars) TKAMD_TM(true, true, true, true); else if (simple) TKAMD_TM(true, true, false, true); else TKAMD_TM(true, false, false, true); }
     else if (ends) { if (chars) TKAMD_TM(true, true, true, false); else if (simple) TKAMD_TM(true, true, false, false); else TKAMD_TM(true, false, false, false); }
     else if (masks) { if (chars) TKAMD_TM(false, true, true, true); else if (simple) TKAMD_TM(false, true, false, true); else TKAMD_TM(false, false, false, true); }

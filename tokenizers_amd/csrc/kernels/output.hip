@@ -576,7 +576,9 @@ constexpr int TM_LEADW = 256;                             // char mode: 64-byte 
 // the general path's flag tests compiled out like SIMPLE's.  Added-token matches are a property of the TILE there: the match mask
 // rides in the mask window, a tile that holds a match bit takes the general path whole.
 template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS, bool NORIG = false>
-__global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
+// (five wavefronts a SIMD where the kernel fits 96 registers without a spill -- the instantiations without end mask and char window --,
+// four elsewhere: a spilled value's reload in the token loop is a wait for the last iteration's stores)
+__global__ __launch_bounds__(256, (MASKS && !CHARS && !HAS_END) ? 5 : 4) void k_token_meta(MetaArgs a) {
     static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
     static_assert(!NORIG || (SIMPLE && MASKS && !CHARS), "the alignment-map path reads the match mask with the mask window; char ranks from memory");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
@@ -595,15 +597,17 @@ __global__ __launch_bounds__(256, 4) void k_token_meta(MetaArgs a) {
     __shared__ uint32_t s_lp[CHARS ? TM_LEADW : 1];
     static_assert(TM_LEADW == 256, "a word a lane");
     static_assert(TM_TOKCAP == 256 * 16, "sixteen boundary bytes a lane");
-    const int64_t P = *a.n_pretok;
-    const uint32_t n_tok = (uint32_t)*a.n_tok;
+    // (scalar registers: what is loaded through a pointer lives in vector registers, and so does everything derived from it -- the tile
+    // count, every tile's base, the addresses of the per-tile scalars, which then are vector loads too)
+    const int64_t P = uniform_i64(*a.n_pretok);
+    const uint32_t n_tok = (uint32_t)uniform_i64(*a.n_tok);
     const int tid = (int)threadIdx.x;
     const int64_t n_tiles = (P + TM_TILE - 1) / TM_TILE;
     if (n_tiles == 0) return;
     const int64_t G = gridDim.x;
     constexpr bool chars = CHARS;
-    const uint32_t lw_max = chars ? (uint32_t)(a.doc_off[a.n_docs] >> 6) : 0u;      // the last word of the lead-byte mask
-    const uint32_t x_len = MASKS ? (uint32_t)(a.x_len_dev ? *a.x_len_dev : a.x_len_host) : 0u;
+    const uint32_t lw_max = chars ? (uint32_t)uniform_i64(a.doc_off[a.n_docs] >> 6) : 0u;      // the last word of the lead-byte mask
+    const uint32_t x_len = MASKS ? (uint32_t)uniform_i64(a.x_len_dev ? *a.x_len_dev : a.x_len_host) : 0u;
     const uint32_t n_mw = MASKS ? (uint32_t)min(a.n_mask_words, (int64_t)(x_len >> 6) + 1) : 0u;     // words of the start mask that hold bits
     auto scal_of = [&](int64_t tile, TmScal& sc) {        // (a tile beyond the end: the last one's, never used)
         const int64_t base = min(tile, n_tiles - 1) * TM_TILE;
