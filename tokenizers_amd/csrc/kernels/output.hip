@@ -578,7 +578,7 @@ constexpr int TM_LEADW = 256;                             // char mode: 64-byte 
 template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS, bool NORIG = false>
 // (five wavefronts a SIMD where the kernel fits 96 registers without a spill -- the instantiations without end mask and char window --,
 // four elsewhere: a spilled value's reload in the token loop is a wait for the last iteration's stores)
-__global__ __launch_bounds__(256, (MASKS && !CHARS && !HAS_END) ? 5 : 4) void k_token_meta(MetaArgs a) {
+__global__ __launch_bounds__(256, (MASKS && !HAS_END) ? 5 : 4) void k_token_meta(MetaArgs a) {
     static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
     static_assert(!NORIG || (SIMPLE && MASKS && !CHARS), "the alignment-map path reads the match mask with the mask window; char ranks from memory");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
@@ -629,7 +629,8 @@ __global__ __launch_bounds__(256, (MASKS && !CHARS && !HAS_END) ? 5 : 4) void k_
         }
         const int64_t d = min((sc.d0 > 0 ? sc.d0 - 1 : 0) + tid, a.n_docs - 1);
         h.dpt = a.doc_pt[d];
-        h.dxo = ((const uint32_t*)a.x_doc_off)[2 * d];    // (the low words: a batch is < 4 GiB)
+        if constexpr (!SIMPLE || NORIG) h.dxo = ((const uint32_t*)a.x_doc_off)[2 * d];    // (the low words: a batch is < 4 GiB; SIMPLE without a map: x text == text, one CSR)
+        else h.dxo = 0u;
         h.dod = ((const uint32_t*)a.doc_off)[2 * d];
         if (a.tok_b8) h.b8 = *(const Unaligned16*)(a.tok_b8 + min(sc.T0 + 16u * (uint32_t)tid, n_tok));     // (readable 64 bytes beyond the tokens)
         else h.b8 = Unaligned16{0u, 0u, 0u, 0u};
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(256, (MASKS && !CHARS && !HAS_END) ? 5 : 4) void k_
         }
         // documents from the one in front of the first of the compaction chunk that holds `base` on (the tile's first pre-tokens may belong
         // to that one): their entries go to the table
-        s_dtab[tid] = make_uint4(h.dpt, h.dxo, h.dod, 0u);
+        s_dtab[tid] = make_uint4(h.dpt, (!SIMPLE || NORIG) ? h.dxo : h.dod, h.dod, 0u);
         if constexpr (CHARS) { s_lm[tid] = h.lm[0]; s_lp[tid] = h.lp[0]; }
         // (char mode: the lead bytes in front of every listed document -- asked for in FRONT of the next tile's loads: loads return in order)
         uint32_t dlead_now = 0u;
