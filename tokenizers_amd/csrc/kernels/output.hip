@@ -578,7 +578,7 @@ constexpr int TM_LEADW = 256;                             // char mode: 64-byte 
 template <bool HAS_END, bool SIMPLE, bool CHARS, bool MASKS, bool NORIG = false>
 // (five wavefronts a SIMD where the kernel fits 96 registers without a spill -- the instantiations without end mask and char window --,
 // four elsewhere: a spilled value's reload in the token loop is a wait for the last iteration's stores)
-__global__ __launch_bounds__(256, (MASKS && !HAS_END) ? 5 : 4) void k_token_meta(MetaArgs a) {
+__global__ __launch_bounds__(256, MASKS ? 5 : 4) void k_token_meta(MetaArgs a) {
     static_assert(SIMPLE || !CHARS, "the LDS window is the SIMPLE path's");
     static_assert(!NORIG || (SIMPLE && MASKS && !CHARS), "the alignment-map path reads the match mask with the mask window; char ranks from memory");
     __shared__ uint2 s_ts[TM_TILE + 1];                   // pre-token i: first token, first byte (one 16-byte read gives i and i + 1)
