@@ -382,10 +382,13 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                 const ulonglong2 c = *(const ulonglong2*)e;
                 unsigned long long c0 = c.x, c1 = c.y;
                 bool fresh1 = false, won = false;
-                if (c0 == 0ull) {
-                    c0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (c0 == 0ull) { c0 = atomicCAS(e, 0ull, w0); won = c0 == 0ull; }
-                }
+                // (a 0 may be stale -- the L2 of an XCD keeps what it read whatever another XCD's compare-and-swap did since.  With the
+                // candidates' own pass the 0 is confirmed by a device-scope load first; inline in pass 2 -- end masks -- the
+                // compare-and-swap itself is the fresh read: one round trip less in the chain of every step, C3's lookup 0.240 -> 0.222 ms,
+                // where the candidates' pass lost on out-of-distribution text, 0.332 -> 0.365 ms with a tenth more words merged on their
+                // own -- the sharers then arrive inside the window of the winner's second store: profiles/r7o_*)
+                if (c0 == 0ull && CAND_PASS) c0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c0 == 0ull) { c0 = atomicCAS(e, 0ull, w0); won = c0 == 0ull; }
                 // The winner's second store comes BEFORE any loser reads word 1, in program order: lanes of one wavefront step often hold
                 // the same word (text of few distinct words), and a loser polling in its own branch would spin on a store its wavefront
                 // has not issued yet.
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(LU_NT, LU_WAVES_PER_SIMD) void k_lookup(LookupArgs 
                 unsigned long long* const e = a.claims + 2u * (size_t)slot;
                 const unsigned long long tag = (0xFFull << 56) | ((unsigned long long)len << 32);
                 unsigned long long c = *e;
-                if (c == 0ull) c = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (c == 0ull && CAND_PASS) c = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (see claim_short)
                 if (c == 0ull) {
                     c = atomicCAS(e, 0ull, tag | (unsigned long long)((uint32_t)t0 + s_rel));
                     if (c == 0ull) return CLAIM_HOLDS;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(CP_NT, CP_ITEMS == 8 ? 2 : 5) void k_compact(const 
     __shared__ uint32_t s_loc[2][CP_CHUNK];              // chunk-local token offset of every pre-token
     __shared__ uint32_t s_tot[2];
     __shared__ unsigned long long s_lbw;
-    const int64_t P = *n_pretok;
+    const int64_t P = uniform_i64(*n_pretok);           // (scalar registers: the chunk count and every chunk's bounds follow it)
     const int64_t n_chunks = (P + CP_CHUNK - 1) / CP_CHUNK;
     const int tid = (int)threadIdx.x;
     if (n_chunks == 0) {                                  // no pre-token at all: every document is empty
