@@ -74,7 +74,6 @@ def test_epilogues_match_wheel():
     for k in _every(E.PAIR_OVERFLOW_CASES, 5, _small):
         E.test_pair_overflowing_encodings_match_wheel(k)
     E.test_enable_truncation_and_padding_at_run_time()
-    E.test_ids_as_16_bit_values()
 
 
 def test_random_truncation_padding_settings_match_the_wheel_live(ref_tokenizers):
