@@ -355,9 +355,10 @@ def main() -> None:
         return el
 
     state = {}
-    # (un-timed, in front of the contract's W warm-up steps: three full rotations over the batches, so that clocks, the workspaces and
-    # the handle's claims statistics are where the repeat blocks find them -- round 5's first block ran 2.5 % behind the later ones)
-    for i in range(3 * n_batches):
+    # (un-timed, in front of the contract's W warm-up steps: twenty full rotations over the batches -- some thirty milliseconds of the
+    # same work -- so that clocks, the workspaces and the handle's claims statistics are where the repeat blocks find them: round 5's
+    # first block ran 2.5 % behind the later ones, with three rotations round 6's still 0.6 %)
+    for i in range(20 * n_batches):
         encode(i)
     torch.cuda.synchronize()
     elapsed = timed(encode)
