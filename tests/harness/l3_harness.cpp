@@ -49,6 +49,11 @@ extern "C" int l3h_run(const char* json, size_t json_len, const uint8_t* text, i
             if (docstart[g]) w.D |= bit;
         }
         uint64_t st = 0, un = 0;
+        if (split_rule_fast_cs(hm.split_rule)) {
+            for (int i = 0; i < 64; ++i)
+                if (base + i >= 0 && base + i < n && (t[base + i] & 0x20u)) w.B5 |= 1ull << i;
+            l3_window_starts_cs(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data(), hm.ucc_stage1.data(), hm.ucc_stage2.data(), &st, &un, hm.split_rule);
+        } else
         l3_window_starts(w, t, base, hm.uc_stage1.data(), hm.uc_stage2.data(), &st, &un, hm.split_rule);      // (the member of the family the JSON names)
         for (int i = L3W_HALO; i < L3W_HALO + L3W_MAIN; ++i) {
             const int64_t g = base + i;

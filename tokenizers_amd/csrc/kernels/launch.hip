@@ -147,13 +147,19 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
                           SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2) {
     // Three tiers: the per-lane bit-parallel kernel, the tile kernel on the tiles where that left bytes undecided, the sequential matcher
     // on the sentences (doc_off: documents, or the pieces between added-token matches) the tile kernel could not finish.  A member of the
-    // family the first two do not implement (tables.hpp split_rule_fast: the case-split letters of o200k / tekken, the `/` in the tail of
-    // an O-run) goes to the sequential matcher whole: every sentence, one lane each.
+    // family with the case-split letters (o200k, tekken: split_rule_fast_cs) runs the per-lane kernel with l3_window_starts_cs and then the
+    // sequential matcher on the sentences that left a byte of undecided; what neither serves goes to the sequential matcher whole: every
+    // sentence, one lane each.
     const L3Seq q{uc1, uc2, ucc1, ucc2, rule};
     const unsigned doc_blocks = std::min<unsigned>(blocks_for(n_docs, 256), 4096u);
     if (split_rule_fast(rule)) {
-        hipLaunchKernelGGL(k_pretok_llama3_lane, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule);
+        hipLaunchKernelGGL(k_pretok_llama3_lane<false>, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule,
+                           (const uint16_t*)nullptr, (const uint8_t*)nullptr);
         hipLaunchKernelGGL(k_pretok_llama3, dim3(blocks_for(n_bytes + 1, PT_TILE)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, 1, rule);
+        hipLaunchKernelGGL(k_l3_slow_docs, dim3(doc_blocks), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
+        hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, q, startmask);
+    } else if (split_rule_fast_cs(rule) && ucc1) {
+        hipLaunchKernelGGL(k_pretok_llama3_lane<true>, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule, ucc1, ucc2);
         hipLaunchKernelGGL(k_l3_slow_docs, dim3(doc_blocks), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
         hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, q, startmask);
     } else {

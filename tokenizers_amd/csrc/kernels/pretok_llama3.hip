@@ -255,12 +255,16 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
 // that tests/test_pretok_core.py checks on the CPU, function for function, against a sequential matcher.  Bytes whose run
 // leaves the window are reported in slowmask; k_pretok_llama3 (refine mode) redoes only the tiles that have any.
 // =================================================================================================
+// CS: the case-split members of the family (o200k, tekken; tables.hpp split_rule_fast_cs) -- l3_window_starts_cs with the case classes ucc1 /
+// ucc2 and bit 5 of every byte (the case of an ASCII letter); what it leaves undecided goes to the sequential matcher by sentence.
+template <bool CS>
 __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __restrict__ text, int64_t n_bytes_host,
                                                             const int64_t* __restrict__ len_dev,
                                                             const unsigned long long* __restrict__ docmask,
                                                             const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                             unsigned long long* __restrict__ startmask,
-                                                            unsigned long long* __restrict__ slowmask, SplitRule rule) {
+                                                            unsigned long long* __restrict__ slowmask, SplitRule rule,
+                                                            const uint16_t* __restrict__ ucc1, const uint8_t* __restrict__ ucc2) {
     __shared__ uint2 lut[SQ_LUT_COPIES * 256];
     {
         const L3Flags f = l3_byte_flags(threadIdx.x);
@@ -319,6 +323,14 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
         }
         m.L &= m.V; m.N &= m.V; m.W &= m.V; m.R &= m.V; m.SP &= m.V; m.C &= m.V; m.AP &= m.V; m.MU &= m.V;
         uint64_t s64, u64;
+        if constexpr (CS) {
+            // bit 5 of the 64 bytes: four bytes a multiply ((x >> 5) & 0x01010101 gathers through 0x01020408 into bits 24..27)
+            unsigned long long b5 = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) b5 |= (unsigned long long)((((w[k] >> 5) & 0x01010101u) * 0x01020408u) >> 24 & 0xFu) << (4 * k);
+            m.B5 = b5;
+            l3_window_starts_cs(m, text, base, uc1, uc2, ucc1, ucc2, &s64, &u64, rule);
+        } else
         l3_window_starts(m, text, base, uc1, uc2, &s64, &u64, rule);
         st = (s64 >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);
         un = (u64 >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);

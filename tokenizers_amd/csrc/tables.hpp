@@ -209,6 +209,9 @@ struct SplitRule {
 constexpr SplitRule SPLIT_RULE_LLAMA3 = {1, 0, 3, 1};
 // the rules the bit-parallel and the tile kernel implement (kernels/pretok_llama3.hip); the others run on the sequential matcher
 TK_HD bool split_rule_fast(const SplitRule& r) { return r.letters == 0 && r.other_tail == 1 && r.contr <= 2; }
+// the case-split rules (o200k, tekken): the bit-parallel kernel with l3_window_starts_cs, then the sequential matcher on the sentences that
+// one left a byte of undecided (no tile tier)
+TK_HD bool split_rule_fast_cs(const SplitRule& r) { return r.letters == 2 && (r.contr == 0 || r.contr == 3); }
 // case classes of the case-split letters (generated data: unicode_case_ranges.inc)
 enum : uint8_t { UCC_UPPER = 1 /* [\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}] */, UCC_LOWER = 2 /* [\p{Ll}\p{Lm}\p{Lo}\p{M}] */ };
 
