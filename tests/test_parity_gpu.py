@@ -837,6 +837,58 @@ def test_claims_pause_while_nothing_is_shared(monkeypatch):
     assert run(repetitive, exp_r) * 8 < n_occ                 # and they are back
 
 
+@pytest.mark.parametrize("name", ["bert_wordpiece_4000_specials", "llama3_small_6000_specials", "gpt2_added_tokens", "bert_wordpiece_4000_added"])
+def test_added_token_speculation(name, monkeypatch):
+    """A tokenizer with added tokens runs a batch as if its text held none (capi/pipeline.cpp: one detection pass per pattern set instead of the
+    matching passes -- natural text holds no special token); a batch that does hold the content of one is run again with the matching
+    passes of AddedVocabulary::extract_and_normalize (added_vocabulary.rs:523-564) when it is synchronised, and the handle's next batches
+    (TKAMD_ADDED_SPEC of them, 32 by default) do not speculate.  Seen from outside: always the oracle's result, with offsets and word ids
+    too, and the pause counting down."""
+    import json
+    import tokenizers_amd as ta
+    monkeypatch.setenv("TKAMD_TEST_HOOKS", "1")
+    monkeypatch.setenv("TKAMD_ADDED_SPEC", "3")
+    js = load_tokenizer_json(name)
+    tok, o = ta.Tokenizer.from_str(js, device=0), orc.Oracle(js)
+    import unicodedata
+    contents = [a["content"] for a in json.loads(js)["added_tokens"]]
+    firsts = {c[0] for c in contents}
+    # (the detection is conservative: the CONTENT of a token anywhere -- in the normalised text for the tokens matched there, across a
+    # document edge too -- ends the speculation; "clean" is clean of that)
+    fold = lambda x: "".join(ch for ch in unicodedata.normalize("NFD", x.lower()) if unicodedata.category(ch) != "Mn")
+    holds = lambda d: any(c in d or fold(c) in fold(d) for c in contents)
+    clean = [d + " ." for d in synth.gen_lines(N(6000), text_seed=311) if not holds(d)]
+    near = [d + " " + c[:-1] + " ." for d, c in zip(clean[:200], contents * 200)] + [f + " ." for f in firsts]      # a token's first byte / all but its last: no match
+    near = [d for d in near if not holds(d)]
+    dirty = list(clean)
+    for k, c in enumerate(contents * 3):
+        dirty[(k * 37) % len(dirty)] += " " + c + " x" + c
+    dirty[-1] = contents[0]
+    if name.startswith("bert"):
+        clean, near, dirty = ([d for d in x if "\u302e" not in d] for x in (clean, near, dirty))
+
+    def run(docs, **kw):
+        exp = o.encode_batch(docs)
+        got = tok.encode_batch_csr(docs, **kw)
+        assert np.array_equal(got.tok_offsets, exp.tok_offsets) and np.array_equal(got.ids, exp.ids)
+        if kw:
+            assert np.array_equal(got.offsets, exp.offsets) and np.array_equal(got.word_ids, exp.words)
+        return tok.queue_sizes()["added_spec_pause"]
+    assert run(clean) == 0                                   # speculative, nothing met
+    assert run(near) == 0
+    assert run(clean, offsets="byte", word_ids=True) == 0
+    assert run(dirty) == 3                                   # met one: run again with the matching passes; three batches will not speculate
+    assert run(clean) == 2                                   # the matching passes, outright
+    assert run(dirty, offsets="byte", word_ids=True) == 1    # still outright: nothing to run again
+    assert run(near) == 0
+    assert run(clean) == 0                                   # speculating again
+    assert run(dirty) == 3
+    monkeypatch.setenv("TKAMD_ADDED_SPEC", "0")              # never speculate
+    tok0 = ta.Tokenizer.from_str(js, device=0)
+    got, exp = tok0.encode_batch_csr(dirty), o.encode_batch(dirty)
+    assert np.array_equal(got.ids, exp.ids) and tok0.queue_sizes()["added_spec_pause"] == 0
+
+
 @pytest.mark.parametrize("name", ["gpt2", "llama3_small_6000_specials", "gpt2_bench_added", "bert_wordpiece_4000_specials"])
 def test_word_cache_never_changes_a_result(name, gpt2_json):
     """tkamd_word_cache: later batches look up the words earlier batches merged (the reference's tokenize_with_cache,

@@ -30,6 +30,7 @@ static std::unique_ptr<tkamd_tokenizer> make_tokenizer(const char* json, size_t 
         build_shortw_table(t.get());
         build_hot_table(t.get());
         if (const char* e = test_hook("TKAMD_CLAIMS_PAUSE")) t->claims_pause_len = std::max(0, atoi(e));
+        if (const char* e = test_hook("TKAMD_ADDED_SPEC")) t->added_spec_len = std::max(0, atoi(e));
         t->cp_grid = compact_grid(t->n_cu);
         if (const char* e = test_hook("TKAMD_CP_GRID")) t->cp_grid = std::max(1, atoi(e));      // test hook: an over- / under-subscribed compaction
         t->devices.push_back(device);

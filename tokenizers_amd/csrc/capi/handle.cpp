@@ -57,6 +57,8 @@ struct Workspace {
     int64_t last_n_enc = -1;                    // encodings of the last call when it materialised overflowing ones, else -1
     int last_ntok_slot = 1;
     uint32_t last_counters[CNT_COUNT] = {0};
+    bool force_general = false;                  // the next run of the pipeline does not speculate on the added tokens (it repeats a batch that met one)
+    bool last_note_added = false;                // the batch synchronised last was speculative and met an added token's content (read_scalars)
     bool last_used_claims = false;               // the batch enqueued last ran with the in-batch claims
     ~Workspace() {
         if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -97,6 +99,11 @@ struct tkamd_tokenizer {
     // quarter of its candidates shared pauses them for the next claims_pause_len batches of the handle; then they are tried again.
     std::atomic<int> q16_fat_hint{1};    // the last batch that ran with the claims left a fat <= 16-byte queue (or none has run yet): see run_pipeline's merge launches
     std::atomic<int> claims_pause{0};
+    // A tokenizer with added tokens runs a batch as if its text held none (one detection pass per pattern set instead of match / resolve /
+    // scatter / piece launches that find nothing in natural text); a batch that did hold one is run again with the matching passes and
+    // the handle's next added_spec_len batches do not speculate (run_pipeline, finish_batch).
+    std::atomic<int> added_spec_pause{0};
+    int added_spec_len = 32;     // (test hook TKAMD_ADDED_SPEC: 0 never speculate; n: the pause behind a miss)
     int claims_pause_len = 32;   // (test hook TKAMD_CLAIMS_PAUSE; 0: never pause)
     std::atomic<uint32_t> q16_div{4};    // capacity of the <= 16-byte queue = n_bytes / q16_div (raised to the worst case when a batch overflows it)
     // profiling

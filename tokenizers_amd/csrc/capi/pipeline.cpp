@@ -11,6 +11,16 @@ struct QueueSizes {
     uint32_t sq_cap[4], row_base[4];
     size_t total;
 };
+// What the error word of a batch that has just been read back asks for besides failing: the batch again with a larger <= 16-byte queue
+// (ERR_QUEUE_FULL alone), or again with the added tokens' matching passes (NOTE_ADDED_SEEN: it was run as if its text held none).
+static bool rerun_wanted(tkamd_tokenizer* t, Workspace* w, int raw) {
+    const int err = raw & ~NOTE_BITS;
+    bool again = false;
+    if (raw & NOTE_ADDED_SEEN) { t->added_spec_pause = t->added_spec_len; w->force_general = true; again = true; }      // (force_general: the run that follows, whoever else draws on the pause)
+    if (err == ERR_QUEUE_FULL && t->q16_div > 1) { t->q16_div = t->q16_div > 2 ? 2 : 1; again = true; }
+    return again;
+}
+
 QueueSizes queue_sizes(size_t N, uint32_t q16_div, int grid) {
     QueueSizes z{};
     const size_t n_tiles = N / LOOKUP_TILE_BYTES + 1;
@@ -265,9 +275,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         HIP_CHECK(hipStreamSynchronize(st));
         if (d_target == (uint32_t*)(sc + SC_PADMAX)) mx = *(const uint32_t*)&head[SC_PADMAX];
         if (!w->pad_exchange) return mx;
-        const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_REORDER_SEEN;
-        if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {
-            t->q16_div = t->q16_div > 2 ? 2 : 1;
+        if (rerun_wanted(t, w, *(const int*)&head[SC_ERR])) {
             *again = true;
             return 0;
         }
@@ -343,9 +351,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             int64_t head[SC_NENC + 1];
             HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_REORDER_SEEN;
-            if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {     // (see finalize(): the batch is run again right away)
-                t->q16_div = t->q16_div > 2 ? 2 : 1;
+            const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_BITS;
+            if (rerun_wanted(t, w, *(const int*)&head[SC_ERR])) {     // (see finalize(): the batch is run again right away)
                 rerun = true;
                 pf.end();
                 return;
@@ -477,11 +484,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             int64_t head[SC_NENC + 1];
             HIP_CHECK(hipMemcpyAsync(head, sc, sizeof(head), hipMemcpyDeviceToHost, st));
             HIP_CHECK(hipStreamSynchronize(st));
-            const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_REORDER_SEEN;
-            if (err_now == ERR_QUEUE_FULL && t->q16_div > 1) {
+            const int err_now = *(const int*)&head[SC_ERR] & ~NOTE_BITS;
+            if (rerun_wanted(t, w, *(const int*)&head[SC_ERR])) {
                 // the token CSR is incomplete: this call is synchronous here anyway, so the batch is run again right away with the
                 // larger queue (what finish_batch does for the calls that never wait)
-                t->q16_div = t->q16_div > 2 ? 2 : 1;
                 rerun = true;
                 pf.end();
                 return;
@@ -588,7 +594,18 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // in between -- with a normalizer -- nothing else: add_prefix_space behind a normalizer is refused above.  Matches are kept as
     // a list (start, stop, id) that is moved from text to text; the bitmasks are scattered from it in the text they are used in.
     const HostModel::PatternSet &setA = hm.at[0], &setB = hm.at[1];
-    const bool have_raw = setA.size() > 0, have_norm = setB.size() > 0, have_added = have_raw || have_norm;
+    // Natural text holds no added token: a tokenizer that has some runs the batch as if it had none -- one detection pass per pattern set
+    // (k_added_candidates with a note instead of a mask) where match / resolve / scatter / piece launches would find nothing -- and a batch
+    // whose text does hold the content of one is run again with the passes below when it is synchronised (NOTE_ADDED_SEEN, finish_batch;
+    // the handle's next added_spec_len batches then do not speculate).
+    bool spec = (setA.size() > 0 || setB.size() > 0) && t->added_spec_len > 0 && !w->force_general;
+    w->force_general = false;
+    if (spec) {
+        int p = t->added_spec_pause.load();
+        while (p > 0 && !t->added_spec_pause.compare_exchange_weak(p, p - 1)) {}
+        if (p > 0) spec = false;
+    }
+    const bool have_raw = setA.size() > 0 && !spec, have_norm = setB.size() > 0 && !spec, have_added = have_raw || have_norm;
     const ull* matchmask = nullptr;
     uint32_t* mlist = nullptr;
     uint32_t* n_match = d_counters + CNT_MATCHES;
@@ -650,6 +667,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     };
 
     if (have_added) HIP_CHECK(hipMemsetAsync(n_match, 0, 4, st));
+    if (spec && setA.size() > 0) {
+        pf.begin("added_token_match");
+        launch_added_detect(st, args_of(0), d_text, n_bytes, nullptr, d_err);
+        pf.end();
+    }
     if (have_raw) {
         // pass 1: the tokens with normalized = false, over the raw documents
         pf.begin("added_token_match");
@@ -719,6 +741,11 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
     // n_in / len_in: the text the second pass (and the prefix-space copy) reads
     const int64_t n_in = hm.norm == NORM_BERT ? n_x : n_bytes;
+    if (spec && setB.size() > 0) {
+        pf.begin("added_token_match2");
+        launch_added_detect(st, args_of(1), x_text, n_in, x_len_dev, d_err);
+        pf.end();
+    }
     if (have_norm) {
         // pass 2: the tokens with normalized = true, by their normalised patterns, over every piece pass 1 left (the whole documents
         // when it found nothing or there is no such token)
@@ -1119,10 +1146,10 @@ int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
 // same call again on the same stream (the output buffers are sized for the worst case, so the result pointers stay).
 int finish_batch(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_tok, int64_t* n_pretok) {
     int bits = read_scalars(t, w, st, n_tok, n_pretok);
-    while ((bits & ERR_QUEUE_FULL) && !(bits & ~ERR_QUEUE_FULL) && t->q16_div > 1) {
-        // half the bytes covers every text whose queued pre-tokens have two bytes or more (a word and its separator); one entry per
-        // byte covers the rest (runs of one-byte pre-tokens the vocabulary does not know, e.g. punctuation under WordPiece)
-        t->q16_div = t->q16_div > 2 ? 2 : 1;
+    // (rerun_wanted: half the bytes covers every text whose queued pre-tokens have two bytes or more (a word and its separator); one entry
+    // per byte covers the rest (runs of one-byte pre-tokens the vocabulary does not know, e.g. punctuation under WordPiece); a speculative
+    // batch that met an added token's content is run again with the matching passes -- whatever else its error word says: that run decides)
+    while (rerun_wanted(t, w, bits | (w->last_note_added ? NOTE_ADDED_SEEN : 0))) {
         tkamd_device_result again{};
         run_pipeline(t, w, w->last_text, w->last_doc_off, w->last_n_docs, w->last_n_bytes, w->last_seq_off, w->last_n_seqs, w->last_flags, st, &again,
                      w->last_inp_off, w->last_n_inputs);
@@ -1143,7 +1170,8 @@ int read_scalars(tkamd_tokenizer* t, Workspace* w, hipStream_t st, int64_t* n_to
     int64_t host[SC_SLOTS];
     HIP_CHECK(hipMemcpyAsync(host, w->w_scalars.p, sizeof(host), hipMemcpyDeviceToHost, st));
     HIP_CHECK(hipStreamSynchronize(st));
-    int err = *(int*)&host[SC_ERR] & ~NOTE_REORDER_SEEN;     // (a note of the normalizer, not an error)
+    int err = *(int*)&host[SC_ERR] & ~NOTE_BITS;             // (notes of the normalizer and of the added tokens' speculation, not errors)
+    w->last_note_added = (*(int*)&host[SC_ERR] & NOTE_ADDED_SEEN) != 0;
     memcpy(w->last_counters, &host[SC_COUNTERS], sizeof(w->last_counters));
     if (w->last_used_claims && t->claims_pause_len > 0) {
         // the claims' yield, counted by the lookup itself: candidates it looked at and how many of them were another pre-token's word.

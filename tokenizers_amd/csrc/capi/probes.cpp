@@ -210,6 +210,7 @@ int tkamd_profile_counters(tkamd_tokenizer* t, uint32_t* out, int n) {
         for (int i = 0; i < n; ++i) out[i] = 0;
         if (!w) return TKAMD_OK;
         for (int i = 0; i < n && i < CNT_COUNT; ++i) out[i] = w->last_counters[i];
+        if (n > 14) out[14] = (uint32_t)std::max(0, t->added_spec_pause.load());      // (batches that will not speculate on the added tokens: a batch met one)
         if (n > 15) out[15] = t->q16_div;                                  // (the <= 16-byte queue's divisor: shrinks when a batch had to be run again)
         if (t->device >= 0 && w->w_qcount.p && !g_forked) {             // queue fills of the last batch: the sub-queue counters, summed per queue
             HIP_CHECK(hipSetDevice(t->device));

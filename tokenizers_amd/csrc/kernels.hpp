@@ -303,6 +303,9 @@ enum : int {
     ERR_INPUT_KIND = 8192,        // an input of a mixed batch that is neither one sequence nor two (tkamd_encode_batch_mixed)
     ERR_UNK_OOV = 4096,           // BPE: a char the vocabulary lacks, and the unk_token that should stand for it is not in the vocabulary either (Error::UnkTokenOutOfVocabulary, bpe/model.rs:528-533)
     NOTE_REORDER_SEEN = 2048,     // not an error: the normalizer met a character NFD's canonical ordering could move (k_bn_reorder_fix then looks at its neighbours)
+    NOTE_ADDED_SEEN = 16384,      // not an error: a batch that was run as if the text held no added token (run_pipeline's speculation) met the content of one: the host runs
+                                  // it again with the matching passes (finish_batch) and stops speculating for a while
+    NOTE_BITS = NOTE_REORDER_SEEN | NOTE_ADDED_SEEN,
     ERR_QUEUE_FULL_PAD = 0,          // a work queue / the row area was too small for this batch: the host grows it and runs the batch again
 };
 
@@ -391,6 +394,8 @@ void launch_pair_finalize(hipStream_t st, int grid, const PairArgs& a);
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
                         uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err);
+// the speculative form of a matching pass: does the content of any pattern occur at all?  (NOTE_ADDED_SEEN into *note)
+void launch_added_detect(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, int* note);
 void launch_scatter_matches(hipStream_t st, const uint32_t* list, const uint32_t* n_list, int64_t n_bytes, const int64_t* len_dev, unsigned long long* matchmask,
                             unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end, uint32_t* dirty);
 void launch_mask_or2(hipStream_t st, unsigned long long* dst, const unsigned long long* a, const unsigned long long* b, int64_t n_words);

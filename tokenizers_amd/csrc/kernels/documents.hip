@@ -81,8 +81,10 @@ __device__ __forceinline__ int added_longest(const AddedArgs& a, const uint8_t* 
 // 16 bytes per lane.  Almost no byte starts a pattern: the lane first asks "is any of my bytes the first byte of a pattern" --
 // four SWAR operations per first byte and 4-byte word when the patterns start with at most four distinct bytes (special tokens:
 // '[' or '<'), a 256-bit set in scalar registers otherwise -- and runs the exact comparison only from the bytes that are.
+// `note` (run_pipeline's speculation "this text holds no added token"): no mask is written; a wavefront that finds the content of a pattern leaves
+// NOTE_ADDED_SEEN there and the host runs the batch again with the matching passes.
 __global__ __launch_bounds__(256) void k_added_candidates(AddedArgs a, const uint8_t* __restrict__ text, int64_t n_bytes_host,
-                                                          const int64_t* __restrict__ len_dev, unsigned long long* __restrict__ candmask) {
+                                                          const int64_t* __restrict__ len_dev, unsigned long long* __restrict__ candmask, int* __restrict__ note) {
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
     uint32_t cand = 0u;                                             // bit j: a pattern starts at byte i0 + j
@@ -107,6 +109,10 @@ __global__ __launch_bounds__(256) void k_added_candidates(AddedArgs a, const uin
                 if ((set >> (b & 63u)) & 1ull) { uint32_t l; if (added_longest(a, text, i0 + j, n_bytes, &l) >= 0) cand |= 1u << j; }
             }
         }
+    }
+    if (note) {
+        if (__ballot(cand != 0u) != 0ull && lane_id() == 0) atomicOr(note, NOTE_ADDED_SEEN);
+        return;
     }
     // the four lanes of a 64-byte word
     unsigned long long m = (unsigned long long)cand << (16 * (threadIdx.x & 3));

@@ -227,10 +227,13 @@ void launch_add_i64(hipStream_t st, int64_t* data, int64_t n, int64_t delta) {
 void launch_added_match(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const int64_t* seg_off, int64_t n_segs,
                         const int64_t* n_segs_dev, const unsigned long long* skipmask, const uint16_t* uc1, const uint8_t* uc2, unsigned long long* candmask,
                         uint32_t* sents, uint32_t* n_sents, uint32_t* match_list, uint32_t* n_match, uint32_t cap, uint32_t len_flag, int* err) {
-    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256 * 16)), dim3(256), 0, st, a, text, n_bytes, len_dev, candmask);
+    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256 * 16)), dim3(256), 0, st, a, text, n_bytes, len_dev, candmask, (int*)nullptr);
     hipLaunchKernelGGL(k_l3_slow_docs, dim3(std::min<unsigned>(blocks_for(n_segs, 256), 4096u)), dim3(256), 0, st, (const unsigned long long*)candmask, seg_off, n_segs, n_segs_dev, sents, n_sents);
     hipLaunchKernelGGL(k_added_resolve, dim3(1024), dim3(64), 0, st, a, text, seg_off, (const uint32_t*)sents, (const uint32_t*)n_sents,
                        (const unsigned long long*)candmask, skipmask, uc1, uc2, match_list, n_match, cap, len_flag, err);
+}
+void launch_added_detect(hipStream_t st, const AddedArgs& a, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, int* note) {
+    hipLaunchKernelGGL(k_added_candidates, dim3(blocks_for(n_bytes + 1, 256 * 16)), dim3(256), 0, st, a, text, n_bytes, len_dev, (unsigned long long*)nullptr, note);
 }
 void launch_scatter_matches(hipStream_t st, const uint32_t* list, const uint32_t* n_list, int64_t n_bytes, const int64_t* len_dev, unsigned long long* matchmask,
                             unsigned long long* spanmask, unsigned long long* stopmask, unsigned long long* hardmask, uint32_t* tmp_end, uint32_t* dirty) {

@@ -1100,6 +1100,7 @@ class Tokenizer:
         out = {"merge16": arr[0], "merge32": arr[3], "merge64": arr[1], "merge_long": arr[2], "pretok_slow_docs": arr[4], "merge_huge": arr[7]}
         if arr[5]:                                       # in-batch claims: candidates the lookup looked at / how many were another pre-token's word
             out["claim_candidates"], out["claim_shared"] = arr[5], arr[6]
+        out["added_spec_pause"] = arr[14]                # batches that will run the added tokens' matching passes outright (a speculative batch met a token's content)
         out["q16_div"] = arr[15]                         # the <= 16-byte queue holds n_bytes / q16_div entries (a queue overflow re-runs the batch with 2, then 1)
         if arr[12]:                                      # (profiling runs) merge-table probes of the LDS merge kernels, (k - 1) + 2 m per word
             out["merge_probes"] = arr[12]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What the members of the tiktoken family cost on the device: the committed Split fixtures (tests/golden/split_*.json.gz, 3,000-entry
 vocabularies) over the bench's 1 M-line batch -- per-kernel HIP-event times, a 1 % oracle check first.  The fast members run the
-bit-parallel tiers; o200k / tekken run every document on the sequential matcher.
+bit-parallel tiers (o200k / tekken: l3_window_starts_cs, then the sequential matcher on the sentences it left undecided).
 usage: python tools/split_family_perf.py [n_lines]"""
 import os
 import sys
