@@ -79,6 +79,13 @@ extern "C" {
 
 /* Readable slack the caller must leave after text[n_bytes] for the device entry
  * points (kernels read whole 16-byte words).  The host entry pads internally. */
+#define TKAMD_NO_SPECULATION  64u   /* A tokenizer with added tokens runs a batch as if its text held none (natural text holds no special token: one
+                                     detection pass instead of the matching passes of AddedVocabulary::extract_and_normalize,
+                                     added_vocabulary.rs:523-564); a batch whose text does hold the content of one is run again with the matching
+                                     passes when the call synchronises (the host entries before they return, the device entry in
+                                     tkamd_device_sync) -- results are the reference's either way.  A caller of the device entry that
+                                     consumes the results stream-ordered behind the call, WITHOUT tkamd_device_sync in between, sets this
+                                     flag: the matching passes run outright.                                                            */
 #define TKAMD_TEXT_PAD 64
 
 typedef struct tkamd_tokenizer tkamd_tokenizer;  /* immutable after creation; owns device tables */

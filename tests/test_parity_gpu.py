@@ -883,6 +883,20 @@ def test_added_token_speculation(name, monkeypatch):
     assert run(near) == 0
     assert run(clean) == 0                                   # speculating again
     assert run(dirty) == 3
+    # TKAMD_NO_SPECULATION (a device-entry caller that never synchronises through the library): the matching passes outright -- right when
+    # the kernels are done, and no pause is set because nothing was run again
+    from tokenizers_amd import _lib
+    tok1 = ta.Tokenizer.from_str(js, device=0)
+    buf, off = ta.pack_documents(dirty)
+    exp = o.encode_batch(dirty)
+    if os.environ.get("TKAMD_SIMT") == "1":
+        b = tok1.encode_batch_device(buf.ctypes.data, off.ctypes.data, len(dirty), int(off[-1]), unsynced=True)
+    else:
+        import torch
+        keep = (torch.from_numpy(np.array(buf)).cuda(), torch.from_numpy(np.array(off)).cuda())
+        b = tok1.encode_batch_device(keep[0].data_ptr(), keep[1].data_ptr(), len(dirty), int(off[-1]), unsynced=True)
+    b.sync()
+    assert b.n_tokens == len(exp.ids) and tok1.queue_sizes()["added_spec_pause"] == 0
     monkeypatch.setenv("TKAMD_ADDED_SPEC", "0")              # never speculate
     tok0 = ta.Tokenizer.from_str(js, device=0)
     got, exp = tok0.encode_batch_csr(dirty), o.encode_batch(dirty)

@@ -24,6 +24,7 @@ WANT_WORD_IDS = 4
 ADD_SPECIAL = 8
 PAIRS = 16
 WANT_OVERFLOW = 32
+NO_SPECULATION = 64      # device entry, results consumed stream-ordered without tkamd_device_sync: the added tokens' matching passes outright
 SKIP_SPECIAL = 1          # tkamd_decode_batch flag
 TEXT_PAD = 64
 MAX_STAGES = 24

@@ -598,7 +598,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     // (k_added_candidates with a note instead of a mask) where match / resolve / scatter / piece launches would find nothing -- and a batch
     // whose text does hold the content of one is run again with the passes below when it is synchronised (NOTE_ADDED_SEEN, finish_batch;
     // the handle's next added_spec_len batches then do not speculate).
-    bool spec = (setA.size() > 0 || setB.size() > 0) && t->added_spec_len > 0 && !w->force_general;
+    bool spec = (setA.size() > 0 || setB.size() > 0) && t->added_spec_len > 0 && !w->force_general && !(flags & TKAMD_NO_SPECULATION);
     w->force_general = false;
     if (spec) {
         int p = t->added_spec_pause.load();

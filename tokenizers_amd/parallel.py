@@ -138,7 +138,7 @@ def device_encoder(tok, device):
         d_text = torch.from_numpy(shard).to(device)
         d_off = torch.from_numpy(np.ascontiguousarray(offsets)).to(device)
         b = tok.encode_batch_device(d_text.data_ptr(), d_off.data_ptr(), len(offsets) - 1, int(offsets[-1]),
-                                    stream=torch.cuda.current_stream(device).cuda_stream)
+                                    stream=torch.cuda.current_stream(device).cuda_stream, unsynced=True)
         b._keep = (d_text, d_off)                      # inputs stay alive until the results have been consumed
         encode_shard.last = b
         return b.ids_tensor_unsynced(), b.tok_offsets_tensor(), b.n_tokens_tensor()

@@ -1060,11 +1060,15 @@ class Tokenizer:
         return self.decode_batch([ids], skip_special_tokens)[0]
 
     def encode_batch_device(self, d_text_ptr: int, d_doc_offsets_ptr: int, n_docs: int, n_bytes: int,
-                            offsets: str = "none", word_ids: bool = False, stream: int = 0) -> DeviceBatch:
-        """Inputs already in HBM (raw device pointers; text needs TEXT_PAD readable slack).  Enqueue only."""
+                            offsets: str = "none", word_ids: bool = False, stream: int = 0, unsynced: bool = False) -> DeviceBatch:
+        """Inputs already in HBM (raw device pointers; text needs TEXT_PAD readable slack).  Enqueue only.  ``unsynced``: the results
+        will be consumed stream-ordered behind this call without :meth:`DeviceBatch.sync` in between (``TKAMD_NO_SPECULATION``: a
+        tokenizer with added tokens runs their matching passes outright instead of leaving a second run to the synchronisation)."""
         flags = {"none": _lib.OFFSETS_NONE, "byte": _lib.OFFSETS_BYTE, "char": _lib.OFFSETS_CHAR}[offsets]
         if word_ids:
             flags |= _lib.WANT_WORD_IDS
+        if unsynced:
+            flags |= _lib.NO_SPECULATION
         res = _lib.DeviceResult()
         _lib.check(self._lib.tkamd_encode_batch_device(self._h, d_text_ptr, d_doc_offsets_ptr, n_docs, n_bytes, flags,
                                                        stream, C.byref(res)))
