@@ -55,6 +55,12 @@ def load_config(config: str):
         return (synth.load_or_train_gpt2(), 60000,
                 "BASELINE configs[1]: GPT-2 byte-level BPE 50,257 vocab / 50k merges" if config == "c2"
                 else "BASELINE configs[4]: GPT-2 byte-level BPE, document lengths Zipf over 8..8192 bytes")
+    if config == "o200k":
+        # not a BASELINE config: the case-split member of the tiktoken Split family on the C2 corpus, with the committed
+        # 3,000-entry fixture (a small vocabulary merges more words than C2's: compare with the family's other members, tools/split_family_perf.py)
+        from tests.helpers import load_tokenizer_json
+        return (load_tokenizer_json("split_o200k"), 60000,
+                "o200k Split pattern (case-split letters, contraction suffix, [\\r\\n/]* tail) + ByteLevel + BPE, 3,000-entry vocabulary (tests/golden/split_o200k.json.gz) on the C2 corpus")
     if config == "c3":
         return synth.load_or_train_bert(), 60000, "BASELINE configs[2]: BertNormalizer + BertPreTokenizer + WordPiece 30,522 vocab"
     return synth.load_or_train_llama3(), 250000, "BASELINE configs[3]: Llama-3 style Split regex + ByteLevel + BPE 128,000 vocab (ignore_merges)"
@@ -279,9 +285,9 @@ def main() -> None:
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines for the CPU baseline sample (0 = auto)")
     ap.add_argument("--cpu-brief", action="store_true", help="CPU baseline: the all-cores encode_batch_fast and encode_batch figures only")
     ap.add_argument("--type-seed", type=int, default=0, help="word-type seed of the ENCODED text (0 = in-distribution)")
-    ap.add_argument("--also", default="c3,c4,c5", help="(N = 1, --config c2 only) further BASELINE configs timed by child runs of this script after the "
+    ap.add_argument("--also", default="c3,c4,c5,o200k", help="(N = 1, --config c2 only) further BASELINE configs timed by child runs of this script after the "
                                                      "headline measurement and attached as `other_configs`; 'none' = skip")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5", "o200k"],
                     help="BASELINE.json config: c2 GPT-2 BPE (the headline metric, default), c3 BERT WordPiece, "
                          "c4 Llama-3 style BPE 128k, c5 GPT-2 BPE on Zipf-length documents")
     args = ap.parse_args()
@@ -630,7 +636,7 @@ def main() -> None:
     # ---- the other BASELINE configs on this GPU (rank 0, N=1, headline config only): the same script, same flags, as child processes
     # one after the other -- so that C3 / C4 are driver-timed numbers too, not only builder-run ones ----
     others_cfg = None
-    also = [c.strip() for c in args.also.split(",") if c.strip() in ("c3", "c4", "c5")]
+    also = [c.strip() for c in args.also.split(",") if c.strip() in ("c3", "c4", "c5", "o200k")]
     if rank == 0 and world == 1 and args.config == "c2" and also:
         others_cfg = {}
         for cfg in also:
