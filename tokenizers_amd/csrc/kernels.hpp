@@ -358,8 +358,8 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
                            uint32_t* nos, uint32_t* noe, int64_t* ndoc_off, int* err);
 // whole-word vocabulary hits of QUEUED pre-tokens longer than 16 bytes (ignore_merges, WordLevel): a hit becomes the result row and
 // the queue entry is retired (length 0) so that the model kernels skip it
-void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
-                       const WordCache& wc);
+void launch_long_vocab3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v1, const QView& v2, const QView& v3, void* rows, uint32_t miss_is_unk,
+                        int* err, const WordCache& wc);
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err);
 void launch_wordpiece_long3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);

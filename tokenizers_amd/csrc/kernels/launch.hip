@@ -129,9 +129,10 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
     hipLaunchKernelGGL(k_bn_doc_offsets, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, ol,
                        (const uint32_t*)wbase, (const int64_t*)x_len, ndoc_off);
 }
-void launch_long_vocab(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t miss_is_unk, int* err,
-                       const WordCache& wc) {
-    hipLaunchKernelGGL(k_long_vocab, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, miss_is_unk, err, wc.claim_mask, wc.claims ? (uint4*)wc.rows : (uint4*)nullptr, wc.claim_pos);
+void launch_long_vocab3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v1, const QView& v2, const QView& v3, void* rows, uint32_t miss_is_unk,
+                        int* err, const WordCache& wc) {
+    hipLaunchKernelGGL(k_long_vocab3, dim3(3 * grid), dim3(256), 0, st, t, text, v1, v2, v3, (uint4*)rows, miss_is_unk, err, wc.claim_mask,
+                       wc.claims ? (uint4*)wc.rows : (uint4*)nullptr, wc.claim_pos);
 }
 void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
                       uint32_t* tmp_end, int* err) {
