@@ -18,6 +18,7 @@ struct Workspace {
     hipStream_t io_in = nullptr, io_out = nullptr;
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     // (sized by the largest batch seen)
+    DevBuf w_l3_tiles;                          // a bit per 2048 bytes: tiles the Llama-3 family's lane kernel left bytes undecided in (zeroed with the batch's scratch)
     DevBuf w_docmask, w_startmask, w_wprefix, w_bsum, w_tile_w, w_pt_start, w_tok0, w_pt_tokoff, w_tmp_ids, w_tmp_end, w_rows;
     DevBuf w_len1, w_fin, w_fbsum, w_pad_count, w_keep, w_type_ids2, w_seq_ids2;   // truncation / padding / pair epilogue
     DevBuf w_ovf_parts, w_enc_base, w_enc_doc, w_enc_start, w_enc_cnt;             // overflowing encodings (TKAMD_WANT_OVERFLOW)

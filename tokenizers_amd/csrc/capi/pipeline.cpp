@@ -154,6 +154,10 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         if (!(len_bound && hm.norm == NORM_BERT)) z.add(w->w_docmask.p, (size_t)(W + 1) * 8);
         z.add(w->w_qcount.p, (size_t)QCNT_WORDS * 4);
         z.add(w->w_cstate.p, cstate_bytes);
+        if (hm.pretok == PT_LLAMA3 && split_rule_fast(hm.split_rule)) {
+            w->w_l3_tiles.reserve(l3_tileflag_words(n_x) * 8);
+            z.add(w->w_l3_tiles.p, l3_tileflag_words(n_x) * 8);
+        }
         if (use_claims) {
             // one slot per 64 bytes of the INPUT text (a word is a few bytes, most are repeats), 2^18 .. 2^24 slots: 32 MB of claims (two
             // 64-bit words a slot) + 32 MB of rows for a 120 MB batch.  (Not of the normalised text's bound, three times that behind BertNormalizer: the
@@ -843,7 +847,8 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
         launch_pretok_llama3(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(),
                              w->w_endmask.as<ull>(), piece_off ? piece_off : x_doc_off, piece_off ? (int64_t)seg_cap : n_docs, piece_n_dev,
                              w->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS, hm.split_rule,
-                             t->t_ucc1.p ? t->t_ucc1.as<uint16_t>() : nullptr, t->t_ucc2.p ? t->t_ucc2.as<uint8_t>() : nullptr);
+                             t->t_ucc1.p ? t->t_ucc1.as<uint16_t>() : nullptr, t->t_ucc2.p ? t->t_ucc2.as<uint8_t>() : nullptr,
+                             w->w_l3_tiles.p ? w->w_l3_tiles.as<ull>() : nullptr);
         pf.end();
     } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
         // ByteLevel(use_regex=false): every document is one pre-token (byte_level.rs:128-130)

@@ -56,23 +56,22 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
                                                        const unsigned long long* __restrict__ docmask,
                                                        const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                        unsigned long long* __restrict__ startmask,
-                                                       unsigned long long* __restrict__ slowmask, int refine, SplitRule rule) {
+                                                       unsigned long long* __restrict__ slowmask, const unsigned long long* __restrict__ tileflags, SplitRule rule) {
     // rule: which member of the family (tables.hpp SplitRule; this kernel: split_rule_fast ones -- the contraction alternative absent /
     // case-insensitive / case-sensitive, digit runs cut every 1, 2, 3 code points or not at all)
-    // refine: k_pretok_llama3_lane has run; only tiles in which it left bytes undecided (bits of slowmask) are redone
-    if (refine) {
-        const int64_t w0 = (int64_t)blockIdx.x * (PT_TILE / 64);
-        const int64_t n_words = (n_bytes_host >> 6) + 1;
-        int any = 0;
-        if ((int)threadIdx.x < PT_TILE / 64 && w0 + (int)threadIdx.x < n_words) any = slowmask[w0 + threadIdx.x] != 0ull;
-        if (!__syncthreads_or(any)) return;
-    }
+    // tileflags (refine): k_pretok_llama3_lane has run and left a bit for every tile in which it left bytes undecided; a workgroup takes
+    // the 64 tiles of one flag word and redoes the flagged ones (natural text: none -- a launch of one load a workgroup, where a
+    // workgroup per tile testing the tile's 32 slow-mask words was 0.022 ms of C4's step).  Null: every tile, one a workgroup.
+    unsigned long long todo = 1ull;
+    if (tileflags) { todo = tileflags[blockIdx.x]; if (!todo) return; }            // (uniform)
+    for (; todo; todo &= todo - 1ull) {
+    const int64_t tile = tileflags ? (int64_t)blockIdx.x * 64 + __builtin_ctzll(todo) : (int64_t)blockIdx.x;
     __shared__ __attribute__((aligned(16))) uint8_t sb[L3_R + 8];
     __shared__ uint8_t si[L3_R + 8];
     __shared__ uint8_t sc[L3_R + 8];     // con: number of letters (1|2) swallowed by a contraction starting at this apostrophe
     __shared__ unsigned long long sdoc[L3_R / 64 + 2];
     const int tid = (int)threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.x * PT_TILE;
+    const int64_t t0 = tile * PT_TILE;
     const int64_t r0 = t0 - L3_HALO;
     const int64_t n_bytes = len_dev ? *len_dev : n_bytes_host;
     {
@@ -246,6 +245,8 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
         uint64_t m = __ballot(start), mu = __ballot(unresolved);
         if ((tid & 63) == 0 && g <= n_bytes_host) { startmask[g >> 6] = m; slowmask[g >> 6] = mu; }
     }
+    __syncthreads();                                             // (the next flagged tile stages into the same LDS)
+    }
 }
 
 // =================================================================================================
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
                                                             const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
                                                             unsigned long long* __restrict__ startmask,
                                                             unsigned long long* __restrict__ slowmask, SplitRule rule,
-                                                            const uint16_t* __restrict__ ucc1, const uint8_t* __restrict__ ucc2) {
+                                                            const uint16_t* __restrict__ ucc1, const uint8_t* __restrict__ ucc2,
+                                                            unsigned long long* __restrict__ tileflags) {
     __shared__ uint2 lut[SQ_LUT_COPIES * 256];
     {
         const L3Flags f = l3_byte_flags(threadIdx.x);
@@ -334,6 +336,11 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
         l3_window_starts(m, text, base, uc1, uc2, &s64, &u64, rule);
         st = (s64 >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);
         un = (u64 >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);
+        if (tileflags && un) {                                   // (rare) the tile kernel's work list: the tiles of my first and last undecided byte
+            const int64_t t_lo = (a + __builtin_ctzll(un)) / PT_TILE, t_hi = (a + 63 - __builtin_clzll(un)) / PT_TILE;
+            atomicOr(&tileflags[t_lo >> 6], 1ull << (t_lo & 63));
+            if (t_hi != t_lo) atomicOr(&tileflags[t_hi >> 6], 1ull << (t_hi & 63));
+        }
     }
     // four lanes' 48-bit results are three 64-bit mask words
     const unsigned long long st_n = __shfl_down(st, 1, 64), un_n = __shfl_down(un, 1, 64);
