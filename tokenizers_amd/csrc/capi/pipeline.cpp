@@ -1036,8 +1036,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
                       w->w_tok0.as<uint32_t>(), plan, d_err, matchmask, t->t_hot.p, wc, shortcut ? 0u : 1u, 0u, phases_of(0), d_counters);
         pf.end();
         pf.begin("wordpiece");
-        launch_wordpiece(st, grid, true, mdt, x_text, plan.v[0], w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);
-        launch_wordpiece_long3(st, t->n_cu, mdt, x_text, plan, w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);      // the words longer than 16 bytes
+        launch_wordpiece_all(st, grid, t->n_cu, mdt, x_text, plan, w->w_rows.p, w->w_tmp_ids.as<uint32_t>(), tmp_end, d_err);      // the <= 16-byte queue and the words longer than that, side by side
         pf.end();
         if (wc.keys) {
             pf.begin("word_cache_insert");

@@ -360,9 +360,8 @@ void launch_bert_normalize(hipStream_t st, const BnTables& bt, const uint8_t* te
 // the queue entry is retired (length 0) so that the model kernels skip it
 void launch_long_vocab3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QView& v1, const QView& v2, const QView& v3, void* rows, uint32_t miss_is_unk,
                         int* err, const WordCache& wc);
-void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
-                      uint32_t* tmp_end, int* err);
-void launch_wordpiece_long3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end, int* err);
+void launch_wordpiece_all(hipStream_t st, int grid_short, int grid_long, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids,
+                          uint32_t* tmp_end, int* err);      // the <= 16-byte queue and the three longer ones in one launch
 // (rule: the member of the tiktoken family, tables.hpp SplitRule; ucc1 / ucc2: the case classes its case-split letter alternatives read, else null)
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,

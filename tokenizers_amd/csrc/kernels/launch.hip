@@ -134,13 +134,10 @@ void launch_long_vocab3(hipStream_t st, int grid, const DevTables& t, const uint
     hipLaunchKernelGGL(k_long_vocab3, dim3(3 * grid), dim3(256), 0, st, t, text, v1, v2, v3, (uint4*)rows, miss_is_unk, err, wc.claim_mask,
                        wc.claims ? (uint4*)wc.rows : (uint4*)nullptr, wc.claim_pos);
 }
-void launch_wordpiece(hipStream_t st, int grid, bool short_words, const DevTables& t, const uint8_t* text, const QView& v, void* rows, uint32_t* tmp_ids,
-                      uint32_t* tmp_end, int* err) {
-    if (short_words) hipLaunchKernelGGL(k_wordpiece<true>, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
-    else hipLaunchKernelGGL(k_wordpiece<false>, dim3(grid), dim3(256), 0, st, t, text, v, (uint4*)rows, tmp_ids, tmp_end, err);
-}
-void launch_wordpiece_long3(hipStream_t st, int grid, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids, uint32_t* tmp_end, int* err) {
-    hipLaunchKernelGGL(k_wordpiece_long3, dim3(3 * grid), dim3(256), 0, st, t, text, plan.v[1], plan.v[2], plan.v[3], (uint4*)rows, tmp_ids, tmp_end, err);
+void launch_wordpiece_all(hipStream_t st, int grid_short, int grid_long, const DevTables& t, const uint8_t* text, const QueuePlan& plan, void* rows, uint32_t* tmp_ids,
+                          uint32_t* tmp_end, int* err) {
+    hipLaunchKernelGGL(k_wordpiece_all, dim3(3 * grid_long + grid_short), dim3(256), 0, st, t, text, plan.v[0], plan.v[1], plan.v[2], plan.v[3], (uint4*)rows, tmp_ids, tmp_end, err,
+                       (uint32_t)(3 * grid_long));
 }
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,

@@ -196,20 +196,19 @@ __device__ __forceinline__ void wordpiece_wide(const DevTables& t, const uint8_t
         }
     }
 }
-template <bool SHORT>
-__global__ __launch_bounds__(256) void k_wordpiece(DevTables t, const uint8_t* __restrict__ text, QView v, uint4* __restrict__ rows,
-                                                   uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
+// All four queues in ONE launch (the queues of words longer than 16 bytes hold a few thousand words between them on natural text: a launch
+// of their own costs more than the walk): the first n_long workgroups (a multiple of three) take the three queues of longer words, a third of them each, the others walk the <= 16-byte
+// queue.  Both halves are chains of dependent trie probes (the long words' one walk of up to 64 steps, the short queue's pieces x steps);
+// one behind the other they were 0.038 + 0.038 ms of C3's step, side by side they are as long as the longer one.
+__global__ __launch_bounds__(256) void k_wordpiece_all(DevTables t, const uint8_t* __restrict__ text, QView v0, QView v1, QView v2, QView v3, uint4* __restrict__ rows,
+                                                       uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err, uint32_t n_long) {
     __shared__ uint32_t s_qpre[NSQ + 1];
-    wordpiece_body<SHORT>(t, text, v, rows, tmp_ids, tmp_end, err, blockIdx.x, gridDim.x, s_qpre);
-}
-// the three queues of words longer than 16 bytes in one launch (a third of the grid each): on natural text they hold a few thousand
-// words between them, and a launch costs more than the walk
-__global__ __launch_bounds__(256) void k_wordpiece_long3(DevTables t, const uint8_t* __restrict__ text, QView v1, QView v2, QView v3, uint4* __restrict__ rows,
-                                                         uint32_t* __restrict__ tmp_ids, uint32_t* __restrict__ tmp_end, int* __restrict__ err) {
-    __shared__ uint32_t s_qpre[NSQ + 1];
-    const uint32_t third = gridDim.x / 3u, which = min(blockIdx.x / third, 2u);
-    // (uniform per workgroup)
+    if (blockIdx.x >= n_long) {                               // (uniform per workgroup)
+        wordpiece_body<true>(t, text, v0, rows, tmp_ids, tmp_end, err, blockIdx.x - n_long, gridDim.x - n_long, s_qpre);
+        return;
+    }
+    const uint32_t third = n_long / 3u, which = min(blockIdx.x / third, 2u);
     if (which == 0u) wordpiece_wide<32>(t, text, v1, rows, tmp_ids, tmp_end, err, blockIdx.x, third, s_qpre);
     else if (which == 1u) wordpiece_wide<64>(t, text, v2, rows, tmp_ids, tmp_end, err, blockIdx.x - third, third, s_qpre);
-    else wordpiece_body<false>(t, text, v3, rows, tmp_ids, tmp_end, err, blockIdx.x - 2u * third, gridDim.x - 2u * third, s_qpre);
+    else wordpiece_body<false>(t, text, v3, rows, tmp_ids, tmp_end, err, blockIdx.x - 2u * third, n_long - 2u * third, s_qpre);
 }
