@@ -685,6 +685,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     }
 
     const uint8_t* x_text = d_text;
+    bool lead_done = false;                                    // the pre-tokenizer wrote the lead-byte mask on its way (char offsets)
     const int64_t* x_doc_off = d_doc_off;
     const int64_t* x_len_dev = nullptr;
     const uint32_t* norig = nullptr;
@@ -837,7 +838,12 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     };
     if (hm.pretok == PT_BYTELEVEL_GPT2) {
         pf.begin("pretok_gpt2_seq");
-        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>());
+        // (char offsets over a text the pre-tokenizer reads as it came: the lead-byte mask rides along)
+        if (off_mode == TKAMD_OFFSETS_CHAR && x_text == d_text && !x_len_dev && n_x == n_bytes) {
+            w->w_leadmask.reserve((size_t)(W0 + 1) * 8);
+            lead_done = true;
+        }
+        launch_pretok_gpt2(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(), lead_done ? w->w_leadmask.as<ull>() : nullptr);
         pf.end();
     } else if (hm.pretok == PT_LLAMA3) {
         w->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
@@ -1121,7 +1127,7 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
             w->w_leadmask.reserve((size_t)(W0 + 1) * 8);
             w->w_lprefix.reserve((size_t)(W0 + 1) * 4);
             pf.begin("leadmask_scan");
-            launch_leadmask(st, d_text, n_bytes, w->w_leadmask.as<ull>());
+            if (!lead_done) launch_leadmask(st, d_text, n_bytes, w->w_leadmask.as<ull>());
             launch_mask_scan(st, w->w_leadmask.as<ull>(), W0, w->w_bsum.as<uint32_t>(), w->w_lprefix.as<uint32_t>(), sc + SC_NCHARS);
             pf.end();
             a.leadmask = w->w_leadmask.as<ull>();

@@ -323,7 +323,7 @@ void launch_mark_doc_starts(hipStream_t st, const int64_t* doc_off, int64_t n_do
 // validates the caller's CSR (ERR_BAD_OFFSETS) and writes the copy every later kernel reads (a trivially valid one if it is malformed)
 void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs, int64_t n_bytes, int* err, int64_t* san);
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask);
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* leadmask = nullptr);      // leadmask: the lead-byte mask of the same text too
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total, const int64_t* len_dev = nullptr, uint32_t* tile_w = nullptr);      // len_dev: only the words of a text of that (device-side) length
 void launch_emit_pretok(hipStream_t st, const unsigned long long* startmask, const uint32_t* wprefix, int64_t n_bytes,

@@ -18,8 +18,9 @@ void launch_validate_csr(hipStream_t st, const int64_t* doc_off, int64_t n_docs,
     hipLaunchKernelGGL(k_sanitize_csr, dim3(blocks_for(n_docs + 1, 256)), dim3(256), 0, st, doc_off, n_docs, n_bytes, (const int*)err, san);
 }
 void launch_pretok_gpt2(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
-                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask) {
-    hipLaunchKernelGGL(k_pretok_gpt2_seq<SQ_LUT_COPIES>, dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask);
+                        const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* leadmask) {
+    if (leadmask) hipLaunchKernelGGL((k_pretok_gpt2_seq<SQ_LUT_COPIES, true>), dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, leadmask);
+    else hipLaunchKernelGGL((k_pretok_gpt2_seq<SQ_LUT_COPIES, false>), dim3(blocks_for(n_bytes + 1, 256 * SQ_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, (unsigned long long*)nullptr);
 }
 void launch_mask_scan(hipStream_t st, const unsigned long long* mask, int64_t n_words, uint32_t* bsum, uint32_t* wprefix,
                       int64_t* total, const int64_t* len_dev, uint32_t* tile_w) {

@@ -64,12 +64,14 @@ __device__ __forceinline__ uint32_t utf8_at(const uint8_t* sb, int k, uint32_t* 
 constexpr int SQ_MAIN = 48, SQ_HALO = 8, SQ_LUT_COPIES = 1;
 struct __attribute__((packed, aligned(8))) SqChunk { uint32_t a, b, c, d; };
 
-template <int COPIES = SQ_LUT_COPIES>
+// LEAD: the lead-byte mask of the same text rides along (char offsets over a text the pre-tokenizer reads as it came -- no normalizer, no
+// prefix space: k_leadmask's pass over the same 120 MB, 0.025 ms, is not launched then).
+template <int COPIES = SQ_LUT_COPIES, bool LEAD = false>
 __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restrict__ text, int64_t n_bytes_host,
                                                          const int64_t* __restrict__ len_dev,
                                                          const unsigned long long* __restrict__ docmask,
                                                          const uint16_t* __restrict__ uc1, const uint8_t* __restrict__ uc2,
-                                                         unsigned long long* __restrict__ startmask) {
+                                                         unsigned long long* __restrict__ startmask, unsigned long long* __restrict__ leadmask) {
     __shared__ Gpt2Flags lut[COPIES * 256];
     {
         const Gpt2Flags f = gpt2_byte_flags(threadIdx.x);    // 256 threads: one table entry each
@@ -81,13 +83,21 @@ __global__ __launch_bounds__(256) void k_pretok_gpt2_seq(const uint8_t* __restri
     const int64_t n_words_host = (n_bytes_host >> 6) + 1;
     const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
     // loads, flag deposit and the regex as mask algebra: pretok_gpt2_core.hpp (the very function the CPU test runs)
+    uint64_t ld = 0;
     const unsigned long long out = gpt2_lane_starts(text, n_bytes, n_words_host, (const uint64_t*)docmask,
-                                                    lut + (threadIdx.x & (COPIES - 1)) * 256, Lg, uc1, uc2);
+                                                    lut + (threadIdx.x & (COPIES - 1)) * 256, Lg, uc1, uc2, LEAD ? &ld : nullptr);
     // four lanes' 48-bit results are three 64-bit mask words
     const unsigned long long nxt = __shfl_down(out, 1, 64);
     const int q = (int)(threadIdx.x & 3);
     if (q < 3) {
         const int64_t word = 3 * (Lg >> 2) + q;
         if (word < n_words_host) startmask[word] = (out >> (16 * q)) | (nxt << (SQ_MAIN - 16 * q));
+    }
+    if constexpr (LEAD) {
+        const unsigned long long ld_n = __shfl_down((unsigned long long)ld, 1, 64);
+        if (q < 3) {
+            const int64_t word = 3 * (Lg >> 2) + q;
+            if (word < n_words_host) leadmask[word] = ((unsigned long long)ld >> (16 * q)) | (ld_n << (SQ_MAIN - 16 * q));
+        }
     }
 }

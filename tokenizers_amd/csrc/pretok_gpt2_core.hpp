@@ -134,10 +134,13 @@ TK_HD void gpt2_window_valid(int64_t base, int64_t n_bytes, int64_t n_words_host
     m.D &= m.V;
 }
 
+// (lead, optional: the lane's 48 bits of "this byte exists and is not a continuation byte" -- the lead-byte mask char offsets count in,
+// kernels/output.hip k_leadmask: the window's flags hold it already)
 TK_HD uint64_t gpt2_lane_starts(const uint8_t* text, int64_t n_bytes, int64_t n_words_host, const uint64_t* docmask, const Gpt2Flags* lut,
-                                int64_t lane, const uint16_t* uc1, const uint8_t* uc2) {
+                                int64_t lane, const uint16_t* uc1, const uint8_t* uc2, uint64_t* lead = nullptr) {
     const int64_t a = lane * G2W_MAIN;                       // first byte this lane decides
     const int64_t base = a - G2W_HALO;                       // window = [base, base + 64)
+    if (lead) *lead = 0;
     if (a >= n_bytes) return 0;
     uint32_t w[16];
     {
@@ -153,6 +156,7 @@ TK_HD uint64_t gpt2_lane_starts(const uint8_t* text, int64_t n_bytes, int64_t n_
     Gpt2Window m;
     gpt2_window_valid(base, n_bytes, n_words_host, docmask, m);      // valid positions of the window and their document-start bits
     gpt2_window_flags(w, lut, m);
+    if (lead) *lead = ((m.V & ~m.C) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
     return (gpt2_window_starts(m, text, base, uc1, uc2) >> G2W_HALO) & ((1ull << G2W_MAIN) - 1ull);
 }
 
