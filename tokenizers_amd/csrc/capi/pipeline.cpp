@@ -848,13 +848,18 @@ void run_pipeline(tkamd_tokenizer* t, Workspace* w, const uint8_t* d_text, const
     } else if (hm.pretok == PT_LLAMA3) {
         w->w_endmask.reserve((size_t)(W + 1) * 8);          // reused as the "unresolved" mask
         w->w_slow_docs.reserve((size_t)(n_docs + 1) * 4);
+        // (char offsets over a text the pre-tokenizer reads as it came: the lead-byte mask rides in the lane kernel of the bit-parallel members)
+        if (off_mode == TKAMD_OFFSETS_CHAR && x_text == d_text && !x_len_dev && n_x == n_bytes && (split_rule_fast(hm.split_rule) || (split_rule_fast_cs(hm.split_rule) && t->t_ucc1.p))) {
+            w->w_leadmask.reserve((size_t)(W0 + 1) * 8);
+            lead_done = true;
+        }
         pf.begin("pretok_llama3");
         w->w_slow_docs.reserve((size_t)((piece_off ? seg_cap : (size_t)n_docs) + 1) * 4);
         launch_pretok_llama3(st, x_text, n_x, x_len_dev, w->w_docmask.as<ull>(), t->dt.uc1, t->dt.uc2, w->w_startmask.as<ull>(),
                              w->w_endmask.as<ull>(), piece_off ? piece_off : x_doc_off, piece_off ? (int64_t)seg_cap : n_docs, piece_n_dev,
                              w->w_slow_docs.as<uint32_t>(), d_counters + CNT_SLOW_DOCS, hm.split_rule,
                              t->t_ucc1.p ? t->t_ucc1.as<uint16_t>() : nullptr, t->t_ucc2.p ? t->t_ucc2.as<uint8_t>() : nullptr,
-                             w->w_l3_tiles.p ? w->w_l3_tiles.as<ull>() : nullptr);
+                             w->w_l3_tiles.p ? w->w_l3_tiles.as<ull>() : nullptr, lead_done ? w->w_leadmask.as<ull>() : nullptr);
         pf.end();
     } else if (hm.pretok == PT_BYTELEVEL_NOREGEX) {
         // ByteLevel(use_regex=false): every document is one pre-token (byte_level.rs:128-130)

@@ -366,7 +366,7 @@ void launch_wordpiece_all(hipStream_t st, int grid_short, int grid_long, const D
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs,
-                          SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2, unsigned long long* tileflags);
+                          SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2, unsigned long long* tileflags, unsigned long long* leadmask = nullptr);      // leadmask: as launch_pretok_gpt2's (the bit-parallel members only)
 // (tileflags: L3_TILEFLAG_WORDS(n_bytes) zeroed 64-bit words -- a bit per 2048 bytes of text, the tile kernel's work list)
 inline size_t l3_tileflag_words(int64_t n_bytes) { return (size_t)((n_bytes + 1) / 2048 + 1) / 64 + 2; }
 void launch_leadmask(hipStream_t st, const uint8_t* text, int64_t n_bytes, unsigned long long* leadmask);

@@ -143,7 +143,7 @@ void launch_wordpiece_all(hipStream_t st, int grid_short, int grid_long, const D
 void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, const int64_t* len_dev, const unsigned long long* docmask,
                           const uint16_t* uc1, const uint8_t* uc2, unsigned long long* startmask, unsigned long long* slowmask,
                           const int64_t* doc_off, int64_t n_docs, const int64_t* n_docs_dev, uint32_t* slow_docs, uint32_t* n_slow_docs,
-                          SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2, unsigned long long* tileflags) {
+                          SplitRule rule, const uint16_t* ucc1, const uint8_t* ucc2, unsigned long long* tileflags, unsigned long long* leadmask) {
     // Three tiers: the per-lane bit-parallel kernel, the tile kernel on the tiles where that left bytes undecided, the sequential matcher
     // on the sentences (doc_off: documents, or the pieces between added-token matches) the tile kernel could not finish.  A member of the
     // family with the case-split letters (o200k, tekken: split_rule_fast_cs) runs the per-lane kernel with l3_window_starts_cs and then the
@@ -153,16 +153,20 @@ void launch_pretok_llama3(hipStream_t st, const uint8_t* text, int64_t n_bytes, 
     const unsigned doc_blocks = std::min<unsigned>(blocks_for(n_docs, 256), 4096u);
     if (split_rule_fast(rule)) {
         // (tileflags: a bit per PT_TILE bytes, zeroed by the caller -- the lane kernel's note of the tiles it left something undecided in)
-        hipLaunchKernelGGL(k_pretok_llama3_lane<false>, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule,
-                           (const uint16_t*)nullptr, (const uint8_t*)nullptr, tileflags);
+        if (leadmask) hipLaunchKernelGGL((k_pretok_llama3_lane<false, true>), dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule,
+                           (const uint16_t*)nullptr, (const uint8_t*)nullptr, tileflags, leadmask);
+        else hipLaunchKernelGGL((k_pretok_llama3_lane<false, false>), dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule,
+                           (const uint16_t*)nullptr, (const uint8_t*)nullptr, tileflags, (unsigned long long*)nullptr);
         const unsigned n_tiles = blocks_for(n_bytes + 1, PT_TILE);      // (without a flag array: every tile, one a workgroup)
         hipLaunchKernelGGL(k_pretok_llama3, dim3(tileflags ? blocks_for(n_tiles, 64) : n_tiles), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask,
                            (const unsigned long long*)tileflags, rule);
         hipLaunchKernelGGL(k_l3_slow_docs, dim3(doc_blocks), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
         hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, q, startmask);
     } else if (split_rule_fast_cs(rule) && ucc1) {
-        hipLaunchKernelGGL(k_pretok_llama3_lane<true>, dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule, ucc1, ucc2,
-                           (unsigned long long*)nullptr);
+        if (leadmask) hipLaunchKernelGGL((k_pretok_llama3_lane<true, true>), dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule, ucc1, ucc2,
+                           (unsigned long long*)nullptr, leadmask);
+        else hipLaunchKernelGGL((k_pretok_llama3_lane<true, false>), dim3(blocks_for(n_bytes + 1, 256 * L3W_MAIN)), dim3(256), 0, st, text, n_bytes, len_dev, docmask, uc1, uc2, startmask, slowmask, rule, ucc1, ucc2,
+                           (unsigned long long*)nullptr, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(k_l3_slow_docs, dim3(doc_blocks), dim3(256), 0, st, (const unsigned long long*)slowmask, doc_off, n_docs, n_docs_dev, slow_docs, n_slow_docs);
         hipLaunchKernelGGL(k_pretok_llama3_slow, dim3(1024), dim3(64), 0, st, text, doc_off, (const uint32_t*)slow_docs, (const uint32_t*)n_slow_docs, q, startmask);
     } else {

@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_pretok_llama3(const uint8_t* __restrict
 // =================================================================================================
 // CS: the case-split members of the family (o200k, tekken; tables.hpp split_rule_fast_cs) -- l3_window_starts_cs with the case classes ucc1 /
 // ucc2 and bit 5 of every byte (the case of an ASCII letter); what it leaves undecided goes to the sequential matcher by sentence.
-template <bool CS>
+// LEAD: the lead-byte mask of the same text rides along (char offsets over a text read as it came: kernels/pretok_gpt2.hip)
+template <bool CS, bool LEAD = false>
 __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __restrict__ text, int64_t n_bytes_host,
                                                             const int64_t* __restrict__ len_dev,
                                                             const unsigned long long* __restrict__ docmask,
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
                                                             unsigned long long* __restrict__ startmask,
                                                             unsigned long long* __restrict__ slowmask, SplitRule rule,
                                                             const uint16_t* __restrict__ ucc1, const uint8_t* __restrict__ ucc2,
-                                                            unsigned long long* __restrict__ tileflags) {
+                                                            unsigned long long* __restrict__ tileflags, unsigned long long* __restrict__ leadmask) {
     __shared__ uint2 lut[SQ_LUT_COPIES * 256];
     {
         const L3Flags f = l3_byte_flags(threadIdx.x);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
     const int64_t Lg = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t a = Lg * L3W_MAIN;                         // first byte this lane decides
     const int64_t base = a - L3W_HALO;                       // window = [base, base + 64), 8-byte aligned
-    unsigned long long st = 0, un = 0;
+    unsigned long long st = 0, un = 0, ld = 0;
     if (a < n_bytes) {
         uint32_t w[16];
         {
@@ -324,6 +325,7 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
             m.MU |= (unsigned long long)(accB >> 24) << (8 * g);
         }
         m.L &= m.V; m.N &= m.V; m.W &= m.V; m.R &= m.V; m.SP &= m.V; m.C &= m.V; m.AP &= m.V; m.MU &= m.V;
+        if constexpr (LEAD) ld = ((m.V & ~m.C) >> L3W_HALO) & ((1ull << L3W_MAIN) - 1ull);
         uint64_t s64, u64;
         if constexpr (CS) {
             // bit 5 of the 64 bytes: four bytes a multiply ((x >> 5) & 0x01010101 gathers through 0x01020408 into bits 24..27)
@@ -350,6 +352,13 @@ __global__ __launch_bounds__(256) void k_pretok_llama3_lane(const uint8_t* __res
         if (word < n_words_host) {
             startmask[word] = (st >> (16 * q)) | (st_n << (L3W_MAIN - 16 * q));
             slowmask[word] = (un >> (16 * q)) | (un_n << (L3W_MAIN - 16 * q));
+        }
+    }
+    if constexpr (LEAD) {
+        const unsigned long long ld_n = __shfl_down(ld, 1, 64);
+        if (q < 3) {
+            const int64_t word = 3 * (Lg >> 2) + q;
+            if (word < n_words_host) leadmask[word] = (ld >> (16 * q)) | (ld_n << (L3W_MAIN - 16 * q));
         }
     }
 }
